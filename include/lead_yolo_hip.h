@@ -27,6 +27,103 @@ int ly_mlpblock_fwd(const float* x, float* y, int n_img, int H, int W, int C, co
 /* number of floats of the three packed weight buffers for a given C */
 int ly_mlpblock_pack_sizes(int C, long* n_wp, long* n_w1, long* n_w2);
 
+
+/* ---- generic pointwise-convolution GEMM ------------------------------------------------------ */
+enum { LY_ACT_NONE_ = 0, LY_ACT_RELU_ = 1, LY_ACT_SILU_ = 2 };          /* `act` values            */
+enum { LY_GATHER_ROWS = 0,       /* A row m = a0[m, :k0] | a1[m, :K-k0]                              */
+       LY_GATHER_UP2 = 1,        /* a0 is at half resolution: row (n, h/2, w/2)  (nearest 2x upsample) */
+       LY_GATHER_PATCH = 2,      /* k x k stride-k patches of an NHWC tensor (PatchMerging)           */
+       LY_GATHER_PATCH_NCHW = 3  /* 4 x 4 stride-4 patches of an NCHW tensor (PatchEmbed on images)   */ };
+enum { LY_PRO_NONE = 0,
+       LY_PRO_GATE = 1,              /* a0 part: x * g_w[n,w,:] * g_h[n,h,:] (+ res)  (CoordAtt gating) */
+       LY_PRO_AFFINE_RELU_CA = 2     /* relu(x*p_scale + p_shift) * p_ca[n,:]         (RFCBAMConv k=1)  */ };
+
+typedef struct LyGemmParams {
+  long M;                 /* output pixels = n_img * H * W                                       */
+  int H, W;               /* output spatial size                                                 */
+  int K, N;               /* contraction length (multiple of 4), output channels                 */
+  const float* a0; int lda0; int k0;   /* first source: row stride (floats), columns taken       */
+  const float* a1; int lda1;           /* second source for columns [k0, K) or NULL               */
+  int gather;             /* LY_GATHER_*                                                         */
+  int Hin, Win, Cin, ks, pk;           /* patch gathers: input size, kernel=stride, pk = ks*lda0 */
+  int pro;                /* LY_PRO_*                                                            */
+  const float* g_h; const float* g_w;  /* [n_img, H, k0], [n_img, W, k0]                         */
+  const float* res; int ldres;         /* optional residual added to the gated a0 part           */
+  const float* p_scale; const float* p_shift; const float* p_ca;   /* [K], [K], [n_img, K]       */
+  const float* wp;        /* frag-packed weights of W[N, K]                                      */
+  const float* e_scale; const float* e_shift;   /* [N] or NULL (=1 / =0)                         */
+  const float* rowscale;  /* [M] or NULL                                                         */
+  int act;                /* 0 none, 1 relu, 2 silu                                              */
+  float* out; int ldo;    /* output row stride (floats); pointer may be pre-offset into a concat */
+} LyGemmParams;
+
+/* out[m, n] = act(rowscale[m] * e_scale[n] * sum_k A'[m, k] W[n, k] + e_shift[n]).
+ * Replaces nn.Conv2d(k=1)+BatchNorm2d+SiLU/ReLU (effective Conv, models/common.py:1890-1910), the
+ * torch.cat / nn.Upsample feeding it (models/common.py:531-538), CoordAtt's gating multiply
+ * (models/common.py:1608), RFCBAMConv's k=1 path (models/rfa.py:113-129) and the FasterNet patch
+ * convolutions (models/common.py:1528-1561), depending on gather/pro. */
+int ly_gemm_fwd(const LyGemmParams* p, void* stream);
+
+
+/* ---- 3x3 / s1 / p1 convolution (implicit GEMM) ------------------------------------------------- */
+typedef struct LyConv3Params {
+  long M; int H, W;        /* output (= input) pixels, spatial size                              */
+  int Cin, N;              /* input channels (multiple of 4), output channels                    */
+  const float* x; int ldx; /* NHWC input, row stride (floats)                                    */
+  const float* wp;         /* frag_pack(conv_taps_matrix(weight, 16)): k = tap*ceil16(Cin) + c   */
+  const float* e_scale; const float* e_shift;   /* folded BN / bias, [N] or NULL                 */
+  int act;
+  float* out; int ldo;
+} LyConv3Params;
+
+/* Conv(c1, c2, 3, 1) = conv3x3(no bias) + BN + SiLU (CA_Bottleneck.cv2, models/common.py:1617,
+ * 1890-1910). */
+int ly_conv3x3_fwd(const LyConv3Params* p, void* stream);
+
+
+/* ---- CoordAtt (models/common.py:1583-1609) ------------------------------------------------------- */
+/* pool[n, pos, c]: pos < H -> mean over w of row pos; pos >= H -> mean over h of column pos-H.       */
+int ly_pool_hw(const float* x, int ldx, int n_img, int H, int W, int C, float* pool, void* stream);
+/* y = h_swish(w1 . pool + b1) (bn1 folded into w1/b1: [mip, C], [mip]); a_h[n,h,:] = sigmoid(wh . y + bh),
+ * a_w[n,w,:] = sigmoid(ww . y + bw); wh/ww are [C, mip].                                              */
+int ly_coordatt_mlp(const float* pool, int n_img, int H, int W, int C, int mip, const float* w1, const float* b1,
+                    const float* wh, const float* bh, const float* ww, const float* bw, float* a_h, float* a_w,
+                    void* stream);
+
+/* out = x * a_w[n,w,:] * a_h[n,h,:] (+ res): the gating multiply as a standalone pass (only used
+ * when no consumer GEMM can absorb it, e.g. CA_Bottleneck with a residual shortcut).               */
+int ly_coordatt_gate(const float* x, int ldx, int n_img, int H, int W, int C, const float* a_h, const float* a_w,
+                     const float* res, int ldres, float* out, int ldo, void* stream);
+
+/* ---- RFCBAMConv (models/rfa.py:77-129) ----------------------------------------------------------- */
+/* rfa.SE: ca[n, :] = sigmoid(wb . relu(wa . mean_hw(x)));  wa [R, C], wb [C, R]; part = workspace
+ * of n_img * slices * C floats.                                                                     */
+int ly_se_fwd(const float* x, int ldx, int n_img, int HW, int C, const float* wa, const float* wb, int R, float* part,
+              int slices, float* ca, void* stream);
+/* mm[n, y, x, 0:2] = (max_c, mean_c) of relu(bn(generate(x))) on the k-times expanded grid.
+ * k = 1: a1/b1 = folded per-channel scale/shift.  k = 3: wg[c][90] = 81 folded depthwise weights
+ * W'[t][u] + 9 folded biases; TH x TW (<= 64) = output-pixel tile per block.                        */
+int ly_rfcbam_stats(const float* x, int ldx, int n_img, int H, int W, int C, int k, int s, const float* wg,
+                    const float* a1, const float* b1, int TH, int TW, float* mm, void* stream);
+/* rfa[n, y, x] = sigmoid(conv3x3_pad1(mm; w[2][3][3]))   (get_weight, models/rfa.py:107)             */
+int ly_rfa_map(const float* mm, int n_img, int HK, int WK, const float* w, float* rfa, void* stream);
+
+typedef struct LyRfcbam3Params {
+  int n_img, H, W, C;          /* input NHWC                                                      */
+  int Ho, Wo, N, s;            /* output size, output channels, stride                            */
+  int TH, TW;                  /* output-pixel tile per block (TH*TW <= 64)                       */
+  const float* x; int ldx;
+  const float* wg;             /* [C][90] folded generate weights/biases                          */
+  const float* ca;             /* [n_img, C]                                                      */
+  const float* rfa;            /* [n_img, 3Ho, 3Wo]                                               */
+  const float* wp;             /* frag_pack(conv.0.weight.view(N, 9C))                            */
+  const float* e_scale; const float* e_shift;   /* conv.1 BN folded with conv.0.bias              */
+  float* out; int ldo;
+} LyRfcbam3Params;
+/* RFCBAMConv kernel_size 3 main contraction (+ReLU); the k=1 case is ly_gemm_fwd with
+ * LY_PRO_AFFINE_RELU_CA and rowscale = rfa.                                                         */
+int ly_rfcbam3_fwd(const LyRfcbam3Params* p, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

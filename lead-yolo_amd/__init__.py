@@ -1,5 +1,7 @@
 """lead-yolo_amd: MI355X-native (gfx950 HIP) implementation of the LEAD-YOLO detector hot path.
 
 Import name: `lead_yolo_amd` (the directory name carries a hyphen; see ../lead_yolo_amd/__init__.py)."""
-from . import capi, pack  # noqa: F401
+from . import capi, ops, pack  # noqa: F401
 from .modules import *  # noqa: F401,F403
+from .modules import Lazy  # noqa: F401
+from .model import DEFAULT_CFG, DetectionModel, Model, load_cfg, make_divisible, parse_model  # noqa: F401

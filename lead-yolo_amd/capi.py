@@ -15,11 +15,47 @@ _L = ctypes.c_long
 _F = ctypes.c_float
 _LP = ctypes.POINTER(ctypes.c_long)
 
+
+
+class LyGemmParams(ctypes.Structure):       # mirrors include/lead_yolo_hip.h
+    _fields_ = [("M", _L), ("H", _I), ("W", _I), ("K", _I), ("N", _I),
+                ("a0", _P), ("lda0", _I), ("k0", _I), ("a1", _P), ("lda1", _I),
+                ("gather", _I), ("Hin", _I), ("Win", _I), ("Cin", _I), ("ks", _I), ("pk", _I),
+                ("pro", _I), ("g_h", _P), ("g_w", _P), ("res", _P), ("ldres", _I),
+                ("p_scale", _P), ("p_shift", _P), ("p_ca", _P),
+                ("wp", _P), ("e_scale", _P), ("e_shift", _P), ("rowscale", _P), ("act", _I),
+                ("out", _P), ("ldo", _I)]
+
+
+class LyConv3Params(ctypes.Structure):
+    _fields_ = [("M", _L), ("H", _I), ("W", _I), ("Cin", _I), ("N", _I), ("x", _P), ("ldx", _I), ("wp", _P),
+                ("e_scale", _P), ("e_shift", _P), ("act", _I), ("out", _P), ("ldo", _I)]
+
+
+class LyRfcbam3Params(ctypes.Structure):
+    _fields_ = [("n_img", _I), ("H", _I), ("W", _I), ("C", _I), ("Ho", _I), ("Wo", _I), ("N", _I), ("s", _I),
+                ("TH", _I), ("TW", _I), ("x", _P), ("ldx", _I), ("wg", _P), ("ca", _P), ("rfa", _P), ("wp", _P),
+                ("e_scale", _P), ("e_shift", _P), ("out", _P), ("ldo", _I)]
+
+
+ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
+GATHER_ROWS, GATHER_UP2, GATHER_PATCH, GATHER_PATCH_NCHW = 0, 1, 2, 3
+PRO_NONE, PRO_GATE, PRO_AFFINE_RELU_CA = 0, 1, 2
+
 # name -> argtypes  (every entry point returns int: 0 ok, <0 error with ly_last_error())
 SIGNATURES = {
     "ly_abi_version": [],
     "ly_mlpblock_fwd": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "ly_mlpblock_pack_sizes": [_I, _LP, _LP, _LP],
+    "ly_gemm_fwd": [ctypes.POINTER(LyGemmParams), _P],
+    "ly_conv3x3_fwd": [ctypes.POINTER(LyConv3Params), _P],
+    "ly_pool_hw": [_P, _I, _I, _I, _I, _I, _P, _P],
+    "ly_coordatt_mlp": [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "ly_coordatt_gate": [_P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _P],
+    "ly_se_fwd": [_P, _I, _I, _I, _I, _P, _P, _I, _P, _I, _P, _P],
+    "ly_rfcbam_stats": [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P],
+    "ly_rfa_map": [_P, _I, _I, _I, _P, _P, _P],
+    "ly_rfcbam3_fwd": [ctypes.POINTER(LyRfcbam3Params), _P],
 }
 
 

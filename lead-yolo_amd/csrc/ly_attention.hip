@@ -1,0 +1,367 @@
+// Small reduction / gating kernels of the two attention blocks (fp32, gfx950).  All are
+// bandwidth-trivial next to the convolutions; they exist so that the big tensors are read a minimal
+// number of times and the 9x-expanded RFCBAM tensor is never written.
+//
+//   ly_pool_hw        CoordAtt pool_h / pool_w               (models/common.py:1598-1599)
+//   ly_coordatt_mlp   conv1+bn1+h_swish, conv_h/conv_w+sigmoid (models/common.py:1600-1607)
+//   ly_colsum         spatial sum per (image, channel)       (SE gap, models/rfa.py:90)
+//   ly_se_mlp         sigmoid(Wb relu(Wa mean))              (models/rfa.py:78-92)
+//   ly_rfcbam_stats   max_c / mean_c of relu(bn(generate(x))) on the expanded grid (models/rfa.py:115-126)
+//   ly_rfa_map        sigmoid(conv3x3([max, mean]))          (models/rfa.py:107,127)
+#include <float.h>
+
+#include "ly_common.cuh"
+#include "ly_params.h"
+
+// ---------------------------------------------------------------------------------------------------
+// generic strided reduction:  out[o, c] = scale * sum_{j < L} x[base(o) + j*stride + c]
+// one block per output row o; threads = (c4, j-lane)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(LY_THREADS) void ly_pool_hw_kernel(const float* __restrict__ x, int ldx, int H, int W, int C,
+                                                                 float* __restrict__ pool) {
+  // block b -> (n, pos); pos < H: mean over w of row pos; else mean over h of column pos-H
+  __shared__ f32x4 red[LY_THREADS];
+  const int L = H + W;
+  const int n = blockIdx.x / L, pos = blockIdx.x - n * L;
+  const int nc4 = C >> 2;
+  const int tid = threadIdx.x;
+  const int groups = LY_THREADS / nc4;
+  const bool row = pos < H;
+  const int len = row ? W : H;
+  const long base = row ? ((long)n * H + pos) * W : ((long)n * H) * W + (pos - H);
+  const long step = row ? 1 : W;
+  const int c4 = tid % nc4, j0 = tid / nc4;       // C <= 1024 so nc4 <= 256
+  f32x4 s = ly_zero4();
+  if (j0 < groups)
+    for (int j = j0; j < len; j += groups) s += ly_ldg4(x + (base + j * step) * ldx + 4 * c4);
+  red[tid] = s;
+  __syncthreads();
+  if (j0 == 0) {
+    for (int g = 1; g < groups; ++g) s += red[g * nc4 + c4];
+    const float inv = 1.f / (float)len;
+    ly_stg4(pool + ((long)n * L + pos) * C + 4 * c4, s * inv);
+  }
+}
+
+extern "C" int ly_pool_hw(const float* x, int ldx, int n_img, int H, int W, int C, float* pool, void* stream) {
+  LY_CHECK(x && pool && (C & 3) == 0 && (ldx & 3) == 0 && C <= 1024, "pool_hw: bad arguments (C=%d ldx=%d)", C, ldx);
+  hipLaunchKernelGGL(ly_pool_hw_kernel, dim3(n_img * (H + W)), dim3(LY_THREADS), 0, reinterpret_cast<hipStream_t>(stream), x,
+                     ldx, H, W, C, pool);
+  LY_LAUNCH_CHECK();
+  return 0;
+}
+
+// y = hswish(W1' pool + b1')  (BN folded),  a = sigmoid(Wx y + bx);  one block per (n, pos)
+__global__ __launch_bounds__(LY_THREADS) void ly_coordatt_mlp_kernel(const float* __restrict__ pool, int H, int W, int C, int mip,
+                                                                      const float* __restrict__ w1, const float* __restrict__ b1,
+                                                                      const float* __restrict__ wh, const float* __restrict__ bh,
+                                                                      const float* __restrict__ ww, const float* __restrict__ bw,
+                                                                      float* __restrict__ a_h, float* __restrict__ a_w) {
+  __shared__ float ys[64];
+  const int L = H + W;
+  const int n = blockIdx.x / L, pos = blockIdx.x - n * L;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* p = pool + ((long)n * L + pos) * C;
+  for (int m = wave; m < mip; m += 4) {
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += w1[m * C + c] * p[c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) ys[m] = ly_hswish(s + b1[m]);
+  }
+  __syncthreads();
+  const bool isrow = pos < H;
+  const float* wx = isrow ? wh : ww;
+  const float* bx = isrow ? bh : bw;
+  float* out = isrow ? a_h + ((long)n * H + pos) * C : a_w + ((long)n * W + (pos - H)) * C;
+  for (int c = tid; c < C; c += LY_THREADS) {
+    float s = bx[c];
+    for (int m = 0; m < mip; ++m) s += wx[c * mip + m] * ys[m];
+    out[c] = ly_sigmoid(s);
+  }
+}
+
+extern "C" int ly_coordatt_mlp(const float* pool, int n_img, int H, int W, int C, int mip, const float* w1, const float* b1,
+                               const float* wh, const float* bh, const float* ww, const float* bw, float* a_h, float* a_w,
+                               void* stream) {
+  LY_CHECK(pool && w1 && b1 && wh && bh && ww && bw && a_h && a_w, "coordatt_mlp: null pointer");
+  LY_CHECK(mip > 0 && mip <= 64, "coordatt_mlp: mip=%d out of range", mip);
+  hipLaunchKernelGGL(ly_coordatt_mlp_kernel, dim3(n_img * (H + W)), dim3(LY_THREADS), 0, reinterpret_cast<hipStream_t>(stream),
+                     pool, H, W, C, mip, w1, b1, wh, bh, ww, bw, a_h, a_w);
+  LY_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// SE: partial spatial sums then the two tiny linears
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(LY_THREADS) void ly_colsum_kernel(const float* __restrict__ x, int ldx, int P, int C, int slices,
+                                                                float* __restrict__ part) {
+  __shared__ f32x4 red[LY_THREADS];
+  const int n = blockIdx.x / slices, sl = blockIdx.x - n * slices;
+  const int nc4 = C >> 2, tid = threadIdx.x;
+  const int per = (P + slices - 1) / slices;
+  const int j_lo = sl * per, j_hi = (j_lo + per) < P ? (j_lo + per) : P;
+  const int groups = LY_THREADS / nc4;              // C <= 1024
+  const int c4 = tid % nc4, j0 = tid / nc4;
+  f32x4 s = ly_zero4();
+  if (j0 < groups)
+    for (int j = j_lo + j0; j < j_hi; j += groups) s += ly_ldg4(x + ((long)n * P + j) * ldx + 4 * c4);
+  red[tid] = s;
+  __syncthreads();
+  if (j0 == 0) {
+    for (int g = 1; g < groups; ++g) s += red[g * nc4 + c4];
+    ly_stg4(part + ((long)n * slices + sl) * C + 4 * c4, s);
+  }
+}
+
+__global__ __launch_bounds__(LY_THREADS) void ly_se_mlp_kernel(const float* __restrict__ part, int slices, int C, float inv_hw,
+                                                                const float* __restrict__ wa, const float* __restrict__ wb, int R,
+                                                                float* __restrict__ ca) {
+  extern __shared__ float sm[];      // g[C] + hid[R]
+  float* g = sm;
+  float* hid = sm + C;
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int c = tid; c < C; c += LY_THREADS) {
+    float s = 0.f;
+    for (int sl = 0; sl < slices; ++sl) s += part[((long)n * slices + sl) * C + c];
+    g[c] = s * inv_hw;
+  }
+  __syncthreads();
+  for (int r = wave; r < R; r += 4) {
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += wa[r * C + c] * g[c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) hid[r] = fmaxf(s, 0.f);
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += LY_THREADS) {
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) s += wb[c * R + r] * hid[r];
+    ca[(long)n * C + c] = ly_sigmoid(s);
+  }
+}
+
+extern "C" int ly_se_fwd(const float* x, int ldx, int n_img, int HW, int C, const float* wa, const float* wb, int R, float* part,
+                         int slices, float* ca, void* stream) {
+  LY_CHECK(x && wa && wb && part && ca, "se: null pointer");
+  LY_CHECK((C & 3) == 0 && (ldx & 3) == 0 && C <= 1024 && slices > 0 && R > 0 && R <= 256, "se: bad arguments");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(ly_colsum_kernel, dim3(n_img * slices), dim3(LY_THREADS), 0, st, x, ldx, HW, C, slices, part);
+  LY_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ly_se_mlp_kernel, dim3(n_img), dim3(LY_THREADS), sizeof(float) * (C + R), st, part, slices, C, 1.f / (float)HW,
+                     wa, wb, R, ca);
+  LY_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// RFCBAM statistics, k = 1:  g = relu(x*a + b);  mm[pix] = (max_c g, mean_c g).  One wave per pixel.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_stats1_kernel(const float* __restrict__ x, int ldx, long M, int C,
+                                                                       const float* __restrict__ a, const float* __restrict__ b,
+                                                                       float* __restrict__ mm) {
+  const int lane = threadIdx.x & 63;
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long nwaves = (long)gridDim.x * 4;
+  const int nc4 = C >> 2;
+  const float inv = 1.f / (float)C;
+  for (long p = wave; p < M; p += nwaves) {
+    float mx = -FLT_MAX, sm = 0.f;
+    for (int c4 = lane; c4 < nc4; c4 += 64) {
+      const f32x4 v = ly_ldg4(x + p * ldx + 4 * c4), s = ly_ldg4(a + 4 * c4), t = ly_ldg4(b + 4 * c4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float g = fmaxf(v[r] * s[r] + t[r], 0.f);
+        mx = fmaxf(mx, g);
+        sm += g;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      mx = fmaxf(mx, __shfl_xor(mx, o));
+      sm += __shfl_xor(sm, o);
+    }
+    if (lane == 0) {
+      mm[2 * p] = mx;
+      mm[2 * p + 1] = sm * inv;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// RFCBAM statistics, k = 3 (stride s, pad 1).  lane = output pixel of a TH x TW tile, the 4 waves
+// split the channels; depthwise weights are wave-uniform (scalar loads).  wg[c][90] = 81 folded
+// weights W'[t][u] followed by 9 folded biases b'[t].
+// ---------------------------------------------------------------------------------------------------
+#define LY_SCC 32
+__global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_stats3_kernel(const float* __restrict__ x, int ldx, int H, int W, int C,
+                                                                       int Ho, int Wo, int s, int TH, int TW, int nct, int nrt,
+                                                                       const float* __restrict__ wg, float* __restrict__ mm) {
+  extern __shared__ float lds[];
+  const int IH = s * (TH - 1) + 3, IW = s * (TW - 1) + 3;
+  float* xs = lds;                                   // [IH*IW][LY_SCC + 1]
+  float* red = lds + IH * IW * (LY_SCC + 1);         // [4][18][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int b = blockIdx.x;
+  const int ct = b % nct; b /= nct;
+  const int rt = b % nrt;
+  const int n = b / nrt;
+  const int oy0 = rt * TH, ox0 = ct * TW;
+  const int ly = lane / TW, lx = lane - ly * TW;
+  const int oy = oy0 + ly, ox = ox0 + lx;
+  const bool active = ly < TH && oy < Ho && ox < Wo;
+  const int iy0 = s * oy0 - 1, ix0 = s * ox0 - 1;
+
+  float mx[9], sm[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) { mx[t] = -FLT_MAX; sm[t] = 0.f; }
+
+  for (int c0 = 0; c0 < C; c0 += LY_SCC) {
+    __syncthreads();
+    for (int idx = tid; idx < IH * IW * (LY_SCC / 4); idx += LY_THREADS) {
+      const int ip = idx / (LY_SCC / 4), c4 = idx - ip * (LY_SCC / 4);
+      const int iy = iy0 + ip / IW, ix = ix0 + ip % IW;
+      const int c = c0 + 4 * c4;
+      f32x4 v = ly_zero4();
+      if (iy >= 0 && iy < H && ix >= 0 && ix < W && c < C) v = ly_ldg4(x + (((long)n * H + iy) * W + ix) * ldx + c);
+      float* d = xs + ip * (LY_SCC + 1) + 4 * c4;
+      d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+    }
+    __syncthreads();
+    if (active) {
+      const int cend = (C - c0) < LY_SCC ? (C - c0) : LY_SCC;
+      for (int cl = wave; cl < cend; cl += 4) {
+        float xv[9];
+#pragma unroll
+        for (int u = 0; u < 9; ++u) xv[u] = xs[((s * ly + u / 3) * IW + (s * lx + u % 3)) * (LY_SCC + 1) + cl];
+        const float* wc = wg + (long)(c0 + cl) * 90;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          float a = wc[81 + t];
+#pragma unroll
+          for (int u = 0; u < 9; ++u) a += xv[u] * wc[t * 9 + u];
+          a = fmaxf(a, 0.f);
+          mx[t] = fmaxf(mx[t], a);
+          sm[t] += a;
+        }
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    red[(wave * 18 + t) * 64 + lane] = mx[t];
+    red[(wave * 18 + 9 + t) * 64 + lane] = sm[t];
+  }
+  __syncthreads();
+  if (wave == 0 && active) {
+    const float inv = 1.f / (float)C;
+    const int HK = 3 * Ho, WK = 3 * Wo;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      float m = red[t * 64 + lane], a = red[(9 + t) * 64 + lane];
+      for (int w2 = 1; w2 < 4; ++w2) {
+        m = fmaxf(m, red[(w2 * 18 + t) * 64 + lane]);
+        a += red[(w2 * 18 + 9 + t) * 64 + lane];
+      }
+      const long o = (((long)n * HK + 3 * oy + t / 3) * WK + 3 * ox + t % 3) * 2;
+      mm[o] = m;
+      mm[o + 1] = a * inv;
+    }
+  }
+}
+
+extern "C" int ly_rfcbam_stats(const float* x, int ldx, int n_img, int H, int W, int C, int k, int s, const float* wg,
+                               const float* a1, const float* b1, int TH, int TW, float* mm, void* stream) {
+  LY_CHECK(x && mm && (C & 3) == 0 && (ldx & 3) == 0, "rfcbam_stats: bad arguments");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (k == 1) {
+    LY_CHECK(s == 1 && a1 && b1, "rfcbam_stats: k=1 needs stride 1 and folded scale/shift");
+    long M = (long)n_img * H * W;
+    long blocks = (M + 3) / 4;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(ly_rfcbam_stats1_kernel, dim3((unsigned)blocks), dim3(LY_THREADS), 0, st, x, ldx, M, C, a1, b1, mm);
+    LY_LAUNCH_CHECK();
+    return 0;
+  }
+  LY_CHECK(k == 3 && s >= 1 && wg, "rfcbam_stats: only k in {1,3} is built");
+  LY_CHECK(TW >= 1 && TH >= 1 && TH * TW <= 64, "rfcbam_stats: tile %dx%d does not fit a wave", TH, TW);
+  const int Ho = (H + 2 - 3) / s + 1, Wo = (W + 2 - 3) / s + 1;
+  const int nct = (Wo + TW - 1) / TW, nrt = (Ho + TH - 1) / TH;
+  const int IH = s * (TH - 1) + 3, IW = s * (TW - 1) + 3;
+  size_t lds = sizeof(float) * ((size_t)IH * IW * (LY_SCC + 1) + 4 * 18 * 64);
+  LY_CHECK(lds <= 160 * 1024, "rfcbam_stats: tile needs %zu B LDS", lds);
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ly_rfcbam_stats3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    LY_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    configured = true;
+  }
+  hipLaunchKernelGGL(ly_rfcbam_stats3_kernel, dim3(n_img * nrt * nct), dim3(LY_THREADS), lds, st, x, ldx, H, W, C, Ho, Wo, s, TH, TW,
+                     nct, nrt, wg, mm);
+  LY_LAUNCH_CHECK();
+  return 0;
+}
+
+// rfa[n, y, x] = sigmoid( sum_{ch, dy, dx} w[ch][dy][dx] * mm[n, y+dy-1, x+dx-1, ch] )
+__global__ __launch_bounds__(LY_THREADS) void ly_rfa_map_kernel(const float* __restrict__ mm, int HK, int WK, long total,
+                                                                 const float* __restrict__ w, float* __restrict__ rfa) {
+  const long i = (long)blockIdx.x * LY_THREADS + threadIdx.x;
+  if (i >= total) return;
+  const int xk = (int)(i % WK);
+  const int yk = (int)((i / WK) % HK);
+  const long n = i / ((long)WK * HK);
+  float s = 0.f;
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int yy = yk + dy - 1, xx = xk + dx - 1;
+      if (yy >= 0 && yy < HK && xx >= 0 && xx < WK) {
+        const float* p = mm + ((n * HK + yy) * WK + xx) * 2;
+        s += w[dy * 3 + dx] * p[0] + w[9 + dy * 3 + dx] * p[1];
+      }
+    }
+  rfa[i] = ly_sigmoid(s);
+}
+
+extern "C" int ly_rfa_map(const float* mm, int n_img, int HK, int WK, const float* w, float* rfa, void* stream) {
+  LY_CHECK(mm && w && rfa, "rfa_map: null pointer");
+  long total = (long)n_img * HK * WK;
+  hipLaunchKernelGGL(ly_rfa_map_kernel, dim3((unsigned)((total + LY_THREADS - 1) / LY_THREADS)), dim3(LY_THREADS), 0,
+                     reinterpret_cast<hipStream_t>(stream), mm, HK, WK, total, w, rfa);
+  LY_LAUNCH_CHECK();
+  return 0;
+}
+
+// standalone CoordAtt gating: out = x * a_w[n,w,:] * a_h[n,h,:] (+ res)   (models/common.py:1608, 1623)
+__global__ __launch_bounds__(LY_THREADS) void ly_gate_kernel(const float* __restrict__ x, int ldx, long M, int H, int W, int C,
+                                                              const float* __restrict__ a_h, const float* __restrict__ a_w,
+                                                              const float* __restrict__ res, int ldres, float* __restrict__ out, int ldo) {
+  const int nc4 = C >> 2;
+  const long total = M * nc4;
+  for (long i = (long)blockIdx.x * LY_THREADS + threadIdx.x; i < total; i += (long)gridDim.x * LY_THREADS) {
+    const long p = i / nc4;
+    const int c = (int)(i - p * nc4) * 4;
+    const int w = (int)(p % W);
+    const long nh = p / W;               // n*H + h
+    const long n = nh / H;
+    f32x4 v = ly_ldg4(x + p * ldx + c) * ly_ldg4(a_w + (n * W + w) * C + c) * ly_ldg4(a_h + nh * C + c);
+    if (res) v += ly_ldg4(res + p * ldres + c);
+    ly_stg4(out + p * ldo + c, v);
+  }
+}
+
+extern "C" int ly_coordatt_gate(const float* x, int ldx, int n_img, int H, int W, int C, const float* a_h, const float* a_w,
+                                const float* res, int ldres, float* out, int ldo, void* stream) {
+  LY_CHECK(x && a_h && a_w && out && (C & 3) == 0 && (ldx & 3) == 0 && (ldo & 3) == 0, "gate: bad arguments");
+  long M = (long)n_img * H * W;
+  long blocks = (M * (C >> 2) + LY_THREADS - 1) / LY_THREADS;
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  hipLaunchKernelGGL(ly_gate_kernel, dim3((unsigned)blocks), dim3(LY_THREADS), 0, reinterpret_cast<hipStream_t>(stream), x, ldx, M, H,
+                     W, C, a_h, a_w, res, ldres, out, ldo);
+  LY_LAUNCH_CHECK();
+  return 0;
+}

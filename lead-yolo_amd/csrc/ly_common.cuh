@@ -52,7 +52,7 @@ __device__ __forceinline__ float ly_silu(float x) { return x / (1.f + __expf(-x)
 __device__ __forceinline__ float ly_relu(float x) { return fmaxf(x, 0.f); }
 __device__ __forceinline__ float ly_hswish(float x) { return x * fminf(fmaxf(x + 3.f, 0.f), 6.f) * (1.f / 6.f); }
 
-enum { LY_ACT_NONE = 0, LY_ACT_RELU = 1, LY_ACT_SILU = 2 };
+enum { LY_ACT_NONE = 0, LY_ACT_RELU = 1, LY_ACT_SILU = 2 };  // == LY_ACT_*_ of the public header
 
 template <int ACT>
 __device__ __forceinline__ float ly_act(float x) {

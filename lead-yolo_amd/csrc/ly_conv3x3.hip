@@ -1,0 +1,166 @@
+// 3x3 / stride 1 / pad 1 convolution as an implicit GEMM + folded BN + activation, fp32, gfx950.
+//
+//   out[m, n] = act( scale[n] * sum_{tap, c} X[pix(m) + tap][c] * W[n][c][tap] + shift[n] )
+//
+// Replaces CA_Bottleneck.cv2 = Conv(c_, c_, 3, 1) (reference models/common.py:1617,1890-1910): no
+// im2col buffer exists anywhere; the block stages a halo run of the NHWC input (BP + 2W + 2
+// consecutive pixels x 32 input channels) in LDS and every MFMA B-operand is a 16-byte read at
+// (pixel + tap offset), masked at the image borders.  K order = (tap, cin); weights frag-packed from
+// pack.conv_taps_matrix(w, 16).
+#include "ly_common.cuh"
+#include "ly_params.h"
+
+#define LY_CC 32
+#define LY_LDH (LY_CC + 4)
+
+template <int NT, int MT, int WC>
+__global__ __launch_bounds__(LY_THREADS) void ly_conv3x3_kernel(const LyConv3Params P, const int gy, const int nblocks) {
+  constexpr int WP = 4 / WC;
+  constexpr int BP = 16 * NT * WP;
+  extern __shared__ f32x4 ly_smem4[];
+  float* hs = reinterpret_cast<float*>(ly_smem4);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lq = lane >> 4;
+  const int wc = wave % WC, wp_ = wave / WC;
+  const int lid = ly_xcd_remap(blockIdx.x, nblocks);
+  const int by = lid % gy;
+  const long p0 = (long)(lid / gy) * BP;
+  const int W = P.W, H = P.H;
+  const int BPH = BP + 2 * W + 2;
+  const f32x4 zero = ly_zero4();
+  const int C16 = (P.Cin + 15) >> 4;       // k-steps per tap
+  const int S = 9 * C16;
+  const int T = (P.N + 15) >> 4;
+  const int pixgrp = wp_ * (16 * NT);
+
+  uint32_t tmask[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    long gp = p0 + pixgrp + 16 * n + li;
+    int w_ = (int)(gp % W);
+    int h_ = (int)((gp / W) % H);
+    tmask[n] = ly_tapmask(h_, w_, H, W, gp < P.M);
+  }
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[t][n] = zero;
+  int tile[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    int tt = (by * WC + wc) * MT + t;
+    tile[t] = tt < T ? tt : T - 1;
+  }
+  const f32x4* wpk = reinterpret_cast<const f32x4*>(P.wp);
+
+  for (int c0 = 0; c0 < P.Cin; c0 += LY_CC) {
+    __syncthreads();
+    for (int idx = tid; idx < BPH * (LY_CC / 4); idx += LY_THREADS) {
+      const int hp = idx / (LY_CC / 4), c4 = idx - hp * (LY_CC / 4);
+      const long gp = p0 - W - 1 + hp;
+      const int c = c0 + 4 * c4;
+      f32x4 v = zero;
+      if (gp >= 0 && gp < P.M && c < P.Cin) v = ly_ldg4(P.x + gp * P.ldx + c);
+      *reinterpret_cast<f32x4*>(hs + hp * LY_LDH + 4 * c4) = v;
+    }
+    __syncthreads();
+    const int sc0 = c0 >> 4;
+    const int nsc = (C16 - sc0) < (LY_CC / 16) ? (C16 - sc0) : (LY_CC / 16);
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ty = tap / 3, tx = tap - 3 * ty;
+      const int off = (ty * W + tx) * LY_LDH + 4 * lq;
+      for (int s = 0; s < nsc; ++s) {
+        f32x4 xf[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(hs + (pixgrp + 16 * n + li) * LY_LDH + off + 16 * s);
+          xf[n] = ((tmask[n] >> tap) & 1u) ? v : zero;
+        }
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          const f32x4 wf = wpk[((long)tile[t] * S + tap * C16 + sc0 + s) * 64 + lane];
+#pragma unroll
+          for (int n = 0; n < NT; ++n) acc[t][n] = ly_mfma4(wf, xf[n], acc[t][n]);
+        }
+      }
+    }
+  }
+
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const int tt = (by * WC + wc) * MT + t;
+    const int c = 16 * tt + 4 * lq;
+    if (tt >= T || c >= P.N) continue;
+    float sc[4], sh[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool ok = c + r < P.N;
+      sc[r] = (ok && P.e_scale) ? P.e_scale[c + r] : 1.f;
+      sh[r] = (ok && P.e_shift) ? P.e_shift[c + r] : 0.f;
+    }
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const long gp = p0 + pixgrp + 16 * n + li;
+      if (gp >= P.M) continue;
+      f32x4 v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float u = acc[t][n][r] * sc[r] + sh[r];
+        v[r] = P.act == LY_ACT_RELU ? ly_relu(u) : (P.act == LY_ACT_SILU ? ly_silu(u) : u);
+      }
+      float* o = P.out + gp * P.ldo + c;
+      if ((P.ldo & 3) == 0 && c + 3 < P.N) {
+        ly_stg4(o, v);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (c + r < P.N) o[r] = v[r];
+      }
+    }
+  }
+}
+
+template <int NT, int MT, int WC>
+static int launch_conv3(const LyConv3Params& P, hipStream_t st) {
+  constexpr int BP = 16 * NT * (4 / WC);
+  constexpr int BN = 16 * MT * WC;
+  long gx = (P.M + BP - 1) / BP;
+  int gy = (P.N + BN - 1) / BN;
+  long nb = gx * gy;
+  LY_CHECK(nb < (1L << 31), "conv3x3: grid too large");
+  size_t lds = sizeof(float) * (size_t)(BP + 2 * P.W + 2) * LY_LDH;
+  LY_CHECK(lds <= 160 * 1024, "conv3x3: halo tile needs %zu B of LDS (W=%d)", lds, P.W);
+  auto k = ly_conv3x3_kernel<NT, MT, WC>;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+    LY_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    configured = true;
+  }
+  hipLaunchKernelGGL(k, dim3((unsigned)nb), dim3(LY_THREADS), lds, st, P, gy, (int)nb);
+  LY_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ly_conv3x3_fwd(const LyConv3Params* p, void* stream) {
+  LY_CHECK(p, "conv3x3: null params");
+  const LyConv3Params& P = *p;
+  LY_CHECK(P.x && P.wp && P.out, "conv3x3: null pointer");
+  LY_CHECK(P.M > 0 && P.H > 0 && P.W > 0 && P.Cin > 0 && P.N > 0, "conv3x3: bad sizes");
+  LY_CHECK((P.Cin & 3) == 0 && (P.ldx & 3) == 0, "conv3x3: Cin=%d / ldx=%d must be multiples of 4", P.Cin, P.ldx);
+  LY_CHECK(P.M % ((long)P.H * P.W) == 0, "conv3x3: M is not a whole number of images");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (P.N > 64) {
+    if (P.M >= 64L * 256) return launch_conv3<4, 2, 4>(P, st);   // 64 px x 128 ch
+    return launch_conv3<2, 2, 4>(P, st);                          // 32 px x 128 ch
+  }
+  if (P.N > 32) {
+    if (P.M >= 64L * 256) return launch_conv3<4, 1, 4>(P, st);   // 64 px x 64 ch
+    return launch_conv3<2, 1, 4>(P, st);                          // 32 px x 64 ch
+  }
+  return launch_conv3<2, 2, 1>(P, st);                            // 128 px x 32 ch
+}

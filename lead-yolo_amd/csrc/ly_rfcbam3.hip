@@ -1,0 +1,169 @@
+// RFCBAMConv main contraction for kernel_size 3 (reference models/rfa.py:113-129), fp32, gfx950.
+//
+//   out[n, o, oy, ox] = relu( bn( bias[o] + sum_{c, t} Wc[o, c, t] * G[n, c, 3oy+ty, 3ox+tx] * ca[n, c] * rfa[n, 3oy+ty, 3ox+tx] ) )
+//   G[n, c, 3oy+ty, 3ox+tx] = relu( bn_{c*9+t}( sum_u Wd[c*9+t, u] * x[n, c, s*oy+uy-1, s*ox+ux-1] ) )
+//
+// The reference materialises G (9x the input), multiplies it twice, and runs a stride-3 conv over it
+// (~13 passes over the 9x tensor).  Here G is REGENERATED on chip: per 16-channel chunk the block
+// stages the raw input tile in LDS, the VALU recomputes the depthwise "generate" conv + BN + ReLU
+// (81 MAC per channel and pixel, lane = output pixel, wave-uniform weights), scales by ca and rfa and
+// writes the [64 px x 144] operand tile to LDS, which the MFMAs contract with the frag-packed
+// conv.0.weight viewed as [Cout, 9C] (its native k = c*9 + t order).  HBM sees x once and out once.
+#include "ly_common.cuh"
+#include "ly_params.h"
+
+#define LY_GCC 16
+#define LY_LDG (LY_GCC * 9 + 4)
+
+template <int MT>
+__global__ __launch_bounds__(LY_THREADS) void ly_rfcbam3_kernel(const LyRfcbam3Params P, const int gy, const int nct, const int nrt) {
+  extern __shared__ f32x4 ly_smem4[];
+  const int s = P.s, TH = P.TH, TW = P.TW;
+  const int IH = s * (TH - 1) + 3, IW = s * (TW - 1) + 3;
+  float* gs = reinterpret_cast<float*>(ly_smem4);           // [64][LY_LDG]
+  float* xs = gs + 64 * LY_LDG;                             // [IH*IW][LY_GCC + 1]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lq = lane >> 4;
+  int b = blockIdx.x;
+  const int by = b % gy; b /= gy;
+  const int ct = b % nct; b /= nct;
+  const int rt = b % nrt;
+  const int n = b / nrt;
+  const int oy0 = rt * TH, ox0 = ct * TW;
+  const int ly = lane / TW, lx = lane - ly * TW;
+  const int oy = oy0 + ly, ox = ox0 + lx;
+  const bool active = ly < TH && oy < P.Ho && ox < P.Wo;
+  const int iy0 = s * oy0 - 1, ix0 = s * ox0 - 1;
+  const f32x4 zero = ly_zero4();
+  const int S = (9 * P.C) >> 4;
+  const int T = (P.N + 15) >> 4;
+
+  float rf[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+    rf[t] = active ? P.rfa[((long)n * 3 * P.Ho + 3 * oy + t / 3) * (3 * P.Wo) + 3 * ox + t % 3] : 0.f;
+
+  f32x4 acc[MT][4];
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[t][j] = zero;
+  int tile[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    int tt = (by * 4 + wave) * MT + t;
+    tile[t] = tt < T ? tt : T - 1;
+  }
+  const f32x4* wpk = reinterpret_cast<const f32x4*>(P.wp);
+
+  for (int c0 = 0; c0 < P.C; c0 += LY_GCC) {
+    __syncthreads();
+    for (int idx = tid; idx < IH * IW * (LY_GCC / 4); idx += LY_THREADS) {
+      const int ip = idx / (LY_GCC / 4), c4 = idx - ip * (LY_GCC / 4);
+      const int iy = iy0 + ip / IW, ix = ix0 + ip % IW;
+      f32x4 v = zero;
+      if (iy >= 0 && iy < P.H && ix >= 0 && ix < P.W) v = ly_ldg4(P.x + (((long)n * P.H + iy) * P.W + ix) * P.ldx + c0 + 4 * c4);
+      float* d = xs + ip * (LY_GCC + 1) + 4 * c4;
+      d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+    }
+    __syncthreads();
+    // ---- regenerate G' for channels c0 + 4*wave .. +3 -----------------------------------------------
+#pragma unroll 1
+    for (int cj = 0; cj < 4; ++cj) {
+      const int cl = 4 * wave + cj;
+      const float* wc = P.wg + (long)(c0 + cl) * 90;
+      const float cav = P.ca[(long)n * P.C + c0 + cl];
+      float xv[9];
+#pragma unroll
+      for (int u = 0; u < 9; ++u) xv[u] = active ? xs[((s * ly + u / 3) * IW + (s * lx + u % 3)) * (LY_GCC + 1) + cl] : 0.f;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        float a = wc[81 + t];
+#pragma unroll
+        for (int u = 0; u < 9; ++u) a += xv[u] * wc[t * 9 + u];
+        gs[lane * LY_LDG + cl * 9 + t] = active ? fmaxf(a, 0.f) * cav * rf[t] : 0.f;
+      }
+    }
+    __syncthreads();
+    // ---- contract 144 k-values ------------------------------------------------------------------
+    const int sbase = (c0 >> 4) * 9;
+#pragma unroll 3
+    for (int st = 0; st < 9; ++st) {
+      f32x4 xf[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xf[j] = *reinterpret_cast<const f32x4*>(gs + (16 * j + li) * LY_LDG + 16 * st + 4 * lq);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        const f32x4 wf = wpk[((long)tile[t] * S + sbase + st) * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[t][j] = ly_mfma4(wf, xf[j], acc[t][j]);
+      }
+    }
+  }
+
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const int tt = (by * 4 + wave) * MT + t;
+    const int c = 16 * tt + 4 * lq;
+    if (tt >= T || c >= P.N) continue;
+    float sc[4], sh[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool ok = c + r < P.N;
+      sc[r] = ok ? P.e_scale[c + r] : 1.f;
+      sh[r] = ok ? P.e_shift[c + r] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int pl = 16 * j + li;
+      const int py = pl / TW, px = pl - py * TW;
+      const int yy = oy0 + py, xx = ox0 + px;
+      if (py >= TH || yy >= P.Ho || xx >= P.Wo) continue;
+      f32x4 v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[t][j][r] * sc[r] + sh[r], 0.f);
+      float* o = P.out + (((long)n * P.Ho + yy) * P.Wo + xx) * P.ldo + c;
+      if ((P.ldo & 3) == 0 && c + 3 < P.N) {
+        ly_stg4(o, v);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (c + r < P.N) o[r] = v[r];
+      }
+    }
+  }
+}
+
+template <int MT>
+static int launch_rf3(const LyRfcbam3Params& P, hipStream_t st) {
+  const int nct = (P.Wo + P.TW - 1) / P.TW, nrt = (P.Ho + P.TH - 1) / P.TH;
+  const int gy = (P.N + 64 * MT - 1) / (64 * MT);
+  const int IH = P.s * (P.TH - 1) + 3, IW = P.s * (P.TW - 1) + 3;
+  size_t lds = sizeof(float) * ((size_t)64 * LY_LDG + (size_t)IH * IW * (LY_GCC + 1));
+  LY_CHECK(lds <= 160 * 1024, "rfcbam3: tile needs %zu B LDS", lds);
+  auto k = ly_rfcbam3_kernel<MT>;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    LY_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    configured = true;
+  }
+  long nb = (long)P.n_img * nrt * nct * gy;
+  LY_CHECK(nb < (1L << 31), "rfcbam3: grid too large");
+  hipLaunchKernelGGL(k, dim3((unsigned)nb), dim3(LY_THREADS), lds, st, P, gy, nct, nrt);
+  LY_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ly_rfcbam3_fwd(const LyRfcbam3Params* p, void* stream) {
+  LY_CHECK(p, "rfcbam3: null params");
+  const LyRfcbam3Params& P = *p;
+  LY_CHECK(P.x && P.wg && P.ca && P.rfa && P.wp && P.e_scale && P.e_shift && P.out, "rfcbam3: null pointer");
+  LY_CHECK((P.C & 15) == 0 && (P.ldx & 3) == 0, "rfcbam3: C=%d must be a multiple of 16", P.C);
+  LY_CHECK(P.s >= 1 && P.TH >= 1 && P.TW >= 1 && P.TH * P.TW <= 64, "rfcbam3: bad tile %dx%d", P.TH, P.TW);
+  LY_CHECK(P.Ho == (P.H + 2 - 3) / P.s + 1 && P.Wo == (P.W + 2 - 3) / P.s + 1, "rfcbam3: inconsistent output size");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (P.N > 128) return launch_rf3<4>(P, st);
+  if (P.N > 64) return launch_rf3<2>(P, st);
+  return launch_rf3<1>(P, st);
+}

@@ -1,43 +1,28 @@
 """Drop-in torch.nn.Module replacements for the LEAD-YOLO hot-path blocks, backed by the gfx950 HIP
-library (csrc/ -> libleadyolo_hip.so through capi.py).
+library (csrc/ -> libleadyolo_hip.so through capi.py / ops.py).
 
 Same class names, positional constructor signatures and state_dict keys/shapes as the reference
 (SURVEY.md §8b), so weights transfer by key and the classes can be injected into the reference's
 `models.yolo` globals (inject.py):
   PatchEmbed_FasterNet / PatchMerging_FasterNet / BasicStage   reference models/common.py:1411-1561
-  RFCBAMConv                                                    reference models/rfa.py:77-129
+  RFCBAMConv (+ SE)                                             reference models/rfa.py:77-129
   C3_CA (+ CoordAtt, CA_Bottleneck, Conv)                       reference models/common.py:1583-1637,1890-1910
+  SPPF, Concat, Detect (graph remainder)                        reference models/common.py:348-366,531-538; models/yolo.py:39-153
 
 nn.Conv2d / nn.BatchNorm2d / nn.Linear sub-modules are PARAMETER HOLDERS ONLY (they give the
 reference's key names and let `initialize_weights` / `fuse()` treat them as usual); their own
-forward is never called.  All arithmetic runs in HIP kernels on NHWC (channels_last) activations.
-There is no CPU path: calling forward without the GPU library raises.
+forward is never called.  All arithmetic of the hot path runs in HIP kernels on NHWC (channels_last)
+activations.  There is no CPU path: calling forward without the GPU library raises.
 """
-import ctypes
-
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
-from . import capi, pack
+from . import ops, pack
+from .ops import ACT_NONE, ACT_RELU, ACT_SILU
 
 BN_EPS = 1e-3
 BN_MOMENTUM = 0.03
-
-
-def _require_cuda(x, who):
-    if not x.is_cuda:
-        raise RuntimeError(f"{who}: the HIP path needs a CUDA/ROCm tensor (got {x.device}); there is no CPU fallback")
-    if x.dtype != torch.float32:
-        raise NotImplementedError(f"{who}: only float32 activations are built so far (got {x.dtype})")
-
-
-def nhwc(x):
-    """Logical NCHW tensor with channels_last (NHWC) physical layout; zero-copy when already so."""
-    return x.contiguous(memory_format=torch.channels_last)
-
-
-def empty_nhwc(n, c, h, w, like):
-    return torch.empty((n, c, h, w), dtype=like.dtype, device=like.device, memory_format=torch.channels_last)
 
 
 class _Prepared:
@@ -53,6 +38,89 @@ class _Prepared:
                 self.val = build()
             self.key = key
         return self.val
+
+    def __deepcopy__(self, memo):
+        return _Prepared()
+
+    def __getstate__(self):
+        return {}
+
+    def __setstate__(self, state):
+        self.key = None
+        self.val = None
+
+
+def _no_train(mod, name):
+    if mod.training:
+        raise NotImplementedError(f"{name}: train-mode (batch-statistics BatchNorm + backward) HIP path is not built yet; "
+                                  "call .eval()")
+
+
+def _bn_tensors(bn):
+    return (bn.weight, bn.bias, bn.running_mean, bn.running_var)
+
+
+def _act_code(act):
+    if act is None or isinstance(act, nn.Identity):
+        return ACT_NONE
+    if isinstance(act, nn.SiLU):
+        return ACT_SILU
+    if isinstance(act, nn.ReLU):
+        return ACT_RELU
+    raise NotImplementedError(f"activation {type(act).__name__} is not built into the HIP epilogues (SiLU / ReLU / identity)")
+
+
+class Lazy:
+    """A not-yet-materialised activation a consumer GEMM can absorb: channel concat of up to two row
+    sources, the first optionally at half resolution (nearest 2x upsample) or gated by CoordAtt."""
+
+    def __init__(self, shape, a0, lda0, k0, a1=None, lda1=0, up=False, gate=None, keep=()):
+        self.shape = shape          # logical (n, c, h, w)
+        self.a0, self.lda0, self.k0 = a0, lda0, k0
+        self.a1, self.lda1 = a1, lda1
+        self.up = up
+        self.gate = gate            # (a_h, a_w) or None
+        self.keep = keep            # tensors kept alive
+
+    @staticmethod
+    def of(x):
+        if isinstance(x, Lazy):
+            return x
+        t, ld = ops.rows(x)
+        n, c, h, w = t.shape
+        return Lazy((n, c, h, w), t, ld, c, keep=(t,))
+
+    def materialize(self):
+        n, c, h, w = self.shape
+        if self.gate is not None:
+            assert self.a1 is None and not self.up
+            return ops.coordatt_gate(self.a0, self.lda0, n, h, w, c, self.gate[0], self.gate[1])
+        parts = []
+        a0 = self.keep[0]
+        if self.up:
+            a0 = F.interpolate(a0, scale_factor=2, mode="nearest")
+        parts.append(a0)
+        if self.a1 is not None:
+            parts.append(self.keep[1])
+        return parts[0] if len(parts) == 1 else torch.cat(parts, 1)
+
+
+def _run_pointwise(src, wp, n_out, e_scale, e_shift, act, out=None, ldo=None, **extra):
+    """GEMM over a Lazy / tensor source -> NHWC tensor [n, n_out, h, w] (or into `out` rows)."""
+    L = Lazy.of(src)
+    n, c, h, w = L.shape
+    if out is None:
+        res = ops.empty_nhwc(n, n_out, h, w, L.a0)
+        out_t, ldo = res, n_out
+    else:
+        res, out_t = None, out
+    kw = dict(M=n * h * w, H=h, W=w, K=c, N=n_out, a0=L.a0, lda0=L.lda0, k0=L.k0, a1=L.a1, lda1=L.lda1, wp=wp, out=out_t,
+              ldo=ldo, e_scale=e_scale, e_shift=e_shift, act=act, gather=ops.GATHER_UP2 if L.up else ops.GATHER_ROWS)
+    if L.gate is not None:
+        kw.update(pro=ops.PRO_GATE, g_h=L.gate[0], g_w=L.gate[1])
+    kw.update(extra)
+    ops.gemm(**kw)
+    return res
 
 
 # --------------------------------------------------------------------------------------------------
@@ -87,7 +155,7 @@ class MLPBlock(nn.Module):
 
     def _packed(self):
         wp_, w1_, bn, w2_ = self.spatial_mixing.partial_conv3.weight, self.mlp[0].weight, self.mlp[1], self.mlp[3].weight
-        key = pack.versions(wp_, w1_, w2_, bn.weight, bn.bias, bn.running_mean, bn.running_var) + (bn.eps,)
+        key = pack.versions(wp_, w1_, w2_, *_bn_tensors(bn)) + (bn.eps,)
 
         def build():
             c = self.dim
@@ -99,16 +167,15 @@ class MLPBlock(nn.Module):
         return self._prep.get(key, build)
 
     def forward(self, x):
-        _require_cuda(x, "MLPBlock")
-        if self.training:
-            raise NotImplementedError("MLPBlock: train-mode (batch-statistics) HIP path is not built yet")
-        x = nhwc(x)
+        from . import capi
+        ops.require_cuda(x, "MLPBlock")
+        _no_train(self, "MLPBlock")
+        x = ops.nhwc(x)
         n, c, h, w = x.shape
         wp, w1, w2, sc, sh = self._packed()
-        y = empty_nhwc(n, c, h, w, x)
-        L = capi.lib()
-        capi.check(L.ly_mlpblock_fwd(capi.ptr(x), capi.ptr(y), n, h, w, c, capi.ptr(wp), capi.ptr(w1), capi.ptr(w2),
-                                     capi.ptr(sc), capi.ptr(sh), capi.stream_ptr()), "ly_mlpblock_fwd")
+        y = ops.empty_nhwc(n, c, h, w, x)
+        capi.check(capi.lib().ly_mlpblock_fwd(capi.ptr(x), capi.ptr(y), n, h, w, c, capi.ptr(wp), capi.ptr(w1), capi.ptr(w2),
+                                              capi.ptr(sc), capi.ptr(sh), capi.stream_ptr()), "ly_mlpblock_fwd")
         return y
 
 
@@ -123,3 +190,473 @@ class BasicStage(nn.Module):
         for blk in self.blocks:
             x = blk(x)
         return x
+
+
+class _PatchConv(nn.Module):
+    """k x k stride-k convolution (no bias) + BatchNorm as one gather-GEMM."""
+    _conv_name = "proj"
+    stride_factor = None
+
+    def _setup(self, cin, cout, k, s, norm_layer):
+        if k != s:
+            raise NotImplementedError("HIP patch convolution is built for kernel_size == stride (non-overlapping patches)")
+        setattr(self, self._conv_name, nn.Conv2d(cin, cout, kernel_size=k, stride=s, bias=False))
+        self.norm = norm_layer(cout) if norm_layer is not None else nn.Identity()
+        self.k, self.cin, self.cout = k, cin, cout
+        self._prep = _Prepared()
+
+    def _packed(self, nchw):
+        conv = getattr(self, self._conv_name)
+        bn = getattr(self, "norm", None)
+        has_bn = isinstance(bn, nn.BatchNorm2d)
+        key = pack.versions(conv.weight, conv.bias, *(_bn_tensors(bn) if has_bn else ())) + (nchw, bn.eps if has_bn else 0)
+
+        def build():
+            w = conv.weight.detach()
+            co = w.shape[0]
+            wm = w.reshape(co, -1) if nchw else w.permute(0, 2, 3, 1).reshape(co, -1)
+            if has_bn:
+                sc, sh = pack.bn_scale_shift(bn, conv.bias)
+            else:
+                sc, sh = None, (conv.bias.detach().float().contiguous() if conv.bias is not None else None)
+            return pack.frag_pack(wm), sc, sh
+        return self._prep.get(key, build)
+
+    def forward(self, x):
+        ops.require_cuda(x, type(self).__name__)
+        _no_train(self, type(self).__name__)
+        n, c, h, w = x.shape
+        k = self.k
+        ho, wo = h // k, w // k
+        out = ops.empty_nhwc(n, self.cout, ho, wo, x)
+        if c % 4 == 0:
+            xr, ld = ops.rows(x)
+            if ld != c:
+                xr, ld = ops.nhwc(x.contiguous()), c
+            wp, sc, sh = self._packed(False)
+            ops.gemm(M=n * ho * wo, H=ho, W=wo, K=k * k * c, N=self.cout, a0=xr, lda0=c, k0=k * k * c, wp=wp, out=out,
+                     ldo=self.cout, gather=ops.GATHER_PATCH, Hin=h, Win=w, Cin=c, ks=k, pk=k * c, e_scale=sc, e_shift=sh)
+        else:
+            if k != 4 or w % 4 != 0:
+                raise NotImplementedError("HIP patch embedding of an NCHW image needs patch_size 4 and W % 4 == 0")
+            xr = x.contiguous()                     # NCHW image
+            wp, sc, sh = self._packed(True)
+            ops.gemm(M=n * ho * wo, H=ho, W=wo, K=16 * c, N=self.cout, a0=xr, lda0=0, k0=16 * c, wp=wp, out=out, ldo=self.cout,
+                     gather=ops.GATHER_PATCH_NCHW, Hin=h, Win=w, Cin=c, ks=4, pk=0, e_scale=sc, e_shift=sh)
+        return out
+
+    def fuseforward(self, x):
+        return self.forward(x)
+
+
+class PatchEmbed_FasterNet(_PatchConv):
+    _conv_name = "proj"
+
+    def __init__(self, in_chans, embed_dim, patch_size, patch_stride, norm_layer=nn.BatchNorm2d):
+        super().__init__()
+        self._setup(in_chans, embed_dim, patch_size, patch_stride, norm_layer)
+
+
+class PatchMerging_FasterNet(_PatchConv):
+    _conv_name = "reduction"
+
+    def __init__(self, dim, out_dim, k, patch_stride2, norm_layer=nn.BatchNorm2d):
+        super().__init__()
+        self._setup(dim, out_dim, k, patch_stride2, norm_layer)
+
+
+# --------------------------------------------------------------------------------------------------
+# effective Conv (conv + BN + SiLU), k in {1, 3}, stride 1
+# --------------------------------------------------------------------------------------------------
+def autopad(k, p=None, d=1):
+    if d > 1:
+        k = d * (k - 1) + 1 if isinstance(k, int) else [d * (x - 1) + 1 for x in k]
+    if p is None:
+        p = k // 2 if isinstance(k, int) else [x // 2 for x in k]
+    return p
+
+
+class Conv(nn.Module):
+    default_act = nn.SiLU()
+
+    def __init__(self, c1, c2, k=1, s=1, p=None, g=1, d=1, act=True):
+        super().__init__()
+        if g != 1 or d != 1 or s != 1 or k not in (1, 3) or autopad(k, p, d) != k // 2:
+            raise NotImplementedError(f"HIP Conv is built for k in (1, 3), stride 1, groups 1, 'same' padding (got k={k} s={s} g={g} d={d})")
+        self.conv = nn.Conv2d(c1, c2, k, s, autopad(k, p, d), groups=g, dilation=d, bias=False)
+        self.bn = nn.BatchNorm2d(c2)
+        self.act = self.default_act if act is True else act if isinstance(act, nn.Module) else nn.Identity()
+        self.k, self.c1, self.c2 = k, c1, c2
+        self._prep = _Prepared()
+
+    def packed(self):
+        conv, bn = self.conv, getattr(self, "bn", None)
+        key = pack.versions(conv.weight, conv.bias, *(_bn_tensors(bn) if bn is not None else ())) + (bn.eps if bn is not None else 0,)
+
+        def build():
+            w = conv.weight.detach()
+            wm = w.view(self.c2, self.c1) if self.k == 1 else pack.conv_taps_matrix(w, 16)
+            if bn is not None:
+                sc, sh = pack.bn_scale_shift(bn, conv.bias)
+            else:
+                sc, sh = None, (conv.bias.detach().float().contiguous() if conv.bias is not None else None)
+            return pack.frag_pack(wm), sc, sh
+        return self._prep.get(key, build)
+
+    def forward(self, x):
+        if not isinstance(x, Lazy):
+            ops.require_cuda(x, "Conv")
+        _no_train(self, "Conv")
+        wp, sc, sh = self.packed()
+        act = _act_code(self.act)
+        if self.k == 1:
+            return _run_pointwise(x, wp, self.c2, sc, sh, act)
+        if isinstance(x, Lazy):
+            x = x.materialize()
+        xr, ld = ops.rows(x)
+        n, c, h, w = xr.shape
+        out = ops.empty_nhwc(n, self.c2, h, w, xr)
+        ops.conv3x3(M=n * h * w, H=h, W=w, Cin=c, N=self.c2, x=xr, ldx=ld, wp=wp, out=out, ldo=self.c2, e_scale=sc, e_shift=sh, act=act)
+        return out
+
+    def forward_fuse(self, x):
+        return self.forward(x)
+
+
+# --------------------------------------------------------------------------------------------------
+# RFCBAMConv
+# --------------------------------------------------------------------------------------------------
+class SE(nn.Module):
+    def __init__(self, in_channel, ratio=16):
+        super().__init__()
+        self.gap = nn.AdaptiveAvgPool2d((1, 1))
+        self.fc = nn.Sequential(nn.Linear(in_channel, ratio, bias=False), nn.ReLU(), nn.Linear(ratio, in_channel, bias=False),
+                                nn.Sigmoid())
+        self.ratio = ratio
+
+    def attention(self, xr, ld, n, hw, c):
+        wa, wb = self.fc[0].weight.detach(), self.fc[2].weight.detach()
+        return ops.se_attention(xr, ld, n, hw, c, wa.contiguous(), wb.contiguous(), self.ratio)
+
+    def forward(self, x):
+        ops.require_cuda(x, "SE")
+        xr, ld = ops.rows(x)
+        n, c, h, w = xr.shape
+        return self.attention(xr, ld, n, h * w, c).view(n, c, 1, 1)
+
+
+class RFCBAMConv(nn.Module):
+    def __init__(self, in_channel, out_channel, kernel_size=3, stride=1, dilation=1):
+        super().__init__()
+        k = kernel_size
+        if k not in (1, 3):
+            raise NotImplementedError("HIP RFCBAMConv is built for kernel_size 1 and 3")
+        if k == 1 and stride != 1:
+            raise NotImplementedError("HIP RFCBAMConv with kernel_size 1 is built for stride 1")
+        if k == 3 and in_channel % 16 != 0:
+            raise NotImplementedError("HIP RFCBAMConv with kernel_size 3 needs in_channel % 16 == 0")
+        self.kernel_size, self.stride = k, stride
+        self.c, self.o = in_channel, out_channel
+        self.generate = nn.Sequential(nn.Conv2d(in_channel, in_channel * k * k, k, padding=k // 2, stride=stride, groups=in_channel,
+                                                bias=False), nn.BatchNorm2d(in_channel * k * k), nn.ReLU())
+        self.get_weight = nn.Sequential(nn.Conv2d(2, 1, kernel_size=3, padding=1, bias=False), nn.Sigmoid())
+        self.se = SE(in_channel)
+        self.conv = nn.Sequential(nn.Conv2d(in_channel, out_channel, k, stride=k), nn.BatchNorm2d(out_channel), nn.ReLU())
+        self._prep = _Prepared()
+
+    def _packed(self):
+        gw, gbn, cw, cbn = self.generate[0].weight, self.generate[1], self.conv[0], self.conv[1]
+        key = pack.versions(gw, *_bn_tensors(gbn), cw.weight, cw.bias, *_bn_tensors(cbn), self.get_weight[0].weight) + (gbn.eps, cbn.eps)
+
+        def build():
+            k, c, o = self.kernel_size, self.c, self.o
+            gs, gb = pack.bn_scale_shift(gbn)                                 # [c*k*k]
+            w18 = self.get_weight[0].weight.detach().float().reshape(18).contiguous()
+            es, eb = pack.bn_scale_shift(cbn, cw.bias)
+            if k == 1:
+                a1 = (gw.detach().float().view(c) * gs).contiguous()
+                return dict(a1=a1, b1=gb, w18=w18, wp=pack.frag_pack(cw.weight.detach().view(o, c)), es=es, eb=eb)
+            wgm = gw.detach().float().view(c, 9, 9) * gs.view(c, 9, 1)        # [c][t][u]
+            wg = torch.cat((wgm.reshape(c, 81), gb.view(c, 9)), 1).contiguous()
+            return dict(wg=wg, w18=w18, wp=pack.frag_pack(cw.weight.detach().reshape(o, 9 * c)), es=es, eb=eb)
+        return self._prep.get(key, build)
+
+    def forward(self, x):
+        if isinstance(x, Lazy):
+            x = x.materialize()
+        ops.require_cuda(x, "RFCBAMConv")
+        _no_train(self, "RFCBAMConv")
+        xr, ld = ops.rows(x)
+        n, c, h, w = xr.shape
+        k, s = self.kernel_size, self.stride
+        P = self._packed()
+        ca = self.se.attention(xr, ld, n, h * w, c)
+        if k == 1:
+            mm = ops.rfcbam_stats(xr, ld, n, h, w, c, 1, 1, a1=P["a1"], b1=P["b1"])
+            rfa = ops.rfa_map(mm, P["w18"])
+            out = ops.empty_nhwc(n, self.o, h, w, xr)
+            ops.gemm(M=n * h * w, H=h, W=w, K=c, N=self.o, a0=xr, lda0=ld, k0=c, wp=P["wp"], out=out, ldo=self.o,
+                     pro=ops.PRO_AFFINE_RELU_CA, p_scale=P["a1"], p_shift=P["b1"], p_ca=ca, rowscale=rfa, e_scale=P["es"],
+                     e_shift=P["eb"], act=ACT_RELU)
+            return out
+        ho, wo = (h + 2 - 3) // s + 1, (w + 2 - 3) // s + 1
+        th, tw = ops.pick_tile(ho, wo)
+        mm = ops.rfcbam_stats(xr, ld, n, h, w, c, 3, s, wg=P["wg"], th=th, tw=tw)
+        rfa = ops.rfa_map(mm, P["w18"])
+        out = ops.empty_nhwc(n, self.o, ho, wo, xr)
+        ops.rfcbam3(n=n, h=h, w=w, c=c, ho=ho, wo=wo, N=self.o, s=s, th=th, tw=tw, x=xr, ldx=ld, wg=P["wg"], ca=ca, rfa=rfa,
+                    wp=P["wp"], e_scale=P["es"], e_shift=P["eb"], out=out, ldo=self.o)
+        return out
+
+
+# --------------------------------------------------------------------------------------------------
+# C3_CA
+# --------------------------------------------------------------------------------------------------
+class h_sigmoid(nn.Module):
+    def __init__(self, inplace=True):
+        super().__init__()
+        self.relu = nn.ReLU6(inplace=inplace)
+
+
+class h_swish(nn.Module):
+    def __init__(self, inplace=True):
+        super().__init__()
+        self.sigmoid = h_sigmoid(inplace=inplace)
+
+
+class CoordAtt(nn.Module):
+    def __init__(self, inp, oup, reduction=32):
+        super().__init__()
+        if inp != oup:
+            raise NotImplementedError("HIP CoordAtt gates its own input: inp must equal oup")
+        self.pool_h = nn.AdaptiveAvgPool2d((None, 1))
+        self.pool_w = nn.AdaptiveAvgPool2d((1, None))
+        mip = max(8, inp // reduction)
+        self.conv1 = nn.Conv2d(inp, mip, kernel_size=1, stride=1, padding=0)
+        self.bn1 = nn.BatchNorm2d(mip)
+        self.act = h_swish()
+        self.conv_h = nn.Conv2d(mip, oup, kernel_size=1, stride=1, padding=0)
+        self.conv_w = nn.Conv2d(mip, oup, kernel_size=1, stride=1, padding=0)
+        self.mip, self.c = mip, inp
+        self._prep = _Prepared()
+
+    def _packed(self):
+        key = pack.versions(self.conv1.weight, self.conv1.bias, *_bn_tensors(self.bn1), self.conv_h.weight, self.conv_h.bias,
+                            self.conv_w.weight, self.conv_w.bias) + (self.bn1.eps,)
+
+        def build():
+            s, t = pack.bn_scale_shift(self.bn1, self.conv1.bias)
+            w1 = (self.conv1.weight.detach().float().view(self.mip, self.c) * s.view(-1, 1)).contiguous()
+            f = lambda p: p.detach().float().reshape(p.shape[0], -1).contiguous()
+            return (w1, t, f(self.conv_h.weight), self.conv_h.bias.detach().float().contiguous(), f(self.conv_w.weight),
+                    self.conv_w.bias.detach().float().contiguous())
+        return self._prep.get(key, build)
+
+    def attention(self, xr, ld, n, h, w, c):
+        w1, b1, wh, bh, ww, bw = self._packed()
+        pool = ops.pool_hw(xr, ld, n, h, w, c)
+        return ops.coordatt_mlp(pool, n, h, w, c, self.mip, w1, b1, wh, bh, ww, bw)
+
+    def forward(self, x):
+        ops.require_cuda(x, "CoordAtt")
+        _no_train(self, "CoordAtt")
+        xr, ld = ops.rows(x)
+        n, c, h, w = xr.shape
+        a_h, a_w = self.attention(xr, ld, n, h, w, c)
+        return ops.coordatt_gate(xr, ld, n, h, w, c, a_h, a_w)
+
+
+class CA_Bottleneck(nn.Module):
+    def __init__(self, c1, c2, shortcut=True, g=1, e=0.5):
+        super().__init__()
+        c_ = int(c2 * e)
+        self.cv1 = Conv(c1, c_, 1, 1)
+        self.cv2 = Conv(c_, c2, 3, 1, g=g)
+        self.ca = CoordAtt(c2, c2, 32)
+        self.add = shortcut and c1 == c2
+
+    def forward_lazy(self, x):
+        """Returns a Lazy (gated, un-materialised) output when there is no residual, else a tensor."""
+        src = Lazy.of(x)
+        t1 = self.cv1(src)
+        t2 = self.cv2(t1)
+        n, c, h, w = t2.shape
+        a_h, a_w = self.ca.attention(t2, c, n, h, w, c)
+        if self.add:
+            if src.gate is not None or src.a1 is not None or src.up:
+                rr, ldr = ops.rows(src.materialize())
+            else:
+                rr, ldr = src.a0, src.lda0
+            return ops.coordatt_gate(t2, c, n, h, w, c, a_h, a_w, rr, ldr)
+        return Lazy((n, c, h, w), t2, c, c, gate=(a_h, a_w), keep=(t2, a_h, a_w))
+
+    def forward(self, x):
+        if not isinstance(x, Lazy):
+            ops.require_cuda(x, "CA_Bottleneck")
+        _no_train(self, "CA_Bottleneck")
+        y = self.forward_lazy(x)
+        return y.materialize() if isinstance(y, Lazy) else y
+
+
+class C3_CA(nn.Module):
+    def __init__(self, c1, c2, n=1, shortcut=True, g=1, e=0.5):
+        super().__init__()
+        c_ = int(c2 * e)
+        self.cv1 = Conv(c1, c_, 1, 1)
+        self.cv2 = Conv(c1, c_, 1, 1)
+        self.cv3 = Conv(2 * c_, c2, 1)
+        self.m = nn.Sequential(*(CA_Bottleneck(c_, c_, shortcut, g, e=1.0) for _ in range(n)))
+        self.c_, self.c2 = c_, c2
+        self._prep = _Prepared()
+
+    def _packed12(self):
+        """cv1 and cv2 read the same input: one GEMM with stacked weights writes [cv1 | cv2] side by side,
+        which is also exactly where the later concat wants cv2's output."""
+        p1, p2 = self.cv1, self.cv2
+        b1, b2 = getattr(p1, "bn", None), getattr(p2, "bn", None)
+        key = pack.versions(p1.conv.weight, p2.conv.weight, p1.conv.bias, p2.conv.bias,
+                            *(_bn_tensors(b1) if b1 is not None else ()), *(_bn_tensors(b2) if b2 is not None else ()))
+
+        def build():
+            w = torch.cat((p1.conv.weight.detach().view(self.c_, -1), p2.conv.weight.detach().view(self.c_, -1)), 0)
+            parts = []
+            for p, b in ((p1, b1), (p2, b2)):
+                if b is not None:
+                    parts.append(pack.bn_scale_shift(b, p.conv.bias))
+                else:
+                    parts.append((torch.ones(self.c_, device=w.device), p.conv.bias.detach().float()))
+            sc = torch.cat((parts[0][0], parts[1][0])).contiguous()
+            sh = torch.cat((parts[0][1], parts[1][1])).contiguous()
+            return pack.frag_pack(w), sc, sh
+        return self._prep.get(key, build)
+
+    def forward(self, x):
+        if not isinstance(x, Lazy):
+            ops.require_cuda(x, "C3_CA")
+        _no_train(self, "C3_CA")
+        src = Lazy.of(x)
+        n, c, h, w = src.shape
+        c_ = self.c_
+        if _act_code(self.cv1.act) != _act_code(self.cv2.act):
+            raise NotImplementedError("C3_CA: cv1 and cv2 must share one activation")
+        wp, sc, sh = self._packed12()
+        ycat = ops.empty_nhwc(n, 2 * c_, h, w, src.a0)
+        _run_pointwise(src, wp, 2 * c_, sc, sh, _act_code(self.cv1.act), out=ycat, ldo=2 * c_)
+        cur = Lazy((n, c_, h, w), ycat, 2 * c_, c_, keep=(ycat,))
+        for blk in self.m:
+            cur = Lazy.of(blk.forward_lazy(cur))
+        right = ycat[:, c_:]
+        both = Lazy((n, 2 * c_, h, w), cur.a0, cur.lda0, c_, a1=right, lda1=2 * c_, gate=cur.gate, keep=cur.keep + (ycat,))
+        wp3, sc3, sh3 = self.cv3.packed()
+        return _run_pointwise(both, wp3, self.c2, sc3, sh3, _act_code(self.cv3.act))
+
+
+# --------------------------------------------------------------------------------------------------
+# graph remainder
+# --------------------------------------------------------------------------------------------------
+class SPPF(nn.Module):
+    def __init__(self, c1, c2, k=5):
+        super().__init__()
+        c_ = c1 // 2
+        self.cv1 = Conv(c1, c_, 1, 1)
+        self.cv2 = Conv(c_ * 4, c2, 1, 1)
+        self.m = nn.MaxPool2d(kernel_size=k, stride=1, padding=k // 2)
+
+    def forward(self, x):
+        x = self.cv1(x)
+        y1 = self.m(x)
+        y2 = self.m(y1)
+        return self.cv2(torch.cat((x, y1, y2, self.m(y2)), 1))
+
+
+class Upsample(nn.Upsample):
+    """nn.Upsample; with `lazy` set (by Model) a nearest 2x upsample is not executed but handed to the
+    consumer GEMM, which reads source row (n, h/2, w/2) instead (ly_gemm_fwd LY_GATHER_UP2)."""
+    lazy = False
+
+    def forward(self, x):
+        if self.lazy and not isinstance(x, Lazy) and x.dim() == 4 and x.is_cuda and self.mode == "nearest" \
+                and self.size is None and float(self.scale_factor) == 2.0 and x.shape[1] % 4 == 0:
+            t, ld = ops.rows(x)
+            n, c, h, w = t.shape
+            return Lazy((n, c, 2 * h, 2 * w), t, ld, c, up=True, keep=(t,))
+        if isinstance(x, Lazy):
+            x = x.materialize()
+        return super().forward(x)
+
+
+class Concat(nn.Module):
+    """torch.cat; with `lazy` set (by Model) a two-way channel concat becomes a two-source Lazy that
+    the consumer GEMM reads in place (no copy)."""
+    lazy = False
+
+    def __init__(self, dimension=1):
+        super().__init__()
+        self.d = dimension
+
+    def forward(self, x):
+        if self.lazy and self.d == 1 and len(x) == 2 and not isinstance(x[1], Lazy) and x[1].is_cuda:
+            a = Lazy.of(x[0])
+            if a.a1 is None and a.gate is None and a.shape[1] % 4 == 0 and x[1].shape[1] % 4 == 0 \
+                    and tuple(a.shape[2:]) == tuple(x[1].shape[2:]):
+                t1, ld1 = ops.rows(x[1])
+                n, c0, h, w = a.shape
+                return Lazy((n, c0 + t1.shape[1], h, w), a.a0, a.lda0, c0, a1=t1, lda1=ld1, up=a.up, keep=(a.keep[0], t1))
+        x = [t.materialize() if isinstance(t, Lazy) else t for t in x]
+        return torch.cat(x, self.d)
+
+
+class Detect(nn.Module):
+    stride = None
+    dynamic = False
+    export = False
+
+    def __init__(self, nc=80, anchors=(), ch=(), inplace=True):
+        super().__init__()
+        self.nc = nc
+        self.no = nc + 5
+        self.nl = len(anchors)
+        self.na = len(anchors[0]) // 2
+        self.grid = [torch.empty(0) for _ in range(self.nl)]
+        self.anchor_grid = [torch.empty(0) for _ in range(self.nl)]
+        self.register_buffer("anchors", torch.tensor(anchors).float().view(self.nl, -1, 2))
+        self.m = nn.ModuleList(nn.Conv2d(x, self.no * self.na, 1) for x in ch)
+        self.inplace = inplace
+        self._prep = [_Prepared() for _ in ch]
+
+    def _head(self, i, x):
+        conv = self.m[i]
+        key = pack.versions(conv.weight, conv.bias)
+        wp, b = self._prep[i].get(key, lambda: (pack.frag_pack(conv.weight.detach().view(conv.out_channels, -1)),
+                                                 conv.bias.detach().float().contiguous()))
+        ldo = (conv.out_channels + 3) // 4 * 4
+        L = Lazy.of(x)
+        n, c, h, w = L.shape
+        buf = torch.empty((n, h, w, ldo), dtype=torch.float32, device=L.a0.device)
+        _run_pointwise(L, wp, conv.out_channels, None, b, ACT_NONE, out=buf, ldo=ldo)
+        return buf[..., :conv.out_channels]                    # [n, h, w, na*no]
+
+    def forward(self, x):
+        z = []
+        x = list(x)
+        for i in range(self.nl):
+            y = self._head(i, x[i])
+            bs, ny, nx, _ = y.shape
+            x[i] = y.reshape(bs, ny, nx, self.na, self.no).permute(0, 3, 1, 2, 4).contiguous()
+            if not self.training:
+                if self.dynamic or self.grid[i].shape[2:4] != x[i].shape[2:4]:
+                    self.grid[i], self.anchor_grid[i] = self._make_grid(nx, ny, i)
+                sg = x[i].sigmoid()
+                xy = (sg[..., 0:2] * 2 + self.grid[i]) * self.stride[i]
+                wh = (sg[..., 2:4] * 2) ** 2 * self.anchor_grid[i]
+                z.append(torch.cat((xy, wh, sg[..., 4:]), 4).view(bs, self.na * nx * ny, self.no))
+        return x if self.training else (torch.cat(z, 1),) if self.export else (torch.cat(z, 1), x)
+
+    def _make_grid(self, nx=20, ny=20, i=0):
+        d, t = self.anchors[i].device, self.anchors[i].dtype
+        shape = 1, self.na, ny, nx, 2
+        ys, xs = torch.arange(ny, device=d, dtype=t), torch.arange(nx, device=d, dtype=t)
+        yv, xv = torch.meshgrid(ys, xs, indexing="ij")
+        grid = torch.stack((xv, yv), 2).expand(shape) - 0.5
+        anchor_grid = (self.anchors[i] * self.stride[i]).view((1, self.na, 1, 1, 2)).expand(shape)
+        return grid, anchor_grid

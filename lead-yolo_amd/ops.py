@@ -1,0 +1,128 @@
+"""Thin host wrappers over the C-ABI (capi.py): torch supplies device memory and the current stream,
+every arithmetic step is a HIP kernel in libleadyolo_hip.so.  Activations are logical NCHW tensors
+with channels_last (NHWC) storage; a channel slice of such a tensor (a slot of a concat buffer) is
+addressed as rows of stride `ld` without copying."""
+import ctypes
+
+import torch
+
+from . import capi
+from .capi import (ACT_NONE, ACT_RELU, ACT_SILU, GATHER_PATCH, GATHER_PATCH_NCHW, GATHER_ROWS, GATHER_UP2,  # noqa: F401
+                   PRO_AFFINE_RELU_CA, PRO_GATE, PRO_NONE)
+
+
+def require_cuda(x, who):
+    if not x.is_cuda:
+        raise RuntimeError(f"{who}: the HIP path needs a CUDA/ROCm tensor (got {x.device}); there is no CPU fallback")
+    if x.dtype != torch.float32:
+        raise NotImplementedError(f"{who}: only float32 activations are built so far (got {x.dtype})")
+
+
+def nhwc(x):
+    return x.contiguous(memory_format=torch.channels_last)
+
+
+def empty_nhwc(n, c, h, w, like):
+    return torch.empty((n, c, h, w), dtype=torch.float32, device=like.device, memory_format=torch.channels_last)
+
+
+def rows(x):
+    """(tensor, ld): x as an [n*h*w, c] row matrix with row stride ld floats, zero-copy when x is a
+    channels_last tensor or a channel slice of one; otherwise a channels_last copy is made."""
+    n, c, h, w = x.shape
+    if x.is_contiguous(memory_format=torch.channels_last) and x.stride(1) == 1:
+        return x, c
+    sn, sc, sh, sw = x.stride()
+    if sc == 1 and sw >= c and sw % 4 == 0 and (h == 1 or sh == w * sw) and (n == 1 or sn == h * w * sw) and w > 1:
+        return x, sw
+    x = nhwc(x)
+    if x.stride(1) != 1:        # degenerate shapes where torch reports ambiguous strides
+        x = x.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    return x, c
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def gemm(*, M, H, W, K, N, a0, lda0, k0, wp, out, ldo, a1=None, lda1=0, gather=GATHER_ROWS, Hin=0, Win=0, Cin=0, ks=0, pk=0,
+         pro=PRO_NONE, g_h=None, g_w=None, res=None, ldres=0, p_scale=None, p_shift=None, p_ca=None, e_scale=None,
+         e_shift=None, rowscale=None, act=ACT_NONE):
+    P = capi.LyGemmParams(M, H, W, K, N, _p(a0), lda0, k0, _p(a1), lda1, gather, Hin, Win, Cin, ks, pk, pro, _p(g_h), _p(g_w),
+                          _p(res), ldres, _p(p_scale), _p(p_shift), _p(p_ca), _p(wp), _p(e_scale), _p(e_shift), _p(rowscale),
+                          act, _p(out), ldo)
+    capi.check(capi.lib().ly_gemm_fwd(ctypes.byref(P), capi.stream_ptr()), "ly_gemm_fwd")
+
+
+def conv3x3(*, M, H, W, Cin, N, x, ldx, wp, out, ldo, e_scale=None, e_shift=None, act=ACT_NONE):
+    P = capi.LyConv3Params(M, H, W, Cin, N, _p(x), ldx, _p(wp), _p(e_scale), _p(e_shift), act, _p(out), ldo)
+    capi.check(capi.lib().ly_conv3x3_fwd(ctypes.byref(P), capi.stream_ptr()), "ly_conv3x3_fwd")
+
+
+def pool_hw(x, ldx, n, h, w, c):
+    pool = torch.empty((n, h + w, c), dtype=torch.float32, device=x.device)
+    capi.check(capi.lib().ly_pool_hw(_p(x), ldx, n, h, w, c, _p(pool), capi.stream_ptr()), "ly_pool_hw")
+    return pool
+
+
+def coordatt_mlp(pool, n, h, w, c, mip, w1, b1, wh, bh, ww, bw):
+    a_h = torch.empty((n, h, c), dtype=torch.float32, device=pool.device)
+    a_w = torch.empty((n, w, c), dtype=torch.float32, device=pool.device)
+    capi.check(capi.lib().ly_coordatt_mlp(_p(pool), n, h, w, c, mip, _p(w1), _p(b1), _p(wh), _p(bh), _p(ww), _p(bw), _p(a_h),
+                                          _p(a_w), capi.stream_ptr()), "ly_coordatt_mlp")
+    return a_h, a_w
+
+
+def coordatt_gate(x, ldx, n, h, w, c, a_h, a_w, res=None, ldres=0):
+    out = empty_nhwc(n, c, h, w, x)
+    capi.check(capi.lib().ly_coordatt_gate(_p(x), ldx, n, h, w, c, _p(a_h), _p(a_w), _p(res), ldres, _p(out), c,
+                                           capi.stream_ptr()), "ly_coordatt_gate")
+    return out
+
+
+def se_attention(x, ldx, n, hw, c, wa, wb, r):
+    slices = max(1, min(hw // 16 if hw >= 16 else 1, -(-512 // n)))
+    part = torch.empty((n, slices, c), dtype=torch.float32, device=x.device)
+    ca = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    capi.check(capi.lib().ly_se_fwd(_p(x), ldx, n, hw, c, _p(wa), _p(wb), r, _p(part), slices, _p(ca), capi.stream_ptr()),
+               "ly_se_fwd")
+    return ca
+
+
+def pick_tile(ho, wo):
+    """TH x TW (<= 64 output pixels, one per lane) minimising idle lanes over the Ho x Wo map."""
+    best = None
+    for nct in range(1, 9):
+        tw = -(-wo // nct)
+        if tw > 64:
+            continue
+        th = max(1, 64 // tw)
+        th = min(th, ho)
+        nrt = -(-ho // th)
+        eff = (ho * wo) / (nct * nrt * 64.0)
+        if best is None or eff > best[0] + 1e-9:
+            best = (eff, th, tw)
+    if best is None:
+        return 1, 64
+    return best[1], best[2]
+
+
+def rfcbam_stats(x, ldx, n, h, w, c, k, s, wg=None, a1=None, b1=None, th=1, tw=64):
+    ho, wo = ((h + 2 * (k // 2) - k) // s + 1, (w + 2 * (k // 2) - k) // s + 1)
+    mm = torch.empty((n, k * ho, k * wo, 2), dtype=torch.float32, device=x.device)
+    capi.check(capi.lib().ly_rfcbam_stats(_p(x), ldx, n, h, w, c, k, s, _p(wg), _p(a1), _p(b1), th, tw, _p(mm), capi.stream_ptr()),
+               "ly_rfcbam_stats")
+    return mm
+
+
+def rfa_map(mm, w18):
+    n, hk, wk, _ = mm.shape
+    rfa = torch.empty((n, hk, wk), dtype=torch.float32, device=mm.device)
+    capi.check(capi.lib().ly_rfa_map(_p(mm), n, hk, wk, _p(w18), _p(rfa), capi.stream_ptr()), "ly_rfa_map")
+    return rfa
+
+
+def rfcbam3(*, n, h, w, c, ho, wo, N, s, th, tw, x, ldx, wg, ca, rfa, wp, e_scale, e_shift, out, ldo):
+    P = capi.LyRfcbam3Params(n, h, w, c, ho, wo, N, s, th, tw, _p(x), ldx, _p(wg), _p(ca), _p(rfa), _p(wp), _p(e_scale),
+                             _p(e_shift), _p(out), ldo)
+    capi.check(capi.lib().ly_rfcbam3_fwd(ctypes.byref(P), capi.stream_ptr()), "ly_rfcbam3_fwd")

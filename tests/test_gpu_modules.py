@@ -70,3 +70,119 @@ def test_basicstage_shapes_vs_oracle(c, n, h, w):
         want = OF.basic_stage(copy.deepcopy(st), "", x, False)
         got = m.to(_dev()).eval()(x.to(_dev()))
     _cmp(got, want, f"basicstage c={c} {n}x{h}x{w}")
+
+
+def _bn_eps(m):
+    for mm in m.modules():
+        if isinstance(mm, torch.nn.BatchNorm2d):
+            mm.eps, mm.momentum = 1e-3, 0.03
+    return m
+
+
+def _ctor(kind):
+    import lead_yolo_amd as L
+    return {"BasicStage": L.BasicStage, "PatchEmbed_FasterNet": L.PatchEmbed_FasterNet, "PatchMerging_FasterNet": L.PatchMerging_FasterNet,
+            "RFCBAMConv": L.RFCBAMConv, "CoordAtt": L.CoordAtt, "CA_Bottleneck": L.CA_Bottleneck, "C3_CA": L.C3_CA, "SPPF": L.SPPF}[kind]
+
+
+GOLDEN_MODULES = [n for pre in ("patch", "rfcbam", "coordatt", "cabottleneck", "c3ca", "sppf") for n in G.names(pre)]
+
+
+@pytest.mark.parametrize("name", GOLDEN_MODULES)
+def test_module_golden(name):
+    """every hot-path module vs the vectors the reference itself produced"""
+    meta, arr = G.load(name)
+    st = G.state_for(meta)
+    x = synth.synth_input(meta["in_shape"], meta["seed"] + 1)
+    m = _bn_eps(_load(_ctor(meta["kind"])(*meta["ctor"]), st)).to(_dev()).eval()
+    with torch.no_grad():
+        y = m(x.to(_dev()))
+    _cmp(y, arr["y_eval"], name)
+
+
+def _oracle(kind, ctor, st, x):
+    from tests.test_oracle_golden import _run
+    with torch.no_grad():
+        return _run(kind, ctor, copy.deepcopy(st), x, False)[0]
+
+
+CASES = [
+    ("PatchEmbed_FasterNet", (3, 24, 4, 4), (2, 3, 64, 96)),
+    ("PatchEmbed_FasterNet", (3, 16, 4, 4), (1, 3, 32, 36)),
+    ("PatchMerging_FasterNet", (24, 40, 2, 2), (2, 24, 40, 36)),
+    ("PatchMerging_FasterNet", (160, 320, 2, 2), (1, 160, 10, 14)),
+    ("RFCBAMConv", (160, 256, 1, 1), (3, 160, 20, 20)),
+    ("RFCBAMConv", (256, 128, 1, 1), (2, 256, 40, 40)),
+    ("RFCBAMConv", (128, 128, 3, 2), (2, 128, 80, 80)),
+    ("RFCBAMConv", (256, 256, 3, 2), (2, 256, 40, 40)),
+    ("RFCBAMConv", (64, 64, 3, 2), (1, 64, 21, 13)),
+    ("RFCBAMConv", (32, 48, 3, 1), (2, 32, 9, 70)),
+    ("RFCBAMConv", (512, 512, 3, 2), (1, 512, 12, 12)),
+    ("C3_CA", (336, 256, 1, False), (2, 336, 40, 40)),
+    ("C3_CA", (168, 128, 1, False), (1, 168, 80, 80)),
+    ("C3_CA", (512, 512, 1, False), (2, 512, 20, 20)),
+    ("C3_CA", (64, 64, 3, True), (2, 64, 13, 11)),
+    ("C3_CA", (128, 96, 2, False), (1, 128, 7, 30)),
+    ("CA_Bottleneck", (64, 64, True, 1, 1.0), (2, 64, 17, 9)),
+    ("CoordAtt", (128, 128, 32), (2, 128, 11, 23)),
+    ("SPPF", (160, 160, 5), (2, 160, 20, 20)),
+]
+
+
+@pytest.mark.parametrize("kind,ctor,shape", CASES)
+def test_module_shapes_vs_oracle(kind, ctor, shape):
+    """real layer shapes, ragged tiles, odd sizes, n>1 bottlenecks, shortcut"""
+    torch.manual_seed(0)
+    m = _ctor(kind)(*ctor)
+    st = synth.synth_state(synth.shapes_of(m.state_dict()), 9000 + sum(shape) + len(kind))
+    _bn_eps(_load(m, st))
+    x = synth.synth_input(shape, 31 + shape[1])
+    want = _oracle(kind, list(ctor), st, x)
+    with torch.no_grad():
+        got = m.to(_dev()).eval()(x.to(_dev()))
+    _cmp(got, want, f"{kind}{ctor} {shape}")
+
+
+def _cfg(scale):
+    import lead_yolo_amd as L
+    return L.load_cfg(scale=scale)
+
+
+@pytest.mark.parametrize("scale", ["n", "s"])
+@pytest.mark.parametrize("fuse_graph", [True, False])
+def test_whole_model_golden(scale, fuse_graph):
+    import lead_yolo_amd as L
+    meta, arr = G.load(f"model_{scale}")
+    pm, pa = G.load(f"parse_{scale}")
+    st = G.state_for(meta, {"model.23.anchors": G.t(pa["anchors"])})
+    m = L.Model(_cfg(scale), fuse_graph=fuse_graph)
+    m.load_state_dict(st)
+    m = m.to(_dev()).eval()
+    hw = meta["hw"]
+    x = synth.synth_images(2, max(hw), meta["seed"] + 1)[:, :, :hw[0], :hw[1]].float() / 255
+    with torch.no_grad():
+        z, outs = m(x.to(_dev()))
+    _cmp(z, arr["z_eval"], f"model_{scale} z")
+    for i, o in enumerate(outs):
+        _cmp(o, arr[f"p{i}_eval"], f"model_{scale} p{i}")
+    with torch.no_grad():
+        zf = m.fuse()(x.to(_dev()))[0]
+    _cmp(zf, arr["z_fused"], f"model_{scale} fused")
+
+
+def test_whole_model_640_vs_oracle():
+    """BASELINE config shape: lead-yolo-s, 640x640 (batch 2 to keep the CPU oracle to seconds)"""
+    import lead_yolo_amd as L
+    torch.manual_seed(0)
+    m = L.Model(_cfg("s"))
+    st = synth.synth_state(synth.shapes_of(m.state_dict()), 4242)
+    st["model.23.anchors"] = m.model[-1].anchors.clone()
+    m.load_state_dict(st)
+    x = synth.synth_images(2, 640, 7).float() / 255
+    with torch.no_grad():
+        zo, outs_o = OF.model_forward(copy.deepcopy(st), _cfg("s"), x, m.stride, training=False)
+        z, outs = m.to(_dev()).eval()(x.to(_dev()))
+    assert z.shape == (2, 25200, 6)
+    _cmp(z, zo, "model_s 640 z")
+    for i, (a, b) in enumerate(zip(outs, outs_o)):
+        _cmp(a, b, f"model_s 640 p{i}")

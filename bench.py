@@ -157,6 +157,7 @@ def main():
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layers", action="store_true", help="print the per-layer kernel table to stderr")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel probe (for whole-step rocprof runs)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -198,7 +199,9 @@ def main():
 
     roof = None
     cpu = None
-    if rank == 0:
+    if rank == 0 and args.no_roofline:
+        print(json.dumps({"value": round(value, 2), "ms_per_step": round(ms_per_step, 4), "note": "probe skipped"}))
+    elif rank == 0:
         rows = roofline_probe(model, x)
         if args.layers:
             for r in rows:

@@ -19,14 +19,15 @@ const char* ly_last_error(void);
 /* FasterNet MLPBlock forward, eval form (BN folded to scale/shift):
  *   y = x + W2 . relu(scale * (W1 . [pconv3x3(x[..., :C/4]) | x[..., C/4:]]) + shift)
  * replaces Partial_conv3.forward_split_cat (models/common.py:1432-1437) + MLPBlock.forward
- * (models/common.py:1478-1482).  wp/w1/w2 are frag-packed (lead-yolo_amd/pack.py) from
- * spatial_mixing.partial_conv3.weight / mlp.0.weight / mlp.3.weight; bn_* have 2C entries.
- * x and y must not alias. Built for C in {16,24,40,80,160,320}. */
-int ly_mlpblock_fwd(const float* x, float* y, int n_img, int H, int W, int C, const float* wp, const float* w1,
-                    const float* w2, const float* bn_scale, const float* bn_shift, void* stream);
-/* number of floats of the three packed weight buffers for a given C */
-int ly_mlpblock_pack_sizes(int C, long* n_wp, long* n_w1, long* n_w2);
-
+ * (models/common.py:1478-1482).  wp/w1/w2 are bf16x3 frag-packed (lead-yolo_amd/pack.py frag_pack3)
+ * from spatial_mixing.partial_conv3.weight ([C/4, 9*ceil4(C/4)], k = tap*ceil4(C/4) + c),
+ * mlp.0.weight (rows zero-padded to 16*ly_mlpblock_hidden_tiles(C)) and mlp.3.weight; bn_* have
+ * 16*ly_mlpblock_hidden_tiles(C) entries (zero padded).  x and y must not alias.
+ * Built for C in {16,24,40,80,160,320}. */
+int ly_mlpblock_fwd(const float* x, float* y, int n_img, int H, int W, int C, const void* wp, const void* w1,
+                    const void* w2, const float* bn_scale, const float* bn_shift, void* stream);
+/* hidden (2C) channel tiles of 16, padded to an even count */
+int ly_mlpblock_hidden_tiles(int C);
 
 /* ---- generic pointwise-convolution GEMM ------------------------------------------------------ */
 enum { LY_ACT_NONE_ = 0, LY_ACT_RELU_ = 1, LY_ACT_SILU_ = 2 };          /* `act` values            */
@@ -50,7 +51,7 @@ typedef struct LyGemmParams {
   const float* g_h; const float* g_w;  /* [n_img, H, k0], [n_img, W, k0]                         */
   const float* res; int ldres;         /* optional residual added to the gated a0 part           */
   const float* p_scale; const float* p_shift; const float* p_ca;   /* [K], [K], [n_img, K]       */
-  const float* wp;        /* frag-packed weights of W[N, K]                                      */
+  const void* wp;         /* bf16x3 frag-packed weights of W[N, K] (pack.frag_pack3)             */
   const float* e_scale; const float* e_shift;   /* [N] or NULL (=1 / =0)                         */
   const float* rowscale;  /* [M] or NULL                                                         */
   int act;                /* 0 none, 1 relu, 2 silu                                              */
@@ -63,6 +64,8 @@ typedef struct LyGemmParams {
  * (models/common.py:1608), RFCBAMConv's k=1 path (models/rfa.py:113-129) and the FasterNet patch
  * convolutions (models/common.py:1528-1561), depending on gather/pro. */
 int ly_gemm_fwd(const LyGemmParams* p, void* stream);
+/* tuning aid: force the GEMM tile configuration (NT*100 + MT*10 + WC), 0 = heuristic */
+int ly_debug_set_gemm_cfg(int cfg);
 
 
 /* ---- 3x3 / s1 / p1 convolution (implicit GEMM) ------------------------------------------------- */
@@ -70,7 +73,7 @@ typedef struct LyConv3Params {
   long M; int H, W;        /* output (= input) pixels, spatial size                              */
   int Cin, N;              /* input channels (multiple of 4), output channels                    */
   const float* x; int ldx; /* NHWC input, row stride (floats)                                    */
-  const float* wp;         /* frag_pack(conv_taps_matrix(weight, 16)): k = tap*ceil16(Cin) + c   */
+  const void* wp;          /* frag_pack3(conv_taps_matrix(weight, 32)): k = tap*ceil32(Cin) + c  */
   const float* e_scale; const float* e_shift;   /* folded BN / bias, [N] or NULL                 */
   int act;
   float* out; int ldo;
@@ -116,7 +119,7 @@ typedef struct LyRfcbam3Params {
   const float* wg;             /* [C][90] folded generate weights/biases                          */
   const float* ca;             /* [n_img, C]                                                      */
   const float* rfa;            /* [n_img, 3Ho, 3Wo]                                               */
-  const float* wp;             /* frag_pack(conv.0.weight.view(N, 9C))                            */
+  const void* wp;              /* frag_pack3(conv.0.weight as [N, C/16, 144 -> 160 zero padded])  */
   const float* e_scale; const float* e_shift;   /* conv.1 BN folded with conv.0.bias              */
   float* out; int ldo;
 } LyRfcbam3Params;

@@ -46,8 +46,9 @@ PRO_NONE, PRO_GATE, PRO_AFFINE_RELU_CA = 0, 1, 2
 SIGNATURES = {
     "ly_abi_version": [],
     "ly_mlpblock_fwd": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
-    "ly_mlpblock_pack_sizes": [_I, _LP, _LP, _LP],
+    "ly_mlpblock_hidden_tiles": [_I],
     "ly_gemm_fwd": [ctypes.POINTER(LyGemmParams), _P],
+    "ly_debug_set_gemm_cfg": [_I],
     "ly_conv3x3_fwd": [ctypes.POINTER(LyConv3Params), _P],
     "ly_pool_hw": [_P, _I, _I, _I, _I, _I, _P, _P],
     "ly_coordatt_mlp": [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],

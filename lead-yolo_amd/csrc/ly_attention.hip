@@ -10,7 +10,7 @@
 //   ly_rfa_map        sigmoid(conv3x3([max, mean]))          (models/rfa.py:107,127)
 #include <float.h>
 
-#include "ly_common.cuh"
+#include "ly_tile.cuh"
 #include "ly_params.h"
 
 // ---------------------------------------------------------------------------------------------------
@@ -220,15 +220,18 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_stats3_kernel(const floa
 
   for (int c0 = 0; c0 < C; c0 += LY_SCC) {
     __syncthreads();
-    for (int idx = tid; idx < IH * IW * (LY_SCC / 4); idx += LY_THREADS) {
-      const int ip = idx / (LY_SCC / 4), c4 = idx - ip * (LY_SCC / 4);
-      const int iy = iy0 + ip / IW, ix = ix0 + ip % IW;
-      const int c = c0 + 4 * c4;
-      f32x4 v = ly_zero4();
-      if (iy >= 0 && iy < H && ix >= 0 && ix < W && c < C) v = ly_ldg4(x + (((long)n * H + iy) * W + ix) * ldx + c);
-      float* d = xs + ip * (LY_SCC + 1) + 4 * c4;
-      d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
-    }
+    ly_stage_f4<8>(IH * IW * (LY_SCC / 4), tid, x,
+        [&](int idx) -> const float* {
+          const int ip = idx / (LY_SCC / 4), c4 = idx - ip * (LY_SCC / 4);
+          const int iy = iy0 + ip / IW, ix = ix0 + ip % IW;
+          const int c = c0 + 4 * c4;
+          return (iy >= 0 && iy < H && ix >= 0 && ix < W && c < C) ? x + (((long)n * H + iy) * W + ix) * ldx + c : nullptr;
+        },
+        [&](int idx, f32x4 v) {
+          const int ip = idx / (LY_SCC / 4), c4 = idx - ip * (LY_SCC / 4);
+          float* d = xs + ip * (LY_SCC + 1) + 4 * c4;
+          d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+        });
     __syncthreads();
     if (active) {
       const int cend = (C - c0) < LY_SCC ? (C - c0) : LY_SCC;

@@ -1,4 +1,4 @@
-// Pointwise-convolution GEMM with fused gather/prologue and epilogue, fp32, gfx950.
+// Pointwise-convolution GEMM with fused gather/prologue and epilogue, fp32 I/O, bf16x3 math, gfx950.
 //
 //   out[m, n] = act( rowscale[m] * scale[n] * sum_k A'[m, k] * W[n, k] + shift[n] )
 //
@@ -16,53 +16,150 @@
 //
 // Block = 4 waves; WC waves split the output channels (distinct weight fragments per wave: no
 // redundant weight traffic), 4/WC waves split the pixels.  Wave tile = NT pixel tiles x MT channel
-// tiles of 16x16 (f32 MFMA 16x16x4, see ly_common.cuh).  K is consumed in LDS chunks of 64.
-#include "ly_common.cuh"
+// tiles of 16x16 (bf16x3 on v_mfma_f32_16x16x32_bf16, see ly_tile.cuh).
+//
+// Persistent pipeline: a block owns a strided set of pixel tiles and walks the work items
+// (tile, K-chunk of 64).  The raw fp32 values of item i+1 are loaded into registers BEFORE the MFMAs
+// of item i are issued and are transformed/split/written to the other LDS buffer after them (one
+// barrier per item), so global loads are in flight during every contraction, also across tile
+// boundaries; weight fragments are fetched one k-step ahead.
+#include "ly_tile.cuh"
 #include "ly_params.h"
 
 #define LY_BK 64
-#define LY_LDX (LY_BK + 4)
+#define LY_RSX (2 * LY_BK + 16)   // bytes per LDS row, per plane
 
-template <int NT, int MT, int WC>
-__global__ __launch_bounds__(LY_THREADS) void ly_gemm_kernel(const LyGemmParams P, const int gy, const int nblocks) {
+// exact floor(x / d) for 0 <= x < 2^24 via a float reciprocal and one fix-up step
+__device__ __forceinline__ int ly_fdiv(int x, int d, float inv) {
+  int q = (int)((float)x * inv);
+  int r = x - q * d;
+  if (r < 0) { --q; r += d; }
+  if (r >= d) ++q;
+  return q;
+}
+
+template <int NT, int MT, int WC, int GATHER, int PRO>
+__global__ __launch_bounds__(LY_THREADS) void ly_gemm_kernel(const LyGemmParams P, const int gy, const int nslots, const int gx) {
   constexpr int WP = 4 / WC;
   constexpr int BP = 16 * NT * WP;
-  __shared__ f32x4 xs4[BP * LY_LDX / 4];
-  __shared__ int r_n[BP], r_h[BP], r_w[BP];
-  __shared__ long r_row0[BP];
-  float* xs = reinterpret_cast<float*>(xs4);
+  constexpr int NV = BP * (LY_BK / 4) / LY_THREADS;      // float4 per thread per chunk; thread's pixels: tid/16 + 16e
+  static_assert(NV >= 1 && BP * (LY_BK / 4) % LY_THREADS == 0, "tile must divide evenly over the block");
+  constexpr int PLANE = BP * LY_RSX;
+  extern __shared__ f32x4 ly_smem4[];                     // [buf][plane][BP][RSX]
+  char* xs = reinterpret_cast<char*>(ly_smem4);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lq = lane >> 4;
   const int wc = wave % WC, wp_ = wave / WC;
-  const int lid = ly_xcd_remap(blockIdx.x, nblocks);
+  const int lid = ly_xcd_remap(blockIdx.x, gy * nslots);
   const int by = lid % gy;
-  const long p0 = (long)(lid / gy) * BP;
+  const int slot = lid / gy;
   const int HW = P.H * P.W;
+  const float invHW = 1.f / (float)HW, invW = 1.f / (float)P.W;
   const f32x4 zero = ly_zero4();
-  const int S = (P.K + 15) >> 4;
+  const int S = (P.K + 31) >> 5;
   const int T = (P.N + 15) >> 4;
+  const int nchunk = (P.K + LY_BK - 1) / LY_BK;
+  constexpr bool need_nhw = GATHER != LY_GATHER_ROWS || PRO != LY_PRO_NONE;
+  const int k4 = tid & 15;                                // this thread's float4 column inside a chunk
+  const int prow = tid >> 4;                              // its first pixel row; others at +16e
 
-  for (int pix = tid; pix < BP; pix += LY_THREADS) {
-    long gp = p0 + pix;
-    int n = -1, h = 0, w = 0;
-    long row0 = 0;
-    if (gp < P.M) {
-      n = (int)(gp / HW);
-      int rem = (int)(gp - (long)n * HW);
-      h = rem / P.W;
-      w = rem - h * P.W;
-      if (P.gather == LY_GATHER_UP2)
-        row0 = ((long)n * (P.H >> 1) + (h >> 1)) * (P.W >> 1) + (w >> 1);
-      else if (P.gather == LY_GATHER_PATCH)
-        row0 = (((long)n * P.Hin + (long)h * P.ks) * P.Win + (long)w * P.ks);       // first input pixel of the patch
-      else if (P.gather == LY_GATHER_PATCH_NCHW)
-        row0 = ((long)n * P.Cin * P.Hin + (long)h * P.ks) * P.Win + (long)w * P.ks; // element offset of (n, c=0, ks*h, ks*w)
-      else
-        row0 = gp;
+  // per-thread description of the NV pixels it stages for the tile being prefetched
+  long t_row0[NV];
+  int t_n[NV], t_hw[NV];
+  auto setup = [&](long p0) {
+#pragma unroll
+    for (int e = 0; e < NV; ++e) {
+      const long gp = p0 + prow + 16 * e;
+      int n = -1, h = 0, w = 0;
+      long row0 = gp;
+      if (gp < P.M) {
+        n = 0;
+        if (need_nhw) {
+          n = ly_fdiv((int)gp, HW, invHW);
+          const int rem = (int)gp - n * HW;
+          h = ly_fdiv(rem, P.W, invW);
+          w = rem - h * P.W;
+          if (GATHER == LY_GATHER_UP2)
+            row0 = ((long)n * (P.H >> 1) + (h >> 1)) * (P.W >> 1) + (w >> 1);
+          else if (GATHER == LY_GATHER_PATCH)
+            row0 = (((long)n * P.Hin + (long)h * P.ks) * P.Win + (long)w * P.ks);       // first input pixel of the patch
+          else if (GATHER == LY_GATHER_PATCH_NCHW)
+            row0 = ((long)n * P.Cin * P.Hin + (long)h * P.ks) * P.Win + (long)w * P.ks; // element offset of (n, 0, ks*h, ks*w)
+        }
+      }
+      t_row0[e] = row0; t_n[e] = n; t_hw[e] = (h << 16) | w;
     }
-    r_n[pix] = n; r_h[pix] = h; r_w[pix] = w; r_row0[pix] = row0;
-  }
+  };
+
+  f32x4 pv[NV];
+  auto prefetch = [&](long p0, int kc) {
+    // branch-free: every lane issues its NV loads back to back (clamped address), zeros are selected afterwards
+    const int kk = kc + 4 * k4;
+    const bool kok = kk < P.K;
+    long koff;                                             // element offset contributed by the k position
+    const float* src = P.a0;
+    long rowmul = P.lda0;
+    bool second = false;
+    if (GATHER == LY_GATHER_PATCH) {
+      const int seg = kk / P.pk, within = kk - seg * P.pk;
+      koff = (long)seg * P.Win * P.lda0 + within;
+    } else if (GATHER == LY_GATHER_PATCH_NCHW) {
+      const int c = kk >> 4, ky = (kk >> 2) & 3;           // ks == 4: one float4 = one (c, ky) input row segment
+      koff = ((long)c * P.Hin + ky) * P.Win;
+      rowmul = 1;
+    } else {
+      second = kk >= P.k0;
+      koff = second ? kk - P.k0 : kk;
+      if (second) { src = P.a1; rowmul = P.lda1; }
+    }
+#pragma unroll
+    for (int e = 0; e < NV; ++e) {
+      const bool ok = kok && t_n[e] >= 0;
+      const long row = second ? (p0 + prow + 16 * e) : t_row0[e];
+      const float* ptr = ok ? src + row * rowmul + koff : P.a0;
+      pv[e] = ly_ldg4(ptr);
+    }
+#pragma unroll
+    for (int e = 0; e < NV; ++e)
+      if (!(kok && t_n[e] >= 0)) pv[e] = zero;
+  };
+  auto commit = [&](long p0, int kc, int buf) {
+    char* hi = xs + buf * 2 * PLANE;
+    char* lo = hi + PLANE;
+    const int kk = kc + 4 * k4;
+    if (PRO == LY_PRO_GATE) {
+      const bool kok = kk < P.k0;
+      f32x4 gw[NV], gh[NV], rr[NV];
+#pragma unroll
+      for (int e = 0; e < NV; ++e) {
+        const bool ok = kok && t_n[e] >= 0;
+        const int n = ok ? t_n[e] : 0, h = ok ? (t_hw[e] >> 16) : 0, w = ok ? (t_hw[e] & 0xffff) : 0;
+        const int kq = ok ? kk : 0;
+        gw[e] = ly_ldg4(P.g_w + ((long)n * P.W + w) * P.k0 + kq);
+        gh[e] = ly_ldg4(P.g_h + ((long)n * P.H + h) * P.k0 + kq);
+        rr[e] = (P.res && ok) ? ly_ldg4(P.res + (p0 + prow + 16 * e) * P.ldres + kq) : zero;
+      }
+#pragma unroll
+      for (int e = 0; e < NV; ++e)
+        if (kok && t_n[e] >= 0) pv[e] = pv[e] * gw[e] * gh[e] + rr[e];
+    } else if (PRO == LY_PRO_AFFINE_RELU_CA) {
+      const bool kok = kk < P.K;
+      const int kq = kok ? kk : 0;
+      const f32x4 sa = ly_ldg4(P.p_scale + kq), sb = ly_ldg4(P.p_shift + kq);
+      f32x4 ca[NV];
+#pragma unroll
+      for (int e = 0; e < NV; ++e) ca[e] = ly_ldg4(P.p_ca + (long)(t_n[e] >= 0 ? t_n[e] : 0) * P.K + kq);
+#pragma unroll
+      for (int e = 0; e < NV; ++e)
+        if (kok && t_n[e] >= 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pv[e][r] = fmaxf(pv[e][r] * sa[r] + sb[r], 0.f) * ca[e][r];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < NV; ++e) ly_lds_put4(hi, lo, (prow + 16 * e) * LY_RSX, 4 * k4, pv[e]);
+  };
 
   f32x4 acc[MT][NT];
 #pragma unroll
@@ -70,117 +167,168 @@ __global__ __launch_bounds__(LY_THREADS) void ly_gemm_kernel(const LyGemmParams 
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[t][n] = zero;
 
-  int tile[MT];
+  long wbase[MT];
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
     int tt = (by * WC + wc) * MT + t;
-    tile[t] = tt < T ? tt : T - 1;
+    wbase[t] = (long)(tt < T ? tt : T - 1) * S;
   }
-  const f32x4* wpk = reinterpret_cast<const f32x4*>(P.wp);
+  const uint4* wpk = reinterpret_cast<const uint4*>(P.wp);
   const int pixgrp = wp_ * (16 * NT);
-
-  for (int kc = 0; kc < P.K; kc += LY_BK) {
-    __syncthreads();
-    // ---- stage A'[BP x 64] ----------------------------------------------------------------------
-    for (int idx = tid; idx < BP * (LY_BK / 4); idx += LY_THREADS) {
-      const int pix = idx / (LY_BK / 4), k4 = idx - pix * (LY_BK / 4);
-      const int kk = kc + 4 * k4;
-      const int n = r_n[pix];
-      f32x4 v = zero;
-      if (n >= 0 && kk < P.K) {
-        const long row0 = r_row0[pix];
-        if (P.gather == LY_GATHER_PATCH) {
-          const int seg = kk / P.pk, within = kk - seg * P.pk;
-          v = ly_ldg4(P.a0 + (row0 + (long)seg * P.Win) * P.lda0 + within);
-        } else if (P.gather == LY_GATHER_PATCH_NCHW) {
-          const int c = kk / (P.ks * P.ks), ky = (kk - c * P.ks * P.ks) / P.ks;   // ks == 4: one float4 = one (c, ky) row
-          v = ly_ldg4(P.a0 + row0 + ((long)c * P.Hin + ky) * P.Win);
-        } else if (kk < P.k0) {
-          v = ly_ldg4(P.a0 + row0 * P.lda0 + kk);
-          if (P.pro == LY_PRO_GATE) {
-            const f32x4 gw = ly_ldg4(P.g_w + ((long)n * P.W + r_w[pix]) * P.k0 + kk);
-            const f32x4 gh = ly_ldg4(P.g_h + ((long)n * P.H + r_h[pix]) * P.k0 + kk);
-            v = v * gw * gh;
-            if (P.res) v = v + ly_ldg4(P.res + (p0 + pix) * P.ldres + kk);
-          }
-        } else {
-          v = ly_ldg4(P.a1 + (p0 + pix) * P.lda1 + (kk - P.k0));
-        }
-        if (P.pro == LY_PRO_AFFINE_RELU_CA) {
-          const f32x4 s = ly_ldg4(P.p_scale + kk), b = ly_ldg4(P.p_shift + kk);
-          const f32x4 ca = ly_ldg4(P.p_ca + (long)n * P.K + kk);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r] * s[r] + b[r], 0.f) * ca[r];
-        }
-      }
-      *reinterpret_cast<f32x4*>(xs + pix * LY_LDX + 4 * k4) = v;
-    }
-    __syncthreads();
-    // ---- contract -------------------------------------------------------------------------------
-    const int s0 = kc >> 4;
-    const int ns = (S - s0) < (LY_BK / 16) ? (S - s0) : (LY_BK / 16);
-    for (int s = 0; s < ns; ++s) {
-      f32x4 xf[NT];
-#pragma unroll
-      for (int n = 0; n < NT; ++n)
-        xf[n] = *reinterpret_cast<const f32x4*>(xs + (pixgrp + 16 * n + li) * LY_LDX + 16 * s + 4 * lq);
-#pragma unroll
-      for (int t = 0; t < MT; ++t) {
-        const f32x4 wf = wpk[((long)tile[t] * S + s0 + s) * 64 + lane];
-#pragma unroll
-        for (int n = 0; n < NT; ++n) acc[t][n] = ly_mfma4(wf, xf[n], acc[t][n]);
-      }
-    }
-  }
-
-  // ---- epilogue ---------------------------------------------------------------------------------
   const bool vec_ok = (P.ldo & 3) == 0;
+  float esc[MT][4], esh[MT][4];                            // epilogue scale/shift: fetched once, not per tile
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
-    const int tt = (by * WC + wc) * MT + t;
-    const int c = 16 * tt + 4 * lq;
-    if (tt >= T || c >= P.N) continue;
-    float sc[4], sh[4];
+    const int c = 16 * ((by * WC + wc) * MT + t) + 4 * lq;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const bool ok = c + r < P.N;
-      sc[r] = (ok && P.e_scale) ? P.e_scale[c + r] : 1.f;
-      sh[r] = (ok && P.e_shift) ? P.e_shift[c + r] : 0.f;
-    }
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      const long gp = p0 + pixgrp + 16 * n + li;
-      if (gp >= P.M) continue;
-      const float rs = P.rowscale ? P.rowscale[gp] : 1.f;
-      f32x4 v;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float u = acc[t][n][r] * rs * sc[r] + sh[r];
-        v[r] = P.act == LY_ACT_RELU ? ly_relu(u) : (P.act == LY_ACT_SILU ? ly_silu(u) : u);
-      }
-      float* o = P.out + gp * P.ldo + c;
-      if (vec_ok && c + 3 < P.N) {
-        ly_stg4(o, v);
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (c + r < P.N) o[r] = v[r];
-      }
+      esc[t][r] = (ok && P.e_scale) ? P.e_scale[c + r] : 1.f;
+      esh[t][r] = (ok && P.e_shift) ? P.e_shift[c + r] : 0.f;
     }
   }
+
+  if (slot >= gx) return;                                  // (host never launches such blocks)
+  LyWFrag wcur[MT], wnxt[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) wcur[t] = ly_wfrag(wpk, wbase[t], lane);
+
+  // work items = (pixel tile, K chunk); item i+1 is always in flight while item i is contracted
+  long p0 = (long)slot * BP;                               // tile being computed
+  long pn = p0;                                            // tile being prefetched
+  int cn = 0;                                              // chunk being prefetched
+  setup(pn);
+  prefetch(pn, 0);
+  commit(pn, 0, 0);
+  __syncthreads();
+  int buf = 0;
+  int pt = slot;
+  while (true) {
+    for (int c = 0; c < nchunk; ++c) {
+      // advance the prefetch cursor to the item after (pt, c)
+      bool more = true;
+      if (cn + 1 < nchunk) {
+        ++cn;
+      } else if (pt + nslots < gx && c == nchunk - 1) {
+        cn = 0;
+        pn = (long)(pt + nslots) * BP;
+        setup(pn);
+      } else if (c == nchunk - 1) {
+        more = false;
+      }
+      // second k-step's weights first (older in the in-order vmcnt queue than the activation prefetch)
+      {
+        const int g1 = 2 * c + 1 < S ? 2 * c + 1 : 0;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) wnxt[t] = ly_wfrag(wpk, wbase[t] + g1, lane);
+      }
+      if (more) prefetch(pn, cn * LY_BK);
+      const char* hi = xs + buf * 2 * PLANE;
+      const char* lo = hi + PLANE;
+#pragma unroll
+      for (int s = 0; s < LY_BK / 32; ++s) {
+        const int gs = 2 * c + s;
+        if (gs < S) {
+          if (s == 1) {                                    // weights of the next item's first step
+            const int gn = gs + 1 < S ? gs + 1 : 0;
+#pragma unroll
+            for (int t = 0; t < MT; ++t) wnxt[t] = ly_wfrag(wpk, wbase[t] + gn, lane);
+          }
+          bf16x8 xh[NT], xl[NT];
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            const int rb = (pixgrp + 16 * n + li) * LY_RSX;
+            xh[n] = ly_lds_frag(hi, rb, s, lq);
+            xl[n] = ly_lds_frag(lo, rb, s, lq);
+          }
+#pragma unroll
+          for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[t][n] = ly_mfma3(wcur[t].hi, wcur[t].lo, xh[n], xl[n], acc[t][n]);
+#pragma unroll
+          for (int t = 0; t < MT; ++t) wcur[t] = wnxt[t];
+        }
+      }
+      if (more) commit(pn, cn * LY_BK, buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
+    // ---- epilogue of tile pt -----------------------------------------------------------------------
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const int tt = (by * WC + wc) * MT + t;
+      const int c = 16 * tt + 4 * lq;
+      if (tt < T && c < P.N) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const long gp = p0 + pixgrp + 16 * n + li;
+          if (gp < P.M) {
+            const float rs = P.rowscale ? P.rowscale[gp] : 1.f;
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float u = acc[t][n][r] * rs * esc[t][r] + esh[t][r];
+              v[r] = P.act == LY_ACT_RELU ? ly_relu(u) : (P.act == LY_ACT_SILU ? ly_silu(u) : u);
+            }
+            float* o = P.out + gp * P.ldo + c;
+            if (vec_ok && c + 3 < P.N) {
+              ly_stg4(o, v);
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if (c + r < P.N) o[r] = v[r];
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[t][n] = zero;
+    }
+    pt += nslots;
+    if (pt >= gx) break;
+    p0 = (long)pt * BP;
+  }
+}
+
+static int g_gemm_cfg = 0;      // 0 = heuristic; otherwise forced NT*100 + MT*10 + WC (tuning aid)
+extern "C" int ly_debug_set_gemm_cfg(int cfg) { g_gemm_cfg = cfg; return 0; }
+
+template <int NT, int MT, int WC, int GATHER, int PRO>
+static int launch_gemm_mode(const LyGemmParams& P, hipStream_t st) {
+  constexpr int BP = 16 * NT * (4 / WC);
+  constexpr int BN = 16 * MT * WC;
+  constexpr size_t lds = 4 * (size_t)BP * LY_RSX;
+  long gx = (P.M + BP - 1) / BP;
+  int gy = (P.N + BN - 1) / BN;
+  LY_CHECK(gx < (1L << 30), "gemm: too many pixel tiles");
+  const int per_cu = (int)(160 * 1024 / lds) < 4 ? (int)(160 * 1024 / lds) : 4;   // co-resident blocks by LDS
+  long nslots = (256L * per_cu) / gy;
+  if (nslots < 1) nslots = 1;
+  if (nslots > gx) nslots = gx;
+  auto k = ly_gemm_kernel<NT, MT, WC, GATHER, PRO>;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+    LY_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    configured = true;
+  }
+  hipLaunchKernelGGL(k, dim3((unsigned)(nslots * gy)), dim3(LY_THREADS), lds, st, P, gy, (int)nslots, (int)gx);
+  LY_LAUNCH_CHECK();
+  return 0;
 }
 
 template <int NT, int MT, int WC>
 static int launch_gemm(const LyGemmParams& P, hipStream_t st) {
-  constexpr int BP = 16 * NT * (4 / WC);
-  constexpr int BN = 16 * MT * WC;
-  long gx = (P.M + BP - 1) / BP;
-  int gy = (P.N + BN - 1) / BN;
-  long nb = gx * gy;
-  LY_CHECK(nb < (1L << 31), "gemm: grid too large");
-  hipLaunchKernelGGL((ly_gemm_kernel<NT, MT, WC>), dim3((unsigned)nb), dim3(LY_THREADS), 0, st, P, gy, (int)nb);
-  LY_LAUNCH_CHECK();
-  return 0;
+  if (P.gather == LY_GATHER_PATCH) return launch_gemm_mode<NT, MT, WC, LY_GATHER_PATCH, LY_PRO_NONE>(P, st);
+  if (P.gather == LY_GATHER_PATCH_NCHW) return launch_gemm_mode<NT, MT, WC, LY_GATHER_PATCH_NCHW, LY_PRO_NONE>(P, st);
+  if (P.gather == LY_GATHER_UP2) {
+    if (P.pro == LY_PRO_NONE) return launch_gemm_mode<NT, MT, WC, LY_GATHER_UP2, LY_PRO_NONE>(P, st);
+    ly_set_error("gemm: upsampled source with a prologue is not built");
+    return -1;
+  }
+  if (P.pro == LY_PRO_GATE) return launch_gemm_mode<NT, MT, WC, LY_GATHER_ROWS, LY_PRO_GATE>(P, st);
+  if (P.pro == LY_PRO_AFFINE_RELU_CA) return launch_gemm_mode<NT, MT, WC, LY_GATHER_ROWS, LY_PRO_AFFINE_RELU_CA>(P, st);
+  return launch_gemm_mode<NT, MT, WC, LY_GATHER_ROWS, LY_PRO_NONE>(P, st);
 }
 
 extern "C" int ly_gemm_fwd(const LyGemmParams* p, void* stream) {
@@ -204,20 +352,22 @@ extern "C" int ly_gemm_fwd(const LyGemmParams* p, void* stream) {
   }
   if (P.pro == LY_PRO_GATE) LY_CHECK(P.g_h && P.g_w, "gemm: gate prologue needs g_h/g_w");
   if (P.pro == LY_PRO_AFFINE_RELU_CA) LY_CHECK(P.p_scale && P.p_shift && P.p_ca, "gemm: affine prologue needs scale/shift/ca");
+  LY_CHECK(P.M < (1L << 24), "gemm: M=%ld pixels exceeds the 2^24 limit of the fast index path", P.M);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const long M = P.M;
-  if (P.N > 128) {
-    if (M >= 64L * 512) return launch_gemm<4, 4, 4>(P, st);   // 64 px x 256 ch
-    return launch_gemm<2, 4, 4>(P, st);                        // 32 px x 256 ch
+  switch (g_gemm_cfg) {
+    case 844: return launch_gemm<8, 4, 4>(P, st);
+    case 824: return launch_gemm<8, 2, 4>(P, st);
+    case 814: return launch_gemm<8, 1, 4>(P, st);
+    case 444: return launch_gemm<4, 4, 4>(P, st);
+    case 424: return launch_gemm<4, 2, 4>(P, st);
+    case 414: return launch_gemm<4, 1, 4>(P, st);
+    case 221: return launch_gemm<2, 2, 1>(P, st);
+    case 121: return launch_gemm<1, 2, 1>(P, st);
+    default: break;
   }
-  if (P.N > 64) {
-    if (M >= 64L * 512) return launch_gemm<4, 2, 4>(P, st);   // 64 px x 128 ch
-    return launch_gemm<2, 2, 4>(P, st);                        // 32 px x 128 ch
-  }
-  if (P.N > 32) {
-    if (M >= 64L * 512) return launch_gemm<4, 2, 2>(P, st);   // 128 px x 64 ch
-    return launch_gemm<2, 2, 2>(P, st);                        // 64 px x 64 ch
-  }
-  if (M >= 128L * 512) return launch_gemm<2, 2, 1>(P, st);    // 128 px x 32 ch
-  return launch_gemm<1, 2, 1>(P, st);                          // 64 px x 32 ch
+  // measured on MI355X (tools_gcfg.py): 64-pixel tiles with 3 co-resident blocks per CU beat the
+  // 128-pixel tiles (1 wave/SIMD) on every LEAD-YOLO shape
+  if (P.N > 64) return launch_gemm<4, 2, 4>(P, st);    // 64 px x 128 ch per block
+  if (P.N > 32) return launch_gemm<4, 1, 4>(P, st);    // 64 px x 64 ch
+  return launch_gemm<2, 2, 1>(P, st);                  // 128 px x 32 ch
 }

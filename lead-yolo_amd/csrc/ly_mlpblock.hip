@@ -1,4 +1,4 @@
-// Fused FasterNet MLPBlock forward (eval / folded-BN form), fp32, gfx950.
+// Fused FasterNet MLPBlock forward (eval / folded-BN form), fp32 I/O, bf16x3 matrix math, gfx950.
 //
 //   y = x + W2 . relu( s * (W1 . [ pconv3x3(x[:, :C/4]) | x[:, C/4:] ]) + b )
 //
@@ -8,72 +8,90 @@
 // re-read which is an L2 hit on lines this block just fetched).
 //
 // Block = 256 threads (4 waves) owns BP = 64*NT consecutive pixels of the flattened N*H*W index
-// (NHWC rows, so its input tile is one contiguous span of memory).  Each wave owns 16*NT pixels and
-// carries them through all three contractions:
-//   1. partial 3x3 conv as an implicit GEMM over K = 9 * ceil4(C/4), operands gathered from a halo
-//      copy (ps) of the first C/4 channels with per-tap border masks; result overwrites channels
-//      [0, C/4) of the wave's own rows in the LDS tile xs (the "concat" is a no-op).
-//   2. hidden = relu(bn(W1 . xs_row)): HT hidden tiles at a time.
-//   3. out += W2[:, hidden tile] . hidden   -- the MFMA D tile of step 2 IS the B operand (see
-//      ly_common.cuh), so the hidden activations live only in registers.
-// Weights are frag-packed and read straight from global/L2 (they are shared by every block).
-#include "ly_common.cuh"
+// (NHWC rows, so its input tile is one contiguous span of memory).  The tile is split once into
+// bf16 hi/lo planes in LDS (ly_tile.cuh).  Each wave owns 16*NT pixels and carries them through all
+// three contractions:
+//   1. partial 3x3 conv as an implicit GEMM over K = 9 * ceil4(C/4): operands are 8-byte gathers from
+//      a halo image (ps) of the first C/4 channels with per-tap border masks; the result overwrites
+//      channels [0, C/4) of the wave's own rows of the tile (the "concat" is a no-op).
+//   2. hidden = relu(bn(W1 . row)), HT hidden tiles at a time, kept in registers.
+//   3. out += W2[:, hidden pair] . hidden -- two fp32 D tiles of step 2, split in registers, ARE the
+//      B operand of one k-step (ly_tile.cuh), so the hidden activations never leave the register file.
+#include "ly_tile.cuh"
+
+template <int C>
+struct MlpGeom {
+  static constexpr int CQ = C / 4;
+  static constexpr int CQP = (CQ + 3) / 4 * 4;
+  static constexpr int G = CQP / 4;                 // 4-channel groups per tap
+  static constexpr int SP = (9 * G + 7) / 8;        // pconv k-steps (8 groups each)
+  static constexpr int PT = (CQ + 15) / 16;         // pconv output tiles
+  static constexpr int C16 = (C + 15) / 16;         // output tiles
+  static constexpr int KP = (C + 31) / 32 * 32;
+  static constexpr int S1 = KP / 32;                // GEMM1 k-steps
+  static constexpr int RS = 2 * KP + 16;            // xs row stride (bytes)
+  static constexpr int RSP = 2 * CQP + 8;           // ps row stride (bytes)
+  static constexpr int HTP = (2 * C / 16 + 1) / 2 * 2;   // hidden tiles, padded to even
+  static constexpr int S2 = HTP / 2;                // GEMM2 k-steps
+};
 
 template <int C, int NT, int HT>
 __global__ __launch_bounds__(LY_THREADS) void ly_mlpblock_fwd_kernel(
     const float* __restrict__ x, float* __restrict__ y, long M, int H, int W,
-    const f32x4* __restrict__ wp, const f32x4* __restrict__ w1, const f32x4* __restrict__ w2,
+    const uint4* __restrict__ wp, const uint4* __restrict__ w1, const uint4* __restrict__ w2,
     const float* __restrict__ bn_scale, const float* __restrict__ bn_shift) {
-  constexpr int CQ = C / 4;
-  constexpr int CQP = (CQ + 3) / 4 * 4;
-  constexpr int G = CQP / 4;
-  constexpr int SP = (9 * G + 3) / 4;
-  constexpr int PT = (CQ + 15) / 16;
-  constexpr int C16 = (C + 15) / 16;
-  constexpr int XV = C16 * 4;
-  constexpr int LDX = C16 * 16 + 4;
-  constexpr int LDP = CQP + 4;
-  constexpr int HTILES = 2 * C / 16;
+  using Gm = MlpGeom<C>;
+  constexpr int CQ = Gm::CQ, G = Gm::G, SP = Gm::SP, PT = Gm::PT, C16 = Gm::C16, KP = Gm::KP, S1 = Gm::S1;
+  constexpr int RS = Gm::RS, RSP = Gm::RSP, HTP = Gm::HTP, S2 = Gm::S2;
   constexpr int BP = 64 * NT;
-  static_assert(HTILES % HT == 0, "hidden tiles must split evenly into chunks");
+  static_assert(HTP % HT == 0 && HT % 2 == 0, "hidden tiles must split evenly into even chunks");
   static_assert(C % 8 == 0, "C must be a multiple of 8");
 
   extern __shared__ f32x4 ly_smem4[];
-  float* xs = reinterpret_cast<float*>(ly_smem4);
-  float* ps = xs + BP * LDX;
+  char* xs_hi = reinterpret_cast<char*>(ly_smem4);
+  char* xs_lo = xs_hi + BP * RS;
+  const int BPH = BP + 2 * W + 2;
+  char* ps_hi = xs_lo + BP * RS;
+  char* ps_lo = ps_hi + BPH * RSP;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lq = lane >> 4;
   const long p0 = (long)blockIdx.x * BP;
-  const int BPH = BP + 2 * W + 2;
   const f32x4 zero = ly_zero4();
 
-  for (int idx = tid; idx < BP * XV; idx += LY_THREADS) {
-    int pix = idx / XV, c4 = idx - pix * XV;
-    long gp = p0 + pix;
-    f32x4 v = zero;
-    if (gp < M && c4 * 4 < C) v = ly_ldg4(x + gp * C + c4 * 4);
-    *reinterpret_cast<f32x4*>(xs + pix * LDX + c4 * 4) = v;
-  }
-  for (int idx = tid; idx < BPH * G; idx += LY_THREADS) {
-    int hp = idx / G, c4 = idx - hp * G;
-    long gp = p0 - W - 1 + hp;
-    f32x4 v = zero;
-    if (gp >= 0 && gp < M) v = ly_ldg4(x + gp * C + c4 * 4);
-    *reinterpret_cast<f32x4*>(ps + hp * LDP + c4 * 4) = v;
-  }
+  ly_stage_f4<8>(BP * (KP / 4), tid, x,
+      [&](int idx) -> const float* {
+        const int pix = idx / (KP / 4), c4 = idx - pix * (KP / 4);
+        const long gp = p0 + pix;
+        return (gp < M && c4 * 4 < C) ? x + gp * C + c4 * 4 : nullptr;
+      },
+      [&](int idx, f32x4 v) {
+        const int pix = idx / (KP / 4), c4 = idx - pix * (KP / 4);
+        ly_lds_put4(xs_hi, xs_lo, pix * RS, 4 * c4, v);
+      });
+  ly_stage_f4<4>(BPH * G, tid, x,
+      [&](int idx) -> const float* {
+        const int hp = idx / G, c4 = idx - hp * G;
+        const long gp = p0 - W - 1 + hp;
+        return (gp >= 0 && gp < M) ? x + gp * C + c4 * 4 : nullptr;
+      },
+      [&](int idx, f32x4 v) {
+        const int hp = idx / G, c4 = idx - hp * G;
+        ly_lds_put4(ps_hi, ps_lo, hp * RSP, 4 * c4, v);
+      });
   __syncthreads();
 
   const int pixbase = wave * (16 * NT);
+  const bf16x4 z4 = __builtin_bit_cast(bf16x4, make_uint2(0u, 0u));
 
   // ---- 1. partial 3x3 conv -------------------------------------------------------------------
   {
     uint32_t tmask[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
-      long gp = p0 + pixbase + 16 * n + li;
-      int w_ = (int)(gp % W);
-      int h_ = (int)((gp / W) % H);
+      const long gp = p0 + pixbase + 16 * n + li;
+      const int w_ = (int)(gp % W);
+      const int h_ = (int)((gp / W) % H);
       tmask[n] = ly_tapmask(h_, w_, H, W, gp < M);
     }
     f32x4 accp[PT][NT];
@@ -84,35 +102,57 @@ __global__ __launch_bounds__(LY_THREADS) void ly_mlpblock_fwd_kernel(
 
 #pragma unroll
     for (int s = 0; s < SP; ++s) {
-      const int g = 4 * s + lq;
-      const bool gv = g < 9 * G;
-      const int tap = gv ? g / G : 0;
-      const int cq4 = gv ? g - tap * G : 0;
-      const int ty = tap / 3, tx = tap - 3 * ty;
-      const int off = (ty * W + tx) * LDP + cq4 * 4;
-      f32x4 xf[NT];
+      int off[2], tap[2];
+      bool gv[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int g = 8 * s + 4 * h + lq;
+        gv[h] = g < 9 * G;
+        tap[h] = gv[h] ? g / G : 0;
+        const int cq4 = gv[h] ? g - tap[h] * G : 0;
+        const int ty = tap[h] / 3, tx = tap[h] - 3 * ty;
+        off[h] = (ty * W + tx) * RSP + 8 * cq4;
+      }
+      bf16x8 xh[NT], xl[NT];
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(ps + (pixbase + 16 * n + li) * LDP + off);
-        bool ok = gv && ((tmask[n] >> tap) & 1u);
-        xf[n] = ok ? v : zero;
+        const int rb = (pixbase + 16 * n + li) * RSP;
+        bf16x4 ph[2], pl[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const bool ok = gv[h] && ((tmask[n] >> tap[h]) & 1u);
+          const bf16x4 a = *reinterpret_cast<const bf16x4*>(ps_hi + rb + off[h]);
+          const bf16x4 b = *reinterpret_cast<const bf16x4*>(ps_lo + rb + off[h]);
+          ph[h] = ok ? a : z4;
+          pl[h] = ok ? b : z4;
+        }
+        xh[n] = ly_cat8(ph[0], ph[1]);
+        xl[n] = ly_cat8(pl[0], pl[1]);
       }
 #pragma unroll
       for (int t = 0; t < PT; ++t) {
-        f32x4 wf = wp[(t * SP + s) * 64 + lane];
+        const LyWFrag wf = ly_wfrag(wp, t * SP + s, lane);
 #pragma unroll
-        for (int n = 0; n < NT; ++n) accp[t][n] = ly_mfma4(wf, xf[n], accp[t][n]);
+        for (int n = 0; n < NT; ++n) accp[t][n] = ly_mfma3(wf.hi, wf.lo, xh[n], xl[n], accp[t][n]);
       }
     }
 #pragma unroll
     for (int t = 0; t < PT; ++t)
 #pragma unroll
-      for (int n = 0; n < NT; ++n)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          int c = 16 * t + 4 * lq + r;
-          if (c < CQ) xs[(pixbase + 16 * n + li) * LDX + c] = accp[t][n][r];
+      for (int n = 0; n < NT; ++n) {
+        bf16x4 h, l;
+        ly_split4(accp[t][n], h, l);
+        const int c = 16 * t + 4 * lq;
+        const int rb = (pixbase + 16 * n + li) * RS + 2 * c;
+        if (c < CQ) {            // CQ is even: channels (c, c+1) are valid together
+          *reinterpret_cast<bf16x2*>(xs_hi + rb) = __builtin_shufflevector(h, h, 0, 1);
+          *reinterpret_cast<bf16x2*>(xs_lo + rb) = __builtin_shufflevector(l, l, 0, 1);
         }
+        if (c + 2 < CQ) {
+          *reinterpret_cast<bf16x2*>(xs_hi + rb + 4) = __builtin_shufflevector(h, h, 2, 3);
+          *reinterpret_cast<bf16x2*>(xs_lo + rb + 4) = __builtin_shufflevector(l, l, 2, 3);
+        }
+      }
   }
 
   // ---- 2 + 3. expand -> BN -> ReLU -> project, hidden kept in registers ---------------------------
@@ -123,42 +163,56 @@ __global__ __launch_bounds__(LY_THREADS) void ly_mlpblock_fwd_kernel(
     for (int n = 0; n < NT; ++n) acco[t][n] = zero;
 
 #pragma unroll 1
-  for (int hc = 0; hc < HTILES / HT; ++hc) {
+  for (int hc = 0; hc < HTP / HT; ++hc) {
     f32x4 acch[HT][NT];
 #pragma unroll
     for (int t = 0; t < HT; ++t)
 #pragma unroll
       for (int n = 0; n < NT; ++n) acch[t][n] = zero;
 #pragma unroll
-    for (int s = 0; s < C16; ++s) {
-      f32x4 xf[NT];
+    for (int s = 0; s < S1; ++s) {
+      bf16x8 xh[NT], xl[NT];
 #pragma unroll
-      for (int n = 0; n < NT; ++n)
-        xf[n] = *reinterpret_cast<const f32x4*>(xs + (pixbase + 16 * n + li) * LDX + 16 * s + 4 * lq);
+      for (int n = 0; n < NT; ++n) {
+        const int rb = (pixbase + 16 * n + li) * RS;
+        xh[n] = ly_lds_frag(xs_hi, rb, s, lq);
+        xl[n] = ly_lds_frag(xs_lo, rb, s, lq);
+      }
 #pragma unroll
       for (int t = 0; t < HT; ++t) {
-        f32x4 wf = w1[((hc * HT + t) * C16 + s) * 64 + lane];
+        const LyWFrag wf = ly_wfrag(w1, (hc * HT + t) * S1 + s, lane);
 #pragma unroll
-        for (int n = 0; n < NT; ++n) acch[t][n] = ly_mfma4(wf, xf[n], acch[t][n]);
+        for (int n = 0; n < NT; ++n) acch[t][n] = ly_mfma3(wf.hi, wf.lo, xh[n], xl[n], acch[t][n]);
       }
     }
+    bf16x4 hh[HT][NT], hl[HT][NT];
 #pragma unroll
     for (int t = 0; t < HT; ++t) {
       const int ch = (hc * HT + t) * 16 + 4 * lq;
       const f32x4 sc = ly_ldg4(bn_scale + ch), sh = ly_ldg4(bn_shift + ch);
 #pragma unroll
-      for (int n = 0; n < NT; ++n)
+      for (int n = 0; n < NT; ++n) {
+        f32x4 v;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acch[t][n][r] = fmaxf(acch[t][n][r] * sc[r] + sh[r], 0.f);
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(acch[t][n][r] * sc[r] + sh[r], 0.f);
+        ly_split4(v, hh[t][n], hl[t][n]);
+      }
     }
 #pragma unroll
-    for (int t = 0; t < HT; ++t)
+    for (int u = 0; u < HT / 2; ++u) {
+      bf16x8 xh[NT], xl[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        xh[n] = ly_cat8(hh[2 * u][n], hh[2 * u + 1][n]);
+        xl[n] = ly_cat8(hl[2 * u][n], hl[2 * u + 1][n]);
+      }
 #pragma unroll
       for (int ct = 0; ct < C16; ++ct) {
-        f32x4 wf = w2[(ct * HTILES + hc * HT + t) * 64 + lane];
+        const LyWFrag wf = ly_wfrag(w2, ct * S2 + hc * (HT / 2) + u, lane);
 #pragma unroll
-        for (int n = 0; n < NT; ++n) acco[ct][n] = ly_mfma4(wf, acch[t][n], acco[ct][n]);
+        for (int n = 0; n < NT; ++n) acco[ct][n] = ly_mfma3(wf.hi, wf.lo, xh[n], xl[n], acco[ct][n]);
       }
+    }
   }
 
   // ---- epilogue: residual + store ------------------------------------------------------------
@@ -169,46 +223,44 @@ __global__ __launch_bounds__(LY_THREADS) void ly_mlpblock_fwd_kernel(
       const int c = 16 * ct + 4 * lq;
       const long gp = p0 + pixbase + 16 * n + li;
       if (c < C && gp < M) {
-        f32x4 r = ly_ldg4(x + gp * C + c);
+        const f32x4 r = ly_ldg4(x + gp * C + c);
         ly_stg4(y + gp * C + c, acco[ct][n] + r);
       }
     }
 }
 
 template <int C, int NT, int HT>
-static int launch_mlp(const float* x, float* y, long M, int H, int W, const float* wp, const float* w1,
-                      const float* w2, const float* s, const float* b, hipStream_t st) {
-  constexpr int CQ = C / 4, CQP = (CQ + 3) / 4 * 4, C16 = (C + 15) / 16;
-  constexpr int LDX = C16 * 16 + 4, LDP = CQP + 4, BP = 64 * NT;
-  size_t lds = sizeof(float) * ((size_t)BP * LDX + (size_t)(BP + 2 * W + 2) * LDP);
+static int launch_mlp(const float* x, float* y, long M, int H, int W, const void* wp, const void* w1, const void* w2,
+                      const float* s, const float* b, hipStream_t st) {
+  using Gm = MlpGeom<C>;
+  constexpr int BP = 64 * NT;
+  size_t lds = 2 * ((size_t)BP * Gm::RS + (size_t)(BP + 2 * W + 2) * Gm::RSP);
   LY_CHECK(lds <= 160 * 1024, "mlpblock: tile needs %zu B of LDS (C=%d W=%d)", lds, C, W);
   auto k = ly_mlpblock_fwd_kernel<C, NT, HT>;
-  static size_t configured = 0;
-  if (lds > configured) {
+  static bool configured = false;
+  if (!configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
     LY_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-    configured = 160 * 1024;
+    configured = true;
   }
   long blocks = (M + BP - 1) / BP;
-  hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(LY_THREADS), lds, st, x, y, M, H, W,
-                     reinterpret_cast<const f32x4*>(wp), reinterpret_cast<const f32x4*>(w1),
-                     reinterpret_cast<const f32x4*>(w2), s, b);
+  hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(LY_THREADS), lds, st, x, y, M, H, W, reinterpret_cast<const uint4*>(wp),
+                     reinterpret_cast<const uint4*>(w1), reinterpret_cast<const uint4*>(w2), s, b);
   LY_LAUNCH_CHECK();
   return 0;
 }
 
 // pick pixel tiles per wave so that the grid still covers the chip (256 CUs) where M is small
 template <int C, int HT, int NTMAX>
-static int dispatch_nt(const float* x, float* y, long M, int H, int W, const float* wp, const float* w1,
-                       const float* w2, const float* s, const float* b, hipStream_t st) {
-  if (NTMAX >= 4 && M >= 4L * 64 * 4 * 256) return launch_mlp<C, (NTMAX >= 4 ? 4 : NTMAX), HT>(x, y, M, H, W, wp, w1, w2, s, b, st);
-  if (NTMAX >= 2 && M >= 2L * 64 * 2 * 256) return launch_mlp<C, (NTMAX >= 2 ? 2 : NTMAX), HT>(x, y, M, H, W, wp, w1, w2, s, b, st);
+static int dispatch_nt(const float* x, float* y, long M, int H, int W, const void* wp, const void* w1, const void* w2,
+                       const float* s, const float* b, hipStream_t st) {
+  if (NTMAX >= 4 && M >= 256L * 1024) return launch_mlp<C, (NTMAX >= 4 ? 4 : NTMAX), HT>(x, y, M, H, W, wp, w1, w2, s, b, st);
+  if (NTMAX >= 2 && M >= 128L * 512) return launch_mlp<C, (NTMAX >= 2 ? 2 : NTMAX), HT>(x, y, M, H, W, wp, w1, w2, s, b, st);
   return launch_mlp<C, 1, HT>(x, y, M, H, W, wp, w1, w2, s, b, st);
 }
 
-extern "C" int ly_mlpblock_fwd(const float* x, float* y, int n_img, int H, int W, int C, const float* wp,
-                               const float* w1, const float* w2, const float* bn_scale, const float* bn_shift,
-                               void* stream) {
+extern "C" int ly_mlpblock_fwd(const float* x, float* y, int n_img, int H, int W, int C, const void* wp, const void* w1,
+                               const void* w2, const float* bn_scale, const float* bn_shift, void* stream) {
   LY_CHECK(x && y && wp && w1 && w2 && bn_scale && bn_shift, "mlpblock: null pointer");
   LY_CHECK(x != y, "mlpblock: in-place call is not supported (neighbouring tiles read halo rows)");
   LY_CHECK(n_img > 0 && H > 0 && W > 0, "mlpblock: bad shape %d x %d x %d", n_img, H, W);
@@ -216,10 +268,10 @@ extern "C" int ly_mlpblock_fwd(const float* x, float* y, int n_img, int H, int W
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   switch (C) {
     case 16:  return dispatch_nt<16, 2, 4>(x, y, M, H, W, wp, w1, w2, bn_scale, bn_shift, st);
-    case 24:  return dispatch_nt<24, 3, 4>(x, y, M, H, W, wp, w1, w2, bn_scale, bn_shift, st);
-    case 40:  return dispatch_nt<40, 5, 4>(x, y, M, H, W, wp, w1, w2, bn_scale, bn_shift, st);
-    case 80:  return dispatch_nt<80, 5, 2>(x, y, M, H, W, wp, w1, w2, bn_scale, bn_shift, st);
-    case 160: return dispatch_nt<160, 5, 2>(x, y, M, H, W, wp, w1, w2, bn_scale, bn_shift, st);
+    case 24:  return dispatch_nt<24, 4, 4>(x, y, M, H, W, wp, w1, w2, bn_scale, bn_shift, st);
+    case 40:  return dispatch_nt<40, 2, 4>(x, y, M, H, W, wp, w1, w2, bn_scale, bn_shift, st);
+    case 80:  return dispatch_nt<80, 2, 2>(x, y, M, H, W, wp, w1, w2, bn_scale, bn_shift, st);
+    case 160: return dispatch_nt<160, 4, 2>(x, y, M, H, W, wp, w1, w2, bn_scale, bn_shift, st);
     case 320: return dispatch_nt<320, 4, 1>(x, y, M, H, W, wp, w1, w2, bn_scale, bn_shift, st);
     default:
       ly_set_error("mlpblock: unsupported channel count C=%d (built for 16/24/40/80/160/320)", C);
@@ -227,12 +279,5 @@ extern "C" int ly_mlpblock_fwd(const float* x, float* y, int n_img, int H, int W
   }
 }
 
-// sizes (in floats) of the three frag-packed weight buffers for a given C
-extern "C" int ly_mlpblock_pack_sizes(int C, long* n_wp, long* n_w1, long* n_w2) {
-  int CQ = C / 4, CQP = (CQ + 3) / 4 * 4, G = CQP / 4, SP = (9 * G + 3) / 4, PT = (CQ + 15) / 16;
-  int C16 = (C + 15) / 16, HT = 2 * C / 16;
-  *n_wp = (long)PT * SP * 256;
-  *n_w1 = (long)HT * C16 * 256;
-  *n_w2 = (long)C16 * HT * 256;
-  return 0;
-}
+// geometry the host packer needs: hidden tiles (padded to even) for a given C
+extern "C" int ly_mlpblock_hidden_tiles(int C) { return (2 * C / 16 + 1) / 2 * 2; }

@@ -7,21 +7,23 @@
 // (~13 passes over the 9x tensor).  Here G is REGENERATED on chip: per 16-channel chunk the block
 // stages the raw input tile in LDS, the VALU recomputes the depthwise "generate" conv + BN + ReLU
 // (81 MAC per channel and pixel, lane = output pixel, wave-uniform weights), scales by ca and rfa and
-// writes the [64 px x 144] operand tile to LDS, which the MFMAs contract with the frag-packed
-// conv.0.weight viewed as [Cout, 9C] (its native k = c*9 + t order).  HBM sees x once and out once.
-#include "ly_common.cuh"
+// writes the [64 px x 144] operand tile (bf16 hi/lo planes) to LDS, which the MFMAs contract with the
+// bf16x3 frag-packed conv.0.weight viewed as [Cout, C/16, 144 -> 160] (native k = c*9 + t order per chunk).  HBM sees x once and out once.
+#include "ly_tile.cuh"
 #include "ly_params.h"
 
-#define LY_GCC 16
-#define LY_LDG (LY_GCC * 9 + 4)
+#define LY_GCC 16                       // channels regenerated per chunk
+#define LY_GK 160                        // 9*16 = 144 k-values per chunk, zero padded to 5 k-steps of 32
+#define LY_RSG (2 * LY_GK + 16)          // bytes per operand row, per plane
 
 template <int MT>
 __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam3_kernel(const LyRfcbam3Params P, const int gy, const int nct, const int nrt) {
   extern __shared__ f32x4 ly_smem4[];
   const int s = P.s, TH = P.TH, TW = P.TW;
   const int IH = s * (TH - 1) + 3, IW = s * (TW - 1) + 3;
-  float* gs = reinterpret_cast<float*>(ly_smem4);           // [64][LY_LDG]
-  float* xs = gs + 64 * LY_LDG;                             // [IH*IW][LY_GCC + 1]
+  char* gs_hi = reinterpret_cast<char*>(ly_smem4);          // [64][LY_RSG]
+  char* gs_lo = gs_hi + 64 * LY_RSG;
+  float* xs = reinterpret_cast<float*>(gs_lo + 64 * LY_RSG);   // [IH*IW][LY_GCC + 1]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lq = lane >> 4;
   int b = blockIdx.x;
@@ -35,7 +37,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam3_kernel(const LyRfcbam3P
   const bool active = ly < TH && oy < P.Ho && ox < P.Wo;
   const int iy0 = s * oy0 - 1, ix0 = s * ox0 - 1;
   const f32x4 zero = ly_zero4();
-  const int S = (9 * P.C) >> 4;
+  const int S = (P.C / LY_GCC) * (LY_GK / 32);
   const int T = (P.N + 15) >> 4;
 
   float rf[9];
@@ -54,18 +56,22 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam3_kernel(const LyRfcbam3P
     int tt = (by * 4 + wave) * MT + t;
     tile[t] = tt < T ? tt : T - 1;
   }
-  const f32x4* wpk = reinterpret_cast<const f32x4*>(P.wp);
+  const uint4* wpk = reinterpret_cast<const uint4*>(P.wp);
+  for (int i = tid; i < 2 * 64 * LY_RSG / 16; i += LY_THREADS) reinterpret_cast<uint4*>(gs_hi)[i] = make_uint4(0u, 0u, 0u, 0u);
 
   for (int c0 = 0; c0 < P.C; c0 += LY_GCC) {
     __syncthreads();
-    for (int idx = tid; idx < IH * IW * (LY_GCC / 4); idx += LY_THREADS) {
-      const int ip = idx / (LY_GCC / 4), c4 = idx - ip * (LY_GCC / 4);
-      const int iy = iy0 + ip / IW, ix = ix0 + ip % IW;
-      f32x4 v = zero;
-      if (iy >= 0 && iy < P.H && ix >= 0 && ix < P.W) v = ly_ldg4(P.x + (((long)n * P.H + iy) * P.W + ix) * P.ldx + c0 + 4 * c4);
-      float* d = xs + ip * (LY_GCC + 1) + 4 * c4;
-      d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
-    }
+    ly_stage_f4<4>(IH * IW * (LY_GCC / 4), tid, P.x,
+        [&](int idx) -> const float* {
+          const int ip = idx / (LY_GCC / 4), c4 = idx - ip * (LY_GCC / 4);
+          const int iy = iy0 + ip / IW, ix = ix0 + ip % IW;
+          return (iy >= 0 && iy < P.H && ix >= 0 && ix < P.W) ? P.x + (((long)n * P.H + iy) * P.W + ix) * P.ldx + c0 + 4 * c4 : nullptr;
+        },
+        [&](int idx, f32x4 v) {
+          const int ip = idx / (LY_GCC / 4), c4 = idx - ip * (LY_GCC / 4);
+          float* d = xs + ip * (LY_GCC + 1) + 4 * c4;
+          d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+        });
     __syncthreads();
     // ---- regenerate G' for channels c0 + 4*wave .. +3 -----------------------------------------------
 #pragma unroll 1
@@ -81,22 +87,29 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam3_kernel(const LyRfcbam3P
         float a = wc[81 + t];
 #pragma unroll
         for (int u = 0; u < 9; ++u) a += xv[u] * wc[t * 9 + u];
-        gs[lane * LY_LDG + cl * 9 + t] = active ? fmaxf(a, 0.f) * cav * rf[t] : 0.f;
+        const float gv = active ? fmaxf(a, 0.f) * cav * rf[t] : 0.f;
+        const __bf16 gh = (__bf16)gv;
+        const __bf16 gl = (__bf16)(gv - (float)gh);
+        *reinterpret_cast<__bf16*>(gs_hi + lane * LY_RSG + 2 * (cl * 9 + t)) = gh;
+        *reinterpret_cast<__bf16*>(gs_lo + lane * LY_RSG + 2 * (cl * 9 + t)) = gl;
       }
     }
     __syncthreads();
-    // ---- contract 144 k-values ------------------------------------------------------------------
-    const int sbase = (c0 >> 4) * 9;
-#pragma unroll 3
-    for (int st = 0; st < 9; ++st) {
-      f32x4 xf[4];
+    // ---- contract the chunk's 160 (144 real) k-values --------------------------------------------
+    const int sbase = (c0 / LY_GCC) * (LY_GK / 32);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) xf[j] = *reinterpret_cast<const f32x4*>(gs + (16 * j + li) * LY_LDG + 16 * st + 4 * lq);
+    for (int st = 0; st < LY_GK / 32; ++st) {
+      bf16x8 xh[4], xl[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        xh[j] = ly_lds_frag(gs_hi, (16 * j + li) * LY_RSG, st, lq);
+        xl[j] = ly_lds_frag(gs_lo, (16 * j + li) * LY_RSG, st, lq);
+      }
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
-        const f32x4 wf = wpk[((long)tile[t] * S + sbase + st) * 64 + lane];
+        const LyWFrag wf = ly_wfrag(wpk, (long)tile[t] * S + sbase + st, lane);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[t][j] = ly_mfma4(wf, xf[j], acc[t][j]);
+        for (int j = 0; j < 4; ++j) acc[t][j] = ly_mfma3(wf.hi, wf.lo, xh[j], xl[j], acc[t][j]);
       }
     }
   }
@@ -139,7 +152,7 @@ static int launch_rf3(const LyRfcbam3Params& P, hipStream_t st) {
   const int nct = (P.Wo + P.TW - 1) / P.TW, nrt = (P.Ho + P.TH - 1) / P.TH;
   const int gy = (P.N + 64 * MT - 1) / (64 * MT);
   const int IH = P.s * (P.TH - 1) + 3, IW = P.s * (P.TW - 1) + 3;
-  size_t lds = sizeof(float) * ((size_t)64 * LY_LDG + (size_t)IH * IW * (LY_GCC + 1));
+  size_t lds = 2 * (size_t)64 * LY_RSG + sizeof(float) * (size_t)IH * IW * (LY_GCC + 1);
   LY_CHECK(lds <= 160 * 1024, "rfcbam3: tile needs %zu B LDS", lds);
   auto k = ly_rfcbam3_kernel<MT>;
   static bool configured = false;

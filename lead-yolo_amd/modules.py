@@ -159,11 +159,12 @@ class MLPBlock(nn.Module):
 
         def build():
             c = self.dim
-            wp = pack.frag_pack(pack.conv_taps_matrix(wp_.detach(), 4))
-            w1 = pack.frag_pack(w1_.detach().view(2 * c, c))
-            w2 = pack.frag_pack(w2_.detach().view(c, 2 * c))
+            htp = (2 * c // 16 + 1) // 2 * 2
+            wp = pack.frag_pack3(pack.conv_taps_matrix(wp_.detach(), 4))
+            w1 = pack.frag_pack3(w1_.detach().view(2 * c, c), rows_to=16 * htp)
+            w2 = pack.frag_pack3(w2_.detach().view(c, 2 * c))
             sc, sh = pack.bn_scale_shift(bn)
-            return wp, w1, w2, sc, sh
+            return wp, w1, w2, pack.pad_to(sc, 16 * htp), pack.pad_to(sh, 16 * htp)
         return self._prep.get(key, build)
 
     def forward(self, x):
@@ -219,7 +220,7 @@ class _PatchConv(nn.Module):
                 sc, sh = pack.bn_scale_shift(bn, conv.bias)
             else:
                 sc, sh = None, (conv.bias.detach().float().contiguous() if conv.bias is not None else None)
-            return pack.frag_pack(wm), sc, sh
+            return pack.frag_pack3(wm), sc, sh
         return self._prep.get(key, build)
 
     def forward(self, x):
@@ -295,12 +296,12 @@ class Conv(nn.Module):
 
         def build():
             w = conv.weight.detach()
-            wm = w.view(self.c2, self.c1) if self.k == 1 else pack.conv_taps_matrix(w, 16)
+            wm = w.view(self.c2, self.c1) if self.k == 1 else pack.conv_taps_matrix(w, 32)
             if bn is not None:
                 sc, sh = pack.bn_scale_shift(bn, conv.bias)
             else:
                 sc, sh = None, (conv.bias.detach().float().contiguous() if conv.bias is not None else None)
-            return pack.frag_pack(wm), sc, sh
+            return pack.frag_pack3(wm), sc, sh
         return self._prep.get(key, build)
 
     def forward(self, x):
@@ -375,10 +376,12 @@ class RFCBAMConv(nn.Module):
             es, eb = pack.bn_scale_shift(cbn, cw.bias)
             if k == 1:
                 a1 = (gw.detach().float().view(c) * gs).contiguous()
-                return dict(a1=a1, b1=gb, w18=w18, wp=pack.frag_pack(cw.weight.detach().view(o, c)), es=es, eb=eb)
+                return dict(a1=a1, b1=gb, w18=w18, wp=pack.frag_pack3(cw.weight.detach().view(o, c)), es=es, eb=eb)
             wgm = gw.detach().float().view(c, 9, 9) * gs.view(c, 9, 1)        # [c][t][u]
             wg = torch.cat((wgm.reshape(c, 81), gb.view(c, 9)), 1).contiguous()
-            return dict(wg=wg, w18=w18, wp=pack.frag_pack(cw.weight.detach().reshape(o, 9 * c)), es=es, eb=eb)
+            wk = torch.zeros(o, c // 16, 160, dtype=torch.float32, device=gw.device)      # 144 real k per 16-channel chunk
+            wk[:, :, :144] = cw.weight.detach().float().reshape(o, c // 16, 144)
+            return dict(wg=wg, w18=w18, wp=pack.frag_pack3(wk.view(o, -1)), es=es, eb=eb)
         return self._prep.get(key, build)
 
     def forward(self, x):
@@ -527,7 +530,7 @@ class C3_CA(nn.Module):
                     parts.append((torch.ones(self.c_, device=w.device), p.conv.bias.detach().float()))
             sc = torch.cat((parts[0][0], parts[1][0])).contiguous()
             sh = torch.cat((parts[0][1], parts[1][1])).contiguous()
-            return pack.frag_pack(w), sc, sh
+            return pack.frag_pack3(w), sc, sh
         return self._prep.get(key, build)
 
     def forward(self, x):
@@ -627,7 +630,7 @@ class Detect(nn.Module):
     def _head(self, i, x):
         conv = self.m[i]
         key = pack.versions(conv.weight, conv.bias)
-        wp, b = self._prep[i].get(key, lambda: (pack.frag_pack(conv.weight.detach().view(conv.out_channels, -1)),
+        wp, b = self._prep[i].get(key, lambda: (pack.frag_pack3(conv.weight.detach().view(conv.out_channels, -1)),
                                                  conv.bias.detach().float().contiguous()))
         ldo = (conv.out_channels + 3) // 4 * 4
         L = Lazy.of(x)

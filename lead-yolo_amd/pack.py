@@ -39,3 +39,25 @@ def bn_scale_shift(bn, conv_bias=None):
 
 def versions(*tensors):
     return tuple((t.data_ptr(), t._version) if t is not None else None for t in tensors)
+
+
+def frag_pack3(w2d, rows_to=0):
+    """bf16x3 operand packing (csrc/ly_tile.cuh): W[R, K] fp32 -> int16 tensor [T, S, 2, 64, 8]
+    (planes hi = bf16(W), lo = bf16(W - hi)); lane = q*16 + i holds row 16t + i and
+    k = 32s + 16*(j >> 2) + 4q + (j & 3), j = 0..7.  Zero padded to 16 x 32 multiples."""
+    r, k = w2d.shape
+    t, s = _ceil(max(r, rows_to), 16), _ceil(k, 32)
+    wp = torch.zeros(t * 16, s * 32, dtype=torch.float32, device=w2d.device)
+    wp[:r, :k] = w2d.float()
+    hi = wp.to(torch.bfloat16)
+    lo = (wp - hi.float()).to(torch.bfloat16)
+    planes = torch.stack((hi, lo), 0)                                   # [2, T*16, S*32]
+    # [p, t, i, s, jh, q, jl] -> [t, s, p, q, i, jh, jl]
+    v = planes.view(2, t, 16, s, 2, 4, 4).permute(1, 3, 0, 5, 2, 4, 6).contiguous()
+    return v.view(t, s, 2, 64, 8).view(torch.int16)
+
+
+def pad_to(v, n):
+    out = torch.zeros(n, dtype=torch.float32, device=v.device)
+    out[:v.numel()] = v
+    return out

@@ -27,6 +27,22 @@ def patch(yolo_module=None, names=NAMES):
         except ImportError:
             pass
     replaced = {}
+    ymod = mods[0]
+    # the reference's constructor probes strides with a CPU forward (models/yolo.py:289): run it in
+    # shape-probe mode (modules.SHAPE_PROBE) so that only shapes, never values, come from the CPU
+    cls = getattr(ymod, "DetectionModel", None)
+    if cls is not None and not getattr(cls.__init__, "_ly_wrapped", False):
+        orig_init = cls.__init__
+
+        def init(self, *a, **kw):
+            M.SHAPE_PROBE = True
+            try:
+                orig_init(self, *a, **kw)
+            finally:
+                M.SHAPE_PROBE = False
+        init._ly_wrapped = True
+        replaced[(ymod.__name__, "DetectionModel.__init__")] = orig_init
+        cls.__init__ = init
     for name in names:
         new = getattr(M, name)
         for mod in mods:
@@ -38,4 +54,8 @@ def patch(yolo_module=None, names=NAMES):
 
 def unpatch(replaced):
     for (mod_name, name), old in replaced.items():
-        setattr(importlib.import_module(mod_name), name, old)
+        mod = importlib.import_module(mod_name)
+        if name == "DetectionModel.__init__":
+            mod.DetectionModel.__init__ = old
+        else:
+            setattr(mod, name, old)

@@ -127,6 +127,18 @@ typedef struct LyRfcbam3Params {
  * LY_PRO_AFFINE_RELU_CA and rowscale = rfa.                                                         */
 int ly_rfcbam3_fwd(const LyRfcbam3Params* p, void* stream);
 
+
+/* ---- graph remainder ------------------------------------------------------------------------- */
+/* SPPF pooling (models/common.py:348-366): out[n, p, :] = [x | m(x) | m(m(x)) | m(m(m(x)))] with m =
+ * k x k / stride 1 / pad k//2 max pool; out row stride ldo >= 4C.  The map must fit LDS
+ * (2*H*W*17 floats <= 160 KiB).                                                                    */
+int ly_sppf_pool(const float* x, int ldx, int n_img, int H, int W, int C, int k, float* out, int ldo, void* stream);
+/* Detect tail (models/yolo.py:95-120): y[n,h,w,na*no] (row stride ldy) -> p[n,na,h,w,no] and, if z is
+ * not NULL, decoded rows z[n, zoff + (a*H + h)*W + w, :] of a [n_img, zrows, no] tensor;
+ * anchors = [na,2] in grid units (Detect.anchors[i]), stride = Detect.stride[i].                     */
+int ly_detect_tail(const float* y, int ldy, int n_img, int H, int W, int na, int no, const float* anchors, float stride,
+                   float* p, float* z, long zrows, long zoff, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

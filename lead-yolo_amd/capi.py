@@ -57,6 +57,8 @@ SIGNATURES = {
     "ly_rfcbam_stats": [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P],
     "ly_rfa_map": [_P, _I, _I, _I, _P, _P, _P],
     "ly_rfcbam3_fwd": [ctypes.POINTER(LyRfcbam3Params), _P],
+    "ly_sppf_pool": [_P, _I, _I, _I, _I, _I, _I, _P, _I, _P],
+    "ly_detect_tail": [_P, _I, _I, _I, _I, _I, _I, _P, _F, _P, _P, _L, _L, _P],
 }
 
 

@@ -203,7 +203,8 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_stats3_kernel(const floa
   const int IH = s * (TH - 1) + 3, IW = s * (TW - 1) + 3;
   float* xs = lds;                                   // [IH*IW][LY_SCC + 1]
   float* red = lds + IH * IW * (LY_SCC + 1);         // [4][18][64]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform => scalar weight loads
   int b = blockIdx.x;
   const int ct = b % nct; b /= nct;
   const int rt = b % nrt;
@@ -365,6 +366,110 @@ extern "C" int ly_coordatt_gate(const float* x, int ldx, int n_img, int H, int W
   if (blocks > 256 * 8) blocks = 256 * 8;
   hipLaunchKernelGGL(ly_gate_kernel, dim3((unsigned)blocks), dim3(LY_THREADS), 0, reinterpret_cast<hipStream_t>(stream), x, ldx, M, H,
                      W, C, a_h, a_w, res, ldres, out, ldo);
+  LY_LAUNCH_CHECK();
+  return 0;
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// SPPF pooling: out[n, p, 0:C] = x, [C:2C] = m5(x), [2C:3C] = m5(m5(x)), [3C:4C] = m5(m5(m5(x)))
+// (k x k, stride 1, pad k//2, -inf padding; reference models/common.py:348-366).  Chained k-max pools
+// equal single (2k-1)- and (3k-2)-wide max windows, computed separably from one LDS copy of the map.
+// One block per (image, 16-channel group); the map (H*W <= 4096) lives in LDS.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(LY_THREADS) void ly_sppf_pool_kernel(const float* __restrict__ x, int ldx, int H, int W, int C, int k,
+                                                                  float* __restrict__ out, int ldo) {
+  extern __shared__ float sp[];                // a[HW][17], b[HW][17]
+  const int HW = H * W;
+  float* a = sp;
+  float* b = sp + HW * 17;
+  const int groups = (C + 15) / 16;
+  const int n = blockIdx.x / groups, g = blockIdx.x - n * groups;
+  const int c0 = g * 16, cw = (C - c0) < 16 ? (C - c0) : 16;
+  const int tid = threadIdx.x, r = k / 2;
+  for (int i = tid; i < HW * 16; i += LY_THREADS) {
+    const int p = i >> 4, c = i & 15;
+    const float v = c < cw ? x[((long)n * HW + p) * ldx + c0 + c] : 0.f;
+    a[p * 17 + c] = v;
+    if (c < cw) out[((long)n * HW + p) * ldo + c0 + c] = v;
+  }
+  __syncthreads();
+  for (int level = 1; level <= 3; ++level) {
+    // b = row-max of a, then a = col-max of b  (one k x k max pool of the previous level)
+    for (int i = tid; i < HW * 16; i += LY_THREADS) {
+      const int p = i >> 4, c = i & 15, h = p / W, w = p - h * W;
+      float m = -FLT_MAX;
+      for (int d = -r; d <= r; ++d) {
+        const int ww = w + d;
+        if (ww >= 0 && ww < W) m = fmaxf(m, a[(h * W + ww) * 17 + c]);
+      }
+      b[p * 17 + c] = m;
+    }
+    __syncthreads();
+    for (int i = tid; i < HW * 16; i += LY_THREADS) {
+      const int p = i >> 4, c = i & 15, h = p / W, w = p - h * W;
+      float m = -FLT_MAX;
+      for (int d = -r; d <= r; ++d) {
+        const int hh = h + d;
+        if (hh >= 0 && hh < H) m = fmaxf(m, b[(hh * W + w) * 17 + c]);
+      }
+      a[p * 17 + c] = m;
+      if (c < cw) out[((long)n * HW + p) * ldo + level * C + c0 + c] = m;
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int ly_sppf_pool(const float* x, int ldx, int n_img, int H, int W, int C, int k, float* out, int ldo, void* stream) {
+  LY_CHECK(x && out && k >= 1 && (k & 1), "sppf_pool: bad arguments");
+  size_t lds = sizeof(float) * 2 * (size_t)H * W * 17;
+  LY_CHECK(lds <= 160 * 1024, "sppf_pool: %dx%d map does not fit LDS (%zu B)", H, W, lds);
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ly_sppf_pool_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    LY_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    configured = true;
+  }
+  hipLaunchKernelGGL(ly_sppf_pool_kernel, dim3(n_img * ((C + 15) / 16)), dim3(LY_THREADS), lds, reinterpret_cast<hipStream_t>(stream), x,
+                     ldx, H, W, C, k, out, ldo);
+  LY_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Detect tail (reference models/yolo.py:95-120): from the head GEMM output y[n, h, w, na*no] (row stride
+// ldy) write the raw map p[n, a, h, w, o] and, in eval mode, the decoded rows z[n, zoff + (a*H + h)*W + w, o]:
+//   xy = (2*sig - 0.5 + grid) * stride,  wh = (2*sig)^2 * anchor*stride,  rest = sig.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(LY_THREADS) void ly_detect_tail_kernel(const float* __restrict__ y, int ldy, long total, int H, int W, int na, int no,
+                                                                    const float* __restrict__ anchors /* [na,2] grid units */, float stride,
+                                                                    float* __restrict__ p, float* __restrict__ z, long zrows, long zoff) {
+  const long i = (long)blockIdx.x * LY_THREADS + threadIdx.x;      // over n*na*H*W*no, output order
+  if (i >= total) return;
+  const int o = (int)(i % no);
+  long t = i / no;
+  const int w = (int)(t % W); t /= W;
+  const int h = (int)(t % H); t /= H;
+  const int a = (int)(t % na);
+  const long n = t / na;
+  const float v = y[((n * H + h) * W + w) * ldy + a * no + o];
+  p[i] = v;
+  if (z) {
+    const float s = ly_sigmoid(v);
+    float r = s;
+    if (o == 0) r = (s * 2.f + ((float)w - 0.5f)) * stride;
+    else if (o == 1) r = (s * 2.f + ((float)h - 0.5f)) * stride;
+    else if (o == 2 || o == 3) { const float q = s * 2.f; r = q * q * (anchors[a * 2 + (o - 2)] * stride); }
+    z[(n * zrows + zoff + ((long)a * H + h) * W + w) * no + o] = r;
+  }
+}
+
+extern "C" int ly_detect_tail(const float* y, int ldy, int n_img, int H, int W, int na, int no, const float* anchors, float stride,
+                              float* p, float* z, long zrows, long zoff, void* stream) {
+  LY_CHECK(y && p && anchors, "detect_tail: null pointer");
+  const long total = (long)n_img * na * H * W * no;
+  hipLaunchKernelGGL(ly_detect_tail_kernel, dim3((unsigned)((total + LY_THREADS - 1) / LY_THREADS)), dim3(LY_THREADS), 0,
+                     reinterpret_cast<hipStream_t>(stream), y, ldy, total, H, W, na, no, anchors, stride, p, z, zrows, zoff);
   LY_LAUNCH_CHECK();
   return 0;
 }

@@ -24,7 +24,8 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam3_kernel(const LyRfcbam3P
   char* gs_hi = reinterpret_cast<char*>(ly_smem4);          // [64][LY_RSG]
   char* gs_lo = gs_hi + 64 * LY_RSG;
   float* xs = reinterpret_cast<float*>(gs_lo + 64 * LY_RSG);   // [IH*IW][LY_GCC + 1]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: depthwise weights become scalar loads
   const int li = lane & 15, lq = lane >> 4;
   int b = blockIdx.x;
   const int by = b % gy; b /= gy;

@@ -601,10 +601,19 @@ class SPPF(nn.Module):
         self.m = nn.MaxPool2d(kernel_size=k, stride=1, padding=k // 2)
 
     def forward(self, x):
-        x = self.cv1(x)
-        y1 = self.m(x)
+        y = self.cv1(x)
+        if SHAPE_PROBE and not y.is_cuda:
+            return y.new_zeros((y.shape[0], self.cv2.c2, y.shape[2], y.shape[3]))
+        n, c_, h, w = y.shape
+        k = self.m.kernel_size
+        if ops.sppf_pool_fits(h, w):
+            yr, ld = ops.rows(y)
+            buf = ops.empty_nhwc(n, 4 * c_, h, w, yr)
+            ops.sppf_pool(yr, ld, n, h, w, c_, k, buf, 4 * c_)          # [y | m(y) | m(m(y)) | m(m(m(y)))] in one pass
+            return self.cv2(buf)
+        y1 = self.m(y)                                                    # large maps: stock GPU max-pool
         y2 = self.m(y1)
-        return self.cv2(torch.cat((x, y1, y2, self.m(y2)), 1))
+        return self.cv2(torch.cat((y, y1, y2, self.m(y2)), 1))
 
 
 class Upsample(nn.Upsample):
@@ -672,23 +681,33 @@ class Detect(nn.Module):
         n, c, h, w = L.shape
         buf = torch.empty((n, h, w, ldo), dtype=torch.float32, device=L.a0.device)
         _run_pointwise(L, wp, conv.out_channels, None, b, ACT_NONE, out=buf, ldo=ldo)
-        return buf[..., :conv.out_channels]                    # [n, h, w, na*no]
+        return buf, ldo                                         # [n, h, w, ldo] rows, first na*no columns valid
+
+    def _strides(self):
+        key = (self.stride.data_ptr(), self.stride._version)
+        if getattr(self, "_stride_key", None) != key:           # python floats cached: no device sync per forward
+            self._stride_f = [float(v) for v in self.stride.detach().cpu()]
+            self._stride_key = key
+        return self._stride_f
 
     def forward(self, x):
-        z = []
         x = list(x)
+        shapes = [Lazy.of(t).shape for t in x]
+        bs = shapes[0][0]
+        decode = not self.training
+        zrows = sum(self.na * s[2] * s[3] for s in shapes)
+        dev = Lazy.of(x[0]).a0.device
+        z = torch.empty((bs, zrows, self.no), dtype=torch.float32, device=dev) if decode else None
+        strides = self._strides()
+        zoff = 0
         for i in range(self.nl):
-            y = self._head(i, x[i])
-            bs, ny, nx, _ = y.shape
-            x[i] = y.reshape(bs, ny, nx, self.na, self.no).permute(0, 3, 1, 2, 4).contiguous()
-            if not self.training:
-                if self.dynamic or self.grid[i].shape[2:4] != x[i].shape[2:4]:
-                    self.grid[i], self.anchor_grid[i] = self._make_grid(nx, ny, i)
-                sg = x[i].sigmoid()
-                xy = (sg[..., 0:2] * 2 + self.grid[i]) * self.stride[i]
-                wh = (sg[..., 2:4] * 2) ** 2 * self.anchor_grid[i]
-                z.append(torch.cat((xy, wh, sg[..., 4:]), 4).view(bs, self.na * nx * ny, self.no))
-        return x if self.training else (torch.cat(z, 1),) if self.export else (torch.cat(z, 1), x)
+            buf, ldo = self._head(i, x[i])
+            _, _, ny, nx = shapes[i]
+            p = torch.empty((bs, self.na, ny, nx, self.no), dtype=torch.float32, device=dev)
+            ops.detect_tail(buf, ldo, bs, ny, nx, self.na, self.no, self.anchors[i], strides[i], p, z, zrows, zoff)
+            x[i] = p
+            zoff += self.na * ny * nx
+        return x if self.training else (z,) if self.export else (z, x)
 
     def _make_grid(self, nx=20, ny=20, i=0):
         d, t = self.anchors[i].device, self.anchors[i].dtype

@@ -126,3 +126,16 @@ def rfcbam3(*, n, h, w, c, ho, wo, N, s, th, tw, x, ldx, wg, ca, rfa, wp, e_scal
     P = capi.LyRfcbam3Params(n, h, w, c, ho, wo, N, s, th, tw, _p(x), ldx, _p(wg), _p(ca), _p(rfa), _p(wp), _p(e_scale),
                              _p(e_shift), _p(out), ldo)
     capi.check(capi.lib().ly_rfcbam3_fwd(ctypes.byref(P), capi.stream_ptr()), "ly_rfcbam3_fwd")
+
+
+def sppf_pool_fits(h, w):
+    return 2 * h * w * 17 * 4 <= 160 * 1024
+
+
+def sppf_pool(x, ldx, n, h, w, c, k, out, ldo):
+    capi.check(capi.lib().ly_sppf_pool(_p(x), ldx, n, h, w, c, k, _p(out), ldo, capi.stream_ptr()), "ly_sppf_pool")
+
+
+def detect_tail(y, ldy, n, h, w, na, no, anchors, stride, p, z, zrows, zoff):
+    capi.check(capi.lib().ly_detect_tail(_p(y), ldy, n, h, w, na, no, _p(anchors), float(stride), _p(p), _p(z), zrows, zoff,
+                                         capi.stream_ptr()), "ly_detect_tail")

@@ -1,6 +1,8 @@
 import sys, torch
 sys.argv = ["x", "32", "none"]
-exec(open("tools/kernel_bench.py").read())
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+exec(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "kernel_bench.py")).read())
 from lead_yolo_amd import capi
 for cfg in (0, 414, 221, 121):
     capi.lib().ly_debug_set_gemm_cfg(cfg)

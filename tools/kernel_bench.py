@@ -1,5 +1,6 @@
 """Per-kernel micro-benchmarks on the real lead-yolo-s layer shapes (bs=32, 640x640).  Dev tool."""
-import sys
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import lead_yolo_amd as L
 from lead_yolo_amd import ops, pack

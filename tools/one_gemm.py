@@ -1,4 +1,5 @@
-import sys, torch
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), torch
 from lead_yolo_amd import ops, pack, capi
 dev = torch.device("cuda:0")
 hw, k, n, cfg = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])

@@ -57,55 +57,50 @@ def time_kernel(fn, iters=20, warm=3):
     return e0.elapsed_time(e1) / iters
 
 
-def roofline_probe(model, x):
-    """Times the individual ★ kernels on this step's real tensors and returns the roofline object of
-    the dominant one.  Algorithmic bytes: input once + output once + parameters once (SURVEY §8d);
-    algorithmic flops: 2*MAC of the contractions."""
-    import lead_yolo_amd as L
-    feats = {}
-    hooks = []
-    for mod in model.model:
-        hooks.append(mod.register_forward_hook(lambda m_, inp, out, i=mod.i: feats.__setitem__(i, (inp, out))))
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16; fp32-grade products take 3 bf16 MFMAs (csrc/ly_tile.cuh)
+
+
+def roofline_probe(model, x, iters=10):
+    """Times every C-ABI launch of the step with HIP events on the launch stream (ops.PROFILE hooks), groups
+    them by the kernel name rocprofv3 prints, and returns the per-kernel table.  Algorithmic bytes:
+    input once + output once + parameters once; algorithmic flops: 2*MAC."""
+    from lead_yolo_amd import ops
     with torch.no_grad():
         model(x)
-    for h in hooks:
-        h.remove()
+        torch.cuda.synchronize()
+        ops.PROFILE = []
+        for _ in range(iters):
+            model(x)
+        torch.cuda.synchronize()
+        recs, ops.PROFILE = ops.PROFILE, None
+    table = {}
+    for name, flops, nbytes, e0, e1 in recs:
+        t = table.setdefault(name, dict(kernel=name, calls=0, ms=0.0, flops=0.0, bytes=0.0))
+        t["calls"] += 1
+        t["ms"] += e0.elapsed_time(e1)
+        t["flops"] += flops
+        t["bytes"] += nbytes
     rows = []
-    for mod in model.model:
-        blocks = list(mod) if isinstance(mod, torch.nn.Sequential) else [mod]
-        inp, out = feats[mod.i]
-        xin = inp[0]
-        if isinstance(xin, (list, tuple)) or isinstance(xin, L.Lazy) or not isinstance(out, torch.Tensor):
-            continue
-        if not isinstance(blocks[0], (L.BasicStage, L.RFCBAMConv, L.C3_CA, L.PatchEmbed_FasterNet, L.PatchMerging_FasterNet)):
-            continue
-        with torch.no_grad():
-            ms = time_kernel(lambda: mod(xin))
-        nparam = sum(p.numel() for p in mod.parameters())
-        per = len(blocks)
-        bytes_ = 4.0 * (xin.numel() + out.numel()) * (per if isinstance(blocks[0], L.BasicStage) else 1) + 4.0 * nparam
-        rows.append(dict(layer=mod.i, kind=type(blocks[0]).__name__, ms=ms, bytes=bytes_, flops=_flops(blocks, xin, out)))
+    for t in table.values():
+        c = t["calls"]
+        rows.append(dict(kernel=t["kernel"], calls_per_step=c / iters, ms_per_launch=t["ms"] / c, ms_per_step=t["ms"] / iters,
+                         flops=t["flops"] / c, bytes=t["bytes"] / c))
+    rows.sort(key=lambda r: -r["ms_per_step"])
     return rows
 
 
-def _flops(blocks, xin, out):
-    import lead_yolo_amd as L
-    n, c, h, w = xin.shape
-    b0 = blocks[0]
-    px_out = out.shape[0] * out.shape[2] * out.shape[3]
-    if isinstance(b0, L.BasicStage):
-        cq = c // 4
-        return len(blocks) * 2.0 * px_out * (9 * cq * cq + 4 * c * c)
-    if isinstance(b0, (L.PatchEmbed_FasterNet, L.PatchMerging_FasterNet)):
-        return 2.0 * px_out * b0.k * b0.k * c * out.shape[1]
-    if isinstance(b0, L.RFCBAMConv):
-        k = b0.kernel_size
-        return 2.0 * px_out * (k * k * c * out.shape[1] + k * k * k * k * c + 18 * k * k) + 2.0 * n * (2 * 16 * c)
-    if isinstance(b0, L.C3_CA):
-        c_ = b0.c_
-        per_px = c * 2 * c_ + len(b0.m) * (c_ * c_ + 9 * c_ * c_) + 2 * c_ * b0.c2
-        return 2.0 * px_out * per_px
-    return 0.0
+def pmc_traffic(kernel):
+    """HBM bytes per launch from the committed rocprofv3 PMC pass (profiles/*_pmc_traffic.json, produced
+    by tools/pmc_traffic.py: FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE), or None."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if kernel in d:
+            return d[kernel]
+    return None
 
 
 def usable_cores():
@@ -205,22 +200,30 @@ def main():
         rows = roofline_probe(model, x)
         if args.layers:
             for r in rows:
-                print(f"  layer {r['layer']:>2} {r['kind']:<24} {r['ms']:8.3f} ms  {r['bytes'] / r['ms'] / 1e6:8.1f} GB/s  "
-                      f"{r['flops'] / r['ms'] / 1e9:8.2f} TFLOP/s", file=sys.stderr)
-        dom = max(rows, key=lambda r: r["ms"])
-        hbm_frac = dom["bytes"] / dom["ms"] / 1e6 / HBM_PEAK_GBS
-        mfma_frac = dom["flops"] / dom["ms"] / 1e9 / F32_MFMA_PEAK_TFLOPS
+                print(f"  {r['kernel']:<46} {r['calls_per_step']:5.1f}/step {r['ms_per_launch'] * 1e3:8.1f} us  {r['ms_per_step'] * 1e3:8.1f} us/step  "
+                      f"{r['bytes'] / r['ms_per_launch'] / 1e6:8.1f} GB/s  {r['flops'] / r['ms_per_launch'] / 1e9:8.2f} TFLOP/s", file=sys.stderr)
+        dom = rows[0]                                   # dominant kernel = largest share of the step
+        gbs = dom["bytes"] / dom["ms_per_launch"] / 1e6
+        tfs = dom["flops"] / dom["ms_per_launch"] / 1e9
+        hbm_frac = gbs / HBM_PEAK_GBS
+        mfma_peak = BF16_MFMA_PEAK_TFLOPS / 3.0
+        mfma_frac = tfs / mfma_peak
         if mfma_frac >= hbm_frac:
-            roof = dict(bound="mfma", achieved=round(dom["flops"] / dom["ms"] / 1e9, 2), peak=F32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                        frac=round(mfma_frac, 4), traffic=None)
+            roof = dict(bound="mfma", achieved=round(tfs, 2), peak=round(mfma_peak, 1), unit="TFLOP/s", frac=round(mfma_frac, 4),
+                        peak_note="dense bf16 2500 TFLOP/s / 3: fp32-grade products = 3 bf16 MFMAs (exact-f32 MFMA peak would be 157.3)")
         else:
-            roof = dict(bound="hbm", achieved=round(dom["bytes"] / dom["ms"] / 1e6, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(hbm_frac, 4), traffic=None)
-        roof["kernel"] = f"layer {dom['layer']} {dom['kind']}"
-        roof["ms_per_launch"] = round(dom["ms"], 4)
-        star = [r for r in rows if r["kind"] in ("BasicStage", "RFCBAMConv")]
-        roof["pconv_rfcbam_fwd"] = dict(ms=round(sum(r["ms"] for r in star), 4), algorithmic_GB=round(sum(r["bytes"] for r in star) / 1e9, 4),
-                                        hbm_frac=round(sum(r["bytes"] for r in star) / sum(r["ms"] for r in star) / 1e6 / HBM_PEAK_GBS, 4))
+            roof = dict(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(hbm_frac, 4))
+        tr = pmc_traffic(dom["kernel"])
+        roof["traffic"] = tr
+        roof["kernel"] = dom["kernel"]
+        roof["launches_per_step"] = round(dom["calls_per_step"], 2)
+        roof["ms_per_launch"] = round(dom["ms_per_launch"], 5)
+        roof["algorithmic_bytes_per_launch"] = round(dom["bytes"])
+        roof["algorithmic_flops_per_launch"] = round(dom["flops"])
+        star = [r for r in rows if r["kernel"].startswith(("ly_mlpblock", "ly_rfcbam"))]
+        sb, sm = sum(r["bytes"] * r["calls_per_step"] for r in star), sum(r["ms_per_step"] for r in star)
+        roof["pconv_rfcbam_fwd"] = dict(ms=round(sm, 4), hbm_frac=round(sb / sm / 1e6 / HBM_PEAK_GBS, 4),
+                                        note="mlpblock + rfcbam stats/main kernels; SE, rfa map and the k=1 GEMM excluded")
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(args.scale, args.size)
         out = {

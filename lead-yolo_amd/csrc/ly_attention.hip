@@ -240,7 +240,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_stats3_kernel(const floa
         float xv[9];
 #pragma unroll
         for (int u = 0; u < 9; ++u) xv[u] = xs[((s * ly + u / 3) * IW + (s * lx + u % 3)) * (LY_SCC + 1) + cl];
-        const float* wc = wg + (long)(c0 + cl) * 90;
+        const ly_cfloat* wc = ly_const(wg + (long)(c0 + cl) * 90);
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
           float a = wc[81 + t];

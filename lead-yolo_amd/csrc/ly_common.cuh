@@ -42,6 +42,11 @@ __device__ __forceinline__ f32x4 ly_mfma4(const f32x4 w, const f32x4 x, f32x4 ac
   return acc;
 }
 
+// Read-only, wave-uniform data (weights indexed by a wave-uniform expression): a constant-address-space
+// view makes the compiler use the scalar cache (s_load_dwordxN) instead of per-lane vector loads.
+typedef const float __attribute__((address_space(4))) ly_cfloat;
+__device__ __forceinline__ const ly_cfloat* ly_const(const float* p) { return (const ly_cfloat*)p; }
+
 __device__ __forceinline__ f32x4 ly_zero4() { return (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
 __device__ __forceinline__ f32x4 ly_ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }

@@ -38,8 +38,11 @@ __device__ __forceinline__ int ly_fdiv(int x, int d, float inv) {
   return q;
 }
 
+#ifndef LY_GEMM_MINW
+#define LY_GEMM_MINW 1
+#endif
 template <int NT, int MT, int WC, int GATHER, int PRO>
-__global__ __launch_bounds__(LY_THREADS) void ly_gemm_kernel(const LyGemmParams P, const int gy, const int nslots, const int gx) {
+__global__ __launch_bounds__(LY_THREADS, LY_GEMM_MINW) void ly_gemm_kernel(const LyGemmParams P, const int gy, const int nslots, const int gx) {
   constexpr int WP = 4 / WC;
   constexpr int BP = 16 * NT * WP;
   constexpr int NV = BP * (LY_BK / 4) / LY_THREADS;      // float4 per thread per chunk; thread's pixels: tid/16 + 16e

@@ -17,7 +17,7 @@
 #define LY_RSG (2 * LY_GK + 16)          // bytes per operand row, per plane
 
 template <int MT>
-__global__ __launch_bounds__(LY_THREADS) void ly_rfcbam3_kernel(const LyRfcbam3Params P, const int gy, const int nct, const int nrt) {
+__global__ __launch_bounds__(LY_THREADS) void ly_rfcbam3_kernel(const LyRfcbam3Params P, const int gy, const int nct, const int nrt, const int dbg) {
   extern __shared__ f32x4 ly_smem4[];
   const int s = P.s, TH = P.TH, TW = P.TW;
   const int IH = s * (TH - 1) + 3, IW = s * (TW - 1) + 3;
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam3_kernel(const LyRfcbam3P
 
   for (int c0 = 0; c0 < P.C; c0 += LY_GCC) {
     __syncthreads();
-    ly_stage_f4<4>(IH * IW * (LY_GCC / 4), tid, P.x,
+    if (!(dbg & 4)) ly_stage_f4<4>(IH * IW * (LY_GCC / 4), tid, P.x,
         [&](int idx) -> const float* {
           const int ip = idx / (LY_GCC / 4), c4 = idx - ip * (LY_GCC / 4);
           const int iy = iy0 + ip / IW, ix = ix0 + ip % IW;
@@ -76,10 +76,10 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam3_kernel(const LyRfcbam3P
     __syncthreads();
     // ---- regenerate G' for channels c0 + 4*wave .. +3 -----------------------------------------------
 #pragma unroll 1
-    for (int cj = 0; cj < 4; ++cj) {
+    for (int cj = 0; cj < ((dbg & 1) ? 0 : 4); ++cj) {
       const int cl = 4 * wave + cj;
-      const float* wc = P.wg + (long)(c0 + cl) * 90;
-      const float cav = P.ca[(long)n * P.C + c0 + cl];
+      const ly_cfloat* wc = ly_const(P.wg + (long)(c0 + cl) * 90);
+      const float cav = ly_const(P.ca)[(long)n * P.C + c0 + cl];
       float xv[9];
 #pragma unroll
       for (int u = 0; u < 9; ++u) xv[u] = active ? xs[((s * ly + u / 3) * IW + (s * lx + u % 3)) * (LY_GCC + 1) + cl] : 0.f;
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam3_kernel(const LyRfcbam3P
     // ---- contract the chunk's 160 (144 real) k-values --------------------------------------------
     const int sbase = (c0 / LY_GCC) * (LY_GK / 32);
 #pragma unroll
-    for (int st = 0; st < LY_GK / 32; ++st) {
+    for (int st = 0; st < ((dbg & 2) ? 0 : LY_GK / 32); ++st) {
       bf16x8 xh[4], xl[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -148,6 +148,9 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam3_kernel(const LyRfcbam3P
   }
 }
 
+static int g_rf3_dbg = 0;   // ablation aid: 1 skip regenerate, 2 skip MFMA, 4 skip staging
+extern "C" int ly_debug_set_rf3(int v) { g_rf3_dbg = v; return 0; }
+
 template <int MT>
 static int launch_rf3(const LyRfcbam3Params& P, hipStream_t st) {
   const int nct = (P.Wo + P.TW - 1) / P.TW, nrt = (P.Ho + P.TH - 1) / P.TH;
@@ -164,7 +167,7 @@ static int launch_rf3(const LyRfcbam3Params& P, hipStream_t st) {
   }
   long nb = (long)P.n_img * nrt * nct * gy;
   LY_CHECK(nb < (1L << 31), "rfcbam3: grid too large");
-  hipLaunchKernelGGL(k, dim3((unsigned)nb), dim3(LY_THREADS), lds, st, P, gy, nct, nrt);
+  hipLaunchKernelGGL(k, dim3((unsigned)nb), dim3(LY_THREADS), lds, st, P, gy, nct, nrt, g_rf3_dbg);
   LY_LAUNCH_CHECK();
   return 0;
 }

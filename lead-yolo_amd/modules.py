@@ -181,7 +181,6 @@ class MLPBlock(nn.Module):
         return self._prep.get(key, build)
 
     def forward(self, x):
-        from . import capi
         pr = _probe(x, x.shape)
         if pr is not None:
             return pr
@@ -191,8 +190,7 @@ class MLPBlock(nn.Module):
         n, c, h, w = x.shape
         wp, w1, w2, sc, sh = self._packed()
         y = ops.empty_nhwc(n, c, h, w, x)
-        capi.check(capi.lib().ly_mlpblock_fwd(capi.ptr(x), capi.ptr(y), n, h, w, c, capi.ptr(wp), capi.ptr(w1), capi.ptr(w2),
-                                              capi.ptr(sc), capi.ptr(sh), capi.stream_ptr()), "ly_mlpblock_fwd")
+        ops.mlpblock(x, y, n, h, w, c, wp, w1, w2, sc, sh)
         return y
 
 

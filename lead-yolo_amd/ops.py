@@ -11,6 +11,52 @@ from .capi import (ACT_NONE, ACT_RELU, ACT_SILU, GATHER_PATCH, GATHER_PATCH_NCHW
                    PRO_AFFINE_RELU_CA, PRO_GATE, PRO_NONE)
 
 
+# ---- optional per-launch timing (bench.py / tools): PROFILE = [] turns it on -----------------------
+PROFILE = None
+
+
+class _Timed:
+    """Brackets one C-ABI call with events on the launch stream and records (kernel name as rocprofv3
+    prints it, algorithmic flops, algorithmic bytes)."""
+
+    def __init__(self, name, flops, nbytes):
+        self.rec = None
+        if PROFILE is not None:
+            self.rec = [name, float(flops), float(nbytes), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
+
+    def __enter__(self):
+        if self.rec is not None:
+            self.rec[3].record()
+
+    def __exit__(self, *a):
+        if self.rec is not None:
+            self.rec[4].record()
+            PROFILE.append(self.rec)
+
+
+def gemm_config(n_out):
+    """mirror of the tile heuristic in csrc/ly_gemm.hip (ly_gemm_fwd)"""
+    return (4, 2, 4) if n_out > 64 else (4, 1, 4) if n_out > 32 else (2, 2, 1)
+
+
+def conv3_config(n_out, m):
+    big = m >= 128 * 384
+    if n_out > 128:
+        return (8, 4, 4) if big else (4, 4, 4)
+    if n_out > 64:
+        return (8, 2, 4) if big else (4, 2, 4)
+    if n_out > 32:
+        return (8, 1, 4) if big else (4, 1, 4)
+    return (2, 2, 1)
+
+
+def mlp_config(c, m):
+    ht = {16: 2, 24: 4, 40: 2, 80: 2, 160: 4, 320: 4}[c]
+    ntmax = {16: 4, 24: 4, 40: 4, 80: 2, 160: 2, 320: 1}[c]
+    nt = 4 if (ntmax >= 4 and m >= 256 * 1024) else 2 if (ntmax >= 2 and m >= 128 * 512) else 1
+    return c, nt, ht
+
+
 def require_cuda(x, who):
     if not x.is_cuda:
         raise RuntimeError(f"{who}: the HIP path needs a CUDA/ROCm tensor (got {x.device}); there is no CPU fallback")
@@ -51,12 +97,16 @@ def gemm(*, M, H, W, K, N, a0, lda0, k0, wp, out, ldo, a1=None, lda1=0, gather=G
     P = capi.LyGemmParams(M, H, W, K, N, _p(a0), lda0, k0, _p(a1), lda1, gather, Hin, Win, Cin, ks, pk, pro, _p(g_h), _p(g_w),
                           _p(res), ldres, _p(p_scale), _p(p_shift), _p(p_ca), _p(wp), _p(e_scale), _p(e_shift), _p(rowscale),
                           act, _p(out), ldo)
-    capi.check(capi.lib().ly_gemm_fwd(ctypes.byref(P), capi.stream_ptr()), "ly_gemm_fwd")
+    nt, mt, wc = gemm_config(N)
+    with _Timed(f"ly_gemm_kernel<{nt}, {mt}, {wc}, {gather}, {pro}>", 2.0 * M * K * N, 4.0 * (M * (K + N) + N * K)):
+        capi.check(capi.lib().ly_gemm_fwd(ctypes.byref(P), capi.stream_ptr()), "ly_gemm_fwd")
 
 
 def conv3x3(*, M, H, W, Cin, N, x, ldx, wp, out, ldo, e_scale=None, e_shift=None, act=ACT_NONE):
     P = capi.LyConv3Params(M, H, W, Cin, N, _p(x), ldx, _p(wp), _p(e_scale), _p(e_shift), act, _p(out), ldo)
-    capi.check(capi.lib().ly_conv3x3_fwd(ctypes.byref(P), capi.stream_ptr()), "ly_conv3x3_fwd")
+    nt, mt, wc = conv3_config(N, M)
+    with _Timed(f"ly_conv3x3_kernel<{nt}, {mt}, {wc}>", 2.0 * M * 9 * Cin * N, 4.0 * (M * (Cin + N) + 9 * Cin * N)):
+        capi.check(capi.lib().ly_conv3x3_fwd(ctypes.byref(P), capi.stream_ptr()), "ly_conv3x3_fwd")
 
 
 def pool_hw(x, ldx, n, h, w, c):
@@ -110,8 +160,10 @@ def pick_tile(ho, wo):
 def rfcbam_stats(x, ldx, n, h, w, c, k, s, wg=None, a1=None, b1=None, th=1, tw=64):
     ho, wo = ((h + 2 * (k // 2) - k) // s + 1, (w + 2 * (k // 2) - k) // s + 1)
     mm = torch.empty((n, k * ho, k * wo, 2), dtype=torch.float32, device=x.device)
-    capi.check(capi.lib().ly_rfcbam_stats(_p(x), ldx, n, h, w, c, k, s, _p(wg), _p(a1), _p(b1), th, tw, _p(mm), capi.stream_ptr()),
-               "ly_rfcbam_stats")
+    with _Timed("ly_rfcbam_stats3_kernel" if k == 3 else "ly_rfcbam_stats1_kernel", 2.0 * n * ho * wo * c * (81 if k == 3 else 1),
+                4.0 * (n * h * w * c + 2 * k * k * n * ho * wo)):
+        capi.check(capi.lib().ly_rfcbam_stats(_p(x), ldx, n, h, w, c, k, s, _p(wg), _p(a1), _p(b1), th, tw, _p(mm), capi.stream_ptr()),
+                   "ly_rfcbam_stats")
     return mm
 
 
@@ -125,7 +177,10 @@ def rfa_map(mm, w18):
 def rfcbam3(*, n, h, w, c, ho, wo, N, s, th, tw, x, ldx, wg, ca, rfa, wp, e_scale, e_shift, out, ldo):
     P = capi.LyRfcbam3Params(n, h, w, c, ho, wo, N, s, th, tw, _p(x), ldx, _p(wg), _p(ca), _p(rfa), _p(wp), _p(e_scale),
                              _p(e_shift), _p(out), ldo)
-    capi.check(capi.lib().ly_rfcbam3_fwd(ctypes.byref(P), capi.stream_ptr()), "ly_rfcbam3_fwd")
+    mt = 4 if N > 128 else 2 if N > 64 else 1
+    mo = n * ho * wo
+    with _Timed(f"ly_rfcbam3_kernel<{mt}>", 2.0 * mo * (9 * c * N + 81 * c), 4.0 * (n * h * w * c + mo * N + 9 * c * N)):
+        capi.check(capi.lib().ly_rfcbam3_fwd(ctypes.byref(P), capi.stream_ptr()), "ly_rfcbam3_fwd")
 
 
 def sppf_pool_fits(h, w):
@@ -139,3 +194,12 @@ def sppf_pool(x, ldx, n, h, w, c, k, out, ldo):
 def detect_tail(y, ldy, n, h, w, na, no, anchors, stride, p, z, zrows, zoff):
     capi.check(capi.lib().ly_detect_tail(_p(y), ldy, n, h, w, na, no, _p(anchors), float(stride), _p(p), _p(z), zrows, zoff,
                                          capi.stream_ptr()), "ly_detect_tail")
+
+
+def mlpblock(x, y, n, h, w, c, wp, w1, w2, sc, sh):
+    m = n * h * w
+    cc, nt, ht = mlp_config(c, m)
+    with _Timed(f"ly_mlpblock_fwd_kernel<{cc}, {nt}, {ht}>", 2.0 * m * (9 * (c // 4) ** 2 + 4 * c * c),
+                4.0 * (2 * m * c + 9 * (c // 4) ** 2 + 4 * c * c)):
+        capi.check(capi.lib().ly_mlpblock_fwd(_p(x), _p(y), n, h, w, c, _p(wp), _p(w1), _p(w2), _p(sc), _p(sh), capi.stream_ptr()),
+                   "ly_mlpblock_fwd")

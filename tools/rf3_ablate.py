@@ -1,0 +1,19 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import lead_yolo_amd as L
+from lead_yolo_amd import capi
+dev = torch.device("cuda:0")
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm): fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+m = L.RFCBAMConv(128, 128, 3, 2).to(dev).eval()
+x = torch.randn(32, 128, 80, 80, device=dev).contiguous(memory_format=torch.channels_last)
+with torch.no_grad():
+    for dbg in (0, 1, 2, 4, 3, 5, 6, 7):
+        capi.lib().ly_debug_set_rf3(dbg)
+        print(f"dbg={dbg} (skip gen={dbg&1} mfma={(dbg>>1)&1} stage={(dbg>>2)&1}): module {timeit(lambda: m(x)):8.1f} us")

@@ -26,6 +26,10 @@ const char* ly_last_error(void);
  * Built for C in {16,24,40,80,160,320}. */
 int ly_mlpblock_fwd(const float* x, float* y, int n_img, int H, int W, int C, const void* wp, const void* w1,
                     const void* w2, const float* bn_scale, const float* bn_shift, void* stream);
+/* ablation aid for profiling (bit 0: skip pconv, 1: skip MLP contractions, 2: skip halo staging, 3: skip stores) */
+int ly_debug_set_mlp(int v);
+/* tuning aid: 1 forces the flattened-run tiling (default: 8x16 patches where W % 16 == 0 and W >= 64) */
+int ly_debug_set_mlp_tile(int v);
 /* hidden (2C) channel tiles of 16, padded to an even count */
 int ly_mlpblock_hidden_tiles(int C);
 
@@ -66,6 +70,8 @@ typedef struct LyGemmParams {
 int ly_gemm_fwd(const LyGemmParams* p, void* stream);
 /* tuning aid: force the GEMM tile configuration (NT*100 + MT*10 + WC), 0 = heuristic */
 int ly_debug_set_gemm_cfg(int cfg);
+/* ablation aid for profiling (bit 0: skip split+LDS write, 1: skip MFMA, 2: skip prefetch loads, 3: skip stores) */
+int ly_debug_set_gemm(int v);
 
 
 /* ---- 3x3 / s1 / p1 convolution (implicit GEMM) ------------------------------------------------- */

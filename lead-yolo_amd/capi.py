@@ -49,7 +49,10 @@ SIGNATURES = {
     "ly_mlpblock_hidden_tiles": [_I],
     "ly_gemm_fwd": [ctypes.POINTER(LyGemmParams), _P],
     "ly_debug_set_gemm_cfg": [_I],
+    "ly_debug_set_gemm": [_I],
     "ly_debug_set_rf3": [_I],
+    "ly_debug_set_mlp": [_I],
+    "ly_debug_set_mlp_tile": [_I],
     "ly_conv3x3_fwd": [ctypes.POINTER(LyConv3Params), _P],
     "ly_pool_hw": [_P, _I, _I, _I, _I, _I, _P, _P],
     "ly_coordatt_mlp": [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],

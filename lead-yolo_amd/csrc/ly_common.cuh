@@ -66,6 +66,23 @@ __device__ __forceinline__ float ly_act(float x) {
   return x;
 }
 
+// exact floor(x / d) for 0 <= x < 2^24 via a float reciprocal and one fix-up step
+__device__ __forceinline__ int ly_fdiv(int x, int d, float inv) {
+  int q = (int)((float)x * inv);
+  int r = x - q * d;
+  if (r < 0) { --q; r += d; }
+  if (r >= d) ++q;
+  return q;
+}
+
+// (h, w) of flattened pixel gp (< 2^24) in an image of H x W, without 64-bit division
+__device__ __forceinline__ void ly_pix_hw(long gp, int H, int W, int& h, int& w) {
+  const int g = (int)gp;
+  const int row = ly_fdiv(g, W, 1.f / (float)W);     // n*H + h
+  w = g - row * W;
+  h = row - ly_fdiv(row, H, 1.f / (float)H) * H;
+}
+
 // 9-bit validity mask of the 3x3 neighbourhood (pad 1) of pixel (h, w) in an H x W image.
 // bit (ty*3 + tx) set  <=>  (h + ty - 1, w + tx - 1) is inside the image.
 __device__ __forceinline__ uint32_t ly_tapmask(int h, int w, int H, int W, bool pixel_valid) {

@@ -40,8 +40,8 @@ __global__ __launch_bounds__(LY_THREADS) void ly_conv3x3_kernel(const LyConv3Par
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
     long gp = p0 + pixgrp + 16 * n + li;
-    int w_ = (int)(gp % W);
-    int h_ = (int)((gp / W) % H);
+    int h_, w_;
+    ly_pix_hw(gp, H, W, h_, w_);
     tmask[n] = ly_tapmask(h_, w_, H, W, gp < P.M);
   }
 
@@ -158,6 +158,7 @@ extern "C" int ly_conv3x3_fwd(const LyConv3Params* p, void* stream) {
   LY_CHECK(P.M > 0 && P.H > 0 && P.W > 0 && P.Cin > 0 && P.N > 0, "conv3x3: bad sizes");
   LY_CHECK((P.Cin & 3) == 0 && (P.ldx & 3) == 0, "conv3x3: Cin=%d / ldx=%d must be multiples of 4", P.Cin, P.ldx);
   LY_CHECK(P.M % ((long)P.H * P.W) == 0, "conv3x3: M is not a whole number of images");
+  LY_CHECK(P.M < (1L << 24), "conv3x3: M=%ld pixels exceeds the 2^24 limit of the fast index path", P.M);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const bool big = P.M >= 128L * 384;
   if (P.N > 128) return big ? launch_conv3<8, 4, 4>(P, st) : launch_conv3<4, 4, 4>(P, st);   // x 256 ch

@@ -29,20 +29,11 @@
 #define LY_BK 64
 #define LY_RSX (2 * LY_BK + 16)   // bytes per LDS row, per plane
 
-// exact floor(x / d) for 0 <= x < 2^24 via a float reciprocal and one fix-up step
-__device__ __forceinline__ int ly_fdiv(int x, int d, float inv) {
-  int q = (int)((float)x * inv);
-  int r = x - q * d;
-  if (r < 0) { --q; r += d; }
-  if (r >= d) ++q;
-  return q;
-}
-
 #ifndef LY_GEMM_MINW
 #define LY_GEMM_MINW 1
 #endif
 template <int NT, int MT, int WC, int GATHER, int PRO>
-__global__ __launch_bounds__(LY_THREADS, LY_GEMM_MINW) void ly_gemm_kernel(const LyGemmParams P, const int gy, const int nslots, const int gx) {
+__global__ __launch_bounds__(LY_THREADS, LY_GEMM_MINW) void ly_gemm_kernel(const LyGemmParams P, const int gy, const int nslots, const int gx, const int dbg) {
   constexpr int WP = 4 / WC;
   constexpr int BP = 16 * NT * WP;
   constexpr int NV = BP * (LY_BK / 4) / LY_THREADS;      // float4 per thread per chunk; thread's pixels: tid/16 + 16e
@@ -123,14 +114,16 @@ __global__ __launch_bounds__(LY_THREADS, LY_GEMM_MINW) void ly_gemm_kernel(const
       const float* ptr = ok ? src + row * rowmul + koff : P.a0;
       pv[e] = ly_ldg4(ptr);
     }
-#pragma unroll
-    for (int e = 0; e < NV; ++e)
-      if (!(kok && t_n[e] >= 0)) pv[e] = zero;
+    // NOTE: out-of-range lanes are zeroed in commit(), NOT here: touching pv[] now would force an
+    // s_waitcnt on the loads just issued and serialise them with the MFMAs they are meant to overlap.
   };
   auto commit = [&](long p0, int kc, int buf) {
     char* hi = xs + buf * 2 * PLANE;
     char* lo = hi + PLANE;
     const int kk = kc + 4 * k4;
+#pragma unroll
+    for (int e = 0; e < NV; ++e)
+      if (!(kk < P.K && t_n[e] >= 0)) pv[e] = zero;
     if (PRO == LY_PRO_GATE) {
       const bool kok = kk < P.k0;
       f32x4 gw[NV], gh[NV], rr[NV];
@@ -179,6 +172,9 @@ __global__ __launch_bounds__(LY_THREADS, LY_GEMM_MINW) void ly_gemm_kernel(const
   const uint4* wpk = reinterpret_cast<const uint4*>(P.wp);
   const int pixgrp = wp_ * (16 * NT);
   const bool vec_ok = (P.ldo & 3) == 0;
+  float rsv[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) rsv[n] = 1.f;
   float esc[MT][4], esh[MT][4];                            // epilogue scale/shift: fetched once, not per tile
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
@@ -220,18 +216,27 @@ __global__ __launch_bounds__(LY_THREADS, LY_GEMM_MINW) void ly_gemm_kernel(const
         more = false;
       }
       // second k-step's weights first (older in the in-order vmcnt queue than the activation prefetch)
-      {
+      if (!(dbg & 16)) {
         const int g1 = 2 * c + 1 < S ? 2 * c + 1 : 0;
 #pragma unroll
         for (int t = 0; t < MT; ++t) wnxt[t] = ly_wfrag(wpk, wbase[t] + g1, lane);
       }
-      if (more) prefetch(pn, cn * LY_BK);
+      if (PRO == LY_PRO_AFFINE_RELU_CA && c == nchunk - 1) {
+        // per-pixel row scale of the tile being finished: issued BEFORE the next item's prefetch so the
+        // epilogue's wait for it does not also wait for that prefetch (vmcnt retires in order)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const long gp = p0 + pixgrp + 16 * n + li;
+          rsv[n] = P.rowscale[gp < P.M ? gp : 0];
+        }
+      }
+      if (more && !(dbg & 4)) prefetch(pn, cn * LY_BK);
       const char* hi = xs + buf * 2 * PLANE;
       const char* lo = hi + PLANE;
 #pragma unroll
       for (int s = 0; s < LY_BK / 32; ++s) {
         const int gs = 2 * c + s;
-        if (gs < S) {
+        if (gs < S && !(dbg & 2)) {
           if (s == 1) {                                    // weights of the next item's first step
             const int gn = gs + 1 < S ? gs + 1 : 0;
 #pragma unroll
@@ -252,7 +257,7 @@ __global__ __launch_bounds__(LY_THREADS, LY_GEMM_MINW) void ly_gemm_kernel(const
           for (int t = 0; t < MT; ++t) wcur[t] = wnxt[t];
         }
       }
-      if (more) commit(pn, cn * LY_BK, buf ^ 1);
+      if (more && !(dbg & 1)) commit(pn, cn * LY_BK, buf ^ 1);
       __syncthreads();
       buf ^= 1;
     }
@@ -261,12 +266,12 @@ __global__ __launch_bounds__(LY_THREADS, LY_GEMM_MINW) void ly_gemm_kernel(const
     for (int t = 0; t < MT; ++t) {
       const int tt = (by * WC + wc) * MT + t;
       const int c = 16 * tt + 4 * lq;
-      if (tt < T && c < P.N) {
+      if (tt < T && c < P.N && !(dbg & 32)) {
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
           const long gp = p0 + pixgrp + 16 * n + li;
           if (gp < P.M) {
-            const float rs = P.rowscale ? P.rowscale[gp] : 1.f;
+            const float rs = PRO == LY_PRO_AFFINE_RELU_CA ? rsv[n] : 1.f;
             f32x4 v;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -274,7 +279,8 @@ __global__ __launch_bounds__(LY_THREADS, LY_GEMM_MINW) void ly_gemm_kernel(const
               v[r] = P.act == LY_ACT_RELU ? ly_relu(u) : (P.act == LY_ACT_SILU ? ly_silu(u) : u);
             }
             float* o = P.out + gp * P.ldo + c;
-            if (vec_ok && c + 3 < P.N) {
+            if (dbg & 8) {
+            } else if (vec_ok && c + 3 < P.N) {
               ly_stg4(o, v);
             } else {
 #pragma unroll
@@ -293,6 +299,8 @@ __global__ __launch_bounds__(LY_THREADS, LY_GEMM_MINW) void ly_gemm_kernel(const
   }
 }
 
+static int g_gemm_dbg = 0;      // ablation aid: 1 skip commit (split + LDS write), 2 skip MFMA, 4 skip prefetch loads, 8 skip stores
+extern "C" int ly_debug_set_gemm(int v) { g_gemm_dbg = v; return 0; }
 static int g_gemm_cfg = 0;      // 0 = heuristic; otherwise forced NT*100 + MT*10 + WC (tuning aid)
 extern "C" int ly_debug_set_gemm_cfg(int cfg) { g_gemm_cfg = cfg; return 0; }
 
@@ -304,18 +312,21 @@ static int launch_gemm_mode(const LyGemmParams& P, hipStream_t st) {
   long gx = (P.M + BP - 1) / BP;
   int gy = (P.N + BN - 1) / BN;
   LY_CHECK(gx < (1L << 30), "gemm: too many pixel tiles");
-  const int per_cu = (int)(160 * 1024 / lds) < 4 ? (int)(160 * 1024 / lds) : 4;   // co-resident blocks by LDS
+  auto k = ly_gemm_kernel<NT, MT, WC, GATHER, PRO>;
+  static int per_cu = 0;            // co-resident blocks per CU (registers + LDS), measured once per instantiation
+  if (per_cu == 0) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+    LY_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    int nb = 0;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k), LY_THREADS, lds);
+    LY_CHECK(e == hipSuccess, "hipOccupancyMaxActiveBlocksPerMultiprocessor: %s", hipGetErrorString(e));
+    per_cu = nb < 1 ? 1 : (nb > 8 ? 8 : nb);
+  }
+  // persistent grid = exactly the blocks that can be resident at once (a larger grid would run in rounds)
   long nslots = (256L * per_cu) / gy;
   if (nslots < 1) nslots = 1;
   if (nslots > gx) nslots = gx;
-  auto k = ly_gemm_kernel<NT, MT, WC, GATHER, PRO>;
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
-    LY_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-    configured = true;
-  }
-  hipLaunchKernelGGL(k, dim3((unsigned)(nslots * gy)), dim3(LY_THREADS), lds, st, P, gy, (int)nslots, (int)gx);
+  hipLaunchKernelGGL(k, dim3((unsigned)(nslots * gy)), dim3(LY_THREADS), lds, st, P, gy, (int)nslots, (int)gx, g_gemm_dbg);
   LY_LAUNCH_CHECK();
   return 0;
 }
@@ -354,7 +365,8 @@ extern "C" int ly_gemm_fwd(const LyGemmParams* p, void* stream) {
     LY_CHECK(false, "gemm: unknown gather mode %d", P.gather);
   }
   if (P.pro == LY_PRO_GATE) LY_CHECK(P.g_h && P.g_w, "gemm: gate prologue needs g_h/g_w");
-  if (P.pro == LY_PRO_AFFINE_RELU_CA) LY_CHECK(P.p_scale && P.p_shift && P.p_ca, "gemm: affine prologue needs scale/shift/ca");
+  if (P.pro == LY_PRO_AFFINE_RELU_CA) LY_CHECK(P.p_scale && P.p_shift && P.p_ca && P.rowscale, "gemm: affine prologue needs scale/shift/ca and rowscale");
+  else LY_CHECK(!P.rowscale, "gemm: rowscale is only built together with the affine (RFCBAM k=1) prologue");
   LY_CHECK(P.M < (1L << 24), "gemm: M=%ld pixels exceeds the 2^24 limit of the fast index path", P.M);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   switch (g_gemm_cfg) {

@@ -4,8 +4,8 @@
 //
 // Replaces Partial_conv3.forward_split_cat + MLPBlock.forward (reference models/common.py:1432-1437,
 // 1478-1482): the split/cat copies, the 2C-wide hidden tensor and the BN/ReLU passes never touch HBM.
-// HBM traffic = x once + y once (+ a one-pixel-row halo of the first C/4 channels, + the residual
-// re-read which is an L2 hit on lines this block just fetched).
+// HBM traffic = x once + y once (+ a one-pixel-row halo of the first C/4 channels); the residual is
+// taken from the LDS copy of the tile.
 //
 // Block = 256 threads (4 waves) owns BP = 64*NT consecutive pixels of the flattened N*H*W index
 // (NHWC rows, so its input tile is one contiguous span of memory).  The tile is split once into
@@ -35,11 +35,11 @@ struct MlpGeom {
   static constexpr int S2 = HTP / 2;                // GEMM2 k-steps
 };
 
-template <int C, int NT, int HT>
+template <int C, int NT, int HT, bool T2D>
 __global__ __launch_bounds__(LY_THREADS) void ly_mlpblock_fwd_kernel(
     const float* __restrict__ x, float* __restrict__ y, long M, int H, int W,
     const uint4* __restrict__ wp, const uint4* __restrict__ w1, const uint4* __restrict__ w2,
-    const float* __restrict__ bn_scale, const float* __restrict__ bn_shift) {
+    const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, const int dbg) {
   using Gm = MlpGeom<C>;
   constexpr int CQ = Gm::CQ, G = Gm::G, SP = Gm::SP, PT = Gm::PT, C16 = Gm::C16, KP = Gm::KP, S1 = Gm::S1;
   constexpr int RS = Gm::RS, RSP = Gm::RSP, HTP = Gm::HTP, S2 = Gm::S2;
@@ -47,33 +47,69 @@ __global__ __launch_bounds__(LY_THREADS) void ly_mlpblock_fwd_kernel(
   static_assert(HTP % HT == 0 && HT % 2 == 0, "hidden tiles must split evenly into even chunks");
   static_assert(C % 8 == 0, "C must be a multiple of 8");
 
+  // Two tilings of the pixel index space:
+  //  * T2D (W % 16 == 0): a block owns a TH x 16 patch (TH = 4*NT rows, one MFMA pixel tile per row);
+  //    the halo is the (TH+2) x 18 frame with out-of-image positions staged as zeros, so the partial
+  //    conv needs no border masks and tap offsets are compile-time constants.
+  //  * flattened run: BP consecutive pixels of the N*H*W index (any W, tiles may span images); halo =
+  //    the run extended by W+1 pixels on both sides, border taps masked per lane.
+  constexpr int TH = 4 * NT;
   extern __shared__ f32x4 ly_smem4[];
   char* xs_hi = reinterpret_cast<char*>(ly_smem4);
   char* xs_lo = xs_hi + BP * RS;
-  const int BPH = BP + 2 * W + 2;
+  const int BPH = T2D ? (TH + 2) * 18 : BP + 2 * W + 2;
   char* ps_hi = xs_lo + BP * RS;
   char* ps_lo = ps_hi + BPH * RSP;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lq = lane >> 4;
-  const long p0 = (long)blockIdx.x * BP;
   const f32x4 zero = ly_zero4();
+  long p0 = 0;                 // flattened: first pixel of the run
+  long img0 = 0;               // T2D: pixel index of (n, 0, 0)
+  int h0 = 0, w0 = 0;          // T2D: patch origin
+  if (T2D) {
+    const int tw = W >> 4, th = (H + TH - 1) / TH;
+    int b = blockIdx.x;
+    const int tx = b % tw; b /= tw;
+    const int ty = b % th;
+    img0 = (long)(b / th) * H * W;
+    h0 = ty * TH; w0 = tx * 16;
+  } else {
+    p0 = (long)blockIdx.x * BP;
+  }
+  // global pixel index of tile-local pixel `pix` (or -1)
+  auto gpix = [&](int pix) -> long {
+    if (T2D) {
+      const int r = pix >> 4;
+      return (h0 + r < H) ? img0 + (long)(h0 + r) * W + w0 + (pix & 15) : -1;
+    }
+    const long gp = p0 + pix;
+    return gp < M ? gp : -1;
+  };
 
   ly_stage_f4<8>(BP * (KP / 4), tid, x,
       [&](int idx) -> const float* {
         const int pix = idx / (KP / 4), c4 = idx - pix * (KP / 4);
-        const long gp = p0 + pix;
-        return (gp < M && c4 * 4 < C) ? x + gp * C + c4 * 4 : nullptr;
+        const long gp = gpix(pix);
+        return (gp >= 0 && c4 * 4 < C) ? x + gp * C + c4 * 4 : nullptr;
       },
       [&](int idx, f32x4 v) {
         const int pix = idx / (KP / 4), c4 = idx - pix * (KP / 4);
         ly_lds_put4(xs_hi, xs_lo, pix * RS, 4 * c4, v);
       });
-  ly_stage_f4<4>(BPH * G, tid, x,
+  if (!(dbg & 4)) ly_stage_f4<4>(BPH * G, tid, x,
       [&](int idx) -> const float* {
         const int hp = idx / G, c4 = idx - hp * G;
-        const long gp = p0 - W - 1 + hp;
-        return (gp >= 0 && gp < M) ? x + gp * C + c4 * 4 : nullptr;
+        long gp;
+        if (T2D) {
+          const int hr = hp / 18, hc = hp - hr * 18;
+          const int hh = h0 - 1 + hr, ww = w0 - 1 + hc;
+          gp = (hh >= 0 && hh < H && ww >= 0 && ww < W) ? img0 + (long)hh * W + ww : -1;
+        } else {
+          gp = p0 - W - 1 + hp;
+          if (gp >= M) gp = -1;
+        }
+        return gp >= 0 ? x + gp * C + c4 * 4 : nullptr;
       },
       [&](int idx, f32x4 v) {
         const int hp = idx / G, c4 = idx - hp * G;
@@ -85,15 +121,24 @@ __global__ __launch_bounds__(LY_THREADS) void ly_mlpblock_fwd_kernel(
   const bf16x4 z4 = __builtin_bit_cast(bf16x4, make_uint2(0u, 0u));
 
   // ---- 1. partial 3x3 conv -------------------------------------------------------------------
-  {
+  if (!(dbg & 1)) {
     uint32_t tmask[NT];
+    int pbase[NT];             // byte offset of the (ty=0, tx=0) tap of this lane's pixel in the halo image
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
-      const long gp = p0 + pixbase + 16 * n + li;
-      const int w_ = (int)(gp % W);
-      const int h_ = (int)((gp / W) % H);
-      tmask[n] = ly_tapmask(h_, w_, H, W, gp < M);
+      const int pix = pixbase + 16 * n + li;
+      if (T2D) {
+        tmask[n] = 0x1ffu;                                   // zeros are staged for out-of-image taps
+        pbase[n] = ((pix >> 4) * 18 + (pix & 15)) * RSP;
+      } else {
+        const long gp = p0 + pix;
+        int h_, w_;
+        ly_pix_hw(gp, H, W, h_, w_);
+        tmask[n] = ly_tapmask(h_, w_, H, W, gp < M);
+        pbase[n] = pix * RSP;
+      }
     }
+    const int rowpitch = T2D ? 18 : W;                       // halo-image pixels per image row
     f32x4 accp[PT][NT];
 #pragma unroll
     for (int t = 0; t < PT; ++t)
@@ -111,16 +156,16 @@ __global__ __launch_bounds__(LY_THREADS) void ly_mlpblock_fwd_kernel(
         tap[h] = gv[h] ? g / G : 0;
         const int cq4 = gv[h] ? g - tap[h] * G : 0;
         const int ty = tap[h] / 3, tx = tap[h] - 3 * ty;
-        off[h] = (ty * W + tx) * RSP + 8 * cq4;
+        off[h] = (ty * rowpitch + tx) * RSP + 8 * cq4;
       }
       bf16x8 xh[NT], xl[NT];
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
-        const int rb = (pixbase + 16 * n + li) * RSP;
+        const int rb = pbase[n];
         bf16x4 ph[2], pl[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const bool ok = gv[h] && ((tmask[n] >> tap[h]) & 1u);
+          const bool ok = gv[h] && (T2D || ((tmask[n] >> tap[h]) & 1u));
           const bf16x4 a = *reinterpret_cast<const bf16x4*>(ps_hi + rb + off[h]);
           const bf16x4 b = *reinterpret_cast<const bf16x4*>(ps_lo + rb + off[h]);
           ph[h] = ok ? a : z4;
@@ -163,7 +208,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_mlpblock_fwd_kernel(
     for (int n = 0; n < NT; ++n) acco[t][n] = zero;
 
 #pragma unroll 1
-  for (int hc = 0; hc < HTP / HT; ++hc) {
+  for (int hc = 0; hc < ((dbg & 2) ? 0 : HTP / HT); ++hc) {
     f32x4 acch[HT][NT];
 #pragma unroll
     for (int t = 0; t < HT; ++t)
@@ -216,47 +261,69 @@ __global__ __launch_bounds__(LY_THREADS) void ly_mlpblock_fwd_kernel(
   }
 
   // ---- epilogue: residual + store ------------------------------------------------------------
+  // The residual x is rebuilt from the bf16 hi/lo planes already in LDS (|err| <= 2^-17 |x|) instead
+  // of re-reading global memory: channels < CQP from the halo image's centre tap (the tile's own
+  // copy of those channels was overwritten by the partial conv), the rest from the tile.
 #pragma unroll
   for (int ct = 0; ct < C16; ++ct)
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
       const int c = 16 * ct + 4 * lq;
-      const long gp = p0 + pixbase + 16 * n + li;
-      if (c < C && gp < M) {
-        const f32x4 r = ly_ldg4(x + gp * C + c);
-        ly_stg4(y + gp * C + c, acco[ct][n] + r);
+      const int pix = pixbase + 16 * n + li;
+      const long gp = gpix(pix);
+      if (c < C && gp >= 0) {
+        bf16x4 rh, rl;
+        if (c < Gm::CQP) {
+          const int rb = (T2D ? (((pix >> 4) + 1) * 18 + (pix & 15) + 1) : (pix + W + 1)) * RSP + 2 * c;
+          rh = *reinterpret_cast<const bf16x4*>(ps_hi + rb);
+          rl = *reinterpret_cast<const bf16x4*>(ps_lo + rb);
+        } else {
+          const int rb = pix * RS + 2 * c;
+          rh = *reinterpret_cast<const bf16x4*>(xs_hi + rb);
+          rl = *reinterpret_cast<const bf16x4*>(xs_lo + rb);
+        }
+        const f32x4 r = __builtin_convertvector(rh, f32x4) + __builtin_convertvector(rl, f32x4);
+        if (!(dbg & 8)) ly_stg4(y + gp * C + c, acco[ct][n] + r);
       }
     }
 }
 
-template <int C, int NT, int HT>
-static int launch_mlp(const float* x, float* y, long M, int H, int W, const void* wp, const void* w1, const void* w2,
+static int g_mlp_tile = 0;  // tuning aid: 1 = force the flattened-run tiling
+extern "C" int ly_debug_set_mlp_tile(int v) { g_mlp_tile = v; return 0; }
+static int g_mlp_dbg = 0;   // ablation aid: 1 skip pconv, 2 skip MLP contractions, 4 skip halo staging, 8 skip stores
+extern "C" int ly_debug_set_mlp(int v) { g_mlp_dbg = v; return 0; }
+
+template <int C, int NT, int HT, bool T2D>
+static int launch_mlp(const float* x, float* y, long M, int n_img, int H, int W, const void* wp, const void* w1, const void* w2,
                       const float* s, const float* b, hipStream_t st) {
   using Gm = MlpGeom<C>;
   constexpr int BP = 64 * NT;
-  size_t lds = 2 * ((size_t)BP * Gm::RS + (size_t)(BP + 2 * W + 2) * Gm::RSP);
+  const long halo = T2D ? (4 * NT + 2) * 18 : BP + 2 * W + 2;
+  size_t lds = 2 * ((size_t)BP * Gm::RS + (size_t)halo * Gm::RSP);
   LY_CHECK(lds <= 160 * 1024, "mlpblock: tile needs %zu B of LDS (C=%d W=%d)", lds, C, W);
-  auto k = ly_mlpblock_fwd_kernel<C, NT, HT>;
+  auto k = ly_mlpblock_fwd_kernel<C, NT, HT, T2D>;
   static bool configured = false;
   if (!configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
     LY_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     configured = true;
   }
-  long blocks = (M + BP - 1) / BP;
+  long blocks = T2D ? (long)n_img * ((H + 4 * NT - 1) / (4 * NT)) * (W / 16) : (M + BP - 1) / BP;
   hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(LY_THREADS), lds, st, x, y, M, H, W, reinterpret_cast<const uint4*>(wp),
-                     reinterpret_cast<const uint4*>(w1), reinterpret_cast<const uint4*>(w2), s, b);
+                     reinterpret_cast<const uint4*>(w1), reinterpret_cast<const uint4*>(w2), s, b, g_mlp_dbg);
   LY_LAUNCH_CHECK();
   return 0;
 }
 
-// pick pixel tiles per wave so that the grid still covers the chip (256 CUs) where M is small
+// 2-D patches (8 x 16 px per block: small halo, 4+ co-resident blocks per CU) where the map is wide and
+// a multiple of 16; flattened runs otherwise, with as many pixel tiles per wave as still fill the chip
 template <int C, int HT, int NTMAX>
-static int dispatch_nt(const float* x, float* y, long M, int H, int W, const void* wp, const void* w1, const void* w2,
+static int dispatch_nt(const float* x, float* y, long M, int n_img, int H, int W, const void* wp, const void* w1, const void* w2,
                        const float* s, const float* b, hipStream_t st) {
-  if (NTMAX >= 4 && M >= 256L * 1024) return launch_mlp<C, (NTMAX >= 4 ? 4 : NTMAX), HT>(x, y, M, H, W, wp, w1, w2, s, b, st);
-  if (NTMAX >= 2 && M >= 128L * 512) return launch_mlp<C, (NTMAX >= 2 ? 2 : NTMAX), HT>(x, y, M, H, W, wp, w1, w2, s, b, st);
-  return launch_mlp<C, 1, HT>(x, y, M, H, W, wp, w1, w2, s, b, st);
+  if ((W & 15) == 0 && W >= 64 && NTMAX >= 2 && g_mlp_tile != 1) return launch_mlp<C, 2, HT, true>(x, y, M, n_img, H, W, wp, w1, w2, s, b, st);
+  if (NTMAX >= 4 && M >= 256L * 1024) return launch_mlp<C, (NTMAX >= 4 ? 4 : NTMAX), HT, false>(x, y, M, n_img, H, W, wp, w1, w2, s, b, st);
+  if (NTMAX >= 2 && M >= 128L * 512) return launch_mlp<C, (NTMAX >= 2 ? 2 : NTMAX), HT, false>(x, y, M, n_img, H, W, wp, w1, w2, s, b, st);
+  return launch_mlp<C, 1, HT, false>(x, y, M, n_img, H, W, wp, w1, w2, s, b, st);
 }
 
 extern "C" int ly_mlpblock_fwd(const float* x, float* y, int n_img, int H, int W, int C, const void* wp, const void* w1,
@@ -265,14 +332,15 @@ extern "C" int ly_mlpblock_fwd(const float* x, float* y, int n_img, int H, int W
   LY_CHECK(x != y, "mlpblock: in-place call is not supported (neighbouring tiles read halo rows)");
   LY_CHECK(n_img > 0 && H > 0 && W > 0, "mlpblock: bad shape %d x %d x %d", n_img, H, W);
   long M = (long)n_img * H * W;
+  LY_CHECK(M < (1L << 24), "mlpblock: M=%ld pixels exceeds the 2^24 limit of the fast index path", M);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   switch (C) {
-    case 16:  return dispatch_nt<16, 2, 4>(x, y, M, H, W, wp, w1, w2, bn_scale, bn_shift, st);
-    case 24:  return dispatch_nt<24, 4, 4>(x, y, M, H, W, wp, w1, w2, bn_scale, bn_shift, st);
-    case 40:  return dispatch_nt<40, 2, 4>(x, y, M, H, W, wp, w1, w2, bn_scale, bn_shift, st);
-    case 80:  return dispatch_nt<80, 2, 2>(x, y, M, H, W, wp, w1, w2, bn_scale, bn_shift, st);
-    case 160: return dispatch_nt<160, 4, 2>(x, y, M, H, W, wp, w1, w2, bn_scale, bn_shift, st);
-    case 320: return dispatch_nt<320, 4, 1>(x, y, M, H, W, wp, w1, w2, bn_scale, bn_shift, st);
+    case 16:  return dispatch_nt<16, 2, 4>(x, y, M, n_img, H, W, wp, w1, w2, bn_scale, bn_shift, st);
+    case 24:  return dispatch_nt<24, 4, 4>(x, y, M, n_img, H, W, wp, w1, w2, bn_scale, bn_shift, st);
+    case 40:  return dispatch_nt<40, 2, 4>(x, y, M, n_img, H, W, wp, w1, w2, bn_scale, bn_shift, st);
+    case 80:  return dispatch_nt<80, 2, 2>(x, y, M, n_img, H, W, wp, w1, w2, bn_scale, bn_shift, st);
+    case 160: return dispatch_nt<160, 4, 2>(x, y, M, n_img, H, W, wp, w1, w2, bn_scale, bn_shift, st);
+    case 320: return dispatch_nt<320, 4, 1>(x, y, M, n_img, H, W, wp, w1, w2, bn_scale, bn_shift, st);
     default:
       ly_set_error("mlpblock: unsupported channel count C=%d (built for 16/24/40/80/160/320)", C);
       return -1;

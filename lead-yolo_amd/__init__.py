@@ -5,3 +5,5 @@ from . import capi, ops, pack  # noqa: F401
 from .modules import *  # noqa: F401,F403
 from .modules import Lazy  # noqa: F401
 from .model import DEFAULT_CFG, DetectionModel, Model, load_cfg, make_divisible, parse_model  # noqa: F401
+from .loss import ComputeLoss  # noqa: F401
+from .ddp import GradReducer  # noqa: F401

@@ -52,8 +52,24 @@ __device__ __forceinline__ f32x4 ly_zero4() { return (f32x4){0.f, 0.f, 0.f, 0.f}
 __device__ __forceinline__ f32x4 ly_ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void ly_stg4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
-__device__ __forceinline__ float ly_sigmoid(float x) { return 1.f / (1.f + __expf(-x)); }
-__device__ __forceinline__ float ly_silu(float x) { return x / (1.f + __expf(-x)); }
+// v_exp_f32 + v_rcp_f32 (each <= 1 ulp): ~3 instructions instead of the ~15 of an IEEE division
+__device__ __forceinline__ float ly_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float ly_silu(float x) { return x * ly_sigmoid(x); }
+
+// activation applied to a whole float4 with ONE uniform switch (no per-element branching)
+__device__ __forceinline__ f32x4 ly_act4(f32x4 u, int act) {
+  f32x4 v;
+  if (act == 2) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = ly_silu(u[r]);
+  } else if (act == 1) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = fmaxf(u[r], 0.f);
+  } else {
+    v = u;
+  }
+  return v;
+}
 __device__ __forceinline__ float ly_relu(float x) { return fmaxf(x, 0.f); }
 __device__ __forceinline__ float ly_hswish(float x) { return x * fminf(fmaxf(x + 3.f, 0.f), 6.f) * (1.f / 6.f); }
 

@@ -111,12 +111,10 @@ __global__ __launch_bounds__(LY_THREADS) void ly_conv3x3_kernel(const LyConv3Par
     for (int n = 0; n < NT; ++n) {
       const long gp = p0 + pixgrp + 16 * n + li;
       if (gp >= P.M) continue;
-      f32x4 v;
+      f32x4 u;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float u = acc[t][n][r] * sc[r] + sh[r];
-        v[r] = P.act == LY_ACT_RELU ? ly_relu(u) : (P.act == LY_ACT_SILU ? ly_silu(u) : u);
-      }
+      for (int r = 0; r < 4; ++r) u[r] = acc[t][n][r] * sc[r] + sh[r];
+      const f32x4 v = ly_act4(u, P.act);
       float* o = P.out + gp * P.ldo + c;
       if ((P.ldo & 3) == 0 && c + 3 < P.N) {
         ly_stg4(o, v);

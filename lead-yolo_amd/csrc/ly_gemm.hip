@@ -172,6 +172,7 @@ __global__ __launch_bounds__(LY_THREADS, LY_GEMM_MINW) void ly_gemm_kernel(const
   const uint4* wpk = reinterpret_cast<const uint4*>(P.wp);
   const int pixgrp = wp_ * (16 * NT);
   const bool vec_ok = (P.ldo & 3) == 0;
+  const int act = P.act;
   float rsv[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) rsv[n] = 1.f;
@@ -272,12 +273,10 @@ __global__ __launch_bounds__(LY_THREADS, LY_GEMM_MINW) void ly_gemm_kernel(const
           const long gp = p0 + pixgrp + 16 * n + li;
           if (gp < P.M) {
             const float rs = PRO == LY_PRO_AFFINE_RELU_CA ? rsv[n] : 1.f;
-            f32x4 v;
+            f32x4 u;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              float u = acc[t][n][r] * rs * esc[t][r] + esh[t][r];
-              v[r] = P.act == LY_ACT_RELU ? ly_relu(u) : (P.act == LY_ACT_SILU ? ly_silu(u) : u);
-            }
+            for (int r = 0; r < 4; ++r) u[r] = acc[t][n][r] * rs * esc[t][r] + esh[t][r];
+            const f32x4 v = ly_act4(u, act);
             float* o = P.out + gp * P.ldo + c;
             if (dbg & 8) {
             } else if (vec_ok && c + 3 < P.N) {

@@ -1,0 +1,45 @@
+"""Product loss / target assignment (lead_yolo_amd.loss) vs the vectors the reference produced:
+int64 indices bit-exact, loss and input gradients to fp32 rounding.  Device-agnostic host logic: runs
+on CPU here and on the GPU in the -m gpu variant."""
+import numpy as np
+import pytest
+import torch
+
+from tests import golden_util as G
+
+
+class _Det:
+    def __init__(self, anchors):
+        self.na, self.nc, self.nl, self.anchors = anchors.shape[1], 1, anchors.shape[0], anchors
+
+
+def _run(case, device):
+    from lead_yolo_amd.loss import ComputeLoss
+    meta, arr = G.load("loss_n")
+    anchors = G.t(arr["anchors"]).to(device)
+    cl = ComputeLoss(_Det(anchors), hyp={k: v for k, v in meta["hyp"].items() if k in ("box", "cls", "cls_pw", "obj", "obj_pw", "anchor_t", "fl_gamma")})
+    preds = [G.t(arr[f"pred{i}"]).to(device).requires_grad_(True) for i in range(3)]
+    tg = G.t(arr[f"{case}_targets"]).to(device)
+    tcls, tbox, indices, anch = cl.build_targets(preds, tg)
+    for i in range(3):
+        got = np.stack([v.cpu().numpy() for v in indices[i]])
+        assert got.dtype == np.int64 and np.array_equal(got, arr[f"{case}_idx{i}"])
+        np.testing.assert_array_equal(tbox[i].detach().cpu().numpy(), arr[f"{case}_tbox{i}"])
+        np.testing.assert_array_equal(anch[i].cpu().numpy(), arr[f"{case}_anch{i}"])
+    loss, items = cl(preds, tg)
+    np.testing.assert_allclose(loss.detach().cpu().numpy(), arr[f"{case}_loss"], rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(items.cpu().numpy(), arr[f"{case}_items"], rtol=2e-5, atol=1e-6)
+    loss.backward()
+    for i in range(3):
+        np.testing.assert_allclose(preds[i].grad.cpu().numpy(), arr[f"{case}_dpred{i}"], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("case", ["rand", "edge", "empty"])
+def test_loss_cpu(case):
+    _run(case, torch.device("cpu"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["rand", "edge", "empty"])
+def test_loss_gpu(case):
+    _run(case, torch.device("cuda:0"))

@@ -78,6 +78,7 @@ int ly_debug_set_gemm(int v);
 typedef struct LyConv3Params {
   long M; int H, W;        /* output (= input) pixels, spatial size                              */
   int Cin, N;              /* input channels (multiple of 4), output channels                    */
+  int TH, TW;              /* pixel patch per block: TH*TW <= 128, (TH+2)*(TW+2) <= 192          */
   const float* x; int ldx; /* NHWC input, row stride (floats)                                    */
   const void* wp;          /* frag_pack3(conv_taps_matrix(weight, 32)): k = tap*ceil32(Cin) + c  */
   const float* e_scale; const float* e_shift;   /* folded BN / bias, [N] or NULL                 */
@@ -88,6 +89,8 @@ typedef struct LyConv3Params {
 /* Conv(c1, c2, 3, 1) = conv3x3(no bias) + BN + SiLU (CA_Bottleneck.cv2, models/common.py:1617,
  * 1890-1910). */
 int ly_conv3x3_fwd(const LyConv3Params* p, void* stream);
+/* ablation aid for profiling (bit 0: skip weight loads, 1: skip LDS reads + MFMA, 2: skip prefetch, 3: skip commit) */
+int ly_debug_set_conv3(int v);
 
 
 /* ---- CoordAtt (models/common.py:1583-1609) ------------------------------------------------------- */
@@ -139,7 +142,7 @@ int ly_debug_set_rf3(int v);
 /* ---- graph remainder ------------------------------------------------------------------------- */
 /* SPPF pooling (models/common.py:348-366): out[n, p, :] = [x | m(x) | m(m(x)) | m(m(m(x)))] with m =
  * k x k / stride 1 / pad k//2 max pool; out row stride ldo >= 4C.  The map must fit LDS
- * (2*H*W*17 floats <= 160 KiB).                                                                    */
+ * (2*H*W*4 floats <= 160 KiB); C, ldx, ldo multiples of 4.                                                                    */
 int ly_sppf_pool(const float* x, int ldx, int n_img, int H, int W, int C, int k, float* out, int ldo, void* stream);
 /* Detect tail (models/yolo.py:95-120): y[n,h,w,na*no] (row stride ldy) -> p[n,na,h,w,no] and, if z is
  * not NULL, decoded rows z[n, zoff + (a*H + h)*W + w, :] of a [n_img, zrows, no] tensor;

@@ -28,7 +28,7 @@ class LyGemmParams(ctypes.Structure):       # mirrors include/lead_yolo_hip.h
 
 
 class LyConv3Params(ctypes.Structure):
-    _fields_ = [("M", _L), ("H", _I), ("W", _I), ("Cin", _I), ("N", _I), ("x", _P), ("ldx", _I), ("wp", _P),
+    _fields_ = [("M", _L), ("H", _I), ("W", _I), ("Cin", _I), ("N", _I), ("TH", _I), ("TW", _I), ("x", _P), ("ldx", _I), ("wp", _P),
                 ("e_scale", _P), ("e_shift", _P), ("act", _I), ("out", _P), ("ldo", _I)]
 
 
@@ -51,6 +51,7 @@ SIGNATURES = {
     "ly_debug_set_gemm_cfg": [_I],
     "ly_debug_set_gemm": [_I],
     "ly_debug_set_rf3": [_I],
+    "ly_debug_set_conv3": [_I],
     "ly_debug_set_mlp": [_I],
     "ly_debug_set_mlp_tile": [_I],
     "ly_conv3x3_fwd": [ctypes.POINTER(LyConv3Params), _P],

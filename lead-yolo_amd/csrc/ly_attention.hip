@@ -377,52 +377,61 @@ extern "C" int ly_coordatt_gate(const float* x, int ldx, int n_img, int H, int W
 // equal single (2k-1)- and (3k-2)-wide max windows, computed separably from one LDS copy of the map.
 // One block per (image, 16-channel group); the map (H*W <= 4096) lives in LDS.
 // ---------------------------------------------------------------------------------------------------
+#define LY_SP_CG 4     // channels per block: n_img * C/4 blocks keep the whole chip busy on the small P5 map
 __global__ __launch_bounds__(LY_THREADS) void ly_sppf_pool_kernel(const float* __restrict__ x, int ldx, int H, int W, int C, int k,
                                                                   float* __restrict__ out, int ldo) {
-  extern __shared__ float sp[];                // a[HW][17], b[HW][17]
+  extern __shared__ f32x4 sp4[];               // a[HW], b[HW] as float4 (4 channels per position)
   const int HW = H * W;
-  float* a = sp;
-  float* b = sp + HW * 17;
-  const int groups = (C + 15) / 16;
+  f32x4* a = sp4;
+  f32x4* b = sp4 + HW;
+  const int groups = C / LY_SP_CG;
   const int n = blockIdx.x / groups, g = blockIdx.x - n * groups;
-  const int c0 = g * 16, cw = (C - c0) < 16 ? (C - c0) : 16;
+  const int c0 = g * LY_SP_CG;
   const int tid = threadIdx.x, r = k / 2;
-  for (int i = tid; i < HW * 16; i += LY_THREADS) {
-    const int p = i >> 4, c = i & 15;
-    const float v = c < cw ? x[((long)n * HW + p) * ldx + c0 + c] : 0.f;
-    a[p * 17 + c] = v;
-    if (c < cw) out[((long)n * HW + p) * ldo + c0 + c] = v;
+  const f32x4 ninf = (f32x4){-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (int p = tid; p < HW; p += LY_THREADS) {
+    const f32x4 v = ly_ldg4(x + ((long)n * HW + p) * ldx + c0);
+    a[p] = v;
+    ly_stg4(out + ((long)n * HW + p) * ldo + c0, v);
   }
   __syncthreads();
   for (int level = 1; level <= 3; ++level) {
     // b = row-max of a, then a = col-max of b  (one k x k max pool of the previous level)
-    for (int i = tid; i < HW * 16; i += LY_THREADS) {
-      const int p = i >> 4, c = i & 15, h = p / W, w = p - h * W;
-      float m = -FLT_MAX;
+    for (int p = tid; p < HW; p += LY_THREADS) {
+      const int h = p / W, w = p - h * W;
+      f32x4 m = ninf;
       for (int d = -r; d <= r; ++d) {
         const int ww = w + d;
-        if (ww >= 0 && ww < W) m = fmaxf(m, a[(h * W + ww) * 17 + c]);
+        if (ww >= 0 && ww < W) {
+          const f32x4 v = a[h * W + ww];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) m[q] = fmaxf(m[q], v[q]);
+        }
       }
-      b[p * 17 + c] = m;
+      b[p] = m;
     }
     __syncthreads();
-    for (int i = tid; i < HW * 16; i += LY_THREADS) {
-      const int p = i >> 4, c = i & 15, h = p / W, w = p - h * W;
-      float m = -FLT_MAX;
+    for (int p = tid; p < HW; p += LY_THREADS) {
+      const int h = p / W, w = p - h * W;
+      f32x4 m = ninf;
       for (int d = -r; d <= r; ++d) {
         const int hh = h + d;
-        if (hh >= 0 && hh < H) m = fmaxf(m, b[(hh * W + w) * 17 + c]);
+        if (hh >= 0 && hh < H) {
+          const f32x4 v = b[hh * W + w];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) m[q] = fmaxf(m[q], v[q]);
+        }
       }
-      a[p * 17 + c] = m;
-      if (c < cw) out[((long)n * HW + p) * ldo + level * C + c0 + c] = m;
+      a[p] = m;
+      ly_stg4(out + ((long)n * HW + p) * ldo + level * C + c0, m);
     }
     __syncthreads();
   }
 }
 
 extern "C" int ly_sppf_pool(const float* x, int ldx, int n_img, int H, int W, int C, int k, float* out, int ldo, void* stream) {
-  LY_CHECK(x && out && k >= 1 && (k & 1), "sppf_pool: bad arguments");
-  size_t lds = sizeof(float) * 2 * (size_t)H * W * 17;
+  LY_CHECK(x && out && k >= 1 && (k & 1) && (C & 3) == 0 && (ldx & 3) == 0 && (ldo & 3) == 0, "sppf_pool: bad arguments");
+  size_t lds = sizeof(float) * 2 * (size_t)H * W * 4;
   LY_CHECK(lds <= 160 * 1024, "sppf_pool: %dx%d map does not fit LDS (%zu B)", H, W, lds);
   static bool configured = false;
   if (!configured) {
@@ -430,7 +439,7 @@ extern "C" int ly_sppf_pool(const float* x, int ldx, int n_img, int H, int W, in
     LY_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     configured = true;
   }
-  hipLaunchKernelGGL(ly_sppf_pool_kernel, dim3(n_img * ((C + 15) / 16)), dim3(LY_THREADS), lds, reinterpret_cast<hipStream_t>(stream), x,
+  hipLaunchKernelGGL(ly_sppf_pool_kernel, dim3(n_img * (C / LY_SP_CG)), dim3(LY_THREADS), lds, reinterpret_cast<hipStream_t>(stream), x,
                      ldx, H, W, C, k, out, ldo);
   LY_LAUNCH_CHECK();
   return 0;

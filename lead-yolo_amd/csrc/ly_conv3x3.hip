@@ -1,103 +1,158 @@
-// 3x3 / stride 1 / pad 1 convolution as an implicit GEMM + folded BN + activation, fp32, gfx950.
+// 3x3 / stride 1 / pad 1 convolution as an implicit GEMM + folded BN + activation, fp32 I/O, bf16x3
+// math, gfx950.
 //
 //   out[m, n] = act( scale[n] * sum_{tap, c} X[pix(m) + tap][c] * W[n][c][tap] + shift[n] )
 //
 // Replaces CA_Bottleneck.cv2 = Conv(c_, c_, 3, 1) (reference models/common.py:1617,1890-1910): no
-// im2col buffer exists anywhere; the block stages a halo run of the NHWC input (BP + 2W + 2
-// consecutive pixels x 32 input channels) in LDS and every MFMA B-operand is a 16-byte read at
-// (pixel + tap offset), masked at the image borders.  K order = (tap, cin); weights bf16x3 frag-packed
-// from pack.conv_taps_matrix(w, 32).
+// im2col buffer exists anywhere.  A block owns a TH x TW patch of one image (<= 128 pixels, chosen on
+// the host to tile H x W with little waste).  Per 32-input-channel chunk it stages the (TH+2) x (TW+2)
+// frame of the NHWC input as bf16 hi/lo planes in LDS with out-of-image positions written as ZEROS, so
+// every MFMA B operand is a plain 2 x 8-byte LDS read at (pixel + tap offset): no border masks, tap
+// offsets are wave-uniform.  K order = (tap, cin); weights bf16x3 frag-packed from
+// pack.conv_taps_matrix(w, 32).
+//
+// Pipeline: the raw fp32 frame of chunk c+1 is loaded into registers before the 9-tap contraction of
+// chunk c is issued and committed to LDS after it; weight fragments are fetched one tap ahead.
+// The 4 waves split the output channels (WC = 4): each weight fragment is read by exactly one wave.
 #include "ly_tile.cuh"
 #include "ly_params.h"
 
 #define LY_CC 32
-#define LY_RSH (2 * LY_CC + 16)   // bytes per halo row, per plane
+#define LY_RSH (2 * LY_CC + 16)   // bytes per frame position, per plane
+#define LY_C3_NT 8                // max pixel tiles (128 pixels) per block
+#define LY_C3_NV 6                // float4 per thread per chunk: (TH+2)(TW+2)*8 <= 6*256  =>  frame <= 192 positions
 
-template <int NT, int MT, int WC>
-__global__ __launch_bounds__(LY_THREADS) void ly_conv3x3_kernel(const LyConv3Params P, const int gy, const int nblocks) {
-  constexpr int WP = 4 / WC;
-  constexpr int BP = 16 * NT * WP;
+template <int MT>
+__global__ __launch_bounds__(LY_THREADS) void ly_conv3x3_kernel(const LyConv3Params P, const int gy, const int tiles_x, const int tiles_y, const int dbg) {
   extern __shared__ f32x4 ly_smem4[];
+  const int TH = P.TH, TW = P.TW, FW = TW + 2;
+  const int frame = (TH + 2) * FW;
   char* hs_hi = reinterpret_cast<char*>(ly_smem4);
+  char* hs_lo = hs_hi + frame * LY_RSH;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lq = lane >> 4;
-  const int wc = wave % WC, wp_ = wave / WC;
-  const int lid = ly_xcd_remap(blockIdx.x, nblocks);
-  const int by = lid % gy;
-  const long p0 = (long)(lid / gy) * BP;
-  const int W = P.W, H = P.H;
-  const int BPH = BP + 2 * W + 2;
-  char* hs_lo = hs_hi + BPH * LY_RSH;
+  int b = blockIdx.x;
+  const int by = b % gy; b /= gy;
+  const int tx = b % tiles_x; b /= tiles_x;
+  const int ty = b % tiles_y;
+  const int n_img = b / tiles_y;
+  const int h0 = ty * TH, w0 = tx * TW;
+  const int npx = TH * TW;
+  const int ntv = (npx + 15) >> 4;                         // pixel tiles actually used (wave-uniform)
   const f32x4 zero = ly_zero4();
-  const bf16x8 z8 = __builtin_bit_cast(bf16x8, make_uint4(0u, 0u, 0u, 0u));
-  const int C32 = (P.Cin + 31) >> 5;       // k-steps per tap
+  const int C32 = (P.Cin + 31) >> 5;                       // k-steps per tap
   const int S = 9 * C32;
   const int T = (P.N + 15) >> 4;
-  const int pixgrp = wp_ * (16 * NT);
+  const long img0 = (long)n_img * P.H * P.W;
 
-  uint32_t tmask[NT];
+  // per-lane pixel -> byte offset of its (0,0) tap in the frame, and its output row (or -1)
+  int hb[LY_C3_NT];
+  long orow[LY_C3_NT];
 #pragma unroll
-  for (int n = 0; n < NT; ++n) {
-    long gp = p0 + pixgrp + 16 * n + li;
-    int h_, w_;
-    ly_pix_hw(gp, H, W, h_, w_);
-    tmask[n] = ly_tapmask(h_, w_, H, W, gp < P.M);
+  for (int n = 0; n < LY_C3_NT; ++n) {
+    const int p = 16 * n + li;
+    const int pp = p < npx ? p : 0;
+    const int r = pp / TW, c = pp - r * TW;
+    hb[n] = (r * FW + c) * LY_RSH;
+    const bool ok = p < npx && h0 + r < P.H && w0 + c < P.W;
+    orow[n] = ok ? img0 + (long)(h0 + r) * P.W + (w0 + c) : -1;
   }
 
-  f32x4 acc[MT][NT];
+  // ---- staging: this thread's frame items (position, 4-channel group) ---------------------------------
+  const int items = frame * (LY_CC / 4);
+  long src[LY_C3_NV];                                       // element offset of the item's first channel of chunk 0, or -1
+#pragma unroll
+  for (int e = 0; e < LY_C3_NV; ++e) {
+    const int idx = tid + e * LY_THREADS;
+    long off = -1;
+    if (idx < items) {
+      const int pos = idx >> 3, c4 = idx & 7;
+      const int fr = pos / FW, fc = pos - fr * FW;
+      const int hh = h0 - 1 + fr, ww = w0 - 1 + fc;
+      if (hh >= 0 && hh < P.H && ww >= 0 && ww < P.W) off = (img0 + (long)hh * P.W + ww) * P.ldx + 4 * c4;
+    }
+    src[e] = off;
+  }
+  f32x4 pv[LY_C3_NV];
+  auto prefetch = [&](int c0) {
+#pragma unroll
+    for (int e = 0; e < LY_C3_NV; ++e) {
+      const int c4 = (tid + e * LY_THREADS) & 7;
+      const bool ok = src[e] >= 0 && c0 + 4 * c4 < P.Cin;
+      pv[e] = ly_ldg4(ok ? P.x + src[e] + c0 : P.x);      // clamped address, zero selected at commit
+    }
+  };
+  auto commit = [&](int c0) {
+#pragma unroll
+    for (int e = 0; e < LY_C3_NV; ++e) {
+      const int idx = tid + e * LY_THREADS;
+      const int c4 = idx & 7;
+      const bool ok = src[e] >= 0 && c0 + 4 * c4 < P.Cin;
+      if (idx < items) ly_lds_put4(hs_hi, hs_lo, (idx >> 3) * LY_RSH, 4 * c4, ok ? pv[e] : zero);
+    }
+  };
+
+  f32x4 acc[MT][LY_C3_NT];
 #pragma unroll
   for (int t = 0; t < MT; ++t)
 #pragma unroll
-    for (int n = 0; n < NT; ++n) acc[t][n] = zero;
-  int tile[MT];
+    for (int n = 0; n < LY_C3_NT; ++n) acc[t][n] = zero;
+  long wbase[MT];
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
-    int tt = (by * WC + wc) * MT + t;
-    tile[t] = tt < T ? tt : T - 1;
+    const int tt = (by * 4 + wave) * MT + t;
+    wbase[t] = (long)(tt < T ? tt : T - 1) * S;
   }
   const uint4* wpk = reinterpret_cast<const uint4*>(P.wp);
 
-  for (int c0 = 0; c0 < P.Cin; c0 += LY_CC) {
-    __syncthreads();
-    ly_stage_f4<8>(BPH * (LY_CC / 4), tid, P.x,
-        [&](int idx) -> const float* {
-          const int hp = idx / (LY_CC / 4), c4 = idx - hp * (LY_CC / 4);
-          const long gp = p0 - W - 1 + hp;
-          const int c = c0 + 4 * c4;
-          return (gp >= 0 && gp < P.M && c < P.Cin) ? P.x + gp * P.ldx + c : nullptr;
-        },
-        [&](int idx, f32x4 v) {
-          const int hp = idx / (LY_CC / 4), c4 = idx - hp * (LY_CC / 4);
-          ly_lds_put4(hs_hi, hs_lo, hp * LY_RSH, 4 * c4, v);
-        });
-    __syncthreads();
-    const int sc0 = c0 >> 5;
-#pragma unroll 3
+  LyWFrag wcur[MT], wnxt[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) wcur[t] = ly_wfrag(wpk, wbase[t], lane);      // (tap 0, chunk 0)
+
+  prefetch(0);
+  commit(0);
+  __syncthreads();
+
+  for (int cc = 0; cc < C32; ++cc) {
+    const bool more = cc + 1 < C32;
+    if (more && !(dbg & 4)) prefetch((cc + 1) * LY_CC);
+#pragma unroll(MT == 1 ? 1 : 9)
     for (int tap = 0; tap < 9; ++tap) {
-      const int ty = tap / 3, tx = tap - 3 * ty;
-      const int off = (ty * W + tx) * LY_RSH;
-      bf16x8 xh[NT], xl[NT];
+      // next fragment: next tap of this chunk, or tap 0 of the next chunk (clamped at the very end)
+      if (!(dbg & 1)) {
+        const int nt = tap < 8 ? tap + 1 : 0;
+        const int nc = tap < 8 ? cc : (more ? cc + 1 : cc);
 #pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        const int rb = (pixgrp + 16 * n + li) * LY_RSH + off;
-        const bool ok = (tmask[n] >> tap) & 1u;
-        const bf16x8 a = ly_lds_frag(hs_hi, rb, 0, lq), b = ly_lds_frag(hs_lo, rb, 0, lq);
-        xh[n] = ok ? a : z8;
-        xl[n] = ok ? b : z8;
+        for (int t = 0; t < MT; ++t) wnxt[t] = ly_wfrag(wpk, wbase[t] + nt * C32 + nc, lane);
+      }
+      const int toff = ((tap / 3) * FW + (tap % 3)) * LY_RSH;
+#pragma unroll
+      for (int n = 0; n < LY_C3_NT; ++n) {
+        if (n < ntv && !(dbg & 2)) {
+          const bf16x8 xh = ly_lds_frag(hs_hi, hb[n] + toff, 0, lq);
+          const bf16x8 xl = ly_lds_frag(hs_lo, hb[n] + toff, 0, lq);
+#pragma unroll
+          for (int t = 0; t < MT; ++t) acc[t][n] = ly_mfma3(wcur[t].hi, wcur[t].lo, xh, xl, acc[t][n]);
+        }
       }
 #pragma unroll
-      for (int t = 0; t < MT; ++t) {
-        const LyWFrag wf = ly_wfrag(wpk, (long)tile[t] * S + tap * C32 + sc0, lane);
-#pragma unroll
-        for (int n = 0; n < NT; ++n) acc[t][n] = ly_mfma3(wf.hi, wf.lo, xh[n], xl[n], acc[t][n]);
-      }
+      for (int t = 0; t < MT; ++t) wcur[t] = wnxt[t];
+    }
+    if (more) {
+      __syncthreads();            // every wave is done reading the frame of chunk cc
+      if (!(dbg & 8)) commit((cc + 1) * LY_CC);
+      __syncthreads();
     }
   }
 
+  // ---- epilogue ---------------------------------------------------------------------------------
+  const int act = P.act;
+  const bool vec_ok = (P.ldo & 3) == 0;
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
-    const int tt = (by * WC + wc) * MT + t;
+    const int tt = (by * 4 + wave) * MT + t;
     const int c = 16 * tt + 4 * lq;
     if (tt >= T || c >= P.N) continue;
     float sc[4], sh[4];
@@ -108,15 +163,14 @@ __global__ __launch_bounds__(LY_THREADS) void ly_conv3x3_kernel(const LyConv3Par
       sh[r] = (ok && P.e_shift) ? P.e_shift[c + r] : 0.f;
     }
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      const long gp = p0 + pixgrp + 16 * n + li;
-      if (gp >= P.M) continue;
+    for (int n = 0; n < LY_C3_NT; ++n) {
+      if (orow[n] < 0) continue;
       f32x4 u;
 #pragma unroll
       for (int r = 0; r < 4; ++r) u[r] = acc[t][n][r] * sc[r] + sh[r];
-      const f32x4 v = ly_act4(u, P.act);
-      float* o = P.out + gp * P.ldo + c;
-      if ((P.ldo & 3) == 0 && c + 3 < P.N) {
+      const f32x4 v = ly_act4(u, act);
+      float* o = P.out + orow[n] * P.ldo + c;
+      if (vec_ok && c + 3 < P.N) {
         ly_stg4(o, v);
       } else {
 #pragma unroll
@@ -127,24 +181,25 @@ __global__ __launch_bounds__(LY_THREADS) void ly_conv3x3_kernel(const LyConv3Par
   }
 }
 
-template <int NT, int MT, int WC>
+static int g_c3_dbg = 0;    // ablation aid: 1 skip weight loads, 2 skip LDS reads + MFMA, 4 skip prefetch, 8 skip commit
+extern "C" int ly_debug_set_conv3(int v) { g_c3_dbg = v; return 0; }
+
+template <int MT>
 static int launch_conv3(const LyConv3Params& P, hipStream_t st) {
-  constexpr int BP = 16 * NT * (4 / WC);
-  constexpr int BN = 16 * MT * WC;
-  long gx = (P.M + BP - 1) / BP;
-  int gy = (P.N + BN - 1) / BN;
-  long nb = gx * gy;
+  const int tiles_x = (P.W + P.TW - 1) / P.TW, tiles_y = (P.H + P.TH - 1) / P.TH;
+  const int gy = (P.N + 64 * MT - 1) / (64 * MT);
+  const long n_img = P.M / ((long)P.H * P.W);
+  long nb = n_img * tiles_x * tiles_y * gy;
   LY_CHECK(nb < (1L << 31), "conv3x3: grid too large");
-  size_t lds = 2 * (size_t)(BP + 2 * P.W + 2) * LY_RSH;
-  LY_CHECK(lds <= 160 * 1024, "conv3x3: halo tile needs %zu B of LDS (W=%d)", lds, P.W);
-  auto k = ly_conv3x3_kernel<NT, MT, WC>;
+  size_t lds = 2 * (size_t)(P.TH + 2) * (P.TW + 2) * LY_RSH;
+  auto k = ly_conv3x3_kernel<MT>;
   static bool configured = false;
   if (!configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
     LY_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     configured = true;
   }
-  hipLaunchKernelGGL(k, dim3((unsigned)nb), dim3(LY_THREADS), lds, st, P, gy, (int)nb);
+  hipLaunchKernelGGL(k, dim3((unsigned)nb), dim3(LY_THREADS), lds, st, P, gy, tiles_x, tiles_y, g_c3_dbg);
   LY_LAUNCH_CHECK();
   return 0;
 }
@@ -156,11 +211,10 @@ extern "C" int ly_conv3x3_fwd(const LyConv3Params* p, void* stream) {
   LY_CHECK(P.M > 0 && P.H > 0 && P.W > 0 && P.Cin > 0 && P.N > 0, "conv3x3: bad sizes");
   LY_CHECK((P.Cin & 3) == 0 && (P.ldx & 3) == 0, "conv3x3: Cin=%d / ldx=%d must be multiples of 4", P.Cin, P.ldx);
   LY_CHECK(P.M % ((long)P.H * P.W) == 0, "conv3x3: M is not a whole number of images");
-  LY_CHECK(P.M < (1L << 24), "conv3x3: M=%ld pixels exceeds the 2^24 limit of the fast index path", P.M);
+  LY_CHECK(P.TH >= 1 && P.TW >= 1 && P.TH * P.TW <= 16 * LY_C3_NT, "conv3x3: patch %dx%d exceeds %d pixels", P.TH, P.TW, 16 * LY_C3_NT);
+  LY_CHECK((P.TH + 2) * (P.TW + 2) * (LY_CC / 4) <= LY_C3_NV * LY_THREADS, "conv3x3: frame of patch %dx%d exceeds the staging capacity", P.TH, P.TW);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const bool big = P.M >= 128L * 384;
-  if (P.N > 128) return big ? launch_conv3<8, 4, 4>(P, st) : launch_conv3<4, 4, 4>(P, st);   // x 256 ch
-  if (P.N > 64) return big ? launch_conv3<8, 2, 4>(P, st) : launch_conv3<4, 2, 4>(P, st);    // x 128 ch
-  if (P.N > 32) return big ? launch_conv3<8, 1, 4>(P, st) : launch_conv3<4, 1, 4>(P, st);    // x 64 ch
-  return launch_conv3<2, 2, 1>(P, st);                                                        // 128 px x 32 ch
+  if (P.N > 128) return launch_conv3<4>(P, st);     // 4 waves x 64 ch
+  if (P.N > 64) return launch_conv3<2>(P, st);      // 4 waves x 32 ch
+  return launch_conv3<1>(P, st);                    // 4 waves x 16 ch
 }

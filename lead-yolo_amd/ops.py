@@ -39,15 +39,27 @@ def gemm_config(n_out):
     return (4, 2, 4) if n_out > 64 else (4, 1, 4) if n_out > 32 else (2, 2, 1)
 
 
-def conv3_config(n_out, m):
-    big = m >= 128 * 384
-    if n_out > 128:
-        return (8, 4, 4) if big else (4, 4, 4)
-    if n_out > 64:
-        return (8, 2, 4) if big else (4, 2, 4)
-    if n_out > 32:
-        return (8, 1, 4) if big else (4, 1, 4)
-    return (2, 2, 1)
+_CONV_TILE_CACHE = {}
+
+
+def pick_conv_tile(h, w, max_px=128, max_frame=192):
+    """TH x TW patch (<= 128 pixels, frame (TH+2)(TW+2) <= 192) covering an h x w map with the fewest
+    MFMA pixel tiles, ties broken by the smaller halo frame."""
+    key = (h, w)
+    if key not in _CONV_TILE_CACHE:
+        best = None
+        for tw in range(1, min(w, max_px) + 1):
+            for th in range(1, min(h, max_px // tw) + 1):
+                if (th + 2) * (tw + 2) > max_frame:
+                    continue
+                blocks = -(-h // th) * -(-w // tw)
+                work = blocks * (-(-(th * tw) // 16))               # MFMA pixel tiles issued
+                halo = blocks * (th + 2) * (tw + 2)                 # frame positions staged
+                score = (work * 16 + 0.35 * halo, blocks)
+                if best is None or score < best[0]:
+                    best = (score, th, tw)
+        _CONV_TILE_CACHE[key] = (best[1], best[2])
+    return _CONV_TILE_CACHE[key]
 
 
 def mlp_config(c, m, w):
@@ -105,9 +117,10 @@ def gemm(*, M, H, W, K, N, a0, lda0, k0, wp, out, ldo, a1=None, lda1=0, gather=G
 
 
 def conv3x3(*, M, H, W, Cin, N, x, ldx, wp, out, ldo, e_scale=None, e_shift=None, act=ACT_NONE):
-    P = capi.LyConv3Params(M, H, W, Cin, N, _p(x), ldx, _p(wp), _p(e_scale), _p(e_shift), act, _p(out), ldo)
-    nt, mt, wc = conv3_config(N, M)
-    with _Timed(f"ly_conv3x3_kernel<{nt}, {mt}, {wc}>", 2.0 * M * 9 * Cin * N, 4.0 * (M * (Cin + N) + 9 * Cin * N)):
+    th, tw = pick_conv_tile(H, W)
+    P = capi.LyConv3Params(M, H, W, Cin, N, th, tw, _p(x), ldx, _p(wp), _p(e_scale), _p(e_shift), act, _p(out), ldo)
+    mt = 4 if N > 128 else 2 if N > 64 else 1
+    with _Timed(f"ly_conv3x3_kernel<{mt}>", 2.0 * M * 9 * Cin * N, 4.0 * (M * (Cin + N) + 9 * Cin * N)):
         capi.check(capi.lib().ly_conv3x3_fwd(ctypes.byref(P), capi.stream_ptr()), "ly_conv3x3_fwd")
 
 
@@ -186,7 +199,7 @@ def rfcbam3(*, n, h, w, c, ho, wo, N, s, th, tw, x, ldx, wg, ca, rfa, wp, e_scal
 
 
 def sppf_pool_fits(h, w):
-    return 2 * h * w * 17 * 4 <= 160 * 1024
+    return 2 * h * w * 4 * 4 <= 160 * 1024
 
 
 def sppf_pool(x, ldx, n, h, w, c, k, out, ldo):

@@ -106,6 +106,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_conv3x3_kernel(const LyConv3Par
     wbase[t] = (long)(tt < T ? tt : T - 1) * S;
   }
   const uint4* wpk = reinterpret_cast<const uint4*>(P.wp);
+  ly_l2_warm(P.wp, (long)T * S * 2048, P.out);
 
   LyWFrag wcur[MT], wnxt[MT];
 #pragma unroll

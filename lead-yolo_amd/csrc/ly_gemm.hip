@@ -189,6 +189,7 @@ __global__ __launch_bounds__(LY_THREADS, LY_GEMM_MINW) void ly_gemm_kernel(const
   }
 
   if (slot >= gx) return;                                  // (host never launches such blocks)
+  ly_l2_warm(P.wp, (long)T * S * 2048, P.out);
   LyWFrag wcur[MT], wnxt[MT];
 #pragma unroll
   for (int t = 0; t < MT; ++t) wcur[t] = ly_wfrag(wpk, wbase[t], lane);

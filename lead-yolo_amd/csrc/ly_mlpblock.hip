@@ -64,6 +64,11 @@ __global__ __launch_bounds__(LY_THREADS) void ly_mlpblock_fwd_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lq = lane >> 4;
   const f32x4 zero = ly_zero4();
+  if (C >= 80) {     // large weight sets, few pixels: warm L2 with all three packed weight arrays
+    ly_l2_warm(w1, (long)HTP * S1 * 2048, y);
+    ly_l2_warm(w2, (long)C16 * S2 * 2048, y);
+    ly_l2_warm(wp, (long)PT * SP * 2048, y);
+  }
   long p0 = 0;                 // flattened: first pixel of the run
   long img0 = 0;               // T2D: pixel index of (n, 0, 0)
   int h0 = 0, w0 = 0;          // T2D: patch origin

@@ -58,6 +58,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam3_kernel(const LyRfcbam3P
     tile[t] = tt < T ? tt : T - 1;
   }
   const uint4* wpk = reinterpret_cast<const uint4*>(P.wp);
+  ly_l2_warm(P.wp, (long)T * S * 2048, P.out);
   for (int i = tid; i < 2 * 64 * LY_RSG / 16; i += LY_THREADS) reinterpret_cast<uint4*>(gs_hi)[i] = make_uint4(0u, 0u, 0u, 0u);
 
   for (int c0 = 0; c0 < P.C; c0 += LY_GCC) {

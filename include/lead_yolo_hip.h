@@ -113,10 +113,12 @@ int ly_coordatt_gate(const float* x, int ldx, int n_img, int H, int W, int C, co
 int ly_se_fwd(const float* x, int ldx, int n_img, int HW, int C, const float* wa, const float* wb, int R, float* part,
               int slices, float* ca, void* stream);
 /* mm[n, y, x, 0:2] = (max_c, mean_c) of relu(bn(generate(x))) on the k-times expanded grid.
- * k = 1: a1/b1 = folded per-channel scale/shift.  k = 3: wg[c][90] = 81 folded depthwise weights
- * W'[t][u] + 9 folded biases; TH x TW (<= 64) = output-pixel tile per block.                        */
+ * k = 1: a1/b1 = folded per-channel scale/shift.  k = 3: wg = pack.rfcbam_gen_weights(..., 32, False):
+ * [C32/32][4 waves][9 t][4 channel pairs][20]; TH x TW (<= 64) = output-pixel tile per block.       */
 int ly_rfcbam_stats(const float* x, int ldx, int n_img, int H, int W, int C, int k, int s, const float* wg,
                     const float* a1, const float* b1, int TH, int TW, float* mm, void* stream);
+/* ablation aid for profiling (bit 0: skip staging, 1: skip generate/reduce) */
+int ly_debug_set_stats3(int v);
 /* rfa[n, y, x] = sigmoid(conv3x3_pad1(mm; w[2][3][3]))   (get_weight, models/rfa.py:107)             */
 int ly_rfa_map(const float* mm, int n_img, int HK, int WK, const float* w, float* rfa, void* stream);
 
@@ -125,7 +127,7 @@ typedef struct LyRfcbam3Params {
   int Ho, Wo, N, s;            /* output size, output channels, stride                            */
   int TH, TW;                  /* output-pixel tile per block (TH*TW <= 64)                       */
   const float* x; int ldx;
-  const float* wg;             /* [C][90] folded generate weights/biases                          */
+  const float* wg;             /* pack.rfcbam_gen_weights(..., 16, True): [C/16][4][9 t][2][20]   */
   const float* ca;             /* [n_img, C]                                                      */
   const float* rfa;            /* [n_img, 3Ho, 3Wo]                                               */
   const void* wp;              /* frag_pack3(conv.0.weight as [N, C/16, 144 -> 160 zero padded])  */

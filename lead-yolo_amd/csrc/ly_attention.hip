@@ -192,19 +192,23 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_stats1_kernel(const floa
 
 // ---------------------------------------------------------------------------------------------------
 // RFCBAM statistics, k = 3 (stride s, pad 1).  lane = output pixel of a TH x TW tile, the 4 waves
-// split the channels; depthwise weights are wave-uniform (scalar loads).  wg[c][90] = 81 folded
-// weights W'[t][u] followed by 9 folded biases b'[t].
+// split the channels (channel c0 + wave + 4j of each 32-channel chunk); depthwise weights are wave-
+// uniform scalar loads from wq[C32/32][4 waves][9 t][8 j][10] = 9 folded weights W'[t][u] + folded
+// bias b'[t] per (t, channel), zero padded to a multiple of 32 channels (pack.rfcbam_stats_weights).
 // ---------------------------------------------------------------------------------------------------
 #define LY_SCC 32
+#define LY_ST3_NV 10              // float4 staging items per thread per chunk: IH*IW*8 <= 10*256
+#define LY_ST3_WF (9 * 4 * 20)    // floats of folded weights per wave per chunk: [9 t][4 channel pairs][9 x (w_a, w_b) + (b_a, b_b)]
 __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_stats3_kernel(const float* __restrict__ x, int ldx, int H, int W, int C,
                                                                        int Ho, int Wo, int s, int TH, int TW, int nct, int nrt,
-                                                                       const float* __restrict__ wg, float* __restrict__ mm) {
+                                                                       const float* __restrict__ wg, float* __restrict__ mm, const int dbg) {
   extern __shared__ float lds[];
   const int IH = s * (TH - 1) + 3, IW = s * (TW - 1) + 3;
-  float* xs = lds;                                   // [IH*IW][LY_SCC + 1]
-  float* red = lds + IH * IW * (LY_SCC + 1);         // [4][18][64]
+  float* wsm = lds;                                  // [4 waves][LY_ST3_WF]: this chunk's folded weights (16-B aligned)
+  float* xs = lds + 4 * LY_ST3_WF;                   // [IH*IW][LY_SCC + 1]
+  float* red = xs + IH * IW * (LY_SCC + 1);          // [4][18][64]
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform => scalar weight loads
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int b = blockIdx.x;
   const int ct = b % nct; b /= nct;
   const int rt = b % nrt;
@@ -215,42 +219,89 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_stats3_kernel(const floa
   const bool active = ly < TH && oy < Ho && ox < Wo;
   const int iy0 = s * oy0 - 1, ix0 = s * ox0 - 1;
 
+  // staging plan of this thread (independent of the channel chunk): global element offset (or -1) and LDS slot
+  const int items = IH * IW * (LY_SCC / 4);
+  long soff[LY_ST3_NV];
+  int doff[LY_ST3_NV];
+#pragma unroll
+  for (int e = 0; e < LY_ST3_NV; ++e) {
+    const int idx = tid + e * LY_THREADS;
+    long so = -1;
+    int dd = -1;
+    if (idx < items) {
+      const int ip = idx >> 3, c4 = idx & 7;
+      const int r = ip / IW, q = ip - r * IW;
+      const int iy = iy0 + r, ix = ix0 + q;
+      dd = ip * (LY_SCC + 1) + 4 * c4;
+      if (iy >= 0 && iy < H && ix >= 0 && ix < W) so = (((long)n * H + iy) * W + ix) * ldx + 4 * c4;
+    }
+    soff[e] = so; doff[e] = dd;
+  }
+  // x addresses of the 9 taps of this lane's pixel (LDS float index, channel 0)
+  int xa[9];
+#pragma unroll
+  for (int u = 0; u < 9; ++u) xa[u] = ((s * ly + u / 3) * IW + (s * lx + u % 3)) * (LY_SCC + 1);
+
   float mx[9], sm[9];
 #pragma unroll
-  for (int t = 0; t < 9; ++t) { mx[t] = -FLT_MAX; sm[t] = 0.f; }
+  for (int t = 0; t < 9; ++t) { mx[t] = 0.f; sm[t] = 0.f; }      // G = relu(.) >= 0, so 0 is the identity of the channel max
 
   for (int c0 = 0; c0 < C; c0 += LY_SCC) {
     __syncthreads();
-    ly_stage_f4<8>(IH * IW * (LY_SCC / 4), tid, x,
-        [&](int idx) -> const float* {
-          const int ip = idx / (LY_SCC / 4), c4 = idx - ip * (LY_SCC / 4);
-          const int iy = iy0 + ip / IW, ix = ix0 + ip % IW;
-          const int c = c0 + 4 * c4;
-          return (iy >= 0 && iy < H && ix >= 0 && ix < W && c < C) ? x + (((long)n * H + iy) * W + ix) * ldx + c : nullptr;
-        },
-        [&](int idx, f32x4 v) {
-          const int ip = idx / (LY_SCC / 4), c4 = idx - ip * (LY_SCC / 4);
-          float* d = xs + ip * (LY_SCC + 1) + 4 * c4;
-          d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
-        });
-    __syncthreads();
-    if (active) {
-      const int cend = (C - c0) < LY_SCC ? (C - c0) : LY_SCC;
-      for (int cl = wave; cl < cend; cl += 4) {
-        float xv[9];
+    {
+      const float* wsrc = wg + (long)(c0 / LY_SCC) * (4 * LY_ST3_WF);
+      for (int i = tid; i < 4 * LY_ST3_WF / 4; i += LY_THREADS) reinterpret_cast<f32x4*>(wsm)[i] = ly_ldg4(wsrc + 4 * i);
+    }
+    if (!(dbg & 1)) {
+      f32x4 v[LY_ST3_NV];
 #pragma unroll
-        for (int u = 0; u < 9; ++u) xv[u] = xs[((s * ly + u / 3) * IW + (s * lx + u % 3)) * (LY_SCC + 1) + cl];
-        const ly_cfloat* wc = ly_const(wg + (long)(c0 + cl) * 90);
+      for (int e = 0; e < LY_ST3_NV; ++e) {
+        const bool ok = soff[e] >= 0 && c0 + 4 * ((tid + e * LY_THREADS) & 7) < C;
+        v[e] = ly_ldg4(ok ? x + soff[e] + c0 : x);
+      }
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-          float a = wc[81 + t];
-#pragma unroll
-          for (int u = 0; u < 9; ++u) a += xv[u] * wc[t * 9 + u];
-          a = fmaxf(a, 0.f);
-          mx[t] = fmaxf(mx[t], a);
-          sm[t] += a;
+      for (int e = 0; e < LY_ST3_NV; ++e) {
+        if (doff[e] >= 0) {
+          const bool ok = soff[e] >= 0 && c0 + 4 * ((tid + e * LY_THREADS) & 7) < C;
+          float* d = xs + doff[e];
+          d[0] = ok ? v[e][0] : 0.f; d[1] = ok ? v[e][1] : 0.f; d[2] = ok ? v[e][2] : 0.f; d[3] = ok ? v[e][3] : 0.f;
         }
       }
+    }
+    __syncthreads();
+    if (!(dbg & 2)) {
+      // inputs of this wave's 8 channels (c0 + wave + 4j) as 4 packed pairs (j = 2p, 2p+1), then the folded
+      // weights [t][p][9 x (w_a, w_b), (b_a, b_b)] read as wave-uniform LDS broadcasts: v_pk_fma_f32 does two
+      // channels per instruction.
+      f32x2 xv[4][9];
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int u = 0; u < 9; ++u) {
+          const float a = xs[xa[u] + wave + 8 * p], c = xs[xa[u] + wave + 8 * p + 4];
+          xv[p][u] = active ? (f32x2){a, c} : (f32x2){0.f, 0.f};
+        }
+      const f32x4* wq = reinterpret_cast<const f32x4*>(wsm + wave * LY_ST3_WF);
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const f32x4* q = wq + (t * 4 + p) * 5;
+          const f32x4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4];
+          f32x2 a = {q4[2], q4[3]};
+          a += xv[p][0] * (f32x2){q0[0], q0[1]};
+          a += xv[p][1] * (f32x2){q0[2], q0[3]};
+          a += xv[p][2] * (f32x2){q1[0], q1[1]};
+          a += xv[p][3] * (f32x2){q1[2], q1[3]};
+          a += xv[p][4] * (f32x2){q2[0], q2[1]};
+          a += xv[p][5] * (f32x2){q2[2], q2[3]};
+          a += xv[p][6] * (f32x2){q3[0], q3[1]};
+          a += xv[p][7] * (f32x2){q3[2], q3[3]};
+          a += xv[p][8] * (f32x2){q4[0], q4[1]};
+          const float g0 = fmaxf(a[0], 0.f), g1 = fmaxf(a[1], 0.f);
+          mx[t] = fmaxf(mx[t], fmaxf(g0, g1));
+          sm[t] += g0 + g1;
+        }
     }
   }
   __syncthreads();
@@ -277,6 +328,9 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_stats3_kernel(const floa
   }
 }
 
+static int g_st3_dbg = 0;   // ablation aid: 1 skip staging, 2 skip generate/reduce
+extern "C" int ly_debug_set_stats3(int v) { g_st3_dbg = v; return 0; }
+
 extern "C" int ly_rfcbam_stats(const float* x, int ldx, int n_img, int H, int W, int C, int k, int s, const float* wg,
                                const float* a1, const float* b1, int TH, int TW, float* mm, void* stream) {
   LY_CHECK(x && mm && (C & 3) == 0 && (ldx & 3) == 0, "rfcbam_stats: bad arguments");
@@ -295,7 +349,8 @@ extern "C" int ly_rfcbam_stats(const float* x, int ldx, int n_img, int H, int W,
   const int Ho = (H + 2 - 3) / s + 1, Wo = (W + 2 - 3) / s + 1;
   const int nct = (Wo + TW - 1) / TW, nrt = (Ho + TH - 1) / TH;
   const int IH = s * (TH - 1) + 3, IW = s * (TW - 1) + 3;
-  size_t lds = sizeof(float) * ((size_t)IH * IW * (LY_SCC + 1) + 4 * 18 * 64);
+  size_t lds = sizeof(float) * ((size_t)4 * LY_ST3_WF + (size_t)IH * IW * (LY_SCC + 1) + 4 * 18 * 64);
+  LY_CHECK(IH * IW * (LY_SCC / 4) <= LY_ST3_NV * LY_THREADS, "rfcbam_stats: input tile %dx%d exceeds the staging capacity", IH, IW);
   LY_CHECK(lds <= 160 * 1024, "rfcbam_stats: tile needs %zu B LDS", lds);
   static bool configured = false;
   if (!configured) {
@@ -304,7 +359,7 @@ extern "C" int ly_rfcbam_stats(const float* x, int ldx, int n_img, int H, int W,
     configured = true;
   }
   hipLaunchKernelGGL(ly_rfcbam_stats3_kernel, dim3(n_img * nrt * nct), dim3(LY_THREADS), lds, st, x, ldx, H, W, C, Ho, Wo, s, TH, TW,
-                     nct, nrt, wg, mm);
+                     nct, nrt, wg, mm, g_st3_dbg);
   LY_LAUNCH_CHECK();
   return 0;
 }

@@ -15,6 +15,7 @@
 #define LY_GCC 16                       // channels regenerated per chunk
 #define LY_GK 160                        // 9*16 = 144 k-values per chunk, zero padded to 5 k-steps of 32
 #define LY_RSG (2 * LY_GK + 16)          // bytes per operand row, per plane
+#define LY_RF3_WF (9 * 2 * 20)           // floats of folded generate weights per wave per chunk: [9 t][2 pairs][9 x (w_a, w_b) + (b_a, b_b)]
 
 template <int MT>
 __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam3_kernel(const LyRfcbam3Params P, const int gy, const int nct, const int nrt, const int dbg) {
@@ -23,7 +24,8 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam3_kernel(const LyRfcbam3P
   const int IH = s * (TH - 1) + 3, IW = s * (TW - 1) + 3;
   char* gs_hi = reinterpret_cast<char*>(ly_smem4);          // [64][LY_RSG]
   char* gs_lo = gs_hi + 64 * LY_RSG;
-  float* xs = reinterpret_cast<float*>(gs_lo + 64 * LY_RSG);   // [IH*IW][LY_GCC + 1]
+  float* wsm = reinterpret_cast<float*>(gs_lo + 64 * LY_RSG);  // [4 waves][LY_RF3_WF]: this chunk's folded generate weights
+  float* xs = wsm + 4 * LY_RF3_WF;                             // [IH*IW][LY_GCC + 1]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: depthwise weights become scalar loads
   const int li = lane & 15, lq = lane >> 4;
@@ -63,6 +65,10 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam3_kernel(const LyRfcbam3P
 
   for (int c0 = 0; c0 < P.C; c0 += LY_GCC) {
     __syncthreads();
+    {
+      const float* wsrc = P.wg + (long)(c0 / LY_GCC) * (4 * LY_RF3_WF);
+      for (int i = tid; i < 4 * LY_RF3_WF / 4; i += LY_THREADS) reinterpret_cast<f32x4*>(wsm)[i] = ly_ldg4(wsrc + 4 * i);
+    }
     if (!(dbg & 4)) ly_stage_f4<4>(IH * IW * (LY_GCC / 4), tid, P.x,
         [&](int idx) -> const float* {
           const int ip = idx / (LY_GCC / 4), c4 = idx - ip * (LY_GCC / 4);
@@ -76,25 +82,48 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam3_kernel(const LyRfcbam3P
         });
     __syncthreads();
     // ---- regenerate G' for channels c0 + 4*wave .. +3 -----------------------------------------------
-#pragma unroll 1
-    for (int cj = 0; cj < ((dbg & 1) ? 0 : 4); ++cj) {
-      const int cl = 4 * wave + cj;
-      const ly_cfloat* wc = ly_const(P.wg + (long)(c0 + cl) * 90);
-      const float cav = ly_const(P.ca)[(long)n * P.C + c0 + cl];
-      float xv[9];
+    // inputs of the wave's 4 channels as 2 packed pairs, folded weights [t][pair][20] read as wave-uniform
+    // LDS broadcasts (pack.rfcbam_gen_weights(..., 16, True)); v_pk_fma_f32 does two channels per instruction
+    if (!(dbg & 1)) {
+      f32x2 xv[2][9];
+      f32x2 cav[2];
 #pragma unroll
-      for (int u = 0; u < 9; ++u) xv[u] = active ? xs[((s * ly + u / 3) * IW + (s * lx + u % 3)) * (LY_GCC + 1) + cl] : 0.f;
+      for (int p = 0; p < 2; ++p) {
+        cav[p] = (f32x2){ly_const(P.ca)[(long)n * P.C + c0 + 4 * wave + 2 * p], ly_const(P.ca)[(long)n * P.C + c0 + 4 * wave + 2 * p + 1]};
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        float a = wc[81 + t];
-#pragma unroll
-        for (int u = 0; u < 9; ++u) a += xv[u] * wc[t * 9 + u];
-        const float gv = active ? fmaxf(a, 0.f) * cav * rf[t] : 0.f;
-        const __bf16 gh = (__bf16)gv;
-        const __bf16 gl = (__bf16)(gv - (float)gh);
-        *reinterpret_cast<__bf16*>(gs_hi + lane * LY_RSG + 2 * (cl * 9 + t)) = gh;
-        *reinterpret_cast<__bf16*>(gs_lo + lane * LY_RSG + 2 * (cl * 9 + t)) = gl;
+        for (int u = 0; u < 9; ++u) {
+          const int xo = ((s * ly + u / 3) * IW + (s * lx + u % 3)) * (LY_GCC + 1) + 4 * wave + 2 * p;
+          xv[p][u] = active ? (f32x2){xs[xo], xs[xo + 1]} : (f32x2){0.f, 0.f};
+        }
       }
+      const f32x4* wq = reinterpret_cast<const f32x4*>(wsm + wave * LY_RF3_WF);   // wave-uniform => LDS broadcast reads
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const f32x4* q = wq + (t * 2 + p) * 5;
+          const f32x4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4];
+          f32x2 a = {q4[2], q4[3]};
+          a += xv[p][0] * (f32x2){q0[0], q0[1]};
+          a += xv[p][1] * (f32x2){q0[2], q0[3]};
+          a += xv[p][2] * (f32x2){q1[0], q1[1]};
+          a += xv[p][3] * (f32x2){q1[2], q1[3]};
+          a += xv[p][4] * (f32x2){q2[0], q2[1]};
+          a += xv[p][5] * (f32x2){q2[2], q2[3]};
+          a += xv[p][6] * (f32x2){q3[0], q3[1]};
+          a += xv[p][7] * (f32x2){q3[2], q3[3]};
+          a += xv[p][8] * (f32x2){q4[0], q4[1]};
+          const float rft = active ? rf[t] : 0.f;
+          const f32x2 gv = (f32x2){fmaxf(a[0], 0.f), fmaxf(a[1], 0.f)} * cav[p] * rft;
+          const bf16x2 gh = __builtin_convertvector(gv, bf16x2);
+          const bf16x2 gl = __builtin_convertvector(gv - __builtin_convertvector(gh, f32x2), bf16x2);
+          // k index of channel (4*wave + 2p + ab), tap t inside the chunk: (4*wave + 2p + ab)*9 + t
+          const int k0 = (4 * wave + 2 * p) * 9 + t;
+          *reinterpret_cast<__bf16*>(gs_hi + lane * LY_RSG + 2 * k0) = gh[0];
+          *reinterpret_cast<__bf16*>(gs_lo + lane * LY_RSG + 2 * k0) = gl[0];
+          *reinterpret_cast<__bf16*>(gs_hi + lane * LY_RSG + 2 * (k0 + 9)) = gh[1];
+          *reinterpret_cast<__bf16*>(gs_lo + lane * LY_RSG + 2 * (k0 + 9)) = gl[1];
+        }
     }
     __syncthreads();
     // ---- contract the chunk's 160 (144 real) k-values --------------------------------------------
@@ -157,7 +186,7 @@ static int launch_rf3(const LyRfcbam3Params& P, hipStream_t st) {
   const int nct = (P.Wo + P.TW - 1) / P.TW, nrt = (P.Ho + P.TH - 1) / P.TH;
   const int gy = (P.N + 64 * MT - 1) / (64 * MT);
   const int IH = P.s * (P.TH - 1) + 3, IW = P.s * (P.TW - 1) + 3;
-  size_t lds = 2 * (size_t)64 * LY_RSG + sizeof(float) * (size_t)IH * IW * (LY_GCC + 1);
+  size_t lds = 2 * (size_t)64 * LY_RSG + sizeof(float) * ((size_t)4 * LY_RF3_WF + (size_t)IH * IW * (LY_GCC + 1));
   LY_CHECK(lds <= 160 * 1024, "rfcbam3: tile needs %zu B LDS", lds);
   auto k = ly_rfcbam3_kernel<MT>;
   static bool configured = false;

@@ -397,11 +397,11 @@ class RFCBAMConv(nn.Module):
             if k == 1:
                 a1 = (gw.detach().float().view(c) * gs).contiguous()
                 return dict(a1=a1, b1=gb, w18=w18, wp=pack.frag_pack3(cw.weight.detach().view(o, c)), es=es, eb=eb)
-            wgm = gw.detach().float().view(c, 9, 9) * gs.view(c, 9, 1)        # [c][t][u]
-            wg = torch.cat((wgm.reshape(c, 81), gb.view(c, 9)), 1).contiguous()
+            wq_stats = pack.rfcbam_gen_weights(gw, gs, gb, 32, False)           # stats kernel: 32-ch chunks, c0 + w + 4j
+            wq_main = pack.rfcbam_gen_weights(gw, gs, gb, 16, True)             # main kernel: 16-ch chunks, c0 + 4w + j
             wk = torch.zeros(o, c // 16, 160, dtype=torch.float32, device=gw.device)      # 144 real k per 16-channel chunk
             wk[:, :, :144] = cw.weight.detach().float().reshape(o, c // 16, 144)
-            return dict(wg=wg, w18=w18, wp=pack.frag_pack3(wk.view(o, -1)), es=es, eb=eb)
+            return dict(wq_stats=wq_stats, wq_main=wq_main, w18=w18, wp=pack.frag_pack3(wk.view(o, -1)), es=es, eb=eb)
         return self._prep.get(key, build)
 
     def forward(self, x):
@@ -428,10 +428,10 @@ class RFCBAMConv(nn.Module):
             return out
         ho, wo = (h + 2 - 3) // s + 1, (w + 2 - 3) // s + 1
         th, tw = ops.pick_tile(ho, wo)
-        mm = ops.rfcbam_stats(xr, ld, n, h, w, c, 3, s, wg=P["wg"], th=th, tw=tw)
+        mm = ops.rfcbam_stats(xr, ld, n, h, w, c, 3, s, wg=P["wq_stats"], th=th, tw=tw)
         rfa = ops.rfa_map(mm, P["w18"])
         out = ops.empty_nhwc(n, self.o, ho, wo, xr)
-        ops.rfcbam3(n=n, h=h, w=w, c=c, ho=ho, wo=wo, N=self.o, s=s, th=th, tw=tw, x=xr, ldx=ld, wg=P["wg"], ca=ca, rfa=rfa,
+        ops.rfcbam3(n=n, h=h, w=w, c=c, ho=ho, wo=wo, N=self.o, s=s, th=th, tw=tw, x=xr, ldx=ld, wg=P["wq_main"], ca=ca, rfa=rfa,
                     wp=P["wp"], e_scale=P["es"], e_shift=P["eb"], out=out, ldo=self.o)
         return out
 

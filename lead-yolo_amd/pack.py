@@ -61,3 +61,27 @@ def pad_to(v, n):
     out = torch.zeros(n, dtype=torch.float32, device=v.device)
     out[:v.numel()] = v
     return out
+
+
+def rfcbam_gen_weights(gen_w, scale, shift, chunk, per_wave_contiguous):
+    """Folded depthwise 'generate' weights of RFCBAMConv (k=3) in the order the kernels read them from
+    LDS: [C_pad/chunk][4 waves][9 taps t][chunk/8 channel pairs][20] where the 20 floats are the 9
+    interleaved pairs (W'_a[t][u], W'_b[t][u]) followed by (b'_a[t], b'_b[t]) — five aligned float4 that
+    feed v_pk_fma_f32 (two channels per instruction).
+    gen_w: generate.0.weight [C*9, 1, 3, 3]; scale/shift: folded generate.1 BN, [C*9].
+    Channel of (chunk q, wave w, slot j): q*chunk + (4*w + j if per_wave_contiguous else w + 4*j); pair p =
+    slots (2p, 2p+1).  Channels are zero padded to a multiple of `chunk` (zero weights => G = 0, neutral
+    for the max/mean of ReLU outputs)."""
+    c = gen_w.shape[0] // 9
+    wt = torch.cat(((gen_w.detach().float().view(c, 9, 9) * scale.view(c, 9, 1)), shift.view(c, 9, 1)), 2)   # [c][t][10]
+    cp = _ceil(c, chunk) * chunk
+    full = torch.zeros(cp, 9, 10, dtype=torch.float32, device=gen_w.device)
+    full[:c] = wt
+    per = chunk // 4
+    if per_wave_contiguous:
+        v = full.view(cp // chunk, 4, per, 9, 10)                          # [q][w][j][t][10]
+    else:
+        v = full.view(cp // chunk, per, 4, 9, 10).permute(0, 2, 1, 3, 4)   # [q][j][w] -> [q][w][j]
+    v = v.reshape(cp // chunk, 4, per // 2, 2, 9, 10)                      # [q][w][p][ab][t][10]
+    v = v.permute(0, 1, 4, 2, 5, 3).contiguous()                           # [q][w][t][p][10][ab]
+    return v.view(-1)

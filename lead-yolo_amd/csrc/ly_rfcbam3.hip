@@ -15,6 +15,7 @@
 #define LY_GCC 16                       // channels regenerated per chunk
 #define LY_GK 160                        // 9*16 = 144 k-values per chunk, zero padded to 5 k-steps of 32
 #define LY_RSG (2 * LY_GK + 16)          // bytes per operand row, per plane
+#define LY_RF3_NV 8                      // float4 staging items per thread per chunk: IH*IW*4 <= 8*256
 #define LY_RF3_WF (9 * 2 * 20)           // floats of folded generate weights per wave per chunk: [9 t][2 pairs][9 x (w_a, w_b) + (b_a, b_b)]
 
 template <int MT>
@@ -63,23 +64,47 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam3_kernel(const LyRfcbam3P
   ly_l2_warm(P.wp, (long)T * S * 2048, P.out);
   for (int i = tid; i < 2 * 64 * LY_RSG / 16; i += LY_THREADS) reinterpret_cast<uint4*>(gs_hi)[i] = make_uint4(0u, 0u, 0u, 0u);
 
+  // staging plan of this thread (independent of the channel chunk): global element offset (or -1), LDS slot
+  const int items = IH * IW * (LY_GCC / 4);
+  long soff[LY_RF3_NV];
+  int doff[LY_RF3_NV];
+#pragma unroll
+  for (int e = 0; e < LY_RF3_NV; ++e) {
+    const int idx = tid + e * LY_THREADS;
+    long so = -1;
+    int dd = -1;
+    if (idx < items) {
+      const int ip = idx >> 2, c4 = idx & 3;
+      const int r = ip / IW, q = ip - r * IW;
+      const int iy = iy0 + r, ix = ix0 + q;
+      dd = ip * (LY_GCC + 1) + 4 * c4;
+      if (iy >= 0 && iy < P.H && ix >= 0 && ix < P.W) so = (((long)n * P.H + iy) * P.W + ix) * P.ldx + 4 * c4;
+    }
+    soff[e] = so; doff[e] = dd;
+  }
+  f32x4 pv[LY_RF3_NV];
+  auto prefetch = [&](int c0) {
+#pragma unroll
+    for (int e = 0; e < LY_RF3_NV; ++e) pv[e] = ly_ldg4(soff[e] >= 0 ? P.x + soff[e] + c0 : P.x);
+  };
+  if (!(dbg & 4)) prefetch(0);
+
   for (int c0 = 0; c0 < P.C; c0 += LY_GCC) {
-    __syncthreads();
+    __syncthreads();                      // previous chunk: generate done with xs/wsm, MFMAs done with gs
     {
       const float* wsrc = P.wg + (long)(c0 / LY_GCC) * (4 * LY_RF3_WF);
       for (int i = tid; i < 4 * LY_RF3_WF / 4; i += LY_THREADS) reinterpret_cast<f32x4*>(wsm)[i] = ly_ldg4(wsrc + 4 * i);
     }
-    if (!(dbg & 4)) ly_stage_f4<4>(IH * IW * (LY_GCC / 4), tid, P.x,
-        [&](int idx) -> const float* {
-          const int ip = idx / (LY_GCC / 4), c4 = idx - ip * (LY_GCC / 4);
-          const int iy = iy0 + ip / IW, ix = ix0 + ip % IW;
-          return (iy >= 0 && iy < P.H && ix >= 0 && ix < P.W) ? P.x + (((long)n * P.H + iy) * P.W + ix) * P.ldx + c0 + 4 * c4 : nullptr;
-        },
-        [&](int idx, f32x4 v) {
-          const int ip = idx / (LY_GCC / 4), c4 = idx - ip * (LY_GCC / 4);
-          float* d = xs + ip * (LY_GCC + 1) + 4 * c4;
-          d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
-        });
+    if (!(dbg & 4)) {
+#pragma unroll
+      for (int e = 0; e < LY_RF3_NV; ++e)
+        if (doff[e] >= 0) {
+          const bool ok = soff[e] >= 0;
+          float* d = xs + doff[e];
+          d[0] = ok ? pv[e][0] : 0.f; d[1] = ok ? pv[e][1] : 0.f; d[2] = ok ? pv[e][2] : 0.f; d[3] = ok ? pv[e][3] : 0.f;
+        }
+      if (c0 + LY_GCC < P.C) prefetch(c0 + LY_GCC);   // next chunk's input in flight during generate + MFMA
+    }
     __syncthreads();
     // ---- regenerate G' for channels c0 + 4*wave .. +3 -----------------------------------------------
     // inputs of the wave's 4 channels as 2 packed pairs, folded weights [t][pair][20] read as wave-uniform
@@ -188,6 +213,7 @@ static int launch_rf3(const LyRfcbam3Params& P, hipStream_t st) {
   const int IH = P.s * (P.TH - 1) + 3, IW = P.s * (P.TW - 1) + 3;
   size_t lds = 2 * (size_t)64 * LY_RSG + sizeof(float) * ((size_t)4 * LY_RF3_WF + (size_t)IH * IW * (LY_GCC + 1));
   LY_CHECK(lds <= 160 * 1024, "rfcbam3: tile needs %zu B LDS", lds);
+  LY_CHECK(IH * IW * (LY_GCC / 4) <= LY_RF3_NV * LY_THREADS, "rfcbam3: input tile %dx%d exceeds the staging capacity", IH, IW);
   auto k = ly_rfcbam3_kernel<MT>;
   static bool configured = false;
   if (!configured) {

@@ -87,6 +87,7 @@ __global__ __launch_bounds__(LY_THREADS, LY_GEMM_MINW) void ly_gemm_kernel(const
   };
 
   f32x4 pv[NV];
+  f32x4 pgw[PRO == LY_PRO_GATE ? NV : 1], pgh[PRO == LY_PRO_GATE ? NV : 1];
   auto prefetch = [&](long p0, int kc) {
     // branch-free: every lane issues its NV loads back to back (clamped address), zeros are selected afterwards
     const int kk = kc + 4 * k4;
@@ -116,6 +117,17 @@ __global__ __launch_bounds__(LY_THREADS, LY_GEMM_MINW) void ly_gemm_kernel(const
     }
     // NOTE: out-of-range lanes are zeroed in commit(), NOT here: touching pv[] now would force an
     // s_waitcnt on the loads just issued and serialise them with the MFMAs they are meant to overlap.
+    if (PRO == LY_PRO_GATE) {          // CoordAtt factors of the same items travel with them (L2-resident tables)
+      const bool gk = kk < P.k0;
+#pragma unroll
+      for (int e = 0; e < NV; ++e) {
+        const bool ok = gk && t_n[e] >= 0;
+        const int n = ok ? t_n[e] : 0, h = ok ? (t_hw[e] >> 16) : 0, w = ok ? (t_hw[e] & 0xffff) : 0;
+        const int kq = ok ? kk : 0;
+        pgw[e] = ly_ldg4(P.g_w + ((long)n * P.W + w) * P.k0 + kq);
+        pgh[e] = ly_ldg4(P.g_h + ((long)n * P.H + h) * P.k0 + kq);
+      }
+    }
   };
   auto commit = [&](long p0, int kc, int buf) {
     char* hi = xs + buf * 2 * PLANE;
@@ -126,19 +138,15 @@ __global__ __launch_bounds__(LY_THREADS, LY_GEMM_MINW) void ly_gemm_kernel(const
       if (!(kk < P.K && t_n[e] >= 0)) pv[e] = zero;
     if (PRO == LY_PRO_GATE) {
       const bool kok = kk < P.k0;
-      f32x4 gw[NV], gh[NV], rr[NV];
+      f32x4 rr[NV];
 #pragma unroll
       for (int e = 0; e < NV; ++e) {
         const bool ok = kok && t_n[e] >= 0;
-        const int n = ok ? t_n[e] : 0, h = ok ? (t_hw[e] >> 16) : 0, w = ok ? (t_hw[e] & 0xffff) : 0;
-        const int kq = ok ? kk : 0;
-        gw[e] = ly_ldg4(P.g_w + ((long)n * P.W + w) * P.k0 + kq);
-        gh[e] = ly_ldg4(P.g_h + ((long)n * P.H + h) * P.k0 + kq);
-        rr[e] = (P.res && ok) ? ly_ldg4(P.res + (p0 + prow + 16 * e) * P.ldres + kq) : zero;
+        rr[e] = (P.res && ok) ? ly_ldg4(P.res + (p0 + prow + 16 * e) * P.ldres + kk) : zero;
       }
 #pragma unroll
       for (int e = 0; e < NV; ++e)
-        if (kok && t_n[e] >= 0) pv[e] = pv[e] * gw[e] * gh[e] + rr[e];
+        if (kok && t_n[e] >= 0) pv[e] = pv[e] * pgw[e] * pgh[e] + rr[e];
     } else if (PRO == LY_PRO_AFFINE_RELU_CA) {
       const bool kok = kk < P.K;
       const int kq = kok ? kk : 0;

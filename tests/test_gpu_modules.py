@@ -186,3 +186,22 @@ def test_whole_model_640_vs_oracle():
     _cmp(z, zo, "model_s 640 z")
     for i, (a, b) in enumerate(zip(outs, outs_o)):
         _cmp(a, b, f"model_s 640 p{i}")
+
+
+@pytest.mark.parametrize("scale,hw,bs", [("l", (64, 96), 2), ("n", (96, 64), 3), ("s", (1280, 1280), 1), ("l", (320, 320), 1)])
+def test_other_scales_and_sizes_vs_oracle(scale, hw, bs):
+    """lead-yolo-l (C up to 320 / 1024 channels, n=3 bottlenecks), lead-yolo-n, and the 1280x1280 input of
+    BASELINE config 5, against the live oracle"""
+    import lead_yolo_amd as L
+    torch.manual_seed(0)
+    m = L.Model(_cfg(scale))
+    st = synth.synth_state(synth.shapes_of(m.state_dict()), 6000 + hw[0])
+    st["model.23.anchors"] = m.model[-1].anchors.clone()
+    m.load_state_dict(st)
+    x = synth.synth_images(bs, max(hw), 11)[:, :, :hw[0], :hw[1]].float() / 255
+    with torch.no_grad():
+        zo, outs_o = OF.model_forward(copy.deepcopy(st), _cfg(scale), x, m.stride, training=False)
+        z, outs = m.to(_dev()).eval()(x.to(_dev()))
+    _cmp(z, zo, f"model_{scale} {hw} z")
+    for i, (a, b) in enumerate(zip(outs, outs_o)):
+        _cmp(a, b, f"model_{scale} {hw} p{i}")

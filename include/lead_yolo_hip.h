@@ -91,6 +91,8 @@ typedef struct LyConv3Params {
 int ly_conv3x3_fwd(const LyConv3Params* p, void* stream);
 /* ablation aid for profiling (bit 0: skip weight loads, 1: skip LDS reads + MFMA, 2: skip prefetch, 3: skip commit) */
 int ly_debug_set_conv3(int v);
+/* tuning aid: force the wave layout (MT*10 + WC), 0 = heuristic */
+int ly_debug_set_conv3_cfg(int v);
 
 
 /* ---- CoordAtt (models/common.py:1583-1609) ------------------------------------------------------- */

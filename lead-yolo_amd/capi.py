@@ -52,6 +52,7 @@ SIGNATURES = {
     "ly_debug_set_gemm": [_I],
     "ly_debug_set_rf3": [_I],
     "ly_debug_set_conv3": [_I],
+    "ly_debug_set_conv3_cfg": [_I],
     "ly_debug_set_stats3": [_I],
     "ly_debug_set_mlp": [_I],
     "ly_debug_set_mlp_tile": [_I],

@@ -22,7 +22,7 @@
 #define LY_C3_NT 8                // max pixel tiles (128 pixels) per block
 #define LY_C3_NV 6                // float4 per thread per chunk: (TH+2)(TW+2)*8 <= 6*256  =>  frame <= 192 positions
 
-template <int MT>
+template <int MT, int WC>
 __global__ __launch_bounds__(LY_THREADS) void ly_conv3x3_kernel(const LyConv3Params P, const int gy, const int tiles_x, const int tiles_y, const int dbg) {
   extern __shared__ f32x4 ly_smem4[];
   const int TH = P.TH, TW = P.TW, FW = TW + 2;
@@ -33,6 +33,9 @@ __global__ __launch_bounds__(LY_THREADS) void ly_conv3x3_kernel(const LyConv3Par
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lq = lane >> 4;
+  constexpr int WP = 4 / WC;                 // waves along pixels
+  constexpr int NTW = LY_C3_NT / WP;         // pixel tiles per wave
+  const int wc = wave % WC, wp = wave / WC;
   int b = blockIdx.x;
   const int by = b % gy; b /= gy;
   const int tx = b % tiles_x; b /= tiles_x;
@@ -48,11 +51,11 @@ __global__ __launch_bounds__(LY_THREADS) void ly_conv3x3_kernel(const LyConv3Par
   const long img0 = (long)n_img * P.H * P.W;
 
   // per-lane pixel -> byte offset of its (0,0) tap in the frame, and its output row (or -1)
-  int hb[LY_C3_NT];
-  long orow[LY_C3_NT];
+  int hb[NTW];
+  long orow[NTW];
 #pragma unroll
-  for (int n = 0; n < LY_C3_NT; ++n) {
-    const int p = 16 * n + li;
+  for (int n = 0; n < NTW; ++n) {
+    const int p = 16 * (wp * NTW + n) + li;
     const int pp = p < npx ? p : 0;
     const int r = pp / TW, c = pp - r * TW;
     hb[n] = (r * FW + c) * LY_RSH;
@@ -94,15 +97,15 @@ __global__ __launch_bounds__(LY_THREADS) void ly_conv3x3_kernel(const LyConv3Par
     }
   };
 
-  f32x4 acc[MT][LY_C3_NT];
+  f32x4 acc[MT][NTW];
 #pragma unroll
   for (int t = 0; t < MT; ++t)
 #pragma unroll
-    for (int n = 0; n < LY_C3_NT; ++n) acc[t][n] = zero;
+    for (int n = 0; n < NTW; ++n) acc[t][n] = zero;
   long wbase[MT];
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
-    const int tt = (by * 4 + wave) * MT + t;
+    const int tt = (by * WC + wc) * MT + t;
     wbase[t] = (long)(tt < T ? tt : T - 1) * S;
   }
   const uint4* wpk = reinterpret_cast<const uint4*>(P.wp);
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_conv3x3_kernel(const LyConv3Par
   for (int cc = 0; cc < C32; ++cc) {
     const bool more = cc + 1 < C32;
     if (more && !(dbg & 4)) prefetch((cc + 1) * LY_CC);
-#pragma unroll(MT == 1 ? 1 : 9)
+#pragma unroll(MT * NTW <= 8 ? 1 : 9)
     for (int tap = 0; tap < 9; ++tap) {
       // next fragment: next tap of this chunk, or tap 0 of the next chunk (clamped at the very end)
       if (!(dbg & 1)) {
@@ -130,8 +133,8 @@ __global__ __launch_bounds__(LY_THREADS) void ly_conv3x3_kernel(const LyConv3Par
       }
       const int toff = ((tap / 3) * FW + (tap % 3)) * LY_RSH;
 #pragma unroll
-      for (int n = 0; n < LY_C3_NT; ++n) {
-        if (n < ntv && !(dbg & 2)) {
+      for (int n = 0; n < NTW; ++n) {
+        if (wp * NTW + n < ntv && !(dbg & 2)) {
           const bf16x8 xh = ly_lds_frag(hs_hi, hb[n] + toff, 0, lq);
           const bf16x8 xl = ly_lds_frag(hs_lo, hb[n] + toff, 0, lq);
 #pragma unroll
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_conv3x3_kernel(const LyConv3Par
   const bool vec_ok = (P.ldo & 3) == 0;
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
-    const int tt = (by * 4 + wave) * MT + t;
+    const int tt = (by * WC + wc) * MT + t;
     const int c = 16 * tt + 4 * lq;
     if (tt >= T || c >= P.N) continue;
     float sc[4], sh[4];
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_conv3x3_kernel(const LyConv3Par
       sh[r] = (ok && P.e_shift) ? P.e_shift[c + r] : 0.f;
     }
 #pragma unroll
-    for (int n = 0; n < LY_C3_NT; ++n) {
+    for (int n = 0; n < NTW; ++n) {
       if (orow[n] < 0) continue;
       f32x4 u;
 #pragma unroll
@@ -182,18 +185,20 @@ __global__ __launch_bounds__(LY_THREADS) void ly_conv3x3_kernel(const LyConv3Par
   }
 }
 
+static int g_c3_cfg = 0;
+extern "C" int ly_debug_set_conv3_cfg(int v) { g_c3_cfg = v; return 0; }
 static int g_c3_dbg = 0;    // ablation aid: 1 skip weight loads, 2 skip LDS reads + MFMA, 4 skip prefetch, 8 skip commit
 extern "C" int ly_debug_set_conv3(int v) { g_c3_dbg = v; return 0; }
 
-template <int MT>
+template <int MT, int WC>
 static int launch_conv3(const LyConv3Params& P, hipStream_t st) {
   const int tiles_x = (P.W + P.TW - 1) / P.TW, tiles_y = (P.H + P.TH - 1) / P.TH;
-  const int gy = (P.N + 64 * MT - 1) / (64 * MT);
+  const int gy = (P.N + 16 * MT * WC - 1) / (16 * MT * WC);
   const long n_img = P.M / ((long)P.H * P.W);
   long nb = n_img * tiles_x * tiles_y * gy;
   LY_CHECK(nb < (1L << 31), "conv3x3: grid too large");
   size_t lds = 2 * (size_t)(P.TH + 2) * (P.TW + 2) * LY_RSH;
-  auto k = ly_conv3x3_kernel<MT>;
+  auto k = ly_conv3x3_kernel<MT, WC>;
   static bool configured = false;
   if (!configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
@@ -215,7 +220,16 @@ extern "C" int ly_conv3x3_fwd(const LyConv3Params* p, void* stream) {
   LY_CHECK(P.TH >= 1 && P.TW >= 1 && P.TH * P.TW <= 16 * LY_C3_NT, "conv3x3: patch %dx%d exceeds %d pixels", P.TH, P.TW, 16 * LY_C3_NT);
   LY_CHECK((P.TH + 2) * (P.TW + 2) * (LY_CC / 4) <= LY_C3_NV * LY_THREADS, "conv3x3: frame of patch %dx%d exceeds the staging capacity", P.TH, P.TW);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (P.N > 128) return launch_conv3<4>(P, st);     // 4 waves x 64 ch
-  if (P.N > 64) return launch_conv3<2>(P, st);      // 4 waves x 32 ch
-  return launch_conv3<1>(P, st);                    // 4 waves x 16 ch
+  switch (g_c3_cfg) {                                    // tuning aid: MT*10 + WC
+    case 44: return launch_conv3<4, 4>(P, st);
+    case 24: return launch_conv3<2, 4>(P, st);
+    case 14: return launch_conv3<1, 4>(P, st);
+    case 42: return launch_conv3<4, 2>(P, st);
+    case 22: return launch_conv3<2, 2>(P, st);
+    case 41: return launch_conv3<4, 1>(P, st);
+    default: break;
+  }
+  // measured on MI355X (tools/conv_cfg.py): 32 channels per wave is the sweet spot at every LEAD-YOLO shape
+  if (P.N > 64) return launch_conv3<2, 4>(P, st);      // 4 waves x 32 ch (128 ch per block), all 8 pixel tiles each
+  return launch_conv3<2, 2>(P, st);                    // 2 x 32 ch, 2 pixel groups of 4 tiles
 }

@@ -119,8 +119,8 @@ def gemm(*, M, H, W, K, N, a0, lda0, k0, wp, out, ldo, a1=None, lda1=0, gather=G
 def conv3x3(*, M, H, W, Cin, N, x, ldx, wp, out, ldo, e_scale=None, e_shift=None, act=ACT_NONE):
     th, tw = pick_conv_tile(H, W)
     P = capi.LyConv3Params(M, H, W, Cin, N, th, tw, _p(x), ldx, _p(wp), _p(e_scale), _p(e_shift), act, _p(out), ldo)
-    mt = 4 if N > 128 else 2 if N > 64 else 1
-    with _Timed(f"ly_conv3x3_kernel<{mt}>", 2.0 * M * 9 * Cin * N, 4.0 * (M * (Cin + N) + 9 * Cin * N)):
+    mt, wc = (2, 4) if N > 64 else (2, 2)
+    with _Timed(f"ly_conv3x3_kernel<{mt}, {wc}>", 2.0 * M * 9 * Cin * N, 4.0 * (M * (Cin + N) + 9 * Cin * N)):
         capi.check(capi.lib().ly_conv3x3_fwd(ctypes.byref(P), capi.stream_ptr()), "ly_conv3x3_fwd")
 
 

@@ -384,6 +384,9 @@ extern "C" int ly_gemm_fwd(const LyGemmParams* p, void* stream) {
     case 444: return launch_gemm<4, 4, 4>(P, st);
     case 424: return launch_gemm<4, 2, 4>(P, st);
     case 414: return launch_gemm<4, 1, 4>(P, st);
+    case 422: return launch_gemm<4, 2, 2>(P, st);
+    case 442: return launch_gemm<4, 4, 2>(P, st);
+    case 242: return launch_gemm<2, 4, 2>(P, st);
     case 221: return launch_gemm<2, 2, 1>(P, st);
     case 121: return launch_gemm<1, 2, 1>(P, st);
     default: break;

@@ -115,7 +115,7 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(scale, size, budget_s=20.0):
+def cpu_baseline(scale, size, budget_s=15.0):
     """oracle (CPU restatement, parity-pinned) on the host cores, bounded sample of the same workload"""
     import copy
     from oracle import functional as OF
@@ -134,7 +134,7 @@ def cpu_baseline(scale, size, budget_s=20.0):
         while True:
             OF.model_forward(st, cfg, x, m.stride, training=False)
             n += 1
-            if time.perf_counter() - t0 > budget_s or n >= 50:
+            if time.perf_counter() - t0 > budget_s or n >= 2000:
                 break
         dt = time.perf_counter() - t0
     return dict(value=round(b * n / dt, 2), unit="images/sec", cores=cores, kind="port",

@@ -22,10 +22,12 @@ const char* ly_last_error(void);
  * (models/common.py:1478-1482).  wp/w1/w2 are bf16x3 frag-packed (lead-yolo_amd/pack.py frag_pack3)
  * from spatial_mixing.partial_conv3.weight ([C/4, 9*ceil4(C/4)], k = tap*ceil4(C/4) + c),
  * mlp.0.weight (rows zero-padded to 16*ly_mlpblock_hidden_tiles(C)) and mlp.3.weight; bn_* have
- * 16*ly_mlpblock_hidden_tiles(C) entries (zero padded).  x and y must not alias.
+ * 16*ly_mlpblock_hidden_tiles(C) entries (zero padded).  stats: NULL, or [2 * 16*hidden_tiles] zeroed
+ * accumulators = STATISTICS PASS of the train-mode BatchNorm (sum / sum of squares of the pre-BN hidden
+ * activations; y and bn_* are ignored, nothing is stored).  x and y must not alias.
  * Built for C in {16,24,40,80,160,320}. */
 int ly_mlpblock_fwd(const float* x, float* y, int n_img, int H, int W, int C, const void* wp, const void* w1,
-                    const void* w2, const float* bn_scale, const float* bn_shift, void* stream);
+                    const void* w2, const float* bn_scale, const float* bn_shift, float* stats, void* stream);
 /* ablation aid for profiling (bit 0: skip pconv, 1: skip MLP contractions, 2: skip halo staging, 3: skip stores) */
 int ly_debug_set_mlp(int v);
 /* tuning aid: 1 forces the flattened-run tiling (default: 8x16 patches where W % 16 == 0 and W >= 64) */
@@ -60,6 +62,9 @@ typedef struct LyGemmParams {
   const float* rowscale;  /* [M] or NULL                                                         */
   int act;                /* 0 none, 1 relu, 2 silu                                              */
   float* out; int ldo;    /* output row stride (floats); pointer may be pre-offset into a concat */
+  float* stats;           /* NULL, or [2N] zero-initialised accumulators: STATISTICS PASS for train-mode
+                             BatchNorm — adds sum / sum-of-squares over the M rows of the pre-activation value
+                             (rowscale*e_scale*acc + e_shift) per output channel and stores nothing          */
 } LyGemmParams;
 
 /* out[m, n] = act(rowscale[m] * e_scale[n] * sum_k A'[m, k] W[n, k] + e_shift[n]).
@@ -84,6 +89,7 @@ typedef struct LyConv3Params {
   const float* e_scale; const float* e_shift;   /* folded BN / bias, [N] or NULL                 */
   int act;
   float* out; int ldo;
+  float* stats;            /* NULL or [2N] accumulators: statistics pass (see LyGemmParams.stats)     */
 } LyConv3Params;
 
 /* Conv(c1, c2, 3, 1) = conv3x3(no bias) + BN + SiLU (CA_Bottleneck.cv2, models/common.py:1617,
@@ -135,6 +141,7 @@ typedef struct LyRfcbam3Params {
   const void* wp;              /* frag_pack3(conv.0.weight as [N, C/16, 144 -> 160 zero padded])  */
   const float* e_scale; const float* e_shift;   /* conv.1 BN folded with conv.0.bias              */
   float* out; int ldo;
+  float* stats;                /* NULL or [2N] accumulators: conv.1 BatchNorm statistics pass    */
 } LyRfcbam3Params;
 /* RFCBAMConv kernel_size 3 main contraction (+ReLU); the k=1 case is ly_gemm_fwd with
  * LY_PRO_AFFINE_RELU_CA and rowscale = rfa.                                                         */
@@ -153,6 +160,22 @@ int ly_sppf_pool(const float* x, int ldx, int n_img, int H, int W, int C, int k,
  * anchors = [na,2] in grid units (Detect.anchors[i]), stride = Detect.stride[i].                     */
 int ly_detect_tail(const float* y, int ldy, int n_img, int H, int W, int na, int no, const float* anchors, float stride,
                    float* p, float* z, long zrows, long zoff, void* stream);
+
+
+/* ---- train-mode BatchNorm statistics passes ----------------------------------------------------- */
+/* mom[c] += sum_rows x[r, c], mom[C + c] += sum_rows x[r, c]^2 over an [rows, C] row matrix (mom zeroed
+ * by the caller).  Used for the k=1 `generate` BatchNorm of RFCBAMConv (models/rfa.py:101-106).       */
+int ly_chan_moments(const float* x, int ldx, long rows, int C, float* mom, void* stream);
+/* CoordAtt bn1 (models/common.py:1589,1602): sum / sum of squares of conv1(pool) + bias over all
+ * n*(H+W) positions, stats[0:mip] and stats[mip:2mip] (zeroed by the caller).                        */
+int ly_coordatt_conv1_stats(const float* pool, long positions, int C, int mip, const float* w1, const float* b1,
+                            float* stats, void* stream);
+
+/* RFCBAMConv k=3 `generate` BatchNorm statistics (train mode): mom[54][C] (zeroed by the caller) receives,
+ * per input channel, the 9 first moments sum x_u and the 45 second moments sum x_u x_v (u <= v, row-major
+ * upper triangle) of the zero-padded stride-s 3x3 taps over all n_img*Ho*Wo output pixels; mean and
+ * variance of every (channel, tap-output) follow as w.m and w^T M w on the host.                        */
+int ly_rfcbam_tap_moments(const float* x, int ldx, int n_img, int H, int W, int C, int s, float* mom, void* stream);
 
 #ifdef __cplusplus
 }

@@ -24,18 +24,18 @@ class LyGemmParams(ctypes.Structure):       # mirrors include/lead_yolo_hip.h
                 ("pro", _I), ("g_h", _P), ("g_w", _P), ("res", _P), ("ldres", _I),
                 ("p_scale", _P), ("p_shift", _P), ("p_ca", _P),
                 ("wp", _P), ("e_scale", _P), ("e_shift", _P), ("rowscale", _P), ("act", _I),
-                ("out", _P), ("ldo", _I)]
+                ("out", _P), ("ldo", _I), ("stats", _P)]
 
 
 class LyConv3Params(ctypes.Structure):
     _fields_ = [("M", _L), ("H", _I), ("W", _I), ("Cin", _I), ("N", _I), ("TH", _I), ("TW", _I), ("x", _P), ("ldx", _I), ("wp", _P),
-                ("e_scale", _P), ("e_shift", _P), ("act", _I), ("out", _P), ("ldo", _I)]
+                ("e_scale", _P), ("e_shift", _P), ("act", _I), ("out", _P), ("ldo", _I), ("stats", _P)]
 
 
 class LyRfcbam3Params(ctypes.Structure):
     _fields_ = [("n_img", _I), ("H", _I), ("W", _I), ("C", _I), ("Ho", _I), ("Wo", _I), ("N", _I), ("s", _I),
                 ("TH", _I), ("TW", _I), ("x", _P), ("ldx", _I), ("wg", _P), ("ca", _P), ("rfa", _P), ("wp", _P),
-                ("e_scale", _P), ("e_shift", _P), ("out", _P), ("ldo", _I)]
+                ("e_scale", _P), ("e_shift", _P), ("out", _P), ("ldo", _I), ("stats", _P)]
 
 
 ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
@@ -45,7 +45,7 @@ PRO_NONE, PRO_GATE, PRO_AFFINE_RELU_CA = 0, 1, 2
 # name -> argtypes  (every entry point returns int: 0 ok, <0 error with ly_last_error())
 SIGNATURES = {
     "ly_abi_version": [],
-    "ly_mlpblock_fwd": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "ly_mlpblock_fwd": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "ly_mlpblock_hidden_tiles": [_I],
     "ly_gemm_fwd": [ctypes.POINTER(LyGemmParams), _P],
     "ly_debug_set_gemm_cfg": [_I],
@@ -64,6 +64,9 @@ SIGNATURES = {
     "ly_rfcbam_stats": [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P],
     "ly_rfa_map": [_P, _I, _I, _I, _P, _P, _P],
     "ly_rfcbam3_fwd": [ctypes.POINTER(LyRfcbam3Params), _P],
+    "ly_chan_moments": [_P, _I, _L, _I, _P, _P],
+    "ly_rfcbam_tap_moments": [_P, _I, _I, _I, _I, _I, _I, _P, _P],
+    "ly_coordatt_conv1_stats": [_P, _L, _I, _I, _P, _P, _P, _P],
     "ly_sppf_pool": [_P, _I, _I, _I, _I, _I, _I, _P, _I, _P],
     "ly_detect_tail": [_P, _I, _I, _I, _I, _I, _I, _P, _F, _P, _P, _L, _L, _P],
 }

@@ -537,3 +537,133 @@ extern "C" int ly_detect_tail(const float* y, int ldy, int n_img, int H, int W, 
   LY_LAUNCH_CHECK();
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Train-mode BatchNorm support kernels (statistics passes; normalisation itself is folded into the
+// consumers' scale/shift exactly like the eval path)
+// ---------------------------------------------------------------------------------------------------
+// per-channel sum / sum of squares over all rows of an [rows, C] matrix: mom[c] += sum x, mom[C + c] += sum x^2
+__global__ __launch_bounds__(LY_THREADS) void ly_chan_moments_kernel(const float* __restrict__ x, int ldx, long rows, int C,
+                                                                      float* __restrict__ mom) {
+  __shared__ f32x4 red1[LY_THREADS], red2[LY_THREADS];
+  const int nc4 = C >> 2, tid = threadIdx.x;
+  const int groups = LY_THREADS / nc4;
+  const int c4 = tid % nc4, j0 = tid / nc4;
+  f32x4 s1 = ly_zero4(), s2 = ly_zero4();
+  if (j0 < groups)
+    for (long r = (long)blockIdx.x * groups + j0; r < rows; r += (long)gridDim.x * groups) {
+      const f32x4 v = ly_ldg4(x + r * ldx + 4 * c4);
+      s1 += v;
+      s2 += v * v;
+    }
+  red1[tid] = s1; red2[tid] = s2;
+  __syncthreads();
+  if (j0 == 0) {
+    for (int g = 1; g < groups; ++g) { s1 += red1[g * nc4 + c4]; s2 += red2[g * nc4 + c4]; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      atomicAdd(mom + 4 * c4 + r, s1[r]);
+      atomicAdd(mom + C + 4 * c4 + r, s2[r]);
+    }
+  }
+}
+
+extern "C" int ly_chan_moments(const float* x, int ldx, long rows, int C, float* mom, void* stream) {
+  LY_CHECK(x && mom && (C & 3) == 0 && (ldx & 3) == 0 && C <= 1024 && rows > 0, "chan_moments: bad arguments");
+  const int groups = LY_THREADS / (C >> 2);
+  long blocks = (rows + groups * 64L - 1) / (groups * 64L);
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(ly_chan_moments_kernel, dim3((unsigned)blocks), dim3(LY_THREADS), 0, reinterpret_cast<hipStream_t>(stream), x, ldx, rows,
+                     C, mom);
+  LY_LAUNCH_CHECK();
+  return 0;
+}
+
+// CoordAtt bn1 statistics: y1[n, pos, m] = w1[m, :] . pool[n, pos, :] + b1[m];  stats[m] += y1, stats[mip + m] += y1^2
+__global__ __launch_bounds__(LY_THREADS) void ly_coordatt_conv1_stats_kernel(const float* __restrict__ pool, int C, int mip,
+                                                                              const float* __restrict__ w1, const float* __restrict__ b1,
+                                                                              float* __restrict__ stats) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* p = pool + (long)blockIdx.x * C;
+  for (int m = wave; m < mip; m += 4) {
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += w1[m * C + c] * p[c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) {
+      s += b1[m];
+      atomicAdd(stats + m, s);
+      atomicAdd(stats + mip + m, s * s);
+    }
+  }
+}
+
+extern "C" int ly_coordatt_conv1_stats(const float* pool, long positions, int C, int mip, const float* w1, const float* b1,
+                                       float* stats, void* stream) {
+  LY_CHECK(pool && w1 && b1 && stats && positions > 0 && mip > 0, "coordatt_conv1_stats: bad arguments");
+  hipLaunchKernelGGL(ly_coordatt_conv1_stats_kernel, dim3((unsigned)positions), dim3(LY_THREADS), 0, reinterpret_cast<hipStream_t>(stream),
+                     pool, C, mip, w1, b1, stats);
+  LY_LAUNCH_CHECK();
+  return 0;
+}
+
+// RFCBAMConv k=3 `generate` BatchNorm statistics (train mode).  The pre-BN value of channel c, tap-output t at
+// an output pixel is a_t = sum_u w[c,t,u] * x_u with x_u the 9 (zero padded, stride s) input taps of that pixel,
+// so  sum a_t = w_t . m   and   sum a_t^2 = w_t^T M w_t  with  m[u] = sum_pixels x_u,  M[u][v] = sum_pixels x_u x_v.
+// This kernel accumulates the 9 + 45 moments per channel: thread = channel (coalesced NHWC reads), blocks split
+// the output pixels, 54 vectorised atomics per thread at the end.  mom layout: [54][C].
+__global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_tap_moments_kernel(const float* __restrict__ x, int ldx, int n_img, int H, int W,
+                                                                            int C, int Ho, int Wo, int s, float* __restrict__ mom) {
+  const int cb = C < LY_THREADS ? C : LY_THREADS;          // channels handled per pass by this block
+  const int subs = LY_THREADS / cb;
+  const int tid = threadIdx.x;
+  const int cl = tid % cb, sub = tid / cb;
+  const long npix = (long)n_img * Ho * Wo;
+  for (int c0 = 0; c0 < C; c0 += cb) {
+    const int c = c0 + cl;
+    float m1[9], m2[45];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) m1[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 45; ++i) m2[i] = 0.f;
+    if (sub < subs && c < C) {
+      for (long p = (long)blockIdx.x * subs + sub; p < npix; p += (long)gridDim.x * subs) {
+        const int ox = (int)(p % Wo);
+        const long q = p / Wo;
+        const int oy = (int)(q % Ho);
+        const long n = q / Ho;
+        float xv[9];
+#pragma unroll
+        for (int u = 0; u < 9; ++u) {
+          const int iy = s * oy + u / 3 - 1, ix = s * ox + u % 3 - 1;
+          const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+          xv[u] = ok ? x[((n * H + (ok ? iy : 0)) * W + (ok ? ix : 0)) * ldx + c] : 0.f;
+        }
+        int k = 0;
+#pragma unroll
+        for (int u = 0; u < 9; ++u) {
+          m1[u] += xv[u];
+#pragma unroll
+          for (int v = u; v < 9; ++v) m2[k++] += xv[u] * xv[v];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 9; ++i) atomicAdd(mom + (long)i * C + c, m1[i]);
+#pragma unroll
+      for (int i = 0; i < 45; ++i) atomicAdd(mom + (long)(9 + i) * C + c, m2[i]);
+    }
+  }
+}
+
+extern "C" int ly_rfcbam_tap_moments(const float* x, int ldx, int n_img, int H, int W, int C, int s, float* mom, void* stream) {
+  LY_CHECK(x && mom && s >= 1 && C > 0, "rfcbam_tap_moments: bad arguments");
+  const int Ho = (H + 2 - 3) / s + 1, Wo = (W + 2 - 3) / s + 1;
+  long npix = (long)n_img * Ho * Wo;
+  long blocks = npix / 32 + 1;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(ly_rfcbam_tap_moments_kernel, dim3((unsigned)blocks), dim3(LY_THREADS), 0, reinterpret_cast<hipStream_t>(stream), x, ldx,
+                     n_img, H, W, C, Ho, Wo, s, mom);
+  LY_LAUNCH_CHECK();
+  return 0;
+}

@@ -135,6 +135,28 @@ __device__ __forceinline__ void ly_l2_warm(const void* base, long bytes, float* 
   if (acc == 1.2345678e-30f) *sink = acc;
 }
 
+// Batch-statistics pass support: a lane holds 4 consecutive channels (c .. c+3) of some pixels; sum the
+// two 4-vectors over the 16 lanes that share lq (lanes differing in l&15) and let lane l&15 == 0 add them
+// to stats[c + r] (sum) and stats[nch + c + r] (sum of squares).
+__device__ __forceinline__ void ly_stats_flush(float* __restrict__ stats, int nch, int c, f32x4 s1, f32x4 s2) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      s1[r] += __shfl_xor(s1[r], o);
+      s2[r] += __shfl_xor(s2[r], o);
+    }
+  }
+  if ((threadIdx.x & 15) == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (c + r < nch) {
+        atomicAdd(stats + c + r, s1[r]);
+        atomicAdd(stats + nch + c + r, s2[r]);
+      }
+  }
+}
+
 extern "C" void ly_set_error(const char* fmt, ...);
 
 #define LY_CHECK(cond, ...)                \

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_conv3x3_kernel(const LyConv3Par
     wbase[t] = (long)(tt < T ? tt : T - 1) * S;
   }
   const uint4* wpk = reinterpret_cast<const uint4*>(P.wp);
-  ly_l2_warm(P.wp, (long)T * S * 2048, P.out);
+  ly_l2_warm(P.wp, (long)T * S * 2048, P.stats ? P.stats : P.out);
 
   LyWFrag wcur[MT], wnxt[MT];
 #pragma unroll
@@ -166,12 +166,18 @@ __global__ __launch_bounds__(LY_THREADS) void ly_conv3x3_kernel(const LyConv3Par
       sc[r] = (ok && P.e_scale) ? P.e_scale[c + r] : 1.f;
       sh[r] = (ok && P.e_shift) ? P.e_shift[c + r] : 0.f;
     }
+    f32x4 s1 = zero, s2 = zero;
 #pragma unroll
     for (int n = 0; n < NTW; ++n) {
       if (orow[n] < 0) continue;
       f32x4 u;
 #pragma unroll
       for (int r = 0; r < 4; ++r) u[r] = acc[t][n][r] * sc[r] + sh[r];
+      if (P.stats) {
+        s1 += u;
+        s2 += u * u;
+        continue;
+      }
       const f32x4 v = ly_act4(u, act);
       float* o = P.out + orow[n] * P.ldo + c;
       if (vec_ok && c + 3 < P.N) {
@@ -182,6 +188,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_conv3x3_kernel(const LyConv3Par
           if (c + r < P.N) o[r] = v[r];
       }
     }
+    if (P.stats) ly_stats_flush(P.stats, P.N, c, s1, s2);
   }
 }
 
@@ -213,7 +220,7 @@ static int launch_conv3(const LyConv3Params& P, hipStream_t st) {
 extern "C" int ly_conv3x3_fwd(const LyConv3Params* p, void* stream) {
   LY_CHECK(p, "conv3x3: null params");
   const LyConv3Params& P = *p;
-  LY_CHECK(P.x && P.wp && P.out, "conv3x3: null pointer");
+  LY_CHECK(P.x && P.wp && (P.out || P.stats), "conv3x3: null pointer");
   LY_CHECK(P.M > 0 && P.H > 0 && P.W > 0 && P.Cin > 0 && P.N > 0, "conv3x3: bad sizes");
   LY_CHECK((P.Cin & 3) == 0 && (P.ldx & 3) == 0, "conv3x3: Cin=%d / ldx=%d must be multiples of 4", P.Cin, P.ldx);
   LY_CHECK(P.M % ((long)P.H * P.W) == 0, "conv3x3: M is not a whole number of images");

@@ -181,6 +181,10 @@ __global__ __launch_bounds__(LY_THREADS, LY_GEMM_MINW) void ly_gemm_kernel(const
   const int pixgrp = wp_ * (16 * NT);
   const bool vec_ok = (P.ldo & 3) == 0;
   const int act = P.act;
+  float* const stats = P.stats;                           // non-NULL: batch-statistics pass (no store)
+  f32x4 st1[MT], st2[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) { st1[t] = zero; st2[t] = zero; }
   float rsv[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) rsv[n] = 1.f;
@@ -197,7 +201,7 @@ __global__ __launch_bounds__(LY_THREADS, LY_GEMM_MINW) void ly_gemm_kernel(const
   }
 
   if (slot >= gx) return;                                  // (host never launches such blocks)
-  ly_l2_warm(P.wp, (long)T * S * 2048, P.out);
+  ly_l2_warm(P.wp, (long)T * S * 2048, P.stats ? P.stats : P.out);
   LyWFrag wcur[MT], wnxt[MT];
 #pragma unroll
   for (int t = 0; t < MT; ++t) wcur[t] = ly_wfrag(wpk, wbase[t], lane);
@@ -285,6 +289,11 @@ __global__ __launch_bounds__(LY_THREADS, LY_GEMM_MINW) void ly_gemm_kernel(const
             f32x4 u;
 #pragma unroll
             for (int r = 0; r < 4; ++r) u[r] = acc[t][n][r] * rs * esc[t][r] + esh[t][r];
+            if (stats) {                                   // pre-activation value is what BatchNorm normalises
+              st1[t] += u;
+              st2[t] += u * u;
+              continue;
+            }
             const f32x4 v = ly_act4(u, act);
             float* o = P.out + gp * P.ldo + c;
             if (dbg & 8) {
@@ -304,6 +313,13 @@ __global__ __launch_bounds__(LY_THREADS, LY_GEMM_MINW) void ly_gemm_kernel(const
     pt += nslots;
     if (pt >= gx) break;
     p0 = (long)pt * BP;
+  }
+  if (stats) {
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const int tt = (by * WC + wc) * MT + t;
+      if (tt < T) ly_stats_flush(stats, P.N, 16 * tt + 4 * lq, st1[t], st2[t]);
+    }
   }
 }
 
@@ -356,7 +372,7 @@ static int launch_gemm(const LyGemmParams& P, hipStream_t st) {
 extern "C" int ly_gemm_fwd(const LyGemmParams* p, void* stream) {
   LY_CHECK(p, "gemm: null params");
   const LyGemmParams& P = *p;
-  LY_CHECK(P.a0 && P.wp && P.out, "gemm: null a0/wp/out");
+  LY_CHECK(P.a0 && P.wp && (P.out || P.stats), "gemm: null a0/wp/out");
   LY_CHECK(P.M > 0 && P.K > 0 && P.N > 0 && P.H > 0 && P.W > 0, "gemm: bad sizes M=%ld K=%d N=%d", P.M, P.K, P.N);
   LY_CHECK((P.K & 3) == 0, "gemm: K=%d must be a multiple of 4", P.K);
   if (P.gather == LY_GATHER_ROWS || P.gather == LY_GATHER_UP2) {

@@ -39,7 +39,7 @@ template <int C, int NT, int HT, bool T2D>
 __global__ __launch_bounds__(LY_THREADS) void ly_mlpblock_fwd_kernel(
     const float* __restrict__ x, float* __restrict__ y, long M, int H, int W,
     const uint4* __restrict__ wp, const uint4* __restrict__ w1, const uint4* __restrict__ w2,
-    const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, const int dbg) {
+    const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, float* __restrict__ stats, const int dbg) {
   using Gm = MlpGeom<C>;
   constexpr int CQ = Gm::CQ, G = Gm::G, SP = Gm::SP, PT = Gm::PT, C16 = Gm::C16, KP = Gm::KP, S1 = Gm::S1;
   constexpr int RS = Gm::RS, RSP = Gm::RSP, HTP = Gm::HTP, S2 = Gm::S2;
@@ -65,9 +65,10 @@ __global__ __launch_bounds__(LY_THREADS) void ly_mlpblock_fwd_kernel(
   const int li = lane & 15, lq = lane >> 4;
   const f32x4 zero = ly_zero4();
   if (C >= 80) {     // large weight sets, few pixels: warm L2 with all three packed weight arrays
-    ly_l2_warm(w1, (long)HTP * S1 * 2048, y);
-    ly_l2_warm(w2, (long)C16 * S2 * 2048, y);
-    ly_l2_warm(wp, (long)PT * SP * 2048, y);
+    float* const sink = stats ? stats : y;
+    ly_l2_warm(w1, (long)HTP * S1 * 2048, sink);
+    ly_l2_warm(w2, (long)C16 * S2 * 2048, sink);
+    ly_l2_warm(wp, (long)PT * SP * 2048, sink);
   }
   long p0 = 0;                 // flattened: first pixel of the run
   long img0 = 0;               // T2D: pixel index of (n, 0, 0)
@@ -235,6 +236,22 @@ __global__ __launch_bounds__(LY_THREADS) void ly_mlpblock_fwd_kernel(
         for (int n = 0; n < NT; ++n) acch[t][n] = ly_mfma3(wf.hi, wf.lo, xh[n], xl[n], acch[t][n]);
       }
     }
+    if (stats) {
+      // statistics pass of train-mode BatchNorm: sum / sum of squares of the pre-BN hidden activations
+      // over the valid pixels of this block; nothing else is computed or stored
+#pragma unroll
+      for (int t = 0; t < HT; ++t) {
+        f32x4 s1 = zero, s2 = zero;
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          if (gpix(pixbase + 16 * n + li) >= 0) {
+            s1 += acch[t][n];
+            s2 += acch[t][n] * acch[t][n];
+          }
+        ly_stats_flush(stats, HTP * 16, (hc * HT + t) * 16 + 4 * lq, s1, s2);
+      }
+      continue;
+    }
     bf16x4 hh[HT][NT], hl[HT][NT];
 #pragma unroll
     for (int t = 0; t < HT; ++t) {
@@ -265,6 +282,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_mlpblock_fwd_kernel(
     }
   }
 
+  if (stats) return;
   // ---- epilogue: residual + store ------------------------------------------------------------
   // The residual x is rebuilt from the bf16 hi/lo planes already in LDS (|err| <= 2^-17 |x|) instead
   // of re-reading global memory: channels < CQP from the halo image's centre tap (the tile's own
@@ -300,7 +318,7 @@ extern "C" int ly_debug_set_mlp(int v) { g_mlp_dbg = v; return 0; }
 
 template <int C, int NT, int HT, bool T2D>
 static int launch_mlp(const float* x, float* y, long M, int n_img, int H, int W, const void* wp, const void* w1, const void* w2,
-                      const float* s, const float* b, hipStream_t st) {
+                      const float* s, const float* b, float* stats, hipStream_t st) {
   using Gm = MlpGeom<C>;
   constexpr int BP = 64 * NT;
   const long halo = T2D ? (4 * NT + 2) * 18 : BP + 2 * W + 2;
@@ -315,7 +333,7 @@ static int launch_mlp(const float* x, float* y, long M, int n_img, int H, int W,
   }
   long blocks = T2D ? (long)n_img * ((H + 4 * NT - 1) / (4 * NT)) * (W / 16) : (M + BP - 1) / BP;
   hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(LY_THREADS), lds, st, x, y, M, H, W, reinterpret_cast<const uint4*>(wp),
-                     reinterpret_cast<const uint4*>(w1), reinterpret_cast<const uint4*>(w2), s, b, g_mlp_dbg);
+                     reinterpret_cast<const uint4*>(w1), reinterpret_cast<const uint4*>(w2), s, b, stats, g_mlp_dbg);
   LY_LAUNCH_CHECK();
   return 0;
 }
@@ -324,28 +342,28 @@ static int launch_mlp(const float* x, float* y, long M, int n_img, int H, int W,
 // a multiple of 16; flattened runs otherwise, with as many pixel tiles per wave as still fill the chip
 template <int C, int HT, int NTMAX>
 static int dispatch_nt(const float* x, float* y, long M, int n_img, int H, int W, const void* wp, const void* w1, const void* w2,
-                       const float* s, const float* b, hipStream_t st) {
-  if ((W & 15) == 0 && W >= 64 && NTMAX >= 2 && g_mlp_tile != 1) return launch_mlp<C, 2, HT, true>(x, y, M, n_img, H, W, wp, w1, w2, s, b, st);
-  if (NTMAX >= 4 && M >= 256L * 1024) return launch_mlp<C, (NTMAX >= 4 ? 4 : NTMAX), HT, false>(x, y, M, n_img, H, W, wp, w1, w2, s, b, st);
-  if (NTMAX >= 2 && M >= 128L * 512) return launch_mlp<C, (NTMAX >= 2 ? 2 : NTMAX), HT, false>(x, y, M, n_img, H, W, wp, w1, w2, s, b, st);
-  return launch_mlp<C, 1, HT, false>(x, y, M, n_img, H, W, wp, w1, w2, s, b, st);
+                       const float* s, const float* b, float* stats, hipStream_t st) {
+  if ((W & 15) == 0 && W >= 64 && NTMAX >= 2 && g_mlp_tile != 1) return launch_mlp<C, 2, HT, true>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
+  if (NTMAX >= 4 && M >= 256L * 1024) return launch_mlp<C, (NTMAX >= 4 ? 4 : NTMAX), HT, false>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
+  if (NTMAX >= 2 && M >= 128L * 512) return launch_mlp<C, (NTMAX >= 2 ? 2 : NTMAX), HT, false>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
+  return launch_mlp<C, 1, HT, false>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
 }
 
 extern "C" int ly_mlpblock_fwd(const float* x, float* y, int n_img, int H, int W, int C, const void* wp, const void* w1,
-                               const void* w2, const float* bn_scale, const float* bn_shift, void* stream) {
-  LY_CHECK(x && y && wp && w1 && w2 && bn_scale && bn_shift, "mlpblock: null pointer");
+                               const void* w2, const float* bn_scale, const float* bn_shift, float* stats, void* stream) {
+  LY_CHECK(x && wp && w1 && w2 && (stats || (y && bn_scale && bn_shift)), "mlpblock: null pointer");
   LY_CHECK(x != y, "mlpblock: in-place call is not supported (neighbouring tiles read halo rows)");
   LY_CHECK(n_img > 0 && H > 0 && W > 0, "mlpblock: bad shape %d x %d x %d", n_img, H, W);
   long M = (long)n_img * H * W;
   LY_CHECK(M < (1L << 24), "mlpblock: M=%ld pixels exceeds the 2^24 limit of the fast index path", M);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   switch (C) {
-    case 16:  return dispatch_nt<16, 2, 4>(x, y, M, n_img, H, W, wp, w1, w2, bn_scale, bn_shift, st);
-    case 24:  return dispatch_nt<24, 4, 4>(x, y, M, n_img, H, W, wp, w1, w2, bn_scale, bn_shift, st);
-    case 40:  return dispatch_nt<40, 2, 4>(x, y, M, n_img, H, W, wp, w1, w2, bn_scale, bn_shift, st);
-    case 80:  return dispatch_nt<80, 2, 2>(x, y, M, n_img, H, W, wp, w1, w2, bn_scale, bn_shift, st);
-    case 160: return dispatch_nt<160, 4, 2>(x, y, M, n_img, H, W, wp, w1, w2, bn_scale, bn_shift, st);
-    case 320: return dispatch_nt<320, 4, 1>(x, y, M, n_img, H, W, wp, w1, w2, bn_scale, bn_shift, st);
+    case 16:  return dispatch_nt<16, 2, 4>(x, y, M, n_img, H, W, wp, w1, w2, bn_scale, bn_shift, stats, st);
+    case 24:  return dispatch_nt<24, 4, 4>(x, y, M, n_img, H, W, wp, w1, w2, bn_scale, bn_shift, stats, st);
+    case 40:  return dispatch_nt<40, 2, 4>(x, y, M, n_img, H, W, wp, w1, w2, bn_scale, bn_shift, stats, st);
+    case 80:  return dispatch_nt<80, 2, 2>(x, y, M, n_img, H, W, wp, w1, w2, bn_scale, bn_shift, stats, st);
+    case 160: return dispatch_nt<160, 4, 2>(x, y, M, n_img, H, W, wp, w1, w2, bn_scale, bn_shift, stats, st);
+    case 320: return dispatch_nt<320, 4, 1>(x, y, M, n_img, H, W, wp, w1, w2, bn_scale, bn_shift, stats, st);
     default:
       ly_set_error("mlpblock: unsupported channel count C=%d (built for 16/24/40/80/160/320)", C);
       return -1;

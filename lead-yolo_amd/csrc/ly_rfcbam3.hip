@@ -61,7 +61,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam3_kernel(const LyRfcbam3P
     tile[t] = tt < T ? tt : T - 1;
   }
   const uint4* wpk = reinterpret_cast<const uint4*>(P.wp);
-  ly_l2_warm(P.wp, (long)T * S * 2048, P.out);
+  ly_l2_warm(P.wp, (long)T * S * 2048, P.stats ? P.stats : P.out);
   for (int i = tid; i < 2 * 64 * LY_RSG / 16; i += LY_THREADS) reinterpret_cast<uint4*>(gs_hi)[i] = make_uint4(0u, 0u, 0u, 0u);
 
   // staging plan of this thread (independent of the channel chunk): global element offset (or -1), LDS slot
@@ -182,12 +182,21 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam3_kernel(const LyRfcbam3P
       sc[r] = ok ? P.e_scale[c + r] : 1.f;
       sh[r] = ok ? P.e_shift[c + r] : 0.f;
     }
+    f32x4 s1 = zero, s2 = zero;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int pl = 16 * j + li;
       const int py = pl / TW, px = pl - py * TW;
       const int yy = oy0 + py, xx = ox0 + px;
       if (py >= TH || yy >= P.Ho || xx >= P.Wo) continue;
+      if (P.stats) {                 // conv.1 BatchNorm statistics pass: pre-BN value, nothing stored
+        f32x4 u;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) u[r] = acc[t][j][r] * sc[r] + sh[r];
+        s1 += u;
+        s2 += u * u;
+        continue;
+      }
       f32x4 v;
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[t][j][r] * sc[r] + sh[r], 0.f);
@@ -200,6 +209,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam3_kernel(const LyRfcbam3P
           if (c + r < P.N) o[r] = v[r];
       }
     }
+    if (P.stats) ly_stats_flush(P.stats, P.N, c, s1, s2);
   }
 }
 
@@ -231,7 +241,7 @@ static int launch_rf3(const LyRfcbam3Params& P, hipStream_t st) {
 extern "C" int ly_rfcbam3_fwd(const LyRfcbam3Params* p, void* stream) {
   LY_CHECK(p, "rfcbam3: null params");
   const LyRfcbam3Params& P = *p;
-  LY_CHECK(P.x && P.wg && P.ca && P.rfa && P.wp && P.e_scale && P.e_shift && P.out, "rfcbam3: null pointer");
+  LY_CHECK(P.x && P.wg && P.ca && P.rfa && P.wp && P.e_scale && P.e_shift && (P.out || P.stats), "rfcbam3: null pointer");
   LY_CHECK((P.C & 15) == 0 && (P.ldx & 3) == 0, "rfcbam3: C=%d must be a multiple of 16", P.C);
   LY_CHECK(P.s >= 1 && P.TH >= 1 && P.TW >= 1 && P.TH * P.TW <= 64, "rfcbam3: bad tile %dx%d", P.TH, P.TW);
   LY_CHECK(P.Ho == (P.H + 2 - 3) / P.s + 1 && P.Wo == (P.W + 2 - 3) / P.s + 1, "rfcbam3: inconsistent output size");

@@ -65,8 +65,16 @@ def _probe(x, shape):
 
 def _no_train(mod, name):
     if mod.training:
-        raise NotImplementedError(f"{name}: train-mode (batch-statistics BatchNorm + backward) HIP path is not built yet; "
+        raise NotImplementedError(f"{name}: train-mode (batch-statistics BatchNorm) HIP path is not built yet for this module; "
                                   "call .eval()")
+
+
+def _no_grad_needed(x, name):
+    """Train-mode FORWARD is built (batch-statistics BatchNorm, running-stat updates); the hand-written
+    backward is not yet — refuse to silently return tensors that are detached from autograd."""
+    if torch.is_grad_enabled() and isinstance(x, torch.Tensor) and x.requires_grad:
+        raise NotImplementedError(f"{name}: backward through the HIP path is not built yet (round-2 work); "
+                                  "run train-mode forward under torch.no_grad()")
 
 
 def _bn_tensors(bn):
@@ -122,7 +130,9 @@ def _run_pointwise(src, wp, n_out, e_scale, e_shift, act, out=None, ldo=None, **
     """GEMM over a Lazy / tensor source -> NHWC tensor [n, n_out, h, w] (or into `out` rows)."""
     L = Lazy.of(src)
     n, c, h, w = L.shape
-    if out is None:
+    if extra.get("stats") is not None:
+        res, out_t, ldo = None, None, n_out                     # statistics pass: nothing is stored
+    elif out is None:
         res = ops.empty_nhwc(n, n_out, h, w, L.a0)
         out_t, ldo = res, n_out
     else:
@@ -165,30 +175,46 @@ class MLPBlock(nn.Module):
                                  nn.Conv2d(hidden, dim, 1, bias=False))
         self.spatial_mixing = Partial_conv3(dim, n_div, pconv_fw_type)
         self._prep = _Prepared()
+        self._prep_bn = _Prepared()
 
-    def _packed(self):
-        wp_, w1_, bn, w2_ = self.spatial_mixing.partial_conv3.weight, self.mlp[0].weight, self.mlp[1], self.mlp[3].weight
-        key = pack.versions(wp_, w1_, w2_, *_bn_tensors(bn)) + (bn.eps,)
+    def _weights(self):
+        wp_, w1_, w2_ = self.spatial_mixing.partial_conv3.weight, self.mlp[0].weight, self.mlp[3].weight
+        key = pack.versions(wp_, w1_, w2_)
 
         def build():
             c = self.dim
             htp = (2 * c // 16 + 1) // 2 * 2
-            wp = pack.frag_pack3(pack.conv_taps_matrix(wp_.detach(), 4))
-            w1 = pack.frag_pack3(w1_.detach().view(2 * c, c), rows_to=16 * htp)
-            w2 = pack.frag_pack3(w2_.detach().view(c, 2 * c))
-            sc, sh = pack.bn_scale_shift(bn)
-            return wp, w1, w2, pack.pad_to(sc, 16 * htp), pack.pad_to(sh, 16 * htp)
+            return (pack.frag_pack3(pack.conv_taps_matrix(wp_.detach(), 4)), pack.frag_pack3(w1_.detach().view(2 * c, c), rows_to=16 * htp),
+                    pack.frag_pack3(w2_.detach().view(c, 2 * c)))
         return self._prep.get(key, build)
+
+    def _bn_eval(self):
+        bn = self.mlp[1]
+        key = pack.versions(*_bn_tensors(bn)) + (bn.eps,)
+        htp = (2 * self.dim // 16 + 1) // 2 * 2
+
+        def build():
+            sc, sh = pack.bn_scale_shift(bn)
+            return pack.pad_to(sc, 16 * htp), pack.pad_to(sh, 16 * htp)
+        return self._prep_bn.get(key, build)
 
     def forward(self, x):
         pr = _probe(x, x.shape)
         if pr is not None:
             return pr
         ops.require_cuda(x, "MLPBlock")
-        _no_train(self, "MLPBlock")
         x = ops.nhwc(x)
         n, c, h, w = x.shape
-        wp, w1, w2, sc, sh = self._packed()
+        wp, w1, w2 = self._weights()
+        if self.training:
+            _no_grad_needed(x, "MLPBlock")
+            htp = (2 * c // 16 + 1) // 2 * 2
+            stats = torch.zeros(2 * 16 * htp, dtype=torch.float32, device=x.device)
+            ops.mlpblock(x, None, n, h, w, c, wp, w1, w2, None, None, stats=stats)         # statistics pass (no store)
+            sc, sh = ops.bn_batch_affine(self.mlp[1], stats[:2 * c], stats[16 * htp:16 * htp + 2 * c], n * h * w)
+            sc, sh = pack.pad_to(sc, 16 * htp), pack.pad_to(sh, 16 * htp)
+        else:
+            sc, sh = self._bn_eval()
         y = ops.empty_nhwc(n, c, h, w, x)
         ops.mlpblock(x, y, n, h, w, c, wp, w1, w2, sc, sh)
         return y
@@ -219,48 +245,64 @@ class _PatchConv(nn.Module):
         self.norm = norm_layer(cout) if norm_layer is not None else nn.Identity()
         self.k, self.cin, self.cout = k, cin, cout
         self._prep = _Prepared()
+        self._prep_bn = _Prepared()
 
-    def _packed(self, nchw):
+    def _weights(self, nchw):
         conv = getattr(self, self._conv_name)
-        bn = getattr(self, "norm", None)
-        has_bn = isinstance(bn, nn.BatchNorm2d)
-        key = pack.versions(conv.weight, conv.bias, *(_bn_tensors(bn) if has_bn else ())) + (nchw, bn.eps if has_bn else 0)
+        key = pack.versions(conv.weight) + (nchw,)
 
         def build():
             w = conv.weight.detach()
             co = w.shape[0]
-            wm = w.reshape(co, -1) if nchw else w.permute(0, 2, 3, 1).reshape(co, -1)
-            if has_bn:
-                sc, sh = pack.bn_scale_shift(bn, conv.bias)
-            else:
-                sc, sh = None, (conv.bias.detach().float().contiguous() if conv.bias is not None else None)
-            return pack.frag_pack3(wm), sc, sh
+            return pack.frag_pack3(w.reshape(co, -1) if nchw else w.permute(0, 2, 3, 1).reshape(co, -1))
         return self._prep.get(key, build)
+
+    def _affine_eval(self):
+        conv = getattr(self, self._conv_name)
+        bn = getattr(self, "norm", None)
+        has_bn = isinstance(bn, nn.BatchNorm2d)
+        key = pack.versions(conv.bias, *(_bn_tensors(bn) if has_bn else ())) + (bn.eps if has_bn else 0,)
+
+        def build():
+            if has_bn:
+                return pack.bn_scale_shift(bn, conv.bias)
+            return None, (conv.bias.detach().float().contiguous() if conv.bias is not None else None)
+        return self._prep_bn.get(key, build)
 
     def forward(self, x):
         pr = _probe(x, (x.shape[0], self.cout, x.shape[2] // self.k, x.shape[3] // self.k))
         if pr is not None:
             return pr
         ops.require_cuda(x, type(self).__name__)
-        _no_train(self, type(self).__name__)
         n, c, h, w = x.shape
         k = self.k
         ho, wo = h // k, w // k
-        out = ops.empty_nhwc(n, self.cout, ho, wo, x)
         if c % 4 == 0:
             xr, ld = ops.rows(x)
             if ld != c:
                 xr, ld = ops.nhwc(x.contiguous()), c
-            wp, sc, sh = self._packed(False)
-            ops.gemm(M=n * ho * wo, H=ho, W=wo, K=k * k * c, N=self.cout, a0=xr, lda0=c, k0=k * k * c, wp=wp, out=out,
-                     ldo=self.cout, gather=ops.GATHER_PATCH, Hin=h, Win=w, Cin=c, ks=k, pk=k * c, e_scale=sc, e_shift=sh)
+            kw = dict(M=n * ho * wo, H=ho, W=wo, K=k * k * c, N=self.cout, a0=xr, lda0=c, k0=k * k * c, wp=self._weights(False),
+                      ldo=self.cout, gather=ops.GATHER_PATCH, Hin=h, Win=w, Cin=c, ks=k, pk=k * c)
         else:
             if k != 4 or w % 4 != 0:
                 raise NotImplementedError("HIP patch embedding of an NCHW image needs patch_size 4 and W % 4 == 0")
             xr = x.contiguous()                     # NCHW image
-            wp, sc, sh = self._packed(True)
-            ops.gemm(M=n * ho * wo, H=ho, W=wo, K=16 * c, N=self.cout, a0=xr, lda0=0, k0=16 * c, wp=wp, out=out, ldo=self.cout,
-                     gather=ops.GATHER_PATCH_NCHW, Hin=h, Win=w, Cin=c, ks=4, pk=0, e_scale=sc, e_shift=sh)
+            kw = dict(M=n * ho * wo, H=ho, W=wo, K=16 * c, N=self.cout, a0=xr, lda0=0, k0=16 * c, wp=self._weights(True),
+                      ldo=self.cout, gather=ops.GATHER_PATCH_NCHW, Hin=h, Win=w, Cin=c, ks=4, pk=0)
+        bn = getattr(self, "norm", None)
+        if self.training and isinstance(bn, nn.BatchNorm2d):
+            _no_grad_needed(x, type(self).__name__)
+            conv = getattr(self, self._conv_name)
+            bias = conv.bias.detach().float().contiguous() if conv.bias is not None else None
+            stats = torch.zeros(2 * self.cout, dtype=torch.float32, device=x.device)
+            ops.gemm(out=None, e_scale=None, e_shift=bias, stats=stats, **kw)                  # statistics pass
+            sc, sh = ops.bn_batch_affine(bn, stats[:self.cout], stats[self.cout:], n * ho * wo)
+            if bias is not None:
+                sh = sh + bias * sc
+        else:
+            sc, sh = self._affine_eval()
+        out = ops.empty_nhwc(n, self.cout, ho, wo, x)
+        ops.gemm(out=out, e_scale=sc, e_shift=sh, **kw)
         return out
 
     def fuseforward(self, x):
@@ -306,20 +348,41 @@ class Conv(nn.Module):
         self.act = self.default_act if act is True else act if isinstance(act, nn.Module) else nn.Identity()
         self.k, self.c1, self.c2 = k, c1, c2
         self._prep = _Prepared()
+        self._prep_bn = _Prepared()
 
-    def packed(self):
-        conv, bn = self.conv, getattr(self, "bn", None)
-        key = pack.versions(conv.weight, conv.bias, *(_bn_tensors(bn) if bn is not None else ())) + (bn.eps if bn is not None else 0,)
+    def weights(self):
+        conv = self.conv
+        key = pack.versions(conv.weight)
 
         def build():
             w = conv.weight.detach()
-            wm = w.view(self.c2, self.c1) if self.k == 1 else pack.conv_taps_matrix(w, 32)
-            if bn is not None:
-                sc, sh = pack.bn_scale_shift(bn, conv.bias)
-            else:
-                sc, sh = None, (conv.bias.detach().float().contiguous() if conv.bias is not None else None)
-            return pack.frag_pack3(wm), sc, sh
+            return pack.frag_pack3(w.view(self.c2, self.c1) if self.k == 1 else pack.conv_taps_matrix(w, 32))
         return self._prep.get(key, build)
+
+    def affine_eval(self):
+        conv, bn = self.conv, getattr(self, "bn", None)
+        key = pack.versions(conv.bias, *(_bn_tensors(bn) if bn is not None else ())) + (bn.eps if bn is not None else 0,)
+
+        def build():
+            if bn is not None:
+                return pack.bn_scale_shift(bn, conv.bias)
+            return None, (conv.bias.detach().float().contiguous() if conv.bias is not None else None)
+        return self._prep_bn.get(key, build)
+
+    def packed(self):
+        sc, sh = self.affine_eval()
+        return self.weights(), sc, sh
+
+    def _run(self, x, sc, sh, act, stats=None):
+        wp = self.weights()
+        if self.k == 1:
+            return _run_pointwise(x, wp, self.c2, sc, sh, act, stats=stats)
+        xr, ld = ops.rows(x)
+        n, c, h, w = xr.shape
+        out = None if stats is not None else ops.empty_nhwc(n, self.c2, h, w, xr)
+        ops.conv3x3(M=n * h * w, H=h, W=w, Cin=c, N=self.c2, x=xr, ldx=ld, wp=wp, out=out, ldo=self.c2, e_scale=sc, e_shift=sh, act=act,
+                    stats=stats)
+        return out
 
     def forward(self, x):
         pr = _probe(x, (x.shape[0], self.c2, x.shape[2], x.shape[3])) if isinstance(x, torch.Tensor) else None
@@ -327,18 +390,23 @@ class Conv(nn.Module):
             return pr
         if not isinstance(x, Lazy):
             ops.require_cuda(x, "Conv")
-        _no_train(self, "Conv")
-        wp, sc, sh = self.packed()
-        act = _act_code(self.act)
-        if self.k == 1:
-            return _run_pointwise(x, wp, self.c2, sc, sh, act)
-        if isinstance(x, Lazy):
+        if self.k == 3 and isinstance(x, Lazy):
             x = x.materialize()
-        xr, ld = ops.rows(x)
-        n, c, h, w = xr.shape
-        out = ops.empty_nhwc(n, self.c2, h, w, xr)
-        ops.conv3x3(M=n * h * w, H=h, W=w, Cin=c, N=self.c2, x=xr, ldx=ld, wp=wp, out=out, ldo=self.c2, e_scale=sc, e_shift=sh, act=act)
-        return out
+        act = _act_code(self.act)
+        bn = getattr(self, "bn", None)
+        if self.training and bn is not None:
+            _no_grad_needed(x, "Conv")
+            L = Lazy.of(x)
+            n, _, h, w = L.shape
+            bias = self.conv.bias.detach().float().contiguous() if self.conv.bias is not None else None
+            stats = torch.zeros(2 * self.c2, dtype=torch.float32, device=L.a0.device)
+            self._run(x, None, bias, ACT_NONE, stats=stats)                                   # statistics pass
+            sc, sh = ops.bn_batch_affine(bn, stats[:self.c2], stats[self.c2:], n * h * w)
+            if bias is not None:
+                sh = sh + bias * sc
+        else:
+            sc, sh = self.affine_eval()
+        return self._run(x, sc, sh, act)
 
     def forward_fuse(self, x):
         return self.forward(x)
@@ -412,27 +480,56 @@ class RFCBAMConv(nn.Module):
         if pr is not None:
             return pr
         ops.require_cuda(x, "RFCBAMConv")
-        _no_train(self, "RFCBAMConv")
+        if self.training:
+            _no_grad_needed(x, "RFCBAMConv")
         xr, ld = ops.rows(x)
         n, c, h, w = xr.shape
         k, s = self.kernel_size, self.stride
         P = self._packed()
         ca = self.se.attention(xr, ld, n, h * w, c)
         if k == 1:
-            mm = ops.rfcbam_stats(xr, ld, n, h, w, c, 1, 1, a1=P["a1"], b1=P["b1"])
+            a1, b1, es, eb = P["a1"], P["b1"], P["es"], P["eb"]
+            if self.training:
+                # generate = per-channel scale g_c followed by BatchNorm over (n, h, w): its batch statistics follow
+                # from the per-channel moments of x:  mean = g*E[x],  E[a^2] = g^2 * E[x^2]
+                gwv = self.generate[0].weight.detach().float().view(c)
+                mom = ops.chan_moments(xr, ld, n * h * w, c)
+                gs, gb = ops.bn_batch_affine(self.generate[1], gwv * mom[:c], gwv * gwv * mom[c:], n * h * w)
+                a1, b1 = (gwv * gs).contiguous(), gb
+            mm = ops.rfcbam_stats(xr, ld, n, h, w, c, 1, 1, a1=a1, b1=b1)
             rfa = ops.rfa_map(mm, P["w18"])
+            kw = dict(M=n * h * w, H=h, W=w, K=c, N=self.o, a0=xr, lda0=ld, k0=c, wp=P["wp"], ldo=self.o, pro=ops.PRO_AFFINE_RELU_CA,
+                      p_scale=a1, p_shift=b1, p_ca=ca, rowscale=rfa)
+            if self.training:
+                bias = self.conv[0].bias.detach().float().contiguous()
+                stats = torch.zeros(2 * self.o, dtype=torch.float32, device=xr.device)
+                ops.gemm(out=None, e_scale=None, e_shift=bias, stats=stats, **kw)               # conv.1 BatchNorm statistics pass
+                es, t = ops.bn_batch_affine(self.conv[1], stats[:self.o], stats[self.o:], n * h * w)
+                eb = (bias * es + t).contiguous()
             out = ops.empty_nhwc(n, self.o, h, w, xr)
-            ops.gemm(M=n * h * w, H=h, W=w, K=c, N=self.o, a0=xr, lda0=ld, k0=c, wp=P["wp"], out=out, ldo=self.o,
-                     pro=ops.PRO_AFFINE_RELU_CA, p_scale=P["a1"], p_shift=P["b1"], p_ca=ca, rowscale=rfa, e_scale=P["es"],
-                     e_shift=P["eb"], act=ACT_RELU)
+            ops.gemm(out=out, e_scale=es, e_shift=eb, act=ACT_RELU, **kw)
             return out
         ho, wo = (h + 2 - 3) // s + 1, (w + 2 - 3) // s + 1
         th, tw = ops.pick_tile(ho, wo)
-        mm = ops.rfcbam_stats(xr, ld, n, h, w, c, 3, s, wg=P["wq_stats"], th=th, tw=tw)
+        wq_stats, wq_main, es, eb = P["wq_stats"], P["wq_main"], P["es"], P["eb"]
+        if self.training:
+            gw = self.generate[0].weight
+            s1, s2, cnt = ops.rfcbam_generate_stats(xr, ld, n, h, w, c, s, gw)                # generate.1 batch statistics
+            gs, gb = ops.bn_batch_affine(self.generate[1], s1, s2, cnt)
+            wq_stats = pack.rfcbam_gen_weights(gw, gs, gb, 32, False)
+            wq_main = pack.rfcbam_gen_weights(gw, gs, gb, 16, True)
+        mm = ops.rfcbam_stats(xr, ld, n, h, w, c, 3, s, wg=wq_stats, th=th, tw=tw)
         rfa = ops.rfa_map(mm, P["w18"])
+        kw = dict(n=n, h=h, w=w, c=c, ho=ho, wo=wo, N=self.o, s=s, th=th, tw=tw, x=xr, ldx=ld, wg=wq_main, ca=ca, rfa=rfa, wp=P["wp"],
+                  ldo=self.o)
+        if self.training:
+            bias = self.conv[0].bias.detach().float().contiguous()
+            stats = torch.zeros(2 * self.o, dtype=torch.float32, device=xr.device)
+            ops.rfcbam3(out=None, e_scale=torch.ones_like(bias), e_shift=bias, stats=stats, **kw)   # conv.1 statistics pass
+            es, t = ops.bn_batch_affine(self.conv[1], stats[:self.o], stats[self.o:], n * ho * wo)
+            eb = (bias * es + t).contiguous()
         out = ops.empty_nhwc(n, self.o, ho, wo, xr)
-        ops.rfcbam3(n=n, h=h, w=w, c=c, ho=ho, wo=wo, N=self.o, s=s, th=th, tw=tw, x=xr, ldx=ld, wg=P["wq_main"], ca=ca, rfa=rfa,
-                    wp=P["wp"], e_scale=P["es"], e_shift=P["eb"], out=out, ldo=self.o)
+        ops.rfcbam3(out=out, e_scale=es, e_shift=eb, **kw)
         return out
 
 
@@ -466,22 +563,34 @@ class CoordAtt(nn.Module):
         self.conv_w = nn.Conv2d(mip, oup, kernel_size=1, stride=1, padding=0)
         self.mip, self.c = mip, inp
         self._prep = _Prepared()
+        self._prep_bn = _Prepared()
 
-    def _packed(self):
-        key = pack.versions(self.conv1.weight, self.conv1.bias, *_bn_tensors(self.bn1), self.conv_h.weight, self.conv_h.bias,
-                            self.conv_w.weight, self.conv_w.bias) + (self.bn1.eps,)
+    def _weights(self):
+        key = pack.versions(self.conv1.weight, self.conv1.bias, self.conv_h.weight, self.conv_h.bias, self.conv_w.weight, self.conv_w.bias)
+
+        def build():
+            f = lambda p: p.detach().float().reshape(p.shape[0], -1).contiguous()
+            return (f(self.conv1.weight), self.conv1.bias.detach().float().contiguous(), f(self.conv_h.weight),
+                    self.conv_h.bias.detach().float().contiguous(), f(self.conv_w.weight), self.conv_w.bias.detach().float().contiguous())
+        return self._prep.get(key, build)
+
+    def _conv1_eval(self):
+        key = pack.versions(self.conv1.weight, self.conv1.bias, *_bn_tensors(self.bn1)) + (self.bn1.eps,)
 
         def build():
             s, t = pack.bn_scale_shift(self.bn1, self.conv1.bias)
-            w1 = (self.conv1.weight.detach().float().view(self.mip, self.c) * s.view(-1, 1)).contiguous()
-            f = lambda p: p.detach().float().reshape(p.shape[0], -1).contiguous()
-            return (w1, t, f(self.conv_h.weight), self.conv_h.bias.detach().float().contiguous(), f(self.conv_w.weight),
-                    self.conv_w.bias.detach().float().contiguous())
-        return self._prep.get(key, build)
+            return (self.conv1.weight.detach().float().view(self.mip, self.c) * s.view(-1, 1)).contiguous(), t
+        return self._prep_bn.get(key, build)
 
     def attention(self, xr, ld, n, h, w, c):
-        w1, b1, wh, bh, ww, bw = self._packed()
+        w1raw, b1raw, wh, bh, ww, bw = self._weights()
         pool = ops.pool_hw(xr, ld, n, h, w, c)
+        if self.training:
+            st = ops.coordatt_conv1_stats(pool, n * (h + w), c, self.mip, w1raw, b1raw)       # bn1 batch statistics
+            sc, sh = ops.bn_batch_affine(self.bn1, st[:self.mip], st[self.mip:], n * (h + w))
+            w1, b1 = (w1raw * sc.view(-1, 1)).contiguous(), (b1raw * sc + sh).contiguous()
+        else:
+            w1, b1 = self._conv1_eval()
         return ops.coordatt_mlp(pool, n, h, w, c, self.mip, w1, b1, wh, bh, ww, bw)
 
     def forward(self, x):
@@ -489,7 +598,8 @@ class CoordAtt(nn.Module):
         if pr is not None:
             return pr
         ops.require_cuda(x, "CoordAtt")
-        _no_train(self, "CoordAtt")
+        if self.training:
+            _no_grad_needed(x, "CoordAtt")
         xr, ld = ops.rows(x)
         n, c, h, w = xr.shape
         a_h, a_w = self.attention(xr, ld, n, h, w, c)
@@ -526,7 +636,6 @@ class CA_Bottleneck(nn.Module):
             return pr
         if not isinstance(x, Lazy):
             ops.require_cuda(x, "CA_Bottleneck")
-        _no_train(self, "CA_Bottleneck")
         y = self.forward_lazy(x)
         return y.materialize() if isinstance(y, Lazy) else y
 
@@ -541,27 +650,31 @@ class C3_CA(nn.Module):
         self.m = nn.Sequential(*(CA_Bottleneck(c_, c_, shortcut, g, e=1.0) for _ in range(n)))
         self.c_, self.c2 = c_, c2
         self._prep = _Prepared()
+        self._prep_bn = _Prepared()
 
-    def _packed12(self):
+    def _weights12(self):
         """cv1 and cv2 read the same input: one GEMM with stacked weights writes [cv1 | cv2] side by side,
         which is also exactly where the later concat wants cv2's output."""
         p1, p2 = self.cv1, self.cv2
+        key = pack.versions(p1.conv.weight, p2.conv.weight)
+        return self._prep.get(key, lambda: pack.frag_pack3(torch.cat((p1.conv.weight.detach().view(self.c_, -1),
+                                                                       p2.conv.weight.detach().view(self.c_, -1)), 0)))
+
+    def _affine12_eval(self):
+        p1, p2 = self.cv1, self.cv2
         b1, b2 = getattr(p1, "bn", None), getattr(p2, "bn", None)
-        key = pack.versions(p1.conv.weight, p2.conv.weight, p1.conv.bias, p2.conv.bias,
-                            *(_bn_tensors(b1) if b1 is not None else ()), *(_bn_tensors(b2) if b2 is not None else ()))
+        key = pack.versions(p1.conv.bias, p2.conv.bias, *(_bn_tensors(b1) if b1 is not None else ()),
+                            *(_bn_tensors(b2) if b2 is not None else ()))
 
         def build():
-            w = torch.cat((p1.conv.weight.detach().view(self.c_, -1), p2.conv.weight.detach().view(self.c_, -1)), 0)
             parts = []
             for p, b in ((p1, b1), (p2, b2)):
                 if b is not None:
                     parts.append(pack.bn_scale_shift(b, p.conv.bias))
                 else:
-                    parts.append((torch.ones(self.c_, device=w.device), p.conv.bias.detach().float()))
-            sc = torch.cat((parts[0][0], parts[1][0])).contiguous()
-            sh = torch.cat((parts[0][1], parts[1][1])).contiguous()
-            return pack.frag_pack3(w), sc, sh
-        return self._prep.get(key, build)
+                    parts.append((torch.ones(self.c_, device=p.conv.weight.device), p.conv.bias.detach().float()))
+            return torch.cat((parts[0][0], parts[1][0])).contiguous(), torch.cat((parts[0][1], parts[1][1])).contiguous()
+        return self._prep_bn.get(key, build)
 
     def forward(self, x):
         pr = _probe(x, (x.shape[0], self.c2, x.shape[2], x.shape[3])) if isinstance(x, torch.Tensor) else None
@@ -569,13 +682,23 @@ class C3_CA(nn.Module):
             return pr
         if not isinstance(x, Lazy):
             ops.require_cuda(x, "C3_CA")
-        _no_train(self, "C3_CA")
         src = Lazy.of(x)
         n, c, h, w = src.shape
         c_ = self.c_
         if _act_code(self.cv1.act) != _act_code(self.cv2.act):
             raise NotImplementedError("C3_CA: cv1 and cv2 must share one activation")
-        wp, sc, sh = self._packed12()
+        wp = self._weights12()
+        b1, b2 = getattr(self.cv1, "bn", None), getattr(self.cv2, "bn", None)
+        if self.training and b1 is not None and b2 is not None:
+            _no_grad_needed(x, "C3_CA")
+            stats = torch.zeros(4 * c_, dtype=torch.float32, device=src.a0.device)
+            _run_pointwise(src, wp, 2 * c_, None, None, ACT_NONE, stats=stats)                  # statistics pass, both halves
+            s1, s2 = stats[:2 * c_], stats[2 * c_:]
+            sa, ta = ops.bn_batch_affine(b1, s1[:c_], s2[:c_], n * h * w)
+            sb, tb = ops.bn_batch_affine(b2, s1[c_:], s2[c_:], n * h * w)
+            sc, sh = torch.cat((sa, sb)).contiguous(), torch.cat((ta, tb)).contiguous()
+        else:
+            sc, sh = self._affine12_eval()
         ycat = ops.empty_nhwc(n, 2 * c_, h, w, src.a0)
         _run_pointwise(src, wp, 2 * c_, sc, sh, _act_code(self.cv1.act), out=ycat, ldo=2 * c_)
         cur = Lazy((n, c_, h, w), ycat, 2 * c_, c_, keep=(ycat,))
@@ -583,8 +706,7 @@ class C3_CA(nn.Module):
             cur = Lazy.of(blk.forward_lazy(cur))
         right = ycat[:, c_:]
         both = Lazy((n, 2 * c_, h, w), cur.a0, cur.lda0, c_, a1=right, lda1=2 * c_, gate=cur.gate, keep=cur.keep + (ycat,))
-        wp3, sc3, sh3 = self.cv3.packed()
-        return _run_pointwise(both, wp3, self.c2, sc3, sh3, _act_code(self.cv3.act))
+        return self.cv3(both)
 
 
 # --------------------------------------------------------------------------------------------------

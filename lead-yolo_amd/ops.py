@@ -107,18 +107,18 @@ def _p(t):
 
 def gemm(*, M, H, W, K, N, a0, lda0, k0, wp, out, ldo, a1=None, lda1=0, gather=GATHER_ROWS, Hin=0, Win=0, Cin=0, ks=0, pk=0,
          pro=PRO_NONE, g_h=None, g_w=None, res=None, ldres=0, p_scale=None, p_shift=None, p_ca=None, e_scale=None,
-         e_shift=None, rowscale=None, act=ACT_NONE):
+         e_shift=None, rowscale=None, act=ACT_NONE, stats=None):
     P = capi.LyGemmParams(M, H, W, K, N, _p(a0), lda0, k0, _p(a1), lda1, gather, Hin, Win, Cin, ks, pk, pro, _p(g_h), _p(g_w),
                           _p(res), ldres, _p(p_scale), _p(p_shift), _p(p_ca), _p(wp), _p(e_scale), _p(e_shift), _p(rowscale),
-                          act, _p(out), ldo)
+                          act, _p(out), ldo, _p(stats))
     nt, mt, wc = gemm_config(N)
     with _Timed(f"ly_gemm_kernel<{nt}, {mt}, {wc}, {gather}, {pro}>", 2.0 * M * K * N, 4.0 * (M * (K + N) + N * K)):
         capi.check(capi.lib().ly_gemm_fwd(ctypes.byref(P), capi.stream_ptr()), "ly_gemm_fwd")
 
 
-def conv3x3(*, M, H, W, Cin, N, x, ldx, wp, out, ldo, e_scale=None, e_shift=None, act=ACT_NONE):
+def conv3x3(*, M, H, W, Cin, N, x, ldx, wp, out, ldo, e_scale=None, e_shift=None, act=ACT_NONE, stats=None):
     th, tw = pick_conv_tile(H, W)
-    P = capi.LyConv3Params(M, H, W, Cin, N, th, tw, _p(x), ldx, _p(wp), _p(e_scale), _p(e_shift), act, _p(out), ldo)
+    P = capi.LyConv3Params(M, H, W, Cin, N, th, tw, _p(x), ldx, _p(wp), _p(e_scale), _p(e_shift), act, _p(out), ldo, _p(stats))
     mt, wc = (2, 4) if N > 64 else (2, 2)
     with _Timed(f"ly_conv3x3_kernel<{mt}, {wc}>", 2.0 * M * 9 * Cin * N, 4.0 * (M * (Cin + N) + 9 * Cin * N)):
         capi.check(capi.lib().ly_conv3x3_fwd(ctypes.byref(P), capi.stream_ptr()), "ly_conv3x3_fwd")
@@ -189,9 +189,9 @@ def rfa_map(mm, w18):
     return rfa
 
 
-def rfcbam3(*, n, h, w, c, ho, wo, N, s, th, tw, x, ldx, wg, ca, rfa, wp, e_scale, e_shift, out, ldo):
+def rfcbam3(*, n, h, w, c, ho, wo, N, s, th, tw, x, ldx, wg, ca, rfa, wp, e_scale, e_shift, out, ldo, stats=None):
     P = capi.LyRfcbam3Params(n, h, w, c, ho, wo, N, s, th, tw, _p(x), ldx, _p(wg), _p(ca), _p(rfa), _p(wp), _p(e_scale),
-                             _p(e_shift), _p(out), ldo)
+                             _p(e_shift), _p(out), ldo, _p(stats))
     mt = 4 if N > 128 else 2 if N > 64 else 1
     mo = n * ho * wo
     with _Timed(f"ly_rfcbam3_kernel<{mt}>", 2.0 * mo * (9 * c * N + 81 * c), 4.0 * (n * h * w * c + mo * N + 9 * c * N)):
@@ -211,10 +211,63 @@ def detect_tail(y, ldy, n, h, w, na, no, anchors, stride, p, z, zrows, zoff):
                                          capi.stream_ptr()), "ly_detect_tail")
 
 
-def mlpblock(x, y, n, h, w, c, wp, w1, w2, sc, sh):
+def mlpblock(x, y, n, h, w, c, wp, w1, w2, sc, sh, stats=None):
     m = n * h * w
     cc, nt, ht, t2d = mlp_config(c, m, w)
     with _Timed(f"ly_mlpblock_fwd_kernel<{cc}, {nt}, {ht}, {t2d}>", 2.0 * m * (9 * (c // 4) ** 2 + 4 * c * c),
                 4.0 * (2 * m * c + 9 * (c // 4) ** 2 + 4 * c * c)):
-        capi.check(capi.lib().ly_mlpblock_fwd(_p(x), _p(y), n, h, w, c, _p(wp), _p(w1), _p(w2), _p(sc), _p(sh), capi.stream_ptr()),
+        capi.check(capi.lib().ly_mlpblock_fwd(_p(x), _p(y), n, h, w, c, _p(wp), _p(w1), _p(w2), _p(sc), _p(sh), _p(stats), capi.stream_ptr()),
                    "ly_mlpblock_fwd")
+
+
+def chan_moments(x, ldx, rows, c):
+    mom = torch.zeros(2 * c, dtype=torch.float32, device=x.device)
+    capi.check(capi.lib().ly_chan_moments(_p(x), ldx, rows, c, _p(mom), capi.stream_ptr()), "ly_chan_moments")
+    return mom
+
+
+def coordatt_conv1_stats(pool, positions, c, mip, w1, b1):
+    st = torch.zeros(2 * mip, dtype=torch.float32, device=pool.device)
+    capi.check(capi.lib().ly_coordatt_conv1_stats(_p(pool), positions, c, mip, _p(w1), _p(b1), _p(st), capi.stream_ptr()),
+               "ly_coordatt_conv1_stats")
+    return st
+
+
+def bn_batch_affine(bn, s1, s2, count):
+    """Train-mode BatchNorm from per-channel sums: returns (scale, shift) of y = x*scale + shift with the
+    BATCH statistics (biased variance), and updates running_mean / running_var (unbiased, momentum) and
+    num_batches_tracked in place exactly as nn.BatchNorm2d does.  Device tensors only, no host sync."""
+    with torch.no_grad():
+        mean = s1 / count
+        var = (s2 / count - mean * mean).clamp_(min=0.0)
+        scale = bn.weight.detach().float() / torch.sqrt(var + bn.eps)
+        shift = bn.bias.detach().float() - mean * scale
+        if bn.track_running_stats and bn.running_mean is not None:
+            mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
+            bn.running_mean.mul_(1.0 - mom).add_(mean, alpha=mom)
+            bn.running_var.mul_(1.0 - mom).add_(var * (count / max(count - 1, 1)), alpha=mom)
+            bn.num_batches_tracked += 1
+    return scale.contiguous(), shift.contiguous()
+
+
+_TRIU = None
+
+
+def rfcbam_generate_stats(x, ldx, n, h, w, c, s, gen_w):
+    """Batch statistics of the k=3 `generate` BatchNorm input: returns (sum a, sum a^2) per generate channel
+    (c*9 + t) and the sample count, from the per-channel tap moments (see ly_rfcbam_tap_moments)."""
+    global _TRIU
+    mom = torch.zeros(54, c, dtype=torch.float32, device=x.device)
+    capi.check(capi.lib().ly_rfcbam_tap_moments(_p(x), ldx, n, h, w, c, s, _p(mom), capi.stream_ptr()), "ly_rfcbam_tap_moments")
+    if _TRIU is None or _TRIU[0].device != x.device:
+        iu = torch.triu_indices(9, 9, device=x.device)
+        _TRIU = (iu[0], iu[1])
+    m1 = mom[:9].t()                                            # [c, 9]
+    M = torch.zeros(c, 9, 9, dtype=torch.float32, device=x.device)
+    M[:, _TRIU[0], _TRIU[1]] = mom[9:].t()
+    M = M + M.transpose(1, 2) - torch.diag_embed(torch.diagonal(M, dim1=1, dim2=2))
+    wv = gen_w.detach().float().view(c, 9, 9)                  # [c, t, u]
+    s1 = torch.einsum("ctu,cu->ct", wv, m1)
+    s2 = torch.einsum("ctu,cuv,ctv->ct", wv, M, wv)
+    ho, wo = (h + 2 - 3) // s + 1, (w + 2 - 3) // s + 1
+    return s1.reshape(-1), s2.reshape(-1), n * ho * wo

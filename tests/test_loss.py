@@ -31,7 +31,15 @@ def _run(case, device):
     np.testing.assert_allclose(items.cpu().numpy(), arr[f"{case}_items"], rtol=2e-5, atol=1e-6)
     loss.backward()
     for i in range(3):
-        np.testing.assert_allclose(preds[i].grad.cpu().numpy(), arr[f"{case}_dpred{i}"], rtol=1e-4, atol=1e-6)
+        got, want = preds[i].grad.cpu().numpy(), arr[f"{case}_dpred{i}"]
+        if device.type == "cpu":
+            np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-6)
+        else:
+            # `tobj[b, a, gj, gi] = iou` has duplicate cells (several targets per cell); on a GPU the winner of the
+            # scatter is unordered (as in the reference itself on CUDA), which can move the objectness gradient of
+            # those few cells
+            bad = np.abs(got - want) > 1e-6 + 1e-4 * np.abs(want)
+            assert bad.mean() < 1e-3 and np.abs(got - want).max() < 5e-3, (bad.sum(), np.abs(got - want).max())
 
 
 @pytest.mark.parametrize("case", ["rand", "edge", "empty"])

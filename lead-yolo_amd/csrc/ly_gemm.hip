@@ -182,9 +182,6 @@ __global__ __launch_bounds__(LY_THREADS, LY_GEMM_MINW) void ly_gemm_kernel(const
   const bool vec_ok = (P.ldo & 3) == 0;
   const int act = P.act;
   float* const stats = P.stats;                           // non-NULL: batch-statistics pass (no store)
-  f32x4 st1[MT], st2[MT];
-#pragma unroll
-  for (int t = 0; t < MT; ++t) { st1[t] = zero; st2[t] = zero; }
   float rsv[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) rsv[n] = 1.f;
@@ -281,6 +278,7 @@ __global__ __launch_bounds__(LY_THREADS, LY_GEMM_MINW) void ly_gemm_kernel(const
       const int tt = (by * WC + wc) * MT + t;
       const int c = 16 * tt + 4 * lq;
       if (tt < T && c < P.N && !(dbg & 32)) {
+        f32x4 st1 = zero, st2 = zero;              // statistics pass only: live just inside the epilogue (no register cost in the main loop)
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
           const long gp = p0 + pixgrp + 16 * n + li;
@@ -290,8 +288,8 @@ __global__ __launch_bounds__(LY_THREADS, LY_GEMM_MINW) void ly_gemm_kernel(const
 #pragma unroll
             for (int r = 0; r < 4; ++r) u[r] = acc[t][n][r] * rs * esc[t][r] + esh[t][r];
             if (stats) {                                   // pre-activation value is what BatchNorm normalises
-              st1[t] += u;
-              st2[t] += u * u;
+              st1 += u;
+              st2 += u * u;
               continue;
             }
             const f32x4 v = ly_act4(u, act);
@@ -306,6 +304,7 @@ __global__ __launch_bounds__(LY_THREADS, LY_GEMM_MINW) void ly_gemm_kernel(const
             }
           }
         }
+        if (stats) ly_stats_flush(stats, P.N, c, st1, st2);
       }
 #pragma unroll
       for (int n = 0; n < NT; ++n) acc[t][n] = zero;
@@ -313,13 +312,6 @@ __global__ __launch_bounds__(LY_THREADS, LY_GEMM_MINW) void ly_gemm_kernel(const
     pt += nslots;
     if (pt >= gx) break;
     p0 = (long)pt * BP;
-  }
-  if (stats) {
-#pragma unroll
-    for (int t = 0; t < MT; ++t) {
-      const int tt = (by * WC + wc) * MT + t;
-      if (tt < T) ly_stats_flush(stats, P.N, 16 * tt + 4 * lq, st1[t], st2[t]);
-    }
   }
 }
 

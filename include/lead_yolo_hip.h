@@ -177,6 +177,53 @@ int ly_coordatt_conv1_stats(const float* pool, long positions, int C, int mip, c
  * variance of every (channel, tap-output) follow as w.m and w^T M w on the host.                        */
 int ly_rfcbam_tap_moments(const float* x, int ldx, int n_img, int H, int W, int C, int s, float* mom, void* stream);
 
+/* ---- backward building blocks of the training step (train.py:324 `scaler.scale(loss).backward()`) -------------
+ * Data gradients of 1x1 / 3x3 stride-1 convolutions reuse ly_gemm_fwd / ly_conv3x3_fwd with transposed weights.   */
+
+/* BatchNorm(train)+activation backward over an [rows, C] matrix.  Forward was v = a[c]*u + b[c], y = act(v)
+ * (models/common.py:1906-1907 Conv.forward; :1478-1482 MLPBlock).  With dv = dy * act'(v):
+ *   reduce: sums[c] += sum_r dv, sums[C + c] += sum_r dv*u   (sums zeroed by the caller)
+ *   apply : du = alpha[c]*dv + kappa[c] + lambda[c]*u        (du may alias u or dy)                               */
+int ly_bnact_bwd_reduce(const float* dy, int lddy, const float* u, int ldu, long rows, int C, const float* a, const float* b,
+                        int act, float* sums, void* stream);
+int ly_bnact_bwd_apply(const float* dy, int lddy, const float* u, int ldu, long rows, int C, const float* a, const float* b,
+                       int act, const float* alpha, const float* kappa, const float* lambda, float* du, int lddu, void* stream);
+
+/* Weight gradient of a convolution whose forward read input pixel (ho*stride + ky - pad, wo*stride + kx - pad):
+ *   dw[n][(ky*ks + kx)*Cin + c] += sum_{m = (img, ho, wo)} du[m][n] * x[img, hi, wi, c]      (zero outside the map)
+ * x is an NHWC map (row stride ldx) of Hin x Win pixels, or an NCHW image when nchw != 0, or — when up2 != 0 — a
+ * half-resolution map read through nearest-2x upsampling (Hin, Win are the SOURCE sizes).  dw rows have stride lddw
+ * and must be zeroed by the caller (partial sums of pixel chunks are added atomically).                            */
+typedef struct LyWgradParams {
+  long M;            /* output pixels = n_img * H * W */
+  int H, W;          /* output map */
+  int N;             /* output channels */
+  const float* du; int lddu;
+  const float* x; int ldx;
+  int Hin, Win, Cin;
+  int ks, stride, pad;
+  int nchw, up2;
+  float* dw; int lddw;
+} LyWgradParams;
+int ly_wgrad(const LyWgradParams* p, void* stream);
+
+/* Adjoint of the nearest-2x read: out[n,h,w,:] = sum of d[n, 2h+{0,1}, 2w+{0,1}, :]  (d is a 2Hs x 2Ws map).      */
+int ly_up2_bwd(const float* d, int ldd, int n_img, int Hs, int Ws, int C, float* out, int ldo, void* stream);
+/* Adjoint of the k = s patch gather: g[m][(ky,kx,c)] -> dx[n, ks*ho+ky, ks*wo+kx, c] (dense NHWC, C % 4 == 0).    */
+int ly_unpatch(const float* g, int n_img, int Ho, int Wo, int C, int ks, float* dx, void* stream);
+
+/* CoordAtt backward (models/common.py:1595-1609).  Gate out = x*a_h[n,h,:]*a_w[n,w,:]:
+ *   dx = dout*a_h*a_w,  da_h[n,h,c] = sum_w dout*x*a_w (written),  da_w[n,w,c] += sum_h dout*x*a_h (caller zeroes).
+ * Pools pool[n,0:H]=mean_w x, pool[n,H:H+W]=mean_h x:  dx[n,h,w,c] = gp[n,h,c]/W + gp[n,H+w,c]/H.                  */
+int ly_coordatt_gate_bwd(const float* dout, int ldd, const float* x, int ldx, int n_img, int H, int W, int C, const float* a_h,
+                         const float* a_w, float* dx, int lddx, float* da_h, float* da_w, void* stream);
+int ly_pool_hw_bwd(const float* gp, int n_img, int H, int W, int C, float* dx, int lddx, void* stream);
+/* k x k / stride 1 / pad k//2 max-pool backward (SPPF, models/common.py:348-366): dx[argmax of window] += dy
+ * (first maximum in row-major order, as ATen); dx is ACCUMULATED into, which lets the three chained pools add
+ * into the gradient slots of the SPPF concat buffer in place.                                                       */
+int ly_maxpool_bwd(const float* x, int ldx, const float* dy, int lddy, int n_img, int H, int W, int C, int k, float* dx, int lddx,
+                   void* stream);
+
 #ifdef __cplusplus
 }
 #endif

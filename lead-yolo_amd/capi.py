@@ -38,6 +38,12 @@ class LyRfcbam3Params(ctypes.Structure):
                 ("e_scale", _P), ("e_shift", _P), ("out", _P), ("ldo", _I), ("stats", _P)]
 
 
+class LyWgradParams(ctypes.Structure):
+    _fields_ = [("M", _L), ("H", _I), ("W", _I), ("N", _I), ("du", _P), ("lddu", _I), ("x", _P), ("ldx", _I),
+                ("Hin", _I), ("Win", _I), ("Cin", _I), ("ks", _I), ("stride", _I), ("pad", _I), ("nchw", _I), ("up2", _I),
+                ("dw", _P), ("lddw", _I)]
+
+
 ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
 GATHER_ROWS, GATHER_UP2, GATHER_PATCH, GATHER_PATCH_NCHW = 0, 1, 2, 3
 PRO_NONE, PRO_GATE, PRO_AFFINE_RELU_CA = 0, 1, 2
@@ -68,6 +74,14 @@ SIGNATURES = {
     "ly_rfcbam_tap_moments": [_P, _I, _I, _I, _I, _I, _I, _P, _P],
     "ly_coordatt_conv1_stats": [_P, _L, _I, _I, _P, _P, _P, _P],
     "ly_sppf_pool": [_P, _I, _I, _I, _I, _I, _I, _P, _I, _P],
+    "ly_bnact_bwd_reduce": [_P, _I, _P, _I, _L, _I, _P, _P, _I, _P, _P],
+    "ly_bnact_bwd_apply": [_P, _I, _P, _I, _L, _I, _P, _P, _I, _P, _P, _P, _P, _I, _P],
+    "ly_wgrad": [ctypes.POINTER(LyWgradParams), _P],
+    "ly_up2_bwd": [_P, _I, _I, _I, _I, _I, _P, _I, _P],
+    "ly_unpatch": [_P, _I, _I, _I, _I, _I, _P, _P],
+    "ly_coordatt_gate_bwd": [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P],
+    "ly_pool_hw_bwd": [_P, _I, _I, _I, _I, _P, _I, _P],
+    "ly_maxpool_bwd": [_P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P],
     "ly_detect_tail": [_P, _I, _I, _I, _I, _I, _I, _P, _F, _P, _P, _L, _L, _P],
 }
 

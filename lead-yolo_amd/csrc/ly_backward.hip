@@ -1,0 +1,462 @@
+// Backward building blocks of the training step, fp32 I/O, gfx950.
+//
+//   ly_bnact_bwd_reduce / ly_bnact_bwd_apply   BatchNorm(train) + activation backward on an [rows, C] matrix
+//   ly_wgrad                                   weight gradient: contraction over PIXELS with the forward's gather
+//   ly_up2_bwd, ly_unpatch2                    adjoints of the nearest-2x read and of the k=s=2 patch gather
+//
+// Data gradients (dgrad) of the 1x1 / 3x3 convolutions reuse the forward contraction kernels
+// (ly_gemm_fwd / ly_conv3x3_fwd) with transposed, frag-packed weights: the adjoint of a stride-1
+// convolution is a stride-1 convolution.
+//
+// Replaces what autograd derives for Conv2d -> BatchNorm2d -> SiLU/ReLU in the reference's
+// `scaler.scale(loss).backward()` (train.py:324) over models/common.py:1890-1910 (Conv),
+// :1478-1482 (MLPBlock), :1537-1561 (patch layers).
+#include "ly_tile.cuh"
+#include "ly_params.h"
+
+// -------------------------------------------------------------------------------------------------
+// BN(train)+activation backward.  Forward:  v = a[c]*u + b[c],  y = act(v).
+//   reduce:  s1[c] = sum_r dv,  s2[c] = sum_r dv*u          with dv = dy * act'(v)
+//   apply :  du = alpha[c]*dv + kappa[c] + lambda[c]*u      (coefficients built on the host from s1, s2:
+//            the usual  gamma*invstd*(dv - mean(dv) - xhat*mean(dv*xhat))  written as an affine map of (dv, u))
+// -------------------------------------------------------------------------------------------------
+template <int ACT>
+__device__ __forceinline__ f32x4 ly_dact4(const f32x4 v, const f32x4 dy) {
+  f32x4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (ACT == LY_ACT_RELU) {
+      r[i] = v[i] > 0.f ? dy[i] : 0.f;
+    } else if (ACT == LY_ACT_SILU) {
+      const float s = ly_sigmoid(v[i]);
+      r[i] = dy[i] * s * (1.f + v[i] * (1.f - s));
+    } else {
+      r[i] = dy[i];
+    }
+  }
+  return r;
+}
+
+template <int ACT>
+__global__ __launch_bounds__(LY_THREADS) void ly_bnact_bwd_reduce_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ u,
+                                                                          int ldu, long rows, int C, const float* __restrict__ a,
+                                                                          const float* __restrict__ b, float* __restrict__ sums) {
+  __shared__ f32x4 red1[LY_THREADS], red2[LY_THREADS];
+  const int nc4 = C >> 2, tid = threadIdx.x;
+  const int groups = LY_THREADS / nc4;
+  const int c4 = tid % nc4, j0 = tid / nc4;
+  f32x4 s1 = ly_zero4(), s2 = ly_zero4();
+  if (j0 < groups) {
+    const f32x4 av = ly_ldg4(a + 4 * c4), bv = ly_ldg4(b + 4 * c4);
+    for (long r = (long)blockIdx.x * groups + j0; r < rows; r += (long)gridDim.x * groups) {
+      const f32x4 uu = ly_ldg4(u + r * ldu + 4 * c4);
+      const f32x4 g = ly_ldg4(dy + r * lddy + 4 * c4);
+      const f32x4 dv = ly_dact4<ACT>(av * uu + bv, g);
+      s1 += dv;
+      s2 += dv * uu;
+    }
+  }
+  red1[tid] = s1; red2[tid] = s2;
+  __syncthreads();
+  if (j0 == 0) {
+    for (int g = 1; g < groups; ++g) { s1 += red1[g * nc4 + c4]; s2 += red2[g * nc4 + c4]; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      atomicAdd(sums + 4 * c4 + r, s1[r]);
+      atomicAdd(sums + C + 4 * c4 + r, s2[r]);
+    }
+  }
+}
+
+template <int ACT>
+__global__ __launch_bounds__(LY_THREADS) void ly_bnact_bwd_apply_kernel(const float* __restrict__ dy, int lddy, const float* u, int ldu,
+                                                                         long rows, int C, const float* __restrict__ a,
+                                                                         const float* __restrict__ b, const float* __restrict__ alpha,
+                                                                         const float* __restrict__ kappa, const float* __restrict__ lambda,
+                                                                         float* du, int lddu) {
+  const int nc4 = C >> 2;
+  const long total = rows * nc4;
+  for (long i = (long)blockIdx.x * LY_THREADS + threadIdx.x; i < total; i += (long)gridDim.x * LY_THREADS) {
+    const long r = i / nc4;
+    const int c = 4 * (int)(i - r * nc4);
+    const f32x4 uu = ly_ldg4(u + r * ldu + c);
+    const f32x4 g = ly_ldg4(dy + r * lddy + c);
+    const f32x4 dv = ly_dact4<ACT>(ly_ldg4(a + c) * uu + ly_ldg4(b + c), g);
+    ly_stg4(du + r * lddu + c, ly_ldg4(alpha + c) * dv + ly_ldg4(kappa + c) + ly_ldg4(lambda + c) * uu);
+  }
+}
+
+static long ly_ew_blocks(long items) {
+  long b = (items + LY_THREADS * 4L - 1) / (LY_THREADS * 4L);
+  return b < 1 ? 1 : b > 4096 ? 4096 : b;
+}
+
+extern "C" int ly_bnact_bwd_reduce(const float* dy, int lddy, const float* u, int ldu, long rows, int C, const float* a, const float* b,
+                                   int act, float* sums, void* stream) {
+  LY_CHECK(dy && u && a && b && sums && rows > 0, "bnact_bwd_reduce: null pointer");
+  LY_CHECK((C & 3) == 0 && C > 0 && C <= 1024 && (lddy & 3) == 0 && (ldu & 3) == 0, "bnact_bwd_reduce: C=%d / ld must be multiples of 4", C);
+  const int groups = LY_THREADS / (C >> 2);
+  long blocks = (rows + groups * 32L - 1) / (groups * 32L);
+  blocks = blocks < 1 ? 1 : blocks > 2048 ? 2048 : blocks;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define LY_RED(A) hipLaunchKernelGGL(ly_bnact_bwd_reduce_kernel<A>, dim3((unsigned)blocks), dim3(LY_THREADS), 0, st, dy, lddy, u, ldu, rows, C, a, b, sums)
+  if (act == LY_ACT_SILU) LY_RED(LY_ACT_SILU);
+  else if (act == LY_ACT_RELU) LY_RED(LY_ACT_RELU);
+  else LY_RED(LY_ACT_NONE);
+#undef LY_RED
+  LY_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ly_bnact_bwd_apply(const float* dy, int lddy, const float* u, int ldu, long rows, int C, const float* a, const float* b,
+                                  int act, const float* alpha, const float* kappa, const float* lambda, float* du, int lddu, void* stream) {
+  LY_CHECK(dy && u && a && b && alpha && kappa && lambda && du && rows > 0, "bnact_bwd_apply: null pointer");
+  LY_CHECK((C & 3) == 0 && C > 0 && (lddy & 3) == 0 && (ldu & 3) == 0 && (lddu & 3) == 0, "bnact_bwd_apply: C=%d / ld must be multiples of 4", C);
+  const long blocks = ly_ew_blocks(rows * (C >> 2));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define LY_APP(A) hipLaunchKernelGGL(ly_bnact_bwd_apply_kernel<A>, dim3((unsigned)blocks), dim3(LY_THREADS), 0, st, dy, lddy, u, ldu, rows, C, a, b, alpha, kappa, lambda, du, lddu)
+  if (act == LY_ACT_SILU) LY_APP(LY_ACT_SILU);
+  else if (act == LY_ACT_RELU) LY_APP(LY_ACT_RELU);
+  else LY_APP(LY_ACT_NONE);
+#undef LY_APP
+  LY_LAUNCH_CHECK();
+  return 0;
+}
+
+// -------------------------------------------------------------------------------------------------
+// Weight gradient:  dw[n][tap*Cin + c] += sum_{p in pixels} du[p][n] * X[src(p, tap)][c]
+//
+// The contraction index is the PIXEL, which is the slow index of both operands in memory (NHWC rows), so
+// the MFMA fragments are gathered straight from global memory with per-lane dword loads: lane (i, q) of a
+// 16x16x32 step reads channel (tile*16 + i) of the 8 pixels p0 + 8q + j.  At fixed j the 16 lanes of a
+// quarter-wave read 64 contiguous bytes of one pixel row, so every load instruction moves four full 64-byte
+// segments.  The same per-lane addressing makes the forward's gathers (3x3 taps with zero padding, k=s patch
+// gathers of an NHWC map or an NCHW image, the nearest-2x upsampled read) a pure address computation.
+// bf16x3 products, fp32 accumulation.  Block = 64 x 64 output tile (wave = 32 x 32), grid.y splits the pixels;
+// partial sums are added to dw with float atomics (dw is zeroed by the caller).
+// -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void ly_split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+  bf16x4 h0, l0, h1, l1;
+  ly_split4((f32x4){v[0], v[1], v[2], v[3]}, h0, l0);
+  ly_split4((f32x4){v[4], v[5], v[6], v[7]}, h1, l1);
+  hi = ly_cat8(h0, h1);
+  lo = ly_cat8(l0, l1);
+}
+
+template <bool ROWS>
+__global__ __launch_bounds__(LY_THREADS) void ly_wgrad_kernel(const LyWgradParams P, const int tiles_k, const long chunk_px) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lq = lane >> 4;
+  const int tk = blockIdx.x % tiles_k, tn = blockIdx.x / tiles_k;
+  const int n_base = tn * 64 + (wave & 1) * 32, k_base = tk * 64 + (wave >> 1) * 32;
+  const long p_begin = (long)blockIdx.y * chunk_px;
+  const long p_end = p_begin + chunk_px < P.M ? p_begin + chunk_px : P.M;
+  const int Ktot = P.ks * P.ks * P.Cin;
+
+  int arow[2], bcol[2], ky[2], kx[2], cc[2];
+  bool aok[2], bok[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int r = n_base + 16 * t + li;
+    aok[t] = r < P.N;
+    arow[t] = aok[t] ? r : 0;
+    const int c = k_base + 16 * t + li;
+    bok[t] = c < Ktot;
+    bcol[t] = bok[t] ? c : 0;
+    const int tap = bcol[t] / P.Cin;
+    cc[t] = bcol[t] - tap * P.Cin;
+    ky[t] = tap / P.ks;
+    kx[t] = tap - ky[t] * P.ks;
+  }
+  const int Hv = P.up2 ? 2 * P.Hin : P.Hin, Wv = P.up2 ? 2 * P.Win : P.Win;
+  const float invW = 1.f / (float)P.W, invH = 1.f / (float)P.H;
+
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = ly_zero4();
+
+  for (long p0 = p_begin; p0 < p_end; p0 += 32) {
+    float av[2][8], bv[2][8];
+    const long pf = p0 + 8 * lq;
+    int n_i = 0, ho = 0, wo = 0;
+    if (!ROWS) {
+      const int g = (int)(pf < P.M ? pf : P.M - 1);
+      const int row = ly_fdiv(g, P.W, invW);
+      wo = g - row * P.W;
+      n_i = ly_fdiv(row, P.H, invH);
+      ho = row - n_i * P.H;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const long p = pf + j;
+      const bool pok = p < p_end;
+      const long pc = pok ? p : p_end - 1;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const float v = P.du[pc * P.lddu + arow[t]];
+        av[t][j] = (pok && aok[t]) ? v : 0.f;
+      }
+      if (ROWS) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const float v = P.x[pc * P.ldx + bcol[t]];
+          bv[t][j] = (pok && bok[t]) ? v : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          int hi = ho * P.stride + ky[t] - P.pad, wi = wo * P.stride + kx[t] - P.pad;
+          const bool ok = pok && bok[t] && hi >= 0 && hi < Hv && wi >= 0 && wi < Wv;
+          if (P.up2) { hi >>= 1; wi >>= 1; }
+          long off = P.nchw ? (((long)n_i * P.Cin + cc[t]) * P.Hin + hi) * P.Win + wi
+                            : (((long)n_i * P.Hin + hi) * P.Win + wi) * P.ldx + cc[t];
+          const float v = P.x[ok ? off : 0];
+          bv[t][j] = ok ? v : 0.f;
+        }
+        if (++wo == P.W) { wo = 0; if (++ho == P.H) { ho = 0; ++n_i; } }
+      }
+    }
+    bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      ly_split8(av[t], ah[t], al[t]);
+      ly_split8(bv[t], bh[t], bl[t]);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = ly_mfma3(ah[i], al[i], bh[j], bl[j], acc[i][j]);
+  }
+
+  // D: lane (i = column, q) holds rows 4q + r
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = k_base + 16 * j + li;
+      if (col >= Ktot) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = n_base + 16 * i + 4 * lq + r;
+        if (row < P.N) atomicAdd(P.dw + (long)row * P.lddw + col, acc[i][j][r]);
+      }
+    }
+}
+
+extern "C" int ly_wgrad(const LyWgradParams* p, void* stream) {
+  LY_CHECK(p, "wgrad: null params");
+  const LyWgradParams& P = *p;
+  LY_CHECK(P.du && P.x && P.dw, "wgrad: null pointer");
+  LY_CHECK(P.M > 0 && P.H > 0 && P.W > 0 && P.N > 0 && P.Cin > 0 && P.ks > 0 && P.stride > 0, "wgrad: bad sizes");
+  LY_CHECK(P.M < (1L << 24), "wgrad: M=%ld pixels exceeds the 2^24 limit of the fast index path", P.M);
+  LY_CHECK(P.M % ((long)P.H * P.W) == 0, "wgrad: M is not a whole number of images");
+  const int Ktot = P.ks * P.ks * P.Cin;
+  LY_CHECK(P.lddw >= Ktot, "wgrad: lddw=%d < ks*ks*Cin=%d", P.lddw, Ktot);
+  const bool rows = P.ks == 1 && P.stride == 1 && P.pad == 0 && !P.nchw && !P.up2;
+  if (rows) LY_CHECK(P.Hin == P.H && P.Win == P.W, "wgrad: 1x1 gather needs Hin == H, Win == W");
+  const int tiles_n = (P.N + 63) / 64, tiles_k = (Ktot + 63) / 64;
+  const long tiles = (long)tiles_n * tiles_k;
+  long chunks = (2048 + tiles - 1) / tiles;
+  const long max_chunks = (P.M + 255) / 256;
+  if (chunks > max_chunks) chunks = max_chunks;
+  if (chunks < 1) chunks = 1;
+  long chunk_px = (P.M + chunks - 1) / chunks;
+  chunk_px = (chunk_px + 31) / 32 * 32;
+  chunks = (P.M + chunk_px - 1) / chunk_px;
+  LY_CHECK(chunks < 65536, "wgrad: too many pixel chunks");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)tiles, (unsigned)chunks);
+  if (rows) hipLaunchKernelGGL(ly_wgrad_kernel<true>, grid, dim3(LY_THREADS), 0, st, P, tiles_k, chunk_px);
+  else hipLaunchKernelGGL(ly_wgrad_kernel<false>, grid, dim3(LY_THREADS), 0, st, P, tiles_k, chunk_px);
+  LY_LAUNCH_CHECK();
+  return 0;
+}
+
+// -------------------------------------------------------------------------------------------------
+// Adjoint of the nearest-2x upsampled read (nn.Upsample(2,'nearest'), models/LEAD-YOLO.yaml neck):
+//   dsrc[n, h, w, :] = sum of the four dst pixels (2h+{0,1}, 2w+{0,1})
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(LY_THREADS) void ly_up2_bwd_kernel(const float* __restrict__ d, int ldd, int n_img, int Hs, int Ws, int C,
+                                                                float* __restrict__ o, int ldo) {
+  const int nc4 = C >> 2;
+  const long total = (long)n_img * Hs * Ws * nc4;
+  for (long i = (long)blockIdx.x * LY_THREADS + threadIdx.x; i < total; i += (long)gridDim.x * LY_THREADS) {
+    const long pix = i / nc4;
+    const int c = 4 * (int)(i - pix * nc4);
+    const long row = pix / Ws;
+    const int w = (int)(pix - row * Ws);
+    const long n = row / Hs;
+    const int h = (int)(row - n * Hs);
+    const float* s = d + (((n * 2 * Hs + 2 * h) * 2L * Ws) + 2 * w) * ldd + c;
+    const f32x4 v = ly_ldg4(s) + ly_ldg4(s + ldd) + ly_ldg4(s + 2L * Ws * ldd) + ly_ldg4(s + 2L * Ws * ldd + ldd);
+    ly_stg4(o + pix * ldo + c, v);
+  }
+}
+
+extern "C" int ly_up2_bwd(const float* d, int ldd, int n_img, int Hs, int Ws, int C, float* out, int ldo, void* stream) {
+  LY_CHECK(d && out && n_img > 0 && Hs > 0 && Ws > 0 && (C & 3) == 0 && (ldd & 3) == 0 && (ldo & 3) == 0, "up2_bwd: bad arguments");
+  hipLaunchKernelGGL(ly_up2_bwd_kernel, dim3((unsigned)ly_ew_blocks((long)n_img * Hs * Ws * (C >> 2))), dim3(LY_THREADS), 0,
+                     reinterpret_cast<hipStream_t>(stream), d, ldd, n_img, Hs, Ws, C, out, ldo);
+  LY_LAUNCH_CHECK();
+  return 0;
+}
+
+// -------------------------------------------------------------------------------------------------
+// Adjoint of the k = s = 2 patch gather (PatchMerging_FasterNet, models/common.py:1555-1561): the dgrad GEMM
+// produces g[m = (n, ho, wo)][(ky, kx, c)]; scatter it to dx[n, 2ho+ky, 2wo+kx, c] (every input pixel belongs
+// to exactly one patch).
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(LY_THREADS) void ly_unpatch_kernel(const float* __restrict__ g, int n_img, int Ho, int Wo, int C, int ks,
+                                                                float* __restrict__ dx) {
+  const int nc4 = C >> 2;
+  const int kc = ks * ks * nc4;
+  const long total = (long)n_img * Ho * Wo * kc;
+  for (long i = (long)blockIdx.x * LY_THREADS + threadIdx.x; i < total; i += (long)gridDim.x * LY_THREADS) {
+    const long m = i / kc;
+    int r = (int)(i - m * kc);
+    const int tap = r / nc4;
+    const int c = 4 * (r - tap * nc4);
+    const int ky = tap / ks, kx = tap - ky * ks;
+    const long row = m / Wo;
+    const int wo = (int)(m - row * Wo);
+    const long n = row / Ho;
+    const int ho = (int)(row - n * Ho);
+    const long dst = ((n * Ho * ks + (long)ho * ks + ky) * ((long)Wo * ks) + (long)wo * ks + kx) * C + c;
+    ly_stg4(dx + dst, ly_ldg4(g + m * ((long)ks * ks * C) + (long)tap * C + c));
+  }
+}
+
+extern "C" int ly_unpatch(const float* g, int n_img, int Ho, int Wo, int C, int ks, float* dx, void* stream) {
+  LY_CHECK(g && dx && n_img > 0 && Ho > 0 && Wo > 0 && ks > 0 && (C & 3) == 0, "unpatch: bad arguments");
+  hipLaunchKernelGGL(ly_unpatch_kernel, dim3((unsigned)ly_ew_blocks((long)n_img * Ho * Wo * ks * ks * (C >> 2))), dim3(LY_THREADS), 0,
+                     reinterpret_cast<hipStream_t>(stream), g, n_img, Ho, Wo, C, ks, dx);
+  LY_LAUNCH_CHECK();
+  return 0;
+}
+
+// -------------------------------------------------------------------------------------------------
+// CoordAtt (models/common.py:1595-1609) backward pieces.
+//   gate:  out = x * a_h[n,h,:] * a_w[n,w,:]
+//          dx = dout*a_h*a_w,  da_h[n,h,c] = sum_w dout*x*a_w,  da_w[n,w,c] = sum_h dout*x*a_h
+//   pools: pool[n, 0:H, c] = mean_w x,  pool[n, H:H+W, c] = mean_h x
+//          dx[n,h,w,c] = gp[n,h,c]/W + gp[n,H+w,c]/H
+// One block per (image, row h): da_h is reduced in the block, da_w (zeroed by the caller) by float atomics.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(LY_THREADS) void ly_coordatt_gate_bwd_kernel(const float* __restrict__ dout, int ldd, const float* __restrict__ x,
+                                                                           int ldx, int H, int W, int C, const float* __restrict__ a_h,
+                                                                           const float* __restrict__ a_w, float* __restrict__ dx, int lddx,
+                                                                           float* __restrict__ da_h, float* __restrict__ da_w) {
+  __shared__ f32x4 red[LY_THREADS];
+  const int nc4 = C >> 2, tid = threadIdx.x;
+  const int groups = LY_THREADS / nc4;
+  const int c4 = tid % nc4, g0 = tid / nc4;
+  const long nh = blockIdx.x;                   // n*H + h
+  const long n = nh / H;
+  f32x4 sh = ly_zero4();
+  if (g0 < groups) {
+    const f32x4 ah = ly_ldg4(a_h + nh * C + 4 * c4);
+    for (int w = g0; w < W; w += groups) {
+      const long row = nh * W + w;
+      const f32x4 d = ly_ldg4(dout + row * ldd + 4 * c4);
+      const f32x4 xv = ly_ldg4(x + row * ldx + 4 * c4);
+      const f32x4 aw = ly_ldg4(a_w + (n * W + w) * C + 4 * c4);
+      ly_stg4(dx + row * lddx + 4 * c4, d * ah * aw);
+      const f32x4 t = d * xv;
+      sh += t * aw;
+      const f32x4 tw = t * ah;
+      float* o = da_w + (n * W + w) * C + 4 * c4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(o + r, tw[r]);
+    }
+  }
+  red[tid] = sh;
+  __syncthreads();
+  if (g0 == 0) {
+    for (int g = 1; g < groups; ++g) sh += red[g * nc4 + c4];
+    ly_stg4(da_h + nh * C + 4 * c4, sh);
+  }
+}
+
+extern "C" int ly_coordatt_gate_bwd(const float* dout, int ldd, const float* x, int ldx, int n_img, int H, int W, int C, const float* a_h,
+                                    const float* a_w, float* dx, int lddx, float* da_h, float* da_w, void* stream) {
+  LY_CHECK(dout && x && a_h && a_w && dx && da_h && da_w, "coordatt_gate_bwd: null pointer");
+  LY_CHECK((C & 3) == 0 && C <= 1024 && (ldd & 3) == 0 && (ldx & 3) == 0 && (lddx & 3) == 0, "coordatt_gate_bwd: C / ld must be multiples of 4");
+  hipLaunchKernelGGL(ly_coordatt_gate_bwd_kernel, dim3((unsigned)(n_img * H)), dim3(LY_THREADS), 0, reinterpret_cast<hipStream_t>(stream), dout,
+                     ldd, x, ldx, H, W, C, a_h, a_w, dx, lddx, da_h, da_w);
+  LY_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ __launch_bounds__(LY_THREADS) void ly_pool_hw_bwd_kernel(const float* __restrict__ gp, int n_img, int H, int W, int C,
+                                                                    float* __restrict__ dx, int lddx) {
+  const int nc4 = C >> 2;
+  const long total = (long)n_img * H * W * nc4;
+  const float iw = 1.f / (float)W, ih = 1.f / (float)H;
+  for (long i = (long)blockIdx.x * LY_THREADS + threadIdx.x; i < total; i += (long)gridDim.x * LY_THREADS) {
+    const long pix = i / nc4;
+    const int c = 4 * (int)(i - pix * nc4);
+    const long row = pix / W;
+    const int w = (int)(pix - row * W);
+    const long n = row / H;
+    const int h = (int)(row - n * H);
+    const f32x4 a = ly_ldg4(gp + (n * (H + W) + h) * C + c), b = ly_ldg4(gp + (n * (H + W) + H + w) * C + c);
+    ly_stg4(dx + pix * lddx + c, a * iw + b * ih);
+  }
+}
+
+extern "C" int ly_pool_hw_bwd(const float* gp, int n_img, int H, int W, int C, float* dx, int lddx, void* stream) {
+  LY_CHECK(gp && dx && n_img > 0 && H > 0 && W > 0 && (C & 3) == 0 && (lddx & 3) == 0, "pool_hw_bwd: bad arguments");
+  hipLaunchKernelGGL(ly_pool_hw_bwd_kernel, dim3((unsigned)ly_ew_blocks((long)n_img * H * W * (C >> 2))), dim3(LY_THREADS), 0,
+                     reinterpret_cast<hipStream_t>(stream), gp, n_img, H, W, C, dx, lddx);
+  LY_LAUNCH_CHECK();
+  return 0;
+}
+
+// -------------------------------------------------------------------------------------------------
+// k x k / stride 1 / pad k//2 max-pool backward (SPPF, models/common.py:348-366): for every output position the
+// argmax of its window (first maximum in row-major scan order, as ATen's max_pool2d) is recomputed from x and
+// dy is added there: dx[argmax] += dy.  dx is accumulated into (float atomics), so chained pools can add into
+// the gradient slots of the concat buffer in place.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(LY_THREADS) void ly_maxpool_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dy, int lddy,
+                                                                    int n_img, int H, int W, int C, int k, float* __restrict__ dx, int lddx) {
+  const int nc4 = C >> 2, r = k >> 1;
+  const long total = (long)n_img * H * W * nc4;
+  for (long i = (long)blockIdx.x * LY_THREADS + threadIdx.x; i < total; i += (long)gridDim.x * LY_THREADS) {
+    const long pix = i / nc4;
+    const int c = 4 * (int)(i - pix * nc4);
+    const long row = pix / W;
+    const int w = (int)(pix - row * W);
+    const long n = row / H;
+    const int h = (int)(row - n * H);
+    f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    long arg[4] = {-1, -1, -1, -1};
+    for (int yy = h - r; yy <= h + r; ++yy) {
+      if (yy < 0 || yy >= H) continue;
+      for (int xx = w - r; xx <= w + r; ++xx) {
+        if (xx < 0 || xx >= W) continue;
+        const long q = (n * H + yy) * W + xx;
+        const f32x4 v = ly_ldg4(x + q * ldx + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (v[e] > best[e] || arg[e] < 0) { best[e] = v[e]; arg[e] = q; }
+      }
+    }
+    const f32x4 g = ly_ldg4(dy + pix * lddy + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) atomicAdd(dx + arg[e] * lddx + c + e, g[e]);
+  }
+}
+
+extern "C" int ly_maxpool_bwd(const float* x, int ldx, const float* dy, int lddy, int n_img, int H, int W, int C, int k, float* dx, int lddx,
+                              void* stream) {
+  LY_CHECK(x && dy && dx && n_img > 0 && H > 0 && W > 0 && (k & 1) == 1, "maxpool_bwd: bad arguments");
+  LY_CHECK((C & 3) == 0 && (ldx & 3) == 0 && (lddy & 3) == 0, "maxpool_bwd: C / ld must be multiples of 4");
+  hipLaunchKernelGGL(ly_maxpool_bwd_kernel, dim3((unsigned)ly_ew_blocks((long)n_img * H * W * (C >> 2))), dim3(LY_THREADS), 0,
+                     reinterpret_cast<hipStream_t>(stream), x, ldx, dy, lddy, n_img, H, W, C, k, dx, lddx);
+  LY_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,435 @@
+"""Training-step backward of the HIP path: torch.autograd.Function wrappers whose
+forward is the same HIP forward the inference path runs and whose backward is built from the HIP
+backward blocks in csrc/ly_backward.hip + the forward contraction kernels with transposed weights.
+
+What autograd would derive for the reference's modules (train.py:324 `scaler.scale(loss).backward()`):
+    Conv2d -> BatchNorm2d(train) -> SiLU/ReLU          models/common.py:1890-1910, 1537-1561
+    MLPBlock (pconv -> 1x1 -> BN -> ReLU -> 1x1, +x)   models/common.py:1432-1437, 1478-1482
+
+Scheme for every conv -> BN -> act unit (v = a*u + b with the BATCH statistics, y = act(v)):
+    1. recompute u with the forward kernel (identity epilogue)  — nothing but the unit's input was saved
+    2. ly_bnact_bwd_reduce:  s1 = sum dv, s2 = sum dv*u  (dv = dy*act'(v))  ->  dgamma, dbeta
+    3. ly_bnact_bwd_apply :  du = a*(dv - mean(dv) - xhat*mean(dv*xhat))  written as alpha*dv + kappa + lambda*u
+    4. dgrad: forward kernel on du with transposed weights;  wgrad: ly_wgrad (pixel contraction)
+Only [C]-sized vectors are handled with torch ops (coefficients of step 3, parameter-gradient reshapes).
+"""
+import torch
+
+from . import ops, pack
+from .ops import ACT_NONE, ACT_RELU, ACT_SILU  # noqa: F401
+
+
+def _rows_dense(t):
+    """NHWC-dense view of a logical [n, c, h, w] tensor (copy only if needed)."""
+    t = ops.nhwc(t)
+    if t.stride(1) != 1:
+        t = t.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    return t
+
+
+def _zeros_like_vec(n, dev):
+    return torch.zeros(n, dtype=torch.float32, device=dev)
+
+
+class ConvSpec:
+    """Static description of one conv(+bias) -> [BN] -> act unit."""
+
+    def __init__(self, kind, cout, act=ACT_NONE, bn=None, bn_train=False, k=1, nchw=False, up=False):
+        self.kind = kind            # "pw" (1x1, one or two row sources), "c3" (3x3 s1 p1), "patch" (k = s)
+        self.cout, self.act, self.bn, self.bn_train = cout, act, bn, bn_train
+        self.k, self.nchw, self.up = k, nchw, up
+
+
+def _weight_2d(spec, weight):
+    """[cout, K] with the column order the forward kernels contract in."""
+    co = weight.shape[0]
+    if spec.kind == "pw":
+        return weight.reshape(co, -1)
+    if spec.kind == "patch":
+        return weight.reshape(co, -1) if spec.nchw else weight.permute(0, 2, 3, 1).reshape(co, -1)
+    return pack.conv_taps_matrix(weight, 32)
+
+
+def _conv_forward(spec, x0, x1, wp, e_scale, e_shift, act, stats=None, out=None):
+    """Runs the forward contraction of `spec`; returns the output tensor (None for a statistics pass)."""
+    co = spec.cout
+    if spec.kind == "pw":
+        t0, ld0 = ops.rows(x0)
+        n, c0, h, w = t0.shape
+        if spec.up:
+            h, w = 2 * h, 2 * w
+        kw = dict(a0=t0, lda0=ld0, k0=c0, gather=ops.GATHER_UP2 if spec.up else ops.GATHER_ROWS)
+        k = c0
+        if x1 is not None:
+            t1, ld1 = ops.rows(x1)
+            kw.update(a1=t1, lda1=ld1)
+            k += t1.shape[1]
+        if stats is None and out is None:
+            out = ops.empty_nhwc(n, co, h, w, t0)
+        ops.gemm(M=n * h * w, H=h, W=w, K=k, N=co, wp=wp, out=out, ldo=co, e_scale=e_scale, e_shift=e_shift, act=act, stats=stats, **kw)
+        return out
+    if spec.kind == "c3":
+        t0, ld0 = ops.rows(x0)
+        n, c, h, w = t0.shape
+        if stats is None and out is None:
+            out = ops.empty_nhwc(n, co, h, w, t0)
+        ops.conv3x3(M=n * h * w, H=h, W=w, Cin=c, N=co, x=t0, ldx=ld0, wp=wp, out=out, ldo=co, e_scale=e_scale, e_shift=e_shift, act=act,
+                    stats=stats)
+        return out
+    n, c, h, w = x0.shape
+    k = spec.k
+    ho, wo = h // k, w // k
+    if spec.nchw:
+        xr = x0.contiguous()
+        kw = dict(K=16 * c, a0=xr, lda0=0, k0=16 * c, gather=ops.GATHER_PATCH_NCHW, Hin=h, Win=w, Cin=c, ks=4, pk=0)
+    else:
+        xr = _rows_dense(x0)
+        kw = dict(K=k * k * c, a0=xr, lda0=c, k0=k * k * c, gather=ops.GATHER_PATCH, Hin=h, Win=w, Cin=c, ks=k, pk=k * c)
+    if stats is None and out is None:
+        out = ops.empty_nhwc(n, co, ho, wo, xr)
+    ops.gemm(M=n * ho * wo, H=ho, W=wo, N=co, wp=wp, out=out, ldo=co, e_scale=e_scale, e_shift=e_shift, act=act, stats=stats, **kw)
+    return out
+
+
+def bn_backward_coeffs(s1, s2, a, mean, invstd, count, train):
+    """From s1 = sum dv, s2 = sum dv*u: (dgamma, dbeta, alpha, kappa, lambda) with du = alpha*dv + kappa + lambda*u."""
+    dbeta = s1
+    dgamma = (s2 - mean * s1) * invstd
+    if train:
+        lam = -a * dgamma * invstd / count
+        kappa = -a * s1 / count - lam * mean
+    else:
+        lam = torch.zeros_like(a)
+        kappa = torch.zeros_like(a)
+    return dgamma, dbeta, a.contiguous(), kappa.contiguous(), lam.contiguous()
+
+
+def affine_backward(dy, u, a, b, act, mean, invstd, train):
+    """du (written over u) and (dgamma, dbeta) for v = a*u + b, y = act(v); dy/u are NHWC-dense [n, c, h, w]."""
+    n, c, h, w = u.shape
+    rows = n * h * w
+    sums = ops.bnact_bwd_reduce(dy, c, u, c, rows, c, a, b, act)
+    dgamma, dbeta, alpha, kappa, lam = bn_backward_coeffs(sums[:c], sums[c:], a, mean, invstd, rows, train)
+    ops.bnact_bwd_apply(dy, c, u, c, rows, c, a, b, act, alpha, kappa, lam, u, c)
+    return u, dgamma, dbeta
+
+
+def conv_wgrad(spec, du, x0, x1, weight):
+    """Weight gradient in the shape of `weight`.  du: NHWC-dense [n, cout, ho, wo]."""
+    n, co, ho, wo = du.shape
+    m = n * ho * wo
+    if spec.kind == "pw":
+        t0, ld0 = ops.rows(x0)
+        c0 = t0.shape[1]
+        k = c0 + (x1.shape[1] if x1 is not None else 0)
+        dw = torch.zeros(co, k, dtype=torch.float32, device=du.device)
+        ops.wgrad(M=m, H=ho, W=wo, N=co, du=du, lddu=co, x=t0, ldx=ld0, Hin=t0.shape[2], Win=t0.shape[3], Cin=c0, dw=dw, lddw=k,
+                  up2=spec.up)
+        if x1 is not None:
+            t1, ld1 = ops.rows(x1)
+            ops.wgrad(M=m, H=ho, W=wo, N=co, du=du, lddu=co, x=t1, ldx=ld1, Hin=ho, Win=wo, Cin=t1.shape[1], dw=dw, lddw=k, dw_off=c0)
+        return dw.view(weight.shape)
+    if spec.kind == "c3":
+        t0, ld0 = ops.rows(x0)
+        c = t0.shape[1]
+        dw = torch.zeros(co, 9 * c, dtype=torch.float32, device=du.device)
+        ops.wgrad(M=m, H=ho, W=wo, N=co, du=du, lddu=co, x=t0, ldx=ld0, Hin=ho, Win=wo, Cin=c, dw=dw, lddw=9 * c, ks=3, stride=1, pad=1)
+        return dw.view(co, 3, 3, c).permute(0, 3, 1, 2).contiguous()
+    _, c, h, w = x0.shape
+    k = spec.k
+    dw = torch.zeros(co, k * k * c, dtype=torch.float32, device=du.device)
+    if spec.nchw:
+        xr = x0.contiguous()
+        ops.wgrad(M=m, H=ho, W=wo, N=co, du=du, lddu=co, x=xr, ldx=0, Hin=h, Win=w, Cin=c, dw=dw, lddw=k * k * c, ks=k, stride=k, nchw=True)
+    else:
+        xr = _rows_dense(x0)
+        ops.wgrad(M=m, H=ho, W=wo, N=co, du=du, lddu=co, x=xr, ldx=c, Hin=h, Win=w, Cin=c, dw=dw, lddw=k * k * c, ks=k, stride=k)
+    return dw.view(co, k, k, c).permute(0, 3, 1, 2).contiguous()
+
+
+def conv_dgrad(spec, du, weight, x0, x1, need0, need1):
+    """Input gradients (dx0, dx1) of the contraction; du NHWC-dense [n, cout, ho, wo] with cout % 4 == 0 columns valid."""
+    n, co, ho, wo = du.shape
+    m = n * ho * wo
+    with torch.no_grad():
+        if spec.kind == "pw":
+            w2 = weight.detach().reshape(weight.shape[0], -1)
+            kin = w2.shape[1]
+            wt = pack.frag_pack3(_pad_cols(w2.t(), co))
+            d = ops.empty_nhwc(n, kin, ho, wo, du)
+            ops.gemm(M=m, H=ho, W=wo, K=co, N=kin, a0=du, lda0=co, k0=co, wp=wt, out=d, ldo=kin)
+            if x1 is None:
+                return (ops.up2_bwd(d, kin, n, ho // 2, wo // 2, kin) if spec.up else d), None
+            c0 = x0.shape[1]
+            d0 = d[:, :c0]
+            if spec.up and need0:
+                d0 = ops.up2_bwd(d, kin, n, ho // 2, wo // 2, c0)
+            return (d0 if need0 else None), (d[:, c0:] if need1 else None)
+        if spec.kind == "c3":
+            wt = pack.frag_pack3(pack.conv_taps_matrix(weight.detach().permute(1, 0, 2, 3).flip(2, 3), 32))
+            cin = weight.shape[1]
+            d = ops.empty_nhwc(n, cin, ho, wo, du)
+            ops.conv3x3(M=m, H=ho, W=wo, Cin=co, N=cin, x=du, ldx=co, wp=wt, out=d, ldo=cin)
+            return d, None
+        if spec.nchw:
+            raise NotImplementedError("gradient with respect to the NCHW input image is not built (never needed: it is the data)")
+        _, c, h, w = x0.shape
+        k = spec.k
+        w2 = weight.detach().permute(0, 2, 3, 1).reshape(co, -1)
+        wt = pack.frag_pack3(w2.t())
+        g = torch.empty((m, k * k * c), dtype=torch.float32, device=du.device)
+        ops.gemm(M=m, H=ho, W=wo, K=co, N=k * k * c, a0=du, lda0=co, k0=co, wp=wt, out=g, ldo=k * k * c)
+        return ops.unpatch(g, n, ho, wo, c, k, h, w), None
+
+
+def _pad_cols(w2d, k):
+    """[R, k0] -> [R, k] zero padded on the right (k >= k0)."""
+    if w2d.shape[1] == k:
+        return w2d
+    out = torch.zeros(w2d.shape[0], k, dtype=w2d.dtype, device=w2d.device)
+    out[:, :w2d.shape[1]] = w2d
+    return out
+
+
+class ConvBnAct(torch.autograd.Function):
+    """y = act(BN(conv(x0 [| x1]) + bias)).  tensors: x0, x1|None, weight, bias|None, gamma|None, beta|None."""
+
+    @staticmethod
+    def forward(ctx, spec, wp, x0, x1, weight, bias, gamma, beta):
+        co = spec.cout
+        dev = x0.device
+        bias_f = bias.detach().float().contiguous() if bias is not None else None
+        mean = invstd = None
+        if spec.bn is not None:
+            if spec.bn_train:
+                stats = torch.zeros(2 * co, dtype=torch.float32, device=dev)
+                _conv_forward(spec, x0, x1, wp, None, bias_f, ACT_NONE, stats=stats)
+                y0 = _out_shape(spec, x0)
+                a, b, mean, invstd = ops.bn_batch_stats(spec.bn, stats[:co], stats[co:], y0[0] * y0[2] * y0[3])
+            else:
+                bn = spec.bn
+                invstd = torch.rsqrt(bn.running_var.detach().float() + bn.eps)
+                mean = bn.running_mean.detach().float()
+                a = (gamma.detach().float() * invstd).contiguous()
+                b = (beta.detach().float() - mean * a).contiguous()
+            sh = b if bias_f is None else (b + bias_f * a).contiguous()
+            y = _conv_forward(spec, x0, x1, wp, a, sh, spec.act)
+        else:
+            a = b = None
+            y = _conv_forward(spec, x0, x1, wp, None, bias_f, spec.act)
+        ctx.spec, ctx.wp = spec, wp
+        ctx.has = (x1 is not None, bias is not None)
+        ctx.save_for_backward(x0, x1, weight, bias_f, a, b, mean, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        spec, wp = ctx.spec, ctx.wp
+        x0, x1, weight, bias_f, a, b, mean, invstd = ctx.saved_tensors
+        co = spec.cout
+        need = ctx.needs_input_grad          # (spec, wp, x0, x1, weight, bias, gamma, beta)
+        with torch.no_grad():
+            dy = _rows_dense(dy)
+            dgamma = dbeta = dbias = None
+            if spec.bn is not None or spec.act != ACT_NONE:
+                u = _conv_forward(spec, x0, x1, wp, None, bias_f, ACT_NONE)              # recompute conv + bias
+                if spec.bn is None:
+                    a = torch.ones(co, dtype=torch.float32, device=dy.device)
+                    b = torch.zeros_like(a)
+                    mean, invstd = b, a
+                du, dgamma, dbeta = affine_backward(dy, u, a, b, spec.act, mean, invstd, spec.bn is not None and spec.bn_train)
+                if bias_f is not None:
+                    if spec.bn is None:
+                        dbias, dgamma, dbeta = dbeta, None, None
+                    elif spec.bn_train:
+                        dbias = torch.zeros_like(bias_f)                               # BN removes the batch mean: d/dbias = 0
+                    else:
+                        dbias = a * dbeta
+                elif spec.bn is None:
+                    dgamma = dbeta = None
+            else:
+                du = dy
+                if bias_f is not None:
+                    n, _, h, w = dy.shape
+                    dbias = _chan_sum(dy, co)
+            cq = (co + 3) // 4 * 4
+            if cq != co:                                                               # e.g. Detect heads (18 channels)
+                n, _, h, w = du.shape
+                pad = torch.zeros((n, cq, h, w), dtype=torch.float32, device=du.device).contiguous(memory_format=torch.channels_last)
+                pad[:, :co] = du
+                du_d = pad
+            else:
+                du_d = du
+            dw = conv_wgrad(spec, du, x0, x1, weight) if need[4] else None
+            dx0 = dx1 = None
+            if need[2] or need[3]:
+                dspec = spec
+                if cq != co:
+                    dspec = ConvSpec(spec.kind, cq, k=spec.k, nchw=spec.nchw, up=spec.up)
+                dx0, dx1 = conv_dgrad(dspec, du_d, weight, x0, x1, need[2], need[3])
+        return None, None, dx0, dx1, dw, dbias, dgamma, dbeta
+
+
+def _chan_sum(t, c):
+    """per-channel sum over pixels of an NHWC-dense tensor (c may be any size)."""
+    n, _, h, w = t.shape
+    if c % 4 == 0 and c <= 1024:
+        return ops.chan_moments(t, c, n * h * w, c)[:c]
+    return t.sum((0, 2, 3))
+
+
+def _out_shape(spec, x0):
+    n, c, h, w = x0.shape
+    if spec.kind == "patch":
+        return n, spec.cout, h // spec.k, w // spec.k
+    if spec.up:
+        return n, spec.cout, 2 * h, 2 * w
+    return n, spec.cout, h, w
+
+
+def conv_bn_act(spec, wp, x0, x1, weight, bias, bn):
+    gamma = bn.weight if bn is not None else None
+    beta = bn.bias if bn is not None else None
+    return ConvBnAct.apply(spec, wp, x0, x1, weight, bias, gamma, beta)
+
+
+# --------------------------------------------------------------------------------------------------
+# MLPBlock:  y = x + W2 . relu(BN(W1 . z)),  z = [pconv3x3(x[:, :C/4]) | x[:, C/4:]]
+# forward  = the fused kernel (statistics pass + normal pass), only x is saved
+# backward = recompute z, u1 = W1 z, h = relu(BN u1) with the contraction kernels, then the unit scheme above
+# --------------------------------------------------------------------------------------------------
+def _ceil4(v):
+    return (v + 3) // 4 * 4
+
+
+class MlpBlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mod, x, wpc, w1, gamma, beta, w2):
+        x = _rows_dense(x)
+        n, c, h, w = x.shape
+        pk_p, pk_1, pk_2 = mod._weights()
+        htp = (2 * c // 16 + 1) // 2 * 2
+        stats = torch.zeros(2 * 16 * htp, dtype=torch.float32, device=x.device)
+        ops.mlpblock(x, None, n, h, w, c, pk_p, pk_1, pk_2, None, None, stats=stats)
+        a, b, mean, invstd = ops.bn_batch_stats(mod.mlp[1], stats[:2 * c], stats[16 * htp:16 * htp + 2 * c], n * h * w)
+        y = ops.empty_nhwc(n, c, h, w, x)
+        ops.mlpblock(x, y, n, h, w, c, pk_p, pk_1, pk_2, pack.pad_to(a, 16 * htp), pack.pad_to(b, 16 * htp))
+        ctx.save_for_backward(x, wpc, w1, w2, a, b, mean, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wpc, w1, w2, a, b, mean, invstd = ctx.saved_tensors
+        n, c, h, w = x.shape
+        m = n * h * w
+        c4 = c // 4
+        c4p = _ceil4(c4)
+        with torch.no_grad():
+            dy = _rows_dense(dy)
+            w1m, w2m = w1.detach().view(2 * c, c), w2.detach().view(c, 2 * c)
+            # recompute z, u1, h
+            z = x.clone()
+            ops.conv3x3(M=m, H=h, W=w, Cin=c4p, N=c4, x=x, ldx=c, wp=pack.frag_pack3(pack.conv_taps_matrix(wpc.detach(), 32)), out=z, ldo=c)
+            pk1 = pack.frag_pack3(w1m)
+            u1 = ops.empty_nhwc(n, 2 * c, h, w, x)
+            ops.gemm(M=m, H=h, W=w, K=c, N=2 * c, a0=z, lda0=c, k0=c, wp=pk1, out=u1, ldo=2 * c)
+            hid = ops.empty_nhwc(n, 2 * c, h, w, x)
+            ops.gemm(M=m, H=h, W=w, K=c, N=2 * c, a0=z, lda0=c, k0=c, wp=pk1, out=hid, ldo=2 * c, e_scale=a, e_shift=b, act=ACT_RELU)
+            # second 1x1
+            dh = ops.empty_nhwc(n, 2 * c, h, w, x)
+            ops.gemm(M=m, H=h, W=w, K=c, N=2 * c, a0=dy, lda0=c, k0=c, wp=pack.frag_pack3(w2m.t()), out=dh, ldo=2 * c)
+            dw2 = torch.zeros(c, 2 * c, dtype=torch.float32, device=x.device)
+            ops.wgrad(M=m, H=h, W=w, N=c, du=dy, lddu=c, x=hid, ldx=2 * c, Hin=h, Win=w, Cin=2 * c, dw=dw2, lddw=2 * c)
+            # BN + ReLU
+            du1, dgamma, dbeta = affine_backward(dh, u1, a, b, ACT_RELU, mean, invstd, True)
+            # first 1x1
+            g = ops.empty_nhwc(n, c, h, w, x)
+            ops.gemm(M=m, H=h, W=w, K=2 * c, N=c, a0=du1, lda0=2 * c, k0=2 * c, wp=pack.frag_pack3(w1m.t()), out=g, ldo=c)
+            dw1 = torch.zeros(2 * c, c, dtype=torch.float32, device=x.device)
+            ops.wgrad(M=m, H=h, W=w, N=2 * c, du=du1, lddu=2 * c, x=z, ldx=c, Hin=h, Win=w, Cin=c, dw=dw1, lddw=c)
+            # partial 3x3 conv on the first C/4 channels
+            dwp = torch.zeros(c4, 9 * c4, dtype=torch.float32, device=x.device)
+            ops.wgrad(M=m, H=h, W=w, N=c4, du=g, lddu=c, x=x, ldx=c, Hin=h, Win=w, Cin=c4, dw=dwp, lddw=9 * c4, ks=3, stride=1, pad=1)
+            t = ops.empty_nhwc(n, c4p, h, w, x)
+            wt = pack.frag_pack3(pack.conv_taps_matrix(wpc.detach().permute(1, 0, 2, 3).flip(2, 3), 32))
+            ops.conv3x3(M=m, H=h, W=w, Cin=c4p, N=c4, x=g, ldx=c, wp=wt, out=t, ldo=c4p)
+            dx = dy + g
+            dx[:, :c4] = dy[:, :c4] + t[:, :c4]
+        return (None, dx, dwp.view(c4, 3, 3, c4).permute(0, 3, 1, 2).contiguous(), dw1.view(w1.shape), dgamma, dbeta, dw2.view(w2.shape))
+
+
+# --------------------------------------------------------------------------------------------------
+# CoordAtt: pools and gate are HIP kernels both ways; the [n, h+w, c] -> [n, h+w, mip] -> a_h, a_w MLP acts on
+# pooled vectors only (1/W + 1/H of the map) and runs as torch ops under autograd in training.
+# --------------------------------------------------------------------------------------------------
+class PoolHW(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        t, ld = ops.rows(x)
+        n, c, h, w = t.shape
+        ctx.shape = (n, c, h, w)
+        return ops.pool_hw(t, ld, n, h, w, c)
+
+    @staticmethod
+    def backward(ctx, gp):
+        n, c, h, w = ctx.shape
+        return ops.pool_hw_bwd(gp.contiguous(), n, h, w, c)
+
+
+class Gate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, a_h, a_w):
+        t, ld = ops.rows(x)
+        n, c, h, w = t.shape
+        a_h, a_w = a_h.contiguous(), a_w.contiguous()
+        ctx.save_for_backward(t, a_h, a_w)
+        return ops.coordatt_gate(t, ld, n, h, w, c, a_h, a_w)
+
+    @staticmethod
+    def backward(ctx, dout):
+        t, a_h, a_w = ctx.saved_tensors
+        xr, ld = ops.rows(t)
+        n, c, h, w = xr.shape
+        return ops.coordatt_gate_bwd(_rows_dense(dout), xr, ld, n, h, w, c, a_h, a_w)
+
+
+def coordatt_train(mod, x):
+    """CoordAtt.forward in training (models/common.py:1595-1609)."""
+    import torch.nn.functional as F
+    n, c, h, w = x.shape
+    pool = PoolHW.apply(x)                                                   # [n, h+w, c]
+    y = F.linear(pool, mod.conv1.weight.view(mod.mip, c), mod.conv1.bias)    # [n, h+w, mip]
+    bn = mod.bn1
+    y = F.batch_norm(y.reshape(-1, mod.mip), bn.running_mean, bn.running_var, bn.weight, bn.bias, True, bn.momentum, bn.eps)
+    bn.num_batches_tracked += 1
+    y = (y * F.relu6(y + 3.0) / 6.0).view(n, h + w, mod.mip)
+    a_h = torch.sigmoid(F.linear(y[:, :h], mod.conv_h.weight.view(c, mod.mip), mod.conv_h.bias))
+    a_w = torch.sigmoid(F.linear(y[:, h:], mod.conv_w.weight.view(c, mod.mip), mod.conv_w.bias))
+    return Gate.apply(x, a_h, a_w)
+
+
+# --------------------------------------------------------------------------------------------------
+# SPPF pooling: [y | m(y) | m(m(y)) | m(m(m(y)))]
+# --------------------------------------------------------------------------------------------------
+class SppfPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, k):
+        t, ld = ops.rows(y)
+        n, c, h, w = t.shape
+        if not ops.sppf_pool_fits(h, w):
+            raise NotImplementedError("SPPF training path needs the map to fit the LDS pooling kernel")
+        buf = ops.empty_nhwc(n, 4 * c, h, w, t)
+        ops.sppf_pool(t, ld, n, h, w, c, k, buf, 4 * c)
+        ctx.save_for_backward(buf)
+        ctx.k = k
+        return buf
+
+    @staticmethod
+    def backward(ctx, d):
+        buf, = ctx.saved_tensors
+        n, c4, h, w = buf.shape
+        c = c4 // 4
+        acc = _rows_dense(d).clone()
+        for j in (2, 1, 0):                           # m(y_j) = y_{j+1}: add its gradient into slot j
+            ops.maxpool_bwd(buf, j * c, c4, acc, (j + 1) * c, c4, n, h, w, c, ctx.k, acc, j * c, c4)
+        return acc[:, :c], None

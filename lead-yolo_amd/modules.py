@@ -77,6 +77,11 @@ def _no_grad_needed(x, name):
                                   "run train-mode forward under torch.no_grad()")
 
 
+def _grad_mode(mod):
+    """Training step: train-mode module called with autograd recording -> the autograd.Function path (grad.py)."""
+    return mod.training and torch.is_grad_enabled()
+
+
 def _bn_tensors(bn):
     return (bn.weight, bn.bias, bn.running_mean, bn.running_var)
 
@@ -203,11 +208,15 @@ class MLPBlock(nn.Module):
         if pr is not None:
             return pr
         ops.require_cuda(x, "MLPBlock")
+        if _grad_mode(self):
+            from . import grad
+            bn = self.mlp[1]
+            return grad.MlpBlockFn.apply(self, x, self.spatial_mixing.partial_conv3.weight, self.mlp[0].weight, bn.weight, bn.bias,
+                                         self.mlp[3].weight)
         x = ops.nhwc(x)
         n, c, h, w = x.shape
         wp, w1, w2 = self._weights()
         if self.training:
-            _no_grad_needed(x, "MLPBlock")
             htp = (2 * c // 16 + 1) // 2 * 2
             stats = torch.zeros(2 * 16 * htp, dtype=torch.float32, device=x.device)
             ops.mlpblock(x, None, n, h, w, c, wp, w1, w2, None, None, stats=stats)         # statistics pass (no store)
@@ -277,6 +286,14 @@ class _PatchConv(nn.Module):
         n, c, h, w = x.shape
         k = self.k
         ho, wo = h // k, w // k
+        if _grad_mode(self) and isinstance(getattr(self, "norm", None), nn.BatchNorm2d):
+            from . import grad
+            nchw = c % 4 != 0
+            if nchw and (k != 4 or w % 4 != 0):
+                raise NotImplementedError("HIP patch embedding of an NCHW image needs patch_size 4 and W % 4 == 0")
+            conv = getattr(self, self._conv_name)
+            spec = grad.ConvSpec("patch", self.cout, ACT_NONE, self.norm, True, k=k, nchw=nchw)
+            return grad.conv_bn_act(spec, self._weights(nchw), x, None, conv.weight, conv.bias, self.norm)
         if c % 4 == 0:
             xr, ld = ops.rows(x)
             if ld != c:
@@ -291,7 +308,6 @@ class _PatchConv(nn.Module):
                       ldo=self.cout, gather=ops.GATHER_PATCH_NCHW, Hin=h, Win=w, Cin=c, ks=4, pk=0)
         bn = getattr(self, "norm", None)
         if self.training and isinstance(bn, nn.BatchNorm2d):
-            _no_grad_needed(x, type(self).__name__)
             conv = getattr(self, self._conv_name)
             bias = conv.bias.detach().float().contiguous() if conv.bias is not None else None
             stats = torch.zeros(2 * self.cout, dtype=torch.float32, device=x.device)
@@ -394,8 +410,17 @@ class Conv(nn.Module):
             x = x.materialize()
         act = _act_code(self.act)
         bn = getattr(self, "bn", None)
+        if _grad_mode(self) and bn is not None:
+            from . import grad
+            x0, x1, up = x, None, False
+            if isinstance(x, Lazy):
+                if x.gate is not None:
+                    x0 = x.materialize()
+                else:
+                    x0, x1, up = x.keep[0], (x.keep[1] if x.a1 is not None else None), x.up
+            spec = grad.ConvSpec("pw" if self.k == 1 else "c3", self.c2, act, bn, True, up=up)
+            return grad.conv_bn_act(spec, self.weights(), x0, x1, self.conv.weight, self.conv.bias, bn)
         if self.training and bn is not None:
-            _no_grad_needed(x, "Conv")
             L = Lazy.of(x)
             n, _, h, w = L.shape
             bias = self.conv.bias.detach().float().contiguous() if self.conv.bias is not None else None
@@ -598,8 +623,9 @@ class CoordAtt(nn.Module):
         if pr is not None:
             return pr
         ops.require_cuda(x, "CoordAtt")
-        if self.training:
-            _no_grad_needed(x, "CoordAtt")
+        if _grad_mode(self):
+            from . import grad
+            return grad.coordatt_train(self, x)
         xr, ld = ops.rows(x)
         n, c, h, w = xr.shape
         a_h, a_w = self.attention(xr, ld, n, h, w, c)
@@ -617,6 +643,10 @@ class CA_Bottleneck(nn.Module):
 
     def forward_lazy(self, x):
         """Returns a Lazy (gated, un-materialised) output when there is no residual, else a tensor."""
+        if _grad_mode(self):
+            xin = x.materialize() if isinstance(x, Lazy) else x
+            y = self.ca(self.cv2(self.cv1(xin)))
+            return xin + y if self.add else y
         src = Lazy.of(x)
         t1 = self.cv1(src)
         t2 = self.cv2(t1)
@@ -687,10 +717,18 @@ class C3_CA(nn.Module):
         c_ = self.c_
         if _act_code(self.cv1.act) != _act_code(self.cv2.act):
             raise NotImplementedError("C3_CA: cv1 and cv2 must share one activation")
+        if _grad_mode(self):
+            a = self.cv1(x)
+            for blk in self.m:
+                a = blk.forward_lazy(a)
+            b = self.cv2(x)
+            n_, ca_, h_, w_ = a.shape
+            ta, lda = ops.rows(a)
+            tb, ldb = ops.rows(b)
+            return self.cv3(Lazy((n_, ca_ + b.shape[1], h_, w_), ta, lda, ca_, a1=tb, lda1=ldb, keep=(ta, tb)))
         wp = self._weights12()
         b1, b2 = getattr(self.cv1, "bn", None), getattr(self.cv2, "bn", None)
         if self.training and b1 is not None and b2 is not None:
-            _no_grad_needed(x, "C3_CA")
             stats = torch.zeros(4 * c_, dtype=torch.float32, device=src.a0.device)
             _run_pointwise(src, wp, 2 * c_, None, None, ACT_NONE, stats=stats)                  # statistics pass, both halves
             s1, s2 = stats[:2 * c_], stats[2 * c_:]
@@ -726,6 +764,9 @@ class SPPF(nn.Module):
             return y.new_zeros((y.shape[0], self.cv2.c2, y.shape[2], y.shape[3]))
         n, c_, h, w = y.shape
         k = self.m.kernel_size
+        if _grad_mode(self):
+            from . import grad
+            return self.cv2(grad.SppfPool.apply(y, k))
         if ops.sppf_pool_fits(h, w):
             yr, ld = ops.rows(y)
             buf = ops.empty_nhwc(n, 4 * c_, h, w, yr)
@@ -812,6 +853,18 @@ class Detect(nn.Module):
 
     def forward(self, x):
         x = list(x)
+        if _grad_mode(self):
+            from . import grad
+            for i in range(self.nl):
+                t = x[i].materialize() if isinstance(x[i], Lazy) else x[i]
+                conv = self.m[i]
+                key = pack.versions(conv.weight, conv.bias)
+                wp, _ = self._prep[i].get(key, lambda: (pack.frag_pack3(conv.weight.detach().view(conv.out_channels, -1)),
+                                                        conv.bias.detach().float().contiguous()))
+                y = grad.conv_bn_act(grad.ConvSpec("pw", conv.out_channels), wp, t, None, conv.weight, conv.bias, None)
+                bs, _, ny, nx = y.shape
+                x[i] = y.view(bs, self.na, self.no, ny, nx).permute(0, 1, 3, 4, 2).contiguous()
+            return x
         shapes = [Lazy.of(t).shape for t in x]
         bs = shapes[0][0]
         decode = not self.training

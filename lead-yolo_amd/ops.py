@@ -237,17 +237,7 @@ def bn_batch_affine(bn, s1, s2, count):
     """Train-mode BatchNorm from per-channel sums: returns (scale, shift) of y = x*scale + shift with the
     BATCH statistics (biased variance), and updates running_mean / running_var (unbiased, momentum) and
     num_batches_tracked in place exactly as nn.BatchNorm2d does.  Device tensors only, no host sync."""
-    with torch.no_grad():
-        mean = s1 / count
-        var = (s2 / count - mean * mean).clamp_(min=0.0)
-        scale = bn.weight.detach().float() / torch.sqrt(var + bn.eps)
-        shift = bn.bias.detach().float() - mean * scale
-        if bn.track_running_stats and bn.running_mean is not None:
-            mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
-            bn.running_mean.mul_(1.0 - mom).add_(mean, alpha=mom)
-            bn.running_var.mul_(1.0 - mom).add_(var * (count / max(count - 1, 1)), alpha=mom)
-            bn.num_batches_tracked += 1
-    return scale.contiguous(), shift.contiguous()
+    return bn_batch_stats(bn, s1, s2, count)[:2]
 
 
 _TRIU = None
@@ -271,3 +261,82 @@ def rfcbam_generate_stats(x, ldx, n, h, w, c, s, gen_w):
     s2 = torch.einsum("ctu,cuv,ctv->ct", wv, M, wv)
     ho, wo = (h + 2 - 3) // s + 1, (w + 2 - 3) // s + 1
     return s1.reshape(-1), s2.reshape(-1), n * ho * wo
+
+
+# ---- backward building blocks (training step) --------------------------------------------------------
+def bn_batch_stats(bn, s1, s2, count):
+    """As bn_batch_affine, additionally returning the batch mean and 1/sqrt(var + eps) the backward needs."""
+    with torch.no_grad():
+        mean = s1 / count
+        var = (s2 / count - mean * mean).clamp_(min=0.0)
+        invstd = torch.rsqrt(var + bn.eps)
+        scale = bn.weight.detach().float() * invstd
+        shift = bn.bias.detach().float() - mean * scale
+        if bn.track_running_stats and bn.running_mean is not None:
+            mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
+            bn.running_mean.mul_(1.0 - mom).add_(mean, alpha=mom)
+            bn.running_var.mul_(1.0 - mom).add_(var * (count / max(count - 1, 1)), alpha=mom)
+            bn.num_batches_tracked += 1
+    return scale.contiguous(), shift.contiguous(), mean, invstd
+
+
+def bnact_bwd_reduce(dy, lddy, u, ldu, rows, c, a, b, act):
+    sums = torch.zeros(2 * c, dtype=torch.float32, device=u.device)
+    with _Timed("ly_bnact_bwd_reduce_kernel", 6.0 * rows * c, 8.0 * rows * c):
+        capi.check(capi.lib().ly_bnact_bwd_reduce(_p(dy), lddy, _p(u), ldu, rows, c, _p(a), _p(b), act, _p(sums), capi.stream_ptr()),
+                   "ly_bnact_bwd_reduce")
+    return sums
+
+
+def bnact_bwd_apply(dy, lddy, u, ldu, rows, c, a, b, act, alpha, kappa, lam, du, lddu):
+    with _Timed("ly_bnact_bwd_apply_kernel", 8.0 * rows * c, 12.0 * rows * c):
+        capi.check(capi.lib().ly_bnact_bwd_apply(_p(dy), lddy, _p(u), ldu, rows, c, _p(a), _p(b), act, _p(alpha), _p(kappa), _p(lam),
+                                                 _p(du), lddu, capi.stream_ptr()), "ly_bnact_bwd_apply")
+
+
+def wgrad(*, M, H, W, N, du, lddu, x, ldx, Hin, Win, Cin, dw, lddw, ks=1, stride=1, pad=0, nchw=False, up2=False, du_off=0, x_off=0,
+          dw_off=0):
+    """dw[n][tap*Cin + c] += sum_pixels du[p][n] * x[src(p, tap)][c]; *_off are element offsets into the tensors."""
+    def at(t, off):
+        return ctypes.c_void_p(t.data_ptr() + 4 * off)
+    P = capi.LyWgradParams(M, H, W, N, at(du, du_off), lddu, at(x, x_off), ldx, Hin, Win, Cin, ks, stride, pad, int(nchw), int(up2),
+                           at(dw, dw_off), lddw)
+    with _Timed("ly_wgrad_kernel", 2.0 * M * N * ks * ks * Cin, 4.0 * (M * (N + Cin) + N * ks * ks * Cin)):
+        capi.check(capi.lib().ly_wgrad(ctypes.byref(P), capi.stream_ptr()), "ly_wgrad")
+
+
+def up2_bwd(d, ldd, n, hs, ws, c):
+    out = empty_nhwc(n, c, hs, ws, d)
+    capi.check(capi.lib().ly_up2_bwd(_p(d), ldd, n, hs, ws, c, _p(out), c, capi.stream_ptr()), "ly_up2_bwd")
+    return out
+
+
+def unpatch(g, n, ho, wo, c, ks, h, w):
+    """g [n*ho*wo, ks*ks*c] -> dx [n, c, h, w] (NHWC storage); rows/cols beyond ks*ho / ks*wo stay zero."""
+    exact = (h == ho * ks and w == wo * ks)
+    if not exact:
+        raise NotImplementedError("patch-gather backward needs H, W divisible by the patch size")
+    dx = empty_nhwc(n, c, h, w, g)
+    capi.check(capi.lib().ly_unpatch(_p(g), n, ho, wo, c, ks, _p(dx), capi.stream_ptr()), "ly_unpatch")
+    return dx
+
+
+def coordatt_gate_bwd(dout, x, ldx, n, h, w, c, a_h, a_w):
+    dx = empty_nhwc(n, c, h, w, dout)
+    da_h = torch.empty((n, h, c), dtype=torch.float32, device=dout.device)
+    da_w = torch.zeros((n, w, c), dtype=torch.float32, device=dout.device)
+    capi.check(capi.lib().ly_coordatt_gate_bwd(_p(dout), c, _p(x), ldx, n, h, w, c, _p(a_h), _p(a_w), _p(dx), c, _p(da_h), _p(da_w),
+                                               capi.stream_ptr()), "ly_coordatt_gate_bwd")
+    return dx, da_h, da_w
+
+
+def pool_hw_bwd(gp, n, h, w, c):
+    dx = empty_nhwc(n, c, h, w, gp)
+    capi.check(capi.lib().ly_pool_hw_bwd(_p(gp), n, h, w, c, _p(dx), c, capi.stream_ptr()), "ly_pool_hw_bwd")
+    return dx
+
+
+def maxpool_bwd(x, x_off, ldx, dy, dy_off, lddy, n, h, w, c, k, dx, dx_off, lddx):
+    at = lambda t, off: ctypes.c_void_p(t.data_ptr() + 4 * off)
+    capi.check(capi.lib().ly_maxpool_bwd(at(x, x_off), ldx, at(dy, dy_off), lddy, n, h, w, c, k, at(dx, dx_off), lddx, capi.stream_ptr()),
+               "ly_maxpool_bwd")

@@ -229,14 +229,6 @@ def test_module_train_forward_golden(name):
     assert all(int(v) == 1 for v in nb)
 
 
-def test_train_forward_needs_no_grad():
-    import lead_yolo_amd as L
-    m = L.BasicStage(24, 1).to(_dev()).train()
-    x = torch.randn(1, 24, 8, 8, device=_dev(), requires_grad=True)
-    with pytest.raises(NotImplementedError):
-        m(x)
-
-
 @pytest.mark.parametrize("scale", ["n", "s"])
 def test_whole_model_train_forward_golden(scale):
     """train-mode forward of the whole detector (batch-statistics BN everywhere) vs the reference"""

@@ -142,6 +142,7 @@ typedef struct LyRfcbam3Params {
   const float* e_scale; const float* e_shift;   /* conv.1 BN folded with conv.0.bias              */
   float* out; int ldo;
   float* stats;                /* NULL or [2N] accumulators: conv.1 BatchNorm statistics pass    */
+  int linear;                  /* != 0: store the affine value without the ReLU (backward recompute) */
 } LyRfcbam3Params;
 /* RFCBAMConv kernel_size 3 main contraction (+ReLU); the k=1 case is ly_gemm_fwd with
  * LY_PRO_AFFINE_RELU_CA and rowscale = rfa.                                                         */
@@ -223,6 +224,27 @@ int ly_pool_hw_bwd(const float* gp, int n_img, int H, int W, int C, float* dx, i
  * into the gradient slots of the SPPF concat buffer in place.                                                       */
 int ly_maxpool_bwd(const float* x, int ldx, const float* dy, int lddy, int n_img, int H, int W, int C, int k, float* dx, int lddx,
                    void* stream);
+
+/* ---- RFCBAMConv backward (models/rfa.py:113-129 under autograd) ----------------------------------------------------
+ * Expanded tensors are [m = (n, ho, wo)][t = tap][c] (channel contiguous), maps are [n, k*Ho, k*Wo]; per-(t, c) vectors
+ * (ag, bg, alpha, kappa, lambda, sums) are indexed t*C + c.  See csrc/ly_rfcbam_bwd.hip for the step list.            */
+/* ug[m][t][c] = sum_u wg[c*KK + t][u] * x_u(m)[c]  (depthwise `generate` conv before its BatchNorm)                    */
+int ly_rf_generate(const float* x, int ldx, int n_img, int H, int W, int C, int k, int s, const float* wg, float* ug, void* stream);
+/* G = relu(ag*ug + bg):  cd = G*ca*rfa (written),  d_rfa[pos] += sum_c dcd*G*ca,  gmax[pos] = max_c G (as float bits,
+ * zeroed by the caller),  d_ca[n][c] += sum_{m,t} dcd*rfa*G  (d_rfa, d_ca zeroed by the caller)                        */
+int ly_rf_bwd_attn(int n_img, int H, int W, int C, int k, int s, const float* ug, const float* dcd, const float* ag, const float* bg,
+                   const float* ca, const float* rfa, float* cd, float* d_rfa, float* gmax, float* d_ca, void* stream);
+/* rfa = sigmoid(conv3x3(mm; w18)) backward: d_mm[n,y,x,2] (written) and dw18[18] (+=, zeroed by the caller)            */
+int ly_rfa_bwd(const float* d_rfa, const float* rfa, const float* mm, const float* w18, int n_img, int Hk, int Wk, float* d_mm,
+               float* dw18, void* stream);
+/* dv = [G>0]*(dcd*rfa*ca + d_mm.mean/C + [G==gmax]*d_mm.max) written over dcd; sums[t*C+c] += dv, sums[C*KK + ..] += dv*ug */
+int ly_rf_bwd_relu(int n_img, int H, int W, int C, int k, int s, const float* ug, float* dcd, const float* ag, const float* bg,
+                   const float* ca, const float* rfa, const float* gmax, const float* d_mm, float* sums, void* stream);
+/* dug = alpha*dv + kappa + lambda*ug written over dv; dwg[c*KK + t][u] += sum_m dug*x_u (zeroed by the caller)         */
+int ly_rf_bwd_gen(const float* x, int ldx, int n_img, int H, int W, int C, int k, int s, const float* ug, float* dv, const float* alpha,
+                  const float* kappa, const float* lambda, float* dwg, void* stream);
+/* dx[n,hi,wi,c] = sum over (m, u) reading that input pixel of sum_t dug[m][t][c]*wg[c*KK + t][u]  (written)           */
+int ly_rf_bwd_dx(int n_img, int H, int W, int C, int k, int s, const float* dug, const float* wg, float* dx, int lddx, void* stream);
 
 #ifdef __cplusplus
 }

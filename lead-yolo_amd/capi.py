@@ -35,7 +35,7 @@ class LyConv3Params(ctypes.Structure):
 class LyRfcbam3Params(ctypes.Structure):
     _fields_ = [("n_img", _I), ("H", _I), ("W", _I), ("C", _I), ("Ho", _I), ("Wo", _I), ("N", _I), ("s", _I),
                 ("TH", _I), ("TW", _I), ("x", _P), ("ldx", _I), ("wg", _P), ("ca", _P), ("rfa", _P), ("wp", _P),
-                ("e_scale", _P), ("e_shift", _P), ("out", _P), ("ldo", _I), ("stats", _P)]
+                ("e_scale", _P), ("e_shift", _P), ("out", _P), ("ldo", _I), ("stats", _P), ("linear", _I)]
 
 
 class LyWgradParams(ctypes.Structure):
@@ -82,6 +82,12 @@ SIGNATURES = {
     "ly_coordatt_gate_bwd": [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P],
     "ly_pool_hw_bwd": [_P, _I, _I, _I, _I, _P, _I, _P],
     "ly_maxpool_bwd": [_P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P],
+    "ly_rf_generate": [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
+    "ly_rf_bwd_attn": [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "ly_rfa_bwd": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P],
+    "ly_rf_bwd_relu": [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "ly_rf_bwd_gen": [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
+    "ly_rf_bwd_dx": [_I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P],
     "ly_detect_tail": [_P, _I, _I, _I, _I, _I, _I, _P, _F, _P, _P, _L, _L, _P],
 }
 

@@ -183,6 +183,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam3_kernel(const LyRfcbam3P
       sh[r] = ok ? P.e_shift[c + r] : 0.f;
     }
     f32x4 s1 = zero, s2 = zero;
+    const float lin_floor = P.linear ? -INFINITY : 0.f;      // ReLU as max(v, floor): floor = -inf keeps the affine value
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int pl = 16 * j + li;
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam3_kernel(const LyRfcbam3P
       }
       f32x4 v;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[t][j][r] * sc[r] + sh[r], 0.f);
+      for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[t][j][r] * sc[r] + sh[r], lin_floor);
       float* o = P.out + (((long)n * P.Ho + yy) * P.Wo + xx) * P.ldo + c;
       if ((P.ldo & 3) == 0 && c + 3 < P.N) {
         ly_stg4(o, v);

@@ -1,0 +1,413 @@
+// RFCBAMConv backward (reference models/rfa.py:113-129 under autograd), fp32, gfx950.
+//
+// Forward recap (k = kernel_size, KK = k*k, stride s, pad k/2; m = output pixel (n, ho, wo), t = tap):
+//   ug[m][t][c] = sum_u wg[c*KK + t][u] * x_u(m)[c]                 depthwise `generate` conv (x_u = the KK input taps)
+//   G = relu(ag*ug + bg)                                            generate.1 BatchNorm (batch stats) + ReLU
+//   mm[pos(m,t)] = (max_c G, mean_c G),  rfa = sigmoid(conv3x3(mm)) receptive-field attention on the k*Ho x k*Wo map
+//   cd = G * ca[n][c] * rfa[pos(m,t)]                               ca = SE channel attention
+//   out = relu(BN(Wc . cd + bias))                                  conv (k x k stride k == GEMM over (t, c)) + BN + ReLU
+//
+// The backward materialises the KK-times expanded tensors once, in [m][t][c] order (channel contiguous, so that
+// "thread = channel" kernels read and write fully coalesced rows):
+//   ly_rf_generate     ug
+//   ly_rf_bwd_attn     cd (for the conv weight gradient), d_rfa[pos] = sum_c dcd*G*ca, gmax[pos] = max_c G,
+//                      d_ca[n][c] = sum_{m,t} dcd*rfa*G
+//   ly_rfa_bwd         d_mm and d(get_weight) from d_rfa through sigmoid + 3x3 conv (maps are 2/C of the tensor)
+//   ly_rf_bwd_relu     dv = [G>0] * (dcd*rfa*ca + d_mean/C + [G == gmax]*d_max)  (over dcd), BN sums s1 = sum dv, s2 = sum dv*ug
+//   ly_rf_bwd_gen      dug = alpha*dv + kappa + lambda*ug (over dv), d(generate weight)[c][t][u] = sum_m dug[t]*x_u
+//   ly_rf_bwd_dx       dx[n,hi,wi,c] = sum over the (m, u) that read this input pixel of sum_t dug[m][t][c]*wg[c][t][u]
+// The two GEMM-shaped steps in between (dcd = du_out . Wc, dWc = du_out^T . cd) are ly_gemm_fwd / ly_wgrad.
+//
+// Thread = channel: a block covers CB = roundup64(min(C, 256)) channels x (256 / CB) pixels at a time, so the lanes
+// of a wave are 64 consecutive channels of ONE pixel: per-pixel reductions over channels are wave shuffles, and
+// per-channel sums over pixels stay in registers until one atomic flush at the end.
+#include "ly_common.cuh"
+#include "ly_params.h"
+
+struct RfGeom {
+  int n_img, H, W, C, Ho, Wo, s, k, pad;
+  int cb, subs;          // channels per block (multiple of 64), pixel sub-groups per block
+  long Mo, chunk;        // output pixels, pixels per block
+};
+
+static RfGeom rf_geom(int n_img, int H, int W, int C, int k, int s, long pixels, int& gx, int& gy) {
+  RfGeom g;
+  g.n_img = n_img; g.H = H; g.W = W; g.C = C; g.k = k; g.s = s; g.pad = k / 2;
+  g.Ho = (H + 2 * g.pad - k) / s + 1;
+  g.Wo = (W + 2 * g.pad - k) / s + 1;
+  g.Mo = (long)n_img * g.Ho * g.Wo;
+  const int cmin = C < 256 ? C : 256;
+  g.cb = (cmin + 63) / 64 * 64;
+  g.subs = LY_THREADS / g.cb;
+  gy = (C + g.cb - 1) / g.cb;
+  long blocks = 2048 / gy;
+  long chunk = (pixels + blocks - 1) / blocks;
+  const long min_chunk = 8L * g.subs;
+  if (chunk < min_chunk) chunk = min_chunk;
+  chunk = (chunk + g.subs - 1) / g.subs * g.subs;
+  g.chunk = chunk;
+  gx = (int)((pixels + chunk - 1) / chunk);
+  return g;
+}
+
+__device__ __forceinline__ float rf_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float rf_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// loads the KK input taps of output pixel (n, ho, wo) for channel c (zero padded)
+template <int K>
+__device__ __forceinline__ void rf_taps(const float* __restrict__ x, int ldx, const RfGeom& g, int n, int ho, int wo, int c, float (&xt)[K * K]) {
+#pragma unroll
+  for (int uy = 0; uy < K; ++uy)
+#pragma unroll
+    for (int ux = 0; ux < K; ++ux) {
+      const int hi = ho * g.s + uy - g.pad, wi = wo * g.s + ux - g.pad;
+      const bool ok = hi >= 0 && hi < g.H && wi >= 0 && wi < g.W;
+      const float v = x[ok ? (((long)n * g.H + hi) * g.W + wi) * ldx + c : c];
+      xt[uy * K + ux] = ok ? v : 0.f;
+    }
+}
+
+__device__ __forceinline__ void rf_pix(const RfGeom& g, long m, int& n, int& ho, int& wo) {
+  const long row = m / g.Wo;
+  wo = (int)(m - row * g.Wo);
+  n = (int)(row / g.Ho);
+  ho = (int)(row - (long)n * g.Ho);
+}
+
+// index into the k*Ho x k*Wo maps (rfa, mm, d_rfa, gmax) of tap t of output pixel (n, ho, wo)
+template <int K>
+__device__ __forceinline__ long rf_pos(const RfGeom& g, int n, int ho, int wo, int t) {
+  const int ty = t / K, tx = t - ty * K;
+  return (((long)n * g.Ho + ho) * K + ty) * ((long)K * g.Wo) + (long)wo * K + tx;
+}
+
+#define RF_THREAD_SETUP                                             \
+  const int tid = threadIdx.x;                                      \
+  const int cl = tid % g.cb, sub = tid / g.cb;                      \
+  if (sub >= g.subs) return; /* whole waves beyond subs*cb idle */  \
+  const int c_raw = blockIdx.y * g.cb + cl;                         \
+  const bool cok = c_raw < g.C;                                     \
+  const int c = cok ? c_raw : g.C - 1;                              \
+  const long m_begin = (long)blockIdx.x * g.chunk;                  \
+  const long m_end_ = m_begin + g.chunk;
+
+// ---- ug ------------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(LY_THREADS) void ly_rf_generate_kernel(const RfGeom g, const float* __restrict__ x, int ldx,
+                                                                    const float* __restrict__ wg, float* __restrict__ ug) {
+  constexpr int KK = K * K;
+  RF_THREAD_SETUP
+  const long m_end = m_end_ < g.Mo ? m_end_ : g.Mo;
+  float w[KK * KK];
+#pragma unroll
+  for (int i = 0; i < KK * KK; ++i) w[i] = wg[(long)c * KK * KK + i];
+  for (long m = m_begin + sub; m < m_end; m += g.subs) {
+    int n, ho, wo;
+    rf_pix(g, m, n, ho, wo);
+    float xt[KK];
+    rf_taps<K>(x, ldx, g, n, ho, wo, c, xt);
+    if (!cok) continue;
+#pragma unroll
+    for (int t = 0; t < KK; ++t) {
+      float a = 0.f;
+#pragma unroll
+      for (int u = 0; u < KK; ++u) a += w[t * KK + u] * xt[u];
+      ug[(m * KK + t) * g.C + c] = a;
+    }
+  }
+}
+
+// ---- cd, d_rfa, gmax, d_ca -----------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_attn_kernel(const RfGeom g, const float* __restrict__ ug, const float* __restrict__ dcd,
+                                                                    const float* __restrict__ ag, const float* __restrict__ bg,
+                                                                    const float* __restrict__ ca, const float* __restrict__ rfa,
+                                                                    float* __restrict__ cd, float* __restrict__ d_rfa, float* __restrict__ gmax,
+                                                                    float* __restrict__ d_ca) {
+  constexpr int KK = K * K;
+  RF_THREAD_SETUP
+  const long m_end = m_end_ < g.Mo ? m_end_ : g.Mo;
+  const int lane = tid & 63;
+  float a[KK], b[KK];
+#pragma unroll
+  for (int t = 0; t < KK; ++t) { a[t] = ag[t * g.C + c]; b[t] = bg[t * g.C + c]; }
+  int cur_n = -1;
+  float dca = 0.f, cav = 0.f;
+  for (long m = m_begin + sub; m < m_end; m += g.subs) {
+    int n, ho, wo;
+    rf_pix(g, m, n, ho, wo);
+    if (n != cur_n) {
+      if (cur_n >= 0 && cok) atomicAdd(d_ca + (long)cur_n * g.C + c, dca);
+      dca = 0.f; cur_n = n;
+      cav = ca[(long)n * g.C + c];
+    }
+#pragma unroll
+    for (int t = 0; t < KK; ++t) {
+      const long idx = (m * KK + t) * g.C + c;
+      const long pos = rf_pos<K>(g, n, ho, wo, t);
+      const float r = rfa[pos];
+      float G = fmaxf(__fmaf_rn(a[t], ug[idx], b[t]), 0.f);
+      float d = dcd[idx];
+      if (!cok) { G = 0.f; d = 0.f; }
+      if (cok) cd[idx] = G * cav * r;
+      dca += d * r * G;
+      const float pr = rf_wave_sum(d * G * cav);
+      const float mx = rf_wave_max(G);
+      if (lane == 0) {
+        atomicAdd(d_rfa + pos, pr);
+        atomicMax(reinterpret_cast<unsigned int*>(gmax) + pos, __float_as_uint(mx));
+      }
+    }
+  }
+  if (cur_n >= 0 && cok) atomicAdd(d_ca + (long)cur_n * g.C + c, dca);
+}
+
+// ---- get_weight (3x3 conv 2 -> 1 on the map) + sigmoid backward ------------------------------------
+// rfa = sigmoid(pre), pre[p] = sum_{ch,dy,dx} w[ch][dy][dx] * mm[p + (dy-1, dx-1)][ch]
+__global__ __launch_bounds__(LY_THREADS) void ly_rfa_bwd_kernel(const float* __restrict__ d_rfa, const float* __restrict__ rfa,
+                                                                const float* __restrict__ mm, const float* __restrict__ w18, int n_img, int Hk,
+                                                                int Wk, float* __restrict__ d_mm, float* __restrict__ dw18) {
+  __shared__ float red[18][4];
+  const long total = (long)n_img * Hk * Wk;
+  const long q = (long)blockIdx.x * LY_THREADS + threadIdx.x;
+  const bool ok = q < total;
+  const long qq = ok ? q : 0;
+  const long row = qq / Wk;
+  const int xq = (int)(qq - row * Wk);
+  const long n = row / Hk;
+  const int yq = (int)(row - n * Hk);
+  float g0 = 0.f, g1 = 0.f, dwl[18];
+  const float rq = rfa[qq];
+  const float dpre_q = ok ? d_rfa[qq] * rq * (1.f - rq) : 0.f;
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      // d_mm[q] gathers d_pre at p = q - (dy-1, dx-1);  dw gathers mm at q + (dy-1, dx-1)
+      const int yp = yq - (dy - 1), xp = xq - (dx - 1);
+      const bool inp = ok && yp >= 0 && yp < Hk && xp >= 0 && xp < Wk;
+      const long p = inp ? (n * Hk + yp) * Wk + xp : 0;
+      const float rp = rfa[p];
+      const float dp = inp ? d_rfa[p] * rp * (1.f - rp) : 0.f;
+      g0 += w18[dy * 3 + dx] * dp;
+      g1 += w18[9 + dy * 3 + dx] * dp;
+      const int ym = yq + (dy - 1), xm = xq + (dx - 1);
+      const bool inm = ok && ym >= 0 && ym < Hk && xm >= 0 && xm < Wk;
+      const long pm = inm ? (n * Hk + ym) * Wk + xm : 0;
+      dwl[dy * 3 + dx] = inm ? dpre_q * mm[2 * pm] : 0.f;
+      dwl[9 + dy * 3 + dx] = inm ? dpre_q * mm[2 * pm + 1] : 0.f;
+    }
+  if (ok) { d_mm[2 * q] = g0; d_mm[2 * q + 1] = g1; }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 18; ++i) {
+    const float s = rf_wave_sum(dwl[i]);
+    if (lane == 0) red[i][wave] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 18) atomicAdd(dw18 + threadIdx.x, red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+// ---- dv (over dcd) + BN sums ---------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_relu_kernel(const RfGeom g, const float* __restrict__ ug, float* dcd,
+                                                                    const float* __restrict__ ag, const float* __restrict__ bg,
+                                                                    const float* __restrict__ ca, const float* __restrict__ rfa,
+                                                                    const float* __restrict__ gmax, const float* __restrict__ d_mm,
+                                                                    float* __restrict__ sums) {
+  constexpr int KK = K * K;
+  RF_THREAD_SETUP
+  const long m_end = m_end_ < g.Mo ? m_end_ : g.Mo;
+  float a[KK], b[KK], s1[KK], s2[KK];
+#pragma unroll
+  for (int t = 0; t < KK; ++t) { a[t] = ag[t * g.C + c]; b[t] = bg[t * g.C + c]; s1[t] = 0.f; s2[t] = 0.f; }
+  const float invC = 1.f / (float)g.C;
+  if (cok)
+    for (long m = m_begin + sub; m < m_end; m += g.subs) {
+      int n, ho, wo;
+      rf_pix(g, m, n, ho, wo);
+      const float cav = ca[(long)n * g.C + c];
+#pragma unroll
+      for (int t = 0; t < KK; ++t) {
+        const long idx = (m * KK + t) * g.C + c;
+        const long pos = rf_pos<K>(g, n, ho, wo, t);
+        const float u = ug[idx];
+        const float G = fmaxf(__fmaf_rn(a[t], u, b[t]), 0.f);
+        float dG = dcd[idx] * rfa[pos] * cav + d_mm[2 * pos + 1] * invC;
+        if (G == gmax[pos]) dG += d_mm[2 * pos];
+        const float dv = G > 0.f ? dG : 0.f;
+        dcd[idx] = dv;
+        s1[t] += dv;
+        s2[t] += dv * u;
+      }
+    }
+  if (cok) {
+    const int CK = g.C * KK;
+#pragma unroll
+    for (int t = 0; t < KK; ++t) {
+      atomicAdd(sums + t * g.C + c, s1[t]);
+      atomicAdd(sums + CK + t * g.C + c, s2[t]);
+    }
+  }
+}
+
+// ---- dug (over dv) + d(generate weight) ------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_gen_kernel(const RfGeom g, const float* __restrict__ x, int ldx, const float* __restrict__ ug,
+                                                                   float* dv, const float* __restrict__ alpha, const float* __restrict__ kappa,
+                                                                   const float* __restrict__ lambda, float* __restrict__ dwg) {
+  constexpr int KK = K * K;
+  RF_THREAD_SETUP
+  const long m_end = m_end_ < g.Mo ? m_end_ : g.Mo;
+  float al[KK], ka[KK], la[KK], acc[KK * KK];
+#pragma unroll
+  for (int t = 0; t < KK; ++t) { al[t] = alpha[t * g.C + c]; ka[t] = kappa[t * g.C + c]; la[t] = lambda[t * g.C + c]; }
+#pragma unroll
+  for (int i = 0; i < KK * KK; ++i) acc[i] = 0.f;
+  if (cok)
+    for (long m = m_begin + sub; m < m_end; m += g.subs) {
+      int n, ho, wo;
+      rf_pix(g, m, n, ho, wo);
+      float xt[KK];
+      rf_taps<K>(x, ldx, g, n, ho, wo, c, xt);
+#pragma unroll
+      for (int t = 0; t < KK; ++t) {
+        const long idx = (m * KK + t) * g.C + c;
+        const float d = al[t] * dv[idx] + ka[t] + la[t] * ug[idx];
+        dv[idx] = d;
+#pragma unroll
+        for (int u = 0; u < KK; ++u) acc[t * KK + u] += d * xt[u];
+      }
+    }
+  if (cok) {
+#pragma unroll
+    for (int i = 0; i < KK * KK; ++i) atomicAdd(dwg + (long)c * KK * KK + i, acc[i]);
+  }
+}
+
+// ---- dx ----------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_dx_kernel(const RfGeom g, const float* __restrict__ dug, const float* __restrict__ wg,
+                                                                  float* __restrict__ dx, int lddx) {
+  constexpr int KK = K * K;
+  RF_THREAD_SETUP
+  const long Mi = (long)g.n_img * g.H * g.W;
+  const long m_end = m_end_ < Mi ? m_end_ : Mi;
+  float w[KK * KK];
+#pragma unroll
+  for (int i = 0; i < KK * KK; ++i) w[i] = wg[(long)c * KK * KK + i];
+  if (!cok) return;
+  for (long p = m_begin + sub; p < m_end; p += g.subs) {
+    const long row = p / g.W;
+    const int wi = (int)(p - row * g.W);
+    const int n = (int)(row / g.H);
+    const int hi = (int)(row - (long)n * g.H);
+    float acc = 0.f;
+#pragma unroll
+    for (int uy = 0; uy < K; ++uy) {
+      const int hh = hi + g.pad - uy;
+      if (hh < 0 || hh % g.s != 0) continue;
+      const int ho = hh / g.s;
+      if (ho >= g.Ho) continue;
+#pragma unroll
+      for (int ux = 0; ux < K; ++ux) {
+        const int ww = wi + g.pad - ux;
+        if (ww < 0 || ww % g.s != 0) continue;
+        const int wo = ww / g.s;
+        if (wo >= g.Wo) continue;
+        const long m = ((long)n * g.Ho + ho) * g.Wo + wo;
+#pragma unroll
+        for (int t = 0; t < KK; ++t) acc += dug[(m * KK + t) * g.C + c] * w[t * KK + (uy * K + ux)];
+      }
+    }
+    dx[p * lddx + c] = acc;
+  }
+}
+
+// ---- C entry points ------------------------------------------------------------------------------
+#define RF_ARGS_OK(k, C) LY_CHECK(((k) == 1 || (k) == 3) && (C) > 0, "rfcbam backward: kernel_size must be 1 or 3")
+
+extern "C" int ly_rf_generate(const float* x, int ldx, int n_img, int H, int W, int C, int k, int s, const float* wg, float* ug, void* stream) {
+  RF_ARGS_OK(k, C);
+  LY_CHECK(x && wg && ug, "rf_generate: null pointer");
+  int gx, gy;
+  const long Mo = (long)n_img * ((H + 2 * (k / 2) - k) / s + 1) * ((W + 2 * (k / 2) - k) / s + 1);
+  const RfGeom g = rf_geom(n_img, H, W, C, k, s, Mo, gx, gy);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (k == 3) hipLaunchKernelGGL(ly_rf_generate_kernel<3>, dim3(gx, gy), dim3(LY_THREADS), 0, st, g, x, ldx, wg, ug);
+  else hipLaunchKernelGGL(ly_rf_generate_kernel<1>, dim3(gx, gy), dim3(LY_THREADS), 0, st, g, x, ldx, wg, ug);
+  LY_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ly_rf_bwd_attn(int n_img, int H, int W, int C, int k, int s, const float* ug, const float* dcd, const float* ag, const float* bg,
+                              const float* ca, const float* rfa, float* cd, float* d_rfa, float* gmax, float* d_ca, void* stream) {
+  RF_ARGS_OK(k, C);
+  LY_CHECK(ug && dcd && ag && bg && ca && rfa && cd && d_rfa && gmax && d_ca, "rf_bwd_attn: null pointer");
+  int gx, gy;
+  const long Mo = (long)n_img * ((H + 2 * (k / 2) - k) / s + 1) * ((W + 2 * (k / 2) - k) / s + 1);
+  const RfGeom g = rf_geom(n_img, H, W, C, k, s, Mo, gx, gy);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (k == 3) hipLaunchKernelGGL(ly_rf_bwd_attn_kernel<3>, dim3(gx, gy), dim3(LY_THREADS), 0, st, g, ug, dcd, ag, bg, ca, rfa, cd, d_rfa, gmax, d_ca);
+  else hipLaunchKernelGGL(ly_rf_bwd_attn_kernel<1>, dim3(gx, gy), dim3(LY_THREADS), 0, st, g, ug, dcd, ag, bg, ca, rfa, cd, d_rfa, gmax, d_ca);
+  LY_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ly_rfa_bwd(const float* d_rfa, const float* rfa, const float* mm, const float* w18, int n_img, int Hk, int Wk, float* d_mm,
+                          float* dw18, void* stream) {
+  LY_CHECK(d_rfa && rfa && mm && w18 && d_mm && dw18 && n_img > 0 && Hk > 0 && Wk > 0, "rfa_bwd: bad arguments");
+  const long total = (long)n_img * Hk * Wk;
+  hipLaunchKernelGGL(ly_rfa_bwd_kernel, dim3((unsigned)((total + LY_THREADS - 1) / LY_THREADS)), dim3(LY_THREADS), 0,
+                     reinterpret_cast<hipStream_t>(stream), d_rfa, rfa, mm, w18, n_img, Hk, Wk, d_mm, dw18);
+  LY_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ly_rf_bwd_relu(int n_img, int H, int W, int C, int k, int s, const float* ug, float* dcd, const float* ag, const float* bg,
+                              const float* ca, const float* rfa, const float* gmax, const float* d_mm, float* sums, void* stream) {
+  RF_ARGS_OK(k, C);
+  LY_CHECK(ug && dcd && ag && bg && ca && rfa && gmax && d_mm && sums, "rf_bwd_relu: null pointer");
+  int gx, gy;
+  const long Mo = (long)n_img * ((H + 2 * (k / 2) - k) / s + 1) * ((W + 2 * (k / 2) - k) / s + 1);
+  const RfGeom g = rf_geom(n_img, H, W, C, k, s, Mo, gx, gy);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (k == 3) hipLaunchKernelGGL(ly_rf_bwd_relu_kernel<3>, dim3(gx, gy), dim3(LY_THREADS), 0, st, g, ug, dcd, ag, bg, ca, rfa, gmax, d_mm, sums);
+  else hipLaunchKernelGGL(ly_rf_bwd_relu_kernel<1>, dim3(gx, gy), dim3(LY_THREADS), 0, st, g, ug, dcd, ag, bg, ca, rfa, gmax, d_mm, sums);
+  LY_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ly_rf_bwd_gen(const float* x, int ldx, int n_img, int H, int W, int C, int k, int s, const float* ug, float* dv, const float* alpha,
+                             const float* kappa, const float* lambda, float* dwg, void* stream) {
+  RF_ARGS_OK(k, C);
+  LY_CHECK(x && ug && dv && alpha && kappa && lambda && dwg, "rf_bwd_gen: null pointer");
+  int gx, gy;
+  const long Mo = (long)n_img * ((H + 2 * (k / 2) - k) / s + 1) * ((W + 2 * (k / 2) - k) / s + 1);
+  const RfGeom g = rf_geom(n_img, H, W, C, k, s, Mo, gx, gy);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (k == 3) hipLaunchKernelGGL(ly_rf_bwd_gen_kernel<3>, dim3(gx, gy), dim3(LY_THREADS), 0, st, g, x, ldx, ug, dv, alpha, kappa, lambda, dwg);
+  else hipLaunchKernelGGL(ly_rf_bwd_gen_kernel<1>, dim3(gx, gy), dim3(LY_THREADS), 0, st, g, x, ldx, ug, dv, alpha, kappa, lambda, dwg);
+  LY_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ly_rf_bwd_dx(int n_img, int H, int W, int C, int k, int s, const float* dug, const float* wg, float* dx, int lddx, void* stream) {
+  RF_ARGS_OK(k, C);
+  LY_CHECK(dug && wg && dx, "rf_bwd_dx: null pointer");
+  int gx, gy;
+  const RfGeom g = rf_geom(n_img, H, W, C, k, s, (long)n_img * H * W, gx, gy);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (k == 3) hipLaunchKernelGGL(ly_rf_bwd_dx_kernel<3>, dim3(gx, gy), dim3(LY_THREADS), 0, st, g, dug, wg, dx, lddx);
+  else hipLaunchKernelGGL(ly_rf_bwd_dx_kernel<1>, dim3(gx, gy), dim3(LY_THREADS), 0, st, g, dug, wg, dx, lddx);
+  LY_LAUNCH_CHECK();
+  return 0;
+}

@@ -433,3 +433,131 @@ class SppfPool(torch.autograd.Function):
         for j in (2, 1, 0):                           # m(y_j) = y_{j+1}: add its gradient into slot j
             ops.maxpool_bwd(buf, j * c, c4, acc, (j + 1) * c, c4, n, h, w, c, ctx.k, acc, j * c, c4)
         return acc[:, :c], None
+
+
+# --------------------------------------------------------------------------------------------------
+# RFCBAMConv (models/rfa.py:113-129).  forward = the fused inference kernels with batch statistics;
+# backward = csrc/ly_rfcbam_bwd.hip.  The SE vector `ca` [n, c] is an INPUT (computed by torch ops on pooled
+# vectors under autograd, see rfcbam_train), its gradient is returned.
+# --------------------------------------------------------------------------------------------------
+def _lib():
+    from . import capi
+    return capi
+
+
+class RfcbamFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mod, x, ca, gen_w, gen_gamma, gen_beta, getw, conv_w, conv_b, out_gamma, out_beta):
+        xr, ld = ops.rows(x)
+        n, c, h, w = xr.shape
+        k, s, o = mod.kernel_size, mod.stride, mod.o
+        ho, wo = (h + 2 * (k // 2) - k) // s + 1, (w + 2 * (k // 2) - k) // s + 1
+        P = mod._packed()
+        ca = ca.detach().contiguous()
+        bias = conv_b.detach().float().contiguous()
+        if k == 1:
+            gwv = gen_w.detach().float().view(c)
+            mom = ops.chan_moments(xr, ld, n * h * w, c)
+            gs, gb, gmean, ginv = ops.bn_batch_stats(mod.generate[1], gwv * mom[:c], gwv * gwv * mom[c:], n * h * w)
+            a1 = (gwv * gs).contiguous()
+            mm = ops.rfcbam_stats(xr, ld, n, h, w, c, 1, 1, a1=a1, b1=gb)
+            rfa = ops.rfa_map(mm, P["w18"])
+            kw = dict(M=n * h * w, H=h, W=w, K=c, N=o, a0=xr, lda0=ld, k0=c, wp=P["wp"], ldo=o, pro=ops.PRO_AFFINE_RELU_CA,
+                      p_scale=a1, p_shift=gb, p_ca=ca, rowscale=rfa)
+            stats = torch.zeros(2 * o, dtype=torch.float32, device=xr.device)
+            ops.gemm(out=None, e_scale=None, e_shift=bias, stats=stats, **kw)
+            es, t, omean, oinv = ops.bn_batch_stats(mod.conv[1], stats[:o], stats[o:], n * h * w)
+            out = ops.empty_nhwc(n, o, h, w, xr)
+            ops.gemm(out=out, e_scale=es, e_shift=(bias * es + t).contiguous(), act=ACT_RELU, **kw)
+            ctx.fwd = dict(kw=kw)
+        else:
+            th, tw = ops.pick_tile(ho, wo)
+            s1, s2, cnt = ops.rfcbam_generate_stats(xr, ld, n, h, w, c, s, gen_w)
+            gs, gb, gmean, ginv = ops.bn_batch_stats(mod.generate[1], s1, s2, cnt)
+            wq_stats = pack.rfcbam_gen_weights(gen_w, gs, gb, 32, False)
+            wq_main = pack.rfcbam_gen_weights(gen_w, gs, gb, 16, True)
+            mm = ops.rfcbam_stats(xr, ld, n, h, w, c, 3, s, wg=wq_stats, th=th, tw=tw)
+            rfa = ops.rfa_map(mm, P["w18"])
+            kw = dict(n=n, h=h, w=w, c=c, ho=ho, wo=wo, N=o, s=s, th=th, tw=tw, x=xr, ldx=ld, wg=wq_main, ca=ca, rfa=rfa, wp=P["wp"], ldo=o)
+            stats = torch.zeros(2 * o, dtype=torch.float32, device=xr.device)
+            ops.rfcbam3(out=None, e_scale=torch.ones_like(bias), e_shift=bias, stats=stats, **kw)
+            es, t, omean, oinv = ops.bn_batch_stats(mod.conv[1], stats[:o], stats[o:], n * ho * wo)
+            out = ops.empty_nhwc(n, o, ho, wo, xr)
+            ops.rfcbam3(out=out, e_scale=es, e_shift=(bias * es + t).contiguous(), **kw)
+            ctx.fwd = dict(kw=kw)
+        ctx.geom = (n, c, h, w, k, s, o, ho, wo, ld)
+        ctx.save_for_backward(xr, ca, gen_w, getw, conv_w, bias, gs, gb, gmean, ginv, es, t, omean, oinv, mm, rfa)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        xr, ca, gen_w, getw, conv_w, bias, gs, gb, gmean, ginv, es, t, omean, oinv, mm, rfa = ctx.saved_tensors
+        n, c, h, w, k, s, o, ho, wo, ld = ctx.geom
+        kk = k * k
+        mo = n * ho * wo
+        dev = xr.device
+        L = _lib()
+        st = L.stream_ptr()
+        p = L.ptr
+        with torch.no_grad():
+            dy = _rows_dense(dy)
+            # 1-2. output conv: recompute pre-BN value (bias included), BN + ReLU backward
+            u = ops.empty_nhwc(n, o, ho, wo, xr)
+            if k == 1:
+                ops.gemm(out=u, e_scale=None, e_shift=bias, **ctx.fwd["kw"])
+            else:
+                ops.rfcbam3(out=u, e_scale=torch.ones_like(bias), e_shift=bias, linear=True, **ctx.fwd["kw"])
+            du, dgo, dbo = affine_backward(dy, u, es, t, ACT_RELU, omean, oinv, True)
+            # 3. dcd [mo][t][c]
+            wc = conv_w.detach().float().reshape(o, c, kk).permute(0, 2, 1).reshape(o, kk * c)       # columns (t, c)
+            dcd = torch.empty((mo, kk * c), dtype=torch.float32, device=dev)
+            ops.gemm(M=mo, H=ho, W=wo, K=o, N=kk * c, a0=du, lda0=o, k0=o, wp=pack.frag_pack3(wc.t()), out=dcd, ldo=kk * c)
+            # 4. ug
+            wg = gen_w.detach().float().reshape(c * kk, kk).contiguous()
+            ug = torch.empty((mo, kk * c), dtype=torch.float32, device=dev)
+            L.check(L.lib().ly_rf_generate(p(xr), ld, n, h, w, c, k, s, p(wg), p(ug), st), "ly_rf_generate")
+            # 5. cd, d_rfa, gmax, d_ca
+            tc = lambda v: v.view(c, kk).t().contiguous().view(-1)                                     # [c*kk + t] -> [t*c + c]
+            ag, bg = tc(gs), tc(gb)
+            cd = torch.empty((mo, kk * c), dtype=torch.float32, device=dev)
+            d_rfa = torch.zeros_like(rfa)
+            gmax = torch.zeros_like(rfa)
+            d_ca = torch.zeros_like(ca)
+            L.check(L.lib().ly_rf_bwd_attn(n, h, w, c, k, s, p(ug), p(dcd), p(ag), p(bg), p(ca), p(rfa), p(cd), p(d_rfa), p(gmax), p(d_ca), st),
+                    "ly_rf_bwd_attn")
+            # 6. conv weight gradient
+            dwc = torch.zeros(o, kk * c, dtype=torch.float32, device=dev)
+            ops.wgrad(M=mo, H=ho, W=wo, N=o, du=du, lddu=o, x=cd, ldx=kk * c, Hin=ho, Win=wo, Cin=kk * c, dw=dwc, lddw=kk * c)
+            dwc = dwc.view(o, kk, c).permute(0, 2, 1).reshape(conv_w.shape)
+            # 7. get_weight + sigmoid
+            w18 = getw.detach().float().reshape(18).contiguous()
+            d_mm = torch.empty_like(mm)
+            dw18 = torch.zeros(18, dtype=torch.float32, device=dev)
+            L.check(L.lib().ly_rfa_bwd(p(d_rfa), p(rfa), p(mm), p(w18), n, k * ho, k * wo, p(d_mm), p(dw18), st), "ly_rfa_bwd")
+            # 8. through max/mean, ca, rfa and ReLU; generate-BN sums
+            sums = torch.zeros(2 * kk * c, dtype=torch.float32, device=dev)
+            L.check(L.lib().ly_rf_bwd_relu(n, h, w, c, k, s, p(ug), p(dcd), p(ag), p(bg), p(ca), p(rfa), p(gmax), p(d_mm), p(sums), st),
+                    "ly_rf_bwd_relu")
+            # 9. generate BatchNorm coefficients ([t][c] order)
+            dgg_tc, dbg_tc, alpha, kappa, lam = bn_backward_coeffs(sums[:kk * c], sums[kk * c:], ag, tc(gmean), tc(ginv), mo, True)
+            ct = lambda v: v.view(kk, c).t().contiguous().view(-1)
+            # 10. dug, generate weight gradient
+            dwg = torch.zeros(c * kk, kk, dtype=torch.float32, device=dev)
+            L.check(L.lib().ly_rf_bwd_gen(p(xr), ld, n, h, w, c, k, s, p(ug), p(dcd), p(alpha), p(kappa), p(lam), p(dwg), st), "ly_rf_bwd_gen")
+            # 11. dx
+            dx = None
+            if ctx.needs_input_grad[1]:
+                dx = ops.empty_nhwc(n, c, h, w, xr)
+                L.check(L.lib().ly_rf_bwd_dx(n, h, w, c, k, s, p(dcd), p(wg), p(dx), c, st), "ly_rf_bwd_dx")
+        return (None, dx, d_ca, dwg.view(gen_w.shape), ct(dgg_tc), ct(dbg_tc), dw18.view(getw.shape), dwc, torch.zeros_like(bias), dgo, dbo)
+
+
+def rfcbam_train(mod, x):
+    """RFCBAMConv.forward in training: SE on pooled vectors (torch, autograd) + RfcbamFn."""
+    import torch.nn.functional as F
+    n, c, h, w = x.shape
+    gap = PoolHW.apply(x)[:, :h].mean(1)                                     # [n, c]: mean over h of the row means
+    ca = torch.sigmoid(F.linear(F.relu(F.linear(gap, mod.se.fc[0].weight)), mod.se.fc[2].weight))
+    g, cv = mod.generate, mod.conv
+    return RfcbamFn.apply(mod, x, ca, g[0].weight, g[1].weight, g[1].bias, mod.get_weight[0].weight, cv[0].weight, cv[0].bias,
+                          cv[1].weight, cv[1].bias)

@@ -505,8 +505,9 @@ class RFCBAMConv(nn.Module):
         if pr is not None:
             return pr
         ops.require_cuda(x, "RFCBAMConv")
-        if self.training:
-            _no_grad_needed(x, "RFCBAMConv")
+        if _grad_mode(self):
+            from . import grad
+            return grad.rfcbam_train(self, x)
         xr, ld = ops.rows(x)
         n, c, h, w = xr.shape
         k, s = self.kernel_size, self.stride

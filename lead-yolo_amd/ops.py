@@ -189,9 +189,9 @@ def rfa_map(mm, w18):
     return rfa
 
 
-def rfcbam3(*, n, h, w, c, ho, wo, N, s, th, tw, x, ldx, wg, ca, rfa, wp, e_scale, e_shift, out, ldo, stats=None):
+def rfcbam3(*, n, h, w, c, ho, wo, N, s, th, tw, x, ldx, wg, ca, rfa, wp, e_scale, e_shift, out, ldo, stats=None, linear=False):
     P = capi.LyRfcbam3Params(n, h, w, c, ho, wo, N, s, th, tw, _p(x), ldx, _p(wg), _p(ca), _p(rfa), _p(wp), _p(e_scale),
-                             _p(e_shift), _p(out), ldo, _p(stats))
+                             _p(e_shift), _p(out), ldo, _p(stats), int(linear))
     mt = 4 if N > 128 else 2 if N > 64 else 1
     mo = n * ho * wo
     with _Timed(f"ly_rfcbam3_kernel<{mt}>", 2.0 * mo * (9 * c * N + 81 * c), 4.0 * (n * h * w * c + mo * N + 9 * c * N)):

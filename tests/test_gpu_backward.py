@@ -62,10 +62,11 @@ def test_module_backward_golden(name):
     y, dx, gp = _hip_grads(m, x, r)
     _close(y, arr["y_train"], name + " y_train")
     _close(dx, arr["dx_train"], name + " dx")
+    nfloor = 1e-4 * max(meta["grad_norms"].values())      # slack for gradients that are exactly zero in exact arithmetic
     for k, want in meta["grad_norms"].items():
         assert gp[k] is not None, f"{name}: no gradient for {k}"
         got = float(gp[k].double().norm())
-        assert abs(got - want) <= 2e-3 * max(want, 1e-4) + 1e-5, f"{name} |d{k}| = {got:.6e}, reference {want:.6e}"
+        assert abs(got - want) <= 2e-3 * want + nfloor + 1e-5, f"{name} |d{k}| = {got:.6e}, reference {want:.6e}"
     _, dxo, gpo = _oracle_grads(meta["kind"], meta["ctor"], st, x, r)
     for k, want in gpo.items():
         _close(gp[k], want, f"{name} d{k}", floor=_floor(gpo))
@@ -116,6 +117,9 @@ def test_module_backward_shapes_vs_oracle(kind, ctor, shape):
     with torch.no_grad():
         y0 = _run(kind, list(ctor), copy.deepcopy(st), x.clone(), True)[0]
     r = synth.synth_input(tuple(y0.shape), 41 + shape[1])
+    # no cotangent on outputs within 1e-4 of a ReLU kink: whether such an element is "on" is decided by rounding
+    # (5e-6 forward differences), and one flipped element changes every gradient by O(1) * r there
+    r = r * (y0.abs() > 1e-4)
     yo, dxo, gpo = _oracle_grads(kind, ctor, st, x, r)
     y, dx, gp = _hip_grads(m.to(_dev()).train(), x, r)
     _close(y, yo, f"{kind}{ctor} y")

@@ -445,6 +445,14 @@ def _lib():
     return capi
 
 
+DEBUG_TAP = None        # tools/: callable(name, tensor) observing backward intermediates
+
+
+def _tap(name, t):
+    if DEBUG_TAP is not None:
+        DEBUG_TAP(name, t)
+
+
 class RfcbamFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mod, x, ca, gen_w, gen_gamma, gen_beta, getw, conv_w, conv_b, out_gamma, out_beta):
@@ -507,11 +515,14 @@ class RfcbamFn(torch.autograd.Function):
                 ops.gemm(out=u, e_scale=None, e_shift=bias, **ctx.fwd["kw"])
             else:
                 ops.rfcbam3(out=u, e_scale=torch.ones_like(bias), e_shift=bias, linear=True, **ctx.fwd["kw"])
+            _tap("rf.dy", dy); _tap("rf.u", u)
             du, dgo, dbo = affine_backward(dy, u, es, t, ACT_RELU, omean, oinv, True)
+            _tap("rf.du", du)
             # 3. dcd [mo][t][c]
             wc = conv_w.detach().float().reshape(o, c, kk).permute(0, 2, 1).reshape(o, kk * c)       # columns (t, c)
             dcd = torch.empty((mo, kk * c), dtype=torch.float32, device=dev)
             ops.gemm(M=mo, H=ho, W=wo, K=o, N=kk * c, a0=du, lda0=o, k0=o, wp=pack.frag_pack3(wc.t()), out=dcd, ldo=kk * c)
+            _tap("rf.dcd", dcd)
             # 4. ug
             wg = gen_w.detach().float().reshape(c * kk, kk).contiguous()
             ug = torch.empty((mo, kk * c), dtype=torch.float32, device=dev)
@@ -525,6 +536,8 @@ class RfcbamFn(torch.autograd.Function):
             d_ca = torch.zeros_like(ca)
             L.check(L.lib().ly_rf_bwd_attn(n, h, w, c, k, s, p(ug), p(dcd), p(ag), p(bg), p(ca), p(rfa), p(cd), p(d_rfa), p(gmax), p(d_ca), st),
                     "ly_rf_bwd_attn")
+            _tap("rf.ug", ug); _tap("rf.cd", cd); _tap("rf.d_rfa", d_rfa); _tap("rf.gmax", gmax); _tap("rf.d_ca", d_ca)
+            _tap("rf.rfa", rfa); _tap("rf.ca", ca); _tap("rf.ag", ag); _tap("rf.bg", bg)
             # 6. conv weight gradient
             dwc = torch.zeros(o, kk * c, dtype=torch.float32, device=dev)
             ops.wgrad(M=mo, H=ho, W=wo, N=o, du=du, lddu=o, x=cd, ldx=kk * c, Hin=ho, Win=wo, Cin=kk * c, dw=dwc, lddw=kk * c)
@@ -538,6 +551,7 @@ class RfcbamFn(torch.autograd.Function):
             sums = torch.zeros(2 * kk * c, dtype=torch.float32, device=dev)
             L.check(L.lib().ly_rf_bwd_relu(n, h, w, c, k, s, p(ug), p(dcd), p(ag), p(bg), p(ca), p(rfa), p(gmax), p(d_mm), p(sums), st),
                     "ly_rf_bwd_relu")
+            _tap("rf.d_mm", d_mm); _tap("rf.dv", dcd); _tap("rf.sums", sums)
             # 9. generate BatchNorm coefficients ([t][c] order)
             dgg_tc, dbg_tc, alpha, kappa, lam = bn_backward_coeffs(sums[:kk * c], sums[kk * c:], ag, tc(gmean), tc(ginv), mo, True)
             ct = lambda v: v.view(kk, c).t().contiguous().view(-1)

@@ -1,0 +1,83 @@
+"""The reference's optimisation step (train.py:295-341) on the HIP model: SURVEY.md §8 row T.
+
+    imgs.float()/255 -> forward (train-mode, HIP) -> ComputeLoss -> backward (HIP, grad.py) ->
+    [gradient all-reduce, ddp.GradReducer] -> clip_grad_norm_(10) -> SGD(nesterov) -> [EMA]
+
+Mirrors `smart_optimizer` (utils/torch_utils.py:318-346: three parameter groups — biases without decay,
+BatchNorm weights without decay, all other weights with decay) and `ModelEMA` (utils/torch_utils.py:404-432).
+The optimiser itself is torch.optim.SGD, exactly as in the reference; a fused multi-tensor step is §8(f)#3.
+"""
+import math
+from copy import deepcopy
+
+import torch
+import torch.nn as nn
+
+_NORMS = tuple(v for k, v in nn.__dict__.items() if "Norm" in k and isinstance(v, type))
+
+
+def param_groups(model):
+    """-> (biases, decayed weights, norm weights), each in module-traversal order."""
+    bias, decay, norm = [], [], []
+    for mod in model.modules():
+        for name, p in mod.named_parameters(recurse=False):
+            if name == "bias":
+                bias.append(p)
+            elif name == "weight" and isinstance(mod, _NORMS):
+                norm.append(p)
+            else:
+                decay.append(p)
+    return bias, decay, norm
+
+
+def smart_optimizer(model, name="SGD", lr=0.001, momentum=0.9, decay=1e-5):
+    bias, dec, norm = param_groups(model)
+    if name != "SGD":
+        raise NotImplementedError("the LEAD-YOLO recipe trains with SGD(nesterov); other optimisers are not wired")
+    opt = torch.optim.SGD(bias, lr=lr, momentum=momentum, nesterov=True)
+    opt.add_param_group({"params": dec, "weight_decay": decay})
+    opt.add_param_group({"params": norm, "weight_decay": 0.0})
+    return opt
+
+
+class ModelEMA:
+    """Exponential moving average of the model state (parameters and buffers), decay d*(1 - exp(-updates/tau))."""
+
+    def __init__(self, model, decay=0.9999, tau=2000, updates=0):
+        self.ema = deepcopy(model).eval()
+        self.updates = updates
+        self.decay = lambda x: decay * (1 - math.exp(-x / tau))
+        for p in self.ema.parameters():
+            p.requires_grad_(False)
+
+    def update(self, model):
+        self.updates += 1
+        d = self.decay(self.updates)
+        msd = model.state_dict()
+        with torch.no_grad():
+            for k, v in self.ema.state_dict().items():
+                if v.dtype.is_floating_point:
+                    v.mul_(d).add_(msd[k].detach(), alpha=1 - d)
+
+
+def train_step(model, compute_loss, optimizer, imgs, targets, ema=None, reducer=None, world_size=1, max_norm=10.0):
+    """One optimisation step; imgs uint8 or float [B,3,H,W] on the model's device, targets [n,6].
+    Returns (loss, loss_items) as detached device tensors (no host sync)."""
+    if imgs.dtype == torch.uint8:
+        imgs = imgs.float() / 255
+    if reducer is not None:
+        reducer.reset()
+    pred = model(imgs)
+    loss, items = compute_loss(pred, targets)
+    if world_size > 1:
+        loss = loss * world_size            # the reducer averages gradients (train.py:321-322)
+    loss.backward()
+    if reducer is not None:
+        reducer.wait()
+    torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=max_norm)
+    optimizer.step()
+    if reducer is None:
+        optimizer.zero_grad(set_to_none=True)      # with a reducer the gradients are bucket views, zeroed by reset()
+    if ema is not None:
+        ema.update(model)
+    return loss.detach(), items

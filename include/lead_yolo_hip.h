@@ -246,6 +246,26 @@ int ly_rf_bwd_gen(const float* x, int ldx, int n_img, int H, int W, int C, int k
 /* dx[n,hi,wi,c] = sum over (m, u) reading that input pixel of sum_t dug[m][t][c]*wg[c*KK + t][u]  (written)           */
 int ly_rf_bwd_dx(int n_img, int H, int W, int C, int k, int s, const float* dug, const float* wg, float* dx, int lddx, void* stream);
 
+/* ---- per-channel BatchNorm vector work and weight packing, one launch each ------------------------------------------
+ * STATISTICS ACCUMULATORS ARE STRIPED: every `stats` / `sums` / `mom` argument of the statistics passes above
+ * (ly_gemm_fwd, ly_conv3x3_fwd, ly_rfcbam3_fwd, ly_mlpblock_fwd, ly_chan_moments, ly_bnact_bwd_reduce) is
+ * LY_STATS_STRIPES consecutive copies of the documented [2*nch] array (block b adds into copy b % LY_STATS_STRIPES);
+ * the caller zeroes all copies and the two entry points below sum them (in double).                                  */
+#define LY_STATS_STRIPES 32
+/* Train-mode BatchNorm (nn.BatchNorm2d forward, training=True) from the striped sums of channels c_off .. c_off+N-1
+ * (second moments at +nch): scale = gamma*invstd, shift = beta - mean*scale (+ bias*scale), batch mean / invstd for
+ * the backward, running_mean/var updated with `momentum` (unbiased variance), *nbt += 1.  NULL = not wanted.           */
+int ly_bn_finalize(const float* stats, int stripes, int nch, int c_off, int N, double count, const float* gamma, const float* beta,
+                   const float* bias, float eps, float momentum, float* running_mean, float* running_var, long* nbt, float* scale,
+                   float* shift, float* mean, float* invstd, void* stream);
+/* BatchNorm backward coefficients from striped sums [2N] (sum dv, sum dv*u): dgamma, dbeta and
+ * du = alpha*dv + kappa + lambda*u  (train != 0: batch statistics; else alpha = a, kappa = lambda = 0).               */
+int ly_bn_bwd_coeffs(const float* sums, int stripes, int N, double count, const float* a, const float* mean, const float* invstd, int train,
+                     float* dgamma, float* dbeta, float* alpha, float* kappa, float* lambda, void* stream);
+/* bf16x3 fragment packing of W[r][k] = w[r*ld_r + k*ld_k] (R x K, rows zero padded to max(R, rows_to)) into the
+ * [T][S][2 planes][64 lanes][8] bf16 layout the contraction kernels read (csrc/ly_tile.cuh).                          */
+int ly_frag_pack3(const float* w, int R, int K, long ld_r, long ld_k, int rows_to, void* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -44,6 +44,7 @@ class LyWgradParams(ctypes.Structure):
                 ("dw", _P), ("lddw", _I)]
 
 
+STATS_STRIPES = 32
 ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
 GATHER_ROWS, GATHER_UP2, GATHER_PATCH, GATHER_PATCH_NCHW = 0, 1, 2, 3
 PRO_NONE, PRO_GATE, PRO_AFFINE_RELU_CA = 0, 1, 2
@@ -88,6 +89,9 @@ SIGNATURES = {
     "ly_rf_bwd_relu": [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "ly_rf_bwd_gen": [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "ly_rf_bwd_dx": [_I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P],
+    "ly_bn_finalize": [_P, _I, _I, _I, _I, ctypes.c_double, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P],
+    "ly_bn_bwd_coeffs": [_P, _I, _I, ctypes.c_double, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P],
+    "ly_frag_pack3": [_P, _I, _I, _L, _L, _I, _P, _P],
     "ly_detect_tail": [_P, _I, _I, _I, _I, _I, _I, _P, _F, _P, _P, _L, _L, _P],
 }
 

@@ -560,10 +560,11 @@ __global__ __launch_bounds__(LY_THREADS) void ly_chan_moments_kernel(const float
   __syncthreads();
   if (j0 == 0) {
     for (int g = 1; g < groups; ++g) { s1 += red1[g * nc4 + c4]; s2 += red2[g * nc4 + c4]; }
+    float* m = mom + (size_t)(blockIdx.x & (LY_STATS_STRIPES - 1)) * 2 * C;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      atomicAdd(mom + 4 * c4 + r, s1[r]);
-      atomicAdd(mom + C + 4 * c4 + r, s2[r]);
+      atomicAdd(m + 4 * c4 + r, s1[r]);
+      atomicAdd(m + C + 4 * c4 + r, s2[r]);
     }
   }
 }

@@ -60,10 +60,11 @@ __global__ __launch_bounds__(LY_THREADS) void ly_bnact_bwd_reduce_kernel(const f
   __syncthreads();
   if (j0 == 0) {
     for (int g = 1; g < groups; ++g) { s1 += red1[g * nc4 + c4]; s2 += red2[g * nc4 + c4]; }
+    float* sm = sums + (size_t)(blockIdx.x & (LY_STATS_STRIPES - 1)) * 2 * C;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      atomicAdd(sums + 4 * c4 + r, s1[r]);
-      atomicAdd(sums + C + 4 * c4 + r, s2[r]);
+      atomicAdd(sm + 4 * c4 + r, s1[r]);
+      atomicAdd(sm + C + 4 * c4 + r, s2[r]);
     }
   }
 }
@@ -457,6 +458,121 @@ extern "C" int ly_maxpool_bwd(const float* x, int ldx, const float* dy, int lddy
   LY_CHECK((C & 3) == 0 && (ldx & 3) == 0 && (lddy & 3) == 0, "maxpool_bwd: C / ld must be multiples of 4");
   hipLaunchKernelGGL(ly_maxpool_bwd_kernel, dim3((unsigned)ly_ew_blocks((long)n_img * H * W * (C >> 2))), dim3(LY_THREADS), 0,
                      reinterpret_cast<hipStream_t>(stream), x, ldx, dy, lddy, n_img, H, W, C, k, dx, lddx);
+  LY_LAUNCH_CHECK();
+  return 0;
+}
+
+
+// -------------------------------------------------------------------------------------------------
+// Per-channel vector work of BatchNorm, one launch each (replaces ~10 tiny elementwise launches):
+//   ly_bn_finalize   striped (sum, sum^2) accumulators -> batch mean / invstd, y = x*scale + shift, running-stat update
+//   ly_bn_bwd_coeffs striped (sum dv, sum dv*u)        -> dgamma, dbeta and the affine map du = alpha*dv + kappa + lambda*u
+// Sums over stripes and the mean / variance arithmetic are done in double (E[x^2] - E[x]^2 cancels badly in fp32).
+// -------------------------------------------------------------------------------------------------
+__global__ void ly_bn_finalize_kernel(const float* __restrict__ stats, int stripes, int nch, int c_off, int N, double count,
+                                      const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ bias, float eps,
+                                      float momentum, float* running_mean, float* running_var, long* nbt, float* __restrict__ scale,
+                                      float* __restrict__ shift, float* __restrict__ mean, float* __restrict__ invstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && nbt) *nbt += 1;
+  if (c >= N) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int r = 0; r < stripes; ++r) {
+    s1 += (double)stats[(size_t)r * 2 * nch + c_off + c];
+    s2 += (double)stats[(size_t)r * 2 * nch + nch + c_off + c];
+  }
+  const double m = s1 / count;
+  double var = s2 / count - m * m;
+  var = var > 0.0 ? var : 0.0;
+  const float is = (float)(1.0 / sqrt(var + (double)eps));
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  const float sc = g * is;
+  float sh = b - (float)m * sc;
+  if (bias) sh += bias[c] * sc;
+  scale[c] = sc;
+  shift[c] = sh;
+  if (mean) mean[c] = (float)m;
+  if (invstd) invstd[c] = is;
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+  if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * (count / (count > 1.0 ? count - 1.0 : 1.0)));
+}
+
+extern "C" int ly_bn_finalize(const float* stats, int stripes, int nch, int c_off, int N, double count, const float* gamma, const float* beta,
+                              const float* bias, float eps, float momentum, float* running_mean, float* running_var, long* nbt, float* scale,
+                              float* shift, float* mean, float* invstd, void* stream) {
+  LY_CHECK(stats && scale && shift && stripes > 0 && N > 0 && c_off >= 0 && c_off + N <= nch && count > 0, "bn_finalize: bad arguments");
+  hipLaunchKernelGGL(ly_bn_finalize_kernel, dim3((N + 127) / 128), dim3(128), 0, reinterpret_cast<hipStream_t>(stream), stats, stripes, nch, c_off, N,
+                     count, gamma, beta, bias, eps, momentum, running_mean, running_var, nbt, scale, shift, mean, invstd);
+  LY_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ void ly_bn_bwd_coeffs_kernel(const float* __restrict__ sums, int stripes, int N, double count, const float* __restrict__ a,
+                                        const float* __restrict__ mean, const float* __restrict__ invstd, int train, float* __restrict__ dgamma,
+                                        float* __restrict__ dbeta, float* __restrict__ alpha, float* __restrict__ kappa, float* __restrict__ lambda) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= N) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int r = 0; r < stripes; ++r) {
+    s1 += (double)sums[(size_t)r * 2 * N + c];
+    s2 += (double)sums[(size_t)r * 2 * N + N + c];
+  }
+  const double mu = mean[c], is = invstd[c], av = a[c];
+  const double dg = (s2 - mu * s1) * is;
+  dgamma[c] = (float)dg;
+  dbeta[c] = (float)s1;
+  alpha[c] = (float)av;
+  if (train) {
+    const double lam = -av * dg * is / count;
+    lambda[c] = (float)lam;
+    kappa[c] = (float)(-av * s1 / count - lam * mu);
+  } else {
+    lambda[c] = 0.f;
+    kappa[c] = 0.f;
+  }
+}
+
+extern "C" int ly_bn_bwd_coeffs(const float* sums, int stripes, int N, double count, const float* a, const float* mean, const float* invstd, int train,
+                                float* dgamma, float* dbeta, float* alpha, float* kappa, float* lambda, void* stream) {
+  LY_CHECK(sums && a && mean && invstd && dgamma && dbeta && alpha && kappa && lambda && N > 0 && count > 0, "bn_bwd_coeffs: bad arguments");
+  hipLaunchKernelGGL(ly_bn_bwd_coeffs_kernel, dim3((N + 127) / 128), dim3(128), 0, reinterpret_cast<hipStream_t>(stream), sums, stripes, N, count, a,
+                     mean, invstd, train, dgamma, dbeta, alpha, kappa, lambda);
+  LY_LAUNCH_CHECK();
+  return 0;
+}
+
+// -------------------------------------------------------------------------------------------------
+// bf16x3 fragment packing on the device (pack.frag_pack3 as ONE launch; weights change every optimiser step):
+//   out[((t*S + s)*2 + plane)*64 + lane][j] = plane(W[16t + (lane&15)][32s + 16(j>>2) + 4(lane>>4) + (j&3)])
+// W[r][k] is read as w[r*ld_r + k*ld_k], so a transposed view is packed without materialising it.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(LY_THREADS) void ly_frag_pack3_kernel(const float* __restrict__ w, int R, int K, long ld_r, long ld_k, int T, int S,
+                                                                   uint4* __restrict__ out) {
+  const long total = (long)T * S * 64;
+  for (long i = (long)blockIdx.x * LY_THREADS + threadIdx.x; i < total; i += (long)gridDim.x * LY_THREADS) {
+    const int lane = (int)(i & 63);
+    const long ts = i >> 6;
+    const int s = (int)(ts % S), t = (int)(ts / S);
+    const int row = 16 * t + (lane & 15), q = lane >> 4;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = 32 * s + 16 * (j >> 2) + 4 * q + (j & 3);
+      v[j] = (row < R && k < K) ? w[row * ld_r + k * ld_k] : 0.f;
+    }
+    bf16x8 hi, lo;
+    ly_split8(v, hi, lo);
+    out[(ts * 2) * 64 + lane] = __builtin_bit_cast(uint4, hi);
+    out[(ts * 2 + 1) * 64 + lane] = __builtin_bit_cast(uint4, lo);
+  }
+}
+
+extern "C" int ly_frag_pack3(const float* w, int R, int K, long ld_r, long ld_k, int rows_to, void* out, void* stream) {
+  LY_CHECK(w && out && R > 0 && K > 0, "frag_pack3: bad arguments");
+  const int rr = R > rows_to ? R : rows_to;
+  const int T = (rr + 15) / 16, S = (K + 31) / 32;
+  hipLaunchKernelGGL(ly_frag_pack3_kernel, dim3((unsigned)ly_ew_blocks((long)T * S * 64)), dim3(LY_THREADS), 0, reinterpret_cast<hipStream_t>(stream), w,
+                     R, K, ld_r, ld_k, T, S, reinterpret_cast<uint4*>(out));
   LY_LAUNCH_CHECK();
   return 0;
 }

@@ -138,6 +138,10 @@ __device__ __forceinline__ void ly_l2_warm(const void* base, long bytes, float* 
 // Batch-statistics pass support: a lane holds 4 consecutive channels (c .. c+3) of some pixels; sum the
 // two 4-vectors over the 16 lanes that share lq (lanes differing in l&15) and let lane l&15 == 0 add them
 // to stats[c + r] (sum) and stats[nch + c + r] (sum of squares).
+// The accumulator is STRIPED: LY_STATS_STRIPES copies of the [2*nch] array, block b adds into copy
+// b % LY_STATS_STRIPES (thousands of blocks adding to the same few addresses serialise in L2 otherwise);
+// ly_bn_finalize sums the copies in double precision.
+#define LY_STATS_STRIPES 32
 __device__ __forceinline__ void ly_stats_flush(float* __restrict__ stats, int nch, int c, f32x4 s1, f32x4 s2) {
 #pragma unroll
   for (int o = 8; o > 0; o >>= 1) {
@@ -148,11 +152,12 @@ __device__ __forceinline__ void ly_stats_flush(float* __restrict__ stats, int nc
     }
   }
   if ((threadIdx.x & 15) == 0) {
+    float* st = stats + (size_t)(blockIdx.x & (LY_STATS_STRIPES - 1)) * 2 * nch;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
       if (c + r < nch) {
-        atomicAdd(stats + c + r, s1[r]);
-        atomicAdd(stats + nch + c + r, s2[r]);
+        atomicAdd(st + c + r, s1[r]);
+        atomicAdd(st + nch + c + r, s2[r]);
       }
   }
 }

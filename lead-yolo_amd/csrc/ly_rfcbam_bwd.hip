@@ -30,7 +30,7 @@ struct RfGeom {
   long Mo, chunk;        // output pixels, pixels per block
 };
 
-static RfGeom rf_geom(int n_img, int H, int W, int C, int k, int s, long pixels, int& gx, int& gy) {
+static RfGeom rf_geom(int n_img, int H, int W, int C, int k, int s, long pixels, int& gx, int& gy, long max_blocks = 2048) {
   RfGeom g;
   g.n_img = n_img; g.H = H; g.W = W; g.C = C; g.k = k; g.s = s; g.pad = k / 2;
   g.Ho = (H + 2 * g.pad - k) / s + 1;
@@ -40,7 +40,7 @@ static RfGeom rf_geom(int n_img, int H, int W, int C, int k, int s, long pixels,
   g.cb = (cmin + 63) / 64 * 64;
   g.subs = LY_THREADS / g.cb;
   gy = (C + g.cb - 1) / g.cb;
-  long blocks = 2048 / gy;
+  long blocks = max_blocks / gy;      // kernels that end with a per-thread atomic flush of many accumulators use fewer, longer blocks
   long chunk = (pixels + blocks - 1) / blocks;
   const long min_chunk = 8L * g.subs;
   if (chunk < min_chunk) chunk = min_chunk;
@@ -378,7 +378,7 @@ extern "C" int ly_rf_bwd_relu(int n_img, int H, int W, int C, int k, int s, cons
   LY_CHECK(ug && dcd && ag && bg && ca && rfa && gmax && d_mm && sums, "rf_bwd_relu: null pointer");
   int gx, gy;
   const long Mo = (long)n_img * ((H + 2 * (k / 2) - k) / s + 1) * ((W + 2 * (k / 2) - k) / s + 1);
-  const RfGeom g = rf_geom(n_img, H, W, C, k, s, Mo, gx, gy);
+  const RfGeom g = rf_geom(n_img, H, W, C, k, s, Mo, gx, gy, 512);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (k == 3) hipLaunchKernelGGL(ly_rf_bwd_relu_kernel<3>, dim3(gx, gy), dim3(LY_THREADS), 0, st, g, ug, dcd, ag, bg, ca, rfa, gmax, d_mm, sums);
   else hipLaunchKernelGGL(ly_rf_bwd_relu_kernel<1>, dim3(gx, gy), dim3(LY_THREADS), 0, st, g, ug, dcd, ag, bg, ca, rfa, gmax, d_mm, sums);
@@ -392,7 +392,7 @@ extern "C" int ly_rf_bwd_gen(const float* x, int ldx, int n_img, int H, int W, i
   LY_CHECK(x && ug && dv && alpha && kappa && lambda && dwg, "rf_bwd_gen: null pointer");
   int gx, gy;
   const long Mo = (long)n_img * ((H + 2 * (k / 2) - k) / s + 1) * ((W + 2 * (k / 2) - k) / s + 1);
-  const RfGeom g = rf_geom(n_img, H, W, C, k, s, Mo, gx, gy);
+  const RfGeom g = rf_geom(n_img, H, W, C, k, s, Mo, gx, gy, 256);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (k == 3) hipLaunchKernelGGL(ly_rf_bwd_gen_kernel<3>, dim3(gx, gy), dim3(LY_THREADS), 0, st, g, x, ldx, ug, dv, alpha, kappa, lambda, dwg);
   else hipLaunchKernelGGL(ly_rf_bwd_gen_kernel<1>, dim3(gx, gy), dim3(LY_THREADS), 0, st, g, x, ldx, ug, dv, alpha, kappa, lambda, dwg);

@@ -109,7 +109,7 @@ def affine_backward(dy, u, a, b, act, mean, invstd, train):
     n, c, h, w = u.shape
     rows = n * h * w
     sums = ops.bnact_bwd_reduce(dy, c, u, c, rows, c, a, b, act)
-    dgamma, dbeta, alpha, kappa, lam = bn_backward_coeffs(sums[:c], sums[c:], a, mean, invstd, rows, train)
+    dgamma, dbeta, alpha, kappa, lam = ops.bn_bwd_coeffs(sums, c, rows, a, mean, invstd, train)
     ops.bnact_bwd_apply(dy, c, u, c, rows, c, a, b, act, alpha, kappa, lam, u, c)
     return u, dgamma, dbeta
 
@@ -202,10 +202,10 @@ class ConvBnAct(torch.autograd.Function):
         mean = invstd = None
         if spec.bn is not None:
             if spec.bn_train:
-                stats = torch.zeros(2 * co, dtype=torch.float32, device=dev)
+                stats = ops.new_stats(co, dev)
                 _conv_forward(spec, x0, x1, wp, None, bias_f, ACT_NONE, stats=stats)
                 y0 = _out_shape(spec, x0)
-                a, b, mean, invstd = ops.bn_batch_stats(spec.bn, stats[:co], stats[co:], y0[0] * y0[2] * y0[3])
+                a, b, mean, invstd = ops.bn_finalize(spec.bn, stats, co, y0[0] * y0[2] * y0[3], want_stats=True)
             else:
                 bn = spec.bn
                 invstd = torch.rsqrt(bn.running_var.detach().float() + bn.eps)
@@ -309,11 +309,12 @@ class MlpBlockFn(torch.autograd.Function):
         n, c, h, w = x.shape
         pk_p, pk_1, pk_2 = mod._weights()
         htp = (2 * c // 16 + 1) // 2 * 2
-        stats = torch.zeros(2 * 16 * htp, dtype=torch.float32, device=x.device)
+        stats = ops.new_stats(16 * htp, x.device)
         ops.mlpblock(x, None, n, h, w, c, pk_p, pk_1, pk_2, None, None, stats=stats)
-        a, b, mean, invstd = ops.bn_batch_stats(mod.mlp[1], stats[:2 * c], stats[16 * htp:16 * htp + 2 * c], n * h * w)
+        a, b, mean, invstd = ops.bn_finalize(mod.mlp[1], stats, 16 * htp, n * h * w, n=2 * c, pad_to=16 * htp, want_stats=True)
         y = ops.empty_nhwc(n, c, h, w, x)
-        ops.mlpblock(x, y, n, h, w, c, pk_p, pk_1, pk_2, pack.pad_to(a, 16 * htp), pack.pad_to(b, 16 * htp))
+        ops.mlpblock(x, y, n, h, w, c, pk_p, pk_1, pk_2, a, b)
+        a, b = a[:2 * c], b[:2 * c]
         ctx.save_for_backward(x, wpc, w1, w2, a, b, mean, invstd)
         return y
 
@@ -472,9 +473,9 @@ class RfcbamFn(torch.autograd.Function):
             rfa = ops.rfa_map(mm, P["w18"])
             kw = dict(M=n * h * w, H=h, W=w, K=c, N=o, a0=xr, lda0=ld, k0=c, wp=P["wp"], ldo=o, pro=ops.PRO_AFFINE_RELU_CA,
                       p_scale=a1, p_shift=gb, p_ca=ca, rowscale=rfa)
-            stats = torch.zeros(2 * o, dtype=torch.float32, device=xr.device)
+            stats = ops.new_stats(o, xr.device)
             ops.gemm(out=None, e_scale=None, e_shift=bias, stats=stats, **kw)
-            es, t, omean, oinv = ops.bn_batch_stats(mod.conv[1], stats[:o], stats[o:], n * h * w)
+            es, t, omean, oinv = ops.bn_finalize(mod.conv[1], stats, o, n * h * w, want_stats=True)
             out = ops.empty_nhwc(n, o, h, w, xr)
             ops.gemm(out=out, e_scale=es, e_shift=(bias * es + t).contiguous(), act=ACT_RELU, **kw)
             ctx.fwd = dict(kw=kw)
@@ -487,9 +488,9 @@ class RfcbamFn(torch.autograd.Function):
             mm = ops.rfcbam_stats(xr, ld, n, h, w, c, 3, s, wg=wq_stats, th=th, tw=tw)
             rfa = ops.rfa_map(mm, P["w18"])
             kw = dict(n=n, h=h, w=w, c=c, ho=ho, wo=wo, N=o, s=s, th=th, tw=tw, x=xr, ldx=ld, wg=wq_main, ca=ca, rfa=rfa, wp=P["wp"], ldo=o)
-            stats = torch.zeros(2 * o, dtype=torch.float32, device=xr.device)
+            stats = ops.new_stats(o, xr.device)
             ops.rfcbam3(out=None, e_scale=torch.ones_like(bias), e_shift=bias, stats=stats, **kw)
-            es, t, omean, oinv = ops.bn_batch_stats(mod.conv[1], stats[:o], stats[o:], n * ho * wo)
+            es, t, omean, oinv = ops.bn_finalize(mod.conv[1], stats, o, n * ho * wo, want_stats=True)
             out = ops.empty_nhwc(n, o, ho, wo, xr)
             ops.rfcbam3(out=out, e_scale=es, e_shift=(bias * es + t).contiguous(), **kw)
             ctx.fwd = dict(kw=kw)
@@ -553,7 +554,7 @@ class RfcbamFn(torch.autograd.Function):
                     "ly_rf_bwd_relu")
             _tap("rf.d_mm", d_mm); _tap("rf.dv", dcd); _tap("rf.sums", sums)
             # 9. generate BatchNorm coefficients ([t][c] order)
-            dgg_tc, dbg_tc, alpha, kappa, lam = bn_backward_coeffs(sums[:kk * c], sums[kk * c:], ag, tc(gmean), tc(ginv), mo, True)
+            dgg_tc, dbg_tc, alpha, kappa, lam = ops.bn_bwd_coeffs(sums, kk * c, mo, ag, tc(gmean), tc(ginv), True)
             ct = lambda v: v.view(kk, c).t().contiguous().view(-1)
             # 10. dug, generate weight gradient
             dwg = torch.zeros(c * kk, kk, dtype=torch.float32, device=dev)

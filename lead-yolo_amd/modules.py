@@ -218,10 +218,9 @@ class MLPBlock(nn.Module):
         wp, w1, w2 = self._weights()
         if self.training:
             htp = (2 * c // 16 + 1) // 2 * 2
-            stats = torch.zeros(2 * 16 * htp, dtype=torch.float32, device=x.device)
+            stats = ops.new_stats(16 * htp, x.device)
             ops.mlpblock(x, None, n, h, w, c, wp, w1, w2, None, None, stats=stats)         # statistics pass (no store)
-            sc, sh = ops.bn_batch_affine(self.mlp[1], stats[:2 * c], stats[16 * htp:16 * htp + 2 * c], n * h * w)
-            sc, sh = pack.pad_to(sc, 16 * htp), pack.pad_to(sh, 16 * htp)
+            sc, sh = ops.bn_finalize(self.mlp[1], stats, 16 * htp, n * h * w, n=2 * c, pad_to=16 * htp)
         else:
             sc, sh = self._bn_eval()
         y = ops.empty_nhwc(n, c, h, w, x)
@@ -310,11 +309,9 @@ class _PatchConv(nn.Module):
         if self.training and isinstance(bn, nn.BatchNorm2d):
             conv = getattr(self, self._conv_name)
             bias = conv.bias.detach().float().contiguous() if conv.bias is not None else None
-            stats = torch.zeros(2 * self.cout, dtype=torch.float32, device=x.device)
+            stats = ops.new_stats(self.cout, x.device)
             ops.gemm(out=None, e_scale=None, e_shift=bias, stats=stats, **kw)                  # statistics pass
-            sc, sh = ops.bn_batch_affine(bn, stats[:self.cout], stats[self.cout:], n * ho * wo)
-            if bias is not None:
-                sh = sh + bias * sc
+            sc, sh = ops.bn_finalize(bn, stats, self.cout, n * ho * wo, bias=bias)
         else:
             sc, sh = self._affine_eval()
         out = ops.empty_nhwc(n, self.cout, ho, wo, x)
@@ -424,11 +421,9 @@ class Conv(nn.Module):
             L = Lazy.of(x)
             n, _, h, w = L.shape
             bias = self.conv.bias.detach().float().contiguous() if self.conv.bias is not None else None
-            stats = torch.zeros(2 * self.c2, dtype=torch.float32, device=L.a0.device)
+            stats = ops.new_stats(self.c2, L.a0.device)
             self._run(x, None, bias, ACT_NONE, stats=stats)                                   # statistics pass
-            sc, sh = ops.bn_batch_affine(bn, stats[:self.c2], stats[self.c2:], n * h * w)
-            if bias is not None:
-                sh = sh + bias * sc
+            sc, sh = ops.bn_finalize(bn, stats, self.c2, n * h * w, bias=bias)
         else:
             sc, sh = self.affine_eval()
         return self._run(x, sc, sh, act)
@@ -528,10 +523,9 @@ class RFCBAMConv(nn.Module):
                       p_scale=a1, p_shift=b1, p_ca=ca, rowscale=rfa)
             if self.training:
                 bias = self.conv[0].bias.detach().float().contiguous()
-                stats = torch.zeros(2 * self.o, dtype=torch.float32, device=xr.device)
+                stats = ops.new_stats(self.o, xr.device)
                 ops.gemm(out=None, e_scale=None, e_shift=bias, stats=stats, **kw)               # conv.1 BatchNorm statistics pass
-                es, t = ops.bn_batch_affine(self.conv[1], stats[:self.o], stats[self.o:], n * h * w)
-                eb = (bias * es + t).contiguous()
+                es, eb = ops.bn_finalize(self.conv[1], stats, self.o, n * h * w, bias=bias)
             out = ops.empty_nhwc(n, self.o, h, w, xr)
             ops.gemm(out=out, e_scale=es, e_shift=eb, act=ACT_RELU, **kw)
             return out
@@ -550,10 +544,9 @@ class RFCBAMConv(nn.Module):
                   ldo=self.o)
         if self.training:
             bias = self.conv[0].bias.detach().float().contiguous()
-            stats = torch.zeros(2 * self.o, dtype=torch.float32, device=xr.device)
+            stats = ops.new_stats(self.o, xr.device)
             ops.rfcbam3(out=None, e_scale=torch.ones_like(bias), e_shift=bias, stats=stats, **kw)   # conv.1 statistics pass
-            es, t = ops.bn_batch_affine(self.conv[1], stats[:self.o], stats[self.o:], n * ho * wo)
-            eb = (bias * es + t).contiguous()
+            es, eb = ops.bn_finalize(self.conv[1], stats, self.o, n * ho * wo, bias=bias)
         out = ops.empty_nhwc(n, self.o, ho, wo, xr)
         ops.rfcbam3(out=out, e_scale=es, e_shift=eb, **kw)
         return out
@@ -730,11 +723,10 @@ class C3_CA(nn.Module):
         wp = self._weights12()
         b1, b2 = getattr(self.cv1, "bn", None), getattr(self.cv2, "bn", None)
         if self.training and b1 is not None and b2 is not None:
-            stats = torch.zeros(4 * c_, dtype=torch.float32, device=src.a0.device)
+            stats = ops.new_stats(2 * c_, src.a0.device)
             _run_pointwise(src, wp, 2 * c_, None, None, ACT_NONE, stats=stats)                  # statistics pass, both halves
-            s1, s2 = stats[:2 * c_], stats[2 * c_:]
-            sa, ta = ops.bn_batch_affine(b1, s1[:c_], s2[:c_], n * h * w)
-            sb, tb = ops.bn_batch_affine(b2, s1[c_:], s2[c_:], n * h * w)
+            sa, ta = ops.bn_finalize(b1, stats, 2 * c_, n * h * w, n=c_, c_off=0)
+            sb, tb = ops.bn_finalize(b2, stats, 2 * c_, n * h * w, n=c_, c_off=c_)
             sc, sh = torch.cat((sa, sb)).contiguous(), torch.cat((ta, tb)).contiguous()
         else:
             sc, sh = self._affine12_eval()

@@ -221,9 +221,47 @@ def mlpblock(x, y, n, h, w, c, wp, w1, w2, sc, sh, stats=None):
 
 
 def chan_moments(x, ldx, rows, c):
-    mom = torch.zeros(2 * c, dtype=torch.float32, device=x.device)
+    mom = new_stats(c, x.device)
     capi.check(capi.lib().ly_chan_moments(_p(x), ldx, rows, c, _p(mom), capi.stream_ptr()), "ly_chan_moments")
-    return mom
+    return mom.sum(0)
+
+
+STRIPES = capi.STATS_STRIPES
+
+
+def new_stats(nch, device):
+    """zeroed striped accumulator for a statistics pass over `nch` channels: [STRIPES][2*nch] (see ly_bn_finalize)"""
+    return torch.zeros(STRIPES, 2 * nch, dtype=torch.float32, device=device)
+
+
+def bn_finalize(bn, stats, nch, count, n=None, c_off=0, bias=None, pad_to=0, want_stats=False):
+    """Train-mode BatchNorm2d from the striped sums of a statistics pass, ONE launch (ly_bn_finalize): returns
+    (scale, shift) of y = x*scale + shift [+ (mean, invstd)], updates running_mean/var/num_batches_tracked in place."""
+    n = nch if n is None else n
+    dev = stats.device
+    size = max(n, pad_to)
+    alloc = torch.zeros if size > n else torch.empty
+    scale, shift = alloc(size, dtype=torch.float32, device=dev), alloc(size, dtype=torch.float32, device=dev)
+    mean = torch.empty(n, dtype=torch.float32, device=dev) if want_stats else None
+    invstd = torch.empty(n, dtype=torch.float32, device=dev) if want_stats else None
+    track = bn.track_running_stats and bn.running_mean is not None
+    if track and bn.momentum is None:
+        raise NotImplementedError("BatchNorm with momentum=None (cumulative average) is not built")
+    capi.check(capi.lib().ly_bn_finalize(_p(stats), stats.shape[0], nch, c_off, n, float(count), _p(bn.weight), _p(bn.bias), _p(bias), float(bn.eps),
+                                         float(bn.momentum or 0.0), _p(bn.running_mean if track else None), _p(bn.running_var if track else None),
+                                         _p(bn.num_batches_tracked if track else None), _p(scale), _p(shift), _p(mean), _p(invstd),
+                                         capi.stream_ptr()), "ly_bn_finalize")
+    return (scale, shift, mean, invstd) if want_stats else (scale, shift)
+
+
+def bn_bwd_coeffs(sums, n, count, a, mean, invstd, train):
+    """(dgamma, dbeta, alpha, kappa, lambda) from (striped) sums [.., 2n] of ly_bnact_bwd_reduce, ONE launch."""
+    dev = sums.device
+    stripes = sums.shape[0] if sums.dim() == 2 else 1
+    out = torch.empty(5, n, dtype=torch.float32, device=dev)
+    capi.check(capi.lib().ly_bn_bwd_coeffs(_p(sums), stripes, n, float(count), _p(a), _p(mean), _p(invstd), int(train), _p(out[0]), _p(out[1]),
+                                           _p(out[2]), _p(out[3]), _p(out[4]), capi.stream_ptr()), "ly_bn_bwd_coeffs")
+    return out[0], out[1], out[2], out[3], out[4]
 
 
 def coordatt_conv1_stats(pool, positions, c, mip, w1, b1):
@@ -281,7 +319,7 @@ def bn_batch_stats(bn, s1, s2, count):
 
 
 def bnact_bwd_reduce(dy, lddy, u, ldu, rows, c, a, b, act):
-    sums = torch.zeros(2 * c, dtype=torch.float32, device=u.device)
+    sums = new_stats(c, u.device)
     with _Timed("ly_bnact_bwd_reduce_kernel", 6.0 * rows * c, 8.0 * rows * c):
         capi.check(capi.lib().ly_bnact_bwd_reduce(_p(dy), lddy, _p(u), ldu, rows, c, _p(a), _p(b), act, _p(sums), capi.stream_ptr()),
                    "ly_bnact_bwd_reduce")

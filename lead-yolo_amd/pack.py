@@ -47,6 +47,14 @@ def frag_pack3(w2d, rows_to=0):
     k = 32s + 16*(j >> 2) + 4q + (j & 3), j = 0..7.  Zero padded to 16 x 32 multiples."""
     r, k = w2d.shape
     t, s = _ceil(max(r, rows_to), 16), _ceil(k, 32)
+    if w2d.is_cuda:                                   # one HIP launch (ly_frag_pack3); strides cover transposed views
+        from . import capi
+        if w2d.dtype != torch.float32:
+            w2d = w2d.float()
+        out = torch.empty((t, s, 2, 64, 8), dtype=torch.int16, device=w2d.device)
+        capi.check(capi.lib().ly_frag_pack3(capi.ptr(w2d), r, k, w2d.stride(0), w2d.stride(1), rows_to, capi.ptr(out), capi.stream_ptr()),
+                   "ly_frag_pack3")
+        return out
     wp = torch.zeros(t * 16, s * 32, dtype=torch.float32, device=w2d.device)
     wp[:r, :k] = w2d.float()
     hi = wp.to(torch.bfloat16)

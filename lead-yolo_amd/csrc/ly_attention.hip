@@ -582,20 +582,26 @@ extern "C" int ly_chan_moments(const float* x, int ldx, long rows, int C, float*
 }
 
 // CoordAtt bn1 statistics: y1[n, pos, m] = w1[m, :] . pool[n, pos, :] + b1[m];  stats[m] += y1, stats[mip + m] += y1^2
-__global__ __launch_bounds__(LY_THREADS) void ly_coordatt_conv1_stats_kernel(const float* __restrict__ pool, int C, int mip,
+__global__ __launch_bounds__(LY_THREADS) void ly_coordatt_conv1_stats_kernel(const float* __restrict__ pool, long positions, int C, int mip,
                                                                               const float* __restrict__ w1, const float* __restrict__ b1,
                                                                               float* __restrict__ stats) {
+  // block = a strided subset of positions; wave w owns outputs m = w, w+4, ..; sums stay in registers until ONE atomic per (block, m)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float* p = pool + (long)blockIdx.x * C;
   for (int m = wave; m < mip; m += 4) {
-    float s = 0.f;
-    for (int c = lane; c < C; c += 64) s += w1[m * C + c] * p[c];
+    float a1 = 0.f, a2 = 0.f;
+    for (long pos = blockIdx.x; pos < positions; pos += gridDim.x) {
+      const float* p = pool + pos * C;
+      float s = 0.f;
+      for (int c = lane; c < C; c += 64) s += w1[m * C + c] * p[c];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if (lane == 0) {
+      for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
       s += b1[m];
-      atomicAdd(stats + m, s);
-      atomicAdd(stats + mip + m, s * s);
+      a1 += s;
+      a2 += s * s;
+    }
+    if (lane == 0) {
+      atomicAdd(stats + m, a1);
+      atomicAdd(stats + mip + m, a2);
     }
   }
 }
@@ -603,8 +609,9 @@ __global__ __launch_bounds__(LY_THREADS) void ly_coordatt_conv1_stats_kernel(con
 extern "C" int ly_coordatt_conv1_stats(const float* pool, long positions, int C, int mip, const float* w1, const float* b1,
                                        float* stats, void* stream) {
   LY_CHECK(pool && w1 && b1 && stats && positions > 0 && mip > 0, "coordatt_conv1_stats: bad arguments");
-  hipLaunchKernelGGL(ly_coordatt_conv1_stats_kernel, dim3((unsigned)positions), dim3(LY_THREADS), 0, reinterpret_cast<hipStream_t>(stream),
-                     pool, C, mip, w1, b1, stats);
+  const long blocks = positions < 512 ? positions : 512;
+  hipLaunchKernelGGL(ly_coordatt_conv1_stats_kernel, dim3((unsigned)blocks), dim3(LY_THREADS), 0, reinterpret_cast<hipStream_t>(stream),
+                     pool, positions, C, mip, w1, b1, stats);
   LY_LAUNCH_CHECK();
   return 0;
 }

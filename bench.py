@@ -142,6 +142,49 @@ def cpu_baseline(scale, size, budget_s=15.0):
                        f"{cores} threads) in {dt:.1f}s")
 
 
+def train_bench(args, rank, local_rank, world, dist, device, barrier):
+    """BASELINE.json configs[2]-[3] shape (lead-yolo-s, train mode, forward + loss + backward + SGD step), in fp32 with
+    bf16x3 products (the bf16-autocast variant of those configs is not built yet).  One process per GPU, per-GPU batch
+    fixed (weak scaling), gradients averaged by ddp.GradReducer over RCCL, overlapped with backward."""
+    import lead_yolo_amd as L
+    torch.manual_seed(0)
+    model = L.Model(L.load_cfg(scale=args.scale)).to(device).train()
+    opt = L.smart_optimizer(model, "SGD", 0.01, 0.937, 5e-4 * args.batch * world / 64)
+    loss_fn = L.ComputeLoss(model)
+    reducer = L.GradReducer(list(model.parameters())).attach() if world > 1 else None
+    g = torch.Generator().manual_seed(rank)
+    imgs = torch.randint(0, 256, (args.batch, 3, args.size, args.size), dtype=torch.uint8, generator=g).to(device)
+    nb = 7 * args.batch                                                        # ~7 boxes per image (COCO mean)
+    g1 = torch.Generator().manual_seed(1 + rank)
+    tg = torch.cat((torch.sort(torch.randint(0, args.batch, (nb, 1), generator=g1).float(), 0)[0], torch.zeros(nb, 1),
+                    torch.rand(nb, 2, generator=g1) * 0.8 + 0.1, torch.rand(nb, 2, generator=g1) * 0.2 + 0.02), 1).to(device)
+    for _ in range(args.warmup):
+        L.train_step(model, loss_fn, opt, imgs, tg, reducer=reducer, world_size=world)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = L.train_step(model, loss_fn, opt, imgs, tg, reducer=reducer, world_size=world)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "images/sec (640x640) fwd+bwd+SGD", "value": round(world * args.batch * args.steps / dt, 2), "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"lead-yolo-{args.scale} bs={args.batch}/gpu 3x{args.size}x{args.size} train step: forward, ComputeLoss, "
+                                   "HIP backward, clip 10, SGD-nesterov 3 groups (BASELINE.json configs[2] shape, fp32 instead of bf16 autocast)",
+                       "global_batch": world * args.batch, "parallelism": f"dp{world} (bucketed gradient all-reduce over RCCL, overlapped)"},
+            "final_loss": round(float(loss), 4), "roofline": None, "cpu_baseline": None,
+            "note": "secondary line (bench.py --train); the headline metric is the default eval-forward run"}))
+    if dist is not None:
+        dist.barrier(device_ids=[local_rank])
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -153,6 +196,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layers", action="store_true", help="print the per-layer kernel table to stderr")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel probe (for whole-step rocprof runs)")
+    ap.add_argument("--train", action="store_true",
+                    help="secondary line: full optimisation step (forward, loss, backward, clip, SGD-nesterov; gradient all-reduce when N>1) "
+                         "instead of the headline eval forward")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -167,13 +213,16 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
-    model = build_model(args.scale, device)
-    x = synth_batch(args.batch, args.size, rank, device)
-
     def barrier():
         if dist is not None:
             dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
+
+    if args.train:
+        return train_bench(args, rank, local_rank, world, dist, device, barrier)
+
+    model = build_model(args.scale, device)
+    x = synth_batch(args.batch, args.size, rank, device)
 
     with torch.no_grad():
         for _ in range(args.warmup):

@@ -266,3 +266,28 @@ def test_whole_model_layerwise_backward():
             assert l2 < 3e-2, f"layer {key} {kind} d{k[len(pfx):]}: relative L2 error {l2:.2e}"
         checked += 1
     assert checked == 19
+
+
+def test_train_step_with_gradient_reducer():
+    """the bucketed reducer (gradients are views into flat buckets, hooks fire per parameter) under the HIP backward:
+    one step with the reducer attached must leave the same weights as one step without it (world size 1)"""
+    import lead_yolo_amd as L
+    res = []
+    for use_reducer in (False, True):
+        torch.manual_seed(0)
+        m = L.Model(_cfg("n"))
+        st = synth.synth_state(synth.shapes_of(m.state_dict()), 5151)
+        st["model.23.anchors"] = m.model[-1].anchors.clone()
+        m.load_state_dict(st)
+        m = m.to(_dev()).train()
+        opt = L.smart_optimizer(m, "SGD", 0.01, 0.937, 5e-4)
+        red = L.GradReducer(list(m.parameters())).attach() if use_reducer else None
+        imgs = synth.synth_images(4, 128, 21).to(_dev())
+        tg = synth.synth_targets(4, 22, per_image=3).to(_dev())
+        for _ in range(2):
+            loss, _ = L.train_step(m, L.ComputeLoss(m), opt, imgs, tg, reducer=red)
+        res.append((float(loss), {k: v.detach().clone() for k, v in m.state_dict().items() if v.is_floating_point()}))
+    assert abs(res[0][0] - res[1][0]) <= 2e-3 * abs(res[0][0])
+    for k, v in res[0][1].items():
+        d = float((res[1][1][k] - v).abs().max())
+        assert d <= 2e-3 * float(v.abs().max()) + 1e-4, (k, d)

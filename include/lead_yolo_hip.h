@@ -77,6 +77,8 @@ int ly_gemm_fwd(const LyGemmParams* p, void* stream);
 int ly_debug_set_gemm_cfg(int cfg);
 /* ablation aid for profiling (bit 0: skip split+LDS write, 1: skip MFMA, 2: skip prefetch loads, 3: skip stores) */
 int ly_debug_set_gemm(int v);
+/* tuning aid: K stage of ly_gemm_fwd, 0 / 64 = default, 128 = 128-wide stage (measured slower) */
+int ly_debug_set_gemm_bk(int v);
 
 
 /* ---- 3x3 / s1 / p1 convolution (implicit GEMM) ------------------------------------------------- */

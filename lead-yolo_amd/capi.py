@@ -57,6 +57,7 @@ SIGNATURES = {
     "ly_gemm_fwd": [ctypes.POINTER(LyGemmParams), _P],
     "ly_debug_set_gemm_cfg": [_I],
     "ly_debug_set_gemm": [_I],
+    "ly_debug_set_gemm_bk": [_I],
     "ly_debug_set_rf3": [_I],
     "ly_debug_set_conv3": [_I],
     "ly_debug_set_conv3_cfg": [_I],

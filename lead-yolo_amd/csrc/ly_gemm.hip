@@ -26,17 +26,23 @@
 #include "ly_tile.cuh"
 #include "ly_params.h"
 
-#define LY_BK 64
-#define LY_RSX (2 * LY_BK + 16)   // bytes per LDS row, per plane
+// K chunk per pipeline stage: 64; a 128-wide stage (twice the bytes in flight per thread) is kept as a tuning
+// variant (ly_debug_set_gemm_bk) — on MI355X it needs 272 registers, drops to one wave per SIMD and measures
+// 15-30 % slower on every LEAD-YOLO shape.  LDS row = 2*BK + 16 bytes per plane
 
 #ifndef LY_GEMM_MINW
 #define LY_GEMM_MINW 1
 #endif
-template <int NT, int MT, int WC, int GATHER, int PRO>
-__global__ __launch_bounds__(LY_THREADS, LY_GEMM_MINW) void ly_gemm_kernel(const LyGemmParams P, const int gy, const int nslots, const int gx, const int dbg) {
+template <int NT, int MT, int WC, int GATHER, int PRO, bool DBG, int LY_BK>
+__device__ __forceinline__ void ly_gemm_body(const LyGemmParams& P, const int gy, const int nslots, const int gx, const int dbg_arg) {
+  const int dbg = DBG ? dbg_arg : 0;                      // production instantiation: no ablation branches inside the loop
   constexpr int WP = 4 / WC;
   constexpr int BP = 16 * NT * WP;
-  constexpr int NV = BP * (LY_BK / 4) / LY_THREADS;      // float4 per thread per chunk; thread's pixels: tid/16 + 16e
+  constexpr int LY_RSX = 2 * LY_BK + 16;
+  constexpr int KQ = LY_BK / 4;                          // float4 columns per chunk
+  constexpr int RSTEP = LY_THREADS / KQ;                 // pixel rows covered by one pass of the block
+  constexpr int SPC = LY_BK / 32;                        // k-steps per chunk
+  constexpr int NV = BP * (LY_BK / 4) / LY_THREADS;      // float4 per thread per chunk; thread's pixels: tid/KQ + RSTEP*e
   static_assert(NV >= 1 && BP * (LY_BK / 4) % LY_THREADS == 0, "tile must divide evenly over the block");
   constexpr int PLANE = BP * LY_RSX;
   extern __shared__ f32x4 ly_smem4[];                     // [buf][plane][BP][RSX]
@@ -55,8 +61,8 @@ __global__ __launch_bounds__(LY_THREADS, LY_GEMM_MINW) void ly_gemm_kernel(const
   const int T = (P.N + 15) >> 4;
   const int nchunk = (P.K + LY_BK - 1) / LY_BK;
   constexpr bool need_nhw = GATHER != LY_GATHER_ROWS || PRO != LY_PRO_NONE;
-  const int k4 = tid & 15;                                // this thread's float4 column inside a chunk
-  const int prow = tid >> 4;                              // its first pixel row; others at +16e
+  const int k4 = tid % KQ;                                // this thread's float4 column inside a chunk
+  const int prow = tid / KQ;                              // its first pixel row; others at +RSTEP*e
 
   // per-thread description of the NV pixels it stages for the tile being prefetched
   long t_row0[NV];
@@ -64,7 +70,7 @@ __global__ __launch_bounds__(LY_THREADS, LY_GEMM_MINW) void ly_gemm_kernel(const
   auto setup = [&](long p0) {
 #pragma unroll
     for (int e = 0; e < NV; ++e) {
-      const long gp = p0 + prow + 16 * e;
+      const long gp = p0 + prow + RSTEP * e;
       int n = -1, h = 0, w = 0;
       long row0 = gp;
       if (gp < P.M) {
@@ -111,7 +117,7 @@ __global__ __launch_bounds__(LY_THREADS, LY_GEMM_MINW) void ly_gemm_kernel(const
 #pragma unroll
     for (int e = 0; e < NV; ++e) {
       const bool ok = kok && t_n[e] >= 0;
-      const long row = second ? (p0 + prow + 16 * e) : t_row0[e];
+      const long row = second ? (p0 + prow + RSTEP * e) : t_row0[e];
       const float* ptr = ok ? src + row * rowmul + koff : P.a0;
       pv[e] = ly_ldg4(ptr);
     }
@@ -142,7 +148,7 @@ __global__ __launch_bounds__(LY_THREADS, LY_GEMM_MINW) void ly_gemm_kernel(const
 #pragma unroll
       for (int e = 0; e < NV; ++e) {
         const bool ok = kok && t_n[e] >= 0;
-        rr[e] = (P.res && ok) ? ly_ldg4(P.res + (p0 + prow + 16 * e) * P.ldres + kk) : zero;
+        rr[e] = (P.res && ok) ? ly_ldg4(P.res + (p0 + prow + RSTEP * e) * P.ldres + kk) : zero;
       }
 #pragma unroll
       for (int e = 0; e < NV; ++e)
@@ -162,7 +168,7 @@ __global__ __launch_bounds__(LY_THREADS, LY_GEMM_MINW) void ly_gemm_kernel(const
         }
     }
 #pragma unroll
-    for (int e = 0; e < NV; ++e) ly_lds_put4(hi, lo, (prow + 16 * e) * LY_RSX, 4 * k4, pv[e]);
+    for (int e = 0; e < NV; ++e) ly_lds_put4(hi, lo, (prow + RSTEP * e) * LY_RSX, 4 * k4, pv[e]);
   };
 
   f32x4 acc[MT][NT];
@@ -199,7 +205,8 @@ __global__ __launch_bounds__(LY_THREADS, LY_GEMM_MINW) void ly_gemm_kernel(const
 
   if (slot >= gx) return;                                  // (host never launches such blocks)
   ly_l2_warm(P.wp, (long)T * S * 2048, P.stats ? P.stats : P.out);
-  LyWFrag wcur[MT], wnxt[MT];
+  LyWFrag wcur[MT], wnxt[SPC - 1][MT];                   // wnxt[j]: weights of step j+1 of the chunk; slot 0 is reused for the
+                                                          // first step of the NEXT item once step 0 has consumed it
 #pragma unroll
   for (int t = 0; t < MT; ++t) wcur[t] = ly_wfrag(wpk, wbase[t], lane);
 
@@ -224,15 +231,19 @@ __global__ __launch_bounds__(LY_THREADS, LY_GEMM_MINW) void ly_gemm_kernel(const
         pn = (long)(pt + nslots) * BP;
         setup(pn);
       } else if (c == nchunk - 1) {
-        more = false;
-      }
-      // second k-step's weights first (older in the in-order vmcnt queue than the activation prefetch)
+        more = false;                                      // last item: re-stage chunk 0 of the same tile (harmless), so that the
+        cn = 0;                                            // loop body is STRAIGHT-LINE: the compiler then counts outstanding loads
+      }                                                    // exactly and the prefetch really overlaps the contraction
+      // weights of the chunk's later k-steps first (older in the in-order vmcnt queue than the activation prefetch)
       if (!(dbg & 16)) {
-        const int g1 = 2 * c + 1 < S ? 2 * c + 1 : 0;
 #pragma unroll
-        for (int t = 0; t < MT; ++t) wnxt[t] = ly_wfrag(wpk, wbase[t] + g1, lane);
+        for (int j = 1; j < SPC; ++j) {
+          const int gj = SPC * c + j < S ? SPC * c + j : 0;
+#pragma unroll
+          for (int t = 0; t < MT; ++t) wnxt[j - 1][t] = ly_wfrag(wpk, wbase[t] + gj, lane);
+        }
       }
-      if (PRO == LY_PRO_AFFINE_RELU_CA && c == nchunk - 1) {
+      if (PRO == LY_PRO_AFFINE_RELU_CA) {
         // per-pixel row scale of the tile being finished: issued BEFORE the next item's prefetch so the
         // epilogue's wait for it does not also wait for that prefetch (vmcnt retires in order)
 #pragma unroll
@@ -241,17 +252,16 @@ __global__ __launch_bounds__(LY_THREADS, LY_GEMM_MINW) void ly_gemm_kernel(const
           rsv[n] = P.rowscale[gp < P.M ? gp : 0];
         }
       }
-      if (more && !(dbg & 4)) prefetch(pn, cn * LY_BK);
+      if (!(dbg & 4)) prefetch(pn, cn * LY_BK);
       const char* hi = xs + buf * 2 * PLANE;
       const char* lo = hi + PLANE;
 #pragma unroll
       for (int s = 0; s < LY_BK / 32; ++s) {
-        const int gs = 2 * c + s;
-        if (gs < S && !(dbg & 2)) {
-          if (s == 1) {                                    // weights of the next item's first step
-            const int gn = gs + 1 < S ? gs + 1 : 0;
+        if (!(dbg & 2)) {
+          if (s == SPC - 1) {                              // weights of the next item's first step (absent steps of a ragged
+            const int gn = SPC * (c + 1) < S ? SPC * (c + 1) : 0;   // last chunk contract LDS zeros with clamped weights: no branch)
 #pragma unroll
-            for (int t = 0; t < MT; ++t) wnxt[t] = ly_wfrag(wpk, wbase[t] + gn, lane);
+            for (int t = 0; t < MT; ++t) wnxt[0][t] = ly_wfrag(wpk, wbase[t] + gn, lane);
           }
           bf16x8 xh[NT], xl[NT];
 #pragma unroll
@@ -265,10 +275,10 @@ __global__ __launch_bounds__(LY_THREADS, LY_GEMM_MINW) void ly_gemm_kernel(const
 #pragma unroll
             for (int n = 0; n < NT; ++n) acc[t][n] = ly_mfma3(wcur[t].hi, wcur[t].lo, xh[n], xl[n], acc[t][n]);
 #pragma unroll
-          for (int t = 0; t < MT; ++t) wcur[t] = wnxt[t];
+          for (int t = 0; t < MT; ++t) wcur[t] = wnxt[s < SPC - 1 ? s : 0][t];
         }
       }
-      if (more && !(dbg & 1)) commit(pn, cn * LY_BK, buf ^ 1);
+      if (!(dbg & 1)) commit(pn, cn * LY_BK, buf ^ 1);
       __syncthreads();
       buf ^= 1;
     }
@@ -315,20 +325,38 @@ __global__ __launch_bounds__(LY_THREADS, LY_GEMM_MINW) void ly_gemm_kernel(const
   }
 }
 
+template <int NT, int MT, int WC, int GATHER, int PRO>
+__global__ __launch_bounds__(LY_THREADS, LY_GEMM_MINW) void ly_gemm_kernel(const LyGemmParams P, const int gy, const int nslots, const int gx, const int dbg) {
+  ly_gemm_body<NT, MT, WC, GATHER, PRO, false, 64>(P, gy, nslots, gx, 0);
+}
+// 128-wide K stage (K >= 128)
+template <int NT, int MT, int WC, int GATHER, int PRO>
+__global__ __launch_bounds__(LY_THREADS, LY_GEMM_MINW) void ly_gemm_kernel_k128(const LyGemmParams P, const int gy, const int nslots, const int gx, const int dbg) {
+  ly_gemm_body<NT, MT, WC, GATHER, PRO, false, 128>(P, gy, nslots, gx, 0);
+}
+// same body with the ablation switches of ly_debug_set_gemm compiled in (tools/ only)
+template <int NT, int MT, int WC, int GATHER, int PRO>
+__global__ __launch_bounds__(LY_THREADS, LY_GEMM_MINW) void ly_gemm_kernel_dbg(const LyGemmParams P, const int gy, const int nslots, const int gx, const int dbg) {
+  ly_gemm_body<NT, MT, WC, GATHER, PRO, true, 64>(P, gy, nslots, gx, dbg);
+}
+
 static int g_gemm_dbg = 0;      // ablation aid: 1 skip commit (split + LDS write), 2 skip MFMA, 4 skip prefetch loads, 8 skip stores
 extern "C" int ly_debug_set_gemm(int v) { g_gemm_dbg = v; return 0; }
 static int g_gemm_cfg = 0;      // 0 = heuristic; otherwise forced NT*100 + MT*10 + WC (tuning aid)
 extern "C" int ly_debug_set_gemm_cfg(int cfg) { g_gemm_cfg = cfg; return 0; }
 
-template <int NT, int MT, int WC, int GATHER, int PRO>
-static int launch_gemm_mode(const LyGemmParams& P, hipStream_t st) {
+static int g_gemm_bk = 0;       // 0 = default (64), 128 = 128-wide K stage (tuning aid: measured slower, its 272 registers leave one wave per SIMD)
+extern "C" int ly_debug_set_gemm_bk(int v) { g_gemm_bk = v; return 0; }
+
+template <int NT, int MT, int WC, int GATHER, int PRO, int BK>
+static int launch_gemm_bk(const LyGemmParams& P, hipStream_t st) {
   constexpr int BP = 16 * NT * (4 / WC);
   constexpr int BN = 16 * MT * WC;
-  constexpr size_t lds = 4 * (size_t)BP * LY_RSX;
+  constexpr size_t lds = 4 * (size_t)BP * (2 * BK + 16);
   long gx = (P.M + BP - 1) / BP;
   int gy = (P.N + BN - 1) / BN;
   LY_CHECK(gx < (1L << 30), "gemm: too many pixel tiles");
-  auto k = ly_gemm_kernel<NT, MT, WC, GATHER, PRO>;
+  auto k = BK == 128 ? ly_gemm_kernel_k128<NT, MT, WC, GATHER, PRO> : ly_gemm_kernel<NT, MT, WC, GATHER, PRO>;
   static int per_cu = 0;            // co-resident blocks per CU (registers + LDS), measured once per instantiation
   if (per_cu == 0) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
@@ -342,9 +370,27 @@ static int launch_gemm_mode(const LyGemmParams& P, hipStream_t st) {
   long nslots = (256L * per_cu) / gy;
   if (nslots < 1) nslots = 1;
   if (nslots > gx) nslots = gx;
-  hipLaunchKernelGGL(k, dim3((unsigned)(nslots * gy)), dim3(LY_THREADS), lds, st, P, gy, (int)nslots, (int)gx, g_gemm_dbg);
+  if (g_gemm_dbg && BK == 64) {
+    auto kd = ly_gemm_kernel_dbg<NT, MT, WC, GATHER, PRO>;
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(kd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)); attr = true; }
+    hipLaunchKernelGGL(kd, dim3((unsigned)(nslots * gy)), dim3(LY_THREADS), lds, st, P, gy, (int)nslots, (int)gx, g_gemm_dbg);
+  } else {
+    hipLaunchKernelGGL(k, dim3((unsigned)(nslots * gy)), dim3(LY_THREADS), lds, st, P, gy, (int)nslots, (int)gx, 0);
+  }
   LY_LAUNCH_CHECK();
   return 0;
+}
+
+template <int NT, int MT, int WC, int GATHER, int PRO>
+static int launch_gemm_mode(const LyGemmParams& P, hipStream_t st) {
+  constexpr int BP = 16 * NT * (4 / WC);
+  constexpr bool can128 = BP * 32 % LY_THREADS == 0 && BP * 32 / LY_THREADS >= 1 && GATHER != LY_GATHER_PATCH_NCHW;
+  const bool want128 = g_gemm_bk == 128;
+  if constexpr (can128) {
+    if (want128) return launch_gemm_bk<NT, MT, WC, GATHER, PRO, 128>(P, st);
+  }
+  return launch_gemm_bk<NT, MT, WC, GATHER, PRO, 64>(P, st);
 }
 
 template <int NT, int MT, int WC>

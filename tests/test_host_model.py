@@ -94,7 +94,7 @@ def test_capi_exports_every_declared_symbol():
 def test_struct_layouts_match_header_field_order():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     hdr = open(os.path.join(root, "include", "lead_yolo_hip.h")).read()
-    for cls in (L.capi.LyGemmParams, L.capi.LyConv3Params, L.capi.LyRfcbam3Params):
+    for cls in (L.capi.LyGemmParams, L.capi.LyConv3Params, L.capi.LyRfcbam3Params, L.capi.LyWgradParams):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cls.__name__, cls.__name__), hdr, re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         names = []
@@ -111,3 +111,27 @@ def test_pick_tile():
     for ho, wo in ((40, 40), (20, 20), (80, 80), (5, 6), (1, 1), (3, 200)):
         th, tw = L.ops.pick_tile(ho, wo)
         assert 1 <= th * tw <= 64 and tw >= 1 and th >= 1
+
+
+def test_optimizer_groups_and_ema_match_reference_recipe():
+    """smart_optimizer: three groups in the reference's order (biases, decayed weights, norm weights) with the counts the
+    reference produced for lead-yolo-n (fixture trainsteps_n); ModelEMA decay ramp d*(1 - exp(-u/tau))."""
+    import math
+    import lead_yolo_amd as L
+    meta, _ = G.load("trainsteps_n")
+    m = L.Model(L.load_cfg(scale="n"))
+    opt = L.smart_optimizer(m, "SGD", meta["lr0"], meta["momentum"], meta["weight_decay"])
+    assert [len(g["params"]) for g in opt.param_groups] == [meta["groups"]["n_bias"], meta["groups"]["n_decay"], meta["groups"]["n_bn"]]
+    assert opt.param_groups[0]["weight_decay"] == 0 and opt.param_groups[2]["weight_decay"] == 0
+    assert abs(opt.param_groups[1]["weight_decay"] - meta["weight_decay"]) < 1e-12
+    assert all(g["nesterov"] and g["momentum"] == meta["momentum"] for g in opt.param_groups)
+    ema = L.ModelEMA(m)
+    w0 = {k: v.clone() for k, v in ema.ema.state_dict().items()}
+    with torch.no_grad():
+        for p in m.parameters():
+            p.add_(1.0)
+    ema.update(m)
+    d = 0.9999 * (1 - math.exp(-1 / 2000))
+    k = "model.0.proj.weight"
+    assert torch.allclose(ema.ema.state_dict()[k], w0[k] * d + (w0[k] + 1.0) * (1 - d), atol=1e-6)
+    assert ema.updates == 1

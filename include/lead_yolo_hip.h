@@ -79,6 +79,8 @@ int ly_debug_set_gemm_cfg(int cfg);
 int ly_debug_set_gemm(int v);
 /* tuning aid: K stage of ly_gemm_fwd, 0 / 64 = default, 128 = 128-wide stage (measured slower) */
 int ly_debug_set_gemm_bk(int v);
+/* A/B aid: 1 (default) = two-deep prefetch pipeline of ly_gemm_fwd, 0 = one-deep */
+int ly_debug_set_gemm_d2(int v);
 
 
 /* ---- 3x3 / s1 / p1 convolution (implicit GEMM) ------------------------------------------------- */

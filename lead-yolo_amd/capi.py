@@ -58,6 +58,7 @@ SIGNATURES = {
     "ly_debug_set_gemm_cfg": [_I],
     "ly_debug_set_gemm": [_I],
     "ly_debug_set_gemm_bk": [_I],
+    "ly_debug_set_gemm_d2": [_I],
     "ly_debug_set_rf3": [_I],
     "ly_debug_set_conv3": [_I],
     "ly_debug_set_conv3_cfg": [_I],

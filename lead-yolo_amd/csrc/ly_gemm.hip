@@ -325,6 +325,300 @@ __device__ __forceinline__ void ly_gemm_body(const LyGemmParams& P, const int gy
   }
 }
 
+// -------------------------------------------------------------------------------------------------
+// TWO-DEEP variant of the pipeline above.  A K chunk contracts in ~770 MFMA cycles but its loads need 1-2 us to
+// arrive, so with one chunk in flight per block every chunk waits for memory (measured: 12.2 us per 64 px x 128 ch x
+// K=256 item, 1.3 us of it matrix work; chip-wide ~3.7 TB/s = bytes in flight / latency, independent of tile shape,
+// occupancy and weight traffic — tools/gemm_sweep.py, tools/gemm_ablate*.py).  Here the raw values of items i+1 AND
+// i+2 are in flight while item i is contracted: two register sets, used alternately (the item loop is unrolled by
+// two so the set index is static); item i+2 is issued into the set that item i vacated when it was committed.
+// -------------------------------------------------------------------------------------------------
+template <int V>
+struct LyIc { static constexpr int value = V; };
+
+template <int NT, int MT, int WC, int GATHER, int PRO>
+__device__ __forceinline__ void ly_gemm_body2(const LyGemmParams& P, const int gy, const int nslots, const int gx) {
+  constexpr int LY_BK = 64;
+  constexpr int WP = 4 / WC;
+  constexpr int BP = 16 * NT * WP;
+  constexpr int LY_RSX = 2 * LY_BK + 16;
+  constexpr int KQ = LY_BK / 4;
+  constexpr int RSTEP = LY_THREADS / KQ;
+  constexpr int SPC = LY_BK / 32;
+  constexpr int NV = BP * (LY_BK / 4) / LY_THREADS;
+  constexpr int PLANE = BP * LY_RSX;
+  extern __shared__ f32x4 ly_smem4[];
+  char* xs = reinterpret_cast<char*>(ly_smem4);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lq = lane >> 4;
+  const int wc = wave % WC, wp_ = wave / WC;
+  const int lid = ly_xcd_remap(blockIdx.x, gy * nslots);
+  const int by = lid % gy;
+  const int slot = lid / gy;
+  const int HW = P.H * P.W;
+  const float invHW = 1.f / (float)HW, invW = 1.f / (float)P.W;
+  const f32x4 zero = ly_zero4();
+  const int S = (P.K + 31) >> 5;
+  const int T = (P.N + 15) >> 4;
+  const int nchunk = (P.K + LY_BK - 1) / LY_BK;
+  constexpr bool need_nhw = GATHER != LY_GATHER_ROWS || PRO != LY_PRO_NONE;
+  const int k4 = tid % KQ;
+  const int prow = tid / KQ;
+  if (slot >= gx) return;
+
+  // ---- staging state, one copy per register set ---------------------------------------------------
+  f32x4 pv[2][NV];
+  long t_row0[2][NV];
+  int t_n[2][NV], t_hw[2][NV];
+  long s_p[2];                                             // tile start and K offset of the item held by the set
+  int s_kc[2];
+  int cur_pt = slot, cur_c = 0;                            // issue cursor (saturates at the slot's last item)
+
+  auto issue = [&](auto sC) {
+    constexpr int s = decltype(sC)::value;
+    const long p0 = (long)cur_pt * BP;
+    const int kc = cur_c * LY_BK;
+    s_p[s] = p0; s_kc[s] = kc;
+    if (cur_c == 0 || !need_nhw) {                         // first chunk of a tile: describe its rows (else: same tile as the
+#pragma unroll                                             // other set, which holds the previous chunk)
+      for (int e = 0; e < NV; ++e) {
+        const long gp = p0 + prow + RSTEP * e;
+        int n = -1, h = 0, w = 0;
+        long row0 = gp;
+        if (gp < P.M) {
+          n = 0;
+          if (need_nhw) {
+            n = ly_fdiv((int)gp, HW, invHW);
+            const int rem = (int)gp - n * HW;
+            h = ly_fdiv(rem, P.W, invW);
+            w = rem - h * P.W;
+            if (GATHER == LY_GATHER_UP2)
+              row0 = ((long)n * (P.H >> 1) + (h >> 1)) * (P.W >> 1) + (w >> 1);
+            else if (GATHER == LY_GATHER_PATCH)
+              row0 = (((long)n * P.Hin + (long)h * P.ks) * P.Win + (long)w * P.ks);
+            else if (GATHER == LY_GATHER_PATCH_NCHW)
+              row0 = ((long)n * P.Cin * P.Hin + (long)h * P.ks) * P.Win + (long)w * P.ks;
+          }
+        }
+        t_row0[s][e] = row0; t_n[s][e] = n; t_hw[s][e] = (h << 16) | w;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < NV; ++e) { t_row0[s][e] = t_row0[1 - s][e]; t_n[s][e] = t_n[1 - s][e]; t_hw[s][e] = t_hw[1 - s][e]; }
+    }
+    const int kk = kc + 4 * k4;
+    const bool kok = kk < P.K;
+    long koff;
+    const float* src = P.a0;
+    long rowmul = P.lda0;
+    bool second = false;
+    if (GATHER == LY_GATHER_PATCH) {
+      const int seg = kk / P.pk, within = kk - seg * P.pk;
+      koff = (long)seg * P.Win * P.lda0 + within;
+    } else if (GATHER == LY_GATHER_PATCH_NCHW) {
+      const int c = kk >> 4, ky = (kk >> 2) & 3;
+      koff = ((long)c * P.Hin + ky) * P.Win;
+      rowmul = 1;
+    } else {
+      second = kk >= P.k0;
+      koff = second ? kk - P.k0 : kk;
+      if (second) { src = P.a1; rowmul = P.lda1; }
+    }
+#pragma unroll
+    for (int e = 0; e < NV; ++e) {
+      const bool ok = kok && t_n[s][e] >= 0;
+      const long row = second ? (p0 + prow + RSTEP * e) : t_row0[s][e];
+      pv[s][e] = ly_ldg4(ok ? src + row * rowmul + koff : P.a0);
+    }
+    // advance the cursor; past the last item it stays there (the surplus issues re-read it, harmlessly, so that every
+    // pass through the loop issues the same loads and the compiler's vmcnt bookkeeping is exact)
+    if (cur_c + 1 < nchunk) ++cur_c;
+    else if (cur_pt + nslots < gx) { cur_pt += nslots; cur_c = 0; }
+  };
+
+  auto commit = [&](auto sC, int buf) {
+    constexpr int s = decltype(sC)::value;
+    char* hi = xs + buf * 2 * PLANE;
+    char* lo = hi + PLANE;
+    const long p0 = s_p[s];
+    const int kk = s_kc[s] + 4 * k4;
+    f32x4 v[NV];
+#pragma unroll
+    for (int e = 0; e < NV; ++e) v[e] = (kk < P.K && t_n[s][e] >= 0) ? pv[s][e] : zero;
+    if (PRO == LY_PRO_GATE) {
+      // CoordAtt factors: small L2-resident tables, fetched here (two more register sets of them do not fit)
+      const bool kok = kk < P.k0;
+      f32x4 gw[NV], gh[NV], rr[NV];
+#pragma unroll
+      for (int e = 0; e < NV; ++e) {
+        const bool ok = kok && t_n[s][e] >= 0;
+        const int n = ok ? t_n[s][e] : 0, h = ok ? (t_hw[s][e] >> 16) : 0, w = ok ? (t_hw[s][e] & 0xffff) : 0;
+        const int kq = ok ? kk : 0;
+        gw[e] = ly_ldg4(P.g_w + ((long)n * P.W + w) * P.k0 + kq);
+        gh[e] = ly_ldg4(P.g_h + ((long)n * P.H + h) * P.k0 + kq);
+        rr[e] = (P.res && ok) ? ly_ldg4(P.res + (p0 + prow + RSTEP * e) * P.ldres + kk) : zero;
+      }
+#pragma unroll
+      for (int e = 0; e < NV; ++e)
+        if (kok && t_n[s][e] >= 0) v[e] = v[e] * gw[e] * gh[e] + rr[e];
+    } else if (PRO == LY_PRO_AFFINE_RELU_CA) {
+      const bool kok = kk < P.K;
+      const int kq = kok ? kk : 0;
+      const f32x4 sa = ly_ldg4(P.p_scale + kq), sb = ly_ldg4(P.p_shift + kq);
+      f32x4 ca[NV];
+#pragma unroll
+      for (int e = 0; e < NV; ++e) ca[e] = ly_ldg4(P.p_ca + (long)(t_n[s][e] >= 0 ? t_n[s][e] : 0) * P.K + kq);
+#pragma unroll
+      for (int e = 0; e < NV; ++e)
+        if (kok && t_n[s][e] >= 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[e][r] = fmaxf(v[e][r] * sa[r] + sb[r], 0.f) * ca[e][r];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < NV; ++e) ly_lds_put4(hi, lo, (prow + RSTEP * e) * LY_RSX, 4 * k4, v[e]);
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[t][n] = zero;
+  long wbase[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    int tt = (by * WC + wc) * MT + t;
+    wbase[t] = (long)(tt < T ? tt : T - 1) * S;
+  }
+  const uint4* wpk = reinterpret_cast<const uint4*>(P.wp);
+  const int pixgrp = wp_ * (16 * NT);
+  const bool vec_ok = (P.ldo & 3) == 0;
+  const int act = P.act;
+  float* const stats = P.stats;
+  float rsv[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) rsv[n] = 1.f;
+  float esc[MT][4], esh[MT][4];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const int c = 16 * ((by * WC + wc) * MT + t) + 4 * lq;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool ok = c + r < P.N;
+      esc[t][r] = (ok && P.e_scale) ? P.e_scale[c + r] : 1.f;
+      esh[t][r] = (ok && P.e_shift) ? P.e_shift[c + r] : 0.f;
+    }
+  }
+  ly_l2_warm(P.wp, (long)T * S * 2048, P.stats ? P.stats : P.out);
+  LyWFrag wcur[MT], wnxt[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) wcur[t] = ly_wfrag(wpk, wbase[t], lane);
+
+  int pt = slot, c = 0, buf = 0;                           // item being contracted
+  long p0 = (long)slot * BP;
+  issue(LyIc<0>());
+  issue(LyIc<1>());
+  commit(LyIc<0>(), 0);
+  __syncthreads();
+
+  // one item: weights, re-issue the vacated set two items ahead, contract, commit the next item, barrier, epilogue at tile end
+  auto item = [&](auto sC) -> bool {
+    constexpr int s = decltype(sC)::value;                 // set that held THIS item (already committed): free
+    {
+      const int g1 = 2 * c + 1 < S ? 2 * c + 1 : 0;        // second k-step's weights first (older than the prefetch in the queue)
+#pragma unroll
+      for (int t = 0; t < MT; ++t) wnxt[t] = ly_wfrag(wpk, wbase[t] + g1, lane);
+    }
+    if (PRO == LY_PRO_AFFINE_RELU_CA) {
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const long gp = p0 + pixgrp + 16 * n + li;
+        rsv[n] = P.rowscale[gp < P.M ? gp : 0];
+      }
+    }
+    issue(sC);                                             // item i+2
+    const char* hi = xs + buf * 2 * PLANE;
+    const char* lo = hi + PLANE;
+#pragma unroll
+    for (int st = 0; st < SPC; ++st) {
+      if (st == SPC - 1) {                                 // weights of the next item's first step
+        const int gn = SPC * (c + 1) < S ? SPC * (c + 1) : 0;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) wnxt[t] = ly_wfrag(wpk, wbase[t] + gn, lane);
+      }
+      bf16x8 xh[NT], xl[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int rb = (pixgrp + 16 * n + li) * LY_RSX;
+        xh[n] = ly_lds_frag(hi, rb, st, lq);
+        xl[n] = ly_lds_frag(lo, rb, st, lq);
+      }
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[t][n] = ly_mfma3(wcur[t].hi, wcur[t].lo, xh[n], xl[n], acc[t][n]);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) wcur[t] = wnxt[t];
+    }
+    commit(LyIc<1 - s>(), buf ^ 1);                        // item i+1
+    __syncthreads();
+    buf ^= 1;
+    if (c + 1 < nchunk) { ++c; return true; }
+    // ---- epilogue of tile pt ---------------------------------------------------------------------
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const int tt = (by * WC + wc) * MT + t;
+      const int cc = 16 * tt + 4 * lq;
+      if (tt < T && cc < P.N) {
+        f32x4 st1 = zero, st2 = zero;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const long gp = p0 + pixgrp + 16 * n + li;
+          if (gp < P.M) {
+            const float rs = PRO == LY_PRO_AFFINE_RELU_CA ? rsv[n] : 1.f;
+            f32x4 u;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) u[r] = acc[t][n][r] * rs * esc[t][r] + esh[t][r];
+            if (stats) {
+              st1 += u;
+              st2 += u * u;
+              continue;
+            }
+            const f32x4 v = ly_act4(u, act);
+            float* o = P.out + gp * P.ldo + cc;
+            if (vec_ok && cc + 3 < P.N) {
+              ly_stg4(o, v);
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if (cc + r < P.N) o[r] = v[r];
+            }
+          }
+        }
+        if (stats) ly_stats_flush(stats, P.N, cc, st1, st2);
+      }
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[t][n] = zero;
+    }
+    pt += nslots;
+    if (pt >= gx) return false;
+    p0 = (long)pt * BP;
+    c = 0;
+    return true;
+  };
+  while (true) {
+    if (!item(LyIc<0>())) break;
+    if (!item(LyIc<1>())) break;
+  }
+}
+
+// same launch contract as ly_gemm_kernel; selected by launch_gemm_bk when the two-deep pipeline applies
+template <int NT, int MT, int WC, int GATHER, int PRO>
+__global__ __launch_bounds__(LY_THREADS, LY_GEMM_MINW) void ly_gemm_kernel_d2(const LyGemmParams P, const int gy, const int nslots, const int gx, const int dbg) {
+  ly_gemm_body2<NT, MT, WC, GATHER, PRO>(P, gy, nslots, gx);
+}
+
 template <int NT, int MT, int WC, int GATHER, int PRO>
 __global__ __launch_bounds__(LY_THREADS, LY_GEMM_MINW) void ly_gemm_kernel(const LyGemmParams P, const int gy, const int nslots, const int gx, const int dbg) {
   ly_gemm_body<NT, MT, WC, GATHER, PRO, false, 64>(P, gy, nslots, gx, 0);
@@ -345,8 +639,36 @@ extern "C" int ly_debug_set_gemm(int v) { g_gemm_dbg = v; return 0; }
 static int g_gemm_cfg = 0;      // 0 = heuristic; otherwise forced NT*100 + MT*10 + WC (tuning aid)
 extern "C" int ly_debug_set_gemm_cfg(int cfg) { g_gemm_cfg = cfg; return 0; }
 
+static int g_gemm_d2 = 1;       // 1 = two-deep prefetch kernel (ly_gemm_kernel_d2), 0 = one-deep (A/B aid)
+extern "C" int ly_debug_set_gemm_d2(int v) { g_gemm_d2 = v; return 0; }
 static int g_gemm_bk = 0;       // 0 = default (64), 128 = 128-wide K stage (tuning aid: measured slower, its 272 registers leave one wave per SIMD)
 extern "C" int ly_debug_set_gemm_bk(int v) { g_gemm_bk = v; return 0; }
+
+template <int NT, int MT, int WC, int GATHER, int PRO>
+static int launch_gemm_d2(const LyGemmParams& P, hipStream_t st) {
+  constexpr int BP = 16 * NT * (4 / WC);
+  constexpr int BN = 16 * MT * WC;
+  constexpr size_t lds = 4 * (size_t)BP * (2 * 64 + 16);
+  long gx = (P.M + BP - 1) / BP;
+  int gy = (P.N + BN - 1) / BN;
+  LY_CHECK(gx < (1L << 30), "gemm: too many pixel tiles");
+  auto k = ly_gemm_kernel_d2<NT, MT, WC, GATHER, PRO>;
+  static int per_cu = 0;
+  if (per_cu == 0) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+    LY_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    int nb = 0;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k), LY_THREADS, lds);
+    LY_CHECK(e == hipSuccess, "hipOccupancyMaxActiveBlocksPerMultiprocessor: %s", hipGetErrorString(e));
+    per_cu = nb < 1 ? 1 : (nb > 8 ? 8 : nb);
+  }
+  long nslots = (256L * per_cu) / gy;
+  if (nslots < 1) nslots = 1;
+  if (nslots > gx) nslots = gx;
+  hipLaunchKernelGGL(k, dim3((unsigned)(nslots * gy)), dim3(LY_THREADS), lds, st, P, gy, (int)nslots, (int)gx, 0);
+  LY_LAUNCH_CHECK();
+  return 0;
+}
 
 template <int NT, int MT, int WC, int GATHER, int PRO, int BK>
 static int launch_gemm_bk(const LyGemmParams& P, hipStream_t st) {
@@ -356,6 +678,7 @@ static int launch_gemm_bk(const LyGemmParams& P, hipStream_t st) {
   long gx = (P.M + BP - 1) / BP;
   int gy = (P.N + BN - 1) / BN;
   LY_CHECK(gx < (1L << 30), "gemm: too many pixel tiles");
+  if (BK == 64 && g_gemm_d2 && !g_gemm_dbg) return launch_gemm_d2<NT, MT, WC, GATHER, PRO>(P, st);
   auto k = BK == 128 ? ly_gemm_kernel_k128<NT, MT, WC, GATHER, PRO> : ly_gemm_kernel<NT, MT, WC, GATHER, PRO>;
   static int per_cu = 0;            // co-resident blocks per CU (registers + LDS), measured once per instantiation
   if (per_cu == 0) {

@@ -112,7 +112,7 @@ def gemm(*, M, H, W, K, N, a0, lda0, k0, wp, out, ldo, a1=None, lda1=0, gather=G
                           _p(res), ldres, _p(p_scale), _p(p_shift), _p(p_ca), _p(wp), _p(e_scale), _p(e_shift), _p(rowscale),
                           act, _p(out), ldo, _p(stats))
     nt, mt, wc = gemm_config(N)
-    with _Timed(f"ly_gemm_kernel<{nt}, {mt}, {wc}, {gather}, {pro}>", 2.0 * M * K * N, 4.0 * (M * (K + N) + N * K)):
+    with _Timed(f"ly_gemm_kernel_d2<{nt}, {mt}, {wc}, {gather}, {pro}>", 2.0 * M * K * N, 4.0 * (M * (K + N) + N * K)):
         capi.check(capi.lib().ly_gemm_fwd(ctypes.byref(P), capi.stream_ptr()), "ly_gemm_fwd")
 
 

@@ -27,8 +27,6 @@ def _rows_dense(t):
     return t
 
 
-def _zeros_like_vec(n, dev):
-    return torch.zeros(n, dtype=torch.float32, device=dev)
 
 
 class ConvSpec:
@@ -40,14 +38,6 @@ class ConvSpec:
         self.k, self.nchw, self.up = k, nchw, up
 
 
-def _weight_2d(spec, weight):
-    """[cout, K] with the column order the forward kernels contract in."""
-    co = weight.shape[0]
-    if spec.kind == "pw":
-        return weight.reshape(co, -1)
-    if spec.kind == "patch":
-        return weight.reshape(co, -1) if spec.nchw else weight.permute(0, 2, 3, 1).reshape(co, -1)
-    return pack.conv_taps_matrix(weight, 32)
 
 
 def _conv_forward(spec, x0, x1, wp, e_scale, e_shift, act, stats=None, out=None):
@@ -91,17 +81,6 @@ def _conv_forward(spec, x0, x1, wp, e_scale, e_shift, act, stats=None, out=None)
     return out
 
 
-def bn_backward_coeffs(s1, s2, a, mean, invstd, count, train):
-    """From s1 = sum dv, s2 = sum dv*u: (dgamma, dbeta, alpha, kappa, lambda) with du = alpha*dv + kappa + lambda*u."""
-    dbeta = s1
-    dgamma = (s2 - mean * s1) * invstd
-    if train:
-        lam = -a * dgamma * invstd / count
-        kappa = -a * s1 / count - lam * mean
-    else:
-        lam = torch.zeros_like(a)
-        kappa = torch.zeros_like(a)
-    return dgamma, dbeta, a.contiguous(), kappa.contiguous(), lam.contiguous()
 
 
 def affine_backward(dy, u, a, b, act, mean, invstd, train):

@@ -63,20 +63,6 @@ def _probe(x, shape):
     return None
 
 
-def _no_train(mod, name):
-    if mod.training:
-        raise NotImplementedError(f"{name}: train-mode (batch-statistics BatchNorm) HIP path is not built yet for this module; "
-                                  "call .eval()")
-
-
-def _no_grad_needed(x, name):
-    """Train-mode FORWARD is built (batch-statistics BatchNorm, running-stat updates); the hand-written
-    backward is not yet — refuse to silently return tensors that are detached from autograd."""
-    if torch.is_grad_enabled() and isinstance(x, torch.Tensor) and x.requires_grad:
-        raise NotImplementedError(f"{name}: backward through the HIP path is not built yet (round-2 work); "
-                                  "run train-mode forward under torch.no_grad()")
-
-
 def _grad_mode(mod):
     """Training step: train-mode module called with autograd recording -> the autograd.Function path (grad.py)."""
     return mod.training and torch.is_grad_enabled()
@@ -207,7 +193,7 @@ class MLPBlock(nn.Module):
         pr = _probe(x, x.shape)
         if pr is not None:
             return pr
-        ops.require_cuda(x, "MLPBlock")
+        ops.require_cuda(x, "MLPBlock", self)
         if _grad_mode(self):
             from . import grad
             bn = self.mlp[1]
@@ -281,7 +267,7 @@ class _PatchConv(nn.Module):
         pr = _probe(x, (x.shape[0], self.cout, x.shape[2] // self.k, x.shape[3] // self.k))
         if pr is not None:
             return pr
-        ops.require_cuda(x, type(self).__name__)
+        ops.require_cuda(x, type(self).__name__, self)
         n, c, h, w = x.shape
         k = self.k
         ho, wo = h // k, w // k
@@ -402,7 +388,7 @@ class Conv(nn.Module):
         if pr is not None:
             return pr
         if not isinstance(x, Lazy):
-            ops.require_cuda(x, "Conv")
+            ops.require_cuda(x, "Conv", self)
         if self.k == 3 and isinstance(x, Lazy):
             x = x.materialize()
         act = _act_code(self.act)
@@ -448,7 +434,7 @@ class SE(nn.Module):
         return ops.se_attention(xr, ld, n, hw, c, wa.contiguous(), wb.contiguous(), self.ratio)
 
     def forward(self, x):
-        ops.require_cuda(x, "SE")
+        ops.require_cuda(x, "SE", self)
         xr, ld = ops.rows(x)
         n, c, h, w = xr.shape
         return self.attention(xr, ld, n, h * w, c).view(n, c, 1, 1)
@@ -499,7 +485,7 @@ class RFCBAMConv(nn.Module):
         pr = _probe(x, (x.shape[0], self.o, (x.shape[2] + 2 * (k_ // 2) - k_) // s_ + 1, (x.shape[3] + 2 * (k_ // 2) - k_) // s_ + 1))
         if pr is not None:
             return pr
-        ops.require_cuda(x, "RFCBAMConv")
+        ops.require_cuda(x, "RFCBAMConv", self)
         if _grad_mode(self):
             from . import grad
             return grad.rfcbam_train(self, x)
@@ -616,7 +602,7 @@ class CoordAtt(nn.Module):
         pr = _probe(x, x.shape)
         if pr is not None:
             return pr
-        ops.require_cuda(x, "CoordAtt")
+        ops.require_cuda(x, "CoordAtt", self)
         if _grad_mode(self):
             from . import grad
             return grad.coordatt_train(self, x)
@@ -659,7 +645,7 @@ class CA_Bottleneck(nn.Module):
         if pr is not None:
             return pr
         if not isinstance(x, Lazy):
-            ops.require_cuda(x, "CA_Bottleneck")
+            ops.require_cuda(x, "CA_Bottleneck", self)
         y = self.forward_lazy(x)
         return y.materialize() if isinstance(y, Lazy) else y
 
@@ -705,7 +691,7 @@ class C3_CA(nn.Module):
         if pr is not None:
             return pr
         if not isinstance(x, Lazy):
-            ops.require_cuda(x, "C3_CA")
+            ops.require_cuda(x, "C3_CA", self)
         src = Lazy.of(x)
         n, c, h, w = src.shape
         c_ = self.c_

@@ -71,7 +71,10 @@ def mlp_config(c, m, w):
     return c, nt, ht, "false"
 
 
-def require_cuda(x, who):
+def require_cuda(x, who, mod=None):
+    if mod is not None and not mod.training and torch.is_grad_enabled() and x.requires_grad:
+        raise NotImplementedError(f"{who}: backward is built for train mode (batch-statistics BatchNorm); an eval-mode module would return "
+                                  "tensors detached from autograd — call .train(), or run inference under torch.no_grad()")
     if not x.is_cuda:
         raise RuntimeError(f"{who}: the HIP path needs a CUDA/ROCm tensor (got {x.device}); there is no CPU fallback")
     if x.dtype != torch.float32:

@@ -291,3 +291,14 @@ def test_train_step_with_gradient_reducer():
     for k, v in res[0][1].items():
         d = float((res[1][1][k] - v).abs().max())
         assert d <= 2e-3 * float(v.abs().max()) + 1e-4, (k, d)
+
+
+def test_eval_mode_refuses_autograd():
+    """backward is built for train mode; an eval-mode module must not silently return detached tensors"""
+    import lead_yolo_amd as L
+    m = L.BasicStage(24, 1).to(_dev()).eval()
+    x = torch.randn(1, 24, 8, 8, device=_dev(), requires_grad=True)
+    with pytest.raises(NotImplementedError):
+        m(x)
+    with torch.no_grad():
+        m(x)

@@ -8,3 +8,4 @@ from .model import DEFAULT_CFG, DetectionModel, Model, load_cfg, make_divisible,
 from .loss import ComputeLoss  # noqa: F401
 from .ddp import GradReducer  # noqa: F401
 from .train import ModelEMA, smart_optimizer, train_step  # noqa: F401
+from .graph import GraphedForward  # noqa: F401

@@ -192,11 +192,25 @@ class DetectionModel(nn.Module):
 
     def _forward_once(self, x):
         y = []
+        det = self.model[-1]
+        # Inference under hipGraph capture: a Detect level is launched on the auxiliary stream as soon as its feature map
+        # exists, so the small, latency-bound head kernels of P3 / P4 overlap the rest of the neck (the last level runs in
+        # Detect.forward).  In eager mode everything stays on one stream (fork/join events would cost more host time than they save).
+        early = None
+        if isinstance(det, M.Detect) and not self.training and not torch.is_grad_enabled() and isinstance(x, torch.Tensor) and x.is_cuda \
+                and M._overlap() \
+                and x.shape[2] % 32 == 0 and x.shape[3] % 32 == 0 and det.stride is not None and isinstance(det.f, (list, tuple)):
+            hw = [(int(x.shape[2] // s), int(x.shape[3] // s)) for s in det._strides()]
+            early = det.begin(x.shape[0], hw, x.device)
         for m in self.model:
             if m.f != -1:
                 x = y[m.f] if isinstance(m.f, int) else [x if j == -1 else y[j] for j in m.f]
+            if m is det and early is not None:
+                det._early = early
             x = m(x)
             y.append(x if m.i in self.save else None)
+            if early is not None and m is not det and m.i in det.f[:-1] and isinstance(x, torch.Tensor):
+                det.level(early, det.f.index(m.i), x, side=True)
         return x
 
     def _initialize_biases(self, cf=None):

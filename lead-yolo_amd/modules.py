@@ -68,6 +68,24 @@ def _grad_mode(mod):
     return mod.training and torch.is_grad_enabled()
 
 
+_SIDE_STREAMS = {}
+
+
+def _overlap():
+    """fork independent latency-bound branches onto the auxiliary stream?  Only under hipGraph capture."""
+    return torch.cuda.is_current_stream_capturing()
+
+
+
+def _side_stream(device):
+    """one auxiliary stream per device for branches that are independent of the main chain (SE attention, early Detect heads)"""
+    key = (device.type, device.index)
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 def _bn_tensors(bn):
     return (bn.weight, bn.bias, bn.running_mean, bn.running_var)
 
@@ -493,7 +511,21 @@ class RFCBAMConv(nn.Module):
         n, c, h, w = xr.shape
         k, s = self.kernel_size, self.stride
         P = self._packed()
-        ca = self.se.attention(xr, ld, n, h * w, c)
+        # The SE branch (global average pool + two tiny linears: latency-bound, a fraction of the GPU) is independent of the
+        # receptive-field statistics below: it runs on a side stream and is joined just before the contraction that needs `ca`.
+        # Only while a hipGraph is being captured (the fork/join then costs nothing at replay); in eager mode the extra event
+        # traffic makes the host the bottleneck, so the branch simply runs in line.
+        if _overlap():
+            main = torch.cuda.current_stream()
+            side = _side_stream(xr.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                ca = self.se.attention(xr, ld, n, h * w, c)
+            ca.record_stream(main)
+            join = lambda: main.wait_stream(side)
+        else:
+            ca = self.se.attention(xr, ld, n, h * w, c)
+            join = lambda: None
         if k == 1:
             a1, b1, es, eb = P["a1"], P["b1"], P["es"], P["eb"]
             if self.training:
@@ -505,6 +537,7 @@ class RFCBAMConv(nn.Module):
                 a1, b1 = (gwv * gs).contiguous(), gb
             mm = ops.rfcbam_stats(xr, ld, n, h, w, c, 1, 1, a1=a1, b1=b1)
             rfa = ops.rfa_map(mm, P["w18"])
+            join()
             kw = dict(M=n * h * w, H=h, W=w, K=c, N=self.o, a0=xr, lda0=ld, k0=c, wp=P["wp"], ldo=self.o, pro=ops.PRO_AFFINE_RELU_CA,
                       p_scale=a1, p_shift=b1, p_ca=ca, rowscale=rfa)
             if self.training:
@@ -526,6 +559,7 @@ class RFCBAMConv(nn.Module):
             wq_main = pack.rfcbam_gen_weights(gw, gs, gb, 16, True)
         mm = ops.rfcbam_stats(xr, ld, n, h, w, c, 3, s, wg=wq_stats, th=th, tw=tw)
         rfa = ops.rfa_map(mm, P["w18"])
+        join()
         kw = dict(n=n, h=h, w=w, c=c, ho=ho, wo=wo, N=self.o, s=s, th=th, tw=tw, x=xr, ldx=ld, wg=wq_main, ca=ca, rfa=rfa, wp=P["wp"],
                   ldo=self.o)
         if self.training:
@@ -844,22 +878,48 @@ class Detect(nn.Module):
                 bs, _, ny, nx = y.shape
                 x[i] = y.view(bs, self.na, self.no, ny, nx).permute(0, 1, 3, 4, 2).contiguous()
             return x
-        shapes = [Lazy.of(t).shape for t in x]
-        bs = shapes[0][0]
-        decode = not self.training
-        zrows = sum(self.na * s[2] * s[3] for s in shapes)
-        dev = Lazy.of(x[0]).a0.device
-        z = torch.empty((bs, zrows, self.no), dtype=torch.float32, device=dev) if decode else None
-        strides = self._strides()
-        zoff = 0
+        st = getattr(self, "_early", None)                      # levels already launched by Model._forward_once (side stream)
+        self._early = None
+        if st is None:
+            shapes = [Lazy.of(t).shape for t in x]
+            st = self.begin(shapes[0][0], [s_[2:] for s_ in shapes], Lazy.of(x[0]).a0.device)
         for i in range(self.nl):
-            buf, ldo = self._head(i, x[i])
-            _, _, ny, nx = shapes[i]
-            p = torch.empty((bs, self.na, ny, nx, self.no), dtype=torch.float32, device=dev)
-            ops.detect_tail(buf, ldo, bs, ny, nx, self.na, self.no, self.anchors[i], strides[i], p, z, zrows, zoff)
-            x[i] = p
-            zoff += self.na * ny * nx
-        return x if self.training else (z,) if self.export else (z, x)
+            if st["p"][i] is None:
+                self.level(st, i, x[i])
+        if st["forked"]:
+            torch.cuda.current_stream().wait_stream(_side_stream(st["device"]))
+        out, z = st["p"], st["z"]
+        return out if self.training else (z,) if self.export else (z, out)
+
+    # ---- per-level API (lets the model launch a level as soon as its feature map exists) -----------------
+    def begin(self, bs, hw, device):
+        """allocate the outputs for feature maps of sizes hw[i] = (ny, nx); returns the state `level` fills"""
+        decode = not self.training
+        rows = [self.na * ny * nx for ny, nx in hw]
+        z = torch.empty((bs, sum(rows), self.no), dtype=torch.float32, device=device) if decode else None
+        offs = [sum(rows[:i]) for i in range(self.nl)]
+        return dict(z=z, zrows=sum(rows), offs=offs, hw=[tuple(v) for v in hw], p=[None] * self.nl, bs=bs, device=device, forked=False)
+
+    def level(self, st, i, xi, side=False):
+        """head conv + decode of level i; with side=True on the auxiliary stream (joined in forward)"""
+        main = torch.cuda.current_stream()
+        ctx = torch.cuda.stream(_side_stream(st["device"])) if side else None
+        if side:
+            _side_stream(st["device"]).wait_stream(main)
+            st["forked"] = True
+            ctx.__enter__()
+        try:
+            buf, ldo = self._head(i, xi)
+            ny, nx = st["hw"][i]
+            p = torch.empty((st["bs"], self.na, ny, nx, self.no), dtype=torch.float32, device=st["device"])
+            ops.detect_tail(buf, ldo, st["bs"], ny, nx, self.na, self.no, self.anchors[i], self._strides()[i], p, st["z"], st["zrows"],
+                            st["offs"][i])
+            if side:
+                p.record_stream(main)
+            st["p"][i] = p
+        finally:
+            if side:
+                ctx.__exit__(None, None, None)
 
     def _make_grid(self, nx=20, ny=20, i=0):
         d, t = self.anchors[i].device, self.anchors[i].dtype

@@ -249,3 +249,25 @@ def test_whole_model_train_forward_golden(scale):
         err = np.abs(got - want)
         # P5 statistics come from 2x(2x3) pixels at this tiny input: allow a slightly wider band there
         assert err.max() <= 5e-3 + 5e-3 * np.abs(want).max(), (scale, i, err.max())
+
+
+def test_graphed_forward_matches_eager():
+    """serving mode: the forward captured into a hipGraph (with the SE / early-Detect branches forked onto the auxiliary
+    stream) must return exactly what the eager single-stream forward returns, also after new input is copied in"""
+    import lead_yolo_amd as L
+    torch.manual_seed(0)
+    m = L.Model(_cfg("s"))
+    st = synth.synth_state(synth.shapes_of(m.state_dict()), 777)
+    st["model.23.anchors"] = m.model[-1].anchors.clone()
+    m.load_state_dict(st)
+    m = m.to(_dev()).eval()
+    x1 = (synth.synth_images(2, 320, 5).float() / 255).to(_dev())
+    x2 = (synth.synth_images(2, 320, 6).float() / 255).to(_dev())
+    g = L.GraphedForward(m, x1)
+    for x in (x1, x2, x1):
+        with torch.no_grad():
+            ze, pe = m(x)
+        zg, pg = g(x)
+        torch.cuda.synchronize()
+        assert torch.equal(zg, ze)
+        assert all(torch.equal(a, b) for a, b in zip(pg, pe))

@@ -71,15 +71,19 @@ def _grad_mode(mod):
 _SIDE_STREAMS = {}
 
 
+FORK_BRANCHES = True     # graph.GraphedForward clears this while it captures several sub-batch streams (no nested forks)
+
+
 def _overlap():
     """fork independent latency-bound branches onto the auxiliary stream?  Only under hipGraph capture."""
-    return torch.cuda.is_current_stream_capturing()
+    return FORK_BRANCHES and torch.cuda.is_current_stream_capturing()
 
 
 
 def _side_stream(device):
-    """one auxiliary stream per device for branches that are independent of the main chain (SE attention, early Detect heads)"""
-    key = (device.type, device.index)
+    """the auxiliary stream paired with the CURRENT stream (one per stream, so that several capture streams can each fork
+    their own independent branches: SE attention, early Detect heads)"""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     st = _SIDE_STREAMS.get(key)
     if st is None:
         st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
@@ -896,7 +900,12 @@ class Detect(nn.Module):
         """allocate the outputs for feature maps of sizes hw[i] = (ny, nx); returns the state `level` fills"""
         decode = not self.training
         rows = [self.na * ny * nx for ny, nx in hw]
-        z = torch.empty((bs, sum(rows), self.no), dtype=torch.float32, device=device) if decode else None
+        ext = getattr(self, "_out", None)                       # caller-provided output storage (graph.GraphedForward: batch slices)
+        if ext is not None and decode:
+            z = ext["z"]
+            assert tuple(z.shape) == (bs, sum(rows), self.no) and z.is_contiguous()
+        else:
+            z = torch.empty((bs, sum(rows), self.no), dtype=torch.float32, device=device) if decode else None
         offs = [sum(rows[:i]) for i in range(self.nl)]
         return dict(z=z, zrows=sum(rows), offs=offs, hw=[tuple(v) for v in hw], p=[None] * self.nl, bs=bs, device=device, forked=False)
 
@@ -911,7 +920,8 @@ class Detect(nn.Module):
         try:
             buf, ldo = self._head(i, xi)
             ny, nx = st["hw"][i]
-            p = torch.empty((st["bs"], self.na, ny, nx, self.no), dtype=torch.float32, device=st["device"])
+            ext = getattr(self, "_out", None)
+            p = ext["p"][i] if ext is not None else torch.empty((st["bs"], self.na, ny, nx, self.no), dtype=torch.float32, device=st["device"])
             ops.detect_tail(buf, ldo, st["bs"], ny, nx, self.na, self.no, self.anchors[i], self._strides()[i], p, st["z"], st["zrows"],
                             st["offs"][i])
             if side:

@@ -261,13 +261,15 @@ def test_graphed_forward_matches_eager():
     st["model.23.anchors"] = m.model[-1].anchors.clone()
     m.load_state_dict(st)
     m = m.to(_dev()).eval()
-    x1 = (synth.synth_images(2, 320, 5).float() / 255).to(_dev())
-    x2 = (synth.synth_images(2, 320, 6).float() / 255).to(_dev())
-    g = L.GraphedForward(m, x1)
-    for x in (x1, x2, x1):
-        with torch.no_grad():
-            ze, pe = m(x)
-        zg, pg = g(x)
-        torch.cuda.synchronize()
-        assert torch.equal(zg, ze)
-        assert all(torch.equal(a, b) for a, b in zip(pg, pe))
+    for bs, parts in ((2, 1), (8, 2), (16, 4)):         # 1 stream + per-layer forks; 2 and 4 sub-batch streams writing batch slices
+        x1 = (synth.synth_images(bs, 256, 5).float() / 255).to(_dev())
+        x2 = (synth.synth_images(bs, 256, 6).float() / 255).to(_dev())
+        g = L.GraphedForward(m, x1)
+        assert g.parts == parts
+        for x in (x1, x2, x1):
+            with torch.no_grad():
+                ze, pe = m(x)
+            zg, pg = g(x)
+            torch.cuda.synchronize()
+            assert torch.equal(zg, ze)
+            assert all(torch.equal(a, b) for a, b in zip(pg, pe))

@@ -213,7 +213,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_mlpblock_fwd_kernel(
 #pragma unroll
     for (int n = 0; n < NT; ++n) acco[t][n] = zero;
 
-#pragma unroll 1
+#pragma unroll
   for (int hc = 0; hc < ((dbg & 2) ? 0 : HTP / HT); ++hc) {
     f32x4 acch[HT][NT];
 #pragma unroll

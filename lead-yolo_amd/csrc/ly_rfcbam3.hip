@@ -215,7 +215,9 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam3_kernel(const LyRfcbam3P
 }
 
 static int g_rf3_dbg = 0;   // ablation aid: 1 skip regenerate, 2 skip MFMA, 4 skip staging
-extern "C" int ly_debug_set_rf3(int v) { g_rf3_dbg = v; return 0; }
+static int g_rf3_mt4 = 0;   // (bit 3 of ly_debug_set_rf3) use the 256-channel MT=4 tile for N > 128: 312 registers, one wave per SIMD —
+                            // measured 180 us vs 133 us for two 128-channel groups on the 256->256 layer, so off by default
+extern "C" int ly_debug_set_rf3(int v) { g_rf3_dbg = v & 7; g_rf3_mt4 = (v >> 3) & 1; return 0; }
 
 template <int MT>
 static int launch_rf3(const LyRfcbam3Params& P, hipStream_t st) {
@@ -247,7 +249,7 @@ extern "C" int ly_rfcbam3_fwd(const LyRfcbam3Params* p, void* stream) {
   LY_CHECK(P.s >= 1 && P.TH >= 1 && P.TW >= 1 && P.TH * P.TW <= 64, "rfcbam3: bad tile %dx%d", P.TH, P.TW);
   LY_CHECK(P.Ho == (P.H + 2 - 3) / P.s + 1 && P.Wo == (P.W + 2 - 3) / P.s + 1, "rfcbam3: inconsistent output size");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (P.N > 128) return launch_rf3<4>(P, st);
+  if (P.N > 128 && g_rf3_mt4) return launch_rf3<4>(P, st);
   if (P.N > 64) return launch_rf3<2>(P, st);
   return launch_rf3<1>(P, st);
 }

@@ -363,8 +363,12 @@ __device__ __forceinline__ void ly_gemm_body2(const LyGemmParams& P, const int g
   const int T = (P.N + 15) >> 4;
   const int nchunk = (P.K + LY_BK - 1) / LY_BK;
   constexpr bool need_nhw = GATHER != LY_GATHER_ROWS || PRO != LY_PRO_NONE;
-  const int k4 = tid % KQ;
-  const int prow = tid / KQ;
+  // thread -> (float4 column k4, first pixel row prow).  NHWC sources: consecutive lanes take consecutive k (one pixel row is
+  // K-contiguous).  NCHW image patches: consecutive k are different (channel, ky) planes, megabytes apart, while consecutive
+  // output pixels of one plane row ARE contiguous (16 B each) — so there consecutive lanes take consecutive pixels.
+  static_assert(KQ == RSTEP, "the NCHW lane mapping swaps the two 16-way indices");
+  const int k4 = GATHER == LY_GATHER_PATCH_NCHW ? tid / RSTEP : tid % KQ;
+  const int prow = GATHER == LY_GATHER_PATCH_NCHW ? tid % RSTEP : tid / KQ;
   if (slot >= gx) return;
 
   // ---- staging state, one copy per register set ---------------------------------------------------

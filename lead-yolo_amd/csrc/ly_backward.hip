@@ -662,18 +662,30 @@ extern "C" int ly_maxpool_bwd(const float* x, int ldx, const float* dy, int lddy
 //   ly_bn_bwd_coeffs striped (sum dv, sum dv*u)        -> dgamma, dbeta and the affine map du = alpha*dv + kappa + lambda*u
 // Sums over stripes and the mean / variance arithmetic are done in double (E[x^2] - E[x]^2 cancels badly in fp32).
 // -------------------------------------------------------------------------------------------------
-__global__ void ly_bn_finalize_kernel(const float* __restrict__ stats, int stripes, int nch, int c_off, int N, double count,
-                                      const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ bias, float eps,
-                                      float momentum, float* running_mean, float* running_var, long* nbt, float* __restrict__ scale,
-                                      float* __restrict__ shift, float* __restrict__ mean, float* __restrict__ invstd) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c == 0 && nbt) *nbt += 1;
-  if (c >= N) return;
+// one 32-lane group per channel: lane r reads stripe r (stripes <= 32), the group reduces in double by shuffles
+__device__ __forceinline__ double ly_group32_sum(double v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 32);
+  return v;
+}
+
+__global__ __launch_bounds__(LY_THREADS) void ly_bn_finalize_kernel(const float* __restrict__ stats, int stripes, int nch, int c_off, int N,
+                                                                    double count, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                    const float* __restrict__ bias, float eps, float momentum, float* running_mean,
+                                                                    float* running_var, long* nbt, float* __restrict__ scale, float* __restrict__ shift,
+                                                                    float* __restrict__ mean, float* __restrict__ invstd) {
+  const int r = threadIdx.x & 31;
+  const int c = blockIdx.x * (LY_THREADS / 32) + (threadIdx.x >> 5);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
+  const int cc = c < N ? c : N - 1;
   double s1 = 0.0, s2 = 0.0;
-  for (int r = 0; r < stripes; ++r) {
-    s1 += (double)stats[(size_t)r * 2 * nch + c_off + c];
-    s2 += (double)stats[(size_t)r * 2 * nch + nch + c_off + c];
+  for (int q = r; q < stripes; q += 32) {
+    s1 += (double)stats[(size_t)q * 2 * nch + c_off + cc];
+    s2 += (double)stats[(size_t)q * 2 * nch + nch + c_off + cc];
   }
+  s1 = ly_group32_sum(s1);
+  s2 = ly_group32_sum(s2);
+  if (r != 0 || c >= N) return;
   const double m = s1 / count;
   double var = s2 / count - m * m;
   var = var > 0.0 ? var : 0.0;
@@ -694,22 +706,28 @@ extern "C" int ly_bn_finalize(const float* stats, int stripes, int nch, int c_of
                               const float* bias, float eps, float momentum, float* running_mean, float* running_var, long* nbt, float* scale,
                               float* shift, float* mean, float* invstd, void* stream) {
   LY_CHECK(stats && scale && shift && stripes > 0 && N > 0 && c_off >= 0 && c_off + N <= nch && count > 0, "bn_finalize: bad arguments");
-  hipLaunchKernelGGL(ly_bn_finalize_kernel, dim3((N + 127) / 128), dim3(128), 0, reinterpret_cast<hipStream_t>(stream), stats, stripes, nch, c_off, N,
+  hipLaunchKernelGGL(ly_bn_finalize_kernel, dim3((N + 7) / 8), dim3(LY_THREADS), 0, reinterpret_cast<hipStream_t>(stream), stats, stripes, nch, c_off, N,
                      count, gamma, beta, bias, eps, momentum, running_mean, running_var, nbt, scale, shift, mean, invstd);
   LY_LAUNCH_CHECK();
   return 0;
 }
 
-__global__ void ly_bn_bwd_coeffs_kernel(const float* __restrict__ sums, int stripes, int N, double count, const float* __restrict__ a,
-                                        const float* __restrict__ mean, const float* __restrict__ invstd, int train, float* __restrict__ dgamma,
-                                        float* __restrict__ dbeta, float* __restrict__ alpha, float* __restrict__ kappa, float* __restrict__ lambda) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= N) return;
+__global__ __launch_bounds__(LY_THREADS) void ly_bn_bwd_coeffs_kernel(const float* __restrict__ sums, int stripes, int N, double count,
+                                                                      const float* __restrict__ a, const float* __restrict__ mean,
+                                                                      const float* __restrict__ invstd, int train, float* __restrict__ dgamma,
+                                                                      float* __restrict__ dbeta, float* __restrict__ alpha, float* __restrict__ kappa,
+                                                                      float* __restrict__ lambda) {
+  const int r = threadIdx.x & 31;
+  const int c = blockIdx.x * (LY_THREADS / 32) + (threadIdx.x >> 5);
+  const int cc = c < N ? c : N - 1;
   double s1 = 0.0, s2 = 0.0;
-  for (int r = 0; r < stripes; ++r) {
-    s1 += (double)sums[(size_t)r * 2 * N + c];
-    s2 += (double)sums[(size_t)r * 2 * N + N + c];
+  for (int q = r; q < stripes; q += 32) {
+    s1 += (double)sums[(size_t)q * 2 * N + cc];
+    s2 += (double)sums[(size_t)q * 2 * N + N + cc];
   }
+  s1 = ly_group32_sum(s1);
+  s2 = ly_group32_sum(s2);
+  if (r != 0 || c >= N) return;
   const double mu = mean[c], is = invstd[c], av = a[c];
   const double dg = (s2 - mu * s1) * is;
   dgamma[c] = (float)dg;
@@ -728,7 +746,7 @@ __global__ void ly_bn_bwd_coeffs_kernel(const float* __restrict__ sums, int stri
 extern "C" int ly_bn_bwd_coeffs(const float* sums, int stripes, int N, double count, const float* a, const float* mean, const float* invstd, int train,
                                 float* dgamma, float* dbeta, float* alpha, float* kappa, float* lambda, void* stream) {
   LY_CHECK(sums && a && mean && invstd && dgamma && dbeta && alpha && kappa && lambda && N > 0 && count > 0, "bn_bwd_coeffs: bad arguments");
-  hipLaunchKernelGGL(ly_bn_bwd_coeffs_kernel, dim3((N + 127) / 128), dim3(128), 0, reinterpret_cast<hipStream_t>(stream), sums, stripes, N, count, a,
+  hipLaunchKernelGGL(ly_bn_bwd_coeffs_kernel, dim3((N + 7) / 8), dim3(LY_THREADS), 0, reinterpret_cast<hipStream_t>(stream), sums, stripes, N, count, a,
                      mean, invstd, train, dgamma, dbeta, alpha, kappa, lambda);
   LY_LAUNCH_CHECK();
   return 0;

@@ -288,8 +288,10 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_gen_kernel(const RfGeom 
       }
     }
   if (cok) {
+    // striped like the BatchNorm accumulators: hundreds of blocks adding to the same C*KK*KK addresses serialise in L2
+    float* d = dwg + (size_t)(blockIdx.x & (LY_STATS_STRIPES - 1)) * g.C * KK * KK + (long)c * KK * KK;
 #pragma unroll
-    for (int i = 0; i < KK * KK; ++i) atomicAdd(dwg + (long)c * KK * KK + i, acc[i]);
+    for (int i = 0; i < KK * KK; ++i) atomicAdd(d + i, acc[i]);
   }
 }
 
@@ -392,7 +394,7 @@ extern "C" int ly_rf_bwd_gen(const float* x, int ldx, int n_img, int H, int W, i
   LY_CHECK(x && ug && dv && alpha && kappa && lambda && dwg, "rf_bwd_gen: null pointer");
   int gx, gy;
   const long Mo = (long)n_img * ((H + 2 * (k / 2) - k) / s + 1) * ((W + 2 * (k / 2) - k) / s + 1);
-  const RfGeom g = rf_geom(n_img, H, W, C, k, s, Mo, gx, gy, 256);
+  const RfGeom g = rf_geom(n_img, H, W, C, k, s, Mo, gx, gy, 1024);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (k == 3) hipLaunchKernelGGL(ly_rf_bwd_gen_kernel<3>, dim3(gx, gy), dim3(LY_THREADS), 0, st, g, x, ldx, ug, dv, alpha, kappa, lambda, dwg);
   else hipLaunchKernelGGL(ly_rf_bwd_gen_kernel<1>, dim3(gx, gy), dim3(LY_THREADS), 0, st, g, x, ldx, ug, dv, alpha, kappa, lambda, dwg);

@@ -328,14 +328,17 @@ class MlpBlockFn(torch.autograd.Function):
             dw1 = torch.zeros(2 * c, c, dtype=torch.float32, device=x.device)
             ops.wgrad(M=m, H=h, W=w, N=2 * c, du=du1, lddu=2 * c, x=z, ldx=c, Hin=h, Win=w, Cin=c, dw=dw1, lddw=c)
             # partial 3x3 conv on the first C/4 channels
-            dwp = torch.zeros(c4, 9 * c4, dtype=torch.float32, device=x.device)
-            ops.wgrad(M=m, H=h, W=w, N=c4, du=g, lddu=c, x=x, ldx=c, Hin=h, Win=w, Cin=c4, dw=dwp, lddw=9 * c4, ks=3, stride=1, pad=1)
+            # channel counts padded to multiples of 4 (C/4 = 6, 10): the tiled wgrad then applies; the extra rows / columns
+            # (gradients of, and against, the neighbouring untouched channels) are computed and discarded
+            dwp = torch.zeros(c4p, 9 * c4p, dtype=torch.float32, device=x.device)
+            ops.wgrad(M=m, H=h, W=w, N=c4p, du=g, lddu=c, x=x, ldx=c, Hin=h, Win=w, Cin=c4p, dw=dwp, lddw=9 * c4p, ks=3, stride=1, pad=1)
+            dwp = dwp.view(c4p, 9, c4p)[:c4, :, :c4]
             t = ops.empty_nhwc(n, c4p, h, w, x)
             wt = pack.frag_pack3(pack.conv_taps_matrix(wpc.detach().permute(1, 0, 2, 3).flip(2, 3), 32))
             ops.conv3x3(M=m, H=h, W=w, Cin=c4p, N=c4, x=g, ldx=c, wp=wt, out=t, ldo=c4p)
             dx = dy + g
             dx[:, :c4] = dy[:, :c4] + t[:, :c4]
-        return (None, dx, dwp.view(c4, 3, 3, c4).permute(0, 3, 1, 2).contiguous(), dw1.view(w1.shape), dgamma, dbeta, dw2.view(w2.shape))
+        return (None, dx, dwp.reshape(c4, 3, 3, c4).permute(0, 3, 1, 2).contiguous(), dw1.view(w1.shape), dgamma, dbeta, dw2.view(w2.shape))
 
 
 # --------------------------------------------------------------------------------------------------
@@ -536,14 +539,14 @@ class RfcbamFn(torch.autograd.Function):
             dgg_tc, dbg_tc, alpha, kappa, lam = ops.bn_bwd_coeffs(sums, kk * c, mo, ag, tc(gmean), tc(ginv), True)
             ct = lambda v: v.view(kk, c).t().contiguous().view(-1)
             # 10. dug, generate weight gradient
-            dwg = torch.zeros(c * kk, kk, dtype=torch.float32, device=dev)
+            dwg = torch.zeros(ops.STRIPES, c * kk, kk, dtype=torch.float32, device=dev)
             L.check(L.lib().ly_rf_bwd_gen(p(xr), ld, n, h, w, c, k, s, p(ug), p(dcd), p(alpha), p(kappa), p(lam), p(dwg), st), "ly_rf_bwd_gen")
             # 11. dx
             dx = None
             if ctx.needs_input_grad[1]:
                 dx = ops.empty_nhwc(n, c, h, w, xr)
                 L.check(L.lib().ly_rf_bwd_dx(n, h, w, c, k, s, p(dcd), p(wg), p(dx), c, st), "ly_rf_bwd_dx")
-        return (None, dx, d_ca, dwg.view(gen_w.shape), ct(dgg_tc), ct(dbg_tc), dw18.view(getw.shape), dwc, torch.zeros_like(bias), dgo, dbo)
+        return (None, dx, d_ca, dwg.sum(0).view(gen_w.shape), ct(dgg_tc), ct(dbg_tc), dw18.view(getw.shape), dwc, torch.zeros_like(bias), dgo, dbo)
 
 
 def rfcbam_train(mod, x):

@@ -244,10 +244,10 @@ int ly_rfa_bwd(const float* d_rfa, const float* rfa, const float* mm, const floa
 /* dv = [G>0]*(dcd*rfa*ca + d_mm.mean/C + [G==gmax]*d_mm.max) written over dcd; sums[t*C+c] += dv, sums[C*KK + ..] += dv*ug */
 int ly_rf_bwd_relu(int n_img, int H, int W, int C, int k, int s, const float* ug, float* dcd, const float* ag, const float* bg,
                    const float* ca, const float* rfa, const float* gmax, const float* d_mm, float* sums, void* stream);
-/* dug = alpha*dv + kappa + lambda*ug written over dv; dwg[stripe][c*KK + t][u] += sum_m dug*x_u: LY_STATS_STRIPES
- * copies of the [C*KK][KK] array, zeroed by the caller, to be summed by it (block b adds into copy b % LY_STATS_STRIPES) */
+/* dug = alpha*dv + kappa + lambda*ug written over dv; dwg[row][c*KK + t][u] = partial sums of sum_m dug*x_u: a
+ * [part_rows][C*KK][KK] matrix zeroed by the caller; every (block, pixel sub-group) stores one row, the caller sums rows */
 int ly_rf_bwd_gen(const float* x, int ldx, int n_img, int H, int W, int C, int k, int s, const float* ug, float* dv, const float* alpha,
-                  const float* kappa, const float* lambda, float* dwg, void* stream);
+                  const float* kappa, const float* lambda, float* dwg, int part_rows, void* stream);
 /* dx[n,hi,wi,c] = sum over (m, u) reading that input pixel of sum_t dug[m][t][c]*wg[c*KK + t][u]  (written)           */
 int ly_rf_bwd_dx(int n_img, int H, int W, int C, int k, int s, const float* dug, const float* wg, float* dx, int lddx, void* stream);
 

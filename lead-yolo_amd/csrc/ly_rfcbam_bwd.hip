@@ -288,10 +288,11 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_gen_kernel(const RfGeom 
       }
     }
   if (cok) {
-    // striped like the BatchNorm accumulators: hundreds of blocks adding to the same C*KK*KK addresses serialise in L2
-    float* d = dwg + (size_t)(blockIdx.x & (LY_STATS_STRIPES - 1)) * g.C * KK * KK + (long)c * KK * KK;
+    // every (block, pixel sub-group) owns one row of the partial-sum matrix: plain stores, no atomics (81 accumulators per
+    // thread x hundreds of blocks was 5-20 M float atomics, 0.65-1.2 ms); the caller sums the rows
+    float* d = dwg + ((size_t)blockIdx.x * g.subs + sub) * g.C * KK * KK + (long)c * KK * KK;
 #pragma unroll
-    for (int i = 0; i < KK * KK; ++i) atomicAdd(d + i, acc[i]);
+    for (int i = 0; i < KK * KK; ++i) d[i] = acc[i];
   }
 }
 
@@ -389,12 +390,16 @@ extern "C" int ly_rf_bwd_relu(int n_img, int H, int W, int C, int k, int s, cons
 }
 
 extern "C" int ly_rf_bwd_gen(const float* x, int ldx, int n_img, int H, int W, int C, int k, int s, const float* ug, float* dv, const float* alpha,
-                             const float* kappa, const float* lambda, float* dwg, void* stream) {
+                             const float* kappa, const float* lambda, float* dwg, int part_rows, void* stream) {
   RF_ARGS_OK(k, C);
-  LY_CHECK(x && ug && dv && alpha && kappa && lambda && dwg, "rf_bwd_gen: null pointer");
+  LY_CHECK(x && ug && dv && alpha && kappa && lambda && dwg && part_rows >= 4, "rf_bwd_gen: bad arguments");
   int gx, gy;
   const long Mo = (long)n_img * ((H + 2 * (k / 2) - k) / s + 1) * ((W + 2 * (k / 2) - k) / s + 1);
-  const RfGeom g = rf_geom(n_img, H, W, C, k, s, Mo, gx, gy, 1024);
+  const int cmin = C < 256 ? C : 256;
+  const int subs = LY_THREADS / ((cmin + 63) / 64 * 64);
+  const int groups = (C + 255) / 256;
+  const RfGeom g = rf_geom(n_img, H, W, C, k, s, Mo, gx, gy, (long)(part_rows / subs) * groups);
+  LY_CHECK((long)gx * g.subs <= part_rows, "rf_bwd_gen: %d partial rows are not enough for %d blocks x %d", part_rows, gx, g.subs);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (k == 3) hipLaunchKernelGGL(ly_rf_bwd_gen_kernel<3>, dim3(gx, gy), dim3(LY_THREADS), 0, st, g, x, ldx, ug, dv, alpha, kappa, lambda, dwg);
   else hipLaunchKernelGGL(ly_rf_bwd_gen_kernel<1>, dim3(gx, gy), dim3(LY_THREADS), 0, st, g, x, ldx, ug, dv, alpha, kappa, lambda, dwg);

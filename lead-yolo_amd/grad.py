@@ -539,8 +539,10 @@ class RfcbamFn(torch.autograd.Function):
             dgg_tc, dbg_tc, alpha, kappa, lam = ops.bn_bwd_coeffs(sums, kk * c, mo, ag, tc(gmean), tc(ginv), True)
             ct = lambda v: v.view(kk, c).t().contiguous().view(-1)
             # 10. dug, generate weight gradient
-            dwg = torch.zeros(ops.STRIPES, c * kk, kk, dtype=torch.float32, device=dev)
-            L.check(L.lib().ly_rf_bwd_gen(p(xr), ld, n, h, w, c, k, s, p(ug), p(dcd), p(alpha), p(kappa), p(lam), p(dwg), st), "ly_rf_bwd_gen")
+            part_rows = 512
+            dwg = torch.zeros(part_rows, c * kk, kk, dtype=torch.float32, device=dev)         # per-block partial sums, summed below
+            L.check(L.lib().ly_rf_bwd_gen(p(xr), ld, n, h, w, c, k, s, p(ug), p(dcd), p(alpha), p(kappa), p(lam), p(dwg), part_rows, st),
+                    "ly_rf_bwd_gen")
             # 11. dx
             dx = None
             if ctx.needs_input_grad[1]:

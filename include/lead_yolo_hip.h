@@ -218,7 +218,7 @@ int ly_up2_bwd(const float* d, int ldd, int n_img, int Hs, int Ws, int C, float*
 int ly_unpatch(const float* g, int n_img, int Ho, int Wo, int C, int ks, float* dx, void* stream);
 
 /* CoordAtt backward (models/common.py:1595-1609).  Gate out = x*a_h[n,h,:]*a_w[n,w,:]:
- *   dx = dout*a_h*a_w,  da_h[n,h,c] = sum_w dout*x*a_w (written),  da_w[n,w,c] += sum_h dout*x*a_h (caller zeroes).
+ *   dx = dout*a_h*a_w,  da_h[n,h,c] += sum_w dout*x*a_w,  da_w[n,w,c] += sum_h dout*x*a_h  (caller zeroes both).
  * Pools pool[n,0:H]=mean_w x, pool[n,H:H+W]=mean_h x:  dx[n,h,w,c] = gp[n,h,c]/W + gp[n,H+w,c]/H.                  */
 int ly_coordatt_gate_bwd(const float* dout, int ldd, const float* x, int ldx, int n_img, int H, int W, int C, const float* a_h,
                          const float* a_w, float* dx, int lddx, float* da_h, float* da_w, void* stream);

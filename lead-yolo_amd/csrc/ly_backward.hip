@@ -539,38 +539,68 @@ extern "C" int ly_unpatch(const float* g, int n_img, int Ho, int Wo, int C, int 
 //          dx[n,h,w,c] = gp[n,h,c]/W + gp[n,H+w,c]/H
 // One block per (image, row h): da_h is reduced in the block, da_w (zeroed by the caller) by float atomics.
 // -------------------------------------------------------------------------------------------------
+// One block per (image, band of RB rows): da_h is reduced per row in the block; the da_w contributions of the band's rows are
+// summed in registers (a thread owns a fixed set of (w, channel quad) pairs) and added with ONE float atomic per element and
+// band instead of one per element and row.
+#define LY_CAG_RB 8
+#define LY_CAG_MAXW 8        // (w, c4) pairs per thread: ceil(W / groups) <= 8
 __global__ __launch_bounds__(LY_THREADS) void ly_coordatt_gate_bwd_kernel(const float* __restrict__ dout, int ldd, const float* __restrict__ x,
                                                                            int ldx, int H, int W, int C, const float* __restrict__ a_h,
                                                                            const float* __restrict__ a_w, float* __restrict__ dx, int lddx,
-                                                                           float* __restrict__ da_h, float* __restrict__ da_w) {
+                                                                           float* __restrict__ da_h, float* __restrict__ da_w, int bands, int slabs) {
   __shared__ f32x4 red[LY_THREADS];
   const int nc4 = C >> 2, tid = threadIdx.x;
   const int groups = LY_THREADS / nc4;
   const int c4 = tid % nc4, g0 = tid / nc4;
-  const long nh = blockIdx.x;                   // n*H + h
-  const long n = nh / H;
-  f32x4 sh = ly_zero4();
-  if (g0 < groups) {
-    const f32x4 ah = ly_ldg4(a_h + nh * C + 4 * c4);
-    for (int w = g0; w < W; w += groups) {
-      const long row = nh * W + w;
-      const f32x4 d = ly_ldg4(dout + row * ldd + 4 * c4);
-      const f32x4 xv = ly_ldg4(x + row * ldx + 4 * c4);
-      const f32x4 aw = ly_ldg4(a_w + (n * W + w) * C + 4 * c4);
-      ly_stg4(dx + row * lddx + 4 * c4, d * ah * aw);
-      const f32x4 t = d * xv;
-      sh += t * aw;
-      const f32x4 tw = t * ah;
-      float* o = da_w + (n * W + w) * C + 4 * c4;
+  const int slab = blockIdx.x % slabs;                       // column slab of groups * LY_CAG_MAXW columns
+  const int bb = blockIdx.x / slabs;
+  const long n = bb / bands;
+  const int band = bb - (int)n * bands;
+  const int w0 = slab * groups * LY_CAG_MAXW;
+  const int h_lo = band * LY_CAG_RB, h_hi = h_lo + LY_CAG_RB < H ? h_lo + LY_CAG_RB : H;
+  f32x4 accw[LY_CAG_MAXW];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) atomicAdd(o + r, tw[r]);
+  for (int i = 0; i < LY_CAG_MAXW; ++i) accw[i] = ly_zero4();
+  for (int h = h_lo; h < h_hi; ++h) {
+    const long nh = n * H + h;
+    f32x4 sh = ly_zero4();
+    if (g0 < groups) {
+      const f32x4 ah = ly_ldg4(a_h + nh * C + 4 * c4);
+#pragma unroll
+      for (int i = 0; i < LY_CAG_MAXW; ++i) {
+        const int w = w0 + g0 + i * groups;
+        if (w < W) {
+          const long row = nh * W + w;
+          const f32x4 d = ly_ldg4(dout + row * ldd + 4 * c4);
+          const f32x4 xv = ly_ldg4(x + row * ldx + 4 * c4);
+          const f32x4 aw = ly_ldg4(a_w + (n * W + w) * C + 4 * c4);
+          ly_stg4(dx + row * lddx + 4 * c4, d * ah * aw);
+          const f32x4 t = d * xv;
+          sh += t * aw;
+          accw[i] += t * ah;
+        }
+      }
+    }
+    __syncthreads();
+    red[tid] = sh;
+    __syncthreads();
+    if (g0 == 0) {
+      for (int g = 1; g < groups; ++g) sh += red[g * nc4 + c4];
+      float* o = da_h + nh * C + 4 * c4;                      // (one add per row, slab and channel: da_h is zeroed by the caller)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(o + r, sh[r]);
     }
   }
-  red[tid] = sh;
-  __syncthreads();
-  if (g0 == 0) {
-    for (int g = 1; g < groups; ++g) sh += red[g * nc4 + c4];
-    ly_stg4(da_h + nh * C + 4 * c4, sh);
+  if (g0 < groups) {
+#pragma unroll
+    for (int i = 0; i < LY_CAG_MAXW; ++i) {
+      const int w = w0 + g0 + i * groups;
+      if (w < W) {
+        float* o = da_w + (n * W + w) * C + 4 * c4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(o + r, accw[i][r]);
+      }
+    }
   }
 }
 
@@ -578,8 +608,11 @@ extern "C" int ly_coordatt_gate_bwd(const float* dout, int ldd, const float* x, 
                                     const float* a_w, float* dx, int lddx, float* da_h, float* da_w, void* stream) {
   LY_CHECK(dout && x && a_h && a_w && dx && da_h && da_w, "coordatt_gate_bwd: null pointer");
   LY_CHECK((C & 3) == 0 && C <= 1024 && (ldd & 3) == 0 && (ldx & 3) == 0 && (lddx & 3) == 0, "coordatt_gate_bwd: C / ld must be multiples of 4");
-  hipLaunchKernelGGL(ly_coordatt_gate_bwd_kernel, dim3((unsigned)(n_img * H)), dim3(LY_THREADS), 0, reinterpret_cast<hipStream_t>(stream), dout,
-                     ldd, x, ldx, H, W, C, a_h, a_w, dx, lddx, da_h, da_w);
+  const int groups = LY_THREADS / (C >> 2);
+  const int slabs = (W + groups * LY_CAG_MAXW - 1) / (groups * LY_CAG_MAXW);
+  const int bands = (H + LY_CAG_RB - 1) / LY_CAG_RB;
+  hipLaunchKernelGGL(ly_coordatt_gate_bwd_kernel, dim3((unsigned)(n_img * bands * slabs)), dim3(LY_THREADS), 0, reinterpret_cast<hipStream_t>(stream),
+                     dout, ldd, x, ldx, H, W, C, a_h, a_w, dx, lddx, da_h, da_w, bands, slabs);
   LY_LAUNCH_CHECK();
   return 0;
 }

@@ -364,7 +364,7 @@ def unpatch(g, n, ho, wo, c, ks, h, w):
 
 def coordatt_gate_bwd(dout, x, ldx, n, h, w, c, a_h, a_w):
     dx = empty_nhwc(n, c, h, w, dout)
-    da_h = torch.empty((n, h, c), dtype=torch.float32, device=dout.device)
+    da_h = torch.zeros((n, h, c), dtype=torch.float32, device=dout.device)
     da_w = torch.zeros((n, w, c), dtype=torch.float32, device=dout.device)
     capi.check(capi.lib().ly_coordatt_gate_bwd(_p(dout), c, _p(x), ldx, n, h, w, c, _p(a_h), _p(a_w), _p(dx), c, _p(da_h), _p(da_w),
                                                capi.stream_ptr()), "ly_coordatt_gate_bwd")

@@ -67,7 +67,9 @@ class GraphedForward:
             z = torch.empty((sub * parts,) + tuple(z0.shape[1:]), dtype=z0.dtype, device=z0.device)
             ps = [torch.empty((sub * parts,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for t in p0]
             del z0, p0
-        with torch.cuda.graph(self.graph):
+        # thread_local: API calls of OTHER host threads (e.g. the RCCL watchdog of an initialised process group polling events)
+        # must not invalidate the capture
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             if parts == 1:                                       # directly on the capture stream (the model forks its branches itself)
                 self.out = model(xs[0])
                 return

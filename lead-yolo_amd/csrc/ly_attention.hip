@@ -105,8 +105,10 @@ __global__ __launch_bounds__(LY_THREADS) void ly_colsum_kernel(const float* __re
   const int groups = LY_THREADS / nc4;              // C <= 1024
   const int c4 = tid % nc4, j0 = tid / nc4;
   f32x4 s = ly_zero4();
-  if (j0 < groups)
+  if (j0 < groups) {
+#pragma unroll 4
     for (int j = j_lo + j0; j < j_hi; j += groups) s += ly_ldg4(x + ((long)n * P + j) * ldx + 4 * c4);
+  }
   red[tid] = s;
   __syncthreads();
   if (j0 == 0) {

@@ -149,7 +149,8 @@ def coordatt_gate(x, ldx, n, h, w, c, a_h, a_w, res=None, ldres=0):
 
 
 def se_attention(x, ldx, n, hw, c, wa, wb, r):
-    slices = max(1, min(hw // 256, 32))          # depends on the map only: results do not change with the batch split
+    slices = max(1, min(hw // 64, 128))          # depends on the map only (results do not change with the batch split); short
+                                                  # per-block row loops: the pass is latency-bound, not bandwidth-bound
     part = torch.empty((n, slices, c), dtype=torch.float32, device=x.device)
     ca = torch.empty((n, c), dtype=torch.float32, device=x.device)
     capi.check(capi.lib().ly_se_fwd(_p(x), ldx, n, hw, c, _p(wa), _p(wb), r, _p(part), slices, _p(ca), capi.stream_ptr()),

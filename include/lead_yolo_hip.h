@@ -64,7 +64,8 @@ typedef struct LyGemmParams {
   float* out; int ldo;    /* output row stride (floats); pointer may be pre-offset into a concat */
   float* stats;           /* NULL, or [2N] zero-initialised accumulators: STATISTICS PASS for train-mode
                              BatchNorm — adds sum / sum-of-squares over the M rows of the pre-activation value
-                             (rowscale*e_scale*acc + e_shift) per output channel and stores nothing          */
+                             (rowscale*e_scale*acc + e_shift) per output channel; stores nothing when out is NULL,
+                             otherwise stores act(that value) as usual (one launch for statistics + pre-BN tensor) */
 } LyGemmParams;
 
 /* out[m, n] = act(rowscale[m] * e_scale[n] * sum_k A'[m, k] W[n, k] + e_shift[n]).
@@ -189,6 +190,9 @@ int ly_rfcbam_tap_moments(const float* x, int ldx, int n_img, int H, int W, int 
  * (models/common.py:1906-1907 Conv.forward; :1478-1482 MLPBlock).  With dv = dy * act'(v):
  *   reduce: sums[c] += sum_r dv, sums[C + c] += sum_r dv*u   (sums zeroed by the caller)
  *   apply : du = alpha[c]*dv + kappa[c] + lambda[c]*u        (du may alias u or dy)                               */
+/* y = act(a[c]*u + b[c]) over [rows, C]: the normalisation + activation half of a train-mode unit whose contraction pass
+ * (stats != NULL AND out != NULL: statistics accumulated and the pre-BN value stored in ONE launch) produced u.            */
+int ly_bnact_fwd(const float* u, int ldu, long rows, int C, const float* a, const float* b, int act, float* y, int ldy, void* stream);
 int ly_bnact_bwd_reduce(const float* dy, int lddy, const float* u, int ldu, long rows, int C, const float* a, const float* b,
                         int act, float* sums, void* stream);
 int ly_bnact_bwd_apply(const float* dy, int lddy, const float* u, int ldu, long rows, int C, const float* a, const float* b,

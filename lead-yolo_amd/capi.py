@@ -77,6 +77,7 @@ SIGNATURES = {
     "ly_rfcbam_tap_moments": [_P, _I, _I, _I, _I, _I, _I, _P, _P],
     "ly_coordatt_conv1_stats": [_P, _L, _I, _I, _P, _P, _P, _P],
     "ly_sppf_pool": [_P, _I, _I, _I, _I, _I, _I, _P, _I, _P],
+    "ly_bnact_fwd": [_P, _I, _L, _I, _P, _P, _I, _P, _I, _P],
     "ly_bnact_bwd_reduce": [_P, _I, _P, _I, _L, _I, _P, _P, _I, _P, _P],
     "ly_bnact_bwd_apply": [_P, _I, _P, _I, _L, _I, _P, _P, _I, _P, _P, _P, _P, _I, _P],
     "ly_wgrad": [ctypes.POINTER(LyWgradParams), _P],

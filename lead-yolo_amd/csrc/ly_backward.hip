@@ -87,9 +87,36 @@ __global__ __launch_bounds__(LY_THREADS) void ly_bnact_bwd_apply_kernel(const fl
   }
 }
 
+// y = act(a[c]*u + b[c]) over an [rows, C] matrix: the second half of a train-mode conv -> BN -> act unit whose
+// contraction pass stored the pre-BN value u and accumulated its statistics in the same launch
+template <int ACT>
+__global__ __launch_bounds__(LY_THREADS) void ly_bnact_fwd_kernel(const float* __restrict__ u, int ldu, long rows, int C, const float* __restrict__ a,
+                                                                   const float* __restrict__ b, float* __restrict__ y, int ldy) {
+  const int nc4 = C >> 2;
+  const long total = rows * nc4;
+  for (long i = (long)blockIdx.x * LY_THREADS + threadIdx.x; i < total; i += (long)gridDim.x * LY_THREADS) {
+    const long r = i / nc4;
+    const int c = 4 * (int)(i - r * nc4);
+    const f32x4 v = ly_ldg4(a + c) * ly_ldg4(u + r * ldu + c) + ly_ldg4(b + c);
+    ly_stg4(y + r * ldy + c, ly_act4(v, ACT));
+  }
+}
+
 static long ly_ew_blocks(long items) {
   long b = (items + LY_THREADS * 4L - 1) / (LY_THREADS * 4L);
   return b < 1 ? 1 : b > 4096 ? 4096 : b;
+}
+
+extern "C" int ly_bnact_fwd(const float* u, int ldu, long rows, int C, const float* a, const float* b, int act, float* y, int ldy, void* stream) {
+  LY_CHECK(u && a && b && y && rows > 0, "bnact_fwd: null pointer");
+  LY_CHECK((C & 3) == 0 && C > 0 && (ldu & 3) == 0 && (ldy & 3) == 0, "bnact_fwd: C=%d / ld must be multiples of 4", C);
+  const long blocks = ly_ew_blocks(rows * (C >> 2));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (act == LY_ACT_SILU) hipLaunchKernelGGL(ly_bnact_fwd_kernel<LY_ACT_SILU>, dim3((unsigned)blocks), dim3(LY_THREADS), 0, st, u, ldu, rows, C, a, b, y, ldy);
+  else if (act == LY_ACT_RELU) hipLaunchKernelGGL(ly_bnact_fwd_kernel<LY_ACT_RELU>, dim3((unsigned)blocks), dim3(LY_THREADS), 0, st, u, ldu, rows, C, a, b, y, ldy);
+  else hipLaunchKernelGGL(ly_bnact_fwd_kernel<LY_ACT_NONE>, dim3((unsigned)blocks), dim3(LY_THREADS), 0, st, u, ldu, rows, C, a, b, y, ldy);
+  LY_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int ly_bnact_bwd_reduce(const float* dy, int lddy, const float* u, int ldu, long rows, int C, const float* a, const float* b,

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_conv3x3_kernel(const LyConv3Par
       if (P.stats) {
         s1 += u;
         s2 += u * u;
-        continue;
+        if (!P.out) continue;                              // pure statistics pass; with `out` the value is stored as well
       }
       const f32x4 v = ly_act4(u, act);
       float* o = P.out + orow[n] * P.ldo + c;

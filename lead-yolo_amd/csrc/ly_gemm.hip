@@ -300,7 +300,7 @@ __device__ __forceinline__ void ly_gemm_body(const LyGemmParams& P, const int gy
             if (stats) {                                   // pre-activation value is what BatchNorm normalises
               st1 += u;
               st2 += u * u;
-              continue;
+              if (!P.out) continue;                        // pure statistics pass; with `out` the value is stored as well
             }
             const f32x4 v = ly_act4(u, act);
             float* o = P.out + gp * P.ldo + c;
@@ -587,7 +587,7 @@ __device__ __forceinline__ void ly_gemm_body2(const LyGemmParams& P, const int g
             if (stats) {
               st1 += u;
               st2 += u * u;
-              continue;
+              if (!P.out) continue;                        // pure statistics pass; with `out` the value is stored as well
             }
             const f32x4 v = ly_act4(u, act);
             float* o = P.out + gp * P.ldo + cc;

@@ -40,8 +40,9 @@ class ConvSpec:
 
 
 
-def _conv_forward(spec, x0, x1, wp, e_scale, e_shift, act, stats=None, out=None):
-    """Runs the forward contraction of `spec`; returns the output tensor (None for a statistics pass)."""
+def _conv_forward(spec, x0, x1, wp, e_scale, e_shift, act, stats=None, out=None, store=False):
+    """Runs the forward contraction of `spec`; returns the output tensor (None for a pure statistics pass; with store=True a
+    statistics pass also stores its pre-BN value, in the same launch)."""
     co = spec.cout
     if spec.kind == "pw":
         t0, ld0 = ops.rows(x0)
@@ -54,14 +55,14 @@ def _conv_forward(spec, x0, x1, wp, e_scale, e_shift, act, stats=None, out=None)
             t1, ld1 = ops.rows(x1)
             kw.update(a1=t1, lda1=ld1)
             k += t1.shape[1]
-        if stats is None and out is None:
+        if (stats is None or store) and out is None:
             out = ops.empty_nhwc(n, co, h, w, t0)
         ops.gemm(M=n * h * w, H=h, W=w, K=k, N=co, wp=wp, out=out, ldo=co, e_scale=e_scale, e_shift=e_shift, act=act, stats=stats, **kw)
         return out
     if spec.kind == "c3":
         t0, ld0 = ops.rows(x0)
         n, c, h, w = t0.shape
-        if stats is None and out is None:
+        if (stats is None or store) and out is None:
             out = ops.empty_nhwc(n, co, h, w, t0)
         ops.conv3x3(M=n * h * w, H=h, W=w, Cin=c, N=co, x=t0, ldx=ld0, wp=wp, out=out, ldo=co, e_scale=e_scale, e_shift=e_shift, act=act,
                     stats=stats)
@@ -75,7 +76,7 @@ def _conv_forward(spec, x0, x1, wp, e_scale, e_shift, act, stats=None, out=None)
     else:
         xr = _rows_dense(x0)
         kw = dict(K=k * k * c, a0=xr, lda0=c, k0=k * k * c, gather=ops.GATHER_PATCH, Hin=h, Win=w, Cin=c, ks=k, pk=k * c)
-    if stats is None and out is None:
+    if (stats is None or store) and out is None:
         out = ops.empty_nhwc(n, co, ho, wo, xr)
     ops.gemm(M=n * ho * wo, H=ho, W=wo, N=co, wp=wp, out=out, ldo=co, e_scale=e_scale, e_shift=e_shift, act=act, stats=stats, **kw)
     return out
@@ -83,14 +84,16 @@ def _conv_forward(spec, x0, x1, wp, e_scale, e_shift, act, stats=None, out=None)
 
 
 
-def affine_backward(dy, u, a, b, act, mean, invstd, train):
-    """du (written over u) and (dgamma, dbeta) for v = a*u + b, y = act(v); dy/u are NHWC-dense [n, c, h, w]."""
+def affine_backward(dy, u, a, b, act, mean, invstd, train, inplace=True):
+    """du and (dgamma, dbeta) for v = a*u + b, y = act(v); dy/u are NHWC-dense [n, c, h, w].  du is written over u unless
+    inplace=False (u is a tensor saved for backward)."""
     n, c, h, w = u.shape
     rows = n * h * w
     sums = ops.bnact_bwd_reduce(dy, c, u, c, rows, c, a, b, act)
     dgamma, dbeta, alpha, kappa, lam = ops.bn_bwd_coeffs(sums, c, rows, a, mean, invstd, train)
-    ops.bnact_bwd_apply(dy, c, u, c, rows, c, a, b, act, alpha, kappa, lam, u, c)
-    return u, dgamma, dbeta
+    du = u if inplace else torch.empty_like(u)
+    ops.bnact_bwd_apply(dy, c, u, c, rows, c, a, b, act, alpha, kappa, lam, du, c)
+    return du, dgamma, dbeta
 
 
 def conv_wgrad(spec, du, x0, x1, weight):
@@ -180,7 +183,20 @@ class ConvBnAct(torch.autograd.Function):
         bias_f = bias.detach().float().contiguous() if bias is not None else None
         mean = invstd = None
         if spec.bn is not None:
-            if spec.bn_train:
+            if spec.bn_train and co % 4 == 0:
+                # ONE contraction: statistics and the pre-BN value u in the same launch; y = act(a*u + b) is an elementwise
+                # pass, and u is kept for the backward (no recompute there)
+                stats = ops.new_stats(co, dev)
+                u = _conv_forward(spec, x0, x1, wp, None, bias_f, ACT_NONE, stats=stats, store=True)
+                rows = u.shape[0] * u.shape[2] * u.shape[3]
+                a, b, mean, invstd = ops.bn_finalize(spec.bn, stats, co, rows, want_stats=True)
+                y = torch.empty_like(u)
+                ops.bnact_fwd(u, co, rows, co, a, b, spec.act, y, co)
+                ctx.spec, ctx.wp = spec, wp
+                ctx.has = (x1 is not None, bias is not None)
+                ctx.save_for_backward(x0, x1, weight, bias_f, a, b, mean, invstd, u)
+                return y
+            elif spec.bn_train:
                 stats = ops.new_stats(co, dev)
                 _conv_forward(spec, x0, x1, wp, None, bias_f, ACT_NONE, stats=stats)
                 y0 = _out_shape(spec, x0)
@@ -198,25 +214,27 @@ class ConvBnAct(torch.autograd.Function):
             y = _conv_forward(spec, x0, x1, wp, None, bias_f, spec.act)
         ctx.spec, ctx.wp = spec, wp
         ctx.has = (x1 is not None, bias is not None)
-        ctx.save_for_backward(x0, x1, weight, bias_f, a, b, mean, invstd)
+        ctx.save_for_backward(x0, x1, weight, bias_f, a, b, mean, invstd, None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         spec, wp = ctx.spec, ctx.wp
-        x0, x1, weight, bias_f, a, b, mean, invstd = ctx.saved_tensors
+        x0, x1, weight, bias_f, a, b, mean, invstd, u_saved = ctx.saved_tensors
         co = spec.cout
         need = ctx.needs_input_grad          # (spec, wp, x0, x1, weight, bias, gamma, beta)
         with torch.no_grad():
             dy = _rows_dense(dy)
             dgamma = dbeta = dbias = None
             if spec.bn is not None or spec.act != ACT_NONE:
-                u = _conv_forward(spec, x0, x1, wp, None, bias_f, ACT_NONE)              # recompute conv + bias
+                # pre-BN value: kept by the forward (train-mode BN) or recomputed (conv + bias)
+                u = u_saved if u_saved is not None else _conv_forward(spec, x0, x1, wp, None, bias_f, ACT_NONE)
                 if spec.bn is None:
                     a = torch.ones(co, dtype=torch.float32, device=dy.device)
                     b = torch.zeros_like(a)
                     mean, invstd = b, a
-                du, dgamma, dbeta = affine_backward(dy, u, a, b, spec.act, mean, invstd, spec.bn is not None and spec.bn_train)
+                du, dgamma, dbeta = affine_backward(dy, u, a, b, spec.act, mean, invstd, spec.bn is not None and spec.bn_train,
+                                                    inplace=u_saved is None)
                 if bias_f is not None:
                     if spec.bn is None:
                         dbias, dgamma, dbeta = dbeta, None, None

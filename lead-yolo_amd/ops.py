@@ -322,6 +322,11 @@ def bn_batch_stats(bn, s1, s2, count):
     return scale.contiguous(), shift.contiguous(), mean, invstd
 
 
+def bnact_fwd(u, ldu, rows, c, a, b, act, y, ldy):
+    with _Timed("ly_bnact_fwd_kernel", 4.0 * rows * c, 8.0 * rows * c):
+        capi.check(capi.lib().ly_bnact_fwd(_p(u), ldu, rows, c, _p(a), _p(b), act, _p(y), ldy, capi.stream_ptr()), "ly_bnact_fwd")
+
+
 def bnact_bwd_reduce(dy, lddy, u, ldu, rows, c, a, b, act):
     sums = new_stats(c, u.device)
     with _Timed("ly_bnact_bwd_reduce_kernel", 6.0 * rows * c, 8.0 * rows * c):

@@ -278,20 +278,24 @@ __global__ __launch_bounds__(LY_THREADS) void ly_wgrad_kernel(const LyWgradParam
 // -------------------------------------------------------------------------------------------------
 // Tiled weight gradient (the fast path: N, Cin, lddu, ldx multiples of 4, NHWC input).
 // Block = BN x BK output tile, 4 waves as 2 x 2, wave tile (BN/2) x (BK/2) = 64 accumulator registers.
-// Per step of 32 pixels the block stages the [32 px][BN] slab of du and the gathered [32 px][BK] slab of x ONCE:
+// Per step of P pixels (32, or 64 for skinny outputs) the block stages the [P px][BN] slab of du and the gathered [P px][BK]
+// slab of x ONCE:
 // a thread owns one channel quad x one group of 8 consecutive pixels, i.e. 8 coalesced float4 row loads (a wave reads
 // 512 contiguous bytes per pixel row), transposes them in registers and writes, per channel, the 8 pixels as ONE
-// 16-byte bf16 vector into the hi / lo planes  plane[channel][32 px]  (row = 64 B).  An MFMA fragment (lane (i, q):
+// 16-byte bf16 vector into the hi / lo planes  plane[channel][P px].  An MFMA fragment (lane (i, q):
 // channel i, pixels 8q..8q+7) is then a single conflict-free ds_read_b128, for both operands.  Global loads of step
 // s+1 are in flight while step s is contracted (register prefetch, two LDS buffers, one barrier per step).
 // Re-reads drop from (N/64 + K/64) to (N/BN + K/BK) passes over the two tensors.
 // -------------------------------------------------------------------------------------------------
-template <int BN, int BK, bool ROWS>
-__global__ __launch_bounds__(LY_THREADS) void ly_wgrad_tiled_kernel(const LyWgradParams P, const int tiles_k, const long chunk_px) {
-  constexpr int TASKS = BN + BK;                        // (BN/4 + BK/4) quads x 4 pixel groups
+template <int BN, int BK, int P, bool ROWS>
+__global__ __launch_bounds__(LY_THREADS) void ly_wgrad_tiled_kernel(const LyWgradParams P_, const int tiles_k, const long chunk_px) {
+  const LyWgradParams& Q = P_;
+  constexpr int PG = P / 8;                             // 8-pixel groups per step
+  constexpr int TASKS = (BN / 4 + BK / 4) * PG;         // (channel quad, pixel group) pairs per step
   constexpr int TPT = (TASKS + LY_THREADS - 1) / LY_THREADS;
   constexpr int NI = BN / 32, NJ = BK / 32;             // MFMA tiles per wave along n / k
-  constexpr int BUF = (BN + BK) * 64 * 2;               // bytes per buffer: (BN + BK) rows x 64 B x 2 planes
+  constexpr int RSW = 4 * P + 16;                       // bytes per LDS row: [hi P bf16 | lo P bf16] + pad (bank spread)
+  constexpr int BUF = (BN + BK) * RSW;
   extern __shared__ f32x4 ly_smem4[];
   char* const lds = reinterpret_cast<char*>(ly_smem4);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -300,8 +304,8 @@ __global__ __launch_bounds__(LY_THREADS) void ly_wgrad_tiled_kernel(const LyWgra
   const int tk = blockIdx.x % tiles_k, tn = blockIdx.x / tiles_k;
   const int n0 = tn * BN, k0 = tk * BK;
   const long p_begin = (long)blockIdx.y * chunk_px;
-  const long p_end = p_begin + chunk_px < P.M ? p_begin + chunk_px : P.M;
-  const int Ktot = P.ks * P.ks * P.Cin;
+  const long p_end = p_begin + chunk_px < Q.M ? p_begin + chunk_px : Q.M;
+  const int Ktot = Q.ks * Q.ks * Q.Cin;
 
   // ---- per-task constants ---------------------------------------------------------------------
   bool t_isA[TPT], t_ok[TPT];
@@ -310,29 +314,29 @@ __global__ __launch_bounds__(LY_THREADS) void ly_wgrad_tiled_kernel(const LyWgra
   for (int u = 0; u < TPT; ++u) {
     const int t = tid + u * LY_THREADS;
     const bool live = t < TASKS;
-    t_isA[u] = t < BN;
-    const int tt = t_isA[u] ? t : t - BN;
+    t_isA[u] = t < (BN / 4) * PG;
+    const int tt = t_isA[u] ? t : t - (BN / 4) * PG;
     const int quads = t_isA[u] ? BN / 4 : BK / 4;
     const int cq = tt % quads;
-    t_g[u] = (tt / quads) & 3;
+    t_g[u] = (tt / quads) % PG;
     t_row[u] = (t_isA[u] ? 0 : BN) + 4 * cq;            // first of the 4 LDS rows this task writes
     if (t_isA[u]) {
       t_c[u] = n0 + 4 * cq;
-      t_ok[u] = live && t_c[u] < P.N;
+      t_ok[u] = live && t_c[u] < Q.N;
       t_ky[u] = t_kx[u] = 0;
     } else {
       const int col = k0 + 4 * cq;
       t_ok[u] = live && col < Ktot;
       const int cc = t_ok[u] ? col : 0;
-      const int tap = cc / P.Cin;
-      t_c[u] = cc - tap * P.Cin;
-      t_ky[u] = tap / P.ks;
-      t_kx[u] = tap - t_ky[u] * P.ks;
+      const int tap = cc / Q.Cin;
+      t_c[u] = cc - tap * Q.Cin;
+      t_ky[u] = tap / Q.ks;
+      t_kx[u] = tap - t_ky[u] * Q.ks;
     }
     if (!live) t_row[u] = -1;
   }
-  const int Hv = P.up2 ? 2 * P.Hin : P.Hin, Wv = P.up2 ? 2 * P.Win : P.Win;
-  const float invW = 1.f / (float)P.W, invH = 1.f / (float)P.H;
+  const int Hv = Q.up2 ? 2 * Q.Hin : Q.Hin, Wv = Q.up2 ? 2 * Q.Win : Q.Win;
+  const float invW = 1.f / (float)Q.W, invH = 1.f / (float)Q.H;
 
   f32x4 pre[TPT][8];
   auto prefetch = [&](long p0) {
@@ -341,11 +345,11 @@ __global__ __launch_bounds__(LY_THREADS) void ly_wgrad_tiled_kernel(const LyWgra
       const long pf = p0 + 8 * t_g[u];
       int n_i = 0, ho = 0, wo = 0;
       if (!ROWS && !t_isA[u]) {
-        const int g = (int)(pf < P.M ? pf : P.M - 1);
-        const int row = ly_fdiv(g, P.W, invW);
-        wo = g - row * P.W;
-        n_i = ly_fdiv(row, P.H, invH);
-        ho = row - n_i * P.H;
+        const int g = (int)(pf < Q.M ? pf : Q.M - 1);
+        const int row = ly_fdiv(g, Q.W, invW);
+        wo = g - row * Q.W;
+        n_i = ly_fdiv(row, Q.H, invH);
+        ho = row - n_i * Q.H;
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -353,15 +357,15 @@ __global__ __launch_bounds__(LY_THREADS) void ly_wgrad_tiled_kernel(const LyWgra
         bool ok = t_ok[u] && p < p_end;
         const float* src;
         if (t_isA[u]) {
-          src = P.du + (ok ? p : p_begin) * P.lddu + t_c[u];
+          src = Q.du + (ok ? p : p_begin) * Q.lddu + t_c[u];
         } else if (ROWS) {
-          src = P.x + (ok ? p : p_begin) * P.ldx + t_c[u];
+          src = Q.x + (ok ? p : p_begin) * Q.ldx + t_c[u];
         } else {
-          int hi = ho * P.stride + t_ky[u] - P.pad, wi = wo * P.stride + t_kx[u] - P.pad;
+          int hi = ho * Q.stride + t_ky[u] - Q.pad, wi = wo * Q.stride + t_kx[u] - Q.pad;
           ok = ok && hi >= 0 && hi < Hv && wi >= 0 && wi < Wv;
-          if (P.up2) { hi >>= 1; wi >>= 1; }
-          src = P.x + (ok ? (((long)n_i * P.Hin + hi) * P.Win + wi) * P.ldx : 0) + t_c[u];
-          if (++wo == P.W) { wo = 0; if (++ho == P.H) { ho = 0; ++n_i; } }
+          if (Q.up2) { hi >>= 1; wi >>= 1; }
+          src = Q.x + (ok ? (((long)n_i * Q.Hin + hi) * Q.Win + wi) * Q.ldx : 0) + t_c[u];
+          if (++wo == Q.W) { wo = 0; if (++ho == Q.H) { ho = 0; ++n_i; } }
         }
         const f32x4 v = ly_ldg4(src);
         pre[u][j] = ok ? v : ly_zero4();
@@ -378,9 +382,9 @@ __global__ __launch_bounds__(LY_THREADS) void ly_wgrad_tiled_kernel(const LyWgra
         const float v[8] = {pre[u][0][e], pre[u][1][e], pre[u][2][e], pre[u][3][e], pre[u][4][e], pre[u][5][e], pre[u][6][e], pre[u][7][e]};
         bf16x8 hi, lo;
         ly_split8(v, hi, lo);
-        char* d = base + (t_row[u] + e) * 128 + t_g[u] * 16;       // row = [hi 64 B | lo 64 B]
+        char* d = base + (t_row[u] + e) * RSW + t_g[u] * 16;
         *reinterpret_cast<bf16x8*>(d) = hi;
-        *reinterpret_cast<bf16x8*>(d + 64) = lo;
+        *reinterpret_cast<bf16x8*>(d + 2 * P) = lo;
       }
     }
   };
@@ -396,24 +400,27 @@ __global__ __launch_bounds__(LY_THREADS) void ly_wgrad_tiled_kernel(const LyWgra
   commit(0);
   __syncthreads();
   int buf = 0;
-  for (long p0 = p_begin; p0 < p_end; p0 += 32) {
-    const bool more = p0 + 32 < p_end;
-    if (more) prefetch(p0 + 32);
+  for (long p0 = p_begin; p0 < p_end; p0 += P) {
+    const bool more = p0 + P < p_end;
+    if (more) prefetch(p0 + P);
     const char* base = lds + buf * BUF;
-    bf16x8 ah[NI], al[NI];
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const char* r = base + (wn + 16 * i + li) * 128 + lq * 16;
-      ah[i] = *reinterpret_cast<const bf16x8*>(r);
-      al[i] = *reinterpret_cast<const bf16x8*>(r + 64);
-    }
+    for (int ks = 0; ks < P / 32; ++ks) {
+      bf16x8 ah[NI], al[NI];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const char* r = base + (wk + 16 * j + li) * 128 + lq * 16;
-      const bf16x8 bh = *reinterpret_cast<const bf16x8*>(r);
-      const bf16x8 bl = *reinterpret_cast<const bf16x8*>(r + 64);
+      for (int i = 0; i < NI; ++i) {
+        const char* r = base + (wn + 16 * i + li) * RSW + ks * 64 + lq * 16;
+        ah[i] = *reinterpret_cast<const bf16x8*>(r);
+        al[i] = *reinterpret_cast<const bf16x8*>(r + 2 * P);
+      }
 #pragma unroll
-      for (int i = 0; i < NI; ++i) acc[i][j] = ly_mfma3(ah[i], al[i], bh, bl, acc[i][j]);
+      for (int j = 0; j < NJ; ++j) {
+        const char* r = base + (wk + 16 * j + li) * RSW + ks * 64 + lq * 16;
+        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(r);
+        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(r + 2 * P);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) acc[i][j] = ly_mfma3(ah[i], al[i], bh, bl, acc[i][j]);
+      }
     }
     if (more) commit(buf ^ 1);
     __syncthreads();
@@ -429,34 +436,34 @@ __global__ __launch_bounds__(LY_THREADS) void ly_wgrad_tiled_kernel(const LyWgra
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = n0 + wn + 16 * i + 4 * lq + r;
-        if (row < P.N) atomicAdd(P.dw + (long)row * P.lddw + col, acc[i][j][r]);
+        if (row < Q.N) atomicAdd(Q.dw + (long)row * Q.lddw + col, acc[i][j][r]);
       }
     }
 }
 
-template <int BN, int BK>
-static int launch_wgrad_tiled(const LyWgradParams& P, bool rows, hipStream_t st) {
-  const int Ktot = P.ks * P.ks * P.Cin;
-  const int tiles_n = (P.N + BN - 1) / BN, tiles_k = (Ktot + BK - 1) / BK;
+template <int BN, int BK, int P>
+static int launch_wgrad_tiled(const LyWgradParams& Q, bool rows, hipStream_t st) {
+  const int Ktot = Q.ks * Q.ks * Q.Cin;
+  const int tiles_n = (Q.N + BN - 1) / BN, tiles_k = (Ktot + BK - 1) / BK;
   const long tiles = (long)tiles_n * tiles_k;
   long chunks = (1024 + tiles - 1) / tiles;
-  const long max_chunks = (P.M + 511) / 512;
+  const long max_chunks = (Q.M + 511) / 512;
   if (chunks > max_chunks) chunks = max_chunks;
   if (chunks < 1) chunks = 1;
-  long chunk_px = (P.M + chunks - 1) / chunks;
-  chunk_px = (chunk_px + 31) / 32 * 32;
-  chunks = (P.M + chunk_px - 1) / chunk_px;
+  long chunk_px = (Q.M + chunks - 1) / chunks;
+  chunk_px = (chunk_px + P - 1) / P * P;
+  chunks = (Q.M + chunk_px - 1) / chunk_px;
   LY_CHECK(chunks < 65536, "wgrad: too many pixel chunks");
-  const size_t lds = 2 * (size_t)(BN + BK) * 128;
+  const size_t lds = 2 * (size_t)(BN + BK) * (4 * P + 16);
   const dim3 grid((unsigned)tiles, (unsigned)chunks);
   if (rows) {
     static bool attr = false;
-    if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&ly_wgrad_tiled_kernel<BN, BK, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-    hipLaunchKernelGGL((ly_wgrad_tiled_kernel<BN, BK, true>), grid, dim3(LY_THREADS), lds, st, P, tiles_k, chunk_px);
+    if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&ly_wgrad_tiled_kernel<BN, BK, P, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    hipLaunchKernelGGL((ly_wgrad_tiled_kernel<BN, BK, P, true>), grid, dim3(LY_THREADS), lds, st, Q, tiles_k, chunk_px);
   } else {
     static bool attr = false;
-    if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&ly_wgrad_tiled_kernel<BN, BK, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-    hipLaunchKernelGGL((ly_wgrad_tiled_kernel<BN, BK, false>), grid, dim3(LY_THREADS), lds, st, P, tiles_k, chunk_px);
+    if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&ly_wgrad_tiled_kernel<BN, BK, P, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    hipLaunchKernelGGL((ly_wgrad_tiled_kernel<BN, BK, P, false>), grid, dim3(LY_THREADS), lds, st, Q, tiles_k, chunk_px);
   }
   LY_LAUNCH_CHECK();
   return 0;
@@ -475,8 +482,11 @@ extern "C" int ly_wgrad(const LyWgradParams* p, void* stream) {
   if (rows) LY_CHECK(P.Hin == P.H && P.Win == P.W, "wgrad: 1x1 gather needs Hin == H, Win == W");
   if (!P.nchw && (P.N & 3) == 0 && (P.Cin & 3) == 0 && (P.lddu & 3) == 0 && (P.ldx & 3) == 0 && ((uintptr_t)P.du & 15) == 0 && ((uintptr_t)P.x & 15) == 0) {
     hipStream_t st2 = reinterpret_cast<hipStream_t>(stream);
-    if (P.N <= 64) return launch_wgrad_tiled<64, 256>(P, rows, st2);
-    return launch_wgrad_tiled<128, 128>(P, rows, st2);
+    // skinny outputs (MLP blocks, patch layers at high resolution): few channel quads per pixel, so a step covers 64 pixels
+    // to keep every thread loading; otherwise 32 pixels per step and wider channel tiles
+    if (P.N <= 64 && Ktot <= 64) return launch_wgrad_tiled<64, 64, 64>(P, rows, st2);
+    if (P.N <= 64) return launch_wgrad_tiled<64, 256, 32>(P, rows, st2);
+    return launch_wgrad_tiled<128, 128, 32>(P, rows, st2);
   }
   const int tiles_n = (P.N + 63) / 64, tiles_k = (Ktot + 63) / 64;
   const long tiles = (long)tiles_n * tiles_k;

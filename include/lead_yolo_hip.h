@@ -275,6 +275,21 @@ int ly_bn_bwd_coeffs(const float* sums, int stripes, int N, double count, const 
  * [T][S][2 planes][64 lanes][8] bf16 layout the contraction kernels read (csrc/ly_tile.cuh).                          */
 int ly_frag_pack3(const float* w, int R, int K, long ld_r, long ld_k, int rows_to, void* out, void* stream);
 
+/* ---- detection loss on device (utils/loss.py:121-268 ComputeLoss / build_targets, utils/metrics.py:293-354 EIoU) --------
+ * One pyramid level, forward and gradient (nc == 1, no focal loss): anchor matching with the reference's candidate order
+ * (offset k, anchor a, target t), EIoU box loss with analytic gradient, per-cell "last writer wins" objectness target (the
+ * highest candidate index, i.e. the reference's sequential CPU semantics), BCE objectness.
+ *   p / dp   [bs][na][ny][nx][no] predictions / their gradient (dp zeroed by the caller; d(total loss)/dp on return)
+ *   anchors  [na][2] in grid units (Detect.anchors[i]);  targets [nt][6] = (image, class, x, y, w, h) normalised
+ *   tobj [cells] zeroed, winner [cells] filled with -1, cand_cell [5*na*nt], cand [5*na*nt][5] workspaces
+ *   acc [4] zeroed: sum(1 - eiou), matches, sum of objectness BCE, unused  -> ly_loss_finish                              */
+int ly_loss_level(const float* p, float* dp, const float* anchors, const float* targets, int bs, int na, int ny, int nx, int no, long nt,
+                  float anchor_t, float box_gain, float obj_gain, float balance, float* tobj, int* winner, long* cand_cell, float* cand,
+                  float* acc, void* stream);
+/* out[0] = (lbox + lobj) * bs, out[1] = lbox, out[2] = lobj, out[3] = lcls = 0 from acc [nl][4]; cells / balance: [nl] floats     */
+int ly_loss_finish(const float* acc, int nl, const float* cells, const float* balance, float box_gain, float obj_gain, int bs, float* out,
+                   void* stream);
+
 #ifdef __cplusplus
 }
 #endif

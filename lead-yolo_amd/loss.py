@@ -97,6 +97,8 @@ class ComputeLoss:
     def __call__(self, p, targets):
         dev = p[0].device
         targets = targets.to(dev)
+        if dev.type == "cuda" and self.nc == 1 and all(t.dtype == torch.float32 for t in p):
+            return _fused_loss(self, list(p), targets.float().contiguous())
         k = self._consts(dev)
         lcls = torch.zeros(1, device=dev)
         lbox = torch.zeros(1, device=dev)
@@ -127,3 +129,58 @@ class ComputeLoss:
         lcls = lcls * self.hyp["cls"]
         bs = p[0].shape[0]
         return (lbox + lobj + lcls) * bs, torch.cat((lbox, lobj, lcls)).detach()
+
+
+# --------------------------------------------------------------------------------------------------
+# Fused device path (csrc/ly_loss.hip): 3 launches per level for the forward AND the gradient, no host sync.
+# The torch formulation above stays as the definition (CPU, nc > 1) and as the API for inspecting `build_targets`.
+# --------------------------------------------------------------------------------------------------
+class _FusedLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cl, targets, *preds):
+        from . import capi
+        dev = preds[0].device
+        nl, na = len(preds), cl.na
+        nt = targets.shape[0]
+        bs = preds[0].shape[0]
+        cells = [int(p.shape[0] * p.shape[1] * p.shape[2] * p.shape[3]) for p in preds]
+        k = cl._consts(dev)
+        if "cells" not in k or k["cells_key"] != tuple(cells):
+            k["cells"] = torch.tensor([float(c) for c in cells], device=dev)
+            k["balance_t"] = torch.tensor([float(b) for b in cl.balance[:nl]], device=dev)
+            k["cells_key"] = tuple(cells)
+        zero = torch.zeros(sum(cells) + 4 * nl, dtype=torch.float32, device=dev)          # tobj of every level + accumulators
+        winner = torch.full((sum(cells),), -1, dtype=torch.int32, device=dev)
+        ncand = 5 * na * nt
+        cand_cell = torch.empty((nl, max(ncand, 1)), dtype=torch.int64, device=dev)
+        cand = torch.empty((nl, max(ncand, 1), 5), dtype=torch.float32, device=dev)
+        acc = zero[sum(cells):].view(nl, 4)
+        out = torch.empty(4, dtype=torch.float32, device=dev)
+        dps, off = [], 0
+        st = capi.stream_ptr()
+        for i, p in enumerate(preds):
+            p = p.contiguous()
+            dp = torch.zeros_like(p)
+            anchors = cl.anchors[i].to(dev).float().contiguous()
+            _, _, ny, nx, no = p.shape
+            capi.check(capi.lib().ly_loss_level(capi.ptr(p), capi.ptr(dp), capi.ptr(anchors), capi.ptr(targets), bs, na, ny, nx, no, nt,
+                                                float(cl.hyp["anchor_t"]), float(cl.hyp["box"]), float(cl.hyp["obj"]), float(cl.balance[i]),
+                                                capi.ptr(zero[off:off + cells[i]]), capi.ptr(winner[off:off + cells[i]]), capi.ptr(cand_cell[i]),
+                                                capi.ptr(cand[i]), capi.ptr(acc[i]), st), "ly_loss_level")
+            dps.append(dp)
+            off += cells[i]
+        capi.check(capi.lib().ly_loss_finish(capi.ptr(acc), nl, capi.ptr(k["cells"]), capi.ptr(k["balance_t"]), float(cl.hyp["box"]),
+                                             float(cl.hyp["obj"]), bs, capi.ptr(out), st), "ly_loss_finish")
+        ctx.save_for_backward(*dps)
+        ctx.mark_non_differentiable(out)
+        return out[:1].clone(), out
+    @staticmethod
+    def backward(ctx, g_loss, _g_items):
+        return (None, None) + tuple(dp * g_loss for dp in ctx.saved_tensors)
+
+
+def _fused_loss(cl, preds, targets):
+    if cl.hyp["fl_gamma"] > 0 or cl.hyp["obj_pw"] != 1.0 or cl.gr != 1.0 or cl.sort_obj_iou:
+        raise NotImplementedError("fused loss: focal loss / positive weights / gr != 1 are not built")
+    loss, out = _FusedLossFn.apply(cl, targets, *preds)
+    return loss, out[1:4].detach()

@@ -1,6 +1,7 @@
 """Product loss / target assignment (lead_yolo_amd.loss) vs the vectors the reference produced:
-int64 indices bit-exact, loss and input gradients to fp32 rounding.  Device-agnostic host logic: runs
-on CPU here and on the GPU in the -m gpu variant."""
+int64 indices bit-exact, loss and input gradients to fp32 rounding.  On the CPU the torch formulation runs; on the GPU
+`ComputeLoss.__call__` is the fused device loss (csrc/ly_loss.hip: forward and gradient in 3 launches per level), while
+`build_targets` (the inspectable index API) is the same host logic on both."""
 import numpy as np
 import pytest
 import torch
@@ -32,14 +33,10 @@ def _run(case, device):
     loss.backward()
     for i in range(3):
         got, want = preds[i].grad.cpu().numpy(), arr[f"{case}_dpred{i}"]
-        if device.type == "cpu":
-            np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-6)
-        else:
-            # `tobj[b, a, gj, gi] = iou` has duplicate cells (several targets per cell); on a GPU the winner of the
-            # scatter is unordered (as in the reference itself on CUDA), which can move the objectness gradient of
-            # those few cells
-            bad = np.abs(got - want) > 1e-6 + 1e-4 * np.abs(want)
-            assert bad.mean() < 1e-3 and np.abs(got - want).max() < 5e-3, (bad.sum(), np.abs(got - want).max())
+        # `tobj[b, a, gj, gi] = iou` has duplicate cells (several targets per cell).  The reference's vectors come from the CPU,
+        # where the last assignment wins; the fused device loss (csrc/ly_loss.hip) elects the same winner (highest candidate
+        # index), so the GPU result matches cell for cell — unlike torch's unordered scatter on a GPU.
+        np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-6)
 
 
 @pytest.mark.parametrize("case", ["rand", "edge", "empty"])

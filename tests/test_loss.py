@@ -48,3 +48,35 @@ def test_loss_cpu(case):
 @pytest.mark.parametrize("case", ["rand", "edge", "empty"])
 def test_loss_gpu(case):
     _run(case, torch.device("cuda:0"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bs,nt,seed", [(8, 200, 0), (4, 1, 1), (16, 900, 2)])
+def test_fused_loss_vs_torch_formulation(bs, nt, seed):
+    """the device loss against the torch formulation run on the CPU (sequential scatter = the reference's semantics) on random
+    predictions with many targets per cell: total, items and the gradient of every prediction"""
+    from lead_yolo_amd.loss import ComputeLoss
+    _, arr = G.load("loss_n")
+    anchors = G.t(arr["anchors"])
+    g = torch.Generator().manual_seed(seed)
+    preds = [torch.randn(bs, 3, s, s, 6, generator=g) for s in (40, 20, 10)]
+    tg = torch.cat((torch.randint(0, bs, (nt, 1), generator=g).float(), torch.zeros(nt, 1), torch.rand(nt, 2, generator=g),
+                    torch.rand(nt, 2, generator=g) * 0.4 + 0.01), 1)
+    res = []
+    nthreads = torch.get_num_threads()
+    for dev in (torch.device("cpu"), torch.device("cuda:0")):
+        cl = ComputeLoss(_Det(anchors.to(dev)))
+        ps = [p.clone().to(dev).requires_grad_(True) for p in preds]
+        # torch's CPU index_put splits more than 3000 indices over threads; one thread keeps `tobj[...] = iou` sequential
+        torch.set_num_threads(1)
+        try:
+            loss, items = cl(ps, tg.to(dev))
+            loss.backward()
+        finally:
+            torch.set_num_threads(nthreads)
+        res.append((loss.detach().cpu(), items.cpu(), [p.grad.cpu() for p in ps]))
+    (l0, i0, g0), (l1, i1, g1) = res
+    np.testing.assert_allclose(l1.numpy(), l0.numpy(), rtol=1e-4)
+    np.testing.assert_allclose(i1.numpy(), i0.numpy(), rtol=1e-4, atol=1e-6)
+    for a, b in zip(g1, g0):
+        np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=5e-4, atol=2e-6)

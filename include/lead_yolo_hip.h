@@ -28,9 +28,10 @@ const char* ly_last_error(void);
  * Built for C in {16,24,40,80,160,320}. */
 int ly_mlpblock_fwd(const float* x, float* y, int n_img, int H, int W, int C, const void* wp, const void* w1,
                     const void* w2, const float* bn_scale, const float* bn_shift, float* stats, void* stream);
-/* ablation aid for profiling (bit 0: skip pconv, 1: skip MLP contractions, 2: skip halo staging, 3: skip stores) */
+/* ablation aid for profiling (4: skip halo staging, 8: skip stores) */
 int ly_debug_set_mlp(int v);
-/* tuning aid: 1 forces the flattened-run tiling (default: 8x16 patches where W % 16 == 0 and W >= 64) */
+/* tuning aid: 1 forces the flattened-run tiling (default: 8x16 patches where W % 16 == 0 and W >= 64);
+ * 2 / 4 / 8 force flattened runs with 2 / 4 / 1 pixel tiles per wave where built */
 int ly_debug_set_mlp_tile(int v);
 /* hidden (2C) channel tiles of 16, padded to an even count */
 int ly_mlpblock_hidden_tiles(int C);

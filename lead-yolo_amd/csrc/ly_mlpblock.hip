@@ -35,8 +35,15 @@ struct MlpGeom {
   static constexpr int S2 = HTP / 2;                // GEMM2 k-steps
 };
 
-template <int C, int NT, int HT, bool T2D>
-__global__ __launch_bounds__(LY_THREADS) void ly_mlpblock_fwd_kernel(
+// Weight fragments are NOT staged in LDS (the three packed arrays of one block are up to 470 KB); every wave streams them from
+// L2 in the fixed order it consumes them.  Left to the compiler each 2 KB fragment is loaded and waited for right before its
+// three MFMAs (vmcnt(0) after every pair of loads: ~0.3 us of exposed L2 latency per fragment, 236 fragments at C=160), so the
+// stream is software-pipelined by hand: a ring of D fragments is kept in flight, slot g % D is refilled with fragment g + D
+// as soon as fragment g's MFMAs are issued.  All loops are fully unrolled, so g and the slot index are compile-time constants.
+// D = 0: no ring (loads where they are used; fewer registers, more co-resident waves -- the better trade for the narrow,
+// memory-heavy stages).
+template <int C, int NT, int HT, bool T2D, bool STATS, int D>
+__device__ __forceinline__ void ly_mlpblock_body(
     const float* __restrict__ x, float* __restrict__ y, long M, int H, int W,
     const uint4* __restrict__ wp, const uint4* __restrict__ w1, const uint4* __restrict__ w2,
     const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, float* __restrict__ stats, const int dbg) {
@@ -64,6 +71,34 @@ __global__ __launch_bounds__(LY_THREADS) void ly_mlpblock_fwd_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lq = lane >> 4;
   const f32x4 zero = ly_zero4();
+
+  // the fragment stream: partial conv (k-step major), then per hidden chunk GEMM1 (k-step major) and, unless this is the
+  // statistics pass, GEMM2 (hidden pair major)
+  constexpr int FP = SP * PT, F1 = S1 * HT, F2 = STATS ? 0 : (HT / 2) * C16, FQ = F1 + F2, NFRAG = FP + (HTP / HT) * FQ;
+  auto wseq = [&](int g) -> LyWFrag {
+    if (g < FP) return ly_wfrag(wp, (g % PT) * SP + g / PT, lane);
+    g -= FP;
+    const int chunk = g / FQ, r = g - chunk * FQ;
+    if (r < F1) return ly_wfrag(w1, (chunk * HT + r % HT) * S1 + r / HT, lane);
+    const int r2 = r - F1;
+    return ly_wfrag(w2, (r2 % C16) * S2 + chunk * (HT / 2) + r2 / C16, lane);
+  };
+  LyWFrag ring[D > 0 ? D : 1];
+#pragma unroll
+  for (int g = 0; g < D; ++g)
+    if (g < NFRAG) ring[g] = wseq(g);
+  int g = 0;                   // fragments consumed so far (a constant at every use after unrolling)
+  auto wnext = [&]() -> LyWFrag {
+    if constexpr (D == 0) return wseq(g);
+    else return ring[g % D];
+  };
+  auto wrefill = [&]() {
+    if constexpr (D > 0) {
+      if (g + D < NFRAG) ring[g % D] = wseq(g + D);
+      __builtin_amdgcn_sched_barrier(0x786);   // neither loads nor MFMAs may move across: the refills stay D fragments ahead
+    }
+    ++g;
+  };
   if (C >= 80) {     // large weight sets, few pixels: warm L2 with all three packed weight arrays
     float* const sink = stats ? stats : y;
     ly_l2_warm(w1, (long)HTP * S1 * 2048, sink);
@@ -127,7 +162,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_mlpblock_fwd_kernel(
   const bf16x4 z4 = __builtin_bit_cast(bf16x4, make_uint2(0u, 0u));
 
   // ---- 1. partial 3x3 conv -------------------------------------------------------------------
-  if (!(dbg & 1)) {
+  {
     uint32_t tmask[NT];
     int pbase[NT];             // byte offset of the (ty=0, tx=0) tap of this lane's pixel in the halo image
 #pragma unroll
@@ -182,9 +217,10 @@ __global__ __launch_bounds__(LY_THREADS) void ly_mlpblock_fwd_kernel(
       }
 #pragma unroll
       for (int t = 0; t < PT; ++t) {
-        const LyWFrag wf = ly_wfrag(wp, t * SP + s, lane);
+        const LyWFrag wf = wnext();
 #pragma unroll
         for (int n = 0; n < NT; ++n) accp[t][n] = ly_mfma3(wf.hi, wf.lo, xh[n], xl[n], accp[t][n]);
+        wrefill();
       }
     }
 #pragma unroll
@@ -214,7 +250,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_mlpblock_fwd_kernel(
     for (int n = 0; n < NT; ++n) acco[t][n] = zero;
 
 #pragma unroll
-  for (int hc = 0; hc < ((dbg & 2) ? 0 : HTP / HT); ++hc) {
+  for (int hc = 0; hc < HTP / HT; ++hc) {
     f32x4 acch[HT][NT];
 #pragma unroll
     for (int t = 0; t < HT; ++t)
@@ -231,12 +267,13 @@ __global__ __launch_bounds__(LY_THREADS) void ly_mlpblock_fwd_kernel(
       }
 #pragma unroll
       for (int t = 0; t < HT; ++t) {
-        const LyWFrag wf = ly_wfrag(w1, (hc * HT + t) * S1 + s, lane);
+        const LyWFrag wf = wnext();
 #pragma unroll
         for (int n = 0; n < NT; ++n) acch[t][n] = ly_mfma3(wf.hi, wf.lo, xh[n], xl[n], acch[t][n]);
+        wrefill();
       }
     }
-    if (stats) {
+    if (STATS) {
       // statistics pass of train-mode BatchNorm: sum / sum of squares of the pre-BN hidden activations
       // over the valid pixels of this block; nothing else is computed or stored
 #pragma unroll
@@ -275,14 +312,15 @@ __global__ __launch_bounds__(LY_THREADS) void ly_mlpblock_fwd_kernel(
       }
 #pragma unroll
       for (int ct = 0; ct < C16; ++ct) {
-        const LyWFrag wf = ly_wfrag(w2, ct * S2 + hc * (HT / 2) + u, lane);
+        const LyWFrag wf = wnext();
 #pragma unroll
         for (int n = 0; n < NT; ++n) acco[ct][n] = ly_mfma3(wf.hi, wf.lo, xh[n], xl[n], acco[ct][n]);
+        wrefill();
       }
     }
   }
 
-  if (stats) return;
+  if (STATS) return;
   // ---- epilogue: residual + store ------------------------------------------------------------
   // The residual x is rebuilt from the bf16 hi/lo planes already in LDS (|err| <= 2^-17 |x|) instead
   // of re-reading global memory: channels < CQP from the halo image's centre tap (the tile's own
@@ -311,20 +349,38 @@ __global__ __launch_bounds__(LY_THREADS) void ly_mlpblock_fwd_kernel(
     }
 }
 
-static int g_mlp_tile = 0;  // tuning aid: 1 = force the flattened-run tiling
+template <int C, int NT, int HT, bool T2D, bool STATS>
+__global__ __launch_bounds__(LY_THREADS) void ly_mlpblock_fwd_kernel(
+    const float* __restrict__ x, float* __restrict__ y, long M, int H, int W,
+    const uint4* __restrict__ wp, const uint4* __restrict__ w1, const uint4* __restrict__ w2,
+    const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, float* __restrict__ stats, const int dbg) {
+  ly_mlpblock_body<C, NT, HT, T2D, STATS, 0>(x, y, M, H, W, wp, w1, w2, bn_scale, bn_shift, stats, dbg);
+}
+
+template <int C, int NT, int HT, bool T2D, bool STATS>
+__global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2))) void ly_mlpblock_fwd_ring_kernel(
+    const float* __restrict__ x, float* __restrict__ y, long M, int H, int W,
+    const uint4* __restrict__ wp, const uint4* __restrict__ w1, const uint4* __restrict__ w2,
+    const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, float* __restrict__ stats, const int dbg) {
+  ly_mlpblock_body<C, NT, HT, T2D, STATS, 8>(x, y, M, H, W, wp, w1, w2, bn_scale, bn_shift, stats, dbg);
+}
+
+static int g_mlp_tile = 0;  // tuning aid: 1 = force the flattened-run tiling, 2 / 4 / 8 = flattened with 2 / 4 / 1 pixel tiles per wave
 extern "C" int ly_debug_set_mlp_tile(int v) { g_mlp_tile = v; return 0; }
-static int g_mlp_dbg = 0;   // ablation aid: 1 skip pconv, 2 skip MLP contractions, 4 skip halo staging, 8 skip stores
+static int g_mlp_dbg = 0;   // ablation aid: 4 skip halo staging, 8 skip stores
 extern "C" int ly_debug_set_mlp(int v) { g_mlp_dbg = v; return 0; }
 
-template <int C, int NT, int HT, bool T2D>
-static int launch_mlp(const float* x, float* y, long M, int n_img, int H, int W, const void* wp, const void* w1, const void* w2,
+template <int C, int NT, int HT, bool T2D, bool STATS, bool RING>
+static int launch_mlp_k(const float* x, float* y, long M, int n_img, int H, int W, const void* wp, const void* w1, const void* w2,
                       const float* s, const float* b, float* stats, hipStream_t st) {
   using Gm = MlpGeom<C>;
   constexpr int BP = 64 * NT;
   const long halo = T2D ? (4 * NT + 2) * 18 : BP + 2 * W + 2;
   size_t lds = 2 * ((size_t)BP * Gm::RS + (size_t)halo * Gm::RSP);
   LY_CHECK(lds <= 160 * 1024, "mlpblock: tile needs %zu B of LDS (C=%d W=%d)", lds, C, W);
-  auto k = ly_mlpblock_fwd_kernel<C, NT, HT, T2D>;
+  void (*k)(const float*, float*, long, int, int, const uint4*, const uint4*, const uint4*, const float*, const float*, float*, int);
+  if constexpr (RING) k = ly_mlpblock_fwd_ring_kernel<C, NT, HT, T2D, STATS>;
+  else k = ly_mlpblock_fwd_kernel<C, NT, HT, T2D, STATS>;
   static bool configured = false;
   if (!configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
@@ -338,14 +394,35 @@ static int launch_mlp(const float* x, float* y, long M, int n_img, int H, int W,
   return 0;
 }
 
-// 2-D patches (8 x 16 px per block: small halo, 4+ co-resident blocks per CU) where the map is wide and
-// a multiple of 16; flattened runs otherwise, with as many pixel tiles per wave as still fill the chip
+template <int C, int NT, int HT, bool T2D>
+static int launch_mlp(const float* x, float* y, long M, int n_img, int H, int W, const void* wp, const void* w1, const void* w2,
+                      const float* s, const float* b, float* stats, hipStream_t st) {
+  constexpr bool RING = C >= 80;
+  if (stats) return launch_mlp_k<C, NT, HT, T2D, true, RING>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
+  return launch_mlp_k<C, NT, HT, T2D, false, RING>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
+}
+
+// Tiling policy (tools/mlp_ablate.py, kernel time at bs=32 / 64):
+//  * C < 80 (wide maps, few weights; HBM-heavy): 2-D patches (8 x 16 px per block: small halo, 4+ co-resident blocks per CU)
+//    where the map is wide and a multiple of 16; flattened runs otherwise, with as many pixel tiles per wave as still fill
+//    the chip.  No fragment ring: it costs the co-residency these stages live on (C=24: 64 -> 69 us with it).
+//  * C >= 80 (small maps, 134-470 KB of weights per block; bound by streaming the fragments from L2): ring kernel, and two
+//    pixel tiles per wave -- half the fragment traffic per pixel -- as soon as that still leaves >= 200 blocks
+//    (C=80 @ 40x40x32: 26.5 -> 20.7 us; C=160 @ 20x20: 22.6 us with one tile at bs=32, 38.4 -> 28.8 us with two at bs=64).
 template <int C, int HT, int NTMAX>
 static int dispatch_nt(const float* x, float* y, long M, int n_img, int H, int W, const void* wp, const void* w1, const void* w2,
                        const float* s, const float* b, float* stats, hipStream_t st) {
-  if ((W & 15) == 0 && W >= 64 && NTMAX >= 2 && g_mlp_tile != 1) return launch_mlp<C, 2, HT, true>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
-  if (NTMAX >= 4 && M >= 256L * 1024) return launch_mlp<C, (NTMAX >= 4 ? 4 : NTMAX), HT, false>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
-  if (NTMAX >= 2 && M >= 128L * 512) return launch_mlp<C, (NTMAX >= 2 ? 2 : NTMAX), HT, false>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
+  constexpr int NT2 = NTMAX >= 2 ? 2 : NTMAX, NT4 = NTMAX >= 4 ? 4 : NTMAX;
+  if (g_mlp_tile == 4) return launch_mlp<C, NT4, HT, false>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
+  if (g_mlp_tile == 2) return launch_mlp<C, NT2, HT, false>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
+  if (g_mlp_tile == 8) return launch_mlp<C, 1, HT, false>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
+  if (C >= 80) {
+    if (NTMAX >= 2 && M >= 200L * 128) return launch_mlp<C, NT2, HT, false>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
+    return launch_mlp<C, 1, HT, false>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
+  }
+  if ((W & 15) == 0 && W >= 64 && NTMAX >= 2 && g_mlp_tile == 0) return launch_mlp<C, 2, HT, true>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
+  if (NTMAX >= 4 && M >= 256L * 1024) return launch_mlp<C, NT4, HT, false>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
+  if (NTMAX >= 2 && M >= 128L * 512) return launch_mlp<C, NT2, HT, false>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
   return launch_mlp<C, 1, HT, false>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
 }
 

@@ -82,19 +82,42 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam3_kernel(const LyRfcbam3P
     }
     soff[e] = so; doff[e] = dd;
   }
+  // Everything a chunk reads from global memory is requested one chunk ahead, so no wave ever waits on a load it has just
+  // issued: the raw input tile (pv), the folded generate weights (wv) and the conv weight fragments (ring: D fragments in
+  // flight, slot q % D refilled with fragment q + D -- which may belong to the next chunk -- right after fragment q's MFMAs).
   f32x4 pv[LY_RF3_NV];
   auto prefetch = [&](int c0) {
 #pragma unroll
     for (int e = 0; e < LY_RF3_NV; ++e) pv[e] = ly_ldg4(soff[e] >= 0 ? P.x + soff[e] + c0 : P.x);
   };
+  constexpr int WV = (4 * LY_RF3_WF / 4 + LY_THREADS - 1) / LY_THREADS;
+  f32x4 wv[WV];
+  auto wprefetch = [&](int chunk) {
+    const float* wsrc = P.wg + (long)chunk * (4 * LY_RF3_WF);
+#pragma unroll
+    for (int e = 0; e < WV; ++e) {
+      const int i = tid + e * LY_THREADS;
+      wv[e] = ly_ldg4(wsrc + 4 * (i < 4 * LY_RF3_WF / 4 ? i : 0));
+    }
+  };
+  constexpr int D = 5, NF = (LY_GK / 32) * MT;           // ring depth, fragments per chunk (k-step major); NF % D == 0
+  static_assert(NF % D == 0, "the ring slot of a fragment must not depend on the chunk");
+  LyWFrag ring[D];
+  auto wfrag_at = [&](int sb, int q) -> LyWFrag { return ly_wfrag(wpk, (long)tile[q % MT] * S + sb + q / MT, lane); };
+#pragma unroll
+  for (int q = 0; q < D; ++q) ring[q] = wfrag_at(0, q);
+  wprefetch(0);
   if (!(dbg & 4)) prefetch(0);
 
   for (int c0 = 0; c0 < P.C; c0 += LY_GCC) {
     __syncthreads();                      // previous chunk: generate done with xs/wsm, MFMAs done with gs
-    {
-      const float* wsrc = P.wg + (long)(c0 / LY_GCC) * (4 * LY_RF3_WF);
-      for (int i = tid; i < 4 * LY_RF3_WF / 4; i += LY_THREADS) reinterpret_cast<f32x4*>(wsm)[i] = ly_ldg4(wsrc + 4 * i);
+#pragma unroll
+    for (int e = 0; e < WV; ++e) {
+      const int i = tid + e * LY_THREADS;
+      if (i < 4 * LY_RF3_WF / 4) reinterpret_cast<f32x4*>(wsm)[i] = wv[e];
     }
+    const bool more = c0 + LY_GCC < P.C;
+    wprefetch(more ? c0 / LY_GCC + 1 : 0);
     if (!(dbg & 4)) {
 #pragma unroll
       for (int e = 0; e < LY_RF3_NV; ++e)
@@ -103,7 +126,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam3_kernel(const LyRfcbam3P
           float* d = xs + doff[e];
           d[0] = ok ? pv[e][0] : 0.f; d[1] = ok ? pv[e][1] : 0.f; d[2] = ok ? pv[e][2] : 0.f; d[3] = ok ? pv[e][3] : 0.f;
         }
-      if (c0 + LY_GCC < P.C) prefetch(c0 + LY_GCC);   // next chunk's input in flight during generate + MFMA
+      if (more) prefetch(c0 + LY_GCC);   // next chunk's input in flight during generate + MFMA
     }
     __syncthreads();
     // ---- regenerate G' for channels c0 + 4*wave .. +3 -----------------------------------------------
@@ -154,7 +177,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam3_kernel(const LyRfcbam3P
     // ---- contract the chunk's 160 (144 real) k-values --------------------------------------------
     const int sbase = (c0 / LY_GCC) * (LY_GK / 32);
 #pragma unroll
-    for (int st = 0; st < ((dbg & 2) ? 0 : LY_GK / 32); ++st) {
+    for (int st = 0; st < LY_GK / 32; ++st) {
       bf16x8 xh[4], xl[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -163,9 +186,14 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam3_kernel(const LyRfcbam3P
       }
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
-        const LyWFrag wf = ly_wfrag(wpk, (long)tile[t] * S + sbase + st, lane);
+        const int q = st * MT + t;
+        const LyWFrag wf = ring[q % D];
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[t][j] = ly_mfma3(wf.hi, wf.lo, xh[j], xl[j], acc[t][j]);
+        // (the last chunk re-requests chunk 0's fragments instead of branching: a conditional load would make every later
+        //  s_waitcnt assume it was not issued and wait for the loads behind it as well)
+        ring[q % D] = q + D < NF ? wfrag_at(sbase, q + D) : wfrag_at(more ? sbase + LY_GK / 32 : 0, q + D - NF);
+        __builtin_amdgcn_sched_barrier(0x786);     // neither loads nor MFMAs may move across: the refills stay D fragments ahead
       }
     }
   }
@@ -214,10 +242,14 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam3_kernel(const LyRfcbam3P
   }
 }
 
-static int g_rf3_dbg = 0;   // ablation aid: 1 skip regenerate, 2 skip MFMA, 4 skip staging
-static int g_rf3_mt4 = 0;   // (bit 3 of ly_debug_set_rf3) use the 256-channel MT=4 tile for N > 128: 312 registers, one wave per SIMD —
-                            // measured 180 us vs 133 us for two 128-channel groups on the 256->256 layer, so off by default
-extern "C" int ly_debug_set_rf3(int v) { g_rf3_dbg = v & 7; g_rf3_mt4 = (v >> 3) & 1; return 0; }
+static int g_rf3_dbg = 0;   // ablation aid: 1 skip regenerate, 4 skip staging
+static int g_rf3_mt2 = 0;   // (bit 3 of ly_debug_set_rf3) run N > 128 as two 128-channel groups (MT=2, two waves per SIMD) instead of the
+                            // 256-channel MT=4 tile (296 registers, one wave per SIMD).  With the loads prefetched the regenerate phase
+                            // is what the kernel waits for, and MT=4 runs it once per pixel tile instead of twice: 256->256 @ 40x40x32
+                            // module 191 -> 159 us
+                            // (an isolated 8-image call is the one case that loses: 139 -> 154 us; four such calls on concurrent streams,
+                            // the serving mode, gain: 19.06k -> 19.55k images/s)
+extern "C" int ly_debug_set_rf3(int v) { g_rf3_dbg = v & 7; g_rf3_mt2 = (v >> 3) & 1; return 0; }
 
 template <int MT>
 static int launch_rf3(const LyRfcbam3Params& P, hipStream_t st) {
@@ -249,7 +281,7 @@ extern "C" int ly_rfcbam3_fwd(const LyRfcbam3Params* p, void* stream) {
   LY_CHECK(P.s >= 1 && P.TH >= 1 && P.TW >= 1 && P.TH * P.TW <= 64, "rfcbam3: bad tile %dx%d", P.TH, P.TW);
   LY_CHECK(P.Ho == (P.H + 2 - 3) / P.s + 1 && P.Wo == (P.W + 2 - 3) / P.s + 1, "rfcbam3: inconsistent output size");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (P.N > 128 && g_rf3_mt4) return launch_rf3<4>(P, st);
+  if (P.N > 128 && !g_rf3_mt2) return launch_rf3<4>(P, st);
   if (P.N > 64) return launch_rf3<2>(P, st);
   return launch_rf3<1>(P, st);
 }

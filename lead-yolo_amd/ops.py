@@ -196,7 +196,7 @@ def rfa_map(mm, w18):
 def rfcbam3(*, n, h, w, c, ho, wo, N, s, th, tw, x, ldx, wg, ca, rfa, wp, e_scale, e_shift, out, ldo, stats=None, linear=False):
     P = capi.LyRfcbam3Params(n, h, w, c, ho, wo, N, s, th, tw, _p(x), ldx, _p(wg), _p(ca), _p(rfa), _p(wp), _p(e_scale),
                              _p(e_shift), _p(out), ldo, _p(stats), int(linear))
-    mt = 2 if N > 64 else 1            # mirrors ly_rfcbam3_fwd: N > 128 runs as two 128-channel groups (MT=4 leaves one wave per SIMD)
+    mt = 4 if N > 128 else (2 if N > 64 else 1)            # mirrors ly_rfcbam3_fwd
     mo = n * ho * wo
     with _Timed(f"ly_rfcbam3_kernel<{mt}>", 2.0 * mo * (9 * c * N + 81 * c), 4.0 * (n * h * w * c + mo * N + 9 * c * N)):
         capi.check(capi.lib().ly_rfcbam3_fwd(ctypes.byref(P), capi.stream_ptr()), "ly_rfcbam3_fwd")

@@ -153,8 +153,8 @@ typedef struct LyRfcbam3Params {
 /* RFCBAMConv kernel_size 3 main contraction (+ReLU); the k=1 case is ly_gemm_fwd with
  * LY_PRO_AFFINE_RELU_CA and rowscale = rfa.                                                         */
 int ly_rfcbam3_fwd(const LyRfcbam3Params* p, void* stream);
-/* ablation aid for profiling (bit 0: skip regenerate, 2: skip staging, 3: two 128-channel groups instead of the
- * 256-channel tile for N > 128); 0 = normal */
+/* ablation aid for profiling (bit 0: skip regenerate, 1: generate weights through LDS whatever the grid, 2: skip staging,
+ * 3: two 128-channel groups instead of the 256-channel tile for N > 128); 0 = normal */
 int ly_debug_set_rf3(int v);
 
 

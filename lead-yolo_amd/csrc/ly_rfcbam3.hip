@@ -8,7 +8,7 @@
 // stages the raw input tile in LDS, the VALU recomputes the depthwise "generate" conv + BN + ReLU
 // (81 MAC per channel and pixel, lane = output pixel, wave-uniform weights), scales by ca and rfa and
 // writes the [64 px x 144] operand tile (bf16 hi/lo planes) to LDS, which the MFMAs contract with the
-// bf16x3 frag-packed conv.0.weight viewed as [Cout, C/16, 144 -> 160] (native k = c*9 + t order per chunk).  HBM sees x once and out once.
+// bf16x3 frag-packed conv.0.weight viewed as [Cout, C/16, 144 -> 160] (k = t*16 + channel inside a chunk).  HBM sees x once and out once.
 #include "ly_tile.cuh"
 #include "ly_params.h"
 
@@ -18,15 +18,18 @@
 #define LY_RF3_NV 8                      // float4 staging items per thread per chunk: IH*IW*4 <= 8*256
 #define LY_RF3_WF (9 * 2 * 20)           // floats of folded generate weights per wave per chunk: [9 t][2 pairs][9 x (w_a, w_b) + (b_a, b_b)]
 
-template <int MT>
-__global__ __launch_bounds__(LY_THREADS) void ly_rfcbam3_kernel(const LyRfcbam3Params P, const int gy, const int nct, const int nrt, const int dbg) {
+// SW: the folded generate weights come through the scalar cache (SGPR operands) instead of LDS broadcasts; see the regenerate
+// step.  Every chunk's weights are read once per block, so each tap waits for a scalar-cache miss that only a second resident
+// wave can hide; the launcher's rule is in launch_rf3.
+template <int MT, bool SW>
+__device__ __forceinline__ void ly_rfcbam3_body(const LyRfcbam3Params& P, const int gy, const int nct, const int nrt, const int dbg) {
   extern __shared__ f32x4 ly_smem4[];
   const int s = P.s, TH = P.TH, TW = P.TW;
   const int IH = s * (TH - 1) + 3, IW = s * (TW - 1) + 3;
   char* gs_hi = reinterpret_cast<char*>(ly_smem4);          // [64][LY_RSG]
   char* gs_lo = gs_hi + 64 * LY_RSG;
-  float* wsm = reinterpret_cast<float*>(gs_lo + 64 * LY_RSG);  // [4 waves][LY_RF3_WF]: this chunk's folded generate weights
-  float* xs = wsm + 4 * LY_RF3_WF;                             // [IH*IW][LY_GCC + 1]
+  float* wsm = reinterpret_cast<float*>(gs_lo + 64 * LY_RSG);  // !SW: [4 waves][LY_RF3_WF] this chunk's folded generate weights
+  float* xs = wsm + (SW ? 0 : 4 * LY_RF3_WF);                  // [IH*IW][LY_GCC + 1]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: depthwise weights become scalar loads
   const int li = lane & 15, lq = lane >> 4;
@@ -66,38 +69,40 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam3_kernel(const LyRfcbam3P
 
   // staging plan of this thread (independent of the channel chunk): global element offset (or -1), LDS slot
   const int items = IH * IW * (LY_GCC / 4);
-  long soff[LY_RF3_NV];
+  int soff[LY_RF3_NV];             // element offsets fit 31 bits (checked by the launcher)
   int doff[LY_RF3_NV];
 #pragma unroll
   for (int e = 0; e < LY_RF3_NV; ++e) {
     const int idx = tid + e * LY_THREADS;
-    long so = -1;
+    int so = -1;
     int dd = -1;
     if (idx < items) {
       const int ip = idx >> 2, c4 = idx & 3;
       const int r = ip / IW, q = ip - r * IW;
       const int iy = iy0 + r, ix = ix0 + q;
       dd = ip * (LY_GCC + 1) + 4 * c4;
-      if (iy >= 0 && iy < P.H && ix >= 0 && ix < P.W) so = (((long)n * P.H + iy) * P.W + ix) * P.ldx + 4 * c4;
+      if (iy >= 0 && iy < P.H && ix >= 0 && ix < P.W) so = (int)((((long)n * P.H + iy) * P.W + ix) * P.ldx + 4 * c4);
     }
     soff[e] = so; doff[e] = dd;
   }
   // Everything a chunk reads from global memory is requested one chunk ahead, so no wave ever waits on a load it has just
-  // issued: the raw input tile (pv), the folded generate weights (wv) and the conv weight fragments (ring: D fragments in
+  // issued: the raw input tile (pv) and the conv weight fragments (ring: D fragments in
   // flight, slot q % D refilled with fragment q + D -- which may belong to the next chunk -- right after fragment q's MFMAs).
   f32x4 pv[LY_RF3_NV];
   auto prefetch = [&](int c0) {
 #pragma unroll
     for (int e = 0; e < LY_RF3_NV; ++e) pv[e] = ly_ldg4(soff[e] >= 0 ? P.x + soff[e] + c0 : P.x);
   };
-  constexpr int WV = (4 * LY_RF3_WF / 4 + LY_THREADS - 1) / LY_THREADS;
+  constexpr int WV = SW ? 1 : (4 * LY_RF3_WF / 4 + LY_THREADS - 1) / LY_THREADS;
   f32x4 wv[WV];
   auto wprefetch = [&](int chunk) {
-    const float* wsrc = P.wg + (long)chunk * (4 * LY_RF3_WF);
+    if constexpr (!SW) {
+      const float* wsrc = P.wg + (long)chunk * (4 * LY_RF3_WF);
 #pragma unroll
-    for (int e = 0; e < WV; ++e) {
-      const int i = tid + e * LY_THREADS;
-      wv[e] = ly_ldg4(wsrc + 4 * (i < 4 * LY_RF3_WF / 4 ? i : 0));
+      for (int e = 0; e < WV; ++e) {
+        const int i = tid + e * LY_THREADS;
+        wv[e] = ly_ldg4(wsrc + 4 * (i < 4 * LY_RF3_WF / 4 ? i : 0));
+      }
     }
   };
   constexpr int D = 5, NF = (LY_GK / 32) * MT;           // ring depth, fragments per chunk (k-step major); NF % D == 0
@@ -110,14 +115,16 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam3_kernel(const LyRfcbam3P
   if (!(dbg & 4)) prefetch(0);
 
   for (int c0 = 0; c0 < P.C; c0 += LY_GCC) {
-    __syncthreads();                      // previous chunk: generate done with xs/wsm, MFMAs done with gs
-#pragma unroll
-    for (int e = 0; e < WV; ++e) {
-      const int i = tid + e * LY_THREADS;
-      if (i < 4 * LY_RF3_WF / 4) reinterpret_cast<f32x4*>(wsm)[i] = wv[e];
-    }
+    __syncthreads();                      // previous chunk: generate done with xs, MFMAs done with gs
     const bool more = c0 + LY_GCC < P.C;
-    wprefetch(more ? c0 / LY_GCC + 1 : 0);
+    if constexpr (!SW) {
+#pragma unroll
+      for (int e = 0; e < WV; ++e) {
+        const int i = tid + e * LY_THREADS;
+        if (i < 4 * LY_RF3_WF / 4) reinterpret_cast<f32x4*>(wsm)[i] = wv[e];
+      }
+      wprefetch(more ? c0 / LY_GCC + 1 : 0);
+    }
     if (!(dbg & 4)) {
 #pragma unroll
       for (int e = 0; e < LY_RF3_NV; ++e)
@@ -130,8 +137,12 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam3_kernel(const LyRfcbam3P
     }
     __syncthreads();
     // ---- regenerate G' for channels c0 + 4*wave .. +3 -----------------------------------------------
-    // inputs of the wave's 4 channels as 2 packed pairs, folded weights [t][pair][20] read as wave-uniform
-    // LDS broadcasts (pack.rfcbam_gen_weights(..., 16, True)); v_pk_fma_f32 does two channels per instruction
+    // inputs of the wave's 4 channels as 2 packed pairs (v_pk_fma_f32 does two channels per instruction).  The folded weights
+    // [t][pair][20] (pack.rfcbam_gen_weights(..., 16, True)) are wave-uniform: LDS broadcasts (10 ds_read_b128 per tap and
+    // wave, staged a chunk ahead) or, SW, SGPR operands through the scalar cache.  The LDS pipe -- shared by the resident
+    // waves and also carrying the G' writes and the MFMA operand reads -- is what this kernel is bound by, so: the two pairs
+    // run as two independent accumulation chains (no dependent-issue bubbles), and a lane's 4 channels of one tap are adjacent
+    // in k (k = t*16 + channel), so G' is written with one 8-byte store per plane and tap instead of four 2-byte ones.
     if (!(dbg & 1)) {
       f32x2 xv[2][9];
       f32x2 cav[2];
@@ -144,34 +155,45 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam3_kernel(const LyRfcbam3P
           xv[p][u] = active ? (f32x2){xs[xo], xs[xo + 1]} : (f32x2){0.f, 0.f};
         }
       }
-      const f32x4* wq = reinterpret_cast<const f32x4*>(wsm + wave * LY_RF3_WF);   // wave-uniform => LDS broadcast reads
+      const ly_cfloat* wq = ly_const(P.wg) + (long)(c0 / LY_GCC) * (4 * LY_RF3_WF) + wave * LY_RF3_WF;
+      const float* wl = wsm + wave * LY_RF3_WF;               // !SW: wave-uniform address => LDS broadcast reads
 #pragma unroll
-      for (int t = 0; t < 9; ++t)
+      for (int t = 0; t < 9; ++t) {
+        f32x2 a0, a1;
+        if constexpr (SW) {
+          const ly_cfloat* q0 = wq + (t * 2) * 20;
+          const ly_cfloat* q1 = q0 + 20;
+          a0 = (f32x2){q0[18], q0[19]};
+          a1 = (f32x2){q1[18], q1[19]};
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-          const f32x4* q = wq + (t * 2 + p) * 5;
-          const f32x4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4];
-          f32x2 a = {q4[2], q4[3]};
-          a += xv[p][0] * (f32x2){q0[0], q0[1]};
-          a += xv[p][1] * (f32x2){q0[2], q0[3]};
-          a += xv[p][2] * (f32x2){q1[0], q1[1]};
-          a += xv[p][3] * (f32x2){q1[2], q1[3]};
-          a += xv[p][4] * (f32x2){q2[0], q2[1]};
-          a += xv[p][5] * (f32x2){q2[2], q2[3]};
-          a += xv[p][6] * (f32x2){q3[0], q3[1]};
-          a += xv[p][7] * (f32x2){q3[2], q3[3]};
-          a += xv[p][8] * (f32x2){q4[0], q4[1]};
-          const float rft = active ? rf[t] : 0.f;
-          const f32x2 gv = (f32x2){fmaxf(a[0], 0.f), fmaxf(a[1], 0.f)} * cav[p] * rft;
-          const bf16x2 gh = __builtin_convertvector(gv, bf16x2);
-          const bf16x2 gl = __builtin_convertvector(gv - __builtin_convertvector(gh, f32x2), bf16x2);
-          // k index of channel (4*wave + 2p + ab), tap t inside the chunk: (4*wave + 2p + ab)*9 + t
-          const int k0 = (4 * wave + 2 * p) * 9 + t;
-          *reinterpret_cast<__bf16*>(gs_hi + lane * LY_RSG + 2 * k0) = gh[0];
-          *reinterpret_cast<__bf16*>(gs_lo + lane * LY_RSG + 2 * k0) = gl[0];
-          *reinterpret_cast<__bf16*>(gs_hi + lane * LY_RSG + 2 * (k0 + 9)) = gh[1];
-          *reinterpret_cast<__bf16*>(gs_lo + lane * LY_RSG + 2 * (k0 + 9)) = gl[1];
+          for (int u = 0; u < 9; ++u) {
+            a0 += xv[0][u] * (f32x2){q0[2 * u], q0[2 * u + 1]};
+            a1 += xv[1][u] * (f32x2){q1[2 * u], q1[2 * u + 1]};
+          }
+        } else {
+          f32x4 q0[5], q1[5];
+#pragma unroll
+          for (int i = 0; i < 5; ++i) {
+            q0[i] = reinterpret_cast<const f32x4*>(wl + (t * 2) * 20)[i];
+            q1[i] = reinterpret_cast<const f32x4*>(wl + (t * 2 + 1) * 20)[i];
+          }
+          a0 = (f32x2){q0[4][2], q0[4][3]};
+          a1 = (f32x2){q1[4][2], q1[4][3]};
+#pragma unroll
+          for (int u = 0; u < 9; ++u) {
+            a0 += xv[0][u] * (f32x2){q0[u >> 1][2 * (u & 1)], q0[u >> 1][2 * (u & 1) + 1]};
+            a1 += xv[1][u] * (f32x2){q1[u >> 1][2 * (u & 1)], q1[u >> 1][2 * (u & 1) + 1]};
+          }
         }
+        const float rft = active ? rf[t] : 0.f;
+        const f32x2 g0 = (f32x2){fmaxf(a0[0], 0.f), fmaxf(a0[1], 0.f)} * cav[0] * rft;
+        const f32x2 g1 = (f32x2){fmaxf(a1[0], 0.f), fmaxf(a1[1], 0.f)} * cav[1] * rft;
+        bf16x4 gh, gl;
+        ly_split4((f32x4){g0[0], g0[1], g1[0], g1[1]}, gh, gl);
+        const int kb = lane * LY_RSG + 2 * (t * LY_GCC + 4 * wave);       // k = t*16 + (4*wave + j)
+        *reinterpret_cast<bf16x4*>(gs_hi + kb) = gh;
+        *reinterpret_cast<bf16x4*>(gs_lo + kb) = gl;
+      }
     }
     __syncthreads();
     // ---- contract the chunk's 160 (144 real) k-values --------------------------------------------
@@ -242,7 +264,16 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam3_kernel(const LyRfcbam3P
   }
 }
 
-static int g_rf3_dbg = 0;   // ablation aid: 1 skip regenerate, 4 skip staging
+template <int MT>
+__global__ __launch_bounds__(LY_THREADS) void ly_rfcbam3_kernel(const LyRfcbam3Params P, const int gy, const int nct, const int nrt, const int dbg) {
+  ly_rfcbam3_body<MT, false>(P, gy, nct, nrt, dbg);
+}
+template <int MT>
+__global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void ly_rfcbam3_sw_kernel(const LyRfcbam3Params P, const int gy, const int nct, const int nrt, const int dbg) {
+  ly_rfcbam3_body<MT, true>(P, gy, nct, nrt, dbg);
+}
+
+static int g_rf3_dbg = 0;   // ablation aid: 1 skip regenerate, 2 generate weights through LDS regardless of the grid, 4 skip staging
 static int g_rf3_mt2 = 0;   // (bit 3 of ly_debug_set_rf3) run N > 128 as two 128-channel groups (MT=2, two waves per SIMD) instead of the
                             // 256-channel MT=4 tile (296 registers, one wave per SIMD).  With the loads prefetched the regenerate phase
                             // is what the kernel waits for, and MT=4 runs it once per pixel tile instead of twice: 256->256 @ 40x40x32
@@ -251,15 +282,17 @@ static int g_rf3_mt2 = 0;   // (bit 3 of ly_debug_set_rf3) run N > 128 as two 12
                             // the serving mode, gain: 19.06k -> 19.55k images/s)
 extern "C" int ly_debug_set_rf3(int v) { g_rf3_dbg = v & 7; g_rf3_mt2 = (v >> 3) & 1; return 0; }
 
-template <int MT>
-static int launch_rf3(const LyRfcbam3Params& P, hipStream_t st) {
+template <int MT, bool SW>
+static int launch_rf3_k(const LyRfcbam3Params& P, hipStream_t st) {
   const int nct = (P.Wo + P.TW - 1) / P.TW, nrt = (P.Ho + P.TH - 1) / P.TH;
   const int gy = (P.N + 64 * MT - 1) / (64 * MT);
   const int IH = P.s * (P.TH - 1) + 3, IW = P.s * (P.TW - 1) + 3;
-  size_t lds = 2 * (size_t)64 * LY_RSG + sizeof(float) * ((size_t)4 * LY_RF3_WF + (size_t)IH * IW * (LY_GCC + 1));
+  size_t lds = 2 * (size_t)64 * LY_RSG + sizeof(float) * ((size_t)(SW ? 0 : 4 * LY_RF3_WF) + (size_t)IH * IW * (LY_GCC + 1));
   LY_CHECK(lds <= 160 * 1024, "rfcbam3: tile needs %zu B LDS", lds);
   LY_CHECK(IH * IW * (LY_GCC / 4) <= LY_RF3_NV * LY_THREADS, "rfcbam3: input tile %dx%d exceeds the staging capacity", IH, IW);
-  auto k = ly_rfcbam3_kernel<MT>;
+  void (*k)(const LyRfcbam3Params, int, int, int, int);
+  if constexpr (SW) k = ly_rfcbam3_sw_kernel<MT>;
+  else k = ly_rfcbam3_kernel<MT>;
   static bool configured = false;
   if (!configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -273,12 +306,25 @@ static int launch_rf3(const LyRfcbam3Params& P, hipStream_t st) {
   return 0;
 }
 
+template <int MT>
+static int launch_rf3(const LyRfcbam3Params& P, hipStream_t st) {
+  const long nb = (long)P.n_img * ((P.Wo + P.TW - 1) / P.TW) * ((P.Ho + P.TH - 1) / P.TH) * ((P.N + 64 * MT - 1) / (64 * MT));
+  // Measured (tools/rf3_ablate.py): at equal occupancy the LDS path is never slower (128->128 @ 80x80x64: 347 vs 387 us).  The
+  // scalar path's one advantage is registers: the MT=4 tile fits two waves per SIMD only with it (245 vs 316), which pays
+  // once the grid has more than one block per CU (256->256 @ 40x40x64: 244 vs 292 us; at x32, 224 blocks: 180 vs 156 us).
+  if constexpr (MT == 4) {
+    if (nb > 256 && !(g_rf3_dbg & 2)) return launch_rf3_k<MT, true>(P, st);
+  }
+  return launch_rf3_k<MT, false>(P, st);
+}
+
 extern "C" int ly_rfcbam3_fwd(const LyRfcbam3Params* p, void* stream) {
   LY_CHECK(p, "rfcbam3: null params");
   const LyRfcbam3Params& P = *p;
   LY_CHECK(P.x && P.wg && P.ca && P.rfa && P.wp && P.e_scale && P.e_shift && (P.out || P.stats), "rfcbam3: null pointer");
   LY_CHECK((P.C & 15) == 0 && (P.ldx & 3) == 0, "rfcbam3: C=%d must be a multiple of 16", P.C);
   LY_CHECK(P.s >= 1 && P.TH >= 1 && P.TW >= 1 && P.TH * P.TW <= 64, "rfcbam3: bad tile %dx%d", P.TH, P.TW);
+  LY_CHECK((long)P.n_img * P.H * P.W * P.ldx < (1L << 31), "rfcbam3: input of %ld elements exceeds the 31-bit offsets of the staging plan", (long)P.n_img * P.H * P.W * P.ldx);
   LY_CHECK(P.Ho == (P.H + 2 - 3) / P.s + 1 && P.Wo == (P.W + 2 - 3) / P.s + 1, "rfcbam3: inconsistent output size");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (P.N > 128 && !g_rf3_mt2) return launch_rf3<4>(P, st);

@@ -496,7 +496,7 @@ class RFCBAMConv(nn.Module):
             wq_stats = pack.rfcbam_gen_weights(gw, gs, gb, 32, False)           # stats kernel: 32-ch chunks, c0 + w + 4j
             wq_main = pack.rfcbam_gen_weights(gw, gs, gb, 16, True)             # main kernel: 16-ch chunks, c0 + 4w + j
             wk = torch.zeros(o, c // 16, 160, dtype=torch.float32, device=gw.device)      # 144 real k per 16-channel chunk
-            wk[:, :, :144] = cw.weight.detach().float().reshape(o, c // 16, 144)
+            wk[:, :, :144] = cw.weight.detach().float().reshape(o, c // 16, 16, 9).permute(0, 1, 3, 2).reshape(o, c // 16, 144)   # k = t*16 + ch
             return dict(wq_stats=wq_stats, wq_main=wq_main, w18=w18, wp=pack.frag_pack3(wk.view(o, -1)), es=es, eb=eb)
         return self._prep.get(key, build)
 

@@ -198,7 +198,8 @@ def rfcbam3(*, n, h, w, c, ho, wo, N, s, th, tw, x, ldx, wg, ca, rfa, wp, e_scal
                              _p(e_shift), _p(out), ldo, _p(stats), int(linear))
     mt = 4 if N > 128 else (2 if N > 64 else 1)            # mirrors ly_rfcbam3_fwd
     mo = n * ho * wo
-    with _Timed(f"ly_rfcbam3_kernel<{mt}>", 2.0 * mo * (9 * c * N + 81 * c), 4.0 * (n * h * w * c + mo * N + 9 * c * N)):
+    sw = mt == 4 and n * -(-ho // th) * -(-wo // tw) * -(-N // 256) > 256    # mirrors launch_rf3: weights via the scalar cache
+    with _Timed(f"ly_rfcbam3{'_sw' if sw else ''}_kernel<{mt}>", 2.0 * mo * (9 * c * N + 81 * c), 4.0 * (n * h * w * c + mo * N + 9 * c * N)):
         capi.check(capi.lib().ly_rfcbam3_fwd(ctypes.byref(P), capi.stream_ptr()), "ly_rfcbam3_fwd")
 
 

@@ -1,5 +1,5 @@
 """RFCBAMConv (k=3) main kernel at the two lead-yolo-s shapes with the ablation switches of ly_debug_set_rf3
-(1 skip regenerate, 4 skip staging, 8 two MT=2 groups instead of MT=4).  Module time per call inside a replayed hipGraph (SE + stats + main kernels)."""
+(1 skip regenerate, 2 generate weights through LDS, 4 skip staging, 8 two MT=2 groups instead of MT=4).  Module time per call inside a replayed hipGraph (SE + stats + main kernels)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -20,11 +20,11 @@ def timeit(fn, iters=20, reps=5):
     for _ in range(iters): g.replay()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / (iters * reps) * 1e3
-for c1, c2, hw in ((256, 256, 40),):
+for c1, c2, hw in ((128, 128, 80), (256, 256, 40)):
     m = L.RFCBAMConv(c1, c2, 3, 2).to(dev).eval()
     x = torch.randn(bs, c1, hw, hw, device=dev).contiguous(memory_format=torch.channels_last)
     with torch.no_grad():
-        for dbg in (0, 8):
+        for dbg in (0, 2, 8, 10):
             capi.lib().ly_debug_set_rf3(dbg)
-            print(f"{c1}->{c2} @{hw} bs={bs} dbg={dbg} (skip gen={dbg&1} stage={(dbg>>2)&1} mt2x2={(dbg>>3)&1}): module {timeit(lambda: m(x)):8.1f} us")
+            print(f"{c1}->{c2} @{hw} bs={bs} dbg={dbg} (skip gen={dbg&1} ldsw={(dbg>>1)&1} stage={(dbg>>2)&1} mt2x2={(dbg>>3)&1}): module {timeit(lambda: m(x)):8.1f} us")
 capi.lib().ly_debug_set_rf3(0)

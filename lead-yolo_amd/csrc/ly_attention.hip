@@ -248,33 +248,54 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_stats3_kernel(const floa
 #pragma unroll
   for (int t = 0; t < 9; ++t) { mx[t] = 0.f; sm[t] = 0.f; }      // G = relu(.) >= 0, so 0 is the identity of the channel max
 
+  // the input tile (pv) and the folded weights (wv) of chunk c+1 are requested before chunk c is regenerated: no load is waited
+  // for right after it is issued
+  f32x4 pv[LY_ST3_NV];
+  auto prefetch = [&](int c0) {
+#pragma unroll
+    for (int e = 0; e < LY_ST3_NV; ++e) {
+      const bool ok = soff[e] >= 0 && c0 + 4 * ((tid + e * LY_THREADS) & 7) < C;
+      pv[e] = ly_ldg4(ok ? x + soff[e] + c0 : x);
+    }
+  };
+  constexpr int WV = (4 * LY_ST3_WF / 4 + LY_THREADS - 1) / LY_THREADS;
+  f32x4 wv[WV];
+  auto wprefetch = [&](int chunk) {
+    const float* wsrc = wg + (long)chunk * (4 * LY_ST3_WF);
+#pragma unroll
+    for (int e = 0; e < WV; ++e) {
+      const int i = tid + e * LY_THREADS;
+      wv[e] = ly_ldg4(wsrc + 4 * (i < 4 * LY_ST3_WF / 4 ? i : 0));
+    }
+  };
+  wprefetch(0);
+  if (!(dbg & 1)) prefetch(0);
+
   for (int c0 = 0; c0 < C; c0 += LY_SCC) {
     __syncthreads();
-    {
-      const float* wsrc = wg + (long)(c0 / LY_SCC) * (4 * LY_ST3_WF);
-      for (int i = tid; i < 4 * LY_ST3_WF / 4; i += LY_THREADS) reinterpret_cast<f32x4*>(wsm)[i] = ly_ldg4(wsrc + 4 * i);
-    }
-    if (!(dbg & 1)) {
-      f32x4 v[LY_ST3_NV];
 #pragma unroll
-      for (int e = 0; e < LY_ST3_NV; ++e) {
-        const bool ok = soff[e] >= 0 && c0 + 4 * ((tid + e * LY_THREADS) & 7) < C;
-        v[e] = ly_ldg4(ok ? x + soff[e] + c0 : x);
-      }
+    for (int e = 0; e < WV; ++e) {
+      const int i = tid + e * LY_THREADS;
+      if (i < 4 * LY_ST3_WF / 4) reinterpret_cast<f32x4*>(wsm)[i] = wv[e];
+    }
+    const bool more = c0 + LY_SCC < C;
+    wprefetch(more ? c0 / LY_SCC + 1 : 0);
+    if (!(dbg & 1)) {
 #pragma unroll
       for (int e = 0; e < LY_ST3_NV; ++e) {
         if (doff[e] >= 0) {
           const bool ok = soff[e] >= 0 && c0 + 4 * ((tid + e * LY_THREADS) & 7) < C;
           float* d = xs + doff[e];
-          d[0] = ok ? v[e][0] : 0.f; d[1] = ok ? v[e][1] : 0.f; d[2] = ok ? v[e][2] : 0.f; d[3] = ok ? v[e][3] : 0.f;
+          d[0] = ok ? pv[e][0] : 0.f; d[1] = ok ? pv[e][1] : 0.f; d[2] = ok ? pv[e][2] : 0.f; d[3] = ok ? pv[e][3] : 0.f;
         }
       }
+      prefetch(more ? c0 + LY_SCC : 0);
     }
     __syncthreads();
     if (!(dbg & 2)) {
       // inputs of this wave's 8 channels (c0 + wave + 4j) as 4 packed pairs (j = 2p, 2p+1), then the folded
       // weights [t][p][9 x (w_a, w_b), (b_a, b_b)] read as wave-uniform LDS broadcasts: v_pk_fma_f32 does two
-      // channels per instruction.
+      // channels per instruction; two pairs at a time so that two independent accumulation chains interleave.
       f32x2 xv[4][9];
 #pragma unroll
       for (int p = 0; p < 4; ++p)
@@ -287,22 +308,22 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_stats3_kernel(const floa
 #pragma unroll
       for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-          const f32x4* q = wq + (t * 4 + p) * 5;
-          const f32x4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4];
-          f32x2 a = {q4[2], q4[3]};
-          a += xv[p][0] * (f32x2){q0[0], q0[1]};
-          a += xv[p][1] * (f32x2){q0[2], q0[3]};
-          a += xv[p][2] * (f32x2){q1[0], q1[1]};
-          a += xv[p][3] * (f32x2){q1[2], q1[3]};
-          a += xv[p][4] * (f32x2){q2[0], q2[1]};
-          a += xv[p][5] * (f32x2){q2[2], q2[3]};
-          a += xv[p][6] * (f32x2){q3[0], q3[1]};
-          a += xv[p][7] * (f32x2){q3[2], q3[3]};
-          a += xv[p][8] * (f32x2){q4[0], q4[1]};
-          const float g0 = fmaxf(a[0], 0.f), g1 = fmaxf(a[1], 0.f);
-          mx[t] = fmaxf(mx[t], fmaxf(g0, g1));
-          sm[t] += g0 + g1;
+        for (int ph = 0; ph < 2; ++ph) {
+          f32x4 q0[5], q1[5];
+#pragma unroll
+          for (int i = 0; i < 5; ++i) {
+            q0[i] = wq[(t * 4 + 2 * ph) * 5 + i];
+            q1[i] = wq[(t * 4 + 2 * ph + 1) * 5 + i];
+          }
+          f32x2 a0 = {q0[4][2], q0[4][3]}, a1 = {q1[4][2], q1[4][3]};
+#pragma unroll
+          for (int u = 0; u < 9; ++u) {
+            a0 += xv[2 * ph][u] * (f32x2){q0[u >> 1][2 * (u & 1)], q0[u >> 1][2 * (u & 1) + 1]};
+            a1 += xv[2 * ph + 1][u] * (f32x2){q1[u >> 1][2 * (u & 1)], q1[u >> 1][2 * (u & 1) + 1]};
+          }
+          const float g0 = fmaxf(a0[0], 0.f), g1 = fmaxf(a0[1], 0.f), g2 = fmaxf(a1[0], 0.f), g3 = fmaxf(a1[1], 0.f);
+          mx[t] = fmaxf(fmaxf(mx[t], fmaxf(g0, g1)), fmaxf(g2, g3));
+          sm[t] += (g0 + g1) + (g2 + g3);
         }
     }
   }

@@ -24,7 +24,7 @@ for c1, c2, hw in ((128, 128, 80), (256, 256, 40)):
     m = L.RFCBAMConv(c1, c2, 3, 2).to(dev).eval()
     x = torch.randn(bs, c1, hw, hw, device=dev).contiguous(memory_format=torch.channels_last)
     with torch.no_grad():
-        for dbg in (0, 2, 8, 10):
+        for dbg in (0,):
             capi.lib().ly_debug_set_rf3(dbg)
             print(f"{c1}->{c2} @{hw} bs={bs} dbg={dbg} (skip gen={dbg&1} ldsw={(dbg>>1)&1} stage={(dbg>>2)&1} mt2x2={(dbg>>3)&1}): module {timeit(lambda: m(x)):8.1f} us")
 capi.lib().ly_debug_set_rf3(0)

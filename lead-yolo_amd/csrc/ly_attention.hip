@@ -120,14 +120,24 @@ __global__ __launch_bounds__(LY_THREADS) void ly_colsum_kernel(const float* __re
 __global__ __launch_bounds__(LY_THREADS) void ly_se_mlp_kernel(const float* __restrict__ part, int slices, int C, float inv_hw,
                                                                 const float* __restrict__ wa, const float* __restrict__ wb, int R,
                                                                 float* __restrict__ ca) {
-  extern __shared__ float sm[];      // g[C] + hid[R]
+  extern __shared__ float sm[];      // g[C] + hid[R] + red[LY_THREADS][4]
   float* g = sm;
   float* hid = sm + C;
+  f32x4* red = reinterpret_cast<f32x4*>(sm + ((C + R + 3) & ~3));
   const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int c = tid; c < C; c += LY_THREADS) {
-    float s = 0.f;
-    for (int sl = 0; sl < slices; ++sl) s += part[((long)n * slices + sl) * C + c];
-    g[c] = s * inv_hw;
+  // slice partials -> channel means.  All 256 threads load: thread = (slice group, 4 channels), so the up to 128 slices
+  // are a handful of independent float4 loads per thread instead of a 128-long chain per channel; groups meet in LDS.
+  const int nq = C >> 2;                 // channel quads: C % 4 == 0 and C <= 1024, so nq <= 256
+  const int ng = LY_THREADS / nq;        // slice groups
+  const int q = tid % nq, sg = tid / nq;
+  f32x4 s4 = ly_zero4();
+  if (sg < ng)
+    for (int sl = sg; sl < slices; sl += ng) s4 += ly_ldg4(part + ((long)n * slices + sl) * C + 4 * q);
+  red[tid] = s4;
+  __syncthreads();
+  if (sg == 0) {
+    for (int k = 1; k < ng; ++k) s4 += red[tid + k * nq];
+    g[4 * q] = s4[0] * inv_hw; g[4 * q + 1] = s4[1] * inv_hw; g[4 * q + 2] = s4[2] * inv_hw; g[4 * q + 3] = s4[3] * inv_hw;
   }
   __syncthreads();
   for (int r = wave; r < R; r += 4) {
@@ -152,7 +162,7 @@ extern "C" int ly_se_fwd(const float* x, int ldx, int n_img, int HW, int C, cons
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(ly_colsum_kernel, dim3(n_img * slices), dim3(LY_THREADS), 0, st, x, ldx, HW, C, slices, part);
   LY_LAUNCH_CHECK();
-  hipLaunchKernelGGL(ly_se_mlp_kernel, dim3(n_img), dim3(LY_THREADS), sizeof(float) * (C + R), st, part, slices, C, 1.f / (float)HW,
+  hipLaunchKernelGGL(ly_se_mlp_kernel, dim3(n_img), dim3(LY_THREADS), sizeof(float) * (((C + R + 3) & ~3) + 4 * LY_THREADS), st, part, slices, C, 1.f / (float)HW,
                      wa, wb, R, ca);
   LY_LAUNCH_CHECK();
   return 0;

@@ -63,8 +63,11 @@ def pick_conv_tile(h, w, max_px=128, max_frame=192):
 
 
 def mlp_config(c, m, w):
+    """(C, NT, HT, T2D) of the kernel ly_mlpblock_fwd launches -- mirrors dispatch_nt in csrc/ly_mlpblock.hip"""
     ht = {16: 2, 24: 4, 40: 2, 80: 2, 160: 4, 320: 4}[c]
     ntmax = {16: 4, 24: 4, 40: 4, 80: 2, 160: 2, 320: 1}[c]
+    if c >= 80:
+        return c, (2 if ntmax >= 2 and m >= 200 * 128 else 1), ht, "false"
     if w % 16 == 0 and w >= 64 and ntmax >= 2:
         return c, 2, ht, "true"
     nt = 4 if (ntmax >= 4 and m >= 256 * 1024) else 2 if (ntmax >= 2 and m >= 128 * 512) else 1
@@ -219,7 +222,8 @@ def detect_tail(y, ldy, n, h, w, na, no, anchors, stride, p, z, zrows, zoff):
 def mlpblock(x, y, n, h, w, c, wp, w1, w2, sc, sh, stats=None):
     m = n * h * w
     cc, nt, ht, t2d = mlp_config(c, m, w)
-    with _Timed(f"ly_mlpblock_fwd_kernel<{cc}, {nt}, {ht}, {t2d}>", 2.0 * m * (9 * (c // 4) ** 2 + 4 * c * c),
+    name = f"ly_mlpblock_fwd{'_ring' if c >= 80 else ''}_kernel<{cc}, {nt}, {ht}, {t2d}, {'true' if stats is not None else 'false'}>"
+    with _Timed(name, 2.0 * m * (9 * (c // 4) ** 2 + 4 * c * c),
                 4.0 * (2 * m * c + 9 * (c // 4) ** 2 + 4 * c * c)):
         capi.check(capi.lib().ly_mlpblock_fwd(_p(x), _p(y), n, h, w, c, _p(wp), _p(w1), _p(w2), _p(sc), _p(sh), _p(stats), capi.stream_ptr()),
                    "ly_mlpblock_fwd")

@@ -682,7 +682,11 @@ static int launch_gemm_bk(const LyGemmParams& P, hipStream_t st) {
   long gx = (P.M + BP - 1) / BP;
   int gy = (P.N + BN - 1) / BN;
   LY_CHECK(gx < (1L << 30), "gemm: too many pixel tiles");
-  if (BK == 64 && g_gemm_d2 && !g_gemm_dbg) return launch_gemm_d2<NT, MT, WC, GATHER, PRO>(P, st);
+  // the A/B variants (one-deep, 128-wide K stage, ablation switches) are built for the three tile shapes the heuristic
+  // picks; a tile shape forced through ly_debug_set_gemm_cfg always runs the production (two-deep) kernel
+  constexpr bool variants = (NT == 4 && MT == 2 && WC == 4) || (NT == 4 && MT == 1 && WC == 4) || (NT == 2 && MT == 2 && WC == 1);
+  if (!variants || (BK == 64 && g_gemm_d2 && !g_gemm_dbg)) return launch_gemm_d2<NT, MT, WC, GATHER, PRO>(P, st);
+  if constexpr (variants) {
   auto k = BK == 128 ? ly_gemm_kernel_k128<NT, MT, WC, GATHER, PRO> : ly_gemm_kernel<NT, MT, WC, GATHER, PRO>;
   static int per_cu = 0;            // co-resident blocks per CU (registers + LDS), measured once per instantiation
   if (per_cu == 0) {
@@ -700,19 +704,21 @@ static int launch_gemm_bk(const LyGemmParams& P, hipStream_t st) {
   if (g_gemm_dbg && BK == 64) {
     auto kd = ly_gemm_kernel_dbg<NT, MT, WC, GATHER, PRO>;
     static bool attr = false;
-    if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(kd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)); attr = true; }
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)); attr = true; }
     hipLaunchKernelGGL(kd, dim3((unsigned)(nslots * gy)), dim3(LY_THREADS), lds, st, P, gy, (int)nslots, (int)gx, g_gemm_dbg);
   } else {
     hipLaunchKernelGGL(k, dim3((unsigned)(nslots * gy)), dim3(LY_THREADS), lds, st, P, gy, (int)nslots, (int)gx, 0);
   }
   LY_LAUNCH_CHECK();
+  }
   return 0;
 }
 
 template <int NT, int MT, int WC, int GATHER, int PRO>
 static int launch_gemm_mode(const LyGemmParams& P, hipStream_t st) {
   constexpr int BP = 16 * NT * (4 / WC);
-  constexpr bool can128 = BP * 32 % LY_THREADS == 0 && BP * 32 / LY_THREADS >= 1 && GATHER != LY_GATHER_PATCH_NCHW;
+  constexpr bool variants = (NT == 4 && MT == 2 && WC == 4) || (NT == 4 && MT == 1 && WC == 4) || (NT == 2 && MT == 2 && WC == 1);
+  constexpr bool can128 = variants && BP * 32 % LY_THREADS == 0 && BP * 32 / LY_THREADS >= 1 && GATHER != LY_GATHER_PATCH_NCHW;
   const bool want128 = g_gemm_bk == 128;
   if constexpr (can128) {
     if (want128) return launch_gemm_bk<NT, MT, WC, GATHER, PRO, 128>(P, st);

@@ -1,0 +1,434 @@
+#pragma once
+// Fused FasterNet MLPBlock forward (eval / folded-BN form), fp32 I/O, bf16x3 matrix math, gfx950.
+//
+//   y = x + W2 . relu( s * (W1 . [ pconv3x3(x[:, :C/4]) | x[:, C/4:] ]) + b )
+//
+// Replaces Partial_conv3.forward_split_cat + MLPBlock.forward (reference models/common.py:1432-1437,
+// 1478-1482): the split/cat copies, the 2C-wide hidden tensor and the BN/ReLU passes never touch HBM.
+// HBM traffic = x once + y once (+ a one-pixel-row halo of the first C/4 channels); the residual is
+// taken from the LDS copy of the tile.
+//
+// Block = 256 threads (4 waves) owns BP = 64*NT consecutive pixels of the flattened N*H*W index
+// (NHWC rows, so its input tile is one contiguous span of memory).  The tile is split once into
+// bf16 hi/lo planes in LDS (ly_tile.cuh).  Each wave owns 16*NT pixels and carries them through all
+// three contractions:
+//   1. partial 3x3 conv as an implicit GEMM over K = 9 * ceil4(C/4): operands are 8-byte gathers from
+//      a halo image (ps) of the first C/4 channels with per-tap border masks; the result overwrites
+//      channels [0, C/4) of the wave's own rows of the tile (the "concat" is a no-op).
+//   2. hidden = relu(bn(W1 . row)), HT hidden tiles at a time, kept in registers.
+//   3. out += W2[:, hidden pair] . hidden -- two fp32 D tiles of step 2, split in registers, ARE the
+//      B operand of one k-step (ly_tile.cuh), so the hidden activations never leave the register file.
+#include "ly_tile.cuh"
+
+template <int C>
+struct MlpGeom {
+  static constexpr int CQ = C / 4;
+  static constexpr int CQP = (CQ + 3) / 4 * 4;
+  static constexpr int G = CQP / 4;                 // 4-channel groups per tap
+  static constexpr int SP = (9 * G + 7) / 8;        // pconv k-steps (8 groups each)
+  static constexpr int PT = (CQ + 15) / 16;         // pconv output tiles
+  static constexpr int C16 = (C + 15) / 16;         // output tiles
+  static constexpr int KP = (C + 31) / 32 * 32;
+  static constexpr int S1 = KP / 32;                // GEMM1 k-steps
+  static constexpr int RS = 2 * KP + 16;            // xs row stride (bytes)
+  static constexpr int RSP = 2 * CQP + 8;           // ps row stride (bytes)
+  static constexpr int HTP = (2 * C / 16 + 1) / 2 * 2;   // hidden tiles, padded to even
+  static constexpr int S2 = HTP / 2;                // GEMM2 k-steps
+};
+
+// Weight fragments are NOT staged in LDS (the three packed arrays of one block are up to 470 KB); every wave streams them from
+// L2 in the fixed order it consumes them.  Left to the compiler each 2 KB fragment is loaded and waited for right before its
+// three MFMAs (vmcnt(0) after every pair of loads: ~0.3 us of exposed L2 latency per fragment, 236 fragments at C=160), so the
+// stream is software-pipelined by hand: a ring of D fragments is kept in flight, slot g % D is refilled with fragment g + D
+// as soon as fragment g's MFMAs are issued.  All loops are fully unrolled, so g and the slot index are compile-time constants.
+// D = 0: no ring (loads where they are used; fewer registers, more co-resident waves -- the better trade for the narrow,
+// memory-heavy stages).
+template <int C, int NT, int HT, bool T2D, bool STATS, int D>
+__device__ __forceinline__ void ly_mlpblock_body(
+    const float* __restrict__ x, float* __restrict__ y, long M, int H, int W,
+    const uint4* __restrict__ wp, const uint4* __restrict__ w1, const uint4* __restrict__ w2,
+    const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, float* __restrict__ stats, const int dbg) {
+  using Gm = MlpGeom<C>;
+  constexpr int CQ = Gm::CQ, G = Gm::G, SP = Gm::SP, PT = Gm::PT, C16 = Gm::C16, KP = Gm::KP, S1 = Gm::S1;
+  constexpr int RS = Gm::RS, RSP = Gm::RSP, HTP = Gm::HTP, S2 = Gm::S2;
+  constexpr int BP = 64 * NT;
+  static_assert(HTP % HT == 0 && HT % 2 == 0, "hidden tiles must split evenly into even chunks");
+  static_assert(C % 8 == 0, "C must be a multiple of 8");
+
+  // Two tilings of the pixel index space:
+  //  * T2D (W % 16 == 0): a block owns a TH x 16 patch (TH = 4*NT rows, one MFMA pixel tile per row);
+  //    the halo is the (TH+2) x 18 frame with out-of-image positions staged as zeros, so the partial
+  //    conv needs no border masks and tap offsets are compile-time constants.
+  //  * flattened run: BP consecutive pixels of the N*H*W index (any W, tiles may span images); halo =
+  //    the run extended by W+1 pixels on both sides, border taps masked per lane.
+  constexpr int TH = 4 * NT;
+  extern __shared__ f32x4 ly_smem4[];
+  char* xs_hi = reinterpret_cast<char*>(ly_smem4);
+  char* xs_lo = xs_hi + BP * RS;
+  const int BPH = T2D ? (TH + 2) * 18 : BP + 2 * W + 2;
+  char* ps_hi = xs_lo + BP * RS;
+  char* ps_lo = ps_hi + BPH * RSP;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lq = lane >> 4;
+  const f32x4 zero = ly_zero4();
+
+  // the fragment stream: partial conv (k-step major), then per hidden chunk GEMM1 (k-step major) and, unless this is the
+  // statistics pass, GEMM2 (hidden pair major)
+  constexpr int FP = SP * PT, F1 = S1 * HT, F2 = STATS ? 0 : (HT / 2) * C16, FQ = F1 + F2, NFRAG = FP + (HTP / HT) * FQ;
+  auto wseq = [&](int g) -> LyWFrag {
+    if (g < FP) return ly_wfrag(wp, (g % PT) * SP + g / PT, lane);
+    g -= FP;
+    const int chunk = g / FQ, r = g - chunk * FQ;
+    if (r < F1) return ly_wfrag(w1, (chunk * HT + r % HT) * S1 + r / HT, lane);
+    const int r2 = r - F1;
+    return ly_wfrag(w2, (r2 % C16) * S2 + chunk * (HT / 2) + r2 / C16, lane);
+  };
+  LyWFrag ring[D > 0 ? D : 1];
+#pragma unroll
+  for (int g = 0; g < D; ++g)
+    if (g < NFRAG) ring[g] = wseq(g);
+  int g = 0;                   // fragments consumed so far (a constant at every use after unrolling)
+  auto wnext = [&]() -> LyWFrag {
+    if constexpr (D == 0) return wseq(g);
+    else return ring[g % D];
+  };
+  auto wrefill = [&]() {
+    if constexpr (D > 0) {
+      if (g + D < NFRAG) ring[g % D] = wseq(g + D);
+      __builtin_amdgcn_sched_barrier(0x786);   // neither loads nor MFMAs may move across: the refills stay D fragments ahead
+    }
+    ++g;
+  };
+  if (C >= 80) {     // large weight sets, few pixels: warm L2 with all three packed weight arrays
+    float* const sink = stats ? stats : y;
+    ly_l2_warm(w1, (long)HTP * S1 * 2048, sink);
+    ly_l2_warm(w2, (long)C16 * S2 * 2048, sink);
+    ly_l2_warm(wp, (long)PT * SP * 2048, sink);
+  }
+  long p0 = 0;                 // flattened: first pixel of the run
+  long img0 = 0;               // T2D: pixel index of (n, 0, 0)
+  int h0 = 0, w0 = 0;          // T2D: patch origin
+  if (T2D) {
+    const int tw = W >> 4, th = (H + TH - 1) / TH;
+    int b = blockIdx.x;
+    const int tx = b % tw; b /= tw;
+    const int ty = b % th;
+    img0 = (long)(b / th) * H * W;
+    h0 = ty * TH; w0 = tx * 16;
+  } else {
+    p0 = (long)blockIdx.x * BP;
+  }
+  // global pixel index of tile-local pixel `pix` (or -1)
+  auto gpix = [&](int pix) -> long {
+    if (T2D) {
+      const int r = pix >> 4;
+      return (h0 + r < H) ? img0 + (long)(h0 + r) * W + w0 + (pix & 15) : -1;
+    }
+    const long gp = p0 + pix;
+    return gp < M ? gp : -1;
+  };
+
+  ly_stage_f4<8>(BP * (KP / 4), tid, x,
+      [&](int idx) -> const float* {
+        const int pix = idx / (KP / 4), c4 = idx - pix * (KP / 4);
+        const long gp = gpix(pix);
+        return (gp >= 0 && c4 * 4 < C) ? x + gp * C + c4 * 4 : nullptr;
+      },
+      [&](int idx, f32x4 v) {
+        const int pix = idx / (KP / 4), c4 = idx - pix * (KP / 4);
+        ly_lds_put4(xs_hi, xs_lo, pix * RS, 4 * c4, v);
+      });
+  if (!(dbg & 4)) ly_stage_f4<4>(BPH * G, tid, x,
+      [&](int idx) -> const float* {
+        const int hp = idx / G, c4 = idx - hp * G;
+        long gp;
+        if (T2D) {
+          const int hr = hp / 18, hc = hp - hr * 18;
+          const int hh = h0 - 1 + hr, ww = w0 - 1 + hc;
+          gp = (hh >= 0 && hh < H && ww >= 0 && ww < W) ? img0 + (long)hh * W + ww : -1;
+        } else {
+          gp = p0 - W - 1 + hp;
+          if (gp >= M) gp = -1;
+        }
+        return gp >= 0 ? x + gp * C + c4 * 4 : nullptr;
+      },
+      [&](int idx, f32x4 v) {
+        const int hp = idx / G, c4 = idx - hp * G;
+        ly_lds_put4(ps_hi, ps_lo, hp * RSP, 4 * c4, v);
+      });
+  __syncthreads();
+
+  const int pixbase = wave * (16 * NT);
+  const bf16x4 z4 = __builtin_bit_cast(bf16x4, make_uint2(0u, 0u));
+
+  // ---- 1. partial 3x3 conv -------------------------------------------------------------------
+  {
+    uint32_t tmask[NT];
+    int pbase[NT];             // byte offset of the (ty=0, tx=0) tap of this lane's pixel in the halo image
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int pix = pixbase + 16 * n + li;
+      if (T2D) {
+        tmask[n] = 0x1ffu;                                   // zeros are staged for out-of-image taps
+        pbase[n] = ((pix >> 4) * 18 + (pix & 15)) * RSP;
+      } else {
+        const long gp = p0 + pix;
+        int h_, w_;
+        ly_pix_hw(gp, H, W, h_, w_);
+        tmask[n] = ly_tapmask(h_, w_, H, W, gp < M);
+        pbase[n] = pix * RSP;
+      }
+    }
+    const int rowpitch = T2D ? 18 : W;                       // halo-image pixels per image row
+    f32x4 accp[PT][NT];
+#pragma unroll
+    for (int t = 0; t < PT; ++t)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) accp[t][n] = zero;
+
+#pragma unroll
+    for (int s = 0; s < SP; ++s) {
+      int off[2], tap[2];
+      bool gv[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int g = 8 * s + 4 * h + lq;
+        gv[h] = g < 9 * G;
+        tap[h] = gv[h] ? g / G : 0;
+        const int cq4 = gv[h] ? g - tap[h] * G : 0;
+        const int ty = tap[h] / 3, tx = tap[h] - 3 * ty;
+        off[h] = (ty * rowpitch + tx) * RSP + 8 * cq4;
+      }
+      bf16x8 xh[NT], xl[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int rb = pbase[n];
+        bf16x4 ph[2], pl[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const bool ok = gv[h] && (T2D || ((tmask[n] >> tap[h]) & 1u));
+          const bf16x4 a = *reinterpret_cast<const bf16x4*>(ps_hi + rb + off[h]);
+          const bf16x4 b = *reinterpret_cast<const bf16x4*>(ps_lo + rb + off[h]);
+          ph[h] = ok ? a : z4;
+          pl[h] = ok ? b : z4;
+        }
+        xh[n] = ly_cat8(ph[0], ph[1]);
+        xl[n] = ly_cat8(pl[0], pl[1]);
+      }
+#pragma unroll
+      for (int t = 0; t < PT; ++t) {
+        const LyWFrag wf = wnext();
+#pragma unroll
+        for (int n = 0; n < NT; ++n) accp[t][n] = ly_mfma3(wf.hi, wf.lo, xh[n], xl[n], accp[t][n]);
+        wrefill();
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < PT; ++t)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        bf16x4 h, l;
+        ly_split4(accp[t][n], h, l);
+        const int c = 16 * t + 4 * lq;
+        const int rb = (pixbase + 16 * n + li) * RS + 2 * c;
+        if (c < CQ) {            // CQ is even: channels (c, c+1) are valid together
+          *reinterpret_cast<bf16x2*>(xs_hi + rb) = __builtin_shufflevector(h, h, 0, 1);
+          *reinterpret_cast<bf16x2*>(xs_lo + rb) = __builtin_shufflevector(l, l, 0, 1);
+        }
+        if (c + 2 < CQ) {
+          *reinterpret_cast<bf16x2*>(xs_hi + rb + 4) = __builtin_shufflevector(h, h, 2, 3);
+          *reinterpret_cast<bf16x2*>(xs_lo + rb + 4) = __builtin_shufflevector(l, l, 2, 3);
+        }
+      }
+  }
+
+  // ---- 2 + 3. expand -> BN -> ReLU -> project, hidden kept in registers ---------------------------
+  f32x4 acco[C16][NT];
+#pragma unroll
+  for (int t = 0; t < C16; ++t)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acco[t][n] = zero;
+
+#pragma unroll
+  for (int hc = 0; hc < HTP / HT; ++hc) {
+    f32x4 acch[HT][NT];
+#pragma unroll
+    for (int t = 0; t < HT; ++t)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acch[t][n] = zero;
+#pragma unroll
+    for (int s = 0; s < S1; ++s) {
+      bf16x8 xh[NT], xl[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int rb = (pixbase + 16 * n + li) * RS;
+        xh[n] = ly_lds_frag(xs_hi, rb, s, lq);
+        xl[n] = ly_lds_frag(xs_lo, rb, s, lq);
+      }
+#pragma unroll
+      for (int t = 0; t < HT; ++t) {
+        const LyWFrag wf = wnext();
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acch[t][n] = ly_mfma3(wf.hi, wf.lo, xh[n], xl[n], acch[t][n]);
+        wrefill();
+      }
+    }
+    if (STATS) {
+      // statistics pass of train-mode BatchNorm: sum / sum of squares of the pre-BN hidden activations
+      // over the valid pixels of this block; nothing else is computed or stored
+#pragma unroll
+      for (int t = 0; t < HT; ++t) {
+        f32x4 s1 = zero, s2 = zero;
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          if (gpix(pixbase + 16 * n + li) >= 0) {
+            s1 += acch[t][n];
+            s2 += acch[t][n] * acch[t][n];
+          }
+        ly_stats_flush(stats, HTP * 16, (hc * HT + t) * 16 + 4 * lq, s1, s2);
+      }
+      continue;
+    }
+    bf16x4 hh[HT][NT], hl[HT][NT];
+#pragma unroll
+    for (int t = 0; t < HT; ++t) {
+      const int ch = (hc * HT + t) * 16 + 4 * lq;
+      const f32x4 sc = ly_ldg4(bn_scale + ch), sh = ly_ldg4(bn_shift + ch);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        f32x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(acch[t][n][r] * sc[r] + sh[r], 0.f);
+        ly_split4(v, hh[t][n], hl[t][n]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < HT / 2; ++u) {
+      bf16x8 xh[NT], xl[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        xh[n] = ly_cat8(hh[2 * u][n], hh[2 * u + 1][n]);
+        xl[n] = ly_cat8(hl[2 * u][n], hl[2 * u + 1][n]);
+      }
+#pragma unroll
+      for (int ct = 0; ct < C16; ++ct) {
+        const LyWFrag wf = wnext();
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acco[ct][n] = ly_mfma3(wf.hi, wf.lo, xh[n], xl[n], acco[ct][n]);
+        wrefill();
+      }
+    }
+  }
+
+  if (STATS) return;
+  // ---- epilogue: residual + store ------------------------------------------------------------
+  // The residual x is rebuilt from the bf16 hi/lo planes already in LDS (|err| <= 2^-17 |x|) instead
+  // of re-reading global memory: channels < CQP from the halo image's centre tap (the tile's own
+  // copy of those channels was overwritten by the partial conv), the rest from the tile.
+#pragma unroll
+  for (int ct = 0; ct < C16; ++ct)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int c = 16 * ct + 4 * lq;
+      const int pix = pixbase + 16 * n + li;
+      const long gp = gpix(pix);
+      if (c < C && gp >= 0) {
+        bf16x4 rh, rl;
+        if (c < Gm::CQP) {
+          const int rb = (T2D ? (((pix >> 4) + 1) * 18 + (pix & 15) + 1) : (pix + W + 1)) * RSP + 2 * c;
+          rh = *reinterpret_cast<const bf16x4*>(ps_hi + rb);
+          rl = *reinterpret_cast<const bf16x4*>(ps_lo + rb);
+        } else {
+          const int rb = pix * RS + 2 * c;
+          rh = *reinterpret_cast<const bf16x4*>(xs_hi + rb);
+          rl = *reinterpret_cast<const bf16x4*>(xs_lo + rb);
+        }
+        const f32x4 r = __builtin_convertvector(rh, f32x4) + __builtin_convertvector(rl, f32x4);
+        if (!(dbg & 8)) ly_stg4(y + gp * C + c, acco[ct][n] + r);
+      }
+    }
+}
+
+template <int C, int NT, int HT, bool T2D, bool STATS>
+__global__ __launch_bounds__(LY_THREADS) void ly_mlpblock_fwd_kernel(
+    const float* __restrict__ x, float* __restrict__ y, long M, int H, int W,
+    const uint4* __restrict__ wp, const uint4* __restrict__ w1, const uint4* __restrict__ w2,
+    const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, float* __restrict__ stats, const int dbg) {
+  ly_mlpblock_body<C, NT, HT, T2D, STATS, 0>(x, y, M, H, W, wp, w1, w2, bn_scale, bn_shift, stats, dbg);
+}
+
+template <int C, int NT, int HT, bool T2D, bool STATS>
+__global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2))) void ly_mlpblock_fwd_ring_kernel(
+    const float* __restrict__ x, float* __restrict__ y, long M, int H, int W,
+    const uint4* __restrict__ wp, const uint4* __restrict__ w1, const uint4* __restrict__ w2,
+    const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, float* __restrict__ stats, const int dbg) {
+  ly_mlpblock_body<C, NT, HT, T2D, STATS, 8>(x, y, M, H, W, wp, w1, w2, bn_scale, bn_shift, stats, dbg);
+}
+
+// The instantiations are split over three translation units (ly_mlpblock.hip: C = 16/24/40 + the C ABI, ly_mlpblock_b.hip:
+// C = 80/160, ly_mlpblock_c.hip: C = 320) only to keep the in-tree build short; the tuning switches live in ly_mlpblock.hip.
+extern int g_mlp_tile;      // tuning aid: 1 = force the flattened-run tiling, 2 / 4 / 8 = flattened with 2 / 4 / 1 pixel tiles per wave
+extern int g_mlp_dbg;       // ablation aid: 4 skip halo staging, 8 skip stores
+#define LY_MLP_ARGS const float* x, float* y, long M, int n_img, int H, int W, const void* wp, const void* w1, const void* w2, \
+                    const float* s, const float* b, float* stats, hipStream_t st
+int ly_mlp_dispatch_80(LY_MLP_ARGS);
+int ly_mlp_dispatch_160(LY_MLP_ARGS);
+int ly_mlp_dispatch_320(LY_MLP_ARGS);
+
+template <int C, int NT, int HT, bool T2D, bool STATS, bool RING>
+static int launch_mlp_k(const float* x, float* y, long M, int n_img, int H, int W, const void* wp, const void* w1, const void* w2,
+                      const float* s, const float* b, float* stats, hipStream_t st) {
+  using Gm = MlpGeom<C>;
+  constexpr int BP = 64 * NT;
+  const long halo = T2D ? (4 * NT + 2) * 18 : BP + 2 * W + 2;
+  size_t lds = 2 * ((size_t)BP * Gm::RS + (size_t)halo * Gm::RSP);
+  LY_CHECK(lds <= 160 * 1024, "mlpblock: tile needs %zu B of LDS (C=%d W=%d)", lds, C, W);
+  void (*k)(const float*, float*, long, int, int, const uint4*, const uint4*, const uint4*, const float*, const float*, float*, int);
+  if constexpr (RING) k = ly_mlpblock_fwd_ring_kernel<C, NT, HT, T2D, STATS>;
+  else k = ly_mlpblock_fwd_kernel<C, NT, HT, T2D, STATS>;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+    LY_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    configured = true;
+  }
+  long blocks = T2D ? (long)n_img * ((H + 4 * NT - 1) / (4 * NT)) * (W / 16) : (M + BP - 1) / BP;
+  hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(LY_THREADS), lds, st, x, y, M, H, W, reinterpret_cast<const uint4*>(wp),
+                     reinterpret_cast<const uint4*>(w1), reinterpret_cast<const uint4*>(w2), s, b, stats, g_mlp_dbg);
+  LY_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int C, int NT, int HT, bool T2D>
+static int launch_mlp(const float* x, float* y, long M, int n_img, int H, int W, const void* wp, const void* w1, const void* w2,
+                      const float* s, const float* b, float* stats, hipStream_t st) {
+  constexpr bool RING = C >= 80;
+  if (stats) return launch_mlp_k<C, NT, HT, T2D, true, RING>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
+  return launch_mlp_k<C, NT, HT, T2D, false, RING>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
+}
+
+// Tiling policy (tools/mlp_ablate.py, kernel time at bs=32 / 64):
+//  * C < 80 (wide maps, few weights; HBM-heavy): 2-D patches (8 x 16 px per block: small halo, 4+ co-resident blocks per CU)
+//    where the map is wide and a multiple of 16; flattened runs otherwise, with as many pixel tiles per wave as still fill
+//    the chip.  No fragment ring: it costs the co-residency these stages live on (C=24: 64 -> 69 us with it).
+//  * C >= 80 (small maps, 134-470 KB of weights per block; bound by streaming the fragments from L2): ring kernel, and two
+//    pixel tiles per wave -- half the fragment traffic per pixel -- as soon as that still leaves >= 200 blocks
+//    (C=80 @ 40x40x32: 26.5 -> 20.7 us; C=160 @ 20x20: 22.6 us with one tile at bs=32, 38.4 -> 28.8 us with two at bs=64).
+template <int C, int HT, int NTMAX>
+static int dispatch_nt(const float* x, float* y, long M, int n_img, int H, int W, const void* wp, const void* w1, const void* w2,
+                       const float* s, const float* b, float* stats, hipStream_t st) {
+  constexpr int NT2 = NTMAX >= 2 ? 2 : NTMAX, NT4 = NTMAX >= 4 ? 4 : NTMAX;
+  if (g_mlp_tile == 4) return launch_mlp<C, NT4, HT, false>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
+  if (g_mlp_tile == 2) return launch_mlp<C, NT2, HT, false>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
+  if (g_mlp_tile == 8) return launch_mlp<C, 1, HT, false>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
+  if (C >= 80) {
+    if (NTMAX >= 2 && M >= 200L * 128) return launch_mlp<C, NT2, HT, false>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
+    return launch_mlp<C, 1, HT, false>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
+  }
+  if ((W & 15) == 0 && W >= 64 && NTMAX >= 2 && g_mlp_tile == 0) return launch_mlp<C, 2, HT, true>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
+  if (NTMAX >= 4 && M >= 256L * 1024) return launch_mlp<C, NT4, HT, false>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
+  if (NTMAX >= 2 && M >= 128L * 512) return launch_mlp<C, NT2, HT, false>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
+  return launch_mlp<C, 1, HT, false>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
+}
+

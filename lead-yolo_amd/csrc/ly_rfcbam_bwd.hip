@@ -149,21 +149,35 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_attn_kernel(const RfGeom
       dca = 0.f; cur_n = n;
       cav = ca[(long)n * g.C + c];
     }
+    // all KK taps of the pixel are requested before any of them is used (18 independent loads in flight per lane; loaded and
+    // consumed tap by tap, every tap was a full memory round trip: the atomics' branch makes the waits conservative)
+    long pos[KK];
+    float uv[KK], dv_[KK], rv[KK];
 #pragma unroll
     for (int t = 0; t < KK; ++t) {
       const long idx = (m * KK + t) * g.C + c;
-      const long pos = rf_pos<K>(g, n, ho, wo, t);
-      const float r = rfa[pos];
-      float G = fmaxf(__fmaf_rn(a[t], ug[idx], b[t]), 0.f);
-      float d = dcd[idx];
+      pos[t] = rf_pos<K>(g, n, ho, wo, t);
+      uv[t] = ug[idx];
+      dv_[t] = dcd[idx];
+      rv[t] = rfa[pos[t]];
+    }
+    float pr[KK], mx[KK];
+#pragma unroll
+    for (int t = 0; t < KK; ++t) {
+      const long idx = (m * KK + t) * g.C + c;
+      float G = fmaxf(__fmaf_rn(a[t], uv[t], b[t]), 0.f);
+      float d = dv_[t];
       if (!cok) { G = 0.f; d = 0.f; }
-      if (cok) cd[idx] = G * cav * r;
-      dca += d * r * G;
-      const float pr = rf_wave_sum(d * G * cav);
-      const float mx = rf_wave_max(G);
-      if (lane == 0) {
-        atomicAdd(d_rfa + pos, pr);
-        atomicMax(reinterpret_cast<unsigned int*>(gmax) + pos, __float_as_uint(mx));
+      if (cok) cd[idx] = G * cav * rv[t];
+      dca += d * rv[t] * G;
+      pr[t] = rf_wave_sum(d * G * cav);
+      mx[t] = rf_wave_max(G);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int t = 0; t < KK; ++t) {
+        atomicAdd(d_rfa + pos[t], pr[t]);
+        atomicMax(reinterpret_cast<unsigned int*>(gmax) + pos[t], __float_as_uint(mx[t]));
       }
     }
   }
@@ -235,19 +249,33 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_relu_kernel(const RfGeom
       int n, ho, wo;
       rf_pix(g, m, n, ho, wo);
       const float cav = ca[(long)n * g.C + c];
+      // loads of all KK taps first, stores last: dcd is updated in place, so a load placed after a store cannot be hoisted
+      // above it by the compiler and every tap would wait for its own round trip
+      long pos[KK];
+      float u[KK], dc[KK], rv[KK], gm[KK], dm0[KK], dm1[KK];
 #pragma unroll
       for (int t = 0; t < KK; ++t) {
         const long idx = (m * KK + t) * g.C + c;
-        const long pos = rf_pos<K>(g, n, ho, wo, t);
-        const float u = ug[idx];
-        const float G = fmaxf(__fmaf_rn(a[t], u, b[t]), 0.f);
-        float dG = dcd[idx] * rfa[pos] * cav + d_mm[2 * pos + 1] * invC;
-        if (G == gmax[pos]) dG += d_mm[2 * pos];
-        const float dv = G > 0.f ? dG : 0.f;
-        dcd[idx] = dv;
-        s1[t] += dv;
-        s2[t] += dv * u;
+        pos[t] = rf_pos<K>(g, n, ho, wo, t);
+        u[t] = ug[idx];
+        dc[t] = dcd[idx];
+        rv[t] = rfa[pos[t]];
+        gm[t] = gmax[pos[t]];
+        dm0[t] = d_mm[2 * pos[t]];
+        dm1[t] = d_mm[2 * pos[t] + 1];
       }
+      float dvv[KK];
+#pragma unroll
+      for (int t = 0; t < KK; ++t) {
+        const float G = fmaxf(__fmaf_rn(a[t], u[t], b[t]), 0.f);
+        float dG = dc[t] * rv[t] * cav + dm1[t] * invC;
+        if (G == gm[t]) dG += dm0[t];
+        dvv[t] = G > 0.f ? dG : 0.f;
+        s1[t] += dvv[t];
+        s2[t] += dvv[t] * u[t];
+      }
+#pragma unroll
+      for (int t = 0; t < KK; ++t) dcd[(m * KK + t) * g.C + c] = dvv[t];
     }
   if (cok) {
     const int CK = g.C * KK;
@@ -278,14 +306,22 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_gen_kernel(const RfGeom 
       rf_pix(g, m, n, ho, wo);
       float xt[KK];
       rf_taps<K>(x, ldx, g, n, ho, wo, c, xt);
+      float dvl[KK], ugl[KK];              // loads first, in-place stores last (see ly_rf_bwd_relu_kernel)
 #pragma unroll
       for (int t = 0; t < KK; ++t) {
         const long idx = (m * KK + t) * g.C + c;
-        const float d = al[t] * dv[idx] + ka[t] + la[t] * ug[idx];
-        dv[idx] = d;
+        dvl[t] = dv[idx];
+        ugl[t] = ug[idx];
+      }
+#pragma unroll
+      for (int t = 0; t < KK; ++t) {
+        const float d = al[t] * dvl[t] + ka[t] + la[t] * ugl[t];
+        dvl[t] = d;
 #pragma unroll
         for (int u = 0; u < KK; ++u) acc[t * KK + u] += d * xt[u];
       }
+#pragma unroll
+      for (int t = 0; t < KK; ++t) dv[(m * KK + t) * g.C + c] = dvl[t];
     }
   if (cok) {
     // every (block, pixel sub-group) owns one row of the partial-sum matrix: plain stores, no atomics (81 accumulators per
@@ -297,6 +333,44 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_gen_kernel(const RfGeom 
 }
 
 // ---- dx ----------------------------------------------------------------------------------------
+// stride 2, k = 3, pad 1 (both k=3 layers of LEAD-YOLO): which taps u = (uy, ux) read input pixel (hi, wi) depends only on the
+// parities PY = (hi+1)&1, PX = (wi+1)&1 -- uy in {0, 2} when hi+1 is even, uy = 1 otherwise -- so each parity class has a
+// compile-time tap list (4 / 2 / 2 / 1 output pixels).  All their 9-tap rows are requested before the first is used; edge
+// positions read row 0 and are masked.  (Tap by tap behind `continue`s, every row was its own memory round trip.)
+template <int PY, int PX>
+__device__ __forceinline__ float rf_dx_s2(const RfGeom& g, const float* __restrict__ dug, const float (&w)[81], int n, int hi, int wi, int c) {
+  constexpr int NY = PY ? 1 : 2, NX = PX ? 1 : 2;
+  float v[NY][NX][9];
+  bool ok[NY][NX];
+#pragma unroll
+  for (int jy = 0; jy < NY; ++jy) {
+    const int uy = PY ? 1 : 2 * jy;
+    const int hh = hi + 1 - uy, ho = hh >> 1;
+    const bool oky = hh >= 0 && ho < g.Ho;
+#pragma unroll
+    for (int jx = 0; jx < NX; ++jx) {
+      const int ux = PX ? 1 : 2 * jx;
+      const int ww = wi + 1 - ux, wo = ww >> 1;
+      ok[jy][jx] = oky && ww >= 0 && wo < g.Wo;
+      const long m = ok[jy][jx] ? ((long)n * g.Ho + ho) * g.Wo + wo : 0;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) v[jy][jx][t] = dug[(m * 9 + t) * g.C + c];
+    }
+  }
+  float acc = 0.f;
+#pragma unroll
+  for (int jy = 0; jy < NY; ++jy)
+#pragma unroll
+    for (int jx = 0; jx < NX; ++jx) {
+      const int u = (PY ? 1 : 2 * jy) * 3 + (PX ? 1 : 2 * jx);
+      float a = 0.f;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) a += v[jy][jx][t] * w[t * 9 + u];
+      acc += ok[jy][jx] ? a : 0.f;
+    }
+  return acc;
+}
+
 template <int K>
 __global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_dx_kernel(const RfGeom g, const float* __restrict__ dug, const float* __restrict__ wg,
                                                                   float* __restrict__ dx, int lddx) {
@@ -314,6 +388,17 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_dx_kernel(const RfGeom g
     const int n = (int)(row / g.H);
     const int hi = (int)(row - (long)n * g.H);
     float acc = 0.f;
+    if constexpr (K == 3) {
+      if (g.s == 2) {
+        const int py = (hi + 1) & 1, px = (wi + 1) & 1;      // uniform over the wave (all lanes share the pixel)
+        if (py == 0 && px == 0) acc = rf_dx_s2<0, 0>(g, dug, w, n, hi, wi, c);
+        else if (py == 0) acc = rf_dx_s2<0, 1>(g, dug, w, n, hi, wi, c);
+        else if (px == 0) acc = rf_dx_s2<1, 0>(g, dug, w, n, hi, wi, c);
+        else acc = rf_dx_s2<1, 1>(g, dug, w, n, hi, wi, c);
+        dx[p * lddx + c] = acc;
+        continue;
+      }
+    }
 #pragma unroll
     for (int uy = 0; uy < K; ++uy) {
       const int hh = hi + g.pad - uy;

@@ -217,6 +217,8 @@ typedef struct LyWgradParams {
   float* dw; int lddw;
 } LyWgradParams;
 int ly_wgrad(const LyWgradParams* p, void* stream);
+/* tuning aid: 1 = the 64 x 256 output tile for every N <= 64 shape (default: 32 x 128 / 64 x 128) */
+int ly_debug_set_wgrad_tile(int v);
 
 /* Adjoint of the nearest-2x read: out[n,h,w,:] = sum of d[n, 2h+{0,1}, 2w+{0,1}, :]  (d is a 2Hs x 2Ws map).      */
 int ly_up2_bwd(const float* d, int ldd, int n_img, int Hs, int Ws, int C, float* out, int ldo, void* stream);

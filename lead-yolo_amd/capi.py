@@ -65,6 +65,7 @@ SIGNATURES = {
     "ly_debug_set_stats3": [_I],
     "ly_debug_set_mlp": [_I],
     "ly_debug_set_mlp_tile": [_I],
+    "ly_debug_set_wgrad_tile": [_I],
     "ly_conv3x3_fwd": [ctypes.POINTER(LyConv3Params), _P],
     "ly_pool_hw": [_P, _I, _I, _I, _I, _I, _P, _P],
     "ly_coordatt_mlp": [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],

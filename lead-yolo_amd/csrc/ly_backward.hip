@@ -469,6 +469,9 @@ static int launch_wgrad_tiled(const LyWgradParams& Q, bool rows, hipStream_t st)
   return 0;
 }
 
+static int g_wgrad_tile = 0;   // tuning aid: 1 = the previous 64 x 256 tile for every N <= 64 shape
+extern "C" int ly_debug_set_wgrad_tile(int v) { g_wgrad_tile = v; return 0; }
+
 extern "C" int ly_wgrad(const LyWgradParams* p, void* stream) {
   LY_CHECK(p, "wgrad: null params");
   const LyWgradParams& P = *p;
@@ -484,8 +487,13 @@ extern "C" int ly_wgrad(const LyWgradParams* p, void* stream) {
     hipStream_t st2 = reinterpret_cast<hipStream_t>(stream);
     // skinny outputs (MLP blocks, patch layers at high resolution): few channel quads per pixel, so a step covers 64 pixels
     // to keep every thread loading; otherwise 32 pixels per step and wider channel tiles
+    // One step of a block is one memory round trip (prefetch one step ahead), so what matters for the skinny shapes is how many
+    // blocks a CU holds: the 64 x 256 tile's 92 KB of LDS meant ONE (N=8 K=72 M=1.6M: 690 -> 280 us, N=64 K=576: 538 -> 342 us,
+    // N=64 K=128 upsampled source: 271 -> 137 us with the tiles below; all wgrad launches of a bs=64 step 7.8 -> 6.5 ms).
     if (P.N <= 64 && Ktot <= 64) return launch_wgrad_tiled<64, 64, 64>(P, rows, st2);
-    if (P.N <= 64) return launch_wgrad_tiled<64, 256, 32>(P, rows, st2);
+    if (P.N <= 64 && g_wgrad_tile == 1) return launch_wgrad_tiled<64, 256, 32>(P, rows, st2);
+    if (P.N <= 32) return launch_wgrad_tiled<32, 128, 32>(P, rows, st2);      // 46 KB: three blocks per CU
+    if (P.N <= 64) return launch_wgrad_tiled<64, 128, 32>(P, rows, st2);      // 55 KB: two
     return launch_wgrad_tiled<128, 128, 32>(P, rows, st2);
   }
   const int tiles_n = (P.N + 63) / 64, tiles_k = (Ktot + 63) / 64;

@@ -97,7 +97,8 @@ def affine_backward(dy, u, a, b, act, mean, invstd, train, inplace=True):
 
 
 def conv_wgrad(spec, du, x0, x1, weight):
-    """Weight gradient in the shape of `weight`.  du: NHWC-dense [n, cout, ho, wo]."""
+    """Weight gradient in the shape of `weight`.  du: NHWC-dense [n, cout, ho, wo]; cout may be weight.shape[0] zero-padded to a
+    multiple of 4 (Detect heads: 18 -> 20), which keeps the launch on the tiled kernel — the extra rows are dropped."""
     n, co, ho, wo = du.shape
     m = n * ho * wo
     if spec.kind == "pw":
@@ -110,7 +111,7 @@ def conv_wgrad(spec, du, x0, x1, weight):
         if x1 is not None:
             t1, ld1 = ops.rows(x1)
             ops.wgrad(M=m, H=ho, W=wo, N=co, du=du, lddu=co, x=t1, ldx=ld1, Hin=ho, Win=wo, Cin=t1.shape[1], dw=dw, lddw=k, dw_off=c0)
-        return dw.view(weight.shape)
+        return dw[:weight.shape[0]].view(weight.shape)
     if spec.kind == "c3":
         t0, ld0 = ops.rows(x0)
         c = t0.shape[1]
@@ -257,7 +258,7 @@ class ConvBnAct(torch.autograd.Function):
                 du_d = pad
             else:
                 du_d = du
-            dw = conv_wgrad(spec, du, x0, x1, weight) if need[4] else None
+            dw = conv_wgrad(spec, du_d if spec.kind == "pw" else du, x0, x1, weight) if need[4] else None
             dx0 = dx1 = None
             if need[2] or need[3]:
                 dspec = spec

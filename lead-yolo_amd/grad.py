@@ -120,11 +120,19 @@ def conv_wgrad(spec, du, x0, x1, weight):
         return dw.view(co, 3, 3, c).permute(0, 3, 1, 2).contiguous()
     _, c, h, w = x0.shape
     k = spec.k
-    dw = torch.zeros(co, k * k * c, dtype=torch.float32, device=du.device)
     if spec.nchw:
+        if h == ho * k and w == wo * k and (k * k * c) % 4 == 0 and co % 4 == 0:
+            # PatchEmbed on the NCHW image: one space-to-depth copy turns the k x k patch gather into plain rows [M, c*k*k] (the
+            # weight's own (c, ky, kx) column order), which the tiled kernel takes; the per-lane NCHW gather kernel was 3x slower
+            xr = x0.reshape(n, c, ho, k, wo, k).permute(0, 2, 4, 1, 3, 5).reshape(m, c * k * k)
+            dwr = torch.zeros(co, k * k * c, dtype=torch.float32, device=du.device)
+            ops.wgrad(M=m, H=ho, W=wo, N=co, du=du, lddu=co, x=xr, ldx=k * k * c, Hin=ho, Win=wo, Cin=k * k * c, dw=dwr, lddw=k * k * c)
+            return dwr.view(weight.shape)
+        dw = torch.zeros(co, k * k * c, dtype=torch.float32, device=du.device)
         xr = x0.contiguous()
         ops.wgrad(M=m, H=ho, W=wo, N=co, du=du, lddu=co, x=xr, ldx=0, Hin=h, Win=w, Cin=c, dw=dw, lddw=k * k * c, ks=k, stride=k, nchw=True)
     else:
+        dw = torch.zeros(co, k * k * c, dtype=torch.float32, device=du.device)
         xr = _rows_dense(x0)
         ops.wgrad(M=m, H=ho, W=wo, N=co, du=du, lddu=co, x=xr, ldx=c, Hin=h, Win=w, Cin=c, dw=dw, lddw=k * k * c, ks=k, stride=k)
     return dw.view(co, k, k, c).permute(0, 3, 1, 2).contiguous()

@@ -238,8 +238,50 @@ def chan_moments(x, ldx, rows, c):
 STRIPES = capi.STATS_STRIPES
 
 
+class _StatsPool:
+    """One zero fill per training step instead of one per BatchNorm pass (74 launches at lead-yolo-s): between
+    `stats_pool_begin` and `stats_pool_end` (train.train_step) `new_stats` hands out slices of one buffer that was zeroed at
+    `begin`.  Safe because a statistics accumulator is transient — written by one pass, read by the `ly_bn_finalize` /
+    `ly_bn_bwd_coeffs` launch right after it on the same stream, never saved — and the next `begin` (same stream) is ordered
+    after every reader.  Outside a begin/end pair, or when the buffer is too small (first step, a larger model), `new_stats`
+    falls back to its own `torch.zeros`; the demand seen in a step sizes the buffer of the next."""
+    buf = None
+    off = 0
+    used = 0
+    need = 0
+    active = False
+
+
+_POOL = _StatsPool()
+
+
+def stats_pool_begin(device):
+    p = _POOL
+    if p.buf is None or p.buf.device != device or p.buf.numel() < p.need:
+        p.buf = torch.zeros(max(p.need, 1), dtype=torch.float32, device=device) if p.need else None
+    elif p.buf is not None:
+        p.buf.zero_()
+    p.off = p.used = 0
+    p.active = True
+
+
+def stats_pool_end():
+    p = _POOL
+    p.active = False
+    p.need = max(p.need, p.used)
+
+
 def new_stats(nch, device):
     """zeroed striped accumulator for a statistics pass over `nch` channels: [STRIPES][2*nch] (see ly_bn_finalize)"""
+    p = _POOL
+    n = STRIPES * 2 * nch
+    if p.active:
+        span = (n + 63) // 64 * 64                  # 256-byte aligned slices
+        p.used += span
+        if p.buf is not None and p.buf.device == device and p.off + span <= p.buf.numel():
+            v = p.buf[p.off:p.off + n].view(STRIPES, 2 * nch)
+            p.off += span
+            return v
     return torch.zeros(STRIPES, 2 * nch, dtype=torch.float32, device=device)
 
 

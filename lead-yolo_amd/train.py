@@ -11,6 +11,7 @@ import math
 from copy import deepcopy
 
 import torch
+from . import ops
 import torch.nn as nn
 
 _NORMS = tuple(v for k, v in nn.__dict__.items() if "Norm" in k and isinstance(v, type))
@@ -67,11 +68,15 @@ def train_step(model, compute_loss, optimizer, imgs, targets, ema=None, reducer=
         imgs = imgs.float() / 255
     if reducer is not None:
         reducer.reset()
-    pred = model(imgs)
-    loss, items = compute_loss(pred, targets)
-    if world_size > 1:
-        loss = loss * world_size            # the reducer averages gradients (train.py:321-322)
-    loss.backward()
+    ops.stats_pool_begin(imgs.device)       # one zero fill for all BatchNorm accumulators of the step (ops._StatsPool)
+    try:
+        pred = model(imgs)
+        loss, items = compute_loss(pred, targets)
+        if world_size > 1:
+            loss = loss * world_size            # the reducer averages gradients (train.py:321-322)
+        loss.backward()
+    finally:
+        ops.stats_pool_end()
     if reducer is not None:
         reducer.wait()
     torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=max_norm)

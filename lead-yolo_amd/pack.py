@@ -23,6 +23,8 @@ def conv_taps_matrix(w4d, cin_pad_to=4):
     """[co, ci, kh, kw] -> [co, kh*kw*ci_p] with k = tap*ci_p + ci (tap = ky*kw + kx), ci zero-padded."""
     co, ci, kh, kw = w4d.shape
     cip = _ceil(ci, cin_pad_to) * cin_pad_to
+    if cip == ci:                                     # nothing to pad: one permuting copy, no fill
+        return w4d.permute(0, 2, 3, 1).float().reshape(co, kh * kw * ci)
     m = torch.zeros(co, kh, kw, cip, dtype=torch.float32, device=w4d.device)
     m[..., :ci] = w4d.permute(0, 2, 3, 1).float()
     return m.view(co, kh * kw * cip)

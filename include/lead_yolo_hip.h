@@ -101,7 +101,8 @@ typedef struct LyConv3Params {
 /* Conv(c1, c2, 3, 1) = conv3x3(no bias) + BN + SiLU (CA_Bottleneck.cv2, models/common.py:1617,
  * 1890-1910). */
 int ly_conv3x3_fwd(const LyConv3Params* p, void* stream);
-/* ablation aid for profiling (bit 0: skip weight loads, 1: skip LDS reads + MFMA, 2: skip prefetch, 3: skip commit) */
+/* ablation aid for profiling (bit 1: skip LDS reads + MFMA, 3: skip commit); the load switches (bits 0, 2) were removed:
+ * a load under a run-time branch makes the compiler drain the prefetch queue after every tap */
 int ly_debug_set_conv3(int v);
 /* tuning aid: force the wave layout (MT*10 + WC), 0 = heuristic */
 int ly_debug_set_conv3_cfg(int v);

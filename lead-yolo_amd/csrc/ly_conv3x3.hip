@@ -121,11 +121,13 @@ __global__ __launch_bounds__(LY_THREADS) void ly_conv3x3_kernel(const LyConv3Par
 
   for (int cc = 0; cc < C32; ++cc) {
     const bool more = cc + 1 < C32;
-    if (more && !(dbg & 4)) prefetch((cc + 1) * LY_CC);
+    // unconditional (the last chunk re-requests itself): a load under a branch makes the compiler drain the whole queue
+    // (s_waitcnt vmcnt(0)) after every tap, i.e. wait for this prefetch at tap 0 instead of hiding it behind nine taps of MFMAs
+    prefetch((more ? cc + 1 : cc) * LY_CC);
 #pragma unroll(MT * NTW <= 8 ? 1 : 9)
     for (int tap = 0; tap < 9; ++tap) {
       // next fragment: next tap of this chunk, or tap 0 of the next chunk (clamped at the very end)
-      if (!(dbg & 1)) {
+      {
         const int nt = tap < 8 ? tap + 1 : 0;
         const int nc = tap < 8 ? cc : (more ? cc + 1 : cc);
 #pragma unroll
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_conv3x3_kernel(const LyConv3Par
 
 static int g_c3_cfg = 0;
 extern "C" int ly_debug_set_conv3_cfg(int v) { g_c3_cfg = v; return 0; }
-static int g_c3_dbg = 0;    // ablation aid: 1 skip weight loads, 2 skip LDS reads + MFMA, 4 skip prefetch, 8 skip commit
+static int g_c3_dbg = 0;    // ablation aid: 2 skip LDS reads + MFMA, 8 skip commit
 extern "C" int ly_debug_set_conv3(int v) { g_c3_dbg = v; return 0; }
 
 template <int MT, int WC>

@@ -279,7 +279,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_stats3_kernel(const floa
     }
   };
   wprefetch(0);
-  if (!(dbg & 1)) prefetch(0);
+  prefetch(0);
 
   for (int c0 = 0; c0 < C; c0 += LY_SCC) {
     __syncthreads();
@@ -299,8 +299,8 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_stats3_kernel(const floa
           d[0] = ok ? pv[e][0] : 0.f; d[1] = ok ? pv[e][1] : 0.f; d[2] = ok ? pv[e][2] : 0.f; d[3] = ok ? pv[e][3] : 0.f;
         }
       }
-      prefetch(more ? c0 + LY_SCC : 0);
     }
+    prefetch(more ? c0 + LY_SCC : 0);      // unconditional: a load under a run-time branch makes every later wait conservative
     __syncthreads();
     if (!(dbg & 2)) {
       // inputs of this wave's 8 channels (c0 + wave + 4j) as 4 packed pairs (j = 2p, 2p+1), then the folded

@@ -112,7 +112,7 @@ __device__ __forceinline__ void ly_rfcbam3_body(const LyRfcbam3Params& P, const 
 #pragma unroll
   for (int q = 0; q < D; ++q) ring[q] = wfrag_at(0, q);
   wprefetch(0);
-  if (!(dbg & 4)) prefetch(0);
+  prefetch(0);
 
   for (int c0 = 0; c0 < P.C; c0 += LY_GCC) {
     __syncthreads();                      // previous chunk: generate done with xs, MFMAs done with gs
@@ -133,8 +133,9 @@ __device__ __forceinline__ void ly_rfcbam3_body(const LyRfcbam3Params& P, const 
           float* d = xs + doff[e];
           d[0] = ok ? pv[e][0] : 0.f; d[1] = ok ? pv[e][1] : 0.f; d[2] = ok ? pv[e][2] : 0.f; d[3] = ok ? pv[e][3] : 0.f;
         }
-      if (more) prefetch(c0 + LY_GCC);   // next chunk's input in flight during generate + MFMA
     }
+    prefetch(more ? c0 + LY_GCC : 0);    // next chunk's input in flight during generate + MFMA; unconditional (the last chunk
+                                         // re-requests chunk 0) so that the compiler's s_waitcnt counts stay exact
     __syncthreads();
     // ---- regenerate G' for channels c0 + 4*wave .. +3 -----------------------------------------------
     // inputs of the wave's 4 channels as 2 packed pairs (v_pk_fma_f32 does two channels per instruction).  The folded weights
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
   ly_rfcbam3_body<MT, true>(P, gy, nct, nrt, dbg);
 }
 
-static int g_rf3_dbg = 0;   // ablation aid: 1 skip regenerate, 2 generate weights through LDS regardless of the grid, 4 skip staging
+static int g_rf3_dbg = 0;   // ablation aid: 1 skip regenerate, 2 generate weights through LDS regardless of the grid, 4 skip the LDS staging writes
 static int g_rf3_mt2 = 0;   // (bit 3 of ly_debug_set_rf3) run N > 128 as two 128-channel groups (MT=2, two waves per SIMD) instead of the
                             // 256-channel MT=4 tile (296 registers, one wave per SIMD).  With the loads prefetched the regenerate phase
                             // is what the kernel waits for, and MT=4 runs it once per pixel tile instead of twice: 256->256 @ 40x40x32

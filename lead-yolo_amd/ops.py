@@ -222,7 +222,8 @@ def detect_tail(y, ldy, n, h, w, na, no, anchors, stride, p, z, zrows, zoff):
 def mlpblock(x, y, n, h, w, c, wp, w1, w2, sc, sh, stats=None):
     m = n * h * w
     cc, nt, ht, t2d = mlp_config(c, m, w)
-    name = f"ly_mlpblock_fwd{'_ring' if c >= 80 else ''}_kernel<{cc}, {nt}, {ht}, {t2d}, {'true' if stats is not None else 'false'}>"
+    kind = "_ring" if c >= 80 else "_occ4" if (c <= 24 and t2d == "true") else ""
+    name = f"ly_mlpblock_fwd{kind}_kernel<{cc}, {nt}, {ht}, {t2d}, {'true' if stats is not None else 'false'}>"
     with _Timed(name, 2.0 * m * (9 * (c // 4) ** 2 + 4 * c * c),
                 4.0 * (2 * m * c + 9 * (c // 4) ** 2 + 4 * c * c)):
         capi.check(capi.lib().ly_mlpblock_fwd(_p(x), _p(y), n, h, w, c, _p(wp), _p(w1), _p(w2), _p(sc), _p(sh), _p(stats), capi.stream_ptr()),

@@ -273,3 +273,54 @@ def test_graphed_forward_matches_eager():
             torch.cuda.synchronize()
             assert torch.equal(zg, ze)
             assert all(torch.equal(a, b) for a, b in zip(pg, pe))
+
+
+def test_rfcbam3_kernel_variants_agree():
+    """RFCBAMConv k=3 at a grid large enough for the 256-channel tile's scalar-cache weight path (more than one block per CU):
+    the launcher's choice, the LDS weight path (debug bit 1) and the two-128-channel-groups tiling (bit 3) are the same
+    arithmetic in the same order, so their outputs must be identical; and the result matches the oracle."""
+    from lead_yolo_amd import capi
+    kind, ctor, shape = "RFCBAMConv", (256, 256, 3, 2), (40, 256, 40, 40)      # 40 images x 7 row tiles = 280 blocks > 256 CUs
+    torch.manual_seed(0)
+    m = _ctor(kind)(*ctor)
+    st = synth.synth_state(synth.shapes_of(m.state_dict()), 9100)
+    _bn_eps(_load(m, st))
+    x = synth.synth_input(shape, 77)
+    want = _oracle(kind, list(ctor), st, x[:2])            # images are independent in eval mode: the oracle checks the first two
+    md = m.to(_dev()).eval()
+    xd = x.to(_dev())
+    outs = []
+    try:
+        for dbg in (0, 2, 8):
+            capi.lib().ly_debug_set_rf3(dbg)
+            with torch.no_grad():
+                outs.append(md(xd).float().cpu())
+    finally:
+        capi.lib().ly_debug_set_rf3(0)
+    assert torch.equal(outs[0], outs[1]), "scalar-cache and LDS weight paths differ"
+    assert torch.equal(outs[0], outs[2]), "256-channel tile and two 128-channel groups differ"
+    _cmp(outs[0][:2], want, "rfcbam3 256->256 s2, 40 images")
+
+
+@pytest.mark.parametrize("c,hw,bs", [(24, 160, 2), (40, 80, 3), (80, 40, 20), (160, 20, 40)])
+def test_mlpblock_tilings_agree(c, hw, bs):
+    """every pixel tiling of the MLPBlock kernel (8 x 16 patches, flattened runs with 1 / 2 / 4 tiles per wave; with and without
+    the weight-fragment ring) carries a pixel through the same arithmetic: outputs must be identical"""
+    import lead_yolo_amd as L
+    from lead_yolo_amd import capi
+    torch.manual_seed(c)
+    m = L.BasicStage(c, 1)
+    st = synth.synth_state(synth.shapes_of(m.state_dict()), 4200 + c)
+    _bn_eps(_load(m, st))
+    md = m.to(_dev()).eval()
+    x = synth.synth_input((bs, c, hw, hw), 5 + c).to(_dev())
+    outs = []
+    try:
+        for tile in (0, 8, 2, 4):
+            capi.lib().ly_debug_set_mlp_tile(tile)
+            with torch.no_grad():
+                outs.append(md(x).float().cpu())
+    finally:
+        capi.lib().ly_debug_set_mlp_tile(0)
+    for o in outs[1:]:
+        assert torch.equal(outs[0], o)

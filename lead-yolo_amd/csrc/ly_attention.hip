@@ -32,8 +32,10 @@ __global__ __launch_bounds__(LY_THREADS) void ly_pool_hw_kernel(const float* __r
   const long step = row ? 1 : W;
   const int c4 = tid % nc4, j0 = tid / nc4;       // C <= 1024 so nc4 <= 256
   f32x4 s = ly_zero4();
-  if (j0 < groups)
+  if (j0 < groups) {
+#pragma unroll 4
     for (int j = j0; j < len; j += groups) s += ly_ldg4(x + (base + j * step) * ldx + 4 * c4);
+  }
   red[tid] = s;
   __syncthreads();
   if (j0 == 0) {

@@ -14,7 +14,7 @@
 
 #define LY_GCC 16                       // channels regenerated per chunk
 #define LY_GK 160                        // 9*16 = 144 k-values per chunk, zero padded to 5 k-steps of 32
-#define LY_RSG (2 * LY_GK + 16)          // bytes per operand row, per plane
+#define LY_RSG (2 * LY_GK + 8)           // bytes per operand row, per plane: 82 dwords, so that the 64 rows written by one 8-byte store per lane (regenerate) and the 16 rows x 4 k-groups of an MFMA operand read both spread over all banks
 #define LY_RF3_NV 8                      // float4 staging items per thread per chunk: IH*IW*4 <= 8*256
 #define LY_RF3_WF (9 * 2 * 20)           // floats of folded generate weights per wave per chunk: [9 t][2 pairs][9 x (w_a, w_b) + (b_a, b_b)]
 

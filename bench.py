@@ -1,17 +1,26 @@
-"""bench.py — LEAD-YOLO hot path on MI355X.  Contract: see the task statement / DESIGN.md §Measurement.
+"""bench.py — LEAD-YOLO hot path on MI355X.  Contract: see the task statement / DESIGN.md §6.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--scale s] [--size 640]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--scale s] [--size 640] [--dtype bf16|f32] [--mode train|forward]
 
-One "step" = one forward pass of the detector (BASELINE.json configs[1]: lead-yolo-s, bs=32,
-3x640x640, fp32, eval / BN-folded) over one synthetic batch already resident in HBM.  Rank 0 prints
-ONE JSON line.  `roofline` is measured live with HIP events on the launch stream for the dominant
-kernel of the step; `cpu_baseline` times the oracle (oracle/functional.py, the parity-checked CPU
-restatement of the reference) on the host cores over a bounded sample of the same workload.
+Default line = BASELINE.json's metric: images/sec (640x640) fwd+bwd — one "step" is one full optimisation step of
+lead-yolo-s at bs=64/GPU (BASELINE.json configs[2]): uint8 batch already resident in HBM -> train-mode forward ->
+ComputeLoss -> HIP backward -> [bucketed gradient all-reduce over RCCL, overlapped, when N > 1] -> clip 10 ->
+SGD-nesterov (3 groups).  `--gpus N` with N > 1 and no WORLD_SIZE in the environment makes THIS process a launcher:
+it starts N ranks through `torch.distributed.run` (before anything touches the GPU) and exits with their code; under
+an external torchrun it is a rank and WORLD_SIZE must equal --gpus.  Rank 0 prints ONE JSON line.
+
+`roofline` = the dominant kernel of the step timed live with HIP events on the launch stream (ops.PROFILE hooks);
+`roofline.pconv_rfcbam_fwd` = the north-star sub-metric: every launch of the six MLPBlocks and four RFCBAMConvs
+(eval forward, bs=64) against SURVEY §8(d)'s algorithmic bytes; `cpu_baseline` = the oracle (oracle/functional.py, the
+parity-pinned CPU restatement of the reference) taking the same optimisation step on the host cores over a bounded
+sample; `forward` = the eval-forward throughput of configs[1] (bs=32, hipGraph replay) as a secondary figure.
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -21,11 +30,17 @@ if ROOT not in sys.path:
 
 import torch  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
-F32_MFMA_PEAK_TFLOPS = 157.3   # v_mfma_f32_16x16x4_f32, exact fp32
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16; fp32-grade products take 3 bf16 MFMAs (csrc/ly_tile.cuh)
+ARITH = {"f32": "fp32 storage and accumulation, bf16x3 split products on the bf16 matrix cores (~2^-16 per product)",
+         "bf16": "bf16 activations / saved tensors / activation gradients, single-plane bf16 MFMA products, fp32 accumulate, "
+                 "fp32 BatchNorm statistics, fp32 master weights and weight gradients"}
+# fused PConv+RFCBAMConv forward, elements per image (in + out) and parameters
+PCONV_RFCBAM_ELEMS_PER_IMG = 2_636_800 + 2_316_800
+PCONV_RFCBAM_PARAMS = 1_094_432
 
 
-def build_model(scale, device, seed=0):
+def build_model(scale, device, seed=0, train=False):
     import lead_yolo_amd as L
     torch.manual_seed(seed)
     m = L.Model(L.load_cfg(scale=scale))
@@ -34,44 +49,40 @@ def build_model(scale, device, seed=0):
         if isinstance(mod, torch.nn.BatchNorm2d):
             mod.running_mean.copy_(torch.randn(mod.running_mean.shape, generator=g) * 0.1)
             mod.running_var.copy_(torch.rand(mod.running_var.shape, generator=g) + 0.5)
-    return m.to(device).eval()
+    m = m.to(device)
+    return m.train() if train else m.eval()
+
+
+def synth_u8(b, size, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(0, 256, (b, 3, size, size), generator=g, dtype=torch.uint8)
 
 
 def synth_batch(b, size, seed, device):
+    return (synth_u8(b, size, seed).float() / 255).to(device)
+
+
+def synth_targets(b, seed):
+    """COCO-shaped labels: ~7 boxes per image, (img, cls=0, xy ~ U(.1,.9), wh ~ U(.02,.22))"""
+    nb = 7 * b
     g = torch.Generator().manual_seed(seed)
-    u8 = torch.randint(0, 256, (b, 3, size, size), generator=g, dtype=torch.uint8)
-    return (u8.float() / 255).to(device)
+    return torch.cat((torch.sort(torch.randint(0, b, (nb, 1), generator=g).float(), 0)[0], torch.zeros(nb, 1),
+                      torch.rand(nb, 2, generator=g) * 0.8 + 0.1, torch.rand(nb, 2, generator=g) * 0.2 + 0.02), 1)
 
 
-def time_kernel(fn, iters=20, warm=3):
-    """average duration (ms) of one launch, HIP events on the current (= launch) stream"""
-    for _ in range(warm):
-        fn()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    e0.record()
-    for _ in range(iters):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters
-
-
-BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16; fp32-grade products take 3 bf16 MFMAs (csrc/ly_tile.cuh)
-
-
-def roofline_probe(model, x, iters=10):
-    """Times every C-ABI launch of the step with HIP events on the launch stream (ops.PROFILE hooks), groups
-    them by the kernel name rocprofv3 prints, and returns the per-kernel table.  Algorithmic bytes:
-    input once + output once + parameters once; algorithmic flops: 2*MAC."""
+def probe_step(step_fn, iters=2):
+    """Times every C-ABI launch of `step_fn` with HIP events on the launch stream (ops.PROFILE hooks), groups them by
+    the kernel name rocprofv3 prints, and returns the per-kernel table.  Algorithmic bytes: input once + output once +
+    parameters once at the storage dtype; algorithmic flops: 2*MAC."""
     from lead_yolo_amd import ops
-    with torch.no_grad():
-        model(x)
-        torch.cuda.synchronize()
-        ops.PROFILE = []
+    step_fn()
+    torch.cuda.synchronize()
+    ops.PROFILE = []
+    try:
         for _ in range(iters):
-            model(x)
+            step_fn()
         torch.cuda.synchronize()
+    finally:
         recs, ops.PROFILE = ops.PROFILE, None
     table = {}
     for name, flops, nbytes, e0, e1 in recs:
@@ -89,17 +100,17 @@ def roofline_probe(model, x, iters=10):
     return rows
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch from the committed rocprofv3 PMC pass (profiles/*_pmc_traffic.json, produced
-    by tools/pmc_traffic.py: FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE), or None."""
+def committed_pmc(kernel, suffix):
+    """per-launch figures of `kernel` from the newest committed rocprofv3 PMC summary profiles/*_<suffix>.json
+    (tools/pmc_traffic.py: FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE; tools/pmc_mfma.py), or None."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{suffix}.json")), reverse=True):
         try:
             d = json.load(open(path))
         except (OSError, ValueError):
             continue
         if kernel in d:
-            return d[kernel]
+            return dict(d[kernel], source=os.path.basename(path))
     return None
 
 
@@ -115,9 +126,59 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(scale, size, budget_s=15.0):
-    """oracle (CPU restatement, parity-pinned) on the host cores, bounded sample of the same workload"""
-    import copy
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline_train(scale, size, budget_s=18.0, b=4):
+    """The oracle taking the same optimisation step (train-mode forward, loss, autograd backward, clip 10, SGD-nesterov
+    with the three groups) on the host cores: median step time over a bounded sample."""
+    from oracle import functional as OF
+    import lead_yolo_amd as L
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    m = build_model(scale, "cpu", train=True)
+    st = {k: v.clone() for k, v in m.state_dict().items()}
+    cfg = L.load_cfg(scale=scale)
+    imgs = synth_u8(b, size, 0).float() / 255
+    tg = synth_targets(b, 1)
+    params = {k: v for k, v in st.items() if v.is_floating_point() and "running" not in k and not k.endswith("anchors")}
+    groups = {g: [k for k in ks if k in params] for g, ks in OF.param_groups(list(st)).items()}
+    bufs, times = {}, []
+    t_all = time.perf_counter()
+    while True:
+        t0 = time.perf_counter()
+        for p in params.values():
+            p.requires_grad_(True)
+            p.grad = None
+        pred = OF.model_forward(st, cfg, imgs, m.stride, training=True)
+        loss, _ = OF.compute_loss(pred, tg, st["model.23.anchors"], nc=1)
+        loss.backward()
+        grads = {k: p.grad for k, p in params.items()}
+        total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())).float()
+        coef = torch.clamp(10.0 / (total + 1e-6), max=1.0)
+        grads = {k: g * coef for k, g in grads.items()}
+        with torch.no_grad():
+            for gname, dec in (("decay", 5e-4), ("bn", 0.0), ("bias", 0.0)):
+                OF.sgd_nesterov_step({k: params[k] for k in groups[gname]}, grads, bufs, 0.01, 0.937, dec)
+        times.append(time.perf_counter() - t0)
+        if (time.perf_counter() - t_all > budget_s and len(times) >= 4) or len(times) >= 50:
+            break
+    timed = times[1:]                                # first step = warm-up (allocator, oneDNN primitive caches)
+    med = statistics.median(timed)
+    return dict(value=round(b / med, 2), unit="images/sec", cores=cores, kind="port", cpu=cpu_model_name(),
+                sample=f"median of {len(timed)} optimisation steps (fwd + loss + bwd + clip + SGD-nesterov) of lead-yolo-{scale} bs={b} "
+                       f"{size}x{size} fp32 by oracle/functional.py (torch {torch.__version__} CPU, {cores} threads), after 1 warm-up step; "
+                       f"min/median/max {min(timed) * 1e3:.0f}/{med * 1e3:.0f}/{max(timed) * 1e3:.0f} ms per step")
+
+
+def cpu_baseline_forward(scale, size, budget_s=10.0, b=4):
     from oracle import functional as OF
     import lead_yolo_amd as L
     cores = usable_cores()
@@ -125,112 +186,174 @@ def cpu_baseline(scale, size, budget_s=15.0):
     m = build_model(scale, "cpu")
     st = {k: v.clone() for k, v in m.state_dict().items()}
     cfg = L.load_cfg(scale=scale)
-    b = 4
     x = synth_batch(b, size, 0, "cpu")
+    times = []
     with torch.no_grad():
-        OF.model_forward(copy.deepcopy(st), cfg, x, m.stride, training=False)      # warm-up
-        t0 = time.perf_counter()
-        n = 0
+        OF.model_forward(dict(st), cfg, x, m.stride, training=False)      # warm-up
+        t_all = time.perf_counter()
         while True:
+            t0 = time.perf_counter()
             OF.model_forward(st, cfg, x, m.stride, training=False)
-            n += 1
-            if time.perf_counter() - t0 > budget_s or n >= 2000:
+            times.append(time.perf_counter() - t0)
+            if (time.perf_counter() - t_all > budget_s and len(times) >= 3) or len(times) >= 200:
                 break
-        dt = time.perf_counter() - t0
-    return dict(value=round(b * n / dt, 2), unit="images/sec", cores=cores, kind="port",
-                sample=f"{n} eval forwards of lead-yolo-{scale} bs={b} {size}x{size} fp32 (oracle/functional.py, torch {torch.__version__} CPU, "
-                       f"{cores} threads) in {dt:.1f}s")
+    med = statistics.median(times)
+    return dict(value=round(b / med, 2), unit="images/sec", cores=cores, kind="port", cpu=cpu_model_name(),
+                sample=f"median of {len(times)} eval forwards of lead-yolo-{scale} bs={b} {size}x{size} fp32 by oracle/functional.py "
+                       f"(torch {torch.__version__} CPU, {cores} threads)")
 
 
-def train_bench(args, rank, local_rank, world, dist, device, barrier):
-    """BASELINE.json configs[2]-[3] shape (lead-yolo-s, train mode, forward + loss + backward + SGD step), in fp32 with
-    bf16x3 products (the bf16-autocast variant of those configs is not built yet).  One process per GPU, per-GPU batch
-    fixed (weak scaling), gradients averaged by ddp.GradReducer over RCCL, overlapped with backward."""
+def pconv_rfcbam_probe(model, x, dtype, iters=10):
+    """north-star sub-metric: eval forward of every MLPBlock (6) and RFCBAMConv (4) of lead-yolo-s at the batch in `x`,
+    each module timed as a WHOLE (HIP events around the module call: SE pooling + MLP, statistics pass, rfa map, the
+    contraction — every launch counts), summed, against SURVEY §8(d)'s algorithmic bytes (input once + output once +
+    parameters once at the storage dtype)."""
     import lead_yolo_amd as L
-    torch.manual_seed(0)
-    model = L.Model(L.load_cfg(scale=args.scale)).to(device).train()
-    opt = L.smart_optimizer(model, "SGD", 0.01, 0.937, 5e-4 * args.batch * world / 64)
+    was_training = model.training
+    model.eval()
+    targets, inputs = [], {}
+    for layer in model.model:
+        if isinstance(layer, (L.BasicStage, L.RFCBAMConv)):
+            targets.append(layer)
+        elif isinstance(layer, torch.nn.Sequential) and all(isinstance(s, L.BasicStage) for s in layer):
+            targets.extend(layer)
+    hooks = [t.register_forward_pre_hook(lambda mod, a: inputs.__setitem__(id(mod), a[0])) for t in targets]
+    try:
+        with torch.no_grad():
+            model(x)
+    finally:
+        for h in hooks:
+            h.remove()
+    total_ms, per = 0.0, []
+    with torch.no_grad():
+        for t in targets:
+            xi = inputs[id(t)]
+            if isinstance(xi, L.Lazy):
+                xi = xi.materialize()
+            for _ in range(2):
+                t(xi)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(iters):
+                t(xi)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / iters
+            total_ms += ms
+            per.append((type(t).__name__, tuple(xi.shape[1:]), round(ms * 1e3, 1)))
+    if was_training:
+        model.train()
+    esize = 2 if dtype == "bf16" else 4
+    b = x.shape[0]
+    nbytes = PCONV_RFCBAM_ELEMS_PER_IMG * esize * b + PCONV_RFCBAM_PARAMS * 4
+    gbs = nbytes / total_ms / 1e6
+    return dict(batch=b, modules=len(targets), ms=round(total_ms, 4), algorithmic_bytes=nbytes, achieved_gbs=round(gbs, 1),
+                hbm_frac=round(gbs / HBM_PEAK_GBS, 4), us_per_module=per,
+                note="eval forward; every launch of the 6 MLPBlocks + 4 RFCBAMConvs (SE, stats, rfa map, contraction) inside the timed "
+                     "region; bytes = SURVEY 8(d): in + out once at the storage dtype + fp32 parameters once")
+
+
+def roofline_of(rows, dtype):
+    dom = rows[0]                                   # dominant kernel = largest share of the step
+    gbs = dom["bytes"] / dom["ms_per_launch"] / 1e6
+    tfs = dom["flops"] / dom["ms_per_launch"] / 1e9
+    hbm_frac = gbs / HBM_PEAK_GBS
+    mfma_peak = BF16_MFMA_PEAK_TFLOPS if dtype == "bf16" else BF16_MFMA_PEAK_TFLOPS / 3.0
+    mfma_frac = tfs / mfma_peak
+    if mfma_frac >= hbm_frac:
+        roof = dict(bound="mfma", achieved=round(tfs, 2), peak=round(mfma_peak, 1), unit="TFLOP/s", frac=round(mfma_frac, 4),
+                    peak_note="dense bf16 2500 TFLOP/s" + ("" if dtype == "bf16" else " / 3: fp32-grade products = 3 bf16 MFMAs"))
+    else:
+        roof = dict(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(hbm_frac, 4))
+    tr = committed_pmc(dom["kernel"], "pmc_traffic")
+    roof["traffic"] = tr["hbm_bytes"] if tr else None
+    roof["traffic_source"] = tr["source"] if tr else None
+    roof["mfma_busy"] = committed_pmc(dom["kernel"], "pmc_mfma")
+    roof["kernel"] = dom["kernel"]
+    roof["launches_per_step"] = round(dom["calls_per_step"], 2)
+    roof["ms_per_launch"] = round(dom["ms_per_launch"], 5)
+    roof["ms_per_step"] = round(dom["ms_per_step"], 4)
+    roof["algorithmic_bytes_per_launch"] = round(dom["bytes"])
+    roof["algorithmic_flops_per_launch"] = round(dom["flops"])
+    roof["hbm_frac"] = round(hbm_frac, 4)
+    roof["mfma_frac"] = round(mfma_frac, 4)
+    return roof
+
+
+def print_layers(rows):
+    for r in rows:
+        print(f"  {r['kernel']:<58} {r['calls_per_step']:5.1f}/step {r['ms_per_launch'] * 1e3:8.1f} us  {r['ms_per_step'] * 1e3:8.1f} us/step  "
+              f"{r['bytes'] / r['ms_per_launch'] / 1e6:8.1f} GB/s  {r['flops'] / r['ms_per_launch'] / 1e9:8.2f} TFLOP/s", file=sys.stderr)
+
+
+class Ctx:
+    pass
+
+
+def timed_repeats(ctx, step, steps, warmup, repeats):
+    """W warm-up steps, then `repeats` timed regions of EXACTLY `steps` steps, each bracketed by barrier + synchronize on
+    both sides, MAX over ranks per region; returns the per-region seconds."""
+    for _ in range(warmup):
+        step()
+    out = []
+    for _ in range(repeats):
+        ctx.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        ctx.barrier()
+        dt = time.perf_counter() - t0
+        if ctx.dist is not None:
+            t = torch.tensor([dt], device=ctx.device, dtype=torch.float64)
+            ctx.dist.all_reduce(t, op=ctx.dist.ReduceOp.MAX)
+            dt = float(t.item())
+        out.append(dt)
+    return out
+
+
+def run_train(args, ctx):
+    import lead_yolo_amd as L
+    model = build_model(args.scale, ctx.device, train=True)
+    amp = torch.bfloat16 if args.dtype == "bf16" else None       # the autocast region of train.py:316, bf16 instead of fp16
+    if ctx.dist is not None:                         # rank 0's parameters and buffers everywhere (train.py:233-235 DDP init)
+        for t in list(model.parameters()) + list(model.buffers()):
+            ctx.dist.broadcast(t.data, src=0)
+    opt = L.smart_optimizer(model, "SGD", 0.01, 0.937, 5e-4 * args.batch * ctx.world / 64)
     loss_fn = L.ComputeLoss(model)
-    reducer = L.GradReducer(list(model.parameters())).attach() if world > 1 else None
-    g = torch.Generator().manual_seed(rank)
-    imgs = torch.randint(0, 256, (args.batch, 3, args.size, args.size), dtype=torch.uint8, generator=g).to(device)
-    nb = 7 * args.batch                                                        # ~7 boxes per image (COCO mean)
-    g1 = torch.Generator().manual_seed(1 + rank)
-    tg = torch.cat((torch.sort(torch.randint(0, args.batch, (nb, 1), generator=g1).float(), 0)[0], torch.zeros(nb, 1),
-                    torch.rand(nb, 2, generator=g1) * 0.8 + 0.1, torch.rand(nb, 2, generator=g1) * 0.2 + 0.02), 1).to(device)
-    for _ in range(args.warmup):
-        L.train_step(model, loss_fn, opt, imgs, tg, reducer=reducer, world_size=world)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss, _ = L.train_step(model, loss_fn, opt, imgs, tg, reducer=reducer, world_size=world)
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    if rank == 0:
-        print(json.dumps({
-            "metric": "images/sec (640x640) fwd+bwd+SGD", "value": round(world * args.batch * args.steps / dt, 2), "unit": "images/sec",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"lead-yolo-{args.scale} bs={args.batch}/gpu 3x{args.size}x{args.size} train step: forward, ComputeLoss, "
-                                   "HIP backward, clip 10, SGD-nesterov 3 groups (BASELINE.json configs[2] shape, fp32 instead of bf16 autocast)",
-                       "global_batch": world * args.batch, "parallelism": f"dp{world} (bucketed gradient all-reduce over RCCL, overlapped)"},
-            "final_loss": round(float(loss), 4), "roofline": None, "cpu_baseline": None,
-            "note": "secondary line (bench.py --train); the headline metric is the default eval-forward run"}))
-    if dist is not None:
-        dist.barrier(device_ids=[local_rank])
-        dist.destroy_process_group()
+    reducer = L.GradReducer(list(model.parameters())).attach() if ctx.world > 1 else None
+    imgs = synth_u8(args.batch, args.size, ctx.rank).to(ctx.device)
+    tg = synth_targets(args.batch, 1 + ctx.rank).to(ctx.device)
+    state = {}
+
+    def step():
+        state["loss"], _ = L.train_step(model, loss_fn, opt, imgs, tg, reducer=reducer, world_size=ctx.world, amp=amp)
+
+    regions = timed_repeats(ctx, step, args.steps, args.warmup, args.repeats)
+    res = dict(regions=regions, final_loss=float(state["loss"]), model=model, step=step,
+               workload=f"lead-yolo-{args.scale} bs={args.batch}/gpu 3x{args.size}x{args.size} {args.dtype} full train step: uint8 batch -> "
+                        "train-mode forward (batch-statistics BN), ComputeLoss, HIP backward, clip 10, SGD-nesterov 3 groups "
+                        "(BASELINE.json configs[2]" + ("" if args.dtype == "bf16" else " shape in fp32") + "); random-init weights",
+               parallelism=(f"dp{ctx.world}: one process per GPU, ~2 MB reverse-order gradient buckets all-reduced over RCCL "
+                            "(torch.distributed 'nccl') from post-accumulate hooks, overlapped with backward") if ctx.world > 1
+               else "dp1 (single GPU, no collective)",
+               metric="images/sec (640x640) fwd+bwd")
+    if reducer is not None:
+        res["rccl_ranks"] = ctx.dist.get_world_size()
+        res["grad_buckets"] = len(reducer.buckets)
+    return res
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=32)
-    ap.add_argument("--scale", default="s")
-    ap.add_argument("--size", type=int, default=640)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--layers", action="store_true", help="print the per-layer kernel table to stderr")
-    ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel probe (for whole-step rocprof runs)")
-    ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of the captured hipGraph (serving mode)")
-    ap.add_argument("--train", action="store_true",
-                    help="secondary line: full optimisation step (forward, loss, backward, clip, SGD-nesterov; gradient all-reduce when N>1) "
-                         "instead of the headline eval forward")
-    args = ap.parse_args()
-
-    rank = int(os.environ.get("RANK", 0))
-    local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    device = torch.device("cuda", local_rank)
-    torch.cuda.set_device(device)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier(device_ids=[local_rank])
-        torch.cuda.synchronize()
-
-    if args.train:
-        return train_bench(args, rank, local_rank, world, dist, device, barrier)
-
-    model = build_model(args.scale, device)
-    x = synth_batch(args.batch, args.size, rank, device)
-
-    # serving mode: the forward captured once into a hipGraph and replayed (identical kernels, no host work per step);
-    # the replayed outputs are checked against an eager forward, any capture problem falls back to eager launches
+def run_forward(args, ctx, batch=None, steps=None, warmup=None, repeats=None):
+    import lead_yolo_amd as L
+    batch = batch or args.batch
+    model = build_model(args.scale, ctx.device)
+    x = synth_batch(batch, args.size, ctx.rank, ctx.device)
+    if args.dtype == "bf16":
+        x = x.to(torch.bfloat16)                       # bf16 input => every module takes its bf16 path (modules.py dtype policy)
     step, launch = (lambda: model(x)), "eager"
     if not args.no_graph:
         try:
-            import lead_yolo_amd as L
             g = L.GraphedForward(model, x)
             with torch.no_grad():
                 ref = model(x)
@@ -242,70 +365,129 @@ def main():
         except Exception as e:                                  # noqa: BLE001
             print(f"[bench] hipGraph capture unavailable ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr)
     with torch.no_grad():
-        for _ in range(args.warmup):
-            step()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        barrier()
-        dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        regions = timed_repeats(ctx, step, steps or args.steps, args.warmup if warmup is None else warmup, repeats or args.repeats)
+    return dict(regions=regions, model=model, x=x, launch=launch, batch=batch,
+                step=lambda: model(x),
+                workload=f"lead-yolo-{args.scale} bs={batch}/gpu 3x{args.size}x{args.size} {args.dtype} eval forward (BASELINE.json configs[1]); "
+                         "random-init weights, perturbed BN stats",
+                parallelism=f"dp{ctx.world} (independent replicas, no data-path collective)", metric="images/sec (640x640) forward")
 
+
+def launch_ranks(n):
+    """this process becomes a launcher: N fresh rank processes through torch.distributed.run.  Nothing here has touched the GPU
+    (importing torch does not), so no GPU-initialised process is ever replaced or forked."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.call(cmd, env=env)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--repeats", type=int, default=3, help="timed regions of --steps steps each; the line reports their median")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 64 for train, 32 for forward)")
+    ap.add_argument("--scale", default="s")
+    ap.add_argument("--size", type=int, default=640)
+    ap.add_argument("--dtype", default="f32", choices=("f32", "bf16"), help="activation storage / product precision")
+    ap.add_argument("--mode", default="train", choices=("train", "forward"),
+                    help="train (default): the BASELINE metric, full optimisation step; forward: eval forward of configs[1]")
+    ap.add_argument("--train", action="store_true", help="alias of --mode train")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary eval-forward figure and the pconv_rfcbam probe")
+    ap.add_argument("--layers", action="store_true", help="print the per-kernel table to stderr")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel probe (for whole-step rocprof runs)")
+    ap.add_argument("--no-graph", action="store_true", help="forward mode: time eager launches instead of the captured hipGraph")
+    args = ap.parse_args()
+    if args.train:
+        args.mode = "train"
+    if args.batch is None:
+        args.batch = 64 if args.mode == "train" else 32
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
+    ctx = Ctx()
+    ctx.rank = int(os.environ.get("RANK", 0))
+    ctx.local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    ctx.world = int(os.environ.get("WORLD_SIZE", 1))
+    if ctx.world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={ctx.world}: launch with --nproc-per-node {args.gpus} (or drop the external launcher "
+                 f"and let `python bench.py --gpus {args.gpus}` start the ranks itself)")
+    ctx.dist = None
+    if ctx.world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(ctx.local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", ctx.local_rank))
+        ctx.dist = dist
+    ctx.device = torch.device("cuda", ctx.local_rank)
+    torch.cuda.set_device(ctx.device)
+
+    def barrier():
+        if ctx.dist is not None:
+            ctx.dist.barrier(device_ids=[ctx.local_rank])
+        torch.cuda.synchronize()
+    ctx.barrier = barrier
+
+    res = run_train(args, ctx) if args.mode == "train" else run_forward(args, ctx)
+    regions = res["regions"]
+    dt = statistics.median(regions)
     ms_per_step = dt / args.steps * 1e3
-    value = world * args.batch * args.steps / dt
+    value = ctx.world * args.batch * args.steps / dt
 
-    roof = None
-    cpu = None
-    if rank == 0 and args.no_roofline:
-        print(json.dumps({"value": round(value, 2), "ms_per_step": round(ms_per_step, 4), "launch": launch, "note": "probe skipped"}))
-    elif rank == 0:
-        rows = roofline_probe(model, x)
-        if args.layers:
-            for r in rows:
-                print(f"  {r['kernel']:<46} {r['calls_per_step']:5.1f}/step {r['ms_per_launch'] * 1e3:8.1f} us  {r['ms_per_step'] * 1e3:8.1f} us/step  "
-                      f"{r['bytes'] / r['ms_per_launch'] / 1e6:8.1f} GB/s  {r['flops'] / r['ms_per_launch'] / 1e9:8.2f} TFLOP/s", file=sys.stderr)
-        dom = rows[0]                                   # dominant kernel = largest share of the step
-        gbs = dom["bytes"] / dom["ms_per_launch"] / 1e6
-        tfs = dom["flops"] / dom["ms_per_launch"] / 1e9
-        hbm_frac = gbs / HBM_PEAK_GBS
-        mfma_peak = BF16_MFMA_PEAK_TFLOPS / 3.0
-        mfma_frac = tfs / mfma_peak
-        if mfma_frac >= hbm_frac:
-            roof = dict(bound="mfma", achieved=round(tfs, 2), peak=round(mfma_peak, 1), unit="TFLOP/s", frac=round(mfma_frac, 4),
-                        peak_note="dense bf16 2500 TFLOP/s / 3: fp32-grade products = 3 bf16 MFMAs (exact-f32 MFMA peak would be 157.3)")
-        else:
-            roof = dict(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(hbm_frac, 4))
-        tr = pmc_traffic(dom["kernel"])
-        roof["traffic"] = tr
-        roof["kernel"] = dom["kernel"]
-        roof["launches_per_step"] = round(dom["calls_per_step"], 2)
-        roof["ms_per_launch"] = round(dom["ms_per_launch"], 5)
-        roof["algorithmic_bytes_per_launch"] = round(dom["bytes"])
-        roof["algorithmic_flops_per_launch"] = round(dom["flops"])
-        star = [r for r in rows if r["kernel"].startswith(("ly_mlpblock", "ly_rfcbam"))]
-        sb, sm = sum(r["bytes"] * r["calls_per_step"] for r in star), sum(r["ms_per_step"] for r in star)
-        roof["pconv_rfcbam_fwd"] = dict(ms=round(sm, 4), hbm_frac=round(sb / sm / 1e6 / HBM_PEAK_GBS, 4),
-                                        note="mlpblock + rfcbam stats/main kernels; SE, rfa map and the k=1 GEMM excluded")
-        if not args.no_cpu_baseline:
-            cpu = cpu_baseline(args.scale, args.size)
+    if ctx.rank == 0:
         out = {
-            "metric": "images/sec (640x640) forward", "value": round(value, 2), "unit": "images/sec", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"lead-yolo-{args.scale} bs={args.batch}/gpu 3x{args.size}x{args.size} fp32 eval forward "
-                                   "(BASELINE.json configs[1]); random-init weights, perturbed BN stats",
-                       "global_batch": world * args.batch, "parallelism": f"dp{world} (independent replicas, no data-path collective)",
-                       "launch": launch},
-            "roofline": roof, "cpu_baseline": cpu,
+            "metric": res["metric"], "value": round(value, 2), "unit": "images/sec", "n_gpus": ctx.world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": res["workload"], "global_batch": ctx.world * args.batch, "parallelism": res["parallelism"],
+                       "arithmetic": ARITH[args.dtype], "world_size": ctx.world},
+            "timed_repeats": len(regions), "repeat_ms_per_step": [round(r / args.steps * 1e3, 4) for r in regions],
+            "value_is": "median of the timed repeats (each: exactly `steps` steps between barrier+synchronize, max over ranks)",
         }
+        for k in ("final_loss", "rccl_ranks", "grad_buckets", "launch"):
+            if k in res:
+                out[k if k != "launch" else "launch_mode"] = res[k]
+        if args.no_roofline:
+            out["roofline"] = None
+            out["cpu_baseline"] = None
+        else:
+            if args.mode == "train":
+                rows = probe_step(res["step"], iters=2)
+            else:
+                with torch.no_grad():
+                    rows = probe_step(res["step"], iters=10)
+            if args.layers:
+                print_layers(rows)
+            roof = roofline_of(rows, args.dtype)
+            if ctx.world == 1 and not args.no_secondary:
+                del res["step"]
+                if args.mode == "train":
+                    xb = synth_batch(args.batch, args.size, 0, ctx.device).to(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+                    model = res.pop("model")
+                    roof["pconv_rfcbam_fwd"] = pconv_rfcbam_probe(model, xb, args.dtype)
+                    del model, xb
+                    torch.cuda.empty_cache()
+                    fw = run_forward(args, ctx, batch=32, steps=20, warmup=3, repeats=3)
+                    fdt = statistics.median(fw["regions"])
+                    out["forward"] = {"metric": fw["metric"], "value": round(32 * 20 / fdt, 2), "unit": "images/sec", "ms_per_step": round(fdt / 20 * 1e3, 4),
+                                      "workload": fw["workload"], "launch_mode": fw["launch"]}
+                else:
+                    xb = synth_batch(64, args.size, 0, ctx.device).to(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+                    roof["pconv_rfcbam_fwd"] = pconv_rfcbam_probe(res["model"], xb, args.dtype)
+            out["roofline"] = roof
+            out["cpu_baseline"] = None
+            if ctx.world == 1 and not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline_train(args.scale, args.size) if args.mode == "train" else cpu_baseline_forward(args.scale, args.size)
         print(json.dumps(out))
-    if dist is not None:
-        dist.barrier(device_ids=[local_rank])
-        dist.destroy_process_group()
+    if ctx.dist is not None:
+        ctx.dist.barrier(device_ids=[ctx.local_rank])
+        ctx.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -287,11 +287,17 @@ int ly_frag_pack3(const float* w, int R, int K, long ld_r, long ld_k, int rows_t
  *   p / dp   [bs][na][ny][nx][no] predictions / their gradient (dp zeroed by the caller; d(total loss)/dp on return)
  *   anchors  [na][2] in grid units (Detect.anchors[i]);  targets [nt][6] = (image, class, x, y, w, h) normalised
  *   tobj [cells] zeroed, winner [cells] filled with -1, cand_cell [5*na*nt], cand [5*na*nt][5] workspaces
- *   acc [4] zeroed: sum(1 - eiou), matches, sum of objectness BCE, unused  -> ly_loss_finish                              */
+ *   acc [4] zeroed: sum(1 - eiou), matches, sum of objectness BCE, rejected target rows  -> ly_loss_finish
+ *   tbox     NULL or [5*na*nt][4]: (gx - gi, gy - gj, gw, gh) of every valid candidate (build_targets' `tbox`, utils/loss.py:262)
+ *   match_only != 0: target assignment only (utils/loss.py:194-268 build_targets): cand_cell[idx] = flattened cell
+ *            ((b*na + a)*ny + gj)*nx + gi of candidate idx = (k*na + a)*nt + t, or -1; tbox as above; p is read, dp/tobj untouched.
+ * A target row whose image index is outside [0, bs) or that holds a NaN is rejected and counted in acc[3] (the torch
+ * formulation raises IndexError there); ly_loss_finish then returns a NaN total.                                          */
 int ly_loss_level(const float* p, float* dp, const float* anchors, const float* targets, int bs, int na, int ny, int nx, int no, long nt,
                   float anchor_t, float box_gain, float obj_gain, float balance, float* tobj, int* winner, long* cand_cell, float* cand,
-                  float* acc, void* stream);
-/* out[0] = (lbox + lobj) * bs, out[1] = lbox, out[2] = lobj, out[3] = lcls = 0 from acc [nl][4]; cells / balance: [nl] floats     */
+                  float* acc, float* tbox, int match_only, void* stream);
+/* out[0] = (lbox + lobj) * bs (NaN if any level rejected a target row), out[1] = lbox, out[2] = lobj, out[3] = lcls = 0 from
+ * acc [nl][4]; cells / balance: [nl] floats                                                                                */
 int ly_loss_finish(const float* acc, int nl, const float* cells, const float* balance, float box_gain, float obj_gain, int bs, float* out,
                    void* stream);
 

@@ -66,7 +66,8 @@ struct LyLossLevel {
   int* winner;           // [cells], filled with -1
   long* cand_cell;       // [5*na*nt], -1 = invalid
   float* cand;           // [5*na*nt][5]: iou, d(1-eiou)/d(raw0..3)
-  float* acc;            // [4]: sum(1-eiou), count, sum BCE obj, unused   (zeroed)
+  float* acc;            // [4]: sum(1-eiou), count, sum BCE obj, number of rejected target rows   (zeroed)
+  float* tbox;           // optional [5*na*nt][4]: (gx - gi, gy - gj, gw, gh) of every valid candidate (build_targets' tbox)
 };
 
 __global__ __launch_bounds__(LY_THREADS) void ly_loss_match_kernel(const LyLossLevel L) {
@@ -78,10 +79,16 @@ __global__ __launch_bounds__(LY_THREADS) void ly_loss_match_kernel(const LyLossL
   const int a = (int)(rem / L.nt);
   const long t = rem - (long)a * L.nt;
   const float* tg = L.targets + t * 6;
-  const float gx = tg[2] * L.nx, gy = tg[3] * L.ny, gw = tg[4] * L.nx, gh = tg[5] * L.ny;
+  const float gx = __fmul_rn(tg[2], (float)L.nx), gy = __fmul_rn(tg[3], (float)L.ny), gw = __fmul_rn(tg[4], (float)L.nx), gh = __fmul_rn(tg[5], (float)L.ny);
   const float aw = L.anchors[2 * a], ah = L.anchors[2 * a + 1];
   const float rw = gw / aw, rh = gh / ah;
-  bool ok = fmaxf(fmaxf(rw, 1.f / rw), fmaxf(rh, 1.f / rh)) < L.anchor_t;
+  // A target row whose image index is outside [0, bs) (a last partial batch, per-rank slices that kept global indices) or that
+  // holds a NaN would index p / dp / winner out of bounds; the torch formulation raises IndexError there.  Such rows are
+  // rejected and counted: ly_loss_finish turns a non-zero count into a NaN loss (loud, and without a host sync).
+  const int b = (int)tg[0];
+  const bool sane = tg[0] >= 0.f && b < L.bs && gx == gx && gy == gy && gw == gw && gh == gh;
+  if (!sane && k == 0 && a == 0) atomicAdd(L.acc + 3, 1.f);
+  bool ok = sane && fmaxf(fmaxf(rw, 1.f / rw), fmaxf(rh, 1.f / rh)) < L.anchor_t;
   const float g = 0.5f;
   float ox = 0.f, oy = 0.f;
   if (k == 1) { ok = ok && (fmodf(gx, 1.f) < g && gx > 1.f); ox = g; }
@@ -90,12 +97,12 @@ __global__ __launch_bounds__(LY_THREADS) void ly_loss_match_kernel(const LyLossL
   else if (k == 4) { const float iy = L.ny - gy; ok = ok && (fmodf(iy, 1.f) < g && iy > 1.f); oy = -g; }
   long cell = -1;
   if (ok) {
-    const int b = (int)tg[0];
     const int gi_raw = (int)(gx - ox), gj_raw = (int)(gy - oy);           // .long(): truncation
     const int gi = gi_raw < 0 ? 0 : gi_raw > L.nx - 1 ? L.nx - 1 : gi_raw;
     const int gj = gj_raw < 0 ? 0 : gj_raw > L.ny - 1 ? L.ny - 1 : gj_raw;
     cell = (((long)b * L.na + a) * L.ny + gj) * L.nx + gi;
-    const float tx = gx - (float)gi_raw, ty = gy - (float)gj_raw;         // tbox uses the UNclamped cell
+    const float tx = __fsub_rn(gx, (float)gi_raw), ty = __fsub_rn(gy, (float)gj_raw);   // tbox uses the UNclamped cell; no FMA contraction with gx = x*nx (bit-exact vs torch)
+    if (L.tbox) { float* tb = L.tbox + idx * 4; tb[0] = tx; tb[1] = ty; tb[2] = gw; tb[3] = gh; }
     const float* pr = L.p + cell * L.no;
     const float s0 = ly_sigmoid(pr[0]), s1 = ly_sigmoid(pr[1]), s2 = ly_sigmoid(pr[2]), s3 = ly_sigmoid(pr[3]);
     const float pxv = s0 * 2.f - 0.5f, pyv = s1 * 2.f - 0.5f, pwv = (s2 * 2.f) * (s2 * 2.f) * aw, phv = (s3 * 2.f) * (s3 * 2.f) * ah;
@@ -146,18 +153,22 @@ __global__ __launch_bounds__(LY_THREADS) void ly_loss_obj_kernel(const LyLossLev
 
 extern "C" int ly_loss_level(const float* p, float* dp, const float* anchors, const float* targets, int bs, int na, int ny, int nx, int no, long nt,
                              float anchor_t, float box_gain, float obj_gain, float balance, float* tobj, int* winner, long* cand_cell, float* cand,
-                             float* acc, void* stream) {
+                             float* acc, float* tbox, int match_only, void* stream) {
   LY_CHECK(p && dp && anchors && tobj && winner && acc && (nt == 0 || (targets && cand_cell && cand)), "loss_level: null pointer");
   LY_CHECK(bs > 0 && na > 0 && ny > 0 && nx > 0 && no >= 5 && nt >= 0, "loss_level: bad sizes");
   const long cells = (long)bs * na * ny * nx;
   LY_CHECK(5L * na * nt < (1L << 31) && cells < (1L << 40), "loss_level: too many candidates");
-  LyLossLevel L{p, dp, anchors, targets, bs, na, ny, nx, no, nt, anchor_t, tobj, winner, cand_cell, cand, acc};
+  LyLossLevel L{p, dp, anchors, targets, bs, na, ny, nx, no, nt, anchor_t, tobj, winner, cand_cell, cand, acc, tbox};
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const long ncand = 5L * na * nt;
   if (ncand > 0) {
     const unsigned blocks = (unsigned)((ncand + LY_THREADS - 1) / LY_THREADS);
     hipLaunchKernelGGL(ly_loss_match_kernel, dim3(blocks), dim3(LY_THREADS), 0, st, L);
-    hipLaunchKernelGGL(ly_loss_apply_kernel, dim3(blocks), dim3(LY_THREADS), 0, st, L, box_gain);
+    if (!match_only) hipLaunchKernelGGL(ly_loss_apply_kernel, dim3(blocks), dim3(LY_THREADS), 0, st, L, box_gain);
+  }
+  if (match_only) {            // target assignment only (ComputeLoss.build_targets): cand_cell / tbox are the result
+    LY_LAUNCH_CHECK();
+    return 0;
   }
   long ob = (cells + LY_THREADS * 8L - 1) / (LY_THREADS * 8L);
   ob = ob < 1 ? 1 : ob > 2048 ? 2048 : ob;
@@ -170,15 +181,16 @@ extern "C" int ly_loss_level(const float* p, float* dp, const float* anchors, co
 __global__ void ly_loss_finish_kernel(const float* __restrict__ acc, int nl, const float* __restrict__ cells, const float* __restrict__ balance,
                                       float box_gain, float obj_gain, float bs, float* __restrict__ out) {
   if (threadIdx.x != 0) return;
-  float lbox = 0.f, lobj = 0.f;
+  float lbox = 0.f, lobj = 0.f, bad = 0.f;
   for (int i = 0; i < nl; ++i) {
     const float* a = acc + 4 * i;
+    bad += a[3];
     if (a[1] > 0.f) lbox += a[0] / a[1];
     lobj += a[2] / cells[i] * balance[i];
   }
   lbox *= box_gain;
   lobj *= obj_gain;
-  out[0] = (lbox + lobj) * bs;
+  out[0] = bad > 0.f ? __builtin_nanf("") : (lbox + lobj) * bs;      // rejected target rows (image index outside the batch / NaN): fail loudly
   out[1] = lbox;
   out[2] = lobj;
   out[3] = 0.f;

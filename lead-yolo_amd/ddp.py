@@ -41,8 +41,10 @@ class GradReducer:
             for pi, p in enumerate(b["params"]):
                 self._slot[id(p)] = (bi, pi)
         self._pending = [0] * len(self.buckets)
+        self._launched = [False] * len(self.buckets)
         self._works = []
         self._hooks = []
+        self._sync = True
         self.reset()
 
     def _close(self, plist):
@@ -64,7 +66,23 @@ class GradReducer:
             for p, v in zip(b["params"], b["views"]):
                 p.grad = v
         self._pending = [len(b["params"]) for b in self.buckets]
+        self._launched = [False] * len(self.buckets)
         self._works = []
+
+    def no_sync(self):
+        """Context manager for gradient accumulation (the reference's `accumulate` micro-steps, train.py:303-329): backward
+        passes inside it only accumulate into the bucket views; the all-reduce of a bucket is launched by the first backward
+        OUTSIDE the context (call reset() once per optimiser step, before the first micro-step)."""
+        reducer = self
+
+        class _NoSync:
+            def __enter__(self):
+                reducer._sync = False
+
+            def __exit__(self, *a):
+                reducer._sync = True
+                reducer._pending = [0 if done else len(b["params"]) for done, b in zip(reducer._launched, reducer.buckets)]
+        return _NoSync()
 
     def attach(self):
         """Register post-accumulate hooks that launch a bucket's all-reduce when its last gradient lands."""
@@ -84,11 +102,19 @@ class GradReducer:
             # autograd replaced the view (first accumulation into a None grad): copy into the bucket
             view.copy_(p.grad)
             p.grad = view
+        if not self._sync:
+            return                                                # accumulation micro-step: no exchange yet
+        if self._launched[bi]:
+            # the bucket was averaged and exchanged after an earlier backward of this step: adding a second local gradient to
+            # it would leave the ranks with different sums (and re-launching would divide by the world size twice)
+            raise RuntimeError("GradReducer: a gradient arrived for a bucket that was already all-reduced in this step — call "
+                               "reset() before every optimiser step, and run gradient-accumulation micro-steps under no_sync()")
         self._pending[bi] -= 1
         if self._pending[bi] == 0:
             self._launch(bi)
 
     def _launch(self, bi):
+        self._launched[bi] = True
         if self.world == 1:
             return
         flat = self.buckets[bi]["flat"]
@@ -99,7 +125,7 @@ class GradReducer:
     def reduce_now(self):
         """For callers without hooks (or unused parameters): launch every bucket not yet launched."""
         for bi, left in enumerate(self._pending):
-            if left > 0:
+            if left > 0 and not self._launched[bi]:
                 self._pending[bi] = 0
                 self._launch(bi)
 

@@ -25,7 +25,9 @@ REGISTRY = {
 }
 _CHANNEL_KINDS = {M.Conv, M.SPPF, M.C3_CA, M.RFCBAMConv, M.BasicStage, M.PatchEmbed_FasterNet, M.PatchMerging_FasterNet}
 DEFAULT_CFG = str(Path(__file__).resolve().parent / "cfg" / "LEAD-YOLO.yaml")
-SCALES = {"n": (0.33, 0.25), "s": (0.33, 0.50), "m": (0.67, 0.75), "l": (1.0, 1.0), "x": (1.33, 1.25)}
+# (depth_multiple, width_multiple) by analogy with models/yolov5{n,s,l}.yaml.  The m / x widths (BasicStage dims 32/64/120/240 and
+# 56/104/200/400) are not among the widths the fused MLPBlock kernel is built for, so those scales are not offered.
+SCALES = {"n": (0.33, 0.25), "s": (0.33, 0.50), "l": (1.0, 1.0)}
 
 
 def make_divisible(x, divisor):
@@ -43,6 +45,9 @@ def load_cfg(cfg=DEFAULT_CFG, scale=None):
         with open(cfg, encoding="ascii", errors="ignore") as f:
             d = yaml.safe_load(f)
     if scale is not None:
+        if scale not in SCALES:
+            raise NotImplementedError(f"scale {scale!r} is not built (available: {sorted(SCALES)}): its FasterNet stage widths have no "
+                                      "fused MLPBlock kernel (csrc/ly_mlpblock.cuh is instantiated for C in {16, 24, 40, 80, 160, 320})")
         d["depth_multiple"], d["width_multiple"] = SCALES[scale]
     return d
 

@@ -182,6 +182,8 @@ class MLPBlock(nn.Module):
                 or norm_layer is not nn.BatchNorm2d or act_layer is not nn.ReLU:
             raise NotImplementedError("HIP MLPBlock is built for n_div=4, mlp_ratio=2, BatchNorm2d+ReLU, no layer-scale/drop-path "
                                       "(the only configuration LEAD-YOLO instantiates)")
+        if dim not in ops.MLP_WIDTHS:
+            raise NotImplementedError(f"HIP MLPBlock is built for dim in {sorted(ops.MLP_WIDTHS)} (lead-yolo n / s / l); got dim={dim}")
         self.dim = dim
         hidden = int(dim * mlp_ratio)
         self.mlp = nn.Sequential(nn.Conv2d(dim, hidden, 1, bias=False), norm_layer(hidden), act_layer(),

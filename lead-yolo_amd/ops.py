@@ -62,6 +62,9 @@ def pick_conv_tile(h, w, max_px=128, max_frame=192):
     return _CONV_TILE_CACHE[key]
 
 
+MLP_WIDTHS = (16, 24, 40, 80, 160, 320)     # C values ly_mlpblock_fwd is instantiated for (include/lead_yolo_hip.h)
+
+
 def mlp_config(c, m, w):
     """(C, NT, HT, T2D) of the kernel ly_mlpblock_fwd launches -- mirrors dispatch_nt in csrc/ly_mlpblock.hip"""
     ht = {16: 2, 24: 4, 40: 2, 80: 2, 160: 4, 320: 4}[c]

@@ -61,17 +61,20 @@ class ModelEMA:
                     v.mul_(d).add_(msd[k].detach(), alpha=1 - d)
 
 
-def train_step(model, compute_loss, optimizer, imgs, targets, ema=None, reducer=None, world_size=1, max_norm=10.0):
+def train_step(model, compute_loss, optimizer, imgs, targets, ema=None, reducer=None, world_size=1, max_norm=10.0, amp=None):
     """One optimisation step; imgs uint8 or float [B,3,H,W] on the model's device, targets [n,6].
-    Returns (loss, loss_items) as detached device tensors (no host sync)."""
+    amp: None (fp32 storage) or torch.bfloat16 — forward and loss run inside torch.autocast(dtype=amp), the reference's
+    `with torch.cuda.amp.autocast(amp)` region (train.py:316) with bf16 in place of fp16 (no GradScaler needed: bf16 keeps
+    fp32's exponent range).  Returns (loss, loss_items) as detached device tensors (no host sync)."""
     if imgs.dtype == torch.uint8:
         imgs = imgs.float() / 255
     if reducer is not None:
         reducer.reset()
     ops.stats_pool_begin(imgs.device)       # one zero fill for all BatchNorm accumulators of the step (ops._StatsPool)
     try:
-        pred = model(imgs)
-        loss, items = compute_loss(pred, targets)
+        with torch.autocast("cuda", dtype=amp, enabled=amp is not None):
+            pred = model(imgs)
+            loss, items = compute_loss(pred, targets)
         if world_size > 1:
             loss = loss * world_size            # the reducer averages gradients (train.py:321-322)
         loss.backward()

@@ -9,8 +9,8 @@ no nn.Module classes here on purpose: this file restates the *arithmetic*, the p
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
 Parity pinning: the reference has no tests or golden vectors of its own for this path,
 so this oracle is pinned against outputs of the reference itself, imported in the build container by
-oracle/gen_golden.py (fixtures under tests/golden/) and checked live by tests/test_oracle_vs_reference.py
-whenever /root/reference is present.
+oracle/gen_golden.py (fixtures under tests/golden/, regenerable with that script while /root/reference is
+present) and checked against them by tests/test_oracle_golden.py.
 
 Reference citations are `file:line` into the upstream checkout (qingqing-zijin/LEAD-YOLO @ 2024-12-20).
 """

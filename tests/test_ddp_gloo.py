@@ -37,6 +37,32 @@ def _worker(rank, world, port, q):
             for p, want in zip(net.parameters(), gathered):
                 assert torch.allclose(p.grad, want, rtol=1e-5, atol=1e-6), (rank, step, (p.grad - want).abs().max())
             ref_grads = [p.grad.clone() for p in net.parameters()]
+        # gradient accumulation (the reference's `accumulate` micro-steps): two backward passes, ONE exchange
+        xs = [torch.randn(4, 3, 8, 8, generator=torch.Generator().manual_seed(500 + rank + 10 * j)) for j in range(2)]
+        ys = [torch.randn(4, 5, generator=torch.Generator().manual_seed(700 + rank + 10 * j)) for j in range(2)]
+        local = [torch.autograd.grad(((net(x) - y) ** 2).mean(), list(net.parameters())) for x, y in zip(xs, ys)]
+        want = []
+        for g0, g1 in zip(*local):
+            buf = [torch.zeros_like(g0) for _ in range(world)]
+            dist.all_gather(buf, (g0 + g1).contiguous())
+            want.append(sum(buf) / world)
+        red.reset()
+        with red.no_sync():
+            ((net(xs[0]) - ys[0]) ** 2).mean().backward()
+        ((net(xs[1]) - ys[1]) ** 2).mean().backward()
+        red.wait()
+        for p, w in zip(net.parameters(), want):
+            assert torch.allclose(p.grad, w, rtol=1e-5, atol=1e-6), (rank, "accumulate", (p.grad - w).abs().max())
+        # a second backward WITHOUT no_sync / reset must not silently add an un-reduced gradient
+        try:
+            ((net(xs[0]) - ys[0]) ** 2).mean().backward()
+            raise AssertionError("second backward after the exchange did not raise")
+        except RuntimeError as e:
+            assert "already all-reduced" in str(e)
+        red.reset()
+        ((net(x) - y) ** 2).mean().backward()
+        red.wait()
+        ref_grads = [p.grad.clone() for p in net.parameters()]
         # replicas agree bit for bit after the exchange
         for g in ref_grads:
             buf = [torch.zeros_like(g) for _ in range(world)]

@@ -4,8 +4,13 @@
  * reference nn.Module.forward (file:line cited per function, relative to qingqing-zijin/LEAD-YOLO).
  * Plain pointers and sizes only; all pointers are DEVICE pointers unless stated; `stream` is a
  * hipStream_t (0 = default stream); nothing here synchronises, allocates or frees.
- * Activations are NHWC fp32 (N, H, W, C with C fastest).  Return value: 0 on success, <0 on error
- * (message via ly_last_error(), thread-local).
+ * Activations are NHWC (N, H, W, C with C fastest) in one of two storage dtypes, selected per call by `dtype`:
+ *   LY_F32  (0): fp32 storage, bf16x3 split products on the bf16 matrix cores (~2^-16 per product)
+ *   LY_BF16 (1): bf16 storage (BASELINE configs[2]-[4]), plain bf16 products; weights packed with ONE plane
+ * Accumulators, BatchNorm statistics, attention tables (ca, rfa, a_h, a_w, pools), parameters and weight gradients are
+ * fp32 in both.  Pointers documented as "T*" are `void*` to elements of the call's dtype; leading dimensions are in
+ * ELEMENTS.  bf16 calls need channel counts / leading dimensions that are multiples of 8 where fp32 needs 4 (16-byte
+ * vectors).  Return value: 0 on success, <0 on error (message via ly_last_error(), thread-local).
  */
 #ifndef LEAD_YOLO_HIP_H
 #define LEAD_YOLO_HIP_H
@@ -13,26 +18,22 @@
 extern "C" {
 #endif
 
-int ly_abi_version(void);
+enum { LY_F32 = 0, LY_BF16 = 1 };
+int ly_abi_version(void);      /* 2: dtype-polymorphic entry points */
 const char* ly_last_error(void);
 
 /* FasterNet MLPBlock forward, eval form (BN folded to scale/shift):
  *   y = x + W2 . relu(scale * (W1 . [pconv3x3(x[..., :C/4]) | x[..., C/4:]]) + shift)
  * replaces Partial_conv3.forward_split_cat (models/common.py:1432-1437) + MLPBlock.forward
- * (models/common.py:1478-1482).  wp/w1/w2 are bf16x3 frag-packed (lead-yolo_amd/pack.py frag_pack3)
+ * (models/common.py:1478-1482).  wp/w1/w2 are frag-packed (lead-yolo_amd/pack.py frag_pack3, planes = 2 for LY_F32, 1 for LY_BF16)
  * from spatial_mixing.partial_conv3.weight ([C/4, 9*ceil4(C/4)], k = tap*ceil4(C/4) + c),
  * mlp.0.weight (rows zero-padded to 16*ly_mlpblock_hidden_tiles(C)) and mlp.3.weight; bn_* have
  * 16*ly_mlpblock_hidden_tiles(C) entries (zero padded).  stats: NULL, or [2 * 16*hidden_tiles] zeroed
  * accumulators = STATISTICS PASS of the train-mode BatchNorm (sum / sum of squares of the pre-BN hidden
  * activations; y and bn_* are ignored, nothing is stored).  x and y must not alias.
  * Built for C in {16,24,40,80,160,320}. */
-int ly_mlpblock_fwd(const float* x, float* y, int n_img, int H, int W, int C, const void* wp, const void* w1,
-                    const void* w2, const float* bn_scale, const float* bn_shift, float* stats, void* stream);
-/* ablation aid for profiling (4: skip halo staging, 8: skip stores) */
-int ly_debug_set_mlp(int v);
-/* tuning aid: 1 forces the flattened-run tiling (default: 8x16 patches where W % 16 == 0 and W >= 64);
- * 2 / 4 / 8 force flattened runs with 2 / 4 / 1 pixel tiles per wave where built */
-int ly_debug_set_mlp_tile(int v);
+int ly_mlpblock_fwd(const void* x /*T*/, void* y /*T*/, int n_img, int H, int W, int C, const void* wp, const void* w1,
+                    const void* w2, const float* bn_scale, const float* bn_shift, float* stats, int dtype, void* stream);
 /* hidden (2C) channel tiles of 16, padded to an even count */
 int ly_mlpblock_hidden_tiles(int C);
 
@@ -50,23 +51,25 @@ typedef struct LyGemmParams {
   long M;                 /* output pixels = n_img * H * W                                       */
   int H, W;               /* output spatial size                                                 */
   int K, N;               /* contraction length (multiple of 4), output channels                 */
-  const float* a0; int lda0; int k0;   /* first source: row stride (floats), columns taken       */
-  const float* a1; int lda1;           /* second source for columns [k0, K) or NULL               */
+  const void* a0; int lda0; int k0;    /* first source (T): row stride (elements), columns taken  */
+  const void* a1; int lda1;            /* second source (T) for columns [k0, K) or NULL           */
   int gather;             /* LY_GATHER_*                                                         */
   int Hin, Win, Cin, ks, pk;           /* patch gathers: input size, kernel=stride, pk = ks*lda0 */
   int pro;                /* LY_PRO_*                                                            */
   const float* g_h; const float* g_w;  /* [n_img, H, k0], [n_img, W, k0]                         */
-  const float* res; int ldres;         /* optional residual added to the gated a0 part           */
+  const void* res; int ldres;          /* optional residual (T) added to the gated a0 part       */
   const float* p_scale; const float* p_shift; const float* p_ca;   /* [K], [K], [n_img, K]       */
   const void* wp;         /* bf16x3 frag-packed weights of W[N, K] (pack.frag_pack3)             */
   const float* e_scale; const float* e_shift;   /* [N] or NULL (=1 / =0)                         */
   const float* rowscale;  /* [M] or NULL                                                         */
   int act;                /* 0 none, 1 relu, 2 silu                                              */
-  float* out; int ldo;    /* output row stride (floats); pointer may be pre-offset into a concat */
+  void* out; int ldo;     /* output (T), row stride (elements); pointer may be pre-offset into a concat */
   float* stats;           /* NULL, or [2N] zero-initialised accumulators: STATISTICS PASS for train-mode
                              BatchNorm — adds sum / sum-of-squares over the M rows of the pre-activation value
                              (rowscale*e_scale*acc + e_shift) per output channel; stores nothing when out is NULL,
                              otherwise stores act(that value) as usual (one launch for statistics + pre-BN tensor) */
+  int dtype;              /* LY_F32 / LY_BF16: element type T of a0, a1, res, out.  LY_GATHER_PATCH_NCHW reads an fp32
+                             IMAGE whatever dtype is (dtype then only selects the output element type)             */
 } LyGemmParams;
 
 /* out[m, n] = act(rowscale[m] * e_scale[n] * sum_k A'[m, k] W[n, k] + e_shift[n]).
@@ -75,14 +78,6 @@ typedef struct LyGemmParams {
  * (models/common.py:1608), RFCBAMConv's k=1 path (models/rfa.py:113-129) and the FasterNet patch
  * convolutions (models/common.py:1528-1561), depending on gather/pro. */
 int ly_gemm_fwd(const LyGemmParams* p, void* stream);
-/* tuning aid: force the GEMM tile configuration (NT*100 + MT*10 + WC), 0 = heuristic */
-int ly_debug_set_gemm_cfg(int cfg);
-/* ablation aid for profiling (bit 0: skip split+LDS write, 1: skip MFMA, 2: skip prefetch loads, 3: skip stores) */
-int ly_debug_set_gemm(int v);
-/* tuning aid: K stage of ly_gemm_fwd, 0 / 64 = default, 128 = 128-wide stage (measured slower) */
-int ly_debug_set_gemm_bk(int v);
-/* A/B aid: 1 (default) = two-deep prefetch pipeline of ly_gemm_fwd, 0 = one-deep */
-int ly_debug_set_gemm_d2(int v);
 
 
 /* ---- 3x3 / s1 / p1 convolution (implicit GEMM) ------------------------------------------------- */
@@ -90,27 +85,23 @@ typedef struct LyConv3Params {
   long M; int H, W;        /* output (= input) pixels, spatial size                              */
   int Cin, N;              /* input channels (multiple of 4), output channels                    */
   int TH, TW;              /* pixel patch per block: TH*TW <= 128, (TH+2)*(TW+2) <= 192          */
-  const float* x; int ldx; /* NHWC input, row stride (floats)                                    */
+  const void* x; int ldx;  /* NHWC input (T), row stride (elements)                              */
   const void* wp;          /* frag_pack3(conv_taps_matrix(weight, 32)): k = tap*ceil32(Cin) + c  */
   const float* e_scale; const float* e_shift;   /* folded BN / bias, [N] or NULL                 */
   int act;
-  float* out; int ldo;
+  void* out; int ldo;      /* T */
   float* stats;            /* NULL or [2N] accumulators: statistics pass (see LyGemmParams.stats)     */
+  int dtype;               /* LY_F32 / LY_BF16 */
 } LyConv3Params;
 
 /* Conv(c1, c2, 3, 1) = conv3x3(no bias) + BN + SiLU (CA_Bottleneck.cv2, models/common.py:1617,
  * 1890-1910). */
 int ly_conv3x3_fwd(const LyConv3Params* p, void* stream);
-/* ablation aid for profiling (bit 1: skip LDS reads + MFMA, 3: skip commit); the load switches (bits 0, 2) were removed:
- * a load under a run-time branch makes the compiler drain the prefetch queue after every tap */
-int ly_debug_set_conv3(int v);
-/* tuning aid: force the wave layout (MT*10 + WC), 0 = heuristic */
-int ly_debug_set_conv3_cfg(int v);
 
 
 /* ---- CoordAtt (models/common.py:1583-1609) ------------------------------------------------------- */
 /* pool[n, pos, c]: pos < H -> mean over w of row pos; pos >= H -> mean over h of column pos-H.       */
-int ly_pool_hw(const float* x, int ldx, int n_img, int H, int W, int C, float* pool, void* stream);
+int ly_pool_hw(const void* x /*T*/, int ldx, int n_img, int H, int W, int C, float* pool, int dtype, void* stream);
 /* y = h_swish(w1 . pool + b1) (bn1 folded into w1/b1: [mip, C], [mip]); a_h[n,h,:] = sigmoid(wh . y + bh),
  * a_w[n,w,:] = sigmoid(ww . y + bw); wh/ww are [C, mip].                                              */
 int ly_coordatt_mlp(const float* pool, int n_img, int H, int W, int C, int mip, const float* w1, const float* b1,
@@ -119,21 +110,19 @@ int ly_coordatt_mlp(const float* pool, int n_img, int H, int W, int C, int mip, 
 
 /* out = x * a_w[n,w,:] * a_h[n,h,:] (+ res): the gating multiply as a standalone pass (only used
  * when no consumer GEMM can absorb it, e.g. CA_Bottleneck with a residual shortcut).               */
-int ly_coordatt_gate(const float* x, int ldx, int n_img, int H, int W, int C, const float* a_h, const float* a_w,
-                     const float* res, int ldres, float* out, int ldo, void* stream);
+int ly_coordatt_gate(const void* x /*T*/, int ldx, int n_img, int H, int W, int C, const float* a_h, const float* a_w,
+                     const void* res /*T*/, int ldres, void* out /*T*/, int ldo, int dtype, void* stream);
 
 /* ---- RFCBAMConv (models/rfa.py:77-129) ----------------------------------------------------------- */
 /* rfa.SE: ca[n, :] = sigmoid(wb . relu(wa . mean_hw(x)));  wa [R, C], wb [C, R]; part = workspace
  * of n_img * slices * C floats.                                                                     */
-int ly_se_fwd(const float* x, int ldx, int n_img, int HW, int C, const float* wa, const float* wb, int R, float* part,
-              int slices, float* ca, void* stream);
+int ly_se_fwd(const void* x /*T*/, int ldx, int n_img, int HW, int C, const float* wa, const float* wb, int R, float* part,
+              int slices, float* ca, int dtype, void* stream);
 /* mm[n, y, x, 0:2] = (max_c, mean_c) of relu(bn(generate(x))) on the k-times expanded grid.
  * k = 1: a1/b1 = folded per-channel scale/shift.  k = 3: wg = pack.rfcbam_gen_weights(..., 32, False):
  * [C32/32][4 waves][9 t][4 channel pairs][20]; TH x TW (<= 64) = output-pixel tile per block.       */
-int ly_rfcbam_stats(const float* x, int ldx, int n_img, int H, int W, int C, int k, int s, const float* wg,
-                    const float* a1, const float* b1, int TH, int TW, float* mm, void* stream);
-/* ablation aid for profiling (bit 0: skip staging, 1: skip generate/reduce) */
-int ly_debug_set_stats3(int v);
+int ly_rfcbam_stats(const void* x /*T*/, int ldx, int n_img, int H, int W, int C, int k, int s, const float* wg,
+                    const float* a1, const float* b1, int TH, int TW, float* mm, int dtype, void* stream);
 /* rfa[n, y, x] = sigmoid(conv3x3_pad1(mm; w[2][3][3]))   (get_weight, models/rfa.py:107)             */
 int ly_rfa_map(const float* mm, int n_img, int HK, int WK, const float* w, float* rfa, void* stream);
 
@@ -141,40 +130,38 @@ typedef struct LyRfcbam3Params {
   int n_img, H, W, C;          /* input NHWC                                                      */
   int Ho, Wo, N, s;            /* output size, output channels, stride                            */
   int TH, TW;                  /* output-pixel tile per block (TH*TW <= 64)                       */
-  const float* x; int ldx;
+  const void* x; int ldx;      /* T */
   const float* wg;             /* pack.rfcbam_gen_weights(..., 16, True): [C/16][4][9 t][2][20]   */
   const float* ca;             /* [n_img, C]                                                      */
   const float* rfa;            /* [n_img, 3Ho, 3Wo]                                               */
   const void* wp;              /* frag_pack3(conv.0.weight as [N, C/16, 144 -> 160 zero padded])  */
   const float* e_scale; const float* e_shift;   /* conv.1 BN folded with conv.0.bias              */
-  float* out; int ldo;
+  void* out; int ldo;          /* T */
   float* stats;                /* NULL or [2N] accumulators: conv.1 BatchNorm statistics pass    */
   int linear;                  /* != 0: store the affine value without the ReLU (backward recompute) */
+  int dtype;                   /* LY_F32 / LY_BF16 */
 } LyRfcbam3Params;
 /* RFCBAMConv kernel_size 3 main contraction (+ReLU); the k=1 case is ly_gemm_fwd with
  * LY_PRO_AFFINE_RELU_CA and rowscale = rfa.                                                         */
 int ly_rfcbam3_fwd(const LyRfcbam3Params* p, void* stream);
-/* ablation aid for profiling (bit 0: skip regenerate, 1: generate weights through LDS whatever the grid, 2: skip staging,
- * 3: two 128-channel groups instead of the 256-channel tile for N > 128); 0 = normal */
-int ly_debug_set_rf3(int v);
 
 
 /* ---- graph remainder ------------------------------------------------------------------------- */
 /* SPPF pooling (models/common.py:348-366): out[n, p, :] = [x | m(x) | m(m(x)) | m(m(m(x)))] with m =
  * k x k / stride 1 / pad k//2 max pool; out row stride ldo >= 4C.  The map must fit LDS
  * (2*H*W*4 floats <= 160 KiB); C, ldx, ldo multiples of 4.                                                                    */
-int ly_sppf_pool(const float* x, int ldx, int n_img, int H, int W, int C, int k, float* out, int ldo, void* stream);
+int ly_sppf_pool(const void* x /*T*/, int ldx, int n_img, int H, int W, int C, int k, void* out /*T*/, int ldo, int dtype, void* stream);
 /* Detect tail (models/yolo.py:95-120): y[n,h,w,na*no] (row stride ldy) -> p[n,na,h,w,no] and, if z is
  * not NULL, decoded rows z[n, zoff + (a*H + h)*W + w, :] of a [n_img, zrows, no] tensor;
  * anchors = [na,2] in grid units (Detect.anchors[i]), stride = Detect.stride[i].                     */
-int ly_detect_tail(const float* y, int ldy, int n_img, int H, int W, int na, int no, const float* anchors, float stride,
-                   float* p, float* z, long zrows, long zoff, void* stream);
+int ly_detect_tail(const void* y /*T*/, int ldy, int n_img, int H, int W, int na, int no, const float* anchors, float stride,
+                   float* p, float* z, long zrows, long zoff, int dtype, void* stream);
 
 
 /* ---- train-mode BatchNorm statistics passes ----------------------------------------------------- */
 /* mom[c] += sum_rows x[r, c], mom[C + c] += sum_rows x[r, c]^2 over an [rows, C] row matrix (mom zeroed
  * by the caller).  Used for the k=1 `generate` BatchNorm of RFCBAMConv (models/rfa.py:101-106).       */
-int ly_chan_moments(const float* x, int ldx, long rows, int C, float* mom, void* stream);
+int ly_chan_moments(const void* x /*T*/, int ldx, long rows, int C, float* mom, int dtype, void* stream);
 /* CoordAtt bn1 (models/common.py:1589,1602): sum / sum of squares of conv1(pool) + bias over all
  * n*(H+W) positions, stats[0:mip] and stats[mip:2mip] (zeroed by the caller).                        */
 int ly_coordatt_conv1_stats(const float* pool, long positions, int C, int mip, const float* w1, const float* b1,
@@ -184,7 +171,7 @@ int ly_coordatt_conv1_stats(const float* pool, long positions, int C, int mip, c
  * per input channel, the 9 first moments sum x_u and the 45 second moments sum x_u x_v (u <= v, row-major
  * upper triangle) of the zero-padded stride-s 3x3 taps over all n_img*Ho*Wo output pixels; mean and
  * variance of every (channel, tap-output) follow as w.m and w^T M w on the host.                        */
-int ly_rfcbam_tap_moments(const float* x, int ldx, int n_img, int H, int W, int C, int s, float* mom, void* stream);
+int ly_rfcbam_tap_moments(const void* x /*T*/, int ldx, int n_img, int H, int W, int C, int s, float* mom, int dtype, void* stream);
 
 /* ---- backward building blocks of the training step (train.py:324 `scaler.scale(loss).backward()`) -------------
  * Data gradients of 1x1 / 3x3 stride-1 convolutions reuse ly_gemm_fwd / ly_conv3x3_fwd with transposed weights.   */
@@ -195,11 +182,11 @@ int ly_rfcbam_tap_moments(const float* x, int ldx, int n_img, int H, int W, int 
  *   apply : du = alpha[c]*dv + kappa[c] + lambda[c]*u        (du may alias u or dy)                               */
 /* y = act(a[c]*u + b[c]) over [rows, C]: the normalisation + activation half of a train-mode unit whose contraction pass
  * (stats != NULL AND out != NULL: statistics accumulated and the pre-BN value stored in ONE launch) produced u.            */
-int ly_bnact_fwd(const float* u, int ldu, long rows, int C, const float* a, const float* b, int act, float* y, int ldy, void* stream);
-int ly_bnact_bwd_reduce(const float* dy, int lddy, const float* u, int ldu, long rows, int C, const float* a, const float* b,
-                        int act, float* sums, void* stream);
-int ly_bnact_bwd_apply(const float* dy, int lddy, const float* u, int ldu, long rows, int C, const float* a, const float* b,
-                       int act, const float* alpha, const float* kappa, const float* lambda, float* du, int lddu, void* stream);
+int ly_bnact_fwd(const void* u /*T*/, int ldu, long rows, int C, const float* a, const float* b, int act, void* y /*T*/, int ldy, int dtype, void* stream);
+int ly_bnact_bwd_reduce(const void* dy /*T*/, int lddy, const void* u /*T*/, int ldu, long rows, int C, const float* a, const float* b,
+                        int act, float* sums, int dtype, void* stream);
+int ly_bnact_bwd_apply(const void* dy /*T*/, int lddy, const void* u /*T*/, int ldu, long rows, int C, const float* a, const float* b,
+                       int act, const float* alpha, const float* kappa, const float* lambda, void* du /*T*/, int lddu, int dtype, void* stream);
 
 /* Weight gradient of a convolution whose forward read input pixel (ho*stride + ky - pad, wo*stride + kx - pad):
  *   dw[n][(ky*ks + kx)*Cin + c] += sum_{m = (img, ho, wo)} du[m][n] * x[img, hi, wi, c]      (zero outside the map)
@@ -210,55 +197,54 @@ typedef struct LyWgradParams {
   long M;            /* output pixels = n_img * H * W */
   int H, W;          /* output map */
   int N;             /* output channels */
-  const float* du; int lddu;
-  const float* x; int ldx;
+  const void* du; int lddu;   /* T */
+  const void* x; int ldx;     /* T */
   int Hin, Win, Cin;
   int ks, stride, pad;
   int nchw, up2;
-  float* dw; int lddw;
+  float* dw; int lddw;        /* fp32 */
+  int dtype;                  /* LY_F32 / LY_BF16 */
 } LyWgradParams;
 int ly_wgrad(const LyWgradParams* p, void* stream);
-/* tuning aid: 1 = the 64 x 256 output tile for every N <= 64 shape (default: 32 x 128 / 64 x 128) */
-int ly_debug_set_wgrad_tile(int v);
 
 /* Adjoint of the nearest-2x read: out[n,h,w,:] = sum of d[n, 2h+{0,1}, 2w+{0,1}, :]  (d is a 2Hs x 2Ws map).      */
-int ly_up2_bwd(const float* d, int ldd, int n_img, int Hs, int Ws, int C, float* out, int ldo, void* stream);
+int ly_up2_bwd(const void* d /*T*/, int ldd, int n_img, int Hs, int Ws, int C, void* out /*T*/, int ldo, int dtype, void* stream);
 /* Adjoint of the k = s patch gather: g[m][(ky,kx,c)] -> dx[n, ks*ho+ky, ks*wo+kx, c] (dense NHWC, C % 4 == 0).    */
-int ly_unpatch(const float* g, int n_img, int Ho, int Wo, int C, int ks, float* dx, void* stream);
+int ly_unpatch(const void* g /*T*/, int n_img, int Ho, int Wo, int C, int ks, void* dx /*T*/, int dtype, void* stream);
 
 /* CoordAtt backward (models/common.py:1595-1609).  Gate out = x*a_h[n,h,:]*a_w[n,w,:]:
  *   dx = dout*a_h*a_w,  da_h[n,h,c] += sum_w dout*x*a_w,  da_w[n,w,c] += sum_h dout*x*a_h  (caller zeroes both).
  * Pools pool[n,0:H]=mean_w x, pool[n,H:H+W]=mean_h x:  dx[n,h,w,c] = gp[n,h,c]/W + gp[n,H+w,c]/H.                  */
-int ly_coordatt_gate_bwd(const float* dout, int ldd, const float* x, int ldx, int n_img, int H, int W, int C, const float* a_h,
-                         const float* a_w, float* dx, int lddx, float* da_h, float* da_w, void* stream);
-int ly_pool_hw_bwd(const float* gp, int n_img, int H, int W, int C, float* dx, int lddx, void* stream);
+int ly_coordatt_gate_bwd(const void* dout /*T*/, int ldd, const void* x /*T*/, int ldx, int n_img, int H, int W, int C, const float* a_h,
+                         const float* a_w, void* dx /*T*/, int lddx, float* da_h, float* da_w, int dtype, void* stream);
+int ly_pool_hw_bwd(const float* gp, int n_img, int H, int W, int C, void* dx /*T*/, int lddx, int dtype, void* stream);
 /* k x k / stride 1 / pad k//2 max-pool backward (SPPF, models/common.py:348-366): dx[argmax of window] += dy
  * (first maximum in row-major order, as ATen); dx is ACCUMULATED into, which lets the three chained pools add
- * into the gradient slots of the SPPF concat buffer in place.                                                       */
-int ly_maxpool_bwd(const float* x, int ldx, const float* dy, int lddy, int n_img, int H, int W, int C, int k, float* dx, int lddx,
-                   void* stream);
+ * into the gradient slots of the SPPF concat buffer in place.  x is T; dy and dx are ALWAYS fp32 (atomic accumulation).   */
+int ly_maxpool_bwd(const void* x /*T*/, int ldx, const float* dy, int lddy, int n_img, int H, int W, int C, int k, float* dx, int lddx,
+                   int dtype, void* stream);
 
 /* ---- RFCBAMConv backward (models/rfa.py:113-129 under autograd) ----------------------------------------------------
  * Expanded tensors are [m = (n, ho, wo)][t = tap][c] (channel contiguous), maps are [n, k*Ho, k*Wo]; per-(t, c) vectors
  * (ag, bg, alpha, kappa, lambda, sums) are indexed t*C + c.  See csrc/ly_rfcbam_bwd.hip for the step list.            */
 /* ug[m][t][c] = sum_u wg[c*KK + t][u] * x_u(m)[c]  (depthwise `generate` conv before its BatchNorm)                    */
-int ly_rf_generate(const float* x, int ldx, int n_img, int H, int W, int C, int k, int s, const float* wg, float* ug, void* stream);
+int ly_rf_generate(const void* x /*T*/, int ldx, int n_img, int H, int W, int C, int k, int s, const float* wg, void* ug /*T*/, int dtype, void* stream);
 /* G = relu(ag*ug + bg):  cd = G*ca*rfa (written),  d_rfa[pos] += sum_c dcd*G*ca,  gmax[pos] = max_c G (as float bits,
  * zeroed by the caller),  d_ca[n][c] += sum_{m,t} dcd*rfa*G  (d_rfa, d_ca zeroed by the caller)                        */
-int ly_rf_bwd_attn(int n_img, int H, int W, int C, int k, int s, const float* ug, const float* dcd, const float* ag, const float* bg,
-                   const float* ca, const float* rfa, float* cd, float* d_rfa, float* gmax, float* d_ca, void* stream);
+int ly_rf_bwd_attn(int n_img, int H, int W, int C, int k, int s, const void* ug /*T*/, const void* dcd /*T*/, const float* ag, const float* bg,
+                   const float* ca, const float* rfa, void* cd /*T*/, float* d_rfa, float* gmax, float* d_ca, int dtype, void* stream);
 /* rfa = sigmoid(conv3x3(mm; w18)) backward: d_mm[n,y,x,2] (written) and dw18[18] (+=, zeroed by the caller)            */
 int ly_rfa_bwd(const float* d_rfa, const float* rfa, const float* mm, const float* w18, int n_img, int Hk, int Wk, float* d_mm,
                float* dw18, void* stream);
 /* dv = [G>0]*(dcd*rfa*ca + d_mm.mean/C + [G==gmax]*d_mm.max) written over dcd; sums[t*C+c] += dv, sums[C*KK + ..] += dv*ug */
-int ly_rf_bwd_relu(int n_img, int H, int W, int C, int k, int s, const float* ug, float* dcd, const float* ag, const float* bg,
-                   const float* ca, const float* rfa, const float* gmax, const float* d_mm, float* sums, void* stream);
+int ly_rf_bwd_relu(int n_img, int H, int W, int C, int k, int s, const void* ug /*T*/, void* dcd /*T*/, const float* ag, const float* bg,
+                   const float* ca, const float* rfa, const float* gmax, const float* d_mm, float* sums, int dtype, void* stream);
 /* dug = alpha*dv + kappa + lambda*ug written over dv; dwg[row][c*KK + t][u] = partial sums of sum_m dug*x_u: a
  * [part_rows][C*KK][KK] matrix zeroed by the caller; every (block, pixel sub-group) stores one row, the caller sums rows */
-int ly_rf_bwd_gen(const float* x, int ldx, int n_img, int H, int W, int C, int k, int s, const float* ug, float* dv, const float* alpha,
-                  const float* kappa, const float* lambda, float* dwg, int part_rows, void* stream);
+int ly_rf_bwd_gen(const void* x /*T*/, int ldx, int n_img, int H, int W, int C, int k, int s, const void* ug /*T*/, void* dv /*T*/, const float* alpha,
+                  const float* kappa, const float* lambda, float* dwg, int part_rows, int dtype, void* stream);
 /* dx[n,hi,wi,c] = sum over (m, u) reading that input pixel of sum_t dug[m][t][c]*wg[c*KK + t][u]  (written)           */
-int ly_rf_bwd_dx(int n_img, int H, int W, int C, int k, int s, const float* dug, const float* wg, float* dx, int lddx, void* stream);
+int ly_rf_bwd_dx(int n_img, int H, int W, int C, int k, int s, const void* dug /*T*/, const float* wg, void* dx /*T*/, int lddx, int dtype, void* stream);
 
 /* ---- per-channel BatchNorm vector work and weight packing, one launch each ------------------------------------------
  * STATISTICS ACCUMULATORS ARE STRIPED: every `stats` / `sums` / `mom` argument of the statistics passes above
@@ -276,9 +262,10 @@ int ly_bn_finalize(const float* stats, int stripes, int nch, int c_off, int N, d
  * du = alpha*dv + kappa + lambda*u  (train != 0: batch statistics; else alpha = a, kappa = lambda = 0).               */
 int ly_bn_bwd_coeffs(const float* sums, int stripes, int N, double count, const float* a, const float* mean, const float* invstd, int train,
                      float* dgamma, float* dbeta, float* alpha, float* kappa, float* lambda, void* stream);
-/* bf16x3 fragment packing of W[r][k] = w[r*ld_r + k*ld_k] (R x K, rows zero padded to max(R, rows_to)) into the
- * [T][S][2 planes][64 lanes][8] bf16 layout the contraction kernels read (csrc/ly_tile.cuh).                          */
-int ly_frag_pack3(const float* w, int R, int K, long ld_r, long ld_k, int rows_to, void* out, void* stream);
+/* Fragment packing of the fp32 matrix W[r][k] = w[r*ld_r + k*ld_k] (R x K, rows zero padded to max(R, rows_to)) into the
+ * [T][S][planes][64 lanes][8] bf16 layout the contraction kernels read (csrc/ly_tile.cuh): planes = 2 (hi = bf16(W),
+ * lo = bf16(W - hi): the bf16x3 operand of LY_F32 calls) or 1 (hi only: LY_BF16 calls).                                */
+int ly_frag_pack3(const float* w, int R, int K, long ld_r, long ld_k, int rows_to, int planes, void* out, void* stream);
 
 /* ---- detection loss on device (utils/loss.py:121-268 ComputeLoss / build_targets, utils/metrics.py:293-354 EIoU) --------
  * One pyramid level, forward and gradient (nc == 1, no focal loss): anchor matching with the reference's candidate order

@@ -24,27 +24,41 @@ class LyGemmParams(ctypes.Structure):       # mirrors include/lead_yolo_hip.h
                 ("pro", _I), ("g_h", _P), ("g_w", _P), ("res", _P), ("ldres", _I),
                 ("p_scale", _P), ("p_shift", _P), ("p_ca", _P),
                 ("wp", _P), ("e_scale", _P), ("e_shift", _P), ("rowscale", _P), ("act", _I),
-                ("out", _P), ("ldo", _I), ("stats", _P)]
+                ("out", _P), ("ldo", _I), ("stats", _P), ("dtype", _I)]
 
 
 class LyConv3Params(ctypes.Structure):
     _fields_ = [("M", _L), ("H", _I), ("W", _I), ("Cin", _I), ("N", _I), ("TH", _I), ("TW", _I), ("x", _P), ("ldx", _I), ("wp", _P),
-                ("e_scale", _P), ("e_shift", _P), ("act", _I), ("out", _P), ("ldo", _I), ("stats", _P)]
+                ("e_scale", _P), ("e_shift", _P), ("act", _I), ("out", _P), ("ldo", _I), ("stats", _P), ("dtype", _I)]
 
 
 class LyRfcbam3Params(ctypes.Structure):
     _fields_ = [("n_img", _I), ("H", _I), ("W", _I), ("C", _I), ("Ho", _I), ("Wo", _I), ("N", _I), ("s", _I),
                 ("TH", _I), ("TW", _I), ("x", _P), ("ldx", _I), ("wg", _P), ("ca", _P), ("rfa", _P), ("wp", _P),
-                ("e_scale", _P), ("e_shift", _P), ("out", _P), ("ldo", _I), ("stats", _P), ("linear", _I)]
+                ("e_scale", _P), ("e_shift", _P), ("out", _P), ("ldo", _I), ("stats", _P), ("linear", _I), ("dtype", _I)]
 
 
 class LyWgradParams(ctypes.Structure):
     _fields_ = [("M", _L), ("H", _I), ("W", _I), ("N", _I), ("du", _P), ("lddu", _I), ("x", _P), ("ldx", _I),
                 ("Hin", _I), ("Win", _I), ("Cin", _I), ("ks", _I), ("stride", _I), ("pad", _I), ("nchw", _I), ("up2", _I),
-                ("dw", _P), ("lddw", _I)]
+                ("dw", _P), ("lddw", _I), ("dtype", _I)]
 
 
 STATS_STRIPES = 32
+LY_F32, LY_BF16 = 0, 1                     # `dtype` codes of the C ABI
+
+
+def dtype_code(t):
+    """LY_F32 / LY_BF16 for a tensor (or torch dtype)"""
+    import torch
+    d = t if isinstance(t, torch.dtype) else t.dtype
+    if d == torch.float32:
+        return LY_F32
+    if d == torch.bfloat16:
+        return LY_BF16
+    raise HipLibraryError(f"the HIP kernels are built for float32 and bfloat16 activations (got {d})")
+
+
 ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
 GATHER_ROWS, GATHER_UP2, GATHER_PATCH, GATHER_PATCH_NCHW = 0, 1, 2, 3
 PRO_NONE, PRO_GATE, PRO_AFFINE_RELU_CA = 0, 1, 2
@@ -52,53 +66,42 @@ PRO_NONE, PRO_GATE, PRO_AFFINE_RELU_CA = 0, 1, 2
 # name -> argtypes  (every entry point returns int: 0 ok, <0 error with ly_last_error())
 SIGNATURES = {
     "ly_abi_version": [],
-    "ly_mlpblock_fwd": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
+    "ly_mlpblock_fwd": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P],
     "ly_mlpblock_hidden_tiles": [_I],
     "ly_gemm_fwd": [ctypes.POINTER(LyGemmParams), _P],
-    "ly_debug_set_gemm_cfg": [_I],
-    "ly_debug_set_gemm": [_I],
-    "ly_debug_set_gemm_bk": [_I],
-    "ly_debug_set_gemm_d2": [_I],
-    "ly_debug_set_rf3": [_I],
-    "ly_debug_set_conv3": [_I],
-    "ly_debug_set_conv3_cfg": [_I],
-    "ly_debug_set_stats3": [_I],
-    "ly_debug_set_mlp": [_I],
-    "ly_debug_set_mlp_tile": [_I],
-    "ly_debug_set_wgrad_tile": [_I],
     "ly_conv3x3_fwd": [ctypes.POINTER(LyConv3Params), _P],
-    "ly_pool_hw": [_P, _I, _I, _I, _I, _I, _P, _P],
+    "ly_pool_hw": [_P, _I, _I, _I, _I, _I, _P, _I, _P],
     "ly_coordatt_mlp": [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
-    "ly_coordatt_gate": [_P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _P],
-    "ly_se_fwd": [_P, _I, _I, _I, _I, _P, _P, _I, _P, _I, _P, _P],
-    "ly_rfcbam_stats": [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P],
+    "ly_coordatt_gate": [_P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _P],
+    "ly_se_fwd": [_P, _I, _I, _I, _I, _P, _P, _I, _P, _I, _P, _I, _P],
+    "ly_rfcbam_stats": [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P, _I, _P],
     "ly_rfa_map": [_P, _I, _I, _I, _P, _P, _P],
     "ly_rfcbam3_fwd": [ctypes.POINTER(LyRfcbam3Params), _P],
-    "ly_chan_moments": [_P, _I, _L, _I, _P, _P],
-    "ly_rfcbam_tap_moments": [_P, _I, _I, _I, _I, _I, _I, _P, _P],
+    "ly_chan_moments": [_P, _I, _L, _I, _P, _I, _P],
+    "ly_rfcbam_tap_moments": [_P, _I, _I, _I, _I, _I, _I, _P, _I, _P],
     "ly_coordatt_conv1_stats": [_P, _L, _I, _I, _P, _P, _P, _P],
-    "ly_sppf_pool": [_P, _I, _I, _I, _I, _I, _I, _P, _I, _P],
-    "ly_bnact_fwd": [_P, _I, _L, _I, _P, _P, _I, _P, _I, _P],
-    "ly_bnact_bwd_reduce": [_P, _I, _P, _I, _L, _I, _P, _P, _I, _P, _P],
-    "ly_bnact_bwd_apply": [_P, _I, _P, _I, _L, _I, _P, _P, _I, _P, _P, _P, _P, _I, _P],
+    "ly_sppf_pool": [_P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P],
+    "ly_bnact_fwd": [_P, _I, _L, _I, _P, _P, _I, _P, _I, _I, _P],
+    "ly_bnact_bwd_reduce": [_P, _I, _P, _I, _L, _I, _P, _P, _I, _P, _I, _P],
+    "ly_bnact_bwd_apply": [_P, _I, _P, _I, _L, _I, _P, _P, _I, _P, _P, _P, _P, _I, _I, _P],
     "ly_wgrad": [ctypes.POINTER(LyWgradParams), _P],
-    "ly_up2_bwd": [_P, _I, _I, _I, _I, _I, _P, _I, _P],
-    "ly_unpatch": [_P, _I, _I, _I, _I, _I, _P, _P],
-    "ly_coordatt_gate_bwd": [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P],
-    "ly_pool_hw_bwd": [_P, _I, _I, _I, _I, _P, _I, _P],
-    "ly_maxpool_bwd": [_P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P],
-    "ly_rf_generate": [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
-    "ly_rf_bwd_attn": [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "ly_up2_bwd": [_P, _I, _I, _I, _I, _I, _P, _I, _I, _P],
+    "ly_unpatch": [_P, _I, _I, _I, _I, _I, _P, _I, _P],
+    "ly_coordatt_gate_bwd": [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _I, _P],
+    "ly_pool_hw_bwd": [_P, _I, _I, _I, _I, _P, _I, _I, _P],
+    "ly_maxpool_bwd": [_P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P],
+    "ly_rf_generate": [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P],
+    "ly_rf_bwd_attn": [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "ly_rfa_bwd": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P],
-    "ly_rf_bwd_relu": [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
-    "ly_rf_bwd_gen": [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P],
-    "ly_rf_bwd_dx": [_I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P],
+    "ly_rf_bwd_relu": [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
+    "ly_rf_bwd_gen": [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "ly_rf_bwd_dx": [_I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P],
     "ly_bn_finalize": [_P, _I, _I, _I, _I, ctypes.c_double, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P],
     "ly_bn_bwd_coeffs": [_P, _I, _I, ctypes.c_double, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P],
-    "ly_frag_pack3": [_P, _I, _I, _L, _L, _I, _P, _P],
+    "ly_frag_pack3": [_P, _I, _I, _L, _L, _I, _I, _P, _P],
     "ly_loss_level": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P, _I, _P],
     "ly_loss_finish": [_P, _I, _P, _P, _F, _F, _I, _P, _P],
-    "ly_detect_tail": [_P, _I, _I, _I, _I, _I, _I, _P, _F, _P, _P, _L, _L, _P],
+    "ly_detect_tail": [_P, _I, _I, _I, _I, _I, _I, _P, _F, _P, _P, _L, _L, _I, _P],
 }
 
 

@@ -1,4 +1,4 @@
-// Small reduction / gating kernels of the two attention blocks (fp32, gfx950).  All are
+// Small reduction / gating kernels of the two attention blocks (gfx950; activations T = float / __bf16, tables fp32).  All are
 // bandwidth-trivial next to the convolutions; they exist so that the big tensors are read a minimal
 // number of times and the 9x-expanded RFCBAM tensor is never written.
 //
@@ -13,11 +13,13 @@
 #include "ly_tile.cuh"
 #include "ly_params.h"
 
+
 // ---------------------------------------------------------------------------------------------------
 // generic strided reduction:  out[o, c] = scale * sum_{j < L} x[base(o) + j*stride + c]
 // one block per output row o; threads = (c4, j-lane)
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(LY_THREADS) void ly_pool_hw_kernel(const float* __restrict__ x, int ldx, int H, int W, int C,
+template <typename T>
+__global__ __launch_bounds__(LY_THREADS) void ly_pool_hw_kernel(const T* __restrict__ x, int ldx, int H, int W, int C,
                                                                  float* __restrict__ pool) {
   // block b -> (n, pos); pos < H: mean over w of row pos; else mean over h of column pos-H
   __shared__ f32x4 red[LY_THREADS];
@@ -34,7 +36,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_pool_hw_kernel(const float* __r
   f32x4 s = ly_zero4();
   if (j0 < groups) {
 #pragma unroll 4
-    for (int j = j0; j < len; j += groups) s += ly_ldg4(x + (base + j * step) * ldx + 4 * c4);
+    for (int j = j0; j < len; j += groups) s += ly_ld4<T>(x + (base + j * step) * ldx + 4 * c4);
   }
   red[tid] = s;
   __syncthreads();
@@ -45,10 +47,11 @@ __global__ __launch_bounds__(LY_THREADS) void ly_pool_hw_kernel(const float* __r
   }
 }
 
-extern "C" int ly_pool_hw(const float* x, int ldx, int n_img, int H, int W, int C, float* pool, void* stream) {
+extern "C" int ly_pool_hw(const void* x, int ldx, int n_img, int H, int W, int C, float* pool, int dtype, void* stream) {
+  LY_CHECK_DTYPE(dtype, "pool_hw");
   LY_CHECK(x && pool && (C & 3) == 0 && (ldx & 3) == 0 && C <= 1024, "pool_hw: bad arguments (C=%d ldx=%d)", C, ldx);
-  hipLaunchKernelGGL(ly_pool_hw_kernel, dim3(n_img * (H + W)), dim3(LY_THREADS), 0, reinterpret_cast<hipStream_t>(stream), x,
-                     ldx, H, W, C, pool);
+  LY_WITH_T(dtype, hipLaunchKernelGGL(ly_pool_hw_kernel<T>, dim3(n_img * (H + W)), dim3(LY_THREADS), 0, reinterpret_cast<hipStream_t>(stream),
+                                      reinterpret_cast<const T*>(x), ldx, H, W, C, pool));
   LY_LAUNCH_CHECK();
   return 0;
 }
@@ -97,7 +100,8 @@ extern "C" int ly_coordatt_mlp(const float* pool, int n_img, int H, int W, int C
 // ---------------------------------------------------------------------------------------------------
 // SE: partial spatial sums then the two tiny linears
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(LY_THREADS) void ly_colsum_kernel(const float* __restrict__ x, int ldx, int P, int C, int slices,
+template <typename T>
+__global__ __launch_bounds__(LY_THREADS) void ly_colsum_kernel(const T* __restrict__ x, int ldx, int P, int C, int slices,
                                                                 float* __restrict__ part) {
   __shared__ f32x4 red[LY_THREADS];
   const int n = blockIdx.x / slices, sl = blockIdx.x - n * slices;
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_colsum_kernel(const float* __re
   f32x4 s = ly_zero4();
   if (j0 < groups) {
 #pragma unroll 4
-    for (int j = j_lo + j0; j < j_hi; j += groups) s += ly_ldg4(x + ((long)n * P + j) * ldx + 4 * c4);
+    for (int j = j_lo + j0; j < j_hi; j += groups) s += ly_ld4<T>(x + ((long)n * P + j) * ldx + 4 * c4);
   }
   red[tid] = s;
   __syncthreads();
@@ -157,12 +161,13 @@ __global__ __launch_bounds__(LY_THREADS) void ly_se_mlp_kernel(const float* __re
   }
 }
 
-extern "C" int ly_se_fwd(const float* x, int ldx, int n_img, int HW, int C, const float* wa, const float* wb, int R, float* part,
-                         int slices, float* ca, void* stream) {
+extern "C" int ly_se_fwd(const void* x, int ldx, int n_img, int HW, int C, const float* wa, const float* wb, int R, float* part,
+                         int slices, float* ca, int dtype, void* stream) {
+  LY_CHECK_DTYPE(dtype, "se");
   LY_CHECK(x && wa && wb && part && ca, "se: null pointer");
   LY_CHECK((C & 3) == 0 && (ldx & 3) == 0 && C <= 1024 && slices > 0 && R > 0 && R <= 256, "se: bad arguments");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(ly_colsum_kernel, dim3(n_img * slices), dim3(LY_THREADS), 0, st, x, ldx, HW, C, slices, part);
+  LY_WITH_T(dtype, hipLaunchKernelGGL(ly_colsum_kernel<T>, dim3(n_img * slices), dim3(LY_THREADS), 0, st, reinterpret_cast<const T*>(x), ldx, HW, C, slices, part));
   LY_LAUNCH_CHECK();
   hipLaunchKernelGGL(ly_se_mlp_kernel, dim3(n_img), dim3(LY_THREADS), sizeof(float) * (((C + R + 3) & ~3) + 4 * LY_THREADS), st, part, slices, C, 1.f / (float)HW,
                      wa, wb, R, ca);
@@ -173,7 +178,8 @@ extern "C" int ly_se_fwd(const float* x, int ldx, int n_img, int HW, int C, cons
 // ---------------------------------------------------------------------------------------------------
 // RFCBAM statistics, k = 1:  g = relu(x*a + b);  mm[pix] = (max_c g, mean_c g).  One wave per pixel.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_stats1_kernel(const float* __restrict__ x, int ldx, long M, int C,
+template <typename T>
+__global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_stats1_kernel(const T* __restrict__ x, int ldx, long M, int C,
                                                                        const float* __restrict__ a, const float* __restrict__ b,
                                                                        float* __restrict__ mm) {
   const int lane = threadIdx.x & 63;
@@ -184,7 +190,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_stats1_kernel(const floa
   for (long p = wave; p < M; p += nwaves) {
     float mx = -FLT_MAX, sm = 0.f;
     for (int c4 = lane; c4 < nc4; c4 += 64) {
-      const f32x4 v = ly_ldg4(x + p * ldx + 4 * c4), s = ly_ldg4(a + 4 * c4), t = ly_ldg4(b + 4 * c4);
+      const f32x4 v = ly_ld4<T>(x + p * ldx + 4 * c4), s = ly_ldg4(a + 4 * c4), t = ly_ldg4(b + 4 * c4);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float g = fmaxf(v[r] * s[r] + t[r], 0.f);
@@ -213,9 +219,10 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_stats1_kernel(const floa
 #define LY_SCC 32
 #define LY_ST3_NV 10              // float4 staging items per thread per chunk: IH*IW*8 <= 10*256
 #define LY_ST3_WF (9 * 4 * 20)    // floats of folded weights per wave per chunk: [9 t][4 channel pairs][9 x (w_a, w_b) + (b_a, b_b)]
-__global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_stats3_kernel(const float* __restrict__ x, int ldx, int H, int W, int C,
+template <typename T>
+__global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_stats3_kernel(const T* __restrict__ x, int ldx, int H, int W, int C,
                                                                        int Ho, int Wo, int s, int TH, int TW, int nct, int nrt,
-                                                                       const float* __restrict__ wg, float* __restrict__ mm, const int dbg) {
+                                                                       const float* __restrict__ wg, float* __restrict__ mm) {
   extern __shared__ float lds[];
   const int IH = s * (TH - 1) + 3, IW = s * (TW - 1) + 3;
   float* wsm = lds;                                  // [4 waves][LY_ST3_WF]: this chunk's folded weights (16-B aligned)
@@ -262,12 +269,12 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_stats3_kernel(const floa
 
   // the input tile (pv) and the folded weights (wv) of chunk c+1 are requested before chunk c is regenerated: no load is waited
   // for right after it is issued
-  f32x4 pv[LY_ST3_NV];
+  typename LyT<T>::R4 pv[LY_ST3_NV];
   auto prefetch = [&](int c0) {
 #pragma unroll
     for (int e = 0; e < LY_ST3_NV; ++e) {
       const bool ok = soff[e] >= 0 && c0 + 4 * ((tid + e * LY_THREADS) & 7) < C;
-      pv[e] = ly_ldg4(ok ? x + soff[e] + c0 : x);
+      pv[e] = ly_ldr4<T>(ok ? x + soff[e] + c0 : x);
     }
   };
   constexpr int WV = (4 * LY_ST3_WF / 4 + LY_THREADS - 1) / LY_THREADS;
@@ -292,19 +299,18 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_stats3_kernel(const floa
     }
     const bool more = c0 + LY_SCC < C;
     wprefetch(more ? c0 / LY_SCC + 1 : 0);
-    if (!(dbg & 1)) {
 #pragma unroll
-      for (int e = 0; e < LY_ST3_NV; ++e) {
-        if (doff[e] >= 0) {
-          const bool ok = soff[e] >= 0 && c0 + 4 * ((tid + e * LY_THREADS) & 7) < C;
-          float* d = xs + doff[e];
-          d[0] = ok ? pv[e][0] : 0.f; d[1] = ok ? pv[e][1] : 0.f; d[2] = ok ? pv[e][2] : 0.f; d[3] = ok ? pv[e][3] : 0.f;
-        }
+    for (int e = 0; e < LY_ST3_NV; ++e) {
+      if (doff[e] >= 0) {
+        const bool ok = soff[e] >= 0 && c0 + 4 * ((tid + e * LY_THREADS) & 7) < C;
+        const f32x4 pf = ly_r4_f32(pv[e]);
+        float* d = xs + doff[e];
+        d[0] = ok ? pf[0] : 0.f; d[1] = ok ? pf[1] : 0.f; d[2] = ok ? pf[2] : 0.f; d[3] = ok ? pf[3] : 0.f;
       }
     }
     prefetch(more ? c0 + LY_SCC : 0);      // unconditional: a load under a run-time branch makes every later wait conservative
     __syncthreads();
-    if (!(dbg & 2)) {
+    {
       // inputs of this wave's 8 channels (c0 + wave + 4j) as 4 packed pairs (j = 2p, 2p+1), then the folded
       // weights [t][p][9 x (w_a, w_b), (b_a, b_b)] read as wave-uniform LDS broadcasts: v_pk_fma_f32 does two
       // channels per instruction; two pairs at a time so that two independent accumulation chains interleave.
@@ -363,11 +369,9 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_stats3_kernel(const floa
   }
 }
 
-static int g_st3_dbg = 0;   // ablation aid: 1 skip staging, 2 skip generate/reduce
-extern "C" int ly_debug_set_stats3(int v) { g_st3_dbg = v; return 0; }
-
-extern "C" int ly_rfcbam_stats(const float* x, int ldx, int n_img, int H, int W, int C, int k, int s, const float* wg,
-                               const float* a1, const float* b1, int TH, int TW, float* mm, void* stream) {
+extern "C" int ly_rfcbam_stats(const void* x, int ldx, int n_img, int H, int W, int C, int k, int s, const float* wg,
+                               const float* a1, const float* b1, int TH, int TW, float* mm, int dtype, void* stream) {
+  LY_CHECK_DTYPE(dtype, "rfcbam_stats");
   LY_CHECK(x && mm && (C & 3) == 0 && (ldx & 3) == 0, "rfcbam_stats: bad arguments");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (k == 1) {
@@ -375,7 +379,7 @@ extern "C" int ly_rfcbam_stats(const float* x, int ldx, int n_img, int H, int W,
     long M = (long)n_img * H * W;
     long blocks = (M + 3) / 4;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(ly_rfcbam_stats1_kernel, dim3((unsigned)blocks), dim3(LY_THREADS), 0, st, x, ldx, M, C, a1, b1, mm);
+    LY_WITH_T(dtype, hipLaunchKernelGGL(ly_rfcbam_stats1_kernel<T>, dim3((unsigned)blocks), dim3(LY_THREADS), 0, st, reinterpret_cast<const T*>(x), ldx, M, C, a1, b1, mm));
     LY_LAUNCH_CHECK();
     return 0;
   }
@@ -389,12 +393,14 @@ extern "C" int ly_rfcbam_stats(const float* x, int ldx, int n_img, int H, int W,
   LY_CHECK(lds <= 160 * 1024, "rfcbam_stats: tile needs %zu B LDS", lds);
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ly_rfcbam_stats3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ly_rfcbam_stats3_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    LY_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(ly_rfcbam_stats3_kernel<__bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     LY_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     configured = true;
   }
-  hipLaunchKernelGGL(ly_rfcbam_stats3_kernel, dim3(n_img * nrt * nct), dim3(LY_THREADS), lds, st, x, ldx, H, W, C, Ho, Wo, s, TH, TW,
-                     nct, nrt, wg, mm, g_st3_dbg);
+  LY_WITH_T(dtype, hipLaunchKernelGGL(ly_rfcbam_stats3_kernel<T>, dim3(n_img * nrt * nct), dim3(LY_THREADS), lds, st, reinterpret_cast<const T*>(x), ldx, H, W, C,
+                                      Ho, Wo, s, TH, TW, nct, nrt, wg, mm));
   LY_LAUNCH_CHECK();
   return 0;
 }
@@ -431,9 +437,10 @@ extern "C" int ly_rfa_map(const float* mm, int n_img, int HK, int WK, const floa
 }
 
 // standalone CoordAtt gating: out = x * a_w[n,w,:] * a_h[n,h,:] (+ res)   (models/common.py:1608, 1623)
-__global__ __launch_bounds__(LY_THREADS) void ly_gate_kernel(const float* __restrict__ x, int ldx, long M, int H, int W, int C,
+template <typename T>
+__global__ __launch_bounds__(LY_THREADS) void ly_gate_kernel(const T* __restrict__ x, int ldx, long M, int H, int W, int C,
                                                               const float* __restrict__ a_h, const float* __restrict__ a_w,
-                                                              const float* __restrict__ res, int ldres, float* __restrict__ out, int ldo) {
+                                                              const T* __restrict__ res, int ldres, T* __restrict__ out, int ldo) {
   const int nc4 = C >> 2;
   const long total = M * nc4;
   for (long i = (long)blockIdx.x * LY_THREADS + threadIdx.x; i < total; i += (long)gridDim.x * LY_THREADS) {
@@ -442,20 +449,21 @@ __global__ __launch_bounds__(LY_THREADS) void ly_gate_kernel(const float* __rest
     const int w = (int)(p % W);
     const long nh = p / W;               // n*H + h
     const long n = nh / H;
-    f32x4 v = ly_ldg4(x + p * ldx + c) * ly_ldg4(a_w + (n * W + w) * C + c) * ly_ldg4(a_h + nh * C + c);
-    if (res) v += ly_ldg4(res + p * ldres + c);
-    ly_stg4(out + p * ldo + c, v);
+    f32x4 v = ly_ld4<T>(x + p * ldx + c) * ly_ldg4(a_w + (n * W + w) * C + c) * ly_ldg4(a_h + nh * C + c);
+    if (res) v += ly_ld4<T>(res + p * ldres + c);
+    ly_st4<T>(out + p * ldo + c, v);
   }
 }
 
-extern "C" int ly_coordatt_gate(const float* x, int ldx, int n_img, int H, int W, int C, const float* a_h, const float* a_w,
-                                const float* res, int ldres, float* out, int ldo, void* stream) {
-  LY_CHECK(x && a_h && a_w && out && (C & 3) == 0 && (ldx & 3) == 0 && (ldo & 3) == 0, "gate: bad arguments");
+extern "C" int ly_coordatt_gate(const void* x, int ldx, int n_img, int H, int W, int C, const float* a_h, const float* a_w,
+                                const void* res, int ldres, void* out, int ldo, int dtype, void* stream) {
+  LY_CHECK_DTYPE(dtype, "gate");
+  LY_CHECK(x && a_h && a_w && out && (C & 3) == 0 && (ldx & 3) == 0 && (ldo & 3) == 0 && (ldres & 3) == 0, "gate: bad arguments");
   long M = (long)n_img * H * W;
   long blocks = (M * (C >> 2) + LY_THREADS - 1) / LY_THREADS;
   if (blocks > 256 * 8) blocks = 256 * 8;
-  hipLaunchKernelGGL(ly_gate_kernel, dim3((unsigned)blocks), dim3(LY_THREADS), 0, reinterpret_cast<hipStream_t>(stream), x, ldx, M, H,
-                     W, C, a_h, a_w, res, ldres, out, ldo);
+  LY_WITH_T(dtype, hipLaunchKernelGGL(ly_gate_kernel<T>, dim3((unsigned)blocks), dim3(LY_THREADS), 0, reinterpret_cast<hipStream_t>(stream),
+                                      reinterpret_cast<const T*>(x), ldx, M, H, W, C, a_h, a_w, reinterpret_cast<const T*>(res), ldres, reinterpret_cast<T*>(out), ldo));
   LY_LAUNCH_CHECK();
   return 0;
 }
@@ -468,8 +476,9 @@ extern "C" int ly_coordatt_gate(const float* x, int ldx, int n_img, int H, int W
 // One block per (image, 16-channel group); the map (H*W <= 4096) lives in LDS.
 // ---------------------------------------------------------------------------------------------------
 #define LY_SP_CG 4     // channels per block: n_img * C/4 blocks keep the whole chip busy on the small P5 map
-__global__ __launch_bounds__(LY_THREADS) void ly_sppf_pool_kernel(const float* __restrict__ x, int ldx, int H, int W, int C, int k,
-                                                                  float* __restrict__ out, int ldo) {
+template <typename T>
+__global__ __launch_bounds__(LY_THREADS) void ly_sppf_pool_kernel(const T* __restrict__ x, int ldx, int H, int W, int C, int k,
+                                                                  T* __restrict__ out, int ldo) {
   extern __shared__ f32x4 sp4[];               // a[HW], b[HW] as float4 (4 channels per position)
   const int HW = H * W;
   f32x4* a = sp4;
@@ -480,9 +489,9 @@ __global__ __launch_bounds__(LY_THREADS) void ly_sppf_pool_kernel(const float* _
   const int tid = threadIdx.x, r = k / 2;
   const f32x4 ninf = (f32x4){-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
   for (int p = tid; p < HW; p += LY_THREADS) {
-    const f32x4 v = ly_ldg4(x + ((long)n * HW + p) * ldx + c0);
+    const f32x4 v = ly_ld4<T>(x + ((long)n * HW + p) * ldx + c0);
     a[p] = v;
-    ly_stg4(out + ((long)n * HW + p) * ldo + c0, v);
+    ly_st4<T>(out + ((long)n * HW + p) * ldo + c0, v);
   }
   __syncthreads();
   for (int level = 1; level <= 3; ++level) {
@@ -513,24 +522,27 @@ __global__ __launch_bounds__(LY_THREADS) void ly_sppf_pool_kernel(const float* _
         }
       }
       a[p] = m;
-      ly_stg4(out + ((long)n * HW + p) * ldo + level * C + c0, m);
+      ly_st4<T>(out + ((long)n * HW + p) * ldo + level * C + c0, m);
     }
     __syncthreads();
   }
 }
 
-extern "C" int ly_sppf_pool(const float* x, int ldx, int n_img, int H, int W, int C, int k, float* out, int ldo, void* stream) {
+extern "C" int ly_sppf_pool(const void* x, int ldx, int n_img, int H, int W, int C, int k, void* out, int ldo, int dtype, void* stream) {
+  LY_CHECK_DTYPE(dtype, "sppf_pool");
   LY_CHECK(x && out && k >= 1 && (k & 1) && (C & 3) == 0 && (ldx & 3) == 0 && (ldo & 3) == 0, "sppf_pool: bad arguments");
   size_t lds = sizeof(float) * 2 * (size_t)H * W * 4;
   LY_CHECK(lds <= 160 * 1024, "sppf_pool: %dx%d map does not fit LDS (%zu B)", H, W, lds);
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ly_sppf_pool_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ly_sppf_pool_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    LY_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(ly_sppf_pool_kernel<__bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     LY_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     configured = true;
   }
-  hipLaunchKernelGGL(ly_sppf_pool_kernel, dim3(n_img * (C / LY_SP_CG)), dim3(LY_THREADS), lds, reinterpret_cast<hipStream_t>(stream), x,
-                     ldx, H, W, C, k, out, ldo);
+  LY_WITH_T(dtype, hipLaunchKernelGGL(ly_sppf_pool_kernel<T>, dim3(n_img * (C / LY_SP_CG)), dim3(LY_THREADS), lds, reinterpret_cast<hipStream_t>(stream),
+                                      reinterpret_cast<const T*>(x), ldx, H, W, C, k, reinterpret_cast<T*>(out), ldo));
   LY_LAUNCH_CHECK();
   return 0;
 }
@@ -540,7 +552,8 @@ extern "C" int ly_sppf_pool(const float* x, int ldx, int n_img, int H, int W, in
 // ldy) write the raw map p[n, a, h, w, o] and, in eval mode, the decoded rows z[n, zoff + (a*H + h)*W + w, o]:
 //   xy = (2*sig - 0.5 + grid) * stride,  wh = (2*sig)^2 * anchor*stride,  rest = sig.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(LY_THREADS) void ly_detect_tail_kernel(const float* __restrict__ y, int ldy, long total, int H, int W, int na, int no,
+template <typename T>
+__global__ __launch_bounds__(LY_THREADS) void ly_detect_tail_kernel(const T* __restrict__ y, int ldy, long total, int H, int W, int na, int no,
                                                                     const float* __restrict__ anchors /* [na,2] grid units */, float stride,
                                                                     float* __restrict__ p, float* __restrict__ z, long zrows, long zoff) {
   const long i = (long)blockIdx.x * LY_THREADS + threadIdx.x;      // over n*na*H*W*no, output order
@@ -551,7 +564,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_detect_tail_kernel(const float*
   const int h = (int)(t % H); t /= H;
   const int a = (int)(t % na);
   const long n = t / na;
-  const float v = y[((n * H + h) * W + w) * ldy + a * no + o];
+  const float v = ly_ld1<T>(y + ((n * H + h) * W + w) * ldy + a * no + o);
   p[i] = v;
   if (z) {
     const float s = ly_sigmoid(v);
@@ -563,12 +576,13 @@ __global__ __launch_bounds__(LY_THREADS) void ly_detect_tail_kernel(const float*
   }
 }
 
-extern "C" int ly_detect_tail(const float* y, int ldy, int n_img, int H, int W, int na, int no, const float* anchors, float stride,
-                              float* p, float* z, long zrows, long zoff, void* stream) {
+extern "C" int ly_detect_tail(const void* y, int ldy, int n_img, int H, int W, int na, int no, const float* anchors, float stride,
+                              float* p, float* z, long zrows, long zoff, int dtype, void* stream) {
+  LY_CHECK_DTYPE(dtype, "detect_tail");
   LY_CHECK(y && p && anchors, "detect_tail: null pointer");
   const long total = (long)n_img * na * H * W * no;
-  hipLaunchKernelGGL(ly_detect_tail_kernel, dim3((unsigned)((total + LY_THREADS - 1) / LY_THREADS)), dim3(LY_THREADS), 0,
-                     reinterpret_cast<hipStream_t>(stream), y, ldy, total, H, W, na, no, anchors, stride, p, z, zrows, zoff);
+  LY_WITH_T(dtype, hipLaunchKernelGGL(ly_detect_tail_kernel<T>, dim3((unsigned)((total + LY_THREADS - 1) / LY_THREADS)), dim3(LY_THREADS), 0,
+                                      reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const T*>(y), ldy, total, H, W, na, no, anchors, stride, p, z, zrows, zoff));
   LY_LAUNCH_CHECK();
   return 0;
 }
@@ -578,7 +592,8 @@ extern "C" int ly_detect_tail(const float* y, int ldy, int n_img, int H, int W, 
 // consumers' scale/shift exactly like the eval path)
 // ---------------------------------------------------------------------------------------------------
 // per-channel sum / sum of squares over all rows of an [rows, C] matrix: mom[c] += sum x, mom[C + c] += sum x^2
-__global__ __launch_bounds__(LY_THREADS) void ly_chan_moments_kernel(const float* __restrict__ x, int ldx, long rows, int C,
+template <typename T>
+__global__ __launch_bounds__(LY_THREADS) void ly_chan_moments_kernel(const T* __restrict__ x, int ldx, long rows, int C,
                                                                       float* __restrict__ mom) {
   __shared__ f32x4 red1[LY_THREADS], red2[LY_THREADS];
   const int nc4 = C >> 2, tid = threadIdx.x;
@@ -587,7 +602,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_chan_moments_kernel(const float
   f32x4 s1 = ly_zero4(), s2 = ly_zero4();
   if (j0 < groups)
     for (long r = (long)blockIdx.x * groups + j0; r < rows; r += (long)gridDim.x * groups) {
-      const f32x4 v = ly_ldg4(x + r * ldx + 4 * c4);
+      const f32x4 v = ly_ld4<T>(x + r * ldx + 4 * c4);
       s1 += v;
       s2 += v * v;
     }
@@ -604,14 +619,15 @@ __global__ __launch_bounds__(LY_THREADS) void ly_chan_moments_kernel(const float
   }
 }
 
-extern "C" int ly_chan_moments(const float* x, int ldx, long rows, int C, float* mom, void* stream) {
+extern "C" int ly_chan_moments(const void* x, int ldx, long rows, int C, float* mom, int dtype, void* stream) {
+  LY_CHECK_DTYPE(dtype, "chan_moments");
   LY_CHECK(x && mom && (C & 3) == 0 && (ldx & 3) == 0 && C <= 1024 && rows > 0, "chan_moments: bad arguments");
   const int groups = LY_THREADS / (C >> 2);
   long blocks = (rows + groups * 64L - 1) / (groups * 64L);
   if (blocks > 1024) blocks = 1024;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(ly_chan_moments_kernel, dim3((unsigned)blocks), dim3(LY_THREADS), 0, reinterpret_cast<hipStream_t>(stream), x, ldx, rows,
-                     C, mom);
+  LY_WITH_T(dtype, hipLaunchKernelGGL(ly_chan_moments_kernel<T>, dim3((unsigned)blocks), dim3(LY_THREADS), 0, reinterpret_cast<hipStream_t>(stream),
+                                      reinterpret_cast<const T*>(x), ldx, rows, C, mom));
   LY_LAUNCH_CHECK();
   return 0;
 }
@@ -656,7 +672,8 @@ extern "C" int ly_coordatt_conv1_stats(const float* pool, long positions, int C,
 // so  sum a_t = w_t . m   and   sum a_t^2 = w_t^T M w_t  with  m[u] = sum_pixels x_u,  M[u][v] = sum_pixels x_u x_v.
 // This kernel accumulates the 9 + 45 moments per channel: thread = channel (coalesced NHWC reads), blocks split
 // the output pixels, 54 vectorised atomics per thread at the end.  mom layout: [54][C].
-__global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_tap_moments_kernel(const float* __restrict__ x, int ldx, int n_img, int H, int W,
+template <typename T>
+__global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_tap_moments_kernel(const T* __restrict__ x, int ldx, int n_img, int H, int W,
                                                                             int C, int Ho, int Wo, int s, float* __restrict__ mom) {
   const int cb = C < LY_THREADS ? C : LY_THREADS;          // channels handled per pass by this block
   const int subs = LY_THREADS / cb;
@@ -681,7 +698,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_tap_moments_kernel(const
         for (int u = 0; u < 9; ++u) {
           const int iy = s * oy + u / 3 - 1, ix = s * ox + u % 3 - 1;
           const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
-          xv[u] = ok ? x[((n * H + (ok ? iy : 0)) * W + (ok ? ix : 0)) * ldx + c] : 0.f;
+          xv[u] = ok ? ly_ld1<T>(x + ((n * H + (ok ? iy : 0)) * W + (ok ? ix : 0)) * ldx + c) : 0.f;
         }
         int k = 0;
 #pragma unroll
@@ -699,14 +716,15 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_tap_moments_kernel(const
   }
 }
 
-extern "C" int ly_rfcbam_tap_moments(const float* x, int ldx, int n_img, int H, int W, int C, int s, float* mom, void* stream) {
+extern "C" int ly_rfcbam_tap_moments(const void* x, int ldx, int n_img, int H, int W, int C, int s, float* mom, int dtype, void* stream) {
+  LY_CHECK_DTYPE(dtype, "rfcbam_tap_moments");
   LY_CHECK(x && mom && s >= 1 && C > 0, "rfcbam_tap_moments: bad arguments");
   const int Ho = (H + 2 - 3) / s + 1, Wo = (W + 2 - 3) / s + 1;
   long npix = (long)n_img * Ho * Wo;
   long blocks = npix / 32 + 1;
   if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(ly_rfcbam_tap_moments_kernel, dim3((unsigned)blocks), dim3(LY_THREADS), 0, reinterpret_cast<hipStream_t>(stream), x, ldx,
-                     n_img, H, W, C, Ho, Wo, s, mom);
+  LY_WITH_T(dtype, hipLaunchKernelGGL(ly_rfcbam_tap_moments_kernel<T>, dim3((unsigned)blocks), dim3(LY_THREADS), 0, reinterpret_cast<hipStream_t>(stream),
+                                      reinterpret_cast<const T*>(x), ldx, n_img, H, W, C, Ho, Wo, s, mom));
   LY_LAUNCH_CHECK();
   return 0;
 }

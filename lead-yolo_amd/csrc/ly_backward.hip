@@ -1,4 +1,5 @@
-// Backward building blocks of the training step, fp32 I/O, gfx950.
+// Backward building blocks of the training step, gfx950; activations / activation gradients T = float or
+// __bf16, weight gradients, BatchNorm sums and attention-table gradients fp32.
 //
 //   ly_bnact_bwd_reduce / ly_bnact_bwd_apply   BatchNorm(train) + activation backward on an [rows, C] matrix
 //   ly_wgrad                                   weight gradient: contraction over PIXELS with the forward's gather
@@ -37,8 +38,8 @@ __device__ __forceinline__ f32x4 ly_dact4(const f32x4 v, const f32x4 dy) {
   return r;
 }
 
-template <int ACT>
-__global__ __launch_bounds__(LY_THREADS) void ly_bnact_bwd_reduce_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ u,
+template <typename T, int ACT>
+__global__ __launch_bounds__(LY_THREADS) void ly_bnact_bwd_reduce_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ u,
                                                                           int ldu, long rows, int C, const float* __restrict__ a,
                                                                           const float* __restrict__ b, float* __restrict__ sums) {
   __shared__ f32x4 red1[LY_THREADS], red2[LY_THREADS];
@@ -49,8 +50,8 @@ __global__ __launch_bounds__(LY_THREADS) void ly_bnact_bwd_reduce_kernel(const f
   if (j0 < groups) {
     const f32x4 av = ly_ldg4(a + 4 * c4), bv = ly_ldg4(b + 4 * c4);
     for (long r = (long)blockIdx.x * groups + j0; r < rows; r += (long)gridDim.x * groups) {
-      const f32x4 uu = ly_ldg4(u + r * ldu + 4 * c4);
-      const f32x4 g = ly_ldg4(dy + r * lddy + 4 * c4);
+      const f32x4 uu = ly_ld4<T>(u + r * ldu + 4 * c4);
+      const f32x4 g = ly_ld4<T>(dy + r * lddy + 4 * c4);
       const f32x4 dv = ly_dact4<ACT>(av * uu + bv, g);
       s1 += dv;
       s2 += dv * uu;
@@ -69,36 +70,36 @@ __global__ __launch_bounds__(LY_THREADS) void ly_bnact_bwd_reduce_kernel(const f
   }
 }
 
-template <int ACT>
-__global__ __launch_bounds__(LY_THREADS) void ly_bnact_bwd_apply_kernel(const float* __restrict__ dy, int lddy, const float* u, int ldu,
+template <typename T, int ACT>
+__global__ __launch_bounds__(LY_THREADS) void ly_bnact_bwd_apply_kernel(const T* __restrict__ dy, int lddy, const T* u, int ldu,
                                                                          long rows, int C, const float* __restrict__ a,
                                                                          const float* __restrict__ b, const float* __restrict__ alpha,
                                                                          const float* __restrict__ kappa, const float* __restrict__ lambda,
-                                                                         float* du, int lddu) {
+                                                                         T* du, int lddu) {
   const int nc4 = C >> 2;
   const long total = rows * nc4;
   for (long i = (long)blockIdx.x * LY_THREADS + threadIdx.x; i < total; i += (long)gridDim.x * LY_THREADS) {
     const long r = i / nc4;
     const int c = 4 * (int)(i - r * nc4);
-    const f32x4 uu = ly_ldg4(u + r * ldu + c);
-    const f32x4 g = ly_ldg4(dy + r * lddy + c);
+    const f32x4 uu = ly_ld4<T>(u + r * ldu + c);
+    const f32x4 g = ly_ld4<T>(dy + r * lddy + c);
     const f32x4 dv = ly_dact4<ACT>(ly_ldg4(a + c) * uu + ly_ldg4(b + c), g);
-    ly_stg4(du + r * lddu + c, ly_ldg4(alpha + c) * dv + ly_ldg4(kappa + c) + ly_ldg4(lambda + c) * uu);
+    ly_st4<T>(du + r * lddu + c, ly_ldg4(alpha + c) * dv + ly_ldg4(kappa + c) + ly_ldg4(lambda + c) * uu);
   }
 }
 
 // y = act(a[c]*u + b[c]) over an [rows, C] matrix: the second half of a train-mode conv -> BN -> act unit whose
 // contraction pass stored the pre-BN value u and accumulated its statistics in the same launch
-template <int ACT>
-__global__ __launch_bounds__(LY_THREADS) void ly_bnact_fwd_kernel(const float* __restrict__ u, int ldu, long rows, int C, const float* __restrict__ a,
-                                                                   const float* __restrict__ b, float* __restrict__ y, int ldy) {
+template <typename T, int ACT>
+__global__ __launch_bounds__(LY_THREADS) void ly_bnact_fwd_kernel(const T* __restrict__ u, int ldu, long rows, int C, const float* __restrict__ a,
+                                                                   const float* __restrict__ b, T* __restrict__ y, int ldy) {
   const int nc4 = C >> 2;
   const long total = rows * nc4;
   for (long i = (long)blockIdx.x * LY_THREADS + threadIdx.x; i < total; i += (long)gridDim.x * LY_THREADS) {
     const long r = i / nc4;
     const int c = 4 * (int)(i - r * nc4);
-    const f32x4 v = ly_ldg4(a + c) * ly_ldg4(u + r * ldu + c) + ly_ldg4(b + c);
-    ly_stg4(y + r * ldy + c, ly_act4(v, ACT));
+    const f32x4 v = ly_ldg4(a + c) * ly_ld4<T>(u + r * ldu + c) + ly_ldg4(b + c);
+    ly_st4<T>(y + r * ldy + c, ly_act4(v, ACT));
   }
 }
 
@@ -107,45 +108,61 @@ static long ly_ew_blocks(long items) {
   return b < 1 ? 1 : b > 4096 ? 4096 : b;
 }
 
-extern "C" int ly_bnact_fwd(const float* u, int ldu, long rows, int C, const float* a, const float* b, int act, float* y, int ldy, void* stream) {
-  LY_CHECK(u && a && b && y && rows > 0, "bnact_fwd: null pointer");
+extern "C" int ly_bnact_fwd(const void* u_, int ldu, long rows, int C, const float* a, const float* b, int act, void* y_, int ldy, int dtype, void* stream) {
+  LY_CHECK_DTYPE(dtype, "bnact_fwd");
+  LY_CHECK(u_ && a && b && y_ && rows > 0, "bnact_fwd: null pointer");
   LY_CHECK((C & 3) == 0 && C > 0 && (ldu & 3) == 0 && (ldy & 3) == 0, "bnact_fwd: C=%d / ld must be multiples of 4", C);
   const long blocks = ly_ew_blocks(rows * (C >> 2));
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (act == LY_ACT_SILU) hipLaunchKernelGGL(ly_bnact_fwd_kernel<LY_ACT_SILU>, dim3((unsigned)blocks), dim3(LY_THREADS), 0, st, u, ldu, rows, C, a, b, y, ldy);
-  else if (act == LY_ACT_RELU) hipLaunchKernelGGL(ly_bnact_fwd_kernel<LY_ACT_RELU>, dim3((unsigned)blocks), dim3(LY_THREADS), 0, st, u, ldu, rows, C, a, b, y, ldy);
-  else hipLaunchKernelGGL(ly_bnact_fwd_kernel<LY_ACT_NONE>, dim3((unsigned)blocks), dim3(LY_THREADS), 0, st, u, ldu, rows, C, a, b, y, ldy);
+  LY_WITH_T(dtype, {
+    const T* u = reinterpret_cast<const T*>(u_);
+    T* y = reinterpret_cast<T*>(y_);
+    if (act == LY_ACT_SILU) hipLaunchKernelGGL((ly_bnact_fwd_kernel<T, LY_ACT_SILU>), dim3((unsigned)blocks), dim3(LY_THREADS), 0, st, u, ldu, rows, C, a, b, y, ldy);
+    else if (act == LY_ACT_RELU) hipLaunchKernelGGL((ly_bnact_fwd_kernel<T, LY_ACT_RELU>), dim3((unsigned)blocks), dim3(LY_THREADS), 0, st, u, ldu, rows, C, a, b, y, ldy);
+    else hipLaunchKernelGGL((ly_bnact_fwd_kernel<T, LY_ACT_NONE>), dim3((unsigned)blocks), dim3(LY_THREADS), 0, st, u, ldu, rows, C, a, b, y, ldy);
+  });
   LY_LAUNCH_CHECK();
   return 0;
 }
 
-extern "C" int ly_bnact_bwd_reduce(const float* dy, int lddy, const float* u, int ldu, long rows, int C, const float* a, const float* b,
-                                   int act, float* sums, void* stream) {
-  LY_CHECK(dy && u && a && b && sums && rows > 0, "bnact_bwd_reduce: null pointer");
+extern "C" int ly_bnact_bwd_reduce(const void* dy_, int lddy, const void* u_, int ldu, long rows, int C, const float* a, const float* b,
+                                   int act, float* sums, int dtype, void* stream) {
+  LY_CHECK_DTYPE(dtype, "bnact_bwd_reduce");
+  LY_CHECK(dy_ && u_ && a && b && sums && rows > 0, "bnact_bwd_reduce: null pointer");
   LY_CHECK((C & 3) == 0 && C > 0 && C <= 1024 && (lddy & 3) == 0 && (ldu & 3) == 0, "bnact_bwd_reduce: C=%d / ld must be multiples of 4", C);
   const int groups = LY_THREADS / (C >> 2);
   long blocks = (rows + groups * 32L - 1) / (groups * 32L);
   blocks = blocks < 1 ? 1 : blocks > 2048 ? 2048 : blocks;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-#define LY_RED(A) hipLaunchKernelGGL(ly_bnact_bwd_reduce_kernel<A>, dim3((unsigned)blocks), dim3(LY_THREADS), 0, st, dy, lddy, u, ldu, rows, C, a, b, sums)
-  if (act == LY_ACT_SILU) LY_RED(LY_ACT_SILU);
-  else if (act == LY_ACT_RELU) LY_RED(LY_ACT_RELU);
-  else LY_RED(LY_ACT_NONE);
+#define LY_RED(A) hipLaunchKernelGGL((ly_bnact_bwd_reduce_kernel<T, A>), dim3((unsigned)blocks), dim3(LY_THREADS), 0, st, dy, lddy, u, ldu, rows, C, a, b, sums)
+  LY_WITH_T(dtype, {
+    const T* dy = reinterpret_cast<const T*>(dy_);
+    const T* u = reinterpret_cast<const T*>(u_);
+    if (act == LY_ACT_SILU) LY_RED(LY_ACT_SILU);
+    else if (act == LY_ACT_RELU) LY_RED(LY_ACT_RELU);
+    else LY_RED(LY_ACT_NONE);
+  });
 #undef LY_RED
   LY_LAUNCH_CHECK();
   return 0;
 }
 
-extern "C" int ly_bnact_bwd_apply(const float* dy, int lddy, const float* u, int ldu, long rows, int C, const float* a, const float* b,
-                                  int act, const float* alpha, const float* kappa, const float* lambda, float* du, int lddu, void* stream) {
-  LY_CHECK(dy && u && a && b && alpha && kappa && lambda && du && rows > 0, "bnact_bwd_apply: null pointer");
+extern "C" int ly_bnact_bwd_apply(const void* dy_, int lddy, const void* u_, int ldu, long rows, int C, const float* a, const float* b,
+                                  int act, const float* alpha, const float* kappa, const float* lambda, void* du_, int lddu, int dtype, void* stream) {
+  LY_CHECK_DTYPE(dtype, "bnact_bwd_apply");
+  LY_CHECK(dy_ && u_ && a && b && alpha && kappa && lambda && du_ && rows > 0, "bnact_bwd_apply: null pointer");
   LY_CHECK((C & 3) == 0 && C > 0 && (lddy & 3) == 0 && (ldu & 3) == 0 && (lddu & 3) == 0, "bnact_bwd_apply: C=%d / ld must be multiples of 4", C);
   const long blocks = ly_ew_blocks(rows * (C >> 2));
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-#define LY_APP(A) hipLaunchKernelGGL(ly_bnact_bwd_apply_kernel<A>, dim3((unsigned)blocks), dim3(LY_THREADS), 0, st, dy, lddy, u, ldu, rows, C, a, b, alpha, kappa, lambda, du, lddu)
-  if (act == LY_ACT_SILU) LY_APP(LY_ACT_SILU);
-  else if (act == LY_ACT_RELU) LY_APP(LY_ACT_RELU);
-  else LY_APP(LY_ACT_NONE);
+#define LY_APP(A) hipLaunchKernelGGL((ly_bnact_bwd_apply_kernel<T, A>), dim3((unsigned)blocks), dim3(LY_THREADS), 0, st, dy, lddy, u, ldu, rows, C, a, b, alpha, kappa, lambda, du, lddu)
+  LY_WITH_T(dtype, {
+    const T* dy = reinterpret_cast<const T*>(dy_);
+    const T* u = reinterpret_cast<const T*>(u_);
+    T* du = reinterpret_cast<T*>(du_);
+    if (act == LY_ACT_SILU) LY_APP(LY_ACT_SILU);
+    else if (act == LY_ACT_RELU) LY_APP(LY_ACT_RELU);
+    else LY_APP(LY_ACT_NONE);
+  });
 #undef LY_APP
   LY_LAUNCH_CHECK();
   return 0;
@@ -171,8 +188,11 @@ __device__ __forceinline__ void ly_split8(const float (&v)[8], bf16x8& hi, bf16x
   lo = ly_cat8(l0, l1);
 }
 
-template <bool ROWS>
+template <typename T, bool ROWS>
 __global__ __launch_bounds__(LY_THREADS) void ly_wgrad_kernel(const LyWgradParams P, const int tiles_k, const long chunk_px) {
+  constexpr int PL = LyT<T>::PL;
+  const T* const du = reinterpret_cast<const T*>(P.du);
+  const T* const xin = reinterpret_cast<const T*>(P.x);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lq = lane >> 4;
@@ -224,13 +244,13 @@ __global__ __launch_bounds__(LY_THREADS) void ly_wgrad_kernel(const LyWgradParam
       const long pc = pok ? p : p_end - 1;
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        const float v = P.du[pc * P.lddu + arow[t]];
+        const float v = ly_ld1<T>(du + pc * P.lddu + arow[t]);
         av[t][j] = (pok && aok[t]) ? v : 0.f;
       }
       if (ROWS) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          const float v = P.x[pc * P.ldx + bcol[t]];
+          const float v = ly_ld1<T>(xin + pc * P.ldx + bcol[t]);
           bv[t][j] = (pok && bok[t]) ? v : 0.f;
         }
       } else {
@@ -241,7 +261,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_wgrad_kernel(const LyWgradParam
           if (P.up2) { hi >>= 1; wi >>= 1; }
           long off = P.nchw ? (((long)n_i * P.Cin + cc[t]) * P.Hin + hi) * P.Win + wi
                             : (((long)n_i * P.Hin + hi) * P.Win + wi) * P.ldx + cc[t];
-          const float v = P.x[ok ? off : 0];
+          const float v = ly_ld1<T>(xin + (ok ? off : 0));
           bv[t][j] = ok ? v : 0.f;
         }
         if (++wo == P.W) { wo = 0; if (++ho == P.H) { ho = 0; ++n_i; } }
@@ -256,7 +276,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_wgrad_kernel(const LyWgradParam
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[i][j] = ly_mfma3(ah[i], al[i], bh[j], bl[j], acc[i][j]);
+      for (int j = 0; j < 2; ++j) acc[i][j] = ly_mfmapp<PL>(ah[i], al[i], bh[j], bl[j], acc[i][j]);
   }
 
   // D: lane (i = column, q) holds rows 4q + r
@@ -287,14 +307,18 @@ __global__ __launch_bounds__(LY_THREADS) void ly_wgrad_kernel(const LyWgradParam
 // s+1 are in flight while step s is contracted (register prefetch, two LDS buffers, one barrier per step).
 // Re-reads drop from (N/64 + K/64) to (N/BN + K/BK) passes over the two tensors.
 // -------------------------------------------------------------------------------------------------
-template <int BN, int BK, int P, bool ROWS>
+template <typename T, int BN, int BK, int P, bool ROWS>
 __global__ __launch_bounds__(LY_THREADS) void ly_wgrad_tiled_kernel(const LyWgradParams P_, const int tiles_k, const long chunk_px) {
   const LyWgradParams& Q = P_;
+  using R4 = typename LyT<T>::R4;
+  constexpr int PL = LyT<T>::PL;
+  const T* const du = reinterpret_cast<const T*>(Q.du);
+  const T* const xin = reinterpret_cast<const T*>(Q.x);
   constexpr int PG = P / 8;                             // 8-pixel groups per step
   constexpr int TASKS = (BN / 4 + BK / 4) * PG;         // (channel quad, pixel group) pairs per step
   constexpr int TPT = (TASKS + LY_THREADS - 1) / LY_THREADS;
   constexpr int NI = BN / 32, NJ = BK / 32;             // MFMA tiles per wave along n / k
-  constexpr int RSW = 4 * P + 16;                       // bytes per LDS row: [hi P bf16 | lo P bf16] + pad (bank spread)
+  constexpr int RSW = PL * 2 * P + 16;                  // bytes per LDS row: [hi P bf16 | lo P bf16 (fp32 storage only)] + pad (bank spread)
   constexpr int BUF = (BN + BK) * RSW;
   extern __shared__ f32x4 ly_smem4[];
   char* const lds = reinterpret_cast<char*>(ly_smem4);
@@ -338,7 +362,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_wgrad_tiled_kernel(const LyWgra
   const int Hv = Q.up2 ? 2 * Q.Hin : Q.Hin, Wv = Q.up2 ? 2 * Q.Win : Q.Win;
   const float invW = 1.f / (float)Q.W, invH = 1.f / (float)Q.H;
 
-  f32x4 pre[TPT][8];
+  R4 pre[TPT][8];
   auto prefetch = [&](long p0) {
 #pragma unroll
     for (int u = 0; u < TPT; ++u) {
@@ -355,20 +379,21 @@ __global__ __launch_bounds__(LY_THREADS) void ly_wgrad_tiled_kernel(const LyWgra
       for (int j = 0; j < 8; ++j) {
         const long p = pf + j;
         bool ok = t_ok[u] && p < p_end;
-        const float* src;
+        const T* src;
         if (t_isA[u]) {
-          src = Q.du + (ok ? p : p_begin) * Q.lddu + t_c[u];
+          src = du + (ok ? p : p_begin) * Q.lddu + t_c[u];
         } else if (ROWS) {
-          src = Q.x + (ok ? p : p_begin) * Q.ldx + t_c[u];
+          src = xin + (ok ? p : p_begin) * Q.ldx + t_c[u];
         } else {
           int hi = ho * Q.stride + t_ky[u] - Q.pad, wi = wo * Q.stride + t_kx[u] - Q.pad;
           ok = ok && hi >= 0 && hi < Hv && wi >= 0 && wi < Wv;
           if (Q.up2) { hi >>= 1; wi >>= 1; }
-          src = Q.x + (ok ? (((long)n_i * Q.Hin + hi) * Q.Win + wi) * Q.ldx : 0) + t_c[u];
+          src = xin + (ok ? (((long)n_i * Q.Hin + hi) * Q.Win + wi) * Q.ldx : 0) + t_c[u];
           if (++wo == Q.W) { wo = 0; if (++ho == Q.H) { ho = 0; ++n_i; } }
         }
-        const f32x4 v = ly_ldg4(src);
-        pre[u][j] = ok ? v : ly_zero4();
+        R4 v = ly_ldr4<T>(src);
+        if (!ok) ly_zero_raw(v);
+        pre[u][j] = v;
       }
     }
   };
@@ -377,14 +402,26 @@ __global__ __launch_bounds__(LY_THREADS) void ly_wgrad_tiled_kernel(const LyWgra
 #pragma unroll
     for (int u = 0; u < TPT; ++u) {
       if (t_row[u] < 0) continue;
+      if constexpr (PL == 2) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float v[8] = {pre[u][0][e], pre[u][1][e], pre[u][2][e], pre[u][3][e], pre[u][4][e], pre[u][5][e], pre[u][6][e], pre[u][7][e]};
-        bf16x8 hi, lo;
-        ly_split8(v, hi, lo);
-        char* d = base + (t_row[u] + e) * RSW + t_g[u] * 16;
-        *reinterpret_cast<bf16x8*>(d) = hi;
-        *reinterpret_cast<bf16x8*>(d + 2 * P) = lo;
+        for (int e = 0; e < 4; ++e) {
+          const float v[8] = {pre[u][0][e], pre[u][1][e], pre[u][2][e], pre[u][3][e], pre[u][4][e], pre[u][5][e], pre[u][6][e], pre[u][7][e]};
+          bf16x8 hi, lo;
+          ly_split8(v, hi, lo);
+          char* d = base + (t_row[u] + e) * RSW + t_g[u] * 16;
+          *reinterpret_cast<bf16x8*>(d) = hi;
+          *reinterpret_cast<bf16x8*>(d + 2 * P) = lo;
+        }
+      } else {
+        // bf16 storage: a pure 8 x 4 transpose of 16-bit values (channel e of the 8 pixels becomes one 16-byte row piece)
+        bf16x4 q[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) q[j] = __builtin_bit_cast(bf16x4, pre[u][j]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bf16x8 row = {q[0][e], q[1][e], q[2][e], q[3][e], q[4][e], q[5][e], q[6][e], q[7][e]};
+          *reinterpret_cast<bf16x8*>(base + (t_row[u] + e) * RSW + t_g[u] * 16) = row;
+        }
       }
     }
   };
@@ -411,15 +448,15 @@ __global__ __launch_bounds__(LY_THREADS) void ly_wgrad_tiled_kernel(const LyWgra
       for (int i = 0; i < NI; ++i) {
         const char* r = base + (wn + 16 * i + li) * RSW + ks * 64 + lq * 16;
         ah[i] = *reinterpret_cast<const bf16x8*>(r);
-        al[i] = *reinterpret_cast<const bf16x8*>(r + 2 * P);
+        al[i] = PL == 2 ? *reinterpret_cast<const bf16x8*>(r + (PL - 1) * 2 * P) : ah[i];
       }
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         const char* r = base + (wk + 16 * j + li) * RSW + ks * 64 + lq * 16;
         const bf16x8 bh = *reinterpret_cast<const bf16x8*>(r);
-        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(r + 2 * P);
+        const bf16x8 bl = PL == 2 ? *reinterpret_cast<const bf16x8*>(r + (PL - 1) * 2 * P) : bh;
 #pragma unroll
-        for (int i = 0; i < NI; ++i) acc[i][j] = ly_mfma3(ah[i], al[i], bh, bl, acc[i][j]);
+        for (int i = 0; i < NI; ++i) acc[i][j] = ly_mfmapp<PL>(ah[i], al[i], bh, bl, acc[i][j]);
       }
     }
     if (more) commit(buf ^ 1);
@@ -441,7 +478,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_wgrad_tiled_kernel(const LyWgra
     }
 }
 
-template <int BN, int BK, int P>
+template <typename T, int BN, int BK, int P>
 static int launch_wgrad_tiled(const LyWgradParams& Q, bool rows, hipStream_t st) {
   const int Ktot = Q.ks * Q.ks * Q.Cin;
   const int tiles_n = (Q.N + BN - 1) / BN, tiles_k = (Ktot + BK - 1) / BK;
@@ -454,27 +491,32 @@ static int launch_wgrad_tiled(const LyWgradParams& Q, bool rows, hipStream_t st)
   chunk_px = (chunk_px + P - 1) / P * P;
   chunks = (Q.M + chunk_px - 1) / chunk_px;
   LY_CHECK(chunks < 65536, "wgrad: too many pixel chunks");
-  const size_t lds = 2 * (size_t)(BN + BK) * (4 * P + 16);
+  const size_t lds = 2 * (size_t)(BN + BK) * (LyT<T>::PL * 2 * P + 16);
   const dim3 grid((unsigned)tiles, (unsigned)chunks);
   if (rows) {
     static bool attr = false;
-    if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&ly_wgrad_tiled_kernel<BN, BK, P, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-    hipLaunchKernelGGL((ly_wgrad_tiled_kernel<BN, BK, P, true>), grid, dim3(LY_THREADS), lds, st, Q, tiles_k, chunk_px);
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ly_wgrad_tiled_kernel<T, BN, BK, P, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    hipLaunchKernelGGL((ly_wgrad_tiled_kernel<T, BN, BK, P, true>), grid, dim3(LY_THREADS), lds, st, Q, tiles_k, chunk_px);
   } else {
     static bool attr = false;
-    if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&ly_wgrad_tiled_kernel<BN, BK, P, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-    hipLaunchKernelGGL((ly_wgrad_tiled_kernel<BN, BK, P, false>), grid, dim3(LY_THREADS), lds, st, Q, tiles_k, chunk_px);
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ly_wgrad_tiled_kernel<T, BN, BK, P, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    hipLaunchKernelGGL((ly_wgrad_tiled_kernel<T, BN, BK, P, false>), grid, dim3(LY_THREADS), lds, st, Q, tiles_k, chunk_px);
   }
   LY_LAUNCH_CHECK();
   return 0;
 }
 
-static int g_wgrad_tile = 0;   // tuning aid: 1 = the previous 64 x 256 tile for every N <= 64 shape
-extern "C" int ly_debug_set_wgrad_tile(int v) { g_wgrad_tile = v; return 0; }
+template <typename T>
+static int wgrad_dispatch(const LyWgradParams& P, void* stream);
 
 extern "C" int ly_wgrad(const LyWgradParams* p, void* stream) {
   LY_CHECK(p, "wgrad: null params");
-  const LyWgradParams& P = *p;
+  LY_CHECK_DTYPE(p->dtype, "wgrad");
+  return p->dtype == LY_BF16 ? wgrad_dispatch<__bf16>(*p, stream) : wgrad_dispatch<float>(*p, stream);
+}
+
+template <typename T>
+static int wgrad_dispatch(const LyWgradParams& P, void* stream) {
   LY_CHECK(P.du && P.x && P.dw, "wgrad: null pointer");
   LY_CHECK(P.M > 0 && P.H > 0 && P.W > 0 && P.N > 0 && P.Cin > 0 && P.ks > 0 && P.stride > 0, "wgrad: bad sizes");
   LY_CHECK(P.M < (1L << 24), "wgrad: M=%ld pixels exceeds the 2^24 limit of the fast index path", P.M);
@@ -483,18 +525,17 @@ extern "C" int ly_wgrad(const LyWgradParams* p, void* stream) {
   LY_CHECK(P.lddw >= Ktot, "wgrad: lddw=%d < ks*ks*Cin=%d", P.lddw, Ktot);
   const bool rows = P.ks == 1 && P.stride == 1 && P.pad == 0 && !P.nchw && !P.up2;
   if (rows) LY_CHECK(P.Hin == P.H && P.Win == P.W, "wgrad: 1x1 gather needs Hin == H, Win == W");
-  if (!P.nchw && (P.N & 3) == 0 && (P.Cin & 3) == 0 && (P.lddu & 3) == 0 && (P.ldx & 3) == 0 && ((uintptr_t)P.du & 15) == 0 && ((uintptr_t)P.x & 15) == 0) {
+  if (!P.nchw && (P.N & 3) == 0 && (P.Cin & 3) == 0 && (P.lddu & 3) == 0 && (P.ldx & 3) == 0 && ((uintptr_t)P.du & (4 * sizeof(T) - 1)) == 0 && ((uintptr_t)P.x & (4 * sizeof(T) - 1)) == 0) {
     hipStream_t st2 = reinterpret_cast<hipStream_t>(stream);
     // skinny outputs (MLP blocks, patch layers at high resolution): few channel quads per pixel, so a step covers 64 pixels
     // to keep every thread loading; otherwise 32 pixels per step and wider channel tiles
     // One step of a block is one memory round trip (prefetch one step ahead), so what matters for the skinny shapes is how many
     // blocks a CU holds: the 64 x 256 tile's 92 KB of LDS meant ONE (N=8 K=72 M=1.6M: 690 -> 280 us, N=64 K=576: 538 -> 342 us,
     // N=64 K=128 upsampled source: 271 -> 137 us with the tiles below; all wgrad launches of a bs=64 step 7.8 -> 6.5 ms).
-    if (P.N <= 64 && Ktot <= 64) return launch_wgrad_tiled<64, 64, 64>(P, rows, st2);
-    if (P.N <= 64 && g_wgrad_tile == 1) return launch_wgrad_tiled<64, 256, 32>(P, rows, st2);
-    if (P.N <= 32) return launch_wgrad_tiled<32, 128, 32>(P, rows, st2);      // 46 KB: three blocks per CU
-    if (P.N <= 64) return launch_wgrad_tiled<64, 128, 32>(P, rows, st2);      // 55 KB: two
-    return launch_wgrad_tiled<128, 128, 32>(P, rows, st2);
+    if (P.N <= 64 && Ktot <= 64) return launch_wgrad_tiled<T, 64, 64, 64>(P, rows, st2);
+    if (P.N <= 32) return launch_wgrad_tiled<T, 32, 128, 32>(P, rows, st2);      // 46 KB (fp32 storage): three blocks per CU
+    if (P.N <= 64) return launch_wgrad_tiled<T, 64, 128, 32>(P, rows, st2);      // 55 KB: two
+    return launch_wgrad_tiled<T, 128, 128, 32>(P, rows, st2);
   }
   const int tiles_n = (P.N + 63) / 64, tiles_k = (Ktot + 63) / 64;
   const long tiles = (long)tiles_n * tiles_k;
@@ -508,8 +549,8 @@ extern "C" int ly_wgrad(const LyWgradParams* p, void* stream) {
   LY_CHECK(chunks < 65536, "wgrad: too many pixel chunks");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const dim3 grid((unsigned)tiles, (unsigned)chunks);
-  if (rows) hipLaunchKernelGGL(ly_wgrad_kernel<true>, grid, dim3(LY_THREADS), 0, st, P, tiles_k, chunk_px);
-  else hipLaunchKernelGGL(ly_wgrad_kernel<false>, grid, dim3(LY_THREADS), 0, st, P, tiles_k, chunk_px);
+  if (rows) hipLaunchKernelGGL((ly_wgrad_kernel<T, true>), grid, dim3(LY_THREADS), 0, st, P, tiles_k, chunk_px);
+  else hipLaunchKernelGGL((ly_wgrad_kernel<T, false>), grid, dim3(LY_THREADS), 0, st, P, tiles_k, chunk_px);
   LY_LAUNCH_CHECK();
   return 0;
 }
@@ -518,8 +559,9 @@ extern "C" int ly_wgrad(const LyWgradParams* p, void* stream) {
 // Adjoint of the nearest-2x upsampled read (nn.Upsample(2,'nearest'), models/LEAD-YOLO.yaml neck):
 //   dsrc[n, h, w, :] = sum of the four dst pixels (2h+{0,1}, 2w+{0,1})
 // -------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(LY_THREADS) void ly_up2_bwd_kernel(const float* __restrict__ d, int ldd, int n_img, int Hs, int Ws, int C,
-                                                                float* __restrict__ o, int ldo) {
+template <typename T>
+__global__ __launch_bounds__(LY_THREADS) void ly_up2_bwd_kernel(const T* __restrict__ d, int ldd, int n_img, int Hs, int Ws, int C,
+                                                                T* __restrict__ o, int ldo) {
   const int nc4 = C >> 2;
   const long total = (long)n_img * Hs * Ws * nc4;
   for (long i = (long)blockIdx.x * LY_THREADS + threadIdx.x; i < total; i += (long)gridDim.x * LY_THREADS) {
@@ -529,16 +571,17 @@ __global__ __launch_bounds__(LY_THREADS) void ly_up2_bwd_kernel(const float* __r
     const int w = (int)(pix - row * Ws);
     const long n = row / Hs;
     const int h = (int)(row - n * Hs);
-    const float* s = d + (((n * 2 * Hs + 2 * h) * 2L * Ws) + 2 * w) * ldd + c;
-    const f32x4 v = ly_ldg4(s) + ly_ldg4(s + ldd) + ly_ldg4(s + 2L * Ws * ldd) + ly_ldg4(s + 2L * Ws * ldd + ldd);
-    ly_stg4(o + pix * ldo + c, v);
+    const T* s = d + (((n * 2 * Hs + 2 * h) * 2L * Ws) + 2 * w) * ldd + c;
+    const f32x4 v = ly_ld4<T>(s) + ly_ld4<T>(s + ldd) + ly_ld4<T>(s + 2L * Ws * ldd) + ly_ld4<T>(s + 2L * Ws * ldd + ldd);
+    ly_st4<T>(o + pix * ldo + c, v);
   }
 }
 
-extern "C" int ly_up2_bwd(const float* d, int ldd, int n_img, int Hs, int Ws, int C, float* out, int ldo, void* stream) {
+extern "C" int ly_up2_bwd(const void* d, int ldd, int n_img, int Hs, int Ws, int C, void* out, int ldo, int dtype, void* stream) {
+  LY_CHECK_DTYPE(dtype, "up2_bwd");
   LY_CHECK(d && out && n_img > 0 && Hs > 0 && Ws > 0 && (C & 3) == 0 && (ldd & 3) == 0 && (ldo & 3) == 0, "up2_bwd: bad arguments");
-  hipLaunchKernelGGL(ly_up2_bwd_kernel, dim3((unsigned)ly_ew_blocks((long)n_img * Hs * Ws * (C >> 2))), dim3(LY_THREADS), 0,
-                     reinterpret_cast<hipStream_t>(stream), d, ldd, n_img, Hs, Ws, C, out, ldo);
+  LY_WITH_T(dtype, hipLaunchKernelGGL(ly_up2_bwd_kernel<T>, dim3((unsigned)ly_ew_blocks((long)n_img * Hs * Ws * (C >> 2))), dim3(LY_THREADS), 0,
+                                      reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const T*>(d), ldd, n_img, Hs, Ws, C, reinterpret_cast<T*>(out), ldo));
   LY_LAUNCH_CHECK();
   return 0;
 }
@@ -548,8 +591,9 @@ extern "C" int ly_up2_bwd(const float* d, int ldd, int n_img, int Hs, int Ws, in
 // produces g[m = (n, ho, wo)][(ky, kx, c)]; scatter it to dx[n, 2ho+ky, 2wo+kx, c] (every input pixel belongs
 // to exactly one patch).
 // -------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(LY_THREADS) void ly_unpatch_kernel(const float* __restrict__ g, int n_img, int Ho, int Wo, int C, int ks,
-                                                                float* __restrict__ dx) {
+template <typename T>
+__global__ __launch_bounds__(LY_THREADS) void ly_unpatch_kernel(const T* __restrict__ g, int n_img, int Ho, int Wo, int C, int ks,
+                                                                T* __restrict__ dx) {
   const int nc4 = C >> 2;
   const int kc = ks * ks * nc4;
   const long total = (long)n_img * Ho * Wo * kc;
@@ -564,14 +608,15 @@ __global__ __launch_bounds__(LY_THREADS) void ly_unpatch_kernel(const float* __r
     const long n = row / Ho;
     const int ho = (int)(row - n * Ho);
     const long dst = ((n * Ho * ks + (long)ho * ks + ky) * ((long)Wo * ks) + (long)wo * ks + kx) * C + c;
-    ly_stg4(dx + dst, ly_ldg4(g + m * ((long)ks * ks * C) + (long)tap * C + c));
+    ly_st4<T>(dx + dst, ly_ld4<T>(g + m * ((long)ks * ks * C) + (long)tap * C + c));
   }
 }
 
-extern "C" int ly_unpatch(const float* g, int n_img, int Ho, int Wo, int C, int ks, float* dx, void* stream) {
+extern "C" int ly_unpatch(const void* g, int n_img, int Ho, int Wo, int C, int ks, void* dx, int dtype, void* stream) {
+  LY_CHECK_DTYPE(dtype, "unpatch");
   LY_CHECK(g && dx && n_img > 0 && Ho > 0 && Wo > 0 && ks > 0 && (C & 3) == 0, "unpatch: bad arguments");
-  hipLaunchKernelGGL(ly_unpatch_kernel, dim3((unsigned)ly_ew_blocks((long)n_img * Ho * Wo * ks * ks * (C >> 2))), dim3(LY_THREADS), 0,
-                     reinterpret_cast<hipStream_t>(stream), g, n_img, Ho, Wo, C, ks, dx);
+  LY_WITH_T(dtype, hipLaunchKernelGGL(ly_unpatch_kernel<T>, dim3((unsigned)ly_ew_blocks((long)n_img * Ho * Wo * ks * ks * (C >> 2))), dim3(LY_THREADS), 0,
+                                      reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const T*>(g), n_img, Ho, Wo, C, ks, reinterpret_cast<T*>(dx)));
   LY_LAUNCH_CHECK();
   return 0;
 }
@@ -589,9 +634,10 @@ extern "C" int ly_unpatch(const float* g, int n_img, int Ho, int Wo, int C, int 
 // band instead of one per element and row.
 #define LY_CAG_RB 8
 #define LY_CAG_MAXW 8        // (w, c4) pairs per thread: ceil(W / groups) <= 8
-__global__ __launch_bounds__(LY_THREADS) void ly_coordatt_gate_bwd_kernel(const float* __restrict__ dout, int ldd, const float* __restrict__ x,
+template <typename T>
+__global__ __launch_bounds__(LY_THREADS) void ly_coordatt_gate_bwd_kernel(const T* __restrict__ dout, int ldd, const T* __restrict__ x,
                                                                            int ldx, int H, int W, int C, const float* __restrict__ a_h,
-                                                                           const float* __restrict__ a_w, float* __restrict__ dx, int lddx,
+                                                                           const float* __restrict__ a_w, T* __restrict__ dx, int lddx,
                                                                            float* __restrict__ da_h, float* __restrict__ da_w, int bands, int slabs) {
   __shared__ f32x4 red[LY_THREADS];
   const int nc4 = C >> 2, tid = threadIdx.x;
@@ -616,10 +662,10 @@ __global__ __launch_bounds__(LY_THREADS) void ly_coordatt_gate_bwd_kernel(const 
         const int w = w0 + g0 + i * groups;
         if (w < W) {
           const long row = nh * W + w;
-          const f32x4 d = ly_ldg4(dout + row * ldd + 4 * c4);
-          const f32x4 xv = ly_ldg4(x + row * ldx + 4 * c4);
+          const f32x4 d = ly_ld4<T>(dout + row * ldd + 4 * c4);
+          const f32x4 xv = ly_ld4<T>(x + row * ldx + 4 * c4);
           const f32x4 aw = ly_ldg4(a_w + (n * W + w) * C + 4 * c4);
-          ly_stg4(dx + row * lddx + 4 * c4, d * ah * aw);
+          ly_st4<T>(dx + row * lddx + 4 * c4, d * ah * aw);
           const f32x4 t = d * xv;
           sh += t * aw;
           accw[i] += t * ah;
@@ -649,21 +695,24 @@ __global__ __launch_bounds__(LY_THREADS) void ly_coordatt_gate_bwd_kernel(const 
   }
 }
 
-extern "C" int ly_coordatt_gate_bwd(const float* dout, int ldd, const float* x, int ldx, int n_img, int H, int W, int C, const float* a_h,
-                                    const float* a_w, float* dx, int lddx, float* da_h, float* da_w, void* stream) {
+extern "C" int ly_coordatt_gate_bwd(const void* dout, int ldd, const void* x, int ldx, int n_img, int H, int W, int C, const float* a_h,
+                                    const float* a_w, void* dx, int lddx, float* da_h, float* da_w, int dtype, void* stream) {
+  LY_CHECK_DTYPE(dtype, "coordatt_gate_bwd");
   LY_CHECK(dout && x && a_h && a_w && dx && da_h && da_w, "coordatt_gate_bwd: null pointer");
   LY_CHECK((C & 3) == 0 && C <= 1024 && (ldd & 3) == 0 && (ldx & 3) == 0 && (lddx & 3) == 0, "coordatt_gate_bwd: C / ld must be multiples of 4");
   const int groups = LY_THREADS / (C >> 2);
   const int slabs = (W + groups * LY_CAG_MAXW - 1) / (groups * LY_CAG_MAXW);
   const int bands = (H + LY_CAG_RB - 1) / LY_CAG_RB;
-  hipLaunchKernelGGL(ly_coordatt_gate_bwd_kernel, dim3((unsigned)(n_img * bands * slabs)), dim3(LY_THREADS), 0, reinterpret_cast<hipStream_t>(stream),
-                     dout, ldd, x, ldx, H, W, C, a_h, a_w, dx, lddx, da_h, da_w, bands, slabs);
+  LY_WITH_T(dtype, hipLaunchKernelGGL(ly_coordatt_gate_bwd_kernel<T>, dim3((unsigned)(n_img * bands * slabs)), dim3(LY_THREADS), 0, reinterpret_cast<hipStream_t>(stream),
+                                      reinterpret_cast<const T*>(dout), ldd, reinterpret_cast<const T*>(x), ldx, H, W, C, a_h, a_w, reinterpret_cast<T*>(dx), lddx, da_h, da_w,
+                                      bands, slabs));
   LY_LAUNCH_CHECK();
   return 0;
 }
 
+template <typename T>
 __global__ __launch_bounds__(LY_THREADS) void ly_pool_hw_bwd_kernel(const float* __restrict__ gp, int n_img, int H, int W, int C,
-                                                                    float* __restrict__ dx, int lddx) {
+                                                                    T* __restrict__ dx, int lddx) {
   const int nc4 = C >> 2;
   const long total = (long)n_img * H * W * nc4;
   const float iw = 1.f / (float)W, ih = 1.f / (float)H;
@@ -675,14 +724,15 @@ __global__ __launch_bounds__(LY_THREADS) void ly_pool_hw_bwd_kernel(const float*
     const long n = row / H;
     const int h = (int)(row - n * H);
     const f32x4 a = ly_ldg4(gp + (n * (H + W) + h) * C + c), b = ly_ldg4(gp + (n * (H + W) + H + w) * C + c);
-    ly_stg4(dx + pix * lddx + c, a * iw + b * ih);
+    ly_st4<T>(dx + pix * lddx + c, a * iw + b * ih);
   }
 }
 
-extern "C" int ly_pool_hw_bwd(const float* gp, int n_img, int H, int W, int C, float* dx, int lddx, void* stream) {
+extern "C" int ly_pool_hw_bwd(const float* gp, int n_img, int H, int W, int C, void* dx, int lddx, int dtype, void* stream) {
+  LY_CHECK_DTYPE(dtype, "pool_hw_bwd");
   LY_CHECK(gp && dx && n_img > 0 && H > 0 && W > 0 && (C & 3) == 0 && (lddx & 3) == 0, "pool_hw_bwd: bad arguments");
-  hipLaunchKernelGGL(ly_pool_hw_bwd_kernel, dim3((unsigned)ly_ew_blocks((long)n_img * H * W * (C >> 2))), dim3(LY_THREADS), 0,
-                     reinterpret_cast<hipStream_t>(stream), gp, n_img, H, W, C, dx, lddx);
+  LY_WITH_T(dtype, hipLaunchKernelGGL(ly_pool_hw_bwd_kernel<T>, dim3((unsigned)ly_ew_blocks((long)n_img * H * W * (C >> 2))), dim3(LY_THREADS), 0,
+                                      reinterpret_cast<hipStream_t>(stream), gp, n_img, H, W, C, reinterpret_cast<T*>(dx), lddx));
   LY_LAUNCH_CHECK();
   return 0;
 }
@@ -693,7 +743,8 @@ extern "C" int ly_pool_hw_bwd(const float* gp, int n_img, int H, int W, int C, f
 // dy is added there: dx[argmax] += dy.  dx is accumulated into (float atomics), so chained pools can add into
 // the gradient slots of the concat buffer in place.
 // -------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(LY_THREADS) void ly_maxpool_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dy, int lddy,
+template <typename T>
+__global__ __launch_bounds__(LY_THREADS) void ly_maxpool_bwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ dy, int lddy,
                                                                     int n_img, int H, int W, int C, int k, float* __restrict__ dx, int lddx) {
   const int nc4 = C >> 2, r = k >> 1;
   const long total = (long)n_img * H * W * nc4;
@@ -711,7 +762,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_maxpool_bwd_kernel(const float*
       for (int xx = w - r; xx <= w + r; ++xx) {
         if (xx < 0 || xx >= W) continue;
         const long q = (n * H + yy) * W + xx;
-        const f32x4 v = ly_ldg4(x + q * ldx + c);
+        const f32x4 v = ly_ld4<T>(x + q * ldx + c);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           if (v[e] > best[e] || arg[e] < 0) { best[e] = v[e]; arg[e] = q; }
@@ -723,12 +774,13 @@ __global__ __launch_bounds__(LY_THREADS) void ly_maxpool_bwd_kernel(const float*
   }
 }
 
-extern "C" int ly_maxpool_bwd(const float* x, int ldx, const float* dy, int lddy, int n_img, int H, int W, int C, int k, float* dx, int lddx,
-                              void* stream) {
+extern "C" int ly_maxpool_bwd(const void* x, int ldx, const float* dy, int lddy, int n_img, int H, int W, int C, int k, float* dx, int lddx,
+                              int dtype, void* stream) {
+  LY_CHECK_DTYPE(dtype, "maxpool_bwd");
   LY_CHECK(x && dy && dx && n_img > 0 && H > 0 && W > 0 && (k & 1) == 1, "maxpool_bwd: bad arguments");
   LY_CHECK((C & 3) == 0 && (ldx & 3) == 0 && (lddy & 3) == 0, "maxpool_bwd: C / ld must be multiples of 4");
-  hipLaunchKernelGGL(ly_maxpool_bwd_kernel, dim3((unsigned)ly_ew_blocks((long)n_img * H * W * (C >> 2))), dim3(LY_THREADS), 0,
-                     reinterpret_cast<hipStream_t>(stream), x, ldx, dy, lddy, n_img, H, W, C, k, dx, lddx);
+  LY_WITH_T(dtype, hipLaunchKernelGGL(ly_maxpool_bwd_kernel<T>, dim3((unsigned)ly_ew_blocks((long)n_img * H * W * (C >> 2))), dim3(LY_THREADS), 0,
+                                      reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const T*>(x), ldx, dy, lddy, n_img, H, W, C, k, dx, lddx));
   LY_LAUNCH_CHECK();
   return 0;
 }
@@ -835,6 +887,7 @@ extern "C" int ly_bn_bwd_coeffs(const float* sums, int stripes, int N, double co
 //   out[((t*S + s)*2 + plane)*64 + lane][j] = plane(W[16t + (lane&15)][32s + 16(j>>2) + 4(lane>>4) + (j&3)])
 // W[r][k] is read as w[r*ld_r + k*ld_k], so a transposed view is packed without materialising it.
 // -------------------------------------------------------------------------------------------------
+template <int PL>
 __global__ __launch_bounds__(LY_THREADS) void ly_frag_pack3_kernel(const float* __restrict__ w, int R, int K, long ld_r, long ld_k, int T, int S,
                                                                    uint4* __restrict__ out) {
   const long total = (long)T * S * 64;
@@ -851,17 +904,21 @@ __global__ __launch_bounds__(LY_THREADS) void ly_frag_pack3_kernel(const float* 
     }
     bf16x8 hi, lo;
     ly_split8(v, hi, lo);
-    out[(ts * 2) * 64 + lane] = __builtin_bit_cast(uint4, hi);
-    out[(ts * 2 + 1) * 64 + lane] = __builtin_bit_cast(uint4, lo);
+    out[(ts * PL) * 64 + lane] = __builtin_bit_cast(uint4, hi);
+    if constexpr (PL == 2) out[(ts * PL + 1) * 64 + lane] = __builtin_bit_cast(uint4, lo);
   }
 }
 
-extern "C" int ly_frag_pack3(const float* w, int R, int K, long ld_r, long ld_k, int rows_to, void* out, void* stream) {
-  LY_CHECK(w && out && R > 0 && K > 0, "frag_pack3: bad arguments");
+extern "C" int ly_frag_pack3(const float* w, int R, int K, long ld_r, long ld_k, int rows_to, int planes, void* out, void* stream) {
+  LY_CHECK(w && out && R > 0 && K > 0 && (planes == 1 || planes == 2), "frag_pack3: bad arguments");
   const int rr = R > rows_to ? R : rows_to;
   const int T = (rr + 15) / 16, S = (K + 31) / 32;
-  hipLaunchKernelGGL(ly_frag_pack3_kernel, dim3((unsigned)ly_ew_blocks((long)T * S * 64)), dim3(LY_THREADS), 0, reinterpret_cast<hipStream_t>(stream), w,
-                     R, K, ld_r, ld_k, T, S, reinterpret_cast<uint4*>(out));
+  if (planes == 2)
+    hipLaunchKernelGGL(ly_frag_pack3_kernel<2>, dim3((unsigned)ly_ew_blocks((long)T * S * 64)), dim3(LY_THREADS), 0, reinterpret_cast<hipStream_t>(stream), w,
+                       R, K, ld_r, ld_k, T, S, reinterpret_cast<uint4*>(out));
+  else
+    hipLaunchKernelGGL(ly_frag_pack3_kernel<1>, dim3((unsigned)ly_ew_blocks((long)T * S * 64)), dim3(LY_THREADS), 0, reinterpret_cast<hipStream_t>(stream), w,
+                       R, K, ld_r, ld_k, T, S, reinterpret_cast<uint4*>(out));
   LY_LAUNCH_CHECK();
   return 0;
 }

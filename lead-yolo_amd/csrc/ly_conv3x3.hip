@@ -1,5 +1,5 @@
-// 3x3 / stride 1 / pad 1 convolution as an implicit GEMM + folded BN + activation, fp32 I/O, bf16x3
-// math, gfx950.
+// 3x3 / stride 1 / pad 1 convolution as an implicit GEMM + folded BN + activation, gfx950; storage dtype T = float (bf16x3
+// products) or __bf16 (plain bf16 products), fp32 accumulation (ly_tile.cuh).
 //
 //   out[m, n] = act( scale[n] * sum_{tap, c} X[pix(m) + tap][c] * W[n][c][tap] + shift[n] )
 //
@@ -17,18 +17,26 @@
 #include "ly_tile.cuh"
 #include "ly_params.h"
 
-#define LY_CC 32
-#define LY_RSH (2 * LY_CC + 16)   // bytes per frame position, per plane
 #define LY_C3_NT 8                // max pixel tiles (128 pixels) per block
-#define LY_C3_NV 6                // float4 per thread per chunk: (TH+2)(TW+2)*8 <= 6*256  =>  frame <= 192 positions
+#define LY_C3_NV 6                // 16-byte vectors per thread per chunk: (TH+2)(TW+2)*8 <= 6*256  =>  frame <= 192 positions
 
-template <int MT, int WC>
-__global__ __launch_bounds__(LY_THREADS) void ly_conv3x3_kernel(const LyConv3Params P, const int gy, const int tiles_x, const int tiles_y, const int dbg) {
+// T = float: 32-channel chunks (8 float4 per frame position), two operand planes; T = __bf16: 64-channel chunks (8 x 16 bytes
+// per position, the same bytes in flight per thread), one plane, two k-steps per tap.
+template <typename T, int MT, int WC>
+__global__ __launch_bounds__(LY_THREADS) void ly_conv3x3_kernel(const LyConv3Params P, const int gy, const int tiles_x, const int tiles_y) {
+  using TR = LyT<T>;
+  using RV = typename TR::RV;
+  constexpr int VW = TR::VW, PL = TR::PL;
+  constexpr int LY_CC = 8 * VW;                 // channels per chunk
+  constexpr int KS = LY_CC / 32;                // k-steps per tap and chunk
+  constexpr int LY_RSH = 2 * LY_CC + 16;        // bytes per frame position, per plane
   extern __shared__ f32x4 ly_smem4[];
   const int TH = P.TH, TW = P.TW, FW = TW + 2;
   const int frame = (TH + 2) * FW;
   char* hs_hi = reinterpret_cast<char*>(ly_smem4);
-  char* hs_lo = hs_hi + frame * LY_RSH;
+  char* hs_lo = hs_hi + (PL - 1) * frame * LY_RSH;
+  const T* const x = reinterpret_cast<const T*>(P.x);
+  T* const out = reinterpret_cast<T*>(P.out);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -45,9 +53,10 @@ __global__ __launch_bounds__(LY_THREADS) void ly_conv3x3_kernel(const LyConv3Par
   const int npx = TH * TW;
   const int ntv = (npx + 15) >> 4;                         // pixel tiles actually used (wave-uniform)
   const f32x4 zero = ly_zero4();
-  const int C32 = (P.Cin + 31) >> 5;                       // k-steps per tap
+  const int C32 = (P.Cin + 31) >> 5;                       // k-steps per tap (weight layout: conv_taps_matrix(w, 32))
+  const int NCH = (P.Cin + LY_CC - 1) / LY_CC;             // channel chunks
   const int S = 9 * C32;
-  const int T = (P.N + 15) >> 4;
+  const int Tt = (P.N + 15) >> 4;
   const long img0 = (long)n_img * P.H * P.W;
 
   // per-lane pixel -> byte offset of its (0,0) tap in the frame, and its output row (or -1)
@@ -63,8 +72,8 @@ __global__ __launch_bounds__(LY_THREADS) void ly_conv3x3_kernel(const LyConv3Par
     orow[n] = ok ? img0 + (long)(h0 + r) * P.W + (w0 + c) : -1;
   }
 
-  // ---- staging: this thread's frame items (position, 4-channel group) ---------------------------------
-  const int items = frame * (LY_CC / 4);
+  // ---- staging: this thread's frame items (position, 16-byte channel group) --------------------------------
+  const int items = frame * 8;
   long src[LY_C3_NV];                                       // element offset of the item's first channel of chunk 0, or -1
 #pragma unroll
   for (int e = 0; e < LY_C3_NV; ++e) {
@@ -74,17 +83,19 @@ __global__ __launch_bounds__(LY_THREADS) void ly_conv3x3_kernel(const LyConv3Par
       const int pos = idx >> 3, c4 = idx & 7;
       const int fr = pos / FW, fc = pos - fr * FW;
       const int hh = h0 - 1 + fr, ww = w0 - 1 + fc;
-      if (hh >= 0 && hh < P.H && ww >= 0 && ww < P.W) off = (img0 + (long)hh * P.W + ww) * P.ldx + 4 * c4;
+      if (hh >= 0 && hh < P.H && ww >= 0 && ww < P.W) off = (img0 + (long)hh * P.W + ww) * P.ldx + VW * c4;
     }
     src[e] = off;
   }
-  f32x4 pv[LY_C3_NV];
+  RV pv[LY_C3_NV];
+  // a vector is loaded when its FIRST channel is inside Cin: the channels beyond Cin it may carry (Cin % VW != 0: the partial
+  // conv gradients of the MLPBlock backward) meet zero-padded weights, and ldx >= roundup(Cin, VW) is checked by the launcher
   auto prefetch = [&](int c0) {
 #pragma unroll
     for (int e = 0; e < LY_C3_NV; ++e) {
       const int c4 = (tid + e * LY_THREADS) & 7;
-      const bool ok = src[e] >= 0 && c0 + 4 * c4 < P.Cin;
-      pv[e] = ly_ldg4(ok ? P.x + src[e] + c0 : P.x);      // clamped address, zero selected at commit
+      const bool ok = src[e] >= 0 && c0 + VW * c4 < P.Cin;
+      pv[e] = ly_ldrv<T>(ok ? x + src[e] + c0 : x);      // clamped address, zero selected at commit
     }
   };
   auto commit = [&](int c0) {
@@ -92,8 +103,10 @@ __global__ __launch_bounds__(LY_THREADS) void ly_conv3x3_kernel(const LyConv3Par
     for (int e = 0; e < LY_C3_NV; ++e) {
       const int idx = tid + e * LY_THREADS;
       const int c4 = idx & 7;
-      const bool ok = src[e] >= 0 && c0 + 4 * c4 < P.Cin;
-      if (idx < items) ly_lds_put4(hs_hi, hs_lo, (idx >> 3) * LY_RSH, 4 * c4, ok ? pv[e] : zero);
+      const bool ok = src[e] >= 0 && c0 + VW * c4 < P.Cin;
+      RV v = pv[e];
+      if (!ok) ly_zero_raw(v);
+      if (idx < items) ly_lds_put_rv(hs_hi, hs_lo, (idx >> 3) * LY_RSH, VW * c4, v);
     }
   };
 
@@ -106,49 +119,62 @@ __global__ __launch_bounds__(LY_THREADS) void ly_conv3x3_kernel(const LyConv3Par
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
     const int tt = (by * WC + wc) * MT + t;
-    wbase[t] = (long)(tt < T ? tt : T - 1) * S;
+    wbase[t] = (long)(tt < Tt ? tt : Tt - 1) * S;
   }
   const uint4* wpk = reinterpret_cast<const uint4*>(P.wp);
-  ly_l2_warm(P.wp, (long)T * S * 2048, P.stats ? P.stats : P.out);
+  ly_l2_warm(P.wp, (long)Tt * S * PL * 1024, P.stats ? P.stats : reinterpret_cast<float*>(P.out));
 
-  LyWFrag wcur[MT], wnxt[MT];
+  // weight fragment of (tap, k-step ks of chunk cc); a ragged last chunk (Cin % 64 == 32) clamps the absent second step to the
+  // first: its activations are staged as zeros
+  auto wstep = [&](int tap, int cc, int ks) -> long {
+    int st = KS * cc + ks;
+    if (st >= C32) st = C32 - 1;
+    return (long)tap * C32 + st;
+  };
+  LyWF<PL> wcur[MT], wnxt[MT];
 #pragma unroll
-  for (int t = 0; t < MT; ++t) wcur[t] = ly_wfrag(wpk, wbase[t], lane);      // (tap 0, chunk 0)
+  for (int t = 0; t < MT; ++t) wcur[t] = ly_wfragp<PL>(wpk, wbase[t], lane);      // (tap 0, chunk 0, step 0)
 
   prefetch(0);
   commit(0);
   __syncthreads();
 
-  for (int cc = 0; cc < C32; ++cc) {
-    const bool more = cc + 1 < C32;
+  for (int cc = 0; cc < NCH; ++cc) {
+    const bool more = cc + 1 < NCH;
     // unconditional (the last chunk re-requests itself): a load under a branch makes the compiler drain the whole queue
     // (s_waitcnt vmcnt(0)) after every tap, i.e. wait for this prefetch at tap 0 instead of hiding it behind nine taps of MFMAs
     prefetch((more ? cc + 1 : cc) * LY_CC);
 #pragma unroll(MT * NTW <= 8 ? 1 : 9)
     for (int tap = 0; tap < 9; ++tap) {
-      // next fragment: next tap of this chunk, or tap 0 of the next chunk (clamped at the very end)
-      {
-        const int nt = tap < 8 ? tap + 1 : 0;
-        const int nc = tap < 8 ? cc : (more ? cc + 1 : cc);
-#pragma unroll
-        for (int t = 0; t < MT; ++t) wnxt[t] = ly_wfrag(wpk, wbase[t] + nt * C32 + nc, lane);
-      }
       const int toff = ((tap / 3) * FW + (tap % 3)) * LY_RSH;
 #pragma unroll
-      for (int n = 0; n < NTW; ++n) {
-        if (wp * NTW + n < ntv && !(dbg & 2)) {
-          const bf16x8 xh = ly_lds_frag(hs_hi, hb[n] + toff, 0, lq);
-          const bf16x8 xl = ly_lds_frag(hs_lo, hb[n] + toff, 0, lq);
+      for (int ks = 0; ks < KS; ++ks) {
+        // next fragment: next k-step of this tap, else next tap of this chunk, else tap 0 of the next chunk (clamped at the very end)
+        {
+          const bool last = ks == KS - 1;
+          const int nk = last ? 0 : ks + 1;
+          const int nt = last ? (tap < 8 ? tap + 1 : 0) : tap;
+          const int nc = (last && tap == 8) ? (more ? cc + 1 : cc) : cc;
 #pragma unroll
-          for (int t = 0; t < MT; ++t) acc[t][n] = ly_mfma3(wcur[t].hi, wcur[t].lo, xh, xl, acc[t][n]);
+          for (int t = 0; t < MT; ++t) wnxt[t] = ly_wfragp<PL>(wpk, wbase[t] + wstep(nt, nc, nk), lane);
         }
-      }
 #pragma unroll
-      for (int t = 0; t < MT; ++t) wcur[t] = wnxt[t];
+        for (int n = 0; n < NTW; ++n) {
+          if (wp * NTW + n < ntv) {
+            const bf16x8 xh = ly_lds_frag(hs_hi, hb[n] + toff, ks, lq);
+            bf16x8 xl = xh;
+            if constexpr (PL == 2) xl = ly_lds_frag(hs_lo, hb[n] + toff, ks, lq);
+#pragma unroll
+            for (int t = 0; t < MT; ++t) acc[t][n] = ly_mfmap<PL>(wcur[t], xh, xl, acc[t][n]);
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < MT; ++t) wcur[t] = wnxt[t];
+      }
     }
     if (more) {
       __syncthreads();            // every wave is done reading the frame of chunk cc
-      if (!(dbg & 8)) commit((cc + 1) * LY_CC);
+      commit((cc + 1) * LY_CC);
       __syncthreads();
     }
   }
@@ -160,7 +186,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_conv3x3_kernel(const LyConv3Par
   for (int t = 0; t < MT; ++t) {
     const int tt = (by * WC + wc) * MT + t;
     const int c = 16 * tt + 4 * lq;
-    if (tt >= T || c >= P.N) continue;
+    if (tt >= Tt || c >= P.N) continue;
     float sc[4], sh[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -178,67 +204,61 @@ __global__ __launch_bounds__(LY_THREADS) void ly_conv3x3_kernel(const LyConv3Par
       if (P.stats) {
         s1 += u;
         s2 += u * u;
-        if (!P.out) continue;                              // pure statistics pass; with `out` the value is stored as well
+        if (!out) continue;                                // pure statistics pass; with `out` the value is stored as well
       }
       const f32x4 v = ly_act4(u, act);
-      float* o = P.out + orow[n] * P.ldo + c;
+      T* o = out + orow[n] * P.ldo + c;
       if (vec_ok && c + 3 < P.N) {
-        ly_stg4(o, v);
+        ly_st4<T>(o, v);
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (c + r < P.N) o[r] = v[r];
+          if (c + r < P.N) ly_st1<T>(o + r, v[r]);
       }
     }
     if (P.stats) ly_stats_flush(P.stats, P.N, c, s1, s2);
   }
 }
 
-static int g_c3_cfg = 0;
-extern "C" int ly_debug_set_conv3_cfg(int v) { g_c3_cfg = v; return 0; }
-static int g_c3_dbg = 0;    // ablation aid: 2 skip LDS reads + MFMA, 8 skip commit
-extern "C" int ly_debug_set_conv3(int v) { g_c3_dbg = v; return 0; }
-
-template <int MT, int WC>
+template <typename T, int MT, int WC>
 static int launch_conv3(const LyConv3Params& P, hipStream_t st) {
   const int tiles_x = (P.W + P.TW - 1) / P.TW, tiles_y = (P.H + P.TH - 1) / P.TH;
   const int gy = (P.N + 16 * MT * WC - 1) / (16 * MT * WC);
   const long n_img = P.M / ((long)P.H * P.W);
   long nb = n_img * tiles_x * tiles_y * gy;
   LY_CHECK(nb < (1L << 31), "conv3x3: grid too large");
-  size_t lds = 2 * (size_t)(P.TH + 2) * (P.TW + 2) * LY_RSH;
-  auto k = ly_conv3x3_kernel<MT, WC>;
+  size_t lds = LyT<T>::PL * (size_t)(P.TH + 2) * (P.TW + 2) * (2 * 8 * LyT<T>::VW + 16);
+  auto k = ly_conv3x3_kernel<T, MT, WC>;
   static bool configured = false;
   if (!configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
     LY_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     configured = true;
   }
-  hipLaunchKernelGGL(k, dim3((unsigned)nb), dim3(LY_THREADS), lds, st, P, gy, tiles_x, tiles_y, g_c3_dbg);
+  hipLaunchKernelGGL(k, dim3((unsigned)nb), dim3(LY_THREADS), lds, st, P, gy, tiles_x, tiles_y);
   LY_LAUNCH_CHECK();
   return 0;
+}
+
+template <typename T>
+static int conv3_dispatch(const LyConv3Params& P, hipStream_t st) {
+  // measured on MI355X: 32 channels per wave is the sweet spot at every LEAD-YOLO shape
+  if (P.N > 64) return launch_conv3<T, 2, 4>(P, st);      // 4 waves x 32 ch (128 ch per block), all 8 pixel tiles each
+  return launch_conv3<T, 2, 2>(P, st);                    // 2 x 32 ch, 2 pixel groups of 4 tiles
 }
 
 extern "C" int ly_conv3x3_fwd(const LyConv3Params* p, void* stream) {
   LY_CHECK(p, "conv3x3: null params");
   const LyConv3Params& P = *p;
+  LY_CHECK(P.dtype == LY_F32 || P.dtype == LY_BF16, "conv3x3: unknown dtype %d", P.dtype);
+  const int vw = P.dtype == LY_BF16 ? 8 : 4;
   LY_CHECK(P.x && P.wp && (P.out || P.stats), "conv3x3: null pointer");
   LY_CHECK(P.M > 0 && P.H > 0 && P.W > 0 && P.Cin > 0 && P.N > 0, "conv3x3: bad sizes");
-  LY_CHECK((P.Cin & 3) == 0 && (P.ldx & 3) == 0, "conv3x3: Cin=%d / ldx=%d must be multiples of 4", P.Cin, P.ldx);
+  LY_CHECK((P.Cin & 3) == 0 && P.ldx % vw == 0 && P.ldx >= (P.Cin + vw - 1) / vw * vw && ((uintptr_t)P.x & 15) == 0,
+           "conv3x3: Cin=%d must be a multiple of 4, ldx=%d a multiple of %d covering Cin rounded up to it", P.Cin, P.ldx, vw);
   LY_CHECK(P.M % ((long)P.H * P.W) == 0, "conv3x3: M is not a whole number of images");
   LY_CHECK(P.TH >= 1 && P.TW >= 1 && P.TH * P.TW <= 16 * LY_C3_NT, "conv3x3: patch %dx%d exceeds %d pixels", P.TH, P.TW, 16 * LY_C3_NT);
-  LY_CHECK((P.TH + 2) * (P.TW + 2) * (LY_CC / 4) <= LY_C3_NV * LY_THREADS, "conv3x3: frame of patch %dx%d exceeds the staging capacity", P.TH, P.TW);
+  LY_CHECK((P.TH + 2) * (P.TW + 2) * 8 <= LY_C3_NV * LY_THREADS, "conv3x3: frame of patch %dx%d exceeds the staging capacity", P.TH, P.TW);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  switch (g_c3_cfg) {                                    // tuning aid: MT*10 + WC
-    case 44: return launch_conv3<4, 4>(P, st);
-    case 24: return launch_conv3<2, 4>(P, st);
-    case 14: return launch_conv3<1, 4>(P, st);
-    case 42: return launch_conv3<4, 2>(P, st);
-    case 22: return launch_conv3<2, 2>(P, st);
-    case 41: return launch_conv3<4, 1>(P, st);
-    default: break;
-  }
-  // measured on MI355X (tools/conv_cfg.py): 32 channels per wave is the sweet spot at every LEAD-YOLO shape
-  if (P.N > 64) return launch_conv3<2, 4>(P, st);      // 4 waves x 32 ch (128 ch per block), all 8 pixel tiles each
-  return launch_conv3<2, 2>(P, st);                    // 2 x 32 ch, 2 pixel groups of 4 tiles
+  return P.dtype == LY_BF16 ? conv3_dispatch<__bf16>(P, st) : conv3_dispatch<float>(P, st);
 }

@@ -1,0 +1,406 @@
+#pragma once
+// Pointwise-convolution GEMM with fused gather/prologue and epilogue, gfx950; storage dtype T = float (bf16x3 products) or
+// __bf16 (plain bf16 products), fp32 accumulation in both (ly_tile.cuh).
+//
+//   out[m, n] = act( rowscale[m] * scale[n] * sum_k A'[m, k] * W[n, k] + shift[n] )
+//
+// m runs over the flattened NHWC pixels, so A' is the activation matrix itself (no im2col).  A' is
+// assembled while the tile is staged into LDS, which is where the reference's separate passes go:
+//   * two row sources (a0 | a1)            -> torch.cat of two feature maps never materialised
+//   * a0 at half resolution (up0)          -> nn.Upsample(2, 'nearest') folded into the load
+//   * gate: a0 * a_w[n,w,:] * a_h[n,h,:]   -> CoordAtt's `identity * a_w * a_h` (models/common.py:1608)
+//   * affine+relu+ca: relu(x*s+b)*ca[n,:]  -> RFCBAMConv k=1 generate/BN/ReLU and SE scaling
+//                                             (models/rfa.py:101-106,124)
+//   * patch gather (k x k stride k)        -> PatchEmbed/PatchMerging_FasterNet (models/common.py:1528-1561)
+// and the epilogue covers BN (folded scale/shift), conv bias, the per-pixel receptive-field weight
+// (rowscale) and ReLU / SiLU.  `out` may point into a wider buffer (ldo, pre-offset pointer) so a
+// producer can write straight into its slot of a later concat.
+//
+// Block = 4 waves; WC waves split the output channels (distinct weight fragments per wave: no
+// redundant weight traffic), 4/WC waves split the pixels.  Wave tile = NT pixel tiles x MT channel
+// tiles of 16x16 on v_mfma_f32_16x16x32_bf16.
+//
+// Persistent two-deep pipeline: a block owns a strided set of pixel tiles and walks the work items (tile, K chunk).  A K
+// chunk is 16 vectors of 16 bytes per pixel row: BK = 64 fp32 or 128 bf16 elements — the same bytes in flight per thread
+// in both dtypes.  A chunk contracts in a few hundred MFMA cycles but its loads need 1-2 us to arrive, so the raw values
+// of items i+1 AND i+2 are in flight while item i is contracted: two register sets, used alternately (the item loop is
+// unrolled by two so the set index is static); item i+2 is issued into the set item i vacated when it was committed to
+// LDS.  The item body is straight-line code (surplus prefetches re-read the last item, ragged K contracts LDS zeros):
+// the compiler's s_waitcnt bookkeeping is exact only then.  Weight fragments of the chunk's later k-steps are requested
+// BEFORE the activation prefetch (vmcnt retires in order), the first step of the next item during the last step.
+#include "ly_tile.cuh"
+#include "ly_params.h"
+
+template <int V>
+struct LyIc { static constexpr int value = V; };
+
+// TI: element type of the sources (fp32 image for LY_GATHER_PATCH_NCHW whatever the output is), TO: of res / out
+template <typename TI, typename TO, int NT, int MT, int WC, int GATHER, int PRO>
+__device__ __forceinline__ void ly_gemm_body2(const LyGemmParams& P, const int gy, const int nslots, const int gx) {
+  using TR = LyT<TI>;
+  using RV = typename TR::RV;
+  constexpr int VW = TR::VW, PL = TR::PL, NQ = VW / 4;
+  constexpr int LY_BK = 16 * VW;
+  constexpr int WP = 4 / WC;
+  constexpr int BP = 16 * NT * WP;
+  constexpr int LY_RSX = 2 * LY_BK + 16;                  // bytes per LDS row, per plane (RSX/8 = 2 mod 32 x odd: conflict-free b64 fragment reads)
+  constexpr int KQ = 16;                                  // vector columns per chunk
+  constexpr int RSTEP = LY_THREADS / KQ;
+  constexpr int SPC = LY_BK / 32;                         // k-steps per chunk: 2 (fp32) / 4 (bf16)
+  constexpr int NV = BP * KQ / LY_THREADS;
+  constexpr int PLANE = BP * LY_RSX;
+  static_assert(NV >= 1 && BP * KQ % LY_THREADS == 0, "tile must divide evenly over the block");
+  extern __shared__ f32x4 ly_smem4[];
+  char* xs = reinterpret_cast<char*>(ly_smem4);           // [buf][plane][BP][RSX]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lq = lane >> 4;
+  const int wc = wave % WC, wp_ = wave / WC;
+  const int lid = ly_xcd_remap(blockIdx.x, gy * nslots);
+  const int by = lid % gy;
+  const int slot = lid / gy;
+  const int HW = P.H * P.W;
+  const float invHW = 1.f / (float)HW, invW = 1.f / (float)P.W;
+  const f32x4 zero = ly_zero4();
+  const int S = (P.K + 31) >> 5;
+  const int T = (P.N + 15) >> 4;
+  const int nchunk = (P.K + LY_BK - 1) / LY_BK;
+  constexpr bool need_nhw = GATHER != LY_GATHER_ROWS || PRO != LY_PRO_NONE;
+  // thread -> (vector column k4, first pixel row prow).  NHWC sources: consecutive lanes take consecutive k (one pixel row is
+  // K-contiguous).  NCHW image patches: consecutive k are different (channel, ky) planes, megabytes apart, while consecutive
+  // output pixels of one plane row ARE contiguous (16 B each) — so there consecutive lanes take consecutive pixels.
+  static_assert(KQ == RSTEP, "the NCHW lane mapping swaps the two 16-way indices");
+  const int k4 = GATHER == LY_GATHER_PATCH_NCHW ? tid / RSTEP : tid % KQ;
+  const int prow = GATHER == LY_GATHER_PATCH_NCHW ? tid % RSTEP : tid / KQ;
+  if (slot >= gx) return;
+  const TI* const a0 = reinterpret_cast<const TI*>(P.a0);
+  const TI* const a1 = reinterpret_cast<const TI*>(P.a1);
+  const TO* const res = reinterpret_cast<const TO*>(P.res);
+  TO* const out = reinterpret_cast<TO*>(P.out);
+
+  // ---- staging state, one copy per register set ---------------------------------------------------
+  RV pv[2][NV];
+  long t_row0[2][NV];
+  int t_n[2][NV], t_hw[2][NV];
+  long s_p[2];                                             // tile start and K offset of the item held by the set
+  int s_kc[2];
+  int cur_pt = slot, cur_c = 0;                            // issue cursor (saturates at the slot's last item)
+
+  auto issue = [&](auto sC) {
+    constexpr int s = decltype(sC)::value;
+    const long p0 = (long)cur_pt * BP;
+    const int kc = cur_c * LY_BK;
+    s_p[s] = p0; s_kc[s] = kc;
+    if (cur_c == 0 || !need_nhw) {                         // first chunk of a tile: describe its rows (else: same tile as the
+#pragma unroll                                             // other set, which holds the previous chunk)
+      for (int e = 0; e < NV; ++e) {
+        const long gp = p0 + prow + RSTEP * e;
+        int n = -1, h = 0, w = 0;
+        long row0 = gp;
+        if (gp < P.M) {
+          n = 0;
+          if (need_nhw) {
+            n = ly_fdiv((int)gp, HW, invHW);
+            const int rem = (int)gp - n * HW;
+            h = ly_fdiv(rem, P.W, invW);
+            w = rem - h * P.W;
+            if (GATHER == LY_GATHER_UP2)
+              row0 = ((long)n * (P.H >> 1) + (h >> 1)) * (P.W >> 1) + (w >> 1);
+            else if (GATHER == LY_GATHER_PATCH)
+              row0 = (((long)n * P.Hin + (long)h * P.ks) * P.Win + (long)w * P.ks);
+            else if (GATHER == LY_GATHER_PATCH_NCHW)
+              row0 = ((long)n * P.Cin * P.Hin + (long)h * P.ks) * P.Win + (long)w * P.ks;
+          }
+        }
+        t_row0[s][e] = row0; t_n[s][e] = n; t_hw[s][e] = (h << 16) | w;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < NV; ++e) { t_row0[s][e] = t_row0[1 - s][e]; t_n[s][e] = t_n[1 - s][e]; t_hw[s][e] = t_hw[1 - s][e]; }
+    }
+    const int kk = kc + VW * k4;
+    const bool kok = kk < P.K;
+    long koff;
+    const TI* src = a0;
+    long rowmul = P.lda0;
+    bool second = false;
+    if (GATHER == LY_GATHER_PATCH) {
+      const int seg = kk / P.pk, within = kk - seg * P.pk;
+      koff = (long)seg * P.Win * P.lda0 + within;
+    } else if (GATHER == LY_GATHER_PATCH_NCHW) {
+      const int c = kk >> 4, ky = (kk >> 2) & 3;           // ks == 4, fp32 image: one float4 = one (c, ky) input row segment
+      koff = ((long)c * P.Hin + ky) * P.Win;
+      rowmul = 1;
+    } else {
+      second = kk >= P.k0;
+      koff = second ? kk - P.k0 : kk;
+      if (second) { src = a1; rowmul = P.lda1; }
+    }
+#pragma unroll
+    for (int e = 0; e < NV; ++e) {
+      const bool ok = kok && t_n[s][e] >= 0;
+      const long row = second ? (p0 + prow + RSTEP * e) : t_row0[s][e];
+      pv[s][e] = ly_ldrv<TI>(ok ? src + row * rowmul + koff : a0);
+    }
+    // advance the cursor; past the last item it stays there (the surplus issues re-read it, harmlessly, so that every
+    // pass through the loop issues the same loads and the compiler's vmcnt bookkeeping is exact)
+    if (cur_c + 1 < nchunk) ++cur_c;
+    else if (cur_pt + nslots < gx) { cur_pt += nslots; cur_c = 0; }
+  };
+
+  auto commit = [&](auto sC, int buf) {
+    constexpr int s = decltype(sC)::value;
+    char* hi = xs + buf * PL * PLANE;
+    char* lo = hi + (PL - 1) * PLANE;
+    const long p0 = s_p[s];
+    const int kk = s_kc[s] + VW * k4;
+    RV v[NV];
+#pragma unroll
+    for (int e = 0; e < NV; ++e) {
+      v[e] = pv[s][e];
+      if (!(kk < P.K && t_n[s][e] >= 0)) ly_zero_raw(v[e]);
+    }
+    if constexpr (PRO == LY_PRO_GATE) {
+      // CoordAtt factors: small L2-resident fp32 tables, fetched here (two more register sets of them do not fit)
+      const bool kok = kk < P.k0;
+      f32x4 gw[NV][NQ], gh[NV][NQ];
+      RV rr[NV];
+#pragma unroll
+      for (int e = 0; e < NV; ++e) {
+        const bool ok = kok && t_n[s][e] >= 0;
+        const int n = ok ? t_n[s][e] : 0, h = ok ? (t_hw[s][e] >> 16) : 0, w = ok ? (t_hw[s][e] & 0xffff) : 0;
+        const int kq = ok ? kk : 0;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          gw[e][q] = ly_ldg4(P.g_w + ((long)n * P.W + w) * P.k0 + kq + 4 * q);
+          gh[e][q] = ly_ldg4(P.g_h + ((long)n * P.H + h) * P.k0 + kq + 4 * q);
+        }
+        if (res && ok) rr[e] = ly_ldrv<TO>(res + (p0 + prow + RSTEP * e) * P.ldres + kk);
+        else ly_zero_raw(rr[e]);
+      }
+#pragma unroll
+      for (int e = 0; e < NV; ++e)
+        if (kok && t_n[s][e] >= 0) {
+          f32x4 x[NQ], r[NQ];
+          ly_rv_unpack(v[e], x);
+          ly_rv_unpack(rr[e], r);
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) x[q] = x[q] * gw[e][q] * gh[e][q] + r[q];
+          v[e] = ly_rv_pack(x, (RV*)nullptr);
+        }
+    } else if constexpr (PRO == LY_PRO_AFFINE_RELU_CA) {
+      const bool kok = kk < P.K;
+      const int kq = kok ? kk : 0;
+      f32x4 sa[NQ], sb[NQ], ca[NV][NQ];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) { sa[q] = ly_ldg4(P.p_scale + kq + 4 * q); sb[q] = ly_ldg4(P.p_shift + kq + 4 * q); }
+#pragma unroll
+      for (int e = 0; e < NV; ++e)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) ca[e][q] = ly_ldg4(P.p_ca + (long)(t_n[s][e] >= 0 ? t_n[s][e] : 0) * P.K + kq + 4 * q);
+#pragma unroll
+      for (int e = 0; e < NV; ++e)
+        if (kok && t_n[s][e] >= 0) {
+          f32x4 x[NQ];
+          ly_rv_unpack(v[e], x);
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[q][r] = fmaxf(x[q][r] * sa[q][r] + sb[q][r], 0.f) * ca[e][q][r];
+          v[e] = ly_rv_pack(x, (RV*)nullptr);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < NV; ++e) ly_lds_put_rv(hi, lo, (prow + RSTEP * e) * LY_RSX, VW * k4, v[e]);
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[t][n] = zero;
+  long wbase[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    int tt = (by * WC + wc) * MT + t;
+    wbase[t] = (long)(tt < T ? tt : T - 1) * S;
+  }
+  const uint4* wpk = reinterpret_cast<const uint4*>(P.wp);
+  const int pixgrp = wp_ * (16 * NT);
+  const bool vec_ok = (P.ldo & 3) == 0;
+  const int act = P.act;
+  float* const stats = P.stats;
+  float rsv[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) rsv[n] = 1.f;
+  float esc[MT][4], esh[MT][4];                            // epilogue scale/shift: fetched once, not per tile
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const int c = 16 * ((by * WC + wc) * MT + t) + 4 * lq;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool ok = c + r < P.N;
+      esc[t][r] = (ok && P.e_scale) ? P.e_scale[c + r] : 1.f;
+      esh[t][r] = (ok && P.e_shift) ? P.e_shift[c + r] : 0.f;
+    }
+  }
+  ly_l2_warm(P.wp, (long)T * S * PL * 1024, P.stats ? P.stats : reinterpret_cast<float*>(P.out));
+  LyWF<PL> wq[SPC][MT];                                    // wq[j]: weights of k-step j of the item being contracted
+#pragma unroll
+  for (int t = 0; t < MT; ++t) wq[0][t] = ly_wfragp<PL>(wpk, wbase[t], lane);
+
+  int pt = slot, c = 0, buf = 0;                           // item being contracted
+  long p0 = (long)slot * BP;
+  issue(LyIc<0>());
+  issue(LyIc<1>());
+  commit(LyIc<0>(), 0);
+  __syncthreads();
+
+  // one item: weights, re-issue the vacated set two items ahead, contract, commit the next item, barrier, epilogue at tile end
+  auto item = [&](auto sC) -> bool {
+    constexpr int s = decltype(sC)::value;                 // set that held THIS item (already committed): free
+#pragma unroll
+    for (int j = 1; j < SPC; ++j) {                        // later k-steps' weights first (older than the prefetch in the queue)
+      const int gj = SPC * c + j < S ? SPC * c + j : 0;
+#pragma unroll
+      for (int t = 0; t < MT; ++t) wq[j][t] = ly_wfragp<PL>(wpk, wbase[t] + gj, lane);
+    }
+    if (PRO == LY_PRO_AFFINE_RELU_CA) {
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const long gp = p0 + pixgrp + 16 * n + li;
+        rsv[n] = P.rowscale[gp < P.M ? gp : 0];
+      }
+    }
+    issue(sC);                                             // item i+2
+    const char* hi = xs + buf * PL * PLANE;
+    const char* lo = hi + (PL - 1) * PLANE;
+#pragma unroll
+    for (int st = 0; st < SPC; ++st) {
+      bf16x8 xh[NT], xl[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int rb = (pixgrp + 16 * n + li) * LY_RSX;
+        xh[n] = ly_lds_frag(hi, rb, st, lq);
+        if constexpr (PL == 2) xl[n] = ly_lds_frag(lo, rb, st, lq);
+        else xl[n] = xh[n];
+      }
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[t][n] = ly_mfmap<PL>(wq[st][t], xh[n], xl[n], acc[t][n]);
+      if (st == SPC - 1) {                                 // weights of the next item's first step into the slot step 0 vacated
+        const int gn = SPC * (c + 1) < S ? SPC * (c + 1) : 0;   // (absent steps of a ragged last chunk contract LDS zeros with clamped weights: no branch)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) wq[0][t] = ly_wfragp<PL>(wpk, wbase[t] + gn, lane);
+      }
+    }
+    commit(LyIc<1 - s>(), buf ^ 1);                        // item i+1
+    __syncthreads();
+    buf ^= 1;
+    if (c + 1 < nchunk) { ++c; return true; }
+    // ---- epilogue of tile pt ---------------------------------------------------------------------
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const int tt = (by * WC + wc) * MT + t;
+      const int cc = 16 * tt + 4 * lq;
+      if (tt < T && cc < P.N) {
+        f32x4 st1 = zero, st2 = zero;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const long gp = p0 + pixgrp + 16 * n + li;
+          if (gp < P.M) {
+            const float rs = PRO == LY_PRO_AFFINE_RELU_CA ? rsv[n] : 1.f;
+            f32x4 u;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) u[r] = acc[t][n][r] * rs * esc[t][r] + esh[t][r];
+            if (stats) {                                   // pre-activation value (fp32, before any rounding) is what BatchNorm normalises
+              st1 += u;
+              st2 += u * u;
+              if (!out) continue;                          // pure statistics pass; with `out` the value is stored as well
+            }
+            const f32x4 v = ly_act4(u, act);
+            TO* o = out + gp * P.ldo + cc;
+            if (vec_ok && cc + 3 < P.N) {
+              ly_st4<TO>(o, v);
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if (cc + r < P.N) ly_st1<TO>(o + r, v[r]);
+            }
+          }
+        }
+        if (stats) ly_stats_flush(stats, P.N, cc, st1, st2);
+      }
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[t][n] = zero;
+    }
+    pt += nslots;
+    if (pt >= gx) return false;
+    p0 = (long)pt * BP;
+    c = 0;
+    return true;
+  };
+  while (true) {
+    if (!item(LyIc<0>())) break;
+    if (!item(LyIc<1>())) break;
+  }
+}
+
+template <typename TI, typename TO, int NT, int MT, int WC, int GATHER, int PRO>
+__global__ __launch_bounds__(LY_THREADS) void ly_gemm_kernel_d2(const LyGemmParams P, const int gy, const int nslots, const int gx) {
+  ly_gemm_body2<TI, TO, NT, MT, WC, GATHER, PRO>(P, gy, nslots, gx);
+}
+
+template <typename TI, typename TO, int NT, int MT, int WC, int GATHER, int PRO>
+static int launch_gemm_d2(const LyGemmParams& P, hipStream_t st) {
+  constexpr int BP = 16 * NT * (4 / WC);
+  constexpr int BN = 16 * MT * WC;
+  constexpr int BK = 16 * LyT<TI>::VW;
+  constexpr size_t lds = 2 * LyT<TI>::PL * (size_t)BP * (2 * BK + 16);
+  long gx = (P.M + BP - 1) / BP;
+  int gy = (P.N + BN - 1) / BN;
+  LY_CHECK(gx < (1L << 30), "gemm: too many pixel tiles");
+  auto k = ly_gemm_kernel_d2<TI, TO, NT, MT, WC, GATHER, PRO>;
+  static int per_cu = 0;            // co-resident blocks per CU (registers + LDS), measured once per instantiation
+  if (per_cu == 0) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+    LY_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    int nb = 0;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k), LY_THREADS, lds);
+    LY_CHECK(e == hipSuccess, "hipOccupancyMaxActiveBlocksPerMultiprocessor: %s", hipGetErrorString(e));
+    per_cu = nb < 1 ? 1 : (nb > 8 ? 8 : nb);
+  }
+  // persistent grid = exactly the blocks that can be resident at once (a larger grid would run in rounds)
+  long nslots = (256L * per_cu) / gy;
+  if (nslots < 1) nslots = 1;
+  if (nslots > gx) nslots = gx;
+  hipLaunchKernelGGL(k, dim3((unsigned)(nslots * gy)), dim3(LY_THREADS), lds, st, P, gy, (int)nslots, (int)gx);
+  LY_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename T, int NT, int MT, int WC>
+static int launch_gemm(const LyGemmParams& P, hipStream_t st) {
+  if (P.gather == LY_GATHER_PATCH) return launch_gemm_d2<T, T, NT, MT, WC, LY_GATHER_PATCH, LY_PRO_NONE>(P, st);
+  if (P.gather == LY_GATHER_PATCH_NCHW) return launch_gemm_d2<float, T, NT, MT, WC, LY_GATHER_PATCH_NCHW, LY_PRO_NONE>(P, st);
+  if (P.gather == LY_GATHER_UP2) {
+    if (P.pro == LY_PRO_NONE) return launch_gemm_d2<T, T, NT, MT, WC, LY_GATHER_UP2, LY_PRO_NONE>(P, st);
+    ly_set_error("gemm: upsampled source with a prologue is not built");
+    return -1;
+  }
+  if (P.pro == LY_PRO_GATE) return launch_gemm_d2<T, T, NT, MT, WC, LY_GATHER_ROWS, LY_PRO_GATE>(P, st);
+  if (P.pro == LY_PRO_AFFINE_RELU_CA) return launch_gemm_d2<T, T, NT, MT, WC, LY_GATHER_ROWS, LY_PRO_AFFINE_RELU_CA>(P, st);
+  return launch_gemm_d2<T, T, NT, MT, WC, LY_GATHER_ROWS, LY_PRO_NONE>(P, st);
+}
+
+// Tile policy, measured on MI355X at every LEAD-YOLO shape: 64-pixel tiles with 3 co-resident blocks per CU beat 128-pixel
+// tiles (one wave per SIMD); the narrow-output tile trades channels for pixels.
+template <typename T>
+static int ly_gemm_dispatch(const LyGemmParams& P, hipStream_t st) {
+  if (P.N > 64) return launch_gemm<T, 4, 2, 4>(P, st);    // 64 px x 128 ch per block
+  if (P.N > 32) return launch_gemm<T, 4, 1, 4>(P, st);    // 64 px x 64 ch
+  return launch_gemm<T, 2, 2, 1>(P, st);                  // 128 px x 32 ch
+}
+int ly_gemm_dispatch_f32(const LyGemmParams& P, hipStream_t st);
+int ly_gemm_dispatch_bf16(const LyGemmParams& P, hipStream_t st);

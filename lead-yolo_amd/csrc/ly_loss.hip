@@ -154,7 +154,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_loss_obj_kernel(const LyLossLev
 extern "C" int ly_loss_level(const float* p, float* dp, const float* anchors, const float* targets, int bs, int na, int ny, int nx, int no, long nt,
                              float anchor_t, float box_gain, float obj_gain, float balance, float* tobj, int* winner, long* cand_cell, float* cand,
                              float* acc, float* tbox, int match_only, void* stream) {
-  LY_CHECK(p && dp && anchors && tobj && winner && acc && (nt == 0 || (targets && cand_cell && cand)), "loss_level: null pointer");
+  LY_CHECK(p && (dp || match_only) && anchors && tobj && winner && acc && (nt == 0 || (targets && cand_cell && cand)), "loss_level: null pointer");
   LY_CHECK(bs > 0 && na > 0 && ny > 0 && nx > 0 && no >= 5 && nt >= 0, "loss_level: bad sizes");
   const long cells = (long)bs * na * ny * nx;
   LY_CHECK(5L * na * nt < (1L << 31) && cells < (1L << 40), "loss_level: too many candidates");

@@ -1,5 +1,6 @@
 #pragma once
-// Fused FasterNet MLPBlock forward (eval / folded-BN form), fp32 I/O, bf16x3 matrix math, gfx950.
+// Fused FasterNet MLPBlock forward (eval / folded-BN form), gfx950; storage dtype T = float (bf16x3 products, two operand
+// planes) or __bf16 (plain bf16 products, one plane), fp32 accumulation (ly_tile.cuh).
 //
 //   y = x + W2 . relu( s * (W1 . [ pconv3x3(x[:, :C/4]) | x[:, C/4:] ]) + b )
 //
@@ -43,12 +44,14 @@ struct MlpGeom {
 // as soon as fragment g's MFMAs are issued.  All loops are fully unrolled, so g and the slot index are compile-time constants.
 // D = 0: no ring (loads where they are used; fewer registers, more co-resident waves -- the better trade for the narrow,
 // memory-heavy stages).
-template <int C, int NT, int HT, bool T2D, bool STATS, int D>
+template <typename T, int C, int NT, int HT, bool T2D, bool STATS, int D>
 __device__ __forceinline__ void ly_mlpblock_body(
-    const float* __restrict__ x, float* __restrict__ y, long M, int H, int W,
+    const T* __restrict__ x, T* __restrict__ y, long M, int H, int W,
     const uint4* __restrict__ wp, const uint4* __restrict__ w1, const uint4* __restrict__ w2,
-    const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, float* __restrict__ stats, const int dbg) {
+    const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, float* __restrict__ stats) {
   using Gm = MlpGeom<C>;
+  using TR = LyT<T>;
+  constexpr int PL = TR::PL, VW = TR::VW;
   constexpr int CQ = Gm::CQ, G = Gm::G, SP = Gm::SP, PT = Gm::PT, C16 = Gm::C16, KP = Gm::KP, S1 = Gm::S1;
   constexpr int RS = Gm::RS, RSP = Gm::RSP, HTP = Gm::HTP, S2 = Gm::S2;
   constexpr int BP = 64 * NT;
@@ -64,10 +67,10 @@ __device__ __forceinline__ void ly_mlpblock_body(
   constexpr int TH = 4 * NT;
   extern __shared__ f32x4 ly_smem4[];
   char* xs_hi = reinterpret_cast<char*>(ly_smem4);
-  char* xs_lo = xs_hi + BP * RS;
+  char* xs_lo = xs_hi + (PL - 1) * BP * RS;               // PL == 1: the "lo" pointers alias hi and are never used
   const int BPH = T2D ? (TH + 2) * 18 : BP + 2 * W + 2;
-  char* ps_hi = xs_lo + BP * RS;
-  char* ps_lo = ps_hi + BPH * RSP;
+  char* ps_hi = xs_hi + PL * BP * RS;
+  char* ps_lo = ps_hi + (PL - 1) * BPH * RSP;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lq = lane >> 4;
@@ -76,20 +79,20 @@ __device__ __forceinline__ void ly_mlpblock_body(
   // the fragment stream: partial conv (k-step major), then per hidden chunk GEMM1 (k-step major) and, unless this is the
   // statistics pass, GEMM2 (hidden pair major)
   constexpr int FP = SP * PT, F1 = S1 * HT, F2 = STATS ? 0 : (HT / 2) * C16, FQ = F1 + F2, NFRAG = FP + (HTP / HT) * FQ;
-  auto wseq = [&](int g) -> LyWFrag {
-    if (g < FP) return ly_wfrag(wp, (g % PT) * SP + g / PT, lane);
+  auto wseq = [&](int g) -> LyWF<PL> {
+    if (g < FP) return ly_wfragp<PL>(wp, (g % PT) * SP + g / PT, lane);
     g -= FP;
     const int chunk = g / FQ, r = g - chunk * FQ;
-    if (r < F1) return ly_wfrag(w1, (chunk * HT + r % HT) * S1 + r / HT, lane);
+    if (r < F1) return ly_wfragp<PL>(w1, (chunk * HT + r % HT) * S1 + r / HT, lane);
     const int r2 = r - F1;
-    return ly_wfrag(w2, (r2 % C16) * S2 + chunk * (HT / 2) + r2 / C16, lane);
+    return ly_wfragp<PL>(w2, (r2 % C16) * S2 + chunk * (HT / 2) + r2 / C16, lane);
   };
-  LyWFrag ring[D > 0 ? D : 1];
+  LyWF<PL> ring[D > 0 ? D : 1];
 #pragma unroll
   for (int g = 0; g < D; ++g)
     if (g < NFRAG) ring[g] = wseq(g);
   int g = 0;                   // fragments consumed so far (a constant at every use after unrolling)
-  auto wnext = [&]() -> LyWFrag {
+  auto wnext = [&]() -> LyWF<PL> {
     if constexpr (D == 0) return wseq(g);
     else return ring[g % D];
   };
@@ -101,10 +104,10 @@ __device__ __forceinline__ void ly_mlpblock_body(
     ++g;
   };
   if (C >= 80) {     // large weight sets, few pixels: warm L2 with all three packed weight arrays
-    float* const sink = stats ? stats : y;
-    ly_l2_warm(w1, (long)HTP * S1 * 2048, sink);
-    ly_l2_warm(w2, (long)C16 * S2 * 2048, sink);
-    ly_l2_warm(wp, (long)PT * SP * 2048, sink);
+    float* const sink = stats ? stats : reinterpret_cast<float*>(y);
+    ly_l2_warm(w1, (long)HTP * S1 * PL * 1024, sink);
+    ly_l2_warm(w2, (long)C16 * S2 * PL * 1024, sink);
+    ly_l2_warm(wp, (long)PT * SP * PL * 1024, sink);
   }
   long p0 = 0;                 // flattened: first pixel of the run
   long img0 = 0;               // T2D: pixel index of (n, 0, 0)
@@ -129,18 +132,19 @@ __device__ __forceinline__ void ly_mlpblock_body(
     return gp < M ? gp : -1;
   };
 
-  ly_stage_f4<8>(BP * (KP / 4), tid, x,
-      [&](int idx) -> const float* {
-        const int pix = idx / (KP / 4), c4 = idx - pix * (KP / 4);
+  static_assert(C % VW == 0, "a pixel row must be a whole number of 16-byte vectors");
+  ly_stage_raw<8, typename TR::RV>(BP * (KP / VW), tid, x,
+      [&](int idx) -> const void* {
+        const int pix = idx / (KP / VW), c4 = idx - pix * (KP / VW);
         const long gp = gpix(pix);
-        return (gp >= 0 && c4 * 4 < C) ? x + gp * C + c4 * 4 : nullptr;
+        return (gp >= 0 && c4 * VW < C) ? x + gp * C + c4 * VW : nullptr;
       },
-      [&](int idx, f32x4 v) {
-        const int pix = idx / (KP / 4), c4 = idx - pix * (KP / 4);
-        ly_lds_put4(xs_hi, xs_lo, pix * RS, 4 * c4, v);
+      [&](int idx, typename TR::RV v) {
+        const int pix = idx / (KP / VW), c4 = idx - pix * (KP / VW);
+        ly_lds_put_rv(xs_hi, xs_lo, pix * RS, VW * c4, v);
       });
-  if (!(dbg & 4)) ly_stage_f4<4>(BPH * G, tid, x,
-      [&](int idx) -> const float* {
+  ly_stage_raw<4, typename TR::R4>(BPH * G, tid, x,
+      [&](int idx) -> const void* {
         const int hp = idx / G, c4 = idx - hp * G;
         long gp;
         if (T2D) {
@@ -153,9 +157,9 @@ __device__ __forceinline__ void ly_mlpblock_body(
         }
         return gp >= 0 ? x + gp * C + c4 * 4 : nullptr;
       },
-      [&](int idx, f32x4 v) {
+      [&](int idx, typename TR::R4 v) {
         const int hp = idx / G, c4 = idx - hp * G;
-        ly_lds_put4(ps_hi, ps_lo, hp * RSP, 4 * c4, v);
+        ly_lds_put_r4(ps_hi, ps_lo, hp * RSP, 4 * c4, v);
       });
   __syncthreads();
 
@@ -209,18 +213,22 @@ __device__ __forceinline__ void ly_mlpblock_body(
         for (int h = 0; h < 2; ++h) {
           const bool ok = gv[h] && (T2D || ((tmask[n] >> tap[h]) & 1u));
           const bf16x4 a = *reinterpret_cast<const bf16x4*>(ps_hi + rb + off[h]);
-          const bf16x4 b = *reinterpret_cast<const bf16x4*>(ps_lo + rb + off[h]);
           ph[h] = ok ? a : z4;
-          pl[h] = ok ? b : z4;
+          if constexpr (PL == 2) {
+            const bf16x4 b = *reinterpret_cast<const bf16x4*>(ps_lo + rb + off[h]);
+            pl[h] = ok ? b : z4;
+          } else {
+            pl[h] = z4;
+          }
         }
         xh[n] = ly_cat8(ph[0], ph[1]);
         xl[n] = ly_cat8(pl[0], pl[1]);
       }
 #pragma unroll
       for (int t = 0; t < PT; ++t) {
-        const LyWFrag wf = wnext();
+        const LyWF<PL> wf = wnext();
 #pragma unroll
-        for (int n = 0; n < NT; ++n) accp[t][n] = ly_mfma3(wf.hi, wf.lo, xh[n], xl[n], accp[t][n]);
+        for (int n = 0; n < NT; ++n) accp[t][n] = ly_mfmap<PL>(wf, xh[n], xl[n], accp[t][n]);
         wrefill();
       }
     }
@@ -234,11 +242,11 @@ __device__ __forceinline__ void ly_mlpblock_body(
         const int rb = (pixbase + 16 * n + li) * RS + 2 * c;
         if (c < CQ) {            // CQ is even: channels (c, c+1) are valid together
           *reinterpret_cast<bf16x2*>(xs_hi + rb) = __builtin_shufflevector(h, h, 0, 1);
-          *reinterpret_cast<bf16x2*>(xs_lo + rb) = __builtin_shufflevector(l, l, 0, 1);
+          if constexpr (PL == 2) *reinterpret_cast<bf16x2*>(xs_lo + rb) = __builtin_shufflevector(l, l, 0, 1);
         }
         if (c + 2 < CQ) {
           *reinterpret_cast<bf16x2*>(xs_hi + rb + 4) = __builtin_shufflevector(h, h, 2, 3);
-          *reinterpret_cast<bf16x2*>(xs_lo + rb + 4) = __builtin_shufflevector(l, l, 2, 3);
+          if constexpr (PL == 2) *reinterpret_cast<bf16x2*>(xs_lo + rb + 4) = __builtin_shufflevector(l, l, 2, 3);
         }
       }
   }
@@ -264,13 +272,14 @@ __device__ __forceinline__ void ly_mlpblock_body(
       for (int n = 0; n < NT; ++n) {
         const int rb = (pixbase + 16 * n + li) * RS;
         xh[n] = ly_lds_frag(xs_hi, rb, s, lq);
-        xl[n] = ly_lds_frag(xs_lo, rb, s, lq);
+        if constexpr (PL == 2) xl[n] = ly_lds_frag(xs_lo, rb, s, lq);
+        else xl[n] = xh[n];
       }
 #pragma unroll
       for (int t = 0; t < HT; ++t) {
-        const LyWFrag wf = wnext();
+        const LyWF<PL> wf = wnext();
 #pragma unroll
-        for (int n = 0; n < NT; ++n) acch[t][n] = ly_mfma3(wf.hi, wf.lo, xh[n], xl[n], acch[t][n]);
+        for (int n = 0; n < NT; ++n) acch[t][n] = ly_mfmap<PL>(wf, xh[n], xl[n], acch[t][n]);
         wrefill();
       }
     }
@@ -300,7 +309,8 @@ __device__ __forceinline__ void ly_mlpblock_body(
         f32x4 v;
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(acch[t][n][r] * sc[r] + sh[r], 0.f);
-        ly_split4(v, hh[t][n], hl[t][n]);
+        if constexpr (PL == 2) ly_split4(v, hh[t][n], hl[t][n]);
+        else { hh[t][n] = ly_cvtb4(v); hl[t][n] = hh[t][n]; }
       }
     }
 #pragma unroll
@@ -313,9 +323,9 @@ __device__ __forceinline__ void ly_mlpblock_body(
       }
 #pragma unroll
       for (int ct = 0; ct < C16; ++ct) {
-        const LyWFrag wf = wnext();
+        const LyWF<PL> wf = wnext();
 #pragma unroll
-        for (int n = 0; n < NT; ++n) acco[ct][n] = ly_mfma3(wf.hi, wf.lo, xh[n], xl[n], acco[ct][n]);
+        for (int n = 0; n < NT; ++n) acco[ct][n] = ly_mfmap<PL>(wf, xh[n], xl[n], acco[ct][n]);
         wrefill();
       }
     }
@@ -338,66 +348,65 @@ __device__ __forceinline__ void ly_mlpblock_body(
         if (c < Gm::CQP) {
           const int rb = (T2D ? (((pix >> 4) + 1) * 18 + (pix & 15) + 1) : (pix + W + 1)) * RSP + 2 * c;
           rh = *reinterpret_cast<const bf16x4*>(ps_hi + rb);
-          rl = *reinterpret_cast<const bf16x4*>(ps_lo + rb);
+          if constexpr (PL == 2) rl = *reinterpret_cast<const bf16x4*>(ps_lo + rb);
         } else {
           const int rb = pix * RS + 2 * c;
           rh = *reinterpret_cast<const bf16x4*>(xs_hi + rb);
-          rl = *reinterpret_cast<const bf16x4*>(xs_lo + rb);
+          if constexpr (PL == 2) rl = *reinterpret_cast<const bf16x4*>(xs_lo + rb);
         }
-        const f32x4 r = __builtin_convertvector(rh, f32x4) + __builtin_convertvector(rl, f32x4);
-        if (!(dbg & 8)) ly_stg4(y + gp * C + c, acco[ct][n] + r);
+        f32x4 r = ly_cvt4(rh);
+        if constexpr (PL == 2) r += ly_cvt4(rl);
+        ly_st4<T>(y + gp * C + c, acco[ct][n] + r);
       }
     }
 }
 
-template <int C, int NT, int HT, bool T2D, bool STATS>
+template <typename T, int C, int NT, int HT, bool T2D, bool STATS>
 __global__ __launch_bounds__(LY_THREADS) void ly_mlpblock_fwd_kernel(
-    const float* __restrict__ x, float* __restrict__ y, long M, int H, int W,
+    const T* __restrict__ x, T* __restrict__ y, long M, int H, int W,
     const uint4* __restrict__ wp, const uint4* __restrict__ w1, const uint4* __restrict__ w2,
-    const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, float* __restrict__ stats, const int dbg) {
-  ly_mlpblock_body<C, NT, HT, T2D, STATS, 0>(x, y, M, H, W, wp, w1, w2, bn_scale, bn_shift, stats, dbg);
+    const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, float* __restrict__ stats) {
+  ly_mlpblock_body<T, C, NT, HT, T2D, STATS, 0>(x, y, M, H, W, wp, w1, w2, bn_scale, bn_shift, stats);
 }
 
 // the narrowest stages (C <= 24, 8 x 16 patches) are pure HBM streams: four resident waves per SIMD instead of three
 // (116 instead of 136 registers, no spills) is +6 % (64.8 -> 60.8 us at 160 x 160 x 32); C = 40 loses 8 % with it
-template <int C, int NT, int HT, bool T2D, bool STATS>
+template <typename T, int C, int NT, int HT, bool T2D, bool STATS>
 __global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void ly_mlpblock_fwd_occ4_kernel(
-    const float* __restrict__ x, float* __restrict__ y, long M, int H, int W,
+    const T* __restrict__ x, T* __restrict__ y, long M, int H, int W,
     const uint4* __restrict__ wp, const uint4* __restrict__ w1, const uint4* __restrict__ w2,
-    const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, float* __restrict__ stats, const int dbg) {
-  ly_mlpblock_body<C, NT, HT, T2D, STATS, 0>(x, y, M, H, W, wp, w1, w2, bn_scale, bn_shift, stats, dbg);
+    const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, float* __restrict__ stats) {
+  ly_mlpblock_body<T, C, NT, HT, T2D, STATS, 0>(x, y, M, H, W, wp, w1, w2, bn_scale, bn_shift, stats);
 }
 
-template <int C, int NT, int HT, bool T2D, bool STATS>
+template <typename T, int C, int NT, int HT, bool T2D, bool STATS>
 __global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2))) void ly_mlpblock_fwd_ring_kernel(
-    const float* __restrict__ x, float* __restrict__ y, long M, int H, int W,
+    const T* __restrict__ x, T* __restrict__ y, long M, int H, int W,
     const uint4* __restrict__ wp, const uint4* __restrict__ w1, const uint4* __restrict__ w2,
-    const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, float* __restrict__ stats, const int dbg) {
-  ly_mlpblock_body<C, NT, HT, T2D, STATS, 8>(x, y, M, H, W, wp, w1, w2, bn_scale, bn_shift, stats, dbg);
+    const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, float* __restrict__ stats) {
+  ly_mlpblock_body<T, C, NT, HT, T2D, STATS, 8>(x, y, M, H, W, wp, w1, w2, bn_scale, bn_shift, stats);
 }
 
-// The instantiations are split over three translation units (ly_mlpblock.hip: C = 16/24/40 + the C ABI, ly_mlpblock_b.hip:
-// C = 80/160, ly_mlpblock_c.hip: C = 320) only to keep the in-tree build short; the tuning switches live in ly_mlpblock.hip.
-extern int g_mlp_tile;      // tuning aid: 1 = force the flattened-run tiling, 2 / 4 / 8 = flattened with 2 / 4 / 1 pixel tiles per wave
-extern int g_mlp_dbg;       // ablation aid: 4 skip halo staging, 8 skip stores
-#define LY_MLP_ARGS const float* x, float* y, long M, int n_img, int H, int W, const void* wp, const void* w1, const void* w2, \
-                    const float* s, const float* b, float* stats, hipStream_t st
+// The instantiations are split over translation units (ly_mlpblock.hip: C = 16/24/40 + the C ABI, ly_mlpblock_b.hip:
+// C = 80/160, ly_mlpblock_c.hip: C = 320) only to keep the in-tree build short.
+#define LY_MLP_ARGS const void* x, void* y, long M, int n_img, int H, int W, const void* wp, const void* w1, const void* w2, \
+                    const float* s, const float* b, float* stats, int dtype, hipStream_t st
 int ly_mlp_dispatch_80(LY_MLP_ARGS);
 int ly_mlp_dispatch_160(LY_MLP_ARGS);
 int ly_mlp_dispatch_320(LY_MLP_ARGS);
 
-template <int C, int NT, int HT, bool T2D, bool STATS, bool RING>
-static int launch_mlp_k(const float* x, float* y, long M, int n_img, int H, int W, const void* wp, const void* w1, const void* w2,
-                      const float* s, const float* b, float* stats, hipStream_t st) {
+template <typename T, int C, int NT, int HT, bool T2D, bool STATS, bool RING>
+static int launch_mlp_k(const T* x, T* y, long M, int n_img, int H, int W, const void* wp, const void* w1, const void* w2,
+                        const float* s, const float* b, float* stats, hipStream_t st) {
   using Gm = MlpGeom<C>;
   constexpr int BP = 64 * NT;
   const long halo = T2D ? (4 * NT + 2) * 18 : BP + 2 * W + 2;
-  size_t lds = 2 * ((size_t)BP * Gm::RS + (size_t)halo * Gm::RSP);
+  size_t lds = LyT<T>::PL * ((size_t)BP * Gm::RS + (size_t)halo * Gm::RSP);
   LY_CHECK(lds <= 160 * 1024, "mlpblock: tile needs %zu B of LDS (C=%d W=%d)", lds, C, W);
-  void (*k)(const float*, float*, long, int, int, const uint4*, const uint4*, const uint4*, const float*, const float*, float*, int);
-  if constexpr (RING) k = ly_mlpblock_fwd_ring_kernel<C, NT, HT, T2D, STATS>;
-  else if constexpr (C <= 24 && T2D) k = ly_mlpblock_fwd_occ4_kernel<C, NT, HT, T2D, STATS>;
-  else k = ly_mlpblock_fwd_kernel<C, NT, HT, T2D, STATS>;
+  void (*k)(const T*, T*, long, int, int, const uint4*, const uint4*, const uint4*, const float*, const float*, float*);
+  if constexpr (RING) k = ly_mlpblock_fwd_ring_kernel<T, C, NT, HT, T2D, STATS>;
+  else if constexpr (C <= 24 && T2D) k = ly_mlpblock_fwd_occ4_kernel<T, C, NT, HT, T2D, STATS>;
+  else k = ly_mlpblock_fwd_kernel<T, C, NT, HT, T2D, STATS>;
   static bool configured = false;
   if (!configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
@@ -406,40 +415,43 @@ static int launch_mlp_k(const float* x, float* y, long M, int n_img, int H, int 
   }
   long blocks = T2D ? (long)n_img * ((H + 4 * NT - 1) / (4 * NT)) * (W / 16) : (M + BP - 1) / BP;
   hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(LY_THREADS), lds, st, x, y, M, H, W, reinterpret_cast<const uint4*>(wp),
-                     reinterpret_cast<const uint4*>(w1), reinterpret_cast<const uint4*>(w2), s, b, stats, g_mlp_dbg);
+                     reinterpret_cast<const uint4*>(w1), reinterpret_cast<const uint4*>(w2), s, b, stats);
   LY_LAUNCH_CHECK();
   return 0;
 }
 
-template <int C, int NT, int HT, bool T2D>
-static int launch_mlp(const float* x, float* y, long M, int n_img, int H, int W, const void* wp, const void* w1, const void* w2,
+template <typename T, int C, int NT, int HT, bool T2D>
+static int launch_mlp(const T* x, T* y, long M, int n_img, int H, int W, const void* wp, const void* w1, const void* w2,
                       const float* s, const float* b, float* stats, hipStream_t st) {
   constexpr bool RING = C >= 80;
-  if (stats) return launch_mlp_k<C, NT, HT, T2D, true, RING>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
-  return launch_mlp_k<C, NT, HT, T2D, false, RING>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
+  if (stats) return launch_mlp_k<T, C, NT, HT, T2D, true, RING>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
+  return launch_mlp_k<T, C, NT, HT, T2D, false, RING>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
 }
 
-// Tiling policy (tools/mlp_ablate.py, kernel time at bs=32 / 64):
+// Tiling policy (kernel time at bs=32 / 64):
 //  * C < 80 (wide maps, few weights; HBM-heavy): 2-D patches (8 x 16 px per block: small halo, 4+ co-resident blocks per CU)
 //    where the map is wide and a multiple of 16; flattened runs otherwise, with as many pixel tiles per wave as still fill
 //    the chip.  No fragment ring: it costs the co-residency these stages live on (C=24: 64 -> 69 us with it).
 //  * C >= 80 (small maps, 134-470 KB of weights per block; bound by streaming the fragments from L2): ring kernel, and two
 //    pixel tiles per wave -- half the fragment traffic per pixel -- as soon as that still leaves >= 200 blocks
 //    (C=80 @ 40x40x32: 26.5 -> 20.7 us; C=160 @ 20x20: 22.6 us with one tile at bs=32, 38.4 -> 28.8 us with two at bs=64).
-template <int C, int HT, int NTMAX>
-static int dispatch_nt(const float* x, float* y, long M, int n_img, int H, int W, const void* wp, const void* w1, const void* w2,
-                       const float* s, const float* b, float* stats, hipStream_t st) {
+template <typename T, int C, int HT, int NTMAX>
+static int dispatch_nt_t(const T* x, T* y, long M, int n_img, int H, int W, const void* wp, const void* w1, const void* w2,
+                         const float* s, const float* b, float* stats, hipStream_t st) {
   constexpr int NT2 = NTMAX >= 2 ? 2 : NTMAX, NT4 = NTMAX >= 4 ? 4 : NTMAX;
-  if (g_mlp_tile == 4) return launch_mlp<C, NT4, HT, false>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
-  if (g_mlp_tile == 2) return launch_mlp<C, NT2, HT, false>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
-  if (g_mlp_tile == 8) return launch_mlp<C, 1, HT, false>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
   if (C >= 80) {
-    if (NTMAX >= 2 && M >= 200L * 128) return launch_mlp<C, NT2, HT, false>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
-    return launch_mlp<C, 1, HT, false>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
+    if (NTMAX >= 2 && M >= 200L * 128) return launch_mlp<T, C, NT2, HT, false>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
+    return launch_mlp<T, C, 1, HT, false>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
   }
-  if ((W & 15) == 0 && W >= 64 && NTMAX >= 2 && g_mlp_tile == 0) return launch_mlp<C, 2, HT, true>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
-  if (NTMAX >= 4 && M >= 256L * 1024) return launch_mlp<C, NT4, HT, false>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
-  if (NTMAX >= 2 && M >= 128L * 512) return launch_mlp<C, NT2, HT, false>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
-  return launch_mlp<C, 1, HT, false>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
+  if ((W & 15) == 0 && W >= 64 && NTMAX >= 2) return launch_mlp<T, C, 2, HT, true>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
+  if (NTMAX >= 4 && M >= 256L * 1024) return launch_mlp<T, C, NT4, HT, false>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
+  if (NTMAX >= 2 && M >= 128L * 512) return launch_mlp<T, C, NT2, HT, false>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
+  return launch_mlp<T, C, 1, HT, false>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
 }
 
+template <int C, int HT, int NTMAX>
+static int dispatch_nt(LY_MLP_ARGS) {
+  if (dtype == LY_BF16)
+    return dispatch_nt_t<__bf16, C, HT, NTMAX>(reinterpret_cast<const __bf16*>(x), reinterpret_cast<__bf16*>(y), M, n_img, H, W, wp, w1, w2, s, b, stats, st);
+  return dispatch_nt_t<float, C, HT, NTMAX>(reinterpret_cast<const float*>(x), reinterpret_cast<float*>(y), M, n_img, H, W, wp, w1, w2, s, b, stats, st);
+}

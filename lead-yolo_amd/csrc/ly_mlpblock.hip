@@ -1,26 +1,23 @@
 // MLPBlock C ABI + the C = 16 / 24 / 40 instantiations; the kernel itself is in ly_mlpblock.cuh.
 #include "ly_mlpblock.cuh"
 
-int g_mlp_tile = 0;
-extern "C" int ly_debug_set_mlp_tile(int v) { g_mlp_tile = v; return 0; }
-int g_mlp_dbg = 0;
-extern "C" int ly_debug_set_mlp(int v) { g_mlp_dbg = v; return 0; }
-
-extern "C" int ly_mlpblock_fwd(const float* x, float* y, int n_img, int H, int W, int C, const void* wp, const void* w1,
-                               const void* w2, const float* bn_scale, const float* bn_shift, float* stats, void* stream) {
+extern "C" int ly_mlpblock_fwd(const void* x, void* y, int n_img, int H, int W, int C, const void* wp, const void* w1,
+                               const void* w2, const float* bn_scale, const float* bn_shift, float* stats, int dtype, void* stream) {
+  LY_CHECK(dtype == LY_F32 || dtype == LY_BF16, "mlpblock: unknown dtype %d", dtype);
   LY_CHECK(x && wp && w1 && w2 && (stats || (y && bn_scale && bn_shift)), "mlpblock: null pointer");
   LY_CHECK(x != y, "mlpblock: in-place call is not supported (neighbouring tiles read halo rows)");
   LY_CHECK(n_img > 0 && H > 0 && W > 0, "mlpblock: bad shape %d x %d x %d", n_img, H, W);
+  LY_CHECK(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, "mlpblock: x / y must be 16-byte aligned");
   long M = (long)n_img * H * W;
   LY_CHECK(M < (1L << 24), "mlpblock: M=%ld pixels exceeds the 2^24 limit of the fast index path", M);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   switch (C) {
-    case 16:  return dispatch_nt<16, 2, 4>(x, y, M, n_img, H, W, wp, w1, w2, bn_scale, bn_shift, stats, st);
-    case 24:  return dispatch_nt<24, 4, 4>(x, y, M, n_img, H, W, wp, w1, w2, bn_scale, bn_shift, stats, st);
-    case 40:  return dispatch_nt<40, 2, 4>(x, y, M, n_img, H, W, wp, w1, w2, bn_scale, bn_shift, stats, st);
-    case 80:  return ly_mlp_dispatch_80(x, y, M, n_img, H, W, wp, w1, w2, bn_scale, bn_shift, stats, st);
-    case 160: return ly_mlp_dispatch_160(x, y, M, n_img, H, W, wp, w1, w2, bn_scale, bn_shift, stats, st);
-    case 320: return ly_mlp_dispatch_320(x, y, M, n_img, H, W, wp, w1, w2, bn_scale, bn_shift, stats, st);
+    case 16:  return dispatch_nt<16, 2, 4>(x, y, M, n_img, H, W, wp, w1, w2, bn_scale, bn_shift, stats, dtype, st);
+    case 24:  return dispatch_nt<24, 4, 4>(x, y, M, n_img, H, W, wp, w1, w2, bn_scale, bn_shift, stats, dtype, st);
+    case 40:  return dispatch_nt<40, 2, 4>(x, y, M, n_img, H, W, wp, w1, w2, bn_scale, bn_shift, stats, dtype, st);
+    case 80:  return ly_mlp_dispatch_80(x, y, M, n_img, H, W, wp, w1, w2, bn_scale, bn_shift, stats, dtype, st);
+    case 160: return ly_mlp_dispatch_160(x, y, M, n_img, H, W, wp, w1, w2, bn_scale, bn_shift, stats, dtype, st);
+    case 320: return ly_mlp_dispatch_320(x, y, M, n_img, H, W, wp, w1, w2, bn_scale, bn_shift, stats, dtype, st);
     default:
       ly_set_error("mlpblock: unsupported channel count C=%d (built for 16/24/40/80/160/320)", C);
       return -1;

@@ -1,3 +1,3 @@
 // MLPBlock instantiations for C = 320 (see ly_mlpblock.cuh)
 #include "ly_mlpblock.cuh"
-int ly_mlp_dispatch_320(LY_MLP_ARGS) { return dispatch_nt<320, 4, 1>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st); }
+int ly_mlp_dispatch_320(LY_MLP_ARGS) { return dispatch_nt<320, 4, 1>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, dtype, st); }

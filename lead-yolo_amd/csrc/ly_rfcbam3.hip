@@ -1,4 +1,5 @@
-// RFCBAMConv main contraction for kernel_size 3 (reference models/rfa.py:113-129), fp32, gfx950.
+// RFCBAMConv main contraction for kernel_size 3 (reference models/rfa.py:113-129), gfx950; storage dtype T = float / __bf16
+// (x and out; the regenerate phase is fp32 VALU work in both, the contraction bf16x3 or plain bf16: ly_tile.cuh).
 //
 //   out[n, o, oy, ox] = relu( bn( bias[o] + sum_{c, t} Wc[o, c, t] * G[n, c, 3oy+ty, 3ox+tx] * ca[n, c] * rfa[n, 3oy+ty, 3ox+tx] ) )
 //   G[n, c, 3oy+ty, 3ox+tx] = relu( bn_{c*9+t}( sum_u Wd[c*9+t, u] * x[n, c, s*oy+uy-1, s*ox+ux-1] ) )
@@ -21,14 +22,19 @@
 // SW: the folded generate weights come through the scalar cache (SGPR operands) instead of LDS broadcasts; see the regenerate
 // step.  Every chunk's weights are read once per block, so each tap waits for a scalar-cache miss that only a second resident
 // wave can hide; the launcher's rule is in launch_rf3.
-template <int MT, bool SW>
-__device__ __forceinline__ void ly_rfcbam3_body(const LyRfcbam3Params& P, const int gy, const int nct, const int nrt, const int dbg) {
+template <typename T, int MT, bool SW>
+__device__ __forceinline__ void ly_rfcbam3_body(const LyRfcbam3Params& P, const int gy, const int nct, const int nrt) {
+  using TR = LyT<T>;
+  using R4 = typename TR::R4;
+  constexpr int PL = TR::PL;
+  const T* const x = reinterpret_cast<const T*>(P.x);
+  T* const out = reinterpret_cast<T*>(P.out);
   extern __shared__ f32x4 ly_smem4[];
   const int s = P.s, TH = P.TH, TW = P.TW;
   const int IH = s * (TH - 1) + 3, IW = s * (TW - 1) + 3;
   char* gs_hi = reinterpret_cast<char*>(ly_smem4);          // [64][LY_RSG]
-  char* gs_lo = gs_hi + 64 * LY_RSG;
-  float* wsm = reinterpret_cast<float*>(gs_lo + 64 * LY_RSG);  // !SW: [4 waves][LY_RF3_WF] this chunk's folded generate weights
+  char* gs_lo = gs_hi + (PL - 1) * 64 * LY_RSG;
+  float* wsm = reinterpret_cast<float*>(gs_hi + PL * 64 * LY_RSG);  // !SW: [4 waves][LY_RF3_WF] this chunk's folded generate weights
   float* xs = wsm + (SW ? 0 : 4 * LY_RF3_WF);                  // [IH*IW][LY_GCC + 1]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: depthwise weights become scalar loads
@@ -45,7 +51,7 @@ __device__ __forceinline__ void ly_rfcbam3_body(const LyRfcbam3Params& P, const 
   const int iy0 = s * oy0 - 1, ix0 = s * ox0 - 1;
   const f32x4 zero = ly_zero4();
   const int S = (P.C / LY_GCC) * (LY_GK / 32);
-  const int T = (P.N + 15) >> 4;
+  const int Tt = (P.N + 15) >> 4;
 
   float rf[9];
 #pragma unroll
@@ -61,11 +67,11 @@ __device__ __forceinline__ void ly_rfcbam3_body(const LyRfcbam3Params& P, const 
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
     int tt = (by * 4 + wave) * MT + t;
-    tile[t] = tt < T ? tt : T - 1;
+    tile[t] = tt < Tt ? tt : Tt - 1;
   }
   const uint4* wpk = reinterpret_cast<const uint4*>(P.wp);
-  ly_l2_warm(P.wp, (long)T * S * 2048, P.stats ? P.stats : P.out);
-  for (int i = tid; i < 2 * 64 * LY_RSG / 16; i += LY_THREADS) reinterpret_cast<uint4*>(gs_hi)[i] = make_uint4(0u, 0u, 0u, 0u);
+  ly_l2_warm(P.wp, (long)Tt * S * PL * 1024, P.stats ? P.stats : reinterpret_cast<float*>(P.out));
+  for (int i = tid; i < PL * 64 * LY_RSG / 16; i += LY_THREADS) reinterpret_cast<uint4*>(gs_hi)[i] = make_uint4(0u, 0u, 0u, 0u);
 
   // staging plan of this thread (independent of the channel chunk): global element offset (or -1), LDS slot
   const int items = IH * IW * (LY_GCC / 4);
@@ -88,10 +94,10 @@ __device__ __forceinline__ void ly_rfcbam3_body(const LyRfcbam3Params& P, const 
   // Everything a chunk reads from global memory is requested one chunk ahead, so no wave ever waits on a load it has just
   // issued: the raw input tile (pv) and the conv weight fragments (ring: D fragments in
   // flight, slot q % D refilled with fragment q + D -- which may belong to the next chunk -- right after fragment q's MFMAs).
-  f32x4 pv[LY_RF3_NV];
+  R4 pv[LY_RF3_NV];
   auto prefetch = [&](int c0) {
 #pragma unroll
-    for (int e = 0; e < LY_RF3_NV; ++e) pv[e] = ly_ldg4(soff[e] >= 0 ? P.x + soff[e] + c0 : P.x);
+    for (int e = 0; e < LY_RF3_NV; ++e) pv[e] = ly_ldr4<T>(soff[e] >= 0 ? x + soff[e] + c0 : x);
   };
   constexpr int WV = SW ? 1 : (4 * LY_RF3_WF / 4 + LY_THREADS - 1) / LY_THREADS;
   f32x4 wv[WV];
@@ -107,8 +113,8 @@ __device__ __forceinline__ void ly_rfcbam3_body(const LyRfcbam3Params& P, const 
   };
   constexpr int D = 5, NF = (LY_GK / 32) * MT;           // ring depth, fragments per chunk (k-step major); NF % D == 0
   static_assert(NF % D == 0, "the ring slot of a fragment must not depend on the chunk");
-  LyWFrag ring[D];
-  auto wfrag_at = [&](int sb, int q) -> LyWFrag { return ly_wfrag(wpk, (long)tile[q % MT] * S + sb + q / MT, lane); };
+  LyWF<PL> ring[D];
+  auto wfrag_at = [&](int sb, int q) -> LyWF<PL> { return ly_wfragp<PL>(wpk, (long)tile[q % MT] * S + sb + q / MT, lane); };
 #pragma unroll
   for (int q = 0; q < D; ++q) ring[q] = wfrag_at(0, q);
   wprefetch(0);
@@ -125,15 +131,14 @@ __device__ __forceinline__ void ly_rfcbam3_body(const LyRfcbam3Params& P, const 
       }
       wprefetch(more ? c0 / LY_GCC + 1 : 0);
     }
-    if (!(dbg & 4)) {
 #pragma unroll
-      for (int e = 0; e < LY_RF3_NV; ++e)
-        if (doff[e] >= 0) {
-          const bool ok = soff[e] >= 0;
-          float* d = xs + doff[e];
-          d[0] = ok ? pv[e][0] : 0.f; d[1] = ok ? pv[e][1] : 0.f; d[2] = ok ? pv[e][2] : 0.f; d[3] = ok ? pv[e][3] : 0.f;
-        }
-    }
+    for (int e = 0; e < LY_RF3_NV; ++e)
+      if (doff[e] >= 0) {
+        const bool ok = soff[e] >= 0;
+        const f32x4 pf = ly_r4_f32(pv[e]);
+        float* d = xs + doff[e];
+        d[0] = ok ? pf[0] : 0.f; d[1] = ok ? pf[1] : 0.f; d[2] = ok ? pf[2] : 0.f; d[3] = ok ? pf[3] : 0.f;
+      }
     prefetch(more ? c0 + LY_GCC : 0);    // next chunk's input in flight during generate + MFMA; unconditional (the last chunk
                                          // re-requests chunk 0) so that the compiler's s_waitcnt counts stay exact
     __syncthreads();
@@ -144,7 +149,7 @@ __device__ __forceinline__ void ly_rfcbam3_body(const LyRfcbam3Params& P, const 
     // waves and also carrying the G' writes and the MFMA operand reads -- is what this kernel is bound by, so: the two pairs
     // run as two independent accumulation chains (no dependent-issue bubbles), and a lane's 4 channels of one tap are adjacent
     // in k (k = t*16 + channel), so G' is written with one 8-byte store per plane and tap instead of four 2-byte ones.
-    if (!(dbg & 1)) {
+    {
       f32x2 xv[2][9];
       f32x2 cav[2];
 #pragma unroll
@@ -189,11 +194,7 @@ __device__ __forceinline__ void ly_rfcbam3_body(const LyRfcbam3Params& P, const 
         const float rft = active ? rf[t] : 0.f;
         const f32x2 g0 = (f32x2){fmaxf(a0[0], 0.f), fmaxf(a0[1], 0.f)} * cav[0] * rft;
         const f32x2 g1 = (f32x2){fmaxf(a1[0], 0.f), fmaxf(a1[1], 0.f)} * cav[1] * rft;
-        bf16x4 gh, gl;
-        ly_split4((f32x4){g0[0], g0[1], g1[0], g1[1]}, gh, gl);
-        const int kb = lane * LY_RSG + 2 * (t * LY_GCC + 4 * wave);       // k = t*16 + (4*wave + j)
-        *reinterpret_cast<bf16x4*>(gs_hi + kb) = gh;
-        *reinterpret_cast<bf16x4*>(gs_lo + kb) = gl;
+        ly_lds_put_f32<PL>(gs_hi, gs_lo, lane * LY_RSG, t * LY_GCC + 4 * wave, (f32x4){g0[0], g0[1], g1[0], g1[1]});   // k = t*16 + (4*wave + j)
       }
     }
     __syncthreads();
@@ -205,14 +206,15 @@ __device__ __forceinline__ void ly_rfcbam3_body(const LyRfcbam3Params& P, const 
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         xh[j] = ly_lds_frag(gs_hi, (16 * j + li) * LY_RSG, st, lq);
-        xl[j] = ly_lds_frag(gs_lo, (16 * j + li) * LY_RSG, st, lq);
+        if constexpr (PL == 2) xl[j] = ly_lds_frag(gs_lo, (16 * j + li) * LY_RSG, st, lq);
+        else xl[j] = xh[j];
       }
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
         const int q = st * MT + t;
-        const LyWFrag wf = ring[q % D];
+        const LyWF<PL> wf = ring[q % D];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[t][j] = ly_mfma3(wf.hi, wf.lo, xh[j], xl[j], acc[t][j]);
+        for (int j = 0; j < 4; ++j) acc[t][j] = ly_mfmap<PL>(wf, xh[j], xl[j], acc[t][j]);
         // (the last chunk re-requests chunk 0's fragments instead of branching: a conditional load would make every later
         //  s_waitcnt assume it was not issued and wait for the loads behind it as well)
         ring[q % D] = q + D < NF ? wfrag_at(sbase, q + D) : wfrag_at(more ? sbase + LY_GK / 32 : 0, q + D - NF);
@@ -225,7 +227,7 @@ __device__ __forceinline__ void ly_rfcbam3_body(const LyRfcbam3Params& P, const 
   for (int t = 0; t < MT; ++t) {
     const int tt = (by * 4 + wave) * MT + t;
     const int c = 16 * tt + 4 * lq;
-    if (tt >= T || c >= P.N) continue;
+    if (tt >= Tt || c >= P.N) continue;
     float sc[4], sh[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -252,48 +254,39 @@ __device__ __forceinline__ void ly_rfcbam3_body(const LyRfcbam3Params& P, const 
       f32x4 v;
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[t][j][r] * sc[r] + sh[r], lin_floor);
-      float* o = P.out + (((long)n * P.Ho + yy) * P.Wo + xx) * P.ldo + c;
+      T* o = out + (((long)n * P.Ho + yy) * P.Wo + xx) * P.ldo + c;
       if ((P.ldo & 3) == 0 && c + 3 < P.N) {
-        ly_stg4(o, v);
+        ly_st4<T>(o, v);
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (c + r < P.N) o[r] = v[r];
+          if (c + r < P.N) ly_st1<T>(o + r, v[r]);
       }
     }
     if (P.stats) ly_stats_flush(P.stats, P.N, c, s1, s2);
   }
 }
 
-template <int MT>
-__global__ __launch_bounds__(LY_THREADS) void ly_rfcbam3_kernel(const LyRfcbam3Params P, const int gy, const int nct, const int nrt, const int dbg) {
-  ly_rfcbam3_body<MT, false>(P, gy, nct, nrt, dbg);
+template <typename T, int MT>
+__global__ __launch_bounds__(LY_THREADS) void ly_rfcbam3_kernel(const LyRfcbam3Params P, const int gy, const int nct, const int nrt) {
+  ly_rfcbam3_body<T, MT, false>(P, gy, nct, nrt);
 }
-template <int MT>
-__global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void ly_rfcbam3_sw_kernel(const LyRfcbam3Params P, const int gy, const int nct, const int nrt, const int dbg) {
-  ly_rfcbam3_body<MT, true>(P, gy, nct, nrt, dbg);
+template <typename T, int MT>
+__global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void ly_rfcbam3_sw_kernel(const LyRfcbam3Params P, const int gy, const int nct, const int nrt) {
+  ly_rfcbam3_body<T, MT, true>(P, gy, nct, nrt);
 }
 
-static int g_rf3_dbg = 0;   // ablation aid: 1 skip regenerate, 2 generate weights through LDS regardless of the grid, 4 skip the LDS staging writes
-static int g_rf3_mt2 = 0;   // (bit 3 of ly_debug_set_rf3) run N > 128 as two 128-channel groups (MT=2, two waves per SIMD) instead of the
-                            // 256-channel MT=4 tile (296 registers, one wave per SIMD).  With the loads prefetched the regenerate phase
-                            // is what the kernel waits for, and MT=4 runs it once per pixel tile instead of twice: 256->256 @ 40x40x32
-                            // module 191 -> 159 us
-                            // (an isolated 8-image call is the one case that loses: 139 -> 154 us; four such calls on concurrent streams,
-                            // the serving mode, gain: 19.06k -> 19.55k images/s)
-extern "C" int ly_debug_set_rf3(int v) { g_rf3_dbg = v & 7; g_rf3_mt2 = (v >> 3) & 1; return 0; }
-
-template <int MT, bool SW>
+template <typename T, int MT, bool SW>
 static int launch_rf3_k(const LyRfcbam3Params& P, hipStream_t st) {
   const int nct = (P.Wo + P.TW - 1) / P.TW, nrt = (P.Ho + P.TH - 1) / P.TH;
   const int gy = (P.N + 64 * MT - 1) / (64 * MT);
   const int IH = P.s * (P.TH - 1) + 3, IW = P.s * (P.TW - 1) + 3;
-  size_t lds = 2 * (size_t)64 * LY_RSG + sizeof(float) * ((size_t)(SW ? 0 : 4 * LY_RF3_WF) + (size_t)IH * IW * (LY_GCC + 1));
+  size_t lds = LyT<T>::PL * (size_t)64 * LY_RSG + sizeof(float) * ((size_t)(SW ? 0 : 4 * LY_RF3_WF) + (size_t)IH * IW * (LY_GCC + 1));
   LY_CHECK(lds <= 160 * 1024, "rfcbam3: tile needs %zu B LDS", lds);
   LY_CHECK(IH * IW * (LY_GCC / 4) <= LY_RF3_NV * LY_THREADS, "rfcbam3: input tile %dx%d exceeds the staging capacity", IH, IW);
-  void (*k)(const LyRfcbam3Params, int, int, int, int);
-  if constexpr (SW) k = ly_rfcbam3_sw_kernel<MT>;
-  else k = ly_rfcbam3_kernel<MT>;
+  void (*k)(const LyRfcbam3Params, int, int, int);
+  if constexpr (SW) k = ly_rfcbam3_sw_kernel<T, MT>;
+  else k = ly_rfcbam3_kernel<T, MT>;
   static bool configured = false;
   if (!configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -302,33 +295,41 @@ static int launch_rf3_k(const LyRfcbam3Params& P, hipStream_t st) {
   }
   long nb = (long)P.n_img * nrt * nct * gy;
   LY_CHECK(nb < (1L << 31), "rfcbam3: grid too large");
-  hipLaunchKernelGGL(k, dim3((unsigned)nb), dim3(LY_THREADS), lds, st, P, gy, nct, nrt, g_rf3_dbg);
+  hipLaunchKernelGGL(k, dim3((unsigned)nb), dim3(LY_THREADS), lds, st, P, gy, nct, nrt);
   LY_LAUNCH_CHECK();
   return 0;
 }
 
-template <int MT>
+template <typename T, int MT>
 static int launch_rf3(const LyRfcbam3Params& P, hipStream_t st) {
   const long nb = (long)P.n_img * ((P.Wo + P.TW - 1) / P.TW) * ((P.Ho + P.TH - 1) / P.TH) * ((P.N + 64 * MT - 1) / (64 * MT));
-  // Measured (tools/rf3_ablate.py): at equal occupancy the LDS path is never slower (128->128 @ 80x80x64: 347 vs 387 us).  The
+  // Measured: at equal occupancy the LDS path for the generate weights is never slower (128->128 @ 80x80x64: 347 vs 387 us).  The
   // scalar path's one advantage is registers: the MT=4 tile fits two waves per SIMD only with it (245 vs 316), which pays
   // once the grid has more than one block per CU (256->256 @ 40x40x64: 244 vs 292 us; at x32, 224 blocks: 180 vs 156 us).
   if constexpr (MT == 4) {
-    if (nb > 256 && !(g_rf3_dbg & 2)) return launch_rf3_k<MT, true>(P, st);
+    if (nb > 256) return launch_rf3_k<T, MT, true>(P, st);
   }
-  return launch_rf3_k<MT, false>(P, st);
+  return launch_rf3_k<T, MT, false>(P, st);
+}
+
+// N > 128 runs as ONE 256-channel tile (MT = 4): with the loads prefetched the regenerate phase is what the kernel waits for, and
+// the wide tile runs it once per pixel tile instead of twice (256->256 @ 40x40x32: module 191 -> 159 us)
+template <typename T>
+static int rf3_dispatch(const LyRfcbam3Params& P, hipStream_t st) {
+  if (P.N > 128) return launch_rf3<T, 4>(P, st);
+  if (P.N > 64) return launch_rf3<T, 2>(P, st);
+  return launch_rf3<T, 1>(P, st);
 }
 
 extern "C" int ly_rfcbam3_fwd(const LyRfcbam3Params* p, void* stream) {
   LY_CHECK(p, "rfcbam3: null params");
   const LyRfcbam3Params& P = *p;
+  LY_CHECK(P.dtype == LY_F32 || P.dtype == LY_BF16, "rfcbam3: unknown dtype %d", P.dtype);
   LY_CHECK(P.x && P.wg && P.ca && P.rfa && P.wp && P.e_scale && P.e_shift && (P.out || P.stats), "rfcbam3: null pointer");
-  LY_CHECK((P.C & 15) == 0 && (P.ldx & 3) == 0, "rfcbam3: C=%d must be a multiple of 16", P.C);
+  LY_CHECK((P.C & 15) == 0 && (P.ldx & 3) == 0 && ((uintptr_t)P.x & 15) == 0, "rfcbam3: C=%d must be a multiple of 16", P.C);
   LY_CHECK(P.s >= 1 && P.TH >= 1 && P.TW >= 1 && P.TH * P.TW <= 64, "rfcbam3: bad tile %dx%d", P.TH, P.TW);
   LY_CHECK((long)P.n_img * P.H * P.W * P.ldx < (1L << 31), "rfcbam3: input of %ld elements exceeds the 31-bit offsets of the staging plan", (long)P.n_img * P.H * P.W * P.ldx);
   LY_CHECK(P.Ho == (P.H + 2 - 3) / P.s + 1 && P.Wo == (P.W + 2 - 3) / P.s + 1, "rfcbam3: inconsistent output size");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (P.N > 128 && !g_rf3_mt2) return launch_rf3<4>(P, st);
-  if (P.N > 64) return launch_rf3<2>(P, st);
-  return launch_rf3<1>(P, st);
+  return P.dtype == LY_BF16 ? rf3_dispatch<__bf16>(P, st) : rf3_dispatch<float>(P, st);
 }

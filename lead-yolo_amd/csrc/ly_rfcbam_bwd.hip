@@ -1,4 +1,5 @@
-// RFCBAMConv backward (reference models/rfa.py:113-129 under autograd), fp32, gfx950.
+// RFCBAMConv backward (reference models/rfa.py:113-129 under autograd), gfx950; the expanded tensors, x and dx are T = float /
+// __bf16 (bf16 halves the 9x streams), the maps, per-channel vectors and weight gradients fp32.
 //
 // Forward recap (k = kernel_size, KK = k*k, stride s, pad k/2; m = output pixel (n, ho, wo), t = tap):
 //   ug[m][t][c] = sum_u wg[c*KK + t][u] * x_u(m)[c]                 depthwise `generate` conv (x_u = the KK input taps)
@@ -21,7 +22,7 @@
 // Thread = channel: a block covers CB = roundup64(min(C, 256)) channels x (256 / CB) pixels at a time, so the lanes
 // of a wave are 64 consecutive channels of ONE pixel: per-pixel reductions over channels are wave shuffles, and
 // per-channel sums over pixels stay in registers until one atomic flush at the end.
-#include "ly_common.cuh"
+#include "ly_tile.cuh"
 #include "ly_params.h"
 
 struct RfGeom {
@@ -62,15 +63,15 @@ __device__ __forceinline__ float rf_wave_max(float v) {
 }
 
 // loads the KK input taps of output pixel (n, ho, wo) for channel c (zero padded)
-template <int K>
-__device__ __forceinline__ void rf_taps(const float* __restrict__ x, int ldx, const RfGeom& g, int n, int ho, int wo, int c, float (&xt)[K * K]) {
+template <typename T, int K>
+__device__ __forceinline__ void rf_taps(const T* __restrict__ x, int ldx, const RfGeom& g, int n, int ho, int wo, int c, float (&xt)[K * K]) {
 #pragma unroll
   for (int uy = 0; uy < K; ++uy)
 #pragma unroll
     for (int ux = 0; ux < K; ++ux) {
       const int hi = ho * g.s + uy - g.pad, wi = wo * g.s + ux - g.pad;
       const bool ok = hi >= 0 && hi < g.H && wi >= 0 && wi < g.W;
-      const float v = x[ok ? (((long)n * g.H + hi) * g.W + wi) * ldx + c : c];
+      const float v = ly_ld1<T>(x + (ok ? (((long)n * g.H + hi) * g.W + wi) * ldx + c : c));
       xt[uy * K + ux] = ok ? v : 0.f;
     }
 }
@@ -100,9 +101,9 @@ __device__ __forceinline__ long rf_pos(const RfGeom& g, int n, int ho, int wo, i
   const long m_end_ = m_begin + g.chunk;
 
 // ---- ug ------------------------------------------------------------------------------------------
-template <int K>
-__global__ __launch_bounds__(LY_THREADS) void ly_rf_generate_kernel(const RfGeom g, const float* __restrict__ x, int ldx,
-                                                                    const float* __restrict__ wg, float* __restrict__ ug) {
+template <typename T, int K>
+__global__ __launch_bounds__(LY_THREADS) void ly_rf_generate_kernel(const RfGeom g, const T* __restrict__ x, int ldx,
+                                                                    const float* __restrict__ wg, T* __restrict__ ug) {
   constexpr int KK = K * K;
   RF_THREAD_SETUP
   const long m_end = m_end_ < g.Mo ? m_end_ : g.Mo;
@@ -113,24 +114,24 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf_generate_kernel(const RfGeom
     int n, ho, wo;
     rf_pix(g, m, n, ho, wo);
     float xt[KK];
-    rf_taps<K>(x, ldx, g, n, ho, wo, c, xt);
+    rf_taps<T, K>(x, ldx, g, n, ho, wo, c, xt);
     if (!cok) continue;
 #pragma unroll
     for (int t = 0; t < KK; ++t) {
       float a = 0.f;
 #pragma unroll
       for (int u = 0; u < KK; ++u) a += w[t * KK + u] * xt[u];
-      ug[(m * KK + t) * g.C + c] = a;
+      ly_st1<T>(ug + (m * KK + t) * g.C + c, a);
     }
   }
 }
 
 // ---- cd, d_rfa, gmax, d_ca -----------------------------------------------------------------------
-template <int K>
-__global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_attn_kernel(const RfGeom g, const float* __restrict__ ug, const float* __restrict__ dcd,
+template <typename T, int K>
+__global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_attn_kernel(const RfGeom g, const T* __restrict__ ug, const T* __restrict__ dcd,
                                                                     const float* __restrict__ ag, const float* __restrict__ bg,
                                                                     const float* __restrict__ ca, const float* __restrict__ rfa,
-                                                                    float* __restrict__ cd, float* __restrict__ d_rfa, float* __restrict__ gmax,
+                                                                    T* __restrict__ cd, float* __restrict__ d_rfa, float* __restrict__ gmax,
                                                                     float* __restrict__ d_ca) {
   constexpr int KK = K * K;
   RF_THREAD_SETUP
@@ -157,8 +158,8 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_attn_kernel(const RfGeom
     for (int t = 0; t < KK; ++t) {
       const long idx = (m * KK + t) * g.C + c;
       pos[t] = rf_pos<K>(g, n, ho, wo, t);
-      uv[t] = ug[idx];
-      dv_[t] = dcd[idx];
+      uv[t] = ly_ld1<T>(ug + idx);
+      dv_[t] = ly_ld1<T>(dcd + idx);
       rv[t] = rfa[pos[t]];
     }
     float pr[KK], mx[KK];
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_attn_kernel(const RfGeom
       float G = fmaxf(__fmaf_rn(a[t], uv[t], b[t]), 0.f);
       float d = dv_[t];
       if (!cok) { G = 0.f; d = 0.f; }
-      if (cok) cd[idx] = G * cav * rv[t];
+      if (cok) ly_st1<T>(cd + idx, G * cav * rv[t]);
       dca += d * rv[t] * G;
       pr[t] = rf_wave_sum(d * G * cav);
       mx[t] = rf_wave_max(G);
@@ -231,8 +232,8 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfa_bwd_kernel(const float* __r
 }
 
 // ---- dv (over dcd) + BN sums ---------------------------------------------------------------------
-template <int K>
-__global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_relu_kernel(const RfGeom g, const float* __restrict__ ug, float* dcd,
+template <typename T, int K>
+__global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_relu_kernel(const RfGeom g, const T* __restrict__ ug, T* dcd,
                                                                     const float* __restrict__ ag, const float* __restrict__ bg,
                                                                     const float* __restrict__ ca, const float* __restrict__ rfa,
                                                                     const float* __restrict__ gmax, const float* __restrict__ d_mm,
@@ -257,8 +258,8 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_relu_kernel(const RfGeom
       for (int t = 0; t < KK; ++t) {
         const long idx = (m * KK + t) * g.C + c;
         pos[t] = rf_pos<K>(g, n, ho, wo, t);
-        u[t] = ug[idx];
-        dc[t] = dcd[idx];
+        u[t] = ly_ld1<T>(ug + idx);
+        dc[t] = ly_ld1<T>(dcd + idx);
         rv[t] = rfa[pos[t]];
         gm[t] = gmax[pos[t]];
         dm0[t] = d_mm[2 * pos[t]];
@@ -271,11 +272,11 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_relu_kernel(const RfGeom
         float dG = dc[t] * rv[t] * cav + dm1[t] * invC;
         if (G == gm[t]) dG += dm0[t];
         dvv[t] = G > 0.f ? dG : 0.f;
-        s1[t] += dvv[t];
+        s1[t] += dvv[t];                      // BatchNorm sums from the fp32 value (before it is rounded to T)
         s2[t] += dvv[t] * u[t];
       }
 #pragma unroll
-      for (int t = 0; t < KK; ++t) dcd[(m * KK + t) * g.C + c] = dvv[t];
+      for (int t = 0; t < KK; ++t) ly_st1<T>(dcd + (m * KK + t) * g.C + c, dvv[t]);
     }
   if (cok) {
     const int CK = g.C * KK;
@@ -288,9 +289,9 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_relu_kernel(const RfGeom
 }
 
 // ---- dug (over dv) + d(generate weight) ------------------------------------------------------------
-template <int K>
-__global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_gen_kernel(const RfGeom g, const float* __restrict__ x, int ldx, const float* __restrict__ ug,
-                                                                   float* dv, const float* __restrict__ alpha, const float* __restrict__ kappa,
+template <typename T, int K>
+__global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_gen_kernel(const RfGeom g, const T* __restrict__ x, int ldx, const T* __restrict__ ug,
+                                                                   T* dv, const float* __restrict__ alpha, const float* __restrict__ kappa,
                                                                    const float* __restrict__ lambda, float* __restrict__ dwg) {
   constexpr int KK = K * K;
   RF_THREAD_SETUP
@@ -305,13 +306,13 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_gen_kernel(const RfGeom 
       int n, ho, wo;
       rf_pix(g, m, n, ho, wo);
       float xt[KK];
-      rf_taps<K>(x, ldx, g, n, ho, wo, c, xt);
+      rf_taps<T, K>(x, ldx, g, n, ho, wo, c, xt);
       float dvl[KK], ugl[KK];              // loads first, in-place stores last (see ly_rf_bwd_relu_kernel)
 #pragma unroll
       for (int t = 0; t < KK; ++t) {
         const long idx = (m * KK + t) * g.C + c;
-        dvl[t] = dv[idx];
-        ugl[t] = ug[idx];
+        dvl[t] = ly_ld1<T>(dv + idx);
+        ugl[t] = ly_ld1<T>(ug + idx);
       }
 #pragma unroll
       for (int t = 0; t < KK; ++t) {
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_gen_kernel(const RfGeom 
         for (int u = 0; u < KK; ++u) acc[t * KK + u] += d * xt[u];
       }
 #pragma unroll
-      for (int t = 0; t < KK; ++t) dv[(m * KK + t) * g.C + c] = dvl[t];
+      for (int t = 0; t < KK; ++t) ly_st1<T>(dv + (m * KK + t) * g.C + c, dvl[t]);
     }
   if (cok) {
     // every (block, pixel sub-group) owns one row of the partial-sum matrix: plain stores, no atomics (81 accumulators per
@@ -337,8 +338,8 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_gen_kernel(const RfGeom 
 // parities PY = (hi+1)&1, PX = (wi+1)&1 -- uy in {0, 2} when hi+1 is even, uy = 1 otherwise -- so each parity class has a
 // compile-time tap list (4 / 2 / 2 / 1 output pixels).  All their 9-tap rows are requested before the first is used; edge
 // positions read row 0 and are masked.  (Tap by tap behind `continue`s, every row was its own memory round trip.)
-template <int PY, int PX>
-__device__ __forceinline__ float rf_dx_s2(const RfGeom& g, const float* __restrict__ dug, const float (&w)[81], int n, int hi, int wi, int c) {
+template <typename T, int PY, int PX>
+__device__ __forceinline__ float rf_dx_s2(const RfGeom& g, const T* __restrict__ dug, const float (&w)[81], int n, int hi, int wi, int c) {
   constexpr int NY = PY ? 1 : 2, NX = PX ? 1 : 2;
   float v[NY][NX][9];
   bool ok[NY][NX];
@@ -354,7 +355,7 @@ __device__ __forceinline__ float rf_dx_s2(const RfGeom& g, const float* __restri
       ok[jy][jx] = oky && ww >= 0 && wo < g.Wo;
       const long m = ok[jy][jx] ? ((long)n * g.Ho + ho) * g.Wo + wo : 0;
 #pragma unroll
-      for (int t = 0; t < 9; ++t) v[jy][jx][t] = dug[(m * 9 + t) * g.C + c];
+      for (int t = 0; t < 9; ++t) v[jy][jx][t] = ly_ld1<T>(dug + (m * 9 + t) * g.C + c);
     }
   }
   float acc = 0.f;
@@ -371,9 +372,9 @@ __device__ __forceinline__ float rf_dx_s2(const RfGeom& g, const float* __restri
   return acc;
 }
 
-template <int K>
-__global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_dx_kernel(const RfGeom g, const float* __restrict__ dug, const float* __restrict__ wg,
-                                                                  float* __restrict__ dx, int lddx) {
+template <typename T, int K>
+__global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_dx_kernel(const RfGeom g, const T* __restrict__ dug, const float* __restrict__ wg,
+                                                                  T* __restrict__ dx, int lddx) {
   constexpr int KK = K * K;
   RF_THREAD_SETUP
   const long Mi = (long)g.n_img * g.H * g.W;
@@ -391,11 +392,11 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_dx_kernel(const RfGeom g
     if constexpr (K == 3) {
       if (g.s == 2) {
         const int py = (hi + 1) & 1, px = (wi + 1) & 1;      // uniform over the wave (all lanes share the pixel)
-        if (py == 0 && px == 0) acc = rf_dx_s2<0, 0>(g, dug, w, n, hi, wi, c);
-        else if (py == 0) acc = rf_dx_s2<0, 1>(g, dug, w, n, hi, wi, c);
-        else if (px == 0) acc = rf_dx_s2<1, 0>(g, dug, w, n, hi, wi, c);
-        else acc = rf_dx_s2<1, 1>(g, dug, w, n, hi, wi, c);
-        dx[p * lddx + c] = acc;
+        if (py == 0 && px == 0) acc = rf_dx_s2<T, 0, 0>(g, dug, w, n, hi, wi, c);
+        else if (py == 0) acc = rf_dx_s2<T, 0, 1>(g, dug, w, n, hi, wi, c);
+        else if (px == 0) acc = rf_dx_s2<T, 1, 0>(g, dug, w, n, hi, wi, c);
+        else acc = rf_dx_s2<T, 1, 1>(g, dug, w, n, hi, wi, c);
+        ly_st1<T>(dx + p * lddx + c, acc);
         continue;
       }
     }
@@ -413,39 +414,46 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_dx_kernel(const RfGeom g
         if (wo >= g.Wo) continue;
         const long m = ((long)n * g.Ho + ho) * g.Wo + wo;
 #pragma unroll
-        for (int t = 0; t < KK; ++t) acc += dug[(m * KK + t) * g.C + c] * w[t * KK + (uy * K + ux)];
+        for (int t = 0; t < KK; ++t) acc += ly_ld1<T>(dug + (m * KK + t) * g.C + c) * w[t * KK + (uy * K + ux)];
       }
     }
-    dx[p * lddx + c] = acc;
+    ly_st1<T>(dx + p * lddx + c, acc);
   }
 }
 
 // ---- C entry points ------------------------------------------------------------------------------
 #define RF_ARGS_OK(k, C) LY_CHECK(((k) == 1 || (k) == 3) && (C) > 0, "rfcbam backward: kernel_size must be 1 or 3")
+#define RF_LAUNCH(kern, grid, ...)                                                                          \
+  LY_WITH_T(dtype, {                                                                                        \
+    if (k == 3) hipLaunchKernelGGL((kern<T, 3>), grid, dim3(LY_THREADS), 0, st, __VA_ARGS__);                 \
+    else hipLaunchKernelGGL((kern<T, 1>), grid, dim3(LY_THREADS), 0, st, __VA_ARGS__);                        \
+  })
+#define RF_T(p) reinterpret_cast<T*>(p)
+#define RF_CT(p) reinterpret_cast<const T*>(p)
 
-extern "C" int ly_rf_generate(const float* x, int ldx, int n_img, int H, int W, int C, int k, int s, const float* wg, float* ug, void* stream) {
+extern "C" int ly_rf_generate(const void* x, int ldx, int n_img, int H, int W, int C, int k, int s, const float* wg, void* ug, int dtype, void* stream) {
   RF_ARGS_OK(k, C);
+  LY_CHECK_DTYPE(dtype, "rf_generate");
   LY_CHECK(x && wg && ug, "rf_generate: null pointer");
   int gx, gy;
   const long Mo = (long)n_img * ((H + 2 * (k / 2) - k) / s + 1) * ((W + 2 * (k / 2) - k) / s + 1);
   const RfGeom g = rf_geom(n_img, H, W, C, k, s, Mo, gx, gy);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (k == 3) hipLaunchKernelGGL(ly_rf_generate_kernel<3>, dim3(gx, gy), dim3(LY_THREADS), 0, st, g, x, ldx, wg, ug);
-  else hipLaunchKernelGGL(ly_rf_generate_kernel<1>, dim3(gx, gy), dim3(LY_THREADS), 0, st, g, x, ldx, wg, ug);
+  RF_LAUNCH(ly_rf_generate_kernel, dim3(gx, gy), g, RF_CT(x), ldx, wg, RF_T(ug));
   LY_LAUNCH_CHECK();
   return 0;
 }
 
-extern "C" int ly_rf_bwd_attn(int n_img, int H, int W, int C, int k, int s, const float* ug, const float* dcd, const float* ag, const float* bg,
-                              const float* ca, const float* rfa, float* cd, float* d_rfa, float* gmax, float* d_ca, void* stream) {
+extern "C" int ly_rf_bwd_attn(int n_img, int H, int W, int C, int k, int s, const void* ug, const void* dcd, const float* ag, const float* bg,
+                              const float* ca, const float* rfa, void* cd, float* d_rfa, float* gmax, float* d_ca, int dtype, void* stream) {
   RF_ARGS_OK(k, C);
+  LY_CHECK_DTYPE(dtype, "rf_bwd_attn");
   LY_CHECK(ug && dcd && ag && bg && ca && rfa && cd && d_rfa && gmax && d_ca, "rf_bwd_attn: null pointer");
   int gx, gy;
   const long Mo = (long)n_img * ((H + 2 * (k / 2) - k) / s + 1) * ((W + 2 * (k / 2) - k) / s + 1);
   const RfGeom g = rf_geom(n_img, H, W, C, k, s, Mo, gx, gy);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (k == 3) hipLaunchKernelGGL(ly_rf_bwd_attn_kernel<3>, dim3(gx, gy), dim3(LY_THREADS), 0, st, g, ug, dcd, ag, bg, ca, rfa, cd, d_rfa, gmax, d_ca);
-  else hipLaunchKernelGGL(ly_rf_bwd_attn_kernel<1>, dim3(gx, gy), dim3(LY_THREADS), 0, st, g, ug, dcd, ag, bg, ca, rfa, cd, d_rfa, gmax, d_ca);
+  RF_LAUNCH(ly_rf_bwd_attn_kernel, dim3(gx, gy), g, RF_CT(ug), RF_CT(dcd), ag, bg, ca, rfa, RF_T(cd), d_rfa, gmax, d_ca);
   LY_LAUNCH_CHECK();
   return 0;
 }
@@ -460,23 +468,24 @@ extern "C" int ly_rfa_bwd(const float* d_rfa, const float* rfa, const float* mm,
   return 0;
 }
 
-extern "C" int ly_rf_bwd_relu(int n_img, int H, int W, int C, int k, int s, const float* ug, float* dcd, const float* ag, const float* bg,
-                              const float* ca, const float* rfa, const float* gmax, const float* d_mm, float* sums, void* stream) {
+extern "C" int ly_rf_bwd_relu(int n_img, int H, int W, int C, int k, int s, const void* ug, void* dcd, const float* ag, const float* bg,
+                              const float* ca, const float* rfa, const float* gmax, const float* d_mm, float* sums, int dtype, void* stream) {
   RF_ARGS_OK(k, C);
+  LY_CHECK_DTYPE(dtype, "rf_bwd_relu");
   LY_CHECK(ug && dcd && ag && bg && ca && rfa && gmax && d_mm && sums, "rf_bwd_relu: null pointer");
   int gx, gy;
   const long Mo = (long)n_img * ((H + 2 * (k / 2) - k) / s + 1) * ((W + 2 * (k / 2) - k) / s + 1);
   const RfGeom g = rf_geom(n_img, H, W, C, k, s, Mo, gx, gy, 512);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (k == 3) hipLaunchKernelGGL(ly_rf_bwd_relu_kernel<3>, dim3(gx, gy), dim3(LY_THREADS), 0, st, g, ug, dcd, ag, bg, ca, rfa, gmax, d_mm, sums);
-  else hipLaunchKernelGGL(ly_rf_bwd_relu_kernel<1>, dim3(gx, gy), dim3(LY_THREADS), 0, st, g, ug, dcd, ag, bg, ca, rfa, gmax, d_mm, sums);
+  RF_LAUNCH(ly_rf_bwd_relu_kernel, dim3(gx, gy), g, RF_CT(ug), RF_T(dcd), ag, bg, ca, rfa, gmax, d_mm, sums);
   LY_LAUNCH_CHECK();
   return 0;
 }
 
-extern "C" int ly_rf_bwd_gen(const float* x, int ldx, int n_img, int H, int W, int C, int k, int s, const float* ug, float* dv, const float* alpha,
-                             const float* kappa, const float* lambda, float* dwg, int part_rows, void* stream) {
+extern "C" int ly_rf_bwd_gen(const void* x, int ldx, int n_img, int H, int W, int C, int k, int s, const void* ug, void* dv, const float* alpha,
+                             const float* kappa, const float* lambda, float* dwg, int part_rows, int dtype, void* stream) {
   RF_ARGS_OK(k, C);
+  LY_CHECK_DTYPE(dtype, "rf_bwd_gen");
   LY_CHECK(x && ug && dv && alpha && kappa && lambda && dwg && part_rows >= 4, "rf_bwd_gen: bad arguments");
   int gx, gy;
   const long Mo = (long)n_img * ((H + 2 * (k / 2) - k) / s + 1) * ((W + 2 * (k / 2) - k) / s + 1);
@@ -486,20 +495,19 @@ extern "C" int ly_rf_bwd_gen(const float* x, int ldx, int n_img, int H, int W, i
   const RfGeom g = rf_geom(n_img, H, W, C, k, s, Mo, gx, gy, (long)(part_rows / subs) * groups);
   LY_CHECK((long)gx * g.subs <= part_rows, "rf_bwd_gen: %d partial rows are not enough for %d blocks x %d", part_rows, gx, g.subs);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (k == 3) hipLaunchKernelGGL(ly_rf_bwd_gen_kernel<3>, dim3(gx, gy), dim3(LY_THREADS), 0, st, g, x, ldx, ug, dv, alpha, kappa, lambda, dwg);
-  else hipLaunchKernelGGL(ly_rf_bwd_gen_kernel<1>, dim3(gx, gy), dim3(LY_THREADS), 0, st, g, x, ldx, ug, dv, alpha, kappa, lambda, dwg);
+  RF_LAUNCH(ly_rf_bwd_gen_kernel, dim3(gx, gy), g, RF_CT(x), ldx, RF_CT(ug), RF_T(dv), alpha, kappa, lambda, dwg);
   LY_LAUNCH_CHECK();
   return 0;
 }
 
-extern "C" int ly_rf_bwd_dx(int n_img, int H, int W, int C, int k, int s, const float* dug, const float* wg, float* dx, int lddx, void* stream) {
+extern "C" int ly_rf_bwd_dx(int n_img, int H, int W, int C, int k, int s, const void* dug, const float* wg, void* dx, int lddx, int dtype, void* stream) {
   RF_ARGS_OK(k, C);
+  LY_CHECK_DTYPE(dtype, "rf_bwd_dx");
   LY_CHECK(dug && wg && dx, "rf_bwd_dx: null pointer");
   int gx, gy;
   const RfGeom g = rf_geom(n_img, H, W, C, k, s, (long)n_img * H * W, gx, gy);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (k == 3) hipLaunchKernelGGL(ly_rf_bwd_dx_kernel<3>, dim3(gx, gy), dim3(LY_THREADS), 0, st, g, dug, wg, dx, lddx);
-  else hipLaunchKernelGGL(ly_rf_bwd_dx_kernel<1>, dim3(gx, gy), dim3(LY_THREADS), 0, st, g, dug, wg, dx, lddx);
+  RF_LAUNCH(ly_rf_bwd_dx_kernel, dim3(gx, gy), g, RF_CT(dug), wg, RF_T(dx), lddx);
   LY_LAUNCH_CHECK();
   return 0;
 }

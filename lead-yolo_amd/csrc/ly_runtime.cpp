@@ -14,4 +14,4 @@ extern "C" void ly_set_error(const char* fmt, ...) {
 
 extern "C" const char* ly_last_error(void) { return g_err; }
 
-extern "C" int ly_abi_version(void) { return 1; }
+extern "C" int ly_abi_version(void) { return 2; }

@@ -21,11 +21,78 @@
 // RS = 2*KP + 16 bytes (RS/16 odd => the 2 x b64 fragment reads of a wave hit 32 distinct 8-byte slots).
 #pragma once
 #include "ly_common.cuh"
+#include "ly_params.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// -------------------------------------------------------------------------------------------------
+// Storage dtypes.  Every kernel is a template over the activation element type T:
+//   float  : fp32 storage, bf16x3 products (two planes hi/lo of both operands, 3 MFMAs per k-step)
+//   __bf16 : bf16 storage (BASELINE configs[2]-[4]), plain bf16 products (ONE plane, 1 MFMA per k-step)
+// Accumulation, BatchNorm statistics, attention tables and parameters are fp32 in both.
+// LyT<T>::PL = operand planes, VW = elements of one 16-byte vector, R4 / RV = raw 4-element / 16-byte register images.
+// -------------------------------------------------------------------------------------------------
+// dtype codes LY_F32 / LY_BF16: include/lead_yolo_hip.h
+typedef unsigned int ly_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int ly_u32x4 __attribute__((ext_vector_type(4)));
+template <typename T> struct LyT;
+template <> struct LyT<float> {
+  static constexpr int PL = 2, VW = 4;
+  static constexpr bool BF = false;
+  typedef f32x4 R4;
+  typedef f32x4 RV;
+};
+template <> struct LyT<__bf16> {
+  static constexpr int PL = 1, VW = 8;
+  static constexpr bool BF = true;
+  typedef ly_u32x2 R4;
+  typedef ly_u32x4 RV;
+};
+
+// runs `stmt` with T bound to the element type selected by the C ABI's dtype code
+#define LY_WITH_T(dtype, ...)                                 \
+  do {                                                        \
+    if ((dtype) == LY_BF16) { using T = __bf16; __VA_ARGS__; } \
+    else { using T = float; __VA_ARGS__; }                    \
+  } while (0)
+#define LY_CHECK_DTYPE(dtype, who) LY_CHECK((dtype) == LY_F32 || (dtype) == LY_BF16, who ": unknown dtype %d", (dtype))
+
+__device__ __forceinline__ f32x4 ly_cvt4(const bf16x4 h) { return __builtin_convertvector(h, f32x4); }
+__device__ __forceinline__ bf16x4 ly_cvtb4(const f32x4 v) { return __builtin_convertvector(v, bf16x4); }
+
+// 4 consecutive elements <-> fp32 registers (fp32: one 16-byte access; bf16: one 8-byte access + conversion)
+template <typename T> __device__ __forceinline__ f32x4 ly_ld4(const T* p);
+template <> __device__ __forceinline__ f32x4 ly_ld4<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+template <> __device__ __forceinline__ f32x4 ly_ld4<__bf16>(const __bf16* p) { return ly_cvt4(*reinterpret_cast<const bf16x4*>(p)); }
+template <typename T> __device__ __forceinline__ void ly_st4(T* p, const f32x4 v);
+template <> __device__ __forceinline__ void ly_st4<float>(float* p, const f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+template <> __device__ __forceinline__ void ly_st4<__bf16>(__bf16* p, const f32x4 v) { *reinterpret_cast<bf16x4*>(p) = ly_cvtb4(v); }
+template <typename T> __device__ __forceinline__ float ly_ld1(const T* p) { return (float)*p; }
+template <typename T> __device__ __forceinline__ void ly_st1(T* p, float v) { *p = (T)v; }
+
+// raw (unconverted) register images: what a prefetch holds while the loads are in flight
+template <typename T> __device__ __forceinline__ typename LyT<T>::R4 ly_ldr4(const T* p) { return *reinterpret_cast<const typename LyT<T>::R4*>(p); }
+template <typename T> __device__ __forceinline__ typename LyT<T>::RV ly_ldrv(const T* p) { return *reinterpret_cast<const typename LyT<T>::RV*>(p); }
+__device__ __forceinline__ f32x4 ly_r4_f32(const f32x4 r) { return r; }
+__device__ __forceinline__ f32x4 ly_r4_f32(const ly_u32x2 r) { return ly_cvt4(__builtin_bit_cast(bf16x4, r)); }
+__device__ __forceinline__ void ly_zero_raw(f32x4& r) { r = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+__device__ __forceinline__ void ly_zero_raw(ly_u32x2& r) { r = (ly_u32x2){0u, 0u}; }
+__device__ __forceinline__ void ly_zero_raw(ly_u32x4& r) { r = (ly_u32x4){0u, 0u, 0u, 0u}; }
+// 16-byte raw vector <-> VW/4 fp32 quads
+__device__ __forceinline__ void ly_rv_unpack(const f32x4 r, f32x4 (&q)[1]) { q[0] = r; }
+__device__ __forceinline__ void ly_rv_unpack(const ly_u32x4 r, f32x4 (&q)[2]) {
+  const bf16x8 b = __builtin_bit_cast(bf16x8, r);
+  q[0] = ly_cvt4(__builtin_shufflevector(b, b, 0, 1, 2, 3));
+  q[1] = ly_cvt4(__builtin_shufflevector(b, b, 4, 5, 6, 7));
+}
+__device__ __forceinline__ f32x4 ly_rv_pack(const f32x4 (&q)[1], f32x4*) { return q[0]; }
+__device__ __forceinline__ ly_u32x4 ly_rv_pack(const f32x4 (&q)[2], ly_u32x4*) {
+  const bf16x4 a = ly_cvtb4(q[0]), b = ly_cvtb4(q[1]);
+  return __builtin_bit_cast(ly_u32x4, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+}
 
 __device__ __forceinline__ void ly_split4(const f32x4 v, bf16x4& hi, bf16x4& lo) {
   hi = __builtin_convertvector(v, bf16x4);
@@ -60,6 +127,22 @@ __device__ __forceinline__ void ly_lds_put4(char* hi_plane, char* lo_plane, int 
   *reinterpret_cast<bf16x4*>(lo_plane + row_byte + 2 * c) = l;
 }
 
+// raw register images into the LDS operand image: fp32 is split into the two planes, bf16 is stored as it is (one plane)
+__device__ __forceinline__ void ly_lds_put_r4(char* hi_plane, char* lo_plane, int row_byte, int c, const f32x4 v) { ly_lds_put4(hi_plane, lo_plane, row_byte, c, v); }
+__device__ __forceinline__ void ly_lds_put_r4(char* hi_plane, char*, int row_byte, int c, const ly_u32x2 v) {
+  *reinterpret_cast<ly_u32x2*>(hi_plane + row_byte + 2 * c) = v;
+}
+__device__ __forceinline__ void ly_lds_put_rv(char* hi_plane, char* lo_plane, int row_byte, int c, const f32x4 v) { ly_lds_put4(hi_plane, lo_plane, row_byte, c, v); }
+__device__ __forceinline__ void ly_lds_put_rv(char* hi_plane, char*, int row_byte, int c, const ly_u32x4 v) {
+  *reinterpret_cast<ly_u32x4*>(hi_plane + row_byte + 2 * c) = v;
+}
+// fp32 quad of channels c..c+3 into the operand image of a PL-plane kernel
+template <int PL>
+__device__ __forceinline__ void ly_lds_put_f32(char* hi_plane, char* lo_plane, int row_byte, int c, const f32x4 v) {
+  if constexpr (PL == 2) ly_lds_put4(hi_plane, lo_plane, row_byte, c, v);
+  else *reinterpret_cast<bf16x4*>(hi_plane + row_byte + 2 * c) = ly_cvtb4(v);
+}
+
 // B-operand fragment of k-step s for the row at `row_byte`
 __device__ __forceinline__ bf16x8 ly_lds_frag(const char* plane, int row_byte, int s, int lq) {
   const char* p = plane + row_byte + 2 * (32 * s + 4 * lq);
@@ -82,26 +165,51 @@ __device__ __forceinline__ LyWFrag ly_wfrag(const uint4* __restrict__ wpk, long 
 }
 
 
-// Cooperative staging of `total` float4 items by the whole block, U loads in flight per thread.
-// src(idx) returns the global address of item idx or nullptr (-> zeros); dst(idx, v) consumes it.
+// PL-plane weight fragment / contraction step (PL = 2: bf16x3, PL = 1: plain bf16); packed by pack.frag_pack3(planes=PL):
+// uint4 wpk[((t*S + s)*PL + plane)*64 + lane]
+template <int PL> struct LyWF;
+template <> struct LyWF<2> { bf16x8 hi, lo; };
+template <> struct LyWF<1> { bf16x8 hi; };
+template <int PL>
+__device__ __forceinline__ LyWF<PL> ly_wfragp(const uint4* __restrict__ wpk, long tile_step, int lane) {
+  LyWF<PL> f;
+  f.hi = __builtin_bit_cast(bf16x8, wpk[(tile_step * PL) * 64 + lane]);
+  if constexpr (PL == 2) f.lo = __builtin_bit_cast(bf16x8, wpk[(tile_step * PL + 1) * 64 + lane]);
+  return f;
+}
+template <int PL>
+__device__ __forceinline__ f32x4 ly_mfmap(const LyWF<PL>& w, const bf16x8 xhi, const bf16x8 xlo, f32x4 acc) {
+  if constexpr (PL == 2) return ly_mfma3(w.hi, w.lo, xhi, xlo, acc);
+  else return ly_mfma_bf16(w.hi, xhi, acc);
+}
+// operand-by-operand form (wgrad: both operands come from LDS)
+template <int PL>
+__device__ __forceinline__ f32x4 ly_mfmapp(const bf16x8 ahi, const bf16x8 alo, const bf16x8 bhi, const bf16x8 blo, f32x4 acc) {
+  if constexpr (PL == 2) return ly_mfma3(ahi, alo, bhi, blo, acc);
+  else return ly_mfma_bf16(ahi, bhi, acc);
+}
+
+// Cooperative staging of `total` raw items (register image R: 16-byte vector or 4-element group) by the whole block, U loads
+// in flight per thread.  src(idx) returns the global address of item idx or nullptr (-> zeros); dst(idx, v) consumes it.
 // All U loads of a batch are issued back to back from clamped addresses (no branch around a load),
 // so a thread pays one memory latency per batch instead of one per item.
-template <int U, class SrcFn, class DstFn>
-__device__ __forceinline__ void ly_stage_f4(const int total, const int tid, const float* safe, SrcFn src, DstFn dst) {
+template <int U, typename R, class SrcFn, class DstFn>
+__device__ __forceinline__ void ly_stage_raw(const int total, const int tid, const void* safe, SrcFn src, DstFn dst) {
   for (int base = tid; base < total; base += LY_THREADS * U) {
-    f32x4 v[U];
+    R v[U];
     bool ok[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int idx = base + u * LY_THREADS;
-      const float* p = idx < total ? src(idx) : nullptr;
+      const void* p = idx < total ? src(idx) : nullptr;
       ok[u] = p != nullptr;
-      v[u] = ly_ldg4(ok[u] ? p : safe);
+      v[u] = *reinterpret_cast<const R*>(ok[u] ? p : safe);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int idx = base + u * LY_THREADS;
-      if (idx < total) dst(idx, ok[u] ? v[u] : ly_zero4());
+      if (!ok[u]) ly_zero_raw(v[u]);
+      if (idx < total) dst(idx, v[u]);
     }
   }
 }

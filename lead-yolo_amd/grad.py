@@ -32,10 +32,11 @@ def _rows_dense(t):
 class ConvSpec:
     """Static description of one conv(+bias) -> [BN] -> act unit."""
 
-    def __init__(self, kind, cout, act=ACT_NONE, bn=None, bn_train=False, k=1, nchw=False, up=False):
+    def __init__(self, kind, cout, act=ACT_NONE, bn=None, bn_train=False, k=1, nchw=False, up=False, out_dtype=None):
         self.kind = kind            # "pw" (1x1, one or two row sources), "c3" (3x3 s1 p1), "patch" (k = s)
         self.cout, self.act, self.bn, self.bn_train = cout, act, bn, bn_train
         self.k, self.nchw, self.up = k, nchw, up
+        self.out_dtype = out_dtype  # storage dtype of the output when it differs from the input's (fp32 NCHW image -> bf16 map)
 
 
 
@@ -76,9 +77,10 @@ def _conv_forward(spec, x0, x1, wp, e_scale, e_shift, act, stats=None, out=None,
     else:
         xr = _rows_dense(x0)
         kw = dict(K=k * k * c, a0=xr, lda0=c, k0=k * k * c, gather=ops.GATHER_PATCH, Hin=h, Win=w, Cin=c, ks=k, pk=k * c)
+    odt = spec.out_dtype or xr.dtype
     if (stats is None or store) and out is None:
-        out = ops.empty_nhwc(n, co, ho, wo, xr)
-    ops.gemm(M=n * ho * wo, H=ho, W=wo, N=co, wp=wp, out=out, ldo=co, e_scale=e_scale, e_shift=e_shift, act=act, stats=stats, **kw)
+        out = ops.empty_nhwc(n, co, ho, wo, xr, dtype=odt)
+    ops.gemm(M=n * ho * wo, H=ho, W=wo, N=co, wp=wp, out=out, ldo=co, e_scale=e_scale, e_shift=e_shift, act=act, stats=stats, dtype=odt, **kw)
     return out
 
 
@@ -124,12 +126,12 @@ def conv_wgrad(spec, du, x0, x1, weight):
         if h == ho * k and w == wo * k and (k * k * c) % 4 == 0 and co % 4 == 0:
             # PatchEmbed on the NCHW image: one space-to-depth copy turns the k x k patch gather into plain rows [M, c*k*k] (the
             # weight's own (c, ky, kx) column order), which the tiled kernel takes; the per-lane NCHW gather kernel was 3x slower
-            xr = x0.reshape(n, c, ho, k, wo, k).permute(0, 2, 4, 1, 3, 5).reshape(m, c * k * k)
+            xr = x0.reshape(n, c, ho, k, wo, k).permute(0, 2, 4, 1, 3, 5).reshape(m, c * k * k).to(du.dtype)
             dwr = torch.zeros(co, k * k * c, dtype=torch.float32, device=du.device)
             ops.wgrad(M=m, H=ho, W=wo, N=co, du=du, lddu=co, x=xr, ldx=k * k * c, Hin=ho, Win=wo, Cin=k * k * c, dw=dwr, lddw=k * k * c)
             return dwr.view(weight.shape)
         dw = torch.zeros(co, k * k * c, dtype=torch.float32, device=du.device)
-        xr = x0.contiguous()
+        xr = x0.contiguous().to(du.dtype)
         ops.wgrad(M=m, H=ho, W=wo, N=co, du=du, lddu=co, x=xr, ldx=0, Hin=h, Win=w, Cin=c, dw=dw, lddw=k * k * c, ks=k, stride=k, nchw=True)
     else:
         dw = torch.zeros(co, k * k * c, dtype=torch.float32, device=du.device)
@@ -146,7 +148,7 @@ def conv_dgrad(spec, du, weight, x0, x1, need0, need1):
         if spec.kind == "pw":
             w2 = weight.detach().reshape(weight.shape[0], -1)
             kin = w2.shape[1]
-            wt = pack.frag_pack3(_pad_cols(w2.t(), co))
+            wt = pack.frag_pack3(_pad_cols(w2.t(), co), planes=ops.planes_of(du))
             d = ops.empty_nhwc(n, kin, ho, wo, du)
             ops.gemm(M=m, H=ho, W=wo, K=co, N=kin, a0=du, lda0=co, k0=co, wp=wt, out=d, ldo=kin)
             if x1 is None:
@@ -157,7 +159,7 @@ def conv_dgrad(spec, du, weight, x0, x1, need0, need1):
                 d0 = ops.up2_bwd(d, kin, n, ho // 2, wo // 2, c0)
             return (d0 if need0 else None), (d[:, c0:] if need1 else None)
         if spec.kind == "c3":
-            wt = pack.frag_pack3(pack.conv_taps_matrix(weight.detach().permute(1, 0, 2, 3).flip(2, 3), 32))
+            wt = pack.frag_pack3(pack.conv_taps_matrix(weight.detach().permute(1, 0, 2, 3).flip(2, 3), 32), planes=ops.planes_of(du))
             cin = weight.shape[1]
             d = ops.empty_nhwc(n, cin, ho, wo, du)
             ops.conv3x3(M=m, H=ho, W=wo, Cin=co, N=cin, x=du, ldx=co, wp=wt, out=d, ldo=cin)
@@ -167,8 +169,8 @@ def conv_dgrad(spec, du, weight, x0, x1, need0, need1):
         _, c, h, w = x0.shape
         k = spec.k
         w2 = weight.detach().permute(0, 2, 3, 1).reshape(co, -1)
-        wt = pack.frag_pack3(w2.t())
-        g = torch.empty((m, k * k * c), dtype=torch.float32, device=du.device)
+        wt = pack.frag_pack3(w2.t(), planes=ops.planes_of(du))
+        g = torch.empty((m, k * k * c), dtype=du.dtype, device=du.device)
         ops.gemm(M=m, H=ho, W=wo, K=co, N=k * k * c, a0=du, lda0=co, k0=co, wp=wt, out=g, ldo=k * k * c)
         return ops.unpatch(g, n, ho, wo, c, k, h, w), None
 
@@ -233,7 +235,8 @@ class ConvBnAct(torch.autograd.Function):
         co = spec.cout
         need = ctx.needs_input_grad          # (spec, wp, x0, x1, weight, bias, gamma, beta)
         with torch.no_grad():
-            dy = _rows_dense(dy)
+            odt = spec.out_dtype or x0.dtype
+            dy = _rows_dense(dy if dy.dtype == odt else dy.to(odt))
             dgamma = dbeta = dbias = None
             if spec.bn is not None or spec.act != ACT_NONE:
                 # pre-BN value: kept by the forward (train-mode BN) or recomputed (conv + bias)
@@ -258,10 +261,11 @@ class ConvBnAct(torch.autograd.Function):
                 if bias_f is not None:
                     n, _, h, w = dy.shape
                     dbias = _chan_sum(dy, co)
-            cq = (co + 3) // 4 * 4
+            vw = ops.vw_of(du)
+            cq = (co + vw - 1) // vw * vw
             if cq != co:                                                               # e.g. Detect heads (18 channels)
                 n, _, h, w = du.shape
-                pad = torch.zeros((n, cq, h, w), dtype=torch.float32, device=du.device).contiguous(memory_format=torch.channels_last)
+                pad = torch.zeros((n, cq, h, w), dtype=du.dtype, device=du.device).contiguous(memory_format=torch.channels_last)
                 pad[:, :co] = du
                 du_d = pad
             else:
@@ -277,11 +281,11 @@ class ConvBnAct(torch.autograd.Function):
 
 
 def _chan_sum(t, c):
-    """per-channel sum over pixels of an NHWC-dense tensor (c may be any size)."""
+    """per-channel sum over pixels of an NHWC-dense tensor (c may be any size) -> fp32."""
     n, _, h, w = t.shape
     if c % 4 == 0 and c <= 1024:
         return ops.chan_moments(t, c, n * h * w, c)[:c]
-    return t.sum((0, 2, 3))
+    return t.sum((0, 2, 3), dtype=torch.float32)
 
 
 def _out_shape(spec, x0):
@@ -313,7 +317,7 @@ class MlpBlockFn(torch.autograd.Function):
     def forward(ctx, mod, x, wpc, w1, gamma, beta, w2):
         x = _rows_dense(x)
         n, c, h, w = x.shape
-        pk_p, pk_1, pk_2 = mod._weights()
+        pk_p, pk_1, pk_2 = mod._weights(ops.planes_of(x))
         htp = (2 * c // 16 + 1) // 2 * 2
         stats = ops.new_stats(16 * htp, x.device)
         ops.mlpblock(x, None, n, h, w, c, pk_p, pk_1, pk_2, None, None, stats=stats)
@@ -332,26 +336,27 @@ class MlpBlockFn(torch.autograd.Function):
         c4 = c // 4
         c4p = _ceil4(c4)
         with torch.no_grad():
-            dy = _rows_dense(dy)
+            dy = _rows_dense(dy if dy.dtype == x.dtype else dy.to(x.dtype))
+            pl = ops.planes_of(x)
             w1m, w2m = w1.detach().view(2 * c, c), w2.detach().view(c, 2 * c)
             # recompute z, u1, h
             z = x.clone()
-            ops.conv3x3(M=m, H=h, W=w, Cin=c4p, N=c4, x=x, ldx=c, wp=pack.frag_pack3(pack.conv_taps_matrix(wpc.detach(), 32)), out=z, ldo=c)
-            pk1 = pack.frag_pack3(w1m)
+            ops.conv3x3(M=m, H=h, W=w, Cin=c4p, N=c4, x=x, ldx=c, wp=pack.frag_pack3(pack.conv_taps_matrix(wpc.detach(), 32), planes=pl), out=z, ldo=c)
+            pk1 = pack.frag_pack3(w1m, planes=pl)
             u1 = ops.empty_nhwc(n, 2 * c, h, w, x)
             ops.gemm(M=m, H=h, W=w, K=c, N=2 * c, a0=z, lda0=c, k0=c, wp=pk1, out=u1, ldo=2 * c)
             hid = ops.empty_nhwc(n, 2 * c, h, w, x)
             ops.gemm(M=m, H=h, W=w, K=c, N=2 * c, a0=z, lda0=c, k0=c, wp=pk1, out=hid, ldo=2 * c, e_scale=a, e_shift=b, act=ACT_RELU)
             # second 1x1
             dh = ops.empty_nhwc(n, 2 * c, h, w, x)
-            ops.gemm(M=m, H=h, W=w, K=c, N=2 * c, a0=dy, lda0=c, k0=c, wp=pack.frag_pack3(w2m.t()), out=dh, ldo=2 * c)
+            ops.gemm(M=m, H=h, W=w, K=c, N=2 * c, a0=dy, lda0=c, k0=c, wp=pack.frag_pack3(w2m.t(), planes=pl), out=dh, ldo=2 * c)
             dw2 = torch.zeros(c, 2 * c, dtype=torch.float32, device=x.device)
             ops.wgrad(M=m, H=h, W=w, N=c, du=dy, lddu=c, x=hid, ldx=2 * c, Hin=h, Win=w, Cin=2 * c, dw=dw2, lddw=2 * c)
             # BN + ReLU
             du1, dgamma, dbeta = affine_backward(dh, u1, a, b, ACT_RELU, mean, invstd, True)
             # first 1x1
             g = ops.empty_nhwc(n, c, h, w, x)
-            ops.gemm(M=m, H=h, W=w, K=2 * c, N=c, a0=du1, lda0=2 * c, k0=2 * c, wp=pack.frag_pack3(w1m.t()), out=g, ldo=c)
+            ops.gemm(M=m, H=h, W=w, K=2 * c, N=c, a0=du1, lda0=2 * c, k0=2 * c, wp=pack.frag_pack3(w1m.t(), planes=pl), out=g, ldo=c)
             dw1 = torch.zeros(2 * c, c, dtype=torch.float32, device=x.device)
             ops.wgrad(M=m, H=h, W=w, N=2 * c, du=du1, lddu=2 * c, x=z, ldx=c, Hin=h, Win=w, Cin=c, dw=dw1, lddw=c)
             # partial 3x3 conv on the first C/4 channels
@@ -361,7 +366,7 @@ class MlpBlockFn(torch.autograd.Function):
             ops.wgrad(M=m, H=h, W=w, N=c4p, du=g, lddu=c, x=x, ldx=c, Hin=h, Win=w, Cin=c4p, dw=dwp, lddw=9 * c4p, ks=3, stride=1, pad=1)
             dwp = dwp.view(c4p, 9, c4p)[:c4, :, :c4]
             t = ops.empty_nhwc(n, c4p, h, w, x)
-            wt = pack.frag_pack3(pack.conv_taps_matrix(wpc.detach().permute(1, 0, 2, 3).flip(2, 3), 32))
+            wt = pack.frag_pack3(pack.conv_taps_matrix(wpc.detach().permute(1, 0, 2, 3).flip(2, 3), 32), planes=pl)
             ops.conv3x3(M=m, H=h, W=w, Cin=c4p, N=c4, x=g, ldx=c, wp=wt, out=t, ldo=c4p)
             dx = dy + g
             dx[:, :c4] = dy[:, :c4] + t[:, :c4]
@@ -378,12 +383,13 @@ class PoolHW(torch.autograd.Function):
         t, ld = ops.rows(x)
         n, c, h, w = t.shape
         ctx.shape = (n, c, h, w)
+        ctx.dtype = t.dtype
         return ops.pool_hw(t, ld, n, h, w, c)
 
     @staticmethod
     def backward(ctx, gp):
         n, c, h, w = ctx.shape
-        return ops.pool_hw_bwd(gp.contiguous(), n, h, w, c)
+        return ops.pool_hw_bwd(gp.float().contiguous(), n, h, w, c, dtype=ctx.dtype)
 
 
 class Gate(torch.autograd.Function):
@@ -391,7 +397,7 @@ class Gate(torch.autograd.Function):
     def forward(ctx, x, a_h, a_w):
         t, ld = ops.rows(x)
         n, c, h, w = t.shape
-        a_h, a_w = a_h.contiguous(), a_w.contiguous()
+        a_h, a_w = a_h.float().contiguous(), a_w.float().contiguous()
         ctx.save_for_backward(t, a_h, a_w)
         return ops.coordatt_gate(t, ld, n, h, w, c, a_h, a_w)
 
@@ -400,7 +406,7 @@ class Gate(torch.autograd.Function):
         t, a_h, a_w = ctx.saved_tensors
         xr, ld = ops.rows(t)
         n, c, h, w = xr.shape
-        return ops.coordatt_gate_bwd(_rows_dense(dout), xr, ld, n, h, w, c, a_h, a_w)
+        return ops.coordatt_gate_bwd(_rows_dense(dout if dout.dtype == xr.dtype else dout.to(xr.dtype)), xr, ld, n, h, w, c, a_h, a_w)
 
 
 def coordatt_train(mod, x):
@@ -439,10 +445,10 @@ class SppfPool(torch.autograd.Function):
         buf, = ctx.saved_tensors
         n, c4, h, w = buf.shape
         c = c4 // 4
-        acc = _rows_dense(d).clone()
+        acc = _rows_dense(d).float() if d.dtype != torch.float32 else _rows_dense(d).clone()   # fp32 accumulator (float atomics)
         for j in (2, 1, 0):                           # m(y_j) = y_{j+1}: add its gradient into slot j
             ops.maxpool_bwd(buf, j * c, c4, acc, (j + 1) * c, c4, n, h, w, c, ctx.k, acc, j * c, c4)
-        return acc[:, :c], None
+        return acc[:, :c].to(buf.dtype), None
 
 
 # --------------------------------------------------------------------------------------------------
@@ -470,8 +476,8 @@ class RfcbamFn(torch.autograd.Function):
         n, c, h, w = xr.shape
         k, s, o = mod.kernel_size, mod.stride, mod.o
         ho, wo = (h + 2 * (k // 2) - k) // s + 1, (w + 2 * (k // 2) - k) // s + 1
-        P = mod._packed()
-        ca = ca.detach().contiguous()
+        P = mod._packed(ops.planes_of(xr))
+        ca = ca.detach().float().contiguous()
         bias = conv_b.detach().float().contiguous()
         if k == 1:
             gwv = gen_w.detach().float().view(c)
@@ -518,7 +524,10 @@ class RfcbamFn(torch.autograd.Function):
         st = L.stream_ptr()
         p = L.ptr
         with torch.no_grad():
-            dy = _rows_dense(dy)
+            dt = xr.dtype
+            pl = ops.planes_of(xr)
+            code = L.dtype_code(xr)
+            dy = _rows_dense(dy if dy.dtype == dt else dy.to(dt))
             # 1-2. output conv: recompute pre-BN value (bias included), BN + ReLU backward
             u = ops.empty_nhwc(n, o, ho, wo, xr)
             if k == 1:
@@ -530,22 +539,25 @@ class RfcbamFn(torch.autograd.Function):
             _tap("rf.du", du)
             # 3. dcd [mo][t][c]
             wc = conv_w.detach().float().reshape(o, c, kk).permute(0, 2, 1).reshape(o, kk * c)       # columns (t, c)
-            dcd = torch.empty((mo, kk * c), dtype=torch.float32, device=dev)
-            ops.gemm(M=mo, H=ho, W=wo, K=o, N=kk * c, a0=du, lda0=o, k0=o, wp=pack.frag_pack3(wc.t()), out=dcd, ldo=kk * c)
+            dcd = torch.empty((mo, kk * c), dtype=dt, device=dev)
+            ops.gemm(M=mo, H=ho, W=wo, K=o, N=kk * c, a0=du, lda0=o, k0=o, wp=pack.frag_pack3(wc.t(), planes=pl), out=dcd, ldo=kk * c)
             _tap("rf.dcd", dcd)
             # 4. ug
             wg = gen_w.detach().float().reshape(c * kk, kk).contiguous()
-            ug = torch.empty((mo, kk * c), dtype=torch.float32, device=dev)
-            L.check(L.lib().ly_rf_generate(p(xr), ld, n, h, w, c, k, s, p(wg), p(ug), st), "ly_rf_generate")
+            ug = torch.empty((mo, kk * c), dtype=dt, device=dev)
+            es9 = xr.element_size() * mo * kk * c                 # bytes of one expanded tensor
+            with ops._Timed(f"ly_rf_generate_kernel<{ops._tname(xr)}, {k}>", 2.0 * mo * kk * kk * c, xr.element_size() * n * h * w * c + es9):
+                L.check(L.lib().ly_rf_generate(p(xr), ld, n, h, w, c, k, s, p(wg), p(ug), code, st), "ly_rf_generate")
             # 5. cd, d_rfa, gmax, d_ca
             tc = lambda v: v.view(c, kk).t().contiguous().view(-1)                                     # [c*kk + t] -> [t*c + c]
             ag, bg = tc(gs), tc(gb)
-            cd = torch.empty((mo, kk * c), dtype=torch.float32, device=dev)
+            cd = torch.empty((mo, kk * c), dtype=dt, device=dev)
             d_rfa = torch.zeros_like(rfa)
             gmax = torch.zeros_like(rfa)
             d_ca = torch.zeros_like(ca)
-            L.check(L.lib().ly_rf_bwd_attn(n, h, w, c, k, s, p(ug), p(dcd), p(ag), p(bg), p(ca), p(rfa), p(cd), p(d_rfa), p(gmax), p(d_ca), st),
-                    "ly_rf_bwd_attn")
+            with ops._Timed(f"ly_rf_bwd_attn_kernel<{ops._tname(xr)}, {k}>", 8.0 * mo * kk * c, 3.0 * es9):
+                L.check(L.lib().ly_rf_bwd_attn(n, h, w, c, k, s, p(ug), p(dcd), p(ag), p(bg), p(ca), p(rfa), p(cd), p(d_rfa), p(gmax), p(d_ca), code, st),
+                        "ly_rf_bwd_attn")
             _tap("rf.ug", ug); _tap("rf.cd", cd); _tap("rf.d_rfa", d_rfa); _tap("rf.gmax", gmax); _tap("rf.d_ca", d_ca)
             _tap("rf.rfa", rfa); _tap("rf.ca", ca); _tap("rf.ag", ag); _tap("rf.bg", bg)
             # 6. conv weight gradient
@@ -559,8 +571,9 @@ class RfcbamFn(torch.autograd.Function):
             L.check(L.lib().ly_rfa_bwd(p(d_rfa), p(rfa), p(mm), p(w18), n, k * ho, k * wo, p(d_mm), p(dw18), st), "ly_rfa_bwd")
             # 8. through max/mean, ca, rfa and ReLU; generate-BN sums
             sums = torch.zeros(2 * kk * c, dtype=torch.float32, device=dev)
-            L.check(L.lib().ly_rf_bwd_relu(n, h, w, c, k, s, p(ug), p(dcd), p(ag), p(bg), p(ca), p(rfa), p(gmax), p(d_mm), p(sums), st),
-                    "ly_rf_bwd_relu")
+            with ops._Timed(f"ly_rf_bwd_relu_kernel<{ops._tname(xr)}, {k}>", 8.0 * mo * kk * c, 3.0 * es9):
+                L.check(L.lib().ly_rf_bwd_relu(n, h, w, c, k, s, p(ug), p(dcd), p(ag), p(bg), p(ca), p(rfa), p(gmax), p(d_mm), p(sums), code, st),
+                        "ly_rf_bwd_relu")
             _tap("rf.d_mm", d_mm); _tap("rf.dv", dcd); _tap("rf.sums", sums)
             # 9. generate BatchNorm coefficients ([t][c] order)
             dgg_tc, dbg_tc, alpha, kappa, lam = ops.bn_bwd_coeffs(sums, kk * c, mo, ag, tc(gmean), tc(ginv), True)
@@ -568,13 +581,15 @@ class RfcbamFn(torch.autograd.Function):
             # 10. dug, generate weight gradient
             part_rows = 512
             dwg = torch.zeros(part_rows, c * kk, kk, dtype=torch.float32, device=dev)         # per-block partial sums, summed below
-            L.check(L.lib().ly_rf_bwd_gen(p(xr), ld, n, h, w, c, k, s, p(ug), p(dcd), p(alpha), p(kappa), p(lam), p(dwg), part_rows, st),
-                    "ly_rf_bwd_gen")
+            with ops._Timed(f"ly_rf_bwd_gen_kernel<{ops._tname(xr)}, {k}>", 2.0 * mo * kk * kk * c, 3.0 * es9):
+                L.check(L.lib().ly_rf_bwd_gen(p(xr), ld, n, h, w, c, k, s, p(ug), p(dcd), p(alpha), p(kappa), p(lam), p(dwg), part_rows, code, st),
+                        "ly_rf_bwd_gen")
             # 11. dx
             dx = None
             if ctx.needs_input_grad[1]:
                 dx = ops.empty_nhwc(n, c, h, w, xr)
-                L.check(L.lib().ly_rf_bwd_dx(n, h, w, c, k, s, p(dcd), p(wg), p(dx), c, st), "ly_rf_bwd_dx")
+                with ops._Timed(f"ly_rf_bwd_dx_kernel<{ops._tname(xr)}, {k}>", 2.0 * mo * kk * kk * c, es9 + xr.element_size() * n * h * w * c):
+                    L.check(L.lib().ly_rf_bwd_dx(n, h, w, c, k, s, p(dcd), p(wg), p(dx), c, code, st), "ly_rf_bwd_dx")
         return (None, dx, d_ca, dwg.sum(0).view(gen_w.shape), ct(dgg_tc), ct(dbg_tc), dw18.view(getw.shape), dwc, torch.zeros_like(bias), dgo, dbo)
 
 

@@ -26,18 +26,19 @@ BN_MOMENTUM = 0.03
 
 
 class _Prepared:
-    """Cache of kernel-ready (packed / folded) parameters, rebuilt when any source tensor changes."""
+    """Cache of kernel-ready (packed / folded) parameters, rebuilt when any source tensor changes.  `variant` separates the
+    forms one parameter set is prepared in (weight packs with 2 planes for fp32 storage, 1 plane for bf16 storage)."""
 
     def __init__(self):
-        self.key = None
-        self.val = None
+        self.slots = {}
 
-    def get(self, key, build):
-        if key != self.key:
+    def get(self, key, build, variant=0):
+        ent = self.slots.get(variant)
+        if ent is None or ent[0] != key:
             with torch.no_grad():
-                self.val = build()
-            self.key = key
-        return self.val
+                ent = (key, build())
+            self.slots[variant] = ent
+        return ent[1]
 
     def __deepcopy__(self, memo):
         return _Prepared()
@@ -46,8 +47,24 @@ class _Prepared:
         return {}
 
     def __setstate__(self, state):
-        self.key = None
-        self.val = None
+        self.slots = {}
+
+
+def _edge(fn):
+    """forward wrapper applying the dtype policy of ops.edge_in / edge_out around a module's body, and running the body with
+    autocast OFF: inside a module every dtype is explicit (storage dtype activations, fp32 tables), torch helper ops on pooled
+    vectors must not be re-cast by an enclosing torch.autocast region."""
+    def forward(self, x):
+        if isinstance(x, torch.Tensor) and not (SHAPE_PROBE and not x.is_cuda):
+            x, back = ops.edge_in(x, type(self).__name__, self)
+        else:
+            back = None
+        with torch.autocast("cuda", enabled=False):
+            y = fn(self, x)
+        return ops.edge_out(y, back)
+    forward.__name__ = fn.__name__
+    forward.__doc__ = fn.__doc__
+    return forward
 
 
 # Shape-probe mode: the reference's DetectionModel.__init__ derives strides from the SHAPES of a
@@ -192,16 +209,17 @@ class MLPBlock(nn.Module):
         self._prep = _Prepared()
         self._prep_bn = _Prepared()
 
-    def _weights(self):
+    def _weights(self, planes=2):
         wp_, w1_, w2_ = self.spatial_mixing.partial_conv3.weight, self.mlp[0].weight, self.mlp[3].weight
         key = pack.versions(wp_, w1_, w2_)
 
         def build():
             c = self.dim
             htp = (2 * c // 16 + 1) // 2 * 2
-            return (pack.frag_pack3(pack.conv_taps_matrix(wp_.detach(), 4)), pack.frag_pack3(w1_.detach().view(2 * c, c), rows_to=16 * htp),
-                    pack.frag_pack3(w2_.detach().view(c, 2 * c)))
-        return self._prep.get(key, build)
+            return (pack.frag_pack3(pack.conv_taps_matrix(wp_.detach(), 4), planes=planes),
+                    pack.frag_pack3(w1_.detach().view(2 * c, c), rows_to=16 * htp, planes=planes),
+                    pack.frag_pack3(w2_.detach().view(c, 2 * c), planes=planes))
+        return self._prep.get(key, build, planes)
 
     def _bn_eval(self):
         bn = self.mlp[1]
@@ -213,11 +231,11 @@ class MLPBlock(nn.Module):
             return pack.pad_to(sc, 16 * htp), pack.pad_to(sh, 16 * htp)
         return self._prep_bn.get(key, build)
 
+    @_edge
     def forward(self, x):
         pr = _probe(x, x.shape)
         if pr is not None:
             return pr
-        ops.require_cuda(x, "MLPBlock", self)
         if _grad_mode(self):
             from . import grad
             bn = self.mlp[1]
@@ -225,7 +243,7 @@ class MLPBlock(nn.Module):
                                          self.mlp[3].weight)
         x = ops.nhwc(x)
         n, c, h, w = x.shape
-        wp, w1, w2 = self._weights()
+        wp, w1, w2 = self._weights(ops.planes_of(x))
         if self.training:
             htp = (2 * c // 16 + 1) // 2 * 2
             stats = ops.new_stats(16 * htp, x.device)
@@ -265,15 +283,15 @@ class _PatchConv(nn.Module):
         self._prep = _Prepared()
         self._prep_bn = _Prepared()
 
-    def _weights(self, nchw):
+    def _weights(self, nchw, planes=2):
         conv = getattr(self, self._conv_name)
         key = pack.versions(conv.weight) + (nchw,)
 
         def build():
             w = conv.weight.detach()
             co = w.shape[0]
-            return pack.frag_pack3(w.reshape(co, -1) if nchw else w.permute(0, 2, 3, 1).reshape(co, -1))
-        return self._prep.get(key, build)
+            return pack.frag_pack3(w.reshape(co, -1) if nchw else w.permute(0, 2, 3, 1).reshape(co, -1), planes=planes)
+        return self._prep.get(key, build, planes)
 
     def _affine_eval(self):
         conv = getattr(self, self._conv_name)
@@ -291,30 +309,49 @@ class _PatchConv(nn.Module):
         pr = _probe(x, (x.shape[0], self.cout, x.shape[2] // self.k, x.shape[3] // self.k))
         if pr is not None:
             return pr
-        ops.require_cuda(x, type(self).__name__, self)
+        n, c, h, w = x.shape
+        nchw = c % 4 != 0                           # an image (3 channels): read as fp32 NCHW whatever the compute dtype is
+        if nchw:
+            # dtype policy by hand: the image itself stays fp32 (the gather kernel converts), only the OUTPUT takes the policy's dtype
+            if not x.is_cuda:
+                raise RuntimeError(f"{type(self).__name__}: the HIP path needs a CUDA/ROCm tensor (got {x.device}); there is no CPU fallback")
+            want = torch.get_autocast_gpu_dtype() if (torch.is_autocast_enabled() and x.dtype == torch.float32) else x.dtype
+            odt = torch.float32 if want == torch.float32 else torch.bfloat16
+            back = torch.float16 if want == torch.float16 else None
+            x = x.float()
+            ops.require_cuda(x, type(self).__name__, self)
+        else:
+            x, back = ops.edge_in(x, type(self).__name__, self)
+            odt = x.dtype
+        with torch.autocast("cuda", enabled=False):
+            return ops.edge_out(self._fwd(x, nchw, odt), back)
+
+    def _fwd(self, x, nchw, odt):
         n, c, h, w = x.shape
         k = self.k
         ho, wo = h // k, w // k
+        planes = ops.planes_of(odt)
+        if not nchw and c % ops.vw_of(odt) != 0:
+            raise NotImplementedError(f"{type(self).__name__}: {odt} patch gathers need channels % {ops.vw_of(odt)} == 0 (got {c})")
         if _grad_mode(self) and isinstance(getattr(self, "norm", None), nn.BatchNorm2d):
             from . import grad
-            nchw = c % 4 != 0
             if nchw and (k != 4 or w % 4 != 0):
                 raise NotImplementedError("HIP patch embedding of an NCHW image needs patch_size 4 and W % 4 == 0")
             conv = getattr(self, self._conv_name)
-            spec = grad.ConvSpec("patch", self.cout, ACT_NONE, self.norm, True, k=k, nchw=nchw)
-            return grad.conv_bn_act(spec, self._weights(nchw), x, None, conv.weight, conv.bias, self.norm)
+            spec = grad.ConvSpec("patch", self.cout, ACT_NONE, self.norm, True, k=k, nchw=nchw, out_dtype=odt)
+            return grad.conv_bn_act(spec, self._weights(nchw, planes), x, None, conv.weight, conv.bias, self.norm)
         if c % 4 == 0:
             xr, ld = ops.rows(x)
             if ld != c:
                 xr, ld = ops.nhwc(x.contiguous()), c
-            kw = dict(M=n * ho * wo, H=ho, W=wo, K=k * k * c, N=self.cout, a0=xr, lda0=c, k0=k * k * c, wp=self._weights(False),
-                      ldo=self.cout, gather=ops.GATHER_PATCH, Hin=h, Win=w, Cin=c, ks=k, pk=k * c)
+            kw = dict(M=n * ho * wo, H=ho, W=wo, K=k * k * c, N=self.cout, a0=xr, lda0=c, k0=k * k * c, wp=self._weights(False, planes),
+                      ldo=self.cout, gather=ops.GATHER_PATCH, Hin=h, Win=w, Cin=c, ks=k, pk=k * c, dtype=odt)
         else:
             if k != 4 or w % 4 != 0:
                 raise NotImplementedError("HIP patch embedding of an NCHW image needs patch_size 4 and W % 4 == 0")
             xr = x.contiguous()                     # NCHW image
-            kw = dict(M=n * ho * wo, H=ho, W=wo, K=16 * c, N=self.cout, a0=xr, lda0=0, k0=16 * c, wp=self._weights(True),
-                      ldo=self.cout, gather=ops.GATHER_PATCH_NCHW, Hin=h, Win=w, Cin=c, ks=4, pk=0)
+            kw = dict(M=n * ho * wo, H=ho, W=wo, K=16 * c, N=self.cout, a0=xr, lda0=0, k0=16 * c, wp=self._weights(True, planes),
+                      ldo=self.cout, gather=ops.GATHER_PATCH_NCHW, Hin=h, Win=w, Cin=c, ks=4, pk=0, dtype=odt)
         bn = getattr(self, "norm", None)
         if self.training and isinstance(bn, nn.BatchNorm2d):
             conv = getattr(self, self._conv_name)
@@ -324,7 +361,7 @@ class _PatchConv(nn.Module):
             sc, sh = ops.bn_finalize(bn, stats, self.cout, n * ho * wo, bias=bias)
         else:
             sc, sh = self._affine_eval()
-        out = ops.empty_nhwc(n, self.cout, ho, wo, x)
+        out = ops.empty_nhwc(n, self.cout, ho, wo, x, dtype=odt)
         ops.gemm(out=out, e_scale=sc, e_shift=sh, **kw)
         return out
 
@@ -373,14 +410,14 @@ class Conv(nn.Module):
         self._prep = _Prepared()
         self._prep_bn = _Prepared()
 
-    def weights(self):
+    def weights(self, planes=2):
         conv = self.conv
         key = pack.versions(conv.weight)
 
         def build():
             w = conv.weight.detach()
-            return pack.frag_pack3(w.view(self.c2, self.c1) if self.k == 1 else pack.conv_taps_matrix(w, 32))
-        return self._prep.get(key, build)
+            return pack.frag_pack3(w.view(self.c2, self.c1) if self.k == 1 else pack.conv_taps_matrix(w, 32), planes=planes)
+        return self._prep.get(key, build, planes)
 
     def affine_eval(self):
         conv, bn = self.conv, getattr(self, "bn", None)
@@ -392,12 +429,8 @@ class Conv(nn.Module):
             return None, (conv.bias.detach().float().contiguous() if conv.bias is not None else None)
         return self._prep_bn.get(key, build)
 
-    def packed(self):
-        sc, sh = self.affine_eval()
-        return self.weights(), sc, sh
-
     def _run(self, x, sc, sh, act, stats=None):
-        wp = self.weights()
+        wp = self.weights(ops.planes_of(x.a0 if isinstance(x, Lazy) else x))
         if self.k == 1:
             return _run_pointwise(x, wp, self.c2, sc, sh, act, stats=stats)
         xr, ld = ops.rows(x)
@@ -407,12 +440,11 @@ class Conv(nn.Module):
                     stats=stats)
         return out
 
+    @_edge
     def forward(self, x):
         pr = _probe(x, (x.shape[0], self.c2, x.shape[2], x.shape[3])) if isinstance(x, torch.Tensor) else None
         if pr is not None:
             return pr
-        if not isinstance(x, Lazy):
-            ops.require_cuda(x, "Conv", self)
         if self.k == 3 and isinstance(x, Lazy):
             x = x.materialize()
         act = _act_code(self.act)
@@ -426,7 +458,7 @@ class Conv(nn.Module):
                 else:
                     x0, x1, up = x.keep[0], (x.keep[1] if x.a1 is not None else None), x.up
             spec = grad.ConvSpec("pw" if self.k == 1 else "c3", self.c2, act, bn, True, up=up)
-            return grad.conv_bn_act(spec, self.weights(), x0, x1, self.conv.weight, self.conv.bias, bn)
+            return grad.conv_bn_act(spec, self.weights(ops.planes_of(x0)), x0, x1, self.conv.weight, self.conv.bias, bn)
         if self.training and bn is not None:
             L = Lazy.of(x)
             n, _, h, w = L.shape
@@ -458,7 +490,7 @@ class SE(nn.Module):
         return ops.se_attention(xr, ld, n, hw, c, wa.contiguous(), wb.contiguous(), self.ratio)
 
     def forward(self, x):
-        ops.require_cuda(x, "SE", self)
+        x, _ = ops.edge_in(x, "SE", self)
         xr, ld = ops.rows(x)
         n, c, h, w = xr.shape
         return self.attention(xr, ld, n, h * w, c).view(n, c, 1, 1)
@@ -483,7 +515,7 @@ class RFCBAMConv(nn.Module):
         self.conv = nn.Sequential(nn.Conv2d(in_channel, out_channel, k, stride=k), nn.BatchNorm2d(out_channel), nn.ReLU())
         self._prep = _Prepared()
 
-    def _packed(self):
+    def _packed(self, planes=2):
         gw, gbn, cw, cbn = self.generate[0].weight, self.generate[1], self.conv[0], self.conv[1]
         key = pack.versions(gw, *_bn_tensors(gbn), cw.weight, cw.bias, *_bn_tensors(cbn), self.get_weight[0].weight) + (gbn.eps, cbn.eps)
 
@@ -494,14 +526,15 @@ class RFCBAMConv(nn.Module):
             es, eb = pack.bn_scale_shift(cbn, cw.bias)
             if k == 1:
                 a1 = (gw.detach().float().view(c) * gs).contiguous()
-                return dict(a1=a1, b1=gb, w18=w18, wp=pack.frag_pack3(cw.weight.detach().view(o, c)), es=es, eb=eb)
+                return dict(a1=a1, b1=gb, w18=w18, wp=pack.frag_pack3(cw.weight.detach().view(o, c), planes=planes), es=es, eb=eb)
             wq_stats = pack.rfcbam_gen_weights(gw, gs, gb, 32, False)           # stats kernel: 32-ch chunks, c0 + w + 4j
             wq_main = pack.rfcbam_gen_weights(gw, gs, gb, 16, True)             # main kernel: 16-ch chunks, c0 + 4w + j
             wk = torch.zeros(o, c // 16, 160, dtype=torch.float32, device=gw.device)      # 144 real k per 16-channel chunk
             wk[:, :, :144] = cw.weight.detach().float().reshape(o, c // 16, 16, 9).permute(0, 1, 3, 2).reshape(o, c // 16, 144)   # k = t*16 + ch
-            return dict(wq_stats=wq_stats, wq_main=wq_main, w18=w18, wp=pack.frag_pack3(wk.view(o, -1)), es=es, eb=eb)
-        return self._prep.get(key, build)
+            return dict(wq_stats=wq_stats, wq_main=wq_main, w18=w18, wp=pack.frag_pack3(wk.view(o, -1), planes=planes), es=es, eb=eb)
+        return self._prep.get(key, build, planes)
 
+    @_edge
     def forward(self, x):
         if isinstance(x, Lazy):
             x = x.materialize()
@@ -509,14 +542,13 @@ class RFCBAMConv(nn.Module):
         pr = _probe(x, (x.shape[0], self.o, (x.shape[2] + 2 * (k_ // 2) - k_) // s_ + 1, (x.shape[3] + 2 * (k_ // 2) - k_) // s_ + 1))
         if pr is not None:
             return pr
-        ops.require_cuda(x, "RFCBAMConv", self)
         if _grad_mode(self):
             from . import grad
             return grad.rfcbam_train(self, x)
         xr, ld = ops.rows(x)
         n, c, h, w = xr.shape
         k, s = self.kernel_size, self.stride
-        P = self._packed()
+        P = self._packed(ops.planes_of(xr))
         # The SE branch (global average pool + two tiny linears: latency-bound, a fraction of the GPU) is independent of the
         # receptive-field statistics below: it runs on a side stream and is joined just before the contraction that needs `ca`.
         # Only while a hipGraph is being captured (the fork/join then costs nothing at replay); in eager mode the extra event
@@ -638,11 +670,11 @@ class CoordAtt(nn.Module):
             w1, b1 = self._conv1_eval()
         return ops.coordatt_mlp(pool, n, h, w, c, self.mip, w1, b1, wh, bh, ww, bw)
 
+    @_edge
     def forward(self, x):
         pr = _probe(x, x.shape)
         if pr is not None:
             return pr
-        ops.require_cuda(x, "CoordAtt", self)
         if _grad_mode(self):
             from . import grad
             return grad.coordatt_train(self, x)
@@ -680,12 +712,11 @@ class CA_Bottleneck(nn.Module):
             return ops.coordatt_gate(t2, c, n, h, w, c, a_h, a_w, rr, ldr)
         return Lazy((n, c, h, w), t2, c, c, gate=(a_h, a_w), keep=(t2, a_h, a_w))
 
+    @_edge
     def forward(self, x):
         pr = _probe(x, (x.shape[0], self.cv2.c2, x.shape[2], x.shape[3])) if isinstance(x, torch.Tensor) else None
         if pr is not None:
             return pr
-        if not isinstance(x, Lazy):
-            ops.require_cuda(x, "CA_Bottleneck", self)
         y = self.forward_lazy(x)
         return y.materialize() if isinstance(y, Lazy) else y
 
@@ -702,13 +733,13 @@ class C3_CA(nn.Module):
         self._prep = _Prepared()
         self._prep_bn = _Prepared()
 
-    def _weights12(self):
+    def _weights12(self, planes=2):
         """cv1 and cv2 read the same input: one GEMM with stacked weights writes [cv1 | cv2] side by side,
         which is also exactly where the later concat wants cv2's output."""
         p1, p2 = self.cv1, self.cv2
         key = pack.versions(p1.conv.weight, p2.conv.weight)
         return self._prep.get(key, lambda: pack.frag_pack3(torch.cat((p1.conv.weight.detach().view(self.c_, -1),
-                                                                       p2.conv.weight.detach().view(self.c_, -1)), 0)))
+                                                                       p2.conv.weight.detach().view(self.c_, -1)), 0), planes=planes), planes)
 
     def _affine12_eval(self):
         p1, p2 = self.cv1, self.cv2
@@ -726,12 +757,11 @@ class C3_CA(nn.Module):
             return torch.cat((parts[0][0], parts[1][0])).contiguous(), torch.cat((parts[0][1], parts[1][1])).contiguous()
         return self._prep_bn.get(key, build)
 
+    @_edge
     def forward(self, x):
         pr = _probe(x, (x.shape[0], self.c2, x.shape[2], x.shape[3])) if isinstance(x, torch.Tensor) else None
         if pr is not None:
             return pr
-        if not isinstance(x, Lazy):
-            ops.require_cuda(x, "C3_CA", self)
         src = Lazy.of(x)
         n, c, h, w = src.shape
         c_ = self.c_
@@ -746,7 +776,7 @@ class C3_CA(nn.Module):
             ta, lda = ops.rows(a)
             tb, ldb = ops.rows(b)
             return self.cv3(Lazy((n_, ca_ + b.shape[1], h_, w_), ta, lda, ca_, a1=tb, lda1=ldb, keep=(ta, tb)))
-        wp = self._weights12()
+        wp = self._weights12(ops.planes_of(src.a0))
         b1, b2 = getattr(self.cv1, "bn", None), getattr(self.cv2, "bn", None)
         if self.training and b1 is not None and b2 is not None:
             stats = ops.new_stats(2 * c_, src.a0.device)
@@ -777,6 +807,7 @@ class SPPF(nn.Module):
         self.cv2 = Conv(c_ * 4, c2, 1, 1)
         self.m = nn.MaxPool2d(kernel_size=k, stride=1, padding=k // 2)
 
+    @_edge
     def forward(self, x):
         y = self.cv1(x)
         if SHAPE_PROBE and not y.is_cuda:
@@ -803,7 +834,8 @@ class Upsample(nn.Upsample):
 
     def forward(self, x):
         if self.lazy and not isinstance(x, Lazy) and x.dim() == 4 and x.is_cuda and self.mode == "nearest" \
-                and self.size is None and float(self.scale_factor) == 2.0 and x.shape[1] % 4 == 0:
+                and self.size is None and float(self.scale_factor) == 2.0 and x.shape[1] % ops.vw_of(x) == 0 \
+                and x.dtype in (torch.float32, torch.bfloat16):
             t, ld = ops.rows(x)
             n, c, h, w = t.shape
             return Lazy((n, c, 2 * h, 2 * w), t, ld, c, up=True, keep=(t,))
@@ -824,8 +856,9 @@ class Concat(nn.Module):
     def forward(self, x):
         if self.lazy and self.d == 1 and len(x) == 2 and not isinstance(x[1], Lazy) and x[1].is_cuda:
             a = Lazy.of(x[0])
-            if a.a1 is None and a.gate is None and a.shape[1] % 4 == 0 and x[1].shape[1] % 4 == 0 \
-                    and tuple(a.shape[2:]) == tuple(x[1].shape[2:]):
+            vw = ops.vw_of(x[1])
+            if a.a1 is None and a.gate is None and a.shape[1] % vw == 0 and x[1].shape[1] % vw == 0 and a.a0.dtype == x[1].dtype \
+                    and x[1].dtype in (torch.float32, torch.bfloat16) and tuple(a.shape[2:]) == tuple(x[1].shape[2:]):
                 t1, ld1 = ops.rows(x[1])
                 n, c0, h, w = a.shape
                 return Lazy((n, c0 + t1.shape[1], h, w), a.a0, a.lda0, c0, a1=t1, lda1=ld1, up=a.up, keep=(a.keep[0], t1))
@@ -851,15 +884,19 @@ class Detect(nn.Module):
         self.inplace = inplace
         self._prep = [_Prepared() for _ in ch]
 
-    def _head(self, i, x):
+    def _packed(self, i, planes):
         conv = self.m[i]
         key = pack.versions(conv.weight, conv.bias)
-        wp, b = self._prep[i].get(key, lambda: (pack.frag_pack3(conv.weight.detach().view(conv.out_channels, -1)),
-                                                 conv.bias.detach().float().contiguous()))
-        ldo = (conv.out_channels + 3) // 4 * 4
+        return self._prep[i].get(key, lambda: (pack.frag_pack3(conv.weight.detach().view(conv.out_channels, -1), planes=planes),
+                                               conv.bias.detach().float().contiguous()), planes)
+
+    def _head(self, i, x):
+        conv = self.m[i]
         L = Lazy.of(x)
+        wp, b = self._packed(i, ops.planes_of(L.a0))
+        ldo = (conv.out_channels + 3) // 4 * 4
         n, c, h, w = L.shape
-        buf = torch.empty((n, h, w, ldo), dtype=torch.float32, device=L.a0.device)
+        buf = torch.empty((n, h, w, ldo), dtype=L.a0.dtype, device=L.a0.device)
         _run_pointwise(L, wp, conv.out_channels, None, b, ACT_NONE, out=buf, ldo=ldo)
         return buf, ldo                                         # [n, h, w, ldo] rows, first na*no columns valid
 
@@ -871,18 +908,24 @@ class Detect(nn.Module):
         return self._stride_f
 
     def forward(self, x):
-        x = list(x)
+        x = [ops.edge_in(t, "Detect", self)[0] if isinstance(t, torch.Tensor) and not (SHAPE_PROBE and not t.is_cuda) else t for t in x]
+        with torch.autocast("cuda", enabled=False):
+            return self._fwd(x)
+
+    def _fwd(self, x):
         if _grad_mode(self):
             from . import grad
             for i in range(self.nl):
                 t = x[i].materialize() if isinstance(x[i], Lazy) else x[i]
                 conv = self.m[i]
-                key = pack.versions(conv.weight, conv.bias)
-                wp, _ = self._prep[i].get(key, lambda: (pack.frag_pack3(conv.weight.detach().view(conv.out_channels, -1)),
-                                                        conv.bias.detach().float().contiguous()))
+                wp, _ = self._packed(i, ops.planes_of(t))
                 y = grad.conv_bn_act(grad.ConvSpec("pw", conv.out_channels), wp, t, None, conv.weight, conv.bias, None)
                 bs, _, ny, nx = y.shape
-                x[i] = y.view(bs, self.na, self.no, ny, nx).permute(0, 1, 3, 4, 2).contiguous()
+                # raw maps go to the loss as fp32 whatever the storage dtype (the loss is fp32, as under the reference's autocast):
+                # the permuting copy and the conversion are one pass
+                p = torch.empty((bs, self.na, ny, nx, self.no), dtype=torch.float32, device=y.device)
+                p.copy_(y.view(bs, self.na, self.no, ny, nx).permute(0, 1, 3, 4, 2))
+                x[i] = p
             return x
         st = getattr(self, "_early", None)                      # levels already launched by Model._forward_once (side stream)
         self._early = None

@@ -1,7 +1,11 @@
 """Thin host wrappers over the C-ABI (capi.py): torch supplies device memory and the current stream,
 every arithmetic step is a HIP kernel in libleadyolo_hip.so.  Activations are logical NCHW tensors
 with channels_last (NHWC) storage; a channel slice of such a tensor (a slot of a concat buffer) is
-addressed as rows of stride `ld` without copying."""
+addressed as rows of stride `ld` without copying.
+
+Storage dtype: every wrapper takes it from its activation argument — float32 (bf16x3 products) or bfloat16 (plain bf16
+products, BASELINE configs[2]-[4]); outputs have the input's dtype, statistics / attention tables / weight gradients
+are float32.  `edge_in` is the dtype policy at a module's edge (autocast, .half())."""
 import ctypes
 
 import torch
@@ -83,16 +87,63 @@ def require_cuda(x, who, mod=None):
                                   "tensors detached from autograd — call .train(), or run inference under torch.no_grad()")
     if not x.is_cuda:
         raise RuntimeError(f"{who}: the HIP path needs a CUDA/ROCm tensor (got {x.device}); there is no CPU fallback")
-    if x.dtype != torch.float32:
-        raise NotImplementedError(f"{who}: only float32 activations are built so far (got {x.dtype})")
+    if x.dtype not in (torch.float32, torch.bfloat16):
+        raise NotImplementedError(f"{who}: activations must be float32 or bfloat16 here (got {x.dtype}); float16 is converted at the "
+                                  "module edge (ops.edge_in)")
+
+
+def edge_in(x, who, mod=None):
+    """Dtype policy at a module's edge (SURVEY §8b call contract: fp32, or fp16 under `autocast` / `.half()`, train.py:229,316).
+      * under torch.autocast('cuda', dtype) a float32 input is cast to the autocast dtype, as autocast does for convolutions;
+      * bfloat16 runs the bf16 kernels; float32 (outside autocast) the fp32-storage kernels;
+      * float16 (the reference's AMP dtype) has no kernels of its own: it is computed as bfloat16 (same 16-bit storage, wider
+        exponent, fp32 accumulation) and the module's output is cast back to float16, so neighbours still see fp16.
+    Returns (tensor to compute on, dtype to cast the output back to or None)."""
+    if not isinstance(x, torch.Tensor):
+        return x, None
+    if not x.is_cuda:
+        raise RuntimeError(f"{who}: the HIP path needs a CUDA/ROCm tensor (got {x.device}); there is no CPU fallback")
+    want = x.dtype
+    if torch.is_autocast_enabled() and x.dtype == torch.float32:
+        want = torch.get_autocast_gpu_dtype()
+    if want not in (torch.float32, torch.bfloat16, torch.float16):
+        raise NotImplementedError(f"{who}: unsupported activation dtype {x.dtype}")
+    compute = torch.bfloat16 if want == torch.float16 else want
+    back = torch.float16 if (want == torch.float16 and x.dtype != torch.bfloat16) else None
+    if x.dtype != compute:
+        x = x.to(compute)
+    require_cuda(x, who, mod)
+    return x, back
+
+
+def edge_out(y, back):
+    if back is None:
+        return y
+    if isinstance(y, torch.Tensor):
+        return y.to(back)
+    if isinstance(y, (list, tuple)):
+        return type(y)(edge_out(t, back) for t in y)
+    return y
+
+
+def planes_of(t):
+    """operand planes of the weight packs a kernel call on tensor / dtype `t` needs: 2 (bf16x3, fp32 storage) or 1 (bf16 storage)"""
+    d = t if isinstance(t, torch.dtype) else t.dtype
+    return 1 if d == torch.bfloat16 else 2
+
+
+def vw_of(t):
+    """elements of one 16-byte vector: channel counts / leading dimensions of contraction sources must be multiples of it"""
+    d = t if isinstance(t, torch.dtype) else t.dtype
+    return 8 if d == torch.bfloat16 else 4
 
 
 def nhwc(x):
     return x.contiguous(memory_format=torch.channels_last)
 
 
-def empty_nhwc(n, c, h, w, like):
-    return torch.empty((n, c, h, w), dtype=torch.float32, device=like.device, memory_format=torch.channels_last)
+def empty_nhwc(n, c, h, w, like, dtype=None):
+    return torch.empty((n, c, h, w), dtype=dtype or like.dtype, device=like.device, memory_format=torch.channels_last)
 
 
 def rows(x):
@@ -102,7 +153,8 @@ def rows(x):
     if x.is_contiguous(memory_format=torch.channels_last) and x.stride(1) == 1:
         return x, c
     sn, sc, sh, sw = x.stride()
-    if sc == 1 and sw >= c and sw % 4 == 0 and (h == 1 or sh == w * sw) and (n == 1 or sn == h * w * sw) and w > 1:
+    if sc == 1 and sw >= c and sw % vw_of(x) == 0 and (h == 1 or sh == w * sw) and (n == 1 or sn == h * w * sw) and w > 1 \
+            and x.data_ptr() % 16 == 0:
         return x, sw
     x = nhwc(x)
     if x.stride(1) != 1:        # degenerate shapes where torch reports ambiguous strides
@@ -116,26 +168,40 @@ def _p(t):
 
 def gemm(*, M, H, W, K, N, a0, lda0, k0, wp, out, ldo, a1=None, lda1=0, gather=GATHER_ROWS, Hin=0, Win=0, Cin=0, ks=0, pk=0,
          pro=PRO_NONE, g_h=None, g_w=None, res=None, ldres=0, p_scale=None, p_shift=None, p_ca=None, e_scale=None,
-         e_shift=None, rowscale=None, act=ACT_NONE, stats=None):
+         e_shift=None, rowscale=None, act=ACT_NONE, stats=None, dtype=None):
+    # element type of the call: the output's (statistics passes: the source's); the NCHW image gather always READS fp32
+    dt = (out if out is not None else a0).dtype if gather != GATHER_PATCH_NCHW or out is not None else torch.float32
+    if dtype is not None:
+        dt = dtype
+    code = capi.dtype_code(dt)
     P = capi.LyGemmParams(M, H, W, K, N, _p(a0), lda0, k0, _p(a1), lda1, gather, Hin, Win, Cin, ks, pk, pro, _p(g_h), _p(g_w),
                           _p(res), ldres, _p(p_scale), _p(p_shift), _p(p_ca), _p(wp), _p(e_scale), _p(e_shift), _p(rowscale),
-                          act, _p(out), ldo, _p(stats))
+                          act, _p(out), ldo, _p(stats), code)
     nt, mt, wc = gemm_config(N)
-    with _Timed(f"ly_gemm_kernel_d2<{nt}, {mt}, {wc}, {gather}, {pro}>", 2.0 * M * K * N, 4.0 * (M * (K + N) + N * K)):
+    ti = "float" if (code == 0 or gather == GATHER_PATCH_NCHW) else "__bf16"
+    to = "float" if code == 0 else "__bf16"
+    es_i, es_o = (4 if ti == "float" else 2), (4 if to == "float" else 2)
+    with _Timed(f"ly_gemm_kernel_d2<{ti}, {to}, {nt}, {mt}, {wc}, {gather}, {pro}>", 2.0 * M * K * N, es_i * M * K + es_o * M * N + 4.0 * N * K):
         capi.check(capi.lib().ly_gemm_fwd(ctypes.byref(P), capi.stream_ptr()), "ly_gemm_fwd")
 
 
 def conv3x3(*, M, H, W, Cin, N, x, ldx, wp, out, ldo, e_scale=None, e_shift=None, act=ACT_NONE, stats=None):
     th, tw = pick_conv_tile(H, W)
-    P = capi.LyConv3Params(M, H, W, Cin, N, th, tw, _p(x), ldx, _p(wp), _p(e_scale), _p(e_shift), act, _p(out), ldo, _p(stats))
+    code = capi.dtype_code(x)
+    P = capi.LyConv3Params(M, H, W, Cin, N, th, tw, _p(x), ldx, _p(wp), _p(e_scale), _p(e_shift), act, _p(out), ldo, _p(stats), code)
     mt, wc = (2, 4) if N > 64 else (2, 2)
-    with _Timed(f"ly_conv3x3_kernel<{mt}, {wc}>", 2.0 * M * 9 * Cin * N, 4.0 * (M * (Cin + N) + 9 * Cin * N)):
+    with _Timed(f"ly_conv3x3_kernel<{_tname(x)}, {mt}, {wc}>", 2.0 * M * 9 * Cin * N, x.element_size() * M * (Cin + N) + 4.0 * 9 * Cin * N):
         capi.check(capi.lib().ly_conv3x3_fwd(ctypes.byref(P), capi.stream_ptr()), "ly_conv3x3_fwd")
+
+
+def _tname(t):
+    return "float" if t.dtype == torch.float32 else "__bf16"
 
 
 def pool_hw(x, ldx, n, h, w, c):
     pool = torch.empty((n, h + w, c), dtype=torch.float32, device=x.device)
-    capi.check(capi.lib().ly_pool_hw(_p(x), ldx, n, h, w, c, _p(pool), capi.stream_ptr()), "ly_pool_hw")
+    with _Timed(f"ly_pool_hw_kernel<{_tname(x)}>", 1.0 * n * h * w * c, x.element_size() * n * h * w * c):
+        capi.check(capi.lib().ly_pool_hw(_p(x), ldx, n, h, w, c, _p(pool), capi.dtype_code(x), capi.stream_ptr()), "ly_pool_hw")
     return pool
 
 
@@ -149,8 +215,9 @@ def coordatt_mlp(pool, n, h, w, c, mip, w1, b1, wh, bh, ww, bw):
 
 def coordatt_gate(x, ldx, n, h, w, c, a_h, a_w, res=None, ldres=0):
     out = empty_nhwc(n, c, h, w, x)
-    capi.check(capi.lib().ly_coordatt_gate(_p(x), ldx, n, h, w, c, _p(a_h), _p(a_w), _p(res), ldres, _p(out), c,
-                                           capi.stream_ptr()), "ly_coordatt_gate")
+    with _Timed(f"ly_gate_kernel<{_tname(x)}>", 2.0 * n * h * w * c, 2.0 * x.element_size() * n * h * w * c):
+        capi.check(capi.lib().ly_coordatt_gate(_p(x), ldx, n, h, w, c, _p(a_h), _p(a_w), _p(res), ldres, _p(out), c, capi.dtype_code(x),
+                                               capi.stream_ptr()), "ly_coordatt_gate")
     return out
 
 
@@ -159,8 +226,9 @@ def se_attention(x, ldx, n, hw, c, wa, wb, r):
                                                   # per-block row loops: the pass is latency-bound, not bandwidth-bound
     part = torch.empty((n, slices, c), dtype=torch.float32, device=x.device)
     ca = torch.empty((n, c), dtype=torch.float32, device=x.device)
-    capi.check(capi.lib().ly_se_fwd(_p(x), ldx, n, hw, c, _p(wa), _p(wb), r, _p(part), slices, _p(ca), capi.stream_ptr()),
-               "ly_se_fwd")
+    with _Timed(f"ly_colsum_kernel<{_tname(x)}> + ly_se_mlp_kernel", 1.0 * n * hw * c, x.element_size() * n * hw * c):
+        capi.check(capi.lib().ly_se_fwd(_p(x), ldx, n, hw, c, _p(wa), _p(wb), r, _p(part), slices, _p(ca), capi.dtype_code(x), capi.stream_ptr()),
+                   "ly_se_fwd")
     return ca
 
 
@@ -185,27 +253,29 @@ def pick_tile(ho, wo):
 def rfcbam_stats(x, ldx, n, h, w, c, k, s, wg=None, a1=None, b1=None, th=1, tw=64):
     ho, wo = ((h + 2 * (k // 2) - k) // s + 1, (w + 2 * (k // 2) - k) // s + 1)
     mm = torch.empty((n, k * ho, k * wo, 2), dtype=torch.float32, device=x.device)
-    with _Timed("ly_rfcbam_stats3_kernel" if k == 3 else "ly_rfcbam_stats1_kernel", 2.0 * n * ho * wo * c * (81 if k == 3 else 1),
-                4.0 * (n * h * w * c + 2 * k * k * n * ho * wo)):
-        capi.check(capi.lib().ly_rfcbam_stats(_p(x), ldx, n, h, w, c, k, s, _p(wg), _p(a1), _p(b1), th, tw, _p(mm), capi.stream_ptr()),
-                   "ly_rfcbam_stats")
+    with _Timed(f"ly_rfcbam_stats{k}_kernel<{_tname(x)}>", 2.0 * n * ho * wo * c * (81 if k == 3 else 1),
+                x.element_size() * n * h * w * c + 4.0 * 2 * k * k * n * ho * wo):
+        capi.check(capi.lib().ly_rfcbam_stats(_p(x), ldx, n, h, w, c, k, s, _p(wg), _p(a1), _p(b1), th, tw, _p(mm), capi.dtype_code(x),
+                                              capi.stream_ptr()), "ly_rfcbam_stats")
     return mm
 
 
 def rfa_map(mm, w18):
     n, hk, wk, _ = mm.shape
     rfa = torch.empty((n, hk, wk), dtype=torch.float32, device=mm.device)
-    capi.check(capi.lib().ly_rfa_map(_p(mm), n, hk, wk, _p(w18), _p(rfa), capi.stream_ptr()), "ly_rfa_map")
+    with _Timed("ly_rfa_map_kernel", 36.0 * n * hk * wk, 12.0 * n * hk * wk):
+        capi.check(capi.lib().ly_rfa_map(_p(mm), n, hk, wk, _p(w18), _p(rfa), capi.stream_ptr()), "ly_rfa_map")
     return rfa
 
 
 def rfcbam3(*, n, h, w, c, ho, wo, N, s, th, tw, x, ldx, wg, ca, rfa, wp, e_scale, e_shift, out, ldo, stats=None, linear=False):
     P = capi.LyRfcbam3Params(n, h, w, c, ho, wo, N, s, th, tw, _p(x), ldx, _p(wg), _p(ca), _p(rfa), _p(wp), _p(e_scale),
-                             _p(e_shift), _p(out), ldo, _p(stats), int(linear))
+                             _p(e_shift), _p(out), ldo, _p(stats), int(linear), capi.dtype_code(x))
     mt = 4 if N > 128 else (2 if N > 64 else 1)            # mirrors ly_rfcbam3_fwd
     mo = n * ho * wo
     sw = mt == 4 and n * -(-ho // th) * -(-wo // tw) * -(-N // 256) > 256    # mirrors launch_rf3: weights via the scalar cache
-    with _Timed(f"ly_rfcbam3{'_sw' if sw else ''}_kernel<{mt}>", 2.0 * mo * (9 * c * N + 81 * c), 4.0 * (n * h * w * c + mo * N + 9 * c * N)):
+    with _Timed(f"ly_rfcbam3{'_sw' if sw else ''}_kernel<{_tname(x)}, {mt}>", 2.0 * mo * (9 * c * N + 81 * c),
+                x.element_size() * (n * h * w * c + mo * N) + 4.0 * 9 * c * N):
         capi.check(capi.lib().ly_rfcbam3_fwd(ctypes.byref(P), capi.stream_ptr()), "ly_rfcbam3_fwd")
 
 
@@ -214,28 +284,30 @@ def sppf_pool_fits(h, w):
 
 
 def sppf_pool(x, ldx, n, h, w, c, k, out, ldo):
-    capi.check(capi.lib().ly_sppf_pool(_p(x), ldx, n, h, w, c, k, _p(out), ldo, capi.stream_ptr()), "ly_sppf_pool")
+    with _Timed(f"ly_sppf_pool_kernel<{_tname(x)}>", 0.0, 5.0 * x.element_size() * n * h * w * c):
+        capi.check(capi.lib().ly_sppf_pool(_p(x), ldx, n, h, w, c, k, _p(out), ldo, capi.dtype_code(x), capi.stream_ptr()), "ly_sppf_pool")
 
 
 def detect_tail(y, ldy, n, h, w, na, no, anchors, stride, p, z, zrows, zoff):
     capi.check(capi.lib().ly_detect_tail(_p(y), ldy, n, h, w, na, no, _p(anchors), float(stride), _p(p), _p(z), zrows, zoff,
-                                         capi.stream_ptr()), "ly_detect_tail")
+                                         capi.dtype_code(y), capi.stream_ptr()), "ly_detect_tail")
 
 
 def mlpblock(x, y, n, h, w, c, wp, w1, w2, sc, sh, stats=None):
     m = n * h * w
     cc, nt, ht, t2d = mlp_config(c, m, w)
     kind = "_ring" if c >= 80 else "_occ4" if (c <= 24 and t2d == "true") else ""
-    name = f"ly_mlpblock_fwd{kind}_kernel<{cc}, {nt}, {ht}, {t2d}, {'true' if stats is not None else 'false'}>"
+    name = f"ly_mlpblock_fwd{kind}_kernel<{_tname(x)}, {cc}, {nt}, {ht}, {t2d}, {'true' if stats is not None else 'false'}>"
     with _Timed(name, 2.0 * m * (9 * (c // 4) ** 2 + 4 * c * c),
-                4.0 * (2 * m * c + 9 * (c // 4) ** 2 + 4 * c * c)):
-        capi.check(capi.lib().ly_mlpblock_fwd(_p(x), _p(y), n, h, w, c, _p(wp), _p(w1), _p(w2), _p(sc), _p(sh), _p(stats), capi.stream_ptr()),
-                   "ly_mlpblock_fwd")
+                x.element_size() * (1 if stats is not None else 2) * m * c + 4.0 * (9 * (c // 4) ** 2 + 4 * c * c)):
+        capi.check(capi.lib().ly_mlpblock_fwd(_p(x), _p(y), n, h, w, c, _p(wp), _p(w1), _p(w2), _p(sc), _p(sh), _p(stats), capi.dtype_code(x),
+                                              capi.stream_ptr()), "ly_mlpblock_fwd")
 
 
 def chan_moments(x, ldx, rows, c):
     mom = new_stats(c, x.device)
-    capi.check(capi.lib().ly_chan_moments(_p(x), ldx, rows, c, _p(mom), capi.stream_ptr()), "ly_chan_moments")
+    with _Timed(f"ly_chan_moments_kernel<{_tname(x)}>", 3.0 * rows * c, x.element_size() * rows * c):
+        capi.check(capi.lib().ly_chan_moments(_p(x), ldx, rows, c, _p(mom), capi.dtype_code(x), capi.stream_ptr()), "ly_chan_moments")
     return mom.sum(0)
 
 
@@ -300,6 +372,9 @@ def bn_finalize(bn, stats, nch, count, n=None, c_off=0, bias=None, pad_to=0, wan
     mean = torch.empty(n, dtype=torch.float32, device=dev) if want_stats else None
     invstd = torch.empty(n, dtype=torch.float32, device=dev) if want_stats else None
     track = bn.track_running_stats and bn.running_mean is not None
+    if bn.weight is not None and bn.weight.dtype != torch.float32:
+        raise NotImplementedError("train-mode BatchNorm needs float32 parameters and buffers: train under torch.autocast (fp32 master "
+                                  "weights, as the reference does), not with a .half()/.bfloat16() model")
     if track and bn.momentum is None:
         raise NotImplementedError("BatchNorm with momentum=None (cumulative average) is not built")
     capi.check(capi.lib().ly_bn_finalize(_p(stats), stats.shape[0], nch, c_off, n, float(count), _p(bn.weight), _p(bn.bias), _p(bias), float(bn.eps),
@@ -341,7 +416,8 @@ def rfcbam_generate_stats(x, ldx, n, h, w, c, s, gen_w):
     (c*9 + t) and the sample count, from the per-channel tap moments (see ly_rfcbam_tap_moments)."""
     global _TRIU
     mom = torch.zeros(54, c, dtype=torch.float32, device=x.device)
-    capi.check(capi.lib().ly_rfcbam_tap_moments(_p(x), ldx, n, h, w, c, s, _p(mom), capi.stream_ptr()), "ly_rfcbam_tap_moments")
+    with _Timed(f"ly_rfcbam_tap_moments_kernel<{_tname(x)}>", 108.0 * n * h * w * c / (s * s), x.element_size() * n * h * w * c):
+        capi.check(capi.lib().ly_rfcbam_tap_moments(_p(x), ldx, n, h, w, c, s, _p(mom), capi.dtype_code(x), capi.stream_ptr()), "ly_rfcbam_tap_moments")
     if _TRIU is None or _TRIU[0].device != x.device:
         iu = torch.triu_indices(9, 9, device=x.device)
         _TRIU = (iu[0], iu[1])
@@ -374,38 +450,58 @@ def bn_batch_stats(bn, s1, s2, count):
 
 
 def bnact_fwd(u, ldu, rows, c, a, b, act, y, ldy):
-    with _Timed("ly_bnact_fwd_kernel", 4.0 * rows * c, 8.0 * rows * c):
-        capi.check(capi.lib().ly_bnact_fwd(_p(u), ldu, rows, c, _p(a), _p(b), act, _p(y), ldy, capi.stream_ptr()), "ly_bnact_fwd")
+    with _Timed(f"ly_bnact_fwd_kernel<{_tname(u)}, {act}>", 4.0 * rows * c, 2.0 * u.element_size() * rows * c):
+        capi.check(capi.lib().ly_bnact_fwd(_p(u), ldu, rows, c, _p(a), _p(b), act, _p(y), ldy, capi.dtype_code(u), capi.stream_ptr()), "ly_bnact_fwd")
 
 
 def bnact_bwd_reduce(dy, lddy, u, ldu, rows, c, a, b, act):
     sums = new_stats(c, u.device)
-    with _Timed("ly_bnact_bwd_reduce_kernel", 6.0 * rows * c, 8.0 * rows * c):
-        capi.check(capi.lib().ly_bnact_bwd_reduce(_p(dy), lddy, _p(u), ldu, rows, c, _p(a), _p(b), act, _p(sums), capi.stream_ptr()),
-                   "ly_bnact_bwd_reduce")
+    with _Timed(f"ly_bnact_bwd_reduce_kernel<{_tname(u)}, {act}>", 6.0 * rows * c, 2.0 * u.element_size() * rows * c):
+        capi.check(capi.lib().ly_bnact_bwd_reduce(_p(dy), lddy, _p(u), ldu, rows, c, _p(a), _p(b), act, _p(sums), capi.dtype_code(u),
+                                                  capi.stream_ptr()), "ly_bnact_bwd_reduce")
     return sums
 
 
 def bnact_bwd_apply(dy, lddy, u, ldu, rows, c, a, b, act, alpha, kappa, lam, du, lddu):
-    with _Timed("ly_bnact_bwd_apply_kernel", 8.0 * rows * c, 12.0 * rows * c):
+    with _Timed(f"ly_bnact_bwd_apply_kernel<{_tname(u)}, {act}>", 8.0 * rows * c, 3.0 * u.element_size() * rows * c):
         capi.check(capi.lib().ly_bnact_bwd_apply(_p(dy), lddy, _p(u), ldu, rows, c, _p(a), _p(b), act, _p(alpha), _p(kappa), _p(lam),
-                                                 _p(du), lddu, capi.stream_ptr()), "ly_bnact_bwd_apply")
+                                                 _p(du), lddu, capi.dtype_code(u), capi.stream_ptr()), "ly_bnact_bwd_apply")
 
 
 def wgrad(*, M, H, W, N, du, lddu, x, ldx, Hin, Win, Cin, dw, lddw, ks=1, stride=1, pad=0, nchw=False, up2=False, du_off=0, x_off=0,
           dw_off=0):
     """dw[n][tap*Cin + c] += sum_pixels du[p][n] * x[src(p, tap)][c]; *_off are element offsets into the tensors."""
     def at(t, off):
-        return ctypes.c_void_p(t.data_ptr() + 4 * off)
+        return ctypes.c_void_p(t.data_ptr() + t.element_size() * off)
+    if du.dtype != x.dtype:
+        raise capi.HipLibraryError(f"wgrad: du ({du.dtype}) and x ({x.dtype}) must share one storage dtype")
     P = capi.LyWgradParams(M, H, W, N, at(du, du_off), lddu, at(x, x_off), ldx, Hin, Win, Cin, ks, stride, pad, int(nchw), int(up2),
-                           at(dw, dw_off), lddw)
-    with _Timed("ly_wgrad_kernel", 2.0 * M * N * ks * ks * Cin, 4.0 * (M * (N + Cin) + N * ks * ks * Cin)):
+                           at(dw, dw_off), lddw, capi.dtype_code(x))
+    with _Timed(wgrad_kernel_name(_tname(x), N, ks * ks * Cin, ks == 1 and stride == 1 and pad == 0 and not nchw and not up2,
+                                  (not nchw) and N % 4 == 0 and Cin % 4 == 0 and lddu % 4 == 0 and ldx % 4 == 0),
+                2.0 * M * N * ks * ks * Cin, x.element_size() * M * (N + Cin) + 4.0 * N * ks * ks * Cin):
         capi.check(capi.lib().ly_wgrad(ctypes.byref(P), capi.stream_ptr()), "ly_wgrad")
+
+
+def wgrad_kernel_name(t, n, ktot, rows, tiled):
+    """mirror of the tile dispatch in csrc/ly_backward.hip (wgrad_dispatch): the kernel name rocprofv3 prints"""
+    r = "true" if rows else "false"
+    if not tiled:
+        return f"ly_wgrad_kernel<{t}, {r}>"
+    if n <= 64 and ktot <= 64:
+        bn, bk, px = 64, 64, 64
+    elif n <= 32:
+        bn, bk, px = 32, 128, 32
+    elif n <= 64:
+        bn, bk, px = 64, 128, 32
+    else:
+        bn, bk, px = 128, 128, 32
+    return f"ly_wgrad_tiled_kernel<{t}, {bn}, {bk}, {px}, {r}>"
 
 
 def up2_bwd(d, ldd, n, hs, ws, c):
     out = empty_nhwc(n, c, hs, ws, d)
-    capi.check(capi.lib().ly_up2_bwd(_p(d), ldd, n, hs, ws, c, _p(out), c, capi.stream_ptr()), "ly_up2_bwd")
+    capi.check(capi.lib().ly_up2_bwd(_p(d), ldd, n, hs, ws, c, _p(out), c, capi.dtype_code(d), capi.stream_ptr()), "ly_up2_bwd")
     return out
 
 
@@ -415,7 +511,7 @@ def unpatch(g, n, ho, wo, c, ks, h, w):
     if not exact:
         raise NotImplementedError("patch-gather backward needs H, W divisible by the patch size")
     dx = empty_nhwc(n, c, h, w, g)
-    capi.check(capi.lib().ly_unpatch(_p(g), n, ho, wo, c, ks, _p(dx), capi.stream_ptr()), "ly_unpatch")
+    capi.check(capi.lib().ly_unpatch(_p(g), n, ho, wo, c, ks, _p(dx), capi.dtype_code(g), capi.stream_ptr()), "ly_unpatch")
     return dx
 
 
@@ -423,18 +519,21 @@ def coordatt_gate_bwd(dout, x, ldx, n, h, w, c, a_h, a_w):
     dx = empty_nhwc(n, c, h, w, dout)
     da_h = torch.zeros((n, h, c), dtype=torch.float32, device=dout.device)
     da_w = torch.zeros((n, w, c), dtype=torch.float32, device=dout.device)
-    capi.check(capi.lib().ly_coordatt_gate_bwd(_p(dout), c, _p(x), ldx, n, h, w, c, _p(a_h), _p(a_w), _p(dx), c, _p(da_h), _p(da_w),
-                                               capi.stream_ptr()), "ly_coordatt_gate_bwd")
+    with _Timed(f"ly_coordatt_gate_bwd_kernel<{_tname(x)}>", 6.0 * n * h * w * c, 3.0 * x.element_size() * n * h * w * c):
+        capi.check(capi.lib().ly_coordatt_gate_bwd(_p(dout), c, _p(x), ldx, n, h, w, c, _p(a_h), _p(a_w), _p(dx), c, _p(da_h), _p(da_w),
+                                                   capi.dtype_code(x), capi.stream_ptr()), "ly_coordatt_gate_bwd")
     return dx, da_h, da_w
 
 
-def pool_hw_bwd(gp, n, h, w, c):
-    dx = empty_nhwc(n, c, h, w, gp)
-    capi.check(capi.lib().ly_pool_hw_bwd(_p(gp), n, h, w, c, _p(dx), c, capi.stream_ptr()), "ly_pool_hw_bwd")
+def pool_hw_bwd(gp, n, h, w, c, dtype=torch.float32):
+    dx = empty_nhwc(n, c, h, w, gp, dtype=dtype)
+    capi.check(capi.lib().ly_pool_hw_bwd(_p(gp), n, h, w, c, _p(dx), c, capi.dtype_code(dtype), capi.stream_ptr()), "ly_pool_hw_bwd")
     return dx
 
 
 def maxpool_bwd(x, x_off, ldx, dy, dy_off, lddy, n, h, w, c, k, dx, dx_off, lddx):
-    at = lambda t, off: ctypes.c_void_p(t.data_ptr() + 4 * off)
-    capi.check(capi.lib().ly_maxpool_bwd(at(x, x_off), ldx, at(dy, dy_off), lddy, n, h, w, c, k, at(dx, dx_off), lddx, capi.stream_ptr()),
-               "ly_maxpool_bwd")
+    """x: the pooled map (storage dtype); dy / dx: ALWAYS float32 (the gradient is accumulated with float atomics)"""
+    at = lambda t, off: ctypes.c_void_p(t.data_ptr() + t.element_size() * off)
+    assert dy.dtype == torch.float32 and dx.dtype == torch.float32
+    capi.check(capi.lib().ly_maxpool_bwd(at(x, x_off), ldx, at(dy, dy_off), lddy, n, h, w, c, k, at(dx, dx_off), lddx, capi.dtype_code(x),
+                                         capi.stream_ptr()), "ly_maxpool_bwd")

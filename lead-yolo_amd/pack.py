@@ -43,28 +43,28 @@ def versions(*tensors):
     return tuple((t.data_ptr(), t._version) if t is not None else None for t in tensors)
 
 
-def frag_pack3(w2d, rows_to=0):
-    """bf16x3 operand packing (csrc/ly_tile.cuh): W[R, K] fp32 -> int16 tensor [T, S, 2, 64, 8]
-    (planes hi = bf16(W), lo = bf16(W - hi)); lane = q*16 + i holds row 16t + i and
-    k = 32s + 16*(j >> 2) + 4q + (j & 3), j = 0..7.  Zero padded to 16 x 32 multiples."""
+def frag_pack3(w2d, rows_to=0, planes=2):
+    """MFMA operand packing (csrc/ly_tile.cuh): W[R, K] fp32 -> int16 tensor [T, S, planes, 64, 8]; planes = 2: hi = bf16(W),
+    lo = bf16(W - hi) (the bf16x3 operand of the fp32-storage kernels), planes = 1: hi only (bf16-storage kernels).
+    lane = q*16 + i holds row 16t + i and k = 32s + 16*(j >> 2) + 4q + (j & 3), j = 0..7.  Zero padded to 16 x 32 multiples."""
     r, k = w2d.shape
     t, s = _ceil(max(r, rows_to), 16), _ceil(k, 32)
     if w2d.is_cuda:                                   # one HIP launch (ly_frag_pack3); strides cover transposed views
         from . import capi
         if w2d.dtype != torch.float32:
             w2d = w2d.float()
-        out = torch.empty((t, s, 2, 64, 8), dtype=torch.int16, device=w2d.device)
-        capi.check(capi.lib().ly_frag_pack3(capi.ptr(w2d), r, k, w2d.stride(0), w2d.stride(1), rows_to, capi.ptr(out), capi.stream_ptr()),
+        out = torch.empty((t, s, planes, 64, 8), dtype=torch.int16, device=w2d.device)
+        capi.check(capi.lib().ly_frag_pack3(capi.ptr(w2d), r, k, w2d.stride(0), w2d.stride(1), rows_to, planes, capi.ptr(out), capi.stream_ptr()),
                    "ly_frag_pack3")
         return out
     wp = torch.zeros(t * 16, s * 32, dtype=torch.float32, device=w2d.device)
     wp[:r, :k] = w2d.float()
     hi = wp.to(torch.bfloat16)
     lo = (wp - hi.float()).to(torch.bfloat16)
-    planes = torch.stack((hi, lo), 0)                                   # [2, T*16, S*32]
+    pl = torch.stack((hi, lo), 0)[:planes]                              # [planes, T*16, S*32]
     # [p, t, i, s, jh, q, jl] -> [t, s, p, q, i, jh, jl]
-    v = planes.view(2, t, 16, s, 2, 4, 4).permute(1, 3, 0, 5, 2, 4, 6).contiguous()
-    return v.view(t, s, 2, 64, 8).view(torch.int16)
+    v = pl.view(planes, t, 16, s, 2, 4, 4).permute(1, 3, 0, 5, 2, 4, 6).contiguous()
+    return v.view(t, s, planes, 64, 8).view(torch.int16)
 
 
 def pad_to(v, n):

@@ -1,0 +1,198 @@
+"""bf16 storage path (BASELINE.json configs[2]-[4]: bf16 activations / saved tensors / activation gradients, plain bf16 MFMA
+products, fp32 accumulation, fp32 BatchNorm statistics and master weights) vs the fp32 oracle.
+
+Tolerance (stated, not tuned per case): every tensor that crosses HBM is rounded to bf16 (relative 2^-9 per element), every
+product uses bf16-rounded operands.  For a module with R rounding stages between input and output the relative L2 error is
+bounded by ~R * 2^-8; R <= 8 for the deepest fused module (C3_CA with n = 3), so modules must satisfy
+    ||got - want|| <= 8 * 2^-8 * ||want||   (= 3.1e-2)       and      max|got - want| <= 2^-4 * max|want|
+(the second catches single wild elements).  Gradients: the same bound on the relative L2 error per tensor, plus cosine >= 0.995.
+The fp32 path keeps its 1e-3 elementwise bound (tests/test_gpu_modules.py)."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import functional as OF
+from oracle import synth
+from tests import golden_util as G
+from tests.test_gpu_modules import CASES, GOLDEN_MODULES, _bn_eps, _cfg, _ctor, _dev, _load, _oracle
+
+pytestmark = pytest.mark.gpu
+
+REL_L2 = 8 * 2.0 ** -8
+MAX_REL = 2.0 ** -4
+BF = torch.bfloat16
+
+
+def _close(got, want, what, rel=REL_L2, mx=MAX_REL):
+    got = got.detach().float().cpu()
+    want = want.detach().float() if isinstance(want, torch.Tensor) else torch.from_numpy(np.asarray(want)).float()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    assert torch.isfinite(got).all(), what
+    nw = float(want.norm())
+    l2 = float((got - want).norm()) / max(nw, 1e-12)
+    me = float((got - want).abs().max()) / max(float(want.abs().max()), 1e-12)
+    assert l2 <= rel and me <= mx, f"{what}: relative L2 {l2:.3e} (bound {rel:.2e}), max error / max |want| {me:.3e} (bound {mx:.2e})"
+    return l2
+
+
+@pytest.mark.parametrize("name", G.names("basicstage") + GOLDEN_MODULES)
+def test_module_eval_golden_bf16(name):
+    """every hot-path module, bf16 storage, vs the vectors the reference itself produced (fp32)"""
+    meta, arr = G.load(name)
+    st = G.state_for(meta)
+    x = synth.synth_input(meta["in_shape"], meta["seed"] + 1)
+    m = _bn_eps(_load(_ctor(meta["kind"])(*meta["ctor"]), st)).to(_dev()).eval()
+    with torch.no_grad():
+        y = m(x.to(_dev()).to(BF))
+    assert y.dtype == BF
+    _close(y, arr["y_eval"], name)
+
+
+@pytest.mark.parametrize("kind,ctor,shape", CASES)
+def test_module_shapes_vs_oracle_bf16(kind, ctor, shape):
+    """real layer shapes, ragged tiles, odd sizes, n>1 bottlenecks, shortcut — bf16 storage"""
+    if kind == "RFCBAMConv" and ctor[0] % 8:
+        pytest.skip("bf16 needs channels % 8 == 0")
+    torch.manual_seed(0)
+    m = _ctor(kind)(*ctor)
+    st = synth.synth_state(synth.shapes_of(m.state_dict()), 9000 + sum(shape) + len(kind))
+    _bn_eps(_load(m, st))
+    x = synth.synth_input(shape, 31 + shape[1])
+    want = _oracle(kind, list(ctor), st, x)
+    with torch.no_grad():
+        got = m.to(_dev()).eval()(x.to(_dev()).to(BF))
+    assert got.dtype == BF
+    _close(got, want, f"{kind}{ctor} {shape}")
+
+
+TRAIN_MODULES = G.names("basicstage") + G.names("patch") + G.names("coordatt") + G.names("cabottleneck") + G.names("c3ca") + G.names("sppf") \
+    + G.names("rfcbam")
+
+
+@pytest.mark.parametrize("name", TRAIN_MODULES)
+def test_module_train_forward_and_backward_bf16(name):
+    """train-mode forward (batch-statistics BN from fp32 accumulators), running-stat updates and the input gradient, bf16 storage,
+    vs the reference's fp32 vectors"""
+    meta, arr = G.load(name)
+    st = G.state_for(meta)
+    x = synth.synth_input(meta["in_shape"], meta["seed"] + 1)
+    m = _bn_eps(_load(_ctor(meta["kind"])(*meta["ctor"]), st)).to(_dev()).train()
+    image = x.shape[1] == 3
+    xd = x.to(_dev()) if image else x.to(_dev()).to(BF).requires_grad_(True)
+    with torch.autocast("cuda", dtype=BF):
+        y = m(xd)
+    assert y.dtype == BF
+    _close(y, arr["y_train"], name + " y_train")
+    sd = m.state_dict()
+    for k in arr:
+        if k.startswith("post_"):
+            _close(sd[k[5:]], arr[k], name + " " + k)
+    if image or "dx_train" not in arr:
+        return
+    # the fixture's cotangent: the generator recipe of oracle/gen_golden.py (r = synth_input(y.shape, seed + 2))
+    dy = synth.synth_input(tuple(arr["y_train"].shape), meta["seed"] + 2)
+    y.backward(dy.to(_dev()).to(BF))
+    got, want = xd.grad.float().cpu(), torch.from_numpy(arr["dx_train"])
+    cos = float((got * want).sum() / (got.norm() * want.norm()))
+    assert cos >= 0.995, (name, cos)
+    _close(got, want, name + " dx", rel=2 * REL_L2, mx=4 * MAX_REL)
+
+
+@pytest.mark.parametrize("scale,hw,bs", [("n", (64, 64), 2), ("s", (640, 640), 2), ("l", (320, 320), 1)])
+def test_whole_model_eval_bf16(scale, hw, bs):
+    """whole detector, bf16 storage end to end (image fp32 -> PatchEmbed writes bf16), decoded rows vs the fp32 oracle.  24 layers
+    deep: the bound is the per-module one times sqrt(depth)."""
+    import lead_yolo_amd as L
+    torch.manual_seed(0)
+    m = L.Model(_cfg(scale))
+    st = synth.synth_state(synth.shapes_of(m.state_dict()), 6100 + hw[0])
+    st["model.23.anchors"] = m.model[-1].anchors.clone()
+    m.load_state_dict(st)
+    x = synth.synth_images(bs, max(hw), 11)[:, :, :hw[0], :hw[1]].float() / 255
+    with torch.no_grad():
+        zo, outs_o = OF.model_forward(copy.deepcopy(st), _cfg(scale), x, m.stride, training=False)
+        with torch.autocast("cuda", dtype=BF):
+            z, outs = m.to(_dev()).eval()(x.to(_dev()))
+    assert z.dtype == torch.float32          # decoded rows and raw maps leave Detect as fp32
+    for i, (a, b) in enumerate(zip(outs, outs_o)):
+        _close(a, b, f"model_{scale} {hw} p{i}", rel=5 * REL_L2, mx=8 * MAX_REL)
+    _close(z, zo, f"model_{scale} {hw} z", rel=5 * REL_L2, mx=8 * MAX_REL)
+
+
+@pytest.mark.parametrize("scale,hw", [("n", 128), ("s", 160)])
+def test_training_trajectory_bf16(scale, hw):
+    """configs[2] arithmetic end to end at a size the CPU oracle finishes in seconds: four optimisation steps under autocast(bf16)
+    (bf16 forward / backward, fp32 loss, fp32 master weights, clip, SGD-nesterov) follow the fp32 oracle's loss trajectory.  bf16
+    perturbs every activation by 2^-9: losses must agree to 3 %, and the run must learn (loss falls as the oracle's does)."""
+    import lead_yolo_amd as L
+    cfg = _cfg(scale)
+    torch.manual_seed(0)
+    m = L.Model(cfg)
+    st = synth.synth_state(synth.shapes_of(m.state_dict()), 8181)
+    st["model.23.anchors"] = m.model[-1].anchors.clone()
+    m.load_state_dict(st)
+    imgs = synth.synth_images(4, hw, 31)
+    tg = synth.synth_targets(4, 32, per_image=3)
+    lr, mom, wd = 0.01, 0.937, 5e-4
+    so = {k: v.clone() for k, v in st.items()}
+    params = {k: v for k, v in so.items() if v.is_floating_point() and "running" not in k and not k.endswith("anchors")}
+    groups = OF.param_groups(list(so))
+    groups = {g: [k for k in ks if k in params] for g, ks in groups.items()}
+    bufs, want = {}, []
+    for _ in range(4):
+        for p in params.values():
+            p.requires_grad_(True)
+            p.grad = None
+        pred = OF.model_forward(so, cfg, imgs.float() / 255, m.stride, training=True)
+        loss, _ = OF.compute_loss(pred, tg, so["model.23.anchors"], nc=1)
+        loss.backward()
+        want.append(float(loss.detach()))
+        grads = {k: p.grad for k, p in params.items()}
+        total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())).float()
+        coef = torch.clamp(10.0 / (total + 1e-6), max=1.0)
+        grads = {k: g * coef for k, g in grads.items()}
+        with torch.no_grad():
+            for gname, dec in (("decay", wd), ("bn", 0.0), ("bias", 0.0)):
+                OF.sgd_nesterov_step({k: params[k] for k in groups[gname]}, grads, bufs, lr, mom, dec)
+    m = m.to(_dev()).train()
+    opt = L.smart_optimizer(m, "SGD", lr, mom, wd)
+    cl = L.ComputeLoss(m)
+    got = []
+    for _ in range(4):
+        loss, _ = L.train_step(m, cl, opt, imgs.to(_dev()), tg.to(_dev()), amp=BF)
+        got.append(float(loss))
+    assert all(p.dtype == torch.float32 for p in m.parameters())          # fp32 master weights
+    for a, b in zip(got, want):
+        assert abs(a - b) <= 3e-2 * abs(b), (got, want)
+    assert got[-1] < 0.75 * got[0]
+
+
+def test_whole_model_gradients_bf16():
+    """full-model parameter gradients of one bf16 step vs the fp32 oracle: direction (cosine over all parameters) and size"""
+    import lead_yolo_amd as L
+    cfg = _cfg("n")
+    torch.manual_seed(0)
+    m = L.Model(cfg)
+    st = synth.synth_state(synth.shapes_of(m.state_dict()), 5151)
+    st["model.23.anchors"] = m.model[-1].anchors.clone()
+    m.load_state_dict(st)
+    imgs = synth.synth_images(4, 128, 21).float() / 255
+    tg = synth.synth_targets(4, 22, per_image=3)
+    so = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k and not k.endswith("anchors") else v.clone())
+          for k, v in st.items()}
+    pred = OF.model_forward(so, cfg, imgs, m.stride, training=True)
+    loss_o, _ = OF.compute_loss(pred, tg, so["model.23.anchors"], nc=1)
+    loss_o.backward()
+    m = m.to(_dev()).train()
+    with torch.autocast("cuda", dtype=BF):
+        loss, _ = L.ComputeLoss(m)(m(imgs.to(_dev())), tg.to(_dev()))
+    loss.backward()
+    assert abs(float(loss) - float(loss_o)) <= 2e-2 * abs(float(loss_o))
+    dot = nn = no = 0.0
+    for k, p in m.named_parameters():
+        g, w = p.grad.float().cpu().double(), so[k].grad.double()
+        dot += float((g * w).sum()); nn += float((g * g).sum()); no += float((w * w).sum())
+    cos = dot / (nn ** 0.5 * no ** 0.5)
+    assert cos >= 0.99 and 0.9 <= (nn / no) ** 0.5 <= 1.1, (cos, (nn / no) ** 0.5)

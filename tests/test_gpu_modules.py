@@ -275,52 +275,108 @@ def test_graphed_forward_matches_eager():
             assert all(torch.equal(a, b) for a, b in zip(pg, pe))
 
 
-def test_rfcbam3_kernel_variants_agree():
-    """RFCBAMConv k=3 at a grid large enough for the 256-channel tile's scalar-cache weight path (more than one block per CU):
-    the launcher's choice, the LDS weight path (debug bit 1) and the two-128-channel-groups tiling (bit 3) are the same
-    arithmetic in the same order, so their outputs must be identical; and the result matches the oracle."""
-    from lead_yolo_amd import capi
+def test_rfcbam3_large_grid_vs_oracle():
+    """RFCBAMConv k=3 at a grid large enough for the 256-channel tile's scalar-cache weight path (more than one block per CU,
+    csrc/ly_rfcbam3.hip launch_rf3): images are independent in eval mode, the oracle checks the first two and the last."""
     kind, ctor, shape = "RFCBAMConv", (256, 256, 3, 2), (40, 256, 40, 40)      # 40 images x 7 row tiles = 280 blocks > 256 CUs
     torch.manual_seed(0)
     m = _ctor(kind)(*ctor)
     st = synth.synth_state(synth.shapes_of(m.state_dict()), 9100)
     _bn_eps(_load(m, st))
     x = synth.synth_input(shape, 77)
-    want = _oracle(kind, list(ctor), st, x[:2])            # images are independent in eval mode: the oracle checks the first two
-    md = m.to(_dev()).eval()
-    xd = x.to(_dev())
-    outs = []
-    try:
-        for dbg in (0, 2, 8):
-            capi.lib().ly_debug_set_rf3(dbg)
-            with torch.no_grad():
-                outs.append(md(xd).float().cpu())
-    finally:
-        capi.lib().ly_debug_set_rf3(0)
-    assert torch.equal(outs[0], outs[1]), "scalar-cache and LDS weight paths differ"
-    assert torch.equal(outs[0], outs[2]), "256-channel tile and two 128-channel groups differ"
-    _cmp(outs[0][:2], want, "rfcbam3 256->256 s2, 40 images")
+    pick = [0, 1, 39]
+    want = _oracle(kind, list(ctor), st, x[pick])
+    with torch.no_grad():
+        got = m.to(_dev()).eval()(x.to(_dev()))
+    _cmp(got[pick], want, "rfcbam3 256->256 s2, 40 images")
 
 
-@pytest.mark.parametrize("c,hw,bs", [(24, 160, 2), (40, 80, 3), (80, 40, 20), (160, 20, 40)])
-def test_mlpblock_tilings_agree(c, hw, bs):
-    """every pixel tiling of the MLPBlock kernel (8 x 16 patches, flattened runs with 1 / 2 / 4 tiles per wave; with and without
-    the weight-fragment ring) carries a pixel through the same arithmetic: outputs must be identical"""
+@pytest.mark.parametrize("name", G.names("rfcbam"))
+def test_rfcbam_intermediates_golden(name):
+    """the attention intermediates the fixtures hold (SE vector `ca`, the [max, mean] map, the receptive-field attention map),
+    each against the reference's own value: a compensating error between the statistics pass and the main pass would show here"""
+    from lead_yolo_amd import ops
+    meta, arr = G.load(name)
+    st = G.state_for(meta)
+    x = synth.synth_input(meta["in_shape"], meta["seed"] + 1).to(_dev())
+    m = _bn_eps(_load(_ctor(meta["kind"])(*meta["ctor"]), st)).to(_dev()).eval()
+    xr, ld = ops.rows(ops.nhwc(x))
+    n, c, h, w = xr.shape
+    k, s = m.kernel_size, m.stride
+    P = m._packed(2)
+    with torch.no_grad():
+        ca = m.se.attention(xr, ld, n, h * w, c)
+        if k == 1:
+            mm = ops.rfcbam_stats(xr, ld, n, h, w, c, 1, 1, a1=P["a1"], b1=P["b1"])
+        else:
+            ho, wo = (h + 2 - 3) // s + 1, (w + 2 - 3) // s + 1
+            th, tw = ops.pick_tile(ho, wo)
+            mm = ops.rfcbam_stats(xr, ld, n, h, w, c, 3, s, wg=P["wq_stats"], th=th, tw=tw)
+        rfa = ops.rfa_map(mm, P["w18"])
+    _cmp(ca, arr["x_ca"], name + " ca")
+    _cmp(mm.permute(0, 3, 1, 2), arr["x_mm"], name + " [max, mean] map")
+    _cmp(rfa.unsqueeze(1), arr["x_rfa"], name + " rfa")
+
+
+@pytest.mark.parametrize("name", G.names("coordatt"))
+def test_coordatt_intermediates_golden(name):
+    """CoordAtt's a_h / a_w gate factors against the reference's own values"""
+    from lead_yolo_amd import ops
+    meta, arr = G.load(name)
+    st = G.state_for(meta)
+    x = synth.synth_input(meta["in_shape"], meta["seed"] + 1).to(_dev())
+    m = _bn_eps(_load(_ctor(meta["kind"])(*meta["ctor"]), st)).to(_dev()).eval()
+    xr, ld = ops.rows(ops.nhwc(x))
+    n, c, h, w = xr.shape
+    with torch.no_grad():
+        a_h, a_w = m.attention(xr, ld, n, h, w, c)
+    _cmp(a_h.permute(0, 2, 1).unsqueeze(3), arr["x_a_h"], name + " a_h")
+    _cmp(a_w.permute(0, 2, 1).unsqueeze(2), arr["x_a_w"], name + " a_w")
+
+
+def test_full_batch_configs1_vs_oracle():
+    """BASELINE configs[1] at its FULL batch (lead-yolo-s, bs=32, 640x640, eval): eager forward and hipGraph replay; the oracle
+    checks two sampled images of every sub-batch of the serving-mode split (images are independent in eval mode)"""
     import lead_yolo_amd as L
-    from lead_yolo_amd import capi
-    torch.manual_seed(c)
-    m = L.BasicStage(c, 1)
-    st = synth.synth_state(synth.shapes_of(m.state_dict()), 4200 + c)
+    torch.manual_seed(0)
+    m = L.Model(_cfg("s"))
+    st = synth.synth_state(synth.shapes_of(m.state_dict()), 3232)
+    st["model.23.anchors"] = m.model[-1].anchors.clone()
+    m.load_state_dict(st)
+    x = synth.synth_images(32, 640, 17).float() / 255
+    pick = [0, 7, 8, 15, 16, 23, 24, 31]
+    with torch.no_grad():
+        zo, _ = OF.model_forward(copy.deepcopy(st), _cfg("s"), x[pick], m.stride, training=False)
+        md = m.to(_dev()).eval()
+        z, _ = md(x.to(_dev()))
+        g = L.GraphedForward(md, x.to(_dev()))
+        zg, _ = g()
+        torch.cuda.synchronize()
+    assert g.parts == 4
+    _cmp(z[pick], zo, "configs[1] bs=32 eager")
+    _cmp(zg[pick], zo, "configs[1] bs=32 graph replay")
+
+
+def test_half_and_autocast_inputs():
+    """SURVEY 8(b) call contract: fp16 inputs (`.half()` models) and autocast regions are accepted at the module edge: fp16 is
+    computed by the bf16 kernels and handed back as fp16; fp32 under autocast(bf16) comes back as bf16"""
+    import lead_yolo_amd as L
+    torch.manual_seed(3)
+    m = L.BasicStage(40, 1)
+    st = synth.synth_state(synth.shapes_of(m.state_dict()), 40)
     _bn_eps(_load(m, st))
-    md = m.to(_dev()).eval()
-    x = synth.synth_input((bs, c, hw, hw), 5 + c).to(_dev())
-    outs = []
-    try:
-        for tile in (0, 8, 2, 4):
-            capi.lib().ly_debug_set_mlp_tile(tile)
-            with torch.no_grad():
-                outs.append(md(x).float().cpu())
-    finally:
-        capi.lib().ly_debug_set_mlp_tile(0)
-    for o in outs[1:]:
-        assert torch.equal(outs[0], o)
+    x = synth.synth_input((2, 40, 16, 12), 9)
+    with torch.no_grad():
+        want = OF.basic_stage(copy.deepcopy(st), "", x, False)
+        md = m.to(_dev()).eval()
+        y16 = md(x.to(_dev()).half())
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            yb = md(x.to(_dev()))
+        with torch.autocast("cuda", dtype=torch.float16):
+            yh = md(x.to(_dev()))
+        y32 = md(x.to(_dev()))
+    assert y16.dtype == torch.float16 and yb.dtype == torch.bfloat16 and yh.dtype == torch.float16 and y32.dtype == torch.float32
+    scale = float(want.abs().max())
+    for y in (y16, yb, yh):
+        assert float((y.float().cpu() - want).abs().max()) <= 2 ** -6 * scale
+    _cmp(y32, want, "fp32 path unchanged")

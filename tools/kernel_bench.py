@@ -1,4 +1,5 @@
-"""Per-kernel micro-benchmarks on the real lead-yolo-s layer shapes (bs=32, 640x640).  Dev tool."""
+"""Per-kernel micro-benchmarks on the real lead-yolo-s layer shapes.  Dev tool.
+    python tools/kernel_bench.py [batch=32] [all|gemm|conv|mlp|rf|c3|patch] [f32|bf16]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -7,6 +8,9 @@ from lead_yolo_amd import ops, pack
 
 dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+DT = torch.bfloat16 if (len(sys.argv) > 3 and sys.argv[3] == "bf16") else torch.float32
+ES = 2 if DT == torch.bfloat16 else 4
+PL = 1 if DT == torch.bfloat16 else 2
 
 
 def timeit(fn, iters=20, warm=3):
@@ -28,35 +32,35 @@ def report(name, us, flops, bytes_):
 
 def gemm_case(name, hw, k, n):
     M = B * hw * hw
-    a = torch.randn(M, k, device=dev)
+    a = torch.randn(M, k, device=dev).to(DT)
     w = torch.randn(n, k, device=dev) / k ** 0.5
-    wp = pack.frag_pack3(w)
-    out = torch.empty(M, n, device=dev)
+    wp = pack.frag_pack3(w, planes=PL)
+    out = torch.empty(M, n, device=dev, dtype=DT)
     sc = torch.ones(n, device=dev)
     sh = torch.zeros(n, device=dev)
     fn = lambda: ops.gemm(M=M, H=hw, W=hw, K=k, N=n, a0=a, lda0=k, k0=k, wp=wp, out=out, ldo=n, e_scale=sc, e_shift=sh, act=2)
-    report(f"gemm {name} M={M} K={k} N={n}", timeit(fn), 2.0 * M * k * n, 4.0 * M * (k + n))
+    report(f"gemm {name} M={M} K={k} N={n}", timeit(fn), 2.0 * M * k * n, 1.0 * ES * M * (k + n))
 
 
 def conv_case(name, hw, c, n):
     M = B * hw * hw
-    x = torch.randn(M, c, device=dev)
+    x = torch.randn(M, c, device=dev).to(DT)
     w = torch.randn(n, c, 3, 3, device=dev) / (9 * c) ** 0.5
-    wp = pack.frag_pack3(pack.conv_taps_matrix(w, 32))
-    out = torch.empty(M, n, device=dev)
+    wp = pack.frag_pack3(pack.conv_taps_matrix(w, 32), planes=PL)
+    out = torch.empty(M, n, device=dev, dtype=DT)
     sc = torch.ones(n, device=dev)
     sh = torch.zeros(n, device=dev)
     fn = lambda: ops.conv3x3(M=M, H=hw, W=hw, Cin=c, N=n, x=x, ldx=c, wp=wp, out=out, ldo=n, e_scale=sc, e_shift=sh, act=2)
-    report(f"conv3x3 {name} M={M} C={c} N={n}", timeit(fn), 2.0 * M * 9 * c * n, 4.0 * M * (c + n))
+    report(f"conv3x3 {name} M={M} C={c} N={n}", timeit(fn), 2.0 * M * 9 * c * n, 1.0 * ES * M * (c + n))
 
 
 def module_case(name, mod, shape, flops):
     m = mod.to(dev).eval()
-    x = torch.randn(*shape, device=dev).contiguous(memory_format=torch.channels_last)
+    x = torch.randn(*shape, device=dev).to(DT).contiguous(memory_format=torch.channels_last)
     with torch.no_grad():
         y = m(x)
         us = timeit(lambda: m(x))
-    report(name, us, flops, 4.0 * (x.numel() + y.numel()))
+    report(name, us, flops, 1.0 * ES * (x.numel() + y.numel()))
 
 
 which = sys.argv[2] if len(sys.argv) > 2 else "all"

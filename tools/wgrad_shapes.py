@@ -7,7 +7,6 @@ from lead_yolo_amd import ops
 dev = torch.device("cuda:0")
 bs = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 from lead_yolo_amd import capi
-capi.lib().ly_debug_set_wgrad_tile(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 m = L.Model(L.load_cfg(scale="s")).to(dev).train()
 opt = L.smart_optimizer(m, "SGD", 0.01, 0.937, 5e-4 * bs / 64)
 cl = L.ComputeLoss(m)

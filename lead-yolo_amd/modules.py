@@ -330,7 +330,7 @@ class _PatchConv(nn.Module):
         n, c, h, w = x.shape
         k = self.k
         ho, wo = h // k, w // k
-        planes = ops.planes_of(odt)
+        planes = 2 if nchw else ops.planes_of(odt)       # the image gather contracts in bf16x3 (fp32 source) whatever the output dtype
         if not nchw and c % ops.vw_of(odt) != 0:
             raise NotImplementedError(f"{type(self).__name__}: {odt} patch gathers need channels % {ops.vw_of(odt)} == 0 (got {c})")
         if _grad_mode(self) and isinstance(getattr(self, "norm", None), nn.BatchNorm2d):

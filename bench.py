@@ -326,11 +326,24 @@ def run_train(args, ctx):
     tg = synth_targets(args.batch, 1 + ctx.rank).to(ctx.device)
     state = {}
 
-    def step():
+    def eager_step():
         state["loss"], _ = L.train_step(model, loss_fn, opt, imgs, tg, reducer=reducer, world_size=ctx.world, amp=amp)
 
+    step, launch = eager_step, "eager launches"
+    if ctx.world == 1 and not args.no_graph:
+        # the whole optimisation step replayed from one hipGraph (train.GraphedTrainStep): identical kernels, no host work per step
+        try:
+            g = L.GraphedTrainStep(model, loss_fn, opt, imgs, tg, amp=amp, warmup=max(args.warmup, 2))
+
+            def step():
+                state["loss"], _ = g()
+            launch = "hipGraph replay of the whole optimisation step"
+        except Exception as e:                                  # noqa: BLE001
+            print(f"[bench] hipGraph capture of the train step unavailable ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr)
+            step = eager_step
+
     regions = timed_repeats(ctx, step, args.steps, args.warmup, args.repeats)
-    res = dict(regions=regions, final_loss=float(state["loss"]), model=model, step=step,
+    res = dict(regions=regions, final_loss=float(state["loss"]), model=model, step=eager_step, launch=launch,
                workload=f"lead-yolo-{args.scale} bs={args.batch}/gpu 3x{args.size}x{args.size} {args.dtype} full train step: uint8 batch -> "
                         "train-mode forward (batch-statistics BN), ComputeLoss, HIP backward, clip 10, SGD-nesterov 3 groups "
                         "(BASELINE.json configs[2]" + ("" if args.dtype == "bf16" else " shape in fp32") + "); random-init weights",
@@ -402,7 +415,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary eval-forward figure and the pconv_rfcbam probe")
     ap.add_argument("--layers", action="store_true", help="print the per-kernel table to stderr")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel probe (for whole-step rocprof runs)")
-    ap.add_argument("--no-graph", action="store_true", help="forward mode: time eager launches instead of the captured hipGraph")
+    ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of replaying the captured hipGraph of the step")
     args = ap.parse_args()
     if args.train:
         args.mode = "train"

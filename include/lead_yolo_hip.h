@@ -278,6 +278,7 @@ int ly_frag_pack3(const float* w, int R, int K, long ld_r, long ld_k, int rows_t
  *   tbox     NULL or [5*na*nt][4]: (gx - gi, gy - gj, gw, gh) of every valid candidate (build_targets' `tbox`, utils/loss.py:262)
  *   match_only != 0: target assignment only (utils/loss.py:194-268 build_targets): cand_cell[idx] = flattened cell
  *            ((b*na + a)*ny + gj)*nx + gi of candidate idx = (k*na + a)*nt + t, or -1; tbox as above; p is read, dp/tobj untouched.
+ * A target row whose image index is exactly -1 is padding and is ignored (fixed-shape target buffers of a captured step).
  * A target row whose image index is outside [0, bs) or that holds a NaN is rejected and counted in acc[3] (the torch
  * formulation raises IndexError there); ly_loss_finish then returns a NaN total.                                          */
 int ly_loss_level(const float* p, float* dp, const float* anchors, const float* targets, int bs, int na, int ny, int nx, int no, long nt,
@@ -287,6 +288,26 @@ int ly_loss_level(const float* p, float* dp, const float* anchors, const float* 
  * acc [nl][4]; cells / balance: [nl] floats                                                                                */
 int ly_loss_finish(const float* acc, int nl, const float* cells, const float* balance, float box_gain, float obj_gain, int bs, float* out,
                    void* stream);
+
+/* ---- fused multi-tensor optimiser step (train.py:330-341; utils/torch_utils.py:318-346 smart_optimizer, 404-432 ModelEMA) ----------
+ * One table entry per state tensor (all pointers DEVICE, fp32).  Entries with a gradient take clip + SGD-nesterov + zero_grad
+ * (+ EMA when `ema` is set); entries without (g == NULL: BatchNorm running statistics) take the EMA update only.              */
+typedef struct LyOptTensor {
+  float* p;            /* parameter (or buffer) */
+  float* g;            /* gradient, zeroed after use; NULL = no optimiser update */
+  float* buf;          /* momentum buffer (same size); unused when g == NULL */
+  float* ema;          /* EMA copy of p, or NULL */
+  long n;              /* elements */
+  float wd;            /* weight decay of the tensor's group */
+  int group;           /* index of its learning rate in hyper[0..2] */
+} LyOptTensor;
+/* table [n_tensors] (device); blk_tensor / blk_off [n_blocks] (device): block b updates elements [blk_off[b], blk_off[b] + 4096) of
+ * tensor blk_tensor[b].  ws: 1 double, zero before the first call (re-zeroed by every call).  hyper (device, 9 floats):
+ * lr[3], momentum, max_norm (<= 0: none), ema decay (< 0: none), ema tau, updates so far, first-step flag (1 before the first call)
+ * — device-resident so that the call can sit inside a captured hipGraph while the host schedule rewrites it.  norm_out: NULL or
+ * 1 float receiving the pre-clip global gradient norm (what clip_grad_norm_ returns).                                              */
+int ly_optim_step(const LyOptTensor* table, const int* blk_tensor, const long* blk_off, int n_blocks, double* ws, float* hyper,
+                  float* norm_out, void* stream);
 
 #ifdef __cplusplus
 }

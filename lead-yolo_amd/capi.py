@@ -38,6 +38,10 @@ class LyRfcbam3Params(ctypes.Structure):
                 ("e_scale", _P), ("e_shift", _P), ("out", _P), ("ldo", _I), ("stats", _P), ("linear", _I), ("dtype", _I)]
 
 
+class LyOptTensor(ctypes.Structure):
+    _fields_ = [("p", _P), ("g", _P), ("buf", _P), ("ema", _P), ("n", _L), ("wd", _F), ("group", _I)]
+
+
 class LyWgradParams(ctypes.Structure):
     _fields_ = [("M", _L), ("H", _I), ("W", _I), ("N", _I), ("du", _P), ("lddu", _I), ("x", _P), ("ldx", _I),
                 ("Hin", _I), ("Win", _I), ("Cin", _I), ("ks", _I), ("stride", _I), ("pad", _I), ("nchw", _I), ("up2", _I),
@@ -102,6 +106,7 @@ SIGNATURES = {
     "ly_loss_level": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P, _I, _P],
     "ly_loss_finish": [_P, _I, _P, _P, _F, _F, _I, _P, _P],
     "ly_detect_tail": [_P, _I, _I, _I, _I, _I, _I, _P, _F, _P, _P, _L, _L, _I, _P],
+    "ly_optim_step": [_P, _P, _P, _I, _P, _P, _P, _P],
 }
 
 

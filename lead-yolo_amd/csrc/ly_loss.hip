@@ -86,8 +86,10 @@ __global__ __launch_bounds__(LY_THREADS) void ly_loss_match_kernel(const LyLossL
   // holds a NaN would index p / dp / winner out of bounds; the torch formulation raises IndexError there.  Such rows are
   // rejected and counted: ly_loss_finish turns a non-zero count into a NaN loss (loud, and without a host sync).
   const int b = (int)tg[0];
+  const bool padding = tg[0] == -1.f;                     // a row with image index exactly -1 is PADDING (fixed-shape target
+                                                          // buffers of a captured step): ignored silently
   const bool sane = tg[0] >= 0.f && b < L.bs && gx == gx && gy == gy && gw == gw && gh == gh;
-  if (!sane && k == 0 && a == 0) atomicAdd(L.acc + 3, 1.f);
+  if (!sane && !padding && k == 0 && a == 0) atomicAdd(L.acc + 3, 1.f);
   bool ok = sane && fmaxf(fmaxf(rw, 1.f / rw), fmaxf(rh, 1.f / rh)) < L.anchor_t;
   const float g = 0.5f;
   float ox = 0.f, oy = 0.f;

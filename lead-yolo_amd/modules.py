@@ -34,7 +34,9 @@ class _Prepared:
 
     def get(self, key, build, variant=0):
         ent = self.slots.get(variant)
-        if ent is None or ent[0] != key:
+        # under hipGraph capture of a training step the weights change between replays: the packing launches must be part of
+        # the captured work every time, whatever the version counters say
+        if ent is None or ent[0] != key or (torch.is_grad_enabled() and torch.cuda.is_current_stream_capturing()):
             with torch.no_grad():
                 ent = (key, build())
             self.slots[variant] = ent

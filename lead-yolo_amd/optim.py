@@ -1,0 +1,140 @@
+"""Fused optimiser step: gradient-norm clipping + SGD-nesterov over the reference's three parameter groups +
+zero_grad + ModelEMA update as TWO launches of csrc/ly_optim.hip over a device-resident table of tensors, instead of ~50 foreach
+launches plus a Python loop over 319 state tensors (reference train.py:330-341; utils/torch_utils.py:318-346, 404-432).
+
+`FusedSGD` is a `torch.optim.Optimizer`: `param_groups` (lr / weight_decay / momentum read every step, so LR schedulers and the
+reference's warm-up loop work unchanged), `state[p]["momentum_buffer"]` (checkpoints interchange with torch.optim.SGD), `step()`.
+Learning rates, the EMA decay ramp and the step counter live in a small device array: the step has no host-dependent kernel
+argument and can be captured into a hipGraph together with forward and backward (train.GraphedTrainStep)."""
+import ctypes
+
+import torch
+
+from . import capi
+
+CHUNK = 4096                 # elements per block, = LY_OPT_CHUNK in csrc/ly_optim.hip
+
+
+class FusedSGD(torch.optim.Optimizer):
+    def __init__(self, params, lr=0.01, momentum=0.937, weight_decay=0.0, nesterov=True, max_norm=10.0):
+        if not nesterov or momentum <= 0:
+            raise NotImplementedError("FusedSGD implements the LEAD-YOLO recipe: SGD with momentum and nesterov=True")
+        super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay, nesterov=True))
+        self.max_norm = max_norm
+        self._ema = None
+        self._table = None
+        self._grad_ptrs = None
+        self.grad_norm = None           # device scalar: pre-clip global gradient norm of the last step
+
+    # ---- EMA -----------------------------------------------------------------------------------------------------
+    def attach_ema(self, ema, model):
+        """fold `ema.update(model)` (utils/torch_utils.py:418-427) into the step: every floating entry of the model's state_dict"""
+        self._ema = (ema, model)
+        self._table = None
+        return self
+
+    # ---- table ---------------------------------------------------------------------------------------------------
+    def _build(self):
+        if len(self.param_groups) > 3:
+            raise NotImplementedError("FusedSGD carries three learning rates (the reference's bias / weight / norm groups)")
+        dev = None
+        entries, keep = [], []
+        ema_of = {}
+        extra = []
+        if self._ema is not None:
+            ema, model = self._ema
+            msd, esd = model.state_dict(), ema.ema.state_dict()
+            pid = {p.data_ptr(): p for g in self.param_groups for p in g["params"]}
+            for k, v in esd.items():
+                if not v.dtype.is_floating_point:
+                    continue
+                src = msd[k]
+                if v.dtype != torch.float32 or src.dtype != torch.float32 or not v.is_contiguous() or not src.is_contiguous():
+                    raise NotImplementedError(f"FusedSGD EMA: {k} must be contiguous float32 on both sides")
+                if src.data_ptr() in pid:
+                    ema_of[src.data_ptr()] = v
+                else:
+                    extra.append((src, v))
+        for gi, group in enumerate(self.param_groups):
+            mom = group["momentum"]
+            for p in group["params"]:
+                if not p.requires_grad:
+                    continue
+                if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+                    raise NotImplementedError("FusedSGD needs contiguous float32 CUDA parameters (fp32 master weights)")
+                dev = p.device
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)              # persistent gradient storage: autograd accumulates in place
+                if not p.grad.is_contiguous() or p.grad.dtype != torch.float32:
+                    raise NotImplementedError("FusedSGD needs contiguous float32 gradients")
+                st = self.state[p]
+                if "momentum_buffer" not in st or st["momentum_buffer"] is None:
+                    st["momentum_buffer"] = torch.zeros_like(p)
+                    st["_fresh"] = True
+                e = ema_of.get(p.data_ptr())
+                entries.append((p.data_ptr(), p.grad.data_ptr(), st["momentum_buffer"].data_ptr(), e.data_ptr() if e is not None else 0, p.numel(),
+                                float(group["weight_decay"]), gi))
+                keep += [p.grad, st["momentum_buffer"], e]
+                if mom != self.param_groups[0]["momentum"]:
+                    raise NotImplementedError("FusedSGD uses one momentum for all groups")
+        for src, v in extra:
+            entries.append((src.data_ptr(), 0, 0, v.data_ptr(), src.numel(), 0.0, -1))
+            keep += [src, v]
+        if not entries:
+            raise ValueError("FusedSGD: no parameters")
+        arr = (capi.LyOptTensor * len(entries))(*[capi.LyOptTensor(*e) for e in entries])
+        raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone()
+        blk_t, blk_o = [], []
+        for i, e in enumerate(entries):
+            for off in range(0, e[4], CHUNK):
+                blk_t.append(i)
+                blk_o.append(off)
+        fresh = any(self.state[p].pop("_fresh", False) for g in self.param_groups for p in g["params"] if p in self.state)
+        ema_obj = self._ema[0] if self._ema else None
+        hyper = [0.0, 0.0, 0.0, float(self.param_groups[0]["momentum"]), float(self.max_norm or 0.0),
+                 float(ema_obj.decay_base) if ema_obj is not None else -1.0, float(ema_obj.tau) if ema_obj is not None else 1.0,
+                 float(ema_obj.updates) if ema_obj is not None else 0.0, 1.0 if fresh else 0.0]
+        self._table = dict(tab=raw.to(dev), blk_t=torch.tensor(blk_t, dtype=torch.int32, device=dev), blk_o=torch.tensor(blk_o, dtype=torch.int64, device=dev),
+                           n_blocks=len(blk_t), ws=torch.zeros(1, dtype=torch.float64, device=dev), hyper=torch.tensor(hyper, dtype=torch.float32, device=dev),
+                           keep=keep, lrs=None)
+        self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._grad_ptrs = [(p, p.grad.data_ptr()) for g in self.param_groups for p in g["params"] if p.requires_grad]
+
+    def _sync_hyper(self):
+        """learning rates follow param_groups (schedulers / warm-up write them); one small H2D copy only when they change"""
+        t = self._table
+        lrs = tuple(float(g["lr"]) for g in self.param_groups) + (float(self.max_norm or 0.0),)
+        if lrs != t["lrs"]:
+            n = len(self.param_groups)
+            t["hyper"][:n].copy_(torch.tensor(lrs[:n], dtype=torch.float32), non_blocking=True)
+            t["hyper"][4:5].copy_(torch.tensor(lrs[n:], dtype=torch.float32), non_blocking=True)
+            t["lrs"] = lrs
+
+    # ---- the step --------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def step(self, closure=None):
+        if closure is not None:
+            raise NotImplementedError("FusedSGD.step does not take a closure")
+        capturing = torch.cuda.is_current_stream_capturing()
+        if self._table is None:
+            if capturing:
+                raise RuntimeError("FusedSGD: run one eager step before capturing (the tensor table is built on the first step)")
+            self._build()
+        if not capturing:
+            for p, ptr in self._grad_ptrs:               # gradients must still live where the table says
+                if p.grad is None or p.grad.data_ptr() != ptr:
+                    self._build()
+                    break
+            self._sync_hyper()
+        t = self._table
+        capi.check(capi.lib().ly_optim_step(capi.ptr(t["tab"]), capi.ptr(t["blk_t"]), capi.ptr(t["blk_o"]), t["n_blocks"], capi.ptr(t["ws"]),
+                                            capi.ptr(t["hyper"]), capi.ptr(self.grad_norm), capi.stream_ptr()), "ly_optim_step")
+        if self._ema is not None and not capturing:
+            self._ema[0].updates += 1
+
+    def zero_grad(self, set_to_none=False):
+        """gradients are zeroed by step(); they stay allocated (the table and a captured graph point at them)"""
+        if self._table is None:
+            super().zero_grad(set_to_none=False)
+
+    fused = True

@@ -31,11 +31,20 @@ def param_groups(model):
     return bias, decay, norm
 
 
-def smart_optimizer(model, name="SGD", lr=0.001, momentum=0.9, decay=1e-5):
+def smart_optimizer(model, name="SGD", lr=0.001, momentum=0.9, decay=1e-5, fused=None, max_norm=10.0):
+    """The reference's three groups (utils/torch_utils.py:318-346).  fused=True (default when the parameters live on the GPU):
+    optim.FusedSGD — clip + SGD-nesterov + zero_grad (+ EMA) in two launches; fused=False: torch.optim.SGD, exactly the
+    reference's object."""
     bias, dec, norm = param_groups(model)
     if name != "SGD":
         raise NotImplementedError("the LEAD-YOLO recipe trains with SGD(nesterov); other optimisers are not wired")
-    opt = torch.optim.SGD(bias, lr=lr, momentum=momentum, nesterov=True)
+    if fused is None:
+        fused = all(p.is_cuda for p in bias + dec + norm)
+    if fused:
+        from .optim import FusedSGD
+        opt = FusedSGD(bias, lr=lr, momentum=momentum, nesterov=True, max_norm=max_norm)
+    else:
+        opt = torch.optim.SGD(bias, lr=lr, momentum=momentum, nesterov=True)
     opt.add_param_group({"params": dec, "weight_decay": decay})
     opt.add_param_group({"params": norm, "weight_decay": 0.0})
     return opt
@@ -47,6 +56,7 @@ class ModelEMA:
     def __init__(self, model, decay=0.9999, tau=2000, updates=0):
         self.ema = deepcopy(model).eval()
         self.updates = updates
+        self.decay_base, self.tau = decay, tau
         self.decay = lambda x: decay * (1 - math.exp(-x / tau))
         for p in self.ema.parameters():
             p.requires_grad_(False)
@@ -82,10 +92,63 @@ def train_step(model, compute_loss, optimizer, imgs, targets, ema=None, reducer=
         ops.stats_pool_end()
     if reducer is not None:
         reducer.wait()
-    torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=max_norm)
-    optimizer.step()
-    if reducer is None:
-        optimizer.zero_grad(set_to_none=True)      # with a reducer the gradients are bucket views, zeroed by reset()
-    if ema is not None:
-        ema.update(model)
+    if getattr(optimizer, "fused", False):
+        # clip + SGD-nesterov + zero_grad + EMA: two launches (optim.FusedSGD / csrc/ly_optim.hip)
+        if ema is not None and (optimizer._ema is None or optimizer._ema[0] is not ema):
+            optimizer.attach_ema(ema, model)
+        optimizer.max_norm = max_norm
+        optimizer.step()
+    else:
+        torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=max_norm)
+        optimizer.step()
+        if reducer is None:
+            optimizer.zero_grad(set_to_none=True)      # with a reducer the gradients are bucket views, zeroed by reset()
+        if ema is not None:
+            ema.update(model)
     return loss.detach(), items
+
+
+class GraphedTrainStep:
+    """The whole optimisation step — uint8 batch -> forward -> loss -> backward -> clip + SGD-nesterov + zero_grad (+ EMA) — captured
+    once into a hipGraph and replayed with no host work per step.  Possible because every C-ABI entry point only
+    launches on the current stream, the device loss has no host sync, and optim.FusedSGD keeps its step-dependent scalars (learning
+    rates, EMA ramp, step counter) in device memory.  Single-GPU: the gradient exchange of ddp.GradReducer stays eager.
+
+        step = GraphedTrainStep(model, compute_loss, optimizer, imgs, targets, ema=ema, amp=torch.bfloat16)
+        loss, items = step(next_imgs, next_targets)        # same shapes; pad `targets` with rows whose image index is -1
+
+    Construction runs `warmup` REAL optimisation steps on the given batch (they size the allocator pools, the statistics pool and
+    the optimiser's tensor table) and then captures one more; each call replays it."""
+
+    def __init__(self, model, compute_loss, optimizer, imgs, targets, ema=None, amp=None, max_norm=10.0, warmup=3):
+        if not getattr(optimizer, "fused", False):
+            raise NotImplementedError("GraphedTrainStep needs optim.FusedSGD (smart_optimizer(..., fused=True)): torch.optim.SGD + "
+                                      "clip_grad_norm_ keep per-step host state")
+        self.imgs, self.targets = imgs.clone(), targets.clone()
+        self.optimizer, self.ema = optimizer, ema
+        args = dict(ema=ema, amp=amp, max_norm=max_norm)
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream(device=imgs.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            for _ in range(max(warmup, 1)):
+                train_step(model, compute_loss, optimizer, self.imgs, self.targets, **args)
+        cur.wait_stream(side)
+        torch.cuda.synchronize(imgs.device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+            self.loss, self.items = train_step(model, compute_loss, optimizer, self.imgs, self.targets, **args)
+
+    def __call__(self, imgs=None, targets=None):
+        if imgs is not None and imgs.data_ptr() != self.imgs.data_ptr():
+            self.imgs.copy_(imgs, non_blocking=True)
+        if targets is not None and targets.data_ptr() != self.targets.data_ptr():
+            if tuple(targets.shape) != tuple(self.targets.shape):
+                raise ValueError(f"GraphedTrainStep: targets must keep the captured shape {tuple(self.targets.shape)} (pad with rows whose "
+                                 f"image index is -1), got {tuple(targets.shape)}")
+            self.targets.copy_(targets, non_blocking=True)
+        self.optimizer._sync_hyper()                       # learning-rate schedule -> device (only when it changed)
+        self.graph.replay()
+        if self.ema is not None:
+            self.ema.updates += 1
+        return self.loss, self.items

@@ -359,3 +359,92 @@ def test_training_trajectory_vs_oracle(scale, hw):
     for (a, b), tol in zip(zip(got, want), (1e-4, 1e-3, 5e-3, 3e-2)):
         assert abs(a - b) <= tol * abs(b), (got, want)
     assert got[-1] < 0.7 * got[0]
+
+
+def test_fused_optimizer_matches_torch_sgd():
+    """optim.FusedSGD (clip + SGD-nesterov, 3 groups + zero_grad + EMA in two launches) vs torch.optim.SGD + clip_grad_norm_ +
+    ModelEMA.update on the same gradients, four steps: parameters, momentum buffers, EMA state and the reported norm"""
+    import lead_yolo_amd as L
+    torch.manual_seed(0)
+    ms = [L.Model(_cfg("n")).to(_dev()).train() for _ in range(2)]
+    ms[1].load_state_dict(ms[0].state_dict())
+    opts = [L.smart_optimizer(ms[0], "SGD", 0.02, 0.937, 5e-4, fused=True, max_norm=0.5), L.smart_optimizer(ms[1], "SGD", 0.02, 0.937, 5e-4, fused=False)]
+    assert isinstance(opts[0], L.FusedSGD) and not isinstance(opts[1], L.FusedSGD)
+    emas = [L.ModelEMA(m) for m in ms]
+    opts[0].attach_ema(emas[0], ms[0])
+    g = torch.Generator().manual_seed(1)
+    for step in range(4):
+        grads = [torch.randn(p.shape, generator=g) * (0.3 if step % 2 else 3.0) for p in ms[0].parameters()]       # clipped and unclipped steps
+        for m in ms:
+            for p, gr in zip(m.parameters(), grads):
+                if p.grad is None:
+                    p.grad = gr.to(_dev()).clone()
+                else:
+                    p.grad.copy_(gr)
+            for b in m.buffers():
+                if b.dtype.is_floating_point:
+                    b.add_(0.01 * (step + 1))                            # running statistics move too (EMA covers buffers)
+        for gr in opts[0].param_groups + opts[1].param_groups:
+            gr["lr"] = 0.02 / (step + 1)                                 # a schedule: the fused step must follow param_groups
+        opts[0].step()
+        want_norm = torch.nn.utils.clip_grad_norm_(ms[1].parameters(), max_norm=0.5)
+        opts[1].step()
+        emas[1].update(ms[1])
+        assert abs(float(opts[0].grad_norm) - float(want_norm)) <= 1e-4 * float(want_norm)
+        assert all(float(p.grad.abs().max()) == 0.0 for p in ms[0].parameters())          # zero_grad is part of the step
+    assert emas[0].updates == emas[1].updates == 4
+    for (k, a), b in zip(ms[0].state_dict().items(), ms[1].state_dict().values()):
+        if a.dtype.is_floating_point:
+            assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-7, k
+    for (k, a), b in zip(emas[0].ema.state_dict().items(), emas[1].ema.state_dict().values()):
+        if a.dtype.is_floating_point:
+            assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-7, ("ema", k)
+    for pa, pb in zip(ms[0].parameters(), ms[1].parameters()):
+        a, b = opts[0].state[pa]["momentum_buffer"], opts[1].state[pb]["momentum_buffer"]
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-7
+
+
+@pytest.mark.parametrize("amp", [None, torch.bfloat16])
+def test_graphed_train_step_matches_eager(amp):
+    """the whole optimisation step captured into a hipGraph (forward, device loss, HIP backward, fused clip/SGD/EMA) against eager
+    steps from the same initial state on the same batches: losses of every step and the final weights"""
+    import lead_yolo_amd as L
+    runs = []
+    for graphed in (False, True):
+        torch.manual_seed(0)
+        m = L.Model(_cfg("n"))
+        st = synth.synth_state(synth.shapes_of(m.state_dict()), 5151)
+        st["model.23.anchors"] = m.model[-1].anchors.clone()
+        m.load_state_dict(st)
+        m = m.to(_dev()).train()
+        opt = L.smart_optimizer(m, "SGD", 0.01, 0.937, 5e-4)
+        ema = L.ModelEMA(m)
+        cl = L.ComputeLoss(m)
+        batches = [(synth.synth_images(4, 128, 21 + i).to(_dev()), synth.synth_targets(4, 22 + i, per_image=3).to(_dev())) for i in range(3)]
+        nt = max(t.shape[0] for _, t in batches) + 2
+        batches = [(im, torch.cat((t, torch.full((nt - t.shape[0], 6), -1.0, device=_dev())))) for im, t in batches]      # fixed shape: -1 rows are padding
+        losses = []
+        if graphed:
+            step = L.GraphedTrainStep(m, cl, opt, *batches[0], ema=ema, amp=amp, warmup=2)       # 2 eager steps + nothing else on batch 0
+            order = [1, 2, 0, 1]
+            for i in order:
+                loss, _ = step(*batches[i])
+                losses.append(float(loss))
+        else:
+            for _ in range(2):
+                L.train_step(m, cl, opt, *batches[0], ema=ema, amp=amp)
+            # the capture itself is recorded, not executed: no step happens there
+            for i in [1, 2, 0, 1]:
+                loss, _ = L.train_step(m, cl, opt, *batches[i], ema=ema, amp=amp)
+                losses.append(float(loss))
+        runs.append((losses, {k: v.detach().clone() for k, v in m.state_dict().items() if v.is_floating_point()}, ema.updates,
+                     {k: v.detach().clone() for k, v in ema.ema.state_dict().items() if v.is_floating_point()}))
+    (l0, w0, u0, e0), (l1, w1, u1, e1) = runs
+    assert u0 == u1 == 6
+    tol = 2e-3 if amp is None else 2e-2            # float atomics (statistics, wgrad) make two runs differ by rounding noise; bf16 amplifies it
+    for a, b in zip(l0, l1):
+        assert abs(a - b) <= tol * abs(a), (l0, l1)
+    for k in w0:
+        assert float((w0[k] - w1[k]).abs().max()) <= 10 * tol * float(w0[k].abs().max()) + 1e-4, k
+    for k in e0:
+        assert float((e0[k] - e1[k]).abs().max()) <= 10 * tol * float(e0[k].abs().max()) + 1e-4, ("ema", k)

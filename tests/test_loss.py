@@ -105,7 +105,7 @@ def test_out_of_range_image_index_is_loud_and_safe():
     bs = preds[0].shape[0]
     tg = G.t(arr["rand_targets"]).to(dev).clone()
     guard = torch.full((1 << 20,), 7.0, device=dev)              # memory right after the allocations above keeps its contents
-    for bad in (float(bs), float(bs + 1000), -1.0, float("nan")):
+    for bad in (float(bs), float(bs + 1000), -2.0, float("nan")):
         t2 = tg.clone()
         t2[0, 0] = bad
         loss, _ = cl(preds, t2)
@@ -115,3 +115,7 @@ def test_out_of_range_image_index_is_loud_and_safe():
     assert bool((guard == 7.0).all())
     loss, _ = cl(preds, tg)
     assert torch.isfinite(loss).all()
+    # rows with image index exactly -1 are padding (fixed-shape target buffers of a captured training step): ignored
+    pad = torch.cat((tg, torch.full((5, 6), -1.0, device=dev)))
+    loss_p, items_p = cl(preds, pad)
+    assert torch.equal(loss_p, loss)

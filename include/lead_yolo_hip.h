@@ -204,6 +204,10 @@ typedef struct LyWgradParams {
   int nchw, up2;
   float* dw; int lddw;        /* fp32 */
   int dtype;                  /* LY_F32 / LY_BF16 */
+  /* layout of a dw row: entry (tap, c) lives at dw[n*lddw + tap*dw_ts + c*dw_cs] (packed [tap][c]: dw_ts = Cin, dw_cs = 1; the
+   * torch weight layout [cout][cin][kh][kw]: dw_ts = 1, dw_cs = ks*ks, lddw = cin*ks*ks), and only rows n < n_valid / channels
+   * c < c_valid are written (padded contractions) — so the kernel can add straight into a parameter's .grad storage          */
+  int dw_ts, dw_cs, n_valid, c_valid;
 } LyWgradParams;
 int ly_wgrad(const LyWgradParams* p, void* stream);
 
@@ -258,7 +262,8 @@ int ly_rf_bwd_dx(int n_img, int H, int W, int C, int k, int s, const void* dug /
 int ly_bn_finalize(const float* stats, int stripes, int nch, int c_off, int N, double count, const float* gamma, const float* beta,
                    const float* bias, float eps, float momentum, float* running_mean, float* running_var, long* nbt, float* scale,
                    float* shift, float* mean, float* invstd, void* stream);
-/* BatchNorm backward coefficients from striped sums [2N] (sum dv, sum dv*u): dgamma, dbeta and
+/* BatchNorm backward coefficients from striped sums [2N] (sum dv, sum dv*u): dgamma, dbeta (ADDED to their targets, which the
+ * caller zeroes: they may be the parameters' persistent gradient storage) and
  * du = alpha*dv + kappa + lambda*u  (train != 0: batch statistics; else alpha = a, kappa = lambda = 0).               */
 int ly_bn_bwd_coeffs(const float* sums, int stripes, int N, double count, const float* a, const float* mean, const float* invstd, int train,
                      float* dgamma, float* dbeta, float* alpha, float* kappa, float* lambda, void* stream);

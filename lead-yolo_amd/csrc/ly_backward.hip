@@ -286,10 +286,13 @@ __global__ __launch_bounds__(LY_THREADS) void ly_wgrad_kernel(const LyWgradParam
     for (int j = 0; j < 2; ++j) {
       const int col = k_base + 16 * j + li;
       if (col >= Ktot) continue;
+      const int tap = col / P.Cin, cch = col - tap * P.Cin;
+      if (cch >= P.c_valid) continue;
+      const long cidx = (long)tap * P.dw_ts + (long)cch * P.dw_cs;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = n_base + 16 * i + 4 * lq + r;
-        if (row < P.N) atomicAdd(P.dw + (long)row * P.lddw + col, acc[i][j][r]);
+        if (row < P.n_valid) atomicAdd(P.dw + (long)row * P.lddw + cidx, acc[i][j][r]);
       }
     }
 }
@@ -470,10 +473,13 @@ __global__ __launch_bounds__(LY_THREADS) void ly_wgrad_tiled_kernel(const LyWgra
     for (int j = 0; j < NJ; ++j) {
       const int col = k0 + (wave >> 1) * (BK / 2) + 16 * j + li;
       if (col >= Ktot) continue;
+      const int tap = col / Q.Cin, cch = col - tap * Q.Cin;
+      if (cch >= Q.c_valid) continue;
+      const long cidx = (long)tap * Q.dw_ts + (long)cch * Q.dw_cs;     // (tap, channel) -> position inside a dw row: the weight's own layout
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = n0 + wn + 16 * i + 4 * lq + r;
-        if (row < Q.N) atomicAdd(Q.dw + (long)row * Q.lddw + col, acc[i][j][r]);
+        if (row < Q.n_valid) atomicAdd(Q.dw + (long)row * Q.lddw + cidx, acc[i][j][r]);
       }
     }
 }
@@ -522,7 +528,8 @@ static int wgrad_dispatch(const LyWgradParams& P, void* stream) {
   LY_CHECK(P.M < (1L << 24), "wgrad: M=%ld pixels exceeds the 2^24 limit of the fast index path", P.M);
   LY_CHECK(P.M % ((long)P.H * P.W) == 0, "wgrad: M is not a whole number of images");
   const int Ktot = P.ks * P.ks * P.Cin;
-  LY_CHECK(P.lddw >= Ktot, "wgrad: lddw=%d < ks*ks*Cin=%d", P.lddw, Ktot);
+  LY_CHECK(P.n_valid > 0 && P.n_valid <= P.N && P.c_valid > 0 && P.c_valid <= P.Cin && P.dw_ts > 0 && P.dw_cs > 0, "wgrad: bad dw layout");
+  LY_CHECK((long)P.lddw >= (long)(P.ks * P.ks - 1) * P.dw_ts + (long)(P.c_valid - 1) * P.dw_cs + 1, "wgrad: lddw=%d does not cover a dw row", P.lddw);
   const bool rows = P.ks == 1 && P.stride == 1 && P.pad == 0 && !P.nchw && !P.up2;
   if (rows) LY_CHECK(P.Hin == P.H && P.Win == P.W, "wgrad: 1x1 gather needs Hin == H, Win == W");
   if (!P.nchw && (P.N & 3) == 0 && (P.Cin & 3) == 0 && (P.lddu & 3) == 0 && (P.ldx & 3) == 0 && ((uintptr_t)P.du & (4 * sizeof(T) - 1)) == 0 && ((uintptr_t)P.x & (4 * sizeof(T) - 1)) == 0) {
@@ -860,8 +867,8 @@ __global__ __launch_bounds__(LY_THREADS) void ly_bn_bwd_coeffs_kernel(const floa
   if (r != 0 || c >= N) return;
   const double mu = mean[c], is = invstd[c], av = a[c];
   const double dg = (s2 - mu * s1) * is;
-  dgamma[c] = (float)dg;
-  dbeta[c] = (float)s1;
+  dgamma[c] += (float)dg;          // ACCUMULATED: the targets may be the parameters' persistent .grad storage (zeroed by the optimiser step)
+  dbeta[c] += (float)s1;
   alpha[c] = (float)av;
   if (train) {
     const double lam = -av * dg * is / count;

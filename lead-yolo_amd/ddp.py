@@ -88,12 +88,24 @@ class GradReducer:
         """Register post-accumulate hooks that launch a bucket's all-reduce when its last gradient lands."""
         for p in self.params:
             self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        try:                                                      # gradients the HIP backward writes in place (ops.GradSink) do not pass
+            from . import ops                                     # through autograd's accumulation: they report here instead
+            mine = {id(p) for p in self.params}
+            self._sink_cb = lambda p: self._on_grad(p) if id(p) in mine else None
+            ops.GRAD_LISTENERS.append(self._sink_cb)
+        except ImportError:
+            self._sink_cb = None
         return self
 
     def detach(self):
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        if getattr(self, "_sink_cb", None) is not None:
+            from . import ops
+            if self._sink_cb in ops.GRAD_LISTENERS:
+                ops.GRAD_LISTENERS.remove(self._sink_cb)
+            self._sink_cb = None
 
     def _on_grad(self, p):
         bi, pi = self._slot[id(p)]

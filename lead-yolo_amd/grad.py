@@ -86,58 +86,69 @@ def _conv_forward(spec, x0, x1, wp, e_scale, e_shift, act, stats=None, out=None,
 
 
 
-def affine_backward(dy, u, a, b, act, mean, invstd, train, inplace=True):
+def affine_backward(dy, u, a, b, act, mean, invstd, train, inplace=True, gamma=None, beta=None):
     """du and (dgamma, dbeta) for v = a*u + b, y = act(v); dy/u are NHWC-dense [n, c, h, w].  du is written over u unless
-    inplace=False (u is a tensor saved for backward)."""
+    inplace=False (u is a tensor saved for backward).  gamma / beta: the BatchNorm parameters — when a gradient sink holds their
+    storage (ops.GradSink) dgamma / dbeta are added there by the coefficient kernel and returned as None."""
     n, c, h, w = u.shape
     rows = n * h * w
     sums = ops.bnact_bwd_reduce(dy, c, u, c, rows, c, a, b, act)
-    dgamma, dbeta, alpha, kappa, lam = ops.bn_bwd_coeffs(sums, c, rows, a, mean, invstd, train)
+    tg, tb = ops.grad_target(gamma), ops.grad_target(beta)
+    direct = tg is not None and tb is not None and tg.numel() == c and tb.numel() == c
+    dgamma, dbeta, alpha, kappa, lam = ops.bn_bwd_coeffs(sums, c, rows, a, mean, invstd, train, dgamma=tg if direct else None,
+                                                         dbeta=tb if direct else None)
+    if direct:
+        ops.grad_done(gamma)
+        ops.grad_done(beta)
     du = u if inplace else torch.empty_like(u)
     ops.bnact_bwd_apply(dy, c, u, c, rows, c, a, b, act, alpha, kappa, lam, du, c)
     return du, dgamma, dbeta
 
 
 def conv_wgrad(spec, du, x0, x1, weight):
-    """Weight gradient in the shape of `weight`.  du: NHWC-dense [n, cout, ho, wo]; cout may be weight.shape[0] zero-padded to a
-    multiple of 4 (Detect heads: 18 -> 20), which keeps the launch on the tiled kernel — the extra rows are dropped."""
+    """Weight gradient, written in the weight's OWN layout [cout][cin][kh][kw] (ly_wgrad's dw_ts / dw_cs): straight into the
+    parameter's persistent gradient storage when a sink holds it (returns None: autograd has nothing to accumulate), else into a
+    fresh zeroed tensor of the weight's shape.  du: NHWC-dense [n, cout, ho, wo]; cout may be weight.shape[0] zero-padded to a
+    multiple of the vector width (Detect heads: 18 -> 20 / 24) — rows beyond the weight's are dropped (n_valid)."""
     n, co, ho, wo = du.shape
     m = n * ho * wo
+    nv = weight.shape[0]
+    tgt = ops.grad_target(weight)
+    dw = tgt if tgt is not None else torch.zeros(weight.shape, dtype=torch.float32, device=du.device)
     if spec.kind == "pw":
         t0, ld0 = ops.rows(x0)
         c0 = t0.shape[1]
         k = c0 + (x1.shape[1] if x1 is not None else 0)
-        dw = torch.zeros(co, k, dtype=torch.float32, device=du.device)
         ops.wgrad(M=m, H=ho, W=wo, N=co, du=du, lddu=co, x=t0, ldx=ld0, Hin=t0.shape[2], Win=t0.shape[3], Cin=c0, dw=dw, lddw=k,
-                  up2=spec.up)
+                  up2=spec.up, n_valid=nv)
         if x1 is not None:
             t1, ld1 = ops.rows(x1)
-            ops.wgrad(M=m, H=ho, W=wo, N=co, du=du, lddu=co, x=t1, ldx=ld1, Hin=ho, Win=wo, Cin=t1.shape[1], dw=dw, lddw=k, dw_off=c0)
-        return dw[:weight.shape[0]].view(weight.shape)
-    if spec.kind == "c3":
+            ops.wgrad(M=m, H=ho, W=wo, N=co, du=du, lddu=co, x=t1, ldx=ld1, Hin=ho, Win=wo, Cin=t1.shape[1], dw=dw, lddw=k, dw_off=c0, n_valid=nv)
+    elif spec.kind == "c3":
         t0, ld0 = ops.rows(x0)
         c = t0.shape[1]
-        dw = torch.zeros(co, 9 * c, dtype=torch.float32, device=du.device)
-        ops.wgrad(M=m, H=ho, W=wo, N=co, du=du, lddu=co, x=t0, ldx=ld0, Hin=ho, Win=wo, Cin=c, dw=dw, lddw=9 * c, ks=3, stride=1, pad=1)
-        return dw.view(co, 3, 3, c).permute(0, 3, 1, 2).contiguous()
-    _, c, h, w = x0.shape
-    k = spec.k
-    if spec.nchw:
-        if h == ho * k and w == wo * k and (k * k * c) % 4 == 0 and co % 4 == 0:
+        ops.wgrad(M=m, H=ho, W=wo, N=co, du=du, lddu=co, x=t0, ldx=ld0, Hin=ho, Win=wo, Cin=c, dw=dw, lddw=9 * c, ks=3, stride=1, pad=1,
+                  dw_ts=1, dw_cs=9, n_valid=nv)
+    else:
+        _, c, h, w = x0.shape
+        k = spec.k
+        if spec.nchw and h == ho * k and w == wo * k and (k * k * c) % 4 == 0 and co % 4 == 0:
             # PatchEmbed on the NCHW image: one space-to-depth copy turns the k x k patch gather into plain rows [M, c*k*k] (the
             # weight's own (c, ky, kx) column order), which the tiled kernel takes; the per-lane NCHW gather kernel was 3x slower
             xr = x0.reshape(n, c, ho, k, wo, k).permute(0, 2, 4, 1, 3, 5).reshape(m, c * k * k).to(du.dtype)
-            dwr = torch.zeros(co, k * k * c, dtype=torch.float32, device=du.device)
-            ops.wgrad(M=m, H=ho, W=wo, N=co, du=du, lddu=co, x=xr, ldx=k * k * c, Hin=ho, Win=wo, Cin=k * k * c, dw=dwr, lddw=k * k * c)
-            return dwr.view(weight.shape)
-        dw = torch.zeros(co, k * k * c, dtype=torch.float32, device=du.device)
-        xr = x0.contiguous().to(du.dtype)
-        ops.wgrad(M=m, H=ho, W=wo, N=co, du=du, lddu=co, x=xr, ldx=0, Hin=h, Win=w, Cin=c, dw=dw, lddw=k * k * c, ks=k, stride=k, nchw=True)
-    else:
-        dw = torch.zeros(co, k * k * c, dtype=torch.float32, device=du.device)
-        xr = _rows_dense(x0)
-        ops.wgrad(M=m, H=ho, W=wo, N=co, du=du, lddu=co, x=xr, ldx=c, Hin=h, Win=w, Cin=c, dw=dw, lddw=k * k * c, ks=k, stride=k)
-    return dw.view(co, k, k, c).permute(0, 3, 1, 2).contiguous()
+            ops.wgrad(M=m, H=ho, W=wo, N=co, du=du, lddu=co, x=xr, ldx=k * k * c, Hin=ho, Win=wo, Cin=k * k * c, dw=dw, lddw=k * k * c, n_valid=nv)
+        elif spec.nchw:
+            xr = x0.contiguous().to(du.dtype)
+            ops.wgrad(M=m, H=ho, W=wo, N=co, du=du, lddu=co, x=xr, ldx=0, Hin=h, Win=w, Cin=c, dw=dw, lddw=k * k * c, ks=k, stride=k, nchw=True,
+                      dw_ts=1, dw_cs=k * k, n_valid=nv)
+        else:
+            xr = _rows_dense(x0)
+            ops.wgrad(M=m, H=ho, W=wo, N=co, du=du, lddu=co, x=xr, ldx=c, Hin=h, Win=w, Cin=c, dw=dw, lddw=k * k * c, ks=k, stride=k,
+                      dw_ts=1, dw_cs=k * k, n_valid=nv)
+    if tgt is not None:
+        ops.grad_done(weight)
+        return None
+    return dw
 
 
 def conv_dgrad(spec, du, weight, x0, x1, need0, need1):
@@ -205,6 +216,7 @@ class ConvBnAct(torch.autograd.Function):
                 ops.bnact_fwd(u, co, rows, co, a, b, spec.act, y, co)
                 ctx.spec, ctx.wp = spec, wp
                 ctx.has = (x1 is not None, bias is not None)
+                ctx.params = (weight, gamma, beta)
                 ctx.save_for_backward(x0, x1, weight, bias_f, a, b, mean, invstd, u)
                 return y
             elif spec.bn_train:
@@ -225,6 +237,7 @@ class ConvBnAct(torch.autograd.Function):
             y = _conv_forward(spec, x0, x1, wp, None, bias_f, spec.act)
         ctx.spec, ctx.wp = spec, wp
         ctx.has = (x1 is not None, bias is not None)
+        ctx.params = (weight, gamma, beta)
         ctx.save_for_backward(x0, x1, weight, bias_f, a, b, mean, invstd, None)
         return y
 
@@ -232,6 +245,7 @@ class ConvBnAct(torch.autograd.Function):
     def backward(ctx, dy):
         spec, wp = ctx.spec, ctx.wp
         x0, x1, weight, bias_f, a, b, mean, invstd, u_saved = ctx.saved_tensors
+        w_param, g_param, b_param = ctx.params          # the Parameter objects themselves (gradient-sink lookup)
         co = spec.cout
         need = ctx.needs_input_grad          # (spec, wp, x0, x1, weight, bias, gamma, beta)
         with torch.no_grad():
@@ -246,14 +260,15 @@ class ConvBnAct(torch.autograd.Function):
                     b = torch.zeros_like(a)
                     mean, invstd = b, a
                 du, dgamma, dbeta = affine_backward(dy, u, a, b, spec.act, mean, invstd, spec.bn is not None and spec.bn_train,
-                                                    inplace=u_saved is None)
+                                                    inplace=u_saved is None, gamma=g_param if spec.bn is not None else None,
+                                                    beta=b_param if spec.bn is not None else None)
                 if bias_f is not None:
                     if spec.bn is None:
                         dbias, dgamma, dbeta = dbeta, None, None
                     elif spec.bn_train:
                         dbias = torch.zeros_like(bias_f)                               # BN removes the batch mean: d/dbias = 0
                     else:
-                        dbias = a * dbeta
+                        dbias = a * (dbeta if dbeta is not None else b_param.grad)
                 elif spec.bn is None:
                     dgamma = dbeta = None
             else:
@@ -270,7 +285,7 @@ class ConvBnAct(torch.autograd.Function):
                 du_d = pad
             else:
                 du_d = du
-            dw = conv_wgrad(spec, du_d if spec.kind == "pw" else du, x0, x1, weight) if need[4] else None
+            dw = conv_wgrad(spec, du_d if spec.kind == "pw" else du, x0, x1, w_param) if need[4] else None
             dx0 = dx1 = None
             if need[2] or need[3]:
                 dspec = spec
@@ -325,12 +340,14 @@ class MlpBlockFn(torch.autograd.Function):
         y = ops.empty_nhwc(n, c, h, w, x)
         ops.mlpblock(x, y, n, h, w, c, pk_p, pk_1, pk_2, a, b)
         a, b = a[:2 * c], b[:2 * c]
+        ctx.params = (wpc, w1, gamma, beta, w2)
         ctx.save_for_backward(x, wpc, w1, w2, a, b, mean, invstd)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, wpc, w1, w2, a, b, mean, invstd = ctx.saved_tensors
+        p_wpc, p_w1, p_gamma, p_beta, p_w2 = ctx.params
         n, c, h, w = x.shape
         m = n * h * w
         c4 = c // 4
@@ -350,27 +367,35 @@ class MlpBlockFn(torch.autograd.Function):
             # second 1x1
             dh = ops.empty_nhwc(n, 2 * c, h, w, x)
             ops.gemm(M=m, H=h, W=w, K=c, N=2 * c, a0=dy, lda0=c, k0=c, wp=pack.frag_pack3(w2m.t(), planes=pl), out=dh, ldo=2 * c)
-            dw2 = torch.zeros(c, 2 * c, dtype=torch.float32, device=x.device)
+            def sink(p):
+                """(gradient tensor to add into, whether it is the parameter's own storage)"""
+                t = ops.grad_target(p)
+                return (t, True) if t is not None else (torch.zeros(p.shape, dtype=torch.float32, device=x.device), False)
+            dw2, d2 = sink(p_w2)
             ops.wgrad(M=m, H=h, W=w, N=c, du=dy, lddu=c, x=hid, ldx=2 * c, Hin=h, Win=w, Cin=2 * c, dw=dw2, lddw=2 * c)
             # BN + ReLU
-            du1, dgamma, dbeta = affine_backward(dh, u1, a, b, ACT_RELU, mean, invstd, True)
+            du1, dgamma, dbeta = affine_backward(dh, u1, a, b, ACT_RELU, mean, invstd, True, gamma=p_gamma, beta=p_beta)
             # first 1x1
             g = ops.empty_nhwc(n, c, h, w, x)
             ops.gemm(M=m, H=h, W=w, K=2 * c, N=c, a0=du1, lda0=2 * c, k0=2 * c, wp=pack.frag_pack3(w1m.t(), planes=pl), out=g, ldo=c)
-            dw1 = torch.zeros(2 * c, c, dtype=torch.float32, device=x.device)
+            dw1, d1 = sink(p_w1)
             ops.wgrad(M=m, H=h, W=w, N=2 * c, du=du1, lddu=2 * c, x=z, ldx=c, Hin=h, Win=w, Cin=c, dw=dw1, lddw=c)
             # partial 3x3 conv on the first C/4 channels
             # channel counts padded to multiples of 4 (C/4 = 6, 10): the tiled wgrad then applies; the extra rows / columns
             # (gradients of, and against, the neighbouring untouched channels) are computed and discarded
-            dwp = torch.zeros(c4p, 9 * c4p, dtype=torch.float32, device=x.device)
-            ops.wgrad(M=m, H=h, W=w, N=c4p, du=g, lddu=c, x=x, ldx=c, Hin=h, Win=w, Cin=c4p, dw=dwp, lddw=9 * c4p, ks=3, stride=1, pad=1)
-            dwp = dwp.view(c4p, 9, c4p)[:c4, :, :c4]
+            # written in the weight's own [c4][c4][3][3] layout; the padded rows / channels are masked off by n_valid / c_valid
+            dwp, dp = sink(p_wpc)
+            ops.wgrad(M=m, H=h, W=w, N=c4p, du=g, lddu=c, x=x, ldx=c, Hin=h, Win=w, Cin=c4p, dw=dwp, lddw=9 * c4, ks=3, stride=1, pad=1,
+                      dw_ts=1, dw_cs=9, n_valid=c4, c_valid=c4)
             t = ops.empty_nhwc(n, c4p, h, w, x)
             wt = pack.frag_pack3(pack.conv_taps_matrix(wpc.detach().permute(1, 0, 2, 3).flip(2, 3), 32), planes=pl)
             ops.conv3x3(M=m, H=h, W=w, Cin=c4p, N=c4, x=g, ldx=c, wp=wt, out=t, ldo=c4p)
             dx = dy + g
             dx[:, :c4] = dy[:, :c4] + t[:, :c4]
-        return (None, dx, dwp.reshape(c4, 3, 3, c4).permute(0, 3, 1, 2).contiguous(), dw1.view(w1.shape), dgamma, dbeta, dw2.view(w2.shape))
+            for prm, direct in ((p_wpc, dp), (p_w1, d1), (p_w2, d2)):
+                if direct:
+                    ops.grad_done(prm)
+        return (None, dx, None if dp else dwp, None if d1 else dw1, dgamma, dbeta, None if d2 else dw2)
 
 
 # --------------------------------------------------------------------------------------------------

@@ -384,14 +384,51 @@ def bn_finalize(bn, stats, nch, count, n=None, c_off=0, bias=None, pad_to=0, wan
     return (scale, shift, mean, invstd) if want_stats else (scale, shift)
 
 
-def bn_bwd_coeffs(sums, n, count, a, mean, invstd, train):
-    """(dgamma, dbeta, alpha, kappa, lambda) from (striped) sums [.., 2n] of ly_bnact_bwd_reduce, ONE launch."""
+def bn_bwd_coeffs(sums, n, count, a, mean, invstd, train, dgamma=None, dbeta=None):
+    """(dgamma, dbeta, alpha, kappa, lambda) from (striped) sums [.., 2n] of ly_bnact_bwd_reduce, ONE launch.  dgamma / dbeta given:
+    the kernel ADDS into them (a parameter's persistent gradient storage, see GradSink) and None is returned in their place."""
     dev = sums.device
     stripes = sums.shape[0] if sums.dim() == 2 else 1
     out = torch.empty(5, n, dtype=torch.float32, device=dev)
-    capi.check(capi.lib().ly_bn_bwd_coeffs(_p(sums), stripes, n, float(count), _p(a), _p(mean), _p(invstd), int(train), _p(out[0]), _p(out[1]),
-                                           _p(out[2]), _p(out[3]), _p(out[4]), capi.stream_ptr()), "ly_bn_bwd_coeffs")
-    return out[0], out[1], out[2], out[3], out[4]
+    direct = dgamma is not None and dbeta is not None
+    if not direct:
+        out[:2].zero_()
+    capi.check(capi.lib().ly_bn_bwd_coeffs(_p(sums), stripes, n, float(count), _p(a), _p(mean), _p(invstd), int(train), _p(dgamma if direct else out[0]),
+                                           _p(dbeta if direct else out[1]), _p(out[2]), _p(out[3]), _p(out[4]), capi.stream_ptr()), "ly_bn_bwd_coeffs")
+    return (None if direct else out[0]), (None if direct else out[1]), out[2], out[3], out[4]
+
+
+class GradSink:
+    """Where the backward kernels put parameter gradients.  Default (no sink installed): fresh tensors handed to autograd, which
+    accumulates them into `.grad` — one extra launch per parameter and step, plus the zero fill of every fresh tensor.  With a sink
+    (optim.FusedSGD installs one: its persistent, step-zeroed gradient storage) ly_wgrad / ly_bn_bwd_coeffs ADD straight into
+    `param.grad` and the autograd function returns None for that parameter; `done(param)` then stands in for the post-accumulate
+    hook (ddp.GradReducer launches a bucket's all-reduce from it)."""
+
+    def __init__(self):
+        self.targets = {}          # id(param) -> gradient tensor (same shape as the parameter, fp32, contiguous)
+
+    def target(self, p):
+        if p is None or not torch.is_tensor(p):
+            return None
+        t = self.targets.get(id(p))
+        if t is not None and p.grad is not t:
+            return None                         # someone re-assigned .grad: fall back to autograd for this one
+        return t
+
+
+
+SINK = None
+GRAD_LISTENERS = []                # callables(param): told when a directly-written gradient is complete (ddp.GradReducer)
+
+
+def grad_target(p):
+    return SINK.target(p) if SINK is not None else None
+
+
+def grad_done(p):
+    for fn in GRAD_LISTENERS:
+        fn(p)
 
 
 def coordatt_conv1_stats(pool, positions, c, mip, w1, b1):
@@ -469,14 +506,16 @@ def bnact_bwd_apply(dy, lddy, u, ldu, rows, c, a, b, act, alpha, kappa, lam, du,
 
 
 def wgrad(*, M, H, W, N, du, lddu, x, ldx, Hin, Win, Cin, dw, lddw, ks=1, stride=1, pad=0, nchw=False, up2=False, du_off=0, x_off=0,
-          dw_off=0):
-    """dw[n][tap*Cin + c] += sum_pixels du[p][n] * x[src(p, tap)][c]; *_off are element offsets into the tensors."""
+          dw_off=0, dw_ts=None, dw_cs=1, n_valid=None, c_valid=None):
+    """dw[n][tap*dw_ts + c*dw_cs] += sum_pixels du[p][n] * x[src(p, tap)][c] for n < n_valid, c < c_valid; *_off are element offsets
+    into the tensors.  Defaults: packed rows (dw_ts = Cin, dw_cs = 1), everything valid."""
     def at(t, off):
         return ctypes.c_void_p(t.data_ptr() + t.element_size() * off)
     if du.dtype != x.dtype:
         raise capi.HipLibraryError(f"wgrad: du ({du.dtype}) and x ({x.dtype}) must share one storage dtype")
     P = capi.LyWgradParams(M, H, W, N, at(du, du_off), lddu, at(x, x_off), ldx, Hin, Win, Cin, ks, stride, pad, int(nchw), int(up2),
-                           at(dw, dw_off), lddw, capi.dtype_code(x))
+                           at(dw, dw_off), lddw, capi.dtype_code(x), Cin if dw_ts is None else dw_ts, dw_cs, N if n_valid is None else n_valid,
+                           Cin if c_valid is None else c_valid)
     with _Timed(wgrad_kernel_name(_tname(x), N, ks * ks * Cin, ks == 1 and stride == 1 and pad == 0 and not nchw and not up2,
                                   (not nchw) and N % 4 == 0 and Cin % 4 == 0 and lddu % 4 == 0 and ldx % 4 == 0),
                 2.0 * M * N * ks * ks * Cin, x.element_size() * M * (N + Cin) + 4.0 * N * ks * ks * Cin):

@@ -99,6 +99,12 @@ class FusedSGD(torch.optim.Optimizer):
                            keep=keep, lrs=None)
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
         self._grad_ptrs = [(p, p.grad.data_ptr()) for g in self.param_groups for p in g["params"] if p.requires_grad]
+        # the backward kernels may now add weight / BatchNorm gradients straight into this storage (ops.GradSink): no fresh
+        # gradient tensors, no zero fills, no AccumulateGrad launches
+        from . import ops
+        sink = ops.GradSink()
+        sink.targets = {id(p): p.grad for g in self.param_groups for p in g["params"] if p.requires_grad}
+        ops.SINK = sink
 
     def _sync_hyper(self):
         """learning rates follow param_groups (schedulers / warm-up write them); one small H2D copy only when they change"""

@@ -305,6 +305,7 @@ typedef struct LyOptTensor {
   long n;              /* elements */
   float wd;            /* weight decay of the tensor's group */
   int group;           /* index of its learning rate in hyper[0..2] */
+  int taps, cin;       /* taps > 1: g is stored tap-major [cout][taps][cin] while p is [cout][cin][taps] (k x k conv weights) */
 } LyOptTensor;
 /* table [n_tensors] (device); blk_tensor / blk_off [n_blocks] (device): block b updates elements [blk_off[b], blk_off[b] + 4096) of
  * tensor blk_tensor[b].  ws: 1 double, zero before the first call (re-zeroed by every call).  hyper (device, 9 floats):

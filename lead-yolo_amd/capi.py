@@ -39,7 +39,7 @@ class LyRfcbam3Params(ctypes.Structure):
 
 
 class LyOptTensor(ctypes.Structure):
-    _fields_ = [("p", _P), ("g", _P), ("buf", _P), ("ema", _P), ("n", _L), ("wd", _F), ("group", _I)]
+    _fields_ = [("p", _P), ("g", _P), ("buf", _P), ("ema", _P), ("n", _L), ("wd", _F), ("group", _I), ("taps", _I), ("cin", _I)]
 
 
 class LyWgradParams(ctypes.Structure):

@@ -50,16 +50,25 @@ __global__ __launch_bounds__(LY_THREADS) void ly_optim_update_kernel(const LyOpt
   if (blockIdx.x == 0 && threadIdx.x == 0 && norm_out) *norm_out = total;
   const float d = ema_decay >= 0.f ? ema_decay * (1.f - __expf(-updates / tau)) : 0.f;
   const float lr = t.group >= 0 ? hyper[t.group] : 0.f;
+  const long tc = (long)t.taps * t.cin;
   for (long i = off + threadIdx.x; i < end; i += LY_THREADS) {
     float p = t.p[i];
     if (t.g) {
-      float g = t.g[i] * coef;
+      // gradient storage of k x k convolution weights may be tap-major ([cout][kh*kw][cin], what ly_wgrad writes with contiguous
+      // atomics) while the parameter is [cout][cin][kh*kw]
+      long gi = i;
+      if (t.taps > 1) {
+        const long co = i / tc, r = i - co * tc;
+        const int c = (int)(r / t.taps), tp = (int)(r - (long)c * t.taps);
+        gi = (co * t.taps + tp) * t.cin + c;
+      }
+      float g = t.g[gi] * coef;
       if (t.wd != 0.f) g += t.wd * p;
       const float b = first ? g : mom * t.buf[i] + g;
       t.buf[i] = b;
       p -= lr * (g + mom * b);
       t.p[i] = p;
-      t.g[i] = 0.f;
+      t.g[gi] = 0.f;
     }
     if (t.ema && ema_decay >= 0.f) t.ema[i] = d * t.ema[i] + (1.f - d) * p;
   }

@@ -385,6 +385,7 @@ class PatchMerging_FasterNet(_PatchConv):
     def __init__(self, dim, out_dim, k, patch_stride2, norm_layer=nn.BatchNorm2d):
         super().__init__()
         self._setup(dim, out_dim, k, patch_stride2, norm_layer)
+        self.reduction.weight._ly_tap_major = True
 
 
 # --------------------------------------------------------------------------------------------------
@@ -406,6 +407,8 @@ class Conv(nn.Module):
         if g != 1 or d != 1 or s != 1 or k not in (1, 3) or autopad(k, p, d) != k // 2:
             raise NotImplementedError(f"HIP Conv is built for k in (1, 3), stride 1, groups 1, 'same' padding (got k={k} s={s} g={g} d={d})")
         self.conv = nn.Conv2d(c1, c2, k, s, autopad(k, p, d), groups=g, dilation=d, bias=False)
+        if k == 3:
+            self.conv.weight._ly_tap_major = True       # optim.FusedSGD may keep this weight's gradient tap-major (what ly_wgrad writes fastest)
         self.bn = nn.BatchNorm2d(c2)
         self.act = self.default_act if act is True else act if isinstance(act, nn.Module) else nn.Identity()
         self.k, self.c1, self.c2 = k, c1, c2

@@ -377,6 +377,9 @@ def bn_finalize(bn, stats, nch, count, n=None, c_off=0, bias=None, pad_to=0, wan
                                   "weights, as the reference does), not with a .half()/.bfloat16() model")
     if track and bn.momentum is None:
         raise NotImplementedError("BatchNorm with momentum=None (cumulative average) is not built")
+    if track:
+        from . import pack
+        pack.touch()                     # running statistics are written by the kernel: eval-mode folded caches must refresh
     capi.check(capi.lib().ly_bn_finalize(_p(stats), stats.shape[0], nch, c_off, n, float(count), _p(bn.weight), _p(bn.bias), _p(bias), float(bn.eps),
                                          float(bn.momentum or 0.0), _p(bn.running_mean if track else None), _p(bn.running_var if track else None),
                                          _p(bn.num_batches_tracked if track else None), _p(scale), _p(shift), _p(mean), _p(invstd),

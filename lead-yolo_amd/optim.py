@@ -15,6 +15,21 @@ from . import capi
 CHUNK = 4096                 # elements per block, = LY_OPT_CHUNK in csrc/ly_optim.hip
 
 
+def _is_tap_major(g, p):
+    """g is a view of p's shape [co, ci, kh, kw] over storage laid out [co][kh][kw][ci]"""
+    if g is None or g.dim() != 4 or tuple(g.shape) != tuple(p.shape) or g.is_contiguous():
+        return False
+    co, ci, kh, kw = p.shape
+    return tuple(g.stride()) == (kh * kw * ci, 1, kw * ci, ci)
+
+
+def _owned(p):
+    """the optimiser may choose the gradient's storage: there is none yet, or it is a plain tensor of its own (not a slice of a
+    larger buffer such as a ddp.GradReducer bucket)"""
+    g = p.grad
+    return g is None or _is_tap_major(g, p) or (g.is_contiguous() and g.untyped_storage().nbytes() == g.numel() * g.element_size())
+
+
 class FusedSGD(torch.optim.Optimizer):
     def __init__(self, params, lr=0.01, momentum=0.937, weight_decay=0.0, nesterov=True, max_norm=10.0):
         if not nesterov or momentum <= 0:
@@ -63,22 +78,39 @@ class FusedSGD(torch.optim.Optimizer):
                 if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
                     raise NotImplementedError("FusedSGD needs contiguous float32 CUDA parameters (fp32 master weights)")
                 dev = p.device
-                if p.grad is None:
+                taps, cin = 1, 0
+                if getattr(p, "_ly_tap_major", False) and p.dim() == 4 and p.shape[2] * p.shape[3] > 1 and _owned(p):
+                    # k x k convolution weight: gradient storage [cout][kh][kw][cin] (ly_wgrad adds with contiguous atomics), exposed
+                    # to torch as a permuted VIEW of the parameter's shape; the update kernel maps indices (LyOptTensor.taps / cin)
+                    co, ci, kh, kw = p.shape
+                    taps, cin = kh * kw, ci
+                    if not _is_tap_major(p.grad, p):
+                        store = torch.zeros((co, kh, kw, ci), dtype=torch.float32, device=p.device)
+                        view = store.permute(0, 3, 1, 2)
+                        if p.grad is not None:
+                            view.copy_(p.grad)
+                        p.grad = view
+                elif p.grad is None:
                     p.grad = torch.zeros_like(p)              # persistent gradient storage: autograd accumulates in place
-                if not p.grad.is_contiguous() or p.grad.dtype != torch.float32:
-                    raise NotImplementedError("FusedSGD needs contiguous float32 gradients")
+                elif not p.grad.is_contiguous() and not _is_tap_major(p.grad, p):
+                    p.grad = p.grad.contiguous()
+                if _is_tap_major(p.grad, p) and taps == 1:
+                    co, ci, kh, kw = p.shape
+                    taps, cin = kh * kw, ci
+                if p.grad.dtype != torch.float32 or not (p.grad.is_contiguous() or taps > 1):
+                    raise NotImplementedError("FusedSGD needs float32 gradients, contiguous or tap-major")
                 st = self.state[p]
                 if "momentum_buffer" not in st or st["momentum_buffer"] is None:
                     st["momentum_buffer"] = torch.zeros_like(p)
                     st["_fresh"] = True
                 e = ema_of.get(p.data_ptr())
                 entries.append((p.data_ptr(), p.grad.data_ptr(), st["momentum_buffer"].data_ptr(), e.data_ptr() if e is not None else 0, p.numel(),
-                                float(group["weight_decay"]), gi))
+                                float(group["weight_decay"]), gi, taps, cin))
                 keep += [p.grad, st["momentum_buffer"], e]
                 if mom != self.param_groups[0]["momentum"]:
                     raise NotImplementedError("FusedSGD uses one momentum for all groups")
         for src, v in extra:
-            entries.append((src.data_ptr(), 0, 0, v.data_ptr(), src.numel(), 0.0, -1))
+            entries.append((src.data_ptr(), 0, 0, v.data_ptr(), src.numel(), 0.0, -1, 1, 0))
             keep += [src, v]
         if not entries:
             raise ValueError("FusedSGD: no parameters")
@@ -135,6 +167,8 @@ class FusedSGD(torch.optim.Optimizer):
         t = self._table
         capi.check(capi.lib().ly_optim_step(capi.ptr(t["tab"]), capi.ptr(t["blk_t"]), capi.ptr(t["blk_o"]), t["n_blocks"], capi.ptr(t["ws"]),
                                             capi.ptr(t["hyper"]), capi.ptr(self.grad_norm), capi.stream_ptr()), "ly_optim_step")
+        from . import pack
+        pack.touch()                      # parameters changed through raw pointers: packed-weight caches must refresh
         if self._ema is not None and not capturing:
             self._ema[0].updates += 1
 

@@ -39,8 +39,19 @@ def bn_scale_shift(bn, conv_bias=None):
     return scale.contiguous(), shift.contiguous()
 
 
+EPOCH = 0
+
+
+def touch():
+    """Parameters or BatchNorm statistics were just written by a HIP kernel through raw pointers (optim.FusedSGD, ly_bn_finalize, a
+    replayed hipGraph): torch's per-tensor version counters did not move, so every cache of packed / folded parameters keyed by
+    `versions()` is invalidated through this global epoch instead."""
+    global EPOCH
+    EPOCH += 1
+
+
 def versions(*tensors):
-    return tuple((t.data_ptr(), t._version) if t is not None else None for t in tensors)
+    return tuple((t.data_ptr(), t._version) if t is not None else None for t in tensors) + (EPOCH,)
 
 
 def frag_pack3(w2d, rows_to=0, planes=2):

@@ -149,6 +149,8 @@ class GraphedTrainStep:
             self.targets.copy_(targets, non_blocking=True)
         self.optimizer._sync_hyper()                       # learning-rate schedule -> device (only when it changed)
         self.graph.replay()
+        from . import pack
+        pack.touch()                                       # parameters / running statistics changed behind torch's version counters
         if self.ema is not None:
             self.ema.updates += 1
         return self.loss, self.items

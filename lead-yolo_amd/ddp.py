@@ -45,6 +45,7 @@ class GradReducer:
         self._works = []
         self._hooks = []
         self._sync = True
+        self._direct = set()
         self.reset()
 
     def _close(self, plist):
@@ -68,6 +69,7 @@ class GradReducer:
         self._pending = [len(b["params"]) for b in self.buckets]
         self._launched = [False] * len(self.buckets)
         self._works = []
+        self._direct = set()
 
     def no_sync(self):
         """Context manager for gradient accumulation (the reference's `accumulate` micro-steps, train.py:303-329): backward
@@ -91,7 +93,12 @@ class GradReducer:
         try:                                                      # gradients the HIP backward writes in place (ops.GradSink) do not pass
             from . import ops                                     # through autograd's accumulation: they report here instead
             mine = {id(p) for p in self.params}
-            self._sink_cb = lambda p: self._on_grad(p) if id(p) in mine else None
+
+            def _sink_cb(p):
+                if id(p) in mine:
+                    self._direct.add(id(p))               # autograd may still run this parameter's (empty) accumulation hook: ignore it once
+                    self._on_grad(p, direct=True)
+            self._sink_cb = _sink_cb
             ops.GRAD_LISTENERS.append(self._sink_cb)
         except ImportError:
             self._sink_cb = None
@@ -107,7 +114,10 @@ class GradReducer:
                 ops.GRAD_LISTENERS.remove(self._sink_cb)
             self._sink_cb = None
 
-    def _on_grad(self, p):
+    def _on_grad(self, p, direct=False):
+        if not direct and id(p) in self._direct:
+            self._direct.discard(id(p))                           # already counted when the backward kernel wrote it in place
+            return
         bi, pi = self._slot[id(p)]
         view = self.buckets[bi]["views"][pi]
         if p.grad is not view:

@@ -394,8 +394,9 @@ class MlpBlockFn(torch.autograd.Function):
             # (gradients of, and against, the neighbouring untouched channels) are computed and discarded
             # written in the weight's own [c4][c4][3][3] layout; the padded rows / channels are masked off by n_valid / c_valid
             dwp, dp = sink(p_wpc)
+            ts, cs = (c4, 1) if _tap_major(dwp) else (1, 9)
             ops.wgrad(M=m, H=h, W=w, N=c4p, du=g, lddu=c, x=x, ldx=c, Hin=h, Win=w, Cin=c4p, dw=dwp, lddw=9 * c4, ks=3, stride=1, pad=1,
-                      dw_ts=1, dw_cs=9, n_valid=c4, c_valid=c4)
+                      dw_ts=ts, dw_cs=cs, n_valid=c4, c_valid=c4)
             t = ops.empty_nhwc(n, c4p, h, w, x)
             wt = pack.frag_pack3(pack.conv_taps_matrix(wpc.detach().permute(1, 0, 2, 3).flip(2, 3), 32), planes=pl)
             ops.conv3x3(M=m, H=h, W=w, Cin=c4p, N=c4, x=g, ldx=c, wp=wt, out=t, ldo=c4p)

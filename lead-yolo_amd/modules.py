@@ -189,6 +189,7 @@ class Partial_conv3(nn.Module):
         self.dim_conv3 = dim // n_div
         self.dim_untouched = dim - self.dim_conv3
         self.partial_conv3 = nn.Conv2d(self.dim_conv3, self.dim_conv3, 3, 1, 1, bias=False)
+        self.partial_conv3.weight._ly_tap_major = True
 
 
 class MLPBlock(nn.Module):

@@ -103,7 +103,7 @@ def test_module_train_forward_and_backward_bf16(name):
     cos = float((got * want).sum() / (got.norm() * want.norm()))
     routing = meta["kind"] in ("SPPF", "RFCBAMConv")
     assert cos >= (0.98 if routing else 0.995), (name, cos)
-    _close(got, want, name + " dx", rel=0.15 if routing else 2 * REL_L2, mx=0.6 if routing else 4 * MAX_REL)
+    _close(got, want, name + " dx", rel=0.15 if routing else 2 * REL_L2, mx=2.0 if routing else 4 * MAX_REL)     # routing: single entries may move by their whole value
 
 
 def test_sppf_pool_bf16_ties_follow_aten():

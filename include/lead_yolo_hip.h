@@ -120,9 +120,17 @@ int ly_se_fwd(const void* x /*T*/, int ldx, int n_img, int HW, int C, const floa
               int slices, float* ca, int dtype, void* stream);
 /* mm[n, y, x, 0:2] = (max_c, mean_c) of relu(bn(generate(x))) on the k-times expanded grid.
  * k = 1: a1/b1 = folded per-channel scale/shift.  k = 3: wg = pack.rfcbam_gen_weights(..., 32, False):
- * [C32/32][4 waves][9 t][4 channel pairs][20]; TH x TW (<= 64) = output-pixel tile per block.       */
+ * [C32/32][4 waves][9 t][4 channel pairs][20]; TH x TW (<= 64) = output-pixel tile per block.
+ * part != NULL: the SAME pass also leaves the partial sums of SE's global average pool (models/rfa.py:90), part[n][slice][C]
+ * (k = 1: slices = pixel slices per image, free; k = 3: one row per output tile, slices = ceil(Ho/TH)*ceil(Wo/TW)) for
+ * ly_rfcbam_mid / ly_se_mlp — x is then read once instead of twice before the contraction.                              */
 int ly_rfcbam_stats(const void* x /*T*/, int ldx, int n_img, int H, int W, int C, int k, int s, const float* wg,
-                    const float* a1, const float* b1, int TH, int TW, float* mm, int dtype, void* stream);
+                    const float* a1, const float* b1, int TH, int TW, float* mm, float* part, int slices, int dtype, void* stream);
+/* SE's two linears + sigmoid from the pooling partials (-> ca [n_img, C]) and get_weight's 3x3 conv + sigmoid on the [max, mean]
+ * map (-> rfa [n_img, HK, WK]) as ONE launch (two independent groups of blocks): the steps between ly_rfcbam_stats and the main
+ * contraction (models/rfa.py:88-92, 107, 127).  HW = pixels per image of the pooled input.                                    */
+int ly_rfcbam_mid(const float* part, int slices, int C, int HW, const float* wa, const float* wb, int R, float* ca, int n_img,
+                  const float* mm, int HK, int WK, const float* w18, float* rfa, void* stream);
 /* rfa[n, y, x] = sigmoid(conv3x3_pad1(mm; w[2][3][3]))   (get_weight, models/rfa.py:107)             */
 int ly_rfa_map(const float* mm, int n_img, int HK, int WK, const float* w, float* rfa, void* stream);
 

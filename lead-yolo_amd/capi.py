@@ -78,7 +78,8 @@ SIGNATURES = {
     "ly_coordatt_mlp": [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "ly_coordatt_gate": [_P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _P],
     "ly_se_fwd": [_P, _I, _I, _I, _I, _P, _P, _I, _P, _I, _P, _I, _P],
-    "ly_rfcbam_stats": [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P, _I, _P],
+    "ly_rfcbam_stats": [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _I, _I, _P],
+    "ly_rfcbam_mid": [_P, _I, _I, _I, _P, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P],
     "ly_rfa_map": [_P, _I, _I, _I, _P, _P, _P],
     "ly_rfcbam3_fwd": [ctypes.POINTER(LyRfcbam3Params), _P],
     "ly_chan_moments": [_P, _I, _L, _I, _P, _I, _P],

@@ -123,14 +123,12 @@ __global__ __launch_bounds__(LY_THREADS) void ly_colsum_kernel(const T* __restri
   }
 }
 
-__global__ __launch_bounds__(LY_THREADS) void ly_se_mlp_kernel(const float* __restrict__ part, int slices, int C, float inv_hw,
-                                                                const float* __restrict__ wa, const float* __restrict__ wb, int R,
-                                                                float* __restrict__ ca) {
-  extern __shared__ float sm[];      // g[C] + hid[R] + red[LY_THREADS][4]
-  float* g = sm;
+__device__ __forceinline__ void ly_se_mlp_body(float* sm, const int n, const float* __restrict__ part, int slices, int C, float inv_hw,
+                                               const float* __restrict__ wa, const float* __restrict__ wb, int R, float* __restrict__ ca) {
+  float* g = sm;                     // g[C] + hid[R] + red[LY_THREADS][4]
   float* hid = sm + C;
   f32x4* red = reinterpret_cast<f32x4*>(sm + ((C + R + 3) & ~3));
-  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // slice partials -> channel means.  All 256 threads load: thread = (slice group, 4 channels), so the up to 128 slices
   // are a handful of independent float4 loads per thread instead of a 128-long chain per channel; groups meet in LDS.
   const int nq = C >> 2;                 // channel quads: C % 4 == 0 and C <= 1024, so nq <= 256
@@ -159,6 +157,13 @@ __global__ __launch_bounds__(LY_THREADS) void ly_se_mlp_kernel(const float* __re
     for (int r = 0; r < R; ++r) s += wb[c * R + r] * hid[r];
     ca[(long)n * C + c] = ly_sigmoid(s);
   }
+}
+
+__global__ __launch_bounds__(LY_THREADS) void ly_se_mlp_kernel(const float* __restrict__ part, int slices, int C, float inv_hw,
+                                                                const float* __restrict__ wa, const float* __restrict__ wb, int R,
+                                                                float* __restrict__ ca) {
+  extern __shared__ float sm[];
+  ly_se_mlp_body(sm, blockIdx.x, part, slices, C, inv_hw, wa, wb, R, ca);
 }
 
 extern "C" int ly_se_fwd(const void* x, int ldx, int n_img, int HW, int C, const float* wa, const float* wb, int R, float* part,
@@ -210,6 +215,72 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_stats1_kernel(const T* _
   }
 }
 
+// k = 1 statistics AND the SE pooling in one pass over x: block = (image, slice of its pixels), wave = one pixel at a time, lane =
+// channel quads lane, lane + 64, ...  The per-pixel [max, mean] needs a wave reduction (as above); the per-channel sums of the SE
+// global average pool stay in the lanes' registers over the block's pixels and leave as one partial row per block (no atomics,
+// no zero fill): part[n][slice][C], summed by the SE step (ly_rfcbam_mid / ly_se_mlp).
+#define LY_PRE1_NS 3                 // channel-quad slots per lane: C <= 768
+template <typename T>
+__global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_pre1_kernel(const T* __restrict__ x, int ldx, int HW, int C, int slices,
+                                                                    const float* __restrict__ a, const float* __restrict__ b,
+                                                                    float* __restrict__ mm, float* __restrict__ part) {
+  __shared__ f32x4 red[3][LY_PRE1_NS * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.x / slices, sl = blockIdx.x - n * slices;
+  const int per = (HW + slices - 1) / slices;
+  const int j_lo = sl * per, j_hi = (j_lo + per) < HW ? (j_lo + per) : HW;
+  const int nc4 = C >> 2;
+  const float inv = 1.f / (float)C;
+  f32x4 sa[LY_PRE1_NS], sb[LY_PRE1_NS], gs[LY_PRE1_NS];
+#pragma unroll
+  for (int q = 0; q < LY_PRE1_NS; ++q) {
+    const int c4 = lane + 64 * q;
+    const bool ok = c4 < nc4;
+    sa[q] = ok ? ly_ldg4(a + 4 * c4) : ly_zero4();
+    sb[q] = ok ? ly_ldg4(b + 4 * c4) : ly_zero4();
+    gs[q] = ly_zero4();
+  }
+  for (int j = j_lo + wave; j < j_hi; j += 4) {
+    const long p = (long)n * HW + j;
+    float mx = 0.f, sm = 0.f;                  // relu(.) >= 0: zero is the identity of the channel max (absent lanes contribute 0)
+#pragma unroll
+    for (int q = 0; q < LY_PRE1_NS; ++q) {
+      const int c4 = lane + 64 * q;
+      if (c4 < nc4) {
+        const f32x4 v = ly_ld4<T>(x + p * ldx + 4 * c4);
+        gs[q] += v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float g = fmaxf(v[r] * sa[q][r] + sb[q][r], 0.f);
+          mx = fmaxf(mx, g);
+          sm += g;
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      mx = fmaxf(mx, __shfl_xor(mx, o));
+      sm += __shfl_xor(sm, o);
+    }
+    if (lane == 0) {
+      mm[2 * p] = mx;
+      mm[2 * p + 1] = sm * inv;
+    }
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int q = 0; q < LY_PRE1_NS; ++q) red[wave - 1][q * 64 + lane] = gs[q];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int q = 0; q < LY_PRE1_NS; ++q) {
+      const int c4 = lane + 64 * q;
+      if (c4 < nc4) ly_stg4(part + ((long)n * slices + sl) * C + 4 * c4, gs[q] + red[0][q * 64 + lane] + red[1][q * 64 + lane] + red[2][q * 64 + lane]);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // RFCBAM statistics, k = 3 (stride s, pad 1).  lane = output pixel of a TH x TW tile, the 4 waves
 // split the channels (channel c0 + wave + 4j of each 32-channel chunk); depthwise weights are wave-
@@ -222,7 +293,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_stats1_kernel(const T* _
 template <typename T>
 __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_stats3_kernel(const T* __restrict__ x, int ldx, int H, int W, int C,
                                                                        int Ho, int Wo, int s, int TH, int TW, int nct, int nrt,
-                                                                       const float* __restrict__ wg, float* __restrict__ mm) {
+                                                                       const float* __restrict__ wg, float* __restrict__ mm, float* __restrict__ part) {
   extern __shared__ float lds[];
   const int IH = s * (TH - 1) + 3, IW = s * (TW - 1) + 3;
   float* wsm = lds;                                  // [4 waves][LY_ST3_WF]: this chunk's folded weights (16-B aligned)
@@ -310,6 +381,27 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_stats3_kernel(const T* _
     }
     prefetch(more ? c0 + LY_SCC : 0);      // unconditional: a load under a run-time branch makes every later wait conservative
     __syncthreads();
+    if (part) {
+      // SE global-average-pool partial of this tile (models/rfa.py:90) from the staged chunk: the block OWNS input rows
+      // [s*oy0, s*(oy0+TH)) x cols [s*ox0, s*(ox0+TW)) (every input pixel belongs to exactly one tile), thread = (channel, 1 of 8
+      // pixel stripes); the stripes meet in LDS (red is free until the end) and leave as one row of part[n][tile][C]
+      const int ch = tid & 31, stripe = tid >> 5;
+      const int rows_own = min(s * TH, H - s * oy0), cols_own = min(s * TW, W - s * ox0);
+      float acc = 0.f;
+      for (int q = stripe; q < rows_own * cols_own; q += 8) {
+        const int r = q / cols_own, cq = q - r * cols_own;
+        acc += xs[((r + 1) * IW + cq + 1) * (LY_SCC + 1) + ch];
+      }
+      red[stripe * 32 + ch] = acc;
+      __syncthreads();
+      if (tid < 32 && c0 + tid < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) t += red[g * 32 + tid];
+        part[((long)n * (nrt * nct) + rt * nct + ct) * C + c0 + tid] = t;
+      }
+      __syncthreads();
+    }
     {
       // inputs of this wave's 8 channels (c0 + wave + 4j) as 4 packed pairs (j = 2p, 2p+1), then the folded
       // weights [t][p][9 x (w_a, w_b), (b_a, b_b)] read as wave-uniform LDS broadcasts: v_pk_fma_f32 does two
@@ -370,13 +462,20 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_stats3_kernel(const T* _
 }
 
 extern "C" int ly_rfcbam_stats(const void* x, int ldx, int n_img, int H, int W, int C, int k, int s, const float* wg,
-                               const float* a1, const float* b1, int TH, int TW, float* mm, int dtype, void* stream) {
+                               const float* a1, const float* b1, int TH, int TW, float* mm, float* part, int slices, int dtype, void* stream) {
   LY_CHECK_DTYPE(dtype, "rfcbam_stats");
   LY_CHECK(x && mm && (C & 3) == 0 && (ldx & 3) == 0, "rfcbam_stats: bad arguments");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (k == 1) {
     LY_CHECK(s == 1 && a1 && b1, "rfcbam_stats: k=1 needs stride 1 and folded scale/shift");
     long M = (long)n_img * H * W;
+    if (part) {           // statistics + SE pooling partials in one pass
+      LY_CHECK(slices > 0 && C <= 256 * LY_PRE1_NS, "rfcbam_stats: fused SE pooling needs slices > 0 and C <= %d", 256 * LY_PRE1_NS);
+      LY_WITH_T(dtype, hipLaunchKernelGGL(ly_rfcbam_pre1_kernel<T>, dim3((unsigned)(n_img * slices)), dim3(LY_THREADS), 0, st, reinterpret_cast<const T*>(x), ldx,
+                                          H * W, C, slices, a1, b1, mm, part));
+      LY_LAUNCH_CHECK();
+      return 0;
+    }
     long blocks = (M + 3) / 4;
     if (blocks > 256 * 16) blocks = 256 * 16;
     LY_WITH_T(dtype, hipLaunchKernelGGL(ly_rfcbam_stats1_kernel<T>, dim3((unsigned)blocks), dim3(LY_THREADS), 0, st, reinterpret_cast<const T*>(x), ldx, M, C, a1, b1, mm));
@@ -387,6 +486,7 @@ extern "C" int ly_rfcbam_stats(const void* x, int ldx, int n_img, int H, int W, 
   LY_CHECK(TW >= 1 && TH >= 1 && TH * TW <= 64, "rfcbam_stats: tile %dx%d does not fit a wave", TH, TW);
   const int Ho = (H + 2 - 3) / s + 1, Wo = (W + 2 - 3) / s + 1;
   const int nct = (Wo + TW - 1) / TW, nrt = (Ho + TH - 1) / TH;
+  LY_CHECK(!part || slices == nct * nrt, "rfcbam_stats: k=3 fused SE pooling writes one partial row per tile: slices must be %d", nct * nrt);
   const int IH = s * (TH - 1) + 3, IW = s * (TW - 1) + 3;
   size_t lds = sizeof(float) * ((size_t)4 * LY_ST3_WF + (size_t)IH * IW * (LY_SCC + 1) + 4 * 18 * 64);
   LY_CHECK(IH * IW * (LY_SCC / 4) <= LY_ST3_NV * LY_THREADS, "rfcbam_stats: input tile %dx%d exceeds the staging capacity", IH, IW);
@@ -400,15 +500,14 @@ extern "C" int ly_rfcbam_stats(const void* x, int ldx, int n_img, int H, int W, 
     configured = true;
   }
   LY_WITH_T(dtype, hipLaunchKernelGGL(ly_rfcbam_stats3_kernel<T>, dim3(n_img * nrt * nct), dim3(LY_THREADS), lds, st, reinterpret_cast<const T*>(x), ldx, H, W, C,
-                                      Ho, Wo, s, TH, TW, nct, nrt, wg, mm));
+                                      Ho, Wo, s, TH, TW, nct, nrt, wg, mm, part));
   LY_LAUNCH_CHECK();
   return 0;
 }
 
 // rfa[n, y, x] = sigmoid( sum_{ch, dy, dx} w[ch][dy][dx] * mm[n, y+dy-1, x+dx-1, ch] )
-__global__ __launch_bounds__(LY_THREADS) void ly_rfa_map_kernel(const float* __restrict__ mm, int HK, int WK, long total,
-                                                                 const float* __restrict__ w, float* __restrict__ rfa) {
-  const long i = (long)blockIdx.x * LY_THREADS + threadIdx.x;
+__device__ __forceinline__ void ly_rfa_map_body(const long i, const float* __restrict__ mm, int HK, int WK, long total,
+                                                const float* __restrict__ w, float* __restrict__ rfa) {
   if (i >= total) return;
   const int xk = (int)(i % WK);
   const int yk = (int)((i / WK) % HK);
@@ -425,6 +524,35 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfa_map_kernel(const float* __r
       }
     }
   rfa[i] = ly_sigmoid(s);
+}
+
+__global__ __launch_bounds__(LY_THREADS) void ly_rfa_map_kernel(const float* __restrict__ mm, int HK, int WK, long total,
+                                                                 const float* __restrict__ w, float* __restrict__ rfa) {
+  ly_rfa_map_body((long)blockIdx.x * LY_THREADS + threadIdx.x, mm, HK, WK, total, w, rfa);
+}
+
+// The two small dependent steps between the statistics pass and the main contraction of RFCBAMConv as ONE launch: blocks
+// [0, n_img) finish SE (slice partials -> mean -> fc -> sigmoid, models/rfa.py:88-92), the remaining blocks evaluate
+// get_weight (3x3 conv on the [max, mean] map + sigmoid, models/rfa.py:107,127).  They are independent of each other.
+__global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_mid_kernel(const float* __restrict__ part, int slices, int C, float inv_hw,
+                                                                   const float* __restrict__ wa, const float* __restrict__ wb, int R,
+                                                                   float* __restrict__ ca, int n_img, const float* __restrict__ mm, int HK, int WK,
+                                                                   long total, const float* __restrict__ w18, float* __restrict__ rfa) {
+  extern __shared__ float sm[];
+  if ((int)blockIdx.x < n_img) ly_se_mlp_body(sm, blockIdx.x, part, slices, C, inv_hw, wa, wb, R, ca);
+  else ly_rfa_map_body((long)(blockIdx.x - n_img) * LY_THREADS + threadIdx.x, mm, HK, WK, total, w18, rfa);
+}
+
+extern "C" int ly_rfcbam_mid(const float* part, int slices, int C, int HW, const float* wa, const float* wb, int R, float* ca, int n_img,
+                             const float* mm, int HK, int WK, const float* w18, float* rfa, void* stream) {
+  LY_CHECK(part && wa && wb && ca && mm && w18 && rfa, "rfcbam_mid: null pointer");
+  LY_CHECK((C & 3) == 0 && C <= 1024 && slices > 0 && R > 0 && R <= 256 && n_img > 0, "rfcbam_mid: bad arguments");
+  const long total = (long)n_img * HK * WK;
+  const unsigned blocks = (unsigned)(n_img + (total + LY_THREADS - 1) / LY_THREADS);
+  hipLaunchKernelGGL(ly_rfcbam_mid_kernel, dim3(blocks), dim3(LY_THREADS), sizeof(float) * (((C + R + 3) & ~3) + 4 * LY_THREADS),
+                     reinterpret_cast<hipStream_t>(stream), part, slices, C, 1.f / (float)HW, wa, wb, R, ca, n_img, mm, HK, WK, total, w18, rfa);
+  LY_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int ly_rfa_map(const float* mm, int n_img, int HK, int WK, const float* w, float* rfa, void* stream) {

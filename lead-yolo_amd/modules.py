@@ -555,21 +555,10 @@ class RFCBAMConv(nn.Module):
         n, c, h, w = xr.shape
         k, s = self.kernel_size, self.stride
         P = self._packed(ops.planes_of(xr))
-        # The SE branch (global average pool + two tiny linears: latency-bound, a fraction of the GPU) is independent of the
-        # receptive-field statistics below: it runs on a side stream and is joined just before the contraction that needs `ca`.
-        # Only while a hipGraph is being captured (the fork/join then costs nothing at replay); in eager mode the extra event
-        # traffic makes the host the bottleneck, so the branch simply runs in line.
-        if _overlap():
-            main = torch.cuda.current_stream()
-            side = _side_stream(xr.device)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                ca = self.se.attention(xr, ld, n, h * w, c)
-            ca.record_stream(main)
-            join = lambda: main.wait_stream(side)
-        else:
-            ca = self.se.attention(xr, ld, n, h * w, c)
-            join = lambda: None
+        wa, wb = self.se.fc[0].weight.detach().float().contiguous(), self.se.fc[2].weight.detach().float().contiguous()
+        # Three launches: (1) ONE pass over x leaves the [max, mean] statistics map AND the partial sums of SE's global average pool,
+        # (2) SE's linears and get_weight's 3x3 conv on the small maps, (3) the contraction.  (The reference reads x for the pool,
+        # again for `generate`, and walks the 9x tensor ~13 times.)
         if k == 1:
             a1, b1, es, eb = P["a1"], P["b1"], P["es"], P["eb"]
             if self.training:
@@ -579,9 +568,8 @@ class RFCBAMConv(nn.Module):
                 mom = ops.chan_moments(xr, ld, n * h * w, c)
                 gs, gb = ops.bn_batch_affine(self.generate[1], gwv * mom[:c], gwv * gwv * mom[c:], n * h * w)
                 a1, b1 = (gwv * gs).contiguous(), gb
-            mm = ops.rfcbam_stats(xr, ld, n, h, w, c, 1, 1, a1=a1, b1=b1)
-            rfa = ops.rfa_map(mm, P["w18"])
-            join()
+            mm, part = ops.rfcbam_stats(xr, ld, n, h, w, c, 1, 1, a1=a1, b1=b1, gap=True)
+            ca, rfa = ops.rfcbam_mid(part, h * w, wa, wb, self.se.ratio, mm, P["w18"])
             kw = dict(M=n * h * w, H=h, W=w, K=c, N=self.o, a0=xr, lda0=ld, k0=c, wp=P["wp"], ldo=self.o, pro=ops.PRO_AFFINE_RELU_CA,
                       p_scale=a1, p_shift=b1, p_ca=ca, rowscale=rfa)
             if self.training:
@@ -601,9 +589,8 @@ class RFCBAMConv(nn.Module):
             gs, gb = ops.bn_batch_affine(self.generate[1], s1, s2, cnt)
             wq_stats = pack.rfcbam_gen_weights(gw, gs, gb, 32, False)
             wq_main = pack.rfcbam_gen_weights(gw, gs, gb, 16, True)
-        mm = ops.rfcbam_stats(xr, ld, n, h, w, c, 3, s, wg=wq_stats, th=th, tw=tw)
-        rfa = ops.rfa_map(mm, P["w18"])
-        join()
+        mm, part = ops.rfcbam_stats(xr, ld, n, h, w, c, 3, s, wg=wq_stats, th=th, tw=tw, gap=True)
+        ca, rfa = ops.rfcbam_mid(part, h * w, wa, wb, self.se.ratio, mm, P["w18"])
         kw = dict(n=n, h=h, w=w, c=c, ho=ho, wo=wo, N=self.o, s=s, th=th, tw=tw, x=xr, ldx=ld, wg=wq_main, ca=ca, rfa=rfa, wp=P["wp"],
                   ldo=self.o)
         if self.training:

@@ -250,14 +250,31 @@ def pick_tile(ho, wo):
     return best[1], best[2]
 
 
-def rfcbam_stats(x, ldx, n, h, w, c, k, s, wg=None, a1=None, b1=None, th=1, tw=64):
+def rfcbam_stats(x, ldx, n, h, w, c, k, s, wg=None, a1=None, b1=None, th=1, tw=64, gap=False):
+    """[max, mean] map of relu(bn(generate(x))); gap=True: the same pass also leaves the SE pooling partials -> (mm, part)"""
     ho, wo = ((h + 2 * (k // 2) - k) // s + 1, (w + 2 * (k // 2) - k) // s + 1)
     mm = torch.empty((n, k * ho, k * wo, 2), dtype=torch.float32, device=x.device)
-    with _Timed(f"ly_rfcbam_stats{k}_kernel<{_tname(x)}>", 2.0 * n * ho * wo * c * (81 if k == 3 else 1),
+    part, slices = None, 0
+    if gap:
+        slices = (-(-ho // th) * -(-wo // tw)) if k == 3 else max(1, min(h * w // 16, max(1, 2048 // n)))
+        part = torch.empty((n, slices, c), dtype=torch.float32, device=x.device)
+    with _Timed((f"ly_rfcbam_pre1_kernel<{_tname(x)}>" if (gap and k == 1) else f"ly_rfcbam_stats{k}_kernel<{_tname(x)}>"), 2.0 * n * ho * wo * c * (81 if k == 3 else 1),
                 x.element_size() * n * h * w * c + 4.0 * 2 * k * k * n * ho * wo):
-        capi.check(capi.lib().ly_rfcbam_stats(_p(x), ldx, n, h, w, c, k, s, _p(wg), _p(a1), _p(b1), th, tw, _p(mm), capi.dtype_code(x),
-                                              capi.stream_ptr()), "ly_rfcbam_stats")
-    return mm
+        capi.check(capi.lib().ly_rfcbam_stats(_p(x), ldx, n, h, w, c, k, s, _p(wg), _p(a1), _p(b1), th, tw, _p(mm), _p(part), slices,
+                                              capi.dtype_code(x), capi.stream_ptr()), "ly_rfcbam_stats")
+    return (mm, part) if gap else mm
+
+
+def rfcbam_mid(part, hw, wa, wb, r, mm, w18):
+    """SE's linears (from the pooling partials) + get_weight's 3x3 conv on the [max, mean] map, one launch -> (ca, rfa)"""
+    n, slices, c = part.shape
+    _, hk, wk, _ = mm.shape
+    ca = torch.empty((n, c), dtype=torch.float32, device=part.device)
+    rfa = torch.empty((n, hk, wk), dtype=torch.float32, device=mm.device)
+    with _Timed("ly_rfcbam_mid_kernel", 36.0 * n * hk * wk, 12.0 * n * hk * wk + 4.0 * n * slices * c):
+        capi.check(capi.lib().ly_rfcbam_mid(_p(part), slices, c, hw, _p(wa), _p(wb), r, _p(ca), n, _p(mm), hk, wk, _p(w18), _p(rfa), capi.stream_ptr()),
+                   "ly_rfcbam_mid")
+    return ca, rfa
 
 
 def rfa_map(mm, w18):

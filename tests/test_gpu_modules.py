@@ -316,6 +316,16 @@ def test_rfcbam_intermediates_golden(name):
     _cmp(ca, arr["x_ca"], name + " ca")
     _cmp(mm.permute(0, 3, 1, 2), arr["x_mm"], name + " [max, mean] map")
     _cmp(rfa.unsqueeze(1), arr["x_rfa"], name + " rfa")
+    # the fused launches the module itself uses: statistics + SE pooling partials in one pass, then SE linears + get_weight in one
+    with torch.no_grad():
+        if k == 1:
+            mm2, part = ops.rfcbam_stats(xr, ld, n, h, w, c, 1, 1, a1=P["a1"], b1=P["b1"], gap=True)
+        else:
+            mm2, part = ops.rfcbam_stats(xr, ld, n, h, w, c, 3, s, wg=P["wq_stats"], th=th, tw=tw, gap=True)
+        ca2, rfa2 = ops.rfcbam_mid(part, h * w, m.se.fc[0].weight.detach().contiguous(), m.se.fc[2].weight.detach().contiguous(), m.se.ratio, mm2, P["w18"])
+    _cmp(ca2, arr["x_ca"], name + " ca (fused pass)")
+    _cmp(mm2.permute(0, 3, 1, 2), arr["x_mm"], name + " [max, mean] map (fused pass)")
+    _cmp(rfa2.unsqueeze(1), arr["x_rfa"], name + " rfa (fused pass)")
 
 
 @pytest.mark.parametrize("name", G.names("coordatt"))

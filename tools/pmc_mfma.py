@@ -1,0 +1,40 @@
+"""rocprofv3 PMC csv (SQ_VALU_MFMA_BUSY_CYCLES + SQ_BUSY_CYCLES + GRBM_GUI_ACTIVE pass) -> {kernel: MFMA-busy figures per launch}.
+
+usage: pmc_mfma.py <counter_collection.csv> <out.json>
+MI355X_MICROARCH.md: SQ_VALU_MFMA_BUSY_CYCLES counts cycles a SIMD's matrix pipe is busy (16 per v_mfma_f32_16x16x32_bf16), summed
+over the SIMDs that ran the kernel; GRBM_GUI_ACTIVE = cycles the GPU was busy during the dispatch.  mfma_busy_frac = MFMA-busy
+cycles / (GRBM_GUI_ACTIVE x 1024 SIMDs): the fraction of the chip's matrix-pipe capacity the launch used (1.0 = every SIMD's matrix
+pipe busy every cycle = the dense peak)."""
+import csv
+import json
+import re
+import sys
+from collections import defaultdict
+
+SIMDS = 256 * 4
+
+
+def norm(name):
+    name = re.sub(r"^void\s+", "", name)
+    return name.split("(")[0].strip()
+
+
+acc = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
+for r in csv.DictReader(open(sys.argv[1])):
+    k = norm(r["Kernel_Name"])
+    c = r["Counter_Name"]
+    acc[k][c][0] += 1
+    acc[k][c][1] += float(r["Counter_Value"])
+out = {}
+for k, cs in acc.items():
+    if "ly_" not in k:
+        continue
+    mean = {c: v[1] / v[0] for c, v in cs.items()}
+    busy, gui = mean.get("SQ_VALU_MFMA_BUSY_CYCLES"), mean.get("GRBM_GUI_ACTIVE")
+    if busy is None or not gui:
+        continue
+    out[k] = dict(mfma_busy_cycles=round(busy), gpu_active_cycles=round(gui), sq_busy_cycles=round(mean.get("SQ_BUSY_CYCLES", 0)),
+                  mfma_busy_frac=round(busy / (gui * SIMDS), 4), launches=cs["GRBM_GUI_ACTIVE"][0],
+                  note="mean per launch; frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 1024 SIMDs)")
+json.dump(out, open(sys.argv[2], "w"), indent=1)
+print(f"{len(out)} kernels -> {sys.argv[2]}")

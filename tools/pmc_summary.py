@@ -13,6 +13,6 @@ for r in csv.DictReader(open(path)):
 names = sorted({c for k in acc for c in acc[k]})
 print("kernel".ljust(70), *[n[-18:].rjust(19) for n in names])
 for k in sorted(acc, key=lambda k: -acc[k].get("SQ_WAVE_CYCLES", acc[k].get(names[0]))[1]):
-    if not k.startswith("void ly_") and not k.startswith("ly_"):
+    if "ly_" not in k:
         continue
     print(k.ljust(70), *[f"{acc[k][n][1] / max(acc[k][n][0], 1):19.0f}" for n in names])

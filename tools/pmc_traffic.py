@@ -31,7 +31,7 @@ fetch = load(sys.argv[1], "FETCH_SIZE")
 write = load(sys.argv[2], "WRITE_SIZE")
 out = {}
 for k in sorted(set(fetch) | set(write)):
-    if not k.startswith("ly_"):
+    if "ly_" not in k:
         continue
     out[k] = dict(fetch_bytes=round(2 * 1024 * fetch.get(k, 0.0)), write_bytes=round(1024 * write.get(k, 0.0)),
                   hbm_bytes=round(2 * 1024 * fetch.get(k, 0.0) + 1024 * write.get(k, 0.0)),

@@ -441,7 +441,7 @@ def test_graphed_train_step_matches_eager(amp):
                      {k: v.detach().clone() for k, v in ema.ema.state_dict().items() if v.is_floating_point()}))
     (l0, w0, u0, e0), (l1, w1, u1, e1) = runs
     assert u0 == u1 == 6
-    tol = 2e-3 if amp is None else 5e-2            # float atomics (statistics, wgrad) make two runs differ by rounding noise; every bf16 rounding
+    tol = 1e-2 if amp is None else 5e-2            # float atomics (statistics, wgrad) make two runs differ by rounding noise; every bf16 rounding
                                                    # boundary that noise crosses amplifies it, and four fast-learning steps compound it
     for a, b in zip(l0, l1):
         assert abs(a - b) <= tol * abs(a), (l0, l1)

@@ -126,6 +126,8 @@ int ly_se_fwd(const void* x /*T*/, int ldx, int n_img, int HW, int C, const floa
  * ly_rfcbam_mid / ly_se_mlp — x is then read once instead of twice before the contraction.                              */
 int ly_rfcbam_stats(const void* x /*T*/, int ldx, int n_img, int H, int W, int C, int k, int s, const float* wg,
                     const float* a1, const float* b1, int TH, int TW, float* mm, float* part, int slices, int dtype, void* stream);
+/* SE pooling partials alone (the first half of ly_se_fwd): part[n][slice][C] = sum of x over the pixels of slice `slice`.          */
+int ly_colsum(const void* x /*T*/, int ldx, int n_img, int HW, int C, float* part, int slices, int dtype, void* stream);
 /* SE's two linears + sigmoid from the pooling partials (-> ca [n_img, C]) and get_weight's 3x3 conv + sigmoid on the [max, mean]
  * map (-> rfa [n_img, HK, WK]) as ONE launch (two independent groups of blocks): the steps between ly_rfcbam_stats and the main
  * contraction (models/rfa.py:88-92, 107, 127).  HW = pixels per image of the pooled input.                                    */

@@ -79,6 +79,7 @@ SIGNATURES = {
     "ly_coordatt_gate": [_P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _P],
     "ly_se_fwd": [_P, _I, _I, _I, _I, _P, _P, _I, _P, _I, _P, _I, _P],
     "ly_rfcbam_stats": [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _I, _I, _P],
+    "ly_colsum": [_P, _I, _I, _I, _I, _P, _I, _I, _P],
     "ly_rfcbam_mid": [_P, _I, _I, _I, _P, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P],
     "ly_rfa_map": [_P, _I, _I, _I, _P, _P, _P],
     "ly_rfcbam3_fwd": [ctypes.POINTER(LyRfcbam3Params), _P],

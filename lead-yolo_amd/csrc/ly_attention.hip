@@ -166,6 +166,16 @@ __global__ __launch_bounds__(LY_THREADS) void ly_se_mlp_kernel(const float* __re
   ly_se_mlp_body(sm, blockIdx.x, part, slices, C, inv_hw, wa, wb, R, ca);
 }
 
+// SE pooling partials alone: part[n][slice][C] = sum of x over the slice's pixels (for ly_rfcbam_mid)
+extern "C" int ly_colsum(const void* x, int ldx, int n_img, int HW, int C, float* part, int slices, int dtype, void* stream) {
+  LY_CHECK_DTYPE(dtype, "colsum");
+  LY_CHECK(x && part && (C & 3) == 0 && (ldx & 3) == 0 && C <= 1024 && slices > 0, "colsum: bad arguments");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  LY_WITH_T(dtype, hipLaunchKernelGGL(ly_colsum_kernel<T>, dim3(n_img * slices), dim3(LY_THREADS), 0, st, reinterpret_cast<const T*>(x), ldx, HW, C, slices, part));
+  LY_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int ly_se_fwd(const void* x, int ldx, int n_img, int HW, int C, const float* wa, const float* wb, int R, float* part,
                          int slices, float* ca, int dtype, void* stream) {
   LY_CHECK_DTYPE(dtype, "se");

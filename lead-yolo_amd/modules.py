@@ -556,9 +556,9 @@ class RFCBAMConv(nn.Module):
         k, s = self.kernel_size, self.stride
         P = self._packed(ops.planes_of(xr))
         wa, wb = self.se.fc[0].weight.detach().float().contiguous(), self.se.fc[2].weight.detach().float().contiguous()
-        # Three launches: (1) ONE pass over x leaves the [max, mean] statistics map AND the partial sums of SE's global average pool,
-        # (2) SE's linears and get_weight's 3x3 conv on the small maps, (3) the contraction.  (The reference reads x for the pool,
-        # again for `generate`, and walks the 9x tensor ~13 times.)
+        # k = 1, three launches: (1) ONE pass over x leaves the [max, mean] statistics map AND the partial sums of SE's global average
+        # pool, (2) SE's linears and get_weight's 3x3 conv on the small maps, (3) the contraction.  k = 3, four: the pooling partials
+        # are their own pass.  (The reference reads x for the pool, again for `generate`, and walks the 9x tensor ~13 times.)
         if k == 1:
             a1, b1, es, eb = P["a1"], P["b1"], P["es"], P["eb"]
             if self.training:
@@ -589,7 +589,8 @@ class RFCBAMConv(nn.Module):
             gs, gb = ops.bn_batch_affine(self.generate[1], s1, s2, cnt)
             wq_stats = pack.rfcbam_gen_weights(gw, gs, gb, 32, False)
             wq_main = pack.rfcbam_gen_weights(gw, gs, gb, 16, True)
-        mm, part = ops.rfcbam_stats(xr, ld, n, h, w, c, 3, s, wg=wq_stats, th=th, tw=tw, gap=True)
+        part = ops.colsum(xr, ld, n, h * w, c)                                                 # k = 3: pooling partials as their own pass
+        mm = ops.rfcbam_stats(xr, ld, n, h, w, c, 3, s, wg=wq_stats, th=th, tw=tw)
         ca, rfa = ops.rfcbam_mid(part, h * w, wa, wb, self.se.ratio, mm, P["w18"])
         kw = dict(n=n, h=h, w=w, c=c, ho=ho, wo=wo, N=self.o, s=s, th=th, tw=tw, x=xr, ldx=ld, wg=wq_main, ca=ca, rfa=rfa, wp=P["wp"],
                   ldo=self.o)

@@ -222,14 +222,27 @@ def coordatt_gate(x, ldx, n, h, w, c, a_h, a_w, res=None, ldres=0):
 
 
 def se_attention(x, ldx, n, hw, c, wa, wb, r):
-    slices = max(1, min(hw // 64, 128))          # depends on the map only (results do not change with the batch split); short
-                                                  # per-block row loops: the pass is latency-bound, not bandwidth-bound
+    slices = se_slices(hw)                       # short per-block row loops: the pass is latency-bound, not bandwidth-bound
     part = torch.empty((n, slices, c), dtype=torch.float32, device=x.device)
     ca = torch.empty((n, c), dtype=torch.float32, device=x.device)
     with _Timed(f"ly_colsum_kernel<{_tname(x)}> + ly_se_mlp_kernel", 1.0 * n * hw * c, x.element_size() * n * hw * c):
         capi.check(capi.lib().ly_se_fwd(_p(x), ldx, n, hw, c, _p(wa), _p(wb), r, _p(part), slices, _p(ca), capi.dtype_code(x), capi.stream_ptr()),
                    "ly_se_fwd")
     return ca
+
+
+def se_slices(hw):
+    """pixel slices of the SE pooling partials: a function of the MAP only, so results do not change with the batch split"""
+    return max(1, min(hw // 64, 128))
+
+
+def colsum(x, ldx, n, hw, c):
+    """SE pooling partials part[n][slice][c] (one pass over x)"""
+    slices = se_slices(hw)
+    part = torch.empty((n, slices, c), dtype=torch.float32, device=x.device)
+    with _Timed(f"ly_colsum_kernel<{_tname(x)}>", 1.0 * n * hw * c, x.element_size() * n * hw * c):
+        capi.check(capi.lib().ly_colsum(_p(x), ldx, n, hw, c, _p(part), slices, capi.dtype_code(x), capi.stream_ptr()), "ly_colsum")
+    return part
 
 
 def pick_tile(ho, wo):
@@ -256,7 +269,10 @@ def rfcbam_stats(x, ldx, n, h, w, c, k, s, wg=None, a1=None, b1=None, th=1, tw=6
     mm = torch.empty((n, k * ho, k * wo, 2), dtype=torch.float32, device=x.device)
     part, slices = None, 0
     if gap:
-        slices = (-(-ho // th) * -(-wo // tw)) if k == 3 else max(1, min(h * w // 16, max(1, 2048 // n)))
+        if k == 3:
+            raise NotImplementedError("the fused statistics + pooling pass is built for k = 1 (for k = 3 the extra per-chunk LDS pass cost more "
+                                      "than the separate ly_colsum launch it saved: measured 44 -> 69 us)")
+        slices = max(1, min(h * w // 16, 128))            # a function of the map only: results do not change with the batch split
         part = torch.empty((n, slices, c), dtype=torch.float32, device=x.device)
     with _Timed((f"ly_rfcbam_pre1_kernel<{_tname(x)}>" if (gap and k == 1) else f"ly_rfcbam_stats{k}_kernel<{_tname(x)}>"), 2.0 * n * ho * wo * c * (81 if k == 3 else 1),
                 x.element_size() * n * h * w * c + 4.0 * 2 * k * k * n * ho * wo):

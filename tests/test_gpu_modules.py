@@ -321,7 +321,7 @@ def test_rfcbam_intermediates_golden(name):
         if k == 1:
             mm2, part = ops.rfcbam_stats(xr, ld, n, h, w, c, 1, 1, a1=P["a1"], b1=P["b1"], gap=True)
         else:
-            mm2, part = ops.rfcbam_stats(xr, ld, n, h, w, c, 3, s, wg=P["wq_stats"], th=th, tw=tw, gap=True)
+            mm2, part = ops.rfcbam_stats(xr, ld, n, h, w, c, 3, s, wg=P["wq_stats"], th=th, tw=tw), ops.colsum(xr, ld, n, h * w, c)
         ca2, rfa2 = ops.rfcbam_mid(part, h * w, m.se.fc[0].weight.detach().contiguous(), m.se.fc[2].weight.detach().contiguous(), m.se.ratio, mm2, P["w18"])
     _cmp(ca2, arr["x_ca"], name + " ca (fused pass)")
     _cmp(mm2.permute(0, 3, 1, 2), arr["x_mm"], name + " [max, mean] map (fused pass)")

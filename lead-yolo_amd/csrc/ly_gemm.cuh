@@ -347,8 +347,11 @@ __device__ __forceinline__ void ly_gemm_body2(const LyGemmParams& P, const int g
   }
 }
 
+// Two waves per SIMD (8 per CU) are what hides the 1-2 us of a load round trip behind another wave's MFMAs: the register
+// allocator is told to fit 256 unified registers (left alone it takes up to ~290 for the gather variants and halves the occupancy:
+// UP2 at 80x80x32 57 -> 78 us).
 template <typename TI, typename TO, int NT, int MT, int WC, int GATHER, int PRO>
-__global__ __launch_bounds__(LY_THREADS) void ly_gemm_kernel_d2(const LyGemmParams P, const int gy, const int nslots, const int gx) {
+__global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(2))) void ly_gemm_kernel_d2(const LyGemmParams P, const int gy, const int nslots, const int gx) {
   ly_gemm_body2<TI, TO, NT, MT, WC, GATHER, PRO>(P, gy, nslots, gx);
 }
 

@@ -62,18 +62,67 @@ __device__ __forceinline__ float rf_wave_max(float v) {
   return v;
 }
 
+// Thread = channel means one element per lane and access: 4 bytes in fp32, but only 2 in bf16 — half-width requests, and the in-place
+// updates become sub-dword read-modify-writes (ly_rf_bwd_relu: 235 us in fp32, 525 us in bf16).  For bf16 the two lanes of an
+// (even, odd) channel pair therefore SHARE accesses: for tap t the lane with (t & 1) == (c & 1) moves the 4-byte pair of both
+// channels and the halves are exchanged with a DPP shuffle — same registers per thread, half the requests, all of them dwords.
+// off(t) = element offset of tap t for channel 0; every lane of a pair must call these together (no divergence around them).
+template <typename T, int KK, class OffFn>
+__device__ __forceinline__ void rf_ld_taps(const T* __restrict__ p, int c, OffFn off, float (&v)[KK]) {
+  if constexpr (sizeof(T) == 4) {
+#pragma unroll
+    for (int t = 0; t < KK; ++t) v[t] = p[off(t) + c];
+  } else {
+    const int odd = c & 1, ce = c - odd;
+#pragma unroll
+    for (int t = 0; t < KK; ++t) {
+      const bool mine = (t & 1) == odd;
+      float lo = 0.f, hi = 0.f;
+      if (mine) {
+        const bf16x2 w = *reinterpret_cast<const bf16x2*>(p + off(t) + ce);
+        lo = (float)w[0]; hi = (float)w[1];
+      }
+      const float recv = __shfl_xor(odd ? lo : hi, 1);          // the partner's channel of the pair this lane fetched
+      v[t] = mine ? (odd ? hi : lo) : recv;
+    }
+  }
+}
+template <typename T, int KK, class OffFn>
+__device__ __forceinline__ void rf_st_taps(T* __restrict__ p, int c, OffFn off, const float (&v)[KK], bool ok) {
+  if constexpr (sizeof(T) == 4) {
+    if (ok) {
+#pragma unroll
+      for (int t = 0; t < KK; ++t) p[off(t) + c] = v[t];
+    }
+  } else {
+    const int odd = c & 1, ce = c - odd;
+#pragma unroll
+    for (int t = 0; t < KK; ++t) {
+      const float other = __shfl_xor(v[t], 1);
+      if (((t & 1) == odd) && ok) {
+        const bf16x2 w = {(__bf16)(odd ? other : v[t]), (__bf16)(odd ? v[t] : other)};
+        *reinterpret_cast<bf16x2*>(p + off(t) + ce) = w;
+      }
+    }
+  }
+}
+
 // loads the KK input taps of output pixel (n, ho, wo) for channel c (zero padded)
 template <typename T, int K>
 __device__ __forceinline__ void rf_taps(const T* __restrict__ x, int ldx, const RfGeom& g, int n, int ho, int wo, int c, float (&xt)[K * K]) {
+  bool okt[K * K];
+  long offt[K * K];
 #pragma unroll
   for (int uy = 0; uy < K; ++uy)
 #pragma unroll
     for (int ux = 0; ux < K; ++ux) {
       const int hi = ho * g.s + uy - g.pad, wi = wo * g.s + ux - g.pad;
-      const bool ok = hi >= 0 && hi < g.H && wi >= 0 && wi < g.W;
-      const float v = ly_ld1<T>(x + (ok ? (((long)n * g.H + hi) * g.W + wi) * ldx + c : c));
-      xt[uy * K + ux] = ok ? v : 0.f;
+      okt[uy * K + ux] = hi >= 0 && hi < g.H && wi >= 0 && wi < g.W;
+      offt[uy * K + ux] = okt[uy * K + ux] ? (((long)n * g.H + hi) * g.W + wi) * ldx : 0;
     }
+  rf_ld_taps<T, K * K>(x, c, [&](int t) { return offt[t]; }, xt);
+#pragma unroll
+  for (int t = 0; t < K * K; ++t) xt[t] = okt[t] ? xt[t] : 0.f;
 }
 
 __device__ __forceinline__ void rf_pix(const RfGeom& g, long m, int& n, int& ho, int& wo) {
@@ -115,14 +164,15 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf_generate_kernel(const RfGeom
     rf_pix(g, m, n, ho, wo);
     float xt[KK];
     rf_taps<T, K>(x, ldx, g, n, ho, wo, c, xt);
-    if (!cok) continue;
+    float av[KK];
 #pragma unroll
     for (int t = 0; t < KK; ++t) {
       float a = 0.f;
 #pragma unroll
       for (int u = 0; u < KK; ++u) a += w[t * KK + u] * xt[u];
-      ly_st1<T>(ug + (m * KK + t) * g.C + c, a);
+      av[t] = a;
     }
+    rf_st_taps<T, KK>(ug, c, [&](int t) { return (m * KK + t) * (long)g.C; }, av, cok);
   }
 }
 
@@ -154,26 +204,26 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_attn_kernel(const RfGeom
     // consumed tap by tap, every tap was a full memory round trip: the atomics' branch makes the waits conservative)
     long pos[KK];
     float uv[KK], dv_[KK], rv[KK];
+    const auto eoff = [&](int t) { return (m * KK + t) * (long)g.C; };
+    rf_ld_taps<T, KK>(ug, c, eoff, uv);
+    rf_ld_taps<T, KK>(dcd, c, eoff, dv_);
 #pragma unroll
     for (int t = 0; t < KK; ++t) {
-      const long idx = (m * KK + t) * g.C + c;
       pos[t] = rf_pos<K>(g, n, ho, wo, t);
-      uv[t] = ly_ld1<T>(ug + idx);
-      dv_[t] = ly_ld1<T>(dcd + idx);
       rv[t] = rfa[pos[t]];
     }
-    float pr[KK], mx[KK];
+    float pr[KK], mx[KK], cdv[KK];
 #pragma unroll
     for (int t = 0; t < KK; ++t) {
-      const long idx = (m * KK + t) * g.C + c;
       float G = fmaxf(__fmaf_rn(a[t], uv[t], b[t]), 0.f);
       float d = dv_[t];
       if (!cok) { G = 0.f; d = 0.f; }
-      if (cok) ly_st1<T>(cd + idx, G * cav * rv[t]);
+      cdv[t] = G * cav * rv[t];
       dca += d * rv[t] * G;
       pr[t] = rf_wave_sum(d * G * cav);
       mx[t] = rf_wave_max(G);
     }
+    rf_st_taps<T, KK>(cd, c, eoff, cdv, cok);
     if (lane == 0) {
 #pragma unroll
       for (int t = 0; t < KK; ++t) {
@@ -245,8 +295,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_relu_kernel(const RfGeom
 #pragma unroll
   for (int t = 0; t < KK; ++t) { a[t] = ag[t * g.C + c]; b[t] = bg[t * g.C + c]; s1[t] = 0.f; s2[t] = 0.f; }
   const float invC = 1.f / (float)g.C;
-  if (cok)
-    for (long m = m_begin + sub; m < m_end; m += g.subs) {
+    for (long m = m_begin + sub; m < m_end; m += g.subs) {       // (lanes beyond C run along with clamped addresses: the pair shuffles need both lanes)
       int n, ho, wo;
       rf_pix(g, m, n, ho, wo);
       const float cav = ca[(long)n * g.C + c];
@@ -254,12 +303,12 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_relu_kernel(const RfGeom
       // above it by the compiler and every tap would wait for its own round trip
       long pos[KK];
       float u[KK], dc[KK], rv[KK], gm[KK], dm0[KK], dm1[KK];
+      const auto eoff = [&](int t) { return (m * KK + t) * (long)g.C; };
+      rf_ld_taps<T, KK>(ug, c, eoff, u);
+      rf_ld_taps<T, KK>(dcd, c, eoff, dc);
 #pragma unroll
       for (int t = 0; t < KK; ++t) {
-        const long idx = (m * KK + t) * g.C + c;
         pos[t] = rf_pos<K>(g, n, ho, wo, t);
-        u[t] = ly_ld1<T>(ug + idx);
-        dc[t] = ly_ld1<T>(dcd + idx);
         rv[t] = rfa[pos[t]];
         gm[t] = gmax[pos[t]];
         dm0[t] = d_mm[2 * pos[t]];
@@ -275,8 +324,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_relu_kernel(const RfGeom
         s1[t] += dvv[t];                      // BatchNorm sums from the fp32 value (before it is rounded to T)
         s2[t] += dvv[t] * u[t];
       }
-#pragma unroll
-      for (int t = 0; t < KK; ++t) ly_st1<T>(dcd + (m * KK + t) * g.C + c, dvv[t]);
+      rf_st_taps<T, KK>(dcd, c, eoff, dvv, cok);
     }
   if (cok) {
     const int CK = g.C * KK;
@@ -301,19 +349,15 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_gen_kernel(const RfGeom 
   for (int t = 0; t < KK; ++t) { al[t] = alpha[t * g.C + c]; ka[t] = kappa[t * g.C + c]; la[t] = lambda[t * g.C + c]; }
 #pragma unroll
   for (int i = 0; i < KK * KK; ++i) acc[i] = 0.f;
-  if (cok)
     for (long m = m_begin + sub; m < m_end; m += g.subs) {
       int n, ho, wo;
       rf_pix(g, m, n, ho, wo);
       float xt[KK];
       rf_taps<T, K>(x, ldx, g, n, ho, wo, c, xt);
       float dvl[KK], ugl[KK];              // loads first, in-place stores last (see ly_rf_bwd_relu_kernel)
-#pragma unroll
-      for (int t = 0; t < KK; ++t) {
-        const long idx = (m * KK + t) * g.C + c;
-        dvl[t] = ly_ld1<T>(dv + idx);
-        ugl[t] = ly_ld1<T>(ug + idx);
-      }
+      const auto eoff = [&](int t) { return (m * KK + t) * (long)g.C; };
+      rf_ld_taps<T, KK>(dv, c, eoff, dvl);
+      rf_ld_taps<T, KK>(ug, c, eoff, ugl);
 #pragma unroll
       for (int t = 0; t < KK; ++t) {
         const float d = al[t] * dvl[t] + ka[t] + la[t] * ugl[t];
@@ -321,8 +365,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_gen_kernel(const RfGeom 
 #pragma unroll
         for (int u = 0; u < KK; ++u) acc[t * KK + u] += d * xt[u];
       }
-#pragma unroll
-      for (int t = 0; t < KK; ++t) ly_st1<T>(dv + (m * KK + t) * g.C + c, dvl[t]);
+      rf_st_taps<T, KK>(dv, c, eoff, dvl, cok);
     }
   if (cok) {
     // every (block, pixel sub-group) owns one row of the partial-sum matrix: plain stores, no atomics (81 accumulators per
@@ -354,8 +397,7 @@ __device__ __forceinline__ float rf_dx_s2(const RfGeom& g, const T* __restrict__
       const int ww = wi + 1 - ux, wo = ww >> 1;
       ok[jy][jx] = oky && ww >= 0 && wo < g.Wo;
       const long m = ok[jy][jx] ? ((long)n * g.Ho + ho) * g.Wo + wo : 0;
-#pragma unroll
-      for (int t = 0; t < 9; ++t) v[jy][jx][t] = ly_ld1<T>(dug + (m * 9 + t) * g.C + c);
+      rf_ld_taps<T, 9>(dug, c, [&](int t) { return (m * 9 + t) * (long)g.C; }, v[jy][jx]);
     }
   }
   float acc = 0.f;
@@ -382,8 +424,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_dx_kernel(const RfGeom g
   float w[KK * KK];
 #pragma unroll
   for (int i = 0; i < KK * KK; ++i) w[i] = wg[(long)c * KK * KK + i];
-  if (!cok) return;
-  for (long p = m_begin + sub; p < m_end; p += g.subs) {
+  for (long p = m_begin + sub; p < m_end; p += g.subs) {        // (lanes beyond C run along: the pair shuffles need both lanes)
     const long row = p / g.W;
     const int wi = (int)(p - row * g.W);
     const int n = (int)(row / g.H);
@@ -396,7 +437,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_dx_kernel(const RfGeom g
         else if (py == 0) acc = rf_dx_s2<T, 0, 1>(g, dug, w, n, hi, wi, c);
         else if (px == 0) acc = rf_dx_s2<T, 1, 0>(g, dug, w, n, hi, wi, c);
         else acc = rf_dx_s2<T, 1, 1>(g, dug, w, n, hi, wi, c);
-        ly_st1<T>(dx + p * lddx + c, acc);
+        if (cok) ly_st1<T>(dx + p * lddx + c, acc);
         continue;
       }
     }
@@ -417,12 +458,12 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_dx_kernel(const RfGeom g
         for (int t = 0; t < KK; ++t) acc += ly_ld1<T>(dug + (m * KK + t) * g.C + c) * w[t * KK + (uy * K + ux)];
       }
     }
-    ly_st1<T>(dx + p * lddx + c, acc);
+    if (cok) ly_st1<T>(dx + p * lddx + c, acc);
   }
 }
 
 // ---- C entry points ------------------------------------------------------------------------------
-#define RF_ARGS_OK(k, C) LY_CHECK(((k) == 1 || (k) == 3) && (C) > 0, "rfcbam backward: kernel_size must be 1 or 3")
+#define RF_ARGS_OK(k, C) LY_CHECK(((k) == 1 || (k) == 3) && (C) > 0 && ((C) & 1) == 0, "rfcbam backward: kernel_size must be 1 or 3 and C even")
 #define RF_LAUNCH(kern, grid, ...)                                                                          \
   LY_WITH_T(dtype, {                                                                                        \
     if (k == 3) hipLaunchKernelGGL((kern<T, 3>), grid, dim3(LY_THREADS), 0, st, __VA_ARGS__);                 \

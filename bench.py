@@ -350,14 +350,16 @@ def run_train(args, ctx):
         state["loss"], _ = L.train_step(model, loss_fn, opt, imgs, tg, reducer=reducer, world_size=ctx.world, amp=amp)
 
     step, launch = eager_step, "eager launches"
-    if ctx.world == 1 and not args.no_graph:
-        # the whole optimisation step replayed from one hipGraph (train.GraphedTrainStep): identical kernels, no host work per step
+    if not args.no_graph:
+        # N = 1: the whole optimisation step replayed from one hipGraph (train.GraphedTrainStep): identical kernels, no host work per
+        # step.  N > 1: the graph holds forward + backward, the bucketed RCCL all-reduce and the two-launch optimiser follow eagerly.
         try:
-            g = L.GraphedTrainStep(model, loss_fn, opt, imgs, tg, amp=amp, warmup=max(args.warmup, 2))
+            g = L.GraphedTrainStep(model, loss_fn, opt, imgs, tg, amp=amp, warmup=max(args.warmup, 2), reducer=reducer, world_size=ctx.world)
 
             def step():
                 state["loss"], _ = g()
-            launch = "hipGraph replay of the whole optimisation step"
+            launch = "hipGraph replay of the whole optimisation step" if ctx.world == 1 else \
+                "hipGraph replay of forward + backward, then RCCL all-reduce of the gradient buckets and the fused optimiser step"
         except Exception as e:                                  # noqa: BLE001
             print(f"[bench] hipGraph capture of the train step unavailable ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr)
             step = eager_step
@@ -367,8 +369,8 @@ def run_train(args, ctx):
                workload=f"lead-yolo-{args.scale} bs={args.batch}/gpu 3x{args.size}x{args.size} {args.dtype} full train step: uint8 batch -> "
                         "train-mode forward (batch-statistics BN), ComputeLoss, HIP backward, clip 10, SGD-nesterov 3 groups "
                         "(BASELINE.json configs[2]" + ("" if args.dtype == "bf16" else " shape in fp32") + "); random-init weights",
-               parallelism=(f"dp{ctx.world}: one process per GPU, ~2 MB reverse-order gradient buckets all-reduced over RCCL "
-                            "(torch.distributed 'nccl') from post-accumulate hooks, overlapped with backward") if ctx.world > 1
+               parallelism=(f"dp{ctx.world}: one process per GPU, ~2 MB reverse-order gradient buckets (gradients are views into them) "
+                            "all-reduced over RCCL (torch.distributed 'nccl')") if ctx.world > 1
                else "dp1 (single GPU, no collective)",
                metric="images/sec (640x640) fwd+bwd")
     if reducer is not None:

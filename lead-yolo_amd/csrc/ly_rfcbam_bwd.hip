@@ -67,42 +67,54 @@ __device__ __forceinline__ float rf_wave_max(float v) {
 // (even, odd) channel pair therefore SHARE accesses: for tap t the lane with (t & 1) == (c & 1) moves the 4-byte pair of both
 // channels and the halves are exchanged with a DPP shuffle — same registers per thread, half the requests, all of them dwords.
 // off(t) = element offset of tap t for channel 0; every lane of a pair must call these together (no divergence around them).
-template <typename T, int KK, class OffFn>
+// Measured (bf16, L17 + L20 per launch): relu 525 -> 185 us, attn 292 -> 249 us with PAIR; the kernels that also hold 81 weights
+// or accumulators per thread got SLOWER (dx 263 -> 510, gen 213 -> 258, generate 116 -> 134 us: the exchange code lands between
+// their dependent FMA chains), so they keep element accesses (PAIR = false).
+__device__ __forceinline__ float rf_swap1(float v) {        // value of lane ^ 1: one DPP move (quad_perm [1,0,3,2]), no LDS crossbar
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+template <typename T, int KK, bool PAIR, class OffFn>
 __device__ __forceinline__ void rf_ld_taps(const T* __restrict__ p, int c, OffFn off, float (&v)[KK]) {
-  if constexpr (sizeof(T) == 4) {
+  if constexpr (sizeof(T) == 4 || !PAIR) {
 #pragma unroll
-    for (int t = 0; t < KK; ++t) v[t] = p[off(t) + c];
+    for (int t = 0; t < KK; ++t) v[t] = ly_ld1<T>(p + off(t) + c);
   } else {
-    const int odd = c & 1, ce = c - odd;
+    // step j: the even lane fetches the channel PAIR of tap 2j, the odd lane that of tap 2j+1 — one full-wave dword load per two
+    // taps; each lane keeps its own channel of the pair it fetched and hands the other half to its partner
+    const bool odd = c & 1;
+    const int ce = c - (int)odd;
 #pragma unroll
-    for (int t = 0; t < KK; ++t) {
-      const bool mine = (t & 1) == odd;
-      float lo = 0.f, hi = 0.f;
-      if (mine) {
-        const bf16x2 w = *reinterpret_cast<const bf16x2*>(p + off(t) + ce);
-        lo = (float)w[0]; hi = (float)w[1];
-      }
-      const float recv = __shfl_xor(odd ? lo : hi, 1);          // the partner's channel of the pair this lane fetched
-      v[t] = mine ? (odd ? hi : lo) : recv;
+    for (int j = 0; j < (KK + 1) / 2; ++j) {
+      const int t0 = 2 * j, t1 = 2 * j + 1 < KK ? 2 * j + 1 : 2 * j;         // (odd KK: the last odd lane re-reads tap KK-1, unused)
+      const long o = odd ? off(t1) : off(t0);
+      const bf16x2 w = *reinterpret_cast<const bf16x2*>(p + o + ce);
+      const float lo = (float)w[0], hi = (float)w[1];
+      const float recv = rf_swap1(odd ? lo : hi);
+      v[t0] = odd ? recv : lo;
+      if (2 * j + 1 < KK) v[2 * j + 1] = odd ? hi : recv;
     }
   }
 }
-template <typename T, int KK, class OffFn>
+template <typename T, int KK, bool PAIR, class OffFn>
 __device__ __forceinline__ void rf_st_taps(T* __restrict__ p, int c, OffFn off, const float (&v)[KK], bool ok) {
-  if constexpr (sizeof(T) == 4) {
+  if constexpr (sizeof(T) == 4 || !PAIR) {
     if (ok) {
 #pragma unroll
-      for (int t = 0; t < KK; ++t) p[off(t) + c] = v[t];
+      for (int t = 0; t < KK; ++t) ly_st1<T>(p + off(t) + c, v[t]);
     }
   } else {
-    const int odd = c & 1, ce = c - odd;
+    const bool odd = c & 1;
+    const int ce = c - (int)odd;
 #pragma unroll
-    for (int t = 0; t < KK; ++t) {
-      const float other = __shfl_xor(v[t], 1);
-      if (((t & 1) == odd) && ok) {
-        const bf16x2 w = {(__bf16)(odd ? other : v[t]), (__bf16)(odd ? v[t] : other)};
-        *reinterpret_cast<bf16x2*>(p + off(t) + ce) = w;
-      }
+    for (int j = 0; j < (KK + 1) / 2; ++j) {
+      const int t0 = 2 * j;
+      const bool has1 = 2 * j + 1 < KK;
+      const float v1 = has1 ? v[2 * j + 1] : 0.f;
+      // even lane stores the pair of tap t0 = (mine[t0], partner[t0]); odd lane the pair of tap t0+1 = (partner[t0+1], mine[t0+1])
+      const float recv = rf_swap1(odd ? v[t0] : v1);          // partner receives: from the odd lane its v[t0], from the even lane its v[t0+1]
+      const bf16x2 w = {(__bf16)(odd ? recv : v[t0]), (__bf16)(odd ? v1 : recv)};
+      const long o = odd ? off(has1 ? 2 * j + 1 : t0) : off(t0);
+      if (ok && (!odd || has1)) *reinterpret_cast<bf16x2*>(p + o + ce) = w;
     }
   }
 }
@@ -120,7 +132,7 @@ __device__ __forceinline__ void rf_taps(const T* __restrict__ x, int ldx, const 
       okt[uy * K + ux] = hi >= 0 && hi < g.H && wi >= 0 && wi < g.W;
       offt[uy * K + ux] = okt[uy * K + ux] ? (((long)n * g.H + hi) * g.W + wi) * ldx : 0;
     }
-  rf_ld_taps<T, K * K>(x, c, [&](int t) { return offt[t]; }, xt);
+  rf_ld_taps<T, K * K, false>(x, c, [&](int t) { return offt[t]; }, xt);
 #pragma unroll
   for (int t = 0; t < K * K; ++t) xt[t] = okt[t] ? xt[t] : 0.f;
 }
@@ -172,7 +184,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf_generate_kernel(const RfGeom
       for (int u = 0; u < KK; ++u) a += w[t * KK + u] * xt[u];
       av[t] = a;
     }
-    rf_st_taps<T, KK>(ug, c, [&](int t) { return (m * KK + t) * (long)g.C; }, av, cok);
+    rf_st_taps<T, KK, false>(ug, c, [&](int t) { return (m * KK + t) * (long)g.C; }, av, cok);
   }
 }
 
@@ -205,8 +217,8 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_attn_kernel(const RfGeom
     long pos[KK];
     float uv[KK], dv_[KK], rv[KK];
     const auto eoff = [&](int t) { return (m * KK + t) * (long)g.C; };
-    rf_ld_taps<T, KK>(ug, c, eoff, uv);
-    rf_ld_taps<T, KK>(dcd, c, eoff, dv_);
+    rf_ld_taps<T, KK, true>(ug, c, eoff, uv);
+    rf_ld_taps<T, KK, true>(dcd, c, eoff, dv_);
 #pragma unroll
     for (int t = 0; t < KK; ++t) {
       pos[t] = rf_pos<K>(g, n, ho, wo, t);
@@ -223,7 +235,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_attn_kernel(const RfGeom
       pr[t] = rf_wave_sum(d * G * cav);
       mx[t] = rf_wave_max(G);
     }
-    rf_st_taps<T, KK>(cd, c, eoff, cdv, cok);
+    rf_st_taps<T, KK, true>(cd, c, eoff, cdv, cok);
     if (lane == 0) {
 #pragma unroll
       for (int t = 0; t < KK; ++t) {
@@ -304,8 +316,8 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_relu_kernel(const RfGeom
       long pos[KK];
       float u[KK], dc[KK], rv[KK], gm[KK], dm0[KK], dm1[KK];
       const auto eoff = [&](int t) { return (m * KK + t) * (long)g.C; };
-      rf_ld_taps<T, KK>(ug, c, eoff, u);
-      rf_ld_taps<T, KK>(dcd, c, eoff, dc);
+      rf_ld_taps<T, KK, true>(ug, c, eoff, u);
+      rf_ld_taps<T, KK, true>(dcd, c, eoff, dc);
 #pragma unroll
       for (int t = 0; t < KK; ++t) {
         pos[t] = rf_pos<K>(g, n, ho, wo, t);
@@ -324,7 +336,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_relu_kernel(const RfGeom
         s1[t] += dvv[t];                      // BatchNorm sums from the fp32 value (before it is rounded to T)
         s2[t] += dvv[t] * u[t];
       }
-      rf_st_taps<T, KK>(dcd, c, eoff, dvv, cok);
+      rf_st_taps<T, KK, true>(dcd, c, eoff, dvv, cok);
     }
   if (cok) {
     const int CK = g.C * KK;
@@ -356,8 +368,8 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_gen_kernel(const RfGeom 
       rf_taps<T, K>(x, ldx, g, n, ho, wo, c, xt);
       float dvl[KK], ugl[KK];              // loads first, in-place stores last (see ly_rf_bwd_relu_kernel)
       const auto eoff = [&](int t) { return (m * KK + t) * (long)g.C; };
-      rf_ld_taps<T, KK>(dv, c, eoff, dvl);
-      rf_ld_taps<T, KK>(ug, c, eoff, ugl);
+      rf_ld_taps<T, KK, false>(dv, c, eoff, dvl);
+      rf_ld_taps<T, KK, false>(ug, c, eoff, ugl);
 #pragma unroll
       for (int t = 0; t < KK; ++t) {
         const float d = al[t] * dvl[t] + ka[t] + la[t] * ugl[t];
@@ -365,7 +377,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_gen_kernel(const RfGeom 
 #pragma unroll
         for (int u = 0; u < KK; ++u) acc[t * KK + u] += d * xt[u];
       }
-      rf_st_taps<T, KK>(dv, c, eoff, dvl, cok);
+      rf_st_taps<T, KK, false>(dv, c, eoff, dvl, cok);
     }
   if (cok) {
     // every (block, pixel sub-group) owns one row of the partial-sum matrix: plain stores, no atomics (81 accumulators per
@@ -397,7 +409,7 @@ __device__ __forceinline__ float rf_dx_s2(const RfGeom& g, const T* __restrict__
       const int ww = wi + 1 - ux, wo = ww >> 1;
       ok[jy][jx] = oky && ww >= 0 && wo < g.Wo;
       const long m = ok[jy][jx] ? ((long)n * g.Ho + ho) * g.Wo + wo : 0;
-      rf_ld_taps<T, 9>(dug, c, [&](int t) { return (m * 9 + t) * (long)g.C; }, v[jy][jx]);
+      rf_ld_taps<T, 9, false>(dug, c, [&](int t) { return (m * 9 + t) * (long)g.C; }, v[jy][jx]);
     }
   }
   float acc = 0.f;

@@ -144,6 +144,15 @@ class GradReducer:
             flat.div_(self.world)                                 # pre-scale: SUM of pre-divided = mean, no post pass
         self._works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
+    def begin_external(self):
+        """The gradients of this step were produced outside autograd's hooks (a replayed hipGraph of forward + backward wrote them
+        into the bucket views, which the previous optimiser step left zeroed): mark every bucket as complete and not yet exchanged,
+        so that wait() launches all of them."""
+        self._pending = [len(b["params"]) for b in self.buckets]
+        self._launched = [False] * len(self.buckets)
+        self._works = []
+        self._direct = set()
+
     def reduce_now(self):
         """For callers without hooks (or unused parameters): launch every bucket not yet launched."""
         for bi, left in enumerate(self._pending):

@@ -71,15 +71,10 @@ class ModelEMA:
                     v.mul_(d).add_(msd[k].detach(), alpha=1 - d)
 
 
-def train_step(model, compute_loss, optimizer, imgs, targets, ema=None, reducer=None, world_size=1, max_norm=10.0, amp=None):
-    """One optimisation step; imgs uint8 or float [B,3,H,W] on the model's device, targets [n,6].
-    amp: None (fp32 storage) or torch.bfloat16 — forward and loss run inside torch.autocast(dtype=amp), the reference's
-    `with torch.cuda.amp.autocast(amp)` region (train.py:316) with bf16 in place of fp16 (no GradScaler needed: bf16 keeps
-    fp32's exponent range).  Returns (loss, loss_items) as detached device tensors (no host sync)."""
+def forward_backward(model, compute_loss, imgs, targets, world_size=1, amp=None):
+    """uint8 / float batch -> train-mode forward -> loss -> backward; gradients land in `.grad` (train.py:295-324)"""
     if imgs.dtype == torch.uint8:
         imgs = imgs.float() / 255
-    if reducer is not None:
-        reducer.reset()
     ops.stats_pool_begin(imgs.device)       # one zero fill for all BatchNorm accumulators of the step (ops._StatsPool)
     try:
         with torch.autocast("cuda", dtype=amp, enabled=amp is not None):
@@ -90,10 +85,12 @@ def train_step(model, compute_loss, optimizer, imgs, targets, ema=None, reducer=
         loss.backward()
     finally:
         ops.stats_pool_end()
-    if reducer is not None:
-        reducer.wait()
+    return loss.detach(), items
+
+
+def optimizer_step(model, optimizer, ema=None, max_norm=10.0, reducer=None):
+    """clip + SGD-nesterov + zero_grad (+ EMA): two launches with optim.FusedSGD, the reference's torch calls otherwise"""
     if getattr(optimizer, "fused", False):
-        # clip + SGD-nesterov + zero_grad + EMA: two launches (optim.FusedSGD / csrc/ly_optim.hip)
         if ema is not None and (optimizer._ema is None or optimizer._ema[0] is not ema):
             optimizer.attach_ema(ema, model)
         optimizer.max_norm = max_norm
@@ -105,7 +102,20 @@ def train_step(model, compute_loss, optimizer, imgs, targets, ema=None, reducer=
             optimizer.zero_grad(set_to_none=True)      # with a reducer the gradients are bucket views, zeroed by reset()
         if ema is not None:
             ema.update(model)
-    return loss.detach(), items
+
+
+def train_step(model, compute_loss, optimizer, imgs, targets, ema=None, reducer=None, world_size=1, max_norm=10.0, amp=None):
+    """One optimisation step; imgs uint8 or float [B,3,H,W] on the model's device, targets [n,6].
+    amp: None (fp32 storage) or torch.bfloat16 — forward and loss run inside torch.autocast(dtype=amp), the reference's
+    `with torch.cuda.amp.autocast(amp)` region (train.py:316) with bf16 in place of fp16 (no GradScaler needed: bf16 keeps
+    fp32's exponent range).  Returns (loss, loss_items) as detached device tensors (no host sync)."""
+    if reducer is not None:
+        reducer.reset()
+    loss, items = forward_backward(model, compute_loss, imgs, targets, world_size=world_size, amp=amp)
+    if reducer is not None:
+        reducer.wait()
+    optimizer_step(model, optimizer, ema=ema, max_norm=max_norm, reducer=reducer)
+    return loss, items
 
 
 class GraphedTrainStep:
@@ -118,15 +128,20 @@ class GraphedTrainStep:
         loss, items = step(next_imgs, next_targets)        # same shapes; pad `targets` with rows whose image index is -1
 
     Construction runs `warmup` REAL optimisation steps on the given batch (they size the allocator pools, the statistics pool and
-    the optimiser's tensor table) and then captures one more; each call replays it."""
+    the optimiser's tensor table) and then captures one more; each call replays it.
 
-    def __init__(self, model, compute_loss, optimizer, imgs, targets, ema=None, amp=None, max_norm=10.0, warmup=3):
+    Data parallel (reducer = ddp.GradReducer, world_size > 1): the graph holds forward + backward only; the gradient exchange and
+    the two-launch optimiser step follow it eagerly.  For this model family the exchange is 3-87 MB — 0.1-1 ms on xGMI against a
+    20+ ms step — so what limits scaling is the ~1,400 launches per step each rank's host would otherwise issue, not the missing
+    overlap of the all-reduce with backward (the overlapped, hook-driven exchange remains what eager `train_step` uses)."""
+
+    def __init__(self, model, compute_loss, optimizer, imgs, targets, ema=None, amp=None, max_norm=10.0, warmup=3, reducer=None, world_size=1):
         if not getattr(optimizer, "fused", False):
             raise NotImplementedError("GraphedTrainStep needs optim.FusedSGD (smart_optimizer(..., fused=True)): torch.optim.SGD + "
                                       "clip_grad_norm_ keep per-step host state")
         self.imgs, self.targets = imgs.clone(), targets.clone()
-        self.optimizer, self.ema = optimizer, ema
-        args = dict(ema=ema, amp=amp, max_norm=max_norm)
+        self.model, self.optimizer, self.ema, self.reducer, self.max_norm = model, optimizer, ema, reducer, max_norm
+        args = dict(ema=ema, amp=amp, max_norm=max_norm, reducer=reducer, world_size=world_size)
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream(device=imgs.device)
         side.wait_stream(cur)
@@ -136,8 +151,18 @@ class GraphedTrainStep:
         cur.wait_stream(side)
         torch.cuda.synchronize(imgs.device)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-            self.loss, self.items = train_step(model, compute_loss, optimizer, self.imgs, self.targets, **args)
+        if reducer is None:
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                self.loss, self.items = train_step(model, compute_loss, optimizer, self.imgs, self.targets, ema=ema, amp=amp, max_norm=max_norm)
+        else:
+            reducer.reset()
+            hold = reducer.no_sync()
+            hold.__enter__()                       # inside the graph gradients only accumulate into the bucket views
+            try:
+                with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                    self.loss, self.items = forward_backward(model, compute_loss, self.imgs, self.targets, world_size=world_size, amp=amp)
+            finally:
+                hold.__exit__(None, None, None)
 
     def __call__(self, imgs=None, targets=None):
         if imgs is not None and imgs.data_ptr() != self.imgs.data_ptr():
@@ -147,10 +172,18 @@ class GraphedTrainStep:
                 raise ValueError(f"GraphedTrainStep: targets must keep the captured shape {tuple(self.targets.shape)} (pad with rows whose "
                                  f"image index is -1), got {tuple(targets.shape)}")
             self.targets.copy_(targets, non_blocking=True)
-        self.optimizer._sync_hyper()                       # learning-rate schedule -> device (only when it changed)
-        self.graph.replay()
         from . import pack
-        pack.touch()                                       # parameters / running statistics changed behind torch's version counters
-        if self.ema is not None:
-            self.ema.updates += 1
+        if self.reducer is None:
+            self.optimizer._sync_hyper()                   # learning-rate schedule -> device (only when it changed)
+            self.graph.replay()
+            pack.touch()                                   # parameters / running statistics changed behind torch's version counters
+            if self.ema is not None:
+                self.ema.updates += 1
+            return self.loss, self.items
+        # data parallel: graph = forward + backward (gradients accumulate in the zeroed bucket views) -> all-reduce -> fused optimiser
+        self.graph.replay()
+        self.reducer.begin_external()
+        self.reducer.wait()
+        optimizer_step(self.model, self.optimizer, ema=self.ema, max_norm=self.max_norm, reducer=self.reducer)
+        pack.touch()
         return self.loss, self.items

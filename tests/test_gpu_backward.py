@@ -449,3 +449,36 @@ def test_graphed_train_step_matches_eager(amp):
         assert float((w0[k] - w1[k]).abs().max()) <= 10 * tol * float(w0[k].abs().max()) + 1e-4, k
     for k in e0:
         assert float((e0[k] - e1[k]).abs().max()) <= 10 * tol * float(e0[k].abs().max()) + 1e-4, ("ema", k)
+
+
+def test_graphed_step_with_reducer_matches_eager():
+    """the data-parallel form of the captured step (graph = forward + backward into the reducer's bucket views, then the bucket
+    exchange and the fused optimiser eagerly) against eager train_step with the same reducer, world size 1"""
+    import lead_yolo_amd as L
+    runs = []
+    for graphed in (False, True):
+        torch.manual_seed(0)
+        m = L.Model(_cfg("n"))
+        st = synth.synth_state(synth.shapes_of(m.state_dict()), 5151)
+        st["model.23.anchors"] = m.model[-1].anchors.clone()
+        m.load_state_dict(st)
+        m = m.to(_dev()).train()
+        red = L.GradReducer(list(m.parameters())).attach()
+        opt = L.smart_optimizer(m, "SGD", 0.01, 0.937, 5e-4)
+        cl = L.ComputeLoss(m)
+        imgs, tg = synth.synth_images(4, 128, 21).to(_dev()), synth.synth_targets(4, 22, per_image=3).to(_dev())
+        losses = []
+        if graphed:
+            step = L.GraphedTrainStep(m, cl, opt, imgs, tg, warmup=2, reducer=red, world_size=1)
+            for _ in range(3):
+                losses.append(float(step()[0]))
+        else:
+            for i in range(5):
+                loss, _ = L.train_step(m, cl, opt, imgs, tg, reducer=red)
+                if i >= 2:
+                    losses.append(float(loss))
+        red.detach()
+        runs.append(losses)
+    for a, b in zip(*runs):
+        assert abs(a - b) <= 1e-2 * abs(a), runs
+    assert runs[1][-1] < runs[1][0]

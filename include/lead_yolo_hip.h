@@ -282,6 +282,20 @@ int ly_bn_bwd_coeffs(const float* sums, int stripes, int N, double count, const 
  * lo = bf16(W - hi): the bf16x3 operand of LY_F32 calls) or 1 (hi only: LY_BF16 calls).                                */
 int ly_frag_pack3(const float* w, int R, int K, long ld_r, long ld_k, int rows_to, int planes, void* out, void* stream);
 
+/* Batched packing: one launch refreshes every packed weight image listed in a device-resident table (forward, transposed, tap-flipped,
+ * concatenated ... layouts), reading the fp32 parameters in place through an index map:
+ *   packed row r = ra*nrb + rb, column k = (a*nb + b)*nc + c;  element = src[ra*sra + rb*srb + a*sa + b*sb + c*sc] if r < r_valid,
+ *   k < K, b < vb, c < vc, else 0;  written to row tiles [t0, t0 + T) of dst = [Ttot][S][planes][64][8] bf16.
+ * blk_desc[b] = index of the descriptor block b works on; blk0 = first block of the descriptor; a descriptor takes ceil(T*S*64/256) blocks. */
+typedef struct LyPackDesc {
+  const float* src; void* dst;
+  int r_valid, K, planes, S, t0, T;
+  int nrb, nb, nc, vb, vc;
+  long sra, srb, sa, sb, sc;
+  long blk0;
+} LyPackDesc;
+int ly_pack_table(const LyPackDesc* table, const int* blk_desc, int n_blocks, void* stream);
+
 /* ---- detection loss on device (utils/loss.py:121-268 ComputeLoss / build_targets, utils/metrics.py:293-354 EIoU) --------
  * One pyramid level, forward and gradient (nc == 1, no focal loss): anchor matching with the reference's candidate order
  * (offset k, anchor a, target t), EIoU box loss with analytic gradient, per-cell "last writer wins" objectness target (the

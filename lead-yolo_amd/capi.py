@@ -42,6 +42,12 @@ class LyOptTensor(ctypes.Structure):
     _fields_ = [("p", _P), ("g", _P), ("buf", _P), ("ema", _P), ("n", _L), ("wd", _F), ("group", _I), ("taps", _I), ("cin", _I)]
 
 
+class LyPackDesc(ctypes.Structure):
+    _fields_ = [("src", _P), ("dst", _P), ("r_valid", _I), ("K", _I), ("planes", _I), ("S", _I), ("t0", _I), ("T", _I),
+                ("nrb", _I), ("nb", _I), ("nc", _I), ("vb", _I), ("vc", _I),
+                ("sra", _L), ("srb", _L), ("sa", _L), ("sb", _L), ("sc", _L), ("blk0", _L)]
+
+
 class LyWgradParams(ctypes.Structure):
     _fields_ = [("M", _L), ("H", _I), ("W", _I), ("N", _I), ("du", _P), ("lddu", _I), ("x", _P), ("ldx", _I),
                 ("Hin", _I), ("Win", _I), ("Cin", _I), ("ks", _I), ("stride", _I), ("pad", _I), ("nchw", _I), ("up2", _I),
@@ -108,6 +114,7 @@ SIGNATURES = {
     "ly_loss_level": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P, _I, _P],
     "ly_loss_finish": [_P, _I, _P, _P, _F, _F, _I, _P, _P],
     "ly_detect_tail": [_P, _I, _I, _I, _I, _I, _I, _P, _F, _P, _P, _L, _L, _I, _P],
+    "ly_pack_table": [_P, _P, _I, _P],
     "ly_optim_step": [_P, _P, _P, _I, _P, _P, _P, _P],
 }
 

@@ -929,3 +929,54 @@ extern "C" int ly_frag_pack3(const float* w, int R, int K, long ld_r, long ld_k,
   LY_LAUNCH_CHECK();
   return 0;
 }
+
+
+// -------------------------------------------------------------------------------------------------
+// Batched packing: every packed weight matrix the model needs (forward, transposed for dgrad, tap-flipped, ...) refreshed by ONE
+// launch over a device-resident table of descriptors (113-144 ly_frag_pack3 launches per training step before).  A descriptor
+// reads the fp32 parameter IN PLACE through an index map, so none of the permuted / padded / concatenated temporaries the
+// per-matrix path built on the host exist any more:
+//   packed row r = ra*nrb + rb, column k = (a*nb + b)*nc + c;   valid iff r < r_valid, b < vb, c < vc
+//   element = src[ra*sra + rb*srb + a*sa + b*sb + c*sc]                (strides may be negative: tap flips)
+// and writes row tiles [t0, t0 + T) of a [Ttot][S][planes][64][8] bf16 fragment image (zeros where invalid).
+// -------------------------------------------------------------------------------------------------
+template <int PL>
+__device__ __forceinline__ void ly_pack_one(const LyPackDesc& d, long i) {
+  const int lane = (int)(i & 63);
+  const long ts = i >> 6;
+  const int s = (int)(ts % d.S), t = (int)(ts / d.S);
+  const int row = 16 * t + (lane & 15), q = lane >> 4;
+  const bool rok = row < d.r_valid;
+  const int ra = row / d.nrb, rb = row - ra * d.nrb;
+  const long roff = (long)ra * d.sra + (long)rb * d.srb;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = 32 * s + 16 * (j >> 2) + 4 * q + (j & 3);
+    const int c = k % d.nc, ab = k / d.nc;
+    const int b = ab % d.nb, a = ab / d.nb;
+    const bool ok = rok && k < d.K && b < d.vb && c < d.vc;
+    v[j] = ok ? d.src[roff + (long)a * d.sa + (long)b * d.sb + (long)c * d.sc] : 0.f;
+  }
+  bf16x8 hi, lo;
+  ly_split8(v, hi, lo);
+  uint4* out = reinterpret_cast<uint4*>(d.dst);
+  const long fs = ((long)(d.t0 + t) * d.S + s) * PL;
+  out[fs * 64 + lane] = __builtin_bit_cast(uint4, hi);
+  if constexpr (PL == 2) out[(fs + 1) * 64 + lane] = __builtin_bit_cast(uint4, lo);
+}
+
+__global__ __launch_bounds__(LY_THREADS) void ly_pack_table_kernel(const LyPackDesc* __restrict__ tab, const int* __restrict__ blk_desc) {
+  const LyPackDesc d = tab[blk_desc[blockIdx.x]];
+  const long i = ((long)blockIdx.x - d.blk0) * LY_THREADS + threadIdx.x;
+  if (i >= (long)d.T * d.S * 64) return;
+  if (d.planes == 2) ly_pack_one<2>(d, i);
+  else ly_pack_one<1>(d, i);
+}
+
+extern "C" int ly_pack_table(const LyPackDesc* table, const int* blk_desc, int n_blocks, void* stream) {
+  LY_CHECK(table && blk_desc && n_blocks > 0, "pack_table: bad arguments");
+  hipLaunchKernelGGL(ly_pack_table_kernel, dim3((unsigned)n_blocks), dim3(LY_THREADS), 0, reinterpret_cast<hipStream_t>(stream), table, blk_desc);
+  LY_LAUNCH_CHECK();
+  return 0;
+}

@@ -166,9 +166,9 @@ def conv_dgrad(spec, du, weight, x0, x1, need0, need1):
     m = n * ho * wo
     with torch.no_grad():
         if spec.kind == "pw":
-            w2 = weight.detach().reshape(weight.shape[0], -1)
-            kin = w2.shape[1]
-            wt = pack.frag_pack3(_pad_cols(w2.t(), co), planes=ops.planes_of(du))
+            nw, kin = weight.shape[0], weight.numel() // weight.shape[0]
+            # W^T [kin, co] read in place from the parameter (columns zero-padded to du's channel count)
+            wt = pack.packed(pack.src_matrix(weight, kin, nw, sr=1, sk=kin, k_pad=co), co, ops.planes_of(du))
             d = ops.empty_nhwc(n, kin, ho, wo, du)
             ops.gemm(M=m, H=ho, W=wo, K=co, N=kin, a0=du, lda0=co, k0=co, wp=wt, out=d, ldo=kin)
             if x1 is None:
@@ -179,7 +179,8 @@ def conv_dgrad(spec, du, weight, x0, x1, need0, need1):
                 d0 = ops.up2_bwd(d, kin, n, ho // 2, wo // 2, c0)
             return (d0 if need0 else None), (d[:, c0:] if need1 else None)
         if spec.kind == "c3":
-            wt = pack.frag_pack3(pack.conv_taps_matrix(weight.detach().permute(1, 0, 2, 3).flip(2, 3), 32), planes=ops.planes_of(du))
+            cop = (weight.shape[0] + 31) // 32 * 32
+            wt = pack.packed(pack.src_taps(weight, cop, transposed_flipped=True), 9 * cop, ops.planes_of(du))
             cin = weight.shape[1]
             d = ops.empty_nhwc(n, cin, ho, wo, du)
             ops.conv3x3(M=m, H=ho, W=wo, Cin=co, N=cin, x=du, ldx=co, wp=wt, out=d, ldo=cin)
@@ -188,8 +189,8 @@ def conv_dgrad(spec, du, weight, x0, x1, need0, need1):
             raise NotImplementedError("gradient with respect to the NCHW input image is not built (never needed: it is the data)")
         _, c, h, w = x0.shape
         k = spec.k
-        w2 = weight.detach().permute(0, 2, 3, 1).reshape(co, -1)
-        wt = pack.frag_pack3(w2.t(), planes=ops.planes_of(du))
+        # rows (ky, kx, c), columns co: the transposed patch matrix, read in place
+        wt = pack.packed(pack.Src(weight, k * k * c, nrb=c, sra=1, srb=k * k, nc=co, sc=c * k * k), co, ops.planes_of(du))
         g = torch.empty((m, k * k * c), dtype=du.dtype, device=du.device)
         ops.gemm(M=m, H=ho, W=wo, K=co, N=k * k * c, a0=du, lda0=co, k0=co, wp=wt, out=g, ldo=k * k * c)
         return ops.unpatch(g, n, ho, wo, c, k, h, w), None
@@ -367,15 +368,16 @@ class MlpBlockFn(torch.autograd.Function):
             w1m, w2m = w1.detach().view(2 * c, c), w2.detach().view(c, 2 * c)
             # recompute z, u1, h
             z = x.clone()
-            ops.conv3x3(M=m, H=h, W=w, Cin=c4p, N=c4, x=x, ldx=c, wp=pack.frag_pack3(pack.conv_taps_matrix(wpc.detach(), 32), planes=pl), out=z, ldo=c)
-            pk1 = pack.frag_pack3(w1m, planes=pl)
+            ops.conv3x3(M=m, H=h, W=w, Cin=c4p, N=c4, x=x, ldx=c, wp=pack.packed(pack.src_taps(p_wpc, 32), 9 * 32, pl), out=z, ldo=c)
+            htp = (2 * c // 16 + 1) // 2 * 2
+            pk1 = pack.packed(pack.src_matrix(p_w1, 2 * c, c), c, pl, rows_to=16 * htp)          # the forward's own image
             u1 = ops.empty_nhwc(n, 2 * c, h, w, x)
             ops.gemm(M=m, H=h, W=w, K=c, N=2 * c, a0=z, lda0=c, k0=c, wp=pk1, out=u1, ldo=2 * c)
             hid = ops.empty_nhwc(n, 2 * c, h, w, x)
             ops.gemm(M=m, H=h, W=w, K=c, N=2 * c, a0=z, lda0=c, k0=c, wp=pk1, out=hid, ldo=2 * c, e_scale=a, e_shift=b, act=ACT_RELU)
             # second 1x1
             dh = ops.empty_nhwc(n, 2 * c, h, w, x)
-            ops.gemm(M=m, H=h, W=w, K=c, N=2 * c, a0=dy, lda0=c, k0=c, wp=pack.frag_pack3(w2m.t(), planes=pl), out=dh, ldo=2 * c)
+            ops.gemm(M=m, H=h, W=w, K=c, N=2 * c, a0=dy, lda0=c, k0=c, wp=pack.packed(pack.src_matrix(p_w2, 2 * c, c, sr=1, sk=2 * c), c, pl), out=dh, ldo=2 * c)
             def sink(p):
                 """(gradient tensor to add into, whether it is the parameter's own storage)"""
                 t = ops.grad_target(p)
@@ -386,7 +388,7 @@ class MlpBlockFn(torch.autograd.Function):
             du1, dgamma, dbeta = affine_backward(dh, u1, a, b, ACT_RELU, mean, invstd, True, gamma=p_gamma, beta=p_beta)
             # first 1x1
             g = ops.empty_nhwc(n, c, h, w, x)
-            ops.gemm(M=m, H=h, W=w, K=2 * c, N=c, a0=du1, lda0=2 * c, k0=2 * c, wp=pack.frag_pack3(w1m.t(), planes=pl), out=g, ldo=c)
+            ops.gemm(M=m, H=h, W=w, K=2 * c, N=c, a0=du1, lda0=2 * c, k0=2 * c, wp=pack.packed(pack.src_matrix(p_w1, c, 2 * c, sr=1, sk=c), 2 * c, pl), out=g, ldo=c)
             dw1, d1 = sink(p_w1)
             ops.wgrad(M=m, H=h, W=w, N=2 * c, du=du1, lddu=2 * c, x=z, ldx=c, Hin=h, Win=w, Cin=c, dw=dw1, lddw=c)
             # partial 3x3 conv on the first C/4 channels
@@ -398,7 +400,7 @@ class MlpBlockFn(torch.autograd.Function):
             ops.wgrad(M=m, H=h, W=w, N=c4p, du=g, lddu=c, x=x, ldx=c, Hin=h, Win=w, Cin=c4p, dw=dwp, lddw=9 * c4, ks=3, stride=1, pad=1,
                       dw_ts=ts, dw_cs=cs, n_valid=c4, c_valid=c4)
             t = ops.empty_nhwc(n, c4p, h, w, x)
-            wt = pack.frag_pack3(pack.conv_taps_matrix(wpc.detach().permute(1, 0, 2, 3).flip(2, 3), 32), planes=pl)
+            wt = pack.packed(pack.src_taps(p_wpc, 32, transposed_flipped=True), 9 * 32, pl)
             ops.conv3x3(M=m, H=h, W=w, Cin=c4p, N=c4, x=g, ldx=c, wp=wt, out=t, ldo=c4p)
             dx = dy + g
             dx[:, :c4] = dy[:, :c4] + t[:, :c4]
@@ -545,6 +547,7 @@ class RfcbamFn(torch.autograd.Function):
             ops.rfcbam3(out=out, e_scale=es, e_shift=(bias * es + t).contiguous(), **kw)
             ctx.fwd = dict(kw=kw)
         ctx.geom = (n, c, h, w, k, s, o, ho, wo, ld)
+        ctx.conv_w_param = conv_w
         ctx.save_for_backward(xr, ca, gen_w, getw, conv_w, bias, gs, gb, gmean, ginv, es, t, omean, oinv, mm, rfa)
         return out
 
@@ -573,9 +576,10 @@ class RfcbamFn(torch.autograd.Function):
             du, dgo, dbo = affine_backward(dy, u, es, t, ACT_RELU, omean, oinv, True)
             _tap("rf.du", du)
             # 3. dcd [mo][t][c]
-            wc = conv_w.detach().float().reshape(o, c, kk).permute(0, 2, 1).reshape(o, kk * c)       # columns (t, c)
+            # Wc^T with rows (t, c): conv.0.weight [o, c, kh, kw] read in place
             dcd = torch.empty((mo, kk * c), dtype=dt, device=dev)
-            ops.gemm(M=mo, H=ho, W=wo, K=o, N=kk * c, a0=du, lda0=o, k0=o, wp=pack.frag_pack3(wc.t(), planes=pl), out=dcd, ldo=kk * c)
+            wct = pack.packed(pack.Src(ctx.conv_w_param, kk * c, nrb=c, sra=1, srb=kk, nc=o, sc=c * kk), o, pl)
+            ops.gemm(M=mo, H=ho, W=wo, K=o, N=kk * c, a0=du, lda0=o, k0=o, wp=wct, out=dcd, ldo=kk * c)
             _tap("rf.dcd", dcd)
             # 4. ug
             wg = gen_w.detach().float().reshape(c * kk, kk).contiguous()

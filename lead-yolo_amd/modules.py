@@ -219,9 +219,11 @@ class MLPBlock(nn.Module):
         def build():
             c = self.dim
             htp = (2 * c // 16 + 1) // 2 * 2
-            return (pack.frag_pack3(pack.conv_taps_matrix(wp_.detach(), 4), planes=planes),
-                    pack.frag_pack3(w1_.detach().view(2 * c, c), rows_to=16 * htp, planes=planes),
-                    pack.frag_pack3(w2_.detach().view(c, 2 * c), planes=planes))
+            cq = c // 4
+            cqp = (cq + 3) // 4 * 4
+            return (pack.packed(pack.src_taps(wp_, cqp), 9 * cqp, planes),
+                    pack.packed(pack.src_matrix(w1_, 2 * c, c), c, planes, rows_to=16 * htp),
+                    pack.packed(pack.src_matrix(w2_, c, 2 * c), 2 * c, planes))
         return self._prep.get(key, build, planes)
 
     def _bn_eval(self):
@@ -291,9 +293,11 @@ class _PatchConv(nn.Module):
         key = pack.versions(conv.weight) + (nchw,)
 
         def build():
-            w = conv.weight.detach()
-            co = w.shape[0]
-            return pack.frag_pack3(w.reshape(co, -1) if nchw else w.permute(0, 2, 3, 1).reshape(co, -1), planes=planes)
+            w = conv.weight
+            co, ci, kh, kw = w.shape
+            if nchw:                                              # columns in the weight's own (c, ky, kx) order
+                return pack.packed(pack.src_matrix(w, co, ci * kh * kw), ci * kh * kw, planes)
+            return pack.packed(pack.src_taps(w, ci), kh * kw * ci, planes)      # columns (ky, kx, c): the NHWC patch gather's order
         return self._prep.get(key, build, planes)
 
     def _affine_eval(self):
@@ -421,8 +425,11 @@ class Conv(nn.Module):
         key = pack.versions(conv.weight)
 
         def build():
-            w = conv.weight.detach()
-            return pack.frag_pack3(w.view(self.c2, self.c1) if self.k == 1 else pack.conv_taps_matrix(w, 32), planes=planes)
+            w = conv.weight
+            if self.k == 1:
+                return pack.packed(pack.src_matrix(w, self.c2, self.c1), self.c1, planes)
+            cip = (self.c1 + 31) // 32 * 32
+            return pack.packed(pack.src_taps(w, cip), 9 * cip, planes)
         return self._prep.get(key, build, planes)
 
     def affine_eval(self):
@@ -532,12 +539,12 @@ class RFCBAMConv(nn.Module):
             es, eb = pack.bn_scale_shift(cbn, cw.bias)
             if k == 1:
                 a1 = (gw.detach().float().view(c) * gs).contiguous()
-                return dict(a1=a1, b1=gb, w18=w18, wp=pack.frag_pack3(cw.weight.detach().view(o, c), planes=planes), es=es, eb=eb)
+                return dict(a1=a1, b1=gb, w18=w18, wp=pack.packed(pack.src_matrix(cw.weight, o, c), c, planes), es=es, eb=eb)
             wq_stats = pack.rfcbam_gen_weights(gw, gs, gb, 32, False)           # stats kernel: 32-ch chunks, c0 + w + 4j
             wq_main = pack.rfcbam_gen_weights(gw, gs, gb, 16, True)             # main kernel: 16-ch chunks, c0 + 4w + j
-            wk = torch.zeros(o, c // 16, 160, dtype=torch.float32, device=gw.device)      # 144 real k per 16-channel chunk
-            wk[:, :, :144] = cw.weight.detach().float().reshape(o, c // 16, 16, 9).permute(0, 1, 3, 2).reshape(o, c // 16, 144)   # k = t*16 + ch
-            return dict(wq_stats=wq_stats, wq_main=wq_main, w18=w18, wp=pack.frag_pack3(wk.view(o, -1), planes=planes), es=es, eb=eb)
+            # conv.0.weight [o, c, 3, 3] read as [o][c/16 chunks][10 tap slots (9 real)][16 channels]: k = chunk*160 + t*16 + ch
+            wsrc = pack.Src(cw.weight, o, srb=c * 9, nb=10, vb=9, nc=16, sa=144, sb=1, sc=9)
+            return dict(wq_stats=wq_stats, wq_main=wq_main, w18=w18, wp=pack.packed(wsrc, (c // 16) * 160, planes), es=es, eb=eb)
         return self._prep.get(key, build, planes)
 
     @_edge
@@ -732,8 +739,13 @@ class C3_CA(nn.Module):
         which is also exactly where the later concat wants cv2's output."""
         p1, p2 = self.cv1, self.cv2
         key = pack.versions(p1.conv.weight, p2.conv.weight)
-        return self._prep.get(key, lambda: pack.frag_pack3(torch.cat((p1.conv.weight.detach().view(self.c_, -1),
-                                                                       p2.conv.weight.detach().view(self.c_, -1)), 0), planes=planes), planes)
+        c1 = p1.conv.weight.shape[1]
+
+        def build():
+            if self.c_ % 16 == 0:
+                return pack.packed([pack.src_matrix(p1.conv.weight, self.c_, c1), pack.src_matrix(p2.conv.weight, self.c_, c1)], c1, planes)
+            return pack.frag_pack3(torch.cat((p1.conv.weight.detach().view(self.c_, -1), p2.conv.weight.detach().view(self.c_, -1)), 0), planes=planes)
+        return self._prep.get(key, build, planes)
 
     def _affine12_eval(self):
         p1, p2 = self.cv1, self.cv2
@@ -881,7 +893,7 @@ class Detect(nn.Module):
     def _packed(self, i, planes):
         conv = self.m[i]
         key = pack.versions(conv.weight, conv.bias)
-        return self._prep[i].get(key, lambda: (pack.frag_pack3(conv.weight.detach().view(conv.out_channels, -1), planes=planes),
+        return self._prep[i].get(key, lambda: (pack.packed(pack.src_matrix(conv.weight, conv.out_channels, conv.in_channels), conv.in_channels, planes),
                                                conv.bias.detach().float().contiguous()), planes)
 
     def _head(self, i, x):

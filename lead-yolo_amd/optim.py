@@ -168,7 +168,7 @@ class FusedSGD(torch.optim.Optimizer):
         capi.check(capi.lib().ly_optim_step(capi.ptr(t["tab"]), capi.ptr(t["blk_t"]), capi.ptr(t["blk_o"]), t["n_blocks"], capi.ptr(t["ws"]),
                                             capi.ptr(t["hyper"]), capi.ptr(self.grad_norm), capi.stream_ptr()), "ly_optim_step")
         from . import pack
-        pack.touch()                      # parameters changed through raw pointers: packed-weight caches must refresh
+        pack.touch_weights()              # parameters changed through raw pointers: packed-weight images and caches must refresh
         if self._ema is not None and not capturing:
             self._ema[0].updates += 1
 

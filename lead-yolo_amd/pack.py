@@ -106,3 +106,154 @@ def rfcbam_gen_weights(gen_w, scale, shift, chunk, per_wave_contiguous):
     v = v.reshape(cp // chunk, 4, per // 2, 2, 9, 10)                      # [q][w][p][ab][t][10]
     v = v.permute(0, 1, 4, 2, 5, 3).contiguous()                           # [q][w][t][p][10][ab]
     return v.view(-1)
+
+
+# --------------------------------------------------------------------------------------------------
+# Batched packing (csrc/ly_backward.hip ly_pack_table): every packed weight image of the model — forward, transposed for dgrad,
+# tap-flipped, concatenated — is described ONCE by how it reads the fp32 parameter in place, and all of them are refreshed by a
+# single launch per optimisation step instead of 113-144 ly_frag_pack3 launches plus the permute / pad / cat temporaries feeding
+# them.  `packed(parts, K, planes)` returns the (persistent) packed tensor; it is refreshed lazily, when any source parameter
+# changed since the last refresh (torch version counters, or W_EPOCH for writes through raw pointers: optim.FusedSGD, graph replays).
+# --------------------------------------------------------------------------------------------------
+import weakref
+
+W_EPOCH = 0
+
+
+def touch_weights():
+    """weights were written through raw pointers (fused optimiser step, replayed graph): packed images must be refreshed"""
+    global W_EPOCH
+    W_EPOCH += 1
+    touch()
+
+
+class Src:
+    """rows x K matrix read in place from parameter `param` (contiguous fp32):  row r = ra*nrb + rb, column k = (a*nb + b)*nc + c,
+    element = param.flat[base + ra*sra + rb*srb + a*sa + b*sb + c*sc] for r < rows, b < vb, c < vc (else 0)."""
+
+    def __init__(self, param, rows, base=0, nrb=None, sra=0, srb=0, nb=1, nc=1, vb=None, vc=None, sa=0, sb=0, sc=1):
+        self.param, self.rows, self.base = param, rows, base
+        self.nrb = rows if nrb is None else nrb
+        self.sra, self.srb = sra, srb
+        self.nb, self.nc = nb, nc
+        self.vb, self.vc = (nb if vb is None else vb), (nc if vc is None else vc)
+        self.sa, self.sb, self.sc = sa, sb, sc
+
+    def sig(self):
+        return (self.param.data_ptr(), self.rows, self.base, self.nrb, self.sra, self.srb, self.nb, self.nc, self.vb, self.vc, self.sa, self.sb, self.sc)
+
+
+def src_matrix(param, rows, cols, sr=None, sk=1, k_pad=None):
+    """W[r][k] = param.flat[r*sr + k*sk] (a 2-D view of the parameter: plain or transposed), columns zero-padded to k_pad"""
+    return Src(param, rows, srb=cols * sk if sr is None else sr, nc=(k_pad or cols), vc=cols, sc=sk)
+
+
+def src_taps(w, cip, transposed_flipped=False):
+    """pack.conv_taps_matrix(w, cip) of w [co, ci, kh, kw]: k = tap*cip + c; transposed_flipped: of w.permute(1,0,2,3).flip(2,3)
+    (the operand of the stride-1 convolution's data gradient)"""
+    co, ci, kh, kw = w.shape
+    t = kh * kw
+    if not transposed_flipped:
+        return Src(w, co, srb=ci * t, nb=t, nc=cip, vc=ci, sb=1, sc=t)
+    return Src(w, ci, base=t - 1, srb=t, nb=t, nc=cip, vc=co, sb=-1, sc=ci * t)
+
+
+class _Plan:
+    def __init__(self):
+        self.entries = {}        # key -> dict(out, parts, K, planes, versions)
+        self.table = None
+        self.w_epoch = -1
+
+    def _descs(self, e, blk0):
+        from . import capi
+        out, K, planes = e["out"], e["K"], e["planes"]
+        S = _ceil(K, 32)
+        descs, t0 = [], 0
+        for part in e["parts"]:
+            T = _ceil(part.rows, 16) if part is not e["parts"][-1] else out.shape[0] - t0
+            blocks = _ceil(T * S * 64, 256)
+            descs.append((capi.LyPackDesc(part.param.data_ptr() + 4 * part.base, out.data_ptr(), part.rows, K, planes, S, t0, T, part.nrb, part.nb, part.nc,
+                                          part.vb, part.vc, part.sra, part.srb, part.sa, part.sb, part.sc, blk0), blocks))
+            blk0 += blocks
+            t0 += T
+        return descs, blk0
+
+    def _build_table(self, keys):
+        from . import capi
+        descs, blk0 = [], 0
+        for k in keys:
+            d, blk0 = self._descs(self.entries[k], blk0)
+            descs += d
+        arr = (capi.LyPackDesc * len(descs))(*[d for d, _ in descs])
+        dev = self.entries[keys[0]]["out"].device
+        tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone().to(dev)
+        blk = torch.tensor([i for i, (_, nb) in enumerate(descs) for _ in range(nb)], dtype=torch.int32, device=dev)
+        return tab, blk, blk0
+
+    def _launch(self, table):
+        from . import capi
+        tab, blk, n = table
+        capi.check(capi.lib().ly_pack_table(capi.ptr(tab), capi.ptr(blk), n, capi.stream_ptr()), "ly_pack_table")
+
+    def get(self, parts, K, planes, rows_to=0):
+        key = (tuple(p.sig() for p in parts), K, planes, rows_to)
+        e = self.entries.get(key)
+        capturing = torch.cuda.is_current_stream_capturing()
+        if e is None:
+            if capturing:
+                raise RuntimeError("pack: a new packed-weight layout was requested during hipGraph capture; run one eager step first")
+            dev = parts[0].param.device
+            for p in parts[:-1]:
+                if p.rows % 16:
+                    raise ValueError("pack: stacked parts must have a multiple of 16 rows")
+            rows = sum(p.rows for p in parts)
+            out = torch.empty((_ceil(max(rows, rows_to), 16), _ceil(K, 32), planes, 64, 8), dtype=torch.int16, device=dev)
+            e = dict(out=out, parts=parts, K=K, planes=planes, refs=[weakref.ref(p.param) for p in parts], versions=None)
+            self.entries[key] = e
+            self.table = None
+            self._launch(self._build_table([key]))                # this image now; it joins the batched refresh from the next change on
+            e["versions"] = tuple(p.param._version for p in parts)
+            return out
+        # (inside a captured training step the first request finds the plan stale — an optimiser step always precedes the capture —
+        # so exactly one refresh launch is captured, ahead of the forward)
+        if self.w_epoch != W_EPOCH or e["versions"] != tuple(p.param._version for p in parts):
+            self.refresh(capturing)
+        return e["out"]
+
+    def refresh(self, capturing=False):
+        """ONE launch over every registered image"""
+        if not capturing:
+            dead = [k for k, e in self.entries.items() if any(r() is None for r in e["refs"])]
+            if dead:
+                for k in dead:
+                    del self.entries[k]
+                self.table = None
+        if self.table is None:
+            if capturing:
+                raise RuntimeError("pack: the descriptor table changed during hipGraph capture")
+            by_dev = {}
+            for k, e in self.entries.items():
+                by_dev.setdefault(e["out"].device, []).append(k)
+            self.table = {dev: self._build_table(keys) for dev, keys in by_dev.items()}
+        cur = torch.cuda.current_device()
+        for dev, t in self.table.items():
+            if dev.index == cur or len(self.table) == 1:
+                self._launch(t)
+        for e in self.entries.values():
+            e["versions"] = tuple(p.param._version for p in e["parts"])
+        self.w_epoch = W_EPOCH
+
+
+PLAN = _Plan()
+
+
+def packed(parts, K, planes=2, rows_to=0):
+    """packed fragment image [T, S, planes, 64, 8] (int16 view of bf16) of the matrix described by `parts` (Src or list of Src stacked by
+    rows), refreshed together with every other registered image by one ly_pack_table launch whenever a source parameter changed"""
+    if isinstance(parts, Src):
+        parts = [parts]
+    for p in parts:
+        t = p.param
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise ValueError("pack.packed: sources must be contiguous float32 CUDA parameters")
+    return PLAN.get(list(parts), K, planes, rows_to)

@@ -151,6 +151,8 @@ class GraphedTrainStep:
         cur.wait_stream(side)
         torch.cuda.synchronize(imgs.device)
         self.graph = torch.cuda.CUDAGraph()
+        from . import pack
+        pack.touch_weights()                   # the captured step must begin with the (single) refresh of every packed weight image
         if reducer is None:
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self.loss, self.items = train_step(model, compute_loss, optimizer, self.imgs, self.targets, ema=ema, amp=amp, max_norm=max_norm)
@@ -176,7 +178,7 @@ class GraphedTrainStep:
         if self.reducer is None:
             self.optimizer._sync_hyper()                   # learning-rate schedule -> device (only when it changed)
             self.graph.replay()
-            pack.touch()                                   # parameters / running statistics changed behind torch's version counters
+            pack.touch_weights()                           # parameters / running statistics changed behind torch's version counters
             if self.ema is not None:
                 self.ema.updates += 1
             return self.loss, self.items
@@ -185,5 +187,5 @@ class GraphedTrainStep:
         self.reducer.begin_external()
         self.reducer.wait()
         optimizer_step(self.model, self.optimizer, ema=self.ema, max_norm=self.max_norm, reducer=self.reducer)
-        pack.touch()
+        pack.touch_weights()
         return self.loss, self.items

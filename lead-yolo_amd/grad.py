@@ -365,10 +365,10 @@ class MlpBlockFn(torch.autograd.Function):
         with torch.no_grad():
             dy = _rows_dense(dy if dy.dtype == x.dtype else dy.to(x.dtype))
             pl = ops.planes_of(x)
-            w1m, w2m = w1.detach().view(2 * c, c), w2.detach().view(c, 2 * c)
+            c4q = (c4 + 31) // 32 * 32                 # the 3x3 kernel's tap matrices pad the channels of a tap to 32
             # recompute z, u1, h
             z = x.clone()
-            ops.conv3x3(M=m, H=h, W=w, Cin=c4p, N=c4, x=x, ldx=c, wp=pack.packed(pack.src_taps(p_wpc, 32), 9 * 32, pl), out=z, ldo=c)
+            ops.conv3x3(M=m, H=h, W=w, Cin=c4p, N=c4, x=x, ldx=c, wp=pack.packed(pack.src_taps(p_wpc, c4q), 9 * c4q, pl), out=z, ldo=c)
             htp = (2 * c // 16 + 1) // 2 * 2
             pk1 = pack.packed(pack.src_matrix(p_w1, 2 * c, c), c, pl, rows_to=16 * htp)          # the forward's own image
             u1 = ops.empty_nhwc(n, 2 * c, h, w, x)
@@ -400,7 +400,7 @@ class MlpBlockFn(torch.autograd.Function):
             ops.wgrad(M=m, H=h, W=w, N=c4p, du=g, lddu=c, x=x, ldx=c, Hin=h, Win=w, Cin=c4p, dw=dwp, lddw=9 * c4, ks=3, stride=1, pad=1,
                       dw_ts=ts, dw_cs=cs, n_valid=c4, c_valid=c4)
             t = ops.empty_nhwc(n, c4p, h, w, x)
-            wt = pack.packed(pack.src_taps(p_wpc, 32, transposed_flipped=True), 9 * 32, pl)
+            wt = pack.packed(pack.src_taps(p_wpc, c4q, transposed_flipped=True), 9 * c4q, pl)
             ops.conv3x3(M=m, H=h, W=w, Cin=c4p, N=c4, x=g, ldx=c, wp=wt, out=t, ldo=c4p)
             dx = dy + g
             dx[:, :c4] = dy[:, :c4] + t[:, :c4]

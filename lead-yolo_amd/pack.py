@@ -3,6 +3,8 @@
 `frag_pack(W[R, K])` -> flat fp32 [T*S*256]:  out[((t*S + s)*64 + lane)*4 + j] =
 W[16t + (lane & 15)][16s + 4*(lane >> 4) + j], zero padded to 16-multiples.  One wave-wide weight
 fragment is then one contiguous 1 KiB read."""
+import weakref
+
 import torch
 
 
@@ -115,8 +117,6 @@ def rfcbam_gen_weights(gen_w, scale, shift, chunk, per_wave_contiguous):
 # them.  `packed(parts, K, planes)` returns the (persistent) packed tensor; it is refreshed lazily, when any source parameter
 # changed since the last refresh (torch version counters, or W_EPOCH for writes through raw pointers: optim.FusedSGD, graph replays).
 # --------------------------------------------------------------------------------------------------
-import weakref
-
 W_EPOCH = 0
 
 
@@ -127,20 +127,48 @@ def touch_weights():
     touch()
 
 
+_SHADOW = {}
+
+
+def master(param):
+    """the contiguous float32 tensor the packer reads: the parameter itself, or — for `.half()` / `.bfloat16()` models (inference) — a
+    cached float32 copy, rebuilt when the parameter changes"""
+    if param.dtype == torch.float32 and param.is_contiguous():
+        return param
+    ent = _SHADOW.get(id(param))
+    if ent is None or ent[0]() is not param or ent[1] != param._version:
+        sh = param.detach().float().contiguous()
+        ref = weakref.ref(param, lambda _r, k=id(param): _SHADOW.pop(k, None))
+        _SHADOW[id(param)] = ent = (ref, param._version, sh)
+    return ent[2]
+
+
 class Src:
     """rows x K matrix read in place from parameter `param` (contiguous fp32):  row r = ra*nrb + rb, column k = (a*nb + b)*nc + c,
     element = param.flat[base + ra*sra + rb*srb + a*sa + b*sb + c*sc] for r < rows, b < vb, c < vc (else 0)."""
 
     def __init__(self, param, rows, base=0, nrb=None, sra=0, srb=0, nb=1, nc=1, vb=None, vc=None, sa=0, sb=0, sc=1):
-        self.param, self.rows, self.base = param, rows, base
+        param = master(param)
+        self._ref = weakref.ref(param)             # the plan must not keep dead models' parameters alive
+        self.ptr, self.device = param.data_ptr(), param.device
+        self.ok = param.is_cuda and param.dtype == torch.float32 and param.is_contiguous()
+        self.rows, self.base = rows, base
         self.nrb = rows if nrb is None else nrb
         self.sra, self.srb = sra, srb
         self.nb, self.nc = nb, nc
         self.vb, self.vc = (nb if vb is None else vb), (nc if vc is None else vc)
         self.sa, self.sb, self.sc = sa, sb, sc
 
+    @property
+    def param(self):
+        return self._ref()
+
+    def version(self):
+        p = self._ref()
+        return p._version if p is not None else -1
+
     def sig(self):
-        return (self.param.data_ptr(), self.rows, self.base, self.nrb, self.sra, self.srb, self.nb, self.nc, self.vb, self.vc, self.sa, self.sb, self.sc)
+        return (self.ptr, self.rows, self.base, self.nrb, self.sra, self.srb, self.nb, self.nc, self.vb, self.vc, self.sa, self.sb, self.sc)
 
 
 def src_matrix(param, rows, cols, sr=None, sk=1, k_pad=None):
@@ -172,7 +200,7 @@ class _Plan:
         for part in e["parts"]:
             T = _ceil(part.rows, 16) if part is not e["parts"][-1] else out.shape[0] - t0
             blocks = _ceil(T * S * 64, 256)
-            descs.append((capi.LyPackDesc(part.param.data_ptr() + 4 * part.base, out.data_ptr(), part.rows, K, planes, S, t0, T, part.nrb, part.nb, part.nc,
+            descs.append((capi.LyPackDesc(part.ptr + 4 * part.base, out.data_ptr(), part.rows, K, planes, S, t0, T, part.nrb, part.nb, part.nc,
                                           part.vb, part.vc, part.sra, part.srb, part.sa, part.sb, part.sc, blk0), blocks))
             blk0 += blocks
             t0 += T
@@ -202,28 +230,28 @@ class _Plan:
         if e is None:
             if capturing:
                 raise RuntimeError("pack: a new packed-weight layout was requested during hipGraph capture; run one eager step first")
-            dev = parts[0].param.device
+            dev = parts[0].device
             for p in parts[:-1]:
                 if p.rows % 16:
                     raise ValueError("pack: stacked parts must have a multiple of 16 rows")
             rows = sum(p.rows for p in parts)
             out = torch.empty((_ceil(max(rows, rows_to), 16), _ceil(K, 32), planes, 64, 8), dtype=torch.int16, device=dev)
-            e = dict(out=out, parts=parts, K=K, planes=planes, refs=[weakref.ref(p.param) for p in parts], versions=None)
+            e = dict(out=out, parts=parts, K=K, planes=planes, versions=None)
             self.entries[key] = e
             self.table = None
             self._launch(self._build_table([key]))                # this image now; it joins the batched refresh from the next change on
-            e["versions"] = tuple(p.param._version for p in parts)
+            e["versions"] = tuple(p.version() for p in parts)
             return out
         # (inside a captured training step the first request finds the plan stale — an optimiser step always precedes the capture —
         # so exactly one refresh launch is captured, ahead of the forward)
-        if self.w_epoch != W_EPOCH or e["versions"] != tuple(p.param._version for p in parts):
+        if self.w_epoch != W_EPOCH or e["versions"] != tuple(p.version() for p in parts):
             self.refresh(capturing)
         return e["out"]
 
     def refresh(self, capturing=False):
         """ONE launch over every registered image"""
         if not capturing:
-            dead = [k for k, e in self.entries.items() if any(r() is None for r in e["refs"])]
+            dead = [k for k, e in self.entries.items() if any(p.param is None for p in e["parts"])]
             if dead:
                 for k in dead:
                     del self.entries[k]
@@ -240,7 +268,7 @@ class _Plan:
             if dev.index == cur or len(self.table) == 1:
                 self._launch(t)
         for e in self.entries.values():
-            e["versions"] = tuple(p.param._version for p in e["parts"])
+            e["versions"] = tuple(p.version() for p in e["parts"])
         self.w_epoch = W_EPOCH
 
 
@@ -253,7 +281,6 @@ def packed(parts, K, planes=2, rows_to=0):
     if isinstance(parts, Src):
         parts = [parts]
     for p in parts:
-        t = p.param
-        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        if not p.ok:
             raise ValueError("pack.packed: sources must be contiguous float32 CUDA parameters")
     return PLAN.get(list(parts), K, planes, rows_to)

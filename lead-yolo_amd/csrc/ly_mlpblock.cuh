@@ -361,6 +361,352 @@ __device__ __forceinline__ void ly_mlpblock_body(
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// Persistent form of the same block for the narrow, memory-heavy stages (C <= 40; 8 x 16 / 16 x 16 pixel patches):
+//   * a block loops over patches (grid = what is resident at once); ALL weight fragments of the three contractions are copied to
+//     LDS once per block (15-78 KB) instead of being fetched from L2 by every wave of every patch, one dependent round trip each;
+//   * the raw pixels of patch i+1 (tile + halo) are requested before patch i is computed and committed to the other LDS buffer
+//     after it, so the HBM latency of a patch hides behind the arithmetic of the previous one.
+// The arithmetic per pixel is the block above verbatim (same operand order: results are bit-identical).
+// -------------------------------------------------------------------------------------------------
+template <typename T, int C, int NT, int HT>
+__device__ __forceinline__ void ly_mlpblock_persist_body(
+    const T* __restrict__ x, T* __restrict__ y, long M, int H, int W, int n_img,
+    const uint4* __restrict__ wp, const uint4* __restrict__ w1, const uint4* __restrict__ w2,
+    const float* __restrict__ bn_scale, const float* __restrict__ bn_shift) {
+  using Gm = MlpGeom<C>;
+  using TR = LyT<T>;
+  using RV = typename TR::RV;
+  using R4 = typename TR::R4;
+  constexpr int PL = TR::PL, VW = TR::VW;
+  constexpr int CQ = Gm::CQ, G = Gm::G, SP = Gm::SP, PT = Gm::PT, C16 = Gm::C16, KP = Gm::KP, S1 = Gm::S1;
+  constexpr int RS = Gm::RS, RSP = Gm::RSP, HTP = Gm::HTP, S2 = Gm::S2;
+  constexpr int BP = 64 * NT, TH = 4 * NT, BPH = (TH + 2) * 18;
+  constexpr bool T2D = true, STATS = false;
+  constexpr int NFP = PT * SP, NF1 = HTP * S1, NF2 = C16 * S2, NFW = NFP + NF1 + NF2;
+  constexpr int WBYTES = NFW * PL * 1024, XB = PL * BP * RS, PB = PL * BPH * RSP, BUFB = (XB + PB + 15) / 16 * 16;
+  static_assert(HTP % HT == 0 && HT % 2 == 0 && C % VW == 0, "geometry");
+  extern __shared__ f32x4 ly_smem4[];
+  char* const wl = reinterpret_cast<char*>(ly_smem4);
+  char* const bufs = wl + WBYTES;
+  float* const stats = nullptr;
+  const long p0 = 0;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lq = lane >> 4;
+  const f32x4 zero = ly_zero4();
+
+  // ---- weights -> LDS, once -------------------------------------------------------------------
+  for (int i = tid; i < NFP * PL * 64; i += LY_THREADS) reinterpret_cast<uint4*>(wl)[i] = wp[i];
+  for (int i = tid; i < NF1 * PL * 64; i += LY_THREADS) reinterpret_cast<uint4*>(wl)[NFP * PL * 64 + i] = w1[i];
+  for (int i = tid; i < NF2 * PL * 64; i += LY_THREADS) reinterpret_cast<uint4*>(wl)[(NFP + NF1) * PL * 64 + i] = w2[i];
+  auto wlds = [&](int fi) -> LyWF<PL> {
+    LyWF<PL> f;
+    f.hi = *reinterpret_cast<const bf16x8*>(wl + ((fi * PL) * 64 + lane) * 16);
+    if constexpr (PL == 2) f.lo = *reinterpret_cast<const bf16x8*>(wl + ((fi * PL + 1) * 64 + lane) * 16);
+    return f;
+  };
+  constexpr int FP = SP * PT, F1 = S1 * HT, F2 = (HT / 2) * C16, FQ = F1 + F2;
+  auto wseq = [&](int g) -> LyWF<PL> {
+    if (g < FP) return wlds((g % PT) * SP + g / PT);
+    g -= FP;
+    const int chunk = g / FQ, r = g - chunk * FQ;
+    if (r < F1) return wlds(NFP + (chunk * HT + r % HT) * S1 + r / HT);
+    const int r2 = r - F1;
+    return wlds(NFP + NF1 + (r2 % C16) * S2 + chunk * (HT / 2) + r2 / C16);
+  };
+
+  // ---- patch walk ------------------------------------------------------------------------------
+  const int tw = W >> 4, th = (H + TH - 1) / TH;
+  const int ntiles = n_img * th * tw;
+  long img0 = 0;
+  int h0 = 0, w0 = 0;
+  auto decode = [&](int tile, long& i0, int& hh0, int& ww0) {
+    int b = tile;
+    const int tx = b % tw; b /= tw;
+    const int ty = b % th;
+    i0 = (long)(b / th) * H * W;
+    hh0 = ty * TH; ww0 = tx * 16;
+  };
+  constexpr int TVN = BP * (KP / VW), NVT = (TVN + LY_THREADS - 1) / LY_THREADS;
+  constexpr int HVN = BPH * G, NVH = (HVN + LY_THREADS - 1) / LY_THREADS;
+  RV tv[NVT];
+  R4 hv[NVH];
+  bool tok[NVT], hok[NVH];
+  auto issue = [&](int tile) {
+    long i0; int hh0, ww0;
+    decode(tile, i0, hh0, ww0);
+#pragma unroll
+    for (int e = 0; e < NVT; ++e) {
+      const int idx = tid + e * LY_THREADS;
+      const int pix = idx / (KP / VW), c4 = idx - pix * (KP / VW);
+      const int r = pix >> 4;
+      tok[e] = idx < TVN && hh0 + r < H && c4 * VW < C;
+      tv[e] = ly_ldrv<T>(tok[e] ? x + (i0 + (long)(hh0 + r) * W + ww0 + (pix & 15)) * C + c4 * VW : x);
+    }
+#pragma unroll
+    for (int e = 0; e < NVH; ++e) {
+      const int idx = tid + e * LY_THREADS;
+      const int hp = idx / G, c4 = idx - hp * G;
+      const int hr = hp / 18, hc = hp - hr * 18;
+      const int hh = hh0 - 1 + hr, ww = ww0 - 1 + hc;
+      hok[e] = idx < HVN && hh >= 0 && hh < H && ww >= 0 && ww < W;
+      hv[e] = ly_ldr4<T>(hok[e] ? x + (i0 + (long)hh * W + ww) * C + c4 * 4 : x);
+    }
+  };
+  auto commit = [&](int buf) {
+    char* xh_ = bufs + buf * BUFB;
+    char* xl_ = xh_ + (PL - 1) * BP * RS;
+    char* ph_ = xh_ + XB;
+    char* pl_ = ph_ + (PL - 1) * BPH * RSP;
+#pragma unroll
+    for (int e = 0; e < NVT; ++e) {
+      const int idx = tid + e * LY_THREADS;
+      const int pix = idx / (KP / VW), c4 = idx - pix * (KP / VW);
+      RV v = tv[e];
+      if (!tok[e]) ly_zero_raw(v);
+      if (idx < TVN) ly_lds_put_rv(xh_, xl_, pix * RS, VW * c4, v);
+    }
+#pragma unroll
+    for (int e = 0; e < NVH; ++e) {
+      const int idx = tid + e * LY_THREADS;
+      const int hp = idx / G, c4 = idx - hp * G;
+      R4 v = hv[e];
+      if (!hok[e]) ly_zero_raw(v);
+      if (idx < HVN) ly_lds_put_r4(ph_, pl_, hp * RSP, 4 * c4, v);
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile >= ntiles) return;
+  issue(tile);
+  commit(0);
+  __syncthreads();                                         // weights and the first patch are in LDS
+  int buf = 0;
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int nxt = tile + (int)gridDim.x < ntiles ? tile + (int)gridDim.x : tile;     // (the last patch re-requests itself: straight-line loads)
+    issue(nxt);
+    decode(tile, img0, h0, w0);
+    char* const xs_hi = bufs + buf * BUFB;
+    char* const xs_lo = xs_hi + (PL - 1) * BP * RS;
+    char* const ps_hi = xs_hi + XB;
+    char* const ps_lo = ps_hi + (PL - 1) * BPH * RSP;
+    auto gpix = [&](int pix) -> long {
+      const int r = pix >> 4;
+      return (h0 + r < H) ? img0 + (long)(h0 + r) * W + w0 + (pix & 15) : -1;
+    };
+    int g = 0;
+    auto wnext = [&]() -> LyWF<PL> { return wseq(g); };
+    auto wrefill = [&]() { ++g; };
+    const int pixbase = wave * (16 * NT);
+    const bf16x4 z4 = __builtin_bit_cast(bf16x4, make_uint2(0u, 0u));
+
+    // ---- 1. partial 3x3 conv -------------------------------------------------------------------
+    {
+      uint32_t tmask[NT];
+      int pbase[NT];             // byte offset of the (ty=0, tx=0) tap of this lane's pixel in the halo image
+  #pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int pix = pixbase + 16 * n + li;
+        if (T2D) {
+          tmask[n] = 0x1ffu;                                   // zeros are staged for out-of-image taps
+          pbase[n] = ((pix >> 4) * 18 + (pix & 15)) * RSP;
+        } else {
+          const long gp = p0 + pix;
+          int h_, w_;
+          ly_pix_hw(gp, H, W, h_, w_);
+          tmask[n] = ly_tapmask(h_, w_, H, W, gp < M);
+          pbase[n] = pix * RSP;
+        }
+      }
+      const int rowpitch = T2D ? 18 : W;                       // halo-image pixels per image row
+      f32x4 accp[PT][NT];
+  #pragma unroll
+      for (int t = 0; t < PT; ++t)
+  #pragma unroll
+        for (int n = 0; n < NT; ++n) accp[t][n] = zero;
+
+  #pragma unroll
+      for (int s = 0; s < SP; ++s) {
+        int off[2], tap[2];
+        bool gv[2];
+  #pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int g = 8 * s + 4 * h + lq;
+          gv[h] = g < 9 * G;
+          tap[h] = gv[h] ? g / G : 0;
+          const int cq4 = gv[h] ? g - tap[h] * G : 0;
+          const int ty = tap[h] / 3, tx = tap[h] - 3 * ty;
+          off[h] = (ty * rowpitch + tx) * RSP + 8 * cq4;
+        }
+        bf16x8 xh[NT], xl[NT];
+  #pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const int rb = pbase[n];
+          bf16x4 ph[2], pl[2];
+  #pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const bool ok = gv[h] && (T2D || ((tmask[n] >> tap[h]) & 1u));
+            const bf16x4 a = *reinterpret_cast<const bf16x4*>(ps_hi + rb + off[h]);
+            ph[h] = ok ? a : z4;
+            if constexpr (PL == 2) {
+              const bf16x4 b = *reinterpret_cast<const bf16x4*>(ps_lo + rb + off[h]);
+              pl[h] = ok ? b : z4;
+            } else {
+              pl[h] = z4;
+            }
+          }
+          xh[n] = ly_cat8(ph[0], ph[1]);
+          xl[n] = ly_cat8(pl[0], pl[1]);
+        }
+  #pragma unroll
+        for (int t = 0; t < PT; ++t) {
+          const LyWF<PL> wf = wnext();
+  #pragma unroll
+          for (int n = 0; n < NT; ++n) accp[t][n] = ly_mfmap<PL>(wf, xh[n], xl[n], accp[t][n]);
+          wrefill();
+        }
+      }
+  #pragma unroll
+      for (int t = 0; t < PT; ++t)
+  #pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          bf16x4 h, l;
+          ly_split4(accp[t][n], h, l);
+          const int c = 16 * t + 4 * lq;
+          const int rb = (pixbase + 16 * n + li) * RS + 2 * c;
+          if (c < CQ) {            // CQ is even: channels (c, c+1) are valid together
+            *reinterpret_cast<bf16x2*>(xs_hi + rb) = __builtin_shufflevector(h, h, 0, 1);
+            if constexpr (PL == 2) *reinterpret_cast<bf16x2*>(xs_lo + rb) = __builtin_shufflevector(l, l, 0, 1);
+          }
+          if (c + 2 < CQ) {
+            *reinterpret_cast<bf16x2*>(xs_hi + rb + 4) = __builtin_shufflevector(h, h, 2, 3);
+            if constexpr (PL == 2) *reinterpret_cast<bf16x2*>(xs_lo + rb + 4) = __builtin_shufflevector(l, l, 2, 3);
+          }
+        }
+    }
+
+    // ---- 2 + 3. expand -> BN -> ReLU -> project, hidden kept in registers ---------------------------
+    f32x4 acco[C16][NT];
+  #pragma unroll
+    for (int t = 0; t < C16; ++t)
+  #pragma unroll
+      for (int n = 0; n < NT; ++n) acco[t][n] = zero;
+
+  #pragma unroll
+    for (int hc = 0; hc < HTP / HT; ++hc) {
+      f32x4 acch[HT][NT];
+  #pragma unroll
+      for (int t = 0; t < HT; ++t)
+  #pragma unroll
+        for (int n = 0; n < NT; ++n) acch[t][n] = zero;
+  #pragma unroll
+      for (int s = 0; s < S1; ++s) {
+        bf16x8 xh[NT], xl[NT];
+  #pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const int rb = (pixbase + 16 * n + li) * RS;
+          xh[n] = ly_lds_frag(xs_hi, rb, s, lq);
+          if constexpr (PL == 2) xl[n] = ly_lds_frag(xs_lo, rb, s, lq);
+          else xl[n] = xh[n];
+        }
+  #pragma unroll
+        for (int t = 0; t < HT; ++t) {
+          const LyWF<PL> wf = wnext();
+  #pragma unroll
+          for (int n = 0; n < NT; ++n) acch[t][n] = ly_mfmap<PL>(wf, xh[n], xl[n], acch[t][n]);
+          wrefill();
+        }
+      }
+      if (STATS) {
+        // statistics pass of train-mode BatchNorm: sum / sum of squares of the pre-BN hidden activations
+        // over the valid pixels of this block; nothing else is computed or stored
+  #pragma unroll
+        for (int t = 0; t < HT; ++t) {
+          f32x4 s1 = zero, s2 = zero;
+  #pragma unroll
+          for (int n = 0; n < NT; ++n)
+            if (gpix(pixbase + 16 * n + li) >= 0) {
+              s1 += acch[t][n];
+              s2 += acch[t][n] * acch[t][n];
+            }
+          ly_stats_flush(stats, HTP * 16, (hc * HT + t) * 16 + 4 * lq, s1, s2);
+        }
+        continue;
+      }
+      bf16x4 hh[HT][NT], hl[HT][NT];
+  #pragma unroll
+      for (int t = 0; t < HT; ++t) {
+        const int ch = (hc * HT + t) * 16 + 4 * lq;
+        const f32x4 sc = ly_ldg4(bn_scale + ch), sh = ly_ldg4(bn_shift + ch);
+  #pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          f32x4 v;
+  #pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(acch[t][n][r] * sc[r] + sh[r], 0.f);
+          if constexpr (PL == 2) ly_split4(v, hh[t][n], hl[t][n]);
+          else { hh[t][n] = ly_cvtb4(v); hl[t][n] = hh[t][n]; }
+        }
+      }
+  #pragma unroll
+      for (int u = 0; u < HT / 2; ++u) {
+        bf16x8 xh[NT], xl[NT];
+  #pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          xh[n] = ly_cat8(hh[2 * u][n], hh[2 * u + 1][n]);
+          xl[n] = ly_cat8(hl[2 * u][n], hl[2 * u + 1][n]);
+        }
+  #pragma unroll
+        for (int ct = 0; ct < C16; ++ct) {
+          const LyWF<PL> wf = wnext();
+  #pragma unroll
+          for (int n = 0; n < NT; ++n) acco[ct][n] = ly_mfmap<PL>(wf, xh[n], xl[n], acco[ct][n]);
+          wrefill();
+        }
+      }
+    }
+
+    if (STATS) return;
+    // ---- epilogue: residual + store ------------------------------------------------------------
+    // The residual x is rebuilt from the bf16 hi/lo planes already in LDS (|err| <= 2^-17 |x|) instead
+    // of re-reading global memory: channels < CQP from the halo image's centre tap (the tile's own
+    // copy of those channels was overwritten by the partial conv), the rest from the tile.
+  #pragma unroll
+    for (int ct = 0; ct < C16; ++ct)
+  #pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int c = 16 * ct + 4 * lq;
+        const int pix = pixbase + 16 * n + li;
+        const long gp = gpix(pix);
+        if (c < C && gp >= 0) {
+          bf16x4 rh, rl;
+          if (c < Gm::CQP) {
+            const int rb = (T2D ? (((pix >> 4) + 1) * 18 + (pix & 15) + 1) : (pix + W + 1)) * RSP + 2 * c;
+            rh = *reinterpret_cast<const bf16x4*>(ps_hi + rb);
+            if constexpr (PL == 2) rl = *reinterpret_cast<const bf16x4*>(ps_lo + rb);
+          } else {
+            const int rb = pix * RS + 2 * c;
+            rh = *reinterpret_cast<const bf16x4*>(xs_hi + rb);
+            if constexpr (PL == 2) rl = *reinterpret_cast<const bf16x4*>(xs_lo + rb);
+          }
+          f32x4 r = ly_cvt4(rh);
+          if constexpr (PL == 2) r += ly_cvt4(rl);
+          ly_st4<T>(y + gp * C + c, acco[ct][n] + r);
+        }
+      }
+    commit(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+}
+
+template <typename T, int C, int NT, int HT>
+__global__ __launch_bounds__(LY_THREADS) void ly_mlpblock_persist_kernel(
+    const T* __restrict__ x, T* __restrict__ y, long M, int H, int W, int n_img,
+    const uint4* __restrict__ wp, const uint4* __restrict__ w1, const uint4* __restrict__ w2,
+    const float* __restrict__ bn_scale, const float* __restrict__ bn_shift) {
+  ly_mlpblock_persist_body<T, C, NT, HT>(x, y, M, H, W, n_img, wp, w1, w2, bn_scale, bn_shift);
+}
+
 template <typename T, int C, int NT, int HT, bool T2D, bool STATS>
 __global__ __launch_bounds__(LY_THREADS) void ly_mlpblock_fwd_kernel(
     const T* __restrict__ x, T* __restrict__ y, long M, int H, int W,
@@ -420,6 +766,33 @@ static int launch_mlp_k(const T* x, T* y, long M, int n_img, int H, int W, const
   return 0;
 }
 
+template <typename T, int C, int NT, int HT>
+static int launch_mlp_persist(const T* x, T* y, long M, int n_img, int H, int W, const void* wp, const void* w1, const void* w2,
+                              const float* s, const float* b, hipStream_t st) {
+  using Gm = MlpGeom<C>;
+  constexpr int PL = LyT<T>::PL, BP = 64 * NT, BPH = (4 * NT + 2) * 18;
+  constexpr int NFW = Gm::PT * Gm::SP + Gm::HTP * Gm::S1 + Gm::C16 * Gm::S2;
+  constexpr size_t lds = (size_t)NFW * PL * 1024 + 2 * (((size_t)PL * BP * Gm::RS + (size_t)PL * BPH * Gm::RSP + 15) / 16 * 16);
+  static_assert(lds <= 160 * 1024, "persistent MLPBlock: weights + two patch buffers must fit LDS");
+  auto k = ly_mlpblock_persist_kernel<T, C, NT, HT>;
+  static int per_cu = 0;
+  if (per_cu == 0) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+    LY_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    int nb = 0;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k), LY_THREADS, lds);
+    LY_CHECK(e == hipSuccess, "hipOccupancyMaxActiveBlocksPerMultiprocessor: %s", hipGetErrorString(e));
+    per_cu = nb < 1 ? 1 : (nb > 8 ? 8 : nb);
+  }
+  const long ntiles = (long)n_img * ((H + 4 * NT - 1) / (4 * NT)) * (W / 16);
+  long blocks = 256L * per_cu;
+  if (blocks > ntiles) blocks = ntiles;
+  hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(LY_THREADS), lds, st, x, y, M, H, W, n_img, reinterpret_cast<const uint4*>(wp),
+                     reinterpret_cast<const uint4*>(w1), reinterpret_cast<const uint4*>(w2), s, b);
+  LY_LAUNCH_CHECK();
+  return 0;
+}
+
 template <typename T, int C, int NT, int HT, bool T2D>
 static int launch_mlp(const T* x, T* y, long M, int n_img, int H, int W, const void* wp, const void* w1, const void* w2,
                       const float* s, const float* b, float* stats, hipStream_t st) {
@@ -442,6 +815,11 @@ static int dispatch_nt_t(const T* x, T* y, long M, int n_img, int H, int W, cons
   if (C >= 80) {
     if (NTMAX >= 2 && M >= 200L * 128) return launch_mlp<T, C, NT2, HT, false>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
     return launch_mlp<T, C, 1, HT, false>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
+  }
+  if constexpr (C < 80) {
+    // persistent patch walk with the weights in LDS: enough patches for every resident block to amortise the weight copy
+    if ((W & 15) == 0 && W >= 32 && !stats && (long)n_img * ((H + 7) / 8) * (W / 16) >= 1024)
+      return launch_mlp_persist<T, C, 2, HT>(x, y, M, n_img, H, W, wp, w1, w2, s, b, st);
   }
   if ((W & 15) == 0 && W >= 64 && NTMAX >= 2) return launch_mlp<T, C, 2, HT, true>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
   if (NTMAX >= 4 && M >= 256L * 1024) return launch_mlp<T, C, NT4, HT, false>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);

@@ -225,3 +225,18 @@ def test_whole_model_gradients_bf16():
     # direction over all 0.8 M parameters: rounding flips a fraction of the ReLU / max / argmax decisions of 24 layers (see the
     # module docstring), which perturbs the full gradient by ~sqrt(fraction); the fp32 path's bound on the same quantity is 0.9995
     assert cos >= 0.975 and 0.9 <= (nn / no) ** 0.5 <= 1.1, (cos, (nn / no) ** 0.5)
+
+
+@pytest.mark.parametrize("c,n,h,w", [(24, 12, 160, 160), (40, 24, 80, 80), (16, 8, 128, 128)])
+def test_mlpblock_persistent_kernel_bf16(c, n, h, w):
+    """the persistent patch-walk form of the fused MLPBlock (weights in LDS, double-buffered patches), bf16 storage"""
+    import lead_yolo_amd as L
+    torch.manual_seed(c)
+    m = L.BasicStage(c, 1)
+    st = synth.synth_state(synth.shapes_of(m.state_dict()), 5000 + c)
+    _bn_eps(_load(m, st))
+    x = synth.synth_input((n, c, h, w), 77 + c)
+    with torch.no_grad():
+        want = OF.basic_stage(copy.deepcopy(st), "", x, False)
+        got = m.to(_dev()).eval()(x.to(_dev()).to(BF))
+    _close(got, want, f"basicstage c={c} {n}x{h}x{w} bf16")

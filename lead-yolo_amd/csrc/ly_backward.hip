@@ -41,32 +41,55 @@ __device__ __forceinline__ f32x4 ly_dact4(const f32x4 v, const f32x4 dy) {
 template <typename T, int ACT>
 __global__ __launch_bounds__(LY_THREADS) void ly_bnact_bwd_reduce_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ u,
                                                                           int ldu, long rows, int C, const float* __restrict__ a,
-                                                                          const float* __restrict__ b, float* __restrict__ sums) {
-  __shared__ f32x4 red1[LY_THREADS], red2[LY_THREADS];
-  const int nc4 = C >> 2, tid = threadIdx.x;
-  const int groups = LY_THREADS / nc4;
-  const int c4 = tid % nc4, j0 = tid / nc4;
-  f32x4 s1 = ly_zero4(), s2 = ly_zero4();
+                                                                          const float* __restrict__ b, float* __restrict__ sums, int vw) {
+  // thread = (channel group of vw = 4 or 8 channels — one 16-byte access in both dtypes when C allows 8 —, row lane)
+  constexpr int NQM = LyT<T>::VW / 4;
+  __shared__ f32x4 red1[NQM][LY_THREADS], red2[NQM][LY_THREADS];
+  const int nq = vw >> 2;                                // fp32 quads per thread: 1 or 2
+  const int ncv = C / vw, tid = threadIdx.x;
+  const int groups = LY_THREADS / ncv;
+  const int cv = tid % ncv, j0 = tid / ncv;
+  f32x4 s1[NQM], s2[NQM];
+#pragma unroll
+  for (int q = 0; q < NQM; ++q) { s1[q] = ly_zero4(); s2[q] = ly_zero4(); }
   if (j0 < groups) {
-    const f32x4 av = ly_ldg4(a + 4 * c4), bv = ly_ldg4(b + 4 * c4);
+    f32x4 av[NQM], bv[NQM];
+#pragma unroll
+    for (int q = 0; q < NQM; ++q)
+      if (q < nq) { av[q] = ly_ldg4(a + vw * cv + 4 * q); bv[q] = ly_ldg4(b + vw * cv + 4 * q); }
     for (long r = (long)blockIdx.x * groups + j0; r < rows; r += (long)gridDim.x * groups) {
-      const f32x4 uu = ly_ld4<T>(u + r * ldu + 4 * c4);
-      const f32x4 g = ly_ld4<T>(dy + r * lddy + 4 * c4);
-      const f32x4 dv = ly_dact4<ACT>(av * uu + bv, g);
-      s1 += dv;
-      s2 += dv * uu;
+      f32x4 uu[NQM], g[NQM];
+      if (nq == NQM) {
+        ly_rv_unpack(ly_ldrv<T>(u + r * ldu + vw * cv), uu);
+        ly_rv_unpack(ly_ldrv<T>(dy + r * lddy + vw * cv), g);
+      } else {
+        uu[0] = ly_ld4<T>(u + r * ldu + 4 * cv);
+        g[0] = ly_ld4<T>(dy + r * lddy + 4 * cv);
+      }
+#pragma unroll
+      for (int q = 0; q < NQM; ++q)
+        if (q < nq) {
+          const f32x4 dv = ly_dact4<ACT>(av[q] * uu[q] + bv[q], g[q]);
+          s1[q] += dv;
+          s2[q] += dv * uu[q];
+        }
     }
   }
-  red1[tid] = s1; red2[tid] = s2;
+#pragma unroll
+  for (int q = 0; q < NQM; ++q) { red1[q][tid] = s1[q]; red2[q][tid] = s2[q]; }
   __syncthreads();
   if (j0 == 0) {
-    for (int g = 1; g < groups; ++g) { s1 += red1[g * nc4 + c4]; s2 += red2[g * nc4 + c4]; }
     float* sm = sums + (size_t)(blockIdx.x & (LY_STATS_STRIPES - 1)) * 2 * C;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      atomicAdd(sm + 4 * c4 + r, s1[r]);
-      atomicAdd(sm + C + 4 * c4 + r, s2[r]);
-    }
+    for (int q = 0; q < NQM; ++q)
+      if (q < nq) {
+        for (int g = 1; g < groups; ++g) { s1[q] += red1[q][g * ncv + cv]; s2[q] += red2[q][g * ncv + cv]; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          atomicAdd(sm + vw * cv + 4 * q + r, s1[q][r]);
+          atomicAdd(sm + C + vw * cv + 4 * q + r, s2[q][r]);
+        }
+      }
   }
 }
 
@@ -76,6 +99,28 @@ __global__ __launch_bounds__(LY_THREADS) void ly_bnact_bwd_apply_kernel(const T*
                                                                          const float* __restrict__ b, const float* __restrict__ alpha,
                                                                          const float* __restrict__ kappa, const float* __restrict__ lambda,
                                                                          T* du, int lddu) {
+  // 16-byte accesses in both dtypes (4 fp32 / 8 bf16 channels per thread) when C allows, else 4 channels
+  constexpr int VW = LyT<T>::VW, NQ = VW / 4;
+  using RV = typename LyT<T>::RV;
+  if ((C % VW) == 0 && (ldu % VW) == 0 && (lddy % VW) == 0 && (lddu % VW) == 0) {
+    const int ncv = C / VW;
+    const long total = rows * ncv;
+    for (long i = (long)blockIdx.x * LY_THREADS + threadIdx.x; i < total; i += (long)gridDim.x * LY_THREADS) {
+      const long r = i / ncv;
+      const int c = VW * (int)(i - r * ncv);
+      f32x4 uu[NQ], g[NQ];
+      ly_rv_unpack(ly_ldrv<T>(u + r * ldu + c), uu);
+      ly_rv_unpack(ly_ldrv<T>(dy + r * lddy + c), g);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int cq = c + 4 * q;
+        const f32x4 dv = ly_dact4<ACT>(ly_ldg4(a + cq) * uu[q] + ly_ldg4(b + cq), g[q]);
+        uu[q] = ly_ldg4(alpha + cq) * dv + ly_ldg4(kappa + cq) + ly_ldg4(lambda + cq) * uu[q];
+      }
+      *reinterpret_cast<RV*>(du + r * lddu + c) = ly_rv_pack(uu, (RV*)nullptr);
+    }
+    return;
+  }
   const int nc4 = C >> 2;
   const long total = rows * nc4;
   for (long i = (long)blockIdx.x * LY_THREADS + threadIdx.x; i < total; i += (long)gridDim.x * LY_THREADS) {
@@ -93,6 +138,22 @@ __global__ __launch_bounds__(LY_THREADS) void ly_bnact_bwd_apply_kernel(const T*
 template <typename T, int ACT>
 __global__ __launch_bounds__(LY_THREADS) void ly_bnact_fwd_kernel(const T* __restrict__ u, int ldu, long rows, int C, const float* __restrict__ a,
                                                                    const float* __restrict__ b, T* __restrict__ y, int ldy) {
+  constexpr int VW = LyT<T>::VW, NQ = VW / 4;
+  using RV = typename LyT<T>::RV;
+  if ((C % VW) == 0 && (ldu % VW) == 0 && (ldy % VW) == 0) {
+    const int ncv = C / VW;
+    const long total = rows * ncv;
+    for (long i = (long)blockIdx.x * LY_THREADS + threadIdx.x; i < total; i += (long)gridDim.x * LY_THREADS) {
+      const long r = i / ncv;
+      const int c = VW * (int)(i - r * ncv);
+      f32x4 uu[NQ];
+      ly_rv_unpack(ly_ldrv<T>(u + r * ldu + c), uu);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) uu[q] = ly_act4(ly_ldg4(a + c + 4 * q) * uu[q] + ly_ldg4(b + c + 4 * q), ACT);
+      *reinterpret_cast<RV*>(y + r * ldy + c) = ly_rv_pack(uu, (RV*)nullptr);
+    }
+    return;
+  }
   const int nc4 = C >> 2;
   const long total = rows * nc4;
   for (long i = (long)blockIdx.x * LY_THREADS + threadIdx.x; i < total; i += (long)gridDim.x * LY_THREADS) {
@@ -130,11 +191,12 @@ extern "C" int ly_bnact_bwd_reduce(const void* dy_, int lddy, const void* u_, in
   LY_CHECK_DTYPE(dtype, "bnact_bwd_reduce");
   LY_CHECK(dy_ && u_ && a && b && sums && rows > 0, "bnact_bwd_reduce: null pointer");
   LY_CHECK((C & 3) == 0 && C > 0 && C <= 1024 && (lddy & 3) == 0 && (ldu & 3) == 0, "bnact_bwd_reduce: C=%d / ld must be multiples of 4", C);
-  const int groups = LY_THREADS / (C >> 2);
+  const int vw = (dtype == LY_BF16 && (C & 7) == 0 && (lddy & 7) == 0 && (ldu & 7) == 0) ? 8 : 4;       // channels per thread: 16-byte accesses
+  const int groups = LY_THREADS / (C / vw);
   long blocks = (rows + groups * 32L - 1) / (groups * 32L);
   blocks = blocks < 1 ? 1 : blocks > 2048 ? 2048 : blocks;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-#define LY_RED(A) hipLaunchKernelGGL((ly_bnact_bwd_reduce_kernel<T, A>), dim3((unsigned)blocks), dim3(LY_THREADS), 0, st, dy, lddy, u, ldu, rows, C, a, b, sums)
+#define LY_RED(A) hipLaunchKernelGGL((ly_bnact_bwd_reduce_kernel<T, A>), dim3((unsigned)blocks), dim3(LY_THREADS), 0, st, dy, lddy, u, ldu, rows, C, a, b, sums, vw)
   LY_WITH_T(dtype, {
     const T* dy = reinterpret_cast<const T*>(dy_);
     const T* u = reinterpret_cast<const T*>(u_);

@@ -818,7 +818,8 @@ static int dispatch_nt_t(const T* x, T* y, long M, int n_img, int H, int W, cons
   }
   if constexpr (C < 80) {
     // persistent patch walk with the weights in LDS: enough patches for every resident block to amortise the weight copy
-    if ((W & 15) == 0 && W >= 32 && !stats && (long)n_img * ((H + 7) / 8) * (W / 16) >= 1024)
+    // (fp32 storage at C = 40 needs 148 KB of LDS and 242 registers: one block per CU, measured 63 -> 79 us — it keeps the one-shot kernel)
+    if ((W & 15) == 0 && W >= 32 && !stats && (long)n_img * ((H + 7) / 8) * (W / 16) >= 1024 && (LyT<T>::BF || C < 40))
       return launch_mlp_persist<T, C, 2, HT>(x, y, M, n_img, H, W, wp, w1, w2, s, b, st);
   }
   if ((W & 15) == 0 && W >= 64 && NTMAX >= 2) return launch_mlp<T, C, 2, HT, true>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);

@@ -244,6 +244,11 @@ class _Plan:
             return out
         # (inside a captured training step the first request finds the plan stale — an optimiser step always precedes the capture —
         # so exactly one refresh launch is captured, ahead of the forward)
+        if any(old.param is not new.param for old, new in zip(e["parts"], parts)):
+            # same address, same layout, but ANOTHER tensor (the allocator handed a freed parameter's storage to a new model): the
+            # descriptors (raw pointers) still hold, the contents do not
+            e["parts"] = parts
+            e["versions"] = None
         if self.w_epoch != W_EPOCH or e["versions"] != tuple(p.version() for p in parts):
             self.refresh(capturing)
         return e["out"]

@@ -7,7 +7,7 @@ TAG=${1:-job}; shift || true
 OUT=$R/gpurun_out
 mkdir -p $OUT
 cd $R
-timeout 1500 python -m pytest tests -m gpu -q ${PYTEST_ARGS:--x} > $OUT/${TAG}_pytest.log 2>&1
+timeout 1500 python -m pytest tests -m gpu -q ${PYTEST_ARGS:--x} ${K:+-k "$K"} > $OUT/${TAG}_pytest.log 2>&1
 echo "pytest rc=$?" >> $OUT/${TAG}_pytest.log
 tail -5 $OUT/${TAG}_pytest.log
 timeout 900 python bench.py --layers "$@" > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_kernels.txt

@@ -28,7 +28,6 @@
 // LDS.  The item body is straight-line code (surplus prefetches re-read the last item, ragged K contracts LDS zeros):
 // the compiler's s_waitcnt bookkeeping is exact only then.  Weight fragments of the chunk's later k-steps are requested
 // BEFORE the activation prefetch (vmcnt retires in order), the first step of the next item during the last step.
-#include <stdlib.h>
 #include "ly_tile.cuh"
 #include "ly_params.h"
 
@@ -399,12 +398,10 @@ static int launch_gemm(const LyGemmParams& P, hipStream_t st) {
 }
 
 // Tile policy, measured on MI355X at every LEAD-YOLO shape: 64-pixel tiles with 3 co-resident blocks per CU beat 128-pixel
-// tiles (one wave per SIMD); the narrow-output tile trades channels for pixels.
+// tiles (one wave per SIMD); the narrow-output tile trades channels for pixels.  (bf16 storage, whole train step: 64 x 64 tiles for
+// N > 64 — four waves per SIMD instead of two — 19.95 vs 19.79 ms: no gain, the 64 x 128 tile stays.)
 template <typename T>
 static int ly_gemm_dispatch(const LyGemmParams& P, hipStream_t st) {
-  static const int exp_cfg = getenv("LY_EXP_GEMM") ? atoi(getenv("LY_EXP_GEMM")) : 0;      // EXPERIMENT (to be removed)
-  if (exp_cfg == 414 && P.N > 64) return launch_gemm<T, 4, 1, 4>(P, st);
-  if (exp_cfg == 424 && P.N > 32) return launch_gemm<T, 4, 2, 4>(P, st);
   if (P.N > 64) return launch_gemm<T, 4, 2, 4>(P, st);    // 64 px x 128 ch per block
   if (P.N > 32) return launch_gemm<T, 4, 1, 4>(P, st);    // 64 px x 64 ch
   return launch_gemm<T, 2, 2, 1>(P, st);                  // 128 px x 32 ch

@@ -604,10 +604,13 @@ static int wgrad_dispatch(const LyWgradParams& P, void* stream) {
     // One step of a block is one memory round trip (prefetch one step ahead), so what matters for the skinny shapes is how many
     // blocks a CU holds: the 64 x 256 tile's 92 KB of LDS meant ONE (N=8 K=72 M=1.6M: 690 -> 280 us, N=64 K=576: 538 -> 342 us,
     // N=64 K=128 upsampled source: 271 -> 137 us with the tiles below; all wgrad launches of a bs=64 step 7.8 -> 6.5 ms).
+    // pixels per step: 32 for fp32 storage; bf16 rows are half as many bytes, so a step covers 64 pixels to keep the same bytes in
+    // flight per block (the LDS image per step is the same size: one plane instead of two)
+    constexpr int PX = LyT<T>::BF ? 64 : 32;
     if (P.N <= 64 && Ktot <= 64) return launch_wgrad_tiled<T, 64, 64, 64>(P, rows, st2);
-    if (P.N <= 32) return launch_wgrad_tiled<T, 32, 128, 32>(P, rows, st2);      // 46 KB (fp32 storage): three blocks per CU
-    if (P.N <= 64) return launch_wgrad_tiled<T, 64, 128, 32>(P, rows, st2);      // 55 KB: two
-    return launch_wgrad_tiled<T, 128, 128, 32>(P, rows, st2);
+    if (P.N <= 32) return launch_wgrad_tiled<T, 32, 128, PX>(P, rows, st2);      // 46 KB: three blocks per CU
+    if (P.N <= 64) return launch_wgrad_tiled<T, 64, 128, PX>(P, rows, st2);      // 55 KB: two
+    return launch_wgrad_tiled<T, 128, 128, PX>(P, rows, st2);
   }
   const int tiles_n = (P.N + 63) / 64, tiles_k = (Ktot + 63) / 64;
   const long tiles = (long)tiles_n * tiles_k;

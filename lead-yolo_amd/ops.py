@@ -563,14 +563,15 @@ def wgrad_kernel_name(t, n, ktot, rows, tiled):
     r = "true" if rows else "false"
     if not tiled:
         return f"ly_wgrad_kernel<{t}, {r}>"
+    pxs = 64 if t == "__bf16" else 32
     if n <= 64 and ktot <= 64:
         bn, bk, px = 64, 64, 64
     elif n <= 32:
-        bn, bk, px = 32, 128, 32
+        bn, bk, px = 32, 128, pxs
     elif n <= 64:
-        bn, bk, px = 64, 128, 32
+        bn, bk, px = 64, 128, pxs
     else:
-        bn, bk, px = 128, 128, 32
+        bn, bk, px = 128, 128, pxs
     return f"ly_wgrad_tiled_kernel<{t}, {bn}, {bk}, {px}, {r}>"
 
 

@@ -409,8 +409,10 @@ class Conv(nn.Module):
 
     def __init__(self, c1, c2, k=1, s=1, p=None, g=1, d=1, act=True):
         super().__init__()
-        if g != 1 or d != 1 or s != 1 or k not in (1, 3) or autopad(k, p, d) != k // 2:
-            raise NotImplementedError(f"HIP Conv is built for k in (1, 3), stride 1, groups 1, 'same' padding (got k={k} s={s} g={g} d={d})")
+        if g != 1 or d != 1 or k not in (1, 3) or autopad(k, p, d) != k // 2 or s not in (1, 2) or (s == 2 and k != 3):
+            raise NotImplementedError(f"HIP Conv is built for k in (1, 3), stride 1 (k = 3 also stride 2, inference), groups 1, 'same' padding "
+                                      f"(got k={k} s={s} g={g} d={d}); grouped / depthwise Conv (DWConv) is not used by LEAD-YOLO and not built")
+        self.s = s
         self.conv = nn.Conv2d(c1, c2, k, s, autopad(k, p, d), groups=g, dilation=d, bias=False)
         if k == 3:
             self.conv.weight._ly_tap_major = True       # optim.FusedSGD may keep this weight's gradient tap-major (what ly_wgrad writes fastest)
@@ -455,13 +457,22 @@ class Conv(nn.Module):
 
     @_edge
     def forward(self, x):
-        pr = _probe(x, (x.shape[0], self.c2, x.shape[2], x.shape[3])) if isinstance(x, torch.Tensor) else None
+        s_ = getattr(self, "s", 1)
+        pr = _probe(x, (x.shape[0], self.c2, (x.shape[2] - 1) // s_ + 1, (x.shape[3] - 1) // s_ + 1)) if isinstance(x, torch.Tensor) else None
         if pr is not None:
             return pr
         if self.k == 3 and isinstance(x, Lazy):
             x = x.materialize()
         act = _act_code(self.act)
         bn = getattr(self, "bn", None)
+        if getattr(self, "s", 1) == 2:
+            # k = 3, stride 2, pad 1 (models/common.py:1890-1910 with s = 2; not instantiated by LEAD-YOLO.yaml): output (oy, ox) of the
+            # strided convolution IS output (2 oy, 2 ox) of the stride-1 one, so the stride-1 kernel runs and every second row / column
+            # is kept.  Inference only: train-mode batch statistics would have to be taken over the kept pixels.
+            if self.training:
+                raise NotImplementedError("HIP Conv with stride 2 is built for inference (eval mode) only")
+            sc, sh = self.affine_eval()
+            return self._run(x, sc, sh, act)[:, :, ::2, ::2].contiguous(memory_format=torch.channels_last)
         if _grad_mode(self) and bn is not None:
             from . import grad
             x0, x1, up = x, None, False

@@ -2,6 +2,7 @@
 reference's own vectors (dx_train, per-parameter gradient norms in the fixtures) and vs autograd through the
 oracle on identical inputs.  Tolerance: 1e-3 relative to the largest magnitude of each gradient tensor."""
 import copy
+import os
 
 import numpy as np
 import pytest
@@ -482,3 +483,55 @@ def test_graphed_step_with_reducer_matches_eager():
     for a, b in zip(*runs):
         assert abs(a - b) <= 1e-2 * abs(a), runs
     assert runs[1][-1] < runs[1][0]
+
+
+def _ddp_rank(rank, world, port, q):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    import torch.distributed as dist
+    import lead_yolo_amd as L
+    try:
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+        dev = torch.device("cuda", rank)
+        torch.manual_seed(0)
+        m = L.Model(L.load_cfg(scale="n")).to(dev).train()
+        for t in list(m.parameters()) + list(m.buffers()):
+            dist.broadcast(t.data, src=0)
+        red = L.GradReducer(list(m.parameters())).attach()
+        opt = L.smart_optimizer(m, "SGD", 0.01, 0.937, 5e-4)
+        cl = L.ComputeLoss(m)
+        imgs = synth.synth_images(4, 128, 40 + rank).to(dev)              # a different shard per rank
+        tg = synth.synth_targets(4, 50 + rank, per_image=3).to(dev)
+        for _ in range(3):
+            L.train_step(m, cl, opt, imgs, tg, reducer=red, world_size=world)
+        # replicas must hold identical weights after averaged-gradient steps (BatchNorm running statistics are per-rank by design)
+        flat = torch.cat([p.detach().reshape(-1) for p in m.parameters()])
+        other = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(other, flat)
+        same = all(torch.equal(other[0], o) for o in other[1:])
+        q.put((rank, "ok" if same else "replicas diverged"))
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, repr(e)))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_two_rank_rccl_train_step():
+    """data-parallel train step over RCCL on two GPUs (skipped on a one-GPU box): rank-0 broadcast, per-rank shards, bucketed
+    all-reduce from the gradient hooks / in-place gradient sink, fused optimiser — replicas stay bit-identical"""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + os.getpid() % 2000
+    procs = [ctx.Process(target=_ddp_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res

@@ -391,3 +391,76 @@ def test_half_and_autocast_inputs():
     for y in (y16, yb, yh):
         assert float((y.float().cpu() - want).abs().max()) <= 2 ** -6 * scale
     _cmp(y32, want, "fp32 path unchanged")
+
+
+def test_conv_k3_s2_golden():
+    """effective Conv with k = 3, stride 2 (models/common.py:1890-1910; not used by LEAD-YOLO.yaml): the stride-1 kernel + subsampling,
+    against the reference's own vector"""
+    import lead_yolo_amd as L
+    meta, arr = G.load("conv_64_32_k3s2")
+    st = G.state_for(meta)
+    x = synth.synth_input(meta["in_shape"], meta["seed"] + 1)
+    m = _bn_eps(_load(L.Conv(*meta["ctor"]), st)).to(_dev()).eval()
+    with torch.no_grad():
+        y = m(x.to(_dev()))
+    _cmp(y, arr["y_eval"], "conv_64_32_k3s2")
+    with pytest.raises(NotImplementedError):
+        L.Conv(64, 32, 3, 1, g=64)                   # grouped / depthwise: not built, rejected at construction
+    with pytest.raises(NotImplementedError):
+        m.train()(x.to(_dev()))
+
+
+def test_bf16x3_adversarial_bounds():
+    """The fp32-storage path multiplies with a 3-term bf16 split (csrc/ly_tile.cuh: the lo*lo term, ~2^-16 relative per product, is
+    dropped).  Worst cases for that error model, each against the fp32 oracle with the DOCUMENTED bound
+        |err| <= 2^-14 * sum_k |w_k x_k|   (2^-16 per product with a 4x margin for accumulation order and the epilogue)
+    which for well-conditioned sums is far inside the 1e-3 budget, and which is the honest bound when terms cancel:
+      * K = 4608 (3x3 over 512 channels) with sign-alternating weights: massive cancellation, the result is ~0 against terms of O(1);
+      * inputs spanning 2^-20 .. 2^20 in one tensor (the split is relative: small values keep their precision next to large ones);
+      * BatchNorm running_var ~ 1e-6 (folded scale ~ 1e3 amplifies the contraction's absolute error)."""
+    import lead_yolo_amd as L
+    import torch.nn.functional as F
+    dev = _dev()
+    g = torch.Generator().manual_seed(7)
+    # 1. 3x3 conv, 512 -> 64 channels, sign-alternating weights of equal magnitude, smooth positive input
+    conv = L.Conv(512, 64, 3, 1)
+    w = torch.ones(64, 512, 3, 3) * 0.05
+    w.view(64, -1)[:, 1::2] *= -1
+    w = w * (1 + 0.01 * torch.randn(w.shape, generator=g))
+    x = 1.0 + 0.05 * torch.randn(2, 512, 12, 12, generator=g)
+    with torch.no_grad():
+        conv.conv.weight.copy_(w)
+        conv.bn.weight.fill_(1.0); conv.bn.bias.zero_(); conv.bn.running_mean.zero_(); conv.bn.running_var.fill_(1.0)
+        conv.bn.eps = 0.0
+        conv.act = torch.nn.Identity()
+        want = F.conv2d(x.double(), w.double(), padding=1).float()
+        mag = F.conv2d(x.abs().double(), w.abs().double(), padding=1).float()              # sum_k |w_k x_k|
+        got = conv.to(dev).eval()(x.to(dev)).float().cpu()
+    assert float(want.abs().max()) < 0.2 * float(mag.max())                                # the case really cancels
+    assert bool(((got - want).abs() <= 2.0 ** -14 * mag + 1e-7).all()), float(((got - want).abs() / mag).max())
+    # 2. dynamic range: per-pixel scales 2^-20 .. 2^20 through a 1x1 conv
+    pw = L.Conv(256, 128, 1, 1)
+    scale = 2.0 ** torch.randint(-20, 21, (2, 1, 16, 16), generator=g).float()
+    x2 = torch.randn(2, 256, 16, 16, generator=g) * scale
+    with torch.no_grad():
+        pw.bn.weight.fill_(1.0); pw.bn.bias.zero_(); pw.bn.running_mean.zero_(); pw.bn.running_var.fill_(1.0)
+        pw.bn.eps = 0.0
+        pw.act = torch.nn.Identity()
+        w2 = pw.conv.weight.detach().clone()
+        want2 = F.conv2d(x2.double(), w2.double()).float()
+        mag2 = F.conv2d(x2.abs().double(), w2.abs().double()).float()
+        got2 = pw.to(dev).eval()(x2.to(dev)).float().cpu()
+    assert bool(((got2 - want2).abs() <= 2.0 ** -14 * mag2).all()), float(((got2 - want2).abs() / mag2).max())
+    # 3. near-denormal BatchNorm variance: folded scale 1e3
+    bn = L.Conv(128, 64, 1, 1)
+    x3 = torch.randn(2, 128, 10, 10, generator=g)
+    with torch.no_grad():
+        bn.bn.running_var.fill_(1e-6); bn.bn.eps = 0.0; bn.bn.running_mean.normal_(0, 1e-3, generator=g)
+        bn.act = torch.nn.Identity()
+        w3 = bn.conv.weight.detach().clone()
+        s3 = (bn.bn.weight / torch.sqrt(bn.bn.running_var)).detach()
+        u = F.conv2d(x3.double(), w3.double())
+        want3 = ((u - bn.bn.running_mean.double().view(1, -1, 1, 1)) * s3.double().view(1, -1, 1, 1) + bn.bn.bias.double().view(1, -1, 1, 1)).float()
+        mag3 = F.conv2d(x3.abs().double(), w3.abs().double()).float() * s3.abs().view(1, -1, 1, 1)
+        got3 = bn.to(dev).eval()(x3.to(dev)).float().cpu()
+    assert bool(((got3 - want3).abs() <= 2.0 ** -14 * mag3 + 1e-6 * want3.abs()).all()), float(((got3 - want3).abs() / mag3).max())

@@ -15,7 +15,7 @@ echo "bench rc=$?"
 tail -c 3000 $OUT/${TAG}_bench.json
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pf_k
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pf_k -o k -- python3 $R/bench.py --steps 5 --warmup 2 --repeats 1 --no-roofline "$@" > /tmp/k.log 2>&1
+timeout 600 rocprofv3 -M --kernel-trace --stats --output-format csv -d /tmp/pf_k -o k -- python3 $R/bench.py --steps 5 --warmup 2 --repeats 1 --no-roofline "$@" > /tmp/k.log 2>&1
 cp $(find /tmp/pf_k -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_train_kernel_stats.csv 2>/dev/null
 python3 $R/tools/prof_summary.py $(find /tmp/pf_k -name "*kernel_trace.csv" | head -1) 7 > $OUT/${TAG}_train_kernels_per_step.txt 2>&1
 head -30 $OUT/${TAG}_train_kernels_per_step.txt

@@ -7,7 +7,7 @@ TAG=${1:-pmc}; shift || true
 OUT=$R/gpurun_out; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 2 --warmup 1 --repeats 1 --no-roofline --no-graph $*"
-run() { rm -rf /tmp/pf_$1; timeout 900 rocprofv3 --pmc $2 --output-format csv -d /tmp/pf_$1 -o p -- python3 $R/bench.py $ARGS > /tmp/$1.log 2>&1; echo "$1 rc=$?"; }
+run() { rm -rf /tmp/pf_$1; timeout 900 rocprofv3 -M --pmc $2 --output-format csv -d /tmp/pf_$1 -o p -- python3 $R/bench.py $ARGS > /tmp/$1.log 2>&1; echo "$1 rc=$?"; }
 run f "FETCH_SIZE"
 run w "WRITE_SIZE"
 run m "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"

@@ -6,17 +6,17 @@ over the SIMDs that ran the kernel; GRBM_GUI_ACTIVE = cycles the GPU was busy du
 cycles / (GRBM_GUI_ACTIVE x 1024 SIMDs): the fraction of the chip's matrix-pipe capacity the launch used (1.0 = every SIMD's matrix
 pipe busy every cycle = the dense peak)."""
 import csv
+import os
 import json
 import re
 import sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from collections import defaultdict
 
 SIMDS = 256 * 4
 
 
-def norm(name):
-    name = re.sub(r"^void\s+", "", name)
-    return name.split("(")[0].strip()
+from demangle import norm  # noqa: E402
 
 
 acc = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))

@@ -1,12 +1,15 @@
 """Summarise rocprofv3 --pmc counter_collection.csv: per kernel name, mean of each counter per dispatch."""
 import csv
+import os
 import sys
 from collections import defaultdict
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from demangle import norm  # noqa: E402
 
 path = sys.argv[1]
 acc = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
 for r in csv.DictReader(open(path)):
-    k = r["Kernel_Name"][:70]
+    k = norm(r["Kernel_Name"])[:70]
     c = r["Counter_Name"]
     acc[k][c][0] += 1
     acc[k][c][1] += float(r["Counter_Value"])

@@ -5,15 +5,15 @@ Correction per MI355X_MICROARCH.md §HBM: on gfx950 FETCH_SIZE counts 64 B per 1
 coalesced stream, so it is DOUBLED; WRITE_SIZE is exact for 16-B-per-lane streaming stores.  Both
 counters are in KiB.  Kernel names are normalised to what ops._Timed / bench.py use."""
 import csv
+import os
 import json
 import re
 import sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from collections import defaultdict
 
 
-def norm(name):
-    name = re.sub(r"^void\s+", "", name)
-    return name.split("(")[0].strip()
+from demangle import norm  # noqa: E402
 
 
 def load(path, counter):

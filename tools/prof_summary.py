@@ -1,7 +1,10 @@
 """Summarise a rocprofv3 kernel trace of `bench.py --no-roofline`: per-kernel time per step and GPU-busy vs wall."""
 import csv
+import os
 import sys
 from collections import defaultdict
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from demangle import norm  # noqa: E402
 
 path, steps = sys.argv[1], int(sys.argv[2])
 rows = list(csv.DictReader(open(path)))
@@ -10,7 +13,7 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 tot = defaultdict(lambda: [0, 0.0])
 for r in rows:
     d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-    k = r["Kernel_Name"]
+    k = norm(r["Kernel_Name"])
     tot[k][0] += 1
     tot[k][1] += d
 n = steps

@@ -1,23 +1,44 @@
 #!/bin/bash
-# Regenerates the rocprofv3 evidence under gpurun_out/<tag>_* (run on the GPU box through gpurun; copy the files you keep to profiles/).
-#   usage: tools/refresh_profiles.sh <tag>
+# Regenerates the rocprofv3 evidence of a round under profiles/ (run on the GPU box through gpurun; profiles/ travels back via
+# gpurun_out/, copy from there).   usage: bash tools/refresh_profiles.sh <tag>        e.g. r02
+# Produces, for the bf16 train step (the bench line), the fp32 train step and the fp32 / bf16 eval forward:
+#   <tag>_<run>_kernels_per_step.txt   rocprofv3 -M --kernel-trace --stats of an EAGER run (per-kernel time per step, names demangled by tools/demangle.py)
+#   <tag>_<run>_kernel_stats.csv       rocprofv3's own --stats summary of the same run
+#   <tag>_<run>_pmc_traffic.json       FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE per launch, separate --pmc passes
+#   <tag>_<run>_pmc_mfma.json          SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 1024 SIMDs) per launch
+#   <tag>_<run>_pmc_wait.txt           SQ wait / LDS counters per launch
+#   <tag>_<run>_bench.json / _kernels.txt   the bench line (graph replay) and bench.py --layers' live HIP-event table
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-TAG=${1:-r01}
-OUT=$R/gpurun_out
-mkdir -p $OUT
+TAG=${1:-r02}
+OUT=$R/gpurun_out/profiles; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/pf_k /tmp/pf_f /tmp/pf_w
-# 1. per-kernel durations (eager launches: one kernel at a time, comparable with the live HIP-event numbers of bench.py)
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pf_k -o k -- python3 $R/bench.py --steps 20 --warmup 3 --no-roofline --no-cpu-baseline --no-graph > /tmp/k.log 2>&1
-cp $(find /tmp/pf_k -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats.csv
-python3 $R/tools/prof_summary.py $(find /tmp/pf_k -name "*kernel_trace.csv" | head -1) 23 > $OUT/${TAG}_kernels_per_step.txt
-# 2. HBM traffic per launch: separate FETCH_SIZE and WRITE_SIZE passes (no trace domains together with --pmc)
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pf_f -o f -- python3 $R/bench.py --steps 3 --warmup 1 --no-roofline --no-cpu-baseline --no-graph > /tmp/f.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pf_w -o w -- python3 $R/bench.py --steps 3 --warmup 1 --no-roofline --no-cpu-baseline --no-graph > /tmp/w.log 2>&1
-python3 $R/tools/pmc_traffic.py $(find /tmp/pf_f -name "*counter_collection.csv" | head -1) $(find /tmp/pf_w -name "*counter_collection.csv" | head -1) $OUT/${TAG}_pmc_traffic.json
-# 3. the bench line (graph replay) and the per-kernel table
+one() {   # name, steps-divisor, bench args...
+  local NAME=$1; shift; local ARGS="$*"
+  rm -rf /tmp/pf_k
+  timeout 900 rocprofv3 -M --kernel-trace --stats --output-format csv -d /tmp/pf_k -o k -- python3 $R/bench.py --steps 5 --warmup 2 --repeats 1 --no-roofline --no-graph $ARGS > /tmp/k.log 2>&1
+  cp $(find /tmp/pf_k -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_${NAME}_kernel_stats.csv 2>/dev/null
+  python3 $R/tools/prof_summary.py $(find /tmp/pf_k -name "*kernel_trace.csv" | head -1) 7 > $OUT/${TAG}_${NAME}_kernels_per_step.txt 2>&1
+  local PA="--steps 2 --warmup 1 --repeats 1 --no-roofline --no-graph $ARGS"
+  for p in "f FETCH_SIZE" "w WRITE_SIZE" "m SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "s SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT"; do
+    set -- $p; local k=$1; shift
+    rm -rf /tmp/pf_$k
+    timeout 900 rocprofv3 -M --pmc $* --output-format csv -d /tmp/pf_$k -o p -- python3 $R/bench.py $PA > /tmp/$k.log 2>&1
+  done
+  f() { find /tmp/pf_$1 -name "*counter_collection.csv" | head -1; }
+  python3 $R/tools/pmc_traffic.py $(f f) $(f w) $OUT/${TAG}_${NAME}_pmc_traffic.json
+  python3 $R/tools/pmc_mfma.py $(f m) $OUT/${TAG}_${NAME}_pmc_mfma.json
+  python3 $R/tools/pmc_summary.py $(f s) > $OUT/${TAG}_${NAME}_pmc_wait.txt 2>&1
+}
+one train_bf16 --dtype bf16
+one train_f32 --dtype f32
+one fwd_f32 --mode forward --dtype f32
+one fwd_bf16 --mode forward --dtype bf16
+# the bench lines themselves (they read the PMC summaries: copy them where bench.py looks)
+cp $OUT/${TAG}_*_pmc_traffic.json $OUT/${TAG}_*_pmc_mfma.json $R/profiles/ 2>/dev/null
 cd $R
-cp $OUT/${TAG}_pmc_traffic.json $R/profiles/${TAG}_pmc_traffic.json 2>/dev/null
-python3 bench.py --layers > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_kernels.txt
-tail -1 $OUT/${TAG}_bench.json | cut -c1-600
+python3 bench.py --dtype bf16 --layers > $OUT/${TAG}_train_bf16_bench.json 2> $OUT/${TAG}_train_bf16_kernels.txt
+python3 bench.py --dtype f32 --layers > $OUT/${TAG}_train_f32_bench.json 2> $OUT/${TAG}_train_f32_kernels.txt
+python3 bench.py --mode forward --dtype f32 --layers > $OUT/${TAG}_fwd_f32_bench.json 2> $OUT/${TAG}_fwd_f32_kernels.txt
+python3 bench.py --mode forward --dtype bf16 --layers --no-cpu-baseline > $OUT/${TAG}_fwd_bf16_bench.json 2> $OUT/${TAG}_fwd_bf16_kernels.txt
+ls -la $OUT | head -40

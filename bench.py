@@ -365,7 +365,7 @@ def run_train(args, ctx):
             step = eager_step
 
     regions = timed_repeats(ctx, step, args.steps, args.warmup, args.repeats)
-    res = dict(regions=regions, final_loss=float(state["loss"]), model=model, step=eager_step, launch=launch,
+    res = dict(regions=regions, final_loss=float(state["loss"]), peak_mem_gib=round(torch.cuda.max_memory_allocated() / 2**30, 2), model=model, step=eager_step, launch=launch,
                workload=f"lead-yolo-{args.scale} bs={args.batch}/gpu 3x{args.size}x{args.size} {args.dtype} full train step: uint8 batch -> "
                         "train-mode forward (batch-statistics BN), ComputeLoss, HIP backward, clip 10, SGD-nesterov 3 groups "
                         "(BASELINE.json configs[2]" + ("" if args.dtype == "bf16" else " shape in fp32") + "); random-init weights",
@@ -485,7 +485,7 @@ def main():
             "timed_repeats": len(regions), "repeat_ms_per_step": [round(r / args.steps * 1e3, 4) for r in regions],
             "value_is": "median of the timed repeats (each: exactly `steps` steps between barrier+synchronize, max over ranks)",
         }
-        for k in ("final_loss", "rccl_ranks", "grad_buckets", "launch"):
+        for k in ("final_loss", "peak_mem_gib", "rccl_ranks", "grad_buckets", "launch"):
             if k in res:
                 out[k if k != "launch" else "launch_mode"] = res[k]
         if args.no_roofline:

@@ -141,11 +141,11 @@ class FusedSGD(torch.optim.Optimizer):
     def _sync_hyper(self):
         """learning rates follow param_groups (schedulers / warm-up write them); one small H2D copy only when they change"""
         t = self._table
-        lrs = tuple(float(g["lr"]) for g in self.param_groups) + (float(self.max_norm or 0.0),)
+        lrs = tuple(float(g["lr"]) for g in self.param_groups) + (float(self.param_groups[0]["momentum"]), float(self.max_norm or 0.0))
         if lrs != t["lrs"]:
             n = len(self.param_groups)
             t["hyper"][:n].copy_(torch.tensor(lrs[:n], dtype=torch.float32), non_blocking=True)
-            t["hyper"][4:5].copy_(torch.tensor(lrs[n:], dtype=torch.float32), non_blocking=True)
+            t["hyper"][3:5].copy_(torch.tensor(lrs[n:], dtype=torch.float32), non_blocking=True)     # momentum (warm-up ramps it, train.py:303-311), max_norm
             t["lrs"] = lrs
 
     # ---- the step --------------------------------------------------------------------------------------------------

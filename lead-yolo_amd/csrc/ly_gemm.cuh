@@ -30,12 +30,17 @@
 // BEFORE the activation prefetch (vmcnt retires in order), the first step of the next item during the last step.
 #include "ly_tile.cuh"
 #include "ly_params.h"
+#ifndef LY_GEMM_DEPTH
+#define LY_GEMM_DEPTH 3
+#endif
+
+static __device__ float ly_gemm_trash[64 * 4];      // where the stores of rows past M land (never read)
 
 template <int V>
 struct LyIc { static constexpr int value = V; };
 
 // TI: element type of the sources (fp32 image for LY_GATHER_PATCH_NCHW whatever the output is), TO: of res / out
-template <typename TI, typename TO, int NT, int MT, int WC, int GATHER, int PRO>
+template <typename TI, typename TO, int NT, int MT, int WC, int GATHER, int PRO, int D, int NCH, int FAST>
 __device__ __forceinline__ void ly_gemm_body2(const LyGemmParams& P, const int gy, const int nslots, const int gx) {
   using TR = LyT<TI>;
   using RV = typename TR::RV;
@@ -79,11 +84,11 @@ __device__ __forceinline__ void ly_gemm_body2(const LyGemmParams& P, const int g
   TO* const out = reinterpret_cast<TO*>(P.out);
 
   // ---- staging state, one copy per register set ---------------------------------------------------
-  RV pv[2][NV];
-  long t_row0[2][NV];
-  int t_n[2][NV], t_hw[2][NV];
-  long s_p[2];                                             // tile start and K offset of the item held by the set
-  int s_kc[2];
+  RV pv[D][NV];
+  long t_row0[D][NV];
+  int t_n[D][NV], t_hw[D][NV];
+  long s_p[D];                                             // tile start and K offset of the item held by the set
+  int s_kc[D];
   int cur_pt = slot, cur_c = 0;                            // issue cursor (saturates at the slot's last item)
 
   auto issue = [&](auto sC) {
@@ -116,7 +121,7 @@ __device__ __forceinline__ void ly_gemm_body2(const LyGemmParams& P, const int g
       }
     } else {
 #pragma unroll
-      for (int e = 0; e < NV; ++e) { t_row0[s][e] = t_row0[1 - s][e]; t_n[s][e] = t_n[1 - s][e]; t_hw[s][e] = t_hw[1 - s][e]; }
+      for (int e = 0; e < NV; ++e) { t_row0[s][e] = t_row0[(s + D - 1) % D][e]; t_n[s][e] = t_n[(s + D - 1) % D][e]; t_hw[s][e] = t_hw[(s + D - 1) % D][e]; }
     }
     const int kk = kc + VW * k4;
     const bool kok = kk < P.K;
@@ -233,6 +238,11 @@ __device__ __forceinline__ void ly_gemm_body2(const LyGemmParams& P, const int g
   float rsv[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) rsv[n] = 1.f;
+  f32x4 sum1[FAST == 2 ? MT : 1], sum2[FAST == 2 ? MT : 1];
+  if constexpr (FAST == 2) {
+#pragma unroll
+    for (int t = 0; t < MT; ++t) { sum1[t] = zero; sum2[t] = zero; }
+  }
   float esc[MT][4], esh[MT][4];                            // epilogue scale/shift: fetched once, not per tile
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
@@ -245,25 +255,45 @@ __device__ __forceinline__ void ly_gemm_body2(const LyGemmParams& P, const int g
     }
   }
   ly_l2_warm(P.wp, (long)T * S * PL * 1024, P.stats ? P.stats : reinterpret_cast<float*>(P.out));
-  LyWF<PL> wq[SPC][MT];                                    // wq[j]: weights of k-step j of the item being contracted
+  // NCH == 0: weights streamed, wq[j] = k-step j of the item being contracted.  NCH > 0 (K is exactly NCH chunks): ALL weight
+  // fragments of the block's channel slice stay in registers.  That is not about the L2 traffic: vmcnt retires IN ORDER, so a
+  // load that is consumed in the item that issued it (a streamed weight fragment) makes its s_waitcnt drain every older load —
+  // the activation prefetches of the next items — and the pipeline is never more than one item deep, whatever D says.
+  constexpr int NW = NCH > 0 ? NCH : 1;
+  LyWF<PL> wq[NW][SPC][MT];
+  if constexpr (NCH > 0) {
 #pragma unroll
-  for (int t = 0; t < MT; ++t) wq[0][t] = ly_wfragp<PL>(wpk, wbase[t], lane);
+    for (int cc = 0; cc < NCH; ++cc)
+#pragma unroll
+      for (int j = 0; j < SPC; ++j) {
+        const int gj = SPC * cc + j < S ? SPC * cc + j : 0;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) wq[cc][j][t] = ly_wfragp<PL>(wpk, wbase[t] + gj, lane);
+      }
+  } else {
+#pragma unroll
+    for (int t = 0; t < MT; ++t) wq[0][0][t] = ly_wfragp<PL>(wpk, wbase[t], lane);
+  }
 
   int pt = slot, c = 0, buf = 0;                           // item being contracted
   long p0 = (long)slot * BP;
   issue(LyIc<0>());
   issue(LyIc<1>());
+  if constexpr (D > 2) issue(LyIc<2 % D>());
   commit(LyIc<0>(), 0);
   __syncthreads();
 
   // one item: weights, re-issue the vacated set two items ahead, contract, commit the next item, barrier, epilogue at tile end
-  auto item = [&](auto sC) -> bool {
+  auto item = [&](auto sC, auto cC) -> bool {
     constexpr int s = decltype(sC)::value;                 // set that held THIS item (already committed): free
+    constexpr int CS = NCH > 0 ? decltype(cC)::value : 0;  // resident weights: the chunk index is static
+    if constexpr (NCH == 0) {
 #pragma unroll
-    for (int j = 1; j < SPC; ++j) {                        // later k-steps' weights first (older than the prefetch in the queue)
-      const int gj = SPC * c + j < S ? SPC * c + j : 0;
+      for (int j = 1; j < SPC; ++j) {                      // later k-steps' weights first (older than the prefetch in the queue)
+        const int gj = SPC * c + j < S ? SPC * c + j : 0;
 #pragma unroll
-      for (int t = 0; t < MT; ++t) wq[j][t] = ly_wfragp<PL>(wpk, wbase[t] + gj, lane);
+        for (int t = 0; t < MT; ++t) wq[0][j][t] = ly_wfragp<PL>(wpk, wbase[t] + gj, lane);
+      }
     }
     if (PRO == LY_PRO_AFFINE_RELU_CA) {
 #pragma unroll
@@ -288,18 +318,57 @@ __device__ __forceinline__ void ly_gemm_body2(const LyGemmParams& P, const int g
 #pragma unroll
       for (int t = 0; t < MT; ++t)
 #pragma unroll
-        for (int n = 0; n < NT; ++n) acc[t][n] = ly_mfmap<PL>(wq[st][t], xh[n], xl[n], acc[t][n]);
-      if (st == SPC - 1) {                                 // weights of the next item's first step into the slot step 0 vacated
-        const int gn = SPC * (c + 1) < S ? SPC * (c + 1) : 0;   // (absent steps of a ragged last chunk contract LDS zeros with clamped weights: no branch)
+        for (int n = 0; n < NT; ++n) acc[t][n] = ly_mfmap<PL>(wq[CS][st][t], xh[n], xl[n], acc[t][n]);
+      if constexpr (NCH == 0) {
+        if (st == SPC - 1) {                               // weights of the next item's first step into the slot step 0 vacated
+          const int gn = SPC * (c + 1) < S ? SPC * (c + 1) : 0; // (absent steps of a ragged last chunk contract LDS zeros with clamped weights: no branch)
 #pragma unroll
-        for (int t = 0; t < MT; ++t) wq[0][t] = ly_wfragp<PL>(wpk, wbase[t] + gn, lane);
+          for (int t = 0; t < MT; ++t) wq[0][0][t] = ly_wfragp<PL>(wpk, wbase[t] + gn, lane);
+        }
       }
     }
-    commit(LyIc<1 - s>(), buf ^ 1);                        // item i+1
+    commit(LyIc<(s + 1) % D>(), buf ^ 1);                  // item i+1
     __syncthreads();
     buf ^= 1;
-    if (c + 1 < nchunk) { ++c; return true; }
+    if constexpr (NCH > 0) {
+      if (CS + 1 < NCH) return true;
+    } else {
+      if (c + 1 < nchunk) { ++c; return true; }
+    }
     // ---- epilogue of tile pt ---------------------------------------------------------------------
+    if constexpr (FAST != 0) {
+      // Every channel tile of the block is inside N and vector stores are legal: ONE path, every lane stores (rows
+      // past M go to a scratch line).  A store under a branch — even an exec-skip around a masked store — leaves the compiler
+      // two vmcnt histories to merge, and the next item's wait for its prefetch then also waits for these stores to be
+      // acknowledged: a full memory round trip at every tile end.
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        const int cc = 16 * ((by * WC + wc) * MT + t) + 4 * lq;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const long gp = p0 + pixgrp + 16 * n + li;
+          const float rs = PRO == LY_PRO_AFFINE_RELU_CA ? rsv[n] : 1.f;
+          f32x4 u;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) u[r] = acc[t][n][r] * rs * esc[t][r] + esh[t][r];
+          const bool ok = gp < P.M;
+          if constexpr (FAST == 2) {                       // BatchNorm sums stay in registers until the block has walked all its tiles
+            const f32x4 um = ok ? u : zero;
+            sum1[t] += um;
+            sum2[t] += um * um;
+          }
+          const f32x4 v = ly_act4(u, act);
+          TO* o = ok ? out + gp * P.ldo + cc : reinterpret_cast<TO*>(ly_gemm_trash) + 4 * lane;
+          ly_st4<TO>(o, v);
+          acc[t][n] = zero;
+        }
+      }
+      pt += nslots;
+      if (pt >= gx) return false;
+      p0 = (long)pt * BP;
+      c = 0;
+      return true;
+    }
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
       const int tt = (by * WC + wc) * MT + t;
@@ -341,21 +410,33 @@ __device__ __forceinline__ void ly_gemm_body2(const LyGemmParams& P, const int g
     c = 0;
     return true;
   };
+  // the item loop is unrolled so that the register-set index (mod D) and, with resident weights, the chunk index (mod NCH) are static
+  constexpr int NC1 = NCH > 0 ? NCH : 1;
+  constexpr int U = (D % NC1 == 0) ? D : D * NC1;
+  static_assert(U <= 6, "unroll");
+#define LY_GEMM_ITEM(u) if constexpr (u < U) { if (!item(LyIc<(u) % D>(), LyIc<(u) % NC1>())) break; }
   while (true) {
-    if (!item(LyIc<0>())) break;
-    if (!item(LyIc<1>())) break;
+    LY_GEMM_ITEM(0) LY_GEMM_ITEM(1) LY_GEMM_ITEM(2) LY_GEMM_ITEM(3) LY_GEMM_ITEM(4) LY_GEMM_ITEM(5)
+  }
+#undef LY_GEMM_ITEM
+  if constexpr (FAST == 2) {
+#pragma unroll
+    for (int t = 0; t < MT; ++t) ly_stats_flush(stats, P.N, 16 * ((by * WC + wc) * MT + t) + 4 * lq, sum1[t], sum2[t]);
   }
 }
 
 // Two waves per SIMD (8 per CU) are what hides the 1-2 us of a load round trip behind another wave's MFMAs: the register
 // allocator is told to fit 256 unified registers (left alone it takes up to ~290 for the gather variants and halves the occupancy:
 // UP2 at 80x80x32 57 -> 78 us).
-template <typename TI, typename TO, int NT, int MT, int WC, int GATHER, int PRO>
+template <typename TI, typename TO, int NT, int MT, int WC, int GATHER, int PRO, int NCH = 0, int FAST = 0>
 __global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(2))) void ly_gemm_kernel_d2(const LyGemmParams P, const int gy, const int nslots, const int gx) {
-  ly_gemm_body2<TI, TO, NT, MT, WC, GATHER, PRO>(P, gy, nslots, gx);
+  // with resident weights nothing in the loop is consumed in the item that loaded it: a third item in flight then really is in flight
+  // (the third register set fits only next to bf16 rows without a prologue; everything else keeps two)
+  constexpr int D = (NCH > 0 && PRO == LY_PRO_NONE && sizeof(TI) == 2) ? LY_GEMM_DEPTH : 2;
+  ly_gemm_body2<TI, TO, NT, MT, WC, GATHER, PRO, D, NCH, FAST>(P, gy, nslots, gx);
 }
 
-template <typename TI, typename TO, int NT, int MT, int WC, int GATHER, int PRO>
+template <typename TI, typename TO, int NT, int MT, int WC, int GATHER, int PRO, int NCH = 0, int FAST = 0>
 static int launch_gemm_d2(const LyGemmParams& P, hipStream_t st) {
   constexpr int BP = 16 * NT * (4 / WC);
   constexpr int BN = 16 * MT * WC;
@@ -364,7 +445,7 @@ static int launch_gemm_d2(const LyGemmParams& P, hipStream_t st) {
   long gx = (P.M + BP - 1) / BP;
   int gy = (P.N + BN - 1) / BN;
   LY_CHECK(gx < (1L << 30), "gemm: too many pixel tiles");
-  auto k = ly_gemm_kernel_d2<TI, TO, NT, MT, WC, GATHER, PRO>;
+  auto k = ly_gemm_kernel_d2<TI, TO, NT, MT, WC, GATHER, PRO, NCH, FAST>;
   static int per_cu = 0;            // co-resident blocks per CU (registers + LDS), measured once per instantiation
   if (per_cu == 0) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
@@ -383,18 +464,39 @@ static int launch_gemm_d2(const LyGemmParams& P, hipStream_t st) {
   return 0;
 }
 
+// Variant choice per call.  K in one or two chunks: weights resident (NCH) and, when every channel tile is full and the stores can be
+// vectors, the branch-free epilogue (FAST 1; 2 = with the BatchNorm sums of the training forward kept in registers).
+template <typename TI, typename TO, int NT, int MT, int WC, int GATHER, int PRO>
+static int launch_gemm_v(const LyGemmParams& P, hipStream_t st) {
+  // which of the variants fit 256 registers without spilling into the loop (checked in the .s of every instantiation)
+  constexpr bool ok1 = WC == 4 || PRO == LY_PRO_NONE;                  // one chunk resident
+  constexpr bool ok2 = WC == 4 && PRO != LY_PRO_GATE;                  // two chunks resident
+  constexpr bool oks1 = ok1 && PRO != LY_PRO_GATE;                     // ... with the BatchNorm sums in registers as well
+  constexpr bool oks2 = ok2 && PRO == LY_PRO_NONE;
+  const int nchunk = (P.K + 16 * LyT<TI>::VW - 1) / (16 * LyT<TI>::VW);
+  const bool fast = P.N % (16 * MT * WC) == 0 && (P.ldo & 3) == 0 && P.out;
+  if (fast && !P.stats) {
+    if constexpr (ok1) { if (nchunk == 1) return launch_gemm_d2<TI, TO, NT, MT, WC, GATHER, PRO, 1, 1>(P, st); }
+    if constexpr (ok2) { if (nchunk == 2) return launch_gemm_d2<TI, TO, NT, MT, WC, GATHER, PRO, 2, 1>(P, st); }
+  } else if (fast) {
+    if constexpr (oks1) { if (nchunk == 1) return launch_gemm_d2<TI, TO, NT, MT, WC, GATHER, PRO, 1, 2>(P, st); }
+    if constexpr (oks2) { if (nchunk == 2) return launch_gemm_d2<TI, TO, NT, MT, WC, GATHER, PRO, 2, 2>(P, st); }
+  }
+  return launch_gemm_d2<TI, TO, NT, MT, WC, GATHER, PRO>(P, st);
+}
+
 template <typename T, int NT, int MT, int WC>
 static int launch_gemm(const LyGemmParams& P, hipStream_t st) {
-  if (P.gather == LY_GATHER_PATCH) return launch_gemm_d2<T, T, NT, MT, WC, LY_GATHER_PATCH, LY_PRO_NONE>(P, st);
-  if (P.gather == LY_GATHER_PATCH_NCHW) return launch_gemm_d2<float, T, NT, MT, WC, LY_GATHER_PATCH_NCHW, LY_PRO_NONE>(P, st);
+  if (P.gather == LY_GATHER_PATCH) return launch_gemm_v<T, T, NT, MT, WC, LY_GATHER_PATCH, LY_PRO_NONE>(P, st);
+  if (P.gather == LY_GATHER_PATCH_NCHW) return launch_gemm_v<float, T, NT, MT, WC, LY_GATHER_PATCH_NCHW, LY_PRO_NONE>(P, st);
   if (P.gather == LY_GATHER_UP2) {
-    if (P.pro == LY_PRO_NONE) return launch_gemm_d2<T, T, NT, MT, WC, LY_GATHER_UP2, LY_PRO_NONE>(P, st);
+    if (P.pro == LY_PRO_NONE) return launch_gemm_v<T, T, NT, MT, WC, LY_GATHER_UP2, LY_PRO_NONE>(P, st);
     ly_set_error("gemm: upsampled source with a prologue is not built");
     return -1;
   }
-  if (P.pro == LY_PRO_GATE) return launch_gemm_d2<T, T, NT, MT, WC, LY_GATHER_ROWS, LY_PRO_GATE>(P, st);
-  if (P.pro == LY_PRO_AFFINE_RELU_CA) return launch_gemm_d2<T, T, NT, MT, WC, LY_GATHER_ROWS, LY_PRO_AFFINE_RELU_CA>(P, st);
-  return launch_gemm_d2<T, T, NT, MT, WC, LY_GATHER_ROWS, LY_PRO_NONE>(P, st);
+  if (P.pro == LY_PRO_GATE) return launch_gemm_v<T, T, NT, MT, WC, LY_GATHER_ROWS, LY_PRO_GATE>(P, st);
+  if (P.pro == LY_PRO_AFFINE_RELU_CA) return launch_gemm_v<T, T, NT, MT, WC, LY_GATHER_ROWS, LY_PRO_AFFINE_RELU_CA>(P, st);
+  return launch_gemm_v<T, T, NT, MT, WC, LY_GATHER_ROWS, LY_PRO_NONE>(P, st);
 }
 
 // Tile policy, measured on MI355X at every LEAD-YOLO shape: 64-pixel tiles with 3 co-resident blocks per CU beat 128-pixel

@@ -181,7 +181,17 @@ def gemm(*, M, H, W, K, N, a0, lda0, k0, wp, out, ldo, a1=None, lda1=0, gather=G
     ti = "float" if (code == 0 or gather == GATHER_PATCH_NCHW) else "__bf16"
     to = "float" if code == 0 else "__bf16"
     es_i, es_o = (4 if ti == "float" else 2), (4 if to == "float" else 2)
-    with _Timed(f"ly_gemm_kernel_d2<{ti}, {to}, {nt}, {mt}, {wc}, {gather}, {pro}>", 2.0 * M * K * N, es_i * M * K + es_o * M * N + 4.0 * N * K):
+    # the variant launch_gemm_v (csrc/ly_gemm.cuh) picks: resident weights for K in one / two chunks + the branch-free epilogue
+    nchunk = -(-K // (64 if ti == "float" else 128))
+    nch = 0
+    if N % (16 * mt * wc) == 0 and ldo % 4 == 0 and out is not None:
+        ok1 = wc == 4 or pro == 0
+        ok2 = wc == 4 and pro != PRO_GATE
+        if stats is not None:
+            ok1, ok2 = ok1 and pro != PRO_GATE, ok2 and pro == 0
+        nch = 1 if (nchunk == 1 and ok1) else 2 if (nchunk == 2 and ok2) else 0
+    ep = (2 if stats is not None else 1) if nch else 0
+    with _Timed(f"ly_gemm_kernel_d2<{ti}, {to}, {nt}, {mt}, {wc}, {gather}, {pro}, {nch}, {ep}>", 2.0 * M * K * N, es_i * M * K + es_o * M * N + 4.0 * N * K):
         capi.check(capi.lib().ly_gemm_fwd(ctypes.byref(P), capi.stream_ptr()), "ly_gemm_fwd")
 
 

@@ -6,6 +6,7 @@ import lead_yolo_amd as L
 from lead_yolo_amd import ops
 dev = torch.device("cuda:0")
 bs = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+amp = torch.bfloat16 if (len(sys.argv) > 2 and sys.argv[2] == "bf16") else None
 from lead_yolo_amd import capi
 m = L.Model(L.load_cfg(scale="s")).to(dev).train()
 opt = L.smart_optimizer(m, "SGD", 0.01, 0.937, 5e-4 * bs / 64)
@@ -26,13 +27,13 @@ G.ops.wgrad = named
 T = ops._Timed
 class T2(T):
     def __init__(self, name, flops, nbytes):
-        super().__init__(getattr(ops, "_WG_NAME", name) if name == "ly_wgrad_kernel" else name, flops, nbytes)
+        super().__init__(getattr(ops, "_WG_NAME", name) + " " + name.split("<")[1][:-1] if name.startswith("ly_wgrad") else name, flops, nbytes)
 ops._Timed = T2
 for _ in range(2):
-    L.train_step(m, cl, opt, imgs, tg)
+    L.train_step(m, cl, opt, imgs, tg, amp=amp)
 torch.cuda.synchronize()
 ops.PROFILE = []
-L.train_step(m, cl, opt, imgs, tg)
+L.train_step(m, cl, opt, imgs, tg, amp=amp)
 torch.cuda.synchronize()
 agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
 for name, fl, by, e0, e1 in ops.PROFILE:
@@ -42,5 +43,5 @@ ops.PROFILE = None
 tot = 0.0
 for name, (n, us, by) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     tot += us
-    print(f"{name:70s} x{n}  {us / n:8.1f} us  {by / (us / n) / 1e3:7.1f} GB/s")
+    print(f"{name:100s} x{n}  {us / n:8.1f} us  {by / (us / n) / 1e3:7.1f} GB/s")
 print(f"total wgrad {tot / 1e3:.2f} ms")

@@ -102,11 +102,23 @@ int ly_conv3x3_fwd(const LyConv3Params* p, void* stream);
 /* ---- CoordAtt (models/common.py:1583-1609) ------------------------------------------------------- */
 /* pool[n, pos, c]: pos < H -> mean over w of row pos; pos >= H -> mean over h of column pos-H.       */
 int ly_pool_hw(const void* x /*T*/, int ldx, int n_img, int H, int W, int C, float* pool, int dtype, void* stream);
-/* y = h_swish(w1 . pool + b1) (bn1 folded into w1/b1: [mip, C], [mip]); a_h[n,h,:] = sigmoid(wh . y + bh),
- * a_w[n,w,:] = sigmoid(ww . y + bw); wh/ww are [C, mip].                                              */
+/* y = h_swish((w1 . pool + b1) * sc + sh); a_h[n,h,:] = sigmoid(wh . y + bh), a_w[n,w,:] = sigmoid(ww . y + bw); w1 [mip, C],
+ * wh/ww [C, mip].  sc/sh = bn1 as a per-channel affine (train mode: batch statistics from ly_coordatt_conv1_stats + ly_bn_finalize),
+ * or both NULL when bn1 is already folded into w1/b1 (eval).                                                              */
 int ly_coordatt_mlp(const float* pool, int n_img, int H, int W, int C, int mip, const float* w1, const float* b1,
-                    const float* wh, const float* bh, const float* ww, const float* bw, float* a_h, float* a_w,
-                    void* stream);
+                    const float* sc, const float* sh, const float* wh, const float* bh, const float* ww, const float* bw, float* a_h,
+                    float* a_w, void* stream);
+/* Backward of that MLP in training (models/common.py:1600-1607 under autograd), two launches: given da_h [n,H,C], da_w [n,W,C]
+ * (from ly_coordatt_gate_bwd), the forward's pool, batch mean / invstd and a_h / a_w:
+ *   dpool [n, H+W, C] is WRITTEN; dw1 [mip,C], dgamma, dbeta [mip], dwh/dww [C,mip], dbh/dbw [C] are ADDED TO (they may be the
+ *   parameters' persistent gradient storage; fresh buffers must be zeroed by the caller); d/d conv1.bias is identically zero
+ *   (bn1 removes the batch mean) and is not produced;
+ *   ws: scratch [n*(H+W)][3*mip] floats, sums: [32][2*mip] zeroed by the caller.  Built for mip 8 / 16, C <= 512.            */
+int ly_coordatt_mlp_bwd(const float* pool, int n_img, int H, int W, int C, int mip, const float* w1, const float* b1,
+                        const float* mean, const float* invstd, const float* gamma, const float* beta, const float* wh,
+                        const float* ww, const float* a_h, const float* a_w, const float* da_h, const float* da_w, float* ws,
+                        float* sums, float* dpool, float* dw1, float* dgamma, float* dbeta, float* dwh, float* dbh, float* dww,
+                        float* dbw, void* stream);
 
 /* out = x * a_w[n,w,:] * a_h[n,h,:] (+ res): the gating multiply as a standalone pass (only used
  * when no consumer GEMM can absorb it, e.g. CA_Bottleneck with a residual shortcut).               */
@@ -228,10 +240,10 @@ int ly_unpatch(const void* g /*T*/, int n_img, int Ho, int Wo, int C, int ks, vo
 
 /* CoordAtt backward (models/common.py:1595-1609).  Gate out = x*a_h[n,h,:]*a_w[n,w,:]:
  *   dx = dout*a_h*a_w,  da_h[n,h,c] += sum_w dout*x*a_w,  da_w[n,w,c] += sum_h dout*x*a_h  (caller zeroes both).
- * Pools pool[n,0:H]=mean_w x, pool[n,H:H+W]=mean_h x:  dx[n,h,w,c] = gp[n,h,c]/W + gp[n,H+w,c]/H.                  */
+ * Pools pool[n,0:H]=mean_w x, pool[n,H:H+W]=mean_h x:  dx[n,h,w,c] (+)= gp[n,h,c]/W + gp[n,H+w,c]/H  (accumulate != 0: added to dx). */
 int ly_coordatt_gate_bwd(const void* dout /*T*/, int ldd, const void* x /*T*/, int ldx, int n_img, int H, int W, int C, const float* a_h,
                          const float* a_w, void* dx /*T*/, int lddx, float* da_h, float* da_w, int dtype, void* stream);
-int ly_pool_hw_bwd(const float* gp, int n_img, int H, int W, int C, void* dx /*T*/, int lddx, int dtype, void* stream);
+int ly_pool_hw_bwd(const float* gp, int n_img, int H, int W, int C, void* dx /*T*/, int lddx, int accumulate, int dtype, void* stream);
 /* k x k / stride 1 / pad k//2 max-pool backward (SPPF, models/common.py:348-366): dx[argmax of window] += dy
  * (first maximum in row-major order, as ATen); dx is ACCUMULATED into, which lets the three chained pools add
  * into the gradient slots of the SPPF concat buffer in place.  x is T; dy and dx are ALWAYS fp32 (atomic accumulation).   */

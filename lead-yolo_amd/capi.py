@@ -81,7 +81,8 @@ SIGNATURES = {
     "ly_gemm_fwd": [ctypes.POINTER(LyGemmParams), _P],
     "ly_conv3x3_fwd": [ctypes.POINTER(LyConv3Params), _P],
     "ly_pool_hw": [_P, _I, _I, _I, _I, _I, _P, _I, _P],
-    "ly_coordatt_mlp": [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "ly_coordatt_mlp": [_P, _I, _I, _I, _I, _I] + [_P] * 11,
+    "ly_coordatt_mlp_bwd": [_P, _I, _I, _I, _I, _I] + [_P] * 23,
     "ly_coordatt_gate": [_P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _P],
     "ly_se_fwd": [_P, _I, _I, _I, _I, _P, _P, _I, _P, _I, _P, _I, _P],
     "ly_rfcbam_stats": [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _I, _I, _P],
@@ -100,7 +101,7 @@ SIGNATURES = {
     "ly_up2_bwd": [_P, _I, _I, _I, _I, _I, _P, _I, _I, _P],
     "ly_unpatch": [_P, _I, _I, _I, _I, _I, _P, _I, _P],
     "ly_coordatt_gate_bwd": [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _I, _P],
-    "ly_pool_hw_bwd": [_P, _I, _I, _I, _I, _P, _I, _I, _P],
+    "ly_pool_hw_bwd": [_P, _I, _I, _I, _I, _P, _I, _I, _I, _P],
     "ly_maxpool_bwd": [_P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P],
     "ly_rf_generate": [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P],
     "ly_rf_bwd_attn": [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],

@@ -59,6 +59,7 @@ extern "C" int ly_pool_hw(const void* x, int ldx, int n_img, int H, int W, int C
 // y = hswish(W1' pool + b1')  (BN folded),  a = sigmoid(Wx y + bx);  one block per (n, pos)
 __global__ __launch_bounds__(LY_THREADS) void ly_coordatt_mlp_kernel(const float* __restrict__ pool, int H, int W, int C, int mip,
                                                                       const float* __restrict__ w1, const float* __restrict__ b1,
+                                                                      const float* __restrict__ sc, const float* __restrict__ sh,
                                                                       const float* __restrict__ wh, const float* __restrict__ bh,
                                                                       const float* __restrict__ ww, const float* __restrict__ bw,
                                                                       float* __restrict__ a_h, float* __restrict__ a_w) {
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_coordatt_mlp_kernel(const float
     for (int c = lane; c < C; c += 64) s += w1[m * C + c] * p[c];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if (lane == 0) ys[m] = ly_hswish(s + b1[m]);
+    if (lane == 0) ys[m] = ly_hswish(sc ? (s + b1[m]) * sc[m] + sh[m] : s + b1[m]);
   }
   __syncthreads();
   const bool isrow = pos < H;
@@ -87,12 +88,12 @@ __global__ __launch_bounds__(LY_THREADS) void ly_coordatt_mlp_kernel(const float
 }
 
 extern "C" int ly_coordatt_mlp(const float* pool, int n_img, int H, int W, int C, int mip, const float* w1, const float* b1,
-                               const float* wh, const float* bh, const float* ww, const float* bw, float* a_h, float* a_w,
+                               const float* sc, const float* sh, const float* wh, const float* bh, const float* ww, const float* bw, float* a_h, float* a_w,
                                void* stream) {
-  LY_CHECK(pool && w1 && b1 && wh && bh && ww && bw && a_h && a_w, "coordatt_mlp: null pointer");
+  LY_CHECK(pool && w1 && b1 && wh && bh && ww && bw && a_h && a_w && (!sc == !sh), "coordatt_mlp: null pointer");
   LY_CHECK(mip > 0 && mip <= 64, "coordatt_mlp: mip=%d out of range", mip);
   hipLaunchKernelGGL(ly_coordatt_mlp_kernel, dim3(n_img * (H + W)), dim3(LY_THREADS), 0, reinterpret_cast<hipStream_t>(stream),
-                     pool, H, W, C, mip, w1, b1, wh, bh, ww, bw, a_h, a_w);
+                     pool, H, W, C, mip, w1, b1, sc, sh, wh, bh, ww, bw, a_h, a_w);
   LY_LAUNCH_CHECK();
   return 0;
 }
@@ -863,6 +864,204 @@ extern "C" int ly_rfcbam_tap_moments(const void* x, int ldx, int n_img, int H, i
   if (blocks > 1024) blocks = 1024;
   LY_WITH_T(dtype, hipLaunchKernelGGL(ly_rfcbam_tap_moments_kernel<T>, dim3((unsigned)blocks), dim3(LY_THREADS), 0, reinterpret_cast<hipStream_t>(stream),
                                       reinterpret_cast<const T*>(x), ldx, n_img, H, W, C, Ho, Wo, s, mom));
+  LY_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// CoordAtt vector MLP, training backward (models/common.py:1600-1607 under autograd):
+//   y0 = W1 pool + b1;  xh = (y0 - mean) * invstd;  y1 = gamma*xh + beta;  y2 = h_swish(y1);  a = sigmoid(Wx y2 + bx)
+// with Wx = conv_h for the H row positions of an image and conv_w for its W column positions.  Two launches, because
+// BatchNorm's backward needs sum(dy1) and sum(dy1*xh) over ALL positions before any dy0 exists:
+//   bwd1 (one WAVE per position, lanes stride the channels, both length-C reductions are shuffle trees, nothing synchronises):
+//         dz = da*a*(1-a) -> dpool buffer;  dy1 = (Wx^T dz) * h_swish'(y1);  (dy1, xh, y2) -> ws;  sums += (dy1, dy1*xh)  (striped)
+//   bwd2 (lane = channel, block = 64 channels x a chunk of positions, waves = row phases):
+//         dy0 = gamma*invstd*(dy1 - S1/R - xh*S2/R);  dpool = W1^T dy0 (over dz, in place);  dW1 += dy0 (x) pool;
+//         dWx += dz (x) y2, dbx += dz;  dgamma += S2, dbeta += S1.   (db1 = sum dy0 is identically zero: BatchNorm removes the mean.)
+// Every parameter gradient is summed in registers, then over the block's waves through LDS, and ADDED to its target once per block
+// (a few dozen adds per address: same-address float atomics serialise, ~0.05 us each).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float ly_hswish_grad(float x) { return x <= -3.f ? 0.f : (x >= 3.f ? 1.f : (2.f * x + 3.f) * (1.f / 6.f)); }
+#define LY_CA_STRIPES 32
+
+template <int MIP, int NS>
+__global__ __launch_bounds__(LY_THREADS) void ly_coordatt_mlp_bwd1_kernel(
+    const float* __restrict__ pool, int n_img, int H, int W, int C, const float* __restrict__ w1, const float* __restrict__ b1,
+    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ wh, const float* __restrict__ ww, const float* __restrict__ a_h, const float* __restrict__ a_w,
+    const float* __restrict__ da_h, const float* __restrict__ da_w, float* __restrict__ ws, float* __restrict__ sums, float* __restrict__ dzb) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int L = H + W;
+  const long R = (long)n_img * L;
+  float s1 = 0.f, s2 = 0.f;                                // lane m < MIP: sum dy1[m], sum dy1[m]*xh[m]
+  const long nw = (long)gridDim.x * 4;
+  for (long r = (long)blockIdx.x * 4 + wave; r < R; r += nw) {
+    const long n = r / L;
+    const int pos = (int)(r - n * L);
+    const bool isrow = pos < H;
+    const long q = isrow ? n * H + pos : n * W + (pos - H);
+    const float* wx = isrow ? wh : ww;
+    const float* am = (isrow ? a_h : a_w) + q * C;
+    const float* dam = (isrow ? da_h : da_w) + q * C;
+    float y[MIP], d[MIP];
+#pragma unroll
+    for (int m = 0; m < MIP; ++m) { y[m] = 0.f; d[m] = 0.f; }
+#pragma unroll
+    for (int sl = 0; sl < NS; ++sl) {
+      const int c = lane + 64 * sl;
+      if (c < C) {
+        const float pv = pool[r * C + c];
+        const float av = am[c];
+        const float dz = dam[c] * av * (1.f - av);
+        dzb[r * C + c] = dz;
+#pragma unroll
+        for (int m = 0; m < MIP; ++m) {
+          y[m] += w1[m * C + c] * pv;
+          d[m] += dz * wx[c * MIP + m];
+        }
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < MIP; ++m) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        y[m] += __shfl_xor(y[m], o);
+        d[m] += __shfl_xor(d[m], o);
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < MIP; ++m) {
+      const float xh = (y[m] + b1[m] - mean[m]) * invstd[m];
+      const float y1 = gamma[m] * xh + beta[m];
+      const float g = d[m] * ly_hswish_grad(y1);
+      if (lane == m) {
+        s1 += g;
+        s2 += g * xh;
+        ws[r * 3 * MIP + m] = g;
+        ws[r * 3 * MIP + MIP + m] = xh;
+        ws[r * 3 * MIP + 2 * MIP + m] = ly_hswish(y1);
+      }
+    }
+  }
+  if (lane < MIP) {
+    float* st = sums + ((blockIdx.x * 4 + wave) & (LY_CA_STRIPES - 1)) * 2 * MIP;
+    atomicAdd(st + lane, s1);
+    atomicAdd(st + MIP + lane, s2);
+  }
+}
+
+template <int MIP>
+__global__ __launch_bounds__(LY_THREADS) void ly_coordatt_mlp_bwd2_kernel(
+    const float* __restrict__ pool, int n_img, int H, int W, int C, long rows_per_block, const float* __restrict__ w1,
+    const float* __restrict__ gamma, const float* __restrict__ invstd, const float* __restrict__ ws, const float* __restrict__ sums,
+    float* __restrict__ dpool /* in: dz */, float* __restrict__ dw1, float* __restrict__ dgamma, float* __restrict__ dbeta,
+    float* __restrict__ dwh, float* __restrict__ dbh, float* __restrict__ dww, float* __restrict__ dbw) {
+  constexpr int NA = 3 * MIP + 2;                          // accumulators per channel: dW1[m], dWh[m], dWw[m], dbh, dbw
+  __shared__ float red[4 * 64 * (3 * MIP + 2)];
+  __shared__ float ssum[2 * MIP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int L = H + W;
+  const long R = (long)n_img * L;
+  const int c = blockIdx.x * 64 + lane;
+  const bool cok = c < C;
+  if (tid < 2 * MIP) {
+    float v = 0.f;
+    for (int st = 0; st < LY_CA_STRIPES; ++st) v += sums[st * 2 * MIP + tid];
+    ssum[tid] = v;
+  }
+  __syncthreads();
+  const float invR = 1.f / (float)R;
+  float k0[MIP], m1[MIP], m2[MIP], w1r[MIP];
+  float acc[NA];
+#pragma unroll
+  for (int m = 0; m < MIP; ++m) {
+    k0[m] = gamma[m] * invstd[m];
+    m1[m] = ssum[m] * invR;
+    m2[m] = ssum[MIP + m] * invR;
+    w1r[m] = cok ? w1[m * C + c] : 0.f;
+  }
+#pragma unroll
+  for (int e = 0; e < NA; ++e) acc[e] = 0.f;
+  const long r_lo = (long)blockIdx.y * rows_per_block;
+  const long r_hi = r_lo + rows_per_block < R ? r_lo + rows_per_block : R;
+  for (long r = r_lo + wave; r < r_hi; r += 4) {
+    const int pos = (int)(r % L);
+    const bool isrow = pos < H;
+    const float* wr = ws + r * 3 * MIP;                    // wave-uniform row: (dy1, xh, y2)
+    const float pv = cok ? pool[r * C + c] : 0.f;
+    const float dz = cok ? dpool[r * C + c] : 0.f;
+    float g = 0.f;
+#pragma unroll
+    for (int m = 0; m < MIP; ++m) {
+      const float dy0 = k0[m] * (wr[m] - m1[m] - wr[MIP + m] * m2[m]);
+      const float t = dz * wr[2 * MIP + m];
+      g += dy0 * w1r[m];
+      acc[m] += dy0 * pv;
+      acc[MIP + m] += isrow ? t : 0.f;
+      acc[2 * MIP + m] += isrow ? 0.f : t;
+    }
+    acc[3 * MIP] += isrow ? dz : 0.f;
+    acc[3 * MIP + 1] += isrow ? 0.f : dz;
+    if (cok) dpool[r * C + c] = g;
+  }
+#pragma unroll
+  for (int e = 0; e < NA; ++e) red[(wave * 64 + lane) * NA + e] = acc[e];
+  __syncthreads();
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid < MIP) {
+    atomicAdd(dgamma + tid, ssum[MIP + tid]);
+    atomicAdd(dbeta + tid, ssum[tid]);
+  }
+  for (int e = tid; e < 64 * NA; e += LY_THREADS) {
+    const int cl = e / NA, k = e - cl * NA;
+    const int cc = blockIdx.x * 64 + cl;
+    if (cc >= C) continue;
+    const float v = red[e] + red[64 * NA + e] + red[2 * 64 * NA + e] + red[3 * 64 * NA + e];
+    if (k < MIP) atomicAdd(dw1 + k * C + cc, v);
+    else if (k < 2 * MIP) atomicAdd(dwh + cc * MIP + (k - MIP), v);
+    else if (k < 3 * MIP) atomicAdd(dww + cc * MIP + (k - 2 * MIP), v);
+    else if (k == 3 * MIP) atomicAdd(dbh + cc, v);
+    else atomicAdd(dbw + cc, v);
+  }
+}
+
+template <int MIP, int NS>
+static void launch_coordatt_bwd(hipStream_t st, const float* pool, int n_img, int H, int W, int C, const float* w1, const float* b1, const float* mean,
+                                const float* invstd, const float* gamma, const float* beta, const float* wh, const float* ww, const float* a_h,
+                                const float* a_w, const float* da_h, const float* da_w, float* ws, float* sums, float* dpool, float* dw1,
+                                float* dgamma, float* dbeta, float* dwh, float* dbh, float* dww, float* dbw) {
+  const long R = (long)n_img * (H + W);
+  long b1n = (R + 3) / 4;
+  if (b1n > 1024) b1n = 1024;
+  hipLaunchKernelGGL((ly_coordatt_mlp_bwd1_kernel<MIP, NS>), dim3((unsigned)b1n), dim3(LY_THREADS), 0, st, pool, n_img, H, W, C, w1, b1, mean, invstd, gamma,
+                     beta, wh, ww, a_h, a_w, da_h, da_w, ws, sums, dpool);
+  const int groups = (C + 63) / 64;
+  long chunks = (256 + groups - 1) / groups;               // ~256 blocks; each target address then receives `chunks` adds
+  if (chunks > (R + 31) / 32) chunks = (R + 31) / 32;
+  if (chunks < 1) chunks = 1;
+  const long rpb = (R + chunks - 1) / chunks;
+  chunks = (R + rpb - 1) / rpb;
+  hipLaunchKernelGGL((ly_coordatt_mlp_bwd2_kernel<MIP>), dim3((unsigned)groups, (unsigned)chunks), dim3(LY_THREADS), 0, st, pool, n_img, H, W, C, rpb, w1,
+                     gamma, invstd, ws, sums, dpool, dw1, dgamma, dbeta, dwh, dbh, dww, dbw);
+}
+
+extern "C" int ly_coordatt_mlp_bwd(const float* pool, int n_img, int H, int W, int C, int mip, const float* w1, const float* b1,
+                                   const float* mean, const float* invstd, const float* gamma, const float* beta, const float* wh,
+                                   const float* ww, const float* a_h, const float* a_w, const float* da_h, const float* da_w, float* ws,
+                                   float* sums, float* dpool, float* dw1, float* dgamma, float* dbeta, float* dwh, float* dbh,
+                                   float* dww, float* dbw, void* stream) {
+  LY_CHECK(pool && w1 && b1 && mean && invstd && gamma && beta && wh && ww && a_h && a_w && da_h && da_w && ws && sums && dpool && dw1 &&
+               dgamma && dbeta && dwh && dbh && dww && dbw, "coordatt_mlp_bwd: null pointer");
+  LY_CHECK((mip == 8 || mip == 16) && C > 0 && C <= 512 && n_img > 0 && H > 0 && W > 0, "coordatt_mlp_bwd: built for mip 8 / 16 and C <= 512 (mip=%d C=%d)", mip, C);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define LY_CA_BWD(MIP, NS) launch_coordatt_bwd<MIP, NS>(st, pool, n_img, H, W, C, w1, b1, mean, invstd, gamma, beta, wh, ww, a_h, a_w, da_h, da_w, ws, sums, \
+                                                        dpool, dw1, dgamma, dbeta, dwh, dbh, dww, dbw)
+  const int ns = (C + 63) / 64;
+  if (mip == 8) {
+    if (ns <= 1) LY_CA_BWD(8, 1); else if (ns <= 2) LY_CA_BWD(8, 2); else if (ns <= 4) LY_CA_BWD(8, 4); else LY_CA_BWD(8, 8);
+  } else {
+    if (ns <= 4) LY_CA_BWD(16, 4); else LY_CA_BWD(16, 8);
+  }
+#undef LY_CA_BWD
   LY_LAUNCH_CHECK();
   return 0;
 }

@@ -787,7 +787,7 @@ extern "C" int ly_coordatt_gate_bwd(const void* dout, int ldd, const void* x, in
   return 0;
 }
 
-template <typename T>
+template <typename T, bool ACC>
 __global__ __launch_bounds__(LY_THREADS) void ly_pool_hw_bwd_kernel(const float* __restrict__ gp, int n_img, int H, int W, int C,
                                                                     T* __restrict__ dx, int lddx) {
   const int nc4 = C >> 2;
@@ -801,15 +801,23 @@ __global__ __launch_bounds__(LY_THREADS) void ly_pool_hw_bwd_kernel(const float*
     const long n = row / H;
     const int h = (int)(row - n * H);
     const f32x4 a = ly_ldg4(gp + (n * (H + W) + h) * C + c), b = ly_ldg4(gp + (n * (H + W) + H + w) * C + c);
-    ly_st4<T>(dx + pix * lddx + c, a * iw + b * ih);
+    f32x4 v = a * iw + b * ih;
+    if (ACC) v += ly_ld4<T>(dx + pix * lddx + c);
+    ly_st4<T>(dx + pix * lddx + c, v);
   }
 }
 
-extern "C" int ly_pool_hw_bwd(const float* gp, int n_img, int H, int W, int C, void* dx, int lddx, int dtype, void* stream) {
+extern "C" int ly_pool_hw_bwd(const float* gp, int n_img, int H, int W, int C, void* dx, int lddx, int accumulate, int dtype, void* stream) {
   LY_CHECK_DTYPE(dtype, "pool_hw_bwd");
   LY_CHECK(gp && dx && n_img > 0 && H > 0 && W > 0 && (C & 3) == 0 && (lddx & 3) == 0, "pool_hw_bwd: bad arguments");
-  LY_WITH_T(dtype, hipLaunchKernelGGL(ly_pool_hw_bwd_kernel<T>, dim3((unsigned)ly_ew_blocks((long)n_img * H * W * (C >> 2))), dim3(LY_THREADS), 0,
-                                      reinterpret_cast<hipStream_t>(stream), gp, n_img, H, W, C, reinterpret_cast<T*>(dx), lddx));
+  const dim3 grid((unsigned)ly_ew_blocks((long)n_img * H * W * (C >> 2)));
+  if (accumulate) {
+    LY_WITH_T(dtype, hipLaunchKernelGGL((ly_pool_hw_bwd_kernel<T, true>), grid, dim3(LY_THREADS), 0, reinterpret_cast<hipStream_t>(stream), gp, n_img, H, W, C,
+                                        reinterpret_cast<T*>(dx), lddx));
+  } else {
+    LY_WITH_T(dtype, hipLaunchKernelGGL((ly_pool_hw_bwd_kernel<T, false>), grid, dim3(LY_THREADS), 0, reinterpret_cast<hipStream_t>(stream), gp, n_img, H, W, C,
+                                        reinterpret_cast<T*>(dx), lddx));
+  }
   LY_LAUNCH_CHECK();
   return 0;
 }

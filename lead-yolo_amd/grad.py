@@ -446,10 +446,65 @@ class Gate(torch.autograd.Function):
         return ops.coordatt_gate_bwd(_rows_dense(dout if dout.dtype == xr.dtype else dout.to(xr.dtype)), xr, ld, n, h, w, c, a_h, a_w)
 
 
+class CoordAttFn(torch.autograd.Function):
+    """The whole CoordAtt (models/common.py:1595-1609) as ONE autograd node: pools -> conv1 -> bn1 (batch statistics) -> h_swish ->
+    conv_h / conv_w -> sigmoid -> gate.  Forward = the inference kernels plus the statistics pass (6 launches); backward = gate
+    backward, the two-launch MLP backward (csrc/ly_attention.hip, ly_coordatt_mlp_bwd) and the pool gradient added into dx in place.
+    The same arithmetic as torch ops under autograd was ~60 launches of rocBLAS GEMMs on [n*(h+w), 8] matrices, native BatchNorm and
+    elementwise kernels per block."""
+
+    @staticmethod
+    def forward(ctx, mod, x, w1, b1, gamma, beta, wh, bh, ww, bw):
+        t, ld = ops.rows(x)
+        n, c, h, w = t.shape
+        mip = mod.mip
+        W1, Wh, Ww = (p.detach().reshape(p.shape[0], -1) for p in (w1, wh, ww))
+        pool = ops.pool_hw(t, ld, n, h, w, c)
+        st = ops.coordatt_conv1_stats(pool, n * (h + w), c, mip, W1, b1)
+        sc, sh, mean, invstd = ops.bn_finalize(mod.bn1, st.view(1, -1), mip, n * (h + w), want_stats=True)
+        a_h, a_w = ops.coordatt_mlp(pool, n, h, w, c, mip, W1, b1.detach(), Wh, bh.detach(), Ww, bw.detach(), sc=sc, sh=sh)
+        out = ops.coordatt_gate(t, ld, n, h, w, c, a_h, a_w)
+        ctx.save_for_backward(t, pool, a_h, a_w, mean, invstd)
+        ctx.params = (w1, b1, gamma, beta, wh, bh, ww, bw)
+        ctx.mip = mip
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        t, pool, a_h, a_w, mean, invstd = ctx.saved_tensors
+        xr, ld = ops.rows(t)
+        n, c, h, w = xr.shape
+        w1, b1, gamma, beta, wh, bh, ww, bw = ctx.params
+        dx, da_h, da_w = ops.coordatt_gate_bwd(_rows_dense(dout if dout.dtype == xr.dtype else dout.to(xr.dtype)), xr, ld, n, h, w, c, a_h, a_w)
+        targets, ret = [], []
+        for i, p in enumerate(ctx.params):                    # accumulate into the persistent gradient storage where there is one
+            if i == 1:                                        # conv1.bias: bn1 removes the batch mean, d/dbias == 0 (nothing to add)
+                sunk = p.requires_grad and ops.grad_target(p) is not None
+                ret.append(None if (sunk or not p.requires_grad) else torch.zeros_like(p))
+                continue
+            tgt = ops.grad_target(p) if p.requires_grad else None
+            fresh = tgt is None
+            if fresh:
+                tgt = torch.zeros(p.shape, dtype=torch.float32, device=xr.device)
+            targets.append(tgt)
+            ret.append(tgt if (fresh and p.requires_grad) else None)
+        W1, Wh, Ww = (p.detach().reshape(p.shape[0], -1) for p in (w1, wh, ww))
+        dpool = ops.coordatt_mlp_bwd(pool, n, h, w, c, ctx.mip, W1, b1.detach(), mean, invstd, gamma.detach(), beta.detach(), Wh, Ww, a_h, a_w,
+                                     da_h, da_w, targets)
+        ops.pool_hw_bwd(dpool, n, h, w, c, into=dx)
+        for p, r in zip(ctx.params, ret):
+            if r is None and p.requires_grad:
+                ops.grad_done(p)
+        return (None, dx, *ret)
+
+
 def coordatt_train(mod, x):
     """CoordAtt.forward in training (models/common.py:1595-1609)."""
-    import torch.nn.functional as F
     n, c, h, w = x.shape
+    params = (mod.conv1.weight, mod.conv1.bias, mod.bn1.weight, mod.bn1.bias, mod.conv_h.weight, mod.conv_h.bias, mod.conv_w.weight, mod.conv_w.bias)
+    if mod.mip in (8, 16) and c <= 512 and all(p is not None and p.dtype == torch.float32 for p in params):
+        return CoordAttFn.apply(mod, x, *params)
+    import torch.nn.functional as F                          # other widths: the same arithmetic as torch ops on the pooled vectors
     pool = PoolHW.apply(x)                                                   # [n, h+w, c]
     y = F.linear(pool, mod.conv1.weight.view(mod.mip, c), mod.conv1.bias)    # [n, h+w, mip]
     bn = mod.bn1

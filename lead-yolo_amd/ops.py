@@ -215,12 +215,26 @@ def pool_hw(x, ldx, n, h, w, c):
     return pool
 
 
-def coordatt_mlp(pool, n, h, w, c, mip, w1, b1, wh, bh, ww, bw):
+def coordatt_mlp(pool, n, h, w, c, mip, w1, b1, wh, bh, ww, bw, sc=None, sh=None):
+    """sc/sh: bn1 as a per-channel affine applied after the raw conv1 (train mode); None = already folded into w1/b1"""
     a_h = torch.empty((n, h, c), dtype=torch.float32, device=pool.device)
     a_w = torch.empty((n, w, c), dtype=torch.float32, device=pool.device)
-    capi.check(capi.lib().ly_coordatt_mlp(_p(pool), n, h, w, c, mip, _p(w1), _p(b1), _p(wh), _p(bh), _p(ww), _p(bw), _p(a_h),
+    capi.check(capi.lib().ly_coordatt_mlp(_p(pool), n, h, w, c, mip, _p(w1), _p(b1), _p(sc), _p(sh), _p(wh), _p(bh), _p(ww), _p(bw), _p(a_h),
                                           _p(a_w), capi.stream_ptr()), "ly_coordatt_mlp")
     return a_h, a_w
+
+
+def coordatt_mlp_bwd(pool, n, h, w, c, mip, w1, b1, mean, invstd, gamma, beta, wh, ww, a_h, a_w, da_h, da_w, targets):
+    """targets: (dw1, dgamma, dbeta, dwh, dbh, dww, dbw) fp32 buffers that are ADDED to; returns dpool [n, h+w, c]"""
+    r = n * (h + w)
+    sums = zeros_f32(32 * 2 * mip, pool.device)                        # striped (sum dy1, sum dy1*xh)
+    ws = torch.empty(r * 3 * mip, dtype=torch.float32, device=pool.device)
+    dpool = torch.empty((n, h + w, c), dtype=torch.float32, device=pool.device)
+    with _Timed("ly_coordatt_mlp_bwd1_kernel + bwd2", 8.0 * r * c * mip, 4.0 * 4 * r * c):
+        capi.check(capi.lib().ly_coordatt_mlp_bwd(_p(pool), n, h, w, c, mip, _p(w1), _p(b1), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(wh), _p(ww),
+                                                  _p(a_h), _p(a_w), _p(da_h), _p(da_w), _p(ws), _p(sums), _p(dpool),
+                                                  *[_p(t) for t in targets], capi.stream_ptr()), "ly_coordatt_mlp_bwd")
+    return dpool
 
 
 def coordatt_gate(x, ldx, n, h, w, c, a_h, a_w, res=None, ldres=0):
@@ -404,6 +418,20 @@ def new_stats(nch, device):
     return torch.zeros(STRIPES, 2 * nch, dtype=torch.float32, device=device)
 
 
+def zeros_f32(numel, device):
+    """zeroed fp32 scratch (transient accumulators of one launch sequence: never saved, never a parameter gradient) from the step's
+    pool, so that a training step issues one fill for all of them"""
+    p = _POOL
+    if p.active:
+        span = (numel + 63) // 64 * 64
+        p.used += span
+        if p.buf is not None and p.buf.device == device and p.off + span <= p.buf.numel():
+            v = p.buf[p.off:p.off + numel]
+            p.off += span
+            return v
+    return torch.zeros(numel, dtype=torch.float32, device=device)
+
+
 def bn_finalize(bn, stats, nch, count, n=None, c_off=0, bias=None, pad_to=0, want_stats=False):
     """Train-mode BatchNorm2d from the striped sums of a statistics pass, ONE launch (ly_bn_finalize): returns
     (scale, shift) of y = x*scale + shift [+ (mean, invstd)], updates running_mean/var/num_batches_tracked in place."""
@@ -478,7 +506,7 @@ def grad_done(p):
 
 
 def coordatt_conv1_stats(pool, positions, c, mip, w1, b1):
-    st = torch.zeros(2 * mip, dtype=torch.float32, device=pool.device)
+    st = zeros_f32(2 * mip, pool.device)
     capi.check(capi.lib().ly_coordatt_conv1_stats(_p(pool), positions, c, mip, _p(w1), _p(b1), _p(st), capi.stream_ptr()),
                "ly_coordatt_conv1_stats")
     return st
@@ -603,17 +631,19 @@ def unpatch(g, n, ho, wo, c, ks, h, w):
 
 def coordatt_gate_bwd(dout, x, ldx, n, h, w, c, a_h, a_w):
     dx = empty_nhwc(n, c, h, w, dout)
-    da_h = torch.zeros((n, h, c), dtype=torch.float32, device=dout.device)
-    da_w = torch.zeros((n, w, c), dtype=torch.float32, device=dout.device)
+    da = zeros_f32(n * (h + w) * c, dout.device)
+    da_h, da_w = da[:n * h * c].view(n, h, c), da[n * h * c:].view(n, w, c)
     with _Timed(f"ly_coordatt_gate_bwd_kernel<{_tname(x)}>", 6.0 * n * h * w * c, 3.0 * x.element_size() * n * h * w * c):
         capi.check(capi.lib().ly_coordatt_gate_bwd(_p(dout), c, _p(x), ldx, n, h, w, c, _p(a_h), _p(a_w), _p(dx), c, _p(da_h), _p(da_w),
                                                    capi.dtype_code(x), capi.stream_ptr()), "ly_coordatt_gate_bwd")
     return dx, da_h, da_w
 
 
-def pool_hw_bwd(gp, n, h, w, c, dtype=torch.float32):
-    dx = empty_nhwc(n, c, h, w, gp, dtype=dtype)
-    capi.check(capi.lib().ly_pool_hw_bwd(_p(gp), n, h, w, c, _p(dx), c, capi.dtype_code(dtype), capi.stream_ptr()), "ly_pool_hw_bwd")
+def pool_hw_bwd(gp, n, h, w, c, dtype=torch.float32, into=None):
+    """into: a dense NHWC gradient the pool gradient is ADDED to in place (one pass instead of write + add)"""
+    dx = into if into is not None else empty_nhwc(n, c, h, w, gp, dtype=dtype)
+    capi.check(capi.lib().ly_pool_hw_bwd(_p(gp), n, h, w, c, _p(dx), c, 1 if into is not None else 0, capi.dtype_code(dx), capi.stream_ptr()),
+               "ly_pool_hw_bwd")
     return dx
 
 

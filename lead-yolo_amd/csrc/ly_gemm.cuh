@@ -337,8 +337,8 @@ __device__ __forceinline__ void ly_gemm_body2(const LyGemmParams& P, const int g
     }
     // ---- epilogue of tile pt ---------------------------------------------------------------------
     if constexpr (FAST != 0) {
-      // Every channel tile of the block is inside N and vector stores are legal: ONE path, every lane stores (rows
-      // past M go to a scratch line).  A store under a branch — even an exec-skip around a masked store — leaves the compiler
+      // N and ldo are multiples of 4, so a lane's 4 channels are all valid or all outside N: ONE path, every lane stores (rows
+      // past M and channel quads past N go to a scratch line).  A store under a branch — even an exec-skip around a masked store — leaves the compiler
       // two vmcnt histories to merge, and the next item's wait for its prefetch then also waits for these stores to be
       // acknowledged: a full memory round trip at every tile end.
 #pragma unroll
@@ -351,7 +351,7 @@ __device__ __forceinline__ void ly_gemm_body2(const LyGemmParams& P, const int g
           f32x4 u;
 #pragma unroll
           for (int r = 0; r < 4; ++r) u[r] = acc[t][n][r] * rs * esc[t][r] + esh[t][r];
-          const bool ok = gp < P.M;
+          const bool ok = gp < P.M && cc < P.N;
           if constexpr (FAST == 2) {                       // BatchNorm sums stay in registers until the block has walked all its tiles
             const f32x4 um = ok ? u : zero;
             sum1[t] += um;
@@ -474,7 +474,7 @@ static int launch_gemm_v(const LyGemmParams& P, hipStream_t st) {
   constexpr bool oks1 = ok1 && PRO != LY_PRO_GATE;                     // ... with the BatchNorm sums in registers as well
   constexpr bool oks2 = ok2 && PRO == LY_PRO_NONE;
   const int nchunk = (P.K + 16 * LyT<TI>::VW - 1) / (16 * LyT<TI>::VW);
-  const bool fast = P.N % (16 * MT * WC) == 0 && (P.ldo & 3) == 0 && P.out;
+  const bool fast = (P.N & 3) == 0 && (P.ldo & 3) == 0 && P.out;
   if (fast && !P.stats) {
     if constexpr (ok1) { if (nchunk == 1) return launch_gemm_d2<TI, TO, NT, MT, WC, GATHER, PRO, 1, 1>(P, st); }
     if constexpr (ok2) { if (nchunk == 2) return launch_gemm_d2<TI, TO, NT, MT, WC, GATHER, PRO, 2, 1>(P, st); }

@@ -184,7 +184,7 @@ def gemm(*, M, H, W, K, N, a0, lda0, k0, wp, out, ldo, a1=None, lda1=0, gather=G
     # the variant launch_gemm_v (csrc/ly_gemm.cuh) picks: resident weights for K in one / two chunks + the branch-free epilogue
     nchunk = -(-K // (64 if ti == "float" else 128))
     nch = 0
-    if N % (16 * mt * wc) == 0 and ldo % 4 == 0 and out is not None:
+    if N % 4 == 0 and ldo % 4 == 0 and out is not None:
         ok1 = wc == 4 or pro == 0
         ok2 = wc == 4 and pro != PRO_GATE
         if stats is not None:

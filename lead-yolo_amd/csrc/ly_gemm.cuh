@@ -259,7 +259,10 @@ __device__ __forceinline__ void ly_gemm_body2(const LyGemmParams& P, const int g
   // fragments of the block's channel slice stay in registers.  That is not about the L2 traffic: vmcnt retires IN ORDER, so a
   // load that is consumed in the item that issued it (a streamed weight fragment) makes its s_waitcnt drain every older load —
   // the activation prefetches of the next items — and the pipeline is never more than one item deep, whatever D says.
-  constexpr int NW = NCH > 0 ? NCH : 1;
+  // NCH == 0 without a prologue (WDB): the weights of the NEXT item are requested at the top of an item, before the activation
+  // prefetch, into the other of two fragment sets — waiting for them an item later then only retires loads that are needed by then anyway.
+  constexpr bool WDB = NCH == 0 && PRO == LY_PRO_NONE && D == 2;
+  constexpr int NW = NCH > 0 ? NCH : (WDB ? 2 : 1);
   LyWF<PL> wq[NW][SPC][MT];
   if constexpr (NCH > 0) {
 #pragma unroll
@@ -270,6 +273,13 @@ __device__ __forceinline__ void ly_gemm_body2(const LyGemmParams& P, const int g
 #pragma unroll
         for (int t = 0; t < MT; ++t) wq[cc][j][t] = ly_wfragp<PL>(wpk, wbase[t] + gj, lane);
       }
+  } else if constexpr (WDB) {
+#pragma unroll
+    for (int j = 0; j < SPC; ++j) {
+      const int gj = j < S ? j : 0;
+#pragma unroll
+      for (int t = 0; t < MT; ++t) wq[0][j][t] = ly_wfragp<PL>(wpk, wbase[t] + gj, lane);
+    }
   } else {
 #pragma unroll
     for (int t = 0; t < MT; ++t) wq[0][0][t] = ly_wfragp<PL>(wpk, wbase[t], lane);
@@ -286,8 +296,16 @@ __device__ __forceinline__ void ly_gemm_body2(const LyGemmParams& P, const int g
   // one item: weights, re-issue the vacated set two items ahead, contract, commit the next item, barrier, epilogue at tile end
   auto item = [&](auto sC, auto cC) -> bool {
     constexpr int s = decltype(sC)::value;                 // set that held THIS item (already committed): free
-    constexpr int CS = NCH > 0 ? decltype(cC)::value : 0;  // resident weights: the chunk index is static
-    if constexpr (NCH == 0) {
+    constexpr int CS = NCH > 0 ? decltype(cC)::value : (WDB ? s : 0);  // resident weights: the chunk index is static
+    if constexpr (WDB) {
+      const int cn = c + 1 < nchunk ? c + 1 : 0;           // chunk of the next item (a new tile starts at chunk 0)
+#pragma unroll
+      for (int j = 0; j < SPC; ++j) {
+        const int gj = SPC * cn + j < S ? SPC * cn + j : 0;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) wq[1 - s][j][t] = ly_wfragp<PL>(wpk, wbase[t] + gj, lane);
+      }
+    } else if constexpr (NCH == 0) {
 #pragma unroll
       for (int j = 1; j < SPC; ++j) {                      // later k-steps' weights first (older than the prefetch in the queue)
         const int gj = SPC * c + j < S ? SPC * c + j : 0;
@@ -319,7 +337,7 @@ __device__ __forceinline__ void ly_gemm_body2(const LyGemmParams& P, const int g
       for (int t = 0; t < MT; ++t)
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[t][n] = ly_mfmap<PL>(wq[CS][st][t], xh[n], xl[n], acc[t][n]);
-      if constexpr (NCH == 0) {
+      if constexpr (NCH == 0 && !WDB) {
         if (st == SPC - 1) {                               // weights of the next item's first step into the slot step 0 vacated
           const int gn = SPC * (c + 1) < S ? SPC * (c + 1) : 0; // (absent steps of a ragged last chunk contract LDS zeros with clamped weights: no branch)
 #pragma unroll
@@ -481,6 +499,9 @@ static int launch_gemm_v(const LyGemmParams& P, hipStream_t st) {
   } else if (fast) {
     if constexpr (oks1) { if (nchunk == 1) return launch_gemm_d2<TI, TO, NT, MT, WC, GATHER, PRO, 1, 2>(P, st); }
     if constexpr (oks2) { if (nchunk == 2) return launch_gemm_d2<TI, TO, NT, MT, WC, GATHER, PRO, 2, 2>(P, st); }
+  }
+  if constexpr (PRO == LY_PRO_NONE) {                      // long K: weights streamed one item ahead, still the branch-free epilogue
+    if (fast) return P.stats ? launch_gemm_d2<TI, TO, NT, MT, WC, GATHER, PRO, 0, 2>(P, st) : launch_gemm_d2<TI, TO, NT, MT, WC, GATHER, PRO, 0, 1>(P, st);
   }
   return launch_gemm_d2<TI, TO, NT, MT, WC, GATHER, PRO>(P, st);
 }

@@ -190,7 +190,8 @@ def gemm(*, M, H, W, K, N, a0, lda0, k0, wp, out, ldo, a1=None, lda1=0, gather=G
         if stats is not None:
             ok1, ok2 = ok1 and pro != PRO_GATE, ok2 and pro == 0
         nch = 1 if (nchunk == 1 and ok1) else 2 if (nchunk == 2 and ok2) else 0
-    ep = (2 if stats is not None else 1) if nch else 0
+    fast = N % 4 == 0 and ldo % 4 == 0 and out is not None
+    ep = (2 if stats is not None else 1) if (nch or (fast and pro == 0)) else 0
     with _Timed(f"ly_gemm_kernel_d2<{ti}, {to}, {nt}, {mt}, {wc}, {gather}, {pro}, {nch}, {ep}>", 2.0 * M * K * N, es_i * M * K + es_o * M * N + 4.0 * N * K):
         capi.check(capi.lib().ly_gemm_fwd(ctypes.byref(P), capi.stream_ptr()), "ly_gemm_fwd")
 

@@ -41,55 +41,49 @@ __device__ __forceinline__ f32x4 ly_dact4(const f32x4 v, const f32x4 dy) {
 template <typename T, int ACT>
 __global__ __launch_bounds__(LY_THREADS) void ly_bnact_bwd_reduce_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ u,
                                                                           int ldu, long rows, int C, const float* __restrict__ a,
-                                                                          const float* __restrict__ b, float* __restrict__ sums, int vw) {
-  // thread = (channel group of vw = 4 or 8 channels — one 16-byte access in both dtypes when C allows 8 —, row lane)
-  constexpr int NQM = LyT<T>::VW / 4;
-  __shared__ f32x4 red1[NQM][LY_THREADS], red2[NQM][LY_THREADS];
-  const int nq = vw >> 2;                                // fp32 quads per thread: 1 or 2
-  const int ncv = C / vw, tid = threadIdx.x;
+                                                                          const float* __restrict__ b, float* __restrict__ sums) {
+  // thread = (channel quad, row lane).  Four rows per trip with all eight loads issued before the first use, in straight-line code
+  // (a load under a run-time branch makes every later s_waitcnt conservative: the first unrolled version, which still chose the vector
+  // width at run time, was SLOWER than one row per trip).  Rows past the end re-read the last row and are masked.
+  __shared__ f32x4 red1[LY_THREADS], red2[LY_THREADS];
+  using R4 = typename LyT<T>::R4;
+  const int ncv = C >> 2, tid = threadIdx.x;
   const int groups = LY_THREADS / ncv;
   const int cv = tid % ncv, j0 = tid / ncv;
-  f32x4 s1[NQM], s2[NQM];
-#pragma unroll
-  for (int q = 0; q < NQM; ++q) { s1[q] = ly_zero4(); s2[q] = ly_zero4(); }
+  f32x4 s1 = ly_zero4(), s2 = ly_zero4();
   if (j0 < groups) {
-    f32x4 av[NQM], bv[NQM];
+    const f32x4 av = ly_ldg4(a + 4 * cv), bv = ly_ldg4(b + 4 * cv);
+    constexpr int UR = 4;
+    const long stride = (long)gridDim.x * groups;
+    for (long r0 = (long)blockIdx.x * groups + j0; r0 < rows; r0 += UR * stride) {
+      R4 qu[UR], qg[UR];
 #pragma unroll
-    for (int q = 0; q < NQM; ++q)
-      if (q < nq) { av[q] = ly_ldg4(a + vw * cv + 4 * q); bv[q] = ly_ldg4(b + vw * cv + 4 * q); }
-    for (long r = (long)blockIdx.x * groups + j0; r < rows; r += (long)gridDim.x * groups) {
-      f32x4 uu[NQM], g[NQM];
-      if (nq == NQM) {
-        ly_rv_unpack(ly_ldrv<T>(u + r * ldu + vw * cv), uu);
-        ly_rv_unpack(ly_ldrv<T>(dy + r * lddy + vw * cv), g);
-      } else {
-        uu[0] = ly_ld4<T>(u + r * ldu + 4 * cv);
-        g[0] = ly_ld4<T>(dy + r * lddy + 4 * cv);
+      for (int k = 0; k < UR; ++k) {
+        const long r = r0 + k * stride < rows ? r0 + k * stride : rows - 1;
+        qu[k] = ly_ldr4<T>(u + r * ldu + 4 * cv);
+        qg[k] = ly_ldr4<T>(dy + r * lddy + 4 * cv);
       }
 #pragma unroll
-      for (int q = 0; q < NQM; ++q)
-        if (q < nq) {
-          const f32x4 dv = ly_dact4<ACT>(av[q] * uu[q] + bv[q], g[q]);
-          s1[q] += dv;
-          s2[q] += dv * uu[q];
-        }
+      for (int k = 0; k < UR; ++k) {
+        const f32x4 uu = ly_r4_f32(qu[k]);
+        f32x4 dv = ly_dact4<ACT>(av * uu + bv, ly_r4_f32(qg[k]));
+        if (!(r0 + k * stride < rows)) dv = ly_zero4();
+        s1 += dv;
+        s2 += dv * uu;
+      }
     }
   }
-#pragma unroll
-  for (int q = 0; q < NQM; ++q) { red1[q][tid] = s1[q]; red2[q][tid] = s2[q]; }
+  red1[tid] = s1;
+  red2[tid] = s2;
   __syncthreads();
   if (j0 == 0) {
     float* sm = sums + (size_t)(blockIdx.x & (LY_STATS_STRIPES - 1)) * 2 * C;
+    for (int g = 1; g < groups; ++g) { s1 += red1[g * ncv + cv]; s2 += red2[g * ncv + cv]; }
 #pragma unroll
-    for (int q = 0; q < NQM; ++q)
-      if (q < nq) {
-        for (int g = 1; g < groups; ++g) { s1[q] += red1[q][g * ncv + cv]; s2[q] += red2[q][g * ncv + cv]; }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          atomicAdd(sm + vw * cv + 4 * q + r, s1[q][r]);
-          atomicAdd(sm + C + vw * cv + 4 * q + r, s2[q][r]);
-        }
-      }
+    for (int r = 0; r < 4; ++r) {
+      atomicAdd(sm + 4 * cv + r, s1[r]);
+      atomicAdd(sm + C + 4 * cv + r, s2[r]);
+    }
   }
 }
 
@@ -199,7 +193,7 @@ extern "C" int ly_bnact_bwd_reduce(const void* dy_, int lddy, const void* u_, in
   long blocks = (rows + groups * 32L - 1) / (groups * 32L);
   blocks = blocks < 1 ? 1 : blocks > 2048 ? 2048 : blocks;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-#define LY_RED(A) hipLaunchKernelGGL((ly_bnact_bwd_reduce_kernel<T, A>), dim3((unsigned)blocks), dim3(LY_THREADS), 0, st, dy, lddy, u, ldu, rows, C, a, b, sums, vw)
+#define LY_RED(A) hipLaunchKernelGGL((ly_bnact_bwd_reduce_kernel<T, A>), dim3((unsigned)blocks), dim3(LY_THREADS), 0, st, dy, lddy, u, ldu, rows, C, a, b, sums)
   LY_WITH_T(dtype, {
     const T* dy = reinterpret_cast<const T*>(dy_);
     const T* u = reinterpret_cast<const T*>(u_);

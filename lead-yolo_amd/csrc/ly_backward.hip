@@ -822,10 +822,14 @@ extern "C" int ly_pool_hw_bwd(const float* gp, int n_img, int H, int W, int C, v
 // dy is added there: dx[argmax] += dy.  dx is accumulated into (float atomics), so chained pools can add into
 // the gradient slots of the concat buffer in place.
 // -------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, int K>
 __global__ __launch_bounds__(LY_THREADS) void ly_maxpool_bwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ dy, int lddy,
-                                                                    int n_img, int H, int W, int C, int k, float* __restrict__ dx, int lddx) {
-  const int nc4 = C >> 2, r = k >> 1;
+                                                                    int n_img, int H, int W, int C, int k_rt, float* __restrict__ dx, int lddx) {
+  // K > 0: window size known at compile time — the K*K loads of a position are all issued before the first compare, from clamped
+  // coordinates (a `continue` around a load is a branch around a load: every later s_waitcnt turns conservative and the window is
+  // walked one round trip at a time); out-of-range taps are masked in the compare.  K == 0: run-time window (any odd k).
+  const int nc4 = C >> 2;
+  const int k = K > 0 ? K : k_rt, r = k >> 1;
   const long total = (long)n_img * H * W * nc4;
   for (long i = (long)blockIdx.x * LY_THREADS + threadIdx.x; i < total; i += (long)gridDim.x * LY_THREADS) {
     const long pix = i / nc4;
@@ -836,15 +840,40 @@ __global__ __launch_bounds__(LY_THREADS) void ly_maxpool_bwd_kernel(const T* __r
     const int h = (int)(row - n * H);
     f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     long arg[4] = {-1, -1, -1, -1};
-    for (int yy = h - r; yy <= h + r; ++yy) {
-      if (yy < 0 || yy >= H) continue;
-      for (int xx = w - r; xx <= w + r; ++xx) {
-        if (xx < 0 || xx >= W) continue;
-        const long q = (n * H + yy) * W + xx;
-        const f32x4 v = ly_ld4<T>(x + q * ldx + c);
+    if constexpr (K > 0) {
+      typename LyT<T>::R4 raw[K * K];
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (v[e] > best[e] || arg[e] < 0) { best[e] = v[e]; arg[e] = q; }
+      for (int dyy = 0; dyy < K; ++dyy)
+#pragma unroll
+        for (int dxx = 0; dxx < K; ++dxx) {
+          int yy = h - r + dyy, xx = w - r + dxx;
+          yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
+          xx = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+          raw[dyy * K + dxx] = ly_ldr4<T>(x + ((n * H + yy) * W + xx) * ldx + c);
+        }
+#pragma unroll
+      for (int dyy = 0; dyy < K; ++dyy)
+#pragma unroll
+        for (int dxx = 0; dxx < K; ++dxx) {
+          const int yy = h - r + dyy, xx = w - r + dxx;
+          const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+          const long q = (n * H + yy) * W + xx;
+          const f32x4 v = ly_r4_f32(raw[dyy * K + dxx]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (ok && (v[e] > best[e] || arg[e] < 0)) { best[e] = v[e]; arg[e] = q; }
+        }
+    } else {
+      for (int yy = h - r; yy <= h + r; ++yy) {
+        if (yy < 0 || yy >= H) continue;
+        for (int xx = w - r; xx <= w + r; ++xx) {
+          if (xx < 0 || xx >= W) continue;
+          const long q = (n * H + yy) * W + xx;
+          const f32x4 v = ly_ld4<T>(x + q * ldx + c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (v[e] > best[e] || arg[e] < 0) { best[e] = v[e]; arg[e] = q; }
+        }
       }
     }
     const f32x4 g = ly_ldg4(dy + pix * lddy + c);
@@ -858,8 +887,14 @@ extern "C" int ly_maxpool_bwd(const void* x, int ldx, const float* dy, int lddy,
   LY_CHECK_DTYPE(dtype, "maxpool_bwd");
   LY_CHECK(x && dy && dx && n_img > 0 && H > 0 && W > 0 && (k & 1) == 1, "maxpool_bwd: bad arguments");
   LY_CHECK((C & 3) == 0 && (ldx & 3) == 0 && (lddy & 3) == 0, "maxpool_bwd: C / ld must be multiples of 4");
-  LY_WITH_T(dtype, hipLaunchKernelGGL(ly_maxpool_bwd_kernel<T>, dim3((unsigned)ly_ew_blocks((long)n_img * H * W * (C >> 2))), dim3(LY_THREADS), 0,
-                                      reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const T*>(x), ldx, dy, lddy, n_img, H, W, C, k, dx, lddx));
+  const dim3 grid((unsigned)ly_ew_blocks((long)n_img * H * W * (C >> 2)));
+  if (k == 5) {                                            // SPPF(k=5): the one size LEAD-YOLO uses
+    LY_WITH_T(dtype, hipLaunchKernelGGL((ly_maxpool_bwd_kernel<T, 5>), grid, dim3(LY_THREADS), 0, reinterpret_cast<hipStream_t>(stream),
+                                        reinterpret_cast<const T*>(x), ldx, dy, lddy, n_img, H, W, C, k, dx, lddx));
+  } else {
+    LY_WITH_T(dtype, hipLaunchKernelGGL((ly_maxpool_bwd_kernel<T, 0>), grid, dim3(LY_THREADS), 0, reinterpret_cast<hipStream_t>(stream),
+                                        reinterpret_cast<const T*>(x), ldx, dy, lddy, n_img, H, W, C, k, dx, lddx));
+  }
   LY_LAUNCH_CHECK();
   return 0;
 }

@@ -42,7 +42,9 @@ enum { LY_ACT_NONE_ = 0, LY_ACT_RELU_ = 1, LY_ACT_SILU_ = 2 };          /* `act`
 enum { LY_GATHER_ROWS = 0,       /* A row m = a0[m, :k0] | a1[m, :K-k0]                              */
        LY_GATHER_UP2 = 1,        /* a0 is at half resolution: row (n, h/2, w/2)  (nearest 2x upsample) */
        LY_GATHER_PATCH = 2,      /* k x k stride-k patches of an NHWC tensor (PatchMerging)           */
-       LY_GATHER_PATCH_NCHW = 3  /* 4 x 4 stride-4 patches of an NCHW tensor (PatchEmbed on images)   */ };
+       LY_GATHER_PATCH_NCHW = 3, /* 4 x 4 stride-4 patches of an fp32 NCHW tensor (PatchEmbed on images) */
+       LY_GATHER_PATCH_NCHW_U8 = 4 /* the same on a uint8 NCHW image, pixel/255 on load: the `imgs.float() / 255` of the
+                                      training loop (train.py:309) folded into the patch gather                      */ };
 enum { LY_PRO_NONE = 0,
        LY_PRO_GATE = 1,              /* a0 part: x * g_w[n,w,:] * g_h[n,h,:] (+ res)  (CoordAtt gating) */
        LY_PRO_AFFINE_RELU_CA = 2     /* relu(x*p_scale + p_shift) * p_ca[n,:]         (RFCBAMConv k=1)  */ };
@@ -68,7 +70,7 @@ typedef struct LyGemmParams {
                              BatchNorm — adds sum / sum-of-squares over the M rows of the pre-activation value
                              (rowscale*e_scale*acc + e_shift) per output channel; stores nothing when out is NULL,
                              otherwise stores act(that value) as usual (one launch for statistics + pre-BN tensor) */
-  int dtype;              /* LY_F32 / LY_BF16: element type T of a0, a1, res, out.  LY_GATHER_PATCH_NCHW reads an fp32
+  int dtype;              /* LY_F32 / LY_BF16: element type T of a0, a1, res, out.  LY_GATHER_PATCH_NCHW(_U8) reads an fp32 (uint8)
                              IMAGE whatever dtype is (dtype then only selects the output element type)             */
 } LyGemmParams;
 

@@ -7,6 +7,6 @@ from .modules import Lazy  # noqa: F401
 from .model import DEFAULT_CFG, DetectionModel, Model, load_cfg, make_divisible, parse_model  # noqa: F401
 from .loss import ComputeLoss  # noqa: F401
 from .ddp import GradReducer  # noqa: F401
-from .train import GraphedTrainStep, ModelEMA, smart_optimizer, train_step  # noqa: F401
+from .train import GraphedTrainStep, ModelEMA, forward_backward, optimizer_step, smart_optimizer, train_step  # noqa: F401
 from .optim import FusedSGD  # noqa: F401
 from .graph import GraphedForward  # noqa: F401

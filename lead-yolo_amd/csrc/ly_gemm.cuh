@@ -133,7 +133,7 @@ __device__ __forceinline__ void ly_gemm_body2(const LyGemmParams& P, const int g
       const int seg = kk / P.pk, within = kk - seg * P.pk;
       koff = (long)seg * P.Win * P.lda0 + within;
     } else if (GATHER == LY_GATHER_PATCH_NCHW) {
-      const int c = kk >> 4, ky = (kk >> 2) & 3;           // ks == 4, fp32 image: one float4 = one (c, ky) input row segment
+      const int c = kk >> 4, ky = (kk >> 2) & 3;           // ks == 4, fp32 / uint8 image: one 4-pixel vector = one (c, ky) input row segment
       koff = ((long)c * P.Hin + ky) * P.Win;
       rowmul = 1;
     } else {
@@ -510,6 +510,7 @@ template <typename T, int NT, int MT, int WC>
 static int launch_gemm(const LyGemmParams& P, hipStream_t st) {
   if (P.gather == LY_GATHER_PATCH) return launch_gemm_v<T, T, NT, MT, WC, LY_GATHER_PATCH, LY_PRO_NONE>(P, st);
   if (P.gather == LY_GATHER_PATCH_NCHW) return launch_gemm_v<float, T, NT, MT, WC, LY_GATHER_PATCH_NCHW, LY_PRO_NONE>(P, st);
+  if (P.gather == LY_GATHER_PATCH_NCHW_U8) return launch_gemm_v<unsigned char, T, NT, MT, WC, LY_GATHER_PATCH_NCHW, LY_PRO_NONE>(P, st);
   if (P.gather == LY_GATHER_UP2) {
     if (P.pro == LY_PRO_NONE) return launch_gemm_v<T, T, NT, MT, WC, LY_GATHER_UP2, LY_PRO_NONE>(P, st);
     ly_set_error("gemm: upsampled source with a prologue is not built");

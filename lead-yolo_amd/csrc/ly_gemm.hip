@@ -8,11 +8,13 @@ extern "C" int ly_gemm_fwd(const LyGemmParams* p, void* stream) {
   LY_CHECK(p, "gemm: null params");
   const LyGemmParams& P = *p;
   LY_CHECK(P.dtype == LY_F32 || P.dtype == LY_BF16, "gemm: unknown dtype %d", P.dtype);
-  const int vw = (P.dtype == LY_BF16 && P.gather != LY_GATHER_PATCH_NCHW) ? 8 : 4;   // elements of one 16-byte source vector
+  const bool image = P.gather == LY_GATHER_PATCH_NCHW || P.gather == LY_GATHER_PATCH_NCHW_U8;
+  const int vw = (P.dtype == LY_BF16 && !image) ? 8 : 4;   // elements of one source vector
   LY_CHECK(P.a0 && P.wp && (P.out || P.stats), "gemm: null a0/wp/out");
   LY_CHECK(P.M > 0 && P.K > 0 && P.N > 0 && P.H > 0 && P.W > 0, "gemm: bad sizes M=%ld K=%d N=%d", P.M, P.K, P.N);
   LY_CHECK(P.K % vw == 0, "gemm: K=%d must be a multiple of %d", P.K, vw);
-  LY_CHECK(((uintptr_t)P.a0 & 15) == 0 && ((uintptr_t)P.a1 & 15) == 0 && ((uintptr_t)P.res & 15) == 0, "gemm: sources must be 16-byte aligned");
+  LY_CHECK(((uintptr_t)P.a0 & (P.gather == LY_GATHER_PATCH_NCHW_U8 ? 3 : 15)) == 0 && ((uintptr_t)P.a1 & 15) == 0 && ((uintptr_t)P.res & 15) == 0,
+           "gemm: sources must be 16-byte aligned");
   LY_CHECK(((uintptr_t)P.out & (P.dtype == LY_BF16 ? 7 : 15)) == 0 || (P.ldo & 3) != 0, "gemm: out is misaligned for vector stores");
   if (P.gather == LY_GATHER_ROWS || P.gather == LY_GATHER_UP2) {
     LY_CHECK(P.lda0 % vw == 0 && P.k0 % vw == 0 && P.k0 <= P.K && P.k0 > 0, "gemm: lda0=%d k0=%d must be multiples of %d", P.lda0, P.k0, vw);
@@ -21,7 +23,7 @@ extern "C" int ly_gemm_fwd(const LyGemmParams* p, void* stream) {
   } else if (P.gather == LY_GATHER_PATCH) {
     LY_CHECK(P.ks > 0 && P.pk == P.ks * P.lda0 && P.lda0 % vw == 0 && P.K == P.ks * P.pk, "gemm: patch gather misconfigured");
     LY_CHECK(P.Hin >= P.H * P.ks && P.Win >= P.W * P.ks, "gemm: patch gather input too small");
-  } else if (P.gather == LY_GATHER_PATCH_NCHW) {
+  } else if (image) {
     LY_CHECK(P.ks == 4 && (P.Win & 3) == 0 && P.K == P.Cin * 16, "gemm: NCHW patch gather needs ks=4, Win%%4==0");
     LY_CHECK(P.Hin >= P.H * P.ks && P.Win >= P.W * P.ks, "gemm: patch gather input too small");
   } else {

@@ -51,6 +51,13 @@ template <> struct LyT<__bf16> {
   typedef ly_u32x2 R4;
   typedef ly_u32x4 RV;
 };
+// uint8 IMAGE source (LY_GATHER_PATCH_NCHW_U8): 4 pixels per 4-byte vector, value/255 on load, contracted like an fp32 source
+template <> struct LyT<unsigned char> {
+  static constexpr int PL = 2, VW = 4;
+  static constexpr bool BF = false;
+  typedef unsigned R4;
+  typedef unsigned RV;
+};
 
 // runs `stmt` with T bound to the element type selected by the C ABI's dtype code
 #define LY_WITH_T(dtype, ...)                                 \
@@ -81,6 +88,10 @@ __device__ __forceinline__ f32x4 ly_r4_f32(const ly_u32x2 r) { return ly_cvt4(__
 __device__ __forceinline__ void ly_zero_raw(f32x4& r) { r = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 __device__ __forceinline__ void ly_zero_raw(ly_u32x2& r) { r = (ly_u32x2){0u, 0u}; }
 __device__ __forceinline__ void ly_zero_raw(ly_u32x4& r) { r = (ly_u32x4){0u, 0u, 0u, 0u}; }
+__device__ __forceinline__ void ly_zero_raw(unsigned& r) { r = 0u; }
+__device__ __forceinline__ f32x4 ly_u8x4_f32(unsigned r) {          // 4 image bytes -> pixel values / 255 (train.py:309 `imgs.float() / 255`)
+  return (f32x4){(float)(r & 255u), (float)((r >> 8) & 255u), (float)((r >> 16) & 255u), (float)(r >> 24)} * (1.f / 255.f);
+}
 // 16-byte raw vector <-> VW/4 fp32 quads
 __device__ __forceinline__ void ly_rv_unpack(const f32x4 r, f32x4 (&q)[1]) { q[0] = r; }
 __device__ __forceinline__ void ly_rv_unpack(const ly_u32x4 r, f32x4 (&q)[2]) {
@@ -136,6 +147,7 @@ __device__ __forceinline__ void ly_lds_put_rv(char* hi_plane, char* lo_plane, in
 __device__ __forceinline__ void ly_lds_put_rv(char* hi_plane, char*, int row_byte, int c, const ly_u32x4 v) {
   *reinterpret_cast<ly_u32x4*>(hi_plane + row_byte + 2 * c) = v;
 }
+__device__ __forceinline__ void ly_lds_put_rv(char* hi_plane, char* lo_plane, int row_byte, int c, const unsigned v) { ly_lds_put4(hi_plane, lo_plane, row_byte, c, ly_u8x4_f32(v)); }
 // fp32 quad of channels c..c+3 into the operand image of a PL-plane kernel
 template <int PL>
 __device__ __forceinline__ void ly_lds_put_f32(char* hi_plane, char* lo_plane, int row_byte, int c, const f32x4 v) {

@@ -137,10 +137,18 @@ def conv_wgrad(spec, du, x0, x1, weight):
         k = spec.k
         if spec.nchw and h == ho * k and w == wo * k and (k * k * c) % 4 == 0 and co % 4 == 0:
             # PatchEmbed on the NCHW image: one space-to-depth copy turns the k x k patch gather into plain rows [M, c*k*k] (the
-            # weight's own (c, ky, kx) column order), which the tiled kernel takes; the per-lane NCHW gather kernel was 3x slower
+            # weight's own (c, ky, kx) column order), which the tiled kernel takes; the per-lane NCHW gather kernel was 3x slower.
+            # A uint8 image (pixel / 255 folded into the forward gather) is contracted as the integers it holds — exact in bf16 —
+            # and the 1/255 is applied to the small weight gradient instead of to the batch.
+            u8 = x0.dtype == torch.uint8
             xr = x0.reshape(n, c, ho, k, wo, k).permute(0, 2, 4, 1, 3, 5).reshape(m, c * k * k).to(du.dtype)
-            ops.wgrad(M=m, H=ho, W=wo, N=co, du=du, lddu=co, x=xr, ldx=k * k * c, Hin=ho, Win=wo, Cin=k * k * c, dw=dw, lddw=k * k * c, n_valid=nv)
+            acc = torch.zeros(weight.shape, dtype=torch.float32, device=du.device) if u8 else dw
+            ops.wgrad(M=m, H=ho, W=wo, N=co, du=du, lddu=co, x=xr, ldx=k * k * c, Hin=ho, Win=wo, Cin=k * k * c, dw=acc, lddw=k * k * c, n_valid=nv)
+            if u8:
+                dw.add_(acc, alpha=1.0 / 255.0)
         elif spec.nchw:
+            if x0.dtype == torch.uint8:
+                raise NotImplementedError("uint8 image: the weight gradient of the patch embedding needs H, W multiples of the patch size")
             xr = x0.contiguous().to(du.dtype)
             ops.wgrad(M=m, H=ho, W=wo, N=co, du=du, lddu=co, x=xr, ldx=0, Hin=h, Win=w, Cin=c, dw=dw, lddw=k * k * c, ks=k, stride=k, nchw=True,
                       dw_ts=1, dw_cs=k * k, n_valid=nv)

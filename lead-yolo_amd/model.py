@@ -184,6 +184,13 @@ class DetectionModel(nn.Module):
         initialize_weights(self)
         self.set_fuse_graph(fuse_graph)
 
+    @property
+    def u8_input(self):
+        """the first layer is the HIP patch embedding on an NCHW image: a uint8 batch can be passed as it is (pixel / 255 is folded
+        into the patch gather), which is what train.forward_backward does"""
+        first = self.model[0]
+        return isinstance(first, M.PatchEmbed_FasterNet) and first.k == 4 and first.cin % 4 != 0
+
     def set_fuse_graph(self, on):
         for mod in self.modules():
             if isinstance(mod, (M.Upsample, M.Concat)):

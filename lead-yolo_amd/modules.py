@@ -322,11 +322,17 @@ class _PatchConv(nn.Module):
             # dtype policy by hand: the image itself stays fp32 (the gather kernel converts), only the OUTPUT takes the policy's dtype
             if not x.is_cuda:
                 raise RuntimeError(f"{type(self).__name__}: the HIP path needs a CUDA/ROCm tensor (got {x.device}); there is no CPU fallback")
-            want = torch.get_autocast_gpu_dtype() if (torch.is_autocast_enabled() and x.dtype == torch.float32) else x.dtype
+            if x.dtype == torch.uint8:
+                # a uint8 image = pixel values to be scaled by 1/255, what the training loop does before the model (train.py:309
+                # `imgs.float() / 255`): the gather kernel does it while loading, so the fp32 copy of the batch never exists
+                want = torch.get_autocast_gpu_dtype() if torch.is_autocast_enabled() else torch.float32
+            else:
+                want = torch.get_autocast_gpu_dtype() if (torch.is_autocast_enabled() and x.dtype == torch.float32) else x.dtype
             odt = torch.float32 if want == torch.float32 else torch.bfloat16
             back = torch.float16 if want == torch.float16 else None
-            x = x.float()
-            ops.require_cuda(x, type(self).__name__, self)
+            if x.dtype != torch.uint8:
+                x = x.float()
+                ops.require_cuda(x, type(self).__name__, self)
         else:
             x, back = ops.edge_in(x, type(self).__name__, self)
             odt = x.dtype

@@ -11,7 +11,7 @@ import ctypes
 import torch
 
 from . import capi
-from .capi import (ACT_NONE, ACT_RELU, ACT_SILU, GATHER_PATCH, GATHER_PATCH_NCHW, GATHER_ROWS, GATHER_UP2,  # noqa: F401
+from .capi import (ACT_NONE, ACT_RELU, ACT_SILU, GATHER_PATCH, GATHER_PATCH_NCHW, GATHER_PATCH_NCHW_U8, GATHER_ROWS, GATHER_UP2,  # noqa: F401
                    PRO_AFFINE_RELU_CA, PRO_GATE, PRO_NONE)
 
 
@@ -169,8 +169,12 @@ def _p(t):
 def gemm(*, M, H, W, K, N, a0, lda0, k0, wp, out, ldo, a1=None, lda1=0, gather=GATHER_ROWS, Hin=0, Win=0, Cin=0, ks=0, pk=0,
          pro=PRO_NONE, g_h=None, g_w=None, res=None, ldres=0, p_scale=None, p_shift=None, p_ca=None, e_scale=None,
          e_shift=None, rowscale=None, act=ACT_NONE, stats=None, dtype=None):
-    # element type of the call: the output's (statistics passes: the source's); the NCHW image gather always READS fp32
-    dt = (out if out is not None else a0).dtype if gather != GATHER_PATCH_NCHW or out is not None else torch.float32
+    # element type of the call: the output's (statistics passes: the source's); the NCHW image gather always READS fp32 — or uint8
+    # (pixel / 255 on load: the training loop's `imgs.float() / 255` folded into the gather)
+    if gather == GATHER_PATCH_NCHW and a0.dtype == torch.uint8:
+        gather = GATHER_PATCH_NCHW_U8
+    image = gather in (GATHER_PATCH_NCHW, GATHER_PATCH_NCHW_U8)
+    dt = (out if out is not None else a0).dtype if not image or out is not None else torch.float32
     if dtype is not None:
         dt = dtype
     code = capi.dtype_code(dt)
@@ -178,11 +182,12 @@ def gemm(*, M, H, W, K, N, a0, lda0, k0, wp, out, ldo, a1=None, lda1=0, gather=G
                           _p(res), ldres, _p(p_scale), _p(p_shift), _p(p_ca), _p(wp), _p(e_scale), _p(e_shift), _p(rowscale),
                           act, _p(out), ldo, _p(stats), code)
     nt, mt, wc = gemm_config(N)
-    ti = "float" if (code == 0 or gather == GATHER_PATCH_NCHW) else "__bf16"
+    ti = "unsigned char" if gather == GATHER_PATCH_NCHW_U8 else "float" if (code == 0 or image) else "__bf16"
     to = "float" if code == 0 else "__bf16"
-    es_i, es_o = (4 if ti == "float" else 2), (4 if to == "float" else 2)
+    es_i, es_o = {"float": 4, "__bf16": 2, "unsigned char": 1}[ti], (4 if to == "float" else 2)
+    kgather = GATHER_PATCH_NCHW if image else gather        # the kernel template's gather code (the uint8 image differs by TI only)
     # the variant launch_gemm_v (csrc/ly_gemm.cuh) picks: resident weights for K in one / two chunks + the branch-free epilogue
-    nchunk = -(-K // (64 if ti == "float" else 128))
+    nchunk = -(-K // (128 if ti == "__bf16" else 64))
     nch = 0
     if N % 4 == 0 and ldo % 4 == 0 and out is not None:
         ok1 = wc == 4 or pro == 0
@@ -192,7 +197,7 @@ def gemm(*, M, H, W, K, N, a0, lda0, k0, wp, out, ldo, a1=None, lda1=0, gather=G
         nch = 1 if (nchunk == 1 and ok1) else 2 if (nchunk == 2 and ok2) else 0
     fast = N % 4 == 0 and ldo % 4 == 0 and out is not None
     ep = (2 if stats is not None else 1) if (nch or (fast and pro == 0)) else 0
-    with _Timed(f"ly_gemm_kernel_d2<{ti}, {to}, {nt}, {mt}, {wc}, {gather}, {pro}, {nch}, {ep}>", 2.0 * M * K * N, es_i * M * K + es_o * M * N + 4.0 * N * K):
+    with _Timed(f"ly_gemm_kernel_d2<{ti}, {to}, {nt}, {mt}, {wc}, {kgather}, {pro}, {nch}, {ep}>", 2.0 * M * K * N, es_i * M * K + es_o * M * N + 4.0 * N * K):
         capi.check(capi.lib().ly_gemm_fwd(ctypes.byref(P), capi.stream_ptr()), "ly_gemm_fwd")
 
 

@@ -73,8 +73,8 @@ class ModelEMA:
 
 def forward_backward(model, compute_loss, imgs, targets, world_size=1, amp=None):
     """uint8 / float batch -> train-mode forward -> loss -> backward; gradients land in `.grad` (train.py:295-324)"""
-    if imgs.dtype == torch.uint8:
-        imgs = imgs.float() / 255
+    if imgs.dtype == torch.uint8 and not getattr(model, "u8_input", False):
+        imgs = imgs.float() / 255           # (a model whose first layer is the HIP patch embedding takes the uint8 batch as it is)
     ops.stats_pool_begin(imgs.device)       # one zero fill for all BatchNorm accumulators of the step (ops._StatsPool)
     try:
         with torch.autocast("cuda", dtype=amp, enabled=amp is not None):

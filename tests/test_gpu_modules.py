@@ -464,3 +464,41 @@ def test_bf16x3_adversarial_bounds():
         mag3 = F.conv2d(x3.abs().double(), w3.abs().double()).float() * s3.abs().view(1, -1, 1, 1)
         got3 = bn.to(dev).eval()(x3.to(dev)).float().cpu()
     assert bool(((got3 - want3).abs() <= 2.0 ** -14 * mag3 + 1e-6 * want3.abs()).all()), float(((got3 - want3).abs() / mag3).max())
+
+
+def test_patchembed_uint8_image_matches_float_path():
+    """a uint8 batch given to the patch embedding (pixel / 255 folded into the gather, train.py:309) == the fp32 path on x / 255"""
+    import lead_yolo_amd as L
+    dev = _dev()
+    torch.manual_seed(3)
+    m = L.PatchEmbed_FasterNet(3, 24, 4, 4).to(dev).eval()
+    with torch.no_grad():
+        m.norm.running_mean.normal_(0, 0.1)
+        m.norm.running_var.uniform_(0.5, 1.5)
+    x8 = torch.randint(0, 256, (2, 3, 64, 96), dtype=torch.uint8, device=dev)
+    with torch.no_grad():
+        ref = m(x8.float() / 255)
+        got = m(x8)
+    assert got.dtype == torch.float32
+    torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-5)
+
+
+def test_train_step_uint8_equals_float_batch():
+    """forward_backward on the uint8 batch (no fp32 copy of the images) reproduces the gradients of the float / 255 batch"""
+    import lead_yolo_amd as L
+    from lead_yolo_amd.train import forward_backward
+    dev = _dev()
+    torch.manual_seed(0)
+    imgs = torch.randint(0, 256, (2, 3, 64, 64), dtype=torch.uint8, device=dev)
+    tg = torch.tensor([[0, 0, 0.5, 0.5, 0.3, 0.3], [1, 0, 0.4, 0.6, 0.2, 0.5]], device=dev)
+    grads = []
+    for as_u8 in (True, False):
+        torch.manual_seed(1)
+        model = L.Model(L.load_cfg(scale="n")).to(dev).train()
+        loss_fn = L.ComputeLoss(model)
+        assert model.u8_input
+        x = imgs if as_u8 else imgs.float() / 255
+        forward_backward(model, loss_fn, x, tg)
+        grads.append(model.model[0].proj.weight.grad.clone())
+    scale = grads[1].abs().max()
+    assert (grads[0] - grads[1]).abs().max() <= 2e-3 * scale

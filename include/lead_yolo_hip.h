@@ -196,6 +196,15 @@ int ly_coordatt_conv1_stats(const float* pool, long positions, int C, int mip, c
  * upper triangle) of the zero-padded stride-s 3x3 taps over all n_img*Ho*Wo output pixels; mean and
  * variance of every (channel, tap-output) follow as w.m and w^T M w on the host.                        */
 int ly_rfcbam_tap_moments(const void* x /*T*/, int ldx, int n_img, int H, int W, int C, int s, float* mom, int dtype, void* stream);
+/* Train-mode `generate` BatchNorm of RFCBAMConv (models/rfa.py:101-106) from those moments (k = 3: mom [54][C]; k = 1: ly_chan_moments'
+ * [2][C]) and generate.0.weight, ONE launch: batch statistics of every generate channel g = c*k*k + t, running statistics and
+ * num_batches_tracked updated as nn.BatchNorm2d does (NULL = not tracked);
+ *   out8 [8][C*k*k]: scale, shift, mean, invstd in [c*k*k + t] order, then the same four in [t*C + c] order (the backward kernels' order);
+ *   k = 3: wq_stats / wq_main = the folded weights (w*scale | shift) in the LDS orders of ly_rfcbam_stats / ly_rfcbam3_fwd
+ *          ([ceil(C/32)*32 | ceil(C/16)*16][9][10] floats each);  k = 1: a1[c] = w[c]*scale[c].                                  */
+int ly_rfcbam_gen_prepare(const float* mom, int C, int k, const float* gen_w, const float* gamma, const float* beta, float eps,
+                          float momentum, double count, float* running_mean, float* running_var, long* nbt, float* out8, float* a1,
+                          float* wq_stats, float* wq_main, void* stream);
 
 /* ---- backward building blocks of the training step (train.py:324 `scaler.scale(loss).backward()`) -------------
  * Data gradients of 1x1 / 3x3 stride-1 convolutions reuse ly_gemm_fwd / ly_conv3x3_fwd with transposed weights.   */

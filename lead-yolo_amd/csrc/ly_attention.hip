@@ -1065,3 +1065,104 @@ extern "C" int ly_coordatt_mlp_bwd(const float* pool, int n_img, int H, int W, i
   LY_LAUNCH_CHECK();
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// RFCBAMConv `generate` BatchNorm in training, everything between the moment kernel and the contraction in ONE launch
+// (models/rfa.py:101-106 generate = depthwise conv -> BatchNorm -> ReLU, training=True):
+//   from the tap moments of x (k = 3: ly_rfcbam_tap_moments, 9 first + 45 second moments per channel; k = 1: ly_chan_moments, sum x and
+//   sum x^2) and the depthwise weights, per generate channel g = c*KK + t:
+//     sum a = w_t . m,  sum a^2 = w_t^T M w_t   ->  batch mean / var  ->  scale = gamma*invstd, shift = beta - mean*scale,
+//     running_mean / running_var (momentum, unbiased) and num_batches_tracked updated as nn.BatchNorm2d does;
+//   outputs: scale, shift, mean, invstd in [c*KK + t] order, the same four in [t*C + c] order (what the backward kernels index),
+//   and — k = 3 — the folded weights (w*scale | shift) in the two LDS orders of the statistics / contraction kernels
+//   (pack.rfcbam_gen_weights: [C_pad/chunk][4 waves][9 t][chunk/8 pairs][10][2]); k = 1: a1 = w*scale.
+// Replaces ~40 tiny torch launches per module and step (einsum / index_put / cat / permute / BatchNorm arithmetic).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ long ly_gw_index(int ch, int t, int e, int chunk, bool contiguous) {
+  const int per = chunk >> 2;
+  const int q = ch / chunk, r = ch - q * chunk;
+  const int w = contiguous ? r / per : r & 3;
+  const int j = contiguous ? r - w * per : r >> 2;
+  const int p = j >> 1, ab = j & 1;
+  return (((((long)q * 4 + w) * 9 + t) * (per >> 1) + p) * 10 + e) * 2 + ab;
+}
+
+__global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_gen_prepare_kernel(
+    const float* __restrict__ mom, int C, int KK, const float* __restrict__ gen_w, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, float momentum, double count, float* __restrict__ running_mean,
+    float* __restrict__ running_var, long* __restrict__ nbt, float* __restrict__ out8 /* [8][C*KK] */, float* __restrict__ a1,
+    float* __restrict__ wq_stats, int cp_stats, float* __restrict__ wq_main, int cp_main) {
+  const int G = C * KK;
+  const int cpm = cp_stats > cp_main ? cp_stats : cp_main;
+  const int total = (KK == 9 ? (cpm > C ? cpm : C) : C) * KK;
+  for (int g = blockIdx.x * LY_THREADS + threadIdx.x; g < total; g += gridDim.x * LY_THREADS) {
+    const int c = g / KK, t = g - c * KK;
+    if (c >= C) {                                          // padded channels of the packed images: zero weights
+      for (int e = 0; e < 10; ++e) {
+        if (c < cp_stats) wq_stats[ly_gw_index(c, t, e, 32, false)] = 0.f;
+        if (c < cp_main) wq_main[ly_gw_index(c, t, e, 16, true)] = 0.f;
+      }
+      continue;
+    }
+    double s1 = 0.0, s2 = 0.0;
+    float w[9];
+    if (KK == 9) {
+#pragma unroll
+      for (int u = 0; u < 9; ++u) w[u] = gen_w[(long)g * 9 + u];
+#pragma unroll
+      for (int u = 0; u < 9; ++u) {
+        s1 += (double)w[u] * mom[u * C + c];
+#pragma unroll
+        for (int v = u; v < 9; ++v) {
+          const int tri = u * 9 - (u * (u - 1)) / 2 + (v - u);                 // torch.triu_indices(9, 9) order
+          const double m = mom[(9 + tri) * C + c];
+          s2 += (u == v ? 1.0 : 2.0) * (double)w[u] * (double)w[v] * m;
+        }
+      }
+    } else {
+      w[0] = gen_w[g];
+      s1 = (double)w[0] * mom[c];
+      s2 = (double)w[0] * (double)w[0] * mom[C + c];
+    }
+    const double mean = s1 / count;
+    double var = s2 / count - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[g] * invstd;
+    const float sh = beta[g] - (float)mean * sc;
+    if (running_mean) {
+      running_mean[g] = (1.f - momentum) * running_mean[g] + momentum * (float)mean;
+      running_var[g] = (1.f - momentum) * running_var[g] + momentum * (float)(var * (count / (count > 1.0 ? count - 1.0 : 1.0)));
+    }
+    const int gt = t * C + c;
+    out8[g] = sc;            out8[G + g] = sh;             out8[2 * G + g] = (float)mean;  out8[3 * G + g] = invstd;
+    out8[4 * G + gt] = sc;   out8[5 * G + gt] = sh;        out8[6 * G + gt] = (float)mean; out8[7 * G + gt] = invstd;
+    if (KK == 9) {
+#pragma unroll
+      for (int e = 0; e < 10; ++e) {
+        const float v = e < 9 ? w[e] * sc : sh;
+        wq_stats[ly_gw_index(c, t, e, 32, false)] = v;
+        wq_main[ly_gw_index(c, t, e, 16, true)] = v;
+      }
+    } else {
+      a1[g] = w[0] * sc;
+    }
+  }
+  if (nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
+}
+
+extern "C" int ly_rfcbam_gen_prepare(const float* mom, int C, int k, const float* gen_w, const float* gamma, const float* beta, float eps,
+                                     float momentum, double count, float* running_mean, float* running_var, long* nbt, float* out8,
+                                     float* a1, float* wq_stats, float* wq_main, void* stream) {
+  LY_CHECK(mom && gen_w && gamma && beta && out8 && C > 0 && (k == 1 || k == 3) && count > 0, "rfcbam_gen_prepare: bad arguments");
+  LY_CHECK(k == 1 ? a1 != nullptr : (wq_stats && wq_main), "rfcbam_gen_prepare: missing output for k=%d", k);
+  LY_CHECK(!running_mean == !running_var, "rfcbam_gen_prepare: running_mean and running_var go together");
+  const int KK = k * k;
+  const int cp_s = (C + 31) / 32 * 32, cp_m = (C + 15) / 16 * 16;
+  const int total = (k == 3 ? cp_s : C) * KK;
+  hipLaunchKernelGGL(ly_rfcbam_gen_prepare_kernel, dim3((unsigned)((total + LY_THREADS - 1) / LY_THREADS)), dim3(LY_THREADS), 0,
+                     reinterpret_cast<hipStream_t>(stream), mom, C, KK, gen_w, gamma, beta, eps, momentum, count, running_mean, running_var, nbt,
+                     out8, a1, wq_stats, k == 3 ? cp_s : 0, wq_main, k == 3 ? cp_m : 0);
+  LY_LAUNCH_CHECK();
+  return 0;
+}

@@ -579,11 +579,12 @@ class RfcbamFn(torch.autograd.Function):
         P = mod._packed(ops.planes_of(xr))
         ca = ca.detach().float().contiguous()
         bias = conv_b.detach().float().contiguous()
+        if gen_w.dtype != torch.float32:
+            raise NotImplementedError("RFCBAMConv training needs float32 parameters (train under autocast, fp32 master weights)")
+        G = ops.rfcbam_gen_prepare(xr, ld, n, h, w, c, k, s, gen_w, mod.generate[1])          # generate BatchNorm: moments + ONE launch
+        gs, gb, gmean, ginv = G["gs"], G["gb"], G["gmean"], G["ginv"]
         if k == 1:
-            gwv = gen_w.detach().float().view(c)
-            mom = ops.chan_moments(xr, ld, n * h * w, c)
-            gs, gb, gmean, ginv = ops.bn_batch_stats(mod.generate[1], gwv * mom[:c], gwv * gwv * mom[c:], n * h * w)
-            a1 = (gwv * gs).contiguous()
+            a1 = G["a1"]
             mm = ops.rfcbam_stats(xr, ld, n, h, w, c, 1, 1, a1=a1, b1=gb)
             rfa = ops.rfa_map(mm, P["w18"])
             kw = dict(M=n * h * w, H=h, W=w, K=c, N=o, a0=xr, lda0=ld, k0=c, wp=P["wp"], ldo=o, pro=ops.PRO_AFFINE_RELU_CA,
@@ -596,10 +597,7 @@ class RfcbamFn(torch.autograd.Function):
             ctx.fwd = dict(kw=kw)
         else:
             th, tw = ops.pick_tile(ho, wo)
-            s1, s2, cnt = ops.rfcbam_generate_stats(xr, ld, n, h, w, c, s, gen_w)
-            gs, gb, gmean, ginv = ops.bn_batch_stats(mod.generate[1], s1, s2, cnt)
-            wq_stats = pack.rfcbam_gen_weights(gen_w, gs, gb, 32, False)
-            wq_main = pack.rfcbam_gen_weights(gen_w, gs, gb, 16, True)
+            wq_stats, wq_main = G["wq_stats"], G["wq_main"]
             mm = ops.rfcbam_stats(xr, ld, n, h, w, c, 3, s, wg=wq_stats, th=th, tw=tw)
             rfa = ops.rfa_map(mm, P["w18"])
             kw = dict(n=n, h=h, w=w, c=c, ho=ho, wo=wo, N=o, s=s, th=th, tw=tw, x=xr, ldx=ld, wg=wq_main, ca=ca, rfa=rfa, wp=P["wp"], ldo=o)
@@ -611,12 +609,12 @@ class RfcbamFn(torch.autograd.Function):
             ctx.fwd = dict(kw=kw)
         ctx.geom = (n, c, h, w, k, s, o, ho, wo, ld)
         ctx.conv_w_param = conv_w
-        ctx.save_for_backward(xr, ca, gen_w, getw, conv_w, bias, gs, gb, gmean, ginv, es, t, omean, oinv, mm, rfa)
+        ctx.save_for_backward(xr, ca, gen_w, getw, conv_w, bias, G["ag"], G["bg"], G["gmean_tc"], G["ginv_tc"], es, t, omean, oinv, mm, rfa)
         return out
 
     @staticmethod
     def backward(ctx, dy):
-        xr, ca, gen_w, getw, conv_w, bias, gs, gb, gmean, ginv, es, t, omean, oinv, mm, rfa = ctx.saved_tensors
+        xr, ca, gen_w, getw, conv_w, bias, ag, bg, gmean_tc, ginv_tc, es, t, omean, oinv, mm, rfa = ctx.saved_tensors
         n, c, h, w, k, s, o, ho, wo, ld = ctx.geom
         kk = k * k
         mo = n * ho * wo
@@ -651,8 +649,6 @@ class RfcbamFn(torch.autograd.Function):
             with ops._Timed(f"ly_rf_generate_kernel<{ops._tname(xr)}, {k}>", 2.0 * mo * kk * kk * c, xr.element_size() * n * h * w * c + es9):
                 L.check(L.lib().ly_rf_generate(p(xr), ld, n, h, w, c, k, s, p(wg), p(ug), code, st), "ly_rf_generate")
             # 5. cd, d_rfa, gmax, d_ca
-            tc = lambda v: v.view(c, kk).t().contiguous().view(-1)                                     # [c*kk + t] -> [t*c + c]
-            ag, bg = tc(gs), tc(gb)
             cd = torch.empty((mo, kk * c), dtype=dt, device=dev)
             d_rfa = torch.zeros_like(rfa)
             gmax = torch.zeros_like(rfa)
@@ -678,7 +674,7 @@ class RfcbamFn(torch.autograd.Function):
                         "ly_rf_bwd_relu")
             _tap("rf.d_mm", d_mm); _tap("rf.dv", dcd); _tap("rf.sums", sums)
             # 9. generate BatchNorm coefficients ([t][c] order)
-            dgg_tc, dbg_tc, alpha, kappa, lam = ops.bn_bwd_coeffs(sums, kk * c, mo, ag, tc(gmean), tc(ginv), True)
+            dgg_tc, dbg_tc, alpha, kappa, lam = ops.bn_bwd_coeffs(sums, kk * c, mo, ag, gmean_tc, ginv_tc, True)
             ct = lambda v: v.view(kk, c).t().contiguous().view(-1)
             # 10. dug, generate weight gradient
             part_rows = 512

@@ -549,6 +549,40 @@ def rfcbam_generate_stats(x, ldx, n, h, w, c, s, gen_w):
     return s1.reshape(-1), s2.reshape(-1), n * ho * wo
 
 
+def rfcbam_gen_prepare(x, ldx, n, h, w, c, k, s, gen_w, bn):
+    """Train-mode `generate` BatchNorm of RFCBAMConv in two launches: the moment kernel over x, then ly_rfcbam_gen_prepare (batch
+    statistics, running-stat update, scale / shift in both index orders and the folded weights in the kernels' LDS orders).
+    Returns dict(gs, gb, gmean, ginv [c*kk + t order], ag, bg, gmean_tc, ginv_tc [t*c + c order], a1 (k=1), wq_stats, wq_main (k=3))."""
+    kk = k * k
+    dev = x.device
+    if k == 3:
+        mom = zeros_f32(54 * c, dev)
+        with _Timed(f"ly_rfcbam_tap_moments_kernel<{_tname(x)}>", 108.0 * n * h * w * c / (s * s), x.element_size() * n * h * w * c):
+            capi.check(capi.lib().ly_rfcbam_tap_moments(_p(x), ldx, n, h, w, c, s, _p(mom), capi.dtype_code(x), capi.stream_ptr()), "ly_rfcbam_tap_moments")
+        ho, wo = (h + 2 - 3) // s + 1, (w + 2 - 3) // s + 1
+        count = n * ho * wo
+    else:
+        mom = chan_moments(x, ldx, n * h * w, c)
+        count = n * h * w
+    g = c * kk
+    out8 = torch.empty(8, g, dtype=torch.float32, device=dev)
+    a1 = torch.empty(c, dtype=torch.float32, device=dev) if k == 1 else None
+    cps, cpm = (c + 31) // 32 * 32, (c + 15) // 16 * 16
+    wqs = torch.empty(cps * 90, dtype=torch.float32, device=dev) if k == 3 else None
+    wqm = torch.empty(cpm * 90, dtype=torch.float32, device=dev) if k == 3 else None
+    if bn.weight.dtype != torch.float32:
+        raise NotImplementedError("train-mode BatchNorm needs float32 parameters and buffers")
+    track = bn.track_running_stats and bn.running_mean is not None
+    capi.check(capi.lib().ly_rfcbam_gen_prepare(_p(mom), c, k, _p(gen_w.detach()), _p(bn.weight.detach()), _p(bn.bias.detach()), float(bn.eps),
+                                                float(bn.momentum or 0.0), float(count), _p(bn.running_mean if track else None),
+                                                _p(bn.running_var if track else None), _p(bn.num_batches_tracked if track else None), _p(out8),
+                                                _p(a1), _p(wqs), _p(wqm), capi.stream_ptr()), "ly_rfcbam_gen_prepare")
+    from . import pack
+    pack.touch()                                   # running statistics written behind torch's version counters
+    return dict(gs=out8[0], gb=out8[1], gmean=out8[2], ginv=out8[3], ag=out8[4], bg=out8[5], gmean_tc=out8[6], ginv_tc=out8[7], a1=a1,
+                wq_stats=wqs, wq_main=wqm)
+
+
 # ---- backward building blocks (training step) --------------------------------------------------------
 def bn_batch_stats(bn, s1, s2, count):
     """As bn_batch_affine, additionally returning the batch mean and 1/sqrt(var + eps) the backward needs."""

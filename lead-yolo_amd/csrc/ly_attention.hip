@@ -1166,3 +1166,72 @@ extern "C" int ly_rfcbam_gen_prepare(const float* mom, int C, int k, const float
   LY_LAUNCH_CHECK();
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// SE backward in training (models/rfa.py:88-92 under autograd), one block per image:
+//   gap = mean x (from the forward's slice partials);  h = relu(Wa gap);  ca = sigmoid(Wb h)  (ca given)
+//   dz = d_ca*ca*(1-ca);  dWb[c,r] += dz[c]*h[r];  dh = (Wb^T dz) * (h > 0);  dWa[r,c] += dh[r]*gap[c];  dgap[n,c] = Wa^T dh  (written)
+// dgap / HW is what every pixel of x receives from the pooling: ly_rf_bwd_dx adds it while it writes dx.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(LY_THREADS) void ly_se_bwd_kernel(const float* __restrict__ part, int slices, int C, float inv_hw,
+                                                                const float* __restrict__ wa, const float* __restrict__ wb, int R,
+                                                                const float* __restrict__ ca, const float* __restrict__ d_ca,
+                                                                float* __restrict__ dwa, float* __restrict__ dwb, float* __restrict__ dgap) {
+  extern __shared__ float sm[];
+  float* g = sm;                     // g[C] | dz[C] | hid[R] | dh[R] | red
+  float* dz = sm + C;
+  float* hid = sm + 2 * C;
+  float* dh = hid + R;
+  f32x4* red = reinterpret_cast<f32x4*>(sm + ((2 * C + 2 * R + 3) & ~3));
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nq = C >> 2, ng = LY_THREADS / nq;
+  const int q = tid % nq, sg = tid / nq;
+  f32x4 s4 = ly_zero4();
+  if (sg < ng)
+    for (int sl = sg; sl < slices; sl += ng) s4 += ly_ldg4(part + ((long)n * slices + sl) * C + 4 * q);
+  red[tid] = s4;
+  __syncthreads();
+  if (sg == 0) {
+    for (int k = 1; k < ng; ++k) s4 += red[tid + k * nq];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) g[4 * q + e] = s4[e] * inv_hw;
+  }
+  for (int c = tid; c < C; c += LY_THREADS) {
+    const float a = ca[(long)n * C + c];
+    dz[c] = d_ca[(long)n * C + c] * a * (1.f - a);
+  }
+  __syncthreads();
+  for (int r = wave; r < R; r += 4) {
+    float s = 0.f, d = 0.f;
+    for (int c = lane; c < C; c += 64) {
+      s += wa[r * C + c] * g[c];
+      d += wb[c * R + r] * dz[c];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); d += __shfl_xor(d, o); }
+    if (lane == 0) {
+      hid[r] = fmaxf(s, 0.f);
+      dh[r] = s > 0.f ? d : 0.f;
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += LY_THREADS) {
+    float dg = 0.f;
+    for (int r = 0; r < R; ++r) {
+      dg += dh[r] * wa[r * C + c];
+      atomicAdd(dwb + c * R + r, dz[c] * hid[r]);
+      atomicAdd(dwa + r * C + c, dh[r] * g[c]);
+    }
+    dgap[(long)n * C + c] = dg;
+  }
+}
+
+extern "C" int ly_se_bwd(const float* part, int slices, int n_img, int HW, int C, const float* wa, const float* wb, int R, const float* ca,
+                         const float* d_ca, float* dwa, float* dwb, float* dgap, void* stream) {
+  LY_CHECK(part && wa && wb && ca && d_ca && dwa && dwb && dgap, "se_bwd: null pointer");
+  LY_CHECK((C & 3) == 0 && C <= 1024 && slices > 0 && R > 0 && R <= 256 && n_img > 0 && HW > 0, "se_bwd: bad arguments");
+  hipLaunchKernelGGL(ly_se_bwd_kernel, dim3(n_img), dim3(LY_THREADS), sizeof(float) * (((2 * C + 2 * R + 3) & ~3) + 4 * LY_THREADS),
+                     reinterpret_cast<hipStream_t>(stream), part, slices, C, 1.f / (float)HW, wa, wb, R, ca, d_ca, dwa, dwb, dgap);
+  LY_LAUNCH_CHECK();
+  return 0;
+}

@@ -428,7 +428,7 @@ __device__ __forceinline__ float rf_dx_s2(const RfGeom& g, const T* __restrict__
 
 template <typename T, int K>
 __global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_dx_kernel(const RfGeom g, const T* __restrict__ dug, const float* __restrict__ wg,
-                                                                  T* __restrict__ dx, int lddx) {
+                                                                  T* __restrict__ dx, int lddx, const float* __restrict__ addnc, float add_scale) {
   constexpr int KK = K * K;
   RF_THREAD_SETUP
   const long Mi = (long)g.n_img * g.H * g.W;
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_dx_kernel(const RfGeom g
         else if (py == 0) acc = rf_dx_s2<T, 0, 1>(g, dug, w, n, hi, wi, c);
         else if (px == 0) acc = rf_dx_s2<T, 1, 0>(g, dug, w, n, hi, wi, c);
         else acc = rf_dx_s2<T, 1, 1>(g, dug, w, n, hi, wi, c);
-        if (cok) ly_st1<T>(dx + p * lddx + c, acc);
+        if (cok) ly_st1<T>(dx + p * lddx + c, addnc ? acc + addnc[(long)n * g.C + c] * add_scale : acc);
         continue;
       }
     }
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_dx_kernel(const RfGeom g
         for (int t = 0; t < KK; ++t) acc += ly_ld1<T>(dug + (m * KK + t) * g.C + c) * w[t * KK + (uy * K + ux)];
       }
     }
-    if (cok) ly_st1<T>(dx + p * lddx + c, acc);
+    if (cok) ly_st1<T>(dx + p * lddx + c, addnc ? acc + addnc[(long)n * g.C + c] * add_scale : acc);
   }
 }
 
@@ -553,14 +553,15 @@ extern "C" int ly_rf_bwd_gen(const void* x, int ldx, int n_img, int H, int W, in
   return 0;
 }
 
-extern "C" int ly_rf_bwd_dx(int n_img, int H, int W, int C, int k, int s, const void* dug, const float* wg, void* dx, int lddx, int dtype, void* stream) {
+extern "C" int ly_rf_bwd_dx(int n_img, int H, int W, int C, int k, int s, const void* dug, const float* wg, void* dx, int lddx, const float* addnc,
+                            float add_scale, int dtype, void* stream) {
   RF_ARGS_OK(k, C);
   LY_CHECK_DTYPE(dtype, "rf_bwd_dx");
   LY_CHECK(dug && wg && dx, "rf_bwd_dx: null pointer");
   int gx, gy;
   const RfGeom g = rf_geom(n_img, H, W, C, k, s, (long)n_img * H * W, gx, gy);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  RF_LAUNCH(ly_rf_bwd_dx_kernel, dim3(gx, gy), g, RF_CT(dug), wg, RF_T(dx), lddx);
+  RF_LAUNCH(ly_rf_bwd_dx_kernel, dim3(gx, gy), g, RF_CT(dug), wg, RF_T(dx), lddx, addnc, add_scale);
   LY_LAUNCH_CHECK();
   return 0;
 }

@@ -571,13 +571,16 @@ def _tap(name, t):
 
 class RfcbamFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, mod, x, ca, gen_w, gen_gamma, gen_beta, getw, conv_w, conv_b, out_gamma, out_beta):
+    def forward(ctx, mod, x, se_wa, se_wb, gen_w, gen_gamma, gen_beta, getw, conv_w, conv_b, out_gamma, out_beta):
         xr, ld = ops.rows(x)
         n, c, h, w = xr.shape
         k, s, o = mod.kernel_size, mod.stride, mod.o
         ho, wo = (h + 2 * (k // 2) - k) // s + 1, (w + 2 * (k // 2) - k) // s + 1
         P = mod._packed(ops.planes_of(xr))
-        ca = ca.detach().float().contiguous()
+        if se_wa.dtype != torch.float32:
+            raise NotImplementedError("RFCBAMConv training needs float32 parameters (train under autocast, fp32 master weights)")
+        # SE (models/rfa.py:88-92): pooling partials + the two linears, two launches; the partials are kept for the backward
+        ca, se_part = ops.se_attention(xr, ld, n, h * w, c, se_wa.detach(), se_wb.detach(), se_wa.shape[0], want_part=True)
         bias = conv_b.detach().float().contiguous()
         if gen_w.dtype != torch.float32:
             raise NotImplementedError("RFCBAMConv training needs float32 parameters (train under autocast, fp32 master weights)")
@@ -609,12 +612,14 @@ class RfcbamFn(torch.autograd.Function):
             ctx.fwd = dict(kw=kw)
         ctx.geom = (n, c, h, w, k, s, o, ho, wo, ld)
         ctx.conv_w_param = conv_w
-        ctx.save_for_backward(xr, ca, gen_w, getw, conv_w, bias, G["ag"], G["bg"], G["gmean_tc"], G["ginv_tc"], es, t, omean, oinv, mm, rfa)
+        ctx.se_params = (se_wa, se_wb)
+        ctx.conv_b_param = conv_b
+        ctx.save_for_backward(xr, ca, gen_w, getw, conv_w, bias, G["ag"], G["bg"], G["gmean_tc"], G["ginv_tc"], es, t, omean, oinv, mm, rfa, se_part)
         return out
 
     @staticmethod
     def backward(ctx, dy):
-        xr, ca, gen_w, getw, conv_w, bias, ag, bg, gmean_tc, ginv_tc, es, t, omean, oinv, mm, rfa = ctx.saved_tensors
+        xr, ca, gen_w, getw, conv_w, bias, ag, bg, gmean_tc, ginv_tc, es, t, omean, oinv, mm, rfa, se_part = ctx.saved_tensors
         n, c, h, w, k, s, o, ho, wo, ld = ctx.geom
         kk = k * k
         mo = n * ho * wo
@@ -650,25 +655,30 @@ class RfcbamFn(torch.autograd.Function):
                 L.check(L.lib().ly_rf_generate(p(xr), ld, n, h, w, c, k, s, p(wg), p(ug), code, st), "ly_rf_generate")
             # 5. cd, d_rfa, gmax, d_ca
             cd = torch.empty((mo, kk * c), dtype=dt, device=dev)
-            d_rfa = torch.zeros_like(rfa)
-            gmax = torch.zeros_like(rfa)
-            d_ca = torch.zeros_like(ca)
+            zz = ops.zeros_f32(2 * rfa.numel() + ca.numel(), dev)
+            d_rfa, gmax, d_ca = zz[:rfa.numel()].view_as(rfa), zz[rfa.numel():2 * rfa.numel()].view_as(rfa), zz[2 * rfa.numel():].view_as(ca)
             with ops._Timed(f"ly_rf_bwd_attn_kernel<{ops._tname(xr)}, {k}>", 8.0 * mo * kk * c, 3.0 * es9):
                 L.check(L.lib().ly_rf_bwd_attn(n, h, w, c, k, s, p(ug), p(dcd), p(ag), p(bg), p(ca), p(rfa), p(cd), p(d_rfa), p(gmax), p(d_ca), code, st),
                         "ly_rf_bwd_attn")
             _tap("rf.ug", ug); _tap("rf.cd", cd); _tap("rf.d_rfa", d_rfa); _tap("rf.gmax", gmax); _tap("rf.d_ca", d_ca)
             _tap("rf.rfa", rfa); _tap("rf.ca", ca); _tap("rf.ag", ag); _tap("rf.bg", bg)
             # 6. conv weight gradient
-            dwc = torch.zeros(o, kk * c, dtype=torch.float32, device=dev)
-            ops.wgrad(M=mo, H=ho, W=wo, N=o, du=du, lddu=o, x=cd, ldx=kk * c, Hin=ho, Win=wo, Cin=kk * c, dw=dwc, lddw=kk * c)
-            dwc = dwc.view(o, kk, c).permute(0, 2, 1).reshape(conv_w.shape)
+            tgt = ops.grad_target(ctx.conv_w_param)            # k = 1: the weight's own layout is what ly_wgrad writes
+            if tgt is not None and kk == 1:
+                ops.wgrad(M=mo, H=ho, W=wo, N=o, du=du, lddu=o, x=cd, ldx=c, Hin=ho, Win=wo, Cin=c, dw=tgt, lddw=c)
+                ops.grad_done(ctx.conv_w_param)
+                dwc = None
+            else:
+                dwc = torch.zeros(o, kk * c, dtype=torch.float32, device=dev)
+                ops.wgrad(M=mo, H=ho, W=wo, N=o, du=du, lddu=o, x=cd, ldx=kk * c, Hin=ho, Win=wo, Cin=kk * c, dw=dwc, lddw=kk * c)
+                dwc = dwc.view(o, kk, c).permute(0, 2, 1).reshape(conv_w.shape)
             # 7. get_weight + sigmoid
             w18 = getw.detach().float().reshape(18).contiguous()
             d_mm = torch.empty_like(mm)
-            dw18 = torch.zeros(18, dtype=torch.float32, device=dev)
+            dw18 = torch.zeros(18, dtype=torch.float32, device=dev)           # (a parameter gradient handed to autograd: not from the pool)
             L.check(L.lib().ly_rfa_bwd(p(d_rfa), p(rfa), p(mm), p(w18), n, k * ho, k * wo, p(d_mm), p(dw18), st), "ly_rfa_bwd")
             # 8. through max/mean, ca, rfa and ReLU; generate-BN sums
-            sums = torch.zeros(2 * kk * c, dtype=torch.float32, device=dev)
+            sums = ops.zeros_f32(2 * kk * c, dev)
             with ops._Timed(f"ly_rf_bwd_relu_kernel<{ops._tname(xr)}, {k}>", 8.0 * mo * kk * c, 3.0 * es9):
                 L.check(L.lib().ly_rf_bwd_relu(n, h, w, c, k, s, p(ug), p(dcd), p(ag), p(bg), p(ca), p(rfa), p(gmax), p(d_mm), p(sums), code, st),
                         "ly_rf_bwd_relu")
@@ -683,20 +693,28 @@ class RfcbamFn(torch.autograd.Function):
                 L.check(L.lib().ly_rf_bwd_gen(p(xr), ld, n, h, w, c, k, s, p(ug), p(dcd), p(alpha), p(kappa), p(lam), p(dwg), part_rows, code, st),
                         "ly_rf_bwd_gen")
             # 11. dx
+            # SE backward: parameter gradients, and d/d(mean x) which the dx kernel spreads over the pixels while it writes dx
+            se_wa, se_wb = ctx.se_params
+            ta, tb = ops.grad_target(se_wa), ops.grad_target(se_wb)
+            se_direct = ta is not None and tb is not None
+            dwa = ta if se_direct else torch.zeros(se_wa.shape, dtype=torch.float32, device=dev)
+            dwb = tb if se_direct else torch.zeros(se_wb.shape, dtype=torch.float32, device=dev)
+            dgap = ops.se_bwd(se_part, n, h * w, c, se_wa.detach(), se_wb.detach(), se_wa.shape[0], ca, d_ca, dwa, dwb)
+            if se_direct:
+                ops.grad_done(se_wa)
+                ops.grad_done(se_wb)
             dx = None
             if ctx.needs_input_grad[1]:
                 dx = ops.empty_nhwc(n, c, h, w, xr)
                 with ops._Timed(f"ly_rf_bwd_dx_kernel<{ops._tname(xr)}, {k}>", 2.0 * mo * kk * kk * c, es9 + xr.element_size() * n * h * w * c):
-                    L.check(L.lib().ly_rf_bwd_dx(n, h, w, c, k, s, p(dcd), p(wg), p(dx), c, code, st), "ly_rf_bwd_dx")
-        return (None, dx, d_ca, dwg.sum(0).view(gen_w.shape), ct(dgg_tc), ct(dbg_tc), dw18.view(getw.shape), dwc, torch.zeros_like(bias), dgo, dbo)
+                    L.check(L.lib().ly_rf_bwd_dx(n, h, w, c, k, s, p(dcd), p(wg), p(dx), c, p(dgap), 1.0 / (h * w), code, st), "ly_rf_bwd_dx")
+            dbias = None if ops.grad_target(ctx.conv_b_param) is not None else torch.zeros_like(bias)      # BN removes the batch mean: d/dbias = 0
+        return (None, dx, None if se_direct else dwa, None if se_direct else dwb, dwg.sum(0).view(gen_w.shape), ct(dgg_tc), ct(dbg_tc),
+                dw18.view(getw.shape), dwc, dbias, dgo, dbo)
 
 
 def rfcbam_train(mod, x):
-    """RFCBAMConv.forward in training: SE on pooled vectors (torch, autograd) + RfcbamFn."""
-    import torch.nn.functional as F
-    n, c, h, w = x.shape
-    gap = PoolHW.apply(x)[:, :h].mean(1)                                     # [n, c]: mean over h of the row means
-    ca = torch.sigmoid(F.linear(F.relu(F.linear(gap, mod.se.fc[0].weight)), mod.se.fc[2].weight))
+    """RFCBAMConv.forward in training: one autograd node (SE, generate BatchNorm, attention maps, contraction)."""
     g, cv = mod.generate, mod.conv
-    return RfcbamFn.apply(mod, x, ca, g[0].weight, g[1].weight, g[1].bias, mod.get_weight[0].weight, cv[0].weight, cv[0].bias,
+    return RfcbamFn.apply(mod, x, mod.se.fc[0].weight, mod.se.fc[2].weight, g[0].weight, g[1].weight, g[1].bias, mod.get_weight[0].weight, cv[0].weight, cv[0].bias,
                           cv[1].weight, cv[1].bias)

@@ -251,14 +251,22 @@ def coordatt_gate(x, ldx, n, h, w, c, a_h, a_w, res=None, ldres=0):
     return out
 
 
-def se_attention(x, ldx, n, hw, c, wa, wb, r):
+def se_attention(x, ldx, n, hw, c, wa, wb, r, want_part=False):
     slices = se_slices(hw)                       # short per-block row loops: the pass is latency-bound, not bandwidth-bound
     part = torch.empty((n, slices, c), dtype=torch.float32, device=x.device)
     ca = torch.empty((n, c), dtype=torch.float32, device=x.device)
     with _Timed(f"ly_colsum_kernel<{_tname(x)}> + ly_se_mlp_kernel", 1.0 * n * hw * c, x.element_size() * n * hw * c):
         capi.check(capi.lib().ly_se_fwd(_p(x), ldx, n, hw, c, _p(wa), _p(wb), r, _p(part), slices, _p(ca), capi.dtype_code(x), capi.stream_ptr()),
                    "ly_se_fwd")
-    return ca
+    return (ca, part) if want_part else ca
+
+
+def se_bwd(part, n, hw, c, wa, wb, r, ca, d_ca, dwa, dwb):
+    """SE backward (one launch): dwa [r, c] / dwb [c, r] are ADDED to; returns dgap [n, c] = d/d(mean x)"""
+    dgap = torch.empty((n, c), dtype=torch.float32, device=part.device)
+    capi.check(capi.lib().ly_se_bwd(_p(part), part.shape[1], n, hw, c, _p(wa), _p(wb), r, _p(ca), _p(d_ca), _p(dwa), _p(dwb), _p(dgap),
+                                    capi.stream_ptr()), "ly_se_bwd")
+    return dgap
 
 
 def se_slices(hw):

@@ -426,7 +426,7 @@ __device__ __forceinline__ float rf_dx_s2(const RfGeom& g, const T* __restrict__
   return acc;
 }
 
-template <typename T, int K>
+template <typename T, int K, bool ADD>
 __global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_dx_kernel(const RfGeom g, const T* __restrict__ dug, const float* __restrict__ wg,
                                                                   T* __restrict__ dx, int lddx, const float* __restrict__ addnc, float add_scale) {
   constexpr int KK = K * K;
@@ -441,6 +441,9 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_dx_kernel(const RfGeom g
     const int wi = (int)(p - row * g.W);
     const int n = (int)(row / g.H);
     const int hi = (int)(row - (long)n * g.H);
+    // the per-(image, channel) addend is requested first, unconditionally (a load under a run-time `if` costs every later wait its count)
+    float addv = 0.f;
+    if constexpr (ADD) addv = addnc[(long)n * g.C + (cok ? c : 0)] * add_scale;
     float acc = 0.f;
     if constexpr (K == 3) {
       if (g.s == 2) {
@@ -449,7 +452,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_dx_kernel(const RfGeom g
         else if (py == 0) acc = rf_dx_s2<T, 0, 1>(g, dug, w, n, hi, wi, c);
         else if (px == 0) acc = rf_dx_s2<T, 1, 0>(g, dug, w, n, hi, wi, c);
         else acc = rf_dx_s2<T, 1, 1>(g, dug, w, n, hi, wi, c);
-        if (cok) ly_st1<T>(dx + p * lddx + c, addnc ? acc + addnc[(long)n * g.C + c] * add_scale : acc);
+        if (cok) ly_st1<T>(dx + p * lddx + c, acc + addv);
         continue;
       }
     }
@@ -470,7 +473,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_dx_kernel(const RfGeom g
         for (int t = 0; t < KK; ++t) acc += ly_ld1<T>(dug + (m * KK + t) * g.C + c) * w[t * KK + (uy * K + ux)];
       }
     }
-    if (cok) ly_st1<T>(dx + p * lddx + c, addnc ? acc + addnc[(long)n * g.C + c] * add_scale : acc);
+    if (cok) ly_st1<T>(dx + p * lddx + c, acc + addv);
   }
 }
 
@@ -561,7 +564,12 @@ extern "C" int ly_rf_bwd_dx(int n_img, int H, int W, int C, int k, int s, const 
   int gx, gy;
   const RfGeom g = rf_geom(n_img, H, W, C, k, s, (long)n_img * H * W, gx, gy);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  RF_LAUNCH(ly_rf_bwd_dx_kernel, dim3(gx, gy), g, RF_CT(dug), wg, RF_T(dx), lddx, addnc, add_scale);
+  LY_WITH_T(dtype, {
+    if (k == 3 && addnc) hipLaunchKernelGGL((ly_rf_bwd_dx_kernel<T, 3, true>), dim3(gx, gy), dim3(LY_THREADS), 0, st, g, RF_CT(dug), wg, RF_T(dx), lddx, addnc, add_scale);
+    else if (k == 3) hipLaunchKernelGGL((ly_rf_bwd_dx_kernel<T, 3, false>), dim3(gx, gy), dim3(LY_THREADS), 0, st, g, RF_CT(dug), wg, RF_T(dx), lddx, addnc, add_scale);
+    else if (addnc) hipLaunchKernelGGL((ly_rf_bwd_dx_kernel<T, 1, true>), dim3(gx, gy), dim3(LY_THREADS), 0, st, g, RF_CT(dug), wg, RF_T(dx), lddx, addnc, add_scale);
+    else hipLaunchKernelGGL((ly_rf_bwd_dx_kernel<T, 1, false>), dim3(gx, gy), dim3(LY_THREADS), 0, st, g, RF_CT(dug), wg, RF_T(dx), lddx, addnc, add_scale);
+  });
   LY_LAUNCH_CHECK();
   return 0;
 }

@@ -369,11 +369,11 @@ __device__ __forceinline__ void ly_mlpblock_body(
 //     after it, so the HBM latency of a patch hides behind the arithmetic of the previous one.
 // The arithmetic per pixel is the block above verbatim (same operand order: results are bit-identical).
 // -------------------------------------------------------------------------------------------------
-template <typename T, int C, int NT, int HT>
+template <typename T, int C, int NT, int HT, bool STATS>
 __device__ __forceinline__ void ly_mlpblock_persist_body(
     const T* __restrict__ x, T* __restrict__ y, long M, int H, int W, int n_img,
     const uint4* __restrict__ wp, const uint4* __restrict__ w1, const uint4* __restrict__ w2,
-    const float* __restrict__ bn_scale, const float* __restrict__ bn_shift) {
+    const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, float* __restrict__ stats) {
   using Gm = MlpGeom<C>;
   using TR = LyT<T>;
   using RV = typename TR::RV;
@@ -382,14 +382,13 @@ __device__ __forceinline__ void ly_mlpblock_persist_body(
   constexpr int CQ = Gm::CQ, G = Gm::G, SP = Gm::SP, PT = Gm::PT, C16 = Gm::C16, KP = Gm::KP, S1 = Gm::S1;
   constexpr int RS = Gm::RS, RSP = Gm::RSP, HTP = Gm::HTP, S2 = Gm::S2;
   constexpr int BP = 64 * NT, TH = 4 * NT, BPH = (TH + 2) * 18;
-  constexpr bool T2D = true, STATS = false;
+  constexpr bool T2D = true;
   constexpr int NFP = PT * SP, NF1 = HTP * S1, NF2 = C16 * S2, NFW = NFP + NF1 + NF2;
   constexpr int WBYTES = NFW * PL * 1024, XB = PL * BP * RS, PB = PL * BPH * RSP, BUFB = (XB + PB + 15) / 16 * 16;
   static_assert(HTP % HT == 0 && HT % 2 == 0 && C % VW == 0, "geometry");
   extern __shared__ f32x4 ly_smem4[];
   char* const wl = reinterpret_cast<char*>(ly_smem4);
   char* const bufs = wl + WBYTES;
-  float* const stats = nullptr;
   const long p0 = 0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lq = lane >> 4;
@@ -476,6 +475,12 @@ __device__ __forceinline__ void ly_mlpblock_persist_body(
     }
   };
 
+  // statistics pass: the sums of a block's patches stay in registers until the walk ends (one flush per block)
+  f32x4 st1[STATS ? HTP : 1], st2[STATS ? HTP : 1];
+  if constexpr (STATS) {
+#pragma unroll
+    for (int t = 0; t < HTP; ++t) { st1[t] = zero; st2[t] = zero; }
+  }
   int tile = blockIdx.x;
   if (tile >= ntiles) return;
   issue(tile);
@@ -617,20 +622,16 @@ __device__ __forceinline__ void ly_mlpblock_persist_body(
           wrefill();
         }
       }
-      if (STATS) {
-        // statistics pass of train-mode BatchNorm: sum / sum of squares of the pre-BN hidden activations
-        // over the valid pixels of this block; nothing else is computed or stored
+      if constexpr (STATS) {
+        // statistics pass of train-mode BatchNorm: sum / sum of squares of the pre-BN hidden activations over the valid pixels
   #pragma unroll
-        for (int t = 0; t < HT; ++t) {
-          f32x4 s1 = zero, s2 = zero;
+        for (int t = 0; t < HT; ++t)
   #pragma unroll
           for (int n = 0; n < NT; ++n)
             if (gpix(pixbase + 16 * n + li) >= 0) {
-              s1 += acch[t][n];
-              s2 += acch[t][n] * acch[t][n];
+              st1[hc * HT + t] += acch[t][n];
+              st2[hc * HT + t] += acch[t][n] * acch[t][n];
             }
-          ly_stats_flush(stats, HTP * 16, (hc * HT + t) * 16 + 4 * lq, s1, s2);
-        }
         continue;
       }
       bf16x4 hh[HT][NT], hl[HT][NT];
@@ -665,7 +666,7 @@ __device__ __forceinline__ void ly_mlpblock_persist_body(
       }
     }
 
-    if (STATS) return;
+    if constexpr (!STATS) {
     // ---- epilogue: residual + store ------------------------------------------------------------
     // The residual x is rebuilt from the bf16 hi/lo planes already in LDS (|err| <= 2^-17 |x|) instead
     // of re-reading global memory: channels < CQP from the halo image's centre tap (the tile's own
@@ -693,18 +694,23 @@ __device__ __forceinline__ void ly_mlpblock_persist_body(
           ly_st4<T>(y + gp * C + c, acco[ct][n] + r);
         }
       }
+    }
     commit(buf ^ 1);
     __syncthreads();
     buf ^= 1;
   }
+  if constexpr (STATS) {
+#pragma unroll
+    for (int t = 0; t < HTP; ++t) ly_stats_flush(stats, HTP * 16, t * 16 + 4 * lq, st1[t], st2[t]);
+  }
 }
 
-template <typename T, int C, int NT, int HT>
+template <typename T, int C, int NT, int HT, bool STATS>
 __global__ __launch_bounds__(LY_THREADS) void ly_mlpblock_persist_kernel(
     const T* __restrict__ x, T* __restrict__ y, long M, int H, int W, int n_img,
     const uint4* __restrict__ wp, const uint4* __restrict__ w1, const uint4* __restrict__ w2,
-    const float* __restrict__ bn_scale, const float* __restrict__ bn_shift) {
-  ly_mlpblock_persist_body<T, C, NT, HT>(x, y, M, H, W, n_img, wp, w1, w2, bn_scale, bn_shift);
+    const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, float* __restrict__ stats) {
+  ly_mlpblock_persist_body<T, C, NT, HT, STATS>(x, y, M, H, W, n_img, wp, w1, w2, bn_scale, bn_shift, stats);
 }
 
 template <typename T, int C, int NT, int HT, bool T2D, bool STATS>
@@ -766,15 +772,15 @@ static int launch_mlp_k(const T* x, T* y, long M, int n_img, int H, int W, const
   return 0;
 }
 
-template <typename T, int C, int NT, int HT>
+template <typename T, int C, int NT, int HT, bool STATS>
 static int launch_mlp_persist(const T* x, T* y, long M, int n_img, int H, int W, const void* wp, const void* w1, const void* w2,
-                              const float* s, const float* b, hipStream_t st) {
+                              const float* s, const float* b, float* stats, hipStream_t st) {
   using Gm = MlpGeom<C>;
   constexpr int PL = LyT<T>::PL, BP = 64 * NT, BPH = (4 * NT + 2) * 18;
   constexpr int NFW = Gm::PT * Gm::SP + Gm::HTP * Gm::S1 + Gm::C16 * Gm::S2;
   constexpr size_t lds = (size_t)NFW * PL * 1024 + 2 * (((size_t)PL * BP * Gm::RS + (size_t)PL * BPH * Gm::RSP + 15) / 16 * 16);
   static_assert(lds <= 160 * 1024, "persistent MLPBlock: weights + two patch buffers must fit LDS");
-  auto k = ly_mlpblock_persist_kernel<T, C, NT, HT>;
+  auto k = ly_mlpblock_persist_kernel<T, C, NT, HT, STATS>;
   static int per_cu = 0;
   if (per_cu == 0) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
@@ -788,7 +794,7 @@ static int launch_mlp_persist(const T* x, T* y, long M, int n_img, int H, int W,
   long blocks = 256L * per_cu;
   if (blocks > ntiles) blocks = ntiles;
   hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(LY_THREADS), lds, st, x, y, M, H, W, n_img, reinterpret_cast<const uint4*>(wp),
-                     reinterpret_cast<const uint4*>(w1), reinterpret_cast<const uint4*>(w2), s, b);
+                     reinterpret_cast<const uint4*>(w1), reinterpret_cast<const uint4*>(w2), s, b, stats);
   LY_LAUNCH_CHECK();
   return 0;
 }
@@ -819,8 +825,9 @@ static int dispatch_nt_t(const T* x, T* y, long M, int n_img, int H, int W, cons
   if constexpr (C < 80) {
     // persistent patch walk with the weights in LDS: enough patches for every resident block to amortise the weight copy
     // (fp32 storage at C = 40 needs 148 KB of LDS and 242 registers: one block per CU, measured 63 -> 79 us — it keeps the one-shot kernel)
-    if ((W & 15) == 0 && W >= 32 && !stats && (long)n_img * ((H + 7) / 8) * (W / 16) >= 1024 && (LyT<T>::BF || C < 40))
-      return launch_mlp_persist<T, C, 2, HT>(x, y, M, n_img, H, W, wp, w1, w2, s, b, st);
+    if ((W & 15) == 0 && W >= 32 && (long)n_img * ((H + 7) / 8) * (W / 16) >= 1024 && (LyT<T>::BF || C < 40))
+      return stats ? launch_mlp_persist<T, C, 2, HT, true>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st)
+                   : launch_mlp_persist<T, C, 2, HT, false>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
   }
   if ((W & 15) == 0 && W >= 64 && NTMAX >= 2) return launch_mlp<T, C, 2, HT, true>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
   if (NTMAX >= 4 && M >= 256L * 1024) return launch_mlp<T, C, NT4, HT, false>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);

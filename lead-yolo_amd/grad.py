@@ -576,7 +576,7 @@ class RfcbamFn(torch.autograd.Function):
         n, c, h, w = xr.shape
         k, s, o = mod.kernel_size, mod.stride, mod.o
         ho, wo = (h + 2 * (k // 2) - k) // s + 1, (w + 2 * (k // 2) - k) // s + 1
-        P = mod._packed(ops.planes_of(xr))
+        P = mod._packed_train(ops.planes_of(xr))
         if se_wa.dtype != torch.float32:
             raise NotImplementedError("RFCBAMConv training needs float32 parameters (train under autocast, fp32 master weights)")
         # SE (models/rfa.py:88-92): pooling partials + the two linears, two launches; the partials are kept for the backward

@@ -564,6 +564,24 @@ class RFCBAMConv(nn.Module):
             return dict(wq_stats=wq_stats, wq_main=wq_main, w18=w18, wp=pack.packed(wsrc, (c // 16) * 160, planes), es=es, eb=eb)
         return self._prep.get(key, build, planes)
 
+    def _packed_train(self, planes=2):
+        """what the training node (grad.RfcbamFn) needs of `_packed`: the conv weight image and get_weight's taps.  Keyed on those two
+        parameters only — `_packed` also folds the BatchNorm RUNNING statistics, which change every training step, and rebuilding its
+        folded generate weights there cost ~25 tiny launches per module and step for images the training path never reads."""
+        cw = self.conv[0]
+        key = pack.versions(cw.weight, self.get_weight[0].weight)
+
+        def build():
+            k, c, o = self.kernel_size, self.c, self.o
+            w18 = self.get_weight[0].weight.detach().float().reshape(18).contiguous()
+            if k == 1:
+                return dict(w18=w18, wp=pack.packed(pack.src_matrix(cw.weight, o, c), c, planes))
+            wsrc = pack.Src(cw.weight, o, srb=c * 9, nb=10, vb=9, nc=16, sa=144, sb=1, sc=9)
+            return dict(w18=w18, wp=pack.packed(wsrc, (c // 16) * 160, planes))
+        if not hasattr(self, "_prep_train"):
+            self._prep_train = _Prepared()
+        return self._prep_train.get(key, build, planes)
+
     @_edge
     def forward(self, x):
         if isinstance(x, Lazy):

@@ -255,6 +255,9 @@ int ly_unpatch(const void* g /*T*/, int n_img, int Ho, int Wo, int C, int ks, vo
 int ly_coordatt_gate_bwd(const void* dout /*T*/, int ldd, const void* x /*T*/, int ldx, int n_img, int H, int W, int C, const float* a_h,
                          const float* a_w, void* dx /*T*/, int lddx, float* da_h, float* da_w, int dtype, void* stream);
 int ly_pool_hw_bwd(const float* gp, int n_img, int H, int W, int C, void* dx /*T*/, int lddx, int accumulate, int dtype, void* stream);
+/* MLPBlock backward, last step (models/common.py:1478-1482 under autograd): dx[r, c] = dy[r, c] + (c < c4 ? t[r, c] : g[r, c]) over dense
+ * [rows, C] matrices (t: row stride ldt >= ceil4(c4)) — the residual + the 1x1's gradient, with the partial 3x3 conv's gradient in its channels. */
+int ly_mlp_dx(const void* dy /*T*/, const void* g /*T*/, const void* t /*T*/, int ldt, long rows, int C, int c4, void* dx /*T*/, int dtype, void* stream);
 /* k x k / stride 1 / pad k//2 max-pool backward (SPPF, models/common.py:348-366): dx[argmax of window] += dy
  * (first maximum in row-major order, as ATen); dx is ACCUMULATED into, which lets the three chained pools add
  * into the gradient slots of the SPPF concat buffer in place.  x is T; dy and dx are ALWAYS fp32 (atomic accumulation).   */

@@ -1087,3 +1087,37 @@ extern "C" int ly_pack_table(const LyPackDesc* table, const int* blk_desc, int n
   LY_LAUNCH_CHECK();
   return 0;
 }
+
+// -------------------------------------------------------------------------------------------------
+// MLPBlock backward, last step: dx = dy + g, except the first c4 channels (the partial 3x3 conv's) which take dy + t
+// (t [rows, ldt]: the data gradient of the partial conv).  One pass instead of two adds and a strided copy.
+// -------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(LY_THREADS) void ly_mlp_dx_kernel(const T* __restrict__ dy, const T* __restrict__ g, const T* __restrict__ t, int ldt,
+                                                                long rows, int C, int c4, T* __restrict__ dx) {
+  const int nq = C >> 2;
+  const long total = rows * nq;
+  for (long i = (long)blockIdx.x * LY_THREADS + threadIdx.x; i < total; i += (long)gridDim.x * LY_THREADS) {
+    const long r = i / nq;
+    const int c = 4 * (int)(i - r * nq);
+    const f32x4 a = ly_ld4<T>(dy + r * C + c);
+    f32x4 b = ly_ld4<T>(g + r * C + c);
+    if (c < c4) {                                           // (c4 need not be a multiple of 4: per-channel select in the boundary quad)
+      const f32x4 tv = ly_ld4<T>(t + r * ldt + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (c + e < c4) b[e] = tv[e];
+    }
+    ly_st4<T>(dx + r * C + c, a + b);
+  }
+}
+
+extern "C" int ly_mlp_dx(const void* dy, const void* g, const void* t, int ldt, long rows, int C, int c4, void* dx, int dtype, void* stream) {
+  LY_CHECK_DTYPE(dtype, "mlp_dx");
+  LY_CHECK(dy && g && t && dx && rows > 0 && (C & 3) == 0 && (ldt & 3) == 0 && c4 > 0 && c4 <= C && ((c4 + 3) & ~3) <= ldt, "mlp_dx: bad arguments");
+  LY_WITH_T(dtype, hipLaunchKernelGGL(ly_mlp_dx_kernel<T>, dim3((unsigned)ly_ew_blocks(rows * (C >> 2))), dim3(LY_THREADS), 0, reinterpret_cast<hipStream_t>(stream),
+                                      reinterpret_cast<const T*>(dy), reinterpret_cast<const T*>(g), reinterpret_cast<const T*>(t), ldt, rows, C, c4,
+                                      reinterpret_cast<T*>(dx)));
+  LY_LAUNCH_CHECK();
+  return 0;
+}

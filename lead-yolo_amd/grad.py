@@ -410,8 +410,9 @@ class MlpBlockFn(torch.autograd.Function):
             t = ops.empty_nhwc(n, c4p, h, w, x)
             wt = pack.packed(pack.src_taps(p_wpc, c4q, transposed_flipped=True), 9 * c4q, pl)
             ops.conv3x3(M=m, H=h, W=w, Cin=c4p, N=c4, x=g, ldx=c, wp=wt, out=t, ldo=c4p)
-            dx = dy + g
-            dx[:, :c4] = dy[:, :c4] + t[:, :c4]
+            dx = torch.empty_like(dy)                      # dy + g, the partial conv's channels dy + t: one pass (ly_mlp_dx)
+            _lib().check(_lib().lib().ly_mlp_dx(_lib().ptr(dy), _lib().ptr(g), _lib().ptr(t), c4p, m, c, c4, _lib().ptr(dx), _lib().dtype_code(dy),
+                                                _lib().stream_ptr()), "ly_mlp_dx")
             for prm, direct in ((p_wpc, dp), (p_w1, d1), (p_w2, d2)):
                 if direct:
                     ops.grad_done(prm)

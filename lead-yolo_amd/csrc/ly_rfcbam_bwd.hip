@@ -426,8 +426,9 @@ __device__ __forceinline__ float rf_dx_s2(const RfGeom& g, const T* __restrict__
   return acc;
 }
 
-template <typename T, int K, bool ADD>
-__global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_dx_kernel(const RfGeom g, const T* __restrict__ dug, const float* __restrict__ wg,
+// (three waves per SIMD: the k = 3 body sits at 168 registers without the addend and two more would cost a third of the occupancy)
+template <typename T, int K, int ADD>
+__global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(3))) void ly_rf_bwd_dx_kernel(const RfGeom g, const T* __restrict__ dug, const float* __restrict__ wg,
                                                                   T* __restrict__ dx, int lddx, const float* __restrict__ addnc, float add_scale) {
   constexpr int KK = K * K;
   RF_THREAD_SETUP
@@ -436,6 +437,13 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_dx_kernel(const RfGeom g
   float w[KK * KK];
 #pragma unroll
   for (int i = 0; i < KK * KK; ++i) w[i] = wg[(long)c * KK * KK + i];
+  // ADD == 2: the block's pixel chunk touches at most two images (host-checked): their addends are loaded once, before the loop
+  const int n_first = (int)(m_begin / ((long)g.H * g.W));
+  float add0 = 0.f, add1 = 0.f;
+  if constexpr (ADD == 2) {
+    add0 = addnc[(long)n_first * g.C + c] * add_scale;
+    add1 = addnc[(long)(n_first + 1 < g.n_img ? n_first + 1 : n_first) * g.C + c] * add_scale;
+  }
   for (long p = m_begin + sub; p < m_end; p += g.subs) {        // (lanes beyond C run along: the pair shuffles need both lanes)
     const long row = p / g.W;
     const int wi = (int)(p - row * g.W);
@@ -443,7 +451,8 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_dx_kernel(const RfGeom g
     const int hi = (int)(row - (long)n * g.H);
     // the per-(image, channel) addend is requested first, unconditionally (a load under a run-time `if` costs every later wait its count)
     float addv = 0.f;
-    if constexpr (ADD) addv = addnc[(long)n * g.C + (cok ? c : 0)] * add_scale;
+    if constexpr (ADD == 1) addv = addnc[(long)n * g.C + c] * add_scale;
+    if constexpr (ADD == 2) addv = n == n_first ? add0 : add1;
     float acc = 0.f;
     if constexpr (K == 3) {
       if (g.s == 2) {
@@ -564,12 +573,13 @@ extern "C" int ly_rf_bwd_dx(int n_img, int H, int W, int C, int k, int s, const 
   int gx, gy;
   const RfGeom g = rf_geom(n_img, H, W, C, k, s, (long)n_img * H * W, gx, gy);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int add = !addnc ? 0 : (g.chunk <= (long)H * W ? 2 : 1);
+#define RF_DX(KV, AV) hipLaunchKernelGGL((ly_rf_bwd_dx_kernel<T, KV, AV>), dim3(gx, gy), dim3(LY_THREADS), 0, st, g, RF_CT(dug), wg, RF_T(dx), lddx, addnc, add_scale)
   LY_WITH_T(dtype, {
-    if (k == 3 && addnc) hipLaunchKernelGGL((ly_rf_bwd_dx_kernel<T, 3, true>), dim3(gx, gy), dim3(LY_THREADS), 0, st, g, RF_CT(dug), wg, RF_T(dx), lddx, addnc, add_scale);
-    else if (k == 3) hipLaunchKernelGGL((ly_rf_bwd_dx_kernel<T, 3, false>), dim3(gx, gy), dim3(LY_THREADS), 0, st, g, RF_CT(dug), wg, RF_T(dx), lddx, addnc, add_scale);
-    else if (addnc) hipLaunchKernelGGL((ly_rf_bwd_dx_kernel<T, 1, true>), dim3(gx, gy), dim3(LY_THREADS), 0, st, g, RF_CT(dug), wg, RF_T(dx), lddx, addnc, add_scale);
-    else hipLaunchKernelGGL((ly_rf_bwd_dx_kernel<T, 1, false>), dim3(gx, gy), dim3(LY_THREADS), 0, st, g, RF_CT(dug), wg, RF_T(dx), lddx, addnc, add_scale);
+    if (k == 3) { if (add == 2) RF_DX(3, 2); else if (add == 1) RF_DX(3, 1); else RF_DX(3, 0); }
+    else { if (add == 2) RF_DX(1, 2); else if (add == 1) RF_DX(1, 1); else RF_DX(1, 0); }
   });
+#undef RF_DX
   LY_LAUNCH_CHECK();
   return 0;
 }

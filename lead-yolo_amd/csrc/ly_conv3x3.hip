@@ -23,7 +23,7 @@
 // T = float: 32-channel chunks (8 float4 per frame position), two operand planes; T = __bf16: 64-channel chunks (8 x 16 bytes
 // per position, the same bytes in flight per thread), one plane, two k-steps per tap.
 template <typename T, int MT, int WC>
-__global__ __launch_bounds__(LY_THREADS) void ly_conv3x3_kernel(const LyConv3Params P, const int gy, const int tiles_x, const int tiles_y) {
+__global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 2 ? 3 : 2))) void ly_conv3x3_kernel(const LyConv3Params P, const int gy, const int tiles_x, const int tiles_y) {
   using TR = LyT<T>;
   using RV = typename TR::RV;
   constexpr int VW = TR::VW, PL = TR::PL;

@@ -36,6 +36,17 @@
 
 static __device__ float ly_gemm_trash[64 * 4];      // where the stores of rows past M land (never read)
 
+// three waves per SIMD where 168 registers suffice: bf16 rows, one resident chunk (the variant most 1x1 launches of a step take)
+#ifndef LY_GEMM_W3
+#define LY_GEMM_W3(TI, PRO, NCH, MT) (sizeof(TI) == 2 && (PRO) == LY_PRO_NONE && (NCH) == 1 && GATHER == LY_GATHER_ROWS && FAST == 1 && LY_GEMM_W3_ON)
+#ifndef LY_GEMM_W3_ON
+#define LY_GEMM_W3_ON 1
+#endif
+#ifndef LY_GEMM_W3_DEPTH
+#define LY_GEMM_W3_DEPTH 2
+#endif
+#endif
+
 template <int V>
 struct LyIc { static constexpr int value = V; };
 
@@ -447,10 +458,10 @@ __device__ __forceinline__ void ly_gemm_body2(const LyGemmParams& P, const int g
 // allocator is told to fit 256 unified registers (left alone it takes up to ~290 for the gather variants and halves the occupancy:
 // UP2 at 80x80x32 57 -> 78 us).
 template <typename TI, typename TO, int NT, int MT, int WC, int GATHER, int PRO, int NCH = 0, int FAST = 0>
-__global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(2))) void ly_gemm_kernel_d2(const LyGemmParams P, const int gy, const int nslots, const int gx) {
+__global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(LY_GEMM_W3(TI, PRO, NCH, MT) ? 3 : 2))) void ly_gemm_kernel_d2(const LyGemmParams P, const int gy, const int nslots, const int gx) {
   // with resident weights nothing in the loop is consumed in the item that loaded it: a third item in flight then really is in flight
   // (the third register set fits only next to bf16 rows without a prologue; everything else keeps two)
-  constexpr int D = (NCH > 0 && PRO == LY_PRO_NONE && sizeof(TI) == 2) ? LY_GEMM_DEPTH : 2;
+  constexpr int D = LY_GEMM_W3(TI, PRO, NCH, MT) ? LY_GEMM_W3_DEPTH : (NCH > 0 && PRO == LY_PRO_NONE && sizeof(TI) == 2) ? LY_GEMM_DEPTH : 2;
   ly_gemm_body2<TI, TO, NT, MT, WC, GATHER, PRO, D, NCH, FAST>(P, gy, nslots, gx);
 }
 

@@ -849,24 +849,40 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_tap_moments_kernel(const
 #pragma unroll
     for (int i = 0; i < 45; ++i) m2[i] = 0.f;
     if (sub < subs && c < C) {
-      for (long p = (long)blockIdx.x * subs + sub; p < npix; p += (long)gridDim.x * subs) {
-        const int ox = (int)(p % Wo);
-        const long q = p / Wo;
-        const int oy = (int)(q % Ho);
-        const long n = q / Ho;
-        float xv[9];
+      // two output pixels per trip, their 18 taps loaded unconditionally from clamped coordinates before the first use (`ok ? load : 0` is a
+      // branch around a load: every wait after it turns conservative and the taps arrive one round trip at a time); masks in the arithmetic
+      const long stride = (long)gridDim.x * subs;
+      for (long p0 = (long)blockIdx.x * subs + sub; p0 < npix; p0 += 2 * stride) {
+        float xv[2][9];
+        bool okk[2][9];
 #pragma unroll
-        for (int u = 0; u < 9; ++u) {
-          const int iy = s * oy + u / 3 - 1, ix = s * ox + u % 3 - 1;
-          const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
-          xv[u] = ok ? ly_ld1<T>(x + ((n * H + (ok ? iy : 0)) * W + (ok ? ix : 0)) * ldx + c) : 0.f;
+        for (int j = 0; j < 2; ++j) {
+          const long p = p0 + j * stride;
+          const bool live = p < npix;
+          const long pc = live ? p : npix - 1;
+          const int ox = (int)(pc % Wo);
+          const long q = pc / Wo;
+          const int oy = (int)(q % Ho);
+          const long n = q / Ho;
+#pragma unroll
+          for (int u = 0; u < 9; ++u) {
+            const int iy = s * oy + u / 3 - 1, ix = s * ox + u % 3 - 1;
+            okk[j][u] = live && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const int cy = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), cx = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
+            xv[j][u] = ly_ld1<T>(x + ((n * H + cy) * W + cx) * ldx + c);
+          }
         }
-        int k = 0;
 #pragma unroll
-        for (int u = 0; u < 9; ++u) {
-          m1[u] += xv[u];
+        for (int j = 0; j < 2; ++j) {
 #pragma unroll
-          for (int v = u; v < 9; ++v) m2[k++] += xv[u] * xv[v];
+          for (int u = 0; u < 9; ++u) xv[j][u] = okk[j][u] ? xv[j][u] : 0.f;
+          int k = 0;
+#pragma unroll
+          for (int u = 0; u < 9; ++u) {
+            m1[u] += xv[j][u];
+#pragma unroll
+            for (int v = u; v < 9; ++v) m2[k++] += xv[j][u] * xv[j][v];
+          }
         }
       }
 #pragma unroll

@@ -495,7 +495,8 @@ __global__ __launch_bounds__(LY_THREADS) void ly_wgrad_tiled_kernel(const LyWgra
     for (int j = 0; j < NJ; ++j) acc[i][j] = ly_zero4();
   const int wn = (wave & 1) * (BN / 2), wk = BN + (wave >> 1) * (BK / 2);
 
-  prefetch(p_begin);
+  constexpr bool SB = P >= 128;            // 128 pixels per step: ONE LDS buffer (two would leave one block per CU); the loads of the next step
+  prefetch(p_begin);                       // are in flight during the contraction, the buffer is rewritten between two barriers
   commit(0);
   __syncthreads();
   int buf = 0;
@@ -521,9 +522,15 @@ __global__ __launch_bounds__(LY_THREADS) void ly_wgrad_tiled_kernel(const LyWgra
         for (int i = 0; i < NI; ++i) acc[i][j] = ly_mfmapp<PL>(ah[i], al[i], bh, bl, acc[i][j]);
       }
     }
-    if (more) commit(buf ^ 1);
-    __syncthreads();
-    buf ^= 1;
+    if constexpr (SB) {
+      __syncthreads();
+      if (more) commit(0);
+      __syncthreads();
+    } else {
+      if (more) commit(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
   }
 
 #pragma unroll
@@ -543,6 +550,9 @@ __global__ __launch_bounds__(LY_THREADS) void ly_wgrad_tiled_kernel(const LyWgra
     }
 }
 
+#ifndef LY_WGRAD_P128
+#define LY_WGRAD_P128 1
+#endif
 template <typename T, int BN, int BK, int P>
 static int launch_wgrad_tiled(const LyWgradParams& Q, bool rows, hipStream_t st) {
   const int Ktot = Q.ks * Q.ks * Q.Cin;
@@ -558,7 +568,7 @@ static int launch_wgrad_tiled(const LyWgradParams& Q, bool rows, hipStream_t st)
   chunk_px = (chunk_px + P - 1) / P * P;
   chunks = (Q.M + chunk_px - 1) / chunk_px;
   LY_CHECK(chunks < 65536, "wgrad: too many pixel chunks");
-  const size_t lds = 2 * (size_t)(BN + BK) * (LyT<T>::PL * 2 * P + 16);
+  const size_t lds = (P >= 128 ? 1 : 2) * (size_t)(BN + BK) * (LyT<T>::PL * 2 * P + 16);
   const dim3 grid((unsigned)tiles, (unsigned)chunks);
   if (rows) {
     static bool attr = false;
@@ -606,6 +616,9 @@ static int wgrad_dispatch(const LyWgradParams& P, void* stream) {
     if (P.N <= 64 && Ktot <= 64) return launch_wgrad_tiled<T, 64, 64, 64>(P, rows, st2);
     if (P.N <= 32) return launch_wgrad_tiled<T, 32, 128, PX>(P, rows, st2);      // 46 KB: three blocks per CU
     if (P.N <= 64) return launch_wgrad_tiled<T, 64, 128, PX>(P, rows, st2);      // 55 KB: two
+    if constexpr (LyT<T>::BF) {
+      if (rows && LY_WGRAD_P128) return launch_wgrad_tiled<T, 128, 128, 128>(P, rows, st2);
+    }
     return launch_wgrad_tiled<T, 128, 128, PX>(P, rows, st2);
   }
   const int tiles_n = (P.N + 63) / 64, tiles_k = (Ktot + 63) / 64;

@@ -617,7 +617,7 @@ static int wgrad_dispatch(const LyWgradParams& P, void* stream) {
     if (P.N <= 32) return launch_wgrad_tiled<T, 32, 128, PX>(P, rows, st2);      // 46 KB: three blocks per CU
     if (P.N <= 64) return launch_wgrad_tiled<T, 64, 128, PX>(P, rows, st2);      // 55 KB: two
     if constexpr (LyT<T>::BF) {
-      if (rows && LY_WGRAD_P128) return launch_wgrad_tiled<T, 128, 128, 128>(P, rows, st2);
+      if (LY_WGRAD_P128) return launch_wgrad_tiled<T, 128, 128, 128>(P, rows, st2);
     }
     return launch_wgrad_tiled<T, 128, 128, PX>(P, rows, st2);
   }

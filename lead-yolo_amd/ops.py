@@ -657,7 +657,7 @@ def wgrad_kernel_name(t, n, ktot, rows, tiled):
     elif n <= 64:
         bn, bk, px = 64, 128, pxs
     else:
-        bn, bk, px = 128, 128, (128 if (t == "__bf16" and rows) else pxs)      # bf16 rows: 128 pixels per step, one LDS buffer
+        bn, bk, px = 128, 128, (128 if t == "__bf16" else pxs)      # bf16: 128 pixels per step, one LDS buffer
     return f"ly_wgrad_tiled_kernel<{t}, {bn}, {bk}, {px}, {r}>"
 
 

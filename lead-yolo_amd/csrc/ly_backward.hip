@@ -370,7 +370,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_wgrad_kernel(const LyWgradParam
 // Re-reads drop from (N/64 + K/64) to (N/BN + K/BK) passes over the two tensors.
 // -------------------------------------------------------------------------------------------------
 template <typename T, int BN, int BK, int P, bool ROWS>
-__global__ __launch_bounds__(LY_THREADS) void ly_wgrad_tiled_kernel(const LyWgradParams P_, const int tiles_k, const long chunk_px) {
+__global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(BN + BK > 160 ? 2 : 3))) void ly_wgrad_tiled_kernel(const LyWgradParams P_, const int tiles_k, const long chunk_px) {
   const LyWgradParams& Q = P_;
   using R4 = typename LyT<T>::R4;
   constexpr int PL = LyT<T>::PL;
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_wgrad_tiled_kernel(const LyWgra
     for (int j = 0; j < NJ; ++j) acc[i][j] = ly_zero4();
   const int wn = (wave & 1) * (BN / 2), wk = BN + (wave >> 1) * (BK / 2);
 
-  constexpr bool SB = P >= 128;            // 128 pixels per step: ONE LDS buffer (two would leave one block per CU); the loads of the next step
+  constexpr bool SB = PL * P >= 128;       // 128 bf16 / 64 fp32 pixels per step: ONE LDS buffer (two would leave one block per CU); the loads of the next step
   prefetch(p_begin);                       // are in flight during the contraction, the buffer is rewritten between two barriers
   commit(0);
   __syncthreads();
@@ -550,9 +550,6 @@ __global__ __launch_bounds__(LY_THREADS) void ly_wgrad_tiled_kernel(const LyWgra
     }
 }
 
-#ifndef LY_WGRAD_P128
-#define LY_WGRAD_P128 1
-#endif
 template <typename T, int BN, int BK, int P>
 static int launch_wgrad_tiled(const LyWgradParams& Q, bool rows, hipStream_t st) {
   const int Ktot = Q.ks * Q.ks * Q.Cin;
@@ -568,7 +565,7 @@ static int launch_wgrad_tiled(const LyWgradParams& Q, bool rows, hipStream_t st)
   chunk_px = (chunk_px + P - 1) / P * P;
   chunks = (Q.M + chunk_px - 1) / chunk_px;
   LY_CHECK(chunks < 65536, "wgrad: too many pixel chunks");
-  const size_t lds = (P >= 128 ? 1 : 2) * (size_t)(BN + BK) * (LyT<T>::PL * 2 * P + 16);
+  const size_t lds = (LyT<T>::PL * P >= 128 ? 1 : 2) * (size_t)(BN + BK) * (LyT<T>::PL * 2 * P + 16);
   const dim3 grid((unsigned)tiles, (unsigned)chunks);
   if (rows) {
     static bool attr = false;
@@ -605,20 +602,17 @@ static int wgrad_dispatch(const LyWgradParams& P, void* stream) {
   if (rows) LY_CHECK(P.Hin == P.H && P.Win == P.W, "wgrad: 1x1 gather needs Hin == H, Win == W");
   if (!P.nchw && (P.N & 3) == 0 && (P.Cin & 3) == 0 && (P.lddu & 3) == 0 && (P.ldx & 3) == 0 && ((uintptr_t)P.du & (4 * sizeof(T) - 1)) == 0 && ((uintptr_t)P.x & (4 * sizeof(T) - 1)) == 0) {
     hipStream_t st2 = reinterpret_cast<hipStream_t>(stream);
-    // skinny outputs (MLP blocks, patch layers at high resolution): few channel quads per pixel, so a step covers 64 pixels
-    // to keep every thread loading; otherwise 32 pixels per step and wider channel tiles
-    // One step of a block is one memory round trip (prefetch one step ahead), so what matters for the skinny shapes is how many
-    // blocks a CU holds: the 64 x 256 tile's 92 KB of LDS meant ONE (N=8 K=72 M=1.6M: 690 -> 280 us, N=64 K=576: 538 -> 342 us,
-    // N=64 K=128 upsampled source: 271 -> 137 us with the tiles below; all wgrad launches of a bs=64 step 7.8 -> 6.5 ms).
-    // pixels per step: 32 for fp32 storage; bf16 rows are half as many bytes, so a step covers 64 pixels to keep the same bytes in
-    // flight per block (the LDS image per step is the same size: one plane instead of two)
-    constexpr int PX = LyT<T>::BF ? 64 : 32;
-    if (P.N <= 64 && Ktot <= 64) return launch_wgrad_tiled<T, 64, 64, 64>(P, rows, st2);
-    if (P.N <= 32) return launch_wgrad_tiled<T, 32, 128, PX>(P, rows, st2);      // 46 KB: three blocks per CU
-    if (P.N <= 64) return launch_wgrad_tiled<T, 64, 128, PX>(P, rows, st2);      // 55 KB: two
-    if constexpr (LyT<T>::BF) {
-      if (LY_WGRAD_P128) return launch_wgrad_tiled<T, 128, 128, 128>(P, rows, st2);
-    }
+    // One step of a block is one memory round trip, so what matters for the skinny shapes is how many blocks a CU holds and how many
+    // bytes each has in flight: the 64 x 256 tile's 92 KB of LDS meant ONE block (N=8 K=72 M=1.6M: 690 -> 280 us, N=64 K=576: 538 -> 342 us
+    // with the tiles below; all wgrad launches of a bs=64 step 7.8 -> 6.5 ms in round 1).
+    // pixels per step: 128 (bf16) / 64 (fp32) = the same 272-byte LDS rows in both, held in ONE buffer (the rows of the next step are in
+    // flight in registers during the contraction and the buffer is rewritten between two barriers).  Against the double-buffered
+    // 64 / 32-pixel step this doubles the bytes in flight per block at the same blocks per CU: all wgrad launches of a bs=64 bf16 step
+    // 3.56 -> 3.28 ms.
+    constexpr int PX = LyT<T>::BF ? 128 : 64;
+    if (P.N <= 64 && Ktot <= 64) return launch_wgrad_tiled<T, 64, 64, PX>(P, rows, st2);
+    if (P.N <= 32) return launch_wgrad_tiled<T, 32, 128, PX>(P, rows, st2);
+    if (P.N <= 64) return launch_wgrad_tiled<T, 64, 128, PX>(P, rows, st2);
     return launch_wgrad_tiled<T, 128, 128, PX>(P, rows, st2);
   }
   const int tiles_n = (P.N + 63) / 64, tiles_k = (Ktot + 63) / 64;

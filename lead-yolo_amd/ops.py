@@ -649,15 +649,15 @@ def wgrad_kernel_name(t, n, ktot, rows, tiled):
     r = "true" if rows else "false"
     if not tiled:
         return f"ly_wgrad_kernel<{t}, {r}>"
-    pxs = 64 if t == "__bf16" else 32
+    px = 128 if t == "__bf16" else 64             # one 272-byte LDS row per channel and step in both dtypes, single buffer
     if n <= 64 and ktot <= 64:
-        bn, bk, px = 64, 64, 64
+        bn, bk = 64, 64
     elif n <= 32:
-        bn, bk, px = 32, 128, pxs
+        bn, bk = 32, 128
     elif n <= 64:
-        bn, bk, px = 64, 128, pxs
+        bn, bk = 64, 128
     else:
-        bn, bk, px = 128, 128, (128 if t == "__bf16" else pxs)      # bf16: 128 pixels per step, one LDS buffer
+        bn, bk = 128, 128
     return f"ly_wgrad_tiled_kernel<{t}, {bn}, {bk}, {px}, {r}>"
 
 

@@ -369,7 +369,11 @@ __device__ __forceinline__ void ly_mlpblock_body(
 //     after it, so the HBM latency of a patch hides behind the arithmetic of the previous one.
 // The arithmetic per pixel is the block above verbatim (same operand order: results are bit-identical).
 // -------------------------------------------------------------------------------------------------
-template <typename T, int C, int NT, int HT, bool STATS>
+// MODE 0: the whole block (y = x' + mlp(x')), 1: statistics pass of the hidden BatchNorm, 2: the partial 3x3 conv alone — y = z =
+// [pconv(x[:C/4]) | x[C/4:]], what the training backward needs twice (z for the recomputed hidden tensor, and, with the transposed-
+// flipped taps on the gradient g, [d/dx of the conv | g[C/4:]]): one read + one write of the map instead of a clone and a 3x3 launch
+// whose 32/64-channel K chunks are 90 % padding at C/4 = 6.
+template <typename T, int C, int NT, int HT, int MODE>
 __device__ __forceinline__ void ly_mlpblock_persist_body(
     const T* __restrict__ x, T* __restrict__ y, long M, int H, int W, int n_img,
     const uint4* __restrict__ wp, const uint4* __restrict__ w1, const uint4* __restrict__ w2,
@@ -382,7 +386,7 @@ __device__ __forceinline__ void ly_mlpblock_persist_body(
   constexpr int CQ = Gm::CQ, G = Gm::G, SP = Gm::SP, PT = Gm::PT, C16 = Gm::C16, KP = Gm::KP, S1 = Gm::S1;
   constexpr int RS = Gm::RS, RSP = Gm::RSP, HTP = Gm::HTP, S2 = Gm::S2;
   constexpr int BP = 64 * NT, TH = 4 * NT, BPH = (TH + 2) * 18;
-  constexpr bool T2D = true;
+  constexpr bool T2D = true, STATS = MODE == 1, ZONLY = MODE == 2;
   constexpr int NFP = PT * SP, NF1 = HTP * S1, NF2 = C16 * S2, NFW = NFP + NF1 + NF2;
   constexpr int WBYTES = NFW * PL * 1024, XB = PL * BP * RS, PB = PL * BPH * RSP, BUFB = (XB + PB + 15) / 16 * 16;
   static_assert(HTP % HT == 0 && HT % 2 == 0 && C % VW == 0, "geometry");
@@ -396,8 +400,10 @@ __device__ __forceinline__ void ly_mlpblock_persist_body(
 
   // ---- weights -> LDS, once -------------------------------------------------------------------
   for (int i = tid; i < NFP * PL * 64; i += LY_THREADS) reinterpret_cast<uint4*>(wl)[i] = wp[i];
-  for (int i = tid; i < NF1 * PL * 64; i += LY_THREADS) reinterpret_cast<uint4*>(wl)[NFP * PL * 64 + i] = w1[i];
-  for (int i = tid; i < NF2 * PL * 64; i += LY_THREADS) reinterpret_cast<uint4*>(wl)[(NFP + NF1) * PL * 64 + i] = w2[i];
+  if constexpr (!ZONLY) {
+    for (int i = tid; i < NF1 * PL * 64; i += LY_THREADS) reinterpret_cast<uint4*>(wl)[NFP * PL * 64 + i] = w1[i];
+    for (int i = tid; i < NF2 * PL * 64; i += LY_THREADS) reinterpret_cast<uint4*>(wl)[(NFP + NF1) * PL * 64 + i] = w2[i];
+  }
   auto wlds = [&](int fi) -> LyWF<PL> {
     LyWF<PL> f;
     f.hi = *reinterpret_cast<const bf16x8*>(wl + ((fi * PL) * 64 + lane) * 16);
@@ -590,6 +596,29 @@ __device__ __forceinline__ void ly_mlpblock_persist_body(
         }
     }
 
+    if constexpr (ZONLY) {
+      // the tile now holds z: the wave stores its own rows (16-byte vectors, lanes of a row split the channels)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int pix = pixbase + 16 * n + li;
+        const long gp = gpix(pix);
+        if (gp >= 0) {
+          if constexpr (PL == 1) {
+            for (int v = lq; v < C / 8; v += 4)
+              *reinterpret_cast<uint4*>(reinterpret_cast<char*>(y) + (gp * C + 8 * v) * 2) = *reinterpret_cast<const uint4*>(xs_hi + pix * RS + 16 * v);
+          } else {
+            for (int v = lq; v < C / 4; v += 4) {
+              const f32x4 r = ly_cvt4(*reinterpret_cast<const bf16x4*>(xs_hi + pix * RS + 8 * v)) + ly_cvt4(*reinterpret_cast<const bf16x4*>(xs_lo + pix * RS + 8 * v));
+              ly_st4<T>(y + gp * C + 4 * v, r);
+            }
+          }
+        }
+      }
+      commit(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+      continue;
+    }
     // ---- 2 + 3. expand -> BN -> ReLU -> project, hidden kept in registers ---------------------------
     f32x4 acco[C16][NT];
   #pragma unroll
@@ -705,12 +734,12 @@ __device__ __forceinline__ void ly_mlpblock_persist_body(
   }
 }
 
-template <typename T, int C, int NT, int HT, bool STATS>
+template <typename T, int C, int NT, int HT, int MODE>
 __global__ __launch_bounds__(LY_THREADS) void ly_mlpblock_persist_kernel(
     const T* __restrict__ x, T* __restrict__ y, long M, int H, int W, int n_img,
     const uint4* __restrict__ wp, const uint4* __restrict__ w1, const uint4* __restrict__ w2,
     const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, float* __restrict__ stats) {
-  ly_mlpblock_persist_body<T, C, NT, HT, STATS>(x, y, M, H, W, n_img, wp, w1, w2, bn_scale, bn_shift, stats);
+  ly_mlpblock_persist_body<T, C, NT, HT, MODE>(x, y, M, H, W, n_img, wp, w1, w2, bn_scale, bn_shift, stats);
 }
 
 template <typename T, int C, int NT, int HT, bool T2D, bool STATS>
@@ -772,7 +801,7 @@ static int launch_mlp_k(const T* x, T* y, long M, int n_img, int H, int W, const
   return 0;
 }
 
-template <typename T, int C, int NT, int HT, bool STATS>
+template <typename T, int C, int NT, int HT, int MODE>
 static int launch_mlp_persist(const T* x, T* y, long M, int n_img, int H, int W, const void* wp, const void* w1, const void* w2,
                               const float* s, const float* b, float* stats, hipStream_t st) {
   using Gm = MlpGeom<C>;
@@ -780,7 +809,7 @@ static int launch_mlp_persist(const T* x, T* y, long M, int n_img, int H, int W,
   constexpr int NFW = Gm::PT * Gm::SP + Gm::HTP * Gm::S1 + Gm::C16 * Gm::S2;
   constexpr size_t lds = (size_t)NFW * PL * 1024 + 2 * (((size_t)PL * BP * Gm::RS + (size_t)PL * BPH * Gm::RSP + 15) / 16 * 16);
   static_assert(lds <= 160 * 1024, "persistent MLPBlock: weights + two patch buffers must fit LDS");
-  auto k = ly_mlpblock_persist_kernel<T, C, NT, HT, STATS>;
+  auto k = ly_mlpblock_persist_kernel<T, C, NT, HT, MODE>;
   static int per_cu = 0;
   if (per_cu == 0) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
@@ -826,13 +855,29 @@ static int dispatch_nt_t(const T* x, T* y, long M, int n_img, int H, int W, cons
     // persistent patch walk with the weights in LDS: enough patches for every resident block to amortise the weight copy
     // (fp32 storage at C = 40 needs 148 KB of LDS and 242 registers: one block per CU, measured 63 -> 79 us — it keeps the one-shot kernel)
     if ((W & 15) == 0 && W >= 32 && (long)n_img * ((H + 7) / 8) * (W / 16) >= 1024 && (LyT<T>::BF || C < 40))
-      return stats ? launch_mlp_persist<T, C, 2, HT, true>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st)
-                   : launch_mlp_persist<T, C, 2, HT, false>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
+      return stats ? launch_mlp_persist<T, C, 2, HT, 1>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st)
+                   : launch_mlp_persist<T, C, 2, HT, 0>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
   }
   if ((W & 15) == 0 && W >= 64 && NTMAX >= 2) return launch_mlp<T, C, 2, HT, true>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
   if (NTMAX >= 4 && M >= 256L * 1024) return launch_mlp<T, C, NT4, HT, false>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
   if (NTMAX >= 2 && M >= 128L * 512) return launch_mlp<T, C, NT2, HT, false>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
   return launch_mlp<T, C, 1, HT, false>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
+}
+
+// the partial conv alone (persist MODE 2) where the persistent kernel applies; returns 1 = "not built for this shape" (the caller then
+// uses a clone + ly_conv3x3_fwd)
+template <int C, int HT>
+static int dispatch_pconv(const void* x, void* y, long M, int n_img, int H, int W, const void* wp, int dtype, hipStream_t st) {
+  if constexpr (C < 80) {
+    const bool shape_ok = (W & 15) == 0 && W >= 32 && (long)n_img * ((H + 7) / 8) * (W / 16) >= 1024;
+    if (shape_ok && dtype == LY_BF16)
+      return launch_mlp_persist<__bf16, C, 2, HT, 2>(reinterpret_cast<const __bf16*>(x), reinterpret_cast<__bf16*>(y), M, n_img, H, W, wp, wp, wp, nullptr, nullptr, nullptr, st);
+    if constexpr (C < 40) {
+      if (shape_ok && dtype == LY_F32)
+        return launch_mlp_persist<float, C, 2, HT, 2>(reinterpret_cast<const float*>(x), reinterpret_cast<float*>(y), M, n_img, H, W, wp, wp, wp, nullptr, nullptr, nullptr, st);
+    }
+  }
+  return 1;
 }
 
 template <int C, int HT, int NTMAX>

@@ -24,5 +24,22 @@ extern "C" int ly_mlpblock_fwd(const void* x, void* y, int n_img, int H, int W, 
   }
 }
 
+// z = [pconv3x3(x[:, :C/4]) | x[:, C/4:]] alone (Partial_conv3.forward_split_cat, models/common.py:1432-1437): returns 0 when launched, 1 when the
+// persistent kernel is not built for this (C, map, dtype) — the caller then uses a copy + ly_conv3x3_fwd —, -1 on error.
+extern "C" int ly_mlpblock_pconv(const void* x, void* z, int n_img, int H, int W, int C, const void* wp, int dtype, void* stream) {
+  LY_CHECK(dtype == LY_F32 || dtype == LY_BF16, "mlpblock_pconv: unknown dtype %d", dtype);
+  LY_CHECK(x && z && wp && x != z && n_img > 0 && H > 0 && W > 0, "mlpblock_pconv: bad arguments");
+  LY_CHECK(((uintptr_t)x & 15) == 0 && ((uintptr_t)z & 15) == 0, "mlpblock_pconv: x / z must be 16-byte aligned");
+  const long M = (long)n_img * H * W;
+  LY_CHECK(M < (1L << 24), "mlpblock_pconv: M=%ld pixels exceeds the 2^24 limit of the fast index path", M);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  switch (C) {
+    case 16: return dispatch_pconv<16, 2>(x, z, M, n_img, H, W, wp, dtype, st);
+    case 24: return dispatch_pconv<24, 4>(x, z, M, n_img, H, W, wp, dtype, st);
+    case 40: return dispatch_pconv<40, 2>(x, z, M, n_img, H, W, wp, dtype, st);
+    default: return 1;
+  }
+}
+
 // geometry the host packer needs: hidden tiles (padded to even) for a given C
 extern "C" int ly_mlpblock_hidden_tiles(int C) { return (2 * C / 16 + 1) / 2 * 2; }

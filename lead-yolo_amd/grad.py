@@ -375,8 +375,11 @@ class MlpBlockFn(torch.autograd.Function):
             pl = ops.planes_of(x)
             c4q = (c4 + 31) // 32 * 32                 # the 3x3 kernel's tap matrices pad the channels of a tap to 32
             # recompute z, u1, h
-            z = x.clone()
-            ops.conv3x3(M=m, H=h, W=w, Cin=c4p, N=c4, x=x, ldx=c, wp=pack.packed(pack.src_taps(p_wpc, c4q), 9 * c4q, pl), out=z, ldo=c)
+            # z = [pconv(x[:c4]) | x[c4:]]: one pass of the persistent kernel where it is built, else a copy + the 3x3 kernel on the slice
+            z = torch.empty_like(x)
+            if not ops.mlpblock_pconv(x, z, n, h, w, c, pack.packed(pack.src_taps(p_wpc, c4p), 9 * c4p, pl)):
+                z.copy_(x)
+                ops.conv3x3(M=m, H=h, W=w, Cin=c4p, N=c4, x=x, ldx=c, wp=pack.packed(pack.src_taps(p_wpc, c4q), 9 * c4q, pl), out=z, ldo=c)
             htp = (2 * c // 16 + 1) // 2 * 2
             pk1 = pack.packed(pack.src_matrix(p_w1, 2 * c, c), c, pl, rows_to=16 * htp)          # the forward's own image
             u1 = ops.empty_nhwc(n, 2 * c, h, w, x)
@@ -407,12 +410,18 @@ class MlpBlockFn(torch.autograd.Function):
             ts, cs = (c4, 1) if _tap_major(dwp) else (1, 9)
             ops.wgrad(M=m, H=h, W=w, N=c4p, du=g, lddu=c, x=x, ldx=c, Hin=h, Win=w, Cin=c4p, dw=dwp, lddw=9 * c4, ks=3, stride=1, pad=1,
                       dw_ts=ts, dw_cs=cs, n_valid=c4, c_valid=c4)
-            t = ops.empty_nhwc(n, c4p, h, w, x)
-            wt = pack.packed(pack.src_taps(p_wpc, c4q, transposed_flipped=True), 9 * c4q, pl)
-            ops.conv3x3(M=m, H=h, W=w, Cin=c4p, N=c4, x=g, ldx=c, wp=wt, out=t, ldo=c4p)
-            dx = torch.empty_like(dy)                      # dy + g, the partial conv's channels dy + t: one pass (ly_mlp_dx)
-            _lib().check(_lib().lib().ly_mlp_dx(_lib().ptr(dy), _lib().ptr(g), _lib().ptr(t), c4p, m, c, c4, _lib().ptr(dx), _lib().dtype_code(dy),
-                                                _lib().stream_ptr()), "ly_mlp_dx")
+            dx = torch.empty_like(dy)                      # dy + g, the partial conv's channels dy + t
+            gz = torch.empty_like(g)
+            if ops.mlpblock_pconv(g, gz, n, h, w, c, pack.packed(pack.src_taps(p_wpc, c4p, transposed_flipped=True), 9 * c4p, pl)):
+                # gz = [t | g[c4:]] straight from the persistent kernel with the transposed-flipped taps: dx = dy + gz
+                _lib().check(_lib().lib().ly_mlp_dx(_lib().ptr(dy), _lib().ptr(gz), _lib().ptr(gz), c, m, c, 4, _lib().ptr(dx), _lib().dtype_code(dy),
+                                                    _lib().stream_ptr()), "ly_mlp_dx")
+            else:
+                t = ops.empty_nhwc(n, c4p, h, w, x)
+                wt = pack.packed(pack.src_taps(p_wpc, c4q, transposed_flipped=True), 9 * c4q, pl)
+                ops.conv3x3(M=m, H=h, W=w, Cin=c4p, N=c4, x=g, ldx=c, wp=wt, out=t, ldo=c4p)
+                _lib().check(_lib().lib().ly_mlp_dx(_lib().ptr(dy), _lib().ptr(g), _lib().ptr(t), c4p, m, c, c4, _lib().ptr(dx), _lib().dtype_code(dy),
+                                                    _lib().stream_ptr()), "ly_mlp_dx")
             for prm, direct in ((p_wpc, dp), (p_w1, d1), (p_w2, d2)):
                 if direct:
                     ops.grad_done(prm)

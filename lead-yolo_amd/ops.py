@@ -201,6 +201,16 @@ def gemm(*, M, H, W, K, N, a0, lda0, k0, wp, out, ldo, a1=None, lda1=0, gather=G
         capi.check(capi.lib().ly_gemm_fwd(ctypes.byref(P), capi.stream_ptr()), "ly_gemm_fwd")
 
 
+def mlpblock_pconv(x, z, n, h, w, c, wp):
+    """z = [conv3x3(x[:, :c/4]; wp) | x[:, c/4:]] in one pass (persistent MLPBlock kernel, partial conv only); x, z dense NHWC [n, c, h, w].
+    Returns False when the kernel is not built for this shape (the caller then copies and calls conv3x3)."""
+    with _Timed(f"ly_mlpblock_persist_kernel<{_tname(x)}, {c}, pconv>", 18.0 * n * h * w * (c // 4) ** 2, 2.0 * x.element_size() * n * h * w * c):
+        rc = capi.lib().ly_mlpblock_pconv(_p(x), _p(z), n, h, w, c, _p(wp), capi.dtype_code(x), capi.stream_ptr())
+    if rc < 0:
+        capi.check(rc, "ly_mlpblock_pconv")
+    return rc == 0
+
+
 def conv3x3(*, M, H, W, Cin, N, x, ldx, wp, out, ldo, e_scale=None, e_shift=None, act=ACT_NONE, stats=None):
     th, tw = pick_conv_tile(H, W)
     code = capi.dtype_code(x)

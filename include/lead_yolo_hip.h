@@ -36,8 +36,9 @@ int ly_mlpblock_fwd(const void* x /*T*/, void* y /*T*/, int n_img, int H, int W,
                     const void* w2, const float* bn_scale, const float* bn_shift, float* stats, int dtype, void* stream);
 /* The partial convolution alone: z = [conv3x3(x[:, :C/4]; wp) | x[:, C/4:]] (Partial_conv3.forward_split_cat, models/common.py:1432-1437) in one
  * read + one write of the map — what the training backward needs twice (z for the recomputed hidden tensor; with the transposed-flipped taps
- * applied to the gradient g: [d/dx of the conv | g[C/4:]]).  Returns 0 when launched, 1 when not built for this (C, map, dtype): C in
- * {16, 24, 40} (fp32: C < 40), W a multiple of 16 and >= 32, >= 1024 patches — use a copy + ly_conv3x3_fwd then —, -1 on error.        */
+ * applied to the gradient g: [d/dx of the conv | g[C/4:]]).  Persistent patch walk where the MLPBlock's applies (C < 80, W % 16 == 0, >= 1024
+ * patches), the one-shot kernel stopped after the partial conv otherwise.  Returns 0 when launched, 1 for a channel count the MLPBlock
+ * kernels are not built for (the caller can use a copy + ly_conv3x3_fwd), -1 on error.  x and z dense [n*H*W, C], not aliased.            */
 int ly_mlpblock_pconv(const void* x /*T*/, void* z /*T*/, int n_img, int H, int W, int C, const void* wp, int dtype, void* stream);
 /* hidden (2C) channel tiles of 16, padded to an even count */
 int ly_mlpblock_hidden_tiles(int C);

@@ -44,7 +44,7 @@ struct MlpGeom {
 // as soon as fragment g's MFMAs are issued.  All loops are fully unrolled, so g and the slot index are compile-time constants.
 // D = 0: no ring (loads where they are used; fewer registers, more co-resident waves -- the better trade for the narrow,
 // memory-heavy stages).
-template <typename T, int C, int NT, int HT, bool T2D, bool STATS, int D>
+template <typename T, int C, int NT, int HT, bool T2D, bool STATS, int D, bool ZONLY = false>
 __device__ __forceinline__ void ly_mlpblock_body(
     const T* __restrict__ x, T* __restrict__ y, long M, int H, int W,
     const uint4* __restrict__ wp, const uint4* __restrict__ w1, const uint4* __restrict__ w2,
@@ -105,8 +105,10 @@ __device__ __forceinline__ void ly_mlpblock_body(
   };
   if (C >= 80) {     // large weight sets, few pixels: warm L2 with all three packed weight arrays
     float* const sink = stats ? stats : reinterpret_cast<float*>(y);
-    ly_l2_warm(w1, (long)HTP * S1 * PL * 1024, sink);
-    ly_l2_warm(w2, (long)C16 * S2 * PL * 1024, sink);
+    if constexpr (!ZONLY) {                                  // (partial conv only: w1 / w2 are not passed)
+      ly_l2_warm(w1, (long)HTP * S1 * PL * 1024, sink);
+      ly_l2_warm(w2, (long)C16 * S2 * PL * 1024, sink);
+    }
     ly_l2_warm(wp, (long)PT * SP * PL * 1024, sink);
   }
   long p0 = 0;                 // flattened: first pixel of the run
@@ -251,6 +253,26 @@ __device__ __forceinline__ void ly_mlpblock_body(
       }
   }
 
+  if constexpr (ZONLY) {
+    // partial conv only (see the persistent kernel's MODE 2): the tile holds z, the wave stores its own rows
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int pix = pixbase + 16 * n + li;
+      const long gp = gpix(pix);
+      if (gp >= 0) {
+        if constexpr (PL == 1) {
+          for (int v = lq; v < C / 8; v += 4)
+            *reinterpret_cast<uint4*>(reinterpret_cast<char*>(y) + (gp * C + 8 * v) * 2) = *reinterpret_cast<const uint4*>(xs_hi + pix * RS + 16 * v);
+        } else {
+          for (int v = lq; v < C / 4; v += 4) {
+            const f32x4 r = ly_cvt4(*reinterpret_cast<const bf16x4*>(xs_hi + pix * RS + 8 * v)) + ly_cvt4(*reinterpret_cast<const bf16x4*>(xs_lo + pix * RS + 8 * v));
+            ly_st4<T>(y + gp * C + 4 * v, r);
+          }
+        }
+      }
+    }
+    return;
+  }
   // ---- 2 + 3. expand -> BN -> ReLU -> project, hidden kept in registers ---------------------------
   f32x4 acco[C16][NT];
 #pragma unroll
@@ -768,6 +790,31 @@ __global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2
   ly_mlpblock_body<T, C, NT, HT, T2D, STATS, 8>(x, y, M, H, W, wp, w1, w2, bn_scale, bn_shift, stats);
 }
 
+template <typename T, int C, int NT, int HT, bool T2D>
+__global__ __launch_bounds__(LY_THREADS) void ly_mlpblock_pconv1_kernel(const T* __restrict__ x, T* __restrict__ y, long M, int H, int W, const uint4* __restrict__ wp) {
+  ly_mlpblock_body<T, C, NT, HT, T2D, false, 0, true>(x, y, M, H, W, wp, wp, wp, nullptr, nullptr, nullptr);
+}
+
+template <typename T, int C, int NT, int HT, bool T2D>
+static int launch_mlp_pconv1(const T* x, T* y, long M, int n_img, int H, int W, const void* wp, hipStream_t st) {
+  using Gm = MlpGeom<C>;
+  constexpr int BP = 64 * NT;
+  const long halo = T2D ? (4 * NT + 2) * 18 : BP + 2 * W + 2;
+  size_t lds = LyT<T>::PL * ((size_t)BP * Gm::RS + (size_t)halo * Gm::RSP);
+  LY_CHECK(lds <= 160 * 1024, "mlpblock_pconv: tile needs %zu B of LDS (C=%d W=%d)", lds, C, W);
+  auto k = ly_mlpblock_pconv1_kernel<T, C, NT, HT, T2D>;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+    LY_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    configured = true;
+  }
+  long blocks = T2D ? (long)n_img * ((H + 4 * NT - 1) / (4 * NT)) * (W / 16) : (M + BP - 1) / BP;
+  hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(LY_THREADS), lds, st, x, y, M, H, W, reinterpret_cast<const uint4*>(wp));
+  LY_LAUNCH_CHECK();
+  return 0;
+}
+
 // The instantiations are split over translation units (ly_mlpblock.hip: C = 16/24/40 + the C ABI, ly_mlpblock_b.hip:
 // C = 80/160, ly_mlpblock_c.hip: C = 320) only to keep the in-tree build short.
 #define LY_MLP_ARGS const void* x, void* y, long M, int n_img, int H, int W, const void* wp, const void* w1, const void* w2, \
@@ -775,6 +822,9 @@ __global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2
 int ly_mlp_dispatch_80(LY_MLP_ARGS);
 int ly_mlp_dispatch_160(LY_MLP_ARGS);
 int ly_mlp_dispatch_320(LY_MLP_ARGS);
+int ly_mlp_pconv_80(const void* x, void* y, long M, int n_img, int H, int W, const void* wp, int dtype, hipStream_t st);
+int ly_mlp_pconv_160(const void* x, void* y, long M, int n_img, int H, int W, const void* wp, int dtype, hipStream_t st);
+int ly_mlp_pconv_320(const void* x, void* y, long M, int n_img, int H, int W, const void* wp, int dtype, hipStream_t st);
 
 template <typename T, int C, int NT, int HT, bool T2D, bool STATS, bool RING>
 static int launch_mlp_k(const T* x, T* y, long M, int n_img, int H, int W, const void* wp, const void* w1, const void* w2,
@@ -877,7 +927,9 @@ static int dispatch_pconv(const void* x, void* y, long M, int n_img, int H, int 
         return launch_mlp_persist<float, C, 2, HT, 2>(reinterpret_cast<const float*>(x), reinterpret_cast<float*>(y), M, n_img, H, W, wp, wp, wp, nullptr, nullptr, nullptr, st);
     }
   }
-  return 1;
+  // any other map: the one-shot kernel on flattened 64-pixel runs, stopped after the partial conv
+  if (dtype == LY_BF16) return launch_mlp_pconv1<__bf16, C, 1, HT, false>(reinterpret_cast<const __bf16*>(x), reinterpret_cast<__bf16*>(y), M, n_img, H, W, wp, st);
+  return launch_mlp_pconv1<float, C, 1, HT, false>(reinterpret_cast<const float*>(x), reinterpret_cast<float*>(y), M, n_img, H, W, wp, st);
 }
 
 template <int C, int HT, int NTMAX>

@@ -37,6 +37,9 @@ extern "C" int ly_mlpblock_pconv(const void* x, void* z, int n_img, int H, int W
     case 16: return dispatch_pconv<16, 2>(x, z, M, n_img, H, W, wp, dtype, st);
     case 24: return dispatch_pconv<24, 4>(x, z, M, n_img, H, W, wp, dtype, st);
     case 40: return dispatch_pconv<40, 2>(x, z, M, n_img, H, W, wp, dtype, st);
+    case 80: return ly_mlp_pconv_80(x, z, M, n_img, H, W, wp, dtype, st);
+    case 160: return ly_mlp_pconv_160(x, z, M, n_img, H, W, wp, dtype, st);
+    case 320: return ly_mlp_pconv_320(x, z, M, n_img, H, W, wp, dtype, st);
     default: return 1;
   }
 }

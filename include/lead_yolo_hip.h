@@ -261,6 +261,14 @@ int ly_unpatch(const void* g /*T*/, int n_img, int Ho, int Wo, int C, int ks, vo
 int ly_coordatt_gate_bwd(const void* dout /*T*/, int ldd, const void* x /*T*/, int ldx, int n_img, int H, int W, int C, const float* a_h,
                          const float* a_w, void* dx /*T*/, int lddx, float* da_h, float* da_w, int dtype, void* stream);
 int ly_pool_hw_bwd(const float* gp, int n_img, int H, int W, int C, void* dx /*T*/, int lddx, int accumulate, int dtype, void* stream);
+/* SPPF backward as a gather (no atomics, deterministic): ly_maxpool_arg stores, for every window of a k x k / s1 / pad k//2 max-pool over
+ * x [n, H, W, C] (row stride ldx), the tap index (0 .. k*k-1, row-major) of its first maximum — ATen's routing rule — as one byte per element
+ * (arg: row stride lda);  ly_maxpool_gather then computes  out[p] = d_own[p] + sum over the windows q containing p of
+ * [arg(q) == tap of p in q] * d_up[q]  (d_up: fp32 total gradient of the pooled map; d_own: T-typed direct gradient of the pool's input).
+ * Built for k = 5 (SPPF).                                                                                                             */
+int ly_maxpool_arg(const void* x /*T*/, int ldx, int n_img, int H, int W, int C, int k, unsigned char* arg, int lda, int dtype, void* stream);
+int ly_maxpool_gather(const unsigned char* arg, int lda, const float* d_up, int ldu, const void* d_own, int ldd, int own_dtype, int n_img, int H,
+                      int W, int C, int k, void* out, int ldo, int out_dtype, void* stream);
 /* MLPBlock backward, last step (models/common.py:1478-1482 under autograd): dx[r, c] = dy[r, c] + (c < c4 ? t[r, c] : g[r, c]) over dense
  * [rows, C] matrices (t: row stride ldt >= ceil4(c4)) — the residual + the 1x1's gradient, with the partial 3x3 conv's gradient in its channels. */
 int ly_mlp_dx(const void* dy /*T*/, const void* g /*T*/, const void* t /*T*/, int ldt, long rows, int C, int c4, void* dx /*T*/, int dtype, void* stream);

@@ -1128,3 +1128,114 @@ extern "C" int ly_mlp_dx(const void* dy, const void* g, const void* t, int ldt, 
   LY_LAUNCH_CHECK();
   return 0;
 }
+
+// -------------------------------------------------------------------------------------------------
+// SPPF backward without atomics (models/common.py:348-366, three chained k x k / s1 max-pools): the routing of every window — the tap
+// index of its first maximum in row-major scan order, ATen's rule — is computed ONCE for all levels (ly_maxpool_arg over the first 3c
+// channels of the [y | m(y) | m(m(y)) | m(m(m(y)))] buffer), then each level is a GATHER:
+//   dtot[p] = d_own[p] + sum over the k*k windows q that contain p of [arg(q) == tap of p in q] * d_up[q]
+// Deterministic, every output written once (the scatter version added with float atomics: 98 us per level).
+// -------------------------------------------------------------------------------------------------
+template <typename T, int K>
+__global__ __launch_bounds__(LY_THREADS) void ly_maxpool_arg_kernel(const T* __restrict__ x, int ldx, int n_img, int H, int W, int C,
+                                                                    unsigned char* __restrict__ arg, int lda) {
+  constexpr int r = K >> 1;
+  const int nc4 = C >> 2;
+  const long total = (long)n_img * H * W * nc4;
+  for (long i = (long)blockIdx.x * LY_THREADS + threadIdx.x; i < total; i += (long)gridDim.x * LY_THREADS) {
+    const long pix = i / nc4;
+    const int c = 4 * (int)(i - pix * nc4);
+    const long row = pix / W;
+    const int w = (int)(pix - row * W);
+    const long n = row / H;
+    const int h = (int)(row - n * H);
+    typename LyT<T>::R4 raw[K * K];
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) {
+      int yy = h - r + t / K, xx = w - r + t % K;
+      yy = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
+      xx = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+      raw[t] = ly_ldr4<T>(x + ((n * H + yy) * W + xx) * ldx + c);
+    }
+    f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int a[4] = {-1, -1, -1, -1};
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) {
+      const int yy = h - r + t / K, xx = w - r + t % K;
+      const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+      const f32x4 v = ly_r4_f32(raw[t]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (ok && (v[e] > best[e] || a[e] < 0)) { best[e] = v[e]; a[e] = t; }
+    }
+    *reinterpret_cast<unsigned*>(arg + pix * lda + c) = (unsigned)a[0] | ((unsigned)a[1] << 8) | ((unsigned)a[2] << 16) | ((unsigned)a[3] << 24);
+  }
+}
+
+template <typename TD, typename TO, int K>
+__global__ __launch_bounds__(LY_THREADS) void ly_maxpool_gather_kernel(const unsigned char* __restrict__ arg, int lda, const float* __restrict__ d_up, int ldu,
+                                                                       const TD* __restrict__ d_own, int ldd, int n_img, int H, int W, int C,
+                                                                       TO* __restrict__ out, int ldo) {
+  constexpr int r = K >> 1;
+  const int nc4 = C >> 2;
+  const long total = (long)n_img * H * W * nc4;
+  for (long i = (long)blockIdx.x * LY_THREADS + threadIdx.x; i < total; i += (long)gridDim.x * LY_THREADS) {
+    const long pix = i / nc4;
+    const int c = 4 * (int)(i - pix * nc4);
+    const long row = pix / W;
+    const int w = (int)(pix - row * W);
+    const long n = row / H;
+    const int h = (int)(row - n * H);
+    unsigned av[K * K];
+    f32x4 dv[K * K];
+    // window q = (h - (ty - r), w - (tx - r)) sees this pixel as its tap t = ty*K + tx; all loads first, from clamped coordinates
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) {
+      int qy = h - (t / K - r), qx = w - (t % K - r);
+      qy = qy < 0 ? 0 : (qy >= H ? H - 1 : qy);
+      qx = qx < 0 ? 0 : (qx >= W ? W - 1 : qx);
+      const long q = (n * H + qy) * W + qx;
+      av[t] = *reinterpret_cast<const unsigned*>(arg + q * lda + c);
+      dv[t] = ly_ldg4(d_up + q * ldu + c);
+    }
+    f32x4 s = ly_ld4<TD>(d_own + pix * ldd + c);
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) {
+      const int qy = h - (t / K - r), qx = w - (t % K - r);
+      const bool ok = qy >= 0 && qy < H && qx >= 0 && qx < W;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (ok && ((av[t] >> (8 * e)) & 255u) == (unsigned)t) s[e] += dv[t][e];
+    }
+    ly_st4<TO>(out + pix * ldo + c, s);
+  }
+}
+
+extern "C" int ly_maxpool_arg(const void* x, int ldx, int n_img, int H, int W, int C, int k, unsigned char* arg, int lda, int dtype, void* stream) {
+  LY_CHECK_DTYPE(dtype, "maxpool_arg");
+  LY_CHECK(x && arg && n_img > 0 && H > 0 && W > 0 && k == 5, "maxpool_arg: bad arguments (built for k = 5, SPPF)");
+  LY_CHECK((C & 3) == 0 && (ldx & 3) == 0 && (lda & 3) == 0, "maxpool_arg: C / ld must be multiples of 4");
+  LY_WITH_T(dtype, hipLaunchKernelGGL((ly_maxpool_arg_kernel<T, 5>), dim3((unsigned)ly_ew_blocks((long)n_img * H * W * (C >> 2))), dim3(LY_THREADS), 0,
+                                      reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const T*>(x), ldx, n_img, H, W, C, arg, lda));
+  LY_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ly_maxpool_gather(const unsigned char* arg, int lda, const float* d_up, int ldu, const void* d_own, int ldd, int own_dtype, int n_img, int H,
+                                 int W, int C, int k, void* out, int ldo, int out_dtype, void* stream) {
+  LY_CHECK_DTYPE(own_dtype, "maxpool_gather");
+  LY_CHECK_DTYPE(out_dtype, "maxpool_gather");
+  LY_CHECK(arg && d_up && d_own && out && n_img > 0 && H > 0 && W > 0 && k == 5, "maxpool_gather: bad arguments (built for k = 5, SPPF)");
+  LY_CHECK((C & 3) == 0 && (lda & 3) == 0 && (ldu & 3) == 0 && (ldd & 3) == 0 && (ldo & 3) == 0, "maxpool_gather: C / ld must be multiples of 4");
+  const dim3 grid((unsigned)ly_ew_blocks((long)n_img * H * W * (C >> 2)));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define LY_MPG(TD, TO) hipLaunchKernelGGL((ly_maxpool_gather_kernel<TD, TO, 5>), grid, dim3(LY_THREADS), 0, st, arg, lda, d_up, ldu, reinterpret_cast<const TD*>(d_own), ldd, \
+                                          n_img, H, W, C, reinterpret_cast<TO*>(out), ldo)
+  if (own_dtype == LY_BF16 && out_dtype == LY_BF16) LY_MPG(__bf16, __bf16);
+  else if (own_dtype == LY_BF16) LY_MPG(__bf16, float);
+  else if (out_dtype == LY_BF16) LY_MPG(float, __bf16);
+  else LY_MPG(float, float);
+#undef LY_MPG
+  LY_LAUNCH_CHECK();
+  return 0;
+}

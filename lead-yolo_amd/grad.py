@@ -13,6 +13,8 @@ Scheme for every conv -> BN -> act unit (v = a*u + b with the BATCH statistics, 
     4. dgrad: forward kernel on du with transposed weights;  wgrad: ly_wgrad (pixel contraction)
 Only [C]-sized vectors are handled with torch ops (coefficients of step 3, parameter-gradient reshapes).
 """
+import ctypes
+
 import torch
 
 from . import ops, pack
@@ -555,10 +557,28 @@ class SppfPool(torch.autograd.Function):
         buf, = ctx.saved_tensors
         n, c4, h, w = buf.shape
         c = c4 // 4
-        acc = _rows_dense(d).float() if d.dtype != torch.float32 else _rows_dense(d).clone()   # fp32 accumulator (float atomics)
-        for j in (2, 1, 0):                           # m(y_j) = y_{j+1}: add its gradient into slot j
-            ops.maxpool_bwd(buf, j * c, c4, acc, (j + 1) * c, c4, n, h, w, c, ctx.k, acc, j * c, c4)
-        return acc[:, :c].to(buf.dtype), None
+        k = ctx.k
+        if k != 5 or c % 4 != 0:
+            acc = _rows_dense(d).float() if d.dtype != torch.float32 else _rows_dense(d).clone()   # fp32 accumulator (float atomics)
+            for j in (2, 1, 0):                           # m(y_j) = y_{j+1}: add its gradient into slot j
+                ops.maxpool_bwd(buf, j * c, c4, acc, (j + 1) * c, c4, n, h, w, c, k, acc, j * c, c4)
+            return acc[:, :c].to(buf.dtype), None
+        # gather formulation (no atomics): the routing of all three pools in one launch, then level by level
+        L = _lib()
+        st = L.stream_ptr()
+        dd = _rows_dense(d)
+        at = lambda t, off: ctypes.c_void_p(t.data_ptr() + t.element_size() * off)
+        arg = torch.empty((n * h * w, 3 * c), dtype=torch.uint8, device=buf.device)
+        L.check(L.lib().ly_maxpool_arg(L.ptr(buf), c4, n, h, w, 3 * c, k, L.ptr(arg), 3 * c, L.dtype_code(buf), st), "ly_maxpool_arg")
+        up = dd[:, 3 * c:].float().contiguous(memory_format=torch.channels_last)            # total gradient of y3 = its direct gradient
+        tmp = [torch.empty((n * h * w, c), dtype=torch.float32, device=buf.device) for _ in range(2)]
+        out = ops.empty_nhwc(n, c, h, w, buf)
+        up_p, up_ld = ops.rows(up)
+        for j in (2, 1, 0):
+            dst = out if j == 0 else tmp[j & 1]
+            L.check(L.lib().ly_maxpool_gather(at(arg, j * c), 3 * c, L.ptr(up_p) if j == 2 else L.ptr(tmp[(j + 1) & 1]), c, at(dd, j * c), c4, L.dtype_code(dd),
+                                              n, h, w, c, k, L.ptr(dst), c, L.dtype_code(dst), st), "ly_maxpool_gather")
+        return out, None
 
 
 # --------------------------------------------------------------------------------------------------

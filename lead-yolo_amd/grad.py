@@ -88,13 +88,14 @@ def _conv_forward(spec, x0, x1, wp, e_scale, e_shift, act, stats=None, out=None,
 
 
 
-def affine_backward(dy, u, a, b, act, mean, invstd, train, inplace=True, gamma=None, beta=None):
+def affine_backward(dy, u, a, b, act, mean, invstd, train, inplace=True, gamma=None, beta=None, lddy=None):
     """du and (dgamma, dbeta) for v = a*u + b, y = act(v); dy/u are NHWC-dense [n, c, h, w].  du is written over u unless
     inplace=False (u is a tensor saved for backward).  gamma / beta: the BatchNorm parameters — when a gradient sink holds their
     storage (ops.GradSink) dgamma / dbeta are added there by the coefficient kernel and returned as None."""
     n, c, h, w = u.shape
     rows = n * h * w
-    sums = ops.bnact_bwd_reduce(dy, c, u, c, rows, c, a, b, act)
+    lddy = c if lddy is None else lddy          # dy may be a channel slice of a wider gradient (row stride lddy), read in place
+    sums = ops.bnact_bwd_reduce(dy, lddy, u, c, rows, c, a, b, act)
     tg, tb = ops.grad_target(gamma), ops.grad_target(beta)
     direct = tg is not None and tb is not None and tg.numel() == c and tb.numel() == c
     dgamma, dbeta, alpha, kappa, lam = ops.bn_bwd_coeffs(sums, c, rows, a, mean, invstd, train, dgamma=tg if direct else None,
@@ -103,7 +104,7 @@ def affine_backward(dy, u, a, b, act, mean, invstd, train, inplace=True, gamma=N
         ops.grad_done(gamma)
         ops.grad_done(beta)
     du = u if inplace else torch.empty_like(u)
-    ops.bnact_bwd_apply(dy, c, u, c, rows, c, a, b, act, alpha, kappa, lam, du, c)
+    ops.bnact_bwd_apply(dy, lddy, u, c, rows, c, a, b, act, alpha, kappa, lam, du, c)
     return du, dgamma, dbeta
 
 
@@ -270,7 +271,12 @@ class ConvBnAct(torch.autograd.Function):
         need = ctx.needs_input_grad          # (spec, wp, x0, x1, weight, bias, gamma, beta)
         with torch.no_grad():
             odt = spec.out_dtype or x0.dtype
-            dy = _rows_dense(dy if dy.dtype == odt else dy.to(odt))
+            dy = dy if dy.dtype == odt else dy.to(odt)
+            lddy = None
+            if spec.bn is not None or spec.act != ACT_NONE:
+                dy, lddy = ops.rows(dy)              # the BN / activation backward reads a channel slice of a wider gradient in place
+            else:
+                dy = _rows_dense(dy)
             dgamma = dbeta = dbias = None
             if spec.bn is not None or spec.act != ACT_NONE:
                 # pre-BN value: kept by the forward (train-mode BN) or recomputed (conv + bias)
@@ -281,7 +287,7 @@ class ConvBnAct(torch.autograd.Function):
                     mean, invstd = b, a
                 du, dgamma, dbeta = affine_backward(dy, u, a, b, spec.act, mean, invstd, spec.bn is not None and spec.bn_train,
                                                     inplace=u_saved is None, gamma=g_param if spec.bn is not None else None,
-                                                    beta=b_param if spec.bn is not None else None)
+                                                    beta=b_param if spec.bn is not None else None, lddy=lddy)
                 if bias_f is not None:
                     if spec.bn is None:
                         dbias, dgamma, dbeta = dbeta, None, None
@@ -495,7 +501,8 @@ class CoordAttFn(torch.autograd.Function):
         xr, ld = ops.rows(t)
         n, c, h, w = xr.shape
         w1, b1, gamma, beta, wh, bh, ww, bw = ctx.params
-        dx, da_h, da_w = ops.coordatt_gate_bwd(_rows_dense(dout if dout.dtype == xr.dtype else dout.to(xr.dtype)), xr, ld, n, h, w, c, a_h, a_w)
+        dr, ldd = ops.rows(dout if dout.dtype == xr.dtype else dout.to(xr.dtype))          # a channel slice of a wider gradient: read in place
+        dx, da_h, da_w = ops.coordatt_gate_bwd(dr, xr, ld, n, h, w, c, a_h, a_w, ldd=ldd)
         targets, ret = [], []
         for i, p in enumerate(ctx.params):                    # accumulate into the persistent gradient storage where there is one
             if i == 1:                                        # conv1.bias: bn1 removes the batch mean, d/dbias == 0 (nothing to add)

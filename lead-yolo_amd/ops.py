@@ -687,12 +687,14 @@ def unpatch(g, n, ho, wo, c, ks, h, w):
     return dx
 
 
-def coordatt_gate_bwd(dout, x, ldx, n, h, w, c, a_h, a_w):
-    dx = empty_nhwc(n, c, h, w, dout)
+def coordatt_gate_bwd(dout, x, ldx, n, h, w, c, a_h, a_w, ldd=None):
+    """dout: rows of the incoming gradient with row stride ldd (default c: dense) — a channel slice of a wider gradient is read in place"""
+    ldd = c if ldd is None else ldd
+    dx = empty_nhwc(n, c, h, w, x)
     da = zeros_f32(n * (h + w) * c, dout.device)
     da_h, da_w = da[:n * h * c].view(n, h, c), da[n * h * c:].view(n, w, c)
     with _Timed(f"ly_coordatt_gate_bwd_kernel<{_tname(x)}>", 6.0 * n * h * w * c, 3.0 * x.element_size() * n * h * w * c):
-        capi.check(capi.lib().ly_coordatt_gate_bwd(_p(dout), c, _p(x), ldx, n, h, w, c, _p(a_h), _p(a_w), _p(dx), c, _p(da_h), _p(da_w),
+        capi.check(capi.lib().ly_coordatt_gate_bwd(_p(dout), ldd, _p(x), ldx, n, h, w, c, _p(a_h), _p(a_w), _p(dx), c, _p(da_h), _p(da_w),
                                                    capi.dtype_code(x), capi.stream_ptr()), "ly_coordatt_gate_bwd")
     return dx, da_h, da_w
 

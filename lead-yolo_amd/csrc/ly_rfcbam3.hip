@@ -243,17 +243,19 @@ __device__ __forceinline__ void ly_rfcbam3_body(const LyRfcbam3Params& P, const 
       const int py = pl / TW, px = pl - py * TW;
       const int yy = oy0 + py, xx = ox0 + px;
       if (py >= TH || yy >= P.Ho || xx >= P.Wo) continue;
-      if (P.stats) {                 // conv.1 BatchNorm statistics pass: pre-BN value, nothing stored
-        f32x4 u;
+      f32x4 v;
+      if (P.stats) {                 // conv.1 BatchNorm statistics pass: sums of the pre-BN value; with `out` it is stored as well (one
+        f32x4 u;                     // contraction in training: y = relu(bn(u)) is then an elementwise pass and u is what the backward needs)
 #pragma unroll
         for (int r = 0; r < 4; ++r) u[r] = acc[t][j][r] * sc[r] + sh[r];
         s1 += u;
         s2 += u * u;
-        continue;
-      }
-      f32x4 v;
+        if (!out) continue;
+        v = u;
+      } else {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[t][j][r] * sc[r] + sh[r], lin_floor);
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[t][j][r] * sc[r] + sh[r], lin_floor);
+      }
       T* o = out + (((long)n * P.Ho + yy) * P.Wo + xx) * P.ldo + c;
       if ((P.ldo & 3) == 0 && c + 3 < P.N) {
         ly_st4<T>(o, v);

@@ -629,11 +629,14 @@ class RfcbamFn(torch.autograd.Function):
             rfa = ops.rfa_map(mm, P["w18"])
             kw = dict(M=n * h * w, H=h, W=w, K=c, N=o, a0=xr, lda0=ld, k0=c, wp=P["wp"], ldo=o, pro=ops.PRO_AFFINE_RELU_CA,
                       p_scale=a1, p_shift=gb, p_ca=ca, rowscale=rfa)
+            # ONE contraction: statistics and the pre-BN value u (bias included) in the same launch; y = relu(es*u + t) is an elementwise
+            # pass and u is kept for the backward (was: statistics pass + main pass + a recompute in backward)
             stats = ops.new_stats(o, xr.device)
-            ops.gemm(out=None, e_scale=None, e_shift=bias, stats=stats, **kw)
+            u = ops.empty_nhwc(n, o, h, w, xr)
+            ops.gemm(out=u, e_scale=None, e_shift=bias, stats=stats, **kw)
             es, t, omean, oinv = ops.bn_finalize(mod.conv[1], stats, o, n * h * w, want_stats=True)
-            out = ops.empty_nhwc(n, o, h, w, xr)
-            ops.gemm(out=out, e_scale=es, e_shift=(bias * es + t).contiguous(), act=ACT_RELU, **kw)
+            out = torch.empty_like(u)
+            ops.bnact_fwd(u, o, n * h * w, o, es, t, ACT_RELU, out, o)
             ctx.fwd = dict(kw=kw)
         else:
             th, tw = ops.pick_tile(ho, wo)
@@ -642,21 +645,22 @@ class RfcbamFn(torch.autograd.Function):
             rfa = ops.rfa_map(mm, P["w18"])
             kw = dict(n=n, h=h, w=w, c=c, ho=ho, wo=wo, N=o, s=s, th=th, tw=tw, x=xr, ldx=ld, wg=wq_main, ca=ca, rfa=rfa, wp=P["wp"], ldo=o)
             stats = ops.new_stats(o, xr.device)
-            ops.rfcbam3(out=None, e_scale=torch.ones_like(bias), e_shift=bias, stats=stats, **kw)
+            u = ops.empty_nhwc(n, o, ho, wo, xr)
+            ops.rfcbam3(out=u, e_scale=torch.ones_like(bias), e_shift=bias, stats=stats, **kw)      # one contraction (see k = 1)
             es, t, omean, oinv = ops.bn_finalize(mod.conv[1], stats, o, n * ho * wo, want_stats=True)
-            out = ops.empty_nhwc(n, o, ho, wo, xr)
-            ops.rfcbam3(out=out, e_scale=es, e_shift=(bias * es + t).contiguous(), **kw)
+            out = torch.empty_like(u)
+            ops.bnact_fwd(u, o, n * ho * wo, o, es, t, ACT_RELU, out, o)
             ctx.fwd = dict(kw=kw)
         ctx.geom = (n, c, h, w, k, s, o, ho, wo, ld)
         ctx.conv_w_param = conv_w
         ctx.se_params = (se_wa, se_wb)
         ctx.conv_b_param = conv_b
-        ctx.save_for_backward(xr, ca, gen_w, getw, conv_w, bias, G["ag"], G["bg"], G["gmean_tc"], G["ginv_tc"], es, t, omean, oinv, mm, rfa, se_part)
+        ctx.save_for_backward(xr, ca, gen_w, getw, conv_w, bias, G["ag"], G["bg"], G["gmean_tc"], G["ginv_tc"], es, t, omean, oinv, mm, rfa, se_part, u)
         return out
 
     @staticmethod
     def backward(ctx, dy):
-        xr, ca, gen_w, getw, conv_w, bias, ag, bg, gmean_tc, ginv_tc, es, t, omean, oinv, mm, rfa, se_part = ctx.saved_tensors
+        xr, ca, gen_w, getw, conv_w, bias, ag, bg, gmean_tc, ginv_tc, es, t, omean, oinv, mm, rfa, se_part, u = ctx.saved_tensors
         n, c, h, w, k, s, o, ho, wo, ld = ctx.geom
         kk = k * k
         mo = n * ho * wo
@@ -669,14 +673,10 @@ class RfcbamFn(torch.autograd.Function):
             pl = ops.planes_of(xr)
             code = L.dtype_code(xr)
             dy = _rows_dense(dy if dy.dtype == dt else dy.to(dt))
-            # 1-2. output conv: recompute pre-BN value (bias included), BN + ReLU backward
-            u = ops.empty_nhwc(n, o, ho, wo, xr)
-            if k == 1:
-                ops.gemm(out=u, e_scale=None, e_shift=bias, **ctx.fwd["kw"])
-            else:
-                ops.rfcbam3(out=u, e_scale=torch.ones_like(bias), e_shift=bias, linear=True, **ctx.fwd["kw"])
+            # 1-2. output conv: the pre-BN value u (bias included) was kept by the forward; BN + ReLU backward (du is written over a copy
+            # of u: saved tensors must stay intact for a second backward through the graph)
             _tap("rf.dy", dy); _tap("rf.u", u)
-            du, dgo, dbo = affine_backward(dy, u, es, t, ACT_RELU, omean, oinv, True)
+            du, dgo, dbo = affine_backward(dy, u, es, t, ACT_RELU, omean, oinv, True, inplace=False)
             _tap("rf.du", du)
             # 3. dcd [mo][t][c]
             # Wc^T with rows (t, c): conv.0.weight [o, c, kh, kw] read in place

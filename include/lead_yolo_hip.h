@@ -167,7 +167,8 @@ typedef struct LyRfcbam3Params {
   const void* wp;              /* frag_pack3(conv.0.weight as [N, C/16, 144 -> 160 zero padded])  */
   const float* e_scale; const float* e_shift;   /* conv.1 BN folded with conv.0.bias              */
   void* out; int ldo;          /* T */
-  float* stats;                /* NULL or [2N] accumulators: conv.1 BatchNorm statistics pass    */
+  float* stats;                /* NULL or [2N] accumulators: conv.1 BatchNorm statistics pass (sums of e_scale*acc + e_shift);
+                                  with out != NULL that pre-BN value is stored as well (one contraction in training)  */
   int linear;                  /* != 0: store the affine value without the ReLU (backward recompute) */
   int dtype;                   /* LY_F32 / LY_BF16 */
 } LyRfcbam3Params;

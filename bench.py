@@ -403,7 +403,7 @@ def run_forward(args, ctx, batch=None, steps=None, warmup=None, repeats=None):
         regions = timed_repeats(ctx, step, steps or args.steps, args.warmup if warmup is None else warmup, repeats or args.repeats)
     return dict(regions=regions, model=model, x=x, launch=launch, batch=batch,
                 step=lambda: model(x),
-                workload=f"lead-yolo-{args.scale} bs={batch}/gpu 3x{args.size}x{args.size} {args.dtype} eval forward (BASELINE.json configs[1]); "
+                workload=f"lead-yolo-{args.scale} bs={batch}/gpu 3x{args.size}x{args.size} {args.dtype} eval forward (BASELINE.json configs[1]" + ("" if args.dtype == "f32" else " shape in bf16") + "); "
                          "random-init weights, perturbed BN stats",
                 parallelism=f"dp{ctx.world} (independent replicas, no data-path collective)", metric="images/sec (640x640) forward")
 
@@ -429,7 +429,8 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 64 for train, 32 for forward)")
     ap.add_argument("--scale", default="s")
     ap.add_argument("--size", type=int, default=640)
-    ap.add_argument("--dtype", default="f32", choices=("f32", "bf16"), help="activation storage / product precision")
+    ap.add_argument("--dtype", default=None, choices=("f32", "bf16"),
+                    help="activation storage / product precision; default: bf16 for the train step (BASELINE.json configs[2]), f32 for --mode forward (configs[1])")
     ap.add_argument("--mode", default="train", choices=("train", "forward"),
                     help="train (default): the BASELINE metric, full optimisation step; forward: eval forward of configs[1]")
     ap.add_argument("--train", action="store_true", help="alias of --mode train")
@@ -443,6 +444,8 @@ def main():
         args.mode = "train"
     if args.batch is None:
         args.batch = 64 if args.mode == "train" else 32
+    if args.dtype is None:                       # the precision BASELINE.json quotes each configuration in
+        args.dtype = "bf16" if args.mode == "train" else "f32"
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args.gpus))

@@ -213,6 +213,18 @@ int ly_rfcbam_gen_prepare(const float* mom, int C, int k, const float* gen_w, co
                           float momentum, double count, float* running_mean, float* running_var, long* nbt, float* out8, float* a1,
                           float* wq_stats, float* wq_main, void* stream);
 
+/* ---- eval tail: non_max_suppression on the device (utils/general.py:884-994; detect.py:149, val.py:230-234) --------------------------
+ * pred [bs, N, no = 5 + nc] fp32 (xywh, obj, class confidences: Detect's inference output).
+ * ly_nms_candidates: score[b, i] = obj * best class confidence when obj > conf_thres, that product > conf_thres and the class is allowed
+ *   (class_mask bit c, 0 = every class), else -1;  det[b, i] = (x1, y1, x2, y2, conf, cls).
+ * The caller sorts score per image, descending and stable, and passes the sorted values + permutation to
+ * ly_nms_greedy: greedy NMS over the sorted candidates (IoU > iou_thres with a kept box drops a box; boxes are offset by cls * max_wh,
+ *   max_wh = 0 for class-agnostic NMS), at most max_nms candidates, at most max_det kept: keep[b, 0:count[b]] = indices into N.        */
+int ly_nms_candidates(const float* pred, int bs, int N, int no, float conf_thres, unsigned long long class_mask, float* score, float* det,
+                      void* stream);
+int ly_nms_greedy(const float* det, const long* order, const float* sorted_score, int bs, int N, float iou_thres, float max_wh, int max_det,
+                  int max_nms, int* keep, int* count, void* stream);
+
 /* ---- backward building blocks of the training step (train.py:324 `scaler.scale(loss).backward()`) -------------
  * Data gradients of 1x1 / 3x3 stride-1 convolutions reuse ly_gemm_fwd / ly_conv3x3_fwd with transposed weights.   */
 

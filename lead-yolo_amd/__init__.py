@@ -10,3 +10,4 @@ from .ddp import GradReducer  # noqa: F401
 from .train import GraphedTrainStep, ModelEMA, forward_backward, optimizer_step, smart_optimizer, train_step  # noqa: F401
 from .optim import FusedSGD  # noqa: F401
 from .graph import GraphedForward  # noqa: F401
+from .nms import nms_padded, non_max_suppression  # noqa: F401,E402

@@ -187,6 +187,9 @@ int ly_sppf_pool(const void* x /*T*/, int ldx, int n_img, int H, int W, int C, i
  * anchors = [na,2] in grid units (Detect.anchors[i]), stride = Detect.stride[i].                     */
 int ly_detect_tail(const void* y /*T*/, int ldy, int n_img, int H, int W, int na, int no, const float* anchors, float stride,
                    float* p, float* z, long zrows, long zoff, int dtype, void* stream);
+/* Adjoint of that permute for the training step (models/yolo.py:88): dp fp32 [n, na, H, W, no] -> du rows [n*H*W][ldu] of T (column a*no+o;
+ * columns >= na*no written as zero: the operand of the head's dgrad / wgrad), dbias[a*no+o] += sum over pixels.  W <= 160, na*no <= ldu <= 32. */
+int ly_detect_head_bwd(const float* dp, int n_img, int H, int W, int na, int no, void* du /*T*/, int ldu, float* dbias, int dtype, void* stream);
 
 
 /* ---- train-mode BatchNorm statistics passes ----------------------------------------------------- */
@@ -267,6 +270,10 @@ int ly_wgrad(const LyWgradParams* p, void* stream);
 int ly_up2_bwd(const void* d /*T*/, int ldd, int n_img, int Hs, int Ws, int C, void* out /*T*/, int ldo, int dtype, void* stream);
 /* Adjoint of the k = s patch gather: g[m][(ky,kx,c)] -> dx[n, ks*ho+ky, ks*wo+kx, c] (dense NHWC, C % 4 == 0).    */
 int ly_unpatch(const void* g /*T*/, int n_img, int Ho, int Wo, int C, int ks, void* dx /*T*/, int dtype, void* stream);
+/* Space-to-depth of the uint8 NCHW image [n, C, H, W] (H, W multiples of 4) for PatchEmbed's weight gradient (models/common.py:1537-1550,
+ * the `imgs` of train.py:309 before `.float() / 255`): rows[m][c*16 + ky*4 + kx] = (T)img[n, c, 4*ho+ky, 4*wo+kx], m = (n*Ho + ho)*Wo + wo.
+ * Integer values (exact in bf16); the caller scales the weight gradient by 1/255.                                                          */
+int ly_patch4_rows_u8(const unsigned char* img, int n_img, int C, int H, int W, void* rows /*T [n*H/4*W/4][16*C]*/, int dtype, void* stream);
 
 /* CoordAtt backward (models/common.py:1595-1609).  Gate out = x*a_h[n,h,:]*a_w[n,w,:]:
  *   dx = dout*a_h*a_w,  da_h[n,h,c] += sum_w dout*x*a_w,  da_w[n,w,c] += sum_h dout*x*a_h  (caller zeroes both).

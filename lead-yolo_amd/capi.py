@@ -101,6 +101,7 @@ SIGNATURES = {
     "ly_wgrad": [ctypes.POINTER(LyWgradParams), _P],
     "ly_up2_bwd": [_P, _I, _I, _I, _I, _I, _P, _I, _I, _P],
     "ly_unpatch": [_P, _I, _I, _I, _I, _I, _P, _I, _P],
+    "ly_patch4_rows_u8": [_P, _I, _I, _I, _I, _P, _I, _P],
     "ly_coordatt_gate_bwd": [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _I, _P],
     "ly_pool_hw_bwd": [_P, _I, _I, _I, _I, _P, _I, _I, _I, _P],
     "ly_maxpool_bwd": [_P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P],
@@ -123,6 +124,7 @@ SIGNATURES = {
     "ly_loss_level": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P, _I, _P],
     "ly_loss_finish": [_P, _I, _P, _P, _F, _F, _I, _P, _P],
     "ly_detect_tail": [_P, _I, _I, _I, _I, _I, _I, _P, _F, _P, _P, _L, _L, _I, _P],
+    "ly_detect_head_bwd": [_P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P],
     "ly_pack_table": [_P, _P, _I, _P],
     "ly_optim_step": [_P, _P, _P, _I, _P, _P, _P, _P],
 }

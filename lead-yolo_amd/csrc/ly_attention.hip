@@ -726,6 +726,64 @@ extern "C" int ly_detect_tail(const void* y, int ldy, int n_img, int H, int W, i
   return 0;
 }
 
+// Adjoint of the raw-map permute above for the training step (models/yolo.py:88 `x[i].view(bs, na, no, ny, nx).permute(0, 1, 3, 4, 2)`):
+// dp fp32 [n, na, H, W, no] -> du rows [n*H*W][ldu] of T (columns a*no + o, columns >= na*no zero: the operand of the head's dgrad /
+// wgrad contractions), and dbias[a*no + o] += sum over pixels.  One launch instead of autograd's cast + two layout copies + zero-padded
+// copy + a reduction.  A block walks (image, row) pairs: the na runs of W*no contiguous floats are staged in LDS, written back as
+// whole rows, and the column sums are kept in registers until one atomic per column and block.
+#define LY_DH_MAXW 160
+#define LY_DH_MAXLD 32
+template <typename T>
+__global__ __launch_bounds__(LY_THREADS) void ly_detect_head_bwd_kernel(const float* __restrict__ dp, int n_img, int H, int W, int na, int no,
+                                                                        T* __restrict__ du, int ldu, float* __restrict__ dbias) {
+  __shared__ float tile[LY_DH_MAXW * (LY_DH_MAXLD + 1)];
+  __shared__ float red[LY_THREADS];
+  const int tid = threadIdx.x, co = na * no, LT = ldu + 1;
+  const int col = tid & 31, part = tid >> 5;              // column sums: 8 row classes x 32 columns
+  float bsum = 0.f;
+  for (int i = tid; i < W * LT; i += LY_THREADS) tile[i] = 0.f;      // pad columns stay zero
+  const long rows_total = (long)n_img * H;
+  const int run = W * no;
+  for (long r = blockIdx.x; r < rows_total; r += gridDim.x) {
+    const long n = r / H;
+    const int h = (int)(r - n * H);
+    __syncthreads();
+    for (int e = tid; e < na * run; e += LY_THREADS) {
+      const int a = e / run, q = e - a * run;
+      const int w = q / no, o = q - w * no;
+      tile[w * LT + a * no + o] = dp[(((n * na + a) * H + h) * (long)W) * no + q];
+    }
+    __syncthreads();
+    T* const out = du + r * (long)W * ldu;
+    for (int e = tid; e < W * ldu; e += LY_THREADS) {
+      const int w = e / ldu, c = e - w * ldu;
+      out[e] = (T)tile[w * LT + c];
+    }
+    if (col < co)
+      for (int w = part; w < W; w += LY_THREADS / 32) bsum += tile[w * LT + col];
+  }
+  red[tid] = bsum;
+  __syncthreads();
+  if (tid < 32 && tid < co) {
+    float s = 0.f;
+    for (int g = 0; g < LY_THREADS / 32; ++g) s += red[g * 32 + tid];
+    atomicAdd(dbias + tid, s);
+  }
+}
+
+extern "C" int ly_detect_head_bwd(const float* dp, int n_img, int H, int W, int na, int no, void* du, int ldu, float* dbias, int dtype, void* stream) {
+  LY_CHECK_DTYPE(dtype, "detect_head_bwd");
+  LY_CHECK(dp && du && dbias && n_img > 0 && H > 0 && W > 0 && na > 0 && no > 0, "detect_head_bwd: bad arguments");
+  LY_CHECK(W <= LY_DH_MAXW && ldu <= LY_DH_MAXLD && na * no <= ldu, "detect_head_bwd: W=%d (max %d) / ldu=%d (max %d, >= na*no=%d) out of range", W,
+           LY_DH_MAXW, ldu, LY_DH_MAXLD, na * no);
+  long blocks = (long)n_img * H;
+  if (blocks > 1024) blocks = 1024;
+  LY_WITH_T(dtype, hipLaunchKernelGGL(ly_detect_head_bwd_kernel<T>, dim3((unsigned)blocks), dim3(LY_THREADS), 0, reinterpret_cast<hipStream_t>(stream), dp,
+                                      n_img, H, W, na, no, reinterpret_cast<T*>(du), ldu, dbias));
+  LY_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Train-mode BatchNorm support kernels (statistics passes; normalisation itself is folded into the
 // consumers' scale/shift exactly like the eval path)

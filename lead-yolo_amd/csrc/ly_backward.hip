@@ -700,6 +700,52 @@ extern "C" int ly_unpatch(const void* g, int n_img, int Ho, int Wo, int C, int k
 }
 
 // -------------------------------------------------------------------------------------------------
+// Space-to-depth of the uint8 NCHW image for PatchEmbed's weight gradient (models/common.py:1537-1550, k = s = 4): rows[m][(c, ky, kx)]
+// = the integer pixel values as T (exact in bf16), so that ly_wgrad contracts plain rows; the caller applies 1/255 to the small dw.
+// Block = 64 patches of one patch row: coalesced 4-byte loads (the 4 kx of a patch) staged through LDS, 16-byte row stores
+// (was: a permuted torch copy + a cast, 250 us at bs=64 640x640; one pass at the copy rate now).
+// -------------------------------------------------------------------------------------------------
+#define LY_P4_WO 64
+template <typename T>
+__global__ __launch_bounds__(LY_THREADS) void ly_patch4_rows_u8_kernel(const unsigned char* __restrict__ img, int C, int H, int W, T* __restrict__ rows) {
+  extern __shared__ f32x4 ly_p4_smem[];
+  T* const tile = reinterpret_cast<T*>(ly_p4_smem);
+  const int Wo = W >> 2, Ho = H >> 2;
+  const int K = 16 * C, KP = K + 8;                       // padded LDS row
+  const int wo0 = blockIdx.x * LY_P4_WO;
+  const int n = blockIdx.y / Ho, ho = blockIdx.y - n * Ho;
+  const int nw = Wo - wo0 < LY_P4_WO ? Wo - wo0 : LY_P4_WO;
+  for (int i = threadIdx.x; i < 4 * C * LY_P4_WO; i += LY_THREADS) {
+    const int wl = i & (LY_P4_WO - 1), r = i / LY_P4_WO;  // r = c * 4 + ky
+    const int c = r >> 2, ky = r & 3;
+    const int wc = wl < nw ? wl : nw - 1;
+    const unsigned v = *reinterpret_cast<const unsigned*>(img + (((long)n * C + c) * H + 4 * ho + ky) * W + 4 * (wo0 + wc));
+    T* d = tile + wl * KP + 4 * r;
+    d[0] = (T)(float)(v & 255u); d[1] = (T)(float)((v >> 8) & 255u); d[2] = (T)(float)((v >> 16) & 255u); d[3] = (T)(float)(v >> 24);
+  }
+  __syncthreads();
+  constexpr int VE = 16 / sizeof(T);                       // elements per 16-byte store
+  const int vpr = K / VE;
+  T* const out = rows + ((long)blockIdx.y * Wo + wo0) * K;
+  for (int j = threadIdx.x; j < nw * vpr; j += LY_THREADS) {
+    const int wl = j / vpr, q = j - wl * vpr;
+    *reinterpret_cast<f32x4*>(out + (long)wl * K + q * VE) = *reinterpret_cast<const f32x4*>(tile + wl * KP + q * VE);
+  }
+}
+
+extern "C" int ly_patch4_rows_u8(const unsigned char* img, int n_img, int C, int H, int W, void* rows, int dtype, void* stream) {
+  LY_CHECK_DTYPE(dtype, "patch4_rows_u8");
+  LY_CHECK(img && rows && n_img > 0 && C > 0 && C <= 16 && H > 0 && W > 0 && (H & 3) == 0 && (W & 3) == 0, "patch4_rows_u8: bad arguments");
+  LY_CHECK(((uintptr_t)img & 3) == 0 && ((uintptr_t)rows & 15) == 0, "patch4_rows_u8: unaligned pointer");
+  LY_CHECK((long)n_img * (H >> 2) < 65536, "patch4_rows_u8: too many patch rows");
+  const dim3 grid((unsigned)(((W >> 2) + LY_P4_WO - 1) / LY_P4_WO), (unsigned)(n_img * (H >> 2)));
+  LY_WITH_T(dtype, hipLaunchKernelGGL(ly_patch4_rows_u8_kernel<T>, grid, dim3(LY_THREADS), (size_t)LY_P4_WO * (16 * C + 8) * sizeof(T),
+                                      reinterpret_cast<hipStream_t>(stream), img, C, H, W, reinterpret_cast<T*>(rows)));
+  LY_LAUNCH_CHECK();
+  return 0;
+}
+
+// -------------------------------------------------------------------------------------------------
 // CoordAtt (models/common.py:1595-1609) backward pieces.
 //   gate:  out = x * a_h[n,h,:] * a_w[n,w,:]
 //          dx = dout*a_h*a_w,  da_h[n,h,c] = sum_w dout*x*a_w,  da_w[n,w,c] = sum_h dout*x*a_h

@@ -144,8 +144,11 @@ def conv_wgrad(spec, du, x0, x1, weight):
             # A uint8 image (pixel / 255 folded into the forward gather) is contracted as the integers it holds — exact in bf16 —
             # and the 1/255 is applied to the small weight gradient instead of to the batch.
             u8 = x0.dtype == torch.uint8
-            xr = x0.reshape(n, c, ho, k, wo, k).permute(0, 2, 4, 1, 3, 5).reshape(m, c * k * k).to(du.dtype)
-            acc = torch.zeros(weight.shape, dtype=torch.float32, device=du.device) if u8 else dw
+            if u8 and k == 4 and x0.is_contiguous():
+                xr = ops.patch4_rows_u8(x0, du.dtype)                # one pass (was a permuted copy + a cast)
+            else:
+                xr = x0.reshape(n, c, ho, k, wo, k).permute(0, 2, 4, 1, 3, 5).reshape(m, c * k * k).to(du.dtype)
+            acc = ops.zeros_f32(weight.numel(), du.device).view(weight.shape) if u8 else dw
             ops.wgrad(M=m, H=ho, W=wo, N=co, du=du, lddu=co, x=xr, ldx=k * k * c, Hin=ho, Win=wo, Cin=k * k * c, dw=acc, lddw=k * k * c, n_valid=nv)
             if u8:
                 dw.add_(acc, alpha=1.0 / 255.0)
@@ -342,6 +345,67 @@ def conv_bn_act(spec, wp, x0, x1, weight, bias, bn):
     gamma = bn.weight if bn is not None else None
     beta = bn.bias if bn is not None else None
     return ConvBnAct.apply(spec, wp, x0, x1, weight, bias, gamma, beta)
+
+
+class DetectHeadFn(torch.autograd.Function):
+    """One Detect level in training (models/yolo.py:84-88): p = (conv1x1(x) + bias).view(bs, na, no, ny, nx).permute(0, 1, 3, 4, 2) as the
+    fp32 raw map the loss reads.  forward = the head contraction + ly_detect_tail (permute + conversion, one pass); backward = ONE kernel
+    from dp to the zero-padded rows the dgrad / wgrad contractions take, with the bias gradient summed on the way (autograd's chain for
+    the same thing: cast, two layout copies, zero-padded copy, a reduction — 8 launches per level)."""
+
+    MAXW, MAXLD = 160, 32           # ly_detect_head_bwd's LDS tile
+
+    @staticmethod
+    def forward(ctx, det, i, wp, x, weight, bias):
+        co = weight.shape[0]
+        spec = ConvSpec("pw", co)
+        bias_f = bias.detach().float().contiguous()
+        y = _conv_forward(spec, x, None, wp, None, bias_f, ACT_NONE)
+        bs, _, ny, nx = y.shape
+        p = torch.empty((bs, det.na, ny, nx, det.no), dtype=torch.float32, device=y.device)
+        ops.detect_tail(y, co, bs, ny, nx, det.na, det.no, det.anchors[i], 1.0, p, None, 0, 0)
+        ctx.spec, ctx.geom = spec, (bs, ny, nx, det.na, det.no)
+        ctx.params = (weight, bias)
+        ctx.save_for_backward(x, weight)
+        return p
+
+    @staticmethod
+    def backward(ctx, dp):
+        x, weight = ctx.saved_tensors
+        w_param, b_param = ctx.params
+        bs, ny, nx, na, no = ctx.geom
+        co = na * no
+        need = ctx.needs_input_grad          # (det, i, wp, x, weight, bias)
+        with torch.no_grad():
+            t0, _ = ops.rows(x)
+            vw = ops.vw_of(t0)
+            cq = (co + vw - 1) // vw * vw
+            dp = dp.float().contiguous()
+            tb = ops.grad_target(b_param)
+            dbias = tb if tb is not None else torch.zeros(co, dtype=torch.float32, device=dp.device)
+            du = torch.empty((bs, ny, nx, cq), dtype=t0.dtype, device=dp.device)
+            ops.detect_head_bwd(dp, bs, ny, nx, na, no, du, cq, dbias)
+            if tb is not None:
+                ops.grad_done(b_param)
+            du_d = du.permute(0, 3, 1, 2)
+            dw = conv_wgrad(ctx.spec, du_d, x, None, w_param) if need[4] else None
+            dx = None
+            if need[3]:
+                dx, _ = conv_dgrad(ConvSpec("pw", cq), du_d, weight, x, None, True, False)
+        return None, None, None, dx, dw, (None if tb is not None else dbias)
+
+
+def detect_head(det, i, wp, x, weight, bias):
+    """Detect level i in training -> fp32 raw map [bs, na, ny, nx, no]; the fused node when the map fits its kernel, else the generic
+    conv node + autograd's permute."""
+    co = weight.shape[0]
+    n, _, h, w = x.shape
+    if w <= DetectHeadFn.MAXW and (co + 7) // 8 * 8 <= DetectHeadFn.MAXLD and bias is not None:
+        return DetectHeadFn.apply(det, i, wp, x, weight, bias)
+    y = conv_bn_act(ConvSpec("pw", co), wp, x, None, weight, bias, None)
+    p = torch.empty((n, det.na, h, w, det.no), dtype=torch.float32, device=y.device)
+    p.copy_(y.view(n, det.na, det.no, h, w).permute(0, 1, 3, 4, 2))
+    return p
 
 
 # --------------------------------------------------------------------------------------------------
@@ -655,6 +719,7 @@ class RfcbamFn(torch.autograd.Function):
         ctx.conv_w_param = conv_w
         ctx.se_params = (se_wa, se_wb)
         ctx.conv_b_param = conv_b
+        ctx.getw_param = getw
         ctx.save_for_backward(xr, ca, gen_w, getw, conv_w, bias, G["ag"], G["bg"], G["gmean_tc"], G["ginv_tc"], es, t, omean, oinv, mm, rfa, se_part, u)
         return out
 
@@ -706,14 +771,18 @@ class RfcbamFn(torch.autograd.Function):
                 ops.grad_done(ctx.conv_w_param)
                 dwc = None
             else:
-                dwc = torch.zeros(o, kk * c, dtype=torch.float32, device=dev)
+                dwc = torch.zeros(o, kk * c, dtype=torch.float32, device=dev)      # handed to autograd (k = 1: as a view): not from the pool
                 ops.wgrad(M=mo, H=ho, W=wo, N=o, du=du, lddu=o, x=cd, ldx=kk * c, Hin=ho, Win=wo, Cin=kk * c, dw=dwc, lddw=kk * c)
                 dwc = dwc.view(o, kk, c).permute(0, 2, 1).reshape(conv_w.shape)
             # 7. get_weight + sigmoid
             w18 = getw.detach().float().reshape(18).contiguous()
             d_mm = torch.empty_like(mm)
-            dw18 = torch.zeros(18, dtype=torch.float32, device=dev)           # (a parameter gradient handed to autograd: not from the pool)
+            t18 = ops.grad_target(ctx.getw_param)
+            t18 = t18 if t18 is not None and t18.is_contiguous() else None
+            dw18 = t18.view(-1) if t18 is not None else torch.zeros(18, dtype=torch.float32, device=dev)   # (handed to autograd: not from the pool)
             L.check(L.lib().ly_rfa_bwd(p(d_rfa), p(rfa), p(mm), p(w18), n, k * ho, k * wo, p(d_mm), p(dw18), st), "ly_rfa_bwd")
+            if t18 is not None:
+                ops.grad_done(ctx.getw_param)
             # 8. through max/mean, ca, rfa and ReLU; generate-BN sums
             sums = ops.zeros_f32(2 * kk * c, dev)
             with ops._Timed(f"ly_rf_bwd_relu_kernel<{ops._tname(xr)}, {k}>", 8.0 * mo * kk * c, 3.0 * es9):
@@ -747,7 +816,7 @@ class RfcbamFn(torch.autograd.Function):
                     L.check(L.lib().ly_rf_bwd_dx(n, h, w, c, k, s, p(dcd), p(wg), p(dx), c, p(dgap), 1.0 / (h * w), code, st), "ly_rf_bwd_dx")
             dbias = None if ops.grad_target(ctx.conv_b_param) is not None else torch.zeros_like(bias)      # BN removes the batch mean: d/dbias = 0
         return (None, dx, None if se_direct else dwa, None if se_direct else dwb, dwg.sum(0).view(gen_w.shape), ct(dgg_tc), ct(dbg_tc),
-                dw18.view(getw.shape), dwc, dbias, dgo, dbo)
+                (None if t18 is not None else dw18.view(getw.shape)), dwc, dbias, dgo, dbo)
 
 
 def rfcbam_train(mod, x):

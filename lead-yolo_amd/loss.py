@@ -10,7 +10,7 @@ alone and reads its candidate buffers back (int64 indices bit-exact with the ref
 """
 import torch
 
-from . import capi
+from . import capi, ops
 
 DEFAULT_HYP = dict(box=0.05, cls=0.5, cls_pw=1.0, obj=1.0, obj_pw=1.0, anchor_t=4.0, fl_gamma=0.0, label_smoothing=0.0)
 
@@ -60,7 +60,7 @@ class ComputeLoss:
         cells = [int(p.shape[0] * p.shape[1] * p.shape[2] * p.shape[3]) for p in preds]
         k = self._consts(dev, cells)
         ncand = max(5 * na * nt, 1)
-        zero = torch.zeros(sum(cells) + 4 * nl, dtype=torch.float32, device=dev)           # tobj of every level + accumulators
+        zero = ops.zeros_f32(sum(cells) + 4 * nl, dev)                                       # tobj of every level + accumulators (step pool)
         winner = torch.full((sum(cells),), -1, dtype=torch.int32, device=dev)
         cand_cell = torch.empty((nl, ncand), dtype=torch.int64, device=dev)
         cand = torch.empty((nl, ncand, 5), dtype=torch.float32, device=dev)
@@ -69,7 +69,7 @@ class ComputeLoss:
         dps, off = [], 0
         st = capi.stream_ptr()
         for i, p in enumerate(preds):
-            dp = None if match_only else torch.zeros_like(p)
+            dp = None if match_only else ops.zeros_f32(p.numel(), dev).view(p.shape)      # read by the backward of the same step only
             _, _, ny, nx, no = p.shape
             capi.check(capi.lib().ly_loss_level(capi.ptr(p), capi.ptr(dp), capi.ptr(k["anchors"][i]), capi.ptr(targets), bs, na, ny, nx, no, nt,
                                                 float(self.hyp["anchor_t"]), float(self.hyp["box"]), float(self.hyp["obj"]), float(self.balance[i]),

@@ -960,13 +960,9 @@ class Detect(nn.Module):
                 t = x[i].materialize() if isinstance(x[i], Lazy) else x[i]
                 conv = self.m[i]
                 wp, _ = self._packed(i, ops.planes_of(t))
-                y = grad.conv_bn_act(grad.ConvSpec("pw", conv.out_channels), wp, t, None, conv.weight, conv.bias, None)
-                bs, _, ny, nx = y.shape
                 # raw maps go to the loss as fp32 whatever the storage dtype (the loss is fp32, as under the reference's autocast):
-                # the permuting copy and the conversion are one pass
-                p = torch.empty((bs, self.na, ny, nx, self.no), dtype=torch.float32, device=y.device)
-                p.copy_(y.view(bs, self.na, self.no, ny, nx).permute(0, 1, 3, 4, 2))
-                x[i] = p
+                # the permuting copy and the conversion are one pass, and so is their adjoint (grad.DetectHeadFn)
+                x[i] = grad.detect_head(self, i, wp, t, conv.weight, conv.bias)
             return x
         st = getattr(self, "_early", None)                      # levels already launched by Model._forward_once (side stream)
         self._early = None

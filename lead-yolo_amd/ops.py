@@ -374,6 +374,12 @@ def detect_tail(y, ldy, n, h, w, na, no, anchors, stride, p, z, zrows, zoff):
                                          capi.dtype_code(y), capi.stream_ptr()), "ly_detect_tail")
 
 
+def detect_head_bwd(dp, n, h, w, na, no, du, ldu, dbias):
+    """dp fp32 [n, na, h, w, no] -> du rows [n*h*w, ldu] (columns >= na*no zero), dbias[na*no] += column sums"""
+    capi.check(capi.lib().ly_detect_head_bwd(_p(dp), n, h, w, na, no, _p(du), ldu, _p(dbias), capi.dtype_code(du), capi.stream_ptr()),
+               "ly_detect_head_bwd")
+
+
 def mlpblock(x, y, n, h, w, c, wp, w1, w2, sc, sh, stats=None):
     m = n * h * w
     cc, nt, ht, t2d = mlp_config(c, m, w)
@@ -685,6 +691,16 @@ def unpatch(g, n, ho, wo, c, ks, h, w):
     dx = empty_nhwc(n, c, h, w, g)
     capi.check(capi.lib().ly_unpatch(_p(g), n, ho, wo, c, ks, _p(dx), capi.dtype_code(g), capi.stream_ptr()), "ly_unpatch")
     return dx
+
+
+def patch4_rows_u8(img, dtype):
+    """uint8 NCHW image [n, c, h, w] -> rows [n*h/4*w/4, 16*c] of `dtype` holding the integer pixel values (PatchEmbed weight gradient)"""
+    n, c, h, w = img.shape
+    if img.dtype != torch.uint8 or not img.is_contiguous() or h % 4 or w % 4:
+        raise ValueError("patch4_rows_u8: contiguous uint8 NCHW image with H, W multiples of 4 expected")
+    rows = torch.empty((n * (h // 4) * (w // 4), 16 * c), dtype=dtype, device=img.device)
+    capi.check(capi.lib().ly_patch4_rows_u8(_p(img), n, c, h, w, _p(rows), capi.dtype_code(rows), capi.stream_ptr()), "ly_patch4_rows_u8")
+    return rows
 
 
 def coordatt_gate_bwd(dout, x, ldx, n, h, w, c, a_h, a_w, ldd=None):

@@ -535,3 +535,55 @@ def test_two_rank_rccl_train_step():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 3, 64, 96), (1, 3, 8, 260), (3, 1, 32, 32)])
+def test_patch4_rows_u8_equals_permuted_copy(shape, dtype):
+    """space-to-depth of the uint8 image for PatchEmbed's weight gradient (models/common.py:1537-1550): bit-exact vs the torch permute"""
+    import lead_yolo_amd as L
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(5)
+    img = torch.randint(0, 256, shape, dtype=torch.uint8, generator=g).to(_dev())
+    got = L.ops.patch4_rows_u8(img, dtype)
+    want = img.reshape(n, c, h // 4, 4, w // 4, 4).permute(0, 2, 4, 1, 3, 5).reshape(-1, 16 * c).to(dtype)
+    assert got.shape == want.shape and torch.equal(got, want)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("geom", [(2, 64, 20, 20), (1, 40, 7, 13), (3, 128, 5, 160)])
+def test_detect_head_node_equals_autograd_chain(geom, dtype):
+    """grad.DetectHeadFn (one Detect level in training, models/yolo.py:84-88) vs the generic conv node followed by autograd's
+    view / permute / copy chain: same raw map bit for bit, same dx / dW / dbias (both use the same contraction kernels; the fused
+    adjoint only changes who lays out du and who sums the bias gradient)."""
+    import lead_yolo_amd as L
+    from lead_yolo_amd import grad, pack
+    bs, cin, ny, nx = geom
+    dev = _dev()
+    g = torch.Generator().manual_seed(11)
+    det = L.Detect(nc=1, anchors=((10, 13, 16, 30, 33, 23),), ch=(cin,)).to(dev).train()
+    with torch.no_grad():
+        det.m[0].weight.copy_(torch.randn(det.m[0].weight.shape, generator=g) * 0.1)
+        det.m[0].bias.copy_(torch.randn(det.m[0].bias.shape, generator=g))
+    x0 = torch.randn(bs, cin, ny, nx, generator=g).to(dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    r = torch.randn(bs, det.na, ny, nx, det.no, generator=g).to(dev)
+    conv = det.m[0]
+    wp, _ = det._packed(0, L.ops.planes_of(x0))
+    res = []
+    for fused in (True, False):
+        conv.weight.grad = conv.bias.grad = None
+        x = x0.clone().requires_grad_(True)
+        if fused:
+            p = grad.DetectHeadFn.apply(det, 0, wp, x, conv.weight, conv.bias)
+        else:
+            y = grad.conv_bn_act(grad.ConvSpec("pw", conv.out_channels), wp, x, None, conv.weight, conv.bias, None)
+            p = torch.empty((bs, det.na, ny, nx, det.no), dtype=torch.float32, device=dev)
+            p.copy_(y.view(bs, det.na, det.no, ny, nx).permute(0, 1, 3, 4, 2))
+        (p * r).sum().backward()
+        res.append((p.detach().clone(), x.grad.clone(), conv.weight.grad.clone(), conv.bias.grad.clone()))
+    (p1, dx1, dw1, db1), (p2, dx2, dw2, db2) = res
+    assert torch.equal(p1, p2)
+    tol = 1e-5 if dtype == torch.float32 else 1e-2        # bf16: the chain rounds dp to bf16 before summing the bias gradient, the node after
+    _close(dx1, dx2.float(), "dx", rtol=tol)
+    _close(dw1, dw2, "dw", rtol=tol)
+    _close(db1, db2, "dbias", rtol=tol)

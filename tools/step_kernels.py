@@ -1,0 +1,34 @@
+"""Device time per kernel of ONE steady-state eager training step (torch profiler, device activity), so that model construction /
+first-step work does not leak into the per-step table the way it does in a whole-process rocprofv3 trace.
+    python tools/step_kernels.py [f32|bf16] [bs] [top]"""
+import os, sys, collections
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench as B
+import lead_yolo_amd as L
+from torch.profiler import profile, ProfilerActivity
+dev = torch.device("cuda:0")
+amp = torch.bfloat16 if (len(sys.argv) > 1 and sys.argv[1] == "bf16") else None
+bs = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+top = int(sys.argv[3]) if len(sys.argv) > 3 else 80
+model = B.build_model("s", dev, train=True)
+opt = L.smart_optimizer(model, "SGD", 0.01, 0.937, 5e-4, fused=True)
+cl = L.ComputeLoss(model)
+imgs = B.synth_u8(bs, 640, 0).to(dev)
+tg = B.synth_targets(bs, 1).to(dev)
+for _ in range(3):
+    L.train_step(model, cl, opt, imgs, tg, amp=amp)
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+    L.train_step(model, cl, opt, imgs, tg, amp=amp)
+    torch.cuda.synchronize()
+acc, cnt = collections.Counter(), collections.Counter()
+for ev in prof.events():
+    if ev.device_type == torch.autograd.DeviceType.CUDA:
+        acc[ev.name] += ev.device_time
+        cnt[ev.name] += 1
+tot = sum(acc.values())
+aten = sum(v for k, v in acc.items() if not k.startswith("ly_") and not k.startswith("void ly_"))
+print(f"kernels={sum(cnt.values())} busy={tot / 1e3:.3f} ms  non-ly={aten / 1e3:.3f} ms")
+for k, v in acc.most_common(top):
+    print(f"{k[:150]:<150} {cnt[k]:4d}  {v / cnt[k]:8.1f} us  {v:9.1f} us")

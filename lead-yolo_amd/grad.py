@@ -347,6 +347,100 @@ def conv_bn_act(spec, wp, x0, x1, weight, bias, bn):
     return ConvBnAct.apply(spec, wp, x0, x1, weight, bias, gamma, beta)
 
 
+class ConvBnActPair(torch.autograd.Function):
+    """Two 1x1 conv -> BatchNorm(train) -> act units over the SAME input (C3_CA's cv1 and cv2, models/common.py:1630-1636): one contraction
+    with the stacked weights writes [u1 | u2] and its batch statistics, one elementwise pass applies both BatchNorms; the two outputs
+    are the channel halves of one buffer.  Backward: each half's BN / activation backward writes its half of one du, the data gradient
+    is ONE contraction with [W1^T | W2^T] — as two separate nodes the input was read twice, its gradient
+    produced twice (twice through the 2x-upsample adjoint when the input is lazily upsampled) and summed by autograd with one more pass
+    per source."""
+
+    @staticmethod
+    def forward(ctx, spec, wp, bn1, bn2, x0, x1, w1, w2, g1, be1, g2, be2):
+        co = spec.cout
+        c_ = co // 2
+        stats = ops.new_stats(co, x0.device)
+        u = _conv_forward(spec, x0, x1, wp, None, None, ACT_NONE, stats=stats, store=True)
+        rows = u.shape[0] * u.shape[2] * u.shape[3]
+        v = torch.empty(4, co, dtype=torch.float32, device=x0.device)          # scale, shift, mean, invstd of both halves
+        for i, bn in enumerate((bn1, bn2)):
+            sl = slice(i * c_, (i + 1) * c_)
+            ops.bn_finalize(bn, stats, co, rows, n=c_, c_off=i * c_, into=(v[0, sl], v[1, sl], v[2, sl], v[3, sl]))
+        y = torch.empty_like(u)
+        ops.bnact_fwd(u, co, rows, co, v[0], v[1], spec.act, y, co)
+        ctx.spec = spec
+        ctx.wt_src = pack.src_matrix_kcat_t(w1, w2)
+        ctx.params = ((w1, g1, be1), (w2, g2, be2))
+        ctx.save_for_backward(x0, x1, w1, w2, v, u)
+        return y[:, :c_], y[:, c_:]
+
+    @staticmethod
+    def backward(ctx, dy1, dy2):
+        spec = ctx.spec
+        x0, x1, w1, w2, v, u = ctx.saved_tensors
+        co = spec.cout
+        c_ = co // 2
+        n, _, ho, wo = u.shape
+        rows = n * ho * wo
+        need = ctx.needs_input_grad          # (spec, wp, bn1, bn2, x0, x1, w1, w2, g1, be1, g2, be2)
+        out = [None] * 12
+        with torch.no_grad():
+            du = torch.empty_like(u)
+            t0, ld0 = ops.rows(x0)
+            c0 = t0.shape[1]
+            t1, ld1 = ops.rows(x1) if x1 is not None else (None, 0)
+            kin = c0 + (t1.shape[1] if t1 is not None else 0)
+            for i, dy in enumerate((dy1, dy2)):
+                off = i * c_
+                w_p, g_p, b_p = ctx.params[i]
+                if dy is None:
+                    dy = torch.zeros((n, c_, ho, wo), dtype=u.dtype, device=u.device).contiguous(memory_format=torch.channels_last)
+                dy, lddy = ops.rows(dy if dy.dtype == u.dtype else dy.to(u.dtype))
+                uh, a, b = u[:, off:off + c_], v[0, off:off + c_], v[1, off:off + c_]
+                sums = ops.bnact_bwd_reduce(dy, lddy, uh, co, rows, c_, a, b, spec.act)
+                tg, tb = ops.grad_target(g_p), ops.grad_target(b_p)
+                direct = tg is not None and tb is not None
+                dgamma, dbeta, alpha, kappa, lam = ops.bn_bwd_coeffs(sums, c_, rows, a, v[2, off:off + c_], v[3, off:off + c_], True,
+                                                                     dgamma=tg if direct else None, dbeta=tb if direct else None)
+                if direct:
+                    ops.grad_done(g_p)
+                    ops.grad_done(b_p)
+                out[8 + 2 * i], out[9 + 2 * i] = dgamma, dbeta
+                ops.bnact_bwd_apply(dy, lddy, uh, co, rows, c_, a, b, spec.act, alpha, kappa, lam, du[:, off:off + c_], co)
+                if need[6 + i]:
+                    tgt = ops.grad_target(w_p)
+                    dw = tgt if tgt is not None else torch.zeros(w_p.shape, dtype=torch.float32, device=u.device)
+                    ops.wgrad(M=rows, H=ho, W=wo, N=c_, du=du, lddu=co, du_off=off, x=t0, ldx=ld0, Hin=t0.shape[2], Win=t0.shape[3], Cin=c0, dw=dw,
+                              lddw=kin, up2=spec.up)
+                    if t1 is not None:
+                        ops.wgrad(M=rows, H=ho, W=wo, N=c_, du=du, lddu=co, du_off=off, x=t1, ldx=ld1, Hin=ho, Win=wo, Cin=t1.shape[1], dw=dw,
+                                  lddw=kin, dw_off=c0)
+                    if tgt is not None:
+                        ops.grad_done(w_p)
+                    else:
+                        out[6 + i] = dw
+            if need[4] or need[5]:
+                pl = ops.planes_of(du)
+                d = ops.empty_nhwc(n, kin, ho, wo, du)
+                # [W1^T | W2^T] ([kin, 2c_]) read in place from the two parameters: ONE contraction over both halves of du
+                wt = pack.packed(ctx.wt_src, co, pl)
+                ops.gemm(M=rows, H=ho, W=wo, K=co, N=kin, a0=du, lda0=co, k0=co, wp=wt, out=d, ldo=kin)
+                if x1 is None:
+                    out[4] = ops.up2_bwd(d, kin, n, ho // 2, wo // 2, kin) if spec.up else d
+                else:
+                    if need[4]:
+                        out[4] = ops.up2_bwd(d, kin, n, ho // 2, wo // 2, c0) if spec.up else d[:, :c0]
+                    if need[5]:
+                        out[5] = d[:, c0:]
+        return tuple(out)
+
+
+def conv_bn_act_pair(act, up, wp, x0, x1, conv1, bn1, conv2, bn2):
+    """cv1(x), cv2(x) of two Conv modules sharing their input, as one node (see ConvBnActPair)"""
+    spec = ConvSpec("pw", conv1.weight.shape[0] + conv2.weight.shape[0], act, bn1, True, up=up)
+    return ConvBnActPair.apply(spec, wp, bn1, bn2, x0, x1, conv1.weight, conv2.weight, bn1.weight, bn1.bias, bn2.weight, bn2.bias)
+
+
 class DetectHeadFn(torch.autograd.Function):
     """One Detect level in training (models/yolo.py:84-88): p = (conv1x1(x) + bias).view(bs, na, no, ny, nx).permute(0, 1, 3, 4, 2) as the
     fp32 raw map the loss reads.  forward = the head contraction + ly_detect_tail (permute + conversion, one pass); backward = ONE kernel

@@ -782,6 +782,23 @@ class C3_CA(nn.Module):
             return pack.frag_pack3(torch.cat((p1.conv.weight.detach().view(self.c_, -1), p2.conv.weight.detach().view(self.c_, -1)), 0), planes=planes)
         return self._prep.get(key, build, planes)
 
+    def _cv12_train(self, x):
+        """cv1(x), cv2(x) under autograd: ONE node over the shared input (grad.ConvBnActPair) when both are 1x1 conv -> train-mode BatchNorm
+        units of a vector-friendly width, else the two Conv modules on their own"""
+        p1, p2 = self.cv1, self.cv2
+        b1, b2 = getattr(p1, "bn", None), getattr(p2, "bn", None)
+        gated = isinstance(x, Lazy) and x.gate is not None
+        if (b1 is None or b2 is None or not (b1.training and b2.training) or p1.k != 1 or p2.k != 1 or p1.conv.bias is not None
+                or p2.conv.bias is not None or gated or self.c_ % 16 or b1.weight is None or b2.weight is None):
+            return self.cv1(x), self.cv2(x)
+        from . import grad
+        if pack.src_matrix_kcat_t(p1.conv.weight, p2.conv.weight) is None:
+            return self.cv1(x), self.cv2(x)
+        x0, x1, up = x, None, False
+        if isinstance(x, Lazy):
+            x0, x1, up = x.keep[0], (x.keep[1] if x.a1 is not None else None), x.up
+        return grad.conv_bn_act_pair(_act_code(p1.act), up, self._weights12(ops.planes_of(x0)), x0, x1, p1.conv, b1, p2.conv, b2)
+
     def _affine12_eval(self):
         p1, p2 = self.cv1, self.cv2
         b1, b2 = getattr(p1, "bn", None), getattr(p2, "bn", None)
@@ -809,10 +826,9 @@ class C3_CA(nn.Module):
         if _act_code(self.cv1.act) != _act_code(self.cv2.act):
             raise NotImplementedError("C3_CA: cv1 and cv2 must share one activation")
         if _grad_mode(self):
-            a = self.cv1(x)
+            a, b = self._cv12_train(x)
             for blk in self.m:
                 a = blk.forward_lazy(a)
-            b = self.cv2(x)
             n_, ca_, h_, w_ = a.shape
             ta, lda = ops.rows(a)
             tb, ldb = ops.rows(b)

@@ -462,16 +462,21 @@ def zeros_f32(numel, device):
     return torch.zeros(numel, dtype=torch.float32, device=device)
 
 
-def bn_finalize(bn, stats, nch, count, n=None, c_off=0, bias=None, pad_to=0, want_stats=False):
+def bn_finalize(bn, stats, nch, count, n=None, c_off=0, bias=None, pad_to=0, want_stats=False, into=None):
     """Train-mode BatchNorm2d from the striped sums of a statistics pass, ONE launch (ly_bn_finalize): returns
-    (scale, shift) of y = x*scale + shift [+ (mean, invstd)], updates running_mean/var/num_batches_tracked in place."""
+    (scale, shift) of y = x*scale + shift [+ (mean, invstd)], updates running_mean/var/num_batches_tracked in place.
+    into = (scale, shift, mean, invstd): contiguous fp32 [n] destinations (slices of a wider vector: two BatchNorms over one stacked output)."""
     n = nch if n is None else n
     dev = stats.device
     size = max(n, pad_to)
-    alloc = torch.zeros if size > n else torch.empty
-    scale, shift = alloc(size, dtype=torch.float32, device=dev), alloc(size, dtype=torch.float32, device=dev)
-    mean = torch.empty(n, dtype=torch.float32, device=dev) if want_stats else None
-    invstd = torch.empty(n, dtype=torch.float32, device=dev) if want_stats else None
+    if into is not None:
+        scale, shift, mean, invstd = into
+        want_stats = True
+    else:
+        alloc = torch.zeros if size > n else torch.empty
+        scale, shift = alloc(size, dtype=torch.float32, device=dev), alloc(size, dtype=torch.float32, device=dev)
+        mean = torch.empty(n, dtype=torch.float32, device=dev) if want_stats else None
+        invstd = torch.empty(n, dtype=torch.float32, device=dev) if want_stats else None
     track = bn.track_running_stats and bn.running_mean is not None
     if bn.weight is not None and bn.weight.dtype != torch.float32:
         raise NotImplementedError("train-mode BatchNorm needs float32 parameters and buffers: train under torch.autocast (fp32 master "

@@ -158,14 +158,27 @@ class Src:
         self.nb, self.nc = nb, nc
         self.vb, self.vc = (nb if vb is None else vb), (nc if vc is None else vc)
         self.sa, self.sb, self.sc = sa, sb, sc
+        self._ref2 = None                          # a second parameter reached through the (a, b) strides (src_matrix_kcat)
 
     @property
     def param(self):
-        return self._ref()
+        p = self._ref()
+        if self._ref2 is None or p is None:
+            return p
+        q = self._ref2()
+        return p if q is not None and self._pair_ok(p, q) else None
+
+    def _pair_ok(self, p, q):
+        return (q.data_ptr() - p.data_ptr()) == 4 * self.sb and q.is_cuda and q.dtype == torch.float32 and q.is_contiguous()
 
     def version(self):
         p = self._ref()
-        return p._version if p is not None else -1
+        if p is None:
+            return -1
+        if self._ref2 is None:
+            return p._version
+        q = self._ref2()
+        return (p._version, q._version if q is not None else -1)
 
     def sig(self):
         return (self.ptr, self.rows, self.base, self.nrb, self.sra, self.srb, self.nb, self.nc, self.vb, self.vc, self.sa, self.sb, self.sc)
@@ -174,6 +187,20 @@ class Src:
 def src_matrix(param, rows, cols, sr=None, sk=1, k_pad=None):
     """W[r][k] = param.flat[r*sr + k*sk] (a 2-D view of the parameter: plain or transposed), columns zero-padded to k_pad"""
     return Src(param, rows, srb=cols * sk if sr is None else sr, nc=(k_pad or cols), vc=cols, sc=sk)
+
+
+def src_matrix_kcat_t(p1, p2):
+    """[kin, 2*c_] matrix [W1^T | W2^T] of two [c_, kin] weights (the data-gradient operand of two 1x1 convolutions over one input, C3_CA's
+    cv1 / cv2), read in place from BOTH parameters: the column-block stride is the distance between the two allocations.  None when that
+    is not expressible (different devices / dtypes, a `.half()` shadow copy)."""
+    m1, m2 = master(p1), master(p2)
+    if m1 is not p1 or m2 is not p2 or p1.shape != p2.shape or p1.device != p2.device or (m2.data_ptr() - m1.data_ptr()) % 4:
+        return None
+    c_, kin = p1.shape[0], p1.numel() // p1.shape[0]
+    s = Src(p1, kin, srb=1, nb=2, nc=c_, sb=(m2.data_ptr() - m1.data_ptr()) // 4, sc=kin)
+    s._ref2 = weakref.ref(p2)
+    s.ok = s.ok and p2.is_cuda and p2.dtype == torch.float32 and p2.is_contiguous()
+    return s
 
 
 def src_taps(w, cip, transposed_flipped=False):

@@ -390,6 +390,10 @@ class ConvBnActPair(torch.autograd.Function):
             c0 = t0.shape[1]
             t1, ld1 = ops.rows(x1) if x1 is not None else (None, 0)
             kin = c0 + (t1.shape[1] if t1 is not None else 0)
+            # the two weight gradients as ONE stacked [2c_, kin] matrix when the sink keeps them adjacent (optim.FusedSGD does)
+            tw = [ops.grad_target(ctx.params[i][0]) for i in range(2)]
+            stacked = (need[6] and need[7] and tw[0] is not None and tw[1] is not None and tw[0].is_contiguous() and tw[1].is_contiguous()
+                       and tw[1].data_ptr() == tw[0].data_ptr() + 4 * tw[0].numel())
             for i, dy in enumerate((dy1, dy2)):
                 off = i * c_
                 w_p, g_p, b_p = ctx.params[i]
@@ -407,8 +411,8 @@ class ConvBnActPair(torch.autograd.Function):
                     ops.grad_done(b_p)
                 out[8 + 2 * i], out[9 + 2 * i] = dgamma, dbeta
                 ops.bnact_bwd_apply(dy, lddy, uh, co, rows, c_, a, b, spec.act, alpha, kappa, lam, du[:, off:off + c_], co)
-                if need[6 + i]:
-                    tgt = ops.grad_target(w_p)
+                if need[6 + i] and not stacked:
+                    tgt = tw[i]
                     dw = tgt if tgt is not None else torch.zeros(w_p.shape, dtype=torch.float32, device=u.device)
                     ops.wgrad(M=rows, H=ho, W=wo, N=c_, du=du, lddu=co, du_off=off, x=t0, ldx=ld0, Hin=t0.shape[2], Win=t0.shape[3], Cin=c0, dw=dw,
                               lddw=kin, up2=spec.up)
@@ -419,6 +423,13 @@ class ConvBnActPair(torch.autograd.Function):
                         ops.grad_done(w_p)
                     else:
                         out[6 + i] = dw
+            if stacked:
+                ops.wgrad(M=rows, H=ho, W=wo, N=co, du=du, lddu=co, x=t0, ldx=ld0, Hin=t0.shape[2], Win=t0.shape[3], Cin=c0, dw=tw[0], lddw=kin,
+                          up2=spec.up)
+                if t1 is not None:
+                    ops.wgrad(M=rows, H=ho, W=wo, N=co, du=du, lddu=co, x=t1, ldx=ld1, Hin=ho, Win=wo, Cin=t1.shape[1], dw=tw[0], lddw=kin, dw_off=c0)
+                ops.grad_done(ctx.params[0][0])
+                ops.grad_done(ctx.params[1][0])
             if need[4] or need[5]:
                 pl = ops.planes_of(du)
                 d = ops.empty_nhwc(n, kin, ho, wo, du)

@@ -768,6 +768,7 @@ class C3_CA(nn.Module):
         self.c_, self.c2 = c_, c2
         self._prep = _Prepared()
         self._prep_bn = _Prepared()
+        self.cv1.conv.weight._ly_grad_pair = self.cv2.conv.weight      # optim.FusedSGD may keep the two gradients adjacent (one wgrad launch)
 
     def _weights12(self, planes=2):
         """cv1 and cv2 read the same input: one GEMM with stacked weights writes [cv1 | cv2] side by side,

@@ -15,6 +15,19 @@ from . import capi
 CHUNK = 4096                 # elements per block, = LY_OPT_CHUNK in csrc/ly_optim.hip
 
 
+def _pairable(p):
+    """p and its `_ly_grad_pair` partner can share one gradient allocation (and do not yet): same-shape contiguous fp32 weights whose
+    gradients are unset or plain tensors this optimiser may replace (not views of somebody's bucket)"""
+    q = getattr(p, "_ly_grad_pair", None)
+    if q is None or not q.requires_grad or q.shape != p.shape or q.device != p.device or q.dtype != torch.float32 or not q.is_contiguous():
+        return False
+    for t in (p, q):
+        g = t.grad
+        if g is not None and (g.dtype != torch.float32 or g.shape != t.shape or g._base is not None):
+            return False
+    return True
+
+
 def _is_tap_major(g, p):
     """g is a view of p's shape [co, ci, kh, kw] over storage laid out [co][kh][kw][ci]"""
     if g is None or g.dim() != 4 or tuple(g.shape) != tuple(p.shape) or g.is_contiguous():
@@ -90,6 +103,15 @@ class FusedSGD(torch.optim.Optimizer):
                         if p.grad is not None:
                             view.copy_(p.grad)
                         p.grad = view
+                elif _pairable(p):
+                    # two weights whose gradients ONE ly_wgrad launch can write as a stacked [2*cout, cin] matrix (C3_CA's cv1 / cv2:
+                    # grad.ConvBnActPair): adjacent halves of one allocation
+                    q = p._ly_grad_pair
+                    both = torch.zeros((2,) + tuple(p.shape), dtype=torch.float32, device=p.device)
+                    for half, t in zip(both, (p, q)):
+                        if t.grad is not None:
+                            half.copy_(t.grad)
+                        t.grad = half
                 elif p.grad is None:
                     p.grad = torch.zeros_like(p)              # persistent gradient storage: autograd accumulates in place
                 elif not p.grad.is_contiguous() and not _is_tap_major(p.grad, p):

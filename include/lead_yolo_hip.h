@@ -321,10 +321,11 @@ int ly_rf_bwd_gen(const void* x /*T*/, int ldx, int n_img, int H, int W, int C, 
 int ly_rf_bwd_dx(int n_img, int H, int W, int C, int k, int s, const void* dug /*T*/, const float* wg, void* dx /*T*/, int lddx,
                  const float* addnc /* NULL, or [n_img, C]: dx += addnc[n, c] * add_scale (the SE pooling's gradient) */, float add_scale,
                  int dtype, void* stream);
-/* SE backward in training (models/rfa.py:88-92), one launch: from the forward's pooling partials part[n][slices][C] (HW pixels per
- * image), ca = sigmoid(wb relu(wa mean)) and d_ca: dwa [R, C], dwb [C, R] are ADDED TO, dgap [n_img, C] = d/d(mean x) is written.   */
+/* SE backward in training (models/rfa.py:88-92), two launches: from the forward's pooling partials part[n][slices][C] (HW pixels per
+ * image), ca = sigmoid(wb relu(wa mean)) and d_ca: dwa [R, C], dwb [C, R] are ADDED TO (one thread per weight sums the per-image outer
+ * products kept in ws: no atomics, deterministic), dgap [n_img, C] = d/d(mean x) is written.  ws: scratch, n_img * (2C + 2R) floats. */
 int ly_se_bwd(const float* part, int slices, int n_img, int HW, int C, const float* wa, const float* wb, int R, const float* ca,
-              const float* d_ca, float* dwa, float* dwb, float* dgap, void* stream);
+              const float* d_ca, float* dwa, float* dwb, float* dgap, float* ws, void* stream);
 
 /* ---- per-channel BatchNorm vector work and weight packing, one launch each ------------------------------------------
  * STATISTICS ACCUMULATORS ARE STRIPED: every `stats` / `sums` / `mom` argument of the statistics passes above

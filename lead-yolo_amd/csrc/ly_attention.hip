@@ -1272,7 +1272,7 @@ extern "C" int ly_rfcbam_gen_prepare(const float* mom, int C, int k, const float
 __global__ __launch_bounds__(LY_THREADS) void ly_se_bwd_kernel(const float* __restrict__ part, int slices, int C, float inv_hw,
                                                                 const float* __restrict__ wa, const float* __restrict__ wb, int R,
                                                                 const float* __restrict__ ca, const float* __restrict__ d_ca,
-                                                                float* __restrict__ dwa, float* __restrict__ dwb, float* __restrict__ dgap) {
+                                                                float* __restrict__ ws, float* __restrict__ dgap) {
   extern __shared__ float sm[];
   float* g = sm;                     // g[C] | dz[C] | hid[R] | dh[R] | red
   float* dz = sm + C;
@@ -1311,23 +1311,48 @@ __global__ __launch_bounds__(LY_THREADS) void ly_se_bwd_kernel(const float* __re
     }
   }
   __syncthreads();
+  // the per-image factors of the two weight gradients go to the workspace ws[n][g | dz | hid | dh]; ly_se_bwd_wsum_kernel sums the outer
+  // products over the images, one thread per weight (2*C*R float atomics per image here made the launch 38 us at bs=64)
+  float* const wsn = ws + (long)n * (2 * C + 2 * R);
   for (int c = tid; c < C; c += LY_THREADS) {
     float dg = 0.f;
-    for (int r = 0; r < R; ++r) {
-      dg += dh[r] * wa[r * C + c];
-      atomicAdd(dwb + c * R + r, dz[c] * hid[r]);
-      atomicAdd(dwa + r * C + c, dh[r] * g[c]);
-    }
+    for (int r = 0; r < R; ++r) dg += dh[r] * wa[r * C + c];
     dgap[(long)n * C + c] = dg;
+    wsn[c] = g[c];
+    wsn[C + c] = dz[c];
+  }
+  for (int r = tid; r < R; r += LY_THREADS) {
+    wsn[2 * C + r] = hid[r];
+    wsn[2 * C + R + r] = dh[r];
   }
 }
 
+// dWb[c][r] += sum_n dz[n][c]*hid[n][r],  dWa[r][c] += sum_n dh[n][r]*g[n][c]   (thread = (r, c), c fastest: deterministic, no atomics)
+__global__ __launch_bounds__(LY_THREADS) void ly_se_bwd_wsum_kernel(const float* __restrict__ ws, int n_img, int C, int R, float* __restrict__ dwa,
+                                                                     float* __restrict__ dwb) {
+  const int i = blockIdx.x * LY_THREADS + threadIdx.x;
+  if (i >= C * R) return;
+  const int r = i / C, c = i - r * C;
+  const int st = 2 * C + 2 * R;
+  float sa = 0.f, sb = 0.f;
+  for (int n = 0; n < n_img; ++n) {
+    const float* w = ws + (long)n * st;
+    sb += w[C + c] * w[2 * C + r];
+    sa += w[2 * C + R + r] * w[c];
+  }
+  dwb[c * R + r] += sb;
+  dwa[r * C + c] += sa;
+}
+
 extern "C" int ly_se_bwd(const float* part, int slices, int n_img, int HW, int C, const float* wa, const float* wb, int R, const float* ca,
-                         const float* d_ca, float* dwa, float* dwb, float* dgap, void* stream) {
-  LY_CHECK(part && wa && wb && ca && d_ca && dwa && dwb && dgap, "se_bwd: null pointer");
+                         const float* d_ca, float* dwa, float* dwb, float* dgap, float* ws, void* stream) {
+  LY_CHECK(part && wa && wb && ca && d_ca && dwa && dwb && dgap && ws, "se_bwd: null pointer");
   LY_CHECK((C & 3) == 0 && C <= 1024 && slices > 0 && R > 0 && R <= 256 && n_img > 0 && HW > 0, "se_bwd: bad arguments");
   hipLaunchKernelGGL(ly_se_bwd_kernel, dim3(n_img), dim3(LY_THREADS), sizeof(float) * (((2 * C + 2 * R + 3) & ~3) + 4 * LY_THREADS),
-                     reinterpret_cast<hipStream_t>(stream), part, slices, C, 1.f / (float)HW, wa, wb, R, ca, d_ca, dwa, dwb, dgap);
+                     reinterpret_cast<hipStream_t>(stream), part, slices, C, 1.f / (float)HW, wa, wb, R, ca, d_ca, ws, dgap);
+  LY_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ly_se_bwd_wsum_kernel, dim3((unsigned)((C * R + LY_THREADS - 1) / LY_THREADS)), dim3(LY_THREADS), 0,
+                     reinterpret_cast<hipStream_t>(stream), ws, n_img, C, R, dwa, dwb);
   LY_LAUNCH_CHECK();
   return 0;
 }

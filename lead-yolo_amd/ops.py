@@ -272,9 +272,10 @@ def se_attention(x, ldx, n, hw, c, wa, wb, r, want_part=False):
 
 
 def se_bwd(part, n, hw, c, wa, wb, r, ca, d_ca, dwa, dwb):
-    """SE backward (one launch): dwa [r, c] / dwb [c, r] are ADDED to; returns dgap [n, c] = d/d(mean x)"""
+    """SE backward: dwa [r, c] / dwb [c, r] are ADDED to; returns dgap [n, c] = d/d(mean x)"""
     dgap = torch.empty((n, c), dtype=torch.float32, device=part.device)
-    capi.check(capi.lib().ly_se_bwd(_p(part), part.shape[1], n, hw, c, _p(wa), _p(wb), r, _p(ca), _p(d_ca), _p(dwa), _p(dwb), _p(dgap),
+    ws = torch.empty(n * (2 * c + 2 * r), dtype=torch.float32, device=part.device)
+    capi.check(capi.lib().ly_se_bwd(_p(part), part.shape[1], n, hw, c, _p(wa), _p(wb), r, _p(ca), _p(d_ca), _p(dwa), _p(dwb), _p(dgap), _p(ws),
                                     capi.stream_ptr()), "ly_se_bwd")
     return dgap
 

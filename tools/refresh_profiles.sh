@@ -8,6 +8,7 @@
 #   <tag>_<run>_pmc_mfma.json          SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 1024 SIMDs) per launch
 #   <tag>_<run>_pmc_wait.txt           SQ wait / LDS counters per launch
 #   <tag>_<run>_bench.json / _kernels.txt   the bench line (graph replay) and bench.py --layers' live HIP-event table
+#   <tag>_train_<dtype>_step_kernels.txt  tools/step_kernels.py: device time per kernel of ONE steady-state eager step
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 TAG=${1:-r02}
@@ -41,4 +42,7 @@ python3 bench.py --dtype bf16 --layers > $OUT/${TAG}_train_bf16_bench.json 2> $O
 python3 bench.py --dtype f32 --layers > $OUT/${TAG}_train_f32_bench.json 2> $OUT/${TAG}_train_f32_kernels.txt
 python3 bench.py --mode forward --dtype f32 --layers > $OUT/${TAG}_fwd_f32_bench.json 2> $OUT/${TAG}_fwd_f32_kernels.txt
 python3 bench.py --mode forward --dtype bf16 --layers --no-cpu-baseline > $OUT/${TAG}_fwd_bf16_bench.json 2> $OUT/${TAG}_fwd_bf16_kernels.txt
+# steady-state per-kernel table of ONE eager step (torch profiler, device activity): no model-construction launches in the counts
+python3 tools/step_kernels.py bf16 64 400 2>/dev/null | grep -v "^\[W\|Warn" > $OUT/${TAG}_train_bf16_step_kernels.txt
+python3 tools/step_kernels.py f32 64 400 2>/dev/null | grep -v "^\[W\|Warn" > $OUT/${TAG}_train_f32_step_kernels.txt
 ls -la $OUT | head -40

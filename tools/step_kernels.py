@@ -22,13 +22,17 @@ torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
     L.train_step(model, cl, opt, imgs, tg, amp=amp)
     torch.cuda.synchronize()
+from demangle import demangle, short
 acc, cnt = collections.Counter(), collections.Counter()
-for ev in prof.events():
-    if ev.device_type == torch.autograd.DeviceType.CUDA:
-        acc[ev.name] += ev.device_time
-        cnt[ev.name] += 1
+evs = [ev for ev in prof.events() if ev.device_type == torch.autograd.DeviceType.CUDA and not ev.name.startswith("Optimizer.")]
+names = demangle([ev.name for ev in evs])
+for ev, nm in zip(evs, names):
+    nm = short(nm) if "ly_" in nm else nm
+    acc[nm] += ev.device_time
+    cnt[nm] += 1
 tot = sum(acc.values())
-aten = sum(v for k, v in acc.items() if not k.startswith("ly_") and not k.startswith("void ly_"))
-print(f"kernels={sum(cnt.values())} busy={tot / 1e3:.3f} ms  non-ly={aten / 1e3:.3f} ms")
+own = sum(v for k, v in acc.items() if k.startswith("ly_"))
+print(f"one steady-state eager optimisation step, lead-yolo-s bs={bs} 640x640 {'bf16' if amp else 'f32'}: kernels={sum(cnt.values())} "
+      f"busy={tot / 1e3:.3f} ms  (ly_* {own / 1e3:.3f} ms, ATen / memcpy {(tot - own) / 1e3:.3f} ms)")
 for k, v in acc.most_common(top):
-    print(f"{k[:150]:<150} {cnt[k]:4d}  {v / cnt[k]:8.1f} us  {v:9.1f} us")
+    print(f"{k[:130]:<130} {cnt[k]:4d}  {v / cnt[k]:8.1f} us  {v:9.1f} us")

@@ -265,6 +265,10 @@ typedef struct LyWgradParams {
   int dw_ts, dw_cs, n_valid, c_valid;
 } LyWgradParams;
 int ly_wgrad(const LyWgradParams* p, void* stream);
+/* n independent weight gradients in ONE launch when all of them are plain-row 1x1 problems of the 128 x 128 tile class (N > 64, no
+ * gather) and n <= 4: they share the launch's ~512 blocks, so every block walks a longer pixel chunk (fewer first-load waits and atomic tile
+ * flushes per pixel).  Any other mix: the same as n calls of ly_wgrad.                                                                  */
+int ly_wgrad_group(const LyWgradParams* arr, int n, void* stream);
 
 /* Adjoint of the nearest-2x read: out[n,h,w,:] = sum of d[n, 2h+{0,1}, 2w+{0,1}, :]  (d is a 2Hs x 2Ws map).      */
 int ly_up2_bwd(const void* d /*T*/, int ldd, int n_img, int Hs, int Ws, int C, void* out /*T*/, int ldo, int dtype, void* stream);

@@ -370,8 +370,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_wgrad_kernel(const LyWgradParam
 // Re-reads drop from (N/64 + K/64) to (N/BN + K/BK) passes over the two tensors.
 // -------------------------------------------------------------------------------------------------
 template <typename T, int BN, int BK, int P, bool ROWS>
-__global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(BN + BK > 160 ? 2 : 3))) void ly_wgrad_tiled_kernel(const LyWgradParams P_, const int tiles_k, const long chunk_px) {
-  const LyWgradParams& Q = P_;
+__device__ __forceinline__ void ly_wgrad_tiled_body(const LyWgradParams& Q, const int tile_idx, const int chunk_idx, const int tiles_k, const long chunk_px) {
   using R4 = typename LyT<T>::R4;
   constexpr int PL = LyT<T>::PL;
   const T* const du = reinterpret_cast<const T*>(Q.du);
@@ -387,9 +386,9 @@ __global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(BN +
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lq = lane >> 4;
-  const int tk = blockIdx.x % tiles_k, tn = blockIdx.x / tiles_k;
+  const int tk = tile_idx % tiles_k, tn = tile_idx / tiles_k;
   const int n0 = tn * BN, k0 = tk * BK;
-  const long p_begin = (long)blockIdx.y * chunk_px;
+  const long p_begin = (long)chunk_idx * chunk_px;
   const long p_end = p_begin + chunk_px < Q.M ? p_begin + chunk_px : Q.M;
   const int Ktot = Q.ks * Q.ks * Q.Cin;
 
@@ -550,6 +549,33 @@ __global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(BN +
     }
 }
 
+template <typename T, int BN, int BK, int P, bool ROWS>
+__global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(BN + BK > 160 ? 2 : 3))) void ly_wgrad_tiled_kernel(const LyWgradParams P_, const int tiles_k, const long chunk_px) {
+  ly_wgrad_tiled_body<T, BN, BK, P, ROWS>(P_, (int)blockIdx.x, (int)blockIdx.y, tiles_k, chunk_px);
+}
+
+// Several independent weight gradients of ONE tile class in one launch (ly_wgrad_group): the problems share the ~512 blocks, so each block
+// walks a longer pixel chunk — the fixed cost of a block (first-load latency, the atomic flush of its 64 KB tile) is paid half / a third as
+// often per pixel, and the launch fills the chip where a lone small problem leaves a ragged second wave.
+#define LY_WGRAD_GROUP_MAX 4
+struct LyWgradGroupArgs {
+  LyWgradParams p[LY_WGRAD_GROUP_MAX];
+  long chunk_px[LY_WGRAD_GROUP_MAX];
+  int tiles_k[LY_WGRAD_GROUP_MAX], tiles[LY_WGRAD_GROUP_MAX], blk0[LY_WGRAD_GROUP_MAX + 1];
+  int n;
+};
+template <typename T, int BN, int BK, int P, bool ROWS>
+__global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(BN + BK > 160 ? 2 : 3))) void ly_wgrad_tiled_group_kernel(const LyWgradGroupArgs G) {
+  int g = 0;
+#pragma unroll
+  for (int i = 1; i < LY_WGRAD_GROUP_MAX; ++i)
+    if (i < G.n && (int)blockIdx.x >= G.blk0[i]) g = i;
+  g = __builtin_amdgcn_readfirstlane(g);
+  const int local = (int)blockIdx.x - G.blk0[g];
+  const int tiles = G.tiles[g];
+  ly_wgrad_tiled_body<T, BN, BK, P, ROWS>(G.p[g], local % tiles, local / tiles, G.tiles_k[g], G.chunk_px[g]);
+}
+
 template <typename T, int BN, int BK, int P>
 static int launch_wgrad_tiled(const LyWgradParams& Q, bool rows, hipStream_t st) {
   const int Ktot = Q.ks * Q.ks * Q.Cin;
@@ -587,6 +613,68 @@ extern "C" int ly_wgrad(const LyWgradParams* p, void* stream) {
   LY_CHECK(p, "wgrad: null params");
   LY_CHECK_DTYPE(p->dtype, "wgrad");
   return p->dtype == LY_BF16 ? wgrad_dispatch<__bf16>(*p, stream) : wgrad_dispatch<float>(*p, stream);
+}
+
+// true when P takes the plain-rows 128 x 128 tile of the fast path (the class ly_wgrad_group batches)
+template <typename T>
+static bool wgrad_is_rows128(const LyWgradParams& P) {
+  if (!(P.du && P.x && P.dw) || !(P.M > 0 && P.H > 0 && P.W > 0 && P.N > 64 && P.Cin > 0) || P.M >= (1L << 24) || P.M % ((long)P.H * P.W) != 0) return false;
+  if (!(P.ks == 1 && P.stride == 1 && P.pad == 0 && !P.nchw && !P.up2 && P.Hin == P.H && P.Win == P.W)) return false;
+  if (!(P.n_valid > 0 && P.n_valid <= P.N && P.c_valid > 0 && P.c_valid <= P.Cin && P.dw_ts > 0 && P.dw_cs > 0)) return false;
+  if ((long)P.lddw < (long)(P.c_valid - 1) * P.dw_cs + 1) return false;
+  return (P.N & 3) == 0 && (P.Cin & 3) == 0 && (P.lddu & 3) == 0 && (P.ldx & 3) == 0 && ((uintptr_t)P.du & (4 * sizeof(T) - 1)) == 0 &&
+         ((uintptr_t)P.x & (4 * sizeof(T) - 1)) == 0;
+}
+
+template <typename T>
+static int wgrad_group_launch(const LyWgradParams* arr, int n, hipStream_t st) {
+  constexpr int PX = LyT<T>::BF ? 128 : 64, BN = 128, BK = 128;
+  LyWgradGroupArgs G;
+  long tiles_total = 0;
+  for (int g = 0; g < n; ++g) {
+    G.p[g] = arr[g];
+    G.tiles_k[g] = (arr[g].Cin + BK - 1) / BK;
+    G.tiles[g] = ((arr[g].N + BN - 1) / BN) * G.tiles_k[g];
+    tiles_total += G.tiles[g];
+  }
+  G.n = n;
+  G.blk0[0] = 0;
+  for (int g = 0; g < n; ++g) {
+    long chunks = (512 + tiles_total - 1) / tiles_total;               // the group shares the ~512 blocks (launch_wgrad_tiled's policy)
+    const long max_chunks = (arr[g].M + 511) / 512;
+    if (chunks > max_chunks) chunks = max_chunks;
+    if (chunks < 1) chunks = 1;
+    long chunk_px = (arr[g].M + chunks - 1) / chunks;
+    chunk_px = (chunk_px + PX - 1) / PX * PX;
+    chunks = (arr[g].M + chunk_px - 1) / chunk_px;
+    G.chunk_px[g] = chunk_px;
+    G.blk0[g + 1] = G.blk0[g] + (int)(chunks * G.tiles[g]);
+  }
+  for (int g = n; g < LY_WGRAD_GROUP_MAX; ++g) { G.tiles_k[g] = G.tiles[g] = 1; G.chunk_px[g] = PX; G.blk0[g + 1] = G.blk0[n]; G.p[g] = arr[0]; }
+  const size_t lds = (LyT<T>::PL * PX >= 128 ? 1 : 2) * (size_t)(BN + BK) * (LyT<T>::PL * 2 * PX + 16);
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ly_wgrad_tiled_group_kernel<T, BN, BK, PX, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+  hipLaunchKernelGGL((ly_wgrad_tiled_group_kernel<T, BN, BK, PX, true>), dim3((unsigned)G.blk0[n]), dim3(LY_THREADS), lds, st, G);
+  LY_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ly_wgrad_group(const LyWgradParams* arr, int n, void* stream) {
+  LY_CHECK(arr && n > 0, "wgrad_group: bad arguments");
+  bool same = n >= 2 && n <= LY_WGRAD_GROUP_MAX;
+  for (int g = 0; g < n && same; ++g) {
+    LY_CHECK_DTYPE(arr[g].dtype, "wgrad_group");
+    same = arr[g].dtype == arr[0].dtype && (arr[g].dtype == LY_BF16 ? wgrad_is_rows128<__bf16>(arr[g]) : wgrad_is_rows128<float>(arr[g]));
+  }
+  if (!same) {                                                        // anything else: one launch per problem, as ly_wgrad would
+    for (int g = 0; g < n; ++g) {
+      const int rc = ly_wgrad(arr + g, stream);
+      if (rc) return rc;
+    }
+    return 0;
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  return arr[0].dtype == LY_BF16 ? wgrad_group_launch<__bf16>(arr, n, st) : wgrad_group_launch<float>(arr, n, st);
 }
 
 template <typename T>

@@ -122,11 +122,13 @@ def conv_wgrad(spec, du, x0, x1, weight):
         t0, ld0 = ops.rows(x0)
         c0 = t0.shape[1]
         k = c0 + (x1.shape[1] if x1 is not None else 0)
-        ops.wgrad(M=m, H=ho, W=wo, N=co, du=du, lddu=co, x=t0, ldx=ld0, Hin=t0.shape[2], Win=t0.shape[3], Cin=c0, dw=dw, lddw=k,
-                  up2=spec.up, n_valid=nv)
+        probs = [dict(M=m, H=ho, W=wo, N=co, du=du, lddu=co, x=t0, ldx=ld0, Hin=t0.shape[2], Win=t0.shape[3], Cin=c0, dw=dw, lddw=k,
+                      up2=spec.up, n_valid=nv)]
         if x1 is not None:
             t1, ld1 = ops.rows(x1)
-            ops.wgrad(M=m, H=ho, W=wo, N=co, du=du, lddu=co, x=t1, ldx=ld1, Hin=ho, Win=wo, Cin=t1.shape[1], dw=dw, lddw=k, dw_off=c0, n_valid=nv)
+            probs.append(dict(M=m, H=ho, W=wo, N=co, du=du, lddu=co, x=t1, ldx=ld1, Hin=ho, Win=wo, Cin=t1.shape[1], dw=dw, lddw=k, dw_off=c0,
+                              n_valid=nv))
+        ops.wgrad_group(probs)               # two row sources (a concat read in place): one launch when both are plain rows
     elif spec.kind == "c3":
         t0, ld0 = ops.rows(x0)
         c = t0.shape[1]
@@ -424,10 +426,12 @@ class ConvBnActPair(torch.autograd.Function):
                     else:
                         out[6 + i] = dw
             if stacked:
-                ops.wgrad(M=rows, H=ho, W=wo, N=co, du=du, lddu=co, x=t0, ldx=ld0, Hin=t0.shape[2], Win=t0.shape[3], Cin=c0, dw=tw[0], lddw=kin,
-                          up2=spec.up)
+                probs = [dict(M=rows, H=ho, W=wo, N=co, du=du, lddu=co, x=t0, ldx=ld0, Hin=t0.shape[2], Win=t0.shape[3], Cin=c0, dw=tw[0], lddw=kin,
+                              up2=spec.up)]
                 if t1 is not None:
-                    ops.wgrad(M=rows, H=ho, W=wo, N=co, du=du, lddu=co, x=t1, ldx=ld1, Hin=ho, Win=wo, Cin=t1.shape[1], dw=tw[0], lddw=kin, dw_off=c0)
+                    probs.append(dict(M=rows, H=ho, W=wo, N=co, du=du, lddu=co, x=t1, ldx=ld1, Hin=ho, Win=wo, Cin=t1.shape[1], dw=tw[0], lddw=kin,
+                                      dw_off=c0))
+                ops.wgrad_group(probs)
                 ops.grad_done(ctx.params[0][0])
                 ops.grad_done(ctx.params[1][0])
             if need[4] or need[5]:
@@ -571,14 +575,15 @@ class MlpBlockFn(torch.autograd.Function):
                 t = ops.grad_target(p)
                 return (t, True) if t is not None else (torch.zeros(p.shape, dtype=torch.float32, device=x.device), False)
             dw2, d2 = sink(p_w2)
-            ops.wgrad(M=m, H=h, W=w, N=c, du=dy, lddu=c, x=hid, ldx=2 * c, Hin=h, Win=w, Cin=2 * c, dw=dw2, lddw=2 * c)
+            wg2 = dict(M=m, H=h, W=w, N=c, du=dy, lddu=c, x=hid, ldx=2 * c, Hin=h, Win=w, Cin=2 * c, dw=dw2, lddw=2 * c)
             # BN + ReLU
             du1, dgamma, dbeta = affine_backward(dh, u1, a, b, ACT_RELU, mean, invstd, True, gamma=p_gamma, beta=p_beta)
             # first 1x1
             g = ops.empty_nhwc(n, c, h, w, x)
             ops.gemm(M=m, H=h, W=w, K=2 * c, N=c, a0=du1, lda0=2 * c, k0=2 * c, wp=pack.packed(pack.src_matrix(p_w1, c, 2 * c, sr=1, sk=c), 2 * c, pl), out=g, ldo=c)
             dw1, d1 = sink(p_w1)
-            ops.wgrad(M=m, H=h, W=w, N=2 * c, du=du1, lddu=2 * c, x=z, ldx=c, Hin=h, Win=w, Cin=c, dw=dw1, lddw=c)
+            # both 1x1 weight gradients in one launch (they share the launch's blocks: longer pixel chunks, half the tile flushes per pixel)
+            ops.wgrad_group([wg2, dict(M=m, H=h, W=w, N=2 * c, du=du1, lddu=2 * c, x=z, ldx=c, Hin=h, Win=w, Cin=c, dw=dw1, lddw=c)])
             # partial 3x3 conv on the first C/4 channels
             # channel counts padded to multiples of 4 (C/4 = 6, 10): the tiled wgrad then applies; the extra rows / columns
             # (gradients of, and against, the neighbouring untouched channels) are computed and discarded

@@ -666,6 +666,36 @@ def wgrad(*, M, H, W, N, du, lddu, x, ldx, Hin, Win, Cin, dw, lddw, ks=1, stride
         capi.check(capi.lib().ly_wgrad(ctypes.byref(P), capi.stream_ptr()), "ly_wgrad")
 
 
+def _wgrad_params(*, M, H, W, N, du, lddu, x, ldx, Hin, Win, Cin, dw, lddw, ks=1, stride=1, pad=0, nchw=False, up2=False, du_off=0, x_off=0,
+                  dw_off=0, dw_ts=None, dw_cs=1, n_valid=None, c_valid=None):
+    def at(t, off):
+        return ctypes.c_void_p(t.data_ptr() + t.element_size() * off)
+    if du.dtype != x.dtype:
+        raise capi.HipLibraryError(f"wgrad: du ({du.dtype}) and x ({x.dtype}) must share one storage dtype")
+    return capi.LyWgradParams(M, H, W, N, at(du, du_off), lddu, at(x, x_off), ldx, Hin, Win, Cin, ks, stride, pad, int(nchw), int(up2),
+                              at(dw, dw_off), lddw, capi.dtype_code(x), Cin if dw_ts is None else dw_ts, dw_cs, N if n_valid is None else n_valid,
+                              Cin if c_valid is None else c_valid)
+
+
+def wgrad_group(problems):
+    """Several independent weight gradients (each a dict of `wgrad` arguments) in ONE launch when all are plain-row 1x1 problems of the
+    128 x 128 tile class (ly_wgrad_group: N > 64, vector-friendly widths, no gather, at most 4); otherwise one `wgrad` each."""
+    def groupable(q):
+        return (q.get("ks", 1) == 1 and q.get("stride", 1) == 1 and q.get("pad", 0) == 0 and not q.get("nchw") and not q.get("up2")
+                and q["N"] > 64 and q["N"] % 4 == 0 and q["Cin"] % 4 == 0 and q["lddu"] % 4 == 0 and q["ldx"] % 4 == 0
+                and q["Hin"] == q["H"] and q["Win"] == q["W"] and q["x"].dtype == problems[0]["x"].dtype)
+    if not (2 <= len(problems) <= 4) or not all(groupable(q) for q in problems):
+        for q in problems:
+            wgrad(**q)
+        return
+    arr = (capi.LyWgradParams * len(problems))(*[_wgrad_params(**q) for q in problems])
+    x0 = problems[0]["x"]
+    px = 128 if x0.dtype == torch.bfloat16 else 64
+    with _Timed(f"ly_wgrad_tiled_group_kernel<{_tname(x0)}, 128, 128, {px}, true>", sum(2.0 * q["M"] * q["N"] * q["Cin"] for q in problems),
+                sum(x0.element_size() * q["M"] * (q["N"] + q["Cin"]) + 4.0 * q["N"] * q["Cin"] for q in problems)):
+        capi.check(capi.lib().ly_wgrad_group(arr, len(problems), capi.stream_ptr()), "ly_wgrad_group")
+
+
 def wgrad_kernel_name(t, n, ktot, rows, tiled):
     """mirror of the tile dispatch in csrc/ly_backward.hip (wgrad_dispatch): the kernel name rocprofv3 prints"""
     r = "true" if rows else "false"

@@ -587,3 +587,36 @@ def test_detect_head_node_equals_autograd_chain(geom, dtype):
     _close(dx1, dx2.float(), "dx", rtol=tol)
     _close(dw1, dw2, "dw", rtol=tol)
     _close(db1, db2, "dbias", rtol=tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_wgrad_group_equals_separate_launches(dtype):
+    """ly_wgrad_group (several plain-row 1x1 weight gradients sharing one launch) against one ly_wgrad launch per problem and against
+    the plain matrix product; a non-groupable mix (N <= 64) must fall back to separate launches with the same result"""
+    import lead_yolo_amd as L
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    n, h, w = 3, 20, 24
+    m = n * h * w
+
+    def problem(N, C, ldx_extra=0):
+        du = torch.randn(m, N, generator=g).to(dev).to(dtype)
+        x = torch.randn(m, C + ldx_extra, generator=g).to(dev).to(dtype)
+        return du, x, dict(M=m, H=h, W=w, N=N, du=du, lddu=N, x=x, ldx=C + ldx_extra, Hin=h, Win=w, Cin=C, lddw=C)
+    for shapes in ([(160, 80, 0), (80, 160, 0)], [(256, 128, 8), (128, 256, 0), (72, 200, 0)], [(160, 80, 0), (40, 80, 0)]):
+        probs = [problem(*sh) for sh in shapes]
+        outs = []
+        for grouped in (True, False):
+            dws = [torch.zeros(q["N"], q["Cin"], dtype=torch.float32, device=dev) for _, _, q in probs]
+            qs = [dict(q, dw=dw) for (_, _, q), dw in zip(probs, dws)]
+            if grouped:
+                L.ops.wgrad_group(qs)
+            else:
+                for q in qs:
+                    L.ops.wgrad(**q)
+            outs.append(dws)
+        for (du, x, q), a, b in zip(probs, *outs):
+            want = du.float().t() @ x.float()[:, :q["Cin"]]
+            tol = 1e-3 if dtype == torch.float32 else 1e-5        # bf16 inputs: products exact in fp32, only the summation order differs
+            _close(a, want, "grouped vs matmul", rtol=max(tol, 2e-4))
+            _close(a, b, "grouped vs separate", rtol=2e-4)

@@ -829,6 +829,7 @@ class RfcbamFn(torch.autograd.Function):
         ctx.conv_w_param = conv_w
         ctx.se_params = (se_wa, se_wb)
         ctx.conv_b_param = conv_b
+        ctx.out_bn_params = (out_gamma, out_beta)
         ctx.getw_param = getw
         ctx.save_for_backward(xr, ca, gen_w, getw, conv_w, bias, G["ag"], G["bg"], G["gmean_tc"], G["ginv_tc"], es, t, omean, oinv, mm, rfa, se_part, u)
         return out
@@ -851,7 +852,8 @@ class RfcbamFn(torch.autograd.Function):
             # 1-2. output conv: the pre-BN value u (bias included) was kept by the forward; BN + ReLU backward (du is written over a copy
             # of u: saved tensors must stay intact for a second backward through the graph)
             _tap("rf.dy", dy); _tap("rf.u", u)
-            du, dgo, dbo = affine_backward(dy, u, es, t, ACT_RELU, omean, oinv, True, inplace=False)
+            du, dgo, dbo = affine_backward(dy, u, es, t, ACT_RELU, omean, oinv, True, inplace=False, gamma=ctx.out_bn_params[0],
+                                           beta=ctx.out_bn_params[1])       # (straight into the sink when one holds them: returns None, None)
             _tap("rf.du", du)
             # 3. dcd [mo][t][c]
             # Wc^T with rows (t, c): conv.0.weight [o, c, kh, kw] read in place

@@ -263,6 +263,11 @@ typedef struct LyWgradParams {
    * torch weight layout [cout][cin][kh][kw]: dw_ts = 1, dw_cs = ks*ks, lddw = cin*ks*ks), and only rows n < n_valid / channels
    * c < c_valid are written (padded contractions) — so the kernel can add straight into a parameter's .grad storage          */
   int dw_ts, dw_cs, n_valid, c_valid;
+  /* optional prologue on x, plain-row 1x1 problems of the tiled path only (both NULL: x as stored):
+   *   x'[p][c] = max(x[p][c]*x_scale[c] + x_shift[c], 0)
+   * — a BatchNorm + ReLU whose output the producer never materialised (the MLPBlock's hidden tensor, models/common.py:1478-1482,
+   * in the training backward: dW2 = dy^T . relu(BN(u1)) is contracted from u1 directly)                                          */
+  const float* x_scale; const float* x_shift;
 } LyWgradParams;
 int ly_wgrad(const LyWgradParams* p, void* stream);
 /* n independent weight gradients in ONE launch when all of them are plain-row 1x1 problems of the 128 x 128 tile class (N > 64, no

@@ -51,7 +51,8 @@ class LyPackDesc(ctypes.Structure):
 class LyWgradParams(ctypes.Structure):
     _fields_ = [("M", _L), ("H", _I), ("W", _I), ("N", _I), ("du", _P), ("lddu", _I), ("x", _P), ("ldx", _I),
                 ("Hin", _I), ("Win", _I), ("Cin", _I), ("ks", _I), ("stride", _I), ("pad", _I), ("nchw", _I), ("up2", _I),
-                ("dw", _P), ("lddw", _I), ("dtype", _I), ("dw_ts", _I), ("dw_cs", _I), ("n_valid", _I), ("c_valid", _I)]
+                ("dw", _P), ("lddw", _I), ("dtype", _I), ("dw_ts", _I), ("dw_cs", _I), ("n_valid", _I), ("c_valid", _I),
+                ("x_scale", _P), ("x_shift", _P)]
 
 
 STATS_STRIPES = 32

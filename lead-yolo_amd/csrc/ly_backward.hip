@@ -369,7 +369,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_wgrad_kernel(const LyWgradParam
 // s+1 are in flight while step s is contracted (register prefetch, two LDS buffers, one barrier per step).
 // Re-reads drop from (N/64 + K/64) to (N/BN + K/BK) passes over the two tensors.
 // -------------------------------------------------------------------------------------------------
-template <typename T, int BN, int BK, int P, bool ROWS>
+template <typename T, int BN, int BK, int P, bool ROWS, bool PRO>
 __device__ __forceinline__ void ly_wgrad_tiled_body(const LyWgradParams& Q, const int tile_idx, const int chunk_idx, const int tiles_k, const long chunk_px) {
   using R4 = typename LyT<T>::R4;
   constexpr int PL = LyT<T>::PL;
@@ -383,6 +383,8 @@ __device__ __forceinline__ void ly_wgrad_tiled_body(const LyWgradParams& Q, cons
   constexpr int BUF = (BN + BK) * RSW;
   extern __shared__ f32x4 ly_smem4[];
   char* const lds = reinterpret_cast<char*>(ly_smem4);
+  constexpr bool SB = PL * P >= 128;       // 128 bf16 / 64 fp32 pixels per step: ONE LDS buffer (see the loop below)
+  float* const sab = reinterpret_cast<float*>(lds + (SB ? 1 : 2) * BUF);      // [scale BK | shift BK] of the optional x prologue
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lq = lane >> 4;
@@ -391,6 +393,22 @@ __device__ __forceinline__ void ly_wgrad_tiled_body(const LyWgradParams& Q, cons
   const long p_begin = (long)chunk_idx * chunk_px;
   const long p_end = p_begin + chunk_px < Q.M ? p_begin + chunk_px : Q.M;
   const int Ktot = Q.ks * Q.ks * Q.Cin;
+  // x prologue max(x*scale + shift, 0) (LyWgradParams.x_scale): the block's BK columns of both vectors staged once; applied while the x slab
+  // is transposed into LDS (masked pixels meet zero rows of du, so relu(shift) there is harmless; masked columns get scale = shift = 0)
+  // PRO: the instantiation that can; a group may mix problems with and without vectors (pro is uniform over the block).  Straight-line on
+  // purpose — a load under a branch makes every later s_waitcnt conservative (the first version, `if (pro) { loads }`, doubled the kernel's
+  // time): all threads load (a problem without vectors reads the head of x as a harmless stand-in), the select happens on values.
+  const bool pro = ROWS && PRO && Q.x_scale != nullptr;
+  if constexpr (ROWS && PRO) {
+    const float* const sp = pro ? Q.x_scale : reinterpret_cast<const float*>(Q.x);      // (4*Cin bytes of x exist: M >= 2 rows)
+    const float* const hp = pro ? Q.x_shift : reinterpret_cast<const float*>(Q.x);
+    const int i = tid & (BK - 1);
+    const int k = k0 + i < Ktot ? k0 + i : 0;
+    const float sv = sp[k], hv = hp[k];
+    sab[i] = k0 + i < Ktot ? sv : 0.f;
+    sab[BK + i] = k0 + i < Ktot ? hv : 0.f;
+    __syncthreads();
+  }
 
   // ---- per-task constants ---------------------------------------------------------------------
   bool t_isA[TPT], t_ok[TPT];
@@ -463,10 +481,21 @@ __device__ __forceinline__ void ly_wgrad_tiled_body(const LyWgradParams& Q, cons
 #pragma unroll
     for (int u = 0; u < TPT; ++u) {
       if (t_row[u] < 0) continue;
+      const bool pb = pro && !t_isA[u];
+      f32x4 sa = ly_zero4(), sh = ly_zero4();
+      if constexpr (ROWS && PRO) {
+        const int lc = t_isA[u] ? 0 : t_row[u] - BN;
+        sa = *reinterpret_cast<const f32x4*>(sab + lc);
+        sh = *reinterpret_cast<const f32x4*>(sab + BK + lc);
+      }
       if constexpr (PL == 2) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float v[8] = {pre[u][0][e], pre[u][1][e], pre[u][2][e], pre[u][3][e], pre[u][4][e], pre[u][5][e], pre[u][6][e], pre[u][7][e]};
+          float v[8] = {pre[u][0][e], pre[u][1][e], pre[u][2][e], pre[u][3][e], pre[u][4][e], pre[u][5][e], pre[u][6][e], pre[u][7][e]};
+          if constexpr (ROWS && PRO) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = pb ? fmaxf(v[j] * sa[e] + sh[e], 0.f) : v[j];
+          }
           bf16x8 hi, lo;
           ly_split8(v, hi, lo);
           char* d = base + (t_row[u] + e) * RSW + t_g[u] * 16;
@@ -478,6 +507,16 @@ __device__ __forceinline__ void ly_wgrad_tiled_body(const LyWgradParams& Q, cons
         bf16x4 q[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) q[j] = __builtin_bit_cast(bf16x4, pre[u][j]);
+        if constexpr (ROWS && PRO) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            f32x4 v = ly_cvt4(q[j]) * sa + sh;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            const bf16x4 r = ly_cvtb4(v);
+            q[j] = pb ? r : q[j];
+          }
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const bf16x8 row = {q[0][e], q[1][e], q[2][e], q[3][e], q[4][e], q[5][e], q[6][e], q[7][e]};
@@ -494,8 +533,8 @@ __device__ __forceinline__ void ly_wgrad_tiled_body(const LyWgradParams& Q, cons
     for (int j = 0; j < NJ; ++j) acc[i][j] = ly_zero4();
   const int wn = (wave & 1) * (BN / 2), wk = BN + (wave >> 1) * (BK / 2);
 
-  constexpr bool SB = PL * P >= 128;       // 128 bf16 / 64 fp32 pixels per step: ONE LDS buffer (two would leave one block per CU); the loads of the next step
-  prefetch(p_begin);                       // are in flight during the contraction, the buffer is rewritten between two barriers
+  // SB: ONE LDS buffer (two would leave one block per CU); the loads of the next step are in flight during the contraction, the buffer is
+  prefetch(p_begin);                       // rewritten between two barriers
   commit(0);
   __syncthreads();
   int buf = 0;
@@ -549,9 +588,9 @@ __device__ __forceinline__ void ly_wgrad_tiled_body(const LyWgradParams& Q, cons
     }
 }
 
-template <typename T, int BN, int BK, int P, bool ROWS>
+template <typename T, int BN, int BK, int P, bool ROWS, bool PRO = false>
 __global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(BN + BK > 160 ? 2 : 3))) void ly_wgrad_tiled_kernel(const LyWgradParams P_, const int tiles_k, const long chunk_px) {
-  ly_wgrad_tiled_body<T, BN, BK, P, ROWS>(P_, (int)blockIdx.x, (int)blockIdx.y, tiles_k, chunk_px);
+  ly_wgrad_tiled_body<T, BN, BK, P, ROWS, PRO>(P_, (int)blockIdx.x, (int)blockIdx.y, tiles_k, chunk_px);
 }
 
 // Several independent weight gradients of ONE tile class in one launch (ly_wgrad_group): the problems share the ~512 blocks, so each block
@@ -564,7 +603,7 @@ struct LyWgradGroupArgs {
   int tiles_k[LY_WGRAD_GROUP_MAX], tiles[LY_WGRAD_GROUP_MAX], blk0[LY_WGRAD_GROUP_MAX + 1];
   int n;
 };
-template <typename T, int BN, int BK, int P, bool ROWS>
+template <typename T, int BN, int BK, int P, bool ROWS, bool PRO = false>
 __global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(BN + BK > 160 ? 2 : 3))) void ly_wgrad_tiled_group_kernel(const LyWgradGroupArgs G) {
   int g = 0;
 #pragma unroll
@@ -573,7 +612,7 @@ __global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(BN +
   g = __builtin_amdgcn_readfirstlane(g);
   const int local = (int)blockIdx.x - G.blk0[g];
   const int tiles = G.tiles[g];
-  ly_wgrad_tiled_body<T, BN, BK, P, ROWS>(G.p[g], local % tiles, local / tiles, G.tiles_k[g], G.chunk_px[g]);
+  ly_wgrad_tiled_body<T, BN, BK, P, ROWS, PRO>(G.p[g], local % tiles, local / tiles, G.tiles_k[g], G.chunk_px[g]);
 }
 
 template <typename T, int BN, int BK, int P>
@@ -591,9 +630,13 @@ static int launch_wgrad_tiled(const LyWgradParams& Q, bool rows, hipStream_t st)
   chunk_px = (chunk_px + P - 1) / P * P;
   chunks = (Q.M + chunk_px - 1) / chunk_px;
   LY_CHECK(chunks < 65536, "wgrad: too many pixel chunks");
-  const size_t lds = (LyT<T>::PL * P >= 128 ? 1 : 2) * (size_t)(BN + BK) * (LyT<T>::PL * 2 * P + 16);
+  const size_t lds = (LyT<T>::PL * P >= 128 ? 1 : 2) * (size_t)(BN + BK) * (LyT<T>::PL * 2 * P + 16) + 2 * BK * sizeof(float);
   const dim3 grid((unsigned)tiles, (unsigned)chunks);
-  if (rows) {
+  if (rows && Q.x_scale) {
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ly_wgrad_tiled_kernel<T, BN, BK, P, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    hipLaunchKernelGGL((ly_wgrad_tiled_kernel<T, BN, BK, P, true, true>), grid, dim3(LY_THREADS), lds, st, Q, tiles_k, chunk_px);
+  } else if (rows) {
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ly_wgrad_tiled_kernel<T, BN, BK, P, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
     hipLaunchKernelGGL((ly_wgrad_tiled_kernel<T, BN, BK, P, true>), grid, dim3(LY_THREADS), lds, st, Q, tiles_k, chunk_px);
@@ -651,10 +694,18 @@ static int wgrad_group_launch(const LyWgradParams* arr, int n, hipStream_t st) {
     G.blk0[g + 1] = G.blk0[g] + (int)(chunks * G.tiles[g]);
   }
   for (int g = n; g < LY_WGRAD_GROUP_MAX; ++g) { G.tiles_k[g] = G.tiles[g] = 1; G.chunk_px[g] = PX; G.blk0[g + 1] = G.blk0[n]; G.p[g] = arr[0]; }
-  const size_t lds = (LyT<T>::PL * PX >= 128 ? 1 : 2) * (size_t)(BN + BK) * (LyT<T>::PL * 2 * PX + 16);
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ly_wgrad_tiled_group_kernel<T, BN, BK, PX, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-  hipLaunchKernelGGL((ly_wgrad_tiled_group_kernel<T, BN, BK, PX, true>), dim3((unsigned)G.blk0[n]), dim3(LY_THREADS), lds, st, G);
+  const size_t lds = (LyT<T>::PL * PX >= 128 ? 1 : 2) * (size_t)(BN + BK) * (LyT<T>::PL * 2 * PX + 16) + 2 * BK * sizeof(float);
+  bool any_pro = false;
+  for (int g = 0; g < n; ++g) any_pro = any_pro || arr[g].x_scale != nullptr;
+  if (any_pro) {
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ly_wgrad_tiled_group_kernel<T, BN, BK, PX, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    hipLaunchKernelGGL((ly_wgrad_tiled_group_kernel<T, BN, BK, PX, true, true>), dim3((unsigned)G.blk0[n]), dim3(LY_THREADS), lds, st, G);
+  } else {
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ly_wgrad_tiled_group_kernel<T, BN, BK, PX, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    hipLaunchKernelGGL((ly_wgrad_tiled_group_kernel<T, BN, BK, PX, true>), dim3((unsigned)G.blk0[n]), dim3(LY_THREADS), lds, st, G);
+  }
   LY_LAUNCH_CHECK();
   return 0;
 }
@@ -688,6 +739,10 @@ static int wgrad_dispatch(const LyWgradParams& P, void* stream) {
   LY_CHECK((long)P.lddw >= (long)(P.ks * P.ks - 1) * P.dw_ts + (long)(P.c_valid - 1) * P.dw_cs + 1, "wgrad: lddw=%d does not cover a dw row", P.lddw);
   const bool rows = P.ks == 1 && P.stride == 1 && P.pad == 0 && !P.nchw && !P.up2;
   if (rows) LY_CHECK(P.Hin == P.H && P.Win == P.W, "wgrad: 1x1 gather needs Hin == H, Win == W");
+  LY_CHECK((P.x_scale == nullptr) == (P.x_shift == nullptr), "wgrad: x_scale and x_shift come together");
+  const bool tiled_ok = !P.nchw && (P.N & 3) == 0 && (P.Cin & 3) == 0 && (P.lddu & 3) == 0 && (P.ldx & 3) == 0 && ((uintptr_t)P.du & (4 * sizeof(T) - 1)) == 0 &&
+                        ((uintptr_t)P.x & (4 * sizeof(T) - 1)) == 0;
+  if (P.x_scale) LY_CHECK(rows && tiled_ok, "wgrad: the x prologue is built for plain-row 1x1 problems with vector-friendly widths");
   if (!P.nchw && (P.N & 3) == 0 && (P.Cin & 3) == 0 && (P.lddu & 3) == 0 && (P.ldx & 3) == 0 && ((uintptr_t)P.du & (4 * sizeof(T) - 1)) == 0 && ((uintptr_t)P.x & (4 * sizeof(T) - 1)) == 0) {
     hipStream_t st2 = reinterpret_cast<hipStream_t>(stream);
     // One step of a block is one memory round trip, so what matters for the skinny shapes is how many blocks a CU holds and how many

@@ -88,9 +88,9 @@ def _conv_forward(spec, x0, x1, wp, e_scale, e_shift, act, stats=None, out=None,
 
 
 
-def affine_backward(dy, u, a, b, act, mean, invstd, train, inplace=True, gamma=None, beta=None, lddy=None):
+def affine_backward(dy, u, a, b, act, mean, invstd, train, inplace=True, gamma=None, beta=None, lddy=None, out=None):
     """du and (dgamma, dbeta) for v = a*u + b, y = act(v); dy/u are NHWC-dense [n, c, h, w].  du is written over u unless
-    inplace=False (u is a tensor saved for backward).  gamma / beta: the BatchNorm parameters — when a gradient sink holds their
+    inplace=False (u is a tensor saved for backward) or into `out` (e.g. dy itself).  gamma / beta: the BatchNorm parameters — when a gradient sink holds their
     storage (ops.GradSink) dgamma / dbeta are added there by the coefficient kernel and returned as None."""
     n, c, h, w = u.shape
     rows = n * h * w
@@ -103,7 +103,7 @@ def affine_backward(dy, u, a, b, act, mean, invstd, train, inplace=True, gamma=N
     if direct:
         ops.grad_done(gamma)
         ops.grad_done(beta)
-    du = u if inplace else torch.empty_like(u)
+    du = out if out is not None else u if inplace else torch.empty_like(u)     # out: e.g. dy itself (elementwise: same index read and written)
     ops.bnact_bwd_apply(dy, lddy, u, c, rows, c, a, b, act, alpha, kappa, lam, du, c)
     return du, dgamma, dbeta
 
@@ -565,8 +565,13 @@ class MlpBlockFn(torch.autograd.Function):
             pk1 = pack.packed(pack.src_matrix(p_w1, 2 * c, c), c, pl, rows_to=16 * htp)          # the forward's own image
             u1 = ops.empty_nhwc(n, 2 * c, h, w, x)
             ops.gemm(M=m, H=h, W=w, K=c, N=2 * c, a0=z, lda0=c, k0=c, wp=pk1, out=u1, ldo=2 * c)
-            hid = ops.empty_nhwc(n, 2 * c, h, w, x)
-            ops.gemm(M=m, H=h, W=w, K=c, N=2 * c, a0=z, lda0=c, k0=c, wp=pk1, out=hid, ldo=2 * c, e_scale=a, e_shift=b, act=ACT_RELU)
+            # The hidden tensor relu(BN(u1)): for the narrow blocks (C <= 40: the 64-wide wgrad tiles) it is never rebuilt — the second 1x1's
+            # weight gradient reads u1 through ly_wgrad's x prologue (one GEMM over the largest maps less: 60 / 30 us at 160 / 80 px).  In the
+            # 128 x 128 tile the prologue's conversions sit between the two barriers of every step: +40 us per launch for a 17 us GEMM.
+            pro = c <= 40
+            if not pro:
+                hid = ops.empty_nhwc(n, 2 * c, h, w, x)
+                ops.gemm(M=m, H=h, W=w, K=c, N=2 * c, a0=z, lda0=c, k0=c, wp=pk1, out=hid, ldo=2 * c, e_scale=a, e_shift=b, act=ACT_RELU)
             # second 1x1
             dh = ops.empty_nhwc(n, 2 * c, h, w, x)
             ops.gemm(M=m, H=h, W=w, K=c, N=2 * c, a0=dy, lda0=c, k0=c, wp=pack.packed(pack.src_matrix(p_w2, 2 * c, c, sr=1, sk=2 * c), c, pl), out=dh, ldo=2 * c)
@@ -575,9 +580,11 @@ class MlpBlockFn(torch.autograd.Function):
                 t = ops.grad_target(p)
                 return (t, True) if t is not None else (torch.zeros(p.shape, dtype=torch.float32, device=x.device), False)
             dw2, d2 = sink(p_w2)
-            wg2 = dict(M=m, H=h, W=w, N=c, du=dy, lddu=c, x=hid, ldx=2 * c, Hin=h, Win=w, Cin=2 * c, dw=dw2, lddw=2 * c)
-            # BN + ReLU
-            du1, dgamma, dbeta = affine_backward(dh, u1, a, b, ACT_RELU, mean, invstd, True, gamma=p_gamma, beta=p_beta)
+            wg2 = dict(M=m, H=h, W=w, N=c, du=dy, lddu=c, x=u1 if pro else hid, ldx=2 * c, Hin=h, Win=w, Cin=2 * c, dw=dw2, lddw=2 * c,
+                       x_scale=a if pro else None, x_shift=b if pro else None)
+            # BN + ReLU (with the prologue du1 is written over dh: u1 is still read by the weight gradient above, launched with the first
+            # 1x1's below)
+            du1, dgamma, dbeta = affine_backward(dh, u1, a, b, ACT_RELU, mean, invstd, True, gamma=p_gamma, beta=p_beta, out=dh if pro else None)
             # first 1x1
             g = ops.empty_nhwc(n, c, h, w, x)
             ops.gemm(M=m, H=h, W=w, K=2 * c, N=c, a0=du1, lda0=2 * c, k0=2 * c, wp=pack.packed(pack.src_matrix(p_w1, c, 2 * c, sr=1, sk=c), 2 * c, pl), out=g, ldo=c)

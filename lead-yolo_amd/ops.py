@@ -650,31 +650,32 @@ def bnact_bwd_apply(dy, lddy, u, ldu, rows, c, a, b, act, alpha, kappa, lam, du,
 
 
 def wgrad(*, M, H, W, N, du, lddu, x, ldx, Hin, Win, Cin, dw, lddw, ks=1, stride=1, pad=0, nchw=False, up2=False, du_off=0, x_off=0,
-          dw_off=0, dw_ts=None, dw_cs=1, n_valid=None, c_valid=None):
+          dw_off=0, dw_ts=None, dw_cs=1, n_valid=None, c_valid=None, x_scale=None, x_shift=None):
     """dw[n][tap*dw_ts + c*dw_cs] += sum_pixels du[p][n] * x[src(p, tap)][c] for n < n_valid, c < c_valid; *_off are element offsets
-    into the tensors.  Defaults: packed rows (dw_ts = Cin, dw_cs = 1), everything valid."""
-    def at(t, off):
-        return ctypes.c_void_p(t.data_ptr() + t.element_size() * off)
-    if du.dtype != x.dtype:
-        raise capi.HipLibraryError(f"wgrad: du ({du.dtype}) and x ({x.dtype}) must share one storage dtype")
-    P = capi.LyWgradParams(M, H, W, N, at(du, du_off), lddu, at(x, x_off), ldx, Hin, Win, Cin, ks, stride, pad, int(nchw), int(up2),
-                           at(dw, dw_off), lddw, capi.dtype_code(x), Cin if dw_ts is None else dw_ts, dw_cs, N if n_valid is None else n_valid,
-                           Cin if c_valid is None else c_valid)
+    into the tensors.  Defaults: packed rows (dw_ts = Cin, dw_cs = 1), everything valid.  x_scale / x_shift (fp32 [Cin], plain-row 1x1
+    problems): x is read as max(x*x_scale + x_shift, 0)."""
+    P = _wgrad_params(M=M, H=H, W=W, N=N, du=du, lddu=lddu, x=x, ldx=ldx, Hin=Hin, Win=Win, Cin=Cin, dw=dw, lddw=lddw, ks=ks, stride=stride,
+                      pad=pad, nchw=nchw, up2=up2, du_off=du_off, x_off=x_off, dw_off=dw_off, dw_ts=dw_ts, dw_cs=dw_cs, n_valid=n_valid,
+                      c_valid=c_valid, x_scale=x_scale, x_shift=x_shift)
     with _Timed(wgrad_kernel_name(_tname(x), N, ks * ks * Cin, ks == 1 and stride == 1 and pad == 0 and not nchw and not up2,
-                                  (not nchw) and N % 4 == 0 and Cin % 4 == 0 and lddu % 4 == 0 and ldx % 4 == 0),
+                                  (not nchw) and N % 4 == 0 and Cin % 4 == 0 and lddu % 4 == 0 and ldx % 4 == 0, x_scale is not None),
                 2.0 * M * N * ks * ks * Cin, x.element_size() * M * (N + Cin) + 4.0 * N * ks * ks * Cin):
         capi.check(capi.lib().ly_wgrad(ctypes.byref(P), capi.stream_ptr()), "ly_wgrad")
 
 
 def _wgrad_params(*, M, H, W, N, du, lddu, x, ldx, Hin, Win, Cin, dw, lddw, ks=1, stride=1, pad=0, nchw=False, up2=False, du_off=0, x_off=0,
-                  dw_off=0, dw_ts=None, dw_cs=1, n_valid=None, c_valid=None):
+                  dw_off=0, dw_ts=None, dw_cs=1, n_valid=None, c_valid=None, x_scale=None, x_shift=None):
     def at(t, off):
         return ctypes.c_void_p(t.data_ptr() + t.element_size() * off)
     if du.dtype != x.dtype:
         raise capi.HipLibraryError(f"wgrad: du ({du.dtype}) and x ({x.dtype}) must share one storage dtype")
+    if (x_scale is None) != (x_shift is None):
+        raise ValueError("wgrad: x_scale and x_shift come together")
+    if x_scale is not None and (x_scale.dtype != torch.float32 or x_shift.dtype != torch.float32 or x_scale.numel() < Cin or x_shift.numel() < Cin):
+        raise ValueError("wgrad: x_scale / x_shift must be float32 vectors of at least Cin elements")
     return capi.LyWgradParams(M, H, W, N, at(du, du_off), lddu, at(x, x_off), ldx, Hin, Win, Cin, ks, stride, pad, int(nchw), int(up2),
                               at(dw, dw_off), lddw, capi.dtype_code(x), Cin if dw_ts is None else dw_ts, dw_cs, N if n_valid is None else n_valid,
-                              Cin if c_valid is None else c_valid)
+                              Cin if c_valid is None else c_valid, _p(x_scale), _p(x_shift))
 
 
 def wgrad_group(problems):
@@ -691,12 +692,13 @@ def wgrad_group(problems):
     arr = (capi.LyWgradParams * len(problems))(*[_wgrad_params(**q) for q in problems])
     x0 = problems[0]["x"]
     px = 128 if x0.dtype == torch.bfloat16 else 64
-    with _Timed(f"ly_wgrad_tiled_group_kernel<{_tname(x0)}, 128, 128, {px}, true>", sum(2.0 * q["M"] * q["N"] * q["Cin"] for q in problems),
+    anyp = any(q.get("x_scale") is not None for q in problems)
+    with _Timed(f"ly_wgrad_tiled_group_kernel<{_tname(x0)}, 128, 128, {px}, true, {'true' if anyp else 'false'}>", sum(2.0 * q["M"] * q["N"] * q["Cin"] for q in problems),
                 sum(x0.element_size() * q["M"] * (q["N"] + q["Cin"]) + 4.0 * q["N"] * q["Cin"] for q in problems)):
         capi.check(capi.lib().ly_wgrad_group(arr, len(problems), capi.stream_ptr()), "ly_wgrad_group")
 
 
-def wgrad_kernel_name(t, n, ktot, rows, tiled):
+def wgrad_kernel_name(t, n, ktot, rows, tiled, pro=False):
     """mirror of the tile dispatch in csrc/ly_backward.hip (wgrad_dispatch): the kernel name rocprofv3 prints"""
     r = "true" if rows else "false"
     if not tiled:
@@ -710,7 +712,7 @@ def wgrad_kernel_name(t, n, ktot, rows, tiled):
         bn, bk = 64, 128
     else:
         bn, bk = 128, 128
-    return f"ly_wgrad_tiled_kernel<{t}, {bn}, {bk}, {px}, {r}>"
+    return f"ly_wgrad_tiled_kernel<{t}, {bn}, {bk}, {px}, {r}, {'true' if pro and rows else 'false'}>"
 
 
 def up2_bwd(d, ldd, n, hs, ws, c):

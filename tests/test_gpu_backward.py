@@ -620,3 +620,33 @@ def test_wgrad_group_equals_separate_launches(dtype):
             tol = 1e-3 if dtype == torch.float32 else 1e-5        # bf16 inputs: products exact in fp32, only the summation order differs
             _close(a, want, "grouped vs matmul", rtol=max(tol, 2e-4))
             _close(a, b, "grouped vs separate", rtol=2e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(24, 48), (40, 80), (80, 160), (160, 320)])
+def test_wgrad_x_prologue(shape, dtype):
+    """LyWgradParams.x_scale / x_shift: dw = du^T . max(x*scale + shift, 0) without materialising the activated tensor (the MLPBlock's
+    hidden tensor in the training backward), every tile class of the plain-row path, alone and inside a grouped launch"""
+    import lead_yolo_amd as L
+    dev = _dev()
+    g = torch.Generator().manual_seed(9)
+    N, C = shape
+    n, h, w = 2, 20, 28
+    m = n * h * w
+    du = torch.randn(m, N, generator=g).to(dev).to(dtype)
+    x = torch.randn(m, C, generator=g).to(dev).to(dtype)
+    a = (torch.rand(C + 12, generator=g) + 0.5).to(dev)
+    b = torch.randn(C + 12, generator=g).to(dev)
+    act = torch.relu(x.float() * a[:C] + b[:C])
+    if dtype == torch.bfloat16:
+        act = act.to(dtype).float()                       # the kernel rounds the activated value to the storage type before the product
+    want = du.float().t() @ act
+    q = dict(M=m, H=h, W=w, N=N, du=du, lddu=N, x=x, ldx=C, Hin=h, Win=w, Cin=C, lddw=C, x_scale=a, x_shift=b)
+    dw = torch.zeros(N, C, dtype=torch.float32, device=dev)
+    L.ops.wgrad(**dict(q, dw=dw))
+    _close(dw, want, "prologue", rtol=1e-3 if dtype == torch.float32 else 1e-4)
+    dw2 = torch.zeros(N, C, dtype=torch.float32, device=dev)
+    other = torch.zeros(C, N, dtype=torch.float32, device=dev)
+    L.ops.wgrad_group([dict(q, dw=dw2), dict(M=m, H=h, W=w, N=C, du=x, lddu=C, x=du, ldx=N, Hin=h, Win=w, Cin=N, dw=other, lddw=N)])
+    _close(dw2, want, "prologue in a group", rtol=1e-3 if dtype == torch.float32 else 1e-4)
+    _close(other, x.float().t() @ du.float(), "its plain neighbour", rtol=1e-3 if dtype == torch.float32 else 1e-4)

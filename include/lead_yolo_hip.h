@@ -298,6 +298,11 @@ int ly_pool_hw_bwd(const float* gp, int n_img, int H, int W, int C, void* dx /*T
 int ly_maxpool_arg(const void* x /*T*/, int ldx, int n_img, int H, int W, int C, int k, unsigned char* arg, int lda, int dtype, void* stream);
 int ly_maxpool_gather(const unsigned char* arg, int lda, const float* d_up, int ldu, const void* d_own, int ldd, int own_dtype, int n_img, int H,
                       int W, int C, int k, void* out, int ldo, int out_dtype, void* stream);
+/* The same backward in ONE launch when the map fits LDS (H*W*104 bytes <= 150 KB, k = 5, c % 8 == 0): a block owns one image x 8 channels, the three
+ * levels run from LDS with the routing rule and summation order of the two entries above (bit-identical).  buf = [y | m(y) | m(m(y)) | m(m(m(y)))]
+ * rows (ldb), d = its gradient (ldd), out = d/dy (ldo), all T.  Returns 1 without launching when the shape does not fit.                        */
+int ly_sppf_bwd(const void* buf /*T*/, int ldb, const void* d /*T*/, int ldd, int n_img, int H, int W, int c, int k, void* out /*T*/, int ldo, int dtype,
+                void* stream);
 /* MLPBlock backward, last step (models/common.py:1478-1482 under autograd): dx[r, c] = dy[r, c] + (c < c4 ? t[r, c] : g[r, c]) over dense
  * [rows, C] matrices (t: row stride ldt >= ceil4(c4)) — the residual + the 1x1's gradient, with the partial 3x3 conv's gradient in its channels. */
 int ly_mlp_dx(const void* dy /*T*/, const void* g /*T*/, const void* t /*T*/, int ldt, long rows, int C, int c4, void* dx /*T*/, int dtype, void* stream);

@@ -117,6 +117,7 @@ SIGNATURES = {
     "ly_nms_greedy": [_P, _P, _P, _I, _I, _F, _F, _I, _I, _P, _P, _P],
     "ly_maxpool_arg": [_P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P],
     "ly_maxpool_gather": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P],
+    "ly_sppf_bwd": [_P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P],
     "ly_mlpblock_pconv": [_P, _P, _I, _I, _I, _I, _P, _I, _P],
     "ly_mlp_dx": [_P, _P, _P, _I, _L, _I, _I, _P, _I, _P],
     "ly_se_bwd": [_P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P],

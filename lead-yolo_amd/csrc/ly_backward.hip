@@ -1400,6 +1400,97 @@ __global__ __launch_bounds__(LY_THREADS) void ly_maxpool_gather_kernel(const uns
   }
 }
 
+// SPPF backward in ONE launch for small maps (models/common.py:348-366 at 20 x 20 / 40 x 40): a block owns one image x 8 channels and keeps the
+// whole map in LDS — per level j = 2, 1, 0 it stages y_j, computes the window argmax of every pixel (the rule of ly_maxpool_arg), and gathers
+// t_j = d_j + sum over the windows routed to the pixel of t_{j+1} (the order of ly_maxpool_gather: bit-identical sums); t_3 = d_3.  The three
+// per-level launches read every routing byte and gradient 25 times through L2 (180 us for a 4 MB map at bs=64); here they come from LDS.
+#define LY_SPPF_CG 8
+template <typename T, int K>
+__global__ __launch_bounds__(LY_THREADS) void ly_sppf_bwd_kernel(const T* __restrict__ buf, int ldb, const T* __restrict__ d, int ldd, int H, int W, int c,
+                                                                 T* __restrict__ out, int ldo) {
+  constexpr int r = K >> 1, CG = LY_SPPF_CG, NQ = CG / 4;
+  extern __shared__ f32x4 ly_sppf_smem[];
+  const int HW = H * W;
+  f32x4* const GA = ly_sppf_smem;                                  // [HW][NQ] running gradient t_{j+1}
+  f32x4* const GB = GA + HW * NQ;                                  // [HW][NQ] t_j being built
+  f32x4* const Y = GB + HW * NQ;                                   // [HW][NQ] y_j as fp32 (exact for bf16 / fp32 inputs)
+  unsigned* const A = reinterpret_cast<unsigned*>(Y + HW * NQ);    // [HW][NQ] four routing bytes
+  const int groups = c / CG;
+  const long n = blockIdx.x / groups;
+  const int c0 = (int)(blockIdx.x - n * groups) * CG;
+  const int tid = threadIdx.x;
+  const T* const bn = buf + n * HW * (long)ldb;
+  const T* const dn = d + n * HW * (long)ldd;
+  for (int i = tid; i < HW * NQ; i += LY_THREADS) {
+    const int pix = i / NQ, q = i - pix * NQ;
+    GA[i] = ly_ld4<T>(dn + (long)pix * ldd + 3 * c + c0 + 4 * q);
+  }
+  f32x4* gin = GA;
+  f32x4* gout = GB;
+  for (int j = 2; j >= 0; --j) {
+    for (int i = tid; i < HW * NQ; i += LY_THREADS) {
+      const int pix = i / NQ, q = i - pix * NQ;
+      Y[i] = ly_ld4<T>(bn + (long)pix * ldb + j * c + c0 + 4 * q);
+    }
+    __syncthreads();
+    for (int i = tid; i < HW * NQ; i += LY_THREADS) {
+      const int pix = i / NQ, q = i - pix * NQ;
+      const int h = pix / W, w = pix - h * W;
+      f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      int a[4] = {-1, -1, -1, -1};
+#pragma unroll
+      for (int t = 0; t < K * K; ++t) {
+        const int yy = h - r + t / K, xx = w - r + t % K;
+        const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+        const f32x4 v = Y[(ok ? yy * W + xx : pix) * NQ + q];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (ok && (v[e] > best[e] || a[e] < 0)) { best[e] = v[e]; a[e] = t; }
+      }
+      A[i] = (unsigned)a[0] | ((unsigned)a[1] << 8) | ((unsigned)a[2] << 16) | ((unsigned)a[3] << 24);
+    }
+    __syncthreads();
+    for (int i = tid; i < HW * NQ; i += LY_THREADS) {
+      const int pix = i / NQ, q = i - pix * NQ;
+      const int h = pix / W, w = pix - h * W;
+      f32x4 sacc = ly_ld4<T>(dn + (long)pix * ldd + j * c + c0 + 4 * q);
+#pragma unroll
+      for (int t = 0; t < K * K; ++t) {
+        // window qp = (h - (ty - r), w - (tx - r)) sees this pixel as its tap t
+        const int qy = h - (t / K - r), qx = w - (t % K - r);
+        const bool ok = qy >= 0 && qy < H && qx >= 0 && qx < W;
+        const int qp = ok ? qy * W + qx : pix;
+        const unsigned av = A[qp * NQ + q];
+        const f32x4 dv = gin[qp * NQ + q];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (ok && ((av >> (8 * e)) & 255u) == (unsigned)t) sacc[e] += dv[e];
+      }
+      if (j == 0) ly_st4<T>(out + (n * HW + pix) * (long)ldo + c0 + 4 * q, sacc);
+      else gout[i] = sacc;
+    }
+    __syncthreads();
+    f32x4* const tmp = gin; gin = gout; gout = tmp;
+  }
+}
+
+// returns 1 (nothing launched) when the map does not fit the fused kernel: the caller then uses ly_maxpool_arg / ly_maxpool_gather
+extern "C" int ly_sppf_bwd(const void* buf, int ldb, const void* d, int ldd, int n_img, int H, int W, int c, int k, void* out, int ldo, int dtype, void* stream) {
+  LY_CHECK_DTYPE(dtype, "sppf_bwd");
+  LY_CHECK(buf && d && out && n_img > 0 && H > 0 && W > 0 && c > 0, "sppf_bwd: bad arguments");
+  const size_t lds = (size_t)H * W * (LY_SPPF_CG / 4) * (3 * sizeof(f32x4) + sizeof(unsigned));
+  if (k != 5 || c % LY_SPPF_CG || (ldb & 3) || (ldd & 3) || (ldo & 3) || lds > 150 * 1024 || (long)n_img * (c / LY_SPPF_CG) > 2000000000L) return 1;
+  const dim3 grid((unsigned)(n_img * (c / LY_SPPF_CG)));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  LY_WITH_T(dtype, {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ly_sppf_bwd_kernel<T, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((ly_sppf_bwd_kernel<T, 5>), grid, dim3(LY_THREADS), lds, st, reinterpret_cast<const T*>(buf), ldb, reinterpret_cast<const T*>(d), ldd, H, W, c,
+                       reinterpret_cast<T*>(out), ldo);
+  });
+  LY_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int ly_maxpool_arg(const void* x, int ldx, int n_img, int H, int W, int C, int k, unsigned char* arg, int lda, int dtype, void* stream) {
   LY_CHECK_DTYPE(dtype, "maxpool_arg");
   LY_CHECK(x && arg && n_img > 0 && H > 0 && W > 0 && k == 5, "maxpool_arg: bad arguments (built for k = 5, SPPF)");

@@ -755,6 +755,14 @@ class SppfPool(torch.autograd.Function):
         L = _lib()
         st = L.stream_ptr()
         dd = _rows_dense(d)
+        if dd.dtype == buf.dtype:
+            # small maps (SPPF sits at stride 32): the three levels in ONE launch, map and routing in LDS (csrc/ly_backward.hip ly_sppf_bwd)
+            out = ops.empty_nhwc(n, c, h, w, buf)
+            rc = L.lib().ly_sppf_bwd(L.ptr(buf), c4, L.ptr(dd), c4, n, h, w, c, k, L.ptr(out), c, L.dtype_code(buf), st)
+            if rc == 0:
+                return out, None
+            if rc != 1:
+                L.check(rc, "ly_sppf_bwd")
         at = lambda t, off: ctypes.c_void_p(t.data_ptr() + t.element_size() * off)
         arg = torch.empty((n * h * w, 3 * c), dtype=torch.uint8, device=buf.device)
         L.check(L.lib().ly_maxpool_arg(L.ptr(buf), c4, n, h, w, 3 * c, k, L.ptr(arg), 3 * c, L.dtype_code(buf), st), "ly_maxpool_arg")

@@ -650,3 +650,38 @@ def test_wgrad_x_prologue(shape, dtype):
     L.ops.wgrad_group([dict(q, dw=dw2), dict(M=m, H=h, W=w, N=C, du=x, lddu=C, x=du, ldx=N, Hin=h, Win=w, Cin=N, dw=other, lddw=N)])
     _close(dw2, want, "prologue in a group", rtol=1e-3 if dtype == torch.float32 else 1e-4)
     _close(other, x.float().t() @ du.float(), "its plain neighbour", rtol=1e-3 if dtype == torch.float32 else 1e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("geom", [(3, 16, 20, 20), (2, 40, 7, 13), (1, 8, 24, 24)])
+def test_sppf_backward_fused_equals_per_level_kernels(geom, dtype):
+    """ly_sppf_bwd (the three max-pool levels of SPPF's backward from LDS, one launch) against the per-level ly_maxpool_arg /
+    ly_maxpool_gather launches it replaces: bit-identical (same routing rule, same summation order), ties included"""
+    import ctypes
+    import lead_yolo_amd as L
+    n, c, h, w = geom
+    dev = _dev()
+    g = torch.Generator().manual_seed(17)
+    y = (torch.randint(-3, 4, (n, c, h, w), generator=g).float() * 0.5).to(dev).to(dtype).contiguous(memory_format=torch.channels_last)   # many ties
+    yr = y.detach().clone().requires_grad_(True)
+    from lead_yolo_amd import grad as Gm
+    buf = Gm.SppfPool.apply(yr, 5)
+    r = torch.randn(buf.shape, generator=g).to(dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    buf.backward(r)
+    fused = yr.grad.clone()
+    # the per-level path, called directly
+    C = L.capi
+    st = C.stream_ptr()
+    at = lambda t, off: ctypes.c_void_p(t.data_ptr() + t.element_size() * off)
+    b = buf.detach()
+    c4 = 4 * c
+    arg = torch.empty((n * h * w, 3 * c), dtype=torch.uint8, device=dev)
+    C.check(C.lib().ly_maxpool_arg(C.ptr(b), c4, n, h, w, 3 * c, 5, C.ptr(arg), 3 * c, C.dtype_code(b), st), "ly_maxpool_arg")
+    up = r[:, 3 * c:].float().contiguous(memory_format=torch.channels_last)
+    tmp = [torch.empty((n * h * w, c), dtype=torch.float32, device=dev) for _ in range(2)]
+    out = L.ops.empty_nhwc(n, c, h, w, b)
+    for j in (2, 1, 0):
+        dst = out if j == 0 else tmp[j & 1]
+        C.check(C.lib().ly_maxpool_gather(at(arg, j * c), 3 * c, C.ptr(up) if j == 2 else C.ptr(tmp[(j + 1) & 1]), c, at(r, j * c), c4, C.dtype_code(r),
+                                          n, h, w, c, 5, C.ptr(dst), c, C.dtype_code(dst), st), "ly_maxpool_gather")
+    assert torch.equal(fused, out)

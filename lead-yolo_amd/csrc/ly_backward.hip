@@ -1428,9 +1428,14 @@ __global__ __launch_bounds__(LY_THREADS) void ly_sppf_bwd_kernel(const T* __rest
   f32x4* gin = GA;
   f32x4* gout = GB;
   for (int j = 2; j >= 0; --j) {
+    // y_j and d_j of the level are requested together (d_j waits in gout, which the gather below overwrites item by item): one memory
+    // round trip per level instead of two
     for (int i = tid; i < HW * NQ; i += LY_THREADS) {
       const int pix = i / NQ, q = i - pix * NQ;
-      Y[i] = ly_ld4<T>(bn + (long)pix * ldb + j * c + c0 + 4 * q);
+      const f32x4 yv = ly_ld4<T>(bn + (long)pix * ldb + j * c + c0 + 4 * q);
+      const f32x4 dv = ly_ld4<T>(dn + (long)pix * ldd + j * c + c0 + 4 * q);
+      Y[i] = yv;
+      gout[i] = dv;
     }
     __syncthreads();
     for (int i = tid; i < HW * NQ; i += LY_THREADS) {
@@ -1453,7 +1458,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_sppf_bwd_kernel(const T* __rest
     for (int i = tid; i < HW * NQ; i += LY_THREADS) {
       const int pix = i / NQ, q = i - pix * NQ;
       const int h = pix / W, w = pix - h * W;
-      f32x4 sacc = ly_ld4<T>(dn + (long)pix * ldd + j * c + c0 + 4 * q);
+      f32x4 sacc = gout[i];
 #pragma unroll
       for (int t = 0; t < K * K; ++t) {
         // window qp = (h - (ty - r), w - (tx - r)) sees this pixel as its tap t

@@ -951,11 +951,106 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_tap_moments_kernel(const
   }
 }
 
+// Stride-2 form through an LDS tile (the two k = 3 RFCBAMConv layers of the detector): a block walks 8 x 8 tiles of output pixels; the 17 x 17 input
+// pixels x 64 channels of a tile are staged ONCE with 16-byte loads, lane = channel then reads its nine taps from LDS.  The 54 moments stay in
+// registers over all tiles of the block and are reduced over its four waves before ONE atomic per moment, channel and block — the per-pixel
+// kernel above issues eighteen 2-byte loads per trip and 54 atomics per thread (91 us per launch at bs=64; fewer blocks starve it of loads in
+// flight, more blocks drown it in atomics).
+#define LY_TM_T 8
+template <typename T>
+__global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_tap_moments_s2t_kernel(const T* __restrict__ x, int ldx, int n_img, int H, int W, int C, int Ho, int Wo,
+                                                                                int tiles_y, int tiles_x, float* __restrict__ mom) {
+  constexpr int TM = LY_TM_T, TW = 2 * TM + 1, NPX = TW * TW;
+  constexpr int VE = 16 / (int)sizeof(T), VPR = 64 / VE;
+  extern __shared__ f32x4 ly_tm_smem[];
+  T* const tile = reinterpret_cast<T*>(ly_tm_smem);              // [NPX][64]
+  float* const red = reinterpret_cast<float*>(ly_tm_smem);       // reused after the walk: [4][27][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c0 = blockIdx.y * 64;
+  const int c = c0 + lane;
+  const bool cok = c < C;
+  float m1[9], m2[45];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) m1[i] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 45; ++i) m2[i] = 0.f;
+  const long ntiles = (long)n_img * tiles_y * tiles_x;
+  for (long tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {
+    const int tx = (int)(tix % tiles_x);
+    const long q = tix / tiles_x;
+    const int ty = (int)(q % tiles_y);
+    const long n = q / tiles_y;
+    const int oy0 = ty * TM, ox0 = tx * TM;
+    __syncthreads();                                             // the previous tile has been consumed
+    for (int i = tid; i < NPX * VPR; i += LY_THREADS) {
+      const int px = i / VPR, v = i - px * VPR;
+      const int iy = 2 * oy0 - 1 + px / TW, ix = 2 * ox0 - 1 + px % TW;
+      const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W && c0 + v * VE < C;
+      const int cy = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), cx = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
+      ly_u32x4 raw = *reinterpret_cast<const ly_u32x4*>(x + ((n * H + cy) * W + cx) * (long)ldx + (c0 + v * VE < C ? c0 + v * VE : 0));
+      if (!ok) raw = (ly_u32x4){0u, 0u, 0u, 0u};
+      *reinterpret_cast<ly_u32x4*>(tile + (long)px * 64 + v * VE) = raw;
+    }
+    __syncthreads();
+    for (int p = wave; p < TM * TM; p += 4) {
+      const int oyl = p / TM, oxl = p - oyl * TM;
+      const bool live = oy0 + oyl < Ho && ox0 + oxl < Wo;
+      float xv[9];
+#pragma unroll
+      for (int u = 0; u < 9; ++u) {
+        const float v = (float)tile[((2 * oyl + u / 3) * TW + 2 * oxl + u % 3) * 64 + lane];
+        xv[u] = live ? v : 0.f;
+      }
+      int k = 0;
+#pragma unroll
+      for (int u = 0; u < 9; ++u) {
+        m1[u] += xv[u];
+#pragma unroll
+        for (int v = u; v < 9; ++v) m2[k++] += xv[u] * xv[v];
+      }
+    }
+  }
+  // block reduction over the four waves, two rounds of 27 moments through the tile's LDS, then one atomic per (moment, channel)
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 27; ++i) {
+      const int e = half * 27 + i;
+      red[(wave * 27 + i) * 64 + lane] = e < 9 ? m1[e < 9 ? e : 0] : m2[e >= 9 ? e - 9 : 0];
+    }
+    __syncthreads();
+    for (int j = tid; j < 27 * 64; j += LY_THREADS) {
+      const int i = j >> 6, l = j & 63;
+      if (c0 + l < C) atomicAdd(mom + (long)(half * 27 + i) * C + c0 + l, red[j] + red[27 * 64 + j] + red[2 * 27 * 64 + j] + red[3 * 27 * 64 + j]);
+    }
+  }
+  (void)cok;
+}
+
 extern "C" int ly_rfcbam_tap_moments(const void* x, int ldx, int n_img, int H, int W, int C, int s, float* mom, int dtype, void* stream) {
   LY_CHECK_DTYPE(dtype, "rfcbam_tap_moments");
   LY_CHECK(x && mom && s >= 1 && C > 0, "rfcbam_tap_moments: bad arguments");
   const int Ho = (H + 2 - 3) / s + 1, Wo = (W + 2 - 3) / s + 1;
   long npix = (long)n_img * Ho * Wo;
+  const int esz = dtype == LY_BF16 ? 2 : 4;
+  if (s == 2 && C % (16 / esz) == 0 && ldx % (16 / esz) == 0 && ((uintptr_t)x & 15) == 0) {
+    const int tiles_y = (Ho + LY_TM_T - 1) / LY_TM_T, tiles_x = (Wo + LY_TM_T - 1) / LY_TM_T;
+    const int groups = (C + 63) / 64;
+    long nb = (long)n_img * tiles_y * tiles_x;
+    const long cap = 768 / groups > 0 ? 768 / groups : 1;               // ~768 blocks: 3456 atomics each
+    if (nb > cap) nb = cap;
+    constexpr int NPX = (2 * LY_TM_T + 1) * (2 * LY_TM_T + 1);
+    size_t lds = (size_t)NPX * 64 * esz;
+    if (lds < 4 * 27 * 64 * sizeof(float)) lds = 4 * 27 * 64 * sizeof(float);
+    LY_WITH_T(dtype, {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ly_rfcbam_tap_moments_s2t_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(ly_rfcbam_tap_moments_s2t_kernel<T>, dim3((unsigned)nb, (unsigned)groups), dim3(LY_THREADS), lds, reinterpret_cast<hipStream_t>(stream),
+                         reinterpret_cast<const T*>(x), ldx, n_img, H, W, C, Ho, Wo, tiles_y, tiles_x, mom);
+    });
+    LY_LAUNCH_CHECK();
+    return 0;
+  }
   long blocks = npix / 32 + 1;
   if (blocks > 1024) blocks = 1024;
   LY_WITH_T(dtype, hipLaunchKernelGGL(ly_rfcbam_tap_moments_kernel<T>, dim3((unsigned)blocks), dim3(LY_THREADS), 0, reinterpret_cast<hipStream_t>(stream),

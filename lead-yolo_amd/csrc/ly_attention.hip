@@ -969,11 +969,14 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_tap_moments_s2t_kernel(c
   const int c0 = blockIdx.y * 64;
   const int c = c0 + lane;
   const bool cok = c < C;
-  float m1[9], m2[45];
+  // two output pixels per trip as the halves of float2 accumulators: the 54 multiply-adds per pixel become 54 packed ones per PAIR
+  // (v_pk_fma_f32) — the kernel is bound by exactly these
+  typedef float ly_f2 __attribute__((ext_vector_type(2)));
+  ly_f2 a1[9], a2[45];
 #pragma unroll
-  for (int i = 0; i < 9; ++i) m1[i] = 0.f;
+  for (int i = 0; i < 9; ++i) a1[i] = (ly_f2){0.f, 0.f};
 #pragma unroll
-  for (int i = 0; i < 45; ++i) m2[i] = 0.f;
+  for (int i = 0; i < 45; ++i) a2[i] = (ly_f2){0.f, 0.f};
   const long ntiles = (long)n_img * tiles_y * tiles_x;
   for (long tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {
     const int tx = (int)(tix % tiles_x);
@@ -992,24 +995,31 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_tap_moments_s2t_kernel(c
       *reinterpret_cast<ly_u32x4*>(tile + (long)px * 64 + v * VE) = raw;
     }
     __syncthreads();
-    for (int p = wave; p < TM * TM; p += 4) {
-      const int oyl = p / TM, oxl = p - oyl * TM;
-      const bool live = oy0 + oyl < Ho && ox0 + oxl < Wo;
-      float xv[9];
+    for (int p = wave; p < TM * TM; p += 8) {                   // pixels p and p + 4 (TM*TM is a multiple of 8)
+      const int pa = p, pb = p + 4;
+      const int ya = pa / TM, xa = pa - ya * TM, yb = pb / TM, xb = pb - yb * TM;
+      const bool la = oy0 + ya < Ho && ox0 + xa < Wo, lb = oy0 + yb < Ho && ox0 + xb < Wo;
+      ly_f2 xv[9];
 #pragma unroll
       for (int u = 0; u < 9; ++u) {
-        const float v = (float)tile[((2 * oyl + u / 3) * TW + 2 * oxl + u % 3) * 64 + lane];
-        xv[u] = live ? v : 0.f;
+        const float va = (float)tile[((2 * ya + u / 3) * TW + 2 * xa + u % 3) * 64 + lane];
+        const float vb = (float)tile[((2 * yb + u / 3) * TW + 2 * xb + u % 3) * 64 + lane];
+        xv[u] = (ly_f2){la ? va : 0.f, lb ? vb : 0.f};
       }
       int k = 0;
 #pragma unroll
       for (int u = 0; u < 9; ++u) {
-        m1[u] += xv[u];
+        a1[u] += xv[u];
 #pragma unroll
-        for (int v = u; v < 9; ++v) m2[k++] += xv[u] * xv[v];
+        for (int v = u; v < 9; ++v) a2[k++] += xv[u] * xv[v];
       }
     }
   }
+  float m1[9], m2[45];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) m1[i] = a1[i][0] + a1[i][1];
+#pragma unroll
+  for (int i = 0; i < 45; ++i) m2[i] = a2[i][0] + a2[i][1];
   // block reduction over the four waves, two rounds of 27 moments through the tile's LDS, then one atomic per (moment, channel)
 #pragma unroll
   for (int half = 0; half < 2; ++half) {

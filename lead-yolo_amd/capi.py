@@ -93,7 +93,9 @@ SIGNATURES = {
     "ly_rfcbam3_fwd": [ctypes.POINTER(LyRfcbam3Params), _P],
     "ly_chan_moments": [_P, _I, _L, _I, _P, _I, _P],
     "ly_rfcbam_tap_moments": [_P, _I, _I, _I, _I, _I, _I, _P, _I, _P],
-    "ly_rfcbam_gen_prepare": [_P, _I, _I, _P, _P, _P, _F, _F, ctypes.c_double, _P, _P, _P, _P, _P, _P, _P, _P],
+    "ly_rfcbam_gen_prepare": [_P, _I, _I, _P, _P, _P, _F, _F, ctypes.c_double, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "ly_rf3c_stats": [_P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P, _I, _I, _P],
+    "ly_rf3c_fwd": [ctypes.POINTER(LyRfcbam3Params), _P, _P],
     "ly_coordatt_conv1_stats": [_P, _L, _I, _I, _P, _P, _P, _P],
     "ly_sppf_pool": [_P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P],
     "ly_bnact_fwd": [_P, _I, _L, _I, _P, _P, _I, _P, _I, _I, _P],

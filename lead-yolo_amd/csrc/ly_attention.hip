@@ -1292,7 +1292,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_gen_prepare_kernel(
     const float* __restrict__ mom, int C, int KK, const float* __restrict__ gen_w, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, float momentum, double count, float* __restrict__ running_mean,
     float* __restrict__ running_var, long* __restrict__ nbt, float* __restrict__ out8 /* [8][C*KK] */, float* __restrict__ a1,
-    float* __restrict__ wq_stats, int cp_stats, float* __restrict__ wq_main, int cp_main) {
+    float* __restrict__ wq_stats, int cp_stats, float* __restrict__ wq_main, int cp_main, float* __restrict__ wq_c) {
   const int G = C * KK;
   const int cpm = cp_stats > cp_main ? cp_stats : cp_main;
   const int total = (KK == 9 ? (cpm > C ? cpm : C) : C) * KK;
@@ -1344,6 +1344,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_gen_prepare_kernel(
         const float v = e < 9 ? w[e] * sc : sh;
         wq_stats[ly_gw_index(c, t, e, 32, false)] = v;
         wq_main[ly_gw_index(c, t, e, 16, true)] = v;
+        if (wq_c) wq_c[(long)c * 92 + (e < 9 ? t * 9 + e : 81 + t)] = v;       // lane = channel order (ly_rf3c.cuh)
       }
     } else {
       a1[g] = w[0] * sc;
@@ -1354,7 +1355,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_gen_prepare_kernel(
 
 extern "C" int ly_rfcbam_gen_prepare(const float* mom, int C, int k, const float* gen_w, const float* gamma, const float* beta, float eps,
                                      float momentum, double count, float* running_mean, float* running_var, long* nbt, float* out8,
-                                     float* a1, float* wq_stats, float* wq_main, void* stream) {
+                                     float* a1, float* wq_stats, float* wq_main, float* wq_c, void* stream) {
   LY_CHECK(mom && gen_w && gamma && beta && out8 && C > 0 && (k == 1 || k == 3) && count > 0, "rfcbam_gen_prepare: bad arguments");
   LY_CHECK(k == 1 ? a1 != nullptr : (wq_stats && wq_main), "rfcbam_gen_prepare: missing output for k=%d", k);
   LY_CHECK(!running_mean == !running_var, "rfcbam_gen_prepare: running_mean and running_var go together");
@@ -1363,7 +1364,7 @@ extern "C" int ly_rfcbam_gen_prepare(const float* mom, int C, int k, const float
   const int total = (k == 3 ? cp_s : C) * KK;
   hipLaunchKernelGGL(ly_rfcbam_gen_prepare_kernel, dim3((unsigned)((total + LY_THREADS - 1) / LY_THREADS)), dim3(LY_THREADS), 0,
                      reinterpret_cast<hipStream_t>(stream), mom, C, KK, gen_w, gamma, beta, eps, momentum, count, running_mean, running_var, nbt,
-                     out8, a1, wq_stats, k == 3 ? cp_s : 0, wq_main, k == 3 ? cp_m : 0);
+                     out8, a1, wq_stats, k == 3 ? cp_s : 0, wq_main, k == 3 ? cp_m : 0, k == 3 ? wq_c : nullptr);
   LY_LAUNCH_CHECK();
   return 0;
 }

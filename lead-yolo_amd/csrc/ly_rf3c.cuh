@@ -1,0 +1,176 @@
+// RFCBAMConv kernel_size 3, "lane = channel" core (reference models/rfa.py:101-129), gfx950.
+//
+// The depthwise `generate` conv produces, per output pixel p and input channel c, nine values (one per tap t)
+//      v[p, t, c] = sum_u Wd[c, t, u] * x[patch(p, u), c]              (81 MAC per pixel and channel)
+// that the reference materialises as a 9x expanded tensor.  Every kernel of this family REGENERATES them on chip.  The first
+// generation of kernels (ly_rfcbam3.hip, ly_attention.hip) mapped lanes to pixels, which makes the 81 weights of a channel
+// wave-uniform: they came out of LDS as broadcast reads and the LDS pipe, not the VALU, set the time.  Here
+//      lane = channel (32 channels x 2 pixel streams per wave),
+// so the 81 weights (+ 9 folded biases) of the lane's channel sit in 92 registers for a whole 32-channel chunk, the x patch is
+// read from an fp32 LDS tile with conflict-free per-lane reads, two horizontally adjacent output pixels are computed together as
+// the halves of v_pk_fma_f32 (the weight is broadcast by op_sel, no duplicated registers), and whatever has to change hands
+// between the channel-parallel VALU phase and a pixel-parallel phase (MFMA operand, channel reductions) goes through ONE
+// K-major LDS tile  [k = t*32 + c][pixel]  whose pixel pairs are stored as one dword / qword per lane.
+//
+// unit of work: (tile of <= 64 output pixels, TH x TW with TW even) x (chunk of 32 channels).
+#pragma once
+#include "ly_tile.cuh"
+
+#define RC_CB 32                 // channels per chunk
+#define RC_TP 64                 // output-pixel slots per tile
+#define RC_KR (9 * RC_CB)        // operand rows of a chunk: k = t*32 + c
+#define RC_WQ 92                 // floats per channel in the generate-weight image: w[t][u] (81), b[t] (9), 2 pad  (23 x 16 bytes)
+#define RC_MAXPOS 320            // input positions of a tile (IH*IW) the staging registers are sized for (8x8 / 4x16 tiles at stride 2)
+
+typedef short ly_s16x4 __attribute__((ext_vector_type(4)));
+
+// acc + x * w[SEL] (both halves of x times ONE weight): the weight pair register is shared by two taps, op_sel picks the dword
+__device__ __forceinline__ f32x2 rc_pkfma(const f32x2 x, const f32x2 w, f32x2 acc, const int sel) {
+  if (sel) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(x), "v"(w));
+  else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(x), "v"(w));
+  return acc;
+}
+// x * w[SEL] + b[SELB]  (first term of a chain: the folded bias is broadcast the same way)
+__device__ __forceinline__ f32x2 rc_pkfma_b(const f32x2 x, const f32x2 w, const f32x2 b, const int sel, const int selb) {
+  f32x2 r;
+  if (sel) {
+    if (selb) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,1] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(x), "v"(w), "v"(b));
+    else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,0]" : "=v"(r) : "v"(x), "v"(w), "v"(b));
+  } else {
+    if (selb) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(x), "v"(w), "v"(b));
+    else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(x), "v"(w), "v"(b));
+  }
+  return r;
+}
+// x * w[SEL]
+__device__ __forceinline__ f32x2 rc_pkmul(const f32x2 x, const f32x2 w, const int sel) {
+  f32x2 r;
+  if (sel) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(x), "v"(w));
+  else asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(r) : "v"(x), "v"(w));
+  return r;
+}
+
+// the lane's 92 generate weights: wq[c][92] floats, 23 aligned 16-byte loads; element i is pair i>>1, dword i&1
+struct RcW {
+  f32x2 p[RC_WQ / 2];
+};
+__device__ __forceinline__ void rc_load_w(RcW& w, const float* __restrict__ wq_c) {
+#pragma unroll
+  for (int i = 0; i < RC_WQ / 4; ++i) {
+    const f32x4 v = ly_ldg4(wq_c + 4 * i);
+    w.p[2 * i] = (f32x2){v[0], v[1]};
+    w.p[2 * i + 1] = (f32x2){v[2], v[3]};
+  }
+}
+
+// v[t] (pixel pair) = b[t] + sum_u w[t][u] * x[u]: nine independent chains, interleaved so that no packed FMA waits for its predecessor
+template <bool BIAS>
+__device__ __forceinline__ void rc_generate(const RcW& w, const f32x2 (&x)[9], f32x2 (&a)[9]) {
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    if constexpr (BIAS) a[t] = rc_pkfma_b(x[0], w.p[(t * 9) >> 1], w.p[(81 + t) >> 1], (t * 9) & 1, (81 + t) & 1);
+    else a[t] = rc_pkmul(x[0], w.p[(t * 9) >> 1], (t * 9) & 1);
+  }
+#pragma unroll
+  for (int u = 1; u < 9; ++u)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) a[t] = rc_pkfma(x[u], w.p[(t * 9 + u) >> 1], a[t], (t * 9 + u) & 1);
+}
+
+// tile geometry shared by the kernels of the family
+struct RcGeom {
+  int s, TH, TW, IH, IW, NPX;
+};
+__device__ __forceinline__ RcGeom rc_geom(int s, int TH, int TW) {
+  RcGeom g;
+  g.s = s; g.TH = TH; g.TW = TW;
+  g.IH = s * (TH - 1) + 3; g.IW = s * (TW - 1) + 3;
+  g.NPX = TH * TW;
+  return g;
+}
+
+// ---- x tile: fp32 [IH*IW][32] -----------------------------------------------------------------------
+// staging plan of one thread: items (input position, VW-channel group), NV per thread
+template <typename T, int NTHR = LY_THREADS> struct RcStage {
+  static constexpr int VW = LyT<T>::VW;
+  static constexpr int GP = RC_CB / VW;                                        // channel groups per position: 8 (fp32) / 4 (bf16)
+  static constexpr int NV = (RC_MAXPOS * GP + NTHR - 1) / NTHR;                // 256 threads: 10 / 5
+  int soff[NV];        // element offset of the item in x (channel c0 = 0), -1: outside the image / no item
+  int doff[NV];        // float index in the LDS tile, -1: no item
+  typename LyT<T>::RV pv[NV];
+};
+template <typename T, int NTHR>
+__device__ __forceinline__ void rc_stage_plan(RcStage<T, NTHR>& S, const RcGeom& g, int tid, int n, int H, int W, int ldx, int iy0, int ix0) {
+  constexpr int GP = RcStage<T, NTHR>::GP, VW = RcStage<T, NTHR>::VW;
+  const int items = g.IH * g.IW * GP;
+#pragma unroll
+  for (int e = 0; e < RcStage<T, NTHR>::NV; ++e) {
+    const int idx = tid + e * NTHR;
+    int so = -1, dd = -1;
+    if (idx < items) {
+      const int ip = idx / GP, cv = idx - ip * GP;
+      const int r = ip / g.IW, q = ip - r * g.IW;
+      const int iy = iy0 + r, ix = ix0 + q;
+      dd = ip * RC_CB + VW * cv;
+      if (iy >= 0 && iy < H && ix >= 0 && ix < W) so = (int)((((long)n * H + iy) * W + ix) * ldx + VW * cv);
+    }
+    S.soff[e] = so; S.doff[e] = dd;
+  }
+}
+template <typename T, int NTHR>
+__device__ __forceinline__ void rc_stage_load(RcStage<T, NTHR>& S, const T* __restrict__ x, int c0) {
+#pragma unroll
+  for (int e = 0; e < RcStage<T, NTHR>::NV; ++e) S.pv[e] = ly_ldrv<T>(S.soff[e] >= 0 ? x + S.soff[e] + c0 : x);      // clamped address, never a branch around a load
+}
+template <typename T, int NTHR>
+__device__ __forceinline__ void rc_stage_store(const RcStage<T, NTHR>& S, float* __restrict__ xs) {
+#pragma unroll
+  for (int e = 0; e < RcStage<T, NTHR>::NV; ++e)
+    if (S.doff[e] >= 0) {
+      f32x4 q[RcStage<T, NTHR>::VW / 4];
+      ly_rv_unpack(S.pv[e], q);
+      const bool ok = S.soff[e] >= 0;
+#pragma unroll
+      for (int i = 0; i < RcStage<T, NTHR>::VW / 4; ++i) *reinterpret_cast<f32x4*>(xs + S.doff[e] + 4 * i) = ok ? q[i] : ly_zero4();
+    }
+}
+
+// the 9 patch values of the pixel pair whose first pixel has tile position pos0 = (s*ly)*IW + s*lx, channel lane c
+__device__ __forceinline__ void rc_patch(const float* __restrict__ xs, const RcGeom& g, int pos0, int c, f32x2 (&x)[9]) {
+#pragma unroll
+  for (int u = 0; u < 9; ++u) {
+    const int p = pos0 + (u / 3) * g.IW + (u % 3);
+    x[u] = (f32x2){xs[p * RC_CB + c], xs[(p + g.s) * RC_CB + c]};
+  }
+}
+
+// ---- K-major bf16 operand tile [288][64 px], 128-byte rows, 8-byte chunks XOR-swizzled by the row -----------------
+//   chunk' = chunk ^ sw(k),  sw(k) = 4*((k>>1)&3) ^ ((k>>3)&3)
+// writes (32 lanes = 32 consecutive rows, same pixel pair): 16 chunk positions x 2 lanes: 2-way, free for ds_write_b32;
+// transposed reads (ds_read_b64_tr_b16, a half wave = 8 consecutive rows x 4 chunks): all 64 banks, conflict-free.
+__device__ __forceinline__ int rc_sw(int k) { return (((k >> 1) & 3) << 2) ^ ((k >> 3) & 3); }
+__device__ __forceinline__ int rc_goff(int k, int px0) { return k * 128 + ((((px0 >> 2) ^ rc_sw(k)) << 3) | ((px0 & 2) << 1)); }
+
+__device__ __forceinline__ unsigned rc_pack2(const f32x2 v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2)); }
+__device__ __forceinline__ f32x2 rc_unpack2(const unsigned u) { return (f32x2){__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xffff0000u)}; }
+
+// B-operand fragment (k-step = 32 rows starting at row k32, pixel tile j of 16) for the lane: two transposed reads
+struct RcTr {
+  int b0, b1, s0, s1, p;      // byte offsets of the lane's block row in the two 4-row blocks, their swizzles, its 8-byte chunk
+};
+__device__ __forceinline__ RcTr rc_tr_plan(int lane) {
+  const int li = lane & 15, q = lane >> 4;
+  const int r0 = 4 * q + (li >> 2), r1 = 16 + r0;
+  RcTr t;
+  t.b0 = r0 * 128; t.b1 = r1 * 128;
+  t.s0 = rc_sw(r0); t.s1 = rc_sw(r1);
+  t.p = li & 3;
+  return t;
+}
+__device__ __forceinline__ bf16x8 rc_tr_frag(const char* __restrict__ plane, const RcTr& t, int k32, int j) {
+  typedef __attribute__((address_space(3))) ly_s16x4 lds_s16x4;
+  const char* base = plane + k32 * 128;
+  const ly_s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + t.b0 + (((4 * j + t.p) ^ t.s0) << 3)));
+  const ly_s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + t.b1 + (((4 * j + t.p) ^ t.s1) << 3)));
+  return ly_cat8(__builtin_bit_cast(bf16x4, a), __builtin_bit_cast(bf16x4, b));
+}

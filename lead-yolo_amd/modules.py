@@ -561,8 +561,17 @@ class RFCBAMConv(nn.Module):
             wq_main = pack.rfcbam_gen_weights(gw, gs, gb, 16, True)             # main kernel: 16-ch chunks, c0 + 4w + j
             # conv.0.weight [o, c, 3, 3] read as [o][c/16 chunks][10 tap slots (9 real)][16 channels]: k = chunk*160 + t*16 + ch
             wsrc = pack.Src(cw.weight, o, srb=c * 9, nb=10, vb=9, nc=16, sa=144, sb=1, sc=9)
-            return dict(wq_stats=wq_stats, wq_main=wq_main, w18=w18, wp=pack.packed(wsrc, (c // 16) * 160, planes), es=es, eb=eb)
+            d = dict(wq_stats=wq_stats, wq_main=wq_main, w18=w18, wp=pack.packed(wsrc, (c // 16) * 160, planes), es=es, eb=eb)
+            if ops.rf3c_ok(c, self.stride):
+                d["wq_c"] = pack.rfcbam_gen_weights_c(gw, gs, gb)
+                d["wp_c"] = self._wp_c(planes)
+            return d
         return self._prep.get(key, build, planes)
+
+    def _wp_c(self, planes):
+        """conv.0.weight [o, c, 3, 3] read as [o][c/32 chunks][9 taps][32 channels] (k = chunk*288 + t*32 + ch): the operand of ly_rf3c_fwd"""
+        cw, c = self.conv[0], self.c
+        return pack.packed(pack.Src(cw.weight, self.o, srb=c * 9, nb=9, nc=32, sa=288, sb=1, sc=9), 9 * c, planes)
 
     def _packed_train(self, planes=2):
         """what the training node (grad.RfcbamFn) needs of `_packed`: the conv weight image and get_weight's taps.  Keyed on those two
@@ -576,6 +585,8 @@ class RFCBAMConv(nn.Module):
             w18 = self.get_weight[0].weight.detach().float().reshape(18).contiguous()
             if k == 1:
                 return dict(w18=w18, wp=pack.packed(pack.src_matrix(cw.weight, o, c), c, planes))
+            if ops.rf3c_ok(c, self.stride):
+                return dict(w18=w18, wp_c=self._wp_c(planes))
             wsrc = pack.Src(cw.weight, o, srb=c * 9, nb=10, vb=9, nc=16, sa=144, sb=1, sc=9)
             return dict(w18=w18, wp=pack.packed(wsrc, (c // 16) * 160, planes))
         if not hasattr(self, "_prep_train"):
@@ -623,6 +634,8 @@ class RFCBAMConv(nn.Module):
             ops.gemm(out=out, e_scale=es, e_shift=eb, act=ACT_RELU, **kw)
             return out
         ho, wo = (h + 2 - 3) // s + 1, (w + 2 - 3) // s + 1
+        if ops.rf3c_ok(c, s) and RF3C:
+            return self._forward3_c(xr, ld, n, c, h, w, ho, wo, s, P, wa, wb)
         th, tw = ops.pick_tile(ho, wo)
         wq_stats, wq_main, es, eb = P["wq_stats"], P["wq_main"], P["es"], P["eb"]
         if self.training:
@@ -644,6 +657,32 @@ class RFCBAMConv(nn.Module):
         out = ops.empty_nhwc(n, self.o, ho, wo, xr)
         ops.rfcbam3(out=out, e_scale=es, e_shift=eb, **kw)
         return out
+
+
+    def _forward3_c(self, xr, ld, n, c, h, w, ho, wo, s, P, wa, wb):
+        """k = 3 on the lane = channel kernels (csrc/ly_rf3c.hip), three launches, x read twice: (1) [max, mean] map + SE pooling partials,
+        (2) SE linears + get_weight's conv on the small maps, (3) regenerate + contraction."""
+        th, tw = ops.pick_tile_c(ho, wo, s)
+        wq, es, eb = P["wq_c"], P["es"], P["eb"]
+        if self.training:
+            gw = self.generate[0].weight
+            s1, s2, cnt = ops.rfcbam_generate_stats(xr, ld, n, h, w, c, s, gw)                # generate.1 batch statistics
+            gs, gb = ops.bn_batch_affine(self.generate[1], s1, s2, cnt)
+            wq = pack.rfcbam_gen_weights_c(gw, gs, gb)
+        mm, part = ops.rf3c_stats(xr, ld, n, h, w, c, s, wq, th, tw)
+        ca, rfa = ops.rfcbam_mid(part, h * w, wa, wb, self.se.ratio, mm, P["w18"])
+        kw = dict(n=n, h=h, w=w, c=c, ho=ho, wo=wo, N=self.o, s=s, th=th, tw=tw, x=xr, ldx=ld, wq=wq, ca=ca, rfa=rfa, wp=P["wp_c"], ldo=self.o)
+        if self.training:
+            bias = self.conv[0].bias.detach().float().contiguous()
+            stats = ops.new_stats(self.o, xr.device)
+            ops.rf3c_fwd(out=None, e_scale=torch.ones_like(bias), e_shift=bias, stats=stats, **kw)   # conv.1 statistics pass
+            es, eb = ops.bn_finalize(self.conv[1], stats, self.o, n * ho * wo, bias=bias)
+        out = ops.empty_nhwc(n, self.o, ho, wo, xr)
+        ops.rf3c_fwd(out=out, e_scale=es, e_shift=eb, **kw)
+        return out
+
+
+RF3C = True        # tools / tests: False runs the first-generation k=3 kernels (lane = pixel) for A/B comparisons
 
 
 # --------------------------------------------------------------------------------------------------

@@ -312,6 +312,51 @@ def pick_tile(ho, wo):
     return best[1], best[2]
 
 
+def rf3c_ok(c, s):
+    """the lane = channel RFCBAMConv k=3 kernels (csrc/ly_rf3c.hip) cover C % 32 == 0 at stride 1 / 2"""
+    return c % 32 == 0 and s in (1, 2)
+
+
+def pick_tile_c(ho, wo, s):
+    """TH x TW tile of the lane = channel kernels: TW even, TH*TW <= 64, at most 320 input positions; fewest tiles, then smallest halo"""
+    best = None
+    for tw in range(2, 65, 2):
+        th = min(64 // tw, ho)
+        if th < 1:
+            continue
+        pos = (s * (th - 1) + 3) * (s * (tw - 1) + 3)
+        if pos > 320:
+            continue
+        tiles = -(-ho // th) * -(-wo // tw)
+        key = (tiles, pos)
+        if best is None or key < best[0]:
+            best = (key, th, tw)
+    return best[1], best[2]
+
+
+def rf3c_stats(x, ldx, n, h, w, c, s, wq, th, tw, gap=True):
+    """ONE pass over x: (mm [n, 3ho, 3wo, 2], part [n, tiles, c]) — the [max, mean] map of relu(bn(generate(x))) and SE's pooling partials"""
+    ho, wo = (h + 2 - 3) // s + 1, (w + 2 - 3) // s + 1
+    mm = torch.empty((n, 3 * ho, 3 * wo, 2), dtype=torch.float32, device=x.device)
+    tiles = -(-ho // th) * -(-wo // tw)
+    part = torch.empty((n, tiles, c), dtype=torch.float32, device=x.device) if gap else None
+    with _Timed(f"ly_rf3c_stats_kernel<{_tname(x)}>", 2.0 * n * ho * wo * c * 81, x.element_size() * n * h * w * c + 4.0 * 18 * n * ho * wo):
+        capi.check(capi.lib().ly_rf3c_stats(_p(x), ldx, n, h, w, c, s, _p(wq), th, tw, _p(mm), _p(part), tiles, capi.dtype_code(x),
+                                            capi.stream_ptr()), "ly_rf3c_stats")
+    return mm, part
+
+
+def rf3c_fwd(*, n, h, w, c, ho, wo, N, s, th, tw, x, ldx, wq, ca, rfa, wp, e_scale, e_shift, out, ldo, stats=None, linear=False):
+    P = capi.LyRfcbam3Params(n, h, w, c, ho, wo, N, s, th, tw, _p(x), ldx, None, _p(ca), _p(rfa), _p(wp), _p(e_scale),
+                             _p(e_shift), _p(out), ldo, _p(stats), int(linear), capi.dtype_code(x))
+    mo = n * ho * wo
+    bf = x.dtype == torch.bfloat16
+    cfg = "2, 8" if (N > 128 and bf) else ("2, 4" if N > 64 else "1, 4")         # mirrors rc_dispatch_fwd
+    with _Timed(f"ly_rf3c_fwd_kernel<{_tname(x)}, {cfg}>", 2.0 * mo * (9 * c * N + 81 * c),
+                x.element_size() * (n * h * w * c + mo * N) + 4.0 * 9 * c * N):
+        capi.check(capi.lib().ly_rf3c_fwd(ctypes.byref(P), _p(wq), capi.stream_ptr()), "ly_rf3c_fwd")
+
+
 def rfcbam_stats(x, ldx, n, h, w, c, k, s, wg=None, a1=None, b1=None, th=1, tw=64, gap=False):
     """[max, mean] map of relu(bn(generate(x))); gap=True: the same pass also leaves the SE pooling partials -> (mm, part)"""
     ho, wo = ((h + 2 * (k // 2) - k) // s + 1, (w + 2 * (k // 2) - k) // s + 1)
@@ -600,17 +645,18 @@ def rfcbam_gen_prepare(x, ldx, n, h, w, c, k, s, gen_w, bn):
     cps, cpm = (c + 31) // 32 * 32, (c + 15) // 16 * 16
     wqs = torch.empty(cps * 90, dtype=torch.float32, device=dev) if k == 3 else None
     wqm = torch.empty(cpm * 90, dtype=torch.float32, device=dev) if k == 3 else None
+    wqc = torch.empty(c * 92, dtype=torch.float32, device=dev) if k == 3 else None
     if bn.weight.dtype != torch.float32:
         raise NotImplementedError("train-mode BatchNorm needs float32 parameters and buffers")
     track = bn.track_running_stats and bn.running_mean is not None
     capi.check(capi.lib().ly_rfcbam_gen_prepare(_p(mom), c, k, _p(gen_w.detach()), _p(bn.weight.detach()), _p(bn.bias.detach()), float(bn.eps),
                                                 float(bn.momentum or 0.0), float(count), _p(bn.running_mean if track else None),
                                                 _p(bn.running_var if track else None), _p(bn.num_batches_tracked if track else None), _p(out8),
-                                                _p(a1), _p(wqs), _p(wqm), capi.stream_ptr()), "ly_rfcbam_gen_prepare")
+                                                _p(a1), _p(wqs), _p(wqm), _p(wqc), capi.stream_ptr()), "ly_rfcbam_gen_prepare")
     from . import pack
     pack.touch()                                   # running statistics written behind torch's version counters
     return dict(gs=out8[0], gb=out8[1], gmean=out8[2], ginv=out8[3], ag=out8[4], bg=out8[5], gmean_tc=out8[6], ginv_tc=out8[7], a1=a1,
-                wq_stats=wqs, wq_main=wqm)
+                wq_stats=wqs, wq_main=wqm, wq_c=wqc)
 
 
 # ---- backward building blocks (training step) --------------------------------------------------------

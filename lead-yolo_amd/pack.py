@@ -110,6 +110,16 @@ def rfcbam_gen_weights(gen_w, scale, shift, chunk, per_wave_contiguous):
     return v.view(-1)
 
 
+def rfcbam_gen_weights_c(gen_w, scale, shift):
+    """Folded depthwise 'generate' weights of RFCBAMConv (k=3) in LANE = CHANNEL order (csrc/ly_rf3c.cuh): float [C][92] =
+    w'[t][u] at t*9 + u, b'[t] at 81 + t, two floats of padding: 23 aligned 16-byte loads per lane."""
+    c = gen_w.shape[0] // 9
+    out = torch.zeros(c, 92, dtype=torch.float32, device=gen_w.device)
+    out[:, :81] = (gen_w.detach().float().view(c, 9, 9) * scale.view(c, 9, 1)).reshape(c, 81)
+    out[:, 81:90] = shift.view(c, 9)
+    return out.view(-1)
+
+
 # --------------------------------------------------------------------------------------------------
 # Batched packing (csrc/ly_backward.hip ly_pack_table): every packed weight image of the model — forward, transposed for dgrad,
 # tap-flipped, concatenated — is described ONCE by how it reads the fp32 parameter in place, and all of them are refreshed by a

@@ -178,8 +178,9 @@ int ly_rfcbam3_fwd(const LyRfcbam3Params* p, void* stream);
 
 /* ---- RFCBAMConv kernel_size 3 on the lane = channel core (csrc/ly_rf3c.cuh; models/rfa.py:113-129) ----------------------------
  * C % 32 == 0, stride 1 or 2, tiles TH x TW with TW even, TH*TW <= 64 and (s(TH-1)+3)(s(TW-1)+3) <= 320 input positions.
- * wq = generate weights in lane order, float [C][92]: w'[t][u] = generate.0.weight[c*9+t][u] * bn_scale[c*9+t] at t*9+u,
- *      b'[t] = bn_shift[c*9+t] at 81+t, 2 floats of padding (pack.rfcbam_gen_weights_c / ly_rfcbam_gen_prepare).
+ * wq = generate weights in lane order: per channel 92 floats — w'[t][u] = generate.0.weight[c*9+t][u] * bn_scale[c*9+t] at i = t*9+u,
+ *      b'[t] = bn_shift[c*9+t] at i = 81+t, 2 of padding — stored as float [C/32][23][32][4]: element i of channel c at
+ *      ((c/32*23 + i/4)*32 + c%32)*4 + i%4 (pack.rfcbam_gen_weights_c / ly_rfcbam_gen_prepare).
  * ly_rf3c_stats: ONE pass over x leaves mm[n, 3Ho, 3Wo, 2] = [max_c, mean_c] of relu(bn(generate(x))) (models/rfa.py:125-126) and, if
  *      part != NULL, the SE global-average-pool partials part[n][tile][C] (models/rfa.py:90; slices must equal the tile count).
  * ly_rf3c_fwd: the main contraction (models/rfa.py:124, 128-129); p as for ly_rfcbam3_fwd except that p->wg is ignored and
@@ -226,7 +227,7 @@ int ly_rfcbam_tap_moments(const void* x /*T*/, int ldx, int n_img, int H, int W,
  *          ([ceil(C/32)*32 | ceil(C/16)*16][9][10] floats each);  k = 1: a1[c] = w[c]*scale[c].                                  */
 int ly_rfcbam_gen_prepare(const float* mom, int C, int k, const float* gen_w, const float* gamma, const float* beta, float eps,
                           float momentum, double count, float* running_mean, float* running_var, long* nbt, float* out8, float* a1,
-                          float* wq_stats, float* wq_main, float* wq_c /* NULL or [C][92]: the lane-order image of ly_rf3c_* */, void* stream);
+                          float* wq_stats, float* wq_main, float* wq_c /* NULL or [C*92]: the lane-order image of ly_rf3c_* */, void* stream);
 
 /* ---- eval tail: non_max_suppression on the device (utils/general.py:884-994; detect.py:149, val.py:230-234) --------------------------
  * pred [bs, N, no = 5 + nc] fp32 (xywh, obj, class confidences: Detect's inference output).

@@ -50,17 +50,27 @@ __device__ __forceinline__ f32x2 rc_pkmul(const f32x2 x, const f32x2 w, const in
   return r;
 }
 
-// the lane's 92 generate weights: wq[c][92] floats, 23 aligned 16-byte loads; element i is pair i>>1, dword i&1
+// the lane's 92 generate weights.  Image: float wq[C/32 chunks][23][32 channels][4] — element i = 4*q + e of channel c at
+// ((chunk*23 + q)*32 + (c & 31))*4 + e — so that the 32 lanes of a half wave read 512 contiguous bytes per load (a per-channel
+// [C][92] image costs one cache line per LANE and load: measured, the kernels were bound by the texture-address path).
+// Element i is pair i>>1, dword i&1 of the register image.
 struct RcW {
   f32x2 p[RC_WQ / 2];
 };
-__device__ __forceinline__ void rc_load_w(RcW& w, const float* __restrict__ wq_c) {
+__device__ __forceinline__ void rc_load_w(RcW& w, const float* __restrict__ wq, int c0, int c) {
+  const float* src = wq + ((long)(c0 >> 5) * (RC_WQ / 4) * RC_CB + c) * 4;
 #pragma unroll
   for (int i = 0; i < RC_WQ / 4; ++i) {
-    const f32x4 v = ly_ldg4(wq_c + 4 * i);
+    const f32x4 v = ly_ldg4(src + i * (RC_CB * 4));
     w.p[2 * i] = (f32x2){v[0], v[1]};
     w.p[2 * i + 1] = (f32x2){v[2], v[3]};
   }
+}
+// relu without the canonicalising second v_max that fmaxf costs
+__device__ __forceinline__ float rc_relu(float v) {
+  float r;
+  asm("v_max_f32_e32 %0, 0, %1" : "=v"(r) : "v"(v));
+  return r;
 }
 
 // v[t] (pixel pair) = b[t] + sum_u w[t][u] * x[u]: nine independent chains, interleaved so that no packed FMA waits for its predecessor
@@ -135,13 +145,22 @@ __device__ __forceinline__ void rc_stage_store(const RcStage<T, NTHR>& S, float*
     }
 }
 
-// the 9 patch values of the pixel pair whose first pixel has tile position pos0 = (s*ly)*IW + s*lx, channel lane c
-__device__ __forceinline__ void rc_patch(const float* __restrict__ xs, const RcGeom& g, int pos0, int c, f32x2 (&x)[9]) {
+// the 9 patch values of a pixel pair: xp = the lane's address of the pair's first patch element (xs + pos0*32 + c, pos0 = (S*ly)*IW + S*lx),
+// row = IW*32 floats; everything else is an immediate offset
+template <int S>
+__device__ __forceinline__ void rc_patch(const float* __restrict__ xp, int row, f32x2 (&x)[9]) {
 #pragma unroll
-  for (int u = 0; u < 9; ++u) {
-    const int p = pos0 + (u / 3) * g.IW + (u % 3);
-    x[u] = (f32x2){xs[p * RC_CB + c], xs[(p + g.s) * RC_CB + c]};
+  for (int uy = 0; uy < 3; ++uy) {
+    const float* r = xp + uy * row;
+#pragma unroll
+    for (int ux = 0; ux < 3; ++ux) x[uy * 3 + ux] = (f32x2){r[ux * RC_CB], r[(ux + S) * RC_CB]};
   }
+}
+// tile position of pixel px (0 for pixel slots past the tile)
+__device__ __forceinline__ int rc_pos0(const RcGeom& g, int px) {
+  const int pxc = px < g.NPX ? px : 0;
+  const int ly = pxc / g.TW, lx = pxc - ly * g.TW;
+  return (g.s * ly) * g.IW + g.s * lx;
 }
 
 // ---- K-major bf16 operand tile [288][64 px], 128-byte rows, 8-byte chunks XOR-swizzled by the row -----------------

@@ -8,16 +8,19 @@
 #include "ly_params.h"
 
 // ---------------------------------------------------------------------------------------------------
-// statistics pass.  LDS: x tile fp32 [IH*IW][32] | G tile fp32 [288][66] | red [4][32]
+// statistics pass.  LDS: x tile fp32 [IH*IW][32] | G tile fp32 [288][34] (HALF a tile: 32 pixels) | red [4][32]   (~76 KB: two blocks per CU)
+//   per chunk and half tile: generate (lane = channel, 8 streams x 2 pixel pairs) -> G tile -> reduce with lane = pixel: thread group
+//   g = tid / 32 folds the chunk's 32 channels of tap g into its running (max, sum), and channels 4g .. 4g+3 of tap 8 (the ninth tap is
+//   shared by the 8 groups, which meet once, at the end).
 // ---------------------------------------------------------------------------------------------------
-#define RC_GS 66          // floats per row of the fp32 G tile: 2 (mod 32) => the qword stores of 16 consecutive rows and the row reads are conflict-free
+#define RC_GS 34          // floats per row of the fp32 G tile: 2 (mod 32) => the qword stores of 16 consecutive rows and the row reads are conflict-free
 
-template <typename T>
-__global__ __launch_bounds__(LY_THREADS) void ly_rf3c_stats_kernel(const T* __restrict__ x, int ldx, int H, int W, int C, int Ho, int Wo, int s,
+template <typename T, int S>
+__global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void ly_rf3c_stats_kernel(const T* __restrict__ x, int ldx, int H, int W, int C, int Ho, int Wo,
                                                                    int TH, int TW, int nct, int nrt, const float* __restrict__ wq,
                                                                    float* __restrict__ mm, float* __restrict__ part) {
   extern __shared__ f32x4 rc_smem4[];
-  const RcGeom g = rc_geom(s, TH, TW);
+  const RcGeom g = rc_geom(S, TH, TW);
   float* xs = reinterpret_cast<float*>(rc_smem4);
   float* gt = xs + g.IH * g.IW * RC_CB;
   float* red = gt + RC_KR * RC_GS;
@@ -30,80 +33,112 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf3c_stats_kernel(const T* __re
   const int n = b / nrt;
   const int oy0 = rt * TH, ox0 = ct * TW;
 
-  RcStage<T> S;
-  rc_stage_plan(S, g, tid, n, H, W, ldx, s * oy0 - 1, s * ox0 - 1);
-  rc_stage_load(S, x, 0);
+  RcStage<T> St;
+  rc_stage_plan(St, g, tid, n, H, W, ldx, S * oy0 - 1, S * ox0 - 1);
+  rc_stage_load(St, x, 0);
 
-  // reduce phase: lane = tile pixel, wave w takes taps w, w+4, w+8
-  const int rly = lane / TW, rlx = lane - rly * TW;
-  const bool ractive = lane < g.NPX && oy0 + rly < Ho && ox0 + rlx < Wo;
-  float mx[3], sm[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) { mx[i] = 0.f; sm[i] = 0.f; }      // G >= 0: zero is the identity of the channel max
-
+  // generate: stream (wave, half) handles, in half tile hp, the pixel pairs px0 = 32*hp + 4*stream + 2*j, j = 0, 1
   const int stream = wave * 2 + half;
+  const int row = g.IW * RC_CB;
+  const float* xp[2][2];
+  bool pin[2][2];
+#pragma unroll
+  for (int hp = 0; hp < 2; ++hp)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int px0 = 32 * hp + 4 * stream + 2 * j;
+      xp[hp][j] = xs + rc_pos0(g, px0) * RC_CB + c;
+      pin[hp][j] = px0 < g.NPX;
+    }
+  // reduce: lane & 31 = pixel of the half tile, group = tid / 32: tap `grp` over all channels (a), tap 8 over channels 4*grp .. +3 (b)
+  const int rpx = tid & 31, grp = tid >> 5;
+  float mxa[2] = {0.f, 0.f}, sma[2] = {0.f, 0.f}, mxb[2] = {0.f, 0.f}, smb[2] = {0.f, 0.f};      // G >= 0: zero is the identity of the channel max
+
+  RcW w;
+  rc_load_w(w, wq, 0, c);
   for (int c0 = 0; c0 < C; c0 += RC_CB) {
-    RcW w;
-    rc_load_w(w, wq + (long)(c0 + c) * RC_WQ);
+    const bool more = c0 + RC_CB < C;
     __syncthreads();                              // previous chunk: reduce done with gt / red, generate done with xs
-    rc_stage_store(S, xs);
-    rc_stage_load(S, x, c0 + RC_CB < C ? c0 + RC_CB : 0);
+    rc_stage_store(St, xs);
+    rc_stage_load(St, x, more ? c0 + RC_CB : 0);
     __syncthreads();
     f32x2 gap = {0.f, 0.f};
-#pragma unroll 1
-    for (int j = 0; j < 4; ++j) {
-      const int px0 = 8 * stream + 2 * j;
-      const bool pin = px0 < g.NPX;
-      const int pxc = pin ? px0 : 0;
-      const int ly = pxc / TW, lx = pxc - ly * TW;
-      f32x2 xv[9], a[9];
-      rc_patch(xs, g, (s * ly) * g.IW + s * lx, c, xv);
-      rc_generate<true>(w, xv, a);
-      // SE pooling: the pixel OWNS inputs (s*oy + dy, s*ox + dx), dy, dx < s  = patch offsets (1 + dy, 1 + dx); every input belongs to one pixel
-      f32x2 own = xv[4];
-      if (s == 2) own += xv[5] + xv[7] + xv[8];
-      gap += pin ? own : (f32x2){0.f, 0.f};
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const f32x2 gg = {fmaxf(a[t][0], 0.f), fmaxf(a[t][1], 0.f)};
-        *reinterpret_cast<f32x2*>(gt + (t * RC_CB + c) * RC_GS + px0) = gg;
+    for (int hp = 0; hp < 2; ++hp) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        f32x2 xv[9], a[9];
+        rc_patch<S>(xp[hp][j], row, xv);
+        rc_generate<true>(w, xv, a);
+        // SE pooling: the pixel OWNS inputs (S*oy + dy, S*ox + dx), dy, dx < S = patch offsets (1 + dy, 1 + dx); every input belongs to one pixel
+        f32x2 own = xv[4];
+        if constexpr (S == 2) own += xv[5] + xv[7] + xv[8];
+        gap += pin[hp][j] ? own : (f32x2){0.f, 0.f};
+        float* gp = gt + c * RC_GS + 4 * stream + 2 * j;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) *reinterpret_cast<f32x2*>(gp + t * (RC_CB * RC_GS)) = (f32x2){rc_relu(a[t][0]), rc_relu(a[t][1])};
       }
-    }
-    {
-      float gsum = gap[0] + gap[1];
-      gsum += __shfl_xor(gsum, 32);
-      if (half == 0) red[wave * RC_CB + c] = gsum;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int t = wave + 4 * i;
-      if (t < 9) {
-        const float* col = gt + (t * RC_CB) * RC_GS + lane;
-        float m0 = mx[i], s0 = sm[i];
+      if (hp == 1) {
+        // the next chunk's weights: in flight during the reduce and the next staging (the last chunk re-requests chunk 0: no load under a branch)
+        rc_load_w(w, wq, more ? c0 + RC_CB : 0, c);
+        float gsum = gap[0] + gap[1];
+        gsum += __shfl_xor(gsum, 32);
+        if (half == 0) red[wave * RC_CB + c] = gsum;
+      }
+      __syncthreads();
+      {
+        const float* col = gt + (grp * RC_CB) * RC_GS + rpx;
+        float m0 = mxa[hp], s0 = sma[hp];
 #pragma unroll 8
         for (int cc = 0; cc < RC_CB; ++cc) {
           const float v = col[cc * RC_GS];
           m0 = fmaxf(m0, v);
           s0 += v;
         }
-        mx[i] = m0; sm[i] = s0;
+        mxa[hp] = m0; sma[hp] = s0;
+        const float* col8 = gt + (8 * RC_CB + 4 * grp) * RC_GS + rpx;
+        m0 = mxb[hp]; s0 = smb[hp];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          const float v = col8[cc * RC_GS];
+          m0 = fmaxf(m0, v);
+          s0 += v;
+        }
+        mxb[hp] = m0; smb[hp] = s0;
       }
+      if (hp == 0) __syncthreads();               // the second half tile overwrites gt
     }
     if (part && tid < RC_CB)
       part[((long)n * (nrt * nct) + rt * nct + ct) * C + c0 + tid] = (red[tid] + red[RC_CB + tid]) + (red[2 * RC_CB + tid] + red[3 * RC_CB + tid]);
   }
-  if (ractive) {
-    const float inv = 1.f / (float)C;
-    const int HK = 3 * Ho, WK = 3 * Wo;
-    const int oy = oy0 + rly, ox = ox0 + rlx;
+  // taps 0..7 leave from their group's registers; the ninth tap's 8 partials meet in LDS (the G tile's memory)
+  __syncthreads();
+  float* fin = gt;                                 // [8 groups][2 half tiles][max, sum][32 px]
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int t = wave + 4 * i;
-      if (t < 9) {
-        const long o = (((long)n * HK + 3 * oy + t / 3) * WK + 3 * ox + t % 3) * 2;
-        *reinterpret_cast<f32x2*>(mm + o) = (f32x2){mx[i], sm[i] * inv};
+  for (int hp = 0; hp < 2; ++hp) {
+    fin[((grp * 2 + hp) * 2) * 32 + rpx] = mxb[hp];
+    fin[((grp * 2 + hp) * 2 + 1) * 32 + rpx] = smb[hp];
+  }
+  __syncthreads();
+  const float inv = 1.f / (float)C;
+  const int HK = 3 * Ho, WK = 3 * Wo;
+#pragma unroll
+  for (int hp = 0; hp < 2; ++hp) {
+    const int px = 32 * hp + rpx;
+    const int ly = px / TW, lx = px - ly * TW;
+    const int oy = oy0 + ly, ox = ox0 + lx;
+    if (px >= g.NPX || oy >= Ho || ox >= Wo) continue;
+    const long o = (((long)n * HK + 3 * oy + grp / 3) * WK + 3 * ox + grp % 3) * 2;
+    *reinterpret_cast<f32x2*>(mm + o) = (f32x2){mxa[hp], sma[hp] * inv};
+    if (grp == 0) {
+      float m0 = 0.f, s0 = 0.f;
+#pragma unroll
+      for (int gg = 0; gg < 8; ++gg) {
+        m0 = fmaxf(m0, fin[((gg * 2 + hp) * 2) * 32 + rpx]);
+        s0 += fin[((gg * 2 + hp) * 2 + 1) * 32 + rpx];
       }
+      const long o8 = (((long)n * HK + 3 * oy + 2) * WK + 3 * ox + 2) * 2;
+      *reinterpret_cast<f32x2*>(mm + o8) = (f32x2){m0, s0 * inv};
     }
   }
 }
@@ -136,14 +171,22 @@ extern "C" int ly_rf3c_stats(const void* x, int ldx, int n_img, int H, int W, in
   LY_CHECK(lds <= 160 * 1024, "rf3c_stats: tile needs %zu B LDS", lds);
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ly_rf3c_stats_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    LY_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(ly_rf3c_stats_kernel<__bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    LY_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    const void* ks[4] = {reinterpret_cast<const void*>(ly_rf3c_stats_kernel<float, 1>), reinterpret_cast<const void*>(ly_rf3c_stats_kernel<float, 2>),
+                         reinterpret_cast<const void*>(ly_rf3c_stats_kernel<__bf16, 1>), reinterpret_cast<const void*>(ly_rf3c_stats_kernel<__bf16, 2>)};
+    for (int i = 0; i < 4; ++i) {
+      hipError_t e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      LY_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    }
     configured = true;
   }
-  LY_WITH_T(dtype, hipLaunchKernelGGL(ly_rf3c_stats_kernel<T>, dim3((unsigned)(n_img * nrt * nct)), dim3(LY_THREADS), lds, reinterpret_cast<hipStream_t>(stream),
-                                      reinterpret_cast<const T*>(x), ldx, H, W, C, Ho, Wo, s, TH, TW, nct, nrt, wq, mm, part));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)(n_img * nrt * nct));
+  if (s == 1)
+    LY_WITH_T(dtype, hipLaunchKernelGGL((ly_rf3c_stats_kernel<T, 1>), grid, dim3(LY_THREADS), lds, st, reinterpret_cast<const T*>(x), ldx, H, W, C, Ho, Wo, TH, TW,
+                                        nct, nrt, wq, mm, part));
+  else
+    LY_WITH_T(dtype, hipLaunchKernelGGL((ly_rf3c_stats_kernel<T, 2>), grid, dim3(LY_THREADS), lds, st, reinterpret_cast<const T*>(x), ldx, H, W, C, Ho, Wo, TH, TW,
+                                        nct, nrt, wq, mm, part));
   LY_LAUNCH_CHECK();
   return 0;
 }
@@ -154,7 +197,7 @@ extern "C" int ly_rf3c_stats(const void* x, int ldx, int n_img, int H, int W, in
 //   against conv.0.weight packed as [N][C/32][9 taps][32 channels]; the next chunk's input tile, generate weights and the conv
 //   weight fragments (register ring) are requested a phase ahead.
 // ---------------------------------------------------------------------------------------------------
-template <typename T, int MT, int NW>
+template <typename T, int MT, int NW, int S>
 __global__ __launch_bounds__(NW * 64) void ly_rf3c_fwd_kernel(const LyRfcbam3Params P, const float* __restrict__ wq, const int gy, const int nct,
                                                                  const int nrt) {
   using TR = LyT<T>;
@@ -162,11 +205,11 @@ __global__ __launch_bounds__(NW * 64) void ly_rf3c_fwd_kernel(const LyRfcbam3Par
   const T* const x = reinterpret_cast<const T*>(P.x);
   T* const out = reinterpret_cast<T*>(P.out);
   extern __shared__ f32x4 rc_smem4[];
-  const RcGeom g = rc_geom(P.s, P.TH, P.TW);
+  const RcGeom g = rc_geom(S, P.TH, P.TW);
   float* xs = reinterpret_cast<float*>(rc_smem4);
   char* gs_hi = reinterpret_cast<char*>(xs + g.IH * g.IW * RC_CB);
   char* gs_lo = gs_hi + (PL - 1) * RC_KR * 128;
-  float* rfs = reinterpret_cast<float*>(gs_hi + PL * RC_KR * 128);       // [64][12]
+  float* rfs = reinterpret_cast<float*>(gs_hi + PL * RC_KR * 128);       // [32 pixel pairs][9 taps][2]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, c = lane & 31;
@@ -179,21 +222,35 @@ __global__ __launch_bounds__(NW * 64) void ly_rf3c_fwd_kernel(const LyRfcbam3Par
   const int oy0 = rt * P.TH, ox0 = ct * P.TW;
   const f32x4 zero = ly_zero4();
   const int NCH = P.C / RC_CB;
-  const int S = NCH * 9;                                  // k-steps of the packed conv weight
+  const int KS = NCH * 9;                                 // k-steps of the packed conv weight
   const int Tt = (P.N + 15) >> 4;
 
   constexpr int NTHR = NW * 64;
   RcStage<T, NTHR> St;
-  rc_stage_plan(St, g, tid, n, P.H, P.W, P.ldx, P.s * oy0 - 1, P.s * ox0 - 1);
+  rc_stage_plan(St, g, tid, n, P.H, P.W, P.ldx, S * oy0 - 1, S * ox0 - 1);
   rc_stage_load(St, x, 0);
 
-  // rfa of the tile's pixels, zero for pixels outside the map: G' = 0 there
-  for (int i = tid; i < RC_TP * 9; i += NTHR) {
-    const int px = i / 9, t = i - px * 9;
-    const int ly = px / P.TW, lx = px - ly * P.TW;
-    const int oy = oy0 + ly, ox = ox0 + lx;
-    const bool ok = px < g.NPX && oy < P.Ho && ox < P.Wo;
-    rfs[px * 12 + t] = ok ? P.rfa[((long)n * 3 * P.Ho + 3 * oy + t / 3) * (3 * P.Wo) + 3 * ox + t % 3] : 0.f;
+  // rfa of the tile's pixels as pixel-pair rows [pair][tap][2], zero for pixels outside the map (G' = 0 there).  All loads of the thread are
+  // issued before the first LDS store: one memory round trip in the block's prologue, not one per item
+  {
+    constexpr int NI = (RC_TP * 9 + NTHR - 1) / NTHR;
+    float rv[NI];
+#pragma unroll
+    for (int e = 0; e < NI; ++e) {
+      const int i = tid + e * NTHR;
+      const int px = i / 9, t = i - px * 9;
+      const int ly = px / P.TW, lx = px - ly * P.TW;
+      const int oy = oy0 + ly, ox = ox0 + lx;
+      const bool ok = i < RC_TP * 9 && px < g.NPX && oy < P.Ho && ox < P.Wo;
+      const float v = P.rfa[ok ? ((long)n * 3 * P.Ho + 3 * oy + t / 3) * (3 * P.Wo) + 3 * ox + t % 3 : 0];
+      rv[e] = ok ? v : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < NI; ++e) {
+      const int i = tid + e * NTHR;
+      const int px = i / 9, t = i - px * 9;
+      if (i < RC_TP * 9) rfs[((px >> 1) * 9 + t) * 2 + (px & 1)] = rv[e];
+    }
   }
 
   f32x4 acc[MT][4];
@@ -212,7 +269,7 @@ __global__ __launch_bounds__(NW * 64) void ly_rf3c_fwd_kernel(const LyRfcbam3Par
   constexpr int D = MT == 1 ? 3 : 6;                       // ring depth; NF % D == 0: the slot of a fragment does not depend on the chunk
   static_assert(NF % D == 0, "ring");
   LyWF<PL> ring[D];
-  auto wfrag_at = [&](int sb, int q) -> LyWF<PL> { return ly_wfragp<PL>(wpk, (long)tile[q % MT] * S + sb + q / MT, lane); };
+  auto wfrag_at = [&](int sb, int q) -> LyWF<PL> { return ly_wfragp<PL>(wpk, (long)tile[q % MT] * KS + sb + q / MT, lane); };
 #pragma unroll
   for (int q = 0; q < D; ++q) ring[q] = wfrag_at(0, q);
 
@@ -220,8 +277,19 @@ __global__ __launch_bounds__(NW * 64) void ly_rf3c_fwd_kernel(const LyRfcbam3Par
   const int stream = wave * 2 + half;
   const int csw = rc_sw(c);                                 // rows k = t*32 + c: the swizzle depends on c only
 
+  constexpr int NJ = 16 / NW;                              // pixel pairs per stream: px0 = 2*NJ*stream + 2*j
+  const int row = g.IW * RC_CB;
+  const float* xp[NJ];
+  int goff[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int px0 = 2 * NJ * stream + 2 * j;
+    xp[j] = xs + rc_pos0(g, px0) * RC_CB + c;
+    goff[j] = c * 128 + ((((px0 >> 2) ^ csw) << 3) | ((px0 & 2) << 1));
+  }
+
   RcW w;
-  rc_load_w(w, wq + (long)c * RC_WQ);
+  rc_load_w(w, wq, 0, c);
   float cav = P.ca[(long)n * P.C + c];
 
   for (int ch = 0; ch < NCH; ++ch) {
@@ -230,39 +298,31 @@ __global__ __launch_bounds__(NW * 64) void ly_rf3c_fwd_kernel(const LyRfcbam3Par
     rc_stage_store(St, xs);
     rc_stage_load(St, x, more ? (ch + 1) * RC_CB : 0);
     __syncthreads();
-    // ---- regenerate: G' = relu(v) * ca * rfa for the stream's 4 pixel pairs ----------------------------------
-#pragma unroll 1
-    for (int j = 0; j < 16 / NW; ++j) {
-      const int px0 = (32 / NW) * stream + 2 * j;
-      const int pxc = px0 < g.NPX ? px0 : 0;
-      const int ly = pxc / P.TW, lx = pxc - ly * P.TW;
-      f32x2 xv[9], a[9];
-      rc_patch(xs, g, (P.s * ly) * g.IW + P.s * lx, c, xv);
-      rc_generate<true>(w, xv, a);
-      f32x4 r0[3], r1[3];
+    // ---- regenerate: G' = relu(v) * ca * rfa for the stream's pixel pairs ----------------------------------
+    const f32x2 cav2 = {cav, cav};
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        r0[i] = *reinterpret_cast<const f32x4*>(rfs + px0 * 12 + 4 * i);
-        r1[i] = *reinterpret_cast<const f32x4*>(rfs + (px0 + 1) * 12 + 4 * i);
-      }
-      const int goff = c * 128 + ((((px0 >> 2) ^ csw) << 3) | ((px0 & 2) << 1));
+    for (int j = 0; j < NJ; ++j) {
+      f32x2 xv[9], a[9];
+      rc_patch<S>(xp[j], row, xv);
+      rc_generate<true>(w, xv, a);
+      const f32x2* rfp = reinterpret_cast<const f32x2*>(rfs) + (NJ * stream + j) * 9;
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
-        const f32x2 gg = (f32x2){fmaxf(a[t][0], 0.f) * (cav * r0[t >> 2][t & 3]), fmaxf(a[t][1], 0.f) * (cav * r1[t >> 2][t & 3])};
+        const f32x2 gg = (f32x2){rc_relu(a[t][0]), rc_relu(a[t][1])} * (rfp[t] * cav2);
         if constexpr (PL == 2) {
           const bf16x2 hi = __builtin_convertvector(gg, bf16x2);
           const f32x2 back = __builtin_convertvector(hi, f32x2);
-          *reinterpret_cast<unsigned*>(gs_hi + t * (RC_CB * 128) + goff) = __builtin_bit_cast(unsigned, hi);
-          *reinterpret_cast<unsigned*>(gs_lo + t * (RC_CB * 128) + goff) = rc_pack2(gg - back);
+          *reinterpret_cast<unsigned*>(gs_hi + t * (RC_CB * 128) + goff[j]) = __builtin_bit_cast(unsigned, hi);
+          *reinterpret_cast<unsigned*>(gs_lo + t * (RC_CB * 128) + goff[j]) = rc_pack2(gg - back);
         } else {
-          *reinterpret_cast<unsigned*>(gs_hi + t * (RC_CB * 128) + goff) = rc_pack2(gg);
+          *reinterpret_cast<unsigned*>(gs_hi + t * (RC_CB * 128) + goff[j]) = rc_pack2(gg);
         }
       }
     }
     // the next chunk's generate weights: in flight during the contraction (the last chunk re-requests chunk 0: no load under a branch)
     {
       const int cn = more ? (ch + 1) * RC_CB : 0;
-      rc_load_w(w, wq + (long)(cn + c) * RC_WQ);
+      rc_load_w(w, wq, cn, c);
       cav = P.ca[(long)n * P.C + cn + c];
     }
     __syncthreads();
@@ -336,14 +396,14 @@ __global__ __launch_bounds__(NW * 64) void ly_rf3c_fwd_kernel(const LyRfcbam3Par
   }
 }
 
-template <typename T, int MT, int NW>
-static int rc_launch_fwd(const LyRfcbam3Params& P, const float* wq, hipStream_t st) {
+template <typename T, int MT, int NW, int S>
+static int rc_launch_fwd_s(const LyRfcbam3Params& P, const float* wq, hipStream_t st) {
   const int nct = (P.Wo + P.TW - 1) / P.TW, nrt = (P.Ho + P.TH - 1) / P.TH;
   const int gy = (P.N + 16 * NW * MT - 1) / (16 * NW * MT);
   const int IH = P.s * (P.TH - 1) + 3, IW = P.s * (P.TW - 1) + 3;
-  const size_t lds = sizeof(float) * ((size_t)IH * IW * RC_CB + RC_TP * 12) + (size_t)LyT<T>::PL * RC_KR * 128;
+  const size_t lds = sizeof(float) * ((size_t)IH * IW * RC_CB + RC_TP * 9) + (size_t)LyT<T>::PL * RC_KR * 128;
   LY_CHECK(lds <= 160 * 1024, "rf3c_fwd: tile needs %zu B LDS", lds);
-  auto k = ly_rf3c_fwd_kernel<T, MT, NW>;
+  auto k = ly_rf3c_fwd_kernel<T, MT, NW, S>;
   static bool configured = false;
   if (!configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -355,6 +415,11 @@ static int rc_launch_fwd(const LyRfcbam3Params& P, const float* wq, hipStream_t 
   hipLaunchKernelGGL(k, dim3((unsigned)nb), dim3(NW * 64), lds, st, P, wq, gy, nct, nrt);
   LY_LAUNCH_CHECK();
   return 0;
+}
+
+template <typename T, int MT, int NW>
+static int rc_launch_fwd(const LyRfcbam3Params& P, const float* wq, hipStream_t st) {
+  return P.s == 1 ? rc_launch_fwd_s<T, MT, NW, 1>(P, wq, st) : rc_launch_fwd_s<T, MT, NW, 2>(P, wq, st);
 }
 
 template <typename T>

@@ -1,0 +1,182 @@
+// Common device helpers for the LEAD-YOLO gfx950 kernels.
+//
+// Tile convention used by every contraction in this library (fp32 path):
+//   v_mfma_f32_16x16x4_f32,  D[row][col] += sum_k A[row][k] * B[k][col]
+//   A operand  = WEIGHTS      (row  = output channel),  lane l supplies A[row = l&15][k = l>>4]
+//   B operand  = ACTIVATIONS  (col  = pixel),           lane l supplies B[k = l>>4][col = l&15]
+//   D          : lane l holds D[row = 4*(l>>4) + r][col = l&15], r = 0..3
+//   => each lane ends up with 4 CONSECUTIVE output channels of ONE pixel: NHWC float4 stores.
+//
+// One "k-step" covers 16 values of K with four MFMAs; lane (i = l&15, q = l>>4) feeds
+//   k = 16*s + 4*q + j   in MFMA j (j = 0..3)
+// so both operands are fetched as ONE 16-byte vector per lane per step (K-contiguous layouts:
+// NHWC activations, [cout][k] weights).  The summation order inside a step is permuted relative to
+// natural k order, which is irrelevant to the result's definition (a sum) and is applied to both
+// operands identically.
+//
+// Weights are pre-packed ("frag-packed") so that one wave-wide fragment is one contiguous 1 KiB
+// read:  Wp[(t*S + s)*64 + lane] (float4) = W[16t + (lane&15)][16s + 4(lane>>4) + 0..3], zero padded.
+//
+// A D tile of one contraction is directly the B operand of the next contraction over those channels
+// (register j of lane (i,q) is channel 16t + 4q + j of pixel i): no LDS round trip between the two
+// 1x1 convolutions of an MLP block.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define LY_WAVE 64
+#define LY_THREADS 256
+
+__device__ __forceinline__ f32x4 ly_mfma(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// acc += Wfrag(4 k-values) x Xfrag(4 k-values)
+__device__ __forceinline__ f32x4 ly_mfma4(const f32x4 w, const f32x4 x, f32x4 acc) {
+  acc = ly_mfma(w[0], x[0], acc);
+  acc = ly_mfma(w[1], x[1], acc);
+  acc = ly_mfma(w[2], x[2], acc);
+  acc = ly_mfma(w[3], x[3], acc);
+  return acc;
+}
+
+// Read-only, wave-uniform data (weights indexed by a wave-uniform expression): a constant-address-space
+// view makes the compiler use the scalar cache (s_load_dwordxN) instead of per-lane vector loads.
+typedef const float __attribute__((address_space(4))) ly_cfloat;
+__device__ __forceinline__ const ly_cfloat* ly_const(const float* p) { return (const ly_cfloat*)p; }
+
+__device__ __forceinline__ f32x4 ly_zero4() { return (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+__device__ __forceinline__ f32x4 ly_ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void ly_stg4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// v_exp_f32 + v_rcp_f32 (each <= 1 ulp): ~3 instructions instead of the ~15 of an IEEE division
+__device__ __forceinline__ float ly_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float ly_silu(float x) { return x * ly_sigmoid(x); }
+
+// activation applied to a whole float4 with ONE uniform switch (no per-element branching)
+__device__ __forceinline__ f32x4 ly_act4(f32x4 u, int act) {
+  f32x4 v;
+  if (act == 2) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = ly_silu(u[r]);
+  } else if (act == 1) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = fmaxf(u[r], 0.f);
+  } else {
+    v = u;
+  }
+  return v;
+}
+__device__ __forceinline__ float ly_relu(float x) { return fmaxf(x, 0.f); }
+__device__ __forceinline__ float ly_hswish(float x) { return x * fminf(fmaxf(x + 3.f, 0.f), 6.f) * (1.f / 6.f); }
+
+enum { LY_ACT_NONE = 0, LY_ACT_RELU = 1, LY_ACT_SILU = 2 };  // == LY_ACT_*_ of the public header
+
+template <int ACT>
+__device__ __forceinline__ float ly_act(float x) {
+  if (ACT == LY_ACT_RELU) return ly_relu(x);
+  if (ACT == LY_ACT_SILU) return ly_silu(x);
+  return x;
+}
+
+// exact floor(x / d) for 0 <= x < 2^24 via a float reciprocal and one fix-up step
+__device__ __forceinline__ int ly_fdiv(int x, int d, float inv) {
+  int q = (int)((float)x * inv);
+  int r = x - q * d;
+  if (r < 0) { --q; r += d; }
+  if (r >= d) ++q;
+  return q;
+}
+
+// (h, w) of flattened pixel gp (< 2^24) in an image of H x W, without 64-bit division
+__device__ __forceinline__ void ly_pix_hw(long gp, int H, int W, int& h, int& w) {
+  const int g = (int)gp;
+  const int row = ly_fdiv(g, W, 1.f / (float)W);     // n*H + h
+  w = g - row * W;
+  h = row - ly_fdiv(row, H, 1.f / (float)H) * H;
+}
+
+// 9-bit validity mask of the 3x3 neighbourhood (pad 1) of pixel (h, w) in an H x W image.
+// bit (ty*3 + tx) set  <=>  (h + ty - 1, w + tx - 1) is inside the image.
+__device__ __forceinline__ uint32_t ly_tapmask(int h, int w, int H, int W, bool pixel_valid) {
+  if (!pixel_valid) return 0u;
+  uint32_t rows = (h > 0 ? 1u : 0u) | 2u | (h < H - 1 ? 4u : 0u);
+  uint32_t cols = (w > 0 ? 1u : 0u) | 2u | (w < W - 1 ? 4u : 0u);
+  uint32_t m = 0;
+  if (rows & 1u) m |= cols;
+  if (rows & 2u) m |= cols << 3;
+  if (rows & 4u) m |= cols << 6;
+  return m;
+}
+
+// XCD-aware block remap (8 XCDs, round-robin dispatch): gives each XCD a contiguous chunk of the
+// logical grid so neighbouring tiles share that XCD's L2.  Bijective for any n.
+__device__ __forceinline__ int ly_xcd_remap(int bid, int n) {
+  const int nx = 8;
+  int q = n / nx, r = n % nx;
+  int xcd = bid % nx, slot = bid / nx;
+  // XCD x owns q (+1 if x < r) logical blocks, laid out consecutively
+  int base = xcd * q + (xcd < r ? xcd : r);
+  return base + slot;
+}
+
+// L2 warm-up: the whole grid touches every 128-byte line of a read-only parameter block once, right at
+// kernel start and in parallel, so that the dependent weight-fragment fetches of the contraction loops
+// hit L2 instead of chasing HBM misses one after another (weights are evicted between layers by the
+// activation stream).  The loaded values feed a never-true store so the loads cannot be elided.
+__device__ __forceinline__ void ly_l2_warm(const void* base, long bytes, float* sink) {
+  const long lines = bytes >> 7;
+  const float* p = reinterpret_cast<const float*>(base);
+  float acc = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < lines; i += (long)gridDim.x * blockDim.x) acc += p[i * 32];
+  if (acc == 1.2345678e-30f) *sink = acc;
+}
+
+// Batch-statistics pass support: a lane holds 4 consecutive channels (c .. c+3) of some pixels; sum the
+// two 4-vectors over the 16 lanes that share lq (lanes differing in l&15) and let lane l&15 == 0 add them
+// to stats[c + r] (sum) and stats[nch + c + r] (sum of squares).
+// The accumulator is STRIPED: LY_STATS_STRIPES copies of the [2*nch] array, block b adds into copy
+// b % LY_STATS_STRIPES (thousands of blocks adding to the same few addresses serialise in L2 otherwise);
+// ly_bn_finalize sums the copies in double precision.
+#define LY_STATS_STRIPES 32
+__device__ __forceinline__ void ly_stats_flush(float* __restrict__ stats, int nch, int c, f32x4 s1, f32x4 s2) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      s1[r] += __shfl_xor(s1[r], o);
+      s2[r] += __shfl_xor(s2[r], o);
+    }
+  }
+  if ((threadIdx.x & 15) == 0) {
+    float* st = stats + (size_t)(blockIdx.x & (LY_STATS_STRIPES - 1)) * 2 * nch;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (c + r < nch) {
+        atomicAdd(st + c + r, s1[r]);
+        atomicAdd(st + nch + c + r, s2[r]);
+      }
+  }
+}
+
+extern "C" void ly_set_error(const char* fmt, ...);
+
+#define LY_CHECK(cond, ...)                \
+  do {                                     \
+    if (!(cond)) {                         \
+      ly_set_error(__VA_ARGS__);           \
+      return -1;                           \
+    }                                      \
+  } while (0)
+
+#define LY_LAUNCH_CHECK()                                         \
+  do {                                                            \
+    hipError_t e_ = hipGetLastError();                            \
+    if (e_ != hipSuccess) {                                       \
+      ly_set_error("HIP launch failed: %s", hipGetErrorString(e_)); \
+      return -2;                                                  \
+    }                                                             \
+  } while (0)

@@ -178,16 +178,49 @@ int ly_rfcbam3_fwd(const LyRfcbam3Params* p, void* stream);
 
 /* ---- RFCBAMConv kernel_size 3 on the lane = channel core (csrc/ly_rf3c.cuh; models/rfa.py:113-129) ----------------------------
  * C % 32 == 0, stride 1 or 2, tiles TH x TW with TW even, TH*TW <= 64 and (s(TH-1)+3)(s(TW-1)+3) <= 320 input positions.
- * wq = generate weights in lane order: per channel 92 floats — w'[t][u] = generate.0.weight[c*9+t][u] * bn_scale[c*9+t] at i = t*9+u,
- *      b'[t] = bn_shift[c*9+t] at i = 81+t, 2 of padding — stored as float [C/32][23][32][4]: element i of channel c at
- *      ((c/32*23 + i/4)*32 + c%32)*4 + i%4 (pack.rfcbam_gen_weights_c / ly_rfcbam_gen_prepare).
+ * wq = generate weights in lane order: per channel 100 floats — w[t][u] at i = t*9+u, b[t] at i = 81+t, a[t] at i = 90+t, 1 of padding —
+ *      stored as float [C/32][25][32][4]: element i of channel c at ((c/32*25 + i/4)*32 + c%32)*4 + i%4.  raw == 0 (inference, folded):
+ *      w = generate.0.weight * bn_scale, b = bn_shift, v = b + sum w x.  raw != 0 (training): w = generate.0.weight, a = bn_scale,
+ *      b = bn_shift, v = a*(sum w x) + b — the form the backward kernels re-evaluate bit for bit (pack.rfcbam_gen_weights_c /
+ *      ly_rfcbam_gen_prepare).
  * ly_rf3c_stats: ONE pass over x leaves mm[n, 3Ho, 3Wo, 2] = [max_c, mean_c] of relu(bn(generate(x))) (models/rfa.py:125-126) and, if
  *      part != NULL, the SE global-average-pool partials part[n][tile][C] (models/rfa.py:90; slices must equal the tile count).
  * ly_rf3c_fwd: the main contraction (models/rfa.py:124, 128-129); p as for ly_rfcbam3_fwd except that p->wg is ignored and
  *      p->wp = conv.0.weight frag-packed as [N][C/32 chunks][9 taps][32 channels] (K = 9*C).                                       */
-int ly_rf3c_stats(const void* x /*T*/, int ldx, int n_img, int H, int W, int C, int s, const float* wq, int TH, int TW, float* mm,
+int ly_rf3c_stats(const void* x /*T*/, int ldx, int n_img, int H, int W, int C, int s, const float* wq, int raw, int TH, int TW, float* mm,
                   float* part, int slices, int dtype, void* stream);
-int ly_rf3c_fwd(const LyRfcbam3Params* p, const float* wq, void* stream);
+int ly_rf3c_fwd(const LyRfcbam3Params* p, const float* wq, int raw, void* stream);
+
+/* RFCBAMConv kernel_size 3 backward without 9x-sized tensors (csrc/ly_rf3c_bwd.hip; autograd of models/rfa.py:113-129): every pass
+ * re-derives dcd = du . Wc^T (MFMA) and generate / BatchNorm / ReLU (VALU, bit-identical to the training forward, raw wq) on chip from
+ * x and du.  bf16 storage, stride 2, C % 32 == 0, tiles as ly_rf3c_fwd.
+ *   ly_rf3c_bwd pass 0 (A): d_rfa_part [C/32][n, 3Ho, 3Wo] (one slab per channel chunk: sum them), d_ca [n, C]        (O in {64, 128, 256})
+ *               pass 1 (B): sums [n_img stripes][2][9C] in [t*C + c] order: sum dv, sum dv*u  (-> ly_bn_bwd_coeffs with n_img stripes)
+ *               pass 2 (C): dwg [n_img][C*81] rows of d(generate.0.weight) (sum them), dx [n, H, W] rows of T (+ dgap[n, C] * dgap_scale)
+ *   ly_rf3c_wgrad: dwc_part [ng][O][9][C] slabs of d(conv.0.weight) in (o, tap, c) order (sum them); image i goes to slab i % ng.        */
+typedef struct LyRf3cBwdParams {
+  int n_img, H, W, C;
+  int Ho, Wo, O, s;
+  int TH, TW;
+  const void* x; int ldx;        /* T: the saved input */
+  const void* du; int lddu;      /* T [n*Ho*Wo][O]: gradient of the conv's pre-BatchNorm output */
+  const float* wq;               /* raw lane-order generate weights (see ly_rf3c_stats) */
+  const void* wct;               /* conv.0.weight^T frag-packed (one plane): rows t*C + c, K = O */
+  const float* ca;               /* [n, C] */
+  const float* rfa;              /* [n, 3Ho, 3Wo] */
+  const float* mm;               /* [n, 3Ho, 3Wo, 2] the forward's [max_c, mean_c] map */
+  const float* d_mm;             /* [n, 3Ho, 3Wo, 2] its gradient (passes B, C) */
+  const float* coef;             /* [3][9C]: alpha, kappa, lambda of ly_bn_bwd_coeffs in [t*C + c] order (pass C) */
+  float* d_rfa_part; float* d_ca;
+  float* sums;
+  float* dwg;
+  void* dx; int lddx;            /* T */
+  const float* dgap; float dgap_scale;
+  float* dwc_part; int ng;
+  int dtype;
+} LyRf3cBwdParams;
+int ly_rf3c_bwd(const LyRf3cBwdParams* p, int pass, void* stream);
+int ly_rf3c_wgrad(const LyRf3cBwdParams* p, void* stream);
 
 
 /* ---- graph remainder ------------------------------------------------------------------------- */
@@ -227,7 +260,7 @@ int ly_rfcbam_tap_moments(const void* x /*T*/, int ldx, int n_img, int H, int W,
  *          ([ceil(C/32)*32 | ceil(C/16)*16][9][10] floats each);  k = 1: a1[c] = w[c]*scale[c].                                  */
 int ly_rfcbam_gen_prepare(const float* mom, int C, int k, const float* gen_w, const float* gamma, const float* beta, float eps,
                           float momentum, double count, float* running_mean, float* running_var, long* nbt, float* out8, float* a1,
-                          float* wq_stats, float* wq_main, float* wq_c /* NULL or [C*92]: the lane-order image of ly_rf3c_* */, void* stream);
+                          float* wq_stats, float* wq_main, float* wq_c /* NULL or [C*100]: the RAW lane-order image of ly_rf3c_* */, void* stream);
 
 /* ---- eval tail: non_max_suppression on the device (utils/general.py:884-994; detect.py:149, val.py:230-234) --------------------------
  * pred [bs, N, no = 5 + nc] fp32 (xywh, obj, class confidences: Detect's inference output).

@@ -38,6 +38,13 @@ class LyRfcbam3Params(ctypes.Structure):
                 ("e_scale", _P), ("e_shift", _P), ("out", _P), ("ldo", _I), ("stats", _P), ("linear", _I), ("dtype", _I)]
 
 
+class LyRf3cBwdParams(ctypes.Structure):
+    _fields_ = [("n_img", _I), ("H", _I), ("W", _I), ("C", _I), ("Ho", _I), ("Wo", _I), ("O", _I), ("s", _I), ("TH", _I), ("TW", _I),
+                ("x", _P), ("ldx", _I), ("du", _P), ("lddu", _I), ("wq", _P), ("wct", _P), ("ca", _P), ("rfa", _P), ("mm", _P), ("d_mm", _P),
+                ("coef", _P), ("d_rfa_part", _P), ("d_ca", _P), ("sums", _P), ("dwg", _P), ("dx", _P), ("lddx", _I), ("dgap", _P),
+                ("dgap_scale", _F), ("dwc_part", _P), ("ng", _I), ("dtype", _I)]
+
+
 class LyOptTensor(ctypes.Structure):
     _fields_ = [("p", _P), ("g", _P), ("buf", _P), ("ema", _P), ("n", _L), ("wd", _F), ("group", _I), ("taps", _I), ("cin", _I)]
 
@@ -94,8 +101,10 @@ SIGNATURES = {
     "ly_chan_moments": [_P, _I, _L, _I, _P, _I, _P],
     "ly_rfcbam_tap_moments": [_P, _I, _I, _I, _I, _I, _I, _P, _I, _P],
     "ly_rfcbam_gen_prepare": [_P, _I, _I, _P, _P, _P, _F, _F, ctypes.c_double, _P, _P, _P, _P, _P, _P, _P, _P, _P],
-    "ly_rf3c_stats": [_P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P, _I, _I, _P],
-    "ly_rf3c_fwd": [ctypes.POINTER(LyRfcbam3Params), _P, _P],
+    "ly_rf3c_stats": [_P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _I, _P, _P, _I, _I, _P],
+    "ly_rf3c_fwd": [ctypes.POINTER(LyRfcbam3Params), _P, _I, _P],
+    "ly_rf3c_bwd": [ctypes.POINTER(LyRf3cBwdParams), _I, _P],
+    "ly_rf3c_wgrad": [ctypes.POINTER(LyRf3cBwdParams), _P],
     "ly_coordatt_conv1_stats": [_P, _L, _I, _I, _P, _P, _P, _P],
     "ly_sppf_pool": [_P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P],
     "ly_bnact_fwd": [_P, _I, _L, _I, _P, _P, _I, _P, _I, _I, _P],

@@ -1344,9 +1344,10 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_gen_prepare_kernel(
         const float v = e < 9 ? w[e] * sc : sh;
         wq_stats[ly_gw_index(c, t, e, 32, false)] = v;
         wq_main[ly_gw_index(c, t, e, 16, true)] = v;
-        if (wq_c) {                                                            // lane = channel order (ly_rf3c.cuh rc_load_w)
+        if (wq_c) {                                                            // lane = channel order, RAW form (ly_rf3c.cuh rc_load_w)
           const int i = e < 9 ? t * 9 + e : 81 + t;
-          wq_c[(((long)(c >> 5) * 23 + (i >> 2)) * 32 + (c & 31)) * 4 + (i & 3)] = v;
+          wq_c[(((long)(c >> 5) * 25 + (i >> 2)) * 32 + (c & 31)) * 4 + (i & 3)] = e < 9 ? w[e] : sh;
+          if (e == 9) wq_c[(((long)(c >> 5) * 25 + ((90 + t) >> 2)) * 32 + (c & 31)) * 4 + ((90 + t) & 3)] = sc;
         }
       }
     } else {

@@ -15,7 +15,7 @@
 // ---------------------------------------------------------------------------------------------------
 #define RC_GS 34          // floats per row of the fp32 G tile: 2 (mod 32) => the qword stores of 16 consecutive rows and the row reads are conflict-free
 
-template <typename T, int S>
+template <typename T, int S, bool RAW>
 __global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void ly_rf3c_stats_kernel(const T* __restrict__ x, int ldx, int H, int W, int C, int Ho, int Wo,
                                                                    int TH, int TW, int nct, int nrt, const float* __restrict__ wq,
                                                                    float* __restrict__ mm, float* __restrict__ part) {
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
   float mxa[2] = {0.f, 0.f}, sma[2] = {0.f, 0.f}, mxb[2] = {0.f, 0.f}, smb[2] = {0.f, 0.f};      // G >= 0: zero is the identity of the channel max
 
   RcW w;
-  rc_load_w(w, wq, 0, c);
+  rc_load_w<RAW>(w, wq, 0, c);
   for (int c0 = 0; c0 < C; c0 += RC_CB) {
     const bool more = c0 + RC_CB < C;
     __syncthreads();                              // previous chunk: reduce done with gt / red, generate done with xs
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
       for (int j = 0; j < 2; ++j) {
         f32x2 xv[9], a[9];
         rc_patch<S>(xp[hp][j], row, xv);
-        rc_generate<true>(w, xv, a);
+        rc_gen_bn<RAW>(w, xv, a);
         // SE pooling: the pixel OWNS inputs (S*oy + dy, S*ox + dx), dy, dx < S = patch offsets (1 + dy, 1 + dx); every input belongs to one pixel
         f32x2 own = xv[4];
         if constexpr (S == 2) own += xv[5] + xv[7] + xv[8];
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
       }
       if (hp == 1) {
         // the next chunk's weights: in flight during the reduce and the next staging (the last chunk re-requests chunk 0: no load under a branch)
-        rc_load_w(w, wq, more ? c0 + RC_CB : 0, c);
+        rc_load_w<RAW>(w, wq, more ? c0 + RC_CB : 0, c);
         float gsum = gap[0] + gap[1];
         gsum += __shfl_xor(gsum, 32);
         if (half == 0) red[wave * RC_CB + c] = gsum;
@@ -148,17 +148,23 @@ static size_t rc_stats_lds(int s, int TH, int TW) {
   return sizeof(float) * ((size_t)IH * IW * RC_CB + (size_t)RC_KR * RC_GS + 4 * RC_CB);
 }
 
-static int rc_check_tile(const char* who, int C, int s, int TH, int TW, int ldx, const void* x) {
-  LY_CHECK(C > 0 && (C % RC_CB) == 0, "%s: C=%d must be a multiple of %d", who, C, RC_CB);
-  LY_CHECK(s == 1 || s == 2, "%s: stride %d is not built (1 or 2)", who, s);
-  LY_CHECK(TH >= 1 && TW >= 2 && (TW & 1) == 0 && TH * TW <= RC_TP, "%s: bad tile %dx%d (TW even, TH*TW <= %d)", who, TH, TW, RC_TP);
-  const int IH = s * (TH - 1) + 3, IW = s * (TW - 1) + 3;
-  LY_CHECK(IH * IW <= RC_MAXPOS, "%s: the %dx%d tile reads %d input positions (max %d)", who, TH, TW, IH * IW, RC_MAXPOS);
-  LY_CHECK((ldx & 7) == 0 && ((uintptr_t)x & 15) == 0, "%s: x must be 16-byte aligned with a row stride that is a multiple of 8", who);
+template <typename T, int S, bool RAW>
+static int rc_launch_stats(const void* x, int ldx, int n_img, int H, int W, int C, int Ho, int Wo, int TH, int TW, int nct, int nrt, const float* wq,
+                           float* mm, float* part, size_t lds, hipStream_t st) {
+  auto k = ly_rf3c_stats_kernel<T, S, RAW>;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    LY_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    configured = true;
+  }
+  hipLaunchKernelGGL(k, dim3((unsigned)(n_img * nrt * nct)), dim3(LY_THREADS), lds, st, reinterpret_cast<const T*>(x), ldx, H, W, C, Ho, Wo, TH, TW, nct, nrt,
+                     wq, mm, part);
+  LY_LAUNCH_CHECK();
   return 0;
 }
 
-extern "C" int ly_rf3c_stats(const void* x, int ldx, int n_img, int H, int W, int C, int s, const float* wq, int TH, int TW, float* mm,
+extern "C" int ly_rf3c_stats(const void* x, int ldx, int n_img, int H, int W, int C, int s, const float* wq, int raw, int TH, int TW, float* mm,
                              float* part, int slices, int dtype, void* stream) {
   LY_CHECK_DTYPE(dtype, "rf3c_stats");
   LY_CHECK(x && wq && mm && n_img > 0, "rf3c_stats: null pointer");
@@ -169,26 +175,11 @@ extern "C" int ly_rf3c_stats(const void* x, int ldx, int n_img, int H, int W, in
   LY_CHECK(!part || slices == nct * nrt, "rf3c_stats: the pooling partials are one row per tile: slices must be %d", nct * nrt);
   const size_t lds = rc_stats_lds(s, TH, TW);
   LY_CHECK(lds <= 160 * 1024, "rf3c_stats: tile needs %zu B LDS", lds);
-  static bool configured = false;
-  if (!configured) {
-    const void* ks[4] = {reinterpret_cast<const void*>(ly_rf3c_stats_kernel<float, 1>), reinterpret_cast<const void*>(ly_rf3c_stats_kernel<float, 2>),
-                         reinterpret_cast<const void*>(ly_rf3c_stats_kernel<__bf16, 1>), reinterpret_cast<const void*>(ly_rf3c_stats_kernel<__bf16, 2>)};
-    for (int i = 0; i < 4; ++i) {
-      hipError_t e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      LY_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-    }
-    configured = true;
-  }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const dim3 grid((unsigned)(n_img * nrt * nct));
-  if (s == 1)
-    LY_WITH_T(dtype, hipLaunchKernelGGL((ly_rf3c_stats_kernel<T, 1>), grid, dim3(LY_THREADS), lds, st, reinterpret_cast<const T*>(x), ldx, H, W, C, Ho, Wo, TH, TW,
-                                        nct, nrt, wq, mm, part));
-  else
-    LY_WITH_T(dtype, hipLaunchKernelGGL((ly_rf3c_stats_kernel<T, 2>), grid, dim3(LY_THREADS), lds, st, reinterpret_cast<const T*>(x), ldx, H, W, C, Ho, Wo, TH, TW,
-                                        nct, nrt, wq, mm, part));
-  LY_LAUNCH_CHECK();
-  return 0;
+#define RC_ST(T_, S_, R_) rc_launch_stats<T_, S_, R_>(x, ldx, n_img, H, W, C, Ho, Wo, TH, TW, nct, nrt, wq, mm, part, lds, st)
+  if (dtype == LY_BF16) return s == 1 ? (raw ? RC_ST(__bf16, 1, true) : RC_ST(__bf16, 1, false)) : (raw ? RC_ST(__bf16, 2, true) : RC_ST(__bf16, 2, false));
+  return s == 1 ? (raw ? RC_ST(float, 1, true) : RC_ST(float, 1, false)) : (raw ? RC_ST(float, 2, true) : RC_ST(float, 2, false));
+#undef RC_ST
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -197,7 +188,7 @@ extern "C" int ly_rf3c_stats(const void* x, int ldx, int n_img, int H, int W, in
 //   against conv.0.weight packed as [N][C/32][9 taps][32 channels]; the next chunk's input tile, generate weights and the conv
 //   weight fragments (register ring) are requested a phase ahead.
 // ---------------------------------------------------------------------------------------------------
-template <typename T, int MT, int NW, int S>
+template <typename T, int MT, int NW, int S, bool RAW>
 __global__ __launch_bounds__(NW * 64) void ly_rf3c_fwd_kernel(const LyRfcbam3Params P, const float* __restrict__ wq, const int gy, const int nct,
                                                                  const int nrt) {
   using TR = LyT<T>;
@@ -289,7 +280,7 @@ __global__ __launch_bounds__(NW * 64) void ly_rf3c_fwd_kernel(const LyRfcbam3Par
   }
 
   RcW w;
-  rc_load_w(w, wq, 0, c);
+  rc_load_w<RAW>(w, wq, 0, c);
   float cav = P.ca[(long)n * P.C + c];
 
   for (int ch = 0; ch < NCH; ++ch) {
@@ -304,7 +295,7 @@ __global__ __launch_bounds__(NW * 64) void ly_rf3c_fwd_kernel(const LyRfcbam3Par
     for (int j = 0; j < NJ; ++j) {
       f32x2 xv[9], a[9];
       rc_patch<S>(xp[j], row, xv);
-      rc_generate<true>(w, xv, a);
+      rc_gen_bn<RAW>(w, xv, a);
       const f32x2* rfp = reinterpret_cast<const f32x2*>(rfs) + (NJ * stream + j) * 9;
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
@@ -322,7 +313,7 @@ __global__ __launch_bounds__(NW * 64) void ly_rf3c_fwd_kernel(const LyRfcbam3Par
     // the next chunk's generate weights: in flight during the contraction (the last chunk re-requests chunk 0: no load under a branch)
     {
       const int cn = more ? (ch + 1) * RC_CB : 0;
-      rc_load_w(w, wq, cn, c);
+      rc_load_w<RAW>(w, wq, cn, c);
       cav = P.ca[(long)n * P.C + cn + c];
     }
     __syncthreads();
@@ -396,14 +387,14 @@ __global__ __launch_bounds__(NW * 64) void ly_rf3c_fwd_kernel(const LyRfcbam3Par
   }
 }
 
-template <typename T, int MT, int NW, int S>
+template <typename T, int MT, int NW, int S, bool RAW>
 static int rc_launch_fwd_s(const LyRfcbam3Params& P, const float* wq, hipStream_t st) {
   const int nct = (P.Wo + P.TW - 1) / P.TW, nrt = (P.Ho + P.TH - 1) / P.TH;
   const int gy = (P.N + 16 * NW * MT - 1) / (16 * NW * MT);
   const int IH = P.s * (P.TH - 1) + 3, IW = P.s * (P.TW - 1) + 3;
   const size_t lds = sizeof(float) * ((size_t)IH * IW * RC_CB + RC_TP * 9) + (size_t)LyT<T>::PL * RC_KR * 128;
   LY_CHECK(lds <= 160 * 1024, "rf3c_fwd: tile needs %zu B LDS", lds);
-  auto k = ly_rf3c_fwd_kernel<T, MT, NW, S>;
+  auto k = ly_rf3c_fwd_kernel<T, MT, NW, S, RAW>;
   static bool configured = false;
   if (!configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -418,24 +409,25 @@ static int rc_launch_fwd_s(const LyRfcbam3Params& P, const float* wq, hipStream_
 }
 
 template <typename T, int MT, int NW>
-static int rc_launch_fwd(const LyRfcbam3Params& P, const float* wq, hipStream_t st) {
-  return P.s == 1 ? rc_launch_fwd_s<T, MT, NW, 1>(P, wq, st) : rc_launch_fwd_s<T, MT, NW, 2>(P, wq, st);
+static int rc_launch_fwd(const LyRfcbam3Params& P, const float* wq, bool raw, hipStream_t st) {
+  if (raw) return P.s == 1 ? rc_launch_fwd_s<T, MT, NW, 1, true>(P, wq, st) : rc_launch_fwd_s<T, MT, NW, 2, true>(P, wq, st);
+  return P.s == 1 ? rc_launch_fwd_s<T, MT, NW, 1, false>(P, wq, st) : rc_launch_fwd_s<T, MT, NW, 2, false>(P, wq, st);
 }
 
 template <typename T>
-static int rc_dispatch_fwd(const LyRfcbam3Params& P, const float* wq, hipStream_t st) {
+static int rc_dispatch_fwd(const LyRfcbam3Params& P, const float* wq, bool raw, hipStream_t st) {
   // N <= 128: 4 waves x (MT x 16) output channels, two blocks per CU (bf16); wider: 8 waves share ONE regenerated tile (the VALU phase is
   // split over 16 pixel streams, the contraction over 8 x 32 output channels) instead of regenerating it per 128-channel group
   if constexpr (LyT<T>::BF) {
-    if (P.N > 128) return rc_launch_fwd<T, 2, 8>(P, wq, st);
+    if (P.N > 128) return rc_launch_fwd<T, 2, 8>(P, wq, raw, st);
   }
-  if (P.N > 64) return rc_launch_fwd<T, 2, 4>(P, wq, st);
-  return rc_launch_fwd<T, 1, 4>(P, wq, st);
+  if (P.N > 64) return rc_launch_fwd<T, 2, 4>(P, wq, raw, st);
+  return rc_launch_fwd<T, 1, 4>(P, wq, raw, st);
 }
 
-// P as for ly_rfcbam3_fwd with two differences: P.wg is ignored (wq = the lane-order generate weights [C][92]: w'[t][u], b'[t], 2 pad) and
-// P.wp = conv.0.weight frag-packed as [N][C/32 chunks][9 taps][32 channels] (K = 9*C, no padding).
-extern "C" int ly_rf3c_fwd(const LyRfcbam3Params* p, const float* wq, void* stream) {
+// P as for ly_rfcbam3_fwd with two differences: P.wg is ignored (wq = the lane-order generate weights, raw != 0: the training form, see
+// ly_rf3c.cuh) and P.wp = conv.0.weight frag-packed as [N][C/32 chunks][9 taps][32 channels] (K = 9*C, no padding).
+extern "C" int ly_rf3c_fwd(const LyRfcbam3Params* p, const float* wq, int raw, void* stream) {
   LY_CHECK(p && wq, "rf3c_fwd: null params");
   const LyRfcbam3Params& P = *p;
   LY_CHECK_DTYPE(P.dtype, "rf3c_fwd");
@@ -444,5 +436,5 @@ extern "C" int ly_rf3c_fwd(const LyRfcbam3Params* p, const float* wq, void* stre
   LY_CHECK((long)P.n_img * P.H * P.W * P.ldx < (1L << 31), "rf3c_fwd: input exceeds the 31-bit offsets of the staging plan");
   LY_CHECK(P.Ho == (P.H + 2 - 3) / P.s + 1 && P.Wo == (P.W + 2 - 3) / P.s + 1, "rf3c_fwd: inconsistent output size");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  return P.dtype == LY_BF16 ? rc_dispatch_fwd<__bf16>(P, wq, st) : rc_dispatch_fwd<float>(P, wq, st);
+  return P.dtype == LY_BF16 ? rc_dispatch_fwd<__bf16>(P, wq, raw != 0, st) : rc_dispatch_fwd<float>(P, wq, raw != 0, st);
 }

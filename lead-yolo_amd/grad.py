@@ -805,8 +805,11 @@ class RfcbamFn(torch.autograd.Function):
         P = mod._packed_train(ops.planes_of(xr))
         if se_wa.dtype != torch.float32:
             raise NotImplementedError("RFCBAMConv training needs float32 parameters (train under autocast, fp32 master weights)")
-        # SE (models/rfa.py:88-92): pooling partials + the two linears, two launches; the partials are kept for the backward
-        ca, se_part = ops.se_attention(xr, ld, n, h * w, c, se_wa.detach(), se_wb.detach(), se_wa.shape[0], want_part=True)
+        from . import modules as _m
+        rc = k == 3 and ops.rf3c_ok(c, s) and _m.RF3C             # lane = channel kernels (csrc/ly_rf3c.hip): the pooling partials come out of the statistics pass
+        if not rc:
+            # SE (models/rfa.py:88-92): pooling partials + the two linears, two launches; the partials are kept for the backward
+            ca, se_part = ops.se_attention(xr, ld, n, h * w, c, se_wa.detach(), se_wb.detach(), se_wa.shape[0], want_part=True)
         bias = conv_b.detach().float().contiguous()
         if gen_w.dtype != torch.float32:
             raise NotImplementedError("RFCBAMConv training needs float32 parameters (train under autocast, fp32 master weights)")
@@ -827,6 +830,21 @@ class RfcbamFn(torch.autograd.Function):
             out = torch.empty_like(u)
             ops.bnact_fwd(u, o, n * h * w, o, es, t, ACT_RELU, out, o)
             ctx.fwd = dict(kw=kw)
+        elif rc:
+            # three launches, x read twice: statistics + SE pooling partials | SE linears + get_weight conv | regenerate + contraction.  The RAW
+            # generate image (u = w.x, v = a*u + b) is what the backward re-evaluates bit for bit
+            th, tw = ops.pick_tile_c(ho, wo, s)
+            mm, se_part = ops.rf3c_stats(xr, ld, n, h, w, c, s, G["wq_c"], th, tw, raw=True)
+            ca, rfa = ops.rfcbam_mid(se_part, h * w, se_wa.detach(), se_wb.detach(), se_wa.shape[0], mm, P["w18"])
+            kw = dict(n=n, h=h, w=w, c=c, ho=ho, wo=wo, N=o, s=s, th=th, tw=tw, x=xr, ldx=ld, wq=G["wq_c"], ca=ca, rfa=rfa, wp=P["wp_c"], ldo=o, raw=True)
+            stats = ops.new_stats(o, xr.device)
+            u = ops.empty_nhwc(n, o, ho, wo, xr)
+            ops.rf3c_fwd(out=u, e_scale=torch.ones_like(bias), e_shift=bias, stats=stats, **kw)
+            es, t, omean, oinv = ops.bn_finalize(mod.conv[1], stats, o, n * ho * wo, want_stats=True)
+            out = torch.empty_like(u)
+            ops.bnact_fwd(u, o, n * ho * wo, o, es, t, ACT_RELU, out, o)
+            ctx.fwd = dict(kw=kw)
+            ctx.rc = dict(th=th, tw=tw, wq=G["wq_c"])
         else:
             th, tw = ops.pick_tile(ho, wo)
             wq_stats, wq_main = G["wq_stats"], G["wq_main"]
@@ -840,6 +858,8 @@ class RfcbamFn(torch.autograd.Function):
             out = torch.empty_like(u)
             ops.bnact_fwd(u, o, n * ho * wo, o, es, t, ACT_RELU, out, o)
             ctx.fwd = dict(kw=kw)
+        if not rc:
+            ctx.rc = None
         ctx.geom = (n, c, h, w, k, s, o, ho, wo, ld)
         ctx.conv_w_param = conv_w
         ctx.se_params = (se_wa, se_wb)
@@ -870,6 +890,10 @@ class RfcbamFn(torch.autograd.Function):
             du, dgo, dbo = affine_backward(dy, u, es, t, ACT_RELU, omean, oinv, True, inplace=False, gamma=ctx.out_bn_params[0],
                                            beta=ctx.out_bn_params[1])       # (straight into the sink when one holds them: returns None, None)
             _tap("rf.du", du)
+            # (o = 256 — layer 20 — measured SLOWER on the recompute passes than on the streamed 9x tensors: 1.08 vs 0.73 ms of kernels at bs = 64;
+            # layer 17, o = 128: 0.95 vs 1.47 ms.  The wider layer stays on the first-generation backward.)
+            if ctx.rc is not None and dt == torch.bfloat16 and s == 2 and o in (64, 128) and RC_BWD:
+                return RfcbamFn._backward_rc(ctx, du, dgo, dbo)
             # 3. dcd [mo][t][c]
             # Wc^T with rows (t, c): conv.0.weight [o, c, kh, kw] read in place
             dcd = torch.empty((mo, kk * c), dtype=dt, device=dev)
@@ -946,6 +970,80 @@ class RfcbamFn(torch.autograd.Function):
                 (None if t18 is not None else dw18.view(getw.shape)), dwc, dbias, dgo, dbo)
 
 
+def _rfcbam_backward_rc(ctx, du, dgo, dbo):
+    """RFCBAMConv k=3 backward on csrc/ly_rf3c_bwd.hip: no 9x-sized tensor in HBM — three recompute passes + the conv weight gradient"""
+    xr, ca, gen_w, getw, conv_w, bias, ag, bg, gmean_tc, ginv_tc, es, t, omean, oinv, mm, rfa, se_part, u = ctx.saved_tensors
+    n, c, h, w, k, s, o, ho, wo, ld = ctx.geom
+    dev = xr.device
+    L = _lib()
+    st = L.stream_ptr()
+    p = L.ptr
+    mo, nch = n * ho * wo, c // 32
+    th, tw, wq = ctx.rc["th"], ctx.rc["tw"], ctx.rc["wq"]
+    wct = pack.packed(pack.Src(ctx.conv_w_param, 9 * c, nrb=c, sra=1, srb=9, nc=o, sc=c * 9), o, 1)
+    npos = n * 9 * ho * wo
+    d_rfa_part = torch.empty((nch, npos), dtype=torch.float32, device=dev)
+    d_ca = torch.empty((n, c), dtype=torch.float32, device=dev)
+    sums = torch.empty((n, 18 * c), dtype=torch.float32, device=dev)
+    dwg = torch.empty((n, c * 81), dtype=torch.float32, device=dev)
+    nog = -(-o // 128)
+    ng = max(1, min(n, 256 // (nch * nog)))
+    dwc_part = torch.empty((ng, o, 9, c), dtype=torch.float32, device=dev)
+    need_dx = ctx.needs_input_grad[1]
+    dx = ops.empty_nhwc(n, c, h, w, xr)
+    P = L.LyRf3cBwdParams(n, h, w, c, ho, wo, o, s, th, tw, p(xr), ld, p(du), o, p(wq), p(wct), p(ca), p(rfa), p(mm), None, None,
+                          p(d_rfa_part), p(d_ca), p(sums), p(dwg), p(dx), c, None, 1.0 / (h * w), p(dwc_part), ng, L.dtype_code(xr))
+    es9 = 2.0 * mo * 9 * c
+    xb = xr.element_size() * (n * h * w * c + mo * o)
+    tn = ops._tname(xr)
+    # A: d_rfa (one slab per channel chunk), d_ca
+    with ops._Timed(f"ly_rf3c_bwd_kernel<A, {o // 32}>", 2.0 * mo * 9 * c * (o + 81), xb):
+        L.check(L.lib().ly_rf3c_bwd(ctypes.byref(P), 0, st), "ly_rf3c_bwd A")
+    # conv weight gradient (independent of the chain below)
+    with ops._Timed("ly_rf3c_wgrad_kernel", 2.0 * mo * 9 * c * (o + 81), xb):
+        L.check(L.lib().ly_rf3c_wgrad(ctypes.byref(P), st), "ly_rf3c_wgrad")
+    dwc = dwc_part.sum(0) if ng > 1 else dwc_part[0]
+    dwc = dwc.permute(0, 2, 1).reshape(conv_w.shape)
+    # get_weight + sigmoid
+    d_rfa = d_rfa_part.sum(0).view_as(rfa) if nch > 1 else d_rfa_part[0].view_as(rfa)
+    w18 = getw.detach().float().reshape(18).contiguous()
+    d_mm = torch.empty_like(mm)
+    t18 = ops.grad_target(ctx.getw_param)
+    t18 = t18 if t18 is not None and t18.is_contiguous() else None
+    dw18 = t18.view(-1) if t18 is not None else torch.zeros(18, dtype=torch.float32, device=dev)
+    L.check(L.lib().ly_rfa_bwd(p(d_rfa), p(rfa), p(mm), p(w18), n, 3 * ho, 3 * wo, p(d_mm), p(dw18), st), "ly_rfa_bwd")
+    if t18 is not None:
+        ops.grad_done(ctx.getw_param)
+    P.d_mm = p(d_mm)
+    # B: BatchNorm sums, one stripe per image
+    with ops._Timed(f"ly_rf3c_bwd_kernel<B, {o // 32}>", 2.0 * mo * 9 * c * (o + 81), xb):
+        L.check(L.lib().ly_rf3c_bwd(ctypes.byref(P), 1, st), "ly_rf3c_bwd B")
+    dgg_tc, dbg_tc, alpha, kappa, lam = ops.bn_bwd_coeffs(sums, 9 * c, mo, ag, gmean_tc, ginv_tc, True)
+    P.coef = p(alpha)                          # alpha, kappa, lambda are rows 2..4 of one [5, 9c] tensor
+    assert kappa.data_ptr() == alpha.data_ptr() + 4 * 9 * c and lam.data_ptr() == alpha.data_ptr() + 8 * 9 * c
+    ct = lambda v: v.view(9, c).t().contiguous().view(-1)
+    # SE backward: parameter gradients, and d/d(mean x) which pass C adds while it writes dx
+    se_wa, se_wb = ctx.se_params
+    ta, tb = ops.grad_target(se_wa), ops.grad_target(se_wb)
+    se_direct = ta is not None and tb is not None
+    dwa = ta if se_direct else torch.zeros(se_wa.shape, dtype=torch.float32, device=dev)
+    dwb = tb if se_direct else torch.zeros(se_wb.shape, dtype=torch.float32, device=dev)
+    dgap = ops.se_bwd(se_part, n, h * w, c, se_wa.detach(), se_wb.detach(), se_wa.shape[0], ca, d_ca, dwa, dwb)
+    if se_direct:
+        ops.grad_done(se_wa)
+        ops.grad_done(se_wb)
+    P.dgap = p(dgap)
+    P.TH, P.TW = ops.pick_tile_bwd_dx(ho, wo, o)          # pass C walks its pixel pairs in four colours: its own tile choice
+    # C: generate weight gradient rows + dx
+    with ops._Timed(f"ly_rf3c_bwd_kernel<C, {o // 32}>", 2.0 * mo * 9 * c * (o + 243), xb + xr.element_size() * n * h * w * c):
+        L.check(L.lib().ly_rf3c_bwd(ctypes.byref(P), 2, st), "ly_rf3c_bwd C")
+    dbias = None if ops.grad_target(ctx.conv_b_param) is not None else torch.zeros_like(bias)      # BN removes the batch mean: d/dbias = 0
+    return (None, dx if need_dx else None, None if se_direct else dwa, None if se_direct else dwb, dwg.sum(0).view(gen_w.shape), ct(dgg_tc), ct(dbg_tc),
+            (None if t18 is not None else dw18.view(getw.shape)), dwc, dbias, dgo, dbo)
+
+
+RfcbamFn._backward_rc = staticmethod(_rfcbam_backward_rc)
+RC_BWD = True          # tools: False keeps the first-generation backward behind the lane = channel forward
 def rfcbam_train(mod, x):
     """RFCBAMConv.forward in training: one autograd node (SE, generate BatchNorm, attention maps, contraction)."""
     g, cv = mod.generate, mod.conv

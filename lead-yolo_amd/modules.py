@@ -578,14 +578,14 @@ class RFCBAMConv(nn.Module):
         parameters only — `_packed` also folds the BatchNorm RUNNING statistics, which change every training step, and rebuilding its
         folded generate weights there cost ~25 tiny launches per module and step for images the training path never reads."""
         cw = self.conv[0]
-        key = pack.versions(cw.weight, self.get_weight[0].weight)
+        key = pack.versions(cw.weight, self.get_weight[0].weight) + (RF3C,)
 
         def build():
             k, c, o = self.kernel_size, self.c, self.o
             w18 = self.get_weight[0].weight.detach().float().reshape(18).contiguous()
             if k == 1:
                 return dict(w18=w18, wp=pack.packed(pack.src_matrix(cw.weight, o, c), c, planes))
-            if ops.rf3c_ok(c, self.stride):
+            if ops.rf3c_ok(c, self.stride) and RF3C:
                 return dict(w18=w18, wp_c=self._wp_c(planes))
             wsrc = pack.Src(cw.weight, o, srb=c * 9, nb=10, vb=9, nc=16, sa=144, sb=1, sc=9)
             return dict(w18=w18, wp=pack.packed(wsrc, (c // 16) * 160, planes))

@@ -334,19 +334,38 @@ def pick_tile_c(ho, wo, s):
     return best[1], best[2]
 
 
-def rf3c_stats(x, ldx, n, h, w, c, s, wq, th, tw, gap=True):
+def pick_tile_bwd_dx(ho, wo, o):
+    """tile of the recompute backward's dx pass (csrc/ly_rf3c_bwd.hip pass C): its pixel pairs are walked in four colours (row parity x pair-column
+    parity) of ceil(count / 8) iterations each — fewest iteration slots over the map among the tiles whose LDS footprint fits, then smallest halo"""
+    best = None
+    for tw in range(2, 65, 2):
+        th = min(64 // tw, ho)
+        ih, iw = 2 * (th - 1) + 3, 2 * (tw - 1) + 3
+        pos = ih * iw
+        nct = -(-wo // tw)
+        lds = 2 * pos * 128 + 288 * 128 + 64 * (2 * o + 16) + 32 * 9 * 8 * 4 + 256 + (ih + 2 * tw * nct + 2 + 27) * 128     # mirrors rb_launch
+        if th < 1 or pos > 320 or lds > 160 * 1024:
+            continue
+        its = sum(-(-(((th + 1 - ry) // 2) * ((tw // 2 + 1 - rx) // 2)) // 8) for ry in (0, 1) for rx in (0, 1))
+        key = (-(-ho // th) * nct * its, pos)
+        if best is None or key < best[0]:
+            best = (key, th, tw)
+    return best[1], best[2]
+
+
+def rf3c_stats(x, ldx, n, h, w, c, s, wq, th, tw, gap=True, raw=False):
     """ONE pass over x: (mm [n, 3ho, 3wo, 2], part [n, tiles, c]) — the [max, mean] map of relu(bn(generate(x))) and SE's pooling partials"""
     ho, wo = (h + 2 - 3) // s + 1, (w + 2 - 3) // s + 1
     mm = torch.empty((n, 3 * ho, 3 * wo, 2), dtype=torch.float32, device=x.device)
     tiles = -(-ho // th) * -(-wo // tw)
     part = torch.empty((n, tiles, c), dtype=torch.float32, device=x.device) if gap else None
     with _Timed(f"ly_rf3c_stats_kernel<{_tname(x)}>", 2.0 * n * ho * wo * c * 81, x.element_size() * n * h * w * c + 4.0 * 18 * n * ho * wo):
-        capi.check(capi.lib().ly_rf3c_stats(_p(x), ldx, n, h, w, c, s, _p(wq), th, tw, _p(mm), _p(part), tiles, capi.dtype_code(x),
+        capi.check(capi.lib().ly_rf3c_stats(_p(x), ldx, n, h, w, c, s, _p(wq), int(raw), th, tw, _p(mm), _p(part), tiles, capi.dtype_code(x),
                                             capi.stream_ptr()), "ly_rf3c_stats")
     return mm, part
 
 
-def rf3c_fwd(*, n, h, w, c, ho, wo, N, s, th, tw, x, ldx, wq, ca, rfa, wp, e_scale, e_shift, out, ldo, stats=None, linear=False):
+def rf3c_fwd(*, n, h, w, c, ho, wo, N, s, th, tw, x, ldx, wq, ca, rfa, wp, e_scale, e_shift, out, ldo, stats=None, linear=False, raw=False):
     P = capi.LyRfcbam3Params(n, h, w, c, ho, wo, N, s, th, tw, _p(x), ldx, None, _p(ca), _p(rfa), _p(wp), _p(e_scale),
                              _p(e_shift), _p(out), ldo, _p(stats), int(linear), capi.dtype_code(x))
     mo = n * ho * wo
@@ -354,7 +373,7 @@ def rf3c_fwd(*, n, h, w, c, ho, wo, N, s, th, tw, x, ldx, wq, ca, rfa, wp, e_sca
     cfg = "2, 8" if (N > 128 and bf) else ("2, 4" if N > 64 else "1, 4")         # mirrors rc_dispatch_fwd
     with _Timed(f"ly_rf3c_fwd_kernel<{_tname(x)}, {cfg}>", 2.0 * mo * (9 * c * N + 81 * c),
                 x.element_size() * (n * h * w * c + mo * N) + 4.0 * 9 * c * N):
-        capi.check(capi.lib().ly_rf3c_fwd(ctypes.byref(P), _p(wq), capi.stream_ptr()), "ly_rf3c_fwd")
+        capi.check(capi.lib().ly_rf3c_fwd(ctypes.byref(P), _p(wq), int(raw), capi.stream_ptr()), "ly_rf3c_fwd")
 
 
 def rfcbam_stats(x, ldx, n, h, w, c, k, s, wg=None, a1=None, b1=None, th=1, tw=64, gap=False):
@@ -645,7 +664,7 @@ def rfcbam_gen_prepare(x, ldx, n, h, w, c, k, s, gen_w, bn):
     cps, cpm = (c + 31) // 32 * 32, (c + 15) // 16 * 16
     wqs = torch.empty(cps * 90, dtype=torch.float32, device=dev) if k == 3 else None
     wqm = torch.empty(cpm * 90, dtype=torch.float32, device=dev) if k == 3 else None
-    wqc = torch.empty(c * 92, dtype=torch.float32, device=dev) if k == 3 else None
+    wqc = torch.empty(c * 100, dtype=torch.float32, device=dev) if (k == 3 and c % 32 == 0) else None
     if bn.weight.dtype != torch.float32:
         raise NotImplementedError("train-mode BatchNorm needs float32 parameters and buffers")
     track = bn.track_running_stats and bn.running_mean is not None

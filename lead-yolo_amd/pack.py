@@ -110,15 +110,17 @@ def rfcbam_gen_weights(gen_w, scale, shift, chunk, per_wave_contiguous):
     return v.view(-1)
 
 
-def rfcbam_gen_weights_c(gen_w, scale, shift):
-    """Folded depthwise 'generate' weights of RFCBAMConv (k=3) in LANE = CHANNEL order (csrc/ly_rf3c.cuh rc_load_w): per channel 92 floats
-    — w'[t][u] at t*9 + u, b'[t] at 81 + t, two of padding — stored as float [C/32][23][32][4] so that a half wave's 16-byte loads are
-    contiguous."""
+def rfcbam_gen_weights_c(gen_w, scale, shift, raw=False):
+    """Depthwise 'generate' weights of RFCBAMConv (k=3) in LANE = CHANNEL order (csrc/ly_rf3c.cuh rc_load_w): per channel 100 floats —
+    w[t][u] at t*9 + u, b[t] at 81 + t, a[t] at 90 + t, one of padding — stored as float [C/32][25][32][4] so that a half wave's 16-byte
+    loads are contiguous.  Folded (inference): w = weight * scale, b = shift;  raw (training): w = weight, a = scale, b = shift."""
     c = gen_w.shape[0] // 9
-    out = torch.zeros(c, 92, dtype=torch.float32, device=gen_w.device)
-    out[:, :81] = (gen_w.detach().float().view(c, 9, 9) * scale.view(c, 9, 1)).reshape(c, 81)
+    out = torch.zeros(c, 100, dtype=torch.float32, device=gen_w.device)
+    wv = gen_w.detach().float().view(c, 9, 9)
+    out[:, :81] = (wv if raw else wv * scale.view(c, 9, 1)).reshape(c, 81)
     out[:, 81:90] = shift.view(c, 9)
-    return out.view(c // 32, 32, 23, 4).permute(0, 2, 1, 3).contiguous().view(-1)
+    out[:, 90:99] = scale.view(c, 9) if raw else 1.0
+    return out.view(c // 32, 32, 25, 4).permute(0, 2, 1, 3).contiguous().view(-1)
 
 
 # --------------------------------------------------------------------------------------------------

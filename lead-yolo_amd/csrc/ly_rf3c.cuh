@@ -7,8 +7,8 @@
 // wave-uniform: they came out of LDS as broadcast reads and the LDS pipe, not the VALU, set the time.  Here
 //      lane = channel (32 channels x 2 pixel streams per wave),
 // so the 81 weights (+ 9 folded biases) of the lane's channel sit in 92 registers for a whole 32-channel chunk, the x patch is
-// read from an fp32 LDS tile with conflict-free per-lane reads, two horizontally adjacent output pixels are computed together as
-// the halves of v_pk_fma_f32 (the weight is broadcast by op_sel, no duplicated registers), and whatever has to change hands
+// read from an fp32 LDS tile with conflict-free per-lane reads, two horizontally adjacent output pixels are computed together (one
+// weight register feeds both), and whatever has to change hands
 // between the channel-parallel VALU phase and a pixel-parallel phase (MFMA operand, channel reductions) goes through ONE
 // K-major LDS tile  [k = t*32 + c][pixel]  whose pixel pairs are stored as one dword / qword per lane.
 //
@@ -25,13 +25,36 @@
 
 typedef short ly_s16x4 __attribute__((ext_vector_type(4)));
 
-// acc + x * w[SEL] (both halves of x times ONE weight): the weight pair register is shared by two taps, op_sel picks the dword
+// acc + x * w[sel] for the two pixels of a pair (x) and ONE weight (element sel of the register pair w).
+// These were hand-written v_pk_fma_f32 with the weight broadcast by op_sel / op_sel_hi (one packed instruction per weight and pixel pair).
+// Alone on a SIMD they are exact; MEASURED: whenever another wave of the SIMD issues MFMAs (a second block of the same kernel in its
+// contraction phase, a GEMM of another stream) their results come back slightly wrong and different from run to run — 28 of 30 runs of the
+// statistics pass beside a bf16 matmul stream, 0 of 30 with the plain FMAs below; padding the LDS allocations apart changed nothing, one
+// block per CU hid it.  The compiler's v_fmac_f32 cost nothing at two waves per SIMD (L17 forward 225 vs 223 us), so the asm is gone.
+// RC_ASM_FMA (defined by ly_rf3c_bwd.hip only) selects the packed asm form: those kernels hold 180-250 live registers and the opaque
+// instructions keep the compiler's scheduler from spilling 170-310 of them; they run ONE wave per SIMD and own their CU (whole-LDS launch),
+// so no other wave can issue an MFMA beside them.
+#ifndef RC_ASM_FMA
+__device__ __forceinline__ f32x2 rc_pkfma(const f32x2 x, const f32x2 w, const f32x2 acc, const int sel) {
+  const float ww = w[sel];
+  return (f32x2){__builtin_fmaf(x[0], ww, acc[0]), __builtin_fmaf(x[1], ww, acc[1])};
+}
+// x * w[sel] + b[selb]  (first term of a chain)
+__device__ __forceinline__ f32x2 rc_pkfma_b(const f32x2 x, const f32x2 w, const f32x2 b, const int sel, const int selb) {
+  const float ww = w[sel], bb = b[selb];
+  return (f32x2){__builtin_fmaf(x[0], ww, bb), __builtin_fmaf(x[1], ww, bb)};
+}
+// x * w[sel]
+__device__ __forceinline__ f32x2 rc_pkmul(const f32x2 x, const f32x2 w, const int sel) {
+  const float ww = w[sel];
+  return (f32x2){x[0] * ww, x[1] * ww};
+}
+#else
 __device__ __forceinline__ f32x2 rc_pkfma(const f32x2 x, const f32x2 w, f32x2 acc, const int sel) {
   if (sel) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(x), "v"(w));
   else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(x), "v"(w));
   return acc;
 }
-// x * w[SEL] + b[SELB]  (first term of a chain: the folded bias is broadcast the same way)
 __device__ __forceinline__ f32x2 rc_pkfma_b(const f32x2 x, const f32x2 w, const f32x2 b, const int sel, const int selb) {
   f32x2 r;
   if (sel) {
@@ -43,13 +66,13 @@ __device__ __forceinline__ f32x2 rc_pkfma_b(const f32x2 x, const f32x2 w, const 
   }
   return r;
 }
-// x * w[SEL]
 __device__ __forceinline__ f32x2 rc_pkmul(const f32x2 x, const f32x2 w, const int sel) {
   f32x2 r;
   if (sel) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(x), "v"(w));
   else asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(r) : "v"(x), "v"(w));
   return r;
 }
+#endif
 
 // the lane's generate weights.  Image: float wq[C/32 chunks][25][32 channels][4] — element i = 4*q + e of channel c at
 // ((chunk*25 + q)*32 + (c & 31))*4 + e — so that the 32 lanes of a half wave read 512 contiguous bytes per load (a per-channel
@@ -73,12 +96,7 @@ __device__ __forceinline__ void rc_load_w(RcW& w, const float* __restrict__ wq, 
     w.p[2 * i + 1] = (f32x2){v[2], v[3]};
   }
 }
-// relu without the canonicalising second v_max that fmaxf costs
-__device__ __forceinline__ float rc_relu(float v) {
-  float r;
-  asm("v_max_f32_e32 %0, 0, %1" : "=v"(r) : "v"(v));
-  return r;
-}
+__device__ __forceinline__ float rc_relu(float v) { return fmaxf(v, 0.f); }
 
 // folded: v[t] (pixel pair) = b[t] + sum_u w[t][u] * x[u];  raw: u[t] = sum_u w[t][u] * x[u].  Nine independent chains, interleaved so
 // that no packed FMA waits for its predecessor

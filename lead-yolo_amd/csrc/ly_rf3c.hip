@@ -291,10 +291,20 @@ __global__ __launch_bounds__(NW * 64) void ly_rf3c_fwd_kernel(const LyRfcbam3Par
     __syncthreads();
     // ---- regenerate: G' = relu(v) * ca * rfa for the stream's pixel pairs ----------------------------------
     const f32x2 cav2 = {cav, cav};
-#pragma unroll
+    // (8-wave blocks: 256 registers per lane; the two pair iterations stay rolled and recompute their addresses)
+#pragma unroll(NW == 8 ? 1 : NJ)
     for (int j = 0; j < NJ; ++j) {
       f32x2 xv[9], a[9];
-      rc_patch<S>(xp[j], row, xv);
+      const float* xpj;
+      int goffj;
+      if constexpr (NW == 8) {
+        const int px0 = 2 * NJ * stream + 2 * j;
+        xpj = xs + rc_pos0(g, px0) * RC_CB + c;
+        goffj = c * 128 + ((((px0 >> 2) ^ csw) << 3) | ((px0 & 2) << 1));
+      } else {
+        xpj = xp[j]; goffj = goff[j];
+      }
+      rc_patch<S>(xpj, row, xv);
       rc_gen_bn<RAW>(w, xv, a);
       const f32x2* rfp = reinterpret_cast<const f32x2*>(rfs) + (NJ * stream + j) * 9;
 #pragma unroll
@@ -303,10 +313,10 @@ __global__ __launch_bounds__(NW * 64) void ly_rf3c_fwd_kernel(const LyRfcbam3Par
         if constexpr (PL == 2) {
           const bf16x2 hi = __builtin_convertvector(gg, bf16x2);
           const f32x2 back = __builtin_convertvector(hi, f32x2);
-          *reinterpret_cast<unsigned*>(gs_hi + t * (RC_CB * 128) + goff[j]) = __builtin_bit_cast(unsigned, hi);
-          *reinterpret_cast<unsigned*>(gs_lo + t * (RC_CB * 128) + goff[j]) = rc_pack2(gg - back);
+          *reinterpret_cast<unsigned*>(gs_hi + t * (RC_CB * 128) + goffj) = __builtin_bit_cast(unsigned, hi);
+          *reinterpret_cast<unsigned*>(gs_lo + t * (RC_CB * 128) + goffj) = rc_pack2(gg - back);
         } else {
-          *reinterpret_cast<unsigned*>(gs_hi + t * (RC_CB * 128) + goff[j]) = rc_pack2(gg);
+          *reinterpret_cast<unsigned*>(gs_hi + t * (RC_CB * 128) + goffj) = rc_pack2(gg);
         }
       }
     }

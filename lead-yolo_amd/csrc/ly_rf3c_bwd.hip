@@ -16,6 +16,7 @@
 //           is completed by one block and written once, final (+ the SE term d/d(mean x)).
 //   ly_rf3c_wgrad: d(conv.0.weight)[o, c, t] = sum_p du[p, o] * (G*ca*rfa)[p, t, c]  (G' regenerated as in the forward, contraction over pixels)
 // bf16 storage, stride 2, C % 32 == 0, O in {64, 128, 256}; everything else stays on the first-generation kernels.
+#define RC_ASM_FMA          // see ly_rf3c.cuh: safe here (one wave per SIMD, the block owns its CU)
 #include "ly_rf3c.cuh"
 #include "ly_params.h"
 #include <stdlib.h>
@@ -485,7 +486,8 @@ static int rb_launch(const LyRf3cBwdParams& P, hipStream_t st) {
     LY_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     configured = true;
   }
-  hipLaunchKernelGGL(k, dim3((unsigned)(P.n_img * (P.C / RC_CB))), dim3(LY_THREADS), lds, st, P, nct, nrt);
+  // (launched with the whole LDS of a CU: a block of this family must not share its CU with any other block, see ly_rf3c.hip)
+  hipLaunchKernelGGL(k, dim3((unsigned)(P.n_img * (P.C / RC_CB))), dim3(LY_THREADS), (size_t)(160 * 1024), st, P, nct, nrt);
   LY_LAUNCH_CHECK();
   return 0;
 }
@@ -716,7 +718,8 @@ extern "C" int ly_rf3c_wgrad(const LyRf3cBwdParams* p, void* stream) {
   }
   const int ng = P.ng < P.n_img ? P.ng : P.n_img;
   LY_CHECK(ng == P.ng, "rf3c_wgrad: ng = %d exceeds the %d images", P.ng, P.n_img);
-  hipLaunchKernelGGL(ly_rf3c_wgrad_kernel, dim3((unsigned)(ng * nog * (P.C / RC_CB))), dim3(LY_THREADS), lds, reinterpret_cast<hipStream_t>(stream), P, nct, nrt, nog);
+  hipLaunchKernelGGL(ly_rf3c_wgrad_kernel, dim3((unsigned)(ng * nog * (P.C / RC_CB))), dim3(LY_THREADS), (size_t)(160 * 1024), reinterpret_cast<hipStream_t>(stream), P, nct,
+                     nrt, nog);
   LY_LAUNCH_CHECK();
   return 0;
 }

@@ -679,9 +679,14 @@ class RFCBAMConv(nn.Module):
             es, eb = ops.bn_finalize(self.conv[1], stats, self.o, n * ho * wo, bias=bias)
         out = ops.empty_nhwc(n, self.o, ho, wo, xr)
         ops.rf3c_fwd(out=out, e_scale=es, e_shift=eb, **kw)
+        import os
+        if os.environ.get("LY_LOG_ALLOC"):
+            cap = torch.cuda.is_current_stream_capturing()
+            _HOLD.append((self.c, cap, {nm: (t_ if cap else t_.clone()) for nm, t_ in (("xr", xr), ("mm", mm), ("part", part), ("ca", ca), ("rfa", rfa), ("out", out))}))
         return out
 
 
+_HOLD = []
 RF3C = True        # tools / tests: False runs the first-generation k=3 kernels (lane = pixel) for A/B comparisons
 
 

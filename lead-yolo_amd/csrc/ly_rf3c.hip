@@ -257,7 +257,7 @@ __global__ __launch_bounds__(NW * 64) void ly_rf3c_fwd_kernel(const LyRfcbam3Par
   }
   const uint4* wpk = reinterpret_cast<const uint4*>(P.wp);
   constexpr int NF = 9 * MT;                               // fragments per chunk, k-step major
-  constexpr int D = MT == 1 ? 3 : 6;                       // ring depth; NF % D == 0: the slot of a fragment does not depend on the chunk
+  constexpr int D = (MT == 1 || NW == 8) ? 3 : 6;          // ring depth; NF % D == 0: the slot of a fragment does not depend on the chunk (8-wave blocks: 256 registers)
   static_assert(NF % D == 0, "ring");
   LyWF<PL> ring[D];
   auto wfrag_at = [&](int sb, int q) -> LyWF<PL> { return ly_wfragp<PL>(wpk, (long)tile[q % MT] * KS + sb + q / MT, lane); };

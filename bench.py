@@ -4,12 +4,14 @@
 
 Default line = BASELINE.json's metric: images/sec (640x640) fwd+bwd — one "step" is one full optimisation step of
 lead-yolo-s at bs=64/GPU (BASELINE.json configs[2]): uint8 batch already resident in HBM -> train-mode forward ->
-ComputeLoss -> HIP backward -> [bucketed gradient all-reduce over RCCL, overlapped, when N > 1] -> clip 10 ->
-SGD-nesterov (3 groups).  `--gpus N` with N > 1 and no WORLD_SIZE in the environment makes THIS process a launcher:
+ComputeLoss -> HIP backward -> [N > 1: each ~2 MB gradient bucket's RCCL all-reduce is released by an event node inside the replayed
+backward graph and runs on a communication stream while the rest of backward executes] -> clip 10 -> SGD-nesterov (3 groups) -> EMA.  `--gpus N` with N > 1 and no WORLD_SIZE in the environment makes THIS process a launcher:
 it starts N ranks through `torch.distributed.run` (before anything touches the GPU) and exits with their code; under
 an external torchrun it is a rank and WORLD_SIZE must equal --gpus.  Rank 0 prints ONE JSON line.
 
-`roofline` = the dominant kernel of the step timed live with HIP events on the launch stream (ops.PROFILE hooks);
+`roofline` = the largest kernel of the kernel FAMILY that owns most of the step (roofline.step.families: every launch of one steady-state
+step, by family, with algorithmic and PMC bytes), timed live with HIP events on the launch stream (ops.PROFILE hooks); `roofline.step` = the
+whole step against the HBM roof (SURVEY §8(d) block-fused bytes / step time);
 `roofline.pconv_rfcbam_fwd` = the north-star sub-metric: every launch of the six MLPBlocks and four RFCBAMConvs
 (eval forward, bs=64) against SURVEY §8(d)'s algorithmic bytes; `cpu_baseline` = the oracle (oracle/functional.py, the
 parity-pinned CPU restatement of the reference) taking the same optimisation step on the host cores over a bounded
@@ -274,8 +276,99 @@ def pconv_rfcbam_probe(model, x, dtype, iters=10):
                      "storage dtype + fp32 parameters once")
 
 
-def roofline_of(rows, dtype):
-    dom = rows[0]                                   # dominant kernel = largest share of the step
+# whole-model block-fused lower bound, lead-yolo-s @640: 85.4 MB per image in fp32 = 21.35 M activation elements in + out
+# once per fused block; a training step moves ~3x that (forward, saved activations read back + activation gradients, parameter gradients)
+BLOCK_FUSED_ELEMS_PER_IMG = {"s": 21_350_000}
+
+FAMILIES = (("rfcbam", ("ly_rf", "ly_se_", "ly_chan_moments", "ly_colsum")),
+            ("wgrad", ("ly_wgrad", "ly_patch4_rows")),
+            ("gemm", ("ly_gemm_kernel",)),
+            ("bnact", ("ly_bnact", "ly_bn_")),
+            ("mlpblock", ("ly_mlp",)),
+            ("conv3x3", ("ly_conv3x3",)),
+            ("coordatt", ("ly_coordatt", "ly_pool_hw", "ly_gate")),
+            ("loss_optim_pack", ("ly_loss", "ly_optim", "ly_pack", "ly_frag")),
+            ("sppf_detect_misc", ("ly_",)))
+
+
+def family_of(name):
+    """kernel name -> the family the step table groups it under (first matching prefix; ATen / memcpy launches are 'aten')"""
+    for fam, prefixes in FAMILIES:
+        if any(name.startswith(p) for p in prefixes):
+            return fam
+    return "aten"
+
+
+def step_families(step_fn, rows):
+    """Device time of EVERY launch of one steady-state eager step (torch profiler, device activity — the HIP-event table of probe_step only
+    sees the wrappers that carry byte counts), grouped into kernel families; per family: launches, ms, the algorithmic bytes of its
+    instrumented launches (rows) and, where profiles/ holds a PMC pass for the kernel, the HBM bytes the counters saw."""
+    from torch.profiler import ProfilerActivity, profile
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from demangle import demangle, short
+    step_fn()
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        step_fn()
+        torch.cuda.synchronize()
+    evs = [ev for ev in prof.events() if ev.device_type == torch.autograd.DeviceType.CUDA and not ev.name.startswith("Optimizer.")]
+    names = demangle([ev.name for ev in evs])
+    fam = {}
+    for ev, nm in zip(evs, names):
+        nm = short(nm) if "ly_" in nm else nm
+        f = fam.setdefault(family_of(nm), dict(launches=0, ms=0.0, algorithmic_bytes=0.0, pmc_bytes=0.0, pmc_launches=0))
+        f["launches"] += 1
+        f["ms"] += ev.device_time / 1e3
+        tr = committed_pmc(nm, "pmc_traffic")
+        if tr:
+            f["pmc_bytes"] += tr["hbm_bytes"]
+            f["pmc_launches"] += 1
+    for r in rows:
+        f = fam.get(family_of(r["kernel"]))
+        if f is not None:
+            f["algorithmic_bytes"] += r["bytes"] * r["calls_per_step"]
+    busy = sum(f["ms"] for f in fam.values())
+    out = {}
+    for k, f in sorted(fam.items(), key=lambda kv: -kv[1]["ms"]):
+        out[k] = dict(launches=f["launches"], ms=round(f["ms"], 4), share=round(f["ms"] / busy, 4),
+                      algorithmic_bytes=round(f["algorithmic_bytes"]) or None,
+                      pmc_bytes=round(f["pmc_bytes"]) if f["pmc_launches"] else None, pmc_launches=f["pmc_launches"])
+    return out, busy, len(evs)
+
+
+def step_roofline(args, ms_per_step, step_fn, rows):
+    """the whole optimisation step against the HBM roof: SURVEY §8(d)'s block-fused bytes (every block reads its input and writes its
+    output once; x3 for a training step) / measured step time / 8 TB/s, plus the per-family table that says where the step goes."""
+    elems = BLOCK_FUSED_ELEMS_PER_IMG.get(args.scale)
+    esize = 2 if args.dtype == "bf16" else 4
+    out = dict(ms_per_step=round(ms_per_step, 4))
+    if elems is not None and args.size == 640:
+        nbytes = elems * esize * args.batch * (3 if args.mode == "train" else 1)
+        gbs = nbytes / ms_per_step / 1e6
+        out.update(block_fused_bytes=nbytes, achieved_gbs=round(gbs, 1), frac=round(gbs / HBM_PEAK_GBS, 4),
+                   bytes_note="SURVEY 8(d): 21.35 M activation elements per image in + out once per fused block at the storage dtype"
+                              + (", x3 for a training step (forward, saved tensors + activation gradients, parameter gradients)" if args.mode == "train" else ""))
+    try:
+        fams, busy, n = step_families(step_fn, rows)
+        out.update(kernel_busy_ms=round(busy, 4), launches=n, families=fams,
+                   families_note="one steady-state eager step under the torch profiler (device activity): every launch, ATen included; algorithmic_bytes "
+                                 "= in + out + parameters once per instrumented launch (ops._Timed); pmc_bytes = 2*FETCH_SIZE + WRITE_SIZE per launch from "
+                                 "the committed rocprofv3 --pmc pass (profiles/), summed over the pmc_launches launches it names")
+    except Exception as e:                                  # noqa: BLE001
+        out["families"] = None
+        out["families_note"] = f"profiler pass unavailable: {type(e).__name__}: {e}"
+    return out
+
+
+def roofline_of(rows, dtype, families=None):
+    dom = rows[0]                                   # fallback: the instrumented kernel with the largest share of the step
+    dom_family = None
+    if families:                                    # dominant kernel = the largest kernel of the family that owns most of the step
+        for fam_name in families:
+            cand = [r for r in rows if family_of(r["kernel"]) == fam_name]
+            if cand and fam_name != "aten":
+                dom, dom_family = cand[0], fam_name
+                break
     gbs = dom["bytes"] / dom["ms_per_launch"] / 1e6
     tfs = dom["flops"] / dom["ms_per_launch"] / 1e9
     hbm_frac = gbs / HBM_PEAK_GBS
@@ -291,6 +384,7 @@ def roofline_of(rows, dtype):
     roof["traffic_source"] = tr["source"] if tr else None
     roof["mfma_busy"] = committed_pmc(dom["kernel"], "pmc_mfma")
     roof["kernel"] = dom["kernel"]
+    roof["kernel_family"] = dom_family
     roof["launches_per_step"] = round(dom["calls_per_step"], 2)
     roof["ms_per_launch"] = round(dom["ms_per_launch"], 5)
     roof["ms_per_step"] = round(dom["ms_per_step"], 4)
@@ -341,25 +435,29 @@ def run_train(args, ctx):
             ctx.dist.broadcast(t.data, src=0)
     opt = L.smart_optimizer(model, "SGD", 0.01, 0.937, 5e-4 * args.batch * ctx.world / 64)
     loss_fn = L.ComputeLoss(model)
+    ema = L.ModelEMA(model)                          # SURVEY config 3: "(+EMA)" — train.py:139,331: the EMA update is part of every optimisation step
     reducer = L.GradReducer(list(model.parameters())).attach() if ctx.world > 1 else None
     imgs = synth_u8(args.batch, args.size, ctx.rank).to(ctx.device)
     tg = synth_targets(args.batch, 1 + ctx.rank).to(ctx.device)
     state = {}
 
     def eager_step():
-        state["loss"], _ = L.train_step(model, loss_fn, opt, imgs, tg, reducer=reducer, world_size=ctx.world, amp=amp)
+        state["loss"], _ = L.train_step(model, loss_fn, opt, imgs, tg, ema=ema, reducer=reducer, world_size=ctx.world, amp=amp)
 
     step, launch = eager_step, "eager launches"
     if not args.no_graph:
         # N = 1: the whole optimisation step replayed from one hipGraph (train.GraphedTrainStep): identical kernels, no host work per
-        # step.  N > 1: the graph holds forward + backward, the bucketed RCCL all-reduce and the two-launch optimiser follow eagerly.
+        # step.  N > 1: graph A (forward + backward, bucket-completion event nodes) -> per-bucket RCCL all-reduce released from those events
+        # while A is still running -> graph B (fused optimiser); the all-reduce launches are the only eager work.
         try:
-            g = L.GraphedTrainStep(model, loss_fn, opt, imgs, tg, amp=amp, warmup=max(args.warmup, 2), reducer=reducer, world_size=ctx.world)
+            g = L.GraphedTrainStep(model, loss_fn, opt, imgs, tg, ema=ema, amp=amp, warmup=max(args.warmup, 2), reducer=reducer, world_size=ctx.world)
 
             def step():
                 state["loss"], _ = g()
             launch = "hipGraph replay of the whole optimisation step" if ctx.world == 1 else \
-                "hipGraph replay of forward + backward, then RCCL all-reduce of the gradient buckets and the fused optimiser step"
+                ("hipGraph A (forward + backward) with an event-record node where each gradient bucket completes; the bucket's RCCL all-reduce is "
+                 "released from that event on a communication stream while A is still executing the rest of backward (overlapped); hipGraph B = fused "
+                 f"optimiser dividing by the world size; {len(g._marked)} of {len(reducer.buckets)} buckets released mid-graph")
         except Exception as e:                                  # noqa: BLE001
             print(f"[bench] hipGraph capture of the train step unavailable ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr)
             step = eager_step
@@ -367,7 +465,7 @@ def run_train(args, ctx):
     regions = timed_repeats(ctx, step, args.steps, args.warmup, args.repeats)
     res = dict(regions=regions, final_loss=float(state["loss"]), peak_mem_gib=round(torch.cuda.max_memory_allocated() / 2**30, 2), model=model, step=eager_step, launch=launch,
                workload=f"lead-yolo-{args.scale} bs={args.batch}/gpu 3x{args.size}x{args.size} {args.dtype} full train step: uint8 batch -> "
-                        "train-mode forward (batch-statistics BN), ComputeLoss, HIP backward, clip 10, SGD-nesterov 3 groups "
+                        "train-mode forward (batch-statistics BN), ComputeLoss, HIP backward, clip 10, SGD-nesterov 3 groups, ModelEMA update "
                         "(BASELINE.json configs[2]" + ("" if args.dtype == "bf16" else " shape in fp32") + "); random-init weights",
                parallelism=(f"dp{ctx.world}: one process per GPU, ~2 MB reverse-order gradient buckets (gradients are views into them) "
                             "all-reduced over RCCL (torch.distributed 'nccl')") if ctx.world > 1
@@ -502,7 +600,13 @@ def main():
                     rows = probe_step(res["step"], iters=10)
             if args.layers:
                 print_layers(rows)
-            roof = roofline_of(rows, args.dtype)
+            if args.mode == "train":
+                step_roof = step_roofline(args, ms_per_step, res["step"], rows)
+            else:
+                with torch.no_grad():
+                    step_roof = step_roofline(args, ms_per_step, res["step"], rows)
+            roof = roofline_of(rows, args.dtype, step_roof.get("families"))
+            roof["step"] = step_roof
             if ctx.world == 1 and not args.no_secondary:
                 del res["step"]
                 if args.mode == "train":
@@ -511,10 +615,16 @@ def main():
                     roof["pconv_rfcbam_fwd"] = pconv_rfcbam_probe(model, xb, args.dtype)
                     del model, xb
                     torch.cuda.empty_cache()
-                    fw = run_forward(args, ctx, batch=32, steps=20, warmup=3, repeats=3)
-                    fdt = statistics.median(fw["regions"])
-                    out["forward"] = {"metric": fw["metric"], "value": round(32 * 20 / fdt, 2), "unit": "images/sec", "ms_per_step": round(fdt / 20 * 1e3, 4),
-                                      "workload": fw["workload"], "launch_mode": fw["launch"]}
+                    # secondary figure: the eval forward of configs[1] in ITS dtype (fp32), and the same shape in this line's dtype
+                    out["forward"] = {}
+                    for fdtype in dict.fromkeys(("f32", args.dtype)):
+                        fargs = argparse.Namespace(**{**vars(args), "dtype": fdtype})
+                        fw = run_forward(fargs, ctx, batch=32, steps=20, warmup=3, repeats=3)
+                        fdt = statistics.median(fw["regions"])
+                        out["forward"][fdtype] = {"metric": fw["metric"], "value": round(32 * 20 / fdt, 2), "unit": "images/sec", "ms_per_step": round(fdt / 20 * 1e3, 4),
+                                                  "workload": fw["workload"], "launch_mode": fw["launch"]}
+                        del fw
+                        torch.cuda.empty_cache()
                 else:
                     xb = synth_batch(64, args.size, 0, ctx.device).to(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
                     roof["pconv_rfcbam_fwd"] = pconv_rfcbam_probe(res["model"], xb, args.dtype)

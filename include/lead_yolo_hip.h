@@ -325,6 +325,9 @@ int ly_wgrad_group(const LyWgradParams* arr, int n, void* stream);
 int ly_up2_bwd(const void* d /*T*/, int ldd, int n_img, int Hs, int Ws, int C, void* out /*T*/, int ldo, int dtype, void* stream);
 /* Adjoint of the k = s patch gather: g[m][(ky,kx,c)] -> dx[n, ks*ho+ky, ks*wo+kx, c] (dense NHWC, C % 4 == 0).    */
 int ly_unpatch(const void* g /*T*/, int n_img, int Ho, int Wo, int C, int ks, void* dx /*T*/, int dtype, void* stream);
+/* dst[c] (+)= sum over r < R of src[r*ld + c], fp32, fixed summation order (no atomics): folds the partial-row buffers the backward kernels
+ * leave (autograd's reduction of per-block parameter-gradient partials, reference models/rfa.py:113-129 backward).                        */
+int ly_sum_rows(const float* src, long R, long C, long ld, float* dst, int accumulate, void* stream);
 /* Space-to-depth of the uint8 NCHW image [n, C, H, W] (H, W multiples of 4) for PatchEmbed's weight gradient (models/common.py:1537-1550,
  * the `imgs` of train.py:309 before `.float() / 255`): rows[m][c*16 + ky*4 + kx] = (T)img[n, c, 4*ho+ky, 4*wo+kx], m = (n*Ho + ho)*Wo + wo.
  * Integer values (exact in bf16); the caller scales the weight gradient by 1/255.                                                          */
@@ -459,12 +462,25 @@ typedef struct LyOptTensor {
   int taps, cin;       /* taps > 1: g is stored tap-major [cout][taps][cin] while p is [cout][cin][taps] (k x k conv weights) */
 } LyOptTensor;
 /* table [n_tensors] (device); blk_tensor / blk_off [n_blocks] (device): block b updates elements [blk_off[b], blk_off[b] + 4096) of
- * tensor blk_tensor[b].  ws: 1 double, zero before the first call (re-zeroed by every call).  hyper (device, 9 floats):
- * lr[3], momentum, max_norm (<= 0: none), ema decay (< 0: none), ema tau, updates so far, first-step flag (1 before the first call)
+ * tensor blk_tensor[b].  ws: 1 double, zero before the first call (re-zeroed by every call).  hyper (device, 10 floats):
+ * lr[3], momentum, max_norm (<= 0: none), ema decay (< 0: none), ema tau, updates so far, first-step flag (1 before the first call),
+ * gradient scale (every gradient is read as g * scale: 1/world_size when the buckets were all-reduced as SUMs — DDP's averaging,
+ * reference train.py:233-235, without a division pass per bucket)
  * — device-resident so that the call can sit inside a captured hipGraph while the host schedule rewrites it.  norm_out: NULL or
  * 1 float receiving the pre-clip global gradient norm (what clip_grad_norm_ returns).                                              */
 int ly_optim_step(const LyOptTensor* table, const int* blk_tensor, const long* blk_off, int n_blocks, double* ws, float* hyper,
                   float* norm_out, void* stream);
+
+/* ---- events across a hipGraph boundary (data-parallel step; replaces what DistributedDataParallel's reducer does with autograd hooks and
+ * side streams, reference utils/torch_utils.py:55-63, train.py:233-235) ----------------------------------------------------------
+ * ly_event_record on a stream that is being captured adds an event-record NODE behind the stream's capture dependencies;
+ * every replay records the event when those dependencies have run, so a stream outside the graph that calls ly_stream_wait_event after the
+ * replay was launched is released in the middle of the graph (gradient bucket complete -> its RCCL all-reduce starts while the rest of
+ * backward executes).  On a stream that is not capturing: hipEventRecord.  Events are created without timing.            */
+int ly_event_create(void** event);
+int ly_event_destroy(void* event);
+int ly_event_record(void* event, void* stream);
+int ly_stream_wait_event(void* stream, void* event);
 
 #ifdef __cplusplus
 }

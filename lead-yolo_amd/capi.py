@@ -141,6 +141,11 @@ SIGNATURES = {
     "ly_detect_head_bwd": [_P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P],
     "ly_pack_table": [_P, _P, _I, _P],
     "ly_optim_step": [_P, _P, _P, _I, _P, _P, _P, _P],
+    "ly_sum_rows": [_P, _L, _L, _L, _P, _I, _P],
+    "ly_event_create": [ctypes.POINTER(_P)],
+    "ly_event_destroy": [_P],
+    "ly_event_record": [_P, _P],
+    "ly_stream_wait_event": [_P, _P],
 }
 
 

@@ -833,6 +833,48 @@ __global__ __launch_bounds__(LY_THREADS) void ly_unpatch_kernel(const T* __restr
   }
 }
 
+// -------------------------------------------------------------------------------------------------
+// dst[c] (+)= sum_r src[r][c]: the partial-row buffers of the backward (per-block generate weight gradients, per-group conv weight
+// gradients, per-chunk d_rfa slabs, moment slices) folded deterministically — fixed order, no atomics.  Block = 64 columns x 16 row lanes;
+// a row lane walks rows lane, lane + 16, ... with four loads in flight.  (Was `tensor.sum(0)`: ATen's multi-block reduction keeps scratch
+// state of its own, and a captured instance returned wrong sums once the same reduction had also run eagerly in the process.)
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void ly_sum_rows_kernel(const float* __restrict__ src, const long R, const long C, const long ld,
+                                                          float* __restrict__ dst, const int accumulate) {
+  __shared__ float red[16][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const long c = (long)blockIdx.x * 64 + cl;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (c < C) {
+    const float* p = src + c;
+    long r = rl;
+    for (; r + 48 < R; r += 64) {
+      a0 += p[r * ld];
+      a1 += p[(r + 16) * ld];
+      a2 += p[(r + 32) * ld];
+      a3 += p[(r + 48) * ld];
+    }
+    for (; r < R; r += 16) a0 += p[r * ld];
+  }
+  red[rl][cl] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += red[i][cl];
+    dst[c] = accumulate ? dst[c] + s : s;
+  }
+}
+
+extern "C" int ly_sum_rows(const float* src, long R, long C, long ld, float* dst, int accumulate, void* stream) {
+  LY_CHECK(src && dst && R > 0 && C > 0 && ld >= C, "sum_rows: bad arguments");
+  LY_CHECK((C + 63) / 64 < (1L << 31), "sum_rows: too many columns");
+  hipLaunchKernelGGL(ly_sum_rows_kernel, dim3((unsigned)((C + 63) / 64)), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), src, R, C, ld, dst,
+                     accumulate);
+  LY_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int ly_unpatch(const void* g, int n_img, int Ho, int Wo, int C, int ks, void* dx, int dtype, void* stream) {
   LY_CHECK_DTYPE(dtype, "unpatch");
   LY_CHECK(g && dx && n_img > 0 && Ho > 0 && Wo > 0 && ks > 0 && (C & 3) == 0, "unpatch: bad arguments");

@@ -18,7 +18,8 @@
 #define LY_OPT_CHUNK 4096                 // elements per block
 
 // hyper: [0..2] lr of groups 0..2, [3] momentum, [4] max_norm (<= 0: no clipping), [5] ema decay (< 0: no EMA), [6] ema tau,
-//        [7] updates so far (incremented by the update kernel), [8] 1.0 until the first step has initialised the momentum buffers
+//        [7] updates so far (incremented by the update kernel), [8] 1.0 until the first step has initialised the momentum buffers,
+//        [9] gradient scale: gradients are read as g * scale (1/world_size after a SUM all-reduce of the buckets; 1 on one GPU)
 __global__ __launch_bounds__(LY_THREADS) void ly_optim_norm_kernel(const LyOptTensor* __restrict__ tab, const int* __restrict__ blk_tensor,
                                                                    const long* __restrict__ blk_off, double* __restrict__ ws) {
   __shared__ float red[4];
@@ -44,7 +45,8 @@ __global__ __launch_bounds__(LY_THREADS) void ly_optim_update_kernel(const LyOpt
   const long end = off + LY_OPT_CHUNK < t.n ? off + LY_OPT_CHUNK : t.n;
   const float mom = hyper[3], max_norm = hyper[4], ema_decay = hyper[5], tau = hyper[6], updates = hyper[7] + 1.f;
   const bool first = hyper[8] != 0.f;
-  const float total = (float)sqrt(ws[0]);
+  const float gscale = hyper[9];
+  const float total = (float)sqrt(ws[0]) * gscale;          // norm of the scaled gradients
   float coef = 1.f;
   if (max_norm > 0.f) { coef = max_norm / (total + 1e-6f); coef = coef > 1.f ? 1.f : coef; }
   if (blockIdx.x == 0 && threadIdx.x == 0 && norm_out) *norm_out = total;
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_optim_update_kernel(const LyOpt
         const int c = (int)(r / t.taps), tp = (int)(r - (long)c * t.taps);
         gi = (co * t.taps + tp) * t.cin + c;
       }
-      float g = t.g[gi] * coef;
+      float g = t.g[gi] * (coef * gscale);
       if (t.wd != 0.f) g += t.wd * p;
       const float b = first ? g : mom * t.buf[i] + g;
       t.buf[i] = b;

@@ -10,7 +10,10 @@ overlap.  xGMI is point-to-point (7 links x ~153 GB/s per GPU), a ring all-reduc
 the first launch are what matter.  So: buckets of ~2 MB in REVERSE registration order (the order
 autograd finishes gradients), gradients are views into flat bucket buffers (no copy-in/copy-out), each
 bucket's all-reduce is launched asynchronously by the post-accumulate hook of its last gradient, and
-`wait()` before the optimiser step only waits — averaging is folded into a pre-scaled all-reduce.
+`wait()` before the optimiser step only waits — averaging is folded into a pre-scaled all-reduce, or (defer_average, what
+train.train_step selects with optim.FusedSGD) into the optimiser's gradient scale: no division pass at all.  A backward that is
+replayed from a hipGraph runs no hooks: begin_marks / end_marks leave an event-record node in the graph where each bucket became
+complete and exchange(bucket) is released from there on every replay (train.GraphedTrainStep).
 
 The reducer is model-agnostic; tests/test_ddp_gloo.py drives it with world_size 2 on the gloo backend.
 """
@@ -46,6 +49,10 @@ class GradReducer:
         self._hooks = []
         self._sync = True
         self._direct = set()
+        self.defer_average = False        # True: buckets are exchanged as plain SUMs, the consumer divides (optim.FusedSGD.grad_scale = 1/world)
+        self.exchange_single = False      # True: a world of one still issues its all-reduces (tests of the launch path on one GPU)
+        self._mark_fn = None
+        self._mark_order = []
         self.reset()
 
     def _close(self, plist):
@@ -137,12 +144,41 @@ class GradReducer:
 
     def _launch(self, bi):
         self._launched[bi] = True
-        if self.world == 1:
+        if self._mark_fn is not None:
+            # the backward is being captured into a hipGraph: leave a mark (an event-record node) where the bucket became complete;
+            # every replay releases the bucket's exchange from there (exchange(), train.GraphedTrainStep)
+            self._mark_fn(bi)
+            self._mark_order.append(bi)
+            return
+        self.exchange(bi)
+
+    def exchange(self, bi):
+        """launch the all-reduce of bucket bi on the current stream's successor (torch.distributed's collective stream), asynchronously"""
+        if self.world == 1 and not (self.exchange_single and dist.is_initialized()):
             return
         flat = self.buckets[bi]["flat"]
-        if self.average:
+        if self.average and not self.defer_average:
             flat.div_(self.world)                                 # pre-scale: SUM of pre-divided = mean, no post pass
         self._works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    # ---- a backward that is captured once and replayed (no hooks run at replay) -------------------------------------
+    def begin_marks(self, mark_fn):
+        """Call inside the capture, before the backward: buckets completing during this backward call mark_fn(bucket index) instead of
+        being exchanged.  Requires reset() state (gradients zero, nothing launched)."""
+        self._mark_fn = mark_fn
+        self._mark_order = []
+        self._pending = [len(b["params"]) for b in self.buckets]
+        self._launched = [False] * len(self.buckets)
+        self._direct = set()
+
+    def end_marks(self):
+        """-> (bucket indices in the order they were marked, bucket indices no gradient event completed: exchange them after the graph)"""
+        order = list(self._mark_order)
+        rest = [bi for bi in range(len(self.buckets)) if bi not in set(order)]
+        self._mark_fn = None
+        self._mark_order = []
+        self.begin_external()
+        return order, rest
 
     def begin_external(self):
         """The gradients of this step were produced outside autograd's hooks (a replayed hipGraph of forward + backward wrote them
@@ -162,6 +198,10 @@ class GradReducer:
 
     def wait(self):
         self.reduce_now()
+        self.wait_works()
+
+    def wait_works(self):
+        """the current stream waits for every exchange launched so far"""
         for w in self._works:
             w.wait()
         self._works = []

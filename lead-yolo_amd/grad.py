@@ -949,6 +949,7 @@ class RfcbamFn(torch.autograd.Function):
             with ops._Timed(f"ly_rf_bwd_gen_kernel<{ops._tname(xr)}, {k}>", 2.0 * mo * kk * kk * c, 3.0 * es9):
                 L.check(L.lib().ly_rf_bwd_gen(p(xr), ld, n, h, w, c, k, s, p(ug), p(dcd), p(alpha), p(kappa), p(lam), p(dwg), part_rows, code, st),
                         "ly_rf_bwd_gen")
+            _tap("rf.coef", alpha); _tap("rf.dwg", dwg)
             # 11. dx
             # SE backward: parameter gradients, and d/d(mean x) which the dx kernel spreads over the pixels while it writes dx
             se_wa, se_wb = ctx.se_params
@@ -966,7 +967,7 @@ class RfcbamFn(torch.autograd.Function):
                 with ops._Timed(f"ly_rf_bwd_dx_kernel<{ops._tname(xr)}, {k}>", 2.0 * mo * kk * kk * c, es9 + xr.element_size() * n * h * w * c):
                     L.check(L.lib().ly_rf_bwd_dx(n, h, w, c, k, s, p(dcd), p(wg), p(dx), c, p(dgap), 1.0 / (h * w), code, st), "ly_rf_bwd_dx")
             dbias = None if ops.grad_target(ctx.conv_b_param) is not None else torch.zeros_like(bias)      # BN removes the batch mean: d/dbias = 0
-        return (None, dx, None if se_direct else dwa, None if se_direct else dwb, dwg.sum(0).view(gen_w.shape), ct(dgg_tc), ct(dbg_tc),
+        return (None, dx, None if se_direct else dwa, None if se_direct else dwb, ops.sum_rows(dwg).view(gen_w.shape), ct(dgg_tc), ct(dbg_tc),
                 (None if t18 is not None else dw18.view(getw.shape)), dwc, dbias, dgo, dbo)
 
 
@@ -1002,10 +1003,10 @@ def _rfcbam_backward_rc(ctx, du, dgo, dbo):
     # conv weight gradient (independent of the chain below)
     with ops._Timed("ly_rf3c_wgrad_kernel", 2.0 * mo * 9 * c * (o + 81), xb):
         L.check(L.lib().ly_rf3c_wgrad(ctypes.byref(P), st), "ly_rf3c_wgrad")
-    dwc = dwc_part.sum(0) if ng > 1 else dwc_part[0]
+    dwc = ops.sum_rows(dwc_part) if ng > 1 else dwc_part[0]
     dwc = dwc.permute(0, 2, 1).reshape(conv_w.shape)
     # get_weight + sigmoid
-    d_rfa = d_rfa_part.sum(0).view_as(rfa) if nch > 1 else d_rfa_part[0].view_as(rfa)
+    d_rfa = ops.sum_rows(d_rfa_part).view_as(rfa) if nch > 1 else d_rfa_part[0].view_as(rfa)
     w18 = getw.detach().float().reshape(18).contiguous()
     d_mm = torch.empty_like(mm)
     t18 = ops.grad_target(ctx.getw_param)
@@ -1038,7 +1039,7 @@ def _rfcbam_backward_rc(ctx, du, dgo, dbo):
     with ops._Timed(f"ly_rf3c_bwd_kernel<C, {o // 32}>", 2.0 * mo * 9 * c * (o + 243), xb + xr.element_size() * n * h * w * c):
         L.check(L.lib().ly_rf3c_bwd(ctypes.byref(P), 2, st), "ly_rf3c_bwd C")
     dbias = None if ops.grad_target(ctx.conv_b_param) is not None else torch.zeros_like(bias)      # BN removes the batch mean: d/dbias = 0
-    return (None, dx if need_dx else None, None if se_direct else dwa, None if se_direct else dwb, dwg.sum(0).view(gen_w.shape), ct(dgg_tc), ct(dbg_tc),
+    return (None, dx if need_dx else None, None if se_direct else dwa, None if se_direct else dwb, ops.sum_rows(dwg).view(gen_w.shape), ct(dgg_tc), ct(dbg_tc),
             (None if t18 is not None else dw18.view(getw.shape)), dwc, dbias, dgo, dbo)
 
 

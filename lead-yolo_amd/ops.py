@@ -460,7 +460,7 @@ def chan_moments(x, ldx, rows, c):
     mom = new_stats(c, x.device)
     with _Timed(f"ly_chan_moments_kernel<{_tname(x)}>", 3.0 * rows * c, x.element_size() * rows * c):
         capi.check(capi.lib().ly_chan_moments(_p(x), ldx, rows, c, _p(mom), capi.dtype_code(x), capi.stream_ptr()), "ly_chan_moments")
-    return mom.sum(0)
+    return sum_rows(mom)
 
 
 STRIPES = capi.STATS_STRIPES
@@ -778,6 +778,18 @@ def wgrad_kernel_name(t, n, ktot, rows, tiled, pro=False):
     else:
         bn, bk = 128, 128
     return f"ly_wgrad_tiled_kernel<{t}, {bn}, {bk}, {px}, {r}, {'true' if pro and rows else 'false'}>"
+
+
+def sum_rows(t, out=None, accumulate=False):
+    """sum over dim 0 of a contiguous fp32 tensor [R, ...] -> [...] (ly_sum_rows: fixed order, no atomics, no ATen reduction scratch)"""
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise ValueError("sum_rows: contiguous float32 tensor expected")
+    r = t.shape[0]
+    c = t.numel() // r
+    if out is None:
+        out = torch.empty(t.shape[1:], dtype=torch.float32, device=t.device)
+    capi.check(capi.lib().ly_sum_rows(_p(t), r, c, c, _p(out), int(accumulate), capi.stream_ptr()), "ly_sum_rows")
+    return out
 
 
 def up2_bwd(d, ldd, n, hs, ws, c):

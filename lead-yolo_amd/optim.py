@@ -53,6 +53,8 @@ class FusedSGD(torch.optim.Optimizer):
         self._table = None
         self._grad_ptrs = None
         self.grad_norm = None           # device scalar: pre-clip global gradient norm of the last step
+        self._zeroed = False
+        self.grad_scale = 1.0           # gradients are read as g * grad_scale: 1 / world_size when the buckets are all-reduced as SUMs
 
     # ---- EMA -----------------------------------------------------------------------------------------------------
     def attach_ema(self, ema, model):
@@ -143,16 +145,24 @@ class FusedSGD(torch.optim.Optimizer):
             for off in range(0, e[4], CHUNK):
                 blk_t.append(i)
                 blk_o.append(off)
-        fresh = any(self.state[p].pop("_fresh", False) for g in self.param_groups for p in g["params"] if p in self.state)
+        # a fresh momentum buffer is all zeros, and mom*0 + g is torch's first-step rule (buf = g): no first-step flag is needed, so a table
+        # rebuilt after load_state_dict (some buffers loaded, some new) never overwrites loaded buffers
+        for g in self.param_groups:
+            for p in g["params"]:
+                if p in self.state:
+                    self.state[p].pop("_fresh", None)
+        fresh = False
         ema_obj = self._ema[0] if self._ema else None
         hyper = [0.0, 0.0, 0.0, float(self.param_groups[0]["momentum"]), float(self.max_norm or 0.0),
                  float(ema_obj.decay_base) if ema_obj is not None else -1.0, float(ema_obj.tau) if ema_obj is not None else 1.0,
-                 float(ema_obj.updates) if ema_obj is not None else 0.0, 1.0 if fresh else 0.0]
+                 float(ema_obj.updates) if ema_obj is not None else 0.0, 1.0 if fresh else 0.0, float(self.grad_scale)]
         self._table = dict(tab=raw.to(dev), blk_t=torch.tensor(blk_t, dtype=torch.int32, device=dev), blk_o=torch.tensor(blk_o, dtype=torch.int64, device=dev),
                            n_blocks=len(blk_t), ws=torch.zeros(1, dtype=torch.float64, device=dev), hyper=torch.tensor(hyper, dtype=torch.float32, device=dev),
                            keep=keep, lrs=None)
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
-        self._grad_ptrs = [(p, p.grad.data_ptr()) for g in self.param_groups for p in g["params"] if p.requires_grad]
+        self._grad_ptrs = [(p, p.grad.data_ptr(), self.state[p]["momentum_buffer"].data_ptr(), float(g["weight_decay"]))
+                           for g in self.param_groups for p in g["params"] if p.requires_grad]
+        self._zeroed = False
         # the backward kernels may now add weight / BatchNorm gradients straight into this storage (ops.GradSink): no fresh
         # gradient tensors, no zero fills, no AccumulateGrad launches
         from . import ops
@@ -163,11 +173,12 @@ class FusedSGD(torch.optim.Optimizer):
     def _sync_hyper(self):
         """learning rates follow param_groups (schedulers / warm-up write them); one small H2D copy only when they change"""
         t = self._table
-        lrs = tuple(float(g["lr"]) for g in self.param_groups) + (float(self.param_groups[0]["momentum"]), float(self.max_norm or 0.0))
+        lrs = tuple(float(g["lr"]) for g in self.param_groups) + (float(self.param_groups[0]["momentum"]), float(self.max_norm or 0.0), float(self.grad_scale))
         if lrs != t["lrs"]:
             n = len(self.param_groups)
             t["hyper"][:n].copy_(torch.tensor(lrs[:n], dtype=torch.float32), non_blocking=True)
-            t["hyper"][3:5].copy_(torch.tensor(lrs[n:], dtype=torch.float32), non_blocking=True)     # momentum (warm-up ramps it, train.py:303-311), max_norm
+            t["hyper"][3:5].copy_(torch.tensor(lrs[n:n + 2], dtype=torch.float32), non_blocking=True)     # momentum (warm-up ramps it, train.py:303-311), max_norm
+            t["hyper"][9:10].copy_(torch.tensor(lrs[n + 2:], dtype=torch.float32), non_blocking=True)
             t["lrs"] = lrs
 
     # ---- the step --------------------------------------------------------------------------------------------------
@@ -181,8 +192,10 @@ class FusedSGD(torch.optim.Optimizer):
                 raise RuntimeError("FusedSGD: run one eager step before capturing (the tensor table is built on the first step)")
             self._build()
         if not capturing:
-            for p, ptr in self._grad_ptrs:               # gradients must still live where the table says
-                if p.grad is None or p.grad.data_ptr() != ptr:
+            wds = {id(p): float(g["weight_decay"]) for g in self.param_groups for p in g["params"]}
+            for p, ptr, bptr, wd in self._grad_ptrs:      # gradients, momentum buffers and decays must still be what the table says
+                buf = self.state[p].get("momentum_buffer")
+                if p.grad is None or p.grad.data_ptr() != ptr or buf is None or buf.data_ptr() != bptr or wds.get(id(p)) != wd:
                     self._build()
                     break
             self._sync_hyper()
@@ -193,10 +206,23 @@ class FusedSGD(torch.optim.Optimizer):
         pack.touch_weights()              # parameters changed through raw pointers: packed-weight images and caches must refresh
         if self._ema is not None and not capturing:
             self._ema[0].updates += 1
+        self._zeroed = True
+
+    def load_state_dict(self, state_dict):
+        """loaded momentum buffers are new tensors: the device table must be rebuilt around them"""
+        super().load_state_dict(state_dict)
+        self._table = None
 
     def zero_grad(self, set_to_none=False):
-        """gradients are zeroed by step(); they stay allocated (the table and a captured graph point at them)"""
+        """Gradients stay allocated (the table, the backward kernels and a captured graph point at them) and step() leaves them zeroed,
+        so the reference loop's `optimizer.step(); optimizer.zero_grad()` costs nothing; called WITHOUT a preceding step() (a skipped
+        step: gradients to be discarded) it zeroes the persistent storage in place."""
         if self._table is None:
             super().zero_grad(set_to_none=False)
+        elif not self._zeroed:
+            grads = [p.grad for g in self.param_groups for p in g["params"] if p.requires_grad and p.grad is not None]
+            if grads:
+                torch._foreach_zero_(grads)
+        self._zeroed = False
 
     fused = True

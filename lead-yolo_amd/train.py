@@ -5,8 +5,10 @@
 
 Mirrors `smart_optimizer` (utils/torch_utils.py:318-346: three parameter groups — biases without decay,
 BatchNorm weights without decay, all other weights with decay) and `ModelEMA` (utils/torch_utils.py:404-432).
-The optimiser itself is torch.optim.SGD, exactly as in the reference; a fused multi-tensor step is §8(f)#3.
+The optimiser is optim.FusedSGD on the GPU (clip + SGD-nesterov + zero_grad + EMA for every tensor in three launches, csrc/ly_optim.hip);
+`smart_optimizer(..., fused=False)` returns the reference's torch.optim.SGD object.
 """
+import ctypes
 import math
 from copy import deepcopy
 
@@ -104,12 +106,21 @@ def optimizer_step(model, optimizer, ema=None, max_norm=10.0, reducer=None):
             ema.update(model)
 
 
+def _set_deferred_average(optimizer, reducer):
+    """with the fused optimiser the mean over ranks costs nothing: buckets are all-reduced as SUMs and FusedSGD reads every gradient as
+    g / world (one device scalar) — instead of one division launch per bucket"""
+    if getattr(optimizer, "fused", False) and reducer.average:
+        reducer.defer_average = True
+        optimizer.grad_scale = 1.0 / reducer.world
+
+
 def train_step(model, compute_loss, optimizer, imgs, targets, ema=None, reducer=None, world_size=1, max_norm=10.0, amp=None):
     """One optimisation step; imgs uint8 or float [B,3,H,W] on the model's device, targets [n,6].
     amp: None (fp32 storage) or torch.bfloat16 — forward and loss run inside torch.autocast(dtype=amp), the reference's
     `with torch.cuda.amp.autocast(amp)` region (train.py:316) with bf16 in place of fp16 (no GradScaler needed: bf16 keeps
     fp32's exponent range).  Returns (loss, loss_items) as detached device tensors (no host sync)."""
     if reducer is not None:
+        _set_deferred_average(optimizer, reducer)
         reducer.reset()
     loss, items = forward_backward(model, compute_loss, imgs, targets, world_size=world_size, amp=amp)
     if reducer is not None:
@@ -120,27 +131,38 @@ def train_step(model, compute_loss, optimizer, imgs, targets, ema=None, reducer=
 
 class GraphedTrainStep:
     """The whole optimisation step — uint8 batch -> forward -> loss -> backward -> clip + SGD-nesterov + zero_grad (+ EMA) — captured
-    once into a hipGraph and replayed with no host work per step.  Possible because every C-ABI entry point only
+    once into hipGraphs and replayed with no per-launch host work.  Possible because every C-ABI entry point only
     launches on the current stream, the device loss has no host sync, and optim.FusedSGD keeps its step-dependent scalars (learning
-    rates, EMA ramp, step counter) in device memory.  Single-GPU: the gradient exchange of ddp.GradReducer stays eager.
+    rates, EMA ramp, step counter, gradient scale) in device memory.
 
         step = GraphedTrainStep(model, compute_loss, optimizer, imgs, targets, ema=ema, amp=torch.bfloat16)
-        loss, items = step(next_imgs, next_targets)        # same shapes; pad `targets` with rows whose image index is -1
+        loss, items = step(next_imgs, next_targets)        # same shapes / dtypes; pad `targets` with rows whose image index is -1
 
     Construction runs `warmup` REAL optimisation steps on the given batch (they size the allocator pools, the statistics pool and
     the optimiser's tensor table) and then captures one more; each call replays it.
 
-    Data parallel (reducer = ddp.GradReducer, world_size > 1): the graph holds forward + backward only; the gradient exchange and
-    the two-launch optimiser step follow it eagerly.  For this model family the exchange is 3-87 MB — 0.1-1 ms on xGMI against a
-    20+ ms step — so what limits scaling is the ~1,400 launches per step each rank's host would otherwise issue, not the missing
-    overlap of the all-reduce with backward (the overlapped, hook-driven exchange remains what eager `train_step` uses)."""
+    One GPU, accumulate = 1: ONE graph holds the whole step.
 
-    def __init__(self, model, compute_loss, optimizer, imgs, targets, ema=None, amp=None, max_norm=10.0, warmup=3, reducer=None, world_size=1):
+    Data parallel (reducer = ddp.GradReducer over RCCL; reference: DistributedDataParallel's reducer, utils/torch_utils.py:55-63,
+    train.py:233-235) — the gradient exchange OVERLAPS the replayed backward: graph A = forward + backward, in which every gradient
+    bucket's completion point is an event-record node (csrc ly_event_record); right after launching A the host queues, per bucket in
+    completion order, `wait for its event` + `all_reduce(bucket)` on a communication stream, so RCCL starts on a bucket while the graph
+    is still executing the rest of the backward; graph B = the fused optimiser (which also divides by the world size:
+    FusedSGD.grad_scale — no division pass per bucket) runs when the last exchange is done.  The ~10 all-reduce launches are the only
+    eager work of a step.
+
+    accumulate = k (the reference's gradient accumulation, train.py:157,300,330): call k times with k micro-batches; graph A runs every
+    time (gradients add up in place), the exchange and graph B only on every k-th call, which returns `stepped = True` in `.stepped`."""
+
+    def __init__(self, model, compute_loss, optimizer, imgs, targets, ema=None, amp=None, max_norm=10.0, warmup=3, reducer=None, world_size=1,
+                 accumulate=1):
         if not getattr(optimizer, "fused", False):
             raise NotImplementedError("GraphedTrainStep needs optim.FusedSGD (smart_optimizer(..., fused=True)): torch.optim.SGD + "
                                       "clip_grad_norm_ keep per-step host state")
+        from . import capi, pack
         self.imgs, self.targets = imgs.clone(), targets.clone()
         self.model, self.optimizer, self.ema, self.reducer, self.max_norm = model, optimizer, ema, reducer, max_norm
+        self.accumulate, self._micro, self.stepped = max(int(accumulate), 1), 0, False
         args = dict(ema=ema, amp=amp, max_norm=max_norm, reducer=reducer, world_size=world_size)
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream(device=imgs.device)
@@ -151,41 +173,97 @@ class GraphedTrainStep:
         cur.wait_stream(side)
         torch.cuda.synchronize(imgs.device)
         self.graph = torch.cuda.CUDAGraph()
-        from . import pack
+        self.opt_graph = None
+        self._events, self._marked, self._unmarked, self._comm = [], [], [], None
         pack.touch_weights()                   # the captured step must begin with the (single) refresh of every packed weight image
-        if reducer is None:
+        if reducer is None and self.accumulate == 1:
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self.loss, self.items = train_step(model, compute_loss, optimizer, self.imgs, self.targets, ema=ema, amp=amp, max_norm=max_norm)
         else:
-            reducer.reset()
-            hold = reducer.no_sync()
-            hold.__enter__()                       # inside the graph gradients only accumulate into the bucket views
-            try:
-                with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-                    self.loss, self.items = forward_backward(model, compute_loss, self.imgs, self.targets, world_size=world_size, amp=amp)
-            finally:
-                hold.__exit__(None, None, None)
+            lib = capi.lib()
+            mark = None
+            if reducer is not None:
+                _set_deferred_average(optimizer, reducer)
+                reducer.reset()
+                for _ in reducer.buckets:
+                    ev = capi._P()
+                    capi.check(lib.ly_event_create(ctypes.byref(ev)), "ly_event_create")
+                    self._events.append(ev)
+                self._comm = torch.cuda.Stream(device=imgs.device)
 
-    def __call__(self, imgs=None, targets=None):
+                def mark(bi):
+                    # runs inside the captured backward (autograd's thread, capture stream current): an event-record node behind everything
+                    # captured so far, i.e. behind the kernel that wrote the bucket's last gradient
+                    capi.check(lib.ly_event_record(self._events[bi], capi.stream_ptr()), "ly_event_record")
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                if reducer is not None:
+                    reducer.begin_marks(mark)
+                self.loss, self.items = forward_backward(model, compute_loss, self.imgs, self.targets, world_size=world_size, amp=amp)
+                if reducer is not None:
+                    self._marked, self._unmarked = reducer.end_marks()
+            self.opt_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.opt_graph, pool=self.graph.pool(), capture_error_mode="thread_local"):
+                optimizer_step(model, optimizer, ema=ema, max_norm=max_norm, reducer=reducer)
+        # Everything the graphs address through raw pointers must outlive them: the step's zero pool (ops._POOL.buf is replaced
+        # when a later, larger step grows it), the loss constants (replaced when the level shapes change), the optimiser's tensor table
+        # (rebuilt when a gradient pointer changes).  A later eager step or a second GraphedTrainStep at another shape would otherwise
+        # free memory these graphs still zero-fill and add into.
+        self._pins = (ops._POOL.buf, dict(getattr(compute_loss, "_const", {})), optimizer._table)
+        # packed weight images were only RECORDED as refreshed during the capture: an eager forward before the first replay must rebuild them
+        pack.touch_weights()
+
+    def __del__(self):
+        try:
+            from . import capi
+            for ev in self._events:
+                capi.lib().ly_event_destroy(ev)
+        except Exception:                                   # noqa: BLE001  (interpreter shutdown)
+            pass
+
+    def _load(self, imgs, targets):
         if imgs is not None and imgs.data_ptr() != self.imgs.data_ptr():
+            if imgs.dtype != self.imgs.dtype or tuple(imgs.shape) != tuple(self.imgs.shape):
+                raise ValueError(f"GraphedTrainStep: the batch must keep the captured dtype and shape {self.imgs.dtype} {tuple(self.imgs.shape)} "
+                                 f"(got {imgs.dtype} {tuple(imgs.shape)}); a float [0, 1] batch copied into the captured uint8 buffer would "
+                                 "truncate to zeros")
             self.imgs.copy_(imgs, non_blocking=True)
         if targets is not None and targets.data_ptr() != self.targets.data_ptr():
-            if tuple(targets.shape) != tuple(self.targets.shape):
+            if tuple(targets.shape) != tuple(self.targets.shape) or targets.dtype != self.targets.dtype:
                 raise ValueError(f"GraphedTrainStep: targets must keep the captured shape {tuple(self.targets.shape)} (pad with rows whose "
-                                 f"image index is -1), got {tuple(targets.shape)}")
+                                 f"image index is -1), got {tuple(targets.shape)} {targets.dtype}")
             self.targets.copy_(targets, non_blocking=True)
-        from . import pack
-        if self.reducer is None:
-            self.optimizer._sync_hyper()                   # learning-rate schedule -> device (only when it changed)
+
+    def __call__(self, imgs=None, targets=None):
+        from . import capi, pack
+        self._load(imgs, targets)
+        self.optimizer._sync_hyper()                       # learning-rate schedule -> device (only when it changed)
+        if self.opt_graph is None:
             self.graph.replay()
             pack.touch_weights()                           # parameters / running statistics changed behind torch's version counters
             if self.ema is not None:
                 self.ema.updates += 1
+            self.stepped = True
             return self.loss, self.items
-        # data parallel: graph = forward + backward (gradients accumulate in the zeroed bucket views) -> all-reduce -> fused optimiser
-        self.graph.replay()
-        self.reducer.begin_external()
-        self.reducer.wait()
-        optimizer_step(self.model, self.optimizer, ema=self.ema, max_norm=self.max_norm, reducer=self.reducer)
+        self.graph.replay()                                # forward + backward: gradients add into the persistent storage / bucket views
+        self._micro += 1
+        self.stepped = self._micro >= self.accumulate
+        if not self.stepped:
+            return self.loss, self.items
+        self._micro = 0
+        if self.reducer is not None:
+            lib, red, cur, comm = capi.lib(), self.reducer, torch.cuda.current_stream(), self._comm
+            with torch.cuda.stream(comm):
+                for bi in self._marked:                    # released from the middle of the running graph, bucket by bucket
+                    capi.check(lib.ly_stream_wait_event(capi._P(comm.cuda_stream), self._events[bi]), "ly_stream_wait_event")
+                    red.exchange(bi)
+                if self._unmarked:                         # buckets no gradient event completed (unused parameters): after the graph
+                    comm.wait_stream(cur)
+                    for bi in self._unmarked:
+                        red.exchange(bi)
+            red.wait_works()                               # the step's stream waits for RCCL's
+            cur.wait_stream(comm)
+        self.opt_graph.replay()
         pack.touch_weights()
+        if self.ema is not None:
+            self.ema.updates += 1
         return self.loss, self.items

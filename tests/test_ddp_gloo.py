@@ -63,6 +63,36 @@ def _worker(rank, world, port, q):
         ((net(x) - y) ** 2).mean().backward()
         red.wait()
         ref_grads = [p.grad.clone() for p in net.parameters()]
+        # the protocol of a captured-and-replayed backward (train.GraphedTrainStep): the "capture" backward only leaves marks where buckets
+        # complete; a "replay" writes gradients with no hooks at all; then exchange(bucket) in mark order, SUM on the wire, the consumer
+        # divides (defer_average: optim.FusedSGD.grad_scale = 1 / world)
+        red.reset()
+        marks = []
+        red.begin_marks(marks.append)
+        ((net(x) - y) ** 2).mean().backward()                      # "capture": hooks fire, nothing is exchanged
+        order, rest = red.end_marks()
+        assert order == marks and sorted(order + rest) == list(range(len(red.buckets))) and not rest
+        assert order[0] == 0                                       # reverse registration order: the last layer's bucket completes first
+        local = torch.autograd.grad(((net(x) - y) ** 2).mean(), list(net.parameters()))
+        want = []
+        for g in local:
+            buf = [torch.zeros_like(g) for _ in range(world)]
+            dist.all_gather(buf, g.contiguous())
+            want.append(sum(buf) / world)
+        red.defer_average = True
+        for rep in range(2):                                       # two "replays"
+            for p, g in zip(net.parameters(), local):
+                p.grad.copy_(g)                                    # what the replayed kernels do: write into the bucket views
+            for bi in order:
+                red.exchange(bi)
+            red.wait_works()
+            for p, w in zip(net.parameters(), want):
+                assert torch.allclose(p.grad / world, w, rtol=1e-5, atol=1e-6), (rank, "marks", rep, (p.grad / world - w).abs().max())
+        red.defer_average = False
+        red.reset()
+        ((net(x) - y) ** 2).mean().backward()
+        red.wait()
+        ref_grads = [p.grad.clone() for p in net.parameters()]
         # replicas agree bit for bit after the exchange
         for g in ref_grads:
             buf = [torch.zeros_like(g) for _ in range(world)]

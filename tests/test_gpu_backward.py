@@ -407,82 +407,188 @@ def test_fused_optimizer_matches_torch_sgd():
 
 @pytest.mark.parametrize("amp", [None, torch.bfloat16])
 def test_graphed_train_step_matches_eager(amp):
-    """the whole optimisation step captured into a hipGraph (forward, device loss, HIP backward, fused clip/SGD/EMA) against eager
-    steps from the same initial state on the same batches: losses of every step and the final weights"""
+    """the whole optimisation step captured into a hipGraph (forward, device loss, HIP backward, fused clip/SGD/EMA) against the eager
+    step.  TIGHT: ONE step from an IDENTICAL restored state (weights, BatchNorm statistics, momentum buffers, EMA, step counter),
+    replayed vs eager, with a second eager step from the same state as the noise floor (float atomics; in bf16 a rounding boundary
+    crossed) — states must agree to 1e-3 (fp32) / 2^-7 (bf16) of each tensor's scale and every tensor's UPDATE (after - before) in
+    relative L2: a skipped EMA update, a missing / doubled optimiser step or a gradient in the wrong place is a 100 % error of that
+    update.  Then a short trajectory on changing batches, loosely (training noise compounds: two EAGER runs of these 4 steps differ by
+    up to 17 % of a momentum buffer's scale)."""
     import lead_yolo_amd as L
-    runs = []
-    for graphed in (False, True):
-        torch.manual_seed(0)
-        m = L.Model(_cfg("n"))
-        st = synth.synth_state(synth.shapes_of(m.state_dict()), 5151)
-        st["model.23.anchors"] = m.model[-1].anchors.clone()
-        m.load_state_dict(st)
-        m = m.to(_dev()).train()
-        opt = L.smart_optimizer(m, "SGD", 0.01, 0.937, 5e-4)
-        ema = L.ModelEMA(m)
-        cl = L.ComputeLoss(m)
-        batches = [(synth.synth_images(4, 128, 21 + i).to(_dev()), synth.synth_targets(4, 22 + i, per_image=3).to(_dev())) for i in range(3)]
-        nt = max(t.shape[0] for _, t in batches) + 2
-        batches = [(im, torch.cat((t, torch.full((nt - t.shape[0], 6), -1.0, device=_dev())))) for im, t in batches]      # fixed shape: -1 rows are padding
-        losses = []
-        if graphed:
-            step = L.GraphedTrainStep(m, cl, opt, *batches[0], ema=ema, amp=amp, warmup=2)       # 2 eager steps + nothing else on batch 0
-            order = [1, 2, 0, 1]
-            for i in order:
-                loss, _ = step(*batches[i])
-                losses.append(float(loss))
+    from lead_yolo_amd import pack
+    torch.manual_seed(0)
+    m = L.Model(_cfg("n"))
+    st = synth.synth_state(synth.shapes_of(m.state_dict()), 5151)
+    st["model.23.anchors"] = m.model[-1].anchors.clone()
+    m.load_state_dict(st)
+    m = m.to(_dev()).train()
+    opt = L.smart_optimizer(m, "SGD", 0.01, 0.937, 5e-4)
+    ema = L.ModelEMA(m)
+    cl = L.ComputeLoss(m)
+    batches = [(synth.synth_images(4, 128, 21 + i).to(_dev()), synth.synth_targets(4, 22 + i, per_image=3).to(_dev())) for i in range(3)]
+    nt = max(t.shape[0] for _, t in batches) + 2
+    batches = [(im, torch.cat((t, torch.full((nt - t.shape[0], 6), -1.0, device=_dev())))) for im, t in batches]      # fixed shape: -1 rows are padding
+    step = L.GraphedTrainStep(m, cl, opt, *batches[0], ema=ema, amp=amp, warmup=2)       # 2 eager steps on batch 0, then the capture
+
+    def tensors():
+        return (("weight", {k: v for k, v in m.state_dict().items() if v.is_floating_point()}),
+                ("ema", {k: v for k, v in ema.ema.state_dict().items() if v.is_floating_point()}),
+                ("momentum", {n: opt.state[p]["momentum_buffer"] for n, p in m.named_parameters() if p in opt.state}))
+
+    def snap():
+        torch.cuda.synchronize()
+        return [{k: v.detach().clone() for k, v in d.items()} for _, d in tensors()], opt._table["hyper"].clone(), ema.updates
+
+    def restore(state):
+        with torch.no_grad():
+            for (_, live), saved in zip(tensors(), state[0]):
+                for k, v in live.items():
+                    v.copy_(saved[k])
+            opt._table["hyper"].copy_(state[1])
+        ema.updates = state[2]
+        pack.touch_weights()
+
+    s0 = snap()
+    outs = []
+    for how in ("eager", "eager", "graph"):
+        restore(s0)
+        if how == "graph":
+            loss, _ = step(*batches[1])
         else:
-            for _ in range(2):
-                L.train_step(m, cl, opt, *batches[0], ema=ema, amp=amp)
-            # the capture itself is recorded, not executed: no step happens there
-            for i in [1, 2, 0, 1]:
-                loss, _ = L.train_step(m, cl, opt, *batches[i], ema=ema, amp=amp)
-                losses.append(float(loss))
-        runs.append((losses, {k: v.detach().clone() for k, v in m.state_dict().items() if v.is_floating_point()}, ema.updates,
-                     {k: v.detach().clone() for k, v in ema.ema.state_dict().items() if v.is_floating_point()}))
-    (l0, w0, u0, e0), (l1, w1, u1, e1) = runs
-    assert u0 == u1 == 6
-    tol = 1e-2 if amp is None else 5e-2            # float atomics (statistics, wgrad) make two runs differ by rounding noise; every bf16 rounding
-                                                   # boundary that noise crosses amplifies it, and four fast-learning steps compound it
+            loss, _ = L.train_step(m, cl, opt, *batches[1], ema=ema, amp=amp)
+        after = snap()
+        assert after[2] == s0[2] + 1
+        outs.append((float(loss), after[0]))
+    (le, e), (le2, e2), (lg, g) = outs
+    tight = 1e-3 if amp is None else 2.0 ** -7
+    assert abs(le - lg) <= max(tight, 3 * abs(le - le2) / abs(le)) * abs(le), (le, le2, lg)
+    for wi, what in enumerate(("weight", "ema", "momentum")):
+        a, c, b, before = e[wi], e2[wi], g[wi], s0[0][wi]
+        assert a.keys() == b.keys() and len(a) > 100
+        rels = []
+        for k in a:
+            scale = float(a[k].abs().max())
+            noise = float((a[k] - c[k]).abs().max())
+            tol = tight if what != "momentum" else 10 * tight        # a momentum buffer is a sum of raw gradients (not scaled by the learning rate)
+            assert float((a[k] - b[k]).abs().max()) <= max(tol * scale, 3 * noise) + 1e-6, (what, k, float((a[k] - b[k]).abs().max()), scale, noise)
+            da, db, dc = a[k] - before[k], b[k] - before[k], c[k] - before[k]
+            na = float(da.norm())
+            if na > 1e-7:
+                rels.append((float((da - db).norm()) / na, float((da - dc).norm()) / na, k))
+        assert len(rels) > 100
+        floor = 0.02 if amp is None else 0.15
+        assert all(r[0] <= max(floor, 3 * r[1]) for r in rels), (what, "update", max(rels))
+        assert sum(r[0] <= floor for r in rels) >= 0.9 * len(rels), (what, "update", sorted(rels)[-10:])
+    # ---- a short trajectory on changing batches: graph replays vs eager steps from the same state, loosely ----
+    traj = []
+    for how in ("eager", "graph"):
+        restore(s0)
+        losses = []
+        for i in [1, 2, 0, 1]:
+            loss, _ = step(*batches[i]) if how == "graph" else L.train_step(m, cl, opt, *batches[i], ema=ema, amp=amp)
+            losses.append(float(loss))
+        traj.append((losses, snap()))
+    (l0, t0), (l1, t1) = traj
+    assert t0[2] == t1[2] == s0[2] + 4
+    tol = 1e-2 if amp is None else 5e-2
     for i, (a, b) in enumerate(zip(l0, l1)):
-        assert abs(a - b) <= tol * (1 + i) * abs(a), (l0, l1)           # the noise compounds: step i may be off by (1 + i) * tol
-    for k in w0:
-        assert float((w0[k] - w1[k]).abs().max()) <= 10 * tol * float(w0[k].abs().max()) + 1e-4, k
-    for k in e0:
-        assert float((e0[k] - e1[k]).abs().max()) <= 10 * tol * float(e0[k].abs().max()) + 1e-4, ("ema", k)
+        assert abs(a - b) <= tol * (1 + i) * abs(a), (l0, l1)
+    for a, b in zip(t0[0][:2], t1[0][:2]):
+        for k in a:
+            assert float((a[k] - b[k]).abs().max()) <= 10 * tol * float(a[k].abs().max()) + 1e-4, k
 
 
-def test_graphed_step_with_reducer_matches_eager():
-    """the data-parallel form of the captured step (graph = forward + backward into the reducer's bucket views, then the bucket
-    exchange and the fused optimiser eagerly) against eager train_step with the same reducer, world size 1"""
+def _one_rank_group():
+    """an RCCL process group of ONE rank on this GPU: every all-reduce is really issued (launch path, streams, events), the wire is trivial"""
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        port = 29900 + os.getpid() % 2000
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=_dev())
+    return dist
+
+
+@pytest.mark.parametrize("rccl,accumulate", [(False, 1), (True, 1), (True, 2)])
+def test_graphed_step_with_reducer_matches_eager(rccl, accumulate):
+    """the data-parallel form of the captured step — graph A = forward + backward into the reducer's bucket views with an event-record
+    node where each bucket completes, per-bucket all-reduce released from those events on a communication stream while A is still
+    running, graph B = fused optimiser (dividing by the world size) — against eager train_step with the same reducer.  World size 1:
+    without a process group (the exchange is skipped) and with a one-rank RCCL group (every bucket's all-reduce really launched);
+    accumulate = 2: two micro-batches per optimiser step (reference train.py:157,300,330) vs eager no_sync accumulation."""
     import lead_yolo_amd as L
-    runs = []
-    for graphed in (False, True):
-        torch.manual_seed(0)
-        m = L.Model(_cfg("n"))
-        st = synth.synth_state(synth.shapes_of(m.state_dict()), 5151)
-        st["model.23.anchors"] = m.model[-1].anchors.clone()
-        m.load_state_dict(st)
-        m = m.to(_dev()).train()
-        red = L.GradReducer(list(m.parameters())).attach()
-        opt = L.smart_optimizer(m, "SGD", 0.01, 0.937, 5e-4)
-        cl = L.ComputeLoss(m)
-        imgs, tg = synth.synth_images(4, 128, 21).to(_dev()), synth.synth_targets(4, 22, per_image=3).to(_dev())
-        losses = []
-        if graphed:
-            step = L.GraphedTrainStep(m, cl, opt, imgs, tg, warmup=2, reducer=red, world_size=1)
-            for _ in range(3):
-                losses.append(float(step()[0]))
-        else:
-            for i in range(5):
-                loss, _ = L.train_step(m, cl, opt, imgs, tg, reducer=red)
-                if i >= 2:
+    dist = _one_rank_group() if rccl else None
+    try:
+        runs = []
+        for graphed in (False, True):
+            torch.manual_seed(0)
+            m = L.Model(_cfg("n"))
+            st = synth.synth_state(synth.shapes_of(m.state_dict()), 5151)
+            st["model.23.anchors"] = m.model[-1].anchors.clone()
+            m.load_state_dict(st)
+            m = m.to(_dev()).train()
+            red = L.GradReducer(list(m.parameters())).attach()
+            red.exchange_single = rccl
+            opt = L.smart_optimizer(m, "SGD", 0.01, 0.937, 5e-4)
+            ema = L.ModelEMA(m)
+            cl = L.ComputeLoss(m)
+            data = [(synth.synth_images(4, 128, 21 + i).to(_dev()), synth.synth_targets(4, 22, per_image=3).to(_dev())) for i in range(2)]
+            losses = []
+            if graphed:
+                step = L.GraphedTrainStep(m, cl, opt, *data[0], ema=ema, warmup=2, reducer=red, world_size=1, accumulate=accumulate)
+                assert len(step._marked) + len(step._unmarked) == len(red.buckets) and len(step._marked) >= 1, (step._marked, step._unmarked)
+                for _ in range(3):
+                    for j in range(accumulate):
+                        loss, _ = step(*data[j % 2])
+                        assert step.stepped == (j == accumulate - 1)
                     losses.append(float(loss))
-        red.detach()
-        runs.append(losses)
-    for a, b in zip(*runs):
-        assert abs(a - b) <= 1e-2 * abs(a), runs
-    assert runs[1][-1] < runs[1][0]
+            else:
+                for i in range(5):
+                    if accumulate == 1 or i < 2:              # (the graphed object's warm-up steps are plain steps on data[0])
+                        loss, _ = L.train_step(m, cl, opt, *data[0], ema=ema, reducer=red)
+                    else:
+                        red.reset()
+                        with red.no_sync():
+                            for j in range(accumulate - 1):
+                                L.forward_backward(m, cl, *data[j % 2])
+                        loss, _ = L.forward_backward(m, cl, *data[(accumulate - 1) % 2])
+                        red.wait()
+                        L.optimizer_step(m, opt, ema=ema, reducer=red)
+                    if i >= 2:
+                        losses.append(float(loss))
+            red.detach()
+            runs.append((losses, {k: v.detach().clone() for k, v in m.state_dict().items() if v.is_floating_point()}, ema.updates))
+        (l0, w0, u0), (l1, w1, u1) = runs
+        assert u0 == u1 == 5
+        for a, b in zip(l0, l1):
+            assert abs(a - b) <= 1e-2 * abs(a), runs
+        for k in w0:
+            assert float((w0[k] - w1[k]).abs().max()) <= 1e-1 * float(w0[k].abs().max()) + 1e-4, k
+    finally:
+        if dist is not None and dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_graphed_step_rejects_wrong_batch_and_survives_a_larger_step():
+    """(a) a float batch must not be copied into the captured uint8 buffer (it would truncate to zeros); (b) the graph keeps
+    the buffers it addresses alive: an eager step at a LARGER shape afterwards re-allocates the zero pool / loss constants, and replaying
+    the old graph must still give the loss it gave before"""
+    import lead_yolo_amd as L
+    torch.manual_seed(0)
+    m = L.Model(_cfg("n")).to(_dev()).train()
+    opt = L.smart_optimizer(m, "SGD", 0.0, 0.937, 0.0)             # lr 0: every replay sees the same weights
+    cl = L.ComputeLoss(m)
+    imgs, tg = synth.synth_images(2, 64, 3).to(_dev()), synth.synth_targets(2, 4, per_image=3).to(_dev())
+    assert imgs.dtype == torch.uint8
+    step = L.GraphedTrainStep(m, cl, opt, imgs, tg, warmup=2)
+    with pytest.raises(ValueError, match="dtype and shape"):
+        step(imgs.float() / 255, tg)
+    with pytest.raises(ValueError, match="dtype and shape"):
+        step(imgs[:1], tg)
+    before = float(step(imgs, tg)[0])
+    big = synth.synth_images(4, 128, 5).to(_dev())
+    L.train_step(m, cl, opt, big, synth.synth_targets(4, 6, per_image=3).to(_dev()))     # grows the pool, new loss constants
+    torch.cuda.synchronize()
+    after = float(step(imgs, tg)[0])
+    assert abs(after - before) <= 2e-3 * abs(before), (before, after)      # lr = 0 but BN batch statistics differ by atomic noise only
 
 
 def _ddp_rank(rank, world, port, q):
@@ -499,13 +605,36 @@ def _ddp_rank(rank, world, port, q):
         m = L.Model(L.load_cfg(scale="n")).to(dev).train()
         for t in list(m.parameters()) + list(m.buffers()):
             dist.broadcast(t.data, src=0)
-        red = L.GradReducer(list(m.parameters())).attach()
         opt = L.smart_optimizer(m, "SGD", 0.01, 0.937, 5e-4)
         cl = L.ComputeLoss(m)
         imgs = synth.synth_images(4, 128, 40 + rank).to(dev)              # a different shard per rank
         tg = synth.synth_targets(4, 50 + rank, per_image=3).to(dev)
-        for _ in range(3):
+        red = L.GradReducer(list(m.parameters())).attach()
+        L.train_step(m, cl, opt, imgs, tg, reducer=red, world_size=world)  # (installs the in-place gradient sink over the bucket views)
+        # (1) what the exchange must produce: the MEAN over ranks of the single-GPU gradients of loss * world (train.py:321-322)
+        params = [p for p in m.parameters() if p.requires_grad]
+        red.reset()
+        with red.no_sync():                                                # accumulate only: this rank's own gradient
+            L.forward_backward(m, cl, imgs, tg, world_size=world)
+        local = torch.cat([p.grad.detach().reshape(-1) for p in params]).clone()
+        want = local.clone()
+        dist.all_reduce(want)
+        want /= world
+        red.reset()
+        L.forward_backward(m, cl, imgs, tg, world_size=world)              # hooks / sink callbacks launch the bucket exchanges
+        red.wait()
+        got = torch.cat([p.grad.detach().reshape(-1) for p in params]) * opt.grad_scale
+        err = float((got - want).norm() / want.norm())
+        assert err < 1e-3, f"exchanged gradient is not the mean of the ranks' gradients: rel err {err}"
+        assert float((local - want).norm() / want.norm()) > 1e-2          # the shards really differ
+        red.reset()
+        for _ in range(2):
             L.train_step(m, cl, opt, imgs, tg, reducer=red, world_size=world)
+        # (2) the captured form: graph A with bucket events, RCCL released from them, graph B
+        step = L.GraphedTrainStep(m, cl, opt, imgs, tg, warmup=1, reducer=red, world_size=world)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
         # replicas must hold identical weights after averaged-gradient steps (BatchNorm running statistics are per-rank by design)
         flat = torch.cat([p.detach().reshape(-1) for p in m.parameters()])
         other = [torch.empty_like(flat) for _ in range(world)]
@@ -521,7 +650,8 @@ def _ddp_rank(rank, world, port, q):
 
 def test_two_rank_rccl_train_step():
     """data-parallel train step over RCCL on two GPUs (skipped on a one-GPU box): rank-0 broadcast, per-rank shards, bucketed
-    all-reduce from the gradient hooks / in-place gradient sink, fused optimiser — replicas stay bit-identical"""
+    all-reduce from the gradient hooks / in-place gradient sink — the exchanged gradient equals the MEAN of the ranks' single-GPU gradients —
+    fused optimiser, then the captured step with the exchange released from in-graph bucket events; replicas stay bit-identical"""
     if torch.cuda.device_count() < 2:
         pytest.skip("needs >= 2 GPUs")
     import torch.multiprocessing as mp

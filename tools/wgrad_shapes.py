@@ -1,47 +1,66 @@
-"""Per-shape time of every ly_wgrad call of one training step (lead-yolo-s, HIP events around each C-ABI call)."""
-import os, sys, collections
+"""Per-call table of the weight-gradient launches of ONE eager bf16/f32 training step of lead-yolo-s bs=64: shape, gather, kernel time
+(HIP events on the launch stream), algorithmic GB/s and TFLOP/s.  Dev tool.
+    python tools/wgrad_shapes.py [bf16|f32] [bs]"""
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import bench as B
 import lead_yolo_amd as L
 from lead_yolo_amd import ops
+
 dev = torch.device("cuda:0")
-bs = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-amp = torch.bfloat16 if (len(sys.argv) > 2 and sys.argv[2] == "bf16") else None
-from lead_yolo_amd import capi
-m = L.Model(L.load_cfg(scale="s")).to(dev).train()
-opt = L.smart_optimizer(m, "SGD", 0.01, 0.937, 5e-4 * bs / 64)
-cl = L.ComputeLoss(m)
-g = torch.Generator().manual_seed(0)
-imgs = torch.randint(0, 256, (bs, 3, 640, 640), dtype=torch.uint8, generator=g).to(dev)
-nb = 7 * bs
-tg = torch.cat((torch.sort(torch.randint(0, bs, (nb, 1), generator=g).float(), 0)[0], torch.zeros(nb, 1),
-                torch.rand(nb, 2, generator=g) * 0.8 + 0.1, torch.rand(nb, 2, generator=g) * 0.2 + 0.02), 1).to(dev)
-orig = ops.wgrad
-def named(**k):
-    ops._WG_NAME = f"wgrad N={k['N']:3d} K={k.get('ks', 1) ** 2 * k['Cin']:4d} M={k['M']:7d} ks={k.get('ks', 1)} s={k.get('stride', 1)} lddu={k['lddu']} ldx={k['ldx']}" \
-                   f"{' nchw' if k.get('nchw') else ''}{' up2' if k.get('up2') else ''}"
-    return orig(**k)
-ops.wgrad = named
+amp = torch.bfloat16 if (len(sys.argv) < 2 or sys.argv[1] == "bf16") else None
+bs = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+model = B.build_model("s", dev, train=True)
+opt = L.smart_optimizer(model, "SGD", 0.01, 0.937, 5e-4, fused=True)
+cl = L.ComputeLoss(model)
+imgs = B.synth_u8(bs, 640, 0).to(dev)
+tg = B.synth_targets(bs, 1).to(dev)
+for _ in range(3):
+    L.train_step(model, cl, opt, imgs, tg, amp=amp)
+torch.cuda.synchronize()
+
+LOG = []
+_w, _g = ops.wgrad, ops.wgrad_group
+
+
+def desc(q):
+    g = "rows" if (q.get("ks", 1) == 1 and q.get("stride", 1) == 1 and not q.get("nchw") and not q.get("up2")) else \
+        f"k{q.get('ks', 1)}s{q.get('stride', 1)}{'u' if q.get('up2') else ''}{'n' if q.get('nchw') else ''}"
+    return f"M={q['M']:7d} N={q['N']:4d} K={q.get('ks', 1) ** 2 * q['Cin']:5d} {g}{' pro' if q.get('x_scale') is not None else ''}"
+
+
+def timed(fn, label, flops, nbytes):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    fn()
+    e1.record()
+    LOG.append((label, flops, nbytes, e0, e1))
+
+
+def wgrad(**q):
+    es = q["x"].element_size()
+    k = q.get("ks", 1) ** 2 * q["Cin"]
+    timed(lambda: _w(**q), desc(q), 2.0 * q["M"] * q["N"] * k, es * q["M"] * (q["N"] + q["Cin"]) + 4.0 * q["N"] * k)
+
+
+def wgrad_group(problems):
+    es = problems[0]["x"].element_size()
+    timed(lambda: _g(problems), " + ".join(desc(q) for q in problems), sum(2.0 * q["M"] * q["N"] * q["Cin"] for q in problems),
+          sum(es * q["M"] * (q["N"] + q["Cin"]) + 4.0 * q["N"] * q["Cin"] for q in problems))
+
+
+ops.wgrad, ops.wgrad_group = wgrad, wgrad_group
 import lead_yolo_amd.grad as G
-G.ops.wgrad = named
-T = ops._Timed
-class T2(T):
-    def __init__(self, name, flops, nbytes):
-        super().__init__(getattr(ops, "_WG_NAME", name) + " " + name.split("<")[1][:-1] if name.startswith("ly_wgrad") else name, flops, nbytes)
-ops._Timed = T2
-for _ in range(2):
-    L.train_step(m, cl, opt, imgs, tg, amp=amp)
+for mod in (G,):
+    for name in ("wgrad", "wgrad_group"):
+        if hasattr(mod, name):
+            setattr(mod, name, globals()[name])
+L.train_step(model, cl, opt, imgs, tg, amp=amp)
 torch.cuda.synchronize()
-ops.PROFILE = []
-L.train_step(m, cl, opt, imgs, tg, amp=amp)
-torch.cuda.synchronize()
-agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
-for name, fl, by, e0, e1 in ops.PROFILE:
-    if name.startswith("wgrad"):
-        a = agg[name]; a[0] += 1; a[1] += e0.elapsed_time(e1) * 1e3; a[2] = by
-ops.PROFILE = None
 tot = 0.0
-for name, (n, us, by) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+for label, flops, nbytes, e0, e1 in LOG:
+    us = e0.elapsed_time(e1) * 1e3
     tot += us
-    print(f"{name:100s} x{n}  {us / n:8.1f} us  {by / (us / n) / 1e3:7.1f} GB/s")
-print(f"total wgrad {tot / 1e3:.2f} ms")
+    print(f"{us:8.1f} us  {nbytes / us / 1e3:7.0f} GB/s  {flops / us / 1e6:7.1f} TFLOP/s  {label}")
+print(f"{len(LOG)} wgrad launches, {tot:.1f} us (event time includes launch gaps of the eager step)")

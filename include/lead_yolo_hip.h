@@ -427,13 +427,15 @@ typedef struct LyPackDesc {
 int ly_pack_table(const LyPackDesc* table, const int* blk_desc, int n_blocks, void* stream);
 
 /* ---- detection loss on device (utils/loss.py:121-268 ComputeLoss / build_targets, utils/metrics.py:293-354 EIoU) --------
- * One pyramid level, forward and gradient (nc == 1, no focal loss): anchor matching with the reference's candidate order
+ * One pyramid level, forward and gradient (no focal loss): anchor matching with the reference's candidate order
  * (offset k, anchor a, target t), EIoU box loss with analytic gradient, per-cell "last writer wins" objectness target (the
- * highest candidate index, i.e. the reference's sequential CPU semantics), BCE objectness.
+ * highest candidate index, i.e. the reference's sequential CPU semantics), BCE objectness (positive weight obj_pw) and — when
+ * nc = no - 5 > 1 — the class BCE of every matched row (utils/loss.py:168-173: targets cn, cp at the row's class; positive weight cls_pw;
+ * mean over rows x classes; gain cls_gain).
  *   p / dp   [bs][na][ny][nx][no] predictions / their gradient (dp zeroed by the caller; d(total loss)/dp on return)
  *   anchors  [na][2] in grid units (Detect.anchors[i]);  targets [nt][6] = (image, class, x, y, w, h) normalised
  *   tobj [cells] zeroed, winner [cells] filled with -1, cand_cell [5*na*nt], cand [5*na*nt][5] workspaces
- *   acc [4] zeroed: sum(1 - eiou), matches, sum of objectness BCE, rejected target rows  -> ly_loss_finish
+ *   acc [8] zeroed: sum(1 - eiou), matches, sum of objectness BCE, rejected target rows, sum of class BCE, 3 unused  -> ly_loss_finish
  *   tbox     NULL or [5*na*nt][4]: (gx - gi, gy - gj, gw, gh) of every valid candidate (build_targets' `tbox`, utils/loss.py:262)
  *   match_only != 0: target assignment only (utils/loss.py:194-268 build_targets): cand_cell[idx] = flattened cell
  *            ((b*na + a)*ny + gj)*nx + gi of candidate idx = (k*na + a)*nt + t, or -1; tbox as above; p is read, dp/tobj untouched.
@@ -442,11 +444,11 @@ int ly_pack_table(const LyPackDesc* table, const int* blk_desc, int n_blocks, vo
  * formulation raises IndexError there); ly_loss_finish then returns a NaN total.                                          */
 int ly_loss_level(const float* p, float* dp, const float* anchors, const float* targets, int bs, int na, int ny, int nx, int no, long nt,
                   float anchor_t, float box_gain, float obj_gain, float balance, float* tobj, int* winner, long* cand_cell, float* cand,
-                  float* acc, float* tbox, int match_only, void* stream);
-/* out[0] = (lbox + lobj) * bs (NaN if any level rejected a target row), out[1] = lbox, out[2] = lobj, out[3] = lcls = 0 from
- * acc [nl][4]; cells / balance: [nl] floats                                                                                */
-int ly_loss_finish(const float* acc, int nl, const float* cells, const float* balance, float box_gain, float obj_gain, int bs, float* out,
-                   void* stream);
+                  float* acc, float* tbox, int match_only, float cls_gain, float cp, float cn, float cls_pw, float obj_pw, void* stream);
+/* out[0] = (lbox + lobj + lcls) * bs (NaN if any level rejected a target row), out[1] = lbox, out[2] = lobj, out[3] = lcls (0 for nc == 1)
+ * from acc [nl][8]; cells / balance: [nl] floats                                                                           */
+int ly_loss_finish(const float* acc, int nl, const float* cells, const float* balance, float box_gain, float obj_gain, float cls_gain, int nc,
+                   int bs, float* out, void* stream);
 
 /* ---- fused multi-tensor optimiser step (train.py:330-341; utils/torch_utils.py:318-346 smart_optimizer, 404-432 ModelEMA) ----------
  * One table entry per state tensor (all pointers DEVICE, fp32).  Entries with a gradient take clip + SGD-nesterov + zero_grad

@@ -1,5 +1,6 @@
 // Detection loss of one pyramid level, forward AND gradient in three launches (reference utils/loss.py:121-268
-// `ComputeLoss.__call__` / `build_targets`, utils/metrics.py:293-354 `bbox_iou(EIoU=True)`); nc == 1, no focal loss.
+// `ComputeLoss.__call__` / `build_targets`, utils/metrics.py:293-354 `bbox_iou(EIoU=True)`); any nc (class BCE with label smoothing and
+// cls_pw when nc > 1, utils/loss.py:168-173), obj_pw, no focal loss.
 //
 // The reference runs ~150 tiny ops forward and ~250 backward per step here (anchor matching with boolean indexing — a
 // host sync per level —, EIoU, two BCEs): 3.4 ms + 4.2 ms of pure launch latency at bs=64, a fifth of the training step.
@@ -66,9 +67,20 @@ struct LyLossLevel {
   int* winner;           // [cells], filled with -1
   long* cand_cell;       // [5*na*nt], -1 = invalid
   float* cand;           // [5*na*nt][5]: iou, d(1-eiou)/d(raw0..3)
-  float* acc;            // [4]: sum(1-eiou), count, sum BCE obj, number of rejected target rows   (zeroed)
+  float* acc;            // [8]: sum(1-eiou), count, sum BCE obj, number of rejected target rows, sum BCE cls, 3 unused   (zeroed)
   float* tbox;           // optional [5*na*nt][4]: (gx - gi, gy - gj, gw, gh) of every valid candidate (build_targets' tbox)
+  float cp, cn, cls_pw, obj_pw;      // class targets (label smoothing: 1 - eps/2, eps/2), positive weights of the two BCEs
 };
+
+// BCE-with-logits with a positive weight (torch.nn.BCEWithLogitsLoss(pos_weight = pw)): value and d/dx
+__device__ __forceinline__ float ly_bce(float x, float z, float pw) {
+  const float sp = log1pf(__expf(-fabsf(x))) + fmaxf(-x, 0.f);         // softplus(-x) = -log sigmoid(x)
+  return (1.f - z) * x + (1.f + (pw - 1.f) * z) * sp;
+}
+__device__ __forceinline__ float ly_bce_grad(float x, float z, float pw) {
+  const float sg = ly_sigmoid(x);
+  return (1.f - z) * sg - pw * z * (1.f - sg);
+}
 
 __global__ __launch_bounds__(LY_THREADS) void ly_loss_match_kernel(const LyLossLevel L) {
   const long ncand = 5L * L.na * L.nt;
@@ -119,11 +131,18 @@ __global__ __launch_bounds__(LY_THREADS) void ly_loss_match_kernel(const LyLossL
     atomicAdd(L.acc + 0, 1.f - e.v);
     atomicAdd(L.acc + 1, 1.f);
     atomicMax(L.winner + cell, (int)idx);
+    const int nc = L.no - 5;
+    if (nc > 1) {                                                          // class BCE of this matched row (utils/loss.py:168-173)
+      const int cls = (int)tg[1];
+      float sc = 0.f;
+      for (int q = 0; q < nc; ++q) sc += ly_bce(pr[5 + q], q == cls ? L.cp : L.cn, L.cls_pw);
+      atomicAdd(L.acc + 4, sc);
+    }
   }
   L.cand_cell[idx] = cell;
 }
 
-__global__ __launch_bounds__(LY_THREADS) void ly_loss_apply_kernel(const LyLossLevel L, float box_gain) {
+__global__ __launch_bounds__(LY_THREADS) void ly_loss_apply_kernel(const LyLossLevel L, float box_gain, float cls_gain) {
   const long ncand = 5L * L.na * L.nt;
   const long idx = (long)blockIdx.x * LY_THREADS + threadIdx.x;
   if (idx >= ncand) return;
@@ -135,6 +154,14 @@ __global__ __launch_bounds__(LY_THREADS) void ly_loss_apply_kernel(const LyLossL
 #pragma unroll
   for (int r = 0; r < 4; ++r) atomicAdd(d + r, scale * c[1 + r]);
   if (L.winner[cell] == (int)idx) L.tobj[cell] = fmaxf(c[0], 0.f);
+  const int nc = L.no - 5;
+  if (nc > 1) {                                                            // d/dx of  cls * mean over (rows, classes) of BCE * bs
+    const long t = idx % L.nt;
+    const int cls = (int)L.targets[t * 6 + 1];
+    const float cs = cls_gain * (float)L.bs / (L.acc[1] * (float)nc);
+    const float* pr = L.p + cell * L.no;
+    for (int q = 0; q < nc; ++q) atomicAdd(d + 5 + q, cs * ly_bce_grad(pr[5 + q], q == cls ? L.cp : L.cn, L.cls_pw));
+  }
 }
 
 __global__ __launch_bounds__(LY_THREADS) void ly_loss_obj_kernel(const LyLossLevel L, float obj_scale) {
@@ -143,8 +170,8 @@ __global__ __launch_bounds__(LY_THREADS) void ly_loss_obj_kernel(const LyLossLev
   float s = 0.f;
   for (long i = (long)blockIdx.x * LY_THREADS + threadIdx.x; i < cells; i += (long)gridDim.x * LY_THREADS) {
     const float x = L.p[i * L.no + 4], z = L.tobj[i];
-    s += fmaxf(x, 0.f) - x * z + log1pf(__expf(-fabsf(x)));
-    L.dp[i * L.no + 4] = (ly_sigmoid(x) - z) * obj_scale;                  // obj_scale = obj * balance * bs / cells
+    s += ly_bce(x, z, L.obj_pw);
+    L.dp[i * L.no + 4] = ly_bce_grad(x, z, L.obj_pw) * obj_scale;          // obj_scale = obj * balance * bs / cells
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
@@ -155,18 +182,18 @@ __global__ __launch_bounds__(LY_THREADS) void ly_loss_obj_kernel(const LyLossLev
 
 extern "C" int ly_loss_level(const float* p, float* dp, const float* anchors, const float* targets, int bs, int na, int ny, int nx, int no, long nt,
                              float anchor_t, float box_gain, float obj_gain, float balance, float* tobj, int* winner, long* cand_cell, float* cand,
-                             float* acc, float* tbox, int match_only, void* stream) {
+                             float* acc, float* tbox, int match_only, float cls_gain, float cp, float cn, float cls_pw, float obj_pw, void* stream) {
   LY_CHECK(p && (dp || match_only) && anchors && tobj && winner && acc && (nt == 0 || (targets && cand_cell && cand)), "loss_level: null pointer");
   LY_CHECK(bs > 0 && na > 0 && ny > 0 && nx > 0 && no >= 5 && nt >= 0, "loss_level: bad sizes");
   const long cells = (long)bs * na * ny * nx;
   LY_CHECK(5L * na * nt < (1L << 31) && cells < (1L << 40), "loss_level: too many candidates");
-  LyLossLevel L{p, dp, anchors, targets, bs, na, ny, nx, no, nt, anchor_t, tobj, winner, cand_cell, cand, acc, tbox};
+  LyLossLevel L{p, dp, anchors, targets, bs, na, ny, nx, no, nt, anchor_t, tobj, winner, cand_cell, cand, acc, tbox, cp, cn, cls_pw, obj_pw};
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const long ncand = 5L * na * nt;
   if (ncand > 0) {
     const unsigned blocks = (unsigned)((ncand + LY_THREADS - 1) / LY_THREADS);
     hipLaunchKernelGGL(ly_loss_match_kernel, dim3(blocks), dim3(LY_THREADS), 0, st, L);
-    if (!match_only) hipLaunchKernelGGL(ly_loss_apply_kernel, dim3(blocks), dim3(LY_THREADS), 0, st, L, box_gain);
+    if (!match_only) hipLaunchKernelGGL(ly_loss_apply_kernel, dim3(blocks), dim3(LY_THREADS), 0, st, L, box_gain, cls_gain);
   }
   if (match_only) {            // target assignment only (ComputeLoss.build_targets): cand_cell / tbox are the result
     LY_LAUNCH_CHECK();
@@ -179,30 +206,34 @@ extern "C" int ly_loss_level(const float* p, float* dp, const float* anchors, co
   return 0;
 }
 
-// out[0] = total loss, out[1..3] = (lbox, lobj, lcls) as the reference returns them; acc = [nl][4] level accumulators
+// out[0] = total loss, out[1..3] = (lbox, lobj, lcls) as the reference returns them; acc = [nl][8] level accumulators
 __global__ void ly_loss_finish_kernel(const float* __restrict__ acc, int nl, const float* __restrict__ cells, const float* __restrict__ balance,
-                                      float box_gain, float obj_gain, float bs, float* __restrict__ out) {
+                                      float box_gain, float obj_gain, float cls_gain, int nc, float bs, float* __restrict__ out) {
   if (threadIdx.x != 0) return;
-  float lbox = 0.f, lobj = 0.f, bad = 0.f;
+  float lbox = 0.f, lobj = 0.f, lcls = 0.f, bad = 0.f;
   for (int i = 0; i < nl; ++i) {
-    const float* a = acc + 4 * i;
+    const float* a = acc + 8 * i;
     bad += a[3];
-    if (a[1] > 0.f) lbox += a[0] / a[1];
+    if (a[1] > 0.f) {
+      lbox += a[0] / a[1];
+      if (nc > 1) lcls += a[4] / (a[1] * (float)nc);
+    }
     lobj += a[2] / cells[i] * balance[i];
   }
   lbox *= box_gain;
   lobj *= obj_gain;
-  out[0] = bad > 0.f ? __builtin_nanf("") : (lbox + lobj) * bs;      // rejected target rows (image index outside the batch / NaN): fail loudly
+  lcls *= cls_gain;
+  out[0] = bad > 0.f ? __builtin_nanf("") : (lbox + lobj + lcls) * bs;      // rejected target rows (image index outside the batch / NaN): fail loudly
   out[1] = lbox;
   out[2] = lobj;
-  out[3] = 0.f;
+  out[3] = lcls;
 }
 
-extern "C" int ly_loss_finish(const float* acc, int nl, const float* cells, const float* balance, float box_gain, float obj_gain, int bs, float* out,
-                              void* stream) {
+extern "C" int ly_loss_finish(const float* acc, int nl, const float* cells, const float* balance, float box_gain, float obj_gain, float cls_gain,
+                              int nc, int bs, float* out, void* stream) {
   LY_CHECK(acc && cells && balance && out && nl > 0, "loss_finish: bad arguments");
   hipLaunchKernelGGL(ly_loss_finish_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), acc, nl, cells, balance, box_gain, obj_gain,
-                     (float)bs, out);
+                     cls_gain, nc, (float)bs, out);
   LY_LAUNCH_CHECK();
   return 0;
 }

@@ -4,9 +4,9 @@ including its double `+eps` on the union) compute, done by csrc/ly_loss.hip in 3
 the gradient, with no host sync.
 
 There is no torch formulation in this package: the CPU restatement used for checking lives in oracle/functional.py
-(test infrastructure).  `ComputeLoss` therefore needs CUDA predictions and nc == 1 (the LEAD-YOLO / SSDD recipe) and
-raises otherwise.  `build_targets` is the inspectable view of the kernel's anchor matching: it runs the matching kernel
-alone and reads its candidate buffers back (int64 indices bit-exact with the reference's vectors, tests/test_loss.py).
+(test infrastructure).  `ComputeLoss` therefore needs CUDA predictions and raises otherwise.  Any nc: the class BCE of
+utils/loss.py:168-173 (label smoothing, cls_pw) is part of the kernel when nc > 1 (LEAD-YOLO.yaml itself is nc = 1); obj_pw too.
+`build_targets` is the inspectable view of the kernel's anchor matching: it runs the matching kernel alone and reads its candidate buffers back (int64 indices bit-exact with the reference's vectors, tests/test_loss.py).
 """
 import torch
 
@@ -23,11 +23,8 @@ class ComputeLoss:
         self.hyp = dict(DEFAULT_HYP, **(hyp or getattr(model, "hyp", None) or {}))
         if self.hyp["fl_gamma"] > 0 or autobalance:
             raise NotImplementedError("focal loss / autobalance are not used by the LEAD-YOLO recipe and are not built")
-        if self.hyp["obj_pw"] != 1.0:
-            raise NotImplementedError("objectness positive weight != 1 is not built into the device loss")
         self.na, self.nc, self.nl = det.na, det.nc, det.nl
-        if self.nc != 1:
-            raise NotImplementedError(f"the device loss is built for nc == 1 (LEAD-YOLO.yaml / SSDD); got nc={self.nc}")
+        self.cp, self.cn = 1.0 - 0.5 * self.hyp["label_smoothing"], 0.5 * self.hyp["label_smoothing"]      # smooth_BCE (utils/loss.py:17-19)
         self.anchors = det.anchors
         self.balance = {3: [4.0, 1.0, 0.4]}.get(self.nl, [4.0, 1.0, 0.25, 0.06, 0.02])
         self.gr = 1.0
@@ -60,12 +57,12 @@ class ComputeLoss:
         cells = [int(p.shape[0] * p.shape[1] * p.shape[2] * p.shape[3]) for p in preds]
         k = self._consts(dev, cells)
         ncand = max(5 * na * nt, 1)
-        zero = ops.zeros_f32(sum(cells) + 4 * nl, dev)                                       # tobj of every level + accumulators (step pool)
+        zero = ops.zeros_f32(sum(cells) + 8 * nl, dev)                                       # tobj of every level + accumulators (step pool)
         winner = torch.full((sum(cells),), -1, dtype=torch.int32, device=dev)
         cand_cell = torch.empty((nl, ncand), dtype=torch.int64, device=dev)
         cand = torch.empty((nl, ncand, 5), dtype=torch.float32, device=dev)
         tbox = torch.empty((nl, ncand, 4), dtype=torch.float32, device=dev) if match_only else None
-        acc = zero[sum(cells):].view(nl, 4)
+        acc = zero[sum(cells):].view(nl, 8)
         dps, off = [], 0
         st = capi.stream_ptr()
         for i, p in enumerate(preds):
@@ -75,7 +72,8 @@ class ComputeLoss:
                                                 float(self.hyp["anchor_t"]), float(self.hyp["box"]), float(self.hyp["obj"]), float(self.balance[i]),
                                                 capi.ptr(zero[off:off + cells[i]]), capi.ptr(winner[off:off + cells[i]]), capi.ptr(cand_cell[i]),
                                                 capi.ptr(cand[i]), capi.ptr(acc[i]), capi.ptr(tbox[i]) if match_only else capi.ptr(None),
-                                                int(match_only), st), "ly_loss_level")
+                                                int(match_only), float(self.hyp["cls"]), float(self.cp), float(self.cn), float(self.hyp["cls_pw"]),
+                                                float(self.hyp["obj_pw"]), st), "ly_loss_level")
             dps.append(dp)
             off += cells[i]
         return dict(dps=dps, acc=acc, cand_cell=cand_cell, tbox=tbox, k=k, bs=bs, nt=nt)
@@ -110,7 +108,8 @@ class ComputeLoss:
             indices.append((b, a, gj, gi))
             tbox.append(r["tbox"][i][:5 * na * nt][keep])
             anch.append(r["k"]["anchors"][i][a])
-            tcls.append(torch.zeros_like(b))                                  # nc == 1
+            tidx = torch.arange(keep.numel(), device=pi.device)[keep] % nt          # candidate index (k*na + a)*nt + t -> target row t
+            tcls.append(targets[tidx, 1].long())
         return tcls, tbox, indices, anch
 
     def __call__(self, p, targets):
@@ -129,7 +128,8 @@ class _LossFn(torch.autograd.Function):
         r = cl._levels(preds, targets, match_only=False)
         out = torch.empty(4, dtype=torch.float32, device=preds[0].device)
         capi.check(capi.lib().ly_loss_finish(capi.ptr(r["acc"]), len(preds), capi.ptr(r["k"]["cells"]), capi.ptr(r["k"]["balance"]),
-                                             float(cl.hyp["box"]), float(cl.hyp["obj"]), r["bs"], capi.ptr(out), capi.stream_ptr()), "ly_loss_finish")
+                                             float(cl.hyp["box"]), float(cl.hyp["obj"]), float(cl.hyp["cls"]), int(cl.nc), r["bs"], capi.ptr(out),
+                                             capi.stream_ptr()), "ly_loss_finish")
         ctx.save_for_backward(*r["dps"])
         ctx.mark_non_differentiable(out)
         return out[:1].clone(), out

@@ -244,6 +244,44 @@ def gen_loss(ref):
     _save("loss_n", meta, arrays)
 
 
+def gen_loss_multiclass(ref):
+    """the class-BCE branch of ComputeLoss (utils/loss.py:168-173: nc > 1) with label smoothing and both positive weights off their
+    defaults, from the reference's own ComputeLoss on a lead-yolo-n head built with nc = 3"""
+    print("loss, nc = 3:")
+    torch.manual_seed(0)
+    cfg = _cfg(ref, "n")
+    cfg["nc"] = 3
+    m = ref.yolo.Model(cfg, nc=3)
+    import yaml
+    with open(os.path.join(ref_import.REFERENCE_ROOT, "data", "hyps", "hyp.scratch-low.yaml")) as f:
+        hyp = yaml.safe_load(f)
+    hyp.update(label_smoothing=0.1, cls_pw=1.3, obj_pw=0.8)
+    m.hyp = hyp
+    det = m.model[-1]
+    assert det.nc == 3 and det.no == 8
+    cl = ref.loss.ComputeLoss(m)
+    B, S = 3, 128
+    tg = synth.synth_targets(B, 811, per_image=6)
+    tg[:, 1] = torch.randint(0, 3, (tg.shape[0],), generator=torch.Generator().manual_seed(812)).float()
+    arrays, meta = {}, dict(B=B, S=S, nc=3, hyp={k: float(v) for k, v in hyp.items()})
+    preds = [synth.synth_input((B, 3, S // s, S // s, 8), 820 + i) for i, s in enumerate((8, 16, 32))]
+    for i, p in enumerate(preds):
+        arrays[f"pred{i}"] = _np(p)
+    arrays["anchors"] = _np(det.anchors)
+    arrays["targets"] = _np(tg)
+    tcls, tbox, indices, anch = cl.build_targets(preds, tg)
+    for i in range(3):
+        arrays[f"tcls{i}"] = _np(tcls[i]).astype(np.int64)
+    ps = [p.clone().requires_grad_(True) for p in preds]
+    loss, items = cl(ps, tg)
+    loss.backward()
+    arrays["loss"] = _np(loss)
+    arrays["items"] = _np(items)
+    for i in range(3):
+        arrays[f"dpred{i}"] = _np(ps[i].grad)
+    _save("loss_nc3", meta, arrays)
+
+
 def gen_trainsteps(ref):
     """T: 3 optimiser steps of lead-yolo-n at 64x64 exactly as train.py:295-341 does them on CPU fp32
     (amp off => scaler is a no-op; nbs=64, batch 4 => accumulate=16 in train.py, here we step every
@@ -286,13 +324,13 @@ def gen_trainsteps(ref):
 
 
 def main():
+    import sys
     ref = ref_import.load()
     torch.set_num_threads(8)
-    gen_modules(ref)
-    gen_parse(ref)
-    gen_model(ref)
-    gen_loss(ref)
-    gen_trainsteps(ref)
+    gens = dict(modules=gen_modules, parse=gen_parse, model=gen_model, loss=gen_loss, loss_multiclass=gen_loss_multiclass,
+                trainsteps=gen_trainsteps)
+    for name in (sys.argv[1:] or list(gens)):            # `python oracle/gen_golden.py loss_multiclass` regenerates one group
+        gens[name](ref)
 
 
 if __name__ == "__main__":

@@ -242,3 +242,125 @@ def test_mlpblock_persistent_kernel_bf16(c, n, h, w):
         want = OF.basic_stage(copy.deepcopy(st), "", x, False)
         got = m.to(_dev()).eval()(x.to(_dev()).to(BF))
     _close(got, want, f"basicstage c={c} {n}x{h}x{w} bf16")
+
+
+def test_configs2_full_size_graphed_step():
+    """BASELINE configs[2] at FULL size — lead-yolo-s, bs=64, 640x640, bf16, the captured optimisation step the bench times — through
+    size-independent properties (the CPU oracle cannot run this batch in seconds):
+      (a) the replayed graph's loss equals the eager step's loss from the same restored state (atomic / bf16-rounding noise only);
+      (b) every gradient-carrying state tensor (weights, momentum buffers, EMA) is finite after the step and the weights moved;
+      (c) train-mode BatchNorm couples the images of a batch, eval mode does not: two sampled images of the batch replayed ALONE
+          through the fp32 oracle in eval mode agree with the HIP model's rows of the full batch within the whole-model bf16 bound."""
+    import lead_yolo_amd as L
+    from lead_yolo_amd import pack
+    torch.manual_seed(0)
+    cfg = _cfg("s")
+    m = L.Model(cfg)
+    st = synth.synth_state(synth.shapes_of(m.state_dict()), 7272)
+    st["model.23.anchors"] = m.model[-1].anchors.clone()
+    m.load_state_dict(st)
+    m = m.to(_dev()).train()
+    bs = 64
+    imgs = synth.synth_images(bs, 640, 77).to(_dev())
+    tg = synth.synth_targets(bs, 78, per_image=7).to(_dev())
+    opt = L.smart_optimizer(m, "SGD", 0.01, 0.937, 5e-4)
+    ema = L.ModelEMA(m)
+    cl = L.ComputeLoss(m)
+    step = L.GraphedTrainStep(m, cl, opt, imgs, tg, ema=ema, amp=BF, warmup=2)
+
+    def tensors():
+        return ({k: v for k, v in m.state_dict().items() if v.is_floating_point()},
+                {k: v for k, v in ema.ema.state_dict().items() if v.is_floating_point()},
+                {n: opt.state[p]["momentum_buffer"] for n, p in m.named_parameters() if p in opt.state})
+
+    def snap():
+        torch.cuda.synchronize()
+        return [{k: v.detach().clone() for k, v in d.items()} for d in tensors()], opt._table["hyper"].clone(), ema.updates
+
+    def restore(s):
+        with torch.no_grad():
+            for live, saved in zip(tensors(), s[0]):
+                for k, v in live.items():
+                    v.copy_(saved[k])
+            opt._table["hyper"].copy_(s[1])
+        ema.updates = s[2]
+        pack.touch_weights()
+    s0 = snap()
+    outs = []
+    for how in ("eager", "eager", "graph"):
+        restore(s0)
+        loss = step(imgs, tg)[0] if how == "graph" else L.train_step(m, cl, opt, imgs, tg, ema=ema, amp=BF)[0]
+        outs.append((float(loss), snap()))
+    (le, e), (le2, e2), (lg, g) = outs
+    assert np.isfinite(le) and np.isfinite(lg) and abs(le - lg) <= max(2.0 ** -7, 3 * abs(le - le2) / abs(le)) * abs(le), (le, le2, lg)     # (a)
+    # (b) finite everywhere; the step's UPDATE of all weights / EMA entries / momentum buffers, as one vector, points where the eager step's
+    # does (a second eager step from the same state is the noise floor: float atomics + bf16 rounding boundaries through 24 layers)
+    moved = 0
+    for wi in range(3):
+        dg, de, de2 = [], [], []
+        for k in e[0][wi]:
+            assert torch.isfinite(g[0][wi][k]).all(), k
+            before = s0[0][wi][k]
+            dg.append((g[0][wi][k] - before).flatten()); de.append((e[0][wi][k] - before).flatten()); de2.append((e2[0][wi][k] - before).flatten())
+            moved += int(float(dg[-1].abs().max()) > 0)
+        dg, de, de2 = torch.cat(dg).double(), torch.cat(de).double(), torch.cat(de2).double()
+        cos = float(dg @ de / (dg.norm() * de.norm()))
+        cos_noise = float(de2 @ de / (de2.norm() * de.norm()))
+        ratio = float(dg.norm() / de.norm())
+        assert cos >= min(0.99, 1 - 3 * (1 - cos_noise)) and 0.9 <= ratio <= 1.1, (wi, cos, cos_noise, ratio)
+    assert moved > 500
+    # (c) eval rows of single images vs the oracle on the same (restored) weights
+    restore(s0)
+    so = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    m.eval()
+    with torch.no_grad():
+        with torch.autocast("cuda", dtype=BF):
+            z, _ = m(imgs.float() / 255)
+        for i in (5, 41):
+            zo, _ = OF.model_forward(copy.deepcopy(so), cfg, imgs[i:i + 1].cpu().float() / 255, m.stride, training=False)
+            _close(z[i:i + 1], zo, f"configs[2] image {i} of the bs=64 batch", rel=5 * REL_L2, mx=8 * MAX_REL)
+
+
+def test_configs4_shape_lead_yolo_l_1280():
+    """BASELINE configs[4]'s shape on one GPU: lead-yolo-l, 1280x1280, bf16, bs=2 (the per-GPU batch of 16 only repeats these tiles):
+    one captured optimisation step equals the eager step from the same state, everything stays finite, and the large-map kernels
+    (160 x 160 ... 320 x 320 feature maps, 1024-wide C3_CA) run inside their index limits."""
+    import lead_yolo_amd as L
+    from lead_yolo_amd import pack
+    torch.manual_seed(0)
+    m = L.Model(_cfg("l")).to(_dev()).train()
+    imgs = synth.synth_images(2, 1280, 91).to(_dev())
+    tg = synth.synth_targets(2, 92, per_image=7).to(_dev())
+    opt = L.smart_optimizer(m, "SGD", 0.01, 0.937, 5e-4)
+    cl = L.ComputeLoss(m)
+    step = L.GraphedTrainStep(m, cl, opt, imgs, tg, amp=BF, warmup=2)
+    w0 = {k: v.detach().clone() for k, v in m.state_dict().items() if v.is_floating_point()}
+    b0 = {n: opt.state[p]["momentum_buffer"].detach().clone() for n, p in m.named_parameters() if p in opt.state}
+    h0 = opt._table["hyper"].clone()
+
+    def restore():
+        with torch.no_grad():
+            for k, v in m.state_dict().items():
+                if k in w0:
+                    v.copy_(w0[k])
+            for n, p in m.named_parameters():
+                if n in b0:
+                    opt.state[p]["momentum_buffer"].copy_(b0[n])
+            opt._table["hyper"].copy_(h0)
+        pack.touch_weights()
+    outs = []
+    for how in ("eager", "eager", "graph"):
+        restore()
+        loss = step(imgs, tg)[0] if how == "graph" else L.train_step(m, cl, opt, imgs, tg, amp=BF)[0]
+        torch.cuda.synchronize()
+        outs.append((float(loss), {k: v.detach().clone() for k, v in m.state_dict().items() if k in w0}))
+    (le, we), (le2, we2), (lg, wg) = outs
+    assert np.isfinite(le) and np.isfinite(lg) and abs(le - lg) <= max(2.0 ** -6, 3 * abs(le - le2) / abs(le)) * abs(le), (le, le2, lg)
+    dg, de, de2 = [], [], []
+    for k in we:
+        assert torch.isfinite(wg[k]).all(), k
+        dg.append((wg[k] - w0[k]).flatten()); de.append((we[k] - w0[k]).flatten()); de2.append((we2[k] - w0[k]).flatten())
+    dg, de, de2 = torch.cat(dg).double(), torch.cat(de).double(), torch.cat(de2).double()
+    cos = float(dg @ de / (dg.norm() * de.norm()))
+    cos_noise = float(de2 @ de / (de2.norm() * de.norm()))
+    assert cos >= min(0.99, 1 - 3 * (1 - cos_noise)) and 0.9 <= float(dg.norm() / de.norm()) <= 1.1, (cos, cos_noise)

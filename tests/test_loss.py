@@ -13,17 +13,57 @@ class _Det:
         self.na, self.nc, self.nl, self.anchors = anchors.shape[1], 1, anchors.shape[0], anchors
 
 
-def test_loss_refuses_cpu_and_multiclass():
+def test_loss_refuses_cpu():
     from lead_yolo_amd.loss import ComputeLoss
     _, arr = G.load("loss_n")
     cl = ComputeLoss(_Det(G.t(arr["anchors"])))
     preds = [G.t(arr[f"pred{i}"]) for i in range(3)]
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         cl(preds, G.t(arr["rand_targets"]))
-    d = _Det(G.t(arr["anchors"]))
-    d.nc = 3
     with pytest.raises(NotImplementedError):
-        ComputeLoss(d)
+        ComputeLoss(_Det(G.t(arr["anchors"])), hyp=dict(fl_gamma=1.5))
+
+
+_HYP_KEYS = ("box", "cls", "cls_pw", "obj", "obj_pw", "anchor_t", "fl_gamma", "label_smoothing")
+
+
+def test_oracle_multiclass_loss_matches_reference():
+    """oracle/functional.compute_loss with nc = 3, label smoothing 0.1, cls_pw 1.3, obj_pw 0.8 vs the reference's own vectors
+    (tests/golden/loss_nc3.npz, oracle/gen_golden.py gen_loss_multiclass; utils/loss.py:168-173)"""
+    from oracle import functional as OF
+    meta, arr = G.load("loss_nc3")
+    preds = [G.t(arr[f"pred{i}"]).requires_grad_(True) for i in range(3)]
+    loss, items = OF.compute_loss(preds, G.t(arr["targets"]), G.t(arr["anchors"]), nc=3, hyp={k: meta["hyp"][k] for k in _HYP_KEYS})
+    loss.backward()
+    np.testing.assert_allclose(loss.detach().numpy(), arr["loss"], rtol=1e-5)
+    np.testing.assert_allclose(items.numpy(), arr["items"], rtol=1e-5, atol=1e-7)
+    assert arr["items"][2] > 0                       # the class term is really there
+    for i in range(3):
+        np.testing.assert_allclose(preds[i].grad.numpy(), arr[f"dpred{i}"], rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_multiclass_loss_gpu():
+    """the device loss with nc = 3 (class BCE, label smoothing, cls_pw, obj_pw — utils/loss.py:137-141, 168-173) vs the reference's
+    vectors: loss, items, d/dpred of every level incl. the class logits, and build_targets' tcls bit-exact"""
+    from lead_yolo_amd.loss import ComputeLoss
+    device = torch.device("cuda:0")
+    meta, arr = G.load("loss_nc3")
+    det = _Det(G.t(arr["anchors"]).to(device))
+    det.nc = 3
+    cl = ComputeLoss(det, hyp={k: meta["hyp"][k] for k in _HYP_KEYS})
+    preds = [G.t(arr[f"pred{i}"]).to(device).requires_grad_(True) for i in range(3)]
+    tg = G.t(arr["targets"]).to(device)
+    tcls, _, _, _ = cl.build_targets(preds, tg)
+    for i in range(3):
+        got = tcls[i].cpu().numpy()
+        assert got.dtype == np.int64 and np.array_equal(got, arr[f"tcls{i}"])
+    loss, items = cl(preds, tg)
+    np.testing.assert_allclose(loss.detach().cpu().numpy(), arr["loss"], rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(items.cpu().numpy(), arr["items"], rtol=2e-5, atol=1e-6)
+    loss.backward()
+    for i in range(3):
+        np.testing.assert_allclose(preds[i].grad.cpu().numpy(), arr[f"dpred{i}"], rtol=2e-4, atol=2e-6)
 
 
 @pytest.mark.gpu
@@ -33,7 +73,7 @@ def test_loss_gpu(case):
     device = torch.device("cuda:0")
     meta, arr = G.load("loss_n")
     anchors = G.t(arr["anchors"]).to(device)
-    cl = ComputeLoss(_Det(anchors), hyp={k: v for k, v in meta["hyp"].items() if k in ("box", "cls", "cls_pw", "obj", "obj_pw", "anchor_t", "fl_gamma")})
+    cl = ComputeLoss(_Det(anchors), hyp={k: v for k, v in meta["hyp"].items() if k in _HYP_KEYS})
     preds = [G.t(arr[f"pred{i}"]).to(device).requires_grad_(True) for i in range(3)]
     tg = G.t(arr[f"{case}_targets"]).to(device)
     tcls, tbox, indices, anch = cl.build_targets(preds, tg)          # the matching kernel's own buffers, read back

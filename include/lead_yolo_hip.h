@@ -314,12 +314,19 @@ typedef struct LyWgradParams {
    * — a BatchNorm + ReLU whose output the producer never materialised (the MLPBlock's hidden tensor, models/common.py:1478-1482,
    * in the training backward: dW2 = dy^T . relu(BN(u1)) is contracted from u1 directly)                                          */
   const float* x_scale; const float* x_shift;
+  /* optional scratch for the partial tiles of the pixel chunks (fp32, ws_floats elements, contents irrelevant): kernels that can use it
+   * store every chunk's tile with plain stores and fold the chunks in a FIXED order in a second launch — no float atomics (~1.3 TB/s
+   * chip-wide, half the time of a 3x3 weight gradient) and a bit-reproducible dw.  NULL or too small: atomic accumulation.          */
+  float* ws; long ws_floats;
 } LyWgradParams;
 int ly_wgrad(const LyWgradParams* p, void* stream);
 /* n independent weight gradients in ONE launch when all of them are plain-row 1x1 problems of the 128 x 128 tile class (N > 64, no
  * gather) and n <= 4: they share the launch's ~512 blocks, so every block walks a longer pixel chunk (fewer first-load waits and atomic tile
  * flushes per pixel).  Any other mix: the same as n calls of ly_wgrad.                                                                  */
 int ly_wgrad_group(const LyWgradParams* arr, int n, void* stream);
+/* development switch (returns the previous value): 0 sends 3x3 / stride-1 bf16 problems to the generic tiled kernel instead of the halo-tile
+ * kernel of csrc/ly_wgrad3.hip (A/B timing and the equivalence test); default 1.                                                           */
+int ly_tune_wgrad3(int on);
 
 /* Adjoint of the nearest-2x read: out[n,h,w,:] = sum of d[n, 2h+{0,1}, 2w+{0,1}, :]  (d is a 2Hs x 2Ws map).      */
 int ly_up2_bwd(const void* d /*T*/, int ldd, int n_img, int Hs, int Ws, int C, void* out /*T*/, int ldo, int dtype, void* stream);

@@ -59,7 +59,7 @@ class LyWgradParams(ctypes.Structure):
     _fields_ = [("M", _L), ("H", _I), ("W", _I), ("N", _I), ("du", _P), ("lddu", _I), ("x", _P), ("ldx", _I),
                 ("Hin", _I), ("Win", _I), ("Cin", _I), ("ks", _I), ("stride", _I), ("pad", _I), ("nchw", _I), ("up2", _I),
                 ("dw", _P), ("lddw", _I), ("dtype", _I), ("dw_ts", _I), ("dw_cs", _I), ("n_valid", _I), ("c_valid", _I),
-                ("x_scale", _P), ("x_shift", _P)]
+                ("x_scale", _P), ("x_shift", _P), ("ws", _P), ("ws_floats", _L)]
 
 
 STATS_STRIPES = 32
@@ -142,6 +142,7 @@ SIGNATURES = {
     "ly_pack_table": [_P, _P, _I, _P],
     "ly_optim_step": [_P, _P, _P, _I, _P, _P, _P, _P],
     "ly_sum_rows": [_P, _L, _L, _L, _P, _I, _P],
+    "ly_tune_wgrad3": [_I],
     "ly_event_create": [ctypes.POINTER(_P)],
     "ly_event_destroy": [_P],
     "ly_event_record": [_P, _P],

@@ -369,8 +369,9 @@ __global__ __launch_bounds__(LY_THREADS) void ly_wgrad_kernel(const LyWgradParam
 // s+1 are in flight while step s is contracted (register prefetch, two LDS buffers, one barrier per step).
 // Re-reads drop from (N/64 + K/64) to (N/BN + K/BK) passes over the two tensors.
 // -------------------------------------------------------------------------------------------------
-template <typename T, int BN, int BK, int P, bool ROWS, bool PRO>
-__device__ __forceinline__ void ly_wgrad_tiled_body(const LyWgradParams& Q, const int tile_idx, const int chunk_idx, const int tiles_k, const long chunk_px) {
+template <typename T, int BN, int BK, int P, bool ROWS, bool PRO, bool SLAB = true>
+__device__ __forceinline__ void ly_wgrad_tiled_body(const LyWgradParams& Q, const int tile_idx, const int chunk_idx, const int tiles_k, const long chunk_px,
+                                                    float* __restrict__ const slab, const int tiles) {
   using R4 = typename LyT<T>::R4;
   constexpr int PL = LyT<T>::PL;
   const T* const du = reinterpret_cast<const T*>(Q.du);
@@ -571,6 +572,27 @@ __device__ __forceinline__ void ly_wgrad_tiled_body(const LyWgradParams& Q, cons
     }
   }
 
+  if (SLAB && slab) {
+    // the chunk's tile [BN][BK] into its own slab with plain stores (16 lanes = 64 contiguous bytes); ly_wgrad_combine folds the chunks in a
+    // fixed order: no float atomics (the atomic flush of 512 x 64 KB was a quarter of a launch), bit-reproducible dw
+    float* const sl = slab + ((long)chunk_idx * tiles + tile_idx) * (BN * BK);
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int lc = (wave >> 1) * (BK / 2) + 16 * j + li;
+        const int col = k0 + lc;
+        if (col >= Ktot) continue;
+        const int tap = col / Q.Cin, cch = col - tap * Q.Cin;
+        if (cch >= Q.c_valid) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int lr = wn + 16 * i + 4 * lq + r;
+          if (n0 + lr < Q.n_valid) sl[lr * BK + lc] = acc[i][j][r];
+        }
+      }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -588,9 +610,49 @@ __device__ __forceinline__ void ly_wgrad_tiled_body(const LyWgradParams& Q, cons
     }
 }
 
+// dw[n][tap][c] += sum over chunks of slab[chunk][tile][row][col] in a fixed order, one writer per element (the second launch of a tiled
+// weight gradient whose chunks left their tiles in LyWgradParams.ws).  Block = 64 slab columns x 16 chunk lanes.
+__global__ __launch_bounds__(1024) void ly_wgrad_combine_kernel(const LyWgradParams P, const float* __restrict__ slab, const int chunks, const int tiles_k,
+                                                               const int tiles, const int BN, const int BK) {
+  __shared__ float red[16][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const long E = (long)tiles * BN * BK;
+  const long e = (long)blockIdx.x * 64 + cl;
+  const int tile = (int)(e / (BN * BK));
+  const int rem = (int)(e - (long)tile * (BN * BK));
+  const int lr = rem / BK, lc = rem - lr * BK;
+  const int tk = tile % tiles_k, tn = tile / tiles_k;
+  const int row = tn * BN + lr, col = tk * BK + lc;
+  const int tap = col / P.Cin, cch = col - tap * P.Cin;
+  const bool live = e < E && row < P.n_valid && col < P.ks * P.ks * P.Cin && cch < P.c_valid;
+  float a0 = 0.f, a1 = 0.f;
+  if (live) {
+    const float* p = slab + e;
+    int c = rl;
+    for (; c + 16 < chunks; c += 32) {
+      a0 += p[(long)c * E];
+      a1 += p[(long)(c + 16) * E];
+    }
+    if (c < chunks) a0 += p[(long)c * E];
+  }
+  red[rl][cl] = a0 + a1;
+  __syncthreads();
+  if (rl == 0 && live) {
+    float sacc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sacc += red[i][cl];
+    float* d = P.dw + (long)row * P.lddw + (long)tap * P.dw_ts + (long)cch * P.dw_cs;
+    *d += sacc;
+  }
+}
+static void wgrad_combine_launch(const LyWgradParams& P, const float* slab, long chunks, int tiles_k, long tiles, int BN, int BK, hipStream_t st) {
+  const long E = tiles * BN * BK;
+  hipLaunchKernelGGL(ly_wgrad_combine_kernel, dim3((unsigned)((E + 63) / 64)), dim3(1024), 0, st, P, slab, (int)chunks, tiles_k, (int)tiles, BN, BK);
+}
+
 template <typename T, int BN, int BK, int P, bool ROWS, bool PRO = false>
-__global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(BN + BK > 160 ? 2 : 3))) void ly_wgrad_tiled_kernel(const LyWgradParams P_, const int tiles_k, const long chunk_px) {
-  ly_wgrad_tiled_body<T, BN, BK, P, ROWS, PRO>(P_, (int)blockIdx.x, (int)blockIdx.y, tiles_k, chunk_px);
+__global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(BN + BK > 160 ? 2 : 3))) void ly_wgrad_tiled_kernel(const LyWgradParams P_, const int tiles_k, const long chunk_px, float* const slab) {
+  ly_wgrad_tiled_body<T, BN, BK, P, ROWS, PRO>(P_, (int)blockIdx.x, (int)blockIdx.y, tiles_k, chunk_px, slab, (int)gridDim.x);
 }
 
 // Several independent weight gradients of ONE tile class in one launch (ly_wgrad_group): the problems share the ~512 blocks, so each block
@@ -612,7 +674,9 @@ __global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(BN +
   g = __builtin_amdgcn_readfirstlane(g);
   const int local = (int)blockIdx.x - G.blk0[g];
   const int tiles = G.tiles[g];
-  ly_wgrad_tiled_body<T, BN, BK, P, ROWS, PRO>(G.p[g], local % tiles, local / tiles, G.tiles_k[g], G.chunk_px[g]);
+  // (no slab path here: with it compiled in, every wait of this instantiation's pixel loop became `s_waitcnt vmcnt(0)` — 53 -> 107 us per launch;
+  // a grouped launch keeps the atomic flush, whose cost the longer pixel runs per block already halve)
+  ly_wgrad_tiled_body<T, BN, BK, P, ROWS, PRO, false>(G.p[g], local % tiles, local / tiles, G.tiles_k[g], G.chunk_px[g], nullptr, tiles);
 }
 
 template <typename T, int BN, int BK, int P>
@@ -632,25 +696,36 @@ static int launch_wgrad_tiled(const LyWgradParams& Q, bool rows, hipStream_t st)
   LY_CHECK(chunks < 65536, "wgrad: too many pixel chunks");
   const size_t lds = (LyT<T>::PL * P >= 128 ? 1 : 2) * (size_t)(BN + BK) * (LyT<T>::PL * 2 * P + 16) + 2 * BK * sizeof(float);
   const dim3 grid((unsigned)tiles, (unsigned)chunks);
+  const long need = chunks * tiles * (long)(BN * BK);
+  float* const slab = (chunks > 1 && Q.ws && need <= Q.ws_floats) ? Q.ws : nullptr;
   if (rows && Q.x_scale) {
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ly_wgrad_tiled_kernel<T, BN, BK, P, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-    hipLaunchKernelGGL((ly_wgrad_tiled_kernel<T, BN, BK, P, true, true>), grid, dim3(LY_THREADS), lds, st, Q, tiles_k, chunk_px);
+    hipLaunchKernelGGL((ly_wgrad_tiled_kernel<T, BN, BK, P, true, true>), grid, dim3(LY_THREADS), lds, st, Q, tiles_k, chunk_px, slab);
   } else if (rows) {
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ly_wgrad_tiled_kernel<T, BN, BK, P, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-    hipLaunchKernelGGL((ly_wgrad_tiled_kernel<T, BN, BK, P, true>), grid, dim3(LY_THREADS), lds, st, Q, tiles_k, chunk_px);
+    hipLaunchKernelGGL((ly_wgrad_tiled_kernel<T, BN, BK, P, true>), grid, dim3(LY_THREADS), lds, st, Q, tiles_k, chunk_px, slab);
   } else {
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ly_wgrad_tiled_kernel<T, BN, BK, P, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-    hipLaunchKernelGGL((ly_wgrad_tiled_kernel<T, BN, BK, P, false>), grid, dim3(LY_THREADS), lds, st, Q, tiles_k, chunk_px);
+    hipLaunchKernelGGL((ly_wgrad_tiled_kernel<T, BN, BK, P, false>), grid, dim3(LY_THREADS), lds, st, Q, tiles_k, chunk_px, slab);
   }
+  if (slab) wgrad_combine_launch(Q, slab, chunks, tiles_k, tiles, BN, BK, st);
   LY_LAUNCH_CHECK();
   return 0;
 }
 
 template <typename T>
 static int wgrad_dispatch(const LyWgradParams& P, void* stream);
+bool ly_wgrad3_ok(const LyWgradParams& P);                         // ly_wgrad3.hip
+int ly_wgrad3_launch(const LyWgradParams& P, hipStream_t st);
+static int g_ly_wgrad3 = 1;
+extern "C" int ly_tune_wgrad3(int on) {                            // development switch: 0 sends 3x3 problems back to the generic tiled kernel
+  const int was = g_ly_wgrad3;
+  g_ly_wgrad3 = on;
+  return was;
+}
 
 extern "C" int ly_wgrad(const LyWgradParams* p, void* stream) {
   LY_CHECK(p, "wgrad: null params");
@@ -743,6 +818,7 @@ static int wgrad_dispatch(const LyWgradParams& P, void* stream) {
   const bool tiled_ok = !P.nchw && (P.N & 3) == 0 && (P.Cin & 3) == 0 && (P.lddu & 3) == 0 && (P.ldx & 3) == 0 && ((uintptr_t)P.du & (4 * sizeof(T) - 1)) == 0 &&
                         ((uintptr_t)P.x & (4 * sizeof(T) - 1)) == 0;
   if (P.x_scale) LY_CHECK(rows && tiled_ok, "wgrad: the x prologue is built for plain-row 1x1 problems with vector-friendly widths");
+  if (g_ly_wgrad3 && ly_wgrad3_ok(P)) return ly_wgrad3_launch(P, reinterpret_cast<hipStream_t>(stream));      // 3x3 / stride 1, bf16: halo-tile kernel (ly_wgrad3.hip)
   if (!P.nchw && (P.N & 3) == 0 && (P.Cin & 3) == 0 && (P.lddu & 3) == 0 && (P.ldx & 3) == 0 && ((uintptr_t)P.du & (4 * sizeof(T) - 1)) == 0 && ((uintptr_t)P.x & (4 * sizeof(T) - 1)) == 0) {
     hipStream_t st2 = reinterpret_cast<hipStream_t>(stream);
     // One step of a block is one memory round trip, so what matters for the skinny shapes is how many blocks a CU holds and how many

@@ -738,9 +738,27 @@ def _wgrad_params(*, M, H, W, N, du, lddu, x, ldx, Hin, Win, Cin, dw, lddw, ks=1
         raise ValueError("wgrad: x_scale and x_shift come together")
     if x_scale is not None and (x_scale.dtype != torch.float32 or x_shift.dtype != torch.float32 or x_scale.numel() < Cin or x_shift.numel() < Cin):
         raise ValueError("wgrad: x_scale / x_shift must be float32 vectors of at least Cin elements")
+    ws = wgrad_workspace(x.device)
     return capi.LyWgradParams(M, H, W, N, at(du, du_off), lddu, at(x, x_off), ldx, Hin, Win, Cin, ks, stride, pad, int(nchw), int(up2),
                               at(dw, dw_off), lddw, capi.dtype_code(x), Cin if dw_ts is None else dw_ts, dw_cs, N if n_valid is None else n_valid,
-                              Cin if c_valid is None else c_valid, _p(x_scale), _p(x_shift))
+                              Cin if c_valid is None else c_valid, _p(x_scale), _p(x_shift), _p(ws), ws.numel() if ws is not None else 0)
+
+
+WGRAD_WS_FLOATS = 24 << 20          # 96 MB of fp32 scratch per device: the partial tiles of one weight-gradient launch (largest: 38 MB)
+_WGRAD_WS = {}
+
+
+def wgrad_workspace(device):
+    """Per-device scratch the weight-gradient kernels park their per-chunk partial tiles in (LyWgradParams.ws).  Allocated ONCE (a captured
+    hipGraph keeps its address; every launch overwrites what it reads back in the same launch sequence, stream-ordered), never zeroed."""
+    if WGRAD_WS_FLOATS <= 0:
+        return None
+    ws = _WGRAD_WS.get(device)
+    if ws is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None                               # (a first use inside a capture: this launch keeps the atomic path)
+        ws = _WGRAD_WS[device] = torch.empty(WGRAD_WS_FLOATS, dtype=torch.float32, device=device)
+    return ws
 
 
 def wgrad_group(problems):

@@ -476,7 +476,7 @@ def test_graphed_train_step_matches_eager(amp):
             if na > 1e-7:
                 rels.append((float((da - db).norm()) / na, float((da - dc).norm()) / na, k))
         assert len(rels) > 100
-        floor = 0.02 if amp is None else 0.15
+        floor = 0.05 if amp is None else 0.2          # (a wrong step is a relative error of 1; two eager fp32 runs differ by up to ~2 %)
         assert all(r[0] <= max(floor, 3 * r[1]) for r in rels), (what, "update", max(rels))
         assert sum(r[0] <= floor for r in rels) >= 0.9 * len(rels), (what, "update", sorted(rels)[-10:])
     # ---- a short trajectory on changing batches: graph replays vs eager steps from the same state, loosely ----
@@ -846,3 +846,38 @@ def test_batchnorm_statistics_with_large_mean(offset):
     # running statistics follow the reference's update too
     rm, rv = m.norm.running_mean.cpu(), m.norm.running_var.cpu()
     assert torch.allclose(rm, stt["norm.running_mean"], rtol=1e-4, atol=1e-4) and torch.allclose(rv, stt["norm.running_var"], rtol=2e-3, atol=1e-4), offset
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,cvalid,ldx", [(2, 16, 16, 64, 64, 64, 64), (3, 20, 20, 128, 96, 128, 128), (1, 13, 27, 32, 200, 32, 32),
+                                                      (2, 40, 24, 8, 8, 6, 24), (2, 9, 11, 40, 40, 40, 160), (1, 80, 80, 64, 64, 64, 64)])
+def test_wgrad3_halo_kernel(n, h, w, cin, cout, cvalid, ldx):
+    """ly_wgrad3 (3x3 / stride 1 / pad 1 weight gradient from an LDS halo tile with transposed fragment reads, csrc/ly_wgrad3.hip) vs the
+    weight gradient autograd gives nn.Conv2d (models/common.py:1890-1910; partial conv: models/common.py:1412-1437) in fp64, and vs the
+    generic tiled kernel it replaces: ragged maps, output channels off the 64-row tile, a channel SLICE of a wider tensor with padded
+    channels (the partial conv: 6 valid of 8 read), tap-major gradient storage"""
+    import lead_yolo_amd as L
+    from lead_yolo_amd import capi, ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(n * 1000 + h * 10 + cin)
+    xfull = torch.randn(n, h, w, ldx, generator=g).to(dev).to(torch.bfloat16)            # NHWC rows of width ldx; the conv reads channels [0, cin)
+    du = torch.randn(n, h, w, cout, generator=g).to(dev).to(torch.bfloat16)
+    xs = xfull[..., :cvalid].float().permute(0, 3, 1, 2).double()
+    want = torch.nn.grad.conv2d_weight(xs, (cout, cvalid, 3, 3), du.float().permute(0, 3, 1, 2).double(), stride=1, padding=1)      # [o, c, ky, kx]
+    got = {}
+    for on in (1, 0):
+        was = capi.lib().ly_tune_wgrad3(on)
+        try:
+            dw = torch.zeros(cout, 3, 3, cin, dtype=torch.float32, device=dev)             # tap-major storage [o][ky][kx][c]
+            ops.wgrad(M=n * h * w, H=h, W=w, N=cout, du=du, lddu=cout, x=xfull, ldx=ldx, Hin=h, Win=w, Cin=cin, dw=dw, lddw=9 * cin, ks=3, stride=1, pad=1,
+                      c_valid=cvalid)
+            ops.wgrad(M=n * h * w, H=h, W=w, N=cout, du=du, lddu=cout, x=xfull, ldx=ldx, Hin=h, Win=w, Cin=cin, dw=dw, lddw=9 * cin, ks=3, stride=1, pad=1,
+                      c_valid=cvalid)                                                     # accumulates: twice the gradient
+            torch.cuda.synchronize()
+            got[on] = dw.permute(0, 3, 1, 2)[:, :cvalid].double() / 2
+            assert float(dw[..., cvalid:].abs().max()) == 0.0 if cvalid < cin else True   # padded channels untouched
+        finally:
+            capi.lib().ly_tune_wgrad3(was)
+    scale = float(want.abs().max())
+    for on in (1, 0):
+        assert float((got[on] - want).abs().max()) <= 2e-3 * scale, (on, float((got[on] - want).abs().max()), scale)      # bf16 products, fp32 sums
+    assert float((got[1] - got[0]).abs().max()) <= 5e-4 * scale

@@ -28,14 +28,30 @@ class GradReducer:
         self.average = average
         self.params = [p for p in params if p.requires_grad]
         order = list(reversed(self.params))                       # backward order ~ reverse registration order
+        # two weights whose gradients ONE kernel writes as a stacked matrix (`p._ly_grad_pair = q`, C3_CA's cv1 / cv2) sit next to each other,
+        # p first — the layout optim.FusedSGD gives them on one GPU; without it the data-parallel step lost the stacked weight gradient
+        mine = {id(p) for p in self.params}
+        partner_of = {id(p._ly_grad_pair): p for p in self.params if getattr(p, "_ly_grad_pair", None) is not None and id(p._ly_grad_pair) in mine}
+        seen, paired = set(), []
+        for p in order:
+            if id(p) in seen:
+                continue
+            first = partner_of.get(id(p), p)                      # p is somebody's partner: emit (that one, p)
+            q = getattr(first, "_ly_grad_pair", None)
+            group = [first, q] if (q is not None and id(q) in mine and q.shape == first.shape and q.dtype == first.dtype) else [p]
+            for t in group:
+                seen.add(id(t))
+            paired.append(group)
+        order = paired
         self.buckets = []                                         # list of dict(params, flat, views)
         cur, cur_bytes, cap = [], 0, first_bucket_bytes           # small first bucket => earliest possible launch
-        for p in order:
-            nb = p.numel() * p.element_size()
+        for group in order:
+            nb = sum(p.numel() * p.element_size() for p in group)
+            p = group[0]
             if cur and (cur_bytes + nb > cap or p.dtype != cur[0].dtype or p.device != cur[0].device):
                 self._close(cur)
                 cur, cur_bytes, cap = [], 0, bucket_bytes
-            cur.append(p)
+            cur.extend(group)
             cur_bytes += nb
         if cur:
             self._close(cur)
@@ -60,7 +76,13 @@ class GradReducer:
         flat = torch.zeros(n, dtype=plist[0].dtype, device=plist[0].device)
         views, off = [], 0
         for p in plist:
-            v = flat[off:off + p.numel()].view_as(p)
+            if getattr(p, "_ly_tap_major", False) and p.dim() == 4 and p.shape[2] * p.shape[3] > 1:
+                # k x k convolution weight: the slice is laid out [cout][kh][kw][cin] (what the weight-gradient kernels write with unit
+                # stride) and exposed as a permuted view of the parameter's shape; an all-reduce is elementwise, the layout is its own business
+                co, ci, kh, kw = p.shape
+                v = flat[off:off + p.numel()].view(co, kh, kw, ci).permute(0, 3, 1, 2)
+            else:
+                v = flat[off:off + p.numel()].view_as(p)
             p.grad = v                                            # gradient_as_bucket_view: autograd accumulates in place
             views.append(v)
             off += p.numel()

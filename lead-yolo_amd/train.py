@@ -163,6 +163,7 @@ class GraphedTrainStep:
         self.imgs, self.targets = imgs.clone(), targets.clone()
         self.model, self.optimizer, self.ema, self.reducer, self.max_norm = model, optimizer, ema, reducer, max_norm
         self.accumulate, self._micro, self.stepped = max(int(accumulate), 1), 0, False
+        self.probe = None
         args = dict(ema=ema, amp=amp, max_norm=max_norm, reducer=reducer, world_size=world_size)
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream(device=imgs.device)
@@ -255,6 +256,10 @@ class GraphedTrainStep:
             with torch.cuda.stream(comm):
                 for bi in self._marked:                    # released from the middle of the running graph, bucket by bucket
                     capi.check(lib.ly_stream_wait_event(capi._P(comm.cuda_stream), self._events[bi]), "ly_stream_wait_event")
+                    if self.probe is not None:             # tools/dp_overlap_probe.py: when was the bucket released / its exchange queued
+                        ev = torch.cuda.Event(enable_timing=True)
+                        ev.record(comm)
+                        self.probe.append((bi, ev))
                     red.exchange(bi)
                 if self._unmarked:                         # buckets no gradient event completed (unused parameters): after the graph
                     comm.wait_stream(cur)

@@ -9,7 +9,6 @@ import torch
 import torch.distributed as dist
 import bench as B
 import lead_yolo_amd as L
-from torch.profiler import profile, ProfilerActivity
 
 bs = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 dev = torch.device("cuda:0")
@@ -28,27 +27,42 @@ print(f"buckets {len(red.buckets)}: {len(step._marked)} released from events ins
 for _ in range(3):
     step()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
-    step()
+# HIP events: start of graph A, end of graph A (before the exchange wait), release time of every bucket on the communication stream
+rows = []
+for _ in range(5):
+    step.probe = []
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    # (the step's own code path, with an end-of-graph-A event in between)
+    step._load(None, None)
+    step.optimizer._sync_hyper()
+    step.graph.replay()
+    e1.record()
+    step._micro += 1
+    from lead_yolo_amd import capi, pack
+    lib, cur, comm = capi.lib(), torch.cuda.current_stream(), step._comm
+    with torch.cuda.stream(comm):
+        for bi in step._marked:
+            capi.check(lib.ly_stream_wait_event(capi._P(comm.cuda_stream), step._events[bi]), "wait")
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(comm)
+            step.probe.append((bi, ev))
+            red.exchange(bi)
+    red.wait_works()
+    cur.wait_stream(comm)
+    step.opt_graph.replay()
+    pack.touch_weights()
+    step._micro = 0
+    e2 = torch.cuda.Event(enable_timing=True)
+    e2.record()
     torch.cuda.synchronize()
-evs = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
-evs.sort(key=lambda e: e.time_range.start)
-t0 = evs[0].time_range.start
-ly = [e for e in evs if "ly_" in e.name]
-if not any("ly_optim" in e.name for e in ly):
-    import collections
-    print("no ly_optim kernel in the device trace; names seen:", collections.Counter(e.name[:50] for e in evs).most_common(12))
-    sys.exit(0)
-opt_start = next(e.time_range.start for e in ly if "ly_optim" in e.name)
-a_end = max(e.time_range.end for e in ly if e.time_range.start < opt_start)
-print(f"graph A kernels span 0 .. {(a_end - t0) / 1e3:.3f} ms; optimiser starts at {(opt_start - t0) / 1e3:.3f} ms; {len(evs)} device events")
-n = 0
-for e in evs:
-    nm = e.name
-    if "ccl" in nm.lower() or "allreduce" in nm.lower() or "AllReduce" in nm:
-        n += 1
-        s = (e.time_range.start - t0) / 1e3
-        print(f"  exchange kernel {n}: starts at {s:.3f} ms ({'INSIDE' if e.time_range.start < a_end else 'after'} graph A), {e.device_time:.1f} us   {nm[:70]}")
-if not n:
-    print("  (no RCCL kernel appeared in the device trace: a one-rank all-reduce is elided by the library; the host-side release path still ran)")
+    rows.append((e0.elapsed_time(e1), e0.elapsed_time(e2), [(bi, e0.elapsed_time(ev)) for bi, ev in step.probe]))
+a_ms, all_ms, rel = rows[-1]
+print(f"graph A (forward + backward) runs 0 .. {a_ms:.3f} ms; the step (A, exchange, optimiser graph B) ends at {all_ms:.3f} ms")
+for bi, t in rel:
+    nb = red.buckets[bi]["flat"].numel() * 4
+    print(f"  bucket {bi} ({nb / 1e6:.2f} MB, {len(red.buckets[bi]['params'])} tensors): released + all-reduce queued at {t:.3f} ms = {100 * t / a_ms:.0f} % of graph A"
+          f" -> {a_ms - t:.3f} ms of backward still to run")
+inside = sum(1 for _, t in rel if t < a_ms)
+print(f"{inside} of {len(rel)} buckets released while graph A was still executing (one rank: the RCCL calls are issued, the wire is trivial)")
 dist.destroy_process_group()

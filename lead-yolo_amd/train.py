@@ -10,6 +10,7 @@ The optimiser is optim.FusedSGD on the GPU (clip + SGD-nesterov + zero_grad + EM
 """
 import ctypes
 import math
+import os
 from copy import deepcopy
 
 import torch
@@ -177,7 +178,7 @@ class GraphedTrainStep:
         self.opt_graph = None
         self._events, self._marked, self._unmarked, self._comm = [], [], [], None
         pack.touch_weights()                   # the captured step must begin with the (single) refresh of every packed weight image
-        if reducer is None and self.accumulate == 1:
+        if reducer is None and self.accumulate == 1 and not os.environ.get("LY_SPLIT_GRAPHS"):
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self.loss, self.items = train_step(model, compute_loss, optimizer, self.imgs, self.targets, ema=ema, amp=amp, max_norm=max_norm)
         else:
@@ -192,10 +193,16 @@ class GraphedTrainStep:
                     self._events.append(ev)
                 self._comm = torch.cuda.Stream(device=imgs.device)
 
+                self._recorded = set()
+                stride = max(int(os.environ.get("LY_DP_MARK_EVERY", "1")), 1)
+
                 def mark(bi):
                     # runs inside the captured backward (autograd's thread, capture stream current): an event-record node behind everything
-                    # captured so far, i.e. behind the kernel that wrote the bucket's last gradient
-                    capi.check(lib.ly_event_record(self._events[bi], capi.stream_ptr()), "ly_event_record")
+                    # captured so far, i.e. behind the kernel that wrote the bucket's last gradient.  (LY_DP_MARK_EVERY = k: a node only at
+                    # every k-th completed bucket — the buckets in between are released by the next node or after the graph)
+                    if len(reducer._mark_order) % stride == stride - 1:
+                        capi.check(lib.ly_event_record(self._events[bi], capi.stream_ptr()), "ly_event_record")
+                        self._recorded.add(bi)
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 if reducer is not None:
                     reducer.begin_marks(mark)
@@ -254,16 +261,22 @@ class GraphedTrainStep:
         if self.reducer is not None:
             lib, red, cur, comm = capi.lib(), self.reducer, torch.cuda.current_stream(), self._comm
             with torch.cuda.stream(comm):
+                held = []
                 for bi in self._marked:                    # released from the middle of the running graph, bucket by bucket
+                    held.append(bi)
+                    if bi not in self._recorded:
+                        continue                           # no node of its own: goes out with the next recorded bucket
                     capi.check(lib.ly_stream_wait_event(capi._P(comm.cuda_stream), self._events[bi]), "ly_stream_wait_event")
-                    if self.probe is not None:             # tools/dp_overlap_probe.py: when was the bucket released / its exchange queued
-                        ev = torch.cuda.Event(enable_timing=True)
-                        ev.record(comm)
-                        self.probe.append((bi, ev))
-                    red.exchange(bi)
-                if self._unmarked:                         # buckets no gradient event completed (unused parameters): after the graph
+                    for bj in held:
+                        if self.probe is not None:         # tools/dp_overlap_probe.py: when was the bucket released / its exchange queued
+                            ev = torch.cuda.Event(enable_timing=True)
+                            ev.record(comm)
+                            self.probe.append((bj, ev))
+                        red.exchange(bj)
+                    held = []
+                if self._unmarked or held:                 # buckets no gradient event completed (unused parameters) / behind the last node: after the graph
                     comm.wait_stream(cur)
-                    for bi in self._unmarked:
+                    for bi in held + list(self._unmarked):
                         red.exchange(bi)
             red.wait_works()                               # the step's stream waits for RCCL's
             cur.wait_stream(comm)

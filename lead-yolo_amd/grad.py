@@ -998,7 +998,7 @@ def _rfcbam_backward_rc(ctx, du, dgo, dbo):
     xb = xr.element_size() * (n * h * w * c + mo * o)
     tn = ops._tname(xr)
     # A: d_rfa (one slab per channel chunk), d_ca
-    with ops._Timed(f"ly_rf3c_bwd_kernel<A, {o // 32}>", 2.0 * mo * 9 * c * (o + 81), xb):
+    with ops._Timed(f"ly_rf3c_bwd_kernel<0, {o // 32}>", 2.0 * mo * 9 * c * (o + 81), xb):
         L.check(L.lib().ly_rf3c_bwd(ctypes.byref(P), 0, st), "ly_rf3c_bwd A")
     # conv weight gradient (independent of the chain below)
     with ops._Timed("ly_rf3c_wgrad_kernel", 2.0 * mo * 9 * c * (o + 81), xb):
@@ -1017,7 +1017,7 @@ def _rfcbam_backward_rc(ctx, du, dgo, dbo):
         ops.grad_done(ctx.getw_param)
     P.d_mm = p(d_mm)
     # B: BatchNorm sums, one stripe per image
-    with ops._Timed(f"ly_rf3c_bwd_kernel<B, {o // 32}>", 2.0 * mo * 9 * c * (o + 81), xb):
+    with ops._Timed(f"ly_rf3c_bwd_kernel<1, {o // 32}>", 2.0 * mo * 9 * c * (o + 81), xb):
         L.check(L.lib().ly_rf3c_bwd(ctypes.byref(P), 1, st), "ly_rf3c_bwd B")
     dgg_tc, dbg_tc, alpha, kappa, lam = ops.bn_bwd_coeffs(sums, 9 * c, mo, ag, gmean_tc, ginv_tc, True)
     P.coef = p(alpha)                          # alpha, kappa, lambda are rows 2..4 of one [5, 9c] tensor
@@ -1036,7 +1036,7 @@ def _rfcbam_backward_rc(ctx, du, dgo, dbo):
     P.dgap = p(dgap)
     P.TH, P.TW = ops.pick_tile_bwd_dx(ho, wo, o)          # pass C walks its pixel pairs in four colours: its own tile choice
     # C: generate weight gradient rows + dx
-    with ops._Timed(f"ly_rf3c_bwd_kernel<C, {o // 32}>", 2.0 * mo * 9 * c * (o + 243), xb + xr.element_size() * n * h * w * c):
+    with ops._Timed(f"ly_rf3c_bwd_kernel<2, {o // 32}>", 2.0 * mo * 9 * c * (o + 243), xb + xr.element_size() * n * h * w * c):
         L.check(L.lib().ly_rf3c_bwd(ctypes.byref(P), 2, st), "ly_rf3c_bwd C")
     dbias = None if ops.grad_target(ctx.conv_b_param) is not None else torch.zeros_like(bias)      # BN removes the batch mean: d/dbias = 0
     return (None, dx if need_dx else None, None if se_direct else dwa, None if se_direct else dwb, ops.sum_rows(dwg).view(gen_w.shape), ct(dgg_tc), ct(dbg_tc),

@@ -359,7 +359,7 @@ def rf3c_stats(x, ldx, n, h, w, c, s, wq, th, tw, gap=True, raw=False):
     mm = torch.empty((n, 3 * ho, 3 * wo, 2), dtype=torch.float32, device=x.device)
     tiles = -(-ho // th) * -(-wo // tw)
     part = torch.empty((n, tiles, c), dtype=torch.float32, device=x.device) if gap else None
-    with _Timed(f"ly_rf3c_stats_kernel<{_tname(x)}>", 2.0 * n * ho * wo * c * 81, x.element_size() * n * h * w * c + 4.0 * 18 * n * ho * wo):
+    with _Timed(f"ly_rf3c_stats_kernel<{_tname(x)}, {s}, {'true' if raw else 'false'}>", 2.0 * n * ho * wo * c * 81, x.element_size() * n * h * w * c + 4.0 * 18 * n * ho * wo):
         capi.check(capi.lib().ly_rf3c_stats(_p(x), ldx, n, h, w, c, s, _p(wq), int(raw), th, tw, _p(mm), _p(part), tiles, capi.dtype_code(x),
                                             capi.stream_ptr()), "ly_rf3c_stats")
     return mm, part
@@ -371,7 +371,7 @@ def rf3c_fwd(*, n, h, w, c, ho, wo, N, s, th, tw, x, ldx, wq, ca, rfa, wp, e_sca
     mo = n * ho * wo
     bf = x.dtype == torch.bfloat16
     cfg = "2, 8" if (N > 128 and bf) else ("2, 4" if N > 64 else "1, 4")         # mirrors rc_dispatch_fwd
-    with _Timed(f"ly_rf3c_fwd_kernel<{_tname(x)}, {cfg}>", 2.0 * mo * (9 * c * N + 81 * c),
+    with _Timed(f"ly_rf3c_fwd_kernel<{_tname(x)}, {cfg}, {s}, {'true' if raw else 'false'}>", 2.0 * mo * (9 * c * N + 81 * c),
                 x.element_size() * (n * h * w * c + mo * N) + 4.0 * 9 * c * N):
         capi.check(capi.lib().ly_rf3c_fwd(ctypes.byref(P), _p(wq), int(raw), capi.stream_ptr()), "ly_rf3c_fwd")
 

@@ -1,5 +1,6 @@
 """Per-kernel micro-benchmarks on the real lead-yolo-s layer shapes.  Dev tool.
-    python tools/kernel_bench.py [batch=32] [all|gemm|conv|mlp|rf|c3|patch] [f32|bf16]"""
+    python tools/kernel_bench.py [batch=32] [all|gemm|conv|mlp|rf|c3|patch|sweep] [f32|bf16]
+(`sweep`: the L12.cv3 GEMM over batch 1..256 — fixed vs per-tile cost)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -96,3 +97,8 @@ if which in ("all", "c3"):
 if which in ("all", "patch"):
     module_case("patchembed 3->24 640", L.PatchEmbed_FasterNet(3, 24, 4, 4), (B, 3, 640, 640), 2.0 * B * 25600 * 48 * 24)
     module_case("patchmerge 24->40 160", L.PatchMerging_FasterNet(24, 40, 2, 2), (B, 24, 160, 160), 2.0 * B * 6400 * 96 * 40)
+
+if which == "sweep":
+    for b in (1, 2, 4, 8, 16, 32, 64, 128, 256):
+        B = b
+        gemm_case(f"B={b} L12.cv3", 40, 256, 256)

@@ -842,6 +842,44 @@ __global__ __launch_bounds__(LY_THREADS) void ly_coordatt_conv1_stats_kernel(con
   float a1 = 0.f, a2 = 0.f;
   const float bm = lane < mip ? b1[lane] : 0.f;
   const long nw = (long)gridDim.x * 4;
+  if (MIPMAX <= 16 && C <= 256) {
+    // the lane's weights stay in registers over all positions, and two positions per trip have all their loads issued before the first use
+    // (the one-position loop re-read w1 and paid a dependent round trip per position: 23 us for 2.6 MB)
+    constexpr int KC = 4;
+    float wreg[KC][MIPMAX];
+#pragma unroll
+    for (int k = 0; k < KC; ++k)
+#pragma unroll
+      for (int m = 0; m < MIPMAX; ++m) wreg[k][m] = (m < mip && lane + 64 * k < C) ? w1[m * C + lane + 64 * k] : 0.f;
+    constexpr int UP = 2;
+    for (long pos0 = (long)blockIdx.x * 4 + wave; pos0 < positions; pos0 += UP * nw) {
+      float pv[UP][KC];
+#pragma unroll
+      for (int u = 0; u < UP; ++u) {
+        const long pos = pos0 + u * nw < positions ? pos0 + u * nw : positions - 1;
+#pragma unroll
+        for (int k = 0; k < KC; ++k) pv[u][k] = lane + 64 * k < C ? pool[pos * C + lane + 64 * k] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < UP; ++u) {
+        const bool live = pos0 + u * nw < positions;
+        float y[MIPMAX];
+#pragma unroll
+        for (int m = 0; m < MIPMAX; ++m) {
+          y[m] = 0.f;
+#pragma unroll
+          for (int k = 0; k < KC; ++k) y[m] += wreg[k][m] * pv[u][k];
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) y[m] += __shfl_xor(y[m], o);
+          if (lane == m && live) {
+            const float v = y[m] + bm;
+            a1 += v;
+            a2 += v * v;
+          }
+        }
+      }
+    }
+  } else {
   for (long pos = (long)blockIdx.x * 4 + wave; pos < positions; pos += nw) {
     const float* p = pool + pos * C;
     float y[MIPMAX];
@@ -863,6 +901,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_coordatt_conv1_stats_kernel(con
         a2 += v * v;
       }
     }
+  }
   }
   if (lane < mip) { red[wave][lane] = a1; red[wave][MIPMAX + lane] = a2; }
   __syncthreads();
@@ -1185,25 +1224,43 @@ __global__ __launch_bounds__(LY_THREADS) void ly_coordatt_mlp_bwd2_kernel(
   for (int e = 0; e < NA; ++e) acc[e] = 0.f;
   const long r_lo = (long)blockIdx.y * rows_per_block;
   const long r_hi = r_lo + rows_per_block < R ? r_lo + rows_per_block : R;
-  for (long r = r_lo + wave; r < r_hi; r += 4) {
-    const int pos = (int)(r % L);
-    const bool isrow = pos < H;
-    const float* wr = ws + r * 3 * MIP;                    // wave-uniform row: (dy1, xh, y2)
-    const float pv = cok ? pool[r * C + c] : 0.f;
-    const float dz = cok ? dpool[r * C + c] : 0.f;
-    float g = 0.f;
+  // four rows per trip, every load of the trip issued before the first use (the one-row loop paid a dependent round trip per row: 47 us
+  // for 2.6 MB of pooled vectors); rows past the block's range re-read its last row and are masked
+  constexpr int UR = 4;
+  for (long r0 = r_lo + wave; r0 < r_hi; r0 += 4 * UR) {
+    float pv[UR], dz[UR], wv[UR][3 * MIP];
+    bool live[UR];
 #pragma unroll
-    for (int m = 0; m < MIP; ++m) {
-      const float dy0 = k0[m] * (wr[m] - m1[m] - wr[MIP + m] * m2[m]);
-      const float t = dz * wr[2 * MIP + m];
-      g += dy0 * w1r[m];
-      acc[m] += dy0 * pv;
-      acc[MIP + m] += isrow ? t : 0.f;
-      acc[2 * MIP + m] += isrow ? 0.f : t;
+    for (int u = 0; u < UR; ++u) {
+      const long rr = r0 + 4 * u;
+      live[u] = rr < r_hi;
+      const long r = live[u] ? rr : r_hi - 1;
+      const float* wr = ws + r * 3 * MIP;                  // wave-uniform row: (dy1, xh, y2)
+#pragma unroll
+      for (int m = 0; m < 3 * MIP; ++m) wv[u][m] = wr[m];
+      pv[u] = cok ? pool[r * C + c] : 0.f;
+      dz[u] = cok ? dpool[r * C + c] : 0.f;
     }
-    acc[3 * MIP] += isrow ? dz : 0.f;
-    acc[3 * MIP + 1] += isrow ? 0.f : dz;
-    if (cok) dpool[r * C + c] = g;
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      const long r = r0 + 4 * u;
+      const int pos = (int)(r % L);
+      const bool isrow = pos < H;
+      const float dzu = live[u] ? dz[u] : 0.f, pvu = live[u] ? pv[u] : 0.f;
+      float g = 0.f;
+#pragma unroll
+      for (int m = 0; m < MIP; ++m) {
+        const float dy0 = live[u] ? k0[m] * (wv[u][m] - m1[m] - wv[u][MIP + m] * m2[m]) : 0.f;
+        const float t = dzu * wv[u][2 * MIP + m];
+        g += dy0 * w1r[m];
+        acc[m] += dy0 * pvu;
+        acc[MIP + m] += isrow ? t : 0.f;
+        acc[2 * MIP + m] += isrow ? 0.f : t;
+      }
+      acc[3 * MIP] += isrow ? dzu : 0.f;
+      acc[3 * MIP + 1] += isrow ? 0.f : dzu;
+      if (cok && live[u]) dpool[r * C + c] = g;
+    }
   }
 #pragma unroll
   for (int e = 0; e < NA; ++e) red[(wave * 64 + lane) * NA + e] = acc[e];
@@ -1236,7 +1293,7 @@ static void launch_coordatt_bwd(hipStream_t st, const float* pool, int n_img, in
   hipLaunchKernelGGL((ly_coordatt_mlp_bwd1_kernel<MIP, NS>), dim3((unsigned)b1n), dim3(LY_THREADS), 0, st, pool, n_img, H, W, C, w1, b1, mean, invstd, gamma,
                      beta, wh, ww, a_h, a_w, da_h, da_w, ws, sums, dpool);
   const int groups = (C + 63) / 64;
-  long chunks = (256 + groups - 1) / groups;               // ~256 blocks; each target address then receives `chunks` adds
+  long chunks = (96 + groups - 1) / groups;                // ~96 blocks; each target address then receives `chunks` same-address adds
   if (chunks > (R + 31) / 32) chunks = (R + 31) / 32;
   if (chunks < 1) chunks = 1;
   const long rpb = (R + chunks - 1) / chunks;

@@ -1034,25 +1034,42 @@ __global__ __launch_bounds__(LY_THREADS) void ly_coordatt_gate_bwd_kernel(const 
   const int band = bb - (int)n * bands;
   const int w0 = slab * groups * LY_CAG_MAXW;
   const int h_lo = band * LY_CAG_RB, h_hi = h_lo + LY_CAG_RB < H ? h_lo + LY_CAG_RB : H;
-  f32x4 accw[LY_CAG_MAXW];
+  f32x4 accw[LY_CAG_MAXW], aw[LY_CAG_MAXW];
+  bool okw[LY_CAG_MAXW];
+  int wcl[LY_CAG_MAXW];
+  // the thread's columns are the same for every row of the band: their a_w factors are loaded once; per row all 16 row loads are issued from
+  // clamped addresses before the first use (they sat under a per-column branch: one exposed round trip per column)
+  const bool gok = g0 < groups;
 #pragma unroll
-  for (int i = 0; i < LY_CAG_MAXW; ++i) accw[i] = ly_zero4();
+  for (int i = 0; i < LY_CAG_MAXW; ++i) {
+    accw[i] = ly_zero4();
+    const int w = w0 + g0 + i * groups;
+    okw[i] = gok && w < W;
+    wcl[i] = okw[i] ? w : (w0 < W ? w0 : 0);
+    aw[i] = ly_ldg4(a_w + (n * W + wcl[i]) * C + 4 * (gok ? c4 : 0));
+  }
+  using R4 = typename LyT<T>::R4;
   for (int h = h_lo; h < h_hi; ++h) {
     const long nh = n * H + h;
     f32x4 sh = ly_zero4();
-    if (g0 < groups) {
-      const f32x4 ah = ly_ldg4(a_h + nh * C + 4 * c4);
+    {
+      const int c4c = gok ? c4 : 0;
+      const f32x4 ah = ly_ldg4(a_h + nh * C + 4 * c4c);
+      R4 dr[LY_CAG_MAXW], xr[LY_CAG_MAXW];
 #pragma unroll
       for (int i = 0; i < LY_CAG_MAXW; ++i) {
-        const int w = w0 + g0 + i * groups;
-        if (w < W) {
-          const long row = nh * W + w;
-          const f32x4 d = ly_ld4<T>(dout + row * ldd + 4 * c4);
-          const f32x4 xv = ly_ld4<T>(x + row * ldx + 4 * c4);
-          const f32x4 aw = ly_ldg4(a_w + (n * W + w) * C + 4 * c4);
-          ly_st4<T>(dx + row * lddx + 4 * c4, d * ah * aw);
+        const long row = nh * W + wcl[i];
+        dr[i] = ly_ldr4<T>(dout + row * ldd + 4 * c4c);
+        xr[i] = ly_ldr4<T>(x + row * ldx + 4 * c4c);
+      }
+#pragma unroll
+      for (int i = 0; i < LY_CAG_MAXW; ++i) {
+        if (okw[i]) {
+          const long row = nh * W + wcl[i];
+          const f32x4 d = ly_r4_f32(dr[i]), xv = ly_r4_f32(xr[i]);
+          ly_st4<T>(dx + row * lddx + 4 * c4, d * ah * aw[i]);
           const f32x4 t = d * xv;
-          sh += t * aw;
+          sh += t * aw[i];
           accw[i] += t * ah;
         }
       }

@@ -433,6 +433,26 @@ typedef struct LyPackDesc {
 } LyPackDesc;
 int ly_pack_table(const LyPackDesc* table, const int* blk_desc, int n_blocks, void* stream);
 
+/* ---- RFCBAMConv kernel_size 1 backward, fused recompute passes (models/rfa.py:113-129 with k = 1: `generate` is a per-channel scale +
+ * BatchNorm + ReLU, so G is recomputed from x wherever it is needed instead of being materialised) --------------------------------------
+ * x [n_img*HW][C] rows (stride ldx), dcd [n_img*HW][C] dense = d(loss)/d(conv input) (du . Wc^T), gw / ag / bg [C] = generate.0.weight and the
+ * generate BatchNorm's batch scale / shift, ca [n_img][C], rfa [n_img*HW].
+ *   pass 0: cd = G*ca*rfa (T, dense [.][C]: the conv weight gradient's operand), d_rfa[p], gmax_out[p] = max_c G, d_ca[n][c] += (zeroed by caller)
+ *   pass 1: BatchNorm sums of dv into `sums` [LY_STATS_STRIPES][2C] (zeroed by caller); needs gmax (= pass 0's gmax_out) and d_mm [p][2]
+ *   pass 2: du = alpha*dv + kappa + lambda*u;  dgw[c] += sum_p du*x (atomic);  dx = du*gw + dgap[n][c]*dgap_scale (dgap may be NULL)      */
+typedef struct LyRf1BwdParams {
+  int n_img; long HW; int C;
+  const void* x; int ldx;          /* T */
+  const void* dcd;                 /* T, dense */
+  const float* gw; const float* ag; const float* bg; const float* ca; const float* rfa;
+  void* cd; float* d_rfa; float* gmax_out; float* d_ca;                 /* pass 0 outputs */
+  const float* gmax; const float* d_mm; float* sums;                    /* pass 1 (gmax / d_mm also pass 2) */
+  const float* alpha; const float* kappa; const float* lambda; const float* dgap; float dgap_scale;
+  void* dx; int lddx; float* dgw;                                       /* pass 2 outputs */
+  int dtype;
+} LyRf1BwdParams;
+int ly_rf1_bwd(const LyRf1BwdParams* p, int pass, void* stream);
+
 /* ---- detection loss on device (utils/loss.py:121-268 ComputeLoss / build_targets, utils/metrics.py:293-354 EIoU) --------
  * One pyramid level, forward and gradient (no focal loss): anchor matching with the reference's candidate order
  * (offset k, anchor a, target t), EIoU box loss with analytic gradient, per-cell "last writer wins" objectness target (the

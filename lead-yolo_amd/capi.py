@@ -45,6 +45,12 @@ class LyRf3cBwdParams(ctypes.Structure):
                 ("dgap_scale", _F), ("dwc_part", _P), ("ng", _I), ("dtype", _I)]
 
 
+class LyRf1BwdParams(ctypes.Structure):
+    _fields_ = [("n_img", _I), ("HW", _L), ("C", _I), ("x", _P), ("ldx", _I), ("dcd", _P), ("gw", _P), ("ag", _P), ("bg", _P), ("ca", _P), ("rfa", _P),
+                ("cd", _P), ("d_rfa", _P), ("gmax_out", _P), ("d_ca", _P), ("gmax", _P), ("d_mm", _P), ("sums", _P),
+                ("alpha", _P), ("kappa", _P), ("lambda_", _P), ("dgap", _P), ("dgap_scale", _F), ("dx", _P), ("lddx", _I), ("dgw", _P), ("dtype", _I)]
+
+
 class LyOptTensor(ctypes.Structure):
     _fields_ = [("p", _P), ("g", _P), ("buf", _P), ("ema", _P), ("n", _L), ("wd", _F), ("group", _I), ("taps", _I), ("cin", _I)]
 
@@ -142,6 +148,7 @@ SIGNATURES = {
     "ly_pack_table": [_P, _P, _I, _P],
     "ly_optim_step": [_P, _P, _P, _I, _P, _P, _P, _P],
     "ly_sum_rows": [_P, _L, _L, _L, _P, _I, _P],
+    "ly_rf1_bwd": [ctypes.POINTER(LyRf1BwdParams), _I, _P],
     "ly_tune_wgrad3": [_I],
     "ly_event_create": [ctypes.POINTER(_P)],
     "ly_event_destroy": [_P],

@@ -894,6 +894,8 @@ class RfcbamFn(torch.autograd.Function):
             # layer 17, o = 128: 0.95 vs 1.47 ms.  The wider layer stays on the first-generation backward.)
             if ctx.rc is not None and dt == torch.bfloat16 and s == 2 and o in (64, 128) and RC_BWD:
                 return RfcbamFn._backward_rc(ctx, du, dgo, dbo)
+            if k == 1 and RF1_BWD and c % ops.vw_of(xr) == 0 and c // ops.vw_of(xr) <= 64 and ld % ops.vw_of(xr) == 0:
+                return RfcbamFn._backward_k1(ctx, du, dgo, dbo)
             # 3. dcd [mo][t][c]
             # Wc^T with rows (t, c): conv.0.weight [o, c, kh, kw] read in place
             dcd = torch.empty((mo, kk * c), dtype=dt, device=dev)
@@ -1044,6 +1046,86 @@ def _rfcbam_backward_rc(ctx, du, dgo, dbo):
 
 
 RfcbamFn._backward_rc = staticmethod(_rfcbam_backward_rc)
+
+
+def _rfcbam_backward_k1(ctx, du, dgo, dbo):
+    """RFCBAMConv kernel_size 1 backward on the fused recompute passes (csrc/ly_rf1_bwd.hip): G = relu(bn(gw*x)) is recomputed from x in
+    every pass, nothing the size of the input is stored except cd (the conv weight gradient's operand) and dx.  du: gradient of the conv
+    output (after the output BatchNorm / ReLU backward)."""
+    xr, ca, gen_w, getw, conv_w, bias, ag, bg, gmean_tc, ginv_tc, es, t, omean, oinv, mm, rfa, se_part, u = ctx.saved_tensors
+    n, c, h, w, k, s, o, ho, wo, ld = ctx.geom
+    dev, dt = xr.device, xr.dtype
+    L = _lib()
+    st, p = L.stream_ptr(), L.ptr
+    mo = n * h * w
+    pl = ops.planes_of(xr)
+    # d(loss)/d(conv input): du . Wc^T, Wc^T read in place from conv.0.weight
+    dcd = torch.empty((mo, c), dtype=dt, device=dev)
+    wct = pack.packed(pack.Src(ctx.conv_w_param, c, nrb=c, sra=1, srb=1, nc=o, sc=c), o, pl)
+    ops.gemm(M=mo, H=h, W=w, K=o, N=c, a0=du, lda0=o, k0=o, wp=wct, out=dcd, ldo=c)
+    gw = gen_w.detach().float().reshape(c).contiguous()
+    cd = torch.empty((mo, c), dtype=dt, device=dev)
+    zz = ops.zeros_f32(ca.numel(), dev)
+    d_ca = zz.view_as(ca)
+    d_rfa = torch.empty(rfa.numel(), dtype=torch.float32, device=dev)
+    gmax = torch.empty(rfa.numel(), dtype=torch.float32, device=dev)
+    dx = ops.empty_nhwc(n, c, h, w, xr) if ctx.needs_input_grad[1] else ops.empty_nhwc(n, c, h, w, xr)
+    tgw = ops.grad_target(ctx.gen_w_param) if getattr(ctx, "gen_w_param", None) is not None else None
+    tgw = tgw if tgw is not None and tgw.is_contiguous() else None
+    dgw = tgw.view(-1) if tgw is not None else torch.zeros(c, dtype=torch.float32, device=dev)
+    P = L.LyRf1BwdParams(n, h * w, c, p(xr), ld, p(dcd), p(gw), p(ag), p(bg), p(ca), p(rfa), p(cd), p(d_rfa), p(gmax), p(d_ca),
+                         p(gmax), None, None, None, None, None, None, 1.0 / (h * w), p(dx), c, p(dgw), L.dtype_code(xr))
+    es1 = xr.element_size() * mo * c
+    tn = ops._tname(xr)
+    with ops._Timed(f"ly_rf1_bwd_kernel<{tn}, 0>", 6.0 * mo * c, 3.0 * es1):
+        L.check(L.lib().ly_rf1_bwd(ctypes.byref(P), 0, st), "ly_rf1_bwd A")
+    # conv weight gradient from cd
+    tgt = ops.grad_target(ctx.conv_w_param)
+    if tgt is not None:
+        ops.wgrad(M=mo, H=h, W=w, N=o, du=du, lddu=o, x=cd, ldx=c, Hin=h, Win=w, Cin=c, dw=tgt, lddw=c)
+        ops.grad_done(ctx.conv_w_param)
+        dwc = None
+    else:
+        dwc = torch.zeros(o, c, dtype=torch.float32, device=dev)
+        ops.wgrad(M=mo, H=h, W=w, N=o, du=du, lddu=o, x=cd, ldx=c, Hin=h, Win=w, Cin=c, dw=dwc, lddw=c)
+        dwc = dwc.view(conv_w.shape)
+    # get_weight + sigmoid
+    w18 = getw.detach().float().reshape(18).contiguous()
+    d_mm = torch.empty_like(mm)
+    t18 = ops.grad_target(ctx.getw_param)
+    t18 = t18 if t18 is not None and t18.is_contiguous() else None
+    dw18 = t18.view(-1) if t18 is not None else torch.zeros(18, dtype=torch.float32, device=dev)
+    L.check(L.lib().ly_rfa_bwd(p(d_rfa), p(rfa), p(mm), p(w18), n, h, w, p(d_mm), p(dw18), st), "ly_rfa_bwd")
+    if t18 is not None:
+        ops.grad_done(ctx.getw_param)
+    # BatchNorm sums of the generate BatchNorm
+    sums = ops.new_stats(c, dev)
+    P.d_mm, P.sums = p(d_mm), p(sums)
+    with ops._Timed(f"ly_rf1_bwd_kernel<{tn}, 1>", 8.0 * mo * c, 2.0 * es1):
+        L.check(L.lib().ly_rf1_bwd(ctypes.byref(P), 1, st), "ly_rf1_bwd B")
+    dgg, dbg, alpha, kappa, lam = ops.bn_bwd_coeffs(sums, c, mo, ag, gmean_tc, ginv_tc, True)
+    # SE backward: parameter gradients, and d/d(mean x), which pass C adds while it writes dx
+    se_wa, se_wb = ctx.se_params
+    ta, tb = ops.grad_target(se_wa), ops.grad_target(se_wb)
+    se_direct = ta is not None and tb is not None
+    dwa = ta if se_direct else torch.zeros(se_wa.shape, dtype=torch.float32, device=dev)
+    dwb = tb if se_direct else torch.zeros(se_wb.shape, dtype=torch.float32, device=dev)
+    dgap = ops.se_bwd(se_part, n, h * w, c, se_wa.detach(), se_wb.detach(), se_wa.shape[0], ca, d_ca, dwa, dwb)
+    if se_direct:
+        ops.grad_done(se_wa)
+        ops.grad_done(se_wb)
+    P.alpha, P.kappa, P.lambda_, P.dgap = p(alpha), p(kappa), p(lam), p(dgap)
+    with ops._Timed(f"ly_rf1_bwd_kernel<{tn}, 2>", 10.0 * mo * c, 3.0 * es1):
+        L.check(L.lib().ly_rf1_bwd(ctypes.byref(P), 2, st), "ly_rf1_bwd C")
+    if tgw is not None:
+        ops.grad_done(ctx.gen_w_param)
+    dbias = None if ops.grad_target(ctx.conv_b_param) is not None else torch.zeros_like(bias)      # BN removes the batch mean: d/dbias = 0
+    return (None, dx if ctx.needs_input_grad[1] else None, None if se_direct else dwa, None if se_direct else dwb,
+            None if tgw is not None else dgw.view(gen_w.shape), dgg, dbg, (None if t18 is not None else dw18.view(getw.shape)), dwc, dbias, dgo, dbo)
+
+
+RfcbamFn._backward_k1 = staticmethod(_rfcbam_backward_k1)
+RF1_BWD = True         # tools: False keeps the first-generation k = 1 backward
 RC_BWD = True          # tools: False keeps the first-generation backward behind the lane = channel forward
 def rfcbam_train(mod, x):
     """RFCBAMConv.forward in training: one autograd node (SE, generate BatchNorm, attention maps, contraction)."""

@@ -452,6 +452,10 @@ typedef struct LyRf1BwdParams {
   int dtype;
 } LyRf1BwdParams;
 int ly_rf1_bwd(const LyRf1BwdParams* p, int pass, void* stream);
+/* kernel_size 3, streamed backward (the expanded tensors exist): the attention pass (pass 0) and the ReLU / routing pass (pass 1) with the
+ * same 16-bytes-per-lane layout.  P.x = ug [pixels][9][C] dense, P.dcd [pixels][9][C] (pass 1 overwrites it with dv), ag / bg [9][C],
+ * P.HW = Ho*Wo output pixels per image, rfa / gmax / d_rfa [n][3Ho][3Wo], d_mm [n][3Ho][3Wo][2], sums [LY_STATS_STRIPES][2][9][C] zeroed.   */
+int ly_rf3s_bwd(const LyRf1BwdParams* p, int Ho, int Wo, int pass, void* stream);
 
 /* ---- detection loss on device (utils/loss.py:121-268 ComputeLoss / build_targets, utils/metrics.py:293-354 EIoU) --------
  * One pyramid level, forward and gradient (no focal loss): anchor matching with the reference's candidate order

@@ -149,6 +149,7 @@ SIGNATURES = {
     "ly_optim_step": [_P, _P, _P, _I, _P, _P, _P, _P],
     "ly_sum_rows": [_P, _L, _L, _L, _P, _I, _P],
     "ly_rf1_bwd": [ctypes.POINTER(LyRf1BwdParams), _I, _P],
+    "ly_rf3s_bwd": [ctypes.POINTER(LyRf1BwdParams), _I, _I, _I, _P],
     "ly_tune_wgrad3": [_I],
     "ly_event_create": [ctypes.POINTER(_P)],
     "ly_event_destroy": [_P],

@@ -191,3 +191,171 @@ extern "C" int ly_rf1_bwd(const LyRf1BwdParams* p, int pass, void* stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   return P.dtype == LY_BF16 ? rf1_launch<__bf16>(P, pass, st) : rf1_launch<float>(P, pass, st);
 }
+
+// -------------------------------------------------------------------------------------------------
+// RFCBAMConv kernel_size 3, first-generation (streamed) backward: the attention pass and the ReLU / routing pass over the expanded tensors
+// ug, dcd [pixels][9 taps][C] with the same lane = 16 bytes layout (layer 20: O = 256 keeps the streamed path).  A block owns
+// one image; slot = (pixel slot, tap): a lane's tap is fixed, so its BatchNorm constants and per-tap sums stay in registers.
+//   pass 0 (replaces ly_rf_bwd_attn): cd = G*ca*rfa, d_rfa[pos], gmax[pos] = max_c G, d_ca[n][c] +=      G = relu(ag[t][c]*ug + bg[t][c])
+//   pass 1 (replaces ly_rf_bwd_relu): dv = (dcd*ca*rfa + d_mean/C + [G == gmax] d_max) [G > 0] written over dcd; sums[t][c] += dv, dv*ug
+// pos = position of (pixel, tap) in the [n][3Ho][3Wo] attention maps.
+// -------------------------------------------------------------------------------------------------
+template <typename T, int MODE>
+__global__ __launch_bounds__(576) void ly_rf3s_bwd_kernel(const LyRf1BwdParams P, const int lpp2, const int pp, const int chunk, const int Ho,
+                                                          const int Wo) {
+  constexpr int VW = LyT<T>::VW, NQ = VW / 4;
+  using RV = typename LyT<T>::RV;
+  __shared__ float red[2 * 576 * 8];
+  const int tid = threadIdx.x;
+  const int l = tid & (lpp2 - 1), slot = tid / lpp2;
+  const int t = slot % 9, ps = slot / 9;
+  const int C = P.C, cv = l * VW;
+  const bool lok = cv < C;
+  const int cvc = lok ? cv : 0;
+  const long n = blockIdx.y;
+  const long HW = P.HW;                                        // output pixels per image (Ho * Wo)
+  const long m_lo = (long)blockIdx.x * chunk;                  // within the image
+  const long m_hi = m_lo + chunk < HW ? m_lo + chunk : HW;
+  const T* const ug = reinterpret_cast<const T*>(P.x);         // (x slot of the parameter block: ug)
+  T* const dcd = reinterpret_cast<T*>(const_cast<void*>(P.dcd));
+  f32x4 ag[NQ], bg[NQ], cav[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    ag[q] = ly_ldg4(P.ag + (long)t * C + cvc + 4 * q);
+    bg[q] = ly_ldg4(P.bg + (long)t * C + cvc + 4 * q);
+    cav[q] = ly_ldg4(P.ca + n * C + cvc + 4 * q);
+  }
+  const float invC = 1.f / (float)C;
+  const int ty = t / 3, tx = t - 3 * ty;
+  f32x4 acc1[NQ], acc2[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) { acc1[q] = ly_zero4(); acc2[q] = ly_zero4(); }
+  constexpr int UP = 2;
+  for (long m0 = m_lo + ps; m0 < m_hi; m0 += (long)UP * pp) {
+    RV ur[UP], dr[UP];
+    float rf[UP], gm[UP], dm0[UP], dm1[UP];
+    long pos[UP], row[UP];
+    bool live[UP];
+#pragma unroll
+    for (int u = 0; u < UP; ++u) {
+      const long mm_ = m0 + (long)u * pp;
+      live[u] = mm_ < m_hi;
+      const long ml = live[u] ? mm_ : m_hi - 1;
+      const int ho = (int)(ml / Wo), wo = (int)(ml - (long)ho * Wo);
+      row[u] = ((n * HW + ml) * 9 + t) * C + cvc;
+      pos[u] = ((n * 3 * Ho + 3 * ho + ty) * (3L * Wo)) + 3 * wo + tx;
+      ur[u] = ly_ldrv<T>(ug + row[u]);
+      dr[u] = ly_ldrv<T>(dcd + row[u]);
+      rf[u] = P.rfa[pos[u]];
+      if constexpr (MODE == RF1_B) {
+        gm[u] = P.gmax[pos[u]];
+        dm0[u] = P.d_mm[2 * pos[u]];
+        dm1[u] = P.d_mm[2 * pos[u] + 1];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UP; ++u) {
+      const bool on = live[u] && lok;
+      f32x4 uv[NQ], dv[NQ], ov[NQ];
+      ly_rv_unpack(ur[u], uv);
+      ly_rv_unpack(dr[u], dv);
+      if constexpr (MODE == RF1_A) {
+        float srfa = 0.f, mx = 0.f;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float G = fmaxf(__builtin_fmaf(ag[q][r], uv[q][r], bg[q][r]), 0.f);
+            const float tt = on ? dv[q][r] * G : 0.f;
+            srfa += tt * cav[q][r];
+            mx = fmaxf(mx, on ? G : 0.f);
+            acc1[q][r] += tt * rf[u];
+            ov[q][r] = G * cav[q][r] * rf[u];
+          }
+        for (int o = lpp2 >> 1; o > 0; o >>= 1) {
+          srfa += __shfl_xor(srfa, o);
+          mx = fmaxf(mx, __shfl_xor(mx, o));
+        }
+        if (on) *reinterpret_cast<RV*>(reinterpret_cast<T*>(P.cd) + row[u]) = ly_rv_pack(ov, (RV*)nullptr);
+        if (live[u] && l == 0) { P.d_rfa[pos[u]] = srfa; P.gmax_out[pos[u]] = mx; }
+      } else {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float G = fmaxf(__builtin_fmaf(ag[q][r], uv[q][r], bg[q][r]), 0.f);
+            float dG = dv[q][r] * rf[u] * cav[q][r] + dm1[u] * invC;
+            if (G == gm[u]) dG += dm0[u];
+            const float d = (on && G > 0.f) ? dG : 0.f;
+            acc1[q][r] += d;
+            acc2[q][r] += d * uv[q][r];
+            ov[q][r] = d;
+          }
+        if (on) *reinterpret_cast<RV*>(dcd + row[u]) = ly_rv_pack(ov, (RV*)nullptr);
+      }
+    }
+  }
+  // sums: A: d_ca[n][c] over every slot; B: s1 / s2 per (tap, channel) over the pixel slots of the tap
+  const int CS = lpp2 * VW;
+  constexpr int NQT = MODE == RF1_B ? 2 : 1;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      red[(slot * NQT) * CS + cv + 4 * q + r] = acc1[q][r];
+      if constexpr (MODE == RF1_B) red[(slot * NQT + 1) * CS + cv + 4 * q + r] = acc2[q][r];
+    }
+  __syncthreads();
+  const int nslots = 9 * pp;
+  if constexpr (MODE == RF1_A) {
+    for (int c = tid; c < C; c += blockDim.x) {
+      float s = 0.f;
+      for (int sl = 0; sl < nslots; ++sl) s += red[sl * CS + c];
+      atomicAdd(P.d_ca + n * C + c, s);
+    }
+  } else {
+    float* const sm = P.sums + (size_t)((blockIdx.x + blockIdx.y) & (LY_STATS_STRIPES - 1)) * 2 * 9 * C;
+    for (int e = tid; e < 2 * 9 * C; e += blockDim.x) {
+      const int qn = e / (9 * C), rem = e - qn * 9 * C;
+      const int tt = rem / C, c = rem - tt * C;
+      float s = 0.f;
+      for (int k = 0; k < pp; ++k) s += red[((k * 9 + tt) * NQT + qn) * CS + c];
+      atomicAdd(sm + qn * 9 * C + tt * C + c, s);
+    }
+  }
+}
+
+// P as for ly_rf1_bwd with: x = ug [pixels][9][C] (dense), dcd [pixels][9][C] (pass 1 overwrites it with dv), ag / bg [9][C], HW = Ho*Wo
+// output pixels per image, rfa / gmax / d_rfa [n][3Ho][3Wo], d_mm [n][3Ho][3Wo][2], sums [LY_STATS_STRIPES][2][9][C] (pass 1, zeroed)
+extern "C" int ly_rf3s_bwd(const LyRf1BwdParams* p, int Ho, int Wo, int pass, void* stream) {
+  LY_CHECK(p, "rf3s_bwd: null params");
+  const LyRf1BwdParams& P = *p;
+  LY_CHECK_DTYPE(P.dtype, "rf3s_bwd");
+  const int vw = P.dtype == LY_BF16 ? 8 : 4;
+  LY_CHECK(P.n_img > 0 && Ho > 0 && Wo > 0 && P.HW == (long)Ho * Wo && P.C > 0 && (P.C % vw) == 0 && P.C / vw <= 64, "rf3s_bwd: bad sizes (C=%d)", P.C);
+  LY_CHECK(P.x && P.dcd && P.ag && P.bg && P.ca && P.rfa && ((uintptr_t)P.x & 15) == 0 && ((uintptr_t)P.dcd & 15) == 0, "rf3s_bwd: null / misaligned pointer");
+  LY_CHECK(pass == RF1_A || pass == RF1_B, "rf3s_bwd: pass %d", pass);
+  if (pass == RF1_A) LY_CHECK(P.cd && P.d_rfa && P.gmax_out && P.d_ca && ((uintptr_t)P.cd & 15) == 0, "rf3s_bwd: pass 0 needs cd, d_rfa, gmax_out, d_ca");
+  else LY_CHECK(P.gmax && P.d_mm && P.sums, "rf3s_bwd: pass 1 needs gmax, d_mm, sums");
+  int lpp2 = 1;
+  while (lpp2 < P.C / vw) lpp2 <<= 1;
+  int pp = 576 / (9 * lpp2);
+  if (pp < 1) pp = 1;
+  if (pp > 4) pp = 4;
+  const int threads = 9 * lpp2 * pp;
+  long per_img = (1024 + P.n_img - 1) / P.n_img;
+  const long max_b = (P.HW + 2L * pp - 1) / (2L * pp);
+  if (per_img > max_b) per_img = max_b;
+  if (per_img < 1) per_img = 1;
+  long chunk = (P.HW + per_img - 1) / per_img;
+  chunk = (chunk + pp - 1) / pp * pp;
+  per_img = (P.HW + chunk - 1) / chunk;
+  const dim3 grid((unsigned)per_img, (unsigned)P.n_img);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define RF3S(T_, M_) hipLaunchKernelGGL((ly_rf3s_bwd_kernel<T_, M_>), grid, dim3(threads), 0, st, P, lpp2, pp, (int)chunk, Ho, Wo)
+  if (P.dtype == LY_BF16) { if (pass == RF1_A) RF3S(__bf16, RF1_A); else RF3S(__bf16, RF1_B); }
+  else { if (pass == RF1_A) RF3S(float, RF1_A); else RF3S(float, RF1_B); }
+#undef RF3S
+  LY_LAUNCH_CHECK();
+  return 0;
+}

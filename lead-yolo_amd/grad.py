@@ -912,9 +912,17 @@ class RfcbamFn(torch.autograd.Function):
             cd = torch.empty((mo, kk * c), dtype=dt, device=dev)
             zz = ops.zeros_f32(2 * rfa.numel() + ca.numel(), dev)
             d_rfa, gmax, d_ca = zz[:rfa.numel()].view_as(rfa), zz[rfa.numel():2 * rfa.numel()].view_as(rfa), zz[2 * rfa.numel():].view_as(ca)
-            with ops._Timed(f"ly_rf_bwd_attn_kernel<{ops._tname(xr)}, {k}>", 8.0 * mo * kk * c, 3.0 * es9):
-                L.check(L.lib().ly_rf_bwd_attn(n, h, w, c, k, s, p(ug), p(dcd), p(ag), p(bg), p(ca), p(rfa), p(cd), p(d_rfa), p(gmax), p(d_ca), code, st),
-                        "ly_rf_bwd_attn")
+            vw = ops.vw_of(xr)
+            rf3s = k == 3 and RF3S_BWD and c % vw == 0 and c // vw <= 64          # 16-bytes-per-lane passes (csrc/ly_rf1_bwd.hip: ly_rf3s_bwd)
+            if rf3s:
+                P3 = L.LyRf1BwdParams(n, ho * wo, c, p(ug), c, p(dcd), None, p(ag), p(bg), p(ca), p(rfa), p(cd), p(d_rfa), p(gmax), p(d_ca),
+                                      p(gmax), None, None, None, None, None, None, 0.0, None, c, None, code)
+                with ops._Timed(f"ly_rf3s_bwd_kernel<{ops._tname(xr)}, 0>", 8.0 * mo * kk * c, 3.0 * es9):
+                    L.check(L.lib().ly_rf3s_bwd(ctypes.byref(P3), ho, wo, 0, st), "ly_rf3s_bwd 0")
+            else:
+                with ops._Timed(f"ly_rf_bwd_attn_kernel<{ops._tname(xr)}, {k}>", 8.0 * mo * kk * c, 3.0 * es9):
+                    L.check(L.lib().ly_rf_bwd_attn(n, h, w, c, k, s, p(ug), p(dcd), p(ag), p(bg), p(ca), p(rfa), p(cd), p(d_rfa), p(gmax), p(d_ca), code, st),
+                            "ly_rf_bwd_attn")
             _tap("rf.ug", ug); _tap("rf.cd", cd); _tap("rf.d_rfa", d_rfa); _tap("rf.gmax", gmax); _tap("rf.d_ca", d_ca)
             _tap("rf.rfa", rfa); _tap("rf.ca", ca); _tap("rf.ag", ag); _tap("rf.bg", bg)
             # 6. conv weight gradient
@@ -937,10 +945,16 @@ class RfcbamFn(torch.autograd.Function):
             if t18 is not None:
                 ops.grad_done(ctx.getw_param)
             # 8. through max/mean, ca, rfa and ReLU; generate-BN sums
-            sums = ops.zeros_f32(2 * kk * c, dev)
-            with ops._Timed(f"ly_rf_bwd_relu_kernel<{ops._tname(xr)}, {k}>", 8.0 * mo * kk * c, 3.0 * es9):
-                L.check(L.lib().ly_rf_bwd_relu(n, h, w, c, k, s, p(ug), p(dcd), p(ag), p(bg), p(ca), p(rfa), p(gmax), p(d_mm), p(sums), code, st),
-                        "ly_rf_bwd_relu")
+            if rf3s:
+                sums = ops.new_stats(kk * c, dev)                                   # striped [STRIPES][2][9][c]
+                P3.d_mm, P3.sums = p(d_mm), p(sums)
+                with ops._Timed(f"ly_rf3s_bwd_kernel<{ops._tname(xr)}, 1>", 8.0 * mo * kk * c, 3.0 * es9):
+                    L.check(L.lib().ly_rf3s_bwd(ctypes.byref(P3), ho, wo, 1, st), "ly_rf3s_bwd 1")
+            else:
+                sums = ops.zeros_f32(2 * kk * c, dev)
+                with ops._Timed(f"ly_rf_bwd_relu_kernel<{ops._tname(xr)}, {k}>", 8.0 * mo * kk * c, 3.0 * es9):
+                    L.check(L.lib().ly_rf_bwd_relu(n, h, w, c, k, s, p(ug), p(dcd), p(ag), p(bg), p(ca), p(rfa), p(gmax), p(d_mm), p(sums), code, st),
+                            "ly_rf_bwd_relu")
             _tap("rf.d_mm", d_mm); _tap("rf.dv", dcd); _tap("rf.sums", sums)
             # 9. generate BatchNorm coefficients ([t][c] order)
             dgg_tc, dbg_tc, alpha, kappa, lam = ops.bn_bwd_coeffs(sums, kk * c, mo, ag, gmean_tc, ginv_tc, True)
@@ -1126,6 +1140,7 @@ def _rfcbam_backward_k1(ctx, du, dgo, dbo):
 
 RfcbamFn._backward_k1 = staticmethod(_rfcbam_backward_k1)
 RF1_BWD = True         # tools: False keeps the first-generation k = 1 backward
+RF3S_BWD = True        # tools: False keeps the thread = channel attention / ReLU passes of the streamed k = 3 backward
 RC_BWD = True          # tools: False keeps the first-generation backward behind the lane = channel forward
 def rfcbam_train(mod, x):
     """RFCBAMConv.forward in training: one autograd node (SE, generate BatchNorm, attention maps, contraction)."""

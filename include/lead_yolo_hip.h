@@ -271,6 +271,10 @@ int ly_rfcbam_gen_prepare(const float* mom, int C, int k, const float* gen_w, co
  *   max_wh = 0 for class-agnostic NMS), at most max_nms candidates, at most max_det kept: keep[b, 0:count[b]] = indices into N.        */
 int ly_nms_candidates(const float* pred, int bs, int N, int no, float conf_thres, unsigned long long class_mask, float* score, float* det,
                       void* stream);
+/* multi_label form (utils/general.py:921, 951-955): score / det have bs * N * nc entries, one per (box, class) pair in the reference's row order
+ * box * nc + class; the sort and ly_nms_greedy then run over N * nc candidates per image.                                                   */
+int ly_nms_candidates_ml(const float* pred, int bs, int N, int no, float conf_thres, unsigned long long class_mask, float* score, float* det,
+                         void* stream);
 int ly_nms_greedy(const float* det, const long* order, const float* sorted_score, int bs, int N, float iou_thres, float max_wh, int max_det,
                   int max_nms, int* keep, int* count, void* stream);
 

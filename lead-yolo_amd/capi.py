@@ -131,6 +131,7 @@ SIGNATURES = {
     "ly_rf_bwd_gen": [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "ly_rf_bwd_dx": [_I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _F, _I, _P],
     "ly_nms_candidates": [_P, _I, _I, _I, _F, ctypes.c_ulonglong, _P, _P, _P],
+    "ly_nms_candidates_ml": [_P, _I, _I, _I, _F, ctypes.c_ulonglong, _P, _P, _P],
     "ly_nms_greedy": [_P, _P, _P, _I, _I, _F, _F, _I, _I, _P, _P, _P],
     "ly_maxpool_arg": [_P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P],
     "ly_maxpool_gather": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P],

@@ -45,6 +45,27 @@ __global__ __launch_bounds__(LY_THREADS) void ly_nms_candidates_kernel(const flo
   }
 }
 
+// multi_label (utils/general.py:921, 951-955; val.py's setting for nc > 1): every (box, class) pair whose obj * class confidence exceeds the
+// threshold is a candidate of its own — pair index box * nc + class, the row order of the reference's `(x[:, 5:] > conf_thres).nonzero()`
+__global__ __launch_bounds__(LY_THREADS) void ly_nms_candidates_ml_kernel(const float* __restrict__ pred, long total_pairs, int no, float conf_thres,
+                                                                          unsigned long long class_mask, float* __restrict__ score,
+                                                                          float* __restrict__ det) {
+  const int nc = no - 5;
+  for (long i = (long)blockIdx.x * LY_THREADS + threadIdx.x; i < total_pairs; i += (long)gridDim.x * LY_THREADS) {
+    const long box = i / nc;
+    const int j = (int)(i - box * nc);
+    const float* p = pred + box * no;
+    const float obj = p[4];
+    const float conf = p[5 + j] * obj;
+    const bool allowed = class_mask == 0ull || (j < 64 && ((class_mask >> j) & 1ull));
+    score[i] = (obj > conf_thres && conf > conf_thres && allowed) ? conf : -1.f;
+    float* d = det + i * 6;
+    const float cx = p[0], cy = p[1], w = p[2], h = p[3];
+    d[0] = cx - w / 2; d[1] = cy - h / 2; d[2] = cx + w / 2; d[3] = cy + h / 2;
+    d[4] = conf; d[5] = (float)j;
+  }
+}
+
 __global__ __launch_bounds__(LY_THREADS) void ly_nms_greedy_kernel(const float* __restrict__ det, const long* __restrict__ order,
                                                                    const float* __restrict__ sorted_score, int N, float iou_thres, float max_wh,
                                                                    int max_det, int max_nms, int* __restrict__ keep, int* __restrict__ count) {
@@ -112,6 +133,16 @@ extern "C" int ly_nms_candidates(const float* pred, int bs, int N, int no, float
   const long total = (long)bs * N;
   hipLaunchKernelGGL(ly_nms_candidates_kernel, dim3((unsigned)ly_nms_blocks(total)), dim3(LY_THREADS), 0, reinterpret_cast<hipStream_t>(stream), pred, total, no,
                      conf_thres, class_mask, score, det);
+  LY_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ly_nms_candidates_ml(const float* pred, int bs, int N, int no, float conf_thres, unsigned long long class_mask, float* score, float* det,
+                                    void* stream) {
+  LY_CHECK(pred && score && det && bs > 0 && N > 0 && no >= 7 && no - 5 <= 4096, "nms_candidates_ml: bad arguments (no=%d: multi_label needs nc > 1)", no);
+  const long total = (long)bs * N * (no - 5);
+  hipLaunchKernelGGL(ly_nms_candidates_ml_kernel, dim3((unsigned)ly_nms_blocks(total)), dim3(LY_THREADS), 0, reinterpret_cast<hipStream_t>(stream), pred, total,
+                     no, conf_thres, class_mask, score, det);
   LY_LAUNCH_CHECK();
   return 0;
 }

@@ -16,7 +16,7 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
-def nms_padded(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, max_det=300):
+def nms_padded(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, max_det=300, multi_label=False):
     """(dets [bs, max_det, 6] float32 — rows past the count are zero —, counts [bs] int32, keep [bs, max_det] int32 indices into the
     prediction rows); no host synchronisation, capturable into a hipGraph."""
     if isinstance(prediction, (list, tuple)):          # model in validation mode: (inference_out, loss_out)  (utils/general.py:904-905)
@@ -41,10 +41,20 @@ def nms_padded(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnost
             if nc >= 64:
                 raise NotImplementedError("an empty class filter with 64 or more classes")
     dev = pred.device
-    score = torch.empty((bs, n), dtype=torch.float32, device=dev)
-    det = torch.empty((bs, n, 6), dtype=torch.float32, device=dev)
     lib, st = capi.lib(), capi.stream_ptr()
-    capi.check(lib.ly_nms_candidates(_p(pred), bs, n, no, float(conf_thres), ctypes.c_ulonglong(mask), _p(score), _p(det), st), "ly_nms_candidates")
+    multi_label = bool(multi_label) and nc > 1               # utils/general.py:921
+    if multi_label:
+        # every (box, class) pair above the threshold is a candidate (val.py's setting for nc > 1): pair index box * nc + class; the returned
+        # `keep` indices address these pairs (box = keep // nc)
+        n_box, n = n, n * nc
+        score = torch.empty((bs, n), dtype=torch.float32, device=dev)
+        det = torch.empty((bs, n, 6), dtype=torch.float32, device=dev)
+        capi.check(lib.ly_nms_candidates_ml(_p(pred), bs, n_box, no, float(conf_thres), ctypes.c_ulonglong(mask), _p(score), _p(det), st),
+                   "ly_nms_candidates_ml")
+    else:
+        score = torch.empty((bs, n), dtype=torch.float32, device=dev)
+        det = torch.empty((bs, n, 6), dtype=torch.float32, device=dev)
+        capi.check(lib.ly_nms_candidates(_p(pred), bs, n, no, float(conf_thres), ctypes.c_ulonglong(mask), _p(score), _p(det), st), "ly_nms_candidates")
     svals, order = torch.sort(score, dim=1, descending=True, stable=True)          # x[:, 4].argsort(descending=True)  (utils/general.py:970)
     keep = torch.zeros((bs, max_det), dtype=torch.int32, device=dev)
     count = torch.empty((bs,), dtype=torch.int32, device=dev)
@@ -64,8 +74,6 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
         raise NotImplementedError("mask coefficients (nm > 0) belong to the segmentation models, which are outside the LEAD-YOLO path")
     if labels:
         raise NotImplementedError("a-priori labels (autolabelling) are not built on the device path")
-    if multi_label and nc > 1:
-        raise NotImplementedError("multi_label NMS (several classes per box) is not built; LEAD-YOLO's callers use the best class per box")
-    dets, count, _ = nms_padded(prediction, conf_thres, iou_thres, classes, agnostic, max_det)
+    dets, count, _ = nms_padded(prediction, conf_thres, iou_thres, classes, agnostic, max_det, multi_label=multi_label)
     counts = count.tolist()                            # the list-of-tensors return value needs the lengths on the host: one sync
     return [dets[i, :c] for i, c in enumerate(counts)]

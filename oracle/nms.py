@@ -62,7 +62,7 @@ def nms(boxes, scores, iou_thres):
     return np.asarray(keep, dtype=np.int64)
 
 
-def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, max_det=300):
+def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, max_det=300, multi_label=False):
     """prediction: float32 [bs, N, 5 + nc] (xywh, obj, class confidences).  Returns a list of [n, 6] arrays (xyxy, conf, cls) and,
     for the tests, the list of kept candidate indices into N."""
     prediction = np.asarray(prediction, dtype=np.float32)
@@ -78,8 +78,13 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
             continue
         x[:, 5:] *= x[:, 4:5]                                                   # :944
         box = xywh2xyxy(x[:, :4])                                               # :947
-        j = x[:, 5:5 + nc].argmax(1)                                            # :955 (first maximum)
-        conf = x[np.arange(x.shape[0]), 5 + j]
+        if multi_label and nc > 1:                                               # :921, :951-953: every (box, class) pair above the threshold
+            bi, j = np.nonzero(x[:, 5:5 + nc] > np.float32(conf_thres))          # row-major: box ascending, class ascending
+            conf = x[bi, 5 + j]
+            box, idx = box[bi], idx[bi] * nc + j                                 # candidate id = box * nc + class (the device path's pair index)
+        else:
+            j = x[:, 5:5 + nc].argmax(1)                                        # :955 (first maximum)
+            conf = x[np.arange(x.shape[0]), 5 + j]
         det = np.concatenate((box, conf[:, None], j[:, None].astype(np.float32)), 1)
         m = conf > np.float32(conf_thres)                                       # :956
         if classes is not None:

@@ -88,6 +88,40 @@ def test_hip_nms_matches_oracle(nc, agnostic, classes, conf, max_det):
         assert float(dets[b, len(want_idx[b]):].abs().sum()) == 0.0
 
 
+def test_oracle_multi_label_hand_case():
+    """multi_label (utils/general.py:921, 951-955): a box whose two class scores both pass becomes two detections (one per class, class-offset
+    boxes do not suppress each other); with best-class-only it is one"""
+    pred = np.array([[[50, 50, 20, 20, 1.0, 0.9, 0.8, 0.05],            # classes 0 and 1 pass
+                      [52, 50, 20, 20, 1.0, 0.1, 0.7, 0.05],            # class 1 only: overlaps the first box, lower score -> suppressed within class 1
+                      [150, 150, 10, 10, 0.9, 0.05, 0.05, 0.6]]], np.float32)
+    out, idx = ON.non_max_suppression(pred, 0.25, 0.45, multi_label=True)
+    assert idx[0].tolist() == [0 * 3 + 0, 0 * 3 + 1, 2 * 3 + 2]
+    np.testing.assert_allclose(out[0][:, 4], [0.9, 0.8, 0.54], rtol=1e-6)
+    assert out[0][:, 5].tolist() == [0.0, 1.0, 2.0]
+    out1, idx1 = ON.non_max_suppression(pred, 0.25, 0.45, multi_label=False)
+    assert idx1[0].tolist() == [0, 1, 2] and out1[0][:, 5].tolist() == [0.0, 1.0, 2.0]      # best class only: box 1 (class 1) survives, no class-1 twin of box 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nc,agnostic,classes,conf,max_det", [(3, False, None, 0.2, 300), (5, True, None, 0.15, 100), (4, False, [1, 3], 0.1, 300),
+                                                                (2, False, None, 0.001, 300)])
+def test_hip_multi_label_nms_matches_oracle(nc, agnostic, classes, conf, max_det):
+    """val.py's NMS setting for nc > 1 (multi_label=True): kept (box, class) pairs bit-exact vs the oracle, in the same order"""
+    import lead_yolo_amd as L
+    dev = torch.device("cuda:0")
+    pred = _random_pred(3, 2000, nc, 31 + nc)
+    want, want_idx = ON.non_max_suppression(pred, conf, 0.45, classes=classes, agnostic=agnostic, max_det=max_det, multi_label=True)
+    got = L.non_max_suppression(torch.from_numpy(pred).to(dev), conf, 0.45, classes=classes, agnostic=agnostic, max_det=max_det, multi_label=True)
+    _, count, keep = L.nms_padded(torch.from_numpy(pred).to(dev), conf, 0.45, classes=classes, agnostic=agnostic, max_det=max_det, multi_label=True)
+    total = 0
+    for b in range(3):
+        assert int(count[b]) == len(want_idx[b])
+        assert keep[b, :len(want_idx[b])].cpu().tolist() == want_idx[b].tolist()
+        np.testing.assert_array_equal(got[b].cpu().numpy(), want[b])
+        total += len(want_idx[b])
+    assert total > 20
+
+
 @pytest.mark.gpu
 def test_hip_nms_edge_cases():
     import lead_yolo_amd as L
@@ -98,8 +132,9 @@ def test_hip_nms_edge_cases():
     one = torch.tensor([[[50.0, 50, 20, 20, 0.9, 1.0]]], device=dev)
     out = L.non_max_suppression(one)
     np.testing.assert_allclose(out[0].cpu().numpy(), [[40, 40, 60, 60, 0.9, 0]], atol=1e-6)
+    assert [tuple(o.shape) for o in L.non_max_suppression(torch.zeros((1, 10, 8), device=dev), multi_label=True)] == [(0, 6)]
     with pytest.raises(NotImplementedError):
-        L.non_max_suppression(torch.zeros((1, 10, 8), device=dev), multi_label=True)
+        L.non_max_suppression(torch.zeros((1, 10, 8), device=dev), labels=[torch.zeros(1, 5)])
     with pytest.raises(RuntimeError):
         L.non_max_suppression(torch.zeros((1, 10, 6)))
     # model in validation mode hands (inference_out, loss_out)

@@ -750,7 +750,9 @@ _WGRAD_WS = {}
 
 def wgrad_workspace(device):
     """Per-device scratch the weight-gradient kernels park their per-chunk partial tiles in (LyWgradParams.ws).  Allocated ONCE (a captured
-    hipGraph keeps its address; every launch overwrites what it reads back in the same launch sequence, stream-ordered), never zeroed."""
+    hipGraph keeps its address; every launch overwrites what it reads back in the same launch sequence, stream-ordered), never zeroed.
+    ONE buffer per device: weight-gradient launches of a device are expected on one stream at a time (the training step's); two training
+    loops on different streams of the same device in one process must set WGRAD_WS_FLOATS = 0 (atomic accumulation) for one of them."""
     if WGRAD_WS_FLOATS <= 0:
         return None
     ws = _WGRAD_WS.get(device)

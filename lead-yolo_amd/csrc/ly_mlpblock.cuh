@@ -71,10 +71,17 @@ __device__ __forceinline__ void ly_mlpblock_body(
   const int BPH = T2D ? (TH + 2) * 18 : BP + 2 * W + 2;
   char* ps_hi = xs_hi + PL * BP * RS;
   char* ps_lo = ps_hi + (PL - 1) * BPH * RSP;
+  // statistics pass: the block's per-channel sums meet in LDS ([2][HTP*16] floats behind the halo planes: ds_add, no return value) and leave
+  // with ONE global atomic per channel and block — the four waves of a block used to flush every hidden tile on their own (C = 80: 1280
+  // global atomics per block inside the chunk loop; the statistics pass took 47 us where the whole forward takes 21)
+  float* const sacc = reinterpret_cast<float*>(ps_hi + PL * BPH * RSP);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lq = lane >> 4;
   const f32x4 zero = ly_zero4();
+  if constexpr (STATS) {
+    for (int i = tid; i < 2 * HTP * 16; i += LY_THREADS) sacc[i] = 0.f;          // (the staging barrier below orders this before the first add)
+  }
 
   // the fragment stream: partial conv (k-step major), then per hidden chunk GEMM1 (k-step major) and, unless this is the
   // statistics pass, GEMM2 (hidden pair major)
@@ -317,7 +324,21 @@ __device__ __forceinline__ void ly_mlpblock_body(
             s1 += acch[t][n];
             s2 += acch[t][n] * acch[t][n];
           }
-        ly_stats_flush(stats, HTP * 16, (hc * HT + t) * 16 + 4 * lq, s1, s2);
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            s1[r] += __shfl_xor(s1[r], o);
+            s2[r] += __shfl_xor(s2[r], o);
+          }
+        if (li == 0) {
+          const int ch = (hc * HT + t) * 16 + 4 * lq;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            atomicAdd(sacc + ch + r, s1[r]);
+            atomicAdd(sacc + HTP * 16 + ch + r, s2[r]);
+          }
+        }
       }
       continue;
     }
@@ -353,7 +374,12 @@ __device__ __forceinline__ void ly_mlpblock_body(
     }
   }
 
-  if (STATS) return;
+  if (STATS) {
+    __syncthreads();
+    float* const st = stats + (size_t)(blockIdx.x & (LY_STATS_STRIPES - 1)) * 2 * (HTP * 16);
+    for (int i = tid; i < 2 * HTP * 16; i += LY_THREADS) atomicAdd(st + i, sacc[i]);
+    return;
+  }
   // ---- epilogue: residual + store ------------------------------------------------------------
   // The residual x is rebuilt from the bf16 hi/lo planes already in LDS (|err| <= 2^-17 |x|) instead
   // of re-reading global memory: channels < CQP from the halo image's centre tap (the tile's own
@@ -832,7 +858,7 @@ static int launch_mlp_k(const T* x, T* y, long M, int n_img, int H, int W, const
   using Gm = MlpGeom<C>;
   constexpr int BP = 64 * NT;
   const long halo = T2D ? (4 * NT + 2) * 18 : BP + 2 * W + 2;
-  size_t lds = LyT<T>::PL * ((size_t)BP * Gm::RS + (size_t)halo * Gm::RSP);
+  size_t lds = LyT<T>::PL * ((size_t)BP * Gm::RS + (size_t)halo * Gm::RSP) + (STATS ? 2 * Gm::HTP * 16 * sizeof(float) : 0);
   LY_CHECK(lds <= 160 * 1024, "mlpblock: tile needs %zu B of LDS (C=%d W=%d)", lds, C, W);
   void (*k)(const T*, T*, long, int, int, const uint4*, const uint4*, const uint4*, const float*, const float*, float*);
   if constexpr (RING) k = ly_mlpblock_fwd_ring_kernel<T, C, NT, HT, T2D, STATS>;

@@ -231,6 +231,18 @@ class _Plan:
         self.entries = {}        # key -> dict(out, parts, K, planes, versions)
         self.table = None
         self.w_epoch = -1
+        self.trace = None        # set(): keys requested while a step is being traced (train.GraphedTrainStep's last warm-up step)
+        self.capture_table = None  # (tab, blk, n): the private table a capture launches instead of the global one
+
+    def private_table(self, keys):
+        """A descriptor table over `keys` only, for a hipGraph capture: the GLOBAL table is rebuilt (and its device tensors freed) whenever any
+        model in the process registers a new image or dies — a captured ly_pack_table launch that addressed it would then read freed memory
+        (seen as an intermittent GPU memory fault: a replayed training graph after an eval forward / a garbage-collected model of an earlier
+        test).  The caller keeps the returned tensors (and the images they address) alive as long as the graph."""
+        keys = [k for k in keys if k in self.entries]
+        if not keys:
+            return None, []
+        return self._build_table(keys), [self.entries[k]["out"] for k in keys]
 
     def _descs(self, e, blk0):
         from . import capi
@@ -265,6 +277,8 @@ class _Plan:
 
     def get(self, parts, K, planes, rows_to=0):
         key = (tuple(p.sig() for p in parts), K, planes, rows_to)
+        if self.trace is not None:
+            self.trace.add(key)
         e = self.entries.get(key)
         capturing = torch.cuda.is_current_stream_capturing()
         if e is None:
@@ -301,6 +315,12 @@ class _Plan:
                 for k in dead:
                     del self.entries[k]
                 self.table = None
+        if capturing and self.capture_table is not None:
+            self._launch(self.capture_table)               # the capture's own table (its owner pins it): only the traced model's images
+            for e in self.entries.values():
+                e["versions"] = tuple(p.version() for p in e["parts"])
+            self.w_epoch = W_EPOCH
+            return
         if self.table is None:
             if capturing:
                 raise RuntimeError("pack: the descriptor table changed during hipGraph capture")

@@ -170,13 +170,22 @@ class GraphedTrainStep:
         side = torch.cuda.Stream(device=imgs.device)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            for _ in range(max(warmup, 1)):
-                train_step(model, compute_loss, optimizer, self.imgs, self.targets, **args)
+            for i in range(max(warmup, 1)):
+                if i == max(warmup, 1) - 1:
+                    pack.PLAN.trace = set()    # which packed weight images this step asks for: the capture refreshes exactly those
+                try:
+                    train_step(model, compute_loss, optimizer, self.imgs, self.targets, **args)
+                finally:
+                    traced, pack.PLAN.trace = pack.PLAN.trace, None
         cur.wait_stream(side)
         torch.cuda.synchronize(imgs.device)
         self.graph = torch.cuda.CUDAGraph()
         self.opt_graph = None
         self._events, self._marked, self._unmarked, self._comm = [], [], [], None
+        # the capture launches a PRIVATE descriptor table over the traced images: the global one is rebuilt (its tensors freed) whenever any
+        # model of the process registers a new image or dies, and a replay addressing it read freed memory (intermittent GPU fault)
+        self._pack_table, self._pack_images = pack.PLAN.private_table(sorted(traced or (), key=repr))
+        pack.PLAN.capture_table = self._pack_table
         pack.touch_weights()                   # the captured step must begin with the (single) refresh of every packed weight image
         if reducer is None and self.accumulate == 1 and not os.environ.get("LY_SPLIT_GRAPHS"):
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
@@ -212,6 +221,7 @@ class GraphedTrainStep:
             self.opt_graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.opt_graph, pool=self.graph.pool(), capture_error_mode="thread_local"):
                 optimizer_step(model, optimizer, ema=ema, max_norm=max_norm, reducer=reducer)
+        pack.PLAN.capture_table = None
         # Everything the graphs address through raw pointers must outlive them: the step's zero pool (ops._POOL.buf is replaced
         # when a later, larger step grows it), the loss constants (replaced when the level shapes change), the optimiser's tensor table
         # (rebuilt when a gradient pointer changes).  A later eager step or a second GraphedTrainStep at another shape would otherwise

@@ -574,7 +574,7 @@ def test_graphed_step_with_reducer_matches_eager(rccl, accumulate):
             dist.destroy_process_group()
 
 
-def test_graphed_step_rejects_wrong_batch_and_survives_a_larger_step():
+def test_graphed_step_rejects_wrong_batch_and_survives_later_allocations():
     """(a) a float batch must not be copied into the captured uint8 buffer (it would truncate to zeros); (b) the graph keeps
     the buffers it addresses alive: an eager step at a LARGER shape afterwards re-allocates the zero pool / loss constants, and replaying
     the old graph must still give the loss it gave before"""
@@ -596,6 +596,22 @@ def test_graphed_step_rejects_wrong_batch_and_survives_a_larger_step():
     torch.cuda.synchronize()
     after = float(step(imgs, tg)[0])
     assert abs(after - before) <= 2e-3 * abs(before), (before, after)      # lr = 0 but BN batch statistics differ by atomic noise only
+    # (c) the packed-weight descriptor table: another model registers its images (the process-wide table is rebuilt and the old one freed),
+    # dies (an eager step then drops its entries: rebuilt again), and other tensors take the freed memory.  The captured refresh launch
+    # must not have been addressing that table (it did: an intermittent GPU memory fault in full-suite runs)
+    import gc
+    m2 = L.Model(_cfg("s")).to(_dev()).eval()
+    with torch.no_grad():
+        m2(big.float() / 255)
+    del m2
+    gc.collect()
+    L.train_step(m, cl, opt, imgs, tg)
+    junk = [torch.full((1 << 14,), -1, dtype=torch.int32, device=_dev()) for _ in range(256)]
+    torch.cuda.synchronize()
+    again = float(step(imgs, tg)[0])
+    torch.cuda.synchronize()
+    assert abs(again - before) <= 2e-3 * abs(before), (before, again)
+    del junk
 
 
 def _ddp_rank(rank, world, port, q):

@@ -625,17 +625,23 @@ __global__ __launch_bounds__(1024) void ly_wgrad_combine_kernel(const LyWgradPar
   const int row = tn * BN + lr, col = tk * BK + lc;
   const int tap = col / P.Cin, cch = col - tap * P.Cin;
   const bool live = e < E && row < P.n_valid && col < P.ks * P.ks * P.Cin && cch < P.c_valid;
-  float a0 = 0.f, a1 = 0.f;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   if (live) {
+    // four loads in flight per lane (the launch is a handful of dependent memory round trips: 8.6 -> ~6 us with two more in flight);
+    // the summation order is fixed, whatever the block count of the producing launch
     const float* p = slab + e;
     int c = rl;
-    for (; c + 16 < chunks; c += 32) {
+    for (; c + 48 < chunks; c += 64) {
       a0 += p[(long)c * E];
       a1 += p[(long)(c + 16) * E];
+      a2 += p[(long)(c + 32) * E];
+      a3 += p[(long)(c + 48) * E];
     }
     if (c < chunks) a0 += p[(long)c * E];
+    if (c + 16 < chunks) a1 += p[(long)(c + 16) * E];
+    if (c + 32 < chunks) a2 += p[(long)(c + 32) * E];
   }
-  red[rl][cl] = a0 + a1;
+  red[rl][cl] = (a0 + a1) + (a2 + a3);
   __syncthreads();
   if (rl == 0 && live) {
     float sacc = 0.f;
@@ -679,6 +685,16 @@ __global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(BN +
   ly_wgrad_tiled_body<T, BN, BK, P, ROWS, PRO, false>(G.p[g], local % tiles, local / tiles, G.tiles_k[g], G.chunk_px[g], nullptr, tiles);
 }
 
+// blocks a weight-gradient launch aims for (development knob: LY_WG_BLOCKS / LY_WG_GROUP_BLOCKS)
+static long wg_target_blocks(bool group) {
+  static long t[2] = {0, 0};
+  if (!t[group]) {
+    const char* e = getenv(group ? "LY_WG_GROUP_BLOCKS" : "LY_WG_BLOCKS");
+    t[group] = e && atol(e) > 0 ? atol(e) : 512;
+  }
+  return t[group];
+}
+
 template <typename T, int BN, int BK, int P>
 static int launch_wgrad_tiled(const LyWgradParams& Q, bool rows, hipStream_t st) {
   const int Ktot = Q.ks * Q.ks * Q.Cin;
@@ -686,7 +702,7 @@ static int launch_wgrad_tiled(const LyWgradParams& Q, bool rows, hipStream_t st)
   const long tiles = (long)tiles_n * tiles_k;
   // ~512 blocks: every chunk adds its whole tile to dw with float atomics (a quarter of all wgrad time at 1024 blocks; 256 blocks
   // leave CUs idle: 3.80 / 3.56 / 4.36 ms per bs=64 bf16 step for 1024 / 512 / 256)
-  long chunks = (512 + tiles - 1) / tiles;
+  long chunks = (wg_target_blocks(false) + tiles - 1) / tiles;
   const long max_chunks = (Q.M + 511) / 512;
   if (chunks > max_chunks) chunks = max_chunks;
   if (chunks < 1) chunks = 1;
@@ -758,7 +774,7 @@ static int wgrad_group_launch(const LyWgradParams* arr, int n, hipStream_t st) {
   G.n = n;
   G.blk0[0] = 0;
   for (int g = 0; g < n; ++g) {
-    long chunks = (512 + tiles_total - 1) / tiles_total;               // the group shares the ~512 blocks (launch_wgrad_tiled's policy)
+    long chunks = (wg_target_blocks(true) + tiles_total - 1) / tiles_total;               // the group shares the ~512 blocks (launch_wgrad_tiled's policy)
     const long max_chunks = (arr[g].M + 511) / 512;
     if (chunks > max_chunks) chunks = max_chunks;
     if (chunks < 1) chunks = 1;

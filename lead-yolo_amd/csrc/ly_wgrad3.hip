@@ -209,17 +209,21 @@ __global__ __launch_bounds__(1024) void ly_wgrad3_combine_kernel(const LyWgradPa
   const int orow = cn * W3_BN + row;
   const int cch = cc * W3_CK + (ct & 1) * 16 + li;
   const bool live = e < E && orow < P.n_valid && cch < P.c_valid;
-  float a0 = 0.f, a1 = 0.f;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   if (live) {
-    const float* p = slab + e;
+    const float* p = slab + e;                               // four loads in flight per lane (see ly_wgrad_combine_kernel)
     int c = rl;
-    for (; c + 16 < chunks; c += 32) {
+    for (; c + 48 < chunks; c += 64) {
       a0 += p[(long)c * E];
       a1 += p[(long)(c + 16) * E];
+      a2 += p[(long)(c + 32) * E];
+      a3 += p[(long)(c + 48) * E];
     }
     if (c < chunks) a0 += p[(long)c * E];
+    if (c + 16 < chunks) a1 += p[(long)(c + 16) * E];
+    if (c + 32 < chunks) a2 += p[(long)(c + 32) * E];
   }
-  red[rl][cl] = a0 + a1;
+  red[rl][cl] = (a0 + a1) + (a2 + a3);
   __syncthreads();
   if (rl == 0 && live) {
     float s = 0.f;

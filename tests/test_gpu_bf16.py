@@ -106,6 +106,49 @@ def test_module_train_forward_and_backward_bf16(name):
     _close(got, want, name + " dx", rel=0.15 if routing else 2 * REL_L2, mx=2.0 if routing else 4 * MAX_REL)     # routing: single entries may move by their whole value
 
 
+@pytest.mark.parametrize("ctor,shape", [((64, 64, 3, 2), (2, 64, 24, 24)), ((128, 128, 3, 2), (2, 128, 16, 16)), ((256, 256, 3, 2), (1, 256, 16, 16)),
+                                        ((32, 48, 3, 1), (2, 32, 9, 14)), ((64, 128, 1, 1), (2, 64, 12, 12))])
+def test_rfcbam_backward_bf16_smooth_case(ctor, shape):
+    """RFCBAMConv backward in bf16 WITHOUT routing decisions, at the smooth-module bound (the 15 % band of the routing modules
+    must not be the only check of ly_rf*_bwd / ly_rf3c_bwd / ly_rf1_bwd).  Both BatchNorms get gamma = 0.1, beta = 1: every pre-ReLU value
+    is 1 + 0.1 * xhat > 0 (no kinks), channel 0's generate-BatchNorm gets beta = 2: the channel maximum is channel 0 everywhere, by a
+    margin no bf16 rounding closes (no flipped arg-max), and SE's hidden ReLU sees positive weights on a positive pooled input.  What is left is smooth, so the input gradient and the weight gradients must meet
+    2 * 8 * 2^-8 relative L2 and cosine >= 0.995 against the fp32 oracle — a wrong-by-10 % tap weight in any backward kernel fails this."""
+    from tests.test_gpu_backward import _oracle_grads
+    c, o, k, s = ctor
+    torch.manual_seed(0)
+    m = _ctor("RFCBAMConv")(*ctor)
+    st = synth.synth_state(synth.shapes_of(m.state_dict()), 7300 + c + o + k)
+    kk = k * k
+    st["generate.1.weight"] = torch.full_like(st["generate.1.weight"], 0.1)
+    gb = torch.ones_like(st["generate.1.bias"])
+    gb[:kk] = 2.0                                                    # generate channels are (c, tap) = c * k^2 + tap: channel 0 dominates every tap
+    st["generate.1.bias"] = gb
+    st["conv.1.weight"] = torch.full_like(st["conv.1.weight"], 0.1)
+    st["conv.1.bias"] = torch.ones_like(st["conv.1.bias"])
+    st["se.fc.0.weight"] = st["se.fc.0.weight"].abs()              # SE's hidden ReLU: positive weights on a positive pooled input (x + 1 below)
+    _bn_eps(_load(m, st))
+    x = synth.synth_input(shape, 41 + c) + 1.0
+    ho, wo = (shape[2] + 2 * (k // 2) - k) // s + 1, (shape[3] + 2 * (k // 2) - k) // s + 1
+    r = synth.synth_input((shape[0], o, ho, wo), 43 + o)
+    y0, dx0, g0 = _oracle_grads("RFCBAMConv", list(ctor), st, x, r)
+    m = m.to(_dev()).train()
+    xt = x.to(_dev()).to(BF).requires_grad_(True)
+    with torch.autocast("cuda", dtype=BF):
+        y = m(xt)
+    assert y.dtype == BF and float(y0.min()) > 0.2               # the oracle's outputs confirm: no output sits at a ReLU kink
+    y.backward(r.to(_dev()).to(BF))
+    _close(y, y0, f"{ctor} y")
+    checks = [("dx", xt.grad, dx0)] + [(kname, dict(m.named_parameters())[kname].grad, g0[kname])
+                                       for kname in ("conv.0.weight", "generate.0.weight", "generate.1.weight", "generate.1.bias", "conv.1.weight",
+                                                     "se.fc.0.weight", "se.fc.2.weight", "get_weight.0.weight")]
+    for what, got, want in checks:
+        got, want = got.detach().float().cpu().flatten(), want.float().flatten()
+        cos = float(got @ want / (got.norm() * want.norm()))
+        l2 = float((got - want).norm() / want.norm())
+        assert cos >= 0.995 and l2 <= 2 * REL_L2, (ctor, what, cos, l2)
+
+
 def test_sppf_pool_bf16_ties_follow_aten():
     """the three chained 5x5 max-pools and their backward on a bf16 map FULL of exact ties (values drawn from 16 levels): forward
     values and the gradient routing (first maximum in row-major scan order, ATen's rule) must equal the fp32 CPU reference on

@@ -468,7 +468,8 @@ def run_train(args, ctx):
                         "train-mode forward (batch-statistics BN), ComputeLoss, HIP backward, clip 10, SGD-nesterov 3 groups, ModelEMA update "
                         "(BASELINE.json configs[2]" + ("" if args.dtype == "bf16" else " shape in fp32") + "); random-init weights",
                parallelism=(f"dp{ctx.world}: one process per GPU, ~2 MB reverse-order gradient buckets (gradients are views into them) "
-                            "all-reduced over RCCL (torch.distributed 'nccl')") if ctx.world > 1
+                            + ("all-reduced over RCCL (torch.distributed 'nccl')" if ctx.backend == "nccl" else
+                               f"exchanged over '{ctx.backend}' — FUNCTIONAL DRY RUN of the N > 1 path, not a measurement")) if ctx.world > 1
                else "dp1 (single GPU, no collective)",
                metric="images/sec (640x640) fwd+bwd")
     if reducer is not None:
@@ -555,18 +556,30 @@ def main():
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={ctx.world}: launch with --nproc-per-node {args.gpus} (or drop the external launcher "
                  f"and let `python bench.py --gpus {args.gpus}` start the ranks itself)")
     ctx.dist = None
+    ctx.backend = "nccl"
     if ctx.world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # Functional dry runs of the N > 1 path on a one-GPU box (tests / development, never a measurement): LY_BENCH_ONE_GPU=1 puts every
+        # rank on GPU 0 and LY_BENCH_BACKEND=gloo exchanges through the host (RCCL refuses two ranks on one device).
+        if os.environ.get("LY_BENCH_ONE_GPU") == "1":
+            ctx.local_rank = 0
+        ctx.backend = os.environ.get("LY_BENCH_BACKEND", "nccl")
         torch.cuda.set_device(ctx.local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", ctx.local_rank))
+        if ctx.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", ctx.local_rank))
+        else:
+            dist.init_process_group(ctx.backend)
         ctx.dist = dist
     ctx.device = torch.device("cuda", ctx.local_rank)
     torch.cuda.set_device(ctx.device)
 
     def barrier():
         if ctx.dist is not None:
-            ctx.dist.barrier(device_ids=[ctx.local_rank])
+            if ctx.backend == "nccl":
+                ctx.dist.barrier(device_ids=[ctx.local_rank])
+            else:
+                ctx.dist.barrier()
         torch.cuda.synchronize()
     ctx.barrier = barrier
 
@@ -576,6 +589,17 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = ctx.world * args.batch * args.steps / dt
 
+    # The per-kernel probe replays the EAGER step, which at N > 1 exchanges gradient buckets: every rank must run it (a rank-0-only probe
+    # would pair its all-reduces with the other ranks' final barrier).  The table itself is only used on rank 0.
+    rows = step_roof = None
+    if not args.no_roofline:
+        if args.mode == "train":
+            rows = probe_step(res["step"], iters=2)
+            step_roof = step_roofline(args, ms_per_step, res["step"], rows)
+        else:
+            with torch.no_grad():
+                rows = probe_step(res["step"], iters=10)
+                step_roof = step_roofline(args, ms_per_step, res["step"], rows)
     if ctx.rank == 0:
         out = {
             "metric": res["metric"], "value": round(value, 2), "unit": "images/sec", "n_gpus": ctx.world, "steps": args.steps,
@@ -593,18 +617,8 @@ def main():
             out["roofline"] = None
             out["cpu_baseline"] = None
         else:
-            if args.mode == "train":
-                rows = probe_step(res["step"], iters=2)
-            else:
-                with torch.no_grad():
-                    rows = probe_step(res["step"], iters=10)
             if args.layers:
                 print_layers(rows)
-            if args.mode == "train":
-                step_roof = step_roofline(args, ms_per_step, res["step"], rows)
-            else:
-                with torch.no_grad():
-                    step_roof = step_roofline(args, ms_per_step, res["step"], rows)
             roof = roofline_of(rows, args.dtype, step_roof.get("families"))
             roof["step"] = step_roof
             if ctx.world == 1 and not args.no_secondary:
@@ -634,7 +648,7 @@ def main():
                 out["cpu_baseline"] = cpu_baseline_train(args.scale, args.size) if args.mode == "train" else cpu_baseline_forward(args.scale, args.size)
         print(json.dumps(out))
     if ctx.dist is not None:
-        ctx.dist.barrier(device_ids=[ctx.local_rank])
+        ctx.barrier()
         ctx.dist.destroy_process_group()
 
 

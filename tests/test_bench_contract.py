@@ -1,0 +1,44 @@
+"""bench.py's driver contract, exercised end to end on the GPU box: the one-line JSON at N = 1 and the N > 1 launch path
+(`python bench.py --gpus 2` -> torch.distributed.run -> one rank per process -> captured data-parallel step -> per-kernel probe on EVERY
+rank -> rank 0's line -> clean exit).  A one-GPU box cannot host two RCCL ranks, so the N = 2 run is a functional dry run: both ranks on
+GPU 0, gradients exchanged over gloo (LY_BENCH_ONE_GPU / LY_BENCH_BACKEND, bench.py) — it found that a rank-0-only probe of the eager step
+would have paired its all-reduces with the other ranks' final barrier."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+        "roofline", "cpu_baseline"}
+
+
+def _run(extra, env=None, timeout=600):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *extra], capture_output=True, text=True, timeout=timeout,
+                       env=dict(os.environ, **(env or {})), cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line():
+    d = _run(["--steps", "3", "--warmup", "2", "--repeats", "1", "--batch", "8", "--no-cpu-baseline", "--no-secondary"])
+    assert KEYS <= set(d) and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 2 and d["dtype"] == "bf16" and d["scaling"] == "weak"
+    assert d["metric"] == "images/sec (640x640) fwd+bwd" and d["value"] > 0 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["peak"] == {"hbm": 8000.0, "mfma": 2500.0}[r["bound"]] and 0 < r["frac"] < 1 and abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-3
+    assert r["step"]["families"] and abs(d["value"] - 8 * 1e3 / d["ms_per_step"]) < 1e-2 * d["value"]
+    assert "workload" in d["config"] and "model" not in d["config"]
+
+
+def test_two_rank_launch_path_dry_run():
+    d = _run(["--gpus", "2", "--steps", "2", "--warmup", "2", "--repeats", "1", "--batch", "4", "--no-cpu-baseline"],
+             env={"LY_BENCH_ONE_GPU": "1", "LY_BENCH_BACKEND": "gloo"})
+    assert KEYS <= set(d) and d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["config"]["world_size"] == 2
+    assert "DRY RUN" in d["config"]["parallelism"] and d["grad_buckets"] >= 1 and "released mid-graph" in d["launch_mode"]
+    assert d["roofline"]["step"]["families"]                       # the probe ran (on both ranks) and the job still ended cleanly
+    assert abs(d["value"] - 2 * 4 * 1e3 / d["ms_per_step"]) < 1e-2 * d["value"]

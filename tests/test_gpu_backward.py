@@ -614,16 +614,19 @@ def test_graphed_step_rejects_wrong_batch_and_survives_later_allocations():
     del junk
 
 
-def _ddp_rank(rank, world, port, q):
+def _ddp_rank(rank, world, port, q, backend="nccl", one_gpu=False):
     import os
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
                       HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     import torch.distributed as dist
     import lead_yolo_amd as L
     try:
-        torch.cuda.set_device(rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
-        dev = torch.device("cuda", rank)
+        dev = torch.device("cuda", 0 if one_gpu else rank)               # one_gpu: both ranks share GPU 0 (gloo stages through the host; RCCL refuses)
+        torch.cuda.set_device(dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
         torch.manual_seed(0)
         m = L.Model(L.load_cfg(scale="n")).to(dev).train()
         for t in list(m.parameters()) + list(m.buffers()):
@@ -648,7 +651,10 @@ def _ddp_rank(rank, world, port, q):
         red.wait()
         got = torch.cat([p.grad.detach().reshape(-1) for p in params]) * opt.grad_scale
         err = float((got - want).norm() / want.norm())
-        assert err < 1e-3, f"exchanged gradient is not the mean of the ranks' gradients: rel err {err}"
+        # `want` comes from ANOTHER backward run of the same batch: two runs differ by float-atomic order and the ReLU / max decisions it
+        # flips (1.3e-3 .. 4e-3 of the whole gradient vector seen on lead-yolo-n at 128 px).  What this must catch is structural: a sum
+        # instead of a mean (err = 1), a bucket that was not exchanged or went out before its last gradient (>= 0.1), a stale gradient
+        assert err < 2e-2, f"exchanged gradient is not the mean of the ranks' gradients: rel err {err}"
         assert float((local - want).norm() / want.norm()) > 1e-2          # the shards really differ
         red.reset()
         for _ in range(2):
@@ -671,23 +677,42 @@ def _ddp_rank(rank, world, port, q):
             dist.destroy_process_group()
 
 
+def _run_two_ranks(backend, one_gpu, port0, timeout):
+    import queue
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = port0 + os.getpid() % 2000
+    procs = [ctx.Process(target=_ddp_rank, args=(r, 2, port, q, backend, one_gpu)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = []
+    try:
+        for _ in procs:
+            res.append(q.get(timeout=timeout))
+    except queue.Empty:
+        res.append((-1, f"no answer within {timeout} s"))
+    for p in procs:
+        p.join(timeout=30)
+        if p.is_alive():
+            p.kill()                                                     # (this exact child: never a pattern kill)
+    return sorted(res)
+
+
 def test_two_rank_rccl_train_step():
     """data-parallel train step over RCCL on two GPUs (skipped on a one-GPU box): rank-0 broadcast, per-rank shards, bucketed
     all-reduce from the gradient hooks / in-place gradient sink — the exchanged gradient equals the MEAN of the ranks' single-GPU gradients —
     fused optimiser, then the captured step with the exchange released from in-graph bucket events; replicas stay bit-identical"""
     if torch.cuda.device_count() < 2:
         pytest.skip("needs >= 2 GPUs")
-    import torch.multiprocessing as mp
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 29600 + os.getpid() % 2000
-    procs = [ctx.Process(target=_ddp_rank, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=600) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
-    assert sorted(res) == [(0, "ok"), (1, "ok")], res
+    assert _run_two_ranks("nccl", False, 29600, 600) == [(0, "ok"), (1, "ok")]
+
+
+def test_two_rank_step_on_one_gpu_over_gloo():
+    """the same two-rank protocol with BOTH ranks on GPU 0 and the gloo backend (which stages device tensors through the host; RCCL refuses
+    two ranks on one device): a world-size-2 HIP training step — in-place gradient sink into bucket views, per-bucket exchange, 1/world in
+    the fused optimiser, the captured graph A / exchange / graph B form — runs under test on a one-GPU box.  The wire is not what is tested."""
+    assert _run_two_ranks("gloo", True, 31600, 300) == [(0, "ok"), (1, "ok")]
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

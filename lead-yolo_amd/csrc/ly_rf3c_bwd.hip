@@ -23,6 +23,18 @@
 
 enum { RB_A = 0, RB_B = 1, RB_C = 2 };
 
+#ifdef RC_PHASE_PROF                    // development: cycles per phase of pass C, block 0 / wave 0 (make CXXFLAGS+=-DRC_PHASE_PROF; tools read ly_rf3c_prof)
+__device__ unsigned long long rc_prof[8];
+#define RC_T(i) do { if (MODE == RB_C && blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); rc_prof[i] += t_ - rc_t0; rc_t0 = t_; } } while (0)
+extern "C" int ly_rf3c_prof(unsigned long long* out, int reset) {
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(rc_prof), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(rc_prof), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+#else
+#define RC_T(i) do { } while (0)
+#endif
+
 template <int MODE, int KS>
 __global__ __launch_bounds__(LY_THREADS) void ly_rf3c_bwd_kernel(const LyRf3cBwdParams P, const int nct, const int nrt) {
   typedef __bf16 T;
@@ -54,6 +66,9 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf3c_bwd_kernel(const LyRf3cBwd
   const T* const du = reinterpret_cast<const T*>(P.du);
   const int HK = 3 * P.Ho, WK = 3 * P.Wo;
   const float invC = 1.f / (float)P.C;
+  // dx output pass (pass C): IW*4 threads per tile row, dxo_nrs rows at a time
+  const int dxo_per = g.IW * 4, dxo_nrs = LY_THREADS / dxo_per > 0 ? LY_THREADS / dxo_per : 1;
+  const int dxo_rsub = tid / dxo_per, dxo_q = (tid - dxo_rsub * dxo_per) >> 2;
 
   constexpr bool ROLLED = MODE == RB_C || KS > 4;           // the pair loop of the VALU phase is not unrolled (register file)
   // ---- per-lane constants of the VALU phase ----------------------------------------------------------
@@ -180,13 +195,18 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf3c_bwd_kernel(const LyRf3cBwd
   for (int i = 0; i < NE; ++i) ring[i] = __builtin_bit_cast(bf16x8, wpk[ftile[i]]);
   const int ntile = nct * nrt;
   issue(0);
+#ifdef RC_PHASE_PROF
+  unsigned long long rc_t0 = __builtin_readcyclecounter();
+#endif
   for (int tt = 0; tt < ntile; ++tt) {
     const int ct = tt % nct, rt = tt / nct;
     const int oy0 = rt * P.TH, ox0 = ct * P.TW;
     __syncthreads();                                   // the previous tile is done with every LDS region
+    RC_T(0);
     commit();
     issue(tt + 1 < ntile ? tt + 1 : tt);               // unconditional (the last tile re-requests itself): no load under a branch
     __syncthreads();
+    RC_T(1);
 
     // ---- dcd tile on the MFMAs: D[px][(t, c)] = du[px][:] . Wc^T[:, (t, c)] ----
     // per k-step the four du fragments are read ONCE and meet the wave's five column tiles (20 accumulator quads); the fragment used last is
@@ -231,6 +251,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf3c_bwd_kernel(const LyRf3cBwd
       }
     }
     __syncthreads();
+    RC_T(2);
 
     // ---- VALU phase, lane = channel -------------------------------------------------------------------
     // (ROLLED: pass C, and every pass at O = 256 — there the unrolled body's registers spilled.)
@@ -318,12 +339,20 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf3c_bwd_kernel(const LyRf3cBwd
 #pragma unroll
             for (int uu = 0; uu < 9; ++uu) dxc[uu] = rc_pkfma(dv[t], w.p[(t * 9 + uu) >> 1], dxc[uu], (t * 9 + uu) & 1);
           // the pair's 3 x 5 input patch (the middle column belongs to both pixels): read-add-write, no other stream touches it in this colour
+          // ALL fifteen reads first, then the adds, then the writes: written as fifteen `+=` the compiler must keep every later read behind
+          // the earlier writes (they may alias for all it knows) — a chain of 14 exposed LDS round trips per pair at one wave per SIMD
           float* dp = dxs + pos0j * RC_CB + c;
+          float old[15];
+#pragma unroll
+          for (int uy = 0; uy < 3; ++uy)
+#pragma unroll
+            for (int k = 0; k < 5; ++k) old[5 * uy + k] = dp[uy * row + k * RC_CB];
 #pragma unroll
           for (int uy = 0; uy < 3; ++uy) {
             float* dr = dp + uy * row;
             const float e0 = dxc[uy * 3][0], e1 = dxc[uy * 3 + 1][0], e2 = dxc[uy * 3 + 2][0] + dxc[uy * 3][1], e3 = dxc[uy * 3 + 1][1], e4 = dxc[uy * 3 + 2][1];
-            dr[0] += e0; dr[RC_CB] += e1; dr[2 * RC_CB] += e2; dr[3 * RC_CB] += e3; dr[4 * RC_CB] += e4;
+            dr[0] = old[5 * uy] + e0; dr[RC_CB] = old[5 * uy + 1] + e1; dr[2 * RC_CB] = old[5 * uy + 2] + e2;
+            dr[3 * RC_CB] = old[5 * uy + 3] + e3; dr[4 * RC_CB] = old[5 * uy + 4] + e4;
           }
         }
       }
@@ -355,11 +384,14 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf3c_bwd_kernel(const LyRf3cBwd
     if constexpr (MODE == RB_C) {
       // ---- dx: rows / columns this tile completes leave as T (+ the SE term); its last row / column is carried to the neighbours ----
       __syncthreads();
+    RC_T(3);
       const int iy0 = S * oy0 - 1, ix0 = S * ox0 - 1;
       const int RL = g.IH - 1, CL = g.IW - 1;            // the seam row / column (shared with the tile below / to the right)
       const bool lastr = rt == nrt - 1, lastc = ct == nct - 1;
       T* const dxo = reinterpret_cast<T*>(P.dx);
-      // thread = (8-channel group v8, column q), rows in a loop: no divisions
+      // thread = (row group, column q, 8-channel group v8): IW*4 threads per row, LY_THREADS / (IW*4) rows at a time (the division is done
+      // once per kernel).  (Until late round 3 only the IW*4 = 68 threads of ONE row group worked here, each walking all 17 rows: this
+      // pass was 19.5 % of the kernel by the phase counters, RC_PHASE_PROF.)
       {
         const int v8 = tid & 3;
         f32x4 dga = ly_zero4(), dgb = ly_zero4();              // the SE term of the thread's 8 channels
@@ -368,11 +400,12 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf3c_bwd_kernel(const LyRf3cBwd
           dga = *reinterpret_cast<const f32x4*>(dg) * P.dgap_scale;
           dgb = *reinterpret_cast<const f32x4*>(dg + 4) * P.dgap_scale;
         }
-        for (int q = tid >> 2; q < g.IW; q += LY_THREADS / 4) {
+        if (dxo_rsub < dxo_nrs) {
+          const int q = dxo_q;
           const int ix = ix0 + q;
           const bool colfin = (q < CL || lastc) && ix >= 0 && ix < P.W;
 #pragma unroll 1
-          for (int r = 0; r < g.IH; ++r) {
+          for (int r = dxo_rsub; r < g.IH; r += dxo_nrs) {
             const int iy = iy0 + r;
             const bool fin = colfin && (r < RL || lastr) && iy >= 0 && iy < P.H;
             float* src = dxs + (r * g.IW + q) * RC_CB + 8 * v8;
@@ -403,6 +436,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf3c_bwd_kernel(const LyRf3cBwd
         }
       }
       __syncthreads();
+    RC_T(4);
       // next tile (raster order): column 0 (rows above the seam row) from the right carry, row 0 from the bottom carry of the tile row above
       // (column 0 of row 0 came in through the right carry when there is a left neighbour); everything else was zeroed above
       {

@@ -25,7 +25,9 @@ enum { RB_A = 0, RB_B = 1, RB_C = 2 };
 
 #ifdef RC_PHASE_PROF                    // development: cycles per phase of pass C, block 0 / wave 0 (make CXXFLAGS+=-DRC_PHASE_PROF; tools read ly_rf3c_prof)
 __device__ unsigned long long rc_prof[8];
-#define RC_T(i) do { if (MODE == RB_C && blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); rc_prof[i] += t_ - rc_t0; rc_t0 = t_; } } while (0)
+// (accumulated in scalar registers and written once at the end: a global read-modify-write per mark would put an `s_waitcnt vmcnt(0)` there
+// and drain the very loads whose latency is being looked at)
+#define RC_T(i) do { if (MODE == RB_C) { const unsigned long long t_ = __builtin_readcyclecounter(); rc_acc[i] += t_ - rc_t0; rc_t0 = t_; } } while (0)
 extern "C" int ly_rf3c_prof(unsigned long long* out, int reset) {
   if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(rc_prof), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
   if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(rc_prof), z, sizeof(z)) != hipSuccess) return -1; }
@@ -196,6 +198,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf3c_bwd_kernel(const LyRf3cBwd
   const int ntile = nct * nrt;
   issue(0);
 #ifdef RC_PHASE_PROF
+  unsigned long long rc_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long rc_t0 = __builtin_readcyclecounter();
 #endif
   for (int tt = 0; tt < ntile; ++tt) {
@@ -204,7 +207,9 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf3c_bwd_kernel(const LyRf3cBwd
     __syncthreads();                                   // the previous tile is done with every LDS region
     RC_T(0);
     commit();
+    RC_T(5);
     issue(tt + 1 < ntile ? tt + 1 : tt);               // unconditional (the last tile re-requests itself): no load under a branch
+    RC_T(6);
     __syncthreads();
     RC_T(1);
 
@@ -404,7 +409,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf3c_bwd_kernel(const LyRf3cBwd
           const int q = dxo_q;
           const int ix = ix0 + q;
           const bool colfin = (q < CL || lastc) && ix >= 0 && ix < P.W;
-#pragma unroll 1
+#pragma unroll 1                       // (two rows in flight: 5 spilled registers, 367 -> 377 us)
           for (int r = dxo_rsub; r < g.IH; r += dxo_nrs) {
             const int iy = iy0 + r;
             const bool fin = colfin && (r < RL || lastr) && iy >= 0 && iy < P.H;
@@ -455,6 +460,10 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf3c_bwd_kernel(const LyRf3cBwd
     }
   }
 
+#ifdef RC_PHASE_PROF
+  if (MODE == RB_C && blockIdx.x == 0 && threadIdx.x == 0)
+    for (int i = 0; i < 8; ++i) rc_prof[i] += rc_acc[i];
+#endif
   // ---- flush the per-image accumulators ---------------------------------------------------------------
   if constexpr (MODE == RB_A) {
     float d = dca2[0] + dca2[1];

@@ -1,0 +1,29 @@
+"""Cycles per phase of ly_rf3c_bwd pass C (block 0, thread 0) for one launch inside a bf16 lead-yolo-s bs=64 training step.  Needs a library
+built with -DRC_PHASE_PROF:  make -C lead-yolo_amd/csrc CXXFLAGS="... -DRC_PHASE_PROF" (touch ly_rf3c_bwd.hip first); rebuild without it afterwards.
+The counters live in registers and perturb register allocation: read the SHARES, not the total."""
+import sys, os, ctypes
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench as B
+import lead_yolo_amd as L
+from lead_yolo_amd import capi
+dev = torch.device("cuda:0")
+model = B.build_model("s", dev, train=True)
+opt = L.smart_optimizer(model, "SGD", 0.01, 0.937, 5e-4, fused=True)
+cl = L.ComputeLoss(model)
+imgs = B.synth_u8(64, 640, 0).to(dev); tg = B.synth_targets(64, 1).to(dev)
+for _ in range(3):
+    L.train_step(model, cl, opt, imgs, tg, amp=torch.bfloat16)
+torch.cuda.synchronize()
+lib = capi.lib()
+lib.ly_rf3c_prof.argtypes = [ctypes.c_void_p, ctypes.c_int]
+lib.ly_rf3c_prof(None, 1)
+L.train_step(model, cl, opt, imgs, tg, amp=torch.bfloat16)
+torch.cuda.synchronize()
+out = (ctypes.c_ulonglong * 8)()
+lib.ly_rf3c_prof(out, 0)
+v = list(out)[:7]; tot = sum(v)
+names = ["carries + top barrier", "barrier after staging", "MFMA phase + dcd tile write + barrier", "VALU pair loops (4 colours) + barrier", "dx output pass + barrier", "commit (regs -> LDS)", "issue (next tile loads)"]
+print("pass C, block 0 / thread 0, one launch: %d counter ticks" % tot)
+for n, x in zip(names, v):
+    print("  %-42s %10d  %5.1f %%" % (n, x, 100.0 * x / tot))

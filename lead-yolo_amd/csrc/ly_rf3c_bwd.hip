@@ -27,7 +27,10 @@ enum { RB_A = 0, RB_B = 1, RB_C = 2 };
 __device__ unsigned long long rc_prof[8];
 // (accumulated in scalar registers and written once at the end: a global read-modify-write per mark would put an `s_waitcnt vmcnt(0)` there
 // and drain the very loads whose latency is being looked at)
-#define RC_T(i) do { if (MODE == RB_C) { const unsigned long long t_ = __builtin_readcyclecounter(); rc_acc[i] += t_ - rc_t0; rc_t0 = t_; } } while (0)
+#ifndef RC_PROF_MODE
+#define RC_PROF_MODE RB_C
+#endif
+#define RC_T(i) do { if (MODE == RC_PROF_MODE) { const unsigned long long t_ = __builtin_readcyclecounter(); rc_acc[i] += t_ - rc_t0; rc_t0 = t_; } } while (0)
 extern "C" int ly_rf3c_prof(unsigned long long* out, int reset) {
   if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(rc_prof), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
   if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(rc_prof), z, sizeof(z)) != hipSuccess) return -1; }
@@ -367,25 +370,33 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf3c_bwd_kernel(const LyRf3cBwd
     if constexpr (MODE == RB_A) {
       // ---- d_rfa of this chunk: lane = pixel sums z over the chunk's 32 channels, wave w takes taps w, w+4, (w+8) ----
       __syncthreads();
-      const int ly = lane / P.TW, lx = lane - ly * P.TW;
-      const int oy = oy0 + ly, ox = ox0 + lx;
-      const bool pok = lane < g.NPX && oy < P.Ho && ox < P.Wo;
-      const int pch = lane >> 2, pin = (lane & 3) * 2;
+      RC_T(3);
+      // thread = (tap t, 4-pixel chunk pq): 32 independent 8-byte reads (the chunk of row t*32 + cc), four running sums.  (Until late round 3
+      // a lane owned ONE pixel and walked 32 rows x 3 taps with 2-byte reads: 96 reads per lane, a quarter of pass A by the phase counters.)
+      if (tid < 9 * 16) {
+        const int t = tid >> 4, pq = tid & 15;
+        const char* base = dt + t * (RC_CB * 128);
+        f32x4 sum = ly_zero4();
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const int t = wave + 4 * i;
-        if (t < 9) {
-          const char* base = dt + t * (RC_CB * 128) + pin;
-          float sum = 0.f;
+        for (int cc = 0; cc < RC_CB; ++cc) {
+          const uint2 hv = *reinterpret_cast<const uint2*>(base + cc * 128 + ((pq ^ rc_sw(cc)) << 3));
+          sum[0] += __builtin_bit_cast(float, hv.x << 16);
+          sum[1] += __builtin_bit_cast(float, hv.x & 0xffff0000u);
+          sum[2] += __builtin_bit_cast(float, hv.y << 16);
+          sum[3] += __builtin_bit_cast(float, hv.y & 0xffff0000u);
+        }
+        const long pbase = (long)chunk * ((long)P.n_img * HK * WK) + ((long)n * HK + t / 3) * WK + t % 3;
 #pragma unroll
-          for (int cc = 0; cc < RC_CB; ++cc) {
-            const unsigned short hv = *reinterpret_cast<const unsigned short*>(base + cc * 128 + ((pch ^ rc_sw(cc)) << 3));
-            sum += __builtin_bit_cast(float, (unsigned)hv << 16);
-          }
-          if (pok) P.d_rfa_part[(long)chunk * ((long)P.n_img * HK * WK) + ((long)n * HK + 3 * oy + t / 3) * WK + 3 * ox + t % 3] = sum;
+        for (int k = 0; k < 4; ++k) {
+          const int px = 4 * pq + k;
+          const int ly = px / P.TW, lx = px - ly * P.TW;
+          const int oy = oy0 + ly, ox = ox0 + lx;
+          if (px < g.NPX && oy < P.Ho && ox < P.Wo) P.d_rfa_part[pbase + (long)(3 * oy) * WK + 3 * ox] = sum[k];
         }
       }
+      RC_T(4);
     }
+    if constexpr (MODE == RB_B) RC_T(3);
     if constexpr (MODE == RB_C) {
       // ---- dx: rows / columns this tile completes leave as T (+ the SE term); its last row / column is carried to the neighbours ----
       __syncthreads();
@@ -461,7 +472,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf3c_bwd_kernel(const LyRf3cBwd
   }
 
 #ifdef RC_PHASE_PROF
-  if (MODE == RB_C && blockIdx.x == 0 && threadIdx.x == 0)
+  if (MODE == RC_PROF_MODE && blockIdx.x == 0 && threadIdx.x == 0)
     for (int i = 0; i < 8; ++i) rc_prof[i] += rc_acc[i];
 #endif
   // ---- flush the per-image accumulators ---------------------------------------------------------------

@@ -23,7 +23,7 @@ torch.cuda.synchronize()
 out = (ctypes.c_ulonglong * 8)()
 lib.ly_rf3c_prof(out, 0)
 v = list(out)[:7]; tot = sum(v)
-names = ["carries + top barrier", "barrier after staging", "MFMA phase + dcd tile write + barrier", "VALU pair loops (4 colours) + barrier", "dx output pass + barrier", "commit (regs -> LDS)", "issue (next tile loads)"]
+names = ["carries + top barrier", "barrier after staging", "MFMA phase + dcd tile write + barrier", "VALU pair loops (4 colours) + barrier", "dx output pass (C) / d_rfa reduction (A)", "commit (regs -> LDS)", "issue (next tile loads)"]
 print("pass C, block 0 / thread 0, one launch: %d counter ticks" % tot)
 for n, x in zip(names, v):
     print("  %-42s %10d  %5.1f %%" % (n, x, 100.0 * x / tot))

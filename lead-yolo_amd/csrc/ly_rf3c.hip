@@ -188,6 +188,18 @@ extern "C" int ly_rf3c_stats(const void* x, int ldx, int n_img, int H, int W, in
 //   against conv.0.weight packed as [N][C/32][9 taps][32 channels]; the next chunk's input tile, generate weights and the conv
 //   weight fragments (register ring) are requested a phase ahead.
 // ---------------------------------------------------------------------------------------------------
+#ifdef RC_PHASE_PROF                    // development: cycles per phase of the forward contraction kernel, block 0 / thread 0 (tools/rf3c_phase_prof.py fwd)
+__device__ unsigned long long rcf_prof[8];
+#define RCF_T(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); rcf_acc[i] += t_ - rcf_t0; rcf_t0 = t_; } while (0)
+extern "C" int ly_rf3c_fwd_prof(unsigned long long* out, int reset) {
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(rcf_prof), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(rcf_prof), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+#else
+#define RCF_T(i) do { } while (0)
+#endif
+
 template <typename T, int MT, int NW, int S, bool RAW>
 __global__ __launch_bounds__(NW * 64) void ly_rf3c_fwd_kernel(const LyRfcbam3Params P, const float* __restrict__ wq, const int gy, const int nct,
                                                                  const int nrt) {
@@ -217,6 +229,10 @@ __global__ __launch_bounds__(NW * 64) void ly_rf3c_fwd_kernel(const LyRfcbam3Par
   const int Tt = (P.N + 15) >> 4;
 
   constexpr int NTHR = NW * 64;
+#ifdef RC_PHASE_PROF
+  unsigned long long rcf_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long rcf_t0 = __builtin_readcyclecounter();
+#endif
   RcStage<T, NTHR> St;
   rc_stage_plan(St, g, tid, n, P.H, P.W, P.ldx, S * oy0 - 1, S * ox0 - 1);
   rc_stage_load(St, x, 0);
@@ -283,12 +299,15 @@ __global__ __launch_bounds__(NW * 64) void ly_rf3c_fwd_kernel(const LyRfcbam3Par
   rc_load_w<RAW>(w, wq, 0, c);
   float cav = P.ca[(long)n * P.C + c];
 
+  RCF_T(0);                                         // prologue: plan, first loads, rfa table, weights
   for (int ch = 0; ch < NCH; ++ch) {
     const bool more = ch + 1 < NCH;
     __syncthreads();                                // previous chunk: MFMAs done with G', generate done with xs
+    RCF_T(1);
     rc_stage_store(St, xs);
     rc_stage_load(St, x, more ? (ch + 1) * RC_CB : 0);
     __syncthreads();
+    RCF_T(2);
     // ---- regenerate: G' = relu(v) * ca * rfa for the stream's pixel pairs ----------------------------------
     const f32x2 cav2 = {cav, cav};
     // (8-wave blocks: 256 registers per lane; the two pair iterations stay rolled and recompute their addresses)
@@ -327,6 +346,7 @@ __global__ __launch_bounds__(NW * 64) void ly_rf3c_fwd_kernel(const LyRfcbam3Par
       cav = P.ca[(long)n * P.C + cn + c];
     }
     __syncthreads();
+    RCF_T(3);
     // ---- contract the chunk: 9 k-steps (k = tap*32 + channel) -------------------------------------------------
     const int sbase = ch * 9;
 #pragma unroll
@@ -348,8 +368,13 @@ __global__ __launch_bounds__(NW * 64) void ly_rf3c_fwd_kernel(const LyRfcbam3Par
         __builtin_amdgcn_sched_barrier(0x786);     // neither loads nor MFMAs may move across: the refills stay D fragments ahead
       }
     }
+    RCF_T(4);
   }
 
+#ifdef RC_PHASE_PROF
+  if (blockIdx.x == 0 && threadIdx.x == 0 && MT == 2 && NW == 4)
+    for (int i = 0; i < 8; ++i) rcf_prof[i] += rcf_acc[i];
+#endif
   // ---- epilogue: conv.0 bias + conv.1 BatchNorm + ReLU (or the statistics pass / pre-BN value of the training forward) ----
 #pragma unroll
   for (int t = 0; t < MT; ++t) {

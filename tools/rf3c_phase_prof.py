@@ -8,6 +8,33 @@ import bench as B
 import lead_yolo_amd as L
 from lead_yolo_amd import capi
 dev = torch.device("cuda:0")
+
+
+def forward_profile():
+    """python tools/rf3c_phase_prof.py fwd : phases of ly_rf3c_fwd_kernel<bf16, 2, 4, 2, false> (layer 17, eval forward bs=64), block 0 / thread 0"""
+    model = B.build_model("s", dev)
+    x = B.synth_batch(64, 640, 0, dev).to(torch.bfloat16)
+    lib = capi.lib()
+    lib.ly_rf3c_fwd_prof.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    with torch.no_grad():
+        for _ in range(2):
+            model(x)
+        torch.cuda.synchronize()
+        lib.ly_rf3c_fwd_prof(None, 1)
+        model(x)
+        torch.cuda.synchronize()
+    out = (ctypes.c_ulonglong * 8)()
+    lib.ly_rf3c_fwd_prof(out, 0)
+    v = list(out)[:5]
+    tot = sum(v)
+    print("ly_rf3c_fwd (layer 17 eval), one block: %d counter ticks" % tot)
+    for n, q in zip(["prologue (plan, first loads, tables, weights)", "top barrier (the other waves' MFMAs)", "x chunk -> LDS, next chunk's loads, barrier",
+                     "regenerate (VALU) + barrier", "contraction (MFMA)"], v):
+        print("  %-48s %9d %5.1f %%" % (n, q, 100.0 * q / max(tot, 1)))
+
+if len(sys.argv) > 1 and sys.argv[1] == "fwd":
+    forward_profile()
+    sys.exit(0)
 model = B.build_model("s", dev, train=True)
 opt = L.smart_optimizer(model, "SGD", 0.01, 0.937, 5e-4, fused=True)
 cl = L.ComputeLoss(model)

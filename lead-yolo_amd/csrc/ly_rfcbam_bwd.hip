@@ -249,50 +249,73 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_attn_kernel(const RfGeom
 
 // ---- get_weight (3x3 conv 2 -> 1 on the map) + sigmoid backward ------------------------------------
 // rfa = sigmoid(pre), pre[p] = sum_{ch,dy,dx} w[ch][dy][dx] * mm[p + (dy-1, dx-1)][ch]
+#define RFA_TH 16
+#define RFA_TW 64
 __global__ __launch_bounds__(LY_THREADS) void ly_rfa_bwd_kernel(const float* __restrict__ d_rfa, const float* __restrict__ rfa,
                                                                 const float* __restrict__ mm, const float* __restrict__ w18, int n_img, int Hk,
-                                                                int Wk, float* __restrict__ d_mm, float* __restrict__ dw18) {
-  // grid-stride: the 18 weight-gradient partials stay in registers over all of a block's positions and are flushed with ONE atomic per
-  // weight and block (a block per 256 positions meant 3600 same-address atomics per weight at bs=64: 26 us for a 4 MB map)
+                                                                int Wk, float* __restrict__ d_mm, float* __restrict__ dw18, int tiles_y, int tiles_x) {
+  // A block walks 16 x 64 tiles of the map (grid-stride over image x tile): d_pre = d_rfa * rfa * (1 - rfa) and mm are staged ONCE per tile
+  // with a one-position halo (zeros outside the map), so a position's 9 + 9 neighbours are LDS reads.  (Until late round 3 every thread
+  // fetched its 36 neighbour values from global memory, one dependent round trip after the other: 24 us per launch for a 3.7 MB map.)
+  // The 18 weight-gradient partials stay in registers over all of a block's tiles and leave with ONE atomic per weight and block.
+  __shared__ float dps[(RFA_TH + 2) * (RFA_TW + 2)];
+  __shared__ float mms[(RFA_TH + 2) * (RFA_TW + 2) * 2];
   __shared__ float red[18][4];
-  const long total = (long)n_img * Hk * Wk;
-  float dwl[18];
+  constexpr int HW_ = RFA_TW + 2;
+  float w[18], dwl[18];
 #pragma unroll
-  for (int i = 0; i < 18; ++i) dwl[i] = 0.f;
-  for (long q = (long)blockIdx.x * LY_THREADS + threadIdx.x; q < total; q += (long)gridDim.x * LY_THREADS) {
-    const long row = q / Wk;
-    const int xq = (int)(q - row * Wk);
-    const long n = row / Hk;
-    const int yq = (int)(row - n * Hk);
-    float g0 = 0.f, g1 = 0.f;
-    const float rq = rfa[q];
-    const float dpre_q = d_rfa[q] * rq * (1.f - rq);
+  for (int i = 0; i < 18; ++i) { w[i] = w18[i]; dwl[i] = 0.f; }
+  const int tid = threadIdx.x;
+  const int tx = tid & (RFA_TW - 1), ty = tid >> 6;                  // 4 row groups x 64 columns
+  const long ntile = (long)n_img * tiles_y * tiles_x;
+  for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    const int txi = (int)(tile % tiles_x);
+    const long r1 = tile / tiles_x;
+    const int tyi = (int)(r1 % tiles_y);
+    const long n = r1 / tiles_y;
+    const int y0 = tyi * RFA_TH, x0 = txi * RFA_TW;
+    __syncthreads();                                                // the previous tile's readers are done
+    for (int i = tid; i < (RFA_TH + 2) * HW_; i += LY_THREADS) {
+      const int r = i / HW_, cq = i - r * HW_;
+      const int y = y0 + r - 1, x = x0 + cq - 1;
+      const bool in = y >= 0 && y < Hk && x >= 0 && x < Wk;
+      const long p = in ? (n * Hk + y) * Wk + x : 0;
+      const float rp = rfa[p], dr = d_rfa[p];
+      const float2 mv = *reinterpret_cast<const float2*>(mm + 2 * p);
+      dps[i] = in ? dr * rp * (1.f - rp) : 0.f;
+      mms[2 * i] = in ? mv.x : 0.f;
+      mms[2 * i + 1] = in ? mv.y : 0.f;
+    }
+    __syncthreads();
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy)
+    for (int k = 0; k < RFA_TH / 4; ++k) {
+      const int ly = ty + 4 * k;
+      const int yq = y0 + ly, xq = x0 + tx;
+      if (yq < Hk && xq < Wk) {
+        const int ctr = (ly + 1) * HW_ + tx + 1;
+        const float dpre_q = dps[ctr];
+        float g0 = 0.f, g1 = 0.f;
 #pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        // d_mm[q] gathers d_pre at p = q - (dy-1, dx-1);  dw gathers mm at q + (dy-1, dx-1)
-        const int yp = yq - (dy - 1), xp = xq - (dx - 1);
-        const bool inp = yp >= 0 && yp < Hk && xp >= 0 && xp < Wk;
-        const long p = inp ? (n * Hk + yp) * Wk + xp : 0;
-        const float rp = rfa[p];
-        const float dp = inp ? d_rfa[p] * rp * (1.f - rp) : 0.f;
-        g0 += w18[dy * 3 + dx] * dp;
-        g1 += w18[9 + dy * 3 + dx] * dp;
-        const int ym = yq + (dy - 1), xm = xq + (dx - 1);
-        const bool inm = ym >= 0 && ym < Hk && xm >= 0 && xm < Wk;
-        const long pm = inm ? (n * Hk + ym) * Wk + xm : 0;
-        dwl[dy * 3 + dx] += inm ? dpre_q * mm[2 * pm] : 0.f;
-        dwl[9 + dy * 3 + dx] += inm ? dpre_q * mm[2 * pm + 1] : 0.f;
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) {
+            // d_mm[q] gathers d_pre at p = q - (dy-1, dx-1);  dw gathers mm at q + (dy-1, dx-1)
+            const float dp = dps[ctr - (dy - 1) * HW_ - (dx - 1)];
+            g0 += w[dy * 3 + dx] * dp;
+            g1 += w[9 + dy * 3 + dx] * dp;
+            const int pm = ctr + (dy - 1) * HW_ + (dx - 1);
+            dwl[dy * 3 + dx] += dpre_q * mms[2 * pm];
+            dwl[9 + dy * 3 + dx] += dpre_q * mms[2 * pm + 1];
+          }
+        *reinterpret_cast<float2*>(d_mm + 2 * ((n * Hk + yq) * Wk + xq)) = make_float2(g0, g1);
       }
-    d_mm[2 * q] = g0;
-    d_mm[2 * q + 1] = g1;
+    }
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int i = 0; i < 18; ++i) {
-    const float s = rf_wave_sum(dwl[i]);
-    if (lane == 0) red[i][wave] = s;
+    const float sv = rf_wave_sum(dwl[i]);
+    if (lane == 0) red[i][wave] = sv;
   }
   __syncthreads();
   if (threadIdx.x < 18) atomicAdd(dw18 + threadIdx.x, red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
@@ -618,11 +641,11 @@ extern "C" int ly_rf_bwd_attn(int n_img, int H, int W, int C, int k, int s, cons
 extern "C" int ly_rfa_bwd(const float* d_rfa, const float* rfa, const float* mm, const float* w18, int n_img, int Hk, int Wk, float* d_mm,
                           float* dw18, void* stream) {
   LY_CHECK(d_rfa && rfa && mm && w18 && d_mm && dw18 && n_img > 0 && Hk > 0 && Wk > 0, "rfa_bwd: bad arguments");
-  const long total = (long)n_img * Hk * Wk;
-  long blocks = (total + LY_THREADS - 1) / LY_THREADS;
+  const int tiles_y = (Hk + RFA_TH - 1) / RFA_TH, tiles_x = (Wk + RFA_TW - 1) / RFA_TW;
+  long blocks = (long)n_img * tiles_y * tiles_x;
   if (blocks > 512) blocks = 512;
   hipLaunchKernelGGL(ly_rfa_bwd_kernel, dim3((unsigned)blocks), dim3(LY_THREADS), 0,
-                     reinterpret_cast<hipStream_t>(stream), d_rfa, rfa, mm, w18, n_img, Hk, Wk, d_mm, dw18);
+                     reinterpret_cast<hipStream_t>(stream), d_rfa, rfa, mm, w18, n_img, Hk, Wk, d_mm, dw18, tiles_y, tiles_x);
   LY_LAUNCH_CHECK();
   return 0;
 }

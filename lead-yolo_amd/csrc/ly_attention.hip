@@ -1501,8 +1501,22 @@ __global__ __launch_bounds__(LY_THREADS) void ly_se_bwd_wsum_kernel(const float*
   if (i >= C * R) return;
   const int r = i / C, c = i - r * C;
   const int st = 2 * C + 2 * R;
+  // eight images per trip, all 32 loads issued before the first use (one image per trip was 64 dependent L2 round trips: 19 us for 80 KB);
+  // the sums keep the image order
   float sa = 0.f, sb = 0.f;
-  for (int n = 0; n < n_img; ++n) {
+  int n = 0;
+  for (; n + 8 <= n_img; n += 8) {
+    float a0[8], a1[8], b0[8], b1[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float* w = ws + (long)(n + k) * st;
+      b0[k] = w[C + c]; b1[k] = w[2 * C + r]; a0[k] = w[2 * C + R + r]; a1[k] = w[c];
+    }
+    __builtin_amdgcn_sched_barrier(0);               // (left alone the scheduler sinks the loads back between the FMAs: four per round trip again)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sb += b0[k] * b1[k]; sa += a0[k] * a1[k]; }
+  }
+  for (; n < n_img; ++n) {
     const float* w = ws + (long)n * st;
     sb += w[C + c] * w[2 * C + r];
     sa += w[2 * C + R + r] * w[c];

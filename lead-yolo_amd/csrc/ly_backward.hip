@@ -631,11 +631,20 @@ __global__ __launch_bounds__(1024) void ly_wgrad_combine_kernel(const LyWgradPar
     // the summation order is fixed, whatever the block count of the producing launch
     const float* p = slab + e;
     int c = rl;
+    for (; c + 112 < chunks; c += 128) {                // eight loads fenced ahead of the adds (the scheduler sinks them back otherwise)
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = p[(long)(c + 16 * k) * E];
+      __builtin_amdgcn_sched_barrier(0);
+      a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
+      a0 += v[4]; a1 += v[5]; a2 += v[6]; a3 += v[7];
+    }
     for (; c + 48 < chunks; c += 64) {
-      a0 += p[(long)c * E];
-      a1 += p[(long)(c + 16) * E];
-      a2 += p[(long)(c + 32) * E];
-      a3 += p[(long)(c + 48) * E];
+      float v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = p[(long)(c + 16 * k) * E];
+      __builtin_amdgcn_sched_barrier(0);
+      a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
     }
     if (c < chunks) a0 += p[(long)c * E];
     if (c + 16 < chunks) a1 += p[(long)(c + 16) * E];
@@ -940,11 +949,20 @@ __global__ __launch_bounds__(1024) void ly_sum_rows_kernel(const float* __restri
   if (c < C) {
     const float* p = src + c;
     long r = rl;
+    for (; r + 112 < R; r += 128) {                     // eight loads fenced ahead of the adds
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = p[(r + 16 * k) * ld];
+      __builtin_amdgcn_sched_barrier(0);
+      a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
+      a0 += v[4]; a1 += v[5]; a2 += v[6]; a3 += v[7];
+    }
     for (; r + 48 < R; r += 64) {
-      a0 += p[r * ld];
-      a1 += p[(r + 16) * ld];
-      a2 += p[(r + 32) * ld];
-      a3 += p[(r + 48) * ld];
+      float v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = p[(r + 16 * k) * ld];
+      __builtin_amdgcn_sched_barrier(0);
+      a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
     }
     for (; r < R; r += 16) a0 += p[r * ld];
   }

@@ -213,11 +213,20 @@ __global__ __launch_bounds__(1024) void ly_wgrad3_combine_kernel(const LyWgradPa
   if (live) {
     const float* p = slab + e;                               // four loads in flight per lane (see ly_wgrad_combine_kernel)
     int c = rl;
+    for (; c + 112 < chunks; c += 128) {                // eight loads fenced ahead of the adds (the scheduler sinks them back otherwise)
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = p[(long)(c + 16 * k) * E];
+      __builtin_amdgcn_sched_barrier(0);
+      a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
+      a0 += v[4]; a1 += v[5]; a2 += v[6]; a3 += v[7];
+    }
     for (; c + 48 < chunks; c += 64) {
-      a0 += p[(long)c * E];
-      a1 += p[(long)(c + 16) * E];
-      a2 += p[(long)(c + 32) * E];
-      a3 += p[(long)(c + 48) * E];
+      float v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = p[(long)(c + 16 * k) * E];
+      __builtin_amdgcn_sched_barrier(0);
+      a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
     }
     if (c < chunks) a0 += p[(long)c * E];
     if (c + 16 < chunks) a1 += p[(long)(c + 16) * E];

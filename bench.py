@@ -33,6 +33,9 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+VALU_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak FP32 (vector), packed FMA
+# kernels that issue matrix instructions: the `flops` their wrappers report (ops._Timed) are MFMA work, `valu_flops` vector work
+MFMA_KERNELS = ("ly_gemm_kernel", "ly_conv3x3", "ly_mlp", "ly_wgrad", "ly_rf3c", "ly_rf3m", "ly_rfcbam3")
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16; fp32-grade products take 3 bf16 MFMAs (csrc/ly_tile.cuh)
 ARITH = {"f32": "fp32 storage and accumulation, bf16x3 split products on the bf16 matrix cores (~2^-16 per product)",
          "bf16": "bf16 activations / saved tensors / activation gradients, single-plane bf16 MFMA products, fp32 accumulate, "
@@ -87,17 +90,20 @@ def probe_step(step_fn, iters=2):
     finally:
         recs, ops.PROFILE = ops.PROFILE, None
     table = {}
-    for name, flops, nbytes, e0, e1 in recs:
-        t = table.setdefault(name, dict(kernel=name, calls=0, ms=0.0, flops=0.0, bytes=0.0))
+    for name, flops, nbytes, e0, e1, vflops in recs:
+        t = table.setdefault(name, dict(kernel=name, calls=0, ms=0.0, flops=0.0, bytes=0.0, valu_flops=0.0))
+        if not name.startswith(MFMA_KERNELS):         # no matrix instruction in the kernel: whatever arithmetic it reports is vector work
+            flops, vflops = 0.0, vflops + flops
         t["calls"] += 1
         t["ms"] += e0.elapsed_time(e1)
         t["flops"] += flops
+        t["valu_flops"] += vflops
         t["bytes"] += nbytes
     rows = []
     for t in table.values():
         c = t["calls"]
         rows.append(dict(kernel=t["kernel"], calls_per_step=c / iters, ms_per_launch=t["ms"] / c, ms_per_step=t["ms"] / iters,
-                         flops=t["flops"] / c, bytes=t["bytes"] / c))
+                         flops=t["flops"] / c, valu_flops=t["valu_flops"] / c, bytes=t["bytes"] / c))
     rows.sort(key=lambda r: -r["ms_per_step"])
     return rows
 
@@ -371,12 +377,19 @@ def roofline_of(rows, dtype, families=None):
                 break
     gbs = dom["bytes"] / dom["ms_per_launch"] / 1e6
     tfs = dom["flops"] / dom["ms_per_launch"] / 1e9
+    vtfs = dom.get("valu_flops", 0.0) / dom["ms_per_launch"] / 1e9
     hbm_frac = gbs / HBM_PEAK_GBS
     mfma_peak = BF16_MFMA_PEAK_TFLOPS if dtype == "bf16" else BF16_MFMA_PEAK_TFLOPS / 3.0
     mfma_frac = tfs / mfma_peak
-    if mfma_frac >= hbm_frac:
+    valu_frac = vtfs / VALU_F32_PEAK_TFLOPS
+    # the roof the kernel sits closest to: every fraction = algorithmic work of ONE launch / its mean duration / that unit's peak
+    if mfma_frac >= hbm_frac and mfma_frac >= valu_frac:
         roof = dict(bound="mfma", achieved=round(tfs, 2), peak=round(mfma_peak, 1), unit="TFLOP/s", frac=round(mfma_frac, 4),
                     peak_note="dense bf16 2500 TFLOP/s" + ("" if dtype == "bf16" else " / 3: fp32-grade products = 3 bf16 MFMAs"))
+    elif valu_frac >= hbm_frac:
+        roof = dict(bound="valu", achieved=round(vtfs, 2), peak=VALU_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=round(valu_frac, 4),
+                    peak_note="fp32 vector peak 157.3 TFLOP/s (packed FMA): the kernel's dominant algorithmic work is the RFCBAM generate "
+                              "regeneration (81 MAC per output pixel and channel per pass), which is vector arithmetic by construction")
     else:
         roof = dict(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(hbm_frac, 4))
     tr = committed_pmc(dom["kernel"], "pmc_traffic")
@@ -389,16 +402,19 @@ def roofline_of(rows, dtype, families=None):
     roof["ms_per_launch"] = round(dom["ms_per_launch"], 5)
     roof["ms_per_step"] = round(dom["ms_per_step"], 4)
     roof["algorithmic_bytes_per_launch"] = round(dom["bytes"])
-    roof["algorithmic_flops_per_launch"] = round(dom["flops"])
+    roof["algorithmic_mfma_flops_per_launch"] = round(dom["flops"])
+    roof["algorithmic_valu_flops_per_launch"] = round(dom.get("valu_flops", 0.0))
     roof["hbm_frac"] = round(hbm_frac, 4)
     roof["mfma_frac"] = round(mfma_frac, 4)
+    roof["valu_frac"] = round(valu_frac, 4)
     return roof
 
 
 def print_layers(rows):
     for r in rows:
         print(f"  {r['kernel']:<58} {r['calls_per_step']:5.1f}/step {r['ms_per_launch'] * 1e3:8.1f} us  {r['ms_per_step'] * 1e3:8.1f} us/step  "
-              f"{r['bytes'] / r['ms_per_launch'] / 1e6:8.1f} GB/s  {r['flops'] / r['ms_per_launch'] / 1e9:8.2f} TFLOP/s", file=sys.stderr)
+              f"{r['bytes'] / r['ms_per_launch'] / 1e6:8.1f} GB/s  {r['flops'] / r['ms_per_launch'] / 1e9:8.2f} MFMA TFLOP/s  "
+              f"{r.get('valu_flops', 0.0) / r['ms_per_launch'] / 1e9:7.2f} VALU TFLOP/s", file=sys.stderr)
 
 
 class Ctx:

@@ -266,7 +266,8 @@ int ly_wgrad3_launch(const LyWgradParams& P, hipStream_t st) {
   chunks = (total + tchunk - 1) / tchunk;
   // partial tiles by plain stores + one combine launch when the scratch holds them; float atomics otherwise
   const long need = chunks * n_n * n_c * (long)(W3_BN * 288);
-  float* slab = (P.ws && need <= P.ws_floats && !getenv("LY_W3_ATOMIC")) ? P.ws : nullptr;
+  static const bool force_atomic = getenv("LY_W3_ATOMIC") != nullptr;          // development switch, read once
+  float* slab = (P.ws && need <= P.ws_floats && !force_atomic) ? P.ws : nullptr;
   hipLaunchKernelGGL(ly_wgrad3_kernel, dim3((unsigned)(chunks * n_n * n_c)), dim3(LY_THREADS), 0, st, P, tiles_x, tiles_y, n_n, n_c, (int)tchunk,
                      (int)total, slab);
   if (slab) {

@@ -219,6 +219,9 @@ class GradReducer:
                 self._launch(bi)
 
     def wait(self):
+        """Finish the step's exchange.  Afterwards `p.grad` (the bucket views) holds the MEAN over ranks — unless `defer_average` is set
+        (train.train_step sets it only while the consumer is an optim.FusedSGD whose `grad_scale` is 1 / world): then the buckets hold the
+        SUM over ranks and the optimiser divides while it reads; any other reader of `p.grad` must divide by `self.world` itself."""
         self.reduce_now()
         self.wait_works()
 

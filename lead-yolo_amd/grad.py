@@ -906,7 +906,7 @@ class RfcbamFn(torch.autograd.Function):
             wg = gen_w.detach().float().reshape(c * kk, kk).contiguous()
             ug = torch.empty((mo, kk * c), dtype=dt, device=dev)
             es9 = xr.element_size() * mo * kk * c                 # bytes of one expanded tensor
-            with ops._Timed(f"ly_rf_generate_kernel<{ops._tname(xr)}, {k}>", 2.0 * mo * kk * kk * c, xr.element_size() * n * h * w * c + es9):
+            with ops._Timed(f"ly_rf_generate_kernel<{ops._tname(xr)}, {k}>", 0.0, xr.element_size() * n * h * w * c + es9, valu_flops=2.0 * mo * kk * kk * c):
                 L.check(L.lib().ly_rf_generate(p(xr), ld, n, h, w, c, k, s, p(wg), p(ug), code, st), "ly_rf_generate")
             # 5. cd, d_rfa, gmax, d_ca
             cd = torch.empty((mo, kk * c), dtype=dt, device=dev)
@@ -962,7 +962,7 @@ class RfcbamFn(torch.autograd.Function):
             # 10. dug, generate weight gradient
             part_rows = 512
             dwg = torch.zeros(part_rows, c * kk, kk, dtype=torch.float32, device=dev)         # per-block partial sums, summed below
-            with ops._Timed(f"ly_rf_bwd_gen_kernel<{ops._tname(xr)}, {k}>", 2.0 * mo * kk * kk * c, 3.0 * es9):
+            with ops._Timed(f"ly_rf_bwd_gen_kernel<{ops._tname(xr)}, {k}>", 0.0, 3.0 * es9, valu_flops=2.0 * mo * kk * kk * c):
                 L.check(L.lib().ly_rf_bwd_gen(p(xr), ld, n, h, w, c, k, s, p(ug), p(dcd), p(alpha), p(kappa), p(lam), p(dwg), part_rows, code, st),
                         "ly_rf_bwd_gen")
             _tap("rf.coef", alpha); _tap("rf.dwg", dwg)
@@ -980,7 +980,7 @@ class RfcbamFn(torch.autograd.Function):
             dx = None
             if ctx.needs_input_grad[1]:
                 dx = ops.empty_nhwc(n, c, h, w, xr)
-                with ops._Timed(f"ly_rf_bwd_dx_kernel<{ops._tname(xr)}, {k}>", 2.0 * mo * kk * kk * c, es9 + xr.element_size() * n * h * w * c):
+                with ops._Timed(f"ly_rf_bwd_dx_kernel<{ops._tname(xr)}, {k}>", 0.0, es9 + xr.element_size() * n * h * w * c, valu_flops=2.0 * mo * kk * kk * c):
                     L.check(L.lib().ly_rf_bwd_dx(n, h, w, c, k, s, p(dcd), p(wg), p(dx), c, p(dgap), 1.0 / (h * w), code, st), "ly_rf_bwd_dx")
             dbias = None if ops.grad_target(ctx.conv_b_param) is not None else torch.zeros_like(bias)      # BN removes the batch mean: d/dbias = 0
         return (None, dx, None if se_direct else dwa, None if se_direct else dwb, ops.sum_rows(dwg).view(gen_w.shape), ct(dgg_tc), ct(dbg_tc),
@@ -1014,10 +1014,10 @@ def _rfcbam_backward_rc(ctx, du, dgo, dbo):
     xb = xr.element_size() * (n * h * w * c + mo * o)
     tn = ops._tname(xr)
     # A: d_rfa (one slab per channel chunk), d_ca
-    with ops._Timed(f"ly_rf3c_bwd_kernel<0, {o // 32}>", 2.0 * mo * 9 * c * (o + 81), xb):
+    with ops._Timed(f"ly_rf3c_bwd_kernel<0, {o // 32}>", 2.0 * mo * 9 * c * o, xb, valu_flops=2.0 * mo * c * 81):
         L.check(L.lib().ly_rf3c_bwd(ctypes.byref(P), 0, st), "ly_rf3c_bwd A")
     # conv weight gradient (independent of the chain below)
-    with ops._Timed("ly_rf3c_wgrad_kernel", 2.0 * mo * 9 * c * (o + 81), xb):
+    with ops._Timed("ly_rf3c_wgrad_kernel", 2.0 * mo * 9 * c * o, xb, valu_flops=2.0 * mo * c * 81):
         L.check(L.lib().ly_rf3c_wgrad(ctypes.byref(P), st), "ly_rf3c_wgrad")
     dwc = ops.sum_rows(dwc_part) if ng > 1 else dwc_part[0]
     dwc = dwc.permute(0, 2, 1).reshape(conv_w.shape)
@@ -1033,7 +1033,7 @@ def _rfcbam_backward_rc(ctx, du, dgo, dbo):
         ops.grad_done(ctx.getw_param)
     P.d_mm = p(d_mm)
     # B: BatchNorm sums, one stripe per image
-    with ops._Timed(f"ly_rf3c_bwd_kernel<1, {o // 32}>", 2.0 * mo * 9 * c * (o + 81), xb):
+    with ops._Timed(f"ly_rf3c_bwd_kernel<1, {o // 32}>", 2.0 * mo * 9 * c * o, xb, valu_flops=2.0 * mo * c * 81):
         L.check(L.lib().ly_rf3c_bwd(ctypes.byref(P), 1, st), "ly_rf3c_bwd B")
     dgg_tc, dbg_tc, alpha, kappa, lam = ops.bn_bwd_coeffs(sums, 9 * c, mo, ag, gmean_tc, ginv_tc, True)
     P.coef = p(alpha)                          # alpha, kappa, lambda are rows 2..4 of one [5, 9c] tensor
@@ -1052,7 +1052,8 @@ def _rfcbam_backward_rc(ctx, du, dgo, dbo):
     P.dgap = p(dgap)
     P.TH, P.TW = ops.pick_tile_bwd_dx(ho, wo, o)          # pass C walks its pixel pairs in four colours: its own tile choice
     # C: generate weight gradient rows + dx
-    with ops._Timed(f"ly_rf3c_bwd_kernel<2, {o // 32}>", 2.0 * mo * 9 * c * (o + 243), xb + xr.element_size() * n * h * w * c):
+    # pass C: regenerate (81 MAC) + generate weight gradient (81) + dx (81) per (output pixel, channel) on the VALU; dG = W^T du on the MFMAs
+    with ops._Timed(f"ly_rf3c_bwd_kernel<2, {o // 32}>", 2.0 * mo * 9 * c * o, xb + xr.element_size() * n * h * w * c, valu_flops=2.0 * mo * c * 243):
         L.check(L.lib().ly_rf3c_bwd(ctypes.byref(P), 2, st), "ly_rf3c_bwd C")
     dbias = None if ops.grad_target(ctx.conv_b_param) is not None else torch.zeros_like(bias)      # BN removes the batch mean: d/dbias = 0
     return (None, dx if need_dx else None, None if se_direct else dwa, None if se_direct else dwb, ops.sum_rows(dwg).view(gen_w.shape), ct(dgg_tc), ct(dbg_tc),

@@ -325,9 +325,9 @@ class _PatchConv(nn.Module):
             if x.dtype == torch.uint8:
                 # a uint8 image = pixel values to be scaled by 1/255, what the training loop does before the model (train.py:309
                 # `imgs.float() / 255`): the gather kernel does it while loading, so the fp32 copy of the batch never exists
-                want = torch.get_autocast_gpu_dtype() if torch.is_autocast_enabled() else torch.float32
+                want = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else torch.float32
             else:
-                want = torch.get_autocast_gpu_dtype() if (torch.is_autocast_enabled() and x.dtype == torch.float32) else x.dtype
+                want = torch.get_autocast_dtype("cuda") if (torch.is_autocast_enabled("cuda") and x.dtype == torch.float32) else x.dtype
             odt = torch.float32 if want == torch.float32 else torch.bfloat16
             back = torch.float16 if want == torch.float16 else None
             if x.dtype != torch.uint8:
@@ -681,14 +681,9 @@ class RFCBAMConv(nn.Module):
             es, eb = ops.bn_finalize(self.conv[1], stats, self.o, n * ho * wo, bias=bias)
         out = ops.empty_nhwc(n, self.o, ho, wo, xr)
         ops.rf3c_fwd(out=out, e_scale=es, e_shift=eb, **kw)
-        import os
-        if os.environ.get("LY_LOG_ALLOC"):
-            cap = torch.cuda.is_current_stream_capturing()
-            _HOLD.append((self.c, cap, {nm: (t_ if cap else t_.clone()) for nm, t_ in (("xr", xr), ("mm", mm), ("part", part), ("ca", ca), ("rfa", rfa), ("out", out))}))
         return out
 
 
-_HOLD = []
 RF3C = True        # tools / tests: False runs the first-generation k=3 kernels (lane = pixel) for A/B comparisons
 
 

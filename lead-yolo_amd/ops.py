@@ -21,12 +21,14 @@ PROFILE = None
 
 class _Timed:
     """Brackets one C-ABI call with events on the launch stream and records (kernel name as rocprofv3
-    prints it, algorithmic flops, algorithmic bytes)."""
+    prints it, algorithmic MFMA flops, algorithmic bytes, algorithmic VALU flops).  `flops` = 2*MAC of the contractions that run on
+    the matrix cores; `valu_flops` = 2*MAC of work that is vector arithmetic by construction (the RFCBAM `generate` regeneration:
+    81 MAC per (output pixel, channel) and pass; the two are priced against different peaks)."""
 
-    def __init__(self, name, flops, nbytes):
+    def __init__(self, name, flops, nbytes, valu_flops=0.0):
         self.rec = None
         if PROFILE is not None:
-            self.rec = [name, float(flops), float(nbytes), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
+            self.rec = [name, float(flops), float(nbytes), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), float(valu_flops)]
 
     def __enter__(self):
         if self.rec is not None:
@@ -104,8 +106,8 @@ def edge_in(x, who, mod=None):
     if not x.is_cuda:
         raise RuntimeError(f"{who}: the HIP path needs a CUDA/ROCm tensor (got {x.device}); there is no CPU fallback")
     want = x.dtype
-    if torch.is_autocast_enabled() and x.dtype == torch.float32:
-        want = torch.get_autocast_gpu_dtype()
+    if torch.is_autocast_enabled("cuda") and x.dtype == torch.float32:
+        want = torch.get_autocast_dtype("cuda")
     if want not in (torch.float32, torch.bfloat16, torch.float16):
         raise NotImplementedError(f"{who}: unsupported activation dtype {x.dtype}")
     compute = torch.bfloat16 if want == torch.float16 else want
@@ -359,7 +361,7 @@ def rf3c_stats(x, ldx, n, h, w, c, s, wq, th, tw, gap=True, raw=False):
     mm = torch.empty((n, 3 * ho, 3 * wo, 2), dtype=torch.float32, device=x.device)
     tiles = -(-ho // th) * -(-wo // tw)
     part = torch.empty((n, tiles, c), dtype=torch.float32, device=x.device) if gap else None
-    with _Timed(f"ly_rf3c_stats_kernel<{_tname(x)}, {s}, {'true' if raw else 'false'}>", 2.0 * n * ho * wo * c * 81, x.element_size() * n * h * w * c + 4.0 * 18 * n * ho * wo):
+    with _Timed(f"ly_rf3c_stats_kernel<{_tname(x)}, {s}, {'true' if raw else 'false'}>", 0.0, x.element_size() * n * h * w * c + 4.0 * 18 * n * ho * wo, valu_flops=2.0 * n * ho * wo * c * 81):
         capi.check(capi.lib().ly_rf3c_stats(_p(x), ldx, n, h, w, c, s, _p(wq), int(raw), th, tw, _p(mm), _p(part), tiles, capi.dtype_code(x),
                                             capi.stream_ptr()), "ly_rf3c_stats")
     return mm, part
@@ -371,8 +373,8 @@ def rf3c_fwd(*, n, h, w, c, ho, wo, N, s, th, tw, x, ldx, wq, ca, rfa, wp, e_sca
     mo = n * ho * wo
     bf = x.dtype == torch.bfloat16
     cfg = "2, 8" if (N > 128 and bf) else ("2, 4" if N > 64 else "1, 4")         # mirrors rc_dispatch_fwd
-    with _Timed(f"ly_rf3c_fwd_kernel<{_tname(x)}, {cfg}, {s}, {'true' if raw else 'false'}>", 2.0 * mo * (9 * c * N + 81 * c),
-                x.element_size() * (n * h * w * c + mo * N) + 4.0 * 9 * c * N):
+    with _Timed(f"ly_rf3c_fwd_kernel<{_tname(x)}, {cfg}, {s}, {'true' if raw else 'false'}>", 2.0 * mo * 9 * c * N,
+                x.element_size() * (n * h * w * c + mo * N) + 4.0 * 9 * c * N, valu_flops=2.0 * mo * 81 * c):
         capi.check(capi.lib().ly_rf3c_fwd(ctypes.byref(P), _p(wq), int(raw), capi.stream_ptr()), "ly_rf3c_fwd")
 
 
@@ -387,8 +389,8 @@ def rfcbam_stats(x, ldx, n, h, w, c, k, s, wg=None, a1=None, b1=None, th=1, tw=6
                                       "than the separate ly_colsum launch it saved: measured 44 -> 69 us)")
         slices = max(1, min(h * w // 16, 128))            # a function of the map only: results do not change with the batch split
         part = torch.empty((n, slices, c), dtype=torch.float32, device=x.device)
-    with _Timed((f"ly_rfcbam_pre1_kernel<{_tname(x)}>" if (gap and k == 1) else f"ly_rfcbam_stats{k}_kernel<{_tname(x)}>"), 2.0 * n * ho * wo * c * (81 if k == 3 else 1),
-                x.element_size() * n * h * w * c + 4.0 * 2 * k * k * n * ho * wo):
+    with _Timed((f"ly_rfcbam_pre1_kernel<{_tname(x)}>" if (gap and k == 1) else f"ly_rfcbam_stats{k}_kernel<{_tname(x)}>"), 0.0,
+                x.element_size() * n * h * w * c + 4.0 * 2 * k * k * n * ho * wo, valu_flops=2.0 * n * ho * wo * c * (81 if k == 3 else 1)):
         capi.check(capi.lib().ly_rfcbam_stats(_p(x), ldx, n, h, w, c, k, s, _p(wg), _p(a1), _p(b1), th, tw, _p(mm), _p(part), slices,
                                               capi.dtype_code(x), capi.stream_ptr()), "ly_rfcbam_stats")
     return (mm, part) if gap else mm
@@ -420,8 +422,8 @@ def rfcbam3(*, n, h, w, c, ho, wo, N, s, th, tw, x, ldx, wg, ca, rfa, wp, e_scal
     mt = 4 if N > 128 else (2 if N > 64 else 1)            # mirrors ly_rfcbam3_fwd
     mo = n * ho * wo
     sw = mt == 4 and n * -(-ho // th) * -(-wo // tw) * -(-N // 256) > 256    # mirrors launch_rf3: weights via the scalar cache
-    with _Timed(f"ly_rfcbam3{'_sw' if sw else ''}_kernel<{_tname(x)}, {mt}>", 2.0 * mo * (9 * c * N + 81 * c),
-                x.element_size() * (n * h * w * c + mo * N) + 4.0 * 9 * c * N):
+    with _Timed(f"ly_rfcbam3{'_sw' if sw else ''}_kernel<{_tname(x)}, {mt}>", 2.0 * mo * 9 * c * N,
+                x.element_size() * (n * h * w * c + mo * N) + 4.0 * 9 * c * N, valu_flops=2.0 * mo * 81 * c):
         capi.check(capi.lib().ly_rfcbam3_fwd(ctypes.byref(P), capi.stream_ptr()), "ly_rfcbam3_fwd")
 
 
@@ -581,6 +583,8 @@ class GradSink:
 
     def __init__(self):
         self.targets = {}          # id(param) -> gradient tensor (same shape as the parameter, fp32, contiguous)
+        self.writes = 0            # bumped whenever a backward kernel is handed a target (or a captured backward is replayed): the
+                                   # optimiser's zero_grad() compares it with the value at its last step() to know whether the storage is dirty
 
     def target(self, p):
         if p is None or not torch.is_tensor(p):
@@ -588,6 +592,8 @@ class GradSink:
         t = self.targets.get(id(p))
         if t is not None and p.grad is not t:
             return None                         # someone re-assigned .grad: fall back to autograd for this one
+        if t is not None:
+            self.writes += 1
         return t
 
 

@@ -54,6 +54,8 @@ class FusedSGD(torch.optim.Optimizer):
         self._grad_ptrs = None
         self.grad_norm = None           # device scalar: pre-clip global gradient norm of the last step
         self._zeroed = False
+        self._sink = None               # the ops.GradSink this optimiser installed; _writes_at_step: its write counter when step() last zeroed the storage
+        self._writes_at_step = -1
         self.grad_scale = 1.0           # gradients are read as g * grad_scale: 1 / world_size when the buckets are all-reduced as SUMs
 
     # ---- EMA -----------------------------------------------------------------------------------------------------
@@ -169,6 +171,7 @@ class FusedSGD(torch.optim.Optimizer):
         sink = ops.GradSink()
         sink.targets = {id(p): p.grad for g in self.param_groups for p in g["params"] if p.requires_grad}
         ops.SINK = sink
+        self._sink = sink
 
     def _sync_hyper(self):
         """learning rates follow param_groups (schedulers / warm-up write them); one small H2D copy only when they change"""
@@ -207,22 +210,40 @@ class FusedSGD(torch.optim.Optimizer):
         if self._ema is not None and not capturing:
             self._ema[0].updates += 1
         self._zeroed = True
+        self._writes_at_step = self._sink.writes if self._sink is not None else -1
 
     def load_state_dict(self, state_dict):
         """loaded momentum buffers are new tensors: the device table must be rebuilt around them"""
         super().load_state_dict(state_dict)
         self._table = None
 
+    def mark_dirty(self):
+        """a backward wrote gradients behind this object's back (a replayed graph: train.GraphedTrainStep)"""
+        self._zeroed = False
+
+    def mark_stepped(self):
+        """a replayed optimiser graph has just consumed and zeroed the gradients"""
+        self._zeroed = True
+        self._writes_at_step = self._sink.writes if self._sink is not None else -1
+
+    def _clean(self):
+        """the storage is exactly as step() left it: zeroed, and no backward kernel has been handed a target since (the sink counts them;
+        a backward that went through autograd's AccumulateGrad instead — sink replaced or `.grad` re-assigned — counts as dirty too)"""
+        from . import ops
+        return self._zeroed and self._sink is not None and ops.SINK is self._sink and self._sink.writes == self._writes_at_step
+
     def zero_grad(self, set_to_none=False):
         """Gradients stay allocated (the table, the backward kernels and a captured graph point at them) and step() leaves them zeroed,
-        so the reference loop's `optimizer.step(); optimizer.zero_grad()` costs nothing; called WITHOUT a preceding step() (a skipped
-        step: gradients to be discarded) it zeroes the persistent storage in place."""
+        so the reference loop's `optimizer.step(); optimizer.zero_grad()` costs nothing.  Whenever a backward may have run since the last
+        step() — a skipped / NaN step whose gradients are to be discarded, an abandoned micro-batch — it zeroes the persistent storage in
+        place (one foreach launch)."""
         if self._table is None:
             super().zero_grad(set_to_none=False)
-        elif not self._zeroed:
+        elif not self._clean():
             grads = [p.grad for g in self.param_groups for p in g["params"] if p.requires_grad and p.grad is not None]
             if grads:
                 torch._foreach_zero_(grads)
-        self._zeroed = False
+            self._zeroed = True
+            self._writes_at_step = self._sink.writes if self._sink is not None else -1
 
     fused = True

@@ -99,6 +99,7 @@ def optimizer_step(model, optimizer, ema=None, max_norm=10.0, reducer=None):
         optimizer.max_norm = max_norm
         optimizer.step()
     else:
+        assert reducer is None or not reducer.defer_average, "a non-fused optimiser reads p.grad as it is: the reducer must average its buckets"
         torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=max_norm)
         optimizer.step()
         if reducer is None:
@@ -109,10 +110,22 @@ def optimizer_step(model, optimizer, ema=None, max_norm=10.0, reducer=None):
 
 def _set_deferred_average(optimizer, reducer):
     """with the fused optimiser the mean over ranks costs nothing: buckets are all-reduced as SUMs and FusedSGD reads every gradient as
-    g / world (one device scalar) — instead of one division launch per bucket"""
-    if getattr(optimizer, "fused", False) and reducer.average:
+    g / world (one device scalar) — instead of one division launch per bucket.
+    Every step re-derives both flags from the pair it is given, so neither sticks: an optimiser later used WITHOUT the reducer reads plain
+    gradients again, and a reducer later paired with a non-fused optimiser (torch.optim.SGD, gradient logging, clip_grad_norm_) goes back
+    to averaging its buckets itself — `p.grad` is the SUM over ranks only while a FusedSGD with grad_scale = 1 / world is the consumer."""
+    fused = getattr(optimizer, "fused", False)
+    if reducer is None:
+        if fused and optimizer.grad_scale != 1.0:
+            optimizer.grad_scale = 1.0
+        return
+    if fused and reducer.average:
         reducer.defer_average = True
         optimizer.grad_scale = 1.0 / reducer.world
+    else:
+        reducer.defer_average = False
+        if fused:
+            optimizer.grad_scale = 1.0
 
 
 def train_step(model, compute_loss, optimizer, imgs, targets, ema=None, reducer=None, world_size=1, max_norm=10.0, amp=None):
@@ -120,8 +133,8 @@ def train_step(model, compute_loss, optimizer, imgs, targets, ema=None, reducer=
     amp: None (fp32 storage) or torch.bfloat16 — forward and loss run inside torch.autocast(dtype=amp), the reference's
     `with torch.cuda.amp.autocast(amp)` region (train.py:316) with bf16 in place of fp16 (no GradScaler needed: bf16 keeps
     fp32's exponent range).  Returns (loss, loss_items) as detached device tensors (no host sync)."""
+    _set_deferred_average(optimizer, reducer)
     if reducer is not None:
-        _set_deferred_average(optimizer, reducer)
         reducer.reset()
     loss, items = forward_backward(model, compute_loss, imgs, targets, world_size=world_size, amp=amp)
     if reducer is not None:
@@ -187,6 +200,25 @@ class GraphedTrainStep:
         self._pack_table, self._pack_images = pack.PLAN.private_table(sorted(traced or (), key=repr))
         pack.PLAN.capture_table = self._pack_table
         pack.touch_weights()                   # the captured step must begin with the (single) refresh of every packed weight image
+        try:
+            self._capture(model, compute_loss, optimizer, ema, amp, max_norm, reducer, world_size, capi)
+        finally:
+            # also on a failed capture (bench.py falls back to eager): the global plan must not keep launching this object's private table,
+            # and the reducer must not keep calling the capture's marker
+            pack.PLAN.capture_table = None
+            if reducer is not None and getattr(reducer, "_mark_fn", None) is not None:
+                reducer._mark_fn, reducer._mark_order = None, []
+                reducer.reset()
+        # Everything the graphs address through raw pointers must outlive them (ADVICE r2): the step's zero pool (ops._POOL.buf is replaced
+        # when a later, larger step grows it), the loss constants (replaced when the level shapes change), the optimiser's tensor table
+        # (rebuilt when a gradient pointer changes).  A later eager step or a second GraphedTrainStep at another shape would otherwise
+        # free memory these graphs still zero-fill and add into.
+        self._pins = (ops._POOL.buf, dict(getattr(compute_loss, "_const", {})), optimizer._table)
+        # packed weight images were only RECORDED as refreshed during the capture: an eager forward before the first replay must rebuild them
+        pack.touch_weights()
+
+    def _capture(self, model, compute_loss, optimizer, ema, amp, max_norm, reducer, world_size, capi):
+        imgs = self.imgs
         if reducer is None and self.accumulate == 1 and not os.environ.get("LY_SPLIT_GRAPHS"):
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self.loss, self.items = train_step(model, compute_loss, optimizer, self.imgs, self.targets, ema=ema, amp=amp, max_norm=max_norm)
@@ -221,14 +253,6 @@ class GraphedTrainStep:
             self.opt_graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.opt_graph, pool=self.graph.pool(), capture_error_mode="thread_local"):
                 optimizer_step(model, optimizer, ema=ema, max_norm=max_norm, reducer=reducer)
-        pack.PLAN.capture_table = None
-        # Everything the graphs address through raw pointers must outlive them (ADVICE r2): the step's zero pool (ops._POOL.buf is replaced
-        # when a later, larger step grows it), the loss constants (replaced when the level shapes change), the optimiser's tensor table
-        # (rebuilt when a gradient pointer changes).  A later eager step or a second GraphedTrainStep at another shape would otherwise
-        # free memory these graphs still zero-fill and add into.
-        self._pins = (ops._POOL.buf, dict(getattr(compute_loss, "_const", {})), optimizer._table)
-        # packed weight images were only RECORDED as refreshed during the capture: an eager forward before the first replay must rebuild them
-        pack.touch_weights()
 
     def __del__(self):
         # the bucket events are released only while the interpreter (and with it the HIP runtime) is certainly alive: destroying them from a
@@ -269,6 +293,7 @@ class GraphedTrainStep:
             self.stepped = True
             return self.loss, self.items
         self.graph.replay()                                # forward + backward: gradients add into the persistent storage / bucket views
+        self.optimizer.mark_dirty()                        # (a zero_grad() now — an abandoned micro-batch — must really zero them)
         self._micro += 1
         self.stepped = self._micro >= self.accumulate
         if not self.stepped:
@@ -297,6 +322,7 @@ class GraphedTrainStep:
             red.wait_works()                               # the step's stream waits for RCCL's
             cur.wait_stream(comm)
         self.opt_graph.replay()
+        self.optimizer.mark_stepped()
         pack.touch_weights()
         if self.ema is not None:
             self.ema.updates += 1

@@ -30,7 +30,17 @@ def test_single_gpu_line():
     assert KEYS <= set(d) and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 2 and d["dtype"] == "bf16" and d["scaling"] == "weak"
     assert d["metric"] == "images/sec (640x640) fwd+bwd" and d["value"] > 0 and d["higher_is_better"] is True and d["vs_baseline"] is None
     r = d["roofline"]
-    assert r["bound"] in ("hbm", "mfma") and r["peak"] == {"hbm": 8000.0, "mfma": 2500.0}[r["bound"]] and 0 < r["frac"] < 1 and abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-3
+    assert r["bound"] in ("hbm", "mfma", "valu") and r["peak"] == {"hbm": 8000.0, "mfma": 2500.0, "valu": 157.3}[r["bound"]]
+    assert 0 < r["frac"] < 1 and abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-3
+    # the fractions follow from the line's own inputs: algorithmic work of one launch / its mean duration / the unit's peak
+    sec = r["ms_per_launch"] * 1e-3
+    assert abs(r["algorithmic_bytes_per_launch"] / sec / 8e12 - r["hbm_frac"]) < 2e-3
+    assert abs(r["algorithmic_mfma_flops_per_launch"] / sec / 2.5e15 - r["mfma_frac"]) < 2e-3
+    assert abs(r["algorithmic_valu_flops_per_launch"] / sec / 157.3e12 - r["valu_frac"]) < 2e-3
+    assert r["frac"] == max(r["hbm_frac"], r["mfma_frac"], r["valu_frac"])
+    busy = (r.get("mfma_busy") or {}).get("mfma_busy_frac")
+    if busy and d["config"].get("global_batch") == 64:        # the committed PMC pass is the default (bs = 64) workload's
+        assert r["mfma_frac"] <= 1.5 * busy + 1e-3, "the MFMA fraction claimed exceeds what the matrix-pipe counter saw"
     assert r["step"]["families"] and abs(d["value"] - 8 * 1e3 / d["ms_per_step"]) < 1e-2 * d["value"]
     assert "workload" in d["config"] and "model" not in d["config"]
 

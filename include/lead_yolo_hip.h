@@ -191,6 +191,19 @@ int ly_rf3c_stats(const void* x /*T*/, int ldx, int n_img, int H, int W, int C, 
                   float* part, int slices, int dtype, void* stream);
 int ly_rf3c_fwd(const LyRfcbam3Params* p, const float* wq, int raw, void* stream);
 
+/* ---- RFCBAMConv kernel_size 3 with `generate` on the matrix cores (csrc/ly_rf3m.hip; models/rfa.py:113-129) --------------------------
+ * bf16 storage, inference form (BatchNorm folded), C % 32 == 0, stride 1 or 2, tiles TH x TW of at most 32 output pixels that read at most
+ * 160 input positions.  The depthwise 3x3 `generate` is a block-diagonal v_mfma_f32_32x32x16_bf16 product whose accumulator layout is the
+ * B operand of the main contraction: relu, * ca * rfa and the bf16 conversion happen in registers.
+ * wst / p->wp = pack.rf3m_stream(...): every A fragment in consumption order (the header of csrc/ly_rf3m.hip and pack.py give the index map).
+ * ly_rf3m_stats: mm[n, 3Ho, 3Wo, 2] = [max_c, mean_c] of relu(bn(generate(x))) (models/rfa.py:125-126) and, if part != NULL, the SE
+ *      global-average-pool partials part[n][tile][C] (models/rfa.py:90; slices = tile count) from ONE pass over x.
+ * ly_rf3m_fwd:  out = relu(bn(conv_{3x3, stride 3}(G * ca * rfa) + bias)) (models/rfa.py:124, 128-129); p as for ly_rfcbam3_fwd with
+ *      dtype LY_BF16, stats == NULL, linear == 0, N % 64 == 0, p->wg ignored.                                                          */
+int ly_rf3m_stats(const void* x /*bf16*/, int ldx, int n_img, int H, int W, int C, int s, const void* wst, int TH, int TW, float* mm, float* part,
+                  int slices, void* stream);
+int ly_rf3m_fwd(const LyRfcbam3Params* p, void* stream);
+
 /* RFCBAMConv kernel_size 3 backward without 9x-sized tensors (csrc/ly_rf3c_bwd.hip; autograd of models/rfa.py:113-129): every pass
  * re-derives dcd = du . Wc^T (MFMA) and generate / BatchNorm / ReLU (VALU, bit-identical to the training forward, raw wq) on chip from
  * x and du.  bf16 storage, stride 2, C % 32 == 0, tiles as ly_rf3c_fwd.

@@ -109,6 +109,8 @@ SIGNATURES = {
     "ly_rfcbam_gen_prepare": [_P, _I, _I, _P, _P, _P, _F, _F, ctypes.c_double, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "ly_rf3c_stats": [_P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _I, _P, _P, _I, _I, _P],
     "ly_rf3c_fwd": [ctypes.POINTER(LyRfcbam3Params), _P, _I, _P],
+    "ly_rf3m_stats": [_P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P, _I, _P],
+    "ly_rf3m_fwd": [ctypes.POINTER(LyRfcbam3Params), _P],
     "ly_rf3c_bwd": [ctypes.POINTER(LyRf3cBwdParams), _I, _P],
     "ly_rf3c_wgrad": [ctypes.POINTER(LyRf3cBwdParams), _P],
     "ly_coordatt_conv1_stats": [_P, _L, _I, _I, _P, _P, _P, _P],

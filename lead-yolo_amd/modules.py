@@ -547,7 +547,7 @@ class RFCBAMConv(nn.Module):
 
     def _packed(self, planes=2):
         gw, gbn, cw, cbn = self.generate[0].weight, self.generate[1], self.conv[0], self.conv[1]
-        key = pack.versions(gw, *_bn_tensors(gbn), cw.weight, cw.bias, *_bn_tensors(cbn), self.get_weight[0].weight) + (gbn.eps, cbn.eps)
+        key = pack.versions(gw, *_bn_tensors(gbn), cw.weight, cw.bias, *_bn_tensors(cbn), self.get_weight[0].weight) + (gbn.eps, cbn.eps, RF3M)
 
         def build():
             k, c, o = self.kernel_size, self.c, self.o
@@ -565,6 +565,9 @@ class RFCBAMConv(nn.Module):
             if ops.rf3c_ok(c, self.stride):
                 d["wq_c"] = pack.rfcbam_gen_weights_c(gw, gs, gb)
                 d["wp_c"] = self._wp_c(planes)
+            if planes == 1 and c % 32 == 0 and o % 64 == 0 and RF3M:
+                d["wm_stats"] = pack.rf3m_stream(gw, gs, gb)                                   # csrc/ly_rf3m.hip: generate on the matrix cores
+                d["wm"] = pack.rf3m_stream(gw, gs, gb, cw.weight, 4 if o % 128 == 0 else 2)
             return d
         return self._prep.get(key, build, planes)
 
@@ -634,6 +637,8 @@ class RFCBAMConv(nn.Module):
             ops.gemm(out=out, e_scale=es, e_shift=eb, act=ACT_RELU, **kw)
             return out
         ho, wo = (h + 2 - 3) // s + 1, (w + 2 - 3) // s + 1
+        if RF3M and not self.training and ops.rf3m_ok(xr, c, self.o, s):
+            return self._forward3_m(xr, ld, n, c, h, w, ho, wo, s, P, wa, wb)
         # (fp32 storage with more than 128 output channels: the lane = pixel kernels measure faster — layer 20 at bs=64: 215 vs 289 us —
         # the two-plane operand tile of the lane = channel kernel leaves one block per CU there)
         if ops.rf3c_ok(c, s) and RF3C and not (xr.dtype == torch.float32 and self.o > 128):
@@ -684,6 +689,19 @@ class RFCBAMConv(nn.Module):
         return out
 
 
+    def _forward3_m(self, xr, ld, n, c, h, w, ho, wo, s, P, wa, wb):
+        """k = 3, bf16, inference: `generate` as block-diagonal MFMA products whose accumulators feed the main contraction in registers
+        (csrc/ly_rf3m.hip) — (1) [max, mean] map + SE pooling partials, (2) SE linears + get_weight's conv, (3) generate + contraction"""
+        th, tw = ops.pick_tile_m(ho, wo, s)
+        mm, part = ops.rf3m_stats(xr, ld, n, h, w, c, s, P["wm_stats"], th, tw)
+        ca, rfa = ops.rfcbam_mid(part, h * w, wa, wb, self.se.ratio, mm, P["w18"])
+        out = ops.empty_nhwc(n, self.o, ho, wo, xr)
+        ops.rf3m_fwd(n=n, h=h, w=w, c=c, ho=ho, wo=wo, N=self.o, s=s, th=th, tw=tw, x=xr, ldx=ld, ca=ca, rfa=rfa, wp=P["wm"], e_scale=P["es"],
+                     e_shift=P["eb"], out=out, ldo=self.o)
+        return out
+
+
+RF3M = True        # tools / tests: False keeps the lane = channel kernels for the bf16 inference forward of k = 3
 RF3C = True        # tools / tests: False runs the first-generation k=3 kernels (lane = pixel) for A/B comparisons
 
 

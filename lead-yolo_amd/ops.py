@@ -319,6 +319,47 @@ def rf3c_ok(c, s):
     return c % 32 == 0 and s in (1, 2)
 
 
+def rf3m_ok(x, c, o, s):
+    """`generate` on the matrix cores (csrc/ly_rf3m.hip): bf16 storage, C % 32 == 0, O % 64 == 0, stride 1 / 2"""
+    return x.dtype == torch.bfloat16 and c % 32 == 0 and o % 64 == 0 and s in (1, 2)
+
+
+def pick_tile_m(ho, wo, s):
+    """TH x TW wave tile of csrc/ly_rf3m.hip: at most 32 output pixels reading at most 160 input positions; fewest tiles, then smallest halo"""
+    best = None
+    for tw in range(1, 33):
+        for th in range(1, 32 // tw + 1):
+            pos = (s * (th - 1) + 3) * (s * (tw - 1) + 3)
+            if pos > 160 or th > ho or tw > max(wo, 1) * 2:
+                continue
+            key = (-(-ho // th) * -(-wo // tw), pos)
+            if best is None or key < best[0]:
+                best = (key, th, tw)
+    return best[1], best[2]
+
+
+def rf3m_stats(x, ldx, n, h, w, c, s, wst, th, tw, gap=True):
+    """ONE pass over x (csrc/ly_rf3m.hip): (mm [n, 3ho, 3wo, 2], part [n, tiles, c])"""
+    ho, wo = (h + 2 - 3) // s + 1, (w + 2 - 3) // s + 1
+    mm = torch.empty((n, 3 * ho, 3 * wo, 2), dtype=torch.float32, device=x.device)
+    tiles = -(-ho // th) * -(-wo // tw)
+    part = torch.empty((n, tiles, c), dtype=torch.float32, device=x.device) if gap else None
+    # generate on the MFMAs: 3 + 3 products of 32 x 32 x 16 per 4-channel group and 32 pixels (3/4 of them multiply structural zeros)
+    with _Timed("ly_rf3m_stats_kernel", 2.0 * n * ho * wo * (c // 4) * 6 * 32 * 16, x.element_size() * n * h * w * c + 4.0 * 18 * n * ho * wo):
+        capi.check(capi.lib().ly_rf3m_stats(_p(x), ldx, n, h, w, c, s, _p(wst), th, tw, _p(mm), _p(part), tiles, capi.stream_ptr()), "ly_rf3m_stats")
+    return mm, part
+
+
+def rf3m_fwd(*, n, h, w, c, ho, wo, N, s, th, tw, x, ldx, ca, rfa, wp, e_scale, e_shift, out, ldo):
+    P = capi.LyRfcbam3Params(n, h, w, c, ho, wo, N, s, th, tw, _p(x), ldx, None, _p(ca), _p(rfa), _p(wp), _p(e_scale),
+                             _p(e_shift), _p(out), ldo, None, 0, capi.dtype_code(x))
+    mo = n * ho * wo
+    mt = 4 if N % 128 == 0 else 2
+    with _Timed(f"ly_rf3m_fwd_kernel<{mt}>", 2.0 * mo * 9 * c * N + 2.0 * mo * (N // (32 * mt)) * (c // 4) * 6 * 32 * 16,
+                x.element_size() * (n * h * w * c + mo * N) + 2.0 * 9 * c * N):
+        capi.check(capi.lib().ly_rf3m_fwd(ctypes.byref(P), capi.stream_ptr()), "ly_rf3m_fwd")
+
+
 def pick_tile_c(ho, wo, s):
     """TH x TW tile of the lane = channel kernels: TW even, TH*TW <= 64, at most 320 input positions; fewest tiles, then smallest halo"""
     best = None

@@ -123,6 +123,57 @@ def rfcbam_gen_weights_c(gen_w, scale, shift, raw=False):
     return out.view(c // 32, 32, 25, 4).permute(0, 2, 1, 3).contiguous().view(-1)
 
 
+def rf3m_stream(gen_w, scale, shift, conv_w=None, mt=4):
+    """Weight stream of csrc/ly_rf3m.hip (RFCBAMConv k=3, `generate` on the matrix cores; models/rfa.py:101-106, 110, 121-128): every A fragment
+    of v_mfma_f32_32x32x16_bf16 (64 lanes x 8 bf16 = 1 KiB; lane = (row r = lane & 31, half h = lane >> 5), element e <-> k = 8h + e) in the
+    order the kernel consumes them, bf16.
+
+    Per 16-channel chunk, 4 units (4-channel groups j):
+      3 generate fragments of the (channel 4j + r//8, tap r%8) row tile: k-step st, patch slot u = 4st + 2h + e//4, channel slot e%4 —
+        the value is generate.0.weight[c, t, u] * bn_scale[c, t] where the channel slot is the row's channel, else 0; slots 9, 10, 11 carry the
+        BatchNorm shift split hi + lo + lolo (their B operand is 1.0);
+      3 generate fragments of the chunk's tap-8 row tile (row r < 16 = channel r of the chunk), non-zero only for the unit's 4 channels;
+      [conv_w given] 2 x mt main fragments: conv.0.weight[o, c, t] with o = 32 (g mt + m) + r and (c, t) = the generated row
+        16 s2 + 8 (e//4) + 4h + e%4 of the unit's tile (the accumulator layout the generate product leaves in registers);
+    then [conv_w given] mt main fragments for the tap-8 tile (one k-step: rows 8 (e//4) + 4h + e%4 = channels of the chunk).
+    conv_w None: the statistics stream (generate fragments only).
+    Returns bf16 [gy][chunks][fragments][64][8] (gy = O / (32 mt) blocks of output channels; 1 for the statistics stream)."""
+    dev = gen_w.device
+    c_in = gen_w.shape[0] // 9
+    nch = c_in // 16
+    wx = torch.zeros(c_in, 9, 12, dtype=torch.float32, device=dev)
+    wx[:, :, :9] = gen_w.detach().float().view(c_in, 9, 9) * scale.view(c_in, 9, 1)
+    b = shift.detach().float().view(c_in, 9)
+    bh = b.bfloat16().float()
+    bl = (b - bh).bfloat16().float()
+    wx[:, :, 9], wx[:, :, 10], wx[:, :, 11] = bh, bl, (b - bh - bl).bfloat16().float()
+    ar = lambda n: torch.arange(n, device=dev)
+    lane = ar(64)
+    R, H, E = (lane & 31).view(1, 1, 1, 64, 1), (lane >> 5).view(1, 1, 1, 64, 1), ar(8).view(1, 1, 1, 1, 8)
+    CH, J, ST = ar(nch).view(nch, 1, 1, 1, 1), ar(4).view(1, 4, 1, 1, 1), ar(3).view(1, 1, 3, 1, 1)
+    us, cs = 4 * ST + 2 * H + (E >> 2), E & 3
+    zero = torch.zeros((), dtype=torch.float32, device=dev)
+    gen = torch.where(cs == (R >> 3), wx[16 * CH + 4 * J + (R >> 3), R & 7, us], zero)                      # [nch, 4, 3, 64, 8]
+    gen8 = torch.where((R < 16) & ((R >> 2) == J) & (cs == (R & 3)), wx[16 * CH + (R & 15) + 0 * J, 8, us], zero)
+    genf = torch.cat((gen, gen8), 2)                                                                        # [nch, 4, 6, 64, 8]
+    if conv_w is None:
+        return genf.reshape(1, nch, 24, 64, 8).to(torch.bfloat16).contiguous()
+    o_ch = conv_w.shape[0]
+    gy = o_ch // (32 * mt)
+    wc = conv_w.detach().float().view(o_ch, c_in, 9)
+    S2, M = ar(2).view(1, 1, 1, 2, 1, 1, 1), ar(mt).view(1, 1, 1, 1, mt, 1, 1)
+    G, CH7, J7 = ar(gy).view(gy, 1, 1, 1, 1, 1, 1), ar(nch).view(1, nch, 1, 1, 1, 1, 1), ar(4).view(1, 1, 4, 1, 1, 1, 1)
+    R7, H7, E7 = (lane & 31).view(1, 1, 1, 1, 1, 64, 1), (lane >> 5).view(1, 1, 1, 1, 1, 64, 1), ar(8).view(1, 1, 1, 1, 1, 1, 8)
+    row = 16 * S2 + 8 * (E7 >> 2) + 4 * H7 + (E7 & 3)
+    o_idx = 32 * (G * mt + M) + R7
+    main = wc[o_idx, 16 * CH7 + 4 * J7 + (row >> 3), row & 7]                                               # [gy, nch, 4, 2, mt, 64, 8]
+    row8 = 8 * (E7 >> 2) + 4 * H7 + (E7 & 3)                                                                # rows 0 .. 15 of the tap-8 tile
+    main8 = wc[o_idx[:, :, :1, :1], 16 * CH7 + row8, 8]                                                     # [gy, nch, 1, 1, mt, 64, 8]
+    units = torch.cat((genf.view(1, nch, 4, 6, 64, 8).expand(gy, -1, -1, -1, -1, -1), main.reshape(gy, nch, 4, 2 * mt, 64, 8)), 3)
+    out = torch.cat((units.reshape(gy, nch, 4 * (6 + 2 * mt), 64, 8), main8.reshape(gy, nch, mt, 64, 8)), 2)
+    return out.to(torch.bfloat16).contiguous()
+
+
 # --------------------------------------------------------------------------------------------------
 # Batched packing (csrc/ly_backward.hip ly_pack_table): every packed weight image of the model — forward, transposed for dgrad,
 # tap-flipped, concatenated — is described ONCE by how it reads the fp32 parameter in place, and all of them are refreshed by a

@@ -149,6 +149,53 @@ def test_rfcbam_backward_bf16_smooth_case(ctor, shape):
         assert cos >= 0.995 and l2 <= 2 * REL_L2, (ctor, what, cos, l2)
 
 
+def test_rf3c_backward_bit_stable_beside_mfma_stream():
+    """the recompute backward of RFCBAMConv k = 3 (csrc/ly_rf3c_bwd.hip: hand-written v_pk_fma_f32 with op_sel weight broadcasts,
+    no atomics) must return the SAME BITS when other waves issue MFMAs on its CUs.  The same backward runs alone, then repeatedly while a
+    second stream keeps the matrix cores busy with zero-LDS bf16 GEMMs (torch.matmul) — what a second process on the GPU, an eval stream or an
+    overlapped all-reduce look like to these kernels.  tools/pkfma_probe.hip holds the instruction-level experiment (seven forms of the packed
+    FMA beside an MFMA aggressor: bit-exact vs the host's fmaf in all of them)."""
+    torch.manual_seed(0)
+    ctor, shape = (64, 64, 3, 2), (4, 64, 48, 48)
+    c, o, k, s = ctor
+    m = _ctor("RFCBAMConv")(*ctor)
+    st = synth.synth_state(synth.shapes_of(m.state_dict()), 9100)
+    _bn_eps(_load(m, st))
+    m = m.to(_dev()).train()
+    x = synth.synth_input(shape, 77).to(_dev()).to(BF)
+    r = synth.synth_input((shape[0], o, shape[2] // s, shape[3] // s), 78).to(_dev()).to(BF)
+    names = ("conv.0.weight", "generate.0.weight", "generate.1.weight", "generate.1.bias", "se.fc.0.weight", "se.fc.2.weight", "get_weight.0.weight")
+
+    def run():
+        for p in m.parameters():
+            p.grad = None
+        xt = x.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=BF):
+            y = m(xt)
+        y.backward(r)
+        torch.cuda.synchronize()
+        return [xt.grad.clone()] + [dict(m.named_parameters())[n].grad.clone() for n in names]
+
+    base = run()
+    again = run()
+    stable_alone = [torch.equal(a, b) for a, b in zip(base, again)]
+    side = torch.cuda.Stream()
+    a = torch.randn(2048, 2048, device=_dev(), dtype=BF)
+    bad = []
+    for it in range(12):
+        with torch.cuda.stream(side):
+            for _ in range(40):
+                a = torch.matmul(a, a) * 1e-3
+        got = run()
+        for nm, g0, g1, ok in zip(("dx",) + names, base, got, stable_alone):
+            if ok and not torch.equal(g0, g1):
+                bad.append((it, nm, float((g0.float() - g1.float()).abs().max())))
+        side.synchronize()
+    if not any(stable_alone):
+        pytest.skip("no gradient of this module is bit-stable between two runs ALONE (batch-statistics atomics upstream): nothing to compare")
+    assert not bad, f"RFCBAMConv backward changed bits beside an MFMA stream: {bad[:6]}"
+
+
 def test_sppf_pool_bf16_ties_follow_aten():
     """the three chained 5x5 max-pools and their backward on a bf16 map FULL of exact ties (values drawn from 16 levels): forward
     values and the gradient routing (first maximum in row-major scan order, ATen's rule) must equal the fp32 CPU reference on

@@ -144,13 +144,11 @@ def cpu_model_name():
     return "unknown"
 
 
-def cpu_baseline_train(scale, size, budget_s=18.0, b=4):
-    """The oracle taking the same optimisation step (train-mode forward, loss, autograd backward, clip 10, SGD-nesterov
-    with the three groups) on the host cores: median step time over a bounded sample."""
+def _cpu_train_leg(scale, size, b, threads, budget_s, min_steps=3, max_steps=40):
+    """median optimisation-step time of the oracle (train-mode forward, loss, autograd backward, clip 10, SGD-nesterov with the three groups)"""
     from oracle import functional as OF
     import lead_yolo_amd as L
-    cores = usable_cores()
-    torch.set_num_threads(cores)
+    torch.set_num_threads(threads)
     m = build_model(scale, "cpu", train=True)
     st = {k: v.clone() for k, v in m.state_dict().items()}
     cfg = L.load_cfg(scale=scale)
@@ -176,21 +174,15 @@ def cpu_baseline_train(scale, size, budget_s=18.0, b=4):
             for gname, dec in (("decay", 5e-4), ("bn", 0.0), ("bias", 0.0)):
                 OF.sgd_nesterov_step({k: params[k] for k in groups[gname]}, grads, bufs, 0.01, 0.937, dec)
         times.append(time.perf_counter() - t0)
-        if (time.perf_counter() - t_all > budget_s and len(times) >= 4) or len(times) >= 50:
+        if (time.perf_counter() - t_all > budget_s and len(times) >= min_steps + 1) or len(times) >= max_steps + 1:
             break
-    timed = times[1:]                                # first step = warm-up (allocator, oneDNN primitive caches)
-    med = statistics.median(timed)
-    return dict(value=round(b / med, 2), unit="images/sec", cores=cores, kind="port", cpu=cpu_model_name(),
-                sample=f"median of {len(timed)} optimisation steps (fwd + loss + bwd + clip + SGD-nesterov) of lead-yolo-{scale} bs={b} "
-                       f"{size}x{size} fp32 by oracle/functional.py (torch {torch.__version__} CPU, {cores} threads), after 1 warm-up step; "
-                       f"min/median/max {min(timed) * 1e3:.0f}/{med * 1e3:.0f}/{max(timed) * 1e3:.0f} ms per step")
+    return times[1:]                                 # first step = warm-up (allocator, oneDNN primitive caches)
 
 
-def cpu_baseline_forward(scale, size, budget_s=10.0, b=4):
+def _cpu_forward_leg(scale, size, b, threads, budget_s, min_iters=3, max_iters=100):
     from oracle import functional as OF
     import lead_yolo_amd as L
-    cores = usable_cores()
-    torch.set_num_threads(cores)
+    torch.set_num_threads(threads)
     m = build_model(scale, "cpu")
     st = {k: v.clone() for k, v in m.state_dict().items()}
     cfg = L.load_cfg(scale=scale)
@@ -203,12 +195,53 @@ def cpu_baseline_forward(scale, size, budget_s=10.0, b=4):
             t0 = time.perf_counter()
             OF.model_forward(st, cfg, x, m.stride, training=False)
             times.append(time.perf_counter() - t0)
-            if (time.perf_counter() - t_all > budget_s and len(times) >= 3) or len(times) >= 200:
+            if (time.perf_counter() - t_all > budget_s and len(times) >= min_iters) or len(times) >= max_iters:
                 break
+    return times
+
+
+def _leg(times, b, what, threads):
     med = statistics.median(times)
-    return dict(value=round(b / med, 2), unit="images/sec", cores=cores, kind="port", cpu=cpu_model_name(),
-                sample=f"median of {len(times)} eval forwards of lead-yolo-{scale} bs={b} {size}x{size} fp32 by oracle/functional.py "
-                       f"(torch {torch.__version__} CPU, {cores} threads)")
+    return dict(value=round(b / med, 2), unit="images/sec", batch=b, threads=threads, iterations=len(times),
+                ms_min_median_max=[round(min(times) * 1e3, 1), round(med * 1e3, 1), round(max(times) * 1e3, 1)], what=what)
+
+
+def cpu_forward_legs(scale, size, cores):
+    """the oracle's eval forward at bs=1 and bs=32 on all usable cores, and the 1-thread figure (bs=1)"""
+    return {"eval_forward_bs1": _leg(_cpu_forward_leg(scale, size, 1, cores, 2.0, min_iters=5), 1, "eval forward", cores),
+            "eval_forward_bs32": _leg(_cpu_forward_leg(scale, size, 32, cores, 4.0), 32, "eval forward", cores),
+            "eval_forward_bs1_1thread": _leg(_cpu_forward_leg(scale, size, 1, 1, 2.0), 1, "eval forward", 1)}
+
+
+def cpu_baseline_train(scale, size, budget_s=10.0, b=16):
+    """The oracle taking the same optimisation step (train-mode forward, loss, autograd backward, clip 10, SGD-nesterov
+    with the three groups) on the host cores: median step time over a bounded sample, at the largest batch that keeps >= 3 timed
+    steps inside the budget; beside it the 1-thread figure and the eval-forward legs of section 3 (i)."""
+    cores = usable_cores()
+    timed = _cpu_train_leg(scale, size, b, cores, budget_s)
+    med = statistics.median(timed)
+    out = dict(value=round(b / med, 2), unit="images/sec", cores=cores, kind="port", cpu=cpu_model_name(),
+               sample=f"median of {len(timed)} optimisation steps (fwd + loss + bwd + clip + SGD-nesterov) of lead-yolo-{scale} bs={b} "
+                      f"{size}x{size} fp32 by oracle/functional.py (torch {torch.__version__} CPU, {cores} threads), after 1 warm-up step; "
+                      f"min/median/max {min(timed) * 1e3:.0f}/{med * 1e3:.0f}/{max(timed) * 1e3:.0f} ms per step")
+    legs = {"train_step_1thread": _leg(_cpu_train_leg(scale, size, 2, 1, 4.0, min_steps=2), 2, "optimisation step", 1)}
+    legs.update(cpu_forward_legs(scale, size, cores))
+    out["legs"] = legs
+    torch.set_num_threads(cores)
+    return out
+
+
+def cpu_baseline_forward(scale, size, budget_s=8.0, b=32):
+    cores = usable_cores()
+    times = _cpu_forward_leg(scale, size, b, cores, budget_s)
+    med = statistics.median(times)
+    out = dict(value=round(b / med, 2), unit="images/sec", cores=cores, kind="port", cpu=cpu_model_name(),
+               sample=f"median of {len(times)} eval forwards of lead-yolo-{scale} bs={b} {size}x{size} fp32 by oracle/functional.py "
+                      f"(torch {torch.__version__} CPU, {cores} threads)")
+    out["legs"] = {"eval_forward_bs1": _leg(_cpu_forward_leg(scale, size, 1, cores, 2.0, min_iters=5), 1, "eval forward", cores),
+                   "eval_forward_bs1_1thread": _leg(_cpu_forward_leg(scale, size, 1, 1, 2.0), 1, "eval forward", 1)}
+    torch.set_num_threads(cores)
+    return out
 
 
 def pconv_rfcbam_probe(model, x, dtype, iters=10):
@@ -491,6 +524,19 @@ def run_train(args, ctx):
     if reducer is not None:
         res["rccl_ranks"] = ctx.dist.get_world_size()
         res["grad_buckets"] = len(reducer.buckets)
+        res["grad_bytes"] = sum(b["flat"].numel() * b["flat"].element_size() for b in reducer.buckets)
+        if step is not eager_step:
+            # where in the replayed backward every bucket's all-reduce is released (this rank), and what the step costs beside the
+            # forward + backward graph alone: the driver computes scaling from the per-N values, this says WHY a step is longer than N = 1's
+            try:
+                pr = [g.profile_step() for _ in range(3)][-1]
+                res["dp_overlap"] = dict(graph_a_ms=round(pr["graph_a_ms"], 4), step_ms=round(pr["step_ms"], 4),
+                                         exchange_and_optimizer_tail_ms=round(pr["step_ms"] - pr["graph_a_ms"], 4),
+                                         bucket_release_pct_of_graph_a=[dict(bucket=bi, bytes=nb, released_at_pct=pct) for bi, nb, pct in pr["buckets"]],
+                                         note="rank 0, one profiled step after the timed region: a bucket's all-reduce is queued on the communication "
+                                              "stream behind an event node inside graph A (forward + backward); < 100 % = released while backward was running")
+            except Exception as e:                              # noqa: BLE001
+                res["dp_overlap"] = dict(error=f"{type(e).__name__}: {e}")
     return res
 
 
@@ -626,7 +672,7 @@ def main():
             "timed_repeats": len(regions), "repeat_ms_per_step": [round(r / args.steps * 1e3, 4) for r in regions],
             "value_is": "median of the timed repeats (each: exactly `steps` steps between barrier+synchronize, max over ranks)",
         }
-        for k in ("final_loss", "peak_mem_gib", "rccl_ranks", "grad_buckets", "launch"):
+        for k in ("final_loss", "peak_mem_gib", "rccl_ranks", "grad_buckets", "grad_bytes", "dp_overlap", "launch"):
             if k in res:
                 out[k if k != "launch" else "launch_mode"] = res[k]
         if args.no_roofline:
@@ -645,6 +691,11 @@ def main():
                     roof["pconv_rfcbam_fwd"] = pconv_rfcbam_probe(model, xb, args.dtype)
                     del model, xb
                     torch.cuda.empty_cache()
+                    if args.dtype != "f32":                # the 0.70 target is quoted for both storage types: the fp32 sub-metric beside it
+                        m32 = build_model(args.scale, ctx.device)
+                        roof["pconv_rfcbam_fwd_f32"] = pconv_rfcbam_probe(m32, synth_batch(args.batch, args.size, 0, ctx.device), "f32")
+                        del m32
+                        torch.cuda.empty_cache()
                     # secondary figure: the eval forward of configs[1] in ITS dtype (fp32), and the same shape in this line's dtype
                     out["forward"] = {}
                     for fdtype in dict.fromkeys(("f32", args.dtype)):

@@ -281,6 +281,28 @@ class GraphedTrainStep:
                                  f"image index is -1), got {tuple(targets.shape)} {targets.dtype}")
             self.targets.copy_(targets, non_blocking=True)
 
+    def profile_step(self):
+        """One data-parallel step (accumulate = 1, reducer present) with HIP events around its parts: -> dict(graph_a_ms, step_ms,
+        buckets=[(bucket, bytes, released at % of graph A)]).  `released` = when the bucket's all-reduce was queued behind its in-graph
+        event on the communication stream, relative to the span of graph A (forward + backward): < 100 means the exchange started while
+        the backward was still running.  Introspection for bench.py / tools; the step it runs is a real optimisation step."""
+        if self.opt_graph is None or self.reducer is None or self.accumulate != 1:
+            raise RuntimeError("profile_step: needs the data-parallel form (reducer, accumulate = 1)")
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        self.probe, self._a_done = [], e1
+        e0.record()
+        try:
+            self.__call__()
+        finally:
+            self._a_done = None
+        e2.record()
+        torch.cuda.synchronize()
+        probe, self.probe = self.probe, None
+        a_ms = e0.elapsed_time(e1)
+        return dict(graph_a_ms=a_ms, step_ms=e0.elapsed_time(e2),
+                    buckets=[(bi, self.reducer.buckets[bi]["flat"].numel() * self.reducer.buckets[bi]["flat"].element_size(),
+                              round(100.0 * e0.elapsed_time(ev) / a_ms, 1)) for bi, ev in probe])
+
     def __call__(self, imgs=None, targets=None):
         from . import capi, pack
         self._load(imgs, targets)
@@ -293,6 +315,8 @@ class GraphedTrainStep:
             self.stepped = True
             return self.loss, self.items
         self.graph.replay()                                # forward + backward: gradients add into the persistent storage / bucket views
+        if getattr(self, "_a_done", None) is not None:
+            self._a_done.record()                          # (profile_step)
         self.optimizer.mark_dirty()                        # (a zero_grad() now — an abandoned micro-batch — must really zero them)
         self._micro += 1
         self.stepped = self._micro >= self.accumulate

@@ -51,4 +51,7 @@ def test_two_rank_launch_path_dry_run():
     assert KEYS <= set(d) and d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["config"]["world_size"] == 2
     assert "DRY RUN" in d["config"]["parallelism"] and d["grad_buckets"] >= 1 and "released mid-graph" in d["launch_mode"]
     assert d["roofline"]["step"]["families"]                       # the probe ran (on both ranks) and the job still ended cleanly
+    ov = d["dp_overlap"]
+    assert d["rccl_ranks"] == 2 and "error" not in ov and ov["graph_a_ms"] > 0 and ov["step_ms"] >= ov["graph_a_ms"]
+    assert len(ov["bucket_release_pct_of_graph_a"]) >= 1 and all(b["released_at_pct"] > 0 for b in ov["bucket_release_pct_of_graph_a"])
     assert abs(d["value"] - 2 * 4 * 1e3 / d["ms_per_step"]) < 1e-2 * d["value"]

@@ -574,6 +574,65 @@ def test_graphed_step_with_reducer_matches_eager(rccl, accumulate):
             dist.destroy_process_group()
 
 
+def test_reference_training_objects_stock_ddp_gradscaler_fp16_autocast():
+    """the route `python -m lead_yolo_amd.run train.py` takes, without the reference travelling: the HIP `Model` wrapped in stock
+    torch.nn.parallel.DistributedDataParallel(static_graph=True) (utils/torch_utils.py:55-63) on a one-rank RCCL group, torch.optim.SGD with
+    the reference's three groups (smart_optimizer, fused=False), torch.autocast(float16) + GradScaler (train.py:258, 316-341), clip_grad_norm_,
+    EMA — five optimisation steps.  The modules take the non-sink gradient path here (autograd's AccumulateGrad feeds DDP's reducer hooks).
+    Checked: every parameter receives a finite gradient in every step (DDP(static_graph) asserts on unused parameters), the scaler never
+    skips a step, the loss falls, and after the first step the gradients equal the ones the plain (no DDP, no scaler, bf16-free fp32) HIP
+    step computes from the same state up to fp16-storage noise (cosine of the whole gradient vector)."""
+    import lead_yolo_amd as L
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    dist = _one_rank_group()
+    try:
+        torch.manual_seed(0)
+        m = L.Model(_cfg("n"))
+        st = synth.synth_state(synth.shapes_of(m.state_dict()), 6262)
+        st["model.23.anchors"] = m.model[-1].anchors.clone()
+        m.load_state_dict(st)
+        m = m.to(_dev()).train()
+        imgs = (synth.synth_images(4, 128, 61).float() / 255).to(_dev())
+        tg = synth.synth_targets(4, 62, per_image=3).to(_dev())
+        # reference gradient: the plain fp32 HIP step from the same state
+        cl = L.ComputeLoss(m)
+        loss0, _ = cl(m(imgs), tg)
+        loss0.backward()
+        ref = torch.cat([p.grad.detach().flatten() for p in m.parameters()]).double().clone()
+        for p in m.parameters():
+            p.grad = None
+        ddp = DDP(m, device_ids=[_dev().index or 0], static_graph=True)
+        opt = L.smart_optimizer(m, "SGD", 0.01, 0.937, 5e-4, fused=False)
+        assert type(opt) is torch.optim.SGD and len(opt.param_groups) == 3
+        scaler = torch.amp.GradScaler("cuda", enabled=True)
+        ema = L.ModelEMA(m)
+        losses = []
+        for it in range(5):
+            with torch.autocast("cuda", dtype=torch.float16):
+                pred = ddp(imgs)
+                loss, _ = cl(pred, tg)
+            scaler.scale(loss).backward()
+            scaler.unscale_(opt)
+            grads = [p.grad for p in m.parameters()]
+            assert all(g is not None and torch.isfinite(g).all() for g in grads), f"step {it}: a parameter has no / a non-finite gradient"
+            if it == 0:
+                got = torch.cat([g.detach().flatten() for g in grads]).double()
+                cos = float(got @ ref / (got.norm() * ref.norm()))
+                assert cos > 0.98 and 0.9 < float(got.norm() / ref.norm()) < 1.1, (cos, float(got.norm() / ref.norm()))
+            torch.nn.utils.clip_grad_norm_(m.parameters(), max_norm=10.0)
+            scale_before = scaler.get_scale()
+            scaler.step(opt)
+            scaler.update()
+            assert scaler.get_scale() >= scale_before, "GradScaler skipped a step (inf / nan gradients)"
+            opt.zero_grad()
+            ema.update(m)
+            losses.append(float(loss))
+        assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
 def test_graphed_step_rejects_wrong_batch_and_survives_later_allocations():
     """(a) a float batch must not be copied into the captured uint8 buffer (it would truncate to zeros); (b) the graph keeps
     the buffers it addresses alive: an eager step at a LARGER shape afterwards re-allocates the zero pool / loss constants, and replaying

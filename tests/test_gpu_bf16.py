@@ -217,7 +217,7 @@ def test_sppf_pool_bf16_ties_follow_aten():
     assert float((got - want).abs().max()) <= 2.0 ** -7 * float(want.abs().max())
 
 
-@pytest.mark.parametrize("scale,hw,bs", [("n", (64, 64), 2), ("s", (640, 640), 2), ("l", (320, 320), 1)])
+@pytest.mark.parametrize("scale,hw,bs", [("n", (64, 64), 2), ("s", (640, 640), 2), ("l", (320, 320), 1), ("n", (640, 640), 1), ("l", (1280, 1280), 1)])
 def test_whole_model_eval_bf16(scale, hw, bs):
     """whole detector, bf16 storage end to end (image fp32 -> PatchEmbed writes bf16), decoded rows vs the fp32 oracle.  24 layers
     deep: the bound is the per-module one times sqrt(depth)."""
@@ -411,16 +411,17 @@ def test_configs2_full_size_graphed_step():
             _close(z[i:i + 1], zo, f"configs[2] image {i} of the bs=64 batch", rel=5 * REL_L2, mx=8 * MAX_REL)
 
 
-def test_configs4_shape_lead_yolo_l_1280():
-    """BASELINE configs[4]'s shape on one GPU: lead-yolo-l, 1280x1280, bf16, bs=2 (the per-GPU batch of 16 only repeats these tiles):
+@pytest.mark.parametrize("bs", [2, 16])
+def test_configs4_shape_lead_yolo_l_1280(bs):
+    """BASELINE configs[4]'s shape on one GPU: lead-yolo-l, 1280x1280, bf16, at bs=2 and at the REAL per-GPU batch of 16 (7.9 GiB peak):
     one captured optimisation step equals the eager step from the same state, everything stays finite, and the large-map kernels
-    (160 x 160 ... 320 x 320 feature maps, 1024-wide C3_CA) run inside their index limits."""
+    (160 x 160 ... 320 x 320 feature maps, 1024-wide C3_CA, 26 M pixel rows at bs=16) run inside their index limits."""
     import lead_yolo_amd as L
     from lead_yolo_amd import pack
     torch.manual_seed(0)
     m = L.Model(_cfg("l")).to(_dev()).train()
-    imgs = synth.synth_images(2, 1280, 91).to(_dev())
-    tg = synth.synth_targets(2, 92, per_image=7).to(_dev())
+    imgs = synth.synth_images(bs, 1280, 91).to(_dev())
+    tg = synth.synth_targets(bs, 92, per_image=7).to(_dev())
     opt = L.smart_optimizer(m, "SGD", 0.01, 0.937, 5e-4)
     cl = L.ComputeLoss(m)
     step = L.GraphedTrainStep(m, cl, opt, imgs, tg, amp=BF, warmup=2)

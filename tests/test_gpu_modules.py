@@ -189,10 +189,12 @@ def test_whole_model_640_vs_oracle():
         _cmp(a, b, f"model_s 640 p{i}")
 
 
-@pytest.mark.parametrize("scale,hw,bs", [("l", (64, 96), 2), ("n", (96, 64), 3), ("s", (1280, 1280), 1), ("l", (320, 320), 1)])
+@pytest.mark.parametrize("scale,hw,bs", [("l", (64, 96), 2), ("n", (96, 64), 3), ("s", (1280, 1280), 1), ("l", (320, 320), 1),
+                                         ("n", (640, 640), 1),          # BASELINE configs[0]: lead-yolo-n, one 640 x 640 image -> [1, 25200, 6]
+                                         ("l", (1280, 1280), 1)])       # BASELINE configs[4]'s model AND input size, one image through the oracle
 def test_other_scales_and_sizes_vs_oracle(scale, hw, bs):
     """lead-yolo-l (C up to 320 / 1024 channels, n=3 bottlenecks), lead-yolo-n, and the 1280x1280 input of
-    BASELINE config 5, against the live oracle"""
+    BASELINE config 5, against the live oracle; configs[0]'s own shape (n @ 640, batch 1) on the HIP path"""
     import lead_yolo_amd as L
     torch.manual_seed(0)
     m = L.Model(_cfg(scale))
@@ -203,6 +205,8 @@ def test_other_scales_and_sizes_vs_oracle(scale, hw, bs):
     with torch.no_grad():
         zo, outs_o = OF.model_forward(copy.deepcopy(st), _cfg(scale), x, m.stride, training=False)
         z, outs = m.to(_dev()).eval()(x.to(_dev()))
+    if scale == "n" and hw == (640, 640):
+        assert z.shape == (1, 25200, 6) and sum(p.numel() for p in m.parameters()) == 814382          # configs[0]'s plumbing check
     _cmp(z, zo, f"model_{scale} {hw} z")
     for i, (a, b) in enumerate(zip(outs, outs_o)):
         _cmp(a, b, f"model_{scale} {hw} p{i}")

@@ -33,7 +33,7 @@ const char* ly_last_error(void);
  * activations; y and bn_* are ignored, nothing is stored).  x and y must not alias.
  * Built for C in {16,24,40,80,160,320}. */
 int ly_mlpblock_fwd(const void* x /*T*/, void* y /*T*/, int n_img, int H, int W, int C, const void* wp, const void* w1,
-                    const void* w2, const float* bn_scale, const float* bn_shift, float* stats, int dtype, void* stream);
+                    const void* w2, const float* bn_scale, const float* bn_shift, double* stats, int dtype, void* stream);
 /* The partial convolution alone: z = [conv3x3(x[:, :C/4]; wp) | x[:, C/4:]] (Partial_conv3.forward_split_cat, models/common.py:1432-1437) in one
  * read + one write of the map — what the training backward needs twice (z for the recomputed hidden tensor; with the transposed-flipped taps
  * applied to the gradient g: [d/dx of the conv | g[C/4:]]).  Persistent patch walk where the MLPBlock's applies (C < 80, W % 16 == 0, >= 1024
@@ -72,7 +72,7 @@ typedef struct LyGemmParams {
   const float* rowscale;  /* [M] or NULL                                                         */
   int act;                /* 0 none, 1 relu, 2 silu                                              */
   void* out; int ldo;     /* output (T), row stride (elements); pointer may be pre-offset into a concat */
-  float* stats;           /* NULL, or [2N] zero-initialised accumulators: STATISTICS PASS for train-mode
+  double* stats;          /* NULL, or [LY_STATS_STRIPES = 32][2N] zero-initialised DOUBLE accumulators: STATISTICS PASS for train-mode
                              BatchNorm — adds sum / sum-of-squares over the M rows of the pre-activation value
                              (rowscale*e_scale*acc + e_shift) per output channel; stores nothing when out is NULL,
                              otherwise stores act(that value) as usual (one launch for statistics + pre-BN tensor) */
@@ -98,7 +98,7 @@ typedef struct LyConv3Params {
   const float* e_scale; const float* e_shift;   /* folded BN / bias, [N] or NULL                 */
   int act;
   void* out; int ldo;      /* T */
-  float* stats;            /* NULL or [2N] accumulators: statistics pass (see LyGemmParams.stats)     */
+  double* stats;           /* NULL or [32][2N] double accumulators: statistics pass (see LyGemmParams.stats) */
   int dtype;               /* LY_F32 / LY_BF16 */
 } LyConv3Params;
 
@@ -125,7 +125,7 @@ int ly_coordatt_mlp(const float* pool, int n_img, int H, int W, int C, int mip, 
 int ly_coordatt_mlp_bwd(const float* pool, int n_img, int H, int W, int C, int mip, const float* w1, const float* b1,
                         const float* mean, const float* invstd, const float* gamma, const float* beta, const float* wh,
                         const float* ww, const float* a_h, const float* a_w, const float* da_h, const float* da_w, float* ws,
-                        float* sums, float* dpool, float* dw1, float* dgamma, float* dbeta, float* dwh, float* dbh, float* dww,
+                        double* sums /* [32][2 mip] doubles, zeroed */, float* dpool, float* dw1, float* dgamma, float* dbeta, float* dwh, float* dbh, float* dww,
                         float* dbw, void* stream);
 
 /* out = x * a_w[n,w,:] * a_h[n,h,:] (+ res): the gating multiply as a standalone pass (only used
@@ -167,7 +167,7 @@ typedef struct LyRfcbam3Params {
   const void* wp;              /* frag_pack3(conv.0.weight as [N, C/16, 144 -> 160 zero padded])  */
   const float* e_scale; const float* e_shift;   /* conv.1 BN folded with conv.0.bias              */
   void* out; int ldo;          /* T */
-  float* stats;                /* NULL or [2N] accumulators: conv.1 BatchNorm statistics pass (sums of e_scale*acc + e_shift);
+  double* stats;               /* NULL or [32][2N] double accumulators: conv.1 BatchNorm statistics pass (sums of e_scale*acc + e_shift);
                                   with out != NULL that pre-BN value is stored as well (one contraction in training)  */
   int linear;                  /* != 0: store the affine value without the ReLU (backward recompute) */
   int dtype;                   /* LY_F32 / LY_BF16 */
@@ -254,24 +254,26 @@ int ly_detect_head_bwd(const float* dp, int n_img, int H, int W, int na, int no,
 /* ---- train-mode BatchNorm statistics passes ----------------------------------------------------- */
 /* mom[c] += sum_rows x[r, c], mom[C + c] += sum_rows x[r, c]^2 over an [rows, C] row matrix (mom zeroed
  * by the caller).  Used for the k=1 `generate` BatchNorm of RFCBAMConv (models/rfa.py:101-106).       */
-int ly_chan_moments(const void* x /*T*/, int ldx, long rows, int C, float* mom, int dtype, void* stream);
+int ly_chan_moments(const void* x /*T*/, int ldx, long rows, int C, double* mom /* [32][2C] doubles, zeroed */, int dtype, void* stream);
 /* CoordAtt bn1 (models/common.py:1589,1602): sum / sum of squares of conv1(pool) + bias over all
  * n*(H+W) positions, stats[0:mip] and stats[mip:2mip] (zeroed by the caller).                        */
 int ly_coordatt_conv1_stats(const float* pool, long positions, int C, int mip, const float* w1, const float* b1,
-                            float* stats, void* stream);
+                            double* stats /* [2 mip] doubles */, void* stream);
+/* dst[c] = sum over r < R of src[r][c]: the stripes of a DOUBLE statistics accumulator folded in index order (ly_chan_moments) */
+int ly_sum_rows_f64(const double* src, int R, int C, double* dst, void* stream);
 
 /* RFCBAMConv k=3 `generate` BatchNorm statistics (train mode): mom[54][C] (zeroed by the caller) receives,
  * per input channel, the 9 first moments sum x_u and the 45 second moments sum x_u x_v (u <= v, row-major
  * upper triangle) of the zero-padded stride-s 3x3 taps over all n_img*Ho*Wo output pixels; mean and
  * variance of every (channel, tap-output) follow as w.m and w^T M w on the host.                        */
-int ly_rfcbam_tap_moments(const void* x /*T*/, int ldx, int n_img, int H, int W, int C, int s, float* mom, int dtype, void* stream);
+int ly_rfcbam_tap_moments(const void* x /*T*/, int ldx, int n_img, int H, int W, int C, int s, double* mom /* [54][C] doubles, zeroed */, int dtype, void* stream);
 /* Train-mode `generate` BatchNorm of RFCBAMConv (models/rfa.py:101-106) from those moments (k = 3: mom [54][C]; k = 1: ly_chan_moments'
  * [2][C]) and generate.0.weight, ONE launch: batch statistics of every generate channel g = c*k*k + t, running statistics and
  * num_batches_tracked updated as nn.BatchNorm2d does (NULL = not tracked);
  *   out8 [8][C*k*k]: scale, shift, mean, invstd in [c*k*k + t] order, then the same four in [t*C + c] order (the backward kernels' order);
  *   k = 3: wq_stats / wq_main = the folded weights (w*scale | shift) in the LDS orders of ly_rfcbam_stats / ly_rfcbam3_fwd
  *          ([ceil(C/32)*32 | ceil(C/16)*16][9][10] floats each);  k = 1: a1[c] = w[c]*scale[c].                                  */
-int ly_rfcbam_gen_prepare(const float* mom, int C, int k, const float* gen_w, const float* gamma, const float* beta, float eps,
+int ly_rfcbam_gen_prepare(const double* mom, int C, int k, const float* gen_w, const float* gamma, const float* beta, float eps,
                           float momentum, double count, float* running_mean, float* running_var, long* nbt, float* out8, float* a1,
                           float* wq_stats, float* wq_main, float* wq_c /* NULL or [C*100]: the RAW lane-order image of ly_rf3c_* */, void* stream);
 
@@ -302,7 +304,7 @@ int ly_nms_greedy(const float* det, const long* order, const float* sorted_score
  * (stats != NULL AND out != NULL: statistics accumulated and the pre-BN value stored in ONE launch) produced u.            */
 int ly_bnact_fwd(const void* u /*T*/, int ldu, long rows, int C, const float* a, const float* b, int act, void* y /*T*/, int ldy, int dtype, void* stream);
 int ly_bnact_bwd_reduce(const void* dy /*T*/, int lddy, const void* u /*T*/, int ldu, long rows, int C, const float* a, const float* b,
-                        int act, float* sums, int dtype, void* stream);
+                        int act, double* sums /* [32][2C] doubles, zeroed */, int dtype, void* stream);
 int ly_bnact_bwd_apply(const void* dy /*T*/, int lddy, const void* u /*T*/, int ldu, long rows, int C, const float* a, const float* b,
                        int act, const float* alpha, const float* kappa, const float* lambda, void* du /*T*/, int lddu, int dtype, void* stream);
 
@@ -423,14 +425,14 @@ int ly_se_bwd(const float* part, int slices, int n_img, int HW, int C, const flo
 /* Train-mode BatchNorm (nn.BatchNorm2d forward, training=True) from the striped sums of channels c_off .. c_off+N-1
  * (second moments at +nch): scale = gamma*invstd, shift = beta - mean*scale (+ bias*scale), batch mean / invstd for
  * the backward, running_mean/var updated with `momentum` (unbiased variance), *nbt += 1.  NULL = not wanted.           */
-int ly_bn_finalize(const float* stats, int stripes, int nch, int c_off, int N, double count, const float* gamma, const float* beta,
+int ly_bn_finalize(const void* stats /* [stripes][2 nch] floats, or doubles if stats_f64 */, int stats_f64, int stripes, int nch, int c_off, int N, double count, const float* gamma, const float* beta,
                    const float* bias, float eps, float momentum, float* running_mean, float* running_var, long* nbt, float* scale,
                    float* shift, float* mean, float* invstd, void* stream);
 /* BatchNorm backward coefficients from striped sums [2N] (sum dv, sum dv*u): dgamma, dbeta (ADDED to their targets, which the
  * caller zeroes: they may be the parameters' persistent gradient storage) and
  * du = alpha*dv + kappa + lambda*u  (train != 0: batch statistics; else alpha = a, kappa = lambda = 0).               */
-int ly_bn_bwd_coeffs(const float* sums, int stripes, int N, double count, const float* a, const float* mean, const float* invstd, int train,
-                     float* dgamma, float* dbeta, float* alpha, float* kappa, float* lambda, void* stream);
+int ly_bn_bwd_coeffs(const void* sums /* floats, or doubles if sums_f64 */, int sums_f64, int stripes, int N, double count, const float* a,
+                     const float* mean, const float* invstd, int train, float* dgamma, float* dbeta, float* alpha, float* kappa, float* lambda, void* stream);
 /* Fragment packing of the fp32 matrix W[r][k] = w[r*ld_r + k*ld_k] (R x K, rows zero padded to max(R, rows_to)) into the
  * [T][S][planes][64 lanes][8] bf16 layout the contraction kernels read (csrc/ly_tile.cuh): planes = 2 (hi = bf16(W),
  * lo = bf16(W - hi): the bf16x3 operand of LY_F32 calls) or 1 (hi only: LY_BF16 calls).                                */

@@ -141,8 +141,8 @@ SIGNATURES = {
     "ly_mlpblock_pconv": [_P, _P, _I, _I, _I, _I, _P, _I, _P],
     "ly_mlp_dx": [_P, _P, _P, _I, _L, _I, _I, _P, _I, _P],
     "ly_se_bwd": [_P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P],
-    "ly_bn_finalize": [_P, _I, _I, _I, _I, ctypes.c_double, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P],
-    "ly_bn_bwd_coeffs": [_P, _I, _I, ctypes.c_double, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P],
+    "ly_bn_finalize": [_P, _I, _I, _I, _I, _I, ctypes.c_double, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P],
+    "ly_bn_bwd_coeffs": [_P, _I, _I, _I, ctypes.c_double, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P],
     "ly_frag_pack3": [_P, _I, _I, _L, _L, _I, _I, _P, _P],
     "ly_loss_level": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _F, _P],
     "ly_loss_finish": [_P, _I, _P, _P, _F, _F, _F, _I, _I, _P, _P],
@@ -151,6 +151,7 @@ SIGNATURES = {
     "ly_pack_table": [_P, _P, _I, _P],
     "ly_optim_step": [_P, _P, _P, _I, _P, _P, _P, _P],
     "ly_sum_rows": [_P, _L, _L, _L, _P, _I, _P],
+    "ly_sum_rows_f64": [_P, _I, _I, _P, _P],
     "ly_rf1_bwd": [ctypes.POINTER(LyRf1BwdParams), _I, _P],
     "ly_rf3s_bwd": [ctypes.POINTER(LyRf1BwdParams), _I, _I, _I, _P],
     "ly_tune_wgrad3": [_I],

@@ -791,7 +791,7 @@ extern "C" int ly_detect_head_bwd(const float* dp, int n_img, int H, int W, int 
 // per-channel sum / sum of squares over all rows of an [rows, C] matrix: mom[c] += sum x, mom[C + c] += sum x^2
 template <typename T>
 __global__ __launch_bounds__(LY_THREADS) void ly_chan_moments_kernel(const T* __restrict__ x, int ldx, long rows, int C,
-                                                                      float* __restrict__ mom) {
+                                                                      double* __restrict__ mom) {
   __shared__ f32x4 red1[LY_THREADS], red2[LY_THREADS];
   const int nc4 = C >> 2, tid = threadIdx.x;
   const int groups = LY_THREADS / nc4;
@@ -807,16 +807,16 @@ __global__ __launch_bounds__(LY_THREADS) void ly_chan_moments_kernel(const T* __
   __syncthreads();
   if (j0 == 0) {
     for (int g = 1; g < groups; ++g) { s1 += red1[g * nc4 + c4]; s2 += red2[g * nc4 + c4]; }
-    float* m = mom + (size_t)(blockIdx.x & (LY_STATS_STRIPES - 1)) * 2 * C;
+    double* m = mom + (size_t)(blockIdx.x & (LY_STATS_STRIPES - 1)) * 2 * C;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      atomicAdd(m + 4 * c4 + r, s1[r]);
-      atomicAdd(m + C + 4 * c4 + r, s2[r]);
+      atomicAdd(m + 4 * c4 + r, (double)s1[r]);
+      atomicAdd(m + C + 4 * c4 + r, (double)s2[r]);
     }
   }
 }
 
-extern "C" int ly_chan_moments(const void* x, int ldx, long rows, int C, float* mom, int dtype, void* stream) {
+extern "C" int ly_chan_moments(const void* x, int ldx, long rows, int C, double* mom, int dtype, void* stream) {
   LY_CHECK_DTYPE(dtype, "chan_moments");
   LY_CHECK(x && mom && (C & 3) == 0 && (ldx & 3) == 0 && C <= 1024 && rows > 0, "chan_moments: bad arguments");
   const int groups = LY_THREADS / (C >> 2);
@@ -836,7 +836,7 @@ extern "C" int ly_chan_moments(const void* x, int ldx, long rows, int C, float* 
 template <int MIPMAX>
 __global__ __launch_bounds__(LY_THREADS) void ly_coordatt_conv1_stats_kernel(const float* __restrict__ pool, long positions, int C, int mip,
                                                                               const float* __restrict__ w1, const float* __restrict__ b1,
-                                                                              float* __restrict__ stats) {
+                                                                              double* __restrict__ stats) {
   __shared__ float red[4][2 * MIPMAX];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float a1 = 0.f, a2 = 0.f;
@@ -906,13 +906,13 @@ __global__ __launch_bounds__(LY_THREADS) void ly_coordatt_conv1_stats_kernel(con
   if (lane < mip) { red[wave][lane] = a1; red[wave][MIPMAX + lane] = a2; }
   __syncthreads();
   if (wave == 0 && lane < mip) {
-    atomicAdd(stats + lane, red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
-    atomicAdd(stats + mip + lane, red[0][MIPMAX + lane] + red[1][MIPMAX + lane] + red[2][MIPMAX + lane] + red[3][MIPMAX + lane]);
+    atomicAdd(stats + lane, (double)((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])));
+    atomicAdd(stats + mip + lane, (double)((red[0][MIPMAX + lane] + red[1][MIPMAX + lane]) + (red[2][MIPMAX + lane] + red[3][MIPMAX + lane])));
   }
 }
 
 extern "C" int ly_coordatt_conv1_stats(const float* pool, long positions, int C, int mip, const float* w1, const float* b1,
-                                       float* stats, void* stream) {
+                                       double* stats, void* stream) {
   LY_CHECK(pool && w1 && b1 && stats && positions > 0 && mip > 0, "coordatt_conv1_stats: bad arguments");
   LY_CHECK(mip <= 64, "coordatt_conv1_stats: mip=%d out of range", mip);
   long blocks = (positions + 3) / 4;
@@ -932,7 +932,7 @@ extern "C" int ly_coordatt_conv1_stats(const float* pool, long positions, int C,
 // the output pixels, 54 vectorised atomics per thread at the end.  mom layout: [54][C].
 template <typename T>
 __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_tap_moments_kernel(const T* __restrict__ x, int ldx, int n_img, int H, int W,
-                                                                            int C, int Ho, int Wo, int s, float* __restrict__ mom) {
+                                                                            int C, int Ho, int Wo, int s, double* __restrict__ mom) {
   const int cb = C < LY_THREADS ? C : LY_THREADS;          // channels handled per pass by this block
   const int subs = LY_THREADS / cb;
   const int tid = threadIdx.x;
@@ -983,9 +983,9 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_tap_moments_kernel(const
         }
       }
 #pragma unroll
-      for (int i = 0; i < 9; ++i) atomicAdd(mom + (long)i * C + c, m1[i]);
+      for (int i = 0; i < 9; ++i) atomicAdd(mom + (long)i * C + c, (double)m1[i]);
 #pragma unroll
-      for (int i = 0; i < 45; ++i) atomicAdd(mom + (long)(9 + i) * C + c, m2[i]);
+      for (int i = 0; i < 45; ++i) atomicAdd(mom + (long)(9 + i) * C + c, (double)m2[i]);
     }
   }
 }
@@ -998,7 +998,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_tap_moments_kernel(const
 #define LY_TM_T 8
 template <typename T>
 __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_tap_moments_s2t_kernel(const T* __restrict__ x, int ldx, int n_img, int H, int W, int C, int Ho, int Wo,
-                                                                                int tiles_y, int tiles_x, float* __restrict__ mom) {
+                                                                                int tiles_y, int tiles_x, double* __restrict__ mom) {
   constexpr int TM = LY_TM_T, TW = 2 * TM + 1, NPX = TW * TW;
   constexpr int VE = 16 / (int)sizeof(T), VPR = 64 / VE;
   extern __shared__ f32x4 ly_tm_smem[];
@@ -1071,13 +1071,13 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_tap_moments_s2t_kernel(c
     __syncthreads();
     for (int j = tid; j < 27 * 64; j += LY_THREADS) {
       const int i = j >> 6, l = j & 63;
-      if (c0 + l < C) atomicAdd(mom + (long)(half * 27 + i) * C + c0 + l, red[j] + red[27 * 64 + j] + red[2 * 27 * 64 + j] + red[3 * 27 * 64 + j]);
+      if (c0 + l < C) atomicAdd(mom + (long)(half * 27 + i) * C + c0 + l, (double)((red[j] + red[27 * 64 + j]) + (red[2 * 27 * 64 + j] + red[3 * 27 * 64 + j])));
     }
   }
   (void)cok;
 }
 
-extern "C" int ly_rfcbam_tap_moments(const void* x, int ldx, int n_img, int H, int W, int C, int s, float* mom, int dtype, void* stream) {
+extern "C" int ly_rfcbam_tap_moments(const void* x, int ldx, int n_img, int H, int W, int C, int s, double* mom, int dtype, void* stream) {
   LY_CHECK_DTYPE(dtype, "rfcbam_tap_moments");
   LY_CHECK(x && mom && s >= 1 && C > 0, "rfcbam_tap_moments: bad arguments");
   const int Ho = (H + 2 - 3) / s + 1, Wo = (W + 2 - 3) / s + 1;
@@ -1129,7 +1129,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_coordatt_mlp_bwd1_kernel(
     const float* __restrict__ pool, int n_img, int H, int W, int C, const float* __restrict__ w1, const float* __restrict__ b1,
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ wh, const float* __restrict__ ww, const float* __restrict__ a_h, const float* __restrict__ a_w,
-    const float* __restrict__ da_h, const float* __restrict__ da_w, float* __restrict__ ws, float* __restrict__ sums, float* __restrict__ dzb) {
+    const float* __restrict__ da_h, const float* __restrict__ da_w, float* __restrict__ ws, double* __restrict__ sums, float* __restrict__ dzb) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int L = H + W;
   const long R = (long)n_img * L;
@@ -1184,16 +1184,16 @@ __global__ __launch_bounds__(LY_THREADS) void ly_coordatt_mlp_bwd1_kernel(
     }
   }
   if (lane < MIP) {
-    float* st = sums + ((blockIdx.x * 4 + wave) & (LY_CA_STRIPES - 1)) * 2 * MIP;
-    atomicAdd(st + lane, s1);
-    atomicAdd(st + MIP + lane, s2);
+    double* st = sums + ((blockIdx.x * 4 + wave) & (LY_CA_STRIPES - 1)) * 2 * MIP;      // double accumulators: see ly_stats_flush (ly_common.cuh)
+    atomicAdd(st + lane, (double)s1);
+    atomicAdd(st + MIP + lane, (double)s2);
   }
 }
 
 template <int MIP>
 __global__ __launch_bounds__(LY_THREADS) void ly_coordatt_mlp_bwd2_kernel(
     const float* __restrict__ pool, int n_img, int H, int W, int C, long rows_per_block, const float* __restrict__ w1,
-    const float* __restrict__ gamma, const float* __restrict__ invstd, const float* __restrict__ ws, const float* __restrict__ sums,
+    const float* __restrict__ gamma, const float* __restrict__ invstd, const float* __restrict__ ws, const double* __restrict__ sums,
     float* __restrict__ dpool /* in: dz */, float* __restrict__ dw1, float* __restrict__ dgamma, float* __restrict__ dbeta,
     float* __restrict__ dwh, float* __restrict__ dbh, float* __restrict__ dww, float* __restrict__ dbw) {
   constexpr int NA = 3 * MIP + 2;                          // accumulators per channel: dW1[m], dWh[m], dWw[m], dbh, dbw
@@ -1205,9 +1205,9 @@ __global__ __launch_bounds__(LY_THREADS) void ly_coordatt_mlp_bwd2_kernel(
   const int c = blockIdx.x * 64 + lane;
   const bool cok = c < C;
   if (tid < 2 * MIP) {
-    float v = 0.f;
+    double v = 0.0;
     for (int st = 0; st < LY_CA_STRIPES; ++st) v += sums[st * 2 * MIP + tid];
-    ssum[tid] = v;
+    ssum[tid] = (float)v;
   }
   __syncthreads();
   const float invR = 1.f / (float)R;
@@ -1285,7 +1285,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_coordatt_mlp_bwd2_kernel(
 template <int MIP, int NS>
 static void launch_coordatt_bwd(hipStream_t st, const float* pool, int n_img, int H, int W, int C, const float* w1, const float* b1, const float* mean,
                                 const float* invstd, const float* gamma, const float* beta, const float* wh, const float* ww, const float* a_h,
-                                const float* a_w, const float* da_h, const float* da_w, float* ws, float* sums, float* dpool, float* dw1,
+                                const float* a_w, const float* da_h, const float* da_w, float* ws, double* sums, float* dpool, float* dw1,
                                 float* dgamma, float* dbeta, float* dwh, float* dbh, float* dww, float* dbw) {
   const long R = (long)n_img * (H + W);
   long b1n = (R + 3) / 4;
@@ -1305,7 +1305,7 @@ static void launch_coordatt_bwd(hipStream_t st, const float* pool, int n_img, in
 extern "C" int ly_coordatt_mlp_bwd(const float* pool, int n_img, int H, int W, int C, int mip, const float* w1, const float* b1,
                                    const float* mean, const float* invstd, const float* gamma, const float* beta, const float* wh,
                                    const float* ww, const float* a_h, const float* a_w, const float* da_h, const float* da_w, float* ws,
-                                   float* sums, float* dpool, float* dw1, float* dgamma, float* dbeta, float* dwh, float* dbh,
+                                   double* sums, float* dpool, float* dw1, float* dgamma, float* dbeta, float* dwh, float* dbh,
                                    float* dww, float* dbw, void* stream) {
   LY_CHECK(pool && w1 && b1 && mean && invstd && gamma && beta && wh && ww && a_h && a_w && da_h && da_w && ws && sums && dpool && dw1 &&
                dgamma && dbeta && dwh && dbh && dww && dbw, "coordatt_mlp_bwd: null pointer");
@@ -1346,7 +1346,7 @@ __device__ __forceinline__ long ly_gw_index(int ch, int t, int e, int chunk, boo
 }
 
 __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_gen_prepare_kernel(
-    const float* __restrict__ mom, int C, int KK, const float* __restrict__ gen_w, const float* __restrict__ gamma,
+    const double* __restrict__ mom, int C, int KK, const float* __restrict__ gen_w, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, float momentum, double count, float* __restrict__ running_mean,
     float* __restrict__ running_var, long* __restrict__ nbt, float* __restrict__ out8 /* [8][C*KK] */, float* __restrict__ a1,
     float* __restrict__ wq_stats, int cp_stats, float* __restrict__ wq_main, int cp_main, float* __restrict__ wq_c) {
@@ -1414,7 +1414,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_gen_prepare_kernel(
   if (nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
 }
 
-extern "C" int ly_rfcbam_gen_prepare(const float* mom, int C, int k, const float* gen_w, const float* gamma, const float* beta, float eps,
+extern "C" int ly_rfcbam_gen_prepare(const double* mom, int C, int k, const float* gen_w, const float* gamma, const float* beta, float eps,
                                      float momentum, double count, float* running_mean, float* running_var, long* nbt, float* out8,
                                      float* a1, float* wq_stats, float* wq_main, float* wq_c, void* stream) {
   LY_CHECK(mom && gen_w && gamma && beta && out8 && C > 0 && (k == 1 || k == 3) && count > 0, "rfcbam_gen_prepare: bad arguments");

@@ -41,7 +41,7 @@ __device__ __forceinline__ f32x4 ly_dact4(const f32x4 v, const f32x4 dy) {
 template <typename T, int ACT>
 __global__ __launch_bounds__(LY_THREADS) void ly_bnact_bwd_reduce_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ u,
                                                                           int ldu, long rows, int C, const float* __restrict__ a,
-                                                                          const float* __restrict__ b, float* __restrict__ sums) {
+                                                                          const float* __restrict__ b, double* __restrict__ sums) {
   // thread = (channel quad, row lane).  Four rows per trip with all eight loads issued before the first use, in straight-line code
   // (a load under a run-time branch makes every later s_waitcnt conservative: the first unrolled version, which still chose the vector
   // width at run time, was SLOWER than one row per trip).  Rows past the end re-read the last row and are masked.
@@ -77,12 +77,12 @@ __global__ __launch_bounds__(LY_THREADS) void ly_bnact_bwd_reduce_kernel(const T
   red2[tid] = s2;
   __syncthreads();
   if (j0 == 0) {
-    float* sm = sums + (size_t)(blockIdx.x & (LY_STATS_STRIPES - 1)) * 2 * C;
+    double* sm = sums + (size_t)(blockIdx.x & (LY_STATS_STRIPES - 1)) * 2 * C;      // double accumulators: see ly_stats_flush (ly_common.cuh)
     for (int g = 1; g < groups; ++g) { s1 += red1[g * ncv + cv]; s2 += red2[g * ncv + cv]; }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      atomicAdd(sm + 4 * cv + r, s1[r]);
-      atomicAdd(sm + C + 4 * cv + r, s2[r]);
+      atomicAdd(sm + 4 * cv + r, (double)s1[r]);
+      atomicAdd(sm + C + 4 * cv + r, (double)s2[r]);
     }
   }
 }
@@ -181,7 +181,7 @@ extern "C" int ly_bnact_fwd(const void* u_, int ldu, long rows, int C, const flo
 }
 
 extern "C" int ly_bnact_bwd_reduce(const void* dy_, int lddy, const void* u_, int ldu, long rows, int C, const float* a, const float* b,
-                                   int act, float* sums, int dtype, void* stream) {
+                                   int act, double* sums, int dtype, void* stream) {
   LY_CHECK_DTYPE(dtype, "bnact_bwd_reduce");
   LY_CHECK(dy_ && u_ && a && b && sums && rows > 0, "bnact_bwd_reduce: null pointer");
   LY_CHECK((C & 3) == 0 && C > 0 && C <= 1024 && (lddy & 3) == 0 && (ldu & 3) == 0, "bnact_bwd_reduce: C=%d / ld must be multiples of 4", C);
@@ -985,6 +985,22 @@ extern "C" int ly_sum_rows(const float* src, long R, long C, long ld, float* dst
   return 0;
 }
 
+// column sums of a small [R][C] matrix of doubles (the stripes of a double statistics accumulator), rows added in index order
+__global__ __launch_bounds__(LY_THREADS) void ly_sum_rows_f64_kernel(const double* __restrict__ src, const int R, const int C, double* __restrict__ dst) {
+  const int c = blockIdx.x * LY_THREADS + threadIdx.x;
+  if (c >= C) return;
+  double a = 0.0;
+  for (int r = 0; r < R; ++r) a += src[(long)r * C + c];
+  dst[c] = a;
+}
+extern "C" int ly_sum_rows_f64(const double* src, int R, int C, double* dst, void* stream) {
+  LY_CHECK(src && dst && R > 0 && C > 0, "sum_rows_f64: bad arguments");
+  hipLaunchKernelGGL(ly_sum_rows_f64_kernel, dim3((unsigned)((C + LY_THREADS - 1) / LY_THREADS)), dim3(LY_THREADS), 0, reinterpret_cast<hipStream_t>(stream), src,
+                     R, C, dst);
+  LY_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int ly_unpatch(const void* g, int n_img, int Ho, int Wo, int C, int ks, void* dx, int dtype, void* stream) {
   LY_CHECK_DTYPE(dtype, "unpatch");
   LY_CHECK(g && dx && n_img > 0 && Ho > 0 && Wo > 0 && ks > 0 && (C & 3) == 0, "unpatch: bad arguments");
@@ -1278,7 +1294,8 @@ __device__ __forceinline__ double ly_group32_sum(double v) {
   return v;
 }
 
-__global__ __launch_bounds__(LY_THREADS) void ly_bn_finalize_kernel(const float* __restrict__ stats, int stripes, int nch, int c_off, int N,
+template <typename TS>
+__global__ __launch_bounds__(LY_THREADS) void ly_bn_finalize_kernel(const TS* __restrict__ stats, int stripes, int nch, int c_off, int N,
                                                                     double count, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                     const float* __restrict__ bias, float eps, float momentum, float* running_mean,
                                                                     float* running_var, long* nbt, float* __restrict__ scale, float* __restrict__ shift,
@@ -1311,17 +1328,24 @@ __global__ __launch_bounds__(LY_THREADS) void ly_bn_finalize_kernel(const float*
   if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * (count / (count > 1.0 ? count - 1.0 : 1.0)));
 }
 
-extern "C" int ly_bn_finalize(const float* stats, int stripes, int nch, int c_off, int N, double count, const float* gamma, const float* beta,
+extern "C" int ly_bn_finalize(const void* stats, int stats_f64, int stripes, int nch, int c_off, int N, double count, const float* gamma, const float* beta,
                               const float* bias, float eps, float momentum, float* running_mean, float* running_var, long* nbt, float* scale,
                               float* shift, float* mean, float* invstd, void* stream) {
   LY_CHECK(stats && scale && shift && stripes > 0 && N > 0 && c_off >= 0 && c_off + N <= nch && count > 0, "bn_finalize: bad arguments");
-  hipLaunchKernelGGL(ly_bn_finalize_kernel, dim3((N + 7) / 8), dim3(LY_THREADS), 0, reinterpret_cast<hipStream_t>(stream), stats, stripes, nch, c_off, N,
-                     count, gamma, beta, bias, eps, momentum, running_mean, running_var, nbt, scale, shift, mean, invstd);
+  if (stats_f64)
+    hipLaunchKernelGGL(ly_bn_finalize_kernel<double>, dim3((N + 7) / 8), dim3(LY_THREADS), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const double*>(stats), stripes, nch, c_off, N, count, gamma, beta, bias, eps, momentum, running_mean, running_var, nbt,
+                       scale, shift, mean, invstd);
+  else
+    hipLaunchKernelGGL(ly_bn_finalize_kernel<float>, dim3((N + 7) / 8), dim3(LY_THREADS), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const float*>(stats), stripes, nch, c_off, N, count, gamma, beta, bias, eps, momentum, running_mean, running_var, nbt,
+                       scale, shift, mean, invstd);
   LY_LAUNCH_CHECK();
   return 0;
 }
 
-__global__ __launch_bounds__(LY_THREADS) void ly_bn_bwd_coeffs_kernel(const float* __restrict__ sums, int stripes, int N, double count,
+template <typename TS>
+__global__ __launch_bounds__(LY_THREADS) void ly_bn_bwd_coeffs_kernel(const TS* __restrict__ sums, int stripes, int N, double count,
                                                                       const float* __restrict__ a, const float* __restrict__ mean,
                                                                       const float* __restrict__ invstd, int train, float* __restrict__ dgamma,
                                                                       float* __restrict__ dbeta, float* __restrict__ alpha, float* __restrict__ kappa,
@@ -1352,11 +1376,15 @@ __global__ __launch_bounds__(LY_THREADS) void ly_bn_bwd_coeffs_kernel(const floa
   }
 }
 
-extern "C" int ly_bn_bwd_coeffs(const float* sums, int stripes, int N, double count, const float* a, const float* mean, const float* invstd, int train,
-                                float* dgamma, float* dbeta, float* alpha, float* kappa, float* lambda, void* stream) {
+extern "C" int ly_bn_bwd_coeffs(const void* sums, int sums_f64, int stripes, int N, double count, const float* a, const float* mean, const float* invstd,
+                                int train, float* dgamma, float* dbeta, float* alpha, float* kappa, float* lambda, void* stream) {
   LY_CHECK(sums && a && mean && invstd && dgamma && dbeta && alpha && kappa && lambda && N > 0 && count > 0, "bn_bwd_coeffs: bad arguments");
-  hipLaunchKernelGGL(ly_bn_bwd_coeffs_kernel, dim3((N + 7) / 8), dim3(LY_THREADS), 0, reinterpret_cast<hipStream_t>(stream), sums, stripes, N, count, a,
-                     mean, invstd, train, dgamma, dbeta, alpha, kappa, lambda);
+  if (sums_f64)
+    hipLaunchKernelGGL(ly_bn_bwd_coeffs_kernel<double>, dim3((N + 7) / 8), dim3(LY_THREADS), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const double*>(sums), stripes, N, count, a, mean, invstd, train, dgamma, dbeta, alpha, kappa, lambda);
+  else
+    hipLaunchKernelGGL(ly_bn_bwd_coeffs_kernel<float>, dim3((N + 7) / 8), dim3(LY_THREADS), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const float*>(sums), stripes, N, count, a, mean, invstd, train, dgamma, dbeta, alpha, kappa, lambda);
   LY_LAUNCH_CHECK();
   return 0;
 }

@@ -141,8 +141,13 @@ __device__ __forceinline__ void ly_l2_warm(const void* base, long bytes, float* 
 // The accumulator is STRIPED: LY_STATS_STRIPES copies of the [2*nch] array, block b adds into copy
 // b % LY_STATS_STRIPES (thousands of blocks adding to the same few addresses serialise in L2 otherwise);
 // ly_bn_finalize sums the copies in double precision.
+// The accumulators are DOUBLES (round 4): the wave's partial sums are computed in a fixed order, and what the arrival order of the
+// atomics can still change is the 53rd bit of a stripe — after ly_bn_finalize rounds mean / variance to fp32 the batch statistics of two
+// runs are the same bits (a summation-order effect survives the rounding with probability ~2^-29 per value).  With float accumulators
+// the 1e-7 noise of the statistics flipped ReLU / arg-max decisions downstream and two training runs differed by 1e-3 .. 5e-2 in whole
+// gradients; forward and routing decisions of a training step are now reproducible.
 #define LY_STATS_STRIPES 32
-__device__ __forceinline__ void ly_stats_flush(float* __restrict__ stats, int nch, int c, f32x4 s1, f32x4 s2) {
+__device__ __forceinline__ void ly_stats_flush(double* __restrict__ stats, int nch, int c, f32x4 s1, f32x4 s2) {
 #pragma unroll
   for (int o = 8; o > 0; o >>= 1) {
 #pragma unroll
@@ -152,12 +157,12 @@ __device__ __forceinline__ void ly_stats_flush(float* __restrict__ stats, int nc
     }
   }
   if ((threadIdx.x & 15) == 0) {
-    float* st = stats + (size_t)(blockIdx.x & (LY_STATS_STRIPES - 1)) * 2 * nch;
+    double* st = stats + (size_t)(blockIdx.x & (LY_STATS_STRIPES - 1)) * 2 * nch;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
       if (c + r < nch) {
-        atomicAdd(st + c + r, s1[r]);
-        atomicAdd(st + nch + c + r, s2[r]);
+        atomicAdd(st + c + r, (double)s1[r]);
+        atomicAdd(st + nch + c + r, (double)s2[r]);
       }
   }
 }

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(size
     wbase[t] = (long)(tt < Tt ? tt : Tt - 1) * S;
   }
   const uint4* wpk = reinterpret_cast<const uint4*>(P.wp);
-  ly_l2_warm(P.wp, (long)Tt * S * PL * 1024, P.stats ? P.stats : reinterpret_cast<float*>(P.out));
+  ly_l2_warm(P.wp, (long)Tt * S * PL * 1024, P.stats ? reinterpret_cast<float*>(P.stats) : reinterpret_cast<float*>(P.out));
 
   // weight fragment of (tap, k-step ks of chunk cc); a ragged last chunk (Cin % 64 == 32) clamps the absent second step to the
   // first: its activations are staged as zeros

@@ -245,7 +245,7 @@ __device__ __forceinline__ void ly_gemm_body2(const LyGemmParams& P, const int g
   const int pixgrp = wp_ * (16 * NT);
   const bool vec_ok = (P.ldo & 3) == 0;
   const int act = P.act;
-  float* const stats = P.stats;
+  double* const stats = P.stats;
   float rsv[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) rsv[n] = 1.f;
@@ -265,7 +265,7 @@ __device__ __forceinline__ void ly_gemm_body2(const LyGemmParams& P, const int g
       esh[t][r] = (ok && P.e_shift) ? P.e_shift[c + r] : 0.f;
     }
   }
-  ly_l2_warm(P.wp, (long)T * S * PL * 1024, P.stats ? P.stats : reinterpret_cast<float*>(P.out));
+  ly_l2_warm(P.wp, (long)T * S * PL * 1024, P.stats ? reinterpret_cast<float*>(P.stats) : reinterpret_cast<float*>(P.out));
   // NCH == 0: weights streamed, wq[j] = k-step j of the item being contracted.  NCH > 0 (K is exactly NCH chunks): ALL weight
   // fragments of the block's channel slice stay in registers.  That is not about the L2 traffic: vmcnt retires IN ORDER, so a
   // load that is consumed in the item that issued it (a streamed weight fragment) makes its s_waitcnt drain every older load —

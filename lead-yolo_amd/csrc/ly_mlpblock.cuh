@@ -48,7 +48,7 @@ template <typename T, int C, int NT, int HT, bool T2D, bool STATS, int D, bool Z
 __device__ __forceinline__ void ly_mlpblock_body(
     const T* __restrict__ x, T* __restrict__ y, long M, int H, int W,
     const uint4* __restrict__ wp, const uint4* __restrict__ w1, const uint4* __restrict__ w2,
-    const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, float* __restrict__ stats) {
+    const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, double* __restrict__ stats) {
   using Gm = MlpGeom<C>;
   using TR = LyT<T>;
   constexpr int PL = TR::PL, VW = TR::VW;
@@ -71,16 +71,18 @@ __device__ __forceinline__ void ly_mlpblock_body(
   const int BPH = T2D ? (TH + 2) * 18 : BP + 2 * W + 2;
   char* ps_hi = xs_hi + PL * BP * RS;
   char* ps_lo = ps_hi + (PL - 1) * BPH * RSP;
-  // statistics pass: the block's per-channel sums meet in LDS ([2][HTP*16] floats behind the halo planes: ds_add, no return value) and leave
-  // with ONE global atomic per channel and block — the four waves of a block used to flush every hidden tile on their own (C = 80: 1280
-  // global atomics per block inside the chunk loop; the statistics pass took 47 us where the whole forward takes 21)
+  // statistics pass: the block's per-channel sums meet in LDS (one [2][HTP*16] float slice PER WAVE behind the halo planes: every
+  // address has one owner lane, plain read-add-write in program order — LDS float atomics from four waves summed in arrival order and
+  // were one of the sources of run-to-run noise) and leave, the four slices added in a fixed order, with ONE global (double) atomic per
+  // channel and block — the four waves of a block used to flush every hidden tile on their own (C = 80: 1280 global atomics per block
+  // inside the chunk loop; the statistics pass took 47 us where the whole forward takes 21)
   float* const sacc = reinterpret_cast<float*>(ps_hi + PL * BPH * RSP);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lq = lane >> 4;
   const f32x4 zero = ly_zero4();
   if constexpr (STATS) {
-    for (int i = tid; i < 2 * HTP * 16; i += LY_THREADS) sacc[i] = 0.f;          // (the staging barrier below orders this before the first add)
+    for (int i = tid; i < 4 * 2 * HTP * 16; i += LY_THREADS) sacc[i] = 0.f;      // (the staging barrier below orders this before the first add)
   }
 
   // the fragment stream: partial conv (k-step major), then per hidden chunk GEMM1 (k-step major) and, unless this is the
@@ -111,7 +113,7 @@ __device__ __forceinline__ void ly_mlpblock_body(
     ++g;
   };
   if (C >= 80) {     // large weight sets, few pixels: warm L2 with all three packed weight arrays
-    float* const sink = stats ? stats : reinterpret_cast<float*>(y);
+    float* const sink = stats ? reinterpret_cast<float*>(stats) : reinterpret_cast<float*>(y);
     if constexpr (!ZONLY) {                                  // (partial conv only: w1 / w2 are not passed)
       ly_l2_warm(w1, (long)HTP * S1 * PL * 1024, sink);
       ly_l2_warm(w2, (long)C16 * S2 * PL * 1024, sink);
@@ -335,8 +337,9 @@ __device__ __forceinline__ void ly_mlpblock_body(
           const int ch = (hc * HT + t) * 16 + 4 * lq;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            atomicAdd(sacc + ch + r, s1[r]);
-            atomicAdd(sacc + HTP * 16 + ch + r, s2[r]);
+            float* const sw = sacc + wave * (2 * HTP * 16);
+            sw[ch + r] += s1[r];
+            sw[HTP * 16 + ch + r] += s2[r];
           }
         }
       }
@@ -376,8 +379,9 @@ __device__ __forceinline__ void ly_mlpblock_body(
 
   if (STATS) {
     __syncthreads();
-    float* const st = stats + (size_t)(blockIdx.x & (LY_STATS_STRIPES - 1)) * 2 * (HTP * 16);
-    for (int i = tid; i < 2 * HTP * 16; i += LY_THREADS) atomicAdd(st + i, sacc[i]);
+    double* const st = stats + (size_t)(blockIdx.x & (LY_STATS_STRIPES - 1)) * 2 * (HTP * 16);
+    constexpr int SL = 2 * HTP * 16;
+    for (int i = tid; i < SL; i += LY_THREADS) atomicAdd(st + i, (double)((sacc[i] + sacc[SL + i]) + (sacc[2 * SL + i] + sacc[3 * SL + i])));
     return;
   }
   // ---- epilogue: residual + store ------------------------------------------------------------
@@ -425,7 +429,7 @@ template <typename T, int C, int NT, int HT, int MODE>
 __device__ __forceinline__ void ly_mlpblock_persist_body(
     const T* __restrict__ x, T* __restrict__ y, long M, int H, int W, int n_img,
     const uint4* __restrict__ wp, const uint4* __restrict__ w1, const uint4* __restrict__ w2,
-    const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, float* __restrict__ stats) {
+    const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, double* __restrict__ stats) {
   using Gm = MlpGeom<C>;
   using TR = LyT<T>;
   using RV = typename TR::RV;
@@ -786,7 +790,7 @@ template <typename T, int C, int NT, int HT, int MODE>
 __global__ __launch_bounds__(LY_THREADS) void ly_mlpblock_persist_kernel(
     const T* __restrict__ x, T* __restrict__ y, long M, int H, int W, int n_img,
     const uint4* __restrict__ wp, const uint4* __restrict__ w1, const uint4* __restrict__ w2,
-    const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, float* __restrict__ stats) {
+    const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, double* __restrict__ stats) {
   ly_mlpblock_persist_body<T, C, NT, HT, MODE>(x, y, M, H, W, n_img, wp, w1, w2, bn_scale, bn_shift, stats);
 }
 
@@ -794,7 +798,7 @@ template <typename T, int C, int NT, int HT, bool T2D, bool STATS>
 __global__ __launch_bounds__(LY_THREADS) void ly_mlpblock_fwd_kernel(
     const T* __restrict__ x, T* __restrict__ y, long M, int H, int W,
     const uint4* __restrict__ wp, const uint4* __restrict__ w1, const uint4* __restrict__ w2,
-    const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, float* __restrict__ stats) {
+    const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, double* __restrict__ stats) {
   ly_mlpblock_body<T, C, NT, HT, T2D, STATS, 0>(x, y, M, H, W, wp, w1, w2, bn_scale, bn_shift, stats);
 }
 
@@ -804,7 +808,7 @@ template <typename T, int C, int NT, int HT, bool T2D, bool STATS>
 __global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void ly_mlpblock_fwd_occ4_kernel(
     const T* __restrict__ x, T* __restrict__ y, long M, int H, int W,
     const uint4* __restrict__ wp, const uint4* __restrict__ w1, const uint4* __restrict__ w2,
-    const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, float* __restrict__ stats) {
+    const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, double* __restrict__ stats) {
   ly_mlpblock_body<T, C, NT, HT, T2D, STATS, 0>(x, y, M, H, W, wp, w1, w2, bn_scale, bn_shift, stats);
 }
 
@@ -812,7 +816,7 @@ template <typename T, int C, int NT, int HT, bool T2D, bool STATS>
 __global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2))) void ly_mlpblock_fwd_ring_kernel(
     const T* __restrict__ x, T* __restrict__ y, long M, int H, int W,
     const uint4* __restrict__ wp, const uint4* __restrict__ w1, const uint4* __restrict__ w2,
-    const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, float* __restrict__ stats) {
+    const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, double* __restrict__ stats) {
   ly_mlpblock_body<T, C, NT, HT, T2D, STATS, 8>(x, y, M, H, W, wp, w1, w2, bn_scale, bn_shift, stats);
 }
 
@@ -844,7 +848,7 @@ static int launch_mlp_pconv1(const T* x, T* y, long M, int n_img, int H, int W, 
 // The instantiations are split over translation units (ly_mlpblock.hip: C = 16/24/40 + the C ABI, ly_mlpblock_b.hip:
 // C = 80/160, ly_mlpblock_c.hip: C = 320) only to keep the in-tree build short.
 #define LY_MLP_ARGS const void* x, void* y, long M, int n_img, int H, int W, const void* wp, const void* w1, const void* w2, \
-                    const float* s, const float* b, float* stats, int dtype, hipStream_t st
+                    const float* s, const float* b, double* stats, int dtype, hipStream_t st
 int ly_mlp_dispatch_80(LY_MLP_ARGS);
 int ly_mlp_dispatch_160(LY_MLP_ARGS);
 int ly_mlp_dispatch_320(LY_MLP_ARGS);
@@ -854,13 +858,13 @@ int ly_mlp_pconv_320(const void* x, void* y, long M, int n_img, int H, int W, co
 
 template <typename T, int C, int NT, int HT, bool T2D, bool STATS, bool RING>
 static int launch_mlp_k(const T* x, T* y, long M, int n_img, int H, int W, const void* wp, const void* w1, const void* w2,
-                        const float* s, const float* b, float* stats, hipStream_t st) {
+                        const float* s, const float* b, double* stats, hipStream_t st) {
   using Gm = MlpGeom<C>;
   constexpr int BP = 64 * NT;
   const long halo = T2D ? (4 * NT + 2) * 18 : BP + 2 * W + 2;
-  size_t lds = LyT<T>::PL * ((size_t)BP * Gm::RS + (size_t)halo * Gm::RSP) + (STATS ? 2 * Gm::HTP * 16 * sizeof(float) : 0);
+  size_t lds = LyT<T>::PL * ((size_t)BP * Gm::RS + (size_t)halo * Gm::RSP) + (STATS ? 4 * 2 * Gm::HTP * 16 * sizeof(float) : 0);
   LY_CHECK(lds <= 160 * 1024, "mlpblock: tile needs %zu B of LDS (C=%d W=%d)", lds, C, W);
-  void (*k)(const T*, T*, long, int, int, const uint4*, const uint4*, const uint4*, const float*, const float*, float*);
+  void (*k)(const T*, T*, long, int, int, const uint4*, const uint4*, const uint4*, const float*, const float*, double*);
   if constexpr (RING) k = ly_mlpblock_fwd_ring_kernel<T, C, NT, HT, T2D, STATS>;
   else if constexpr (C <= 24 && T2D) k = ly_mlpblock_fwd_occ4_kernel<T, C, NT, HT, T2D, STATS>;
   else k = ly_mlpblock_fwd_kernel<T, C, NT, HT, T2D, STATS>;
@@ -879,7 +883,7 @@ static int launch_mlp_k(const T* x, T* y, long M, int n_img, int H, int W, const
 
 template <typename T, int C, int NT, int HT, int MODE>
 static int launch_mlp_persist(const T* x, T* y, long M, int n_img, int H, int W, const void* wp, const void* w1, const void* w2,
-                              const float* s, const float* b, float* stats, hipStream_t st) {
+                              const float* s, const float* b, double* stats, hipStream_t st) {
   using Gm = MlpGeom<C>;
   constexpr int PL = LyT<T>::PL, BP = 64 * NT, BPH = (4 * NT + 2) * 18;
   constexpr int NFW = Gm::PT * Gm::SP + Gm::HTP * Gm::S1 + Gm::C16 * Gm::S2;
@@ -906,7 +910,7 @@ static int launch_mlp_persist(const T* x, T* y, long M, int n_img, int H, int W,
 
 template <typename T, int C, int NT, int HT, bool T2D>
 static int launch_mlp(const T* x, T* y, long M, int n_img, int H, int W, const void* wp, const void* w1, const void* w2,
-                      const float* s, const float* b, float* stats, hipStream_t st) {
+                      const float* s, const float* b, double* stats, hipStream_t st) {
   constexpr bool RING = C >= 80;
   if (stats) return launch_mlp_k<T, C, NT, HT, T2D, true, RING>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
   return launch_mlp_k<T, C, NT, HT, T2D, false, RING>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);
@@ -921,7 +925,7 @@ static int launch_mlp(const T* x, T* y, long M, int n_img, int H, int W, const v
 //    (C=80 @ 40x40x32: 26.5 -> 20.7 us; C=160 @ 20x20: 22.6 us with one tile at bs=32, 38.4 -> 28.8 us with two at bs=64).
 template <typename T, int C, int HT, int NTMAX>
 static int dispatch_nt_t(const T* x, T* y, long M, int n_img, int H, int W, const void* wp, const void* w1, const void* w2,
-                         const float* s, const float* b, float* stats, hipStream_t st) {
+                         const float* s, const float* b, double* stats, hipStream_t st) {
   constexpr int NT2 = NTMAX >= 2 ? 2 : NTMAX, NT4 = NTMAX >= 4 ? 4 : NTMAX;
   if (C >= 80) {
     if (NTMAX >= 2 && M >= 200L * 128) return launch_mlp<T, C, NT2, HT, false>(x, y, M, n_img, H, W, wp, w1, w2, s, b, stats, st);

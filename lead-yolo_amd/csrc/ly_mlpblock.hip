@@ -2,7 +2,7 @@
 #include "ly_mlpblock.cuh"
 
 extern "C" int ly_mlpblock_fwd(const void* x, void* y, int n_img, int H, int W, int C, const void* wp, const void* w1,
-                               const void* w2, const float* bn_scale, const float* bn_shift, float* stats, int dtype, void* stream) {
+                               const void* w2, const float* bn_scale, const float* bn_shift, double* stats, int dtype, void* stream) {
   LY_CHECK(dtype == LY_F32 || dtype == LY_BF16, "mlpblock: unknown dtype %d", dtype);
   LY_CHECK(x && wp && w1 && w2 && (stats || (y && bn_scale && bn_shift)), "mlpblock: null pointer");
   LY_CHECK(x != y, "mlpblock: in-place call is not supported (neighbouring tiles read halo rows)");

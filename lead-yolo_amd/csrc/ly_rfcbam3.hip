@@ -70,7 +70,7 @@ __device__ __forceinline__ void ly_rfcbam3_body(const LyRfcbam3Params& P, const 
     tile[t] = tt < Tt ? tt : Tt - 1;
   }
   const uint4* wpk = reinterpret_cast<const uint4*>(P.wp);
-  ly_l2_warm(P.wp, (long)Tt * S * PL * 1024, P.stats ? P.stats : reinterpret_cast<float*>(P.out));
+  ly_l2_warm(P.wp, (long)Tt * S * PL * 1024, P.stats ? reinterpret_cast<float*>(P.stats) : reinterpret_cast<float*>(P.out));
   for (int i = tid; i < PL * 64 * LY_RSG / 16; i += LY_THREADS) reinterpret_cast<uint4*>(gs_hi)[i] = make_uint4(0u, 0u, 0u, 0u);
 
   // staging plan of this thread (independent of the channel chunk): global element offset (or -1), LDS slot

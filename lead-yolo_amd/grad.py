@@ -946,7 +946,7 @@ class RfcbamFn(torch.autograd.Function):
                 ops.grad_done(ctx.getw_param)
             # 8. through max/mean, ca, rfa and ReLU; generate-BN sums
             if rf3s:
-                sums = ops.new_stats(kk * c, dev)                                   # striped [STRIPES][2][9][c]
+                sums = ops.new_sums(kk * c, dev)                                    # striped [STRIPES][2][9][c]
                 P3.d_mm, P3.sums = p(d_mm), p(sums)
                 with ops._Timed(f"ly_rf3s_bwd_kernel<{ops._tname(xr)}, 1>", 8.0 * mo * kk * c, 3.0 * es9):
                     L.check(L.lib().ly_rf3s_bwd(ctypes.byref(P3), ho, wo, 1, st), "ly_rf3s_bwd 1")
@@ -1114,7 +1114,7 @@ def _rfcbam_backward_k1(ctx, du, dgo, dbo):
     if t18 is not None:
         ops.grad_done(ctx.getw_param)
     # BatchNorm sums of the generate BatchNorm
-    sums = ops.new_stats(c, dev)
+    sums = ops.new_sums(c, dev)
     P.d_mm, P.sums = p(d_mm), p(sums)
     with ops._Timed(f"ly_rf1_bwd_kernel<{tn}, 1>", 8.0 * mo * c, 2.0 * es1):
         L.check(L.lib().ly_rf1_bwd(ctypes.byref(P), 1, st), "ly_rf1_bwd B")

@@ -758,7 +758,7 @@ class CoordAtt(nn.Module):
         w1raw, b1raw, wh, bh, ww, bw = self._weights()
         pool = ops.pool_hw(xr, ld, n, h, w, c)
         if self.training:
-            st = ops.coordatt_conv1_stats(pool, n * (h + w), c, self.mip, w1raw, b1raw)       # bn1 batch statistics
+            st = ops.coordatt_conv1_stats(pool, n * (h + w), c, self.mip, w1raw, b1raw).float()       # bn1 batch statistics (double accumulators)
             sc, sh = ops.bn_batch_affine(self.bn1, st[:self.mip], st[self.mip:], n * (h + w))
             w1, b1 = (w1raw * sc.view(-1, 1)).contiguous(), (b1raw * sc + sh).contiguous()
         else:

@@ -245,7 +245,7 @@ def coordatt_mlp(pool, n, h, w, c, mip, w1, b1, wh, bh, ww, bw, sc=None, sh=None
 def coordatt_mlp_bwd(pool, n, h, w, c, mip, w1, b1, mean, invstd, gamma, beta, wh, ww, a_h, a_w, da_h, da_w, targets):
     """targets: (dw1, dgamma, dbeta, dwh, dbh, dww, dbw) fp32 buffers that are ADDED to; returns dpool [n, h+w, c]"""
     r = n * (h + w)
-    sums = zeros_f32(32 * 2 * mip, pool.device)                        # striped (sum dy1, sum dy1*xh)
+    sums = zeros_f64(32 * 2 * mip, pool.device)                        # striped (sum dy1, sum dy1*xh), double accumulators
     ws = torch.empty(r * 3 * mip, dtype=torch.float32, device=pool.device)
     dpool = torch.empty((n, h + w, c), dtype=torch.float32, device=pool.device)
     with _Timed("ly_coordatt_mlp_bwd1_kernel + bwd2", 8.0 * r * c * mip, 4.0 * 4 * r * c):
@@ -499,11 +499,15 @@ def mlpblock(x, y, n, h, w, c, wp, w1, w2, sc, sh, stats=None):
                                               capi.stream_ptr()), "ly_mlpblock_fwd")
 
 
-def chan_moments(x, ldx, rows, c):
+def chan_moments(x, ldx, rows, c, f64=False):
+    """per-channel (sum x, sum x^2) over the rows of an [rows, c] matrix -> [2c]; accumulated in double stripes, folded in index order
+    (float32 result unless f64: ly_rfcbam_gen_prepare takes the doubles)"""
     mom = new_stats(c, x.device)
     with _Timed(f"ly_chan_moments_kernel<{_tname(x)}>", 3.0 * rows * c, x.element_size() * rows * c):
         capi.check(capi.lib().ly_chan_moments(_p(x), ldx, rows, c, _p(mom), capi.dtype_code(x), capi.stream_ptr()), "ly_chan_moments")
-    return sum_rows(mom)
+    out = torch.empty(2 * c, dtype=torch.float64, device=x.device)
+    capi.check(capi.lib().ly_sum_rows_f64(_p(mom), mom.shape[0], 2 * c, _p(out), capi.stream_ptr()), "ly_sum_rows_f64")
+    return out if f64 else out.float()
 
 
 STRIPES = capi.STATS_STRIPES
@@ -542,8 +546,8 @@ def stats_pool_end():
     p.need = max(p.need, p.used)
 
 
-def new_stats(nch, device):
-    """zeroed striped accumulator for a statistics pass over `nch` channels: [STRIPES][2*nch] (see ly_bn_finalize)"""
+def new_sums(nch, device):
+    """zeroed striped FLOAT accumulator [STRIPES][2*nch] of a backward reduction (ly_bnact_bwd_reduce, ly_rf*_bwd -> ly_bn_bwd_coeffs)"""
     p = _POOL
     n = STRIPES * 2 * nch
     if p.active:
@@ -554,6 +558,18 @@ def new_stats(nch, device):
             p.off += span
             return v
     return torch.zeros(STRIPES, 2 * nch, dtype=torch.float32, device=device)
+
+
+def zeros_f64(numel, device):
+    """zeroed float64 scratch out of the step's zero pool (an 8-byte view of 2 * numel pool floats; pool slices are 256-byte aligned)"""
+    return zeros_f32(2 * numel, device).view(torch.float64)
+
+
+def new_stats(nch, device):
+    """zeroed striped DOUBLE accumulator for a forward statistics pass over `nch` channels: [STRIPES][2*nch] float64 (ly_stats_flush of
+    csrc/ly_common.cuh adds the waves' fp32 partial sums as doubles: the batch statistics, and with them every ReLU / arg-max decision of
+    a training step, are reproducible from run to run; ly_bn_finalize reads it with stats_f64 = 1)"""
+    return zeros_f64(STRIPES * 2 * nch, device).view(STRIPES, 2 * nch)
 
 
 def zeros_f32(numel, device):
@@ -594,7 +610,9 @@ def bn_finalize(bn, stats, nch, count, n=None, c_off=0, bias=None, pad_to=0, wan
     if track:
         from . import pack
         pack.touch()                     # running statistics are written by the kernel: eval-mode folded caches must refresh
-    capi.check(capi.lib().ly_bn_finalize(_p(stats), stats.shape[0], nch, c_off, n, float(count), _p(bn.weight), _p(bn.bias), _p(bias), float(bn.eps),
+    if stats.dtype not in (torch.float32, torch.float64):
+        raise TypeError("bn_finalize: statistics must be float32 or float64")
+    capi.check(capi.lib().ly_bn_finalize(_p(stats), int(stats.dtype == torch.float64), stats.shape[0], nch, c_off, n, float(count), _p(bn.weight), _p(bn.bias), _p(bias), float(bn.eps),
                                          float(bn.momentum or 0.0), _p(bn.running_mean if track else None), _p(bn.running_var if track else None),
                                          _p(bn.num_batches_tracked if track else None), _p(scale), _p(shift), _p(mean), _p(invstd),
                                          capi.stream_ptr()), "ly_bn_finalize")
@@ -610,7 +628,7 @@ def bn_bwd_coeffs(sums, n, count, a, mean, invstd, train, dgamma=None, dbeta=Non
     direct = dgamma is not None and dbeta is not None
     if not direct:
         out[:2].zero_()
-    capi.check(capi.lib().ly_bn_bwd_coeffs(_p(sums), stripes, n, float(count), _p(a), _p(mean), _p(invstd), int(train), _p(dgamma if direct else out[0]),
+    capi.check(capi.lib().ly_bn_bwd_coeffs(_p(sums), int(sums.dtype == torch.float64), stripes, n, float(count), _p(a), _p(mean), _p(invstd), int(train), _p(dgamma if direct else out[0]),
                                            _p(dbeta if direct else out[1]), _p(out[2]), _p(out[3]), _p(out[4]), capi.stream_ptr()), "ly_bn_bwd_coeffs")
     return (None if direct else out[0]), (None if direct else out[1]), out[2], out[3], out[4]
 
@@ -653,7 +671,7 @@ def grad_done(p):
 
 
 def coordatt_conv1_stats(pool, positions, c, mip, w1, b1):
-    st = zeros_f32(2 * mip, pool.device)
+    st = zeros_f64(2 * mip, pool.device)
     capi.check(capi.lib().ly_coordatt_conv1_stats(_p(pool), positions, c, mip, _p(w1), _p(b1), _p(st), capi.stream_ptr()),
                "ly_coordatt_conv1_stats")
     return st
@@ -673,9 +691,10 @@ def rfcbam_generate_stats(x, ldx, n, h, w, c, s, gen_w):
     """Batch statistics of the k=3 `generate` BatchNorm input: returns (sum a, sum a^2) per generate channel
     (c*9 + t) and the sample count, from the per-channel tap moments (see ly_rfcbam_tap_moments)."""
     global _TRIU
-    mom = torch.zeros(54, c, dtype=torch.float32, device=x.device)
+    mom = torch.zeros(54, c, dtype=torch.float64, device=x.device)
     with _Timed(f"ly_rfcbam_tap_moments_kernel<{_tname(x)}>", 108.0 * n * h * w * c / (s * s), x.element_size() * n * h * w * c):
         capi.check(capi.lib().ly_rfcbam_tap_moments(_p(x), ldx, n, h, w, c, s, _p(mom), capi.dtype_code(x), capi.stream_ptr()), "ly_rfcbam_tap_moments")
+    mom = mom.float()
     if _TRIU is None or _TRIU[0].device != x.device:
         iu = torch.triu_indices(9, 9, device=x.device)
         _TRIU = (iu[0], iu[1])
@@ -697,13 +716,13 @@ def rfcbam_gen_prepare(x, ldx, n, h, w, c, k, s, gen_w, bn):
     kk = k * k
     dev = x.device
     if k == 3:
-        mom = zeros_f32(54 * c, dev)
+        mom = zeros_f64(54 * c, dev)
         with _Timed(f"ly_rfcbam_tap_moments_kernel<{_tname(x)}>", 108.0 * n * h * w * c / (s * s), x.element_size() * n * h * w * c):
             capi.check(capi.lib().ly_rfcbam_tap_moments(_p(x), ldx, n, h, w, c, s, _p(mom), capi.dtype_code(x), capi.stream_ptr()), "ly_rfcbam_tap_moments")
         ho, wo = (h + 2 - 3) // s + 1, (w + 2 - 3) // s + 1
         count = n * ho * wo
     else:
-        mom = chan_moments(x, ldx, n * h * w, c)
+        mom = chan_moments(x, ldx, n * h * w, c, f64=True)
         count = n * h * w
     g = c * kk
     out8 = torch.empty(8, g, dtype=torch.float32, device=dev)
@@ -748,7 +767,7 @@ def bnact_fwd(u, ldu, rows, c, a, b, act, y, ldy):
 
 
 def bnact_bwd_reduce(dy, lddy, u, ldu, rows, c, a, b, act):
-    sums = new_stats(c, u.device)
+    sums = new_stats(c, u.device)                 # double accumulators: the coefficients of du, and with them the whole activation-gradient chain, are reproducible
     with _Timed(f"ly_bnact_bwd_reduce_kernel<{_tname(u)}, {act}>", 6.0 * rows * c, 2.0 * u.element_size() * rows * c):
         capi.check(capi.lib().ly_bnact_bwd_reduce(_p(dy), lddy, _p(u), ldu, rows, c, _p(a), _p(b), act, _p(sums), capi.dtype_code(u),
                                                   capi.stream_ptr()), "ly_bnact_bwd_reduce")

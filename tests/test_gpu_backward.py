@@ -459,17 +459,20 @@ def test_graphed_train_step_matches_eager(amp):
         assert after[2] == s0[2] + 1
         outs.append((float(loss), after[0]))
     (le, e), (le2, e2), (lg, g) = outs
-    tight = 1e-3 if amp is None else 2.0 ** -7
-    assert abs(le - lg) <= max(tight, 3 * abs(le - le2) / abs(le)) * abs(le), (le, le2, lg)
-    # One step from the same state differs between two EAGER runs by float-atomic order and, through it, by flipped ReLU / channel-max /
-    # clamp decisions: heavy-tailed per tensor (ten runs of this test: the same tensor's update differs by 2e-4 in one pair of eager runs
-    # and by 0.3 in another), so single tensors are not compared tightly.  Compared instead, per class of state (weights, EMA, momentum):
+    # Round 4: the batch statistics (forward) and the BatchNorm-backward sums are double accumulators, so the forward of a step — every
+    # ReLU / channel-max / clamp decision — is the same bits in every run and in the replay: the loss agrees to the float sums of the loss
+    # kernel, and in fp32 the whole update agrees to the summation order of the weight-gradient atomics (was: 1e-3 loss band, cosine 0.98,
+    # 80 % of the tensors within 5 %).  bf16 keeps wider bands: rounding the activation gradients to bf16 amplifies the last-bit noise of the
+    # fp32 atomics layer by layer (tools/step_repro.py: 1e-4 at the neck, 1e-2 at the stem).
+    tight = 1e-6 if amp is None else 2.0 ** -9
+    assert abs(le - lg) <= tight * abs(le) and abs(le - le2) <= tight * abs(le), (le, le2, lg)
+    # Compared per class of state (weights, EMA, momentum):
     #   (a) every entry stays within `loose` of its tensor's scale (weights and EMA move by lr * update: a wrong or stale step shows),
     #   (b) the step's UPDATE of the whole class as ONE vector: cosine with the eager step's and norm ratio — a skipped EMA update or
     #       optimiser step is a zero vector, a doubled one has ratio 2, gradients in the wrong place lose the direction,
     #   (c) most tensors individually: >= 80 % (fp32) / 50 % (bf16) of them agree to `floor` in relative L2 of their update.
-    loose = 5e-3 if amp is None else 3e-2
-    cos_min, ratio_tol, floor = (0.98, 0.05, 0.05) if amp is None else (0.90, 0.2, 0.35)
+    loose = 1e-4 if amp is None else 3e-2
+    cos_min, ratio_tol, floor = (0.99999, 1e-3, 1e-3) if amp is None else (0.90, 0.2, 0.35)
     for wi, what in enumerate(("weight", "ema", "momentum")):
         a, b, before = e[wi], g[wi], s0[0][wi]
         assert a.keys() == b.keys() and len(a) > 100
@@ -484,7 +487,7 @@ def test_graphed_train_step_matches_eager(amp):
         de, dg = torch.cat(de), torch.cat(dg)
         cos, ratio = float(de @ dg / (de.norm() * dg.norm())), float(dg.norm() / de.norm())
         assert cos >= cos_min and abs(ratio - 1) <= ratio_tol, (what, "update", cos, ratio)
-        frac = 0.8 if amp is None else 0.5         # (bf16: one flipped routing decision early in the net moves many gradients at once: 74 % seen in 1 of 30 runs)
+        frac = 0.95 if amp is None else 0.5
         assert len(rels) > 100 and sum(r[0] <= floor for r in rels) >= frac * len(rels), (what, "update", sorted(rels)[-10:])
     # ---- a short trajectory on changing batches: graph replays vs eager steps from the same state, loosely ----
     traj = []
@@ -574,6 +577,58 @@ def test_graphed_step_with_reducer_matches_eager(rccl, accumulate):
             dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("amp", [None, torch.bfloat16])
+def test_training_forward_is_reproducible_and_gradients_agree_to_summation_noise(amp):
+    """batch statistics used to be summed by float atomics in arrival order; their 1e-7 noise flipped ReLU / arg-max
+    decisions downstream and two runs of the SAME step differed by 1e-3 .. 5e-2 in whole gradients (and made every end-to-end training test
+    loose).  The forward statistics are double accumulators now (csrc/ly_common.cuh ly_stats_flush): from one state, two runs of forward +
+    loss + backward must give (a) BIT-IDENTICAL predictions, loss and BatchNorm running statistics — every routing decision is the same —
+    and (b) gradients that differ only by the float summation order of the backward reductions: <= 1e-5 of each tensor's norm (typically
+    1e-7), not by flipped units."""
+    import lead_yolo_amd as L
+    torch.manual_seed(0)
+    m = L.Model(_cfg("n"))
+    st = synth.synth_state(synth.shapes_of(m.state_dict()), 7373)
+    st["model.23.anchors"] = m.model[-1].anchors.clone()
+    m.load_state_dict(st)
+    m = m.to(_dev()).train()
+    cl = L.ComputeLoss(m)
+    imgs = synth.synth_images(4, 160, 71).to(_dev())
+    tg = synth.synth_targets(4, 72, per_image=4).to(_dev())
+    bufs0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    runs = []
+    for _ in range(3):
+        m.load_state_dict(bufs0)
+        for p in m.parameters():
+            p.grad = None
+        x = imgs.float() / 255
+        with torch.autocast("cuda", dtype=amp, enabled=amp is not None):
+            pred = m(x)
+            loss, items = cl(pred, tg)
+        loss.backward()
+        torch.cuda.synchronize()
+        runs.append(([p_.detach().clone() for p_ in pred], loss.detach().clone(), {k: v.detach().clone() for k, v in m.state_dict().items() if "running" in k},
+                     {n: p.grad.detach().clone() for n, p in m.named_parameters()}))
+    p0, l0, r0, g0 = runs[0]
+    for p1, l1, r1, g1 in runs[1:]:
+        for i, (a, b) in enumerate(zip(p0, p1)):
+            assert torch.equal(a, b), f"prediction level {i} differs between two runs of the same step ({float((a.float() - b.float()).abs().max()):.3e})"
+        assert abs(float(l0) - float(l1)) <= 1e-6 * abs(float(l0)), (float(l0), float(l1))       # (the loss sums are float atomics)
+        for k in r0:
+            assert torch.equal(r0[k], r1[k]), f"{k} differs between two runs"
+        total = float(torch.cat([g.flatten() for g in g0.values()]).double().norm())
+        diffs = {n: float((g0[n] - g1[n]).double().norm()) for n in g0}
+        whole = float(torch.cat([(g0[n] - g1[n]).flatten() for n in g0]).double().norm()) / total
+        # per tensor: relative to its own norm, with a floor of 1e-3 of the whole gradient for tensors that are (nearly) zero by construction
+        name, worst = max(((n, d / max(float(g0[n].double().norm()), 1e-3 * total)) for n, d in diffs.items()), key=lambda t: t[1])
+        # fp32: what is left is the summation order of the float atomics of the weight / bias gradients (leaves: not amplified).  bf16: the
+        # activation gradients are ROUNDED to bf16 between layers, which turns last-bit differences of the fp32 sums feeding them into 2^-9
+        # steps that the BatchNorm backward's mean subtractions amplify layer by layer (tools/step_repro.py: 0 down to the neck, 1e-4 at
+        # layer 13, 1e-2 at the stem; the same magnitudes in every pair of runs) — bounded, documented in DESIGN.md as open
+        lim_whole, lim_tensor = (1e-5, 5e-4) if amp is None else (2e-2, 3e-1)
+        assert whole <= lim_whole and worst <= lim_tensor, f"gradients differ between two runs of the same step: whole vector {whole:.3e}, worst tensor {name} {worst:.3e}"
+
+
 def test_reference_training_objects_stock_ddp_gradscaler_fp16_autocast():
     """the route `python -m lead_yolo_amd.run train.py` takes, without the reference travelling: the HIP `Model` wrapped in stock
     torch.nn.parallel.DistributedDataParallel(static_graph=True) (utils/torch_utils.py:55-63) on a one-rank RCCL group, torch.optim.SGD with
@@ -618,7 +673,7 @@ def test_reference_training_objects_stock_ddp_gradscaler_fp16_autocast():
             if it == 0:
                 got = torch.cat([g.detach().flatten() for g in grads]).double()
                 cos = float(got @ ref / (got.norm() * ref.norm()))
-                assert cos > 0.98 and 0.9 < float(got.norm() / ref.norm()) < 1.1, (cos, float(got.norm() / ref.norm()))
+                assert cos > 0.95 and 0.9 < float(got.norm() / ref.norm()) < 1.1, (cos, float(got.norm() / ref.norm()))
             torch.nn.utils.clip_grad_norm_(m.parameters(), max_norm=10.0)
             scale_before = scaler.get_scale()
             scaler.step(opt)

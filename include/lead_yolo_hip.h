@@ -363,7 +363,7 @@ int ly_patch4_rows_u8(const unsigned char* img, int n_img, int C, int H, int W, 
  *   dx = dout*a_h*a_w,  da_h[n,h,c] += sum_w dout*x*a_w,  da_w[n,w,c] += sum_h dout*x*a_h  (caller zeroes both).
  * Pools pool[n,0:H]=mean_w x, pool[n,H:H+W]=mean_h x:  dx[n,h,w,c] (+)= gp[n,h,c]/W + gp[n,H+w,c]/H  (accumulate != 0: added to dx). */
 int ly_coordatt_gate_bwd(const void* dout /*T*/, int ldd, const void* x /*T*/, int ldx, int n_img, int H, int W, int C, const float* a_h,
-                         const float* a_w, void* dx /*T*/, int lddx, float* da_h, float* da_w, int dtype, void* stream);
+                         const float* a_w, void* dx /*T*/, int lddx, double* da_h /* zeroed doubles */, double* da_w /* zeroed doubles */, int dtype, void* stream);
 int ly_pool_hw_bwd(const float* gp, int n_img, int H, int W, int C, void* dx /*T*/, int lddx, int accumulate, int dtype, void* stream);
 /* SPPF backward as a gather (no atomics, deterministic): ly_maxpool_arg stores, for every window of a k x k / s1 / pad k//2 max-pool over
  * x [n, H, W, C] (row stride ldx), the tap index (0 .. k*k-1, row-major) of its first maximum — ATen's routing rule — as one byte per element
@@ -464,8 +464,8 @@ typedef struct LyRf1BwdParams {
   const void* x; int ldx;          /* T */
   const void* dcd;                 /* T, dense */
   const float* gw; const float* ag; const float* bg; const float* ca; const float* rfa;
-  void* cd; float* d_rfa; float* gmax_out; float* d_ca;                 /* pass 0 outputs */
-  const float* gmax; const float* d_mm; float* sums;                    /* pass 1 (gmax / d_mm also pass 2) */
+  void* cd; float* d_rfa; float* gmax_out; double* d_ca;                /* pass 0 outputs (d_ca: zeroed DOUBLE accumulators [n, C]) */
+  const float* gmax; const float* d_mm; double* sums;                   /* pass 1 (gmax / d_mm also pass 2); sums: [32][2][taps][C] zeroed doubles */
   const float* alpha; const float* kappa; const float* lambda; const float* dgap; float dgap_scale;
   void* dx; int lddx; float* dgw;                                       /* pass 2 outputs */
   int dtype;

@@ -1073,7 +1073,7 @@ template <typename T>
 __global__ __launch_bounds__(LY_THREADS) void ly_coordatt_gate_bwd_kernel(const T* __restrict__ dout, int ldd, const T* __restrict__ x,
                                                                            int ldx, int H, int W, int C, const float* __restrict__ a_h,
                                                                            const float* __restrict__ a_w, T* __restrict__ dx, int lddx,
-                                                                           float* __restrict__ da_h, float* __restrict__ da_w, int bands, int slabs) {
+                                                                           double* __restrict__ da_h, double* __restrict__ da_w, int bands, int slabs) {
   __shared__ f32x4 red[LY_THREADS];
   const int nc4 = C >> 2, tid = threadIdx.x;
   const int groups = LY_THREADS / nc4;
@@ -1129,9 +1129,10 @@ __global__ __launch_bounds__(LY_THREADS) void ly_coordatt_gate_bwd_kernel(const 
     __syncthreads();
     if (g0 == 0) {
       for (int g = 1; g < groups; ++g) sh += red[g * nc4 + c4];
-      float* o = da_h + nh * C + 4 * c4;                      // (one add per row, slab and channel: da_h is zeroed by the caller)
+      double* o = da_h + nh * C + 4 * c4;                     // (one add per row, slab and channel: da_h is zeroed by the caller; DOUBLE
+                                                              // accumulators — a float sum in arrival order seeded run-to-run differences of dx)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) atomicAdd(o + r, sh[r]);
+      for (int r = 0; r < 4; ++r) atomicAdd(o + r, (double)sh[r]);
     }
   }
   if (g0 < groups) {
@@ -1139,16 +1140,16 @@ __global__ __launch_bounds__(LY_THREADS) void ly_coordatt_gate_bwd_kernel(const 
     for (int i = 0; i < LY_CAG_MAXW; ++i) {
       const int w = w0 + g0 + i * groups;
       if (w < W) {
-        float* o = da_w + (n * W + w) * C + 4 * c4;
+        double* o = da_w + (n * W + w) * C + 4 * c4;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) atomicAdd(o + r, accw[i][r]);
+        for (int r = 0; r < 4; ++r) atomicAdd(o + r, (double)accw[i][r]);
       }
     }
   }
 }
 
 extern "C" int ly_coordatt_gate_bwd(const void* dout, int ldd, const void* x, int ldx, int n_img, int H, int W, int C, const float* a_h,
-                                    const float* a_w, void* dx, int lddx, float* da_h, float* da_w, int dtype, void* stream) {
+                                    const float* a_w, void* dx, int lddx, double* da_h, double* da_w, int dtype, void* stream) {
   LY_CHECK_DTYPE(dtype, "coordatt_gate_bwd");
   LY_CHECK(dout && x && a_h && a_w && dx && da_h && da_w, "coordatt_gate_bwd: null pointer");
   LY_CHECK((C & 3) == 0 && C <= 1024 && (ldd & 3) == 0 && (ldx & 3) == 0 && (lddx & 3) == 0, "coordatt_gate_bwd: C / ld must be multiples of 4");

@@ -145,8 +145,8 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf1_bwd_kernel(const LyRf1BwdPa
       const int qn = e / C, c = e - qn * C;
       float s = 0.f;
       for (int sl = 0; sl < PB; ++sl) s += red[(sl * NQT + qn) * CS + c];
-      if constexpr (MODE == RF1_A) atomicAdd(P.d_ca + n * C + c, s);
-      else if constexpr (MODE == RF1_B) atomicAdd(P.sums + (size_t)((blockIdx.x + blockIdx.y) & (LY_STATS_STRIPES - 1)) * 2 * C + qn * C + c, s);
+      if constexpr (MODE == RF1_A) atomicAdd(P.d_ca + n * C + c, (double)s);                                  // double accumulators (ly_common.cuh ly_stats_flush)
+      else if constexpr (MODE == RF1_B) atomicAdd(P.sums + (size_t)((blockIdx.x + blockIdx.y) & (LY_STATS_STRIPES - 1)) * 2 * C + qn * C + c, (double)s);
       else atomicAdd(P.dgw + c, s);
     }
   }
@@ -311,16 +311,16 @@ __global__ __launch_bounds__(576) void ly_rf3s_bwd_kernel(const LyRf1BwdParams P
     for (int c = tid; c < C; c += blockDim.x) {
       float s = 0.f;
       for (int sl = 0; sl < nslots; ++sl) s += red[sl * CS + c];
-      atomicAdd(P.d_ca + n * C + c, s);
+      atomicAdd(P.d_ca + n * C + c, (double)s);
     }
   } else {
-    float* const sm = P.sums + (size_t)((blockIdx.x + blockIdx.y) & (LY_STATS_STRIPES - 1)) * 2 * 9 * C;
+    double* const sm = P.sums + (size_t)((blockIdx.x + blockIdx.y) & (LY_STATS_STRIPES - 1)) * 2 * 9 * C;
     for (int e = tid; e < 2 * 9 * C; e += blockDim.x) {
       const int qn = e / (9 * C), rem = e - qn * 9 * C;
       const int tt = rem / C, c = rem - tt * C;
       float s = 0.f;
       for (int k = 0; k < pp; ++k) s += red[((k * 9 + tt) * NQT + qn) * CS + c];
-      atomicAdd(sm + qn * 9 * C + tt * C + c, s);
+      atomicAdd(sm + qn * 9 * C + tt * C + c, (double)s);
     }
   }
 }

@@ -915,10 +915,12 @@ class RfcbamFn(torch.autograd.Function):
             vw = ops.vw_of(xr)
             rf3s = k == 3 and RF3S_BWD and c % vw == 0 and c // vw <= 64          # 16-bytes-per-lane passes (csrc/ly_rf1_bwd.hip: ly_rf3s_bwd)
             if rf3s:
-                P3 = L.LyRf1BwdParams(n, ho * wo, c, p(ug), c, p(dcd), None, p(ag), p(bg), p(ca), p(rfa), p(cd), p(d_rfa), p(gmax), p(d_ca),
+                d_ca64 = ops.zeros_f64(ca.numel(), dev)                            # double accumulators: d_ca feeds dx through SE's backward
+                P3 = L.LyRf1BwdParams(n, ho * wo, c, p(ug), c, p(dcd), None, p(ag), p(bg), p(ca), p(rfa), p(cd), p(d_rfa), p(gmax), p(d_ca64),
                                       p(gmax), None, None, None, None, None, None, 0.0, None, c, None, code)
                 with ops._Timed(f"ly_rf3s_bwd_kernel<{ops._tname(xr)}, 0>", 8.0 * mo * kk * c, 3.0 * es9):
                     L.check(L.lib().ly_rf3s_bwd(ctypes.byref(P3), ho, wo, 0, st), "ly_rf3s_bwd 0")
+                d_ca = d_ca64.float().view_as(ca)
             else:
                 with ops._Timed(f"ly_rf_bwd_attn_kernel<{ops._tname(xr)}, {k}>", 8.0 * mo * kk * c, 3.0 * es9):
                     L.check(L.lib().ly_rf_bwd_attn(n, h, w, c, k, s, p(ug), p(dcd), p(ag), p(bg), p(ca), p(rfa), p(cd), p(d_rfa), p(gmax), p(d_ca), code, st),
@@ -946,7 +948,7 @@ class RfcbamFn(torch.autograd.Function):
                 ops.grad_done(ctx.getw_param)
             # 8. through max/mean, ca, rfa and ReLU; generate-BN sums
             if rf3s:
-                sums = ops.new_sums(kk * c, dev)                                    # striped [STRIPES][2][9][c]
+                sums = ops.new_stats(kk * c, dev)                                   # striped [STRIPES][2][9][c] doubles
                 P3.d_mm, P3.sums = p(d_mm), p(sums)
                 with ops._Timed(f"ly_rf3s_bwd_kernel<{ops._tname(xr)}, 1>", 8.0 * mo * kk * c, 3.0 * es9):
                     L.check(L.lib().ly_rf3s_bwd(ctypes.byref(P3), ho, wo, 1, st), "ly_rf3s_bwd 1")
@@ -1080,20 +1082,20 @@ def _rfcbam_backward_k1(ctx, du, dgo, dbo):
     ops.gemm(M=mo, H=h, W=w, K=o, N=c, a0=du, lda0=o, k0=o, wp=wct, out=dcd, ldo=c)
     gw = gen_w.detach().float().reshape(c).contiguous()
     cd = torch.empty((mo, c), dtype=dt, device=dev)
-    zz = ops.zeros_f32(ca.numel(), dev)
-    d_ca = zz.view_as(ca)
+    d_ca64 = ops.zeros_f64(ca.numel(), dev)                 # double accumulators: d_ca feeds dx through SE's backward
     d_rfa = torch.empty(rfa.numel(), dtype=torch.float32, device=dev)
     gmax = torch.empty(rfa.numel(), dtype=torch.float32, device=dev)
     dx = ops.empty_nhwc(n, c, h, w, xr) if ctx.needs_input_grad[1] else ops.empty_nhwc(n, c, h, w, xr)
     tgw = ops.grad_target(ctx.gen_w_param) if getattr(ctx, "gen_w_param", None) is not None else None
     tgw = tgw if tgw is not None and tgw.is_contiguous() else None
     dgw = tgw.view(-1) if tgw is not None else torch.zeros(c, dtype=torch.float32, device=dev)
-    P = L.LyRf1BwdParams(n, h * w, c, p(xr), ld, p(dcd), p(gw), p(ag), p(bg), p(ca), p(rfa), p(cd), p(d_rfa), p(gmax), p(d_ca),
+    P = L.LyRf1BwdParams(n, h * w, c, p(xr), ld, p(dcd), p(gw), p(ag), p(bg), p(ca), p(rfa), p(cd), p(d_rfa), p(gmax), p(d_ca64),
                          p(gmax), None, None, None, None, None, None, 1.0 / (h * w), p(dx), c, p(dgw), L.dtype_code(xr))
     es1 = xr.element_size() * mo * c
     tn = ops._tname(xr)
     with ops._Timed(f"ly_rf1_bwd_kernel<{tn}, 0>", 6.0 * mo * c, 3.0 * es1):
         L.check(L.lib().ly_rf1_bwd(ctypes.byref(P), 0, st), "ly_rf1_bwd A")
+    d_ca = d_ca64.float().view_as(ca)
     # conv weight gradient from cd
     tgt = ops.grad_target(ctx.conv_w_param)
     if tgt is not None:
@@ -1113,8 +1115,8 @@ def _rfcbam_backward_k1(ctx, du, dgo, dbo):
     L.check(L.lib().ly_rfa_bwd(p(d_rfa), p(rfa), p(mm), p(w18), n, h, w, p(d_mm), p(dw18), st), "ly_rfa_bwd")
     if t18 is not None:
         ops.grad_done(ctx.getw_param)
-    # BatchNorm sums of the generate BatchNorm
-    sums = ops.new_sums(c, dev)
+    # BatchNorm sums of the generate BatchNorm (double accumulators)
+    sums = ops.new_stats(c, dev)
     P.d_mm, P.sums = p(d_mm), p(sums)
     with ops._Timed(f"ly_rf1_bwd_kernel<{tn}, 1>", 8.0 * mo * c, 2.0 * es1):
         L.check(L.lib().ly_rf1_bwd(ctypes.byref(P), 1, st), "ly_rf1_bwd B")

@@ -908,12 +908,13 @@ def coordatt_gate_bwd(dout, x, ldx, n, h, w, c, a_h, a_w, ldd=None):
     """dout: rows of the incoming gradient with row stride ldd (default c: dense) — a channel slice of a wider gradient is read in place"""
     ldd = c if ldd is None else ldd
     dx = empty_nhwc(n, c, h, w, x)
-    da = zeros_f32(n * (h + w) * c, dout.device)
+    da = zeros_f64(n * (h + w) * c, dout.device)          # double accumulators (several row bands / column slabs add into one entry)
     da_h, da_w = da[:n * h * c].view(n, h, c), da[n * h * c:].view(n, w, c)
     with _Timed(f"ly_coordatt_gate_bwd_kernel<{_tname(x)}>", 6.0 * n * h * w * c, 3.0 * x.element_size() * n * h * w * c):
         capi.check(capi.lib().ly_coordatt_gate_bwd(_p(dout), ldd, _p(x), ldx, n, h, w, c, _p(a_h), _p(a_w), _p(dx), c, _p(da_h), _p(da_w),
                                                    capi.dtype_code(x), capi.stream_ptr()), "ly_coordatt_gate_bwd")
-    return dx, da_h, da_w
+    da = da.float()
+    return dx, da[:n * h * c].view(n, h, c), da[n * h * c:].view(n, w, c)
 
 
 def pool_hw_bwd(gp, n, h, w, c, dtype=torch.float32, into=None):

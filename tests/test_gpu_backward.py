@@ -464,15 +464,15 @@ def test_graphed_train_step_matches_eager(amp):
     # kernel, and in fp32 the whole update agrees to the summation order of the weight-gradient atomics (was: 1e-3 loss band, cosine 0.98,
     # 80 % of the tensors within 5 %).  bf16 keeps wider bands: rounding the activation gradients to bf16 amplifies the last-bit noise of the
     # fp32 atomics layer by layer (tools/step_repro.py: 1e-4 at the neck, 1e-2 at the stem).
-    tight = 1e-6 if amp is None else 2.0 ** -9
+    tight = 1e-6 if amp is None else 1e-5
     assert abs(le - lg) <= tight * abs(le) and abs(le - le2) <= tight * abs(le), (le, le2, lg)
     # Compared per class of state (weights, EMA, momentum):
     #   (a) every entry stays within `loose` of its tensor's scale (weights and EMA move by lr * update: a wrong or stale step shows),
     #   (b) the step's UPDATE of the whole class as ONE vector: cosine with the eager step's and norm ratio — a skipped EMA update or
     #       optimiser step is a zero vector, a doubled one has ratio 2, gradients in the wrong place lose the direction,
     #   (c) most tensors individually: >= 80 % (fp32) / 50 % (bf16) of them agree to `floor` in relative L2 of their update.
-    loose = 1e-4 if amp is None else 3e-2
-    cos_min, ratio_tol, floor = (0.99999, 1e-3, 1e-3) if amp is None else (0.90, 0.2, 0.35)
+    loose = 1e-4 if amp is None else 1e-3
+    cos_min, ratio_tol, floor = (0.99999, 1e-3, 1e-3) if amp is None else (0.9999, 1e-3, 1e-2)
     for wi, what in enumerate(("weight", "ema", "momentum")):
         a, b, before = e[wi], g[wi], s0[0][wi]
         assert a.keys() == b.keys() and len(a) > 100
@@ -487,7 +487,7 @@ def test_graphed_train_step_matches_eager(amp):
         de, dg = torch.cat(de), torch.cat(dg)
         cos, ratio = float(de @ dg / (de.norm() * dg.norm())), float(dg.norm() / de.norm())
         assert cos >= cos_min and abs(ratio - 1) <= ratio_tol, (what, "update", cos, ratio)
-        frac = 0.95 if amp is None else 0.5
+        frac = 0.95
         assert len(rels) > 100 and sum(r[0] <= floor for r in rels) >= frac * len(rels), (what, "update", sorted(rels)[-10:])
     # ---- a short trajectory on changing batches: graph replays vs eager steps from the same state, loosely ----
     traj = []
@@ -621,11 +621,11 @@ def test_training_forward_is_reproducible_and_gradients_agree_to_summation_noise
         whole = float(torch.cat([(g0[n] - g1[n]).flatten() for n in g0]).double().norm()) / total
         # per tensor: relative to its own norm, with a floor of 1e-3 of the whole gradient for tensors that are (nearly) zero by construction
         name, worst = max(((n, d / max(float(g0[n].double().norm()), 1e-3 * total)) for n, d in diffs.items()), key=lambda t: t[1])
-        # fp32: what is left is the summation order of the float atomics of the weight / bias gradients (leaves: not amplified).  bf16: the
-        # activation gradients are ROUNDED to bf16 between layers, which turns last-bit differences of the fp32 sums feeding them into 2^-9
-        # steps that the BatchNorm backward's mean subtractions amplify layer by layer (tools/step_repro.py: 0 down to the neck, 1e-4 at
-        # layer 13, 1e-2 at the stem; the same magnitudes in every pair of runs) — bounded, documented in DESIGN.md as open
-        lim_whole, lim_tensor = (1e-5, 5e-4) if amp is None else (2e-2, 3e-1)
+        # what is left is the summation order of the float atomics of the weight / bias gradients (leaves: nothing amplifies them).  Every sum
+        # that feeds an ACTIVATION gradient is a double accumulator (BatchNorm backward sums, CoordAtt's gate / MLP backward, RFCBAM's d_ca):
+        # in bf16 a last-bit difference there became a 2^-9 step of a rounded activation gradient, which the BatchNorm backward's mean
+        # subtractions amplified layer by layer (tools/step_repro.py, before: 1e-4 at layer 13, 1e-2 at the stem, model.0.norm.bias 10 %)
+        lim_whole, lim_tensor = (1e-5, 5e-4)
         assert whole <= lim_whole and worst <= lim_tensor, f"gradients differ between two runs of the same step: whole vector {whole:.3e}, worst tensor {name} {worst:.3e}"
 
 
@@ -765,10 +765,11 @@ def _ddp_rank(rank, world, port, q, backend="nccl", one_gpu=False):
         red.wait()
         got = torch.cat([p.grad.detach().reshape(-1) for p in params]) * opt.grad_scale
         err = float((got - want).norm() / want.norm())
-        # `want` comes from ANOTHER backward run of the same batch: two runs differ by float-atomic order and the ReLU / max decisions it
-        # flips (1.3e-3 .. 4e-3 of the whole gradient vector seen on lead-yolo-n at 128 px).  What this must catch is structural: a sum
-        # instead of a mean (err = 1), a bucket that was not exchanged or went out before its last gradient (>= 0.1), a stale gradient
-        assert err < 2e-2, f"exchanged gradient is not the mean of the ranks' gradients: rel err {err}"
+        # `want` comes from ANOTHER backward run of the same batch: since round 4 two runs of a step differ only by the summation order of the
+        # weight-gradient atomics (~1e-7; the 2e-2 band this used to need failed once at 5e-2 with the float statistics accumulators).  What
+        # this must catch is structural: a sum instead of a mean (err = 1), a bucket that was not exchanged or went out before its last
+        # gradient (>= 0.1), a stale gradient
+        assert err < 1e-4, f"exchanged gradient is not the mean of the ranks' gradients: rel err {err}"
         assert float((local - want).norm() / want.norm()) > 1e-2          # the shards really differ
         red.reset()
         for _ in range(2):

@@ -382,9 +382,11 @@ def test_configs2_full_size_graphed_step():
         loss = step(imgs, tg)[0] if how == "graph" else L.train_step(m, cl, opt, imgs, tg, ema=ema, amp=BF)[0]
         outs.append((float(loss), snap()))
     (le, e), (le2, e2), (lg, g) = outs
-    assert np.isfinite(le) and np.isfinite(lg) and abs(le - lg) <= max(2.0 ** -7, 3 * abs(le - le2) / abs(le)) * abs(le), (le, le2, lg)     # (a)
-    # (b) finite everywhere; the step's UPDATE of all weights / EMA entries / momentum buffers, as one vector, points where the eager step's
-    # does (a second eager step from the same state is the noise floor: float atomics + bf16 rounding boundaries through 24 layers)
+    # (a) the forward of a step is reproducible bit for bit (double statistics accumulators, round 4): the loss of the replay and of two
+    # eager steps agree to the float sums of the loss kernel
+    assert np.isfinite(le) and np.isfinite(lg) and abs(le - lg) <= 1e-5 * abs(le) and abs(le - le2) <= 1e-5 * abs(le), (le, le2, lg)
+    # (b) finite everywhere; the step's UPDATE of all weights / EMA entries / momentum buffers, as one vector, equals the eager step's up to
+    # the summation order of the weight-gradient atomics (was: cosine >= 0.9, norm ratio 0.8 .. 1.25 — a 20 % wrong learning rate passed)
     moved = 0
     for wi in range(3):
         dg, de, de2 = [], [], []
@@ -397,7 +399,7 @@ def test_configs2_full_size_graphed_step():
         cos = float(dg @ de / (dg.norm() * de.norm()))
         cos_noise = float(de2 @ de / (de2.norm() * de.norm()))
         ratio = float(dg.norm() / de.norm())
-        assert cos >= min(0.9, 1 - 3 * (1 - cos_noise)) and 0.8 <= ratio <= 1.25, (wi, cos, cos_noise, ratio)
+        assert cos >= 0.99999 and cos_noise >= 0.99999 and abs(ratio - 1) <= 1e-3, (wi, cos, cos_noise, ratio)
     assert moved > 500
     # (c) eval rows of single images vs the oracle on the same (restored) weights
     restore(s0)
@@ -446,7 +448,7 @@ def test_configs4_shape_lead_yolo_l_1280(bs):
         torch.cuda.synchronize()
         outs.append((float(loss), {k: v.detach().clone() for k, v in m.state_dict().items() if k in w0}))
     (le, we), (le2, we2), (lg, wg) = outs
-    assert np.isfinite(le) and np.isfinite(lg) and abs(le - lg) <= max(2.0 ** -6, 3 * abs(le - le2) / abs(le)) * abs(le), (le, le2, lg)
+    assert np.isfinite(le) and np.isfinite(lg) and abs(le - lg) <= 1e-5 * abs(le) and abs(le - le2) <= 1e-5 * abs(le), (le, le2, lg)
     dg, de, de2 = [], [], []
     for k in we:
         assert torch.isfinite(wg[k]).all(), k
@@ -454,4 +456,5 @@ def test_configs4_shape_lead_yolo_l_1280(bs):
     dg, de, de2 = torch.cat(dg).double(), torch.cat(de).double(), torch.cat(de2).double()
     cos = float(dg @ de / (dg.norm() * de.norm()))
     cos_noise = float(de2 @ de / (de2.norm() * de.norm()))
-    assert cos >= min(0.9, 1 - 3 * (1 - cos_noise)) and 0.8 <= float(dg.norm() / de.norm()) <= 1.25, (cos, cos_noise)
+    # (round 4: reproducible forward + double accumulators wherever a sum feeds an activation gradient: the replay's update equals the eager one)
+    assert cos >= 0.99999 and cos_noise >= 0.99999 and abs(float(dg.norm() / de.norm()) - 1) <= 1e-3, (cos, cos_noise)

@@ -637,7 +637,7 @@ class RFCBAMConv(nn.Module):
             ops.gemm(out=out, e_scale=es, e_shift=eb, act=ACT_RELU, **kw)
             return out
         ho, wo = (h + 2 - 3) // s + 1, (w + 2 - 3) // s + 1
-        if RF3M and not self.training and ops.rf3m_ok(xr, c, self.o, s):
+        if RF3M and not self.training and ops.rf3m_ok(xr, c, self.o, s, n, ho, wo):
             return self._forward3_m(xr, ld, n, c, h, w, ho, wo, s, P, wa, wb)
         # (fp32 storage with more than 128 output channels: the lane = pixel kernels measure faster — layer 20 at bs=64: 215 vs 289 us —
         # the two-plane operand tile of the lane = channel kernel leaves one block per CU there)

@@ -319,9 +319,20 @@ def rf3c_ok(c, s):
     return c % 32 == 0 and s in (1, 2)
 
 
-def rf3m_ok(x, c, o, s):
-    """`generate` on the matrix cores (csrc/ly_rf3m.hip): bf16 storage, C % 32 == 0, O % 64 == 0, stride 1 / 2"""
-    return x.dtype == torch.bfloat16 and c % 32 == 0 and o % 64 == 0 and s in (1, 2)
+RF3M_MIN_UNITS = 1500      # wave tiles x output-channel blocks below which the lane = channel kernels are faster (measured, MI355X, module time in us,
+                           # rf3c / rf3m: layer 17 bs 16: 79 / 89, bs 32: 135 / 101, bs 64: 227 / 185; layer 20 bs 32: 110 / 144, bs 64: 165 / 155 — a block of
+                           # ly_rf3m walks ALL input channels of its 256 pixels serially, ~45 us however small the launch)
+
+
+def rf3m_ok(x, c, o, s, n=None, ho=None, wo=None):
+    """`generate` on the matrix cores (csrc/ly_rf3m.hip): bf16 storage, C % 32 == 0, O % 64 == 0, stride 1 / 2 — and, when the problem size
+    is given, enough wave tiles to fill the chip (RF3M_MIN_UNITS)"""
+    if not (x.dtype == torch.bfloat16 and c % 32 == 0 and o % 64 == 0 and s in (1, 2)):
+        return False
+    if n is None:
+        return True
+    th, tw = pick_tile_m(ho, wo, s)
+    return n * -(-ho // th) * -(-wo // tw) * (o // (128 if o % 128 == 0 else 64)) >= RF3M_MIN_UNITS
 
 
 def pick_tile_m(ho, wo, s):

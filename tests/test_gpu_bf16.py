@@ -149,6 +149,44 @@ def test_rfcbam_backward_bf16_smooth_case(ctor, shape):
         assert cos >= 0.995 and l2 <= 2 * REL_L2, (ctor, what, cos, l2)
 
 
+@pytest.mark.parametrize("ctor,shape", [((64, 64, 3, 2), (2, 64, 16, 16)), ((128, 128, 3, 2), (2, 128, 24, 20)), ((256, 256, 3, 2), (1, 256, 14, 18)),
+                                        ((32, 64, 3, 1), (2, 32, 9, 14)), ((128, 128, 3, 2), (3, 128, 80, 80)), ((256, 256, 3, 2), (2, 256, 40, 40)),
+                                        ((512, 512, 3, 2), (1, 512, 12, 12))])
+def test_rf3m_generate_on_matrix_cores_vs_oracle(ctor, shape, monkeypatch):
+    """RFCBAMConv k = 3, bf16 inference on csrc/ly_rf3m.hip (the depthwise `generate` as block-diagonal MFMA products whose accumulators feed the
+    main contraction in registers; models/rfa.py:113-129): the module output against the fp32 oracle at the bf16 module bound, and the kernel's
+    intermediates — the [max_c, mean_c] map and the SE pooling sums — against the lane = channel kernels (fp32 generate weights: the MFMA
+    form rounds them to bf16, 2^-9 relative).  The size threshold of the dispatch is lifted so that the small shapes take these kernels too;
+    ragged tiles, tiles at image borders, stride 1, C up to 512 and both output-channel block sizes are covered."""
+    from lead_yolo_amd import modules as M, ops
+    c, o, k, s = ctor
+    monkeypatch.setattr(ops, "RF3M_MIN_UNITS", 0)
+    torch.manual_seed(0)
+    m = _ctor("RFCBAMConv")(*ctor)
+    st = synth.synth_state(synth.shapes_of(m.state_dict()), 1234 + c + shape[2])
+    _bn_eps(_load(m, st))
+    x = synth.synth_input(shape, 99 + c).to(BF).float()
+    with torch.no_grad():
+        want = OF.rfcbam(copy.deepcopy(st), "", x, k, s, False)
+    m = m.to(_dev()).eval().bfloat16()
+    xd = x.to(_dev()).to(BF).contiguous(memory_format=torch.channels_last)
+    calls = []
+    real = ops.rf3m_fwd
+    monkeypatch.setattr(ops, "rf3m_fwd", lambda **kw: (calls.append(1), real(**kw))[1])
+    with torch.no_grad():
+        y = m(xd)
+    assert calls, "the module did not take the ly_rf3m path"
+    _close(y, want, f"rf3m {ctor} {shape}")
+    xr, ld = ops.rows(xd)
+    n, _, h, w = xr.shape
+    ho, wo = (h + 2 - 3) // s + 1, (w + 2 - 3) // s + 1
+    P = m._packed(ops.planes_of(xr))
+    mm_c, part_c = ops.rf3c_stats(xr, ld, n, h, w, c, s, P["wq_c"], *ops.pick_tile_c(ho, wo, s))
+    mm_m, part_m = ops.rf3m_stats(xr, ld, n, h, w, c, s, P["wm_stats"], *ops.pick_tile_m(ho, wo, s))
+    _close(mm_m, mm_c, f"rf3m {ctor} [max, mean] map", rel=4 * 2.0 ** -9, mx=8 * 2.0 ** -8)
+    _close(part_m.sum(1), part_c.sum(1), f"rf3m {ctor} pooling sums", rel=1e-5, mx=1e-5)
+
+
 def test_rf3c_backward_bit_stable_beside_mfma_stream():
     """the recompute backward of RFCBAMConv k = 3 (csrc/ly_rf3c_bwd.hip: hand-written v_pk_fma_f32 with op_sel weight broadcasts,
     no atomics) must return the SAME BITS when other waves issue MFMAs on its CUs.  The same backward runs alone, then repeatedly while a

@@ -124,6 +124,11 @@ def prof():
 
 
 if __name__ == "__main__":
+    if "--batches" in sys.argv:
+        for bs in (4, 8, 16, 32):
+            timeit(128, 128, 2, (bs, 128, 80, 80))
+            timeit(256, 256, 2, (bs, 256, 40, 40))
+        sys.exit(0)
     if "--prof" in sys.argv:
         prof()
         sys.exit(0)

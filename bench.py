@@ -36,7 +36,7 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s 
 VALU_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak FP32 (vector), packed FMA
 # kernels that issue matrix instructions: the `flops` their wrappers report (ops._Timed) are MFMA work, `valu_flops` vector work
 MFMA_KERNELS = ("ly_gemm_kernel", "ly_conv3x3", "ly_mlp", "ly_wgrad", "ly_rf3c", "ly_rf3m", "ly_rfcbam3")
-BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16; fp32-grade products take 3 bf16 MFMAs (csrc/ly_tile.cuh)
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16; fp32-grade products take 3 bf16 MFMAs (csrc/ly_tile.hpp)
 ARITH = {"f32": "fp32 storage and accumulation, bf16x3 split products on the bf16 matrix cores (~2^-16 per product)",
          "bf16": "bf16 activations / saved tensors / activation gradients, single-plane bf16 MFMA products, fp32 accumulate, "
                  "fp32 BatchNorm statistics, fp32 master weights and weight gradients"}
@@ -475,6 +475,24 @@ def timed_repeats(ctx, step, steps, warmup, repeats):
     return out
 
 
+def sustained_run(ctx, step, sec_per_step, seconds=3.0):
+    """The same step for ~3 s without a pause (every rank the same count): a second, longer measurement beside the contract's K timed steps —
+    and a window in which an outside observer (rocm-smi sampled by the driver) sees the GPU busy: the K-step regions are 0.2 s bursts between
+    host-side phases (CPU baseline, graph capture)."""
+    n = int(min(max(seconds / max(sec_per_step, 1e-6), 50), 2000))
+    ctx.barrier()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step()
+    ctx.barrier()
+    dt = time.perf_counter() - t0
+    if ctx.dist is not None:
+        t = torch.tensor([dt], device=ctx.device, dtype=torch.float64)
+        ctx.dist.all_reduce(t, op=ctx.dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dict(steps=n, seconds=round(dt, 3), ms_per_step=round(dt / n * 1e3, 4))
+
+
 def run_train(args, ctx):
     import lead_yolo_amd as L
     model = build_model(args.scale, ctx.device, train=True)
@@ -512,7 +530,8 @@ def run_train(args, ctx):
             step = eager_step
 
     regions = timed_repeats(ctx, step, args.steps, args.warmup, args.repeats)
-    res = dict(regions=regions, final_loss=float(state["loss"]), peak_mem_gib=round(torch.cuda.max_memory_allocated() / 2**30, 2), model=model, step=eager_step, launch=launch,
+    sustained = sustained_run(ctx, step, statistics.median(regions) / args.steps) if not args.no_sustained else None
+    res = dict(regions=regions, sustained=sustained, final_loss=float(state["loss"]), peak_mem_gib=round(torch.cuda.max_memory_allocated() / 2**30, 2), model=model, step=eager_step, launch=launch,
                workload=f"lead-yolo-{args.scale} bs={args.batch}/gpu 3x{args.size}x{args.size} {args.dtype} full train step: uint8 batch -> "
                         "train-mode forward (batch-statistics BN), ComputeLoss, HIP backward, clip 10, SGD-nesterov 3 groups, ModelEMA update "
                         "(BASELINE.json configs[2]" + ("" if args.dtype == "bf16" else " shape in fp32") + "); random-init weights",
@@ -596,6 +615,7 @@ def main():
                     help="train (default): the BASELINE metric, full optimisation step; forward: eval forward of configs[1]")
     ap.add_argument("--train", action="store_true", help="alias of --mode train")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the ~3 s back-to-back replay after the timed repeats")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary eval-forward figure and the pconv_rfcbam probe")
     ap.add_argument("--layers", action="store_true", help="print the per-kernel table to stderr")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel probe (for whole-step rocprof runs)")
@@ -672,6 +692,9 @@ def main():
             "timed_repeats": len(regions), "repeat_ms_per_step": [round(r / args.steps * 1e3, 4) for r in regions],
             "value_is": "median of the timed repeats (each: exactly `steps` steps between barrier+synchronize, max over ranks)",
         }
+        if res.get("sustained"):
+            out["sustained"] = dict(res["sustained"], value=round(ctx.world * args.batch / res["sustained"]["ms_per_step"] * 1e3, 2), unit="images/sec",
+                                    note="the same step replayed back to back for ~3 s after the timed repeats (not `value`: the contract's K steps are)")
         for k in ("final_loss", "peak_mem_gib", "rccl_ranks", "grad_buckets", "grad_bytes", "dp_overlap", "launch"):
             if k in res:
                 out[k if k != "launch" else "launch_mode"] = res[k]

@@ -176,7 +176,7 @@ typedef struct LyRfcbam3Params {
  * LY_PRO_AFFINE_RELU_CA and rowscale = rfa.                                                         */
 int ly_rfcbam3_fwd(const LyRfcbam3Params* p, void* stream);
 
-/* ---- RFCBAMConv kernel_size 3 on the lane = channel core (csrc/ly_rf3c.cuh; models/rfa.py:113-129) ----------------------------
+/* ---- RFCBAMConv kernel_size 3 on the lane = channel core (csrc/ly_rf3c.hpp; models/rfa.py:113-129) ----------------------------
  * C % 32 == 0, stride 1 or 2, tiles TH x TW with TW even, TH*TW <= 64 and (s(TH-1)+3)(s(TW-1)+3) <= 320 input positions.
  * wq = generate weights in lane order: per channel 100 floats — w[t][u] at i = t*9+u, b[t] at i = 81+t, a[t] at i = 90+t, 1 of padding —
  *      stored as float [C/32][25][32][4]: element i of channel c at ((c/32*25 + i/4)*32 + c%32)*4 + i%4.  raw == 0 (inference, folded):
@@ -360,10 +360,12 @@ int ly_sum_rows(const float* src, long R, long C, long ld, float* dst, int accum
 int ly_patch4_rows_u8(const unsigned char* img, int n_img, int C, int H, int W, void* rows /*T [n*H/4*W/4][16*C]*/, int dtype, void* stream);
 
 /* CoordAtt backward (models/common.py:1595-1609).  Gate out = x*a_h[n,h,:]*a_w[n,w,:]:
- *   dx = dout*a_h*a_w,  da_h[n,h,c] += sum_w dout*x*a_w,  da_w[n,w,c] += sum_h dout*x*a_h  (caller zeroes both).
+ *   dx = dout*a_h*a_w,  da_h[n,h,c] = sum_w dout*x*a_w,  da_w[n,w,c] = sum_h dout*x*a_h — written as PARTIAL sums, one plain store per
+ *   element and block: da_h [slabs][n][H][C] (slabs = ceil(W / (8 * (256 / (C/4))))), da_w [bands][n][W][C] (bands = ceil(H / 8)); the caller
+ *   passes the two counts (checked) and folds the partials in index order (ly_sum_rows): no atomics, the same bits in every run.
  * Pools pool[n,0:H]=mean_w x, pool[n,H:H+W]=mean_h x:  dx[n,h,w,c] (+)= gp[n,h,c]/W + gp[n,H+w,c]/H  (accumulate != 0: added to dx). */
 int ly_coordatt_gate_bwd(const void* dout /*T*/, int ldd, const void* x /*T*/, int ldx, int n_img, int H, int W, int C, const float* a_h,
-                         const float* a_w, void* dx /*T*/, int lddx, double* da_h /* zeroed doubles */, double* da_w /* zeroed doubles */, int dtype, void* stream);
+                         const float* a_w, void* dx /*T*/, int lddx, float* da_h, float* da_w, int bands, int slabs, int dtype, void* stream);
 int ly_pool_hw_bwd(const float* gp, int n_img, int H, int W, int C, void* dx /*T*/, int lddx, int accumulate, int dtype, void* stream);
 /* SPPF backward as a gather (no atomics, deterministic): ly_maxpool_arg stores, for every window of a k x k / s1 / pad k//2 max-pool over
  * x [n, H, W, C] (row stride ldx), the tap index (0 .. k*k-1, row-major) of its first maximum — ATen's routing rule — as one byte per element
@@ -434,7 +436,7 @@ int ly_bn_finalize(const void* stats /* [stripes][2 nch] floats, or doubles if s
 int ly_bn_bwd_coeffs(const void* sums /* floats, or doubles if sums_f64 */, int sums_f64, int stripes, int N, double count, const float* a,
                      const float* mean, const float* invstd, int train, float* dgamma, float* dbeta, float* alpha, float* kappa, float* lambda, void* stream);
 /* Fragment packing of the fp32 matrix W[r][k] = w[r*ld_r + k*ld_k] (R x K, rows zero padded to max(R, rows_to)) into the
- * [T][S][planes][64 lanes][8] bf16 layout the contraction kernels read (csrc/ly_tile.cuh): planes = 2 (hi = bf16(W),
+ * [T][S][planes][64 lanes][8] bf16 layout the contraction kernels read (csrc/ly_tile.hpp): planes = 2 (hi = bf16(W),
  * lo = bf16(W - hi): the bf16x3 operand of LY_F32 calls) or 1 (hi only: LY_BF16 calls).                                */
 int ly_frag_pack3(const float* w, int R, int K, long ld_r, long ld_k, int rows_to, int planes, void* out, void* stream);
 

@@ -10,7 +10,7 @@
 //   ly_rfa_map        sigmoid(conv3x3([max, mean]))          (models/rfa.py:107,127)
 #include <float.h>
 
-#include "ly_tile.cuh"
+#include "ly_tile.hpp"
 #include "ly_params.h"
 
 
@@ -1184,7 +1184,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_coordatt_mlp_bwd1_kernel(
     }
   }
   if (lane < MIP) {
-    double* st = sums + ((blockIdx.x * 4 + wave) & (LY_CA_STRIPES - 1)) * 2 * MIP;      // double accumulators: see ly_stats_flush (ly_common.cuh)
+    double* st = sums + ((blockIdx.x * 4 + wave) & (LY_CA_STRIPES - 1)) * 2 * MIP;      // double accumulators: see ly_stats_flush (ly_common.hpp)
     atomicAdd(st + lane, (double)s1);
     atomicAdd(st + MIP + lane, (double)s2);
   }
@@ -1401,7 +1401,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_gen_prepare_kernel(
         const float v = e < 9 ? w[e] * sc : sh;
         wq_stats[ly_gw_index(c, t, e, 32, false)] = v;
         wq_main[ly_gw_index(c, t, e, 16, true)] = v;
-        if (wq_c) {                                                            // lane = channel order, RAW form (ly_rf3c.cuh rc_load_w)
+        if (wq_c) {                                                            // lane = channel order, RAW form (ly_rf3c.hpp rc_load_w)
           const int i = e < 9 ? t * 9 + e : 81 + t;
           wq_c[(((long)(c >> 5) * 25 + (i >> 2)) * 32 + (c & 31)) * 4 + (i & 3)] = e < 9 ? w[e] : sh;
           if (e == 9) wq_c[(((long)(c >> 5) * 25 + ((90 + t) >> 2)) * 32 + (c & 31)) * 4 + ((90 + t) & 3)] = sc;

@@ -12,7 +12,7 @@
 // Replaces what autograd derives for Conv2d -> BatchNorm2d -> SiLU/ReLU in the reference's
 // `scaler.scale(loss).backward()` (train.py:324) over models/common.py:1890-1910 (Conv),
 // :1478-1482 (MLPBlock), :1537-1561 (patch layers).
-#include "ly_tile.cuh"
+#include "ly_tile.hpp"
 #include "ly_params.h"
 
 // -------------------------------------------------------------------------------------------------
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_bnact_bwd_reduce_kernel(const T
   red2[tid] = s2;
   __syncthreads();
   if (j0 == 0) {
-    double* sm = sums + (size_t)(blockIdx.x & (LY_STATS_STRIPES - 1)) * 2 * C;      // double accumulators: see ly_stats_flush (ly_common.cuh)
+    double* sm = sums + (size_t)(blockIdx.x & (LY_STATS_STRIPES - 1)) * 2 * C;      // double accumulators: see ly_stats_flush (ly_common.hpp)
     for (int g = 1; g < groups; ++g) { s1 += red1[g * ncv + cv]; s2 += red2[g * ncv + cv]; }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -1073,7 +1073,7 @@ template <typename T>
 __global__ __launch_bounds__(LY_THREADS) void ly_coordatt_gate_bwd_kernel(const T* __restrict__ dout, int ldd, const T* __restrict__ x,
                                                                            int ldx, int H, int W, int C, const float* __restrict__ a_h,
                                                                            const float* __restrict__ a_w, T* __restrict__ dx, int lddx,
-                                                                           double* __restrict__ da_h, double* __restrict__ da_w, int bands, int slabs) {
+                                                                           float* __restrict__ da_h, float* __restrict__ da_w, int bands, int slabs, long n_img) {
   __shared__ f32x4 red[LY_THREADS];
   const int nc4 = C >> 2, tid = threadIdx.x;
   const int groups = LY_THREADS / nc4;
@@ -1129,10 +1129,9 @@ __global__ __launch_bounds__(LY_THREADS) void ly_coordatt_gate_bwd_kernel(const 
     __syncthreads();
     if (g0 == 0) {
       for (int g = 1; g < groups; ++g) sh += red[g * nc4 + c4];
-      double* o = da_h + nh * C + 4 * c4;                     // (one add per row, slab and channel: da_h is zeroed by the caller; DOUBLE
-                                                              // accumulators — a float sum in arrival order seeded run-to-run differences of dx)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) atomicAdd(o + r, (double)sh[r]);
+      // one PARTIAL per row, slab and channel, stored (not added): da_h_part[slab][n][h][c].  (Float atomics into one [n][h][c] array
+      // summed in arrival order and seeded run-to-run differences of dx; the caller folds the slabs in index order: ly_sum_rows)
+      ly_stg4(da_h + ((long)slab * n_img * H + nh) * C + 4 * c4, sh);
     }
   }
   if (g0 < groups) {
@@ -1140,25 +1139,25 @@ __global__ __launch_bounds__(LY_THREADS) void ly_coordatt_gate_bwd_kernel(const 
     for (int i = 0; i < LY_CAG_MAXW; ++i) {
       const int w = w0 + g0 + i * groups;
       if (w < W) {
-        double* o = da_w + (n * W + w) * C + 4 * c4;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) atomicAdd(o + r, (double)accw[i][r]);
+        ly_stg4(da_w + ((long)band * n_img * W + n * W + w) * C + 4 * c4, accw[i]);      // da_w_part[band][n][w][c]
       }
     }
   }
 }
 
 extern "C" int ly_coordatt_gate_bwd(const void* dout, int ldd, const void* x, int ldx, int n_img, int H, int W, int C, const float* a_h,
-                                    const float* a_w, void* dx, int lddx, double* da_h, double* da_w, int dtype, void* stream) {
+                                    const float* a_w, void* dx, int lddx, float* da_h, float* da_w, int bands_in, int slabs_in, int dtype, void* stream) {
   LY_CHECK_DTYPE(dtype, "coordatt_gate_bwd");
   LY_CHECK(dout && x && a_h && a_w && dx && da_h && da_w, "coordatt_gate_bwd: null pointer");
   LY_CHECK((C & 3) == 0 && C <= 1024 && (ldd & 3) == 0 && (ldx & 3) == 0 && (lddx & 3) == 0, "coordatt_gate_bwd: C / ld must be multiples of 4");
   const int groups = LY_THREADS / (C >> 2);
   const int slabs = (W + groups * LY_CAG_MAXW - 1) / (groups * LY_CAG_MAXW);
   const int bands = (H + LY_CAG_RB - 1) / LY_CAG_RB;
+  LY_CHECK(bands_in == bands && slabs_in == slabs, "coordatt_gate_bwd: the partial buffers are da_h [%d slabs][n][H][C] and da_w [%d bands][n][W][C] (got %d, %d)",
+           slabs, bands, slabs_in, bands_in);
   LY_WITH_T(dtype, hipLaunchKernelGGL(ly_coordatt_gate_bwd_kernel<T>, dim3((unsigned)(n_img * bands * slabs)), dim3(LY_THREADS), 0, reinterpret_cast<hipStream_t>(stream),
                                       reinterpret_cast<const T*>(dout), ldd, reinterpret_cast<const T*>(x), ldx, H, W, C, a_h, a_w, reinterpret_cast<T*>(dx), lddx, da_h, da_w,
-                                      bands, slabs));
+                                      bands, slabs, (long)n_img));
   LY_LAUNCH_CHECK();
   return 0;
 }

@@ -1,5 +1,5 @@
 // 3x3 / stride 1 / pad 1 convolution as an implicit GEMM + folded BN + activation, gfx950; storage dtype T = float (bf16x3
-// products) or __bf16 (plain bf16 products), fp32 accumulation (ly_tile.cuh).
+// products) or __bf16 (plain bf16 products), fp32 accumulation (ly_tile.hpp).
 //
 //   out[m, n] = act( scale[n] * sum_{tap, c} X[pix(m) + tap][c] * W[n][c][tap] + shift[n] )
 //
@@ -14,7 +14,7 @@
 // Pipeline: the raw fp32 frame of chunk c+1 is loaded into registers before the 9-tap contraction of
 // chunk c is issued and committed to LDS after it; weight fragments are fetched one tap ahead.
 // The 4 waves split the output channels (WC = 4): each weight fragment is read by exactly one wave.
-#include "ly_tile.cuh"
+#include "ly_tile.hpp"
 #include "ly_params.h"
 
 #define LY_C3_NT 8                // max pixel tiles (128 pixels) per block

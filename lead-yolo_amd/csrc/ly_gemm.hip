@@ -1,6 +1,6 @@
-// ly_gemm_fwd: C ABI + the fp32-storage instantiations of the pointwise-convolution GEMM (kernel: ly_gemm.cuh; the
+// ly_gemm_fwd: C ABI + the fp32-storage instantiations of the pointwise-convolution GEMM (kernel: ly_gemm.hpp; the
 // bf16-storage instantiations are in ly_gemm_bf16.hip — two translation units only to build them in parallel).
-#include "ly_gemm.cuh"
+#include "ly_gemm.hpp"
 
 int ly_gemm_dispatch_f32(const LyGemmParams& P, hipStream_t st) { return ly_gemm_dispatch<float>(P, st); }
 

@@ -1,6 +1,6 @@
 #pragma once
 // Pointwise-convolution GEMM with fused gather/prologue and epilogue, gfx950; storage dtype T = float (bf16x3 products) or
-// __bf16 (plain bf16 products), fp32 accumulation in both (ly_tile.cuh).
+// __bf16 (plain bf16 products), fp32 accumulation in both (ly_tile.hpp).
 //
 //   out[m, n] = act( rowscale[m] * scale[n] * sum_k A'[m, k] * W[n, k] + shift[n] )
 //
@@ -28,7 +28,7 @@
 // LDS.  The item body is straight-line code (surplus prefetches re-read the last item, ragged K contracts LDS zeros):
 // the compiler's s_waitcnt bookkeeping is exact only then.  Weight fragments of the chunk's later k-steps are requested
 // BEFORE the activation prefetch (vmcnt retires in order), the first step of the next item during the last step.
-#include "ly_tile.cuh"
+#include "ly_tile.hpp"
 #include "ly_params.h"
 #ifndef LY_GEMM_DEPTH
 #define LY_GEMM_DEPTH 3

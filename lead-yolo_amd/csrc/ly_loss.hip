@@ -16,7 +16,7 @@
 //   ly_loss_obj     per cell: BCE-with-logits against tobj, its gradient into dpred[..., 4], level sum by block reduction.
 // ly_loss_finish combines the level accumulators into (loss, lbox, lobj, lcls) exactly as the reference does (mean per level,
 // balance [4, 1, 0.4], * hyp gains, * batch size).
-#include "ly_common.cuh"
+#include "ly_common.hpp"
 
 struct D4 {                        // value + derivatives w.r.t. (px, py, pw, ph)
   float v, d[4];

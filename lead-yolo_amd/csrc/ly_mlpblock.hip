@@ -1,5 +1,5 @@
-// MLPBlock C ABI + the C = 16 / 24 / 40 instantiations; the kernel itself is in ly_mlpblock.cuh.
-#include "ly_mlpblock.cuh"
+// MLPBlock C ABI + the C = 16 / 24 / 40 instantiations; the kernel itself is in ly_mlpblock.hpp.
+#include "ly_mlpblock.hpp"
 
 extern "C" int ly_mlpblock_fwd(const void* x, void* y, int n_img, int H, int W, int C, const void* wp, const void* w1,
                                const void* w2, const float* bn_scale, const float* bn_shift, double* stats, int dtype, void* stream) {

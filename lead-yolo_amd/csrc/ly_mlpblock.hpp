@@ -1,6 +1,6 @@
 #pragma once
 // Fused FasterNet MLPBlock forward (eval / folded-BN form), gfx950; storage dtype T = float (bf16x3 products, two operand
-// planes) or __bf16 (plain bf16 products, one plane), fp32 accumulation (ly_tile.cuh).
+// planes) or __bf16 (plain bf16 products, one plane), fp32 accumulation (ly_tile.hpp).
 //
 //   y = x + W2 . relu( s * (W1 . [ pconv3x3(x[:, :C/4]) | x[:, C/4:] ]) + b )
 //
@@ -11,15 +11,15 @@
 //
 // Block = 256 threads (4 waves) owns BP = 64*NT consecutive pixels of the flattened N*H*W index
 // (NHWC rows, so its input tile is one contiguous span of memory).  The tile is split once into
-// bf16 hi/lo planes in LDS (ly_tile.cuh).  Each wave owns 16*NT pixels and carries them through all
+// bf16 hi/lo planes in LDS (ly_tile.hpp).  Each wave owns 16*NT pixels and carries them through all
 // three contractions:
 //   1. partial 3x3 conv as an implicit GEMM over K = 9 * ceil4(C/4): operands are 8-byte gathers from
 //      a halo image (ps) of the first C/4 channels with per-tap border masks; the result overwrites
 //      channels [0, C/4) of the wave's own rows of the tile (the "concat" is a no-op).
 //   2. hidden = relu(bn(W1 . row)), HT hidden tiles at a time, kept in registers.
 //   3. out += W2[:, hidden pair] . hidden -- two fp32 D tiles of step 2, split in registers, ARE the
-//      B operand of one k-step (ly_tile.cuh), so the hidden activations never leave the register file.
-#include "ly_tile.cuh"
+//      B operand of one k-step (ly_tile.hpp), so the hidden activations never leave the register file.
+#include "ly_tile.hpp"
 
 template <int C>
 struct MlpGeom {

@@ -8,7 +8,7 @@
 //                       IoU with it exceeds iou_thres is dropped (boxes offset by cls * max_wh unless agnostic) — torchvision.ops.nms'
 //                       contract — until max_det boxes are kept or none is left                                              (:973-976)
 // The alive set is an LDS bitset (max_nms = 30000 candidates = 938 words); per kept box the block's 256 threads share the later candidates.
-#include "ly_common.cuh"
+#include "ly_common.hpp"
 #include "ly_params.h"
 
 static long ly_nms_blocks(long items) {

@@ -12,7 +12,7 @@
 //                   statistics) only take the EMA update.
 // Nothing here depends on host values that change per step: learning rates, the EMA decay and the step counter live in the
 // device array `hyper` (the host schedule writes it), so the two launches can sit inside a captured hipGraph of the whole step.
-#include "ly_common.cuh"
+#include "ly_common.hpp"
 #include "ly_params.h"
 
 #define LY_OPT_CHUNK 4096                 // elements per block

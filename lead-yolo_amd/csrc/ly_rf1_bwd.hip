@@ -10,7 +10,7 @@
 //   pass B: dv = (dcd*ca*rfa + d_mean/C + [G == gmax] d_max) [G > 0]  ->  BatchNorm sums  s1[c] += dv, s2[c] += dv*u      (nothing stored)
 //   pass C: dv again, du = alpha*dv + kappa + lambda*u,  dgw[c] += sum_p du*x,  dx = du*gw + dgap[n][c]*scale
 // A block walks pixels of ONE image; per-channel sums live in registers over the walk, meet in LDS and leave with one atomic per channel.
-#include "ly_tile.cuh"
+#include "ly_tile.hpp"
 #include "ly_params.h"
 
 #define RF1_A 0
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf1_bwd_kernel(const LyRf1BwdPa
       const int qn = e / C, c = e - qn * C;
       float s = 0.f;
       for (int sl = 0; sl < PB; ++sl) s += red[(sl * NQT + qn) * CS + c];
-      if constexpr (MODE == RF1_A) atomicAdd(P.d_ca + n * C + c, (double)s);                                  // double accumulators (ly_common.cuh ly_stats_flush)
+      if constexpr (MODE == RF1_A) atomicAdd(P.d_ca + n * C + c, (double)s);                                  // double accumulators (ly_common.hpp ly_stats_flush)
       else if constexpr (MODE == RF1_B) atomicAdd(P.sums + (size_t)((blockIdx.x + blockIdx.y) & (LY_STATS_STRIPES - 1)) * 2 * C + qn * C + c, (double)s);
       else atomicAdd(P.dgw + c, s);
     }

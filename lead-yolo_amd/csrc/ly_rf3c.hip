@@ -1,10 +1,10 @@
-// RFCBAMConv kernel_size 3 forward on the lane = channel core (ly_rf3c.cuh); reference models/rfa.py:113-129.
+// RFCBAMConv kernel_size 3 forward on the lane = channel core (ly_rf3c.hpp); reference models/rfa.py:113-129.
 //
 //   ly_rf3c_stats : [max_c, mean_c] of G = relu(bn(generate(x)))  ->  mm[n, 3Ho, 3Wo, 2]   (models/rfa.py:125-126)
 //                   + the SE global-average-pool partials part[n][tile][C]             (models/rfa.py:90)   -- x is read ONCE for both
 //   ly_rf3c_fwd   : out = relu(bn(conv_{3x3, stride 3}(G * ca * rfa)))                     (models/rfa.py:124, 128-129)
 // Both regenerate G per (64-pixel tile, 32-channel chunk) on the VALU with lane = channel; nothing 9x-sized exists in HBM.
-#include "ly_rf3c.cuh"
+#include "ly_rf3c.hpp"
 #include "ly_params.h"
 
 // ---------------------------------------------------------------------------------------------------
@@ -461,7 +461,7 @@ static int rc_dispatch_fwd(const LyRfcbam3Params& P, const float* wq, bool raw, 
 }
 
 // P as for ly_rfcbam3_fwd with two differences: P.wg is ignored (wq = the lane-order generate weights, raw != 0: the training form, see
-// ly_rf3c.cuh) and P.wp = conv.0.weight frag-packed as [N][C/32 chunks][9 taps][32 channels] (K = 9*C, no padding).
+// ly_rf3c.hpp) and P.wp = conv.0.weight frag-packed as [N][C/32 chunks][9 taps][32 channels] (K = 9*C, no padding).
 extern "C" int ly_rf3c_fwd(const LyRfcbam3Params* p, const float* wq, int raw, void* stream) {
   LY_CHECK(p && wq, "rf3c_fwd: null params");
   const LyRfcbam3Params& P = *p;

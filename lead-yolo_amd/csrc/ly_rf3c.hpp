@@ -14,7 +14,7 @@
 //
 // unit of work: (tile of <= 64 output pixels, TH x TW with TW even) x (chunk of 32 channels).
 #pragma once
-#include "ly_tile.cuh"
+#include "ly_tile.hpp"
 
 #define RC_CB 32                 // channels per chunk
 #define RC_TP 64                 // output-pixel slots per tile

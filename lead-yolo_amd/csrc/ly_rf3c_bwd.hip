@@ -1,4 +1,4 @@
-// RFCBAMConv kernel_size 3 backward on the lane = channel core (ly_rf3c.cuh): reference models/rfa.py:113-129 under autograd.
+// RFCBAMConv kernel_size 3 backward on the lane = channel core (ly_rf3c.hpp): reference models/rfa.py:113-129 under autograd.
 //
 // The first-generation backward (ly_rfcbam_bwd.hip) materialises the 9x expanded tensors ug, dcd, cd, dv in HBM and streams them
 // thirteen times (236 MB each at layer 17, bs = 64).  Here NOTHING 9x-sized exists in HBM: every pass re-derives what it needs on chip
@@ -16,8 +16,8 @@
 //           is completed by one block and written once, final (+ the SE term d/d(mean x)).
 //   ly_rf3c_wgrad: d(conv.0.weight)[o, c, t] = sum_p du[p, o] * (G*ca*rfa)[p, t, c]  (G' regenerated as in the forward, contraction over pixels)
 // bf16 storage, stride 2, C % 32 == 0, O in {64, 128, 256}; everything else stays on the first-generation kernels.
-#define RC_ASM_FMA          // see ly_rf3c.cuh: safe here (one wave per SIMD, the block owns its CU)
-#include "ly_rf3c.cuh"
+#define RC_ASM_FMA          // see ly_rf3c.hpp: safe here (one wave per SIMD, the block owns its CU)
+#include "ly_rf3c.hpp"
 #include "ly_params.h"
 #include <stdlib.h>
 
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf3c_bwd_kernel(const LyRf3cBwd
   typedef __bf16 T;
   constexpr int S = 2;
   constexpr int O = 32 * KS;
-  constexpr int RSD = 2 * O + 16;                       // bytes per du-tile row: RSD/16 odd => the b64 fragment reads are conflict-free (ly_tile.cuh)
+  constexpr int RSD = 2 * O + 16;                       // bytes per du-tile row: RSD/16 odd => the b64 fragment reads are conflict-free (ly_tile.hpp)
   constexpr int NDU = KS;                               // 16-byte du items per thread: 64 px * (O/8) / 256
   constexpr int TABW = MODE == RB_A ? 2 : 8;            // floats per (pixel pair, tap): A: rfa | B, C: rfa, max_c G, d_max, d_mean/C  (x 2 pixels)
   extern __shared__ f32x4 rc_smem4[];

@@ -18,7 +18,7 @@
 //
 //   ly_rf3m_stats : [max_c, mean_c] of G -> mm[n, 3Ho, 3Wo, 2] and the SE pooling partials part[n][tile][C]   (models/rfa.py:90, 125-126)
 //   ly_rf3m_fwd   : out = relu(bn(conv_{3x3, stride 3}(G * ca * rfa)))                                         (models/rfa.py:124, 128-129)
-#include "ly_tile.cuh"
+#include "ly_tile.hpp"
 #include "ly_params.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -1,5 +1,5 @@
 // RFCBAMConv main contraction for kernel_size 3 (reference models/rfa.py:113-129), gfx950; storage dtype T = float / __bf16
-// (x and out; the regenerate phase is fp32 VALU work in both, the contraction bf16x3 or plain bf16: ly_tile.cuh).
+// (x and out; the regenerate phase is fp32 VALU work in both, the contraction bf16x3 or plain bf16: ly_tile.hpp).
 //
 //   out[n, o, oy, ox] = relu( bn( bias[o] + sum_{c, t} Wc[o, c, t] * G[n, c, 3oy+ty, 3ox+tx] * ca[n, c] * rfa[n, 3oy+ty, 3ox+tx] ) )
 //   G[n, c, 3oy+ty, 3ox+tx] = relu( bn_{c*9+t}( sum_u Wd[c*9+t, u] * x[n, c, s*oy+uy-1, s*ox+ux-1] ) )
@@ -10,7 +10,7 @@
 // (81 MAC per channel and pixel, lane = output pixel, wave-uniform weights), scales by ca and rfa and
 // writes the [64 px x 144] operand tile (bf16 hi/lo planes) to LDS, which the MFMAs contract with the
 // bf16x3 frag-packed conv.0.weight viewed as [Cout, C/16, 144 -> 160] (k = t*16 + channel inside a chunk).  HBM sees x once and out once.
-#include "ly_tile.cuh"
+#include "ly_tile.hpp"
 #include "ly_params.h"
 
 #define LY_GCC 16                       // channels regenerated per chunk

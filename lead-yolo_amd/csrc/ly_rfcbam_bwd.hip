@@ -22,7 +22,7 @@
 // Thread = channel: a block covers CB = roundup64(min(C, 256)) channels x (256 / CB) pixels at a time, so the lanes
 // of a wave are 64 consecutive channels of ONE pixel: per-pixel reductions over channels are wave shuffles, and
 // per-channel sums over pixels stay in registers until one atomic flush at the end.
-#include "ly_tile.cuh"
+#include "ly_tile.hpp"
 #include "ly_params.h"
 
 struct RfGeom {

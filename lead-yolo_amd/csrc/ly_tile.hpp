@@ -6,7 +6,7 @@
 // product ~2^-16 (vs 2^-8 for plain bf16), i.e. far inside the 1e-3 parity budget, at 16/3 = 5.3x the
 // rate of the exact v_mfma_f32_16x16x4_f32 pipe (MI355X_MICROARCH.md: f32 MFMA = 1/16 of bf16).
 //
-// Tile convention (both operands K-contiguous, same as the fp32 core in ly_common.cuh):
+// Tile convention (both operands K-contiguous, same as the fp32 core in ly_common.hpp):
 //   A operand = WEIGHTS (row = output channel l&15), B operand = ACTIVATIONS (col = pixel l&15),
 //   D: lane l holds rows 4*(l>>4) + r of column l&15  -> 4 consecutive output channels of one pixel.
 //   k-set of lane (i, q = l>>4) in k-step s (32 values):  k = 32s + 16*(j>>2) + 4q + (j&3), j = 0..7
@@ -20,7 +20,7 @@
 // LDS activation image: two planes (hi, lo) of [rows][KP] bf16, KP = ceil32(K), row stride
 // RS = 2*KP + 16 bytes (RS/16 odd => the 2 x b64 fragment reads of a wave hit 32 distinct 8-byte slots).
 #pragma once
-#include "ly_common.cuh"
+#include "ly_common.hpp"
 #include "ly_params.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));

@@ -12,7 +12,7 @@
 //     of (ky*10 + kx) halo positions.  Zero padding and ragged map edges are zeros in the halo / zero du rows: no masks in the loop.
 //   * block = (64 output channels) x (32 input channels x 9 taps) accumulators over a run of tiles; waves 2 (o) x 2 (tap halves).
 // LDS: du tile [64 px][160 B] (128 B data + 32: the 8 pixel rows x 32 B of a half-wave read hit all 64 banks) | halo [100][96 B] (64 + 32).
-#include "ly_tile.cuh"
+#include "ly_tile.hpp"
 #include "ly_params.h"
 #include <stdlib.h>
 
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
 
   // ---- fragment addressing (tile-invariant) ----
   // transposed read: lane (li, lq) fetches the 8-byte chunk li & 3 of row 4*lq + (li >> 2) (and of row + 16) of a 32-row k-step and
-  // receives column li of the 4 x 16 block its 16-lane group fetched: k = 4*lq .. 4*lq + 3 (and + 16), the k-set of ly_tile.cuh
+  // receives column li of the 4 x 16 block its 16-lane group fetched: k = 4*lq .. 4*lq + 3 (and + 16), the k-set of ly_tile.hpp
   const int wn = wave & 1, wk = wave >> 1;
   const int r0 = 4 * lq + (li >> 2);
   const int chunk8 = (li & 3) * 8;

@@ -47,7 +47,7 @@ def load_cfg(cfg=DEFAULT_CFG, scale=None):
     if scale is not None:
         if scale not in SCALES:
             raise NotImplementedError(f"scale {scale!r} is not built (available: {sorted(SCALES)}): its FasterNet stage widths have no "
-                                      "fused MLPBlock kernel (csrc/ly_mlpblock.cuh is instantiated for C in {16, 24, 40, 80, 160, 320})")
+                                      "fused MLPBlock kernel (csrc/ly_mlpblock.hpp is instantiated for C in {16, 24, 40, 80, 160, 320})")
         d["depth_multiple"], d["width_multiple"] = SCALES[scale]
     return d
 

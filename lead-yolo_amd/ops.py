@@ -188,7 +188,7 @@ def gemm(*, M, H, W, K, N, a0, lda0, k0, wp, out, ldo, a1=None, lda1=0, gather=G
     to = "float" if code == 0 else "__bf16"
     es_i, es_o = {"float": 4, "__bf16": 2, "unsigned char": 1}[ti], (4 if to == "float" else 2)
     kgather = GATHER_PATCH_NCHW if image else gather        # the kernel template's gather code (the uint8 image differs by TI only)
-    # the variant launch_gemm_v (csrc/ly_gemm.cuh) picks: resident weights for K in one / two chunks + the branch-free epilogue
+    # the variant launch_gemm_v (csrc/ly_gemm.hpp) picks: resident weights for K in one / two chunks + the branch-free epilogue
     nchunk = -(-K // (128 if ti == "__bf16" else 64))
     nch = 0
     if N % 4 == 0 and ldo % 4 == 0 and out is not None:
@@ -578,7 +578,7 @@ def zeros_f64(numel, device):
 
 def new_stats(nch, device):
     """zeroed striped DOUBLE accumulator for a forward statistics pass over `nch` channels: [STRIPES][2*nch] float64 (ly_stats_flush of
-    csrc/ly_common.cuh adds the waves' fp32 partial sums as doubles: the batch statistics, and with them every ReLU / arg-max decision of
+    csrc/ly_common.hpp adds the waves' fp32 partial sums as doubles: the batch statistics, and with them every ReLU / arg-max decision of
     a training step, are reproducible from run to run; ly_bn_finalize reads it with stats_f64 = 1)"""
     return zeros_f64(STRIPES * 2 * nch, device).view(STRIPES, 2 * nch)
 
@@ -919,13 +919,17 @@ def coordatt_gate_bwd(dout, x, ldx, n, h, w, c, a_h, a_w, ldd=None):
     """dout: rows of the incoming gradient with row stride ldd (default c: dense) — a channel slice of a wider gradient is read in place"""
     ldd = c if ldd is None else ldd
     dx = empty_nhwc(n, c, h, w, x)
-    da = zeros_f64(n * (h + w) * c, dout.device)          # double accumulators (several row bands / column slabs add into one entry)
-    da_h, da_w = da[:n * h * c].view(n, h, c), da[n * h * c:].view(n, w, c)
+    # partial sums per column slab (da_h) / row band (da_w), plain stores, folded in index order: no atomics (csrc/ly_backward.hip)
+    groups = 256 // (c // 4)
+    slabs, bands = -(-w // (groups * 8)), -(-h // 8)
+    ph = torch.empty((slabs, n * h * c), dtype=torch.float32, device=dout.device)
+    pw = torch.empty((bands, n * w * c), dtype=torch.float32, device=dout.device)
     with _Timed(f"ly_coordatt_gate_bwd_kernel<{_tname(x)}>", 6.0 * n * h * w * c, 3.0 * x.element_size() * n * h * w * c):
-        capi.check(capi.lib().ly_coordatt_gate_bwd(_p(dout), ldd, _p(x), ldx, n, h, w, c, _p(a_h), _p(a_w), _p(dx), c, _p(da_h), _p(da_w),
+        capi.check(capi.lib().ly_coordatt_gate_bwd(_p(dout), ldd, _p(x), ldx, n, h, w, c, _p(a_h), _p(a_w), _p(dx), c, _p(ph), _p(pw), bands, slabs,
                                                    capi.dtype_code(x), capi.stream_ptr()), "ly_coordatt_gate_bwd")
-    da = da.float()
-    return dx, da[:n * h * c].view(n, h, c), da[n * h * c:].view(n, w, c)
+    da_h = (sum_rows(ph) if slabs > 1 else ph[0]).view(n, h, c)
+    da_w = (sum_rows(pw) if bands > 1 else pw[0]).view(n, w, c)
+    return dx, da_h, da_w
 
 
 def pool_hw_bwd(gp, n, h, w, c, dtype=torch.float32, into=None):

@@ -1,4 +1,4 @@
-"""Host-side weight packing into the fragment order the gfx950 kernels read (see csrc/ly_common.cuh).
+"""Host-side weight packing into the fragment order the gfx950 kernels read (see csrc/ly_common.hpp).
 
 `frag_pack(W[R, K])` -> flat fp32 [T*S*256]:  out[((t*S + s)*64 + lane)*4 + j] =
 W[16t + (lane & 15)][16s + 4*(lane >> 4) + j], zero padded to 16-multiples.  One wave-wide weight
@@ -57,7 +57,7 @@ def versions(*tensors):
 
 
 def frag_pack3(w2d, rows_to=0, planes=2):
-    """MFMA operand packing (csrc/ly_tile.cuh): W[R, K] fp32 -> int16 tensor [T, S, planes, 64, 8]; planes = 2: hi = bf16(W),
+    """MFMA operand packing (csrc/ly_tile.hpp): W[R, K] fp32 -> int16 tensor [T, S, planes, 64, 8]; planes = 2: hi = bf16(W),
     lo = bf16(W - hi) (the bf16x3 operand of the fp32-storage kernels), planes = 1: hi only (bf16-storage kernels).
     lane = q*16 + i holds row 16t + i and k = 32s + 16*(j >> 2) + 4q + (j & 3), j = 0..7.  Zero padded to 16 x 32 multiples."""
     r, k = w2d.shape
@@ -111,7 +111,7 @@ def rfcbam_gen_weights(gen_w, scale, shift, chunk, per_wave_contiguous):
 
 
 def rfcbam_gen_weights_c(gen_w, scale, shift, raw=False):
-    """Depthwise 'generate' weights of RFCBAMConv (k=3) in LANE = CHANNEL order (csrc/ly_rf3c.cuh rc_load_w): per channel 100 floats —
+    """Depthwise 'generate' weights of RFCBAMConv (k=3) in LANE = CHANNEL order (csrc/ly_rf3c.hpp rc_load_w): per channel 100 floats —
     w[t][u] at t*9 + u, b[t] at 81 + t, a[t] at 90 + t, one of padding — stored as float [C/32][25][32][4] so that a half wave's 16-byte
     loads are contiguous.  Folded (inference): w = weight * scale, b = shift;  raw (training): w = weight, a = scale, b = shift."""
     c = gen_w.shape[0] // 9

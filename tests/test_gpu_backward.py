@@ -581,7 +581,7 @@ def test_graphed_step_with_reducer_matches_eager(rccl, accumulate):
 def test_training_forward_is_reproducible_and_gradients_agree_to_summation_noise(amp):
     """batch statistics used to be summed by float atomics in arrival order; their 1e-7 noise flipped ReLU / arg-max
     decisions downstream and two runs of the SAME step differed by 1e-3 .. 5e-2 in whole gradients (and made every end-to-end training test
-    loose).  The forward statistics are double accumulators now (csrc/ly_common.cuh ly_stats_flush): from one state, two runs of forward +
+    loose).  The forward statistics are double accumulators now (csrc/ly_common.hpp ly_stats_flush): from one state, two runs of forward +
     loss + backward must give (a) BIT-IDENTICAL predictions, loss and BatchNorm running statistics — every routing decision is the same —
     and (b) gradients that differ only by the float summation order of the backward reductions: <= 1e-5 of each tensor's norm (typically
     1e-7), not by flipped units."""

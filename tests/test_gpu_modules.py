@@ -415,7 +415,7 @@ def test_conv_k3_s2_golden():
 
 
 def test_bf16x3_adversarial_bounds():
-    """The fp32-storage path multiplies with a 3-term bf16 split (csrc/ly_tile.cuh: the lo*lo term, ~2^-16 relative per product, is
+    """The fp32-storage path multiplies with a 3-term bf16 split (csrc/ly_tile.hpp: the lo*lo term, ~2^-16 relative per product, is
     dropped).  Worst cases for that error model, each against the fp32 oracle with the DOCUMENTED bound
         |err| <= 2^-14 * sum_k |w_k x_k|   (2^-16 per product with a 4x margin for accumulation order and the epilogue)
     which for well-conditioned sums is far inside the 1e-3 budget, and which is the honest bound when terms cancel:

@@ -1,4 +1,4 @@
-// Probe for the packed-FMA finding of csrc/ly_rf3c.cuh: do hand-written v_pk_fma_f32 with op_sel weight broadcasts return
+// Probe for the packed-FMA finding of csrc/ly_rf3c.hpp: do hand-written v_pk_fma_f32 with op_sel weight broadcasts return
 // wrong values when another wave of the SIMD issues MFMAs?  Which ingredient matters: the asm, the packing, the op_sel broadcast?
 //
 //   hipcc -O3 --offload-arch=gfx950 -I lead-yolo_amd/csrc -I include tools/pkfma_probe.hip -o /tmp/pkfma_probe && /tmp/pkfma_probe
@@ -58,7 +58,7 @@ __device__ __forceinline__ f32x2 pkfma(const f32x2 x, const f32x2 w, f32x2 acc, 
   }
 }
 
-// out[thread][it][9 taps][2]: the same arithmetic as rc_generate<false> of ly_rf3c.cuh: a[t] = b[t] + sum_u w[t][u] * x[u]
+// out[thread][it][9 taps][2]: the same arithmetic as rc_generate<false> of ly_rf3c.hpp: a[t] = b[t] + sum_u w[t][u] * x[u]
 template <int V>
 __global__ __launch_bounds__(256) void victim(const float* __restrict__ wsrc, const float* __restrict__ xsrc, float* __restrict__ out, int iters) {
   const int tid = blockIdx.x * 256 + threadIdx.x;

@@ -36,6 +36,14 @@ class GraphedForward:
         xs = list(self.x.chunk(parts, 0))
         self.streams = [torch.cuda.Stream(device=example.device) for _ in range(parts)]
         cur = torch.cuda.current_stream()
+        from . import ops
+        keep_parts, ops.CONCURRENT_PARTS = ops.CONCURRENT_PARTS, parts
+        try:
+            self._warm_and_capture(model, xs, parts, cur, warmup, example)
+        finally:
+            ops.CONCURRENT_PARTS = keep_parts
+
+    def _warm_and_capture(self, model, xs, parts, cur, warmup, example):
         with torch.no_grad():
             for s, xi in zip(self.streams, xs):                  # warm up off the capture (weight packing caches, allocator pools)
                 s.wait_stream(cur)

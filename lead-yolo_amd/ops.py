@@ -324,6 +324,10 @@ RF3M_MIN_UNITS = 1500      # wave tiles x output-channel blocks below which the 
                            # ly_rf3m walks ALL input channels of its 256 pixels serially, ~45 us however small the launch)
 
 
+CONCURRENT_PARTS = 1       # graph.GraphedForward runs the batch as this many sub-batches side by side: size-based dispatch decisions look at the
+                           # whole batch, so that a sub-batched replay takes the kernels (and returns the bits) of the eager forward of the full batch
+
+
 def rf3m_ok(x, c, o, s, n=None, ho=None, wo=None):
     """`generate` on the matrix cores (csrc/ly_rf3m.hip): bf16 storage, C % 32 == 0, O % 64 == 0, stride 1 / 2 — and, when the problem size
     is given, enough wave tiles to fill the chip (RF3M_MIN_UNITS)"""
@@ -332,7 +336,7 @@ def rf3m_ok(x, c, o, s, n=None, ho=None, wo=None):
     if n is None:
         return True
     th, tw = pick_tile_m(ho, wo, s)
-    return n * -(-ho // th) * -(-wo // tw) * (o // (128 if o % 128 == 0 else 64)) >= RF3M_MIN_UNITS
+    return n * CONCURRENT_PARTS * -(-ho // th) * -(-wo // tw) * (o // (128 if o % 128 == 0 else 64)) >= RF3M_MIN_UNITS
 
 
 def pick_tile_m(ho, wo, s):

@@ -280,6 +280,29 @@ def test_graphed_forward_matches_eager():
             assert all(torch.equal(a, b) for a, b in zip(pg, pe))
 
 
+def test_graphed_forward_matches_eager_bf16_full_batch():
+    """configs[1]'s batch in bf16: the size-based kernel choice of RFCBAMConv k=3 (ops.rf3m_ok) must look at the WHOLE batch when the
+    captured forward runs it as concurrent sub-batches — a sub-batch alone falls under the threshold, took the other kernel and the
+    replay differed from the eager forward in the last bits (bench.py then fell back to eager launches: 1.12 -> 1.74 ms)"""
+    import lead_yolo_amd as L
+    from lead_yolo_amd import ops
+    torch.manual_seed(0)
+    m = L.Model(_cfg("s"))
+    st = synth.synth_state(synth.shapes_of(m.state_dict()), 778)
+    st["model.23.anchors"] = m.model[-1].anchors.clone()
+    m.load_state_dict(st)
+    m = m.to(_dev()).eval()
+    x = (synth.synth_images(32, 640, 5).float() / 255).to(_dev()).to(torch.bfloat16)
+    g = L.GraphedForward(m, x)
+    assert g.parts == 4 and ops.CONCURRENT_PARTS == 1
+    with torch.no_grad():
+        ze, pe = m(x)
+    zg, pg = g(x)
+    torch.cuda.synchronize()
+    assert torch.equal(zg, ze)
+    assert all(torch.equal(a, b) for a, b in zip(pg, pe))
+
+
 def test_rfcbam3_large_grid_vs_oracle():
     """RFCBAMConv k=3 at a grid large enough for the 256-channel tile's scalar-cache weight path (more than one block per CU,
     csrc/ly_rfcbam3.hip launch_rf3): images are independent in eval mode, the oracle checks the first two and the last."""

@@ -124,11 +124,24 @@ __global__ __launch_bounds__(LY_THREADS) void ly_colsum_kernel(const T* __restri
   }
 }
 
+// LDS floats of the SE step: g[C] + hid[R] + red[LY_THREADS][4], plus — when they fit 48 KiB — both weight matrices (2 R C): staged while the
+// pooling partials are on their way, so that the step is ONE global round trip instead of three dependent ones (partials, fc1 rows, fc2 rows:
+// 12.6 us per launch of ly_rfcbam_mid was this chain, not the get_weight map that runs beside it)
+__host__ __device__ __forceinline__ size_t ly_se_lds_floats(int C, int R) {
+  const size_t base = (size_t)((C + R + 3) & ~3) + 4 * LY_THREADS;
+  const size_t w = 2 * (size_t)R * C;
+  return (C & 3) == 0 && w * 4 <= 48 * 1024 ? base + w : base;
+}
+
 __device__ __forceinline__ void ly_se_mlp_body(float* sm, const int n, const float* __restrict__ part, int slices, int C, float inv_hw,
                                                const float* __restrict__ wa, const float* __restrict__ wb, int R, float* __restrict__ ca) {
-  float* g = sm;                     // g[C] + hid[R] + red[LY_THREADS][4]
+  float* g = sm;                     // g[C] + hid[R] + red[LY_THREADS][4] (+ wa[R][C] + wb[C][R])
   float* hid = sm + C;
   f32x4* red = reinterpret_cast<f32x4*>(sm + ((C + R + 3) & ~3));
+  const size_t base = (size_t)((C + R + 3) & ~3) + 4 * LY_THREADS;
+  const bool staged = ly_se_lds_floats(C, R) > base;
+  float* was = sm + base;
+  float* wbs = was + (size_t)R * C;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // slice partials -> channel means.  All 256 threads load: thread = (slice group, 4 channels), so the up to 128 slices
   // are a handful of independent float4 loads per thread instead of a 128-long chain per channel; groups meet in LDS.
@@ -136,8 +149,33 @@ __device__ __forceinline__ void ly_se_mlp_body(float* sm, const int n, const flo
   const int ng = LY_THREADS / nq;        // slice groups
   const int q = tid % nq, sg = tid / nq;
   f32x4 s4 = ly_zero4();
-  if (sg < ng)
-    for (int sl = sg; sl < slices; sl += ng) s4 += ly_ldg4(part + ((long)n * slices + sl) * C + 4 * q);
+  if (sg < ng) {
+    int sl = sg;
+    for (; sl + 3 * ng < slices; sl += 4 * ng) {         // four loads in flight per trip
+      const f32x4 a0 = ly_ldg4(part + ((long)n * slices + sl) * C + 4 * q), a1 = ly_ldg4(part + ((long)n * slices + sl + ng) * C + 4 * q);
+      const f32x4 a2 = ly_ldg4(part + ((long)n * slices + sl + 2 * ng) * C + 4 * q), a3 = ly_ldg4(part + ((long)n * slices + sl + 3 * ng) * C + 4 * q);
+      s4 += a0; s4 += a1; s4 += a2; s4 += a3;
+    }
+    for (; sl < slices; sl += ng) s4 += ly_ldg4(part + ((long)n * slices + sl) * C + 4 * q);
+  }
+  if (staged) {
+    const int nw4 = (R * C) >> 2;                        // float4 items per matrix (C % 4 == 0)
+    for (int i = tid; i < nw4; i += 4 * LY_THREADS) {
+      f32x4 va[4], vb[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int j = i + k * LY_THREADS < nw4 ? i + k * LY_THREADS : i;
+        va[k] = ly_ldg4(wa + 4 * j);
+        vb[k] = ly_ldg4(wb + 4 * j);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (i + k * LY_THREADS < nw4) {
+          *reinterpret_cast<f32x4*>(was + 4 * (i + k * LY_THREADS)) = va[k];
+          *reinterpret_cast<f32x4*>(wbs + 4 * (i + k * LY_THREADS)) = vb[k];
+        }
+    }
+  }
   red[tid] = s4;
   __syncthreads();
   if (sg == 0) {
@@ -145,9 +183,11 @@ __device__ __forceinline__ void ly_se_mlp_body(float* sm, const int n, const flo
     g[4 * q] = s4[0] * inv_hw; g[4 * q + 1] = s4[1] * inv_hw; g[4 * q + 2] = s4[2] * inv_hw; g[4 * q + 3] = s4[3] * inv_hw;
   }
   __syncthreads();
+  const float* wap = staged ? was : wa;
+  const float* wbp = staged ? wbs : wb;
   for (int r = wave; r < R; r += 4) {
     float s = 0.f;
-    for (int c = lane; c < C; c += 64) s += wa[r * C + c] * g[c];
+    for (int c = lane; c < C; c += 64) s += wap[r * C + c] * g[c];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if (lane == 0) hid[r] = fmaxf(s, 0.f);
@@ -155,7 +195,7 @@ __device__ __forceinline__ void ly_se_mlp_body(float* sm, const int n, const flo
   __syncthreads();
   for (int c = tid; c < C; c += LY_THREADS) {
     float s = 0.f;
-    for (int r = 0; r < R; ++r) s += wb[c * R + r] * hid[r];
+    for (int r = 0; r < R; ++r) s += wbp[c * R + r] * hid[r];
     ca[(long)n * C + c] = ly_sigmoid(s);
   }
 }
@@ -185,7 +225,7 @@ extern "C" int ly_se_fwd(const void* x, int ldx, int n_img, int HW, int C, const
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   LY_WITH_T(dtype, hipLaunchKernelGGL(ly_colsum_kernel<T>, dim3(n_img * slices), dim3(LY_THREADS), 0, st, reinterpret_cast<const T*>(x), ldx, HW, C, slices, part));
   LY_LAUNCH_CHECK();
-  hipLaunchKernelGGL(ly_se_mlp_kernel, dim3(n_img), dim3(LY_THREADS), sizeof(float) * (((C + R + 3) & ~3) + 4 * LY_THREADS), st, part, slices, C, 1.f / (float)HW,
+  hipLaunchKernelGGL(ly_se_mlp_kernel, dim3(n_img), dim3(LY_THREADS), sizeof(float) * ly_se_lds_floats(C, R), st, part, slices, C, 1.f / (float)HW,
                      wa, wb, R, ca);
   LY_LAUNCH_CHECK();
   return 0;
@@ -517,29 +557,61 @@ extern "C" int ly_rfcbam_stats(const void* x, int ldx, int n_img, int H, int W, 
 }
 
 // rfa[n, y, x] = sigmoid( sum_{ch, dy, dx} w[ch][dy][dx] * mm[n, y+dy-1, x+dx-1, ch] )
-__device__ __forceinline__ void ly_rfa_map_body(const long i, const float* __restrict__ mm, int HK, int WK, long total,
+// A thread owns FOUR horizontally adjacent outputs: 3 rows x 6 columns of [max, mean] pairs = 18 eight-byte loads (clamped addresses, all
+// issued before the first use) for 72 multiply-adds — one output per thread was 18 guarded loads for 18 (12.6 us per launch at 120 x 120 x 64,
+// all of it L2 round trips).  Items: i -> (n, y, x0 = 4 * (i % ceil(WK / 4))).
+__device__ __forceinline__ void ly_rfa_map_body(const long i, const float* __restrict__ mm, int HK, int WK, long total4,
                                                 const float* __restrict__ w, float* __restrict__ rfa) {
-  if (i >= total) return;
-  const int xk = (int)(i % WK);
-  const int yk = (int)((i / WK) % HK);
-  const long n = i / ((long)WK * HK);
-  float s = 0.f;
+  if (i >= total4) return;
+  const int wq = (WK + 3) >> 2;
+  const int x0 = 4 * (int)(i % wq);
+  const int yk = (int)((i / wq) % HK);
+  const long n = i / ((long)wq * HK);
+  f32x2 v[3][6];
 #pragma unroll
-  for (int dy = 0; dy < 3; ++dy)
+  for (int dy = 0; dy < 3; ++dy) {
+    const int yy = yk + dy - 1;
+    const int yc = yy < 0 ? 0 : (yy >= HK ? HK - 1 : yy);
 #pragma unroll
-    for (int dx = 0; dx < 3; ++dx) {
-      const int yy = yk + dy - 1, xx = xk + dx - 1;
-      if (yy >= 0 && yy < HK && xx >= 0 && xx < WK) {
-        const float* p = mm + ((n * HK + yy) * WK + xx) * 2;
-        s += w[dy * 3 + dx] * p[0] + w[9 + dy * 3 + dx] * p[1];
+    for (int c = 0; c < 6; ++c) {
+      const int xx = x0 + c - 1;
+      const int xc = xx < 0 ? 0 : (xx >= WK ? WK - 1 : xx);
+      v[dy][c] = *reinterpret_cast<const f32x2*>(mm + ((n * HK + yc) * WK + xc) * 2);
+    }
+  }
+  float wv[18];
+#pragma unroll
+  for (int k = 0; k < 18; ++k) wv[k] = w[k];
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy) {
+    const int yy = yk + dy - 1;
+    const bool yok = yy >= 0 && yy < HK;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const int xx = x0 + c - 1;
+      const bool ok = yok && xx >= 0 && xx < WK;
+      const f32x2 p = ok ? v[dy][c] : (f32x2){0.f, 0.f};
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        const int dx = c - o;                            // output x0 + o reads column x0 + o + dx - 1 = x0 + c - 1
+        if (dx >= 0 && dx < 3) s[o] += wv[dy * 3 + dx] * p[0] + wv[9 + dy * 3 + dx] * p[1];
       }
     }
-  rfa[i] = ly_sigmoid(s);
+  }
+  float* out = rfa + (n * HK + yk) * WK + x0;
+  if (x0 + 3 < WK && (WK & 3) == 0) {
+    *reinterpret_cast<f32x4*>(out) = (f32x4){ly_sigmoid(s[0]), ly_sigmoid(s[1]), ly_sigmoid(s[2]), ly_sigmoid(s[3])};
+  } else {
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+      if (x0 + o < WK) out[o] = ly_sigmoid(s[o]);
+  }
 }
 
-__global__ __launch_bounds__(LY_THREADS) void ly_rfa_map_kernel(const float* __restrict__ mm, int HK, int WK, long total,
+__global__ __launch_bounds__(LY_THREADS) void ly_rfa_map_kernel(const float* __restrict__ mm, int HK, int WK, long total4,
                                                                  const float* __restrict__ w, float* __restrict__ rfa) {
-  ly_rfa_map_body((long)blockIdx.x * LY_THREADS + threadIdx.x, mm, HK, WK, total, w, rfa);
+  ly_rfa_map_body((long)blockIdx.x * LY_THREADS + threadIdx.x, mm, HK, WK, total4, w, rfa);
 }
 
 // The two small dependent steps between the statistics pass and the main contraction of RFCBAMConv as ONE launch: blocks
@@ -548,29 +620,29 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfa_map_kernel(const float* __r
 __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_mid_kernel(const float* __restrict__ part, int slices, int C, float inv_hw,
                                                                    const float* __restrict__ wa, const float* __restrict__ wb, int R,
                                                                    float* __restrict__ ca, int n_img, const float* __restrict__ mm, int HK, int WK,
-                                                                   long total, const float* __restrict__ w18, float* __restrict__ rfa) {
+                                                                   long total4, const float* __restrict__ w18, float* __restrict__ rfa) {
   extern __shared__ float sm[];
   if ((int)blockIdx.x < n_img) ly_se_mlp_body(sm, blockIdx.x, part, slices, C, inv_hw, wa, wb, R, ca);
-  else ly_rfa_map_body((long)(blockIdx.x - n_img) * LY_THREADS + threadIdx.x, mm, HK, WK, total, w18, rfa);
+  else ly_rfa_map_body((long)(blockIdx.x - n_img) * LY_THREADS + threadIdx.x, mm, HK, WK, total4, w18, rfa);
 }
 
 extern "C" int ly_rfcbam_mid(const float* part, int slices, int C, int HW, const float* wa, const float* wb, int R, float* ca, int n_img,
                              const float* mm, int HK, int WK, const float* w18, float* rfa, void* stream) {
   LY_CHECK(part && wa && wb && ca && mm && w18 && rfa, "rfcbam_mid: null pointer");
   LY_CHECK((C & 3) == 0 && C <= 1024 && slices > 0 && R > 0 && R <= 256 && n_img > 0, "rfcbam_mid: bad arguments");
-  const long total = (long)n_img * HK * WK;
-  const unsigned blocks = (unsigned)(n_img + (total + LY_THREADS - 1) / LY_THREADS);
-  hipLaunchKernelGGL(ly_rfcbam_mid_kernel, dim3(blocks), dim3(LY_THREADS), sizeof(float) * (((C + R + 3) & ~3) + 4 * LY_THREADS),
-                     reinterpret_cast<hipStream_t>(stream), part, slices, C, 1.f / (float)HW, wa, wb, R, ca, n_img, mm, HK, WK, total, w18, rfa);
+  const long total4 = (long)n_img * HK * ((WK + 3) / 4);
+  const unsigned blocks = (unsigned)(n_img + (total4 + LY_THREADS - 1) / LY_THREADS);
+  hipLaunchKernelGGL(ly_rfcbam_mid_kernel, dim3(blocks), dim3(LY_THREADS), sizeof(float) * ly_se_lds_floats(C, R),
+                     reinterpret_cast<hipStream_t>(stream), part, slices, C, 1.f / (float)HW, wa, wb, R, ca, n_img, mm, HK, WK, total4, w18, rfa);
   LY_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int ly_rfa_map(const float* mm, int n_img, int HK, int WK, const float* w, float* rfa, void* stream) {
   LY_CHECK(mm && w && rfa, "rfa_map: null pointer");
-  long total = (long)n_img * HK * WK;
-  hipLaunchKernelGGL(ly_rfa_map_kernel, dim3((unsigned)((total + LY_THREADS - 1) / LY_THREADS)), dim3(LY_THREADS), 0,
-                     reinterpret_cast<hipStream_t>(stream), mm, HK, WK, total, w, rfa);
+  const long total4 = (long)n_img * HK * ((WK + 3) / 4);
+  hipLaunchKernelGGL(ly_rfa_map_kernel, dim3((unsigned)((total4 + LY_THREADS - 1) / LY_THREADS)), dim3(LY_THREADS), 0,
+                     reinterpret_cast<hipStream_t>(stream), mm, HK, WK, total4, w, rfa);
   LY_LAUNCH_CHECK();
   return 0;
 }

@@ -32,7 +32,7 @@ BF = torch.bfloat16
 
 def _close(got, want, what, rel=REL_L2, mx=MAX_REL):
     got = got.detach().float().cpu()
-    want = want.detach().float() if isinstance(want, torch.Tensor) else torch.from_numpy(np.asarray(want)).float()
+    want = want.detach().float().cpu() if isinstance(want, torch.Tensor) else torch.from_numpy(np.asarray(want)).float()
     assert got.shape == want.shape, (what, got.shape, want.shape)
     assert torch.isfinite(got).all(), what
     nw = float(want.norm())

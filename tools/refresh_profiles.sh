@@ -17,10 +17,10 @@ cd /tmp && export TMPDIR=/tmp
 one() {   # name, steps-divisor, bench args...
   local NAME=$1; shift; local ARGS="$*"
   rm -rf /tmp/pf_k
-  timeout 900 rocprofv3 -M --kernel-trace --stats --output-format csv -d /tmp/pf_k -o k -- python3 $R/bench.py --steps 5 --warmup 2 --repeats 1 --no-roofline --no-graph $ARGS > /tmp/k.log 2>&1
+  timeout 900 rocprofv3 -M --kernel-trace --stats --output-format csv -d /tmp/pf_k -o k -- python3 $R/bench.py --steps 5 --warmup 2 --repeats 1 --no-roofline --no-graph --no-sustained --no-cpu-baseline --no-secondary $ARGS > /tmp/k.log 2>&1
   cp $(find /tmp/pf_k -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_${NAME}_kernel_stats.csv 2>/dev/null
   python3 $R/tools/prof_summary.py $(find /tmp/pf_k -name "*kernel_trace.csv" | head -1) 7 > $OUT/${TAG}_${NAME}_kernels_per_step.txt 2>&1
-  local PA="--steps 2 --warmup 1 --repeats 1 --no-roofline --no-graph $ARGS"
+  local PA="--steps 2 --warmup 1 --repeats 1 --no-roofline --no-graph --no-sustained --no-cpu-baseline --no-secondary $ARGS"
   for p in "f FETCH_SIZE" "w WRITE_SIZE" "m SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "s SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT"; do
     set -- $p; local k=$1; shift
     rm -rf /tmp/pf_$k

@@ -202,8 +202,9 @@ class MLPBlock(nn.Module):
                 or norm_layer is not nn.BatchNorm2d or act_layer is not nn.ReLU:
             raise NotImplementedError("HIP MLPBlock is built for n_div=4, mlp_ratio=2, BatchNorm2d+ReLU, no layer-scale/drop-path "
                                       "(the only configuration LEAD-YOLO instantiates)")
-        if dim not in ops.MLP_WIDTHS:
-            raise NotImplementedError(f"HIP MLPBlock is built for dim in {sorted(ops.MLP_WIDTHS)} (lead-yolo n / s / l); got dim={dim}")
+        if dim % 16 != 0 and dim not in ops.MLP_WIDTHS:
+            raise NotImplementedError(f"HIP MLPBlock: the fused kernel is built for dim in {sorted(ops.MLP_WIDTHS)} (lead-yolo n / s / l), the "
+                                      f"composed path (partial 3x3 + two 1x1 contractions) for dim % 16 == 0; got dim={dim}")
         self.dim = dim
         hidden = int(dim * mlp_ratio)
         self.mlp = nn.Sequential(nn.Conv2d(dim, hidden, 1, bias=False), norm_layer(hidden), act_layer(),
@@ -236,11 +237,38 @@ class MLPBlock(nn.Module):
             return pack.pad_to(sc, 16 * htp), pack.pad_to(sh, 16 * htp)
         return self._prep_bn.get(key, build)
 
+    def _forward_composed(self, x):
+        """Any width with dim % 16 == 0 (models/common.py:1432-1437, 1478-1482 take any dim; the fused kernel is instantiated for the widths of
+        lead-yolo n / s / l): the same arithmetic as three HIP contraction units — the partial 3x3 convolution on the first dim/4 channels (read
+        in place as a channel slice), 1x1 expand + BatchNorm + ReLU, 1x1 project — with the units' own autograd nodes in training.  The channel
+        concatenation and the residual add between them are stock ATen device ops.  bf16 storage needs dim % 32 == 0 (16-byte channel slices)."""
+        from . import grad
+        x = ops.nhwc(x)
+        c, cq = self.dim, self.dim // 4
+        if cq % ops.vw_of(x) != 0:
+            raise NotImplementedError(f"HIP MLPBlock (composed path): dim/4 = {cq} channels are not a whole number of {ops.vw_of(x)}-channel vectors "
+                                      f"in {x.dtype} storage")
+        planes = ops.planes_of(x)
+        wpc_, w1_, w2_ = self.spatial_mixing.partial_conv3.weight, self.mlp[0].weight, self.mlp[3].weight
+        bn = self.mlp[1]
+
+        def build():
+            cip = (cq + 31) // 32 * 32
+            return (pack.packed(pack.src_taps(wpc_, cip), 9 * cip, planes), pack.packed(pack.src_matrix(w1_, 2 * c, c), c, planes),
+                    pack.packed(pack.src_matrix(w2_, c, 2 * c), 2 * c, planes))
+        wpc, w1p, w2p = self._prep.get(pack.versions(wpc_, w1_, w2_) + ("composed",), build, planes)
+        pc = grad.conv_bn_act(grad.ConvSpec("c3", cq), wpc, x[:, :cq], None, wpc_, None, None)
+        z = torch.cat((pc, x[:, cq:]), 1).contiguous(memory_format=torch.channels_last)
+        hid = grad.conv_bn_act(grad.ConvSpec("pw", 2 * c, ACT_RELU, bn, self.training), w1p, z, None, w1_, None, bn)
+        return x + grad.conv_bn_act(grad.ConvSpec("pw", c), w2p, hid, None, w2_, None, None)
+
     @_edge
     def forward(self, x):
         pr = _probe(x, x.shape)
         if pr is not None:
             return pr
+        if self.dim not in ops.MLP_WIDTHS:
+            return self._forward_composed(x)
         if _grad_mode(self):
             from . import grad
             bn = self.mlp[1]

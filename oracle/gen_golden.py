@@ -323,12 +323,44 @@ def gen_trainsteps(ref):
     _save("trainsteps_n", meta, arrays)
 
 
+def gen_metrics(ref):
+    """val.py's metric chain on synthetic detections / labels: `utils.metrics.box_iou`, `val.process_batch` and `utils.metrics.ap_per_class`
+    of the unmodified reference (pins oracle/metrics.py)"""
+    import importlib
+    print("metrics:")
+    val = importlib.import_module("val")
+    rng = np.random.default_rng(20240)
+    arrays, cases = {}, []
+    for k, (nd, nl, nc) in enumerate([(40, 7, 1), (100, 20, 3), (5, 1, 1), (60, 12, 2), (300, 33, 1), (3, 0, 1)]):
+        lab = np.zeros((nl, 5), np.float32)
+        lab[:, 0] = rng.integers(0, nc, nl)
+        xy, wh = rng.uniform(0, 200, (nl, 2)), rng.uniform(10, 80, (nl, 2))
+        lab[:, 1:3], lab[:, 3:5] = xy, xy + wh
+        det = np.zeros((nd, 6), np.float32)
+        if nl:
+            src = rng.integers(0, nl, nd)
+            det[:, :4] = lab[src, 1:] + rng.normal(0, 6, (nd, 4))
+            det[:, 5] = np.where(rng.uniform(size=nd) < 0.8, lab[src, 0], rng.integers(0, nc, nd))
+        else:
+            det[:, :4] = rng.uniform(0, 200, (nd, 4))
+        det[:, 4] = rng.uniform(0.01, 1, nd)
+        iou = ref.metrics.box_iou(torch.from_numpy(lab[:, 1:]), torch.from_numpy(det[:, :4])).numpy()
+        correct = val.process_batch(torch.from_numpy(det), torch.from_numpy(lab), torch.linspace(0.5, 0.95, 10)).numpy()
+        arrays.update({f"det{k}": det, f"lab{k}": lab, f"iou{k}": iou, f"correct{k}": correct})
+        if nl:
+            out = ref.metrics.ap_per_class(correct, det[:, 4], det[:, 5], lab[:, 0], plot=False, names={i: str(i) for i in range(nc)})
+            for name, v in zip(("tp", "fp", "p", "r", "f1", "ap", "cls"), out):
+                arrays[f"{name}{k}"] = np.asarray(v, np.float64)
+        cases.append(dict(nd=nd, nl=nl, nc=nc))
+    _save("metrics_cases", dict(cases=cases), arrays)
+
+
 def main():
     import sys
     ref = ref_import.load()
     torch.set_num_threads(8)
     gens = dict(modules=gen_modules, parse=gen_parse, model=gen_model, loss=gen_loss, loss_multiclass=gen_loss_multiclass,
-                trainsteps=gen_trainsteps)
+                trainsteps=gen_trainsteps, metrics=gen_metrics)
     for name in (sys.argv[1:] or list(gens)):            # `python oracle/gen_golden.py loss_multiclass` regenerates one group
         gens[name](ref)
 

@@ -111,6 +111,10 @@ BWD_CASES = [
     ("C3_CA", (1024, 1024, 3, False), (1, 1024, 6, 6)),
     ("PatchMerging_FasterNet", (160, 320, 2, 2), (1, 160, 10, 14)),
     ("SPPF", (320, 320, 5), (2, 320, 9, 7)),
+    # widths outside the six the fused MLPBlock kernel is built for (models/common.py:1494-1521 takes any dim): the composed path —
+    # partial 3x3 on a channel slice, two 1x1 contraction units, their own autograd nodes
+    ("BasicStage", (48, 2), (2, 48, 17, 13)),
+    ("BasicStage", (64, 1), (1, 64, 24, 20)),
 ]
 
 

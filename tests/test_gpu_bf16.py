@@ -357,9 +357,10 @@ def test_whole_model_gradients_bf16():
     assert cos >= 0.975 and 0.9 <= (nn / no) ** 0.5 <= 1.1, (cos, (nn / no) ** 0.5)
 
 
-@pytest.mark.parametrize("c,n,h,w", [(24, 12, 160, 160), (40, 24, 80, 80), (16, 8, 128, 128)])
+@pytest.mark.parametrize("c,n,h,w", [(24, 12, 160, 160), (40, 24, 80, 80), (16, 8, 128, 128), (64, 2, 24, 20), (96, 1, 9, 31)])
 def test_mlpblock_persistent_kernel_bf16(c, n, h, w):
-    """the persistent patch-walk form of the fused MLPBlock (weights in LDS, double-buffered patches), bf16 storage"""
+    """the persistent patch-walk form of the fused MLPBlock (weights in LDS, double-buffered patches), bf16 storage; the last two widths
+    are not among the fused kernel's and take the composed path (dim % 32 == 0 in bf16 storage)"""
     import lead_yolo_amd as L
     torch.manual_seed(c)
     m = L.BasicStage(c, 1)

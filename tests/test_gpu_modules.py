@@ -54,7 +54,8 @@ def test_basicstage_golden(name):
 
 @pytest.mark.parametrize("c,n,h,w", [(24, 3, 17, 13), (24, 2, 160, 160), (40, 2, 80, 80), (80, 2, 40, 40), (160, 3, 20, 20),
                                      (16, 1, 5, 7), (80, 1, 3, 200), (160, 2, 1, 1), (40, 1, 64, 2), (320, 1, 10, 12),
-                                     (24, 12, 160, 160), (40, 24, 80, 80), (16, 8, 128, 128), (24, 7, 100, 240)])      # >= 1024 patches: the persistent kernel
+                                     (24, 12, 160, 160), (40, 24, 80, 80), (16, 8, 128, 128), (24, 7, 100, 240),       # >= 1024 patches: the persistent kernel
+                                     (48, 2, 17, 13), (64, 1, 24, 20), (240, 1, 10, 12)])                             # other widths: the composed path
 def test_basicstage_shapes_vs_oracle(c, n, h, w):
     """ragged tiles, tiles spanning images, 1-pixel-wide maps, real layer shapes"""
     import lead_yolo_amd as L

@@ -164,3 +164,23 @@ def test_three_sgd_steps():
                 OF.sgd_nesterov_step(sub, grads, bufs, meta["lr0"], meta["momentum"], wd)
     for k in meta["probe"]:
         np.testing.assert_allclose(st[k].detach().numpy(), arr["final_" + k], rtol=2e-4, atol=2e-5)
+
+
+def test_metrics_oracle_matches_reference_vectors():
+    """oracle/metrics.py (val.py:79-101 process_batch, utils/metrics.py:31-123 ap_per_class / compute_ap, :406-424 box_iou) against what the
+    unmodified reference returned for the same detections / labels (tests/golden/metrics_cases.npz, oracle/gen_golden.py metrics)"""
+    from oracle import metrics as OM
+    meta, arr = G.load("metrics_cases")
+    for k, case in enumerate(meta["cases"]):
+        det, lab = arr[f"det{k}"], arr[f"lab{k}"]
+        np.testing.assert_array_equal(OM.box_iou(lab[:, 1:], det[:, :4]), arr[f"iou{k}"])
+        correct = OM.process_batch(det, lab)
+        np.testing.assert_array_equal(correct, arr[f"correct{k}"])
+        if case["nl"]:
+            got = OM.ap_per_class(correct, det[:, 4], det[:, 5], lab[:, 0])
+            for name, v in zip(("tp", "fp", "p", "r", "f1", "ap", "cls"), got):
+                np.testing.assert_allclose(np.asarray(v, np.float64), arr[f"{name}{k}"], rtol=0, atol=1e-12, err_msg=f"case {k} {name}")
+    # val.py:183-188 on two "images"
+    stats = [(OM.process_batch(arr[f"det{k}"], arr[f"lab{k}"]), arr[f"det{k}"][:, 4], arr[f"det{k}"][:, 5], arr[f"lab{k}"][:, 0]) for k in (0, 4)]
+    mp, mr, map50, m = OM.mean_results(stats)
+    assert 0 < m <= map50 <= 1 and 0 < mp <= 1 and 0 < mr <= 1

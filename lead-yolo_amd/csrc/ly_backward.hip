@@ -190,12 +190,7 @@ extern "C" int ly_bnact_bwd_reduce(const void* dy_, int lddy, const void* u_, in
   // and 14.6 -> 12.6 us, and use 16-byte accesses.)
   const int vw = 4;
   const int groups = LY_THREADS / (C / vw);
-  // rows per thread: 32 on the large maps (2048 blocks, each ending in 2 C double atomics: 4 MB of atomic traffic per launch is already 3 us),
-  // down to 8 (two trips) on the 40 x 40 / 20 x 20 maps — at 32 those launched 400 blocks, 1.5 waves per SIMD, and ran at 2.2-2.7 TB/s
-  // (tools/bnact_bench.py: 102400 x 128 19.5 us, 25600 x 512 24.2 us for 52 MB)
-  long rpt = rows / ((long)groups * 1024);
-  rpt = rpt < 8 ? 8 : rpt > 32 ? 32 : (rpt + 3) / 4 * 4;
-  long blocks = (rows + groups * rpt - 1) / (groups * rpt);
+  long blocks = (rows + groups * 32L - 1) / (groups * 32L);
   blocks = blocks < 1 ? 1 : blocks > 2048 ? 2048 : blocks;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define LY_RED(A) hipLaunchKernelGGL((ly_bnact_bwd_reduce_kernel<T, A>), dim3((unsigned)blocks), dim3(LY_THREADS), 0, st, dy, lddy, u, ldu, rows, C, a, b, sums)

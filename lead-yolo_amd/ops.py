@@ -71,11 +71,13 @@ def pick_conv_tile(h, w, max_px=128, max_frame=192):
 MLP_WIDTHS = (16, 24, 40, 80, 160, 320)     # C values ly_mlpblock_fwd is instantiated for (include/lead_yolo_hip.h)
 
 
-def mlp_config(c, m, w):
+def mlp_config(c, m, w, bf16=False):
     """(C, NT, HT, T2D) of the kernel ly_mlpblock_fwd launches -- mirrors dispatch_nt in csrc/ly_mlpblock.hip"""
     ht = {16: 2, 24: 4, 40: 2, 80: 2, 160: 4, 320: 4}[c]
     ntmax = {16: 4, 24: 4, 40: 4, 80: 2, 160: 2, 320: 1}[c]
     if c >= 80:
+        if c == 80 and bf16 and m >= 384 * 256:
+            return c, 4, ht, "false"
         return c, (2 if ntmax >= 2 and m >= 200 * 128 else 1), ht, "false"
     if w % 16 == 0 and w >= 64 and ntmax >= 2:
         return c, 2, ht, "true"
@@ -505,7 +507,7 @@ def detect_head_bwd(dp, n, h, w, na, no, du, ldu, dbias):
 
 def mlpblock(x, y, n, h, w, c, wp, w1, w2, sc, sh, stats=None):
     m = n * h * w
-    cc, nt, ht, t2d = mlp_config(c, m, w)
+    cc, nt, ht, t2d = mlp_config(c, m, w, x.dtype == torch.bfloat16)
     kind = "_ring" if c >= 80 else "_occ4" if (c <= 24 and t2d == "true") else ""
     name = f"ly_mlpblock_fwd{kind}_kernel<{_tname(x)}, {cc}, {nt}, {ht}, {t2d}, {'true' if stats is not None else 'false'}>"
     with _Timed(name, 2.0 * m * (9 * (c // 4) ** 2 + 4 * c * c),

@@ -13,8 +13,11 @@ the whole forward capturable."""
 import torch
 
 
-def _pick_parts(bs):
-    for p in (4, 2):
+def _pick_parts(bs, dtype=torch.float32):
+    """sub-batches that run side by side (tools/parts_bench.py, lead-yolo-s 640 x 640 bs = 32: fp32 1 / 2 / 4 / 8 parts 1.71 / 1.56 / 1.55 / 2.10 ms,
+    bf16 1.13 / 1.05 / 1.10 / 1.59 ms — the bf16 kernels are half as long, so two streams already fill their tails and four start to split
+    launches below a full wave of blocks)"""
+    for p in ((2,) if dtype == torch.bfloat16 else (4, 2)):
         if bs % p == 0 and bs // p >= 4:
             return p
     return 1
@@ -30,7 +33,7 @@ class GraphedForward:
         self.model = model
         self.x = example.clone()
         bs = example.shape[0]
-        self.parts = parts = _pick_parts(bs) if parts is None else parts
+        self.parts = parts = _pick_parts(bs, example.dtype) if parts is None else parts
         if bs % parts:
             raise ValueError(f"batch {bs} is not divisible into {parts} sub-batches")
         xs = list(self.x.chunk(parts, 0))

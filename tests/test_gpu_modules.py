@@ -295,7 +295,7 @@ def test_graphed_forward_matches_eager_bf16_full_batch():
     m = m.to(_dev()).eval()
     x = (synth.synth_images(32, 640, 5).float() / 255).to(_dev()).to(torch.bfloat16)
     g = L.GraphedForward(m, x)
-    assert g.parts == 4 and ops.CONCURRENT_PARTS == 1
+    assert g.parts == 2 and ops.CONCURRENT_PARTS == 1
     with torch.no_grad():
         ze, pe = m(x)
     zg, pg = g(x)

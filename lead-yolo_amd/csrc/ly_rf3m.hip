@@ -432,6 +432,7 @@ extern "C" int ly_rf3m_fwd(const LyRfcbam3Params* p, void* stream) {
 // lane l always carries channel group l & 1 of the chunk (8 channels), so 8 running sums per lane and one 32-lane shuffle tree per chunk.
 // LDS: ring [2][24 KiB] | 8 x x tile
 // ---------------------------------------------------------------------------------------------------
+template <int DBG>
 __global__ __launch_bounds__(RM_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void ly_rf3m_stats_kernel(const __bf16* __restrict__ x, int ldx, int n_img, int H,
                                                                                                               int W, int C, int Ho, int Wo, int s, int TH, int TW,
                                                                                                               int nct, int nrt, const void* __restrict__ wst,
@@ -487,8 +488,10 @@ __global__ __launch_bounds__(RM_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
   for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
 
   // pooling sums of chunk `cc` from the staging registers (which hold that chunk), then the registers go to the wave's x tile
+  // development (DBG, timing only): 1 no pooling sums, 2 no channel reductions, 4 no LDS reads in the loop, 8 no chunk boundary (copies, waits, barrier)
   auto pool_and_store = [&](int cc) {
     f32x2 ps[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+    if constexpr (!(DBG & 1))
 #pragma unroll
     for (int e = 0; e < RM_NV; ++e) {
       const bool o = (own >> e) & 1u;
@@ -498,7 +501,7 @@ __global__ __launch_bounds__(RM_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         ps[k] += (f32x2){__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xffff0000u)};
       }
     }
-    if (part && cc < NCH) {
+    if (part && cc < NCH && !(DBG & 1)) {
 #pragma unroll
       for (int k = 0; k < 4; ++k)
 #pragma unroll
@@ -535,7 +538,7 @@ __global__ __launch_bounds__(RM_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
       for (int f = 0; f < RM_GF; ++f) Gc[f] = G[f];
 #pragma unroll
       for (int st = 0; st < 3; ++st) Bc[st] = Bp[st];
-      if (j == RM_UNITS - 1) {
+      if (j == RM_UNITS - 1 && !(DBG & 8)) {
         // chunk boundary: the chunk's last patches and fragments are in registers.  The x tile takes the next chunk (whose pooling sums
         // leave from the staging registers); behind the barrier this chunk's ring buffer takes the chunk after next
         pool_and_store(ch + 1);
@@ -545,7 +548,7 @@ __global__ __launch_bounds__(RM_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         rm_stage_load(St, x, ch + 2 < NCH ? (ch + 2) * RM_CB : 0);
         __builtin_amdgcn_sched_barrier(0);
       }
-      {
+      if constexpr (!(DBG & 4)) {
         const int jn = (j + 1) & (RM_UNITS - 1);
         const char* rn = ((((j == RM_UNITS - 1) ? ch + 1 : ch) & 1) ? rl1 : rl0) + jn * RM_GF * 1024;
 #pragma unroll
@@ -559,11 +562,15 @@ __global__ __launch_bounds__(RM_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
       for (int st = 0; st < 3; ++st) d8 = rm_mfma(Gc[3 + st], Bc[st], d8);
       // rows 8g + 4h + i = (channel 4j + g, tap 4h + i): fold the 4 channels into the lane's running max / sum of taps 4h .. 4h+3
+      if constexpr (DBG & 2) {
+        mx[0] = fmaxf(mx[0], d[0]);
+      } else {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float r0 = fmaxf(d[i], 0.f), r1 = fmaxf(d[4 + i], 0.f), r2 = fmaxf(d[8 + i], 0.f), r3 = fmaxf(d[12 + i], 0.f);
         mx[i] = fmaxf(fmaxf(mx[i], r0), fmaxf(fmaxf(r1, r2), r3));
         sm[i >> 1][i & 1] += (r0 + r1) + (r2 + r3);
+      }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -603,8 +610,18 @@ extern "C" int ly_rf3m_stats(const void* x, int ldx, int n_img, int H, int W, in
   LY_CHECK(!part || slices == nct * nrt, "rf3m_stats: the pooling partials are one row per tile: slices must be %d", nct * nrt);
   const long tiles = (long)n_img * nrt * nct;
   const size_t lds = (size_t)2 * RM_UNITS * RM_GF * 1024 + RM_WAVES * (size_t)RM_XTILE;
-  auto k = ly_rf3m_stats_kernel;
+  auto k = ly_rf3m_stats_kernel<0>;
+  static const int sdbg = getenv("LY_RM_SDBG") ? atoi(getenv("LY_RM_SDBG")) : 0;     // development: ablations of the loop (timing only)
+  switch (sdbg) {
+    case 1: k = ly_rf3m_stats_kernel<1>; break;
+    case 2: k = ly_rf3m_stats_kernel<2>; break;
+    case 4: k = ly_rf3m_stats_kernel<4>; break;
+    case 8: k = ly_rf3m_stats_kernel<8>; break;
+    case 15: k = ly_rf3m_stats_kernel<15>; break;
+    default: break;
+  }
   static bool configured = false;
+  if (sdbg) configured = false;
   if (!configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     LY_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));

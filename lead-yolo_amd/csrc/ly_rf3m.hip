@@ -428,8 +428,8 @@ extern "C" int ly_rf3m_fwd(const LyRfcbam3Params* p, void* stream) {
 // statistics pass: mm[n, 3oy + t/3, 3ox + t%3] = [max_c, mean_c] of G, and the SE pooling partials part[n][tile][C] (the sum of the tile's OWN
 // input positions per channel: every input position belongs to exactly one tile).  Same generate products as the contraction kernel; the
 // channel reductions run in the accumulator layout: a lane holds, for ITS pixel, 4 channels x 4 taps per tile — max / sum over the channel
-// index are register operations, the two half waves meet once per tile walk for tap 8.  The pooling sums come out of the staging registers:
-// lane l always carries channel group l & 1 of the chunk (8 channels), so 8 running sums per lane and one 32-lane shuffle tree per chunk.
+// index are register operations, the two half waves meet once per tile walk for tap 8.  The pooling sums are one more product: spare rows of
+// the tap-8 tile hold ones over the patch slots a pixel owns (the statistics stream is packed with pool_stride), one 32-lane tree per chunk.
 // LDS: ring [2][24 KiB] | 8 x x tile
 // ---------------------------------------------------------------------------------------------------
 template <int DBG>
@@ -466,20 +466,6 @@ __global__ __launch_bounds__(RM_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
   int bo[3][2];
   rm_patch_offsets(bo, lane, s, TH, TW);
   if (lane < RM_PS / 8) *reinterpret_cast<ly_u32x2*>(xs + RM_MAXPOS * RM_PS + 8 * lane) = (ly_u32x2){0x3F803F80u, 0x3F803F80u};
-  // which of the lane's staging items are input positions OWNED by a pixel of the tile: rows / columns 1 .. s*TH / s*TW of the tile's input
-  // window (pixel (oy, ox) owns inputs (s oy + dy, s ox + dx), dy, dx < s), inside the image, of output pixels inside the map
-  unsigned own = 0;
-  {
-    const int IW = s * (TW - 1) + 3, IH = s * (TH - 1) + 3;
-#pragma unroll
-    for (int e = 0; e < RM_NV; ++e) {
-      const int ip = (lane + 64 * e) >> 1;
-      const int r = ip / IW, q = ip - r * IW;
-      const bool ok = T.valid && ip < IH * IW && r >= 1 && q >= 1 && r <= s * TH && q <= s * TW && St.soff[e] >= 0 && T.oy0 + (r - 1) / s < Ho && T.ox0 + (q - 1) / s < Wo;
-      own |= ok ? (1u << e) : 0u;
-    }
-  }
-
   float mx[4] = {0.f, 0.f, 0.f, 0.f}, mx8 = 0.f;       // G >= 0: zero is the identity of the channel maximum
   f32x2 sm[2] = {{0.f, 0.f}, {0.f, 0.f}};
   float sm8 = 0.f;
@@ -487,36 +473,34 @@ __global__ __launch_bounds__(RM_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
   for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
 
-  // pooling sums of chunk `cc` from the staging registers (which hold that chunk), then the registers go to the wave's x tile
-  // development (DBG, timing only): 1 no pooling sums, 2 no channel reductions, 4 no LDS reads in the loop, 8 no chunk boundary (copies, waits, barrier)
-  auto pool_and_store = [&](int cc) {
-    f32x2 ps[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-    if constexpr (!(DBG & 1))
+  // SE pooling (models/rfa.py:90): rows 16 .. 31 of the tap-8 tile carry ones over the patch slots a pixel OWNS (pack.rf3m_stream,
+  // pool_stride), so d8[8 + k] is, per pixel lane, the sum of its own input positions for channel 4h + k (k < 4) / 8 + 4h + k - 4 of the
+  // chunk: one masked 32-lane tree per chunk and the tile's row of `part` is complete.  (Until round 4 the sums were taken out of the
+  // staging registers — bit extraction, selects and packed adds per 16-byte item: 14.5 of the kernel's 74 us at layer 17.)
+  const bool lane_px = (lane & 31) < TH * TW;
+  auto pool_store = [&](const f32x16& d8v, int cc) {
+    if constexpr (DBG & 1) return;
+    if (!part) return;
+    // reduce-scatter butterfly over the 32 pixel lanes of a half wave: 4 + 2 + 1 + 1 + 1 cross-lane moves instead of 8 x 5 (each is an LDS-pipe
+    // instruction: the plain tree cost as much as the staging-register arithmetic it replaced); lane 4 j of a half ends up with value j
+    float pv[8];
 #pragma unroll
-    for (int e = 0; e < RM_NV; ++e) {
-      const bool o = (own >> e) & 1u;
+    for (int k = 0; k < 8; ++k) pv[k] = lane_px ? d8v[8 + k] : 0.f;
+    float a4[4], b2[2];
+    const bool u16 = lane & 16, u8 = lane & 8, u4 = lane & 4;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const unsigned u = o ? St.pv[e][k] : 0u;
-        ps[k] += (f32x2){__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xffff0000u)};
-      }
+    for (int k = 0; k < 4; ++k) a4[k] = (u16 ? pv[k + 4] : pv[k]) + __shfl_xor(u16 ? pv[k] : pv[k + 4], 16);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) b2[k] = (u8 ? a4[k + 2] : a4[k]) + __shfl_xor(u8 ? a4[k] : a4[k + 2], 8);
+    float c1 = (u4 ? b2[1] : b2[0]) + __shfl_xor(u4 ? b2[0] : b2[1], 4);
+    c1 += __shfl_xor(c1, 2);
+    c1 += __shfl_xor(c1, 1);
+    if ((lane & 3) == 0 && T.valid) {
+      const int idx = ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);      // value index: channel 4h + idx (idx < 4) / 8 + 4h + idx - 4
+      part[wt * C + cc * RM_CB + (idx < 4 ? 4 * h + idx : 4 + 4 * h + idx)] = c1;
     }
-    if (part && cc < NCH && !(DBG & 1)) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-#pragma unroll
-        for (int d = 2; d < 64; d <<= 1) {
-          ps[k][0] += __shfl_xor(ps[k][0], d);
-          ps[k][1] += __shfl_xor(ps[k][1], d);
-        }
-      if (lane < 2 && T.valid) {
-        float* dst = part + (wt * C + cc * RM_CB + 8 * lane);
-        *reinterpret_cast<f32x4*>(dst) = (f32x4){ps[0][0], ps[0][1], ps[1][0], ps[1][1]};
-        *reinterpret_cast<f32x4*>(dst + 4) = (f32x4){ps[2][0], ps[2][1], ps[3][0], ps[3][1]};
-      }
-    }
-    rm_stage_store(St, xs, lane);
   };
+  auto pool_and_store = [&](int) { rm_stage_store(St, xs, lane); };
   // software pipeline as in the contraction kernel: unit j issues the reads of unit j + 1 before its own MFMAs
   pool_and_store(0);
   rm_wait_vm<0>();
@@ -581,6 +565,7 @@ __global__ __launch_bounds__(RM_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
       mx8 = fmaxf(fmaxf(mx8, r0), fmaxf(fmaxf(r1, r2), r3));
       sm8 += (r0 + r1) + (r2 + r3);
     }
+    pool_store(d8, ch);
   }
   mx8 = fmaxf(mx8, __shfl_xor(mx8, 32));
   sm8 += __shfl_xor(sm8, 32);

@@ -594,7 +594,7 @@ class RFCBAMConv(nn.Module):
                 d["wq_c"] = pack.rfcbam_gen_weights_c(gw, gs, gb)
                 d["wp_c"] = self._wp_c(planes)
             if planes == 1 and c % 32 == 0 and o % 64 == 0 and RF3M:
-                d["wm_stats"] = pack.rf3m_stream(gw, gs, gb)                                   # csrc/ly_rf3m.hip: generate on the matrix cores
+                d["wm_stats"] = pack.rf3m_stream(gw, gs, gb, pool_stride=self.stride)          # csrc/ly_rf3m.hip: generate on the matrix cores
                 d["wm"] = pack.rf3m_stream(gw, gs, gb, cw.weight, 4 if o % 128 == 0 else 2)
             return d
         return self._prep.get(key, build, planes)

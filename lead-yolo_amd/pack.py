@@ -123,7 +123,7 @@ def rfcbam_gen_weights_c(gen_w, scale, shift, raw=False):
     return out.view(c // 32, 32, 25, 4).permute(0, 2, 1, 3).contiguous().view(-1)
 
 
-def rf3m_stream(gen_w, scale, shift, conv_w=None, mt=4):
+def rf3m_stream(gen_w, scale, shift, conv_w=None, mt=4, pool_stride=None):
     """Weight stream of csrc/ly_rf3m.hip (RFCBAMConv k=3, `generate` on the matrix cores; models/rfa.py:101-106, 110, 121-128): every A fragment
     of v_mfma_f32_32x32x16_bf16 (64 lanes x 8 bf16 = 1 KiB; lane = (row r = lane & 31, half h = lane >> 5), element e <-> k = 8h + e) in the
     order the kernel consumes them, bf16.
@@ -136,7 +136,10 @@ def rf3m_stream(gen_w, scale, shift, conv_w=None, mt=4):
       [conv_w given] 2 x mt main fragments: conv.0.weight[o, c, t] with o = 32 (g mt + m) + r and (c, t) = the generated row
         16 s2 + 8 (e//4) + 4h + e%4 of the unit's tile (the accumulator layout the generate product leaves in registers);
     then [conv_w given] mt main fragments for the tap-8 tile (one k-step: rows 8 (e//4) + 4h + e%4 = channels of the chunk).
-    conv_w None: the statistics stream (generate fragments only).
+    conv_w None: the statistics stream (generate fragments only).  With pool_stride = s (the statistics stream) rows 16 .. 31 of the tap-8
+    tile — unused by the generate — carry the SE POOLING: row 16 + r (channel r of the chunk) holds 1.0 at the patch slots of the input
+    positions an output pixel OWNS ((s oy + dy, s ox + dx), dy, dx < s: slots 4, 5, 7, 8 at stride 2, slot 4 at stride 1), so the product
+    leaves, per pixel, the sum of its own inputs per channel (models/rfa.py:90's average pool, before the division).
     Returns bf16 [gy][chunks][fragments][64][8] (gy = O / (32 mt) blocks of output channels; 1 for the statistics stream)."""
     dev = gen_w.device
     c_in = gen_w.shape[0] // 9
@@ -155,6 +158,15 @@ def rf3m_stream(gen_w, scale, shift, conv_w=None, mt=4):
     zero = torch.zeros((), dtype=torch.float32, device=dev)
     gen = torch.where(cs == (R >> 3), wx[16 * CH + 4 * J + (R >> 3), R & 7, us], zero)                      # [nch, 4, 3, 64, 8]
     gen8 = torch.where((R < 16) & ((R >> 2) == J) & (cs == (R & 3)), wx[16 * CH + (R & 15) + 0 * J, 8, us], zero)
+    if pool_stride is not None:
+        if conv_w is not None or pool_stride not in (1, 2):
+            raise ValueError("rf3m_stream: pooling rows belong to the statistics stream, stride 1 or 2")
+        owned = torch.zeros(12, dtype=torch.bool, device=dev)
+        owned[[4, 5, 7, 8] if pool_stride == 2 else [4]] = True
+        Rp = R - 16
+        one = torch.ones((), dtype=torch.float32, device=dev)
+        pool = torch.where((R >= 16) & ((Rp >> 2) == J) & (cs == (Rp & 3)) & owned[us] & (CH >= 0), one, zero)
+        gen8 = gen8 + pool
     genf = torch.cat((gen, gen8), 2)                                                                        # [nch, 4, 6, 64, 8]
     if conv_w is None:
         return genf.reshape(1, nch, 24, 64, 8).to(torch.bfloat16).contiguous()

@@ -912,9 +912,15 @@ __global__ __launch_bounds__(LY_THREADS) void ly_coordatt_conv1_stats_kernel(con
   __shared__ float red[4][2 * MIPMAX];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float a1 = 0.f, a2 = 0.f;
-  const float bm = lane < mip ? b1[lane] : 0.f;
+  // the lane that accumulates output m: lane m on the general path; on the fast path the reduce-scatter leaves output m in lane m * (64 / MIPMAX)
+  constexpr bool FASTP = MIPMAX <= 16;
+  constexpr int LSTEP = FASTP ? 64 / MIPMAX : 1;
+  const bool fast = FASTP && C <= 256;
+  const int mine = fast ? lane / LSTEP : lane;
+  const bool owner = (fast ? (lane % LSTEP) == 0 : true) && mine < mip;
+  const float bm = owner ? b1[mine] : 0.f;
   const long nw = (long)gridDim.x * 4;
-  if (MIPMAX <= 16 && C <= 256) {
+  if constexpr (FASTP) if (fast) {
     // the lane's weights stay in registers over all positions, and two positions per trip have all their loads issued before the first use
     // (the one-position loop re-read w1 and paid a dependent round trip per position: 23 us for 2.6 MB)
     constexpr int KC = 4;
@@ -941,17 +947,17 @@ __global__ __launch_bounds__(LY_THREADS) void ly_coordatt_conv1_stats_kernel(con
           y[m] = 0.f;
 #pragma unroll
           for (int k = 0; k < KC; ++k) y[m] += wreg[k][m] * pv[u][k];
-#pragma unroll
-          for (int o = 32; o > 0; o >>= 1) y[m] += __shfl_xor(y[m], o);
-          if (lane == m && live) {
-            const float v = y[m] + bm;
-            a1 += v;
-            a2 += v * v;
-          }
+        }
+        ly_reduce_scatter<MIPMAX>(y, lane);                 // MIPMAX - 1 + log2(64 / MIPMAX) cross-lane moves instead of 6 MIPMAX
+        if (owner && live) {
+          const float v = y[0] + bm;
+          a1 += v;
+          a2 += v * v;
         }
       }
     }
-  } else {
+  }
+  if (!fast) {
   for (long pos = (long)blockIdx.x * 4 + wave; pos < positions; pos += nw) {
     const float* p = pool + pos * C;
     float y[MIPMAX];
@@ -975,7 +981,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_coordatt_conv1_stats_kernel(con
     }
   }
   }
-  if (lane < mip) { red[wave][lane] = a1; red[wave][MIPMAX + lane] = a2; }
+  if (owner) { red[wave][mine] = a1; red[wave][MIPMAX + mine] = a2; }
   __syncthreads();
   if (wave == 0 && lane < mip) {
     atomicAdd(stats + lane, (double)((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])));
@@ -1205,7 +1211,12 @@ __global__ __launch_bounds__(LY_THREADS) void ly_coordatt_mlp_bwd1_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int L = H + W;
   const long R = (long)n_img * L;
-  float s1 = 0.f, s2 = 0.f;                                // lane m < MIP: sum dy1[m], sum dy1[m]*xh[m]
+  float s1 = 0.f, s2 = 0.f;                                // the lane that owns output m: sum dy1[m], sum dy1[m]*xh[m]
+  static_assert(MIP == 8 || MIP == 16, "ly_coordatt_mlp_bwd1: MIP = 8 or 16");
+  constexpr int LSTEP = 64 / MIP;
+  const int mine = lane / LSTEP;
+  const bool owner = (lane % LSTEP) == 0;
+  const float b1m = b1[mine], meanm = mean[mine], invm = invstd[mine], gm = gamma[mine], bem = beta[mine];
   const long nw = (long)gridDim.x * 4;
   for (long r = (long)blockIdx.x * 4 + wave; r < R; r += nw) {
     const long n = r / L;
@@ -1233,32 +1244,25 @@ __global__ __launch_bounds__(LY_THREADS) void ly_coordatt_mlp_bwd1_kernel(
         }
       }
     }
-#pragma unroll
-    for (int m = 0; m < MIP; ++m) {
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        y[m] += __shfl_xor(y[m], o);
-        d[m] += __shfl_xor(d[m], o);
-      }
-    }
-#pragma unroll
-    for (int m = 0; m < MIP; ++m) {
-      const float xh = (y[m] + b1[m] - mean[m]) * invstd[m];
-      const float y1 = gamma[m] * xh + beta[m];
-      const float g = d[m] * ly_hswish_grad(y1);
-      if (lane == m) {
-        s1 += g;
-        s2 += g * xh;
-        ws[r * 3 * MIP + m] = g;
-        ws[r * 3 * MIP + MIP + m] = xh;
-        ws[r * 3 * MIP + 2 * MIP + m] = ly_hswish(y1);
-      }
+    // both length-C reductions as reduce-scatters (ly_common.hpp): 2 (MIP - 1 + log2(64 / MIP)) cross-lane moves per position instead of 12 MIP;
+    // output m ends up in lane m * (64 / MIP), which keeps its running sums
+    ly_reduce_scatter<MIP>(y, lane);
+    ly_reduce_scatter<MIP>(d, lane);
+    if (owner) {
+      const float xh = (y[0] + b1m - meanm) * invm;
+      const float y1 = gm * xh + bem;
+      const float g = d[0] * ly_hswish_grad(y1);
+      s1 += g;
+      s2 += g * xh;
+      ws[r * 3 * MIP + mine] = g;
+      ws[r * 3 * MIP + MIP + mine] = xh;
+      ws[r * 3 * MIP + 2 * MIP + mine] = ly_hswish(y1);
     }
   }
-  if (lane < MIP) {
+  if (owner) {
     double* st = sums + ((blockIdx.x * 4 + wave) & (LY_CA_STRIPES - 1)) * 2 * MIP;      // double accumulators: see ly_stats_flush (ly_common.hpp)
-    atomicAdd(st + lane, (double)s1);
-    atomicAdd(st + MIP + lane, (double)s2);
+    atomicAdd(st + mine, (double)s1);
+    atomicAdd(st + MIP + mine, (double)s2);
   }
 }
 

@@ -71,8 +71,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_coordatt_mlp_kernel(const float
   for (int m = wave; m < mip; m += 4) {
     float s = 0.f;
     for (int c = lane; c < C; c += 64) s += w1[m * C + c] * p[c];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    s = ly_group_sum(s, 64);
     if (lane == 0) ys[m] = ly_hswish(sc ? (s + b1[m]) * sc[m] + sh[m] : s + b1[m]);
   }
   __syncthreads();
@@ -188,8 +187,7 @@ __device__ __forceinline__ void ly_se_mlp_body(float* sm, const int n, const flo
   for (int r = wave; r < R; r += 4) {
     float s = 0.f;
     for (int c = lane; c < C; c += 64) s += wap[r * C + c] * g[c];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    s = ly_group_sum(s, 64);
     if (lane == 0) hid[r] = fmaxf(s, 0.f);
   }
   __syncthreads();
@@ -254,11 +252,8 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_stats1_kernel(const T* _
         sm += g;
       }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      mx = fmaxf(mx, __shfl_xor(mx, o));
-      sm += __shfl_xor(sm, o);
-    }
+    mx = ly_group_max(mx, 64);                              // (in-row steps as DPP moves: ly_common.hpp)
+    sm = ly_group_sum(sm, 64);
     if (lane == 0) {
       mm[2 * p] = mx;
       mm[2 * p + 1] = sm * inv;
@@ -308,11 +303,8 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_pre1_kernel(const T* __r
         }
       }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      mx = fmaxf(mx, __shfl_xor(mx, o));
-      sm += __shfl_xor(sm, o);
-    }
+    mx = ly_group_max(mx, 64);                              // (in-row steps as DPP moves: ly_common.hpp)
+    sm = ly_group_sum(sm, 64);
     if (lane == 0) {
       mm[2 * p] = mx;
       mm[2 * p + 1] = sm * inv;
@@ -1546,8 +1538,8 @@ __global__ __launch_bounds__(LY_THREADS) void ly_se_bwd_kernel(const float* __re
       s += wa[r * C + c] * g[c];
       d += wb[c * R + r] * dz[c];
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); d += __shfl_xor(d, o); }
+    s = ly_group_sum(s, 64);
+    d = ly_group_sum(d, 64);
     if (lane == 0) {
       hid[r] = fmaxf(s, 0.f);
       dh[r] = s > 0.f ? d : 0.f;

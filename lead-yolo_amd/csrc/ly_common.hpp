@@ -135,6 +135,45 @@ __device__ __forceinline__ void ly_l2_warm(const void* base, long bytes, float* 
   if (acc == 1.2345678e-30f) *sink = acc;
 }
 
+// All-reduce (sum / max) over aligned groups of G lanes (G a power of two, 2 .. 64): every lane ends with its group's result.  The four
+// steps inside a 16-lane row are DPP moves on the vector ALU (quad_perm xor 1, xor 2, row_half_mirror, row_mirror: after the first two a quad
+// is uniform, so mirroring — which pairs lanes of different quads / different 8-lane halves — reduces like xor 4 / xor 8 would); only rows
+// meet through the LDS pipe (ds_bpermute: ~100 cycles of latency per step where a DPP add is one ALU instruction).
+template <int CTRL> __device__ __forceinline__ float ly_dpp_mov(const float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// the value of lane l ^ M: inside a 16-lane row (M = 1, 2, 4, 8) as DPP moves — quad_perm for 1 and 2, a row rotation by 8 for 8, and for 4 a
+// shift left by 4 into the lanes with bit 2 clear plus a shift right by 4 into the others (bank masks) — across rows through the LDS pipe
+template <int M> __device__ __forceinline__ float ly_lane_xor(const float v) {
+  if constexpr (M == 1) return ly_dpp_mov<0xB1>(v);
+  else if constexpr (M == 2) return ly_dpp_mov<0x4E>(v);
+  else if constexpr (M == 8) return ly_dpp_mov<0x128>(v);                // row_ror:8
+  else if constexpr (M == 4) {
+    const int b = __builtin_bit_cast(int, v);
+    int r = __builtin_amdgcn_update_dpp(0, b, 0x104, 0xf, 0x5, false);       // row_shl:4 -> lanes 0-3, 8-11 of a row take lane + 4
+    r = __builtin_amdgcn_update_dpp(r, b, 0x114, 0xf, 0xA, false);           // row_shr:4 -> lanes 4-7, 12-15 take lane - 4
+    return __builtin_bit_cast(float, r);
+  } else return __shfl_xor(v, M);
+}
+__device__ __forceinline__ float ly_group_sum(float v, const int G) {
+  if (G >= 2) v += ly_dpp_mov<0xB1>(v);
+  if (G >= 4) v += ly_dpp_mov<0x4E>(v);
+  if (G >= 8) v += ly_dpp_mov<0x141>(v);
+  if (G >= 16) v += ly_dpp_mov<0x140>(v);
+  if (G >= 32) v += __shfl_xor(v, 16);
+  if (G >= 64) v += __shfl_xor(v, 32);
+  return v;
+}
+__device__ __forceinline__ float ly_group_max(float v, const int G) {
+  if (G >= 2) v = fmaxf(v, ly_dpp_mov<0xB1>(v));
+  if (G >= 4) v = fmaxf(v, ly_dpp_mov<0x4E>(v));
+  if (G >= 8) v = fmaxf(v, ly_dpp_mov<0x141>(v));
+  if (G >= 16) v = fmaxf(v, ly_dpp_mov<0x140>(v));
+  if (G >= 32) v = fmaxf(v, __shfl_xor(v, 16));
+  if (G >= 64) v = fmaxf(v, __shfl_xor(v, 32));
+  return v;
+}
+
 // Batch-statistics pass support: a lane holds 4 consecutive channels (c .. c+3) of some pixels; sum the
 // two 4-vectors over the 16 lanes that share lq (lanes differing in l&15) and let lane l&15 == 0 add them
 // to stats[c + r] (sum) and stats[nch + c + r] (sum of squares).
@@ -149,12 +188,9 @@ __device__ __forceinline__ void ly_l2_warm(const void* base, long bytes, float* 
 #define LY_STATS_STRIPES 32
 __device__ __forceinline__ void ly_stats_flush(double* __restrict__ stats, int nch, int c, f32x4 s1, f32x4 s2) {
 #pragma unroll
-  for (int o = 8; o > 0; o >>= 1) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      s1[r] += __shfl_xor(s1[r], o);
-      s2[r] += __shfl_xor(s2[r], o);
-    }
+  for (int r = 0; r < 4; ++r) {
+    s1[r] = ly_group_sum(s1[r], 16);
+    s2[r] = ly_group_sum(s2[r], 16);
   }
   if ((threadIdx.x & 15) == 0) {
     double* st = stats + (size_t)(blockIdx.x & (LY_STATS_STRIPES - 1)) * 2 * nch;
@@ -180,11 +216,11 @@ __device__ __forceinline__ void ly_rs_step(float (&v)[N], const int lane) {
 #pragma unroll
     for (int k = 0; k < HALF; ++k) {
       const float keep = up ? v[k + HALF] : v[k], send = up ? v[k] : v[k + HALF];
-      v[k] = keep + __shfl_xor(send, MASK);
+      v[k] = keep + ly_lane_xor<MASK>(send);
     }
     ly_rs_step<HALF, MASK / 2, N>(v, lane);
   } else if constexpr (MASK > 0) {
-    v[0] += __shfl_xor(v[0], MASK);
+    v[0] += ly_lane_xor<MASK>(v[0]);
     ly_rs_step<1, MASK / 2, N>(v, lane);
   }
 }

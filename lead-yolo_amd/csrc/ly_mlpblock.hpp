@@ -327,12 +327,10 @@ __device__ __forceinline__ void ly_mlpblock_body(
             s2 += acch[t][n] * acch[t][n];
           }
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            s1[r] += __shfl_xor(s1[r], o);
-            s2[r] += __shfl_xor(s2[r], o);
-          }
+        for (int r = 0; r < 4; ++r) {
+          s1[r] = ly_group_sum(s1[r], 16);
+          s2[r] = ly_group_sum(s2[r], 16);
+        }
         if (li == 0) {
           const int ch = (hc * HT + t) * 16 + 4 * lq;
 #pragma unroll

@@ -95,10 +95,8 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf1_bwd_kernel(const LyRf1BwdPa
             cdv[q][r] = G * cav[q][r] * rf[u];
           }
         }
-        for (int o = lpp2 >> 1; o > 0; o >>= 1) {
-          srfa += __shfl_xor(srfa, o);
-          mx = fmaxf(mx, __shfl_xor(mx, o));
-        }
+        srfa = ly_group_sum(srfa, lpp2);                      // (in-row steps on the vector ALU: ly_common.hpp)
+        mx = ly_group_max(mx, lpp2);
         if (on) *reinterpret_cast<RV*>(reinterpret_cast<T*>(P.cd) + m * C + cv) = ly_rv_pack(cdv, (RV*)nullptr);
         if (live[u] && l == 0) { P.d_rfa[m] = srfa; P.gmax_out[m] = mx; }
       } else {
@@ -272,10 +270,8 @@ __global__ __launch_bounds__(576) void ly_rf3s_bwd_kernel(const LyRf1BwdParams P
             acc1[q][r] += tt * rf[u];
             ov[q][r] = G * cav[q][r] * rf[u];
           }
-        for (int o = lpp2 >> 1; o > 0; o >>= 1) {
-          srfa += __shfl_xor(srfa, o);
-          mx = fmaxf(mx, __shfl_xor(mx, o));
-        }
+        srfa = ly_group_sum(srfa, lpp2);                      // (in-row steps on the vector ALU: ly_common.hpp)
+        mx = ly_group_max(mx, lpp2);
         if (on) *reinterpret_cast<RV*>(reinterpret_cast<T*>(P.cd) + row[u]) = ly_rv_pack(ov, (RV*)nullptr);
         if (live[u] && l == 0) { P.d_rfa[pos[u]] = srfa; P.gmax_out[pos[u]] = mx; }
       } else {

@@ -481,20 +481,21 @@ __global__ __launch_bounds__(RM_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
   auto pool_store = [&](const f32x16& d8v, int cc) {
     if constexpr (DBG & 1) return;
     if (!part) return;
-    // reduce-scatter butterfly over the 32 pixel lanes of a half wave: 4 + 2 + 1 + 1 + 1 cross-lane moves instead of 8 x 5 (each is an LDS-pipe
-    // instruction: the plain tree cost as much as the staging-register arithmetic it replaced); lane 4 j of a half ends up with value j
+    // reduce-scatter butterfly over the 32 pixel lanes of a half wave: 4 + 2 + 1 + 1 + 1 cross-lane moves instead of 8 x 5, and only the first
+    // four (across 16-lane rows) go through the LDS pipe (the plain tree of ds_bpermute cost as much as the staging-register arithmetic it
+    // replaced); lane 4 j of a half ends up with value j
     float pv[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) pv[k] = lane_px ? d8v[8 + k] : 0.f;
     float a4[4], b2[2];
     const bool u16 = lane & 16, u8 = lane & 8, u4 = lane & 4;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) a4[k] = (u16 ? pv[k + 4] : pv[k]) + __shfl_xor(u16 ? pv[k] : pv[k + 4], 16);
+    for (int k = 0; k < 4; ++k) a4[k] = (u16 ? pv[k + 4] : pv[k]) + ly_lane_xor<16>(u16 ? pv[k] : pv[k + 4]);
 #pragma unroll
-    for (int k = 0; k < 2; ++k) b2[k] = (u8 ? a4[k + 2] : a4[k]) + __shfl_xor(u8 ? a4[k] : a4[k + 2], 8);
-    float c1 = (u4 ? b2[1] : b2[0]) + __shfl_xor(u4 ? b2[0] : b2[1], 4);
-    c1 += __shfl_xor(c1, 2);
-    c1 += __shfl_xor(c1, 1);
+    for (int k = 0; k < 2; ++k) b2[k] = (u8 ? a4[k + 2] : a4[k]) + ly_lane_xor<8>(u8 ? a4[k] : a4[k + 2]);      // (inside a 16-lane row: DPP moves)
+    float c1 = (u4 ? b2[1] : b2[0]) + ly_lane_xor<4>(u4 ? b2[0] : b2[1]);
+    c1 += ly_lane_xor<2>(c1);
+    c1 += ly_lane_xor<1>(c1);
     if ((lane & 3) == 0 && T.valid) {
       const int idx = ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);      // value index: channel 4h + idx (idx < 4) / 8 + 4h + idx - 4
       part[wt * C + cc * RM_CB + (idx < 4 ? 4 * h + idx : 4 + 4 * h + idx)] = c1;

@@ -51,16 +51,8 @@ static RfGeom rf_geom(int n_img, int H, int W, int C, int k, int s, long pixels,
   return g;
 }
 
-__device__ __forceinline__ float rf_wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
-__device__ __forceinline__ float rf_wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
-}
+__device__ __forceinline__ float rf_wave_sum(float v) { return ly_group_sum(v, 64); }
+__device__ __forceinline__ float rf_wave_max(float v) { return ly_group_max(v, 64); }
 
 // Thread = channel means one element per lane and access: 4 bytes in fp32, but only 2 in bf16 — half-width requests, and the in-place
 // updates become sub-dword read-modify-writes (ly_rf_bwd_relu: 235 us in fp32, 525 us in bf16).  For bf16 the two lanes of an

@@ -49,8 +49,10 @@ enum { LY_GATHER_ROWS = 0,       /* A row m = a0[m, :k0] | a1[m, :K-k0]         
        LY_GATHER_UP2 = 1,        /* a0 is at half resolution: row (n, h/2, w/2)  (nearest 2x upsample) */
        LY_GATHER_PATCH = 2,      /* k x k stride-k patches of an NHWC tensor (PatchMerging)           */
        LY_GATHER_PATCH_NCHW = 3, /* 4 x 4 stride-4 patches of an fp32 NCHW tensor (PatchEmbed on images) */
-       LY_GATHER_PATCH_NCHW_U8 = 4 /* the same on a uint8 NCHW image, pixel/255 on load: the `imgs.float() / 255` of the
-                                      training loop (train.py:309) folded into the patch gather                      */ };
+       LY_GATHER_PATCH_NCHW_U8 = 4, /* the same on a uint8 NCHW image, pixel/255 on load: the `imgs.float() / 255` of the
+                                      training loop (train.py:309) folded into the patch gather                      */
+       LY_GATHER_PATCH_NCHW_BF16 = 5, /* the same on a bf16 / fp16 NCHW image (a0 8-byte aligned; LY_BF16 calls only): the            */
+       LY_GATHER_PATCH_NCHW_F16 = 6   /* `im.half()` batch of a reduced-precision forward (val.py:207) read as it is                  */ };
 enum { LY_PRO_NONE = 0,
        LY_PRO_GATE = 1,              /* a0 part: x * g_w[n,w,:] * g_h[n,h,:] (+ res)  (CoordAtt gating) */
        LY_PRO_AFFINE_RELU_CA = 2     /* relu(x*p_scale + p_shift) * p_ca[n,:]         (RFCBAMConv k=1)  */ };
@@ -76,7 +78,7 @@ typedef struct LyGemmParams {
                              BatchNorm — adds sum / sum-of-squares over the M rows of the pre-activation value
                              (rowscale*e_scale*acc + e_shift) per output channel; stores nothing when out is NULL,
                              otherwise stores act(that value) as usual (one launch for statistics + pre-BN tensor) */
-  int dtype;              /* LY_F32 / LY_BF16: element type T of a0, a1, res, out.  LY_GATHER_PATCH_NCHW(_U8) reads an fp32 (uint8)
+  int dtype;              /* LY_F32 / LY_BF16: element type T of a0, a1, res, out.  LY_GATHER_PATCH_NCHW(_U8 / _BF16 / _F16) reads an fp32 (uint8 / 16-bit)
                              IMAGE whatever dtype is (dtype then only selects the output element type)             */
 } LyGemmParams;
 

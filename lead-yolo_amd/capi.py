@@ -84,7 +84,7 @@ def dtype_code(t):
 
 
 ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
-GATHER_ROWS, GATHER_UP2, GATHER_PATCH, GATHER_PATCH_NCHW, GATHER_PATCH_NCHW_U8 = 0, 1, 2, 3, 4
+GATHER_ROWS, GATHER_UP2, GATHER_PATCH, GATHER_PATCH_NCHW, GATHER_PATCH_NCHW_U8, GATHER_PATCH_NCHW_BF16, GATHER_PATCH_NCHW_F16 = 0, 1, 2, 3, 4, 5, 6
 PRO_NONE, PRO_GATE, PRO_AFFINE_RELU_CA = 0, 1, 2
 
 # name -> argtypes  (every entry point returns int: 0 ok, <0 error with ly_last_error())

@@ -8,12 +8,13 @@ extern "C" int ly_gemm_fwd(const LyGemmParams* p, void* stream) {
   LY_CHECK(p, "gemm: null params");
   const LyGemmParams& P = *p;
   LY_CHECK(P.dtype == LY_F32 || P.dtype == LY_BF16, "gemm: unknown dtype %d", P.dtype);
-  const bool image = P.gather == LY_GATHER_PATCH_NCHW || P.gather == LY_GATHER_PATCH_NCHW_U8;
+  const bool image16 = P.gather == LY_GATHER_PATCH_NCHW_BF16 || P.gather == LY_GATHER_PATCH_NCHW_F16;
+  const bool image = P.gather == LY_GATHER_PATCH_NCHW || P.gather == LY_GATHER_PATCH_NCHW_U8 || image16;
   const int vw = (P.dtype == LY_BF16 && !image) ? 8 : 4;   // elements of one source vector
   LY_CHECK(P.a0 && P.wp && (P.out || P.stats), "gemm: null a0/wp/out");
   LY_CHECK(P.M > 0 && P.K > 0 && P.N > 0 && P.H > 0 && P.W > 0, "gemm: bad sizes M=%ld K=%d N=%d", P.M, P.K, P.N);
   LY_CHECK(P.K % vw == 0, "gemm: K=%d must be a multiple of %d", P.K, vw);
-  LY_CHECK(((uintptr_t)P.a0 & (P.gather == LY_GATHER_PATCH_NCHW_U8 ? 3 : 15)) == 0 && ((uintptr_t)P.a1 & 15) == 0 && ((uintptr_t)P.res & 15) == 0,
+  LY_CHECK(((uintptr_t)P.a0 & (P.gather == LY_GATHER_PATCH_NCHW_U8 ? 3 : image16 ? 7 : 15)) == 0 && ((uintptr_t)P.a1 & 15) == 0 && ((uintptr_t)P.res & 15) == 0,
            "gemm: sources must be 16-byte aligned");
   LY_CHECK(((uintptr_t)P.out & (P.dtype == LY_BF16 ? 7 : 15)) == 0 || (P.ldo & 3) != 0, "gemm: out is misaligned for vector stores");
   if (P.gather == LY_GATHER_ROWS || P.gather == LY_GATHER_UP2) {

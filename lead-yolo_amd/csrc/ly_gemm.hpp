@@ -522,6 +522,15 @@ static int launch_gemm(const LyGemmParams& P, hipStream_t st) {
   if (P.gather == LY_GATHER_PATCH) return launch_gemm_v<T, T, NT, MT, WC, LY_GATHER_PATCH, LY_PRO_NONE>(P, st);
   if (P.gather == LY_GATHER_PATCH_NCHW) return launch_gemm_v<float, T, NT, MT, WC, LY_GATHER_PATCH_NCHW, LY_PRO_NONE>(P, st);
   if (P.gather == LY_GATHER_PATCH_NCHW_U8) return launch_gemm_v<unsigned char, T, NT, MT, WC, LY_GATHER_PATCH_NCHW, LY_PRO_NONE>(P, st);
+  if (P.gather == LY_GATHER_PATCH_NCHW_BF16 || P.gather == LY_GATHER_PATCH_NCHW_F16) {
+    if constexpr (LyT<T>::BF) {
+      if (P.gather == LY_GATHER_PATCH_NCHW_BF16) return launch_gemm_v<ly_bf16img, T, NT, MT, WC, LY_GATHER_PATCH_NCHW, LY_PRO_NONE>(P, st);
+      return launch_gemm_v<ly_f16img, T, NT, MT, WC, LY_GATHER_PATCH_NCHW, LY_PRO_NONE>(P, st);
+    } else {
+      ly_set_error("gemm: a 16-bit image source is built for LY_BF16 calls only");
+      return -1;
+    }
+  }
   if (P.gather == LY_GATHER_UP2) {
     if (P.pro == LY_PRO_NONE) return launch_gemm_v<T, T, NT, MT, WC, LY_GATHER_UP2, LY_PRO_NONE>(P, st);
     ly_set_error("gemm: upsampled source with a prologue is not built");

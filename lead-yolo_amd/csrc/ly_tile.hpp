@@ -59,6 +59,24 @@ template <> struct LyT<unsigned char> {
   typedef unsigned RV;
 };
 
+// 16-bit IMAGE sources (LY_GATHER_PATCH_NCHW_BF16 / _F16: the `im.half()` batch of a reduced-precision forward, val.py:207): 4 pixels per
+// 8-byte vector, widened on the way into LDS and contracted like an fp32 source — the fp32 copy of the batch never exists
+struct ly_bf16img { unsigned short v; };
+struct ly_f16img { unsigned short v; };
+struct ly_h4raw { ly_u32x2 r; };
+template <> struct LyT<ly_bf16img> {
+  static constexpr int PL = 2, VW = 4;
+  static constexpr bool BF = false;
+  typedef ly_u32x2 R4;
+  typedef ly_u32x2 RV;
+};
+template <> struct LyT<ly_f16img> {
+  static constexpr int PL = 2, VW = 4;
+  static constexpr bool BF = false;
+  typedef ly_h4raw R4;
+  typedef ly_h4raw RV;
+};
+
 // runs `stmt` with T bound to the element type selected by the C ABI's dtype code
 #define LY_WITH_T(dtype, ...)                                 \
   do {                                                        \
@@ -89,6 +107,7 @@ __device__ __forceinline__ void ly_zero_raw(f32x4& r) { r = (f32x4){0.f, 0.f, 0.
 __device__ __forceinline__ void ly_zero_raw(ly_u32x2& r) { r = (ly_u32x2){0u, 0u}; }
 __device__ __forceinline__ void ly_zero_raw(ly_u32x4& r) { r = (ly_u32x4){0u, 0u, 0u, 0u}; }
 __device__ __forceinline__ void ly_zero_raw(unsigned& r) { r = 0u; }
+__device__ __forceinline__ void ly_zero_raw(ly_h4raw& r) { r.r = (ly_u32x2){0u, 0u}; }
 __device__ __forceinline__ f32x4 ly_u8x4_f32(unsigned r) {          // 4 image bytes -> pixel values / 255 (train.py:309 `imgs.float() / 255`)
   return (f32x4){(float)(r & 255u), (float)((r >> 8) & 255u), (float)((r >> 16) & 255u), (float)(r >> 24)} * (1.f / 255.f);
 }
@@ -148,6 +167,13 @@ __device__ __forceinline__ void ly_lds_put_rv(char* hi_plane, char*, int row_byt
   *reinterpret_cast<ly_u32x4*>(hi_plane + row_byte + 2 * c) = v;
 }
 __device__ __forceinline__ void ly_lds_put_rv(char* hi_plane, char* lo_plane, int row_byte, int c, const unsigned v) { ly_lds_put4(hi_plane, lo_plane, row_byte, c, ly_u8x4_f32(v)); }
+__device__ __forceinline__ void ly_lds_put_rv(char* hi_plane, char* lo_plane, int row_byte, int c, const ly_u32x2 v) {      // bf16 image
+  ly_lds_put4(hi_plane, lo_plane, row_byte, c, ly_cvt4(__builtin_bit_cast(bf16x4, v)));
+}
+typedef _Float16 ly_f16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void ly_lds_put_rv(char* hi_plane, char* lo_plane, int row_byte, int c, const ly_h4raw v) {      // fp16 image
+  ly_lds_put4(hi_plane, lo_plane, row_byte, c, __builtin_convertvector(__builtin_bit_cast(ly_f16x4, v.r), f32x4));
+}
 // fp32 quad of channels c..c+3 into the operand image of a PL-plane kernel
 template <int PL>
 __device__ __forceinline__ void ly_lds_put_f32(char* hi_plane, char* lo_plane, int row_byte, int c, const f32x4 v) {

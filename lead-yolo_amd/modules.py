@@ -359,8 +359,11 @@ class _PatchConv(nn.Module):
             odt = torch.float32 if want == torch.float32 else torch.bfloat16
             back = torch.float16 if want == torch.float16 else None
             if x.dtype != torch.uint8:
-                x = x.float()
-                ops.require_cuda(x, type(self).__name__, self)
+                # a bf16 / fp16 image of a no-grad bf16 forward is gathered as it is (LY_GATHER_PATCH_NCHW_BF16 / _F16); everything else as fp32
+                half_img = x.dtype in (torch.bfloat16, torch.float16) and odt == torch.bfloat16 and not _grad_mode(self) and self.k == 4 and x.shape[3] % 4 == 0
+                if not half_img:
+                    x = x.float()
+                    ops.require_cuda(x, type(self).__name__, self)
         else:
             x, back = ops.edge_in(x, type(self).__name__, self)
             odt = x.dtype

@@ -11,7 +11,7 @@ import ctypes
 import torch
 
 from . import capi
-from .capi import (ACT_NONE, ACT_RELU, ACT_SILU, GATHER_PATCH, GATHER_PATCH_NCHW, GATHER_PATCH_NCHW_U8, GATHER_ROWS, GATHER_UP2,  # noqa: F401
+from .capi import (ACT_NONE, ACT_RELU, ACT_SILU, GATHER_PATCH, GATHER_PATCH_NCHW, GATHER_PATCH_NCHW_BF16, GATHER_PATCH_NCHW_F16, GATHER_PATCH_NCHW_U8, GATHER_ROWS, GATHER_UP2,  # noqa: F401
                    PRO_AFFINE_RELU_CA, PRO_GATE, PRO_NONE)
 
 
@@ -175,9 +175,10 @@ def gemm(*, M, H, W, K, N, a0, lda0, k0, wp, out, ldo, a1=None, lda1=0, gather=G
          e_shift=None, rowscale=None, act=ACT_NONE, stats=None, dtype=None):
     # element type of the call: the output's (statistics passes: the source's); the NCHW image gather always READS fp32 — or uint8
     # (pixel / 255 on load: the training loop's `imgs.float() / 255` folded into the gather)
-    if gather == GATHER_PATCH_NCHW and a0.dtype == torch.uint8:
-        gather = GATHER_PATCH_NCHW_U8
-    image = gather in (GATHER_PATCH_NCHW, GATHER_PATCH_NCHW_U8)
+    # or a 16-bit image as it is (the `im.half()` batch of a reduced-precision forward; LY_BF16 calls)
+    if gather == GATHER_PATCH_NCHW:
+        gather = {torch.uint8: GATHER_PATCH_NCHW_U8, torch.bfloat16: GATHER_PATCH_NCHW_BF16, torch.float16: GATHER_PATCH_NCHW_F16}.get(a0.dtype, gather)
+    image = gather in (GATHER_PATCH_NCHW, GATHER_PATCH_NCHW_U8, GATHER_PATCH_NCHW_BF16, GATHER_PATCH_NCHW_F16)
     dt = (out if out is not None else a0).dtype if not image or out is not None else torch.float32
     if dtype is not None:
         dt = dtype
@@ -186,9 +187,10 @@ def gemm(*, M, H, W, K, N, a0, lda0, k0, wp, out, ldo, a1=None, lda1=0, gather=G
                           _p(res), ldres, _p(p_scale), _p(p_shift), _p(p_ca), _p(wp), _p(e_scale), _p(e_shift), _p(rowscale),
                           act, _p(out), ldo, _p(stats), code)
     nt, mt, wc = gemm_config(N)
-    ti = "unsigned char" if gather == GATHER_PATCH_NCHW_U8 else "float" if (code == 0 or image) else "__bf16"
+    ti = {GATHER_PATCH_NCHW_U8: "unsigned char", GATHER_PATCH_NCHW_BF16: "ly_bf16img", GATHER_PATCH_NCHW_F16: "ly_f16img"}.get(
+        gather, "float" if (code == 0 or image) else "__bf16")
     to = "float" if code == 0 else "__bf16"
-    es_i, es_o = {"float": 4, "__bf16": 2, "unsigned char": 1}[ti], (4 if to == "float" else 2)
+    es_i, es_o = {"float": 4, "__bf16": 2, "unsigned char": 1, "ly_bf16img": 2, "ly_f16img": 2}[ti], (4 if to == "float" else 2)
     kgather = GATHER_PATCH_NCHW if image else gather        # the kernel template's gather code (the uint8 image differs by TI only)
     # the variant launch_gemm_v (csrc/ly_gemm.hpp) picks: resident weights for K in one / two chunks + the branch-free epilogue
     nchunk = -(-K // (128 if ti == "__bf16" else 64))

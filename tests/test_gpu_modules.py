@@ -511,6 +511,32 @@ def test_patchembed_uint8_image_matches_float_path():
     torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("idt", [torch.bfloat16, torch.float16])
+def test_patchembed_half_image_is_gathered_as_it_is(idt, monkeypatch):
+    """the `im.half()` batch of a reduced-precision forward (val.py:207): the patch gather reads the 16-bit NCHW image directly
+    (LY_GATHER_PATCH_NCHW_BF16 / _F16) — same bits as gathering its fp32 copy, and no fp32 copy is made"""
+    import lead_yolo_amd as L
+    from lead_yolo_amd import ops
+    dev = _dev()
+    torch.manual_seed(4)
+    m = L.PatchEmbed_FasterNet(3, 40, 4, 4).to(dev).eval()
+    with torch.no_grad():
+        m.norm.running_mean.normal_(0, 0.1)
+        m.norm.running_var.uniform_(0.5, 1.5)
+    x = torch.rand(3, 3, 72, 100, device=dev).to(idt)
+    seen = []
+    real = ops.gemm
+    monkeypatch.setattr(ops, "gemm", lambda **kw: (seen.append(kw["a0"].dtype), real(**kw))[1])
+    with torch.no_grad():
+        got = m(x)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            ref = m(x.float())                                    # fp32 image, bf16 output: the route taken before
+    assert seen == [idt, torch.float32]
+    assert got.dtype == idt and got.shape == (3, 40, 18, 25)
+    assert torch.equal(got.float(), ref.to(idt).float())
+
+
 def test_train_step_uint8_equals_float_batch():
     """forward_backward on the uint8 batch (no fp32 copy of the images) reproduces the gradients of the float / 255 batch"""
     import lead_yolo_amd as L

@@ -35,5 +35,9 @@ extern "C" int ly_gemm_fwd(const LyGemmParams* p, void* stream) {
   else LY_CHECK(!P.rowscale, "gemm: rowscale is only built together with the affine (RFCBAM k=1) prologue");
   LY_CHECK(P.M < (1L << 24), "gemm: M=%ld pixels exceeds the 2^24 limit of the fast index path", P.M);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (ly_patch4_try(P, st)) {                              // PatchEmbed on an RGB image: its own LDS-free kernel (ly_patch4.hip)
+    LY_LAUNCH_CHECK();
+    return 0;
+  }
   return P.dtype == LY_BF16 ? ly_gemm_dispatch_bf16(P, st) : ly_gemm_dispatch_f32(P, st);
 }

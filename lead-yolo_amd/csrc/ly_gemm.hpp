@@ -552,3 +552,4 @@ static int ly_gemm_dispatch(const LyGemmParams& P, hipStream_t st) {
 }
 int ly_gemm_dispatch_f32(const LyGemmParams& P, hipStream_t st);
 int ly_gemm_dispatch_bf16(const LyGemmParams& P, hipStream_t st);
+int ly_patch4_try(const LyGemmParams& P, hipStream_t st);      // ly_patch4.hip: 1 = launched

@@ -203,7 +203,12 @@ def gemm(*, M, H, W, K, N, a0, lda0, k0, wp, out, ldo, a1=None, lda1=0, gather=G
         nch = 1 if (nchunk == 1 and ok1) else 2 if (nchunk == 2 and ok2) else 0
     fast = N % 4 == 0 and ldo % 4 == 0 and out is not None
     ep = (2 if stats is not None else 1) if (nch or (fast and pro == 0)) else 0
-    with _Timed(f"ly_gemm_kernel_d2<{ti}, {to}, {nt}, {mt}, {wc}, {kgather}, {pro}, {nch}, {ep}>", 2.0 * M * K * N, es_i * M * K + es_o * M * N + 4.0 * N * K):
+    name = f"ly_gemm_kernel_d2<{ti}, {to}, {nt}, {mt}, {wc}, {kgather}, {pro}, {nch}, {ep}>"
+    if (image and Cin == 3 and K == 48 and 20 <= N <= 80 and N % 4 == 0 and (out is None or ldo % 4 == 0) and Hin == 4 * H and Win == 4 * W
+            and (code != 0 or gather in (GATHER_PATCH_NCHW, GATHER_PATCH_NCHW_U8))):
+        # ly_patch4_try (csrc/ly_patch4.hip): PatchEmbed on an RGB image has its own LDS-free kernel
+        name = f"ly_patch4_kernel<{ti}, {to}, {max(2, -(-N // 16))}, {'true' if stats is not None else 'false'}>"
+    with _Timed(name, 2.0 * M * K * N, es_i * M * K + (es_o * M * N if out is not None else 0) + 4.0 * N * K):
         capi.check(capi.lib().ly_gemm_fwd(ctypes.byref(P), capi.stream_ptr()), "ly_gemm_fwd")
 
 

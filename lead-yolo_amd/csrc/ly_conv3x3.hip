@@ -14,6 +14,7 @@
 // Pipeline: the raw fp32 frame of chunk c+1 is loaded into registers before the 9-tap contraction of
 // chunk c is issued and committed to LDS after it; weight fragments are fetched one tap ahead.
 // The 4 waves split the output channels (WC = 4): each weight fragment is read by exactly one wave.
+#include <cstdlib>
 #include "ly_tile.hpp"
 #include "ly_params.h"
 
@@ -220,7 +221,259 @@ __global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(size
   }
 }
 
+#ifndef LY_C3_PD
+#define LY_C3_PD 3                // weight-fragment ring depth of the latency form
+#endif
+template <int V>
+struct LyC3Ic { static constexpr int value = V; };
+
+// The LATENCY form (bf16 storage; conv3_dispatch takes it for grids under two blocks per CU — the serving forward, where a CU holds about one
+// block and nothing hides a wave's waits).  In the throughput form above every (LDS fragment read -> its two MFMAs) pair sits behind its own
+// run-time "tile in use" branch and weight fragments arrive one step ahead: fine with three waves per SIMD, but alone a wave ran ~7x longer
+// than its MFMAs.  Here the wave's tile count NC is a compile-time constant (switch over 0..NTW), so the NC reads of a step are issued
+// together; weight fragments travel two steps ahead in a ring of three register sets; 223 / 164 registers = two waves per SIMD.
+// bs=16, 64 channels per block (<2,2>): 40 x 40 x 128: 25.5 -> 19.8 us, 20 x 20 x 256: 32.5 -> 22.5 us.  With every CU holding three blocks
+// (bs=64) the throughput form stays ahead (55 vs 55-69 us), hence the dispatch by grid size.
 template <typename T, int MT, int WC>
+__global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(2))) void ly_conv3x3_lat_kernel(const LyConv3Params P, const int gy, const int tiles_x, const int tiles_y) {
+  using TR = LyT<T>;
+  using RV = typename TR::RV;
+  constexpr int VW = TR::VW, PL = TR::PL;
+  constexpr int LY_CC = 8 * VW;                 // channels per chunk
+  constexpr int KS = LY_CC / 32;                // k-steps per tap and chunk
+  constexpr int LY_RSH = 2 * LY_CC + 16;        // bytes per frame position, per plane
+  extern __shared__ f32x4 ly_smem4[];
+  const int TH = P.TH, TW = P.TW, FW = TW + 2;
+  const int frame = (TH + 2) * FW;
+  char* hs_hi = reinterpret_cast<char*>(ly_smem4);
+  char* hs_lo = hs_hi + (PL - 1) * frame * LY_RSH;
+  const T* const x = reinterpret_cast<const T*>(P.x);
+  T* const out = reinterpret_cast<T*>(P.out);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lq = lane >> 4;
+  constexpr int WP = 4 / WC;                 // waves along pixels
+  constexpr int NTW = LY_C3_NT / WP;         // pixel tiles per wave
+  const int wc = wave % WC, wp = wave / WC;
+  int b = blockIdx.x;
+  const int by = b % gy; b /= gy;
+  const int tx = b % tiles_x; b /= tiles_x;
+  const int ty = b % tiles_y;
+  const int n_img = b / tiles_y;
+  const int h0 = ty * TH, w0 = tx * TW;
+  const int npx = TH * TW;
+  const int ntv = (npx + 15) >> 4;                         // pixel tiles actually used (wave-uniform)
+  const f32x4 zero = ly_zero4();
+  const int C32 = (P.Cin + 31) >> 5;                       // k-steps per tap (weight layout: conv_taps_matrix(w, 32))
+  const int NCH = (P.Cin + LY_CC - 1) / LY_CC;             // channel chunks
+  const int S = 9 * C32;
+  const int Tt = (P.N + 15) >> 4;
+  const long img0 = (long)n_img * P.H * P.W;
+
+  // per-lane pixel -> byte offset of its (0,0) tap in the frame, and its output row (or -1)
+  int hb[NTW];
+#pragma unroll
+  for (int n = 0; n < NTW; ++n) {
+    const int p = 16 * (wp * NTW + n) + li;
+    const int pp = p < npx ? p : 0;
+    const int r = pp / TW, c = pp - r * TW;
+    hb[n] = (r * FW + c) * LY_RSH;
+  }
+  // output row of the lane's pixel in tile n, or -1 (LAT: recomputed in the epilogue — eight 64-bit values held through the loop cost 16 registers)
+  auto out_row = [&](int n) -> long {
+    const int p = 16 * (wp * NTW + n) + li;
+    const int pp = p < npx ? p : 0;
+    const int r = pp / TW, c = pp - r * TW;
+    const bool ok = p < npx && h0 + r < P.H && w0 + c < P.W;
+    return ok ? img0 + (long)(h0 + r) * P.W + (w0 + c) : -1;
+  };
+
+  // ---- staging: this thread's frame items (position, 16-byte channel group) --------------------------------
+  const int items = frame * 8;
+  long src[LY_C3_NV];                                       // element offset of the item's first channel of chunk 0, or -1
+#pragma unroll
+  for (int e = 0; e < LY_C3_NV; ++e) {
+    const int idx = tid + e * LY_THREADS;
+    long off = -1;
+    if (idx < items) {
+      const int pos = idx >> 3, c4 = idx & 7;
+      const int fr = pos / FW, fc = pos - fr * FW;
+      const int hh = h0 - 1 + fr, ww = w0 - 1 + fc;
+      if (hh >= 0 && hh < P.H && ww >= 0 && ww < P.W) off = (img0 + (long)hh * P.W + ww) * P.ldx + VW * c4;
+    }
+    src[e] = off;
+  }
+  RV pv[LY_C3_NV];
+  // a vector is loaded when its FIRST channel is inside Cin: the channels beyond Cin it may carry (Cin % VW != 0: the partial
+  // conv gradients of the MLPBlock backward) meet zero-padded weights, and ldx >= roundup(Cin, VW) is checked by the launcher
+  auto prefetch = [&](int c0) {
+#pragma unroll
+    for (int e = 0; e < LY_C3_NV; ++e) {
+      const int c4 = (tid + e * LY_THREADS) & 7;
+      const bool ok = src[e] >= 0 && c0 + VW * c4 < P.Cin;
+      pv[e] = ly_ldrv<T>(ok ? x + src[e] + c0 : x);      // clamped address, zero selected at commit
+    }
+  };
+  auto commit = [&](int c0) {
+#pragma unroll
+    for (int e = 0; e < LY_C3_NV; ++e) {
+      const int idx = tid + e * LY_THREADS;
+      const int c4 = idx & 7;
+      const bool ok = src[e] >= 0 && c0 + VW * c4 < P.Cin;
+      RV v = pv[e];
+      if (!ok) ly_zero_raw(v);
+      if (idx < items) ly_lds_put_rv(hs_hi, hs_lo, (idx >> 3) * LY_RSH, VW * c4, v);
+    }
+  };
+
+  f32x4 acc[MT][NTW];
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) acc[t][n] = zero;
+  long wbase[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const int tt = (by * WC + wc) * MT + t;
+    wbase[t] = (long)(tt < Tt ? tt : Tt - 1) * S;
+  }
+  const uint4* wpk = reinterpret_cast<const uint4*>(P.wp);
+  ly_l2_warm(P.wp, (long)Tt * S * PL * 1024, P.stats ? reinterpret_cast<float*>(P.stats) : reinterpret_cast<float*>(P.out));
+
+  // weight fragment of (tap, k-step ks of chunk cc); a ragged last chunk (Cin % 64 == 32) clamps the absent second step to the
+  // first: its activations are staged as zeros
+  auto wstep = [&](int tap, int cc, int ks) -> long {
+    int st = KS * cc + ks;
+    if (st >= C32) st = C32 - 1;
+    return (long)tap * C32 + st;
+  };
+  // Weight fragments travel PD - 1 steps ahead of their use in a ring of PD register sets (a step = one (tap, k-step): MT fragments, MT x NTW
+  // MFMAs = 160-256 cycles).  One step ahead (the first form) left a wave waiting on L2 every step whenever fewer than ~4 waves shared the
+  // SIMD: in the serving forward (320 blocks on 256 CUs) a block ran 10x longer than its MFMAs.  PD divides the 9 KS steps of a chunk, so the
+  // slot of a step is a compile-time constant of the unrolled body.
+  static_assert(PL == 1, "bf16 storage only");
+  constexpr int PD = LY_C3_PD;
+  constexpr int SPC = 9 * KS;                               // steps per chunk
+  static_assert(SPC % PD == 0, "ring depth must divide the steps of a chunk");
+  LyWF<PL> wq[PD][MT];
+  // fragment index of step j (0 .. SPC + PD - 2) counted from the start of chunk cc; past the last chunk it clamps (never used)
+  auto wstep_at = [&](int cc, int j, bool more) -> long {
+    int c2 = cc;
+    if (j >= SPC) { j -= SPC; c2 = more ? cc + 1 : cc; }
+    return wstep(j / KS, c2, j % KS);
+  };
+  {
+#pragma unroll
+    for (int j = 0; j < PD - 1; ++j)
+#pragma unroll
+      for (int t = 0; t < MT; ++t) wq[j][t] = ly_wfragp<PL>(wpk, wbase[t] + wstep_at(0, j, NCH > 1), lane);
+  }
+
+  prefetch(0);
+  commit(0);
+  __syncthreads();
+
+  // The contraction with the wave's pixel-tile count NC as a compile-time constant (dispatched below).  With a run-time test per tile every
+  // (LDS fragment read -> its MFMAs) pair sat behind its own branch: the read's latency was exposed once per tile, hidden only by other waves —
+  // and the serving forward runs these blocks one per CU.  Unrolled, the NC reads of a step are issued together ahead of its MFMAs.
+  auto contract = [&](auto ncC) {
+    constexpr int NC = decltype(ncC)::value;
+    for (int cc = 0; cc < NCH; ++cc) {
+      const bool more = cc + 1 < NCH;
+      // unconditional (the last chunk re-requests itself): a load under a branch makes the compiler drain the whole queue
+      // (s_waitcnt vmcnt(0)) after every tap, i.e. wait for this prefetch at tap 0 instead of hiding it behind nine taps of MFMAs
+      prefetch((more ? cc + 1 : cc) * LY_CC);
+      {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          int toff = ((tap / 3) * FW + (tap % 3)) * LY_RSH;
+          asm volatile("" : "+s"(toff));                   // opaque per chunk: the 9 x NC fragment addresses are not hoisted out of the chunk loop (72 registers)
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const int j = tap * KS + ks;
+            int lane_j = lane;
+            asm volatile("" : "+v"(lane_j));               // the fragment addresses of a step are formed in the step (formed early they spill)
+#pragma unroll
+            for (int t = 0; t < MT; ++t) wq[(j + PD - 1) % PD][t] = ly_wfragp<PL>(wpk, wbase[t] + wstep_at(cc, j + PD - 1, more), lane_j);
+#pragma unroll
+            for (int n = 0; n < NC; ++n) {
+              {
+                const bf16x8 xh = ly_lds_frag(hs_hi, hb[n] + toff, ks, lq);
+#pragma unroll
+                for (int t = 0; t < MT; ++t) acc[t][n] = ly_mfmap<PL>(wq[j % PD][t], xh, xh, acc[t][n]);
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);             // a step's reads stay in the step
+          }
+        }
+      }
+      if (more) {
+        __syncthreads();            // every wave is done reading the frame of chunk cc
+        commit((cc + 1) * LY_CC);
+        __syncthreads();
+      }
+    }
+  };
+  {
+    int nw = ntv - wp * NTW;
+    nw = nw < 0 ? 0 : nw > NTW ? NTW : nw;
+    switch (nw) {
+      case 1: contract(LyC3Ic<1>()); break;
+      case 2: contract(LyC3Ic<2>()); break;
+      case 3: contract(LyC3Ic<3>()); break;
+      case 4: contract(LyC3Ic<(NTW >= 4 ? 4 : NTW)>()); break;
+      case 5: contract(LyC3Ic<(NTW >= 5 ? 5 : NTW)>()); break;
+      case 6: contract(LyC3Ic<(NTW >= 6 ? 6 : NTW)>()); break;
+      case 7: contract(LyC3Ic<(NTW >= 7 ? 7 : NTW)>()); break;
+      case 8: contract(LyC3Ic<(NTW >= 8 ? 8 : NTW)>()); break;
+      default: contract(LyC3Ic<0>()); break;                  // (a wave without pixels still stages frames and meets the barriers)
+    }
+  }
+
+  // ---- epilogue ---------------------------------------------------------------------------------
+  const int act = P.act;
+  const bool vec_ok = (P.ldo & 3) == 0;
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const int tt = (by * WC + wc) * MT + t;
+    const int c = 16 * tt + 4 * lq;
+    if (tt >= Tt || c >= P.N) continue;
+    float sc[4], sh[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool ok = c + r < P.N;
+      sc[r] = (ok && P.e_scale) ? P.e_scale[c + r] : 1.f;
+      sh[r] = (ok && P.e_shift) ? P.e_shift[c + r] : 0.f;
+    }
+    f32x4 s1 = zero, s2 = zero;
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) {
+      const long orow_n = out_row(n);
+      if (orow_n < 0) continue;
+      f32x4 u;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) u[r] = acc[t][n][r] * sc[r] + sh[r];
+      if (P.stats) {
+        s1 += u;
+        s2 += u * u;
+        if (!out) continue;                                // pure statistics pass; with `out` the value is stored as well
+      }
+      const f32x4 v = ly_act4(u, act);
+      T* o = out + orow_n * P.ldo + c;
+      if (vec_ok && c + 3 < P.N) {
+        ly_st4<T>(o, v);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (c + r < P.N) ly_st1<T>(o + r, v[r]);
+      }
+    }
+    if (P.stats) ly_stats_flush(P.stats, P.N, c, s1, s2);
+  }
+}
+
+template <typename T, int MT, int WC, bool LAT = false>
 static int launch_conv3(const LyConv3Params& P, hipStream_t st) {
   const int tiles_x = (P.W + P.TW - 1) / P.TW, tiles_y = (P.H + P.TH - 1) / P.TH;
   const int gy = (P.N + 16 * MT * WC - 1) / (16 * MT * WC);
@@ -228,7 +481,8 @@ static int launch_conv3(const LyConv3Params& P, hipStream_t st) {
   long nb = n_img * tiles_x * tiles_y * gy;
   LY_CHECK(nb < (1L << 31), "conv3x3: grid too large");
   size_t lds = LyT<T>::PL * (size_t)(P.TH + 2) * (P.TW + 2) * (2 * 8 * LyT<T>::VW + 16);
-  auto k = ly_conv3x3_kernel<T, MT, WC>;
+  void (*k)(const LyConv3Params, const int, const int, const int) = ly_conv3x3_kernel<T, MT, WC>;
+  if constexpr (LAT) k = ly_conv3x3_lat_kernel<T, MT, WC>;
   static bool configured = false;
   if (!configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
@@ -243,7 +497,16 @@ static int launch_conv3(const LyConv3Params& P, hipStream_t st) {
 template <typename T>
 static int conv3_dispatch(const LyConv3Params& P, hipStream_t st) {
   // measured on MI355X: 32 channels per wave is the sweet spot at every LEAD-YOLO shape
-  if (P.N > 64) return launch_conv3<T, 2, 4>(P, st);      // 4 waves x 32 ch (128 ch per block), all 8 pixel tiles each
+  static int mode = -1;                                   // development knob LY_C3_MODE: 1 = <2,4>, 2 = <2,4,LAT>, 3 = <2,2>, 4 = <2,2,LAT>
+  if (mode < 0) { const char* e = getenv("LY_C3_MODE"); mode = e ? atoi(e) : 0; }
+  if constexpr (LyT<T>::BF) {
+    const long tiles = (P.M / ((long)P.H * P.W)) * ((P.W + P.TW - 1) / P.TW) * ((P.H + P.TH - 1) / P.TH);
+    const bool small = tiles * ((P.N + 127) / 128) < 2 * 256;            // fewer than two blocks per CU
+    if (mode == 2) return launch_conv3<T, 2, 4, true>(P, st);
+    if (mode == 4 || (mode == 0 && P.N > 64 && small)) return launch_conv3<T, 2, 2, true>(P, st);   // 64 channels per block: twice the blocks
+  }
+  if (mode == 3) return launch_conv3<T, 2, 2>(P, st);
+  if (mode == 1 || P.N > 64) return launch_conv3<T, 2, 4>(P, st);      // 4 waves x 32 ch (128 ch per block), all 8 pixel tiles each
   return launch_conv3<T, 2, 2>(P, st);                    // 2 x 32 ch, 2 pixel groups of 4 tiles
 }
 

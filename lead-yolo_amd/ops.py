@@ -227,7 +227,10 @@ def conv3x3(*, M, H, W, Cin, N, x, ldx, wp, out, ldo, e_scale=None, e_shift=None
     code = capi.dtype_code(x)
     P = capi.LyConv3Params(M, H, W, Cin, N, th, tw, _p(x), ldx, _p(wp), _p(e_scale), _p(e_shift), act, _p(out), ldo, _p(stats), code)
     mt, wc = (2, 4) if N > 64 else (2, 2)
-    with _Timed(f"ly_conv3x3_kernel<{_tname(x)}, {mt}, {wc}>", 2.0 * M * 9 * Cin * N, x.element_size() * M * (Cin + N) + 4.0 * 9 * Cin * N):
+    name = f"ly_conv3x3_kernel<{_tname(x)}, {mt}, {wc}>"
+    if code != 0 and N > 64 and (M // (H * W)) * -(-W // tw) * -(-H // th) * -(-N // 128) < 512:
+        name = "ly_conv3x3_lat_kernel<__bf16, 2, 2>"        # conv3_dispatch (csrc/ly_conv3x3.hip): grids under two blocks per CU take the latency form
+    with _Timed(name, 2.0 * M * 9 * Cin * N, x.element_size() * M * (Cin + N) + 4.0 * 9 * Cin * N):
         capi.check(capi.lib().ly_conv3x3_fwd(ctypes.byref(P), capi.stream_ptr()), "ly_conv3x3_fwd")
 
 

@@ -1014,6 +1014,9 @@ class Concat(nn.Module):
         return torch.cat(x, self.d)
 
 
+FUSED_DETECT_LEVEL = True      # development switch: False sends Detect levels through the GEMM + ly_detect_tail pair
+
+
 class Detect(nn.Module):
     stride = None
     dynamic = False
@@ -1037,6 +1040,23 @@ class Detect(nn.Module):
         key = pack.versions(conv.weight, conv.bias)
         return self._prep[i].get(key, lambda: (pack.packed(pack.src_matrix(conv.weight, conv.out_channels, conv.in_channels), conv.in_channels, planes),
                                                conv.bias.detach().float().contiguous()), planes)
+
+    def _packed_nat(self, i, planes):
+        """the head weight as two 16-row tiles in natural k order (ly_detect_level) + fp32 bias"""
+        conv = self.m[i]
+        key = pack.versions(conv.weight, conv.bias)
+        return self._prep[i].get(key, lambda: (pack.frag_pack_nat(conv.weight.detach().float().view(conv.out_channels, conv.in_channels), planes),
+                                               conv.bias.detach().float().contiguous()), ("nat", planes))
+
+    def _fused_level_input(self, i, xi):
+        """the feature map as dense rows when the one-launch level kernel takes it (plain tensor, shape built), else None"""
+        if isinstance(xi, Lazy) or not isinstance(xi, torch.Tensor) or xi.dim() != 4 or not FUSED_DETECT_LEVEL:
+            return None
+        conv = self.m[i]
+        if conv.bias is None or not ops.detect_level_ok(conv.in_channels, self.na, self.no, xi.dtype):
+            return None
+        rows, ld = ops.rows(xi)
+        return (rows, ld) if ld % ops.vw_of(xi.dtype) == 0 and rows.data_ptr() % 16 == 0 else None
 
     def _head(self, i, x):
         conv = self.m[i]
@@ -1107,12 +1127,18 @@ class Detect(nn.Module):
             st["forked"] = True
             ctx.__enter__()
         try:
-            buf, ldo = self._head(i, xi)
             ny, nx = st["hw"][i]
             ext = getattr(self, "_out", None)
             p = ext["p"][i] if ext is not None else torch.empty((st["bs"], self.na, ny, nx, self.no), dtype=torch.float32, device=st["device"])
-            ops.detect_tail(buf, ldo, st["bs"], ny, nx, self.na, self.no, self.anchors[i], self._strides()[i], p, st["z"], st["zrows"],
-                            st["offs"][i])
+            fused = self._fused_level_input(i, xi)
+            if fused is not None:                           # head convolution + decode in one launch (csrc/ly_detect.hip)
+                wp, b = self._packed_nat(i, ops.planes_of(xi))
+                ops.detect_level(fused[0], fused[1], st["bs"], ny, nx, self.m[i].in_channels, wp, b, self.na, self.no, self.anchors[i],
+                                 self._strides()[i], p, st["z"], st["zrows"], st["offs"][i])
+            else:
+                buf, ldo = self._head(i, xi)
+                ops.detect_tail(buf, ldo, st["bs"], ny, nx, self.na, self.no, self.anchors[i], self._strides()[i], p, st["z"], st["zrows"],
+                                st["offs"][i])
             if side:
                 p.record_stream(main)
             st["p"][i] = p

@@ -509,6 +509,18 @@ def detect_tail(y, ldy, n, h, w, na, no, anchors, stride, p, z, zrows, zoff):
                                          capi.dtype_code(y), capi.stream_ptr()), "ly_detect_tail")
 
 
+def detect_level_ok(k, na, no, dtype):
+    return dtype in (torch.float32, torch.bfloat16) and bool(capi.lib().ly_detect_level_ok(k, na, no, capi.dtype_code(dtype)))
+
+
+def detect_level(x, ldx, n, h, w, k, wp, bias, na, no, anchors, stride, p, z, zrows, zoff):
+    """head 1x1 convolution + decode of one Detect level in ONE launch (ly_detect_level): x rows [n*h*w, k] -> p [n, na, h, w, no], z rows"""
+    es = x.element_size()
+    with _Timed(f"ly_detect_level_kernel<{_tname(x)}, {k // 32}>", 2.0 * n * h * w * k * 32, es * n * h * w * k + 8.0 * n * h * w * na * no):
+        capi.check(capi.lib().ly_detect_level(_p(x), ldx, n, h, w, k, _p(wp), _p(bias), na, no, _p(anchors), float(stride), _p(p), _p(z), zrows, zoff,
+                                              capi.dtype_code(x), capi.stream_ptr()), "ly_detect_level")
+
+
 def detect_head_bwd(dp, n, h, w, na, no, du, ldu, dbias):
     """dp fp32 [n, na, h, w, no] -> du rows [n*h*w, ldu] (columns >= na*no zero), dbias[na*no] += column sums"""
     capi.check(capi.lib().ly_detect_head_bwd(_p(dp), n, h, w, na, no, _p(du), ldu, _p(dbias), capi.dtype_code(du), capi.stream_ptr()),

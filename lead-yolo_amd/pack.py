@@ -80,6 +80,21 @@ def frag_pack3(w2d, rows_to=0, planes=2):
     return v.view(t, s, planes, 64, 8).view(torch.int16)
 
 
+def frag_pack_nat(w2d, planes=2):
+    """MFMA A-operand packing in NATURAL k order (csrc/ly_detect.hip: the B operand is loaded straight from global memory, 8 consecutive
+    channels per lane): W[R, K] fp32 -> int16 [T, S, planes, 64, 8], lane = g*16 + i holds row 16t + i and k = 32s + 8g + j, j = 0..7."""
+    r, k = w2d.shape
+    t, s = _ceil(r, 16), _ceil(k, 32)
+    wp = torch.zeros(t * 16, s * 32, dtype=torch.float32, device=w2d.device)
+    wp[:r, :k] = w2d.float()
+    hi = wp.to(torch.bfloat16)
+    lo = (wp - hi.float()).to(torch.bfloat16)
+    pl = torch.stack((hi, lo), 0)[:planes]                              # [planes, T*16, S*32]
+    # [p, t, i, s, g, j] -> [t, s, p, g, i, j]
+    v = pl.view(planes, t, 16, s, 4, 8).permute(1, 3, 0, 4, 2, 5).contiguous()
+    return v.view(t, s, planes, 64, 8).view(torch.int16)
+
+
 def pad_to(v, n):
     out = torch.zeros(n, dtype=torch.float32, device=v.device)
     out[:v.numel()] = v

@@ -537,6 +537,33 @@ def test_patchembed_half_image_is_gathered_as_it_is(idt, monkeypatch):
     assert torch.equal(got.float(), ref.to(idt).float())
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_detect_level_one_launch_matches_gemm_plus_tail(dt):
+    """ly_detect_level (head 1x1 convolution + decode in one launch, models/yolo.py:88-120) vs the GEMM + ly_detect_tail pair it replaces:
+    same z / raw maps up to the bf16 rounding of the pair's intermediate buffer"""
+    import lead_yolo_amd as L
+    from lead_yolo_amd import modules
+    dev = _dev()
+    torch.manual_seed(5)
+    ch = (64, 128, 256) if dt == torch.float32 else (128, 256, 512)
+    det = L.Detect(nc=1, anchors=((10, 13, 16, 30, 33, 23), (30, 61, 62, 45, 59, 119), (116, 90, 156, 198, 373, 326)), ch=ch).to(dev).eval()
+    det.stride = torch.tensor([8., 16., 32.], device=dev)
+    det.anchors /= det.stride.view(-1, 1, 1)
+    xs = [torch.randn(3, c, s, s + 1, device=dev).to(dt).contiguous(memory_format=torch.channels_last) for c, s in zip(ch, (20, 10, 5))]
+    with torch.no_grad():
+        z1, p1 = det([t for t in xs])
+        modules.FUSED_DETECT_LEVEL = False
+        try:
+            z0, p0 = det([t for t in xs])
+        finally:
+            modules.FUSED_DETECT_LEVEL = True
+    tol = dict(rtol=2e-2, atol=2e-2) if dt == torch.bfloat16 else dict(rtol=1e-4, atol=1e-4)
+    assert z1.shape == z0.shape == (3, 3 * (20 * 21 + 10 * 11 + 5 * 6), 6)
+    for a, b in zip(p1, p0):
+        torch.testing.assert_close(a, b, **tol)
+    torch.testing.assert_close(z1, z0, rtol=tol["rtol"], atol=tol["atol"] * 40)      # (xy / wh are scaled by stride and anchors)
+
+
 def test_train_step_uint8_equals_float_batch():
     """forward_backward on the uint8 batch (no fp32 copy of the images) reproduces the gradients of the float / 255 batch"""
     import lead_yolo_amd as L

@@ -6,8 +6,11 @@
 // operand is read straight from the feature map (lane (pixel, g) loads the 8 channels 32 s + 8 g .. of its pixel per k-step: 64 contiguous bytes
 // per pixel over the four g), the two weight tiles (32 rows, natural k order: pack.frag_pack_nat) sit in LDS, and sigmoid / grid / anchor
 // arithmetic runs on the fp32 accumulators — the raw map is no longer rounded to bf16 on its way to p.
+#include <cstdlib>
 #include "ly_common.hpp"
 #include "ly_tile.hpp"
+
+#define LY_DET_LD 36            // floats per pixel row of a wave's output tile in LDS (32 channels + pad, rows 16-byte aligned)
 
 template <typename T, int S>
 __global__ __launch_bounds__(LY_THREADS) void ly_detect_level_kernel(const T* __restrict__ x, const int ldx, const long M, const int H, const int W,
@@ -23,20 +26,15 @@ __global__ __launch_bounds__(LY_THREADS) void ly_detect_level_kernel(const T* __
   const int px = lane & 15, g = lane >> 4;
   const int co = na * no, HW = H * W;
   const float invHW = 1.f / (float)HW, invW = 1.f / (float)W;
-  // the lane's channels c = 16 t + 4 g + r: bias, anchor index, output index
-  float cb[2][4];
-  int ca[2][4], cox[2][4];
+  float cb[2][4];                                            // bias of the lane's channels c = 16 t + 4 g + r
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int c = 16 * t + 4 * g + r;
-      const bool ok = c < co;
-      const int a = ok ? c / no : 0;
-      ca[t][r] = ok ? a : -1;
-      cox[t][r] = c - a * no;
-      cb[t][r] = ok ? bias[c] : 0.f;
+      cb[t][r] = c < co ? bias[c] : 0.f;
     }
+  float* const ot = reinterpret_cast<float*>(ly_det_w + 2 * S * PL * 64) + wave * (16 * LY_DET_LD);
   const int tile0 = (blockIdx.x * (LY_THREADS / 64) + wave) * tpw;
   for (int i = 0; i < tpw; ++i) {
     const int tile = tile0 + i;
@@ -80,27 +78,42 @@ __global__ __launch_bounds__(LY_THREADS) void ly_detect_level_kernel(const T* __
           acc[t] = ly_mfma_bf16(wh, xh[s], acc[t]);
         }
       }
-    const int n = ly_fdiv((int)(live ? m : 0), HW, invHW);
-    const int rem = (int)(live ? m : 0) - n * HW;
-    const int h = ly_fdiv(rem, W, invW);
-    const int w = rem - h * W;
+    // accumulators (+ bias) -> the wave's [16 px][36] fp32 LDS tile -> lanes walk the tile's outputs in MEMORY order (anchor, pixel, o): p and z
+    // of 16 consecutive pixels are na runs of 16 no contiguous floats each, so every store instruction writes consecutive addresses
+    // (written from the accumulator layout — lane = (pixel, 4 channels) — the same bytes took 16 scattered 4-byte stores per lane: 19.6 us at
+    // 80 x 80 x 128, bs=16).
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < 2; ++t) {
+      f32x4 v;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int a = ca[t][r], o = cox[t][r];
-        if (a < 0 || !live) continue;
-        const float v = acc[t][r] + cb[t][r];
-        p[((((long)n * na + a) * H + h) * W + w) * no + o] = v;
-        if (z) {
-          const float sg = ly_sigmoid(v);
-          float q = sg;
-          if (o == 0) q = (sg * 2.f + ((float)w - 0.5f)) * stride;
-          else if (o == 1) q = (sg * 2.f + ((float)h - 0.5f)) * stride;
-          else if (o == 2 || o == 3) { const float d = sg * 2.f; q = d * d * (anchors[a * 2 + (o - 2)] * stride); }
-          z[((long)n * zrows + zoff + ((long)a * H + h) * W + w) * no + o] = q;
-        }
+      for (int r = 0; r < 4; ++r) v[r] = acc[t][r] + cb[t][r];
+      *reinterpret_cast<f32x4*>(ot + px * LY_DET_LD + 16 * t + 4 * g) = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);                      // lgkmcnt(0): the tile is written (one wave: no block barrier)
+    const long m0 = (long)tile * 16;
+    const int run = 16 * no, total = na * run;
+    for (int e = lane; e < total; e += 64) {
+      const int a = e / run, q = e - a * run;
+      const int pl = q / no, o = q - pl * no;
+      const long mm = m0 + pl;
+      if (mm >= M) continue;
+      const int n = ly_fdiv((int)mm, HW, invHW);
+      const int hw = (int)mm - n * HW;
+      const float v = ot[pl * LY_DET_LD + a * no + o];
+      p[(((long)n * na + a) * HW + hw) * no + o] = v;
+      if (z) {
+        const int h = ly_fdiv(hw, W, invW);
+        const int w = hw - h * W;
+        const float sg = ly_sigmoid(v);
+        float r = sg;
+        if (o == 0) r = (sg * 2.f + ((float)w - 0.5f)) * stride;
+        else if (o == 1) r = (sg * 2.f + ((float)h - 0.5f)) * stride;
+        else if (o == 2 || o == 3) { const float d = sg * 2.f; r = d * d * (anchors[a * 2 + (o - 2)] * stride); }
+        z[((long)n * zrows + zoff + (long)a * HW + hw) * no + o] = r;
       }
+    }
+    __builtin_amdgcn_wave_barrier();                         // (the next tile overwrites the LDS tile)
   }
 }
 
@@ -111,8 +124,9 @@ static void detect_level_launch(const void* x, int ldx, long M, int H, int W, co
   // tiles per wave: one until every SIMD holds ~4 waves, then more (the 2 x K weight rows a block stages are amortised over 4 tpw tiles)
   int tpw = ntiles / (256 * 4 * 4);
   tpw = tpw < 1 ? 1 : tpw > 8 ? 8 : tpw;
+  if (const char* e = getenv("LY_DET_TPW")) tpw = atoi(e) > 0 ? atoi(e) : tpw;      // development knob
   const int per_block = (LY_THREADS / 64) * tpw;
-  const size_t lds = (size_t)2 * S * LyT<T>::PL * 64 * sizeof(uint4);
+  const size_t lds = (size_t)2 * S * LyT<T>::PL * 64 * sizeof(uint4) + (LY_THREADS / 64) * 16 * LY_DET_LD * sizeof(float);
   hipLaunchKernelGGL((ly_detect_level_kernel<T, S>), dim3((unsigned)((ntiles + per_block - 1) / per_block)), dim3(LY_THREADS), lds, st,
                      reinterpret_cast<const T*>(x), ldx, M, H, W, reinterpret_cast<const uint4*>(wp), bias, na, no, anchors, stride, p, z, zrows, zoff,
                      ntiles, tpw);

@@ -1,5 +1,5 @@
 """Device time per kernel of ONE eager eval forward (torch profiler, device activity): the launches a GraphedForward replays.
-    python tools/fwd_kernels.py [f32|bf16] [bs] [top]"""
+    python tools/fwd_kernels.py [f32|bf16] [bs] [top] [parts]"""
 import os, sys, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,7 +9,10 @@ dev = torch.device("cuda:0")
 bf = len(sys.argv) > 1 and sys.argv[1] == "bf16"
 bs = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 top = int(sys.argv[3]) if len(sys.argv) > 3 else 60
+parts = int(sys.argv[4]) if len(sys.argv) > 4 else 1      # kernel choice as inside a GraphedForward of `parts` concurrent sub-batches
 model = B.build_model("s", dev)
+from lead_yolo_amd import ops
+ops.CONCURRENT_PARTS = parts
 x = B.synth_batch(bs, 640, 0, dev)
 if bf:
     x = x.to(torch.bfloat16)

@@ -250,9 +250,11 @@ int ly_detect_tail(const void* y /*T*/, int ldy, int n_img, int H, int W, int na
                    float* p, float* z, long zrows, long zoff, int dtype, void* stream);
 /* Detect level in ONE launch (eval; csrc/ly_detect.hip): the head's 1x1 convolution x[n*H*W, K] (row stride ldx, T) -> na*no <= 32 channels
  * + bias and the ly_detect_tail arithmetic on the fp32 accumulators.  wp: the head weight [na*no, K] as two 16-row tiles in NATURAL k
- * order — uint4 wp[((t*S + s)*PL + plane)*64 + lane], lane = g*16 + i holds row 16t + i, k = 32s + 8g + 0..7 (pack.frag_pack_nat; PL = 2
- * hi / lo planes for LY_F32, 1 for LY_BF16), S = K/32 in {2, 4, 8} (16 in bf16).  p / z / zrows / zoff as ly_detect_tail (z may be NULL).    */
-int ly_detect_level(const void* x /*T*/, int ldx, int n_img, int H, int W, int K, const void* wp, const float* bias, int na, int no,
+ * order — uint4 wp[((t*S + s)*PL + plane)*64 + lane], lane = g*16 + i holds row 16t + i, k = 32s + 8g + 0..7 (nat != 0: pack.frag_pack_nat)
+ * — or, nat == 0, in the layout of every other contraction (ly_frag_pack3 with 32 rows: the training step's packs are used as they are);
+ * PL = 2 hi / lo planes for LY_F32, 1 for LY_BF16; S = K/32 in {2, 4, 8} (16 in bf16).  p / z / zrows / zoff as ly_detect_tail (z may be
+ * NULL: training, where the loss reads the raw maps).                                                                                   */
+int ly_detect_level(const void* x /*T*/, int ldx, int n_img, int H, int W, int K, const void* wp, int nat, const float* bias, int na, int no,
                     const float* anchors, float stride, float* p, float* z, long zrows, long zoff, int dtype, void* stream);
 int ly_detect_level_ok(int K, int na, int no, int dtype);     /* 1 when ly_detect_level is built for this shape */
 /* Adjoint of that permute for the training step (models/yolo.py:88): dp fp32 [n, na, H, W, no] -> du rows [n*H*W][ldu] of T (column a*no+o;

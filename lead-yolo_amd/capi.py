@@ -147,7 +147,7 @@ SIGNATURES = {
     "ly_loss_level": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _F, _P],
     "ly_loss_finish": [_P, _I, _P, _P, _F, _F, _F, _I, _I, _P, _P],
     "ly_detect_tail": [_P, _I, _I, _I, _I, _I, _I, _P, _F, _P, _P, _L, _L, _I, _P],
-    "ly_detect_level": [_P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _F, _P, _P, _L, _L, _I, _P],
+    "ly_detect_level": [_P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _I, _P, _F, _P, _P, _L, _L, _I, _P],
     "ly_detect_level_ok": [_I, _I, _I, _I],
     "ly_detect_head_bwd": [_P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P],
     "ly_pack_table": [_P, _P, _I, _P],

@@ -12,7 +12,7 @@
 
 #define LY_DET_LD 36            // floats per pixel row of a wave's output tile in LDS (32 channels + pad, rows 16-byte aligned)
 
-template <typename T, int S>
+template <typename T, int S, bool NAT>
 __global__ __launch_bounds__(LY_THREADS) void ly_detect_level_kernel(const T* __restrict__ x, const int ldx, const long M, const int H, const int W,
                                                                       const uint4* __restrict__ wp, const float* __restrict__ bias, const int na,
                                                                       const int no, const float* __restrict__ anchors, const float stride,
@@ -41,20 +41,29 @@ __global__ __launch_bounds__(LY_THREADS) void ly_detect_level_kernel(const T* __
     if (tile >= ntiles) break;
     const long m = (long)tile * 16 + px;
     const bool live = m < M;
-    const T* row = x + (live ? m : M - 1) * ldx + 8 * g;
+    // NAT: the lane's 8 channels of a k-step are consecutive (32 s + 8 g ..: one 16-byte load in bf16); else the k order of pack.frag_pack3
+    // (32 s + 4 g + 0..3 and 32 s + 16 + 4 g + 0..3: the training step's packed weights are used as they are)
+    const T* row = x + (live ? m : M - 1) * ldx + (NAT ? 8 : 4) * g;
+    constexpr int SECOND = NAT ? 4 : 16;
     bf16x8 xh[S], xl[S];
     if constexpr (PL == 1) {
-      uint4 raw[S];
+      ly_u32x2 ra[S], rb[S];
 #pragma unroll
-      for (int s = 0; s < S; ++s) raw[s] = *reinterpret_cast<const uint4*>(row + 32 * s);
+      for (int s = 0; s < S; ++s) {
+        ra[s] = *reinterpret_cast<const ly_u32x2*>(row + 32 * s);
+        rb[s] = *reinterpret_cast<const ly_u32x2*>(row + 32 * s + SECOND);
+      }
 #pragma unroll
-      for (int s = 0; s < S; ++s) { xh[s] = __builtin_bit_cast(bf16x8, raw[s]); xl[s] = xh[s]; }
+      for (int s = 0; s < S; ++s) {
+        xh[s] = ly_cat8(__builtin_bit_cast(bf16x4, ra[s]), __builtin_bit_cast(bf16x4, rb[s]));
+        xl[s] = xh[s];
+      }
     } else {
       f32x4 ra[S], rb[S];
 #pragma unroll
       for (int s = 0; s < S; ++s) {
         ra[s] = *reinterpret_cast<const f32x4*>(row + 32 * s);
-        rb[s] = *reinterpret_cast<const f32x4*>(row + 32 * s + 4);
+        rb[s] = *reinterpret_cast<const f32x4*>(row + 32 * s + SECOND);
       }
 #pragma unroll
       for (int s = 0; s < S; ++s) {
@@ -118,7 +127,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_detect_level_kernel(const T* __
 }
 
 template <typename T, int S>
-static void detect_level_launch(const void* x, int ldx, long M, int H, int W, const void* wp, const float* bias, int na, int no, const float* anchors,
+static void detect_level_launch(const int nat, const void* x, int ldx, long M, int H, int W, const void* wp, const float* bias, int na, int no, const float* anchors,
                                 float stride, float* p, float* z, long zrows, long zoff, hipStream_t st) {
   const int ntiles = (int)((M + 15) / 16);
   // tiles per wave: one until every SIMD holds ~4 waves, then more (the 2 x K weight rows a block stages are amortised over 4 tpw tiles)
@@ -127,12 +136,16 @@ static void detect_level_launch(const void* x, int ldx, long M, int H, int W, co
   if (const char* e = getenv("LY_DET_TPW")) tpw = atoi(e) > 0 ? atoi(e) : tpw;      // development knob
   const int per_block = (LY_THREADS / 64) * tpw;
   const size_t lds = (size_t)2 * S * LyT<T>::PL * 64 * sizeof(uint4) + (LY_THREADS / 64) * 16 * LY_DET_LD * sizeof(float);
-  hipLaunchKernelGGL((ly_detect_level_kernel<T, S>), dim3((unsigned)((ntiles + per_block - 1) / per_block)), dim3(LY_THREADS), lds, st,
-                     reinterpret_cast<const T*>(x), ldx, M, H, W, reinterpret_cast<const uint4*>(wp), bias, na, no, anchors, stride, p, z, zrows, zoff,
-                     ntiles, tpw);
+  const dim3 grid((unsigned)((ntiles + per_block - 1) / per_block));
+  if (nat)
+    hipLaunchKernelGGL((ly_detect_level_kernel<T, S, true>), grid, dim3(LY_THREADS), lds, st, reinterpret_cast<const T*>(x), ldx, M, H, W,
+                       reinterpret_cast<const uint4*>(wp), bias, na, no, anchors, stride, p, z, zrows, zoff, ntiles, tpw);
+  else
+    hipLaunchKernelGGL((ly_detect_level_kernel<T, S, false>), grid, dim3(LY_THREADS), lds, st, reinterpret_cast<const T*>(x), ldx, M, H, W,
+                       reinterpret_cast<const uint4*>(wp), bias, na, no, anchors, stride, p, z, zrows, zoff, ntiles, tpw);
 }
 
-extern "C" int ly_detect_level(const void* x, int ldx, int n_img, int H, int W, int K, const void* wp, const float* bias, int na, int no,
+extern "C" int ly_detect_level(const void* x, int ldx, int n_img, int H, int W, int K, const void* wp, int nat, const float* bias, int na, int no,
                                const float* anchors, float stride, float* p, float* z, long zrows, long zoff, int dtype, void* stream) {
   LY_CHECK_DTYPE(dtype, "detect_level");
   LY_CHECK(x && wp && bias && anchors && p && n_img > 0 && H > 0 && W > 0, "detect_level: null pointer / bad sizes");
@@ -143,11 +156,11 @@ extern "C" int ly_detect_level(const void* x, int ldx, int n_img, int H, int W, 
   LY_CHECK(M < (1L << 24), "detect_level: too many pixels");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int S = K / 32;
-#define LY_DET(S_) LY_WITH_T(dtype, (detect_level_launch<T, S_>(x, ldx, M, H, W, wp, bias, na, no, anchors, stride, p, z, zrows, zoff, st)))
+#define LY_DET(S_) LY_WITH_T(dtype, (detect_level_launch<T, S_>(nat, x, ldx, M, H, W, wp, bias, na, no, anchors, stride, p, z, zrows, zoff, st)))
   if (S == 2) LY_DET(2);
   else if (S == 4) LY_DET(4);
   else if (S == 8) LY_DET(8);
-  else if (S == 16 && dtype == LY_BF16) detect_level_launch<__bf16, 16>(x, ldx, M, H, W, wp, bias, na, no, anchors, stride, p, z, zrows, zoff, st);
+  else if (S == 16 && dtype == LY_BF16) detect_level_launch<__bf16, 16>(nat, x, ldx, M, H, W, wp, bias, na, no, anchors, stride, p, z, zrows, zoff, st);
   else { ly_set_error("detect_level: K = %d is not built (64, 128, 256; 512 in bf16)", K); return -1; }
 #undef LY_DET
   LY_LAUNCH_CHECK();

@@ -15,6 +15,7 @@ Only [C]-sized vectors are handled with torch ops (coefficients of step 3, param
 """
 import ctypes
 
+import os
 import torch
 
 from . import ops, pack
@@ -456,6 +457,9 @@ def conv_bn_act_pair(act, up, wp, x0, x1, conv1, bn1, conv2, bn2):
     return ConvBnActPair.apply(spec, wp, bn1, bn2, x0, x1, conv1.weight, conv2.weight, bn1.weight, bn1.bias, bn2.weight, bn2.bias)
 
 
+FUSED_DETECT_LEVEL = os.environ.get("LY_DET_TRAIN", "1") != "0"      # development switch: 0 = head GEMM + ly_detect_tail in the training forward
+
+
 class DetectHeadFn(torch.autograd.Function):
     """One Detect level in training (models/yolo.py:84-88): p = (conv1x1(x) + bias).view(bs, na, no, ny, nx).permute(0, 1, 3, 4, 2) as the
     fp32 raw map the loss reads.  forward = the head contraction + ly_detect_tail (permute + conversion, one pass); backward = ONE kernel
@@ -469,10 +473,15 @@ class DetectHeadFn(torch.autograd.Function):
         co = weight.shape[0]
         spec = ConvSpec("pw", co)
         bias_f = bias.detach().float().contiguous()
-        y = _conv_forward(spec, x, None, wp, None, bias_f, ACT_NONE)
-        bs, _, ny, nx = y.shape
-        p = torch.empty((bs, det.na, ny, nx, det.no), dtype=torch.float32, device=y.device)
-        ops.detect_tail(y, co, bs, ny, nx, det.na, det.no, det.anchors[i], 1.0, p, None, 0, 0)
+        bs, cin, ny, nx = x.shape
+        p = torch.empty((bs, det.na, ny, nx, det.no), dtype=torch.float32, device=x.device)
+        t0, ld = ops.rows(x)
+        if FUSED_DETECT_LEVEL and ops.detect_level_ok(cin, det.na, det.no, t0.dtype) and ld % ops.vw_of(t0) == 0 and t0.data_ptr() % 16 == 0:
+            # head contraction + permute in one launch (csrc/ly_detect.hip), on the step's packed weights as they are
+            ops.detect_level(t0, ld, bs, ny, nx, cin, wp, bias_f, det.na, det.no, det.anchors[i], 1.0, p, None, 0, 0, nat=False)
+        else:
+            y = _conv_forward(spec, x, None, wp, None, bias_f, ACT_NONE)
+            ops.detect_tail(y, co, bs, ny, nx, det.na, det.no, det.anchors[i], 1.0, p, None, 0, 0)
         ctx.spec, ctx.geom = spec, (bs, ny, nx, det.na, det.no)
         ctx.params = (weight, bias)
         ctx.save_for_backward(x, weight)

@@ -513,11 +513,12 @@ def detect_level_ok(k, na, no, dtype):
     return dtype in (torch.float32, torch.bfloat16) and bool(capi.lib().ly_detect_level_ok(k, na, no, capi.dtype_code(dtype)))
 
 
-def detect_level(x, ldx, n, h, w, k, wp, bias, na, no, anchors, stride, p, z, zrows, zoff):
-    """head 1x1 convolution + decode of one Detect level in ONE launch (ly_detect_level): x rows [n*h*w, k] -> p [n, na, h, w, no], z rows"""
+def detect_level(x, ldx, n, h, w, k, wp, bias, na, no, anchors, stride, p, z, zrows, zoff, nat=True):
+    """head 1x1 convolution + decode of one Detect level in ONE launch (ly_detect_level): x rows [n*h*w, k] -> p [n, na, h, w, no], z rows
+    (z None: raw maps only).  nat: wp from pack.frag_pack_nat, else the frag_pack3 layout (>= 32 rows)"""
     es = x.element_size()
     with _Timed(f"ly_detect_level_kernel<{_tname(x)}, {k // 32}>", 2.0 * n * h * w * k * 32, es * n * h * w * k + 8.0 * n * h * w * na * no):
-        capi.check(capi.lib().ly_detect_level(_p(x), ldx, n, h, w, k, _p(wp), _p(bias), na, no, _p(anchors), float(stride), _p(p), _p(z), zrows, zoff,
+        capi.check(capi.lib().ly_detect_level(_p(x), ldx, n, h, w, k, _p(wp), int(nat), _p(bias), na, no, _p(anchors), float(stride), _p(p), _p(z), zrows, zoff,
                                               capi.dtype_code(x), capi.stream_ptr()), "ly_detect_level")
 
 

@@ -851,8 +851,9 @@ def test_patch4_rows_u8_equals_permuted_copy(shape, dtype):
 @pytest.mark.parametrize("geom", [(2, 64, 20, 20), (1, 40, 7, 13), (3, 128, 5, 160)])
 def test_detect_head_node_equals_autograd_chain(geom, dtype):
     """grad.DetectHeadFn (one Detect level in training, models/yolo.py:84-88) vs the generic conv node followed by autograd's
-    view / permute / copy chain: same raw map bit for bit, same dx / dW / dbias (both use the same contraction kernels; the fused
-    adjoint only changes who lays out du and who sums the bias gradient)."""
+    view / permute / copy chain: same raw map (the node's forward is ly_detect_level where it is built: the fp32 accumulators go to the
+    map as they are, the chain rounds the head output to the storage type first), same dx / dW / dbias (both use the same contraction
+    kernels; the fused adjoint only changes who lays out du and who sums the bias gradient)."""
     import lead_yolo_amd as L
     from lead_yolo_amd import grad, pack
     bs, cin, ny, nx = geom
@@ -879,7 +880,7 @@ def test_detect_head_node_equals_autograd_chain(geom, dtype):
         (p * r).sum().backward()
         res.append((p.detach().clone(), x.grad.clone(), conv.weight.grad.clone(), conv.bias.grad.clone()))
     (p1, dx1, dw1, db1), (p2, dx2, dw2, db2) = res
-    assert torch.equal(p1, p2)
+    torch.testing.assert_close(p1, p2, rtol=1e-5 if dtype == torch.float32 else 8e-3, atol=1e-5 if dtype == torch.float32 else 8e-3)
     tol = 1e-5 if dtype == torch.float32 else 1e-2        # bf16: the chain rounds dp to bf16 before summing the bias gradient, the node after
     _close(dx1, dx2.float(), "dx", rtol=tol)
     _close(dw1, dw2, "dw", rtol=tol)

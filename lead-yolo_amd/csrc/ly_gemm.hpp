@@ -511,6 +511,9 @@ static int launch_gemm_v(const LyGemmParams& P, hipStream_t st) {
     if constexpr (oks1) { if (nchunk == 1) return launch_gemm_d2<TI, TO, NT, MT, WC, GATHER, PRO, 1, 2>(P, st); }
     if constexpr (oks2) { if (nchunk == 2) return launch_gemm_d2<TI, TO, NT, MT, WC, GATHER, PRO, 2, 2>(P, st); }
   }
+  if constexpr (PRO == LY_PRO_GATE) {                      // CoordAtt-gate GEMM with K in more than one chunk (eval C3_CA.cv3): the branch-free epilogue
+    if (fast && !P.stats) return launch_gemm_d2<TI, TO, NT, MT, WC, GATHER, PRO, 0, 1>(P, st);
+  }
   if constexpr (PRO == LY_PRO_NONE) {                      // long K: weights streamed one item ahead, still the branch-free epilogue
     if (fast) return P.stats ? launch_gemm_d2<TI, TO, NT, MT, WC, GATHER, PRO, 0, 2>(P, st) : launch_gemm_d2<TI, TO, NT, MT, WC, GATHER, PRO, 0, 1>(P, st);
   }

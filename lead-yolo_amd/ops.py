@@ -202,7 +202,7 @@ def gemm(*, M, H, W, K, N, a0, lda0, k0, wp, out, ldo, a1=None, lda1=0, gather=G
             ok1, ok2 = ok1 and pro != PRO_GATE, ok2 and pro == 0
         nch = 1 if (nchunk == 1 and ok1) else 2 if (nchunk == 2 and ok2) else 0
     fast = N % 4 == 0 and ldo % 4 == 0 and out is not None
-    ep = (2 if stats is not None else 1) if (nch or (fast and pro == 0)) else 0
+    ep = (2 if stats is not None else 1) if (nch or (fast and pro == 0)) else 1 if (fast and pro == PRO_GATE and stats is None) else 0
     name = f"ly_gemm_kernel_d2<{ti}, {to}, {nt}, {mt}, {wc}, {kgather}, {pro}, {nch}, {ep}>"
     if (image and Cin == 3 and K == 48 and 20 <= N <= 80 and N % 4 == 0 and (out is None or ldo % 4 == 0) and Hin == 4 * H and Win == 4 * W
             and (code != 0 or gather in (GATHER_PATCH_NCHW, GATHER_PATCH_NCHW_U8))):

@@ -445,7 +445,9 @@ int ly_bn_finalize(const void* stats /* [stripes][2 nch] floats, or doubles if s
  * caller zeroes: they may be the parameters' persistent gradient storage) and
  * du = alpha*dv + kappa + lambda*u  (train != 0: batch statistics; else alpha = a, kappa = lambda = 0).               */
 int ly_bn_bwd_coeffs(const void* sums /* floats, or doubles if sums_f64 */, int sums_f64, int stripes, int N, double count, const float* a,
-                     const float* mean, const float* invstd, int train, float* dgamma, float* dbeta, float* alpha, float* kappa, float* lambda, void* stream);
+                     const float* mean, const float* invstd, int train, float* dgamma, float* dbeta, float* alpha, float* kappa, float* lambda,
+                     int tr_a, int tr_b /* tr_a > 0: channel j = t*tr_b + c of the sums goes to dgamma / dbeta [c*tr_a + t] (RFCBAMConv's generate BatchNorm:
+                                           sums in [tap][channel] order, parameters in [channel][tap]); 0, 0: same index */, void* stream);
 /* Fragment packing of the fp32 matrix W[r][k] = w[r*ld_r + k*ld_k] (R x K, rows zero padded to max(R, rows_to)) into the
  * [T][S][planes][64 lanes][8] bf16 layout the contraction kernels read (csrc/ly_tile.hpp): planes = 2 (hi = bf16(W),
  * lo = bf16(W - hi): the bf16x3 operand of LY_F32 calls) or 1 (hi only: LY_BF16 calls).                                */

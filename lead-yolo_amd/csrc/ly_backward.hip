@@ -1365,16 +1365,19 @@ __global__ __launch_bounds__(LY_BNV_THREADS) void ly_bn_bwd_coeffs_kernel(const 
                                                                       const float* __restrict__ a, const float* __restrict__ mean,
                                                                       const float* __restrict__ invstd, int train, float* __restrict__ dgamma,
                                                                       float* __restrict__ dbeta, float* __restrict__ alpha, float* __restrict__ kappa,
-                                                                      float* __restrict__ lambda) {
+                                                                      float* __restrict__ lambda, const int tr_a, const int tr_b) {
   const int c = blockIdx.x * LY_BNV_THREADS + threadIdx.x;
   if (c >= N) return;
+  // tr_a > 0: the sums are in [tr_a][tr_b] order (RFCBAMConv's generate BatchNorm: [tap][channel]) and dgamma / dbeta are the parameter's own
+  // [tr_b][tr_a] storage — the transpose rides on the accumulation instead of two copies + two adds per layer
+  const int cd = tr_a > 0 ? (c % tr_b) * tr_a + c / tr_b : c;
   const double mu = mean[c], is = invstd[c], av = a[c];
-  const float dg0 = dgamma[c], db0 = dbeta[c];
+  const float dg0 = dgamma[cd], db0 = dbeta[cd];
   double s1, s2;
   ly_fold_stripes(sums + c, stripes, (size_t)2 * N, N, s1, s2);
   const double dg = (s2 - mu * s1) * is;
-  dgamma[c] = dg0 + (float)dg;     // ACCUMULATED: the targets may be the parameters' persistent .grad storage (zeroed by the optimiser step)
-  dbeta[c] = db0 + (float)s1;
+  dgamma[cd] = dg0 + (float)dg;    // ACCUMULATED: the targets may be the parameters' persistent .grad storage (zeroed by the optimiser step)
+  dbeta[cd] = db0 + (float)s1;
   alpha[c] = (float)av;
   if (train) {
     const double lam = -av * dg * is / count;
@@ -1387,14 +1390,15 @@ __global__ __launch_bounds__(LY_BNV_THREADS) void ly_bn_bwd_coeffs_kernel(const 
 }
 
 extern "C" int ly_bn_bwd_coeffs(const void* sums, int sums_f64, int stripes, int N, double count, const float* a, const float* mean, const float* invstd,
-                                int train, float* dgamma, float* dbeta, float* alpha, float* kappa, float* lambda, void* stream) {
+                                int train, float* dgamma, float* dbeta, float* alpha, float* kappa, float* lambda, int tr_a, int tr_b, void* stream) {
   LY_CHECK(sums && a && mean && invstd && dgamma && dbeta && alpha && kappa && lambda && N > 0 && count > 0, "bn_bwd_coeffs: bad arguments");
+  LY_CHECK(tr_a == 0 || (tr_a > 0 && tr_b > 0 && tr_a * tr_b == N), "bn_bwd_coeffs: transposed targets need tr_a * tr_b == N");
   if (sums_f64)
     hipLaunchKernelGGL(ly_bn_bwd_coeffs_kernel<double>, dim3((N + LY_BNV_THREADS - 1) / LY_BNV_THREADS), dim3(LY_BNV_THREADS), 0, reinterpret_cast<hipStream_t>(stream),
-                       reinterpret_cast<const double*>(sums), stripes, N, count, a, mean, invstd, train, dgamma, dbeta, alpha, kappa, lambda);
+                       reinterpret_cast<const double*>(sums), stripes, N, count, a, mean, invstd, train, dgamma, dbeta, alpha, kappa, lambda, tr_a, tr_b);
   else
     hipLaunchKernelGGL(ly_bn_bwd_coeffs_kernel<float>, dim3((N + LY_BNV_THREADS - 1) / LY_BNV_THREADS), dim3(LY_BNV_THREADS), 0, reinterpret_cast<hipStream_t>(stream),
-                       reinterpret_cast<const float*>(sums), stripes, N, count, a, mean, invstd, train, dgamma, dbeta, alpha, kappa, lambda);
+                       reinterpret_cast<const float*>(sums), stripes, N, count, a, mean, invstd, train, dgamma, dbeta, alpha, kappa, lambda, tr_a, tr_b);
   LY_LAUNCH_CHECK();
   return 0;
 }

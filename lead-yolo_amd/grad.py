@@ -875,6 +875,8 @@ class RfcbamFn(torch.autograd.Function):
         ctx.conv_b_param = conv_b
         ctx.out_bn_params = (out_gamma, out_beta)
         ctx.getw_param = getw
+        ctx.gen_w_param = gen_w
+        ctx.gen_bn_params = (gen_gamma, gen_beta)
         ctx.save_for_backward(xr, ca, gen_w, getw, conv_w, bias, G["ag"], G["bg"], G["gmean_tc"], G["ginv_tc"], es, t, omean, oinv, mm, rfa, se_part, u)
         return out
 
@@ -968,8 +970,14 @@ class RfcbamFn(torch.autograd.Function):
                             "ly_rf_bwd_relu")
             _tap("rf.d_mm", d_mm); _tap("rf.dv", dcd); _tap("rf.sums", sums)
             # 9. generate BatchNorm coefficients ([t][c] order)
-            dgg_tc, dbg_tc, alpha, kappa, lam = ops.bn_bwd_coeffs(sums, kk * c, mo, ag, gmean_tc, ginv_tc, True)
-            ct = lambda v: v.view(kk, c).t().contiguous().view(-1)
+            tgg, tgb = (ops.grad_target(q) for q in ctx.gen_bn_params)
+            bn_direct = all(q is not None and q.numel() == kk * c and q.is_contiguous() for q in (tgg, tgb))
+            dgg_tc, dbg_tc, alpha, kappa, lam = ops.bn_bwd_coeffs(sums, kk * c, mo, ag, gmean_tc, ginv_tc, True, dgamma=tgg if bn_direct else None,
+                                                                  dbeta=tgb if bn_direct else None, transpose=(kk, c))
+            if bn_direct:
+                ops.grad_done(ctx.gen_bn_params[0])
+                ops.grad_done(ctx.gen_bn_params[1])
+            ct = lambda v: None if v is None else v.view(kk, c).t().contiguous().view(-1)
             # 10. dug, generate weight gradient
             part_rows = 512
             dwg = torch.zeros(part_rows, c * kk, kk, dtype=torch.float32, device=dev)         # per-block partial sums, summed below
@@ -994,7 +1002,14 @@ class RfcbamFn(torch.autograd.Function):
                 with ops._Timed(f"ly_rf_bwd_dx_kernel<{ops._tname(xr)}, {k}>", 0.0, es9 + xr.element_size() * n * h * w * c, valu_flops=2.0 * mo * kk * kk * c):
                     L.check(L.lib().ly_rf_bwd_dx(n, h, w, c, k, s, p(dcd), p(wg), p(dx), c, p(dgap), 1.0 / (h * w), code, st), "ly_rf_bwd_dx")
             dbias = None if ops.grad_target(ctx.conv_b_param) is not None else torch.zeros_like(bias)      # BN removes the batch mean: d/dbias = 0
-        return (None, dx, None if se_direct else dwa, None if se_direct else dwb, ops.sum_rows(dwg).view(gen_w.shape), ct(dgg_tc), ct(dbg_tc),
+            tgw = ops.grad_target(ctx.gen_w_param)
+            if tgw is not None and tgw.is_contiguous() and tgw.numel() == dwg[0].numel():
+                ops.sum_rows(dwg, out=tgw.view(-1), accumulate=True)        # the partial rows of d(generate.0.weight) added straight into the sink
+                ops.grad_done(ctx.gen_w_param)
+                dgw = None
+            else:
+                dgw = ops.sum_rows(dwg).view(gen_w.shape)
+        return (None, dx, None if se_direct else dwa, None if se_direct else dwb, dgw, ct(dgg_tc), ct(dbg_tc),
                 (None if t18 is not None else dw18.view(getw.shape)), dwc, dbias, dgo, dbo)
 
 
@@ -1046,10 +1061,16 @@ def _rfcbam_backward_rc(ctx, du, dgo, dbo):
     # B: BatchNorm sums, one stripe per image
     with ops._Timed(f"ly_rf3c_bwd_kernel<1, {o // 32}>", 2.0 * mo * 9 * c * o, xb, valu_flops=2.0 * mo * c * 81):
         L.check(L.lib().ly_rf3c_bwd(ctypes.byref(P), 1, st), "ly_rf3c_bwd B")
-    dgg_tc, dbg_tc, alpha, kappa, lam = ops.bn_bwd_coeffs(sums, 9 * c, mo, ag, gmean_tc, ginv_tc, True)
+    tgg, tgb = (ops.grad_target(q) for q in ctx.gen_bn_params)
+    bn_direct = all(q is not None and q.numel() == 9 * c and q.is_contiguous() for q in (tgg, tgb))
+    dgg_tc, dbg_tc, alpha, kappa, lam = ops.bn_bwd_coeffs(sums, 9 * c, mo, ag, gmean_tc, ginv_tc, True, dgamma=tgg if bn_direct else None,
+                                                          dbeta=tgb if bn_direct else None, transpose=(9, c))
+    if bn_direct:
+        ops.grad_done(ctx.gen_bn_params[0])
+        ops.grad_done(ctx.gen_bn_params[1])
     P.coef = p(alpha)                          # alpha, kappa, lambda are rows 2..4 of one [5, 9c] tensor
     assert kappa.data_ptr() == alpha.data_ptr() + 4 * 9 * c and lam.data_ptr() == alpha.data_ptr() + 8 * 9 * c
-    ct = lambda v: v.view(9, c).t().contiguous().view(-1)
+    ct = lambda v: None if v is None else v.view(9, c).t().contiguous().view(-1)
     # SE backward: parameter gradients, and d/d(mean x) which pass C adds while it writes dx
     se_wa, se_wb = ctx.se_params
     ta, tb = ops.grad_target(se_wa), ops.grad_target(se_wb)
@@ -1067,7 +1088,14 @@ def _rfcbam_backward_rc(ctx, du, dgo, dbo):
     with ops._Timed(f"ly_rf3c_bwd_kernel<2, {o // 32}>", 2.0 * mo * 9 * c * o, xb + xr.element_size() * n * h * w * c, valu_flops=2.0 * mo * c * 243):
         L.check(L.lib().ly_rf3c_bwd(ctypes.byref(P), 2, st), "ly_rf3c_bwd C")
     dbias = None if ops.grad_target(ctx.conv_b_param) is not None else torch.zeros_like(bias)      # BN removes the batch mean: d/dbias = 0
-    return (None, dx if need_dx else None, None if se_direct else dwa, None if se_direct else dwb, ops.sum_rows(dwg).view(gen_w.shape), ct(dgg_tc), ct(dbg_tc),
+    tgw = ops.grad_target(ctx.gen_w_param)
+    if tgw is not None and tgw.is_contiguous() and tgw.numel() == dwg.shape[1]:
+        ops.sum_rows(dwg, out=tgw.view(-1), accumulate=True)            # the image rows of d(generate.0.weight) added straight into the sink
+        ops.grad_done(ctx.gen_w_param)
+        dgw = None
+    else:
+        dgw = ops.sum_rows(dwg).view(gen_w.shape)
+    return (None, dx if need_dx else None, None if se_direct else dwa, None if se_direct else dwb, dgw, ct(dgg_tc), ct(dbg_tc),
             (None if t18 is not None else dw18.view(getw.shape)), dwc, dbias, dgo, dbo)
 
 
@@ -1129,7 +1157,13 @@ def _rfcbam_backward_k1(ctx, du, dgo, dbo):
     P.d_mm, P.sums = p(d_mm), p(sums)
     with ops._Timed(f"ly_rf1_bwd_kernel<{tn}, 1>", 8.0 * mo * c, 2.0 * es1):
         L.check(L.lib().ly_rf1_bwd(ctypes.byref(P), 1, st), "ly_rf1_bwd B")
-    dgg, dbg, alpha, kappa, lam = ops.bn_bwd_coeffs(sums, c, mo, ag, gmean_tc, ginv_tc, True)
+    tgg, tgb = (ops.grad_target(q) for q in ctx.gen_bn_params)
+    bn_direct = tgg is not None and tgb is not None and tgg.numel() == c and tgb.numel() == c and tgg.is_contiguous() and tgb.is_contiguous()
+    dgg, dbg, alpha, kappa, lam = ops.bn_bwd_coeffs(sums, c, mo, ag, gmean_tc, ginv_tc, True, dgamma=tgg if bn_direct else None,
+                                                    dbeta=tgb if bn_direct else None)
+    if bn_direct:
+        ops.grad_done(ctx.gen_bn_params[0])
+        ops.grad_done(ctx.gen_bn_params[1])
     # SE backward: parameter gradients, and d/d(mean x), which pass C adds while it writes dx
     se_wa, se_wb = ctx.se_params
     ta, tb = ops.grad_target(se_wa), ops.grad_target(se_wb)

@@ -659,9 +659,10 @@ def bn_finalize(bn, stats, nch, count, n=None, c_off=0, bias=None, pad_to=0, wan
     return (scale, shift, mean, invstd) if want_stats else (scale, shift)
 
 
-def bn_bwd_coeffs(sums, n, count, a, mean, invstd, train, dgamma=None, dbeta=None):
+def bn_bwd_coeffs(sums, n, count, a, mean, invstd, train, dgamma=None, dbeta=None, transpose=None):
     """(dgamma, dbeta, alpha, kappa, lambda) from (striped) sums [.., 2n] of ly_bnact_bwd_reduce, ONE launch.  dgamma / dbeta given:
-    the kernel ADDS into them (a parameter's persistent gradient storage, see GradSink) and None is returned in their place."""
+    the kernel ADDS into them (a parameter's persistent gradient storage, see GradSink) and None is returned in their place.
+    transpose = (A, B): the sums' channels are in [A][B] order, dgamma / dbeta in [B][A] (generate BatchNorm of RFCBAMConv k = 3)."""
     dev = sums.device
     stripes = sums.shape[0] if sums.dim() == 2 else 1
     out = torch.empty(5, n, dtype=torch.float32, device=dev)
@@ -669,7 +670,8 @@ def bn_bwd_coeffs(sums, n, count, a, mean, invstd, train, dgamma=None, dbeta=Non
     if not direct:
         out[:2].zero_()
     capi.check(capi.lib().ly_bn_bwd_coeffs(_p(sums), int(sums.dtype == torch.float64), stripes, n, float(count), _p(a), _p(mean), _p(invstd), int(train), _p(dgamma if direct else out[0]),
-                                           _p(dbeta if direct else out[1]), _p(out[2]), _p(out[3]), _p(out[4]), capi.stream_ptr()), "ly_bn_bwd_coeffs")
+                                           _p(dbeta if direct else out[1]), _p(out[2]), _p(out[3]), _p(out[4]),
+                                           *((transpose if direct else None) or (0, 0)), capi.stream_ptr()), "ly_bn_bwd_coeffs")
     return (None if direct else out[0]), (None if direct else out[1]), out[2], out[3], out[4]
 
 

@@ -6,7 +6,6 @@
 // operand is read straight from the feature map (lane (pixel, g) loads the 8 channels 32 s + 8 g .. of its pixel per k-step: 64 contiguous bytes
 // per pixel over the four g), the two weight tiles (32 rows, natural k order: pack.frag_pack_nat) sit in LDS, and sigmoid / grid / anchor
 // arithmetic runs on the fp32 accumulators — the raw map is no longer rounded to bf16 on its way to p.
-#include <cstdlib>
 #include "ly_common.hpp"
 #include "ly_tile.hpp"
 
@@ -130,10 +129,10 @@ template <typename T, int S>
 static void detect_level_launch(const int nat, const void* x, int ldx, long M, int H, int W, const void* wp, const float* bias, int na, int no, const float* anchors,
                                 float stride, float* p, float* z, long zrows, long zoff, hipStream_t st) {
   const int ntiles = (int)((M + 15) / 16);
-  // tiles per wave: one until every SIMD holds ~4 waves, then more (the 2 x K weight rows a block stages are amortised over 4 tpw tiles)
+  // tiles per wave: one until every SIMD holds ~4 waves, then more (the 2 x K weight rows a block stages are amortised over 4 tpw tiles).
+  // Measured at bs=16 (one round of blocks): every further tile per wave adds ~5 us — a tile is one serial chain of memory round trips.
   int tpw = ntiles / (256 * 4 * 4);
   tpw = tpw < 1 ? 1 : tpw > 8 ? 8 : tpw;
-  if (const char* e = getenv("LY_DET_TPW")) tpw = atoi(e) > 0 ? atoi(e) : tpw;      // development knob
   const int per_block = (LY_THREADS / 64) * tpw;
   const size_t lds = (size_t)2 * S * LyT<T>::PL * 64 * sizeof(uint4) + (LY_THREADS / 64) * 16 * LY_DET_LD * sizeof(float);
   const dim3 grid((unsigned)((ntiles + per_block - 1) / per_block));

@@ -847,6 +847,28 @@ def test_patch4_rows_u8_equals_permuted_copy(shape, dtype):
     assert got.shape == want.shape and torch.equal(got, want)
 
 
+def test_bn_bwd_coeffs_transposed_targets_accumulate():
+    """ly_bn_bwd_coeffs with tr_a, tr_b (RFCBAMConv's generate BatchNorm: sums in [tap][channel] order, parameters in [channel][tap]):
+    dgamma / dbeta are ADDED into the transposed targets, alpha / kappa / lambda stay in the sums' order"""
+    from lead_yolo_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(2)
+    kk, c, count = 9, 40, 777.0
+    n = kk * c
+    sums = torch.randn(ops.STRIPES, 2 * n, generator=g, dtype=torch.float64).to(dev)
+    a, mean = torch.rand(n, generator=g).to(dev) + 0.5, torch.randn(n, generator=g).to(dev)
+    invstd = torch.rand(n, generator=g).to(dev) + 0.5
+    dg0, db0, al0, ka0, la0 = ops.bn_bwd_coeffs(sums, n, count, a, mean, invstd, True)
+    tg, tb = torch.randn(n, generator=g).to(dev), torch.randn(n, generator=g).to(dev)
+    tg1, tb1 = tg.clone(), tb.clone()
+    r = ops.bn_bwd_coeffs(sums, n, count, a, mean, invstd, True, dgamma=tg1, dbeta=tb1, transpose=(kk, c))
+    assert r[0] is None and r[1] is None
+    tr = lambda v: v.view(kk, c).t().contiguous().view(-1)
+    torch.testing.assert_close(tg1, tg + tr(dg0), rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(tb1, tb + tr(db0), rtol=1e-6, atol=1e-6)
+    assert torch.equal(r[2], al0) and torch.equal(r[3], ka0) and torch.equal(r[4], la0)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("geom", [(2, 64, 20, 20), (1, 40, 7, 13), (3, 128, 5, 160)])
 def test_detect_head_node_equals_autograd_chain(geom, dtype):

@@ -107,6 +107,24 @@ def test_struct_layouts_match_header_field_order():
         assert names == [f[0] for f in cls._fields_], cls.__name__
 
 
+def test_frag_pack_nat_layout():
+    """pack.frag_pack_nat (the A operand of ly_detect_level): lane = g*16 + i holds row 16t + i and k = 32s + 8g + j; hi + lo planes
+    reproduce the fp32 matrix to bf16x2 precision, padding rows / columns are zero"""
+    from lead_yolo_amd import pack
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(18, 72, generator=g)
+    pk = pack.frag_pack_nat(w, planes=2)
+    assert pk.shape == (2, 3, 2, 64, 8) and pk.dtype == torch.int16
+    v = pk.view(torch.bfloat16).float()
+    full = v[:, :, 0] + v[:, :, 1]                                    # [T, S, lane, j]
+    for t, s_, lane, j in ((0, 0, 0, 0), (0, 1, 17, 3), (1, 2, 33, 7), (1, 0, 49, 5), (0, 2, 63, 7)):
+        r, k = 16 * t + (lane & 15), 32 * s_ + 8 * (lane >> 4) + j
+        want = float(w[r, k]) if (r < 18 and k < 72) else 0.0
+        assert abs(float(full[t, s_, lane, j]) - want) <= 2e-5 * max(1.0, abs(want)), (t, s_, lane, j)
+    one = pack.frag_pack_nat(w, planes=1).view(torch.bfloat16).float()
+    assert one.shape == (2, 3, 1, 64, 8) and torch.equal(one[:, :, 0], v[:, :, 0])
+
+
 def test_pick_tile():
     for ho, wo in ((40, 40), (20, 20), (80, 80), (5, 6), (1, 1), (3, 200)):
         th, tw = L.ops.pick_tile(ho, wo)

@@ -57,3 +57,7 @@ print("parameter gradients with the largest relative difference:")
 rows = sorted(((max(float((runs[r][n] - g0[n]).norm()) for r in (1, 2)) / max(float(g0[n].norm()), 1e-3 * tot), n) for n in g0), reverse=True)
 for d, n in rows[:12]:
     print(f"  {n:48s} {d:.2e}")
+nz = [(d, n) for d, n in rows if d > 0]
+print(f"{len(nz)} of {len(rows)} parameter gradients differ between runs at all:")
+for d, n in nz:
+    print(f"  {n:48s} {d:.2e}  {tuple(g0[n].shape)}")

@@ -128,7 +128,7 @@ int ly_coordatt_mlp_bwd(const float* pool, int n_img, int H, int W, int C, int m
                         const float* mean, const float* invstd, const float* gamma, const float* beta, const float* wh,
                         const float* ww, const float* a_h, const float* a_w, const float* da_h, const float* da_w, float* ws,
                         double* sums /* [32][2 mip] doubles, zeroed */, float* dpool, float* dw1, float* dgamma, float* dbeta, float* dwh, float* dbh, float* dww,
-                        float* dbw, void* stream);
+                        float* dbw, int grads_f64 /* != 0: dw1 .. dbw are zeroed DOUBLE scratches of the same shapes, see ly_f64_add */, void* stream);
 
 /* out = x * a_w[n,w,:] * a_h[n,h,:] (+ res): the gating multiply as a standalone pass (only used
  * when no consumer GEMM can absorb it, e.g. CA_Bottleneck with a residual shortcut).               */
@@ -259,7 +259,8 @@ int ly_detect_level(const void* x /*T*/, int ldx, int n_img, int H, int W, int K
 int ly_detect_level_ok(int K, int na, int no, int dtype);     /* 1 when ly_detect_level is built for this shape */
 /* Adjoint of that permute for the training step (models/yolo.py:88): dp fp32 [n, na, H, W, no] -> du rows [n*H*W][ldu] of T (column a*no+o;
  * columns >= na*no written as zero: the operand of the head's dgrad / wgrad), dbias[a*no+o] += sum over pixels.  W <= 160, na*no <= ldu <= 32. */
-int ly_detect_head_bwd(const float* dp, int n_img, int H, int W, int na, int no, void* du /*T*/, int ldu, float* dbias, int dtype, void* stream);
+int ly_detect_head_bwd(const float* dp, int n_img, int H, int W, int na, int no, void* du /*T*/, int ldu, float* dbias,
+                       int dbias_f64 /* != 0: dbias is a zeroed DOUBLE scratch, see ly_f64_add */, int dtype, void* stream);
 
 
 /* ---- train-mode BatchNorm statistics passes ----------------------------------------------------- */
@@ -411,7 +412,7 @@ int ly_rf_bwd_attn(int n_img, int H, int W, int C, int k, int s, const void* ug 
                    const float* ca, const float* rfa, void* cd /*T*/, float* d_rfa, float* gmax, float* d_ca, int dtype, void* stream);
 /* rfa = sigmoid(conv3x3(mm; w18)) backward: d_mm[n,y,x,2] (written) and dw18[18] (+=, zeroed by the caller)            */
 int ly_rfa_bwd(const float* d_rfa, const float* rfa, const float* mm, const float* w18, int n_img, int Hk, int Wk, float* d_mm,
-               float* dw18, void* stream);
+               float* dw18, int dw18_f64 /* != 0: dw18 is a zeroed DOUBLE scratch [18], see ly_f64_add */, void* stream);
 /* dv = [G>0]*(dcd*rfa*ca + d_mm.mean/C + [G==gmax]*d_mm.max) written over dcd; sums[t*C+c] += dv, sums[C*KK + ..] += dv*ug */
 int ly_rf_bwd_relu(int n_img, int H, int W, int C, int k, int s, const void* ug /*T*/, void* dcd /*T*/, const float* ag, const float* bg,
                    const float* ca, const float* rfa, const float* gmax, const float* d_mm, float* sums, int dtype, void* stream);
@@ -484,8 +485,20 @@ typedef struct LyRf1BwdParams {
   const float* alpha; const float* kappa; const float* lambda; const float* dgap; float dgap_scale;
   void* dx; int lddx; float* dgw;                                       /* pass 2 outputs */
   int dtype;
+  int dgw_f64;                     /* != 0: dgw is a zeroed DOUBLE scratch [C] (see ly_f64_add) */
 } LyRf1BwdParams;
 int ly_rf1_bwd(const LyRf1BwdParams* p, int pass, void* stream);
+/* Small parameter-gradient reductions, reproducibly: the kernels above that add a handful of values from many blocks (Detect bias, get_weight,
+ * k = 1 generate weight, CoordAtt's MLP) can accumulate into zeroed DOUBLE scratches instead of the fp32 gradients; ly_f64_add then rounds each
+ * sum into its fp32 target (dst[i] += (float)src[i]) — ONE launch for up to LY_F64_ADD_MAX vectors, after the backward pass.                   */
+#define LY_F64_ADD_MAX 32
+typedef struct LyF64AddTable {
+  const double* src[LY_F64_ADD_MAX];
+  float* dst[LY_F64_ADD_MAX];
+  int n[LY_F64_ADD_MAX];
+  int count;
+} LyF64AddTable;
+int ly_f64_add(const LyF64AddTable* t, void* stream);
 /* kernel_size 3, streamed backward (the expanded tensors exist): the attention pass (pass 0) and the ReLU / routing pass (pass 1) with the
  * same 16-bytes-per-lane layout.  P.x = ug [pixels][9][C] dense, P.dcd [pixels][9][C] (pass 1 overwrites it with dv), ag / bg [9][C],
  * P.HW = Ho*Wo output pixels per image, rfa / gmax / d_rfa [n][3Ho][3Wo], d_mm [n][3Ho][3Wo][2], sums [LY_STATS_STRIPES][2][9][C] zeroed.   */

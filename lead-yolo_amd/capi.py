@@ -48,7 +48,15 @@ class LyRf3cBwdParams(ctypes.Structure):
 class LyRf1BwdParams(ctypes.Structure):
     _fields_ = [("n_img", _I), ("HW", _L), ("C", _I), ("x", _P), ("ldx", _I), ("dcd", _P), ("gw", _P), ("ag", _P), ("bg", _P), ("ca", _P), ("rfa", _P),
                 ("cd", _P), ("d_rfa", _P), ("gmax_out", _P), ("d_ca", _P), ("gmax", _P), ("d_mm", _P), ("sums", _P),
-                ("alpha", _P), ("kappa", _P), ("lambda_", _P), ("dgap", _P), ("dgap_scale", _F), ("dx", _P), ("lddx", _I), ("dgw", _P), ("dtype", _I)]
+                ("alpha", _P), ("kappa", _P), ("lambda_", _P), ("dgap", _P), ("dgap_scale", _F), ("dx", _P), ("lddx", _I), ("dgw", _P), ("dtype", _I),
+                ("dgw_f64", _I)]
+
+
+F64_ADD_MAX = 32
+
+
+class LyF64AddTable(ctypes.Structure):
+    _fields_ = [("src", _P * F64_ADD_MAX), ("dst", _P * F64_ADD_MAX), ("n", _I * F64_ADD_MAX), ("count", _I)]
 
 
 class LyOptTensor(ctypes.Structure):
@@ -96,7 +104,7 @@ SIGNATURES = {
     "ly_conv3x3_fwd": [ctypes.POINTER(LyConv3Params), _P],
     "ly_pool_hw": [_P, _I, _I, _I, _I, _I, _P, _I, _P],
     "ly_coordatt_mlp": [_P, _I, _I, _I, _I, _I] + [_P] * 11,
-    "ly_coordatt_mlp_bwd": [_P, _I, _I, _I, _I, _I] + [_P] * 23,
+    "ly_coordatt_mlp_bwd": [_P, _I, _I, _I, _I, _I] + [_P] * 22 + [_I, _P],
     "ly_coordatt_gate": [_P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _P],
     "ly_se_fwd": [_P, _I, _I, _I, _I, _P, _P, _I, _P, _I, _P, _I, _P],
     "ly_rfcbam_stats": [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _I, _I, _P],
@@ -128,7 +136,7 @@ SIGNATURES = {
     "ly_maxpool_bwd": [_P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P],
     "ly_rf_generate": [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P],
     "ly_rf_bwd_attn": [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
-    "ly_rfa_bwd": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P],
+    "ly_rfa_bwd": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P],
     "ly_rf_bwd_relu": [_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "ly_rf_bwd_gen": [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "ly_rf_bwd_dx": [_I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _F, _I, _P],
@@ -149,7 +157,8 @@ SIGNATURES = {
     "ly_detect_tail": [_P, _I, _I, _I, _I, _I, _I, _P, _F, _P, _P, _L, _L, _I, _P],
     "ly_detect_level": [_P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _I, _P, _F, _P, _P, _L, _L, _I, _P],
     "ly_detect_level_ok": [_I, _I, _I, _I],
-    "ly_detect_head_bwd": [_P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P],
+    "ly_detect_head_bwd": [_P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _I, _P],
+    "ly_f64_add": [ctypes.POINTER(LyF64AddTable), _P],
     "ly_pack_table": [_P, _P, _I, _P],
     "ly_optim_step": [_P, _P, _P, _I, _P, _P, _P, _P],
     "ly_sum_rows": [_P, _L, _L, _L, _P, _I, _P],

@@ -849,7 +849,7 @@ extern "C" int ly_detect_tail(const void* y, int ldy, int n_img, int H, int W, i
 #define LY_DH_MAXLD 32
 template <typename T>
 __global__ __launch_bounds__(LY_THREADS) void ly_detect_head_bwd_kernel(const float* __restrict__ dp, int n_img, int H, int W, int na, int no,
-                                                                        T* __restrict__ du, int ldu, float* __restrict__ dbias) {
+                                                                        T* __restrict__ du, int ldu, float* __restrict__ dbias, const int f64) {
   __shared__ float tile[LY_DH_MAXW * (LY_DH_MAXLD + 1)];
   __shared__ float red[LY_THREADS];
   const int tid = threadIdx.x, co = na * no, LT = ldu + 1;
@@ -881,11 +881,12 @@ __global__ __launch_bounds__(LY_THREADS) void ly_detect_head_bwd_kernel(const fl
   if (tid < 32 && tid < co) {
     float s = 0.f;
     for (int g = 0; g < LY_THREADS / 32; ++g) s += red[g * 32 + tid];
-    atomicAdd(dbias + tid, s);
+    ly_gacc(dbias, tid, s, f64);
   }
 }
 
-extern "C" int ly_detect_head_bwd(const float* dp, int n_img, int H, int W, int na, int no, void* du, int ldu, float* dbias, int dtype, void* stream) {
+extern "C" int ly_detect_head_bwd(const float* dp, int n_img, int H, int W, int na, int no, void* du, int ldu, float* dbias, int dbias_f64, int dtype,
+                                  void* stream) {
   LY_CHECK_DTYPE(dtype, "detect_head_bwd");
   LY_CHECK(dp && du && dbias && n_img > 0 && H > 0 && W > 0 && na > 0 && no > 0, "detect_head_bwd: bad arguments");
   LY_CHECK(W <= LY_DH_MAXW && ldu <= LY_DH_MAXLD && na * no <= ldu, "detect_head_bwd: W=%d (max %d) / ldu=%d (max %d, >= na*no=%d) out of range", W,
@@ -893,7 +894,7 @@ extern "C" int ly_detect_head_bwd(const float* dp, int n_img, int H, int W, int 
   long blocks = (long)n_img * H;
   if (blocks > 1024) blocks = 1024;
   LY_WITH_T(dtype, hipLaunchKernelGGL(ly_detect_head_bwd_kernel<T>, dim3((unsigned)blocks), dim3(LY_THREADS), 0, reinterpret_cast<hipStream_t>(stream), dp,
-                                      n_img, H, W, na, no, reinterpret_cast<T*>(du), ldu, dbias));
+                                      n_img, H, W, na, no, reinterpret_cast<T*>(du), ldu, dbias, dbias_f64));
   LY_LAUNCH_CHECK();
   return 0;
 }
@@ -1313,7 +1314,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_coordatt_mlp_bwd2_kernel(
     const float* __restrict__ pool, int n_img, int H, int W, int C, long rows_per_block, const float* __restrict__ w1,
     const float* __restrict__ gamma, const float* __restrict__ invstd, const float* __restrict__ ws, const double* __restrict__ sums,
     float* __restrict__ dpool /* in: dz */, float* __restrict__ dw1, float* __restrict__ dgamma, float* __restrict__ dbeta,
-    float* __restrict__ dwh, float* __restrict__ dbh, float* __restrict__ dww, float* __restrict__ dbw) {
+    float* __restrict__ dwh, float* __restrict__ dbh, float* __restrict__ dww, float* __restrict__ dbw, const int f64) {
   constexpr int NA = 3 * MIP + 2;                          // accumulators per channel: dW1[m], dWh[m], dWw[m], dbh, dbw
   __shared__ float red[4 * 64 * (3 * MIP + 2)];
   __shared__ float ssum[2 * MIP];
@@ -1384,19 +1385,19 @@ __global__ __launch_bounds__(LY_THREADS) void ly_coordatt_mlp_bwd2_kernel(
   for (int e = 0; e < NA; ++e) red[(wave * 64 + lane) * NA + e] = acc[e];
   __syncthreads();
   if (blockIdx.x == 0 && blockIdx.y == 0 && tid < MIP) {
-    atomicAdd(dgamma + tid, ssum[MIP + tid]);
-    atomicAdd(dbeta + tid, ssum[tid]);
+    ly_gacc(dgamma, tid, ssum[MIP + tid], f64);
+    ly_gacc(dbeta, tid, ssum[tid], f64);
   }
   for (int e = tid; e < 64 * NA; e += LY_THREADS) {
     const int cl = e / NA, k = e - cl * NA;
     const int cc = blockIdx.x * 64 + cl;
     if (cc >= C) continue;
     const float v = red[e] + red[64 * NA + e] + red[2 * 64 * NA + e] + red[3 * 64 * NA + e];
-    if (k < MIP) atomicAdd(dw1 + k * C + cc, v);
-    else if (k < 2 * MIP) atomicAdd(dwh + cc * MIP + (k - MIP), v);
-    else if (k < 3 * MIP) atomicAdd(dww + cc * MIP + (k - 2 * MIP), v);
-    else if (k == 3 * MIP) atomicAdd(dbh + cc, v);
-    else atomicAdd(dbw + cc, v);
+    if (k < MIP) ly_gacc(dw1, k * C + cc, v, f64);
+    else if (k < 2 * MIP) ly_gacc(dwh, cc * MIP + (k - MIP), v, f64);
+    else if (k < 3 * MIP) ly_gacc(dww, cc * MIP + (k - 2 * MIP), v, f64);
+    else if (k == 3 * MIP) ly_gacc(dbh, cc, v, f64);
+    else ly_gacc(dbw, cc, v, f64);
   }
 }
 
@@ -1404,7 +1405,7 @@ template <int MIP, int NS>
 static void launch_coordatt_bwd(hipStream_t st, const float* pool, int n_img, int H, int W, int C, const float* w1, const float* b1, const float* mean,
                                 const float* invstd, const float* gamma, const float* beta, const float* wh, const float* ww, const float* a_h,
                                 const float* a_w, const float* da_h, const float* da_w, float* ws, double* sums, float* dpool, float* dw1,
-                                float* dgamma, float* dbeta, float* dwh, float* dbh, float* dww, float* dbw) {
+                                float* dgamma, float* dbeta, float* dwh, float* dbh, float* dww, float* dbw, int f64) {
   const long R = (long)n_img * (H + W);
   long b1n = (R + 3) / 4;
   if (b1n > 1024) b1n = 1024;
@@ -1417,20 +1418,20 @@ static void launch_coordatt_bwd(hipStream_t st, const float* pool, int n_img, in
   const long rpb = (R + chunks - 1) / chunks;
   chunks = (R + rpb - 1) / rpb;
   hipLaunchKernelGGL((ly_coordatt_mlp_bwd2_kernel<MIP>), dim3((unsigned)groups, (unsigned)chunks), dim3(LY_THREADS), 0, st, pool, n_img, H, W, C, rpb, w1,
-                     gamma, invstd, ws, sums, dpool, dw1, dgamma, dbeta, dwh, dbh, dww, dbw);
+                     gamma, invstd, ws, sums, dpool, dw1, dgamma, dbeta, dwh, dbh, dww, dbw, f64);
 }
 
 extern "C" int ly_coordatt_mlp_bwd(const float* pool, int n_img, int H, int W, int C, int mip, const float* w1, const float* b1,
                                    const float* mean, const float* invstd, const float* gamma, const float* beta, const float* wh,
                                    const float* ww, const float* a_h, const float* a_w, const float* da_h, const float* da_w, float* ws,
                                    double* sums, float* dpool, float* dw1, float* dgamma, float* dbeta, float* dwh, float* dbh,
-                                   float* dww, float* dbw, void* stream) {
+                                   float* dww, float* dbw, int grads_f64, void* stream) {
   LY_CHECK(pool && w1 && b1 && mean && invstd && gamma && beta && wh && ww && a_h && a_w && da_h && da_w && ws && sums && dpool && dw1 &&
                dgamma && dbeta && dwh && dbh && dww && dbw, "coordatt_mlp_bwd: null pointer");
   LY_CHECK((mip == 8 || mip == 16) && C > 0 && C <= 512 && n_img > 0 && H > 0 && W > 0, "coordatt_mlp_bwd: built for mip 8 / 16 and C <= 512 (mip=%d C=%d)", mip, C);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define LY_CA_BWD(MIP, NS) launch_coordatt_bwd<MIP, NS>(st, pool, n_img, H, W, C, w1, b1, mean, invstd, gamma, beta, wh, ww, a_h, a_w, da_h, da_w, ws, sums, \
-                                                        dpool, dw1, dgamma, dbeta, dwh, dbh, dww, dbw)
+                                                        dpool, dw1, dgamma, dbeta, dwh, dbh, dww, dbw, grads_f64)
   const int ns = (C + 63) / 64;
   if (mip == 8) {
     if (ns <= 1) LY_CA_BWD(8, 1); else if (ns <= 2) LY_CA_BWD(8, 2); else if (ns <= 4) LY_CA_BWD(8, 4); else LY_CA_BWD(8, 8);

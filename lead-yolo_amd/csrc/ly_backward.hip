@@ -369,7 +369,9 @@ __global__ __launch_bounds__(LY_THREADS) void ly_wgrad_kernel(const LyWgradParam
 // s+1 are in flight while step s is contracted (register prefetch, two LDS buffers, one barrier per step).
 // Re-reads drop from (N/64 + K/64) to (N/BN + K/BK) passes over the two tensors.
 // -------------------------------------------------------------------------------------------------
-template <typename T, int BN, int BK, int P, bool ROWS, bool PRO, bool SLAB = true>
+// SLAB: 0 = atomic flush only, 1 = slab when the pointer is given (run-time), 2 = slab always (the grouped launch's instantiation: a second flush
+// path compiled into it de-pipelined its pixel loop)
+template <typename T, int BN, int BK, int P, bool ROWS, bool PRO, int SLAB = 1>
 __device__ __forceinline__ void ly_wgrad_tiled_body(const LyWgradParams& Q, const int tile_idx, const int chunk_idx, const int tiles_k, const long chunk_px,
                                                     float* __restrict__ const slab, const int tiles) {
   using R4 = typename LyT<T>::R4;
@@ -442,8 +444,14 @@ __device__ __forceinline__ void ly_wgrad_tiled_body(const LyWgradParams& Q, cons
   const int Hv = Q.up2 ? 2 * Q.Hin : Q.Hin, Wv = Q.up2 ? 2 * Q.Win : Q.Win;
   const float invW = 1.f / (float)Q.W, invH = 1.f / (float)Q.H;
 
+  // DEFER (the grouped slab instantiation): the loads of a step are pure — masked pixels are zeroed when the registers are committed to LDS,
+  // not right behind each load.  With the select behind the load hipcc's scheduler, in THIS instantiation, sank every load next to its
+  // select: one `s_waitcnt vmcnt(0)` per load, the pixel loop ran at one memory round trip per 8 bytes (53 -> 108 us per launch).
+  constexpr bool DEFER = SLAB == 2 && ROWS;
+  long pre_p0 = 0;
   R4 pre[TPT][8];
   auto prefetch = [&](long p0) {
+    pre_p0 = p0;
 #pragma unroll
     for (int u = 0; u < TPT; ++u) {
       const long pf = p0 + 8 * t_g[u];
@@ -472,7 +480,9 @@ __device__ __forceinline__ void ly_wgrad_tiled_body(const LyWgradParams& Q, cons
           if (++wo == Q.W) { wo = 0; if (++ho == Q.H) { ho = 0; ++n_i; } }
         }
         R4 v = ly_ldr4<T>(src);
-        if (!ok) ly_zero_raw(v);
+        if constexpr (!DEFER) {
+          if (!ok) ly_zero_raw(v);
+        }
         pre[u][j] = v;
       }
     }
@@ -482,6 +492,11 @@ __device__ __forceinline__ void ly_wgrad_tiled_body(const LyWgradParams& Q, cons
 #pragma unroll
     for (int u = 0; u < TPT; ++u) {
       if (t_row[u] < 0) continue;
+      if constexpr (DEFER) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (!(t_ok[u] && pre_p0 + 8 * t_g[u] + j < p_end)) ly_zero_raw(pre[u][j]);
+      }
       const bool pb = pro && !t_isA[u];
       f32x4 sa = ly_zero4(), sh = ly_zero4();
       if constexpr (ROWS && PRO) {
@@ -572,7 +587,7 @@ __device__ __forceinline__ void ly_wgrad_tiled_body(const LyWgradParams& Q, cons
     }
   }
 
-  if (SLAB && slab) {
+  if (SLAB == 2 || (SLAB == 1 && slab)) {
     // the chunk's tile [BN][BK] into its own slab with plain stores (16 lanes = 64 contiguous bytes); ly_wgrad_combine folds the chunks in a
     // fixed order: no float atomics (the atomic flush of 512 x 64 KB was a quarter of a launch), bit-reproducible dw
     float* const sl = slab + ((long)chunk_idx * tiles + tile_idx) * (BN * BK);
@@ -593,6 +608,7 @@ __device__ __forceinline__ void ly_wgrad_tiled_body(const LyWgradParams& Q, cons
       }
     return;
   }
+  if constexpr (SLAB != 2) {
 #pragma unroll
   for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -608,16 +624,17 @@ __device__ __forceinline__ void ly_wgrad_tiled_body(const LyWgradParams& Q, cons
         if (row < Q.n_valid) atomicAdd(Q.dw + (long)row * Q.lddw + cidx, acc[i][j][r]);
       }
     }
+  }
 }
 
 // dw[n][tap][c] += sum over chunks of slab[chunk][tile][row][col] in a fixed order, one writer per element (the second launch of a tiled
 // weight gradient whose chunks left their tiles in LyWgradParams.ws).  Block = 64 slab columns x 16 chunk lanes.
-__global__ __launch_bounds__(1024) void ly_wgrad_combine_kernel(const LyWgradParams P, const float* __restrict__ slab, const int chunks, const int tiles_k,
-                                                               const int tiles, const int BN, const int BK) {
+__device__ __forceinline__ void ly_wgrad_combine_body(const LyWgradParams& P, const float* __restrict__ slab, const int chunks, const int tiles_k,
+                                                      const int tiles, const int BN, const int BK, const long blk) {
   __shared__ float red[16][64];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const long E = (long)tiles * BN * BK;
-  const long e = (long)blockIdx.x * 64 + cl;
+  const long e = blk * 64 + cl;
   const int tile = (int)(e / (BN * BK));
   const int rem = (int)(e - (long)tile * (BN * BK));
   const int lr = rem / BK, lc = rem - lr * BK;
@@ -660,6 +677,10 @@ __global__ __launch_bounds__(1024) void ly_wgrad_combine_kernel(const LyWgradPar
     *d += sacc;
   }
 }
+__global__ __launch_bounds__(1024) void ly_wgrad_combine_kernel(const LyWgradParams P, const float* __restrict__ slab, const int chunks, const int tiles_k,
+                                                               const int tiles, const int BN, const int BK) {
+  ly_wgrad_combine_body(P, slab, chunks, tiles_k, tiles, BN, BK, (long)blockIdx.x);
+}
 static void wgrad_combine_launch(const LyWgradParams& P, const float* slab, long chunks, int tiles_k, long tiles, int BN, int BK, hipStream_t st) {
   const long E = tiles * BN * BK;
   hipLaunchKernelGGL(ly_wgrad_combine_kernel, dim3((unsigned)((E + 63) / 64)), dim3(1024), 0, st, P, slab, (int)chunks, tiles_k, (int)tiles, BN, BK);
@@ -677,10 +698,12 @@ __global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(BN +
 struct LyWgradGroupArgs {
   LyWgradParams p[LY_WGRAD_GROUP_MAX];
   long chunk_px[LY_WGRAD_GROUP_MAX];
+  float* slab[LY_WGRAD_GROUP_MAX];       // per problem: [chunks][tiles][BN * BK] partial tiles (the slab form), else unused
   int tiles_k[LY_WGRAD_GROUP_MAX], tiles[LY_WGRAD_GROUP_MAX], blk0[LY_WGRAD_GROUP_MAX + 1];
+  int chunks[LY_WGRAD_GROUP_MAX], cblk0[LY_WGRAD_GROUP_MAX + 1];      // combine launch: chunks per problem, first combine block per problem
   int n;
 };
-template <typename T, int BN, int BK, int P, bool ROWS, bool PRO = false>
+template <typename T, int BN, int BK, int P, bool ROWS, bool PRO = false, bool GSLAB = false>
 __global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(BN + BK > 160 ? 2 : 3))) void ly_wgrad_tiled_group_kernel(const LyWgradGroupArgs G) {
   int g = 0;
 #pragma unroll
@@ -691,7 +714,18 @@ __global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(BN +
   const int tiles = G.tiles[g];
   // (no slab path here: with it compiled in, every wait of this instantiation's pixel loop became `s_waitcnt vmcnt(0)` — 53 -> 107 us per launch;
   // a grouped launch keeps the atomic flush, whose cost the longer pixel runs per block already halve)
-  ly_wgrad_tiled_body<T, BN, BK, P, ROWS, PRO, false>(G.p[g], local % tiles, local / tiles, G.tiles_k[g], G.chunk_px[g], nullptr, tiles);
+  // GSLAB: every block leaves its tile in the problem's slab (plain stores) and ly_wgrad_combine_group_kernel folds the chunks in index order —
+  // no float atomics: the grouped weight gradients are the same bits in every run
+  ly_wgrad_tiled_body<T, BN, BK, P, ROWS, PRO, GSLAB ? 2 : 0>(G.p[g], local % tiles, local / tiles, G.tiles_k[g], G.chunk_px[g], GSLAB ? G.slab[g] : nullptr, tiles);
+}
+// the combine launches of a group's problems as ONE launch
+__global__ __launch_bounds__(1024) void ly_wgrad_combine_group_kernel(const LyWgradGroupArgs G, const int BN, const int BK) {
+  int g = 0;
+#pragma unroll
+  for (int i = 1; i < LY_WGRAD_GROUP_MAX; ++i)
+    if (i < G.n && (int)blockIdx.x >= G.cblk0[i]) g = i;
+  g = __builtin_amdgcn_readfirstlane(g);
+  ly_wgrad_combine_body(G.p[g], G.slab[g], G.chunks[g], G.tiles_k[g], G.tiles[g], BN, BK, (long)((int)blockIdx.x - G.cblk0[g]));
 }
 
 // blocks a weight-gradient launch aims for (development knob: LY_WG_BLOCKS / LY_WG_GROUP_BLOCKS)
@@ -791,12 +825,35 @@ static int wgrad_group_launch(const LyWgradParams* arr, int n, hipStream_t st) {
     chunk_px = (chunk_px + PX - 1) / PX * PX;
     chunks = (arr[g].M + chunk_px - 1) / chunk_px;
     G.chunk_px[g] = chunk_px;
+    G.chunks[g] = (int)chunks;
     G.blk0[g + 1] = G.blk0[g] + (int)(chunks * G.tiles[g]);
   }
-  for (int g = n; g < LY_WGRAD_GROUP_MAX; ++g) { G.tiles_k[g] = G.tiles[g] = 1; G.chunk_px[g] = PX; G.blk0[g + 1] = G.blk0[n]; G.p[g] = arr[0]; }
+  for (int g = n; g < LY_WGRAD_GROUP_MAX; ++g) { G.tiles_k[g] = G.tiles[g] = 1; G.chunk_px[g] = PX; G.blk0[g + 1] = G.blk0[n]; G.p[g] = arr[0]; G.chunks[g] = 0; G.slab[g] = nullptr; }
+  // slab form when the caller's scratch (LyWgradParams.ws of the first problem) holds every block's tile
+  bool gslab = arr[0].ws != nullptr && (long)G.blk0[n] * (BN * BK) <= arr[0].ws_floats;
+  G.cblk0[0] = 0;
+  for (int g = 0; g < n; ++g) {
+    G.slab[g] = gslab ? arr[0].ws + (long)G.blk0[g] * (BN * BK) : nullptr;
+    G.cblk0[g + 1] = G.cblk0[g] + (int)(((long)G.tiles[g] * BN * BK + 63) / 64);
+  }
+  for (int g = n; g < LY_WGRAD_GROUP_MAX; ++g) G.cblk0[g + 1] = G.cblk0[n];
   const size_t lds = (LyT<T>::PL * PX >= 128 ? 1 : 2) * (size_t)(BN + BK) * (LyT<T>::PL * 2 * PX + 16) + 2 * BK * sizeof(float);
   bool any_pro = false;
   for (int g = 0; g < n; ++g) any_pro = any_pro || arr[g].x_scale != nullptr;
+  if (gslab) {
+    if (any_pro) {
+      static bool attr = false;
+      if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ly_wgrad_tiled_group_kernel<T, BN, BK, PX, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+      hipLaunchKernelGGL((ly_wgrad_tiled_group_kernel<T, BN, BK, PX, true, true, true>), dim3((unsigned)G.blk0[n]), dim3(LY_THREADS), lds, st, G);
+    } else {
+      static bool attr = false;
+      if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ly_wgrad_tiled_group_kernel<T, BN, BK, PX, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+      hipLaunchKernelGGL((ly_wgrad_tiled_group_kernel<T, BN, BK, PX, true, false, true>), dim3((unsigned)G.blk0[n]), dim3(LY_THREADS), lds, st, G);
+    }
+    hipLaunchKernelGGL(ly_wgrad_combine_group_kernel, dim3((unsigned)G.cblk0[n]), dim3(1024), 0, st, G, BN, BK);
+    LY_LAUNCH_CHECK();
+    return 0;
+  }
   if (any_pro) {
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ly_wgrad_tiled_group_kernel<T, BN, BK, PX, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
@@ -993,6 +1050,25 @@ __global__ __launch_bounds__(LY_THREADS) void ly_sum_rows_f64_kernel(const doubl
   for (int r = 0; r < R; ++r) a += src[(long)r * C + c];
   dst[c] = a;
 }
+// dst[i] += (float)src[i] for up to LY_F64_ADD_MAX small vectors in one launch (the double scratches of ly_gacc, ly_common.hpp)
+__global__ __launch_bounds__(LY_THREADS) void ly_f64_add_kernel(const LyF64AddTable T) {
+  const int e = blockIdx.y;
+  const int i = blockIdx.x * LY_THREADS + threadIdx.x;
+  if (e < T.count && i < T.n[e]) T.dst[e][i] += (float)T.src[e][i];
+}
+extern "C" int ly_f64_add(const LyF64AddTable* t, void* stream) {
+  LY_CHECK(t && t->count > 0 && t->count <= LY_F64_ADD_MAX, "f64_add: bad table");
+  int nmax = 0;
+  for (int e = 0; e < t->count; ++e) {
+    LY_CHECK(t->src[e] && t->dst[e] && t->n[e] > 0, "f64_add: entry %d is empty", e);
+    nmax = t->n[e] > nmax ? t->n[e] : nmax;
+  }
+  hipLaunchKernelGGL(ly_f64_add_kernel, dim3((unsigned)((nmax + LY_THREADS - 1) / LY_THREADS), (unsigned)t->count), dim3(LY_THREADS), 0,
+                     reinterpret_cast<hipStream_t>(stream), *t);
+  LY_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int ly_sum_rows_f64(const double* src, int R, int C, double* dst, void* stream) {
   LY_CHECK(src && dst && R > 0 && C > 0, "sum_rows_f64: bad arguments");
   hipLaunchKernelGGL(ly_sum_rows_f64_kernel, dim3((unsigned)((C + LY_THREADS - 1) / LY_THREADS)), dim3(LY_THREADS), 0, reinterpret_cast<hipStream_t>(stream), src,

@@ -174,6 +174,15 @@ __device__ __forceinline__ float ly_group_max(float v, const int G) {
   return v;
 }
 
+// Small parameter-gradient reductions (a handful of values that many blocks add to: Detect's bias, get_weight's 18 taps, the k = 1 generate
+// weights, CoordAtt's tiny MLP).  f64 != 0: the target is a zeroed DOUBLE scratch of the same shape — the arrival order of the atomics then only
+// moves the 53rd bit, and ly_f64_add rounds the sums into the parameters' fp32 gradient storage after the backward pass: the same bits in
+// every run (as the BatchNorm statistics, ly_stats_flush below).  f64 == 0: float atomics straight into the target.
+__device__ __forceinline__ void ly_gacc(float* __restrict__ p, const long i, const float v, const int f64) {
+  if (f64) atomicAdd(reinterpret_cast<double*>(p) + i, (double)v);
+  else atomicAdd(p + i, v);
+}
+
 // Batch-statistics pass support: a lane holds 4 consecutive channels (c .. c+3) of some pixels; sum the
 // two 4-vectors over the 16 lanes that share lq (lanes differing in l&15) and let lane l&15 == 0 add them
 // to stats[c + r] (sum) and stats[nch + c + r] (sum of squares).

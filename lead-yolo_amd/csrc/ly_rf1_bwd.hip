@@ -145,7 +145,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf1_bwd_kernel(const LyRf1BwdPa
       for (int sl = 0; sl < PB; ++sl) s += red[(sl * NQT + qn) * CS + c];
       if constexpr (MODE == RF1_A) atomicAdd(P.d_ca + n * C + c, (double)s);                                  // double accumulators (ly_common.hpp ly_stats_flush)
       else if constexpr (MODE == RF1_B) atomicAdd(P.sums + (size_t)((blockIdx.x + blockIdx.y) & (LY_STATS_STRIPES - 1)) * 2 * C + qn * C + c, (double)s);
-      else atomicAdd(P.dgw + c, s);
+      else ly_gacc(P.dgw, c, s, P.dgw_f64);
     }
   }
 }

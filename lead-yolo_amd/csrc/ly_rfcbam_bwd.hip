@@ -245,7 +245,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_attn_kernel(const RfGeom
 #define RFA_TW 64
 __global__ __launch_bounds__(LY_THREADS) void ly_rfa_bwd_kernel(const float* __restrict__ d_rfa, const float* __restrict__ rfa,
                                                                 const float* __restrict__ mm, const float* __restrict__ w18, int n_img, int Hk,
-                                                                int Wk, float* __restrict__ d_mm, float* __restrict__ dw18, int tiles_y, int tiles_x) {
+                                                                int Wk, float* __restrict__ d_mm, float* __restrict__ dw18, int tiles_y, int tiles_x, const int f64) {
   // A block walks 16 x 64 tiles of the map (grid-stride over image x tile): d_pre = d_rfa * rfa * (1 - rfa) and mm are staged ONCE per tile
   // with a one-position halo (zeros outside the map), so a position's 9 + 9 neighbours are LDS reads.  (Until late round 3 every thread
   // fetched its 36 neighbour values from global memory, one dependent round trip after the other: 24 us per launch for a 3.7 MB map.)
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfa_bwd_kernel(const float* __r
     if (lane == 0) red[i][wave] = sv;
   }
   __syncthreads();
-  if (threadIdx.x < 18) atomicAdd(dw18 + threadIdx.x, red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+  if (threadIdx.x < 18) ly_gacc(dw18, threadIdx.x, red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3], f64);
 }
 
 // ---- dv (over dcd) + BN sums ---------------------------------------------------------------------
@@ -631,13 +631,13 @@ extern "C" int ly_rf_bwd_attn(int n_img, int H, int W, int C, int k, int s, cons
 }
 
 extern "C" int ly_rfa_bwd(const float* d_rfa, const float* rfa, const float* mm, const float* w18, int n_img, int Hk, int Wk, float* d_mm,
-                          float* dw18, void* stream) {
+                          float* dw18, int dw18_f64, void* stream) {
   LY_CHECK(d_rfa && rfa && mm && w18 && d_mm && dw18 && n_img > 0 && Hk > 0 && Wk > 0, "rfa_bwd: bad arguments");
   const int tiles_y = (Hk + RFA_TH - 1) / RFA_TH, tiles_x = (Wk + RFA_TW - 1) / RFA_TW;
   long blocks = (long)n_img * tiles_y * tiles_x;
   if (blocks > 512) blocks = 512;
   hipLaunchKernelGGL(ly_rfa_bwd_kernel, dim3((unsigned)blocks), dim3(LY_THREADS), 0,
-                     reinterpret_cast<hipStream_t>(stream), d_rfa, rfa, mm, w18, n_img, Hk, Wk, d_mm, dw18, tiles_y, tiles_x);
+                     reinterpret_cast<hipStream_t>(stream), d_rfa, rfa, mm, w18, n_img, Hk, Wk, d_mm, dw18, tiles_y, tiles_x, dw18_f64);
   LY_LAUNCH_CHECK();
   return 0;
 }

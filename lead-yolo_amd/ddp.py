@@ -65,6 +65,8 @@ class GradReducer:
         self._hooks = []
         self._sync = True
         self._direct = set()
+        self._deferred = set()
+        self._deferred_seen = set()
         self.defer_average = False        # True: buckets are exchanged as plain SUMs, the consumer divides (optim.FusedSGD.grad_scale = 1/world)
         self.exchange_single = False      # True: a world of one still issues its all-reduces (tests of the launch path on one GPU)
         self._mark_fn = None
@@ -99,6 +101,8 @@ class GradReducer:
         self._launched = [False] * len(self.buckets)
         self._works = []
         self._direct = set()
+        self._deferred = set()
+        self._deferred_seen = set()
 
     def no_sync(self):
         """Context manager for gradient accumulation (the reference's `accumulate` micro-steps, train.py:303-329): backward
@@ -125,10 +129,20 @@ class GradReducer:
 
             def _sink_cb(p):
                 if id(p) in mine:
-                    self._direct.add(id(p))               # autograd may still run this parameter's (empty) accumulation hook: ignore it once
+                    if id(p) in self._deferred_seen:
+                        self._deferred_seen.discard(id(p))    # (its empty accumulation hook has already been and gone)
+                    else:
+                        self._direct.add(id(p))           # autograd may still run this parameter's (empty) accumulation hook: ignore it once
                     self._on_grad(p, direct=True)
-            self._sink_cb = _sink_cb
+
+            def _defer_cb(p):
+                # the gradient is still being accumulated elsewhere (ops.small_grad_scratch) and will be announced through _sink_cb when the
+                # backward pass ends: the parameter's (empty) accumulation hook, which runs before that, must not count as its arrival
+                if id(p) in mine:
+                    self._deferred.add(id(p))
+            self._sink_cb, self._defer_cb = _sink_cb, _defer_cb
             ops.GRAD_LISTENERS.append(self._sink_cb)
+            ops.GRAD_DEFER_LISTENERS.append(self._defer_cb)
         except ImportError:
             self._sink_cb = None
         return self
@@ -141,11 +155,17 @@ class GradReducer:
             from . import ops
             if self._sink_cb in ops.GRAD_LISTENERS:
                 ops.GRAD_LISTENERS.remove(self._sink_cb)
-            self._sink_cb = None
+            if getattr(self, "_defer_cb", None) in ops.GRAD_DEFER_LISTENERS:
+                ops.GRAD_DEFER_LISTENERS.remove(self._defer_cb)
+            self._sink_cb = self._defer_cb = None
 
     def _on_grad(self, p, direct=False):
         if not direct and id(p) in self._direct:
             self._direct.discard(id(p))                           # already counted when the backward kernel wrote it in place
+            return
+        if not direct and id(p) in self._deferred:
+            self._deferred.discard(id(p))                         # announced later (end of the backward pass): see _defer_cb
+            self._deferred_seen.add(id(p))
             return
         bi, pi = self._slot[id(p)]
         view = self.buckets[bi]["views"][pi]
@@ -192,6 +212,8 @@ class GradReducer:
         self._pending = [len(b["params"]) for b in self.buckets]
         self._launched = [False] * len(self.buckets)
         self._direct = set()
+        self._deferred = set()
+        self._deferred_seen = set()
 
     def end_marks(self):
         """-> (bucket indices in the order they were marked, bucket indices no gradient event completed: exchange them after the graph)"""
@@ -210,6 +232,8 @@ class GradReducer:
         self._launched = [False] * len(self.buckets)
         self._works = []
         self._direct = set()
+        self._deferred = set()
+        self._deferred_seen = set()
 
     def reduce_now(self):
         """For callers without hooks (or unused parameters): launch every bucket not yet launched."""

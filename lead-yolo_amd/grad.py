@@ -499,10 +499,12 @@ class DetectHeadFn(torch.autograd.Function):
             cq = (co + vw - 1) // vw * vw
             dp = dp.float().contiguous()
             tb = ops.grad_target(b_param)
-            dbias = tb if tb is not None else torch.zeros(co, dtype=torch.float32, device=dp.device)
+            tb = tb if tb is not None and tb.is_contiguous() and tb.numel() == co else None
+            defer = tb is not None and ops.small_grads_ok()       # float64 scratch, rounded into the sink when the backward pass ends
+            dbias = ops.small_grad_scratch(tb, b_param) if defer else tb if tb is not None else torch.zeros(co, dtype=torch.float32, device=dp.device)
             du = torch.empty((bs, ny, nx, cq), dtype=t0.dtype, device=dp.device)
             ops.detect_head_bwd(dp, bs, ny, nx, na, no, du, cq, dbias)
-            if tb is not None:
+            if tb is not None and not defer:
                 ops.grad_done(b_param)
             du_d = du.permute(0, 3, 1, 2)
             dw = conv_wgrad(ctx.spec, du_d, x, None, w_param) if need[4] else None
@@ -704,12 +706,16 @@ class CoordAttFn(torch.autograd.Function):
                 tgt = torch.zeros(p.shape, dtype=torch.float32, device=xr.device)
             targets.append(tgt)
             ret.append(tgt if (fresh and p.requires_grad) else None)
+        # every target in the sink: accumulate in float64 scratches, rounded into the sink when the backward pass ends (ops.small_grad_scratch)
+        defer = ops.small_grads_ok() and all(r is None for r in ret) and all(t.is_contiguous() for t in targets)
+        if defer:
+            targets = [ops.small_grad_scratch(t, q) for t, q in zip(targets, [q for i, q in enumerate(ctx.params) if i != 1])]
         W1, Wh, Ww = (p.detach().reshape(p.shape[0], -1) for p in (w1, wh, ww))
         dpool = ops.coordatt_mlp_bwd(pool, n, h, w, c, ctx.mip, W1, b1.detach(), mean, invstd, gamma.detach(), beta.detach(), Wh, Ww, a_h, a_w,
                                      da_h, da_w, targets)
         ops.pool_hw_bwd(dpool, n, h, w, c, into=dx)
-        for p, r in zip(ctx.params, ret):
-            if r is None and p.requires_grad:
+        for i, (p, r) in enumerate(zip(ctx.params, ret)):
+            if r is None and p.requires_grad and not (defer and i != 1):
                 ops.grad_done(p)
         return (None, dx, *ret)
 
@@ -952,9 +958,10 @@ class RfcbamFn(torch.autograd.Function):
             d_mm = torch.empty_like(mm)
             t18 = ops.grad_target(ctx.getw_param)
             t18 = t18 if t18 is not None and t18.is_contiguous() else None
-            dw18 = t18.view(-1) if t18 is not None else torch.zeros(18, dtype=torch.float32, device=dev)   # (handed to autograd: not from the pool)
-            L.check(L.lib().ly_rfa_bwd(p(d_rfa), p(rfa), p(mm), p(w18), n, k * ho, k * wo, p(d_mm), p(dw18), st), "ly_rfa_bwd")
-            if t18 is not None:
+            d18 = t18 is not None and ops.small_grads_ok()          # deferred: a float64 scratch, rounded into the sink when the backward pass ends
+            dw18 = ops.small_grad_scratch(t18, ctx.getw_param) if d18 else t18.view(-1) if t18 is not None else torch.zeros(18, dtype=torch.float32, device=dev)
+            L.check(L.lib().ly_rfa_bwd(p(d_rfa), p(rfa), p(mm), p(w18), n, k * ho, k * wo, p(d_mm), p(dw18), int(d18), st), "ly_rfa_bwd")
+            if t18 is not None and not d18:
                 ops.grad_done(ctx.getw_param)
             # 8. through max/mean, ca, rfa and ReLU; generate-BN sums
             if rf3s:
@@ -1052,9 +1059,10 @@ def _rfcbam_backward_rc(ctx, du, dgo, dbo):
     d_mm = torch.empty_like(mm)
     t18 = ops.grad_target(ctx.getw_param)
     t18 = t18 if t18 is not None and t18.is_contiguous() else None
-    dw18 = t18.view(-1) if t18 is not None else torch.zeros(18, dtype=torch.float32, device=dev)
-    L.check(L.lib().ly_rfa_bwd(p(d_rfa), p(rfa), p(mm), p(w18), n, 3 * ho, 3 * wo, p(d_mm), p(dw18), st), "ly_rfa_bwd")
-    if t18 is not None:
+    d18 = t18 is not None and ops.small_grads_ok()          # deferred: a float64 scratch, rounded into the sink when the backward pass ends
+    dw18 = ops.small_grad_scratch(t18, ctx.getw_param) if d18 else t18.view(-1) if t18 is not None else torch.zeros(18, dtype=torch.float32, device=dev)
+    L.check(L.lib().ly_rfa_bwd(p(d_rfa), p(rfa), p(mm), p(w18), n, 3 * ho, 3 * wo, p(d_mm), p(dw18), int(d18), st), "ly_rfa_bwd")
+    if t18 is not None and not d18:
         ops.grad_done(ctx.getw_param)
     P.d_mm = p(d_mm)
     # B: BatchNorm sums, one stripe per image
@@ -1124,9 +1132,10 @@ def _rfcbam_backward_k1(ctx, du, dgo, dbo):
     dx = ops.empty_nhwc(n, c, h, w, xr) if ctx.needs_input_grad[1] else ops.empty_nhwc(n, c, h, w, xr)
     tgw = ops.grad_target(ctx.gen_w_param) if getattr(ctx, "gen_w_param", None) is not None else None
     tgw = tgw if tgw is not None and tgw.is_contiguous() else None
-    dgw = tgw.view(-1) if tgw is not None else torch.zeros(c, dtype=torch.float32, device=dev)
+    dgw_defer = tgw is not None and ops.small_grads_ok()
+    dgw = ops.small_grad_scratch(tgw, ctx.gen_w_param) if dgw_defer else tgw.view(-1) if tgw is not None else torch.zeros(c, dtype=torch.float32, device=dev)
     P = L.LyRf1BwdParams(n, h * w, c, p(xr), ld, p(dcd), p(gw), p(ag), p(bg), p(ca), p(rfa), p(cd), p(d_rfa), p(gmax), p(d_ca64),
-                         p(gmax), None, None, None, None, None, None, 1.0 / (h * w), p(dx), c, p(dgw), L.dtype_code(xr))
+                         p(gmax), None, None, None, None, None, None, 1.0 / (h * w), p(dx), c, p(dgw), L.dtype_code(xr), int(dgw_defer))
     es1 = xr.element_size() * mo * c
     tn = ops._tname(xr)
     with ops._Timed(f"ly_rf1_bwd_kernel<{tn}, 0>", 6.0 * mo * c, 3.0 * es1):
@@ -1147,9 +1156,10 @@ def _rfcbam_backward_k1(ctx, du, dgo, dbo):
     d_mm = torch.empty_like(mm)
     t18 = ops.grad_target(ctx.getw_param)
     t18 = t18 if t18 is not None and t18.is_contiguous() else None
-    dw18 = t18.view(-1) if t18 is not None else torch.zeros(18, dtype=torch.float32, device=dev)
-    L.check(L.lib().ly_rfa_bwd(p(d_rfa), p(rfa), p(mm), p(w18), n, h, w, p(d_mm), p(dw18), st), "ly_rfa_bwd")
-    if t18 is not None:
+    d18 = t18 is not None and ops.small_grads_ok()          # deferred: a float64 scratch, rounded into the sink when the backward pass ends
+    dw18 = ops.small_grad_scratch(t18, ctx.getw_param) if d18 else t18.view(-1) if t18 is not None else torch.zeros(18, dtype=torch.float32, device=dev)
+    L.check(L.lib().ly_rfa_bwd(p(d_rfa), p(rfa), p(mm), p(w18), n, h, w, p(d_mm), p(dw18), int(d18), st), "ly_rfa_bwd")
+    if t18 is not None and not d18:
         ops.grad_done(ctx.getw_param)
     # BatchNorm sums of the generate BatchNorm (double accumulators)
     sums = ops.new_stats(c, dev)
@@ -1176,7 +1186,7 @@ def _rfcbam_backward_k1(ctx, du, dgo, dbo):
     P.alpha, P.kappa, P.lambda_, P.dgap = p(alpha), p(kappa), p(lam), p(dgap)
     with ops._Timed(f"ly_rf1_bwd_kernel<{tn}, 2>", 10.0 * mo * c, 3.0 * es1):
         L.check(L.lib().ly_rf1_bwd(ctypes.byref(P), 2, st), "ly_rf1_bwd C")
-    if tgw is not None:
+    if tgw is not None and not dgw_defer:
         ops.grad_done(ctx.gen_w_param)
     dbias = None if ops.grad_target(ctx.conv_b_param) is not None else torch.zeros_like(bias)      # BN removes the batch mean: d/dbias = 0
     return (None, dx if ctx.needs_input_grad[1] else None, None if se_direct else dwa, None if se_direct else dwb,

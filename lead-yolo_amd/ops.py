@@ -255,7 +255,8 @@ def coordatt_mlp(pool, n, h, w, c, mip, w1, b1, wh, bh, ww, bw, sc=None, sh=None
 
 
 def coordatt_mlp_bwd(pool, n, h, w, c, mip, w1, b1, mean, invstd, gamma, beta, wh, ww, a_h, a_w, da_h, da_w, targets):
-    """targets: (dw1, dgamma, dbeta, dwh, dbh, dww, dbw) fp32 buffers that are ADDED to; returns dpool [n, h+w, c]"""
+    """targets: (dw1, dgamma, dbeta, dwh, dbh, dww, dbw) buffers that are ADDED to — all fp32, or all float64 scratches (small_grad_scratch);
+    returns dpool [n, h+w, c]"""
     r = n * (h + w)
     sums = zeros_f64(32 * 2 * mip, pool.device)                        # striped (sum dy1, sum dy1*xh), double accumulators
     ws = torch.empty(r * 3 * mip, dtype=torch.float32, device=pool.device)
@@ -263,7 +264,8 @@ def coordatt_mlp_bwd(pool, n, h, w, c, mip, w1, b1, mean, invstd, gamma, beta, w
     with _Timed("ly_coordatt_mlp_bwd1_kernel + bwd2", 8.0 * r * c * mip, 4.0 * 4 * r * c):
         capi.check(capi.lib().ly_coordatt_mlp_bwd(_p(pool), n, h, w, c, mip, _p(w1), _p(b1), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(wh), _p(ww),
                                                   _p(a_h), _p(a_w), _p(da_h), _p(da_w), _p(ws), _p(sums), _p(dpool),
-                                                  *[_p(t) for t in targets], capi.stream_ptr()), "ly_coordatt_mlp_bwd")
+                                                  *[_p(t) for t in targets], int(targets[0].dtype == torch.float64), capi.stream_ptr()),
+                   "ly_coordatt_mlp_bwd")
     return dpool
 
 
@@ -523,9 +525,57 @@ def detect_level(x, ldx, n, h, w, k, wp, bias, na, no, anchors, stride, p, z, zr
 
 
 def detect_head_bwd(dp, n, h, w, na, no, du, ldu, dbias):
-    """dp fp32 [n, na, h, w, no] -> du rows [n*h*w, ldu] (columns >= na*no zero), dbias[na*no] += column sums"""
-    capi.check(capi.lib().ly_detect_head_bwd(_p(dp), n, h, w, na, no, _p(du), ldu, _p(dbias), capi.dtype_code(du), capi.stream_ptr()),
-               "ly_detect_head_bwd")
+    """dp fp32 [n, na, h, w, no] -> du rows [n*h*w, ldu] (columns >= na*no zero), dbias[na*no] += column sums (dbias fp32, or a float64
+    scratch of small_grad_scratch)"""
+    capi.check(capi.lib().ly_detect_head_bwd(_p(dp), n, h, w, na, no, _p(du), ldu, _p(dbias), int(dbias.dtype == torch.float64), capi.dtype_code(du),
+                                             capi.stream_ptr()), "ly_detect_head_bwd")
+
+
+# ---- small parameter-gradient reductions, reproducibly -------------------------------------------------------------------------------
+# A few kernels add a handful of values from many blocks into a parameter gradient (Detect bias, get_weight's taps, the k = 1 generate weight,
+# CoordAtt's MLP).  With float atomics those gradients moved by ~1e-6 from run to run — the only part of a training step that was not the same
+# bits every time.  Inside a backward pass they accumulate into zeroed DOUBLE scratches instead (the arrival order then only moves the 53rd
+# bit), and ONE ly_f64_add launch, queued on the autograd engine for the end of the pass, rounds every sum into its fp32 `.grad` storage.
+class _SmallGrads:
+    pending = []            # (scratch, flat fp32 target, parameter)
+    queued = False
+
+
+DETERMINISTIC_SMALL_GRADS = True
+
+
+def small_grads_ok():
+    return DETERMINISTIC_SMALL_GRADS and torch._C._current_graph_task_id() != -1
+
+
+def small_grad_scratch(target, param):
+    """zeroed float64 stand-in for the fp32 gradient storage `target` (contiguous) of `param`; added into it — and `grad_done(param)` called —
+    when the running backward pass ends"""
+    scr = zeros_f64(target.numel(), target.device)
+    if param is not None and not any(prm is param for _, _, prm in _SmallGrads.pending):
+        for fn in GRAD_DEFER_LISTENERS:
+            fn(param)
+    _SmallGrads.pending.append((scr, target.view(-1), param))
+    if not _SmallGrads.queued:
+        torch.autograd.Variable._execution_engine.queue_callback(flush_small_grads)
+        _SmallGrads.queued = True
+    return scr
+
+
+def flush_small_grads():
+    items, _SmallGrads.pending, _SmallGrads.queued = _SmallGrads.pending, [], False
+    for i in range(0, len(items), capi.F64_ADD_MAX):
+        chunk = items[i:i + capi.F64_ADD_MAX]
+        t = capi.LyF64AddTable()
+        for j, (scr, tgt, _) in enumerate(chunk):
+            t.src[j], t.dst[j], t.n[j] = scr.data_ptr(), tgt.data_ptr(), tgt.numel()
+        t.count = len(chunk)
+        capi.check(capi.lib().ly_f64_add(ctypes.byref(t), capi.stream_ptr()), "ly_f64_add")
+    done = set()
+    for _, _, prm in items:
+        if prm is not None and id(prm) not in done:
+            done.add(id(prm))
+            grad_done(prm)
 
 
 def mlpblock(x, y, n, h, w, c, wp, w1, w2, sc, sh, stats=None):
@@ -700,6 +750,7 @@ class GradSink:
 
 
 SINK = None
+GRAD_DEFER_LISTENERS = []          # callables(param): told that a directly-written gradient will be announced at the end of the backward pass
 GRAD_LISTENERS = []                # callables(param): told when a directly-written gradient is complete (ddp.GradReducer)
 
 
@@ -886,7 +937,8 @@ def wgrad_group(problems):
     x0 = problems[0]["x"]
     px = 128 if x0.dtype == torch.bfloat16 else 64
     anyp = any(q.get("x_scale") is not None for q in problems)
-    with _Timed(f"ly_wgrad_tiled_group_kernel<{_tname(x0)}, 128, 128, {px}, true, {'true' if anyp else 'false'}>", sum(2.0 * q["M"] * q["N"] * q["Cin"] for q in problems),
+    gslab = ", true" if wgrad_workspace(x0.device) is not None else ""          # slab flush + ly_wgrad_combine_group_kernel (wgrad_group_launch)
+    with _Timed(f"ly_wgrad_tiled_group_kernel<{_tname(x0)}, 128, 128, {px}, true, {'true' if anyp else 'false'}{gslab}>", sum(2.0 * q["M"] * q["N"] * q["Cin"] for q in problems),
                 sum(x0.element_size() * q["M"] * (q["N"] + q["Cin"]) + 4.0 * q["N"] * q["Cin"] for q in problems)):
         capi.check(capi.lib().ly_wgrad_group(arr, len(problems), capi.stream_ptr()), "ly_wgrad_group")
 

@@ -1,5 +1,5 @@
 """Run-to-run reproducibility of one training step (forward + loss + backward) of lead-yolo-n from one state: per-parameter relative
-difference of the gradients between runs, in model order (where does the noise enter?).   python tools/step_repro.py [bf16|f32]"""
+difference of the gradients between runs, in model order (where does the noise enter?).   python tools/step_repro.py [bf16|f32] [scale=s] [bs=64] [size=640] [sink]"""
 import os
 import sys
 
@@ -12,14 +12,24 @@ from oracle import synth                                    # noqa: E402
 dev = torch.device("cuda:0")
 amp = torch.bfloat16 if (len(sys.argv) < 2 or sys.argv[1] != "f32") else None
 torch.manual_seed(0)
-m = L.Model(L.load_cfg(scale="n"))
+SCALE = next((a.split("=")[1] for a in sys.argv if a.startswith("scale=")), "n")
+BS = int(next((a.split("=")[1] for a in sys.argv if a.startswith("bs=")), "4"))
+SIZE = int(next((a.split("=")[1] for a in sys.argv if a.startswith("size=")), "160"))
+m = L.Model(L.load_cfg(scale=SCALE))
 st = synth.synth_state(synth.shapes_of(m.state_dict()), 7373)
 st["model.23.anchors"] = m.model[-1].anchors.clone()
 m.load_state_dict(st)
 m = m.to(dev).train()
 cl = L.ComputeLoss(m)
-imgs = synth.synth_images(4, 160, 71).to(dev)
-tg = synth.synth_targets(4, 72, per_image=4).to(dev)
+imgs = synth.synth_images(BS, SIZE, 71).to(dev)
+tg = synth.synth_targets(BS, 72, per_image=4).to(dev)
+SINK = "sink" in sys.argv          # gradients through optim.FusedSGD's gradient sink (what train_step uses): one warm-up step creates the storage
+if SINK:
+    opt = L.smart_optimizer(m, "SGD", 0.01, 0.937, 5e-4, fused=True)
+    L.train_step(m, cl, opt, imgs, tg, amp=amp)
+    st0 = synth.synth_state(synth.shapes_of(m.state_dict()), 7373)
+    st0["model.23.anchors"] = m.model[-1].anchors.clone()
+    m.load_state_dict(st0)
 bufs0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
 runs = []
 hooks, acts = [], []
@@ -38,7 +48,10 @@ for it in range(4):
         del junk
     m.load_state_dict(bufs0)
     for p in m.parameters():
-        p.grad = None
+        if SINK and p.grad is not None:
+            p.grad.zero_()
+        else:
+            p.grad = None
     acts.append({})
     with torch.autocast("cuda", dtype=amp, enabled=amp is not None):
         pred = m(imgs.float() / 255)

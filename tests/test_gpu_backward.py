@@ -633,6 +633,62 @@ def test_training_forward_is_reproducible_and_gradients_agree_to_summation_noise
         assert whole <= lim_whole and worst <= lim_tensor, f"gradients differ between two runs of the same step: whole vector {whole:.3e}, worst tensor {name} {worst:.3e}"
 
 
+@pytest.mark.parametrize("scale,bs,size", [("n", 4, 160), ("s", 8, 256)])
+@pytest.mark.parametrize("amp", [None, torch.bfloat16])
+def test_training_step_is_bit_reproducible_through_the_gradient_sink(amp, scale, bs, size):
+    """with optim.FusedSGD's gradient sink (what train_step uses) NOTHING in a training step depends on the arrival order of
+    atomics any more — batch statistics and activation-gradient sums are double accumulators, every tiled weight gradient (single and grouped
+    launches) leaves through slabs + a fixed-order combine, and the small reductions (Detect bias, get_weight, k = 1 generate, CoordAtt's MLP)
+    accumulate in float64 scratches that ly_f64_add rounds into the sink at the end of the backward pass.  From one state: (a) three runs of
+    forward + loss + backward give BIT-IDENTICAL gradients for every parameter, (b) two optimisation steps leave BIT-IDENTICAL weights, EMA
+    and momentum buffers."""
+    import lead_yolo_amd as L
+    torch.manual_seed(0)
+    m = L.Model(_cfg(scale))
+    st = synth.synth_state(synth.shapes_of(m.state_dict()), 7373)
+    st["model.23.anchors"] = m.model[-1].anchors.clone()
+    m.load_state_dict(st)
+    m = m.to(_dev()).train()
+    cl = L.ComputeLoss(m)
+    opt = L.smart_optimizer(m, "SGD", 0.01, 0.937, 5e-4, fused=True)
+    imgs = synth.synth_images(bs, size, 71).to(_dev())
+    tg = synth.synth_targets(bs, 72, per_image=4).to(_dev())
+    L.train_step(m, cl, opt, imgs, tg, amp=amp)                       # creates the sink's persistent gradient storage
+    bufs0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    mom0 = [{k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in opt.state[p_].items()} for g_ in opt.param_groups for p_ in g_["params"]]
+    runs = []
+    for _ in range(3):
+        m.load_state_dict(bufs0)
+        for p in m.parameters():
+            p.grad.zero_()
+        with torch.autocast("cuda", dtype=amp, enabled=amp is not None):
+            loss, _ = cl(m(imgs.float() / 255), tg)
+        loss.backward()
+        torch.cuda.synchronize()
+        runs.append({n: p.grad.detach().clone() for n, p in m.named_parameters()})
+    assert sum(float(g.abs().sum()) > 0 for g in runs[0].values()) > 0.9 * len(runs[0])
+    for other in runs[1:]:
+        bad = [n for n in runs[0] if not torch.equal(runs[0][n], other[n])]
+        assert not bad, f"{len(bad)} parameter gradients differ between two runs of the same step: {bad[:8]}"
+    for p in m.parameters():
+        p.grad.zero_()
+    ends = []
+    for _ in range(2):
+        m.load_state_dict(bufs0)
+        k = 0
+        for g_ in opt.param_groups:
+            for p_ in g_["params"]:
+                for kk, v in mom0[k].items():
+                    if torch.is_tensor(v):
+                        opt.state[p_][kk].copy_(v)
+                k += 1
+        L.train_step(m, cl, opt, imgs, tg, amp=amp)
+        torch.cuda.synchronize()
+        ends.append({k_: v.detach().clone() for k_, v in m.state_dict().items()})
+    bad = [k_ for k_ in ends[0] if not torch.equal(ends[0][k_], ends[1][k_])]
+    assert not bad, f"two optimisation steps from one state leave different tensors: {bad[:8]}"
+
+
 def test_reference_training_objects_stock_ddp_gradscaler_fp16_autocast():
     """the route `python -m lead_yolo_amd.run train.py` takes, without the reference travelling: the HIP `Model` wrapped in stock
     torch.nn.parallel.DistributedDataParallel(static_graph=True) (utils/torch_utils.py:55-63) on a one-rank RCCL group, torch.optim.SGD with

@@ -470,29 +470,19 @@ def test_graphed_train_step_matches_eager(amp):
     # fp32 atomics layer by layer (tools/step_repro.py: 1e-4 at the neck, 1e-2 at the stem).
     tight = 1e-6 if amp is None else 1e-5
     assert abs(le - lg) <= tight * abs(le) and abs(le - le2) <= tight * abs(le), (le, le2, lg)
-    # Compared per class of state (weights, EMA, momentum):
-    #   (a) every entry stays within `loose` of its tensor's scale (weights and EMA move by lr * update: a wrong or stale step shows),
-    #   (b) the step's UPDATE of the whole class as ONE vector: cosine with the eager step's and norm ratio — a skipped EMA update or
-    #       optimiser step is a zero vector, a doubled one has ratio 2, gradients in the wrong place lose the direction,
-    #   (c) most tensors individually: >= 80 % (fp32) / 50 % (bf16) of them agree to `floor` in relative L2 of their update.
-    loose = 1e-4 if amp is None else 1e-3
-    cos_min, ratio_tol, floor = (0.99999, 1e-3, 1e-3) if amp is None else (0.9999, 1e-3, 1e-2)
+    # Round 4 (second half): nothing in the step depends on the arrival order of atomics any more (slab + fixed-order combine for every tiled
+    # weight gradient, float64 scratches for the small reductions, double accumulators everywhere else) — the cosine / ratio / 95 % bands this
+    # test carried are gone: two eager steps from one state, and the graph replay of that step, leave the SAME BITS in every weight, EMA
+    # entry and momentum buffer.
     for wi, what in enumerate(("weight", "ema", "momentum")):
-        a, b, before = e[wi], g[wi], s0[0][wi]
-        assert a.keys() == b.keys() and len(a) > 100
-        rels, dg, de = [], [], []
-        for k in a:
-            if what != "momentum":
-                assert float((a[k] - b[k]).abs().max()) <= loose * float(a[k].abs().max()) + 1e-6, (what, k)
-            da, db = (a[k] - before[k]).flatten().double(), (b[k] - before[k]).flatten().double()
-            de.append(da); dg.append(db)
-            if float(da.norm()) > 1e-9:
-                rels.append((float((da - db).norm() / da.norm()), k))
-        de, dg = torch.cat(de), torch.cat(dg)
-        cos, ratio = float(de @ dg / (de.norm() * dg.norm())), float(dg.norm() / de.norm())
-        assert cos >= cos_min and abs(ratio - 1) <= ratio_tol, (what, "update", cos, ratio)
-        frac = 0.95
-        assert len(rels) > 100 and sum(r[0] <= floor for r in rels) >= frac * len(rels), (what, "update", sorted(rels)[-10:])
+        a, a2, b = e[wi], e2[wi], g[wi]
+        assert a.keys() == b.keys() == a2.keys() and len(a) > 100
+        bad_e = [k for k in a if not torch.equal(a[k], a2[k])]
+        bad_g = [k for k in a if not torch.equal(a[k], b[k])]
+        assert not bad_e, (what, "two eager steps differ", len(bad_e), bad_e[:6])
+        assert not bad_g, (what, "graph replay differs from the eager step", len(bad_g), bad_g[:6])
+        moved = sum(not torch.equal(a[k], s0[0][wi][k]) for k in a)
+        assert moved > 0.9 * len(a), (what, "the step did not move the state", moved, len(a))
     # ---- a short trajectory on changing batches: graph replays vs eager steps from the same state, loosely ----
     traj = []
     for how in ("eager", "graph"):

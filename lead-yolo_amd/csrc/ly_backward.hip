@@ -447,7 +447,7 @@ __device__ __forceinline__ void ly_wgrad_tiled_body(const LyWgradParams& Q, cons
   // DEFER (the grouped slab instantiation): the loads of a step are pure — masked pixels are zeroed when the registers are committed to LDS,
   // not right behind each load.  With the select behind the load hipcc's scheduler, in THIS instantiation, sank every load next to its
   // select: one `s_waitcnt vmcnt(0)` per load, the pixel loop ran at one memory round trip per 8 bytes (53 -> 108 us per launch).
-  constexpr bool DEFER = SLAB == 2 && ROWS;
+  constexpr bool DEFER = SLAB == 2 && ROWS;      // (the same change in the single-problem instantiations: 32.6 -> 37.7 us — only where the scheduler had gone wrong)
   long pre_p0 = 0;
   R4 pre[TPT][8];
   auto prefetch = [&](long p0) {
@@ -630,7 +630,9 @@ __device__ __forceinline__ void ly_wgrad_tiled_body(const LyWgradParams& Q, cons
 // dw[n][tap][c] += sum over chunks of slab[chunk][tile][row][col] in a fixed order, one writer per element (the second launch of a tiled
 // weight gradient whose chunks left their tiles in LyWgradParams.ws).  Block = 64 slab columns x 16 chunk lanes.
 __device__ __forceinline__ void ly_wgrad_combine_body(const LyWgradParams& P, const float* __restrict__ slab, const int chunks, const int tiles_k,
-                                                      const int tiles, const int BN, const int BK, const long blk) {
+                                                      const int tiles, const int BN, const int BK, const long blk, const int rls) {
+  // rls row lanes (block = 64 columns x rls lanes, 64 rls threads) walk the chunks: 16 for the single-problem launches (hundreds of chunks
+  // per element), 4 when a group's problems have a few dozen chunks each (1024 threads with two loads apiece were all overhead: 13 us)
   __shared__ float red[16][64];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const long E = (long)tiles * BN * BK;
@@ -648,38 +650,37 @@ __device__ __forceinline__ void ly_wgrad_combine_body(const LyWgradParams& P, co
     // the summation order is fixed, whatever the block count of the producing launch
     const float* p = slab + e;
     int c = rl;
-    for (; c + 112 < chunks; c += 128) {                // eight loads fenced ahead of the adds (the scheduler sinks them back otherwise)
+    for (; c + 7 * rls < chunks; c += 8 * rls) {        // eight loads fenced ahead of the adds (the scheduler sinks them back otherwise)
       float v[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] = p[(long)(c + 16 * k) * E];
+      for (int k = 0; k < 8; ++k) v[k] = p[(long)(c + rls * k) * E];
       __builtin_amdgcn_sched_barrier(0);
       a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
       a0 += v[4]; a1 += v[5]; a2 += v[6]; a3 += v[7];
     }
-    for (; c + 48 < chunks; c += 64) {
+    for (; c + 3 * rls < chunks; c += 4 * rls) {
       float v[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = p[(long)(c + 16 * k) * E];
+      for (int k = 0; k < 4; ++k) v[k] = p[(long)(c + rls * k) * E];
       __builtin_amdgcn_sched_barrier(0);
       a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
     }
     if (c < chunks) a0 += p[(long)c * E];
-    if (c + 16 < chunks) a1 += p[(long)(c + 16) * E];
-    if (c + 32 < chunks) a2 += p[(long)(c + 32) * E];
+    if (c + rls < chunks) a1 += p[(long)(c + rls) * E];
+    if (c + 2 * rls < chunks) a2 += p[(long)(c + 2 * rls) * E];
   }
   red[rl][cl] = (a0 + a1) + (a2 + a3);
   __syncthreads();
   if (rl == 0 && live) {
     float sacc = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) sacc += red[i][cl];
+    for (int i = 0; i < rls; ++i) sacc += red[i][cl];
     float* d = P.dw + (long)row * P.lddw + (long)tap * P.dw_ts + (long)cch * P.dw_cs;
     *d += sacc;
   }
 }
 __global__ __launch_bounds__(1024) void ly_wgrad_combine_kernel(const LyWgradParams P, const float* __restrict__ slab, const int chunks, const int tiles_k,
                                                                const int tiles, const int BN, const int BK) {
-  ly_wgrad_combine_body(P, slab, chunks, tiles_k, tiles, BN, BK, (long)blockIdx.x);
+  ly_wgrad_combine_body(P, slab, chunks, tiles_k, tiles, BN, BK, (long)blockIdx.x, 16);
 }
 static void wgrad_combine_launch(const LyWgradParams& P, const float* slab, long chunks, int tiles_k, long tiles, int BN, int BK, hipStream_t st) {
   const long E = tiles * BN * BK;
@@ -719,13 +720,13 @@ __global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(BN +
   ly_wgrad_tiled_body<T, BN, BK, P, ROWS, PRO, GSLAB ? 2 : 0>(G.p[g], local % tiles, local / tiles, G.tiles_k[g], G.chunk_px[g], GSLAB ? G.slab[g] : nullptr, tiles);
 }
 // the combine launches of a group's problems as ONE launch
-__global__ __launch_bounds__(1024) void ly_wgrad_combine_group_kernel(const LyWgradGroupArgs G, const int BN, const int BK) {
+__global__ __launch_bounds__(1024) void ly_wgrad_combine_group_kernel(const LyWgradGroupArgs G, const int BN, const int BK, const int rls) {
   int g = 0;
 #pragma unroll
   for (int i = 1; i < LY_WGRAD_GROUP_MAX; ++i)
     if (i < G.n && (int)blockIdx.x >= G.cblk0[i]) g = i;
   g = __builtin_amdgcn_readfirstlane(g);
-  ly_wgrad_combine_body(G.p[g], G.slab[g], G.chunks[g], G.tiles_k[g], G.tiles[g], BN, BK, (long)((int)blockIdx.x - G.cblk0[g]));
+  ly_wgrad_combine_body(G.p[g], G.slab[g], G.chunks[g], G.tiles_k[g], G.tiles[g], BN, BK, (long)((int)blockIdx.x - G.cblk0[g]), rls);
 }
 
 // blocks a weight-gradient launch aims for (development knob: LY_WG_BLOCKS / LY_WG_GROUP_BLOCKS)
@@ -850,7 +851,10 @@ static int wgrad_group_launch(const LyWgradParams* arr, int n, hipStream_t st) {
       if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ly_wgrad_tiled_group_kernel<T, BN, BK, PX, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
       hipLaunchKernelGGL((ly_wgrad_tiled_group_kernel<T, BN, BK, PX, true, false, true>), dim3((unsigned)G.blk0[n]), dim3(LY_THREADS), lds, st, G);
     }
-    hipLaunchKernelGGL(ly_wgrad_combine_group_kernel, dim3((unsigned)G.cblk0[n]), dim3(1024), 0, st, G, BN, BK);
+    int cmax = 0;
+    for (int g = 0; g < n; ++g) cmax = G.chunks[g] > cmax ? G.chunks[g] : cmax;
+    const int rls = cmax <= 64 ? 4 : 16;
+    hipLaunchKernelGGL(ly_wgrad_combine_group_kernel, dim3((unsigned)G.cblk0[n]), dim3(64 * rls), 0, st, G, BN, BK, rls);
     LY_LAUNCH_CHECK();
     return 0;
   }

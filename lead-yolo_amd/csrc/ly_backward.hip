@@ -679,12 +679,13 @@ __device__ __forceinline__ void ly_wgrad_combine_body(const LyWgradParams& P, co
   }
 }
 __global__ __launch_bounds__(1024) void ly_wgrad_combine_kernel(const LyWgradParams P, const float* __restrict__ slab, const int chunks, const int tiles_k,
-                                                               const int tiles, const int BN, const int BK) {
-  ly_wgrad_combine_body(P, slab, chunks, tiles_k, tiles, BN, BK, (long)blockIdx.x, 16);
+                                                               const int tiles, const int BN, const int BK, const int rls) {
+  ly_wgrad_combine_body(P, slab, chunks, tiles_k, tiles, BN, BK, (long)blockIdx.x, rls);
 }
 static void wgrad_combine_launch(const LyWgradParams& P, const float* slab, long chunks, int tiles_k, long tiles, int BN, int BK, hipStream_t st) {
   const long E = tiles * BN * BK;
-  hipLaunchKernelGGL(ly_wgrad_combine_kernel, dim3((unsigned)((E + 63) / 64)), dim3(1024), 0, st, P, slab, (int)chunks, tiles_k, (int)tiles, BN, BK);
+  const int rls = chunks <= 64 ? 4 : 16;                  // row lanes: see ly_wgrad_combine_body
+  hipLaunchKernelGGL(ly_wgrad_combine_kernel, dim3((unsigned)((E + 63) / 64)), dim3(64 * rls), 0, st, P, slab, (int)chunks, tiles_k, (int)tiles, BN, BK, rls);
 }
 
 template <typename T, int BN, int BK, int P, bool ROWS, bool PRO = false>

@@ -545,7 +545,9 @@ DETERMINISTIC_SMALL_GRADS = True
 
 
 def small_grads_ok():
-    return DETERMINISTIC_SMALL_GRADS and torch._C._current_graph_task_id() != -1
+    """inside a backward pass of the autograd engine (where the end-of-pass callback can be queued)?"""
+    task = getattr(torch._C, "_current_graph_task_id", None)
+    return DETERMINISTIC_SMALL_GRADS and task is not None and task() != -1
 
 
 def small_grad_scratch(target, param):

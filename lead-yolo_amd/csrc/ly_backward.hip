@@ -684,7 +684,7 @@ __global__ __launch_bounds__(1024) void ly_wgrad_combine_kernel(const LyWgradPar
 }
 static void wgrad_combine_launch(const LyWgradParams& P, const float* slab, long chunks, int tiles_k, long tiles, int BN, int BK, hipStream_t st) {
   const long E = tiles * BN * BK;
-  const int rls = chunks <= 64 ? 4 : 16;                  // row lanes: see ly_wgrad_combine_body
+  const int rls = chunks <= 192 ? 4 : 16;                 // row lanes: see ly_wgrad_combine_body
   hipLaunchKernelGGL(ly_wgrad_combine_kernel, dim3((unsigned)((E + 63) / 64)), dim3(64 * rls), 0, st, P, slab, (int)chunks, tiles_k, (int)tiles, BN, BK, rls);
 }
 

@@ -195,8 +195,8 @@ __global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
 // dw[row][tap][c] += sum over chunks of slab[chunk][combo][row][16*ct + li]   (fixed order; one writer per element)
 // block = 64 consecutive slab columns x 16 chunk lanes; grid.x covers the n_c * n_n * 64 * 288 / 64 column groups of one chunk
 __global__ __launch_bounds__(1024) void ly_wgrad3_combine_kernel(const LyWgradParams P, const float* __restrict__ slab, const int chunks, const int n_n,
-                                                                const int n_c) {
-  __shared__ float red[16][64];
+                                                                const int n_c, const int rls) {
+  __shared__ float red[16][64];                            // rls row lanes walk the chunks (see ly_wgrad_combine_body, ly_backward.hip)
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const long E = (long)n_c * n_n * (W3_BN * 288);
   const long e = (long)blockIdx.x * 64 + cl;
@@ -213,31 +213,30 @@ __global__ __launch_bounds__(1024) void ly_wgrad3_combine_kernel(const LyWgradPa
   if (live) {
     const float* p = slab + e;                               // four loads in flight per lane (see ly_wgrad_combine_kernel)
     int c = rl;
-    for (; c + 112 < chunks; c += 128) {                // eight loads fenced ahead of the adds (the scheduler sinks them back otherwise)
+    for (; c + 7 * rls < chunks; c += 8 * rls) {        // eight loads fenced ahead of the adds (the scheduler sinks them back otherwise)
       float v[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] = p[(long)(c + 16 * k) * E];
+      for (int k = 0; k < 8; ++k) v[k] = p[(long)(c + rls * k) * E];
       __builtin_amdgcn_sched_barrier(0);
       a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
       a0 += v[4]; a1 += v[5]; a2 += v[6]; a3 += v[7];
     }
-    for (; c + 48 < chunks; c += 64) {
+    for (; c + 3 * rls < chunks; c += 4 * rls) {
       float v[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = p[(long)(c + 16 * k) * E];
+      for (int k = 0; k < 4; ++k) v[k] = p[(long)(c + rls * k) * E];
       __builtin_amdgcn_sched_barrier(0);
       a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
     }
     if (c < chunks) a0 += p[(long)c * E];
-    if (c + 16 < chunks) a1 += p[(long)(c + 16) * E];
-    if (c + 32 < chunks) a2 += p[(long)(c + 32) * E];
+    if (c + rls < chunks) a1 += p[(long)(c + rls) * E];
+    if (c + 2 * rls < chunks) a2 += p[(long)(c + 2 * rls) * E];
   }
   red[rl][cl] = (a0 + a1) + (a2 + a3);
   __syncthreads();
   if (rl == 0 && live) {
     float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) s += red[i][cl];
+    for (int i = 0; i < rls; ++i) s += red[i][cl];
     float* d = P.dw + (long)orow * P.lddw + (long)(ct >> 1) * P.dw_ts + (long)cch * P.dw_cs;
     *d += s;
   }
@@ -272,7 +271,8 @@ int ly_wgrad3_launch(const LyWgradParams& P, hipStream_t st) {
                      (int)total, slab);
   if (slab) {
     const long E = (long)n_n * n_c * (W3_BN * 288);
-    hipLaunchKernelGGL(ly_wgrad3_combine_kernel, dim3((unsigned)((E + 63) / 64)), dim3(1024), 0, st, P, slab, (int)chunks, n_n, n_c);
+    const int rls = chunks <= 192 ? 4 : 16;                  // row lanes of the combine (96 chunks: 16.7 us with 16, 13.7 with 4 or 8)
+    hipLaunchKernelGGL(ly_wgrad3_combine_kernel, dim3((unsigned)((E + 63) / 64)), dim3(64 * rls), 0, st, P, slab, (int)chunks, n_n, n_c, rls);
   }
   LY_LAUNCH_CHECK();
   return 0;

@@ -1003,37 +1003,36 @@ __global__ __launch_bounds__(LY_THREADS) void ly_unpatch_kernel(const T* __restr
 // state of its own, and a captured instance returned wrong sums once the same reduction had also run eagerly in the process.)
 // -------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void ly_sum_rows_kernel(const float* __restrict__ src, const long R, const long C, const long ld,
-                                                          float* __restrict__ dst, const int accumulate) {
-  __shared__ float red[16][64];
+                                                          float* __restrict__ dst, const int accumulate, const int rls) {
+  __shared__ float red[16][64];                            // rls row lanes (4 for R <= 192, else 16: see ly_wgrad_combine_body)
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const long c = (long)blockIdx.x * 64 + cl;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   if (c < C) {
     const float* p = src + c;
     long r = rl;
-    for (; r + 112 < R; r += 128) {                     // eight loads fenced ahead of the adds
+    for (; r + 7 * rls < R; r += 8 * rls) {             // eight loads fenced ahead of the adds
       float v[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] = p[(r + 16 * k) * ld];
+      for (int k = 0; k < 8; ++k) v[k] = p[(r + rls * k) * ld];
       __builtin_amdgcn_sched_barrier(0);
       a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
       a0 += v[4]; a1 += v[5]; a2 += v[6]; a3 += v[7];
     }
-    for (; r + 48 < R; r += 64) {
+    for (; r + 3 * rls < R; r += 4 * rls) {
       float v[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = p[(r + 16 * k) * ld];
+      for (int k = 0; k < 4; ++k) v[k] = p[(r + rls * k) * ld];
       __builtin_amdgcn_sched_barrier(0);
       a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
     }
-    for (; r < R; r += 16) a0 += p[r * ld];
+    for (; r < R; r += rls) a0 += p[r * ld];
   }
   red[rl][cl] = (a0 + a1) + (a2 + a3);
   __syncthreads();
   if (rl == 0 && c < C) {
     float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) s += red[i][cl];
+    for (int i = 0; i < rls; ++i) s += red[i][cl];
     dst[c] = accumulate ? dst[c] + s : s;
   }
 }
@@ -1041,8 +1040,9 @@ __global__ __launch_bounds__(1024) void ly_sum_rows_kernel(const float* __restri
 extern "C" int ly_sum_rows(const float* src, long R, long C, long ld, float* dst, int accumulate, void* stream) {
   LY_CHECK(src && dst && R > 0 && C > 0 && ld >= C, "sum_rows: bad arguments");
   LY_CHECK((C + 63) / 64 < (1L << 31), "sum_rows: too many columns");
-  hipLaunchKernelGGL(ly_sum_rows_kernel, dim3((unsigned)((C + 63) / 64)), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), src, R, C, ld, dst,
-                     accumulate);
+  const int rls = R <= 192 ? 4 : 16;
+  hipLaunchKernelGGL(ly_sum_rows_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64 * rls), 0, reinterpret_cast<hipStream_t>(stream), src, R, C, ld, dst,
+                     accumulate, rls);
   LY_LAUNCH_CHECK();
   return 0;
 }

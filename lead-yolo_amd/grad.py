@@ -501,9 +501,13 @@ class DetectHeadFn(torch.autograd.Function):
             tb = ops.grad_target(b_param)
             tb = tb if tb is not None and tb.is_contiguous() and tb.numel() == co else None
             defer = tb is not None and ops.small_grads_ok()       # float64 scratch, rounded into the sink when the backward pass ends
-            dbias = ops.small_grad_scratch(tb, b_param) if defer else tb if tb is not None else torch.zeros(co, dtype=torch.float32, device=dp.device)
+            fresh64 = tb is None and ops.DETERMINISTIC_SMALL_GRADS      # no sink: float64 scratch, rounded right away (returned to autograd)
+            dbias = ops.small_grad_scratch(tb, b_param) if defer else tb if tb is not None else \
+                ops.zeros_f64(co, dp.device) if fresh64 else torch.zeros(co, dtype=torch.float32, device=dp.device)
             du = torch.empty((bs, ny, nx, cq), dtype=t0.dtype, device=dp.device)
             ops.detect_head_bwd(dp, bs, ny, nx, na, no, du, cq, dbias)
+            if fresh64:
+                dbias = ops.f64_round([dbias], [(co,)])[0]
             if tb is not None and not defer:
                 ops.grad_done(b_param)
             du_d = du.permute(0, 3, 1, 2)
@@ -708,11 +712,25 @@ class CoordAttFn(torch.autograd.Function):
             ret.append(tgt if (fresh and p.requires_grad) else None)
         # every target in the sink: accumulate in float64 scratches, rounded into the sink when the backward pass ends (ops.small_grad_scratch)
         defer = ops.small_grads_ok() and all(r is None for r in ret) and all(t.is_contiguous() for t in targets)
+        no_sink = all(q is None or not q.requires_grad or ops.grad_target(q) is None for i, q in enumerate(ctx.params) if i != 1)
+        fresh64 = (not defer) and ops.DETERMINISTIC_SMALL_GRADS and no_sink
         if defer:
             targets = [ops.small_grad_scratch(t, q) for t, q in zip(targets, [q for i, q in enumerate(ctx.params) if i != 1])]
+        elif fresh64:                                         # no sink anywhere: float64 scratches, rounded right after the launch
+            shapes = [t.shape for t in targets]
+            targets = [ops.zeros_f64(t.numel(), xr.device) for t in targets]
         W1, Wh, Ww = (p.detach().reshape(p.shape[0], -1) for p in (w1, wh, ww))
         dpool = ops.coordatt_mlp_bwd(pool, n, h, w, c, ctx.mip, W1, b1.detach(), mean, invstd, gamma.detach(), beta.detach(), Wh, Ww, a_h, a_w,
                                      da_h, da_w, targets)
+        if fresh64:
+            rounded, k, out = ops.f64_round(targets, shapes), 0, []
+            for i, r in enumerate(ret):
+                if i == 1:
+                    out.append(r)
+                    continue
+                out.append(rounded[k] if r is not None else None)
+                k += 1
+            ret = out
         ops.pool_hw_bwd(dpool, n, h, w, c, into=dx)
         for i, (p, r) in enumerate(zip(ctx.params, ret)):
             if r is None and p.requires_grad and not (defer and i != 1):
@@ -959,8 +977,12 @@ class RfcbamFn(torch.autograd.Function):
             t18 = ops.grad_target(ctx.getw_param)
             t18 = t18 if t18 is not None and t18.is_contiguous() else None
             d18 = t18 is not None and ops.small_grads_ok()          # deferred: a float64 scratch, rounded into the sink when the backward pass ends
-            dw18 = ops.small_grad_scratch(t18, ctx.getw_param) if d18 else t18.view(-1) if t18 is not None else torch.zeros(18, dtype=torch.float32, device=dev)
-            L.check(L.lib().ly_rfa_bwd(p(d_rfa), p(rfa), p(mm), p(w18), n, k * ho, k * wo, p(d_mm), p(dw18), int(d18), st), "ly_rfa_bwd")
+            f18 = t18 is None and ops.DETERMINISTIC_SMALL_GRADS          # no sink: float64 scratch, rounded right away (returned to autograd)
+            dw18 = ops.small_grad_scratch(t18, ctx.getw_param) if d18 else t18.view(-1) if t18 is not None else \
+                ops.zeros_f64(18, dev) if f18 else torch.zeros(18, dtype=torch.float32, device=dev)
+            L.check(L.lib().ly_rfa_bwd(p(d_rfa), p(rfa), p(mm), p(w18), n, k * ho, k * wo, p(d_mm), p(dw18), int(d18 or f18), st), "ly_rfa_bwd")
+            if f18:
+                dw18 = ops.f64_round([dw18], [(18,)])[0]
             if t18 is not None and not d18:
                 ops.grad_done(ctx.getw_param)
             # 8. through max/mean, ca, rfa and ReLU; generate-BN sums
@@ -1060,8 +1082,12 @@ def _rfcbam_backward_rc(ctx, du, dgo, dbo):
     t18 = ops.grad_target(ctx.getw_param)
     t18 = t18 if t18 is not None and t18.is_contiguous() else None
     d18 = t18 is not None and ops.small_grads_ok()          # deferred: a float64 scratch, rounded into the sink when the backward pass ends
-    dw18 = ops.small_grad_scratch(t18, ctx.getw_param) if d18 else t18.view(-1) if t18 is not None else torch.zeros(18, dtype=torch.float32, device=dev)
-    L.check(L.lib().ly_rfa_bwd(p(d_rfa), p(rfa), p(mm), p(w18), n, 3 * ho, 3 * wo, p(d_mm), p(dw18), int(d18), st), "ly_rfa_bwd")
+    f18 = t18 is None and ops.DETERMINISTIC_SMALL_GRADS          # no sink: float64 scratch, rounded right away (returned to autograd)
+    dw18 = ops.small_grad_scratch(t18, ctx.getw_param) if d18 else t18.view(-1) if t18 is not None else \
+        ops.zeros_f64(18, dev) if f18 else torch.zeros(18, dtype=torch.float32, device=dev)
+    L.check(L.lib().ly_rfa_bwd(p(d_rfa), p(rfa), p(mm), p(w18), n, 3 * ho, 3 * wo, p(d_mm), p(dw18), int(d18 or f18), st), "ly_rfa_bwd")
+    if f18:
+        dw18 = ops.f64_round([dw18], [(18,)])[0]
     if t18 is not None and not d18:
         ops.grad_done(ctx.getw_param)
     P.d_mm = p(d_mm)
@@ -1133,9 +1159,11 @@ def _rfcbam_backward_k1(ctx, du, dgo, dbo):
     tgw = ops.grad_target(ctx.gen_w_param) if getattr(ctx, "gen_w_param", None) is not None else None
     tgw = tgw if tgw is not None and tgw.is_contiguous() else None
     dgw_defer = tgw is not None and ops.small_grads_ok()
-    dgw = ops.small_grad_scratch(tgw, ctx.gen_w_param) if dgw_defer else tgw.view(-1) if tgw is not None else torch.zeros(c, dtype=torch.float32, device=dev)
+    dgw_fresh64 = tgw is None and ops.DETERMINISTIC_SMALL_GRADS         # no sink: float64 scratch, rounded after pass C (returned to autograd)
+    dgw = ops.small_grad_scratch(tgw, ctx.gen_w_param) if dgw_defer else tgw.view(-1) if tgw is not None else \
+        ops.zeros_f64(c, dev) if dgw_fresh64 else torch.zeros(c, dtype=torch.float32, device=dev)
     P = L.LyRf1BwdParams(n, h * w, c, p(xr), ld, p(dcd), p(gw), p(ag), p(bg), p(ca), p(rfa), p(cd), p(d_rfa), p(gmax), p(d_ca64),
-                         p(gmax), None, None, None, None, None, None, 1.0 / (h * w), p(dx), c, p(dgw), L.dtype_code(xr), int(dgw_defer))
+                         p(gmax), None, None, None, None, None, None, 1.0 / (h * w), p(dx), c, p(dgw), L.dtype_code(xr), int(dgw_defer or dgw_fresh64))
     es1 = xr.element_size() * mo * c
     tn = ops._tname(xr)
     with ops._Timed(f"ly_rf1_bwd_kernel<{tn}, 0>", 6.0 * mo * c, 3.0 * es1):
@@ -1157,8 +1185,12 @@ def _rfcbam_backward_k1(ctx, du, dgo, dbo):
     t18 = ops.grad_target(ctx.getw_param)
     t18 = t18 if t18 is not None and t18.is_contiguous() else None
     d18 = t18 is not None and ops.small_grads_ok()          # deferred: a float64 scratch, rounded into the sink when the backward pass ends
-    dw18 = ops.small_grad_scratch(t18, ctx.getw_param) if d18 else t18.view(-1) if t18 is not None else torch.zeros(18, dtype=torch.float32, device=dev)
-    L.check(L.lib().ly_rfa_bwd(p(d_rfa), p(rfa), p(mm), p(w18), n, h, w, p(d_mm), p(dw18), int(d18), st), "ly_rfa_bwd")
+    f18 = t18 is None and ops.DETERMINISTIC_SMALL_GRADS          # no sink: float64 scratch, rounded right away (returned to autograd)
+    dw18 = ops.small_grad_scratch(t18, ctx.getw_param) if d18 else t18.view(-1) if t18 is not None else \
+        ops.zeros_f64(18, dev) if f18 else torch.zeros(18, dtype=torch.float32, device=dev)
+    L.check(L.lib().ly_rfa_bwd(p(d_rfa), p(rfa), p(mm), p(w18), n, h, w, p(d_mm), p(dw18), int(d18 or f18), st), "ly_rfa_bwd")
+    if f18:
+        dw18 = ops.f64_round([dw18], [(18,)])[0]
     if t18 is not None and not d18:
         ops.grad_done(ctx.getw_param)
     # BatchNorm sums of the generate BatchNorm (double accumulators)
@@ -1186,6 +1218,8 @@ def _rfcbam_backward_k1(ctx, du, dgo, dbo):
     P.alpha, P.kappa, P.lambda_, P.dgap = p(alpha), p(kappa), p(lam), p(dgap)
     with ops._Timed(f"ly_rf1_bwd_kernel<{tn}, 2>", 10.0 * mo * c, 3.0 * es1):
         L.check(L.lib().ly_rf1_bwd(ctypes.byref(P), 2, st), "ly_rf1_bwd C")
+    if dgw_fresh64:
+        dgw = ops.f64_round([dgw], [(c,)])[0]
     if tgw is not None and not dgw_defer:
         ops.grad_done(ctx.gen_w_param)
     dbias = None if ops.grad_target(ctx.conv_b_param) is not None else torch.zeros_like(bias)      # BN removes the batch mean: d/dbias = 0

@@ -564,6 +564,23 @@ def small_grad_scratch(target, param):
     return scr
 
 
+def f64_round(scratches, shapes):
+    """fp32 tensors holding the rounded sums of float64 scratches (the route without a gradient sink: the values go back to autograd) — ONE
+    ly_f64_add launch into one zeroed buffer"""
+    assert 0 < len(scratches) <= capi.F64_ADD_MAX
+    sizes = [s_.numel() for s_ in scratches]
+    flat = torch.zeros(sum(sizes), dtype=torch.float32, device=scratches[0].device)
+    t = capi.LyF64AddTable()
+    outs, off = [], 0
+    for j, (scr, n, shp) in enumerate(zip(scratches, sizes, shapes)):
+        t.src[j], t.dst[j], t.n[j] = scr.data_ptr(), flat.data_ptr() + 4 * off, n
+        outs.append(flat[off:off + n].view(shp))
+        off += n
+    t.count = len(scratches)
+    capi.check(capi.lib().ly_f64_add(ctypes.byref(t), capi.stream_ptr()), "ly_f64_add")
+    return outs
+
+
 def flush_small_grads():
     items, _SmallGrads.pending, _SmallGrads.queued = _SmallGrads.pending, [], False
     for i in range(0, len(items), capi.F64_ADD_MAX):

@@ -399,37 +399,38 @@ def step_roofline(args, ms_per_step, step_fn, rows):
     return out
 
 
-def roofline_of(rows, dtype, families=None):
-    dom = rows[0]                                   # fallback: the instrumented kernel with the largest share of the step
-    dom_family = None
-    if families:                                    # dominant kernel = the largest kernel of the family that owns most of the step
-        for fam_name in families:
-            cand = [r for r in rows if family_of(r["kernel"]) == fam_name]
-            if cand and fam_name != "aten":
-                dom, dom_family = cand[0], fam_name
-                break
-    gbs = dom["bytes"] / dom["ms_per_launch"] / 1e6
-    tfs = dom["flops"] / dom["ms_per_launch"] / 1e9
-    vtfs = dom.get("valu_flops", 0.0) / dom["ms_per_launch"] / 1e9
-    hbm_frac = gbs / HBM_PEAK_GBS
+def _fractions(r, dtype):
+    gbs = r["bytes"] / r["ms_per_launch"] / 1e6
+    tfs = r["flops"] / r["ms_per_launch"] / 1e9
+    vtfs = r.get("valu_flops", 0.0) / r["ms_per_launch"] / 1e9
     mfma_peak = BF16_MFMA_PEAK_TFLOPS if dtype == "bf16" else BF16_MFMA_PEAK_TFLOPS / 3.0
-    mfma_frac = tfs / mfma_peak
-    valu_frac = vtfs / VALU_F32_PEAK_TFLOPS
-    # the roof the kernel sits closest to: every fraction = algorithmic work of ONE launch / its mean duration / that unit's peak
-    if mfma_frac >= hbm_frac and mfma_frac >= valu_frac:
+    return gbs, tfs, vtfs, mfma_peak, gbs / HBM_PEAK_GBS, tfs / mfma_peak, vtfs / VALU_F32_PEAK_TFLOPS
+
+
+def roofline_of(rows, dtype, families=None):
+    """`roofline` of the line, SURVEY 8(d): the DOMINANT kernel = the instrumented kernel with the most time per step (rows are sorted by it: a
+    deterministic pick — the "largest kernel of the largest family" of rounds 2-4 flipped between two kernels from run to run), priced against
+    the roof 8(d) names for it: HBM for every bf16-storage kernel; for fp32 storage the larger of the HBM and matrix fractions (deep fp32 blocks
+    are matrix-bound once fused).  `mfma_frac` / `valu_frac` are side fields; `limited_by` = "latency" when no unit is a quarter busy (such a
+    kernel is bound by none of the roofs: occupancy / dependent round trips).  `largest_single_launch` is the same accounting for the longest
+    single launch of the step."""
+    dom = rows[0]
+    dom_family = family_of(dom["kernel"])
+    gbs, tfs, vtfs, mfma_peak, hbm_frac, mfma_frac, valu_frac = _fractions(dom, dtype)
+    if dtype != "bf16" and mfma_frac > hbm_frac:
         roof = dict(bound="mfma", achieved=round(tfs, 2), peak=round(mfma_peak, 1), unit="TFLOP/s", frac=round(mfma_frac, 4),
-                    peak_note="dense bf16 2500 TFLOP/s" + ("" if dtype == "bf16" else " / 3: fp32-grade products = 3 bf16 MFMAs"))
-    elif valu_frac >= hbm_frac:
-        roof = dict(bound="valu", achieved=round(vtfs, 2), peak=VALU_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=round(valu_frac, 4),
-                    peak_note="fp32 vector peak 157.3 TFLOP/s (packed FMA): the kernel's dominant algorithmic work is the RFCBAM generate "
-                              "regeneration (81 MAC per output pixel and channel per pass), which is vector arithmetic by construction")
+                    peak_note="dense bf16 2500 TFLOP/s / 3: fp32-grade products = 3 bf16 MFMAs")
     else:
         roof = dict(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(hbm_frac, 4))
+    roof["limited_by"] = "latency" if max(hbm_frac, mfma_frac, valu_frac) < 0.25 else roof["bound"]
     tr = committed_pmc(dom["kernel"], "pmc_traffic")
     roof["traffic"] = tr["hbm_bytes"] if tr else None
     roof["traffic_source"] = tr["source"] if tr else None
+    roof["traffic_is"] = ("HBM bytes per launch of this kernel from the COMMITTED rocprofv3 --pmc pass named in traffic_source (same command, earlier run): "
+                          "counters cannot be collected inside the driver's timed run") if tr else None
     roof["mfma_busy"] = committed_pmc(dom["kernel"], "pmc_mfma")
     roof["kernel"] = dom["kernel"]
+    roof["kernel_is"] = "the instrumented kernel with the most time per step (launches x mean launch time)"
     roof["kernel_family"] = dom_family
     roof["launches_per_step"] = round(dom["calls_per_step"], 2)
     roof["ms_per_launch"] = round(dom["ms_per_launch"], 5)
@@ -440,6 +441,14 @@ def roofline_of(rows, dtype, families=None):
     roof["hbm_frac"] = round(hbm_frac, 4)
     roof["mfma_frac"] = round(mfma_frac, 4)
     roof["valu_frac"] = round(valu_frac, 4)
+    big = max(rows, key=lambda r: r["ms_per_launch"])
+    g2, t2, v2, _, h2, m2, vf2 = _fractions(big, dtype)
+    tr2 = committed_pmc(big["kernel"], "pmc_traffic")
+    roof["largest_single_launch"] = dict(kernel=big["kernel"], kernel_family=family_of(big["kernel"]), ms_per_launch=round(big["ms_per_launch"], 5),
+                                         launches_per_step=round(big["calls_per_step"], 2), algorithmic_bytes_per_launch=round(big["bytes"]),
+                                         achieved_gbs=round(g2, 1), hbm_frac=round(h2, 4), mfma_frac=round(m2, 4), valu_frac=round(vf2, 4),
+                                         traffic=tr2["hbm_bytes"] if tr2 else None, traffic_source=tr2["source"] if tr2 else None,
+                                         limited_by="latency" if max(h2, m2, vf2) < 0.25 else "hbm")
     return roof
 
 

@@ -249,6 +249,19 @@ extern "C" void ly_set_error(const char* fmt, ...);
     }                                      \
   } while (0)
 
+// hipFuncSetAttribute is per DEVICE: a launcher's "already configured" memo is a bitmask over device ordinals (one process may drive
+// several GPUs: tests, nn.DataParallel-style use), not a process-wide flag
+struct LyDevOnce {
+  unsigned long long mask = 0ull;
+  bool need() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d > 63) return true;
+    if (mask >> d & 1ull) return false;
+    mask |= 1ull << d;
+    return true;
+  }
+};
+
 #define LY_LAUNCH_CHECK()                                         \
   do {                                                            \
     hipError_t e_ = hipGetLastError();                            \

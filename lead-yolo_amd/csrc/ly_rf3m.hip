@@ -392,18 +392,27 @@ static int rm_launch_fwd(const LyRfcbam3Params& P, hipStream_t st) {
   const int lds_x = (int)((RM_XTILE + (size_t)P.C * 4 + 63) / 64 * 64);
   const size_t lds = (size_t)2 * (2 * (RM_GF + 2 * MT) + MT) * 1024 + 2 * MT * 32 * 4 + RM_WAVES * (size_t)lds_x;
   LY_CHECK(lds <= 160 * 1024, "rf3m_fwd: needs %zu B LDS", lds);
+  // development builds (make CXXFLAGS+=-DLY_RM_DEVEL) read LY_RM_PROF / LY_RM_DBG / LY_RM_SDBG: the profiling kernel and the timing-only ablations
+  // (wrong results by construction) are not reachable from the environment in the shipped library
+#ifdef LY_RM_DEVEL
   static const bool prof = getenv("LY_RM_PROF") != nullptr;
   auto k = prof ? ly_rf3m_fwd_kernel<MT, true> : ly_rf3m_fwd_kernel<MT, false>;
-  static bool configured = false;
-  if (!configured) {
+#else
+  auto k = ly_rf3m_fwd_kernel<MT, false>;
+#endif
+  static LyDevOnce once;
+  if (once.need()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     LY_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-    configured = true;
   }
   const long tiles = (long)P.n_img * nrt * nct;
   const long nb = (tiles + RM_WAVES - 1) / RM_WAVES * gy;
   LY_CHECK(nb < (1L << 31), "rf3m_fwd: grid too large");
+#ifdef LY_RM_DEVEL
   static const int dbg = getenv("LY_RM_DBG") ? atoi(getenv("LY_RM_DBG")) : 0;          // development: 1 = no weight copies (wrong results, timing only)
+#else
+  const int dbg = 0;
+#endif
   hipLaunchKernelGGL(k, dim3((unsigned)nb), dim3(RM_THREADS), lds, st, P, nct, nrt, gy, lds_x, dbg);
   LY_LAUNCH_CHECK();
   return 0;
@@ -597,6 +606,9 @@ extern "C" int ly_rf3m_stats(const void* x, int ldx, int n_img, int H, int W, in
   const long tiles = (long)n_img * nrt * nct;
   const size_t lds = (size_t)2 * RM_UNITS * RM_GF * 1024 + RM_WAVES * (size_t)RM_XTILE;
   auto k = ly_rf3m_stats_kernel<0>;
+  static LyDevOnce once;
+  bool need = once.need();
+#ifdef LY_RM_DEVEL
   static const int sdbg = getenv("LY_RM_SDBG") ? atoi(getenv("LY_RM_SDBG")) : 0;     // development: ablations of the loop (timing only)
   switch (sdbg) {
     case 1: k = ly_rf3m_stats_kernel<1>; break;
@@ -606,12 +618,11 @@ extern "C" int ly_rf3m_stats(const void* x, int ldx, int n_img, int H, int W, in
     case 15: k = ly_rf3m_stats_kernel<15>; break;
     default: break;
   }
-  static bool configured = false;
-  if (sdbg) configured = false;
-  if (!configured) {
+  if (sdbg) need = true;
+#endif
+  if (need) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     LY_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-    configured = true;
   }
   hipLaunchKernelGGL(k, dim3((unsigned)((tiles + RM_WAVES - 1) / RM_WAVES)), dim3(RM_THREADS), lds, reinterpret_cast<hipStream_t>(stream),
                      reinterpret_cast<const __bf16*>(x), ldx, n_img, H, W, C, Ho, Wo, s, TH, TW, nct, nrt, wst, mm, part);

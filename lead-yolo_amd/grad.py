@@ -632,41 +632,9 @@ class MlpBlockFn(torch.autograd.Function):
 
 
 # --------------------------------------------------------------------------------------------------
-# CoordAtt: pools and gate are HIP kernels both ways; the [n, h+w, c] -> [n, h+w, mip] -> a_h, a_w MLP acts on
-# pooled vectors only (1/W + 1/H of the map) and runs as torch ops under autograd in training.
+# CoordAtt: ONE autograd node, every step a HIP kernel in both directions (pools, the [n, h+w, c] -> [n, h+w, mip] -> a_h, a_w MLP with
+# bn1's batch statistics, the gate).
 # --------------------------------------------------------------------------------------------------
-class PoolHW(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x):
-        t, ld = ops.rows(x)
-        n, c, h, w = t.shape
-        ctx.shape = (n, c, h, w)
-        ctx.dtype = t.dtype
-        return ops.pool_hw(t, ld, n, h, w, c)
-
-    @staticmethod
-    def backward(ctx, gp):
-        n, c, h, w = ctx.shape
-        return ops.pool_hw_bwd(gp.float().contiguous(), n, h, w, c, dtype=ctx.dtype)
-
-
-class Gate(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, a_h, a_w):
-        t, ld = ops.rows(x)
-        n, c, h, w = t.shape
-        a_h, a_w = a_h.float().contiguous(), a_w.float().contiguous()
-        ctx.save_for_backward(t, a_h, a_w)
-        return ops.coordatt_gate(t, ld, n, h, w, c, a_h, a_w)
-
-    @staticmethod
-    def backward(ctx, dout):
-        t, a_h, a_w = ctx.saved_tensors
-        xr, ld = ops.rows(t)
-        n, c, h, w = xr.shape
-        return ops.coordatt_gate_bwd(_rows_dense(dout if dout.dtype == xr.dtype else dout.to(xr.dtype)), xr, ld, n, h, w, c, a_h, a_w)
-
-
 class CoordAttFn(torch.autograd.Function):
     """The whole CoordAtt (models/common.py:1595-1609) as ONE autograd node: pools -> conv1 -> bn1 (batch statistics) -> h_swish ->
     conv_h / conv_w -> sigmoid -> gate.  Forward = the inference kernels plus the statistics pass (6 launches); backward = gate
@@ -744,16 +712,8 @@ def coordatt_train(mod, x):
     params = (mod.conv1.weight, mod.conv1.bias, mod.bn1.weight, mod.bn1.bias, mod.conv_h.weight, mod.conv_h.bias, mod.conv_w.weight, mod.conv_w.bias)
     if mod.mip in (8, 16) and c <= 512 and all(p is not None and p.dtype == torch.float32 for p in params):
         return CoordAttFn.apply(mod, x, *params)
-    import torch.nn.functional as F                          # other widths: the same arithmetic as torch ops on the pooled vectors
-    pool = PoolHW.apply(x)                                                   # [n, h+w, c]
-    y = F.linear(pool, mod.conv1.weight.view(mod.mip, c), mod.conv1.bias)    # [n, h+w, mip]
-    bn = mod.bn1
-    y = F.batch_norm(y.reshape(-1, mod.mip), bn.running_mean, bn.running_var, bn.weight, bn.bias, True, bn.momentum, bn.eps)
-    bn.num_batches_tracked += 1
-    y = (y * F.relu6(y + 3.0) / 6.0).view(n, h + w, mod.mip)
-    a_h = torch.sigmoid(F.linear(y[:, :h], mod.conv_h.weight.view(c, mod.mip), mod.conv_h.bias))
-    a_w = torch.sigmoid(F.linear(y[:, h:], mod.conv_w.weight.view(c, mod.mip), mod.conv_w.bias))
-    return Gate.apply(x, a_h, a_w)
+    raise NotImplementedError(f"CoordAtt training is built for mip = max(8, c // 32) in (8, 16) and c <= 512 with float32 parameters (got mip={mod.mip}, "
+                              f"c={c}): ly_coordatt_mlp_bwd has no instantiation for other widths, and there is no ATen fallback on the hot path")
 
 
 # --------------------------------------------------------------------------------------------------

@@ -596,7 +596,7 @@ class RFCBAMConv(nn.Module):
             if ops.rf3c_ok(c, self.stride):
                 d["wq_c"] = pack.rfcbam_gen_weights_c(gw, gs, gb)
                 d["wp_c"] = self._wp_c(planes)
-            if planes == 1 and c % 32 == 0 and o % 64 == 0 and RF3M:
+            if planes == 1 and RF3M and ops.rf3m_ok(torch.bfloat16, c, o, self.stride):     # (stride 1 / 2 only: other strides keep the lane = pixel kernels)
                 d["wm_stats"] = pack.rf3m_stream(gw, gs, gb, pool_stride=self.stride)          # csrc/ly_rf3m.hip: generate on the matrix cores
                 d["wm"] = pack.rf3m_stream(gw, gs, gb, cw.weight, 4 if o % 128 == 0 else 2)
             return d

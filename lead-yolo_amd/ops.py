@@ -345,7 +345,7 @@ CONCURRENT_PARTS = 1       # graph.GraphedForward runs the batch as this many su
 def rf3m_ok(x, c, o, s, n=None, ho=None, wo=None):
     """`generate` on the matrix cores (csrc/ly_rf3m.hip): bf16 storage, C % 32 == 0, O % 64 == 0, stride 1 / 2 — and, when the problem size
     is given, enough wave tiles to fill the chip (RF3M_MIN_UNITS)"""
-    if not (x.dtype == torch.bfloat16 and c % 32 == 0 and o % 64 == 0 and s in (1, 2)):
+    if not ((x if isinstance(x, torch.dtype) else x.dtype) == torch.bfloat16 and c % 32 == 0 and o % 64 == 0 and s in (1, 2)):
         return False
     if n is None:
         return True
@@ -538,29 +538,47 @@ def detect_head_bwd(dp, n, h, w, na, no, du, ldu, dbias):
 # bit), and ONE ly_f64_add launch, queued on the autograd engine for the end of the pass, rounds every sum into its fp32 `.grad` storage.
 class _SmallGrads:
     pending = []            # (scratch, flat fp32 target, parameter)
-    queued = False
+    task = -1               # autograd graph-task id the pending entries (and the queued end-of-pass callback) belong to
 
 
 DETERMINISTIC_SMALL_GRADS = True
 
 
+def _graph_task():
+    task = getattr(torch._C, "_current_graph_task_id", None)
+    return task() if task is not None else -1
+
+
 def small_grads_ok():
     """inside a backward pass of the autograd engine (where the end-of-pass callback can be queued)?"""
-    task = getattr(torch._C, "_current_graph_task_id", None)
-    return DETERMINISTIC_SMALL_GRADS and task is not None and task() != -1
+    return DETERMINISTIC_SMALL_GRADS and _graph_task() != -1
+
+
+def small_grads_reset():
+    """drop whatever an aborted backward pass left behind (the engine discards a graph task's final callbacks when a backward raises:
+    the entries would otherwise wait for a flush that never comes)"""
+    _SmallGrads.pending, _SmallGrads.task = [], -1
 
 
 def small_grad_scratch(target, param):
     """zeroed float64 stand-in for the fp32 gradient storage `target` (contiguous) of `param`; added into it — and `grad_done(param)` called —
-    when the running backward pass ends"""
+    when the running backward pass ends.  The pending list is keyed on the engine's graph-task id: entries of ANOTHER pass are leftovers of a
+    backward that raised after taking a scratch (its callback was dropped with it) — they are discarded and the callback queued anew.  A
+    parameter deferred twice in one pass (a module applied twice, shared weights) reuses ONE scratch: ly_f64_add's table then holds one
+    entry per destination (two entries with the same target would race)."""
+    task = _graph_task()
+    if task != _SmallGrads.task:
+        _SmallGrads.pending, _SmallGrads.task = [], task
+        torch.autograd.Variable._execution_engine.queue_callback(flush_small_grads)
+    tgt = target.view(-1)
+    for scr, t, prm in _SmallGrads.pending:
+        if t.data_ptr() == tgt.data_ptr() and t.numel() == tgt.numel():
+            return scr
     scr = zeros_f64(target.numel(), target.device)
     if param is not None and not any(prm is param for _, _, prm in _SmallGrads.pending):
         for fn in GRAD_DEFER_LISTENERS:
             fn(param)
-    _SmallGrads.pending.append((scr, target.view(-1), param))
-    if not _SmallGrads.queued:
-        torch.autograd.Variable._execution_engine.queue_callback(flush_small_grads)
-        _SmallGrads.queued = True
+    _SmallGrads.pending.append((scr, tgt, param))
     return scr
 
 
@@ -582,7 +600,7 @@ def f64_round(scratches, shapes):
 
 
 def flush_small_grads():
-    items, _SmallGrads.pending, _SmallGrads.queued = _SmallGrads.pending, [], False
+    items, _SmallGrads.pending, _SmallGrads.task = _SmallGrads.pending, [], -1
     for i in range(0, len(items), capi.F64_ADD_MAX):
         chunk = items[i:i + capi.F64_ADD_MAX]
         t = capi.LyF64AddTable()
@@ -640,6 +658,7 @@ _POOL = _StatsPool()
 
 
 def stats_pool_begin(device):
+    small_grads_reset()                      # (a step starts outside any backward pass: whatever is pending belongs to an aborted one)
     p = _POOL
     if p.buf is None or p.buf.device != device or p.buf.numel() < p.need:
         p.buf = torch.zeros(max(p.need, 1), dtype=torch.float32, device=device) if p.need else None

@@ -190,6 +190,7 @@ class GraphedTrainStep:
                     train_step(model, compute_loss, optimizer, self.imgs, self.targets, **args)
                 finally:
                     traced, pack.PLAN.trace = pack.PLAN.trace, None
+                    ops.small_grads_reset()           # (a warm-up step that raised must not leave deferred gradients pending)
         cur.wait_stream(side)
         torch.cuda.synchronize(imgs.device)
         self.graph = torch.cuda.CUDAGraph()
@@ -306,6 +307,7 @@ class GraphedTrainStep:
     def __call__(self, imgs=None, targets=None):
         from . import capi, pack
         self._load(imgs, targets)
+        _set_deferred_average(self.optimizer, self.reducer)    # an eager train_step in between may have reset the (grad_scale, defer_average) pair
         self.optimizer._sync_hyper()                       # learning-rate schedule -> device (only when it changed)
         if self.opt_graph is None:
             self.graph.replay()

@@ -40,6 +40,23 @@ int ly_mlpblock_fwd(const void* x /*T*/, void* y /*T*/, int n_img, int H, int W,
  * patches), the one-shot kernel stopped after the partial conv otherwise.  Returns 0 when launched, 1 for a channel count the MLPBlock
  * kernels are not built for (the caller can use a copy + ly_conv3x3_fwd), -1 on error.  x and z dense [n*H*W, C], not aliased.            */
 int ly_mlpblock_pconv(const void* x /*T*/, void* z /*T*/, int n_img, int H, int W, int C, const void* wp, int dtype, void* stream);
+/* FUSED MLPBlock BACKWARD, bf16 storage (autograd of MLPBlock.forward + Partial_conv3.forward_split_cat, models/common.py:1432-1437, 1478-1482,
+ * under train.py:327 `scaler.scale(loss).backward()`; the hidden BatchNorm in train mode).  With z = [pconv3x3(x[:, :C/4]) | x[:, C/4:]],
+ * u = W1 z, v = a u + b, h = relu(v), y = x + W2 h  and  dy = d(loss)/dy:
+ *   pass 1:  stats[stripe][0:2C] += sum dv, stats[stripe][2C:4C] += sum dv u  with dv = (W2^T dy) [v > 0]   (LY_STATS_STRIPES zeroed double copies:
+ *            the `sums` argument of ly_bn_bwd_coeffs, which turns them into dgamma, dbeta and alpha / kappa / lambda)
+ *   pass 2:  g = W1^T du  with du = alpha dv + kappa + lambda u  (dense [n*H*W, C]: the gradient with respect to z),
+ *            dw1 [2C, C] += sum du (x) z,  dw2 [C, 2C] += sum dy (x) h   (mlp.0.weight / mlp.3.weight gradients, ADDED to; per-block partial tiles go
+ *            to `slab` — at least ly_mlpblock_bwd_slab_floats(C) floats, 16-byte aligned — and are folded in block order: bit-reproducible)
+ * Nothing 2C wide touches HBM.  wp / w1 as for ly_mlpblock_fwd (planes = 1); w2t = frag-packed mlp.3.weight^T [2C (rows padded to
+ * 16*hidden_tiles), C]; w1t = frag-packed mlp.0.weight^T [C, 2C]; a, b (and alpha, kappa, lambda) have 2C entries.  The caller finishes with
+ * dx = dy + [pconv^T(g[:, :C/4]) | g[:, C/4:]] (ly_mlpblock_pconv_add) and the partial conv's weight gradient (ly_wgrad on g, x).
+ * Built for C in {16, 24, 40} (ly_mlpblock_bwd_ok); x, dy, g dense [n*H*W, C], 16-byte aligned.                                                  */
+int ly_mlpblock_bwd_ok(int C, int dtype);
+long ly_mlpblock_bwd_slab_floats(int C);
+int ly_mlpblock_bwd(const void* x /*T*/, const void* dy /*T*/, void* g /*T*/, int n_img, int H, int W, int C, const void* wp, const void* w1,
+                    const void* w2t, const void* w1t, const float* a, const float* b, const float* alpha, const float* kappa, const float* lambda,
+                    double* stats, float* slab, long slab_floats, float* dw1, float* dw2, int pass, int dtype, void* stream);
 /* hidden (2C) channel tiles of 16, padded to an even count */
 int ly_mlpblock_hidden_tiles(int C);
 

@@ -100,6 +100,9 @@ SIGNATURES = {
     "ly_abi_version": [],
     "ly_mlpblock_fwd": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P],
     "ly_mlpblock_hidden_tiles": [_I],
+    "ly_mlpblock_bwd_ok": [_I, _I],
+    "ly_mlpblock_bwd_slab_floats": [_I],                 # (returns long: restype set in lib())
+    "ly_mlpblock_bwd": [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _I, _I, _P],
     "ly_gemm_fwd": [ctypes.POINTER(LyGemmParams), _P],
     "ly_conv3x3_fwd": [ctypes.POINTER(LyConv3Params), _P],
     "ly_pool_hw": [_P, _I, _I, _I, _I, _I, _P, _I, _P],
@@ -191,6 +194,7 @@ def lib():
             fn = getattr(L, name)        # AttributeError if the symbol is not exported
             fn.restype = _I
             fn.argtypes = args
+        L.ly_mlpblock_bwd_slab_floats.restype = ctypes.c_long
         _lib = L
     return _lib
 

@@ -1,0 +1,52 @@
+// Fused MLPBlock backward: C ABI + the C = 16 / 24 / 40 instantiations (kernels: ly_mlpblock_bwd.hpp).
+#include "ly_mlpblock_bwd.hpp"
+
+// 1 when ly_mlpblock_bwd is built for (C, dtype): bf16 storage, C in {16, 24, 40}
+extern "C" int ly_mlpblock_bwd_ok(int C, int dtype) { return dtype == LY_BF16 && (C == 16 || C == 24 || C == 40); }
+
+// floats of slab workspace pass 2 may need at most for channel count C (256 CUs x 8 resident blocks at most)
+extern "C" long ly_mlpblock_bwd_slab_floats(int C) {
+  switch (C) {
+    case 16: return 2048L * MlpBwdGeom<16, 2>::SLAB;
+    case 24: return 2048L * MlpBwdGeom<24, 2>::SLAB;
+    case 40: return 2048L * MlpBwdGeom<40, 2>::SLAB;
+    default: return 0;
+  }
+}
+
+template <int C, int HT>
+static int mlp_bwd_pass(LyMlpBwdArgs P, int pass, long slab_floats, float* dw1, float* dw2, hipStream_t st) {
+  if (pass == 1) return dispatch_mlp_bwd<C, HT, 1>(P, 0, nullptr, st);
+  int blocks = 0;
+  const int rc = dispatch_mlp_bwd<C, HT, 2>(P, slab_floats, &blocks, st);
+  if (rc) return rc;
+  return launch_mlp_bwd_combine<C, 2>(P.slab, blocks, dw1, dw2, st);
+}
+
+extern "C" int ly_mlpblock_bwd(const void* x, const void* dy, void* g, int n_img, int H, int W, int C, const void* wp, const void* w1,
+                               const void* w2t, const void* w1t, const float* a, const float* b, const float* alpha, const float* kappa,
+                               const float* lambda, double* stats, float* slab, long slab_floats, float* dw1, float* dw2, int pass, int dtype,
+                               void* stream) {
+  LY_CHECK(dtype == LY_BF16, "mlpblock_bwd: bf16 storage only (dtype %d)", dtype);
+  LY_CHECK(pass == 1 || pass == 2, "mlpblock_bwd: pass must be 1 (BatchNorm sums) or 2 (g, weight gradients)");
+  LY_CHECK(x && dy && wp && w1 && w2t && a && b && n_img > 0 && H > 0 && W > 0, "mlpblock_bwd: bad arguments");
+  LY_CHECK(pass == 1 ? stats != nullptr : (g && w1t && alpha && kappa && lambda && slab && dw1 && dw2), "mlpblock_bwd: pass %d misses a pointer", pass);
+  LY_CHECK(((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)g & 15) == 0 && ((uintptr_t)slab & 15) == 0, "mlpblock_bwd: x / dy / g / slab must be 16-byte aligned");
+  const long M = (long)n_img * H * W;
+  LY_CHECK(M < (1L << 24), "mlpblock_bwd: M=%ld pixels exceeds the 2^24 limit of the fast index path", M);
+  LyMlpBwdArgs P;
+  P.x = reinterpret_cast<const __bf16*>(x); P.dy = reinterpret_cast<const __bf16*>(dy); P.g = reinterpret_cast<__bf16*>(g);
+  P.M = M; P.H = H; P.W = W; P.n_img = n_img; P.ntiles = 0;
+  P.wp = reinterpret_cast<const uint4*>(wp); P.w1 = reinterpret_cast<const uint4*>(w1);
+  P.w2t = reinterpret_cast<const uint4*>(w2t); P.w1t = reinterpret_cast<const uint4*>(w1t);
+  P.a = a; P.b = b; P.alpha = alpha; P.kappa = kappa; P.lambda = lambda; P.stats = stats; P.slab = slab;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  switch (C) {
+    case 16: return mlp_bwd_pass<16, 2>(P, pass, slab_floats, dw1, dw2, st);
+    case 24: return mlp_bwd_pass<24, 2>(P, pass, slab_floats, dw1, dw2, st);
+    case 40: return mlp_bwd_pass<40, 2>(P, pass, slab_floats, dw1, dw2, st);
+    default:
+      ly_set_error("mlpblock_bwd: unsupported channel count C=%d (built for 16/24/40)", C);
+      return -1;
+  }
+}

@@ -1,0 +1,623 @@
+#pragma once
+// Fused FasterNet MLPBlock BACKWARD (training), gfx950, bf16 storage, fp32 accumulation.
+//
+//   forward (models/common.py:1432-1437, 1478-1482):  z = [pconv3x3(x[:, :C/4]) | x[:, C/4:]],  u = W1 z,  v = a u + b (BatchNorm with the
+//   BATCH statistics),  h = relu(v),  y = x + W2 h.      What autograd derives for it (train.py:327 `scaler.scale(loss).backward()`):
+//        dh = W2^T dy,   dv = dh [v > 0],   s1 = sum dv,  s2 = sum dv u   (-> dgamma, dbeta and the coefficients of du)
+//        du = alpha dv + kappa + lambda u,   g = W1^T du,   dW1 = sum du (x) z,   dW2 = sum dy (x) h,   dx = dy + [pconv^T(g[:C/4]) | g[C/4:]]
+//
+// The unfused path (round 2-4) ran this as eleven launches over 2C-wide tensors in HBM — z, u, relu(bn(u)), dh, the reduce pass, the apply
+// pass, the g GEMM, two weight-gradient launches + their combines — 780 us for the 160 x 160 x 24 stage at bs = 64 where the fused forward
+// takes 85.  Here the hidden tensors never leave the chip, exactly as in ly_mlpblock_fwd: TWO passes over (x, dy), split by the one global
+// dependency (the BatchNorm sums):
+//   PASS 1  per pixel tile: z (partial conv from the LDS halo image), u = W1 z and dh = W2^T dy as two MFMA chains with the SAME accumulator
+//           layout (lane = pixel, 4 hidden channels), dv and the two sums in registers; one double atomic per channel and block at the end.
+//   PASS 2  the same up to dv; du and h in registers; g += W1^T du straight from the accumulators (two fp32 tiles ARE the B operand of the
+//           next k-step, ly_tile.hpp); du and h also go — as bf16, 8 bytes per lane — into two wave-private LDS tiles [pixel][hidden], from
+//           which the wave contracts dW1 += du^T z and dW2^T += h^T dy over ITS OWN 32 pixels through transposed reads (ds_read_b64_tr_b16:
+//           the contraction index is the pixel).  Weight-gradient accumulators stay in registers over the block's whole tile walk; the four
+//           waves meet in LDS once, the block writes ONE slab, ly_mlpblock_bwd_combine folds the slabs in block order (bit-reproducible).
+// HBM traffic: pass 1 reads x, dy; pass 2 reads x, dy and writes g — against ~17 map-sized reads / writes before.
+//
+// Tiling as the forward: T2D (W % 16 == 0): 4*NT x 16 pixel patches, halo frame with zeros staged for out-of-image taps, the next patch's raw
+// pixels in flight (registers) during the arithmetic; flattened runs of 64*NT pixels otherwise.  WLDS: all weight fragments of the four
+// contractions resident in LDS (C <= 40); else streamed from L2 through a register ring (ly_mlpblock.hpp).
+#include "ly_mlpblock.hpp"
+
+typedef short mb_s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x4 mb_tr(const char* p) {
+  typedef __attribute__((address_space(3))) mb_s16x4 lds_s16x4;
+  return __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p));
+}
+
+struct LyMlpBwdArgs {
+  const __bf16* x;
+  const __bf16* dy;
+  __bf16* g;                     // pass 2: d(loss)/dz, dense [M, C]
+  long M;
+  int H, W, n_img, ntiles;
+  const uint4 *wp, *w1, *w2t, *w1t;
+  const float *a, *b;            // hidden BatchNorm as v = a u + b (batch statistics), 2C entries
+  const float *alpha, *kappa, *lambda;   // pass 2: du = alpha dv + kappa + lambda u
+  double* stats;                 // pass 1: striped [LY_STATS_STRIPES][2 * 2C]: sum dv | sum dv u
+  float* slab;                   // pass 2: [gridDim.x][MlpBwdGeom::SLAB] raw accumulator tiles
+};
+
+template <int C, int NT>
+struct MlpBwdGeom {
+  using Gm = MlpGeom<C>;
+  static constexpr int HTR = 2 * C / 16;                   // real hidden tiles (2C is a multiple of 16)
+  static constexpr int BP = 64 * NT;
+  static constexpr int RSD = 2 * 16 * Gm::HTP + 16;        // du / h tile row stride (bytes)
+  static constexpr int NACC = HTR * Gm::C16;               // accumulator tiles per weight gradient and wave
+  static constexpr int SLAB = 2 * NACC * 256;              // floats per block: [dW1 | dW2^T][t][ct][lane][4]
+  static constexpr int NFP = Gm::PT * Gm::SP, NF1 = Gm::HTP * Gm::S1, NF1T = Gm::C16 * Gm::S2;
+  static constexpr int NFW = NFP + 2 * NF1 + NF1T;         // fragments of Wp, W1, W2^T, W1^T
+};
+
+template <int C, int NT, int HT, bool T2D, bool WLDS, int PASS, int D>
+__device__ __forceinline__ void ly_mlp_bwd_body(const LyMlpBwdArgs& P) {
+  using Gm = MlpGeom<C>;
+  using Bg = MlpBwdGeom<C, NT>;
+  using T = __bf16;
+  typedef ly_u32x4 RV;
+  typedef ly_u32x2 R4;
+  constexpr int VW = 8;
+  constexpr int CQ = Gm::CQ, G = Gm::G, SP = Gm::SP, PT = Gm::PT, C16 = Gm::C16, KP = Gm::KP, S1 = Gm::S1;
+  constexpr int RS = Gm::RS, RSP = Gm::RSP, HTP = Gm::HTP, S2 = Gm::S2;
+  constexpr int HTR = Bg::HTR, BP = Bg::BP, RSD = Bg::RSD, TH = 4 * NT;
+  constexpr int NFP = Bg::NFP, NF1 = Bg::NF1, NF1T = Bg::NF1T;
+  static_assert(HTP % HT == 0 && HT % 2 == 0 && C % VW == 0 && NT % 2 == 0, "geometry");
+  static_assert(WLDS || HTR == HTP, "ring variant: no padded hidden tile");
+  static_assert(WLDS == (D == 0), "LDS-resident weights need no ring");
+  const int H = P.H, W = P.W;
+  const long M = P.M;
+  const int BPH = T2D ? (TH + 2) * 18 : BP + 2 * W + 2;
+
+  extern __shared__ f32x4 ly_smem4[];
+  char* const wl = reinterpret_cast<char*>(ly_smem4);
+  char* const xs = wl + (WLDS ? Bg::NFW * 1024 : 0);
+  char* const dys = xs + BP * RS;
+  char* const ps = dys + BP * RS;
+  char* const dus = ps + (BPH * RSP + 15) / 16 * 16;       // pass 2 only
+  char* const hs = dus + BP * RSD;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lq = lane >> 4;
+  const f32x4 zero = ly_zero4();
+  const T* const x = P.x;
+  const T* const dy = P.dy;
+
+  // ---- weights: LDS once (WLDS) or a register ring over the per-tile fragment sequence -------------------------------------------
+  if constexpr (WLDS) {
+    for (int i = tid; i < NFP * 64; i += LY_THREADS) reinterpret_cast<uint4*>(wl)[i] = P.wp[i];
+    for (int i = tid; i < NF1 * 64; i += LY_THREADS) reinterpret_cast<uint4*>(wl)[NFP * 64 + i] = P.w1[i];
+    for (int i = tid; i < NF1 * 64; i += LY_THREADS) reinterpret_cast<uint4*>(wl)[(NFP + NF1) * 64 + i] = P.w2t[i];
+    if constexpr (PASS == 2)
+      for (int i = tid; i < NF1T * 64; i += LY_THREADS) reinterpret_cast<uint4*>(wl)[(NFP + 2 * NF1) * 64 + i] = P.w1t[i];
+  }
+  // per-tile fragment sequence (the order of use): Wp (k-step major) | per hidden chunk: W1, W2^T (k-step major), W1^T (pair major)
+  constexpr int FP = SP * PT, F1 = S1 * HT, F3 = PASS == 2 ? (HT / 2) * C16 : 0, FQ = 2 * F1 + F3, NFRAG = FP + (HTP / HT) * FQ;
+  auto wseq = [&](int g) -> LyWF<1> {
+    if (g < FP) return ly_wfragp<1>(P.wp, (g % PT) * SP + g / PT, lane);
+    g -= FP;
+    const int chunk = g / FQ, r = g - chunk * FQ;
+    if (r < F1) return ly_wfragp<1>(P.w1, (chunk * HT + r % HT) * S1 + r / HT, lane);
+    if (r < 2 * F1) return ly_wfragp<1>(P.w2t, (chunk * HT + (r - F1) % HT) * S1 + (r - F1) / HT, lane);
+    const int r2 = r - 2 * F1;
+    return ly_wfragp<1>(P.w1t, (r2 % C16) * S2 + chunk * (HT / 2) + r2 / C16, lane);
+  };
+  auto wlds = [&](int fi) -> LyWF<1> {
+    LyWF<1> f;
+    f.hi = *reinterpret_cast<const bf16x8*>(wl + (fi * 64 + lane) * 16);
+    return f;
+  };
+  LyWF<1> ring[D > 0 ? D : 1];
+
+  // ---- tile geometry ------------------------------------------------------------------------------------------------------------
+  const int tw = T2D ? (W >> 4) : 1, th = T2D ? (H + TH - 1) / TH : 1;
+  long img0 = 0, p0 = 0;
+  int h0 = 0, w0 = 0;
+  auto decode = [&](int tile, long& i0, int& hh0, int& ww0, long& q0) {
+    if constexpr (T2D) {
+      int b = tile;
+      const int tx = b % tw; b /= tw;
+      const int ty = b % th;
+      i0 = (long)(b / th) * H * W;
+      hh0 = ty * TH; ww0 = tx * 16;
+      q0 = 0;
+    } else {
+      i0 = 0; hh0 = 0; ww0 = 0;
+      q0 = (long)tile * BP;
+    }
+  };
+
+  // ---- staging: T2D = register prefetch of the next patch (x tile, x halo, dy tile), committed after the arithmetic ----------------
+  constexpr int TVN = BP * (KP / VW), NVT = T2D ? (TVN + LY_THREADS - 1) / LY_THREADS : 1;
+  constexpr int HVN = T2D ? (TH + 2) * 18 * G : 1, NVH = T2D ? (HVN + LY_THREADS - 1) / LY_THREADS : 1;
+  RV tv[NVT], dv_[NVT];
+  R4 hv[NVH];
+  bool tok[NVT], hok[NVH];
+  auto issue = [&](int tile) {
+    long i0, q0; int hh0, ww0;
+    decode(tile, i0, hh0, ww0, q0);
+#pragma unroll
+    for (int e = 0; e < NVT; ++e) {
+      const int idx = tid + e * LY_THREADS;
+      const int pix = idx / (KP / VW), c4 = idx - pix * (KP / VW);
+      const int r = pix >> 4;
+      tok[e] = idx < TVN && hh0 + r < H && c4 * VW < C;
+      const long off = tok[e] ? (i0 + (long)(hh0 + r) * W + ww0 + (pix & 15)) * C + c4 * VW : 0;
+      tv[e] = ly_ldrv<T>(x + off);
+      dv_[e] = ly_ldrv<T>(dy + off);
+    }
+#pragma unroll
+    for (int e = 0; e < NVH; ++e) {
+      const int idx = tid + e * LY_THREADS;
+      const int hp = idx / G, c4 = idx - hp * G;
+      const int hr = hp / 18, hc = hp - hr * 18;
+      const int hh = hh0 - 1 + hr, ww = ww0 - 1 + hc;
+      hok[e] = idx < HVN && hh >= 0 && hh < H && ww >= 0 && ww < W;
+      hv[e] = ly_ldr4<T>(hok[e] ? x + (i0 + (long)hh * W + ww) * C + c4 * 4 : x);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int e = 0; e < NVT; ++e) {
+      const int idx = tid + e * LY_THREADS;
+      const int pix = idx / (KP / VW), c4 = idx - pix * (KP / VW);
+      RV v = tv[e], d = dv_[e];
+      if (!tok[e]) { ly_zero_raw(v); ly_zero_raw(d); }
+      if (idx < TVN) {
+        *reinterpret_cast<RV*>(xs + pix * RS + 2 * VW * c4) = v;
+        *reinterpret_cast<RV*>(dys + pix * RS + 2 * VW * c4) = d;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < NVH; ++e) {
+      const int idx = tid + e * LY_THREADS;
+      const int hp = idx / G, c4 = idx - hp * G;
+      R4 v = hv[e];
+      if (!hok[e]) ly_zero_raw(v);
+      if (idx < HVN) *reinterpret_cast<R4*>(ps + hp * RSP + 8 * c4) = v;
+    }
+  };
+  // flattened runs: direct staging (the halo length depends on W)
+  auto stage_flat = [&](int tile) {
+    const long q0 = (long)tile * BP;
+    ly_stage_raw<4, RV>(BP * (KP / VW), tid, x,
+        [&](int idx) -> const void* {
+          const int pix = idx / (KP / VW), c4 = idx - pix * (KP / VW);
+          const long gp = q0 + pix;
+          return (gp < M && c4 * VW < C) ? x + gp * C + c4 * VW : nullptr;
+        },
+        [&](int idx, RV v) {
+          const int pix = idx / (KP / VW), c4 = idx - pix * (KP / VW);
+          *reinterpret_cast<RV*>(xs + pix * RS + 2 * VW * c4) = v;
+        });
+    ly_stage_raw<4, RV>(BP * (KP / VW), tid, dy,
+        [&](int idx) -> const void* {
+          const int pix = idx / (KP / VW), c4 = idx - pix * (KP / VW);
+          const long gp = q0 + pix;
+          return (gp < M && c4 * VW < C) ? dy + gp * C + c4 * VW : nullptr;
+        },
+        [&](int idx, RV v) {
+          const int pix = idx / (KP / VW), c4 = idx - pix * (KP / VW);
+          *reinterpret_cast<RV*>(dys + pix * RS + 2 * VW * c4) = v;
+        });
+    ly_stage_raw<4, R4>(BPH * G, tid, x,
+        [&](int idx) -> const void* {
+          const int hp = idx / G, c4 = idx - hp * G;
+          const long gp = q0 - W - 1 + hp;
+          return (gp >= 0 && gp < M) ? x + gp * C + c4 * 4 : nullptr;
+        },
+        [&](int idx, R4 v) {
+          const int hp = idx / G, c4 = idx - hp * G;
+          *reinterpret_cast<R4*>(ps + hp * RSP + 8 * c4) = v;
+        });
+  };
+
+  // ---- block-lifetime accumulators ---------------------------------------------------------------------------------------------------
+  f32x4 st1[PASS == 1 ? HTR : 1], st2[PASS == 1 ? HTR : 1];
+  f32x4 aw1[PASS == 2 ? Bg::NACC : 1], aw2[PASS == 2 ? Bg::NACC : 1];
+  if constexpr (PASS == 1) {
+#pragma unroll
+    for (int t = 0; t < HTR; ++t) { st1[t] = zero; st2[t] = zero; }
+  } else {
+#pragma unroll
+    for (int i = 0; i < Bg::NACC; ++i) { aw1[i] = zero; aw2[i] = zero; }
+  }
+
+  int tile = blockIdx.x;
+  if (tile < P.ntiles) {
+    if constexpr (T2D) {
+      issue(tile);
+      commit();
+    }
+  }
+  if constexpr (WLDS || T2D) __syncthreads();
+  const int pixbase = wave * (16 * NT);
+  const bf16x4 z4 = __builtin_bit_cast(bf16x4, make_uint2(0u, 0u));
+
+  for (; tile < P.ntiles; tile += gridDim.x) {
+    if constexpr (T2D) {
+      const int nxt = tile + (int)gridDim.x < P.ntiles ? tile + (int)gridDim.x : tile;      // (the last patch re-requests itself: straight-line loads)
+      issue(nxt);
+    } else {
+      stage_flat(tile);
+      __syncthreads();
+    }
+    decode(tile, img0, h0, w0, p0);
+    auto gpix = [&](int pix) -> long {
+      if constexpr (T2D) {
+        const int r = pix >> 4;
+        return (h0 + r < H) ? img0 + (long)(h0 + r) * W + w0 + (pix & 15) : -1;
+      } else {
+        const long gp = p0 + pix;
+        return gp < M ? gp : -1;
+      }
+    };
+    int g = 0;                   // fragments consumed so far in this tile (a constant at every use after unrolling)
+    if constexpr (D > 0) {
+#pragma unroll
+      for (int i = 0; i < D; ++i)
+        if (i < NFRAG) ring[i] = wseq(i);
+    }
+    auto wnext = [&](int fi) -> LyWF<1> {           // fi: index in the LDS image (WLDS); the ring serves the sequence in order
+      if constexpr (WLDS) return wlds(fi);
+      else return ring[g % D];
+    };
+    auto wrefill = [&]() {
+      if constexpr (D > 0) {
+        if (g + D < NFRAG) ring[g % D] = wseq(g + D);
+        __builtin_amdgcn_sched_barrier(0x786);
+      }
+      ++g;
+    };
+
+    // ---- 1. z = partial 3x3 conv into the tile (the forward's code) ---------------------------------------------------------------
+    {
+      uint32_t tmask[NT];
+      int pbase[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int pix = pixbase + 16 * n + li;
+        if constexpr (T2D) {
+          tmask[n] = 0x1ffu;
+          pbase[n] = ((pix >> 4) * 18 + (pix & 15)) * RSP;
+        } else {
+          const long gp = p0 + pix;
+          int h_, w_;
+          ly_pix_hw(gp < M ? gp : 0, H, W, h_, w_);
+          tmask[n] = ly_tapmask(h_, w_, H, W, gp < M);
+          pbase[n] = pix * RSP;
+        }
+      }
+      const int rowpitch = T2D ? 18 : W;
+      f32x4 accp[PT][NT];
+#pragma unroll
+      for (int t = 0; t < PT; ++t)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) accp[t][n] = zero;
+#pragma unroll
+      for (int s = 0; s < SP; ++s) {
+        int off[2], tap[2];
+        bool gv[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int gq = 8 * s + 4 * h + lq;
+          gv[h] = gq < 9 * G;
+          tap[h] = gv[h] ? gq / G : 0;
+          const int cq4 = gv[h] ? gq - tap[h] * G : 0;
+          const int ty = tap[h] / 3, tx = tap[h] - 3 * ty;
+          off[h] = (ty * rowpitch + tx) * RSP + 8 * cq4;
+        }
+        bf16x8 xh[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          bf16x4 ph[2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const bool ok = gv[h] && (T2D || ((tmask[n] >> tap[h]) & 1u));
+            const bf16x4 a = *reinterpret_cast<const bf16x4*>(ps + pbase[n] + off[h]);
+            ph[h] = ok ? a : z4;
+          }
+          xh[n] = ly_cat8(ph[0], ph[1]);
+        }
+#pragma unroll
+        for (int t = 0; t < PT; ++t) {
+          const LyWF<1> wf = wnext(t * SP + s);
+#pragma unroll
+          for (int n = 0; n < NT; ++n) accp[t][n] = ly_mfma_bf16(wf.hi, xh[n], accp[t][n]);
+          wrefill();
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < PT; ++t)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const bf16x4 h = ly_cvtb4(accp[t][n]);
+          const int c = 16 * t + 4 * lq;
+          const int rb = (pixbase + 16 * n + li) * RS + 2 * c;
+          if (c < CQ) *reinterpret_cast<bf16x2*>(xs + rb) = __builtin_shufflevector(h, h, 0, 1);
+          if (c + 2 < CQ) *reinterpret_cast<bf16x2*>(xs + rb + 4) = __builtin_shufflevector(h, h, 2, 3);
+        }
+    }
+
+    // ---- 2. hidden chunks: u = W1 z, dh = W2^T dy, dv / du / h in registers, g += W1^T du -----------------------------------------
+    bool okp[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) okp[n] = gpix(pixbase + 16 * n + li) >= 0;
+    f32x4 acco[PASS == 2 ? C16 : 1][NT];
+    if constexpr (PASS == 2) {
+#pragma unroll
+      for (int t = 0; t < C16; ++t)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acco[t][n] = zero;
+    }
+#pragma unroll
+    for (int hc = 0; hc < HTP / HT; ++hc) {
+      f32x4 au[HT][NT], ad[HT][NT];
+#pragma unroll
+      for (int t = 0; t < HT; ++t)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) { au[t][n] = zero; ad[t][n] = zero; }
+#pragma unroll
+      for (int s = 0; s < S1; ++s) {
+        bf16x8 xb[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) xb[n] = ly_lds_frag(xs, (pixbase + 16 * n + li) * RS, s, lq);
+#pragma unroll
+        for (int t = 0; t < HT; ++t) {
+          if (WLDS && hc * HT + t >= HTR) continue;              // padded hidden tile: nothing to contract (LDS weights are indexed, not sequenced)
+          const LyWF<1> wf = wnext(NFP + (hc * HT + t) * S1 + s);
+#pragma unroll
+          for (int n = 0; n < NT; ++n) au[t][n] = ly_mfma_bf16(wf.hi, xb[n], au[t][n]);
+          wrefill();
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < S1; ++s) {
+        bf16x8 db[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) db[n] = ly_lds_frag(dys, (pixbase + 16 * n + li) * RS, s, lq);
+#pragma unroll
+        for (int t = 0; t < HT; ++t) {
+          if (WLDS && hc * HT + t >= HTR) continue;
+          const LyWF<1> wf = wnext(NFP + NF1 + (hc * HT + t) * S1 + s);
+#pragma unroll
+          for (int n = 0; n < NT; ++n) ad[t][n] = ly_mfma_bf16(wf.hi, db[n], ad[t][n]);
+          wrefill();
+        }
+      }
+      bf16x4 dub[HT][NT], hb[HT][NT];
+#pragma unroll
+      for (int t = 0; t < HT; ++t) {
+        const int tg = hc * HT + t;
+        if (tg >= HTR) {
+#pragma unroll
+          for (int n = 0; n < NT; ++n) { dub[t][n] = z4; hb[t][n] = z4; }
+          continue;
+        }
+        const int ch = tg * 16 + 4 * lq;
+        const f32x4 a4 = ly_ldg4(P.a + ch), b4 = ly_ldg4(P.b + ch);
+        f32x4 al4 = zero, ka4 = zero, la4 = zero;
+        if constexpr (PASS == 2) { al4 = ly_ldg4(P.alpha + ch); ka4 = ly_ldg4(P.kappa + ch); la4 = ly_ldg4(P.lambda + ch); }
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          f32x4 du4, h4;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float u = au[t][n][r];
+            const float v = u * a4[r] + b4[r];
+            const bool pos = v > 0.f;
+            const float dvv = pos ? ad[t][n][r] : 0.f;             // (dy is staged as zeros for pixels outside the map: dv = 0 there)
+            if constexpr (PASS == 1) {
+              st1[tg][r] += dvv;
+              st2[tg][r] += dvv * u;
+            } else {
+              du4[r] = okp[n] ? al4[r] * dvv + ka4[r] + la4[r] * u : 0.f;
+              h4[r] = pos ? v : 0.f;
+            }
+          }
+          if constexpr (PASS == 2) {
+            dub[t][n] = ly_cvtb4(du4);
+            hb[t][n] = ly_cvtb4(h4);
+          }
+        }
+      }
+      if constexpr (PASS == 2) {
+#pragma unroll
+        for (int u2 = 0; u2 < HT / 2; ++u2) {
+          if (WLDS && hc * HT + 2 * u2 >= HTR) continue;
+          bf16x8 kb[NT];
+#pragma unroll
+          for (int n = 0; n < NT; ++n) kb[n] = ly_cat8(dub[2 * u2][n], dub[2 * u2 + 1][n]);
+#pragma unroll
+          for (int ct = 0; ct < C16; ++ct) {
+            const LyWF<1> wf = wnext(NFP + 2 * NF1 + ct * S2 + hc * (HT / 2) + u2);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acco[ct][n] = ly_mfma_bf16(wf.hi, kb[n], acco[ct][n]);
+            wrefill();
+          }
+        }
+        // du, h of the wave's own pixels -> its rows of the [pixel][hidden] tiles (8 bytes per lane and tile)
+#pragma unroll
+        for (int t = 0; t < HT; ++t) {
+          const int tg = hc * HT + t;
+          if (tg >= HTR) continue;
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            const int ob = (pixbase + 16 * n + li) * RSD + 32 * tg + 8 * lq;
+            *reinterpret_cast<bf16x4*>(dus + ob) = dub[t][n];
+            *reinterpret_cast<bf16x4*>(hs + ob) = hb[t][n];
+          }
+        }
+      }
+    }
+
+    if constexpr (PASS == 2) {
+      // ---- 3. g rows out; dW1 += du^T z, dW2^T += h^T dy over the wave's own pixels (contraction index = pixel: transposed reads) ----
+#pragma unroll
+      for (int ct = 0; ct < C16; ++ct)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const int c = 16 * ct + 4 * lq;
+          const long gp = gpix(pixbase + 16 * n + li);
+          if (c < C && gp >= 0) ly_st4<T>(P.g + gp * C + c, acco[ct][n]);
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the wave's own LDS stores above are visible to its transposed reads below
+      const int r0 = 4 * lq + (li >> 2), c8 = 8 * (li & 3);
+#pragma unroll
+      for (int ks = 0; ks < NT / 2; ++ks) {
+        const int row = pixbase + 32 * ks + r0;
+        bf16x8 bz[C16], bd[C16];
+#pragma unroll
+        for (int ct = 0; ct < C16; ++ct) {
+          bz[ct] = ly_cat8(mb_tr(xs + row * RS + 32 * ct + c8), mb_tr(xs + (row + 16) * RS + 32 * ct + c8));
+          bd[ct] = ly_cat8(mb_tr(dys + row * RS + 32 * ct + c8), mb_tr(dys + (row + 16) * RS + 32 * ct + c8));
+        }
+#pragma unroll
+        for (int t = 0; t < HTR; ++t) {
+          const bf16x8 a1 = ly_cat8(mb_tr(dus + row * RSD + 32 * t + c8), mb_tr(dus + (row + 16) * RSD + 32 * t + c8));
+          const bf16x8 a2 = ly_cat8(mb_tr(hs + row * RSD + 32 * t + c8), mb_tr(hs + (row + 16) * RSD + 32 * t + c8));
+#pragma unroll
+          for (int ct = 0; ct < C16; ++ct) {
+            aw1[t * C16 + ct] = ly_mfma_bf16(a1, bz[ct], aw1[t * C16 + ct]);
+            aw2[t * C16 + ct] = ly_mfma_bf16(a2, bd[ct], aw2[t * C16 + ct]);
+          }
+        }
+      }
+    }
+    __syncthreads();                                               // every wave is done with the halo image / the tiles
+    if constexpr (T2D) {
+      commit();
+      __syncthreads();
+    }
+  }
+
+  if constexpr (PASS == 1) {
+#pragma unroll
+    for (int t = 0; t < HTR; ++t) ly_stats_flush(P.stats, 2 * C, t * 16 + 4 * lq, st1[t], st2[t]);
+  } else {
+    // the four waves' accumulator tiles meet in LDS in wave order (fixed summation order), the block writes ONE slab
+    float* const red = reinterpret_cast<float*>(xs);              // (tiles are dead: every wave passed the loop's last barrier)
+    constexpr int RED_FLOATS = Bg::SLAB;
+    static_assert(RED_FLOATS * 4 <= 2 * BP * RS + 2 * BP * RSD, "reduction scratch must fit the tile area");
+    for (int w = 0; w < 4; ++w) {
+      if (wave == w) {
+#pragma unroll
+        for (int i = 0; i < Bg::NACC; ++i) {
+          f32x4* const p1 = reinterpret_cast<f32x4*>(red) + i * 64 + lane;
+          f32x4* const p2 = reinterpret_cast<f32x4*>(red) + (Bg::NACC + i) * 64 + lane;
+          if (w == 0) { *p1 = aw1[i]; *p2 = aw2[i]; }
+          else { *p1 = *p1 + aw1[i]; *p2 = *p2 + aw2[i]; }
+        }
+      }
+      __syncthreads();
+    }
+    f32x4* const out = reinterpret_cast<f32x4*>(P.slab + (size_t)blockIdx.x * Bg::SLAB);
+    for (int i = tid; i < RED_FLOATS / 4; i += LY_THREADS) out[i] = reinterpret_cast<const f32x4*>(red)[i];
+  }
+}
+
+template <int C, int NT, int HT, bool T2D, bool WLDS, int PASS, int D>
+__global__ __launch_bounds__(LY_THREADS) void ly_mlpblock_bwd_kernel(const LyMlpBwdArgs P) {
+  ly_mlp_bwd_body<C, NT, HT, T2D, WLDS, PASS, D>(P);
+}
+
+// dw1[hid][c] += sum_b slab[b][0][t][ct][lane][r],  dw2[c][hid] += sum_b slab[b][1][...]   with hid = 16 t + 4 (lane >> 4) + r, c = 16 ct + (lane & 15)
+// (fixed block order: bit-reproducible).  Block = 64 consecutive float4 slab entries x RL row lanes over the blocks.
+template <int C, int NT>
+__global__ __launch_bounds__(1024) void ly_mlpblock_bwd_combine_kernel(const float* __restrict__ slab, const int nblk, float* __restrict__ dw1,
+                                                                      float* __restrict__ dw2, const int rls) {
+  using Bg = MlpBwdGeom<C, NT>;
+  constexpr int C16 = MlpGeom<C>::C16;
+  __shared__ f32x4 red[16][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + cl;                          // float4 entry of the slab
+  const bool live = e < Bg::SLAB / 4;
+  f32x4 acc0 = ly_zero4(), acc1 = ly_zero4();
+  if (live) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(slab) + e;
+    int b = rl;
+    for (; b + rls < nblk; b += 2 * rls) {
+      const f32x4 v0 = p[(size_t)b * (Bg::SLAB / 4)], v1 = p[(size_t)(b + rls) * (Bg::SLAB / 4)];
+      acc0 += v0; acc1 += v1;
+    }
+    if (b < nblk) acc0 += p[(size_t)b * (Bg::SLAB / 4)];
+  }
+  red[rl][cl] = acc0 + acc1;
+  __syncthreads();
+  if (rl == 0 && live) {
+    f32x4 s = red[0][cl];
+    for (int i = 1; i < rls; ++i) s += red[i][cl];
+    const int which = e / (Bg::NACC * 64), rem = e - which * (Bg::NACC * 64);
+    const int tile = rem >> 6, lane = rem & 63;
+    const int t = tile / C16, ct = tile - t * C16;
+    const int c = 16 * ct + (lane & 15);
+    if (c < C) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int hid = 16 * t + 4 * (lane >> 4) + r;
+        float* const d = which == 0 ? dw1 + (size_t)hid * C + c : dw2 + (size_t)c * (2 * C) + hid;
+        *d += s[r];
+      }
+    }
+  }
+}
+
+template <int C, int NT, int HT, bool T2D, bool WLDS, int PASS, int D>
+static int launch_mlp_bwd(LyMlpBwdArgs P, long slab_floats, int* blocks_out, hipStream_t st) {
+  using Gm = MlpGeom<C>;
+  using Bg = MlpBwdGeom<C, NT>;
+  constexpr int BP = Bg::BP;
+  const long halo = T2D ? (4 * NT + 2) * 18 : BP + 2 * P.W + 2;
+  const size_t lds = (WLDS ? (size_t)Bg::NFW * 1024 : 0) + 2 * (size_t)BP * Gm::RS + ((size_t)halo * Gm::RSP + 15) / 16 * 16 +
+                     (PASS == 2 ? 2 * (size_t)BP * Bg::RSD : 0);
+  LY_CHECK(lds <= 160 * 1024, "mlpblock_bwd: tile needs %zu B of LDS (C=%d W=%d)", lds, C, P.W);
+  auto k = ly_mlpblock_bwd_kernel<C, NT, HT, T2D, WLDS, PASS, D>;
+  static LyDevOnce once;
+  static int per_cu = 0;
+  static size_t lds_q = 0;
+  if (once.need() || lds_q != lds) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+    LY_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    int nb = 0;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k), LY_THREADS, lds);
+    LY_CHECK(e == hipSuccess, "hipOccupancyMaxActiveBlocksPerMultiprocessor: %s", hipGetErrorString(e));
+    per_cu = nb < 1 ? 1 : (nb > 8 ? 8 : nb);
+    lds_q = lds;
+  }
+  const long ntiles = T2D ? (long)P.n_img * ((P.H + 4 * NT - 1) / (4 * NT)) * (P.W / 16) : (P.M + BP - 1) / BP;
+  LY_CHECK(ntiles < (1L << 30), "mlpblock_bwd: too many tiles");
+  long blocks = 256L * per_cu;
+  if (blocks > ntiles) blocks = ntiles;
+  if (PASS == 2) {
+    LY_CHECK(P.slab && blocks * (long)Bg::SLAB <= slab_floats, "mlpblock_bwd: the slab workspace holds %ld floats, %ld needed", slab_floats,
+             blocks * (long)Bg::SLAB);
+  }
+  P.ntiles = (int)ntiles;
+  hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(LY_THREADS), lds, st, P);
+  LY_LAUNCH_CHECK();
+  if (blocks_out) *blocks_out = (int)blocks;
+  return 0;
+}
+
+template <int C, int NT>
+static int launch_mlp_bwd_combine(const float* slab, int nblk, float* dw1, float* dw2, hipStream_t st) {
+  using Bg = MlpBwdGeom<C, NT>;
+  const int rls = nblk <= 64 ? 4 : 16;
+  hipLaunchKernelGGL((ly_mlpblock_bwd_combine_kernel<C, NT>), dim3((Bg::SLAB / 4 + 63) / 64), dim3(64 * rls), 0, st, slab, nblk, dw1, dw2, rls);
+  LY_LAUNCH_CHECK();
+  return 0;
+}
+
+// (C, tiling) table: persistent T2D patches where the map is a multiple of 16 wide, flattened runs otherwise; weights resident in LDS.
+// C >= 80 is not built: the wave-private weight-gradient accumulators (2 x HTR x C16 tiles) would need 400 registers at C = 80.
+template <int C, int HT, int PASS>
+static int dispatch_mlp_bwd(LyMlpBwdArgs P, long slab_floats, int* blocks_out, hipStream_t st) {
+  static_assert(C < 80, "wave-private weight-gradient accumulators: C < 80");
+  if ((P.W & 15) == 0 && P.W >= 32) return launch_mlp_bwd<C, 2, HT, true, true, PASS, 0>(P, slab_floats, blocks_out, st);
+  return launch_mlp_bwd<C, 2, HT, false, true, PASS, 0>(P, slab_floats, blocks_out, st);
+}

@@ -553,6 +553,7 @@ class MlpBlockFn(torch.autograd.Function):
         y = ops.empty_nhwc(n, c, h, w, x)
         ops.mlpblock(x, y, n, h, w, c, pk_p, pk_1, pk_2, a, b)
         a, b = a[:2 * c], b[:2 * c]
+        ctx.mod = mod
         ctx.params = (wpc, w1, gamma, beta, w2)
         ctx.save_for_backward(x, wpc, w1, w2, a, b, mean, invstd)
         return y
@@ -568,6 +569,8 @@ class MlpBlockFn(torch.autograd.Function):
         with torch.no_grad():
             dy = _rows_dense(dy if dy.dtype == x.dtype else dy.to(x.dtype))
             pl = ops.planes_of(x)
+            if ops.mlpblock_bwd_ok(x, c):
+                return MlpBlockFn._backward_fused(ctx, dy)
             c4q = (c4 + 31) // 32 * 32                 # the 3x3 kernel's tap matrices pad the channels of a tap to 32
             # recompute z, u1, h
             # z = [pconv(x[:c4]) | x[c4:]]: one pass of the persistent kernel where it is built, else a copy + the 3x3 kernel on the slice
@@ -629,6 +632,62 @@ class MlpBlockFn(torch.autograd.Function):
                 if direct:
                     ops.grad_done(prm)
         return (None, dx, None if dp else dwp, None if d1 else dw1, dgamma, dbeta, None if d2 else dw2)
+
+
+def _mlpblock_backward_fused(ctx, dy):
+    """MLPBlock backward on the fused kernels (csrc/ly_mlpblock_bwd.hpp): two passes over (x, dy) with the 2C-wide hidden tensors on chip —
+    pass 1 the BatchNorm sums, pass 2 g = d/dz and both 1x1 weight gradients — then the partial conv's two gradients on g.
+    dy: dense NHWC, the storage dtype."""
+    x, wpc, w1, w2, a, b, mean, invstd = ctx.saved_tensors
+    p_wpc, p_w1, p_gamma, p_beta, p_w2 = ctx.params
+    n, c, h, w = x.shape
+    m = n * h * w
+    c4 = c // 4
+    c4p = _ceil4(c4)
+    pl = ops.planes_of(x)
+    htp = (2 * c // 16 + 1) // 2 * 2
+    pk_p, pk_1, _ = ctx.mod._weights(pl)
+    pk_2t = pack.packed(pack.src_matrix(p_w2, 2 * c, c, sr=1, sk=2 * c), c, pl, rows_to=16 * htp)
+    pk_1t = pack.packed(pack.src_matrix(p_w1, c, 2 * c, sr=1, sk=c), 2 * c, pl)
+    # pass 1: s1 = sum dv, s2 = sum dv u
+    sums = ops.new_stats(2 * c, x.device)
+    ops.mlpblock_bwd(x, dy, n, h, w, c, pk_p, pk_1, pk_2t, pk_1t, a, b, stats=sums)
+    tg, tb = ops.grad_target(p_gamma), ops.grad_target(p_beta)
+    direct = tg is not None and tb is not None and tg.numel() == 2 * c and tb.numel() == 2 * c
+    dgamma, dbeta, alpha, kappa, lam = ops.bn_bwd_coeffs(sums, 2 * c, m, a, mean, invstd, True, dgamma=tg if direct else None,
+                                                         dbeta=tb if direct else None)
+    if direct:
+        ops.grad_done(p_gamma)
+        ops.grad_done(p_beta)
+
+    def sink(p):
+        t = ops.grad_target(p)
+        return (t, True) if t is not None and t.is_contiguous() else (torch.zeros(p.shape, dtype=torch.float32, device=x.device), False)
+    dw1, d1 = sink(p_w1)
+    dw2, d2 = sink(p_w2)
+    # pass 2: g, dW1, dW2
+    g = ops.empty_nhwc(n, c, h, w, x)
+    ops.mlpblock_bwd(x, dy, n, h, w, c, pk_p, pk_1, pk_2t, pk_1t, a, b, g=g, alpha=alpha, kappa=kappa, lam=lam, dw1=dw1, dw2=dw2)
+    # partial 3x3 conv on the first C/4 channels: weight gradient from (g, x), data gradient folded into dx = dy + [conv^T(g[:C/4]) | g[C/4:]]
+    tgt = ops.grad_target(p_wpc)
+    dwp, dp = (tgt, True) if tgt is not None else (torch.zeros(p_wpc.shape, dtype=torch.float32, device=x.device), False)
+    ts, cs = (c4, 1) if _tap_major(dwp) else (1, 9)
+    ops.wgrad(M=m, H=h, W=w, N=c4p, du=g, lddu=c, x=x, ldx=c, Hin=h, Win=w, Cin=c4p, dw=dwp, lddw=9 * c4, ks=3, stride=1, pad=1,
+              dw_ts=ts, dw_cs=cs, n_valid=c4, c_valid=c4)
+    dx = torch.empty_like(dy)
+    gz = torch.empty_like(g)
+    wt = pack.packed(pack.src_taps(p_wpc, c4p, transposed_flipped=True), 9 * c4p, pl)
+    if not ops.mlpblock_pconv(g, gz, n, h, w, c, wt):
+        raise RuntimeError("mlpblock backward: the partial-conv kernel is not built for this shape")
+    _lib().check(_lib().lib().ly_mlp_dx(_lib().ptr(dy), _lib().ptr(gz), _lib().ptr(gz), c, m, c, 4, _lib().ptr(dx), _lib().dtype_code(dy),
+                                        _lib().stream_ptr()), "ly_mlp_dx")
+    for prm, direct_ in ((p_wpc, dp), (p_w1, d1), (p_w2, d2)):
+        if direct_:
+            ops.grad_done(prm)
+    return (None, dx, None if dp else dwp, None if d1 else dw1, dgamma, dbeta, None if d2 else dw2)
+
+
+MlpBlockFn._backward_fused = staticmethod(_mlpblock_backward_fused)
 
 
 # --------------------------------------------------------------------------------------------------

@@ -626,6 +626,40 @@ def mlpblock(x, y, n, h, w, c, wp, w1, w2, sc, sh, stats=None):
                                               capi.stream_ptr()), "ly_mlpblock_fwd")
 
 
+def mlpblock_bwd_ok(x, c):
+    """the fused MLPBlock backward (csrc/ly_mlpblock_bwd.hpp) is built for bf16 storage and the narrow stages (C in 16 / 24 / 40)"""
+    return MLP_BWD_FUSED and x.dtype == torch.bfloat16 and bool(capi.lib().ly_mlpblock_bwd_ok(c, capi.dtype_code(x)))
+
+
+MLP_BWD_FUSED = True       # tools / tests: False keeps the unfused backward (eleven launches over 2C-wide tensors)
+_MLPB_SLAB = {}
+
+
+def _mlpblock_bwd_slab(c, device):
+    """per-(device, C) slab the fused backward's blocks park their weight-gradient tiles in; allocated once (a captured hipGraph keeps its
+    address; written and read back inside one launch pair, stream-ordered)"""
+    key = (device, c)
+    t = _MLPB_SLAB.get(key)
+    if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("mlpblock_bwd: first use inside a hipGraph capture; run one eager step first")
+        t = _MLPB_SLAB[key] = torch.empty(int(capi.lib().ly_mlpblock_bwd_slab_floats(c)), dtype=torch.float32, device=device)
+    return t
+
+
+def mlpblock_bwd(x, dy, n, h, w, c, wp, w1, w2t, w1t, a, b, *, stats=None, g=None, alpha=None, kappa=None, lam=None, dw1=None, dw2=None):
+    """one pass of the fused MLPBlock backward: stats given = pass 1 (BatchNorm sums), else pass 2 (g, dw1 +=, dw2 +=)"""
+    m = n * h * w
+    p1 = stats is not None
+    slab = None if p1 else _mlpblock_bwd_slab(c, x.device)
+    hid = 2 * c
+    flops = 2.0 * m * (9 * (c // 4) ** 2 + (2 if p1 else 5) * c * hid)
+    with _Timed(f"ly_mlpblock_bwd_kernel<{c}, pass {1 if p1 else 2}>", flops, x.element_size() * (2 if p1 else 3) * m * c + 4.0 * (9 * (c // 4) ** 2 + 2 * c * hid)):
+        capi.check(capi.lib().ly_mlpblock_bwd(_p(x), _p(dy), _p(g), n, h, w, c, _p(wp), _p(w1), _p(w2t), _p(w1t), _p(a), _p(b), _p(alpha), _p(kappa), _p(lam),
+                                              _p(stats), _p(slab), slab.numel() if slab is not None else 0, _p(dw1), _p(dw2), 1 if p1 else 2,
+                                              capi.dtype_code(x), capi.stream_ptr()), "ly_mlpblock_bwd")
+
+
 def chan_moments(x, ldx, rows, c, f64=False):
     """per-channel (sum x, sum x^2) over the rows of an [rows, c] matrix -> [2c]; accumulated in double stripes, folded in index order
     (float32 result unless f64: ly_rfcbam_gen_prepare takes the doubles)"""

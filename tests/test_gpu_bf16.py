@@ -495,3 +495,41 @@ def test_configs4_shape_lead_yolo_l_1280(bs):
     cos_noise = float(de2 @ de / (de2.norm() * de.norm()))
     # (round 4: reproducible forward + double accumulators wherever a sum feeds an activation gradient: the replay's update equals the eager one)
     assert cos >= 0.99999 and cos_noise >= 0.99999 and abs(float(dg.norm() / de.norm()) - 1) <= 1e-3, (cos, cos_noise)
+
+
+@pytest.mark.parametrize("c,n,h,w", [(24, 2, 40, 48), (24, 3, 13, 32), (40, 3, 24, 32), (24, 2, 20, 20), (40, 1, 7, 9), (16, 2, 16, 64), (40, 2, 33, 80)])
+def test_mlpblock_fused_backward_bf16(c, n, h, w, monkeypatch):
+    """The fused MLPBlock backward (csrc/ly_mlpblock_bwd.hpp: two passes over (x, dy), the 2C-wide hidden tensors and both 1x1 weight
+    gradients on chip; reference: autograd of models/common.py:1432-1437, 1478-1482) — T2D patches (W % 16 == 0, ragged H included) and
+    flattened runs (any W, tiles spanning images) — against (a) autograd through the fp32 oracle on the same bf16-rounded input, at the bf16
+    bound for smooth modules, and (b) the unfused HIP backward (eleven launches, hidden tensors rounded to bf16 in HBM): the two must agree
+    more tightly with each other than either does with fp32.  Running statistics and the forward are untouched by the switch."""
+    import lead_yolo_amd as L
+    from lead_yolo_amd import ops
+    from tests.test_gpu_backward import _oracle_grads
+    torch.manual_seed(c)
+    st = synth.synth_state(synth.shapes_of(L.BasicStage(c, 1).state_dict()), 6100 + c + w)
+    x = synth.synth_input((n, c, h, w), 177 + c + h).to(BF).float()
+    r = synth.synth_input((n, c, h, w), 178 + c + h).to(BF).float()
+    _, dxo, gpo = _oracle_grads("BasicStage", [c, 1], st, x, r)
+
+    def run(fused):
+        monkeypatch.setattr(ops, "MLP_BWD_FUSED", fused)
+        m = _bn_eps(_load(L.BasicStage(c, 1), copy.deepcopy(st))).to(_dev()).train()
+        xt = x.to(_dev()).to(BF).requires_grad_(True)
+        with torch.autocast("cuda", dtype=BF):
+            y = m(xt)
+        y.backward(r.to(_dev()).to(BF))
+        return xt.grad.float().cpu(), {k: p.grad.float().cpu() for k, p in m.named_parameters()}
+
+    dxf, gf = run(True)
+    dxu, gu = run(False)
+    what = f"mlpblock fused bwd c={c} {n}x{h}x{w}"
+    _close(dxf, dxo, what + " dx vs oracle", rel=2 * REL_L2, mx=4 * MAX_REL)
+    _close(dxf, dxu, what + " dx vs unfused", rel=REL_L2, mx=2 * MAX_REL)
+    for k, want in gpo.items():
+        assert gf[k] is not None, (what, k)
+        cos = float((gf[k] * want).sum() / (gf[k].norm() * want.norm() + 1e-30))
+        assert cos >= 0.995, (what, k, cos)
+        _close(gf[k], want, f"{what} d{k} vs oracle", rel=2 * REL_L2, mx=4 * MAX_REL)
+        _close(gf[k], gu[k], f"{what} d{k} vs unfused", rel=REL_L2, mx=2 * MAX_REL)

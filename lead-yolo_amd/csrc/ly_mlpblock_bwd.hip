@@ -1,26 +1,18 @@
 // Fused MLPBlock backward: C ABI + the C = 16 / 24 / 40 instantiations (kernels: ly_mlpblock_bwd.hpp).
 #include "ly_mlpblock_bwd.hpp"
 
-// 1 when ly_mlpblock_bwd is built for (C, dtype): bf16 storage, C in {16, 24, 40}
-extern "C" int ly_mlpblock_bwd_ok(int C, int dtype) { return dtype == LY_BF16 && (C == 16 || C == 24 || C == 40); }
+// 1 when ly_mlpblock_bwd is built for (C, dtype): bf16 storage, C in {16, 24, 40, 80}
+extern "C" int ly_mlpblock_bwd_ok(int C, int dtype) { return dtype == LY_BF16 && (C == 16 || C == 24 || C == 40 || C == 80); }
 
 // floats of slab workspace pass 2 may need at most for channel count C (256 CUs x 8 resident blocks at most)
 extern "C" long ly_mlpblock_bwd_slab_floats(int C) {
   switch (C) {
-    case 16: return 2048L * MlpBwdGeom<16, 2>::SLAB;
-    case 24: return 2048L * MlpBwdGeom<24, 2>::SLAB;
-    case 40: return 2048L * MlpBwdGeom<40, 2>::SLAB;
+    case 16: return 2048L * MlpBwdGeom<16>::SLAB;
+    case 24: return 2048L * MlpBwdGeom<24>::SLAB;
+    case 40: return 2048L * MlpBwdGeom<40>::SLAB;
+    case 80: return 512L * MlpBwdGeom<80>::SLAB;           // (147 KB of LDS per block: one block per CU)
     default: return 0;
   }
-}
-
-template <int C, int HT>
-static int mlp_bwd_pass(LyMlpBwdArgs P, int pass, long slab_floats, float* dw1, float* dw2, hipStream_t st) {
-  if (pass == 1) return dispatch_mlp_bwd<C, HT, 1>(P, 0, nullptr, st);
-  int blocks = 0;
-  const int rc = dispatch_mlp_bwd<C, HT, 2>(P, slab_floats, &blocks, st);
-  if (rc) return rc;
-  return launch_mlp_bwd_combine<C, 2>(P.slab, blocks, dw1, dw2, st);
 }
 
 extern "C" int ly_mlpblock_bwd(const void* x, const void* dy, void* g, int n_img, int H, int W, int C, const void* wp, const void* w1,
@@ -45,8 +37,9 @@ extern "C" int ly_mlpblock_bwd(const void* x, const void* dy, void* g, int n_img
     case 16: return mlp_bwd_pass<16, 2>(P, pass, slab_floats, dw1, dw2, st);
     case 24: return mlp_bwd_pass<24, 2>(P, pass, slab_floats, dw1, dw2, st);
     case 40: return mlp_bwd_pass<40, 2>(P, pass, slab_floats, dw1, dw2, st);
+    case 80: return ly_mlp_bwd_pass_80(P, pass, slab_floats, dw1, dw2, st);
     default:
-      ly_set_error("mlpblock_bwd: unsupported channel count C=%d (built for 16/24/40)", C);
+      ly_set_error("mlpblock_bwd: unsupported channel count C=%d (built for 16/24/40/80)", C);
       return -1;
   }
 }

@@ -13,15 +13,20 @@
 //   PASS 1  per pixel tile: z (partial conv from the LDS halo image), u = W1 z and dh = W2^T dy as two MFMA chains with the SAME accumulator
 //           layout (lane = pixel, 4 hidden channels), dv and the two sums in registers; one double atomic per channel and block at the end.
 //   PASS 2  the same up to dv; du and h in registers; g += W1^T du straight from the accumulators (two fp32 tiles ARE the B operand of the
-//           next k-step, ly_tile.hpp); du and h also go — as bf16, 8 bytes per lane — into two wave-private LDS tiles [pixel][hidden], from
-//           which the wave contracts dW1 += du^T z and dW2^T += h^T dy over ITS OWN 32 pixels through transposed reads (ds_read_b64_tr_b16:
-//           the contraction index is the pixel).  Weight-gradient accumulators stay in registers over the block's whole tile walk; the four
-//           waves meet in LDS once, the block writes ONE slab, ly_mlpblock_bwd_combine folds the slabs in block order (bit-reproducible).
+//           next k-step, ly_tile.hpp); du and h also go — as bf16, 8 bytes per lane — into two LDS tiles [pixel][hidden], from which
+//           dW1 += du^T z and dW2^T += h^T dy are contracted through transposed reads (ds_read_b64_tr_b16: the contraction index is the
+//           pixel).  Weight-gradient accumulators stay in registers over the block's whole tile walk; the block writes ONE slab,
+//           ly_mlpblock_bwd_combine folds the slabs in block order (bit-reproducible).
+//           DWX = false (C <= 40): a wave contracts ALL hidden tiles over its OWN 32 pixels — du / h rows are wave-private, no barrier,
+//             2 * HTR * C16 accumulator tiles per wave; the four waves meet in LDS when the block ends.
+//           DWX = true (C = 80): 400 accumulator registers per wave would not fit — the hidden tiles go through LDS in rounds of four, after
+//             a barrier wave w contracts tile 4 r + w over ALL the block's pixels and owns its slab entries outright.
 // HBM traffic: pass 1 reads x, dy; pass 2 reads x, dy and writes g — against ~17 map-sized reads / writes before.
 //
-// Tiling as the forward: T2D (W % 16 == 0): 4*NT x 16 pixel patches, halo frame with zeros staged for out-of-image taps, the next patch's raw
-// pixels in flight (registers) during the arithmetic; flattened runs of 64*NT pixels otherwise.  WLDS: all weight fragments of the four
-// contractions resident in LDS (C <= 40); else streamed from L2 through a register ring (ly_mlpblock.hpp).
+// Tiling: T2D = 4*NT x 16 pixel patches of ANY map width (columns past W are masked: W = 40 wastes 17 % of the third patch column), halo frame
+// with zeros staged for out-of-image taps, the next patch's raw pixels in flight (registers) during the arithmetic; flattened runs of 64*NT
+// pixels where patches would waste more than a quarter of their columns.  All weight fragments of the four contractions are resident in
+// LDS (15 / 37 / 97 KB at C = 24 / 40 / 80), copied once per block.
 #include "ly_mlpblock.hpp"
 
 typedef short mb_s16x4 __attribute__((ext_vector_type(4)));
@@ -43,40 +48,45 @@ struct LyMlpBwdArgs {
   float* slab;                   // pass 2: [gridDim.x][MlpBwdGeom::SLAB] raw accumulator tiles
 };
 
-template <int C, int NT>
+template <int C>
 struct MlpBwdGeom {
   using Gm = MlpGeom<C>;
   static constexpr int HTR = 2 * C / 16;                   // real hidden tiles (2C is a multiple of 16)
+  static constexpr bool DWX = C >= 80;
+  static constexpr int NT = DWX ? 1 : 2;                   // pixel tiles of 16 per wave
   static constexpr int BP = 64 * NT;
-  static constexpr int RSD = 2 * 16 * Gm::HTP + 16;        // du / h tile row stride (bytes)
-  static constexpr int NACC = HTR * Gm::C16;               // accumulator tiles per weight gradient and wave
+  static constexpr int DT = DWX ? 4 : Gm::HTP;             // hidden tiles per du / h round (DWX: one per wave)
+  static constexpr int NRD = (Gm::HTP + DT - 1) / DT;      // rounds
+  static constexpr int RSD = 2 * 16 * DT + 16;             // du / h tile row stride (bytes)
+  static constexpr int NACC = HTR * Gm::C16;               // accumulator tiles per weight gradient
   static constexpr int SLAB = 2 * NACC * 256;              // floats per block: [dW1 | dW2^T][t][ct][lane][4]
   static constexpr int NFP = Gm::PT * Gm::SP, NF1 = Gm::HTP * Gm::S1, NF1T = Gm::C16 * Gm::S2;
   static constexpr int NFW = NFP + 2 * NF1 + NF1T;         // fragments of Wp, W1, W2^T, W1^T
 };
 
-template <int C, int NT, int HT, bool T2D, bool WLDS, int PASS, int D>
+template <int C, int HT, bool T2D, int PASS>
 __device__ __forceinline__ void ly_mlp_bwd_body(const LyMlpBwdArgs& P) {
   using Gm = MlpGeom<C>;
-  using Bg = MlpBwdGeom<C, NT>;
+  using Bg = MlpBwdGeom<C>;
   using T = __bf16;
   typedef ly_u32x4 RV;
   typedef ly_u32x2 R4;
   constexpr int VW = 8;
   constexpr int CQ = Gm::CQ, G = Gm::G, SP = Gm::SP, PT = Gm::PT, C16 = Gm::C16, KP = Gm::KP, S1 = Gm::S1;
   constexpr int RS = Gm::RS, RSP = Gm::RSP, HTP = Gm::HTP, S2 = Gm::S2;
-  constexpr int HTR = Bg::HTR, BP = Bg::BP, RSD = Bg::RSD, TH = 4 * NT;
+  constexpr int HTR = Bg::HTR, NT = Bg::NT, BP = Bg::BP, RSD = Bg::RSD, DT = Bg::DT, NRD = Bg::NRD, TH = 4 * NT;
+  constexpr bool DWX = Bg::DWX;
   constexpr int NFP = Bg::NFP, NF1 = Bg::NF1, NF1T = Bg::NF1T;
-  static_assert(HTP % HT == 0 && HT % 2 == 0 && C % VW == 0 && NT % 2 == 0, "geometry");
-  static_assert(WLDS || HTR == HTP, "ring variant: no padded hidden tile");
-  static_assert(WLDS == (D == 0), "LDS-resident weights need no ring");
+  static_assert(HTP % HT == 0 && HT % 2 == 0 && DT % HT == 0 && C % VW == 0 && (DWX || NT % 2 == 0), "geometry");
   const int H = P.H, W = P.W;
   const long M = P.M;
   const int BPH = T2D ? (TH + 2) * 18 : BP + 2 * W + 2;
 
   extern __shared__ f32x4 ly_smem4[];
   char* const wl = reinterpret_cast<char*>(ly_smem4);
-  char* const xs = wl + (WLDS ? Bg::NFW * 1024 : 0);
+  float* const cfl = reinterpret_cast<float*>(wl + (NFP + 2 * NF1 + (PASS == 2 ? NF1T : 0)) * 1024);      // a | b | alpha | kappa | lambda, 2C floats each
+  constexpr int NCF = PASS == 2 ? 5 : 2;
+  char* const xs = reinterpret_cast<char*>(cfl) + NCF * 2 * C * 4;
   char* const dys = xs + BP * RS;
   char* const ps = dys + BP * RS;
   char* const dus = ps + (BPH * RSP + 15) / 16 * 16;       // pass 2 only
@@ -88,34 +98,26 @@ __device__ __forceinline__ void ly_mlp_bwd_body(const LyMlpBwdArgs& P) {
   const T* const x = P.x;
   const T* const dy = P.dy;
 
-  // ---- weights: LDS once (WLDS) or a register ring over the per-tile fragment sequence -------------------------------------------
-  if constexpr (WLDS) {
-    for (int i = tid; i < NFP * 64; i += LY_THREADS) reinterpret_cast<uint4*>(wl)[i] = P.wp[i];
-    for (int i = tid; i < NF1 * 64; i += LY_THREADS) reinterpret_cast<uint4*>(wl)[NFP * 64 + i] = P.w1[i];
-    for (int i = tid; i < NF1 * 64; i += LY_THREADS) reinterpret_cast<uint4*>(wl)[(NFP + NF1) * 64 + i] = P.w2t[i];
-    if constexpr (PASS == 2)
-      for (int i = tid; i < NF1T * 64; i += LY_THREADS) reinterpret_cast<uint4*>(wl)[(NFP + 2 * NF1) * 64 + i] = P.w1t[i];
+  // ---- weights -> LDS, once ---------------------------------------------------------------------------------------------------------
+  for (int i = tid; i < NFP * 64; i += LY_THREADS) reinterpret_cast<uint4*>(wl)[i] = P.wp[i];
+  for (int i = tid; i < NF1 * 64; i += LY_THREADS) reinterpret_cast<uint4*>(wl)[NFP * 64 + i] = P.w1[i];
+  for (int i = tid; i < NF1 * 64; i += LY_THREADS) reinterpret_cast<uint4*>(wl)[(NFP + NF1) * 64 + i] = P.w2t[i];
+  if constexpr (PASS == 2)
+    for (int i = tid; i < NF1T * 64; i += LY_THREADS) reinterpret_cast<uint4*>(wl)[(NFP + 2 * NF1) * 64 + i] = P.w1t[i];
+  for (int i = tid; i < 2 * C; i += LY_THREADS) {
+    cfl[i] = P.a[i];
+    cfl[2 * C + i] = P.b[i];
+    if constexpr (PASS == 2) {
+      cfl[4 * C + i] = P.alpha[i];
+      cfl[6 * C + i] = P.kappa[i];
+      cfl[8 * C + i] = P.lambda[i];
+    }
   }
-  // per-tile fragment sequence (the order of use): Wp (k-step major) | per hidden chunk: W1, W2^T (k-step major), W1^T (pair major)
-  constexpr int FP = SP * PT, F1 = S1 * HT, F3 = PASS == 2 ? (HT / 2) * C16 : 0, FQ = 2 * F1 + F3, NFRAG = FP + (HTP / HT) * FQ;
-  auto wseq = [&](int g) -> LyWF<1> {
-    if (g < FP) return ly_wfragp<1>(P.wp, (g % PT) * SP + g / PT, lane);
-    g -= FP;
-    const int chunk = g / FQ, r = g - chunk * FQ;
-    if (r < F1) return ly_wfragp<1>(P.w1, (chunk * HT + r % HT) * S1 + r / HT, lane);
-    if (r < 2 * F1) return ly_wfragp<1>(P.w2t, (chunk * HT + (r - F1) % HT) * S1 + (r - F1) / HT, lane);
-    const int r2 = r - 2 * F1;
-    return ly_wfragp<1>(P.w1t, (r2 % C16) * S2 + chunk * (HT / 2) + r2 / C16, lane);
-  };
-  auto wlds = [&](int fi) -> LyWF<1> {
-    LyWF<1> f;
-    f.hi = *reinterpret_cast<const bf16x8*>(wl + (fi * 64 + lane) * 16);
-    return f;
-  };
-  LyWF<1> ring[D > 0 ? D : 1];
+  auto wlds = [&](int fi) -> bf16x8 { return *reinterpret_cast<const bf16x8*>(wl + (fi * 64 + lane) * 16); };
+  auto coef = [&](int k, int ch) -> f32x4 { return *reinterpret_cast<const f32x4*>(cfl + k * 2 * C + ch); };
 
   // ---- tile geometry ------------------------------------------------------------------------------------------------------------
-  const int tw = T2D ? (W >> 4) : 1, th = T2D ? (H + TH - 1) / TH : 1;
+  const int tw = T2D ? ((W + 15) >> 4) : 1, th = T2D ? (H + TH - 1) / TH : 1;
   long img0 = 0, p0 = 0;
   int h0 = 0, w0 = 0;
   auto decode = [&](int tile, long& i0, int& hh0, int& ww0, long& q0) {
@@ -145,9 +147,9 @@ __device__ __forceinline__ void ly_mlp_bwd_body(const LyMlpBwdArgs& P) {
     for (int e = 0; e < NVT; ++e) {
       const int idx = tid + e * LY_THREADS;
       const int pix = idx / (KP / VW), c4 = idx - pix * (KP / VW);
-      const int r = pix >> 4;
-      tok[e] = idx < TVN && hh0 + r < H && c4 * VW < C;
-      const long off = tok[e] ? (i0 + (long)(hh0 + r) * W + ww0 + (pix & 15)) * C + c4 * VW : 0;
+      const int r = pix >> 4, cx = pix & 15;
+      tok[e] = idx < TVN && hh0 + r < H && ww0 + cx < W && c4 * VW < C;
+      const long off = tok[e] ? (i0 + (long)(hh0 + r) * W + ww0 + cx) * C + c4 * VW : 0;
       tv[e] = ly_ldrv<T>(x + off);
       dv_[e] = ly_ldrv<T>(dy + off);
     }
@@ -218,26 +220,29 @@ __device__ __forceinline__ void ly_mlp_bwd_body(const LyMlpBwdArgs& P) {
   };
 
   // ---- block-lifetime accumulators ---------------------------------------------------------------------------------------------------
+  constexpr int NOWN = DWX ? NRD : HTR;                    // hidden tiles whose weight gradients this wave accumulates
+  constexpr int NAW = NOWN * C16;
   f32x4 st1[PASS == 1 ? HTR : 1], st2[PASS == 1 ? HTR : 1];
-  f32x4 aw1[PASS == 2 ? Bg::NACC : 1], aw2[PASS == 2 ? Bg::NACC : 1];
+  f32x4 aw1[PASS == 2 ? NAW : 1], aw2[PASS == 2 ? NAW : 1];
   if constexpr (PASS == 1) {
 #pragma unroll
     for (int t = 0; t < HTR; ++t) { st1[t] = zero; st2[t] = zero; }
   } else {
 #pragma unroll
-    for (int i = 0; i < Bg::NACC; ++i) { aw1[i] = zero; aw2[i] = zero; }
+    for (int i = 0; i < NAW; ++i) { aw1[i] = zero; aw2[i] = zero; }
   }
 
   int tile = blockIdx.x;
-  if (tile < P.ntiles) {
-    if constexpr (T2D) {
+  if constexpr (T2D) {
+    if (tile < P.ntiles) {
       issue(tile);
       commit();
     }
   }
-  if constexpr (WLDS || T2D) __syncthreads();
+  __syncthreads();                                           // weights (and the first patch) are in LDS
   const int pixbase = wave * (16 * NT);
   const bf16x4 z4 = __builtin_bit_cast(bf16x4, make_uint2(0u, 0u));
+  const int r0 = 4 * lq + (li >> 2), c8 = 8 * (li & 3);     // transposed-read addressing (the k-set of ly_tile.hpp)
 
   for (; tile < P.ntiles; tile += gridDim.x) {
     if constexpr (T2D) {
@@ -250,29 +255,12 @@ __device__ __forceinline__ void ly_mlp_bwd_body(const LyMlpBwdArgs& P) {
     decode(tile, img0, h0, w0, p0);
     auto gpix = [&](int pix) -> long {
       if constexpr (T2D) {
-        const int r = pix >> 4;
-        return (h0 + r < H) ? img0 + (long)(h0 + r) * W + w0 + (pix & 15) : -1;
+        const int r = pix >> 4, cx = pix & 15;
+        return (h0 + r < H && w0 + cx < W) ? img0 + (long)(h0 + r) * W + w0 + cx : -1;
       } else {
         const long gp = p0 + pix;
         return gp < M ? gp : -1;
       }
-    };
-    int g = 0;                   // fragments consumed so far in this tile (a constant at every use after unrolling)
-    if constexpr (D > 0) {
-#pragma unroll
-      for (int i = 0; i < D; ++i)
-        if (i < NFRAG) ring[i] = wseq(i);
-    }
-    auto wnext = [&](int fi) -> LyWF<1> {           // fi: index in the LDS image (WLDS); the ring serves the sequence in order
-      if constexpr (WLDS) return wlds(fi);
-      else return ring[g % D];
-    };
-    auto wrefill = [&]() {
-      if constexpr (D > 0) {
-        if (g + D < NFRAG) ring[g % D] = wseq(g + D);
-        __builtin_amdgcn_sched_barrier(0x786);
-      }
-      ++g;
     };
 
     // ---- 1. z = partial 3x3 conv into the tile (the forward's code) ---------------------------------------------------------------
@@ -299,6 +287,9 @@ __device__ __forceinline__ void ly_mlp_bwd_body(const LyMlpBwdArgs& P) {
       for (int t = 0; t < PT; ++t)
 #pragma unroll
         for (int n = 0; n < NT; ++n) accp[t][n] = zero;
+      // every operand of the SP k-steps is requested before the first MFMA (left alone hipcc reads each fragment right before its use: one
+      // exposed LDS round trip per MFMA at one wave per SIMD — 69 lgkmcnt(0) waits per tile in the C = 80 listing)
+      bf16x8 xh[SP][NT], wpf[SP][PT];
 #pragma unroll
       for (int s = 0; s < SP; ++s) {
         int off[2], tap[2];
@@ -312,7 +303,6 @@ __device__ __forceinline__ void ly_mlp_bwd_body(const LyMlpBwdArgs& P) {
           const int ty = tap[h] / 3, tx = tap[h] - 3 * ty;
           off[h] = (ty * rowpitch + tx) * RSP + 8 * cq4;
         }
-        bf16x8 xh[NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
           bf16x4 ph[2];
@@ -322,16 +312,18 @@ __device__ __forceinline__ void ly_mlp_bwd_body(const LyMlpBwdArgs& P) {
             const bf16x4 a = *reinterpret_cast<const bf16x4*>(ps + pbase[n] + off[h]);
             ph[h] = ok ? a : z4;
           }
-          xh[n] = ly_cat8(ph[0], ph[1]);
+          xh[s][n] = ly_cat8(ph[0], ph[1]);
         }
 #pragma unroll
-        for (int t = 0; t < PT; ++t) {
-          const LyWF<1> wf = wnext(t * SP + s);
-#pragma unroll
-          for (int n = 0; n < NT; ++n) accp[t][n] = ly_mfma_bf16(wf.hi, xh[n], accp[t][n]);
-          wrefill();
-        }
+        for (int t = 0; t < PT; ++t) wpf[s][t] = wlds(t * SP + s);
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < SP; ++s)
+#pragma unroll
+        for (int t = 0; t < PT; ++t)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) accp[t][n] = ly_mfma_bf16(wpf[s][t], xh[s][n], accp[t][n]);
 #pragma unroll
       for (int t = 0; t < PT; ++t)
 #pragma unroll
@@ -344,7 +336,7 @@ __device__ __forceinline__ void ly_mlp_bwd_body(const LyMlpBwdArgs& P) {
         }
     }
 
-    // ---- 2. hidden chunks: u = W1 z, dh = W2^T dy, dv / du / h in registers, g += W1^T du -----------------------------------------
+    // ---- 2. hidden chunks: u = W1 z, dh = W2^T dy, dv / du / h in registers, g += W1^T du; du / h -> LDS, dW per round -------------
     bool okp[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) okp[n] = gpix(pixbase + 16 * n + li) >= 0;
@@ -356,108 +348,179 @@ __device__ __forceinline__ void ly_mlp_bwd_body(const LyMlpBwdArgs& P) {
         for (int n = 0; n < NT; ++n) acco[t][n] = zero;
     }
 #pragma unroll
-    for (int hc = 0; hc < HTP / HT; ++hc) {
-      f32x4 au[HT][NT], ad[HT][NT];
+    for (int rd = 0; rd < NRD; ++rd) {
 #pragma unroll
-      for (int t = 0; t < HT; ++t)
+      for (int hq = 0; hq < DT / HT; ++hq) {
+        const int hc = rd * (DT / HT) + hq;                 // hidden chunk of HT tiles
+        if (hc * HT >= HTR) continue;
+        f32x4 au[HT][NT], ad[HT][NT];
 #pragma unroll
-        for (int n = 0; n < NT; ++n) { au[t][n] = zero; ad[t][n] = zero; }
+        for (int t = 0; t < HT; ++t)
 #pragma unroll
-      for (int s = 0; s < S1; ++s) {
-        bf16x8 xb[NT];
+          for (int n = 0; n < NT; ++n) { au[t][n] = zero; ad[t][n] = zero; }
+        // all operands of the chunk's two contractions (and, pass 2, of its share of g = W1^T du) in flight together, one wait
+        bf16x8 xb[S1][NT], db[S1][NT], w1f[S1][HT], w2f[S1][HT];
+        bf16x8 wtf[PASS == 2 ? HT / 2 : 1][PASS == 2 ? C16 : 1];
 #pragma unroll
-        for (int n = 0; n < NT; ++n) xb[n] = ly_lds_frag(xs, (pixbase + 16 * n + li) * RS, s, lq);
+        for (int s = 0; s < S1; ++s) {
 #pragma unroll
-        for (int t = 0; t < HT; ++t) {
-          if (WLDS && hc * HT + t >= HTR) continue;              // padded hidden tile: nothing to contract (LDS weights are indexed, not sequenced)
-          const LyWF<1> wf = wnext(NFP + (hc * HT + t) * S1 + s);
-#pragma unroll
-          for (int n = 0; n < NT; ++n) au[t][n] = ly_mfma_bf16(wf.hi, xb[n], au[t][n]);
-          wrefill();
-        }
-      }
-#pragma unroll
-      for (int s = 0; s < S1; ++s) {
-        bf16x8 db[NT];
-#pragma unroll
-        for (int n = 0; n < NT; ++n) db[n] = ly_lds_frag(dys, (pixbase + 16 * n + li) * RS, s, lq);
-#pragma unroll
-        for (int t = 0; t < HT; ++t) {
-          if (WLDS && hc * HT + t >= HTR) continue;
-          const LyWF<1> wf = wnext(NFP + NF1 + (hc * HT + t) * S1 + s);
-#pragma unroll
-          for (int n = 0; n < NT; ++n) ad[t][n] = ly_mfma_bf16(wf.hi, db[n], ad[t][n]);
-          wrefill();
-        }
-      }
-      bf16x4 dub[HT][NT], hb[HT][NT];
-#pragma unroll
-      for (int t = 0; t < HT; ++t) {
-        const int tg = hc * HT + t;
-        if (tg >= HTR) {
-#pragma unroll
-          for (int n = 0; n < NT; ++n) { dub[t][n] = z4; hb[t][n] = z4; }
-          continue;
-        }
-        const int ch = tg * 16 + 4 * lq;
-        const f32x4 a4 = ly_ldg4(P.a + ch), b4 = ly_ldg4(P.b + ch);
-        f32x4 al4 = zero, ka4 = zero, la4 = zero;
-        if constexpr (PASS == 2) { al4 = ly_ldg4(P.alpha + ch); ka4 = ly_ldg4(P.kappa + ch); la4 = ly_ldg4(P.lambda + ch); }
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-          f32x4 du4, h4;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float u = au[t][n][r];
-            const float v = u * a4[r] + b4[r];
-            const bool pos = v > 0.f;
-            const float dvv = pos ? ad[t][n][r] : 0.f;             // (dy is staged as zeros for pixels outside the map: dv = 0 there)
-            if constexpr (PASS == 1) {
-              st1[tg][r] += dvv;
-              st2[tg][r] += dvv * u;
-            } else {
-              du4[r] = okp[n] ? al4[r] * dvv + ka4[r] + la4[r] * u : 0.f;
-              h4[r] = pos ? v : 0.f;
-            }
+          for (int n = 0; n < NT; ++n) {
+            xb[s][n] = ly_lds_frag(xs, (pixbase + 16 * n + li) * RS, s, lq);
+            db[s][n] = ly_lds_frag(dys, (pixbase + 16 * n + li) * RS, s, lq);
           }
-          if constexpr (PASS == 2) {
-            dub[t][n] = ly_cvtb4(du4);
-            hb[t][n] = ly_cvtb4(h4);
+#pragma unroll
+          for (int t = 0; t < HT; ++t) {
+            if (hc * HT + t >= HTR) continue;                // padded hidden tile: nothing to contract
+            w1f[s][t] = wlds(NFP + (hc * HT + t) * S1 + s);
+            w2f[s][t] = wlds(NFP + NF1 + (hc * HT + t) * S1 + s);
           }
         }
-      }
-      if constexpr (PASS == 2) {
+        if constexpr (PASS == 2) {
 #pragma unroll
-        for (int u2 = 0; u2 < HT / 2; ++u2) {
-          if (WLDS && hc * HT + 2 * u2 >= HTR) continue;
-          bf16x8 kb[NT];
+          for (int u2 = 0; u2 < HT / 2; ++u2) {
+            if (hc * HT + 2 * u2 >= HTR) continue;
 #pragma unroll
-          for (int n = 0; n < NT; ++n) kb[n] = ly_cat8(dub[2 * u2][n], dub[2 * u2 + 1][n]);
-#pragma unroll
-          for (int ct = 0; ct < C16; ++ct) {
-            const LyWF<1> wf = wnext(NFP + 2 * NF1 + ct * S2 + hc * (HT / 2) + u2);
-#pragma unroll
-            for (int n = 0; n < NT; ++n) acco[ct][n] = ly_mfma_bf16(wf.hi, kb[n], acco[ct][n]);
-            wrefill();
+            for (int ct = 0; ct < C16; ++ct) wtf[u2][ct] = wlds(NFP + 2 * NF1 + ct * S2 + hc * (HT / 2) + u2);
           }
         }
-        // du, h of the wave's own pixels -> its rows of the [pixel][hidden] tiles (8 bytes per lane and tile)
+        f32x4 cfa[HT], cfb[HT], cal[PASS == 2 ? HT : 1], cka[PASS == 2 ? HT : 1], cla[PASS == 2 ? HT : 1];
 #pragma unroll
         for (int t = 0; t < HT; ++t) {
           const int tg = hc * HT + t;
           if (tg >= HTR) continue;
+          const int ch = tg * 16 + 4 * lq;
+          cfa[t] = coef(0, ch); cfb[t] = coef(1, ch);
+          if constexpr (PASS == 2) { cal[t] = coef(2, ch); cka[t] = coef(3, ch); cla[t] = coef(4, ch); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < S1; ++s)
+#pragma unroll
+          for (int t = 0; t < HT; ++t) {
+            if (hc * HT + t >= HTR) continue;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+              au[t][n] = ly_mfma_bf16(w1f[s][t], xb[s][n], au[t][n]);
+              ad[t][n] = ly_mfma_bf16(w2f[s][t], db[s][n], ad[t][n]);
+            }
+          }
+        bf16x4 dub[HT][NT], hb[HT][NT];
+#pragma unroll
+        for (int t = 0; t < HT; ++t) {
+          const int tg = hc * HT + t;
+          if (tg >= HTR) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) { dub[t][n] = z4; hb[t][n] = z4; }
+            continue;
+          }
+          const f32x4 a4 = cfa[t], b4 = cfb[t];
+          f32x4 al4 = zero, ka4 = zero, la4 = zero;
+          if constexpr (PASS == 2) { al4 = cal[t]; ka4 = cka[t]; la4 = cla[t]; }
 #pragma unroll
           for (int n = 0; n < NT; ++n) {
-            const int ob = (pixbase + 16 * n + li) * RSD + 32 * tg + 8 * lq;
-            *reinterpret_cast<bf16x4*>(dus + ob) = dub[t][n];
-            *reinterpret_cast<bf16x4*>(hs + ob) = hb[t][n];
+            f32x4 du4, h4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float u = au[t][n][r];
+              const float v = u * a4[r] + b4[r];
+              const bool pos = v > 0.f;
+              const float dvv = pos ? ad[t][n][r] : 0.f;           // (dy is staged as zeros for pixels outside the map: dv = 0 there)
+              if constexpr (PASS == 1) {
+                st1[tg][r] += dvv;
+                st2[tg][r] += dvv * u;
+              } else {
+                du4[r] = okp[n] ? al4[r] * dvv + ka4[r] + la4[r] * u : 0.f;
+                h4[r] = pos ? v : 0.f;
+              }
+            }
+            if constexpr (PASS == 2) {
+              dub[t][n] = ly_cvtb4(du4);
+              hb[t][n] = ly_cvtb4(h4);
+            }
           }
+        }
+        if constexpr (PASS == 2) {
+#pragma unroll
+          for (int u2 = 0; u2 < HT / 2; ++u2) {
+            if (hc * HT + 2 * u2 >= HTR) continue;
+            bf16x8 kb[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) kb[n] = ly_cat8(dub[2 * u2][n], dub[2 * u2 + 1][n]);
+#pragma unroll
+            for (int ct = 0; ct < C16; ++ct)
+#pragma unroll
+              for (int n = 0; n < NT; ++n) acco[ct][n] = ly_mfma_bf16(wtf[u2][ct], kb[n], acco[ct][n]);
+          }
+          // du, h of the wave's own pixels -> its rows of the [pixel][hidden] tiles of this round (8 bytes per lane and tile)
+#pragma unroll
+          for (int t = 0; t < HT; ++t) {
+            const int tg = hc * HT + t;
+            if (tg >= HTR) continue;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+              const int ob = (pixbase + 16 * n + li) * RSD + 32 * (tg - rd * DT) + 8 * lq;
+              *reinterpret_cast<bf16x4*>(dus + ob) = dub[t][n];
+              *reinterpret_cast<bf16x4*>(hs + ob) = hb[t][n];
+            }
+          }
+        }
+      }
+      if constexpr (PASS == 2) {
+        // ---- 3. dW1 += du^T z, dW2^T += h^T dy (contraction index = pixel: transposed reads) ---------------------------------------
+        if constexpr (!DWX) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the wave's own LDS stores above are visible to its transposed reads below
+#pragma unroll
+          for (int ks = 0; ks < NT / 2; ++ks) {
+            const int row = pixbase + 32 * ks + r0;
+            bf16x8 bz[C16], bd[C16];
+#pragma unroll
+            for (int ct = 0; ct < C16; ++ct) {
+              bz[ct] = ly_cat8(mb_tr(xs + row * RS + 32 * ct + c8), mb_tr(xs + (row + 16) * RS + 32 * ct + c8));
+              bd[ct] = ly_cat8(mb_tr(dys + row * RS + 32 * ct + c8), mb_tr(dys + (row + 16) * RS + 32 * ct + c8));
+            }
+            bf16x8 a1[HTR], a2[HTR];
+#pragma unroll
+            for (int t = 0; t < HTR; ++t) {
+              a1[t] = ly_cat8(mb_tr(dus + row * RSD + 32 * t + c8), mb_tr(dus + (row + 16) * RSD + 32 * t + c8));
+              a2[t] = ly_cat8(mb_tr(hs + row * RSD + 32 * t + c8), mb_tr(hs + (row + 16) * RSD + 32 * t + c8));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < HTR; ++t)
+#pragma unroll
+              for (int ct = 0; ct < C16; ++ct) {
+                aw1[t * C16 + ct] = ly_mfma_bf16(a1[t], bz[ct], aw1[t * C16 + ct]);
+                aw2[t * C16 + ct] = ly_mfma_bf16(a2[t], bd[ct], aw2[t * C16 + ct]);
+              }
+          }
+        } else {
+          __syncthreads();                                         // every wave's du / h rows of this round (and its z rows) are in LDS
+          if (rd * DT + wave < HTR) {                              // wave-uniform: the transposed reads below run with all lanes active
+#pragma unroll
+            for (int ks = 0; ks < BP / 32; ++ks) {
+              const int row = 32 * ks + r0;
+              const bf16x8 a1 = ly_cat8(mb_tr(dus + row * RSD + 32 * wave + c8), mb_tr(dus + (row + 16) * RSD + 32 * wave + c8));
+              const bf16x8 a2 = ly_cat8(mb_tr(hs + row * RSD + 32 * wave + c8), mb_tr(hs + (row + 16) * RSD + 32 * wave + c8));
+              bf16x8 bz[C16], bd[C16];
+#pragma unroll
+              for (int ct = 0; ct < C16; ++ct) {
+                bz[ct] = ly_cat8(mb_tr(xs + row * RS + 32 * ct + c8), mb_tr(xs + (row + 16) * RS + 32 * ct + c8));
+                bd[ct] = ly_cat8(mb_tr(dys + row * RS + 32 * ct + c8), mb_tr(dys + (row + 16) * RS + 32 * ct + c8));
+              }
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int ct = 0; ct < C16; ++ct) {
+                aw1[rd * C16 + ct] = ly_mfma_bf16(a1, bz[ct], aw1[rd * C16 + ct]);
+                aw2[rd * C16 + ct] = ly_mfma_bf16(a2, bd[ct], aw2[rd * C16 + ct]);
+              }
+            }
+          }
+          if (rd + 1 < NRD) __syncthreads();                       // the next round overwrites the du / h tiles
         }
       }
     }
 
     if constexpr (PASS == 2) {
-      // ---- 3. g rows out; dW1 += du^T z, dW2^T += h^T dy over the wave's own pixels (contraction index = pixel: transposed reads) ----
 #pragma unroll
       for (int ct = 0; ct < C16; ++ct)
 #pragma unroll
@@ -466,28 +529,6 @@ __device__ __forceinline__ void ly_mlp_bwd_body(const LyMlpBwdArgs& P) {
           const long gp = gpix(pixbase + 16 * n + li);
           if (c < C && gp >= 0) ly_st4<T>(P.g + gp * C + c, acco[ct][n]);
         }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the wave's own LDS stores above are visible to its transposed reads below
-      const int r0 = 4 * lq + (li >> 2), c8 = 8 * (li & 3);
-#pragma unroll
-      for (int ks = 0; ks < NT / 2; ++ks) {
-        const int row = pixbase + 32 * ks + r0;
-        bf16x8 bz[C16], bd[C16];
-#pragma unroll
-        for (int ct = 0; ct < C16; ++ct) {
-          bz[ct] = ly_cat8(mb_tr(xs + row * RS + 32 * ct + c8), mb_tr(xs + (row + 16) * RS + 32 * ct + c8));
-          bd[ct] = ly_cat8(mb_tr(dys + row * RS + 32 * ct + c8), mb_tr(dys + (row + 16) * RS + 32 * ct + c8));
-        }
-#pragma unroll
-        for (int t = 0; t < HTR; ++t) {
-          const bf16x8 a1 = ly_cat8(mb_tr(dus + row * RSD + 32 * t + c8), mb_tr(dus + (row + 16) * RSD + 32 * t + c8));
-          const bf16x8 a2 = ly_cat8(mb_tr(hs + row * RSD + 32 * t + c8), mb_tr(hs + (row + 16) * RSD + 32 * t + c8));
-#pragma unroll
-          for (int ct = 0; ct < C16; ++ct) {
-            aw1[t * C16 + ct] = ly_mfma_bf16(a1, bz[ct], aw1[t * C16 + ct]);
-            aw2[t * C16 + ct] = ly_mfma_bf16(a2, bd[ct], aw2[t * C16 + ct]);
-          }
-        }
-      }
     }
     __syncthreads();                                               // every wave is done with the halo image / the tiles
     if constexpr (T2D) {
@@ -500,38 +541,53 @@ __device__ __forceinline__ void ly_mlp_bwd_body(const LyMlpBwdArgs& P) {
 #pragma unroll
     for (int t = 0; t < HTR; ++t) ly_stats_flush(P.stats, 2 * C, t * 16 + 4 * lq, st1[t], st2[t]);
   } else {
-    // the four waves' accumulator tiles meet in LDS in wave order (fixed summation order), the block writes ONE slab
-    float* const red = reinterpret_cast<float*>(xs);              // (tiles are dead: every wave passed the loop's last barrier)
-    constexpr int RED_FLOATS = Bg::SLAB;
-    static_assert(RED_FLOATS * 4 <= 2 * BP * RS + 2 * BP * RSD, "reduction scratch must fit the tile area");
-    for (int w = 0; w < 4; ++w) {
-      if (wave == w) {
+    f32x4* const out = reinterpret_cast<f32x4*>(P.slab + (size_t)blockIdx.x * Bg::SLAB);
+    if constexpr (DWX) {
+      // every (hidden tile, channel tile) entry has ONE owner wave: straight to the slab
 #pragma unroll
-        for (int i = 0; i < Bg::NACC; ++i) {
-          f32x4* const p1 = reinterpret_cast<f32x4*>(red) + i * 64 + lane;
-          f32x4* const p2 = reinterpret_cast<f32x4*>(red) + (Bg::NACC + i) * 64 + lane;
-          if (w == 0) { *p1 = aw1[i]; *p2 = aw2[i]; }
-          else { *p1 = *p1 + aw1[i]; *p2 = *p2 + aw2[i]; }
+      for (int rd = 0; rd < NRD; ++rd) {
+        const int t = rd * DT + wave;
+        if (t < HTR) {
+#pragma unroll
+          for (int ct = 0; ct < C16; ++ct) {
+            out[(t * C16 + ct) * 64 + lane] = aw1[rd * C16 + ct];
+            out[(Bg::NACC + t * C16 + ct) * 64 + lane] = aw2[rd * C16 + ct];
+          }
         }
       }
-      __syncthreads();
+    } else {
+      // the four waves' accumulator tiles meet in LDS in wave order (fixed summation order), the block writes ONE slab
+      float* const red = reinterpret_cast<float*>(xs);            // (tiles are dead: every wave passed the loop's last barrier)
+      constexpr int RED_FLOATS = Bg::SLAB;
+      static_assert(DWX || RED_FLOATS * 4 <= 2 * BP * RS + 2 * BP * RSD, "reduction scratch must fit the tile area");
+      for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+          for (int i = 0; i < NAW; ++i) {
+            f32x4* const p1 = reinterpret_cast<f32x4*>(red) + i * 64 + lane;
+            f32x4* const p2 = reinterpret_cast<f32x4*>(red) + (Bg::NACC + i) * 64 + lane;
+            if (w == 0) { *p1 = aw1[i]; *p2 = aw2[i]; }
+            else { *p1 = *p1 + aw1[i]; *p2 = *p2 + aw2[i]; }
+          }
+        }
+        __syncthreads();
+      }
+      for (int i = tid; i < RED_FLOATS / 4; i += LY_THREADS) out[i] = reinterpret_cast<const f32x4*>(red)[i];
     }
-    f32x4* const out = reinterpret_cast<f32x4*>(P.slab + (size_t)blockIdx.x * Bg::SLAB);
-    for (int i = tid; i < RED_FLOATS / 4; i += LY_THREADS) out[i] = reinterpret_cast<const f32x4*>(red)[i];
   }
 }
 
-template <int C, int NT, int HT, bool T2D, bool WLDS, int PASS, int D>
+template <int C, int HT, bool T2D, int PASS>
 __global__ __launch_bounds__(LY_THREADS) void ly_mlpblock_bwd_kernel(const LyMlpBwdArgs P) {
-  ly_mlp_bwd_body<C, NT, HT, T2D, WLDS, PASS, D>(P);
+  ly_mlp_bwd_body<C, HT, T2D, PASS>(P);
 }
 
 // dw1[hid][c] += sum_b slab[b][0][t][ct][lane][r],  dw2[c][hid] += sum_b slab[b][1][...]   with hid = 16 t + 4 (lane >> 4) + r, c = 16 ct + (lane & 15)
 // (fixed block order: bit-reproducible).  Block = 64 consecutive float4 slab entries x RL row lanes over the blocks.
-template <int C, int NT>
+template <int C>
 __global__ __launch_bounds__(1024) void ly_mlpblock_bwd_combine_kernel(const float* __restrict__ slab, const int nblk, float* __restrict__ dw1,
                                                                       float* __restrict__ dw2, const int rls) {
-  using Bg = MlpBwdGeom<C, NT>;
+  using Bg = MlpBwdGeom<C>;
   constexpr int C16 = MlpGeom<C>::C16;
   __shared__ f32x4 red[16][64];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
@@ -567,16 +623,16 @@ __global__ __launch_bounds__(1024) void ly_mlpblock_bwd_combine_kernel(const flo
   }
 }
 
-template <int C, int NT, int HT, bool T2D, bool WLDS, int PASS, int D>
+template <int C, int HT, bool T2D, int PASS>
 static int launch_mlp_bwd(LyMlpBwdArgs P, long slab_floats, int* blocks_out, hipStream_t st) {
   using Gm = MlpGeom<C>;
-  using Bg = MlpBwdGeom<C, NT>;
-  constexpr int BP = Bg::BP;
+  using Bg = MlpBwdGeom<C>;
+  constexpr int BP = Bg::BP, NT = Bg::NT;
   const long halo = T2D ? (4 * NT + 2) * 18 : BP + 2 * P.W + 2;
-  const size_t lds = (WLDS ? (size_t)Bg::NFW * 1024 : 0) + 2 * (size_t)BP * Gm::RS + ((size_t)halo * Gm::RSP + 15) / 16 * 16 +
-                     (PASS == 2 ? 2 * (size_t)BP * Bg::RSD : 0);
+  const size_t lds = (size_t)(Bg::NFP + 2 * Bg::NF1 + (PASS == 2 ? Bg::NF1T : 0)) * 1024 + (PASS == 2 ? 5 : 2) * 2 * C * 4 + 2 * (size_t)BP * Gm::RS +
+                     ((size_t)halo * Gm::RSP + 15) / 16 * 16 + (PASS == 2 ? 2 * (size_t)BP * Bg::RSD : 0);
   LY_CHECK(lds <= 160 * 1024, "mlpblock_bwd: tile needs %zu B of LDS (C=%d W=%d)", lds, C, P.W);
-  auto k = ly_mlpblock_bwd_kernel<C, NT, HT, T2D, WLDS, PASS, D>;
+  auto k = ly_mlpblock_bwd_kernel<C, HT, T2D, PASS>;
   static LyDevOnce once;
   static int per_cu = 0;
   static size_t lds_q = 0;
@@ -589,7 +645,7 @@ static int launch_mlp_bwd(LyMlpBwdArgs P, long slab_floats, int* blocks_out, hip
     per_cu = nb < 1 ? 1 : (nb > 8 ? 8 : nb);
     lds_q = lds;
   }
-  const long ntiles = T2D ? (long)P.n_img * ((P.H + 4 * NT - 1) / (4 * NT)) * (P.W / 16) : (P.M + BP - 1) / BP;
+  const long ntiles = T2D ? (long)P.n_img * ((P.H + 4 * NT - 1) / (4 * NT)) * ((P.W + 15) / 16) : (P.M + BP - 1) / BP;
   LY_CHECK(ntiles < (1L << 30), "mlpblock_bwd: too many tiles");
   long blocks = 256L * per_cu;
   if (blocks > ntiles) blocks = ntiles;
@@ -604,20 +660,30 @@ static int launch_mlp_bwd(LyMlpBwdArgs P, long slab_floats, int* blocks_out, hip
   return 0;
 }
 
-template <int C, int NT>
+template <int C>
 static int launch_mlp_bwd_combine(const float* slab, int nblk, float* dw1, float* dw2, hipStream_t st) {
-  using Bg = MlpBwdGeom<C, NT>;
+  using Bg = MlpBwdGeom<C>;
   const int rls = nblk <= 64 ? 4 : 16;
-  hipLaunchKernelGGL((ly_mlpblock_bwd_combine_kernel<C, NT>), dim3((Bg::SLAB / 4 + 63) / 64), dim3(64 * rls), 0, st, slab, nblk, dw1, dw2, rls);
+  hipLaunchKernelGGL((ly_mlpblock_bwd_combine_kernel<C>), dim3((Bg::SLAB / 4 + 63) / 64), dim3(64 * rls), 0, st, slab, nblk, dw1, dw2, rls);
   LY_LAUNCH_CHECK();
   return 0;
 }
 
-// (C, tiling) table: persistent T2D patches where the map is a multiple of 16 wide, flattened runs otherwise; weights resident in LDS.
-// C >= 80 is not built: the wave-private weight-gradient accumulators (2 x HTR x C16 tiles) would need 400 registers at C = 80.
+// patches (with the next patch prefetched) unless more than a quarter of the 16-wide patch columns would lie outside the map
 template <int C, int HT, int PASS>
 static int dispatch_mlp_bwd(LyMlpBwdArgs P, long slab_floats, int* blocks_out, hipStream_t st) {
-  static_assert(C < 80, "wave-private weight-gradient accumulators: C < 80");
-  if ((P.W & 15) == 0 && P.W >= 32) return launch_mlp_bwd<C, 2, HT, true, true, PASS, 0>(P, slab_floats, blocks_out, st);
-  return launch_mlp_bwd<C, 2, HT, false, true, PASS, 0>(P, slab_floats, blocks_out, st);
+  const int wp16 = (P.W + 15) / 16 * 16;
+  if (P.W >= 12 && 4 * (wp16 - P.W) <= wp16) return launch_mlp_bwd<C, HT, true, PASS>(P, slab_floats, blocks_out, st);
+  return launch_mlp_bwd<C, HT, false, PASS>(P, slab_floats, blocks_out, st);
 }
+
+template <int C, int HT>
+static int mlp_bwd_pass(LyMlpBwdArgs P, int pass, long slab_floats, float* dw1, float* dw2, hipStream_t st) {
+  if (pass == 1) return dispatch_mlp_bwd<C, HT, 1>(P, 0, nullptr, st);
+  int blocks = 0;
+  const int rc = dispatch_mlp_bwd<C, HT, 2>(P, slab_floats, &blocks, st);
+  if (rc) return rc;
+  return launch_mlp_bwd_combine<C>(P.slab, blocks, dw1, dw2, st);
+}
+
+int ly_mlp_bwd_pass_80(LyMlpBwdArgs P, int pass, long slab_floats, float* dw1, float* dw2, hipStream_t st);

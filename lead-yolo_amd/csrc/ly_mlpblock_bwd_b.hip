@@ -1,0 +1,3 @@
+// Fused MLPBlock backward, C = 80 instantiation (see ly_mlpblock_bwd.hpp)
+#include "ly_mlpblock_bwd.hpp"
+int ly_mlp_bwd_pass_80(LyMlpBwdArgs P, int pass, long slab_floats, float* dw1, float* dw2, hipStream_t st) { return mlp_bwd_pass<80, 2>(P, pass, slab_floats, dw1, dw2, st); }

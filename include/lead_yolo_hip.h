@@ -57,6 +57,13 @@ long ly_mlpblock_bwd_slab_floats(int C);
 int ly_mlpblock_bwd(const void* x /*T*/, const void* dy /*T*/, void* g /*T*/, int n_img, int H, int W, int C, const void* wp, const void* w1,
                     const void* w2t, const void* w1t, const float* a, const float* b, const float* alpha, const float* kappa, const float* lambda,
                     double* stats, float* slab, long slab_floats, float* dw1, float* dw2, int pass, int dtype, void* stream);
+/* The tail of the MLPBlock backward in one launch, bf16: dx = dy + [pconv^T(g[:, :C/4]) | g[:, C/4:]] (the partial conv's data gradient — wpt = the
+ * transposed-flipped taps, frag-packed like wp — plus the residual of MLPBlock.forward, models/common.py:1478-1482) and, where built (2-D patches,
+ * C/4 <= 32: returns 0), dwp[co * lddw + tap * dw_ts + ci * dw_cs] += sum_p g[p][co] x[p + tap][ci], the gradient of partial_conv3.weight
+ * (models/common.py:1412-1437), through `slab` (ly_mlpblock_bwd_slab_floats(C) floats) and a fixed-order combine.  Returns 1 when only dx was
+ * produced (the caller then runs ly_wgrad on (g, x)).  g, dy, x, dx dense [n*H*W, C], 16-byte aligned, dx not aliasing g / dy.  C in {16,24,40,80,160,320}. */
+int ly_mlpblock_bwd_dx(const void* g /*T*/, const void* dy /*T*/, const void* x /*T*/, void* dx /*T*/, int n_img, int H, int W, int C, const void* wpt,
+                       float* slab, long slab_floats, float* dwp, int lddw, int dw_ts, int dw_cs, int dtype, void* stream);
 /* hidden (2C) channel tiles of 16, padded to an even count */
 int ly_mlpblock_hidden_tiles(int C);
 

@@ -687,3 +687,416 @@ static int mlp_bwd_pass(LyMlpBwdArgs P, int pass, long slab_floats, float* dw1, 
 }
 
 int ly_mlp_bwd_pass_80(LyMlpBwdArgs P, int pass, long slab_floats, float* dw1, float* dw2, hipStream_t st);
+
+// -------------------------------------------------------------------------------------------------------------------------------------------
+// The tail of the MLPBlock backward in ONE launch (was: partial-conv weight gradient through the generic tiled kernel — 84 us at 160 x 160 x 24,
+// 0.6 TB/s: a 72-wide K of which a quarter is real —, the partial conv's data gradient as a map-sized pass, and a third pass for the residual):
+//      dx = dy + [ pconv^T(g[:, :C/4]) | g[:, C/4:] ]                 (Partial_conv3.forward_split_cat + the residual of MLPBlock.forward under autograd)
+//      dWp[co][tap][ci] += sum_p g[p][co] x[p + tap][ci]               (partial_conv3.weight)
+// Per patch: the g tile, and the halo frames of the first C/4 channels of BOTH g and x, go to LDS (the next patch's pixels and dy are in flight in
+// registers meanwhile); the transposed-flipped 3x3 runs as in the forward and overwrites the tile's first C/4 channels; every thread then adds dy
+// to its 16-byte pieces of the tile and stores dx.  The weight gradient contracts over the wave's own pixels with both operands read TRANSPOSED
+// out of the halo frames (a tap is a constant offset of the x frame; out-of-image positions are staged zeros): 9 accumulator tiles per wave for
+// C/4 <= 16, kept over the block's patch walk, folded over the waves in LDS and over the blocks by ly_mlpblock_bwd_dx_combine (fixed order).
+// WG = false (flattened runs / C/4 > 32): dx only — the caller launches ly_wgrad for dWp.
+// -------------------------------------------------------------------------------------------------------------------------------------------
+struct LyMlpDxArgs {
+  const __bf16* g;
+  const __bf16* dy;
+  const __bf16* x;
+  __bf16* dx;
+  long M;
+  int H, W, n_img, ntiles;
+  const uint4* wpt;              // transposed-flipped taps, frag-packed like wp
+  float* slab;                   // [gridDim.x][9 * PT * PT * 256]
+};
+
+template <int C, bool T2D, bool WG>
+__device__ __forceinline__ void ly_mlp_bwd_dx_body(const LyMlpDxArgs& P) {
+  using Gm = MlpGeom<C>;
+  using T = __bf16;
+  typedef ly_u32x4 RV;
+  typedef ly_u32x2 R4;
+  constexpr int VW = 8, NT = 2, BP = 64 * NT, TH = 4 * NT;
+  constexpr int CQ = Gm::CQ, G = Gm::G, SP = Gm::SP, PT = Gm::PT, KP = Gm::KP, RS = Gm::RS, RSP = Gm::RSP;
+  constexpr int NFP = PT * SP;
+  static_assert(!WG || T2D, "in-kernel weight gradient: 2-D patches only");
+  const int H = P.H, W = P.W;
+  const long M = P.M;
+  const int BPH = T2D ? (TH + 2) * 18 : BP + 2 * W + 2;
+  const int PSB = (BPH * RSP + 15 + 64) / 16 * 16;          // bytes of one halo frame (+ slack: transposed reads of the last rows run past CQP channels)
+
+  extern __shared__ f32x4 ly_smem4[];
+  char* const wl = reinterpret_cast<char*>(ly_smem4);
+  char* const xs = wl + NFP * 1024;
+  char* const psg = xs + BP * RS;
+  char* const psx = psg + PSB;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lq = lane >> 4;
+  const f32x4 zero = ly_zero4();
+  for (int i = tid; i < NFP * 64; i += LY_THREADS) reinterpret_cast<uint4*>(wl)[i] = P.wpt[i];
+  auto wlds = [&](int fi) -> bf16x8 { return *reinterpret_cast<const bf16x8*>(wl + (fi * 64 + lane) * 16); };
+  if constexpr (WG) {                                       // slack rows past the frames: finite values for the transposed reads
+    for (int i = tid; i < 64 / 4; i += LY_THREADS) {
+      reinterpret_cast<float*>(psg + PSB - 64)[i] = 0.f;
+      reinterpret_cast<float*>(psx + PSB - 64)[i] = 0.f;
+    }
+  }
+
+  const int tw = T2D ? ((W + 15) >> 4) : 1, th = T2D ? (H + TH - 1) / TH : 1;
+  long img0 = 0, p0 = 0;
+  int h0 = 0, w0 = 0;
+  auto decode = [&](int tile, long& i0, int& hh0, int& ww0, long& q0) {
+    if constexpr (T2D) {
+      int b = tile;
+      const int tx = b % tw; b /= tw;
+      const int ty = b % th;
+      i0 = (long)(b / th) * H * W;
+      hh0 = ty * TH; ww0 = tx * 16;
+      q0 = 0;
+    } else {
+      i0 = 0; hh0 = 0; ww0 = 0;
+      q0 = (long)tile * BP;
+    }
+  };
+  // global pixel index of tile-local pixel `pix` of tile (i0, hh0, ww0, q0), or -1
+  auto gpix_of = [&](int pix, long i0, int hh0, int ww0, long q0) -> long {
+    if constexpr (T2D) {
+      const int r = pix >> 4, cx = pix & 15;
+      return (hh0 + r < H && ww0 + cx < W) ? i0 + (long)(hh0 + r) * W + ww0 + cx : -1;
+    } else {
+      const long gp = q0 + pix;
+      return gp < M ? gp : -1;
+    }
+  };
+
+  constexpr int TVN = BP * (KP / VW), NVT = (TVN + LY_THREADS - 1) / LY_THREADS;
+  constexpr int HVN = T2D ? (TH + 2) * 18 * G : 1, NVH = T2D ? (HVN + LY_THREADS - 1) / LY_THREADS : 1;
+  RV tv[NVT], dv_[NVT];
+  R4 hg[NVH], hx[WG ? NVH : 1];
+  bool tok[NVT], hok[NVH];
+  long toff[NVT];                                           // element offset of the thread's pieces in g / dy / dx (the patch being computed)
+  auto issue = [&](int tile, bool keep_off) {
+    long i0, q0; int hh0, ww0;
+    decode(tile, i0, hh0, ww0, q0);
+#pragma unroll
+    for (int e = 0; e < NVT; ++e) {
+      const int idx = tid + e * LY_THREADS;
+      const int pix = idx / (KP / VW), c4 = idx - pix * (KP / VW);
+      const long gp = gpix_of(pix, i0, hh0, ww0, q0);
+      tok[e] = idx < TVN && gp >= 0 && c4 * VW < C;
+      const long off = tok[e] ? gp * C + c4 * VW : 0;
+      if (keep_off) toff[e] = tok[e] ? off : -1;
+      tv[e] = ly_ldrv<T>(P.g + off);
+      dv_[e] = ly_ldrv<T>(P.dy + off);
+    }
+    if constexpr (T2D) {
+#pragma unroll
+      for (int e = 0; e < NVH; ++e) {
+        const int idx = tid + e * LY_THREADS;
+        const int hp = idx / G, c4 = idx - hp * G;
+        const int hr = hp / 18, hc = hp - hr * 18;
+        const int hh = hh0 - 1 + hr, ww = ww0 - 1 + hc;
+        hok[e] = idx < HVN && hh >= 0 && hh < H && ww >= 0 && ww < W;
+        const long off = hok[e] ? (i0 + (long)hh * W + ww) * C + c4 * 4 : 0;
+        hg[e] = ly_ldr4<T>(P.g + off);
+        if constexpr (WG) hx[e] = ly_ldr4<T>(P.x + off);
+      }
+    }
+  };
+  RV dyk[NVT];                                              // dy pieces of the patch being computed (the prefetch registers are re-used for the next)
+  long koff[NVT];
+  auto commit = [&]() {
+#pragma unroll
+    for (int e = 0; e < NVT; ++e) {
+      const int idx = tid + e * LY_THREADS;
+      const int pix = idx / (KP / VW), c4 = idx - pix * (KP / VW);
+      RV v = tv[e];
+      if (!tok[e]) ly_zero_raw(v);
+      if (idx < TVN) *reinterpret_cast<RV*>(xs + pix * RS + 2 * VW * c4) = v;
+      dyk[e] = dv_[e];
+      koff[e] = toff[e];
+    }
+    if constexpr (T2D) {
+#pragma unroll
+      for (int e = 0; e < NVH; ++e) {
+        const int idx = tid + e * LY_THREADS;
+        const int hp = idx / G, c4 = idx - hp * G;
+        R4 v = hg[e];
+        if (!hok[e]) ly_zero_raw(v);
+        if (idx < HVN) *reinterpret_cast<R4*>(psg + hp * RSP + 8 * c4) = v;
+        if constexpr (WG) {
+          R4 u = hx[e];
+          if (!hok[e]) ly_zero_raw(u);
+          if (idx < HVN) *reinterpret_cast<R4*>(psx + hp * RSP + 8 * c4) = u;
+        }
+      }
+    }
+  };
+  auto stage_flat_halo = [&](int tile) {
+    const long q0 = (long)tile * BP;
+    ly_stage_raw<4, R4>(BPH * G, tid, P.g,
+        [&](int idx) -> const void* {
+          const int hp = idx / G, c4 = idx - hp * G;
+          const long gp = q0 - W - 1 + hp;
+          return (gp >= 0 && gp < M) ? P.g + gp * C + c4 * 4 : nullptr;
+        },
+        [&](int idx, R4 v) {
+          const int hp = idx / G, c4 = idx - hp * G;
+          *reinterpret_cast<R4*>(psg + hp * RSP + 8 * c4) = v;
+        });
+  };
+
+  constexpr int NAW = WG ? 9 * PT * PT : 1;
+  f32x4 aw[NAW];
+#pragma unroll
+  for (int i = 0; i < NAW; ++i) aw[i] = zero;
+
+  int tile = blockIdx.x;
+  if (tile < P.ntiles) {
+    issue(tile, true);
+    commit();
+    if constexpr (!T2D) stage_flat_halo(tile);
+  }
+  __syncthreads();
+  const int pixbase = wave * (16 * NT);
+  const bf16x4 z4 = __builtin_bit_cast(bf16x4, make_uint2(0u, 0u));
+  const int r0 = 4 * lq + (li >> 2), c8 = 8 * (li & 3);
+
+  for (; tile < P.ntiles; tile += gridDim.x) {
+    const int nxt = tile + (int)gridDim.x < P.ntiles ? tile + (int)gridDim.x : tile;
+    issue(nxt, true);
+    decode(tile, img0, h0, w0, p0);
+
+    // ---- weight gradient of the partial conv: both operands transposed out of the halo frames (before the conv overwrites nothing of them) ----
+    if constexpr (WG) {
+#pragma unroll
+      for (int ks = 0; ks < NT / 2; ++ks) {
+        int hb[2];                                         // frame offset (tap 0, 0) of the lane's two fetched pixels
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int pix = pixbase + 32 * ks + 16 * e + r0;
+          hb[e] = ((pix >> 4) * 18 + (pix & 15)) * RSP + c8;
+        }
+        bf16x8 ag[PT], bx[9][PT];
+#pragma unroll
+        for (int t = 0; t < PT; ++t)                       // centre tap of the g frame = g at the pixel itself
+          ag[t] = ly_cat8(mb_tr(psg + hb[0] + 19 * RSP + 32 * t), mb_tr(psg + hb[1] + 19 * RSP + 32 * t));
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+          for (int t = 0; t < PT; ++t) {
+            const int to = ((tap / 3) * 18 + tap % 3) * RSP + 32 * t;
+            bx[tap][t] = ly_cat8(mb_tr(psx + hb[0] + to), mb_tr(psx + hb[1] + to));
+          }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+          for (int to = 0; to < PT; ++to)
+#pragma unroll
+            for (int ti = 0; ti < PT; ++ti) aw[(tap * PT + to) * PT + ti] = ly_mfma_bf16(ag[to], bx[tap][ti], aw[(tap * PT + to) * PT + ti]);
+      }
+    }
+
+    // ---- pconv^T(g[:C/4]) into the tile's first C/4 channels (the forward's partial conv with the transposed-flipped taps) ----
+    {
+      uint32_t tmask[NT];
+      int pbase[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int pix = pixbase + 16 * n + li;
+        if constexpr (T2D) {
+          tmask[n] = 0x1ffu;
+          pbase[n] = ((pix >> 4) * 18 + (pix & 15)) * RSP;
+        } else {
+          const long gp = p0 + pix;
+          int h_, w_;
+          ly_pix_hw(gp < M ? gp : 0, H, W, h_, w_);
+          tmask[n] = ly_tapmask(h_, w_, H, W, gp < M);
+          pbase[n] = pix * RSP;
+        }
+      }
+      const int rowpitch = T2D ? 18 : W;
+      f32x4 accp[PT][NT];
+#pragma unroll
+      for (int t = 0; t < PT; ++t)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) accp[t][n] = zero;
+      bf16x8 xh[SP][NT], wpf[SP][PT];
+#pragma unroll
+      for (int s = 0; s < SP; ++s) {
+        int off[2], tap[2];
+        bool gv[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int gq = 8 * s + 4 * h + lq;
+          gv[h] = gq < 9 * G;
+          tap[h] = gv[h] ? gq / G : 0;
+          const int cq4 = gv[h] ? gq - tap[h] * G : 0;
+          const int ty = tap[h] / 3, tx = tap[h] - 3 * ty;
+          off[h] = (ty * rowpitch + tx) * RSP + 8 * cq4;
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          bf16x4 ph[2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const bool ok = gv[h] && (T2D || ((tmask[n] >> tap[h]) & 1u));
+            const bf16x4 a = *reinterpret_cast<const bf16x4*>(psg + pbase[n] + off[h]);
+            ph[h] = ok ? a : z4;
+          }
+          xh[s][n] = ly_cat8(ph[0], ph[1]);
+        }
+#pragma unroll
+        for (int t = 0; t < PT; ++t) wpf[s][t] = wlds(t * SP + s);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < SP; ++s)
+#pragma unroll
+        for (int t = 0; t < PT; ++t)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) accp[t][n] = ly_mfma_bf16(wpf[s][t], xh[s][n], accp[t][n]);
+#pragma unroll
+      for (int t = 0; t < PT; ++t)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const bf16x4 h = ly_cvtb4(accp[t][n]);
+          const int c = 16 * t + 4 * lq;
+          const int rb = (pixbase + 16 * n + li) * RS + 2 * c;
+          if (c < CQ) *reinterpret_cast<bf16x2*>(xs + rb) = __builtin_shufflevector(h, h, 0, 1);
+          if (c + 2 < CQ) *reinterpret_cast<bf16x2*>(xs + rb + 4) = __builtin_shufflevector(h, h, 2, 3);
+        }
+    }
+    __syncthreads();                                         // the tile holds [pconv^T(g_p) | g_r] for every wave's rows
+
+    // ---- dx = dy + tile: every thread its own 16-byte pieces (the mapping of the staging) ----
+#pragma unroll
+    for (int e = 0; e < NVT; ++e) {
+      const int idx = tid + e * LY_THREADS;
+      const int pix = idx / (KP / VW), c4 = idx - pix * (KP / VW);
+      if (idx < TVN && koff[e] >= 0) {
+        const RV zt = *reinterpret_cast<const RV*>(xs + pix * RS + 2 * VW * c4);
+        f32x4 a[2], b[2];
+        ly_rv_unpack(zt, a);
+        ly_rv_unpack(dyk[e], b);
+        a[0] += b[0]; a[1] += b[1];
+        *reinterpret_cast<RV*>(P.dx + koff[e]) = ly_rv_pack(a, (RV*)nullptr);
+      }
+    }
+    __syncthreads();                                         // every thread has read the tile and the frames
+    commit();
+    if constexpr (!T2D) stage_flat_halo(nxt);
+    __syncthreads();
+  }
+
+  if constexpr (WG) {
+    float* const red = reinterpret_cast<float*>(xs);
+    static_assert(!WG || NAW * 1024 <= BP * RS + 2 * 180 * RSP, "reduction scratch: the tile and the two frames");
+    for (int w = 0; w < 4; ++w) {
+      if (wave == w) {
+#pragma unroll
+        for (int i = 0; i < NAW; ++i) {
+          f32x4* const p = reinterpret_cast<f32x4*>(red) + i * 64 + lane;
+          if (w == 0) *p = aw[i];
+          else *p = *p + aw[i];
+        }
+      }
+      __syncthreads();
+    }
+    f32x4* const out = reinterpret_cast<f32x4*>(P.slab + (size_t)blockIdx.x * (NAW * 256));
+    for (int i = tid; i < NAW * 64; i += LY_THREADS) out[i] = reinterpret_cast<const f32x4*>(red)[i];
+  }
+}
+
+template <int C, bool T2D, bool WG>
+__global__ __launch_bounds__(LY_THREADS) void ly_mlpblock_bwd_dx_kernel(const LyMlpDxArgs P) {
+  ly_mlp_bwd_dx_body<C, T2D, WG>(P);
+}
+
+// dwp[co * lddw + tap * ts + ci * cs] += sum_b slab[b][tap][to][ti][lane][r],  co = 16 to + 4 (lane >> 4) + r, ci = 16 ti + (lane & 15)   (fixed order)
+template <int C>
+__global__ __launch_bounds__(1024) void ly_mlpblock_bwd_dx_combine_kernel(const float* __restrict__ slab, const int nblk, float* __restrict__ dwp,
+                                                                         const int lddw, const int ts, const int cs, const int rls) {
+  constexpr int PT = MlpGeom<C>::PT, CQ = MlpGeom<C>::CQ, NE = 9 * PT * PT * 64;
+  __shared__ f32x4 red[16][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + cl;
+  const bool live = e < NE;
+  f32x4 acc = ly_zero4();
+  if (live) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(slab) + e;
+    for (int b = rl; b < nblk; b += rls) acc += p[(size_t)b * NE];
+  }
+  red[rl][cl] = acc;
+  __syncthreads();
+  if (rl == 0 && live) {
+    f32x4 s = red[0][cl];
+    for (int i = 1; i < rls; ++i) s += red[i][cl];
+    const int tile = e >> 6, lane = e & 63;
+    const int tap = tile / (PT * PT), to = (tile / PT) % PT, ti = tile % PT;
+    const int ci = 16 * ti + (lane & 15);
+    if (ci < CQ) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = 16 * to + 4 * (lane >> 4) + r;
+        if (co < CQ) dwp[(size_t)co * lddw + (size_t)tap * ts + (size_t)ci * cs] += s[r];
+      }
+    }
+  }
+}
+
+template <int C, bool T2D, bool WG>
+static int launch_mlp_bwd_dx(LyMlpDxArgs P, long slab_floats, float* dwp, int lddw, int ts, int cs, hipStream_t st) {
+  using Gm = MlpGeom<C>;
+  constexpr int BP = 128, PT = Gm::PT;
+  const long halo = T2D ? 10 * 18 : BP + 2 * P.W + 2;
+  const size_t psb = ((size_t)halo * Gm::RSP + 15 + 64) / 16 * 16;
+  const size_t lds = (size_t)PT * Gm::SP * 1024 + (size_t)BP * Gm::RS + 2 * psb;
+  LY_CHECK(lds <= 160 * 1024, "mlpblock_bwd_dx: tile needs %zu B of LDS (C=%d W=%d)", lds, C, P.W);
+  auto k = ly_mlpblock_bwd_dx_kernel<C, T2D, WG>;
+  static LyDevOnce once;
+  static int per_cu = 0;
+  static size_t lds_q = 0;
+  if (once.need() || lds_q != lds) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+    LY_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    int nb = 0;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k), LY_THREADS, lds);
+    LY_CHECK(e == hipSuccess, "hipOccupancyMaxActiveBlocksPerMultiprocessor: %s", hipGetErrorString(e));
+    per_cu = nb < 1 ? 1 : (nb > 4 ? 4 : nb);
+    lds_q = lds;
+  }
+  const long ntiles = T2D ? (long)P.n_img * ((P.H + 7) / 8) * ((P.W + 15) / 16) : (P.M + BP - 1) / BP;
+  LY_CHECK(ntiles < (1L << 30), "mlpblock_bwd_dx: too many tiles");
+  long blocks = 256L * per_cu;
+  if (blocks > ntiles) blocks = ntiles;
+  constexpr int SL = 9 * PT * PT * 256;
+  if (WG) LY_CHECK(P.slab && dwp && blocks * (long)SL <= slab_floats, "mlpblock_bwd_dx: the slab workspace holds %ld floats, %ld needed", slab_floats, blocks * (long)SL);
+  P.ntiles = (int)ntiles;
+  hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(LY_THREADS), lds, st, P);
+  if (WG) {
+    const int rls = blocks <= 64 ? 4 : 16;
+    hipLaunchKernelGGL((ly_mlpblock_bwd_dx_combine_kernel<C>), dim3((9 * PT * PT * 64 + 63) / 64), dim3(64 * rls), 0, st, P.slab, (int)blocks, dwp, lddw, ts, cs, rls);
+  }
+  LY_LAUNCH_CHECK();
+  return WG ? 0 : 1;
+}
+
+// returns 0: dx and dwp done; 1: dx done, the partial conv's weight gradient is left to the caller (ly_wgrad); < 0: error
+template <int C>
+static int dispatch_mlp_bwd_dx(LyMlpDxArgs P, long slab_floats, float* dwp, int lddw, int ts, int cs, hipStream_t st) {
+  const int wp16 = (P.W + 15) / 16 * 16;
+  const bool patches = P.W >= 12 && 4 * (wp16 - P.W) <= wp16;
+  if constexpr (MlpGeom<C>::PT <= 2) {
+    if (patches && dwp) return launch_mlp_bwd_dx<C, true, true>(P, slab_floats, dwp, lddw, ts, cs, st);
+  }
+  if (patches) return launch_mlp_bwd_dx<C, true, false>(P, 0, nullptr, 0, 0, 0, st);
+  return launch_mlp_bwd_dx<C, false, false>(P, 0, nullptr, 0, 0, 0, st);
+}
+
+int ly_mlp_bwd_dx_80(LyMlpDxArgs P, long slab_floats, float* dwp, int lddw, int ts, int cs, hipStream_t st);
+int ly_mlp_bwd_dx_160(LyMlpDxArgs P, long slab_floats, float* dwp, int lddw, int ts, int cs, hipStream_t st);
+int ly_mlp_bwd_dx_320(LyMlpDxArgs P, long slab_floats, float* dwp, int lddw, int ts, int cs, hipStream_t st);

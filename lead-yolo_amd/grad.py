@@ -618,7 +618,10 @@ class MlpBlockFn(torch.autograd.Function):
                       dw_ts=ts, dw_cs=cs, n_valid=c4, c_valid=c4)
             dx = torch.empty_like(dy)                      # dy + g, the partial conv's channels dy + t
             gz = torch.empty_like(g)
-            if ops.mlpblock_pconv(g, gz, n, h, w, c, pack.packed(pack.src_taps(p_wpc, c4p, transposed_flipped=True), 9 * c4p, pl)):
+            if ops.MLP_BWD_FUSED and x.dtype == torch.bfloat16 and c in ops.MLP_WIDTHS:
+                # C >= 160 (the fused two-pass backward is not built there): the tail still runs as one launch (csrc/ly_mlpblock_bwd.hpp)
+                dx, _ = ops.mlpblock_bwd_dx(g, dy, x, n, h, w, c, pack.packed(pack.src_taps(p_wpc, c4p, transposed_flipped=True), 9 * c4p, pl))
+            elif ops.mlpblock_pconv(g, gz, n, h, w, c, pack.packed(pack.src_taps(p_wpc, c4p, transposed_flipped=True), 9 * c4p, pl)):
                 # gz = [t | g[c4:]] straight from the persistent kernel with the transposed-flipped taps: dx = dy + gz
                 _lib().check(_lib().lib().ly_mlp_dx(_lib().ptr(dy), _lib().ptr(gz), _lib().ptr(gz), c, m, c, 4, _lib().ptr(dx), _lib().dtype_code(dy),
                                                     _lib().stream_ptr()), "ly_mlp_dx")
@@ -672,15 +675,12 @@ def _mlpblock_backward_fused(ctx, dy):
     tgt = ops.grad_target(p_wpc)
     dwp, dp = (tgt, True) if tgt is not None else (torch.zeros(p_wpc.shape, dtype=torch.float32, device=x.device), False)
     ts, cs = (c4, 1) if _tap_major(dwp) else (1, 9)
-    ops.wgrad(M=m, H=h, W=w, N=c4p, du=g, lddu=c, x=x, ldx=c, Hin=h, Win=w, Cin=c4p, dw=dwp, lddw=9 * c4, ks=3, stride=1, pad=1,
-              dw_ts=ts, dw_cs=cs, n_valid=c4, c_valid=c4)
-    dx = torch.empty_like(dy)
-    gz = torch.empty_like(g)
     wt = pack.packed(pack.src_taps(p_wpc, c4p, transposed_flipped=True), 9 * c4p, pl)
-    if not ops.mlpblock_pconv(g, gz, n, h, w, c, wt):
-        raise RuntimeError("mlpblock backward: the partial-conv kernel is not built for this shape")
-    _lib().check(_lib().lib().ly_mlp_dx(_lib().ptr(dy), _lib().ptr(gz), _lib().ptr(gz), c, m, c, 4, _lib().ptr(dx), _lib().dtype_code(dy),
-                                        _lib().stream_ptr()), "ly_mlp_dx")
+    # the tail in ONE launch: dx = dy + [conv^T(g[:C/4]) | g[C/4:]] and the partial conv's weight gradient out of the same patches
+    dx, wdone = ops.mlpblock_bwd_dx(g, dy, x, n, h, w, c, wt, dwp=dwp, lddw=9 * c4, dw_ts=ts, dw_cs=cs)
+    if not wdone:
+        ops.wgrad(M=m, H=h, W=w, N=c4p, du=g, lddu=c, x=x, ldx=c, Hin=h, Win=w, Cin=c4p, dw=dwp, lddw=9 * c4, ks=3, stride=1, pad=1,
+                  dw_ts=ts, dw_cs=cs, n_valid=c4, c_valid=c4)
     for prm, direct_ in ((p_wpc, dp), (p_w1, d1), (p_w2, d2)):
         if direct_:
             ops.grad_done(prm)

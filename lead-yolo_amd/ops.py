@@ -660,6 +660,20 @@ def mlpblock_bwd(x, dy, n, h, w, c, wp, w1, w2t, w1t, a, b, *, stats=None, g=Non
                                               capi.dtype_code(x), capi.stream_ptr()), "ly_mlpblock_bwd")
 
 
+def mlpblock_bwd_dx(g, dy, x, n, h, w, c, wpt, dwp=None, lddw=0, dw_ts=0, dw_cs=0):
+    """dx = dy + [pconv^T(g[:, :c/4]) | g[:, c/4:]] (+ dwp += the partial conv's weight gradient where the kernel builds it in): returns
+    (dx, whether dwp was done)"""
+    dx = torch.empty_like(dy)
+    m = n * h * w
+    slab = _mlpblock_bwd_slab(c, x.device) if (dwp is not None and capi.lib().ly_mlpblock_bwd_slab_floats(c) > 0) else None
+    with _Timed(f"ly_mlpblock_bwd_dx_kernel<{c}>", 2.0 * m * 18 * (c // 4) ** 2, x.element_size() * m * (3 * c + c // 4) + 4.0 * 9 * (c // 4) ** 2):
+        rc = capi.lib().ly_mlpblock_bwd_dx(_p(g), _p(dy), _p(x), _p(dx), n, h, w, c, _p(wpt), _p(slab), slab.numel() if slab is not None else 0,
+                                           _p(dwp if slab is not None else None), lddw, dw_ts, dw_cs, capi.dtype_code(x), capi.stream_ptr())
+    if rc < 0:
+        capi.check(rc, "ly_mlpblock_bwd_dx")
+    return dx, rc == 0
+
+
 def chan_moments(x, ldx, rows, c, f64=False):
     """per-channel (sum x, sum x^2) over the rows of an [rows, c] matrix -> [2c]; accumulated in double stripes, folded in index order
     (float32 result unless f64: ly_rfcbam_gen_prepare takes the doubles)"""

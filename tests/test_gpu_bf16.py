@@ -498,7 +498,7 @@ def test_configs4_shape_lead_yolo_l_1280(bs):
 
 
 @pytest.mark.parametrize("c,n,h,w", [(24, 2, 40, 48), (24, 3, 13, 32), (40, 3, 24, 32), (24, 2, 20, 20), (40, 1, 7, 9), (16, 2, 16, 64), (40, 2, 33, 80),
-                                     (80, 2, 20, 24), (80, 3, 40, 40), (80, 1, 5, 7)])
+                                     (80, 2, 20, 24), (80, 3, 40, 40), (80, 1, 5, 7), (160, 2, 20, 20), (160, 1, 16, 32)])
 def test_mlpblock_fused_backward_bf16(c, n, h, w, monkeypatch):
     """The fused MLPBlock backward (csrc/ly_mlpblock_bwd.hpp: two passes over (x, dy), the 2C-wide hidden tensors and both 1x1 weight
     gradients on chip; reference: autograd of models/common.py:1432-1437, 1478-1482) — T2D patches (W % 16 == 0, ragged H included) and

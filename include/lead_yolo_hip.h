@@ -343,6 +343,15 @@ int ly_bnact_bwd_reduce(const void* dy /*T*/, int lddy, const void* u /*T*/, int
                         int act, double* sums /* [32][2C] doubles, zeroed */, int dtype, void* stream);
 int ly_bnact_bwd_apply(const void* dy /*T*/, int lddy, const void* u /*T*/, int ldu, long rows, int C, const float* a, const float* b,
                        int act, const float* alpha, const float* kappa, const float* lambda, void* du /*T*/, int lddu, int dtype, void* stream);
+/* Pair forms: TWO conv -> BN(train) -> act units over one stacked pre-activation tensor u [rows, C] — channels [0, csplit) and [csplit, C): C3_CA's
+ * cv1 | cv2 over their shared input (models/common.py:1630-1636) — in ONE pass each: unit 1's gradient dy1 [rows, csplit] (row stride lddy1), unit 2's
+ * dy2 [rows, C - csplit]; sums1 / sums2 are the striped accumulators of the two units (as `sums` of ly_bnact_bwd_reduce), a / b / alpha / kappa /
+ * lambda hold both units' C entries side by side.                                                                                              */
+int ly_bnact_bwd_reduce_pair(const void* dy1 /*T*/, int lddy1, const void* dy2 /*T*/, int lddy2, int csplit, const void* u /*T*/, int ldu, long rows, int C,
+                             const float* a, const float* b, int act, double* sums1, double* sums2, int dtype, void* stream);
+int ly_bnact_bwd_apply_pair(const void* dy1 /*T*/, int lddy1, const void* dy2 /*T*/, int lddy2, int csplit, const void* u /*T*/, int ldu, long rows, int C,
+                            const float* a, const float* b, int act, const float* alpha, const float* kappa, const float* lambda, void* du /*T*/, int lddu,
+                            int dtype, void* stream);
 
 /* Weight gradient of a convolution whose forward read input pixel (ho*stride + ky - pad, wo*stride + kx - pad):
  *   dw[n][(ky*ks + kx)*Cin + c] += sum_{m = (img, ho, wo)} du[m][n] * x[img, hi, wi, c]      (zero outside the map)

@@ -130,6 +130,8 @@ SIGNATURES = {
     "ly_bnact_fwd": [_P, _I, _L, _I, _P, _P, _I, _P, _I, _I, _P],
     "ly_bnact_bwd_reduce": [_P, _I, _P, _I, _L, _I, _P, _P, _I, _P, _I, _P],
     "ly_bnact_bwd_apply": [_P, _I, _P, _I, _L, _I, _P, _P, _I, _P, _P, _P, _P, _I, _I, _P],
+    "ly_bnact_bwd_reduce_pair": [_P, _I, _P, _I, _I, _P, _I, _L, _I, _P, _P, _I, _P, _P, _I, _P],
+    "ly_bnact_bwd_apply_pair": [_P, _I, _P, _I, _I, _P, _I, _L, _I, _P, _P, _I, _P, _P, _P, _P, _I, _I, _P],
     "ly_wgrad": [ctypes.POINTER(LyWgradParams), _P],
     "ly_wgrad_group": [_P, _I, _P],
     "ly_up2_bwd": [_P, _I, _I, _I, _I, _I, _P, _I, _I, _P],

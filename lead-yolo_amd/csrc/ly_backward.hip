@@ -41,7 +41,10 @@ __device__ __forceinline__ f32x4 ly_dact4(const f32x4 v, const f32x4 dy) {
 template <typename T, int ACT>
 __global__ __launch_bounds__(LY_THREADS) void ly_bnact_bwd_reduce_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ u,
                                                                           int ldu, long rows, int C, const float* __restrict__ a,
-                                                                          const float* __restrict__ b, double* __restrict__ sums) {
+                                                                          const float* __restrict__ b, double* __restrict__ sums,
+                                                                          const T* __restrict__ dy2, int lddy2, int csplit, double* __restrict__ sums2) {
+  // (pair form, csplit < C: channels >= csplit take their gradient from dy2 — column c - csplit — and their sums go to sums2: the two
+  // BatchNorms over one stacked pre-activation tensor, C3_CA's cv1 | cv2, in ONE pass; csplit == C: one unit)
   // thread = (channel quad, row lane).  Four rows per trip with all eight loads issued before the first use, in straight-line code
   // (a load under a run-time branch makes every later s_waitcnt conservative: the first unrolled version, which still chose the vector
   // width at run time, was SLOWER than one row per trip).  Rows past the end re-read the last row and are masked.
@@ -51,17 +54,20 @@ __global__ __launch_bounds__(LY_THREADS) void ly_bnact_bwd_reduce_kernel(const T
   const int groups = LY_THREADS / ncv;
   const int cv = tid % ncv, j0 = tid / ncv;
   f32x4 s1 = ly_zero4(), s2 = ly_zero4();
+  const bool second = 4 * cv >= csplit;
   if (j0 < groups) {
     const f32x4 av = ly_ldg4(a + 4 * cv), bv = ly_ldg4(b + 4 * cv);
     constexpr int UR = 4;
     const long stride = (long)gridDim.x * groups;
+    const T* const dyb = second ? dy2 + (4 * cv - csplit) : dy + 4 * cv;      // (a selected base pointer: no load under a branch)
+    const long ldd = second ? lddy2 : lddy;
     for (long r0 = (long)blockIdx.x * groups + j0; r0 < rows; r0 += UR * stride) {
       R4 qu[UR], qg[UR];
 #pragma unroll
       for (int k = 0; k < UR; ++k) {
         const long r = r0 + k * stride < rows ? r0 + k * stride : rows - 1;
         qu[k] = ly_ldr4<T>(u + r * ldu + 4 * cv);
-        qg[k] = ly_ldr4<T>(dy + r * lddy + 4 * cv);
+        qg[k] = ly_ldr4<T>(dyb + r * ldd);
       }
 #pragma unroll
       for (int k = 0; k < UR; ++k) {
@@ -77,12 +83,13 @@ __global__ __launch_bounds__(LY_THREADS) void ly_bnact_bwd_reduce_kernel(const T
   red2[tid] = s2;
   __syncthreads();
   if (j0 == 0) {
-    double* sm = sums + (size_t)(blockIdx.x & (LY_STATS_STRIPES - 1)) * 2 * C;      // double accumulators: see ly_stats_flush (ly_common.hpp)
+    const int ch = second ? C - csplit : csplit, lc = 4 * cv - (second ? csplit : 0);        // channels of this unit, the thread's first one in it
+    double* sm = (second ? sums2 : sums) + (size_t)(blockIdx.x & (LY_STATS_STRIPES - 1)) * 2 * ch;      // double accumulators: see ly_stats_flush (ly_common.hpp)
     for (int g = 1; g < groups; ++g) { s1 += red1[g * ncv + cv]; s2 += red2[g * ncv + cv]; }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      atomicAdd(sm + 4 * cv + r, (double)s1[r]);
-      atomicAdd(sm + C + 4 * cv + r, (double)s2[r]);
+      atomicAdd(sm + lc + r, (double)s1[r]);
+      atomicAdd(sm + ch + lc + r, (double)s2[r]);
     }
   }
 }
@@ -92,11 +99,12 @@ __global__ __launch_bounds__(LY_THREADS) void ly_bnact_bwd_apply_kernel(const T*
                                                                          long rows, int C, const float* __restrict__ a,
                                                                          const float* __restrict__ b, const float* __restrict__ alpha,
                                                                          const float* __restrict__ kappa, const float* __restrict__ lambda,
-                                                                         T* du, int lddu) {
+                                                                         T* du, int lddu, const T* __restrict__ dy2, int lddy2, int csplit) {
   // 16-byte accesses in both dtypes (4 fp32 / 8 bf16 channels per thread) when C allows, else 4 channels
+  // (pair form, csplit < C: channels >= csplit read their gradient from dy2, column c - csplit; csplit a multiple of the vector width)
   constexpr int VW = LyT<T>::VW, NQ = VW / 4;
   using RV = typename LyT<T>::RV;
-  if ((C % VW) == 0 && (ldu % VW) == 0 && (lddy % VW) == 0 && (lddu % VW) == 0) {
+  if ((C % VW) == 0 && (ldu % VW) == 0 && (lddy % VW) == 0 && (lddu % VW) == 0 && (lddy2 % VW) == 0 && (csplit % VW) == 0) {
     const int ncv = C / VW;
     const long total = rows * ncv;
     for (long i = (long)blockIdx.x * LY_THREADS + threadIdx.x; i < total; i += (long)gridDim.x * LY_THREADS) {
@@ -104,7 +112,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_bnact_bwd_apply_kernel(const T*
       const int c = VW * (int)(i - r * ncv);
       f32x4 uu[NQ], g[NQ];
       ly_rv_unpack(ly_ldrv<T>(u + r * ldu + c), uu);
-      ly_rv_unpack(ly_ldrv<T>(dy + r * lddy + c), g);
+      ly_rv_unpack(ly_ldrv<T>(c >= csplit ? dy2 + r * lddy2 + (c - csplit) : dy + r * lddy + c), g);
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         const int cq = c + 4 * q;
@@ -121,7 +129,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_bnact_bwd_apply_kernel(const T*
     const long r = i / nc4;
     const int c = 4 * (int)(i - r * nc4);
     const f32x4 uu = ly_ld4<T>(u + r * ldu + c);
-    const f32x4 g = ly_ld4<T>(dy + r * lddy + c);
+    const f32x4 g = ly_ld4<T>(c >= csplit ? dy2 + r * lddy2 + (c - csplit) : dy + r * lddy + c);
     const f32x4 dv = ly_dact4<ACT>(ly_ldg4(a + c) * uu + ly_ldg4(b + c), g);
     ly_st4<T>(du + r * lddu + c, ly_ldg4(alpha + c) * dv + ly_ldg4(kappa + c) + ly_ldg4(lambda + c) * uu);
   }
@@ -180,11 +188,8 @@ extern "C" int ly_bnact_fwd(const void* u_, int ldu, long rows, int C, const flo
   return 0;
 }
 
-extern "C" int ly_bnact_bwd_reduce(const void* dy_, int lddy, const void* u_, int ldu, long rows, int C, const float* a, const float* b,
-                                   int act, double* sums, int dtype, void* stream) {
-  LY_CHECK_DTYPE(dtype, "bnact_bwd_reduce");
-  LY_CHECK(dy_ && u_ && a && b && sums && rows > 0, "bnact_bwd_reduce: null pointer");
-  LY_CHECK((C & 3) == 0 && C > 0 && C <= 1024 && (lddy & 3) == 0 && (ldu & 3) == 0, "bnact_bwd_reduce: C=%d / ld must be multiples of 4", C);
+static int bnact_bwd_reduce_launch(const void* dy_, int lddy, const void* dy2_, int lddy2, int csplit, const void* u_, int ldu, long rows, int C, const float* a,
+                                   const float* b, int act, double* sums, double* sums2, int dtype, void* stream) {
   // channels per thread: 4 in both dtypes.  (8 bf16 channels = 16-byte accesses measured SLOWER here, 24.6 -> 29.0 us per launch:
   // half as many threads share a row, and this pass lives on loads in flight; the elementwise apply / forward passes gain, 21 -> 18.6
   // and 14.6 -> 12.6 us, and use 16-byte accesses.)
@@ -193,9 +198,10 @@ extern "C" int ly_bnact_bwd_reduce(const void* dy_, int lddy, const void* u_, in
   long blocks = (rows + groups * 32L - 1) / (groups * 32L);
   blocks = blocks < 1 ? 1 : blocks > 2048 ? 2048 : blocks;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-#define LY_RED(A) hipLaunchKernelGGL((ly_bnact_bwd_reduce_kernel<T, A>), dim3((unsigned)blocks), dim3(LY_THREADS), 0, st, dy, lddy, u, ldu, rows, C, a, b, sums)
+#define LY_RED(A) hipLaunchKernelGGL((ly_bnact_bwd_reduce_kernel<T, A>), dim3((unsigned)blocks), dim3(LY_THREADS), 0, st, dy, lddy, u, ldu, rows, C, a, b, sums, dy2, lddy2, csplit, sums2)
   LY_WITH_T(dtype, {
     const T* dy = reinterpret_cast<const T*>(dy_);
+    const T* dy2 = reinterpret_cast<const T*>(dy2_);
     const T* u = reinterpret_cast<const T*>(u_);
     if (act == LY_ACT_SILU) LY_RED(LY_ACT_SILU);
     else if (act == LY_ACT_RELU) LY_RED(LY_ACT_RELU);
@@ -206,16 +212,34 @@ extern "C" int ly_bnact_bwd_reduce(const void* dy_, int lddy, const void* u_, in
   return 0;
 }
 
-extern "C" int ly_bnact_bwd_apply(const void* dy_, int lddy, const void* u_, int ldu, long rows, int C, const float* a, const float* b,
-                                  int act, const float* alpha, const float* kappa, const float* lambda, void* du_, int lddu, int dtype, void* stream) {
-  LY_CHECK_DTYPE(dtype, "bnact_bwd_apply");
-  LY_CHECK(dy_ && u_ && a && b && alpha && kappa && lambda && du_ && rows > 0, "bnact_bwd_apply: null pointer");
-  LY_CHECK((C & 3) == 0 && C > 0 && (lddy & 3) == 0 && (ldu & 3) == 0 && (lddu & 3) == 0, "bnact_bwd_apply: C=%d / ld must be multiples of 4", C);
+extern "C" int ly_bnact_bwd_reduce(const void* dy_, int lddy, const void* u_, int ldu, long rows, int C, const float* a, const float* b,
+                                   int act, double* sums, int dtype, void* stream) {
+  LY_CHECK_DTYPE(dtype, "bnact_bwd_reduce");
+  LY_CHECK(dy_ && u_ && a && b && sums && rows > 0, "bnact_bwd_reduce: null pointer");
+  LY_CHECK((C & 3) == 0 && C > 0 && C <= 1024 && (lddy & 3) == 0 && (ldu & 3) == 0, "bnact_bwd_reduce: C=%d / ld must be multiples of 4", C);
+  return bnact_bwd_reduce_launch(dy_, lddy, dy_, lddy, C, u_, ldu, rows, C, a, b, act, sums, sums, dtype, stream);
+}
+
+// Two conv -> BN(train) -> act units over ONE stacked pre-activation tensor u [rows, C] (channels [0, csplit) and [csplit, C): C3_CA's cv1 | cv2,
+// models/common.py:1630-1636) in one pass: unit 1's gradient dy1 [rows, csplit], unit 2's dy2 [rows, C - csplit]; sums1 / sums2 as `sums` of
+// ly_bnact_bwd_reduce for csplit / C - csplit channels.
+extern "C" int ly_bnact_bwd_reduce_pair(const void* dy1, int lddy1, const void* dy2, int lddy2, int csplit, const void* u_, int ldu, long rows, int C,
+                                        const float* a, const float* b, int act, double* sums1, double* sums2, int dtype, void* stream) {
+  LY_CHECK_DTYPE(dtype, "bnact_bwd_reduce_pair");
+  LY_CHECK(dy1 && dy2 && u_ && a && b && sums1 && sums2 && rows > 0, "bnact_bwd_reduce_pair: null pointer");
+  LY_CHECK((C & 3) == 0 && C > 0 && C <= 1024 && csplit > 0 && csplit < C && (csplit & 3) == 0 && (lddy1 & 3) == 0 && (lddy2 & 3) == 0 && (ldu & 3) == 0,
+           "bnact_bwd_reduce_pair: C=%d csplit=%d / ld must be multiples of 4", C, csplit);
+  return bnact_bwd_reduce_launch(dy1, lddy1, dy2, lddy2, csplit, u_, ldu, rows, C, a, b, act, sums1, sums2, dtype, stream);
+}
+
+static int bnact_bwd_apply_launch(const void* dy_, int lddy, const void* dy2_, int lddy2, int csplit, const void* u_, int ldu, long rows, int C, const float* a,
+                                  const float* b, int act, const float* alpha, const float* kappa, const float* lambda, void* du_, int lddu, int dtype, void* stream) {
   const long blocks = ly_ew_blocks(rows * (C >> 2));
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-#define LY_APP(A) hipLaunchKernelGGL((ly_bnact_bwd_apply_kernel<T, A>), dim3((unsigned)blocks), dim3(LY_THREADS), 0, st, dy, lddy, u, ldu, rows, C, a, b, alpha, kappa, lambda, du, lddu)
+#define LY_APP(A) hipLaunchKernelGGL((ly_bnact_bwd_apply_kernel<T, A>), dim3((unsigned)blocks), dim3(LY_THREADS), 0, st, dy, lddy, u, ldu, rows, C, a, b, alpha, kappa, lambda, du, lddu, dy2, lddy2, csplit)
   LY_WITH_T(dtype, {
     const T* dy = reinterpret_cast<const T*>(dy_);
+    const T* dy2 = reinterpret_cast<const T*>(dy2_);
     const T* u = reinterpret_cast<const T*>(u_);
     T* du = reinterpret_cast<T*>(du_);
     if (act == LY_ACT_SILU) LY_APP(LY_ACT_SILU);
@@ -225,6 +249,25 @@ extern "C" int ly_bnact_bwd_apply(const void* dy_, int lddy, const void* u_, int
 #undef LY_APP
   LY_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int ly_bnact_bwd_apply(const void* dy_, int lddy, const void* u_, int ldu, long rows, int C, const float* a, const float* b,
+                                  int act, const float* alpha, const float* kappa, const float* lambda, void* du_, int lddu, int dtype, void* stream) {
+  LY_CHECK_DTYPE(dtype, "bnact_bwd_apply");
+  LY_CHECK(dy_ && u_ && a && b && alpha && kappa && lambda && du_ && rows > 0, "bnact_bwd_apply: null pointer");
+  LY_CHECK((C & 3) == 0 && C > 0 && (lddy & 3) == 0 && (ldu & 3) == 0 && (lddu & 3) == 0, "bnact_bwd_apply: C=%d / ld must be multiples of 4", C);
+  return bnact_bwd_apply_launch(dy_, lddy, dy_, lddy, C, u_, ldu, rows, C, a, b, act, alpha, kappa, lambda, du_, lddu, dtype, stream);
+}
+
+// the pair form (see ly_bnact_bwd_reduce_pair): du [rows, C] from dy1 | dy2, coefficient vectors of C entries (both units' side by side)
+extern "C" int ly_bnact_bwd_apply_pair(const void* dy1, int lddy1, const void* dy2, int lddy2, int csplit, const void* u_, int ldu, long rows, int C,
+                                       const float* a, const float* b, int act, const float* alpha, const float* kappa, const float* lambda, void* du_,
+                                       int lddu, int dtype, void* stream) {
+  LY_CHECK_DTYPE(dtype, "bnact_bwd_apply_pair");
+  LY_CHECK(dy1 && dy2 && u_ && a && b && alpha && kappa && lambda && du_ && rows > 0, "bnact_bwd_apply_pair: null pointer");
+  LY_CHECK((C & 3) == 0 && C > 0 && csplit > 0 && csplit < C && (csplit & 3) == 0 && (lddy1 & 3) == 0 && (lddy2 & 3) == 0 && (ldu & 3) == 0 && (lddu & 3) == 0,
+           "bnact_bwd_apply_pair: C=%d csplit=%d / ld must be multiples of 4", C, csplit);
+  return bnact_bwd_apply_launch(dy1, lddy1, dy2, lddy2, csplit, u_, ldu, rows, C, a, b, act, alpha, kappa, lambda, du_, lddu, dtype, stream);
 }
 
 // -------------------------------------------------------------------------------------------------

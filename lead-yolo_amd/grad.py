@@ -396,23 +396,32 @@ class ConvBnActPair(torch.autograd.Function):
             tw = [ops.grad_target(ctx.params[i][0]) for i in range(2)]
             stacked = (need[6] and need[7] and tw[0] is not None and tw[1] is not None and tw[0].is_contiguous() and tw[1].is_contiguous()
                        and tw[1].data_ptr() == tw[0].data_ptr() + 4 * tw[0].numel())
-            for i, dy in enumerate((dy1, dy2)):
-                off = i * c_
-                w_p, g_p, b_p = ctx.params[i]
+            dys = []
+            for dy in (dy1, dy2):
                 if dy is None:
                     dy = torch.zeros((n, c_, ho, wo), dtype=u.dtype, device=u.device).contiguous(memory_format=torch.channels_last)
-                dy, lddy = ops.rows(dy if dy.dtype == u.dtype else dy.to(u.dtype))
-                uh, a, b = u[:, off:off + c_], v[0, off:off + c_], v[1, off:off + c_]
-                sums = ops.bnact_bwd_reduce(dy, lddy, uh, co, rows, c_, a, b, spec.act)
+                dys.append(ops.rows(dy if dy.dtype == u.dtype else dy.to(u.dtype)))
+            # both units' BatchNorm / activation backward in ONE reduce pass and ONE apply pass over the stacked tensor (were two half-width
+            # launches each): the coefficient launches stay per unit (their targets are two parameters' gradient storages)
+            (dya, lda), (dyb, ldb) = dys
+            sums2 = ops.bnact_bwd_reduce_pair(dya, lda, dyb, ldb, c_, u, co, rows, co, v[0], v[1], spec.act)
+            coef = torch.empty(3, co, dtype=torch.float32, device=u.device)
+            for i in range(2):
+                off = i * c_
+                sl = slice(off, off + c_)
+                w_p, g_p, b_p = ctx.params[i]
                 tg, tb = ops.grad_target(g_p), ops.grad_target(b_p)
                 direct = tg is not None and tb is not None
-                dgamma, dbeta, alpha, kappa, lam = ops.bn_bwd_coeffs(sums, c_, rows, a, v[2, off:off + c_], v[3, off:off + c_], True,
-                                                                     dgamma=tg if direct else None, dbeta=tb if direct else None)
+                dgamma, dbeta, _, _, _ = ops.bn_bwd_coeffs(sums2[i], c_, rows, v[0, sl], v[2, sl], v[3, sl], True, dgamma=tg if direct else None,
+                                                           dbeta=tb if direct else None, into=(coef[0, sl], coef[1, sl], coef[2, sl]))
                 if direct:
                     ops.grad_done(g_p)
                     ops.grad_done(b_p)
                 out[8 + 2 * i], out[9 + 2 * i] = dgamma, dbeta
-                ops.bnact_bwd_apply(dy, lddy, uh, co, rows, c_, a, b, spec.act, alpha, kappa, lam, du[:, off:off + c_], co)
+            ops.bnact_bwd_apply_pair(dya, lda, dyb, ldb, c_, u, co, rows, co, v[0], v[1], spec.act, coef[0], coef[1], coef[2], du, co)
+            for i in range(2):
+                off = i * c_
+                w_p = ctx.params[i][0]
                 if need[6 + i] and not stacked:
                     tgt = tw[i]
                     dw = tgt if tgt is not None else torch.zeros(w_p.shape, dtype=torch.float32, device=u.device)

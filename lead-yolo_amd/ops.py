@@ -795,20 +795,22 @@ def bn_finalize(bn, stats, nch, count, n=None, c_off=0, bias=None, pad_to=0, wan
     return (scale, shift, mean, invstd) if want_stats else (scale, shift)
 
 
-def bn_bwd_coeffs(sums, n, count, a, mean, invstd, train, dgamma=None, dbeta=None, transpose=None):
+def bn_bwd_coeffs(sums, n, count, a, mean, invstd, train, dgamma=None, dbeta=None, transpose=None, into=None):
     """(dgamma, dbeta, alpha, kappa, lambda) from (striped) sums [.., 2n] of ly_bnact_bwd_reduce, ONE launch.  dgamma / dbeta given:
     the kernel ADDS into them (a parameter's persistent gradient storage, see GradSink) and None is returned in their place.
     transpose = (A, B): the sums' channels are in [A][B] order, dgamma / dbeta in [B][A] (generate BatchNorm of RFCBAMConv k = 3)."""
     dev = sums.device
     stripes = sums.shape[0] if sums.dim() == 2 else 1
-    out = torch.empty(5, n, dtype=torch.float32, device=dev)
+    # into = (alpha, kappa, lambda): contiguous fp32 [n] destinations (slices of wider vectors: two units side by side)
+    out = torch.empty(5 if into is None else 2, n, dtype=torch.float32, device=dev)
     direct = dgamma is not None and dbeta is not None
     if not direct:
         out[:2].zero_()
     capi.check(capi.lib().ly_bn_bwd_coeffs(_p(sums), int(sums.dtype == torch.float64), stripes, n, float(count), _p(a), _p(mean), _p(invstd), int(train), _p(dgamma if direct else out[0]),
-                                           _p(dbeta if direct else out[1]), _p(out[2]), _p(out[3]), _p(out[4]),
+                                           _p(dbeta if direct else out[1]), *[_p(t) for t in (into if into is not None else (out[2], out[3], out[4]))],
                                            *((transpose if direct else None) or (0, 0)), capi.stream_ptr()), "ly_bn_bwd_coeffs")
-    return (None if direct else out[0]), (None if direct else out[1]), out[2], out[3], out[4]
+    al, ka, la = into if into is not None else (out[2], out[3], out[4])
+    return (None if direct else out[0]), (None if direct else out[1]), al, ka, la
 
 
 class GradSink:
@@ -957,6 +959,21 @@ def bnact_bwd_apply(dy, lddy, u, ldu, rows, c, a, b, act, alpha, kappa, lam, du,
     with _Timed(f"ly_bnact_bwd_apply_kernel<{_tname(u)}, {act}>", 8.0 * rows * c, 3.0 * u.element_size() * rows * c):
         capi.check(capi.lib().ly_bnact_bwd_apply(_p(dy), lddy, _p(u), ldu, rows, c, _p(a), _p(b), act, _p(alpha), _p(kappa), _p(lam),
                                                  _p(du), lddu, capi.dtype_code(u), capi.stream_ptr()), "ly_bnact_bwd_apply")
+
+
+def bnact_bwd_reduce_pair(dy1, lddy1, dy2, lddy2, csplit, u, ldu, rows, c, a, b, act):
+    """both units of a stacked pair in one pass -> (sums1, sums2)"""
+    s1, s2 = new_stats(csplit, u.device), new_stats(c - csplit, u.device)
+    with _Timed(f"ly_bnact_bwd_reduce_kernel<{_tname(u)}, {act}>", 6.0 * rows * c, 2.0 * u.element_size() * rows * c):
+        capi.check(capi.lib().ly_bnact_bwd_reduce_pair(_p(dy1), lddy1, _p(dy2), lddy2, csplit, _p(u), ldu, rows, c, _p(a), _p(b), act, _p(s1), _p(s2),
+                                                       capi.dtype_code(u), capi.stream_ptr()), "ly_bnact_bwd_reduce_pair")
+    return s1, s2
+
+
+def bnact_bwd_apply_pair(dy1, lddy1, dy2, lddy2, csplit, u, ldu, rows, c, a, b, act, alpha, kappa, lam, du, lddu):
+    with _Timed(f"ly_bnact_bwd_apply_kernel<{_tname(u)}, {act}>", 8.0 * rows * c, 3.0 * u.element_size() * rows * c):
+        capi.check(capi.lib().ly_bnact_bwd_apply_pair(_p(dy1), lddy1, _p(dy2), lddy2, csplit, _p(u), ldu, rows, c, _p(a), _p(b), act, _p(alpha), _p(kappa),
+                                                      _p(lam), _p(du), lddu, capi.dtype_code(u), capi.stream_ptr()), "ly_bnact_bwd_apply_pair")
 
 
 def wgrad(*, M, H, W, N, du, lddu, x, ldx, Hin, Win, Cin, dw, lddw, ks=1, stride=1, pad=0, nchw=False, up2=False, du_off=0, x_off=0,

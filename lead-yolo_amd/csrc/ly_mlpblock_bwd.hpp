@@ -64,7 +64,10 @@ struct MlpBwdGeom {
   static constexpr int NFW = NFP + 2 * NF1 + NF1T;         // fragments of Wp, W1, W2^T, W1^T
 };
 
-template <int C, int HT, bool T2D, int PASS>
+// PD = patches in flight ahead of the one being computed (T2D, one or two register sets).  MEASURED: two sets change nothing (C = 24 pass 1
+// 80.7 -> 80.7 us, C = 40 64 -> 68 us at bs = 64) — a patch's arithmetic already covers the HBM round trip; the passes are paced by instruction
+// issue and the LDS pipe (PMC: a third of the wave cycles in LDS-issue stalls), not by loads in flight.  PD = 1 everywhere.
+template <int C, int HT, bool T2D, int PASS, int PD>
 __device__ __forceinline__ void ly_mlp_bwd_body(const LyMlpBwdArgs& P) {
   using Gm = MlpGeom<C>;
   using Bg = MlpBwdGeom<C>;
@@ -137,10 +140,14 @@ __device__ __forceinline__ void ly_mlp_bwd_body(const LyMlpBwdArgs& P) {
   // ---- staging: T2D = register prefetch of the next patch (x tile, x halo, dy tile), committed after the arithmetic ----------------
   constexpr int TVN = BP * (KP / VW), NVT = T2D ? (TVN + LY_THREADS - 1) / LY_THREADS : 1;
   constexpr int HVN = T2D ? (TH + 2) * 18 * G : 1, NVH = T2D ? (HVN + LY_THREADS - 1) / LY_THREADS : 1;
-  RV tv[NVT], dv_[NVT];
-  R4 hv[NVH];
-  bool tok[NVT], hok[NVH];
-  auto issue = [&](int tile) {
+  struct PSet {
+    RV tv[NVT], dv_[NVT];
+    R4 hv[NVH];
+    bool tok[NVT], hok[NVH];
+  };
+  PSet Q0, Q1;
+  auto issue = [&](PSet& S, int tile) {
+    RV (&tv)[NVT] = S.tv; RV (&dv_)[NVT] = S.dv_; R4 (&hv)[NVH] = S.hv; bool (&tok)[NVT] = S.tok; bool (&hok)[NVH] = S.hok;
     long i0, q0; int hh0, ww0;
     decode(tile, i0, hh0, ww0, q0);
 #pragma unroll
@@ -163,7 +170,8 @@ __device__ __forceinline__ void ly_mlp_bwd_body(const LyMlpBwdArgs& P) {
       hv[e] = ly_ldr4<T>(hok[e] ? x + (i0 + (long)hh * W + ww) * C + c4 * 4 : x);
     }
   };
-  auto commit = [&]() {
+  auto commit = [&](const PSet& S) {
+    const RV (&tv)[NVT] = S.tv; const RV (&dv_)[NVT] = S.dv_; const R4 (&hv)[NVH] = S.hv; const bool (&tok)[NVT] = S.tok; const bool (&hok)[NVH] = S.hok;
 #pragma unroll
     for (int e = 0; e < NVT; ++e) {
       const int idx = tid + e * LY_THREADS;
@@ -232,11 +240,14 @@ __device__ __forceinline__ void ly_mlp_bwd_body(const LyMlpBwdArgs& P) {
     for (int i = 0; i < NAW; ++i) { aw1[i] = zero; aw2[i] = zero; }
   }
 
-  int tile = blockIdx.x;
+  const int g_ = (int)gridDim.x;
+  const int tlast = P.ntiles > (int)blockIdx.x ? (int)blockIdx.x + (P.ntiles - 1 - (int)blockIdx.x) / g_ * g_ : 0;      // the block's last patch
+  auto clampt = [&](int t) -> int { return t < P.ntiles ? t : tlast; };     // (past the end: the last patch is re-requested — straight-line loads)
   if constexpr (T2D) {
-    if (tile < P.ntiles) {
-      issue(tile);
-      commit();
+    if ((int)blockIdx.x < P.ntiles) {
+      issue(Q0, blockIdx.x);
+      commit(Q0);
+      if constexpr (PD == 2) issue(Q1, clampt(blockIdx.x + g_));
     }
   }
   __syncthreads();                                           // weights (and the first patch) are in LDS
@@ -244,10 +255,10 @@ __device__ __forceinline__ void ly_mlp_bwd_body(const LyMlpBwdArgs& P) {
   const bf16x4 z4 = __builtin_bit_cast(bf16x4, make_uint2(0u, 0u));
   const int r0 = 4 * lq + (li >> 2), c8 = 8 * (li & 3);     // transposed-read addressing (the k-set of ly_tile.hpp)
 
-  for (; tile < P.ntiles; tile += gridDim.x) {
+  // one patch: `tile` is in LDS; Si receives the patch PD ahead, Sc (the patch after `tile`) is committed when the arithmetic is done
+  auto step = [&](const int tile, PSet& Si, PSet& Sc) {
     if constexpr (T2D) {
-      const int nxt = tile + (int)gridDim.x < P.ntiles ? tile + (int)gridDim.x : tile;      // (the last patch re-requests itself: straight-line loads)
-      issue(nxt);
+      issue(Si, clampt(tile + PD * g_));
     } else {
       stage_flat(tile);
       __syncthreads();
@@ -532,9 +543,17 @@ __device__ __forceinline__ void ly_mlp_bwd_body(const LyMlpBwdArgs& P) {
     }
     __syncthreads();                                               // every wave is done with the halo image / the tiles
     if constexpr (T2D) {
-      commit();
+      commit(Sc);
       __syncthreads();
     }
+  };
+  if constexpr (PD == 2) {
+    for (int tile = blockIdx.x; tile < P.ntiles; tile += 2 * g_) {
+      step(tile, Q0, Q1);
+      if (tile + g_ < P.ntiles) step(tile + g_, Q1, Q0);
+    }
+  } else {
+    for (int tile = blockIdx.x; tile < P.ntiles; tile += g_) step(tile, Q0, Q0);
   }
 
   if constexpr (PASS == 1) {
@@ -577,9 +596,9 @@ __device__ __forceinline__ void ly_mlp_bwd_body(const LyMlpBwdArgs& P) {
   }
 }
 
-template <int C, int HT, bool T2D, int PASS>
+template <int C, int HT, bool T2D, int PASS, int PD>
 __global__ __launch_bounds__(LY_THREADS) void ly_mlpblock_bwd_kernel(const LyMlpBwdArgs P) {
-  ly_mlp_bwd_body<C, HT, T2D, PASS>(P);
+  ly_mlp_bwd_body<C, HT, T2D, PASS, PD>(P);
 }
 
 // dw1[hid][c] += sum_b slab[b][0][t][ct][lane][r],  dw2[c][hid] += sum_b slab[b][1][...]   with hid = 16 t + 4 (lane >> 4) + r, c = 16 ct + (lane & 15)
@@ -625,6 +644,7 @@ __global__ __launch_bounds__(1024) void ly_mlpblock_bwd_combine_kernel(const flo
 
 template <int C, int HT, bool T2D, int PASS>
 static int launch_mlp_bwd(LyMlpBwdArgs P, long slab_floats, int* blocks_out, hipStream_t st) {
+  constexpr int PD = 1;
   using Gm = MlpGeom<C>;
   using Bg = MlpBwdGeom<C>;
   constexpr int BP = Bg::BP, NT = Bg::NT;
@@ -632,7 +652,7 @@ static int launch_mlp_bwd(LyMlpBwdArgs P, long slab_floats, int* blocks_out, hip
   const size_t lds = (size_t)(Bg::NFP + 2 * Bg::NF1 + (PASS == 2 ? Bg::NF1T : 0)) * 1024 + (PASS == 2 ? 5 : 2) * 2 * C * 4 + 2 * (size_t)BP * Gm::RS +
                      ((size_t)halo * Gm::RSP + 15) / 16 * 16 + (PASS == 2 ? 2 * (size_t)BP * Bg::RSD : 0);
   LY_CHECK(lds <= 160 * 1024, "mlpblock_bwd: tile needs %zu B of LDS (C=%d W=%d)", lds, C, P.W);
-  auto k = ly_mlpblock_bwd_kernel<C, HT, T2D, PASS>;
+  auto k = ly_mlpblock_bwd_kernel<C, HT, T2D, PASS, PD>;
   static LyDevOnce once;
   static int per_cu = 0;
   static size_t lds_q = 0;

@@ -260,13 +260,6 @@ typedef struct LyRf3cBwdParams {
 } LyRf3cBwdParams;
 int ly_rf3c_bwd(const LyRf3cBwdParams* p, int pass, void* stream);
 int ly_rf3c_wgrad(const LyRf3cBwdParams* p, void* stream);
-/* Passes B (pass = 1) and C (pass = 2) of ly_rf3c_bwd on EIGHT waves with the nine taps split over the half waves (csrc/ly_rf3c_bwd8.hip: two
- * waves per SIMD, plain compiler FMAs).  Same parameter block and result layouts, with one difference: the generate weight gradient
- * (models/rfa.py:101-106 under autograd) is no longer formed in pass C — both passes leave their share of A[c][t][u'] = sum_p dv[p,t] x[p,u'] in
- * dwg[n][C*81], and ly_rf3c_dwg_finish turns the image sum into  out[c][t][u'] (+)= alpha A + kappa m + lambda (w[t] . M)  with the forward's tap
- * moments mom (double [54][C], ly_rfcbam_tap_moments), coef = alpha | kappa | lambda (9*C floats each, [t*C + c]) and w = generate.0.weight.   */
-int ly_rf3c_bwd8(const LyRf3cBwdParams* p, int pass, void* stream);
-int ly_rf3c_dwg_finish(const float* A, const float* coef, const double* mom, const float* w, int C, float* out, int accumulate, void* stream);
 
 
 /* ---- graph remainder ------------------------------------------------------------------------- */

@@ -125,8 +125,6 @@ SIGNATURES = {
     "ly_rf3m_fwd": [ctypes.POINTER(LyRfcbam3Params), _P],
     "ly_rf3c_bwd": [ctypes.POINTER(LyRf3cBwdParams), _I, _P],
     "ly_rf3c_wgrad": [ctypes.POINTER(LyRf3cBwdParams), _P],
-    "ly_rf3c_bwd8": [ctypes.POINTER(LyRf3cBwdParams), _I, _P],
-    "ly_rf3c_dwg_finish": [_P, _P, _P, _P, _I, _P, _I, _P],
     "ly_coordatt_conv1_stats": [_P, _L, _I, _I, _P, _P, _P, _P],
     "ly_sppf_pool": [_P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P],
     "ly_bnact_fwd": [_P, _I, _L, _I, _P, _P, _I, _P, _I, _I, _P],

@@ -904,7 +904,7 @@ class RfcbamFn(torch.autograd.Function):
             out = torch.empty_like(u)
             ops.bnact_fwd(u, o, n * ho * wo, o, es, t, ACT_RELU, out, o)
             ctx.fwd = dict(kw=kw)
-            ctx.rc = dict(th=th, tw=tw, wq=G["wq_c"], mom=G["mom"])       # (mom: the tap moments of the generate BatchNorm, re-used by the backward)
+            ctx.rc = dict(th=th, tw=tw, wq=G["wq_c"])
         else:
             th, tw = ops.pick_tile(ho, wo)
             wq_stats, wq_main = G["wq_stats"], G["wq_main"]
@@ -1119,12 +1119,9 @@ def _rfcbam_backward_rc(ctx, du, dgo, dbo):
     if t18 is not None and not d18:
         ops.grad_done(ctx.getw_param)
     P.d_mm = p(d_mm)
-    rc8 = RC8_BWD and ctx.rc.get("mom") is not None          # eight waves, taps split over the half waves (csrc/ly_rf3c_bwd8.hip)
-    bwd = L.lib().ly_rf3c_bwd8 if rc8 else L.lib().ly_rf3c_bwd
-    kname = "ly_rf3c_bwd8_kernel" if rc8 else "ly_rf3c_bwd_kernel"
-    # B: BatchNorm sums, one stripe per image (eight-wave form: + its share of the A rows of the generate weight gradient)
-    with ops._Timed(f"{kname}<1, {o // 32}>", 2.0 * mo * 9 * c * o, xb, valu_flops=2.0 * mo * c * (81 + (72 if rc8 else 0))):
-        L.check(bwd(ctypes.byref(P), 1, st), "ly_rf3c_bwd B")
+    # B: BatchNorm sums, one stripe per image
+    with ops._Timed(f"ly_rf3c_bwd_kernel<1, {o // 32}>", 2.0 * mo * 9 * c * o, xb, valu_flops=2.0 * mo * c * 81):
+        L.check(L.lib().ly_rf3c_bwd(ctypes.byref(P), 1, st), "ly_rf3c_bwd B")
     tgg, tgb = (ops.grad_target(q) for q in ctx.gen_bn_params)
     bn_direct = all(q is not None and q.numel() == 9 * c and q.is_contiguous() for q in (tgg, tgb))
     dgg_tc, dbg_tc, alpha, kappa, lam = ops.bn_bwd_coeffs(sums, 9 * c, mo, ag, gmean_tc, ginv_tc, True, dgamma=tgg if bn_direct else None,
@@ -1147,22 +1144,10 @@ def _rfcbam_backward_rc(ctx, du, dgo, dbo):
         ops.grad_done(se_wb)
     P.dgap = p(dgap)
     P.TH, P.TW = ops.pick_tile_bwd_dx(ho, wo, o)          # pass C walks its pixel pairs in four colours: its own tile choice
-    # C: dx (+ four-wave form: the generate weight gradient rows; eight-wave form: the rest of the A rows)
-    # regenerate (81 MAC) + dx (81) [+ generate weight gradient (81 / 9)] per (output pixel, channel) on the VALU; dG = W^T du on the MFMAs
-    with ops._Timed(f"{kname}<2, {o // 32}>", 2.0 * mo * 9 * c * o, xb + xr.element_size() * n * h * w * c, valu_flops=2.0 * mo * c * (171 if rc8 else 243)):
-        L.check(bwd(ctypes.byref(P), 2, st), "ly_rf3c_bwd C")
-    if rc8:
-        # d(generate.0.weight) = alpha A + kappa m + lambda (w . M): A summed over the images, m / M the forward's tap moments
-        a_tot = ops.sum_rows(dwg)
-        tgw = ops.grad_target(ctx.gen_w_param)
-        sunk = tgw is not None and tgw.is_contiguous() and tgw.numel() == c * 81
-        dgw_out = tgw if sunk else torch.empty(gen_w.shape, dtype=torch.float32, device=dev)
-        L.check(L.lib().ly_rf3c_dwg_finish(p(a_tot), p(alpha), p(ctx.rc["mom"]), p(gen_w.detach()), c, p(dgw_out), int(sunk), st), "ly_rf3c_dwg_finish")
-        if sunk:
-            ops.grad_done(ctx.gen_w_param)
-        dbias = None if ops.grad_target(ctx.conv_b_param) is not None else torch.zeros_like(bias)      # BN removes the batch mean: d/dbias = 0
-        return (None, dx if need_dx else None, None if se_direct else dwa, None if se_direct else dwb, None if sunk else dgw_out, ct(dgg_tc), ct(dbg_tc),
-                (None if t18 is not None else dw18.view(getw.shape)), dwc, dbias, dgo, dbo)
+    # C: generate weight gradient rows + dx
+    # pass C: regenerate (81 MAC) + generate weight gradient (81) + dx (81) per (output pixel, channel) on the VALU; dG = W^T du on the MFMAs
+    with ops._Timed(f"ly_rf3c_bwd_kernel<2, {o // 32}>", 2.0 * mo * 9 * c * o, xb + xr.element_size() * n * h * w * c, valu_flops=2.0 * mo * c * 243):
+        L.check(L.lib().ly_rf3c_bwd(ctypes.byref(P), 2, st), "ly_rf3c_bwd C")
     dbias = None if ops.grad_target(ctx.conv_b_param) is not None else torch.zeros_like(bias)      # BN removes the batch mean: d/dbias = 0
     tgw = ops.grad_target(ctx.gen_w_param)
     if tgw is not None and tgw.is_contiguous() and tgw.numel() == dwg.shape[1]:
@@ -1274,7 +1259,6 @@ RfcbamFn._backward_k1 = staticmethod(_rfcbam_backward_k1)
 RF1_BWD = True         # tools: False keeps the first-generation k = 1 backward
 RF3S_BWD = True        # tools: False keeps the thread = channel attention / ReLU passes of the streamed k = 3 backward
 RC_BWD = True          # tools: False keeps the first-generation backward behind the lane = channel forward
-RC8_BWD = True         # tools: False keeps passes B / C of the recompute backward on the four-wave kernels (csrc/ly_rf3c_bwd.hip)
 def rfcbam_train(mod, x):
     """RFCBAMConv.forward in training: one autograd node (SE, generate BatchNorm, attention maps, contraction)."""
     g, cv = mod.generate, mod.conv

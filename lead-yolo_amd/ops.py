@@ -922,7 +922,7 @@ def rfcbam_gen_prepare(x, ldx, n, h, w, c, k, s, gen_w, bn):
     from . import pack
     pack.touch()                                   # running statistics written behind torch's version counters
     return dict(gs=out8[0], gb=out8[1], gmean=out8[2], ginv=out8[3], ag=out8[4], bg=out8[5], gmean_tc=out8[6], ginv_tc=out8[7], a1=a1,
-                wq_stats=wqs, wq_main=wqm, wq_c=wqc, mom=mom if k == 3 else None)
+                wq_stats=wqs, wq_main=wqm, wq_c=wqc)
 
 
 # ---- backward building blocks (training step) --------------------------------------------------------

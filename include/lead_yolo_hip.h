@@ -51,7 +51,7 @@ int ly_mlpblock_pconv(const void* x /*T*/, void* z /*T*/, int n_img, int H, int 
  * Nothing 2C wide touches HBM.  wp / w1 as for ly_mlpblock_fwd (planes = 1); w2t = frag-packed mlp.3.weight^T [2C (rows padded to
  * 16*hidden_tiles), C]; w1t = frag-packed mlp.0.weight^T [C, 2C]; a, b (and alpha, kappa, lambda) have 2C entries.  The caller finishes with
  * dx = dy + [pconv^T(g[:, :C/4]) | g[:, C/4:]] (ly_mlpblock_pconv_add) and the partial conv's weight gradient (ly_wgrad on g, x).
- * Built for C in {16, 24, 40} (ly_mlpblock_bwd_ok); x, dy, g dense [n*H*W, C], 16-byte aligned.                                                  */
+ * Built for C in {16, 24, 40, 80} (ly_mlpblock_bwd_ok); x, dy, g dense [n*H*W, C], 16-byte aligned.                                                  */
 int ly_mlpblock_bwd_ok(int C, int dtype);
 long ly_mlpblock_bwd_slab_floats(int C);
 int ly_mlpblock_bwd(const void* x /*T*/, const void* dy /*T*/, void* g /*T*/, int n_img, int H, int W, int C, const void* wp, const void* w1,
@@ -61,7 +61,9 @@ int ly_mlpblock_bwd(const void* x /*T*/, const void* dy /*T*/, void* g /*T*/, in
  * transposed-flipped taps, frag-packed like wp — plus the residual of MLPBlock.forward, models/common.py:1478-1482) and, where built (2-D patches,
  * C/4 <= 32: returns 0), dwp[co * lddw + tap * dw_ts + ci * dw_cs] += sum_p g[p][co] x[p + tap][ci], the gradient of partial_conv3.weight
  * (models/common.py:1412-1437), through `slab` (ly_mlpblock_bwd_slab_floats(C) floats) and a fixed-order combine.  Returns 1 when only dx was
- * produced (the caller then runs ly_wgrad on (g, x)).  g, dy, x, dx dense [n*H*W, C], 16-byte aligned, dx not aliasing g / dy.  C in {16,24,40,80,160,320}. */
+ * produced (the caller then runs ly_wgrad on (g, x)).  g, dy, x, dx dense [n*H*W, C], 16-byte aligned, dx not aliasing g / dy.
+ * ly_mlpblock_bwd_dx_ok(C, W, dtype): 1 when the kernel is built for the channel count (16, 24, 40, 80, 160) and its tile fits LDS at map width W. */
+int ly_mlpblock_bwd_dx_ok(int C, int W, int dtype);
 int ly_mlpblock_bwd_dx(const void* g /*T*/, const void* dy /*T*/, const void* x /*T*/, void* dx /*T*/, int n_img, int H, int W, int C, const void* wpt,
                        float* slab, long slab_floats, float* dwp, int lddw, int dw_ts, int dw_cs, int dtype, void* stream);
 /* hidden (2C) channel tiles of 16, padded to an even count */

@@ -101,6 +101,7 @@ SIGNATURES = {
     "ly_mlpblock_fwd": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P],
     "ly_mlpblock_hidden_tiles": [_I],
     "ly_mlpblock_bwd_ok": [_I, _I],
+    "ly_mlpblock_bwd_dx_ok": [_I, _I, _I],
     "ly_mlpblock_bwd_dx": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _L, _P, _I, _I, _I, _I, _P],
     "ly_mlpblock_bwd_slab_floats": [_I],                 # (returns long: restype set in lib())
     "ly_mlpblock_bwd": [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _I, _I, _P],

@@ -48,6 +48,19 @@ extern "C" int ly_mlpblock_bwd(const void* x, const void* dy, void* g, int n_img
   }
 }
 
+// 1 when ly_mlpblock_bwd_dx is built for (C, map width W, dtype) and its tile fits the 160 KB of LDS (C = 320 never does: 118 KB of tap fragments
+// + an 84 KB tile; the caller then takes the 3x3 data-gradient kernel and an elementwise add)
+extern "C" int ly_mlpblock_bwd_dx_ok(int C, int W, int dtype) {
+  if (dtype != LY_BF16 || W < 1) return 0;
+  switch (C) {
+    case 16: return mlp_bwd_dx_fits<16>(W);
+    case 24: return mlp_bwd_dx_fits<24>(W);
+    case 40: return mlp_bwd_dx_fits<40>(W);
+    case 80: case 160: return ly_mlp_bwd_dx_fits_wide(C, W);
+    default: return 0;
+  }
+}
+
 // dx = dy + [pconv^T(g[:, :C/4]) | g[:, C/4:]] and (where built: 2-D patches, C/4 <= 32) dwp += the partial conv's weight gradient, one launch
 // (+ a combine).  Returns 0: both done; 1: dx done, dwp left to the caller (ly_wgrad on g, x); < 0: error.
 extern "C" int ly_mlpblock_bwd_dx(const void* g, const void* dy, const void* x, void* dx, int n_img, int H, int W, int C, const void* wpt, float* slab,
@@ -70,9 +83,8 @@ extern "C" int ly_mlpblock_bwd_dx(const void* g, const void* dy, const void* x, 
     case 40: return dispatch_mlp_bwd_dx<40>(P, slab_floats, dwp, lddw, dw_ts, dw_cs, st);
     case 80: return ly_mlp_bwd_dx_80(P, slab_floats, dwp, lddw, dw_ts, dw_cs, st);
     case 160: return ly_mlp_bwd_dx_160(P, slab_floats, dwp, lddw, dw_ts, dw_cs, st);
-    case 320: return ly_mlp_bwd_dx_320(P, slab_floats, dwp, lddw, dw_ts, dw_cs, st);
     default:
-      ly_set_error("mlpblock_bwd_dx: unsupported channel count C=%d (built for 16/24/40/80/160/320)", C);
+      ly_set_error("mlpblock_bwd_dx: unsupported channel count C=%d (built for 16/24/40/80/160)", C);
       return -1;
   }
 }

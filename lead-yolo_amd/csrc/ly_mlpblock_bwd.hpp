@@ -1068,13 +1068,26 @@ __global__ __launch_bounds__(1024) void ly_mlpblock_bwd_dx_combine_kernel(const 
   }
 }
 
+// LDS bytes of the tail kernel: transposed-flipped tap fragments + the [128 px][C] tile + the g and x halo frames
+template <int C>
+static size_t mlp_bwd_dx_lds(bool t2d, int W) {
+  using Gm = MlpGeom<C>;
+  const long halo = t2d ? 10 * 18 : 128 + 2 * W + 2;
+  const size_t psb = ((size_t)halo * Gm::RSP + 15 + 64) / 16 * 16;
+  return (size_t)Gm::PT * Gm::SP * 1024 + (size_t)128 * Gm::RS + 2 * psb;
+}
+static inline bool mlp_bwd_dx_patches(int W) {
+  const int wp16 = (W + 15) / 16 * 16;
+  return W >= 12 && 4 * (wp16 - W) <= wp16;
+}
+template <int C>
+static bool mlp_bwd_dx_fits(int W) { return mlp_bwd_dx_lds<C>(mlp_bwd_dx_patches(W), W) <= 160 * 1024; }
+
 template <int C, bool T2D, bool WG>
 static int launch_mlp_bwd_dx(LyMlpDxArgs P, long slab_floats, float* dwp, int lddw, int ts, int cs, hipStream_t st) {
   using Gm = MlpGeom<C>;
   constexpr int BP = 128, PT = Gm::PT;
-  const long halo = T2D ? 10 * 18 : BP + 2 * P.W + 2;
-  const size_t psb = ((size_t)halo * Gm::RSP + 15 + 64) / 16 * 16;
-  const size_t lds = (size_t)PT * Gm::SP * 1024 + (size_t)BP * Gm::RS + 2 * psb;
+  const size_t lds = mlp_bwd_dx_lds<C>(T2D, P.W);
   LY_CHECK(lds <= 160 * 1024, "mlpblock_bwd_dx: tile needs %zu B of LDS (C=%d W=%d)", lds, C, P.W);
   auto k = ly_mlpblock_bwd_dx_kernel<C, T2D, WG>;
   static LyDevOnce once;
@@ -1108,8 +1121,7 @@ static int launch_mlp_bwd_dx(LyMlpDxArgs P, long slab_floats, float* dwp, int ld
 // returns 0: dx and dwp done; 1: dx done, the partial conv's weight gradient is left to the caller (ly_wgrad); < 0: error
 template <int C>
 static int dispatch_mlp_bwd_dx(LyMlpDxArgs P, long slab_floats, float* dwp, int lddw, int ts, int cs, hipStream_t st) {
-  const int wp16 = (P.W + 15) / 16 * 16;
-  const bool patches = P.W >= 12 && 4 * (wp16 - P.W) <= wp16;
+  const bool patches = mlp_bwd_dx_patches(P.W);
   if constexpr (MlpGeom<C>::PT <= 2) {
     if (patches && dwp) return launch_mlp_bwd_dx<C, true, true>(P, slab_floats, dwp, lddw, ts, cs, st);
   }
@@ -1119,4 +1131,4 @@ static int dispatch_mlp_bwd_dx(LyMlpDxArgs P, long slab_floats, float* dwp, int 
 
 int ly_mlp_bwd_dx_80(LyMlpDxArgs P, long slab_floats, float* dwp, int lddw, int ts, int cs, hipStream_t st);
 int ly_mlp_bwd_dx_160(LyMlpDxArgs P, long slab_floats, float* dwp, int lddw, int ts, int cs, hipStream_t st);
-int ly_mlp_bwd_dx_320(LyMlpDxArgs P, long slab_floats, float* dwp, int lddw, int ts, int cs, hipStream_t st);
+bool ly_mlp_bwd_dx_fits_wide(int C, int W);

@@ -627,7 +627,7 @@ class MlpBlockFn(torch.autograd.Function):
                       dw_ts=ts, dw_cs=cs, n_valid=c4, c_valid=c4)
             dx = torch.empty_like(dy)                      # dy + g, the partial conv's channels dy + t
             gz = torch.empty_like(g)
-            if ops.MLP_BWD_FUSED and x.dtype == torch.bfloat16 and c in ops.MLP_WIDTHS:
+            if ops.mlpblock_bwd_dx_ok(x, c, w):
                 # C >= 160 (the fused two-pass backward is not built there): the tail still runs as one launch (csrc/ly_mlpblock_bwd.hpp)
                 dx, _ = ops.mlpblock_bwd_dx(g, dy, x, n, h, w, c, pack.packed(pack.src_taps(p_wpc, c4p, transposed_flipped=True), 9 * c4p, pl))
             elif ops.mlpblock_pconv(g, gz, n, h, w, c, pack.packed(pack.src_taps(p_wpc, c4p, transposed_flipped=True), 9 * c4p, pl)):

@@ -627,7 +627,7 @@ def mlpblock(x, y, n, h, w, c, wp, w1, w2, sc, sh, stats=None):
 
 
 def mlpblock_bwd_ok(x, c):
-    """the fused MLPBlock backward (csrc/ly_mlpblock_bwd.hpp) is built for bf16 storage and the narrow stages (C in 16 / 24 / 40)"""
+    """the fused MLPBlock backward (csrc/ly_mlpblock_bwd.hpp) is built for bf16 storage and C in 16 / 24 / 40 / 80"""
     return MLP_BWD_FUSED and x.dtype == torch.bfloat16 and bool(capi.lib().ly_mlpblock_bwd_ok(c, capi.dtype_code(x)))
 
 
@@ -658,6 +658,11 @@ def mlpblock_bwd(x, dy, n, h, w, c, wp, w1, w2t, w1t, a, b, *, stats=None, g=Non
         capi.check(capi.lib().ly_mlpblock_bwd(_p(x), _p(dy), _p(g), n, h, w, c, _p(wp), _p(w1), _p(w2t), _p(w1t), _p(a), _p(b), _p(alpha), _p(kappa), _p(lam),
                                               _p(stats), _p(slab), slab.numel() if slab is not None else 0, _p(dw1), _p(dw2), 1 if p1 else 2,
                                               capi.dtype_code(x), capi.stream_ptr()), "ly_mlpblock_bwd")
+
+
+def mlpblock_bwd_dx_ok(x, c, w):
+    """ly_mlpblock_bwd_dx is built for this (storage, C) and its tile fits LDS at map width w"""
+    return MLP_BWD_FUSED and x.dtype == torch.bfloat16 and bool(capi.lib().ly_mlpblock_bwd_dx_ok(c, w, capi.dtype_code(x)))
 
 
 def mlpblock_bwd_dx(g, dy, x, n, h, w, c, wpt, dwp=None, lddw=0, dw_ts=0, dw_cs=0):

@@ -41,7 +41,7 @@ def test_single_gpu_line():
     assert abs(r["algorithmic_valu_flops_per_launch"] / sec / 157.3e12 - r["valu_frac"]) < 2e-3
     # the named kernel is picked deterministically: the instrumented kernel with the most time per step; the longest single launch beside it
     big = r["largest_single_launch"]
-    assert big["ms_per_launch"] >= r["ms_per_launch"] - 1e-9 and r["ms_per_step"] >= big["ms_per_launch"] * big["launches_per_step"] - 1e-6
+    assert big["ms_per_launch"] >= r["ms_per_launch"] - 1e-9 and r["ms_per_step"] >= big["ms_per_launch"] * big["launches_per_step"] - 1e-3   # both rounded to 4-5 digits
     busy = (r.get("mfma_busy") or {}).get("mfma_busy_frac")
     if busy and d["config"].get("global_batch") == 64:        # the committed PMC pass is the default (bs = 64) workload's
         assert r["mfma_frac"] <= 1.5 * busy + 1e-3, "the MFMA fraction claimed exceeds what the matrix-pipe counter saw"
@@ -59,7 +59,11 @@ def test_named_kernel_is_row_0_of_the_committed_step_table():
     d = json.loads([ln for ln in open(path).read().splitlines() if ln.startswith("{")][-1])
     rows = [ln for ln in open(table).read().splitlines()[1:] if ln.strip()]
     name = d["roofline"]["kernel"]
-    assert rows[0].startswith(name.split("<")[0]) and d["roofline"]["frac"] == d["roofline"]["hbm_frac"]
+    assert rows[0].startswith(name) and d["roofline"]["frac"] == d["roofline"]["hbm_frac"]
+    # the whole-process rocprofv3 trace of the same command (kernel-trace --stats, per step) names the same kernel first
+    trace = os.path.join(ROOT, "profiles", "r05_train_bf16_kernels_per_step.txt")
+    if os.path.exists(trace):
+        assert [ln for ln in open(trace).read().splitlines()[1:] if ln.strip()][0].startswith(name)
 
 
 def test_two_rank_launch_path_dry_run():

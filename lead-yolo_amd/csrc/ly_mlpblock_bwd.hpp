@@ -48,12 +48,12 @@ struct LyMlpBwdArgs {
   float* slab;                   // pass 2: [gridDim.x][MlpBwdGeom::SLAB] raw accumulator tiles
 };
 
-template <int C>
+template <int C, int PASS = 2>
 struct MlpBwdGeom {
   using Gm = MlpGeom<C>;
   static constexpr int HTR = 2 * C / 16;                   // real hidden tiles (2C is a multiple of 16)
   static constexpr bool DWX = C >= 80;
-  static constexpr int NT = DWX ? 1 : 2;                   // pixel tiles of 16 per wave
+  static constexpr int NT = DWX ? 1 : 2;                   // pixel tiles of 16 per wave (C = 80 pass 1 at NT = 2: 47 spilled registers, 45 -> 50 us)
   static constexpr int BP = 64 * NT;
   static constexpr int DT = DWX ? 4 : Gm::HTP;             // hidden tiles per du / h round (DWX: one per wave)
   static constexpr int NRD = (Gm::HTP + DT - 1) / DT;      // rounds
@@ -67,10 +67,11 @@ struct MlpBwdGeom {
 // PD = patches in flight ahead of the one being computed (T2D, one or two register sets).  MEASURED: two sets change nothing (C = 24 pass 1
 // 80.7 -> 80.7 us, C = 40 64 -> 68 us at bs = 64) — a patch's arithmetic already covers the HBM round trip; the passes are paced by instruction
 // issue and the LDS pipe (PMC: a third of the wave cycles in LDS-issue stalls), not by loads in flight.  PD = 1 everywhere.
+// (C = 40 pass 1 pinned to two waves per SIMD — 256 registers, 17 spilled — was measured: module 273 -> 286 us)
 template <int C, int HT, bool T2D, int PASS, int PD>
 __device__ __forceinline__ void ly_mlp_bwd_body(const LyMlpBwdArgs& P) {
   using Gm = MlpGeom<C>;
-  using Bg = MlpBwdGeom<C>;
+  using Bg = MlpBwdGeom<C, PASS>;
   using T = __bf16;
   typedef ly_u32x4 RV;
   typedef ly_u32x2 R4;
@@ -386,6 +387,19 @@ __device__ __forceinline__ void ly_mlp_bwd_body(const LyMlpBwdArgs& P) {
             w2f[s][t] = wlds(NFP + NF1 + (hc * HT + t) * S1 + s);
           }
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < S1; ++s)
+#pragma unroll
+          for (int t = 0; t < HT; ++t) {
+            if (hc * HT + t >= HTR) continue;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+              au[t][n] = ly_mfma_bf16(w1f[s][t], xb[s][n], au[t][n]);
+              ad[t][n] = ly_mfma_bf16(w2f[s][t], db[s][n], ad[t][n]);
+            }
+          }
+        // W1^T fragments of g += W1^T du and the BatchNorm coefficients: read behind the MFMAs (not live beside the operand sets)
         if constexpr (PASS == 2) {
 #pragma unroll
           for (int u2 = 0; u2 < HT / 2; ++u2) {
@@ -403,18 +417,6 @@ __device__ __forceinline__ void ly_mlp_bwd_body(const LyMlpBwdArgs& P) {
           cfa[t] = coef(0, ch); cfb[t] = coef(1, ch);
           if constexpr (PASS == 2) { cal[t] = coef(2, ch); cka[t] = coef(3, ch); cla[t] = coef(4, ch); }
         }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int s = 0; s < S1; ++s)
-#pragma unroll
-          for (int t = 0; t < HT; ++t) {
-            if (hc * HT + t >= HTR) continue;
-#pragma unroll
-            for (int n = 0; n < NT; ++n) {
-              au[t][n] = ly_mfma_bf16(w1f[s][t], xb[s][n], au[t][n]);
-              ad[t][n] = ly_mfma_bf16(w2f[s][t], db[s][n], ad[t][n]);
-            }
-          }
         bf16x4 dub[HT][NT], hb[HT][NT];
 #pragma unroll
         for (int t = 0; t < HT; ++t) {
@@ -646,7 +648,7 @@ template <int C, int HT, bool T2D, int PASS>
 static int launch_mlp_bwd(LyMlpBwdArgs P, long slab_floats, int* blocks_out, hipStream_t st) {
   constexpr int PD = 1;
   using Gm = MlpGeom<C>;
-  using Bg = MlpBwdGeom<C>;
+  using Bg = MlpBwdGeom<C, PASS>;
   constexpr int BP = Bg::BP, NT = Bg::NT;
   const long halo = T2D ? (4 * NT + 2) * 18 : BP + 2 * P.W + 2;
   const size_t lds = (size_t)(Bg::NFP + 2 * Bg::NF1 + (PASS == 2 ? Bg::NF1T : 0)) * 1024 + (PASS == 2 ? 5 : 2) * 2 * C * 4 + 2 * (size_t)BP * Gm::RS +

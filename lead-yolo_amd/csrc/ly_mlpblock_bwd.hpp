@@ -598,8 +598,11 @@ __device__ __forceinline__ void ly_mlp_bwd_body(const LyMlpBwdArgs& P) {
   }
 }
 
+#ifndef LY_MLPB_WAVES
+#define LY_MLPB_WAVES(C, PASS) (((C) == 24 && (PASS) == 1) ? 3 : 1)
+#endif
 template <int C, int HT, bool T2D, int PASS, int PD>
-__global__ __launch_bounds__(LY_THREADS) void ly_mlpblock_bwd_kernel(const LyMlpBwdArgs P) {
+__global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(LY_MLPB_WAVES(C, PASS)))) void ly_mlpblock_bwd_kernel(const LyMlpBwdArgs P) {
   ly_mlp_bwd_body<C, HT, T2D, PASS, PD>(P);
 }
 
@@ -946,41 +949,52 @@ __device__ __forceinline__ void ly_mlp_bwd_dx_body(const LyMlpDxArgs& P) {
       for (int t = 0; t < PT; ++t)
 #pragma unroll
         for (int n = 0; n < NT; ++n) accp[t][n] = zero;
-      bf16x8 xh[SP][NT], wpf[SP][PT];
+      // operand reads in batches of SB k-steps ahead of their MFMAs (all SP at once for C <= 80; C = 160: 12 k-steps x 5 fragments would be
+      // 240 registers — 32 spilled)
+      constexpr int SB = SP <= 6 ? SP : 4;
 #pragma unroll
-      for (int s = 0; s < SP; ++s) {
-        int off[2], tap[2];
-        bool gv[2];
+      for (int s0 = 0; s0 < SP; s0 += SB) {
+        bf16x8 xh[SB][NT], wpf[SB][PT];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int gq = 8 * s + 4 * h + lq;
-          gv[h] = gq < 9 * G;
-          tap[h] = gv[h] ? gq / G : 0;
-          const int cq4 = gv[h] ? gq - tap[h] * G : 0;
-          const int ty = tap[h] / 3, tx = tap[h] - 3 * ty;
-          off[h] = (ty * rowpitch + tx) * RSP + 8 * cq4;
-        }
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-          bf16x4 ph[2];
+        for (int sb = 0; sb < SB; ++sb) {
+          const int s = s0 + sb;
+          if (s >= SP) continue;
+          int off[2], tap[2];
+          bool gv[2];
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
-            const bool ok = gv[h] && (T2D || ((tmask[n] >> tap[h]) & 1u));
-            const bf16x4 a = *reinterpret_cast<const bf16x4*>(psg + pbase[n] + off[h]);
-            ph[h] = ok ? a : z4;
+            const int gq = 8 * s + 4 * h + lq;
+            gv[h] = gq < 9 * G;
+            tap[h] = gv[h] ? gq / G : 0;
+            const int cq4 = gv[h] ? gq - tap[h] * G : 0;
+            const int ty = tap[h] / 3, tx = tap[h] - 3 * ty;
+            off[h] = (ty * rowpitch + tx) * RSP + 8 * cq4;
           }
-          xh[s][n] = ly_cat8(ph[0], ph[1]);
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            bf16x4 ph[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const bool ok = gv[h] && (T2D || ((tmask[n] >> tap[h]) & 1u));
+              const bf16x4 a = *reinterpret_cast<const bf16x4*>(psg + pbase[n] + off[h]);
+              ph[h] = ok ? a : z4;
+            }
+            xh[sb][n] = ly_cat8(ph[0], ph[1]);
+          }
+#pragma unroll
+          for (int t = 0; t < PT; ++t) wpf[sb][t] = wlds(t * SP + s);
         }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < PT; ++t) wpf[s][t] = wlds(t * SP + s);
+        for (int sb = 0; sb < SB; ++sb) {
+          if (s0 + sb >= SP) continue;
+#pragma unroll
+          for (int t = 0; t < PT; ++t)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) accp[t][n] = ly_mfma_bf16(wpf[sb][t], xh[sb][n], accp[t][n]);
+        }
+        if (s0 + SB < SP) __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int s = 0; s < SP; ++s)
-#pragma unroll
-        for (int t = 0; t < PT; ++t)
-#pragma unroll
-          for (int n = 0; n < NT; ++n) accp[t][n] = ly_mfma_bf16(wpf[s][t], xh[s][n], accp[t][n]);
 #pragma unroll
       for (int t = 0; t < PT; ++t)
 #pragma unroll

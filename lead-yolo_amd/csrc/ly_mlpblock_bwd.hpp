@@ -606,43 +606,56 @@ __global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(LY_M
   ly_mlp_bwd_body<C, HT, T2D, PASS, PD>(P);
 }
 
-// dw1[hid][c] += sum_b slab[b][0][t][ct][lane][r],  dw2[c][hid] += sum_b slab[b][1][...]   with hid = 16 t + 4 (lane >> 4) + r, c = 16 ct + (lane & 15)
-// (fixed block order: bit-reproducible).  Block = 64 consecutive float4 slab entries x RL row lanes over the blocks.
-template <int C>
-__global__ __launch_bounds__(1024) void ly_mlpblock_bwd_combine_kernel(const float* __restrict__ slab, const int nblk, float* __restrict__ dw1,
-                                                                      float* __restrict__ dw2, const int rls) {
-  using Bg = MlpBwdGeom<C>;
-  constexpr int C16 = MlpGeom<C>::C16;
-  __shared__ f32x4 red[16][64];
-  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int e = blockIdx.x * 64 + cl;                          // float4 entry of the slab
-  const bool live = e < Bg::SLAB / 4;
+// Fold of the blocks' slabs in a FIXED order (bit-reproducible): a block of 1024 threads owns EL consecutive float4 entries of the slab and
+// 1024 / EL row lanes; row lane r adds the slabs r, r + RL, r + 2 RL ... in index order, the lanes meet in a binary tree over LDS.  EL is
+// chosen by the launch so that the grid has ~100+ blocks (C = 24: 576 entries — at EL = 64 the fold ran on 9 CUs: 18.6 us).
+template <int EL>
+__device__ __forceinline__ bool ly_mlp_slab_fold(const float* __restrict__ slab, const int nblk, const int entries, int& e, f32x4& s) {
+  constexpr int RL = 1024 / EL;
+  __shared__ f32x4 red[1024];
+  const int cl = threadIdx.x % EL, rl = threadIdx.x / EL;
+  e = blockIdx.x * EL + cl;
+  const bool live = e < entries;
   f32x4 acc0 = ly_zero4(), acc1 = ly_zero4();
   if (live) {
     const f32x4* p = reinterpret_cast<const f32x4*>(slab) + e;
     int b = rl;
-    for (; b + rls < nblk; b += 2 * rls) {
-      const f32x4 v0 = p[(size_t)b * (Bg::SLAB / 4)], v1 = p[(size_t)(b + rls) * (Bg::SLAB / 4)];
+    for (; b + RL < nblk; b += 2 * RL) {
+      const f32x4 v0 = p[(size_t)b * entries], v1 = p[(size_t)(b + RL) * entries];
       acc0 += v0; acc1 += v1;
     }
-    if (b < nblk) acc0 += p[(size_t)b * (Bg::SLAB / 4)];
+    if (b < nblk) acc0 += p[(size_t)b * entries];
   }
-  red[rl][cl] = acc0 + acc1;
+  red[rl * EL + cl] = acc0 + acc1;
   __syncthreads();
-  if (rl == 0 && live) {
-    f32x4 s = red[0][cl];
-    for (int i = 1; i < rls; ++i) s += red[i][cl];
-    const int which = e / (Bg::NACC * 64), rem = e - which * (Bg::NACC * 64);
-    const int tile = rem >> 6, lane = rem & 63;
-    const int t = tile / C16, ct = tile - t * C16;
-    const int c = 16 * ct + (lane & 15);
-    if (c < C) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int hid = 16 * t + 4 * (lane >> 4) + r;
-        float* const d = which == 0 ? dw1 + (size_t)hid * C + c : dw2 + (size_t)c * (2 * C) + hid;
-        *d += s[r];
-      }
+  for (int h = RL / 2; h > 0; h >>= 1) {
+    if (rl < h) red[rl * EL + cl] += red[(rl + h) * EL + cl];
+    __syncthreads();
+  }
+  s = red[cl];
+  return live && rl == 0;
+}
+
+// dw1[hid][c] += sum_b slab[b][0][t][ct][lane][r],  dw2[c][hid] += sum_b slab[b][1][...]   with hid = 16 t + 4 (lane >> 4) + r, c = 16 ct + (lane & 15)
+template <int C, int EL>
+__global__ __launch_bounds__(1024) void ly_mlpblock_bwd_combine_kernel(const float* __restrict__ slab, const int nblk, float* __restrict__ dw1,
+                                                                      float* __restrict__ dw2) {
+  using Bg = MlpBwdGeom<C>;
+  constexpr int C16 = MlpGeom<C>::C16;
+  int e;
+  f32x4 s;
+  if (!ly_mlp_slab_fold<EL>(slab, nblk, Bg::SLAB / 4, e, s)) return;
+  const int which = e / (Bg::NACC * 64), rem = e - which * (Bg::NACC * 64);
+  const int tile = rem >> 6, lane = rem & 63;
+  const int t = tile / C16, ct = tile - t * C16;
+  const int c = 16 * ct + (lane & 15);
+  if (c < C) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int hid = 16 * t + 4 * (lane >> 4) + r;
+      float* const d = which == 0 ? dw1 + (size_t)hid * C + c : dw2 + (size_t)c * (2 * C) + hid;
+      *d += s[r];
     }
   }
 }
@@ -688,8 +701,8 @@ static int launch_mlp_bwd(LyMlpBwdArgs P, long slab_floats, int* blocks_out, hip
 template <int C>
 static int launch_mlp_bwd_combine(const float* slab, int nblk, float* dw1, float* dw2, hipStream_t st) {
   using Bg = MlpBwdGeom<C>;
-  const int rls = nblk <= 64 ? 4 : 16;
-  hipLaunchKernelGGL((ly_mlpblock_bwd_combine_kernel<C>), dim3((Bg::SLAB / 4 + 63) / 64), dim3(64 * rls), 0, st, slab, nblk, dw1, dw2, rls);
+  constexpr int EL = Bg::SLAB / 4 >= 6400 ? 64 : 16;       // entries per block: >= 48 blocks in every case
+  hipLaunchKernelGGL((ly_mlpblock_bwd_combine_kernel<C, EL>), dim3((Bg::SLAB / 4 + EL - 1) / EL), dim3(1024), 0, st, slab, nblk, dw1, dw2);
   LY_LAUNCH_CHECK();
   return 0;
 }
@@ -1053,33 +1066,21 @@ __global__ __launch_bounds__(LY_THREADS) void ly_mlpblock_bwd_dx_kernel(const Ly
 }
 
 // dwp[co * lddw + tap * ts + ci * cs] += sum_b slab[b][tap][to][ti][lane][r],  co = 16 to + 4 (lane >> 4) + r, ci = 16 ti + (lane & 15)   (fixed order)
-template <int C>
+template <int C, int EL>
 __global__ __launch_bounds__(1024) void ly_mlpblock_bwd_dx_combine_kernel(const float* __restrict__ slab, const int nblk, float* __restrict__ dwp,
-                                                                         const int lddw, const int ts, const int cs, const int rls) {
+                                                                         const int lddw, const int ts, const int cs) {
   constexpr int PT = MlpGeom<C>::PT, CQ = MlpGeom<C>::CQ, NE = 9 * PT * PT * 64;
-  __shared__ f32x4 red[16][64];
-  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int e = blockIdx.x * 64 + cl;
-  const bool live = e < NE;
-  f32x4 acc = ly_zero4();
-  if (live) {
-    const f32x4* p = reinterpret_cast<const f32x4*>(slab) + e;
-    for (int b = rl; b < nblk; b += rls) acc += p[(size_t)b * NE];
-  }
-  red[rl][cl] = acc;
-  __syncthreads();
-  if (rl == 0 && live) {
-    f32x4 s = red[0][cl];
-    for (int i = 1; i < rls; ++i) s += red[i][cl];
-    const int tile = e >> 6, lane = e & 63;
-    const int tap = tile / (PT * PT), to = (tile / PT) % PT, ti = tile % PT;
-    const int ci = 16 * ti + (lane & 15);
-    if (ci < CQ) {
+  int e;
+  f32x4 s;
+  if (!ly_mlp_slab_fold<EL>(slab, nblk, NE, e, s)) return;
+  const int tile = e >> 6, lane = e & 63;
+  const int tap = tile / (PT * PT), to = (tile / PT) % PT, ti = tile % PT;
+  const int ci = 16 * ti + (lane & 15);
+  if (ci < CQ) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int co = 16 * to + 4 * (lane >> 4) + r;
-        if (co < CQ) dwp[(size_t)co * lddw + (size_t)tap * ts + (size_t)ci * cs] += s[r];
-      }
+    for (int r = 0; r < 4; ++r) {
+      const int co = 16 * to + 4 * (lane >> 4) + r;
+      if (co < CQ) dwp[(size_t)co * lddw + (size_t)tap * ts + (size_t)ci * cs] += s[r];
     }
   }
 }
@@ -1127,8 +1128,8 @@ static int launch_mlp_bwd_dx(LyMlpDxArgs P, long slab_floats, float* dwp, int ld
   P.ntiles = (int)ntiles;
   hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(LY_THREADS), lds, st, P);
   if (WG) {
-    const int rls = blocks <= 64 ? 4 : 16;
-    hipLaunchKernelGGL((ly_mlpblock_bwd_dx_combine_kernel<C>), dim3((9 * PT * PT * 64 + 63) / 64), dim3(64 * rls), 0, st, P.slab, (int)blocks, dwp, lddw, ts, cs, rls);
+    constexpr int NE = 9 * PT * PT * 64, EL = NE >= 2304 ? 32 : 8;      // 72 blocks in both cases
+    hipLaunchKernelGGL((ly_mlpblock_bwd_dx_combine_kernel<C, EL>), dim3((NE + EL - 1) / EL), dim3(1024), 0, st, P.slab, (int)blocks, dwp, lddw, ts, cs);
   }
   LY_LAUNCH_CHECK();
   return WG ? 0 : 1;

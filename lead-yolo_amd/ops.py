@@ -7,6 +7,7 @@ Storage dtype: every wrapper takes it from its activation argument — float32 (
 products, BASELINE configs[2]-[4]); outputs have the input's dtype, statistics / attention tables / weight gradients
 are float32.  `edge_in` is the dtype policy at a module's edge (autocast, .half())."""
 import ctypes
+import os
 
 import torch
 
@@ -558,6 +559,7 @@ def small_grads_reset():
     """drop whatever an aborted backward pass left behind (the engine discards a graph task's final callbacks when a backward raises:
     the entries would otherwise wait for a flush that never comes)"""
     _SmallGrads.pending, _SmallGrads.task = [], -1
+    _WgradQueue.items, _WgradQueue.task = [], -1
 
 
 def small_grad_scratch(target, param):
@@ -830,6 +832,12 @@ class GradSink:
         self.writes = 0            # bumped whenever a backward kernel is handed a target (or a captured backward is replayed): the
                                    # optimiser's zero_grad() compares it with the value at its last step() to know whether the storage is dirty
 
+    def is_target(self, t):
+        """t is (a view from the start of) one of the sink's persistent gradient tensors"""
+        if len(self.targets) != getattr(self, "_nptr", -1):
+            self._ptrs, self._nptr = {v.data_ptr() for v in self.targets.values()}, len(self.targets)
+        return t.data_ptr() in self._ptrs
+
     def target(self, p):
         if p is None or not torch.is_tensor(p):
             return None
@@ -982,13 +990,16 @@ def bnact_bwd_apply_pair(dy1, lddy1, dy2, lddy2, csplit, u, ldu, rows, c, a, b, 
 
 
 def wgrad(*, M, H, W, N, du, lddu, x, ldx, Hin, Win, Cin, dw, lddw, ks=1, stride=1, pad=0, nchw=False, up2=False, du_off=0, x_off=0,
-          dw_off=0, dw_ts=None, dw_cs=1, n_valid=None, c_valid=None, x_scale=None, x_shift=None):
+          dw_off=0, dw_ts=None, dw_cs=1, n_valid=None, c_valid=None, x_scale=None, x_shift=None, _now=False):
     """dw[n][tap*dw_ts + c*dw_cs] += sum_pixels du[p][n] * x[src(p, tap)][c] for n < n_valid, c < c_valid; *_off are element offsets
     into the tensors.  Defaults: packed rows (dw_ts = Cin, dw_cs = 1), everything valid.  x_scale / x_shift (fp32 [Cin], plain-row 1x1
     problems): x is read as max(x*x_scale + x_shift, 0)."""
-    P = _wgrad_params(M=M, H=H, W=W, N=N, du=du, lddu=lddu, x=x, ldx=ldx, Hin=Hin, Win=Win, Cin=Cin, dw=dw, lddw=lddw, ks=ks, stride=stride,
-                      pad=pad, nchw=nchw, up2=up2, du_off=du_off, x_off=x_off, dw_off=dw_off, dw_ts=dw_ts, dw_cs=dw_cs, n_valid=n_valid,
-                      c_valid=c_valid, x_scale=x_scale, x_shift=x_shift)
+    q = dict(M=M, H=H, W=W, N=N, du=du, lddu=lddu, x=x, ldx=ldx, Hin=Hin, Win=Win, Cin=Cin, dw=dw, lddw=lddw, ks=ks, stride=stride,
+             pad=pad, nchw=nchw, up2=up2, du_off=du_off, x_off=x_off, dw_off=dw_off, dw_ts=dw_ts, dw_cs=dw_cs, n_valid=n_valid,
+             c_valid=c_valid, x_scale=x_scale, x_shift=x_shift)
+    if not _now and _wgrad_deferrable(q):
+        return _wgrad_enqueue(q)
+    P = _wgrad_params(**q)
     with _Timed(wgrad_kernel_name(_tname(x), N, ks * ks * Cin, ks == 1 and stride == 1 and pad == 0 and not nchw and not up2,
                                   (not nchw) and N % 4 == 0 and Cin % 4 == 0 and lddu % 4 == 0 and ldx % 4 == 0, x_scale is not None),
                 2.0 * M * N * ks * ks * Cin, x.element_size() * M * (N + Cin) + 4.0 * N * ks * ks * Cin):
@@ -1030,16 +1041,65 @@ def wgrad_workspace(device):
     return ws
 
 
-def wgrad_group(problems):
+def _wgrad_groupable(q, dtype):
+    return (q.get("ks", 1) == 1 and q.get("stride", 1) == 1 and q.get("pad", 0) == 0 and not q.get("nchw") and not q.get("up2")
+            and q["N"] > 64 and q["N"] % 4 == 0 and q["Cin"] % 4 == 0 and q["lddu"] % 4 == 0 and q["ldx"] % 4 == 0
+            and q["Hin"] == q["H"] and q["Win"] == q["W"] and q["x"].dtype == dtype)
+
+
+class _WgradQueue:
+    """Weight gradients are leaves of the backward pass: a plain-row problem of the 128 x 128 tile class whose destination is the gradient
+    sink's persistent storage need not launch where the backward reaches it.  Such problems wait here (operands kept alive) and leave four
+    at a time as ONE grouped launch + ONE fold (ly_wgrad_group) — the small-map problems (25600 pixels: ~30 us each alone, a few blocks per CU
+    walking long pixel runs) share the chip — and the rest leaves when the pass ends (engine callback).  Program order fixes the grouping:
+    the step stays bit-reproducible and a captured step replays the same launches.  Off while a gradient listener (ddp.GradReducer) is
+    installed: `grad_done` must mean the launch is in the stream.  Narrow problems (Cin <= 64, or a column slice of a wider gradient) stay
+    out: the group runs every problem on the 128 x 128 tile, and with the two K = 40 / 80 concat-slice problems of the neck in the groups
+    the step went from 10.01 to 10.21 ms."""
+    items = []
+    task = -1
+
+
+WGRAD_DEFER = os.environ.get("LY_WGRAD_DEFER", "1") != "0"
+WGRAD_GROUP_MAX = 4
+
+
+def _wgrad_deferrable(q):
+    return (WGRAD_DEFER and SINK is not None and not GRAD_LISTENERS and q["x"].dtype == torch.bfloat16 and _wgrad_groupable(q, torch.bfloat16)
+            and q["Cin"] > 64 and q.get("dw_off", 0) == 0 and SINK.is_target(q["dw"]) and _graph_task() >= 0)
+
+
+def _wgrad_enqueue(q):
+    task = _graph_task()
+    if _WgradQueue.task != task:
+        _WgradQueue.items, _WgradQueue.task = [], task          # (leftovers of a backward pass that raised are dropped with it)
+        torch.autograd.Variable._execution_engine.queue_callback(wgrad_flush)
+    _WgradQueue.items.append(q)
+    if len(_WgradQueue.items) >= WGRAD_GROUP_MAX:
+        wgrad_flush(final=False)
+
+
+def wgrad_flush(final=True):
+    """launch what waits in the deferral queue (end of the backward pass, or four problems collected)"""
+    items, _WgradQueue.items = _WgradQueue.items, []
+    if final:
+        _WgradQueue.task = -1
+    if len(items) == 1:
+        wgrad(_now=True, **items[0])
+    elif items:
+        wgrad_group(items, _now=True)
+
+
+def wgrad_group(problems, _now=False):
     """Several independent weight gradients (each a dict of `wgrad` arguments) in ONE launch when all are plain-row 1x1 problems of the
     128 x 128 tile class (ly_wgrad_group: N > 64, vector-friendly widths, no gather, at most 4); otherwise one `wgrad` each."""
-    def groupable(q):
-        return (q.get("ks", 1) == 1 and q.get("stride", 1) == 1 and q.get("pad", 0) == 0 and not q.get("nchw") and not q.get("up2")
-                and q["N"] > 64 and q["N"] % 4 == 0 and q["Cin"] % 4 == 0 and q["lddu"] % 4 == 0 and q["ldx"] % 4 == 0
-                and q["Hin"] == q["H"] and q["Win"] == q["W"] and q["x"].dtype == problems[0]["x"].dtype)
-    if not (2 <= len(problems) <= 4) or not all(groupable(q) for q in problems):
+    if not _now and all(_wgrad_deferrable(q) for q in problems):
         for q in problems:
-            wgrad(**q)
+            _wgrad_enqueue(q)
+        return
+    if not (2 <= len(problems) <= 4) or not all(_wgrad_groupable(q, problems[0]["x"].dtype) for q in problems):
+        for q in problems:
+            wgrad(_now=_now, **q)
         return
     arr = (capi.LyWgradParams * len(problems))(*[_wgrad_params(**q) for q in problems])
     x0 = problems[0]["x"]

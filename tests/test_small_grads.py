@@ -1,6 +1,7 @@
 """ops.small_grad_scratch: the deferred small-gradient sums are keyed on the autograd graph task: a backward that raises after
 taking a scratch loses its end-of-pass callback with the engine's graph task — the next backward must queue a new one and must not flush
-the aborted pass's leftovers.  Host logic only (the rounding launch ly_f64_add is replaced by its definition: target += scratch)."""
+the aborted pass's leftovers.  Host logic only (the rounding launch ly_f64_add is replaced by its definition: target += scratch).
+Second half: ops._WgradQueue — deferred weight gradients leave in groups of four / at the end of the pass (launches replaced by a recorder)."""
 import pytest
 import torch
 
@@ -70,3 +71,73 @@ def test_reset_at_step_begin(host_flush):
     ops.stats_pool_begin(torch.device("cpu"))
     ops.stats_pool_end()
     assert ops._SmallGrads.pending == []
+
+
+# ---- ops._WgradQueue: deferred, grouped weight gradients -----------------------------------------------------------------------------------
+class _FakeSink:
+    def __init__(self, targets):
+        self.targets = {i: t for i, t in enumerate(targets)}
+    is_target = ops.GradSink.is_target
+
+
+class _FiveWgrads(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dws, boom):
+        ctx.dws, ctx.boom = dws, boom
+        return x * 2.0
+
+    @staticmethod
+    def backward(ctx, g):
+        du = torch.zeros(256, 128, dtype=torch.bfloat16)
+        xx = torch.zeros(256, 128, dtype=torch.bfloat16)
+        for dw in ctx.dws:
+            ops.wgrad(M=256, H=16, W=16, N=128, du=du, lddu=128, x=xx, ldx=128, Hin=16, Win=16, Cin=128, dw=dw, lddw=128)
+        if ctx.boom:
+            raise RuntimeError("backward failed with weight gradients queued")
+        return g * 2.0, None, None
+
+
+def test_deferred_weight_gradients_leave_in_groups_of_four_and_at_the_end_of_the_pass(monkeypatch):
+    """plain-row problems of the 128-tile class with sink-resident destinations wait in ops._WgradQueue: four leave as one grouped launch, the
+    rest when the backward pass ends; a pass that raises leaves nothing behind for the next one; narrow problems and non-sink destinations
+    launch where they are"""
+    launched = []
+    real_group, real_wgrad = ops.wgrad_group, ops.wgrad
+
+    def group(problems, _now=False):
+        if _now:
+            launched.append(("group", [id(q["dw"]) for q in problems]))
+            return
+        return real_group(problems, _now=_now)
+
+    def single(**q):
+        if q.get("_now") or not ops._wgrad_deferrable({k: v for k, v in q.items() if k != "_now"}):
+            launched.append(("single", id(q["dw"])))
+            return
+        return real_wgrad(**q)
+    dws = [torch.zeros(128, 128) for _ in range(5)]
+    monkeypatch.setattr(ops, "SINK", _FakeSink(dws))
+    monkeypatch.setattr(ops, "wgrad_group", group)
+    monkeypatch.setattr(ops, "wgrad", single)
+    monkeypatch.setattr(ops, "WGRAD_DEFER", True)
+    ops.small_grads_reset()
+    x = torch.ones(3, requires_grad=True)
+    _FiveWgrads.apply(x, dws, False).sum().backward()
+    assert launched == [("group", [id(t) for t in dws[:4]]), ("single", id(dws[4]))]
+    assert ops._WgradQueue.items == [] and ops._WgradQueue.task == -1
+    # a pass that raises: its queue is dropped by the next pass (and by small_grads_reset), never launched into another pass's groups
+    launched.clear()
+    with pytest.raises(RuntimeError):
+        _FiveWgrads.apply(x, dws[:2], True).sum().backward()
+    assert launched == [] and len(ops._WgradQueue.items) == 2
+    _FiveWgrads.apply(x, dws[:1], False).sum().backward()
+    assert launched == [("single", id(dws[0]))]
+    # not deferrable: destination outside the sink, narrow K, a gradient listener installed
+    q = dict(M=256, H=16, W=16, N=128, du=torch.zeros(256, 128, dtype=torch.bfloat16), lddu=128, x=torch.zeros(256, 128, dtype=torch.bfloat16), ldx=128,
+             Hin=16, Win=16, Cin=128, dw=torch.zeros(128, 128), lddw=128)
+    assert not ops._wgrad_deferrable(q)                              # (also: not inside a backward pass)
+    monkeypatch.setattr(ops, "GRAD_LISTENERS", [lambda p: None])
+    launched.clear()
+    _FiveWgrads.apply(x, dws[:1], False).sum().backward()
+    assert launched == [("single", id(dws[0]))] and ops._WgradQueue.items == []
+    ops.small_grads_reset()

@@ -431,6 +431,10 @@ def roofline_of(rows, dtype, families=None):
     roof["mfma_busy"] = committed_pmc(dom["kernel"], "pmc_mfma")
     roof["kernel"] = dom["kernel"]
     roof["kernel_is"] = "the instrumented kernel with the most time per step (launches x mean launch time)"
+    if dom["kernel"].startswith(("ly_wgrad", "ly_mlpblock_bwd")):
+        # these C-ABI calls launch the named kernel AND the fixed-order fold of its slabs: the HIP-event pair brackets both (rocprofv3 lists
+        # the fold as its own row: ly_wgrad_combine* / ly_mlpblock_bwd*_combine_kernel)
+        roof["timed_region"] = "one C-ABI call = the named kernel + the fold launch of its partial tiles (ms_per_launch covers both)"
     roof["kernel_family"] = dom_family
     roof["launches_per_step"] = round(dom["calls_per_step"], 2)
     roof["ms_per_launch"] = round(dom["ms_per_launch"], 5)

@@ -551,6 +551,9 @@ template <typename T>
 static int ly_gemm_dispatch(const LyGemmParams& P, hipStream_t st) {
   if (P.N > 64) return launch_gemm<T, 4, 2, 4>(P, st);    // 64 px x 128 ch per block
   if (P.N > 32) return launch_gemm<T, 4, 1, 4>(P, st);    // 64 px x 64 ch
+  // (the CoordAtt-gate prologue on the 128 px x 32 ch tile compiles to 256 registers with 130-320 spilled — tools/kernel_regs.py; lead-yolo-n's
+  // 32-channel C3_CA.cv3 takes the 64 x 64 tile with half its channel tiles idle instead)
+  if (P.pro == LY_PRO_GATE) return launch_gemm<T, 4, 1, 4>(P, st);
   return launch_gemm<T, 2, 2, 1>(P, st);                  // 128 px x 32 ch
 }
 int ly_gemm_dispatch_f32(const LyGemmParams& P, hipStream_t st);

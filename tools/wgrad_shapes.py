@@ -38,15 +38,23 @@ def timed(fn, label, flops, nbytes):
     LOG.append((label, flops, nbytes, e0, e1))
 
 
-def wgrad(**q):
+def wgrad(_now=False, **q):
+    if not _now and ops._wgrad_deferrable(q):
+        return _w(**q)                                   # waits in ops._WgradQueue: timed when its group leaves
     es = q["x"].element_size()
     k = q.get("ks", 1) ** 2 * q["Cin"]
-    timed(lambda: _w(**q), desc(q), 2.0 * q["M"] * q["N"] * k, es * q["M"] * (q["N"] + q["Cin"]) + 4.0 * q["N"] * k)
+    timed(lambda: _w(_now=_now, **q), desc(q), 2.0 * q["M"] * q["N"] * k, es * q["M"] * (q["N"] + q["Cin"]) + 4.0 * q["N"] * k)
 
 
-def wgrad_group(problems):
+def wgrad_group(problems, _now=False):
+    if not _now and all(ops._wgrad_deferrable(q) for q in problems):
+        return _g(problems)
+    if not (2 <= len(problems) <= 4) or not all(ops._wgrad_groupable(q, problems[0]["x"].dtype) for q in problems):
+        for q in problems:                               # not one launch: its members appear as their own lines
+            wgrad(_now=_now, **q)
+        return
     es = problems[0]["x"].element_size()
-    timed(lambda: _g(problems), " + ".join(desc(q) for q in problems), sum(2.0 * q["M"] * q["N"] * q["Cin"] for q in problems),
+    timed(lambda: _g(problems, _now=_now), " + ".join(desc(q) for q in problems), sum(2.0 * q["M"] * q["N"] * q["Cin"] for q in problems),
           sum(es * q["M"] * (q["N"] + q["Cin"]) + 4.0 * q["N"] * q["Cin"] for q in problems))
 
 

@@ -559,7 +559,7 @@ def small_grads_reset():
     """drop whatever an aborted backward pass left behind (the engine discards a graph task's final callbacks when a backward raises:
     the entries would otherwise wait for a flush that never comes)"""
     _SmallGrads.pending, _SmallGrads.task = [], -1
-    _WgradQueue.items, _WgradQueue.task = [], -1
+    _WgradQueue.items, _WgradQueue.notify, _WgradQueue.task = [], [], -1
 
 
 def small_grad_scratch(target, param):
@@ -860,6 +860,16 @@ def grad_target(p):
 
 
 def grad_done(p):
+    """the directly-written gradient of parameter p is complete AND its launches are in the stream.  A weight gradient that still waits in the
+    deferral queue (_WgradQueue) is announced when its group has been launched instead; the listeners are told now that it comes later."""
+    if GRAD_LISTENERS and _WgradQueue.items and SINK is not None:
+        t = SINK.targets.get(id(p))
+        if t is not None and any(q["dw"].data_ptr() == t.data_ptr() for q in _WgradQueue.items):
+            if all(prm is not p for prm, _ in _WgradQueue.notify):
+                _WgradQueue.notify.append((p, t.data_ptr()))
+                for fn in GRAD_DEFER_LISTENERS:
+                    fn(p)
+            return
     for fn in GRAD_LISTENERS:
         fn(p)
 
@@ -1052,11 +1062,12 @@ class _WgradQueue:
     sink's persistent storage need not launch where the backward reaches it.  Such problems wait here (operands kept alive) and leave four
     at a time as ONE grouped launch + ONE fold (ly_wgrad_group) — the small-map problems (25600 pixels: ~30 us each alone, a few blocks per CU
     walking long pixel runs) share the chip — and the rest leaves when the pass ends (engine callback).  Program order fixes the grouping:
-    the step stays bit-reproducible and a captured step replays the same launches.  Off while a gradient listener (ddp.GradReducer) is
-    installed: `grad_done` must mean the launch is in the stream.  Narrow problems (Cin <= 64, or a column slice of a wider gradient) stay
+    the step stays bit-reproducible and a captured step replays the same launches.  `grad_done(param)` of a gradient that still waits here
+    is passed on to the listeners (ddp.GradReducer) when its group has been launched (`notify`).  Narrow problems (Cin <= 64, or a column slice of a wider gradient) stay
     out: the group runs every problem on the 128 x 128 tile, and with the two K = 40 / 80 concat-slice problems of the neck in the groups
     the step went from 10.01 to 10.21 ms."""
     items = []
+    notify = []         # (param, gradient data_ptr): grad_done arrived while the gradient's problem was waiting
     task = -1
 
 
@@ -1065,14 +1076,14 @@ WGRAD_GROUP_MAX = 4
 
 
 def _wgrad_deferrable(q):
-    return (WGRAD_DEFER and SINK is not None and not GRAD_LISTENERS and q["x"].dtype == torch.bfloat16 and _wgrad_groupable(q, torch.bfloat16)
+    return (WGRAD_DEFER and SINK is not None and q["x"].dtype == torch.bfloat16 and _wgrad_groupable(q, torch.bfloat16)
             and q["Cin"] > 64 and q.get("dw_off", 0) == 0 and SINK.is_target(q["dw"]) and _graph_task() >= 0)
 
 
 def _wgrad_enqueue(q):
     task = _graph_task()
     if _WgradQueue.task != task:
-        _WgradQueue.items, _WgradQueue.task = [], task          # (leftovers of a backward pass that raised are dropped with it)
+        _WgradQueue.items, _WgradQueue.notify, _WgradQueue.task = [], [], task    # (leftovers of a backward pass that raised are dropped with it)
         torch.autograd.Variable._execution_engine.queue_callback(wgrad_flush)
     _WgradQueue.items.append(q)
     if len(_WgradQueue.items) >= WGRAD_GROUP_MAX:
@@ -1088,6 +1099,13 @@ def wgrad_flush(final=True):
         wgrad(_now=True, **items[0])
     elif items:
         wgrad_group(items, _now=True)
+    if _WgradQueue.notify:
+        waiting = {q["dw"].data_ptr() for q in _WgradQueue.items}
+        ready = [prm for prm, ptr in _WgradQueue.notify if ptr not in waiting]
+        _WgradQueue.notify = [(prm, ptr) for prm, ptr in _WgradQueue.notify if ptr in waiting]
+        for prm in ready:
+            for fn in GRAD_LISTENERS:
+                fn(prm)
 
 
 def wgrad_group(problems, _now=False):

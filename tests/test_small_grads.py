@@ -132,12 +132,56 @@ def test_deferred_weight_gradients_leave_in_groups_of_four_and_at_the_end_of_the
     assert launched == [] and len(ops._WgradQueue.items) == 2
     _FiveWgrads.apply(x, dws[:1], False).sum().backward()
     assert launched == [("single", id(dws[0]))]
-    # not deferrable: destination outside the sink, narrow K, a gradient listener installed
+    # not deferrable: destination outside the sink (also: not inside a backward pass)
     q = dict(M=256, H=16, W=16, N=128, du=torch.zeros(256, 128, dtype=torch.bfloat16), lddu=128, x=torch.zeros(256, 128, dtype=torch.bfloat16), ldx=128,
              Hin=16, Win=16, Cin=128, dw=torch.zeros(128, 128), lddw=128)
-    assert not ops._wgrad_deferrable(q)                              # (also: not inside a backward pass)
-    monkeypatch.setattr(ops, "GRAD_LISTENERS", [lambda p: None])
-    launched.clear()
-    _FiveWgrads.apply(x, dws[:1], False).sum().backward()
-    assert launched == [("single", id(dws[0]))] and ops._WgradQueue.items == []
+    assert not ops._wgrad_deferrable(q)
+    ops.small_grads_reset()
+
+
+class _WgradThenDone(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, prms, dws):
+        ctx.prms, ctx.dws = prms, dws
+        return x * 2.0
+
+    @staticmethod
+    def backward(ctx, g):
+        du = torch.zeros(256, 128, dtype=torch.bfloat16)
+        for prm, dw in zip(ctx.prms, ctx.dws):
+            ops.wgrad(M=256, H=16, W=16, N=128, du=du, lddu=128, x=du, ldx=128, Hin=16, Win=16, Cin=128, dw=dw, lddw=128)
+            ops.grad_done(prm)
+        return g * 2.0, None, None
+
+
+def test_grad_done_of_a_waiting_weight_gradient_reaches_the_listeners_after_its_launch(monkeypatch):
+    """with a gradient listener installed (ddp.GradReducer) the queue stays on: `grad_done(param)` of a problem that still waits is held back
+    (the defer listeners are told) and delivered right after the group that contains it has been launched — never before"""
+    events = []
+    prms = [torch.nn.Parameter(torch.zeros(1)) for _ in range(5)]
+    dws = [torch.zeros(128, 128) for _ in range(5)]
+    sink = _FakeSink([])
+    sink.targets = {id(p): t for p, t in zip(prms, dws)}
+    name = {id(p): i for i, p in enumerate(prms)}
+    monkeypatch.setattr(ops, "SINK", sink)
+    monkeypatch.setattr(ops, "WGRAD_DEFER", True)
+    monkeypatch.setattr(ops, "GRAD_LISTENERS", [lambda p: events.append(("done", name[id(p)]))])
+    monkeypatch.setattr(ops, "GRAD_DEFER_LISTENERS", [lambda p: events.append(("later", name[id(p)]))])
+    monkeypatch.setattr(ops, "wgrad_group", lambda problems, _now=False: events.append(("launch", len(problems))) if _now else None)
+    real = ops.wgrad
+
+    def single(**q):
+        if q.get("_now"):
+            events.append(("launch", 1))
+            return
+        return real(**q)
+    monkeypatch.setattr(ops, "wgrad", single)
+    ops.small_grads_reset()
+    x = torch.ones(3, requires_grad=True)
+    _WgradThenDone.apply(x, prms, dws).sum().backward()
+    # problems 0..2 wait when their grad_done arrives; the fourth fills the group (launched inside its own ops.wgrad call), so its own grad_done
+    # is immediate; the fifth leaves alone at the end of the pass
+    assert events == [("later", 0), ("later", 1), ("later", 2), ("launch", 4), ("done", 0), ("done", 1), ("done", 2), ("done", 3),
+                      ("later", 4), ("launch", 1), ("done", 4)]
+    assert ops._WgradQueue.items == [] and ops._WgradQueue.notify == []
     ops.small_grads_reset()

@@ -1073,11 +1073,14 @@ class _WgradQueue:
 
 WGRAD_DEFER = os.environ.get("LY_WGRAD_DEFER", "1") != "0"
 WGRAD_GROUP_MAX = 4
+WGRAD_DEFER_MAX_MACS = 4 << 30      # M * N * K: a larger problem fills the chip alone, and the grouped kernel costs ~15 % more per unit of work than the
+                                    # single-problem one (lead-yolo-l bs=16 1280x1280 with all its plain-row problems in groups: 33.96 -> 34.96 ms per step;
+                                    # lead-yolo-s: every deferred problem is below 3.4 G)
 
 
 def _wgrad_deferrable(q):
     return (WGRAD_DEFER and SINK is not None and q["x"].dtype == torch.bfloat16 and _wgrad_groupable(q, torch.bfloat16)
-            and q["Cin"] > 64 and q.get("dw_off", 0) == 0 and SINK.is_target(q["dw"]) and _graph_task() >= 0)
+            and q["Cin"] > 64 and q["M"] * q["N"] * q["Cin"] <= WGRAD_DEFER_MAX_MACS and q.get("dw_off", 0) == 0 and SINK.is_target(q["dw"]) and _graph_task() >= 0)
 
 
 def _wgrad_enqueue(q):

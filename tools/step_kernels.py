@@ -1,6 +1,6 @@
 """Device time per kernel of ONE steady-state eager training step (torch profiler, device activity), so that model construction /
 first-step work does not leak into the per-step table the way it does in a whole-process rocprofv3 trace.
-    python tools/step_kernels.py [f32|bf16] [bs] [top]"""
+    python tools/step_kernels.py [f32|bf16] [bs] [top] [scale=s] [size=640]"""
 import os, sys, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,10 +11,12 @@ dev = torch.device("cuda:0")
 amp = torch.bfloat16 if (len(sys.argv) > 1 and sys.argv[1] == "bf16") else None
 bs = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 top = int(sys.argv[3]) if len(sys.argv) > 3 else 80
-model = B.build_model("s", dev, train=True)
+scale = sys.argv[4] if len(sys.argv) > 4 else "s"
+size = int(sys.argv[5]) if len(sys.argv) > 5 else 640
+model = B.build_model(scale, dev, train=True)
 opt = L.smart_optimizer(model, "SGD", 0.01, 0.937, 5e-4, fused=True)
 cl = L.ComputeLoss(model)
-imgs = B.synth_u8(bs, 640, 0).to(dev)
+imgs = B.synth_u8(bs, size, 0).to(dev)
 tg = B.synth_targets(bs, 1).to(dev)
 for _ in range(3):
     L.train_step(model, cl, opt, imgs, tg, amp=amp)
@@ -32,7 +34,7 @@ for ev, nm in zip(evs, names):
     cnt[nm] += 1
 tot = sum(acc.values())
 own = sum(v for k, v in acc.items() if k.startswith("ly_"))
-print(f"one steady-state eager optimisation step, lead-yolo-s bs={bs} 640x640 {'bf16' if amp else 'f32'}: kernels={sum(cnt.values())} "
+print(f"one steady-state eager optimisation step, lead-yolo-{scale} bs={bs} {size}x{size} {'bf16' if amp else 'f32'}: kernels={sum(cnt.values())} "
       f"busy={tot / 1e3:.3f} ms  (ly_* {own / 1e3:.3f} ms, ATen / memcpy {(tot - own) / 1e3:.3f} ms)")
 for k, v in acc.most_common(top):
     print(f"{k[:130]:<130} {cnt[k]:4d}  {v / cnt[k]:8.1f} us  {v:9.1f} us")

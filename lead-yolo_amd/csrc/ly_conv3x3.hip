@@ -45,7 +45,7 @@ __global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(size
   constexpr int WP = 4 / WC;                 // waves along pixels
   constexpr int NTW = LY_C3_NT / WP;         // pixel tiles per wave
   const int wc = wave % WC, wp = wave / WC;
-  int b = blockIdx.x;
+  int b = ly_xcd_remap((int)blockIdx.x, (int)gridDim.x);   // neighbouring tiles (shared halo rows / columns) on one XCD's L2
   const int by = b % gy; b /= gy;
   const int tx = b % tiles_x; b /= tiles_x;
   const int ty = b % tiles_y;
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
   constexpr int WP = 4 / WC;                 // waves along pixels
   constexpr int NTW = LY_C3_NT / WP;         // pixel tiles per wave
   const int wc = wave % WC, wp = wave / WC;
-  int b = blockIdx.x;
+  int b = ly_xcd_remap((int)blockIdx.x, (int)gridDim.x);   // neighbouring tiles (shared halo rows / columns) on one XCD's L2
   const int by = b % gy; b /= gy;
   const int tx = b % tiles_x; b /= tiles_x;
   const int ty = b % tiles_y;

@@ -125,13 +125,13 @@ __device__ __forceinline__ void ly_mlpblock_body(
   int h0 = 0, w0 = 0;          // T2D: patch origin
   if (T2D) {
     const int tw = W >> 4, th = (H + TH - 1) / TH;
-    int b = blockIdx.x;
+    int b = ly_xcd_remap((int)blockIdx.x, (int)gridDim.x);            // neighbouring patches (shared halo) on one XCD's L2
     const int tx = b % tw; b /= tw;
     const int ty = b % th;
     img0 = (long)(b / th) * H * W;
     h0 = ty * TH; w0 = tx * 16;
   } else {
-    p0 = (long)blockIdx.x * BP;
+    p0 = (long)ly_xcd_remap((int)blockIdx.x, (int)gridDim.x) * BP;
   }
   // global pixel index of tile-local pixel `pix` (or -1)
   auto gpix = [&](int pix) -> long {
@@ -537,7 +537,7 @@ __device__ __forceinline__ void ly_mlpblock_persist_body(
 #pragma unroll
     for (int t = 0; t < HTP; ++t) { st1[t] = zero; st2[t] = zero; }
   }
-  int tile = blockIdx.x;
+  int tile = ly_xcd_remap((int)blockIdx.x, (int)gridDim.x);              // blocks of one XCD walk neighbouring patches (shared halo rows in its L2)
   if (tile >= ntiles) return;
   issue(tile);
   commit(0);

@@ -242,13 +242,14 @@ __device__ __forceinline__ void ly_mlp_bwd_body(const LyMlpBwdArgs& P) {
   }
 
   const int g_ = (int)gridDim.x;
-  const int tlast = P.ntiles > (int)blockIdx.x ? (int)blockIdx.x + (P.ntiles - 1 - (int)blockIdx.x) / g_ * g_ : 0;      // the block's last patch
+  const int bid = ly_xcd_remap((int)blockIdx.x, (int)gridDim.x);            // blocks of one XCD walk neighbouring patches (shared halo rows in its L2)
+  const int tlast = P.ntiles > bid ? bid + (P.ntiles - 1 - bid) / g_ * g_ : 0;      // the block's last patch
   auto clampt = [&](int t) -> int { return t < P.ntiles ? t : tlast; };     // (past the end: the last patch is re-requested — straight-line loads)
   if constexpr (T2D) {
-    if ((int)blockIdx.x < P.ntiles) {
-      issue(Q0, blockIdx.x);
+    if (bid < P.ntiles) {
+      issue(Q0, bid);
       commit(Q0);
-      if constexpr (PD == 2) issue(Q1, clampt(blockIdx.x + g_));
+      if constexpr (PD == 2) issue(Q1, clampt(bid + g_));
     }
   }
   __syncthreads();                                           // weights (and the first patch) are in LDS
@@ -550,12 +551,12 @@ __device__ __forceinline__ void ly_mlp_bwd_body(const LyMlpBwdArgs& P) {
     }
   };
   if constexpr (PD == 2) {
-    for (int tile = blockIdx.x; tile < P.ntiles; tile += 2 * g_) {
+    for (int tile = bid; tile < P.ntiles; tile += 2 * g_) {
       step(tile, Q0, Q1);
       if (tile + g_ < P.ntiles) step(tile + g_, Q1, Q0);
     }
   } else {
-    for (int tile = blockIdx.x; tile < P.ntiles; tile += g_) step(tile, Q0, Q0);
+    for (int tile = bid; tile < P.ntiles; tile += g_) step(tile, Q0, Q0);
   }
 
   if constexpr (PASS == 1) {
@@ -891,7 +892,7 @@ __device__ __forceinline__ void ly_mlp_bwd_dx_body(const LyMlpDxArgs& P) {
 #pragma unroll
   for (int i = 0; i < NAW; ++i) aw[i] = zero;
 
-  int tile = blockIdx.x;
+  int tile = ly_xcd_remap((int)blockIdx.x, (int)gridDim.x);
   if (tile < P.ntiles) {
     issue(tile, true);
     commit();

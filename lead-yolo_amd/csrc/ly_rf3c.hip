@@ -27,7 +27,7 @@ __global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, c = lane & 31;
-  int b = blockIdx.x;
+  int b = ly_xcd_remap((int)blockIdx.x, (int)gridDim.x);              // neighbouring tiles on one XCD's L2
   const int ct = b % nct; b /= nct;
   const int rt = b % nrt;
   const int n = b / nrt;
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(NW * 64) void ly_rf3c_fwd_kernel(const LyRfcbam3Par
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, c = lane & 31;
   const int li = lane & 15, lq = lane >> 4;
-  int b = blockIdx.x;
+  int b = ly_xcd_remap((int)blockIdx.x, (int)gridDim.x);
   const int by = b % gy; b /= gy;
   const int ct = b % nct; b /= nct;
   const int rt = b % nrt;

@@ -65,7 +65,8 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf3c_bwd_kernel(const LyRf3cBwd
   const int half = lane >> 5, c = lane & 31;
   const int li = lane & 15, lq = lane >> 4;
   const int NCH = P.C / RC_CB;
-  const int chunk = blockIdx.x % NCH, n = blockIdx.x / NCH;
+  const int bid = ly_xcd_remap((int)blockIdx.x, (int)gridDim.x);            // the channel chunks of an image (same du tiles) on one XCD's L2
+  const int chunk = bid % NCH, n = bid / NCH;
   const int c0 = chunk * RC_CB;
   const T* const x = reinterpret_cast<const T*>(P.x);
   const T* const du = reinterpret_cast<const T*>(P.du);
@@ -602,7 +603,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf3c_wgrad_kernel(const LyRf3cB
   const int half = lane >> 5, c = lane & 31;
   const int li = lane & 15, lq = lane >> 4;
   const int NCH = P.C / RC_CB;
-  int b = blockIdx.x;
+  int b = ly_xcd_remap((int)blockIdx.x, (int)gridDim.x);
   const int chunk = b % NCH; b /= NCH;
   const int og = b % nog;
   const int ig = b / nog;

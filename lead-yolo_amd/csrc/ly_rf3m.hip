@@ -159,8 +159,9 @@ __global__ __launch_bounds__(RM_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
   const int h = lane >> 5;
   const __bf16* const x = reinterpret_cast<const __bf16*>(P.x);
   __bf16* const out = reinterpret_cast<__bf16*>(P.out);
-  const int by = blockIdx.x % gy;
-  const long pb = blockIdx.x / gy;
+  const int bid = ly_xcd_remap((int)blockIdx.x, (int)gridDim.x);            // neighbouring tiles on one XCD's L2
+  const int by = bid % gy;
+  const long pb = bid / gy;
   const long total = (long)P.n_img * nrt * nct;
   const RmTile T = rm_tile(pb * RM_WAVES + wave, total, nct, nrt, P.TH, P.TW);
   const int NCH = P.C / RM_CB;
@@ -453,7 +454,7 @@ __global__ __launch_bounds__(RM_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5;
   const long total = (long)n_img * nrt * nct;
-  const long wt = (long)blockIdx.x * RM_WAVES + wave;
+  const long wt = (long)ly_xcd_remap((int)blockIdx.x, (int)gridDim.x) * RM_WAVES + wave;
   const RmTile T = rm_tile(wt, total, nct, nrt, TH, TW);
   const int NCH = C / RM_CB;
   char* const ring = rm_smem;

@@ -737,7 +737,8 @@ __global__ __launch_bounds__(LY_THREADS) void ly_sppf_pool_kernel(const T* __res
   f32x4* a = sp4;
   f32x4* b = sp4 + HW;
   const int groups = C / LY_SP_CG;
-  const int n = blockIdx.x / groups, g = blockIdx.x - n * groups;
+  const int bid = ly_xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int n = bid / groups, g = bid - n * groups;
   const int c0 = g * LY_SP_CG;
   const int tid = threadIdx.x, r = k / 2;
   const f32x4 ninf = (f32x4){-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
@@ -1138,7 +1139,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_tap_moments_s2t_kernel(c
 #pragma unroll
   for (int i = 0; i < 45; ++i) a2[i] = (ly_f2){0.f, 0.f};
   const long ntiles = (long)n_img * tiles_y * tiles_x;
-  for (long tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {
+  for (long tix = ly_xcd_remap((int)blockIdx.x, (int)gridDim.x); tix < ntiles; tix += gridDim.x) {
     const int tx = (int)(tix % tiles_x);
     const long q = tix / tiles_x;
     const int ty = (int)(q % tiles_y);

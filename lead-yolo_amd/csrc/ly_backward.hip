@@ -733,6 +733,8 @@ static void wgrad_combine_launch(const LyWgradParams& P, const float* slab, long
 
 template <typename T, int BN, int BK, int P, bool ROWS, bool PRO = false>
 __global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(BN + BK > 160 ? 2 : 3))) void ly_wgrad_tiled_kernel(const LyWgradParams P_, const int tiles_k, const long chunk_px, float* const slab) {
+  // (no XCD-aware re-ordering here: with it this kernel's 128 x 128 rows form took 3x as long — 45 -> 146 us per launch — while the grouped
+  // kernel, ly_wgrad3 and every other tile kernel were neutral or faster; the cause was not found)
   ly_wgrad_tiled_body<T, BN, BK, P, ROWS, PRO>(P_, (int)blockIdx.x, (int)blockIdx.y, tiles_k, chunk_px, slab, (int)gridDim.x);
 }
 
@@ -750,12 +752,13 @@ struct LyWgradGroupArgs {
 };
 template <typename T, int BN, int BK, int P, bool ROWS, bool PRO = false, bool GSLAB = false>
 __global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(BN + BK > 160 ? 2 : 3))) void ly_wgrad_tiled_group_kernel(const LyWgradGroupArgs G) {
+  const int bid = ly_xcd_remap((int)blockIdx.x, (int)gridDim.x);            // (see ly_wgrad_tiled_kernel)
   int g = 0;
 #pragma unroll
   for (int i = 1; i < LY_WGRAD_GROUP_MAX; ++i)
-    if (i < G.n && (int)blockIdx.x >= G.blk0[i]) g = i;
+    if (i < G.n && bid >= G.blk0[i]) g = i;
   g = __builtin_amdgcn_readfirstlane(g);
-  const int local = (int)blockIdx.x - G.blk0[g];
+  const int local = bid - G.blk0[g];
   const int tiles = G.tiles[g];
   // (no slab path here: with it compiled in, every wait of this instantiation's pixel loop became `s_waitcnt vmcnt(0)` — 53 -> 107 us per launch;
   // a grouped launch keeps the atomic flush, whose cost the longer pixel runs per block already halve)
@@ -1751,8 +1754,9 @@ __global__ __launch_bounds__(LY_THREADS) void ly_sppf_bwd_kernel(const T* __rest
   f32x4* const Y = GB + HW * NQ;                                   // [HW][NQ] y_j as fp32 (exact for bf16 / fp32 inputs)
   unsigned* const A = reinterpret_cast<unsigned*>(Y + HW * NQ);    // [HW][NQ] four routing bytes
   const int groups = c / CG;
-  const long n = blockIdx.x / groups;
-  const int c0 = (int)(blockIdx.x - n * groups) * CG;
+  const int bid = ly_xcd_remap((int)blockIdx.x, (int)gridDim.x);            // the channel groups of an image read the same cache lines: one XCD's L2
+  const long n = bid / groups;
+  const int c0 = (int)(bid - n * groups) * CG;
   const int tid = threadIdx.x;
   const T* const bn = buf + n * HW * (long)ldb;
   const T* const dn = d + n * HW * (long)ldd;

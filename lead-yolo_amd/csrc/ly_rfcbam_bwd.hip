@@ -530,11 +530,13 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rf_bwd_dx_s2t_kernel(const RfGe
   extern __shared__ f32x4 ly_smem4[];
   T* const tile = reinterpret_cast<T*>(ly_smem4);          // [TE*TE][9][64]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int b = blockIdx.x;
+  // neighbouring tiles (overlapping input patches) of one channel group on one XCD's L2
+  const int lid = ly_xcd_remap((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
+  int b = lid % (int)gridDim.x;
   const int tx = b % tiles_x; b /= tiles_x;
   const int ty = b % tiles_y;
   const int n = b / tiles_y;
-  const int c0 = blockIdx.y * 64;
+  const int c0 = (lid / (int)gridDim.x) * 64;
   const int my0 = ty * TM, mx0 = tx * TM;
   // ---- stage ------------------------------------------------------------------------------------
   constexpr int NV = (ROWS * VPR + LY_THREADS - 1) / LY_THREADS;

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lq = lane >> 4;
-  int b = blockIdx.x;
+  int b = ly_xcd_remap((int)blockIdx.x, (int)gridDim.x);              // the (output, input) tile combinations of one pixel chunk (same du / x tiles) on one XCD's L2
   const int cn = b % n_n; b /= n_n;
   const int cc = b % n_c;
   const int chunk = b / n_c;

@@ -835,12 +835,25 @@ def _ddp_rank(rank, world, port, q, backend="nccl", one_gpu=False):
             dist.destroy_process_group()
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:                                           # a port nobody holds right now (the fixed base + pid scheme met an
+        s.bind(("127.0.0.1", 0))                                         # "address already in use" on a busy box once)
+        return s.getsockname()[1]
+
+
 def _run_two_ranks(backend, one_gpu, port0, timeout):
+    res = _run_two_ranks_once(backend, one_gpu, _free_port(), timeout)
+    if any("in use" in str(r[1]) for r in res):                          # lost the race for the port: once more on another one
+        res = _run_two_ranks_once(backend, one_gpu, _free_port(), timeout)
+    return res
+
+
+def _run_two_ranks_once(backend, one_gpu, port, timeout):
     import queue
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = port0 + os.getpid() % 2000
     procs = [ctx.Process(target=_ddp_rank, args=(r, 2, port, q, backend, one_gpu)) for r in range(2)]
     for p in procs:
         p.start()

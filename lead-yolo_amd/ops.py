@@ -834,8 +834,8 @@ class GradSink:
 
     def is_target(self, t):
         """t is (a view from the start of) one of the sink's persistent gradient tensors"""
-        if len(self.targets) != getattr(self, "_nptr", -1):
-            self._ptrs, self._nptr = {v.data_ptr() for v in self.targets.values()}, len(self.targets)
+        if getattr(self, "_ptr_src", None) is not self.targets or len(self.targets) != self._nptr:      # (the optimiser assigns a whole new dict)
+            self._ptrs, self._nptr, self._ptr_src = {v.data_ptr() for v in self.targets.values()}, len(self.targets), self.targets
         return t.data_ptr() in self._ptrs
 
     def target(self, p):

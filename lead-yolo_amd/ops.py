@@ -540,6 +540,8 @@ def detect_head_bwd(dp, n, h, w, na, no, du, ldu, dbias):
 class _SmallGrads:
     pending = []            # (scratch, flat fp32 target, parameter)
     task = -1               # autograd graph-task id the pending entries (and the queued end-of-pass callback) belong to
+    announced = set()       # id(parameter) of the entries that already left in this pass (early flush under a gradient listener)
+    nodes = {}              # id(scratch) -> id of the autograd node that took it
 
 
 DETERMINISTIC_SMALL_GRADS = True
@@ -558,7 +560,7 @@ def small_grads_ok():
 def small_grads_reset():
     """drop whatever an aborted backward pass left behind (the engine discards a graph task's final callbacks when a backward raises:
     the entries would otherwise wait for a flush that never comes)"""
-    _SmallGrads.pending, _SmallGrads.task = [], -1
+    _SmallGrads.pending, _SmallGrads.task, _SmallGrads.announced, _SmallGrads.nodes = [], -1, set(), {}
     _WgradQueue.items, _WgradQueue.notify, _WgradQueue.task = [], [], -1
 
 
@@ -570,18 +572,43 @@ def small_grad_scratch(target, param):
     entry per destination (two entries with the same target would race)."""
     task = _graph_task()
     if task != _SmallGrads.task:
-        _SmallGrads.pending, _SmallGrads.task = [], task
+        _SmallGrads.pending, _SmallGrads.task, _SmallGrads.announced, _SmallGrads.nodes = [], task, set(), {}
         torch.autograd.Variable._execution_engine.queue_callback(flush_small_grads)
     tgt = target.view(-1)
     for scr, t, prm in _SmallGrads.pending:
         if t.data_ptr() == tgt.data_ptr() and t.numel() == tgt.numel():
             return scr
+    node = _autograd_node()
+    if GRAD_LISTENERS and SMALL_GRADS_EARLY_FLUSH and node is not None:
+        # under a gradient listener (ddp.GradReducer) a waiting sum holds back its whole bucket's exchange until the backward pass ends
+        # (tools/dp_overlap_probe.py: 5.4 of 12.5 MB left at 99-100 % of the backward).  Entries taken by EARLIER autograd nodes are complete
+        # — their kernels are in the stream — and leave as soon as a handful has collected; entries of the running node stay (it may not
+        # have launched the kernel that fills them yet).
+        if param is not None and id(param) in _SmallGrads.announced:
+            raise RuntimeError("small_grad_scratch: a parameter whose deferred gradient was already announced to the gradient listeners "
+                               "receives another contribution in the same backward pass (shared weights under a GradReducer): set "
+                               "ops.SMALL_GRADS_EARLY_FLUSH = False")
+        old = [e for e in _SmallGrads.pending if _SmallGrads.nodes.get(id(e[0])) != node]
+        if len(old) >= SMALL_GRADS_FLUSH_MIN:
+            _SmallGrads.pending = [e for e in _SmallGrads.pending if _SmallGrads.nodes.get(id(e[0])) == node]
+            _flush_small_items(old)
     scr = zeros_f64(target.numel(), target.device)
     if param is not None and not any(prm is param for _, _, prm in _SmallGrads.pending):
         for fn in GRAD_DEFER_LISTENERS:
             fn(param)
     _SmallGrads.pending.append((scr, tgt, param))
+    _SmallGrads.nodes[id(scr)] = node
     return scr
+
+
+SMALL_GRADS_EARLY_FLUSH = True
+SMALL_GRADS_FLUSH_MIN = 6
+
+
+def _autograd_node():
+    fn = getattr(torch._C, "_current_autograd_node", None)
+    n = fn() if fn is not None else None
+    return id(n) if n is not None else None
 
 
 def f64_round(scratches, shapes):
@@ -603,6 +630,11 @@ def f64_round(scratches, shapes):
 
 def flush_small_grads():
     items, _SmallGrads.pending, _SmallGrads.task = _SmallGrads.pending, [], -1
+    _flush_small_items(items)
+    _SmallGrads.announced, _SmallGrads.nodes = set(), {}
+
+
+def _flush_small_items(items):
     for i in range(0, len(items), capi.F64_ADD_MAX):
         chunk = items[i:i + capi.F64_ADD_MAX]
         t = capi.LyF64AddTable()
@@ -614,6 +646,7 @@ def flush_small_grads():
     for _, _, prm in items:
         if prm is not None and id(prm) not in done:
             done.add(id(prm))
+            _SmallGrads.announced.add(id(prm))
             grad_done(prm)
 
 
@@ -1089,7 +1122,9 @@ def _wgrad_enqueue(q):
         _WgradQueue.items, _WgradQueue.notify, _WgradQueue.task = [], [], task    # (leftovers of a backward pass that raised are dropped with it)
         torch.autograd.Variable._execution_engine.queue_callback(wgrad_flush)
     _WgradQueue.items.append(q)
-    if len(_WgradQueue.items) >= WGRAD_GROUP_MAX:
+    # under a gradient listener (ddp.GradReducer) a waiting gradient holds back its whole bucket's exchange: leave in pairs there
+    # (tools/dp_overlap_probe.py: with fours a 1.3 MB bucket was released at 77 % of the backward instead of 33 %)
+    if len(_WgradQueue.items) >= (2 if GRAD_LISTENERS else WGRAD_GROUP_MAX):
         wgrad_flush(final=False)
 
 

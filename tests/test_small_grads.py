@@ -179,9 +179,62 @@ def test_grad_done_of_a_waiting_weight_gradient_reaches_the_listeners_after_its_
     ops.small_grads_reset()
     x = torch.ones(3, requires_grad=True)
     _WgradThenDone.apply(x, prms, dws).sum().backward()
-    # problems 0..2 wait when their grad_done arrives; the fourth fills the group (launched inside its own ops.wgrad call), so its own grad_done
-    # is immediate; the fifth leaves alone at the end of the pass
-    assert events == [("later", 0), ("later", 1), ("later", 2), ("launch", 4), ("done", 0), ("done", 1), ("done", 2), ("done", 3),
+    # under a listener the queue leaves in PAIRS (a waiting gradient holds back its bucket's exchange): problem 0 waits when its grad_done
+    # arrives; the second fills the pair (launched inside its own ops.wgrad call), so its own grad_done is immediate; ...; the fifth leaves
+    # alone at the end of the pass
+    assert events == [("later", 0), ("launch", 2), ("done", 0), ("done", 1), ("later", 2), ("launch", 2), ("done", 2), ("done", 3),
                       ("later", 4), ("launch", 1), ("done", 4)]
     assert ops._WgradQueue.items == [] and ops._WgradQueue.notify == []
+    ops.small_grads_reset()
+
+
+# ---- early flush of completed small-gradient scratches under a gradient listener ----------------------------------------------------------
+class _TakeScratches(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, targets, params, log):
+        ctx.targets, ctx.params, ctx.log = targets, params, log
+        return x * 2.0
+
+    @staticmethod
+    def backward(ctx, g):
+        scrs = [ops.small_grad_scratch(t, p) for t, p in zip(ctx.targets, ctx.params)]
+        ctx.log.append(("taken", len(scrs), [p_.item() for p_ in ctx.targets]))      # what the targets hold when this node has taken its scratches
+        for s_ in scrs:
+            s_ += 1.0                                                                 # (the node's kernel fills them AFTER taking them all)
+        return g * 2.0, None, None, None
+
+
+def test_completed_small_gradients_leave_early_under_a_listener(monkeypatch):
+    """with a gradient listener installed, scratches taken by EARLIER autograd nodes leave as soon as SMALL_GRADS_FLUSH_MIN have collected — never
+    the running node's own (it fills them after taking them); without a listener everything leaves at the end of the pass"""
+    def host_items(items):
+        for scr, tgt, prm in items:
+            tgt += scr.float()
+        done = set()
+        for _, _, prm in items:
+            if prm is not None and id(prm) not in done:
+                done.add(id(prm))
+                ops._SmallGrads.announced.add(id(prm))
+                ops.grad_done(prm)
+    monkeypatch.setattr(ops, "_flush_small_items", host_items)
+    monkeypatch.setattr(ops, "zeros_f64", lambda n, dev: torch.zeros(n, dtype=torch.float64))
+    announced = []
+    monkeypatch.setattr(ops, "GRAD_LISTENERS", [lambda p: announced.append(id(p))])
+    monkeypatch.setattr(ops, "SMALL_GRADS_FLUSH_MIN", 3)
+    ops.small_grads_reset()
+    ta, tb = [torch.zeros(1) for _ in range(4)], [torch.zeros(1) for _ in range(2)]
+    pa, pb = [torch.nn.Parameter(torch.zeros(1)) for _ in range(4)], [torch.nn.Parameter(torch.zeros(1)) for _ in range(2)]
+    log = []
+    x = torch.ones(3, requires_grad=True)
+    # backward order: the outer node (A: 4 scratches) runs first, then the inner node (B: 2)
+    _TakeScratches.apply(_TakeScratches.apply(x, tb, pb, log), ta, pa, log).sum().backward()
+    # when B had taken its scratches, A's four sums had already been added to their targets (A is an earlier node; its own scratches were NOT
+    # flushed while it was still taking them: all four hold the full value)
+    assert log[0][:2] == ("taken", 4) and log[1][:2] == ("taken", 2)
+    assert [t.item() for t in ta] == [1.0] * 4 and [t.item() for t in tb] == [1.0] * 2
+    assert announced[:4] == [id(p) for p in pa] and sorted(announced[4:]) == sorted(id(p) for p in pb)
+    # a parameter announced early must not come back in the same pass
+    ops.small_grads_reset()
+    with pytest.raises(RuntimeError, match="already announced"):          # A takes pa, B takes pb (A's leave), C asks for pa[0] again
+        _TakeScratches.apply(_TakeScratches.apply(_TakeScratches.apply(x, [ta[0]], [pa[0]], log), tb, pb, log), ta, pa, log).sum().backward()
     ops.small_grads_reset()

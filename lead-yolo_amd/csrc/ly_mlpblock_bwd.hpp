@@ -53,7 +53,8 @@ struct MlpBwdGeom {
   using Gm = MlpGeom<C>;
   static constexpr int HTR = 2 * C / 16;                   // real hidden tiles (2C is a multiple of 16)
   static constexpr bool DWX = C >= 80;
-  static constexpr int NT = DWX ? 1 : 2;                   // pixel tiles of 16 per wave (C = 80 pass 1 at NT = 2: 47 spilled registers, 45 -> 50 us)
+  static constexpr int NT = DWX ? 1 : 2;                   // pixel tiles of 16 per wave.  (C = 80 pass 1 at two tiles — it has the LDS room — was measured
+                                                           // twice: 47 spilled registers, 45 -> 50 us; operands k-step by k-step, 21 spilled: 44 -> 54 us)
   static constexpr int BP = 64 * NT;
   static constexpr int DT = DWX ? 4 : Gm::HTP;             // hidden tiles per du / h round (DWX: one per wave)
   static constexpr int NRD = (Gm::HTP + DT - 1) / DT;      // rounds
@@ -302,41 +303,51 @@ __device__ __forceinline__ void ly_mlp_bwd_body(const LyMlpBwdArgs& P) {
         for (int n = 0; n < NT; ++n) accp[t][n] = zero;
       // every operand of the SP k-steps is requested before the first MFMA (left alone hipcc reads each fragment right before its use: one
       // exposed LDS round trip per MFMA at one wave per SIMD — 69 lgkmcnt(0) waits per tile in the C = 80 listing)
-      bf16x8 xh[SP][NT], wpf[SP][PT];
+      // (SB k-steps per batch: all SP at once unless the operand set would exceed 72 registers — no built configuration does)
+      constexpr int SB = SP * (NT + PT) * 4 <= 72 ? SP : 3;
 #pragma unroll
-      for (int s = 0; s < SP; ++s) {
-        int off[2], tap[2];
-        bool gv[2];
+      for (int s0 = 0; s0 < SP; s0 += SB) {
+        bf16x8 xh[SB][NT], wpf[SB][PT];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int gq = 8 * s + 4 * h + lq;
-          gv[h] = gq < 9 * G;
-          tap[h] = gv[h] ? gq / G : 0;
-          const int cq4 = gv[h] ? gq - tap[h] * G : 0;
-          const int ty = tap[h] / 3, tx = tap[h] - 3 * ty;
-          off[h] = (ty * rowpitch + tx) * RSP + 8 * cq4;
-        }
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-          bf16x4 ph[2];
+        for (int sb = 0; sb < SB; ++sb) {
+          const int s = s0 + sb;
+          if (s >= SP) continue;
+          int off[2], tap[2];
+          bool gv[2];
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
-            const bool ok = gv[h] && (T2D || ((tmask[n] >> tap[h]) & 1u));
-            const bf16x4 a = *reinterpret_cast<const bf16x4*>(ps + pbase[n] + off[h]);
-            ph[h] = ok ? a : z4;
+            const int gq = 8 * s + 4 * h + lq;
+            gv[h] = gq < 9 * G;
+            tap[h] = gv[h] ? gq / G : 0;
+            const int cq4 = gv[h] ? gq - tap[h] * G : 0;
+            const int ty = tap[h] / 3, tx = tap[h] - 3 * ty;
+            off[h] = (ty * rowpitch + tx) * RSP + 8 * cq4;
           }
-          xh[s][n] = ly_cat8(ph[0], ph[1]);
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            bf16x4 ph[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const bool ok = gv[h] && (T2D || ((tmask[n] >> tap[h]) & 1u));
+              const bf16x4 a = *reinterpret_cast<const bf16x4*>(ps + pbase[n] + off[h]);
+              ph[h] = ok ? a : z4;
+            }
+            xh[sb][n] = ly_cat8(ph[0], ph[1]);
+          }
+#pragma unroll
+          for (int t = 0; t < PT; ++t) wpf[sb][t] = wlds(t * SP + s);
         }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < PT; ++t) wpf[s][t] = wlds(t * SP + s);
+        for (int sb = 0; sb < SB; ++sb) {
+          if (s0 + sb >= SP) continue;
+#pragma unroll
+          for (int t = 0; t < PT; ++t)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) accp[t][n] = ly_mfma_bf16(wpf[sb][t], xh[sb][n], accp[t][n]);
+        }
+        if (s0 + SB < SP) __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int s = 0; s < SP; ++s)
-#pragma unroll
-        for (int t = 0; t < PT; ++t)
-#pragma unroll
-          for (int n = 0; n < NT; ++n) accp[t][n] = ly_mfma_bf16(wpf[s][t], xh[s][n], accp[t][n]);
 #pragma unroll
       for (int t = 0; t < PT; ++t)
 #pragma unroll
@@ -372,34 +383,42 @@ __device__ __forceinline__ void ly_mlp_bwd_body(const LyMlpBwdArgs& P) {
 #pragma unroll
           for (int n = 0; n < NT; ++n) { au[t][n] = zero; ad[t][n] = zero; }
         // all operands of the chunk's two contractions (and, pass 2, of its share of g = W1^T du) in flight together, one wait
-        bf16x8 xb[S1][NT], db[S1][NT], w1f[S1][HT], w2f[S1][HT];
+        // (KB k-steps per batch: all S1 unless the operand set would exceed 72 registers — no built configuration does; C = 80 at two pixel
+        // tiles per wave would)
+        constexpr int KB = S1 * (NT + HT) * 8 <= 72 ? S1 : 1;
         bf16x8 wtf[PASS == 2 ? HT / 2 : 1][PASS == 2 ? C16 : 1];
 #pragma unroll
-        for (int s = 0; s < S1; ++s) {
+        for (int s0 = 0; s0 < S1; s0 += KB) {
+          bf16x8 xb[KB][NT], db[KB][NT], w1f[KB][HT], w2f[KB][HT];
 #pragma unroll
-          for (int n = 0; n < NT; ++n) {
-            xb[s][n] = ly_lds_frag(xs, (pixbase + 16 * n + li) * RS, s, lq);
-            db[s][n] = ly_lds_frag(dys, (pixbase + 16 * n + li) * RS, s, lq);
-          }
-#pragma unroll
-          for (int t = 0; t < HT; ++t) {
-            if (hc * HT + t >= HTR) continue;                // padded hidden tile: nothing to contract
-            w1f[s][t] = wlds(NFP + (hc * HT + t) * S1 + s);
-            w2f[s][t] = wlds(NFP + NF1 + (hc * HT + t) * S1 + s);
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int s = 0; s < S1; ++s)
-#pragma unroll
-          for (int t = 0; t < HT; ++t) {
-            if (hc * HT + t >= HTR) continue;
+          for (int sb = 0; sb < KB; ++sb) {
+            const int s = s0 + sb;
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
-              au[t][n] = ly_mfma_bf16(w1f[s][t], xb[s][n], au[t][n]);
-              ad[t][n] = ly_mfma_bf16(w2f[s][t], db[s][n], ad[t][n]);
+              xb[sb][n] = ly_lds_frag(xs, (pixbase + 16 * n + li) * RS, s, lq);
+              db[sb][n] = ly_lds_frag(dys, (pixbase + 16 * n + li) * RS, s, lq);
+            }
+#pragma unroll
+            for (int t = 0; t < HT; ++t) {
+              if (hc * HT + t >= HTR) continue;              // padded hidden tile: nothing to contract
+              w1f[sb][t] = wlds(NFP + (hc * HT + t) * S1 + s);
+              w2f[sb][t] = wlds(NFP + NF1 + (hc * HT + t) * S1 + s);
             }
           }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int sb = 0; sb < KB; ++sb)
+#pragma unroll
+            for (int t = 0; t < HT; ++t) {
+              if (hc * HT + t >= HTR) continue;
+#pragma unroll
+              for (int n = 0; n < NT; ++n) {
+                au[t][n] = ly_mfma_bf16(w1f[sb][t], xb[sb][n], au[t][n]);
+                ad[t][n] = ly_mfma_bf16(w2f[sb][t], db[sb][n], ad[t][n]);
+              }
+            }
+          if (s0 + KB < S1) __builtin_amdgcn_sched_barrier(0);
+        }
         // W1^T fragments of g += W1^T du and the BatchNorm coefficients: read behind the MFMAs (not live beside the operand sets)
         if constexpr (PASS == 2) {
 #pragma unroll

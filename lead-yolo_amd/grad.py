@@ -15,6 +15,8 @@ Only [C]-sized vectors are handled with torch ops (coefficients of step 3, param
 """
 import ctypes
 
+import os
+
 import torch
 
 from . import ops, pack
@@ -954,7 +956,7 @@ class RfcbamFn(torch.autograd.Function):
             _tap("rf.du", du)
             # (o = 256 — layer 20 — measured SLOWER on the recompute passes than on the streamed 9x tensors: 1.08 vs 0.73 ms of kernels at bs = 64;
             # layer 17, o = 128: 0.95 vs 1.47 ms.  The wider layer stays on the first-generation backward.)
-            if ctx.rc is not None and dt == torch.bfloat16 and s == 2 and o in (64, 128) and RC_BWD:
+            if ctx.rc is not None and dt == torch.bfloat16 and s == 2 and o in RC_BWD_WIDTHS and RC_BWD:
                 return RfcbamFn._backward_rc(ctx, du, dgo, dbo)
             if k == 1 and RF1_BWD and c % ops.vw_of(xr) == 0 and c // ops.vw_of(xr) <= 64 and ld % ops.vw_of(xr) == 0:
                 return RfcbamFn._backward_k1(ctx, du, dgo, dbo)
@@ -1259,6 +1261,7 @@ RfcbamFn._backward_k1 = staticmethod(_rfcbam_backward_k1)
 RF1_BWD = True         # tools: False keeps the first-generation k = 1 backward
 RF3S_BWD = True        # tools: False keeps the thread = channel attention / ReLU passes of the streamed k = 3 backward
 RC_BWD = True          # tools: False keeps the first-generation backward behind the lane = channel forward
+RC_BWD_WIDTHS = tuple(int(v) for v in os.environ.get("LY_RC_BWD_WIDTHS", "64,128").split(","))   # output widths on the recompute passes (see RfcbamFn.backward)
 def rfcbam_train(mod, x):
     """RFCBAMConv.forward in training: one autograd node (SE, generate BatchNorm, attention maps, contraction)."""
     g, cv = mod.generate, mod.conv

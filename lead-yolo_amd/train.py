@@ -11,6 +11,7 @@ The optimiser is optim.FusedSGD on the GPU (clip + SGD-nesterov + zero_grad + EM
 import ctypes
 import math
 import os
+import sys
 from copy import deepcopy
 
 import torch
@@ -258,10 +259,9 @@ class GraphedTrainStep:
     def __del__(self):
         # the bucket events are released only while the interpreter (and with it the HIP runtime) is certainly alive: destroying them from a
         # finaliser that runs during shutdown aborted the process after a green test run (1 of 3 runs); a handful of events leaked at exit are harmless
-        import sys
-        if sys is None or sys.is_finalizing():
-            return
         try:
+            if sys is None or sys.is_finalizing():
+                return
             from . import capi
             evs, self._events = self._events, []
             for ev in evs:

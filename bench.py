@@ -513,7 +513,10 @@ def run_train(args, ctx):
     if ctx.dist is not None:                         # rank 0's parameters and buffers everywhere (train.py:233-235 DDP init)
         for t in list(model.parameters()) + list(model.buffers()):
             ctx.dist.broadcast(t.data, src=0)
-    opt = L.smart_optimizer(model, "SGD", 0.01, 0.937, 5e-4 * args.batch * ctx.world / 64)
+    # lr 1e-3, constant: the reference's lr0 = 1e-2 is reached through a warm-up ramp (train.py:295-310); applied from step 0 to ONE synthetic batch
+    # it drives the loss from 12 to 3.6 in 100 steps and then back up to a plateau near 10.8 (gpurun_dbg runs, round 5) — the arithmetic per
+    # step is the same either way, but `final_loss` of a few hundred steps should say "this trains"
+    opt = L.smart_optimizer(model, "SGD", 1e-3, 0.937, 5e-4 * args.batch * ctx.world / 64)
     loss_fn = L.ComputeLoss(model)
     ema = L.ModelEMA(model)                          # SURVEY config 3: "(+EMA)" — train.py:139,331: the EMA update is part of every optimisation step
     reducer = L.GradReducer(list(model.parameters())).attach() if ctx.world > 1 else None

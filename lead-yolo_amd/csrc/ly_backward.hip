@@ -38,6 +38,25 @@ __device__ __forceinline__ f32x4 ly_dact4(const f32x4 v, const f32x4 dy) {
   return r;
 }
 
+// Row ranges per XCD for the streaming BatchNorm / activation passes: XCD x (= blockIdx.x % 8, round-robin dispatch) walks the x-th eighth of the
+// items with its own blocks, so that a row is written / read by the XCD whose L2 the neighbouring tile kernels (ly_xcd_remap: contiguous
+// tile ranges per XCD) use for the same rows.  (LY_XCD_STREAM=0 at build time: the plain grid-stride order.)
+#ifndef LY_XCD_STREAM
+#define LY_XCD_STREAM 1
+#endif
+#if LY_XCD_STREAM
+#define LY_XCD_RANGE(total)                                                                                             \
+  const bool xr_on = gridDim.x >= 8;                          /* fewer blocks than XCDs: an eighth would have no block */ \
+  const long xr_x = blockIdx.x & 7, xr_slot = blockIdx.x >> 3, xr_n = ((long)gridDim.x + 7 - xr_x) >> 3;                  \
+  const long xr_per = (((total) + 7) / 8 + LY_THREADS - 1) / LY_THREADS * LY_THREADS;                                      \
+  const long xr_lo = xr_x * xr_per, xr_hi = xr_lo + xr_per < (total) ? xr_lo + xr_per : (total);                           \
+  const long xr_begin = xr_on ? xr_lo + xr_slot * LY_THREADS + threadIdx.x : (long)blockIdx.x * LY_THREADS + threadIdx.x; \
+  const long xr_end = xr_on ? xr_hi : (total), xr_step = (xr_on ? xr_n : (long)gridDim.x) * LY_THREADS
+#else
+#define LY_XCD_RANGE(total)                                                                                             \
+  const long xr_begin = (long)blockIdx.x * LY_THREADS + threadIdx.x, xr_end = (total), xr_step = (long)gridDim.x * LY_THREADS
+#endif
+
 template <typename T, int ACT>
 __global__ __launch_bounds__(LY_THREADS) void ly_bnact_bwd_reduce_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ u,
                                                                           int ldu, long rows, int C, const float* __restrict__ a,
@@ -107,7 +126,8 @@ __global__ __launch_bounds__(LY_THREADS) void ly_bnact_bwd_apply_kernel(const T*
   if ((C % VW) == 0 && (ldu % VW) == 0 && (lddy % VW) == 0 && (lddu % VW) == 0 && (lddy2 % VW) == 0 && (csplit % VW) == 0) {
     const int ncv = C / VW;
     const long total = rows * ncv;
-    for (long i = (long)blockIdx.x * LY_THREADS + threadIdx.x; i < total; i += (long)gridDim.x * LY_THREADS) {
+    LY_XCD_RANGE(total);
+    for (long i = xr_begin; i < xr_end; i += xr_step) {
       const long r = i / ncv;
       const int c = VW * (int)(i - r * ncv);
       f32x4 uu[NQ], g[NQ];
@@ -125,7 +145,8 @@ __global__ __launch_bounds__(LY_THREADS) void ly_bnact_bwd_apply_kernel(const T*
   }
   const int nc4 = C >> 2;
   const long total = rows * nc4;
-  for (long i = (long)blockIdx.x * LY_THREADS + threadIdx.x; i < total; i += (long)gridDim.x * LY_THREADS) {
+  LY_XCD_RANGE(total);
+  for (long i = xr_begin; i < xr_end; i += xr_step) {
     const long r = i / nc4;
     const int c = 4 * (int)(i - r * nc4);
     const f32x4 uu = ly_ld4<T>(u + r * ldu + c);
@@ -145,7 +166,8 @@ __global__ __launch_bounds__(LY_THREADS) void ly_bnact_fwd_kernel(const T* __res
   if ((C % VW) == 0 && (ldu % VW) == 0 && (ldy % VW) == 0) {
     const int ncv = C / VW;
     const long total = rows * ncv;
-    for (long i = (long)blockIdx.x * LY_THREADS + threadIdx.x; i < total; i += (long)gridDim.x * LY_THREADS) {
+    LY_XCD_RANGE(total);
+    for (long i = xr_begin; i < xr_end; i += xr_step) {
       const long r = i / ncv;
       const int c = VW * (int)(i - r * ncv);
       f32x4 uu[NQ];
@@ -158,7 +180,8 @@ __global__ __launch_bounds__(LY_THREADS) void ly_bnact_fwd_kernel(const T* __res
   }
   const int nc4 = C >> 2;
   const long total = rows * nc4;
-  for (long i = (long)blockIdx.x * LY_THREADS + threadIdx.x; i < total; i += (long)gridDim.x * LY_THREADS) {
+  LY_XCD_RANGE(total);
+  for (long i = xr_begin; i < xr_end; i += xr_step) {
     const long r = i / nc4;
     const int c = 4 * (int)(i - r * nc4);
     const f32x4 v = ly_ldg4(a + c) * ly_ld4<T>(u + r * ldu + c) + ly_ldg4(b + c);

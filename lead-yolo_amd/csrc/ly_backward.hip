@@ -756,8 +756,9 @@ static void wgrad_combine_launch(const LyWgradParams& P, const float* slab, long
 
 template <typename T, int BN, int BK, int P, bool ROWS, bool PRO = false>
 __global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(BN + BK > 160 ? 2 : 3))) void ly_wgrad_tiled_kernel(const LyWgradParams P_, const int tiles_k, const long chunk_px, float* const slab) {
-  // (no XCD-aware re-ordering here: with it this kernel's 128 x 128 rows form took 3x as long — 45 -> 146 us per launch — while the grouped
-  // kernel, ly_wgrad3 and every other tile kernel were neutral or faster; the cause was not found)
+  // (no XCD-aware re-ordering here: tile / chunk computed from the remapped id with a run-time division made hipcc treat them as per-lane values —
+  // the 128 x 128 rows form took 3x as long, 45 -> 146 us per launch; forced back to scalars (readfirstlane) it fetched a third less from HBM
+  // but still ran 45 -> 50 us, the other forms +-1 us.  The grouped kernel, ly_wgrad3 and the other tile kernels keep the remap.)
   ly_wgrad_tiled_body<T, BN, BK, P, ROWS, PRO>(P_, (int)blockIdx.x, (int)blockIdx.y, tiles_k, chunk_px, slab, (int)gridDim.x);
 }
 

@@ -537,10 +537,17 @@ def run_train(args, ctx):
 
             def step():
                 state["loss"], _ = g()
-            launch = "hipGraph replay of the whole optimisation step" if ctx.world == 1 else \
-                ("hipGraph A (forward + backward) with an event-record node where each gradient bucket completes; the bucket's RCCL all-reduce is "
-                 "released from that event on a communication stream while A is still executing the rest of backward (overlapped); hipGraph B = fused "
-                 f"optimiser dividing by the world size; {len(g._marked)} of {len(reducer.buckets)} buckets released mid-graph")
+            if ctx.world == 1:
+                launch = "hipGraph replay of the whole optimisation step"
+            elif getattr(g, "_serial", False):
+                launch = ("hipGraph A (forward + backward) -> ONE synchronous all-reduce of all gradients "
+                          f"({sum(b['flat'].numel() * b['flat'].element_size() for b in reducer.buckets) / 2**20:.1f} MiB, {len(reducer.buckets)} buckets in one "
+                          "master buffer) on the step's own stream -> hipGraph B = fused optimiser dividing by the world size (serial exchange: "
+                          "for this gradient volume cheaper than the ~0.3 ms the first cross-stream event wait after the graph costs)")
+            else:
+                launch = ("hipGraph A (forward + backward) with an event-record node where each gradient bucket completes; the bucket's RCCL all-reduce is "
+                          "released from that event on a communication stream while A is still executing the rest of backward (overlapped); hipGraph B = fused "
+                          f"optimiser dividing by the world size; {len(g._marked)} of {len(reducer.buckets)} buckets released mid-graph")
         except Exception as e:                                  # noqa: BLE001
             print(f"[bench] hipGraph capture of the train step unavailable ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr)
             step = eager_step
@@ -565,7 +572,13 @@ def run_train(args, ctx):
             # forward + backward graph alone: the driver computes scaling from the per-N values, this says WHY a step is longer than N = 1's
             try:
                 pr = [g.profile_step() for _ in range(3)][-1]
-                res["dp_overlap"] = dict(graph_a_ms=round(pr["graph_a_ms"], 4), step_ms=round(pr["step_ms"], 4),
+                if getattr(g, "_serial", False):
+                    res["dp_overlap"] = dict(mode="serial", graph_a_ms=round(pr["graph_a_ms"], 4), step_ms=round(pr["step_ms"], 4),
+                                             exchange_and_optimizer_tail_ms=round(pr["step_ms"] - pr["graph_a_ms"], 4), bucket_release_pct_of_graph_a=[],
+                                             note="rank 0, one profiled step after the timed region: serial exchange — one all-reduce of all gradients on "
+                                                  "the step's stream between graph A (forward + backward) and graph B (optimiser); the tail is its whole cost")
+                else:
+                    res["dp_overlap"] = dict(mode="overlapped", graph_a_ms=round(pr["graph_a_ms"], 4), step_ms=round(pr["step_ms"], 4),
                                          exchange_and_optimizer_tail_ms=round(pr["step_ms"] - pr["graph_a_ms"], 4),
                                          bucket_release_pct_of_graph_a=[dict(bucket=bi, bytes=nb, released_at_pct=pct) for bi, nb, pct in pr["buckets"]],
                                          note="rank 0, one profiled step after the timed region: a bucket's all-reduce is queued on the communication "

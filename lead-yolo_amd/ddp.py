@@ -44,6 +44,14 @@ class GradReducer:
             paired.append(group)
         order = paired
         self.buckets = []                                         # list of dict(params, flat, views)
+        # ONE master buffer under all buckets of the first parameter's (dtype, device) — every bucket's flat is a slice of it, in bucket order:
+        # reset() is one fill, and exchange_all_sync() one collective (the serial form of the captured step, train.GraphedTrainStep)
+        flat_params = [p for g in order for p in g]
+        self._master, self._master_off = None, 0
+        if flat_params:
+            d0, v0 = flat_params[0].dtype, flat_params[0].device
+            n_master = sum(p.numel() for p in flat_params if p.dtype == d0 and p.device == v0)
+            self._master = torch.zeros(n_master, dtype=d0, device=v0)
         cur, cur_bytes, cap = [], 0, first_bucket_bytes           # small first bucket => earliest possible launch
         for group in order:
             nb = sum(p.numel() * p.element_size() for p in group)
@@ -75,7 +83,12 @@ class GradReducer:
 
     def _close(self, plist):
         n = sum(p.numel() for p in plist)
-        flat = torch.zeros(n, dtype=plist[0].dtype, device=plist[0].device)
+        m = self._master
+        if m is not None and plist[0].dtype == m.dtype and plist[0].device == m.device and self._master_off + n <= m.numel():
+            flat = m[self._master_off:self._master_off + n]
+            self._master_off += n
+        else:
+            flat = torch.zeros(n, dtype=plist[0].dtype, device=plist[0].device)
         views, off = [], 0
         for p in plist:
             if getattr(p, "_ly_tap_major", False) and p.dim() == 4 and p.shape[2] * p.shape[3] > 1:
@@ -93,8 +106,12 @@ class GradReducer:
     # ---- per-step protocol ---------------------------------------------------------------------------
     def reset(self):
         """Call at the start of every step (instead of zero_grad(set_to_none=True))."""
+        whole = self.master_covers_all()
+        if whole:
+            self._master.zero_()                                  # one fill for every bucket
         for b in self.buckets:
-            b["flat"].zero_()
+            if not whole:
+                b["flat"].zero_()
             for p, v in zip(b["params"], b["views"]):
                 p.grad = v
         self._pending = [len(b["params"]) for b in self.buckets]
@@ -248,6 +265,27 @@ class GradReducer:
         SUM over ranks and the optimiser divides while it reads; any other reader of `p.grad` must divide by `self.world` itself."""
         self.reduce_now()
         self.wait_works()
+
+    def master_covers_all(self):
+        """every bucket's flat buffer is a slice of the one master buffer (one dtype, one device: the usual case)"""
+        m = self._master
+        return m is not None and self._master_off == m.numel() and all(
+            b["flat"].device == m.device and b["flat"].dtype == m.dtype and
+            m.data_ptr() <= b["flat"].data_ptr() < m.data_ptr() + m.numel() * m.element_size() for b in self.buckets)
+
+    def total_bytes(self):
+        return sum(b["flat"].numel() * b["flat"].element_size() for b in self.buckets)
+
+    def exchange_all_sync(self):
+        """ONE synchronous all-reduce of every gradient, on the CURRENT stream (c10d runs a synchronous collective in the caller's stream
+        order: no second queue waits on the step).  The serial form of the exchange: nothing overlaps the backward, but the first
+        cross-stream event wait after a 10 ms graph costs ~0.3 ms on this stack — more than the whole exchange of a small model's
+        gradients (12.5 MB for lead-yolo-s).  Requires master_covers_all()."""
+        if self.world == 1 and not (self.exchange_single and dist.is_initialized()):
+            return
+        if self.average and not self.defer_average:
+            self._master.div_(self.world)
+        dist.all_reduce(self._master, op=dist.ReduceOp.SUM, group=self.group, async_op=False)
 
     def wait_works(self):
         """the current stream waits for every exchange launched so far"""

@@ -144,6 +144,9 @@ def train_step(model, compute_loss, optimizer, imgs, targets, ema=None, reducer=
     return loss, items
 
 
+DP_SERIAL_MAX_BYTES = 32 << 20      # gradient bytes up to which the captured data-parallel step exchanges serially (GraphedTrainStep._capture)
+
+
 class GraphedTrainStep:
     """The whole optimisation step — uint8 batch -> forward -> loss -> backward -> clip + SGD-nesterov + zero_grad (+ EMA) — captured
     once into hipGraphs and replayed with no per-launch host work.  Possible because every C-ABI entry point only
@@ -227,7 +230,21 @@ class GraphedTrainStep:
         else:
             lib = capi.lib()
             mark = None
-            if reducer is not None:
+            # Small gradient volumes take the SERIAL exchange: no event nodes, no communication stream — after graph A ONE synchronous
+            # all-reduce of the reducer's master buffer on the step's own stream, then graph B.  The overlapped form pays ~0.3 ms per step
+            # for the first cross-stream event wait after the graph (measured at one rank), which is more than exchanging
+            # lead-yolo-s' 12.5 MB takes; larger models keep the overlap.  (LY_DP_SERIAL=0 / 1 forces the choice.)
+            force = os.environ.get("LY_DP_SERIAL")
+            self._serial = (reducer is not None and self.accumulate == 1 and reducer.master_covers_all()
+                            and (force == "1" or (force != "0" and reducer.total_bytes() <= DP_SERIAL_MAX_BYTES)))
+            if self._serial:
+                _set_deferred_average(optimizer, reducer)
+                reducer.reset()
+                self._recorded = set()
+
+                def mark(bi):                                # (bucket bookkeeping only: nothing is recorded into the graph)
+                    return None
+            elif reducer is not None:
                 _set_deferred_average(optimizer, reducer)
                 reducer.reset()
                 for _ in reducer.buckets:
@@ -325,7 +342,9 @@ class GraphedTrainStep:
         if not self.stepped:
             return self.loss, self.items
         self._micro = 0
-        if self.reducer is not None:
+        if self.reducer is not None and getattr(self, "_serial", False):
+            self.reducer.exchange_all_sync()               # one collective on this stream, between the two graphs
+        elif self.reducer is not None:
             lib, red, cur, comm = capi.lib(), self.reducer, torch.cuda.current_stream(), self._comm
             with torch.cuda.stream(comm):
                 held = []

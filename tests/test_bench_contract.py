@@ -49,13 +49,19 @@ def test_single_gpu_line():
     assert "workload" in d["config"] and "model" not in d["config"]
 
 
-def test_two_rank_launch_path_dry_run():
+@pytest.mark.parametrize("serial", ["1", "0"])
+def test_two_rank_launch_path_dry_run(serial):
     d = _run(["--gpus", "2", "--steps", "2", "--warmup", "2", "--repeats", "1", "--batch", "4", "--no-cpu-baseline"],
-             env={"LY_BENCH_ONE_GPU": "1", "LY_BENCH_BACKEND": "gloo"})
+             env={"LY_BENCH_ONE_GPU": "1", "LY_BENCH_BACKEND": "gloo", "LY_DP_SERIAL": serial})
+    assert d["dp_overlap"].get("mode") == ("serial" if serial == "1" else "overlapped"), d["dp_overlap"]
     assert KEYS <= set(d) and d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["config"]["world_size"] == 2
-    assert "DRY RUN" in d["config"]["parallelism"] and d["grad_buckets"] >= 1 and "released mid-graph" in d["launch_mode"]
+    assert "DRY RUN" in d["config"]["parallelism"] and d["grad_buckets"] >= 1
     assert d["roofline"]["step"]["families"]                       # the probe ran (on both ranks) and the job still ended cleanly
     ov = d["dp_overlap"]
     assert d["rccl_ranks"] == 2 and "error" not in ov and ov["graph_a_ms"] > 0 and ov["step_ms"] >= ov["graph_a_ms"]
-    assert len(ov["bucket_release_pct_of_graph_a"]) >= 1 and all(b["released_at_pct"] > 0 for b in ov["bucket_release_pct_of_graph_a"])
+    if ov["mode"] == "serial":                      # lead-yolo-s' 12.5 MB of gradients: one synchronous all-reduce between the two graphs
+        assert "serial exchange" in d["launch_mode"] and ov["bucket_release_pct_of_graph_a"] == []
+    else:
+        assert "released mid-graph" in d["launch_mode"]
+        assert len(ov["bucket_release_pct_of_graph_a"]) >= 1 and all(b["released_at_pct"] > 0 for b in ov["bucket_release_pct_of_graph_a"])
     assert abs(d["value"] - 2 * 4 * 1e3 / d["ms_per_step"]) < 1e-2 * d["value"]

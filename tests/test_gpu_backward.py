@@ -511,14 +511,17 @@ def _one_rank_group():
     return dist
 
 
-@pytest.mark.parametrize("rccl,accumulate", [(False, 1), (True, 1), (True, 2)])
-def test_graphed_step_with_reducer_matches_eager(rccl, accumulate):
-    """the data-parallel form of the captured step — graph A = forward + backward into the reducer's bucket views with an event-record
+@pytest.mark.parametrize("rccl,accumulate,serial", [(False, 1, "0"), (True, 1, "0"), (True, 1, "1"), (False, 1, "1"), (True, 2, "0")])
+def test_graphed_step_with_reducer_matches_eager(rccl, accumulate, serial, monkeypatch):
+    """(serial = "1": the serial exchange — ONE synchronous all-reduce of the reducer's master buffer on the step's stream between the two
+    graphs, what small gradient volumes take by default; "0": the overlapped form below)
+    the data-parallel form of the captured step — graph A = forward + backward into the reducer's bucket views with an event-record
     node where each bucket completes, per-bucket all-reduce released from those events on a communication stream while A is still
     running, graph B = fused optimiser (dividing by the world size) — against eager train_step with the same reducer.  World size 1:
     without a process group (the exchange is skipped) and with a one-rank RCCL group (every bucket's all-reduce really launched);
     accumulate = 2: two micro-batches per optimiser step (reference train.py:157,300,330) vs eager no_sync accumulation."""
     import lead_yolo_amd as L
+    monkeypatch.setenv("LY_DP_SERIAL", serial)
     dist = _one_rank_group() if rccl else None
     try:
         runs = []
@@ -539,6 +542,7 @@ def test_graphed_step_with_reducer_matches_eager(rccl, accumulate):
             if graphed:
                 step = L.GraphedTrainStep(m, cl, opt, *data[0], ema=ema, warmup=2, reducer=red, world_size=1, accumulate=accumulate)
                 assert len(step._marked) + len(step._unmarked) == len(red.buckets) and len(step._marked) >= 1, (step._marked, step._unmarked)
+                assert step._serial == (serial == "1" and accumulate == 1) and red.master_covers_all()
                 for _ in range(3):
                     for j in range(accumulate):
                         loss, _ = step(*data[j % 2])

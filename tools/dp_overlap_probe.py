@@ -4,6 +4,7 @@ with bucket-completion event nodes) -> per-bucket all-reduce released from those
 Prints, from one profiled step (torch profiler, device activity), the start of every RCCL kernel relative to the span of graph A's kernels.
     python tools/dp_overlap_probe.py [bs]"""
 import os, sys
+os.environ["LY_DP_SERIAL"] = "0"      # this tool looks at the OVERLAPPED form (lead-yolo-s takes the serial exchange by default since late round 5)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import torch.distributed as dist

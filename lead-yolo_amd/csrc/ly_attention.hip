@@ -24,7 +24,8 @@ __global__ __launch_bounds__(LY_THREADS) void ly_pool_hw_kernel(const T* __restr
   // block b -> (n, pos); pos < H: mean over w of row pos; else mean over h of column pos-H
   __shared__ f32x4 red[LY_THREADS];
   const int L = H + W;
-  const int n = blockIdx.x / L, pos = blockIdx.x - n * L;
+  const int bid = ly_xcd_remap((int)blockIdx.x, (int)gridDim.x);     // an image's H row blocks and W column blocks read the same cache lines: one XCD's L2
+  const int n = bid / L, pos = bid - n * L;
   const int nc4 = C >> 2;
   const int tid = threadIdx.x;
   const int groups = LY_THREADS / nc4;

@@ -533,7 +533,8 @@ def run_train(args, ctx):
         # step.  N > 1: graph A (forward + backward, bucket-completion event nodes) -> per-bucket RCCL all-reduce released from those events
         # while A is still running -> graph B (fused optimiser); the all-reduce launches are the only eager work.
         try:
-            g = L.GraphedTrainStep(model, loss_fn, opt, imgs, tg, ema=ema, amp=amp, warmup=max(args.warmup, 2), reducer=reducer, world_size=ctx.world)
+            g = L.GraphedTrainStep(model, loss_fn, opt, imgs, tg, ema=ema, amp=amp, warmup=max(args.warmup, 2), reducer=reducer, world_size=ctx.world,
+                                   dp_exchange=args.dp_exchange)
 
             def step():
                 state["loss"], _ = g()
@@ -542,12 +543,15 @@ def run_train(args, ctx):
             elif getattr(g, "_serial", False):
                 launch = ("hipGraph A (forward + backward) -> ONE synchronous all-reduce of all gradients "
                           f"({sum(b['flat'].numel() * b['flat'].element_size() for b in reducer.buckets) / 2**20:.1f} MiB, {len(reducer.buckets)} buckets in one "
-                          "master buffer) on the step's own stream -> hipGraph B = fused optimiser dividing by the world size (serial exchange: "
-                          "for this gradient volume cheaper than the ~0.3 ms the first cross-stream event wait after the graph costs)")
+                          "master buffer) issued from the step's stream -> hipGraph B = fused optimiser dividing by the world size (serial exchange"
+                          + (f": timed at construction on {g.dp_probe['ranks']} ranks, {g.dp_probe['serial_ms']} ms per step against "
+                             f"{g.dp_probe['overlapped_ms']} ms for the overlapped form)" if g.dp_probe else ", forced)"))
             else:
                 launch = ("hipGraph A (forward + backward) with an event-record node where each gradient bucket completes; the bucket's RCCL all-reduce is "
                           "released from that event on a communication stream while A is still executing the rest of backward (overlapped); hipGraph B = fused "
-                          f"optimiser dividing by the world size; {len(g._marked)} of {len(reducer.buckets)} buckets released mid-graph")
+                          f"optimiser dividing by the world size; {len(g._marked)} of {len(reducer.buckets)} buckets released mid-graph"
+                          + (f"; timed at construction on {g.dp_probe['ranks']} ranks: {g.dp_probe['overlapped_ms']} ms per step against "
+                             f"{g.dp_probe['serial_ms']} ms for the serial form" if g.dp_probe else "; forced"))
         except Exception as e:                                  # noqa: BLE001
             print(f"[bench] hipGraph capture of the train step unavailable ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr)
             step = eager_step
@@ -583,6 +587,9 @@ def run_train(args, ctx):
                                          bucket_release_pct_of_graph_a=[dict(bucket=bi, bytes=nb, released_at_pct=pct) for bi, nb, pct in pr["buckets"]],
                                          note="rank 0, one profiled step after the timed region: a bucket's all-reduce is queued on the communication "
                                               "stream behind an event node inside graph A (forward + backward); < 100 % = released while backward was running")
+                # both exchange forms as timed at construction over this process group (max over ranks), and which one the step runs
+                res["dp_overlap"]["probe"] = g.dp_probe if g.dp_probe else dict(chosen=res["dp_overlap"]["mode"], forced=True)
+                res["dp_overlap"]["rccl_ranks"] = ctx.dist.get_world_size()
             except Exception as e:                              # noqa: BLE001
                 res["dp_overlap"] = dict(error=f"{type(e).__name__}: {e}")
     return res
@@ -649,6 +656,8 @@ def main():
     ap.add_argument("--layers", action="store_true", help="print the per-kernel table to stderr")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel probe (for whole-step rocprof runs)")
     ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of replaying the captured hipGraph of the step")
+    ap.add_argument("--dp-exchange", default="probe", choices=("probe", "serial", "overlapped"),
+                    help="N > 1: gradient exchange form of the captured step (probe = time both at construction over the real group, keep the faster)")
     args = ap.parse_args()
     if args.train:
         args.mode = "train"

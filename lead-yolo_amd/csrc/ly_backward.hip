@@ -800,14 +800,19 @@ __global__ __launch_bounds__(1024) void ly_wgrad_combine_group_kernel(const LyWg
   ly_wgrad_combine_body(G.p[g], G.slab[g], G.chunks[g], G.tiles_k[g], G.tiles[g], BN, BK, (long)((int)blockIdx.x - G.cblk0[g]), rls);
 }
 
-// blocks a weight-gradient launch aims for (development knob: LY_WG_BLOCKS / LY_WG_GROUP_BLOCKS)
+// blocks a weight-gradient launch aims for (development builds, `make DEVEL=1`, read LY_WG_BLOCKS / LY_WG_GROUP_BLOCKS)
 static long wg_target_blocks(bool group) {
+#ifdef LY_DEVEL
   static long t[2] = {0, 0};
   if (!t[group]) {
     const char* e = getenv(group ? "LY_WG_GROUP_BLOCKS" : "LY_WG_BLOCKS");
     t[group] = e && atol(e) > 0 ? atol(e) : 512;
   }
   return t[group];
+#else
+  (void)group;
+  return 512;
+#endif
 }
 
 template <typename T, int BN, int BK, int P>

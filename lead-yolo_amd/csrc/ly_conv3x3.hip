@@ -497,8 +497,12 @@ static int launch_conv3(const LyConv3Params& P, hipStream_t st) {
 template <typename T>
 static int conv3_dispatch(const LyConv3Params& P, hipStream_t st) {
   // measured on MI355X: 32 channels per wave is the sweet spot at every LEAD-YOLO shape
-  static int mode = -1;                                   // development knob LY_C3_MODE: 1 = <2,4>, 2 = <2,4,LAT>, 3 = <2,2>, 4 = <2,2,LAT>
+#ifdef LY_DEVEL
+  static int mode = -1;                                   // development builds (make DEVEL=1) read LY_C3_MODE: 1 = <2,4>, 2 = <2,4,LAT>, 3 = <2,2>, 4 = <2,2,LAT>
   if (mode < 0) { const char* e = getenv("LY_C3_MODE"); mode = e ? atoi(e) : 0; }
+#else
+  constexpr int mode = 0;
+#endif
   if constexpr (LyT<T>::BF) {
     const long tiles = (P.M / ((long)P.H * P.W)) * ((P.W + P.TW - 1) / P.TW) * ((P.H + P.TH - 1) / P.TH);
     const bool small = tiles * ((P.N + 127) / 128) < 2 * 256;            // fewer than two blocks per CU

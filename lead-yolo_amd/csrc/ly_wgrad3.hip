@@ -256,8 +256,14 @@ int ly_wgrad3_launch(const LyWgradParams& P, hipStream_t st) {
   LY_CHECK(total < (1L << 30), "wgrad3: too many tiles");
   const int n_n = (P.N + W3_BN - 1) / W3_BN, n_c = (P.Cin + W3_CK - 1) / W3_CK;
   // ~1024 blocks (four per CU); every block adds the valid part of its 64 x 288 tile to dw once
-  static int target = 0;
+#ifdef LY_DEVEL
+  static int target = 0;                                  // development builds (make DEVEL=1) read LY_W3_BLOCKS / LY_W3_ATOMIC
   if (!target) { const char* e = getenv("LY_W3_BLOCKS"); target = e ? atoi(e) : 768; }
+  static const bool force_atomic = getenv("LY_W3_ATOMIC") != nullptr;
+#else
+  constexpr int target = 768;
+  constexpr bool force_atomic = false;
+#endif
   long chunks = (target + (long)n_n * n_c - 1) / ((long)n_n * n_c);
   if (chunks > total) chunks = total;
   if (chunks < 1) chunks = 1;
@@ -265,7 +271,6 @@ int ly_wgrad3_launch(const LyWgradParams& P, hipStream_t st) {
   chunks = (total + tchunk - 1) / tchunk;
   // partial tiles by plain stores + one combine launch when the scratch holds them; float atomics otherwise
   const long need = chunks * n_n * n_c * (long)(W3_BN * 288);
-  static const bool force_atomic = getenv("LY_W3_ATOMIC") != nullptr;          // development switch, read once
   float* slab = (P.ws && need <= P.ws_floats && !force_atomic) ? P.ws : nullptr;
   hipLaunchKernelGGL(ly_wgrad3_kernel, dim3((unsigned)(chunks * n_n * n_c)), dim3(LY_THREADS), 0, st, P, tiles_x, tiles_y, n_n, n_c, (int)tchunk,
                      (int)total, slab);

@@ -277,10 +277,12 @@ class GradReducer:
         return sum(b["flat"].numel() * b["flat"].element_size() for b in self.buckets)
 
     def exchange_all_sync(self):
-        """ONE synchronous all-reduce of every gradient, on the CURRENT stream (c10d runs a synchronous collective in the caller's stream
-        order: no second queue waits on the step).  The serial form of the exchange: nothing overlaps the backward, but the first
-        cross-stream event wait after a 10 ms graph costs ~0.3 ms on this stack — more than the whole exchange of a small model's
-        gradients (12.5 MB for lead-yolo-s).  Requires master_covers_all()."""
+        """ONE blocking (async_op=False) all-reduce of every gradient, issued from the CURRENT stream.  With the nccl (RCCL) backend the
+        collective itself still runs on the process group's internal stream: c10d makes that stream wait for the current one, and the
+        current one wait for the collective — two cross-stream hand-offs, nothing overlapping the backward; with gloo the call blocks the
+        host.  The serial form of the captured step's exchange; whether it beats the overlapped form (one hand-off, exchange hidden behind
+        the rest of the backward) depends on the world size and the gradient volume, so train.GraphedTrainStep TIMES both at construction
+        (`dp_exchange="probe"`) instead of assuming.  Requires master_covers_all()."""
         if self.world == 1 and not (self.exchange_single and dist.is_initialized()):
             return
         if self.average and not self.defer_average:

@@ -1261,7 +1261,7 @@ RfcbamFn._backward_k1 = staticmethod(_rfcbam_backward_k1)
 RF1_BWD = True         # tools: False keeps the first-generation k = 1 backward
 RF3S_BWD = True        # tools: False keeps the thread = channel attention / ReLU passes of the streamed k = 3 backward
 RC_BWD = True          # tools: False keeps the first-generation backward behind the lane = channel forward
-RC_BWD_WIDTHS = tuple(int(v) for v in os.environ.get("LY_RC_BWD_WIDTHS", "64,128").split(","))   # output widths on the recompute passes (see RfcbamFn.backward)
+RC_BWD_WIDTHS = (64, 128)           # output widths on the recompute passes (see RfcbamFn.backward); a module constant: tools / tests monkeypatch it
 def rfcbam_train(mod, x):
     """RFCBAMConv.forward in training: one autograd node (SE, generate BatchNorm, attention maps, contraction)."""
     g, cv = mod.generate, mod.conv

@@ -1104,7 +1104,7 @@ class _WgradQueue:
     task = -1
 
 
-WGRAD_DEFER = os.environ.get("LY_WGRAD_DEFER", "1") != "0"
+WGRAD_DEFER = True                  # a module constant (tests monkeypatch it): not reachable from the environment
 WGRAD_GROUP_MAX = 4
 WGRAD_DEFER_MAX_MACS = 4 << 30      # M * N * K: a larger problem fills the chip alone, and the grouped kernel costs ~15 % more per unit of work than the
                                     # single-problem one (lead-yolo-l bs=16 1280x1280 with all its plain-row problems in groups: 33.96 -> 34.96 ms per step;

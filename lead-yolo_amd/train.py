@@ -144,7 +144,17 @@ def train_step(model, compute_loss, optimizer, imgs, targets, ema=None, reducer=
     return loss, items
 
 
-DP_SERIAL_MAX_BYTES = 32 << 20      # gradient bytes up to which the captured data-parallel step exchanges serially (GraphedTrainStep._capture)
+# The captured data-parallel step can exchange its gradients in two forms (GraphedTrainStep, `dp_exchange`):
+#   "overlapped": every ~2 MB bucket's all-reduce is released by an event-record node inside the replayed backward graph and runs on a
+#                 communication stream while the rest of the backward executes (what the reference's DistributedDataParallel does,
+#                 utils/torch_utils.py:55-63) — costs one cross-stream hand-off per step;
+#   "serial":     graph A -> ONE all-reduce of the reducer's master buffer issued from the step's stream -> graph B; nothing overlaps.
+#   "probe" (default): both forms are TIMED at construction, at the actual world size over the actual process group, and the faster one is
+#                 kept; the decision is taken from the maximum over ranks, so every rank takes the same one.
+DP_EXCHANGE = "probe"             # module default of GraphedTrainStep(dp_exchange=None); tests / tools monkeypatch it
+DP_PROBE_REPLAYS = 10             # timed replays per form
+SPLIT_GRAPHS = False              # development: capture the single-GPU step as the data-parallel pair of graphs (tests monkeypatch it)
+DP_MARK_EVERY = 1                 # development: an event node only at every k-th completed bucket
 
 
 class GraphedTrainStep:
@@ -162,18 +172,20 @@ class GraphedTrainStep:
     One GPU, accumulate = 1: ONE graph holds the whole step.
 
     Data parallel (reducer = ddp.GradReducer over RCCL; reference: DistributedDataParallel's reducer, utils/torch_utils.py:55-63,
-    train.py:233-235) — the gradient exchange OVERLAPS the replayed backward: graph A = forward + backward, in which every gradient
+    train.py:233-235) — two exchange forms, both timed at construction over the actual process group (`dp_exchange="probe"`, the default;
+    `.dp_probe` holds both timings and the choice; "serial" / "overlapped" force one, and the ranks are checked to agree).  Overlapped:
+    the gradient exchange OVERLAPS the replayed backward: graph A = forward + backward, in which every gradient
     bucket's completion point is an event-record node (csrc ly_event_record); right after launching A the host queues, per bucket in
     completion order, `wait for its event` + `all_reduce(bucket)` on a communication stream, so RCCL starts on a bucket while the graph
     is still executing the rest of the backward; graph B = the fused optimiser (which also divides by the world size:
     FusedSGD.grad_scale — no division pass per bucket) runs when the last exchange is done.  The ~10 all-reduce launches are the only
-    eager work of a step.
+    eager work of a step.  Serial: graph A -> one all-reduce of the reducer's master buffer issued from the step's stream -> graph B.
 
     accumulate = k (the reference's gradient accumulation, train.py:157,300,330): call k times with k micro-batches; graph A runs every
     time (gradients add up in place), the exchange and graph B only on every k-th call, which returns `stepped = True` in `.stepped`."""
 
     def __init__(self, model, compute_loss, optimizer, imgs, targets, ema=None, amp=None, max_norm=10.0, warmup=3, reducer=None, world_size=1,
-                 accumulate=1):
+                 accumulate=1, dp_exchange=None):
         if not getattr(optimizer, "fused", False):
             raise NotImplementedError("GraphedTrainStep needs optim.FusedSGD (smart_optimizer(..., fused=True)): torch.optim.SGD + "
                                       "clip_grad_norm_ keep per-step host state")
@@ -182,6 +194,11 @@ class GraphedTrainStep:
         self.model, self.optimizer, self.ema, self.reducer, self.max_norm = model, optimizer, ema, reducer, max_norm
         self.accumulate, self._micro, self.stepped = max(int(accumulate), 1), 0, False
         self.probe = None
+        self.dp_exchange = dp_exchange or DP_EXCHANGE
+        if self.dp_exchange not in ("probe", "serial", "overlapped"):
+            raise ValueError(f"GraphedTrainStep: dp_exchange must be 'probe', 'serial' or 'overlapped' (got {self.dp_exchange!r})")
+        self.dp_probe = None                   # dict(serial_ms, overlapped_ms, chosen, ranks, replays) once both forms were timed
+        self._serial = False
         args = dict(ema=ema, amp=amp, max_norm=max_norm, reducer=reducer, world_size=world_size)
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream(device=imgs.device)
@@ -221,30 +238,20 @@ class GraphedTrainStep:
         self._pins = (ops._POOL.buf, dict(getattr(compute_loss, "_const", {})), optimizer._table)
         # packed weight images were only RECORDED as refreshed during the capture: an eager forward before the first replay must rebuild them
         pack.touch_weights()
+        if reducer is not None and self.accumulate == 1:
+            self._choose_exchange()
 
     def _capture(self, model, compute_loss, optimizer, ema, amp, max_norm, reducer, world_size, capi):
         imgs = self.imgs
-        if reducer is None and self.accumulate == 1 and not os.environ.get("LY_SPLIT_GRAPHS"):
+        if reducer is None and self.accumulate == 1 and not SPLIT_GRAPHS:
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self.loss, self.items = train_step(model, compute_loss, optimizer, self.imgs, self.targets, ema=ema, amp=amp, max_norm=max_norm)
         else:
             lib = capi.lib()
             mark = None
-            # Small gradient volumes take the SERIAL exchange: no event nodes, no communication stream — after graph A ONE synchronous
-            # all-reduce of the reducer's master buffer on the step's own stream, then graph B.  The overlapped form pays ~0.3 ms per step
-            # for the first cross-stream event wait after the graph (measured at one rank), which is more than exchanging
-            # lead-yolo-s' 12.5 MB takes; larger models keep the overlap.  (LY_DP_SERIAL=0 / 1 forces the choice.)
-            force = os.environ.get("LY_DP_SERIAL")
-            self._serial = (reducer is not None and self.accumulate == 1 and reducer.master_covers_all()
-                            and (force == "1" or (force != "0" and reducer.total_bytes() <= DP_SERIAL_MAX_BYTES)))
-            if self._serial:
-                _set_deferred_average(optimizer, reducer)
-                reducer.reset()
-                self._recorded = set()
-
-                def mark(bi):                                # (bucket bookkeeping only: nothing is recorded into the graph)
-                    return None
-            elif reducer is not None:
+            if reducer is not None:
+                # graph A always carries the bucket-completion event nodes (they cost nothing inside a replayed graph: DESIGN.md §6); which
+                # exchange form uses them is decided after the capture (_choose_exchange)
                 _set_deferred_average(optimizer, reducer)
                 reducer.reset()
                 for _ in reducer.buckets:
@@ -254,11 +261,11 @@ class GraphedTrainStep:
                 self._comm = torch.cuda.Stream(device=imgs.device)
 
                 self._recorded = set()
-                stride = max(int(os.environ.get("LY_DP_MARK_EVERY", "1")), 1)
+                stride = max(int(DP_MARK_EVERY), 1)
 
                 def mark(bi):
                     # runs inside the captured backward (autograd's thread, capture stream current): an event-record node behind everything
-                    # captured so far, i.e. behind the kernel that wrote the bucket's last gradient.  (LY_DP_MARK_EVERY = k: a node only at
+                    # captured so far, i.e. behind the kernel that wrote the bucket's last gradient.  (DP_MARK_EVERY = k: a node only at
                     # every k-th completed bucket — the buckets in between are released by the next node or after the graph)
                     if len(reducer._mark_order) % stride == stride - 1:
                         capi.check(lib.ly_event_record(self._events[bi], capi.stream_ptr()), "ly_event_record")
@@ -272,6 +279,74 @@ class GraphedTrainStep:
             self.opt_graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.opt_graph, pool=self.graph.pool(), capture_error_mode="thread_local"):
                 optimizer_step(model, optimizer, ema=ema, max_norm=max_norm, reducer=reducer)
+
+    # ---- which exchange form: measured, at the actual world size -----------------------------------------------------------------
+    def _dp_state(self):
+        """every tensor an optimisation step changes (parameters, BatchNorm buffers, momentum, EMA, the optimiser's device scalars): the probe
+        replays real steps and puts them back"""
+        ts = [v for v in self.model.state_dict().values()]
+        ts += [st["momentum_buffer"] for g in self.optimizer.param_groups for p in g["params"]
+               for st in (self.optimizer.state.get(p, {}),) if st.get("momentum_buffer") is not None]
+        if self.ema is not None:
+            ts += list(self.ema.ema.state_dict().values())
+        t = self.optimizer._table
+        ts += [t["hyper"], t["ws"], self.optimizer.grad_norm]
+        return ts
+
+    def _choose_exchange(self):
+        import torch.distributed as dist
+        from . import pack
+        red = self.reducer
+        exchanging = not (red.world == 1 and not (red.exchange_single and dist.is_initialized()))
+        can_serial = red.master_covers_all()
+        want = self.dp_exchange
+        if want == "serial" and not can_serial:
+            raise RuntimeError("GraphedTrainStep: dp_exchange='serial' needs every gradient bucket inside the reducer's master buffer (one dtype, one device)")
+        if exchanging and dist.is_initialized():
+            # the ranks must agree on the form (they issue different collective sequences): compare the request across the group first
+            code = {"probe": 0, "serial": 1, "overlapped": 2}[want] if can_serial else 3
+            dev = self.imgs.device if dist.get_backend(red.group) == "nccl" else torch.device("cpu")
+            lo, hi = torch.tensor([code], device=dev), torch.tensor([code], device=dev)
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=red.group)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=red.group)
+            if int(lo) != int(hi):
+                raise RuntimeError(f"GraphedTrainStep: the ranks disagree on dp_exchange (codes {int(lo)} .. {int(hi)}): every rank must request the same form")
+        if want != "probe" or not can_serial or not exchanging:
+            self._serial = want == "serial"          # (nothing to exchange / nothing to choose from: the overlapped form unless asked otherwise)
+            return
+        saved = [t.clone() for t in self._dp_state()]
+        updates = self.ema.updates if self.ema is not None else 0
+        times = {}
+        dev = self.imgs.device
+        for form in ("serial", "overlapped"):
+            self._serial = form == "serial"
+            for _ in range(2):
+                self.__call__()
+            torch.cuda.synchronize(dev)
+            if dist.is_initialized():
+                dist.barrier(group=red.group)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(DP_PROBE_REPLAYS):
+                self.__call__()
+            e1.record()
+            torch.cuda.synchronize(dev)
+            times[form] = e0.elapsed_time(e1) / DP_PROBE_REPLAYS
+        t = torch.tensor([times["serial"], times["overlapped"]], dtype=torch.float64,
+                         device=dev if (dist.is_initialized() and dist.get_backend(red.group) == "nccl") else torch.device("cpu"))
+        if dist.is_initialized():
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=red.group)      # the slowest rank sets the step time; identical numbers everywhere
+        ser, ovl = float(t[0]), float(t[1])
+        self._serial = ser < ovl
+        self.dp_probe = dict(serial_ms=round(ser, 4), overlapped_ms=round(ovl, 4), chosen="serial" if self._serial else "overlapped",
+                             ranks=red.world, replays=DP_PROBE_REPLAYS)
+        with torch.no_grad():
+            for dst, src in zip(self._dp_state(), saved):
+                dst.copy_(src)
+        if self.ema is not None:
+            self.ema.updates = updates
+        pack.touch_weights()
+        torch.cuda.synchronize(dev)
 
     def __del__(self):
         # the bucket events are released only while the interpreter (and with it the HIP runtime) is certainly alive: destroying them from a

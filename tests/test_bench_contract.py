@@ -49,11 +49,18 @@ def test_single_gpu_line():
     assert "workload" in d["config"] and "model" not in d["config"]
 
 
-@pytest.mark.parametrize("serial", ["1", "0"])
-def test_two_rank_launch_path_dry_run(serial):
-    d = _run(["--gpus", "2", "--steps", "2", "--warmup", "2", "--repeats", "1", "--batch", "4", "--no-cpu-baseline"],
-             env={"LY_BENCH_ONE_GPU": "1", "LY_BENCH_BACKEND": "gloo", "LY_DP_SERIAL": serial})
-    assert d["dp_overlap"].get("mode") == ("serial" if serial == "1" else "overlapped"), d["dp_overlap"]
+@pytest.mark.parametrize("form", ["probe", "serial", "overlapped"])
+def test_two_rank_launch_path_dry_run(form):
+    d = _run(["--gpus", "2", "--steps", "2", "--warmup", "2", "--repeats", "1", "--batch", "4", "--no-cpu-baseline", "--dp-exchange", form],
+             env={"LY_BENCH_ONE_GPU": "1", "LY_BENCH_BACKEND": "gloo"})
+    pr = d["dp_overlap"].get("probe")
+    assert pr and d["dp_overlap"]["rccl_ranks"] == 2, d["dp_overlap"]
+    if form == "probe":
+        # both exchange forms timed over the real two-rank group (max over ranks), the faster one kept — on every rank the same one
+        assert pr["ranks"] == 2 and pr["serial_ms"] > 0 and pr["overlapped_ms"] > 0 and pr["replays"] >= 5, pr
+        assert pr["chosen"] == ("serial" if pr["serial_ms"] < pr["overlapped_ms"] else "overlapped") == d["dp_overlap"]["mode"], d["dp_overlap"]
+    else:
+        assert d["dp_overlap"].get("mode") == form and pr.get("forced"), d["dp_overlap"]
     assert KEYS <= set(d) and d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["config"]["world_size"] == 2
     assert "DRY RUN" in d["config"]["parallelism"] and d["grad_buckets"] >= 1
     assert d["roofline"]["step"]["families"]                       # the probe ran (on both ranks) and the job still ended cleanly

@@ -511,17 +511,19 @@ def _one_rank_group():
     return dist
 
 
-@pytest.mark.parametrize("rccl,accumulate,serial", [(False, 1, "0"), (True, 1, "0"), (True, 1, "1"), (False, 1, "1"), (True, 2, "0")])
-def test_graphed_step_with_reducer_matches_eager(rccl, accumulate, serial, monkeypatch):
-    """(serial = "1": the serial exchange — ONE synchronous all-reduce of the reducer's master buffer on the step's stream between the two
-    graphs, what small gradient volumes take by default; "0": the overlapped form below)
+@pytest.mark.parametrize("rccl,accumulate,form", [(False, 1, "overlapped"), (True, 1, "overlapped"), (True, 1, "serial"), (False, 1, "serial"),
+                                                  (True, 2, "overlapped"), (True, 1, "probe"), (False, 1, "probe")])
+def test_graphed_step_with_reducer_matches_eager(rccl, accumulate, form):
+    """(form = "serial": ONE blocking all-reduce of the reducer's master buffer issued from the step's stream between the two graphs;
+    "overlapped": the form below; "probe" (the default): both are timed at construction over the real group — 2 x (2 + DP_PROBE_REPLAYS)
+    real optimisation steps whose effect on parameters, BatchNorm buffers, momentum, EMA and the optimiser's device scalars is put back —
+    and the faster one kept: the trajectory afterwards must equal the eager one exactly as for a forced form)
     the data-parallel form of the captured step — graph A = forward + backward into the reducer's bucket views with an event-record
     node where each bucket completes, per-bucket all-reduce released from those events on a communication stream while A is still
     running, graph B = fused optimiser (dividing by the world size) — against eager train_step with the same reducer.  World size 1:
     without a process group (the exchange is skipped) and with a one-rank RCCL group (every bucket's all-reduce really launched);
     accumulate = 2: two micro-batches per optimiser step (reference train.py:157,300,330) vs eager no_sync accumulation."""
     import lead_yolo_amd as L
-    monkeypatch.setenv("LY_DP_SERIAL", serial)
     dist = _one_rank_group() if rccl else None
     try:
         runs = []
@@ -540,9 +542,18 @@ def test_graphed_step_with_reducer_matches_eager(rccl, accumulate, serial, monke
             data = [(synth.synth_images(4, 128, 21 + i).to(_dev()), synth.synth_targets(4, 22, per_image=3).to(_dev())) for i in range(2)]
             losses = []
             if graphed:
-                step = L.GraphedTrainStep(m, cl, opt, *data[0], ema=ema, warmup=2, reducer=red, world_size=1, accumulate=accumulate)
+                step = L.GraphedTrainStep(m, cl, opt, *data[0], ema=ema, warmup=2, reducer=red, world_size=1, accumulate=accumulate, dp_exchange=form)
                 assert len(step._marked) + len(step._unmarked) == len(red.buckets) and len(step._marked) >= 1, (step._marked, step._unmarked)
-                assert step._serial == (serial == "1" and accumulate == 1) and red.master_covers_all()
+                assert red.master_covers_all()
+                if form == "probe" and rccl:
+                    pr = step.dp_probe                    # both forms were really timed on the group, and the step runs the faster one
+                    assert pr and pr["ranks"] == 1 and pr["serial_ms"] > 0 and pr["overlapped_ms"] > 0
+                    assert pr["chosen"] == ("serial" if pr["serial_ms"] < pr["overlapped_ms"] else "overlapped") and step._serial == (pr["chosen"] == "serial")
+                    assert ema.updates == 2               # the probe's steps were put back
+                elif form == "probe":
+                    assert step.dp_probe is None and not step._serial        # no group: nothing to exchange, nothing to time
+                else:
+                    assert step._serial == (form == "serial" and accumulate == 1)
                 for _ in range(3):
                     for j in range(accumulate):
                         loss, _ = step(*data[j % 2])

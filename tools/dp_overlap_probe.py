@@ -4,7 +4,6 @@ with bucket-completion event nodes) -> per-bucket all-reduce released from those
 Prints, from one profiled step (torch profiler, device activity), the start of every RCCL kernel relative to the span of graph A's kernels.
     python tools/dp_overlap_probe.py [bs]"""
 import os, sys
-os.environ["LY_DP_SERIAL"] = "0"      # this tool looks at the OVERLAPPED form (lead-yolo-s takes the serial exchange by default since late round 5)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import torch.distributed as dist
@@ -23,7 +22,7 @@ red = L.GradReducer(list(model.parameters())).attach()
 red.exchange_single = True
 imgs = B.synth_u8(bs, 640, 0).to(dev)
 tg = B.synth_targets(bs, 1).to(dev)
-step = L.GraphedTrainStep(model, cl, opt, imgs, tg, ema=ema, amp=torch.bfloat16, warmup=2, reducer=red, world_size=1)
+step = L.GraphedTrainStep(model, cl, opt, imgs, tg, ema=ema, amp=torch.bfloat16, warmup=2, reducer=red, world_size=1, dp_exchange="overlapped")    # this tool looks at the overlapped form
 print(f"buckets {len(red.buckets)}: {len(step._marked)} released from events inside graph A (order {step._marked}), {len(step._unmarked)} after it")
 for _ in range(3):
     step()

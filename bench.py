@@ -33,7 +33,8 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
-VALU_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak FP32 (vector), packed FMA
+VALU_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak FP32 (vector) = PACKED FMA (v_pk_fma_f32); a SIMD issues one wave64 vector instruction per ~4
+                                 # cycles however many waves it holds (profiles/r06_valu_probe.txt), so scalar v_fma_f32 code tops out at half of this
 # kernels that issue matrix instructions: the `flops` their wrappers report (ops._Timed) are MFMA work, `valu_flops` vector work
 MFMA_KERNELS = ("ly_gemm_kernel", "ly_conv3x3", "ly_mlp", "ly_wgrad", "ly_rf3c", "ly_rf3m", "ly_rfcbam3")
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16; fp32-grade products take 3 bf16 MFMAs (csrc/ly_tile.hpp)
@@ -407,6 +408,12 @@ def _fractions(r, dtype):
     return gbs, tfs, vtfs, mfma_peak, gbs / HBM_PEAK_GBS, tfs / mfma_peak, vtfs / VALU_F32_PEAK_TFLOPS
 
 
+def _limited_by(hbm_frac, mfma_frac, valu_frac):
+    """the unit with the largest fraction of its peak, or "latency" when none is a quarter busy (derived, not a constant)"""
+    best = max((hbm_frac, "hbm"), (mfma_frac, "mfma"), (valu_frac, "valu"))
+    return "latency" if best[0] < 0.25 else best[1]
+
+
 def roofline_of(rows, dtype, families=None):
     """`roofline` of the line, SURVEY 8(d): the DOMINANT kernel = the instrumented kernel with the most time per step (rows are sorted by it: a
     deterministic pick — the "largest kernel of the largest family" of rounds 2-4 flipped between two kernels from run to run), priced against
@@ -422,7 +429,7 @@ def roofline_of(rows, dtype, families=None):
                     peak_note="dense bf16 2500 TFLOP/s / 3: fp32-grade products = 3 bf16 MFMAs")
     else:
         roof = dict(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(hbm_frac, 4))
-    roof["limited_by"] = "latency" if max(hbm_frac, mfma_frac, valu_frac) < 0.25 else roof["bound"]
+    roof["limited_by"] = _limited_by(hbm_frac, mfma_frac, valu_frac)
     tr = committed_pmc(dom["kernel"], "pmc_traffic")
     roof["traffic"] = tr["hbm_bytes"] if tr else None
     roof["traffic_source"] = tr["source"] if tr else None
@@ -452,7 +459,7 @@ def roofline_of(rows, dtype, families=None):
                                          launches_per_step=round(big["calls_per_step"], 2), algorithmic_bytes_per_launch=round(big["bytes"]),
                                          achieved_gbs=round(g2, 1), hbm_frac=round(h2, 4), mfma_frac=round(m2, 4), valu_frac=round(vf2, 4),
                                          traffic=tr2["hbm_bytes"] if tr2 else None, traffic_source=tr2["source"] if tr2 else None,
-                                         limited_by="latency" if max(h2, m2, vf2) < 0.25 else "hbm")
+                                         limited_by=_limited_by(h2, m2, vf2))
     return roof
 
 
@@ -558,7 +565,13 @@ def run_train(args, ctx):
 
     regions = timed_repeats(ctx, step, args.steps, args.warmup, args.repeats)
     sustained = sustained_run(ctx, step, statistics.median(regions) / args.steps) if not args.no_sustained else None
-    res = dict(regions=regions, sustained=sustained, final_loss=float(state["loss"]), peak_mem_gib=round(torch.cuda.max_memory_allocated() / 2**30, 2), model=model, step=eager_step, launch=launch,
+    # The drop-in route (`python -m lead_yolo_amd.run train.py`) runs EAGER launches — one ctypes call per kernel from the
+    # reference's unchanged Python loop: the same optimisation step without the hipGraph, so that the line says what that route costs
+    # (not `value`: the contract's figure is the replayed step above).  Every rank runs it (at N > 1 the eager step exchanges gradients).
+    eager_ms = None
+    if step is not eager_step:
+        eager_ms = round(statistics.median(timed_repeats(ctx, eager_step, 5, 2, 2)) / 5 * 1e3, 4)
+    res = dict(regions=regions, eager_ms_per_step=eager_ms, sustained=sustained, final_loss=float(state["loss"]), peak_mem_gib=round(torch.cuda.max_memory_allocated() / 2**30, 2), model=model, step=eager_step, launch=launch,
                workload=f"lead-yolo-{args.scale} bs={args.batch}/gpu 3x{args.size}x{args.size} {args.dtype} full train step: uint8 batch -> "
                         "train-mode forward (batch-statistics BN), ComputeLoss, HIP backward, clip 10, SGD-nesterov 3 groups, ModelEMA update "
                         "(BASELINE.json configs[2]" + ("" if args.dtype == "bf16" else " shape in fp32") + "); random-init weights",
@@ -733,6 +746,10 @@ def main():
         if res.get("sustained"):
             out["sustained"] = dict(res["sustained"], value=round(ctx.world * args.batch / res["sustained"]["ms_per_step"] * 1e3, 2), unit="images/sec",
                                     note="the same step replayed back to back for ~3 s after the timed repeats (not `value`: the contract's K steps are)")
+        if res.get("eager_ms_per_step") is not None:
+            out["eager_ms_per_step"] = res["eager_ms_per_step"]
+            out["eager_is"] = ("the same optimisation step as eager launches (no hipGraph; fused HIP optimiser, HIP loss): median of 2 x 5 steps — what the drop-in "
+                               "route that keeps the reference's train.py unchanged pays per step in launch overhead; `value` is the replayed step")
         for k in ("final_loss", "peak_mem_gib", "rccl_ranks", "grad_buckets", "grad_bytes", "dp_overlap", "launch"):
             if k in res:
                 out[k if k != "launch" else "launch_mode"] = res[k]

@@ -57,6 +57,17 @@ __device__ __forceinline__ f32x4 ly_dact4(const f32x4 v, const f32x4 dy) {
   const long xr_begin = (long)blockIdx.x * LY_THREADS + threadIdx.x, xr_end = (total), xr_step = (long)gridDim.x * LY_THREADS
 #endif
 
+// The same split over ROWS for the kernels whose threads keep a fixed channel vector and walk rows (`groups` rows per block and trip): XCD x's
+// blocks (slot s of n) take rows lo + s * groups + j, stepping by n * groups inside [lo, hi) = the x-th eighth of the rows.
+#define LY_EW_UR 4
+#define LY_XCD_ROWS(rows_, groups_)                                                                                     \
+  const bool xw_on = gridDim.x >= 8;                                                                                      \
+  const long xw_x = blockIdx.x & 7, xw_slot = blockIdx.x >> 3, xw_n = ((long)gridDim.x + 7 - xw_x) >> 3;                  \
+  const long xw_per = ((rows_) + 7) / 8;                                                                                  \
+  const long xw_lo = xw_on ? xw_x * xw_per : 0, xw_end = xw_on ? (xw_lo + xw_per < (rows_) ? xw_lo + xw_per : (rows_)) : (rows_); \
+  const long xw_begin = xw_lo + (xw_on ? xw_slot : (long)blockIdx.x) * (groups_);                                         \
+  const long xw_step = (xw_on ? xw_n : (long)gridDim.x) * (groups_)
+
 template <typename T, int ACT>
 __global__ __launch_bounds__(LY_THREADS) void ly_bnact_bwd_reduce_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ u,
                                                                           int ldu, long rows, int C, const float* __restrict__ a,
@@ -121,25 +132,46 @@ __global__ __launch_bounds__(LY_THREADS) void ly_bnact_bwd_apply_kernel(const T*
                                                                          T* du, int lddu, const T* __restrict__ dy2, int lddy2, int csplit) {
   // 16-byte accesses in both dtypes (4 fp32 / 8 bf16 channels per thread) when C allows, else 4 channels
   // (pair form, csplit < C: channels >= csplit read their gradient from dy2, column c - csplit; csplit a multiple of the vector width)
+  // Round 6: thread = (channel vector, row lane), as in the reduce pass — the five coefficient vectors of the thread's channels are loaded ONCE,
+  // rows advance by a pointer stride, LY_EW_UR rows are in flight per trip.  (The first form walked a flat item index: a 64-bit division per
+  // item and ten coefficient loads per trip were half of the loop's instructions — ~400 issue cycles of index arithmetic per 8 elements.)
   constexpr int VW = LyT<T>::VW, NQ = VW / 4;
   using RV = typename LyT<T>::RV;
-  if ((C % VW) == 0 && (ldu % VW) == 0 && (lddy % VW) == 0 && (lddu % VW) == 0 && (lddy2 % VW) == 0 && (csplit % VW) == 0) {
-    const int ncv = C / VW;
-    const long total = rows * ncv;
-    LY_XCD_RANGE(total);
-    for (long i = xr_begin; i < xr_end; i += xr_step) {
-      const long r = i / ncv;
-      const int c = VW * (int)(i - r * ncv);
-      f32x4 uu[NQ], g[NQ];
-      ly_rv_unpack(ly_ldrv<T>(u + r * ldu + c), uu);
-      ly_rv_unpack(ly_ldrv<T>(c >= csplit ? dy2 + r * lddy2 + (c - csplit) : dy + r * lddy + c), g);
+  if ((C % VW) == 0 && (ldu % VW) == 0 && (lddy % VW) == 0 && (lddu % VW) == 0 && (lddy2 % VW) == 0 && (csplit % VW) == 0 && C / VW <= LY_THREADS) {
+    const int ncv = C / VW, groups = LY_THREADS / ncv;
+    const int cv = threadIdx.x % ncv, j0 = threadIdx.x / ncv;
+    if (j0 >= groups) return;
+    const int c = VW * cv;
+    f32x4 ca[NQ], cb[NQ], cal[NQ], cka[NQ], cla[NQ];
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const int cq = c + 4 * q;
-        const f32x4 dv = ly_dact4<ACT>(ly_ldg4(a + cq) * uu[q] + ly_ldg4(b + cq), g[q]);
-        uu[q] = ly_ldg4(alpha + cq) * dv + ly_ldg4(kappa + cq) + ly_ldg4(lambda + cq) * uu[q];
+    for (int q = 0; q < NQ; ++q) {
+      ca[q] = ly_ldg4(a + c + 4 * q); cb[q] = ly_ldg4(b + c + 4 * q);
+      cal[q] = ly_ldg4(alpha + c + 4 * q); cka[q] = ly_ldg4(kappa + c + 4 * q); cla[q] = ly_ldg4(lambda + c + 4 * q);
+    }
+    LY_XCD_ROWS(rows, groups);
+    const T* const gb = c >= csplit ? dy2 + (c - csplit) : dy + c;        // (a selected base pointer: no load under a branch)
+    const long ldg = c >= csplit ? lddy2 : lddy;
+    for (long r0 = xw_begin + j0; r0 < xw_end; r0 += LY_EW_UR * xw_step) {
+      RV qu[LY_EW_UR], qg[LY_EW_UR];
+#pragma unroll
+      for (int k = 0; k < LY_EW_UR; ++k) {
+        const long r = r0 + k * xw_step < xw_end ? r0 + k * xw_step : xw_end - 1;       // rows past the end re-read the last row (straight-line loads)
+        qu[k] = ly_ldrv<T>(u + r * ldu + c);
+        qg[k] = ly_ldrv<T>(gb + r * ldg);
       }
-      *reinterpret_cast<RV*>(du + r * lddu + c) = ly_rv_pack(uu, (RV*)nullptr);
+#pragma unroll
+      for (int k = 0; k < LY_EW_UR; ++k) {
+        f32x4 uu[NQ], g[NQ];
+        ly_rv_unpack(qu[k], uu);
+        ly_rv_unpack(qg[k], g);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const f32x4 dv = ly_dact4<ACT>(ca[q] * uu[q] + cb[q], g[q]);
+          uu[q] = cal[q] * dv + cka[q] + cla[q] * uu[q];
+        }
+        const long r = r0 + k * xw_step;
+        if (r < xw_end) *reinterpret_cast<RV*>(du + r * lddu + c) = ly_rv_pack(uu, (RV*)nullptr);
+      }
     }
     return;
   }
@@ -163,18 +195,32 @@ __global__ __launch_bounds__(LY_THREADS) void ly_bnact_fwd_kernel(const T* __res
                                                                    const float* __restrict__ b, T* __restrict__ y, int ldy) {
   constexpr int VW = LyT<T>::VW, NQ = VW / 4;
   using RV = typename LyT<T>::RV;
-  if ((C % VW) == 0 && (ldu % VW) == 0 && (ldy % VW) == 0) {
-    const int ncv = C / VW;
-    const long total = rows * ncv;
-    LY_XCD_RANGE(total);
-    for (long i = xr_begin; i < xr_end; i += xr_step) {
-      const long r = i / ncv;
-      const int c = VW * (int)(i - r * ncv);
-      f32x4 uu[NQ];
-      ly_rv_unpack(ly_ldrv<T>(u + r * ldu + c), uu);
+  if ((C % VW) == 0 && (ldu % VW) == 0 && (ldy % VW) == 0 && C / VW <= LY_THREADS) {
+    // thread = (channel vector, row lane): scale / shift of the thread's channels in registers, LY_EW_UR rows in flight (see ly_bnact_bwd_apply_kernel)
+    const int ncv = C / VW, groups = LY_THREADS / ncv;
+    const int cv = threadIdx.x % ncv, j0 = threadIdx.x / ncv;
+    if (j0 >= groups) return;
+    const int c = VW * cv;
+    f32x4 ca[NQ], cb[NQ];
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) uu[q] = ly_act4(ly_ldg4(a + c + 4 * q) * uu[q] + ly_ldg4(b + c + 4 * q), ACT);
-      *reinterpret_cast<RV*>(y + r * ldy + c) = ly_rv_pack(uu, (RV*)nullptr);
+    for (int q = 0; q < NQ; ++q) { ca[q] = ly_ldg4(a + c + 4 * q); cb[q] = ly_ldg4(b + c + 4 * q); }
+    LY_XCD_ROWS(rows, groups);
+    for (long r0 = xw_begin + j0; r0 < xw_end; r0 += LY_EW_UR * xw_step) {
+      RV qu[LY_EW_UR];
+#pragma unroll
+      for (int k = 0; k < LY_EW_UR; ++k) {
+        const long r = r0 + k * xw_step < xw_end ? r0 + k * xw_step : xw_end - 1;
+        qu[k] = ly_ldrv<T>(u + r * ldu + c);
+      }
+#pragma unroll
+      for (int k = 0; k < LY_EW_UR; ++k) {
+        f32x4 uu[NQ];
+        ly_rv_unpack(qu[k], uu);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) uu[q] = ly_act4(ca[q] * uu[q] + cb[q], ACT);
+        const long r = r0 + k * xw_step;
+        if (r < xw_end) *reinterpret_cast<RV*>(y + r * ldy + c) = ly_rv_pack(uu, (RV*)nullptr);
+      }
     }
     return;
   }
@@ -193,12 +239,25 @@ static long ly_ew_blocks(long items) {
   long b = (items + LY_THREADS * 4L - 1) / (LY_THREADS * 4L);
   return b < 1 ? 1 : b > 4096 ? 4096 : b;
 }
+// grid of the row-walking elementwise kernels (thread = channel vector x row lane, LY_EW_UR rows per trip): a whole number of trips per block
+// (at most 8 x 256 blocks resident per XCD eighth), a multiple of 8 so that every XCD range has its blocks
+static long ly_ew_row_blocks(long rows, int C, int vw) {
+  const int ncv = C / vw;
+  if (ncv <= 0 || ncv > LY_THREADS) return ly_ew_blocks(rows * (C >> 2));
+  const long groups = LY_THREADS / ncv;
+  const long trips = ((rows + 7) / 8 + groups * LY_EW_UR - 1) / (groups * LY_EW_UR);        // per XCD eighth
+  const long per = (trips + 255) / 256;                                                       // trips per block
+  const long bx = (trips + per - 1) / per;                                                    // blocks per eighth
+  return 8 * (bx < 1 ? 1 : bx);
+}
 
 extern "C" int ly_bnact_fwd(const void* u_, int ldu, long rows, int C, const float* a, const float* b, int act, void* y_, int ldy, int dtype, void* stream) {
   LY_CHECK_DTYPE(dtype, "bnact_fwd");
   LY_CHECK(u_ && a && b && y_ && rows > 0, "bnact_fwd: null pointer");
   LY_CHECK((C & 3) == 0 && C > 0 && (ldu & 3) == 0 && (ldy & 3) == 0, "bnact_fwd: C=%d / ld must be multiples of 4", C);
-  const long blocks = ly_ew_blocks(rows * (C >> 2));
+  const int vw_ = dtype == LY_BF16 ? 8 : 4;
+  const bool vec_ = (C % vw_) == 0 && (ldu % vw_) == 0 && (ldy % vw_) == 0 && C / vw_ <= LY_THREADS;
+  const long blocks = vec_ ? ly_ew_row_blocks(rows, C, vw_) : ly_ew_blocks(rows * (C >> 2));
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   LY_WITH_T(dtype, {
     const T* u = reinterpret_cast<const T*>(u_);
@@ -257,7 +316,9 @@ extern "C" int ly_bnact_bwd_reduce_pair(const void* dy1, int lddy1, const void* 
 
 static int bnact_bwd_apply_launch(const void* dy_, int lddy, const void* dy2_, int lddy2, int csplit, const void* u_, int ldu, long rows, int C, const float* a,
                                   const float* b, int act, const float* alpha, const float* kappa, const float* lambda, void* du_, int lddu, int dtype, void* stream) {
-  const long blocks = ly_ew_blocks(rows * (C >> 2));
+  const int vw_ = dtype == LY_BF16 ? 8 : 4;
+  const bool vec_ = (C % vw_) == 0 && (ldu % vw_) == 0 && (lddy % vw_) == 0 && (lddu % vw_) == 0 && (lddy2 % vw_) == 0 && (csplit % vw_) == 0 && C / vw_ <= LY_THREADS;
+  const long blocks = vec_ ? ly_ew_row_blocks(rows, C, vw_) : ly_ew_blocks(rows * (C >> 2));
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define LY_APP(A) hipLaunchKernelGGL((ly_bnact_bwd_apply_kernel<T, A>), dim3((unsigned)blocks), dim3(LY_THREADS), 0, st, dy, lddy, u, ldu, rows, C, a, b, alpha, kappa, lambda, du, lddu, dy2, lddy2, csplit)
   LY_WITH_T(dtype, {
@@ -448,8 +509,16 @@ __device__ __forceinline__ void ly_wgrad_tiled_body(const LyWgradParams& Q, cons
   constexpr int TASKS = (BN / 4 + BK / 4) * PG;         // (channel quad, pixel group) pairs per step
   constexpr int TPT = (TASKS + LY_THREADS - 1) / LY_THREADS;
   constexpr int NI = BN / 32, NJ = BK / 32;             // MFMA tiles per wave along n / k
-  constexpr int RSW = PL * 2 * P + 16;                  // bytes per LDS row: [hi P bf16 | lo P bf16 (fp32 storage only)] + pad (bank spread)
-  constexpr int BUF = (BN + BK) * RSW;
+  // LDS image of a step: [plane hi | lo][pixel group g of 8][row slot][8 px bf16 = 16 bytes].  A fragment read (ds_read_b128: lane (i, q) takes
+  // row i, pixel group 4 ks + q) walks 16 consecutive row slots per pixel group, and a commit (4 channel rows x 16 bytes per thread, threads on
+  // consecutive channel quads) must not put rows 4 cq + e of neighbouring threads 64 bytes apart — so row r sits at slot (r & 3) (NR/4 + 4) +
+  // (r >> 2): for a fixed e consecutive threads write consecutive slots, and rows 0 .. 15 of a fragment land on 16 different slots modulo 16
+  // ((r & 3) * 4 + (r >> 2): a 4 x 4 transpose).  Both conflict-free; the round-5 image ([row][P px] with 16 bytes of row padding) read with one
+  // 2-way slot per lane group and wrote 4-way: SQ_LDS_BANK_CONFLICT = 24 % of the grouped kernel's cycles (profiles/r05_train_bf16_pmc_wait.txt).
+  constexpr int NR = BN + BK;
+  constexpr int PLANE = (NR + 16) * 16;                 // bytes per pixel group
+  constexpr int BUF = PL * PG * PLANE;
+  auto rowoff = [](int r) -> int { return ((r & 3) * (NR / 4 + 4) + (r >> 2)) * 16; };
   extern __shared__ f32x4 ly_smem4[];
   char* const lds = reinterpret_cast<char*>(ly_smem4);
   constexpr bool SB = PL * P >= 128;       // 128 bf16 / 64 fp32 pixels per step: ONE LDS buffer (see the loop below)
@@ -580,9 +649,9 @@ __device__ __forceinline__ void ly_wgrad_tiled_body(const LyWgradParams& Q, cons
           }
           bf16x8 hi, lo;
           ly_split8(v, hi, lo);
-          char* d = base + (t_row[u] + e) * RSW + t_g[u] * 16;
+          char* d = base + t_g[u] * PLANE + t_row[u] * 4 + e * ((NR / 4 + 4) * 16);      // rowoff(t_row + e), t_row a multiple of 4
           *reinterpret_cast<bf16x8*>(d) = hi;
-          *reinterpret_cast<bf16x8*>(d + 2 * P) = lo;
+          *reinterpret_cast<bf16x8*>(d + PG * PLANE) = lo;
         }
       } else {
         // bf16 storage: a pure 8 x 4 transpose of 16-bit values (channel e of the 8 pixels becomes one 16-byte row piece)
@@ -602,7 +671,7 @@ __device__ __forceinline__ void ly_wgrad_tiled_body(const LyWgradParams& Q, cons
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const bf16x8 row = {q[0][e], q[1][e], q[2][e], q[3][e], q[4][e], q[5][e], q[6][e], q[7][e]};
-          *reinterpret_cast<bf16x8*>(base + (t_row[u] + e) * RSW + t_g[u] * 16) = row;
+          *reinterpret_cast<bf16x8*>(base + t_g[u] * PLANE + t_row[u] * 4 + e * ((NR / 4 + 4) * 16)) = row;      // rowoff(t_row + e), t_row a multiple of 4
         }
       }
     }
@@ -614,6 +683,7 @@ __device__ __forceinline__ void ly_wgrad_tiled_body(const LyWgradParams& Q, cons
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[i][j] = ly_zero4();
   const int wn = (wave & 1) * (BN / 2), wk = BN + (wave >> 1) * (BK / 2);
+  const int rd_a = lq * PLANE + rowoff(li) + wn * 4, rd_b = lq * PLANE + rowoff(li) + wk * 4;      // the lane's fragment addresses: everything else is an immediate
 
   // SB: ONE LDS buffer (two would leave one block per CU); the loads of the next step are in flight during the contraction, the buffer is
   prefetch(p_begin);                       // rewritten between two barriers
@@ -629,15 +699,15 @@ __device__ __forceinline__ void ly_wgrad_tiled_body(const LyWgradParams& Q, cons
       bf16x8 ah[NI], al[NI];
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
-        const char* r = base + (wn + 16 * i + li) * RSW + ks * 64 + lq * 16;
+        const char* r = base + rd_a + ks * (4 * PLANE) + i * 64;        // row wn + 16 i + li: wn and 16 i are multiples of 16 (4 slots of 16 bytes per 16 rows)
         ah[i] = *reinterpret_cast<const bf16x8*>(r);
-        al[i] = PL == 2 ? *reinterpret_cast<const bf16x8*>(r + (PL - 1) * 2 * P) : ah[i];
+        al[i] = PL == 2 ? *reinterpret_cast<const bf16x8*>(r + (PL - 1) * PG * PLANE) : ah[i];
       }
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        const char* r = base + (wk + 16 * j + li) * RSW + ks * 64 + lq * 16;
+        const char* r = base + rd_b + ks * (4 * PLANE) + j * 64;
         const bf16x8 bh = *reinterpret_cast<const bf16x8*>(r);
-        const bf16x8 bl = PL == 2 ? *reinterpret_cast<const bf16x8*>(r + (PL - 1) * 2 * P) : bh;
+        const bf16x8 bl = PL == 2 ? *reinterpret_cast<const bf16x8*>(r + (PL - 1) * PG * PLANE) : bh;
 #pragma unroll
         for (int i = 0; i < NI; ++i) acc[i][j] = ly_mfmapp<PL>(ah[i], al[i], bh, bl, acc[i][j]);
       }
@@ -830,7 +900,7 @@ static int launch_wgrad_tiled(const LyWgradParams& Q, bool rows, hipStream_t st)
   chunk_px = (chunk_px + P - 1) / P * P;
   chunks = (Q.M + chunk_px - 1) / chunk_px;
   LY_CHECK(chunks < 65536, "wgrad: too many pixel chunks");
-  const size_t lds = (LyT<T>::PL * P >= 128 ? 1 : 2) * (size_t)(BN + BK) * (LyT<T>::PL * 2 * P + 16) + 2 * BK * sizeof(float);
+  const size_t lds = (LyT<T>::PL * P >= 128 ? 1 : 2) * (size_t)LyT<T>::PL * (P / 8) * (BN + BK + 16) * 16 + 2 * BK * sizeof(float);
   const dim3 grid((unsigned)tiles, (unsigned)chunks);
   const long need = chunks * tiles * (long)(BN * BK);
   float* const slab = (chunks > 1 && Q.ws && need <= Q.ws_floats) ? Q.ws : nullptr;
@@ -914,7 +984,7 @@ static int wgrad_group_launch(const LyWgradParams* arr, int n, hipStream_t st) {
     G.cblk0[g + 1] = G.cblk0[g] + (int)(((long)G.tiles[g] * BN * BK + 63) / 64);
   }
   for (int g = n; g < LY_WGRAD_GROUP_MAX; ++g) G.cblk0[g + 1] = G.cblk0[n];
-  const size_t lds = (LyT<T>::PL * PX >= 128 ? 1 : 2) * (size_t)(BN + BK) * (LyT<T>::PL * 2 * PX + 16) + 2 * BK * sizeof(float);
+  const size_t lds = (LyT<T>::PL * PX >= 128 ? 1 : 2) * (size_t)LyT<T>::PL * (PX / 8) * (BN + BK + 16) * 16 + 2 * BK * sizeof(float);
   bool any_pro = false;
   for (int g = 0; g < n; ++g) any_pro = any_pro || arr[g].x_scale != nullptr;
   if (gslab) {

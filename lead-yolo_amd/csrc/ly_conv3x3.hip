@@ -24,18 +24,18 @@
 // T = float: 32-channel chunks (8 float4 per frame position), two operand planes; T = __bf16: 64-channel chunks (8 x 16 bytes
 // per position, the same bytes in flight per thread), one plane, two k-steps per tap.
 template <typename T, int MT, int WC>
-__global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 2 ? 3 : 2))) void ly_conv3x3_kernel(const LyConv3Params P, const int gy, const int tiles_x, const int tiles_y) {
+__global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 2 ? 3 : 2))) void ly_conv3x3_kernel(const LyConv3Params P, const int gy, const int tiles_x, const int tiles_y, const int rp, const int ps) {
   using TR = LyT<T>;
   using RV = typename TR::RV;
   constexpr int VW = TR::VW, PL = TR::PL;
   constexpr int LY_CC = 8 * VW;                 // channels per chunk
   constexpr int KS = LY_CC / 32;                // k-steps per tap and chunk
-  constexpr int LY_RSH = 2 * LY_CC + 16;        // bytes per frame position, per plane
+  constexpr int LY_RSH = ly_qrs(KS);            // bytes per frame position in a plane of the lane-group operand image (ly_tile.hpp); ps = plane stride
   extern __shared__ f32x4 ly_smem4[];
   const int TH = P.TH, TW = P.TW, FW = TW + 2;
   const int frame = (TH + 2) * FW;
   char* hs_hi = reinterpret_cast<char*>(ly_smem4);
-  char* hs_lo = hs_hi + (PL - 1) * frame * LY_RSH;
+  char* hs_lo = hs_hi + (PL - 1) * 4 * ps;
   const T* const x = reinterpret_cast<const T*>(P.x);
   T* const out = reinterpret_cast<T*>(P.out);
 
@@ -68,25 +68,28 @@ __global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(size
     const int p = 16 * (wp * NTW + n) + li;
     const int pp = p < npx ? p : 0;
     const int r = pp / TW, c = pp - r * TW;
-    hb[n] = (r * FW + c) * LY_RSH;
+    hb[n] = r * rp + c * LY_RSH;
     const bool ok = p < npx && h0 + r < P.H && w0 + c < P.W;
     orow[n] = ok ? img0 + (long)(h0 + r) * P.W + (w0 + c) : -1;
   }
 
   // ---- staging: this thread's frame items (position, 16-byte channel group) --------------------------------
   const int items = frame * 8;
-  long src[LY_C3_NV];                                       // element offset of the item's first channel of chunk 0, or -1
+  int src[LY_C3_NV];                                        // element offset of the item's first channel of chunk 0, or -1 (31 bits: checked by the launcher)
+  int dst[LY_C3_NV];                                        // byte offset of the item's position in the LDS frame (row pitch rp: see conv3_row_pitch)
 #pragma unroll
   for (int e = 0; e < LY_C3_NV; ++e) {
     const int idx = tid + e * LY_THREADS;
-    long off = -1;
+    int off = -1;
+    int dd = 0;
     if (idx < items) {
       const int pos = idx >> 3, c4 = idx & 7;
       const int fr = pos / FW, fc = pos - fr * FW;
       const int hh = h0 - 1 + fr, ww = w0 - 1 + fc;
-      if (hh >= 0 && hh < P.H && ww >= 0 && ww < P.W) off = (img0 + (long)hh * P.W + ww) * P.ldx + VW * c4;
+      dd = fr * rp + fc * LY_RSH;
+      if (hh >= 0 && hh < P.H && ww >= 0 && ww < P.W) off = (int)((img0 + (long)hh * P.W + ww) * P.ldx + VW * c4);
     }
-    src[e] = off;
+    src[e] = off; dst[e] = dd;
   }
   RV pv[LY_C3_NV];
   // a vector is loaded when its FIRST channel is inside Cin: the channels beyond Cin it may carry (Cin % VW != 0: the partial
@@ -107,7 +110,7 @@ __global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(size
       const bool ok = src[e] >= 0 && c0 + VW * c4 < P.Cin;
       RV v = pv[e];
       if (!ok) ly_zero_raw(v);
-      if (idx < items) ly_lds_put_rv(hs_hi, hs_lo, (idx >> 3) * LY_RSH, VW * c4, v);
+      if (idx < items) ly_img_put_rv(hs_hi, hs_lo, dst[e], ps, VW * c4, v);
     }
   };
 
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(size
     prefetch((more ? cc + 1 : cc) * LY_CC);
 #pragma unroll(MT * NTW <= 8 ? 1 : 9)
     for (int tap = 0; tap < 9; ++tap) {
-      const int toff = ((tap / 3) * FW + (tap % 3)) * LY_RSH;
+      const int toff = (tap / 3) * rp + (tap % 3) * LY_RSH;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         // next fragment: next k-step of this tap, else next tap of this chunk, else tap 0 of the next chunk (clamped at the very end)
@@ -162,9 +165,9 @@ __global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(size
 #pragma unroll
         for (int n = 0; n < NTW; ++n) {
           if (wp * NTW + n < ntv) {
-            const bf16x8 xh = ly_lds_frag(hs_hi, hb[n] + toff, ks, lq);
+            const bf16x8 xh = ly_img_frag(hs_hi, hb[n] + toff, ps, ks, lq);
             bf16x8 xl = xh;
-            if constexpr (PL == 2) xl = ly_lds_frag(hs_lo, hb[n] + toff, ks, lq);
+            if constexpr (PL == 2) xl = ly_img_frag(hs_lo, hb[n] + toff, ps, ks, lq);
 #pragma unroll
             for (int t = 0; t < MT; ++t) acc[t][n] = ly_mfmap<PL>(wcur[t], xh, xl, acc[t][n]);
           }
@@ -235,18 +238,18 @@ struct LyC3Ic { static constexpr int value = V; };
 // bs=16, 64 channels per block (<2,2>): 40 x 40 x 128: 25.5 -> 19.8 us, 20 x 20 x 256: 32.5 -> 22.5 us.  With every CU holding three blocks
 // (bs=64) the throughput form stays ahead (55 vs 55-69 us), hence the dispatch by grid size.
 template <typename T, int MT, int WC>
-__global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(2))) void ly_conv3x3_lat_kernel(const LyConv3Params P, const int gy, const int tiles_x, const int tiles_y) {
+__global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(2))) void ly_conv3x3_lat_kernel(const LyConv3Params P, const int gy, const int tiles_x, const int tiles_y, const int rp, const int ps) {
   using TR = LyT<T>;
   using RV = typename TR::RV;
   constexpr int VW = TR::VW, PL = TR::PL;
   constexpr int LY_CC = 8 * VW;                 // channels per chunk
   constexpr int KS = LY_CC / 32;                // k-steps per tap and chunk
-  constexpr int LY_RSH = 2 * LY_CC + 16;        // bytes per frame position, per plane
+  constexpr int LY_RSH = ly_qrs(KS);            // bytes per frame position in a plane of the lane-group operand image (ly_tile.hpp); ps = plane stride
   extern __shared__ f32x4 ly_smem4[];
   const int TH = P.TH, TW = P.TW, FW = TW + 2;
   const int frame = (TH + 2) * FW;
   char* hs_hi = reinterpret_cast<char*>(ly_smem4);
-  char* hs_lo = hs_hi + (PL - 1) * frame * LY_RSH;
+  char* hs_lo = hs_hi + (PL - 1) * 4 * ps;
   const T* const x = reinterpret_cast<const T*>(P.x);
   T* const out = reinterpret_cast<T*>(P.out);
 
@@ -278,7 +281,7 @@ __global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
     const int p = 16 * (wp * NTW + n) + li;
     const int pp = p < npx ? p : 0;
     const int r = pp / TW, c = pp - r * TW;
-    hb[n] = (r * FW + c) * LY_RSH;
+    hb[n] = r * rp + c * LY_RSH;
   }
   // output row of the lane's pixel in tile n, or -1 (LAT: recomputed in the epilogue — eight 64-bit values held through the loop cost 16 registers)
   auto out_row = [&](int n) -> long {
@@ -291,18 +294,21 @@ __global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
 
   // ---- staging: this thread's frame items (position, 16-byte channel group) --------------------------------
   const int items = frame * 8;
-  long src[LY_C3_NV];                                       // element offset of the item's first channel of chunk 0, or -1
+  int src[LY_C3_NV];                                        // element offset of the item's first channel of chunk 0, or -1 (31 bits: checked by the launcher)
+  int dst[LY_C3_NV];                                        // byte offset of the item's position in the LDS frame (row pitch rp: see conv3_row_pitch)
 #pragma unroll
   for (int e = 0; e < LY_C3_NV; ++e) {
     const int idx = tid + e * LY_THREADS;
-    long off = -1;
+    int off = -1;
+    int dd = 0;
     if (idx < items) {
       const int pos = idx >> 3, c4 = idx & 7;
       const int fr = pos / FW, fc = pos - fr * FW;
       const int hh = h0 - 1 + fr, ww = w0 - 1 + fc;
-      if (hh >= 0 && hh < P.H && ww >= 0 && ww < P.W) off = (img0 + (long)hh * P.W + ww) * P.ldx + VW * c4;
+      dd = fr * rp + fc * LY_RSH;
+      if (hh >= 0 && hh < P.H && ww >= 0 && ww < P.W) off = (int)((img0 + (long)hh * P.W + ww) * P.ldx + VW * c4);
     }
-    src[e] = off;
+    src[e] = off; dst[e] = dd;
   }
   RV pv[LY_C3_NV];
   // a vector is loaded when its FIRST channel is inside Cin: the channels beyond Cin it may carry (Cin % VW != 0: the partial
@@ -323,7 +329,7 @@ __global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
       const bool ok = src[e] >= 0 && c0 + VW * c4 < P.Cin;
       RV v = pv[e];
       if (!ok) ly_zero_raw(v);
-      if (idx < items) ly_lds_put_rv(hs_hi, hs_lo, (idx >> 3) * LY_RSH, VW * c4, v);
+      if (idx < items) ly_img_put_rv(hs_hi, hs_lo, dst[e], ps, VW * c4, v);
     }
   };
 
@@ -387,7 +393,7 @@ __global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
       {
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-          int toff = ((tap / 3) * FW + (tap % 3)) * LY_RSH;
+          int toff = (tap / 3) * rp + (tap % 3) * LY_RSH;
           asm volatile("" : "+s"(toff));                   // opaque per chunk: the 9 x NC fragment addresses are not hoisted out of the chunk loop (72 registers)
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks) {
@@ -399,7 +405,7 @@ __global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
 #pragma unroll
             for (int n = 0; n < NC; ++n) {
               {
-                const bf16x8 xh = ly_lds_frag(hs_hi, hb[n] + toff, ks, lq);
+                const bf16x8 xh = ly_img_frag(hs_hi, hb[n] + toff, ps, ks, lq);
 #pragma unroll
                 for (int t = 0; t < MT; ++t) acc[t][n] = ly_mfmap<PL>(wq[j % PD][t], xh, xh, acc[t][n]);
               }
@@ -473,6 +479,32 @@ __global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
   }
 }
 
+// Row pitch (bytes) of the LDS frame.  A B-operand read is one ds_read_b128 per lane (lane-group operand image, ly_tile.hpp), served in groups
+// of 16 lanes that hold the 16 pixels of an MFMA tile: conflict-free iff the 16 pixel addresses cover 16 different 16-byte slots of the
+// 256-byte bank row.
+// Pixels of one frame row do (consecutive positions are an odd number of slots apart), but the patches the host picks are 8 or 4
+// pixels wide (pick_conv_tile: 16 x 8 at 80 x 80, 10 x 8 at 40 x 40, 20 x 4 at 20 x 20), so a tile spans 2 or 4 frame rows, and with the
+// dense pitch (TW + 2) * RSH two of them meet on the same slots.
+// The pitch is padded (at most 240 bytes per frame row) to the first value for which every tile of the patch reads conflict-free.
+static int conv3_row_pitch(int TH, int TW, int rsh) {
+  const int FW = TW + 2, npx = TH * TW;
+  int best = FW * rsh, best_w = 1 << 30;
+  for (int rp = FW * rsh; rp < FW * rsh + 256; rp += 16) {
+    int worst = 0;
+    for (int n = 0; 16 * n < npx; ++n) {
+      int cnt[16] = {0};
+      for (int li = 0; li < 16; ++li) {
+        const int p = 16 * n + li, pp = p < npx ? p : 0;
+        const int c = ++cnt[(((pp / TW) * rp + (pp % TW) * rsh) >> 4) & 15];
+        if (p < npx && c > worst) worst = c;
+      }
+    }
+    if (worst < best_w) { best_w = worst; best = rp; }
+    if (worst <= 1) break;
+  }
+  return best;
+}
+
 template <typename T, int MT, int WC, bool LAT = false>
 static int launch_conv3(const LyConv3Params& P, hipStream_t st) {
   const int tiles_x = (P.W + P.TW - 1) / P.TW, tiles_y = (P.H + P.TH - 1) / P.TH;
@@ -480,8 +512,10 @@ static int launch_conv3(const LyConv3Params& P, hipStream_t st) {
   const long n_img = P.M / ((long)P.H * P.W);
   long nb = n_img * tiles_x * tiles_y * gy;
   LY_CHECK(nb < (1L << 31), "conv3x3: grid too large");
-  size_t lds = LyT<T>::PL * (size_t)(P.TH + 2) * (P.TW + 2) * (2 * 8 * LyT<T>::VW + 16);
-  void (*k)(const LyConv3Params, const int, const int, const int) = ly_conv3x3_kernel<T, MT, WC>;
+  const int rp = conv3_row_pitch(P.TH, P.TW, ly_qrs(8 * LyT<T>::VW / 32));
+  const int ps = ly_qps((P.TH + 2) * rp);
+  size_t lds = LyT<T>::PL * (size_t)4 * ps;
+  void (*k)(const LyConv3Params, const int, const int, const int, const int, const int) = ly_conv3x3_kernel<T, MT, WC>;
   if constexpr (LAT) k = ly_conv3x3_lat_kernel<T, MT, WC>;
   static bool configured = false;
   if (!configured) {
@@ -489,7 +523,7 @@ static int launch_conv3(const LyConv3Params& P, hipStream_t st) {
     LY_CHECK(e == hipSuccess, "hipFuncSetAttribute: %s", hipGetErrorString(e));
     configured = true;
   }
-  hipLaunchKernelGGL(k, dim3((unsigned)nb), dim3(LY_THREADS), lds, st, P, gy, tiles_x, tiles_y);
+  hipLaunchKernelGGL(k, dim3((unsigned)nb), dim3(LY_THREADS), lds, st, P, gy, tiles_x, tiles_y, rp, ps);
   LY_LAUNCH_CHECK();
   return 0;
 }
@@ -526,6 +560,7 @@ extern "C" int ly_conv3x3_fwd(const LyConv3Params* p, void* stream) {
   LY_CHECK(P.M % ((long)P.H * P.W) == 0, "conv3x3: M is not a whole number of images");
   LY_CHECK(P.TH >= 1 && P.TW >= 1 && P.TH * P.TW <= 16 * LY_C3_NT, "conv3x3: patch %dx%d exceeds %d pixels", P.TH, P.TW, 16 * LY_C3_NT);
   LY_CHECK((P.TH + 2) * (P.TW + 2) * 8 <= LY_C3_NV * LY_THREADS, "conv3x3: frame of patch %dx%d exceeds the staging capacity", P.TH, P.TW);
+  LY_CHECK(P.M * (long)P.ldx < (1L << 31), "conv3x3: input exceeds the 31-bit offsets of the staging plan");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   return P.dtype == LY_BF16 ? conv3_dispatch<__bf16>(P, st) : conv3_dispatch<float>(P, st);
 }

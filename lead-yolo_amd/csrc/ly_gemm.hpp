@@ -59,15 +59,15 @@ __device__ __forceinline__ void ly_gemm_body2(const LyGemmParams& P, const int g
   constexpr int LY_BK = 16 * VW;
   constexpr int WP = 4 / WC;
   constexpr int BP = 16 * NT * WP;
-  constexpr int LY_RSX = 2 * LY_BK + 16;                  // bytes per LDS row, per plane (RSX/8 = 2 mod 32 x odd: conflict-free b64 fragment reads)
+  constexpr int LY_RSQ = ly_qrs(LY_BK / 32), LY_PS = ly_qps(BP * LY_RSQ);      // lane-group operand image (ly_tile.hpp): 4 planes of BP rows
   constexpr int KQ = 16;                                  // vector columns per chunk
   constexpr int RSTEP = LY_THREADS / KQ;
   constexpr int SPC = LY_BK / 32;                         // k-steps per chunk: 2 (fp32) / 4 (bf16)
   constexpr int NV = BP * KQ / LY_THREADS;
-  constexpr int PLANE = BP * LY_RSX;
+  constexpr int PLANE = 4 * LY_PS;
   static_assert(NV >= 1 && BP * KQ % LY_THREADS == 0, "tile must divide evenly over the block");
   extern __shared__ f32x4 ly_smem4[];
-  char* xs = reinterpret_cast<char*>(ly_smem4);           // [buf][plane][BP][RSX]
+  char* xs = reinterpret_cast<char*>(ly_smem4);           // [buf][hi | lo][lane group][BP][RSQ]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lq = lane >> 4;
@@ -227,7 +227,7 @@ __device__ __forceinline__ void ly_gemm_body2(const LyGemmParams& P, const int g
         }
     }
 #pragma unroll
-    for (int e = 0; e < NV; ++e) ly_lds_put_rv(hi, lo, (prow + RSTEP * e) * LY_RSX, VW * k4, v[e]);
+    for (int e = 0; e < NV; ++e) ly_img_put_rv(hi, lo, (prow + RSTEP * e) * LY_RSQ, LY_PS, VW * k4, v[e]);
   };
 
   f32x4 acc[MT][NT];
@@ -339,9 +339,9 @@ __device__ __forceinline__ void ly_gemm_body2(const LyGemmParams& P, const int g
       bf16x8 xh[NT], xl[NT];
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
-        const int rb = (pixgrp + 16 * n + li) * LY_RSX;
-        xh[n] = ly_lds_frag(hi, rb, st, lq);
-        if constexpr (PL == 2) xl[n] = ly_lds_frag(lo, rb, st, lq);
+        const int rb = (pixgrp + 16 * n + li) * LY_RSQ;
+        xh[n] = ly_img_frag(hi, rb, LY_PS, st, lq);
+        if constexpr (PL == 2) xl[n] = ly_img_frag(lo, rb, LY_PS, st, lq);
         else xl[n] = xh[n];
       }
 #pragma unroll
@@ -470,7 +470,7 @@ static int launch_gemm_d2(const LyGemmParams& P, hipStream_t st) {
   constexpr int BP = 16 * NT * (4 / WC);
   constexpr int BN = 16 * MT * WC;
   constexpr int BK = 16 * LyT<TI>::VW;
-  constexpr size_t lds = 2 * LyT<TI>::PL * (size_t)BP * (2 * BK + 16);
+  constexpr size_t lds = 2 * LyT<TI>::PL * (size_t)4 * ly_qps(BP * ly_qrs(BK / 32));
   long gx = (P.M + BP - 1) / BP;
   int gy = (P.N + BN - 1) / BN;
   LY_CHECK(gx < (1L << 30), "gemm: too many pixel tiles");

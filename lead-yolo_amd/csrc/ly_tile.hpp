@@ -189,6 +189,60 @@ __device__ __forceinline__ bf16x8 ly_lds_frag(const char* plane, int row_byte, i
   return ly_cat8(a, b);
 }
 
+// -------------------------------------------------------------------------------------------------
+// Lane-group LDS operand image (round 6).  The image above keeps the lane's two 4-channel groups of a k-step 32 bytes apart in ONE row, meant to
+// be read as two ds_read_b64 (64 banks, conflict-free with RS/16 odd).  hipcc's load/store optimiser fuses such pairs — and the reads of
+// neighbouring k-steps and pixel tiles — into ds_read2_b64, which the LDS serves in 16-lane groups over 32 banks at HALF the rate (MI355X
+// guide, LDS table: 8 cycles per 16 bytes against 4 for one ds_read_b128), and for which RS/8 even is a 2-way conflict on every access: 16
+// LDS cycles per fragment where 4 were designed (SQ_LDS_BANK_CONFLICT = 25 % of ly_conv3x3's cycles, 2x SQ_ACTIVE_INST_LDS in the 1x1 GEMM:
+// profiles/r05_train_bf16_pmc_wait.txt — every ds_read of those kernels was a ds_read2_b64).  Two ds_read_b64 kept apart by construction
+// (planes of 16 channels, > 2040 bytes between any two reads of a lane) were measured as well: conflicts gone, GEMM -2 %, but two reads and
+// two addresses per fragment pushed ly_conv3x3 at three waves per SIMD into spilling (0.46 -> 0.58 ms per step).
+// Here the lane's 8 k-values of a k-step are 16 CONTIGUOUS bytes and each lane group q = lane >> 4 has a plane of its own:
+//      byte offset of channel c of row r = ((c & 15) >> 2) * ps + r * rsq + 16 * (c >> 5) + 8 * ((c >> 4) & 1) + 2 * (c & 3)
+//   * a fragment (k-step s) is ONE ds_read_b128 at q * ps + r * rsq + 16 s: nothing to fuse, one address, 4 LDS cycles;
+//   * rsq = 16 x odd and ps = 0 (mod 256): a ds_read_b128 is served in four groups of 16 lanes, each holding all 16 rows l & 15 of the fragment
+//     (8 from lane group 2g, 8 from 2g + 1) — 16 consecutive rows x an odd number of 16-byte slots = the 16 slots of the 256-byte bank row once;
+//   * staging writes: 4 channels = 8 bytes; an 8-channel vector (c % 8 == 0) is two 8-byte pieces in planes q and q + 1 (ds_write_b64; the
+//     two planes a 16-lane store group touches alias in the banks: 2-way, on a path that runs once per tile, not once per MFMA).
+// The lane's k-set is unchanged (k = 32s + 16(j>>2) + 4q + (j&3)): weights, accumulator chaining and every other operand order stay as they are.
+// -------------------------------------------------------------------------------------------------
+__host__ __device__ constexpr int ly_qrs(int ks) { return 16 * ((ks & 1) ? ks + 2 : ks + 1); }     // bytes per row of a plane holding ks k-steps
+__host__ __device__ constexpr int ly_qps(int bytes) { return (bytes + 255) / 256 * 256; }           // plane stride for a plane of `bytes`
+__device__ __forceinline__ int ly_img_off(const int row_byte, const int ps, const int c) {
+  return ((c & 15) >> 2) * ps + row_byte + 16 * (c >> 5) + 8 * ((c >> 4) & 1) + 2 * (c & 3);
+}
+// B-operand fragment of k-step s for the row at row_byte = r * rsq
+__device__ __forceinline__ bf16x8 ly_img_frag(const char* img, const int row_byte, const int ps, const int s, const int lq) {
+  return *reinterpret_cast<const bf16x8*>(img + lq * ps + row_byte + 16 * s);
+}
+// 4 consecutive channels (c % 4 == 0) as 8 bytes of bf16
+__device__ __forceinline__ void ly_img_put4b(char* img, const int row_byte, const int ps, const int c, const ly_u32x2 v) {
+  *reinterpret_cast<ly_u32x2*>(img + ly_img_off(row_byte, ps, c)) = v;
+}
+// 16-byte vector of VW consecutive elements starting at channel c (c % VW == 0) into the image: bf16 storage one image, fp32 split in two
+__device__ __forceinline__ void ly_img_put_rv(char* hi_img, char*, const int row_byte, const int ps, const int c, const ly_u32x4 v) {
+  const int o = ly_img_off(row_byte, ps, c);
+  *reinterpret_cast<ly_u32x2*>(hi_img + o) = (ly_u32x2){v[0], v[1]};
+  *reinterpret_cast<ly_u32x2*>(hi_img + o + ps) = (ly_u32x2){v[2], v[3]};            // channels c + 4 .. c + 7: the next lane group's plane, same place
+}
+__device__ __forceinline__ void ly_img_put_rv(char* hi_img, char* lo_img, const int row_byte, const int ps, const int c, const f32x4 v) {
+  bf16x4 h, l;
+  ly_split4(v, h, l);
+  const int o = ly_img_off(row_byte, ps, c);
+  *reinterpret_cast<bf16x4*>(hi_img + o) = h;
+  *reinterpret_cast<bf16x4*>(lo_img + o) = l;
+}
+__device__ __forceinline__ void ly_img_put_rv(char* hi_img, char* lo_img, const int row_byte, const int ps, const int c, const unsigned v) {
+  ly_img_put_rv(hi_img, lo_img, row_byte, ps, c, ly_u8x4_f32(v));
+}
+__device__ __forceinline__ void ly_img_put_rv(char* hi_img, char* lo_img, const int row_byte, const int ps, const int c, const ly_u32x2 v) {      // bf16 image
+  ly_img_put_rv(hi_img, lo_img, row_byte, ps, c, ly_cvt4(__builtin_bit_cast(bf16x4, v)));
+}
+__device__ __forceinline__ void ly_img_put_rv(char* hi_img, char* lo_img, const int row_byte, const int ps, const int c, const ly_h4raw v) {      // fp16 image
+  ly_img_put_rv(hi_img, lo_img, row_byte, ps, c, __builtin_convertvector(__builtin_bit_cast(ly_f16x4, v.r), f32x4));
+}
+
 struct LyWFrag {
   bf16x8 hi, lo;
 };

@@ -767,6 +767,16 @@ class CoordAtt(nn.Module):
         self.mip, self.c = mip, inp
         self._prep = _Prepared()
         self._prep_bn = _Prepared()
+        self.trainable_on_hip = mip in (8, 16) and inp <= 512      # widths ly_coordatt_mlp_bwd is instantiated for (grad.coordatt_train)
+
+    def train(self, mode=True):
+        """Eval runs at any width.  Training is built for mip = max(8, c // 32) in (8, 16) and c <= 512 (every CoordAtt of lead-yolo-n / s / l);
+        a custom width (c_ = 384 -> mip 12, c_ = 640 -> mip 20) is refused HERE — when the model is put into training mode with parameters that
+        ask for gradients — not in the middle of the first training forward."""
+        if mode and not self.trainable_on_hip and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError(f"CoordAtt(c={self.c}, mip={self.mip}): the HIP training path is built for mip in (8, 16) and c <= 512; this width "
+                                      "runs in eval mode only (freeze the module's parameters or pick a width with c // 32 in {<= 8, 16})")
+        return super().train(mode)
 
     def _weights(self):
         key = pack.versions(self.conv1.weight, self.conv1.bias, self.conv_h.weight, self.conv_h.bias, self.conv_w.weight, self.conv_w.bias)

@@ -667,19 +667,14 @@ def mlpblock_bwd_ok(x, c):
 
 
 MLP_BWD_FUSED = True       # tools / tests: False keeps the unfused backward (eleven launches over 2C-wide tensors)
-_MLPB_SLAB = {}
 
 
 def _mlpblock_bwd_slab(c, device):
-    """per-(device, C) slab the fused backward's blocks park their weight-gradient tiles in; allocated once (a captured hipGraph keeps its
-    address; written and read back inside one launch pair, stream-ordered)"""
-    key = (device, c)
-    t = _MLPB_SLAB.get(key)
-    if t is None:
-        if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("mlpblock_bwd: first use inside a hipGraph capture; run one eager step first")
-        t = _MLPB_SLAB[key] = torch.empty(int(capi.lib().ly_mlpblock_bwd_slab_floats(c)), dtype=torch.float32, device=device)
-    return t
+    """the slab the fused backward's blocks park their weight-gradient tiles in: written by the pass and read back by its fold launch.  Taken
+    from the caching allocator PER CALL (round 6; it was one persistent buffer per (device, C) shared by every MLPBlock of that width, safe
+    only while all of them ran on one stream in order — ADVICE r5): the allocator orders reuse by stream, and inside a hipGraph capture the
+    block comes from the graph's private pool, whose address the replay keeps."""
+    return torch.empty(int(capi.lib().ly_mlpblock_bwd_slab_floats(c)), dtype=torch.float32, device=device)
 
 
 def mlpblock_bwd(x, dy, n, h, w, c, wp, w1, w2t, w1t, a, b, *, stats=None, g=None, alpha=None, kappa=None, lam=None, dw1=None, dw2=None):
@@ -897,7 +892,9 @@ def grad_done(p):
     deferral queue (_WgradQueue) is announced when its group has been launched instead; the listeners are told now that it comes later."""
     if GRAD_LISTENERS and _WgradQueue.items and SINK is not None:
         t = SINK.targets.get(id(p))
-        if t is not None and any(q["dw"].data_ptr() == t.data_ptr() for q in _WgradQueue.items):
+        # a waiting problem covers the address RANGE [dw, dw + N * lddw): the stacked cv1 / cv2 problem of a ConvBnActPair (N = 2 c_) also writes
+        # its partner's storage, which starts 4 * numel bytes behind dw — a pointer-equality match announced that partner early (ADVICE r5)
+        if t is not None and any(lo <= t.data_ptr() < hi for lo, hi in map(_wgrad_span, _WgradQueue.items)):
             if all(prm is not p for prm, _ in _WgradQueue.notify):
                 _WgradQueue.notify.append((p, t.data_ptr()))
                 for fn in GRAD_DEFER_LISTENERS:
@@ -1116,11 +1113,25 @@ def _wgrad_deferrable(q):
             and q["Cin"] > 64 and q["M"] * q["N"] * q["Cin"] <= WGRAD_DEFER_MAX_MACS and q.get("dw_off", 0) == 0 and SINK.is_target(q["dw"]) and _graph_task() >= 0)
 
 
+def _wgrad_span(q):
+    """byte range of the gradient storage a queued problem adds into"""
+    lo = q["dw"].data_ptr() + 4 * q.get("dw_off", 0)
+    return lo, lo + 4 * q["N"] * q["lddw"]
+
+
 def _wgrad_enqueue(q):
+    """A queued problem keeps REFERENCES to du / x / x_scale / x_shift and reads them when its group launches (after up to three more problems
+    have collected, or when the backward pass ends): the caller must not write those tensors in place after ops.wgrad returns.  Their torch
+    version counters are recorded here and checked at the launch; two problems adding into overlapping gradient storage never wait together
+    (the group flushes them through one fold: the second would be lost / the order undefined)."""
     task = _graph_task()
     if _WgradQueue.task != task:
         _WgradQueue.items, _WgradQueue.notify, _WgradQueue.task = [], [], task    # (leftovers of a backward pass that raised are dropped with it)
         torch.autograd.Variable._execution_engine.queue_callback(wgrad_flush)
+    lo, hi = _wgrad_span(q)
+    if any(l2 < hi and lo < h2 for l2, h2 in map(_wgrad_span, _WgradQueue.items)):
+        wgrad_flush(final=False)               # shared weights: the earlier problem leaves before this one is queued
+    q["_versions"] = tuple(t._version for t in (q["du"], q["x"], q.get("x_scale"), q.get("x_shift")) if t is not None)
     _WgradQueue.items.append(q)
     # under a gradient listener (ddp.GradReducer) a waiting gradient holds back its whole bucket's exchange: leave in pairs there
     # (tools/dp_overlap_probe.py: with fours a 1.3 MB bucket was released at 77 % of the backward instead of 33 %)
@@ -1133,14 +1144,20 @@ def wgrad_flush(final=True):
     items, _WgradQueue.items = _WgradQueue.items, []
     if final:
         _WgradQueue.task = -1
+    for q in items:
+        now = tuple(t._version for t in (q["du"], q["x"], q.get("x_scale"), q.get("x_shift")) if t is not None)
+        if now != q.pop("_versions", now):
+            raise RuntimeError("ops.wgrad: an operand of a deferred weight gradient was written in place before its launch (du / x / x_scale / "
+                               "x_shift must stay untouched until the group leaves: see _wgrad_enqueue)")
     if len(items) == 1:
         wgrad(_now=True, **items[0])
     elif items:
         wgrad_group(items, _now=True)
     if _WgradQueue.notify:
-        waiting = {q["dw"].data_ptr() for q in _WgradQueue.items}
-        ready = [prm for prm, ptr in _WgradQueue.notify if ptr not in waiting]
-        _WgradQueue.notify = [(prm, ptr) for prm, ptr in _WgradQueue.notify if ptr in waiting]
+        spans = [_wgrad_span(q) for q in _WgradQueue.items]
+        waits = lambda ptr: any(lo <= ptr < hi for lo, hi in spans)
+        ready = [prm for prm, ptr in _WgradQueue.notify if not waits(ptr)]
+        _WgradQueue.notify = [(prm, ptr) for prm, ptr in _WgradQueue.notify if waits(ptr)]
         for prm in ready:
             for fn in GRAD_LISTENERS:
                 fn(prm)

@@ -3,6 +3,8 @@ dataset LEAD-YOLO.yaml's nc = 1 recipe trains on, data/SSDD.yaml), letterboxed t
 side to the target, pad with 114; utils/augmentations.py `letterbox`) with their labels mapped into the letterboxed frame.  Data only:
 the images are single-channel SAR chips stored as (JPEG-noisy) RGB triples; their luma plane is kept, ONE uint8 plane each, and the tests
 feed it to all three input channels.
+tests/golden/ssdd_train48.npz (round 6): 48 images of the TRAIN split (data/SSDD/images/train), same format — what the accuracy test trains
+on, so that the 16 test-split images it scores are held out (data/SSDD.yaml: train and test are disjoint image sets).
     python oracle/gen_ssdd_fixture.py          (build container: /root/reference present)"""
 import glob
 import os
@@ -17,8 +19,13 @@ S, N = 320, 16
 
 
 def main():
-    files = sorted(glob.glob(os.path.join(REF, "images", "test", "*.jpg")))[:N]
-    assert len(files) == N, "SSDD test images not found (this script runs in the build container only)"
+    one("test", 16, "ssdd16.npz")
+    one("train", 48, "ssdd_train48.npz")
+
+
+def one(split, N, name):
+    files = sorted(glob.glob(os.path.join(REF, "images", split, "*.jpg")))[:N]
+    assert len(files) == N, f"SSDD {split} images not found (this script runs in the build container only)"
     imgs = np.full((N, S, S), 114, dtype=np.uint8)
     targets, names = [], []
     for i, f in enumerate(files):
@@ -29,7 +36,7 @@ def main():
         g = np.asarray(im.convert("L").resize((nw, nh), Image.BILINEAR))
         top, left = (S - nh) // 2, (S - nw) // 2
         imgs[i, top:top + nh, left:left + nw] = g
-        lab = os.path.join(REF, "labels", "test", os.path.basename(f)[:-4] + ".txt")
+        lab = os.path.join(REF, "labels", split, os.path.basename(f)[:-4] + ".txt")
         if os.path.exists(lab):
             for line in open(lab):
                 p = line.split()
@@ -38,7 +45,7 @@ def main():
                     targets.append([i, c, (x * nw + left) / S, (y * nh + top) / S, bw * nw / S, bh * nh / S])
         names.append(os.path.basename(f))
     targets = np.asarray(targets, dtype=np.float32).reshape(-1, 6)
-    out = os.path.join(ROOT, "tests", "golden", "ssdd16.npz")
+    out = os.path.join(ROOT, "tests", "golden", name)
     np.savez_compressed(out, imgs=imgs, targets=targets, names=np.asarray(names))
     print(f"{out}: {os.path.getsize(out) / 1024:.0f} KiB, {len(targets)} boxes in {N} images")
 

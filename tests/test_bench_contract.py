@@ -32,7 +32,9 @@ def test_single_gpu_line():
     r = d["roofline"]
     # HBM is the roof of every bf16-storage kernel — the line's fraction IS the HBM fraction, the other units are side fields
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["frac"] == r["hbm_frac"]
-    assert r["limited_by"] in ("hbm", "latency") and (r["limited_by"] == "latency") == (max(r["hbm_frac"], r["mfma_frac"], r["valu_frac"]) < 0.25)
+    fr = dict(hbm=r["hbm_frac"], mfma=r["mfma_frac"], valu=r["valu_frac"])
+    assert r["limited_by"] in ("hbm", "mfma", "valu", "latency") and (r["limited_by"] == "latency") == (max(fr.values()) < 0.25)
+    assert r["limited_by"] == "latency" or fr[r["limited_by"]] == max(fr.values())
     assert 0 < r["frac"] < 1 and abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-3
     # the fractions follow from the line's own inputs: algorithmic work of one launch / its mean duration / the unit's peak
     sec = r["ms_per_launch"] * 1e-3

@@ -121,43 +121,75 @@ def _stats_of(boxes_per_image, tg, size):
     return out
 
 
+TRAIN_FIX = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ssdd_train48.npz")
+
+
+def _train_batches():
+    """the 48 TRAIN-split images (tests/golden/ssdd_train48.npz, oracle/gen_ssdd_fixture.py) as three batches of 16 with batch-local image indices"""
+    d = np.load(TRAIN_FIX)
+    g = torch.from_numpy(d["imgs"]).unsqueeze(1).expand(-1, 3, -1, -1).contiguous()
+    tg = torch.from_numpy(d["targets"])
+    out = []
+    for b in range(3):
+        rows = tg[(tg[:, 0] >= 16 * b) & (tg[:, 0] < 16 * b + 16)].clone()
+        rows[:, 0] -= 16 * b
+        out.append((g[16 * b:16 * b + 16].contiguous(), rows))
+    return out
+
+
+def test_train_and_test_fixtures_are_disjoint_splits():
+    a, b = np.load(TRAIN_FIX), np.load(FIX)
+    assert a["imgs"].shape == (48, 320, 320) and not (set(a["names"].tolist()) & set(b["names"].tolist()))
+
+
 @pytest.mark.gpu
-def test_ssdd_short_training_then_map_hip_vs_oracle():
-    """VERDICT r3 missing 4 — accuracy evidence at the metric level on the dataset the recipe trains on (data/SSDD.yaml, val.py:183-188):
-    lead-yolo-n is trained for STEPS optimisation steps of the HIP training step (train.py:295-341: uint8 batch, ComputeLoss, clip, SGD-nesterov
-    with the reference's warm-up, EMA) on the 16 letterboxed SSDD images, then mAP@0.5 / mAP@0.5:0.95 of the TRAINED weights on those images
-    is computed twice — HIP eval forward + device NMS, and fp32 CPU oracle forward + oracle NMS — with the reference's metric code
-    (oracle/metrics.py, pinned by tests/golden/metrics_cases.npz).  The two pipelines must agree to 0.02 mAP, the loss must have fallen, and
-    the detector must have learnt the ships it was shown (mAP@0.5 well above the ~0 of the initial weights)."""
+def test_ssdd_short_training_then_heldout_map_hip_vs_oracle():
+    """Accuracy evidence at the metric level on the dataset the recipe trains on (data/SSDD.yaml: 928 train / 232 test images, val.py:183-188),
+    HELD OUT: lead-yolo-n is trained for STEPS optimisation steps of the HIP training step (train.py:295-341: uint8 batch, ComputeLoss, clip,
+    SGD-nesterov with the reference's warm-up, EMA) on 48 letterboxed images of the TRAIN split, then mAP@0.5 / mAP@0.5:0.95 of the trained
+    EMA weights is computed on the 16 images of the TEST split (none of them seen in training) twice — HIP eval forward + device NMS, and
+    fp32 CPU oracle forward + oracle NMS — with the reference's metric code (oracle/metrics.py, pinned by tests/golden/metrics_cases.npz).
+    The two pipelines must agree to 0.02 mAP, the loss must have fallen, and the detector must find ships it has never seen (held-out
+    mAP@0.5 far above the ~0 of the initial weights; the figure on its own training images is printed beside it)."""
     import lead_yolo_amd as L
     from lead_yolo_amd import train as T
-    imgs, tg = _batch()
+    imgs, tg = _batch()                                                      # the held-out test images
+    batches = [(x.to(_dev()), t.to(_dev())) for x, t in _train_batches()]
     torch.manual_seed(0)
     cfg = _cfg("n")
     m = L.Model(cfg).to(_dev()).train()                                     # the model's own initialisation (models/yolo.py:213-233)
     loss_fn = L.ComputeLoss(m)
     opt = T.smart_optimizer(m, "SGD", 0.01, 0.937, 5e-4)
     ema = T.ModelEMA(m)
-    xb, tb = imgs.to(_dev()), tg.to(_dev())
     losses = []
     for it in range(STEPS):
         lr = 0.01 * min(1.0, (it + 1) / 30)                                   # linear warm-up of train.py:300-307, then the base rate
         for gi, g in enumerate(opt.param_groups):
             g["lr"] = max(0.1 - 0.09 * it / 30, lr) if gi == 0 else lr        # the bias group (first, utils/torch_utils.py:337) warms DOWN from 0.1
+        xb, tb = batches[it % 3]
         loss, _ = T.train_step(m, loss_fn, opt, xb, tb, ema=ema)
         losses.append(float(loss))
     assert np.isfinite(losses).all() and np.mean(losses[-10:]) < 0.6 * np.mean(losses[:10]), (losses[:3], losses[-3:])
     me = ema.ema.eval()
-    x = imgs.float() / 255
     sd = {k: v.detach().float().cpu() for k, v in me.state_dict().items()}
-    with torch.no_grad():
-        z, _ = me(x.to(_dev()))
-        zo, _ = OF.model_forward(copy.deepcopy(sd), cfg, x, m.stride.cpu(), training=False)
-    got = [b.cpu().numpy() for b in L.non_max_suppression(z, 0.001, 0.6)]      # val.py:230-234 settings
-    want, _ = ONMS.non_max_suppression(zo.numpy(), 0.001, 0.6)
-    rg = OMET.mean_results(_stats_of(got, tg, 320))
-    rw = OMET.mean_results(_stats_of(want, tg, 320))
-    print(f"SSDD-16 after {STEPS} steps: loss {np.mean(losses[:10]):.3f} -> {np.mean(losses[-10:]):.3f}; (P, R, mAP50, mAP) HIP {rg} oracle {rw}")
+
+    def score(images, targets, oracle):
+        x = images.float() / 255
+        with torch.no_grad():
+            if oracle:
+                zo, _ = OF.model_forward(copy.deepcopy(sd), cfg, x, m.stride.cpu(), training=False)
+                boxes, _ = ONMS.non_max_suppression(zo.numpy(), 0.001, 0.6)
+            else:
+                z, _ = me(x.to(_dev()))
+                boxes = [b.cpu().numpy() for b in L.non_max_suppression(z, 0.001, 0.6)]      # val.py:230-234 settings
+        return OMET.mean_results(_stats_of(boxes, targets, 320))
+
+    rg, rw = score(imgs, tg, False), score(imgs, tg, True)
+    seen = score(*_train_batches()[0], False)
+    print(f"SSDD after {STEPS} steps on 48 train images: loss {np.mean(losses[:10]):.3f} -> {np.mean(losses[-10:]):.3f}; held-out (P, R, mAP50, mAP) "
+          f"HIP {rg} oracle {rw}; on 16 of its training images HIP {seen}")
     assert abs(rg[2] - rw[2]) <= 0.02 and abs(rg[3] - rw[3]) <= 0.02, (rg, rw)
-    # measured: loss 3.51 -> 0.31, (P, R, mAP@0.5, mAP@0.5:0.95) = (0.998, 1.0, 0.995, 0.966) on both pipelines
-    assert rg[2] > 0.9 and rg[3] > 0.8, ("the trained detector does not find the ships it was trained on", rg, losses[-3:])
+    assert rg[2] > HELDOUT_MAP50_MIN and seen[2] > 0.9, ("the trained detector does not generalise / has not learnt its training images", rg, seen, losses[-3:])
+
+
+HELDOUT_MAP50_MIN = 0.25          # measured on MI355X (round 6): see the print above; the initial weights score ~0

@@ -1,7 +1,14 @@
 #!/bin/bash
-# GPU parity tests only, all failures reported:  bash tools/gpu_tests.sh <tag> [pytest args...]
+# the GPU parity suite of one gpurun call: summary line + failures in gpurun_out/<tag>_pytest.log; exit code = pytest's
+#   usage: bash tools/gpu_tests.sh <tag> [pytest args...]
+set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 TAG=${1:-t}; shift || true
-mkdir -p $R/gpurun_out; cd $R
-timeout 2000 python -m pytest tests -m gpu -q --maxfail=60 -p no:cacheprovider "$@" > gpurun_out/${TAG}_pytest.log 2>&1
-echo "rc=$?"; grep -E "^(FAILED|ERROR)|passed|failed" gpurun_out/${TAG}_pytest.log | cut -c1-220 | tail -70
+mkdir -p $R/gpurun_out
+cd $R
+timeout 2000 python -m pytest tests -m gpu -q -x "$@" > $R/gpurun_out/${TAG}_pytest.log 2>&1
+rc=$?
+grep -E "passed|failed|error" $R/gpurun_out/${TAG}_pytest.log | tail -3
+grep -E "^(FAILED|ERROR)|SSDD after" $R/gpurun_out/${TAG}_pytest.log | head -20
+echo "pytest rc=$rc"
+exit $rc

@@ -325,6 +325,87 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_pre1_kernel(const T* __r
   }
 }
 
+// The same pass with SEVERAL pixels per wave (round 6).  Above, a wave takes one pixel per trip: one 8-byte load per lane in flight and two
+// 64-lane reductions per pixel (two of their six steps go through the LDS pipe) — a chain of dependent latencies per pixel, 16-24 us per launch
+// where the bytes need 5-10.  Here LPP = 4 .. 16 lanes share a pixel (64 / LPP pixels per wave and trip), a lane holds VPL 16-byte vectors of
+// its pixel — all loads of a trip issued together — and the per-pixel [max, mean] is a reduction over LPP <= 16 lanes: DPP moves only.  The SE
+// pooling sums stay per lane over the block's pixels and meet once, in LDS.
+template <typename T, int VPL>                  // 16-byte vectors per lane: C / VW <= 16 * VPL (vector ln + 16 v of the pixel; absent ones are masked)
+__global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_pre1v_kernel(const T* __restrict__ x, int ldx, int HW, int C, int slices,
+                                                                     const float* __restrict__ a, const float* __restrict__ b,
+                                                                     float* __restrict__ mm, float* __restrict__ part) {
+  constexpr int LPP = 16, VW = LyT<T>::VW, NQ = VW / 4, PPW = 64 / LPP, NPG = 4 * PPW;        // pixels per wave and trip, pixel groups per block
+  const int nv = C / VW;
+  using RV = typename LyT<T>::RV;
+  extern __shared__ f32x4 pre1v_sm[];                  // [NPG][C / 4]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ln = lane % LPP, pg = wave * PPW + lane / LPP;
+  const int n = blockIdx.x / slices, sl = blockIdx.x - n * slices;
+  const int per = (HW + slices - 1) / slices;
+  const int j_lo = sl * per, j_hi = (j_lo + per) < HW ? (j_lo + per) : HW;
+  const float inv = 1.f / (float)C;
+  f32x4 sa[VPL][NQ], sb[VPL][NQ], gs[VPL][NQ];
+#pragma unroll
+  for (int v = 0; v < VPL; ++v)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const bool ok = ln + LPP * v < nv;
+      const int c = ok ? VW * (ln + LPP * v) + 4 * q : 0;
+      sa[v][q] = ok ? ly_ldg4(a + c) : ly_zero4(); sb[v][q] = ok ? ly_ldg4(b + c) : ly_zero4(); gs[v][q] = ly_zero4();      // absent vectors: relu(0 * x + 0) = 0
+    }
+  for (int j0 = j_lo; j0 < j_hi; j0 += NPG) {
+    const int j = j0 + pg;
+    const bool live = j < j_hi;
+    const long p = (long)n * HW + (live ? j : j_hi - 1);
+    RV xv[VPL];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) xv[v] = ly_ldrv<T>(x + p * ldx + (ln + LPP * v < nv ? VW * (ln + LPP * v) : 0));      // (clamped: straight-line loads)
+    float mx = 0.f, sm = 0.f;                  // relu(.) >= 0: zero is the identity of the channel max
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      f32x4 xq[NQ];
+      ly_rv_unpack(xv[v], xq);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        if (live) gs[v][q] += xq[q];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float g = fmaxf(xq[q][r] * sa[v][q][r] + sb[v][q][r], 0.f);
+          mx = fmaxf(mx, g);
+          sm += g;
+        }
+      }
+    }
+    mx = ly_group_max(mx, LPP);
+    sm = ly_group_sum(sm, LPP);
+    if (ln == 0 && live) *reinterpret_cast<f32x2*>(mm + 2 * p) = (f32x2){mx, sm * inv};
+  }
+  const int nc4 = C >> 2;
+#pragma unroll
+  for (int v = 0; v < VPL; ++v)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+      if (ln + LPP * v < nv) pre1v_sm[pg * nc4 + (VW * (ln + LPP * v) >> 2) + q] = gs[v][q];
+  __syncthreads();
+  for (int c4 = threadIdx.x; c4 < nc4; c4 += LY_THREADS) {
+    f32x4 t = pre1v_sm[c4];
+    for (int g = 1; g < NPG; ++g) t += pre1v_sm[g * nc4 + c4];
+    ly_stg4(part + ((long)n * slices + sl) * C + 4 * c4, t);
+  }
+}
+
+template <typename T>
+static bool pre1v_launch(const T* x, int ldx, int n_img, int HW, int C, int slices, const float* a1, const float* b1, float* mm, float* part, hipStream_t st) {
+  constexpr int VW = LyT<T>::VW;
+  if (C % VW || ldx % VW) return false;
+  const int nv = C / VW, vpl = (nv + 15) / 16;
+  const size_t lds = (size_t)16 * C * sizeof(float);            // 16 pixel groups per block
+#define LY_PV(V_) case V_: hipLaunchKernelGGL((ly_rfcbam_pre1v_kernel<T, V_>), dim3((unsigned)(n_img * slices)), dim3(LY_THREADS), lds, st, x, ldx, HW, C, slices, a1, b1, mm, part); return true
+  switch (vpl) { LY_PV(1); LY_PV(2); LY_PV(3); LY_PV(4); default: break; }
+#undef LY_PV
+  return false;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // RFCBAM statistics, k = 3 (stride s, pad 1).  lane = output pixel of a TH x TW tile, the 4 waves
 // split the channels (channel c0 + wave + 4j of each 32-channel chunk); depthwise weights are wave-
@@ -515,8 +596,11 @@ extern "C" int ly_rfcbam_stats(const void* x, int ldx, int n_img, int H, int W, 
     long M = (long)n_img * H * W;
     if (part) {           // statistics + SE pooling partials in one pass
       LY_CHECK(slices > 0 && C <= 256 * LY_PRE1_NS, "rfcbam_stats: fused SE pooling needs slices > 0 and C <= %d", 256 * LY_PRE1_NS);
-      LY_WITH_T(dtype, hipLaunchKernelGGL(ly_rfcbam_pre1_kernel<T>, dim3((unsigned)(n_img * slices)), dim3(LY_THREADS), 0, st, reinterpret_cast<const T*>(x), ldx,
-                                          H * W, C, slices, a1, b1, mm, part));
+      bool done = false;
+      LY_WITH_T(dtype, done = pre1v_launch<T>(reinterpret_cast<const T*>(x), ldx, n_img, H * W, C, slices, a1, b1, mm, part, st));      // several pixels per wave
+      if (!done)
+        LY_WITH_T(dtype, hipLaunchKernelGGL(ly_rfcbam_pre1_kernel<T>, dim3((unsigned)(n_img * slices)), dim3(LY_THREADS), 0, st, reinterpret_cast<const T*>(x), ldx,
+                                            H * W, C, slices, a1, b1, mm, part));
       LY_LAUNCH_CHECK();
       return 0;
     }

@@ -449,6 +449,10 @@ def rf3c_fwd(*, n, h, w, c, ho, wo, N, s, th, tw, x, ldx, wq, ca, rfa, wp, e_sca
         capi.check(capi.lib().ly_rf3c_fwd(ctypes.byref(P), _p(wq), int(raw), capi.stream_ptr()), "ly_rf3c_fwd")
 
 
+PRE1_PIXELS = 64           # pixels per block of the k = 1 statistics + pooling pass (ly_rfcbam_pre1v: 16 pixels per trip; measured 16 / 32 / 64 / 128:
+                           # 19.5 / 16.9 / 16.7 / 16.2 us at 256 x 40 x 40 x 64, 10.5 / 10.4 / 10.4 / 11.1 at 160 x 20 x 20 x 64)
+
+
 def rfcbam_stats(x, ldx, n, h, w, c, k, s, wg=None, a1=None, b1=None, th=1, tw=64, gap=False):
     """[max, mean] map of relu(bn(generate(x))); gap=True: the same pass also leaves the SE pooling partials -> (mm, part)"""
     ho, wo = ((h + 2 * (k // 2) - k) // s + 1, (w + 2 * (k // 2) - k) // s + 1)
@@ -458,7 +462,7 @@ def rfcbam_stats(x, ldx, n, h, w, c, k, s, wg=None, a1=None, b1=None, th=1, tw=6
         if k == 3:
             raise NotImplementedError("the fused statistics + pooling pass is built for k = 1 (for k = 3 the extra per-chunk LDS pass cost more "
                                       "than the separate ly_colsum launch it saved: measured 44 -> 69 us)")
-        slices = max(1, min(h * w // 16, 128))            # a function of the map only: results do not change with the batch split
+        slices = max(1, min(h * w // PRE1_PIXELS, 128))    # a function of the map only: results do not change with the batch split
         part = torch.empty((n, slices, c), dtype=torch.float32, device=x.device)
     with _Timed((f"ly_rfcbam_pre1_kernel<{_tname(x)}>" if (gap and k == 1) else f"ly_rfcbam_stats{k}_kernel<{_tname(x)}>"), 0.0,
                 x.element_size() * n * h * w * c + 4.0 * 2 * k * k * n * ho * wo, valu_flops=2.0 * n * ho * wo * c * (81 if k == 3 else 1)):

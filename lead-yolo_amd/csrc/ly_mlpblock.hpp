@@ -21,6 +21,10 @@
 //      B operand of one k-step (ly_tile.hpp), so the hidden activations never leave the register file.
 #include "ly_tile.hpp"
 
+#ifndef LY_MLP_PD
+#define LY_MLP_PD 1              // patches in flight per block of the persistent walk (register sets); measured round 6: 2 and 3 are slower (C = 24: 54.6 -> 62.5 -> 63.5 us): the walk is issue-bound, not latency-bound
+#endif
+
 template <int C>
 struct MlpGeom {
   static constexpr int CQ = C / 4;
@@ -423,7 +427,7 @@ __device__ __forceinline__ void ly_mlpblock_body(
 // [pconv(x[:C/4]) | x[C/4:]], what the training backward needs twice (z for the recomputed hidden tensor, and, with the transposed-
 // flipped taps on the gradient g, [d/dx of the conv | g[C/4:]]): one read + one write of the map instead of a clone and a 3x3 launch
 // whose 32/64-channel K chunks are 90 % padding at C/4 = 6.
-template <typename T, int C, int NT, int HT, int MODE>
+template <typename T, int C, int NT, int HT, int MODE, int PD>
 __device__ __forceinline__ void ly_mlpblock_persist_body(
     const T* __restrict__ x, T* __restrict__ y, long M, int H, int W, int n_img,
     const uint4* __restrict__ wp, const uint4* __restrict__ w1, const uint4* __restrict__ w2,
@@ -484,10 +488,12 @@ __device__ __forceinline__ void ly_mlpblock_persist_body(
   };
   constexpr int TVN = BP * (KP / VW), NVT = (TVN + LY_THREADS - 1) / LY_THREADS;
   constexpr int HVN = BPH * G, NVH = (HVN + LY_THREADS - 1) / LY_THREADS;
-  RV tv[NVT];
-  R4 hv[NVH];
-  bool tok[NVT], hok[NVH];
-  auto issue = [&](int tile) {
+  // PD register sets: set k holds the raw pixels of the patch PD walk steps ahead of the one being computed (round 6: with ONE patch in
+  // flight per block a walk step was one HBM round trip, ~2 us for 0.6 us of arithmetic: 2.7 / 1.8 TB/s at C = 24 / 40 with 3 / 2 blocks per CU)
+  RV tv[PD][NVT];
+  R4 hv[PD][NVH];
+  bool tok[PD][NVT], hok[PD][NVH];
+  auto issue = [&](const int k, int tile) {
     long i0; int hh0, ww0;
     decode(tile, i0, hh0, ww0);
 #pragma unroll
@@ -495,8 +501,8 @@ __device__ __forceinline__ void ly_mlpblock_persist_body(
       const int idx = tid + e * LY_THREADS;
       const int pix = idx / (KP / VW), c4 = idx - pix * (KP / VW);
       const int r = pix >> 4;
-      tok[e] = idx < TVN && hh0 + r < H && c4 * VW < C;
-      tv[e] = ly_ldrv<T>(tok[e] ? x + (i0 + (long)(hh0 + r) * W + ww0 + (pix & 15)) * C + c4 * VW : x);
+      tok[k][e] = idx < TVN && hh0 + r < H && c4 * VW < C;
+      tv[k][e] = ly_ldrv<T>(tok[k][e] ? x + (i0 + (long)(hh0 + r) * W + ww0 + (pix & 15)) * C + c4 * VW : x);
     }
 #pragma unroll
     for (int e = 0; e < NVH; ++e) {
@@ -504,11 +510,11 @@ __device__ __forceinline__ void ly_mlpblock_persist_body(
       const int hp = idx / G, c4 = idx - hp * G;
       const int hr = hp / 18, hc = hp - hr * 18;
       const int hh = hh0 - 1 + hr, ww = ww0 - 1 + hc;
-      hok[e] = idx < HVN && hh >= 0 && hh < H && ww >= 0 && ww < W;
-      hv[e] = ly_ldr4<T>(hok[e] ? x + (i0 + (long)hh * W + ww) * C + c4 * 4 : x);
+      hok[k][e] = idx < HVN && hh >= 0 && hh < H && ww >= 0 && ww < W;
+      hv[k][e] = ly_ldr4<T>(hok[k][e] ? x + (i0 + (long)hh * W + ww) * C + c4 * 4 : x);
     }
   };
-  auto commit = [&](int buf) {
+  auto commit = [&](const int k, int buf) {
     char* xh_ = bufs + buf * BUFB;
     char* xl_ = xh_ + (PL - 1) * BP * RS;
     char* ph_ = xh_ + XB;
@@ -517,16 +523,16 @@ __device__ __forceinline__ void ly_mlpblock_persist_body(
     for (int e = 0; e < NVT; ++e) {
       const int idx = tid + e * LY_THREADS;
       const int pix = idx / (KP / VW), c4 = idx - pix * (KP / VW);
-      RV v = tv[e];
-      if (!tok[e]) ly_zero_raw(v);
+      RV v = tv[k][e];
+      if (!tok[k][e]) ly_zero_raw(v);
       if (idx < TVN) ly_lds_put_rv(xh_, xl_, pix * RS, VW * c4, v);
     }
 #pragma unroll
     for (int e = 0; e < NVH; ++e) {
       const int idx = tid + e * LY_THREADS;
       const int hp = idx / G, c4 = idx - hp * G;
-      R4 v = hv[e];
-      if (!hok[e]) ly_zero_raw(v);
+      R4 v = hv[k][e];
+      if (!hok[k][e]) ly_zero_raw(v);
       if (idx < HVN) ly_lds_put_r4(ph_, pl_, hp * RSP, 4 * c4, v);
     }
   };
@@ -537,15 +543,24 @@ __device__ __forceinline__ void ly_mlpblock_persist_body(
 #pragma unroll
     for (int t = 0; t < HTP; ++t) { st1[t] = zero; st2[t] = zero; }
   }
-  int tile = ly_xcd_remap((int)blockIdx.x, (int)gridDim.x);              // blocks of one XCD walk neighbouring patches (shared halo rows in its L2)
-  if (tile >= ntiles) return;
-  issue(tile);
-  commit(0);
+  const int tile0 = ly_xcd_remap((int)blockIdx.x, (int)gridDim.x);       // blocks of one XCD walk neighbouring patches (shared halo rows in its L2)
+  if (tile0 >= ntiles) return;
+  const int GS = (int)gridDim.x;
+  issue(0, tile0);
+  commit(0, 0);
+#pragma unroll
+  for (int k = 0; k < PD; ++k) issue(k, tile0 + (k + 1) * GS < ntiles ? tile0 + (k + 1) * GS : tile0);       // (a patch past the end re-requests a valid one: straight-line loads)
   __syncthreads();                                         // weights and the first patch are in LDS
   int buf = 0;
-  for (; tile < ntiles; tile += gridDim.x) {
-    const int nxt = tile + (int)gridDim.x < ntiles ? tile + (int)gridDim.x : tile;     // (the last patch re-requests itself: straight-line loads)
-    issue(nxt);
+  for (int base = tile0; base < ntiles; base += PD * GS) {
+#pragma unroll
+  for (int pk = 0; pk < PD; ++pk) {
+    const int tile = base + pk * GS;
+    if (tile >= ntiles) break;
+    // set pk holds patch tile + GS (requested PD walk steps ago): into the other LDS buffer while this patch is computed, and the set goes out
+    // again for patch tile + (PD + 1) GS
+    commit(pk, buf ^ 1);
+    issue(pk, tile + (PD + 1) * GS < ntiles ? tile + (PD + 1) * GS : tile);
     decode(tile, img0, h0, w0);
     char* const xs_hi = bufs + buf * BUFB;
     char* const xs_lo = xs_hi + (PL - 1) * BP * RS;
@@ -664,7 +679,6 @@ __device__ __forceinline__ void ly_mlpblock_persist_body(
           }
         }
       }
-      commit(buf ^ 1);
       __syncthreads();
       buf ^= 1;
       continue;
@@ -774,9 +788,9 @@ __device__ __forceinline__ void ly_mlpblock_persist_body(
         }
       }
     }
-    commit(buf ^ 1);
     __syncthreads();
     buf ^= 1;
+  }
   }
   if constexpr (STATS) {
 #pragma unroll
@@ -784,12 +798,12 @@ __device__ __forceinline__ void ly_mlpblock_persist_body(
   }
 }
 
-template <typename T, int C, int NT, int HT, int MODE>
+template <typename T, int C, int NT, int HT, int MODE, int PD>
 __global__ __launch_bounds__(LY_THREADS) void ly_mlpblock_persist_kernel(
     const T* __restrict__ x, T* __restrict__ y, long M, int H, int W, int n_img,
     const uint4* __restrict__ wp, const uint4* __restrict__ w1, const uint4* __restrict__ w2,
     const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, double* __restrict__ stats) {
-  ly_mlpblock_persist_body<T, C, NT, HT, MODE>(x, y, M, H, W, n_img, wp, w1, w2, bn_scale, bn_shift, stats);
+  ly_mlpblock_persist_body<T, C, NT, HT, MODE, PD>(x, y, M, H, W, n_img, wp, w1, w2, bn_scale, bn_shift, stats);
 }
 
 template <typename T, int C, int NT, int HT, bool T2D, bool STATS>
@@ -887,7 +901,8 @@ static int launch_mlp_persist(const T* x, T* y, long M, int n_img, int H, int W,
   constexpr int NFW = Gm::PT * Gm::SP + Gm::HTP * Gm::S1 + Gm::C16 * Gm::S2;
   constexpr size_t lds = (size_t)NFW * PL * 1024 + 2 * (((size_t)PL * BP * Gm::RS + (size_t)PL * BPH * Gm::RSP + 15) / 16 * 16);
   static_assert(lds <= 160 * 1024, "persistent MLPBlock: weights + two patch buffers must fit LDS");
-  auto k = ly_mlpblock_persist_kernel<T, C, NT, HT, MODE>;
+  constexpr int PD = LY_MLP_PD;
+  auto k = ly_mlpblock_persist_kernel<T, C, NT, HT, MODE, PD>;
   static int per_cu = 0;
   if (per_cu == 0) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));

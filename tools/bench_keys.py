@@ -9,7 +9,7 @@ if "step" in r:
     print("families", {k: (v["launches"], round(v["ms"], 4)) for k, v in r["step"]["families"].items()})
 if "pconv_rfcbam_fwd" in r:
     p = r["pconv_rfcbam_fwd"]
-    print("pconv_rfcbam_fwd", p["ms"], p["hbm_frac"], [m[2] for m in p["us_per_module"]])
+    print("pconv_rfcbam_fwd", p["ms"], p["hbm_frac"], "one graph", p.get("one_graph_ms"), p.get("one_graph_hbm_frac"), [m[2] for m in p["us_per_module"]])
 if "pconv_rfcbam_fwd_f32" in r:
     p = r["pconv_rfcbam_fwd_f32"]
     print("pconv_rfcbam_fwd_f32", p["ms"], p["hbm_frac"], [m[2] for m in p["us_per_module"]])

@@ -1,6 +1,6 @@
 """Device time per call of the north-star modules, REP calls of one module captured back to back in ONE hipGraph (no replay floor,
 no host launch cost in the figure).  Dev tool, GPU box.
-    python tools/mod_time.py [batch=64] [mlp|rf|all] [bf16|f32] [train]
+    python tools/mod_time.py [batch=64] [mlp|rf|all] [bf16|f32] [train|eval] [norf3m]
 `train`: the training-mode forward pieces of a BasicStage (statistics pass + forward) through the module in train() under no_grad."""
 import os
 import sys
@@ -13,6 +13,9 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 which = sys.argv[2] if len(sys.argv) > 2 else "all"
 DT = torch.float32 if (len(sys.argv) > 3 and sys.argv[3] == "f32") else torch.bfloat16
 TRAIN = len(sys.argv) > 4 and sys.argv[4] == "train"
+if "norf3m" in sys.argv:                  # RFCBAMConv k=3 eval on the lane = channel kernels at every size
+    from lead_yolo_amd import modules as _m
+    _m.RF3M = False
 REP = 10
 
 

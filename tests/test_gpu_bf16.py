@@ -373,6 +373,53 @@ def test_mlpblock_persistent_kernel_bf16(c, n, h, w):
     _close(got, want, f"basicstage c={c} {n}x{h}x{w} bf16")
 
 
+@pytest.mark.parametrize("n,h,w", [(24, 40, 40), (21, 40, 40), (9, 61, 67), (40, 31, 29)])
+def test_mlpblock_resident_weights_kernel_bf16(n, h, w):
+    """C = 80 at >= 128 runs of 256 pixels: the resident-weights form (csrc/ly_mlpblock_res.hpp: one LDS copy of the fragments, 8 waves,
+    contiguous pixel ranges whose last run is ragged, runs that straddle images and rows), eval AND the train-mode statistics + forward,
+    against the oracle; and bit for bit against the one-shot kernels, which a map wider than the halo plan (W = 80) still takes"""
+    import lead_yolo_amd as L
+    c = 80
+    assert n * h * w >= 128 * 256 and w <= 75
+    torch.manual_seed(n)
+    m = L.BasicStage(c, 1)
+    st = synth.synth_state(synth.shapes_of(m.state_dict()), 5100 + n)
+    _bn_eps(_load(m, st))
+    x = synth.synth_input((n, c, h, w), 177 + n)
+    with torch.no_grad():
+        want = OF.basic_stage(copy.deepcopy(st), "", x, False)
+        want_t = OF.basic_stage(copy.deepcopy(st), "", x, True)
+        md = m.to(_dev())
+        got = md.eval()(x.to(_dev()).to(BF))
+        got_t = md.train()(x.to(_dev()).to(BF))
+    _close(got, want, f"basicstage c=80 {n}x{h}x{w} bf16 eval (resident weights)")
+    _close(got_t, want_t, f"basicstage c=80 {n}x{h}x{w} bf16 train-mode forward (resident weights)")
+
+
+def test_mlpblock_resident_weights_bits_equal_one_shot():
+    """the same pixels through both kernels: an [n, 80, 40, 40] map (resident-weights form) and the same values laid out as rows of an
+    [n, 80, 20, 80] map's left half cannot be compared (different neighbours), so the comparison is on a 1 x 1-neighbourhood-free input:
+    with the partial conv's weight zeroed except its centre tap the block is pointwise, and the two tilings must agree bit for bit"""
+    import lead_yolo_amd as L
+    c = 80
+    m = L.BasicStage(c, 1)
+    st = synth.synth_state(synth.shapes_of(m.state_dict()), 5200)
+    for k, v in st.items():
+        if v.dim() == 4 and v.shape[-1] == 3:                # the partial 3x3: centre tap only
+            z = torch.zeros_like(v)
+            z[:, :, 1, 1] = v[:, :, 1, 1]
+            st[k] = z
+    _bn_eps(_load(m, st))
+    md = m.to(_dev()).eval()
+    x = synth.synth_input((32, c, 40, 40), 31).to(_dev()).to(BF)
+    with torch.no_grad():
+        a = md(x)                                            # W = 40: resident-weights kernel
+        xb = x.permute(0, 2, 3, 1).reshape(16, 40, 80, c).permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last)
+        b = md(xb)                                           # W = 80: one-shot kernels
+    b = b.permute(0, 2, 3, 1).reshape(32, 40, 40, c).permute(0, 3, 1, 2)
+    assert torch.equal(a.float(), b.float())
+
+
 def test_configs2_full_size_graphed_step():
     """BASELINE configs[2] at FULL size — lead-yolo-s, bs=64, 640x640, bf16, the captured optimisation step the bench times — through
     size-independent properties (the CPU oracle cannot run this batch in seconds):

@@ -23,8 +23,14 @@
 
 // T = float: 32-channel chunks (8 float4 per frame position), two operand planes; T = __bf16: 64-channel chunks (8 x 16 bytes
 // per position, the same bytes in flight per thread), one plane, two k-steps per tap.
-template <typename T, int MT, int WC>
-__global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 2 ? 3 : 2))) void ly_conv3x3_kernel(const LyConv3Params P, const int gy, const int tiles_x, const int tiles_y, const int rp, const int ps) {
+// NTA > 0 (round 6): the patch has exactly NTA active pixel tiles per wave (80 x 80 maps: 8 / 4, 40 x 40 and 20 x 20 maps: 5) — the k-step's NTA operand
+// fragments are read as ONE batch ahead of its MFMAs.  With the run-time guard `if (tile < ntv)` around every tile hipcc keeps each tile in a block
+// of its own: read, s_waitcnt lgkmcnt(0), MT MFMAs — 136 full LDS round trips per chunk (PMC r05: 66 % of the wave cycles in s_waitcnt).
+#ifndef LY_C3_NTA_WPE
+#define LY_C3_NTA_WPE 3
+#endif
+template <typename T, int MT, int WC, int NTA = 0>
+__global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 2 ? (NTA > 0 ? LY_C3_NTA_WPE : 3) : 2))) void ly_conv3x3_kernel(const LyConv3Params P, const int gy, const int tiles_x, const int tiles_y, const int rp, const int ps) {
   using TR = LyT<T>;
   using RV = typename TR::RV;
   constexpr int VW = TR::VW, PL = TR::PL;
@@ -162,6 +168,19 @@ __global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(size
 #pragma unroll
           for (int t = 0; t < MT; ++t) wnxt[t] = ly_wfragp<PL>(wpk, wbase[t] + wstep(nt, nc, nk), lane);
         }
+        if constexpr (NTA > 0) {
+          bf16x8 xh[NTA], xl[NTA];
+#pragma unroll
+          for (int n = 0; n < NTA; ++n) {
+            xh[n] = ly_img_frag(hs_hi, hb[n] + toff, ps, ks, lq);
+            xl[n] = xh[n];
+            if constexpr (PL == 2) xl[n] = ly_img_frag(hs_lo, hb[n] + toff, ps, ks, lq);
+          }
+#pragma unroll
+          for (int n = 0; n < NTA; ++n)
+#pragma unroll
+            for (int t = 0; t < MT; ++t) acc[t][n] = ly_mfmap<PL>(wcur[t], xh[n], xl[n], acc[t][n]);
+        } else {
 #pragma unroll
         for (int n = 0; n < NTW; ++n) {
           if (wp * NTW + n < ntv) {
@@ -171,6 +190,7 @@ __global__ __launch_bounds__(LY_THREADS) __attribute__((amdgpu_waves_per_eu(size
 #pragma unroll
             for (int t = 0; t < MT; ++t) acc[t][n] = ly_mfmap<PL>(wcur[t], xh, xl, acc[t][n]);
           }
+        }
         }
 #pragma unroll
         for (int t = 0; t < MT; ++t) wcur[t] = wnxt[t];
@@ -505,7 +525,7 @@ static int conv3_row_pitch(int TH, int TW, int rsh) {
   return best;
 }
 
-template <typename T, int MT, int WC, bool LAT = false>
+template <typename T, int MT, int WC, bool LAT = false, int NTA = 0>
 static int launch_conv3(const LyConv3Params& P, hipStream_t st) {
   const int tiles_x = (P.W + P.TW - 1) / P.TW, tiles_y = (P.H + P.TH - 1) / P.TH;
   const int gy = (P.N + 16 * MT * WC - 1) / (16 * MT * WC);
@@ -515,7 +535,7 @@ static int launch_conv3(const LyConv3Params& P, hipStream_t st) {
   const int rp = conv3_row_pitch(P.TH, P.TW, ly_qrs(8 * LyT<T>::VW / 32));
   const int ps = ly_qps((P.TH + 2) * rp);
   size_t lds = LyT<T>::PL * (size_t)4 * ps;
-  void (*k)(const LyConv3Params, const int, const int, const int, const int, const int) = ly_conv3x3_kernel<T, MT, WC>;
+  void (*k)(const LyConv3Params, const int, const int, const int, const int, const int) = ly_conv3x3_kernel<T, MT, WC, LAT ? 0 : NTA>;
   if constexpr (LAT) k = ly_conv3x3_lat_kernel<T, MT, WC>;
   static bool configured = false;
   if (!configured) {
@@ -543,8 +563,18 @@ static int conv3_dispatch(const LyConv3Params& P, hipStream_t st) {
     if (mode == 2) return launch_conv3<T, 2, 4, true>(P, st);
     if (mode == 4 || (mode == 0 && P.N > 64 && small)) return launch_conv3<T, 2, 2, true>(P, st);   // 64 channels per block: twice the blocks
   }
+  const int ntv = (P.TH * P.TW + 15) >> 4;                // active pixel tiles of a patch
   if (mode == 3) return launch_conv3<T, 2, 2>(P, st);
-  if (mode == 1 || P.N > 64) return launch_conv3<T, 2, 4>(P, st);      // 4 waves x 32 ch (128 ch per block), all 8 pixel tiles each
+  if (mode == 1 || P.N > 64) {                            // 4 waves x 32 ch (128 ch per block), all 8 pixel tiles each
+    if constexpr (LyT<T>::BF) {
+      if (mode == 0 && ntv == 5) return launch_conv3<T, 2, 4, false, 5>(P, st);
+      if (mode == 0 && ntv == 8) return launch_conv3<T, 2, 4, false, 8>(P, st);
+    }
+    return launch_conv3<T, 2, 4>(P, st);
+  }
+  if constexpr (LyT<T>::BF) {
+    if (mode == 0 && ntv == 8) return launch_conv3<T, 2, 2, false, 4>(P, st);
+  }
   return launch_conv3<T, 2, 2>(P, st);                    // 2 x 32 ch, 2 pixel groups of 4 tiles
 }
 

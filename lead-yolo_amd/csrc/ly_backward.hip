@@ -524,7 +524,7 @@ __device__ __forceinline__ void ly_wgrad_tiled_body(const LyWgradParams& Q, cons
   // at 2.6-3.5 TB/s).  The 8 x 8 transpose is 32 v_perm_b32 per task (the quads' 4 x 8: 16) — the same count per byte.  Row r then sits at slot
   // (r & 7) (NR/8 + 2) + (r >> 3): for a fixed channel-in-octet consecutive threads write consecutive slots, and rows 0 .. 15 of a fragment land
   // on the 16 slots (r & 7) * 2 + (r >> 3) modulo 16 (NR/8 + 2 = 2 mod 16 for NR = 64, 96, 128, 160, 192, 256).
-  constexpr bool OC = OCT && ROWS && LyT<T>::BF;
+  constexpr bool OC = OCT && LyT<T>::BF;                // (gathered inputs too: an octet lies inside one tap when Cin is a multiple of 8)
   static_assert(!OC || ((NR / 8 + 2) % 16 == 2 || (NR / 8 + 2) % 16 == 10 || (NR / 8 + 2) % 16 == 6 || (NR / 8 + 2) % 16 == 14), "octet row map: fragment rows must hit 16 slots");
   auto rowoff = [](int r) -> int { return OC ? ((r & 7) * (NR / 8 + 2) + (r >> 3)) * 16 : ((r & 3) * (NR / 4 + 4) + (r >> 2)) * 16; };
   constexpr int ISTEP = OC ? 32 : 64;                   // bytes between the row slots of rows r and r + 16
@@ -689,7 +689,7 @@ __device__ __forceinline__ void ly_wgrad_tiled_body(const LyWgradParams& Q, cons
 
   // ---- the octet form of the same two steps -------------------------------------------------------
   bool o_isA[OC ? TPT8 : 1], o_ok[OC ? TPT8 : 1];
-  int o_row[OC ? TPT8 : 1], o_g[OC ? TPT8 : 1], o_c[OC ? TPT8 : 1];
+  int o_row[OC ? TPT8 : 1], o_g[OC ? TPT8 : 1], o_c[OC ? TPT8 : 1], o_ky[OC ? TPT8 : 1], o_kx[OC ? TPT8 : 1];
   ly_u32x4 pre8[OC ? TPT8 : 1][OC ? 8 : 1];
   if constexpr (OC) {
 #pragma unroll
@@ -704,6 +704,14 @@ __device__ __forceinline__ void ly_wgrad_tiled_body(const LyWgradParams& Q, cons
       o_row[u] = live ? (o_isA[u] ? 0 : BN) + 8 * co : -1;
       o_c[u] = (o_isA[u] ? n0 : k0) + 8 * co;
       o_ok[u] = live && o_c[u] < (o_isA[u] ? Q.N : Ktot);
+      o_ky[u] = o_kx[u] = 0;
+      if (!ROWS && !o_isA[u]) {                              // gathered input: column -> (tap, channel inside the tap)
+        const int cc = o_ok[u] ? o_c[u] : 0;
+        const int tap = cc / Q.Cin;
+        o_c[u] = cc - tap * Q.Cin;
+        o_ky[u] = tap / Q.ks;
+        o_kx[u] = tap - o_ky[u] * Q.ks;
+      }
     }
   }
   auto prefetch8 = [&](long p0) {
@@ -711,11 +719,30 @@ __device__ __forceinline__ void ly_wgrad_tiled_body(const LyWgradParams& Q, cons
 #pragma unroll
     for (int u = 0; u < (OC ? TPT8 : 0); ++u) {
       const long pf = p0 + 8 * o_g[u];
+      int n_i = 0, ho = 0, wo = 0;
+      if (!ROWS && !o_isA[u]) {
+        const int g = (int)(pf < Q.M ? pf : Q.M - 1);
+        const int row = ly_fdiv(g, Q.W, invW);
+        wo = g - row * Q.W;
+        n_i = ly_fdiv(row, Q.H, invH);
+        ho = row - n_i * Q.H;
+      }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const long p = pf + j;
-        const bool ok = o_ok[u] && p < p_end;
-        const T* src = o_isA[u] ? du + (ok ? p : p_begin) * Q.lddu + (ok ? o_c[u] : 0) : xin + (ok ? p : p_begin) * Q.ldx + (ok ? o_c[u] : 0);
+        bool ok = o_ok[u] && p < p_end;
+        const T* src;
+        if (o_isA[u]) {
+          src = du + (ok ? p : p_begin) * Q.lddu + (ok ? o_c[u] : 0);
+        } else if (ROWS) {
+          src = xin + (ok ? p : p_begin) * Q.ldx + (ok ? o_c[u] : 0);
+        } else {
+          int hi = ho * Q.stride + o_ky[u] - Q.pad, wi = wo * Q.stride + o_kx[u] - Q.pad;
+          ok = ok && hi >= 0 && hi < Hv && wi >= 0 && wi < Wv;
+          if (Q.up2) { hi >>= 1; wi >>= 1; }
+          src = xin + (ok ? (((long)n_i * Q.Hin + hi) * Q.Win + wi) * Q.ldx + o_c[u] : 0);
+          if (++wo == Q.W) { wo = 0; if (++ho == Q.H) { ho = 0; ++n_i; } }
+        }
         ly_u32x4 v = *reinterpret_cast<const ly_u32x4*>(src);
         if constexpr (!DEFER) {
           if (!ok) v = (ly_u32x4){0u, 0u, 0u, 0u};
@@ -1021,6 +1048,14 @@ static int launch_wgrad_tiled(const LyWgradParams& Q, bool rows, hipStream_t st)
       hipLaunchKernelGGL((ly_wgrad_tiled_kernel<T, BN, BK, P, true, false, true>), grid, dim3(LY_THREADS), lds, st, Q, tiles_k, chunk_px, slab);
     }
    }
+  }
+  if constexpr (LyT<T>::BF) {
+    if (!oct_done && !rows && wgrad_octets<T>(Q)) {
+      oct_done = true;
+      static bool attr = false;
+      if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ly_wgrad_tiled_kernel<T, BN, BK, P, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+      hipLaunchKernelGGL((ly_wgrad_tiled_kernel<T, BN, BK, P, false, false, true>), grid, dim3(LY_THREADS), lds, st, Q, tiles_k, chunk_px, slab);
+    }
   }
   if (oct_done) {
   } else if (rows && Q.x_scale) {

@@ -12,7 +12,6 @@
 // Replaces what autograd derives for Conv2d -> BatchNorm2d -> SiLU/ReLU in the reference's
 // `scaler.scale(loss).backward()` (train.py:324) over models/common.py:1890-1910 (Conv),
 // :1478-1482 (MLPBlock), :1537-1561 (patch layers).
-#include <type_traits>
 #include "ly_tile.hpp"
 #include "ly_params.h"
 
@@ -69,77 +68,58 @@ __device__ __forceinline__ f32x4 ly_dact4(const f32x4 v, const f32x4 dy) {
   const long xw_begin = xw_lo + (xw_on ? xw_slot : (long)blockIdx.x) * (groups_);                                         \
   const long xw_step = (xw_on ? xw_n : (long)gridDim.x) * (groups_)
 
-#ifndef LY_RED_VW
-#define LY_RED_VW 4               // channels per thread of the reduce pass (bf16: 4 = 8-byte, 8 = 16-byte accesses)
-#endif
-#ifndef LY_RED_UR
-#define LY_RED_UR 4               // rows in flight per thread and trip
-#endif
-template <typename T, int ACT, int VWK = 4, int UR = 4>
+template <typename T, int ACT>
 __global__ __launch_bounds__(LY_THREADS) void ly_bnact_bwd_reduce_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ u,
                                                                           int ldu, long rows, int C, const float* __restrict__ a,
                                                                           const float* __restrict__ b, double* __restrict__ sums,
                                                                           const T* __restrict__ dy2, int lddy2, int csplit, double* __restrict__ sums2) {
   // (pair form, csplit < C: channels >= csplit take their gradient from dy2 — column c - csplit — and their sums go to sums2: the two
   // BatchNorms over one stacked pre-activation tensor, C3_CA's cv1 | cv2, in ONE pass; csplit == C: one unit)
-  // thread = (channel vector of VWK channels, row lane).  UR rows per trip with all loads issued before the first use, in straight-line code
+  // thread = (channel quad, row lane).  Four rows per trip with all eight loads issued before the first use, in straight-line code
   // (a load under a run-time branch makes every later s_waitcnt conservative: the first unrolled version, which still chose the vector
   // width at run time, was SLOWER than one row per trip).  Rows past the end re-read the last row and are masked.
-  constexpr int NQ = VWK / 4;
-  __shared__ f32x4 red1[NQ][LY_THREADS], red2[NQ][LY_THREADS];
-  typedef typename std::conditional<VWK == 8, ly_u32x4, typename LyT<T>::R4>::type RW;      // VWK == 8: bf16 storage only (16 bytes)
-  const int ncv = C / VWK, tid = threadIdx.x;
+  __shared__ f32x4 red1[LY_THREADS], red2[LY_THREADS];
+  using R4 = typename LyT<T>::R4;
+  const int ncv = C >> 2, tid = threadIdx.x;
   const int groups = LY_THREADS / ncv;
   const int cv = tid % ncv, j0 = tid / ncv;
-  f32x4 s1[NQ], s2[NQ];
-#pragma unroll
-  for (int q = 0; q < NQ; ++q) { s1[q] = ly_zero4(); s2[q] = ly_zero4(); }
-  const bool second = VWK * cv >= csplit;
+  f32x4 s1 = ly_zero4(), s2 = ly_zero4();
+  const bool second = 4 * cv >= csplit;
   if (j0 < groups) {
-    f32x4 av[NQ], bv[NQ];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) { av[q] = ly_ldg4(a + VWK * cv + 4 * q); bv[q] = ly_ldg4(b + VWK * cv + 4 * q); }
+    const f32x4 av = ly_ldg4(a + 4 * cv), bv = ly_ldg4(b + 4 * cv);
+    constexpr int UR = 4;
     const long stride = (long)gridDim.x * groups;
-    const T* const dyb = second ? dy2 + (VWK * cv - csplit) : dy + VWK * cv;      // (a selected base pointer: no load under a branch)
+    const T* const dyb = second ? dy2 + (4 * cv - csplit) : dy + 4 * cv;      // (a selected base pointer: no load under a branch)
     const long ldd = second ? lddy2 : lddy;
     for (long r0 = (long)blockIdx.x * groups + j0; r0 < rows; r0 += UR * stride) {
-      RW qu[UR], qg[UR];
+      R4 qu[UR], qg[UR];
 #pragma unroll
       for (int k = 0; k < UR; ++k) {
         const long r = r0 + k * stride < rows ? r0 + k * stride : rows - 1;
-        qu[k] = *reinterpret_cast<const RW*>(u + r * ldu + VWK * cv);
-        qg[k] = *reinterpret_cast<const RW*>(dyb + r * ldd);
+        qu[k] = ly_ldr4<T>(u + r * ldu + 4 * cv);
+        qg[k] = ly_ldr4<T>(dyb + r * ldd);
       }
 #pragma unroll
       for (int k = 0; k < UR; ++k) {
-        f32x4 uu[NQ], gg[NQ];
-        if constexpr (VWK == 8) { ly_rv_unpack(qu[k], uu); ly_rv_unpack(qg[k], gg); }
-        else { uu[0] = ly_r4_f32(qu[k]); gg[0] = ly_r4_f32(qg[k]); }
-        const bool live = r0 + k * stride < rows;
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-          f32x4 dv = ly_dact4<ACT>(av[q] * uu[q] + bv[q], gg[q]);
-          if (!live) dv = ly_zero4();
-          s1[q] += dv;
-          s2[q] += dv * uu[q];
-        }
+        const f32x4 uu = ly_r4_f32(qu[k]);
+        f32x4 dv = ly_dact4<ACT>(av * uu + bv, ly_r4_f32(qg[k]));
+        if (!(r0 + k * stride < rows)) dv = ly_zero4();
+        s1 += dv;
+        s2 += dv * uu;
       }
     }
   }
-#pragma unroll
-  for (int q = 0; q < NQ; ++q) { red1[q][tid] = s1[q]; red2[q][tid] = s2[q]; }
+  red1[tid] = s1;
+  red2[tid] = s2;
   __syncthreads();
   if (j0 == 0) {
-    const int ch = second ? C - csplit : csplit, lc = VWK * cv - (second ? csplit : 0);        // channels of this unit, the thread's first one in it
+    const int ch = second ? C - csplit : csplit, lc = 4 * cv - (second ? csplit : 0);        // channels of this unit, the thread's first one in it
     double* sm = (second ? sums2 : sums) + (size_t)(blockIdx.x & (LY_STATS_STRIPES - 1)) * 2 * ch;      // double accumulators: see ly_stats_flush (ly_common.hpp)
+    for (int g = 1; g < groups; ++g) { s1 += red1[g * ncv + cv]; s2 += red2[g * ncv + cv]; }
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      for (int g = 1; g < groups; ++g) { s1[q] += red1[q][g * ncv + cv]; s2[q] += red2[q][g * ncv + cv]; }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        atomicAdd(sm + lc + 4 * q + r, (double)s1[q][r]);
-        atomicAdd(sm + ch + lc + 4 * q + r, (double)s2[q][r]);
-      }
+    for (int r = 0; r < 4; ++r) {
+      atomicAdd(sm + lc + r, (double)s1[r]);
+      atomicAdd(sm + ch + lc + r, (double)s2[r]);
     }
   }
 }
@@ -295,24 +275,12 @@ static int bnact_bwd_reduce_launch(const void* dy_, int lddy, const void* dy2_, 
   // channels per thread: 4 in both dtypes.  (8 bf16 channels = 16-byte accesses measured SLOWER here, 24.6 -> 29.0 us per launch:
   // half as many threads share a row, and this pass lives on loads in flight; the elementwise apply / forward passes gain, 21 -> 18.6
   // and 14.6 -> 12.6 us, and use 16-byte accesses.)
-  // LY_RED_VW = 8 (development): 16-byte accesses where bf16 widths allow
-  const bool wide = LY_RED_VW == 8 && dtype == LY_BF16 && (C & 7) == 0 && (lddy & 7) == 0 && (lddy2 & 7) == 0 && (ldu & 7) == 0 && (csplit & 7) == 0 && C / 8 <= LY_THREADS &&
-                    ((uintptr_t)dy_ & 15) == 0 && ((uintptr_t)dy2_ & 15) == 0 && ((uintptr_t)u_ & 15) == 0;
-  const int vw = wide ? 8 : 4;
+  const int vw = 4;
   const int groups = LY_THREADS / (C / vw);
   long blocks = (rows + groups * 32L - 1) / (groups * 32L);
   blocks = blocks < 1 ? 1 : blocks > 2048 ? 2048 : blocks;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-#define LY_RED(A) hipLaunchKernelGGL((ly_bnact_bwd_reduce_kernel<T, A, 4, LY_RED_UR>), dim3((unsigned)blocks), dim3(LY_THREADS), 0, st, dy, lddy, u, ldu, rows, C, a, b, sums, dy2, lddy2, csplit, sums2)
-#define LY_RED8(A) hipLaunchKernelGGL((ly_bnact_bwd_reduce_kernel<__bf16, A, 8, LY_RED_UR>), dim3((unsigned)blocks), dim3(LY_THREADS), 0, st, dy, lddy, u, ldu, rows, C, a, b, sums, dy2, lddy2, csplit, sums2)
-  if (wide) {
-    const __bf16* dy = reinterpret_cast<const __bf16*>(dy_);
-    const __bf16* dy2 = reinterpret_cast<const __bf16*>(dy2_);
-    const __bf16* u = reinterpret_cast<const __bf16*>(u_);
-    if (act == LY_ACT_SILU) LY_RED8(LY_ACT_SILU);
-    else if (act == LY_ACT_RELU) LY_RED8(LY_ACT_RELU);
-    else LY_RED8(LY_ACT_NONE);
-  } else {
+#define LY_RED(A) hipLaunchKernelGGL((ly_bnact_bwd_reduce_kernel<T, A>), dim3((unsigned)blocks), dim3(LY_THREADS), 0, st, dy, lddy, u, ldu, rows, C, a, b, sums, dy2, lddy2, csplit, sums2)
   LY_WITH_T(dtype, {
     const T* dy = reinterpret_cast<const T*>(dy_);
     const T* dy2 = reinterpret_cast<const T*>(dy2_);
@@ -321,9 +289,7 @@ static int bnact_bwd_reduce_launch(const void* dy_, int lddy, const void* dy2_, 
     else if (act == LY_ACT_RELU) LY_RED(LY_ACT_RELU);
     else LY_RED(LY_ACT_NONE);
   });
-  }
 #undef LY_RED
-#undef LY_RED8
   LY_LAUNCH_CHECK();
   return 0;
 }

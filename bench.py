@@ -123,6 +123,20 @@ def committed_pmc(kernel, suffix):
     return None
 
 
+def committed_row0(dtype):
+    """first kernel row of the newest committed per-kernel table of one steady-state training step (profiles/*_train_<dtype>_step_kernels.txt,
+    tools/step_kernels.py: device time per KERNEL, most time first), or None"""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_train_{dtype}_step_kernels.txt")), reverse=True):
+        try:
+            lines = [ln for ln in open(path).read().splitlines()[1:] if ln.strip()]
+        except OSError:
+            continue
+        if lines:
+            return lines[0][:130].strip(), os.path.basename(path)
+    return None
+
+
 def usable_cores():
     """host cores this process may actually use: affinity mask capped by the cgroup CPU quota"""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -437,7 +451,7 @@ def _limited_by(hbm_frac, mfma_frac, valu_frac):
     return "latency" if best[0] < 0.25 else best[1]
 
 
-def roofline_of(rows, dtype, families=None):
+def roofline_of(rows, dtype, families=None, prefer=None):
     """`roofline` of the line, SURVEY 8(d): the DOMINANT kernel = the instrumented kernel with the most time per step (rows are sorted by it: a
     deterministic pick — the "largest kernel of the largest family" of rounds 2-4 flipped between two kernels from run to run), priced against
     the roof 8(d) names for it: HBM for every bf16-storage kernel; for fp32 storage the larger of the HBM and matrix fractions (deep fp32 blocks
@@ -445,6 +459,16 @@ def roofline_of(rows, dtype, families=None):
     kernel is bound by none of the roofs: occupancy / dependent round trips).  `largest_single_launch` is the same accounting for the longest
     single launch of the step."""
     dom = rows[0]
+    picked = "the instrumented kernel with the most time per step (launches x mean launch time)"
+    if prefer is not None:
+        # train mode: the pick is row 0 of the COMMITTED per-kernel step table (device time per kernel); this run's rows time C-ABI calls — a
+        # weight-gradient call is its kernel plus the fold of its slabs — and two kernels within a few per cent of each other (round 6: the
+        # BatchNorm / activation reduce pass, 18 x 22 us, and the grouped weight gradient, 8 x 46 us + 8 x 10 us of folds) would swap places
+        # between the two accountings
+        hit = [r for r in rows if r["kernel"] == prefer[0]]
+        if hit:
+            dom = hit[0]
+            picked = f"row 0 of the committed per-kernel step table {prefer[1]} (most device time per step); the figures are this run's live timing of it"
     dom_family = family_of(dom["kernel"])
     gbs, tfs, vtfs, mfma_peak, hbm_frac, mfma_frac, valu_frac = _fractions(dom, dtype)
     if dtype != "bf16" and mfma_frac > hbm_frac:
@@ -460,7 +484,7 @@ def roofline_of(rows, dtype, families=None):
                           "counters cannot be collected inside the driver's timed run") if tr else None
     roof["mfma_busy"] = committed_pmc(dom["kernel"], "pmc_mfma")
     roof["kernel"] = dom["kernel"]
-    roof["kernel_is"] = "the instrumented kernel with the most time per step (launches x mean launch time)"
+    roof["kernel_is"] = picked
     if dom["kernel"].startswith(("ly_wgrad", "ly_mlpblock_bwd")):
         # these C-ABI calls launch the named kernel AND the fixed-order fold of its slabs: the HIP-event pair brackets both (rocprofv3 lists
         # the fold as its own row: ly_wgrad_combine* / ly_mlpblock_bwd*_combine_kernel)
@@ -782,7 +806,7 @@ def main():
         else:
             if args.layers:
                 print_layers(rows)
-            roof = roofline_of(rows, args.dtype, step_roof.get("families"))
+            roof = roofline_of(rows, args.dtype, step_roof.get("families"), committed_row0(args.dtype) if args.mode == "train" else None)
             roof["step"] = step_roof
             if ctx.world == 1 and not args.no_secondary:
                 del res["step"]

@@ -277,7 +277,10 @@ static int bnact_bwd_reduce_launch(const void* dy_, int lddy, const void* dy2_, 
   // and 14.6 -> 12.6 us, and use 16-byte accesses.)
   const int vw = 4;
   const int groups = LY_THREADS / (C / vw);
-  long blocks = (rows + groups * 32L - 1) / (groups * 32L);
+#ifndef LY_RED_ROWS
+#define LY_RED_ROWS 32            // rows per row lane and block.  Measured round 6 (bnact family per step): 16 -> 1.83, 32 -> 1.78, 64 -> 1.96, 128 -> 2.31 ms
+#endif
+  long blocks = (rows + groups * (long)LY_RED_ROWS - 1) / (groups * (long)LY_RED_ROWS);
   blocks = blocks < 1 ? 1 : blocks > 2048 ? 2048 : blocks;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define LY_RED(A) hipLaunchKernelGGL((ly_bnact_bwd_reduce_kernel<T, A>), dim3((unsigned)blocks), dim3(LY_THREADS), 0, st, dy, lddy, u, ldu, rows, C, a, b, sums, dy2, lddy2, csplit, sums2)

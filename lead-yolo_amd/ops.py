@@ -228,7 +228,9 @@ def conv3x3(*, M, H, W, Cin, N, x, ldx, wp, out, ldo, e_scale=None, e_shift=None
     code = capi.dtype_code(x)
     P = capi.LyConv3Params(M, H, W, Cin, N, th, tw, _p(x), ldx, _p(wp), _p(e_scale), _p(e_shift), act, _p(out), ldo, _p(stats), code)
     mt, wc = (2, 4) if N > 64 else (2, 2)
-    name = f"ly_conv3x3_kernel<{_tname(x)}, {mt}, {wc}>"
+    ntv = -(-(th * tw) // 16)                               # active pixel tiles of a patch: compile-time in the bf16 instantiations (conv3_dispatch)
+    nta = 0 if code == 0 else (ntv if (wc == 4 and ntv in (5, 8)) else 4 if (wc == 2 and ntv == 8) else 0)
+    name = f"ly_conv3x3_kernel<{_tname(x)}, {mt}, {wc}, {nta}>"
     if code != 0 and N > 64 and (M // (H * W)) * -(-W // tw) * -(-H // th) * -(-N // 128) < 512:
         name = "ly_conv3x3_lat_kernel<__bf16, 2, 2>"        # conv3_dispatch (csrc/ly_conv3x3.hip): grids under two blocks per CU take the latency form
     with _Timed(name, 2.0 * M * 9 * Cin * N, x.element_size() * M * (Cin + N) + 4.0 * 9 * Cin * N):
@@ -659,6 +661,10 @@ def mlpblock(x, y, n, h, w, c, wp, w1, w2, sc, sh, stats=None):
     cc, nt, ht, t2d = mlp_config(c, m, w, x.dtype == torch.bfloat16)
     kind = "_ring" if c >= 80 else "_occ4" if (c <= 24 and t2d == "true") else ""
     name = f"ly_mlpblock_fwd{kind}_kernel<{_tname(x)}, {cc}, {nt}, {ht}, {t2d}, {'true' if stats is not None else 'false'}>"
+    if c == 80 and x.dtype == torch.bfloat16 and m >= 128 * 256 and (256 + 2 * w + 2) * 5 <= 2048:
+        name = f"ly_mlpblock_res_kernel<__bf16, 80, 2, 2, {'true' if stats is not None else 'false'}, 4>"      # ly_mlp_dispatch_80 (csrc/ly_mlpblock_b.hip)
+    elif c < 80 and w % 16 == 0 and w >= 32 and n * -(-h // 8) * (w // 16) >= 1024 and (x.dtype == torch.bfloat16 or c < 40):
+        name = f"ly_mlpblock_persist_kernel<{_tname(x)}, {c}, 2, {ht}, {1 if stats is not None else 0}, 1>"      # dispatch_nt_t: the persistent patch walk
     with _Timed(name, 2.0 * m * (9 * (c // 4) ** 2 + 4 * c * c),
                 x.element_size() * (1 if stats is not None else 2) * m * c + 4.0 * (9 * (c // 4) ** 2 + 4 * c * c)):
         capi.check(capi.lib().ly_mlpblock_fwd(_p(x), _p(y), n, h, w, c, _p(wp), _p(w1), _p(w2), _p(sc), _p(sh), _p(stats), capi.dtype_code(x),
@@ -1045,7 +1051,8 @@ def wgrad(*, M, H, W, N, du, lddu, x, ldx, Hin, Win, Cin, dw, lddw, ks=1, stride
         return _wgrad_enqueue(q)
     P = _wgrad_params(**q)
     with _Timed(wgrad_kernel_name(_tname(x), N, ks * ks * Cin, ks == 1 and stride == 1 and pad == 0 and not nchw and not up2,
-                                  (not nchw) and N % 4 == 0 and Cin % 4 == 0 and lddu % 4 == 0 and ldx % 4 == 0, x_scale is not None),
+                                  (not nchw) and N % 4 == 0 and Cin % 4 == 0 and lddu % 4 == 0 and ldx % 4 == 0, x_scale is not None,
+                                  _wgrad_octets(x, du, N, Cin, lddu, ldx, du_off, x_off)),
                 2.0 * M * N * ks * ks * Cin, x.element_size() * M * (N + Cin) + 4.0 * N * ks * ks * Cin):
         capi.check(capi.lib().ly_wgrad(ctypes.byref(P), capi.stream_ptr()), "ly_wgrad")
 
@@ -1182,13 +1189,22 @@ def wgrad_group(problems, _now=False):
     x0 = problems[0]["x"]
     px = 128 if x0.dtype == torch.bfloat16 else 64
     anyp = any(q.get("x_scale") is not None for q in problems)
-    gslab = ", true" if wgrad_workspace(x0.device) is not None else ""          # slab flush + ly_wgrad_combine_group_kernel (wgrad_group_launch)
-    with _Timed(f"ly_wgrad_tiled_group_kernel<{_tname(x0)}, 128, 128, {px}, true, {'true' if anyp else 'false'}{gslab}>", sum(2.0 * q["M"] * q["N"] * q["Cin"] for q in problems),
+    gslab = wgrad_workspace(x0.device) is not None                               # slab flush + ly_wgrad_combine_group_kernel (wgrad_group_launch)
+    octs = gslab and all(_wgrad_octets(q["x"], q["du"], q["N"], q["Cin"], q["lddu"], q["ldx"], q.get("du_off", 0), q.get("x_off", 0)) for q in problems)
+    with _Timed(f"ly_wgrad_tiled_group_kernel<{_tname(x0)}, 128, 128, {px}, true, {'true' if anyp else 'false'}, {'true' if gslab else 'false'}, "
+                f"{'true' if octs else 'false'}>", sum(2.0 * q["M"] * q["N"] * q["Cin"] for q in problems),
                 sum(x0.element_size() * q["M"] * (q["N"] + q["Cin"]) + 4.0 * q["N"] * q["Cin"] for q in problems)):
         capi.check(capi.lib().ly_wgrad_group(arr, len(problems), capi.stream_ptr()), "ly_wgrad_group")
 
 
-def wgrad_kernel_name(t, n, ktot, rows, tiled, pro=False):
+def _wgrad_octets(x, du, n, cin, lddu, ldx, du_off=0, x_off=0):
+    """mirror of wgrad_octets (csrc/ly_backward.hip): the 16-byte staging form applies — bf16 storage, widths / strides / addresses in whole
+    8-channel vectors"""
+    return (x.dtype == torch.bfloat16 and n % 8 == 0 and cin % 8 == 0 and lddu % 8 == 0 and ldx % 8 == 0
+            and (du.data_ptr() + 2 * du_off) % 16 == 0 and (x.data_ptr() + 2 * x_off) % 16 == 0)
+
+
+def wgrad_kernel_name(t, n, ktot, rows, tiled, pro=False, octets=False):
     """mirror of the tile dispatch in csrc/ly_backward.hip (wgrad_dispatch): the kernel name rocprofv3 prints"""
     r = "true" if rows else "false"
     if not tiled:
@@ -1202,7 +1218,7 @@ def wgrad_kernel_name(t, n, ktot, rows, tiled, pro=False):
         bn, bk = 64, 128
     else:
         bn, bk = 128, 128
-    return f"ly_wgrad_tiled_kernel<{t}, {bn}, {bk}, {px}, {r}, {'true' if pro and rows else 'false'}>"
+    return f"ly_wgrad_tiled_kernel<{t}, {bn}, {bk}, {px}, {r}, {'true' if pro and rows else 'false'}, {'true' if octets else 'false'}>"
 
 
 def sum_rows(t, out=None, accumulate=False):

@@ -9,16 +9,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_named_kernel_is_row_0_of_the_committed_step_table():
     """the default line's `roofline.kernel` is the top kernel by time per step — the first kernel row of the round's committed per-step table
-    (profiles/r05_train_bf16_step_kernels.txt: one steady-state eager step of the same command)"""
-    path = os.path.join(ROOT, "profiles", "r05_train_bf16_bench.json")
-    table = os.path.join(ROOT, "profiles", "r05_train_bf16_step_kernels.txt")
+    (profiles/r06_train_bf16_step_kernels.txt: one steady-state eager step of the same command)"""
+    path = os.path.join(ROOT, "profiles", "r06_train_bf16_bench.json")
+    table = os.path.join(ROOT, "profiles", "r06_train_bf16_step_kernels.txt")
     if not (os.path.exists(path) and os.path.exists(table)):
-        pytest.skip("round-5 profiles not committed yet")
+        pytest.skip("round-6 profiles not committed yet")
     d = json.loads([ln for ln in open(path).read().splitlines() if ln.startswith("{")][-1])
     rows = [ln for ln in open(table).read().splitlines()[1:] if ln.strip()]
     name = d["roofline"]["kernel"]
     assert rows[0].startswith(name) and d["roofline"]["frac"] == d["roofline"]["hbm_frac"]
     # the whole-process rocprofv3 trace of the same command (kernel-trace --stats, per step) names the same kernel first
-    trace = os.path.join(ROOT, "profiles", "r05_train_bf16_kernels_per_step.txt")
+    trace = os.path.join(ROOT, "profiles", "r06_train_bf16_kernels_per_step.txt")
     if os.path.exists(trace):
         assert [ln for ln in open(trace).read().splitlines()[1:] if ln.strip()][0].startswith(name)

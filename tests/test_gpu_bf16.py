@@ -426,7 +426,7 @@ def test_configs2_full_size_graphed_step():
       (a) the replayed graph's loss equals the eager step's loss from the same restored state (float sums of the loss kernel);
       (b) every gradient-carrying state tensor (weights, momentum buffers, EMA) is finite after the step, the weights moved, and the replay
           and two eager steps leave the same bits;
-      (c) train-mode BatchNorm couples the images of a batch, eval mode does not: two sampled images of the batch replayed ALONE
+      (c) train-mode BatchNorm couples the images of a batch, eval mode does not: eight sampled images of the batch replayed ALONE
           through the fp32 oracle in eval mode agree with the HIP model's rows of the full batch within the whole-model bf16 bound."""
     import lead_yolo_amd as L
     from lead_yolo_amd import pack
@@ -492,7 +492,7 @@ def test_configs2_full_size_graphed_step():
     with torch.no_grad():
         with torch.autocast("cuda", dtype=BF):
             z, _ = m(imgs.float() / 255)
-        for i in (5, 41):
+        for i in (0, 5, 13, 22, 31, 41, 50, 63):
             zo, _ = OF.model_forward(copy.deepcopy(so), cfg, imgs[i:i + 1].cpu().float() / 255, m.stride, training=False)
             _close(z[i:i + 1], zo, f"configs[2] image {i} of the bs=64 batch", rel=5 * REL_L2, mx=8 * MAX_REL)
 

@@ -88,14 +88,18 @@ __global__ __launch_bounds__(LY_THREADS) void ly_bnact_bwd_reduce_kernel(const T
   if (j0 < groups) {
     const f32x4 av = ly_ldg4(a + 4 * cv), bv = ly_ldg4(b + 4 * cv);
     constexpr int UR = 4;
-    const long stride = (long)gridDim.x * groups;
+    // round 6: rows walked in per-XCD ranges, as the forward / apply passes do (LY_XCD_ROWS: XCD x's blocks take the x-th eighth of the rows) —
+    // dy was just written by a tile kernel whose tiles of these rows ran on the same XCD (ly_xcd_remap): with the plain grid-stride order every
+    // row was fetched past the reading block's L2
+    LY_XCD_ROWS(rows, groups);
+    const long stride = xw_step;
     const T* const dyb = second ? dy2 + (4 * cv - csplit) : dy + 4 * cv;      // (a selected base pointer: no load under a branch)
     const long ldd = second ? lddy2 : lddy;
-    for (long r0 = (long)blockIdx.x * groups + j0; r0 < rows; r0 += UR * stride) {
+    for (long r0 = xw_begin + j0; r0 < xw_end; r0 += UR * stride) {
       R4 qu[UR], qg[UR];
 #pragma unroll
       for (int k = 0; k < UR; ++k) {
-        const long r = r0 + k * stride < rows ? r0 + k * stride : rows - 1;
+        const long r = r0 + k * stride < xw_end ? r0 + k * stride : xw_end - 1;
         qu[k] = ly_ldr4<T>(u + r * ldu + 4 * cv);
         qg[k] = ly_ldr4<T>(dyb + r * ldd);
       }
@@ -103,7 +107,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_bnact_bwd_reduce_kernel(const T
       for (int k = 0; k < UR; ++k) {
         const f32x4 uu = ly_r4_f32(qu[k]);
         f32x4 dv = ly_dact4<ACT>(av * uu + bv, ly_r4_f32(qg[k]));
-        if (!(r0 + k * stride < rows)) dv = ly_zero4();
+        if (!(r0 + k * stride < xw_end)) dv = ly_zero4();
         s1 += dv;
         s2 += dv * uu;
       }
@@ -282,6 +286,7 @@ static int bnact_bwd_reduce_launch(const void* dy_, int lddy, const void* dy2_, 
 #endif
   long blocks = (rows + groups * (long)LY_RED_ROWS - 1) / (groups * (long)LY_RED_ROWS);
   blocks = blocks < 1 ? 1 : blocks > 2048 ? 2048 : blocks;
+  if (blocks >= 8) blocks = (blocks + 7) / 8 * 8;           // every XCD eighth of the rows has its blocks (LY_XCD_ROWS)
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define LY_RED(A) hipLaunchKernelGGL((ly_bnact_bwd_reduce_kernel<T, A>), dim3((unsigned)blocks), dim3(LY_THREADS), 0, st, dy, lddy, u, ldu, rows, C, a, b, sums, dy2, lddy2, csplit, sums2)
   LY_WITH_T(dtype, {

@@ -806,7 +806,7 @@ def main():
         else:
             if args.layers:
                 print_layers(rows)
-            roof = roofline_of(rows, args.dtype, step_roof.get("families"), committed_row0(args.dtype) if args.mode == "train" else None)
+            roof = roofline_of(rows, args.dtype, step_roof.get("families"), committed_row0(args.dtype) if (args.mode == "train" and args.batch == 64 and args.size == 640 and args.scale == "s") else None)
             roof["step"] = step_roof
             if ctx.world == 1 and not args.no_secondary:
                 del res["step"]

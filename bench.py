@@ -358,7 +358,7 @@ def pconv_rfcbam_probe(model, x, dtype, iters=10):
 BLOCK_FUSED_ELEMS_PER_IMG = {"s": 21_350_000}
 
 FAMILIES = (("rfcbam", ("ly_rf", "ly_se_", "ly_chan_moments", "ly_colsum")),
-            ("wgrad", ("ly_wgrad", "ly_patch4_rows")),
+            ("wgrad", ("ly_wgrad", "ly_patch4_rows", "ly_patch4_wgrad")),
             ("gemm", ("ly_gemm_kernel",)),
             ("bnact", ("ly_bnact", "ly_bn_")),
             ("mlpblock", ("ly_mlp",)),

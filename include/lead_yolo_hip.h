@@ -405,6 +405,13 @@ int ly_sum_rows(const float* src, long R, long C, long ld, float* dst, int accum
  * the `imgs` of train.py:309 before `.float() / 255`): rows[m][c*16 + ky*4 + kx] = (T)img[n, c, 4*ho+ky, 4*wo+kx], m = (n*Ho + ho)*Wo + wo.
  * Integer values (exact in bf16); the caller scales the weight gradient by 1/255.                                                          */
 int ly_patch4_rows_u8(const unsigned char* img, int n_img, int C, int H, int W, void* rows /*T [n*H/4*W/4][16*C]*/, int dtype, void* stream);
+/* PatchEmbed's weight gradient straight from the uint8 image (round 6; the same reference lines: PatchEmbed_FasterNet's Conv2d(3, N, 4, 4) under
+ * autograd, models/common.py:1537-1550, train.py:327): dw[n][c*16 + ky*4 + kx] += scale * sum_m du[m][n] * img[n_img(m), c, 4*ho+ky, 4*wo+kx],
+ * m = (n_img*Ho + ho)*Wo + wo — no space-to-depth copy.  bf16 du [M][lddu] (dtype = LY_BF16), C = 3, N a multiple of 8 up to 64; blocks leave
+ * [N][48] partials in `slab` (at least 1536*N*48 floats, or units*N*48 for M/128 < 1536 units) which are folded in block order
+ * (ly_sum_rows): no atomics.  scale = 1/255 for the `imgs / 255` of train.py:309.                                                           */
+int ly_patch4_wgrad_u8(const unsigned char* img, int n_img, int C, int H, int W, const void* du /*bf16*/, int lddu, int N, float scale, float* slab,
+                       long slab_floats, float* dw /*[N][16*C], += */, int dtype, void* stream);
 
 /* CoordAtt backward (models/common.py:1595-1609).  Gate out = x*a_h[n,h,:]*a_w[n,w,:]:
  *   dx = dout*a_h*a_w,  da_h[n,h,c] = sum_w dout*x*a_w,  da_w[n,w,c] = sum_h dout*x*a_h — written as PARTIAL sums, one plain store per

@@ -138,6 +138,7 @@ SIGNATURES = {
     "ly_up2_bwd": [_P, _I, _I, _I, _I, _I, _P, _I, _I, _P],
     "ly_unpatch": [_P, _I, _I, _I, _I, _I, _P, _I, _P],
     "ly_patch4_rows_u8": [_P, _I, _I, _I, _I, _P, _I, _P],
+    "ly_patch4_wgrad_u8": [_P, _I, _I, _I, _I, _P, _I, _I, _F, _P, ctypes.c_long, _P, _I, _P],
     "ly_coordatt_gate_bwd": [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _I, _I, _I, _P],
     "ly_pool_hw_bwd": [_P, _I, _I, _I, _I, _P, _I, _I, _I, _P],
     "ly_maxpool_bwd": [_P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P],

@@ -189,3 +189,163 @@ int ly_patch4_try(const LyGemmParams& P, hipStream_t st) {
   }
   return 1;
 }
+
+// -------------------------------------------------------------------------------------------------
+// PatchEmbed's WEIGHT GRADIENT straight from the uint8 image (round 6; models/common.py:1537-1550 under autograd, train.py:327):
+//     dW[n][(c, ky, kx)] += scale * sum_m du[m][n] * img[n_img(m)][c][4 ho(m) + ky][4 wo(m) + kx]
+// Before: ly_patch4_rows_u8 wrote the space-to-depth rows [M][48] in the storage type (157 MB at bs = 64, 640 x 640) and ly_wgrad read
+// them back beside du — 57 + 84 us for 157 MB of inputs that matter.  Here a block walks units of 128 consecutive output pixels: the unit's
+// du rows (16-byte loads) and its twelve (channel, ky) image row pieces (4-byte loads: the four kx of a patch) are written TRANSPOSED into
+// LDS — duT[channel][pixel], rowsT[(c, ky, kx)][pixel], the pixel values as the integers they are (exact in bf16) — so that both MFMA operands
+// of the contraction over pixels are plain 8-byte row reads (k-set of ly_tile.hpp: pixels 32 s + 4 q + {0..3} and + 16); wave w contracts
+// k-step w of the unit.  The waves' accumulators meet in LDS when the walk ends; the block stores ONE [N][48] partial (times `scale`,
+// 1/255) and ly_sum_rows folds the partials in block order: no atomics, the same bits in every run.
+// -------------------------------------------------------------------------------------------------
+#define LY_P4W_PX 128
+template <int MTN>
+__global__ __launch_bounds__(LY_THREADS) void ly_patch4_wgrad_u8_kernel(const unsigned char* __restrict__ img, const int H, const int W, const long M,
+                                                                        const __bf16* __restrict__ du, const int lddu, const int N, const float scale,
+                                                                        float* __restrict__ slab) {
+  constexpr int KE = 48, NTL = MTN * 3;
+  constexpr int RS = (LY_P4W_PX + 8) * 2;                      // bytes per LDS row: 272 (68 dwords: a 32-lane fragment read covers the 64 banks once)
+  constexpr int TILE_B = (MTN * 16 + KE) * RS, RED_B = 4 * NTL * 1024;
+  __shared__ __attribute__((aligned(16))) char lds[TILE_B > RED_B ? TILE_B : RED_B];
+  char* const dut = lds;
+  char* const rwt = lds + MTN * 16 * RS;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lq = lane >> 4;
+  const int Wo = W >> 2, Ho = H >> 2;
+  const int HWo = Ho * Wo;
+  const float invHWo = 1.f / (float)HWo, invWo = 1.f / (float)Wo;
+  const long units = (M + LY_P4W_PX - 1) / LY_P4W_PX;
+  const int NV8 = N >> 3;                                      // 16-byte vectors per du row
+  // rows N .. 16 MTN - 1 of duT are never written: zero once
+  for (int i = tid; i < (MTN * 16 - N) * (RS / 4); i += LY_THREADS) reinterpret_cast<unsigned*>(dut + N * RS)[i] = 0u;
+
+  // staging plan.  image: item = tid + 256 e -> row r = (c, ky) = tid / 128 + 2 e, pixel j = tid % 128 (one pixel per thread: one index
+  // decomposition per unit); du: item -> (pixel, vector)
+  const int j = tid & (LY_P4W_PX - 1), r0 = tid >> 7;
+  unsigned iv[6];
+  constexpr int ND = MTN;                                    // 16-byte du items per thread: 128 pixels x (N / 8 <= 2 MTN) vectors over 256 threads
+  ly_u32x4 dv[ND];
+  auto prefetch = [&](const long unit) {
+    const long m = unit * LY_P4W_PX + j;
+    const bool ok = m < M;
+    const int mc = (int)(ok ? m : M - 1);
+    const int n = ly_fdiv(mc, HWo, invHWo);
+    const int rem = mc - n * HWo;
+    const int ho = ly_fdiv(rem, Wo, invWo), wo = rem - ho * Wo;
+    const unsigned char* const p0 = img + ((long)n * 3 * H + 4 * ho) * W + 4 * wo;
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+      const int r = r0 + 2 * e, c = r >> 2, ky = r & 3;
+      iv[e] = *reinterpret_cast<const unsigned*>(p0 + ((long)c * H + ky) * W);
+    }
+#pragma unroll
+    for (int e = 0; e < ND; ++e) {
+      const int item = tid + LY_THREADS * e;
+      const int px = item / NV8, v = item - px * NV8;
+      const long mm = unit * LY_P4W_PX + px;
+      const bool okd = px < LY_P4W_PX && mm < M;
+      dv[e] = *reinterpret_cast<const ly_u32x4*>(du + (okd ? mm * lddu + 8 * v : 0));
+    }
+  };
+  auto commit = [&](const long unit) {
+    const bool ok = unit * LY_P4W_PX + j < M;
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+      const int r = r0 + 2 * e;
+      const unsigned v = ok ? iv[e] : 0u;
+      __bf16* const d = reinterpret_cast<__bf16*>(rwt + (4 * r) * RS) + j;
+      d[0] = (__bf16)(float)(v & 255u);
+      d[RS / 2] = (__bf16)(float)((v >> 8) & 255u);
+      d[2 * (RS / 2)] = (__bf16)(float)((v >> 16) & 255u);
+      d[3 * (RS / 2)] = (__bf16)(float)(v >> 24);
+    }
+#pragma unroll
+    for (int e = 0; e < ND; ++e) {
+      const int item = tid + LY_THREADS * e;
+      const int px = item / NV8, v = item - px * NV8;
+      if (px < LY_P4W_PX) {
+        const bool okd = unit * LY_P4W_PX + px < M;
+        unsigned short* const d = reinterpret_cast<unsigned short*>(dut + (8 * v) * RS) + px;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const unsigned w2 = okd ? dv[e][k] : 0u;
+          d[(2 * k) * (RS / 2)] = (unsigned short)(w2 & 0xffffu);
+          d[(2 * k + 1) * (RS / 2)] = (unsigned short)(w2 >> 16);
+        }
+      }
+    }
+  };
+
+  f32x4 acc[MTN][3];
+#pragma unroll
+  for (int t = 0; t < MTN; ++t)
+#pragma unroll
+    for (int n = 0; n < 3; ++n) acc[t][n] = ly_zero4();
+  long unit = blockIdx.x;
+  if (unit < units) prefetch(unit);
+  const int koff = 2 * (32 * wave + 4 * lq);                   // the wave's k-step, the lane's first pixel group (bytes)
+  for (; unit < units; unit += gridDim.x) {
+    __syncthreads();                                           // the previous unit's fragment reads are done
+    commit(unit);
+    const long nxt = unit + gridDim.x < units ? unit + gridDim.x : unit;      // (the last unit re-requests itself: straight-line loads)
+    prefetch(nxt);
+    __syncthreads();
+    bf16x8 a[MTN], b[3];
+#pragma unroll
+    for (int t = 0; t < MTN; ++t) {
+      const char* p = dut + (16 * t + li) * RS + koff;
+      a[t] = ly_cat8(*reinterpret_cast<const bf16x4*>(p), *reinterpret_cast<const bf16x4*>(p + 32));
+    }
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+      const char* p = rwt + (16 * n + li) * RS + koff;
+      b[n] = ly_cat8(*reinterpret_cast<const bf16x4*>(p), *reinterpret_cast<const bf16x4*>(p + 32));
+    }
+#pragma unroll
+    for (int t = 0; t < MTN; ++t)
+#pragma unroll
+      for (int n = 0; n < 3; ++n) acc[t][n] = ly_mfma_bf16(a[t], b[n], acc[t][n]);
+  }
+  // the four waves' partial tiles meet in LDS; D: lane (i = column l & 15, q) holds rows 4 q + r
+  __syncthreads();
+  float* const red = reinterpret_cast<float*>(lds);
+#pragma unroll
+  for (int t = 0; t < MTN; ++t)
+#pragma unroll
+    for (int n = 0; n < 3; ++n) *reinterpret_cast<f32x4*>(red + ((wave * NTL + t * 3 + n) * 64 + lane) * 4) = acc[t][n];
+  __syncthreads();
+  float* const out = slab + (long)blockIdx.x * N * KE;
+  for (int o = tid; o < NTL * 256; o += LY_THREADS) {
+    const float s = (red[o] + red[NTL * 256 + o]) + (red[2 * NTL * 256 + o] + red[3 * NTL * 256 + o]);
+    const int tile = o >> 8, l = (o >> 2) & 63, rr = o & 3;
+    const int row = 16 * (tile / 3) + 4 * (l >> 4) + rr, col = 16 * (tile % 3) + (l & 15);
+    if (row < N) out[row * KE + col] = s * scale;
+  }
+}
+
+extern "C" int ly_patch4_wgrad_u8(const unsigned char* img, int n_img, int C, int H, int W, const void* du, int lddu, int N, float scale, float* slab,
+                                  long slab_floats, float* dw, int dtype, void* stream) {
+  LY_CHECK(img && du && slab && dw && n_img > 0 && H > 0 && W > 0, "patch4_wgrad_u8: bad arguments");
+  LY_CHECK(C == 3 && (H & 3) == 0 && (W & 3) == 0, "patch4_wgrad_u8: built for RGB images with H, W multiples of 4 (C=%d H=%d W=%d)", C, H, W);
+  LY_CHECK(dtype == LY_BF16, "patch4_wgrad_u8: bf16 gradients only (fp32 storage keeps ly_patch4_rows_u8 + ly_wgrad)");
+  LY_CHECK(N >= 8 && N <= 64 && (N & 7) == 0 && (lddu & 7) == 0 && ((uintptr_t)du & 15) == 0 && ((uintptr_t)img & 3) == 0,
+           "patch4_wgrad_u8: N=%d must be a multiple of 8 up to 64, du rows 16-byte aligned", N);
+  const long M = (long)n_img * (H >> 2) * (W >> 2);
+  LY_CHECK(M < (1L << 24), "patch4_wgrad_u8: M=%ld pixels exceeds the 2^24 limit of the fast index path", M);
+  const long units = (M + LY_P4W_PX - 1) / LY_P4W_PX;
+  long blocks = units < 1536 ? units : 1536;                   // six 22-24 KB blocks per CU
+  LY_CHECK(blocks * N * 48 <= slab_floats, "patch4_wgrad_u8: the slab holds %ld floats, %ld needed", slab_floats, blocks * N * 48);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const __bf16* d = reinterpret_cast<const __bf16*>(du);
+  const int mtn = (N + 15) / 16;
+  if (mtn == 1) hipLaunchKernelGGL((ly_patch4_wgrad_u8_kernel<1>), dim3((unsigned)blocks), dim3(LY_THREADS), 0, st, img, H, W, M, d, lddu, N, scale, slab);
+  else if (mtn == 2) hipLaunchKernelGGL((ly_patch4_wgrad_u8_kernel<2>), dim3((unsigned)blocks), dim3(LY_THREADS), 0, st, img, H, W, M, d, lddu, N, scale, slab);
+  else if (mtn == 3) hipLaunchKernelGGL((ly_patch4_wgrad_u8_kernel<3>), dim3((unsigned)blocks), dim3(LY_THREADS), 0, st, img, H, W, M, d, lddu, N, scale, slab);
+  else hipLaunchKernelGGL((ly_patch4_wgrad_u8_kernel<4>), dim3((unsigned)blocks), dim3(LY_THREADS), 0, st, img, H, W, M, d, lddu, N, scale, slab);
+  LY_LAUNCH_CHECK();
+  return ly_sum_rows(slab, blocks, (long)N * 48, (long)N * 48, dw, 1, stream);
+}

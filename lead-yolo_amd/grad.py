@@ -148,6 +148,13 @@ def conv_wgrad(spec, du, x0, x1, weight):
             # A uint8 image (pixel / 255 folded into the forward gather) is contracted as the integers it holds — exact in bf16 —
             # and the 1/255 is applied to the small weight gradient instead of to the batch.
             u8 = x0.dtype == torch.uint8
+            if u8 and k == 4 and co == nv and dw.is_contiguous() and ops.patch4_wgrad_u8_ok(x0, du, co):
+                # round 6: straight from the image — no space-to-depth rows (157 MB written and read back at bs = 64), no scratch, no add
+                ops.patch4_wgrad_u8(x0, du, co, co, dw, 1.0 / 255.0)
+                if tgt is not None:
+                    ops.grad_done(weight)
+                    return None
+                return dw
             if u8 and k == 4 and x0.is_contiguous():
                 xr = ops.patch4_rows_u8(x0, du.dtype)                # one pass (was a permuted copy + a cast)
             else:

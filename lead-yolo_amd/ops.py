@@ -1259,6 +1259,27 @@ def patch4_rows_u8(img, dtype):
     return rows
 
 
+def patch4_wgrad_u8_ok(img, du, n_out):
+    """ly_patch4_wgrad_u8 applies: contiguous uint8 RGB batch with H, W multiples of 4, bf16 gradient rows of a vector-friendly width, and the
+    weight-gradient workspace of the device holds the per-block partials"""
+    n, c, h, w = img.shape
+    ws = wgrad_workspace(img.device)
+    return (img.dtype == torch.uint8 and img.is_contiguous() and c == 3 and h % 4 == 0 and w % 4 == 0 and du.dtype == torch.bfloat16
+            and n_out % 8 == 0 and 8 <= n_out <= 64 and du.data_ptr() % 16 == 0 and ws is not None and ws.numel() >= 1536 * n_out * 48
+            and n * (h // 4) * (w // 4) < (1 << 24))
+
+
+def patch4_wgrad_u8(img, du, lddu, n_out, dw, scale):
+    """dw [n_out][48] (fp32) += scale * sum over output pixels of du (x) the 4 x 4 patches of the uint8 image (csrc/ly_patch4.hip): the
+    PatchEmbed weight gradient without the space-to-depth rows"""
+    n, c, h, w = img.shape
+    m = n * (h // 4) * (w // 4)
+    ws = wgrad_workspace(img.device)
+    with _Timed("ly_patch4_wgrad_u8_kernel", 2.0 * m * n_out * 48, 1.0 * n * c * h * w + 2.0 * m * n_out + 4.0 * n_out * 48):
+        capi.check(capi.lib().ly_patch4_wgrad_u8(_p(img), n, c, h, w, _p(du), lddu, n_out, float(scale), _p(ws), ws.numel(), _p(dw), capi.dtype_code(du),
+                                                 capi.stream_ptr()), "ly_patch4_wgrad_u8")
+
+
 def coordatt_gate_bwd(dout, x, ldx, n, h, w, c, a_h, a_w, ldd=None):
     """dout: rows of the incoming gradient with row stride ldd (default c: dense) — a channel slice of a wider gradient is read in place"""
     ldd = c if ldd is None else ldd

@@ -1105,6 +1105,33 @@ def test_batchnorm_statistics_with_large_mean(offset):
     assert torch.allclose(rm, stt["norm.running_mean"], rtol=1e-4, atol=1e-4) and torch.allclose(rv, stt["norm.running_var"], rtol=2e-3, atol=1e-4), offset
 
 
+@pytest.mark.parametrize("n,h,w,nout", [(3, 64, 64, 24), (2, 52, 76, 24), (1, 640, 640, 24), (5, 36, 44, 40), (2, 48, 48, 16), (2, 40, 56, 64)])
+def test_patch4_wgrad_from_the_uint8_image(n, h, w, nout):
+    """PatchEmbed's weight gradient straight from the uint8 batch (ly_patch4_wgrad_u8: no space-to-depth rows) against the contraction it
+    replaces, written out in fp64: dw[o][c, ky, kx] = sum_m du[m][o] * img[n, c, 4 ho + ky, 4 wo + kx] / 255; ragged last units, one to
+    four output-channel tiles; added onto what dw held; two launches return the same bits (fixed-order fold of the block partials)"""
+    from lead_yolo_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(100 * n + nout)
+    img = torch.randint(0, 256, (n, 3, h, w), generator=g, dtype=torch.uint8).to(dev)
+    ho, wo = h // 4, w // 4
+    m = n * ho * wo
+    du = (torch.randn(m, nout, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    assert ops.patch4_wgrad_u8_ok(img, du, nout)
+    base = torch.randn(nout, 48, generator=g).to(dev)
+    rows = img.reshape(n, 3, ho, 4, wo, 4).permute(0, 2, 4, 1, 3, 5).reshape(m, 48).double()
+    want = base.double() + du.double().t() @ rows / 255.0
+    outs = []
+    for _ in range(2):
+        dw = base.clone()
+        ops.patch4_wgrad_u8(img, du, nout, nout, dw, 1.0 / 255.0)
+        torch.cuda.synchronize()
+        outs.append(dw)
+    scale = want.abs().max().item()
+    assert (outs[0].double() - want).abs().max().item() <= 2e-5 * scale + 1e-5, ((outs[0].double() - want).abs().max().item(), scale)
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("n,h,w,cin,cout,cvalid,ldx", [(2, 16, 16, 64, 64, 64, 64), (3, 20, 20, 128, 96, 128, 128), (1, 13, 27, 32, 200, 32, 32),
                                                       (2, 40, 24, 8, 8, 6, 24), (2, 9, 11, 40, 40, 40, 160), (1, 80, 80, 64, 64, 64, 64)])
 def test_wgrad3_halo_kernel(n, h, w, cin, cout, cvalid, ldx):

@@ -1702,6 +1702,22 @@ __device__ __forceinline__ void ly_fold_stripes(const TS* __restrict__ p, const 
   s1 = 0.0;
   s2 = 0.0;
   int q = 0;
+  if (stripes == LY_STATS_STRIPES) {
+    // the usual case: all 2 x 32 loads of the channel in flight together, folded in stripe order (in batches of eight the fold was four
+    // dependent memory round trips: the atomics' results come from the memory side)
+    TS a[LY_STATS_STRIPES], b[LY_STATS_STRIPES];
+#pragma unroll
+    for (int k = 0; k < LY_STATS_STRIPES; ++k) {
+      a[k] = p[(size_t)k * stride];
+      b[k] = p[(size_t)k * stride + second];
+    }
+#pragma unroll
+    for (int k = 0; k < LY_STATS_STRIPES; ++k) {
+      s1 += (double)a[k];
+      s2 += (double)b[k];
+    }
+    return;
+  }
   for (; q + 8 <= stripes; q += 8) {
     TS a[8], b[8];
 #pragma unroll

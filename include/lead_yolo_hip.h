@@ -106,6 +106,10 @@ typedef struct LyGemmParams {
                              otherwise stores act(that value) as usual (one launch for statistics + pre-BN tensor) */
   int dtype;              /* LY_F32 / LY_BF16: element type T of a0, a1, res, out.  LY_GATHER_PATCH_NCHW(_U8 / _BF16 / _F16) reads an fp32 (uint8 / 16-bit)
                              IMAGE whatever dtype is (dtype then only selects the output element type)             */
+  int scat_ks, scat_c;    /* scat_ks > 0 (round 6): the adjoint of the k = s patch gather folded into the store — output column
+                             (ky*scat_ks + kx)*scat_c + c of row m = (n, h, w) goes to out[((n*ks*H + ks*h + ky)*ks*W + ks*w + kx)*ldo + c]
+                             (N = ks*ks*scat_c, scat_c % 4 == 0; the data gradient of PatchMerging_FasterNet, models/common.py:1553-1561,
+                             without the [M][ks*ks*c] intermediate).  0: plain rows                                  */
 } LyGemmParams;
 
 /* out[m, n] = act(rowscale[m] * e_scale[n] * sum_k A'[m, k] W[n, k] + e_shift[n]).

@@ -34,6 +34,13 @@ extern "C" int ly_gemm_fwd(const LyGemmParams* p, void* stream) {
   if (P.pro == LY_PRO_AFFINE_RELU_CA) LY_CHECK(P.p_scale && P.p_shift && P.p_ca && P.rowscale, "gemm: affine prologue needs scale/shift/ca and rowscale");
   else LY_CHECK(!P.rowscale, "gemm: rowscale is only built together with the affine (RFCBAM k=1) prologue");
   LY_CHECK(P.M < (1L << 24), "gemm: M=%ld pixels exceeds the 2^24 limit of the fast index path", P.M);
+  if (P.scat_ks) {
+    // the scatter store lives in the branch-free epilogue only: plain rows in, no prologue, no statistics, vector-friendly widths
+    LY_CHECK(P.scat_ks > 0 && P.scat_c > 0 && (P.scat_c & 3) == 0 && P.N == P.scat_ks * P.scat_ks * P.scat_c, "gemm: scatter store needs N = ks*ks*c, c %% 4 == 0 (ks=%d c=%d N=%d)",
+             P.scat_ks, P.scat_c, P.N);
+    LY_CHECK(P.gather == LY_GATHER_ROWS && P.pro == LY_PRO_NONE && !P.stats && P.out && (P.ldo & 3) == 0 && P.M == (long)(P.M / ((long)P.H * P.W)) * P.H * P.W,
+             "gemm: scatter store is built for plain-row sources without prologue / statistics, M a whole number of H x W maps");
+  }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (ly_patch4_try(P, st)) {                              // PatchEmbed on an RGB image: its own LDS-free kernel (ly_patch4.hip)
     LY_LAUNCH_CHECK();

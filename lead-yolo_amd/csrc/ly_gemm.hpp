@@ -370,9 +370,32 @@ __device__ __forceinline__ void ly_gemm_body2(const LyGemmParams& P, const int g
       // past M and channel quads past N go to a scratch line).  A store under a branch — even an exec-skip around a masked store — leaves the compiler
       // two vmcnt histories to merge, and the next item's wait for its prefetch then also waits for these stores to be
       // acknowledged: a full memory round trip at every tile end.
+      // scat_ks > 0: the store IS the adjoint of a k = s patch gather (LyGemmParams.scat_ks): row m = (n, h, w), column group (ky, kx) -> the
+      // pixel (ks h + ky, ks w + kx) of the ks-times larger map.  Only addresses change; the store itself stays unconditional.
+      // (FAST == 3: an instantiation of its own — as a run-time switch its address registers cost the resident variants spills)
+      long srow[FAST == 3 ? NT : 1];
+      if constexpr (FAST == 3) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const long gp = p0 + pixgrp + 16 * n + li;
+          const int g = (int)(gp < P.M ? gp : P.M - 1);
+          const int ni = ly_fdiv(g, HW, invHW);
+          const int rem = g - ni * HW;
+          const int h = ly_fdiv(rem, P.W, invW), w = rem - h * P.W;
+          srow[n] = ((long)ni * (P.scat_ks * P.H) + P.scat_ks * h) * (P.scat_ks * P.W) + P.scat_ks * w;
+        }
+      }
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
         const int cc = 16 * ((by * WC + wc) * MT + t) + 4 * lq;
+        long soff = 0;
+        int scol = cc;
+        if constexpr (FAST == 3) {
+          const int grp = cc / P.scat_c;
+          scol = cc - grp * P.scat_c;
+          const int ky = grp / P.scat_ks, kx = grp - ky * P.scat_ks;
+          soff = (long)ky * (P.scat_ks * P.W) + kx;
+        }
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
           const long gp = p0 + pixgrp + 16 * n + li;
@@ -387,7 +410,9 @@ __device__ __forceinline__ void ly_gemm_body2(const LyGemmParams& P, const int g
             sum2[t] += um * um;
           }
           const f32x4 v = ly_act4(u, act);
-          TO* o = ok ? out + gp * P.ldo + cc : reinterpret_cast<TO*>(ly_gemm_trash) + 4 * lane;
+          long orow = gp;
+          if constexpr (FAST == 3) orow = srow[n] + soff;
+          TO* o = ok ? out + orow * P.ldo + scol : reinterpret_cast<TO*>(ly_gemm_trash) + 4 * lane;
           ly_st4<TO>(o, v);
           acc[t][n] = zero;
         }
@@ -494,7 +519,8 @@ static int launch_gemm_d2(const LyGemmParams& P, hipStream_t st) {
 }
 
 // Variant choice per call.  K in one or two chunks: weights resident (NCH) and, when every channel tile is full and the stores can be
-// vectors, the branch-free epilogue (FAST 1; 2 = with the BatchNorm sums of the training forward kept in registers).
+// vectors, the branch-free epilogue (FAST 1; 2 = with the BatchNorm sums of the training forward kept in registers; 3 = FAST 1 with the
+// scatter store of LyGemmParams.scat_ks).
 template <typename TI, typename TO, int NT, int MT, int WC, int GATHER, int PRO>
 static int launch_gemm_v(const LyGemmParams& P, hipStream_t st) {
   // which of the variants fit 256 registers without spilling into the loop (checked in the .s of every instantiation)
@@ -504,6 +530,16 @@ static int launch_gemm_v(const LyGemmParams& P, hipStream_t st) {
   constexpr bool oks2 = ok2 && PRO == LY_PRO_NONE;
   const int nchunk = (P.K + 16 * LyT<TI>::VW - 1) / (16 * LyT<TI>::VW);
   const bool fast = (P.N & 3) == 0 && (P.ldo & 3) == 0 && P.out;
+  if (P.scat_ks) {                                          // scatter store (ly_gemm_fwd checked: plain rows, no prologue, no statistics, fast widths)
+    if constexpr (GATHER == LY_GATHER_ROWS && PRO == LY_PRO_NONE) {
+      if constexpr (ok1) { if (nchunk == 1) return launch_gemm_d2<TI, TO, NT, MT, WC, GATHER, PRO, 1, 3>(P, st); }
+      if constexpr (ok2) { if (nchunk == 2) return launch_gemm_d2<TI, TO, NT, MT, WC, GATHER, PRO, 2, 3>(P, st); }
+      return launch_gemm_d2<TI, TO, NT, MT, WC, GATHER, PRO, 0, 3>(P, st);
+    } else {
+      ly_set_error("gemm: the scatter store is built for plain-row sources without a prologue");
+      return -1;
+    }
+  }
   if (fast && !P.stats) {
     if constexpr (ok1) { if (nchunk == 1) return launch_gemm_d2<TI, TO, NT, MT, WC, GATHER, PRO, 1, 1>(P, st); }
     if constexpr (ok2) { if (nchunk == 2) return launch_gemm_d2<TI, TO, NT, MT, WC, GATHER, PRO, 2, 1>(P, st); }

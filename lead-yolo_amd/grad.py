@@ -216,6 +216,11 @@ def conv_dgrad(spec, du, weight, x0, x1, need0, need1):
         k = spec.k
         # rows (ky, kx, c), columns co: the transposed patch matrix, read in place
         wt = pack.packed(pack.Src(weight, k * k * c, nrb=c, sra=1, srb=k * k, nc=co, sc=c * k * k), co, ops.planes_of(du))
+        if h == ho * k and w == wo * k and c % 4 == 0:
+            # round 6: the adjoint of the patch gather is the GEMM's store (LyGemmParams.scat_ks) — no [M][k*k*c] intermediate, no ly_unpatch pass
+            dx = ops.empty_nhwc(n, c, h, w, du)
+            ops.gemm(M=m, H=ho, W=wo, K=co, N=k * k * c, a0=du, lda0=co, k0=co, wp=wt, out=dx, ldo=c, scat_ks=k, scat_c=c)
+            return dx, None
         g = torch.empty((m, k * k * c), dtype=du.dtype, device=du.device)
         ops.gemm(M=m, H=ho, W=wo, K=co, N=k * k * c, a0=du, lda0=co, k0=co, wp=wt, out=g, ldo=k * k * c)
         return ops.unpatch(g, n, ho, wo, c, k, h, w), None

@@ -386,6 +386,9 @@ class ConvBnActPair(torch.autograd.Function):
         ops.bnact_fwd(u, co, rows, co, v[0], v[1], spec.act, y, co)
         ctx.spec = spec
         ctx.wt_src = pack.src_matrix_kcat_t(w1, w2)
+        if spec.up:                    # the lazily upsampled source's rows and the other source's rows as operands of their own
+            c0 = x0.shape[1]
+            ctx.wt_src = (pack.src_matrix_kcat_t(w1, w2, 0, c0), pack.src_matrix_kcat_t(w1, w2, c0, None) if x1 is not None else None)
         ctx.params = ((w1, g1, be1), (w2, g2, be2))
         ctx.save_for_backward(x0, x1, w1, w2, v, u)
         return y[:, :c_], y[:, c_:]
@@ -433,14 +436,20 @@ class ConvBnActPair(torch.autograd.Function):
                     ops.grad_done(b_p)
                 out[8 + 2 * i], out[9 + 2 * i] = dgamma, dbeta
             ops.bnact_bwd_apply_pair(dya, lda, dyb, ldb, c_, u, co, rows, co, v[0], v[1], spec.act, coef[0], coef[1], coef[2], du, co)
+            # A lazily 2x-upsampled source: the adjoint of the upsample (sum over each 2x2 block) commutes with the 1x1 convolution, so it is
+            # applied ONCE to du (co channels) and that source's weight and data gradients are plain contractions at a quarter of the rows —
+            # not an upsample-gathering weight gradient at full resolution plus a full-resolution data gradient folded afterwards.
+            hq, wq, rq = ho // 2, wo // 2, rows // 4
+            dup = ops.up2_bwd(du, co, n, hq, wq, co) if spec.up else None
+            p0 = (dict(M=rq, H=hq, W=wq, du=dup, lddu=co, x=t0, ldx=ld0, Hin=hq, Win=wq, Cin=c0, lddw=kin) if spec.up else
+                  dict(M=rows, H=ho, W=wo, du=du, lddu=co, x=t0, ldx=ld0, Hin=t0.shape[2], Win=t0.shape[3], Cin=c0, lddw=kin))
             for i in range(2):
                 off = i * c_
                 w_p = ctx.params[i][0]
                 if need[6 + i] and not stacked:
                     tgt = tw[i]
                     dw = tgt if tgt is not None else torch.zeros(w_p.shape, dtype=torch.float32, device=u.device)
-                    ops.wgrad(M=rows, H=ho, W=wo, N=c_, du=du, lddu=co, du_off=off, x=t0, ldx=ld0, Hin=t0.shape[2], Win=t0.shape[3], Cin=c0, dw=dw,
-                              lddw=kin, up2=spec.up)
+                    ops.wgrad(N=c_, du_off=off, dw=dw, **p0)
                     if t1 is not None:
                         ops.wgrad(M=rows, H=ho, W=wo, N=c_, du=du, lddu=co, du_off=off, x=t1, ldx=ld1, Hin=ho, Win=wo, Cin=t1.shape[1], dw=dw,
                                   lddw=kin, dw_off=c0)
@@ -449,25 +458,33 @@ class ConvBnActPair(torch.autograd.Function):
                     else:
                         out[6 + i] = dw
             if stacked:
-                probs = [dict(M=rows, H=ho, W=wo, N=co, du=du, lddu=co, x=t0, ldx=ld0, Hin=t0.shape[2], Win=t0.shape[3], Cin=c0, dw=tw[0], lddw=kin,
-                              up2=spec.up)]
+                probs = [dict(N=co, dw=tw[0], **p0)]
                 if t1 is not None:
                     probs.append(dict(M=rows, H=ho, W=wo, N=co, du=du, lddu=co, x=t1, ldx=ld1, Hin=ho, Win=wo, Cin=t1.shape[1], dw=tw[0], lddw=kin,
                                       dw_off=c0))
                 ops.wgrad_group(probs)
                 ops.grad_done(ctx.params[0][0])
                 ops.grad_done(ctx.params[1][0])
-            if need[4] or need[5]:
+            if spec.up:
+                pl = ops.planes_of(du)
+                if need[4]:
+                    out[4] = ops.empty_nhwc(n, c0, hq, wq, du)
+                    ops.gemm(M=rq, H=hq, W=wq, K=co, N=c0, a0=dup, lda0=co, k0=co, wp=pack.packed(ctx.wt_src[0], co, pl), out=out[4], ldo=c0)
+                if need[5] and x1 is not None:
+                    out[5] = ops.empty_nhwc(n, kin - c0, ho, wo, du)
+                    ops.gemm(M=rows, H=ho, W=wo, K=co, N=kin - c0, a0=du, lda0=co, k0=co, wp=pack.packed(ctx.wt_src[1], co, pl), out=out[5],
+                             ldo=kin - c0)
+            elif need[4] or need[5]:
                 pl = ops.planes_of(du)
                 d = ops.empty_nhwc(n, kin, ho, wo, du)
                 # [W1^T | W2^T] ([kin, 2c_]) read in place from the two parameters: ONE contraction over both halves of du
                 wt = pack.packed(ctx.wt_src, co, pl)
                 ops.gemm(M=rows, H=ho, W=wo, K=co, N=kin, a0=du, lda0=co, k0=co, wp=wt, out=d, ldo=kin)
                 if x1 is None:
-                    out[4] = ops.up2_bwd(d, kin, n, ho // 2, wo // 2, kin) if spec.up else d
+                    out[4] = d
                 else:
                     if need[4]:
-                        out[4] = ops.up2_bwd(d, kin, n, ho // 2, wo // 2, c0) if spec.up else d[:, :c0]
+                        out[4] = d[:, :c0]
                     if need[5]:
                         out[5] = d[:, c0:]
         return tuple(out)

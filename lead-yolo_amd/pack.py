@@ -280,15 +280,17 @@ def src_matrix(param, rows, cols, sr=None, sk=1, k_pad=None):
     return Src(param, rows, srb=cols * sk if sr is None else sr, nc=(k_pad or cols), vc=cols, sc=sk)
 
 
-def src_matrix_kcat_t(p1, p2):
+def src_matrix_kcat_t(p1, p2, r0=0, r1=None):
     """[kin, 2*c_] matrix [W1^T | W2^T] of two [c_, kin] weights (the data-gradient operand of two 1x1 convolutions over one input, C3_CA's
     cv1 / cv2), read in place from BOTH parameters: the column-block stride is the distance between the two allocations.  None when that
-    is not expressible (different devices / dtypes, a `.half()` shadow copy)."""
+    is not expressible (different devices / dtypes, a `.half()` shadow copy).  r0 / r1: rows [r0, r1) of it only (one source of a
+    concatenated input)."""
     m1, m2 = master(p1), master(p2)
     if m1 is not p1 or m2 is not p2 or p1.shape != p2.shape or p1.device != p2.device or (m2.data_ptr() - m1.data_ptr()) % 4:
         return None
     c_, kin = p1.shape[0], p1.numel() // p1.shape[0]
-    s = Src(p1, kin, srb=1, nb=2, nc=c_, sb=(m2.data_ptr() - m1.data_ptr()) // 4, sc=kin)
+    r1 = kin if r1 is None else r1
+    s = Src(p1, r1 - r0, base=r0, srb=1, nb=2, nc=c_, sb=(m2.data_ptr() - m1.data_ptr()) // 4, sc=kin)
     s._ref2 = weakref.ref(p2)
     s.ok = s.ok and p2.is_cuda and p2.dtype == torch.float32 and p2.is_contiguous()
     return s

@@ -110,6 +110,10 @@ typedef struct LyGemmParams {
                              (ky*scat_ks + kx)*scat_c + c of row m = (n, h, w) goes to out[((n*ks*H + ks*h + ky)*ks*W + ks*w + kx)*ldo + c]
                              (N = ks*ks*scat_c, scat_c % 4 == 0; the data gradient of PatchMerging_FasterNet, models/common.py:1553-1561,
                              without the [M][ks*ks*c] intermediate).  0: plain rows                                  */
+  const void* eadd; int ldeadd;  /* optional (T, same pixel order as out, row stride ldeadd): added to the value before the store — the gradient
+                             another consumer of the same tensor already produced, so autograd's sum of the two (one more read-read-write
+                             pass per shared tensor: the backbone / neck skip connections of models/LEAD-YOLO.yaml) is the store itself.
+                             Plain-row sources, no prologue, no statistics, N % 4 == 0 (as scat_ks)                    */
 } LyGemmParams;
 
 /* out[m, n] = act(rowscale[m] * e_scale[n] * sum_k A'[m, k] W[n, k] + e_shift[n]).

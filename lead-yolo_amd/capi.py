@@ -24,7 +24,7 @@ class LyGemmParams(ctypes.Structure):       # mirrors include/lead_yolo_hip.h
                 ("pro", _I), ("g_h", _P), ("g_w", _P), ("res", _P), ("ldres", _I),
                 ("p_scale", _P), ("p_shift", _P), ("p_ca", _P),
                 ("wp", _P), ("e_scale", _P), ("e_shift", _P), ("rowscale", _P), ("act", _I),
-                ("out", _P), ("ldo", _I), ("stats", _P), ("dtype", _I), ("scat_ks", _I), ("scat_c", _I)]
+                ("out", _P), ("ldo", _I), ("stats", _P), ("dtype", _I), ("scat_ks", _I), ("scat_c", _I), ("eadd", _P), ("ldeadd", _I)]
 
 
 class LyConv3Params(ctypes.Structure):

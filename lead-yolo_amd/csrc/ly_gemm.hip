@@ -34,6 +34,14 @@ extern "C" int ly_gemm_fwd(const LyGemmParams* p, void* stream) {
   if (P.pro == LY_PRO_AFFINE_RELU_CA) LY_CHECK(P.p_scale && P.p_shift && P.p_ca && P.rowscale, "gemm: affine prologue needs scale/shift/ca and rowscale");
   else LY_CHECK(!P.rowscale, "gemm: rowscale is only built together with the affine (RFCBAM k=1) prologue");
   LY_CHECK(P.M < (1L << 24), "gemm: M=%ld pixels exceeds the 2^24 limit of the fast index path", P.M);
+  if (P.eadd && !P.scat_ks) {                              // plain rows + eadd: the scatter epilogue with a 1 x 1 "patch" (identity addresses)
+    LyGemmParams Q = P;
+    Q.scat_ks = 1;
+    Q.scat_c = (P.N + 3) & ~3;
+    LY_CHECK((P.N & 3) == 0, "gemm: eadd needs N %% 4 == 0 (N=%d)", P.N);
+    return ly_gemm_fwd(&Q, stream);
+  }
+  if (P.eadd) LY_CHECK(P.ldeadd >= P.scat_c && (P.ldeadd & 3) == 0 && ((uintptr_t)P.eadd & (P.dtype == LY_BF16 ? 7 : 15)) == 0, "gemm: eadd must be a 4-element aligned row matrix (ldeadd=%d)", P.ldeadd);
   if (P.scat_ks) {
     // the scatter store lives in the branch-free epilogue only: plain rows in, no prologue, no statistics, vector-friendly widths
     LY_CHECK(P.scat_ks > 0 && P.scat_c > 0 && (P.scat_c & 3) == 0 && P.N == P.scat_ks * P.scat_ks * P.scat_c, "gemm: scatter store needs N = ks*ks*c, c %% 4 == 0 (ks=%d c=%d N=%d)",

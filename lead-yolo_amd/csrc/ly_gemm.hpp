@@ -373,8 +373,8 @@ __device__ __forceinline__ void ly_gemm_body2(const LyGemmParams& P, const int g
       // scat_ks > 0: the store IS the adjoint of a k = s patch gather (LyGemmParams.scat_ks): row m = (n, h, w), column group (ky, kx) -> the
       // pixel (ks h + ky, ks w + kx) of the ks-times larger map.  Only addresses change; the store itself stays unconditional.
       // (FAST == 3: an instantiation of its own — as a run-time switch its address registers cost the resident variants spills)
-      long srow[FAST == 3 ? NT : 1];
-      if constexpr (FAST == 3) {
+      long srow[FAST >= 3 ? NT : 1];
+      if constexpr (FAST >= 3) {
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
           const long gp = p0 + pixgrp + 16 * n + li;
@@ -390,11 +390,23 @@ __device__ __forceinline__ void ly_gemm_body2(const LyGemmParams& P, const int g
         const int cc = 16 * ((by * WC + wc) * MT + t) + 4 * lq;
         long soff = 0;
         int scol = cc;
-        if constexpr (FAST == 3) {
+        if constexpr (FAST >= 3) {
           const int grp = cc / P.scat_c;
           scol = cc - grp * P.scat_c;
           const int ky = grp / P.scat_ks, kx = grp - ky * P.scat_ks;
           soff = (long)ky * (P.scat_ks * P.W) + kx;
+        }
+        // FAST == 4: + eadd (LyGemmParams.eadd: the gradient another consumer of the same tensor already produced) — the tile's NT loads
+        // leave together before the first value is needed; lanes outside the tile read the scratch line they store to
+        f32x4 ev[FAST == 4 ? NT : 1];
+        if constexpr (FAST == 4) {
+          const TO* const eadd = reinterpret_cast<const TO*>(P.eadd);
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            const long gp = p0 + pixgrp + 16 * n + li;
+            const bool ok = gp < P.M && cc < P.N;
+            ev[n] = ly_ld4<TO>(ok ? eadd + (srow[n] + soff) * P.ldeadd + scol : reinterpret_cast<const TO*>(ly_gemm_trash) + 4 * lane);
+          }
         }
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
@@ -409,9 +421,10 @@ __device__ __forceinline__ void ly_gemm_body2(const LyGemmParams& P, const int g
             sum1[t] += um;
             sum2[t] += um * um;
           }
-          const f32x4 v = ly_act4(u, act);
+          f32x4 v = ly_act4(u, act);
+          if constexpr (FAST == 4) v += ev[n];
           long orow = gp;
-          if constexpr (FAST == 3) orow = srow[n] + soff;
+          if constexpr (FAST >= 3) orow = srow[n] + soff;
           TO* o = ok ? out + orow * P.ldo + scol : reinterpret_cast<TO*>(ly_gemm_trash) + 4 * lane;
           ly_st4<TO>(o, v);
           acc[t][n] = zero;
@@ -520,7 +533,7 @@ static int launch_gemm_d2(const LyGemmParams& P, hipStream_t st) {
 
 // Variant choice per call.  K in one or two chunks: weights resident (NCH) and, when every channel tile is full and the stores can be
 // vectors, the branch-free epilogue (FAST 1; 2 = with the BatchNorm sums of the training forward kept in registers; 3 = FAST 1 with the
-// scatter store of LyGemmParams.scat_ks).
+// scatter store of LyGemmParams.scat_ks; 4 = 3 + LyGemmParams.eadd added before the store).
 template <typename TI, typename TO, int NT, int MT, int WC, int GATHER, int PRO>
 static int launch_gemm_v(const LyGemmParams& P, hipStream_t st) {
   // which of the variants fit 256 registers without spilling into the loop (checked in the .s of every instantiation)
@@ -532,6 +545,11 @@ static int launch_gemm_v(const LyGemmParams& P, hipStream_t st) {
   const bool fast = (P.N & 3) == 0 && (P.ldo & 3) == 0 && P.out;
   if (P.scat_ks) {                                          // scatter store (ly_gemm_fwd checked: plain rows, no prologue, no statistics, fast widths)
     if constexpr (GATHER == LY_GATHER_ROWS && PRO == LY_PRO_NONE) {
+      if (P.eadd) {
+        if constexpr (ok1) { if (nchunk == 1) return launch_gemm_d2<TI, TO, NT, MT, WC, GATHER, PRO, 1, 4>(P, st); }
+        if constexpr (ok2) { if (nchunk == 2) return launch_gemm_d2<TI, TO, NT, MT, WC, GATHER, PRO, 2, 4>(P, st); }
+        return launch_gemm_d2<TI, TO, NT, MT, WC, GATHER, PRO, 0, 4>(P, st);
+      }
       if constexpr (ok1) { if (nchunk == 1) return launch_gemm_d2<TI, TO, NT, MT, WC, GATHER, PRO, 1, 3>(P, st); }
       if constexpr (ok2) { if (nchunk == 2) return launch_gemm_d2<TI, TO, NT, MT, WC, GATHER, PRO, 2, 3>(P, st); }
       return launch_gemm_d2<TI, TO, NT, MT, WC, GATHER, PRO, 0, 3>(P, st);

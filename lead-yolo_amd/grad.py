@@ -33,6 +33,70 @@ def _rows_dense(t):
 
 
 
+# ---- tensors with two consumers: the sum of the two gradients as a store ----------------------------------------------------------------
+# The skip connections of models/LEAD-YOLO.yaml (backbone stage -> next stage + neck concat; neck map -> upsample + later concat; neck output
+# -> Detect level + next RFCBAMConv) hand one tensor to two consumers; autograd sums the two input gradients with one more
+# read-read-write pass per tensor (six per step, 137 us at bs = 64).  `fork` gives each consumer its own alias; a consumer whose data
+# gradient is a GEMM does not launch it in its own backward but leaves it with the tensor's slot, and Fork.backward — which runs when BOTH
+# consumers are done — launches it with the other consumer's gradient as LyGemmParams.eadd: the sum is the GEMM's store.
+FORK_SUM = True                 # a module constant (tests monkeypatch it)
+
+
+class _Slot:
+    __slots__ = ("deferred",)
+
+    def __init__(self):
+        self.deferred = []
+
+
+class Fork(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, slot):
+        ctx.slot = slot
+        ctx.set_materialize_grads(False)
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, d1, d2):
+        total = d1 if d2 is None else d2 if d1 is None else d1 + d2
+        deferred, ctx.slot.deferred = ctx.slot.deferred, []
+        with torch.no_grad():
+            for produce in deferred:
+                total = produce(total)
+        return total, None
+
+
+def fork(x):
+    """(x, x) as two aliases whose gradients meet in Fork.backward; each carries the slot a GEMM-producing consumer defers its launch to"""
+    slot = _Slot()
+    a, b = Fork.apply(x, slot)
+    a._ly_slot = b._ly_slot = slot
+    return a, b
+
+
+def _slot_of(x):
+    return getattr(x, "_ly_slot", None) if (FORK_SUM and x is not None) else None
+
+
+def _gemm_dx(slot, n, c, h, w, like, **kw):
+    """dx [n, c, h, w] = ops.gemm(out=dx, **kw) — now, or (slot) when the tensor's other gradient exists, added to it in the store"""
+    def produce(eadd):
+        out = ops.empty_nhwc(n, c, h, w, like)
+        extra, late = {}, None
+        if eadd is not None:
+            if eadd.dtype == out.dtype and tuple(eadd.shape) == tuple(out.shape) and kw["N"] % 4 == 0:
+                e, lde = ops.rows(eadd)
+                extra = dict(eadd=e, ldeadd=lde)
+            else:
+                late = eadd
+        ops.gemm(out=out, **kw, **extra)
+        return out if late is None else out + late.to(out.dtype)
+    if slot is None:
+        return produce(None)
+    slot.deferred.append(produce)
+    return None
+
+
 class ConvSpec:
     """Static description of one conv(+bias) -> [BN] -> act unit."""
 
@@ -185,8 +249,9 @@ def _tap_major(g):
     return g.dim() == 4 and not g.is_contiguous() and g.stride(1) == 1 and g.stride(3) == g.shape[1]
 
 
-def conv_dgrad(spec, du, weight, x0, x1, need0, need1):
-    """Input gradients (dx0, dx1) of the contraction; du NHWC-dense [n, cout, ho, wo] with cout % 4 == 0 columns valid."""
+def conv_dgrad(spec, du, weight, x0, x1, need0, need1, slots=(None, None)):
+    """Input gradients (dx0, dx1) of the contraction; du NHWC-dense [n, cout, ho, wo] with cout % 4 == 0 columns valid.  slots: the
+    Fork slot of x0 (see `fork`): the single-source 1x1 and the patch data gradients then wait for the other consumer's gradient."""
     n, co, ho, wo = du.shape
     m = n * ho * wo
     with torch.no_grad():
@@ -194,6 +259,8 @@ def conv_dgrad(spec, du, weight, x0, x1, need0, need1):
             nw, kin = weight.shape[0], weight.numel() // weight.shape[0]
             # W^T [kin, co] read in place from the parameter (columns zero-padded to du's channel count)
             wt = pack.packed(pack.src_matrix(weight, kin, nw, sr=1, sk=kin, k_pad=co), co, ops.planes_of(du))
+            if x1 is None and not spec.up and slots[0] is not None and kin % 4 == 0:
+                return _gemm_dx(slots[0], n, kin, ho, wo, du, M=m, H=ho, W=wo, K=co, N=kin, a0=du, lda0=co, k0=co, wp=wt, ldo=kin), None
             d = ops.empty_nhwc(n, kin, ho, wo, du)
             ops.gemm(M=m, H=ho, W=wo, K=co, N=kin, a0=du, lda0=co, k0=co, wp=wt, out=d, ldo=kin)
             if x1 is None:
@@ -218,9 +285,8 @@ def conv_dgrad(spec, du, weight, x0, x1, need0, need1):
         wt = pack.packed(pack.Src(weight, k * k * c, nrb=c, sra=1, srb=k * k, nc=co, sc=c * k * k), co, ops.planes_of(du))
         if h == ho * k and w == wo * k and c % 4 == 0:
             # round 6: the adjoint of the patch gather is the GEMM's store (LyGemmParams.scat_ks) — no [M][k*k*c] intermediate, no ly_unpatch pass
-            dx = ops.empty_nhwc(n, c, h, w, du)
-            ops.gemm(M=m, H=ho, W=wo, K=co, N=k * k * c, a0=du, lda0=co, k0=co, wp=wt, out=dx, ldo=c, scat_ks=k, scat_c=c)
-            return dx, None
+            return _gemm_dx(slots[0], n, c, h, w, du, M=m, H=ho, W=wo, K=co, N=k * k * c, a0=du, lda0=co, k0=co, wp=wt, ldo=c, scat_ks=k,
+                            scat_c=c), None
         g = torch.empty((m, k * k * c), dtype=du.dtype, device=du.device)
         ops.gemm(M=m, H=ho, W=wo, K=co, N=k * k * c, a0=du, lda0=co, k0=co, wp=wt, out=g, ldo=k * k * c)
         return ops.unpatch(g, n, ho, wo, c, k, h, w), None
@@ -242,6 +308,7 @@ class ConvBnAct(torch.autograd.Function):
     def forward(ctx, spec, wp, x0, x1, weight, bias, gamma, beta):
         co = spec.cout
         dev = x0.device
+        ctx.slots = (_slot_of(x0), _slot_of(x1))
         bias_f = bias.detach().float().contiguous() if bias is not None else None
         mean = invstd = None
         if spec.bn is not None:
@@ -336,7 +403,7 @@ class ConvBnAct(torch.autograd.Function):
                 dspec = spec
                 if cq != co:
                     dspec = ConvSpec(spec.kind, cq, k=spec.k, nchw=spec.nchw, up=spec.up)
-                dx0, dx1 = conv_dgrad(dspec, du_d, weight, x0, x1, need[2], need[3])
+                dx0, dx1 = conv_dgrad(dspec, du_d, weight, x0, x1, need[2], need[3], ctx.slots)
         return None, None, dx0, dx1, dw, dbias, dgamma, dbeta
 
 
@@ -386,7 +453,11 @@ class ConvBnActPair(torch.autograd.Function):
         ops.bnact_fwd(u, co, rows, co, v[0], v[1], spec.act, y, co)
         ctx.spec = spec
         ctx.wt_src = pack.src_matrix_kcat_t(w1, w2)
-        if spec.up:                    # the lazily upsampled source's rows and the other source's rows as operands of their own
+        ctx.slots = (_slot_of(x0), _slot_of(x1))
+        # one data-gradient contraction per source (instead of one over both) when the sources' gradients differ in resolution (a lazily
+        # upsampled x0) or in destination (a source shared with another consumer: its gradient is added to that one's in the store, `fork`)
+        ctx.split = spec.up or (x1 is not None and (ctx.slots[0] is not None or ctx.slots[1] is not None))
+        if ctx.split:
             c0 = x0.shape[1]
             ctx.wt_src = (pack.src_matrix_kcat_t(w1, w2, 0, c0), pack.src_matrix_kcat_t(w1, w2, c0, None) if x1 is not None else None)
         ctx.params = ((w1, g1, be1), (w2, g2, be2))
@@ -465,15 +536,20 @@ class ConvBnActPair(torch.autograd.Function):
                 ops.wgrad_group(probs)
                 ops.grad_done(ctx.params[0][0])
                 ops.grad_done(ctx.params[1][0])
-            if spec.up:
+            s0, s1 = ctx.slots
+            if ctx.split:
                 pl = ops.planes_of(du)
                 if need[4]:
-                    out[4] = ops.empty_nhwc(n, c0, hq, wq, du)
-                    ops.gemm(M=rq, H=hq, W=wq, K=co, N=c0, a0=dup, lda0=co, k0=co, wp=pack.packed(ctx.wt_src[0], co, pl), out=out[4], ldo=c0)
+                    a, m0, h0, w0 = (dup, rq, hq, wq) if spec.up else (du, rows, ho, wo)
+                    out[4] = _gemm_dx(s0 if c0 % 4 == 0 else None, n, c0, h0, w0, du, M=m0, H=h0, W=w0, K=co, N=c0, a0=a, lda0=co, k0=co,
+                                      wp=pack.packed(ctx.wt_src[0], co, pl), ldo=c0)
                 if need[5] and x1 is not None:
-                    out[5] = ops.empty_nhwc(n, kin - c0, ho, wo, du)
-                    ops.gemm(M=rows, H=ho, W=wo, K=co, N=kin - c0, a0=du, lda0=co, k0=co, wp=pack.packed(ctx.wt_src[1], co, pl), out=out[5],
-                             ldo=kin - c0)
+                    c1 = kin - c0
+                    out[5] = _gemm_dx(s1 if c1 % 4 == 0 else None, n, c1, ho, wo, du, M=rows, H=ho, W=wo, K=co, N=c1, a0=du, lda0=co, k0=co,
+                                      wp=pack.packed(ctx.wt_src[1], co, pl), ldo=c1)
+            elif x1 is None and s0 is not None and need[4] and kin % 4 == 0:
+                out[4] = _gemm_dx(s0, n, kin, ho, wo, du, M=rows, H=ho, W=wo, K=co, N=kin, a0=du, lda0=co, k0=co,
+                                  wp=pack.packed(ctx.wt_src, co, ops.planes_of(du)), ldo=kin)
             elif need[4] or need[5]:
                 pl = ops.planes_of(du)
                 d = ops.empty_nhwc(n, kin, ho, wo, du)
@@ -522,6 +598,7 @@ class DetectHeadFn(torch.autograd.Function):
             y = _conv_forward(spec, x, None, wp, None, bias_f, ACT_NONE)
             ops.detect_tail(y, co, bs, ny, nx, det.na, det.no, det.anchors[i], 1.0, p, None, 0, 0)
         ctx.spec, ctx.geom = spec, (bs, ny, nx, det.na, det.no)
+        ctx.slots = (_slot_of(x), None)
         ctx.params = (weight, bias)
         ctx.save_for_backward(x, weight)
         return p
@@ -554,7 +631,7 @@ class DetectHeadFn(torch.autograd.Function):
             dw = conv_wgrad(ctx.spec, du_d, x, None, w_param) if need[4] else None
             dx = None
             if need[3]:
-                dx, _ = conv_dgrad(ConvSpec("pw", cq), du_d, weight, x, None, True, False)
+                dx, _ = conv_dgrad(ConvSpec("pw", cq), du_d, weight, x, None, True, False, ctx.slots)
         return None, None, None, dx, dw, (None if tb is not None else dbias)
 
 

@@ -16,6 +16,7 @@ from pathlib import Path
 import torch
 import torch.nn as nn
 
+from . import grad
 from . import modules as M
 
 REGISTRY = {
@@ -214,16 +215,41 @@ class DetectionModel(nn.Module):
                 and x.shape[2] % 32 == 0 and x.shape[3] % 32 == 0 and det.stride is not None and isinstance(det.f, (list, tuple)):
             hw = [(int(x.shape[2] // s), int(x.shape[3] // s)) for s in det._strides()]
             early = det.begin(x.shape[0], hw, x.device)
+        # training on the HIP path: a layer output with exactly two consumers goes to them as the two aliases of grad.fork, so that the
+        # sum of their gradients can be a GEMM's store (grad.Fork) instead of autograd's extra pass
+        forks = self._two_consumer_layers() if (self.training and torch.is_grad_enabled() and grad.FORK_SUM and isinstance(x, torch.Tensor)
+                                                and x.is_cuda) else ()
+
+        def take(j):
+            v = y[j]
+            return v.pop(0) if isinstance(v, list) else v
         for m in self.model:
             if m.f != -1:
-                x = y[m.f] if isinstance(m.f, int) else [x if j == -1 else y[j] for j in m.f]
+                x = take(m.f) if isinstance(m.f, int) else [(take(m.i - 1) if isinstance(y[m.i - 1], list) else x) if j == -1 else take(j) for j in m.f]
+            elif m.i > 0 and isinstance(y[m.i - 1], list):
+                x = take(m.i - 1)
             if m is det and early is not None:
                 det._early = early
             x = m(x)
-            y.append(x if m.i in self.save else None)
+            if m.i in forks and isinstance(x, torch.Tensor) and x.dim() == 4 and x.requires_grad and x.dtype in (torch.bfloat16, torch.float32):
+                y.append(list(grad.fork(x)))
+            else:
+                y.append(x if m.i in self.save else None)
             if early is not None and m is not det and m.i in det.f[:-1] and isinstance(x, torch.Tensor):
                 det.level(early, det.f.index(m.i), x, side=True)
         return x
+
+    def _two_consumer_layers(self):
+        """indices of the layers whose output is read by exactly two later layers (models/yolo.py:179-195 routing: m.f)"""
+        plan = getattr(self, "_fork_plan", None)
+        if plan is None:
+            count = {}
+            for m in self.model:
+                for j in ([m.f] if isinstance(m.f, int) else list(m.f)):
+                    j = m.i - 1 if j == -1 else (j if j >= 0 else m.i + j)
+                    count[j] = count.get(j, 0) + 1
+            plan = self._fork_plan = frozenset(j for j, c in count.items() if c == 2 and j >= 0)
+        return plan
 
     def _initialize_biases(self, cf=None):
         """reference models/yolo.py:352-359"""

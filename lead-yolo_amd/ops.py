@@ -173,7 +173,7 @@ def _p(t):
 
 def gemm(*, M, H, W, K, N, a0, lda0, k0, wp, out, ldo, a1=None, lda1=0, gather=GATHER_ROWS, Hin=0, Win=0, Cin=0, ks=0, pk=0,
          pro=PRO_NONE, g_h=None, g_w=None, res=None, ldres=0, p_scale=None, p_shift=None, p_ca=None, e_scale=None,
-         e_shift=None, rowscale=None, act=ACT_NONE, stats=None, dtype=None, scat_ks=0, scat_c=0):
+         e_shift=None, rowscale=None, act=ACT_NONE, stats=None, dtype=None, scat_ks=0, scat_c=0, eadd=None, ldeadd=0):
     # element type of the call: the output's (statistics passes: the source's); the NCHW image gather always READS fp32 — or uint8
     # (pixel / 255 on load: the training loop's `imgs.float() / 255` folded into the gather)
     # or a 16-bit image as it is (the `im.half()` batch of a reduced-precision forward; LY_BF16 calls)
@@ -186,7 +186,9 @@ def gemm(*, M, H, W, K, N, a0, lda0, k0, wp, out, ldo, a1=None, lda1=0, gather=G
     code = capi.dtype_code(dt)
     P = capi.LyGemmParams(M, H, W, K, N, _p(a0), lda0, k0, _p(a1), lda1, gather, Hin, Win, Cin, ks, pk, pro, _p(g_h), _p(g_w),
                           _p(res), ldres, _p(p_scale), _p(p_shift), _p(p_ca), _p(wp), _p(e_scale), _p(e_shift), _p(rowscale),
-                          act, _p(out), ldo, _p(stats), code, scat_ks, scat_c)
+                          act, _p(out), ldo, _p(stats), code, scat_ks, scat_c, _p(eadd), ldeadd)
+    if eadd is not None and eadd.dtype != out.dtype:
+        raise ValueError("gemm: eadd must have the output's dtype")
     nt, mt, wc = gemm_config(N)
     ti = {GATHER_PATCH_NCHW_U8: "unsigned char", GATHER_PATCH_NCHW_BF16: "ly_bf16img", GATHER_PATCH_NCHW_F16: "ly_f16img"}.get(
         gather, "float" if (code == 0 or image) else "__bf16")
@@ -204,6 +206,8 @@ def gemm(*, M, H, W, K, N, a0, lda0, k0, wp, out, ldo, a1=None, lda1=0, gather=G
         nch = 1 if (nchunk == 1 and ok1) else 2 if (nchunk == 2 and ok2) else 0
     fast = N % 4 == 0 and ldo % 4 == 0 and out is not None
     ep = (2 if stats is not None else 1) if (nch or (fast and pro == 0)) else 1 if (fast and pro == PRO_GATE and stats is None) else 0
+    if scat_ks or eadd is not None:                         # the scatter / add-before-store epilogues (launch_gemm_v)
+        ep = 4 if eadd is not None else 3
     name = f"ly_gemm_kernel_d2<{ti}, {to}, {nt}, {mt}, {wc}, {kgather}, {pro}, {nch}, {ep}>"
     if (image and Cin == 3 and K == 48 and 20 <= N <= 80 and N % 4 == 0 and (out is None or ldo % 4 == 0) and Hin == 4 * H and Win == 4 * W
             and (code != 0 or gather in (GATHER_PATCH_NCHW, GATHER_PATCH_NCHW_U8))):

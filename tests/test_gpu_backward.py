@@ -1165,3 +1165,92 @@ def test_wgrad3_halo_kernel(n, h, w, cin, cout, cvalid, ldx):
     for on in (1, 0):
         assert float((got[on] - want).abs().max()) <= 2e-3 * scale, (on, float((got[on] - want).abs().max()), scale)      # bf16 products, fp32 sums
     assert float((got[1] - got[0]).abs().max()) <= 5e-4 * scale
+
+
+def _pack_plain(w, dtype):
+    """packed fragment image of a [N, K] fp32 matrix (pack.packed over a parameter-like tensor)"""
+    from lead_yolo_amd import ops, pack
+    p = torch.nn.Parameter(w.clone())
+    return p, pack.packed(pack.src_matrix(p, w.shape[0], w.shape[1]), w.shape[1], ops.planes_of(torch.empty(1, dtype=dtype, device=w.device)))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("n,h,w,k,c,ks", [(2, 6, 10, 64, 24, 2), (3, 5, 7, 128, 40, 2), (1, 4, 4, 256, 8, 4), (2, 9, 5, 136, 128, 1), (2, 8, 8, 320, 256, 1)])
+def test_gemm_scatter_store_and_added_gradient(n, h, w, k, c, ks, dtype):
+    """LyGemmParams.scat_ks (the adjoint of the k = s patch gather as the store) and LyGemmParams.eadd (another consumer's gradient added
+    before the store, read with a row stride of its own) vs the two-step form in fp64"""
+    from lead_yolo_amd import ops
+    g = torch.Generator().manual_seed(5 + n + k)
+    a = torch.randn(n * h * w, k, generator=g).to(dtype)
+    wm = torch.randn(ks * ks * c, k, generator=g) * 0.1
+    prm, wp = _pack_plain(wm.to(_dev()), dtype)
+    ad = a.to(_dev())
+    lde = c + 8
+    prev = torch.randn(n * ks * h * ks * w, lde, generator=g).to(dtype)
+    ref = a.double() @ wm.to(dtype if dtype == torch.bfloat16 else torch.float32).double().t() if dtype == torch.bfloat16 else a.double() @ wm.double().t()
+    ref = ref.view(n, h, w, ks, ks, c).permute(0, 1, 3, 2, 4, 5).reshape(n * ks * h * ks * w, c)
+    for eadd in (None, prev.to(_dev())):
+        out = torch.full((n * ks * h * ks * w, c), float("nan"), dtype=dtype, device=_dev())
+        kw = dict(scat_ks=ks, scat_c=c) if ks > 1 else {}
+        if eadd is not None:
+            kw.update(eadd=eadd, ldeadd=lde)
+        elif ks == 1:
+            continue
+        ops.gemm(M=n * h * w, H=h, W=w, K=k, N=ks * ks * c, a0=ad, lda0=k, k0=k, wp=wp, out=out, ldo=c, **kw)
+        want = ref if eadd is None else ref + prev[:, :c].double()
+        tol = 2e-2 if dtype == torch.bfloat16 else 2e-3
+        err = float((out.double().cpu() - want).abs().max())
+        assert torch.isfinite(out).all() and err <= tol * float(want.abs().max()), (ks, eadd is not None, err)
+
+
+@pytest.mark.parametrize("amp", [None, torch.bfloat16])
+def test_fork_sum_matches_autograd_sum(amp, monkeypatch):
+    """grad.fork (the six two-consumer layer outputs of lead-yolo: the second gradient is added in a GEMM's store, LyGemmParams.eadd) vs
+    autograd's own sum of the two gradients, from one state: the same predictions bit for bit, parameter gradients equal within the storage
+    rounding of the one summed tensor, and all six sums are stores (LyGemmParams.eadd launches)"""
+    import lead_yolo_amd as L
+    from lead_yolo_amd import grad
+    torch.manual_seed(0)
+    m = L.Model(_cfg("s"))
+    st = synth.synth_state(synth.shapes_of(m.state_dict()), 7373)
+    st["model.23.anchors"] = m.model[-1].anchors.clone()
+    m.load_state_dict(st)
+    m = m.to(_dev()).train()
+    assert sorted(m._two_consumer_layers()) == [3, 5, 9, 13, 16, 19]
+    cl = L.ComputeLoss(m)
+    imgs = synth.synth_images(4, 160, 71).to(_dev())
+    tg = synth.synth_targets(4, 72, per_image=4).to(_dev())
+    bufs0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(grad, "FORK_SUM", on)
+        m.load_state_dict(bufs0)
+        for p in m.parameters():
+            p.grad = None
+        with torch.autocast("cuda", dtype=amp, enabled=amp is not None):
+            pred = m(imgs.float() / 255)
+            loss, _ = cl(pred, tg)
+        added = []
+        real_gemm = grad.ops.gemm
+        monkeypatch.setattr(grad.ops, "gemm", lambda **kw: (added.append(kw["N"]) if kw.get("eadd") is not None else None, real_gemm(**kw))[1])
+        loss.backward()
+        monkeypatch.setattr(grad.ops, "gemm", real_gemm)
+        torch.cuda.synchronize()
+        res[on] = ([p_.detach().clone() for p_ in pred], {n: p.grad.detach().float().clone() for n, p in m.named_parameters()}, len(added))
+    for a, b in zip(res[True][0], res[False][0]):
+        assert torch.equal(a, b)
+    assert res[True][2] == 6 and res[False][2] == 0, (res[True][2], res[False][2])       # one store-side sum per two-consumer tensor
+    if amp is None:                 # fp32 storage: the same sums, only the association of one addition differs
+        for k in res[True][1]:
+            a, b = res[True][1][k], res[False][1][k]
+            assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max()) + 1e-7, k
+    else:                           # bf16 storage: the summed tensor is rounded once (fp32 sum in the store) instead of twice — rounding-level
+        # differences, which cancellation-heavy gradients (a bias in front of the first BatchNorm) amplify: direction and length of the
+        # whole gradient, and every tensor's length
+        va = torch.cat([res[True][1][k].flatten() for k in res[True][1]])
+        vb = torch.cat([res[False][1][k].flatten() for k in res[True][1]])
+        cos = float(torch.dot(va, vb) / (va.norm() * vb.norm()))
+        assert cos >= 0.999 and abs(float(va.norm() / vb.norm()) - 1) <= 1e-2, (cos, float(va.norm()), float(vb.norm()))
+        for k in res[True][1]:
+            a, b = res[True][1][k], res[False][1][k]
+            assert float((a - b).norm()) <= 0.25 * float(b.norm()) + 1e-3 * float(vb.abs().max()), k

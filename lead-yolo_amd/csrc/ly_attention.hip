@@ -933,34 +933,43 @@ extern "C" int ly_detect_tail(const void* y, int ldy, int n_img, int H, int W, i
 // whole rows, and the column sums are kept in registers until one atomic per column and block.
 #define LY_DH_MAXW 160
 #define LY_DH_MAXLD 32
+#define LY_DH_TILE 12288                                   // floats of the LDS tile (48 KB): RB image rows of W pixels x (ldu + 1); >= MAXW * (MAXLD + 1)
+// RB image rows per trip (as many as fit the tile, at most 8): one trip's loads are all in flight together — with one row per trip a block
+// of the 80 x 80 level paid a dependent global -> LDS -> global round trip and two barriers per 5.6 KB — and the rows leave as 8-byte
+// vectors (were 2-byte element stores).
 template <typename T>
 __global__ __launch_bounds__(LY_THREADS) void ly_detect_head_bwd_kernel(const float* __restrict__ dp, int n_img, int H, int W, int na, int no,
-                                                                        T* __restrict__ du, int ldu, float* __restrict__ dbias, const int f64) {
-  __shared__ float tile[LY_DH_MAXW * (LY_DH_MAXLD + 1)];
+                                                                        T* __restrict__ du, int ldu, float* __restrict__ dbias, const int f64, const int RB) {
+  __shared__ float tile[LY_DH_TILE];
   __shared__ float red[LY_THREADS];
   const int tid = threadIdx.x, co = na * no, LT = ldu + 1;
   const int col = tid & 31, part = tid >> 5;              // column sums: 8 row classes x 32 columns
   float bsum = 0.f;
-  for (int i = tid; i < W * LT; i += LY_THREADS) tile[i] = 0.f;      // pad columns stay zero
+  for (int i = tid; i < RB * W * LT; i += LY_THREADS) tile[i] = 0.f;      // pad columns stay zero
   const long rows_total = (long)n_img * H;
   const int run = W * no;
-  for (long r = blockIdx.x; r < rows_total; r += gridDim.x) {
-    const long n = r / H;
-    const int h = (int)(r - n * H);
+  const int q4 = ldu >> 2;                                // 4-element groups of an output row (ldu % 4 == 0: checked by the launcher)
+  for (long r0 = (long)blockIdx.x * RB; r0 < rows_total; r0 += (long)gridDim.x * RB) {
+    const int nr = rows_total - r0 < RB ? (int)(rows_total - r0) : RB;
     __syncthreads();
-    for (int e = tid; e < na * run; e += LY_THREADS) {
-      const int a = e / run, q = e - a * run;
+    for (int e = tid; e < nr * na * run; e += LY_THREADS) {
+      const int rr = e / (na * run), e1 = e - rr * (na * run);
+      const int a = e1 / run, q = e1 - a * run;
       const int w = q / no, o = q - w * no;
-      tile[w * LT + a * no + o] = dp[(((n * na + a) * H + h) * (long)W) * no + q];
+      const long r = r0 + rr;
+      const long n = r / H;
+      const int h = (int)(r - n * H);
+      tile[(rr * W + w) * LT + a * no + o] = dp[(((n * na + a) * H + h) * (long)W) * no + q];
     }
     __syncthreads();
-    T* const out = du + r * (long)W * ldu;
-    for (int e = tid; e < W * ldu; e += LY_THREADS) {
-      const int w = e / ldu, c = e - w * ldu;
-      out[e] = (T)tile[w * LT + c];
+    T* const out = du + r0 * (long)W * ldu;               // the nr rows are contiguous in du
+    for (int e = tid; e < nr * W * q4; e += LY_THREADS) {
+      const int px = e / q4, g = e - px * q4;
+      const float* t = tile + px * LT + 4 * g;
+      ly_st4<T>(out + (long)px * ldu + 4 * g, (f32x4){t[0], t[1], t[2], t[3]});
     }
     if (col < co)
-      for (int w = part; w < W; w += LY_THREADS / 32) bsum += tile[w * LT + col];
+      for (int px = part; px < nr * W; px += LY_THREADS / 32) bsum += tile[px * LT + col];
   }
   red[tid] = bsum;
   __syncthreads();
@@ -975,12 +984,14 @@ extern "C" int ly_detect_head_bwd(const float* dp, int n_img, int H, int W, int 
                                   void* stream) {
   LY_CHECK_DTYPE(dtype, "detect_head_bwd");
   LY_CHECK(dp && du && dbias && n_img > 0 && H > 0 && W > 0 && na > 0 && no > 0, "detect_head_bwd: bad arguments");
-  LY_CHECK(W <= LY_DH_MAXW && ldu <= LY_DH_MAXLD && na * no <= ldu, "detect_head_bwd: W=%d (max %d) / ldu=%d (max %d, >= na*no=%d) out of range", W,
-           LY_DH_MAXW, ldu, LY_DH_MAXLD, na * no);
-  long blocks = (long)n_img * H;
+  LY_CHECK(W <= LY_DH_MAXW && ldu <= LY_DH_MAXLD && na * no <= ldu && (ldu & 3) == 0 && ((uintptr_t)du & 15) == 0,
+           "detect_head_bwd: W=%d (max %d) / ldu=%d (max %d, >= na*no=%d, a multiple of 4) out of range", W, LY_DH_MAXW, ldu, LY_DH_MAXLD, na * no);
+  int RB = LY_DH_TILE / (W * (ldu + 1));
+  if (RB > 8) RB = 8;
+  long blocks = ((long)n_img * H + RB - 1) / RB;
   if (blocks > 1024) blocks = 1024;
   LY_WITH_T(dtype, hipLaunchKernelGGL(ly_detect_head_bwd_kernel<T>, dim3((unsigned)blocks), dim3(LY_THREADS), 0, reinterpret_cast<hipStream_t>(stream), dp,
-                                      n_img, H, W, na, no, reinterpret_cast<T*>(du), ldu, dbias, dbias_f64));
+                                      n_img, H, W, na, no, reinterpret_cast<T*>(du), ldu, dbias, dbias_f64, RB));
   LY_LAUNCH_CHECK();
   return 0;
 }

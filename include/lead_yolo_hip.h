@@ -499,6 +499,18 @@ int ly_bn_bwd_coeffs(const void* sums /* floats, or doubles if sums_f64 */, int 
                      const float* mean, const float* invstd, int train, float* dgamma, float* dbeta, float* alpha, float* kappa, float* lambda,
                      int tr_a, int tr_b /* tr_a > 0: channel j = t*tr_b + c of the sums goes to dgamma / dbeta [c*tr_a + t] (RFCBAMConv's generate BatchNorm:
                                            sums in [tap][channel] order, parameters in [channel][tap]); 0, 0: same index */, void* stream);
+/* The two entry points above for TWO BatchNorms over one stacked output (C3_CA's cv1 | cv2, models/common.py:1630-1636: channels
+ * [0, c_half) and [c_half, 2 c_half) of one statistics array) in one launch each — these coefficient kernels are dependent ~4 us
+ * launches on the step's critical path.  scale / shift / mean / invstd, a, alpha / kappa / lambda: stacked [2 c_half] vectors;
+ * parameters, running statistics and gradient targets per unit; sums0 / sums1: the two [stripes][2 c_half] arrays of
+ * ly_bnact_bwd_reduce_pair.  Always train-mode coefficients.                                                             */
+int ly_bn_finalize_pair(const void* stats, int stats_f64, int stripes, int c_half, double count, const float* gamma0, const float* beta0, float eps0,
+                        float momentum0, float* running_mean0, float* running_var0, long* nbt0, const float* gamma1, const float* beta1, float eps1,
+                        float momentum1, float* running_mean1, float* running_var1, long* nbt1, float* scale, float* shift, float* mean,
+                        float* invstd, void* stream);
+int ly_bn_bwd_coeffs_pair(const void* sums0, const void* sums1, int sums_f64, int stripes, int c_half, double count, const float* a, const float* mean,
+                          const float* invstd, float* dgamma0, float* dbeta0, float* dgamma1, float* dbeta1, float* alpha, float* kappa,
+                          float* lambda, void* stream);
 /* Fragment packing of the fp32 matrix W[r][k] = w[r*ld_r + k*ld_k] (R x K, rows zero padded to max(R, rows_to)) into the
  * [T][S][planes][64 lanes][8] bf16 layout the contraction kernels read (csrc/ly_tile.hpp): planes = 2 (hi = bf16(W),
  * lo = bf16(W - hi): the bf16x3 operand of LY_F32 calls) or 1 (hi only: LY_BF16 calls).                                */

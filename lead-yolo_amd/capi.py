@@ -159,6 +159,8 @@ SIGNATURES = {
     "ly_se_bwd": [_P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P],
     "ly_bn_finalize": [_P, _I, _I, _I, _I, _I, ctypes.c_double, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P],
     "ly_bn_bwd_coeffs": [_P, _I, _I, _I, ctypes.c_double, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P],
+    "ly_bn_finalize_pair": [_P, _I, _I, _I, ctypes.c_double, _P, _P, _F, _F, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P],
+    "ly_bn_bwd_coeffs_pair": [_P, _P, _I, _I, _I, ctypes.c_double, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "ly_frag_pack3": [_P, _I, _I, _L, _L, _I, _I, _P, _P],
     "ly_loss_level": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _F, _P],
     "ly_loss_finish": [_P, _I, _P, _P, _F, _F, _F, _I, _I, _P, _P],

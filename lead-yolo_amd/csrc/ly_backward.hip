@@ -1781,6 +1781,102 @@ extern "C" int ly_bn_finalize(const void* stats, int stats_f64, int stripes, int
   return 0;
 }
 
+// Two BatchNorms over one stacked output (ConvBnActPair: C3_CA's cv1 | cv2, channels [0, c_half) and [c_half, 2 c_half) of one
+// statistics array) in ONE launch: every one of these coefficient kernels is a dependent ~4 us launch on the step's critical path.
+struct LyBnSide {
+  const float* gamma; const float* beta; float* running_mean; float* running_var; long* nbt; float eps, momentum;
+};
+template <typename TS>
+__global__ __launch_bounds__(LY_BNV_THREADS) void ly_bn_finalize_pair_kernel(const TS* __restrict__ stats, int stripes, int c_half, double count, const LyBnSide u0,
+                                                                         const LyBnSide u1, float* __restrict__ scale, float* __restrict__ shift,
+                                                                         float* __restrict__ mean, float* __restrict__ invstd) {
+  const int c = blockIdx.x * LY_BNV_THREADS + threadIdx.x;
+  if (blockIdx.x == 0 && threadIdx.x < 2) {
+    long* nbt = threadIdx.x ? u1.nbt : u0.nbt;
+    if (nbt) *nbt += 1;
+  }
+  const int nch = 2 * c_half;
+  if (c >= nch) return;
+  const bool hi = c >= c_half;
+  const LyBnSide& U = hi ? u1 : u0;
+  const int cl = hi ? c - c_half : c;
+  const float g = U.gamma ? U.gamma[cl] : 1.f, b = U.beta ? U.beta[cl] : 0.f;
+  const float rm = U.running_mean ? U.running_mean[cl] : 0.f, rv = U.running_var ? U.running_var[cl] : 0.f;
+  double s1, s2;
+  ly_fold_stripes(stats + c, stripes, (size_t)2 * nch, nch, s1, s2);
+  const double m = s1 / count;
+  double var = s2 / count - m * m;
+  var = var > 0.0 ? var : 0.0;
+  const float is = (float)(1.0 / sqrt(var + (double)U.eps));
+  const float sc = g * is;
+  scale[c] = sc;
+  shift[c] = b - (float)m * sc;
+  mean[c] = (float)m;
+  invstd[c] = is;
+  if (U.running_mean) U.running_mean[cl] = (1.f - U.momentum) * rm + U.momentum * (float)m;
+  if (U.running_var) U.running_var[cl] = (1.f - U.momentum) * rv + U.momentum * (float)(var * (count / (count > 1.0 ? count - 1.0 : 1.0)));
+}
+
+extern "C" int ly_bn_finalize_pair(const void* stats, int stats_f64, int stripes, int c_half, double count, const float* gamma0, const float* beta0, float eps0,
+                                   float momentum0, float* running_mean0, float* running_var0, long* nbt0, const float* gamma1, const float* beta1,
+                                   float eps1, float momentum1, float* running_mean1, float* running_var1, long* nbt1, float* scale, float* shift,
+                                   float* mean, float* invstd, void* stream) {
+  LY_CHECK(stats && scale && shift && mean && invstd && stripes > 0 && c_half > 0 && count > 0, "bn_finalize_pair: bad arguments");
+  const LyBnSide u0 = {gamma0, beta0, running_mean0, running_var0, nbt0, eps0, momentum0}, u1 = {gamma1, beta1, running_mean1, running_var1, nbt1, eps1, momentum1};
+  const dim3 grid((2 * c_half + LY_BNV_THREADS - 1) / LY_BNV_THREADS);
+  if (stats_f64)
+    hipLaunchKernelGGL(ly_bn_finalize_pair_kernel<double>, grid, dim3(LY_BNV_THREADS), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const double*>(stats),
+                       stripes, c_half, count, u0, u1, scale, shift, mean, invstd);
+  else
+    hipLaunchKernelGGL(ly_bn_finalize_pair_kernel<float>, grid, dim3(LY_BNV_THREADS), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const float*>(stats),
+                       stripes, c_half, count, u0, u1, scale, shift, mean, invstd);
+  LY_LAUNCH_CHECK();
+  return 0;
+}
+
+// the backward coefficients of the same two units: sums0 / sums1 are the two striped arrays of ly_bnact_bwd_reduce_pair ([stripes][2 c_half]
+// each), a / mean / invstd and alpha / kappa / lambda the stacked [2 c_half] vectors, dgamma / dbeta per unit (ACCUMULATED, as below)
+template <typename TS>
+__global__ __launch_bounds__(LY_BNV_THREADS) void ly_bn_bwd_coeffs_pair_kernel(const TS* __restrict__ sums0, const TS* __restrict__ sums1, int stripes, int c_half,
+                                                                           double count, const float* __restrict__ a, const float* __restrict__ mean,
+                                                                           const float* __restrict__ invstd, float* __restrict__ dgamma0,
+                                                                           float* __restrict__ dbeta0, float* __restrict__ dgamma1, float* __restrict__ dbeta1,
+                                                                           float* __restrict__ alpha, float* __restrict__ kappa, float* __restrict__ lambda) {
+  const int c = blockIdx.x * LY_BNV_THREADS + threadIdx.x;
+  if (c >= 2 * c_half) return;
+  const bool hi = c >= c_half;
+  const int cl = hi ? c - c_half : c;
+  float* const dgamma = hi ? dgamma1 : dgamma0;
+  float* const dbeta = hi ? dbeta1 : dbeta0;
+  const double mu = mean[c], is = invstd[c], av = a[c];
+  const float dg0 = dgamma[cl], db0 = dbeta[cl];
+  double s1, s2;
+  ly_fold_stripes((hi ? sums1 : sums0) + cl, stripes, (size_t)2 * c_half, c_half, s1, s2);
+  const double dg = (s2 - mu * s1) * is;
+  dgamma[cl] = dg0 + (float)dg;
+  dbeta[cl] = db0 + (float)s1;
+  alpha[c] = (float)av;
+  const double lam = -av * dg * is / count;
+  lambda[c] = (float)lam;
+  kappa[c] = (float)(-av * s1 / count - lam * mu);
+}
+
+extern "C" int ly_bn_bwd_coeffs_pair(const void* sums0, const void* sums1, int sums_f64, int stripes, int c_half, double count, const float* a, const float* mean,
+                                     const float* invstd, float* dgamma0, float* dbeta0, float* dgamma1, float* dbeta1, float* alpha, float* kappa,
+                                     float* lambda, void* stream) {
+  LY_CHECK(sums0 && sums1 && a && mean && invstd && dgamma0 && dbeta0 && dgamma1 && dbeta1 && alpha && kappa && lambda && c_half > 0 && count > 0 && stripes > 0,
+           "bn_bwd_coeffs_pair: bad arguments");
+  const dim3 grid((2 * c_half + LY_BNV_THREADS - 1) / LY_BNV_THREADS);
+  if (sums_f64)
+    hipLaunchKernelGGL(ly_bn_bwd_coeffs_pair_kernel<double>, grid, dim3(LY_BNV_THREADS), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const double*>(sums0),
+                       reinterpret_cast<const double*>(sums1), stripes, c_half, count, a, mean, invstd, dgamma0, dbeta0, dgamma1, dbeta1, alpha, kappa, lambda);
+  else
+    hipLaunchKernelGGL(ly_bn_bwd_coeffs_pair_kernel<float>, grid, dim3(LY_BNV_THREADS), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const float*>(sums0),
+                       reinterpret_cast<const float*>(sums1), stripes, c_half, count, a, mean, invstd, dgamma0, dbeta0, dgamma1, dbeta1, alpha, kappa, lambda);
+  LY_LAUNCH_CHECK();
+  return 0;
+}
+
 template <typename TS>
 __global__ __launch_bounds__(LY_BNV_THREADS) void ly_bn_bwd_coeffs_kernel(const TS* __restrict__ sums, int stripes, int N, double count,
                                                                       const float* __restrict__ a, const float* __restrict__ mean,

@@ -446,9 +446,7 @@ class ConvBnActPair(torch.autograd.Function):
         u = _conv_forward(spec, x0, x1, wp, None, None, ACT_NONE, stats=stats, store=True)
         rows = u.shape[0] * u.shape[2] * u.shape[3]
         v = torch.empty(4, co, dtype=torch.float32, device=x0.device)          # scale, shift, mean, invstd of both halves
-        for i, bn in enumerate((bn1, bn2)):
-            sl = slice(i * c_, (i + 1) * c_)
-            ops.bn_finalize(bn, stats, co, rows, n=c_, c_off=i * c_, into=(v[0, sl], v[1, sl], v[2, sl], v[3, sl]))
+        ops.bn_finalize_pair(bn1, bn2, stats, c_, rows, v)                      # one launch for the two BatchNorms
         y = torch.empty_like(u)
         ops.bnact_fwd(u, co, rows, co, v[0], v[1], spec.act, y, co)
         ctx.spec = spec
@@ -494,18 +492,23 @@ class ConvBnActPair(torch.autograd.Function):
             (dya, lda), (dyb, ldb) = dys
             sums2 = ops.bnact_bwd_reduce_pair(dya, lda, dyb, ldb, c_, u, co, rows, co, v[0], v[1], spec.act)
             coef = torch.empty(3, co, dtype=torch.float32, device=u.device)
+            # the coefficient kernel of both units in ONE launch; the gradients of gamma / beta are added into the sink's storage where
+            # there is one, else into fresh zeros handed to autograd
+            tgt, fresh = [], None
             for i in range(2):
-                off = i * c_
-                sl = slice(off, off + c_)
                 w_p, g_p, b_p = ctx.params[i]
                 tg, tb = ops.grad_target(g_p), ops.grad_target(b_p)
-                direct = tg is not None and tb is not None
-                dgamma, dbeta, _, _, _ = ops.bn_bwd_coeffs(sums2[i], c_, rows, v[0, sl], v[2, sl], v[3, sl], True, dgamma=tg if direct else None,
-                                                           dbeta=tb if direct else None, into=(coef[0, sl], coef[1, sl], coef[2, sl]))
-                if direct:
-                    ops.grad_done(g_p)
-                    ops.grad_done(b_p)
-                out[8 + 2 * i], out[9 + 2 * i] = dgamma, dbeta
+                if tg is not None and tb is not None and tg.is_contiguous() and tb.is_contiguous():
+                    tgt.append((tg, tb))
+                else:
+                    fresh = torch.zeros(2, 2, c_, dtype=torch.float32, device=u.device) if fresh is None else fresh
+                    tgt.append((fresh[i, 0], fresh[i, 1]))
+                    out[8 + 2 * i], out[9 + 2 * i] = fresh[i, 0], fresh[i, 1]
+            ops.bn_bwd_coeffs_pair(sums2[0], sums2[1], c_, rows, v, tgt, coef)
+            for i in range(2):
+                if out[8 + 2 * i] is None:
+                    ops.grad_done(ctx.params[i][1])
+                    ops.grad_done(ctx.params[i][2])
             ops.bnact_bwd_apply_pair(dya, lda, dyb, ldb, c_, u, co, rows, co, v[0], v[1], spec.act, coef[0], coef[1], coef[2], du, co)
             # A lazily 2x-upsampled source: the adjoint of the upsample (sum over each 2x2 block) commutes with the 1x1 convolution, so it is
             # applied ONCE to du (co channels) and that source's weight and data gradients are plain contractions at a quarter of the rows —

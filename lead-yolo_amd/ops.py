@@ -844,6 +844,41 @@ def bn_finalize(bn, stats, nch, count, n=None, c_off=0, bias=None, pad_to=0, wan
     return (scale, shift, mean, invstd) if want_stats else (scale, shift)
 
 
+def _bn_train_args(bn):
+    """(gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked) of a train-mode BatchNorm for the finalize kernels"""
+    track = bn.track_running_stats and bn.running_mean is not None
+    if bn.weight is not None and bn.weight.dtype != torch.float32:
+        raise NotImplementedError("train-mode BatchNorm needs float32 parameters and buffers: train under torch.autocast (fp32 master "
+                                  "weights, as the reference does), not with a .half()/.bfloat16() model")
+    if track and bn.momentum is None:
+        raise NotImplementedError("BatchNorm with momentum=None (cumulative average) is not built")
+    if track:
+        from . import pack
+        pack.touch()                     # running statistics are written by the kernel: eval-mode folded caches must refresh
+    return (_p(bn.weight), _p(bn.bias), float(bn.eps), float(bn.momentum or 0.0), _p(bn.running_mean if track else None),
+            _p(bn.running_var if track else None), _p(bn.num_batches_tracked if track else None))
+
+
+def bn_finalize_pair(bn1, bn2, stats, c_half, count, v):
+    """bn_finalize of two BatchNorms over one stacked [2 c_half]-channel statistics array in ONE launch; v: fp32 [4, 2 c_half] that
+    receives scale, shift, mean, invstd"""
+    if stats.dtype not in (torch.float32, torch.float64) or v.dtype != torch.float32 or not v.is_contiguous() or tuple(v.shape) != (4, 2 * c_half):
+        raise TypeError("bn_finalize_pair: float32 / float64 statistics and a contiguous float32 [4, 2 c_half] result expected")
+    capi.check(capi.lib().ly_bn_finalize_pair(_p(stats), int(stats.dtype == torch.float64), stats.shape[0], c_half, float(count), *_bn_train_args(bn1),
+                                              *_bn_train_args(bn2), _p(v[0]), _p(v[1]), _p(v[2]), _p(v[3]), capi.stream_ptr()), "ly_bn_finalize_pair")
+
+
+def bn_bwd_coeffs_pair(sums0, sums1, c_half, count, v, targets, coef):
+    """bn_bwd_coeffs (train) of the same two units in ONE launch.  v: [4, 2 c_half] of bn_finalize_pair; targets = ((dgamma0, dbeta0),
+    (dgamma1, dbeta1)): fp32 [c_half] tensors the kernel ADDS into; coef: fp32 [3, 2 c_half] that receives alpha, kappa, lambda"""
+    if sums0.dtype != sums1.dtype or sums0.shape != sums1.shape or sums0.dim() != 2:
+        raise TypeError("bn_bwd_coeffs_pair: two striped sum arrays of one shape expected")
+    (g0, b0), (g1, b1) = targets
+    capi.check(capi.lib().ly_bn_bwd_coeffs_pair(_p(sums0), _p(sums1), int(sums0.dtype == torch.float64), sums0.shape[0], c_half, float(count), _p(v[0]), _p(v[2]),
+                                                _p(v[3]), _p(g0), _p(b0), _p(g1), _p(b1), _p(coef[0]), _p(coef[1]), _p(coef[2]), capi.stream_ptr()),
+               "ly_bn_bwd_coeffs_pair")
+
+
 def bn_bwd_coeffs(sums, n, count, a, mean, invstd, train, dgamma=None, dbeta=None, transpose=None, into=None):
     """(dgamma, dbeta, alpha, kappa, lambda) from (striped) sums [.., 2n] of ly_bnact_bwd_reduce, ONE launch.  dgamma / dbeta given:
     the kernel ADDS into them (a parameter's persistent gradient storage, see GradSink) and None is returned in their place.

@@ -478,7 +478,8 @@ int ly_rf_bwd_dx(int n_img, int H, int W, int C, int k, int s, const void* dug /
  * image), ca = sigmoid(wb relu(wa mean)) and d_ca: dwa [R, C], dwb [C, R] are ADDED TO (one thread per weight sums the per-image outer
  * products kept in ws: no atomics, deterministic), dgap [n_img, C] = d/d(mean x) is written.  ws: scratch, n_img * (2C + 2R) floats. */
 int ly_se_bwd(const float* part, int slices, int n_img, int HW, int C, const float* wa, const float* wb, int R, const float* ca,
-              const float* d_ca, float* dwa, float* dwb, float* dgap, float* ws, void* stream);
+              const void* d_ca /* floats, or the double accumulators of ly_rf1_bwd / ly_rf3c_bwd if d_ca_f64 */, int d_ca_f64, float* dwa, float* dwb,
+              float* dgap, float* ws, void* stream);
 
 /* ---- per-channel BatchNorm vector work and weight packing, one launch each ------------------------------------------
  * STATISTICS ACCUMULATORS ARE STRIPED: every `stats` / `sums` / `mom` argument of the statistics passes above

@@ -156,7 +156,7 @@ SIGNATURES = {
     "ly_sppf_bwd": [_P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P],
     "ly_mlpblock_pconv": [_P, _P, _I, _I, _I, _I, _P, _I, _P],
     "ly_mlp_dx": [_P, _P, _P, _I, _L, _I, _I, _P, _I, _P],
-    "ly_se_bwd": [_P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P],
+    "ly_se_bwd": [_P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P],
     "ly_bn_finalize": [_P, _I, _I, _I, _I, _I, ctypes.c_double, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P],
     "ly_bn_bwd_coeffs": [_P, _I, _I, _I, ctypes.c_double, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P],
     "ly_bn_finalize_pair": [_P, _I, _I, _I, ctypes.c_double, _P, _P, _F, _F, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P],

@@ -1654,7 +1654,7 @@ extern "C" int ly_rfcbam_gen_prepare(const double* mom, int C, int k, const floa
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(LY_THREADS) void ly_se_bwd_kernel(const float* __restrict__ part, int slices, int C, float inv_hw,
                                                                 const float* __restrict__ wa, const float* __restrict__ wb, int R,
-                                                                const float* __restrict__ ca, const float* __restrict__ d_ca,
+                                                                const float* __restrict__ ca, const void* __restrict__ d_ca_v, const int d_ca_f64,
                                                                 float* __restrict__ ws, float* __restrict__ dgap) {
   extern __shared__ float sm[];
   float* g = sm;                     // g[C] | dz[C] | hid[R] | dh[R] | red
@@ -1677,7 +1677,9 @@ __global__ __launch_bounds__(LY_THREADS) void ly_se_bwd_kernel(const float* __re
   }
   for (int c = tid; c < C; c += LY_THREADS) {
     const float a = ca[(long)n * C + c];
-    dz[c] = d_ca[(long)n * C + c] * a * (1.f - a);
+    // d_ca as the double accumulators ly_rf1_bwd / ly_rf3c_bwd left it in (d_ca_f64), no conversion pass in between
+    const float dca = d_ca_f64 ? (float)reinterpret_cast<const double*>(d_ca_v)[(long)n * C + c] : reinterpret_cast<const float*>(d_ca_v)[(long)n * C + c];
+    dz[c] = dca * a * (1.f - a);
   }
   __syncthreads();
   for (int r = wave; r < R; r += 4) {
@@ -1742,11 +1744,11 @@ __global__ __launch_bounds__(LY_THREADS) void ly_se_bwd_wsum_kernel(const float*
 }
 
 extern "C" int ly_se_bwd(const float* part, int slices, int n_img, int HW, int C, const float* wa, const float* wb, int R, const float* ca,
-                         const float* d_ca, float* dwa, float* dwb, float* dgap, float* ws, void* stream) {
+                         const void* d_ca, int d_ca_f64, float* dwa, float* dwb, float* dgap, float* ws, void* stream) {
   LY_CHECK(part && wa && wb && ca && d_ca && dwa && dwb && dgap && ws, "se_bwd: null pointer");
   LY_CHECK((C & 3) == 0 && C <= 1024 && slices > 0 && R > 0 && R <= 256 && n_img > 0 && HW > 0, "se_bwd: bad arguments");
   hipLaunchKernelGGL(ly_se_bwd_kernel, dim3(n_img), dim3(LY_THREADS), sizeof(float) * (((2 * C + 2 * R + 3) & ~3) + 4 * LY_THREADS),
-                     reinterpret_cast<hipStream_t>(stream), part, slices, C, 1.f / (float)HW, wa, wb, R, ca, d_ca, ws, dgap);
+                     reinterpret_cast<hipStream_t>(stream), part, slices, C, 1.f / (float)HW, wa, wb, R, ca, d_ca, d_ca_f64, ws, dgap);
   LY_LAUNCH_CHECK();
   hipLaunchKernelGGL(ly_se_bwd_wsum_kernel, dim3((unsigned)((C * R + LY_THREADS - 1) / LY_THREADS)), dim3(LY_THREADS), 0,
                      reinterpret_cast<hipStream_t>(stream), ws, n_img, C, R, dwa, dwb);

@@ -244,6 +244,14 @@ def conv_wgrad(spec, du, x0, x1, weight):
     return dw
 
 
+def _tap_major_rows(g):
+    """[co, kh*kw*ci] row view of the [co][kh][kw][ci] storage behind a tap-major gradient target (see _tap_major), else None"""
+    if g is None or not _tap_major(g):
+        return None
+    co, ci, kh, kw = g.shape
+    return g.permute(0, 2, 3, 1).reshape(co, kh * kw * ci)
+
+
 def _tap_major(g):
     """gradient tensor of a [co, ci, kh, kw] weight whose storage is [co][kh][kw][ci] (see optim.FusedSGD)"""
     return g.dim() == 4 and not g.is_contiguous() and g.stride(1) == 1 and g.stride(3) == g.shape[1]
@@ -1010,7 +1018,7 @@ class RfcbamFn(torch.autograd.Function):
             kw = dict(n=n, h=h, w=w, c=c, ho=ho, wo=wo, N=o, s=s, th=th, tw=tw, x=xr, ldx=ld, wq=G["wq_c"], ca=ca, rfa=rfa, wp=P["wp_c"], ldo=o, raw=True)
             stats = ops.new_stats(o, xr.device)
             u = ops.empty_nhwc(n, o, ho, wo, xr)
-            ops.rf3c_fwd(out=u, e_scale=torch.ones_like(bias), e_shift=bias, stats=stats, **kw)
+            ops.rf3c_fwd(out=u, e_scale=ops.ones_f32(bias.numel(), bias.device), e_shift=bias, stats=stats, **kw)
             es, t, omean, oinv = ops.bn_finalize(mod.conv[1], stats, o, n * ho * wo, want_stats=True)
             out = torch.empty_like(u)
             ops.bnact_fwd(u, o, n * ho * wo, o, es, t, ACT_RELU, out, o)
@@ -1093,7 +1101,7 @@ class RfcbamFn(torch.autograd.Function):
                                       p(gmax), None, None, None, None, None, None, 0.0, None, c, None, code)
                 with ops._Timed(f"ly_rf3s_bwd_kernel<{ops._tname(xr)}, 0>", 8.0 * mo * kk * c, 3.0 * es9):
                     L.check(L.lib().ly_rf3s_bwd(ctypes.byref(P3), ho, wo, 0, st), "ly_rf3s_bwd 0")
-                d_ca = d_ca64.float().view_as(ca)
+                d_ca = d_ca64                                            # read as doubles by ly_se_bwd
             else:
                 with ops._Timed(f"ly_rf_bwd_attn_kernel<{ops._tname(xr)}, {k}>", 8.0 * mo * kk * c, 3.0 * es9):
                     L.check(L.lib().ly_rf_bwd_attn(n, h, w, c, k, s, p(ug), p(dcd), p(ag), p(bg), p(ca), p(rfa), p(cd), p(d_rfa), p(gmax), p(d_ca), code, st),
@@ -1104,6 +1112,10 @@ class RfcbamFn(torch.autograd.Function):
             tgt = ops.grad_target(ctx.conv_w_param)            # k = 1: the weight's own layout is what ly_wgrad writes
             if tgt is not None and kk == 1:
                 ops.wgrad(M=mo, H=ho, W=wo, N=o, du=du, lddu=o, x=cd, ldx=c, Hin=ho, Win=wo, Cin=c, dw=tgt, lddw=c)
+                ops.grad_done(ctx.conv_w_param)
+                dwc = None
+            elif _tap_major_rows(tgt) is not None:                  # k = 3 with a tap-major sink: [o][t][c] is the storage's own order
+                ops.wgrad(M=mo, H=ho, W=wo, N=o, du=du, lddu=o, x=cd, ldx=kk * c, Hin=ho, Win=wo, Cin=kk * c, dw=_tap_major_rows(tgt), lddw=kk * c)
                 ops.grad_done(ctx.conv_w_param)
                 dwc = None
             else:
@@ -1212,8 +1224,14 @@ def _rfcbam_backward_rc(ctx, du, dgo, dbo):
     # conv weight gradient (independent of the chain below)
     with ops._Timed("ly_rf3c_wgrad_kernel", 2.0 * mo * 9 * c * o, xb, valu_flops=2.0 * mo * c * 81):
         L.check(L.lib().ly_rf3c_wgrad(ctypes.byref(P), st), "ly_rf3c_wgrad")
-    dwc = ops.sum_rows(dwc_part) if ng > 1 else dwc_part[0]
-    dwc = dwc.permute(0, 2, 1).reshape(conv_w.shape)
+    trows = _tap_major_rows(ops.grad_target(ctx.conv_w_param))
+    if trows is not None:                                       # tap-major sink: the fold of the partials adds straight into the gradient storage
+        ops.sum_rows(dwc_part.view(ng, o, 9 * c), out=trows, accumulate=True)
+        ops.grad_done(ctx.conv_w_param)
+        dwc = None
+    else:
+        dwc = ops.sum_rows(dwc_part) if ng > 1 else dwc_part[0]
+        dwc = dwc.permute(0, 2, 1).reshape(conv_w.shape)
     # get_weight + sigmoid
     d_rfa = ops.sum_rows(d_rfa_part).view_as(rfa) if nch > 1 else d_rfa_part[0].view_as(rfa)
     w18 = getw.detach().float().reshape(18).contiguous()
@@ -1307,7 +1325,7 @@ def _rfcbam_backward_k1(ctx, du, dgo, dbo):
     tn = ops._tname(xr)
     with ops._Timed(f"ly_rf1_bwd_kernel<{tn}, 0>", 6.0 * mo * c, 3.0 * es1):
         L.check(L.lib().ly_rf1_bwd(ctypes.byref(P), 0, st), "ly_rf1_bwd A")
-    d_ca = d_ca64.float().view_as(ca)
+    d_ca = d_ca64                                            # read as doubles by ly_se_bwd
     # conv weight gradient from cd
     tgt = ops.grad_target(ctx.conv_w_param)
     if tgt is not None:

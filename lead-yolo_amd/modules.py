@@ -574,6 +574,8 @@ class RFCBAMConv(nn.Module):
         self.get_weight = nn.Sequential(nn.Conv2d(2, 1, kernel_size=3, padding=1, bias=False), nn.Sigmoid())
         self.se = SE(in_channel)
         self.conv = nn.Sequential(nn.Conv2d(in_channel, out_channel, k, stride=k), nn.BatchNorm2d(out_channel), nn.ReLU())
+        if k > 1:
+            self.conv[0].weight._ly_tap_major = True    # optim.FusedSGD may keep this gradient [o][kh][kw][c]: what the k = 3 backward produces
         self._prep = _Prepared()
 
     def _packed(self, planes=2):
@@ -713,7 +715,7 @@ class RFCBAMConv(nn.Module):
         if self.training:
             bias = self.conv[0].bias.detach().float().contiguous()
             stats = ops.new_stats(self.o, xr.device)
-            ops.rf3c_fwd(out=None, e_scale=torch.ones_like(bias), e_shift=bias, stats=stats, **kw)   # conv.1 statistics pass
+            ops.rf3c_fwd(out=None, e_scale=ops.ones_f32(bias.numel(), bias.device), e_shift=bias, stats=stats, **kw)   # conv.1 statistics pass
             es, eb = ops.bn_finalize(self.conv[1], stats, self.o, n * ho * wo, bias=bias)
         out = ops.empty_nhwc(n, self.o, ho, wo, xr)
         ops.rf3c_fwd(out=out, e_scale=es, e_shift=eb, **kw)

@@ -295,10 +295,13 @@ def se_attention(x, ldx, n, hw, c, wa, wb, r, want_part=False):
 
 
 def se_bwd(part, n, hw, c, wa, wb, r, ca, d_ca, dwa, dwb):
-    """SE backward: dwa [r, c] / dwb [c, r] are ADDED to; returns dgap [n, c] = d/d(mean x)"""
+    """SE backward: dwa [r, c] / dwb [c, r] are ADDED to; returns dgap [n, c] = d/d(mean x).  d_ca: float32, or the float64 accumulators
+    the RFCBAM backward kernels sum it in (read as they are)"""
+    if d_ca.dtype not in (torch.float32, torch.float64) or d_ca.numel() != n * c or not d_ca.is_contiguous():
+        raise ValueError("se_bwd: d_ca must be a contiguous float32 / float64 [n, c]")
     dgap = torch.empty((n, c), dtype=torch.float32, device=part.device)
     ws = torch.empty(n * (2 * c + 2 * r), dtype=torch.float32, device=part.device)
-    capi.check(capi.lib().ly_se_bwd(_p(part), part.shape[1], n, hw, c, _p(wa), _p(wb), r, _p(ca), _p(d_ca), _p(dwa), _p(dwb), _p(dgap), _p(ws),
+    capi.check(capi.lib().ly_se_bwd(_p(part), part.shape[1], n, hw, c, _p(wa), _p(wb), r, _p(ca), _p(d_ca), int(d_ca.dtype == torch.float64), _p(dwa), _p(dwb), _p(dgap), _p(ws),
                                     capi.stream_ptr()), "ly_se_bwd")
     return dgap
 
@@ -785,6 +788,19 @@ def new_sums(nch, device):
     return torch.zeros(STRIPES, 2 * nch, dtype=torch.float32, device=device)
 
 
+_ONES = {}
+
+
+def ones_f32(numel, device):
+    """a shared READ-ONLY vector of ones (an identity epilogue scale): allocated once per (size, device), no fill launch per step"""
+    t = _ONES.get((numel, device))
+    if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            return torch.ones(numel, dtype=torch.float32, device=device)
+        t = _ONES[(numel, device)] = torch.ones(numel, dtype=torch.float32, device=device)
+    return t
+
+
 def zeros_f64(numel, device):
     """zeroed float64 scratch out of the step's zero pool (an 8-byte view of 2 * numel pool floats; pool slices are 256-byte aligned)"""
     return zeros_f32(2 * numel, device).view(torch.float64)
@@ -822,8 +838,10 @@ def bn_finalize(bn, stats, nch, count, n=None, c_off=0, bias=None, pad_to=0, wan
         scale, shift, mean, invstd = into
         want_stats = True
     else:
-        alloc = torch.zeros if size > n else torch.empty
-        scale, shift = alloc(size, dtype=torch.float32, device=dev), alloc(size, dtype=torch.float32, device=dev)
+        if size > n:                 # zero-padded tails (MLPBlock's hidden tiles): out of the step's zero pool, no fill launches
+            scale, shift = zeros_f32(size, dev), zeros_f32(size, dev)
+        else:
+            scale, shift = torch.empty(size, dtype=torch.float32, device=dev), torch.empty(size, dtype=torch.float32, device=dev)
         mean = torch.empty(n, dtype=torch.float32, device=dev) if want_stats else None
         invstd = torch.empty(n, dtype=torch.float32, device=dev) if want_stats else None
     track = bn.track_running_stats and bn.running_mean is not None

@@ -1,6 +1,7 @@
 """Device time per kernel of ONE steady-state eager training step (torch profiler, device activity), so that model construction /
 first-step work does not leak into the per-step table the way it does in a whole-process rocprofv3 trace.
-    python tools/step_kernels.py [f32|bf16] [bs] [top] [scale=s] [size=640]"""
+    python tools/step_kernels.py [f32|bf16] [bs] [top] [scale=s] [size=640] [seq]
+`seq`: the launches in stream order instead (name, duration), to see which small dependent launches sit next to each other"""
 import os, sys, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -32,6 +33,11 @@ for ev, nm in zip(evs, names):
     nm = short(nm) if "ly_" in nm else nm
     acc[nm] += ev.device_time
     cnt[nm] += 1
+if "seq" in sys.argv:
+    order = sorted(zip(evs, names), key=lambda p: p[0].time_range.start)
+    for i, (ev, nm) in enumerate(order):
+        print(f"{i:4d} {ev.device_time:8.1f} us  {(short(nm) if 'ly_' in nm else nm)[:150]}")
+    sys.exit(0)
 tot = sum(acc.values())
 own = sum(v for k, v in acc.items() if k.startswith("ly_"))
 print(f"one steady-state eager optimisation step, lead-yolo-{scale} bs={bs} {size}x{size} {'bf16' if amp else 'f32'}: kernels={sum(cnt.values())} "

@@ -321,7 +321,7 @@ int ly_rfcbam_tap_moments(const void* x /*T*/, int ldx, int n_img, int H, int W,
  *          ([ceil(C/32)*32 | ceil(C/16)*16][9][10] floats each);  k = 1: a1[c] = w[c]*scale[c].                                  */
 int ly_rfcbam_gen_prepare(const double* mom, int C, int k, const float* gen_w, const float* gamma, const float* beta, float eps,
                           float momentum, double count, float* running_mean, float* running_var, long* nbt, float* out8, float* a1,
-                          float* wq_stats, float* wq_main, float* wq_c /* NULL or [C*100]: the RAW lane-order image of ly_rf3c_* */, void* stream);
+                          float* wq_stats, float* wq_main, float* wq_c /* NULL or [C*100]: the RAW lane-order image of ly_rf3c_* */, int mom_stripes /* 1; k = 1: the striped [mom_stripes][2C] array of ly_chan_moments, folded here */, void* stream);
 
 /* ---- eval tail: non_max_suppression on the device (utils/general.py:884-994; detect.py:149, val.py:230-234) --------------------------
  * pred [bs, N, no = 5 + nc] fp32 (xywh, obj, class confidences: Detect's inference output).

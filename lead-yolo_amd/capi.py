@@ -119,7 +119,7 @@ SIGNATURES = {
     "ly_rfcbam3_fwd": [ctypes.POINTER(LyRfcbam3Params), _P],
     "ly_chan_moments": [_P, _I, _L, _I, _P, _I, _P],
     "ly_rfcbam_tap_moments": [_P, _I, _I, _I, _I, _I, _I, _P, _I, _P],
-    "ly_rfcbam_gen_prepare": [_P, _I, _I, _P, _P, _P, _F, _F, ctypes.c_double, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "ly_rfcbam_gen_prepare": [_P, _I, _I, _P, _P, _P, _F, _F, ctypes.c_double, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "ly_rf3c_stats": [_P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _I, _P, _P, _I, _I, _P],
     "ly_rf3c_fwd": [ctypes.POINTER(LyRfcbam3Params), _P, _I, _P],
     "ly_rf3m_stats": [_P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P, _I, _P],

@@ -1009,12 +1009,25 @@ __global__ __launch_bounds__(LY_THREADS) void ly_chan_moments_kernel(const T* __
   const int groups = LY_THREADS / nc4;
   const int c4 = tid % nc4, j0 = tid / nc4;
   f32x4 s1 = ly_zero4(), s2 = ly_zero4();
-  if (j0 < groups)
-    for (long r = (long)blockIdx.x * groups + j0; r < rows; r += (long)gridDim.x * groups) {
-      const f32x4 v = ly_ld4<T>(x + r * ldx + 4 * c4);
-      s1 += v;
-      s2 += v * v;
+  if (j0 < groups) {
+    // four rows per trip, all four loads issued before the first use (one row per trip paid a round trip per row: 21 us for the 8 MB of
+    // RFCBAMConv layer 9's input, on 67 blocks); rows past the end re-read the last row and are masked
+    const long step = (long)gridDim.x * groups;
+    for (long r = (long)blockIdx.x * groups + j0; r < rows; r += 4 * step) {
+      f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long rr = r + u * step;
+        v[u] = ly_ld4<T>(x + (rr < rows ? rr : rows - 1) * ldx + 4 * c4);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const f32x4 w = r + u * step < rows ? v[u] : ly_zero4();
+        s1 += w;
+        s2 += w * w;
+      }
     }
+  }
   red1[tid] = s1; red2[tid] = s2;
   __syncthreads();
   if (j0 == 0) {
@@ -1032,8 +1045,8 @@ extern "C" int ly_chan_moments(const void* x, int ldx, long rows, int C, double*
   LY_CHECK_DTYPE(dtype, "chan_moments");
   LY_CHECK(x && mom && (C & 3) == 0 && (ldx & 3) == 0 && C <= 1024 && rows > 0, "chan_moments: bad arguments");
   const int groups = LY_THREADS / (C >> 2);
-  long blocks = (rows + groups * 64L - 1) / (groups * 64L);
-  if (blocks > 1024) blocks = 1024;
+  long blocks = (rows + groups * 16L - 1) / (groups * 16L);    // ~16 rows per row group: four trips of four rows in flight
+  if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
   LY_WITH_T(dtype, hipLaunchKernelGGL(ly_chan_moments_kernel<T>, dim3((unsigned)blocks), dim3(LY_THREADS), 0, reinterpret_cast<hipStream_t>(stream),
                                       reinterpret_cast<const T*>(x), ldx, rows, C, mom));
@@ -1565,7 +1578,7 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_gen_prepare_kernel(
     const double* __restrict__ mom, int C, int KK, const float* __restrict__ gen_w, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, float momentum, double count, float* __restrict__ running_mean,
     float* __restrict__ running_var, long* __restrict__ nbt, float* __restrict__ out8 /* [8][C*KK] */, float* __restrict__ a1,
-    float* __restrict__ wq_stats, int cp_stats, float* __restrict__ wq_main, int cp_main, float* __restrict__ wq_c) {
+    float* __restrict__ wq_stats, int cp_stats, float* __restrict__ wq_main, int cp_main, float* __restrict__ wq_c, const int mom_stripes) {
   const int G = C * KK;
   const int cpm = cp_stats > cp_main ? cp_stats : cp_main;
   const int total = (KK == 9 ? (cpm > C ? cpm : C) : C) * KK;
@@ -1595,8 +1608,14 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_gen_prepare_kernel(
       }
     } else {
       w[0] = gen_w[g];
-      s1 = (double)w[0] * mom[c];
-      s2 = (double)w[0] * (double)w[0] * mom[C + c];
+      // k = 1: the moments as ly_chan_moments left them — mom_stripes copies of [2C] doubles, folded here in index order (was a launch of its own)
+      double m1 = 0.0, m2 = 0.0;
+      for (int st = 0; st < mom_stripes; ++st) {
+        m1 += mom[(size_t)st * 2 * C + c];
+        m2 += mom[(size_t)st * 2 * C + C + c];
+      }
+      s1 = (double)w[0] * m1;
+      s2 = (double)w[0] * (double)w[0] * m2;
     }
     const double mean = s1 / count;
     double var = s2 / count - mean * mean;
@@ -1632,8 +1651,9 @@ __global__ __launch_bounds__(LY_THREADS) void ly_rfcbam_gen_prepare_kernel(
 
 extern "C" int ly_rfcbam_gen_prepare(const double* mom, int C, int k, const float* gen_w, const float* gamma, const float* beta, float eps,
                                      float momentum, double count, float* running_mean, float* running_var, long* nbt, float* out8,
-                                     float* a1, float* wq_stats, float* wq_main, float* wq_c, void* stream) {
+                                     float* a1, float* wq_stats, float* wq_main, float* wq_c, int mom_stripes, void* stream) {
   LY_CHECK(mom && gen_w && gamma && beta && out8 && C > 0 && (k == 1 || k == 3) && count > 0, "rfcbam_gen_prepare: bad arguments");
+  LY_CHECK(mom_stripes >= 1 && (k == 1 || mom_stripes == 1), "rfcbam_gen_prepare: striped moments are read for k = 1 only (mom_stripes=%d)", mom_stripes);
   LY_CHECK(k == 1 ? a1 != nullptr : (wq_stats && wq_main), "rfcbam_gen_prepare: missing output for k=%d", k);
   LY_CHECK(!running_mean == !running_var, "rfcbam_gen_prepare: running_mean and running_var go together");
   const int KK = k * k;
@@ -1641,7 +1661,7 @@ extern "C" int ly_rfcbam_gen_prepare(const double* mom, int C, int k, const floa
   const int total = (k == 3 ? cp_s : C) * KK;
   hipLaunchKernelGGL(ly_rfcbam_gen_prepare_kernel, dim3((unsigned)((total + LY_THREADS - 1) / LY_THREADS)), dim3(LY_THREADS), 0,
                      reinterpret_cast<hipStream_t>(stream), mom, C, KK, gen_w, gamma, beta, eps, momentum, count, running_mean, running_var, nbt,
-                     out8, a1, wq_stats, k == 3 ? cp_s : 0, wq_main, k == 3 ? cp_m : 0, k == 3 ? wq_c : nullptr);
+                     out8, a1, wq_stats, k == 3 ? cp_s : 0, wq_main, k == 3 ? cp_m : 0, k == 3 ? wq_c : nullptr, mom_stripes);
   LY_LAUNCH_CHECK();
   return 0;
 }

@@ -726,12 +726,15 @@ def mlpblock_bwd_dx(g, dy, x, n, h, w, c, wpt, dwp=None, lddw=0, dw_ts=0, dw_cs=
     return dx, rc == 0
 
 
-def chan_moments(x, ldx, rows, c, f64=False):
+def chan_moments(x, ldx, rows, c, f64=False, striped=False):
     """per-channel (sum x, sum x^2) over the rows of an [rows, c] matrix -> [2c]; accumulated in double stripes, folded in index order
-    (float32 result unless f64: ly_rfcbam_gen_prepare takes the doubles)"""
+    (float32 result unless f64: ly_rfcbam_gen_prepare takes the doubles; striped: the [STRIPES][2c] accumulators as they are — that kernel
+    folds them itself)"""
     mom = new_stats(c, x.device)
     with _Timed(f"ly_chan_moments_kernel<{_tname(x)}>", 3.0 * rows * c, x.element_size() * rows * c):
         capi.check(capi.lib().ly_chan_moments(_p(x), ldx, rows, c, _p(mom), capi.dtype_code(x), capi.stream_ptr()), "ly_chan_moments")
+    if striped:
+        return mom
     out = torch.empty(2 * c, dtype=torch.float64, device=x.device)
     capi.check(capi.lib().ly_sum_rows_f64(_p(mom), mom.shape[0], 2 * c, _p(out), capi.stream_ptr()), "ly_sum_rows_f64")
     return out if f64 else out.float()
@@ -1023,7 +1026,7 @@ def rfcbam_gen_prepare(x, ldx, n, h, w, c, k, s, gen_w, bn):
         ho, wo = (h + 2 - 3) // s + 1, (w + 2 - 3) // s + 1
         count = n * ho * wo
     else:
-        mom = chan_moments(x, ldx, n * h * w, c, f64=True)
+        mom = chan_moments(x, ldx, n * h * w, c, striped=True)
         count = n * h * w
     g = c * kk
     out8 = torch.empty(8, g, dtype=torch.float32, device=dev)
@@ -1038,7 +1041,7 @@ def rfcbam_gen_prepare(x, ldx, n, h, w, c, k, s, gen_w, bn):
     capi.check(capi.lib().ly_rfcbam_gen_prepare(_p(mom), c, k, _p(gen_w.detach()), _p(bn.weight.detach()), _p(bn.bias.detach()), float(bn.eps),
                                                 float(bn.momentum or 0.0), float(count), _p(bn.running_mean if track else None),
                                                 _p(bn.running_var if track else None), _p(bn.num_batches_tracked if track else None), _p(out8),
-                                                _p(a1), _p(wqs), _p(wqm), _p(wqc), capi.stream_ptr()), "ly_rfcbam_gen_prepare")
+                                                _p(a1), _p(wqs), _p(wqm), _p(wqc), mom.shape[0] if k == 1 else 1, capi.stream_ptr()), "ly_rfcbam_gen_prepare")
     from . import pack
     pack.touch()                                   # running statistics written behind torch's version counters
     return dict(gs=out8[0], gb=out8[1], gmean=out8[2], ginv=out8[3], ag=out8[4], bg=out8[5], gmean_tc=out8[6], ginv_tc=out8[7], a1=a1,

@@ -18,7 +18,9 @@ def test_named_kernel_is_row_0_of_the_committed_step_table():
     rows = [ln for ln in open(table).read().splitlines()[1:] if ln.strip()]
     name = d["roofline"]["kernel"]
     assert rows[0].startswith(name) and d["roofline"]["frac"] == d["roofline"]["hbm_frac"]
-    # the whole-process rocprofv3 trace of the same command (kernel-trace --stats, per step) names the same kernel first
+    # the whole-process rocprofv3 trace of the same command (kernel-trace --stats, per step) names the same kernel first among the library's
+    # kernels (that trace also holds the set-up of the process — ~820 `__amd_rocclr_copyBuffer` device copies of model construction, the EMA
+    # deep copy and the state load, divided by the 7 steps like everything else — which the steady-state table above does not)
     trace = os.path.join(ROOT, "profiles", "r06_train_bf16_kernels_per_step.txt")
     if os.path.exists(trace):
-        assert [ln for ln in open(trace).read().splitlines()[1:] if ln.strip()][0].startswith(name)
+        assert [ln for ln in open(trace).read().splitlines()[1:] if ln.strip().startswith("ly_")][0].startswith(name)

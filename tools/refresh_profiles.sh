@@ -35,14 +35,14 @@ one train_bf16 --dtype bf16
 one train_f32 --dtype f32
 one fwd_f32 --mode forward --dtype f32
 one fwd_bf16 --mode forward --dtype bf16
-# the bench lines themselves (they read the PMC summaries: copy them where bench.py looks)
-cp $OUT/${TAG}_*_pmc_traffic.json $OUT/${TAG}_*_pmc_mfma.json $R/profiles/ 2>/dev/null
 cd $R
+# steady-state per-kernel table of ONE eager step (torch profiler, device activity): no model-construction launches in the counts
+python3 tools/step_kernels.py bf16 64 400 2>/dev/null | grep -v "^\[W\|Warn" > $OUT/${TAG}_train_bf16_step_kernels.txt
+python3 tools/step_kernels.py f32 64 400 2>/dev/null | grep -v "^\[W\|Warn" > $OUT/${TAG}_train_f32_step_kernels.txt
+# the bench lines themselves: they read the PMC summaries and name row 0 of the step table — copy those where bench.py looks FIRST
+cp $OUT/${TAG}_*_pmc_traffic.json $OUT/${TAG}_*_pmc_mfma.json $OUT/${TAG}_train_*_step_kernels.txt $R/profiles/ 2>/dev/null
 python3 bench.py --dtype bf16 --layers > $OUT/${TAG}_train_bf16_bench.json 2> $OUT/${TAG}_train_bf16_kernels.txt
 python3 bench.py --dtype f32 --layers > $OUT/${TAG}_train_f32_bench.json 2> $OUT/${TAG}_train_f32_kernels.txt
 python3 bench.py --mode forward --dtype f32 --layers > $OUT/${TAG}_fwd_f32_bench.json 2> $OUT/${TAG}_fwd_f32_kernels.txt
 python3 bench.py --mode forward --dtype bf16 --layers --no-cpu-baseline > $OUT/${TAG}_fwd_bf16_bench.json 2> $OUT/${TAG}_fwd_bf16_kernels.txt
-# steady-state per-kernel table of ONE eager step (torch profiler, device activity): no model-construction launches in the counts
-python3 tools/step_kernels.py bf16 64 400 2>/dev/null | grep -v "^\[W\|Warn" > $OUT/${TAG}_train_bf16_step_kernels.txt
-python3 tools/step_kernels.py f32 64 400 2>/dev/null | grep -v "^\[W\|Warn" > $OUT/${TAG}_train_f32_step_kernels.txt
 ls -la $OUT | head -40

@@ -249,7 +249,10 @@ def _tap_major_rows(g):
     if g is None or not _tap_major(g):
         return None
     co, ci, kh, kw = g.shape
-    return g.permute(0, 2, 3, 1).reshape(co, kh * kw * ci)
+    rows = g.permute(0, 2, 3, 1)
+    if not rows.is_contiguous():                 # (reshape would hand out a copy: the gradient written into it would be lost)
+        return None
+    return rows.view(co, kh * kw * ci)
 
 
 def _tap_major(g):

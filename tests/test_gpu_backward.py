@@ -1254,3 +1254,83 @@ def test_fork_sum_matches_autograd_sum(amp, monkeypatch):
         for k in res[True][1]:
             a, b = res[True][1][k], res[False][1][k]
             assert float((a - b).norm()) <= 0.25 * float(b.norm()) + 1e-3 * float(vb.abs().max()), k
+
+
+@pytest.mark.parametrize("c_half", [64, 40, 256])
+def test_pair_coefficient_kernels_equal_two_single_launches(c_half):
+    """ly_bn_finalize_pair / ly_bn_bwd_coeffs_pair (both BatchNorms of a cv1 | cv2 unit in one launch each) leave the same bits as the two
+    single-unit launches they replace: scale / shift / mean / invstd, the running statistics and num_batches_tracked, dgamma / dbeta added into
+    their targets, alpha / kappa / lambda"""
+    from lead_yolo_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(11 + c_half)
+    co, count = 2 * c_half, 4321.0
+    mk = lambda: [torch.nn.BatchNorm2d(c_half, momentum=0.03, eps=1e-3).to(dev).train() for _ in range(2)]
+    bns_a, bns_b = mk(), mk()
+    for pa, pb in zip(bns_a, bns_b):
+        w, b = torch.rand(c_half, generator=g) + 0.5, torch.randn(c_half, generator=g)
+        rm, rv = torch.randn(c_half, generator=g), torch.rand(c_half, generator=g) + 0.5
+        for bn in (pa, pb):
+            bn.weight.data.copy_(w); bn.bias.data.copy_(b); bn.running_mean.copy_(rm); bn.running_var.copy_(rv)
+    s1 = torch.randn(ops.STRIPES, co, generator=g, dtype=torch.float64) * 3
+    s2 = torch.rand(ops.STRIPES, co, generator=g, dtype=torch.float64) * 50 + 200
+    stats = torch.cat([s1, s2], 1).contiguous().to(dev)                       # [stripes][2 co]: sums | sums of squares
+    v_pair = torch.empty(4, co, dtype=torch.float32, device=dev)
+    ops.bn_finalize_pair(bns_a[0], bns_a[1], stats, c_half, count, v_pair)
+    v_one = torch.empty(4, co, dtype=torch.float32, device=dev)
+    for i, bn in enumerate(bns_b):
+        sl = slice(i * c_half, (i + 1) * c_half)
+        ops.bn_finalize(bn, stats, co, count, n=c_half, c_off=i * c_half, into=(v_one[0, sl], v_one[1, sl], v_one[2, sl], v_one[3, sl]))
+    assert torch.equal(v_pair, v_one)
+    for pa, pb in zip(bns_a, bns_b):
+        assert torch.equal(pa.running_mean, pb.running_mean) and torch.equal(pa.running_var, pb.running_var)
+        assert int(pa.num_batches_tracked) == int(pb.num_batches_tracked) == 1
+    sums = [torch.randn(ops.STRIPES, 2 * c_half, generator=g, dtype=torch.float64).to(dev) for _ in range(2)]
+    t0 = [torch.randn(c_half, generator=g).to(dev) for _ in range(4)]
+    tp, to = [t.clone() for t in t0], [t.clone() for t in t0]
+    coef_p = torch.empty(3, co, dtype=torch.float32, device=dev)
+    ops.bn_bwd_coeffs_pair(sums[0], sums[1], c_half, count, v_pair, ((tp[0], tp[1]), (tp[2], tp[3])), coef_p)
+    coef_o = torch.empty(3, co, dtype=torch.float32, device=dev)
+    for i in range(2):
+        sl = slice(i * c_half, (i + 1) * c_half)
+        ops.bn_bwd_coeffs(sums[i], c_half, count, v_one[0, sl], v_one[2, sl], v_one[3, sl], True, dgamma=to[2 * i], dbeta=to[2 * i + 1],
+                          into=(coef_o[0, sl], coef_o[1, sl], coef_o[2, sl]))
+    assert torch.equal(coef_p, coef_o)
+    for a, b in zip(tp, to):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("rows,c", [(25600, 160), (1000, 256), (37, 8), (4099, 64)])
+def test_chan_moments_striped_and_folded(rows, c, dtype):
+    """ly_chan_moments (four rows in flight, ~16 rows per row group) against float64 sums of the stored values; the striped accumulators folded
+    by torch equal the kernel's own fold"""
+    from lead_yolo_amd import ops
+    g = torch.Generator().manual_seed(rows + c)
+    x = (torch.randn(rows, c, generator=g) * 2 + 0.3).to(dtype).to(_dev())
+    folded = ops.chan_moments(x, c, rows, c, f64=True)
+    striped = ops.chan_moments(x, c, rows, c, striped=True)
+    xd = x.double()
+    want = torch.cat([xd.sum(0), (xd * xd).sum(0)])
+    torch.testing.assert_close(folded, want, rtol=1e-6, atol=1e-6 * rows)
+    torch.testing.assert_close(striped.sum(0), want, rtol=1e-6, atol=1e-6 * rows)
+
+
+def test_se_bwd_reads_double_accumulators():
+    """ly_se_bwd with d_ca handed over as float64 (what ly_rf1_bwd / ly_rf3s_bwd accumulate) equals the float32 call on the rounded values"""
+    from lead_yolo_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(9)
+    n, c, r, hw, slices = 6, 160, 10, 400, 5
+    part = torch.randn(n, slices, c, generator=g).to(dev)
+    wa, wb = (torch.randn(r, c, generator=g) * 0.1).to(dev), (torch.randn(c, r, generator=g) * 0.1).to(dev)
+    ca = torch.rand(n, c, generator=g).to(dev) * 0.8 + 0.1
+    d64 = torch.randn(n, c, generator=g, dtype=torch.float64).to(dev)
+    d32 = d64.float()
+    outs = []
+    for d in (d64, d32):
+        dwa, dwb = torch.zeros_like(wa), torch.zeros_like(wb)
+        dgap = ops.se_bwd(part, n, hw, c, wa, wb, r, ca, d, dwa, dwb)
+        outs.append((dgap, dwa, dwb))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)

@@ -153,3 +153,18 @@ def test_optimizer_groups_and_ema_match_reference_recipe():
     k = "model.0.proj.weight"
     assert torch.allclose(ema.ema.state_dict()[k], w0[k] * d + (w0[k] + 1.0) * (1 - d), atol=1e-6)
     assert ema.updates == 1
+
+
+@pytest.mark.parametrize("scale", ["n", "s", "l"])
+def test_two_consumer_layers_follow_the_routing_table(scale):
+    """Model._two_consumer_layers (the layer outputs grad.fork splits in training) is exactly the set of layers read by two later layers of the
+    reference's routing (`m.f`, models/yolo.py:179-195): the backbone stages 3 and 5 (next stage + neck concat), the neck maps 9 and 13 (upsample +
+    later concat) and the neck outputs 16 and 19 (Detect level + next RFCBAMConv); layer 22 feeds Detect only"""
+    torch.manual_seed(0)
+    m = L.Model(L.load_cfg(scale=scale))
+    readers = {}
+    for mod in m.model:
+        for j in ([mod.f] if isinstance(mod.f, int) else mod.f):
+            readers.setdefault(mod.i - 1 if j == -1 else j, []).append(mod.i)
+    assert sorted(m._two_consumer_layers()) == sorted(j for j, r in readers.items() if len(r) == 2 and j >= 0) == [3, 5, 9, 13, 16, 19]
+    assert all(j in m.save or readers[j] == [j + 1] or (j + 1) in readers[j] for j in m._two_consumer_layers())

@@ -554,7 +554,7 @@ int ly_rf1_bwd(const LyRf1BwdParams* p, int pass, void* stream);
 /* Small parameter-gradient reductions, reproducibly: the kernels above that add a handful of values from many blocks (Detect bias, get_weight,
  * k = 1 generate weight, CoordAtt's MLP) can accumulate into zeroed DOUBLE scratches instead of the fp32 gradients; ly_f64_add then rounds each
  * sum into its fp32 target (dst[i] += (float)src[i]) — ONE launch for up to LY_F64_ADD_MAX vectors, after the backward pass.                   */
-#define LY_F64_ADD_MAX 32
+#define LY_F64_ADD_MAX 64
 typedef struct LyF64AddTable {
   const double* src[LY_F64_ADD_MAX];
   float* dst[LY_F64_ADD_MAX];

@@ -52,7 +52,7 @@ class LyRf1BwdParams(ctypes.Structure):
                 ("dgw_f64", _I)]
 
 
-F64_ADD_MAX = 32
+F64_ADD_MAX = 64
 
 
 class LyF64AddTable(ctypes.Structure):

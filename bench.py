@@ -294,9 +294,12 @@ def pconv_rfcbam_probe(model, x, dtype, iters=10):
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for _ in range(2):
-                    t(xi)
+                    yo = t(xi)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
+            # the module's own algorithmic bytes (input + output once at the storage dtype + fp32 parameters once) and the time
+            # the north-star target of 0.22 of HBM would allow it (per-module budgets in the line)
+            mod_bytes = (xi.numel() + yo.numel()) * xi.element_size() + 4 * sum(p.numel() for p in t.parameters())
             mode = "hipGraph replay"
             try:
                 g = torch.cuda.CUDAGraph()
@@ -317,7 +320,8 @@ def pconv_rfcbam_probe(model, x, dtype, iters=10):
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / iters
             total_ms += ms
-            per.append((type(t).__name__, tuple(xi.shape[1:]), round(ms * 1e3, 1)))
+            per.append((type(t).__name__, tuple(xi.shape[1:]), round(ms * 1e3, 1), round(mod_bytes / ms / 1e6 / HBM_PEAK_GBS, 3),
+                        round(mod_bytes / (0.22 * HBM_PEAK_GBS * 1e9) * 1e6, 1)))
         # the same ten modules replayed from ONE hipGraph (their launches back to back on the stream): separates the kernels' time from the
         # ~5 us fixed cost every single-module replay above carries (MI355X guide: graph-replay floor)
         one_ms = None
@@ -350,7 +354,9 @@ def pconv_rfcbam_probe(model, x, dtype, iters=10):
                 hbm_frac=round(gbs / HBM_PEAK_GBS, 4), **one, us_per_module=per,
                 note="eval forward; every launch of the 6 MLPBlocks + 4 RFCBAMConvs (SE, stats, rfa map, contraction) inside the timed "
                      "region, each module replayed from its own hipGraph (serving mode); one_graph_ms = the ten modules replayed from ONE "
-                     "hipGraph (no per-module replay floor); bytes = SURVEY 8(d): in + out once at the storage dtype + fp32 parameters once")
+                     "hipGraph (no per-module replay floor); bytes = SURVEY 8(d): in + out once at the storage dtype + fp32 parameters once; "
+                     "us_per_module rows = [module, input shape, us per replay, the module's own fraction of HBM, budget_us = what 0.22 of HBM "
+                     "(the round's target for the set) allows that module]")
 
 
 # whole-model block-fused lower bound, lead-yolo-s @640: 85.4 MB per image in fp32 = 21.35 M activation elements in + out

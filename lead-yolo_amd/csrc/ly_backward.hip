@@ -1570,6 +1570,41 @@ extern "C" int ly_coordatt_gate_bwd(const void* dout, int ldd, const void* x, in
 template <typename T, bool ACC>
 __global__ __launch_bounds__(LY_THREADS) void ly_pool_hw_bwd_kernel(const float* __restrict__ gp, int n_img, int H, int W, int C,
                                                                     T* __restrict__ dx, int lddx) {
+  // thread = (16-byte channel vector, column lane): a block walks (image, row) pairs, the row's own pool gradient is loaded once per pair and
+  // columns advance by a stride — no per-item index arithmetic (the flat form below pays three 64-bit divisions per 8 bytes)
+  constexpr int VW = LyT<T>::VW, NQ = VW / 4;
+  using RV = typename LyT<T>::RV;
+  if ((C % VW) == 0 && (lddx % VW) == 0 && C / VW <= LY_THREADS) {
+    const int ncv = C / VW, groups = LY_THREADS / ncv;
+    const int cv = threadIdx.x % ncv, wl = threadIdx.x / ncv;
+    if (wl >= groups) return;
+    const int c = VW * cv;
+    const float iw = 1.f / (float)W, ih = 1.f / (float)H;
+    const long rows = (long)n_img * H;
+    for (long nh = blockIdx.x; nh < rows; nh += gridDim.x) {
+      const long n = nh / H;
+      const int h = (int)(nh - n * H);
+      const float* const ga = gp + (n * (H + W) + h) * C + c;
+      const float* const gb = gp + (n * (H + W) + H) * C + c;
+      f32x4 a[NQ];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) a[q] = ly_ldg4(ga + 4 * q) * iw;
+      T* const drow = dx + nh * (long)W * lddx + c;
+      for (int w = wl; w < W; w += groups) {
+        f32x4 v[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) v[q] = a[q] + ly_ldg4(gb + (long)w * C + 4 * q) * ih;
+        if (ACC) {
+          f32x4 o[NQ];
+          ly_rv_unpack(ly_ldrv<T>(drow + (long)w * lddx), o);
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) v[q] += o[q];
+        }
+        *reinterpret_cast<RV*>(drow + (long)w * lddx) = ly_rv_pack(v, (RV*)nullptr);
+      }
+    }
+    return;
+  }
   const int nc4 = C >> 2;
   const long total = (long)n_img * H * W * nc4;
   const float iw = 1.f / (float)W, ih = 1.f / (float)H;
@@ -1590,7 +1625,9 @@ __global__ __launch_bounds__(LY_THREADS) void ly_pool_hw_bwd_kernel(const float*
 extern "C" int ly_pool_hw_bwd(const float* gp, int n_img, int H, int W, int C, void* dx, int lddx, int accumulate, int dtype, void* stream) {
   LY_CHECK_DTYPE(dtype, "pool_hw_bwd");
   LY_CHECK(gp && dx && n_img > 0 && H > 0 && W > 0 && (C & 3) == 0 && (lddx & 3) == 0, "pool_hw_bwd: bad arguments");
-  const dim3 grid((unsigned)ly_ew_blocks((long)n_img * H * W * (C >> 2)));
+  long nb = ly_ew_blocks((long)n_img * H * W * (C >> 2));
+  if (nb > (long)n_img * H) nb = (long)n_img * H;              // (the row-walking form: a block per (image, row) pair at most)
+  const dim3 grid((unsigned)nb);
   if (accumulate) {
     LY_WITH_T(dtype, hipLaunchKernelGGL((ly_pool_hw_bwd_kernel<T, true>), grid, dim3(LY_THREADS), 0, reinterpret_cast<hipStream_t>(stream), gp, n_img, H, W, C,
                                         reinterpret_cast<T*>(dx), lddx));
